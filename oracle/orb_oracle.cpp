@@ -1,0 +1,1156 @@
+/*
+ * orb_oracle.cpp -- CPU oracle for the ORB front-end (TEST INFRASTRUCTURE, not product).
+ *
+ * A restatement, in dependency-free C++17, of
+ *   - ORB_SLAM3::ORBextractor            reference src/ORBextractor.cc, include/ORBextractor.h
+ *   - the Hamming brute-force searches   reference src/ORBmatcher.cc:269-471, 823-963, 1208-1449, 2545-2607
+ *   - Frame::ComputeStereoFishEyeMatches' knn-2 brute force   reference src/Frame.cc:1119-1159
+ *   - KannalaBrandt8::unproject          reference src/CameraModels/KannalaBrandt8.cpp:96-123
+ * and of the OpenCV primitives they call (cv::resize, cv::copyMakeBorder, cv::FAST,
+ * cv::GaussianBlur, cv::fastAtan2, cvRound, cv::BFMatcher), whose arithmetic lives in
+ * OpenCV ("4.0, else >= 3.0", reference CMakeLists.txt:36-42) -- an un-vendored
+ * dependency that is absent from this image.  Their published algorithms are restated
+ * here as SURVEY.md Appendix B describes them.
+ *
+ * PARITY UNPINNED: the reference holds no tests, fixtures or golden vectors for this
+ * path, and neither the reference nor OpenCV can be built here.  The oracle is pinned
+ * by closed-form known-answer tests (tests/test_oracle_*.py) only.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this
+ * library.  Build: make -C oracle   (g++ -O2 -ffp-contract=off; no FMA contraction so
+ * float expressions round exactly as written).
+ */
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <list>
+#include <utility>
+#include <vector>
+
+#include "orb_pattern.inc"
+#include "orb_sincos_cr.h"
+
+namespace {
+
+typedef orb_oracle_kp KP;
+
+const int PATCH_SIZE = 31;      // reference src/ORBextractor.cc:70
+const int HALF_PATCH_SIZE = 15; // :71
+const int EDGE_THRESHOLD = 19;  // :72
+
+// cvRound: round-half-to-even (SSE cvtss2si / cvtsd2si), SURVEY.md B.6
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(double v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+inline int cv_ceil(double v)
+{
+    int i = (int)v;
+    return i + (i < v);
+}
+inline int16_t sat_s16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+inline int reflect101(int i, int n)
+{
+    // cv::borderInterpolate(BORDER_REFLECT_101), SURVEY.md B.2
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        else i = 2 * n - 2 - i;
+    }
+    return i;
+}
+
+// ---------------------------------------------------------------- cv::resize
+// INTER_LINEAR, 8UC1, generic fixed-point path.
+void resize_linear(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh, int dw, size_t dstride)
+{
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<int16_t> ialpha(2 * dw), ibeta(2 * dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_s16(cv_round((1.f - fx) * 2048));
+        ialpha[2 * dx + 1] = sat_s16(cv_round(fx * 2048));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[2 * dy] = sat_s16(cv_round((1.f - fy) * 2048));
+        ibeta[2 * dy + 1] = sat_s16(cv_round(fy * 2048));
+    }
+    std::vector<int> H0(dw), H1(dw);
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = std::min(std::max(yofs[dy], 0), sh - 1);
+        int sy1 = std::min(std::max(yofs[dy] + 1, 0), sh - 1);
+        const uint8_t* S0 = src + (size_t)sy0 * sstride;
+        const uint8_t* S1 = src + (size_t)sy1 * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx], sx1 = std::min(sx + 1, sw - 1);
+            int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            H0[dx] = S0[sx] * a0 + S0[sx1] * a1;
+            H1[dx] = S1[sx] * a0 + S1[sx1] * a1;
+        }
+        int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int v = (((b0 * (H0[dx] >> 4)) >> 16) + ((b1 * (H1[dx] >> 4)) >> 16) + 2) >> 2;
+            D[dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+// cv::copyMakeBorder(REFLECT_101) in place: buf is the padded buffer (rows x cols incl. border);
+// the interior [border, rows-border) x [border, cols-border) is the source.
+void border_reflect101(uint8_t* buf, int rows, int cols, size_t stride, int border)
+{
+    const int h = rows - 2 * border, w = cols - 2 * border;
+    for (int y = 0; y < rows; y++) {
+        int sy = reflect101(y - border, h) + border;
+        uint8_t* drow = buf + (size_t)y * stride;
+        const uint8_t* srow = buf + (size_t)sy * stride;
+        const bool interior_row = (y >= border && y < border + h);
+        for (int x = 0; x < cols; x++) {
+            if (interior_row && x >= border && x < border + w) continue;
+            int sx = reflect101(x - border, w) + border;
+            drow[x] = srow[sx];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cv::FAST
+// TYPE_9_16 ring, SURVEY.md B.3.
+const int RING_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+const int RING_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+inline bool has_run9(unsigned m16)
+{
+    unsigned x = m16 | (m16 << 16);
+    x &= x >> 1; // runs >= 2
+    x &= x >> 2; // >= 4
+    x &= x >> 4; // >= 8
+    x &= x >> 1; // >= 9
+    return (x & 0xFFFFu) != 0;
+}
+
+inline bool fast_is_corner(const uint8_t* c, size_t stride, int t)
+{
+    const int v = c[0];
+    unsigned bright = 0, dark = 0;
+    for (int k = 0; k < 16; k++) {
+        int r = c[(ptrdiff_t)RING_DY[k] * (ptrdiff_t)stride + RING_DX[k]];
+        if (r > v + t) bright |= 1u << k;
+        if (r < v - t) dark |= 1u << k;
+    }
+    return has_run9(bright) || has_run9(dark);
+}
+
+// closed form: largest t' for which the pixel is still a FAST-9 corner.
+int fast_score_closed(const uint8_t* c, size_t stride)
+{
+    int d[25];
+    const int v = c[0];
+    for (int k = 0; k < 16; k++) d[k] = (int)c[(ptrdiff_t)RING_DY[k] * (ptrdiff_t)stride + RING_DX[k]] - v;
+    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+    int best = -1000;
+    for (int k = 0; k < 16; k++) {
+        int mn = 1000, mx = -1000;
+        for (int j = 0; j < 9; j++) {
+            mn = std::min(mn, d[k + j]);
+            mx = std::max(mx, d[k + j]);
+        }
+        best = std::max(best, mn);  // bright arc: min(r - v)
+        best = std::max(best, -mx); // dark arc:   min(v - r)
+    }
+    return best - 1;
+}
+
+// OpenCV's cornerScore<16> two-loop form (early-outs, seeded with the threshold); kept as a
+// cross-check of the closed form (tests/test_oracle_fast.py).
+int fast_score_2loop(const uint8_t* c, size_t stride, int threshold)
+{
+    const int N = 25;
+    int d[N];
+    const int v = c[0];
+    for (int k = 0; k < N; k++) {
+        int kk = k & 15;
+        d[k] = v - (int)c[(ptrdiff_t)RING_DY[kk] * (ptrdiff_t)stride + RING_DX[kk]];
+    }
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = std::min(d[k + 1], d[k + 2]);
+        a = std::min(a, d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, d[k + 4]);
+        a = std::min(a, d[k + 5]);
+        a = std::min(a, d[k + 6]);
+        a = std::min(a, d[k + 7]);
+        a = std::min(a, d[k + 8]);
+        a0 = std::max(a0, std::min(a, d[k]));
+        a0 = std::max(a0, std::min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = std::max(d[k + 1], d[k + 2]);
+        b = std::max(b, d[k + 3]);
+        b = std::max(b, d[k + 4]);
+        b = std::max(b, d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, d[k + 6]);
+        b = std::max(b, d[k + 7]);
+        b = std::max(b, d[k + 8]);
+        b0 = std::min(b0, std::max(b, d[k]));
+        b0 = std::min(b0, std::max(b, d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+// cv::FAST(img, kps, threshold, nonmaxSuppression).  Row-major output; size=7, angle=-1.
+void fast_detect(const uint8_t* img, int rows, int cols, size_t stride, int threshold, bool nms, std::vector<KP>& out)
+{
+    out.clear();
+    threshold = std::min(std::max(threshold, 0), 255);
+    if (rows < 7 || cols < 7) return;
+    std::vector<int> score((size_t)rows * cols, 0);
+    std::vector<uint8_t> corner((size_t)rows * cols, 0);
+    for (int y = 3; y < rows - 3; y++)
+        for (int x = 3; x < cols - 3; x++) {
+            const uint8_t* c = img + (size_t)y * stride + x;
+            if (fast_is_corner(c, stride, threshold)) {
+                corner[(size_t)y * cols + x] = 1;
+                if (nms) score[(size_t)y * cols + x] = fast_score_closed(c, stride);
+            }
+        }
+    for (int y = 3; y < rows - 3; y++)
+        for (int x = 3; x < cols - 3; x++) {
+            if (!corner[(size_t)y * cols + x]) continue;
+            int s = score[(size_t)y * cols + x];
+            if (nms) {
+                bool keep = true;
+                for (int dy = -1; dy <= 1 && keep; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dx && !dy) continue;
+                        if (!(s > score[(size_t)(y + dy) * cols + (x + dx)])) { keep = false; break; }
+                    }
+                if (!keep) continue;
+            }
+            KP k;
+            k.x = (float)x;
+            k.y = (float)y;
+            k.size = 7.f;
+            k.angle = -1.f;
+            k.response = nms ? (float)s : 0.f;
+            k.octave = 0;
+            k.class_id = -1;
+            out.push_back(k);
+        }
+}
+
+// -------------------------------------------------------------- GaussianBlur
+// 7x7, sigma 2, BORDER_REFLECT_101, 8UC1, OpenCV 4.x fixed-point path:
+// taps in 8.8, horizontal pass exact in u16, vertical pass 16.16, round-to-nearest.
+void gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride,
+                    const int* taps)
+{
+    std::vector<uint32_t> H((size_t)rows * cols);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            uint32_t acc = 0;
+            for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * src[(size_t)y * sstride + reflect101(x + i - 3, cols)];
+            H[(size_t)y * cols + x] = acc > 65535u ? 65535u : acc; // ufixedpoint16 saturating add
+        }
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            uint64_t acc = 0;
+            for (int j = 0; j < 7; j++) acc += (uint64_t)taps[j] * H[(size_t)reflect101(y + j - 3, rows) * cols + x];
+            uint64_t v = (acc + 32768u) >> 16;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+}
+
+// ---------------------------------------------------------------- fastAtan2
+// cv::fastAtan2 (degrees); single precision, no FMA.
+float fast_atan2(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16; // (float)DBL_EPSILON
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// ------------------------------------------------- ORBextractor restatement
+struct Pt2i {
+    int x, y;
+};
+
+// reference include/ORBextractor.h:30-41 (ExtractorNode) + src/ORBextractor.cc:479-535 (DivideNode)
+struct Node {
+    std::vector<KP> vKeys;
+    Pt2i UL, UR, BL, BR;
+    std::list<Node>::iterator lit;
+    bool bNoMore = false;
+    long seq = 0; // creation sequence number: canonical replacement for the heap address
+
+    void Divide(Node& n1, Node& n2, Node& n3, Node& n4) const
+    {
+        const int halfX = (int)std::ceil(static_cast<float>(UR.x - UL.x) / 2);
+        const int halfY = (int)std::ceil(static_cast<float>(BR.y - UL.y) / 2);
+        n1.UL = UL;
+        n1.UR = {UL.x + halfX, UL.y};
+        n1.BL = {UL.x, UL.y + halfY};
+        n1.BR = {UL.x + halfX, UL.y + halfY};
+        n2.UL = n1.UR;
+        n2.UR = UR;
+        n2.BL = n1.BR;
+        n2.BR = {UR.x, UL.y + halfY};
+        n3.UL = n1.BL;
+        n3.UR = n1.BR;
+        n3.BL = BL;
+        n3.BR = {n1.BR.x, BL.y};
+        n4.UL = n3.UR;
+        n4.UR = n2.BR;
+        n4.BL = n3.BR;
+        n4.BR = BR;
+        for (size_t i = 0; i < vKeys.size(); i++) {
+            const KP& kp = vKeys[i];
+            if (kp.x < n1.UR.x) {
+                if (kp.y < n1.BR.y) n1.vKeys.push_back(kp);
+                else n3.vKeys.push_back(kp);
+            } else if (kp.y < n1.BR.y)
+                n2.vKeys.push_back(kp);
+            else
+                n4.vKeys.push_back(kp);
+        }
+        if (n1.vKeys.size() == 1) n1.bNoMore = true;
+        if (n2.vKeys.size() == 1) n2.bNoMore = true;
+        if (n3.vKeys.size() == 1) n3.bNoMore = true;
+        if (n4.vKeys.size() == 1) n4.bNoMore = true;
+    }
+};
+
+typedef std::pair<int, long> SizeSeq; // (size, seq) -- sort key of :682 with seq in place of the pointer
+
+// reference src/ORBextractor.cc:537-761, literal list semantics.
+std::vector<KP> DistributeOctTree(const std::vector<KP>& vToDistributeKeys, int minX, int maxX, int minY, int maxY,
+                                  int N)
+{
+    std::vector<KP> vResultKeys;
+    const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+    if (nIni < 1) return vResultKeys; // reference divides by zero here (portrait ratio < 0.5)
+    const float hX = static_cast<float>(maxX - minX) / nIni;
+
+    std::list<Node> lNodes;
+    std::vector<Node*> vpIniNodes(nIni);
+    long seq = 0;
+    for (int i = 0; i < nIni; i++) {
+        Node ni;
+        ni.UL = {(int)(hX * static_cast<float>(i)), 0};
+        ni.UR = {(int)(hX * static_cast<float>(i + 1)), 0};
+        ni.BL = {ni.UL.x, maxY - minY};
+        ni.BR = {ni.UR.x, maxY - minY};
+        ni.seq = seq++;
+        lNodes.push_back(ni);
+        vpIniNodes[i] = &lNodes.back();
+    }
+    for (size_t i = 0; i < vToDistributeKeys.size(); i++) {
+        const KP& kp = vToDistributeKeys[i];
+        int r = (int)(kp.x / hX);
+        if (r >= nIni) r = nIni - 1; // cannot happen for x < maxX-minX; guards UB of the reference
+        vpIniNodes[r]->vKeys.push_back(kp);
+    }
+    std::list<Node>::iterator lit = lNodes.begin();
+    while (lit != lNodes.end()) {
+        if (lit->vKeys.size() == 1) {
+            lit->bNoMore = true;
+            lit++;
+        } else if (lit->vKeys.empty())
+            lit = lNodes.erase(lit);
+        else
+            lit++;
+    }
+
+    bool bFinish = false;
+    std::vector<std::pair<SizeSeq, Node*>> vSizeAndPointerToNode;
+
+    auto push_children = [&](Node (&n)[4], int* nToExpand) {
+        for (int c = 0; c < 4; c++) {
+            if (n[c].vKeys.size() > 0) {
+                n[c].seq = seq++;
+                lNodes.push_front(n[c]);
+                if (n[c].vKeys.size() > 1) {
+                    if (nToExpand) (*nToExpand)++;
+                    vSizeAndPointerToNode.push_back(
+                        std::make_pair(SizeSeq((int)n[c].vKeys.size(), lNodes.front().seq), &lNodes.front()));
+                    lNodes.front().lit = lNodes.begin();
+                }
+            }
+        }
+    };
+
+    while (!bFinish) {
+        int prevSize = (int)lNodes.size();
+        lit = lNodes.begin();
+        int nToExpand = 0;
+        vSizeAndPointerToNode.clear();
+        while (lit != lNodes.end()) {
+            if (lit->bNoMore) {
+                lit++;
+                continue;
+            }
+            Node n[4];
+            lit->Divide(n[0], n[1], n[2], n[3]);
+            push_children(n, &nToExpand);
+            lit = lNodes.erase(lit);
+        }
+        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+            bFinish = true;
+        } else if (((int)lNodes.size() + nToExpand * 3) > N) {
+            while (!bFinish) {
+                prevSize = (int)lNodes.size();
+                std::vector<std::pair<SizeSeq, Node*>> vPrev = vSizeAndPointerToNode;
+                vSizeAndPointerToNode.clear();
+                std::sort(vPrev.begin(), vPrev.end(),
+                          [](const std::pair<SizeSeq, Node*>& a, const std::pair<SizeSeq, Node*>& b) {
+                              return a.first < b.first;
+                          });
+                for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+                    Node n[4];
+                    vPrev[j].second->Divide(n[0], n[1], n[2], n[3]);
+                    push_children(n, nullptr);
+                    lNodes.erase(vPrev[j].second->lit);
+                    if ((int)lNodes.size() >= N) break;
+                }
+                if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+            }
+        }
+    }
+
+    vResultKeys.reserve(lNodes.size());
+    for (std::list<Node>::iterator it = lNodes.begin(); it != lNodes.end(); it++) {
+        std::vector<KP>& vNodeKeys = it->vKeys;
+        KP* pKP = &vNodeKeys[0];
+        float maxResponse = pKP->response;
+        for (size_t k = 1; k < vNodeKeys.size(); k++) {
+            if (vNodeKeys[k].response > maxResponse) {
+                pKP = &vNodeKeys[k];
+                maxResponse = vNodeKeys[k].response;
+            }
+        }
+        vResultKeys.push_back(*pKP);
+    }
+    return vResultKeys;
+}
+
+struct Level {
+    int rows = 0, cols = 0;    // level size (without border)
+    size_t stride = 0;         // of the padded buffer
+    std::vector<uint8_t> buf;  // (rows+38) x (cols+38)
+    std::vector<uint8_t> blur; // rows x cols (only when the level has keypoints)
+    uint8_t* roi() { return buf.data() + (size_t)EDGE_THRESHOLD * stride + EDGE_THRESHOLD; }
+};
+
+} // namespace
+
+struct orb_oracle {
+    int nfeatures;
+    double scaleFactor; // reference include/ORBextractor.h:96 -- a double initialised from a float
+    int nlevels, iniThFAST, minThFAST;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    int trig_mode = ORB_ORACLE_TRIG_LIBM;
+    std::vector<Level> pyr;
+    std::vector<std::vector<KP>> cands, allKeypoints;
+
+    // reference src/ORBextractor.cc:408-468
+    orb_oracle(int _nfeatures, float _scaleFactor, int _nlevels, int _ini, int _min)
+        : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_ini), minThFAST(_min)
+    {
+        mvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvScaleFactor[0] = 1.0f;
+        mvLevelSigma2[0] = 1.0f;
+        for (int i = 1; i < nlevels; i++) {
+            mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor);
+            mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+        }
+        mvInvScaleFactor.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        for (int i = 0; i < nlevels; i++) {
+            mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+            mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+        }
+        mnFeaturesPerLevel.resize(nlevels);
+        float factor = (float)(1.0f / scaleFactor);
+        float nDesiredFeaturesPerScale =
+            nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+        int sumFeatures = 0;
+        for (int level = 0; level < nlevels - 1; level++) {
+            mnFeaturesPerLevel[level] = cv_round(nDesiredFeaturesPerScale);
+            sumFeatures += mnFeaturesPerLevel[level];
+            nDesiredFeaturesPerScale *= factor;
+        }
+        mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
+
+        umax.resize(HALF_PATCH_SIZE + 1);
+        int v, v0, vmax = cv_floor(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1);
+        int vmin = cv_ceil(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+        const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+        for (v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt(hp2 - v * v));
+        for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+        pyr.resize(nlevels);
+    }
+
+    // reference :1152-1177
+    void ComputePyramid(const uint8_t* img, int rows, int cols, size_t stride)
+    {
+        for (int level = 0; level < nlevels; ++level) {
+            float scale = mvInvScaleFactor[level];
+            Level& L = pyr[level];
+            L.cols = cv_round((float)cols * scale);
+            L.rows = cv_round((float)rows * scale);
+            L.stride = (size_t)L.cols + EDGE_THRESHOLD * 2;
+            L.buf.assign((size_t)(L.rows + EDGE_THRESHOLD * 2) * L.stride, 0);
+            L.blur.clear();
+            if (level != 0) {
+                Level& P = pyr[level - 1];
+                resize_linear(P.roi(), P.rows, P.cols, P.stride, L.roi(), L.rows, L.cols, L.stride);
+            } else {
+                for (int y = 0; y < rows; y++) memcpy(L.roi() + (size_t)y * L.stride, img + (size_t)y * stride, cols);
+            }
+            border_reflect101(L.buf.data(), L.rows + 2 * EDGE_THRESHOLD, L.cols + 2 * EDGE_THRESHOLD, L.stride,
+                              EDGE_THRESHOLD);
+        }
+    }
+
+    // reference :75-102
+    float IC_Angle(Level& L, float ptx, float pty)
+    {
+        int m_01 = 0, m_10 = 0;
+        const uint8_t* center = L.roi() + (size_t)cv_round(pty) * L.stride + cv_round(ptx);
+        for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+        int step = (int)L.stride;
+        for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+            int v_sum = 0;
+            int d = umax[v];
+            for (int u = -d; u <= d; ++u) {
+                int val_plus = center[u + v * step], val_minus = center[u - v * step];
+                v_sum += (val_plus - val_minus);
+                m_10 += u * (val_plus + val_minus);
+            }
+            m_01 += v * v_sum;
+        }
+        return fast_atan2((float)m_01, (float)m_10);
+    }
+
+    // reference :763-878.  Returns false when a level is too small for the 35-px cell grid.
+    bool ComputeKeyPointsOctTree()
+    {
+        allKeypoints.assign(nlevels, std::vector<KP>());
+        cands.assign(nlevels, std::vector<KP>());
+        const float W = 35;
+        for (int level = 0; level < nlevels; ++level) {
+            Level& L = pyr[level];
+            const int minBorderX = EDGE_THRESHOLD - 3;
+            const int minBorderY = minBorderX;
+            const int maxBorderX = L.cols - EDGE_THRESHOLD + 3;
+            const int maxBorderY = L.rows - EDGE_THRESHOLD + 3;
+            std::vector<KP>& vToDistributeKeys = cands[level];
+            const float width = (float)(maxBorderX - minBorderX);
+            const float height = (float)(maxBorderY - minBorderY);
+            const int nCols = (int)(width / W);
+            const int nRows = (int)(height / W);
+            if (nCols < 1 || nRows < 1) return false; // reference divides by zero
+            const int wCell = (int)std::ceil(width / nCols);
+            const int hCell = (int)std::ceil(height / nRows);
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = (float)(minBorderY + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBorderY - 3) continue;
+                if (maxY > maxBorderY) maxY = (float)maxBorderY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = (float)(minBorderX + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBorderX - 6) continue;
+                    if (maxX > maxBorderX) maxX = (float)maxBorderX;
+                    std::vector<KP> vKeysCell;
+                    const uint8_t* roi = L.roi() + (size_t)(int)iniY * L.stride + (int)iniX;
+                    const int rr = (int)maxY - (int)iniY, cc = (int)maxX - (int)iniX;
+                    fast_detect(roi, rr, cc, L.stride, iniThFAST, true, vKeysCell);
+                    if (vKeysCell.empty()) fast_detect(roi, rr, cc, L.stride, minThFAST, true, vKeysCell);
+                    for (KP& k : vKeysCell) {
+                        k.x += j * wCell;
+                        k.y += i * hCell;
+                        vToDistributeKeys.push_back(k);
+                    }
+                }
+            }
+            std::vector<KP>& keypoints = allKeypoints[level];
+            keypoints = DistributeOctTree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY,
+                                          mnFeaturesPerLevel[level]);
+            const int scaledPatchSize = (int)(PATCH_SIZE * mvScaleFactor[level]);
+            for (KP& k : keypoints) {
+                k.x += minBorderX;
+                k.y += minBorderY;
+                k.octave = level;
+                k.size = (float)scaledPatchSize;
+            }
+        }
+        for (int level = 0; level < nlevels; ++level)
+            for (KP& k : allKeypoints[level]) k.angle = IC_Angle(pyr[level], k.x, k.y);
+        return true;
+    }
+
+    // reference :104-145
+    void computeOrbDescriptor(const KP& kpt, const uint8_t* img, int step, uint8_t* desc)
+    {
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        float angle = (float)kpt.angle * factorPI;
+        float a, b;
+        if (trig_mode == ORB_ORACLE_TRIG_LIBM) {
+            a = cosf(angle);
+            b = sinf(angle);
+        } else {
+            orb_sincos_cr_impl(angle, &b, &a);
+        }
+        const uint8_t* center = img + (size_t)cv_round(kpt.y) * step + cv_round(kpt.x);
+        for (int i = 0; i < 32; ++i) {
+            int val = 0;
+            for (int j = 0; j < 8; j++) {
+                const signed char* p = ORB_PATTERN_31[i * 8 + j];
+                int t0 = center[cv_round(p[0] * b + p[1] * a) * step + cv_round(p[0] * a - p[1] * b)];
+                int t1 = center[cv_round(p[2] * b + p[3] * a) * step + cv_round(p[2] * a - p[3] * b)];
+                val |= (t0 < t1) << j;
+            }
+            desc[i] = (uint8_t)val;
+        }
+    }
+
+    // reference :1068-1150
+    int extract(const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1, KP* kps, uint8_t* desc,
+                int cap, int* n_out)
+    {
+        if (n_out) *n_out = 0;
+        if (!img || rows <= 0 || cols <= 0) return -1;
+        ComputePyramid(img, rows, cols, stride);
+        if (!ComputeKeyPointsOctTree()) return -2;
+        int nkeypoints = 0;
+        for (int level = 0; level < nlevels; ++level) nkeypoints += (int)allKeypoints[level].size();
+        if (nkeypoints > cap) return -2;
+        if (n_out) *n_out = nkeypoints;
+        int monoIndex = 0, stereoIndex = nkeypoints - 1;
+        for (int level = 0; level < nlevels; ++level) {
+            std::vector<KP>& keypoints = allKeypoints[level];
+            if (keypoints.empty()) continue;
+            Level& L = pyr[level];
+            L.blur.resize((size_t)L.rows * L.cols);
+            gaussian_blur7(L.roi(), L.rows, L.cols, L.stride, L.blur.data(), (size_t)L.cols, taps);
+            float scale = mvScaleFactor[level];
+            for (KP& kp0 : keypoints) {
+                uint8_t d[32];
+                computeOrbDescriptor(kp0, L.blur.data(), L.cols, d);
+                KP kp = kp0;
+                if (level != 0) {
+                    kp.x *= scale;
+                    kp.y *= scale;
+                }
+                int dst;
+                if (kp.x >= lap0 && kp.x <= lap1) dst = stereoIndex--;
+                else dst = monoIndex++;
+                kps[dst] = kp;
+                memcpy(desc + (size_t)dst * 32, d, 32);
+            }
+        }
+        return monoIndex;
+    }
+};
+
+// ------------------------------------------------------------------ matcher
+namespace {
+
+const int TH_LOW = 50;       // reference src/ORBmatcher.cc:37
+const int HISTO_LENGTH = 30; // :38
+
+// reference src/ORBmatcher.cc:2591-2607
+int DescriptorDistance(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        unsigned int v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// reference :2545-2586 (on bin sizes)
+void ComputeThreeMaxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            ind3 = ind2;
+            ind2 = ind1;
+            ind1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            ind3 = ind2;
+            ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+inline int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / HISTO_LENGTH; // sic: 1/30, reference :282,394
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// merge-join of two CSR feature vectors by node id (std::map walk + lower_bound, :285-448)
+template <class F>
+void for_each_shared_node(const orb_oracle_fv* a, const orb_oracle_fv* b, F f)
+{
+    int i = 0, j = 0;
+    while (i < a->nn && j < b->nn) {
+        if (a->node_ids[i] == b->node_ids[j]) {
+            f(i, j);
+            i++;
+            j++;
+        } else if (a->node_ids[i] < b->node_ids[j]) {
+            while (i < a->nn && a->node_ids[i] < b->node_ids[j]) i++;
+        } else {
+            while (j < b->nn && b->node_ids[j] < a->node_ids[i]) j++;
+        }
+    }
+}
+
+int cull_rotation(std::vector<int>* rotHist, int32_t* match, int nmatches)
+{
+    int counts[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        if (i == ind1 || i == ind2 || i == ind3) continue;
+        for (size_t j = 0; j < rotHist[i].size(); j++) {
+            match[rotHist[i][j]] = -1;
+            nmatches--;
+        }
+    }
+    return nmatches;
+}
+
+} // namespace
+
+extern "C" {
+
+orb_oracle* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+{
+    if (nfeatures < 0 || nlevels < 1 || nlevels > 32 || !(scaleFactor > 1.0f)) return nullptr;
+    return new orb_oracle(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+}
+void orb_oracle_destroy(orb_oracle* o) { delete o; }
+void orb_oracle_set_gauss_taps(orb_oracle* o, const int* t)
+{
+    for (int i = 0; i < 7; i++) o->taps[i] = t[i];
+}
+void orb_oracle_set_trig_mode(orb_oracle* o, int mode) { o->trig_mode = mode; }
+
+int orb_oracle_extract(orb_oracle* o, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
+                       orb_oracle_kp* kps, uint8_t* desc, int cap, int* n_out)
+{
+    return o->extract(img, rows, cols, stride, lap0, lap1, kps, desc, cap, n_out);
+}
+
+void orb_oracle_get_scale_tables(orb_oracle* o, float* sf, float* inv, float* s2, float* is2)
+{
+    for (int i = 0; i < o->nlevels; i++) {
+        if (sf) sf[i] = o->mvScaleFactor[i];
+        if (inv) inv[i] = o->mvInvScaleFactor[i];
+        if (s2) s2[i] = o->mvLevelSigma2[i];
+        if (is2) is2[i] = o->mvInvLevelSigma2[i];
+    }
+}
+void orb_oracle_get_features_per_level(orb_oracle* o, int* n)
+{
+    for (int i = 0; i < o->nlevels; i++) n[i] = o->mnFeaturesPerLevel[i];
+}
+void orb_oracle_get_umax(orb_oracle* o, int* u)
+{
+    for (int i = 0; i < 16; i++) u[i] = o->umax[i];
+}
+
+int orb_oracle_get_level(orb_oracle* o, int level, const uint8_t** data, int* rows, int* cols, size_t* stride)
+{
+    if (level < 0 || level >= o->nlevels || o->pyr[level].buf.empty()) return -1;
+    Level& L = o->pyr[level];
+    *data = L.buf.data();
+    *rows = L.rows + 2 * EDGE_THRESHOLD;
+    *cols = L.cols + 2 * EDGE_THRESHOLD;
+    *stride = L.stride;
+    return 0;
+}
+int orb_oracle_get_blurred(orb_oracle* o, int level, const uint8_t** data, int* rows, int* cols, size_t* stride)
+{
+    if (level < 0 || level >= o->nlevels || o->pyr[level].blur.empty()) return -1;
+    Level& L = o->pyr[level];
+    *data = L.blur.data();
+    *rows = L.rows;
+    *cols = L.cols;
+    *stride = (size_t)L.cols;
+    return 0;
+}
+int orb_oracle_get_candidates(orb_oracle* o, int level, const orb_oracle_kp** kps)
+{
+    if (level < 0 || level >= (int)o->cands.size()) return -1;
+    *kps = o->cands[level].data();
+    return (int)o->cands[level].size();
+}
+int orb_oracle_get_level_keypoints(orb_oracle* o, int level, const orb_oracle_kp** kps)
+{
+    if (level < 0 || level >= (int)o->allKeypoints.size()) return -1;
+    *kps = o->allKeypoints[level].data();
+    return (int)o->allKeypoints[level].size();
+}
+
+void orb_oracle_resize_linear(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                              size_t dstride)
+{
+    resize_linear(src, sh, sw, sstride, dst, dh, dw, dstride);
+}
+void orb_oracle_border_reflect101(uint8_t* buf, int rows, int cols, size_t stride, int border)
+{
+    border_reflect101(buf, rows, cols, stride, border);
+}
+int orb_oracle_fast(const uint8_t* img, int rows, int cols, size_t stride, int threshold, int nms, orb_oracle_kp* out,
+                    int cap)
+{
+    std::vector<KP> v;
+    fast_detect(img, rows, cols, stride, threshold, nms != 0, v);
+    int n = (int)v.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = v[i];
+    return n;
+}
+int orb_oracle_fast_score_closed(const uint8_t* c, size_t stride) { return fast_score_closed(c, stride); }
+int orb_oracle_fast_score_2loop(const uint8_t* c, size_t stride, int t) { return fast_score_2loop(c, stride, t); }
+void orb_oracle_gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride,
+                               const int* taps7)
+{
+    const int def[7] = {18, 34, 48, 56, 48, 34, 18};
+    gaussian_blur7(src, rows, cols, sstride, dst, dstride, taps7 ? taps7 : def);
+}
+float orb_oracle_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+void orb_oracle_sincos_cr(float a, float* s, float* c) { orb_sincos_cr_impl(a, s, c); }
+
+int orb_oracle_distribute_octree(const orb_oracle_kp* cands, int n, int minX, int maxX, int minY, int maxY, int N,
+                                 orb_oracle_kp* out, int cap)
+{
+    std::vector<KP> v(cands, cands + n);
+    std::vector<KP> r = DistributeOctTree(v, minX, maxX, minY, maxY, N);
+    for (int i = 0; i < (int)r.size() && i < cap; i++) out[i] = r[i];
+    return (int)r.size();
+}
+
+int orb_oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+void orb_oracle_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D)
+{
+    for (int i = 0; i < nA; i++)
+        for (int j = 0; j < nB; j++) D[(size_t)i * nB + j] = (uint16_t)DescriptorDistance(A + 32 * i, B + 32 * j);
+}
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(k=2), SURVEY.md B.7: two smallest, ties -> lower train index.
+void orb_oracle_bfknn2(const uint8_t* Q, int nQ, const uint8_t* T, int nT, int32_t* idx, int32_t* dist)
+{
+    for (int q = 0; q < nQ; q++) {
+        int d0 = 1 << 30, d1 = 1 << 30, i0 = -1, i1 = -1;
+        for (int t = 0; t < nT; t++) {
+            int d = DescriptorDistance(Q + 32 * q, T + 32 * t);
+            if (d < d0) {
+                d1 = d0;
+                i1 = i0;
+                d0 = d;
+                i0 = t;
+            } else if (d < d1) {
+                d1 = d;
+                i1 = t;
+            }
+        }
+        idx[2 * q] = i0;
+        idx[2 * q + 1] = i1;
+        dist[2 * q] = i0 >= 0 ? d0 : -1;
+        dist[2 * q + 1] = i1 >= 0 ? d1 : -1;
+    }
+}
+
+void orb_oracle_three_maxima(const int* histo, int L, int* i1, int* i2, int* i3)
+{
+    int a = -1, b = -1, c = -1;
+    ComputeThreeMaxima(histo, L, a, b, c);
+    *i1 = a;
+    *i2 = b;
+    *i3 = c;
+}
+
+int orb_oracle_search_bow_kf_f(const uint8_t* descKF, int nKF, const uint8_t* maskKF, const float* angKF,
+                               const orb_oracle_fv* fvKF, const uint8_t* descF, int nF, const float* angF,
+                               const orb_oracle_fv* fvF, int Nleft, float nnratio, int checkOri, int32_t* match)
+{
+    (void)nKF;
+    for (int i = 0; i < nF; i++) match[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for_each_shared_node(fvKF, fvF, [&](int a, int b) {
+        for (int iKF = fvKF->offsets[a]; iKF < fvKF->offsets[a + 1]; iKF++) {
+            const int realIdxKF = fvKF->indices[iKF];
+            if (!maskKF[realIdxKF]) continue;
+            const uint8_t* dKF = descKF + 32 * (size_t)realIdxKF;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+            for (int iF = fvF->offsets[b]; iF < fvF->offsets[b + 1]; iF++) {
+                const int realIdxF = fvF->indices[iF];
+                if (match[realIdxF] >= 0) continue;
+                const int dist = DescriptorDistance(dKF, descF + 32 * (size_t)realIdxF);
+                if (Nleft == -1) {
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                } else {
+                    if (realIdxF < Nleft && dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = realIdxF;
+                    } else if (realIdxF < Nleft && dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                    if (realIdxF >= Nleft && dist < bestDist1R) {
+                        bestDist2R = bestDist1R;
+                        bestDist1R = dist;
+                        bestIdxFR = realIdxF;
+                    } else if (realIdxF >= Nleft && dist < bestDist2R) {
+                        bestDist2R = dist;
+                    }
+                }
+            }
+            if (bestDist1 <= TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    match[bestIdxF] = realIdxKF;
+                    if (checkOri) rotHist[rot_bin(angKF[realIdxKF], angF[bestIdxF])].push_back(bestIdxF);
+                    nmatches++;
+                }
+                if (bestDist1R <= TH_LOW) {
+                    // ratio test is "|| true" in the reference (:405)
+                    match[bestIdxFR] = realIdxKF;
+                    if (checkOri) rotHist[rot_bin(angKF[realIdxKF], angF[bestIdxFR])].push_back(bestIdxFR);
+                    nmatches++;
+                }
+            }
+        }
+    });
+    if (checkOri) nmatches = cull_rotation(rotHist, match, nmatches);
+    return nmatches;
+}
+
+int orb_oracle_search_bow_kf_kf(const uint8_t* desc1, int n1, const uint8_t* mask1, const float* ang1,
+                                const orb_oracle_fv* fv1, int lim1, const uint8_t* desc2, int n2,
+                                const uint8_t* mask2, const float* ang2, const orb_oracle_fv* fv2, int lim2,
+                                float nnratio, int checkOri, int32_t* match12)
+{
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<uint8_t> vbMatched2(n2, 0);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for_each_shared_node(fv1, fv2, [&](int a, int b) {
+        for (int i1 = fv1->offsets[a]; i1 < fv1->offsets[a + 1]; i1++) {
+            const int idx1 = fv1->indices[i1];
+            if (lim1 != -1 && idx1 >= lim1) continue;
+            if (!mask1[idx1]) continue;
+            const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int i2 = fv2->offsets[b]; i2 < fv2->offsets[b + 1]; i2++) {
+                const int idx2 = fv2->indices[i2];
+                if (lim2 != -1 && idx2 >= lim2) continue;
+                if (vbMatched2[idx2] || !mask2[idx2]) continue;
+                int dist = DescriptorDistance(d1, desc2 + 32 * (size_t)idx2);
+                if (dist < bestDist1) {
+                    bestDist2 = bestDist1;
+                    bestDist1 = dist;
+                    bestIdx2 = idx2;
+                } else if (dist < bestDist2) {
+                    bestDist2 = dist;
+                }
+            }
+            if (bestDist1 < TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    match12[idx1] = bestIdx2;
+                    vbMatched2[bestIdx2] = 1;
+                    if (checkOri) rotHist[rot_bin(ang1[idx1], ang2[bestIdx2])].push_back(idx1);
+                    nmatches++;
+                }
+            }
+        }
+    });
+    if (checkOri) nmatches = cull_rotation(rotHist, match12, nmatches);
+    return nmatches;
+}
+
+int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t* hasMP1, const float* kp1xy,
+                                    const float* ang1, const int32_t* oct1, const float* uRight1,
+                                    const orb_oracle_fv* fv1, const uint8_t* desc2, int n2, const uint8_t* hasMP2,
+                                    const float* kp2xy, const float* ang2, const int32_t* oct2, const float* uRight2,
+                                    const orb_oracle_fv* fv2, const float* F12, float epx, float epy,
+                                    const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
+                                    int bCoarse, int checkOri, int32_t* pairs)
+{
+    (void)oct1;
+    (void)n2;
+    std::vector<int32_t> vMatches12(n1, -1);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for_each_shared_node(fv1, fv2, [&](int a, int b) {
+        for (int i1 = fv1->offsets[a]; i1 < fv1->offsets[a + 1]; i1++) {
+            const int idx1 = fv1->indices[i1];
+            if (hasMP1[idx1]) continue;
+            const bool bStereo1 = uRight1[idx1] >= 0;
+            if (bOnlyStereo && !bStereo1) continue;
+            const float k1x = kp1xy[2 * idx1], k1y = kp1xy[2 * idx1 + 1];
+            const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+            int bestDist = TH_LOW;
+            int bestIdx2 = -1;
+            for (int i2 = fv2->offsets[b]; i2 < fv2->offsets[b + 1]; i2++) {
+                const int idx2 = fv2->indices[i2];
+                if (hasMP2[idx2]) continue; // vbMatched2 is never set in the reference
+                const bool bStereo2 = uRight2[idx2] >= 0;
+                if (bOnlyStereo && !bStereo2) continue;
+                const int dist = DescriptorDistance(d1, desc2 + 32 * (size_t)idx2);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const float k2x = kp2xy[2 * idx2], k2y = kp2xy[2 * idx2 + 1];
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = epx - k2x;
+                    const float distey = epy - k2y;
+                    if (distex * distex + distey * distey < 100 * scaleFactors2[oct2[idx2]]) continue;
+                }
+                // Pinhole::epipolarConstrain_ (src/CameraModels/Pinhole.cpp:159-181) with F12 given
+                bool ok = false;
+                {
+                    const float la = k1x * F12[0] + k1y * F12[3] + F12[6];
+                    const float lb = k1x * F12[1] + k1y * F12[4] + F12[7];
+                    const float lc = k1x * F12[2] + k1y * F12[5] + F12[8];
+                    const float num = la * k2x + lb * k2y + lc;
+                    const float den = la * la + lb * lb;
+                    if (den != 0) {
+                        const float dsqr = num * num / den;
+                        ok = dsqr < 3.84 * levelSigma2_2[oct2[idx2]];
+                    }
+                }
+                if (ok || bCoarse) {
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                }
+            }
+            if (bestIdx2 >= 0) {
+                vMatches12[idx1] = bestIdx2;
+                nmatches++;
+                if (checkOri) rotHist[rot_bin(ang1[idx1], ang2[bestIdx2])].push_back(idx1);
+            }
+        }
+    });
+    if (checkOri) nmatches = cull_rotation(rotHist, vMatches12.data(), nmatches);
+    int np = 0;
+    for (int i = 0; i < n1; i++) {
+        if (vMatches12[i] < 0) continue;
+        pairs[2 * np] = i;
+        pairs[2 * np + 1] = vMatches12[i];
+        np++;
+    }
+    return np;
+}
+
+void orb_oracle_kb8_unproject(const float* P, const float* uv, int n, float* rays)
+{
+    const float precision = 1e-6f; // reference include/CameraModels/KannalaBrandt8.h (precision member)
+    for (int i = 0; i < n; i++) {
+        float pwx = (uv[2 * i] - P[2]) / P[0], pwy = (uv[2 * i + 1] - P[3]) / P[1];
+        float scale = 1.f;
+        float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+        theta_d = fminf(fmaxf((float)(-3.14159265358979323846 / 2.f), theta_d), (float)(3.14159265358979323846 / 2.f));
+        if (theta_d > 1e-8) {
+            float theta = theta_d;
+            for (int j = 0; j < 10; j++) {
+                float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2,
+                      theta8 = theta4 * theta4;
+                float k0_theta2 = P[4] * theta2, k1_theta4 = P[5] * theta4;
+                float k2_theta6 = P[6] * theta6, k3_theta8 = P[7] * theta8;
+                float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                  (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+                theta = theta - theta_fix;
+                if (fabsf(theta_fix) < precision) break;
+            }
+            scale = std::tan(theta) / theta_d;
+        }
+        rays[3 * i] = pwx * scale;
+        rays[3 * i + 1] = pwy * scale;
+        rays[3 * i + 2] = 1.f;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,115 @@
+/*
+ * orb_oracle.h -- C API of the CPU oracle (TEST INFRASTRUCTURE, not product).
+ *
+ * The oracle is a CPU restatement of the reference's ORB front-end
+ * (src/ORBextractor.cc, the Hamming loops of src/ORBmatcher.cc, and the OpenCV
+ * primitives they call).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product
+ * (orb_slam3_detailed_comments_kor_amd/) never does.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for
+ * this path and cannot be compiled here (it needs OpenCV, which is absent), so
+ * this oracle is pinned only by closed-form known-answer tests and by its own
+ * committed fixtures (see DESIGN.md "Oracle").
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orb_oracle_kp;
+
+typedef struct orb_oracle orb_oracle;
+
+/* trig modes for the steered-BRIEF rotation (reference src/ORBextractor.cc:111) */
+enum { ORB_ORACLE_TRIG_LIBM = 0,   /* host libm cosf/sinf, what the reference calls   */
+       ORB_ORACLE_TRIG_CR = 1 };   /* correctly-rounded float sin/cos (shared routine) */
+
+orb_oracle* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void orb_oracle_destroy(orb_oracle*);
+void orb_oracle_set_gauss_taps(orb_oracle*, const int* taps7);
+void orb_oracle_set_trig_mode(orb_oracle*, int mode);
+
+/* ORBextractor::operator() -- returns monoIndex (>=0), -1 for an empty image, -2 bad args/too small. */
+int orb_oracle_extract(orb_oracle*, const uint8_t* img, int rows, int cols, size_t stride,
+                       int lap0, int lap1, orb_oracle_kp* kps, uint8_t* desc, int cap, int* n_out);
+
+/* tables (ctor) */
+void orb_oracle_get_scale_tables(orb_oracle*, float* sf, float* inv, float* sigma2, float* inv_sigma2);
+void orb_oracle_get_features_per_level(orb_oracle*, int* n_per_level);
+void orb_oracle_get_umax(orb_oracle*, int* umax16);
+
+/* stage taps, valid after orb_oracle_extract() */
+int orb_oracle_get_level(orb_oracle*, int level, const uint8_t** data /* padded buffer */, int* rows, int* cols,
+                         size_t* stride); /* rows/cols of the padded buffer = level + 38 */
+int orb_oracle_get_blurred(orb_oracle*, int level, const uint8_t** data, int* rows, int* cols, size_t* stride);
+int orb_oracle_get_candidates(orb_oracle*, int level, const orb_oracle_kp** kps);      /* vToDistributeKeys  */
+int orb_oracle_get_level_keypoints(orb_oracle*, int level, const orb_oracle_kp** kps); /* allKeypoints[level] */
+
+/* OpenCV primitives as restated */
+void orb_oracle_resize_linear(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                              size_t dstride);
+void orb_oracle_border_reflect101(uint8_t* buf, int rows, int cols, size_t stride, int border);
+int orb_oracle_fast(const uint8_t* img, int rows, int cols, size_t stride, int threshold, int nms,
+                    orb_oracle_kp* out, int cap);
+int orb_oracle_fast_score_closed(const uint8_t* center, size_t stride);
+int orb_oracle_fast_score_2loop(const uint8_t* center, size_t stride, int threshold);
+void orb_oracle_gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride,
+                               const int* taps7);
+float orb_oracle_fast_atan2(float y, float x);
+void orb_oracle_sincos_cr(float angle_rad, float* s, float* c);
+int orb_oracle_distribute_octree(const orb_oracle_kp* cands, int n, int minX, int maxX, int minY, int maxY, int N,
+                                 orb_oracle_kp* out, int cap);
+
+/* matcher (src/ORBmatcher.cc) */
+int orb_oracle_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void orb_oracle_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
+void orb_oracle_bfknn2(const uint8_t* Q, int nQ, const uint8_t* T, int nT, int32_t* idx, int32_t* dist);
+void orb_oracle_three_maxima(const int* histo_counts, int L, int* ind1, int* ind2, int* ind3);
+
+/* CSR FeatureVector: node_ids[nn] ascending, offsets[nn+1], indices[offsets[nn]] */
+typedef struct {
+    int nn;
+    const uint32_t* node_ids;
+    const int32_t* offsets;
+    const int32_t* indices;
+} orb_oracle_fv;
+
+/* SearchByBoW(KeyFrame*,Frame&) src/ORBmatcher.cc:269-471.
+ * match[N_F] = KF feature index or -1.  Returns nmatches. */
+int orb_oracle_search_bow_kf_f(const uint8_t* descKF, int nKF, const uint8_t* maskKF /*1=good MapPoint*/,
+                               const float* angKF, const orb_oracle_fv* fvKF, const uint8_t* descF, int nF,
+                               const float* angF, const orb_oracle_fv* fvF, int Nleft /* -1 = mono */,
+                               float nnratio, int checkOri, int32_t* match);
+/* SearchByBoW(KeyFrame*,KeyFrame*) src/ORBmatcher.cc:823-963.  match12[n1] = idx2 or -1. */
+int orb_oracle_search_bow_kf_kf(const uint8_t* desc1, int n1, const uint8_t* mask1, const float* ang1,
+                                const orb_oracle_fv* fv1, int lim1 /* -1 or mvKeysUn.size() */, const uint8_t* desc2,
+                                int n2, const uint8_t* mask2, const float* ang2, const orb_oracle_fv* fv2, int lim2,
+                                float nnratio, int checkOri, int32_t* match12);
+/* SearchForTriangulation_ src/ORBmatcher.cc:1208-1449, monocular/rectified pinhole case
+ * (no second camera).  kp = {x,y} pairs, uRight<0 => monocular feature.
+ * F12 as Pinhole::epipolarConstrain_ would form it (src/CameraModels/Pinhole.cpp:159-181).
+ * pairs[2*k] = idx1, pairs[2*k+1] = idx2, sorted by idx1.  Returns npairs. */
+int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t* hasMP1, const float* kp1xy,
+                                    const float* ang1, const int32_t* oct1, const float* uRight1,
+                                    const orb_oracle_fv* fv1, const uint8_t* desc2, int n2, const uint8_t* hasMP2,
+                                    const float* kp2xy, const float* ang2, const int32_t* oct2, const float* uRight2,
+                                    const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
+                                    const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
+                                    int bCoarse, int checkOri, int32_t* pairs);
+/* KannalaBrandt8::unproject src/CameraModels/KannalaBrandt8.cpp:96-123; params = fx,fy,cx,cy,k0..k3 */
+void orb_oracle_kb8_unproject(const float* params8, const float* uv, int n, float* rays3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

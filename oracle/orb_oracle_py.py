@@ -1,0 +1,335 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+TRIG_LIBM, TRIG_CR = 0, 1
+
+
+class _FV(C.Structure):
+    _fields_ = [("nn", C.c_int), ("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborb_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orb_oracle_create.restype = C.c_void_p
+        L.orb_oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orb_oracle_destroy.argtypes = [C.c_void_p]
+        L.orb_oracle_set_gauss_taps.argtypes = [C.c_void_p, C.c_void_p]
+        L.orb_oracle_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orb_oracle_extract.restype = C.c_int
+        L.orb_oracle_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orb_oracle_get_scale_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orb_oracle_get_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
+        L.orb_oracle_get_umax.argtypes = [C.c_void_p, C.c_void_p]
+        for f in (L.orb_oracle_get_level, L.orb_oracle_get_blurred):
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                          C.POINTER(C.c_size_t)]
+        for f in (L.orb_oracle_get_candidates, L.orb_oracle_get_level_keypoints):
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.orb_oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_size_t]
+        L.orb_oracle_border_reflect101.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int]
+        L.orb_oracle_fast.restype = C.c_int
+        L.orb_oracle_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orb_oracle_fast_score_closed.restype = C.c_int
+        L.orb_oracle_fast_score_closed.argtypes = [C.c_void_p, C.c_size_t]
+        L.orb_oracle_fast_score_2loop.restype = C.c_int
+        L.orb_oracle_fast_score_2loop.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.orb_oracle_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                C.c_void_p]
+        L.orb_oracle_fast_atan2.restype = C.c_float
+        L.orb_oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orb_oracle_sincos_cr.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orb_oracle_distribute_octree.restype = C.c_int
+        L.orb_oracle_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_int]
+        L.orb_oracle_descriptor_distance.restype = C.c_int
+        L.orb_oracle_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orb_oracle_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orb_oracle_bfknn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orb_oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]
+        L.orb_oracle_search_bow_kf_f.restype = C.c_int
+        L.orb_oracle_search_bow_kf_f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_FV),
+                                                 C.c_void_p, C.c_int, C.c_void_p, C.POINTER(_FV), C.c_int, C.c_float,
+                                                 C.c_int, C.c_void_p]
+        L.orb_oracle_search_bow_kf_kf.restype = C.c_int
+        L.orb_oracle_search_bow_kf_kf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_FV),
+                                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(_FV), C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orb_oracle_search_triangulation.restype = C.c_int
+        L.orb_oracle_search_triangulation.argtypes = (
+            [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_FV)] * 2
+            + [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        L.orb_oracle_kb8_unproject.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fv(fv):
+    node_ids, offsets, indices = fv
+    node_ids = np.ascontiguousarray(node_ids, np.uint32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    indices = np.ascontiguousarray(indices, np.int32)
+    s = _FV(len(node_ids), node_ids.ctypes.data, offsets.ctypes.data, indices.ctypes.data)
+    s._keep = (node_ids, offsets, indices)
+    return s
+
+
+class Extractor:
+    """Oracle ORBextractor (reference src/ORBextractor.cc)."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, trig=TRIG_LIBM, taps=None):
+        self.L = lib()
+        self.h = self.L.orb_oracle_create(nfeatures, scale, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("bad ORBextractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.L.orb_oracle_set_trig_mode(self.h, trig)
+        if taps is not None:
+            t = np.ascontiguousarray(taps, np.int32)
+            self.L.orb_oracle_set_gauss_taps(self.h, _p(t))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orb_oracle_destroy(self.h)
+            self.h = None
+
+    def extract(self, img, lap=(0, 0), cap=None):
+        """Returns (monoIndex, kps[KP_DTYPE], desc[n,32])."""
+        img = np.asarray(img)
+        if img.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        cap = cap or (self.nfeatures + 64 + 16 * self.nlevels)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        r = self.L.orb_oracle_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1],
+                                      _p(kps), _p(desc), cap, C.byref(n))
+        if r < -1:
+            raise RuntimeError("oracle extract failed: %d" % r)
+        return r, kps[: n.value].copy(), desc[: n.value].copy()
+
+    def scale_tables(self):
+        out = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        self.L.orb_oracle_get_scale_tables(self.h, *[_p(o) for o in out])
+        return out
+
+    def features_per_level(self):
+        o = np.zeros(self.nlevels, np.int32)
+        self.L.orb_oracle_get_features_per_level(self.h, _p(o))
+        return o
+
+    def umax(self):
+        o = np.zeros(16, np.int32)
+        self.L.orb_oracle_get_umax(self.h, _p(o))
+        return o
+
+    def _img(self, fn, level):
+        d, r, c, s = C.c_void_p(), C.c_int(), C.c_int(), C.c_size_t()
+        if fn(self.h, level, C.byref(d), C.byref(r), C.byref(c), C.byref(s)) != 0:
+            return None
+        buf = (C.c_uint8 * (r.value * s.value)).from_address(d.value)
+        a = np.frombuffer(buf, np.uint8).reshape(r.value, s.value)[:, : c.value]
+        return a.copy()
+
+    def level(self, level):
+        """Padded level (rows+38, cols+38), i.e. the buffer behind mvImagePyramid[level]."""
+        return self._img(self.L.orb_oracle_get_level, level)
+
+    def blurred(self, level):
+        return self._img(self.L.orb_oracle_get_blurred, level)
+
+    def _kps(self, fn, level):
+        p = C.c_void_p()
+        n = fn(self.h, level, C.byref(p))
+        if n <= 0:
+            return np.zeros(0, KP_DTYPE)
+        buf = (C.c_uint8 * (n * 28)).from_address(p.value)
+        return np.frombuffer(buf, KP_DTYPE).copy()
+
+    def candidates(self, level):
+        return self._kps(self.L.orb_oracle_get_candidates, level)
+
+    def level_keypoints(self, level):
+        return self._kps(self.L.orb_oracle_get_level_keypoints, level)
+
+
+def resize_linear(src, dh, dw):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orb_oracle_resize_linear(_p(src), src.shape[0], src.shape[1], src.strides[0], _p(dst), dh, dw, dst.strides[0])
+    return dst
+
+
+def border_reflect101(interior, border):
+    h, w = interior.shape
+    buf = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    buf[border:border + h, border:border + w] = interior
+    lib().orb_oracle_border_reflect101(_p(buf), buf.shape[0], buf.shape[1], buf.strides[0], border)
+    return buf
+
+
+def fast(img, threshold, nms=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(max(cap, 1), KP_DTYPE)
+    n = lib().orb_oracle_fast(_p(img), img.shape[0], img.shape[1], img.strides[0], threshold, int(nms), _p(out), cap)
+    return out[:n].copy()
+
+
+def fast_score_closed(patch7):
+    p = np.ascontiguousarray(patch7, np.uint8)
+    assert p.shape == (7, 7)
+    return lib().orb_oracle_fast_score_closed(C.c_void_p(p.ctypes.data + 3 * 7 + 3), 7)
+
+
+def fast_score_2loop(patch7, threshold):
+    p = np.ascontiguousarray(patch7, np.uint8)
+    assert p.shape == (7, 7)
+    return lib().orb_oracle_fast_score_2loop(C.c_void_p(p.ctypes.data + 3 * 7 + 3), 7, threshold)
+
+
+def gaussian_blur7(img, taps=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    dst = np.zeros_like(img)
+    t = None if taps is None else np.ascontiguousarray(taps, np.int32)
+    lib().orb_oracle_gaussian_blur7(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(dst), dst.strides[0],
+                                    None if t is None else _p(t))
+    return dst
+
+
+def fast_atan2(y, x):
+    return float(lib().orb_oracle_fast_atan2(float(y), float(x)))
+
+
+def sincos_cr(angle):
+    s, c = C.c_float(), C.c_float()
+    lib().orb_oracle_sincos_cr(float(angle), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def distribute_octree(cands, minX, maxX, minY, maxY, N):
+    cands = np.ascontiguousarray(cands, KP_DTYPE)
+    cap = max(len(cands), 1)
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().orb_oracle_distribute_octree(_p(cands), len(cands), minX, maxX, minY, maxY, N, _p(out), cap)
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orb_oracle_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_matrix(A, B):
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32)
+    B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    D = np.zeros((len(A), len(B)), np.uint16)
+    lib().orb_oracle_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(D))
+    return D
+
+
+def bfknn2(Q, T):
+    Q = np.ascontiguousarray(Q, np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(Q), 2), np.int32)
+    dist = np.zeros((len(Q), 2), np.int32)
+    lib().orb_oracle_bfknn2(_p(Q), len(Q), _p(T), len(T), _p(idx), _p(dist))
+    return idx, dist
+
+
+def three_maxima(counts):
+    c = np.ascontiguousarray(counts, np.int32)
+    a, b, d = C.c_int(), C.c_int(), C.c_int()
+    lib().orb_oracle_three_maxima(_p(c), len(c), C.byref(a), C.byref(b), C.byref(d))
+    return a.value, b.value, d.value
+
+
+def search_bow_kf_f(descKF, maskKF, angKF, fvKF, descF, angF, fvF, Nleft=-1, nnratio=0.7, check_ori=True):
+    descKF = np.ascontiguousarray(descKF, np.uint8).reshape(-1, 32)
+    descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+    maskKF = np.ascontiguousarray(maskKF, np.uint8)
+    angKF = np.ascontiguousarray(angKF, np.float32)
+    angF = np.ascontiguousarray(angF, np.float32)
+    a, b = _fv(fvKF), _fv(fvF)
+    match = np.zeros(len(descF), np.int32)
+    n = lib().orb_oracle_search_bow_kf_f(_p(descKF), len(descKF), _p(maskKF), _p(angKF), C.byref(a), _p(descF),
+                                         len(descF), _p(angF), C.byref(b), Nleft, nnratio, int(check_ori), _p(match))
+    return n, match
+
+
+def search_bow_kf_kf(desc1, mask1, ang1, fv1, desc2, mask2, ang2, fv2, lim1=-1, lim2=-1, nnratio=0.9,
+                     check_ori=True):
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    mask1 = np.ascontiguousarray(mask1, np.uint8)
+    mask2 = np.ascontiguousarray(mask2, np.uint8)
+    ang1 = np.ascontiguousarray(ang1, np.float32)
+    ang2 = np.ascontiguousarray(ang2, np.float32)
+    a, b = _fv(fv1), _fv(fv2)
+    match = np.zeros(len(desc1), np.int32)
+    n = lib().orb_oracle_search_bow_kf_kf(_p(desc1), len(desc1), _p(mask1), _p(ang1), C.byref(a), lim1, _p(desc2),
+                                          len(desc2), _p(mask2), _p(ang2), C.byref(b), lim2, nnratio, int(check_ori),
+                                          _p(match))
+    return n, match
+
+
+def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasMP2, kp2xy, ang2, oct2, uR2, fv2, F12,
+                         ep, scaleFactors2, levelSigma2_2, only_stereo=False, coarse=False, check_ori=True):
+    def prep(desc, has, xy, ang, oc, ur):
+        return (np.ascontiguousarray(desc, np.uint8).reshape(-1, 32), np.ascontiguousarray(has, np.uint8),
+                np.ascontiguousarray(xy, np.float32).reshape(-1, 2), np.ascontiguousarray(ang, np.float32),
+                np.ascontiguousarray(oc, np.int32), np.ascontiguousarray(ur, np.float32))
+
+    d1, h1, x1, a1, o1, u1 = prep(desc1, hasMP1, kp1xy, ang1, oct1, uR1)
+    d2, h2, x2, a2, o2, u2 = prep(desc2, hasMP2, kp2xy, ang2, oct2, uR2)
+    f1, f2 = _fv(fv1), _fv(fv2)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf2 = np.ascontiguousarray(scaleFactors2, np.float32)
+    ls2 = np.ascontiguousarray(levelSigma2_2, np.float32)
+    pairs = np.zeros((max(len(d1), 1), 2), np.int32)
+    n = lib().orb_oracle_search_triangulation(
+        _p(d1), len(d1), _p(h1), _p(x1), _p(a1), _p(o1), _p(u1), C.byref(f1),
+        _p(d2), len(d2), _p(h2), _p(x2), _p(a2), _p(o2), _p(u2), C.byref(f2),
+        _p(F), float(ep[0]), float(ep[1]), _p(sf2), _p(ls2), int(only_stereo), int(coarse), int(check_ori), _p(pairs))
+    return pairs[:n].copy()
+
+
+def kb8_unproject(params8, uv):
+    P = np.ascontiguousarray(params8, np.float32)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    rays = np.zeros((len(uv), 3), np.float32)
+    lib().orb_oracle_kb8_unproject(_p(P), _p(uv), len(uv), _p(rays))
+    return rays

@@ -1,0 +1,107 @@
+"""Seeded synthetic grayscale frames with EuRoC-like corner density.
+
+There are no datasets in the build or measurement environment, so the parity tests
+and bench.py use these frames: a low-frequency value-noise
+background, a few hundred random axis-aligned / rotated rectangles of uniform grey
+(FAST corners at many scales), additive Gaussian noise, plus a flat region so that
+some cells exercise the minThFAST fallback (reference src/ORBextractor.cc:825-828).
+"""
+import numpy as np
+
+
+def _value_noise(rng, h, w, lattice=64, sigma=40.0):
+    gh, gw = h // lattice + 2, w // lattice + 2
+    g = rng.normal(0.0, sigma, size=(gh, gw))
+    ys = np.arange(h) / lattice
+    xs = np.arange(w) / lattice
+    y0 = ys.astype(np.int64)
+    x0 = xs.astype(np.int64)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_frame(h, w, seed, nrect=None, noise_sigma=2.0, flat_frac=0.08):
+    """Return an (h, w) uint8 frame; deterministic in (h, w, seed)."""
+    rng = np.random.default_rng(int(seed))
+    img = 128.0 + _value_noise(rng, h, w)
+    if nrect is None:
+        nrect = int(300 + 300 * (h * w) / (752.0 * 480.0) ** 1.0 * 0.5)
+        nrect = min(nrect, 900)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(nrect):
+        cx = rng.uniform(0, w)
+        cy = rng.uniform(0, h)
+        hw = rng.uniform(3, 0.08 * w)
+        hh = rng.uniform(3, 0.08 * h)
+        grey = rng.uniform(0, 255)
+        if rng.uniform() < 0.5:
+            ang = 0.0
+        else:
+            ang = rng.uniform(0, np.pi)
+        r = int(np.ceil(np.hypot(hw, hh))) + 1
+        x0, x1 = max(0, int(cx) - r), min(w, int(cx) + r + 1)
+        y0, y1 = max(0, int(cy) - r), min(h, int(cy) + r + 1)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        dx = xx[y0:y1, x0:x1] - cx
+        dy = yy[y0:y1, x0:x1] - cy
+        ca, sa = np.cos(ang), np.sin(ang)
+        u = dx * ca + dy * sa
+        v = -dx * sa + dy * ca
+        m = (np.abs(u) <= hw) & (np.abs(v) <= hh)
+        sub = img[y0:y1, x0:x1]
+        sub[m] = grey
+    # a flat patch (exercises the minThFAST fallback and empty cells)
+    fw = int(w * np.sqrt(flat_frac))
+    fh = int(h * np.sqrt(flat_frac))
+    fx0 = int(rng.uniform(0, w - fw))
+    fy0 = int(rng.uniform(0, h - fh))
+    img[fy0:fy0 + fh, fx0:fx0 + fw] = 0.5 * img[fy0:fy0 + fh, fx0:fx0 + fw].mean() + 60.0
+    img[fy0:fy0 + fh // 2, fx0:fx0 + fw // 2] += 9.0  # weak corner: only visible at minThFAST
+    img += rng.normal(0.0, noise_sigma, size=(h, w))
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+
+
+def make_stereo_pair(h, w, seed, shift=24):
+    """Left frame and a horizontally shifted, re-noised right frame (config C3)."""
+    left = make_frame(h, w, seed)
+    rng = np.random.default_rng(int(seed) + 7919)
+    right = np.empty_like(left)
+    right[:, : w - shift] = left[:, shift:]
+    right[:, w - shift:] = left[:, w - shift - 1: w - 2 * shift - 1: -1] if shift > 0 else left[:, :0]
+    right = np.clip(right.astype(np.float64) + rng.normal(0, 1.5, size=right.shape), 0, 255)
+    return left, np.ascontiguousarray(np.rint(right).astype(np.uint8))
+
+
+def make_batch(n, h, w, seed0=1234):
+    """n frames, frame i uses seed seed0+i."""
+    return np.stack([make_frame(h, w, seed0 + i) for i in range(n)], axis=0)
+
+
+def make_feature_vectors(desc, seed, branching=10, depth=2):
+    """Synthetic DBoW2-like FeatureVector in CSR form.
+
+    Assigns every 32-byte descriptor to the nearest (Hamming) of branching**depth
+    random 256-bit centroids; node ids ascending, feature indices ascending in a node.
+    Returns (node_ids uint32[nn], offsets int32[nn+1], indices int32[N]).
+    """
+    rng = np.random.default_rng(int(seed))
+    ncent = branching ** depth
+    cent = rng.integers(0, 256, size=(ncent, 32), dtype=np.uint8)
+    d = np.asarray(desc, dtype=np.uint8).reshape(-1, 32)
+    if d.shape[0] == 0:
+        return (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    x = np.bitwise_xor(d[:, None, :], cent[None, :, :])
+    dist = np.unpackbits(x, axis=2).sum(axis=2)
+    node = dist.argmin(axis=1)
+    order = np.argsort(node, kind="stable")
+    nodes_sorted = node[order]
+    node_ids, counts = np.unique(nodes_sorted, return_counts=True)
+    offsets = np.zeros(len(node_ids) + 1, np.int32)
+    offsets[1:] = np.cumsum(counts)
+    return node_ids.astype(np.uint32), offsets, order.astype(np.int32)
