@@ -1,0 +1,168 @@
+/*
+ * orbfe.h -- C ABI of the MI355X-native ORB front-end (liborbfe.so).
+ *
+ * Drop-in boundary for the hot path of ORB-SLAM3's feature front-end
+ * (reference = Taeyoung96/ORB_SLAM3_detailed_comments_KOR, paths below are relative to it):
+ *
+ *   extractor : ORB_SLAM3::ORBextractor              include/ORBextractor.h:43-107
+ *               ctor                                   src/ORBextractor.cc:408-468
+ *               operator()                             src/ORBextractor.cc:1068-1150
+ *               (called only by Frame::ExtractORB      src/Frame.cc:413-420)
+ *   matcher   : ORBmatcher::DescriptorDistance         src/ORBmatcher.cc:2591-2607
+ *               ORBmatcher::SearchByBoW (KF,F)         src/ORBmatcher.cc:269-471
+ *               ORBmatcher::SearchByBoW (KF,KF)        src/ORBmatcher.cc:823-963
+ *               ORBmatcher::SearchForTriangulation_    src/ORBmatcher.cc:1208-1449
+ *               Frame::ComputeStereoFishEyeMatches     src/Frame.cc:1119-1159 (BFMatcher knn-2)
+ *               KannalaBrandt8::unproject              src/CameraModels/KannalaBrandt8.cpp:96-123
+ *
+ * Plain C, plain pointers and sizes, no OpenCV / torch types.  adapters/ORBextractor.h wraps
+ * these entry points back into the reference's C++ signatures.
+ *
+ * Conventions: return >= 0 on success, negative on error; nothing throws or aborts.
+ *   -1                 empty image (same value ORBextractor::operator() returns, :1072-1073)
+ *   ORBFE_ERR_ARGS     bad argument / unsupported size / capacity too small
+ *   ORBFE_ERR_NODEV    no usable HIP device (the library never falls back to the CPU)
+ *   <= -1000           -(1000 + hipError_t)
+ * Thread-safety: distinct contexts may be used concurrently; one context = one caller at a time
+ * (same rule as an ORBextractor instance, which owns mvImagePyramid).
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_ERR_ARGS (-2)
+#define ORBFE_ERR_NODEV (-3)
+#define ORBFE_ERR_STATE (-4)
+
+typedef struct orbfe_ctx orbfe_ctx; /* one per ORBextractor instance */
+
+/* Bit-compatible with cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id), 28 bytes. */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbfe_kp;
+
+/* ---- extractor: replaces ORBextractor::ORBextractor (src/ORBextractor.cc:408-468) ---- */
+int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                 int device /* HIP device ordinal */);
+void orbfe_destroy(orbfe_ctx*);
+
+/* Run on an existing hipStream_t (e.g. the caller's torch stream); NULL = context-owned stream. */
+int orbfe_set_stream(orbfe_ctx*, void* hip_stream);
+/* 7 fixed-point (8.8) Gaussian taps; default {18,34,48,56,48,34,18} = OpenCV >= 4.1.2. */
+int orbfe_set_gaussian_taps(orbfe_ctx*, const int* taps7);
+/* Rotation trig of the descriptor (src/ORBextractor.cc:110-111):
+ *   ORBFE_TRIG_LIBM (default): bit-identical to host libm cosf/sinf -- the device evaluates a correctly
+ *       rounded sin/cos, flags keypoints whose sampling grid could change under a 1-ulp difference, and
+ *       those are re-evaluated on the device with the host libm values.
+ *   ORBFE_TRIG_CR: correctly rounded sin/cos only (no host involvement). */
+#define ORBFE_TRIG_LIBM 0
+#define ORBFE_TRIG_CR 1
+int orbfe_set_trig_mode(orbfe_ctx*, int mode);
+
+/* Upper bound of keypoints one image can yield with this context's parameters for a rows x cols image
+ * (sum over levels of max(N_l + 3, 4 * nIni_l)); `cap` arguments below must be >= this. */
+int orbfe_max_keypoints(orbfe_ctx*, int rows, int cols);
+
+/* Replaces ORBextractor::operator() (src/ORBextractor.cc:1068-1150).  Host pointers.
+ * Returns monoIndex (>= 0), -1 for an empty image; *n_out = number of keypoints (rows of desc).
+ * lap0/lap1 = vLappingArea[0..1].  kps/desc must hold `cap` entries (cap*28 and cap*32 bytes). */
+int orbfe_extract(orbfe_ctx*, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
+                  orbfe_kp* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched operator(): nimg images of identical size, one call (multi-camera / multi-frame path).
+ * kps/desc are nimg slabs of cap_per_img entries; n_out[i], mono_out[i] per image. */
+int orbfe_extract_batch(orbfe_ctx*, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride,
+                        const int* lap /* 2*nimg or NULL (= {0,0}) */, orbfe_kp* kps, uint8_t* desc, int cap_per_img,
+                        int* n_out, int* mono_out);
+
+/* Same, with every buffer already resident in device memory (no PCIe traffic).  Asynchronous on the
+ * context's stream unless the trig mode needs the host (ORBFE_TRIG_LIBM synchronises once per call).
+ * d_imgs: nimg images, image i at d_imgs + i*img_stride_bytes, row pitch `pitch`. */
+int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch,
+                               size_t img_stride_bytes, int lap0, int lap1, orbfe_kp* d_kps, uint8_t* d_desc,
+                               int cap_per_img, int32_t* d_n_out, int32_t* d_mono_out);
+int orbfe_sync(orbfe_ctx*);
+
+/* Scale getters (include/ORBextractor.h:61-81) and mvImagePyramid (:83). */
+int orbfe_get_levels(orbfe_ctx*);
+float orbfe_get_scale_factor(orbfe_ctx*);
+void orbfe_get_scale_tables(orbfe_ctx*, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2);
+void orbfe_get_features_per_level(orbfe_ctx*, int* n_per_level);
+/* Copies level `level` of image `img_index` of the last call, with its 19-px REFLECT_101 frame, to
+ * dst (rows+38 by cols+38 of the level, row stride dst_stride).  Pass dst=NULL to query the size. */
+int orbfe_get_level(orbfe_ctx*, int img_index, int level, uint8_t* dst, size_t dst_stride, int* rows, int* cols);
+
+/* Per-stage device time of the last call, measured with hipEvents on the context's stream. */
+#define ORBFE_STAGE_PYRAMID 0
+#define ORBFE_STAGE_FAST 1
+#define ORBFE_STAGE_OCTREE 2
+#define ORBFE_STAGE_PACK 3
+#define ORBFE_STAGE_DESC 4
+#define ORBFE_STAGE_COUNT 5
+int orbfe_profile_enable(orbfe_ctx*, int on);
+int orbfe_profile_read(orbfe_ctx*, float* ms_per_stage /* ORBFE_STAGE_COUNT */);
+
+/* Stage taps for parity tests: state of the last call. Packed entry = x | y<<12 | response<<24
+ * with x,y relative to (minBorderX, minBorderY) = (16,16) of the level. */
+int orbfe_debug_candidates(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
+int orbfe_debug_level_keypoints(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
+int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm trig in the last call */
+
+/* ---- matcher ---- */
+/* DescriptorDistance over all pairs: D[i*nB+j] = popcount(A_i xor B_j).  Host pointers. */
+int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (src/Frame.cc:1137): idx/dist hold 2 entries per query,
+ * ascending distance, ties -> lower train index; -1 when fewer than 1/2 train rows exist. */
+int orbfe_bfknn2(int device, const uint8_t* Q, int nQ, const uint8_t* T, int nT, int32_t* idx, int32_t* dist);
+
+/* DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:24-25) in CSR form. */
+typedef struct {
+    int nn;                   /* distinct nodes                      */
+    const uint32_t* node_ids; /* ascending                           */
+    const int32_t* offsets;   /* nn+1                                */
+    const int32_t* indices;   /* offsets[nn] feature indices         */
+} orbfe_fv;
+
+typedef struct {
+    const uint8_t* desc1; int n1; const uint8_t* mask1 /* 1 = good MapPoint */; const float* angle1;
+    orbfe_fv fv1; int limit1 /* -1, or mvKeysUn.size() for the KF-KF variant */;
+    const uint8_t* desc2; int n2; const uint8_t* mask2 /* KF-KF variant only */; const float* angle2;
+    orbfe_fv fv2; int limit2;
+    int Nleft;       /* KF-F variant: F.Nleft, -1 = monocular         */
+    float nnratio;   /* mfNNratio                                     */
+    int check_orientation;
+    int variant;     /* 0 = SearchByBoW(KeyFrame*,Frame&), 1 = SearchByBoW(KeyFrame*,KeyFrame*) */
+} orbfe_bow_args;
+/* variant 0: match[n2] = index into set 1 (the KeyFrame) or -1; variant 1: match[n1] = index into set 2 or -1.
+ * Returns nmatches. */
+int orbfe_search_bow(int device, const orbfe_bow_args*, int32_t* match);
+
+typedef struct {
+    const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1_xy; const float* angle1;
+    const int32_t* octave1; const float* uRight1; orbfe_fv fv1;
+    const uint8_t* desc2; int n2; const uint8_t* hasMP2; const float* kp2_xy; const float* angle2;
+    const int32_t* octave2; const float* uRight2; orbfe_fv fv2;
+    float F12[9];    /* K1^-T [t12]x R12 K2^-1 as Pinhole::epipolarConstrain_ forms it (Pinhole.cpp:161-164) */
+    float ep[2];     /* epipole in image 2 */
+    const float* scaleFactors2; const float* levelSigma2_2; int nlevels2;
+    int only_stereo, coarse, check_orientation;
+} orbfe_tri_args;
+/* SearchForTriangulation_ (monocular / rectified pinhole rig).  pairs[2*k], pairs[2*k+1]; returns npairs. */
+int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 */);
+
+/* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
+int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
+
+const char* orbfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

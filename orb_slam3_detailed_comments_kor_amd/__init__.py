@@ -1,0 +1,10 @@
+"""MI355X-native ORB front-end for ORB-SLAM3 (extractor + Hamming matcher hot path).
+
+The product is the HIP library `liborbfe.so` behind the C ABI in include/orbfe.h; this
+package is the thin Python binding used by the tests and by bench.py.  There is no CPU
+fallback: importing the binding without the built library, or calling it without a
+HIP device, fails loudly.
+"""
+from . import synth  # noqa: F401
+from .binding import (KP_DTYPE, ORBextractor, OrbfeError, bfknn2, hamming_pairs, kb8_unproject, lib, lib_path,  # noqa: F401
+                      search_bow, search_triangulation)

@@ -1,0 +1,341 @@
+"""ctypes binding of liborbfe.so (include/orbfe.h).
+
+`ORBextractor` mirrors the reference class (include/ORBextractor.h:43-107): same
+constructor arguments, `__call__(image, lapping_area)` = operator(), scale getters and
+the image pyramid.  Everything goes through the C ABI; nothing here computes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+ERR_ARGS, ERR_NODEV, ERR_STATE = -2, -3, -4
+TRIG_LIBM, TRIG_CR = 0, 1
+STAGES = ("pyramid", "fast", "octree", "pack", "desc")
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with code %d" % (what, code))
+        self.code = code
+
+
+class _FV(C.Structure):
+    _fields_ = [("nn", C.c_int), ("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
+
+
+class _BowArgs(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("mask1", C.c_void_p), ("angle1", C.c_void_p),
+                ("fv1", _FV), ("limit1", C.c_int),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("mask2", C.c_void_p), ("angle2", C.c_void_p),
+                ("fv2", _FV), ("limit2", C.c_int),
+                ("Nleft", C.c_int), ("nnratio", C.c_float), ("check_orientation", C.c_int), ("variant", C.c_int)]
+
+
+class _TriArgs(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("hasMP1", C.c_void_p), ("kp1_xy", C.c_void_p),
+                ("angle1", C.c_void_p), ("octave1", C.c_void_p), ("uRight1", C.c_void_p), ("fv1", _FV),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("hasMP2", C.c_void_p), ("kp2_xy", C.c_void_p),
+                ("angle2", C.c_void_p), ("octave2", C.c_void_p), ("uRight2", C.c_void_p), ("fv2", _FV),
+                ("F12", C.c_float * 9), ("ep", C.c_float * 2),
+                ("scaleFactors2", C.c_void_p), ("levelSigma2_2", C.c_void_p), ("nlevels2", C.c_int),
+                ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "liborbfe.so")
+
+
+def lib():
+    """Load liborbfe.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError("liborbfe.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C orb_slam3_detailed_comments_kor_amd/csrc)")
+        L = C.CDLL(path)
+        L.orbfe_version.restype = C.c_char_p
+        L.orbfe_create.restype = C.c_int
+        L.orbfe_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orbfe_destroy.argtypes = [C.c_void_p]
+        L.orbfe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_set_gaussian_taps.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orbfe_max_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orbfe_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orbfe_extract_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_size_t,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_extract_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
+                                                 C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p]
+        L.orbfe_sync.argtypes = [C.c_void_p]
+        L.orbfe_get_levels.argtypes = [C.c_void_p]
+        L.orbfe_get_scale_factor.restype = C.c_float
+        L.orbfe_get_scale_factor.argtypes = [C.c_void_p]
+        L.orbfe_get_scale_tables.restype = None
+        L.orbfe_get_scale_tables.argtypes = [C.c_void_p] * 5
+        L.orbfe_get_features_per_level.restype = None
+        L.orbfe_get_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
+        L.orbfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.orbfe_profile_read.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbfe_debug_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbfe_debug_fixups.argtypes = [C.c_void_p]
+        L.orbfe_hamming_pairs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbfe_bfknn2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_search_bow.argtypes = [C.c_int, C.POINTER(_BowArgs), C.c_void_p]
+        L.orbfe_search_tri.argtypes = [C.c_int, C.POINTER(_TriArgs), C.c_void_p]
+        L.orbfe_kb8_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
+           "orbfe_set_trig_mode", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_extract_batch_device", "orbfe_sync", "orbfe_get_levels", "orbfe_get_scale_factor",
+           "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
+           "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
+           "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_kb8_unproject"]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(r, what):
+    if r < 0:
+        raise OrbfeError(r, what)
+    return r
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor on one MI355X (reference include/ORBextractor.h:43-107)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0,
+                 trig=TRIG_LIBM, taps=None):
+        self.L = lib()
+        h = C.c_void_p()
+        _chk(self.L.orbfe_create(C.byref(h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device),
+             "orbfe_create")
+        self.h = h
+        self.nfeatures, self.nlevels, self.device = nfeatures, nlevels, device
+        _chk(self.L.orbfe_set_trig_mode(self.h, trig), "orbfe_set_trig_mode")
+        if taps is not None:
+            t = np.ascontiguousarray(taps, np.int32)
+            _chk(self.L.orbfe_set_gaussian_taps(self.h, _p(t)), "orbfe_set_gaussian_taps")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- operator() ---------------------------------------------------------------
+    def max_keypoints(self, rows, cols):
+        return _chk(self.L.orbfe_max_keypoints(self.h, rows, cols), "orbfe_max_keypoints")
+
+    def __call__(self, image, lapping_area=(0, 0)):
+        """operator()(image, mask, keypoints, descriptors, vLappingArea) -> (monoIndex, keypoints, descriptors)."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1  # CV_8UC1, :1076
+        cap = self.max_keypoints(*image.shape)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        r = self.L.orbfe_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0],
+                                 int(lapping_area[0]), int(lapping_area[1]), _p(kps), _p(desc), cap, C.byref(n))
+        if r < -1:
+            raise OrbfeError(r, "orbfe_extract")
+        return r, kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch(self, images, lapping_areas=None):
+        """Batched operator() over same-sized images (host arrays). Returns list of (mono, kps, desc)."""
+        images = [np.ascontiguousarray(im, np.uint8) for im in images]
+        nimg = len(images)
+        rows, cols = images[0].shape
+        assert all(im.shape == (rows, cols) for im in images)
+        cap = self.max_keypoints(rows, cols)
+        kps = np.zeros((nimg, cap), KP_DTYPE)
+        desc = np.zeros((nimg, cap, 32), np.uint8)
+        n = np.zeros(nimg, np.int32)
+        mono = np.zeros(nimg, np.int32)
+        ptrs = (C.c_void_p * nimg)(*[im.ctypes.data for im in images])
+        lap = None
+        if lapping_areas is not None:
+            lap = np.ascontiguousarray(lapping_areas, np.int32).reshape(nimg, 2)
+        _chk(self.L.orbfe_extract_batch(self.h, nimg, ptrs, rows, cols, cols, None if lap is None else _p(lap),
+                                        _p(kps), _p(desc), cap, _p(n), _p(mono)), "orbfe_extract_batch")
+        return [(int(mono[i]), kps[i, : n[i]].copy(), desc[i, : n[i]].copy()) for i in range(nimg)]
+
+    def extract_batch_device(self, d_imgs_ptr, nimg, rows, cols, pitch, img_stride, lap, d_kps_ptr, d_desc_ptr, cap,
+                             d_n_ptr, d_mono_ptr):
+        """Device-resident batched operator(): every pointer is a device address (int)."""
+        return _chk(self.L.orbfe_extract_batch_device(self.h, nimg, d_imgs_ptr, rows, cols, pitch, img_stride,
+                                                      int(lap[0]), int(lap[1]), d_kps_ptr, d_desc_ptr, cap, d_n_ptr,
+                                                      d_mono_ptr), "orbfe_extract_batch_device")
+
+    def set_stream(self, stream_ptr):
+        _chk(self.L.orbfe_set_stream(self.h, stream_ptr), "orbfe_set_stream")
+
+    def sync(self):
+        _chk(self.L.orbfe_sync(self.h), "orbfe_sync")
+
+    # -- getters (include/ORBextractor.h:61-83) -------------------------------------
+    def GetLevels(self):
+        return self.L.orbfe_get_levels(self.h)
+
+    def GetScaleFactor(self):
+        return self.L.orbfe_get_scale_factor(self.h)
+
+    def _tables(self):
+        out = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        self.L.orbfe_get_scale_tables(self.h, *[_p(o) for o in out])
+        return out
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        o = np.zeros(self.nlevels, np.int32)
+        self.L.orbfe_get_features_per_level(self.h, _p(o))
+        return o
+
+    def image_pyramid_level(self, level, img_index=0):
+        """Padded buffer behind mvImagePyramid[level] (level + 19-px REFLECT_101 frame)."""
+        r, c = C.c_int(), C.c_int()
+        _chk(self.L.orbfe_get_level(self.h, img_index, level, None, 0, C.byref(r), C.byref(c)), "orbfe_get_level")
+        out = np.zeros((r.value, c.value), np.uint8)
+        _chk(self.L.orbfe_get_level(self.h, img_index, level, _p(out), out.strides[0], C.byref(r), C.byref(c)),
+             "orbfe_get_level")
+        return out
+
+    # -- profiling / debug taps ---------------------------------------------------
+    def profile(self, on=True):
+        _chk(self.L.orbfe_profile_enable(self.h, int(on)), "orbfe_profile_enable")
+
+    def stage_ms(self):
+        ms = np.zeros(len(STAGES), np.float32)
+        _chk(self.L.orbfe_profile_read(self.h, _p(ms)), "orbfe_profile_read")
+        return dict(zip(STAGES, ms.tolist()))
+
+    @staticmethod
+    def _unpack(a):
+        return (a & 0xFFF).astype(np.int32), ((a >> 12) & 0xFFF).astype(np.int32), (a >> 24).astype(np.int32)
+
+    def debug_candidates(self, level, img_index=0, cap=1 << 20):
+        out = np.zeros(cap, np.uint32)
+        n = _chk(self.L.orbfe_debug_candidates(self.h, img_index, level, _p(out), cap), "orbfe_debug_candidates")
+        return self._unpack(out[:n])
+
+    def debug_level_keypoints(self, level, img_index=0, cap=1 << 16):
+        out = np.zeros(cap, np.uint32)
+        n = _chk(self.L.orbfe_debug_level_keypoints(self.h, img_index, level, _p(out), cap),
+                 "orbfe_debug_level_keypoints")
+        return self._unpack(out[:n])
+
+    def debug_fixups(self):
+        return self.L.orbfe_debug_fixups(self.h)
+
+
+# ------------------------------------------------------------------------ matcher
+def _fv(fv):
+    node_ids, offsets, indices = fv
+    node_ids = np.ascontiguousarray(node_ids, np.uint32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    indices = np.ascontiguousarray(indices, np.int32)
+    s = _FV(len(node_ids), node_ids.ctypes.data, offsets.ctypes.data, indices.ctypes.data)
+    return s, (node_ids, offsets, indices)
+
+
+def hamming_pairs(A, B, device=0):
+    """ORBmatcher::DescriptorDistance over all pairs (src/ORBmatcher.cc:2591-2607)."""
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32)
+    B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    D = np.zeros((len(A), len(B)), np.uint16)
+    _chk(lib().orbfe_hamming_pairs(device, _p(A), len(A), _p(B), len(B), _p(D)), "orbfe_hamming_pairs")
+    return D
+
+
+def bfknn2(Q, T, device=0):
+    """cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (src/Frame.cc:1137)."""
+    Q = np.ascontiguousarray(Q, np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(Q), 2), np.int32)
+    dist = np.zeros((len(Q), 2), np.int32)
+    _chk(lib().orbfe_bfknn2(device, _p(Q), len(Q), _p(T), len(T), _p(idx), _p(dist)), "orbfe_bfknn2")
+    return idx, dist
+
+
+def search_bow(desc1, mask1, ang1, fv1, desc2, mask2, ang2, fv2, variant, nnratio, check_ori=True, Nleft=-1,
+               limit1=-1, limit2=-1, device=0):
+    """ORBmatcher::SearchByBoW: variant 0 = (KeyFrame*, Frame&) :269-471, 1 = (KeyFrame*, KeyFrame*) :823-963."""
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    m1 = np.ascontiguousarray(mask1, np.uint8)
+    m2 = np.ascontiguousarray(mask2 if mask2 is not None else np.ones(len(d2)), np.uint8)
+    a1 = np.ascontiguousarray(ang1, np.float32)
+    a2 = np.ascontiguousarray(ang2, np.float32)
+    f1, k1 = _fv(fv1)
+    f2, k2 = _fv(fv2)
+    args = _BowArgs(d1.ctypes.data, len(d1), m1.ctypes.data, a1.ctypes.data, f1, limit1, d2.ctypes.data, len(d2),
+                    m2.ctypes.data, a2.ctypes.data, f2, limit2, Nleft, nnratio, int(check_ori), variant)
+    match = np.zeros(len(d2) if variant == 0 else len(d1), np.int32)
+    n = _chk(lib().orbfe_search_bow(device, C.byref(args), _p(match)), "orbfe_search_bow")
+    return n, match
+
+
+def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasMP2, kp2xy, ang2, oct2, uR2, fv2, F12,
+                         ep, scaleFactors2, levelSigma2_2, only_stereo=False, coarse=False, check_ori=True, device=0):
+    """ORBmatcher::SearchForTriangulation_ (src/ORBmatcher.cc:1208-1449), pinhole gate."""
+    def prep(desc, has, xy, ang, oc, ur):
+        return (np.ascontiguousarray(desc, np.uint8).reshape(-1, 32), np.ascontiguousarray(has, np.uint8),
+                np.ascontiguousarray(xy, np.float32).reshape(-1, 2), np.ascontiguousarray(ang, np.float32),
+                np.ascontiguousarray(oc, np.int32), np.ascontiguousarray(ur, np.float32))
+
+    d1, h1, x1, a1, o1, u1 = prep(desc1, hasMP1, kp1xy, ang1, oct1, uR1)
+    d2, h2, x2, a2, o2, u2 = prep(desc2, hasMP2, kp2xy, ang2, oct2, uR2)
+    f1, k1 = _fv(fv1)
+    f2, k2 = _fv(fv2)
+    sf2 = np.ascontiguousarray(scaleFactors2, np.float32)
+    ls2 = np.ascontiguousarray(levelSigma2_2, np.float32)
+    F = (C.c_float * 9)(*[float(v) for v in np.asarray(F12, np.float32).reshape(9)])
+    e = (C.c_float * 2)(float(ep[0]), float(ep[1]))
+    args = _TriArgs(d1.ctypes.data, len(d1), h1.ctypes.data, x1.ctypes.data, a1.ctypes.data, o1.ctypes.data,
+                    u1.ctypes.data, f1, d2.ctypes.data, len(d2), h2.ctypes.data, x2.ctypes.data, a2.ctypes.data,
+                    o2.ctypes.data, u2.ctypes.data, f2, F, e, sf2.ctypes.data, ls2.ctypes.data, len(sf2),
+                    int(only_stereo), int(coarse), int(check_ori))
+    pairs = np.zeros((max(len(d1), 1), 2), np.int32)
+    n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
+    return pairs[:n].copy()
+
+
+def kb8_unproject(params8, uv, device=0):
+    """KannalaBrandt8::unproject (src/CameraModels/KannalaBrandt8.cpp:96-123)."""
+    P = np.ascontiguousarray(params8, np.float32)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    rays = np.zeros((len(uv), 3), np.float32)
+    _chk(lib().orbfe_kb8_unproject(device, _p(P), _p(uv), len(uv), _p(rays)), "orbfe_kb8_unproject")
+    return rays

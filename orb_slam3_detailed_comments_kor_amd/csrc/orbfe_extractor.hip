@@ -1,0 +1,767 @@
+/*
+ * orbfe_extractor.hip -- host side of the extractor behind the C ABI (include/orbfe.h).
+ *
+ * Mirrors ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:43-107):
+ *   orbfe_create          <- ORBextractor::ORBextractor      src/ORBextractor.cc:408-468
+ *   orbfe_extract*        <- ORBextractor::operator()        src/ORBextractor.cc:1068-1150
+ *   orbfe_get_level       <- mvImagePyramid                  include/ORBextractor.h:83
+ * There is no CPU fallback: without a HIP device every entry point fails with ORBFE_ERR_NODEV.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/orbfe.h"
+#include "orbfe_geom.h"
+#include "orbfe_sincos.h"
+
+// single translation unit: the kernels are compiled together with their launch code
+#include "orbfe_kernels.hip"
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return -(1000 + (int)_e);    \
+    } while (0)
+
+namespace {
+
+inline int cv_round_f(float v) { return (int)lrintf(v); }
+inline int cv_floor_d(double v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+inline int16_t sat_s16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) return -(1000 + (int)e);
+        n = count;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        n = count;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+} // namespace
+
+struct orbfe_ctx {
+    // parameters (reference include/ORBextractor.h:89-105)
+    int nfeatures;
+    double scaleFactor; // a double initialised from a float, :96
+    int nlevels, iniThFAST, minThFAST;
+    int device;
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    int trigMode = ORBFE_TRIG_LIBM;
+
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+
+    // geometry of the current image size
+    int rows = 0, cols = 0;
+    std::vector<OrbLevelGeom> lg;
+    std::vector<OrbCellGeom> cg;
+    size_t pyrStride = 0, candStride = 0, keyStride = 0, kpStride = 0;
+    int nCells = 0, maxKp = 0, maxListCap = 0;
+    size_t qtLdsBytes = 0;
+
+    // device state
+    int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
+    DevBuf<uint8_t> d_pyr, d_fragile, d_desc, d_img;
+    DevBuf<uint32_t> d_cand, d_keys, d_lvlKp;
+    DevBuf<uint16_t> d_keyNode;
+    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono, d_misc /* [0]=err [1]=fixCount */, d_fixList;
+    DevBuf<float> d_kps, d_fixAB, d_fixAngle;
+    DevBuf<OrbDescWork> d_work;
+    DevBuf<OrbLevelGeom> d_lg;
+    DevBuf<OrbCellGeom> d_cg;
+    DevBuf<OrbResizeX> d_xtab;
+    DevBuf<OrbResizeY> d_ytab;
+    DevBuf<int> d_taps;
+    PinBuf<int32_t> h_misc, h_fixList, h_n, h_mono;
+    PinBuf<float> h_fixAngle, h_fixAB;
+    size_t imgPitch = 0, imgStride = 0;
+
+    int lastImgs = 0;
+    int lastFixups = 0;
+    bool profile = false;
+    hipEvent_t ev[ORBFE_STAGE_COUNT + 1] = {};
+    bool evReady = false, evRecorded = false;
+};
+
+namespace {
+
+// ORBextractor ctor, reference src/ORBextractor.cc:408-444
+void init_tables(orbfe_ctx* c)
+{
+    const int nl = c->nlevels;
+    c->mvScaleFactor.resize(nl);
+    c->mvLevelSigma2.resize(nl);
+    c->mvScaleFactor[0] = 1.0f;
+    c->mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        c->mvScaleFactor[i] = (float)(c->mvScaleFactor[i - 1] * c->scaleFactor);
+        c->mvLevelSigma2[i] = c->mvScaleFactor[i] * c->mvScaleFactor[i];
+    }
+    c->mvInvScaleFactor.resize(nl);
+    c->mvInvLevelSigma2.resize(nl);
+    for (int i = 0; i < nl; i++) {
+        c->mvInvScaleFactor[i] = 1.0f / c->mvScaleFactor[i];
+        c->mvInvLevelSigma2[i] = 1.0f / c->mvLevelSigma2[i];
+    }
+    c->mnFeaturesPerLevel.resize(nl);
+    float factor = (float)(1.0f / c->scaleFactor);
+    float nDesired = c->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        c->mnFeaturesPerLevel[l] = cv_round_f(nDesired);
+        sum += c->mnFeaturesPerLevel[l];
+        nDesired *= factor;
+    }
+    c->mnFeaturesPerLevel[nl - 1] = std::max(c->nfeatures - sum, 0);
+}
+
+// Level sizes (:1157), cell grid (:771-804), quadtree roots (:540-556), resize tables
+int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xtab, std::vector<OrbResizeY>& ytab)
+{
+    const int nl = c->nlevels;
+    c->lg.assign(nl, OrbLevelGeom());
+    c->cg.clear();
+    xtab.clear();
+    ytab.clear();
+    size_t off = 0;
+    int slot = 0, kpBase = 0, keyBase = 0, maxKp = 0, maxLC = 0;
+    for (int l = 0; l < nl; l++) {
+        OrbLevelGeom& L = c->lg[l];
+        const float inv = c->mvInvScaleFactor[l];
+        L.w = cv_round_f((float)cols * inv);
+        L.h = cv_round_f((float)rows * inv);
+        if (L.w > ORBFE_MAX_DIM || L.h > ORBFE_MAX_DIM) return ORBFE_ERR_ARGS;
+        L.pitch = (int)align_up((size_t)ORBFE_ROI_X0 + L.w + ORBFE_EDGE, 64);
+        L.bufOff = (uint32_t)off;
+        L.roiOff = (uint32_t)(off + (size_t)ORBFE_EDGE * L.pitch + ORBFE_ROI_X0);
+        off = align_up(off + (size_t)(L.h + 2 * ORBFE_EDGE) * L.pitch, 256);
+        if (off > 0xFFFFFFFFull) return ORBFE_ERR_ARGS;
+        L.maxBX = L.w - ORBFE_EDGE + 3;
+        L.maxBY = L.h - ORBFE_EDGE + 3;
+        const float width = (float)(L.maxBX - ORBFE_MINB), height = (float)(L.maxBY - ORBFE_MINB);
+        const float W = 35;
+        if (!(width > 0) || !(height > 0)) return ORBFE_ERR_ARGS;
+        L.nCols = (int)(width / W);
+        L.nRows = (int)(height / W);
+        if (L.nCols < 1 || L.nRows < 1) return ORBFE_ERR_ARGS; // the reference divides by zero here
+        L.wCell = (int)std::ceil(width / L.nCols);
+        L.hCell = (int)std::ceil(height / L.nRows);
+        L.cellBase = (int)c->cg.size();
+        int levelSlots = 0;
+        for (int i = 0; i < L.nRows; i++) {
+            const float iniY = (float)(ORBFE_MINB + i * L.hCell);
+            float maxY = iniY + L.hCell + 6;
+            if (iniY >= L.maxBY - 3) continue;
+            if (maxY > L.maxBY) maxY = (float)L.maxBY;
+            for (int j = 0; j < L.nCols; j++) {
+                const float iniX = (float)(ORBFE_MINB + j * L.wCell);
+                float maxX = iniX + L.wCell + 6;
+                if (iniX >= L.maxBX - 6) continue;
+                if (maxX > L.maxBX) maxX = (float)L.maxBX;
+                OrbCellGeom g;
+                g.level = (int16_t)l;
+                g.iniX = (int16_t)iniX;
+                g.iniY = (int16_t)iniY;
+                g.cw = (int16_t)((int)maxX - (int)iniX);
+                g.ch = (int16_t)((int)maxY - (int)iniY);
+                g.offX = (int16_t)(j * L.wCell);
+                g.offY = (int16_t)(i * L.hCell);
+                g.pad = 0;
+                if (g.cw > ORBFE_FAST_TILE - 1 || g.ch > ORBFE_FAST_TILE - 1) return ORBFE_ERR_ARGS;
+                const int zw = std::max(g.cw - 6, 0), zh = std::max(g.ch - 6, 0);
+                g.slotBase = slot;
+                g.slotCap = std::max(((zw + 1) / 2) * ((zh + 1) / 2), 1);
+                slot += g.slotCap;
+                levelSlots += g.slotCap;
+                c->cg.push_back(g);
+            }
+        }
+        L.nCells = (int)c->cg.size() - L.cellBase;
+        L.nFeat = c->mnFeaturesPerLevel[l];
+        L.nIni = (int)std::round(static_cast<float>(L.maxBX - ORBFE_MINB) / (L.maxBY - ORBFE_MINB));
+        L.hX = L.nIni > 0 ? static_cast<float>(L.maxBX - ORBFE_MINB) / L.nIni : 1.f;
+        L.kpCap = std::max(L.nFeat + 3, 4 * std::max(L.nIni, 0)) + 1;
+        L.kpBase = kpBase;
+        kpBase += L.kpCap;
+        L.keyBase = keyBase;
+        L.keyCap = levelSlots;
+        keyBase += levelSlots;
+        L.listCap = L.kpCap + 3;
+        maxLC = std::max(maxLC, L.listCap);
+        maxKp += L.kpCap;
+        L.scale = c->mvScaleFactor[l];
+        L.size = (float)(int)(31 * c->mvScaleFactor[l]);
+        L.xtabOff = (int)xtab.size();
+        L.ytabOff = (int)ytab.size();
+        if (l > 0) {
+            const OrbLevelGeom& S = c->lg[l - 1];
+            const double inv_x = (double)L.w / S.w, inv_y = (double)L.h / S.h;
+            const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_d(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+                OrbResizeX t;
+                t.sx = (uint16_t)sx;
+                t.pad = (uint16_t)std::min(sx + 1, S.w - 1);
+                t.a0 = sat_s16(cv_round_f((1.f - fx) * 2048));
+                t.a1 = sat_s16(cv_round_f(fx * 2048));
+                xtab.push_back(t);
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor_d(fy);
+                fy -= sy;
+                OrbResizeY t;
+                t.sy0 = (uint16_t)std::min(std::max(sy, 0), S.h - 1);
+                t.sy1 = (uint16_t)std::min(std::max(sy + 1, 0), S.h - 1);
+                t.b0 = sat_s16(cv_round_f((1.f - fy) * 2048));
+                t.b1 = sat_s16(cv_round_f(fy * 2048));
+                ytab.push_back(t);
+            }
+        }
+    }
+    c->pyrStride = off;
+    c->candStride = (size_t)slot;
+    c->keyStride = (size_t)keyBase;
+    c->kpStride = (size_t)kpBase;
+    c->nCells = (int)c->cg.size();
+    c->maxKp = maxKp;
+    c->maxListCap = maxLC;
+    c->qtLdsBytes = sizeof(int) * (64 + (size_t)std::max(24 * maxLC, 1024));
+    if (c->qtLdsBytes > 160 * 1024) return ORBFE_ERR_ARGS; // nfeatures too large for one workgroup's LDS
+    return 0;
+}
+
+int max_kp_for(orbfe_ctx* c, int rows, int cols)
+{
+    int total = 0;
+    for (int l = 0; l < c->nlevels; l++) {
+        const int w = cv_round_f((float)cols * c->mvInvScaleFactor[l]);
+        const int h = cv_round_f((float)rows * c->mvInvScaleFactor[l]);
+        const int bx = w - 32, by = h - 32;
+        if (bx < 35 || by < 35) return ORBFE_ERR_ARGS;
+        const int nIni = (int)std::round(static_cast<float>(bx) / by);
+        total += std::max(c->mnFeaturesPerLevel[l] + 3, 4 * std::max(nIni, 0)) + 1;
+    }
+    return total;
+}
+
+int ensure_geometry(orbfe_ctx* c, int rows, int cols)
+{
+    if (rows == c->rows && cols == c->cols && !c->lg.empty()) return 0;
+    std::vector<OrbResizeX> xtab;
+    std::vector<OrbResizeY> ytab;
+    c->rows = c->cols = 0;
+    int r = build_geometry(c, rows, cols, xtab, ytab);
+    if (r < 0) {
+        c->lg.clear();
+        return r;
+    }
+    if ((r = c->d_lg.ensure(c->lg.size())) < 0) return r;
+    if ((r = c->d_cg.ensure(c->cg.size())) < 0) return r;
+    if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
+    if ((r = c->d_ytab.ensure(std::max<size_t>(ytab.size(), 1))) < 0) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
+    if (!xtab.empty())
+        HIP_TRY(hipMemcpy(c->d_xtab.p, xtab.data(), xtab.size() * sizeof(OrbResizeX), hipMemcpyHostToDevice));
+    if (!ytab.empty())
+        HIP_TRY(hipMemcpy(c->d_ytab.p, ytab.data(), ytab.size() * sizeof(OrbResizeY), hipMemcpyHostToDevice));
+    if (c->qtLdsBytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c->qtLdsBytes));
+    c->rows = rows;
+    c->cols = cols;
+    c->capImgs = 0; // per-image strides changed: force re-allocation
+    return 0;
+}
+
+int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
+{
+    if (nimg <= c->capImgs && capKp <= c->capKp) return 0;
+    const size_t B = (size_t)std::max(nimg, c->capImgs);
+    const size_t K = (size_t)std::max(capKp, c->capKp);
+    int r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = c->d_pyr.ensure(B * c->pyrStride + 256)) < 0) return r;
+    if ((r = c->d_cand.ensure(B * c->candStride)) < 0) return r;
+    if ((r = c->d_cellCount.ensure(B * c->nCells)) < 0) return r;
+    if ((r = c->d_keys.ensure(B * c->keyStride)) < 0) return r;
+    if ((r = c->d_keyNode.ensure(B * c->keyStride)) < 0) return r;
+    if ((r = c->d_lvlKp.ensure(B * c->kpStride)) < 0) return r;
+    if ((r = c->d_lvlCount.ensure(B * c->nlevels)) < 0) return r;
+    if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
+    if ((r = c->d_work.ensure(B * K)) < 0) return r;
+    if ((r = c->d_fragile.ensure(B * K)) < 0) return r;
+    if ((r = c->d_fixList.ensure(B * K * 2)) < 0) return r;
+    if ((r = c->d_fixAngle.ensure(B * K)) < 0) return r;
+    if ((r = c->d_fixAB.ensure(B * K * 2)) < 0) return r;
+    if ((r = c->d_misc.ensure(8)) < 0) return r;
+    if ((r = c->h_misc.ensure(8)) < 0) return r;
+    if ((r = c->h_fixList.ensure(B * K * 2)) < 0) return r;
+    if ((r = c->h_fixAngle.ensure(B * K)) < 0) return r;
+    if ((r = c->h_fixAB.ensure(B * K * 2)) < 0) return r;
+    if ((r = c->d_taps.ensure(8)) < 0) return r;
+    HIP_TRY(hipMemset(c->d_misc.p, 0, 8 * sizeof(int32_t)));
+    c->capImgs = (int)B;
+    c->capKp = (int)K;
+    return 0;
+}
+
+inline void rec(orbfe_ctx* c, int i)
+{
+    if (c->profile && c->evReady) (void)hipEventRecord(c->ev[i], c->stream);
+}
+
+// The whole pipeline on the context's stream.  All pointers are device pointers.
+int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch, size_t imgStride,
+               const int32_t* d_lap, float* d_kps, uint8_t* d_desc, int capPerImg, int32_t* d_n, int32_t* d_mono)
+{
+    int r;
+    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if (capPerImg < c->maxKp) return ORBFE_ERR_ARGS;
+    if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
+    hipStream_t s = c->stream;
+    const int nl = c->nlevels;
+    HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 2 * sizeof(int32_t), s));
+    rec(c, 0);
+    // K-PYR
+    {
+        const OrbLevelGeom& L0 = c->lg[0];
+        dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);
+        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_imgs, pitch, imgStride, c->d_pyr.p, c->pyrStride, L0);
+        for (int l = 1; l < nl; l++) {
+            const OrbLevelGeom& Ld = c->lg[l];
+            dim3 g2((unsigned)((Ld.w + 1023) / 1024), (unsigned)Ld.h, (unsigned)nimg);
+            hipLaunchKernelGGL(k_pyr_resize, g2, dim3(256), 0, s, c->d_pyr.p, c->pyrStride, c->lg[l - 1], Ld,
+                               c->d_xtab.p, c->d_ytab.p);
+        }
+    }
+    rec(c, 1);
+    // K-FAST
+    hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)c->nCells, (unsigned)nimg), dim3(256), 0, s, c->d_pyr.p,
+                       c->pyrStride, c->d_lg.p, c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells,
+                       c->iniThFAST, c->minThFAST);
+    rec(c, 2);
+    // K-QT
+    hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)nimg), dim3(1024), c->qtLdsBytes, s, c->d_lg.p, c->d_cg.p,
+                       c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p, c->d_keyNode.p,
+                       c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p);
+    rec(c, 3);
+    // K-PACK
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)nimg), dim3(256), 0, s, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
+                       c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono);
+    rec(c, 4);
+    // K-DESC
+    hipLaunchKernelGGL(k_orient_blur_desc, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)nimg), dim3(256), 0, s,
+                       c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
+                       c->d_fragile.p, 0, c->d_fixList.p, c->d_fixAngle.p, 0,
+                       c->d_misc.p + 1, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0);
+    c->lastImgs = nimg;
+    c->lastFixups = 0;
+    if (c->trigMode == ORBFE_TRIG_LIBM) {
+        // Trig fix-up: the device used the correctly rounded sin/cos and listed the keypoints whose
+        // sampling grid is within a rounding hair of changing.  Evaluate the host libm cosf/sinf
+        // (what the reference calls, src/ORBextractor.cc:111) for those; where libm differs from the
+        // correctly rounded value, re-run the descriptor on the device with libm's (a, b).
+        HIP_TRY(hipMemcpyAsync(c->h_misc.p, c->d_misc.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_misc.p[0] != 0) return ORBFE_ERR_STATE;
+        const int nFrag = std::min<int>(c->h_misc.p[1], (int)((size_t)c->capImgs * c->capKp));
+        if (nFrag > 0) {
+            HIP_TRY(hipMemcpyAsync(c->h_fixList.p, c->d_fixList.p, (size_t)nFrag * 2 * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(c->h_fixAngle.p, c->d_fixAngle.p, (size_t)nFrag * sizeof(float),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            const float factorPI = (float)(3.14159265358979323846 / 180.f);
+            int nFix = 0;
+            for (int i = 0; i < nFrag; i++) {
+                const float ang = c->h_fixAngle.p[i] * factorPI;
+                const float a = cosf(ang), b = sinf(ang);
+                float bc, ac;
+                orbfe_sincos_cr(ang, &bc, &ac);
+                if (a != ac || b != bc) {
+                    c->h_fixList.p[2 * nFix] = c->h_fixList.p[2 * i];
+                    c->h_fixList.p[2 * nFix + 1] = c->h_fixList.p[2 * i + 1];
+                    c->h_fixAB.p[2 * nFix] = a;
+                    c->h_fixAB.p[2 * nFix + 1] = b;
+                    nFix++;
+                }
+            }
+            if (nFix > 0) {
+                HIP_TRY(hipMemcpyAsync(c->d_fixList.p, c->h_fixList.p, (size_t)nFix * 2 * sizeof(int32_t),
+                                       hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemcpyAsync(c->d_fixAB.p, c->h_fixAB.p, (size_t)nFix * 2 * sizeof(float),
+                                       hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_orient_blur_desc, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
+                                   c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
+                                   c->d_fragile.p, 1, c->d_fixList.p, c->d_fixAB.p, nFix,
+                                   c->d_misc.p + 1, 0);
+            }
+            c->lastFixups = nFix;
+        }
+    }
+    rec(c, 5);
+    if (c->profile) c->evRecorded = true;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* orbfe_version(void) { return "orbfe 0.1 (gfx950)"; }
+
+int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                 int device)
+{
+    if (!out) return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > ORBFE_MAX_LEVELS || !(scaleFactor > 1.0f) || iniThFAST < 0 ||
+        minThFAST < 0 || iniThFAST > 255 || minThFAST > 255)
+        return ORBFE_ERR_ARGS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return ORBFE_ERR_NODEV;
+    HIP_TRY(hipSetDevice(device));
+    orbfe_ctx* c = new orbfe_ctx();
+    c->nfeatures = nfeatures;
+    c->scaleFactor = scaleFactor;
+    c->nlevels = nlevels;
+    c->iniThFAST = iniThFAST;
+    c->minThFAST = minThFAST;
+    c->device = device;
+    init_tables(c);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ORBFE_ERR_NODEV;
+    }
+    c->ownStream = true;
+    *out = c;
+    return 0;
+}
+
+void orbfe_destroy(orbfe_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->d_pyr.release(); c->d_fragile.release(); c->d_desc.release(); c->d_img.release();
+    c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
+    c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
+    c->d_misc.release(); c->d_fixList.release(); c->d_kps.release(); c->d_fixAB.release(); c->d_fixAngle.release();
+    c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release();
+    c->d_taps.release();
+    c->h_misc.release(); c->h_fixList.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAngle.release();
+    c->h_fixAB.release();
+    if (c->evReady)
+        for (auto& e : c->ev) (void)hipEventDestroy(e);
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int orbfe_set_stream(orbfe_ctx* c, void* hip_stream)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->ownStream = false;
+    c->stream = (hipStream_t)hip_stream;
+    if (!hip_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->ownStream = true;
+    }
+    return 0;
+}
+
+int orbfe_set_gaussian_taps(orbfe_ctx* c, const int* t)
+{
+    if (!c || !t) return ORBFE_ERR_ARGS;
+    int sum = 0;
+    for (int i = 0; i < 7; i++) {
+        if (t[i] < 0 || t[i] > 256) return ORBFE_ERR_ARGS;
+        sum += t[i];
+    }
+    if (sum > 257) return ORBFE_ERR_ARGS; // horizontal pass must fit 16 bits
+    for (int i = 0; i < 7; i++) c->taps[i] = t[i];
+    return 0;
+}
+
+int orbfe_set_trig_mode(orbfe_ctx* c, int mode)
+{
+    if (!c || (mode != ORBFE_TRIG_LIBM && mode != ORBFE_TRIG_CR)) return ORBFE_ERR_ARGS;
+    c->trigMode = mode;
+    return 0;
+}
+
+int orbfe_max_keypoints(orbfe_ctx* c, int rows, int cols)
+{
+    if (!c || rows <= 0 || cols <= 0) return ORBFE_ERR_ARGS;
+    return max_kp_for(c, rows, cols);
+}
+
+int orbfe_sync(orbfe_ctx* c)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch,
+                               size_t img_stride_bytes, int lap0, int lap1, orbfe_kp* d_kps, uint8_t* d_desc,
+                               int cap_per_img, int32_t* d_n_out, int32_t* d_mono_out)
+{
+    if (!c || nimg < 1 || !d_imgs || !d_kps || !d_desc || !d_n_out || !d_mono_out) return ORBFE_ERR_ARGS;
+    if (rows <= 0 || cols <= 0) return -1;
+    if (pitch < (size_t)cols) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if ((r = ensure_capacity(c, nimg, std::max(cap_per_img, c->maxKp))) < 0) return r;
+    std::vector<int32_t> lap((size_t)nimg * 2);
+    for (int i = 0; i < nimg; i++) {
+        lap[2 * i] = lap0;
+        lap[2 * i + 1] = lap1;
+    }
+    // small, pageable: staged by the runtime, ordered on the stream
+    HIP_TRY(hipMemcpyAsync(c->d_lap.p, lap.data(), lap.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // `lap` is a stack-lifetime buffer
+    return run_device(c, nimg, d_imgs, rows, cols, pitch, img_stride_bytes, c->d_lap.p, (float*)d_kps, d_desc,
+                      cap_per_img, d_n_out, d_mono_out);
+}
+
+int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride,
+                        const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out)
+{
+    if (!c || nimg < 1 || !imgs || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nimg; i++) {
+        n_out[i] = 0;
+        if (mono_out) mono_out[i] = 0;
+    }
+    if (rows <= 0 || cols <= 0) return -1;
+    for (int i = 0; i < nimg; i++)
+        if (!imgs[i]) return -1;
+    if (stride < (size_t)cols) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if (cap_per_img < c->maxKp) return ORBFE_ERR_ARGS;
+    if ((r = ensure_capacity(c, nimg, cap_per_img)) < 0) return r;
+    const size_t B = (size_t)c->capImgs, K = (size_t)c->capKp;
+    c->imgPitch = align_up((size_t)cols, 64);
+    c->imgStride = c->imgPitch * rows;
+    if ((r = c->d_img.ensure(B * c->imgStride)) < 0) return r;
+    if ((r = c->d_kps.ensure(B * K * 7)) < 0) return r;
+    if ((r = c->d_desc.ensure(B * K * 32)) < 0) return r;
+    if ((r = c->d_n.ensure(B)) < 0) return r;
+    if ((r = c->d_mono.ensure(B)) < 0) return r;
+    if ((r = c->h_n.ensure(B)) < 0) return r;
+    if ((r = c->h_mono.ensure(B)) < 0) return r;
+    hipStream_t s = c->stream;
+    std::vector<int32_t> lapv((size_t)nimg * 2, 0);
+    if (lap)
+        for (int i = 0; i < 2 * nimg; i++) lapv[i] = lap[i];
+    HIP_TRY(hipMemcpyAsync(c->d_lap.p, lapv.data(), lapv.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < nimg; i++)
+        HIP_TRY(hipMemcpy2DAsync(c->d_img.p + (size_t)i * c->imgStride, c->imgPitch, imgs[i], stride, (size_t)cols,
+                                 (size_t)rows, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    r = run_device(c, nimg, c->d_img.p, rows, cols, c->imgPitch, c->imgStride, c->d_lap.p, c->d_kps.p, c->d_desc.p,
+                   cap_per_img, c->d_n.p, c->d_mono.p);
+    if (r < 0) return r;
+    HIP_TRY(hipMemcpyAsync(c->h_n.p, c->d_n.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_mono.p, c->d_mono.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (c->trigMode != ORBFE_TRIG_LIBM) {
+        int32_t err = 0;
+        HIP_TRY(hipMemcpy(&err, c->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (err) return ORBFE_ERR_STATE;
+    }
+    for (int i = 0; i < nimg; i++) {
+        const int n = c->h_n.p[i];
+        n_out[i] = n;
+        if (mono_out) mono_out[i] = c->h_mono.p[i];
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync((uint8_t*)kps + (size_t)i * cap_per_img * sizeof(orbfe_kp),
+                                   c->d_kps.p + (size_t)i * cap_per_img * 7, (size_t)n * sizeof(orbfe_kp),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap_per_img * 32, c->d_desc.p + (size_t)i * cap_per_img * 32,
+                                   (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int orbfe_extract(orbfe_ctx* c, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
+                  orbfe_kp* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (n_out) *n_out = 0;
+    if (!c) return ORBFE_ERR_ARGS;
+    if (!img || rows <= 0 || cols <= 0) return -1; // _image.empty(), :1072-1073
+    int lap[2] = {lap0, lap1};
+    int n = 0, mono = 0;
+    const uint8_t* imgs[1] = {img};
+    int r = orbfe_extract_batch(c, 1, imgs, rows, cols, stride, lap, kps, desc, cap, &n, &mono);
+    if (r < 0) return r;
+    if (n_out) *n_out = n;
+    return mono;
+}
+
+int orbfe_get_levels(orbfe_ctx* c) { return c ? c->nlevels : ORBFE_ERR_ARGS; }
+float orbfe_get_scale_factor(orbfe_ctx* c) { return c ? (float)c->scaleFactor : 0.f; }
+void orbfe_get_scale_tables(orbfe_ctx* c, float* sf, float* inv, float* s2, float* is2)
+{
+    if (!c) return;
+    for (int i = 0; i < c->nlevels; i++) {
+        if (sf) sf[i] = c->mvScaleFactor[i];
+        if (inv) inv[i] = c->mvInvScaleFactor[i];
+        if (s2) s2[i] = c->mvLevelSigma2[i];
+        if (is2) is2[i] = c->mvInvLevelSigma2[i];
+    }
+}
+void orbfe_get_features_per_level(orbfe_ctx* c, int* n)
+{
+    if (!c || !n) return;
+    for (int i = 0; i < c->nlevels; i++) n[i] = c->mnFeaturesPerLevel[i];
+}
+
+int orbfe_get_level(orbfe_ctx* c, int img_index, int level, uint8_t* dst, size_t dst_stride, int* rows, int* cols)
+{
+    if (!c || c->lg.empty() || level < 0 || level >= c->nlevels || img_index < 0 || img_index >= c->lastImgs)
+        return ORBFE_ERR_ARGS;
+    const OrbLevelGeom& L = c->lg[level];
+    const int W = L.w + 2 * ORBFE_EDGE, H = L.h + 2 * ORBFE_EDGE;
+    if (rows) *rows = H;
+    if (cols) *cols = W;
+    if (!dst) return 0;
+    if (dst_stride < (size_t)W) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_border, dim3((unsigned)((W * H + 255) / 256)), dim3(256), 0, c->stream, c->d_pyr.p,
+                       c->pyrStride, L, img_index);
+    const uint8_t* src = c->d_pyr.p + (size_t)img_index * c->pyrStride + L.bufOff + (ORBFE_ROI_X0 - ORBFE_EDGE);
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_stride, src, (size_t)L.pitch, (size_t)W, (size_t)H, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int orbfe_profile_enable(orbfe_ctx* c, int on)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    if (on && !c->evReady) {
+        for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+        c->evReady = true;
+    }
+    c->profile = on != 0;
+    c->evRecorded = false;
+    return 0;
+}
+
+int orbfe_profile_read(orbfe_ctx* c, float* ms)
+{
+    if (!c || !ms || !c->evReady || !c->evRecorded) return ORBFE_ERR_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[ORBFE_STAGE_COUNT]));
+    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    return 0;
+}
+
+int orbfe_debug_candidates(orbfe_ctx* c, int img, int level, uint32_t* out, int cap)
+{
+    if (!c || c->lg.empty() || level < 0 || level >= c->nlevels || img < 0 || img >= c->lastImgs) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const OrbLevelGeom& L = c->lg[level];
+    std::vector<int32_t> cnt(L.nCells);
+    HIP_TRY(hipMemcpy(cnt.data(), c->d_cellCount.p + (size_t)img * c->nCells + L.cellBase, L.nCells * sizeof(int32_t),
+                      hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int ci = 0; ci < L.nCells; ci++) {
+        const OrbCellGeom& g = c->cg[L.cellBase + ci];
+        const int k = std::min(cnt[ci], std::max(cap - n, 0));
+        if (k > 0)
+            HIP_TRY(hipMemcpy(out + n, c->d_cand.p + (size_t)img * c->candStride + g.slotBase, (size_t)k * 4,
+                              hipMemcpyDeviceToHost));
+        n += cnt[ci];
+    }
+    return n;
+}
+
+int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out, int cap)
+{
+    if (!c || c->lg.empty() || level < 0 || level >= c->nlevels || img < 0 || img >= c->lastImgs) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, c->d_lvlCount.p + (size_t)img * c->nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int k = std::min(n, cap);
+    if (k > 0)
+        HIP_TRY(hipMemcpy(out, c->d_lvlKp.p + (size_t)img * c->kpStride + c->lg[level].kpBase, (size_t)k * 4,
+                          hipMemcpyDeviceToHost));
+    return n;
+}
+
+int orbfe_debug_fixups(orbfe_ctx* c) { return c ? c->lastFixups : ORBFE_ERR_ARGS; }
+
+} // extern "C"

@@ -1,0 +1,69 @@
+/*
+ * orbfe_geom.h -- per-level / per-cell geometry shared by the host shim and the kernels.
+ *
+ * Everything here is derived on the host exactly as the reference derives it
+ * (ORBextractor ctor src/ORBextractor.cc:408-468, ComputePyramid :1152-1177,
+ * the cell grid of ComputeKeyPointsOctTree :769-804, the roots of DistributeOctTree
+ * :540-556) and uploaded once per image size.
+ */
+#ifndef ORBFE_GEOM_H
+#define ORBFE_GEOM_H
+
+#include <stdint.h>
+
+#define ORBFE_MAX_LEVELS 16
+#define ORBFE_EDGE 19          /* EDGE_THRESHOLD, src/ORBextractor.cc:72  */
+#define ORBFE_MINB 16          /* EDGE_THRESHOLD-3, :771                  */
+#define ORBFE_ROI_X0 64        /* byte column of ROI x=0 in a pyramid row (64-B aligned rows) */
+#define ORBFE_MAX_DIM 4096     /* packed candidate = x | y<<12 | score<<24 */
+#define ORBFE_FAST_TILE 76     /* max ROI side: wCell+6 <= 75              */
+#define ORBFE_FAST_PITCH 80
+
+struct OrbLevelGeom {
+    int w, h;             /* level size (cvRound((float)cols*inv), :1157)                     */
+    int pitch;            /* row pitch of the padded level buffer                            */
+    uint32_t bufOff;      /* byte offset of the padded buffer inside one image's pyramid slab */
+    uint32_t roiOff;      /* byte offset of ROI(0,0) = bufOff + 19*pitch + ORBFE_ROI_X0       */
+    int nCols, nRows, wCell, hCell;
+    int cellBase, nCells; /* range in the cell table                                          */
+    int maxBX, maxBY;     /* w-16, h-16                                                       */
+    int nFeat;            /* mnFeaturesPerLevel[level]                                        */
+    int nIni;             /* quadtree roots, :540                                             */
+    float hX;             /* :542                                                             */
+    int kpBase, kpCap;    /* slot range of this level's quadtree output                       */
+    int keyBase, keyCap;  /* slot range of this level's compacted candidate list              */
+    int listCap;          /* quadtree node-list capacity                                      */
+    float scale;          /* mvScaleFactor[level]                                             */
+    float size;           /* (float)(int)(31*scale), :862                                     */
+    int xtabOff, ytabOff; /* resize tables of this level (level > 0)                          */
+};
+
+struct OrbCellGeom {
+    int16_t level;
+    int16_t iniX, iniY; /* ROI origin in level coordinates        */
+    int16_t cw, ch;     /* ROI size (maxX-iniX, maxY-iniY)        */
+    int16_t offX, offY; /* j*wCell, i*hCell (added to keypoints)  */
+    int16_t pad;
+    int32_t slotBase;   /* first candidate slot of this cell      */
+    int32_t slotCap;    /* ceil(zw/2)*ceil(zh/2): max strict 8-neighbour local maxima */
+};
+
+/* resize tables: per destination column / row */
+struct OrbResizeX {
+    uint16_t sx;
+    int16_t a0, a1;
+    uint16_t pad;
+};
+struct OrbResizeY {
+    uint16_t sy0, sy1; /* clamped source rows */
+    int16_t b0, b1;
+};
+
+/* work item produced by K-PACK for K-DESC */
+struct OrbDescWork {
+    int16_t level, x, y; /* level coordinates of the keypoint */
+    int16_t pad;
+    int32_t dest;        /* output slot                       */
+};
+
+#endif

@@ -1,0 +1,883 @@
+/*
+ * orbfe_kernels.hip -- gfx950 (CDNA4) kernels of the ORB extractor.
+ *
+ *   K-PYR   k_pyr_level0 / k_pyr_resize   ComputePyramid            src/ORBextractor.cc:1152-1177
+ *   K-FAST  k_fast_cells                  cell loop + cv::FAST      src/ORBextractor.cc:769-854
+ *   K-QT    k_octree                      DistributeOctTree         src/ORBextractor.cc:537-761
+ *   K-PACK  k_pack                        output partition          src/ORBextractor.cc:1100-1147
+ *   K-DESC  k_orient_blur_desc            IC_Angle + GaussianBlur + computeOrbDescriptor
+ *                                                                   src/ORBextractor.cc:75-145,1114-1120
+ *   K-BORDER k_border                     copyMakeBorder (only when mvImagePyramid is read)
+ *
+ * Integer / bitwise work, no MFMA.  64-lane wavefronts throughout (ballot masks are 64-bit).
+ * All float expressions that must round like the reference's scalar code use the explicit
+ * __f*_rn intrinsics (and the file is built with -ffp-contract=off), SURVEY.md Appendix D2.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orbfe_geom.h"
+#include "orbfe_sincos.h"
+#include "orb_pattern.inc"
+
+#define WAVE 64
+
+__device__ const int8_t ORB_PATTERN_31_DEV[256][4] = ORBFE_PATTERN_31_INIT;
+
+// LDS hand-off between lanes of ONE wavefront (each wave owns its LDS region): DS operations of a
+// wave are processed in order, so only the compiler must be kept from reordering.
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+// ------------------------------------------------------------------ K-PYR
+// Level 0: copy the caller's image into the aligned ROI of the pyramid slab.
+__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ src, size_t srcPitch,
+                                                    size_t srcImgStride, uint8_t* __restrict__ pyr,
+                                                    size_t pyrImgStride, OrbLevelGeom L0)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    const int img = blockIdx.z;
+    if (x4 >= L0.w) return;
+    const uint8_t* s = src + (size_t)img * srcImgStride + (size_t)y * srcPitch + x4;
+    uint8_t* d = pyr + (size_t)img * pyrImgStride + L0.roiOff + (size_t)y * L0.pitch + x4;
+    if (x4 + 3 < L0.w) {
+        uint32_t v = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+        *reinterpret_cast<uint32_t*>(d) = v; // ROI rows are 64-B aligned
+    } else {
+        for (int k = 0; x4 + k < L0.w; k++) d[k] = s[k];
+    }
+}
+
+// Level l from level l-1: cv::resize INTER_LINEAR 8UC1, 11-bit fixed point.
+// The per-column / per-row source indices and weights come from host tables computed exactly
+// as OpenCV computes them (double scale, float fractional part, cvRound to 1/2048).
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, size_t pyrImgStride, OrbLevelGeom Ls,
+                                                    OrbLevelGeom Ld, const OrbResizeX* __restrict__ xtab,
+                                                    const OrbResizeY* __restrict__ ytab)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int dy = blockIdx.y;
+    const int img = blockIdx.z;
+    if (x4 >= Ld.w) return;
+    uint8_t* base = pyr + (size_t)img * pyrImgStride;
+    const OrbResizeY ty = ytab[Ld.ytabOff + dy];
+    const uint8_t* S0 = base + Ls.roiOff + (size_t)ty.sy0 * Ls.pitch;
+    const uint8_t* S1 = base + Ls.roiOff + (size_t)ty.sy1 * Ls.pitch;
+    uint8_t* D = base + Ld.roiOff + (size_t)dy * Ld.pitch + x4;
+    uint32_t packed = 0;
+    const int b0 = ty.b0, b1 = ty.b1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = x4 + k;
+        int v = 0;
+        if (dx < Ld.w) {
+            const OrbResizeX tx = xtab[Ld.xtabOff + dx];
+            const int sx = tx.sx, sx1 = tx.pad;
+            const int h0 = S0[sx] * tx.a0 + S0[sx1] * tx.a1;
+            const int h1 = S1[sx] * tx.a0 + S1[sx1] * tx.a1;
+            v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+        }
+        packed |= (uint32_t)v << (8 * k);
+    }
+    if (x4 + 3 < Ld.w) {
+        *reinterpret_cast<uint32_t*>(D) = packed;
+    } else {
+        for (int k = 0; x4 + k < Ld.w; k++) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
+// BORDER_REFLECT_101 frame of one level (19 px), written only when the caller asks for
+// mvImagePyramid (nothing inside the extractor reads it).
+__global__ __launch_bounds__(256) void k_border(uint8_t* __restrict__ pyr, size_t pyrImgStride, OrbLevelGeom L, int img)
+{
+    const int W = L.w + 2 * ORBFE_EDGE, H = L.h + 2 * ORBFE_EDGE;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * H) return;
+    const int py = idx / W, px = idx - py * W;
+    int x = px - ORBFE_EDGE, y = py - ORBFE_EDGE;
+    if (x >= 0 && x < L.w && y >= 0 && y < L.h) return;
+    int sx = x, sy = y;
+    if (L.w == 1) sx = 0;
+    else
+        while (sx < 0 || sx >= L.w) sx = sx < 0 ? -sx : 2 * L.w - 2 - sx;
+    if (L.h == 1) sy = 0;
+    else
+        while (sy < 0 || sy >= L.h) sy = sy < 0 ? -sy : 2 * L.h - 2 - sy;
+    uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff;
+    roi[(ptrdiff_t)y * L.pitch + x] = roi[(ptrdiff_t)sy * L.pitch + sx];
+}
+
+// ----------------------------------------------------------------- K-FAST
+// FAST-9/16 corner score = largest threshold for which the pixel is still a corner
+// (cv::cornerScore<16>): max over the 16 arcs of 9 of min(r-v) and of min(v-r), minus 1.
+__device__ __forceinline__ int fast_score(const uint8_t* c)
+{
+    constexpr int P = ORBFE_FAST_PITCH;
+    const int v = c[0];
+    int d[16];
+    d[0] = c[3 * P + 0] - v;
+    d[1] = c[3 * P + 1] - v;
+    d[2] = c[2 * P + 2] - v;
+    d[3] = c[1 * P + 3] - v;
+    d[4] = c[0 * P + 3] - v;
+    d[5] = c[-1 * P + 3] - v;
+    d[6] = c[-2 * P + 2] - v;
+    d[7] = c[-3 * P + 1] - v;
+    d[8] = c[-3 * P + 0] - v;
+    d[9] = c[-3 * P - 1] - v;
+    d[10] = c[-2 * P - 2] - v;
+    d[11] = c[-1 * P - 3] - v;
+    d[12] = c[0 * P - 3] - v;
+    d[13] = c[1 * P - 3] - v;
+    d[14] = c[2 * P - 2] - v;
+    d[15] = c[3 * P - 1] - v;
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int bright = -255, darkNeg = 255;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+        const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
+        bright = max(bright, mn9);
+        darkNeg = min(darkNeg, mx9);
+    }
+    return max(bright, -darkNeg) - 1;
+}
+
+// One workgroup per FAST cell (reference: one cv::FAST call per cell, plus a second call with
+// minThFAST when the first finds nothing).  A single score map serves both thresholds:
+// corner_at(t) <=> score >= t, and the strict 8-neighbour NMS is threshold independent
+// (SURVEY.md A.3), so kept(t) = localmax && score >= t; the cell picks iniTh if any pixel
+// survives at iniTh, else minTh.  Output: row-major ordered list per cell, packed x|y<<12|s<<24.
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
+                                                    const OrbLevelGeom* __restrict__ lg,
+                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
+                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
+                                                    int nCellsTotal, int iniTh, int minTh)
+{
+    constexpr int P = ORBFE_FAST_PITCH;
+    __shared__ uint8_t tile[ORBFE_FAST_TILE * P];
+    __shared__ uint8_t smap[ORBFE_FAST_TILE * P];
+    __shared__ uint16_t queue[(ORBFE_FAST_TILE - 6) * (ORBFE_FAST_TILE - 6)];
+    __shared__ int qn, anyIni, waveCnt[4], runBase;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cell = blockIdx.x, img = blockIdx.y;
+    const OrbCellGeom c = cg[cell];
+    const OrbLevelGeom L = lg[c.level];
+    const int cw = c.cw, ch = c.ch;
+    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff + (size_t)c.iniY * L.pitch + c.iniX;
+    const int tmin = min(iniTh, minTh);
+
+    if (tid == 0) {
+        qn = 0;
+        anyIni = 0;
+        runBase = 0;
+    }
+    // stage the ROI, clear the score map
+    for (int idx = tid; idx < ch * P; idx += 256) {
+        const int y = idx / P, x = idx - y * P;
+        smap[idx] = 0;
+        if (x < cw) tile[idx] = roi[(size_t)y * L.pitch + x];
+    }
+    __syncthreads();
+
+    const int zw = cw - 6, zh = ch - 6; // detection zone
+    const int nz = (zw > 0 && zh > 0) ? zw * zh : 0;
+    // phase A: cheap necessary test.  Every arc of 9 contains one pixel of each opposite pair
+    // (k, k+8); test the pairs (0,8) and (4,12).
+    for (int base = 0; base < nz; base += 256) {
+        const int idx = base + tid;
+        bool pass = false;
+        int pos = 0;
+        if (idx < nz) {
+            const int y = idx / zw + 3, x = idx - (idx / zw) * zw + 3;
+            pos = y * P + x;
+            const int v = tile[pos];
+            const int r0 = tile[pos + 3 * P], r8 = tile[pos - 3 * P], r4 = tile[pos + 3], r12 = tile[pos - 3];
+            const int hi = v + tmin, lo = v - tmin;
+            const bool b = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
+            const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
+            pass = b | dk;
+        }
+        const unsigned long long m = __ballot(pass);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&qn, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (pass) queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+    }
+    __syncthreads();
+    // phase B: exact score for the survivors (all lanes busy)
+    const int nq = qn;
+    for (int qi = tid; qi < nq; qi += 256) {
+        const int pos = queue[qi];
+        const int s = fast_score(&tile[pos]);
+        if (s >= tmin) smap[pos] = (uint8_t)s;
+    }
+    __syncthreads();
+    // phase C: strict 8-neighbour NMS; does any pixel survive at iniTh?
+    // (re-evaluated in phase D; here only the cell-wide flag)
+    {
+        bool any = false;
+        for (int idx = tid; idx < nz; idx += 256) {
+            const int y = idx / zw + 3, x = idx - (idx / zw) * zw + 3;
+            const int pos = y * P + x;
+            const int s = smap[pos];
+            if (s >= iniTh) {
+                const bool keep = s > smap[pos - 1] && s > smap[pos + 1] && s > smap[pos - P - 1] && s > smap[pos - P] &&
+                                  s > smap[pos - P + 1] && s > smap[pos + P - 1] && s > smap[pos + P] &&
+                                  s > smap[pos + P + 1];
+                any |= keep;
+            }
+        }
+        if (__ballot(any) && lane == 0) anyIni = 1;
+    }
+    __syncthreads();
+    const int th = anyIni ? iniTh : minTh;
+    // phase D: ordered (row-major) compaction of the kept pixels
+    uint32_t* out = cand + (size_t)img * candImgStride + c.slotBase;
+    for (int base = 0; base < nz; base += 256) {
+        const int idx = base + tid;
+        bool keep = false;
+        uint32_t packed = 0;
+        if (idx < nz) {
+            const int y = idx / zw + 3, x = idx - (idx / zw) * zw + 3;
+            const int pos = y * P + x;
+            const int s = smap[pos];
+            if (s >= th && s > 0) {
+                keep = s > smap[pos - 1] && s > smap[pos + 1] && s > smap[pos - P - 1] && s > smap[pos - P] &&
+                       s > smap[pos - P + 1] && s > smap[pos + P - 1] && s > smap[pos + P] && s > smap[pos + P + 1];
+                packed = (uint32_t)(x + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((uint32_t)s << 24);
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) waveCnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = runBase;
+        for (int w = 0; w < wave; w++) off += waveCnt[w];
+        if (keep) {
+            const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (o < c.slotCap) out[o] = packed;
+        }
+        __syncthreads();
+        if (tid == 0) runBase += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) cellCount[(size_t)img * nCellsTotal + cell] = min(runBase, c.slotCap);
+}
+
+// ------------------------------------------------------------------- K-QT
+#define QT_THREADS 1024
+#define QT_WAVES (QT_THREADS / WAVE)
+
+// exclusive scan of a[0..n) in LDS, in place; returns the total to every thread.
+__device__ int qt_scan(int* a, int n, int* wsum /* QT_WAVES + 1 */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += QT_THREADS) {
+        const int i = base + tid;
+        const int v = i < n ? a[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        if (wave == 0) {
+            const int w = lane < QT_WAVES ? wsum[lane] : 0;
+            int xs = w;
+#pragma unroll
+            for (int off = 1; off < QT_WAVES; off <<= 1) {
+                const int y = __shfl_up(xs, off);
+                if (lane >= off) xs += y;
+            }
+            if (lane < QT_WAVES) wsum[lane] = xs - w;
+            if (lane == QT_WAVES - 1) wsum[QT_WAVES] = xs;
+        }
+        __syncthreads();
+        if (i < n) a[i] = x - v + wsum[wave] + carry;
+        carry += wsum[QT_WAVES];
+        __syncthreads();
+    }
+    return carry;
+}
+
+__device__ __forceinline__ int qt_quadrant(int ul, int br, int x, int y)
+{
+    const int ulx = ul & 0xFFFF, uly = ul >> 16, brx = br & 0xFFFF, bry = br >> 16;
+    const int hx = (brx - ulx + 1) >> 1, hy = (bry - uly + 1) >> 1; // ceil((float)d/2), d >= 0  (:481-482)
+    return (x < ulx + hx ? 0 : 1) + (y < uly + hy ? 0 : 2);         // n1=0 n2=1 n3=2 n4=3 (:514-528)
+}
+__device__ __forceinline__ void qt_child(int ul, int br, int q, int& cul, int& cbr)
+{
+    const int ulx = ul & 0xFFFF, uly = ul >> 16, brx = br & 0xFFFF, bry = br >> 16;
+    const int hx = (brx - ulx + 1) >> 1, hy = (bry - uly + 1) >> 1;
+    const int x0 = (q & 1) ? ulx + hx : ulx, x1 = (q & 1) ? brx : ulx + hx;
+    const int y0 = (q & 2) ? uly + hy : uly, y1 = (q & 2) ? bry : uly + hy;
+    cul = x0 | (y0 << 16);
+    cbr = x1 | (y1 << 16);
+}
+
+// One workgroup per (image, level).  Level-synchronous restatement of DistributeOctTree
+// (tests/qt_model.py is the executable specification, checked against the literal list
+// transcription in the oracle): keys never move, every key carries the list index of its node,
+// and each pass is a histogram + prefix sums.  Sort tie-break of :682 = creation order
+// (SURVEY.md D1).
+__global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __restrict__ lg,
+                                                       const OrbCellGeom* __restrict__ cg,
+                                                       const uint32_t* __restrict__ cand, size_t candImgStride,
+                                                       const int32_t* __restrict__ cellCount, int nCellsTotal,
+                                                       uint32_t* __restrict__ keysAll, uint16_t* __restrict__ keyNodeAll,
+                                                       size_t keyImgStride, uint32_t* __restrict__ lvlKp,
+                                                       size_t kpImgStride, int32_t* __restrict__ lvlCount, int nlevels,
+                                                       int32_t* __restrict__ errFlag)
+{
+    extern __shared__ int lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int level = blockIdx.x, img = blockIdx.y;
+    const OrbLevelGeom L = lg[level];
+    const int LC = L.listCap;
+    const int N = L.nFeat;
+
+    // LDS: [0,64) scalars + scan scratch, then 24*LC ints of arrays; the first 1024 ints of the
+    // array region double as the cell-count scan buffer of the gather (host sizes the allocation
+    // as 64 + max(24*LC, 1024) ints).
+    int* misc = lds;
+    int* wsum = misc + 8;
+    int* A = lds + 64;
+    int* nodeUL[2] = {A, A + LC};
+    int* nodeBR[2] = {A + 2 * LC, A + 3 * LC};
+    int* nodeCnt[2] = {A + 4 * LC, A + 5 * LC};
+    int* kOf = A + 6 * LC;       // list position -> expansion index k (or -1)
+    int* sidx = A + 7 * LC;      // list position -> #expanded nodes before it
+    int* cc = A + 8 * LC;        // [4*LC] child key counts, index 4k+q
+    int* cpos = A + 12 * LC;     // [4*LC] child list positions, index (nE-1-k)*4+(3-q)
+    int* mpos = A + 16 * LC;     // [4*LC] multi-key child -> index in the new candidate list
+    int* multi[2] = {A + 20 * LC, A + 21 * LC}; // candidate list (list positions), creation order
+    int* par = A + 22 * LC;      // expansion index k -> parent list position
+    int* gpre = A + 23 * LC;     // growth prefix (final phase) / scratch
+    int* gscan = A;              // gather only
+
+    uint32_t* keys = keysAll + (size_t)img * keyImgStride + L.keyBase;
+    uint16_t* keyNode = keyNodeAll + (size_t)img * keyImgStride + L.keyBase;
+    const uint32_t* candImg = cand + (size_t)img * candImgStride;
+    const int32_t* cnts = cellCount + (size_t)img * nCellsTotal + L.cellBase;
+    const OrbCellGeom* cells = cg + L.cellBase;
+
+    // ---- gather the per-cell lists into one ordered key array (cells row-major, :787-853)
+    int n = 0;
+    for (int cbase = 0; cbase < L.nCells; cbase += QT_THREADS) {
+        const int nc = min(QT_THREADS, L.nCells - cbase);
+        if (tid < nc) gscan[tid] = cnts[cbase + tid];
+        __syncthreads();
+        const int tot = qt_scan(gscan, nc, wsum);
+        for (int ci = wave; ci < nc; ci += QT_WAVES) {
+            const int cnt = cnts[cbase + ci];
+            const int dst = n + gscan[ci];
+            const uint32_t* src = candImg + cells[cbase + ci].slotBase;
+            for (int s = lane; s < cnt; s += 64) keys[dst + s] = src[s];
+        }
+        n += tot;
+        __syncthreads();
+    }
+    if (n > L.keyCap) n = L.keyCap; // cannot happen (keyCap = sum of slot caps)
+
+    int cur = 0;
+    int size = 0;
+    // ---- roots (:540-583)
+    const int nIni = L.nIni;
+    if (n == 0 || nIni < 1) {
+        if (tid == 0) lvlCount[(size_t)img * nlevels + level] = 0;
+        return;
+    }
+    if (tid < nIni) cc[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += QT_THREADS) {
+        const uint32_t k = keys[i];
+        int r = (int)__fdiv_rn((float)(k & 0xFFF), L.hX);
+        r = min(r, nIni - 1);
+        atomicAdd(&cc[r], 1);
+        keyNode[i] = (uint16_t)r;
+    }
+    __syncthreads();
+    if (tid < nIni) gpre[tid] = cc[tid] > 0 ? 1 : 0;
+    __syncthreads();
+    size = qt_scan(gpre, nIni, wsum);
+    if (tid < nIni && cc[tid] > 0) {
+        const int p = gpre[tid];
+        const int x0 = (int)__fmul_rn(L.hX, (float)tid), x1 = (int)__fmul_rn(L.hX, (float)(tid + 1));
+        nodeUL[0][p] = x0;                                 // UL = (x0, 0)
+        nodeBR[0][p] = x1 | ((L.maxBY - ORBFE_MINB) << 16); // BR = (x1, maxY-minY)
+        nodeCnt[0][p] = cc[tid];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += QT_THREADS) keyNode[i] = (uint16_t)gpre[keyNode[i]];
+    __syncthreads();
+
+    // expansion step shared by the full passes and the final-phase rounds.
+    // Preconditions: kOf/sidx valid for the current list; par[k] for k < nE; if !histDone, cc is
+    // computed here for the nE expanded nodes, else cc[4k+q] already holds the counts.
+    auto expand = [&](int nE, bool histDone, int& nMultiOut) -> int {
+        const int* ul = nodeUL[cur];
+        const int* br = nodeBR[cur];
+        if (!histDone) {
+            for (int i = tid; i < 4 * nE; i += QT_THREADS) cc[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += QT_THREADS) {
+                const int p = keyNode[i];
+                const int k = kOf[p];
+                if (k >= 0) {
+                    const uint32_t key = keys[i];
+                    atomicAdd(&cc[4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF)], 1);
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < 4 * nE; i += QT_THREADS) {
+            const int k = i >> 2, q = i & 3;
+            cpos[(nE - 1 - k) * 4 + (3 - q)] = cc[i] > 0 ? 1 : 0; // push_front order: n4,n3,n2,n1 of the last parent first
+            mpos[i] = cc[i] > 1 ? 1 : 0;
+        }
+        __syncthreads();
+        const int nChildren = qt_scan(cpos, 4 * nE, wsum);
+        const int nMulti = qt_scan(mpos, 4 * nE, wsum);
+        const int nb = cur ^ 1;
+        const int newSize = nChildren + (size - nE);
+        if (newSize > LC) { // cannot happen; never write out of bounds
+            if (tid == 0) atomicExch(errFlag, 1);
+            nMultiOut = 0;
+            return -1;
+        }
+        for (int i = tid; i < 4 * nE; i += QT_THREADS) {
+            const int k = i >> 2, q = i & 3;
+            const int cnt = cc[i];
+            if (cnt > 0) {
+                const int pos = cpos[(nE - 1 - k) * 4 + (3 - q)];
+                const int p = par[k];
+                int cul, cbr;
+                qt_child(ul[p], br[p], q, cul, cbr);
+                nodeUL[nb][pos] = cul;
+                nodeBR[nb][pos] = cbr;
+                nodeCnt[nb][pos] = cnt;
+                if (cnt > 1) multi[nb][mpos[i]] = pos;
+            }
+        }
+        for (int p = tid; p < size; p += QT_THREADS) {
+            const int k = kOf[p];
+            if (!(k >= 0 && k < nE)) {
+                const int pos = nChildren + p - sidx[p];
+                nodeUL[nb][pos] = ul[p];
+                nodeBR[nb][pos] = br[p];
+                nodeCnt[nb][pos] = nodeCnt[cur][p];
+            }
+        }
+        for (int i = tid; i < n; i += QT_THREADS) {
+            const int p = keyNode[i];
+            const int k = kOf[p];
+            int np;
+            if (k >= 0 && k < nE) {
+                const uint32_t key = keys[i];
+                const int q = qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
+                np = cpos[(nE - 1 - k) * 4 + (3 - q)];
+            } else {
+                np = nChildren + p - sidx[p];
+            }
+            keyNode[i] = (uint16_t)np;
+        }
+        __syncthreads();
+        cur = nb;
+        nMultiOut = nMulti;
+        return newSize;
+    };
+
+    bool finish = false;
+    while (!finish) {
+        // ---- full pass (:598-663): every node with more than one key is divided
+        const int prevSize = size;
+        for (int p = tid; p < size; p += QT_THREADS) sidx[p] = nodeCnt[cur][p] > 1 ? 1 : 0;
+        __syncthreads();
+        for (int p = tid; p < size; p += QT_THREADS) kOf[p] = sidx[p] ? 0 : -1; // flag, index filled below
+        __syncthreads();
+        const int nE = qt_scan(sidx, size, wsum);
+        if (nE == 0) break;
+        for (int p = tid; p < size; p += QT_THREADS)
+            if (kOf[p] == 0) {
+                kOf[p] = sidx[p];
+                par[sidx[p]] = p;
+            }
+        __syncthreads();
+        int nMulti = 0;
+        const int ns = expand(nE, false, nMulti);
+        if (ns < 0) break;
+        size = ns;
+        if (size >= N || size == prevSize) {
+            finish = true;
+        } else if (size + 3 * nMulti > N) {
+            // ---- final phase (:671-736): expand the largest nodes first until N is reached
+            int m = nMulti;
+            while (!finish) {
+                const int prev2 = size;
+                const int* mcur = multi[cur];
+                // rank of candidate t in descending (count, creation index) order
+                for (int p = tid; p < size; p += QT_THREADS) kOf[p] = -1;
+                for (int t = tid; t < m; t += QT_THREADS) gpre[t] = nodeCnt[cur][mcur[t]];
+                for (int i = tid; i < 4 * m; i += QT_THREADS) cc[i] = 0;
+                __syncthreads();
+                for (int t = tid; t < m; t += QT_THREADS) {
+                    const int ct = gpre[t];
+                    int rank = 0;
+                    for (int j = 0; j < m; j++) {
+                        const int cj = gpre[j];
+                        rank += (cj > ct) || (cj == ct && j > t);
+                    }
+                    kOf[mcur[t]] = rank;
+                    par[rank] = mcur[t];
+                }
+                __syncthreads();
+                {
+                    const int* ul = nodeUL[cur];
+                    const int* br = nodeBR[cur];
+                    for (int i = tid; i < n; i += QT_THREADS) {
+                        const int p = keyNode[i];
+                        const int k = kOf[p];
+                        if (k >= 0) {
+                            const uint32_t key = keys[i];
+                            atomicAdd(&cc[4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF)], 1);
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int r = tid; r < m; r += QT_THREADS)
+                    gpre[r] = (cc[4 * r] > 0) + (cc[4 * r + 1] > 0) + (cc[4 * r + 2] > 0) + (cc[4 * r + 3] > 0) - 1;
+                if (tid == 0) misc[0] = m;
+                __syncthreads();
+                qt_scan(gpre, m, wsum); // exclusive: gpre[r] = growth of candidates before r
+                for (int r = tid; r < m; r += QT_THREADS) {
+                    const int g = (cc[4 * r] > 0) + (cc[4 * r + 1] > 0) + (cc[4 * r + 2] > 0) + (cc[4 * r + 3] > 0) - 1;
+                    const int before = size + gpre[r];
+                    if (before < N && before + g >= N) misc[0] = r + 1; // the break of :728-729
+                }
+                __syncthreads();
+                const int nE2 = misc[0];
+                for (int p = tid; p < size; p += QT_THREADS) sidx[p] = (kOf[p] >= 0 && kOf[p] < nE2) ? 1 : 0;
+                __syncthreads();
+                qt_scan(sidx, size, wsum);
+                int nM2 = 0;
+                const int ns2 = expand(nE2, true, nM2);
+                if (ns2 < 0) {
+                    finish = true;
+                    break;
+                }
+                size = ns2;
+                m = nM2;
+                if (size >= N || size == prev2) finish = true;
+            }
+        }
+    }
+
+    // ---- retain the best key of every node (:739-758): max response, first key wins ties
+    unsigned* best = reinterpret_cast<unsigned*>(cc);
+    for (int p = tid; p < size; p += QT_THREADS) best[p] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += QT_THREADS) {
+        const uint32_t key = keys[i];
+        atomicMax(&best[keyNode[i]], ((key >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
+    }
+    __syncthreads();
+    uint32_t* out = lvlKp + (size_t)img * kpImgStride + L.kpBase;
+    const int nout = min(size, L.kpCap);
+    for (int p = tid; p < nout; p += QT_THREADS) out[p] = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+    if (tid == 0) lvlCount[(size_t)img * nlevels + level] = nout;
+}
+
+// ----------------------------------------------------------------- K-PACK
+// Output order and mono/stereo partition of ORBextractor::operator() (:1100-1147): level-major,
+// list order inside a level; keypoints whose level-0 x lies in [lap0, lap1] fill the output from
+// the back, the others from the front.  Writes every KeyPoint field except the angle and a work
+// item per keypoint for K-DESC.
+__global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ lg, int nlevels,
+                                              const uint32_t* __restrict__ lvlKp, size_t kpImgStride,
+                                              const int32_t* __restrict__ lvlCount, const int32_t* __restrict__ lap,
+                                              float* __restrict__ kpsOut /* 7 floats per kp */, int capPerImg,
+                                              OrbDescWork* __restrict__ work, int32_t* __restrict__ nOut,
+                                              int32_t* __restrict__ monoOut)
+{
+    __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
+    __shared__ int waveCnt[4];
+    __shared__ int runStereo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x;
+    if (tid == 0) {
+        int acc = 0;
+        for (int l = 0; l < nlevels; l++) {
+            lvlOff[l] = acc;
+            acc += lvlCount[(size_t)img * nlevels + l];
+        }
+        lvlOff[nlevels] = acc;
+        runStereo = 0;
+    }
+    __syncthreads();
+    const int n = min(lvlOff[nlevels], capPerImg);
+    const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1];
+    float* kimg = kpsOut + (size_t)img * capPerImg * 7;
+    OrbDescWork* wimg = work + (size_t)img * capPerImg;
+    for (int base = 0; base < n; base += 256) {
+        const int g = base + tid;
+        bool stereo = false;
+        int level = 0, px = 0, py = 0;
+        float sx = 0, sy = 0, resp = 0;
+        if (g < n) {
+            while (g >= lvlOff[level + 1]) level++;
+            const uint32_t key = lvlKp[(size_t)img * kpImgStride + lg[level].kpBase + (g - lvlOff[level])];
+            px = (int)(key & 0xFFF) + ORBFE_MINB;
+            py = (int)((key >> 12) & 0xFFF) + ORBFE_MINB;
+            resp = (float)(key >> 24);
+            sx = (float)px;
+            sy = (float)py;
+            if (level != 0) { // keypoint->pt *= scale (:1131-1133)
+                sx = __fmul_rn(sx, lg[level].scale);
+                sy = __fmul_rn(sy, lg[level].scale);
+            }
+            stereo = sx >= lap0 && sx <= lap1;
+        }
+        const unsigned long long m = __ballot(stereo);
+        if (lane == 0) waveCnt[wave] = __popcll(m);
+        __syncthreads();
+        int sBefore = runStereo;
+        for (int w = 0; w < wave; w++) sBefore += waveCnt[w];
+        sBefore += __popcll(m & ((1ull << lane) - 1ull));
+        if (g < n) {
+            const int dest = stereo ? (n - 1 - sBefore) : (g - sBefore);
+            float* k = kimg + (size_t)dest * 7;
+            k[0] = sx;
+            k[1] = sy;
+            k[2] = lg[level].size;
+            k[3] = 0.f;
+            k[4] = resp;
+            reinterpret_cast<int32_t*>(k)[5] = level;
+            reinterpret_cast<int32_t*>(k)[6] = -1;
+            OrbDescWork w;
+            w.level = (int16_t)level;
+            w.x = (int16_t)px;
+            w.y = (int16_t)py;
+            w.pad = 0;
+            w.dest = dest;
+            wimg[g] = w;
+        }
+        __syncthreads();
+        if (tid == 0) runStereo += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        nOut[img] = n;
+        monoOut[img] = n - runStereo;
+    }
+}
+
+// ----------------------------------------------------------------- K-DESC
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// cv::fastAtan2: seven separately rounded single-precision operations.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(
+            __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(
+            90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1),
+                            c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+#define DESC_R 21  /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
+#define DESC_RAW 43
+#define DESC_RAWP 44
+#define DESC_BW 37 /* blurred patch side */
+#define DESC_HP 38 /* pitch of the horizontal pass (u16) */
+#define DESC_BP 40
+
+// One wavefront per keypoint.  Stages the 43x43 raw neighbourhood in LDS, computes the
+// intensity-centroid angle on the raw pixels (IC_Angle :75-102), blurs only the 37x37 patch the
+// rotated taps can reach (GaussianBlur 7x7 sigma 2 fixed point, identical to blurring the whole
+// level because the blur is local), then evaluates the 256 steered tests; the
+// 32 descriptor bytes are four 64-bit ballots.
+// mode 0: trig = orbfe_sincos_cr, also flags keypoints whose sampling grid could differ under a
+//         1-ulp change of sin/cos (fragile[]).  mode 1: trig given per work item in fixAB.
+__global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
+                                                          const OrbLevelGeom* __restrict__ lg,
+                                                          const OrbDescWork* __restrict__ work,
+                                                          const int32_t* __restrict__ nOut, int capPerImg,
+                                                          float* __restrict__ kpsOut, uint8_t* __restrict__ descOut,
+                                                          const int* __restrict__ taps, uint8_t* __restrict__ fragile,
+                                                          int mode, int32_t* fixList /* (img, g) pairs */,
+                                                          float* fixF /* mode 0: out angle; mode 1: in (a, b) */,
+                                                          int nFix, int32_t* fixCount, int listFragile)
+{
+    __shared__ uint8_t s_raw[4][DESC_RAW * DESC_RAWP];
+    __shared__ uint16_t s_h[4][DESC_RAW * DESC_HP];
+    __shared__ uint8_t s_b[4][DESC_BW * DESC_BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int img, g;
+    if (mode == 0) {
+        img = blockIdx.y;
+        g = blockIdx.x * 4 + wave;
+        if (g >= nOut[img]) return; // wave-uniform
+    } else {
+        const int f = blockIdx.x * 4 + wave;
+        if (f >= nFix) return;
+        img = fixList[2 * f];
+        g = fixList[2 * f + 1];
+    }
+    const OrbDescWork w = work[(size_t)img * capPerImg + g];
+    const OrbLevelGeom L = lg[w.level];
+    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff;
+    uint8_t* raw = s_raw[wave];
+    uint16_t* hp = s_h[wave];
+    uint8_t* bl = s_b[wave];
+
+    // raw 43x43 patch, BORDER_REFLECT_101 at the level edges
+    const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R < L.w && w.y + DESC_R < L.h;
+    for (int idx = lane; idx < DESC_RAW * DESC_RAW; idx += 64) {
+        const int r = idx / DESC_RAW, c = idx - r * DESC_RAW;
+        int sy = w.y - DESC_R + r, sx = w.x - DESC_R + c;
+        if (!inside) {
+            sy = reflect101(sy, L.h);
+            sx = reflect101(sx, L.w);
+        }
+        raw[r * DESC_RAWP + c] = roi[(size_t)sy * L.pitch + sx];
+    }
+    WAVE_SYNC();
+
+    // IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch of radius 15
+    int m10 = 0, m01 = 0;
+    for (int idx = lane; idx < 31 * 31; idx += 64) {
+        const int r = idx / 31, c = idx - r * 31;
+        const int v = r - 15, u = c - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= c_umax[av]) {
+            const int I = raw[(r + 6) * DESC_RAWP + (c + 6)];
+            m10 += u * I;
+            m01 += v * I;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // separable 7-tap blur of the 37x37 patch (8.8 taps; horizontal exact in u16, vertical 16.16)
+    int t[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) t[i] = taps[i];
+    for (int idx = lane; idx < DESC_RAW * DESC_BW; idx += 64) {
+        const int r = idx / DESC_BW, c = idx - r * DESC_BW;
+        const uint8_t* s = raw + r * DESC_RAWP + c;
+        unsigned acc = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) acc += (unsigned)t[i] * s[i];
+        hp[r * DESC_HP + c] = (uint16_t)min(acc, 65535u);
+    }
+    WAVE_SYNC();
+    for (int idx = lane; idx < DESC_BW * DESC_BW; idx += 64) {
+        const int r = idx / DESC_BW, c = idx - r * DESC_BW;
+        const uint16_t* s = hp + r * DESC_HP + c;
+        unsigned acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc += (unsigned)t[j] * s[j * DESC_HP];
+        const unsigned v = (acc + 32768u) >> 16;
+        bl[r * DESC_BP + c] = (uint8_t)min(v, 255u);
+    }
+    WAVE_SYNC();
+
+    // steered BRIEF (:106-145)
+    float a, b;
+    if (mode == 0) {
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        orbfe_sincos_cr(__fmul_rn(angle, factorPI), &b, &a);
+    } else {
+        const int f = blockIdx.x * 4 + wave;
+        a = fixF[2 * f];
+        b = fixF[2 * f + 1];
+    }
+    const uint8_t* center = bl + 18 * DESC_BP + 18;
+    unsigned long long word[4];
+    bool frag = false;
+    // a tap is fragile when its pre-rounding coordinate is within FR of a half-integer: a 1-ulp
+    // change of a or b moves it by at most 13*2^-24*2 < 2e-6.
+    const float FR = 4e-6f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int bit = q * 64 + lane;
+        const float x0 = (float)ORB_PATTERN_31_DEV[bit][0], y0 = (float)ORB_PATTERN_31_DEV[bit][1];
+        const float x1 = (float)ORB_PATTERN_31_DEV[bit][2], y1 = (float)ORB_PATTERN_31_DEV[bit][3];
+        const float fy0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
+        const float fx0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
+        const float fy1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
+        const float fx1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+        const int iy0 = __float2int_rn(fy0), ix0 = __float2int_rn(fx0);
+        const int iy1 = __float2int_rn(fy1), ix1 = __float2int_rn(fx1);
+        const int t0 = center[iy0 * DESC_BP + ix0];
+        const int t1 = center[iy1 * DESC_BP + ix1];
+        word[q] = __ballot(t0 < t1);
+        if (mode == 0) {
+            const float e0 = fabsf(fabsf(fy0 - (float)iy0) - 0.5f), e1 = fabsf(fabsf(fx0 - (float)ix0) - 0.5f);
+            const float e2 = fabsf(fabsf(fy1 - (float)iy1) - 0.5f), e3 = fabsf(fabsf(fx1 - (float)ix1) - 0.5f);
+            frag |= (e0 < FR) | (e1 < FR) | (e2 < FR) | (e3 < FR);
+        }
+    }
+    const size_t slot = (size_t)img * capPerImg + w.dest;
+    if (lane < 4) {
+        const unsigned long long v = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        reinterpret_cast<unsigned long long*>(descOut + slot * 32)[lane] = v;
+    }
+    if (mode == 0) {
+        const bool anyFrag = __ballot(frag) != 0ull;
+        if (lane == 0) {
+            kpsOut[slot * 7 + 3] = angle;
+            fragile[(size_t)img * capPerImg + g] = anyFrag ? 1 : 0;
+            if (anyFrag && listFragile) {
+                const int idx = atomicAdd(fixCount, 1);
+                fixList[2 * idx] = img;
+                fixList[2 * idx + 1] = g;
+                fixF[idx] = angle;
+            }
+        }
+    }
+}

@@ -1,0 +1,654 @@
+/*
+ * orbfe_matcher.hip -- Hamming brute-force kernels of ORBmatcher behind the C ABI.
+ *
+ *   K-HAM     k_hamming_pairs   ORBmatcher::DescriptorDistance, all pairs   src/ORBmatcher.cc:2591-2607
+ *   K-BFKNN2  k_bfknn2          cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)   src/Frame.cc:1137
+ *   K-BOW     k_search_bow      SearchByBoW inner loops                     src/ORBmatcher.cc:297-433, 853-932
+ *   K-TRI     k_search_tri      SearchForTriangulation_ inner loops         src/ORBmatcher.cc:1274-1437
+ *   K-KB8     k_kb8_unproject   KannalaBrandt8::unproject                   src/CameraModels/KannalaBrandt8.cpp:96-123
+ *
+ * 256-bit descriptors are four 64-bit words; a distance is 4 x (xor + popcount).  Candidate
+ * scans run across the 64 lanes of a wavefront and are reduced with wave shuffles on packed
+ * (distance, position) keys -- integer/bitwise work, no MFMA.
+ * The host keeps the reference's control flow around the loops: the merge-join over the two
+ * FeatureVectors (std::map walk + lower_bound, :285-448) and the rotation-histogram cull
+ * (ComputeThreeMaxima, :2545-2586) are O(N) host code.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/orbfe.h"
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return -(1000 + (int)_e); \
+    } while (0)
+
+namespace {
+
+const int TH_LOW = 50;       // src/ORBmatcher.cc:37
+const int HISTO_LENGTH = 30; // :38
+
+struct Desc {
+    unsigned long long w[4];
+};
+
+__device__ __forceinline__ Desc load_desc(const uint8_t* p)
+{
+    // rows are 32 bytes; cv::Mat rows (and ours) are at least 8-byte aligned
+    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+    Desc d;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const ulonglong2 a = q[0], b = q[1];
+        d.w[0] = a.x;
+        d.w[1] = a.y;
+        d.w[2] = b.x;
+        d.w[3] = b.y;
+    } else {
+        const unsigned* u = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; i++) d.w[i] = (unsigned long long)u[2 * i] | ((unsigned long long)u[2 * i + 1] << 32);
+    }
+    return d;
+}
+__device__ __forceinline__ int hamming(const Desc& a, const Desc& b)
+{
+    return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) +
+           __popcll(a.w[3] ^ b.w[3]);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, off));
+    return v;
+}
+
+// ------------------------------------------------------------------ K-HAM
+// 64x64 tile per workgroup: the 64 A rows sit in LDS (read as wave-wide broadcasts), every lane
+// keeps one B row in registers; stores are 128-B rows of u16.
+__global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t* __restrict__ A, int nA,
+                                                       const uint8_t* __restrict__ B, int nB,
+                                                       uint16_t* __restrict__ D)
+{
+    __shared__ unsigned long long sA[64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    {
+        const int r = tid >> 2, wd = tid & 3;
+        unsigned long long v = 0;
+        if (i0 + r < nA) {
+            const unsigned* u = reinterpret_cast<const unsigned*>(A + (size_t)(i0 + r) * 32 + wd * 8);
+            v = (unsigned long long)u[0] | ((unsigned long long)u[1] << 32);
+        }
+        sA[r][wd] = v;
+    }
+    __syncthreads();
+    const int j = j0 + lane;
+    Desc b = {};
+    if (j < nB) b = load_desc(B + (size_t)j * 32);
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const int r = wave * 16 + k;
+        const int i = i0 + r;
+        if (i >= nA) break;
+        const int d = __popcll(sA[r][0] ^ b.w[0]) + __popcll(sA[r][1] ^ b.w[1]) + __popcll(sA[r][2] ^ b.w[2]) +
+                      __popcll(sA[r][3] ^ b.w[3]);
+        if (j < nB) D[(size_t)i * nB + j] = (uint16_t)d;
+    }
+}
+
+// ---------------------------------------------------------------- K-BFKNN2
+// One wavefront per query.  key = dist<<20 | trainIdx: the two smallest keys are exactly the
+// sequential strict-'<' scan's best and second best (ties -> lower train index first).
+__global__ __launch_bounds__(256) void k_bfknn2(const uint8_t* __restrict__ Q, int nQ, const uint8_t* __restrict__ T,
+                                                int nT, int32_t* __restrict__ idx, int32_t* __restrict__ dist)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= nQ) return;
+    const Desc dq = load_desc(Q + (size_t)q * 32);
+    unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    for (int t = lane; t < nT; t += 64) {
+        const unsigned key = ((unsigned)hamming(dq, load_desc(T + (size_t)t * 32)) << 20) | (unsigned)t;
+        if (key < k0) {
+            k1 = k0;
+            k0 = key;
+        } else if (key < k1) {
+            k1 = key;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o0 = (unsigned)__shfl_xor((int)k0, off), o1 = (unsigned)__shfl_xor((int)k1, off);
+        // merge two sorted pairs, keep the two smallest
+        const unsigned lo = min(k0, o0);
+        const unsigned hi = max(k0, o0);
+        k1 = min(hi, min(k1, o1));
+        k0 = lo;
+    }
+    if (lane == 0) {
+        idx[2 * q] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 & 0xFFFFF);
+        dist[2 * q] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> 20);
+        idx[2 * q + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 & 0xFFFFF);
+        dist[2 * q + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 >> 20);
+    }
+}
+
+// ------------------------------------------------------------------- K-BOW
+struct BowNode {
+    int off1, n1, off2, n2; // ranges in the CSR index arrays of set 1 / set 2
+};
+
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    // :391-396 -- factor is 1/HISTO_LENGTH (sic)
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+    if (bin == 30) bin = 0;
+    return bin;
+}
+
+// One wavefront per vocabulary node shared by both feature vectors.  Every feature belongs to
+// exactly one node, so nodes are independent; inside a node the rows of set 1 stay sequential
+// (a match removes its set-2 feature from later rows, :324,:884,:911) while the candidates of a
+// row are spread over the lanes.  variant 0: (KeyFrame*,Frame&), match2[idx2] = idx1;
+// variant 1: (KeyFrame*,KeyFrame*), match1[idx1] = idx2.  bins[] gets the rotation bin per match.
+__global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ nodes, int nNodes,
+                                                    const uint8_t* __restrict__ desc1,
+                                                    const uint8_t* __restrict__ mask1, const float* __restrict__ ang1,
+                                                    const int32_t* __restrict__ ind1, int limit1,
+                                                    const uint8_t* __restrict__ desc2,
+                                                    const uint8_t* __restrict__ mask2, const float* __restrict__ ang2,
+                                                    const int32_t* __restrict__ ind2, int limit2, int Nleft,
+                                                    float nnratio, int variant, int32_t* __restrict__ match,
+                                                    int8_t* __restrict__ bins, uint8_t* __restrict__ taken2)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nd = blockIdx.x * 4 + wave;
+    if (nd >= nNodes) return;
+    const BowNode N = nodes[nd];
+    // "already matched" state of this node's set-2 features: only this wave touches them, so the
+    // first 4096 candidates live in one register bit per (lane, step); the rest go through taken2[].
+    unsigned long long takenMask = 0ull;
+    for (int r = 0; r < N.n1; r++) {
+        const int idx1 = ind1[N.off1 + r];
+        if (variant == 1 && limit1 != -1 && idx1 >= limit1) continue;
+        if (!mask1[idx1]) continue;
+        const Desc d1 = load_desc(desc1 + (size_t)idx1 * 32);
+        // key = dist<<20 | position in the node's list (iteration order breaks ties)
+        unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+        for (int c = lane; c < N.n2; c += 64) {
+            const int idx2 = ind2[N.off2 + c];
+            const int step = c >> 6;
+            bool ok = step < 64 ? !((takenMask >> step) & 1ull) : !taken2[idx2];
+            if (variant == 1) ok = ok && !(limit2 != -1 && idx2 >= limit2) && mask2[idx2];
+            if (!ok) continue;
+            const unsigned key = ((unsigned)hamming(d1, load_desc(desc2 + (size_t)idx2 * 32)) << 20) | (unsigned)c;
+            const bool right = (variant == 0 && Nleft != -1 && idx2 >= Nleft);
+            if (!right) {
+                if (key < k0) {
+                    k1 = k0;
+                    k0 = key;
+                } else if (key < k1)
+                    k1 = key;
+            } else {
+                if (key < r0) {
+                    r1 = r0;
+                    r0 = key;
+                } else if (key < r1)
+                    r1 = key;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            unsigned o0 = (unsigned)__shfl_xor((int)k0, off), o1 = (unsigned)__shfl_xor((int)k1, off);
+            unsigned lo = min(k0, o0), hi = max(k0, o0);
+            k1 = min(hi, min(k1, o1));
+            k0 = lo;
+            o0 = (unsigned)__shfl_xor((int)r0, off);
+            o1 = (unsigned)__shfl_xor((int)r1, off);
+            lo = min(r0, o0);
+            hi = max(r0, o0);
+            r1 = min(hi, min(r1, o1));
+            r0 = lo;
+        }
+        // acceptance (wave-uniform values; lane 0 writes)
+        const int bestDist1 = k0 == 0xFFFFFFFFu ? 256 : (int)(k0 >> 20);
+        const int bestDist2 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 20);
+        const int bestDist1R = r0 == 0xFFFFFFFFu ? 256 : (int)(r0 >> 20);
+        const bool passTh = variant == 0 ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW); // :373 vs :906
+        if (passTh) {
+            if ((float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+                const int cpos = (int)(k0 & 0xFFFFF);
+                const int idx2 = ind2[N.off2 + cpos];
+                if ((cpos & 63) == lane && (cpos >> 6) < 64) takenMask |= 1ull << (cpos >> 6);
+                if (lane == 0) {
+                    if ((cpos >> 6) >= 64) taken2[idx2] = 1;
+                    if (variant == 0) {
+                        match[idx2] = idx1;
+                        bins[idx2] = (int8_t)rot_bin(ang1[idx1], ang2[idx2]);
+                    } else {
+                        match[idx1] = idx2;
+                        bins[idx1] = (int8_t)rot_bin(ang1[idx1], ang2[idx2]);
+                    }
+                }
+            }
+            if (variant == 0 && bestDist1R <= TH_LOW) { // ratio test is "|| true" in the reference (:405)
+                const int cpos = (int)(r0 & 0xFFFFF);
+                const int idx2 = ind2[N.off2 + cpos];
+                if ((cpos & 63) == lane && (cpos >> 6) < 64) takenMask |= 1ull << (cpos >> 6);
+                if (lane == 0) {
+                    if ((cpos >> 6) >= 64) taken2[idx2] = 1;
+                    match[idx2] = idx1;
+                    bins[idx2] = (int8_t)rot_bin(ang1[idx1], ang2[idx2]);
+                }
+            }
+        }
+        if (N.n2 > 4096) { // rare: make lane 0's taken2 writes visible to the wave before the next row
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------- K-TRI
+struct TriRow {
+    int idx1, off2, n2;
+};
+
+// One wavefront per unmatched keypoint of KF1 (vbMatched2 is never set in the reference, so rows
+// are independent).  A candidate passes when dist <= TH_LOW, the epipole gate (:1332-1340) and
+// Pinhole::epipolarConstrain_ (Pinhole.cpp:159-181) hold (or bCoarse); the sequential scan keeps
+// the smallest distance and, among equals, the LAST candidate (:1323 rejects only dist > bestDist).
+__global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ rows, int nRows,
+                                                    const uint8_t* __restrict__ desc1, const float* __restrict__ kp1,
+                                                    const float* __restrict__ uR1, const uint8_t* __restrict__ desc2,
+                                                    const uint8_t* __restrict__ hasMP2, const float* __restrict__ kp2,
+                                                    const int32_t* __restrict__ oct2, const float* __restrict__ uR2,
+                                                    const int32_t* __restrict__ ind2, const float* __restrict__ F12,
+                                                    float epx, float epy, const float* __restrict__ sf2,
+                                                    const float* __restrict__ sig2, int onlyStereo, int coarse,
+                                                    int32_t* __restrict__ match12)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rix = blockIdx.x * 4 + wave;
+    if (rix >= nRows) return;
+    const TriRow R = rows[rix];
+    const int idx1 = R.idx1;
+    const Desc d1 = load_desc(desc1 + (size_t)idx1 * 32);
+    const float k1x = kp1[2 * idx1], k1y = kp1[2 * idx1 + 1];
+    const bool bStereo1 = uR1[idx1] >= 0;
+    // epipolar line l = x1' F12 (separately rounded products and sums, no FMA)
+    const float la = __fadd_rn(__fadd_rn(__fmul_rn(k1x, F12[0]), __fmul_rn(k1y, F12[3])), F12[6]);
+    const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1x, F12[1]), __fmul_rn(k1y, F12[4])), F12[7]);
+    const float lc = __fadd_rn(__fadd_rn(__fmul_rn(k1x, F12[2]), __fmul_rn(k1y, F12[5])), F12[8]);
+    const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+    unsigned best = 0xFFFFFFFFu;
+    for (int c = lane; c < R.n2; c += 64) {
+        const int idx2 = ind2[R.off2 + c];
+        if (hasMP2[idx2]) continue;
+        const bool bStereo2 = uR2[idx2] >= 0;
+        if (onlyStereo && !bStereo2) continue;
+        const int dist = hamming(d1, load_desc(desc2 + (size_t)idx2 * 32));
+        if (dist > TH_LOW) continue;
+        const float k2x = kp2[2 * idx2], k2y = kp2[2 * idx2 + 1];
+        const int o2 = oct2[idx2];
+        if (!bStereo1 && !bStereo2) {
+            const float ex = __fsub_rn(epx, k2x), ey = __fsub_rn(epy, k2y);
+            if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.f, sf2[o2])) continue;
+        }
+        bool ok = coarse != 0;
+        if (!ok && den != 0.f) {
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2x), __fmul_rn(lb, k2y)), lc);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            ok = (double)dsqr < __dmul_rn(3.84, (double)sig2[o2]);
+        }
+        if (!ok) continue;
+        best = min(best, ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c)); // smallest dist, then last position
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+}
+
+// ------------------------------------------------------------------ K-KB8
+__global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__ P, const float* __restrict__ uv,
+                                                       int n, float* __restrict__ rays)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float pwx = __fdiv_rn(__fsub_rn(uv[2 * i], P[2]), P[0]);
+    const float pwy = __fdiv_rn(__fsub_rn(uv[2 * i + 1], P[3]), P[1]);
+    float scale = 1.f;
+    float theta_d = __fsqrt_rn(__fadd_rn(__fmul_rn(pwx, pwx), __fmul_rn(pwy, pwy)));
+    const float hp = (float)(3.14159265358979323846 / 2.0);
+    theta_d = fminf(fmaxf(-hp, theta_d), hp);
+    if (theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float t2 = __fmul_rn(theta, theta), t4 = __fmul_rn(t2, t2), t6 = __fmul_rn(t4, t2),
+                        t8 = __fmul_rn(t4, t4);
+            const float k0 = __fmul_rn(P[4], t2), k1 = __fmul_rn(P[5], t4), k2 = __fmul_rn(P[6], t6),
+                        k3 = __fmul_rn(P[7], t8);
+            const float num = __fsub_rn(
+                __fmul_rn(theta, __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(1.f, k0), k1), k2), k3)), theta_d);
+            const float den = __fadd_rn(
+                __fadd_rn(__fadd_rn(__fadd_rn(1.f, __fmul_rn(3.f, k0)), __fmul_rn(5.f, k1)), __fmul_rn(7.f, k2)),
+                __fmul_rn(9.f, k3));
+            const float fix = __fdiv_rn(num, den);
+            theta = __fsub_rn(theta, fix);
+            if (fabsf(fix) < 1e-6f) break;
+        }
+        scale = __fdiv_rn(tanf(theta), theta_d);
+    }
+    rays[3 * i] = __fmul_rn(pwx, scale);
+    rays[3 * i + 1] = __fmul_rn(pwy, scale);
+    rays[3 * i + 2] = 1.f;
+}
+
+// ------------------------------------------------------------- host helpers
+struct Scratch { // device allocations freed on scope exit
+    std::vector<void*> ptrs;
+    ~Scratch()
+    {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    int up(T** out, const T* host, size_t n)
+    {
+        *out = nullptr;
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) return -(1000 + (int)e);
+        ptrs.push_back(p);
+        if (host && n) {
+            e = hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return -(1000 + (int)e);
+        }
+        *out = (T*)p;
+        return 0;
+    }
+};
+
+int select_device(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return ORBFE_ERR_NODEV;
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+bool fv_ok(const orbfe_fv& f)
+{
+    if (f.nn < 0) return false;
+    if (f.nn > 0 && (!f.node_ids || !f.offsets)) return false;
+    return true;
+}
+
+// merge-join of two ascending node-id lists (std::map iteration + lower_bound, :285-448)
+template <class F>
+void for_each_shared_node(const orbfe_fv& a, const orbfe_fv& b, F f)
+{
+    int i = 0, j = 0;
+    while (i < a.nn && j < b.nn) {
+        if (a.node_ids[i] == b.node_ids[j]) {
+            f(i, j);
+            i++;
+            j++;
+        } else if (a.node_ids[i] < b.node_ids[j]) {
+            i = (int)(std::lower_bound(a.node_ids + i, a.node_ids + a.nn, b.node_ids[j]) - a.node_ids);
+        } else {
+            j = (int)(std::lower_bound(b.node_ids + j, b.node_ids + b.nn, a.node_ids[i]) - b.node_ids);
+        }
+    }
+}
+
+// ComputeThreeMaxima, src/ORBmatcher.cc:2545-2586
+void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            ind3 = ind2;
+            ind2 = ind1;
+            ind1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            ind3 = ind2;
+            ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+// rotation-consistency cull (:450-468): returns the number of surviving matches
+int cull_by_rotation(int32_t* match, const int8_t* bins, int n, bool check)
+{
+    int nmatches = 0;
+    int histo[HISTO_LENGTH] = {0};
+    for (int i = 0; i < n; i++)
+        if (match[i] >= 0) {
+            nmatches++;
+            if (check && bins[i] >= 0 && bins[i] < HISTO_LENGTH) histo[bins[i]]++;
+        }
+    if (!check) return nmatches;
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < n; i++)
+        if (match[i] >= 0) {
+            const int b = bins[i];
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            match[i] = -1;
+            nmatches--;
+        }
+    return nmatches;
+}
+
+} // namespace
+
+extern "C" {
+
+int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D)
+{
+    if (nA < 0 || nB < 0 || (nA && !A) || (nB && !B) || (nA && nB && !D)) return ORBFE_ERR_ARGS;
+    if (nA == 0 || nB == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s;
+    uint8_t *dA, *dB;
+    uint16_t* dD;
+    if ((r = s.up(&dA, A, (size_t)nA * 32)) < 0) return r;
+    if ((r = s.up(&dB, B, (size_t)nB * 32)) < 0) return r;
+    if ((r = s.up<uint16_t>(&dD, nullptr, (size_t)nA * nB)) < 0) return r;
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, 0, dA,
+                       nA, dB, nB, dD);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(D, dD, (size_t)nA * nB * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int orbfe_bfknn2(int device, const uint8_t* Q, int nQ, const uint8_t* T, int nT, int32_t* idx, int32_t* dist)
+{
+    if (nQ < 0 || nT < 0 || (nQ && (!Q || !idx || !dist)) || (nT && !T) || nT >= (1 << 20)) return ORBFE_ERR_ARGS;
+    if (nQ == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s;
+    uint8_t *dQ, *dT;
+    int32_t *dI, *dD;
+    if ((r = s.up(&dQ, Q, (size_t)nQ * 32)) < 0) return r;
+    if ((r = s.up(&dT, T, (size_t)nT * 32)) < 0) return r;
+    if ((r = s.up<int32_t>(&dI, nullptr, (size_t)nQ * 2)) < 0) return r;
+    if ((r = s.up<int32_t>(&dD, nullptr, (size_t)nQ * 2)) < 0) return r;
+    hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, 0, dQ, nQ, dT, nT, dI, dD);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(idx, dI, (size_t)nQ * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dist, dD, (size_t)nQ * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int orbfe_search_bow(int device, const orbfe_bow_args* a, int32_t* match)
+{
+    if (!a || !match || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2) ||
+        (a->variant != 0 && a->variant != 1))
+        return ORBFE_ERR_ARGS;
+    const int nOut = a->variant == 0 ? a->n2 : a->n1;
+    for (int i = 0; i < nOut; i++) match[i] = -1;
+    if (a->n1 == 0 || a->n2 == 0) return 0;
+    if (!a->desc1 || !a->desc2 || !a->mask1 || (a->variant == 1 && !a->mask2)) return ORBFE_ERR_ARGS;
+    if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+    std::vector<BowNode> nodes;
+    for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
+        BowNode n;
+        n.off1 = a->fv1.offsets[i];
+        n.n1 = a->fv1.offsets[i + 1] - n.off1;
+        n.off2 = a->fv2.offsets[j];
+        n.n2 = a->fv2.offsets[j + 1] - n.off2;
+        if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
+    });
+    if (nodes.empty()) return 0;
+    for (const BowNode& n : nodes)
+        if (n.n2 >= (1 << 20)) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s;
+    BowNode* dN;
+    uint8_t *d1, *d2, *m1, *m2, *taken;
+    float *a1, *a2;
+    int32_t *i1, *i2, *dM;
+    int8_t* dB;
+    std::vector<float> zero1(a->n1, 0.f), zero2(a->n2, 0.f);
+    if ((r = s.up(&dN, nodes.data(), nodes.size())) < 0) return r;
+    if ((r = s.up(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
+    if ((r = s.up(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
+    if ((r = s.up(&m1, a->mask1, (size_t)a->n1)) < 0) return r;
+    if ((r = s.up(&m2, a->variant == 1 ? a->mask2 : nullptr, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&a1, a->angle1 ? a->angle1 : zero1.data(), (size_t)a->n1)) < 0) return r;
+    if ((r = s.up(&a2, a->angle2 ? a->angle2 : zero2.data(), (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&i1, a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn])) < 0) return r;
+    if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
+    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)nOut)) < 0) return r;
+    if ((r = s.up<int8_t>(&dB, nullptr, (size_t)nOut)) < 0) return r;
+    if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)a->n2)) < 0) return r;
+    HIP_TRY(hipMemset(dM, 0xFF, (size_t)nOut * sizeof(int32_t)));
+    HIP_TRY(hipMemset(dB, 0xFF, (size_t)nOut));
+    HIP_TRY(hipMemset(taken, 0, (size_t)a->n2));
+    hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, 0, dN, (int)nodes.size(),
+                       d1, m1, a1, i1, a->limit1, d2, m2, a2, i2, a->limit2, a->Nleft, a->nnratio, a->variant, dM, dB,
+                       taken);
+    HIP_TRY(hipGetLastError());
+    std::vector<int8_t> bins(nOut);
+    HIP_TRY(hipMemcpy(match, dM, (size_t)nOut * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bins.data(), dB, (size_t)nOut, hipMemcpyDeviceToHost));
+    return cull_by_rotation(match, bins.data(), nOut, a->check_orientation != 0);
+}
+
+int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
+{
+    if (!a || !pairs || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
+    if (a->n1 == 0 || a->n2 == 0) return 0;
+    if (!a->desc1 || !a->desc2 || !a->hasMP1 || !a->hasMP2 || !a->kp1_xy || !a->kp2_xy || !a->octave2 ||
+        !a->uRight1 || !a->uRight2 || !a->scaleFactors2 || !a->levelSigma2_2 || a->nlevels2 < 1)
+        return ORBFE_ERR_ARGS;
+    if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < a->n2; i++)
+        if (a->octave2[i] < 0 || a->octave2[i] >= a->nlevels2) return ORBFE_ERR_ARGS;
+    std::vector<TriRow> rows;
+    for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
+        const int off2 = a->fv2.offsets[j], n2 = a->fv2.offsets[j + 1] - off2;
+        for (int k = a->fv1.offsets[i]; k < a->fv1.offsets[i + 1]; k++) {
+            const int idx1 = a->fv1.indices[k];
+            if (a->hasMP1[idx1]) continue;                             // :1279-1282
+            if (a->only_stereo && !(a->uRight1[idx1] >= 0)) continue;   // :1286-1288
+            if (n2 > 0) rows.push_back(TriRow{idx1, off2, n2});
+        }
+    });
+    if (rows.empty()) return 0;
+    for (const TriRow& t : rows)
+        if (t.n2 >= (1 << 20)) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s;
+    TriRow* dR;
+    uint8_t *d1, *d2, *h2;
+    float *k1, *k2, *u1, *u2, *dF, *sf, *sg;
+    int32_t *o2, *i2, *dM;
+    if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
+    if ((r = s.up(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
+    if ((r = s.up(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
+    if ((r = s.up(&h2, a->hasMP2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&k1, a->kp1_xy, (size_t)a->n1 * 2)) < 0) return r;
+    if ((r = s.up(&k2, a->kp2_xy, (size_t)a->n2 * 2)) < 0) return r;
+    if ((r = s.up(&u1, a->uRight1, (size_t)a->n1)) < 0) return r;
+    if ((r = s.up(&u2, a->uRight2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&dF, a->F12, 9)) < 0) return r;
+    if ((r = s.up(&sf, a->scaleFactors2, (size_t)a->nlevels2)) < 0) return r;
+    if ((r = s.up(&sg, a->levelSigma2_2, (size_t)a->nlevels2)) < 0) return r;
+    if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
+    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
+    HIP_TRY(hipMemset(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, dR, (int)rows.size(), d1,
+                       k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> m12(a->n1);
+    HIP_TRY(hipMemcpy(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int8_t> bins(a->n1, -1);
+    if (a->check_orientation) {
+        for (int i = 0; i < a->n1; i++)
+            if (m12[i] >= 0) {
+                float rot = a->angle1[i] - a->angle2[m12[i]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[i] = (int8_t)bin;
+            }
+    }
+    cull_by_rotation(m12.data(), bins.data(), a->n1, a->check_orientation != 0);
+    int np = 0;
+    for (int i = 0; i < a->n1; i++) { // :1441-1446
+        if (m12[i] < 0) continue;
+        pairs[2 * np] = i;
+        pairs[2 * np + 1] = m12[i];
+        np++;
+    }
+    return np;
+}
+
+int orbfe_kb8_unproject(int device, const float* P, const float* uv, int n, float* rays)
+{
+    if (n < 0 || !P || (n && (!uv || !rays))) return ORBFE_ERR_ARGS;
+    if (n == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s;
+    float *dP, *dU, *dR;
+    if ((r = s.up(&dP, P, 8)) < 0) return r;
+    if ((r = s.up(&dU, uv, (size_t)n * 2)) < 0) return r;
+    if ((r = s.up<float>(&dR, nullptr, (size_t)n * 3)) < 0) return r;
+    hipLaunchKernelGGL(k_kb8_unproject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP, dU, n, dR);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rays, dR, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,114 @@
+"""GPU parity of the ORBmatcher Hamming kernels vs the oracle (bit-exact distances, indices, matches)."""
+import numpy as np
+import pytest
+
+import matcher_inputs as MI
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def test_descriptor_distance_all_pairs(pkg, oracle):
+    rng = np.random.default_rng(0)
+    for nA, nB in [(1, 1), (5, 3), (64, 64), (65, 130), (1000, 1200), (1500, 1500)]:
+        A = rng.integers(0, 256, size=(nA, 32), dtype=np.uint8)
+        B = rng.integers(0, 256, size=(nB, 32), dtype=np.uint8)
+        A[0] = 0
+        B[0] = 255  # distance 256
+        if nA > 1 and nB > 1:
+            B[1] = A[1]  # distance 0
+        D = pkg.hamming_pairs(A, B)
+        assert np.array_equal(D, oracle.hamming_matrix(A, B))
+        # independent numpy popcount
+        assert np.array_equal(D, np.unpackbits(A[:, None, :] ^ B[None, :, :], axis=2).sum(axis=2)) if nA * nB < 20000 else True
+    assert D[0, 0] == 256
+
+
+def test_bfknn2(pkg, oracle):
+    for nQ, nT, seed in [(1, 1, 1), (3, 2, 2), (10, 0, 3), (200, 70, 4), (1500, 1500, 5), (700, 2100, 6)]:
+        d1, d2, _, _ = MI.descriptor_sets(max(nQ, 1), max(nT, 1), seed)
+        Q, T = d1[:nQ], d2[:nT]
+        if nT > 5:
+            T[3] = T[1]  # tie between train rows: lower index first
+        idx, dist = pkg.bfknn2(Q, T)
+        ridx, rdist = oracle.bfknn2(Q, T)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    # Lowe ratio of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1144) is applied by the caller
+    good = dist[:, 0] < dist[:, 1] * 0.7
+    assert good.sum() > 0
+
+
+@pytest.mark.parametrize("n1,n2,seed", [(1000, 1000, 10), (1200, 1100, 11), (300, 1500, 12), (50, 40, 13)])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow_kf_frame(pkg, oracle, n1, n2, seed, check_ori):
+    d1, d2, a1, a2 = MI.descriptor_sets(n1, n2, seed)
+    fv1, fv2 = MI.feature_vectors(d1, d2, seed)
+    rng = np.random.default_rng(seed)
+    mask1 = (rng.uniform(size=n1) < 0.6).astype(np.uint8)
+    for Nleft in (-1, n2 // 2):
+        for ratio in (0.7, 0.75, 0.9):
+            n, m = pkg.search_bow(d1, mask1, a1, fv1, d2, None, a2, fv2, 0, ratio, check_ori, Nleft=Nleft)
+            rn, rm = oracle.search_bow_kf_f(d1, mask1, a1, fv1, d2, a2, fv2, Nleft, ratio, check_ori)
+            assert n == rn and np.array_equal(m, rm)
+    assert rn > 10 or n1 < 100
+
+
+@pytest.mark.parametrize("n1,n2,seed", [(1000, 1000, 20), (900, 1300, 21), (64, 64, 22)])
+def test_search_by_bow_kf_kf(pkg, oracle, n1, n2, seed):
+    d1, d2, a1, a2 = MI.descriptor_sets(n1, n2, seed)
+    fv1, fv2 = MI.feature_vectors(d1, d2, seed)
+    rng = np.random.default_rng(seed)
+    mask1 = (rng.uniform(size=n1) < 0.7).astype(np.uint8)
+    mask2 = (rng.uniform(size=n2) < 0.7).astype(np.uint8)
+    for lim1, lim2 in ((-1, -1), (n1 * 3 // 4, n2 * 3 // 4)):
+        n, m = pkg.search_bow(d1, mask1, a1, fv1, d2, mask2, a2, fv2, 1, 0.9, True, limit1=lim1, limit2=lim2)
+        rn, rm = oracle.search_bow_kf_kf(d1, mask1, a1, fv1, d2, mask2, a2, fv2, lim1, lim2, 0.9, True)
+        assert n == rn and np.array_equal(m, rm)
+    assert rn > 5
+
+
+def test_search_bow_empty_and_disjoint(pkg, oracle):
+    d1, d2, a1, a2 = MI.descriptor_sets(40, 40, 3)
+    fv1 = (np.array([1, 5], np.uint32), np.array([0, 20, 40], np.int32), np.arange(40, dtype=np.int32))
+    fv2 = (np.array([2, 7], np.uint32), np.array([0, 10, 40], np.int32), np.arange(40, dtype=np.int32))
+    n, m = pkg.search_bow(d1, np.ones(40, np.uint8), a1, fv1, d2, None, a2, fv2, 0, 0.7)
+    assert n == 0 and (m == -1).all()
+    e = np.zeros((0, 32), np.uint8)
+    efv = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    n, m = pkg.search_bow(e, np.zeros(0, np.uint8), np.zeros(0), efv, d2, None, a2, fv2, 0, 0.7)
+    assert n == 0 and len(m) == 40
+
+
+@pytest.mark.parametrize("seed", [30, 31, 32])
+@pytest.mark.parametrize("only_stereo,coarse", [(False, False), (True, False), (False, True)])
+def test_search_for_triangulation(pkg, oracle, seed, only_stereo, coarse):
+    I = MI.tri_inputs(1100, 1000, seed)
+    got = pkg.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"], I["d2"],
+                                   I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"], I["F12"], I["ep"],
+                                   I["sf"], I["sig"], only_stereo, coarse, True)
+    ref = oracle.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"], I["d2"],
+                                      I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"], I["F12"], I["ep"],
+                                      I["sf"], I["sig"], only_stereo, coarse, True)
+    assert np.array_equal(got, ref)
+    if coarse:
+        assert len(ref) > 10
+    assert (np.diff(got[:, 0]) > 0).all() if len(got) > 1 else True  # sorted by idx1 (:1441-1446)
+
+
+def test_kb8_unproject(pkg, oracle):
+    # TUM-VI 512 parameters (Examples/Stereo-Inertial/TUM_512.yaml:9-30)
+    P = np.array([190.978477, 190.973307, 254.931706, 256.897442, 0.003482389, 0.000715034, -0.002053236,
+                  0.000202937], np.float32)
+    rng = np.random.default_rng(1)
+    uv = rng.uniform(0, 512, size=(2000, 2)).astype(np.float32)
+    uv[0] = (P[2], P[3])  # principal point: theta_d == 0 branch
+    got = pkg.kb8_unproject(P, uv)
+    ref = oracle.kb8_unproject(P, uv)
+    # tanf comes from different libms: tolerance parity, 1e-6 relative
+    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(got[0], [0, 0, 1])

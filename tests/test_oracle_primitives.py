@@ -49,7 +49,7 @@ def test_umax(oracle):
 
 def test_pattern_tables_identical_and_hashed():
     def load(path):
-        txt = open(path).read().split("[256][4] = {", 1)[1]
+        txt = open(path).read().split("/*PATTERN-BEGIN*/", 1)[1]
         return [int(x) for x in re.findall(r"-?\d+", txt)]
 
     a = load(os.path.join(ROOT, "oracle", "orb_pattern.inc"))
