@@ -1,0 +1,184 @@
+/*
+ * adapters/ORBextractor.h -- ORB_SLAM3::ORBextractor with its reference signatures, backed by the
+ * C ABI of liborbfe.so (include/orbfe.h).
+ *
+ * Drop this header in place of the reference's include/ORBextractor.h (and remove
+ * src/ORBextractor.cc from the build): Frame::ExtractORB (src/Frame.cc:413-420), the three
+ * `new ORBextractor(...)` in Tracking (src/Tracking.cc:1151-1157) and every scale getter call
+ * (src/Frame.cc:107-113) compile unchanged.  Public surface mirrored from
+ * include/ORBextractor.h:43-107: ctor, operator(), GetLevels/GetScaleFactor/GetScaleFactors/
+ * GetInverseScaleFactors/GetScaleSigmaSquares/GetInverseScaleSigmaSquares, mvImagePyramid.
+ *
+ * With OpenCV present the cv:: types are used; without it (this repo's own test build) a minimal
+ * stand-in for cv::KeyPoint / cv::Mat is provided so the adapter itself can be compiled and
+ * exercised.  mvImagePyramid is filled lazily: set ORBextractor::fetchPyramid = true (rectified
+ * stereo needs it for the SAD refinement in Frame::ComputeStereoMatches, src/Frame.cc:894-909).
+ */
+#ifndef ORBFE_ADAPTER_ORBEXTRACTOR_H
+#define ORBFE_ADAPTER_ORBEXTRACTOR_H
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "../include/orbfe.h"
+
+#if !defined(ORBFE_NO_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#define ORBFE_HAVE_OPENCV 1
+#endif
+#endif
+
+#ifndef ORBFE_HAVE_OPENCV
+namespace cv {
+struct Point2f {
+    float x, y;
+};
+struct KeyPoint { // same layout as cv::KeyPoint
+    Point2f pt;
+    float size, angle, response;
+    int octave, class_id;
+};
+class Mat { // 8-bit single-channel rows x cols with a row step; just enough for the adapter
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    uint8_t* data = nullptr;
+    Mat() {}
+    Mat(int r, int c) { create(r, c); }
+    Mat(int r, int c, uint8_t* ext, size_t s) : rows(r), cols(c), step(s), data(ext) {}
+    void create(int r, int c)
+    {
+        rows = r;
+        cols = c;
+        step = (size_t)c;
+        store.assign((size_t)r * c, 0);
+        data = store.data();
+    }
+    void release()
+    {
+        rows = cols = 0;
+        step = 0;
+        store.clear();
+        data = nullptr;
+    }
+    bool empty() const { return rows == 0 || cols == 0 || !data; }
+    uint8_t* ptr(int r) { return data + (size_t)r * step; }
+    const uint8_t* ptr(int r) const { return data + (size_t)r * step; }
+
+private:
+    std::vector<uint8_t> store;
+};
+typedef const Mat& InputArray;
+typedef Mat& OutputArray;
+} // namespace cv
+#endif
+
+namespace ORB_SLAM3 {
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+        : ctx(nullptr), nlevels(nlevels), scaleFactor(scaleFactor)
+    {
+        const int r = orbfe_create(&ctx, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device);
+        if (r < 0) throw std::runtime_error("orbfe_create failed (no HIP device or bad parameters)");
+        mvScaleFactor.resize(nlevels);
+        mvInvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        orbfe_get_scale_tables(ctx, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                               mvInvLevelSigma2.data());
+        mvImagePyramid.resize(nlevels);
+    }
+    ~ORBextractor() { orbfe_destroy(ctx); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // Compute the ORB features and descriptors on an image (mask is ignored, as in the reference :56).
+    int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea)
+    {
+#ifdef ORBFE_HAVE_OPENCV
+        cv::Mat image = _image.getMat();
+        if (image.empty()) return -1;
+        CV_Assert(image.type() == CV_8UC1);
+        const uint8_t* data = image.data;
+        const size_t step = image.step;
+#else
+        const cv::Mat& image = _image;
+        if (image.empty()) return -1;
+        const uint8_t* data = image.data;
+        const size_t step = image.step;
+#endif
+        const int cap = orbfe_max_keypoints(ctx, image.rows, image.cols);
+        if (cap < 0) throw std::runtime_error("image too small for the 8-level 35-px cell grid");
+        static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_kp), "cv::KeyPoint layout");
+        std::vector<cv::KeyPoint> kps((size_t)cap);
+        std::vector<uint8_t> desc((size_t)cap * 32);
+        int n = 0;
+        const int mono = orbfe_extract(ctx, data, image.rows, image.cols, step, vLappingArea[0], vLappingArea[1],
+                                       reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(), cap, &n);
+        if (mono < -1) throw std::runtime_error("orbfe_extract failed");
+        kps.resize((size_t)n);
+        _keypoints.swap(kps);
+#ifdef ORBFE_HAVE_OPENCV
+        if (n == 0) {
+            _descriptors.release();
+        } else {
+            _descriptors.create(n, 32, CV_8U);
+            cv::Mat d = _descriptors.getMat();
+            for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), desc.data() + (size_t)i * 32, 32);
+        }
+#else
+        if (n == 0) {
+            _descriptors.release();
+        } else {
+            _descriptors.create(n, 32);
+            std::memcpy(_descriptors.data, desc.data(), (size_t)n * 32);
+        }
+#endif
+        if (fetchPyramid) {
+            for (int l = 0; l < nlevels; l++) {
+                int r = 0, c = 0;
+                orbfe_get_level(ctx, 0, l, nullptr, 0, &r, &c);
+#ifdef ORBFE_HAVE_OPENCV
+                pyramidStore[l].create(r, c, CV_8U);
+                orbfe_get_level(ctx, 0, l, pyramidStore[l].data, pyramidStore[l].step, &r, &c);
+                mvImagePyramid[l] = pyramidStore[l](cv::Rect(19, 19, c - 38, r - 38)); // ROI inside the padded buffer
+#else
+                pyramidStore[l].create(r, c);
+                orbfe_get_level(ctx, 0, l, pyramidStore[l].data, pyramidStore[l].step, &r, &c);
+                mvImagePyramid[l] = cv::Mat(r - 38, c - 38, pyramidStore[l].ptr(19) + 19, pyramidStore[l].step);
+#endif
+            }
+        }
+        return mono;
+    }
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return (float)scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    std::vector<cv::Mat> mvImagePyramid;
+    bool fetchPyramid = false;
+    orbfe_ctx* handle() { return ctx; }
+
+protected:
+    orbfe_ctx* ctx;
+    int nlevels;
+    double scaleFactor;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<cv::Mat> pyramidStore = std::vector<cv::Mat>(16);
+};
+
+} // namespace ORB_SLAM3
+
+#endif

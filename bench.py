@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- keypoints+descriptors/s of the MI355X ORB front-end (BASELINE.json metric).
+
+A "step" = one pass of the whole extractor hot path (pyramid -> FAST -> quadtree -> pack ->
+orientation+blur+descriptor, plus the host-libm trig fix-up) over one batch of synthetic frames that
+is ALREADY RESIDENT in HBM; outputs stay in HBM.  Workload = BASELINE.json configs[1]: 752x480,
+8 levels, scale 1.2, nFeatures 1000, FAST 20/7 -- as a batch of --batch frames per GPU per step.
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank extracts its own
+shard of frames (weak scaling) and ONE RCCL all-gather per step exchanges the descriptor slabs for
+cross-camera matching.  Timing: W warm-up steps, then exactly K steps between barrier +
+torch.cuda.synchronize(), MAX over ranks; rank 0 prints one JSON line.
+
+Extra objects in the line:
+  roofline     -- dominant kernel (by hipEvent time on the extractor's stream, measured live over
+                  the timed steps): algorithmic bytes per launch / average launch time vs 8 TB/s HBM.
+  cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
+                  built without OpenCV) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def level_sizes(rows, cols, nlevels=8, scale=1.2):
+    sf = np.float32(1.0)
+    out = []
+    for _ in range(nlevels):
+        inv = np.float32(1.0) / sf
+        out.append((int(np.rint(np.float32(cols) * inv)), int(np.rint(np.float32(rows) * inv))))
+        sf = np.float32(np.float64(sf) * np.float64(np.float32(scale)))
+    return out
+
+
+def algorithmic_bytes_per_frame(rows, cols, n_kp, nlevels=8):
+    """Per-stage split of SURVEY.md section 8d's B_frame = 5*SumP - P_7 + 2390*N."""
+    P = [w * h for (w, h) in level_sizes(rows, cols, nlevels)]
+    sp = sum(P)
+    return {
+        "pyramid": 2 * sp - P[-1],          # SumP_{l<7} read + SumP written
+        "fast": sp,                          # every level read once
+        "octree": 0,                         # candidate lists: second order, excluded by 8d
+        "pack": 28 * n_kp,                   # KeyPoint records written
+        "desc": 2 * sp + (31 * 31 + 37 * 37) * n_kp + 32 * n_kp,  # blur r/w + patches + descriptors
+        "trigfix": 0,                        # host libm check + fix-up of a handful of keypoints
+    }
+
+
+def cpu_baseline(rows, cols, nfeatures, seconds=12.0):
+    """Oracle extractor (C++ threads, one extractor per thread) over independent frames, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orb_oracle_py as O
+    from orb_slam3_detailed_comments_kor_amd import synth
+    O.build()
+    cores = os.cpu_count() or 1
+    frames = np.stack([synth.make_frame(rows, cols, 1234 + i) for i in range(4)])
+    # single-thread rate first (mono protocol, reference src/Frame.cc:306)
+    n1, t1 = O.extract_many(frames, 1, 4, nfeatures, lap=(0, 1000))
+    reps1 = max(4, int(0.2 * seconds / (t1 / 4)))
+    n1, t1 = O.extract_many(frames, 1, reps1, nfeatures, lap=(0, 1000))
+    per_frame = t1 / reps1
+    # all cores: calibrate with 2 frames per thread, then size the run for the remaining budget
+    nc, tc = O.extract_many(frames, cores, 2, nfeatures, lap=(0, 1000))
+    reps = int(min(max(2, 0.6 * seconds / (tc / 2)), 200))
+    n, dt = O.extract_many(frames, cores, reps, nfeatures, lap=(0, 1000))
+    return {
+        "value": n / dt,
+        "unit": "keypoints/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d threads x %d frames of %dx%d (nF=%d) in %.1f s; 1 thread: %.0f keypoints/s (%.1f ms/frame)"
+                  % (cores, reps, cols, rows, nfeatures, dt, n1 / t1, 1e3 * per_frame),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--rows", type=int, default=480)
+    ap.add_argument("--cols", type=int, default=752)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--trig", choices=["libm", "cr"], default="libm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    from orb_slam3_detailed_comments_kor_amd.multicam import DescriptorExchange
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, H, W = args.batch, args.rows, args.cols
+    # distinct frames per rank: a few generated frames, horizontally rolled to fill the batch
+    nuniq = min(B, 8)
+    base = [pkg.synth.make_frame(H, W, 1234 + rank * 1000 + i) for i in range(nuniq)]
+    imgs = np.stack([np.roll(base[i % nuniq], 23 * (i // nuniq), axis=1) for i in range(B)])
+    d_img = torch.from_numpy(imgs).to(dev)
+
+    ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank,
+                          trig=pkg.binding.TRIG_LIBM if args.trig == "libm" else pkg.binding.TRIG_CR)
+    stream = torch.cuda.current_stream()
+    ex.set_stream(stream.cuda_stream)  # kernels run on torch's current stream
+    cap = ex.max_keypoints(H, W)
+    xch = DescriptorExchange(B, cap, dev, world, rank)
+    d_desc = xch.desc_view()
+    d_n = xch.count_view()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
+    lap = (0, 1000)  # mono protocol, src/Frame.cc:306
+
+    def step():
+        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), d_mono.data_ptr())
+        if world > 1:
+            xch.all_gather()  # one RCCL all-gather of descriptor slabs per batch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ex.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # every call records one set of stage events on the stream (no extra sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    stage_ms = ex.stage_ms()  # hipEvent times averaged over the timed steps
+    ex.profile(False)
+
+    n_local = int(d_n.sum().item())
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([n_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    kp_per_step = float(cnt.item())
+
+    if rank == 0:
+        dom = max(stage_ms, key=stage_ms.get)
+        abytes = algorithmic_bytes_per_frame(H, W, n_local / B)
+        launch_bytes = abytes[dom] * B
+        achieved = launch_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("batch") == B and j.get("rows") == H and j.get("cols") == W:
+                    traffic = j.get("hbm_bytes_per_launch", {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "keypoints+descriptors/sec on 752x480x8-level pyramid",
+            "value": kp_per_step * args.steps / dt,
+            "unit": "keypoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d grayscale, 8-level pyramid, nFeatures=%d, FAST 20/7, %d frames/GPU/step "
+                            "resident in HBM (BASELINE configs[1] batched)" % (W, H, args.nfeatures, B),
+                "frames_per_step": B * world,
+                "keypoints_per_step": kp_per_step,
+                "trig": args.trig,
+                "exchange": "1 all-gather of descriptor slabs per step" if world > 1 else "none",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": launch_bytes,
+                "avg_launch_ms": stage_ms[dom],
+                "stage_ms": stage_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,13 +99,16 @@ void orbfe_get_features_per_level(orbfe_ctx*, int* n_per_level);
  * dst (rows+38 by cols+38 of the level, row stride dst_stride).  Pass dst=NULL to query the size. */
 int orbfe_get_level(orbfe_ctx*, int img_index, int level, uint8_t* dst, size_t dst_stride, int* rows, int* cols);
 
-/* Per-stage device time of the last call, measured with hipEvents on the context's stream. */
+/* Per-stage device time measured with hipEvents on the context's stream.  Enabling resets the
+ * statistics; every call then records one event set (ring of 256); orbfe_profile_read() waits for
+ * the stream, writes the per-stage AVERAGE over the recorded calls and returns their number. */
 #define ORBFE_STAGE_PYRAMID 0
 #define ORBFE_STAGE_FAST 1
 #define ORBFE_STAGE_OCTREE 2
 #define ORBFE_STAGE_PACK 3
 #define ORBFE_STAGE_DESC 4
-#define ORBFE_STAGE_COUNT 5
+#define ORBFE_STAGE_TRIGFIX 5 /* host libm check of the flagged keypoints + fix-up launch (ORBFE_TRIG_LIBM) */
+#define ORBFE_STAGE_COUNT 6
 int orbfe_profile_enable(orbfe_ctx*, int on);
 int orbfe_profile_read(orbfe_ctx*, float* ms_per_stage /* ORBFE_STAGE_COUNT */);
 

@@ -23,6 +23,8 @@
 #include "orb_oracle.h"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -72,8 +74,14 @@ void resize_linear(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* 
 {
     const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
     const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
-    std::vector<int> xofs(dw), yofs(dh);
-    std::vector<int16_t> ialpha(2 * dw), ibeta(2 * dh);
+    static thread_local std::vector<int> xofs, yofs, H0, H1;
+    static thread_local std::vector<int16_t> ialpha, ibeta;
+    xofs.resize(dw);
+    yofs.resize(dh);
+    ialpha.resize(2 * dw);
+    ibeta.resize(2 * dh);
+    H0.resize(dw);
+    H1.resize(dw);
     for (int dx = 0; dx < dw; dx++) {
         float fx = (float)((dx + 0.5) * scale_x - 0.5);
         int sx = cv_floor(fx);
@@ -92,7 +100,6 @@ void resize_linear(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* 
         ibeta[2 * dy] = sat_s16(cv_round((1.f - fy) * 2048));
         ibeta[2 * dy + 1] = sat_s16(cv_round(fy * 2048));
     }
-    std::vector<int> H0(dw), H1(dw);
     for (int dy = 0; dy < dh; dy++) {
         int sy0 = std::min(std::max(yofs[dy], 0), sh - 1);
         int sy1 = std::min(std::max(yofs[dy] + 1, 0), sh - 1);
@@ -149,6 +156,24 @@ inline bool has_run9(unsigned m16)
 inline bool fast_is_corner(const uint8_t* c, size_t stride, int t)
 {
     const int v = c[0];
+    {
+        // every arc of 9 holds one pixel of each opposite pair (k, k+8): cheap rejection first,
+        // as cv::FAST does with its threshold table
+        const ptrdiff_t s = (ptrdiff_t)stride;
+        const int hi = v + t, lo = v - t;
+        const int r0 = c[3 * s], r8 = c[-3 * s];
+        unsigned d = ((r0 > hi) | (r8 > hi) ? 1u : 0u) | ((r0 < lo) | (r8 < lo) ? 2u : 0u);
+        if (!d) return false;
+        const int r4 = c[3], r12 = c[-3];
+        d &= ((r4 > hi) | (r12 > hi) ? 1u : 0u) | ((r4 < lo) | (r12 < lo) ? 2u : 0u);
+        if (!d) return false;
+        const int r2 = c[2 * s + 2], r10 = c[-2 * s - 2];
+        d &= ((r2 > hi) | (r10 > hi) ? 1u : 0u) | ((r2 < lo) | (r10 < lo) ? 2u : 0u);
+        if (!d) return false;
+        const int r6 = c[-2 * s + 2], r14 = c[2 * s - 2];
+        d &= ((r6 > hi) | (r14 > hi) ? 1u : 0u) | ((r6 < lo) | (r14 < lo) ? 2u : 0u);
+        if (!d) return false;
+    }
     unsigned bright = 0, dark = 0;
     for (int k = 0; k < 16; k++) {
         int r = c[(ptrdiff_t)RING_DY[k] * (ptrdiff_t)stride + RING_DX[k]];
@@ -224,8 +249,10 @@ void fast_detect(const uint8_t* img, int rows, int cols, size_t stride, int thre
     out.clear();
     threshold = std::min(std::max(threshold, 0), 255);
     if (rows < 7 || cols < 7) return;
-    std::vector<int> score((size_t)rows * cols, 0);
-    std::vector<uint8_t> corner((size_t)rows * cols, 0);
+    static thread_local std::vector<int> score;
+    static thread_local std::vector<uint8_t> corner;
+    score.assign((size_t)rows * cols, 0);
+    corner.assign((size_t)rows * cols, 0);
     for (int y = 3; y < rows - 3; y++)
         for (int x = 3; x < cols - 3; x++) {
             const uint8_t* c = img + (size_t)y * stride + x;
@@ -265,20 +292,34 @@ void fast_detect(const uint8_t* img, int rows, int cols, size_t stride, int thre
 void gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride,
                     const int* taps)
 {
-    std::vector<uint32_t> H((size_t)rows * cols);
-    for (int y = 0; y < rows; y++)
+    // horizontal pass into H (u16, saturating like ufixedpoint16), rows padded by REFLECT_101
+    // scratch is kept per thread: large per-call allocations go through mmap/munmap, which
+    // serialises many-thread runs on the process-wide mm lock
+    static thread_local std::vector<uint16_t> H;
+    static thread_local std::vector<uint8_t> prow;
+    H.resize((size_t)rows * cols);
+    prow.resize((size_t)cols + 6);
+    for (int y = 0; y < rows; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        for (int x = -3; x < cols + 3; x++) prow[x + 3] = s[reflect101(x, cols)];
+        uint16_t* h = &H[(size_t)y * cols];
         for (int x = 0; x < cols; x++) {
             uint32_t acc = 0;
-            for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * src[(size_t)y * sstride + reflect101(x + i - 3, cols)];
-            H[(size_t)y * cols + x] = acc > 65535u ? 65535u : acc; // ufixedpoint16 saturating add
+            for (int i = 0; i < 7; i++) acc += (uint32_t)taps[i] * prow[x + i];
+            h[x] = (uint16_t)(acc > 65535u ? 65535u : acc);
         }
-    for (int y = 0; y < rows; y++)
+    }
+    for (int y = 0; y < rows; y++) {
+        const uint16_t* r[7];
+        for (int j = 0; j < 7; j++) r[j] = &H[(size_t)reflect101(y + j - 3, rows) * cols];
+        uint8_t* d = dst + (size_t)y * dstride;
         for (int x = 0; x < cols; x++) {
-            uint64_t acc = 0;
-            for (int j = 0; j < 7; j++) acc += (uint64_t)taps[j] * H[(size_t)reflect101(y + j - 3, rows) * cols + x];
-            uint64_t v = (acc + 32768u) >> 16;
-            dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
+            uint32_t acc = 0;
+            for (int j = 0; j < 7; j++) acc += (uint32_t)taps[j] * r[j][x];
+            const uint32_t v = (acc + 32768u) >> 16;
+            d[x] = (uint8_t)(v > 255 ? 255 : v);
         }
+    }
 }
 
 // ---------------------------------------------------------------- fastAtan2
@@ -904,6 +945,39 @@ int orb_oracle_distribute_octree(const orb_oracle_kp* cands, int n, int minX, in
     std::vector<KP> r = DistributeOctTree(v, minX, maxX, minY, maxY, N);
     for (int i = 0; i < (int)r.size() && i < cap; i++) out[i] = r[i];
     return (int)r.size();
+}
+
+// CPU-baseline helper: `nthreads` threads, each with its own extractor (the reference's
+// one-extractor-per-thread protocol, src/Frame.cc:119-122), each running `reps` extractions over the
+// given frames.  Returns the total number of keypoints; *seconds = wall time.
+long orb_oracle_extract_many(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
+                             const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, double* seconds)
+{
+    std::vector<orb_oracle*> ex(nthreads);
+    for (auto& e : ex) e = new orb_oracle(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    std::vector<long> counts(nthreads, 0);
+    const int cap = nfeatures + 64 + 16 * nlevels;
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&, t]() {
+            std::vector<KP> kps(cap);
+            std::vector<uint8_t> desc((size_t)cap * 32);
+            long c = 0;
+            for (int r = 0; r < reps; r++) {
+                int n = 0;
+                const uint8_t* im = imgs + (size_t)((t + r) % nimg) * rows * cols;
+                ex[t]->extract(im, rows, cols, (size_t)cols, lap0, lap1, kps.data(), desc.data(), cap, &n);
+                c += n;
+            }
+            counts[t] = c;
+        });
+    for (auto& t : th) t.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    long total = 0;
+    for (long c : counts) total += c;
+    for (auto& e : ex) delete e;
+    return total;
 }
 
 int orb_oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }

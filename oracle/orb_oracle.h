@@ -43,6 +43,10 @@ void orb_oracle_set_trig_mode(orb_oracle*, int mode);
 int orb_oracle_extract(orb_oracle*, const uint8_t* img, int rows, int cols, size_t stride,
                        int lap0, int lap1, orb_oracle_kp* kps, uint8_t* desc, int cap, int* n_out);
 
+/* CPU-baseline helper: nthreads threads x reps extractions, one extractor per thread. */
+long orb_oracle_extract_many(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
+                             const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, double* seconds);
+
 /* tables (ctor) */
 void orb_oracle_get_scale_tables(orb_oracle*, float* sf, float* inv, float* sigma2, float* inv_sigma2);
 void orb_oracle_get_features_per_level(orb_oracle*, int* n_per_level);

@@ -41,6 +41,10 @@ def lib():
         L.orb_oracle_extract.restype = C.c_int
         L.orb_oracle_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orb_oracle_extract_many.restype = C.c_long
+        L.orb_oracle_extract_many.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_double)]
         L.orb_oracle_get_scale_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.orb_oracle_get_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
         L.orb_oracle_get_umax.argtypes = [C.c_void_p, C.c_void_p]
@@ -183,6 +187,16 @@ class Extractor:
 
     def level_keypoints(self, level):
         return self._kps(self.L.orb_oracle_get_level_keypoints, level)
+
+
+def extract_many(imgs, nthreads, reps, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, lap=(0, 0)):
+    """Threaded CPU baseline: returns (total keypoints, seconds)."""
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    assert imgs.ndim == 3
+    sec = C.c_double(0)
+    n = lib().orb_oracle_extract_many(nthreads, reps, nfeatures, scale, nlevels, ini_th, min_th, _p(imgs),
+                                      imgs.shape[0], imgs.shape[1], imgs.shape[2], lap[0], lap[1], C.byref(sec))
+    return int(n), sec.value
 
 
 def resize_linear(src, dh, dw):

@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 ERR_ARGS, ERR_NODEV, ERR_STATE = -2, -3, -4
 TRIG_LIBM, TRIG_CR = 0, 1
-STAGES = ("pyramid", "fast", "octree", "pack", "desc")
+STAGES = ("pyramid", "fast", "octree", "pack", "desc", "trigfix")
 
 
 class OrbfeError(RuntimeError):
@@ -48,6 +48,20 @@ class _TriArgs(C.Structure):
                 ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process: torch bundles its own libamdhip64.so (same SONAME as the system
+    one).  Loading it first makes the dynamic linker bind liborbfe.so to that copy, so device
+    pointers, streams and events are interchangeable with torch's (two runtimes in one process
+    cannot both own the GPU)."""
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing only; without it the system runtime is used
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib_path():
     return os.path.join(_HERE, "liborbfe.so")
 
@@ -60,6 +74,7 @@ def lib():
         if not os.path.exists(path):
             raise ImportError("liborbfe.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(make -C orb_slam3_detailed_comments_kor_amd/csrc)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(path)
         L.orbfe_version.restype = C.c_char_p
         L.orbfe_create.restype = C.c_int

@@ -112,7 +112,7 @@ struct orbfe_ctx {
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
-    DevBuf<uint8_t> d_pyr, d_fragile, d_desc, d_img;
+    DevBuf<uint8_t> d_pyr, d_desc, d_img;
     DevBuf<uint32_t> d_cand, d_keys, d_lvlKp;
     DevBuf<uint16_t> d_keyNode;
     DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono, d_misc /* [0]=err [1]=fixCount */, d_fixList;
@@ -123,15 +123,19 @@ struct orbfe_ctx {
     DevBuf<OrbResizeX> d_xtab;
     DevBuf<OrbResizeY> d_ytab;
     DevBuf<int> d_taps;
+    DevBuf<float4> d_patternF;
     PinBuf<int32_t> h_misc, h_fixList, h_n, h_mono;
     PinBuf<float> h_fixAngle, h_fixAB;
     size_t imgPitch = 0, imgStride = 0;
 
     int lastImgs = 0;
     int lastFixups = 0;
+    // profiling: a ring of event sets, one set per call, read (averaged) after the timed region
+    static const int kProfSets = 256;
     bool profile = false;
-    hipEvent_t ev[ORBFE_STAGE_COUNT + 1] = {};
-    bool evReady = false, evRecorded = false;
+    std::vector<hipEvent_t> ev; // kProfSets * (ORBFE_STAGE_COUNT + 1)
+    bool evReady = false;
+    long profCalls = 0;
 };
 
 namespace {
@@ -347,7 +351,6 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_lvlCount.ensure(B * c->nlevels)) < 0) return r;
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
     if ((r = c->d_work.ensure(B * K)) < 0) return r;
-    if ((r = c->d_fragile.ensure(B * K)) < 0) return r;
     if ((r = c->d_fixList.ensure(B * K * 2)) < 0) return r;
     if ((r = c->d_fixAngle.ensure(B * K)) < 0) return r;
     if ((r = c->d_fixAB.ensure(B * K * 2)) < 0) return r;
@@ -357,6 +360,13 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->h_fixAngle.ensure(B * K)) < 0) return r;
     if ((r = c->h_fixAB.ensure(B * K * 2)) < 0) return r;
     if ((r = c->d_taps.ensure(8)) < 0) return r;
+    if (!c->d_patternF.p) {
+        if ((r = c->d_patternF.ensure(256)) < 0) return r;
+        static const signed char pat[256][4] = ORBFE_PATTERN_31_INIT;
+        std::vector<float4> pf(256);
+        for (int i = 0; i < 256; i++) pf[i] = make_float4((float)pat[i][0], (float)pat[i][1], (float)pat[i][2], (float)pat[i][3]);
+        HIP_TRY(hipMemcpy(c->d_patternF.p, pf.data(), 256 * sizeof(float4), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemset(c->d_misc.p, 0, 8 * sizeof(int32_t)));
     c->capImgs = (int)B;
     c->capKp = (int)K;
@@ -365,7 +375,9 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
 
 inline void rec(orbfe_ctx* c, int i)
 {
-    if (c->profile && c->evReady) (void)hipEventRecord(c->ev[i], c->stream);
+    if (c->profile && c->evReady)
+        (void)hipEventRecord(c->ev[(size_t)(c->profCalls % orbfe_ctx::kProfSets) * (ORBFE_STAGE_COUNT + 1) + i],
+                             c->stream);
 }
 
 // The whole pipeline on the context's stream.  All pointers are device pointers.
@@ -409,10 +421,11 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                        c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono);
     rec(c, 4);
     // K-DESC
-    hipLaunchKernelGGL(k_orient_blur_desc, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)nimg), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)nimg), dim3(256), 0, s,
                        c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                       c->d_fragile.p, 0, c->d_fixList.p, c->d_fixAngle.p, 0,
-                       c->d_misc.p + 1, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0);
+                       c->d_patternF.p, c->d_fixList.p, c->d_fixAngle.p, 0, c->d_misc.p + 1,
+                       c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0);
+    rec(c, 5);
     c->lastImgs = nimg;
     c->lastFixups = 0;
     if (c->trigMode == ORBFE_TRIG_LIBM) {
@@ -450,16 +463,15 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                        hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemcpyAsync(c->d_fixAB.p, c->h_fixAB.p, (size_t)nFix * 2 * sizeof(float),
                                        hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(k_orient_blur_desc, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
+                hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                    c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                                   c->d_fragile.p, 1, c->d_fixList.p, c->d_fixAB.p, nFix,
-                                   c->d_misc.p + 1, 0);
+                                   c->d_patternF.p, c->d_fixList.p, c->d_fixAB.p, nFix, c->d_misc.p + 1, 0);
             }
             c->lastFixups = nFix;
         }
     }
-    rec(c, 5);
-    if (c->profile) c->evRecorded = true;
+    rec(c, 6);
+    if (c->profile && c->evReady) c->profCalls++;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -503,12 +515,12 @@ void orbfe_destroy(orbfe_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_pyr.release(); c->d_fragile.release(); c->d_desc.release(); c->d_img.release();
+    c->d_pyr.release(); c->d_desc.release(); c->d_img.release();
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
     c->d_misc.release(); c->d_fixList.release(); c->d_kps.release(); c->d_fixAB.release(); c->d_fixAngle.release();
     c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release();
-    c->d_taps.release();
+    c->d_taps.release(); c->d_patternF.release();
     c->h_misc.release(); c->h_fixList.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAngle.release();
     c->h_fixAB.release();
     if (c->evReady)
@@ -537,7 +549,7 @@ int orbfe_set_gaussian_taps(orbfe_ctx* c, const int* t)
     if (!c || !t) return ORBFE_ERR_ARGS;
     int sum = 0;
     for (int i = 0; i < 7; i++) {
-        if (t[i] < 0 || t[i] > 256) return ORBFE_ERR_ARGS;
+        if (t[i] < 0 || t[i] > 255) return ORBFE_ERR_ARGS; // taps are u8 operands of v_dot4_u32_u8
         sum += t[i];
     }
     if (sum > 257) return ORBFE_ERR_ARGS; // horizontal pass must fit 16 bits
@@ -710,21 +722,32 @@ int orbfe_profile_enable(orbfe_ctx* c, int on)
     if (!c) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
     if (on && !c->evReady) {
+        c->ev.resize((size_t)orbfe_ctx::kProfSets * (ORBFE_STAGE_COUNT + 1));
         for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
         c->evReady = true;
     }
     c->profile = on != 0;
-    c->evRecorded = false;
+    if (on) c->profCalls = 0;
     return 0;
 }
 
 int orbfe_profile_read(orbfe_ctx* c, float* ms)
 {
-    if (!c || !ms || !c->evReady || !c->evRecorded) return ORBFE_ERR_STATE;
+    if (!c || !ms || !c->evReady || c->profCalls == 0) return ORBFE_ERR_STATE;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[ORBFE_STAGE_COUNT]));
-    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
-    return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int nset = (int)std::min<long>(c->profCalls, orbfe_ctx::kProfSets);
+    double acc[ORBFE_STAGE_COUNT] = {0};
+    for (int k = 0; k < nset; k++) {
+        const hipEvent_t* e = &c->ev[(size_t)k * (ORBFE_STAGE_COUNT + 1)];
+        for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, e[i], e[i + 1]));
+            acc[i] += t;
+        }
+    }
+    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) ms[i] = (float)(acc[i] / nset);
+    return nset;
 }
 
 int orbfe_debug_candidates(orbfe_ctx* c, int img, int level, uint32_t* out, int cap)

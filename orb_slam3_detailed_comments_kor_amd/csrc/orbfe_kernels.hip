@@ -724,36 +724,43 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-#define DESC_R 21  /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
-#define DESC_RAW 43
-#define DESC_RAWP 44
-#define DESC_BW 37 /* blurred patch side */
-#define DESC_HP 38 /* pitch of the horizontal pass (u16) */
-#define DESC_BP 40
+#define DESC_R 21    /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
+#define DESC_RAW 43  /* raw patch side */
+#define DESC_RAWP 44 /* raw pitch in bytes = 11 dwords */
+#define DESC_BW 37   /* blurred patch side */
+#define DESC_HP 40   /* pitch of the horizontal pass in u16 (80 B, 8-B aligned groups of 4) */
+#define DESC_BP 40   /* pitch of the blurred patch in bytes */
+#define DESC_RAW_BYTES (DESC_RAW * DESC_RAWP + 20) /* + slack: the last column group reads 12 B */
+#define DESC_H_BYTES (DESC_RAW * DESC_HP * 2)
+#define DESC_LDS_PER_WAVE (DESC_RAW_BYTES + DESC_H_BYTES) /* blurred patch aliases the raw patch */
 
 // One wavefront per keypoint.  Stages the 43x43 raw neighbourhood in LDS, computes the
 // intensity-centroid angle on the raw pixels (IC_Angle :75-102), blurs only the 37x37 patch the
 // rotated taps can reach (GaussianBlur 7x7 sigma 2 fixed point, identical to blurring the whole
 // level because the blur is local), then evaluates the 256 steered tests; the
 // 32 descriptor bytes are four 64-bit ballots.
-// mode 0: trig = orbfe_sincos_cr, also flags keypoints whose sampling grid could differ under a
-//         1-ulp change of sin/cos (fragile[]).  mode 1: trig given per work item in fixAB.
+//   LDS traffic is kept wide: the patch is staged as dwords, the horizontal pass is
+//   v_dot4_u32_u8 on (aligned / v_alignbyte-shifted) dwords producing 4 outputs per lane and one
+//   ds_write_b64, the vertical pass reads 4 x u16 per ds_read_b64.
+// MODE 0: trig = orbfe_sincos_cr; keypoints whose sampling grid could differ under a 1-ulp change
+//         of sin/cos are appended to fixList (angle in fixF) when listFragile is set.
+// MODE 1: fix-up launch: one wave per fixList entry, trig (a, b) given in fixF.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                           const OrbLevelGeom* __restrict__ lg,
                                                           const OrbDescWork* __restrict__ work,
                                                           const int32_t* __restrict__ nOut, int capPerImg,
                                                           float* __restrict__ kpsOut, uint8_t* __restrict__ descOut,
-                                                          const int* __restrict__ taps, uint8_t* __restrict__ fragile,
-                                                          int mode, int32_t* fixList /* (img, g) pairs */,
-                                                          float* fixF /* mode 0: out angle; mode 1: in (a, b) */,
+                                                          const int* __restrict__ taps,
+                                                          const float4* __restrict__ patternF,
+                                                          int32_t* fixList /* (img, g) pairs */,
+                                                          float* fixF /* MODE 0: out angle; MODE 1: in (a, b) */,
                                                           int nFix, int32_t* fixCount, int listFragile)
 {
-    __shared__ uint8_t s_raw[4][DESC_RAW * DESC_RAWP];
-    __shared__ uint16_t s_h[4][DESC_RAW * DESC_HP];
-    __shared__ uint8_t s_b[4][DESC_BW * DESC_BP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int img, g;
-    if (mode == 0) {
+    if (MODE == 0) {
         img = blockIdx.y;
         g = blockIdx.x * 4 + wave;
         if (g >= nOut[img]) return; // wave-uniform
@@ -766,34 +773,55 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     const OrbDescWork w = work[(size_t)img * capPerImg + g];
     const OrbLevelGeom L = lg[w.level];
     const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff;
-    uint8_t* raw = s_raw[wave];
-    uint16_t* hp = s_h[wave];
-    uint8_t* bl = s_b[wave];
+    uint8_t* raw = s_all[wave];
+    uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave] + DESC_RAW_BYTES);
+    uint8_t* bl = raw; // the blurred patch overwrites the raw patch once the horizontal pass is done
 
-    // raw 43x43 patch, BORDER_REFLECT_101 at the level edges
-    const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R < L.w && w.y + DESC_R < L.h;
-    for (int idx = lane; idx < DESC_RAW * DESC_RAW; idx += 64) {
-        const int r = idx / DESC_RAW, c = idx - r * DESC_RAW;
-        int sy = w.y - DESC_R + r, sx = w.x - DESC_R + c;
-        if (!inside) {
-            sy = reflect101(sy, L.h);
-            sx = reflect101(sx, L.w);
+    // ---- raw 43x43 patch (11 dwords per row; the 44th column is never used)
+    const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R + 1 < L.w && w.y + DESC_R < L.h;
+    if (inside) {
+        const uint8_t* p0 = roi + (size_t)(w.y - DESC_R) * L.pitch + (w.x - DESC_R);
+        // 473 dwords = 8 per lane, all loads in flight before the first LDS store; global dword
+        // loads may be unaligned (the patch origin is arbitrary)
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = min(lane + 64 * k, DESC_RAW * 11 - 1);
+            const int r = idx / 11, c4 = idx - r * 11;
+            __builtin_memcpy(&v[k], p0 + (size_t)r * L.pitch + 4 * c4, 4);
         }
-        raw[r * DESC_RAWP + c] = roi[(size_t)sy * L.pitch + sx];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = lane + 64 * k;
+            const int r = idx / 11, c4 = idx - r * 11;
+            if (idx < DESC_RAW * 11) *reinterpret_cast<uint32_t*>(raw + r * DESC_RAWP + 4 * c4) = v[k];
+        }
+    } else { // BORDER_REFLECT_101 at the level edges (keypoints within 21 px of an edge)
+        for (int idx = lane; idx < DESC_RAW * DESC_RAW; idx += 64) {
+            const int r = idx / DESC_RAW, c = idx - r * DESC_RAW;
+            const int sy = reflect101(w.y - DESC_R + r, L.h), sx = reflect101(w.x - DESC_R + c, L.w);
+            raw[r * DESC_RAWP + c] = roi[(size_t)sy * L.pitch + sx];
+        }
     }
     WAVE_SYNC();
 
-    // IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch of radius 15
+    // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch of radius 15.
+    // items = (row, dword): rows 6..36, dwords 1..9 (columns 4..39 cover u = -15..15 = columns 6..36)
     int m10 = 0, m01 = 0;
-    for (int idx = lane; idx < 31 * 31; idx += 64) {
-        const int r = idx / 31, c = idx - r * 31;
-        const int v = r - 15, u = c - 15;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= c_umax[av]) {
-            const int I = raw[(r + 6) * DESC_RAWP + (c + 6)];
+    for (int idx = lane; idx < 31 * 9; idx += 64) {
+        const int r = idx / 9, d = idx - r * 9;
+        const int v = r - 15;
+        const int um = c_umax[v < 0 ? -v : v];
+        const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (r + 6) * DESC_RAWP + 4 * (d + 1));
+        int rowsum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = 4 * (d + 1) + k - DESC_R;
+            const int I = (u >= -um && u <= um) ? (int)((px >> (8 * k)) & 0xFF) : 0;
+            rowsum += I;
             m10 += u * I;
-            m01 += v * I;
         }
+        m01 += v * rowsum;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -802,33 +830,55 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // separable 7-tap blur of the 37x37 patch (8.8 taps; horizontal exact in u16, vertical 16.16)
-    int t[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) t[i] = taps[i];
-    for (int idx = lane; idx < DESC_RAW * DESC_BW; idx += 64) {
-        const int r = idx / DESC_BW, c = idx - r * DESC_BW;
-        const uint8_t* s = raw + r * DESC_RAWP + c;
-        unsigned acc = 0;
-#pragma unroll
-        for (int i = 0; i < 7; i++) acc += (unsigned)t[i] * s[i];
-        hp[r * DESC_HP + c] = (uint16_t)min(acc, 65535u);
+    // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
+    const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
+    const uint32_t TLO = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), THI = t4 | (t5 << 8) | (t6 << 16);
+    // horizontal: item = (row r, group of 4 output columns); 43 x 10 items
+    for (int idx = lane; idx < DESC_RAW * 10; idx += 64) {
+        const int r = idx / 10, gq = idx - r * 10;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DESC_RAWP + 4 * gq);
+        const uint32_t d0 = s[0], d1 = s[1], d2 = s[2];
+        uint32_t o0 = __builtin_amdgcn_udot4(d0, TLO, 0u, false);
+        o0 = __builtin_amdgcn_udot4(d1, THI, o0, false);
+        uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), TLO, 0u, false);
+        o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), THI, o1, false);
+        uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), TLO, 0u, false);
+        o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), THI, o2, false);
+        uint32_t o3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), TLO, 0u, false);
+        o3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), THI, o3, false);
+        o0 = min(o0, 65535u); // ufixedpoint16 saturating add (only reachable with non-default taps)
+        o1 = min(o1, 65535u);
+        o2 = min(o2, 65535u);
+        o3 = min(o3, 65535u);
+        uint2 pk;
+        pk.x = o0 | (o1 << 16);
+        pk.y = o2 | (o3 << 16);
+        *reinterpret_cast<uint2*>(hp + r * DESC_HP + 4 * gq) = pk;
     }
     WAVE_SYNC();
-    for (int idx = lane; idx < DESC_BW * DESC_BW; idx += 64) {
-        const int r = idx / DESC_BW, c = idx - r * DESC_BW;
-        const uint16_t* s = hp + r * DESC_HP + c;
-        unsigned acc = 0;
+    // vertical: item = (row r, group of 4 columns); 37 x 10 items, written over the raw patch
+    for (int idx = lane; idx < DESC_BW * 10; idx += 64) {
+        const int r = idx / 10, gq = idx - r * 10;
+        const uint2* s = reinterpret_cast<const uint2*>(hp + r * DESC_HP + 4 * gq);
+        uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += (unsigned)t[j] * s[j * DESC_HP];
-        const unsigned v = (acc + 32768u) >> 16;
-        bl[r * DESC_BP + c] = (uint8_t)min(v, 255u);
+        for (int j = 0; j < 7; j++) {
+            const uint2 q = s[j * (DESC_HP / 4)];
+            const uint32_t tj = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : j == 3 ? t3 : j == 4 ? t4 : j == 5 ? t5 : t6;
+            a0 += tj * (q.x & 0xFFFFu);
+            a1 += tj * (q.x >> 16);
+            a2 += tj * (q.y & 0xFFFFu);
+            a3 += tj * (q.y >> 16);
+        }
+        const uint32_t b0 = min(a0 >> 16, 255u), b1 = min(a1 >> 16, 255u), b2 = min(a2 >> 16, 255u),
+                       b3 = min(a3 >> 16, 255u);
+        *reinterpret_cast<uint32_t*>(bl + r * DESC_BP + 4 * gq) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     }
     WAVE_SYNC();
 
-    // steered BRIEF (:106-145)
+    // ---- steered BRIEF (:106-145)
     float a, b;
-    if (mode == 0) {
+    if (MODE == 0) {
         const float factorPI = (float)(3.14159265358979323846 / 180.f);
         orbfe_sincos_cr(__fmul_rn(angle, factorPI), &b, &a);
     } else {
@@ -844,19 +894,17 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     const float FR = 4e-6f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int bit = q * 64 + lane;
-        const float x0 = (float)ORB_PATTERN_31_DEV[bit][0], y0 = (float)ORB_PATTERN_31_DEV[bit][1];
-        const float x1 = (float)ORB_PATTERN_31_DEV[bit][2], y1 = (float)ORB_PATTERN_31_DEV[bit][3];
-        const float fy0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
-        const float fx0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
-        const float fy1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
-        const float fx1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+        const float4 pt = patternF[q * 64 + lane]; // (x0, y0, x1, y1) of test bit q*64+lane
+        const float fy0 = __fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a));
+        const float fx0 = __fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b));
+        const float fy1 = __fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a));
+        const float fx1 = __fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b));
         const int iy0 = __float2int_rn(fy0), ix0 = __float2int_rn(fx0);
         const int iy1 = __float2int_rn(fy1), ix1 = __float2int_rn(fx1);
-        const int t0 = center[iy0 * DESC_BP + ix0];
-        const int t1 = center[iy1 * DESC_BP + ix1];
-        word[q] = __ballot(t0 < t1);
-        if (mode == 0) {
+        const int v0 = center[iy0 * DESC_BP + ix0];
+        const int v1 = center[iy1 * DESC_BP + ix1];
+        word[q] = __ballot(v0 < v1);
+        if (MODE == 0) {
             const float e0 = fabsf(fabsf(fy0 - (float)iy0) - 0.5f), e1 = fabsf(fabsf(fx0 - (float)ix0) - 0.5f);
             const float e2 = fabsf(fabsf(fy1 - (float)iy1) - 0.5f), e3 = fabsf(fabsf(fx1 - (float)ix1) - 0.5f);
             frag |= (e0 < FR) | (e1 < FR) | (e2 < FR) | (e3 < FR);
@@ -867,11 +915,10 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         const unsigned long long v = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
         reinterpret_cast<unsigned long long*>(descOut + slot * 32)[lane] = v;
     }
-    if (mode == 0) {
+    if (MODE == 0) {
         const bool anyFrag = __ballot(frag) != 0ull;
         if (lane == 0) {
             kpsOut[slot * 7 + 3] = angle;
-            fragile[(size_t)img * capPerImg + g] = anyFrag ? 1 : 0;
             if (anyFrag && listFragile) {
                 const int idx = atomicAdd(fixCount, 1);
                 fixList[2 * idx] = img;

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__
     const float pwx = __fdiv_rn(__fsub_rn(uv[2 * i], P[2]), P[0]);
     const float pwy = __fdiv_rn(__fsub_rn(uv[2 * i + 1], P[3]), P[1]);
     float scale = 1.f;
-    float theta_d = __fsqrt_rn(__fadd_rn(__fmul_rn(pwx, pwx), __fmul_rn(pwy, pwy)));
+    // v_sqrt_f32 is only 1-ulp accurate: take the (correctly rounded) float sqrt through double
+    float theta_d = (float)__dsqrt_rn((double)__fadd_rn(__fmul_rn(pwx, pwx), __fmul_rn(pwy, pwy)));
     const float hp = (float)(3.14159265358979323846 / 2.0);
     theta_d = fminf(fmaxf(-hp, theta_d), hp);
     if (theta_d > 1e-8) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__
             theta = __fsub_rn(theta, fix);
             if (fabsf(fix) < 1e-6f) break;
         }
-        scale = __fdiv_rn(tanf(theta), theta_d);
+        scale = __fdiv_rn((float)tan((double)theta), theta_d); // correctly rounded tan; host libm tanf is < 1 ulp
     }
     rays[3 * i] = __fmul_rn(pwx, scale);
     rays[3 * i + 1] = __fmul_rn(pwy, scale);

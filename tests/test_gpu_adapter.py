@@ -1,0 +1,37 @@
+"""The C++ adapter (adapters/ORBextractor.h) keeps the reference's signatures: a C++ caller written like
+Frame::ExtractORB gets the same bytes as the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fnv(desc, kps):
+    h = 1469598103934665603
+    for b in desc.tobytes() + kps.tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_cpp_adapter_matches_oracle(tmp_path, oracle):
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    exe = str(tmp_path / "test_adapter")
+    libdir = os.path.join(ROOT, "orb_slam3_detailed_comments_kor_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "adapters"),
+                           os.path.join(ROOT, "adapters", "test_adapter.cpp"), "-o", exe, "-L" + libdir, "-lorbfe",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    img = pkg.synth.make_frame(480, 752, 4242)
+    raw = tmp_path / "img.raw"
+    raw.write_bytes(img.tobytes())
+    out = subprocess.check_output([exe, str(raw), "480", "752", "1000"], text=True).split("\n")
+    mono, n, h, levels, prow, pcol = [int(v) for v in out[0].split()]
+    ref = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    rmono, rkps, rdesc = ref.extract(img, (0, 1000))
+    assert (mono, n, levels) == (rmono, len(rkps), 8)
+    assert h == _fnv(rdesc, rkps)
+    assert (prow, pcol) == (278, 435)          # mvImagePyramid[3] of a 752x480 frame
+    assert int(out[1]) == -1                   # empty image -> -1 (:1072-1073)

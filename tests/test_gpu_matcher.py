@@ -109,6 +109,8 @@ def test_kb8_unproject(pkg, oracle):
     uv[0] = (P[2], P[3])  # principal point: theta_d == 0 branch
     got = pkg.kb8_unproject(P, uv)
     ref = oracle.kb8_unproject(P, uv)
-    # tanf comes from different libms: tolerance parity, 1e-6 relative
-    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+    # the Newton iteration is bit-identical float arithmetic; only tan() comes from different
+    # libms (device: correctly rounded via double, host: glibc tanf < 1 ulp): tolerance 2 ulp.
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)
+    assert rel.max() <= 2.5e-7, rel.max()
     assert np.array_equal(got[0], [0, 0, 1])
