@@ -54,13 +54,36 @@ def algorithmic_bytes_per_frame(rows, cols, n_kp, nlevels=8):
     }
 
 
+def usable_cores():
+    """CPUs this process may actually use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(rows, cols, nfeatures, seconds=12.0):
     """Oracle extractor (C++ threads, one extractor per thread) over independent frames, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orb_oracle_py as O
     from orb_slam3_detailed_comments_kor_amd import synth
     O.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     frames = np.stack([synth.make_frame(rows, cols, 1234 + i) for i in range(4)])
     # single-thread rate first (mono protocol, reference src/Frame.cc:306)
     n1, t1 = O.extract_many(frames, 1, 4, nfeatures, lap=(0, 1000))

@@ -109,6 +109,9 @@ struct orbfe_ctx {
     size_t pyrStride = 0, candStride = 0, keyStride = 0, kpStride = 0;
     int nCells = 0, maxKp = 0, maxListCap = 0;
     size_t qtLdsBytes = 0;
+    int fastPitch = 0, fastRows = 0, fastThreads = 256;
+    size_t fastLdsBytes = 0;
+    int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
@@ -122,6 +125,9 @@ struct orbfe_ctx {
     DevBuf<OrbCellGeom> d_cg;
     DevBuf<OrbResizeX> d_xtab;
     DevBuf<OrbResizeY> d_ytab;
+    DevBuf<OrbPyrRange> d_prx, d_pry;
+    int pyrNtx = 0, pyrNty = 0, pyrBuf0 = 0, pyrBuf1 = 0, pyrStageX = 0, pyrStageY = 0;
+    bool pyrFused = true;
     DevBuf<int> d_taps;
     DevBuf<float4> d_patternF;
     PinBuf<int32_t> h_misc, h_fixList, h_n, h_mono;
@@ -285,6 +291,22 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     c->nCells = (int)c->cg.size();
     c->maxKp = maxKp;
     c->maxListCap = maxLC;
+    {
+        int maxCw = 0, maxCh = 0, maxZone = 0;
+        for (const OrbCellGeom& g : c->cg) {
+            maxCw = std::max<int>(maxCw, g.cw);
+            maxCh = std::max<int>(maxCh, g.ch);
+            maxZone = std::max(maxZone, std::max(g.cw - 6, 0) * std::max(g.ch - 6, 0));
+        }
+        c->fastPitch = (int)align_up((size_t)maxCw + 3, 4) + 4; // + one dword: phase A reads d+1
+        c->fastRows = maxCh;
+        c->fastLdsBytes = align_up((size_t)2 * c->fastRows * c->fastPitch + 2 * (size_t)std::max(maxZone, 1), 16);
+        // one mask bit per pixel of a thread's run in phase C: run length <= 64
+        int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
+        if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
+            nt = std::max(nt, c->fastThreadsOverride);
+        c->fastThreads = nt;
+    }
     c->qtLdsBytes = sizeof(int) * (64 + (size_t)std::max(24 * maxLC, 1024));
     if (c->qtLdsBytes > 160 * 1024) return ORBFE_ERR_ARGS; // nfeatures too large for one workgroup's LDS
     return 0;
@@ -302,6 +324,40 @@ int max_kp_for(orbfe_ctx* c, int rows, int cols)
         total += std::max(c->mnFeaturesPerLevel[l] + 3, 4 * std::max(nIni, 0)) + 1;
     }
     return total;
+}
+
+// Tile ranges of the fused pyramid kernel along one axis (see OrbPyrRange).  lo0[t]/hi1[t] give, for
+// destination index t of level l, the first / last source index of level l-1 it reads.
+void build_pyr_ranges(int nlevels, const std::vector<int>& extent, const std::vector<std::vector<int>>& srcLo,
+                      const std::vector<std::vector<int>>& srcHi, int ntiles, std::vector<OrbPyrRange>& out,
+                      int* maxNeed0, int* maxNeed1)
+{
+    const int top = nlevels - 1;
+    std::vector<std::vector<int>> b(nlevels, std::vector<int>(ntiles + 1));
+    for (int i = 0; i <= ntiles; i++) b[top][i] = std::min(i * ORBFE_PYR_TILE, extent[top]);
+    b[top][ntiles] = extent[top];
+    for (int l = top; l >= 1; l--) {
+        for (int i = 0; i < ntiles; i++) b[l - 1][i] = b[l][i] < extent[l] ? srcLo[l][b[l][i]] : extent[l - 1];
+        b[l - 1][0] = 0;
+        b[l - 1][ntiles] = extent[l - 1];
+    }
+    out.assign((size_t)nlevels * ntiles, OrbPyrRange());
+    for (int i = 0; i < ntiles; i++) {
+        int need = b[top][i + 1];
+        for (int l = top; l >= 0; l--) {
+            OrbPyrRange r;
+            r.lo = (int16_t)b[l][i];
+            r.ownHi = (int16_t)b[l][i + 1];
+            need = std::max(need, b[l][i + 1]);
+            if (need < b[l][i]) need = b[l][i];
+            r.needHi = (int16_t)need;
+            r.pad = 0;
+            out[(size_t)l * ntiles + i] = r;
+            if (l == 0) *maxNeed0 = std::max(*maxNeed0, need - b[l][i]);
+            if (l == 1) *maxNeed1 = std::max(*maxNeed1, need - b[l][i]);
+            if (l >= 1) need = need > b[l][i] ? srcHi[l][need - 1] + 1 : b[l - 1][i]; // footprint in level l-1
+        }
+    }
 }
 
 int ensure_geometry(orbfe_ctx* c, int rows, int cols)
@@ -326,6 +382,54 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
         HIP_TRY(hipMemcpy(c->d_xtab.p, xtab.data(), xtab.size() * sizeof(OrbResizeX), hipMemcpyHostToDevice));
     if (!ytab.empty())
         HIP_TRY(hipMemcpy(c->d_ytab.p, ytab.data(), ytab.size() * sizeof(OrbResizeY), hipMemcpyHostToDevice));
+    {
+        // fused pyramid: tile ranges per level along x and y
+        const int nl = c->nlevels;
+        std::vector<int> ex(nl), ey(nl);
+        std::vector<std::vector<int>> xlo(nl), xhi(nl), ylo(nl), yhi(nl);
+        for (int l = 0; l < nl; l++) {
+            ex[l] = c->lg[l].w;
+            ey[l] = c->lg[l].h;
+            if (l == 0) continue;
+            xlo[l].resize(ex[l]);
+            xhi[l].resize(ex[l]);
+            ylo[l].resize(ey[l]);
+            yhi[l].resize(ey[l]);
+            for (int t = 0; t < ex[l]; t++) {
+                xlo[l][t] = xtab[c->lg[l].xtabOff + t].sx;
+                xhi[l][t] = xtab[c->lg[l].xtabOff + t].pad;
+            }
+            for (int t = 0; t < ey[l]; t++) {
+                ylo[l][t] = ytab[c->lg[l].ytabOff + t].sy0;
+                yhi[l][t] = ytab[c->lg[l].ytabOff + t].sy1;
+            }
+        }
+        c->pyrNtx = (ex[nl - 1] + ORBFE_PYR_TILE - 1) / ORBFE_PYR_TILE;
+        c->pyrNty = (ey[nl - 1] + ORBFE_PYR_TILE - 1) / ORBFE_PYR_TILE;
+        std::vector<OrbPyrRange> prx, pry;
+        int mx0 = 0, mx1 = 0, my0 = 0, my1 = 0;
+        build_pyr_ranges(nl, ex, xlo, xhi, c->pyrNtx, prx, &mx0, &mx1);
+        build_pyr_ranges(nl, ey, ylo, yhi, c->pyrNty, pry, &my0, &my1);
+        c->pyrBuf0 = (int)align_up((size_t)((mx0 + 3) & ~3) * my0, 16);
+        c->pyrBuf1 = (int)align_up((size_t)((mx1 + 3) & ~3) * std::max(my1, 1), 16);
+        if ((r = c->d_prx.ensure(prx.size())) < 0) return r;
+        if ((r = c->d_pry.ensure(pry.size())) < 0) return r;
+        HIP_TRY(hipMemcpy(c->d_prx.p, prx.data(), prx.size() * sizeof(OrbPyrRange), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_pry.p, pry.data(), pry.size() * sizeof(OrbPyrRange), hipMemcpyHostToDevice));
+        c->pyrStageX = c->pyrStageY = 0;
+        for (int i = 0; i < c->pyrNtx; i++) {
+            int sum = 0;
+            for (int l = 1; l < nl; l++) sum += prx[(size_t)l * c->pyrNtx + i].needHi - prx[(size_t)l * c->pyrNtx + i].lo;
+            c->pyrStageX = std::max(c->pyrStageX, sum);
+        }
+        for (int j = 0; j < c->pyrNty; j++) {
+            int sum = 0;
+            for (int l = 1; l < nl; l++) sum += pry[(size_t)l * c->pyrNty + j].needHi - pry[(size_t)l * c->pyrNty + j].lo;
+            c->pyrStageY = std::max(c->pyrStageY, sum);
+        }
+        c->pyrFused = (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY) <= 64 * 1024 &&
+                      getenv("ORBFE_PYR_UNFUSED") == nullptr;
+    }
     if (c->qtLdsBytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)c->qtLdsBytes));
@@ -394,7 +498,12 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 2 * sizeof(int32_t), s));
     rec(c, 0);
     // K-PYR
-    {
+    if (c->pyrFused) {
+        hipLaunchKernelGGL(k_pyr_fused, dim3((unsigned)c->pyrNtx, (unsigned)c->pyrNty, (unsigned)nimg), dim3(256),
+                           (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY), s, d_imgs, pitch,
+                           imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p, c->pyrNtx,
+                           c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX, cols);
+    } else {
         const OrbLevelGeom& L0 = c->lg[0];
         dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);
         hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_imgs, pitch, imgStride, c->d_pyr.p, c->pyrStride, L0);
@@ -407,9 +516,17 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     }
     rec(c, 1);
     // K-FAST
-    hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)c->nCells, (unsigned)nimg), dim3(256), 0, s, c->d_pyr.p,
-                       c->pyrStride, c->d_lg.p, c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells,
-                       c->iniThFAST, c->minThFAST);
+    {
+        const dim3 grid((unsigned)c->nCells, (unsigned)nimg);
+#define ORBFE_FAST_LAUNCH(NT)                                                                                        \
+    hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, s, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
+                       c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
+                       c->minThFAST, c->fastPitch, c->fastRows)
+        if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
+        else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
+        else ORBFE_FAST_LAUNCH(256);
+#undef ORBFE_FAST_LAUNCH
+    }
     rec(c, 2);
     // K-QT
     hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)nimg), dim3(1024), c->qtLdsBytes, s, c->d_lg.p, c->d_cg.p,
@@ -501,6 +618,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     c->minThFAST = minThFAST;
     c->device = device;
     init_tables(c);
+    if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ORBFE_ERR_NODEV;
@@ -519,7 +637,7 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
     c->d_misc.release(); c->d_fixList.release(); c->d_kps.release(); c->d_fixAB.release(); c->d_fixAngle.release();
-    c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release();
+    c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
     c->d_taps.release(); c->d_patternF.release();
     c->h_misc.release(); c->h_fixList.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAngle.release();
     c->h_fixAB.release();

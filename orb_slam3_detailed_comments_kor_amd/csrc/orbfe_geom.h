@@ -59,6 +59,14 @@ struct OrbResizeY {
     int16_t b0, b1;
 };
 
+/* Fused pyramid kernel: per (level, tile index) ranges along one axis.  Tile i owns [lo, ownHi) of the
+ * level (the ranges of all tiles partition the level) and must compute [lo, needHi) so that the next
+ * level's needed range can be interpolated from it (halo, recomputed identically by neighbours). */
+struct OrbPyrRange {
+    int16_t lo, ownHi, needHi, pad;
+};
+#define ORBFE_PYR_TILE 16 /* tile side at the coarsest level */
+
 /* work item produced by K-PACK for K-DESC */
 struct OrbDescWork {
     int16_t level, x, y; /* level coordinates of the keypoint */

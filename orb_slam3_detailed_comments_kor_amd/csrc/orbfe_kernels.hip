@@ -91,6 +91,152 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
     }
 }
 
+// Whole pyramid in ONE launch.  A workgroup owns one ORBFE_PYR_TILE^2 tile of the coarsest level
+// and walks the chain level 0 -> nlevels-1 through two LDS buffers: it loads the level-0 region its
+// chain needs from the caller's image, and at every level interpolates the next region from LDS
+// (cv::resize INTER_LINEAR fixed point, same tables as k_pyr_resize), writing the part it owns to
+// the pyramid slab.  Halo pixels are recomputed by neighbouring workgroups from identical inputs,
+// so every level is bit-identical to the level-by-level result; the image is read from HBM once
+// and no level is ever read back.
+__global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ src, size_t srcPitch,
+                                                   size_t srcImgStride, uint8_t* __restrict__ pyr,
+                                                   size_t pyrImgStride, const OrbLevelGeom* __restrict__ lg,
+                                                   int nlevels, const OrbPyrRange* __restrict__ rx,
+                                                   const OrbPyrRange* __restrict__ ry, int ntx, int nty,
+                                                   const OrbResizeX* __restrict__ xtab,
+                                                   const OrbResizeY* __restrict__ ytab, int bufBytes0,
+                                                   int bufBytes1, int stageX, int imgCols)
+{
+    // dynamic LDS: region buffer A | region buffer B | staged x-table slices | staged y-table slices
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
+    uint8_t* bufA = pyr_lds;
+    uint8_t* bufB = pyr_lds + bufBytes0;
+    OrbResizeX* xt = reinterpret_cast<OrbResizeX*>(pyr_lds + bufBytes0 + bufBytes1);
+    OrbResizeY* yt = reinterpret_cast<OrbResizeY*>(xt + stageX);
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int ti = blockIdx.x, tj = blockIdx.y, img = blockIdx.z;
+    uint8_t* base = pyr + (size_t)img * pyrImgStride;
+
+    // per-level parameters once into LDS (one round of global loads instead of a dependent scalar
+    // load chain per level)
+    __shared__ int lvXlo[ORBFE_MAX_LEVELS], lvXown[ORBFE_MAX_LEVELS], lvXneed[ORBFE_MAX_LEVELS];
+    __shared__ int lvYlo[ORBFE_MAX_LEVELS], lvYown[ORBFE_MAX_LEVELS], lvYneed[ORBFE_MAX_LEVELS];
+    __shared__ int lvRoi[ORBFE_MAX_LEVELS], lvPitch[ORBFE_MAX_LEVELS], lvXt[ORBFE_MAX_LEVELS], lvYt[ORBFE_MAX_LEVELS];
+    if (tid < nlevels) {
+        const OrbPyrRange X = rx[tid * ntx + ti], Y = ry[tid * nty + tj];
+        lvXlo[tid] = X.lo;
+        lvXown[tid] = X.ownHi;
+        lvXneed[tid] = X.needHi;
+        lvYlo[tid] = Y.lo;
+        lvYown[tid] = Y.ownHi;
+        lvYneed[tid] = Y.needHi;
+        lvRoi[tid] = (int)lg[tid].roiOff;
+        lvPitch[tid] = lg[tid].pitch;
+        lvXt[tid] = lg[tid].xtabOff;
+        lvYt[tid] = lg[tid].ytabOff;
+    }
+    __syncthreads();
+    // stage the interpolation-table slices of every level (all loads in flight at once; the per-pixel
+    // loop below then touches LDS only)
+    {
+        int xo = 0, yo = 0;
+        for (int l = 1; l < nlevels; l++) {
+            const int nW = lvXneed[l] - lvXlo[l], nH = lvYneed[l] - lvYlo[l];
+            const int xb = lvXt[l] + lvXlo[l], yb = lvYt[l] + lvYlo[l];
+            for (int k = tid; k < nW; k += 256) xt[xo + k] = xtab[xb + k];
+            for (int k = tid; k < nH; k += 256) yt[yo + k] = ytab[yb + k];
+            xo += nW;
+            yo += nH;
+        }
+    }
+    // level 0: stage the needed region of the input image, write the owned part
+    int nW = lvXneed[0] - lvXlo[0], nH = lvYneed[0] - lvYlo[0];
+    int sp = (nW + 3) & ~3; // LDS pitch of the current source region
+    {
+        const int pitch0 = lvPitch[0];
+        const int xlo = lvXlo[0], ylo = lvYlo[0];
+        const uint8_t* s0 = src + (size_t)img * srcImgStride + (size_t)ylo * srcPitch + xlo;
+        uint8_t* d0 = base + (uint32_t)lvRoi[0] + (size_t)ylo * pitch0 + xlo;
+        const int ownW = lvXown[0] - xlo, ownH = lvYown[0] - ylo;
+        // dword granularity (global dword accesses may be unaligned), 8 loads in flight per thread
+        const int ndw = (nW + 3) >> 2;           // dwords per region row (LDS pitch sp == 4*ndw)
+        const int nItems = ndw * nH;
+        const int safeW = imgCols - xlo;         // bytes readable in a row without leaving the image row
+        for (int base0 = 0; base0 < nItems; base0 += 256 * 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int idx = base0 + k * 256 + tid;
+                v[k] = 0;
+                if (idx < nItems) {
+                    const int r = idx / ndw, c = 4 * (idx - r * ndw);
+                    const uint8_t* p = s0 + (size_t)r * srcPitch + c;
+                    if (c + 4 <= safeW) {
+                        __builtin_memcpy(&v[k], p, 4);
+                    } else {
+                        for (int b = 0; c + b < safeW && b < 4; b++) v[k] |= (uint32_t)p[b] << (8 * b);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int idx = base0 + k * 256 + tid;
+                if (idx < nItems) {
+                    const int r = idx / ndw, c = 4 * (idx - r * ndw);
+                    *reinterpret_cast<uint32_t*>(bufA + r * sp + c) = v[k];
+                    if (r < ownH) {
+                        uint8_t* q = d0 + (size_t)r * pitch0 + c;
+                        if (c + 4 <= ownW) {
+                            __builtin_memcpy(q, &v[k], 4);
+                        } else {
+                            for (int b = 0; c + b < ownW; b++) q[b] = (uint8_t)(v[k] >> (8 * b));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int srcLoX = lvXlo[0], srcLoY = lvYlo[0];
+    int xo = 0, yo = 0;
+    const uint8_t* S = bufA;
+    uint8_t* D = bufB;
+    for (int l = 1; l < nlevels; l++) {
+        const int xlo = lvXlo[l], ylo = lvYlo[l], gpitch = lvPitch[l];
+        nW = lvXneed[l] - xlo;
+        nH = lvYneed[l] - ylo;
+        const int dp = (nW + 3) & ~3;
+        uint8_t* g = base + (uint32_t)lvRoi[l] + (size_t)ylo * gpitch + xlo;
+        const int ownW = lvXown[l] - xlo, ownH = lvYown[l] - ylo;
+        for (int c = tx; c < nW; c += 16) {
+            const OrbResizeX tX = xt[xo + c];
+            const int sx = (int)tX.sx - srcLoX, sx1 = (int)tX.pad - srcLoX;
+            const int a0 = tX.a0, a1 = tX.a1;
+            for (int r = ty; r < nH; r += 16) {
+                const OrbResizeY tY = yt[yo + r];
+                const uint8_t* S0 = S + ((int)tY.sy0 - srcLoY) * sp;
+                const uint8_t* S1 = S + ((int)tY.sy1 - srcLoY) * sp;
+                const int h0 = S0[sx] * a0 + S0[sx1] * a1;
+                const int h1 = S1[sx] * a0 + S1[sx1] * a1;
+                int v = ((((int)tY.b0 * (h0 >> 4)) >> 16) + (((int)tY.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                D[r * dp + c] = (uint8_t)v;
+                if (r < ownH && c < ownW) g[(size_t)r * gpitch + c] = (uint8_t)v;
+            }
+        }
+        __syncthreads();
+        srcLoX = xlo;
+        srcLoY = ylo;
+        sp = dp;
+        xo += nW;
+        yo += nH;
+        uint8_t* t = const_cast<uint8_t*>(S);
+        S = D;
+        D = t;
+    }
+}
+
 // BORDER_REFLECT_101 frame of one level (19 px), written only when the caller asks for
 // mvImagePyramid (nothing inside the extractor reads it).
 __global__ __launch_bounds__(256) void k_border(uint8_t* __restrict__ pyr, size_t pyrImgStride, OrbLevelGeom L, int img)
@@ -115,9 +261,8 @@ __global__ __launch_bounds__(256) void k_border(uint8_t* __restrict__ pyr, size_
 // ----------------------------------------------------------------- K-FAST
 // FAST-9/16 corner score = largest threshold for which the pixel is still a corner
 // (cv::cornerScore<16>): max over the 16 arcs of 9 of min(r-v) and of min(v-r), minus 1.
-__device__ __forceinline__ int fast_score(const uint8_t* c)
+__device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
 {
-    constexpr int P = ORBFE_FAST_PITCH;
     const int v = c[0];
     int d[16];
     d[0] = c[3 * P + 0] - v;
@@ -158,121 +303,160 @@ __device__ __forceinline__ int fast_score(const uint8_t* c)
 // corner_at(t) <=> score >= t, and the strict 8-neighbour NMS is threshold independent
 // (SURVEY.md A.3), so kept(t) = localmax && score >= t; the cell picks iniTh if any pixel
 // survives at iniTh, else minTh.  Output: row-major ordered list per cell, packed x|y<<12|s<<24.
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
-                                                    const OrbLevelGeom* __restrict__ lg,
-                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
-                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
-                                                    int nCellsTotal, int iniTh, int minTh)
+//
+// The ROI is staged as aligned dwords (tile column 0 = level column iniX & ~3, ROI rows of the
+// pyramid are 64-B aligned), phase A tests 4 pixels per lane from 5 dword LDS reads, phase B
+// scores the queued survivors with all lanes busy, phase C does NMS + threshold choice + ordered
+// compaction with one block-wide scan.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
+                                                   const OrbLevelGeom* __restrict__ lg,
+                                                   const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
+                                                   size_t candImgStride, int32_t* __restrict__ cellCount,
+                                                   int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
+                                                   int tileRows)
 {
-    constexpr int P = ORBFE_FAST_PITCH;
-    __shared__ uint8_t tile[ORBFE_FAST_TILE * P];
-    __shared__ uint8_t smap[ORBFE_FAST_TILE * P];
-    __shared__ uint16_t queue[(ORBFE_FAST_TILE - 6) * (ORBFE_FAST_TILE - 6)];
-    __shared__ int qn, anyIni, waveCnt[4], runBase;
+    // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[(tileRows-6)*(P-6)] u16 -- sized by the
+    // host from the largest cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+    const int PD = P >> 2;
+    uint8_t* tile = fast_lds;
+    uint8_t* smap = fast_lds + tileRows * P;
+    uint16_t* queue = reinterpret_cast<uint16_t*>(fast_lds + 2 * tileRows * P);
+    __shared__ int qn, waveTot[4];
+    constexpr int NW = NT / 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cell = blockIdx.x, img = blockIdx.y;
     const OrbCellGeom c = cg[cell];
     const OrbLevelGeom L = lg[c.level];
     const int cw = c.cw, ch = c.ch;
-    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff + (size_t)c.iniY * L.pitch + c.iniX;
+    const int ox = c.iniX & 3; // tile x = roi x + ox
+    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff + (size_t)c.iniY * L.pitch + (c.iniX - ox);
     const int tmin = min(iniTh, minTh);
+    const int nd = (cw + ox + 3) >> 2; // dwords per tile row
 
-    if (tid == 0) {
-        qn = 0;
-        anyIni = 0;
-        runBase = 0;
-    }
+    if (tid == 0) qn = 0;
     // stage the ROI, clear the score map
-    for (int idx = tid; idx < ch * P; idx += 256) {
-        const int y = idx / P, x = idx - y * P;
-        smap[idx] = 0;
-        if (x < cw) tile[idx] = roi[(size_t)y * L.pitch + x];
+    for (int idx = tid; idx < ch * PD; idx += NT) {
+        const int y = idx / PD, d = idx - y * PD;
+        reinterpret_cast<uint32_t*>(smap)[idx] = 0u;
+        if (d < nd) reinterpret_cast<uint32_t*>(tile)[idx] = *reinterpret_cast<const uint32_t*>(roi + (size_t)y * L.pitch + 4 * d);
     }
     __syncthreads();
 
     const int zw = cw - 6, zh = ch - 6; // detection zone
     const int nz = (zw > 0 && zh > 0) ? zw * zh : 0;
+    const int txLo = 3 + ox, txHi = cw - 4 + ox; // zone columns in tile coordinates (inclusive)
     // phase A: cheap necessary test.  Every arc of 9 contains one pixel of each opposite pair
-    // (k, k+8); test the pairs (0,8) and (4,12).
-    for (int base = 0; base < nz; base += 256) {
-        const int idx = base + tid;
-        bool pass = false;
-        int pos = 0;
-        if (idx < nz) {
-            const int y = idx / zw + 3, x = idx - (idx / zw) * zw + 3;
-            pos = y * P + x;
-            const int v = tile[pos];
-            const int r0 = tile[pos + 3 * P], r8 = tile[pos - 3 * P], r4 = tile[pos + 3], r12 = tile[pos - 3];
-            const int hi = v + tmin, lo = v - tmin;
-            const bool b = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
-            const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
-            pass = b | dk;
+    // (k, k+8); test the pairs (0,8) and (4,12).  Item = (zone row, dword): 4 pixels per lane.
+    if (nz > 0) {
+        const int d0 = txLo >> 2, ndz = (txHi >> 2) - d0 + 1;
+        const int nItems = zh * ndz;
+        const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+        for (int base = 0; base < nItems; base += NT) {
+            const int idx = base + tid;
+            unsigned passBits = 0;
+            int y = 0, d = 0;
+            if (idx < nItems) {
+                y = idx / ndz;
+                d = idx - y * ndz + d0;
+                y += 3;
+                const uint32_t C = T[y * PD + d], Lf = T[y * PD + d - 1], R = T[y * PD + d + 1];
+                const uint32_t U = T[(y - 3) * PD + d], Dn = T[(y + 3) * PD + d];
+                // x-3 of the 4 pixels: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
+                const uint32_t W12 = __builtin_amdgcn_alignbyte(C, Lf, 1);
+                const uint32_t W4 = __builtin_amdgcn_alignbyte(R, C, 3);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int tx = 4 * d + k;
+                    const int v = (C >> (8 * k)) & 0xFF;
+                    const int r0 = (Dn >> (8 * k)) & 0xFF, r8 = (U >> (8 * k)) & 0xFF;
+                    const int r4 = (W4 >> (8 * k)) & 0xFF, r12 = (W12 >> (8 * k)) & 0xFF;
+                    const int hi = v + tmin, lo = v - tmin;
+                    const bool b = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
+                    const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
+                    if ((b | dk) && tx >= txLo && tx <= txHi) passBits |= 1u << k;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool pass = (passBits >> k) & 1u;
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    int wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&qn, __popcll(m));
+                    wbase = __shfl(wbase, 0);
+                    if (pass) queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * P + 4 * d + k);
+                }
+            }
         }
-        const unsigned long long m = __ballot(pass);
-        int wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&qn, __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (pass) queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
     }
     __syncthreads();
     // phase B: exact score for the survivors (all lanes busy)
     const int nq = qn;
-    for (int qi = tid; qi < nq; qi += 256) {
+    for (int qi = tid; qi < nq; qi += NT) {
         const int pos = queue[qi];
-        const int s = fast_score(&tile[pos]);
+        const int s = fast_score(&tile[pos], P);
         if (s >= tmin) smap[pos] = (uint8_t)s;
     }
     __syncthreads();
-    // phase C: strict 8-neighbour NMS; does any pixel survive at iniTh?
-    // (re-evaluated in phase D; here only the cell-wide flag)
+    // phase C: strict 8-neighbour NMS on a contiguous run of zone pixels per thread (row-major),
+    // kept-at-minTh / kept-at-iniTh bit masks, one block-wide OR and one block-wide scan.
+    const int RL = (nz + NT - 1) / NT; // the host picks NT so that RL <= 64 (one mask bit per pixel of the run)
+    unsigned long long keptMin = 0, keptIni = 0;
+    const int start = tid * RL;
     {
-        bool any = false;
-        for (int idx = tid; idx < nz; idx += 256) {
-            const int y = idx / zw + 3, x = idx - (idx / zw) * zw + 3;
-            const int pos = y * P + x;
+        int y = 0, x = 0;
+        if (start < nz) {
+            y = start / zw;
+            x = start - y * zw;
+        }
+        for (int k = 0; k < RL; k++) {
+            const int idx = start + k;
+            if (idx >= nz) break;
+            const int pos = (y + 3) * P + x + txLo;
             const int s = smap[pos];
-            if (s >= iniTh) {
+            if (s > 0) {
                 const bool keep = s > smap[pos - 1] && s > smap[pos + 1] && s > smap[pos - P - 1] && s > smap[pos - P] &&
                                   s > smap[pos - P + 1] && s > smap[pos + P - 1] && s > smap[pos + P] &&
                                   s > smap[pos + P + 1];
-                any |= keep;
+                if (keep) {
+                    if (s >= minTh) keptMin |= 1ull << k;
+                    if (s >= iniTh) keptIni |= 1ull << k;
+                }
+            }
+            if (++x == zw) {
+                x = 0;
+                y++;
             }
         }
-        if (__ballot(any) && lane == 0) anyIni = 1;
     }
+    const bool anyIni = __syncthreads_or(keptIni != 0ull) != 0;
+    unsigned long long sel = anyIni ? keptIni : keptMin;
+    const int cnt = __popcll(sel);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) waveTot[wave] = incl;
     __syncthreads();
-    const int th = anyIni ? iniTh : minTh;
-    // phase D: ordered (row-major) compaction of the kept pixels
+    int o = incl - cnt;
+    for (int w = 0; w < wave && w < NW; w++) o += waveTot[w];
     uint32_t* out = cand + (size_t)img * candImgStride + c.slotBase;
-    for (int base = 0; base < nz; base += 256) {
-        const int idx = base + tid;
-        bool keep = false;
-        uint32_t packed = 0;
-        if (idx < nz) {
-            const int y = idx / zw + 3, x = idx - (idx / zw) * zw + 3;
-            const int pos = y * P + x;
-            const int s = smap[pos];
-            if (s >= th && s > 0) {
-                keep = s > smap[pos - 1] && s > smap[pos + 1] && s > smap[pos - P - 1] && s > smap[pos - P] &&
-                       s > smap[pos - P + 1] && s > smap[pos + P - 1] && s > smap[pos + P] && s > smap[pos + P + 1];
-                packed = (uint32_t)(x + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((uint32_t)s << 24);
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) waveCnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = runBase;
-        for (int w = 0; w < wave; w++) off += waveCnt[w];
-        if (keep) {
-            const int o = off + __popcll(m & ((1ull << lane) - 1ull));
-            if (o < c.slotCap) out[o] = packed;
-        }
-        __syncthreads();
-        if (tid == 0) runBase += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
-        __syncthreads();
+    while (sel) {
+        const int k = __ffsll((long long)sel) - 1;
+        sel &= sel - 1;
+        const int idx = start + k;
+        const int y = idx / zw, x = idx - y * zw;
+        const int pos = (y + 3) * P + x + txLo;
+        if (o < c.slotCap)
+            out[o] = (uint32_t)(x + 3 + c.offX) | ((uint32_t)(y + 3 + c.offY) << 12) | ((uint32_t)smap[pos] << 24);
+        o++;
     }
-    if (tid == 0) cellCount[(size_t)img * nCellsTotal + cell] = min(runBase, c.slotCap);
+    if (tid == NT - 1) cellCount[(size_t)img * nCellsTotal + cell] = min(o, c.slotCap);
 }
 
 // ------------------------------------------------------------------- K-QT
@@ -808,20 +992,28 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch of radius 15.
     // items = (row, dword): rows 6..36, dwords 1..9 (columns 4..39 cover u = -15..15 = columns 6..36)
     int m10 = 0, m01 = 0;
-    for (int idx = lane; idx < 31 * 9; idx += 64) {
-        const int r = idx / 9, d = idx - r * 9;
-        const int v = r - 15;
-        const int um = c_umax[v < 0 ? -v : v];
-        const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (r + 6) * DESC_RAWP + 4 * (d + 1));
-        int rowsum = 0;
+    {
+        int r = lane / 9, d = lane - 9 * (lane / 9); // item = (r, d); +64 items = +7 rows +1 dword
+        for (int idx = lane; idx < 31 * 9; idx += 64) {
+            const int v = r - 15;
+            const int um = c_umax[v < 0 ? -v : v];
+            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (r + 6) * DESC_RAWP + 4 * (d + 1));
+            int rowsum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int u = 4 * (d + 1) + k - DESC_R;
-            const int I = (u >= -um && u <= um) ? (int)((px >> (8 * k)) & 0xFF) : 0;
-            rowsum += I;
-            m10 += u * I;
+            for (int k = 0; k < 4; k++) {
+                const int u = 4 * (d + 1) + k - DESC_R;
+                const int I = (u >= -um && u <= um) ? (int)((px >> (8 * k)) & 0xFF) : 0;
+                rowsum += I;
+                m10 += __mul24(u, I);
+            }
+            m01 += __mul24(v, rowsum);
+            r += 7;
+            d += 1;
+            if (d >= 9) {
+                d -= 9;
+                r += 1;
+            }
         }
-        m01 += v * rowsum;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -834,8 +1026,15 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
     const uint32_t TLO = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), THI = t4 | (t5 << 8) | (t6 << 16);
     // horizontal: item = (row r, group of 4 output columns); 43 x 10 items
+    int hr = lane / 10, hg = lane - 10 * (lane / 10); // item = (row, group); +64 items = +6 rows +4 groups
     for (int idx = lane; idx < DESC_RAW * 10; idx += 64) {
-        const int r = idx / 10, gq = idx - r * 10;
+        const int r = hr, gq = hg;
+        hr += 6;
+        hg += 4;
+        if (hg >= 10) {
+            hg -= 10;
+            hr += 1;
+        }
         const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DESC_RAWP + 4 * gq);
         const uint32_t d0 = s[0], d1 = s[1], d2 = s[2];
         uint32_t o0 = __builtin_amdgcn_udot4(d0, TLO, 0u, false);
@@ -857,18 +1056,27 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     WAVE_SYNC();
     // vertical: item = (row r, group of 4 columns); 37 x 10 items, written over the raw patch
+    hr = lane / 10;
+    hg = lane - 10 * (lane / 10);
     for (int idx = lane; idx < DESC_BW * 10; idx += 64) {
-        const int r = idx / 10, gq = idx - r * 10;
+        const int r = hr, gq = hg;
+        hr += 6;
+        hg += 4;
+        if (hg >= 10) {
+            hg -= 10;
+            hr += 1;
+        }
         const uint2* s = reinterpret_cast<const uint2*>(hp + r * DESC_HP + 4 * gq);
         uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const uint2 q = s[j * (DESC_HP / 4)];
             const uint32_t tj = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : j == 3 ? t3 : j == 4 ? t4 : j == 5 ? t5 : t6;
-            a0 += tj * (q.x & 0xFFFFu);
-            a1 += tj * (q.x >> 16);
-            a2 += tj * (q.y & 0xFFFFu);
-            a3 += tj * (q.y >> 16);
+            // operands < 2^24 (taps <= 255, H <= 65535): 24-bit multiply-add, full rate
+            a0 += __umul24(tj, q.x & 0xFFFFu);
+            a1 += __umul24(tj, q.x >> 16);
+            a2 += __umul24(tj, q.y & 0xFFFFu);
+            a3 += __umul24(tj, q.y >> 16);
         }
         const uint32_t b0 = min(a0 >> 16, 255u), b1 = min(a1 >> 16, 255u), b2 = min(a2 >> 16, 255u),
                        b3 = min(a3 >> 16, 255u);
