@@ -190,13 +190,19 @@ def main():
         abytes = algorithmic_bytes_per_frame(H, W, n_local / B)
         launch_bytes = abytes[dom] * B
         achieved = launch_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        # HBM bytes per launch from the rocprofv3 counter passes (tools/collect_profiles.sh, collected in
+        # separate --pmc runs and corrected with the FETCH_SIZE calibration), if they match this workload
         traffic = None
+        kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
+                     "desc": "k_orient_blur_desc<0>", "trigfix": "k_orient_blur_desc<1>"}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("batch") == B and j.get("rows") == H and j.get("cols") == W:
-                    traffic = j.get("hbm_bytes_per_launch", {}).get(dom)
+                if j.get("workload") == {"batch": B, "rows": H, "cols": W, "nfeatures": args.nfeatures}:
+                    for k, e in j.get("kernels", {}).items():
+                        if k.startswith(kernel_of[dom]) and "hbm_bytes_per_launch" in e:
+                            traffic = e["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         out = {
@@ -222,7 +228,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": dom,
+                "kernel": kernel_of[dom],
+                "stage": dom,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

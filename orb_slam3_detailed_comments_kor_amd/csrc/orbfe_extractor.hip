@@ -112,6 +112,7 @@ struct orbfe_ctx {
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
+    int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning)
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
@@ -517,11 +518,12 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     rec(c, 1);
     // K-FAST
     {
-        const dim3 grid((unsigned)c->nCells, (unsigned)nimg);
+        const int G = c->fastXcdGroup;
+        const dim3 grid((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)nimg); // whole groups per XCD
 #define ORBFE_FAST_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, s, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
                        c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows)
+                       c->minThFAST, c->fastPitch, c->fastRows, G)
         if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
         else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
         else ORBFE_FAST_LAUNCH(256);
@@ -619,6 +621,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     c->device = device;
     init_tables(c);
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
+    if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(1, atoi(e));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ORBFE_ERR_NODEV;

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
-                                                   int tileRows)
+                                                   int tileRows, int xcdGroup)
 {
     // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[(tileRows-6)*(P-6)] u16 -- sized by the
     // host from the largest cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
@@ -327,7 +327,17 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     constexpr int NW = NT / 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cell = blockIdx.x, img = blockIdx.y;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2);
+    // neighbouring cells share 128-B lines of the level rows (their ROIs overlap by 6 px), which
+    // should hit in ONE L2 instead of being fetched by several.
+    // Groups of `xcdGroup` consecutive cells (row neighbours) go to one XCD; the groups themselves
+    // stay round-robin so that every XCD sees cells from all over the image (a contiguous chunk per
+    // XCD cut the fetched bytes 3.6x but lost 25% to load imbalance: busy and flat regions are
+    // spatially correlated).
+    const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    const int cell = ((slot / xcdGroup) * 8 + xcd) * xcdGroup + slot % xcdGroup;
+    const int img = blockIdx.y;
+    if (cell >= nCellsTotal) return;
     const OrbCellGeom c = cg[cell];
     const OrbLevelGeom L = lg[c.level];
     const int cw = c.cw, ch = c.ch;
@@ -908,14 +918,37 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 __constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+// byte mask of the circular patch for IC_Angle: entry [|v|][d] covers patch columns 4(d+1) .. 4(d+1)+3
+// (u = column - 21); a byte is 0xFF when |u| <= umax[|v|].
+struct AngleMaskTab {
+    uint32_t m[16][9];
+};
+__host__ __device__ constexpr AngleMaskTab make_angle_masks()
+{
+    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    AngleMaskTab t = {};
+    for (int v = 0; v < 16; v++)
+        for (int d = 0; d < 9; d++) {
+            uint32_t m = 0;
+            for (int k = 0; k < 4; k++) {
+                const int u = 4 * (d + 1) + k - 21;
+                if (u >= -umax[v] && u <= umax[v]) m |= 0xFFu << (8 * k);
+            }
+            t.m[v][d] = m;
+        }
+    return t;
+}
+__constant__ AngleMaskTab c_angleMask = make_angle_masks();
+
 #define DESC_R 21    /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
 #define DESC_RAW 43  /* raw patch side */
 #define DESC_RAWP 44 /* raw pitch in bytes = 11 dwords */
 #define DESC_BW 37   /* blurred patch side */
-#define DESC_HP 40   /* pitch of the horizontal pass in u16 (80 B, 8-B aligned groups of 4) */
+#define DESC_HP 40   /* pitch of the horizontal pass: 40 dwords per PAIR of rows (row 2p in the low, 2p+1 in the high half) */
+#define DESC_HPAIRS 22 /* ceil(43/2) + 0: pair-rows 0..21 (row 43 is never used) */
 #define DESC_BP 40   /* pitch of the blurred patch in bytes */
-#define DESC_RAW_BYTES (DESC_RAW * DESC_RAWP + 20) /* + slack: the last column group reads 12 B */
-#define DESC_H_BYTES (DESC_RAW * DESC_HP * 2)
+#define DESC_RAW_BYTES (DESC_RAW * DESC_RAWP + 28) /* + slack (last column group reads 12 B); multiple of 16 */
+#define DESC_H_BYTES (DESC_HPAIRS * DESC_HP * 4)
 #define DESC_LDS_PER_WAVE (DESC_RAW_BYTES + DESC_H_BYTES) /* blurred patch aliases the raw patch */
 
 // One wavefront per keypoint.  Stages the 43x43 raw neighbourhood in LDS, computes the
@@ -968,17 +1001,33 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         // 473 dwords = 8 per lane, all loads in flight before the first LDS store; global dword
         // loads may be unaligned (the patch origin is arbitrary)
         uint32_t v[8];
+        const int r0 = lane / 11, c0 = lane - 11 * (lane / 11); // item = (row, dword); +64 items = +5 rows +9 dwords
+        {
+            int r = r0, c4 = c0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int idx = min(lane + 64 * k, DESC_RAW * 11 - 1);
-            const int r = idx / 11, c4 = idx - r * 11;
-            __builtin_memcpy(&v[k], p0 + (size_t)r * L.pitch + 4 * c4, 4);
+            for (int k = 0; k < 8; k++) {
+                const int rr = min(r, DESC_RAW - 1);
+                __builtin_memcpy(&v[k], p0 + (size_t)rr * L.pitch + 4 * c4, 4);
+                r += 5;
+                c4 += 9;
+                if (c4 >= 11) {
+                    c4 -= 11;
+                    r += 1;
+                }
+            }
         }
+        {
+            int r = r0, c4 = c0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int idx = lane + 64 * k;
-            const int r = idx / 11, c4 = idx - r * 11;
-            if (idx < DESC_RAW * 11) *reinterpret_cast<uint32_t*>(raw + r * DESC_RAWP + 4 * c4) = v[k];
+            for (int k = 0; k < 8; k++) {
+                if (r < DESC_RAW) *reinterpret_cast<uint32_t*>(raw + r * DESC_RAWP + 4 * c4) = v[k];
+                r += 5;
+                c4 += 9;
+                if (c4 >= 11) {
+                    c4 -= 11;
+                    r += 1;
+                }
+            }
         }
     } else { // BORDER_REFLECT_101 at the level edges (keypoints within 21 px of an edge)
         for (int idx = lane; idx < DESC_RAW * DESC_RAW; idx += 64) {
@@ -996,17 +1045,13 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         int r = lane / 9, d = lane - 9 * (lane / 9); // item = (r, d); +64 items = +7 rows +1 dword
         for (int idx = lane; idx < 31 * 9; idx += 64) {
             const int v = r - 15;
-            const int um = c_umax[v < 0 ? -v : v];
-            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (r + 6) * DESC_RAWP + 4 * (d + 1));
-            int rowsum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int u = 4 * (d + 1) + k - DESC_R;
-                const int I = (u >= -um && u <= um) ? (int)((px >> (8 * k)) & 0xFF) : 0;
-                rowsum += I;
-                m10 += __mul24(u, I);
-            }
-            m01 += __mul24(v, rowsum);
+            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (r + 6) * DESC_RAWP + 4 * (d + 1)) &
+                                c_angleMask.m[v < 0 ? -v : v][d];
+            // sum_k (u0 + k) * I_k = u0 * sum I_k + sum k * I_k  (two byte dot products)
+            const int S = (int)__builtin_amdgcn_udot4(px, 0x01010101u, 0u, false);
+            const int K = (int)__builtin_amdgcn_udot4(px, 0x03020100u, 0u, false);
+            m10 += __mul24(4 * (d + 1) - DESC_R, S) + K;
+            m01 += __mul24(v, S);
             r += 7;
             d += 1;
             if (d >= 9) {
@@ -1025,62 +1070,90 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
     const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
     const uint32_t TLO = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), THI = t4 | (t5 << 8) | (t6 << 16);
-    // horizontal: item = (row r, group of 4 output columns); 43 x 10 items
-    int hr = lane / 10, hg = lane - 10 * (lane / 10); // item = (row, group); +64 items = +6 rows +4 groups
-    for (int idx = lane; idx < DESC_RAW * 10; idx += 64) {
-        const int r = hr, gq = hg;
-        hr += 6;
-        hg += 4;
-        if (hg >= 10) {
-            hg -= 10;
-            hr += 1;
+    // horizontal: item = (pair of rows 2p, 2p+1; group of 4 output columns) -> 22 x 10 items; the two
+    // rows are packed as the low / high u16 of one dword so that the vertical pass can use
+    // v_dot2_u32_u16 on vertically adjacent values.
+    uint32_t* hp2 = reinterpret_cast<uint32_t*>(hp);
+    {
+        int pr = lane / 10, hg = lane - 10 * (lane / 10); // +64 items = +6 pair-rows +4 groups
+        for (int idx = lane; idx < DESC_HPAIRS * 10; idx += 64) {
+            const int ra = 2 * pr, rb = min(2 * pr + 1, DESC_RAW - 1);
+            const uint32_t* sa = reinterpret_cast<const uint32_t*>(raw + ra * DESC_RAWP + 4 * hg);
+            const uint32_t* sb = reinterpret_cast<const uint32_t*>(raw + rb * DESC_RAWP + 4 * hg);
+            const uint32_t a0 = sa[0], a1 = sa[1], a2 = sa[2];
+            const uint32_t b0 = sb[0], b1 = sb[1], b2 = sb[2];
+            uint4 o;
+#define ORBFE_HROW(d0, d1, d2, SH)                                                                       \
+    min(__builtin_amdgcn_udot4(SH == 0 ? d1 : __builtin_amdgcn_alignbyte(d2, d1, SH), THI,               \
+                               __builtin_amdgcn_udot4(SH == 0 ? d0 : __builtin_amdgcn_alignbyte(d1, d0, SH), TLO, \
+                                                      0u, false),                                        \
+                               false),                                                                   \
+        65535u) /* ufixedpoint16 saturating add (only reachable with non-default taps) */
+            o.x = ORBFE_HROW(a0, a1, a2, 0) | (ORBFE_HROW(b0, b1, b2, 0) << 16);
+            o.y = ORBFE_HROW(a0, a1, a2, 1) | (ORBFE_HROW(b0, b1, b2, 1) << 16);
+            o.z = ORBFE_HROW(a0, a1, a2, 2) | (ORBFE_HROW(b0, b1, b2, 2) << 16);
+            o.w = ORBFE_HROW(a0, a1, a2, 3) | (ORBFE_HROW(b0, b1, b2, 3) << 16);
+#undef ORBFE_HROW
+            *reinterpret_cast<uint4*>(hp2 + pr * DESC_HP + 4 * hg) = o;
+            pr += 6;
+            hg += 4;
+            if (hg >= 10) {
+                hg -= 10;
+                pr += 1;
+            }
         }
-        const uint32_t* s = reinterpret_cast<const uint32_t*>(raw + r * DESC_RAWP + 4 * gq);
-        const uint32_t d0 = s[0], d1 = s[1], d2 = s[2];
-        uint32_t o0 = __builtin_amdgcn_udot4(d0, TLO, 0u, false);
-        o0 = __builtin_amdgcn_udot4(d1, THI, o0, false);
-        uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), TLO, 0u, false);
-        o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), THI, o1, false);
-        uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), TLO, 0u, false);
-        o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), THI, o2, false);
-        uint32_t o3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), TLO, 0u, false);
-        o3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), THI, o3, false);
-        o0 = min(o0, 65535u); // ufixedpoint16 saturating add (only reachable with non-default taps)
-        o1 = min(o1, 65535u);
-        o2 = min(o2, 65535u);
-        o3 = min(o3, 65535u);
-        uint2 pk;
-        pk.x = o0 | (o1 << 16);
-        pk.y = o2 | (o3 << 16);
-        *reinterpret_cast<uint2*>(hp + r * DESC_HP + 4 * gq) = pk;
     }
     WAVE_SYNC();
-    // vertical: item = (row r, group of 4 columns); 37 x 10 items, written over the raw patch
-    hr = lane / 10;
-    hg = lane - 10 * (lane / 10);
-    for (int idx = lane; idx < DESC_BW * 10; idx += 64) {
-        const int r = hr, gq = hg;
-        hr += 6;
-        hg += 4;
-        if (hg >= 10) {
-            hg -= 10;
-            hr += 1;
+    // vertical: item = (row r, group of 4 columns); 37 x 10 items, written over the raw patch.
+    // Row r needs H rows r..r+6 = four row pairs; tap pairs depend on the parity of r.
+    {
+        typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+        union U2 {
+            uint32_t u;
+            us2 v;
+        };
+        U2 e0, e1, e2, e3, o0, o1, o2, o3; // even r: (t0,t1)(t2,t3)(t4,t5)(t6,0); odd r: (0,t0)(t1,t2)(t3,t4)(t5,t6)
+        e0.u = t0 | (t1 << 16);
+        e1.u = t2 | (t3 << 16);
+        e2.u = t4 | (t5 << 16);
+        e3.u = t6;
+        o0.u = t0 << 16;
+        o1.u = t1 | (t2 << 16);
+        o2.u = t3 | (t4 << 16);
+        o3.u = t5 | (t6 << 16);
+        int vr = lane / 10, hg = lane - 10 * (lane / 10);
+        for (int idx = lane; idx < DESC_BW * 10; idx += 64) {
+            const bool odd = vr & 1;
+            const uint4* sp4 = reinterpret_cast<const uint4*>(hp2 + (vr >> 1) * DESC_HP + 4 * hg);
+            const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
+            const us2 w0 = odd ? o0.v : e0.v, w1 = odd ? o1.v : e1.v, w2 = odd ? o2.v : e2.v, w3 = odd ? o3.v : e3.v;
+            uint32_t outp = 0;
+#define ORBFE_VCOL(F, SHIFT)                                                                           \
+    {                                                                                                   \
+        U2 q0, q1, q2, q3;                                                                              \
+        q0.u = p0.F;                                                                                    \
+        q1.u = p1.F;                                                                                    \
+        q2.u = p2.F;                                                                                    \
+        q3.u = p3.F;                                                                                    \
+        uint32_t acc = __builtin_amdgcn_udot2(q0.v, w0, 32768u, false);                                 \
+        acc = __builtin_amdgcn_udot2(q1.v, w1, acc, false);                                             \
+        acc = __builtin_amdgcn_udot2(q2.v, w2, acc, false);                                             \
+        acc = __builtin_amdgcn_udot2(q3.v, w3, acc, false);                                             \
+        outp |= min(acc >> 16, 255u) << SHIFT;                                                          \
+    }
+            ORBFE_VCOL(x, 0)
+            ORBFE_VCOL(y, 8)
+            ORBFE_VCOL(z, 16)
+            ORBFE_VCOL(w, 24)
+#undef ORBFE_VCOL
+            *reinterpret_cast<uint32_t*>(bl + vr * DESC_BP + 4 * hg) = outp;
+            vr += 6;
+            hg += 4;
+            if (hg >= 10) {
+                hg -= 10;
+                vr += 1;
+            }
         }
-        const uint2* s = reinterpret_cast<const uint2*>(hp + r * DESC_HP + 4 * gq);
-        uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const uint2 q = s[j * (DESC_HP / 4)];
-            const uint32_t tj = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : j == 3 ? t3 : j == 4 ? t4 : j == 5 ? t5 : t6;
-            // operands < 2^24 (taps <= 255, H <= 65535): 24-bit multiply-add, full rate
-            a0 += __umul24(tj, q.x & 0xFFFFu);
-            a1 += __umul24(tj, q.x >> 16);
-            a2 += __umul24(tj, q.y & 0xFFFFu);
-            a3 += __umul24(tj, q.y >> 16);
-        }
-        const uint32_t b0 = min(a0 >> 16, 255u), b1 = min(a1 >> 16, 255u), b2 = min(a2 >> 16, 255u),
-                       b3 = min(a3 >> 16, 255u);
-        *reinterpret_cast<uint32_t*>(bl + r * DESC_BP + 4 * gq) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     }
     WAVE_SYNC();
 
