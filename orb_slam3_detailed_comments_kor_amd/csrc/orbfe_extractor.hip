@@ -119,8 +119,9 @@ struct orbfe_ctx {
     DevBuf<uint8_t> d_pyr, d_desc, d_img;
     DevBuf<uint32_t> d_cand, d_keys, d_lvlKp;
     DevBuf<uint16_t> d_keyNode;
-    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono, d_misc /* [0]=err [1]=fixCount */, d_fixList;
-    DevBuf<float> d_kps, d_fixAB, d_fixAngle;
+    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono, d_misc /* [0]=err */;
+    DevBuf<int4> d_fix; // [0] = {count,0,0,0}, then one entry per flagged keypoint
+    DevBuf<float> d_kps;
     DevBuf<OrbDescWork> d_work;
     DevBuf<OrbLevelGeom> d_lg;
     DevBuf<OrbCellGeom> d_cg;
@@ -131,8 +132,8 @@ struct orbfe_ctx {
     bool pyrFused = true;
     DevBuf<int> d_taps;
     DevBuf<float4> d_patternF;
-    PinBuf<int32_t> h_misc, h_fixList, h_n, h_mono;
-    PinBuf<float> h_fixAngle, h_fixAB;
+    PinBuf<int32_t> h_misc, h_n, h_mono;
+    PinBuf<int4> h_fix, h_fixAB; // pinned: h_fixAB is read by the fix-up kernel directly (zero-copy)
     size_t imgPitch = 0, imgStride = 0;
 
     int lastImgs = 0;
@@ -456,14 +457,11 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_lvlCount.ensure(B * c->nlevels)) < 0) return r;
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
     if ((r = c->d_work.ensure(B * K)) < 0) return r;
-    if ((r = c->d_fixList.ensure(B * K * 2)) < 0) return r;
-    if ((r = c->d_fixAngle.ensure(B * K)) < 0) return r;
-    if ((r = c->d_fixAB.ensure(B * K * 2)) < 0) return r;
+    if ((r = c->d_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->d_misc.ensure(8)) < 0) return r;
     if ((r = c->h_misc.ensure(8)) < 0) return r;
-    if ((r = c->h_fixList.ensure(B * K * 2)) < 0) return r;
-    if ((r = c->h_fixAngle.ensure(B * K)) < 0) return r;
-    if ((r = c->h_fixAB.ensure(B * K * 2)) < 0) return r;
+    if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
+    if ((r = c->h_fixAB.ensure(B * K + 1)) < 0) return r;
     if ((r = c->d_taps.ensure(8)) < 0) return r;
     if (!c->d_patternF.p) {
         if ((r = c->d_patternF.ensure(256)) < 0) return r;
@@ -497,6 +495,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     const int nl = c->nlevels;
     HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 2 * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
     rec(c, 0);
     // K-PYR
     if (c->pyrFused) {
@@ -531,7 +530,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     }
     rec(c, 2);
     // K-QT
-    hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)nimg), dim3(1024), c->qtLdsBytes, s, c->d_lg.p, c->d_cg.p,
+    hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)nimg), dim3(QT_THREADS), c->qtLdsBytes, s, c->d_lg.p, c->d_cg.p,
                        c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p, c->d_keyNode.p,
                        c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p);
     rec(c, 3);
@@ -542,8 +541,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     // K-DESC
     hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)nimg), dim3(256), 0, s,
                        c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                       c->d_patternF.p, c->d_fixList.p, c->d_fixAngle.p, 0, c->d_misc.p + 1,
-                       c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0);
+                       c->d_patternF.p, c->d_fix.p, 0, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0);
     rec(c, 5);
     c->lastImgs = nimg;
     c->lastFixups = 0;
@@ -552,42 +550,41 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // sampling grid is within a rounding hair of changing.  Evaluate the host libm cosf/sinf
         // (what the reference calls, src/ORBextractor.cc:111) for those; where libm differs from the
         // correctly rounded value, re-run the descriptor on the device with libm's (a, b).
-        HIP_TRY(hipMemcpyAsync(c->h_misc.p, c->d_misc.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        // one D2H covers the error word, the count and the first 1023 entries (normally all of them)
+        const size_t total = (size_t)c->capImgs * c->capKp;
+        const size_t first = std::min<size_t>(1023, total);
+        HIP_TRY(hipMemcpyAsync(c->h_misc.p, c->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_fix.p, c->d_fix.p, (1 + first) * sizeof(int4), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (c->h_misc.p[0] != 0) return ORBFE_ERR_STATE;
-        const int nFrag = std::min<int>(c->h_misc.p[1], (int)((size_t)c->capImgs * c->capKp));
-        if (nFrag > 0) {
-            HIP_TRY(hipMemcpyAsync(c->h_fixList.p, c->d_fixList.p, (size_t)nFrag * 2 * sizeof(int32_t),
-                                   hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(c->h_fixAngle.p, c->d_fixAngle.p, (size_t)nFrag * sizeof(float),
+        const size_t nFrag = std::min<size_t>((size_t)c->h_fix.p[0].x, total);
+        if (nFrag > first) {
+            HIP_TRY(hipMemcpyAsync(c->h_fix.p + 1 + first, c->d_fix.p + 1 + first, (nFrag - first) * sizeof(int4),
                                    hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            const float factorPI = (float)(3.14159265358979323846 / 180.f);
-            int nFix = 0;
-            for (int i = 0; i < nFrag; i++) {
-                const float ang = c->h_fixAngle.p[i] * factorPI;
-                const float a = cosf(ang), b = sinf(ang);
-                float bc, ac;
-                orbfe_sincos_cr(ang, &bc, &ac);
-                if (a != ac || b != bc) {
-                    c->h_fixList.p[2 * nFix] = c->h_fixList.p[2 * i];
-                    c->h_fixList.p[2 * nFix + 1] = c->h_fixList.p[2 * i + 1];
-                    c->h_fixAB.p[2 * nFix] = a;
-                    c->h_fixAB.p[2 * nFix + 1] = b;
-                    nFix++;
-                }
-            }
-            if (nFix > 0) {
-                HIP_TRY(hipMemcpyAsync(c->d_fixList.p, c->h_fixList.p, (size_t)nFix * 2 * sizeof(int32_t),
-                                       hipMemcpyHostToDevice, s));
-                HIP_TRY(hipMemcpyAsync(c->d_fixAB.p, c->h_fixAB.p, (size_t)nFix * 2 * sizeof(float),
-                                       hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
-                                   c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                                   c->d_patternF.p, c->d_fixList.p, c->d_fixAB.p, nFix, c->d_misc.p + 1, 0);
-            }
-            c->lastFixups = nFix;
         }
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        int nFix = 0;
+        for (size_t i = 0; i < nFrag; i++) {
+            const int4 e = c->h_fix.p[1 + i];
+            float angDeg;
+            std::memcpy(&angDeg, &e.z, 4);
+            const float ang = angDeg * factorPI;
+            const float a = cosf(ang), b = sinf(ang);
+            float bc, ac;
+            orbfe_sincos_cr(ang, &bc, &ac);
+            if (a != ac || b != bc) {
+                int4 o = e;
+                std::memcpy(&o.z, &a, 4);
+                std::memcpy(&o.w, &b, 4);
+                c->h_fixAB.p[nFix++] = o;
+            }
+        }
+        if (nFix > 0) // the kernel reads the pinned list in place
+            hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
+                               c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0);
+        c->lastFixups = nFix;
     }
     rec(c, 6);
     if (c->profile && c->evReady) c->profCalls++;
@@ -639,11 +636,10 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_pyr.release(); c->d_desc.release(); c->d_img.release();
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
-    c->d_misc.release(); c->d_fixList.release(); c->d_kps.release(); c->d_fixAB.release(); c->d_fixAngle.release();
+    c->d_misc.release(); c->d_fix.release(); c->d_kps.release();
     c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
     c->d_taps.release(); c->d_patternF.release();
-    c->h_misc.release(); c->h_fixList.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAngle.release();
-    c->h_fixAB.release();
+    c->h_misc.release(); c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release();
     if (c->evReady)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);

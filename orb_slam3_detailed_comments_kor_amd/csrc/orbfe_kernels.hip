@@ -470,7 +470,9 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 }
 
 // ------------------------------------------------------------------- K-QT
-#define QT_THREADS 1024
+#ifndef QT_THREADS
+#define QT_THREADS 512 /* measured: 1024 -> 85 us, 512 -> 61 us, 256 -> 79 us (64 x 752x480) */
+#endif
 #define QT_WAVES (QT_THREADS / WAVE)
 
 // exclusive scan of a[0..n) in LDS, in place; returns the total to every thread.
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     int* kOf = A + 6 * LC;       // list position -> expansion index k (or -1)
     int* sidx = A + 7 * LC;      // list position -> #expanded nodes before it
     int* cc = A + 8 * LC;        // [4*LC] child key counts, index 4k+q
-    int* cpos = A + 12 * LC;     // [4*LC] child list positions, index (nE-1-k)*4+(3-q)
-    int* mpos = A + 16 * LC;     // [4*LC] multi-key child -> index in the new candidate list
+    int* cpos = A + 12 * LC;     // [4*LC] child list positions, index 4k+q
+    int* mpos = A + 16 * LC;     // [4*LC] packed scan: multi-key children (low 16) | non-empty children (high 16)
     int* multi[2] = {A + 20 * LC, A + 21 * LC}; // candidate list (list positions), creation order
     int* par = A + 22 * LC;      // expansion index k -> parent list position
     int* gpre = A + 23 * LC;     // growth prefix (final phase) / scratch
@@ -639,14 +641,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             }
             __syncthreads();
         }
-        for (int i = tid; i < 4 * nE; i += QT_THREADS) {
-            const int k = i >> 2, q = i & 3;
-            cpos[(nE - 1 - k) * 4 + (3 - q)] = cc[i] > 0 ? 1 : 0; // push_front order: n4,n3,n2,n1 of the last parent first
-            mpos[i] = cc[i] > 1 ? 1 : 0;
-        }
+        // One packed scan over i = 4k+q: low half counts multi-key children (creation order), high
+        // half counts non-empty children.  Children are push_front'ed, so their list order is the
+        // REVERSE of i (n4,n3,n2,n1 of the last parent first): position = nChildren - 1 - (#non-empty before i).
+        for (int i = tid; i < 4 * nE; i += QT_THREADS) mpos[i] = (cc[i] > 1 ? 1 : 0) | (cc[i] > 0 ? 0x10000 : 0);
         __syncthreads();
-        const int nChildren = qt_scan(cpos, 4 * nE, wsum);
-        const int nMulti = qt_scan(mpos, 4 * nE, wsum);
+        const int tot = qt_scan(mpos, 4 * nE, wsum);
+        const int nChildren = tot >> 16, nMulti = tot & 0xFFFF;
         const int nb = cur ^ 1;
         const int newSize = nChildren + (size - nE);
         if (newSize > LC) { // cannot happen; never write out of bounds
@@ -658,16 +659,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             const int k = i >> 2, q = i & 3;
             const int cnt = cc[i];
             if (cnt > 0) {
-                const int pos = cpos[(nE - 1 - k) * 4 + (3 - q)];
+                const int pos = nChildren - 1 - (mpos[i] >> 16);
+                cpos[i] = pos;
                 const int p = par[k];
                 int cul, cbr;
                 qt_child(ul[p], br[p], q, cul, cbr);
                 nodeUL[nb][pos] = cul;
                 nodeBR[nb][pos] = cbr;
                 nodeCnt[nb][pos] = cnt;
-                if (cnt > 1) multi[nb][mpos[i]] = pos;
+                if (cnt > 1) multi[nb][mpos[i] & 0xFFFF] = pos;
             }
         }
+        __syncthreads();
         for (int p = tid; p < size; p += QT_THREADS) {
             const int k = kOf[p];
             if (!(k >= 0 && k < nE)) {
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             if (k >= 0 && k < nE) {
                 const uint32_t key = keys[i];
                 const int q = qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
-                np = cpos[(nE - 1 - k) * 4 + (3 - q)];
+                np = cpos[4 * k + q];
             } else {
                 np = nChildren + p - sidx[p];
             }
@@ -970,9 +973,10 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           float* __restrict__ kpsOut, uint8_t* __restrict__ descOut,
                                                           const int* __restrict__ taps,
                                                           const float4* __restrict__ patternF,
-                                                          int32_t* fixList /* (img, g) pairs */,
-                                                          float* fixF /* MODE 0: out angle; MODE 1: in (a, b) */,
-                                                          int nFix, int32_t* fixCount, int listFragile)
+                                                          int4* fixList /* MODE 0: out {img, g, angle bits, 0} after
+                                                                           a 16-B header whose first word is the
+                                                                           count; MODE 1: in {img, g, a bits, b bits} */,
+                                                          int nFix, int listFragile)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -984,8 +988,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     } else {
         const int f = blockIdx.x * 4 + wave;
         if (f >= nFix) return;
-        img = fixList[2 * f];
-        g = fixList[2 * f + 1];
+        img = fixList[f].x;
+        g = fixList[f].y;
     }
     const OrbDescWork w = work[(size_t)img * capPerImg + g];
     const OrbLevelGeom L = lg[w.level];
@@ -1164,8 +1168,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         orbfe_sincos_cr(__fmul_rn(angle, factorPI), &b, &a);
     } else {
         const int f = blockIdx.x * 4 + wave;
-        a = fixF[2 * f];
-        b = fixF[2 * f + 1];
+        a = __int_as_float(fixList[f].z);
+        b = __int_as_float(fixList[f].w);
     }
     const uint8_t* center = bl + 18 * DESC_BP + 18;
     unsigned long long word[4];
@@ -1201,10 +1205,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         if (lane == 0) {
             kpsOut[slot * 7 + 3] = angle;
             if (anyFrag && listFragile) {
-                const int idx = atomicAdd(fixCount, 1);
-                fixList[2 * idx] = img;
-                fixList[2 * idx + 1] = g;
-                fixF[idx] = angle;
+                const int idx = atomicAdd(reinterpret_cast<int*>(fixList), 1);
+                fixList[1 + idx] = make_int4(img, g, __float_as_int(angle), 0);
             }
         }
     }
