@@ -113,6 +113,7 @@ struct orbfe_ctx {
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
     int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning)
+    int fastDbgStop = 0;         // ORBFE_FAST_STOP env: phase ablation for profiling only (results invalid)
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
@@ -229,7 +230,19 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
                 g.ch = (int16_t)((int)maxY - (int)iniY);
                 g.offX = (int16_t)(j * L.wCell);
                 g.offY = (int16_t)(i * L.hCell);
-                g.pad = 0;
+                {
+                    const int ox = g.iniX & 3;
+                    const int nd = (g.cw + ox + 3) >> 2;
+                    const int txLo = 3 + ox, txHi = g.cw - 4 + ox;
+                    const int ndz = std::max((txHi >> 2) - (txLo >> 2) + 1, 1);
+                    const int zw1 = std::max(g.cw - 6, 1);
+                    g.nd = (int16_t)nd;
+                    auto recip = [](int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / (uint64_t)d); };
+                    g.mNd = recip(nd);
+                    g.mNdz = recip(ndz);
+                    g.mZw = recip(zw1);
+                    g.pad2 = 0;
+                }
                 if (g.cw > ORBFE_FAST_TILE - 1 || g.ch > ORBFE_FAST_TILE - 1) return ORBFE_ERR_ARGS;
                 const int zw = std::max(g.cw - 6, 0), zh = std::max(g.ch - 6, 0);
                 g.slotBase = slot;
@@ -522,7 +535,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
 #define ORBFE_FAST_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, s, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
                        c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows, G)
+                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop)
         if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
         else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
         else ORBFE_FAST_LAUNCH(256);
@@ -619,6 +632,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     init_tables(c);
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(1, atoi(e));
+    if (const char* e = getenv("ORBFE_FAST_STOP")) c->fastDbgStop = atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ORBFE_ERR_NODEV;

@@ -43,9 +43,12 @@ struct OrbCellGeom {
     int16_t iniX, iniY; /* ROI origin in level coordinates        */
     int16_t cw, ch;     /* ROI size (maxX-iniX, maxY-iniY)        */
     int16_t offX, offY; /* j*wCell, i*hCell (added to keypoints)  */
-    int16_t pad;
+    int16_t nd;         /* dwords per staged tile row: (cw + (iniX&3) + 3) / 4 */
     int32_t slotBase;   /* first candidate slot of this cell      */
     int32_t slotCap;    /* ceil(zw/2)*ceil(zh/2): max strict 8-neighbour local maxima */
+    /* ceil(2^32/d) reciprocals (0 encodes d == 1): x/d == umulhi(x, m) while x*d < 2^32 */
+    uint32_t mNd, mNdz, mZw;
+    uint32_t pad2;
 };
 
 /* resize tables: per destination column / row */

@@ -298,6 +298,9 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
     return max(bright, -darkNeg) - 1;
 }
 
+// x / d with a host-made reciprocal m = ceil(2^32 / d) (m == 0 encodes d == 1): exact while x*d < 2^32.
+__device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (int)__umulhi(x, m) : (int)x; }
+
 // One workgroup per FAST cell (reference: one cv::FAST call per cell, plus a second call with
 // minThFAST when the first finds nothing).  A single score map serves both thresholds:
 // corner_at(t) <=> score >= t, and the strict 8-neighbour NMS is threshold independent
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
-                                                   int tileRows, int xcdGroup)
+                                                   int tileRows, int xcdGroup, int dbgStop)
 {
     // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[(tileRows-6)*(P-6)] u16 -- sized by the
     // host from the largest cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
@@ -344,17 +347,19 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     const int ox = c.iniX & 3; // tile x = roi x + ox
     const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff + (size_t)c.iniY * L.pitch + (c.iniX - ox);
     const int tmin = min(iniTh, minTh);
-    const int nd = (cw + ox + 3) >> 2; // dwords per tile row
+    const int nd = c.nd; // dwords per tile row
 
     if (tid == 0) qn = 0;
-    // stage the ROI, clear the score map
-    for (int idx = tid; idx < ch * PD; idx += NT) {
-        const int y = idx / PD, d = idx - y * PD;
-        reinterpret_cast<uint32_t*>(smap)[idx] = 0u;
-        if (d < nd) reinterpret_cast<uint32_t*>(tile)[idx] = *reinterpret_cast<const uint32_t*>(roi + (size_t)y * L.pitch + 4 * d);
+    // stage the ROI (rows x nd dwords), clear the score map; divisions by per-cell constants use
+    // host-made reciprocals (fast_div)
+    for (int idx = tid; idx < ch * nd; idx += NT) {
+        const int y = fast_div((unsigned)idx, c.mNd), d = idx - y * nd;
+        reinterpret_cast<uint32_t*>(smap)[y * PD + d] = 0u;
+        reinterpret_cast<uint32_t*>(tile)[y * PD + d] = *reinterpret_cast<const uint32_t*>(roi + (size_t)y * L.pitch + 4 * d);
     }
     __syncthreads();
 
+    if (dbgStop == 1) return;
     const int zw = cw - 6, zh = ch - 6; // detection zone
     const int nz = (zw > 0 && zh > 0) ? zw * zh : 0;
     const int txLo = 3 + ox, txHi = cw - 4 + ox; // zone columns in tile coordinates (inclusive)
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
             unsigned passBits = 0;
             int y = 0, d = 0;
             if (idx < nItems) {
-                y = idx / ndz;
+                y = fast_div((unsigned)idx, c.mNdz);
                 d = idx - y * ndz + d0;
                 y += 3;
                 const uint32_t C = T[y * PD + d], Lf = T[y * PD + d - 1], R = T[y * PD + d + 1];
@@ -403,44 +408,80 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         }
     }
     __syncthreads();
-    // phase B: exact score for the survivors (all lanes busy)
+    if (dbgStop == 2) return;
+    // phase B: exact score for the survivors (all lanes busy); real corners (score >= tmin) are
+    // recorded in a second queue (it overwrites the first one from the front: entry qi is consumed
+    // before any corner index <= qi can be written, because cn never exceeds the number consumed)
     const int nq = qn;
-    for (int qi = tid; qi < nq; qi += NT) {
-        const int pos = queue[qi];
-        const int s = fast_score(&tile[pos], P);
-        if (s >= tmin) smap[pos] = (uint8_t)s;
+    __syncthreads();
+    if (tid == 0) qn = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += NT) {
+        const int qi = base + tid;
+        int pos = 0, sc = 0;
+        if (qi < nq) {
+            pos = queue[qi];
+            sc = fast_score(&tile[pos], P);
+            if (sc >= tmin) smap[pos] = (uint8_t)sc;
+        }
+        __syncthreads(); // every entry of this round has been read
+        const bool isc = qi < nq && sc >= tmin;
+        const unsigned long long m = __ballot(isc);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&qn, __popcll(m));
+            wbase = __shfl(wbase, 0);
+            if (isc) queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+        }
     }
     __syncthreads();
-    // phase C: strict 8-neighbour NMS on a contiguous run of zone pixels per thread (row-major),
-    // kept-at-minTh / kept-at-iniTh bit masks, one block-wide OR and one block-wide scan.
+    if (dbgStop == 3) return;
+    // phase C1: strict 8-neighbour NMS of the corners only (all 8 reads issued together), decisions
+    // in registers; C2: losers are cleared, so the score map afterwards holds exactly the kept pixels
+    const int nc = qn;
+    {
+        unsigned long long loser = 0; // bit r: the corner this thread handled in round r lost (<= 38 rounds)
+        int r = 0;
+        for (int qi = tid; qi < nc; qi += NT, r++) {
+            const int pos = queue[qi];
+            const int s0 = smap[pos];
+            const int n0 = smap[pos - 1], n1 = smap[pos + 1], n2 = smap[pos - P - 1], n3 = smap[pos - P],
+                      n4 = smap[pos - P + 1], n5 = smap[pos + P - 1], n6 = smap[pos + P], n7 = smap[pos + P + 1];
+            const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+            if (!(s0 > mx)) loser |= 1ull << r;
+        }
+        __syncthreads(); // every comparison was made on the untouched map
+        r = 0;
+        for (int qi = tid; qi < nc; qi += NT, r++)
+            if ((loser >> r) & 1ull) smap[queue[qi]] = 0;
+    }
+    __syncthreads();
+    // phase C3: ordered pass over a contiguous run of zone pixels per thread (row-major): a non-zero
+    // score is a kept pixel; kept-at-minTh / kept-at-iniTh bit masks, one block-wide OR and one scan.
     const int RL = (nz + NT - 1) / NT; // the host picks NT so that RL <= 64 (one mask bit per pixel of the run)
     unsigned long long keptMin = 0, keptIni = 0;
     const int start = tid * RL;
     {
         int y = 0, x = 0;
         if (start < nz) {
-            y = start / zw;
+            y = fast_div((unsigned)start, c.mZw);
             x = start - y * zw;
         }
         for (int k = 0; k < RL; k++) {
             const int idx = start + k;
             if (idx >= nz) break;
-            const int pos = (y + 3) * P + x + txLo;
-            const int s = smap[pos];
-            if (s > 0) {
-                const bool keep = s > smap[pos - 1] && s > smap[pos + 1] && s > smap[pos - P - 1] && s > smap[pos - P] &&
-                                  s > smap[pos - P + 1] && s > smap[pos + P - 1] && s > smap[pos + P] &&
-                                  s > smap[pos + P + 1];
-                if (keep) {
-                    if (s >= minTh) keptMin |= 1ull << k;
-                    if (s >= iniTh) keptIni |= 1ull << k;
-                }
-            }
+            const int s = smap[(y + 3) * P + x + txLo];
+            if (s > 0 && s >= minTh) keptMin |= 1ull << k;
+            if (s > 0 && s >= iniTh) keptIni |= 1ull << k;
             if (++x == zw) {
                 x = 0;
                 y++;
             }
         }
+    }
+    if (dbgStop == 4) {
+        if (keptMin == 0x123456789ull) cellCount[0] = (int)keptIni;
+        return;
     }
     const bool anyIni = __syncthreads_or(keptIni != 0ull) != 0;
     unsigned long long sel = anyIni ? keptIni : keptMin;
@@ -460,7 +501,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         const int k = __ffsll((long long)sel) - 1;
         sel &= sel - 1;
         const int idx = start + k;
-        const int y = idx / zw, x = idx - y * zw;
+        const int y = fast_div((unsigned)idx, c.mZw), x = idx - y * zw;
         const int pos = (y + 3) * P + x + txLo;
         if (o < c.slotCap)
             out[o] = (uint32_t)(x + 3 + c.offX) | ((uint32_t)(y + 3 + c.offY) << 12) | ((uint32_t)smap[pos] << 24);
