@@ -146,6 +146,10 @@ typedef struct {
 /* variant 0: match[n2] = index into set 1 (the KeyFrame) or -1; variant 1: match[n1] = index into set 2 or -1.
  * Returns nmatches. */
 int orbfe_search_bow(int device, const orbfe_bow_args*, int32_t* match);
+/* `count` independent SearchByBoW problems (relocalisation candidates, src/Tracking.cc:3784; covisible
+ * keyframes of a loop candidate, src/LoopClosing.cc:725) in ONE upload / launch / download.
+ * match[p] sized like the single call's output; nmatches[p] per problem.  Returns 0 or an error. */
+int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, int32_t* const* match, int* nmatches);
 
 typedef struct {
     const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1_xy; const float* angle1;
@@ -162,6 +166,9 @@ int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 *
 
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
+
+/* Device time (ms, hipEvents) of the matcher kernel launched by the last matcher call of this thread. */
+float orbfe_matcher_last_kernel_ms(void);
 
 const char* orbfe_version(void);
 

@@ -110,7 +110,9 @@ def lib():
         L.orbfe_bfknn2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orbfe_search_bow.argtypes = [C.c_int, C.POINTER(_BowArgs), C.c_void_p]
         L.orbfe_search_tri.argtypes = [C.c_int, C.POINTER(_TriArgs), C.c_void_p]
+        L.orbfe_search_bow_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_BowArgs), C.POINTER(C.c_void_p), C.c_void_p]
         L.orbfe_kb8_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbfe_matcher_last_kernel_ms.restype = C.c_float
         _LIB = L
     return _LIB
 
@@ -120,7 +122,8 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
-           "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_kb8_unproject"]
+           "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
+           "orbfe_matcher_last_kernel_ms"]
 
 
 def _p(a):
@@ -285,6 +288,10 @@ def _fv(fv):
     return s, (node_ids, offsets, indices)
 
 
+def matcher_last_kernel_ms():
+    return float(lib().orbfe_matcher_last_kernel_ms())
+
+
 def hamming_pairs(A, B, device=0):
     """ORBmatcher::DescriptorDistance over all pairs (src/ORBmatcher.cc:2591-2607)."""
     A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32)
@@ -320,6 +327,39 @@ def search_bow(desc1, mask1, ang1, fv1, desc2, mask2, ang2, fv2, variant, nnrati
     match = np.zeros(len(d2) if variant == 0 else len(d1), np.int32)
     n = _chk(lib().orbfe_search_bow(device, C.byref(args), _p(match)), "orbfe_search_bow")
     return n, match
+
+
+def _bow_args(desc1, mask1, ang1, fv1, desc2, mask2, ang2, fv2, variant, nnratio, check_ori, Nleft, limit1, limit2):
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    m1 = np.ascontiguousarray(mask1, np.uint8)
+    m2 = np.ascontiguousarray(mask2 if mask2 is not None else np.ones(len(d2)), np.uint8)
+    a1 = np.ascontiguousarray(ang1, np.float32)
+    a2 = np.ascontiguousarray(ang2, np.float32)
+    f1, k1 = _fv(fv1)
+    f2, k2 = _fv(fv2)
+    args = _BowArgs(d1.ctypes.data, len(d1), m1.ctypes.data, a1.ctypes.data, f1, limit1, d2.ctypes.data, len(d2),
+                    m2.ctypes.data, a2.ctypes.data, f2, limit2, Nleft, nnratio, int(check_ori), variant)
+    return args, (d1, d2, m1, m2, a1, a2, k1, k2), (len(d2) if variant == 0 else len(d1))
+
+
+def search_bow_batch(problems, device=0):
+    """problems: list of dicts with the keyword arguments of search_bow(); one launch for all of them.
+    Returns [(nmatches, match), ...]."""
+    n = len(problems)
+    arr = (_BowArgs * n)()
+    keep, outs = [], []
+    for i, pr in enumerate(problems):
+        a, k, nout = _bow_args(pr["desc1"], pr["mask1"], pr["ang1"], pr["fv1"], pr["desc2"], pr.get("mask2"),
+                               pr["ang2"], pr["fv2"], pr["variant"], pr["nnratio"], pr.get("check_ori", True),
+                               pr.get("Nleft", -1), pr.get("limit1", -1), pr.get("limit2", -1))
+        arr[i] = a
+        keep.append(k)
+        outs.append(np.zeros(nout, np.int32))
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    nm = np.zeros(n, np.int32)
+    _chk(lib().orbfe_search_bow_batch(device, n, arr, ptrs, _p(nm)), "orbfe_search_bow_batch")
+    return [(int(nm[i]), outs[i]) for i in range(n)]
 
 
 def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasMP2, kp2xy, ang2, oct2, uR2, fv2, F12,

@@ -142,7 +142,14 @@ __global__ __launch_bounds__(256) void k_bfknn2(const uint8_t* __restrict__ Q, i
 
 // ------------------------------------------------------------------- K-BOW
 struct BowNode {
-    int off1, n1, off2, n2; // ranges in the CSR index arrays of set 1 / set 2
+    int off1, n1, off2, n2; // ranges in the (pooled) CSR index arrays of set 1 / set 2
+    int prob;               // problem this node belongs to
+};
+// One (set 1, set 2) matching problem of a batch; *Base are row offsets into the pooled arrays.
+struct BowProb {
+    int d1Base, d2Base, outBase;
+    int limit1, limit2, Nleft, variant;
+    float nnratio;
 };
 
 __device__ __forceinline__ int rot_bin(float a1, float a2)
@@ -161,19 +168,32 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
 // row are spread over the lanes.  variant 0: (KeyFrame*,Frame&), match2[idx2] = idx1;
 // variant 1: (KeyFrame*,KeyFrame*), match1[idx1] = idx2.  bins[] gets the rotation bin per match.
 __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ nodes, int nNodes,
-                                                    const uint8_t* __restrict__ desc1,
-                                                    const uint8_t* __restrict__ mask1, const float* __restrict__ ang1,
-                                                    const int32_t* __restrict__ ind1, int limit1,
-                                                    const uint8_t* __restrict__ desc2,
-                                                    const uint8_t* __restrict__ mask2, const float* __restrict__ ang2,
-                                                    const int32_t* __restrict__ ind2, int limit2, int Nleft,
-                                                    float nnratio, int variant, int32_t* __restrict__ match,
-                                                    int8_t* __restrict__ bins, uint8_t* __restrict__ taken2)
+                                                    const BowProb* __restrict__ probs,
+                                                    const uint8_t* __restrict__ descPool,
+                                                    const uint8_t* __restrict__ maskPool,
+                                                    const float* __restrict__ angPool,
+                                                    const int32_t* __restrict__ indPool,
+                                                    int32_t* __restrict__ matchPool, int8_t* __restrict__ binsPool,
+                                                    uint8_t* __restrict__ takenPool)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nd = blockIdx.x * 4 + wave;
     if (nd >= nNodes) return;
     const BowNode N = nodes[nd];
+    const BowProb Pb = probs[N.prob];
+    const uint8_t* desc1 = descPool + (size_t)Pb.d1Base * 32;
+    const uint8_t* desc2 = descPool + (size_t)Pb.d2Base * 32;
+    const uint8_t* mask1 = maskPool + Pb.d1Base;
+    const uint8_t* mask2 = maskPool + Pb.d2Base;
+    const float* ang1 = angPool + Pb.d1Base;
+    const float* ang2 = angPool + Pb.d2Base;
+    const int32_t* ind1 = indPool; // node offsets are already pooled
+    const int32_t* ind2 = indPool;
+    int32_t* match = matchPool + Pb.outBase;
+    int8_t* bins = binsPool + Pb.outBase;
+    uint8_t* taken2 = takenPool + Pb.d2Base;
+    const int limit1 = Pb.limit1, limit2 = Pb.limit2, Nleft = Pb.Nleft, variant = Pb.variant;
+    const float nnratio = Pb.nnratio;
     // "already matched" state of this node's set-2 features: only this wave touches them, so the
     // first 4096 candidates live in one register bit per (lane, step); the rest go through taken2[].
     unsigned long long takenMask = 0ull;
@@ -354,26 +374,83 @@ __global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__
 }
 
 // ------------------------------------------------------------- host helpers
-struct Scratch { // device allocations freed on scope exit
-    std::vector<void*> ptrs;
+// Per-thread, per-device arena: matcher calls are tiny (tens of KB), so hipMalloc/hipFree per call
+// would cost more than the kernels.  The arena is a bump allocator over one persistent device
+// buffer; a call that outgrows it falls back to hipMalloc for the overflow and the arena is
+// enlarged before the next call.
+struct Arena {
+    int device = -1;
+    uint8_t* base = nullptr;
+    size_t cap = 0, off = 0, want = 0;
+};
+thread_local Arena g_arena[16];
+
+struct Scratch { // device allocations of one call
+    Arena* ar = nullptr;
+    std::vector<void*> overflow;
+    explicit Scratch(int device)
+    {
+        ar = &g_arena[device & 15];
+        if (ar->want > ar->cap) { // grow between calls
+            if (ar->base) (void)hipFree(ar->base);
+            ar->base = nullptr;
+            ar->cap = 0;
+            void* p = nullptr;
+            const size_t want = std::max<size_t>(ar->want * 2, 1 << 20);
+            if (hipMalloc(&p, want) == hipSuccess) {
+                ar->base = (uint8_t*)p;
+                ar->cap = want;
+            }
+        }
+        ar->off = 0;
+        ar->want = 0;
+    }
     ~Scratch()
     {
-        for (void* p : ptrs) (void)hipFree(p);
+        for (void* p : overflow) (void)hipFree(p);
     }
     template <class T>
     int up(T** out, const T* host, size_t n)
     {
         *out = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) return -(1000 + (int)e);
-        ptrs.push_back(p);
+        ar->want += bytes;
+        if (ar->base && ar->off + bytes <= ar->cap) {
+            p = ar->base + ar->off;
+            ar->off += bytes;
+        } else {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return -(1000 + (int)e);
+            overflow.push_back(p);
+        }
         if (host && n) {
-            e = hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, 0);
             if (e != hipSuccess) return -(1000 + (int)e);
         }
         *out = (T*)p;
         return 0;
+    }
+};
+
+// device time of the last matcher kernel launched by this thread (hipEvents around the launch)
+thread_local float g_lastKernelMs = -1.f;
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer()
+    {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, 0);
+    }
+    ~KernelTimer()
+    {
+        (void)hipEventRecord(b, 0);
+        (void)hipEventSynchronize(b);
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess) g_lastKernelMs = ms;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
     }
 };
 
@@ -474,14 +551,17 @@ int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, 
     if (nA == 0 || nB == 0) return 0;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    Scratch s;
+    Scratch s(device);
     uint8_t *dA, *dB;
     uint16_t* dD;
     if ((r = s.up(&dA, A, (size_t)nA * 32)) < 0) return r;
     if ((r = s.up(&dB, B, (size_t)nB * 32)) < 0) return r;
     if ((r = s.up<uint16_t>(&dD, nullptr, (size_t)nA * nB)) < 0) return r;
+    {
+        KernelTimer timer;
     hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, 0, dA,
                        nA, dB, nB, dD);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(D, dD, (size_t)nA * nB * sizeof(uint16_t), hipMemcpyDeviceToHost));
     return 0;
@@ -493,74 +573,132 @@ int orbfe_bfknn2(int device, const uint8_t* Q, int nQ, const uint8_t* T, int nT,
     if (nQ == 0) return 0;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    Scratch s;
+    Scratch s(device);
     uint8_t *dQ, *dT;
     int32_t *dI, *dD;
     if ((r = s.up(&dQ, Q, (size_t)nQ * 32)) < 0) return r;
     if ((r = s.up(&dT, T, (size_t)nT * 32)) < 0) return r;
     if ((r = s.up<int32_t>(&dI, nullptr, (size_t)nQ * 2)) < 0) return r;
     if ((r = s.up<int32_t>(&dD, nullptr, (size_t)nQ * 2)) < 0) return r;
+    {
+        KernelTimer timer;
     hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, 0, dQ, nQ, dT, nT, dI, dD);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(idx, dI, (size_t)nQ * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dist, dD, (size_t)nQ * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
-int orbfe_search_bow(int device, const orbfe_bow_args* a, int32_t* match)
+// Batched SearchByBoW: `count` independent (set 1, set 2) problems -- e.g. the relocalisation
+// candidates of Tracking::Relocalization (src/Tracking.cc:3784, one call per candidate KF) or the
+// covisible keyframes of LoopClosing (src/LoopClosing.cc:725) -- pooled into ONE upload, ONE launch
+// (one wavefront per shared vocabulary node of any problem) and ONE download.
+int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, int32_t* const* match, int* nmatches)
 {
-    if (!a || !match || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2) ||
-        (a->variant != 0 && a->variant != 1))
-        return ORBFE_ERR_ARGS;
-    const int nOut = a->variant == 0 ? a->n2 : a->n1;
-    for (int i = 0; i < nOut; i++) match[i] = -1;
-    if (a->n1 == 0 || a->n2 == 0) return 0;
-    if (!a->desc1 || !a->desc2 || !a->mask1 || (a->variant == 1 && !a->mask2)) return ORBFE_ERR_ARGS;
-    if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+    if (count < 0 || (count && (!args || !match || !nmatches))) return ORBFE_ERR_ARGS;
     std::vector<BowNode> nodes;
-    for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
-        BowNode n;
-        n.off1 = a->fv1.offsets[i];
-        n.n1 = a->fv1.offsets[i + 1] - n.off1;
-        n.off2 = a->fv2.offsets[j];
-        n.n2 = a->fv2.offsets[j + 1] - n.off2;
-        if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
-    });
+    std::vector<BowProb> probs(count);
+    std::vector<uint8_t> descPool, maskPool;
+    std::vector<float> angPool;
+    std::vector<int32_t> indPool;
+    std::vector<int> outN(count);
+    int rows = 0, outTotal = 0;
+    for (int p = 0; p < count; p++) {
+        const orbfe_bow_args* a = &args[p];
+        if (!match[p] || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2) ||
+            (a->variant != 0 && a->variant != 1))
+            return ORBFE_ERR_ARGS;
+        const int nOut = a->variant == 0 ? a->n2 : a->n1;
+        outN[p] = nOut;
+        for (int i = 0; i < nOut; i++) match[p][i] = -1;
+        nmatches[p] = 0;
+        BowProb& P = probs[p];
+        P.d1Base = rows;
+        P.d2Base = rows + a->n1;
+        P.outBase = outTotal;
+        P.limit1 = a->limit1;
+        P.limit2 = a->limit2;
+        P.Nleft = a->Nleft;
+        P.variant = a->variant;
+        P.nnratio = a->nnratio;
+        outTotal += nOut;
+        if (a->n1 == 0 || a->n2 == 0) continue;
+        if (!a->desc1 || !a->desc2 || !a->mask1 || (a->variant == 1 && !a->mask2)) return ORBFE_ERR_ARGS;
+        if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+        const int i1Base = (int)indPool.size();
+        indPool.insert(indPool.end(), a->fv1.indices, a->fv1.indices + a->fv1.offsets[a->fv1.nn]);
+        const int i2Base = (int)indPool.size();
+        indPool.insert(indPool.end(), a->fv2.indices, a->fv2.indices + a->fv2.offsets[a->fv2.nn]);
+        bool bad = false;
+        for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
+            BowNode n;
+            n.off1 = i1Base + a->fv1.offsets[i];
+            n.n1 = a->fv1.offsets[i + 1] - a->fv1.offsets[i];
+            n.off2 = i2Base + a->fv2.offsets[j];
+            n.n2 = a->fv2.offsets[j + 1] - a->fv2.offsets[j];
+            n.prob = p;
+            if (n.n2 >= (1 << 20)) bad = true;
+            if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
+        });
+        if (bad) return ORBFE_ERR_ARGS;
+        descPool.insert(descPool.end(), a->desc1, a->desc1 + (size_t)a->n1 * 32);
+        descPool.insert(descPool.end(), a->desc2, a->desc2 + (size_t)a->n2 * 32);
+        maskPool.insert(maskPool.end(), a->mask1, a->mask1 + a->n1);
+        if (a->variant == 1) maskPool.insert(maskPool.end(), a->mask2, a->mask2 + a->n2);
+        else maskPool.insert(maskPool.end(), (size_t)a->n2, (uint8_t)1);
+        if (a->angle1) angPool.insert(angPool.end(), a->angle1, a->angle1 + a->n1);
+        else angPool.insert(angPool.end(), (size_t)a->n1, 0.f);
+        if (a->angle2) angPool.insert(angPool.end(), a->angle2, a->angle2 + a->n2);
+        else angPool.insert(angPool.end(), (size_t)a->n2, 0.f);
+        rows += a->n1 + a->n2;
+    }
     if (nodes.empty()) return 0;
-    for (const BowNode& n : nodes)
-        if (n.n2 >= (1 << 20)) return ORBFE_ERR_ARGS;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    Scratch s;
+    Scratch s(device);
     BowNode* dN;
-    uint8_t *d1, *d2, *m1, *m2, *taken;
-    float *a1, *a2;
-    int32_t *i1, *i2, *dM;
+    BowProb* dP;
+    uint8_t *dDesc, *dMask, *taken;
+    float* dAng;
+    int32_t *dInd, *dM;
     int8_t* dB;
-    std::vector<float> zero1(a->n1, 0.f), zero2(a->n2, 0.f);
     if ((r = s.up(&dN, nodes.data(), nodes.size())) < 0) return r;
-    if ((r = s.up(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
-    if ((r = s.up(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
-    if ((r = s.up(&m1, a->mask1, (size_t)a->n1)) < 0) return r;
-    if ((r = s.up(&m2, a->variant == 1 ? a->mask2 : nullptr, (size_t)a->n2)) < 0) return r;
-    if ((r = s.up(&a1, a->angle1 ? a->angle1 : zero1.data(), (size_t)a->n1)) < 0) return r;
-    if ((r = s.up(&a2, a->angle2 ? a->angle2 : zero2.data(), (size_t)a->n2)) < 0) return r;
-    if ((r = s.up(&i1, a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn])) < 0) return r;
-    if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
-    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)nOut)) < 0) return r;
-    if ((r = s.up<int8_t>(&dB, nullptr, (size_t)nOut)) < 0) return r;
-    if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)a->n2)) < 0) return r;
-    HIP_TRY(hipMemset(dM, 0xFF, (size_t)nOut * sizeof(int32_t)));
-    HIP_TRY(hipMemset(dB, 0xFF, (size_t)nOut));
-    HIP_TRY(hipMemset(taken, 0, (size_t)a->n2));
-    hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, 0, dN, (int)nodes.size(),
-                       d1, m1, a1, i1, a->limit1, d2, m2, a2, i2, a->limit2, a->Nleft, a->nnratio, a->variant, dM, dB,
-                       taken);
+    if ((r = s.up(&dP, probs.data(), probs.size())) < 0) return r;
+    if ((r = s.up(&dDesc, descPool.data(), descPool.size())) < 0) return r;
+    if ((r = s.up(&dMask, maskPool.data(), maskPool.size())) < 0) return r;
+    if ((r = s.up(&dAng, angPool.data(), angPool.size())) < 0) return r;
+    if ((r = s.up(&dInd, indPool.data(), indPool.size())) < 0) return r;
+    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
+    if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
+    if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)rows)) < 0) return r;
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), 0));
+    HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, 0));
+    HIP_TRY(hipMemsetAsync(taken, 0, (size_t)rows, 0));
+    {
+        KernelTimer timer;
+        hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, 0, dN, (int)nodes.size(),
+                           dP, dDesc, dMask, dAng, dInd, dM, dB, taken);
+    }
     HIP_TRY(hipGetLastError());
-    std::vector<int8_t> bins(nOut);
-    HIP_TRY(hipMemcpy(match, dM, (size_t)nOut * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(bins.data(), dB, (size_t)nOut, hipMemcpyDeviceToHost));
-    return cull_by_rotation(match, bins.data(), nOut, a->check_orientation != 0);
+    std::vector<int32_t> m(outTotal);
+    std::vector<int8_t> bins(outTotal);
+    HIP_TRY(hipMemcpy(m.data(), dM, (size_t)outTotal * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bins.data(), dB, (size_t)outTotal, hipMemcpyDeviceToHost));
+    for (int p = 0; p < count; p++) {
+        std::memcpy(match[p], m.data() + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
+        nmatches[p] = cull_by_rotation(match[p], bins.data() + probs[p].outBase, outN[p], args[p].check_orientation != 0);
+    }
+    return 0;
+}
+
+int orbfe_search_bow(int device, const orbfe_bow_args* a, int32_t* match)
+{
+    if (!a || !match) return ORBFE_ERR_ARGS;
+    int n = 0;
+    int32_t* mp[1] = {match};
+    const int r = orbfe_search_bow_batch(device, 1, a, mp, &n);
+    return r < 0 ? r : n;
 }
 
 int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
@@ -588,7 +726,7 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
         if (t.n2 >= (1 << 20)) return ORBFE_ERR_ARGS;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    Scratch s;
+    Scratch s(device);
     TriRow* dR;
     uint8_t *d1, *d2, *h2;
     float *k1, *k2, *u1, *u2, *dF, *sf, *sg;
@@ -607,9 +745,12 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
-    HIP_TRY(hipMemset(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), 0));
+    {
+        KernelTimer timer;
     hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, dR, (int)rows.size(), d1,
                        k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM);
+    }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m12(a->n1);
     HIP_TRY(hipMemcpy(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -635,18 +776,23 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     return np;
 }
 
+float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
+
 int orbfe_kb8_unproject(int device, const float* P, const float* uv, int n, float* rays)
 {
     if (n < 0 || !P || (n && (!uv || !rays))) return ORBFE_ERR_ARGS;
     if (n == 0) return 0;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    Scratch s;
+    Scratch s(device);
     float *dP, *dU, *dR;
     if ((r = s.up(&dP, P, 8)) < 0) return r;
     if ((r = s.up(&dU, uv, (size_t)n * 2)) < 0) return r;
     if ((r = s.up<float>(&dR, nullptr, (size_t)n * 3)) < 0) return r;
+    {
+        KernelTimer timer;
     hipLaunchKernelGGL(k_kb8_unproject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP, dU, n, dR);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(rays, dR, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;

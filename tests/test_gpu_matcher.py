@@ -72,6 +72,37 @@ def test_search_by_bow_kf_kf(pkg, oracle, n1, n2, seed):
     assert rn > 5
 
 
+def test_search_bow_batch_equals_singles(pkg, oracle):
+    """Relocalisation-style batch: one frame against many candidate keyframes, one launch."""
+    probs, refs = [], []
+    dF, _, aF, _ = MI.descriptor_sets(1000, 10, 99)
+    for k in range(12):
+        n1 = 700 + 37 * k
+        d1, d2, a1, a2 = MI.descriptor_sets(n1, 1000, 100 + k)
+        fv1, fv2 = MI.feature_vectors(d1, d2, 100 + k)
+        rng = np.random.default_rng(k)
+        mask1 = (rng.uniform(size=n1) < 0.6).astype(np.uint8)
+        variant = k % 2
+        mask2 = (rng.uniform(size=1000) < 0.7).astype(np.uint8) if variant == 1 else None
+        ratio = 0.75 if variant == 0 else 0.9
+        probs.append(dict(desc1=d1, mask1=mask1, ang1=a1, fv1=fv1, desc2=d2, mask2=mask2, ang2=a2, fv2=fv2,
+                          variant=variant, nnratio=ratio, check_ori=True))
+        if variant == 0:
+            refs.append(oracle.search_bow_kf_f(d1, mask1, a1, fv1, d2, a2, fv2, -1, ratio, True))
+        else:
+            refs.append(oracle.search_bow_kf_kf(d1, mask1, a1, fv1, d2, mask2, a2, fv2, -1, -1, ratio, True))
+    # an empty problem in the middle of the batch
+    e = np.zeros((0, 32), np.uint8)
+    efv = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    probs.insert(5, dict(desc1=e, mask1=np.zeros(0, np.uint8), ang1=np.zeros(0), fv1=efv, desc2=probs[0]["desc2"],
+                         mask2=None, ang2=probs[0]["ang2"], fv2=probs[0]["fv2"], variant=0, nnratio=0.7))
+    refs.insert(5, (0, np.full(1000, -1, np.int32)))
+    got = pkg.search_bow_batch(probs)
+    assert len(got) == len(refs)
+    for (n, m), (rn, rm) in zip(got, refs):
+        assert n == rn and np.array_equal(m, rm)
+
+
 def test_search_bow_empty_and_disjoint(pkg, oracle):
     d1, d2, a1, a2 = MI.descriptor_sets(40, 40, 3)
     fv1 = (np.array([1, 5], np.uint32), np.array([0, 20, 40], np.int32), np.arange(40, dtype=np.int32))

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Matcher micro-benchmark (secondary metrics of SURVEY.md section 8d): per entry point the device time
+of the kernel (hipEvents inside the shim), the end-to-end call through the C ABI with host pointers
+(H2D + kernel + D2H + host epilogue) and the CPU oracle on one core, on seeded inputs.  One JSON line each."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
+import orb_oracle_py as O  # noqa: E402
+import matcher_inputs as MI  # noqa: E402
+
+
+def timeit(f, reps):
+    f()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f()
+    return (time.perf_counter() - t0) / reps
+
+
+def report(name, units, unit_name, gpu_call, cpu_call, reps=20, algo_bytes=None):
+    gpu_call()
+    k = []
+    for _ in range(reps):
+        gpu_call()
+        k.append(pkg.binding.matcher_last_kernel_ms())
+    kernel_ms = float(np.median(k))
+    e2e = timeit(gpu_call, reps)
+    cpu = timeit(cpu_call, max(2, reps // 5))
+    out = {"op": name, "units": units, "unit": unit_name, "kernel_ms": kernel_ms, "call_ms": 1e3 * e2e,
+           "cpu_oracle_ms_1core": 1e3 * cpu, "kernel_units_per_s": units / (kernel_ms * 1e-3),
+           "call_units_per_s": units / e2e, "cpu_units_per_s": units / cpu}
+    if algo_bytes:
+        out["kernel_GBps_algorithmic"] = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps(out))
+
+
+def main():
+    rng = np.random.default_rng(0)
+    A = rng.integers(0, 256, size=(1500, 32), dtype=np.uint8)
+    B = rng.integers(0, 256, size=(1500, 32), dtype=np.uint8)
+    report("hamming_pairs 1500x1500", 1500 * 1500, "distances", lambda: pkg.hamming_pairs(A, B),
+           lambda: O.hamming_matrix(A, B), algo_bytes=3000 * 32 + 1500 * 1500 * 2)
+    report("bfknn2 1500x1500 (C5 lapping-area brute force)", 1500 * 1500, "distances", lambda: pkg.bfknn2(A, B),
+           lambda: O.bfknn2(A, B), algo_bytes=3000 * 32 + 1500 * 16)
+    d1, d2, a1, a2 = MI.descriptor_sets(1200, 1200, 5)
+    fv1, fv2 = MI.feature_vectors(d1, d2, 5, 10, 2)
+    mask1 = (rng.uniform(size=1200) < 0.6).astype(np.uint8)
+    npairs = sum(int(fv1[1][i + 1] - fv1[1][i]) * int(fv2[1][j + 1] - fv2[1][j])
+                 for i, a in enumerate(fv1[0]) for j, b in enumerate(fv2[0]) if a == b)
+    report("SearchByBoW(KF,F) N=1200, 100 nodes", npairs, "candidate pairs",
+           lambda: pkg.search_bow(d1, mask1, a1, fv1, d2, None, a2, fv2, 0, 0.7, True),
+           lambda: O.search_bow_kf_f(d1, mask1, a1, fv1, d2, a2, fv2, -1, 0.7, True))
+    # relocalisation-style batch: 64 (KF, F) problems in one launch
+    probs = []
+    for k in range(64):
+        e1, e2, b1, b2 = MI.descriptor_sets(1200, 1200, 50 + k)
+        g1, g2 = MI.feature_vectors(e1, e2, 50 + k, 10, 2)
+        probs.append(dict(desc1=e1, mask1=mask1, ang1=b1, fv1=g1, desc2=e2, mask2=None, ang2=b2, fv2=g2, variant=0,
+                          nnratio=0.75, check_ori=True))
+    npb = 0
+    for pr in probs:
+        f1, f2 = pr["fv1"], pr["fv2"]
+        common = {int(a): i for i, a in enumerate(f1[0])}
+        for j, b in enumerate(f2[0]):
+            if int(b) in common:
+                i = common[int(b)]
+                npb += int(f1[1][i + 1] - f1[1][i]) * int(f2[1][j + 1] - f2[1][j])
+    report("SearchByBoW batch of 64 (KF,F) pairs, N=1200", npb, "candidate pairs", lambda: pkg.search_bow_batch(probs),
+           lambda: [O.search_bow_kf_f(p["desc1"], p["mask1"], p["ang1"], p["fv1"], p["desc2"], p["ang2"], p["fv2"], -1,
+                                      0.75, True) for p in probs], reps=10)
+    I = MI.tri_inputs(1200, 1200, 9)
+    report("SearchForTriangulation_ N=1200", npairs, "candidate pairs",
+           lambda: pkg.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"],
+                                            I["d2"], I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"],
+                                            I["F12"], I["ep"], I["sf"], I["sig"]),
+           lambda: O.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"],
+                                          I["d2"], I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"],
+                                          I["F12"], I["ep"], I["sf"], I["sig"]))
+
+
+if __name__ == "__main__":
+    main()
