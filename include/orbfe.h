@@ -66,6 +66,15 @@ int orbfe_set_gaussian_taps(orbfe_ctx*, const int* taps7);
 #define ORBFE_TRIG_CR 1
 int orbfe_set_trig_mode(orbfe_ctx*, int mode);
 
+/* Fisheye rigs (KannalaBrandt8, src/CameraModels/KannalaBrandt8.cpp:96-123): when params8 = {fx,fy,cx,cy,k0..k3}
+ * is set, the extractor also unprojects every keypoint to its bearing ray in the output-packing kernel
+ * (no extra pass).  Rays are indexed like the keypoints: 3 floats each.  NULL disables.
+ * Host API: read them with orbfe_get_rays(); device API: orbfe_set_ray_output() gives the device buffer
+ * (nimg * cap_per_img * 3 floats) the next device calls write to (NULL = context-owned buffer). */
+int orbfe_set_kb8(orbfe_ctx*, const float* params8);
+int orbfe_set_ray_output(orbfe_ctx*, float* d_rays);
+int orbfe_get_rays(orbfe_ctx*, int img_index, int cap_per_img, float* rays, int n);
+
 /* Upper bound of keypoints one image can yield with this context's parameters for a rows x cols image
  * (sum over levels of max(N_l + 3, 4 * nIni_l)); `cap` arguments below must be >= this. */
 int orbfe_max_keypoints(orbfe_ctx*, int rows, int cols);

@@ -84,6 +84,9 @@ def lib():
         L.orbfe_set_gaussian_taps.argtypes = [C.c_void_p, C.c_void_p]
         L.orbfe_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_max_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orbfe_set_kb8.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_set_ray_output.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_get_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orbfe_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.orbfe_extract_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_size_t,
@@ -118,7 +121,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -159,6 +162,20 @@ class ORBextractor:
 
     def __del__(self):
         self.close()
+
+    def set_kb8(self, params8):
+        """Enable fused KannalaBrandt8::unproject (bearing rays per keypoint); None disables."""
+        if params8 is None:
+            _chk(self.L.orbfe_set_kb8(self.h, None), "orbfe_set_kb8")
+        else:
+            p = np.ascontiguousarray(params8, np.float32)
+            assert p.shape == (8,)
+            _chk(self.L.orbfe_set_kb8(self.h, _p(p)), "orbfe_set_kb8")
+
+    def rays(self, n, cap, img_index=0):
+        out = np.zeros((n, 3), np.float32)
+        _chk(self.L.orbfe_get_rays(self.h, img_index, cap, _p(out), n), "orbfe_get_rays")
+        return out
 
     # -- operator() ---------------------------------------------------------------
     def max_keypoints(self, rows, cols):

@@ -122,7 +122,10 @@ struct orbfe_ctx {
     DevBuf<uint16_t> d_keyNode;
     DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono, d_misc /* [0]=err */;
     DevBuf<int4> d_fix; // [0] = {count,0,0,0}, then one entry per flagged keypoint
-    DevBuf<float> d_kps;
+    DevBuf<float> d_kps, d_kb8, d_rays;
+    bool kb8On = false;
+    float kb8[8] = {0};
+    float* userRays = nullptr; // device pointer supplied by orbfe_set_ray_output
     DevBuf<OrbDescWork> d_work;
     DevBuf<OrbLevelGeom> d_lg;
     DevBuf<OrbCellGeom> d_cg;
@@ -476,6 +479,8 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fixAB.ensure(B * K + 1)) < 0) return r;
     if ((r = c->d_taps.ensure(8)) < 0) return r;
+    if ((r = c->d_kb8.ensure(8)) < 0) return r;
+    if (c->kb8On && (r = c->d_rays.ensure(B * K * 3)) < 0) return r;
     if (!c->d_patternF.p) {
         if ((r = c->d_patternF.ensure(256)) < 0) return r;
         static const signed char pat[256][4] = ORBFE_PATTERN_31_INIT;
@@ -507,6 +512,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     hipStream_t s = c->stream;
     const int nl = c->nlevels;
     HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
+    if (c->kb8On) HIP_TRY(hipMemcpyAsync(c->d_kb8.p, c->kb8, 8 * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 2 * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
     rec(c, 0);
@@ -549,7 +555,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     rec(c, 3);
     // K-PACK
     hipLaunchKernelGGL(k_pack, dim3((unsigned)nimg), dim3(256), 0, s, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
-                       c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono);
+                       c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
+                       c->kb8On ? c->d_kb8.p : nullptr, c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr);
     rec(c, 4);
     // K-DESC
     hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)nimg), dim3(256), 0, s,
@@ -650,7 +657,7 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_pyr.release(); c->d_desc.release(); c->d_img.release();
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
-    c->d_misc.release(); c->d_fix.release(); c->d_kps.release();
+    c->d_misc.release(); c->d_fix.release(); c->d_kps.release(); c->d_kb8.release(); c->d_rays.release();
     c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
     c->d_taps.release(); c->d_patternF.release();
     c->h_misc.release(); c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release();
@@ -692,6 +699,37 @@ int orbfe_set_trig_mode(orbfe_ctx* c, int mode)
 {
     if (!c || (mode != ORBFE_TRIG_LIBM && mode != ORBFE_TRIG_CR)) return ORBFE_ERR_ARGS;
     c->trigMode = mode;
+    return 0;
+}
+
+int orbfe_set_kb8(orbfe_ctx* c, const float* params8)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    c->kb8On = params8 != nullptr;
+    if (params8) {
+        for (int i = 0; i < 8; i++) c->kb8[i] = params8[i];
+        c->capImgs = 0; // make ensure_capacity allocate the ray buffer
+    }
+    return 0;
+}
+
+int orbfe_set_ray_output(orbfe_ctx* c, float* d_rays)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    c->userRays = d_rays;
+    return 0;
+}
+
+int orbfe_get_rays(orbfe_ctx* c, int img_index, int cap_per_img, float* rays, int n)
+{
+    if (!c || !c->kb8On || c->userRays || !c->d_rays.p || img_index < 0 || img_index >= c->lastImgs || n < 0 ||
+        n > cap_per_img || (n && !rays))
+        return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n)
+        HIP_TRY(hipMemcpy(rays, c->d_rays.p + (size_t)img_index * cap_per_img * 3, (size_t)n * 3 * sizeof(float),
+                          hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -18,6 +18,7 @@
 
 #include "orbfe_geom.h"
 #include "orbfe_sincos.h"
+#include "orbfe_kb8.h"
 #include "orb_pattern.inc"
 
 #define WAVE 64
@@ -850,7 +851,8 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
                                               const int32_t* __restrict__ lvlCount, const int32_t* __restrict__ lap,
                                               float* __restrict__ kpsOut /* 7 floats per kp */, int capPerImg,
                                               OrbDescWork* __restrict__ work, int32_t* __restrict__ nOut,
-                                              int32_t* __restrict__ monoOut)
+                                              int32_t* __restrict__ monoOut, const float* __restrict__ kb8 /* or NULL */,
+                                              float* __restrict__ raysOut /* 3 floats per kp, or NULL */)
 {
     __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
     __shared__ int waveCnt[4];
@@ -906,6 +908,8 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
             k[4] = resp;
             reinterpret_cast<int32_t*>(k)[5] = level;
             reinterpret_cast<int32_t*>(k)[6] = -1;
+            // fisheye rigs: bearing ray of the keypoint, KannalaBrandt8::unproject fused into the pack
+            if (kb8 && raysOut) orbfe_kb8_unproject_dev(kb8, sx, sy, raysOut + ((size_t)img * capPerImg + dest) * 3);
             OrbDescWork w;
             w.level = (int16_t)level;
             w.x = (int16_t)px;

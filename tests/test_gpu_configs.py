@@ -1,0 +1,91 @@
+"""BASELINE.json configs C3 (EuRoC-like stereo pair + Hamming matching) and C5 (1024x1024 fisheye stereo,
+nFeatures=1500, KannalaBrandt8 unproject fused into the extractor) end to end on the GPU vs the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def _same(kps, rkps, desc, rdesc):
+    assert len(kps) == len(rkps)
+    for f in FIELDS:
+        assert np.array_equal(kps[f], rkps[f]), f
+    assert np.array_equal(desc, rdesc)
+
+
+def test_c3_stereo_pair_two_threads_and_matching(pkg, oracle):
+    left, right = pkg.synth.make_stereo_pair(480, 752, 31)
+    exL = pkg.ORBextractor(1200, 1.2, 8, 20, 7)   # mpORBextractorLeft / Right (src/Tracking.cc:1151-1154)
+    exR = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    res = {}
+
+    def run(tag, ex, im):   # Frame::Frame(stereo) drives the two extractors from two threads (src/Frame.cc:119-122)
+        res[tag] = ex(im, (0, 0))
+
+    tl = threading.Thread(target=run, args=("L", exL, left))
+    tr = threading.Thread(target=run, args=("R", exR, right))
+    tl.start(); tr.start(); tl.join(); tr.join()
+    ref = oracle.Extractor(1200, 1.2, 8, 20, 7)
+    rL = ref.extract(left, (0, 0))
+    rR = ref.extract(right, (0, 0))
+    for tag, r in (("L", rL), ("R", rR)):
+        mono, kps, desc = res[tag]
+        assert mono == r[0] == len(kps)           # lapping {0,0}: monoIndex == N
+        _same(kps, r[1], desc, r[2])
+    dL, dR = res["L"][2], res["R"][2]
+    # Hamming brute force between the two frames, bit exact
+    assert np.array_equal(pkg.hamming_pairs(dL, dR), oracle.hamming_matrix(dL, dR))
+    idx, dist = pkg.bfknn2(dL, dR)
+    ridx, rdist = oracle.bfknn2(dL, dR)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    # the shifted right image really matches: most ratio-test survivors have a small y difference
+    good = np.nonzero(dist[:, 0] < dist[:, 1] * 0.7)[0]
+    assert len(good) > 200
+    dy = np.abs(res["L"][1]["y"][good] - res["R"][1]["y"][idx[good, 0]])
+    assert np.median(dy) < 2.0
+    # SearchByBoW on synthetic FeatureVectors of the two descriptor sets
+    fvL = pkg.synth.make_feature_vectors(dL, 7, 10, 2)
+    fvR = pkg.synth.make_feature_vectors(dR, 7, 10, 2)
+    mask = np.ones(len(dL), np.uint8)
+    n, m = pkg.search_bow(dL, mask, res["L"][1]["angle"], fvL, dR, None, res["R"][1]["angle"], fvR, 0, 0.7, True)
+    rn, rm = oracle.search_bow_kf_f(dL, mask, res["L"][1]["angle"], fvL, dR, res["R"][1]["angle"], fvR, -1, 0.7, True)
+    assert n == rn and np.array_equal(m, rm) and n > 100
+
+
+def test_c5_fisheye_1024_with_fused_unproject(pkg, oracle):
+    left, right = pkg.synth.make_stereo_pair(1024, 1024, 51, shift=40)
+    # TUM-VI 512 KB8 parameters (Examples/Stereo-Inertial/TUM_512.yaml:9-30) scaled x2 for 1024x1024
+    P = np.array([2 * 190.978477, 2 * 190.973307, 2 * 254.931706, 2 * 256.897442, 0.003482389, 0.000715034,
+                  -0.002053236, 0.000202937], np.float32)
+    lap = (0, 1023)
+    ref = oracle.Extractor(1500, 1.2, 8, 20, 7)
+    outs = []
+    for im in (left, right):
+        ex = pkg.ORBextractor(1500, 1.2, 8, 20, 7)
+        ex.set_kb8(P)
+        mono, kps, desc = ex(im, lap)
+        rmono, rkps, rdesc = ref.extract(im, lap)
+        assert mono == rmono == 0                   # everything lies in the lapping area
+        _same(kps, rkps, desc, rdesc)
+        rays = ex.rays(len(kps), ex.max_keypoints(1024, 1024))
+        rref = oracle.kb8_unproject(P, np.stack([rkps["x"], rkps["y"]], 1))
+        rel = np.abs(rays - rref) / np.maximum(np.abs(rref), 1e-30)
+        assert rel.max() <= 2.5e-7, rel.max()       # only tan() differs between libms (<= 2 ulp)
+        assert (rays[:, 2] == 1).all()
+        outs.append((mono, kps, desc))
+        ex.close()
+    # Frame::ComputeStereoFishEyeMatches: knn-2 brute force over the lapping-area tails + Lowe ratio
+    (mL, kL, dL), (mR, kR, dR) = outs
+    idx, dist = pkg.bfknn2(dL[mL:], dR[mR:])
+    ridx, rdist = oracle.bfknn2(dL[mL:], dR[mR:])
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert (dist[:, 0] < dist[:, 1] * 0.7).sum() > 100
