@@ -127,6 +127,14 @@ int orbfe_debug_candidates(orbfe_ctx*, int img_index, int level, uint32_t* out, 
 int orbfe_debug_level_keypoints(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
 int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm trig in the last call */
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:797-967), rectified stereo.  `left` / `right` are the contexts
+ * that just extracted the two images (same size and parameters, same device): their pyramids are read in
+ * place for the 11x11 SAD refinement, so mvImagePyramid never leaves the device.  uRight / depth hold one
+ * float per left keypoint (-1 = no match, like mvuRight / mvDepth).  Returns the number of matches. */
+int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_kp* kpsL, const uint8_t* descL, int nL,
+                                 const orbfe_kp* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* uRight,
+                                 float* depth);
+
 /* ---- matcher ---- */
 /* DescriptorDistance over all pairs: D[i*nB+j] = popcount(A_i xor B_j).  Host pointers. */
 int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);

@@ -1199,6 +1199,125 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
     return np;
 }
 
+// Frame::ComputeStereoMatches, reference src/Frame.cc:797-967.  L / R are the oracle extractors that
+// processed the left / right image (their mvImagePyramid is read for the SAD refinement).
+int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_oracle_kp* mvKeys,
+                                      const uint8_t* mDescriptors, int N, const orb_oracle_kp* mvKeysRight,
+                                      const uint8_t* mDescriptorsRight, int Nr, float mb, float mbf, float* mvuRight,
+                                      float* mvDepth)
+{
+    const int TH_HIGH = 100;
+    for (int i = 0; i < N; i++) {
+        mvuRight[i] = -1.0f;
+        mvDepth[i] = -1.0f;
+    }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = L->pyr[0].rows;
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) {
+        const KP& kp = mvKeysRight[iR];
+        const float kpY = kp.y;
+        const float r = 2.0f * R->mvScaleFactor[kp.octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR); // the reference indexes unchecked
+    }
+    const float minZ = mb;
+    const float minD = 0;
+    const float maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < N; iL++) {
+        const KP& kpL = mvKeys[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y;
+        const float uL = kpL.x;
+        if ((int)vL < 0 || (int)vL >= nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD;
+        const float maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = mDescriptors + 32 * (size_t)iL;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const KP& kpR = mvKeysRight[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = DescriptorDistance(dL, mDescriptorsRight + 32 * iR);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = mvKeysRight[bestIdxR].x;
+            const float scaleFactor = L->mvInvScaleFactor[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5;
+            Level& PL = L->pyr[kpL.octave];
+            Level& PR = R->pyr[kpL.octave];
+            int bestDistS = 0x7fffffff;
+            int bestincR = 0;
+            const int Lw = 5;
+            std::vector<float> vDists(2 * Lw + 1);
+            const float iniu = scaleduR0 + Lw - w;
+            const float endu = scaleduR0 + Lw + w + 1;
+            if (iniu < 0 || endu >= PR.cols) continue;
+            for (int incR = -Lw; incR <= +Lw; incR++) {
+                // cv::norm(IL, IR, NORM_L1) over the 11x11 windows
+                double nrm = 0;
+                for (int dy = -w; dy <= w; dy++) {
+                    const uint8_t* rl = PL.roi() + (size_t)((int)scaledvL + dy) * PL.stride + ((int)scaleduL - w);
+                    const uint8_t* rr = PR.roi() + (size_t)((int)scaledvL + dy) * PR.stride + ((int)scaleduR0 + incR - w);
+                    for (int dx = 0; dx <= 2 * w; dx++) nrm += std::abs((int)rl[dx] - (int)rr[dx]);
+                }
+                float dist = (float)nrm;
+                if (dist < bestDistS) {
+                    bestDistS = (int)dist;
+                    bestincR = incR;
+                }
+                vDists[Lw + incR] = dist;
+            }
+            if (bestincR == -Lw || bestincR == Lw) continue;
+            const float dist1 = vDists[Lw + bestincR - 1];
+            const float dist2 = vDists[Lw + bestincR];
+            const float dist3 = vDists[Lw + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = L->mvScaleFactor[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01;
+                    bestuR = uL - 0.01;
+                }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0; // the reference reads vDistIdx[0] of an empty vector here
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        mvuRight[vDistIdx[i].second] = -1;
+        mvDepth[vDistIdx[i].second] = -1;
+        kept--;
+    }
+    return kept;
+}
+
 void orb_oracle_kb8_unproject(const float* P, const float* uv, int n, float* rays)
 {
     const float precision = 1e-6f; // reference include/CameraModels/KannalaBrandt8.h (precision member)

@@ -110,6 +110,11 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
+/* Frame::ComputeStereoMatches src/Frame.cc:797-967 (rectified stereo).  L, R = the oracle extractors that
+ * processed the left / right image.  uRight/depth sized N (left keypoints), -1 = no match.  Returns #matches. */
+int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_oracle_kp* kpsL, const uint8_t* descL,
+                                      int N, const orb_oracle_kp* kpsR, const uint8_t* descR, int Nr, float mb,
+                                      float mbf, float* uRight, float* depth);
 /* KannalaBrandt8::unproject src/CameraModels/KannalaBrandt8.cpp:96-123; params = fx,fy,cx,cy,k0..k3 */
 void orb_oracle_kb8_unproject(const float* params8, const float* uv, int n, float* rays3);
 

@@ -90,6 +90,10 @@ def lib():
         L.orb_oracle_search_triangulation.argtypes = (
             [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_FV)] * 2
             + [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        L.orb_oracle_compute_stereo_matches.restype = C.c_int
+        L.orb_oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                        C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                                        C.c_void_p, C.c_void_p]
         L.orb_oracle_kb8_unproject.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
@@ -339,6 +343,19 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
         _p(d2), len(d2), _p(h2), _p(x2), _p(a2), _p(o2), _p(u2), C.byref(f2),
         _p(F), float(ep[0]), float(ep[1]), _p(sf2), _p(ls2), int(only_stereo), int(coarse), int(check_ori), _p(pairs))
     return pairs[:n].copy()
+
+
+def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
+    """Frame::ComputeStereoMatches; exL/exR = oracle Extractors that just processed the two images."""
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    dL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    dR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    uR = np.zeros(len(kpsL), np.float32)
+    dep = np.zeros(len(kpsL), np.float32)
+    n = lib().orb_oracle_compute_stereo_matches(exL.h, exR.h, _p(kpsL), _p(dL), len(kpsL), _p(kpsR), _p(dR),
+                                                len(kpsR), mb, mbf, _p(uR), _p(dep))
+    return n, uR, dep
 
 
 def kb8_unproject(params8, uv):

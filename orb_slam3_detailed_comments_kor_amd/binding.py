@@ -95,6 +95,8 @@ def lib():
                                                  C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p]
         L.orbfe_sync.argtypes = [C.c_void_p]
+        L.orbfe_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                   C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orbfe_get_levels.argtypes = [C.c_void_p]
         L.orbfe_get_scale_factor.restype = C.c_float
         L.orbfe_get_scale_factor.argtypes = [C.c_void_p]
@@ -122,7 +124,7 @@ def lib():
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
            "orbfe_set_trig_mode", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
-           "orbfe_extract_batch_device", "orbfe_sync", "orbfe_get_levels", "orbfe_get_scale_factor",
+           "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
@@ -293,6 +295,19 @@ class ORBextractor:
 
     def debug_fixups(self):
         return self.L.orbfe_debug_fixups(self.h)
+
+
+def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
+    """Frame::ComputeStereoMatches (src/Frame.cc:797-967) on the pyramids held by the two extractors."""
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    dL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    dR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    uR = np.zeros(len(kpsL), np.float32)
+    dep = np.zeros(len(kpsL), np.float32)
+    n = _chk(lib().orbfe_compute_stereo_matches(exL.h, exR.h, _p(kpsL), _p(dL), len(kpsL), _p(kpsR), _p(dR), len(kpsR),
+                                                mb, mbf, _p(uR), _p(dep)), "orbfe_compute_stereo_matches")
+    return n, uR, dep
 
 
 # ------------------------------------------------------------------------ matcher

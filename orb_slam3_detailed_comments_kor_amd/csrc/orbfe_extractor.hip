@@ -886,6 +886,80 @@ int orbfe_get_level(orbfe_ctx* c, int img_index, int level, uint8_t* dst, size_t
     return 0;
 }
 
+// Frame::ComputeStereoMatches (src/Frame.cc:797-967) on the pyramids the two extractors left on the device.
+int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_kp* kpsL, const uint8_t* descL, int nL,
+                                 const orbfe_kp* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* uRight,
+                                 float* depth)
+{
+    if (!left || !right || nL < 0 || nR < 0 || (nL && (!kpsL || !descL || !uRight || !depth)) ||
+        (nR && (!kpsR || !descR)) || nR >= (1 << 20) || !(mb > 0))
+        return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nL; i++) {
+        uRight[i] = -1.0f;
+        depth[i] = -1.0f;
+    }
+    if (nL == 0 || nR == 0) return 0;
+    if (left->lg.empty() || right->lg.empty() || left->lastImgs < 1 || right->lastImgs < 1 ||
+        left->device != right->device || left->rows != right->rows || left->cols != right->cols ||
+        left->nlevels != right->nlevels || left->scaleFactor != right->scaleFactor)
+        return ORBFE_ERR_STATE;
+    HIP_TRY(hipSetDevice(left->device));
+    HIP_TRY(hipStreamSynchronize(left->stream));
+    HIP_TRY(hipStreamSynchronize(right->stream));
+    float *dKL = nullptr, *dKR = nullptr, *dU = nullptr, *dD = nullptr;
+    uint8_t *dDL = nullptr, *dDR = nullptr;
+    int32_t* dS = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dKL); (void)hipFree(dKR); (void)hipFree(dU); (void)hipFree(dD); (void)hipFree(dDL);
+        (void)hipFree(dDR); (void)hipFree(dS);
+    };
+#define ST_TRY(expr)                                 \
+    do {                                             \
+        hipError_t _e = (expr);                      \
+        if (_e != hipSuccess) {                      \
+            cleanup();                               \
+            return -(1000 + (int)_e);                \
+        }                                            \
+    } while (0)
+    ST_TRY(hipMalloc((void**)&dKL, (size_t)nL * 28));
+    ST_TRY(hipMalloc((void**)&dKR, (size_t)nR * 28));
+    ST_TRY(hipMalloc((void**)&dDL, (size_t)nL * 32));
+    ST_TRY(hipMalloc((void**)&dDR, (size_t)nR * 32));
+    ST_TRY(hipMalloc((void**)&dU, (size_t)nL * 4));
+    ST_TRY(hipMalloc((void**)&dD, (size_t)nL * 4));
+    ST_TRY(hipMalloc((void**)&dS, (size_t)nL * 4));
+    hipStream_t s = left->stream;
+    ST_TRY(hipMemcpyAsync(dKL, kpsL, (size_t)nL * 28, hipMemcpyHostToDevice, s));
+    ST_TRY(hipMemcpyAsync(dKR, kpsR, (size_t)nR * 28, hipMemcpyHostToDevice, s));
+    ST_TRY(hipMemcpyAsync(dDL, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s));
+    ST_TRY(hipMemcpyAsync(dDR, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_stereo_match, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, s, left->d_pyr.p, right->d_pyr.p,
+                       left->d_lg.p, left->nlevels, dKL, dDL, nL, dKR, dDR, nR, mb, mbf, dU, dD, dS);
+    std::vector<int32_t> sad(nL);
+    ST_TRY(hipMemcpyAsync(uRight, dU, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    ST_TRY(hipMemcpyAsync(depth, dD, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    ST_TRY(hipMemcpyAsync(sad.data(), dS, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    ST_TRY(hipStreamSynchronize(s));
+#undef ST_TRY
+    cleanup();
+    // outlier cut (:952-966): matches whose SAD is >= 1.5*1.4*median are dropped
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int i = 0; i < nL; i++)
+        if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
+    if (vDistIdx.empty()) return 0;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        uRight[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+        kept--;
+    }
+    return kept;
+}
+
 int orbfe_profile_enable(orbfe_ctx* c, int on)
 {
     if (!c) return ORBFE_ERR_ARGS;

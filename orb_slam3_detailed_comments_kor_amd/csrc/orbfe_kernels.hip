@@ -1256,3 +1256,118 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         }
     }
 }
+
+// --------------------------------------------------------------- K-STEREO
+// Frame::ComputeStereoMatches (reference src/Frame.cc:797-967), rectified stereo: one wavefront per
+// left keypoint.  The row table of the reference (vRowIndices) only restricts and orders candidates
+// (ascending right index inside a row), and the scan keeps the first minimum, so the best candidate
+// is argmin (distance, right index) over ALL right keypoints whose row band covers (int)vL -- a
+// brute-force pass across the lanes.  The 11x11 SAD refinement reads both image pyramids where the
+// extractors left them in HBM (no mvImagePyramid download).  The median-based outlier cut
+// (:952-966) needs all matches and stays O(N) host code.
+__global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict__ pyrL,
+                                                      const uint8_t* __restrict__ pyrR,
+                                                      const OrbLevelGeom* __restrict__ lg, int nlevels,
+                                                      const float* __restrict__ kpsL, const uint8_t* __restrict__ descL,
+                                                      int nL, const float* __restrict__ kpsR,
+                                                      const uint8_t* __restrict__ descR, int nR, float mb, float mbf,
+                                                      float* __restrict__ uRight, float* __restrict__ depth,
+                                                      int32_t* __restrict__ sadOut)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iL = blockIdx.x * 4 + wave;
+    if (iL >= nL) return;
+    const float uL = kpsL[iL * 7 + 0], vL = kpsL[iL * 7 + 1];
+    const int levelL = reinterpret_cast<const int32_t*>(kpsL)[iL * 7 + 5];
+    const int vLi = (int)vL;
+    const float maxD = __fdiv_rn(mbf, mb); // mbf / minZ, minZ = mb (:825-827)
+    const float minU = __fsub_rn(uL, maxD), maxU = uL;
+    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(descL + (size_t)iL * 32);
+    const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
+    unsigned best = 0xFFFFFFFFu;
+    for (int iR = lane; iR < nR; iR += 64) {
+        const float uR = kpsR[iR * 7 + 0], kpY = kpsR[iR * 7 + 1];
+        const int octR = reinterpret_cast<const int32_t*>(kpsR)[iR * 7 + 5];
+        if (octR < 0 || octR >= nlevels) continue;
+        const float r = __fmul_rn(2.0f, lg[octR].scale);
+        const int maxr = (int)ceilf(__fadd_rn(kpY, r)), minr = (int)floorf(__fsub_rn(kpY, r));
+        if (vLi < minr || vLi > maxr) continue;
+        if (octR < levelL - 1 || octR > levelL + 1) continue;
+        if (!(uR >= minU && uR <= maxU)) continue;
+        const unsigned long long* dr = reinterpret_cast<const unsigned long long*>(descR + (size_t)iR * 32);
+        const int dist = __popcll(l0 ^ dr[0]) + __popcll(l1 ^ dr[1]) + __popcll(l2 ^ dr[2]) + __popcll(l3 ^ dr[3]);
+        if (dist < 100) best = min(best, ((unsigned)dist << 20) | (unsigned)iR); // TH_HIGH
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
+    float outU = -1.0f, outD = -1.0f;
+    int outS = -1;
+    const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 20);
+    if (bestDist < 75 && levelL >= 0 && levelL < nlevels) { // thOrbDist = (TH_HIGH+TH_LOW)/2
+        const int bestIdxR = (int)(best & 0xFFFFF);
+        const float uR0 = kpsR[bestIdxR * 7 + 0];
+        const OrbLevelGeom G = lg[levelL];
+        const float sf = __fdiv_rn(1.0f, G.scale); // mvInvScaleFactors[octave]
+        const float scaleduL = roundf(__fmul_rn(uL, sf)), scaledvL = roundf(__fmul_rn(vL, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const int w = 5, Lw = 5;
+        const float iniu = scaleduR0 + Lw - w, endu = scaleduR0 + Lw + w + 1;
+        const int su = (int)scaleduL, sv = (int)scaledvL, sr = (int)scaleduR0;
+        const bool inside = su - w >= 0 && su + w < G.w && sv - w >= 0 && sv + w < G.h && sr - Lw - w >= 0;
+        if (!(iniu < 0 || endu >= (float)G.w) && inside) {
+            const uint8_t* PL = pyrL + G.roiOff;
+            const uint8_t* PR = pyrR + G.roiOff;
+            int sad[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++) sad[k] = 0;
+            for (int p = lane; p < 121; p += 64) {
+                const int dy = p / 11 - w, dx = p - (p / 11) * 11 - w;
+                const int vl = PL[(size_t)(sv + dy) * G.pitch + su + dx];
+                const uint8_t* rr = PR + (size_t)(sv + dy) * G.pitch + sr + dx;
+#pragma unroll
+                for (int k = 0; k < 11; k++) sad[k] += abs(vl - (int)rr[k - Lw]);
+            }
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sad[k] += __shfl_xor(sad[k], off);
+            int bestS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+                if (sad[k] < bestS) {
+                    bestS = sad[k];
+                    bestinc = k - Lw;
+                }
+            if (!(bestinc == -Lw || bestinc == Lw)) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int k = 1; k < 10; k++)
+                    if (k - Lw == bestinc) {
+                        d1 = (float)sad[k - 1];
+                        d2 = (float)sad[k];
+                        d3 = (float)sad[k + 1];
+                    }
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(G.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= 0 && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = (float)0.01;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        outD = __fdiv_rn(mbf, disparity);
+                        outU = bestuR;
+                        outS = bestS;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        uRight[iL] = outU;
+        depth[iL] = outD;
+        sadOut[iL] = outS;
+    }
+}

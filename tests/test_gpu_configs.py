@@ -89,3 +89,26 @@ def test_c5_fisheye_1024_with_fused_unproject(pkg, oracle):
     ridx, rdist = oracle.bfknn2(dL[mL:], dR[mR:])
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     assert (dist[:, 0] < dist[:, 1] * 0.7).sum() > 100
+
+
+def test_compute_stereo_matches_on_device_pyramids(pkg, oracle):
+    """SURVEY.md section 8f rank 1: Frame::ComputeStereoMatches (src/Frame.cc:797-967) without downloading
+    mvImagePyramid.  EuRoC stereo parameters (Examples/Stereo/EuRoC.yaml: bf = 47.906, fx = 435.2)."""
+    mbf, mb = 47.90639384423901, 47.90639384423901 / 435.2046959714599
+    for seed, shift in ((31, 24), (32, 3), (33, 61)):
+        left, right = pkg.synth.make_stereo_pair(480, 752, seed, shift=shift)
+        exL = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+        exR = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+        mL, kL, dL = exL(left, (0, 0))
+        mR, kR, dR = exR(right, (0, 0))
+        oL = oracle.Extractor(1200, 1.2, 8, 20, 7)
+        oR = oracle.Extractor(1200, 1.2, 8, 20, 7)
+        _, rkL, rdL = oL.extract(left, (0, 0))
+        _, rkR, rdR = oR.extract(right, (0, 0))
+        n, uR, dep = pkg.compute_stereo_matches(exL, exR, kL, dL, kR, dR, mb, mbf)
+        rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf)
+        assert n == rn and n > 300
+        assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)      # bit-exact floats
+        disp = (kL["x"] - uR)[uR >= 0]
+        assert abs(np.median(disp) - shift) < 0.2                          # sub-pixel disparity = the true shift
+        exL.close(); exR.close()
