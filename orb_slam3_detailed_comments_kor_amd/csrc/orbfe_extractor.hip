@@ -113,6 +113,9 @@ struct orbfe_ctx {
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
     int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning)
+    int nStreams = 1;            // ORBFE_STREAMS env / orbfe_set_streams: sub-batches on separate streams
+    hipStream_t sub[8] = {};
+    hipEvent_t evFork = nullptr, evJoin[8] = {};
     int fastDbgStop = 0;         // ORBFE_FAST_STOP env: phase ablation for profiling only (results invalid)
 
     // device state
@@ -347,12 +350,12 @@ int max_kp_for(orbfe_ctx* c, int rows, int cols)
 // Tile ranges of the fused pyramid kernel along one axis (see OrbPyrRange).  lo0[t]/hi1[t] give, for
 // destination index t of level l, the first / last source index of level l-1 it reads.
 void build_pyr_ranges(int nlevels, const std::vector<int>& extent, const std::vector<std::vector<int>>& srcLo,
-                      const std::vector<std::vector<int>>& srcHi, int ntiles, std::vector<OrbPyrRange>& out,
+                      const std::vector<std::vector<int>>& srcHi, int ntiles, int T, std::vector<OrbPyrRange>& out,
                       int* maxNeed0, int* maxNeed1)
 {
     const int top = nlevels - 1;
     std::vector<std::vector<int>> b(nlevels, std::vector<int>(ntiles + 1));
-    for (int i = 0; i <= ntiles; i++) b[top][i] = std::min(i * ORBFE_PYR_TILE, extent[top]);
+    for (int i = 0; i <= ntiles; i++) b[top][i] = std::min(i * T, extent[top]);
     b[top][ntiles] = extent[top];
     for (int l = top; l >= 1; l--) {
         for (int i = 0; i < ntiles; i++) b[l - 1][i] = b[l][i] < extent[l] ? srcLo[l][b[l][i]] : extent[l - 1];
@@ -422,12 +425,14 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
                 yhi[l][t] = ytab[c->lg[l].ytabOff + t].sy1;
             }
         }
-        c->pyrNtx = (ex[nl - 1] + ORBFE_PYR_TILE - 1) / ORBFE_PYR_TILE;
-        c->pyrNty = (ey[nl - 1] + ORBFE_PYR_TILE - 1) / ORBFE_PYR_TILE;
+        int T = ORBFE_PYR_TILE;
+        if (const char* e = getenv("ORBFE_PYR_TILE")) T = std::min(64, std::max(8, atoi(e)));
+        c->pyrNtx = (ex[nl - 1] + T - 1) / T;
+        c->pyrNty = (ey[nl - 1] + T - 1) / T;
         std::vector<OrbPyrRange> prx, pry;
         int mx0 = 0, mx1 = 0, my0 = 0, my1 = 0;
-        build_pyr_ranges(nl, ex, xlo, xhi, c->pyrNtx, prx, &mx0, &mx1);
-        build_pyr_ranges(nl, ey, ylo, yhi, c->pyrNty, pry, &my0, &my1);
+        build_pyr_ranges(nl, ex, xlo, xhi, c->pyrNtx, T, prx, &mx0, &mx1);
+        build_pyr_ranges(nl, ey, ylo, yhi, c->pyrNty, T, pry, &my0, &my1);
         c->pyrBuf0 = (int)align_up((size_t)((mx0 + 3) & ~3) * my0, 16);
         c->pyrBuf1 = (int)align_up((size_t)((mx1 + 3) & ~3) * std::max(my1, 1), 16);
         if ((r = c->d_prx.ensure(prx.size())) < 0) return r;
@@ -516,52 +521,75 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 2 * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
     rec(c, 0);
-    // K-PYR
-    if (c->pyrFused) {
-        hipLaunchKernelGGL(k_pyr_fused, dim3((unsigned)c->pyrNtx, (unsigned)c->pyrNty, (unsigned)nimg), dim3(256),
-                           (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY), s, d_imgs, pitch,
-                           imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p, c->pyrNtx,
-                           c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX, cols);
-    } else {
-        const OrbLevelGeom& L0 = c->lg[0];
-        dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);
-        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_imgs, pitch, imgStride, c->d_pyr.p, c->pyrStride, L0);
-        for (int l = 1; l < nl; l++) {
-            const OrbLevelGeom& Ld = c->lg[l];
-            dim3 g2((unsigned)((Ld.w + 1023) / 1024), (unsigned)Ld.h, (unsigned)nimg);
-            hipLaunchKernelGGL(k_pyr_resize, g2, dim3(256), 0, s, c->d_pyr.p, c->pyrStride, c->lg[l - 1], Ld,
-                               c->d_xtab.p, c->d_ytab.p);
+    // Sub-batches on separate streams (ORBFE_STREAMS > 1): the image pipelines are independent, so the
+    // latency-bound stages of one sub-batch overlap with the issue-bound stages of another.  Stage
+    // events are only meaningful with one stream.
+    const int nsub = (c->pyrFused && c->nStreams > 1) ? std::min(c->nStreams, nimg) : 1;
+    if (nsub > 1) {
+        HIP_TRY(hipEventRecord(c->evFork, s));
+        for (int k = 0; k < nsub; k++) HIP_TRY(hipStreamWaitEvent(c->sub[k], c->evFork, 0));
+    }
+    for (int k = 0; k < nsub; k++) {
+        const int i0 = (int)((long)nimg * k / nsub), i1 = (int)((long)nimg * (k + 1) / nsub);
+        const int ni = i1 - i0;
+        if (ni <= 0) continue;
+        hipStream_t q = nsub > 1 ? c->sub[k] : s;
+        // K-PYR
+        if (c->pyrFused) {
+            hipLaunchKernelGGL(k_pyr_fused, dim3((unsigned)c->pyrNtx, (unsigned)c->pyrNty, (unsigned)ni), dim3(256),
+                               (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY), q, d_imgs,
+                               pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p,
+                               c->pyrNtx, c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
+                               cols, i0);
+        } else {
+            const OrbLevelGeom& L0 = c->lg[0];
+            dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);
+            hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, q, d_imgs, pitch, imgStride, c->d_pyr.p, c->pyrStride,
+                               L0);
+            for (int l = 1; l < nl; l++) {
+                const OrbLevelGeom& Ld = c->lg[l];
+                dim3 g2((unsigned)((Ld.w + 1023) / 1024), (unsigned)Ld.h, (unsigned)nimg);
+                hipLaunchKernelGGL(k_pyr_resize, g2, dim3(256), 0, q, c->d_pyr.p, c->pyrStride, c->lg[l - 1], Ld,
+                                   c->d_xtab.p, c->d_ytab.p);
+            }
+        }
+        if (nsub == 1) rec(c, 1);
+        // K-FAST
+        {
+            const int G = c->fastXcdGroup;
+            const dim3 grid((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)ni); // whole groups per XCD
+#define ORBFE_FAST_LAUNCH(NT)                                                                                        \
+    hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
+                       c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
+                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0)
+            if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
+            else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
+            else ORBFE_FAST_LAUNCH(256);
+#undef ORBFE_FAST_LAUNCH
+        }
+        if (nsub == 1) rec(c, 2);
+        // K-QT
+        hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)ni), dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
+                           c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
+                           c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p, i0);
+        if (nsub == 1) rec(c, 3);
+        // K-PACK
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(256), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
+                           c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
+                           c->kb8On ? c->d_kb8.p : nullptr,
+                           c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0);
+        if (nsub == 1) rec(c, 4);
+        // K-DESC
+        hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
+                           c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
+                           c->d_patternF.p, c->d_fix.p, 0, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0, i0);
+        if (nsub > 1) {
+            HIP_TRY(hipEventRecord(c->evJoin[k], q));
+            HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
         }
     }
-    rec(c, 1);
-    // K-FAST
-    {
-        const int G = c->fastXcdGroup;
-        const dim3 grid((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)nimg); // whole groups per XCD
-#define ORBFE_FAST_LAUNCH(NT)                                                                                        \
-    hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, s, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
-                       c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop)
-        if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
-        else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
-        else ORBFE_FAST_LAUNCH(256);
-#undef ORBFE_FAST_LAUNCH
-    }
-    rec(c, 2);
-    // K-QT
-    hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)nimg), dim3(QT_THREADS), c->qtLdsBytes, s, c->d_lg.p, c->d_cg.p,
-                       c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p, c->d_keyNode.p,
-                       c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p);
-    rec(c, 3);
-    // K-PACK
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)nimg), dim3(256), 0, s, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
-                       c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
-                       c->kb8On ? c->d_kb8.p : nullptr, c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr);
-    rec(c, 4);
-    // K-DESC
-    hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)nimg), dim3(256), 0, s,
-                       c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                       c->d_patternF.p, c->d_fix.p, 0, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0);
+    if (nsub > 1)
+        for (int i = 1; i <= 4; i++) rec(c, i);
     rec(c, 5);
     c->lastImgs = nimg;
     c->lastFixups = 0;
@@ -603,7 +631,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                               c->d_patternF.p, c->h_fixAB.p, nFix, 0);
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0);
         c->lastFixups = nFix;
     }
     rec(c, 6);
@@ -640,6 +668,14 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(1, atoi(e));
     if (const char* e = getenv("ORBFE_FAST_STOP")) c->fastDbgStop = atoi(e);
+    if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
+    if (c->nStreams > 1) {
+        bool ok = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < c->nStreams && ok; k++)
+            ok = hipStreamCreateWithFlags(&c->sub[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) c->nStreams = 1;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ORBFE_ERR_NODEV;
@@ -664,6 +700,11 @@ void orbfe_destroy(orbfe_ctx* c)
     if (c->evReady)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    for (int k = 0; k < 8; k++) {
+        if (c->sub[k]) (void)hipStreamDestroy(c->sub[k]);
+        if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
+    }
     delete c;
 }
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                                                    const OrbPyrRange* __restrict__ ry, int ntx, int nty,
                                                    const OrbResizeX* __restrict__ xtab,
                                                    const OrbResizeY* __restrict__ ytab, int bufBytes0,
-                                                   int bufBytes1, int stageX, int imgCols)
+                                                   int bufBytes1, int stageX, int imgCols, int imgBase)
 {
     // dynamic LDS: region buffer A | region buffer B | staged x-table slices | staged y-table slices
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
@@ -115,8 +115,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     OrbResizeX* xt = reinterpret_cast<OrbResizeX*>(pyr_lds + bufBytes0 + bufBytes1);
     OrbResizeY* yt = reinterpret_cast<OrbResizeY*>(xt + stageX);
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int ti = blockIdx.x, tj = blockIdx.y, img = blockIdx.z;
+    const int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z + imgBase;
     uint8_t* base = pyr + (size_t)img * pyrImgStride;
 
     // per-level parameters once into LDS (one round of global loads instead of a dependent scalar
@@ -124,6 +123,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     __shared__ int lvXlo[ORBFE_MAX_LEVELS], lvXown[ORBFE_MAX_LEVELS], lvXneed[ORBFE_MAX_LEVELS];
     __shared__ int lvYlo[ORBFE_MAX_LEVELS], lvYown[ORBFE_MAX_LEVELS], lvYneed[ORBFE_MAX_LEVELS];
     __shared__ int lvRoi[ORBFE_MAX_LEVELS], lvPitch[ORBFE_MAX_LEVELS], lvXt[ORBFE_MAX_LEVELS], lvYt[ORBFE_MAX_LEVELS];
+    __shared__ unsigned lvRecip[ORBFE_MAX_LEVELS]; // ceil(2^32 / needed width), 0 when the width is 1
     if (tid < nlevels) {
         const OrbPyrRange X = rx[tid * ntx + ti], Y = ry[tid * nty + tj];
         lvXlo[tid] = X.lo;
@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         lvPitch[tid] = lg[tid].pitch;
         lvXt[tid] = lg[tid].xtabOff;
         lvYt[tid] = lg[tid].ytabOff;
+        const int nw = X.needHi - X.lo;
+        lvRecip[tid] = nw > 1 ? (unsigned)(((1ull << 32) + (unsigned)nw - 1) / (unsigned)nw) : 0u;
     }
     __syncthreads();
     // stage the interpolation-table slices of every level (all loads in flight at once; the per-pixel
@@ -210,21 +212,22 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         const int dp = (nW + 3) & ~3;
         uint8_t* g = base + (uint32_t)lvRoi[l] + (size_t)ylo * gpitch + xlo;
         const int ownW = lvXown[l] - xlo, ownH = lvYown[l] - ylo;
-        for (int c = tx; c < nW; c += 16) {
+        // flat index over the needed region (no idle lanes at ragged region edges); idx / nW by reciprocal
+        const unsigned rcp = lvRecip[l];
+        for (int idx = tid; idx < nW * nH; idx += 256) {
+            const int r = rcp ? (int)__umulhi((unsigned)idx, rcp) : idx;
+            const int c = idx - r * nW;
             const OrbResizeX tX = xt[xo + c];
+            const OrbResizeY tY = yt[yo + r];
             const int sx = (int)tX.sx - srcLoX, sx1 = (int)tX.pad - srcLoX;
-            const int a0 = tX.a0, a1 = tX.a1;
-            for (int r = ty; r < nH; r += 16) {
-                const OrbResizeY tY = yt[yo + r];
-                const uint8_t* S0 = S + ((int)tY.sy0 - srcLoY) * sp;
-                const uint8_t* S1 = S + ((int)tY.sy1 - srcLoY) * sp;
-                const int h0 = S0[sx] * a0 + S0[sx1] * a1;
-                const int h1 = S1[sx] * a0 + S1[sx1] * a1;
-                int v = ((((int)tY.b0 * (h0 >> 4)) >> 16) + (((int)tY.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                v = min(max(v, 0), 255);
-                D[r * dp + c] = (uint8_t)v;
-                if (r < ownH && c < ownW) g[(size_t)r * gpitch + c] = (uint8_t)v;
-            }
+            const uint8_t* S0 = S + ((int)tY.sy0 - srcLoY) * sp;
+            const uint8_t* S1 = S + ((int)tY.sy1 - srcLoY) * sp;
+            const int h0 = S0[sx] * (int)tX.a0 + S0[sx1] * (int)tX.a1;
+            const int h1 = S1[sx] * (int)tX.a0 + S1[sx1] * (int)tX.a1;
+            int v = ((((int)tY.b0 * (h0 >> 4)) >> 16) + (((int)tY.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            D[r * dp + c] = (uint8_t)v;
+            if (r < ownH && c < ownW) g[(size_t)r * gpitch + c] = (uint8_t)v;
         }
         __syncthreads();
         srcLoX = xlo;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
-                                                   int tileRows, int xcdGroup, int dbgStop)
+                                                   int tileRows, int xcdGroup, int dbgStop, int imgBase)
 {
     // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[(tileRows-6)*(P-6)] u16 -- sized by the
     // host from the largest cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     // spatially correlated).
     const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
     const int cell = ((slot / xcdGroup) * 8 + xcd) * xcdGroup + slot % xcdGroup;
-    const int img = blockIdx.y;
+    const int img = (int)blockIdx.y + imgBase;
     if (cell >= nCellsTotal) return;
     const OrbCellGeom c = cg[cell];
     const OrbLevelGeom L = lg[c.level];
@@ -580,11 +583,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                                        uint32_t* __restrict__ keysAll, uint16_t* __restrict__ keyNodeAll,
                                                        size_t keyImgStride, uint32_t* __restrict__ lvlKp,
                                                        size_t kpImgStride, int32_t* __restrict__ lvlCount, int nlevels,
-                                                       int32_t* __restrict__ errFlag)
+                                                       int32_t* __restrict__ errFlag, int imgBase)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int level = blockIdx.x, img = blockIdx.y;
+    const int level = blockIdx.x, img = (int)blockIdx.y + imgBase;
     const OrbLevelGeom L = lg[level];
     const int LC = L.listCap;
     const int N = L.nFeat;
@@ -852,13 +855,13 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
                                               float* __restrict__ kpsOut /* 7 floats per kp */, int capPerImg,
                                               OrbDescWork* __restrict__ work, int32_t* __restrict__ nOut,
                                               int32_t* __restrict__ monoOut, const float* __restrict__ kb8 /* or NULL */,
-                                              float* __restrict__ raysOut /* 3 floats per kp, or NULL */)
+                                              float* __restrict__ raysOut /* 3 floats per kp, or NULL */, int imgBase)
 {
     __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
     __shared__ int waveCnt[4];
     __shared__ int runStereo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int img = blockIdx.x;
+    const int img = (int)blockIdx.x + imgBase;
     if (tid == 0) {
         int acc = 0;
         for (int l = 0; l < nlevels; l++) {
@@ -1021,13 +1024,13 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           int4* fixList /* MODE 0: out {img, g, angle bits, 0} after
                                                                            a 16-B header whose first word is the
                                                                            count; MODE 1: in {img, g, a bits, b bits} */,
-                                                          int nFix, int listFragile)
+                                                          int nFix, int listFragile, int imgBase)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int img, g;
     if (MODE == 0) {
-        img = blockIdx.y;
+        img = (int)blockIdx.y + imgBase;
         g = blockIdx.x * 4 + wave;
         if (g >= nOut[img]) return; // wave-uniform
     } else {
