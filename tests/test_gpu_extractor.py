@@ -225,3 +225,51 @@ def test_device_resident_batch_and_full_size_properties(pkg, oracle):
         for j, f in enumerate(FIELDS):
             got[f] = raw[:, j].view(np.int32) if f in ("octave", "class_id") else raw[:, j]
         _same(got, rkps, desc[i, : n[i]], rdesc)
+
+
+def test_context_reuse_across_sizes_and_batches(pkg, oracle):
+    """One ORBextractor instance fed different image sizes and batch sizes (geometry and buffers are
+    rebuilt / regrown in place), like a rig whose cameras differ."""
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(800, 1.2, 8, 20, 7)
+    seq = [((480, 752), 1), ((480, 640), 3), ((480, 752), 5), ((376, 1241), 2), ((480, 640), 1)]
+    for k, (hw, nb) in enumerate(seq):
+        imgs = [_frame(pkg, hw[0], hw[1], 700 + 10 * k + i) for i in range(nb)]
+        res = ex.extract_batch(imgs, [(0, 0)] * nb) if nb > 1 else [ex(imgs[0], (0, 0))]
+        for im, (mono, kps, desc) in zip(imgs, res):
+            rmono, rkps, rdesc = ref.extract(im, (0, 0))
+            assert mono == rmono
+            _same(kps, rkps, desc, rdesc)
+
+
+def test_device_batch_with_row_pitch(pkg, oracle):
+    """Device-resident input with a row pitch larger than the width and an image stride with padding."""
+    import torch
+    B, H, W, PITCH = 3, 240, 376, 512
+    frames = [_frame(pkg, H, W, 810 + i) for i in range(B)]
+    buf = np.zeros((B, H + 7, PITCH), np.uint8)
+    for i, f in enumerate(frames):
+        buf[i, :H, :W] = f
+        buf[i, :H, W:] = 255 - f[:, : PITCH - W]  # garbage right of the image must not be read
+    ex = pkg.ORBextractor(400, 1.2, 8, 20, 7)
+    cap = ex.max_keypoints(H, W)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(buf).to(dev)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_img.data_ptr(), B, H, W, PITCH, (H + 7) * PITCH, (0, 1000), d_kps.data_ptr(),
+                            d_desc.data_ptr(), cap, d_n.data_ptr(), d_mono.data_ptr())
+    ex.sync()
+    n = d_n.cpu().numpy()
+    ref = oracle.Extractor(400, 1.2, 8, 20, 7)
+    for i in range(B):
+        rmono, rkps, rdesc = ref.extract(frames[i], (0, 1000))
+        assert int(d_mono[i]) == rmono and n[i] == len(rkps)
+        raw = d_kps[i, : n[i]].cpu().numpy()
+        got = np.zeros(n[i], pkg.KP_DTYPE)
+        for j, f in enumerate(FIELDS):
+            got[f] = raw[:, j].view(np.int32) if f in ("octave", "class_id") else raw[:, j]
+        _same(got, rkps, d_desc[i, : n[i]].cpu().numpy(), rdesc)
