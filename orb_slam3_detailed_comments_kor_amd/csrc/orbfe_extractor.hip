@@ -109,7 +109,8 @@ struct orbfe_ctx {
     size_t pyrStride = 0, candStride = 0, keyStride = 0, kpStride = 0;
     int nCells = 0, maxKp = 0, maxListCap = 0;
     size_t qtLdsBytes = 0;
-    int fastPitch = 0, fastRows = 0, fastThreads = 256;
+    int fastPitch = 0, fastRows = 0, fastThreads = 256, fastKqOff = 0, fastCqOff = 0;
+    uint32_t fastRecipP = 0;
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
     int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning)
@@ -247,7 +248,9 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
                     g.mNd = recip(nd);
                     g.mNdz = recip(ndz);
                     g.mZw = recip(zw1);
-                    g.pad2 = 0;
+                    g.pad2[0] = g.pad2[1] = g.pad2[2] = 0;
+                    g.roiOff = L.roiOff;
+                    g.pitch = L.pitch;
                 }
                 if (g.cw > ORBFE_FAST_TILE - 1 || g.ch > ORBFE_FAST_TILE - 1) return ORBFE_ERR_ARGS;
                 const int zw = std::max(g.cw - 6, 0), zh = std::max(g.ch - 6, 0);
@@ -313,16 +316,22 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     c->maxKp = maxKp;
     c->maxListCap = maxLC;
     {
-        int maxCw = 0, maxCh = 0, maxZone = 0;
+        int maxCw = 0, maxCh = 0, maxZone = 0, maxSlots = 1;
         for (const OrbCellGeom& g : c->cg) {
             maxCw = std::max<int>(maxCw, g.cw);
             maxCh = std::max<int>(maxCh, g.ch);
             maxZone = std::max(maxZone, std::max(g.cw - 6, 0) * std::max(g.ch - 6, 0));
+            maxSlots = std::max(maxSlots, (int)g.slotCap);
         }
         c->fastPitch = (int)align_up((size_t)maxCw + 3, 4) + 4; // + one dword: phase A reads d+1
         c->fastRows = maxCh;
+        c->fastKqOff = (int)align_up((size_t)2 * c->fastRows * c->fastPitch + 2 * (size_t)std::max(maxZone, 1), 16);
+        c->fastCqOff = 0;
+        // the survivor list of the NMS (4 B per slot) lives in the tile area after phase B
+        // (4 * slotCap <= zone area < tile area, so it always fits)
+        if (4 * (size_t)maxSlots > (size_t)c->fastRows * c->fastPitch) return ORBFE_ERR_ARGS;
         c->fastLdsBytes = align_up((size_t)2 * c->fastRows * c->fastPitch + 2 * (size_t)std::max(maxZone, 1), 16);
-        // one mask bit per pixel of a thread's run in phase C: run length <= 64
+        c->fastRecipP = (uint32_t)(((1ull << 32) + c->fastPitch - 1) / (uint64_t)c->fastPitch);
         int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
         if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
             nt = std::max(nt, c->fastThreadsOverride);
@@ -561,7 +570,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
 #define ORBFE_FAST_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
                        c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0)
+                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0, c->fastKqOff, c->fastRecipP, c->fastCqOff)
             if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
             else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
             else ORBFE_FAST_LAUNCH(256);

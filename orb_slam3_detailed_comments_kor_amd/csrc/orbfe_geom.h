@@ -48,7 +48,9 @@ struct OrbCellGeom {
     int32_t slotCap;    /* ceil(zw/2)*ceil(zh/2): max strict 8-neighbour local maxima */
     /* ceil(2^32/d) reciprocals (0 encodes d == 1): x/d == umulhi(x, m) while x*d < 2^32 */
     uint32_t mNd, mNdz, mZw;
-    uint32_t pad2;
+    uint32_t roiOff;    /* copy of the level's roiOff and pitch: saves the kernel a dependent load */
+    int32_t pitch;
+    int32_t pad2[3];
 };
 
 /* resize tables: per destination column / row */
@@ -75,6 +77,10 @@ struct OrbDescWork {
     int16_t level, x, y; /* level coordinates of the keypoint */
     int16_t pad;
     int32_t dest;        /* output slot                       */
+    uint32_t roiOff;     /* level geometry copied by K-PACK: saves K-DESC a dependent load */
+    int32_t pitch;
+    int16_t w, h;
+    int32_t pad2[2];
 };
 
 #endif

@@ -302,6 +302,28 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
     return max(bright, -darkNeg) - 1;
 }
 
+typedef short fast_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fast_s2 fast_unpack_lo(uint32_t x) // bytes 0,1 -> two i16
+{
+    const uint32_t r = __builtin_amdgcn_perm(0u, x, 0x0C010C00u);
+    return *reinterpret_cast<const fast_s2*>(&r);
+}
+__device__ __forceinline__ fast_s2 fast_unpack_hi(uint32_t x) // bytes 2,3 -> two i16
+{
+    const uint32_t r = __builtin_amdgcn_perm(0u, x, 0x0C030C02u);
+    return *reinterpret_cast<const fast_s2*>(&r);
+}
+// sign bits (15, 31) set where the pixel survives the (0,8)&(4,12) opposite-pair test at threshold t
+__device__ __forceinline__ uint32_t fast_pass_pair(fast_s2 v, fast_s2 r0, fast_s2 r8, fast_s2 r4, fast_s2 r12, int t)
+{
+    const fast_s2 tt = {(short)t, (short)t};
+    const fast_s2 hi = v + tt, lo = v - tt;
+    const fast_s2 bmin = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+    const fast_s2 dmax = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
+    const fast_s2 o = (hi - bmin) | (dmax - lo);
+    return *reinterpret_cast<const uint32_t*>(&o) & 0x80008000u;
+}
+
 // x / d with a host-made reciprocal m = ceil(2^32 / d) (m == 0 encodes d == 1): exact while x*d < 2^32.
 __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (int)__umulhi(x, m) : (int)x; }
 
@@ -321,16 +343,24 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
-                                                   int tileRows, int xcdGroup, int dbgStop, int imgBase)
+                                                   int tileRows, int xcdGroup, int dbgStop, int imgBase, int kqOff,
+                                                   unsigned mP /* ceil(2^32 / P) */, int cqOff)
 {
-    // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[(tileRows-6)*(P-6)] u16 -- sized by the
+    // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[max zone] u16 | kq[max slotCap] u32 -- sized by the
     // host from the largest cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
     const int PD = P >> 2;
     uint8_t* tile = fast_lds;
     uint8_t* smap = fast_lds + tileRows * P;
     uint16_t* queue = reinterpret_cast<uint16_t*>(fast_lds + 2 * tileRows * P);
-    __shared__ int qn, waveTot[4];
+    // LDS is what limits residency here (more resident workgroups = better latency hiding: +4 KB cost
+    // 10 %), so the later phases reuse dead storage: the corner queue overwrites the survivor queue
+    // from the front, the NMS survivors (pos | score<<16) overwrite the tile once phase B is done.
+    uint32_t* kq = reinterpret_cast<uint32_t*>(tile);
+    uint16_t* cq = queue;
+    (void)kqOff;
+    (void)cqOff;
+    __shared__ int qn, cn, kn, waveTot[4];
     constexpr int NW = NT / 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -346,20 +376,40 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     const int img = (int)blockIdx.y + imgBase;
     if (cell >= nCellsTotal) return;
     const OrbCellGeom c = cg[cell];
-    const OrbLevelGeom L = lg[c.level];
+    (void)lg;
     const int cw = c.cw, ch = c.ch;
     const int ox = c.iniX & 3; // tile x = roi x + ox
-    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff + (size_t)c.iniY * L.pitch + (c.iniX - ox);
+    const int gpitch = c.pitch;
+    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + c.roiOff + (size_t)c.iniY * gpitch + (c.iniX - ox);
     const int tmin = min(iniTh, minTh);
     const int nd = c.nd; // dwords per tile row
 
-    if (tid == 0) qn = 0;
+    if (tid == 0) {
+        qn = 0;
+        cn = 0;
+        kn = 0;
+    }
     // stage the ROI (rows x nd dwords), clear the score map; divisions by per-cell constants use
-    // host-made reciprocals (fast_div)
-    for (int idx = tid; idx < ch * nd; idx += NT) {
-        const int y = fast_div((unsigned)idx, c.mNd), d = idx - y * nd;
-        reinterpret_cast<uint32_t*>(smap)[y * PD + d] = 0u;
-        reinterpret_cast<uint32_t*>(tile)[y * PD + d] = *reinterpret_cast<const uint32_t*>(roi + (size_t)y * L.pitch + 4 * d);
+    // host-made reciprocals (fast_div).  Loads are issued four at a time before the first LDS store.
+    {
+        const int nItems = ch * nd;
+        for (int base = 0; base < nItems; base += 4 * NT) {
+            uint32_t v[4];
+            int off[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int idx = min(base + k * NT + tid, nItems - 1);
+                const int y = fast_div((unsigned)idx, c.mNd), d = idx - y * nd;
+                off[k] = y * PD + d;
+                v[k] = *reinterpret_cast<const uint32_t*>(roi + (size_t)y * gpitch + 4 * d);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (base + k * NT + tid < nItems) {
+                    reinterpret_cast<uint32_t*>(smap)[off[k]] = 0u;
+                    reinterpret_cast<uint32_t*>(tile)[off[k]] = v[k];
+                }
+        }
     }
     __syncthreads();
 
@@ -386,40 +436,43 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                 // x-3 of the 4 pixels: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
                 const uint32_t W12 = __builtin_amdgcn_alignbyte(C, Lf, 1);
                 const uint32_t W4 = __builtin_amdgcn_alignbyte(R, C, 3);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int tx = 4 * d + k;
-                    const int v = (C >> (8 * k)) & 0xFF;
-                    const int r0 = (Dn >> (8 * k)) & 0xFF, r8 = (U >> (8 * k)) & 0xFF;
-                    const int r4 = (W4 >> (8 * k)) & 0xFF, r12 = (W12 >> (8 * k)) & 0xFF;
-                    const int hi = v + tmin, lo = v - tmin;
-                    const bool b = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
-                    const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
-                    if ((b | dk) && tx >= txLo && tx <= txHi) passBits |= 1u << k;
-                }
+                // two pixels per instruction: bytes -> u16 pairs (v_perm_b32), then v_pk_{add,sub,min,max}_i16;
+                // a pixel passes when the sign bit of (hi - min(max(r0,r8), max(r4,r12))) or of
+                // (max(min(r0,r8), min(r4,r12)) - lo) is set.
+                const uint32_t pl = fast_pass_pair(fast_unpack_lo(C), fast_unpack_lo(Dn), fast_unpack_lo(U),
+                                                   fast_unpack_lo(W4), fast_unpack_lo(W12), tmin);
+                const uint32_t ph = fast_pass_pair(fast_unpack_hi(C), fast_unpack_hi(Dn), fast_unpack_hi(U),
+                                                   fast_unpack_hi(W4), fast_unpack_hi(W12), tmin);
+                passBits = ((pl >> 15) & 1u) | ((pl >> 30) & 2u) | ((ph >> 13) & 4u) | ((ph >> 28) & 8u);
+                // only the zone columns [txLo, txHi] count
+                const int tx0 = 4 * d;
+                unsigned valid = 0xFu;
+                if (tx0 < txLo) valid &= 0xFu << (txLo - tx0);
+                if (tx0 + 3 > txHi) valid &= 0xFu >> (tx0 + 3 - txHi);
+                passBits &= valid;
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool pass = (passBits >> k) & 1u;
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    int wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&qn, __popcll(m));
-                    wbase = __shfl(wbase, 0);
-                    if (pass) queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * P + 4 * d + k);
-                }
+            // one LDS atomic per wave and round: the four pixel masks are queued back to back
+            const unsigned long long m0 = __ballot(passBits & 1u), m1 = __ballot(passBits & 2u),
+                                     m2 = __ballot(passBits & 4u), m3 = __ballot(passBits & 8u);
+            const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+            if (c0 + c1 + c2 + c3) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&qn, c0 + c1 + c2 + c3);
+                wbase = __shfl(wbase, 0);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int pos0 = y * P + 4 * d;
+                if (passBits & 1u) queue[wbase + __popcll(m0 & lt)] = (uint16_t)pos0;
+                if (passBits & 2u) queue[wbase + c0 + __popcll(m1 & lt)] = (uint16_t)(pos0 + 1);
+                if (passBits & 4u) queue[wbase + c0 + c1 + __popcll(m2 & lt)] = (uint16_t)(pos0 + 2);
+                if (passBits & 8u) queue[wbase + c0 + c1 + c2 + __popcll(m3 & lt)] = (uint16_t)(pos0 + 3);
             }
         }
     }
     __syncthreads();
     if (dbgStop == 2) return;
     // phase B: exact score for the survivors (all lanes busy); real corners (score >= tmin) are
-    // recorded in a second queue (it overwrites the first one from the front: entry qi is consumed
-    // before any corner index <= qi can be written, because cn never exceeds the number consumed)
+    // recorded in a second queue for the NMS
     const int nq = qn;
-    __syncthreads();
-    if (tid == 0) qn = 0;
-    __syncthreads();
     for (int base = 0; base < nq; base += NT) {
         const int qi = base + tid;
         int pos = 0, sc = 0;
@@ -428,90 +481,79 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
             sc = fast_score(&tile[pos], P);
             if (sc >= tmin) smap[pos] = (uint8_t)sc;
         }
-        __syncthreads(); // every entry of this round has been read
+        __syncthreads(); // every entry of this round has been read: cq may overwrite the queue up to here
         const bool isc = qi < nq && sc >= tmin;
         const unsigned long long m = __ballot(isc);
         if (m) {
             int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&qn, __popcll(m));
+            if (lane == 0) wbase = atomicAdd(&cn, __popcll(m));
             wbase = __shfl(wbase, 0);
-            if (isc) queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+            if (isc) cq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
         }
     }
     __syncthreads();
     if (dbgStop == 3) return;
-    // phase C1: strict 8-neighbour NMS of the corners only (all 8 reads issued together), decisions
-    // in registers; C2: losers are cleared, so the score map afterwards holds exactly the kept pixels
-    const int nc = qn;
-    {
-        unsigned long long loser = 0; // bit r: the corner this thread handled in round r lost (<= 38 rounds)
-        int r = 0;
-        for (int qi = tid; qi < nc; qi += NT, r++) {
-            const int pos = queue[qi];
+    // phase C: strict 8-neighbour NMS of the corners only (all 8 reads issued together; the score map
+    // is not modified, so every comparison sees the true scores).  Survivors are compacted into kq
+    // as pos | score<<16; the cell uses iniTh if any survivor reaches it, else minTh; the output order
+    // is row-major = ascending pos, obtained by ranking the (few) selected survivors against each other.
+    const int nc = cn;
+    bool sawIni = false;
+    for (int base = 0; base < nc; base += NT) {
+        const int qi = base + tid;
+        bool keep = false;
+        uint32_t ent = 0;
+        if (qi < nc) {
+            const int pos = cq[qi];
             const int s0 = smap[pos];
             const int n0 = smap[pos - 1], n1 = smap[pos + 1], n2 = smap[pos - P - 1], n3 = smap[pos - P],
                       n4 = smap[pos - P + 1], n5 = smap[pos + P - 1], n6 = smap[pos + P], n7 = smap[pos + P + 1];
             const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-            if (!(s0 > mx)) loser |= 1ull << r;
+            keep = s0 > mx; // s0 >= min(iniTh, minTh) already (phase B)
+            ent = (uint32_t)pos | ((uint32_t)s0 << 16);
+            sawIni |= keep && s0 >= iniTh;
         }
-        __syncthreads(); // every comparison was made on the untouched map
-        r = 0;
-        for (int qi = tid; qi < nc; qi += NT, r++)
-            if ((loser >> r) & 1ull) smap[queue[qi]] = 0;
-    }
-    __syncthreads();
-    // phase C3: ordered pass over a contiguous run of zone pixels per thread (row-major): a non-zero
-    // score is a kept pixel; kept-at-minTh / kept-at-iniTh bit masks, one block-wide OR and one scan.
-    const int RL = (nz + NT - 1) / NT; // the host picks NT so that RL <= 64 (one mask bit per pixel of the run)
-    unsigned long long keptMin = 0, keptIni = 0;
-    const int start = tid * RL;
-    {
-        int y = 0, x = 0;
-        if (start < nz) {
-            y = fast_div((unsigned)start, c.mZw);
-            x = start - y * zw;
-        }
-        for (int k = 0; k < RL; k++) {
-            const int idx = start + k;
-            if (idx >= nz) break;
-            const int s = smap[(y + 3) * P + x + txLo];
-            if (s > 0 && s >= minTh) keptMin |= 1ull << k;
-            if (s > 0 && s >= iniTh) keptIni |= 1ull << k;
-            if (++x == zw) {
-                x = 0;
-                y++;
-            }
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&kn, __popcll(m));
+            wbase = __shfl(wbase, 0);
+            if (keep) kq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = ent;
         }
     }
-    if (dbgStop == 4) {
-        if (keptMin == 0x123456789ull) cellCount[0] = (int)keptIni;
-        return;
-    }
-    const bool anyIni = __syncthreads_or(keptIni != 0ull) != 0;
-    unsigned long long sel = anyIni ? keptIni : keptMin;
-    const int cnt = __popcll(sel);
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) waveTot[wave] = incl;
-    __syncthreads();
-    int o = incl - cnt;
-    for (int w = 0; w < wave && w < NW; w++) o += waveTot[w];
+    const bool anyIni = __syncthreads_or(sawIni) != 0; // also orders the kq writes before the reads below
+    if (dbgStop == 4) return;
+    const int th = anyIni ? iniTh : minTh;
+    const int nk = kn;
     uint32_t* out = cand + (size_t)img * candImgStride + c.slotBase;
-    while (sel) {
-        const int k = __ffsll((long long)sel) - 1;
-        sel &= sel - 1;
-        const int idx = start + k;
-        const int y = fast_div((unsigned)idx, c.mZw), x = idx - y * zw;
-        const int pos = (y + 3) * P + x + txLo;
-        if (o < c.slotCap)
-            out[o] = (uint32_t)(x + 3 + c.offX) | ((uint32_t)(y + 3 + c.offY) << 12) | ((uint32_t)smap[pos] << 24);
-        o++;
+    int mine = 0;
+    for (int i = tid; i < nk; i += NT) {
+        const uint32_t e = kq[i];
+        if ((int)(e >> 16) < th) continue;
+        const uint32_t pos = e & 0xFFFFu;
+        int rank = 0;
+        for (int j = 0; j < nk; j++) {
+            const uint32_t f = kq[j];
+            rank += ((int)(f >> 16) >= th) && ((f & 0xFFFFu) < pos);
+        }
+        const int y = fast_div(pos, mP), x = (int)pos - y * P; // tile coordinates
+        if (rank < c.slotCap)
+            out[rank] = (uint32_t)(x - ox + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((e >> 16) << 24);
+        mine++;
     }
-    if (tid == NT - 1) cellCount[(size_t)img * nCellsTotal + cell] = min(o, c.slotCap);
+    // number of outputs = number of selected survivors
+    {
+        int tot = mine;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0) waveTot[wave] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < NW; w++) t += waveTot[w];
+            cellCount[(size_t)img * nCellsTotal + cell] = min(t, c.slotCap);
+        }
+    }
 }
 
 // ------------------------------------------------------------------- K-QT
@@ -919,6 +961,11 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
             w.y = (int16_t)py;
             w.pad = 0;
             w.dest = dest;
+            w.roiOff = lg[level].roiOff;
+            w.pitch = lg[level].pitch;
+            w.w = (int16_t)lg[level].w;
+            w.h = (int16_t)lg[level].h;
+            w.pad2[0] = w.pad2[1] = 0;
             wimg[g] = w;
         }
         __syncthreads();
@@ -1040,8 +1087,11 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         g = fixList[f].y;
     }
     const OrbDescWork w = work[(size_t)img * capPerImg + g];
-    const OrbLevelGeom L = lg[w.level];
-    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + L.roiOff;
+    (void)lg;
+    struct {
+        int w, h, pitch;
+    } L = {w.w, w.h, w.pitch};
+    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + w.roiOff;
     uint8_t* raw = s_all[wave];
     uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave] + DESC_RAW_BYTES);
     uint8_t* bl = raw; // the blurred patch overwrites the raw patch once the horizontal pass is done
