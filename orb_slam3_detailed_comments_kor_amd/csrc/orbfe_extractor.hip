@@ -442,8 +442,9 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
         int mx0 = 0, mx1 = 0, my0 = 0, my1 = 0;
         build_pyr_ranges(nl, ex, xlo, xhi, c->pyrNtx, T, prx, &mx0, &mx1);
         build_pyr_ranges(nl, ey, ylo, yhi, c->pyrNty, T, pry, &my0, &my1);
-        c->pyrBuf0 = (int)align_up((size_t)((mx0 + 3) & ~3) * my0, 16);
-        c->pyrBuf1 = (int)align_up((size_t)((mx1 + 3) & ~3) * std::max(my1, 1), 16);
+        // + 16 B slack: the interpolation reads 3 aligned dwords per source row from its first pixel
+        c->pyrBuf0 = (int)align_up((size_t)((mx0 + 3) & ~3) * my0 + 16, 16);
+        c->pyrBuf1 = (int)align_up((size_t)((mx1 + 3) & ~3) * std::max(my1, 1) + 16, 16);
         if ((r = c->d_prx.ensure(prx.size())) < 0) return r;
         if ((r = c->d_pry.ensure(pry.size())) < 0) return r;
         HIP_TRY(hipMemcpy(c->d_prx.p, prx.data(), prx.size() * sizeof(OrbPyrRange), hipMemcpyHostToDevice));

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     __shared__ int lvXlo[ORBFE_MAX_LEVELS], lvXown[ORBFE_MAX_LEVELS], lvXneed[ORBFE_MAX_LEVELS];
     __shared__ int lvYlo[ORBFE_MAX_LEVELS], lvYown[ORBFE_MAX_LEVELS], lvYneed[ORBFE_MAX_LEVELS];
     __shared__ int lvRoi[ORBFE_MAX_LEVELS], lvPitch[ORBFE_MAX_LEVELS], lvXt[ORBFE_MAX_LEVELS], lvYt[ORBFE_MAX_LEVELS];
-    __shared__ unsigned lvRecip[ORBFE_MAX_LEVELS]; // ceil(2^32 / needed width), 0 when the width is 1
+    __shared__ unsigned lvRecip[ORBFE_MAX_LEVELS]; // ceil(2^32 / column groups per row), 0 when there is one
     if (tid < nlevels) {
         const OrbPyrRange X = rx[tid * ntx + ti], Y = ry[tid * nty + tj];
         lvXlo[tid] = X.lo;
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         lvPitch[tid] = lg[tid].pitch;
         lvXt[tid] = lg[tid].xtabOff;
         lvYt[tid] = lg[tid].ytabOff;
-        const int nw = X.needHi - X.lo;
-        lvRecip[tid] = nw > 1 ? (unsigned)(((1ull << 32) + (unsigned)nw - 1) / (unsigned)nw) : 0u;
+        const int ng = (X.needHi - X.lo + 3) >> 2; // groups of 4 columns per region row
+        lvRecip[tid] = ng > 1 ? (unsigned)(((1ull << 32) + (unsigned)ng - 1) / (unsigned)ng) : 0u;
     }
     __syncthreads();
     // stage the interpolation-table slices of every level (all loads in flight at once; the per-pixel
@@ -212,22 +212,48 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         const int dp = (nW + 3) & ~3;
         uint8_t* g = base + (uint32_t)lvRoi[l] + (size_t)ylo * gpitch + xlo;
         const int ownW = lvXown[l] - xlo, ownH = lvYown[l] - ylo;
-        // flat index over the needed region (no idle lanes at ragged region edges); idx / nW by reciprocal
+        // item = (row, group of 4 destination columns); flat index, idx / groups-per-row by reciprocal.
+        // Source pixels of the 4 columns span <= 9 bytes of each source row: 3 aligned dword LDS reads per
+        // row, bytes picked with v_alignbyte; 4 results leave as one dword LDS store.
+        const int nG = dp >> 2;
         const unsigned rcp = lvRecip[l];
-        for (int idx = tid; idx < nW * nH; idx += 256) {
+        for (int idx = tid; idx < nG * nH; idx += 256) {
             const int r = rcp ? (int)__umulhi((unsigned)idx, rcp) : idx;
-            const int c = idx - r * nW;
-            const OrbResizeX tX = xt[xo + c];
+            const int c0 = 4 * (idx - r * nG);
             const OrbResizeY tY = yt[yo + r];
-            const int sx = (int)tX.sx - srcLoX, sx1 = (int)tX.pad - srcLoX;
-            const uint8_t* S0 = S + ((int)tY.sy0 - srcLoY) * sp;
-            const uint8_t* S1 = S + ((int)tY.sy1 - srcLoY) * sp;
-            const int h0 = S0[sx] * (int)tX.a0 + S0[sx1] * (int)tX.a1;
-            const int h1 = S1[sx] * (int)tX.a0 + S1[sx1] * (int)tX.a1;
-            int v = ((((int)tY.b0 * (h0 >> 4)) >> 16) + (((int)tY.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            D[r * dp + c] = (uint8_t)v;
-            if (r < ownH && c < ownW) g[(size_t)r * gpitch + c] = (uint8_t)v;
+            OrbResizeX tX[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tX[k] = xt[xo + min(c0 + k, nW - 1)];
+            const int sxr0 = (int)tX[0].sx - srcLoX;
+            const int sbase = sxr0 & ~3;
+            const uint32_t* S0 = reinterpret_cast<const uint32_t*>(S + ((int)tY.sy0 - srcLoY) * sp + sbase);
+            const uint32_t* S1 = reinterpret_cast<const uint32_t*>(S + ((int)tY.sy1 - srcLoY) * sp + sbase);
+            const uint32_t d0 = S0[0], d1 = S0[1], d2 = S0[2];
+            const uint32_t e0 = S1[0], e1 = S1[1], e2 = S1[2];
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = (int)tX[k].sx - srcLoX - sbase; // 0..7; the right neighbour is byte i+1
+                const bool up = i >= 4;
+                // (sx, sx+1) as the low 16 bits; sx+1 instead of min(sx+1, w-1) is harmless: a1 == 0 there
+                const uint32_t p0 = __builtin_amdgcn_alignbyte(up ? d2 : d1, up ? d1 : d0, i & 3);
+                const uint32_t p1 = __builtin_amdgcn_alignbyte(up ? e2 : e1, up ? e1 : e0, i & 3);
+                const int a0 = tX[k].a0, a1 = tX[k].a1;
+                const int h0 = (int)(p0 & 0xFFu) * a0 + (int)((p0 >> 8) & 0xFFu) * a1;
+                const int h1 = (int)(p1 & 0xFFu) * a0 + (int)((p1 >> 8) & 0xFFu) * a1;
+                int v = ((((int)tY.b0 * (h0 >> 4)) >> 16) + (((int)tY.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                packed |= (uint32_t)v << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(D + r * dp + c0) = packed;
+            if (r < ownH && c0 < ownW) {
+                uint8_t* q = g + (size_t)r * gpitch + c0;
+                if (c0 + 4 <= ownW) {
+                    __builtin_memcpy(q, &packed, 4);
+                } else {
+                    for (int k = 0; c0 + k < ownW; k++) q[k] = (uint8_t)(packed >> (8 * k));
+                }
+            }
         }
         __syncthreads();
         srcLoX = xlo;
@@ -1282,15 +1308,16 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         const float fx0 = __fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b));
         const float fy1 = __fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a));
         const float fx1 = __fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b));
-        const int iy0 = __float2int_rn(fy0), ix0 = __float2int_rn(fx0);
-        const int iy1 = __float2int_rn(fy1), ix1 = __float2int_rn(fx1);
+        // cvRound (:113-118) = round-half-even: v_rndne_f32, reused by the fragility test below
+        const float ry0 = rintf(fy0), rx0 = rintf(fx0), ry1 = rintf(fy1), rx1 = rintf(fx1);
+        const int iy0 = (int)ry0, ix0 = (int)rx0, iy1 = (int)ry1, ix1 = (int)rx1;
         const int v0 = center[iy0 * DESC_BP + ix0];
         const int v1 = center[iy1 * DESC_BP + ix1];
         word[q] = __ballot(v0 < v1);
         if (MODE == 0) {
-            const float e0 = fabsf(fabsf(fy0 - (float)iy0) - 0.5f), e1 = fabsf(fabsf(fx0 - (float)ix0) - 0.5f);
-            const float e2 = fabsf(fabsf(fy1 - (float)iy1) - 0.5f), e3 = fabsf(fabsf(fx1 - (float)ix1) - 0.5f);
-            frag |= (e0 < FR) | (e1 < FR) | (e2 < FR) | (e3 < FR);
+            // |f - round(f)| > 0.5 - FR  <=>  f is within FR of a half-integer
+            const float TH = 0.5f - FR;
+            frag |= fmaxf(fmaxf(fabsf(fy0 - ry0), fabsf(fx0 - rx0)), fmaxf(fabsf(fy1 - ry1), fabsf(fx1 - rx1))) > TH;
         }
     }
     const size_t slot = (size_t)img * capPerImg + w.dest;
