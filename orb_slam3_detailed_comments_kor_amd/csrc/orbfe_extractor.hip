@@ -109,6 +109,7 @@ struct orbfe_ctx {
     size_t pyrStride = 0, candStride = 0, keyStride = 0, kpStride = 0;
     int nCells = 0, maxKp = 0, maxListCap = 0;
     size_t qtLdsBytes = 0;
+    int qtKeyOff = 0, qtKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256, fastKqOff = 0, fastCqOff = 0;
     uint32_t fastRecipP = 0;
     size_t fastLdsBytes = 0;
@@ -337,8 +338,15 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             nt = std::max(nt, c->fastThreadsOverride);
         c->fastThreads = nt;
     }
-    c->qtLdsBytes = sizeof(int) * (64 + (size_t)std::max(24 * maxLC, 1024));
+    c->qtKeyOff = 64 + std::max(24 * maxLC, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
+    c->qtLdsBytes = sizeof(int) * (size_t)c->qtKeyOff;
     if (c->qtLdsBytes > 160 * 1024) return ORBFE_ERR_ARGS; // nfeatures too large for one workgroup's LDS
+    // room for the key arrays (4 B key + 2 B node index each) while staying under 64 KB
+    c->qtKeyCap = 0;
+    if (c->qtLdsBytes + 6 * 1024 <= 64 * 1024) {
+        c->qtKeyCap = (int)std::min<size_t>(4096, (64 * 1024 - c->qtLdsBytes) / 6) & ~63;
+        c->qtLdsBytes += 6 * (size_t)c->qtKeyCap;
+    }
     return 0;
 }
 
@@ -581,7 +589,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // K-QT
         hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)ni), dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                            c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
-                           c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p, i0);
+                           c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p, i0,
+                           c->qtKeyOff, c->qtKeyCap);
         if (nsub == 1) rec(c, 3);
         // K-PACK
         hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(256), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,

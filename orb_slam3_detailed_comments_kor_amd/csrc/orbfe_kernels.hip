@@ -589,11 +589,13 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 #define QT_WAVES (QT_THREADS / WAVE)
 
 // exclusive scan of a[0..n) in LDS, in place; returns the total to every thread.
-__device__ int qt_scan(int* a, int n, int* wsum /* QT_WAVES + 1 */)
+// One barrier per 512-element chunk plus one at the end (every wave sums the <= 8 wave totals
+// itself; the totals are double buffered so that a chunk never overwrites values still being read).
+__device__ int qt_scan(int* a, int n, int* wsum /* 2 * QT_WAVES */)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int carry = 0;
-    for (int base = 0; base < n; base += QT_THREADS) {
+    int carry = 0, chunk = 0;
+    for (int base = 0; base < n; base += QT_THREADS, chunk ^= 1) {
         const int i = base + tid;
         const int v = i < n ? a[i] : 0;
         int x = v;
@@ -602,24 +604,20 @@ __device__ int qt_scan(int* a, int n, int* wsum /* QT_WAVES + 1 */)
             const int y = __shfl_up(x, off);
             if (lane >= off) x += y;
         }
-        if (lane == 63) wsum[wave] = x;
+        int* ws = wsum + chunk * QT_WAVES;
+        if (lane == 63) ws[wave] = x;
         __syncthreads();
-        if (wave == 0) {
-            const int w = lane < QT_WAVES ? wsum[lane] : 0;
-            int xs = w;
+        int prefix = 0, total = 0;
 #pragma unroll
-            for (int off = 1; off < QT_WAVES; off <<= 1) {
-                const int y = __shfl_up(xs, off);
-                if (lane >= off) xs += y;
-            }
-            if (lane < QT_WAVES) wsum[lane] = xs - w;
-            if (lane == QT_WAVES - 1) wsum[QT_WAVES] = xs;
+        for (int w = 0; w < QT_WAVES; w++) {
+            const int t = ws[w];
+            total += t;
+            if (w < wave) prefix += t;
         }
-        __syncthreads();
-        if (i < n) a[i] = x - v + wsum[wave] + carry;
-        carry += wsum[QT_WAVES];
-        __syncthreads();
+        if (i < n) a[i] = x - v + prefix + carry;
+        carry += total;
     }
+    __syncthreads();
     return carry;
 }
 
@@ -651,7 +649,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                                        uint32_t* __restrict__ keysAll, uint16_t* __restrict__ keyNodeAll,
                                                        size_t keyImgStride, uint32_t* __restrict__ lvlKp,
                                                        size_t kpImgStride, int32_t* __restrict__ lvlCount, int nlevels,
-                                                       int32_t* __restrict__ errFlag, int imgBase)
+                                                       int32_t* __restrict__ errFlag, int imgBase, int keyLdsOff /* ints */,
+                                                       int keyLdsCap /* keys */)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -685,18 +684,46 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     const int32_t* cnts = cellCount + (size_t)img * nCellsTotal + L.cellBase;
     const OrbCellGeom* cells = cg + L.cellBase;
 
+    // Every pass walks the key arrays twice; keep them in LDS when the level's candidates fit (the
+    // usual case), else in the global scratch arrays.  (Generic pointers: flat loads serve both.)
+    {
+        int part = 0;
+        for (int ci = tid; ci < L.nCells; ci += QT_THREADS) part += cnts[ci];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) wsum[wave] = part;
+        __syncthreads();
+        int total = 0;
+        for (int w = 0; w < QT_WAVES; w++) total += wsum[w];
+        __syncthreads();
+        if (total <= keyLdsCap) {
+            keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
+            keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
+        }
+    }
+
     // ---- gather the per-cell lists into one ordered key array (cells row-major, :787-853)
+    // Flat over the output index: every thread finds the cell of its key by binary search in the
+    // chunk's prefix array, so all global loads of the copy are independent (a per-cell copy loop
+    // serialised three dependent global loads per cell and dominated this kernel).
     int n = 0;
+    int* gbase = gscan + QT_THREADS; // slot base of the chunk's cells
     for (int cbase = 0; cbase < L.nCells; cbase += QT_THREADS) {
         const int nc = min(QT_THREADS, L.nCells - cbase);
-        if (tid < nc) gscan[tid] = cnts[cbase + tid];
+        if (tid < nc) {
+            gscan[tid] = cnts[cbase + tid];
+            gbase[tid] = cells[cbase + tid].slotBase;
+        }
         __syncthreads();
-        const int tot = qt_scan(gscan, nc, wsum);
-        for (int ci = wave; ci < nc; ci += QT_WAVES) {
-            const int cnt = cnts[cbase + ci];
-            const int dst = n + gscan[ci];
-            const uint32_t* src = candImg + cells[cbase + ci].slotBase;
-            for (int s = lane; s < cnt; s += 64) keys[dst + s] = src[s];
+        const int tot = qt_scan(gscan, nc, wsum); // exclusive prefix of the counts
+        for (int i = tid; i < tot; i += QT_THREADS) {
+            int lo = 0, hi = nc - 1; // last cell whose prefix <= i (cells with zero keys share a prefix; take the last)
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (gscan[mid] <= i) lo = mid;
+                else hi = mid - 1;
+            }
+            keys[n + i] = candImg[gbase[lo] + (i - gscan[lo])];
         }
         n += tot;
         __syncthreads();
