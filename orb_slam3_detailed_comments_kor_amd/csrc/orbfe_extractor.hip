@@ -142,6 +142,8 @@ struct orbfe_ctx {
     DevBuf<int> d_taps;
     DevBuf<float4> d_patternF;
     PinBuf<int32_t> h_misc, h_n, h_mono;
+    PinBuf<float> h_kps;
+    PinBuf<uint8_t> h_desc;
     PinBuf<int4> h_fix, h_fixAB; // pinned: h_fixAB is read by the fix-up kernel directly (zero-copy)
     size_t imgPitch = 0, imgStride = 0;
 
@@ -715,7 +717,7 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_misc.release(); c->d_fix.release(); c->d_kps.release(); c->d_kb8.release(); c->d_rays.release();
     c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
     c->d_taps.release(); c->d_patternF.release();
-    c->h_misc.release(); c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release();
+    c->h_misc.release(); c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release(); c->h_kps.release(); c->h_desc.release();
     if (c->evReady)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -877,16 +879,30 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
         HIP_TRY(hipMemcpy(&err, c->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost));
         if (err) return ORBFE_ERR_STATE;
     }
+    // two slab downloads into pinned staging (128 small copies cost ~1 ms for 64 images), then the
+    // rows each image actually produced are copied out
+    int nmax = 0;
+    for (int i = 0; i < nimg; i++) nmax = std::max(nmax, c->h_n.p[i]);
+    if (nimg > 1 && nmax > 0) {
+        const size_t K = (size_t)cap_per_img;
+        if ((r = c->h_kps.ensure((size_t)nimg * K * 7)) < 0) return r;
+        if ((r = c->h_desc.ensure((size_t)nimg * K * 32)) < 0) return r;
+        HIP_TRY(hipMemcpyAsync(c->h_kps.p, c->d_kps.p, (size_t)nimg * K * 28, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_desc.p, c->d_desc.p, (size_t)nimg * K * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     for (int i = 0; i < nimg; i++) {
         const int n = c->h_n.p[i];
         n_out[i] = n;
         if (mono_out) mono_out[i] = c->h_mono.p[i];
-        if (n > 0) {
-            HIP_TRY(hipMemcpyAsync((uint8_t*)kps + (size_t)i * cap_per_img * sizeof(orbfe_kp),
-                                   c->d_kps.p + (size_t)i * cap_per_img * 7, (size_t)n * sizeof(orbfe_kp),
-                                   hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(desc + (size_t)i * cap_per_img * 32, c->d_desc.p + (size_t)i * cap_per_img * 32,
-                                   (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        if (n <= 0) continue;
+        if (nimg > 1) {
+            std::memcpy((uint8_t*)kps + (size_t)i * cap_per_img * sizeof(orbfe_kp),
+                        c->h_kps.p + (size_t)i * cap_per_img * 7, (size_t)n * sizeof(orbfe_kp));
+            std::memcpy(desc + (size_t)i * cap_per_img * 32, c->h_desc.p + (size_t)i * cap_per_img * 32, (size_t)n * 32);
+        } else {
+            HIP_TRY(hipMemcpyAsync((uint8_t*)kps, c->d_kps.p, (size_t)n * sizeof(orbfe_kp), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(desc, c->d_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, s));
         }
     }
     HIP_TRY(hipStreamSynchronize(s));

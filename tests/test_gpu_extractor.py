@@ -273,3 +273,29 @@ def test_device_batch_with_row_pitch(pkg, oracle):
         for j, f in enumerate(FIELDS):
             got[f] = raw[:, j].view(np.int32) if f in ("octave", "class_id") else raw[:, j]
         _same(got, rkps, d_desc[i, : n[i]].cpu().numpy(), rdesc)
+
+
+@pytest.mark.parametrize("hw,nf", [((1080, 1920), 2000), ((2160, 3840), 3000)])
+def test_large_frames(pkg, oracle, hw, nf):
+    """Full-HD and 4K frames (thousands of cells per level)."""
+    img = _frame(pkg, hw[0], hw[1], 555)
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    mono, kps, desc = ex(img, (0, 0))
+    rmono, rkps, rdesc = ref.extract(img, (0, 0))
+    assert mono == rmono
+    _same(kps, rkps, desc, rdesc)
+    assert np.array_equal(ex.image_pyramid_level(7), ref.level(7))
+
+
+def test_many_candidates_use_global_key_arrays(pkg, oracle):
+    """> 4096 candidates in one level: K-QT keeps the key arrays in global memory instead of LDS."""
+    rng = np.random.default_rng(10)
+    img = rng.integers(0, 256, size=(480, 640), dtype=np.uint8)
+    ex = pkg.ORBextractor(1500, 1.2, 4, 20, 7)
+    ref = oracle.Extractor(1500, 1.2, 4, 20, 7)
+    mono, kps, desc = ex(img, (0, 0))
+    rmono, rkps, rdesc = ref.extract(img, (0, 0))
+    assert len(ref.candidates(0)) > 4096
+    assert mono == rmono
+    _same(kps, rkps, desc, rdesc)
