@@ -532,7 +532,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
 {
     int r;
     if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
-    if (capPerImg < c->maxKp) return ORBFE_ERR_ARGS;
+    if (capPerImg < c->maxKp || capPerImg > 65535 || nimg > 32767) return ORBFE_ERR_ARGS; // fix-list packing
     if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
     hipStream_t s = c->stream;
     const int nl = c->nlevels;
@@ -635,13 +635,13 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         const float factorPI = (float)(3.14159265358979323846 / 180.f);
         int nFix = 0;
         for (size_t i = 0; i < nFrag; i++) {
-            const int4 e = c->h_fix.p[1 + i];
-            float angDeg;
-            std::memcpy(&angDeg, &e.z, 4);
+            const int4 e = c->h_fix.p[1 + i]; // {img<<16|g, angle, device cos, device sin} as float bits
+            float angDeg, ac, bc;
+            std::memcpy(&angDeg, &e.y, 4);
+            std::memcpy(&ac, &e.z, 4);
+            std::memcpy(&bc, &e.w, 4);
             const float ang = angDeg * factorPI;
-            const float a = cosf(ang), b = sinf(ang);
-            float bc, ac;
-            orbfe_sincos_cr(ang, &bc, &ac);
+            const float a = cosf(ang), b = sinf(ang); // what the reference evaluates (src/ORBextractor.cc:111)
             if (a != ac || b != bc) {
                 int4 o = e;
                 std::memcpy(&o.z, &a, 4);

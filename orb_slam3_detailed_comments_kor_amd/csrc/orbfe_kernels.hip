@@ -1121,9 +1121,9 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           float* __restrict__ kpsOut, uint8_t* __restrict__ descOut,
                                                           const int* __restrict__ taps,
                                                           const float4* __restrict__ patternF,
-                                                          int4* fixList /* MODE 0: out {img, g, angle bits, 0} after
-                                                                           a 16-B header whose first word is the
-                                                                           count; MODE 1: in {img, g, a bits, b bits} */,
+                                                          int4* fixList /* MODE 0: out {img<<16|g, angle, a, b} (float
+                                                                           bits) after a 16-B header whose first word
+                                                                           is the count; MODE 1: in {img<<16|g, -, a, b} */,
                                                           int nFix, int listFragile, int imgBase)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
@@ -1136,8 +1136,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     } else {
         const int f = blockIdx.x * 4 + wave;
         if (f >= nFix) return;
-        img = fixList[f].x;
-        g = fixList[f].y;
+        img = fixList[f].x >> 16;
+        g = fixList[f].x & 0xFFFF;
     }
     const OrbDescWork w = work[(size_t)img * capPerImg + g];
     (void)lg;
@@ -1325,9 +1325,11 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     const uint8_t* center = bl + 18 * DESC_BP + 18;
     unsigned long long word[4];
     bool frag = false;
-    // a tap is fragile when its pre-rounding coordinate is within FR of a half-integer: a 1-ulp
-    // change of a or b moves it by at most 13*2^-24*2 < 2e-6.
-    const float FR = 4e-6f;
+    // A tap is fragile when its pre-rounding coordinate v = fl(fl(x*b) + fl(y*a)) is within FR of a
+    // half-integer.  With a, b each off by at most 1 ulp (2^-24, |a|,|b| <= 1) and |x|,|y| <= 13,
+    // |v| < 18.4:  |dv| <= (|x|+|y|) 2^-24 + ulp(x*b) + ulp(y*a) + ulp(v)
+    //                   <= 1.55e-6 + 2 * 9.5e-7 + 1.9e-6 = 5.4e-6  ->  FR = 6e-6.
+    const float FR = 6e-6f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float4 pt = patternF[q * 64 + lane]; // (x0, y0, x1, y1) of test bit q*64+lane
@@ -1358,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             kpsOut[slot * 7 + 3] = angle;
             if (anyFrag && listFragile) {
                 const int idx = atomicAdd(reinterpret_cast<int*>(fixList), 1);
-                fixList[1 + idx] = make_int4(img, g, __float_as_int(angle), 0);
+                fixList[1 + idx] = make_int4((img << 16) | g, __float_as_int(angle), __float_as_int(a), __float_as_int(b));
             }
         }
     }
