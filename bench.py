@@ -142,8 +142,12 @@ def main():
 
     ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank,
                           trig=pkg.binding.TRIG_LIBM if args.trig == "libm" else pkg.binding.TRIG_CR)
-    stream = torch.cuda.current_stream()
-    ex.set_stream(stream.cuda_stream)  # kernels run on torch's current stream
+    # One explicit stream for everything: the extractor's kernels, torch's ops and the RCCL collective
+    # (which orders itself after the current stream) -- the legacy null stream would not order a
+    # non-blocking stream.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ex.set_stream(stream.cuda_stream)
     cap = ex.max_keypoints(H, W)
     xch = DescriptorExchange(B, cap, dev, world, rank)
     d_desc = xch.desc_view()
