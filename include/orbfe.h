@@ -184,6 +184,26 @@ int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 *
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
 
+/* DBoW2 vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) in CSR form: children of node i are
+ * child_ids[child_off[i] .. child_off[i+1]) in stored order, node 0 is the root; leaves carry word id + weight. */
+typedef struct {
+    int nnodes;
+    const uint8_t* node_desc;   /* nnodes * 32                         */
+    const int32_t* child_off;   /* nnodes + 1                          */
+    const int32_t* child_ids;   /* child_off[nnodes]                   */
+    const int32_t* node_word;   /* word id of a leaf, -1 otherwise     */
+    const double* node_weight;  /* WordValue of a leaf (idf weight)    */
+    int L;                      /* depth levels m_L                    */
+} orbfe_vocab;
+typedef struct orbfe_vocab_dev orbfe_vocab_dev; /* the tree resident on one device */
+int orbfe_vocab_upload(orbfe_vocab_dev** out, int device, const orbfe_vocab* v);
+void orbfe_vocab_free(orbfe_vocab_dev*);
+/* TemplatedVocabulary::transform(feature, word_id, weight, &nid, levelsup) (:1217-1259) for n features in one
+ * launch (Frame::ComputeBoW, src/Frame.cc:724-731, uses levelsup = 4).  The caller folds the per-feature
+ * results into BowVector::addWeight / FeatureVector::addFeature in feature order (:1147-1160). */
+int orbfe_vocab_transform(orbfe_vocab_dev*, const uint8_t* feats, int n, int levelsup, int32_t* word_id,
+                          int32_t* node_id, double* weight);
+
 /* Device time (ms, hipEvents) of the matcher kernel launched by the last matcher call of this thread. */
 float orbfe_matcher_last_kernel_ms(void);
 

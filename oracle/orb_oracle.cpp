@@ -1199,6 +1199,40 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
     return np;
 }
 
+// TemplatedVocabulary::transform for one feature, reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259
+// (F::distance = FORB::distance = Hamming, FORB.cpp:81-101).  The tree is given in CSR form.
+void orb_oracle_vocab_transform(int nnodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_ids,
+                                const int32_t* node_word, const double* node_weight, int L, const uint8_t* feats, int n,
+                                int levelsup, int32_t* word_id, int32_t* node_id, double* weight)
+{
+    (void)nnodes;
+    for (int f = 0; f < n; f++) {
+        const uint8_t* feature = feats + 32 * (size_t)f;
+        const int nid_level = L - levelsup;
+        int nid = 0; // root when nid_level <= 0
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
+            if (c0 >= c1) break; // malformed: inner node without children
+            final_id = child_ids[c0];
+            double best_d = DescriptorDistance(feature, node_desc + 32 * (size_t)final_id);
+            for (int k = c0 + 1; k < c1; k++) {
+                const int id = child_ids[k];
+                const double d = DescriptorDistance(feature, node_desc + 32 * (size_t)id);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = id;
+                }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (child_off[final_id] < child_off[final_id + 1]);
+        word_id[f] = node_word[final_id];
+        weight[f] = node_weight[final_id];
+        node_id[f] = nid;
+    }
+}
+
 // Frame::ComputeStereoMatches, reference src/Frame.cc:797-967.  L / R are the oracle extractors that
 // processed the left / right image (their mvImagePyramid is read for the SAD refinement).
 int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_oracle_kp* mvKeys,

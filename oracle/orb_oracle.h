@@ -110,6 +110,12 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
+/* DBoW2 TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259) per feature:
+ * leaf word id, leaf weight and the node id `levelsup` levels above the leaves.  Tree in CSR form:
+ * children of node i = child_ids[child_off[i] .. child_off[i+1]) in stored order; node 0 is the root. */
+void orb_oracle_vocab_transform(int nnodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_ids,
+                                const int32_t* node_word, const double* node_weight, int L, const uint8_t* feats, int n,
+                                int levelsup, int32_t* word_id, int32_t* node_id, double* weight);
 /* Frame::ComputeStereoMatches src/Frame.cc:797-967 (rectified stereo).  L, R = the oracle extractors that
  * processed the left / right image.  uRight/depth sized N (left keypoints), -1 = no match.  Returns #matches. */
 int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_oracle_kp* kpsL, const uint8_t* descL,

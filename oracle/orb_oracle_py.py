@@ -94,6 +94,9 @@ def lib():
         L.orb_oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                         C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                         C.c_void_p, C.c_void_p]
+        L.orb_oracle_vocab_transform.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
         L.orb_oracle_kb8_unproject.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
@@ -356,6 +359,19 @@ def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
     n = lib().orb_oracle_compute_stereo_matches(exL.h, exR.h, _p(kpsL), _p(dL), len(kpsL), _p(kpsR), _p(dR),
                                                 len(kpsR), mb, mbf, _p(uR), _p(dep))
     return n, uR, dep
+
+
+def vocab_transform(vocab, feats, levelsup=4):
+    """vocab = dict(desc[nn,32] u8, child_off[nn+1] i32, child_ids i32, word[nn] i32, weight[nn] f64, L)."""
+    feats = np.ascontiguousarray(feats, np.uint8).reshape(-1, 32)
+    n = len(feats)
+    w = np.zeros(n, np.int32)
+    nid = np.zeros(n, np.int32)
+    wt = np.zeros(n, np.float64)
+    lib().orb_oracle_vocab_transform(len(vocab["word"]), _p(vocab["desc"]), _p(vocab["child_off"]),
+                                     _p(vocab["child_ids"]), _p(vocab["word"]), _p(vocab["weight"]), int(vocab["L"]),
+                                     _p(feats), n, levelsup, _p(w), _p(nid), _p(wt))
+    return w, nid, wt
 
 
 def kb8_unproject(params8, uv):

@@ -38,6 +38,11 @@ class _BowArgs(C.Structure):
                 ("Nleft", C.c_int), ("nnratio", C.c_float), ("check_orientation", C.c_int), ("variant", C.c_int)]
 
 
+class _Vocab(C.Structure):
+    _fields_ = [("nnodes", C.c_int), ("node_desc", C.c_void_p), ("child_off", C.c_void_p), ("child_ids", C.c_void_p),
+                ("node_word", C.c_void_p), ("node_weight", C.c_void_p), ("L", C.c_int)]
+
+
 class _TriArgs(C.Structure):
     _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("hasMP1", C.c_void_p), ("kp1_xy", C.c_void_p),
                 ("angle1", C.c_void_p), ("octave1", C.c_void_p), ("uRight1", C.c_void_p), ("fv1", _FV),
@@ -118,6 +123,9 @@ def lib():
         L.orbfe_search_bow_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_BowArgs), C.POINTER(C.c_void_p), C.c_void_p]
         L.orbfe_kb8_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_matcher_last_kernel_ms.restype = C.c_float
+        L.orbfe_vocab_upload.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(_Vocab)]
+        L.orbfe_vocab_free.argtypes = [C.c_void_p]
+        L.orbfe_vocab_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -128,7 +136,7 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
-           "orbfe_matcher_last_kernel_ms"]
+           "orbfe_matcher_last_kernel_ms", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
 
 
 def _p(a):
@@ -417,6 +425,58 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
     pairs = np.zeros((max(len(d1), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
     return pairs[:n].copy()
+
+
+class Vocabulary:
+    """DBoW2 vocabulary tree resident on the device (TemplatedVocabulary.h); vocab = the CSR dict of
+    synth.make_vocabulary / an ORBvoc.txt loader."""
+
+    def __init__(self, vocab, device=0):
+        self.L = lib()
+        self._keep = {k: np.ascontiguousarray(vocab[k]) for k in ("desc", "child_off", "child_ids", "word", "weight")}
+        k = self._keep
+        v = _Vocab(len(k["word"]), k["desc"].ctypes.data, k["child_off"].ctypes.data, k["child_ids"].ctypes.data,
+                   k["word"].ctypes.data, k["weight"].ctypes.data, int(vocab["L"]))
+        h = C.c_void_p()
+        _chk(self.L.orbfe_vocab_upload(C.byref(h), device, C.byref(v)), "orbfe_vocab_upload")
+        self.h = h
+
+    def transform(self, feats, levelsup=4):
+        """Per feature: (word id, node id `levelsup` levels above the leaves, weight)."""
+        feats = np.ascontiguousarray(feats, np.uint8).reshape(-1, 32)
+        n = len(feats)
+        w = np.zeros(n, np.int32)
+        nid = np.zeros(n, np.int32)
+        wt = np.zeros(n, np.float64)
+        _chk(self.L.orbfe_vocab_transform(self.h, _p(feats), n, levelsup, _p(w), _p(nid), _p(wt)), "orbfe_vocab_transform")
+        return w, nid, wt
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_vocab_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def bow_from_transform(word, node, weight):
+    """BowVector / FeatureVector as TemplatedVocabulary::transform builds them (:1147-1160, TF_IDF + L1):
+    returns (bow dict word -> normalised weight, CSR feature vector (node_ids, offsets, indices))."""
+    bow = {}
+    keep = weight > 0  # w > 0: not a stop word
+    for w_id, w in zip(word[keep].tolist(), weight[keep].tolist()):
+        bow[w_id] = bow.get(w_id, 0.0) + w
+    norm = sum(abs(v) for v in (bow[k] for k in sorted(bow)))
+    if norm > 0:
+        bow = {k: bow[k] / norm for k in sorted(bow)}
+    idx = np.nonzero(keep)[0].astype(np.int32)
+    order = np.argsort(node[idx], kind="stable")
+    nodes_sorted = node[idx][order]
+    node_ids, counts = np.unique(nodes_sorted, return_counts=True)
+    offsets = np.zeros(len(node_ids) + 1, np.int32)
+    offsets[1:] = np.cumsum(counts)
+    return bow, (node_ids.astype(np.uint32), offsets, idx[order])
 
 
 def kb8_unproject(params8, uv, device=0):

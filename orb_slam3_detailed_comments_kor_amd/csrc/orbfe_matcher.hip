@@ -338,6 +338,53 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
 }
 
+// ------------------------------------------------------------------ K-VOC
+// DBoW2 TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259): walk the
+// vocabulary tree, at every level the child with the smallest Hamming distance (first minimum in stored
+// order, strict '<').  16 lanes per feature: one child per lane, group-min over (distance<<8 | order).
+__global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restrict__ nodeDesc,
+                                                         const int32_t* __restrict__ childOff,
+                                                         const int32_t* __restrict__ childIds,
+                                                         const int32_t* __restrict__ nodeWord,
+                                                         const double* __restrict__ nodeWeight, int L,
+                                                         const uint8_t* __restrict__ feats, int n, int levelsup,
+                                                         int32_t* __restrict__ wordOut, int32_t* __restrict__ nodeOut,
+                                                         double* __restrict__ weightOut)
+{
+    const int sub = threadIdx.x & 15;
+    const int f = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = f < n;
+    const Desc df = live ? load_desc(feats + (size_t)f * 32) : Desc{};
+    const int nidLevel = L - levelsup;
+    int nid = 0, finalId = 0, level = 0;
+    bool done = !live;
+    // all 16 lanes of a group follow the same path; groups of a wave may finish at different depths
+    for (int guard = 0; guard < 64; guard++) {
+        const int c0 = done ? 0 : childOff[finalId], c1 = done ? 0 : childOff[finalId + 1];
+        if (c0 >= c1) done = true; // leaf
+        if (__ballot(!done) == 0ull) break;
+        unsigned best = 0xFFFFFFFFu;
+        if (!done)
+            for (int k = c0 + sub; k < c1; k += 16) {
+                const int id = childIds[k];
+                const unsigned d = (unsigned)hamming(df, load_desc(nodeDesc + (size_t)id * 32));
+                best = min(best, (d << 20) | (unsigned)(k - c0));
+            }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off, 16));
+        if (!done) {
+            finalId = childIds[c0 + (int)(best & 0xFFFFFu)];
+            level++;
+            if (level == nidLevel) nid = finalId;
+        }
+    }
+    if (live && sub == 0) {
+        wordOut[f] = nodeWord[finalId];
+        weightOut[f] = nodeWeight[finalId];
+        nodeOut[f] = nid;
+    }
+}
+
 // ------------------------------------------------------------------ K-KB8
 __global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__ P, const float* __restrict__ uv,
                                                        int n, float* __restrict__ rays)
@@ -751,6 +798,87 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
 }
 
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
+
+struct orbfe_vocab_dev {
+    int device, nnodes, L;
+    uint8_t* desc;
+    int32_t *childOff, *childIds, *word;
+    double* weight;
+};
+
+int orbfe_vocab_upload(orbfe_vocab_dev** out, int device, const orbfe_vocab* v)
+{
+    if (!out || !v || v->nnodes < 1 || !v->node_desc || !v->child_off || !v->node_word || !v->node_weight || v->L < 1)
+        return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    const int nchild = v->child_off[v->nnodes];
+    if (nchild < 0 || (nchild && !v->child_ids)) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < v->nnodes; i++)
+        if (v->child_off[i] > v->child_off[i + 1] || v->child_off[i + 1] - v->child_off[i] >= (1 << 20)) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nchild; i++)
+        if (v->child_ids[i] <= 0 || v->child_ids[i] >= v->nnodes) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    orbfe_vocab_dev* d = new orbfe_vocab_dev();
+    d->device = device;
+    d->nnodes = v->nnodes;
+    d->L = v->L;
+    bool ok = hipMalloc((void**)&d->desc, (size_t)v->nnodes * 32) == hipSuccess &&
+              hipMalloc((void**)&d->childOff, (size_t)(v->nnodes + 1) * 4) == hipSuccess &&
+              hipMalloc((void**)&d->childIds, (size_t)std::max(nchild, 1) * 4) == hipSuccess &&
+              hipMalloc((void**)&d->word, (size_t)v->nnodes * 4) == hipSuccess &&
+              hipMalloc((void**)&d->weight, (size_t)v->nnodes * 8) == hipSuccess;
+    ok = ok && hipMemcpy(d->desc, v->node_desc, (size_t)v->nnodes * 32, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d->childOff, v->child_off, (size_t)(v->nnodes + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         (nchild == 0 || hipMemcpy(d->childIds, v->child_ids, (size_t)nchild * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+         hipMemcpy(d->word, v->node_word, (size_t)v->nnodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d->weight, v->node_weight, (size_t)v->nnodes * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        orbfe_vocab_free(d);
+        return ORBFE_ERR_NODEV;
+    }
+    *out = d;
+    return 0;
+}
+
+void orbfe_vocab_free(orbfe_vocab_dev* d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipFree(d->desc);
+    (void)hipFree(d->childOff);
+    (void)hipFree(d->childIds);
+    (void)hipFree(d->word);
+    (void)hipFree(d->weight);
+    delete d;
+}
+
+int orbfe_vocab_transform(orbfe_vocab_dev* d, const uint8_t* feats, int n, int levelsup, int32_t* word_id,
+                          int32_t* node_id, double* weight)
+{
+    if (!d || n < 0 || (n && (!feats || !word_id || !node_id || !weight))) return ORBFE_ERR_ARGS;
+    if (n == 0) return 0;
+    int r;
+    if ((r = select_device(d->device)) < 0) return r;
+    Scratch s(d->device);
+    uint8_t* dF;
+    int32_t *dW, *dN;
+    double* dWt;
+    if ((r = s.up(&dF, feats, (size_t)n * 32)) < 0) return r;
+    if ((r = s.up<int32_t>(&dW, nullptr, (size_t)n)) < 0) return r;
+    if ((r = s.up<int32_t>(&dN, nullptr, (size_t)n)) < 0) return r;
+    if ((r = s.up<double>(&dWt, nullptr, (size_t)n)) < 0) return r;
+    {
+        KernelTimer timer;
+        hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, 0, d->desc, d->childOff,
+                           d->childIds, d->word, d->weight, d->L, dF, n, levelsup, dW, dN, dWt);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(word_id, dW, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(node_id, dN, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(weight, dWt, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int orbfe_kb8_unproject(int device, const float* P, const float* uv, int n, float* rays)
 {

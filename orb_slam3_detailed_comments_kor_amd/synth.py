@@ -105,3 +105,50 @@ def make_feature_vectors(desc, seed, branching=10, depth=2):
     offsets = np.zeros(len(node_ids) + 1, np.int32)
     offsets[1:] = np.cumsum(counts)
     return node_ids.astype(np.uint32), offsets, order.astype(np.int32)
+
+
+def make_vocabulary(seed, k=10, L=4, ragged=True):
+    """Synthetic DBoW2-style vocabulary tree (the real ORBvoc.txt, k=10 L=6, is not available here).
+
+    Breadth-first node ids like DBoW2's loader produces; node 0 is the root.  With ragged=True some
+    inner nodes have fewer than k children and some branches end early (leaves at different depths),
+    which DBoW2 trees built by k-means can show.  Children descriptors are noisy copies of their parent
+    so that descending the tree is meaningful.  Returns the CSR dict used by the oracle and the product.
+    """
+    rng = np.random.default_rng(int(seed))
+    desc = [np.zeros(32, np.uint8)]
+    children = [[]]
+    depth = [0]
+    frontier = [0]
+    for lvl in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            if ragged and lvl > 1 and rng.uniform() < 0.08:
+                continue  # early leaf
+            nk = k if not ragged else int(rng.integers(max(2, k - 3), k + 1))
+            for _ in range(nk):
+                bits = np.unpackbits(desc[p]) if lvl > 1 else rng.integers(0, 2, 256, dtype=np.uint8)
+                flip = rng.permutation(256)[: int(rng.integers(20, 70))]
+                bits = bits.copy()
+                bits[flip] ^= 1
+                desc.append(np.packbits(bits))
+                children.append([])
+                depth.append(lvl)
+                children[p].append(len(desc) - 1)
+                nxt.append(len(desc) - 1)
+        frontier = nxt
+    nn = len(desc)
+    child_off = np.zeros(nn + 1, np.int32)
+    for i in range(nn):
+        child_off[i + 1] = child_off[i] + len(children[i])
+    child_ids = np.array([c for ch in children for c in ch], np.int32)
+    word = -np.ones(nn, np.int32)
+    weight = np.zeros(nn, np.float64)
+    wid = 0
+    for i in range(nn):
+        if not children[i] and i != 0:
+            word[i] = wid
+            wid += 1
+            weight[i] = float(rng.uniform(0.5, 9.0)) if rng.uniform() > 0.02 else 0.0  # a few stop words
+    return dict(desc=np.ascontiguousarray(np.stack(desc)), child_off=child_off, child_ids=child_ids, word=word,
+                weight=weight, L=L)

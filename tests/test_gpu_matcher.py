@@ -145,3 +145,34 @@ def test_kb8_unproject(pkg, oracle):
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)
     assert rel.max() <= 2.5e-7, rel.max()
     assert np.array_equal(got[0], [0, 0, 1])
+
+
+@pytest.mark.parametrize("k,L,ragged,levelsup", [(10, 4, True, 2), (10, 3, False, 4), (6, 5, True, 4), (17, 2, True, 1)])
+def test_vocabulary_transform(pkg, oracle, k, L, ragged, levelsup):
+    """DBoW2 transform on a synthetic tree: word, node and weight per feature exact,
+    then the BowVector / FeatureVector fold and a SearchByBoW on the resulting feature vectors."""
+    vocab = pkg.synth.make_vocabulary(40 + k + L, k, L, ragged)
+    d1, d2, a1, a2 = MI.descriptor_sets(900, 1000, 60 + L)
+    # descriptors near vocabulary nodes so that different features share words
+    leaves = np.nonzero(vocab["word"] >= 0)[0]
+    rng = np.random.default_rng(3)
+    pick = rng.choice(leaves, size=500)
+    bits = np.unpackbits(vocab["desc"][pick], axis=1)
+    for r in range(500):
+        bits[r, rng.permutation(256)[:20]] ^= 1
+    d1[:500] = np.packbits(bits, axis=1)
+    V = pkg.Vocabulary(vocab)
+    for d in (d1, d2):
+        w, nid, wt = V.transform(d, levelsup)
+        rw, rnid, rwt = oracle.vocab_transform(vocab, d, levelsup)
+        assert np.array_equal(w, rw) and np.array_equal(nid, rnid) and np.array_equal(wt, rwt)
+    w1, n1, wt1 = V.transform(d1, levelsup)
+    w2, n2, wt2 = V.transform(d2, levelsup)
+    bow1, fv1 = pkg.bow_from_transform(w1, n1, wt1)
+    bow2, fv2 = pkg.bow_from_transform(w2, n2, wt2)
+    assert abs(sum(bow1.values()) - 1.0) < 1e-9
+    mask = np.ones(len(d1), np.uint8)
+    n, m = pkg.search_bow(d1, mask, a1, fv1, d2, None, a2, fv2, 0, 0.7, True)
+    rn, rm = oracle.search_bow_kf_f(d1, mask, a1, fv1, d2, a2, fv2, -1, 0.7, True)
+    assert n == rn and np.array_equal(m, rm)
+    V.close()

@@ -62,3 +62,33 @@ def test_feature_vector_csr(oracle):
     for k in range(len(node_ids)):
         seg = indices[offsets[k]:offsets[k + 1]]
         assert (np.diff(seg) > 0).all()                   # ascending inside a node (push_back order)
+
+
+def test_vocab_transform_properties(oracle):
+    """DBoW2 transform on a synthetic tree: results are leaves, the node id sits `levelsup` levels above
+    the leaf level on the root-to-leaf path, and a feature equal to a leaf descriptor finds that leaf."""
+    from orb_slam3_detailed_comments_kor_amd import synth
+    vocab = synth.make_vocabulary(5, 8, 4, ragged=False)
+    nn = len(vocab["word"])
+    parent = -np.ones(nn, np.int64)
+    for i in range(nn):
+        for c in vocab["child_ids"][vocab["child_off"][i]:vocab["child_off"][i + 1]]:
+            parent[c] = i
+    leaves = np.nonzero(vocab["word"] >= 0)[0]
+    feats = vocab["desc"][leaves[:300]]
+    w, nid, wt = oracle.vocab_transform(vocab, feats, 2)
+    # greedy descent is not guaranteed to reach the generating leaf, but it must reach *a* leaf whose
+    # distance to the feature is small, and for most features the generating leaf itself
+    assert (w >= 0).all()
+    assert (w == vocab["word"][leaves[:300]]).mean() > 0.9
+    for f in range(50):
+        leaf = int(np.nonzero(vocab["word"] == w[f])[0][0])
+        path = [leaf]
+        while parent[path[-1]] >= 0:
+            path.append(int(parent[path[-1]]))
+        path = path[::-1]            # root ... leaf ; level = index
+        assert nid[f] == path[vocab["L"] - 2]
+        assert wt[f] == vocab["weight"][leaf]
+    # levelsup >= L -> node id is the root
+    _, nid0, _ = oracle.vocab_transform(vocab, feats[:10], 4)
+    assert (nid0 == 0).all()
