@@ -184,6 +184,11 @@ int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 *
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:355-420) for npts map points in one launch: the
+ * observation descriptors are pooled, point p owns rows offsets[p] .. offsets[p+1); best[p] = index (relative
+ * to the point) of the descriptor with the least median distance to the others, -1 if the point has none. */
+int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best);
+
 /* DBoW2 vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) in CSR form: children of node i are
  * child_ids[child_off[i] .. child_off[i+1]) in stored order, node 0 is the root; leaves carry word id + weight. */
 typedef struct {

@@ -1199,6 +1199,39 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
     return np;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors, reference src/MapPoint.cc:387-419, for `npts` map points whose
+// observation descriptors are pooled: point p owns rows offsets[p] .. offsets[p+1).  best[p] = row (relative
+// to the point) with the least median distance to the rest, -1 for a point without descriptors.
+void orb_oracle_distinctive_descriptors(const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best)
+{
+    for (int p = 0; p < npts; p++) {
+        const int N = offsets[p + 1] - offsets[p];
+        const uint8_t* D = pool + 32 * (size_t)offsets[p];
+        if (N <= 0) {
+            best[p] = -1;
+            continue;
+        }
+        std::vector<std::vector<int>> Distances(N, std::vector<int>(N, 0));
+        for (int i = 0; i < N; i++)
+            for (int j = i + 1; j < N; j++) {
+                const int d = DescriptorDistance(D + 32 * (size_t)i, D + 32 * (size_t)j);
+                Distances[i][j] = d;
+                Distances[j][i] = d;
+            }
+        int BestMedian = 0x7fffffff, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances[i]);
+            std::sort(vDists.begin(), vDists.end());
+            const int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) {
+                BestMedian = median;
+                BestIdx = i;
+            }
+        }
+        best[p] = BestIdx;
+    }
+}
+
 // TemplatedVocabulary::transform for one feature, reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259
 // (F::distance = FORB::distance = Hamming, FORB.cpp:81-101).  The tree is given in CSR form.
 void orb_oracle_vocab_transform(int nnodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_ids,

@@ -110,6 +110,8 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
+/* MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:387-419 for npts points with pooled descriptors. */
+void orb_oracle_distinctive_descriptors(const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best);
 /* DBoW2 TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259) per feature:
  * leaf word id, leaf weight and the node id `levelsup` levels above the leaves.  Tree in CSR form:
  * children of node i = child_ids[child_off[i] .. child_off[i+1]) in stored order; node 0 is the root. */

@@ -94,6 +94,7 @@ def lib():
         L.orb_oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                         C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                         C.c_void_p, C.c_void_p]
+        L.orb_oracle_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orb_oracle_vocab_transform.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_void_p]
@@ -359,6 +360,14 @@ def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
     n = lib().orb_oracle_compute_stereo_matches(exL.h, exR.h, _p(kpsL), _p(dL), len(kpsL), _p(kpsR), _p(dR),
                                                 len(kpsR), mb, mbf, _p(uR), _p(dep))
     return n, uR, dep
+
+
+def distinctive_descriptors(pool, offsets):
+    pool = np.ascontiguousarray(pool, np.uint8).reshape(-1, 32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    best = np.zeros(len(offsets) - 1, np.int32)
+    lib().orb_oracle_distinctive_descriptors(_p(pool), _p(offsets), len(best), _p(best))
+    return best
 
 
 def vocab_transform(vocab, feats, levelsup=4):

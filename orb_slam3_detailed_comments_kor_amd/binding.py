@@ -123,6 +123,7 @@ def lib():
         L.orbfe_search_bow_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_BowArgs), C.POINTER(C.c_void_p), C.c_void_p]
         L.orbfe_kb8_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_matcher_last_kernel_ms.restype = C.c_float
+        L.orbfe_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_vocab_upload.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(_Vocab)]
         L.orbfe_vocab_free.argtypes = [C.c_void_p]
         L.orbfe_vocab_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -136,7 +137,7 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
-           "orbfe_matcher_last_kernel_ms", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
+           "orbfe_matcher_last_kernel_ms", "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
 
 
 def _p(a):
@@ -425,6 +426,16 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
     pairs = np.zeros((max(len(d1), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
     return pairs[:n].copy()
+
+
+def distinctive_descriptors(pool, offsets, device=0):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:355-420) for many map points at once."""
+    pool = np.ascontiguousarray(pool, np.uint8).reshape(-1, 32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    best = np.zeros(len(offsets) - 1, np.int32)
+    _chk(lib().orbfe_distinctive_descriptors(device, _p(pool), _p(offsets), len(best), _p(best)),
+         "orbfe_distinctive_descriptors")
+    return best
 
 
 class Vocabulary:

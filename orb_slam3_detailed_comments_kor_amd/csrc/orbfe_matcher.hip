@@ -338,6 +338,43 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
 }
 
+// ------------------------------------------------------------------ K-DIST
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:387-419): among the N observation descriptors of
+// a map point pick the one with the least median Hamming distance to all of them (self distance 0
+// included, median = sorted[(int)(0.5*(N-1))], first minimum wins).  One wavefront per map point, one
+// descriptor per lane; the k-th smallest distance of a row is found by bisection on the value
+// (distances are 0..256), recomputing the popcounts instead of storing an N x N matrix.
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__ pool,
+                                                     const int32_t* __restrict__ offsets, int npts,
+                                                     int32_t* __restrict__ best)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= npts) return;
+    const int o = offsets[p], N = offsets[p + 1] - o;
+    if (N <= 0) {
+        if (lane == 0) best[p] = -1;
+        return;
+    }
+    const uint8_t* D = pool + (size_t)o * 32;
+    const int k = (int)(0.5 * (double)(N - 1));
+    unsigned bestKey = 0xFFFFFFFFu; // median << 20 | index
+    for (int i = lane; i < N; i += 64) {
+        const Desc di = load_desc(D + (size_t)i * 32);
+        int lo = 0, hi = 256; // smallest v with #{j : d_ij <= v} >= k + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; j++) cnt += hamming(di, load_desc(D + (size_t)j * 32)) <= mid;
+            if (cnt >= k + 1) hi = mid;
+            else lo = mid + 1;
+        }
+        bestKey = min(bestKey, ((unsigned)lo << 20) | (unsigned)i);
+    }
+    bestKey = wave_min_u32(bestKey);
+    if (lane == 0) best[p] = (int)(bestKey & 0xFFFFFu);
+}
+
 // ------------------------------------------------------------------ K-VOC
 // DBoW2 TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259): walk the
 // vocabulary tree, at every level the child with the smallest Hamming distance (first minimum in stored
@@ -795,6 +832,31 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
         np++;
     }
     return np;
+}
+
+int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best)
+{
+    if (npts < 0 || (npts && (!offsets || !best))) return ORBFE_ERR_ARGS;
+    if (npts == 0) return 0;
+    const int total = offsets[npts];
+    if (offsets[0] != 0 || total < 0 || (total && !pool)) return ORBFE_ERR_ARGS;
+    for (int p = 0; p < npts; p++)
+        if (offsets[p + 1] < offsets[p] || offsets[p + 1] - offsets[p] >= (1 << 20)) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    uint8_t* dP;
+    int32_t *dO, *dB;
+    if ((r = s.up(&dP, pool, (size_t)total * 32)) < 0) return r;
+    if ((r = s.up(&dO, offsets, (size_t)npts + 1)) < 0) return r;
+    if ((r = s.up<int32_t>(&dB, nullptr, (size_t)npts)) < 0) return r;
+    {
+        KernelTimer timer;
+        hipLaunchKernelGGL(k_distinctive, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, 0, dP, dO, npts, dB);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(best, dB, (size_t)npts * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }

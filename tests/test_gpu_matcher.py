@@ -176,3 +176,25 @@ def test_vocabulary_transform(pkg, oracle, k, L, ragged, levelsup):
     rn, rm = oracle.search_bow_kf_f(d1, mask, a1, fv1, d2, a2, fv2, -1, 0.7, True)
     assert n == rn and np.array_equal(m, rm)
     V.close()
+
+
+def test_distinctive_descriptors(pkg, oracle):
+    """MapPoint::ComputeDistinctiveDescriptors for a batch of map points (1..130 observations each, ties)."""
+    rng = np.random.default_rng(8)
+    sizes = [1, 2, 3, 5, 8, 13, 21, 40, 64, 65, 130, 0, 7] + rng.integers(1, 30, size=200).tolist()
+    offsets = np.zeros(len(sizes) + 1, np.int32)
+    offsets[1:] = np.cumsum(sizes)
+    pool = np.zeros((offsets[-1], 32), np.uint8)
+    for p, n in enumerate(sizes):
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        bits = np.unpackbits(base)
+        for i in range(n):
+            b = bits.copy()
+            b[rng.permutation(256)[: int(rng.integers(0, 40))]] ^= 1
+            pool[offsets[p] + i] = np.packbits(b)
+        if n >= 4:
+            pool[offsets[p] + 1] = pool[offsets[p] + 3]  # duplicates -> equal medians, first index wins
+    got = pkg.distinctive_descriptors(pool, offsets)
+    ref = oracle.distinctive_descriptors(pool, offsets)
+    assert np.array_equal(got, ref)
+    assert got[11] == -1 and got[0] == 0

@@ -92,3 +92,22 @@ def test_vocab_transform_properties(oracle):
     # levelsup >= L -> node id is the root
     _, nid0, _ = oracle.vocab_transform(vocab, feats[:10], 4)
     assert (nid0 == 0).all()
+
+
+def test_distinctive_descriptors_against_numpy_spec(oracle):
+    """ComputeDistinctiveDescriptors (src/MapPoint.cc:387-419): least median of the sorted distance row
+    (self distance included, index int(0.5*(N-1))), first minimum wins."""
+    rng = np.random.default_rng(4)
+    sizes = [0, 1, 2, 3, 4, 9, 10, 33]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pool = rng.integers(0, 256, (offsets[-1], 32), dtype=np.uint8)
+    pool[offsets[5] + 2] = pool[offsets[5] + 6]
+    got = oracle.distinctive_descriptors(pool, offsets)
+    for p, n in enumerate(sizes):
+        if n == 0:
+            assert got[p] == -1
+            continue
+        d = pool[offsets[p]:offsets[p + 1]]
+        dist = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(axis=2)
+        med = np.sort(dist, axis=1)[:, int(0.5 * (n - 1))]
+        assert got[p] == int(np.argmin(med))
