@@ -184,6 +184,48 @@ int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 *
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
 
+/* Inner loops of ORBmatcher::SearchByProjection over one frame's grid:
+ *   mode 0  (Frame& F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), src/ORBmatcher.cc:44-197
+ *           (Tracking::SearchLocalPoints): best / second best with the same-level ratio test;
+ *   mode 1  (Frame& CurrentFrame, const Frame& LastFrame, th, bMono) :2193-2419 and
+ *           (Frame& CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) :2421-2541: best only, TH = th_high,
+ *           rotation-histogram cull when check_orientation.
+ * The caller keeps the object walk (isBad, projection, RadiusByViewingCos, mnTrackScaleLevel ...) and passes
+ * one query per GetFeaturesInArea call, in the reference's loop order.  Frame side: the N features with the
+ * keypoints GetFeaturesInArea reads (mvKeysUn when Nleft == -1, else mvKeys ++ mvKeysRight), the grid
+ * parameters of src/Frame.cc:158-159, and taken[i] = F.mvpMapPoints[i] && Observations()>0 (:83-85; for the
+ * relocalisation overload simply non-null, :2484).  The library rebuilds Frame::AssignFeaturesToGrid
+ * (src/Frame.cc:380-410) on the device. */
+typedef struct {
+    const uint8_t* desc; int n;            /* F.mDescriptors, 32-B rows                                  */
+    const float* kx; const float* ky;      /* keypoint coordinates                                        */
+    const int32_t* octave;
+    const float* angle;                    /* only read for mode 1 + check_orientation                    */
+    const float* uright;                   /* F.mvuRight or NULL; gate of :87-92 / :2270-2276 (Nleft == -1) */
+    const uint8_t* taken;                  /* or NULL = none                                              */
+    int Nleft;                             /* F.Nleft (-1 unless two-camera fisheye rig)                  */
+    const int32_t* left_to_right;          /* F.mvLeftToRightMatch (Nleft entries) or NULL; mode 0        */
+    const int32_t* right_to_left;          /* F.mvRightToLeftMatch (n - Nleft entries) or NULL; mode 0    */
+    float minX, minY, gridWInv, gridHInv;  /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
+    int nq;
+    const uint8_t* qdesc;                  /* pMP->GetDescriptor(), 32 B per query                        */
+    const float* qx; const float* qy;      /* projection                                                  */
+    const float* qr;                       /* window half-size handed to GetFeaturesInArea                */
+    const int32_t* qmin_level; const int32_t* qmax_level; /* its minLevel / maxLevel arguments           */
+    const float* qxr;                      /* mTrackProjXR (:89) or uv.x - mbf*invzc (:2272); with uright */
+    const uint8_t* qflags;                 /* or NULL. bit0: right-camera grid (bRight); bit1: right-camera
+                                              search of the previous query's map point, skipped when that
+                                              query was rejected by the ratio test (`continue`, :128)     */
+    const float* qangle;                   /* keypoint angle in the last frame / keyframe (mode 1)        */
+    const uint8_t* qblocks;                /* or NULL = all. pMP->Observations()>0 of the query's point   */
+    int mode; float nnratio; int th_high; int check_orientation;
+} orbfe_proj_args;
+/* q_match[nq] = feature written by the query itself (before the orientation cull) or -1; feat_match[n] =
+ * index of the query whose map point ends up in F.mvpMapPoints[i], -1 = entry left as it was (or culled).
+ * Returns nmatches, or an error. */
+int orbfe_search_projection(int device, const orbfe_proj_args*, int32_t* q_match, int32_t* feat_match);
+int orbfe_search_projection_last_sweeps(void); /* sweeps the last call on this thread needed (diagnostic) */
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:355-420) for npts map points in one launch: the
  * observation descriptors are pooled, point p owns rows offsets[p] .. offsets[p+1); best[p] = index (relative
  * to the point) of the descriptor with the least median distance to the others, -1 if the point has none. */

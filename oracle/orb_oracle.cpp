@@ -1199,6 +1199,143 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
     return np;
 }
 
+// ORBmatcher::SearchByProjection over flattened inputs.  mode 0 = (Frame&, vector<MapPoint*>&, th, ...)
+// src/ORBmatcher.cc:44-197: one query per camera a map point is tracked in (qflags bit0 = right camera,
+// bit1 = "this is the right-camera search of the previous query's map point", which the `continue` at :128
+// skips when the left search was rejected by the ratio test).  mode 1 = best-only search of
+// (Frame& CurrentFrame, const Frame& LastFrame, th, bMono) :2193-2419 and of the relocalisation overload
+// :2421-2541, with the rotation histogram.  The grid is Frame::AssignFeaturesToGrid (src/Frame.cc:380-410),
+// the window Frame::GetFeaturesInArea (:643-708).  Occupancy follows F.mvpMapPoints: `taken` = non-null and
+// Observations()>0 on entry; a query's map point blocks a feature when qblocks[q] (NULL = all block).
+int orb_oracle_search_projection(const orb_oracle_proj_args* a, int32_t* q_match, int32_t* feat_match)
+{
+    const int GC = 64, GR = 48; // FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h
+    const int N = a->n, Nleft = a->Nleft;
+    std::vector<std::vector<size_t>> mGrid((size_t)GC * GR), mGridRight((size_t)GC * GR);
+    for (int i = 0; i < N; i++) {
+        const int posX = (int)std::round((a->kx[i] - a->minX) * a->gridWInv);
+        const int posY = (int)std::round((a->ky[i] - a->minY) * a->gridHInv);
+        if (posX < 0 || posX >= GC || posY < 0 || posY >= GR) continue;
+        if (Nleft == -1 || i < Nleft) mGrid[(size_t)posX * GR + posY].push_back((size_t)i);
+        else mGridRight[(size_t)posX * GR + posY].push_back((size_t)(i - Nleft));
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r, int minLevel, int maxLevel, bool bRight) {
+        std::vector<size_t> vIndices;
+        const float factorX = r, factorY = r;
+        const float fx0 = std::floor((x - a->minX - factorX) * a->gridWInv);
+        if (!(fx0 < (float)GC)) return vIndices;
+        const int nMinCellX = fx0 > 0.f ? (int)fx0 : 0;
+        const float fx1 = std::ceil((x - a->minX + factorX) * a->gridWInv);
+        if (!(fx1 >= 0.f)) return vIndices;
+        const int nMaxCellX = fx1 < (float)(GC - 1) ? (int)fx1 : GC - 1;
+        const float fy0 = std::floor((y - a->minY - factorY) * a->gridHInv);
+        if (!(fy0 < (float)GR)) return vIndices;
+        const int nMinCellY = fy0 > 0.f ? (int)fy0 : 0;
+        const float fy1 = std::ceil((y - a->minY + factorY) * a->gridHInv);
+        if (!(fy1 >= 0.f)) return vIndices;
+        const int nMaxCellY = fy1 < (float)(GR - 1) ? (int)fy1 : GR - 1;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = !bRight ? mGrid[(size_t)ix * GR + iy] : mGridRight[(size_t)ix * GR + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const size_t g = (Nleft == -1 || !bRight) ? vCell[j] : vCell[j] + (size_t)Nleft;
+                    if (bCheckLevels) {
+                        if (a->octave[g] < minLevel) continue;
+                        if (maxLevel >= 0)
+                            if (a->octave[g] > maxLevel) continue;
+                    }
+                    const float distx = a->kx[g] - x, disty = a->ky[g] - y;
+                    if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    };
+    // occupant of F.mvpMapPoints[i]: -2 NULL or obs==0 on entry, -1 blocking on entry, q >= 0 written by query q
+    std::vector<int> occupant(N);
+    for (int i = 0; i < N; i++) {
+        occupant[i] = (a->taken && a->taken[i]) ? -1 : -2;
+        feat_match[i] = -1;
+    }
+    auto blocked = [&](size_t i) {
+        const int o = occupant[i];
+        if (o == -2) return false;
+        if (o == -1) return true;
+        return a->qblocks ? a->qblocks[o] != 0 : true;
+    };
+    auto write = [&](size_t i, int q) {
+        occupant[i] = q;
+        feat_match[i] = q;
+    };
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    bool prevRatioRejected = false;
+    for (int q = 0; q < a->nq; q++) {
+        q_match[q] = -1;
+        const bool bRight = a->qflags && (a->qflags[q] & 1);
+        const bool linked = a->qflags && (a->qflags[q] & 2);
+        const bool skip = linked && prevRatioRejected;
+        prevRatioRejected = false;
+        if (skip) continue;
+        const size_t base = bRight ? (size_t)Nleft : 0;
+        const float r = a->qr[q];
+        const std::vector<size_t> vIndices = GetFeaturesInArea(a->qx[q], a->qy[q], r, a->qmin_level[q], a->qmax_level[q], bRight);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = a->qdesc + 32 * (size_t)q;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = vIndices[k];
+            if (blocked(idx + base)) continue;
+            if (!bRight && Nleft == -1 && a->uright && a->uright[idx] > 0) {
+                const float er = std::fabs(a->qxr[q] - a->uright[idx]);
+                if (er > r) continue;
+            }
+            const int dist = DescriptorDistance(MPdescriptor, a->desc + 32 * (idx + base));
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = a->octave[idx + base];
+                bestIdx = (int)idx;
+            } else if (a->mode == 0 && dist < bestDist2) {
+                bestLevel2 = a->octave[idx + base];
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= a->th_high) {
+            if (a->mode == 0) {
+                if (bestLevel == bestLevel2 && bestDist > a->nnratio * bestDist2) {
+                    prevRatioRejected = true;
+                    continue;
+                }
+                if (!bRight) {
+                    write((size_t)bestIdx, q);
+                    if (Nleft != -1 && a->left_to_right && a->left_to_right[bestIdx] != -1) {
+                        write((size_t)(a->left_to_right[bestIdx] + Nleft), q);
+                        nmatches++;
+                    }
+                    nmatches++;
+                } else {
+                    if (Nleft != -1 && a->right_to_left && a->right_to_left[bestIdx] != -1) {
+                        write((size_t)a->right_to_left[bestIdx], q);
+                        nmatches++;
+                    }
+                    write((size_t)bestIdx + base, q);
+                    nmatches++;
+                }
+                q_match[q] = bestIdx + (int)base;
+            } else {
+                write((size_t)bestIdx + base, q);
+                nmatches++;
+                q_match[q] = bestIdx + (int)base;
+                if (a->check_orientation) rotHist[rot_bin(a->qangle[q], a->angle[bestIdx + base])].push_back(bestIdx + (int)base);
+            }
+        }
+    }
+    if (a->mode == 1 && a->check_orientation) nmatches = cull_rotation(rotHist, feat_match, nmatches);
+    return nmatches;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors, reference src/MapPoint.cc:387-419, for `npts` map points whose
 // observation descriptors are pooled: point p owns rows offsets[p] .. offsets[p+1).  best[p] = row (relative
 // to the point) with the least median distance to the rest, -1 for a point without descriptors.

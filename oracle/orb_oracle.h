@@ -110,6 +110,21 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
+/* Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197 mode 0, :2193-2419 / :2421-2541
+ * mode 1) over flattened inputs; same layout as orbfe_proj_args (include/orbfe.h). */
+typedef struct {
+    const uint8_t* desc; int n;
+    const float* kx; const float* ky; const int32_t* octave; const float* angle;
+    const float* uright; const uint8_t* taken;
+    int Nleft; const int32_t* left_to_right; const int32_t* right_to_left;
+    float minX, minY, gridWInv, gridHInv;
+    int nq; const uint8_t* qdesc;
+    const float* qx; const float* qy; const float* qr;
+    const int32_t* qmin_level; const int32_t* qmax_level;
+    const float* qxr; const uint8_t* qflags; const float* qangle; const uint8_t* qblocks;
+    int mode; float nnratio; int th_high; int check_orientation;
+} orb_oracle_proj_args;
+int orb_oracle_search_projection(const orb_oracle_proj_args* a, int32_t* q_match, int32_t* feat_match);
 /* MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:387-419 for npts points with pooled descriptors. */
 void orb_oracle_distinctive_descriptors(const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best);
 /* DBoW2 TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259) per feature:

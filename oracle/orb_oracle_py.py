@@ -94,6 +94,7 @@ def lib():
         L.orb_oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                         C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                         C.c_void_p, C.c_void_p]
+        L.orb_oracle_search_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orb_oracle_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orb_oracle_vocab_transform.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -360,6 +361,54 @@ def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
     n = lib().orb_oracle_compute_stereo_matches(exL.h, exR.h, _p(kpsL), _p(dL), len(kpsL), _p(kpsR), _p(dR),
                                                 len(kpsR), mb, mbf, _p(uR), _p(dep))
     return n, uR, dep
+
+
+class _ProjArgs(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("n", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p),
+                ("angle", C.c_void_p), ("uright", C.c_void_p), ("taken", C.c_void_p), ("Nleft", C.c_int),
+                ("left_to_right", C.c_void_p), ("right_to_left", C.c_void_p),
+                ("minX", C.c_float), ("minY", C.c_float), ("gridWInv", C.c_float), ("gridHInv", C.c_float),
+                ("nq", C.c_int), ("qdesc", C.c_void_p), ("qx", C.c_void_p), ("qy", C.c_void_p), ("qr", C.c_void_p),
+                ("qmin_level", C.c_void_p), ("qmax_level", C.c_void_p), ("qxr", C.c_void_p), ("qflags", C.c_void_p),
+                ("qangle", C.c_void_p), ("qblocks", C.c_void_p),
+                ("mode", C.c_int), ("nnratio", C.c_float), ("th_high", C.c_int), ("check_orientation", C.c_int)]
+
+
+_PROJ_ARRAYS = [("desc", np.uint8), ("kx", np.float32), ("ky", np.float32), ("octave", np.int32), ("angle", np.float32),
+                ("uright", np.float32), ("taken", np.uint8), ("left_to_right", np.int32), ("right_to_left", np.int32),
+                ("qdesc", np.uint8), ("qx", np.float32), ("qy", np.float32), ("qr", np.float32),
+                ("qmin_level", np.int32), ("qmax_level", np.int32), ("qxr", np.float32), ("qflags", np.uint8),
+                ("qangle", np.float32), ("qblocks", np.uint8)]
+
+
+def _proj_args(pr):
+    """dict with the fields of the projection-search argument struct -> (struct, keep-alive arrays, n, nq)."""
+    keep = {}
+    a = _ProjArgs()
+    for name, dt in _PROJ_ARRAYS:
+        v = pr.get(name)
+        if v is None:
+            setattr(a, name, None)
+        else:
+            keep[name] = np.ascontiguousarray(v, dt)
+            setattr(a, name, keep[name].ctypes.data)
+    a.n = len(keep["kx"])
+    a.nq = len(keep["qx"])
+    a.Nleft = int(pr.get("Nleft", -1))
+    for name in ("minX", "minY", "gridWInv", "gridHInv", "nnratio"):
+        setattr(a, name, float(pr[name]))
+    a.mode = int(pr["mode"])
+    a.th_high = int(pr.get("th_high", 100))
+    a.check_orientation = int(pr.get("check_orientation", 0))
+    return a, keep, a.n, a.nq
+
+
+def search_projection(problem):
+    a, keep, n, nq = _proj_args(problem)
+    qm = np.full(max(nq, 1), -1, np.int32)
+    fm = np.full(max(n, 1), -1, np.int32)
+    r = lib().orb_oracle_search_projection(C.byref(a), _p(qm), _p(fm))
+    return r, qm[:nq], fm[:n]
 
 
 def distinctive_descriptors(pool, offsets):

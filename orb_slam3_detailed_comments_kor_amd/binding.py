@@ -53,6 +53,46 @@ class _TriArgs(C.Structure):
                 ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+class _ProjArgs(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("n", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p),
+                ("angle", C.c_void_p), ("uright", C.c_void_p), ("taken", C.c_void_p), ("Nleft", C.c_int),
+                ("left_to_right", C.c_void_p), ("right_to_left", C.c_void_p),
+                ("minX", C.c_float), ("minY", C.c_float), ("gridWInv", C.c_float), ("gridHInv", C.c_float),
+                ("nq", C.c_int), ("qdesc", C.c_void_p), ("qx", C.c_void_p), ("qy", C.c_void_p), ("qr", C.c_void_p),
+                ("qmin_level", C.c_void_p), ("qmax_level", C.c_void_p), ("qxr", C.c_void_p), ("qflags", C.c_void_p),
+                ("qangle", C.c_void_p), ("qblocks", C.c_void_p),
+                ("mode", C.c_int), ("nnratio", C.c_float), ("th_high", C.c_int), ("check_orientation", C.c_int)]
+
+
+_PROJ_ARRAYS = [("desc", np.uint8), ("kx", np.float32), ("ky", np.float32), ("octave", np.int32), ("angle", np.float32),
+                ("uright", np.float32), ("taken", np.uint8), ("left_to_right", np.int32), ("right_to_left", np.int32),
+                ("qdesc", np.uint8), ("qx", np.float32), ("qy", np.float32), ("qr", np.float32),
+                ("qmin_level", np.int32), ("qmax_level", np.int32), ("qxr", np.float32), ("qflags", np.uint8),
+                ("qangle", np.float32), ("qblocks", np.uint8)]
+
+
+def _proj_args(pr):
+    """dict with the fields of the projection-search argument struct -> (struct, keep-alive arrays, n, nq)."""
+    keep = {}
+    a = _ProjArgs()
+    for name, dt in _PROJ_ARRAYS:
+        v = pr.get(name)
+        if v is None:
+            setattr(a, name, None)
+        else:
+            keep[name] = np.ascontiguousarray(v, dt)
+            setattr(a, name, keep[name].ctypes.data)
+    a.n = len(keep["kx"])
+    a.nq = len(keep["qx"])
+    a.Nleft = int(pr.get("Nleft", -1))
+    for name in ("minX", "minY", "gridWInv", "gridHInv", "nnratio"):
+        setattr(a, name, float(pr[name]))
+    a.mode = int(pr["mode"])
+    a.th_high = int(pr.get("th_high", 100))
+    a.check_orientation = int(pr.get("check_orientation", 0))
+    return a, keep, a.n, a.nq
+
+
 def _share_hip_runtime_with_torch():
     """One HIP runtime per process: torch bundles its own libamdhip64.so (same SONAME as the system
     one).  Loading it first makes the dynamic linker bind liborbfe.so to that copy, so device
@@ -123,6 +163,8 @@ def lib():
         L.orbfe_search_bow_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_BowArgs), C.POINTER(C.c_void_p), C.c_void_p]
         L.orbfe_kb8_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_matcher_last_kernel_ms.restype = C.c_float
+        L.orbfe_search_projection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbfe_search_projection_last_sweeps.argtypes = []
         L.orbfe_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_vocab_upload.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(_Vocab)]
         L.orbfe_vocab_free.argtypes = [C.c_void_p]
@@ -137,7 +179,8 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
-           "orbfe_matcher_last_kernel_ms", "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
+           "orbfe_matcher_last_kernel_ms", "orbfe_search_projection", "orbfe_search_projection_last_sweeps",
+           "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
 
 
 def _p(a):
@@ -426,6 +469,20 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
     pairs = np.zeros((max(len(d1), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
     return pairs[:n].copy()
+
+
+def search_projection(problem, device=0):
+    """Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197 mode 0; :2193-2419, :2421-2541
+    mode 1); `problem` holds the fields of orbfe_proj_args.  Returns (nmatches, q_match, feat_match)."""
+    a, keep, n, nq = _proj_args(problem)
+    qm = np.full(max(nq, 1), -1, np.int32)
+    fm = np.full(max(n, 1), -1, np.int32)
+    r = _chk(lib().orbfe_search_projection(device, C.byref(a), _p(qm), _p(fm)), "orbfe_search_projection")
+    return r, qm[:nq], fm[:n]
+
+
+def search_projection_last_sweeps():
+    return int(lib().orbfe_search_projection_last_sweeps())
 
 
 def distinctive_descriptors(pool, offsets, device=0):

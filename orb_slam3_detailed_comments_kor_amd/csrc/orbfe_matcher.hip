@@ -338,6 +338,307 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
 }
 
+// ------------------------------------------------------------------ K-PROJ
+// Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197, :2193-2419, :2421-2541): window
+// query in the frame grid (Frame::GetFeaturesInArea, src/Frame.cc:643-708) + best / second-best Hamming
+// distance + the reference's sequential occupancy rule (a feature that an earlier map point took is skipped
+// by later ones, :83-85).  Three launches:
+//   k_proj_grid        Frame::AssignFeaturesToGrid (src/Frame.cc:380-410) as a CSR, one workgroup;
+//   k_proj_candidates  one wavefront per query: every candidate that passes the static tests (window, level,
+//                      mvuRight gate, occupied on entry) gets a key  distance | visit order | feature, and the
+//                      keys of a query are stored sorted -- the order in which the reference's `dist<bestDist`
+//                      / `dist<bestDist2` chain ranks them;
+//   k_proj_sweeps      the sequential rule as a fixpoint: query q sees feature f as taken when the least-index
+//                      blocking writer of f in the previous sweep is < q; its best / second best are the
+//                      first two untaken keys.  The result of q depends only on queries < q, so the unique
+//                      fixpoint is the sequential result and sweep k fixes at least queries 0..k (2-5 sweeps
+//                      in practice).  One workgroup, because a sweep ends in a grid-wide barrier.
+struct ProjDev {
+    const uint8_t* desc;
+    const float *kx, *ky;
+    const int32_t* octave;
+    const float* uright;
+    const uint8_t* taken;
+    const int32_t *l2r, *r2l;
+    int n, Nleft;
+    float minX, minY, wInv, hInv;
+    int nq;
+    const uint8_t* qdesc;
+    const float *qx, *qy, *qr, *qxr;
+    const int32_t *qmin, *qmax;
+    const uint8_t *qflags, *qblocks;
+    int mode;
+    float nnratio;
+    int thHigh;
+    int32_t* cellStart; // 2 * 3072 + 1
+    int32_t* cellItems; // n
+    int32_t* cellOf;    // n
+    unsigned long long *rawKeys, *sortedKeys;
+    int keyCap;
+    int32_t *qStart, *qCount; // nq
+    int32_t* minW;      // 2 * n
+    int32_t* state;     // 2 * 3 * nq: choice, partner, rejected
+    int32_t* qMatch;    // nq
+    int32_t* featMatch; // n
+    int32_t* status;    // nmatches, sweeps, keys needed
+};
+#define PROJ_GC 64
+#define PROJ_GR 48
+#define PROJ_CELLS (PROJ_GC * PROJ_GR)
+#define PROJ_THREADS 1024
+// key = dist(9) << 55 | cell sequence(12) << 43 | position in cell(19) << 24 | feature(24, only 19 used)
+#define PROJ_MAXN (1 << 19)
+
+__global__ __launch_bounds__(PROJ_THREADS) void k_proj_grid(ProjDev P)
+{
+    __shared__ int sCnt[2 * PROJ_CELLS];
+    __shared__ int sWave[PROJ_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n;
+    for (int c = tid; c < 2 * PROJ_CELLS; c += PROJ_THREADS) sCnt[c] = 0;
+    if (tid == 0) P.status[2] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += PROJ_THREADS) {
+        const float fx = roundf(__fmul_rn(__fsub_rn(P.kx[i], P.minX), P.wInv));
+        const float fy = roundf(__fmul_rn(__fsub_rn(P.ky[i], P.minY), P.hInv));
+        int c = -1;
+        if (fx >= 0.f && fx < (float)PROJ_GC && fy >= 0.f && fy < (float)PROJ_GR) {
+            c = (int)fx * PROJ_GR + (int)fy + ((P.Nleft != -1 && i >= P.Nleft) ? PROJ_CELLS : 0);
+            atomicAdd(&sCnt[c], 1);
+        }
+        P.cellOf[i] = c;
+    }
+    __syncthreads();
+    {
+        const int per = 2 * PROJ_CELLS / PROJ_THREADS; // 6
+        int loc[per], sum = 0;
+#pragma unroll
+        for (int k = 0; k < per; k++) {
+            loc[k] = sum;
+            sum += sCnt[tid * per + k];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) sWave[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; w++) wbase += sWave[w];
+        const int excl = wbase + inc - sum;
+#pragma unroll
+        for (int k = 0; k < per; k++) {
+            const int st = excl + loc[k];
+            P.cellStart[tid * per + k] = st;
+            sCnt[tid * per + k] = st; // becomes the fill cursor
+        }
+        if (tid == PROJ_THREADS - 1) P.cellStart[2 * PROJ_CELLS] = excl + sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PROJ_THREADS) {
+        const int c = P.cellOf[i];
+        if (c >= 0) P.cellItems[atomicAdd(&sCnt[c], 1)] = (P.Nleft != -1 && i >= P.Nleft) ? i - P.Nleft : i;
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * PROJ_CELLS; c += PROJ_THREADS) { // push_back order = ascending feature index
+        const int st = P.cellStart[c], en = sCnt[c];
+        for (int a = st + 1; a < en; a++) {
+            const int v = P.cellItems[a];
+            int b = a - 1;
+            while (b >= st && P.cellItems[b] > v) {
+                P.cellItems[b + 1] = P.cellItems[b];
+                b--;
+            }
+            P.cellItems[b + 1] = v;
+        }
+    }
+}
+
+// static tests of one candidate (everything except "taken by an earlier query")
+__device__ __forceinline__ bool proj_static_ok(const ProjDev& P, int g, float x, float y, float r, int minLevel,
+                                               int maxLevel, bool gate, float xr)
+{
+    const int oct = P.octave[g];
+    if (oct < minLevel || (maxLevel >= 0 && oct > maxLevel)) return false;
+    if (!(fabsf(__fsub_rn(P.kx[g], x)) < r && fabsf(__fsub_rn(P.ky[g], y)) < r)) return false;
+    if (P.taken && P.taken[g]) return false;
+    if (gate) {
+        const float ur = P.uright[g];
+        if (ur > 0.f && fabsf(__fsub_rn(xr, ur)) > r) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= P.nq) return;
+    const int flags = P.qflags ? P.qflags[q] : 0;
+    const bool bRight = flags & 1;
+    const float x = P.qx[q], y = P.qy[q], r = P.qr[q];
+    const float fx0 = floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, P.minX), r), P.wInv));
+    const float fx1 = ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, P.minX), r), P.wInv));
+    const float fy0 = floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.minY), r), P.hInv));
+    const float fy1 = ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, P.minY), r), P.hInv));
+    int m = 0, base = 0;
+    if (fx0 < (float)PROJ_GC && fx1 >= 0.f && fy0 < (float)PROJ_GR && fy1 >= 0.f) {
+        const int cx0 = fx0 > 0.f ? (int)fx0 : 0, cx1 = fx1 < (float)(PROJ_GC - 1) ? (int)fx1 : PROJ_GC - 1;
+        const int cy0 = fy0 > 0.f ? (int)fy0 : 0, cy1 = fy1 < (float)(PROJ_GR - 1) ? (int)fy1 : PROJ_GR - 1;
+        const int ncy = cy1 - cy0 + 1, total = (cx1 - cx0 + 1) * ncy;
+        const int fbase = bRight ? P.Nleft : 0, side = bRight ? PROJ_CELLS : 0;
+        const int minLevel = P.qmin[q], maxLevel = P.qmax[q];
+        const bool gate = !bRight && P.Nleft == -1 && P.uright != nullptr;
+        const float xr = gate ? P.qxr[q] : 0.f;
+        int cnt = 0;
+        for (int s = lane; s < total; s += 64) {
+            const int c = side + (cx0 + s / ncy) * PROJ_GR + cy0 + s % ncy;
+            const int st = P.cellStart[c], en = P.cellStart[c + 1];
+            for (int j = st; j < en; j++)
+                cnt += proj_static_ok(P, P.cellItems[j] + fbase, x, y, r, minLevel, maxLevel, gate, xr);
+        }
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        m = __shfl(inc, 63);
+        if (m > 0) {
+            if (lane == 0) base = atomicAdd(&P.status[2], m);
+            base = __shfl(base, 0);
+            if (base + m > P.keyCap) {
+                m = -1; // the host enlarges the key buffers and runs again
+            } else {
+                const Desc dq = load_desc(P.qdesc + (size_t)q * 32);
+                int o = base + inc - cnt;
+                for (int s = lane; s < total; s += 64) {
+                    const int c = side + (cx0 + s / ncy) * PROJ_GR + cy0 + s % ncy;
+                    const int st = P.cellStart[c], en = P.cellStart[c + 1];
+                    for (int j = st; j < en; j++) {
+                        const int g = P.cellItems[j] + fbase;
+                        if (!proj_static_ok(P, g, x, y, r, minLevel, maxLevel, gate, xr)) continue;
+                        const int dist = hamming(dq, load_desc(P.desc + (size_t)g * 32));
+                        P.rawKeys[o++] = ((unsigned long long)dist << 55) | ((unsigned long long)s << 43) |
+                                         ((unsigned long long)(j - st) << 24) | (unsigned long long)g;
+                    }
+                }
+                __threadfence();
+                // rank sort (keys are distinct); a window rarely holds more than a few dozen candidates
+                for (int e = lane; e < m; e += 64) {
+                    const unsigned long long key = P.rawKeys[base + e];
+                    int rank = 0;
+                    for (int k = 0; k < m; k++) rank += P.rawKeys[base + k] < key;
+                    P.sortedKeys[base + rank] = key;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        P.qStart[q] = base;
+        P.qCount[q] = m;
+    }
+}
+
+__global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps(ProjDev P)
+{
+    __shared__ int sChanged;
+    const int tid = threadIdx.x;
+    const int n = P.n, nq = P.nq;
+    for (int i = tid; i < 2 * n; i += PROJ_THREADS) P.minW[i] = 0x7fffffff;
+    for (int i = tid; i < 2 * 3 * nq; i += PROJ_THREADS) P.state[i] = -2;
+    __syncthreads();
+    int sweep = 0, last = 0;
+    for (; sweep < nq + 2; sweep++) {
+        const int32_t* prevW = P.minW + (size_t)(sweep & 1) * n;
+        int32_t* newW = P.minW + (size_t)((sweep + 1) & 1) * n;
+        const int32_t* prevS = P.state + (size_t)(sweep & 1) * 3 * nq;
+        int32_t* newS = P.state + (size_t)((sweep + 1) & 1) * 3 * nq;
+        last = (sweep + 1) & 1;
+        for (int i = tid; i < n; i += PROJ_THREADS) newW[i] = 0x7fffffff;
+        if (tid == 0) sChanged = 0;
+        __syncthreads();
+        for (int q = tid; q < nq; q += PROJ_THREADS) {
+            const int flags = P.qflags ? P.qflags[q] : 0;
+            const bool bRight = flags & 1;
+            int choice = -1, partner = -1, rejected = 0;
+            const bool skip = (flags & 2) && q > 0 && prevS[3 * (q - 1) + 2] == 1;
+            const int m = skip ? 0 : P.qCount[q];
+            const unsigned long long* K = P.sortedKeys + P.qStart[q];
+            int g1 = -1, d1 = 256, g2 = -1, d2 = 256;
+            for (int k = 0; k < m; k++) {
+                const unsigned long long key = K[k];
+                const int d = (int)(key >> 55);
+                if (d >= 256) break; // `dist<bestDist` with bestDist = 256 never accepts these
+                const int g = (int)(key & 0xFFFFFF);
+                if (prevW[g] < q) continue;
+                if (g1 < 0) {
+                    g1 = g;
+                    d1 = d;
+                    if (P.mode != 0) break;
+                } else {
+                    g2 = g;
+                    d2 = d;
+                    break;
+                }
+            }
+            if (g1 >= 0 && d1 <= P.thHigh) {
+                bool ok = true;
+                if (P.mode == 0) {
+                    const int bestLevel2 = g2 >= 0 ? P.octave[g2] : -1;
+                    if (P.octave[g1] == bestLevel2 && (float)d1 > __fmul_rn(P.nnratio, (float)d2)) {
+                        ok = false;
+                        rejected = 1;
+                    }
+                }
+                if (ok) {
+                    choice = g1;
+                    if (P.mode == 0 && P.Nleft != -1) {
+                        if (!bRight && P.l2r && P.l2r[g1] != -1) partner = P.l2r[g1] + P.Nleft;
+                        if (bRight && P.r2l && P.r2l[g1 - P.Nleft] != -1) partner = P.r2l[g1 - P.Nleft];
+                    }
+                }
+            }
+            newS[3 * q] = choice;
+            newS[3 * q + 1] = partner;
+            newS[3 * q + 2] = rejected;
+            if (choice != prevS[3 * q] || partner != prevS[3 * q + 1] || rejected != prevS[3 * q + 2]) sChanged = 1;
+            if (!P.qblocks || P.qblocks[q]) {
+                if (choice >= 0) atomicMin(&newW[choice], q);
+                if (partner >= 0) atomicMin(&newW[partner], q);
+            }
+        }
+        __syncthreads();
+        if (!sChanged) break;
+        __syncthreads();
+    }
+
+    // ---- final state of F.mvpMapPoints: the last writer of every feature
+    const int32_t* S = P.state + (size_t)last * 3 * nq;
+    for (int i = tid; i < n; i += PROJ_THREADS) P.featMatch[i] = -1;
+    if (tid == 0) {
+        P.status[0] = 0;
+        P.status[1] = sweep + 1;
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int q = tid; q < nq; q += PROJ_THREADS) {
+        const int c = S[3 * q], p = S[3 * q + 1];
+        P.qMatch[q] = c;
+        if (c >= 0) {
+            atomicMax(&P.featMatch[c], q);
+            cnt++;
+        }
+        if (p >= 0) {
+            atomicMax(&P.featMatch[p], q);
+            cnt++;
+        }
+    }
+    if (cnt) atomicAdd(&P.status[0], cnt);
+}
+
 // ------------------------------------------------------------------ K-DIST
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:387-419): among the N observation descriptors of
 // a map point pick the one with the least median Hamming distance to all of them (self distance 0
@@ -493,6 +794,7 @@ struct Scratch { // device allocations of one call
 
 // device time of the last matcher kernel launched by this thread (hipEvents around the launch)
 thread_local float g_lastKernelMs = -1.f;
+thread_local int g_lastProjSweeps = 0;
 struct KernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     KernelTimer()
@@ -833,6 +1135,132 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     }
     return np;
 }
+
+int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)
+{
+    if (!a || a->n < 0 || a->nq < 0 || (a->mode != 0 && a->mode != 1)) return ORBFE_ERR_ARGS;
+    if (a->n && (!a->desc || !a->kx || !a->ky || !a->octave || !feat_match)) return ORBFE_ERR_ARGS;
+    if (a->nq && (!a->qdesc || !a->qx || !a->qy || !a->qr || !a->qmin_level || !a->qmax_level || !q_match))
+        return ORBFE_ERR_ARGS;
+    if (a->Nleft != -1 && (a->Nleft < 0 || a->Nleft > a->n)) return ORBFE_ERR_ARGS;
+    if (a->n >= PROJ_MAXN || a->nq >= (1 << 28)) return ORBFE_ERR_ARGS;
+    const bool orient = a->mode == 1 && a->check_orientation;
+    if (orient && a->nq && (!a->angle || !a->qangle)) return ORBFE_ERR_ARGS;
+    if (a->Nleft == -1 && a->uright && a->nq && !a->qxr) return ORBFE_ERR_ARGS;
+    for (int q = 0; q < a->nq; q++) {
+        const int f = a->qflags ? a->qflags[q] : 0;
+        if ((f & 1) && a->Nleft == -1) return ORBFE_ERR_ARGS; // there is no right grid
+        // a non-blocking map point (Observations()==0) that overwrites a stereo partner could free a taken
+        // feature again (:117-121); the sweep formulation does not represent that
+        if (a->qblocks && !a->qblocks[q] && a->mode == 0 && a->Nleft != -1 && (a->left_to_right || a->right_to_left))
+            return ORBFE_ERR_ARGS;
+    }
+    for (int i = 0; i < a->n; i++) feat_match[i] = -1;
+    if (a->nq == 0) return 0;
+    if (a->n == 0) {
+        for (int q = 0; q < a->nq; q++) q_match[q] = -1;
+        return 0;
+    }
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    ProjDev P{};
+    const size_t n = (size_t)a->n, nq = (size_t)a->nq;
+    uint8_t *dDesc, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
+    float *dKx, *dKy, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
+    int32_t *dOct, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
+    if ((r = s.up(&dDesc, a->desc, n * 32)) < 0) return r;
+    if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
+    if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
+    if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
+    if (a->uright && a->Nleft == -1 && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+    if (a->taken && (r = s.up(&dTaken, a->taken, n)) < 0) return r;
+    if (a->Nleft != -1 && a->mode == 0) {
+        if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
+        if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
+        for (int i = 0; a->left_to_right && i < a->Nleft; i++)
+            if (a->left_to_right[i] < -1 || a->left_to_right[i] >= a->n - a->Nleft) return ORBFE_ERR_ARGS;
+        for (int i = 0; a->right_to_left && i < a->n - a->Nleft; i++)
+            if (a->right_to_left[i] < -1 || a->right_to_left[i] >= a->Nleft) return ORBFE_ERR_ARGS;
+    }
+    if ((r = s.up(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
+    if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
+    if ((r = s.up(&dQy, a->qy, nq)) < 0) return r;
+    if ((r = s.up(&dQr, a->qr, nq)) < 0) return r;
+    if (dUr && (r = s.up(&dQxr, a->qxr, nq)) < 0) return r;
+    if ((r = s.up(&dQmin, a->qmin_level, nq)) < 0) return r;
+    if ((r = s.up(&dQmax, a->qmax_level, nq)) < 0) return r;
+    if (a->qflags && (r = s.up(&dQflags, a->qflags, nq)) < 0) return r;
+    if (a->qblocks && (r = s.up(&dQblocks, a->qblocks, nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.cellStart, nullptr, 2 * PROJ_CELLS + 1)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.cellItems, nullptr, n)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.cellOf, nullptr, n)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.minW, nullptr, 2 * n)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.state, nullptr, 6 * nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.qStart, nullptr, nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.qCount, nullptr, nq)) < 0) return r;
+    // outputs in one block: status[4] | qMatch[nq] | featMatch[n]
+    int32_t* dOut;
+    if ((r = s.up<int32_t>(&dOut, nullptr, 4 + nq + n)) < 0) return r;
+    P.status = dOut;
+    P.qMatch = dOut + 4;
+    P.featMatch = dOut + 4 + nq;
+    size_t keyCap = std::max<size_t>(64 * nq, 1 << 16);
+    if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
+    if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
+    P.keyCap = (int)keyCap;
+    P.desc = dDesc; P.kx = dKx; P.ky = dKy; P.octave = dOct; P.uright = dUr; P.taken = dTaken;
+    P.l2r = dL2r; P.r2l = dR2l; P.n = a->n; P.Nleft = a->Nleft;
+    P.minX = a->minX; P.minY = a->minY; P.wInv = a->gridWInv; P.hInv = a->gridHInv;
+    P.nq = a->nq; P.qdesc = dQdesc; P.qx = dQx; P.qy = dQy; P.qr = dQr; P.qxr = dQxr;
+    P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
+    P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
+    std::vector<int32_t> out(4 + nq + n);
+    for (int attempt = 0;; attempt++) {
+        {
+            KernelTimer timer;
+            hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
+            hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, 0, P);
+            hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
+        if (out[2] >= 0 && (size_t)out[2] <= keyCap) break;
+        // more candidate keys than the buffers hold: the kernel reported how many it needs
+        if (attempt > 0 || out[2] < 0) return ORBFE_ERR_STATE;
+        keyCap = (size_t)out[2];
+        if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
+        if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
+        P.keyCap = (int)keyCap;
+    }
+    int nmatches = out[0];
+    g_lastProjSweeps = out[1];
+    std::copy(out.begin() + 4, out.begin() + 4 + nq, q_match);
+    std::copy(out.begin() + 4 + nq, out.end(), feat_match);
+    if (orient) { // rotation histogram of :2307-2323 / :2397-2416 over the matches in query order
+        std::vector<int8_t> bins(nq, -1);
+        int histo[HISTO_LENGTH] = {0};
+        for (size_t q = 0; q < nq; q++)
+            if (q_match[q] >= 0) {
+                float rot = a->qangle[q] - a->angle[q_match[q]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[q] = (int8_t)bin;
+                if (bin >= 0 && bin < HISTO_LENGTH) histo[bin]++;
+            }
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (size_t q = 0; q < nq; q++)
+            if (q_match[q] >= 0 && bins[q] != ind1 && bins[q] != ind2 && bins[q] != ind3) {
+                feat_match[q_match[q]] = -1;
+                nmatches--;
+            }
+    }
+    return nmatches;
+}
+
+int orbfe_search_projection_last_sweeps(void) { return g_lastProjSweeps; }
 
 int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best)
 {

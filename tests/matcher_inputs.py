@@ -58,3 +58,80 @@ def tri_inputs(n1, n2, seed):
     ep = (900.0, 250.0)
     return dict(d1=d1, d2=d2, a1=a1, a2=a2, fv1=fv1, fv2=fv2, kp1=kp1, kp2=kp2, oct1=oct1, oct2=oct2, u1=u1, u2=u2,
                 has1=has1, has2=has2, F12=F12, sf=sf, sig=sig, ep=ep)
+
+
+def projection_problem(seed, n=1200, nq=900, mode=0, stereo=False, Nleft=-1, th=1.0, nnratio=0.8, taken_frac=0.1,
+                       crowd=True, check_orientation=False, partners=False, blocks=None, w=752, h=480):
+    """Flattened SearchByProjection problem (fields of orbfe_proj_args).  Queries are map points that project
+    near existing features, with descriptors a few bits away; `crowd` makes several queries compete for the
+    same feature so that the sequential occupancy rule matters."""
+    rng = np.random.default_rng(seed)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    kx = rng.uniform(-3, w + 3, n).astype(np.float32)
+    ky = rng.uniform(-3, h + 3, n).astype(np.float32)
+    if crowd:  # clusters: many features inside one window
+        k = n // 4
+        cx, cy = rng.uniform(50, w - 50, 12), rng.uniform(50, h - 50, 12)
+        c = rng.integers(0, 12, k)
+        kx[:k] = (cx[c] + rng.normal(0, 6, k)).astype(np.float32)
+        ky[:k] = (cy[c] + rng.normal(0, 6, k)).astype(np.float32)
+    octave = rng.integers(0, 8, n).astype(np.int32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    angle = rng.uniform(0, 360, n).astype(np.float32)
+    pr = dict(desc=desc, kx=kx, ky=ky, octave=octave, angle=angle, Nleft=Nleft,
+              minX=np.float32(-2.5), minY=np.float32(-1.5),
+              gridWInv=np.float32(64) / np.float32(w + 4.0), gridHInv=np.float32(48) / np.float32(h + 3.5),
+              mode=mode, nnratio=nnratio, th_high=100, check_orientation=int(check_orientation))
+    pr["taken"] = (rng.random(n) < taken_frac).astype(np.uint8)
+    if stereo:
+        ur = np.where(rng.random(n) < 0.6, kx - rng.uniform(1, 40, n), -1).astype(np.float32)
+        pr["uright"] = ur
+    tgt = rng.integers(0, n, nq)
+    if crowd:
+        tgt[: nq // 3] = rng.integers(0, max(n // 4, 1), nq // 3)  # compete inside the clusters
+        tgt[nq // 3: nq // 2] = tgt[: nq // 2 - nq // 3]           # exact duplicates of earlier targets
+    qdesc = desc[tgt].copy()
+    bits = np.unpackbits(qdesc, axis=1)
+    flips = rng.random(bits.shape) < rng.uniform(0.0, 0.25, (nq, 1))
+    qdesc = np.packbits(bits ^ flips, axis=1)
+    qx = (kx[tgt] + rng.normal(0, 2.0, nq)).astype(np.float32)
+    qy = (ky[tgt] + rng.normal(0, 2.0, nq)).astype(np.float32)
+    lvl = np.clip(octave[tgt] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+    if mode == 0:  # RadiusByViewingCos (:199-205) times th
+        rad = np.where(rng.random(nq) < 0.5, np.float32(2.5), np.float32(4.0)).astype(np.float32)
+        if th != 1.0:
+            rad = (rad * np.float32(th)).astype(np.float32)
+    else:          # radius = th * mvScaleFactors[nLastOctave] (:2244)
+        rad = np.full(nq, th, np.float32)
+    pr["qr"] = (rad * sf[lvl]).astype(np.float32)
+    if mode == 0:
+        pr["qmin_level"] = (lvl - 1).astype(np.int32)
+        pr["qmax_level"] = lvl
+    else:
+        kind = rng.integers(0, 3, nq)  # forward / backward / neither (:2248-2253)
+        pr["qmin_level"] = np.where(kind == 0, lvl, np.where(kind == 1, 0, lvl - 1)).astype(np.int32)
+        pr["qmax_level"] = np.where(kind == 0, -1, np.where(kind == 1, lvl, lvl + 1)).astype(np.int32)
+    pr.update(qdesc=qdesc, qx=qx, qy=qy, qangle=rng.uniform(0, 360, nq).astype(np.float32))
+    if stereo:
+        t_ur = pr["uright"][tgt]
+        pr["qxr"] = np.where(t_ur > 0, t_ur + rng.normal(0, 3.0, nq), qx - 10).astype(np.float32)
+    if Nleft != -1:
+        right = (tgt >= Nleft)
+        flags = right.astype(np.uint8)
+        if mode == 0:  # right-camera searches directly after a left one are linked to it
+            prev_left = np.concatenate([[False], ~right[:-1]])
+            flags |= ((right & prev_left & (rng.random(nq) < 0.7)).astype(np.uint8) << 1)
+        pr["qflags"] = flags
+        if partners:
+            nr = n - Nleft
+            l2r = np.full(Nleft, -1, np.int32)
+            r2l = np.full(nr, -1, np.int32)
+            m = min(Nleft, nr) // 3
+            li = rng.permutation(Nleft)[:m]
+            ri = rng.permutation(nr)[:m]
+            l2r[li] = ri
+            r2l[ri] = li
+            pr["left_to_right"], pr["right_to_left"] = l2r, r2l
+    if blocks is not None:
+        pr["qblocks"] = (rng.random(nq) < blocks).astype(np.uint8)
+    return pr

@@ -198,3 +198,45 @@ def test_distinctive_descriptors(pkg, oracle):
     ref = oracle.distinctive_descriptors(pool, offsets)
     assert np.array_equal(got, ref)
     assert got[11] == -1 and got[0] == 0
+
+
+PROJ_CASES = [
+    dict(seed=1, mode=0),
+    dict(seed=2, mode=0, stereo=True, th=3.0),
+    dict(seed=3, mode=0, Nleft=700, partners=True),
+    dict(seed=4, mode=0, Nleft=500, partners=False, th=5.0, nnratio=0.9),
+    dict(seed=5, mode=1, check_orientation=True, th=7.0),
+    dict(seed=6, mode=1, stereo=True, th=15.0, check_orientation=True),
+    dict(seed=7, mode=1, Nleft=650, th=15.0, check_orientation=False),
+    dict(seed=8, mode=0, blocks=0.7, th=3.0),
+    dict(seed=9, mode=1, blocks=0.5, th=10.0, check_orientation=True),
+    dict(seed=10, mode=0, n=4000, nq=6000, th=5.0, taken_frac=0.0),
+    dict(seed=11, mode=0, n=3, nq=40),
+    dict(seed=12, mode=1, n=200, nq=1, crowd=False),
+    dict(seed=13, mode=0, n=3000, nq=200, th=200.0),  # every feature is a candidate: key buffers regrow
+]
+
+
+@pytest.mark.parametrize("case", PROJ_CASES, ids=lambda c: "s%d" % c["seed"])
+def test_search_projection(pkg, oracle, case):
+    """SearchByProjection inner loops incl. the sequential occupancy rule (src/ORBmatcher.cc:83-85)."""
+    from matcher_inputs import projection_problem
+    pr = projection_problem(**case)
+    n_ref, q_ref, f_ref = oracle.search_projection(pr)
+    n_got, q_got, f_got = pkg.search_projection(pr)
+    assert n_got == n_ref
+    assert np.array_equal(q_got, q_ref)
+    assert np.array_equal(f_got, f_ref)
+    if case["seed"] in (1, 5, 10):
+        assert n_ref > 50  # the case is not vacuous
+        assert pkg.search_projection_last_sweeps() >= 2  # and the occupancy rule was exercised
+
+
+def test_search_projection_errors(pkg):
+    from matcher_inputs import projection_problem
+    pr = projection_problem(1, mode=0, Nleft=700, partners=True, blocks=0.5)
+    with pytest.raises(RuntimeError):
+        pkg.search_projection(pr)  # non-blocking map points + stereo partner writes: refused, not approximated
+    pr = projection_problem(1, n=50, nq=0)
+    n, q, f = pkg.search_projection(pr)
+    assert n == 0 and len(q) == 0 and (f == -1).all()

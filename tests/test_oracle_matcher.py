@@ -1,5 +1,6 @@
 """CPU-only checks of the matcher oracle (KATs from first principles)."""
 import numpy as np
+import pytest
 
 import matcher_inputs as MI
 
@@ -111,3 +112,113 @@ def test_distinctive_descriptors_against_numpy_spec(oracle):
         dist = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(axis=2)
         med = np.sort(dist, axis=1)[:, int(0.5 * (n - 1))]
         assert got[p] == int(np.argmin(med))
+
+
+def _proj_spec(pr):
+    """Independent restatement of SearchByProjection's inner loops: brute force over all features instead of
+    the grid walk (visit order = cell column, cell row, feature index), dict-free sequential occupancy."""
+    f32 = np.float32
+    n, nq, Nleft, mode = len(pr["kx"]), len(pr["qx"]), pr["Nleft"], pr["mode"]
+    cx = np.round((pr["kx"] - f32(pr["minX"])) * f32(pr["gridWInv"]))
+    cy = np.round((pr["ky"] - f32(pr["minY"])) * f32(pr["gridHInv"]))
+    # np.round is half-even, C round() is half-away: fix exact .5 cases
+    for arr, src, mn, inv in ((cx, pr["kx"], pr["minX"], pr["gridWInv"]), (cy, pr["ky"], pr["minY"], pr["gridHInv"])):
+        v = (src - f32(mn)) * f32(inv)
+        half = (np.abs(v - np.trunc(v)) == 0.5)
+        arr[half] = np.trunc(v[half]) + np.sign(v[half])
+    ingrid = (cx >= 0) & (cx < 64) & (cy >= 0) & (cy < 48)
+    order = np.lexsort((np.arange(n), cy, cx))
+    occ = [(-1 if (pr.get("taken") is not None and pr["taken"][i]) else -2) for i in range(n)]
+    blocks = pr.get("qblocks")
+    feat = np.full(n, -1, np.int32)
+    qm = np.full(nq, -1, np.int32)
+    flags = pr.get("qflags")
+    nmatches, prev_rej = 0, False
+    writes_hist = []
+    for q in range(nq):
+        right = bool(flags is not None and flags[q] & 1)
+        linked = bool(flags is not None and flags[q] & 2)
+        skip, prev_rej = linked and prev_rej, False
+        if skip:
+            continue
+        x, y, r = pr["qx"][q], pr["qy"][q], pr["qr"][q]
+        mn, mx = pr["qmin_level"][q], pr["qmax_level"][q]
+        best = (256, -1, -1)
+        second = (256, -1)
+        for g in order:
+            if not ingrid[g]:
+                continue
+            if Nleft != -1 and (g >= Nleft) != right:
+                continue
+            if pr["octave"][g] < mn or (mx >= 0 and pr["octave"][g] > mx):
+                continue
+            if not (abs(pr["kx"][g] - x) < r and abs(pr["ky"][g] - y) < r):
+                continue
+            o = occ[g]
+            if o == -1 or (o >= 0 and (blocks is None or blocks[o])):
+                continue
+            if not right and Nleft == -1 and pr.get("uright") is not None and pr["uright"][g] > 0:
+                if abs(pr["qxr"][q] - pr["uright"][g]) > r:
+                    continue
+            d = int(np.unpackbits(pr["qdesc"][q] ^ pr["desc"][g]).sum())
+            if d < best[0]:
+                second = (best[0], best[1])
+                best = (d, int(pr["octave"][g]), int(g))
+            elif mode == 0 and d < second[0]:
+                second = (d, int(pr["octave"][g]))
+        if best[2] < 0 or best[0] > pr["th_high"]:
+            continue
+        if mode == 0 and best[1] == second[1] and f32(best[0]) > f32(pr["nnratio"]) * f32(second[0]):
+            prev_rej = True
+            continue
+        g = best[2]
+        targets = [g]
+        if mode == 0 and Nleft != -1:
+            if not right and pr.get("left_to_right") is not None and pr["left_to_right"][g] != -1:
+                targets.append(int(pr["left_to_right"][g]) + Nleft)
+            if right and pr.get("right_to_left") is not None and pr["right_to_left"][g - Nleft] != -1:
+                targets.append(int(pr["right_to_left"][g - Nleft]))
+        for t in targets:
+            occ[t] = q
+            feat[t] = q
+            nmatches += 1
+        qm[q] = g
+        if mode == 1 and pr["check_orientation"]:
+            rot = f32(pr["qangle"][q]) - f32(pr["angle"][g])
+            if rot < 0:
+                rot = f32(rot + f32(360.0))
+            b = int(np.floor(f32(rot * f32(1.0 / 30)) + f32(0.5)))
+            writes_hist.append((0 if b == 30 else b, g))
+    if mode == 1 and pr["check_orientation"]:
+        cnt = np.bincount([b for b, _ in writes_hist], minlength=30)
+        top = sorted(range(30), key=lambda i: (-cnt[i], i))[:3]
+        m1 = cnt[top[0]]
+        keep = {top[0]} if m1 > 0 else set()
+        if m1 > 0 and not cnt[top[1]] < f32(0.1) * f32(m1):
+            keep.add(top[1])
+            if not cnt[top[2]] < f32(0.1) * f32(m1):
+                keep.add(top[2])
+        for b, g in writes_hist:
+            if b not in keep:
+                feat[g] = -1
+                nmatches -= 1
+    return nmatches, qm, feat
+
+
+@pytest.mark.parametrize("case", [
+    dict(seed=21, mode=0, n=300, nq=260),
+    dict(seed=22, mode=0, n=300, nq=260, stereo=True, th=3.0),
+    dict(seed=23, mode=0, n=320, nq=300, Nleft=170, partners=True, th=3.0),
+    dict(seed=24, mode=1, n=300, nq=260, th=7.0, check_orientation=True),
+    dict(seed=25, mode=1, n=300, nq=260, Nleft=150, th=15.0),
+    dict(seed=26, mode=0, n=300, nq=260, blocks=0.6, th=3.0),
+], ids=lambda c: "s%d" % c["seed"])
+def test_search_projection_against_bruteforce_spec(oracle, case):
+    from matcher_inputs import projection_problem
+    pr = projection_problem(**case)
+    n_ref, q_ref, f_ref = _proj_spec(pr)
+    n_got, q_got, f_got = oracle.search_projection(pr)
+    assert n_ref > 10
+    assert np.array_equal(q_got, q_ref)
+    assert np.array_equal(f_got, f_ref)
+    assert n_got == n_ref

@@ -86,6 +86,19 @@ def main():
            lambda: O.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"],
                                           I["d2"], I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"],
                                           I["F12"], I["ep"], I["sf"], I["sig"]))
+    # Tracking::SearchLocalPoints-sized projection search (1500 local map points into a 2000-feature frame)
+    pr = MI.projection_problem(31, n=2000, nq=1500, mode=0, stereo=True, th=1.0, crowd=False)
+    report("SearchByProjection(F, local map) N=2000, 1500 points", 1500, "map points",
+           lambda: pkg.search_projection(pr), lambda: O.search_projection(pr))
+    pr2 = MI.projection_problem(32, n=2000, nq=1500, mode=1, stereo=True, th=15.0, crowd=False, check_orientation=True)
+    report("SearchByProjection(Current, Last) N=2000, 1500 points, th=15", 1500, "map points",
+           lambda: pkg.search_projection(pr2), lambda: O.search_projection(pr2))
+    sizes = rng.integers(2, 25, size=4000)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pool = rng.integers(0, 256, size=(int(offs[-1]), 32), dtype=np.uint8)
+    report("ComputeDistinctiveDescriptors, 4000 map points", 4000, "map points",
+           lambda: pkg.distinctive_descriptors(pool, offs), lambda: O.distinctive_descriptors(pool, offs))
+    print(json.dumps({"op": "projection sweeps", "mode0": None, "last": pkg.search_projection_last_sweeps()}))
 
 
 if __name__ == "__main__":
