@@ -197,6 +197,7 @@ def main():
         # HBM bytes per launch from the rocprofv3 counter passes (tools/collect_profiles.sh, collected in
         # separate --pmc runs and corrected with the FETCH_SIZE calibration), if they match this workload
         traffic = None
+        valu_issue = None
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
                      "desc": "k_orient_blur_desc<0>", "trigfix": "k_orient_blur_desc<1>"}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -207,6 +208,11 @@ def main():
                     for k, e in j.get("kernels", {}).items():
                         if k.startswith(kernel_of[dom]) and "hbm_bytes_per_launch" in e:
                             traffic = e["hbm_bytes_per_launch"]
+                            # share of the chip's VALU issue slots this kernel's wave-instructions occupy
+                            # (1024 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz): the bound that
+                            # actually binds these integer kernels
+                            if "SQ_INSTS_VALU" in e and e.get("avg_duration_us"):
+                                valu_issue = e["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6)
             except Exception:
                 traffic = None
         out = {
@@ -239,6 +245,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                "valu_issue_frac": valu_issue,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_ms": stage_ms[dom],
                 "stage_ms": stage_ms,

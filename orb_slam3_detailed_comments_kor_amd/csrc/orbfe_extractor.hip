@@ -118,6 +118,7 @@ struct orbfe_ctx {
     int nStreams = 1;            // ORBFE_STREAMS env / orbfe_set_streams: sub-batches on separate streams
     hipStream_t sub[8] = {};
     hipEvent_t evFork = nullptr, evJoin[8] = {};
+    int xcdAffine = 1;           // ORBFE_XCD_AFFINE env: whole images per XCD when the batch is a multiple of 8
     int fastDbgStop = 0;         // ORBFE_FAST_STOP env: phase ablation for profiling only (results invalid)
 
     // device state
@@ -603,7 +604,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // K-DESC
         hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                           c->d_patternF.p, c->d_fix.p, 0, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0, i0);
+                           c->d_patternF.p, c->d_fix.p, 0, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0, i0,
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0);
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
             HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
@@ -652,7 +654,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0);
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0);
         c->lastFixups = nFix;
     }
     rec(c, 6);
@@ -689,6 +691,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(1, atoi(e));
     if (const char* e = getenv("ORBFE_FAST_STOP")) c->fastDbgStop = atoi(e);
+    if (const char* e = getenv("ORBFE_XCD_AFFINE")) c->xcdAffine = atoi(e);
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (c->nStreams > 1) {
         bool ok = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;

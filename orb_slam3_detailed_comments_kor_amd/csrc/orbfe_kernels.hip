@@ -1124,14 +1124,23 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           int4* fixList /* MODE 0: out {img<<16|g, angle, a, b} (float
                                                                            bits) after a 16-B header whose first word
                                                                            is the count; MODE 1: in {img<<16|g, -, a, b} */,
-                                                          int nFix, int listFragile, int imgBase)
+                                                          int nFix, int listFragile, int imgBase, int xcdAffine)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int img, g;
     if (MODE == 0) {
-        img = (int)blockIdx.y + imgBase;
-        g = blockIdx.x * 4 + wave;
+        // XCD affinity: workgroups are dealt round-robin over the 8 XCDs in linear-id order; with a
+        // multiple of 8 images every XCD keeps whole images to itself, so a pyramid is fetched into one
+        // L2 instead of eight (measured: 258 MB -> see DESIGN.md per 64 frames)
+        int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+        if (xcdAffine) {
+            const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, k = lin >> 3;
+            by = 8 * (int)(k / gridDim.x) + (int)(lin & 7);
+            bx = (int)(k % gridDim.x);
+        }
+        img = by + imgBase;
+        g = bx * 4 + wave;
         if (g >= nOut[img]) return; // wave-uniform
     } else {
         const int f = blockIdx.x * 4 + wave;
