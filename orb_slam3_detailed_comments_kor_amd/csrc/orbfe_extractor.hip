@@ -139,6 +139,8 @@ struct orbfe_ctx {
     DevBuf<OrbResizeY> d_ytab;
     DevBuf<OrbPyrRange> d_prx, d_pry;
     int pyrNtx = 0, pyrNty = 0, pyrBuf0 = 0, pyrBuf1 = 0, pyrStageX = 0, pyrStageY = 0;
+    size_t pyrLdsBytes = 0;
+    bool pyrWeightsOk = true; // all resize weights in [0, 2050] with a0+a1, b0+b1 <= 2050 (k_pyr_fused drops the clamp)
     bool pyrFused = true;
     DevBuf<int> d_taps;
     DevBuf<float4> d_patternF;
@@ -198,6 +200,7 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     c->cg.clear();
     xtab.clear();
     ytab.clear();
+    c->pyrWeightsOk = true;
     size_t off = 0;
     int slot = 0, kpBase = 0, keyBase = 0, maxKp = 0, maxLC = 0;
     for (int l = 0; l < nl; l++) {
@@ -297,7 +300,10 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
                 t.pad = (uint16_t)std::min(sx + 1, S.w - 1);
                 t.a0 = sat_s16(cv_round_f((1.f - fx) * 2048));
                 t.a1 = sat_s16(cv_round_f(fx * 2048));
+                if (t.a0 < 0 || t.a1 < 0 || t.a0 + t.a1 > 2050) c->pyrWeightsOk = false;
                 xtab.push_back(t);
+                // k_pyr_fused: the source pixels of any 4 consecutive destination columns fit an 8-byte window
+                if (dx >= 3 && (int)t.sx - (int)xtab[xtab.size() - 4].sx > 6) c->pyrWeightsOk = false;
             }
             for (int dy = 0; dy < L.h; dy++) {
                 float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -308,6 +314,7 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
                 t.sy1 = (uint16_t)std::min(std::max(sy + 1, 0), S.h - 1);
                 t.b0 = sat_s16(cv_round_f((1.f - fy) * 2048));
                 t.b1 = sat_s16(cv_round_f(fy * 2048));
+                if (t.b0 < 0 || t.b1 < 0 || t.b0 + t.b1 > 2050) c->pyrWeightsOk = false;
                 ytab.push_back(t);
             }
         }
@@ -471,7 +478,11 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
             for (int l = 1; l < nl; l++) sum += pry[(size_t)l * c->pyrNty + j].needHi - pry[(size_t)l * c->pyrNty + j].lo;
             c->pyrStageY = std::max(c->pyrStageY, sum);
         }
-        c->pyrFused = (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY) <= 64 * 1024 &&
+        // staged x entries 8 B (padded to an even count), y entries 16 B; the kernel deals whole column
+        // groups (4 px) of a region row to its 256 threads
+        c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + (c->pyrStageX & 1)) +
+                         16 * (size_t)c->pyrStageY;
+        c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk &&
                       getenv("ORBFE_PYR_UNFUSED") == nullptr;
     }
     if (c->qtLdsBytes > 64 * 1024)
@@ -558,7 +569,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // K-PYR
         if (c->pyrFused) {
             hipLaunchKernelGGL(k_pyr_fused, dim3((unsigned)c->pyrNtx, (unsigned)c->pyrNty, (unsigned)ni), dim3(256),
-                               (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY), q, d_imgs,
+                               c->pyrLdsBytes, q, d_imgs,
                                pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p,
                                c->pyrNtx, c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
                                cols, i0);

@@ -108,12 +108,15 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                                                    const OrbResizeY* __restrict__ ytab, int bufBytes0,
                                                    int bufBytes1, int stageX, int imgCols, int imgBase)
 {
-    // dynamic LDS: region buffer A | region buffer B | staged x-table slices | staged y-table slices
+    // dynamic LDS: region buffer A | region buffer B | staged x entries (8 B) | staged y entries (16 B)
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
     uint8_t* bufA = pyr_lds;
     uint8_t* bufB = pyr_lds + bufBytes0;
-    OrbResizeX* xt = reinterpret_cast<OrbResizeX*>(pyr_lds + bufBytes0 + bufBytes1);
-    OrbResizeY* yt = reinterpret_cast<OrbResizeY*>(xt + stageX);
+    // staged x entry: .x = source column relative to the source region, .y = a0 | a1 << 16
+    // staged y entry: .x / .y = LDS byte offset of source row sy0 / sy1 inside the source region,
+    //                 .z / .w = b0 << 16 / b1 << 16  ((b * t) >> 16 == mulhi(b << 16, t))
+    uint2* xt = reinterpret_cast<uint2*>(pyr_lds + bufBytes0 + bufBytes1);
+    uint4* yt = reinterpret_cast<uint4*>(xt + stageX + (stageX & 1)); // 16-B aligned
     const int tid = threadIdx.x;
     const int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z + imgBase;
     uint8_t* base = pyr + (size_t)img * pyrImgStride;
@@ -140,125 +143,165 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         lvRecip[tid] = ng > 1 ? (unsigned)(((1ull << 32) + (unsigned)ng - 1) / (unsigned)ng) : 0u;
     }
     __syncthreads();
-    // stage the interpolation-table slices of every level (all loads in flight at once; the per-pixel
-    // loop below then touches LDS only)
+    // stage the interpolation tables of every level, already reduced to what the inner loop needs
+    // (region-relative LDS offsets, packed weights); all global loads are in flight at once and the
+    // per-pixel loop below then touches LDS only
     {
         int xo = 0, yo = 0;
         for (int l = 1; l < nlevels; l++) {
             const int nW = lvXneed[l] - lvXlo[l], nH = lvYneed[l] - lvYlo[l];
             const int xb = lvXt[l] + lvXlo[l], yb = lvYt[l] + lvYlo[l];
-            for (int k = tid; k < nW; k += 256) xt[xo + k] = xtab[xb + k];
-            for (int k = tid; k < nH; k += 256) yt[yo + k] = ytab[yb + k];
+            const int sLoX = lvXlo[l - 1], sLoY = lvYlo[l - 1];
+            const int sPitch = (lvXneed[l - 1] - sLoX + 3) & ~3; // LDS pitch of the source region
+            for (int k = tid; k < nW; k += 256) {
+                const OrbResizeX e = xtab[xb + k];
+                xt[xo + k] = make_uint2((unsigned)((int)e.sx - sLoX), (unsigned)(uint16_t)e.a0 | ((unsigned)(uint16_t)e.a1 << 16));
+            }
+            for (int k = tid; k < nH; k += 256) {
+                const OrbResizeY e = ytab[yb + k];
+                yt[yo + k] = make_uint4((unsigned)(((int)e.sy0 - sLoY) * sPitch), (unsigned)(((int)e.sy1 - sLoY) * sPitch),
+                                        (unsigned)(uint16_t)e.b0 << 16, (unsigned)(uint16_t)e.b1 << 16);
+            }
             xo += nW;
             yo += nH;
         }
     }
     // level 0: stage the needed region of the input image, write the owned part
     int nW = lvXneed[0] - lvXlo[0], nH = lvYneed[0] - lvYlo[0];
-    int sp = (nW + 3) & ~3; // LDS pitch of the current source region
     {
+        const int sp = (nW + 3) & ~3; // LDS pitch of the level-0 region
         const int pitch0 = lvPitch[0];
         const int xlo = lvXlo[0], ylo = lvYlo[0];
         const uint8_t* s0 = src + (size_t)img * srcImgStride + (size_t)ylo * srcPitch + xlo;
         uint8_t* d0 = base + (uint32_t)lvRoi[0] + (size_t)ylo * pitch0 + xlo;
         const int ownW = lvXown[0] - xlo, ownH = lvYown[0] - ylo;
-        // dword granularity (global dword accesses may be unaligned), 8 loads in flight per thread
+        // dword granularity (global dword accesses may be unaligned).  A thread keeps one dword column
+        // and walks down the rows, four loads in flight per step; no per-item division.
         const int ndw = (nW + 3) >> 2;           // dwords per region row (LDS pitch sp == 4*ndw)
-        const int nItems = ndw * nH;
         const int safeW = imgCols - xlo;         // bytes readable in a row without leaving the image row
-        for (int base0 = 0; base0 < nItems; base0 += 256 * 8) {
-            uint32_t v[8];
+        const unsigned rcp0 = lvRecip[0];
+        const int rr = rcp0 ? (int)__umulhi((unsigned)tid, rcp0) : tid; // tid / ndw
+        const int c = 4 * (tid - rr * ndw);
+        const int rpp = rcp0 ? (int)__umulhi(256u, rcp0) : 256;        // rows per pass
+        if (rr < rpp) {
+            const bool fullLoad = c + 4 <= safeW, colOwned = c < ownW, fullStore = c + 4 <= ownW;
+            const uint8_t* p = s0 + (size_t)rr * srcPitch + c;
+            uint8_t* q = d0 + (size_t)rr * pitch0 + c;
+            uint8_t* dq = bufA + rr * sp + c;
+            const size_t pStep = (size_t)rpp * srcPitch;
+            const int qStep = rpp * pitch0, dStep = rpp * sp;
+            for (int r = rr; r < nH; r += 4 * rpp) {
+                uint32_t v[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int idx = base0 + k * 256 + tid;
-                v[k] = 0;
-                if (idx < nItems) {
-                    const int r = idx / ndw, c = 4 * (idx - r * ndw);
-                    const uint8_t* p = s0 + (size_t)r * srcPitch + c;
-                    if (c + 4 <= safeW) {
-                        __builtin_memcpy(&v[k], p, 4);
-                    } else {
-                        for (int b = 0; c + b < safeW && b < 4; b++) v[k] |= (uint32_t)p[b] << (8 * b);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int idx = base0 + k * 256 + tid;
-                if (idx < nItems) {
-                    const int r = idx / ndw, c = 4 * (idx - r * ndw);
-                    *reinterpret_cast<uint32_t*>(bufA + r * sp + c) = v[k];
-                    if (r < ownH) {
-                        uint8_t* q = d0 + (size_t)r * pitch0 + c;
-                        if (c + 4 <= ownW) {
-                            __builtin_memcpy(q, &v[k], 4);
+                for (int k = 0; k < 4; k++) {
+                    v[k] = 0;
+                    if (r + k * rpp < nH) {
+                        const uint8_t* pk = p + k * pStep;
+                        if (fullLoad) {
+                            __builtin_memcpy(&v[k], pk, 4);
                         } else {
-                            for (int b = 0; c + b < ownW; b++) q[b] = (uint8_t)(v[k] >> (8 * b));
+                            for (int b = 0; c + b < safeW && b < 4; b++) v[k] |= (uint32_t)pk[b] << (8 * b);
                         }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int rk = r + k * rpp;
+                    if (rk < nH) {
+                        *reinterpret_cast<uint32_t*>(dq + k * dStep) = v[k];
+                        if (rk < ownH && colOwned) {
+                            uint8_t* qk = q + (size_t)k * qStep;
+                            if (fullStore) {
+                                __builtin_memcpy(qk, &v[k], 4);
+                            } else {
+                                for (int b = 0; c + b < ownW; b++) qk[b] = (uint8_t)(v[k] >> (8 * b));
+                            }
+                        }
+                    }
+                }
+                p += 4 * pStep;
+                q += 4 * (size_t)qStep;
+                dq += 4 * dStep;
             }
         }
     }
     __syncthreads();
-    int srcLoX = lvXlo[0], srcLoY = lvYlo[0];
     int xo = 0, yo = 0;
     const uint8_t* S = bufA;
     uint8_t* D = bufB;
+    typedef unsigned short pyr_us2 __attribute__((ext_vector_type(2)));
     for (int l = 1; l < nlevels; l++) {
         const int xlo = lvXlo[l], ylo = lvYlo[l], gpitch = lvPitch[l];
         nW = lvXneed[l] - xlo;
         nH = lvYneed[l] - ylo;
         const int dp = (nW + 3) & ~3;
-        uint8_t* g = base + (uint32_t)lvRoi[l] + (size_t)ylo * gpitch + xlo;
         const int ownW = lvXown[l] - xlo, ownH = lvYown[l] - ylo;
-        // item = (row, group of 4 destination columns); flat index, idx / groups-per-row by reciprocal.
-        // Source pixels of the 4 columns span <= 9 bytes of each source row: 3 aligned dword LDS reads per
-        // row, bytes picked with v_alignbyte; 4 results leave as one dword LDS store.
+        // A thread keeps one group of 4 destination columns (its four x entries stay in registers) and
+        // walks down the rows.  Per row: one 16-B y entry and, from each of the two source rows, three
+        // ALIGNED dwords starting at the dword of the group's first source pixel (a misaligned LDS access
+        // costs 64 cycles per wave on gfx950, tools/lds_rate.hip); two v_alignbyte_b32 turn them into
+        // the 8 bytes that start at that pixel, and every destination pixel picks its source pair
+        // (sx, sx+1) with one v_perm_b32 whose selector is a per-column constant (the host checks that the
+        // four columns of any group span at most 7 source pixels).  Then two v_dot2_u32_u16 against the
+        // packed (a0, a1) and two v_mul_hi_u32 against b << 16.  sx+1 instead of min(sx+1, w-1) is
+        // harmless: a1 == 0 there.
         const int nG = dp >> 2;
         const unsigned rcp = lvRecip[l];
-        for (int idx = tid; idx < nG * nH; idx += 256) {
-            const int r = rcp ? (int)__umulhi((unsigned)idx, rcp) : idx;
-            const int c0 = 4 * (idx - r * nG);
-            const OrbResizeY tY = yt[yo + r];
-            OrbResizeX tX[4];
+        const int rr = rcp ? (int)__umulhi((unsigned)tid, rcp) : tid; // tid / nG
+        const int g = tid - rr * nG;
+        const int rowsPerPass = rcp ? (int)__umulhi(256u, rcp) : 256;  // 256 / nG (host guarantees nG <= 256)
+        const int c0 = 4 * g;
+        if (rr < rowsPerPass) {
+            uint2 X[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) tX[k] = xt[xo + min(c0 + k, nW - 1)];
-            const int sxr0 = (int)tX[0].sx - srcLoX;
-            const int sbase = sxr0 & ~3;
-            const uint32_t* S0 = reinterpret_cast<const uint32_t*>(S + ((int)tY.sy0 - srcLoY) * sp + sbase);
-            const uint32_t* S1 = reinterpret_cast<const uint32_t*>(S + ((int)tY.sy1 - srcLoY) * sp + sbase);
-            const uint32_t d0 = S0[0], d1 = S0[1], d2 = S0[2];
-            const uint32_t e0 = S1[0], e1 = S1[1], e2 = S1[2];
-            uint32_t packed = 0;
+            for (int k = 0; k < 4; k++) X[k] = xt[xo + min(c0 + k, nW - 1)];
+            const uint32_t xbase = X[0].x & ~3u, sh = X[0].x & 3u;
+            uint32_t sel[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int i = (int)tX[k].sx - srcLoX - sbase; // 0..7; the right neighbour is byte i+1
-                const bool up = i >= 4;
-                // (sx, sx+1) as the low 16 bits; sx+1 instead of min(sx+1, w-1) is harmless: a1 == 0 there
-                const uint32_t p0 = __builtin_amdgcn_alignbyte(up ? d2 : d1, up ? d1 : d0, i & 3);
-                const uint32_t p1 = __builtin_amdgcn_alignbyte(up ? e2 : e1, up ? e1 : e0, i & 3);
-                const int a0 = tX[k].a0, a1 = tX[k].a1;
-                const int h0 = (int)(p0 & 0xFFu) * a0 + (int)((p0 >> 8) & 0xFFu) * a1;
-                const int h1 = (int)(p1 & 0xFFu) * a0 + (int)((p1 >> 8) & 0xFFu) * a1;
-                int v = ((((int)tY.b0 * (h0 >> 4)) >> 16) + (((int)tY.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                v = min(max(v, 0), 255);
-                packed |= (uint32_t)v << (8 * k);
+                const uint32_t o = X[k].x - X[0].x; // 0..6
+                sel[k] = 0x0C000C00u | o | ((o + 1u) << 16);
             }
-            *reinterpret_cast<uint32_t*>(D + r * dp + c0) = packed;
-            if (r < ownH && c0 < ownW) {
-                uint8_t* q = g + (size_t)r * gpitch + c0;
-                if (c0 + 4 <= ownW) {
-                    __builtin_memcpy(q, &packed, 4);
-                } else {
-                    for (int k = 0; c0 + k < ownW; k++) q[k] = (uint8_t)(packed >> (8 * k));
+            // destination addresses advance by whole passes (no per-row multiplies)
+            uint8_t* q = base + (uint32_t)lvRoi[l] + (size_t)(ylo + rr) * gpitch + xlo + c0;
+            uint8_t* dq = D + rr * dp + c0;
+            const int qStep = rowsPerPass * gpitch, dStep = rowsPerPass * dp;
+            const bool colOwned = c0 < ownW, fullDword = c0 + 4 <= ownW;
+            for (int r = rr; r < nH; r += rowsPerPass, q += qStep, dq += dStep) {
+                const uint4 Y = yt[yo + r];
+                const uint32_t* S0 = reinterpret_cast<const uint32_t*>(S + Y.x + xbase);
+                const uint32_t* S1 = reinterpret_cast<const uint32_t*>(S + Y.y + xbase);
+                const uint32_t d0 = S0[0], d1 = S0[1], d2 = S0[2];
+                const uint32_t e0 = S1[0], e1 = S1[1], e2 = S1[2];
+                const uint32_t W0 = __builtin_amdgcn_alignbyte(d1, d0, sh), W1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                const uint32_t V0 = __builtin_amdgcn_alignbyte(e1, e0, sh), V1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
+                uint32_t t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t p0 = __builtin_amdgcn_perm(W1, W0, sel[k]); // (I[sx], I[sx+1]) as two u16
+                    const uint32_t p1 = __builtin_amdgcn_perm(V1, V0, sel[k]);
+                    const pyr_us2 a = *reinterpret_cast<const pyr_us2*>(&X[k].y);
+                    const uint32_t h0 = __builtin_amdgcn_udot2(*reinterpret_cast<const pyr_us2*>(&p0), a, 0u, false);
+                    const uint32_t h1 = __builtin_amdgcn_udot2(*reinterpret_cast<const pyr_us2*>(&p1), a, 0u, false);
+                    // cv::resize: (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+                    t[k] = __umulhi(Y.z, h0 >> 4) + __umulhi(Y.w, h1 >> 4);
+                }
+                // (t + 2) >> 2 on two 16-bit fields at a time (t <= 1021: the host checks a0 + a1 <= 2050 and
+                // b0 + b1 <= 2050, so the result is <= 255 and needs no saturation), then interleave the bytes
+                const uint32_t u02 = (((t[0] | (t[2] << 16)) + 0x00020002u) >> 2) & 0x00FF00FFu;
+                const uint32_t u13 = (((t[1] | (t[3] << 16)) + 0x00020002u) >> 2) & 0x00FF00FFu;
+                const uint32_t packed = u02 | (u13 << 8);
+                *reinterpret_cast<uint32_t*>(dq) = packed;
+                if (r < ownH && colOwned) {
+                    if (fullDword) {
+                        __builtin_memcpy(q, &packed, 4);
+                    } else {
+                        for (int k = 0; c0 + k < ownW; k++) q[k] = (uint8_t)(packed >> (8 * k));
+                    }
                 }
             }
         }
         __syncthreads();
-        srcLoX = xlo;
-        srcLoY = ylo;
-        sp = dp;
         xo += nW;
         yo += nH;
         uint8_t* t = const_cast<uint8_t*>(S);
