@@ -126,7 +126,7 @@ struct orbfe_ctx {
     DevBuf<uint8_t> d_pyr, d_desc, d_img;
     DevBuf<uint32_t> d_cand, d_keys, d_lvlKp;
     DevBuf<uint16_t> d_keyNode;
-    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono, d_misc /* [0]=err */;
+    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono;
     DevBuf<int4> d_fix; // [0] = {count,0,0,0}, then one entry per flagged keypoint
     DevBuf<float> d_kps, d_kb8, d_rays;
     bool kb8On = false;
@@ -143,8 +143,9 @@ struct orbfe_ctx {
     bool pyrWeightsOk = true; // all resize weights in [0, 2050] with a0+a1, b0+b1 <= 2050 (k_pyr_fused drops the clamp)
     bool pyrFused = true;
     DevBuf<int> d_taps;
+    bool tapsDirty = true;
     DevBuf<float4> d_patternF;
-    PinBuf<int32_t> h_misc, h_n, h_mono;
+    PinBuf<int32_t> h_n, h_mono;
     PinBuf<float> h_kps;
     PinBuf<uint8_t> h_desc;
     PinBuf<int4> h_fix, h_fixAB; // pinned: h_fixAB is read by the fix-up kernel directly (zero-copy)
@@ -511,8 +512,6 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
     if ((r = c->d_work.ensure(B * K)) < 0) return r;
     if ((r = c->d_fix.ensure(B * K + 1)) < 0) return r;
-    if ((r = c->d_misc.ensure(8)) < 0) return r;
-    if ((r = c->h_misc.ensure(8)) < 0) return r;
     if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fixAB.ensure(B * K + 1)) < 0) return r;
     if ((r = c->d_taps.ensure(8)) < 0) return r;
@@ -525,7 +524,6 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
         for (int i = 0; i < 256; i++) pf[i] = make_float4((float)pat[i][0], (float)pat[i][1], (float)pat[i][2], (float)pat[i][3]);
         HIP_TRY(hipMemcpy(c->d_patternF.p, pf.data(), 256 * sizeof(float4), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMemset(c->d_misc.p, 0, 8 * sizeof(int32_t)));
     c->capImgs = (int)B;
     c->capKp = (int)K;
     return 0;
@@ -548,10 +546,16 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
     hipStream_t s = c->stream;
     const int nl = c->nlevels;
-    HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
+    if (c->tapsDirty) { // 28 bytes, but a separate command on the stream: only when they changed
+        HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
+        c->tapsDirty = false;
+    }
     if (c->kb8On) HIP_TRY(hipMemcpyAsync(c->d_kb8.p, c->kb8, 8 * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, 2 * sizeof(int32_t), s));
-    HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
+    // 16-B header of the fix list = {fragile count, error flag, 0, 0}.  The fused pyramid kernel clears it
+    // (first command of the batch on this stream); the other configurations need a memset command.
+    int32_t* const d_hdr = reinterpret_cast<int32_t*>(c->d_fix.p);
+    const bool kernelClearsHdr = c->pyrFused && !(c->nStreams > 1 && nimg > 1);
+    if (!kernelClearsHdr) HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
     rec(c, 0);
     // Sub-batches on separate streams (ORBFE_STREAMS > 1): the image pipelines are independent, so the
     // latency-bound stages of one sub-batch overlap with the issue-bound stages of another.  Stage
@@ -572,7 +576,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                c->pyrLdsBytes, q, d_imgs,
                                pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p,
                                c->pyrNtx, c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
-                               cols, i0);
+                               cols, i0, kernelClearsHdr ? d_hdr : nullptr);
         } else {
             const OrbLevelGeom& L0 = c->lg[0];
             dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);
@@ -603,7 +607,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // K-QT
         hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)ni), dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                            c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
-                           c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, c->d_misc.p, i0,
+                           c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
                            c->qtKeyOff, c->qtKeyCap);
         if (nsub == 1) rec(c, 3);
         // K-PACK
@@ -632,13 +636,12 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // sampling grid is within a rounding hair of changing.  Evaluate the host libm cosf/sinf
         // (what the reference calls, src/ORBextractor.cc:111) for those; where libm differs from the
         // correctly rounded value, re-run the descriptor on the device with libm's (a, b).
-        // one D2H covers the error word, the count and the first 1023 entries (normally all of them)
+        // one D2H covers the header (count, error word) and the first 1023 entries (normally all of them)
         const size_t total = (size_t)c->capImgs * c->capKp;
         const size_t first = std::min<size_t>(1023, total);
-        HIP_TRY(hipMemcpyAsync(c->h_misc.p, c->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(c->h_fix.p, c->d_fix.p, (1 + first) * sizeof(int4), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (c->h_misc.p[0] != 0) return ORBFE_ERR_STATE;
+        if (c->h_fix.p[0].y != 0) return ORBFE_ERR_STATE;
         const size_t nFrag = std::min<size_t>((size_t)c->h_fix.p[0].x, total);
         if (nFrag > first) {
             HIP_TRY(hipMemcpyAsync(c->h_fix.p + 1 + first, c->d_fix.p + 1 + first, (nFrag - first) * sizeof(int4),
@@ -728,10 +731,10 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_pyr.release(); c->d_desc.release(); c->d_img.release();
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
-    c->d_misc.release(); c->d_fix.release(); c->d_kps.release(); c->d_kb8.release(); c->d_rays.release();
+    c->d_fix.release(); c->d_kps.release(); c->d_kb8.release(); c->d_rays.release();
     c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
     c->d_taps.release(); c->d_patternF.release();
-    c->h_misc.release(); c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release(); c->h_kps.release(); c->h_desc.release();
+    c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release(); c->h_kps.release(); c->h_desc.release();
     if (c->evReady)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -768,6 +771,7 @@ int orbfe_set_gaussian_taps(orbfe_ctx* c, const int* t)
     }
     if (sum > 257) return ORBFE_ERR_ARGS; // horizontal pass must fit 16 bits
     for (int i = 0; i < 7; i++) c->taps[i] = t[i];
+    c->tapsDirty = true;
     return 0;
 }
 
@@ -890,7 +894,7 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     HIP_TRY(hipStreamSynchronize(s));
     if (c->trigMode != ORBFE_TRIG_LIBM) {
         int32_t err = 0;
-        HIP_TRY(hipMemcpy(&err, c->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&err, reinterpret_cast<int32_t*>(c->d_fix.p) + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
         if (err) return ORBFE_ERR_STATE;
     }
     // two slab downloads into pinned staging (128 small copies cost ~1 ms for 64 images), then the

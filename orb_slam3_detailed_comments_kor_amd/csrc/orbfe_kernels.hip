@@ -106,8 +106,11 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                                                    const OrbPyrRange* __restrict__ ry, int ntx, int nty,
                                                    const OrbResizeX* __restrict__ xtab,
                                                    const OrbResizeY* __restrict__ ytab, int bufBytes0,
-                                                   int bufBytes1, int stageX, int imgCols, int imgBase)
+                                                   int bufBytes1, int stageX, int imgCols, int imgBase,
+                                                   int32_t* __restrict__ clearHdr /* 4 words or nullptr */)
 {
+    // first kernel of a batch: clear the {fragile count, error flag, -, -} header the later kernels append to
+    if (clearHdr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < 4) clearHdr[threadIdx.x] = 0;
     // dynamic LDS: region buffer A | region buffer B | staged x entries (8 B) | staged y entries (16 B)
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
     uint8_t* bufA = pyr_lds;
@@ -469,26 +472,33 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         cn = 0;
         kn = 0;
     }
-    // stage the ROI (rows x nd dwords), clear the score map; divisions by per-cell constants use
-    // host-made reciprocals (fast_div).  Loads are issued four at a time before the first LDS store.
+    // stage the ROI (rows x nd dwords) and clear the score map.  A thread keeps one dword column and walks
+    // down the rows (one division per thread by a host-made reciprocal, then constant strides); up to six
+    // loads are in flight before the first LDS store.
     {
-        const int nItems = ch * nd;
-        for (int base = 0; base < nItems; base += 4 * NT) {
-            uint32_t v[4];
-            int off[4];
+        const int r0 = fast_div((unsigned)tid, c.mNd), d = tid - r0 * nd;
+        const int rpp = fast_div((unsigned)NT, c.mNd); // rows per pass
+        if (r0 < rpp) {
+            const uint8_t* gp = roi + (size_t)r0 * gpitch + 4 * d;
+            const size_t gStep = (size_t)rpp * gpitch;
+            int off = r0 * PD + d;
+            const int oStep = rpp * PD;
+            for (int r = r0; r < ch; r += 6 * rpp) {
+                uint32_t v[6];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int idx = min(base + k * NT + tid, nItems - 1);
-                const int y = fast_div((unsigned)idx, c.mNd), d = idx - y * nd;
-                off[k] = y * PD + d;
-                v[k] = *reinterpret_cast<const uint32_t*>(roi + (size_t)y * gpitch + 4 * d);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (base + k * NT + tid < nItems) {
-                    reinterpret_cast<uint32_t*>(smap)[off[k]] = 0u;
-                    reinterpret_cast<uint32_t*>(tile)[off[k]] = v[k];
+                for (int k = 0; k < 6; k++) {
+                    v[k] = 0;
+                    if (r + k * rpp < ch) v[k] = *reinterpret_cast<const uint32_t*>(gp + k * gStep);
                 }
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    if (r + k * rpp < ch) {
+                        reinterpret_cast<uint32_t*>(smap)[off + k * oStep] = 0u;
+                        reinterpret_cast<uint32_t*>(tile)[off + k * oStep] = v[k];
+                    }
+                gp += 6 * gStep;
+                off += 6 * oStep;
+            }
         }
     }
     __syncthreads();
