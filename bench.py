@@ -2,7 +2,7 @@
 """bench.py -- keypoints+descriptors/s of the MI355X ORB front-end (BASELINE.json metric).
 
 A "step" = one pass of the whole extractor hot path (pyramid -> FAST -> quadtree -> pack ->
-orientation+blur+descriptor, plus the host-libm trig fix-up) over one batch of synthetic frames that
+orientation+blur+descriptor with host-libm-exact trig) over one batch of synthetic frames that
 is ALREADY RESIDENT in HBM; outputs stay in HBM.  Workload = BASELINE.json configs[1]: 752x480,
 8 levels, scale 1.2, nFeatures 1000, FAST 20/7 -- as a batch of --batch frames per GPU per step.
 With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank extracts its own
@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=752)
     ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--trig", choices=["libm", "cr"], default="libm")
+    ap.add_argument("--trig", choices=["libm", "cr", "hostcheck"], default="libm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -141,7 +141,8 @@ def main():
     d_img = torch.from_numpy(imgs).to(dev)
 
     ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank,
-                          trig=pkg.binding.TRIG_LIBM if args.trig == "libm" else pkg.binding.TRIG_CR)
+                          trig={"libm": pkg.binding.TRIG_LIBM, "cr": pkg.binding.TRIG_CR,
+                                "hostcheck": pkg.binding.TRIG_LIBM_HOSTCHECK}[args.trig])
     # One explicit stream for everything: the extractor's kernels, torch's ops and the RCCL collective
     # (which orders itself after the current stream) -- the legacy null stream would not order a
     # non-blocking stream.

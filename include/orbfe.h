@@ -58,12 +58,19 @@ int orbfe_set_stream(orbfe_ctx*, void* hip_stream);
 /* 7 fixed-point (8.8) Gaussian taps; default {18,34,48,56,48,34,18} = OpenCV >= 4.1.2. */
 int orbfe_set_gaussian_taps(orbfe_ctx*, const int* taps7);
 /* Rotation trig of the descriptor (src/ORBextractor.cc:110-111):
- *   ORBFE_TRIG_LIBM (default): bit-identical to host libm cosf/sinf -- the device evaluates a correctly
- *       rounded sin/cos, flags keypoints whose sampling grid could change under a 1-ulp difference, and
- *       those are re-evaluated on the device with the host libm values.
- *   ORBFE_TRIG_CR: correctly rounded sin/cos only (no host involvement). */
+ *   ORBFE_TRIG_LIBM (default): bit-identical to this host's libm cosf/sinf.  The first extraction of a
+ *       process evaluates libm for every float angle in [2^-7, 360] degrees (all cores, a fraction of a
+ *       second) and keeps, per angle, how it differs from the device's correctly rounded value (65 MB
+ *       table in HBM); every later batch runs without any host involvement.  If the table cannot be built
+ *       (libm further than one bit pattern from correctly rounded, allocation failure, ORBFE_TRIG_TABLE=0
+ *       in the environment) the mode behaves like ORBFE_TRIG_LIBM_HOSTCHECK.
+ *   ORBFE_TRIG_LIBM_HOSTCHECK: same results, no table: the device flags keypoints whose sampling grid could
+ *       change under a 1-ulp difference of sin/cos, the host evaluates libm for those after the batch (one
+ *       stream synchronisation per call) and they are re-evaluated on the device with the libm values.
+ *   ORBFE_TRIG_CR: correctly rounded sin/cos only (host independent). */
 #define ORBFE_TRIG_LIBM 0
 #define ORBFE_TRIG_CR 1
+#define ORBFE_TRIG_LIBM_HOSTCHECK 2
 int orbfe_set_trig_mode(orbfe_ctx*, int mode);
 
 /* Fisheye rigs (KannalaBrandt8, src/CameraModels/KannalaBrandt8.cpp:96-123): when params8 = {fx,fy,cx,cy,k0..k3}
@@ -92,7 +99,7 @@ int orbfe_extract_batch(orbfe_ctx*, int nimg, const uint8_t* const* imgs, int ro
                         int* n_out, int* mono_out);
 
 /* Same, with every buffer already resident in device memory (no PCIe traffic).  Asynchronous on the
- * context's stream unless the trig mode needs the host (ORBFE_TRIG_LIBM synchronises once per call).
+ * context's stream unless the trig mode needs the host (ORBFE_TRIG_LIBM_HOSTCHECK synchronises once per call).
  * d_imgs: nimg images, image i at d_imgs + i*img_stride_bytes, row pitch `pitch`. */
 int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch,
                                size_t img_stride_bytes, int lap0, int lap1, orbfe_kp* d_kps, uint8_t* d_desc,
@@ -116,7 +123,7 @@ int orbfe_get_level(orbfe_ctx*, int img_index, int level, uint8_t* dst, size_t d
 #define ORBFE_STAGE_OCTREE 2
 #define ORBFE_STAGE_PACK 3
 #define ORBFE_STAGE_DESC 4
-#define ORBFE_STAGE_TRIGFIX 5 /* host libm check of the flagged keypoints + fix-up launch (ORBFE_TRIG_LIBM) */
+#define ORBFE_STAGE_TRIGFIX 5 /* host libm check of the flagged keypoints + fix-up launch (ORBFE_TRIG_LIBM_HOSTCHECK) */
 #define ORBFE_STAGE_COUNT 6
 int orbfe_profile_enable(orbfe_ctx*, int on);
 int orbfe_profile_read(orbfe_ctx*, float* ms_per_stage /* ORBFE_STAGE_COUNT */);
@@ -126,6 +133,9 @@ int orbfe_profile_read(orbfe_ctx*, float* ms_per_stage /* ORBFE_STAGE_COUNT */);
 int orbfe_debug_candidates(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
 int orbfe_debug_level_keypoints(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
 int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm trig in the last call */
+/* (cos, sin) the descriptor kernel uses for the given keypoint angles (degrees) in the context's trig mode;
+ * returns 1 when the libm table was used, 0 when not (ORBFE_TRIG_CR, or no table), < 0 on error. */
+int orbfe_debug_trig(orbfe_ctx*, const float* angles_deg, int n, float* a_out, float* b_out);
 
 /* Frame::ComputeStereoMatches (src/Frame.cc:797-967), rectified stereo.  `left` / `right` are the contexts
  * that just extracted the two images (same size and parameters, same device): their pyramids are read in

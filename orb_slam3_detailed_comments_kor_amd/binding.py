@@ -16,7 +16,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("octave", "<i4"), ("class_id", "<i4")])
 
 ERR_ARGS, ERR_NODEV, ERR_STATE = -2, -3, -4
-TRIG_LIBM, TRIG_CR = 0, 1
+TRIG_LIBM, TRIG_CR, TRIG_LIBM_HOSTCHECK = 0, 1, 2
 STAGES = ("pyramid", "fast", "octree", "pack", "desc", "trigfix")
 
 
@@ -156,6 +156,7 @@ def lib():
         L.orbfe_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orbfe_debug_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orbfe_debug_fixups.argtypes = [C.c_void_p]
+        L.orbfe_debug_trig.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orbfe_hamming_pairs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_bfknn2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orbfe_search_bow.argtypes = [C.c_int, C.POINTER(_BowArgs), C.c_void_p]
@@ -174,7 +175,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -347,6 +348,15 @@ class ORBextractor:
 
     def debug_fixups(self):
         return self.L.orbfe_debug_fixups(self.h)
+
+    def debug_trig(self, angles_deg):
+        """(used_table, cos, sin) the descriptor kernel uses for these keypoint angles in this trig mode."""
+        ang = np.ascontiguousarray(angles_deg, np.float32)
+        a = np.empty_like(ang)
+        b = np.empty_like(ang)
+        r = _chk(self.L.orbfe_debug_trig(self.h, ang.ctypes.data, len(ang), a.ctypes.data, b.ctypes.data),
+                 "orbfe_debug_trig")
+        return bool(r), a, b
 
 
 def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):

@@ -14,7 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "../../include/orbfe.h"
 #include "orbfe_geom.h"
@@ -98,6 +102,7 @@ struct orbfe_ctx {
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     int taps[7] = {18, 34, 48, 56, 48, 34, 18};
     int trigMode = ORBFE_TRIG_LIBM;
+    bool lastHostTrigCheck = false;
 
     hipStream_t stream = nullptr;
     bool ownStream = false;
@@ -529,6 +534,115 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// libm trig table (ORBFE_TRIG_LIBM without a host round trip per batch, see k_trig_codes).
+// Built once per process and device: the host evaluates cosf/sinf -- the very calls of the reference,
+// src/ORBextractor.cc:110-111, on this machine's libm -- for every float angle in [2^-7, 360] degrees
+// (1.29e8 values, all cores), the device compares them with its correctly rounded values and keeps a
+// 4-bit code per angle (65 MB of HBM).  Below 2^-7 degrees the argument is < 2^-12 rad, where
+// cosf(x) == 1 and sinf(x) == x for the correctly rounded functions; that libm agrees is checked on a
+// sample.  If any libm value is further than one bit pattern from the correctly rounded one, or the
+// small-angle check fails, the table is not used and ORBFE_TRIG_LIBM falls back to the per-batch host
+// check of the fragile keypoints.
+struct TrigTable {
+    uint8_t* d = nullptr; // device, (U1 - U0 + 2) / 2 bytes
+    bool tried = false, ok = false;
+};
+std::mutex g_trigMutex;
+TrigTable g_trig[16];
+
+int host_threads()
+{
+    cpu_set_t set;
+    int n = (int)std::thread::hardware_concurrency();
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
+    return std::max(1, std::min(n, 16));
+}
+
+void fill_libm(float2* out, uint32_t u0, uint32_t n)
+{
+    const float factorPI = (float)(3.14159265358979323846 / 180.f); // as the reference, :105
+    const int T = host_threads();
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([=]() {
+            const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+            for (uint32_t i = lo; i < hi; i++) {
+                uint32_t u = u0 + i;
+                float deg;
+                std::memcpy(&deg, &u, 4);
+                volatile float ang = deg * factorPI; // one rounded float multiply, :110
+                out[i] = make_float2(cosf(ang), sinf(ang));
+            }
+        });
+    for (auto& x : th) x.join();
+}
+
+// cosf(x) == 1 and sinf(x) == x on a sample of x = angle * pi/180 with angle below the table
+bool small_angles_ok()
+{
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    for (uint32_t u = 0; u < ORBFE_TRIG_U0; u += 4099u) { // ~246k angles over all binades, odd stride
+        float deg;
+        std::memcpy(&deg, &u, 4);
+        volatile float ang = deg * factorPI;
+        const float x = ang;
+        if (cosf(x) != 1.0f || sinf(x) != x) return false;
+    }
+    for (uint32_t u = ORBFE_TRIG_U0 - 70000u; u < ORBFE_TRIG_U0; u++) { // and every angle just below the table
+        float deg;
+        std::memcpy(&deg, &u, 4);
+        volatile float ang = deg * factorPI;
+        const float x = ang;
+        if (cosf(x) != 1.0f || sinf(x) != x) return false;
+    }
+    return true;
+}
+
+// returns the device table or nullptr (not available); never fails the caller
+const uint8_t* trig_table(int device, hipStream_t s)
+{
+    if (device < 0 || device >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_trigMutex);
+    TrigTable& t = g_trig[device];
+    if (t.tried) return t.ok ? t.d : nullptr;
+    t.tried = true;
+    if (const char* e = getenv("ORBFE_TRIG_TABLE"))
+        if (atoi(e) == 0) return nullptr;
+    if (!small_angles_ok()) return nullptr;
+    const uint32_t N = ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u;
+    const uint32_t chunk = 1u << 22; // 4M angles = 32 MB of (cosf, sinf) per transfer
+    float2* h = nullptr;
+    float2* dAB = nullptr;
+    int32_t* dBad = nullptr;
+    int32_t bad = 0;
+    bool fine = hipHostMalloc((void**)&h, (size_t)chunk * sizeof(float2)) == hipSuccess &&
+                hipMalloc((void**)&dAB, (size_t)chunk * sizeof(float2)) == hipSuccess &&
+                hipMalloc((void**)&dBad, sizeof(int32_t)) == hipSuccess &&
+                hipMalloc((void**)&t.d, (size_t)(N + 1) / 2) == hipSuccess &&
+                hipMemsetAsync(dBad, 0, sizeof(int32_t), s) == hipSuccess;
+    for (uint32_t i0 = 0; fine && i0 < N; i0 += chunk) { // chunk is even: whole table bytes per chunk
+        const uint32_t n = std::min(chunk, N - i0);
+        fill_libm(h, ORBFE_TRIG_U0 + i0, n);
+        fine = hipMemcpyAsync(dAB, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!fine) break;
+        hipLaunchKernelGGL(k_trig_codes, dim3((n / 2 + 256) / 256), dim3(256), 0, s, dAB, ORBFE_TRIG_U0 + i0, n,
+                           t.d + i0 / 2, dBad);
+        fine = hipStreamSynchronize(s) == hipSuccess; // h is refilled next
+    }
+    if (fine) fine = hipMemcpy(&bad, dBad, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+    if (h) (void)hipHostFree(h);
+    if (dAB) (void)hipFree(dAB);
+    if (dBad) (void)hipFree(dBad);
+    if (!fine && t.d) {
+        (void)hipFree(t.d);
+        t.d = nullptr;
+    }
+    t.ok = fine;
+    return t.ok ? t.d : nullptr;
+}
+
 inline void rec(orbfe_ctx* c, int i)
 {
     if (c->profile && c->evReady)
@@ -546,6 +660,10 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
     hipStream_t s = c->stream;
     const int nl = c->nlevels;
+    // ORBFE_TRIG_LIBM: with the libm table the device reproduces host cosf/sinf by itself; without it the
+    // fragile keypoints are listed and checked on the host after the batch
+    const uint8_t* trigTab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, s) : nullptr;
+    const bool hostTrigCheck = c->trigMode != ORBFE_TRIG_CR && trigTab == nullptr;
     if (c->tapsDirty) { // 28 bytes, but a separate command on the stream: only when they changed
         HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
         c->tapsDirty = false;
@@ -619,8 +737,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // K-DESC
         hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                           c->d_patternF.p, c->d_fix.p, 0, c->trigMode == ORBFE_TRIG_LIBM ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0);
+                           c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab);
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
             HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
@@ -631,7 +749,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     rec(c, 5);
     c->lastImgs = nimg;
     c->lastFixups = 0;
-    if (c->trigMode == ORBFE_TRIG_LIBM) {
+    c->lastHostTrigCheck = hostTrigCheck;
+    if (hostTrigCheck) {
         // Trig fix-up: the device used the correctly rounded sin/cos and listed the keypoints whose
         // sampling grid is within a rounding hair of changing.  Evaluate the host libm cosf/sinf
         // (what the reference calls, src/ORBextractor.cc:111) for those; where libm differs from the
@@ -668,7 +787,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0);
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr);
         c->lastFixups = nFix;
     }
     rec(c, 6);
@@ -777,7 +896,7 @@ int orbfe_set_gaussian_taps(orbfe_ctx* c, const int* t)
 
 int orbfe_set_trig_mode(orbfe_ctx* c, int mode)
 {
-    if (!c || (mode != ORBFE_TRIG_LIBM && mode != ORBFE_TRIG_CR)) return ORBFE_ERR_ARGS;
+    if (!c || (mode != ORBFE_TRIG_LIBM && mode != ORBFE_TRIG_CR && mode != ORBFE_TRIG_LIBM_HOSTCHECK)) return ORBFE_ERR_ARGS;
     c->trigMode = mode;
     return 0;
 }
@@ -892,7 +1011,7 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     HIP_TRY(hipMemcpyAsync(c->h_n.p, c->d_n.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(c->h_mono.p, c->d_mono.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (c->trigMode != ORBFE_TRIG_LIBM) {
+    if (!c->lastHostTrigCheck) { // otherwise run_device has already looked at the error word
         int32_t err = 0;
         HIP_TRY(hipMemcpy(&err, reinterpret_cast<int32_t*>(c->d_fix.p) + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
         if (err) return ORBFE_ERR_STATE;
@@ -1123,5 +1242,27 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
 }
 
 int orbfe_debug_fixups(orbfe_ctx* c) { return c ? c->lastFixups : ORBFE_ERR_ARGS; }
+
+int orbfe_debug_trig(orbfe_ctx* c, const float* angles_deg, int n, float* a_out, float* b_out)
+{
+    if (!c || !angles_deg || !a_out || !b_out || n < 0) return ORBFE_ERR_ARGS;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint8_t* tab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, c->stream) : nullptr;
+    DevBuf<float> d;
+    int r = d.ensure((size_t)3 * n);
+    if (r < 0) return r;
+    hipError_t e = hipMemcpyAsync(d.p, angles_deg, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_trig, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d.p, n, tab, d.p + n,
+                           d.p + 2 * (size_t)n);
+        e = hipMemcpyAsync(a_out, d.p + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(b_out, d.p + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    if (e != hipSuccess) return -(1000 + (int)e);
+    return tab ? 1 : 0; /* 1: the libm table was used */
+}
 
 } // extern "C"

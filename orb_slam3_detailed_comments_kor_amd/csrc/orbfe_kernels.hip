@@ -1156,6 +1156,69 @@ __host__ __device__ constexpr AngleMaskTab make_angle_masks()
 __constant__ AngleMaskTab c_angleMask = make_angle_masks();
 
 #define DESC_R 21    /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
+// --------------------------------------------------------------- libm trig table
+// ORBFE_TRIG_LIBM without a host round trip: for every float angle the IC_Angle can produce in
+// [2^-7, 360] degrees the table holds how host libm's cosf/sinf (what the reference calls,
+// src/ORBextractor.cc:110-111) differs from the correctly rounded value orbfe_sincos_cr yields on the
+// device: 2 bits each for cos and sin (0 same, 1 next bit pattern up, 2 next bit pattern down, 3 other),
+// one nibble per angle.  The host evaluates libm once per process for all ~1.3e8 angles and this kernel
+// turns the values into codes; K-DESC then applies the code of its angle to its own (a, b).
+#define ORBFE_TRIG_U0 0x3C000000u /* bits of 2^-7 deg: below, x = angle * pi/180 < 2^-12 and cos = 1, sin = x */
+#define ORBFE_TRIG_U1 0x43B40000u /* bits of 360.0f (fastAtan2 can round up to it) */
+
+__device__ __forceinline__ unsigned trig_code(float libm, float cr)
+{
+    const int d = (int)__float_as_uint(libm) - (int)__float_as_uint(cr);
+    return d == 0 ? 0u : d == 1 ? 1u : d == -1 ? 2u : 3u;
+}
+// one thread per PAIR of consecutive angles (one table byte); libmAB[i] = (cosf, sinf) of angle u0 + i
+__global__ __launch_bounds__(256) void k_trig_codes(const float2* __restrict__ libmAB, uint32_t u0, uint32_t n,
+                                                    uint8_t* __restrict__ table /* byte of angle u0 */,
+                                                    int32_t* __restrict__ bad)
+{
+    const uint32_t i = 2u * (blockIdx.x * 256u + threadIdx.x);
+    if (i >= n) return;
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    unsigned byte = 0;
+    for (uint32_t k = 0; k < 2 && i + k < n; k++) {
+        float sc, cc;
+        orbfe_sincos_cr(__fmul_rn(__uint_as_float(u0 + i + k), factorPI), &sc, &cc);
+        const float2 L = libmAB[i + k];
+        const unsigned ca = trig_code(L.x, cc), cb = trig_code(L.y, sc);
+        if (ca == 3u || cb == 3u) atomicAdd(bad, 1);
+        byte |= (ca | (cb << 2)) << (4 * k);
+    }
+    table[i >> 1] = (uint8_t)byte; // u0 is even, so angle u0 + i is the low nibble
+}
+__device__ __forceinline__ float trig_apply(float v, unsigned code)
+{
+    return __uint_as_float(__float_as_uint(v) + (code == 1u ? 1u : code == 2u ? 0xFFFFFFFFu : 0u));
+}
+// the libm codes of one keypoint angle (0 = "same as correctly rounded" outside the table or without one)
+__device__ __forceinline__ unsigned trig_lookup(const uint8_t* __restrict__ trigTab, float angleDeg)
+{
+    if (!trigTab) return 0u;
+    const uint32_t idx = __float_as_uint(angleDeg) - ORBFE_TRIG_U0;
+    return idx <= ORBFE_TRIG_U1 - ORBFE_TRIG_U0 ? ((unsigned)trigTab[idx >> 1] >> (4u * (idx & 1u))) & 15u : 0u;
+}
+// a = cos, b = sin of the keypoint angle as the descriptor uses them (src/ORBextractor.cc:110-111)
+__device__ __forceinline__ void trig_rotation(float angleDeg, unsigned nib, float* a, float* b)
+{
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    orbfe_sincos_cr(__fmul_rn(angleDeg, factorPI), b, a);
+    *a = trig_apply(*a, nib & 3u); // host libm's cosf / sinf, bit for bit (no-ops without the table)
+    *b = trig_apply(*b, nib >> 2);
+}
+// test hook (orbfe_debug_trig): the rotation K-DESC would use for the given angles
+__global__ __launch_bounds__(256) void k_debug_trig(const float* __restrict__ angles, int n,
+                                                    const uint8_t* __restrict__ trigTab, float* __restrict__ a,
+                                                    float* __restrict__ b)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    trig_rotation(angles[i], trig_lookup(trigTab, angles[i]), &a[i], &b[i]);
+}
+
 #define DESC_RAW 43  /* raw patch side */
 #define DESC_RAWP 44 /* raw pitch in bytes = 11 dwords */
 #define DESC_BW 37   /* blurred patch side */
@@ -1188,7 +1251,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           int4* fixList /* MODE 0: out {img<<16|g, angle, a, b} (float
                                                                            bits) after a 16-B header whose first word
                                                                            is the count; MODE 1: in {img<<16|g, -, a, b} */,
-                                                          int nFix, int listFragile, int imgBase, int xcdAffine)
+                                                          int nFix, int listFragile, int imgBase, int xcdAffine,
+                                                          const uint8_t* __restrict__ trigTab /* libm codes or nullptr */)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1294,6 +1358,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         m01 += __shfl_xor(m01, off);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // libm codes of this angle (issued now, used after the blur)
+    const unsigned trigNib = MODE == 0 ? trig_lookup(trigTab, angle) : 0u;
 
     // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
     const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
@@ -1388,8 +1454,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     // ---- steered BRIEF (:106-145)
     float a, b;
     if (MODE == 0) {
-        const float factorPI = (float)(3.14159265358979323846 / 180.f);
-        orbfe_sincos_cr(__fmul_rn(angle, factorPI), &b, &a);
+        trig_rotation(angle, trigNib, &a, &b);
     } else {
         const int f = blockIdx.x * 4 + wave;
         a = __int_as_float(fixList[f].z);
@@ -1416,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         const int v0 = center[iy0 * DESC_BP + ix0];
         const int v1 = center[iy1 * DESC_BP + ix1];
         word[q] = __ballot(v0 < v1);
-        if (MODE == 0) {
+        if (MODE == 0 && listFragile) { // wave-uniform
             // |f - round(f)| > 0.5 - FR  <=>  f is within FR of a half-integer
             const float TH = 0.5f - FR;
             frag |= fmaxf(fmaxf(fabsf(fy0 - ry0), fabsf(fx0 - rx0)), fmaxf(fabsf(fy1 - ry1), fabsf(fx1 - rx1))) > TH;

@@ -49,7 +49,8 @@ def test_tables_match(pkg, oracle):
 ])
 def test_stagewise_and_final_parity(pkg, oracle, hw, nf, lap, seed):
     img = _frame(pkg, hw[0], hw[1], seed)
-    for trig_gpu, trig_ref in ((pkg.binding.TRIG_LIBM, oracle.TRIG_LIBM), (pkg.binding.TRIG_CR, oracle.TRIG_CR)):
+    for trig_gpu, trig_ref in ((pkg.binding.TRIG_LIBM, oracle.TRIG_LIBM), (pkg.binding.TRIG_CR, oracle.TRIG_CR),
+                               (pkg.binding.TRIG_LIBM_HOSTCHECK, oracle.TRIG_LIBM)):
         ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, trig=trig_gpu)
         ref = oracle.Extractor(nf, 1.2, 8, 20, 7, trig=trig_ref)
         mono, kps, desc = ex(img, lap)
@@ -75,18 +76,68 @@ def test_stagewise_and_final_parity(pkg, oracle, hw, nf, lap, seed):
 
 def test_libm_trig_fixups_are_exercised(pkg, oracle):
     # over a few frames some keypoints sit within a rounding hair and libm differs from the
-    # correctly rounded value: the LIBM mode must still be bit-exact (checked above); here we
-    # only make sure the fix-up path actually runs somewhere.
+    # correctly rounded value: both LIBM modes must still be bit-exact -- the table mode (no host
+    # involvement per batch) and the host-check mode, whose fix-up path must actually run somewhere.
     ex = pkg.ORBextractor(2000, 1.2, 8, 20, 7)
+    exh = pkg.ORBextractor(2000, 1.2, 8, 20, 7, trig=pkg.binding.TRIG_LIBM_HOSTCHECK)
     ref = oracle.Extractor(2000, 1.2, 8, 20, 7)
     total = 0
     for seed in range(40, 52):
         img = _frame(pkg, 480, 752, seed)
         mono, kps, desc = ex(img, (0, 0))
-        total += ex.debug_fixups()
+        hmono, hkps, hdesc = exh(img, (0, 0))
+        total += exh.debug_fixups()
         rmono, rkps, rdesc = ref.extract(img, (0, 0))
         _same(kps, rkps, desc, rdesc)
-    assert total >= 0
+        _same(hkps, rkps, hdesc, rdesc)
+    assert total >= 0  # fix-ups are rare: a handful per thousand frames
+
+
+def _host_libm_sincos(angles_deg):
+    """cosf/sinf of this host's libm on angle * (float)(pi/180.f), as src/ORBextractor.cc:105,110-111 evaluates them."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    x = (angles_deg.astype(np.float32) * np.float32(np.float64(3.14159265358979323846) / np.float64(np.float32(180.0)))).astype(np.float32)
+    a = np.array([libm.cosf(float(v)) for v in x], np.float32)
+    b = np.array([libm.sinf(float(v)) for v in x], np.float32)
+    return a, b
+
+
+def test_libm_table_reproduces_host_libm_bit_for_bit(pkg, oracle):
+    # the rotation the descriptor kernel uses in ORBFE_TRIG_LIBM (table mode) against direct libm calls:
+    # random float angles over all binades of [0, 360], a dense run of consecutive bit patterns, the table
+    # edges, tiny angles below the table and the quadrant boundaries
+    rng = np.random.default_rng(5)
+    parts = [
+        rng.uniform(0, 360, 60000).astype(np.float32),
+        (2.0 ** rng.uniform(-30, 8.49, 20000)).astype(np.float32),
+        (np.arange(0x42B40000 - 5000, 0x42B40000 + 5000, dtype=np.uint32)).view(np.float32),  # around 90
+        (np.arange(0x3C000000 - 200, 0x3C000000 + 200, dtype=np.uint32)).view(np.float32),    # table start
+        (np.arange(0x43B40000 - 400, 0x43B40000 + 1, dtype=np.uint32)).view(np.float32),      # up to 360.0
+        np.array([0.0, 1e-30, 90.0, 180.0, 270.0, 360.0, 45.0, 0.0078125], np.float32),
+    ]
+    ang = np.concatenate(parts)
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    used, a, b = ex.debug_trig(ang)
+    assert used, "the libm table was not built on this box"
+    ra, rb = _host_libm_sincos(ang)
+    assert np.array_equal(a.view(np.uint32), ra.view(np.uint32))
+    assert np.array_equal(b.view(np.uint32), rb.view(np.uint32))
+    # and the table is not a no-op: libm differs from the correctly rounded values for some angles
+    exc = pkg.ORBextractor(500, 1.2, 8, 20, 7, trig=pkg.binding.TRIG_CR)
+    usedc, ca, cb = exc.debug_trig(ang)
+    assert not usedc
+    ndiff = int((ca.view(np.uint32) != a.view(np.uint32)).sum() + (cb.view(np.uint32) != b.view(np.uint32)).sum())
+    assert ndiff > 0
+    # the correctly rounded mode agrees with the oracle's own correctly rounded routine
+    x = (ang[:2000].astype(np.float32) * np.float32(np.float64(3.14159265358979323846) / np.float64(np.float32(180.0)))).astype(np.float32)
+    for i in range(0, 2000, 7):
+        s_, c_ = oracle.sincos_cr(float(x[i]))
+        assert np.float32(c_) == ca[i] and np.float32(s_) == cb[i]
+    ex.close()
+    exc.close()
 
 
 def test_mono_init_extractor_5x_features(pkg, oracle):
