@@ -200,7 +200,7 @@ def main():
         traffic = None
         valu_issue = None
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
-                     "desc": "k_orient_blur_desc<0>", "trigfix": "k_orient_blur_desc<1>"}
+                     "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc):
             try:

@@ -735,10 +735,20 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                            c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0);
         if (nsub == 1) rec(c, 4);
         // K-DESC
-        hipLaunchKernelGGL(k_orient_blur_desc<0>, dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
+        {
+            int tapSum = 0;
+            for (int i = 0; i < 7; i++) tapSum += c->taps[i];
+            if (tapSum > 256)
+        hipLaunchKernelGGL((k_orient_blur_desc<0, true>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
                            (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab);
+            else
+        hipLaunchKernelGGL((k_orient_blur_desc<0, false>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
+                           c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
+                           c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab);
+        }
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
             HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
@@ -785,7 +795,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             }
         }
         if (nFix > 0) // the kernel reads the pinned list in place
-            hipLaunchKernelGGL(k_orient_blur_desc<1>, dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
+            hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                                c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr);
         c->lastFixups = nFix;

@@ -1219,6 +1219,18 @@ __global__ __launch_bounds__(256) void k_debug_trig(const float* __restrict__ an
     trig_rotation(angles[i], trig_lookup(trigTab, angles[i]), &a[i], &b[i]);
 }
 
+// Sum over the 64 lanes with DPP (quad permutes, half-row and row mirrors) and four v_readlane: no LDS
+// traffic, unlike __shfl_xor (ds_bpermute); the result is wave-uniform.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); // row_mirror: every lane holds its row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
 #define DESC_RAW 43  /* raw patch side */
 #define DESC_RAWP 44 /* raw pitch in bytes = 11 dwords */
 #define DESC_BW 37   /* blurred patch side */
@@ -1240,7 +1252,14 @@ __global__ __launch_bounds__(256) void k_debug_trig(const float* __restrict__ an
 // MODE 0: trig = orbfe_sincos_cr; keypoints whose sampling grid could differ under a 1-ulp change
 //         of sin/cos are appended to fixList (angle in fixF) when listFragile is set.
 // MODE 1: fix-up launch: one wave per fixList entry, trig (a, b) given in fixF.
-template <int MODE>
+template <bool SAT>
+__device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
+{
+    return SAT ? min(v, 65535u) : v;
+}
+// SAT: the taps sum to more than 256 (non-default taps only), so the horizontal pass can exceed 16 bits and
+//      saturates like ufixedpoint16; with the default taps the sum is at most 255 * 256 and the min is dropped.
+template <int MODE, bool SAT>
 __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                           const OrbLevelGeom* __restrict__ lg,
                                                           const OrbDescWork* __restrict__ work,
@@ -1352,11 +1371,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
-    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // libm codes of this angle (issued now, used after the blur)
     const unsigned trigNib = MODE == 0 ? trig_lookup(trigTab, angle) : 0u;
@@ -1378,11 +1394,10 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             const uint32_t b0 = sb[0], b1 = sb[1], b2 = sb[2];
             uint4 o;
 #define ORBFE_HROW(d0, d1, d2, SH)                                                                       \
-    min(__builtin_amdgcn_udot4(SH == 0 ? d1 : __builtin_amdgcn_alignbyte(d2, d1, SH), THI,               \
+    desc_hsat<SAT>(__builtin_amdgcn_udot4(SH == 0 ? d1 : __builtin_amdgcn_alignbyte(d2, d1, SH), THI,    \
                                __builtin_amdgcn_udot4(SH == 0 ? d0 : __builtin_amdgcn_alignbyte(d1, d0, SH), TLO, \
                                                       0u, false),                                        \
-                               false),                                                                   \
-        65535u) /* ufixedpoint16 saturating add (only reachable with non-default taps) */
+                               false)) /* ufixedpoint16 saturating add (only reachable with non-default taps) */
             o.x = ORBFE_HROW(a0, a1, a2, 0) | (ORBFE_HROW(b0, b1, b2, 0) << 16);
             o.y = ORBFE_HROW(a0, a1, a2, 1) | (ORBFE_HROW(b0, b1, b2, 1) << 16);
             o.z = ORBFE_HROW(a0, a1, a2, 2) | (ORBFE_HROW(b0, b1, b2, 2) << 16);
