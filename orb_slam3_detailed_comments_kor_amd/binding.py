@@ -204,7 +204,7 @@ class ORBextractor:
         _chk(self.L.orbfe_create(C.byref(h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device),
              "orbfe_create")
         self.h = h
-        self.nfeatures, self.nlevels, self.device = nfeatures, nlevels, device
+        self.nfeatures, self.nlevels, self.device, self.trig = nfeatures, nlevels, device, trig
         _chk(self.L.orbfe_set_trig_mode(self.h, trig), "orbfe_set_trig_mode")
         if taps is not None:
             t = np.ascontiguousarray(taps, np.int32)

@@ -1305,6 +1305,25 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave] + DESC_RAW_BYTES);
     uint8_t* bl = raw; // the blurred patch overwrites the raw patch once the horizontal pass is done
 
+    // ---- IC_Angle masks first: they do not depend on the patch, so their loads overlap the staging
+    // item = (r, d) = (idx / 9, idx % 9), idx = lane + 64 k; +64 items = +7 rows +1 dword.  Fully unrolled
+    // so that the five mask loads (constant table, L2 latency) are all in flight before the first use.
+    int icR = lane / 9, icD = lane - 9 * (lane / 9);
+    uint32_t msk[5];
+    int rr[5], dd[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        rr[k] = icR;
+        dd[k] = icD;
+        const int v = min(icR, 30) - 15; // r > 30 only for lanes past the last item (k == 4), masked below
+        msk[k] = (lane + 64 * k < 31 * 9) ? c_angleMask.m[v < 0 ? -v : v][icD] : 0u;
+        icR += 7;
+        icD += 1;
+        if (icD >= 9) {
+            icD -= 9;
+            icR += 1;
+        }
+    }
     // ---- raw 43x43 patch (11 dwords per row; the 44th column is never used)
     const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R + 1 < L.w && w.y + DESC_R < L.h;
     if (inside) {
@@ -1353,22 +1372,15 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     // items = (row, dword): rows 6..36, dwords 1..9 (columns 4..39 cover u = -15..15 = columns 6..36)
     int m10 = 0, m01 = 0;
     {
-        int r = lane / 9, d = lane - 9 * (lane / 9); // item = (r, d); +64 items = +7 rows +1 dword
-        for (int idx = lane; idx < 31 * 9; idx += 64) {
-            const int v = r - 15;
-            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (r + 6) * DESC_RAWP + 4 * (d + 1)) &
-                                c_angleMask.m[v < 0 ? -v : v][d];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int rk = min(rr[k], 30), v = rk - 15;
+            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (rk + 6) * DESC_RAWP + 4 * (dd[k] + 1)) & msk[k];
             // sum_k (u0 + k) * I_k = u0 * sum I_k + sum k * I_k  (two byte dot products)
             const int S = (int)__builtin_amdgcn_udot4(px, 0x01010101u, 0u, false);
             const int K = (int)__builtin_amdgcn_udot4(px, 0x03020100u, 0u, false);
-            m10 += __mul24(4 * (d + 1) - DESC_R, S) + K;
+            m10 += __mul24(4 * (dd[k] + 1) - DESC_R, S) + K;
             m01 += __mul24(v, S);
-            r += 7;
-            d += 1;
-            if (d >= 9) {
-                d -= 9;
-                r += 1;
-            }
         }
     }
     m10 = wave_sum_i32(m10);
