@@ -411,10 +411,10 @@ __device__ __forceinline__ int lds_add_per_lane(int* p, int v)
 __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (int)__umulhi(x, m) : (int)x; }
 
 // One workgroup per FAST cell (reference: one cv::FAST call per cell, plus a second call with
-// minThFAST when the first finds nothing).  A single score map serves both thresholds:
-// corner_at(t) <=> score >= t, and the strict 8-neighbour NMS is threshold independent
-// (SURVEY.md A.3), so kept(t) = localmax && score >= t; the cell picks iniTh if any pixel
-// survives at iniTh, else minTh.  Output: row-major ordered list per cell, packed x|y<<12|s<<24.
+// minThFAST when the first finds nothing) -- and the kernel does exactly that: a pass at iniThFAST and,
+// only for a cell where it keeps nothing, a pass at minThFAST.  corner_at(t) <=> score >= t and the
+// strict 8-neighbour NMS only ever loses to higher scores, so one score map serves both
+// passes.  Output: row-major ordered list per cell, packed x|y<<12|s<<24.
 //
 // The ROI is staged as aligned dwords (tile column 0 = level column iniX & ~3, ROI rows of the
 // pyramid are 64-B aligned), phase A tests 4 pixels per lane from 5 dword LDS reads, phase B
@@ -443,10 +443,9 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     uint16_t* cq = queue;
     (void)kqOff;
     (void)cqOff;
-    __shared__ int qn, cn, kn, waveTot[4];
-    constexpr int NW = NT / 64;
+    __shared__ int qn, cn, kn;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2);
     // neighbouring cells share 128-B lines of the level rows (their ROIs overlap by 6 px), which
     // should hit in ONE L2 instead of being fetched by several.
@@ -464,7 +463,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     const int ox = c.iniX & 3; // tile x = roi x + ox
     const int gpitch = c.pitch;
     const uint8_t* roi = pyr + (size_t)img * pyrImgStride + c.roiOff + (size_t)c.iniY * gpitch + (c.iniX - ox);
-    const int tmin = min(iniTh, minTh);
     const int nd = c.nd; // dwords per tile row
 
     if (tid == 0) {
@@ -507,143 +505,142 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     const int zw = cw - 6, zh = ch - 6; // detection zone
     const int nz = (zw > 0 && zh > 0) ? zw * zh : 0;
     const int txLo = 3 + ox, txHi = cw - 4 + ox; // zone columns in tile coordinates (inclusive)
-    // phase A: cheap necessary test.  Every arc of 9 contains one pixel of each opposite pair
-    // (k, k+8); test the pairs (0,8) and (4,12).  A thread keeps one dword column of the zone (4 pixels
-    // per row) and walks down the rows, so addresses advance by a constant and the column mask is a
-    // per-thread constant.
-    // The test itself is SWAR on two 16-bit fields per register (pixels 0,2 in the "even" register,
-    // 1,3 in the "odd" one) with plain 32-bit add/sub/and/or, which issue at twice the rate of the packed
-    // 16-bit instructions on gfx950 (tools/valu_rate.hip).  With H = v + t + 0x8000 and L = v + 0x7fff - t
-    // per field, bit 15 of (H - r) is set iff r <= v + t (not brighter) and bit 15 of (L - r) iff
-    // r < v - t (darker); no field ever borrows from its neighbour (0x7fff - 510 > 0).
-    if (nz > 0) {
-        const int d0 = txLo >> 2, ndz = (txHi >> 2) - d0 + 1;
-        const int r0 = fast_div((unsigned)tid, c.mNdz), dz = tid - r0 * ndz;
-        const int rpp = fast_div((unsigned)NT, c.mNdz); // zone rows per pass
-        if (r0 < rpp) {
-            const int d = d0 + dz, tx0 = 4 * d;
-            unsigned valid = 0xFu; // only the zone columns [txLo, txHi] count
-            if (tx0 < txLo) valid &= 0xFu << (txLo - tx0);
-            if (tx0 + 3 > txHi) valid &= 0xFu >> (tx0 + 3 - txHi);
-            const uint32_t vE = ((valid & 1u) << 15) | ((valid & 4u) << 29), vO = ((valid & 2u) << 14) | ((valid & 8u) << 28);
-            const uint32_t M = 0x00FF00FFu;
-            const uint32_t KH = (uint32_t)(tmin + 0x8000) * 0x10001u, KL = (uint32_t)(0x7FFF - tmin) * 0x10001u;
-            const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
-            const int P3 = 3 * PD, aStep = rpp * PD;
-            int a = (r0 + 3) * PD + d; // dword index of the four centre pixels
-            for (int r = r0; r < zh; r += rpp, a += aStep) {
-                const uint32_t C = T[a], Lf = T[a - 1], R = T[a + 1], U = T[a - P3], Dn = T[a + P3];
-                const uint32_t Ce = C & M, Co = (C >> 8) & M;
-                const uint32_t Ue = U & M, Uo = (U >> 8) & M, De = Dn & M, Do = (Dn >> 8) & M;
-                // x-3: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
-                const uint32_t Le = (Lf >> 8) & M, Lo = __builtin_amdgcn_perm(C, Lf, 0x0C040C02u);
-                const uint32_t Re = __builtin_amdgcn_perm(R, C, 0x0C050C03u), Ro = R & M;
-                const uint32_t HE = Ce + KH, HO = Co + KH, LE = Ce + KL, LO = Co + KL;
-                const uint32_t brightE = ~(((HE - De) & (HE - Ue)) | ((HE - Re) & (HE - Le)));
-                const uint32_t darkE = ((LE - De) | (LE - Ue)) & ((LE - Re) | (LE - Le));
-                const uint32_t brightO = ~(((HO - Do) & (HO - Uo)) | ((HO - Ro) & (HO - Lo)));
-                const uint32_t darkO = ((LO - Do) | (LO - Uo)) & ((LO - Ro) | (LO - Lo));
-                const uint32_t pE = (brightE | darkE) & vE, pO = (brightO | darkO) & vO; // bits 15 / 31
-                // the order of the queue is irrelevant (scores go to the map by position, the output is
-                // ranked by position): every lane reserves its own slots
-                const int n = __popc(pE) + __popc(pO);
-                if (n) {
-                    int slot = lds_add_per_lane(&qn, n);
-                    const int pos0 = a << 2;
-                    if (pE & 0x8000u) queue[slot++] = (uint16_t)pos0;
-                    if (pO & 0x8000u) queue[slot++] = (uint16_t)(pos0 + 1);
-                    if (pE >> 31) queue[slot++] = (uint16_t)(pos0 + 2);
-                    if (pO >> 31) queue[slot] = (uint16_t)(pos0 + 3);
+    // The reference's two calls, literally: pass 0 = cv::FAST(iniThFAST); only when it returns nothing,
+    // pass 1 = cv::FAST(minThFAST) (:808-828).  At iniTh far fewer pixels survive the cheap test than at
+    // minTh, so the common cell scores a third of the pixels a single pass at min(iniTh, minTh) would, and
+    // only the few flat cells pay for a second pass.  (cv::FAST's NMS compares against scores of corners at
+    // the SAME threshold only; a neighbour that is a corner only at a lower threshold has a lower score and
+    // never suppresses, so the map may keep scores of an earlier pass.)
+    int th = iniTh;
+    for (int pass = 0;; pass++) {
+        // phase A: cheap necessary test.  Every arc of 9 contains one pixel of each opposite pair
+        // (k, k+8); test the pairs (0,8) and (4,12).  A thread keeps one dword column of the zone (4 pixels
+        // per row) and walks down the rows, so addresses advance by a constant and the column mask is a
+        // per-thread constant.
+        // The test itself is SWAR on two 16-bit fields per register (pixels 0,2 in the "even" register,
+        // 1,3 in the "odd" one) with plain 32-bit add/sub/and/or, which issue at twice the rate of the packed
+        // 16-bit instructions on gfx950 (tools/valu_rate.hip).  With H = v + t + 0x8000 and L = v + 0x7fff - t
+        // per field, bit 15 of (H - r) is set iff r <= v + t (not brighter) and bit 15 of (L - r) iff
+        // r < v - t (darker); no field ever borrows from its neighbour (0x7fff - 510 > 0).
+        if (nz > 0) {
+            const int d0 = txLo >> 2, ndz = (txHi >> 2) - d0 + 1;
+            const int r0 = fast_div((unsigned)tid, c.mNdz), dz = tid - r0 * ndz;
+            const int rpp = fast_div((unsigned)NT, c.mNdz); // zone rows per pass
+            if (r0 < rpp) {
+                const int d = d0 + dz, tx0 = 4 * d;
+                unsigned valid = 0xFu; // only the zone columns [txLo, txHi] count
+                if (tx0 < txLo) valid &= 0xFu << (txLo - tx0);
+                if (tx0 + 3 > txHi) valid &= 0xFu >> (tx0 + 3 - txHi);
+                const uint32_t vE = ((valid & 1u) << 15) | ((valid & 4u) << 29), vO = ((valid & 2u) << 14) | ((valid & 8u) << 28);
+                const uint32_t M = 0x00FF00FFu;
+                const uint32_t KH = (uint32_t)(th + 0x8000) * 0x10001u, KL = (uint32_t)(0x7FFF - th) * 0x10001u;
+                const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+                const int P3 = 3 * PD, aStep = rpp * PD;
+                int a = (r0 + 3) * PD + d; // dword index of the four centre pixels
+                for (int r = r0; r < zh; r += rpp, a += aStep) {
+                    const uint32_t C = T[a], Lf = T[a - 1], R = T[a + 1], U = T[a - P3], Dn = T[a + P3];
+                    const uint32_t Ce = C & M, Co = (C >> 8) & M;
+                    const uint32_t Ue = U & M, Uo = (U >> 8) & M, De = Dn & M, Do = (Dn >> 8) & M;
+                    // x-3: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
+                    const uint32_t Le = (Lf >> 8) & M, Lo = __builtin_amdgcn_perm(C, Lf, 0x0C040C02u);
+                    const uint32_t Re = __builtin_amdgcn_perm(R, C, 0x0C050C03u), Ro = R & M;
+                    const uint32_t HE = Ce + KH, HO = Co + KH, LE = Ce + KL, LO = Co + KL;
+                    const uint32_t brightE = ~(((HE - De) & (HE - Ue)) | ((HE - Re) & (HE - Le)));
+                    const uint32_t darkE = ((LE - De) | (LE - Ue)) & ((LE - Re) | (LE - Le));
+                    const uint32_t brightO = ~(((HO - Do) & (HO - Uo)) | ((HO - Ro) & (HO - Lo)));
+                    const uint32_t darkO = ((LO - Do) | (LO - Uo)) & ((LO - Ro) | (LO - Lo));
+                    const uint32_t pE = (brightE | darkE) & vE, pO = (brightO | darkO) & vO; // bits 15 / 31
+                    // the order of the queue is irrelevant (scores go to the map by position, the output is
+                    // ranked by position): every lane reserves its own slots
+                    const int n = __popc(pE) + __popc(pO);
+                    if (n) {
+                        int slot = lds_add_per_lane(&qn, n);
+                        const int pos0 = a << 2;
+                        if (pE & 0x8000u) queue[slot++] = (uint16_t)pos0;
+                        if (pO & 0x8000u) queue[slot++] = (uint16_t)(pos0 + 1);
+                        if (pE >> 31) queue[slot++] = (uint16_t)(pos0 + 2);
+                        if (pO >> 31) queue[slot] = (uint16_t)(pos0 + 3);
+                    }
                 }
             }
         }
+        __syncthreads();
+        if (dbgStop == 2) return;
+        // phase B: exact score for the survivors (all lanes busy); the corners of this pass (score >= th) are
+        // recorded in a second queue for the NMS
+        const int nq = qn;
+        for (int base = 0; base < nq; base += NT) {
+            const int qi = base + tid;
+            int pos = 0, sc = 0;
+            if (qi < nq) {
+                pos = queue[qi];
+                sc = fast_score(&tile[pos], P);
+                if (sc >= th) smap[pos] = (uint8_t)sc;
+            }
+            __syncthreads(); // every entry of this round has been read: cq may overwrite the queue up to here
+            const bool isc = qi < nq && sc >= th;
+            const unsigned long long m = __ballot(isc);
+            if (m) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&cn, __popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (isc) cq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+            }
+        }
+        __syncthreads();
+        if (dbgStop == 3) return;
+        // phase C: strict 8-neighbour NMS of the corners only (all 8 reads issued together; the score map
+        // is not modified, so every comparison sees the true scores).  Survivors are compacted into kq
+        // as pos | score<<16 (kq aliases the tile: nothing is written when no corner survives, so a second
+        // pass still finds the pixels).
+        const int nc = cn;
+        for (int base = 0; base < nc; base += NT) {
+            const int qi = base + tid;
+            bool keep = false;
+            uint32_t ent = 0;
+            if (qi < nc) {
+                const int pos = cq[qi];
+                const int s0 = smap[pos];
+                const int n0 = smap[pos - 1], n1 = smap[pos + 1], n2 = smap[pos - P - 1], n3 = smap[pos - P],
+                          n4 = smap[pos - P + 1], n5 = smap[pos + P - 1], n6 = smap[pos + P], n7 = smap[pos + P + 1];
+                const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                keep = s0 > mx; // s0 >= th already (phase B)
+                ent = (uint32_t)pos | ((uint32_t)s0 << 16);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&kn, __popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (keep) kq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = ent;
+            }
+        }
+        __syncthreads(); // kn and kq are final for this pass
+        if (kn > 0 || pass == 1 || minTh == iniTh) break;
+        // nothing at iniThFAST: the same again with minThFAST (:825-828).  The barrier below separates the
+        // reads of kn above from the reset.
+        th = minTh;
+        __syncthreads();
+        if (tid == 0) {
+            qn = 0;
+            cn = 0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (dbgStop == 2) return;
-    // phase B: exact score for the survivors (all lanes busy); real corners (score >= tmin) are
-    // recorded in a second queue for the NMS
-    const int nq = qn;
-    for (int base = 0; base < nq; base += NT) {
-        const int qi = base + tid;
-        int pos = 0, sc = 0;
-        if (qi < nq) {
-            pos = queue[qi];
-            sc = fast_score(&tile[pos], P);
-            if (sc >= tmin) smap[pos] = (uint8_t)sc;
-        }
-        __syncthreads(); // every entry of this round has been read: cq may overwrite the queue up to here
-        const bool isc = qi < nq && sc >= tmin;
-        const unsigned long long m = __ballot(isc);
-        if (m) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&cn, __popcll(m));
-            wbase = __shfl(wbase, 0);
-            if (isc) cq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
-        }
-    }
-    __syncthreads();
-    if (dbgStop == 3) return;
-    // phase C: strict 8-neighbour NMS of the corners only (all 8 reads issued together; the score map
-    // is not modified, so every comparison sees the true scores).  Survivors are compacted into kq
-    // as pos | score<<16; the cell uses iniTh if any survivor reaches it, else minTh; the output order
-    // is row-major = ascending pos, obtained by ranking the (few) selected survivors against each other.
-    const int nc = cn;
-    bool sawIni = false;
-    for (int base = 0; base < nc; base += NT) {
-        const int qi = base + tid;
-        bool keep = false;
-        uint32_t ent = 0;
-        if (qi < nc) {
-            const int pos = cq[qi];
-            const int s0 = smap[pos];
-            const int n0 = smap[pos - 1], n1 = smap[pos + 1], n2 = smap[pos - P - 1], n3 = smap[pos - P],
-                      n4 = smap[pos - P + 1], n5 = smap[pos + P - 1], n6 = smap[pos + P], n7 = smap[pos + P + 1];
-            const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-            keep = s0 > mx; // s0 >= min(iniTh, minTh) already (phase B)
-            ent = (uint32_t)pos | ((uint32_t)s0 << 16);
-            sawIni |= keep && s0 >= iniTh;
-        }
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&kn, __popcll(m));
-            wbase = __shfl(wbase, 0);
-            if (keep) kq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = ent;
-        }
-    }
-    const bool anyIni = __syncthreads_or(sawIni) != 0; // also orders the kq writes before the reads below
     if (dbgStop == 4) return;
-    const int th = anyIni ? iniTh : minTh;
+    // output: row-major = ascending pos, obtained by ranking the (few) survivors against each other
     const int nk = kn;
     uint32_t* out = cand + (size_t)img * candImgStride + c.slotBase;
-    int mine = 0;
     for (int i = tid; i < nk; i += NT) {
         const uint32_t e = kq[i];
-        if ((int)(e >> 16) < th) continue;
         const uint32_t pos = e & 0xFFFFu;
         int rank = 0;
-        for (int j = 0; j < nk; j++) {
-            const uint32_t f = kq[j];
-            rank += ((int)(f >> 16) >= th) && ((f & 0xFFFFu) < pos);
-        }
+        for (int j = 0; j < nk; j++) rank += (kq[j] & 0xFFFFu) < pos;
         const int y = fast_div(pos, mP), x = (int)pos - y * P; // tile coordinates
         if (rank < c.slotCap)
             out[rank] = (uint32_t)(x - ox + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((e >> 16) << 24);
-        mine++;
     }
-    // number of outputs = number of selected survivors
-    {
-        int tot = mine;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
-        if (lane == 0) waveTot[wave] = tot;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < NW; w++) t += waveTot[w];
-            cellCount[(size_t)img * nCellsTotal + cell] = min(t, c.slotCap);
-        }
-    }
+    if (tid == 0) cellCount[(size_t)img * nCellsTotal + cell] = min(nk, c.slotCap);
 }
 
 // ------------------------------------------------------------------- K-QT
