@@ -151,6 +151,31 @@ def test_mono_init_extractor_5x_features(pkg, oracle):
     _same(kps, rkps, desc, rdesc)
 
 
+@pytest.mark.parametrize("ini,mn", [(20, 7), (7, 20), (12, 12), (60, 3), (250, 1), (1, 0)])
+def test_fast_threshold_pairs_and_fallback_cells(pkg, oracle, ini, mn):
+    # the two-call protocol of the cell loop (:808-828): FAST(iniTh), and FAST(minTh) only where the first
+    # call returns nothing -- for the usual order, the reversed one, equal thresholds and extreme values; the
+    # frame has flat areas, so some cells take the second call, which the per-level candidate lists show
+    img = _frame(pkg, 376, 500, 321)
+    img[:, 260:] = (img[:, 260:].astype(np.int32) // 6 + 100).astype(np.uint8)  # low-contrast half: minTh cells
+    ex = pkg.ORBextractor(700, 1.2, 6, ini, mn)
+    ref = oracle.Extractor(700, 1.2, 6, ini, mn)
+    mono, kps, desc = ex(img, (0, 0))
+    rmono, rkps, rdesc = ref.extract(img, (0, 0), cap=2000)
+    for lvl in range(6):
+        cx, cy, cs = ex.debug_candidates(lvl)
+        rc = ref.candidates(lvl)
+        assert len(cx) == len(rc), "candidate count level %d" % lvl
+        assert np.array_equal(cx, rc["x"].astype(np.int32)) and np.array_equal(cy, rc["y"].astype(np.int32))
+        assert np.array_equal(cs, rc["response"].astype(np.int32))
+    if (ini, mn) == (20, 7):
+        cs0 = ex.debug_candidates(0)[2]
+        assert (cs0 < 20).any() and (cs0 >= 20).any()  # both kinds of cell occur
+    assert mono == rmono
+    _same(kps, rkps, desc, rdesc)
+    ex.close()
+
+
 def test_noise_image_many_candidates(pkg, oracle):
     rng = np.random.default_rng(9)
     img = rng.integers(0, 256, size=(240, 320), dtype=np.uint8)
