@@ -199,7 +199,14 @@ int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n
  *           (Tracking::SearchLocalPoints): best / second best with the same-level ratio test;
  *   mode 1  (Frame& CurrentFrame, const Frame& LastFrame, th, bMono) :2193-2419 and
  *           (Frame& CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) :2421-2541: best only, TH = th_high,
- *           rotation-histogram cull when check_orientation.
+ *           rotation-histogram cull when check_orientation.  The same loop, without the cull, is
+ *           (KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) :473-586 and its vpMatchedKF twin :588-704
+ *           (taken = vpMatched non-null, levels [pred-1, pred], th_high = floor(TH_LOW * ratioHamming)); and
+ *           with qblocks all zero (no query hides a feature from a later one) it is the candidate search of
+ *           Fuse(KeyFrame*, vpMapPoints, th, bRight) :1643-1841 (chi2_gate = 1, th_high = TH_LOW),
+ *           Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) :1843-1965 and both directions of SearchBySim3
+ *           :1967-2191 (th_high = TH_HIGH); q_match[q] is then that loop's bestIdx and the caller keeps the
+ *           object logic (Replace / AddObservation, the mutual-agreement check).
  * The caller keeps the object walk (isBad, projection, RadiusByViewingCos, mnTrackScaleLevel ...) and passes
  * one query per GetFeaturesInArea call, in the reference's loop order.  Frame side: the N features with the
  * keypoints GetFeaturesInArea reads (mvKeysUn when Nleft == -1, else mvKeys ++ mvKeysRight), the grid
@@ -229,6 +236,12 @@ typedef struct {
     const float* qangle;                   /* keypoint angle in the last frame / keyframe (mode 1)        */
     const uint8_t* qblocks;                /* or NULL = all. pMP->Observations()>0 of the query's point   */
     int mode; float nnratio; int th_high; int check_orientation;
+    const float* inv_level_sigma2;         /* pKF->mvInvLevelSigma2, read when chi2_gate                   */
+    int n_levels;                          /* its length (octaves are checked against it)                  */
+    int chi2_gate;                         /* mode 1: Fuse's per-candidate reprojection test (:1773-1799):
+                                              e2 = ex^2 + ey^2 (+ (qxr - uright)^2 when uright >= 0) with
+                                              e2 * inv_level_sigma2[octave] > 5.99 (7.8) -> skipped; replaces
+                                              the uright window gate of :2270-2276                          */
 } orbfe_proj_args;
 /* q_match[nq] = feature written by the query itself (before the orientation cull) or -1; feat_match[n] =
  * index of the query whose map point ends up in F.mvpMapPoints[i], -1 = entry left as it was (or culled).

@@ -1286,7 +1286,25 @@ int orb_oracle_search_projection(const orb_oracle_proj_args* a, int32_t* q_match
         for (size_t k = 0; k < vIndices.size(); k++) {
             const size_t idx = vIndices[k];
             if (blocked(idx + base)) continue;
-            if (!bRight && Nleft == -1 && a->uright && a->uright[idx] > 0) {
+            if (a->chi2_gate) {
+                // Fuse, src/ORBmatcher.cc:1773-1799.  pKF->mvuRight[idx] is read with the index BEFORE
+                // `idx += pKF->NLeft` (:1801), also for right-camera candidates.
+                const float kpx = a->kx[idx + base], kpy = a->ky[idx + base];
+                const int kpLevel = a->octave[idx + base];
+                if (a->uright && a->uright[idx] >= 0) {
+                    const float kpr = a->uright[idx];
+                    const float ex = a->qx[q] - kpx;
+                    const float ey = a->qy[q] - kpy;
+                    const float er = a->qxr[q] - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * a->inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = a->qx[q] - kpx;
+                    const float ey = a->qy[q] - kpy;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * a->inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            } else if (!bRight && Nleft == -1 && a->uright && a->uright[idx] > 0) {
                 const float er = std::fabs(a->qxr[q] - a->uright[idx]);
                 if (er > r) continue;
             }

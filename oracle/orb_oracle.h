@@ -111,7 +111,9 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
 /* Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197 mode 0, :2193-2419 / :2421-2541
- * mode 1) over flattened inputs; same layout as orbfe_proj_args (include/orbfe.h). */
+ * mode 1) over flattened inputs; same layout as orbfe_proj_args (include/orbfe.h).  Mode 1 also covers the
+ * Sim3 overloads (:473-586, :588-704), and with qblocks all zero (independent queries) Fuse (:1643-1841 with
+ * chi2_gate, :1843-1965 without) and SearchBySim3's two directions (:1967-2191). */
 typedef struct {
     const uint8_t* desc; int n;
     const float* kx; const float* ky; const int32_t* octave; const float* angle;
@@ -123,6 +125,7 @@ typedef struct {
     const int32_t* qmin_level; const int32_t* qmax_level;
     const float* qxr; const uint8_t* qflags; const float* qangle; const uint8_t* qblocks;
     int mode; float nnratio; int th_high; int check_orientation;
+    const float* inv_level_sigma2; int n_levels; int chi2_gate; /* Fuse's per-candidate reprojection test, src/ORBmatcher.cc:1773-1799 */
 } orb_oracle_proj_args;
 int orb_oracle_search_projection(const orb_oracle_proj_args* a, int32_t* q_match, int32_t* feat_match);
 /* MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:387-419 for npts points with pooled descriptors. */

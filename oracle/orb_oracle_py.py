@@ -371,14 +371,15 @@ class _ProjArgs(C.Structure):
                 ("nq", C.c_int), ("qdesc", C.c_void_p), ("qx", C.c_void_p), ("qy", C.c_void_p), ("qr", C.c_void_p),
                 ("qmin_level", C.c_void_p), ("qmax_level", C.c_void_p), ("qxr", C.c_void_p), ("qflags", C.c_void_p),
                 ("qangle", C.c_void_p), ("qblocks", C.c_void_p),
-                ("mode", C.c_int), ("nnratio", C.c_float), ("th_high", C.c_int), ("check_orientation", C.c_int)]
+                ("mode", C.c_int), ("nnratio", C.c_float), ("th_high", C.c_int), ("check_orientation", C.c_int),
+                ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int), ("chi2_gate", C.c_int)]
 
 
 _PROJ_ARRAYS = [("desc", np.uint8), ("kx", np.float32), ("ky", np.float32), ("octave", np.int32), ("angle", np.float32),
                 ("uright", np.float32), ("taken", np.uint8), ("left_to_right", np.int32), ("right_to_left", np.int32),
                 ("qdesc", np.uint8), ("qx", np.float32), ("qy", np.float32), ("qr", np.float32),
                 ("qmin_level", np.int32), ("qmax_level", np.int32), ("qxr", np.float32), ("qflags", np.uint8),
-                ("qangle", np.float32), ("qblocks", np.uint8)]
+                ("qangle", np.float32), ("qblocks", np.uint8), ("inv_level_sigma2", np.float32)]
 
 
 def _proj_args(pr):
@@ -400,6 +401,8 @@ def _proj_args(pr):
     a.mode = int(pr["mode"])
     a.th_high = int(pr.get("th_high", 100))
     a.check_orientation = int(pr.get("check_orientation", 0))
+    a.chi2_gate = int(pr.get("chi2_gate", 0))
+    a.n_levels = len(keep["inv_level_sigma2"]) if "inv_level_sigma2" in keep else 0
     return a, keep, a.n, a.nq
 
 

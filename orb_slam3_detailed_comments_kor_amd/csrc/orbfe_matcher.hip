@@ -370,6 +370,8 @@ struct ProjDev {
     int mode;
     float nnratio;
     int thHigh;
+    const float* invSigma2; // per level, chi2 gate
+    int chi2;
     int32_t* cellStart; // 2 * 3072 + 1
     int32_t* cellItems; // n
     int32_t* cellOf;    // n
@@ -456,15 +458,29 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_proj_grid(ProjDev P)
     }
 }
 
-// static tests of one candidate (everything except "taken by an earlier query")
-__device__ __forceinline__ bool proj_static_ok(const ProjDev& P, int g, float x, float y, float r, int minLevel,
-                                               int maxLevel, bool gate, float xr)
+// static tests of one candidate (everything except "taken by an earlier query"); g = feature index into the
+// frame arrays, local = its index inside its camera's list (what the grid cells hold)
+__device__ __forceinline__ bool proj_static_ok(const ProjDev& P, int g, int local, float x, float y, float r,
+                                               int minLevel, int maxLevel, bool gate, float xr)
 {
     const int oct = P.octave[g];
     if (oct < minLevel || (maxLevel >= 0 && oct > maxLevel)) return false;
-    if (!(fabsf(__fsub_rn(P.kx[g], x)) < r && fabsf(__fsub_rn(P.ky[g], y)) < r)) return false;
+    const float kpx = P.kx[g], kpy = P.ky[g];
+    if (!(fabsf(__fsub_rn(kpx, x)) < r && fabsf(__fsub_rn(kpy, y)) < r)) return false;
     if (P.taken && P.taken[g]) return false;
-    if (gate) {
+    if (P.chi2) {
+        // Fuse (src/ORBmatcher.cc:1773-1799): mvuRight is read with the camera-local index (before :1801)
+        const float ex = __fsub_rn(x, kpx), ey = __fsub_rn(y, kpy);
+        float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+        const float kpr = P.uright ? P.uright[local] : -1.f;
+        double lim = 5.99;
+        if (kpr >= 0.f) {
+            const float er = __fsub_rn(xr, kpr);
+            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+            lim = 7.8;
+        }
+        if ((double)__fmul_rn(e2, P.invSigma2[oct]) > lim) return false;
+    } else if (gate) {
         const float ur = P.uright[g];
         if (ur > 0.f && fabsf(__fsub_rn(xr, ur)) > r) return false;
     }
@@ -491,13 +507,13 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
         const int fbase = bRight ? P.Nleft : 0, side = bRight ? PROJ_CELLS : 0;
         const int minLevel = P.qmin[q], maxLevel = P.qmax[q];
         const bool gate = !bRight && P.Nleft == -1 && P.uright != nullptr;
-        const float xr = gate ? P.qxr[q] : 0.f;
+        const float xr = (gate || (P.chi2 && P.qxr)) ? P.qxr[q] : 0.f;
         int cnt = 0;
         for (int s = lane; s < total; s += 64) {
             const int c = side + (cx0 + s / ncy) * PROJ_GR + cy0 + s % ncy;
             const int st = P.cellStart[c], en = P.cellStart[c + 1];
             for (int j = st; j < en; j++)
-                cnt += proj_static_ok(P, P.cellItems[j] + fbase, x, y, r, minLevel, maxLevel, gate, xr);
+                cnt += proj_static_ok(P, P.cellItems[j] + fbase, P.cellItems[j], x, y, r, minLevel, maxLevel, gate, xr);
         }
         int inc = cnt;
 #pragma unroll
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
                     const int st = P.cellStart[c], en = P.cellStart[c + 1];
                     for (int j = st; j < en; j++) {
                         const int g = P.cellItems[j] + fbase;
-                        if (!proj_static_ok(P, g, x, y, r, minLevel, maxLevel, gate, xr)) continue;
+                        if (!proj_static_ok(P, g, g - fbase, x, y, r, minLevel, maxLevel, gate, xr)) continue;
                         const int dist = hamming(dq, load_desc(P.desc + (size_t)g * 32));
                         P.rawKeys[o++] = ((unsigned long long)dist << 55) | ((unsigned long long)s << 43) |
                                          ((unsigned long long)(j - st) << 24) | (unsigned long long)g;
@@ -1147,6 +1163,11 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     const bool orient = a->mode == 1 && a->check_orientation;
     if (orient && a->nq && (!a->angle || !a->qangle)) return ORBFE_ERR_ARGS;
     if (a->Nleft == -1 && a->uright && a->nq && !a->qxr) return ORBFE_ERR_ARGS;
+    if (a->chi2_gate) { // Fuse's reprojection test: sigma table indexed by the candidates' octaves
+        if (a->mode != 1 || !a->inv_level_sigma2 || a->n_levels < 1 || (a->uright && a->nq && !a->qxr)) return ORBFE_ERR_ARGS;
+        for (int i = 0; i < a->n; i++)
+            if (a->octave[i] < 0 || a->octave[i] >= a->n_levels) return ORBFE_ERR_ARGS;
+    }
     for (int q = 0; q < a->nq; q++) {
         const int f = a->qflags ? a->qflags[q] : 0;
         if ((f & 1) && a->Nleft == -1) return ORBFE_ERR_ARGS; // there is no right grid
@@ -1173,7 +1194,9 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
     if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
     if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
-    if (a->uright && a->Nleft == -1 && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+    if (a->uright && (a->Nleft == -1 || a->chi2_gate) && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+    float* dInvSigma2 = nullptr;
+    if (a->chi2_gate && (r = s.up(&dInvSigma2, a->inv_level_sigma2, (size_t)a->n_levels)) < 0) return r;
     if (a->taken && (r = s.up(&dTaken, a->taken, n)) < 0) return r;
     if (a->Nleft != -1 && a->mode == 0) {
         if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
@@ -1215,6 +1238,7 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     P.nq = a->nq; P.qdesc = dQdesc; P.qx = dQx; P.qy = dQy; P.qr = dQr; P.qxr = dQxr;
     P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
     P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
+    P.invSigma2 = dInvSigma2; P.chi2 = a->chi2_gate ? 1 : 0;
     std::vector<int32_t> out(4 + nq + n);
     for (int attempt = 0;; attempt++) {
         {

@@ -61,7 +61,7 @@ def tri_inputs(n1, n2, seed):
 
 
 def projection_problem(seed, n=1200, nq=900, mode=0, stereo=False, Nleft=-1, th=1.0, nnratio=0.8, taken_frac=0.1,
-                       crowd=True, check_orientation=False, partners=False, blocks=None, w=752, h=480):
+                       crowd=True, check_orientation=False, partners=False, blocks=None, w=752, h=480, loop=None):
     """Flattened SearchByProjection problem (fields of orbfe_proj_args).  Queries are map points that project
     near existing features, with descriptors a few bits away; `crowd` makes several queries compete for the
     same feature so that the sequential occupancy rule matters."""
@@ -134,4 +134,25 @@ def projection_problem(seed, n=1200, nq=900, mode=0, stereo=False, Nleft=-1, th=
             pr["left_to_right"], pr["right_to_left"] = l2r, r2l
     if blocks is not None:
         pr["qblocks"] = (rng.random(nq) < blocks).astype(np.uint8)
+    # the other ORBmatcher loops that run on mode 1 (include/orbfe.h):
+    if loop in ("sim3_projection", "fuse", "fuse_sim3", "search_by_sim3"):
+        assert mode == 1
+        pr["qmin_level"] = (lvl - 1).astype(np.int32)  # kpLevel<nPredictedLevel-1 || kpLevel>nPredictedLevel
+        pr["qmax_level"] = lvl
+        pr["check_orientation"] = 0
+        pr["th_high"] = {"sim3_projection": int(np.floor(50 * 0.9)), "fuse": 50, "fuse_sim3": 50, "search_by_sim3": 100}[loop]
+        if loop != "sim3_projection":                  # independent queries: nothing a query takes is hidden
+            pr["qblocks"] = np.zeros(nq, np.uint8)
+            pr["taken"] = np.zeros(n, np.uint8)
+        if loop == "fuse":                             # per-candidate chi2 test on the reprojection error
+            pr["chi2_gate"] = 1
+            sigma2 = (sf * sf).astype(np.float32)
+            pr["inv_level_sigma2"] = (np.float32(1.0) / sigma2).astype(np.float32)
+            if stereo:                                 # mvuRight >= 0 selects the 3-dof test (7.8)
+                pr["uright"] = np.where(rng.random(n) < 0.5, kx - rng.uniform(0, 30, n), -1).astype(np.float32)
+                t_ur = pr["uright"][tgt]
+                pr["qxr"] = np.where(t_ur >= 0, t_ur + rng.normal(0, 1.5, nq), qx - 10).astype(np.float32)
+        else:
+            pr.pop("uright", None)
+            pr.pop("qxr", None)
     return pr

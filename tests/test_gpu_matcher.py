@@ -214,6 +214,13 @@ PROJ_CASES = [
     dict(seed=11, mode=0, n=3, nq=40),
     dict(seed=12, mode=1, n=200, nq=1, crowd=False),
     dict(seed=13, mode=0, n=3000, nq=200, th=200.0),  # every feature is a candidate: key buffers regrow
+    # the other ORBmatcher loops on the same kernels (include/orbfe.h, mode 1):
+    dict(seed=14, mode=1, th=4.0, loop="sim3_projection", taken_frac=0.3),   # :473-586 / :588-704
+    dict(seed=15, mode=1, th=3.0, loop="fuse"),                               # :1643-1841, monocular keyframe
+    dict(seed=16, mode=1, th=3.0, loop="fuse", stereo=True),                  # stereo keyframe: 3-dof chi2 test
+    dict(seed=17, mode=1, th=3.0, loop="fuse", Nleft=700),                    # two-camera rig, bRight queries
+    dict(seed=18, mode=1, th=4.0, loop="fuse_sim3"),                          # :1843-1965
+    dict(seed=19, mode=1, th=7.5, loop="search_by_sim3", n=2000, nq=1500),    # :1967-2191, one direction
 ]
 
 
@@ -230,6 +237,13 @@ def test_search_projection(pkg, oracle, case):
     if case["seed"] in (1, 5, 10):
         assert n_ref > 50  # the case is not vacuous
         assert pkg.search_projection_last_sweeps() >= 2  # and the occupancy rule was exercised
+    if case.get("loop"):
+        assert n_ref > 50
+    if case.get("loop") == "fuse":  # the chi2 test must have removed candidates the plain search would take
+        plain = dict(pr)
+        plain["chi2_gate"] = 0
+        plain.pop("uright", None)
+        assert not np.array_equal(oracle.search_projection(plain)[1], q_ref)
 
 
 def test_search_projection_errors(pkg):

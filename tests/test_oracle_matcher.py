@@ -157,7 +157,18 @@ def _proj_spec(pr):
             o = occ[g]
             if o == -1 or (o >= 0 and (blocks is None or blocks[o])):
                 continue
-            if not right and Nleft == -1 and pr.get("uright") is not None and pr["uright"][g] > 0:
+            if pr.get("chi2_gate"):
+                loc = g - (Nleft if right else 0)  # mvuRight is read with the camera-local index (:1775)
+                ex, ey = f32(x - pr["kx"][g]), f32(y - pr["ky"][g])
+                e2 = f32(f32(ex * ex) + f32(ey * ey))
+                lim = 5.99
+                if pr.get("uright") is not None and pr["uright"][loc] >= 0:
+                    er = f32(pr["qxr"][q] - pr["uright"][loc])
+                    e2 = f32(e2 + f32(er * er))
+                    lim = 7.8
+                if float(f32(e2 * pr["inv_level_sigma2"][pr["octave"][g]])) > lim:
+                    continue
+            elif not right and Nleft == -1 and pr.get("uright") is not None and pr["uright"][g] > 0:
                 if abs(pr["qxr"][q] - pr["uright"][g]) > r:
                     continue
             d = int(np.unpackbits(pr["qdesc"][q] ^ pr["desc"][g]).sum())
@@ -212,6 +223,12 @@ def _proj_spec(pr):
     dict(seed=24, mode=1, n=300, nq=260, th=7.0, check_orientation=True),
     dict(seed=25, mode=1, n=300, nq=260, Nleft=150, th=15.0),
     dict(seed=26, mode=0, n=300, nq=260, blocks=0.6, th=3.0),
+    dict(seed=27, mode=1, n=300, nq=260, th=4.0, loop="sim3_projection", taken_frac=0.3),
+    dict(seed=28, mode=1, n=300, nq=260, th=3.0, loop="fuse"),
+    dict(seed=29, mode=1, n=300, nq=260, th=3.0, loop="fuse", stereo=True),
+    dict(seed=30, mode=1, n=320, nq=280, th=3.0, loop="fuse", Nleft=170),
+    dict(seed=31, mode=1, n=300, nq=260, th=4.0, loop="fuse_sim3"),
+    dict(seed=32, mode=1, n=300, nq=260, th=7.5, loop="search_by_sim3"),
 ], ids=lambda c: "s%d" % c["seed"])
 def test_search_projection_against_bruteforce_spec(oracle, case):
     from matcher_inputs import projection_problem
