@@ -116,8 +116,10 @@ void orbfe_get_features_per_level(orbfe_ctx*, int* n_per_level);
 int orbfe_get_level(orbfe_ctx*, int img_index, int level, uint8_t* dst, size_t dst_stride, int* rows, int* cols);
 
 /* Per-stage device time measured with hipEvents on the context's stream.  Enabling resets the
- * statistics; every call then records one event set (ring of 256); orbfe_profile_read() waits for
- * the stream, writes the per-stage AVERAGE over the recorded calls and returns their number. */
+ * statistics; with on = N >= 1 every N-th call then records one event set (ring of 256) -- the seven
+ * event records cost ~25 us of a 64-frame batch, so a sampling period keeps them out of the throughput;
+ * orbfe_profile_read() waits for the stream, writes the per-stage AVERAGE over the recorded calls and
+ * returns their number. */
 #define ORBFE_STAGE_PYRAMID 0
 #define ORBFE_STAGE_FAST 1
 #define ORBFE_STAGE_OCTREE 2

@@ -161,6 +161,9 @@ struct orbfe_ctx {
     // profiling: a ring of event sets, one set per call, read (averaged) after the timed region
     static const int kProfSets = 256;
     bool profile = false;
+    int profEvery = 1;   // record an event set on every profEvery-th call
+    long profSeen = 0;   // calls since profiling was enabled
+    bool recNow = false; // the current call records
     std::vector<hipEvent_t> ev; // kProfSets * (ORBFE_STAGE_COUNT + 1)
     bool evReady = false;
     long profCalls = 0;
@@ -645,7 +648,7 @@ const uint8_t* trig_table(int device, hipStream_t s)
 
 inline void rec(orbfe_ctx* c, int i)
 {
-    if (c->profile && c->evReady)
+    if (c->recNow)
         (void)hipEventRecord(c->ev[(size_t)(c->profCalls % orbfe_ctx::kProfSets) * (ORBFE_STAGE_COUNT + 1) + i],
                              c->stream);
 }
@@ -674,6 +677,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     int32_t* const d_hdr = reinterpret_cast<int32_t*>(c->d_fix.p);
     const bool kernelClearsHdr = c->pyrFused && !(c->nStreams > 1 && nimg > 1);
     if (!kernelClearsHdr) HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
+    c->recNow = c->profile && c->evReady && c->profSeen % c->profEvery == 0;
     rec(c, 0);
     // Sub-batches on separate streams (ORBFE_STREAMS > 1): the image pipelines are independent, so the
     // latency-bound stages of one sub-batch overlap with the issue-bound stages of another.  Stage
@@ -801,7 +805,9 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         c->lastFixups = nFix;
     }
     rec(c, 6);
-    if (c->profile && c->evReady) c->profCalls++;
+    if (c->recNow) c->profCalls++;
+    if (c->profile) c->profSeen++;
+    c->recNow = false;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1193,7 +1199,8 @@ int orbfe_profile_enable(orbfe_ctx* c, int on)
         c->evReady = true;
     }
     c->profile = on != 0;
-    if (on) c->profCalls = 0;
+    c->profEvery = on > 1 ? on : 1;
+    if (on) c->profCalls = c->profSeen = 0;
     return 0;
 }
 
