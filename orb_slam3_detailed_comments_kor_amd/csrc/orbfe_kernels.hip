@@ -1388,49 +1388,64 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
 
     // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
     const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
-    const uint32_t TLO = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), THI = t4 | (t5 << 8) | (t6 << 16);
     // horizontal: item = (pair of rows 2p, 2p+1; group of 4 output columns) -> 22 x 10 items; the two
     // rows are packed as the low / high u16 of one dword so that the vertical pass can use
-    // v_dot2_u32_u16 on vertically adjacent values.
+    // v_dot2_u32_u16 on vertically adjacent values.  Output j of a group needs source bytes j..j+6 of the
+    // three aligned dwords (A, B, C) of its row: instead of shifting the DATA (v_alignbyte) the TAPS are
+    // shifted -- ten v_dot4_u32_u8 per row against wave-uniform tap words, no byte shuffles.
     uint32_t* hp2 = reinterpret_cast<uint32_t*>(hp);
     {
-        int pr = lane / 10, hg = lane - 10 * (lane / 10); // +64 items = +6 pair-rows +4 groups
-        for (int idx = lane; idx < DESC_HPAIRS * 10; idx += 64) {
-            const int ra = 2 * pr, rb = min(2 * pr + 1, DESC_RAW - 1);
-            const uint32_t* sa = reinterpret_cast<const uint32_t*>(raw + ra * DESC_RAWP + 4 * hg);
-            const uint32_t* sb = reinterpret_cast<const uint32_t*>(raw + rb * DESC_RAWP + 4 * hg);
-            const uint32_t a0 = sa[0], a1 = sa[1], a2 = sa[2];
-            const uint32_t b0 = sb[0], b1 = sb[1], b2 = sb[2];
-            uint4 o;
-#define ORBFE_HROW(d0, d1, d2, SH)                                                                       \
-    desc_hsat<SAT>(__builtin_amdgcn_udot4(SH == 0 ? d1 : __builtin_amdgcn_alignbyte(d2, d1, SH), THI,    \
-                               __builtin_amdgcn_udot4(SH == 0 ? d0 : __builtin_amdgcn_alignbyte(d1, d0, SH), TLO, \
-                                                      0u, false),                                        \
-                               false)) /* ufixedpoint16 saturating add (only reachable with non-default taps) */
-            o.x = ORBFE_HROW(a0, a1, a2, 0) | (ORBFE_HROW(b0, b1, b2, 0) << 16);
-            o.y = ORBFE_HROW(a0, a1, a2, 1) | (ORBFE_HROW(b0, b1, b2, 1) << 16);
-            o.z = ORBFE_HROW(a0, a1, a2, 2) | (ORBFE_HROW(b0, b1, b2, 2) << 16);
-            o.w = ORBFE_HROW(a0, a1, a2, 3) | (ORBFE_HROW(b0, b1, b2, 3) << 16);
-#undef ORBFE_HROW
-            *reinterpret_cast<uint4*>(hp2 + pr * DESC_HP + 4 * hg) = o;
-            pr += 6;
-            hg += 4;
-            if (hg >= 10) {
-                hg -= 10;
-                pr += 1;
+        const uint32_t A0 = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), B0 = t4 | (t5 << 8) | (t6 << 16);
+        const uint32_t A1 = (t0 << 8) | (t1 << 16) | (t2 << 24), B1 = t3 | (t4 << 8) | (t5 << 16) | (t6 << 24);
+        const uint32_t A2 = (t0 << 16) | (t1 << 24), B2 = t2 | (t3 << 8) | (t4 << 16) | (t5 << 24), C2 = t6;
+        const uint32_t A3 = t0 << 24, B3 = t1 | (t2 << 8) | (t3 << 16) | (t4 << 24), C3 = t5 | (t6 << 8);
+        // item idx = 10 * pr + hg = lane + 64 k: the H buffer is linear in idx (16 B per item); the raw offset
+        // 88 * pr + 4 * hg advances by 544 (pr += 6, hg += 4) or, when hg wraps, by 592 (pr += 7, hg -= 6).
+        // Pair-row 21 reads "row 43" past the patch: its values only ever meet a zero tap (row 43 is the
+        // high half of the last pair), and the bytes lie inside this wave's LDS region.
+        int hg = lane - 10 * (lane / 10);
+        int off = 88 * (lane / 10) + 4 * hg;
+        uint4* dst = reinterpret_cast<uint4*>(hp2) + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (lane + 64 * k < DESC_HPAIRS * 10) {
+                const uint32_t* sa = reinterpret_cast<const uint32_t*>(raw + off);
+                const uint32_t a0 = sa[0], a1 = sa[1], a2 = sa[2];
+                const uint32_t b0 = sa[11], b1 = sa[12], b2 = sa[13]; // next row: + DESC_RAWP bytes
+#define ORBFE_H0(A, B, C) desc_hsat<SAT>(__builtin_amdgcn_udot4(B, B0, __builtin_amdgcn_udot4(A, A0, 0u, false), false))
+#define ORBFE_H1(A, B, C) desc_hsat<SAT>(__builtin_amdgcn_udot4(B, B1, __builtin_amdgcn_udot4(A, A1, 0u, false), false))
+#define ORBFE_H2(A, B, C) \
+    desc_hsat<SAT>(__builtin_amdgcn_udot4(C, C2, __builtin_amdgcn_udot4(B, B2, __builtin_amdgcn_udot4(A, A2, 0u, false), false), false))
+#define ORBFE_H3(A, B, C) \
+    desc_hsat<SAT>(__builtin_amdgcn_udot4(C, C3, __builtin_amdgcn_udot4(B, B3, __builtin_amdgcn_udot4(A, A3, 0u, false), false), false))
+                uint4 o;
+                o.x = ORBFE_H0(a0, a1, a2) | (ORBFE_H0(b0, b1, b2) << 16);
+                o.y = ORBFE_H1(a0, a1, a2) | (ORBFE_H1(b0, b1, b2) << 16);
+                o.z = ORBFE_H2(a0, a1, a2) | (ORBFE_H2(b0, b1, b2) << 16);
+                o.w = ORBFE_H3(a0, a1, a2) | (ORBFE_H3(b0, b1, b2) << 16);
+#undef ORBFE_H0
+#undef ORBFE_H1
+#undef ORBFE_H2
+#undef ORBFE_H3
+                dst[64 * k] = o;
             }
+            const bool wrap = hg >= 6;
+            off += wrap ? 592 : 544;
+            hg += wrap ? -6 : 4;
         }
     }
     WAVE_SYNC();
-    // vertical: item = (row r, group of 4 columns); 37 x 10 items, written over the raw patch.
-    // Row r needs H rows r..r+6 = four row pairs; tap pairs depend on the parity of r.
+    // vertical: item = (pair of output rows 2k, 2k+1; group of 4 columns) -> 19 x 10 items = three nearly
+    // full rounds.  Both rows read the same four row pairs of the H buffer (H rows 2k..2k+7): the even row
+    // weighs them (t0,t1)(t2,t3)(t4,t5)(t6,0), the odd one (0,t0)(t1,t2)(t3,t4)(t5,t6).  Output row 37 (second
+    // row of the last pair) does not exist; it lands in unused bytes of the patch buffer.
     {
         typedef __attribute__((ext_vector_type(2))) unsigned short us2;
         union U2 {
             uint32_t u;
             us2 v;
         };
-        U2 e0, e1, e2, e3, o0, o1, o2, o3; // even r: (t0,t1)(t2,t3)(t4,t5)(t6,0); odd r: (0,t0)(t1,t2)(t3,t4)(t5,t6)
+        U2 e0, e1, e2, e3, o0, o1, o2, o3;
         e0.u = t0 | (t1 << 16);
         e1.u = t2 | (t3 << 16);
         e2.u = t4 | (t5 << 16);
@@ -1439,13 +1454,15 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         o1.u = t1 | (t2 << 16);
         o2.u = t3 | (t4 << 16);
         o3.u = t5 | (t6 << 16);
-        int vr = lane / 10, hg = lane - 10 * (lane / 10);
-        for (int idx = lane; idx < DESC_BW * 10; idx += 64) {
-            const bool odd = vr & 1;
-            const uint4* sp4 = reinterpret_cast<const uint4*>(hp2 + (vr >> 1) * DESC_HP + 4 * hg);
-            const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
-            const us2 w0 = odd ? o0.v : e0.v, w1 = odd ? o1.v : e1.v, w2 = odd ? o2.v : e2.v, w3 = odd ? o3.v : e3.v;
-            uint32_t outp = 0;
+        int hg = lane - 10 * (lane / 10);
+        int boff = 2 * DESC_BP * (lane / 10) + 4 * hg; // byte offset of output row 2k in the blurred patch
+        const uint4* src = reinterpret_cast<const uint4*>(hp2) + lane;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (lane + 64 * k < 19 * 10) {
+                const uint4* sp4 = src + 64 * k;
+                const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
+                uint32_t outE = 0, outO = 0;
 #define ORBFE_VCOL(F, SHIFT)                                                                           \
     {                                                                                                   \
         U2 q0, q1, q2, q3;                                                                              \
@@ -1453,24 +1470,28 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         q1.u = p1.F;                                                                                    \
         q2.u = p2.F;                                                                                    \
         q3.u = p3.F;                                                                                    \
-        uint32_t acc = __builtin_amdgcn_udot2(q0.v, w0, 32768u, false);                                 \
-        acc = __builtin_amdgcn_udot2(q1.v, w1, acc, false);                                             \
-        acc = __builtin_amdgcn_udot2(q2.v, w2, acc, false);                                             \
-        acc = __builtin_amdgcn_udot2(q3.v, w3, acc, false);                                             \
-        outp |= min(acc >> 16, 255u) << SHIFT;                                                          \
+        uint32_t acc = __builtin_amdgcn_udot2(q0.v, e0.v, 32768u, false);                               \
+        acc = __builtin_amdgcn_udot2(q1.v, e1.v, acc, false);                                           \
+        acc = __builtin_amdgcn_udot2(q2.v, e2.v, acc, false);                                           \
+        acc = __builtin_amdgcn_udot2(q3.v, e3.v, acc, false);                                           \
+        outE |= min(acc >> 16, 255u) << SHIFT;                                                          \
+        acc = __builtin_amdgcn_udot2(q0.v, o0.v, 32768u, false);                                        \
+        acc = __builtin_amdgcn_udot2(q1.v, o1.v, acc, false);                                           \
+        acc = __builtin_amdgcn_udot2(q2.v, o2.v, acc, false);                                           \
+        acc = __builtin_amdgcn_udot2(q3.v, o3.v, acc, false);                                           \
+        outO |= min(acc >> 16, 255u) << SHIFT;                                                          \
     }
-            ORBFE_VCOL(x, 0)
-            ORBFE_VCOL(y, 8)
-            ORBFE_VCOL(z, 16)
-            ORBFE_VCOL(w, 24)
+                ORBFE_VCOL(x, 0)
+                ORBFE_VCOL(y, 8)
+                ORBFE_VCOL(z, 16)
+                ORBFE_VCOL(w, 24)
 #undef ORBFE_VCOL
-            *reinterpret_cast<uint32_t*>(bl + vr * DESC_BP + 4 * hg) = outp;
-            vr += 6;
-            hg += 4;
-            if (hg >= 10) {
-                hg -= 10;
-                vr += 1;
+                *reinterpret_cast<uint32_t*>(bl + boff) = outE;
+                *reinterpret_cast<uint32_t*>(bl + boff + DESC_BP) = outO;
             }
+            const bool wrap = hg >= 6;
+            boff += wrap ? (7 * 2 * DESC_BP - 24) : (6 * 2 * DESC_BP + 16);
+            hg += wrap ? -6 : 4;
         }
     }
     WAVE_SYNC();
