@@ -487,10 +487,10 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
             for (int l = 1; l < nl; l++) sum += pry[(size_t)l * c->pyrNty + j].needHi - pry[(size_t)l * c->pyrNty + j].lo;
             c->pyrStageY = std::max(c->pyrStageY, sum);
         }
-        // staged x entries 8 B (padded to an even count), y entries 16 B; the kernel deals whole column
-        // groups (4 px) of a region row to its 256 threads
-        c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + (c->pyrStageX & 1)) +
-                         16 * (size_t)c->pyrStageY;
+        // staged x and y entries 8 B each (y: 16-bit LDS row offsets, so a region must stay below 64 KB -- it
+        // does, the whole allocation is); the kernel deals whole column groups (4 px) of a region row to its
+        // 256 threads
+        c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY);
         c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk &&
                       getenv("ORBFE_PYR_UNFUSED") == nullptr;
     }
@@ -500,6 +500,12 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
     c->rows = rows;
     c->cols = cols;
     c->capImgs = 0; // per-image strides changed: force re-allocation
+    if (getenv("ORBFE_VERBOSE"))
+        fprintf(stderr,
+                "orbfe: %dx%d: pyramid %zu B/img, %d FAST cells; LDS per workgroup: k_pyr_fused %zu B (%dx%d tiles of "
+                "%d px, fused=%d), k_fast_cells %zu B (%d threads), k_octree %zu B\n",
+                cols, rows, c->pyrStride, c->nCells, c->pyrLdsBytes, c->pyrNtx, c->pyrNty, ORBFE_PYR_TILE,
+                (int)c->pyrFused, c->fastLdsBytes, c->fastThreads, c->qtLdsBytes);
     return 0;
 }
 

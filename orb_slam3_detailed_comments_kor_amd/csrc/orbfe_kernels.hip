@@ -111,15 +111,15 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
 {
     // first kernel of a batch: clear the {fragile count, error flag, -, -} header the later kernels append to
     if (clearHdr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < 4) clearHdr[threadIdx.x] = 0;
-    // dynamic LDS: region buffer A | region buffer B | staged x entries (8 B) | staged y entries (16 B)
+    // dynamic LDS: region buffer A | region buffer B | staged x entries (8 B) | staged y entries (8 B)
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
     uint8_t* bufA = pyr_lds;
     uint8_t* bufB = pyr_lds + bufBytes0;
     // staged x entry: .x = source column relative to the source region, .y = a0 | a1 << 16
-    // staged y entry: .x / .y = LDS byte offset of source row sy0 / sy1 inside the source region,
-    //                 .z / .w = b0 << 16 / b1 << 16  ((b * t) >> 16 == mulhi(b << 16, t))
+    // staged y entry (8 B, to keep seven workgroups per CU): .x = LDS byte offsets of the source rows sy0 | sy1 << 16
+    //                 inside the source region, .y = b0 | b1 << 16  ((b * t) >> 16 == mulhi(b << 16, t))
     uint2* xt = reinterpret_cast<uint2*>(pyr_lds + bufBytes0 + bufBytes1);
-    uint4* yt = reinterpret_cast<uint4*>(xt + stageX + (stageX & 1)); // 16-B aligned
+    uint2* yt = xt + stageX;
     const int tid = threadIdx.x;
     const int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z + imgBase;
     uint8_t* base = pyr + (size_t)img * pyrImgStride;
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
             }
             for (int k = tid; k < nH; k += 256) {
                 const OrbResizeY e = ytab[yb + k];
-                yt[yo + k] = make_uint4((unsigned)(((int)e.sy0 - sLoY) * sPitch), (unsigned)(((int)e.sy1 - sLoY) * sPitch),
-                                        (unsigned)(uint16_t)e.b0 << 16, (unsigned)(uint16_t)e.b1 << 16);
+                yt[yo + k] = make_uint2((unsigned)(((int)e.sy0 - sLoY) * sPitch) | ((unsigned)(((int)e.sy1 - sLoY) * sPitch) << 16),
+                                        (unsigned)(uint16_t)e.b0 | ((unsigned)(uint16_t)e.b1 << 16));
             }
             xo += nW;
             yo += nH;
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
             const int qStep = rowsPerPass * gpitch, dStep = rowsPerPass * dp;
             const bool colOwned = c0 < ownW, fullDword = c0 + 4 <= ownW;
             for (int r = rr; r < nH; r += rowsPerPass, q += qStep, dq += dStep) {
-                const uint4 Y = yt[yo + r];
+                const uint2 Yp = yt[yo + r];
+                const uint4 Y = make_uint4(Yp.x & 0xFFFFu, Yp.x >> 16, Yp.y << 16, Yp.y & 0xFFFF0000u);
                 const uint32_t* S0 = reinterpret_cast<const uint32_t*>(S + Y.x + xbase);
                 const uint32_t* S1 = reinterpret_cast<const uint32_t*>(S + Y.y + xbase);
                 const uint32_t d0 = S0[0], d1 = S0[1], d2 = S0[2];
