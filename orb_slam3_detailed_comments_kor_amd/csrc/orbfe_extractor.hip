@@ -739,7 +739,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                            c->qtKeyOff, c->qtKeyCap);
         if (nsub == 1) rec(c, 3);
         // K-PACK
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(256), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(PACK_THREADS), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
                            c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
                            c->kb8On ? c->d_kb8.p : nullptr,
                            c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0);

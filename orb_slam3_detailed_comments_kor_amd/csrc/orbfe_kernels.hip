@@ -1006,7 +1006,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
 // list order inside a level; keypoints whose level-0 x lies in [lap0, lap1] fill the output from
 // the back, the others from the front.  Writes every KeyPoint field except the angle and a work
 // item per keypoint for K-DESC.
-__global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ lg, int nlevels,
+#define PACK_THREADS 1024 /* one round for the usual <= 1024 keypoints per image (256: four rounds, 8.8 -> see DESIGN.md) */
+__global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __restrict__ lg, int nlevels,
                                               const uint32_t* __restrict__ lvlKp, size_t kpImgStride,
                                               const int32_t* __restrict__ lvlCount, const int32_t* __restrict__ lap,
                                               float* __restrict__ kpsOut /* 7 floats per kp */, int capPerImg,
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
                                               float* __restrict__ raysOut /* 3 floats per kp, or NULL */, int imgBase)
 {
     __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
-    __shared__ int waveCnt[4];
+    __shared__ int waveCnt[PACK_THREADS / 64];
     __shared__ int runStereo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img = (int)blockIdx.x + imgBase;
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
     const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1];
     float* kimg = kpsOut + (size_t)img * capPerImg * 7;
     OrbDescWork* wimg = work + (size_t)img * capPerImg;
-    for (int base = 0; base < n; base += 256) {
+    for (int base = 0; base < n; base += PACK_THREADS) {
         const int g = base + tid;
         bool stereo = false;
         int level = 0, px = 0, py = 0;
@@ -1084,7 +1085,11 @@ __global__ __launch_bounds__(256) void k_pack(const OrbLevelGeom* __restrict__ l
             wimg[g] = w;
         }
         __syncthreads();
-        if (tid == 0) runStereo += waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < PACK_THREADS / 64; w++) t += waveCnt[w];
+            runStereo += t;
+        }
         __syncthreads();
     }
     if (tid == 0) {
