@@ -126,7 +126,7 @@ def main():
     import torch
     import torch.distributed as dist
     import orb_slam3_detailed_comments_kor_amd as pkg
-    from orb_slam3_detailed_comments_kor_amd.multicam import DescriptorExchange
+    from orb_slam3_detailed_comments_kor_amd.multicam import PipelinedExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,9 +135,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("ORBFE_BENCH_FORCE_DIST"):  # the latter: rehearse the N>1 code path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, H, W = args.batch, args.rows, args.cols
     # distinct frames per rank: a few generated frames, horizontally rolled to fill the batch
@@ -156,9 +157,10 @@ def main():
     torch.cuda.set_stream(stream)
     ex.set_stream(stream.cuda_stream)
     cap = ex.max_keypoints(H, W)
-    xch = DescriptorExchange(B, cap, dev, world, rank)
-    d_desc = xch.desc_view()
-    d_n = xch.count_view()
+    # two slab pairs: the all-gather of batch i (process group's stream) overlaps the extraction of batch i+1
+    pipe = PipelinedExchange(B, cap, dev, world, rank)
+    d_desc = pipe.x[0].desc_view()
+    d_n = pipe.x[0].count_view()
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
     lap = (0, 1000)  # mono protocol, src/Frame.cc:306
@@ -184,12 +186,14 @@ def main():
             e2.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, k2.data_ptr(), de2.data_ptr(), cap,
                                     n2.data_ptr(), m2.data_ptr())
             return
-        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                d_n.data_ptr(), d_mono.data_ptr())
-        if world > 1:
-            xch.all_gather()  # one RCCL all-gather of descriptor slabs per batch
+        x = pipe.begin()  # waits (on the stream) for the collective that last read this slab
+        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(), cap,
+                                x.count_view().data_ptr(), d_mono.data_ptr())
+        if dist.is_initialized():
+            pipe.submit()  # one RCCL all-gather of descriptor slabs per batch, asynchronous
 
     def barrier():
+        pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -295,7 +299,8 @@ def main():
                 "keypoints_per_step": kp_per_step,
                 "trig": args.trig,
                 "contexts": 1 + len(extra),
-                "exchange": "1 all-gather of descriptor slabs per step" if world > 1 else "none",
+                "exchange": ("1 all-gather of descriptor slabs per step, overlapped with the next step's extraction"
+                             if dist.is_initialized() else "none"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -318,7 +323,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -26,6 +26,44 @@ def owner_of_frame(f, nframes, world):
     return f // (base + 1) if f < cut else rem + (f - cut) // max(base, 1)
 
 
+class PipelinedExchange:
+    """Two DescriptorExchange buffers used alternately: the all-gather of batch i runs while batch i+1 is being
+    extracted into the other slab (collectives overlapped with compute on a separate stream).  Usage per batch:
+        x = pipe.begin()          # waits for the collective that last used this slab pair, returns the exchange
+        ... extractor writes into x.desc_view() / x.count_view() ...
+        pipe.submit()             # starts this batch's all-gather asynchronously
+    and `pipe.drain()` after the last batch; `pipe.completed()` is the most recent exchange whose gathered
+    buffer is final after drain()."""
+
+    def __init__(self, frames_per_rank, cap, device, world=None, rank=None, depth=2):
+        self.x = [DescriptorExchange(frames_per_rank, cap, device, world, rank) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.i = 0
+        self.last = None
+
+    def begin(self):
+        k = self.i % len(self.x)
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        return self.x[k]
+
+    def submit(self):
+        k = self.i % len(self.x)
+        self.pending[k] = self.x[k].all_gather_async()
+        self.last = self.x[k]
+        self.i += 1
+
+    def drain(self):
+        for k, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[k] = None
+
+    def completed(self):
+        return self.last
+
+
 class DescriptorExchange:
     """Owns this rank's slab and the gathered buffer; all_gather() is one collective per batch."""
 
@@ -56,6 +94,16 @@ class DescriptorExchange:
         """(counts[frames] int32, desc[frames, cap, 32]) contributed by rank r."""
         s = self.gathered[r * self.slab_bytes:(r + 1) * self.slab_bytes]
         return s[self.desc_bytes:].view(torch.int32), s[: self.desc_bytes].view(self.frames, self.cap, 32)
+
+    def all_gather_async(self):
+        """Start the collective and return its work handle (None when there is nothing to wait for).  With the
+        "nccl" backend the collective runs on the process group's own stream, ordered after everything already
+        queued on the current stream -- so the next batch's kernels overlap it; call `.wait()` on the handle
+        (makes the current stream wait) before the slab or the gathered buffer is touched again."""
+        if self.world == 1 and not dist.is_initialized():
+            self.gathered.copy_(self.slab)
+            return None
+        return dist.all_gather_into_tensor(self.gathered, self.slab, async_op=True)
 
     def query_shard(self):
         """Cross-camera matching is sharded by query frame: global frame ids this rank matches."""

@@ -42,6 +42,22 @@ def _worker(rank, world, port, frames, cap, q):
             ed = rr.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
             gn, gd = xch.unpack(r)
             ok &= np.array_equal(gn.numpy(), en) and np.array_equal(gd.numpy(), ed)
+        # the double-buffered asynchronous form the bench uses: three batches through two slab pairs
+        from orb_slam3_detailed_comments_kor_amd.multicam import PipelinedExchange
+        pipe = PipelinedExchange(frames, cap, torch.device("cpu"), world, rank)
+        for b in range(3):
+            x = pipe.begin()
+            rb = np.random.default_rng(1000 * b + rank)
+            x.count_view().copy_(torch.from_numpy(rb.integers(0, cap, size=frames).astype(np.int32)))
+            x.desc_view().copy_(torch.from_numpy(rb.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)))
+            pipe.submit()
+        pipe.drain()
+        for r in range(world):
+            rb = np.random.default_rng(1000 * 2 + r)
+            en = rb.integers(0, cap, size=frames).astype(np.int32)
+            ed = rb.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
+            gn, gd = pipe.completed().unpack(r)
+            ok &= np.array_equal(gn.numpy(), en) and np.array_equal(gd.numpy(), ed)
         qs = list(xch.query_shard())
         first, count = shard_frames(world * frames, world, rank)
         ok &= qs == list(range(first, first + count))
