@@ -193,6 +193,31 @@ typedef struct {
 /* SearchForTriangulation_ (monocular / rectified pinhole rig).  pairs[2*k], pairs[2*k+1]; returns npairs. */
 int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 */);
 
+/* SearchForTriangulation_ for KannalaBrandt8 cameras (src/ORBmatcher.cc:1208-1449 with the gate
+ * KannalaBrandt8::epipolarConstrain_ = TriangulateMatches_ > 0.0001f, src/CameraModels/KannalaBrandt8.cpp:239-242,
+ * :409-480): a monocular fisheye keyframe pair (Nleft1 == Nleft2 == -1) or a two-camera rig (features [0, Nleft)
+ * from the left camera, the rest from the right one; kp*_xy = mvKeys ++ mvKeysRight; the four relative poses of
+ * :1238-1248 in the order ll, lr, rl, rr, only the first without a rig; R12 row-major).  The gate is a
+ * floating-point triangulation per candidate (Newton unprojection, 4x4 Jacobi SVD as cv::SVD::compute, atan2f /
+ * cosf / sinf projection): its value agrees with the host's to ~1e-6 relative, so a decision can differ from
+ * the reference's only for a candidate that close to one of its thresholds (parity by tolerance, not bit-exact). */
+typedef struct {
+    const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1_xy; const float* angle1;
+    const int32_t* octave1; const float* uRight1 /* or NULL */; orbfe_fv fv1; int Nleft1;
+    const uint8_t* desc2; int n2; const uint8_t* hasMP2; const float* kp2_xy; const float* angle2;
+    const int32_t* octave2; const float* uRight2 /* or NULL */; orbfe_fv fv2; int Nleft2;
+    const float* kb8_1L; const float* kb8_1R; const float* kb8_2L; const float* kb8_2R; /* fx,fy,cx,cy,k0..k3; R: rigs */
+    const float* R12; const float* t12;   /* 4 x 9 and 4 x 3 (1 x 9, 1 x 3 without a rig) */
+    float ep[2];                          /* epipole in image 2 (only read without a rig, :1325-1333) */
+    const float* scaleFactors2; const float* levelSigma2_1; const float* levelSigma2_2; int nlevels1, nlevels2;
+    int only_stereo, coarse, check_orientation;
+} orbfe_tri_kb8_args;
+int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args*, int32_t* pairs /* 2*n1 */);
+/* KannalaBrandt8::TriangulateMatches_ for n explicit keypoint pairs (the gate above; also what
+ * ComputeStereoFishEyeMatches' matchAndtriangulate evaluates per knn match): z1[i] = depth in camera 1 or -1. */
+int orbfe_kb8_triangulate(int device, const float* params1, const float* params2, const float* kp1_xy, const float* kp2_xy,
+                          const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1);
+
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
 

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -1538,6 +1539,266 @@ int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_or
         kept--;
     }
     return kept;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// KannalaBrandt8 gate of SearchForTriangulation_ for fisheye rigs: KannalaBrandt8::epipolarConstrain_
+// (src/CameraModels/KannalaBrandt8.cpp:239-242) = TriangulateMatches_ (:409-480) > 0.0001f, with project
+// (:25-41), unproject (:96-123), Triangulate_ (:514-535) and, inside it, cv::SVD::compute of a 4x4 float
+// matrix.  OpenCV is absent here, so the SVD is restated from its published algorithm (one-sided Jacobi,
+// modules/core/src/lapack.cpp JacobiSVDImpl_<float>, scalar path; eps = 2 FLT_EPSILON; double accumulators):
+// like every OpenCV primitive of this oracle it is unpinned.  cv::Matx arithmetic is float with sequential
+// accumulation (MatxMul, dot), cv::norm accumulates in double, Matx / scalar multiplies by 1.f / scalar.
+namespace {
+
+void kb8_project_pt(const float* P, float x, float y, float z, float* u, float* v)
+{
+    const float x2_plus_y2 = x * x + y * y;
+    const float theta = atan2f(sqrtf(x2_plus_y2), z);
+    const float psi = atan2f(y, x);
+    const float theta2 = theta * theta;
+    const float theta3 = theta * theta2;
+    const float theta5 = theta3 * theta2;
+    const float theta7 = theta5 * theta2;
+    const float theta9 = theta7 * theta2;
+    const float r = theta + P[4] * theta3 + P[5] * theta5 + P[6] * theta7 + P[7] * theta9;
+    // `cos(psi)` on a float with <cmath>: the float overload
+    *u = P[0] * r * cosf(psi) + P[2];
+    *v = P[1] * r * sinf(psi) + P[3];
+}
+
+// rows of vt = right singular vectors, by descending singular value
+void jacobi_svd_vt_4x4(const float A[16], float vt[16])
+{
+    const int m = 4, n = 4;
+    float At[16];
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 4; k++) At[i * 4 + k] = A[k * 4 + i]; // transpose(src, temp_a)
+    double W[4];
+    const float eps = FLT_EPSILON * 2;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) {
+            const float t = At[i * 4 + k];
+            sd += (double)t * t;
+        }
+        W[i] = sd;
+        for (int k = 0; k < n; k++) vt[i * 4 + k] = 0;
+        vt[i * 4 + i] = 1;
+    }
+    const int max_iter = 30; // std::max(m, 30)
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                float *Ai = At + i * 4, *Aj = At + j * 4;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+                if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot((double)p, beta);
+                float c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = (float)std::sqrt(delta / gamma);
+                    c = (float)(p / (gamma * s * 2));
+                } else {
+                    c = (float)std::sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * c * 2));
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    const float t0 = c * Ai[k] + s * Aj[k];
+                    const float t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0;
+                    Aj[k] = t1;
+                    a += (double)t0 * t0;
+                    b += (double)t1 * t1;
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = true;
+                float *Vi = vt + i * 4, *Vj = vt + j * 4;
+                for (int k = 0; k < n; k++) {
+                    const float t0 = c * Vi[k] + s * Vj[k];
+                    const float t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0;
+                    Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) {
+            const float t = At[i * 4 + k];
+            sd += (double)t * t;
+        }
+        W[i] = std::sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            std::swap(W[i], W[j]);
+            for (int k = 0; k < m; k++) std::swap(At[i * 4 + k], At[j * 4 + k]);
+            for (int k = 0; k < n; k++) std::swap(vt[i * 4 + k], vt[j * 4 + k]);
+        }
+    }
+}
+
+void matx33_mul31(const float* R, const float* v, float* out)
+{
+    for (int i = 0; i < 3; i++) {
+        float s = 0;
+        for (int k = 0; k < 3; k++) s += R[i * 3 + k] * v[k];
+        out[i] = s;
+    }
+}
+float matx_dot3(const float* a, const float* b)
+{
+    float s = 0;
+    for (int i = 0; i < 3; i++) s += a[i] * b[i];
+    return s;
+}
+double matx_norm3(const float* a)
+{
+    double s = 0;
+    for (int i = 0; i < 3; i++) {
+        const double v = a[i];
+        s += v * v;
+    }
+    return std::sqrt(s);
+}
+
+} // namespace
+
+float orb_oracle_kb8_triangulate_matches(const float* P1, const float* P2, const float* kp1, const float* kp2,
+                                         const float* R12, const float* t12, float sigmaLevel, float unc, float* p3D)
+{
+    float r1[3], r2[3];
+    orb_oracle_kb8_unproject(P1, kp1, 1, r1);
+    orb_oracle_kb8_unproject(P2, kp2, 1, r2);
+    // Check parallax
+    float r21[3];
+    matx33_mul31(R12, r2, r21);
+    const float cosParallaxRays = (float)(matx_dot3(r1, r21) / (matx_norm3(r1) * matx_norm3(r21)));
+    if (cosParallaxRays > 0.9998) return -1;
+    // Parallax is good, so we try to triangulate
+    const float p11x = r1[0], p11y = r1[1], p22x = r2[0], p22y = r2[1];
+    float Tcw1[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float R21[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R21[i * 3 + j] = R12[j * 3 + i];
+    float nR21[9], t21[3];
+    for (int i = 0; i < 9; i++) nR21[i] = R21[i] * -1.f; // -R21 (Matx unary minus = scale by -1)
+    matx33_mul31(nR21, t12, t21);
+    float Tcw2[16] = {R21[0], R21[1], R21[2], t21[0], R21[3], R21[4], R21[5], t21[1],
+                      R21[6], R21[7], R21[8], t21[2], 0.f, 0.f, 0.f, 1.f};
+    // Triangulate_
+    float A[16];
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = p11x * Tcw1[2 * 4 + k] - Tcw1[0 * 4 + k];
+        A[1 * 4 + k] = p11y * Tcw1[2 * 4 + k] - Tcw1[1 * 4 + k];
+        A[2 * 4 + k] = p22x * Tcw2[2 * 4 + k] - Tcw2[0 * 4 + k];
+        A[3 * 4 + k] = p22y * Tcw2[2 * 4 + k] - Tcw2[1 * 4 + k];
+    }
+    float vt[16];
+    jacobi_svd_vt_4x4(A, vt);
+    const float inv = 1.f / vt[3 * 4 + 3]; // Matx / float
+    const float x3D[3] = {vt[3 * 4 + 0] * inv, vt[3 * 4 + 1] * inv, vt[3 * 4 + 2] * inv};
+    const float z1 = x3D[2];
+    if (z1 <= 0) return -1;
+    const float z2 = matx_dot3(R21 + 6, x3D) + t21[2];
+    if (z2 <= 0) return -1;
+    // Check reprojection error
+    float u1, v1;
+    kb8_project_pt(P1, x3D[0], x3D[1], x3D[2], &u1, &v1);
+    const float errX1 = u1 - kp1[0];
+    const float errY1 = v1 - kp1[1];
+    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -1;
+    float x3D2[3];
+    matx33_mul31(R21, x3D, x3D2);
+    for (int i = 0; i < 3; i++) x3D2[i] = x3D2[i] + t21[i];
+    float u2, v2;
+    kb8_project_pt(P2, x3D2[0], x3D2[1], x3D2[2], &u2, &v2);
+    const float errX2 = u2 - kp2[0];
+    const float errY2 = v2 - kp2[1];
+    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -1;
+    if (p3D) {
+        p3D[0] = x3D[0];
+        p3D[1] = x3D[1];
+        p3D[2] = x3D[2];
+    }
+    return z1;
+}
+
+// SearchForTriangulation_ (src/ORBmatcher.cc:1208-1449) with KannalaBrandt8 cameras: a monocular fisheye
+// keyframe pair (Nleft == -1, one camera each) or a two-camera rig (features [0, Nleft) from the left camera,
+// the rest from the right one, :1293-1297, and the four relative poses ll / lr / rl / rr of :1238-1248).
+int orb_oracle_search_triangulation_kb8(const orb_oracle_tri_kb8_args* a, int32_t* pairs)
+{
+    std::vector<int32_t> vMatches12(a->n1, -1);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const bool rig = a->Nleft1 != -1 && a->Nleft2 != -1; // pKF1->mpCamera2 && pKF2->mpCamera2
+    for_each_shared_node(a->fv1, a->fv2, [&](int na, int nb) {
+        for (int i1 = a->fv1->offsets[na]; i1 < a->fv1->offsets[na + 1]; i1++) {
+            const int idx1 = a->fv1->indices[i1];
+            if (a->hasMP1[idx1]) continue;
+            const bool bStereo1 = !rig && a->uRight1 && a->uRight1[idx1] >= 0; // :1286
+            if (a->only_stereo && !bStereo1) continue;
+            const float* kp1 = a->kp1xy + 2 * idx1;
+            const bool bRight1 = !(a->Nleft1 == -1 || idx1 < a->Nleft1);
+            const uint8_t* d1 = a->desc1 + 32 * (size_t)idx1;
+            int bestDist = TH_LOW;
+            int bestIdx2 = -1;
+            for (int i2 = a->fv2->offsets[nb]; i2 < a->fv2->offsets[nb + 1]; i2++) {
+                const int idx2 = a->fv2->indices[i2];
+                if (a->hasMP2[idx2]) continue;
+                const bool bStereo2 = !rig && a->uRight2 && a->uRight2[idx2] >= 0;
+                if (a->only_stereo && !bStereo2) continue;
+                const int dist = DescriptorDistance(d1, a->desc2 + 32 * (size_t)idx2);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const float* kp2 = a->kp2xy + 2 * idx2;
+                const bool bRight2 = !(a->Nleft2 == -1 || idx2 < a->Nleft2);
+                if (!bStereo1 && !bStereo2 && !rig) {
+                    const float distex = a->ep[0] - kp2[0];
+                    const float distey = a->ep[1] - kp2[1];
+                    if (distex * distex + distey * distey < 100 * a->scaleFactors2[a->oct2[idx2]]) continue;
+                }
+                int sel = 0; // ll
+                const float *P1 = a->kb8_1L, *P2 = a->kb8_2L;
+                if (rig) {
+                    if (bRight1 && bRight2) { sel = 3; P1 = a->kb8_1R; P2 = a->kb8_2R; }
+                    else if (bRight1 && !bRight2) { sel = 2; P1 = a->kb8_1R; P2 = a->kb8_2L; }
+                    else if (!bRight1 && bRight2) { sel = 1; P1 = a->kb8_1L; P2 = a->kb8_2R; }
+                }
+                const bool ok = orb_oracle_kb8_triangulate_matches(P1, P2, kp1, kp2, a->R12 + 9 * sel, a->t12 + 3 * sel,
+                                                                   a->levelSigma2_1[a->oct1[idx1]],
+                                                                   a->levelSigma2_2[a->oct2[idx2]], nullptr) > 0.0001f;
+                if (ok || a->coarse) {
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                }
+            }
+            if (bestIdx2 >= 0) {
+                vMatches12[idx1] = bestIdx2;
+                nmatches++;
+                if (a->check_orientation) rotHist[rot_bin(a->ang1[idx1], a->ang2[bestIdx2])].push_back(idx1);
+            }
+        }
+    });
+    if (a->check_orientation) nmatches = cull_rotation(rotHist, vMatches12.data(), nmatches);
+    int np = 0;
+    for (int i = 0; i < a->n1; i++) {
+        if (vMatches12[i] < 0) continue;
+        pairs[2 * np] = i;
+        pairs[2 * np + 1] = vMatches12[i];
+        np++;
+    }
+    return np;
 }
 
 void orb_oracle_kb8_unproject(const float* P, const float* uv, int n, float* rays)

@@ -110,6 +110,24 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
+/* KannalaBrandt8::TriangulateMatches_ (src/CameraModels/KannalaBrandt8.cpp:409-480): depth of the triangulated
+ * point in camera 1, or -1 (low parallax, behind a camera, reprojection error).  P = fx,fy,cx,cy,k0..k3;
+ * R12 row-major 3x3, t12; p3D may be NULL.  epipolarConstrain_ (:239-242) is `> 0.0001f`. */
+float orb_oracle_kb8_triangulate_matches(const float* P1, const float* P2, const float* kp1xy, const float* kp2xy,
+                                         const float* R12, const float* t12, float sigmaLevel, float unc, float* p3D);
+/* SearchForTriangulation_ with the KannalaBrandt8 gate (fisheye monocular pair or two-camera rig). */
+typedef struct {
+    const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1xy; const float* ang1; const int32_t* oct1;
+    const float* uRight1; const orb_oracle_fv* fv1; int Nleft1;
+    const uint8_t* desc2; int n2; const uint8_t* hasMP2; const float* kp2xy; const float* ang2; const int32_t* oct2;
+    const float* uRight2; const orb_oracle_fv* fv2; int Nleft2;
+    const float* kb8_1L; const float* kb8_1R; const float* kb8_2L; const float* kb8_2R; /* 8 floats each; R: rigs */
+    const float* R12; const float* t12;   /* 4 x 9 and 4 x 3: ll, lr, rl, rr (:1238-1248); only [0] without a rig */
+    float ep[2];
+    const float* scaleFactors2; const float* levelSigma2_1; const float* levelSigma2_2;
+    int only_stereo, coarse, check_orientation;
+} orb_oracle_tri_kb8_args;
+int orb_oracle_search_triangulation_kb8(const orb_oracle_tri_kb8_args* a, int32_t* pairs);
 /* Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197 mode 0, :2193-2419 / :2421-2541
  * mode 1) over flattened inputs; same layout as orbfe_proj_args (include/orbfe.h).  Mode 1 also covers the
  * Sim3 overloads (:473-586, :588-704), and with qblocks all zero (independent queries) Fuse (:1643-1841 with

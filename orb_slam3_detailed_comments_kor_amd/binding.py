@@ -53,6 +53,18 @@ class _TriArgs(C.Structure):
                 ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+class _TriKb8Args(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("hasMP1", C.c_void_p), ("kp1_xy", C.c_void_p),
+                ("angle1", C.c_void_p), ("octave1", C.c_void_p), ("uRight1", C.c_void_p), ("fv1", _FV), ("Nleft1", C.c_int),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("hasMP2", C.c_void_p), ("kp2_xy", C.c_void_p),
+                ("angle2", C.c_void_p), ("octave2", C.c_void_p), ("uRight2", C.c_void_p), ("fv2", _FV), ("Nleft2", C.c_int),
+                ("kb8_1L", C.c_void_p), ("kb8_1R", C.c_void_p), ("kb8_2L", C.c_void_p), ("kb8_2R", C.c_void_p),
+                ("R12", C.c_void_p), ("t12", C.c_void_p), ("ep", C.c_float * 2),
+                ("scaleFactors2", C.c_void_p), ("levelSigma2_1", C.c_void_p), ("levelSigma2_2", C.c_void_p),
+                ("nlevels1", C.c_int), ("nlevels2", C.c_int),
+                ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
+
+
 class _ProjArgs(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p),
                 ("angle", C.c_void_p), ("uright", C.c_void_p), ("taken", C.c_void_p), ("Nleft", C.c_int),
@@ -178,7 +190,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -482,6 +494,49 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
     pairs = np.zeros((max(len(d1), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
     return pairs[:n].copy()
+
+
+def search_triangulation_kb8(I, only_stereo=False, coarse=False, check_ori=True, device=0):
+    """SearchForTriangulation_ with the KannalaBrandt8 gate; I = dict of tests/matcher_inputs.tri_kb8_inputs."""
+    keep = []
+
+    def arr(v, dt, shape=None):
+        if v is None:
+            return None
+        a = np.ascontiguousarray(v, dt)
+        if shape:
+            a = a.reshape(shape)
+        keep.append(a)
+        return a.ctypes.data
+
+    f1, k1 = _fv(I["fv1"])
+    f2, k2 = _fv(I["fv2"])
+    sf = np.ascontiguousarray(I["sf"], np.float32)
+    s1 = np.ascontiguousarray(I["sig1"], np.float32)
+    s2 = np.ascontiguousarray(I["sig2"], np.float32)
+    a = _TriKb8Args(arr(I["d1"], np.uint8), len(I["d1"]), arr(I["has1"], np.uint8), arr(I["kp1"], np.float32),
+                    arr(I["a1"], np.float32), arr(I["oct1"], np.int32), arr(I.get("u1"), np.float32), f1, int(I["Nleft1"]),
+                    arr(I["d2"], np.uint8), len(I["d2"]), arr(I["has2"], np.uint8), arr(I["kp2"], np.float32),
+                    arr(I["a2"], np.float32), arr(I["oct2"], np.int32), arr(I.get("u2"), np.float32), f2, int(I["Nleft2"]),
+                    arr(I["P1L"], np.float32), arr(I.get("P1R"), np.float32), arr(I["P2L"], np.float32),
+                    arr(I.get("P2R"), np.float32), arr(I["R12"], np.float32), arr(I["t12"], np.float32),
+                    (C.c_float * 2)(float(I["ep"][0]), float(I["ep"][1])), sf.ctypes.data, s1.ctypes.data, s2.ctypes.data,
+                    len(s1), len(s2), int(only_stereo), int(coarse), int(check_ori))
+    pairs = np.zeros((max(len(I["d1"]), 1), 2), np.int32)
+    n = _chk(lib().orbfe_search_tri_kb8(device, C.byref(a), _p(pairs)), "orbfe_search_tri_kb8")
+    return pairs[:n].copy()
+
+
+def kb8_triangulate(P1, P2, kp1, kp2, R12, t12, sigma1, sigma2, device=0):
+    """KannalaBrandt8::TriangulateMatches_ for explicit pairs: z1 (depth in camera 1) or -1."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    n = len(kp1)
+    A = [np.ascontiguousarray(v, np.float32) for v in (P1, P2, R12, t12, sigma1, sigma2)]
+    z = np.zeros(max(n, 1), np.float32)
+    _chk(lib().orbfe_kb8_triangulate(device, _p(A[0]), _p(A[1]), _p(kp1), _p(kp2), _p(A[2]), _p(A[3]), _p(A[4]), _p(A[5]), n,
+                                     _p(z)), "orbfe_kb8_triangulate")
+    return z[:n]
 
 
 def search_projection(problem, device=0):

@@ -37,4 +37,173 @@ __device__ __forceinline__ void orbfe_kb8_unproject_dev(const float* __restrict_
     ray[1] = __fmul_rn(pwy, scale);
     ray[2] = 1.f;
 }
+
+#ifdef ORBFE_SINCOS_H
+/* KannalaBrandt8::project (KannalaBrandt8.cpp:25-41).  atan2f through double atan2 and cosf/sinf through the
+ * correctly rounded routine: the host's libm values are within 1 ulp of these. */
+__device__ __forceinline__ void orbfe_kb8_project_dev(const float* __restrict__ P, float x, float y, float z, float* u,
+                                                      float* v)
+{
+    const float x2y2 = __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
+    const float theta = (float)atan2((double)(float)__dsqrt_rn((double)x2y2), (double)z);
+    const float psi = (float)atan2((double)y, (double)x);
+    const float t2 = __fmul_rn(theta, theta), t3 = __fmul_rn(theta, t2), t5 = __fmul_rn(t3, t2), t7 = __fmul_rn(t5, t2),
+                t9 = __fmul_rn(t7, t2);
+    const float r = __fadd_rn(
+        __fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(P[4], t3)), __fmul_rn(P[5], t5)), __fmul_rn(P[6], t7)),
+        __fmul_rn(P[7], t9));
+    float sn, cs;
+    orbfe_sincos_cr(psi, &sn, &cs);
+    *u = __fadd_rn(__fmul_rn(__fmul_rn(P[0], r), cs), P[2]);
+    *v = __fadd_rn(__fmul_rn(__fmul_rn(P[1], r), sn), P[3]);
+}
+
+/* cv::SVD::compute on a 4x4 float matrix as Triangulate_ uses it (KannalaBrandt8.cpp:514-535): one-sided Jacobi
+ * (OpenCV modules/core/src/lapack.cpp, JacobiSVDImpl_<float>), returns the right singular vector of the
+ * smallest singular value (row 3 of vt).  Same operation order as the oracle's restatement; sqrt / hypot in
+ * double. */
+__device__ inline void orbfe_svd4_last_vt(const float* A, float* h)
+{
+    float At[16], Vt[16];
+    double W[4];
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 4; k++) At[i * 4 + k] = A[k * 4 + i];
+    const float eps = 2.384185791015625e-07f; // FLT_EPSILON * 2
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+        for (int k = 0; k < 4; k++) sd = __dadd_rn(sd, __dmul_rn((double)At[i * 4 + k], (double)At[i * 4 + k]));
+        W[i] = sd;
+        for (int k = 0; k < 4; k++) Vt[i * 4 + k] = (i == k) ? 1.f : 0.f;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int i = 0; i < 3; i++)
+            for (int j = i + 1; j < 4; j++) {
+                float *Ai = At + i * 4, *Aj = At + j * 4;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < 4; k++) p = __dadd_rn(p, __dmul_rn((double)Ai[k], (double)Aj[k]));
+                if (fabs(p) <= __dmul_rn((double)eps, __dsqrt_rn(__dmul_rn(a, b)))) continue;
+                p = __dmul_rn(p, 2.0);
+                const double beta = __dadd_rn(a, -b), gamma = hypot(p, beta);
+                float c, s;
+                if (beta < 0) {
+                    const double delta = __dmul_rn(__dadd_rn(gamma, -beta), 0.5);
+                    s = (float)__dsqrt_rn(__ddiv_rn(delta, gamma));
+                    c = (float)__ddiv_rn(p, __dmul_rn(__dmul_rn(gamma, (double)s), 2.0));
+                } else {
+                    c = (float)__dsqrt_rn(__ddiv_rn(__dadd_rn(gamma, beta), __dmul_rn(gamma, 2.0)));
+                    s = (float)__ddiv_rn(p, __dmul_rn(__dmul_rn(gamma, (double)c), 2.0));
+                }
+                a = b = 0;
+                for (int k = 0; k < 4; k++) {
+                    const float t0 = __fadd_rn(__fmul_rn(c, Ai[k]), __fmul_rn(s, Aj[k]));
+                    const float t1 = __fadd_rn(__fmul_rn(-s, Ai[k]), __fmul_rn(c, Aj[k]));
+                    Ai[k] = t0;
+                    Aj[k] = t1;
+                    a = __dadd_rn(a, __dmul_rn((double)t0, (double)t0));
+                    b = __dadd_rn(b, __dmul_rn((double)t1, (double)t1));
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = true;
+                float *Vi = Vt + i * 4, *Vj = Vt + j * 4;
+                for (int k = 0; k < 4; k++) {
+                    const float t0 = __fadd_rn(__fmul_rn(c, Vi[k]), __fmul_rn(s, Vj[k]));
+                    const float t1 = __fadd_rn(__fmul_rn(-s, Vi[k]), __fmul_rn(c, Vj[k]));
+                    Vi[k] = t0;
+                    Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+        for (int k = 0; k < 4; k++) sd = __dadd_rn(sd, __dmul_rn((double)At[i * 4 + k], (double)At[i * 4 + k]));
+        W[i] = __dsqrt_rn(sd);
+    }
+    // the descending selection sort of the reference moves the row with the least W to position 3: simulate it
+    int perm[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 3; i++) {
+        int j = i;
+        for (int k = i + 1; k < 4; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            const double tw = W[i];
+            W[i] = W[j];
+            W[j] = tw;
+            const int tp = perm[i];
+            perm[i] = perm[j];
+            perm[j] = tp;
+        }
+    }
+    for (int k = 0; k < 4; k++) h[k] = Vt[perm[3] * 4 + k];
+}
+
+/* KannalaBrandt8::TriangulateMatches_ (KannalaBrandt8.cpp:409-480): z1 of the triangulated point or -1. */
+__device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, const float* __restrict__ P2, float k1x,
+                                                  float k1y, float k2x, float k2y, const float* __restrict__ R12,
+                                                  const float* __restrict__ t12, float sigmaLevel, float unc)
+{
+    float r1[3], r2[3], r21[3];
+    orbfe_kb8_unproject_dev(P1, k1x, k1y, r1);
+    orbfe_kb8_unproject_dev(P2, k2x, k2y, r2);
+    for (int i = 0; i < 3; i++) {
+        float s = 0.f;
+        for (int k = 0; k < 3; k++) s = __fadd_rn(s, __fmul_rn(R12[i * 3 + k], r2[k]));
+        r21[i] = s;
+    }
+    float dot = 0.f;
+    double n1 = 0, n2 = 0;
+    for (int i = 0; i < 3; i++) {
+        dot = __fadd_rn(dot, __fmul_rn(r1[i], r21[i]));
+        n1 = __dadd_rn(n1, __dmul_rn((double)r1[i], (double)r1[i]));
+        n2 = __dadd_rn(n2, __dmul_rn((double)r21[i], (double)r21[i]));
+    }
+    const float cosParallax = (float)__ddiv_rn((double)dot, __dmul_rn(__dsqrt_rn(n1), __dsqrt_rn(n2)));
+    if ((double)cosParallax > 0.9998) return -1.f;
+    float R21[9], t21[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R21[i * 3 + j] = R12[j * 3 + i];
+    for (int i = 0; i < 3; i++) {
+        float s = 0.f;
+        for (int k = 0; k < 3; k++) s = __fadd_rn(s, __fmul_rn(__fmul_rn(R21[i * 3 + k], -1.f), t12[k]));
+        t21[i] = s;
+    }
+    // rows of A = p.x * T.row(2) - T.row(0), p.y * T.row(2) - T.row(1) with Tcw1 = [I | 0] (last row zero)
+    float A[16];
+    const float T1[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    const float T2[12] = {R21[0], R21[1], R21[2], t21[0], R21[3], R21[4], R21[5], t21[1], R21[6], R21[7], R21[8], t21[2]};
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = __fsub_rn(__fmul_rn(r1[0], T1[8 + k]), T1[k]);
+        A[1 * 4 + k] = __fsub_rn(__fmul_rn(r1[1], T1[8 + k]), T1[4 + k]);
+        A[2 * 4 + k] = __fsub_rn(__fmul_rn(r2[0], T2[8 + k]), T2[k]);
+        A[3 * 4 + k] = __fsub_rn(__fmul_rn(r2[1], T2[8 + k]), T2[4 + k]);
+    }
+    float h[4];
+    orbfe_svd4_last_vt(A, h);
+    const float inv = __fdiv_rn(1.f, h[3]);
+    const float X[3] = {__fmul_rn(h[0], inv), __fmul_rn(h[1], inv), __fmul_rn(h[2], inv)};
+    const float z1 = X[2];
+    if (!(z1 > 0.f)) return -1.f; // also NaN
+    float z2 = 0.f;
+    for (int k = 0; k < 3; k++) z2 = __fadd_rn(z2, __fmul_rn(R21[6 + k], X[k]));
+    z2 = __fadd_rn(z2, t21[2]);
+    if (!(z2 > 0.f)) return -1.f;
+    float u1, v1;
+    orbfe_kb8_project_dev(P1, X[0], X[1], X[2], &u1, &v1);
+    const float ex1 = __fsub_rn(u1, k1x), ey1 = __fsub_rn(v1, k1y);
+    if ((double)__fadd_rn(__fmul_rn(ex1, ex1), __fmul_rn(ey1, ey1)) > __dmul_rn(5.991, (double)sigmaLevel)) return -1.f;
+    float X2[3];
+    for (int i = 0; i < 3; i++) {
+        float s = 0.f;
+        for (int k = 0; k < 3; k++) s = __fadd_rn(s, __fmul_rn(R21[i * 3 + k], X[k]));
+        X2[i] = __fadd_rn(s, t21[i]);
+    }
+    float u2, v2;
+    orbfe_kb8_project_dev(P2, X2[0], X2[1], X2[2], &u2, &v2);
+    const float ex2 = __fsub_rn(u2, k2x), ey2 = __fsub_rn(v2, k2y);
+    if ((double)__fadd_rn(__fmul_rn(ex2, ex2), __fmul_rn(ey2, ey2)) > __dmul_rn(5.991, (double)unc)) return -1.f;
+    return z1;
+}
+#endif /* ORBFE_SINCOS_H */
 #endif

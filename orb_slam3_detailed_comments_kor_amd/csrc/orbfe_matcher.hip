@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/orbfe.h"
+#include "orbfe_sincos.h"
 #include "orbfe_kb8.h"
 
 #define HIP_TRY(expr)                                   \
@@ -336,6 +337,79 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     }
     best = wave_min_u32(best);
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+}
+
+// K-TRI with the KannalaBrandt8 gate (fisheye monocular pairs and two-camera rigs): same row / candidate
+// structure as k_search_tri; the gate of a candidate is KannalaBrandt8::epipolarConstrain_ = a full
+// triangulation (unproject x2, 4x4 Jacobi SVD, project x2) per lane.  Float-library functions (atan2f,
+// tanf, cosf, sinf, hypot) are evaluated through double on the device, so gate values agree with the host to
+// ~1e-6 relative and decisions can differ only within that distance of a threshold.
+struct TriKb8Dev {
+    const TriRow* rows;
+    int nRows;
+    const uint8_t *desc1, *desc2, *hasMP2;
+    const float *kp1, *kp2, *uR1, *uR2;
+    const int32_t *oct1, *oct2, *ind2;
+    int Nleft1, Nleft2, rig;
+    float P[4][8];   // 1L, 1R, 2L, 2R
+    float R12[4][9]; // ll, lr, rl, rr
+    float t12[4][3];
+    float epx, epy;
+    const float *sf2, *sig1, *sig2;
+    int onlyStereo, coarse;
+    int32_t* match12;
+};
+__global__ __launch_bounds__(256) void k_search_tri_kb8(TriKb8Dev T)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rix = blockIdx.x * 4 + wave;
+    if (rix >= T.nRows) return;
+    const TriRow R = T.rows[rix];
+    const int idx1 = R.idx1;
+    const Desc d1 = load_desc(T.desc1 + (size_t)idx1 * 32);
+    const float k1x = T.kp1[2 * idx1], k1y = T.kp1[2 * idx1 + 1];
+    const bool bStereo1 = !T.rig && T.uR1 && T.uR1[idx1] >= 0;
+    const bool bRight1 = !(T.Nleft1 == -1 || idx1 < T.Nleft1);
+    const float sigma1 = T.sig1[T.oct1[idx1]];
+    unsigned best = 0xFFFFFFFFu;
+    for (int c = lane; c < R.n2; c += 64) {
+        const int idx2 = T.ind2[R.off2 + c];
+        if (T.hasMP2[idx2]) continue;
+        const bool bStereo2 = !T.rig && T.uR2 && T.uR2[idx2] >= 0;
+        if (T.onlyStereo && !bStereo2) continue;
+        const int dist = hamming(d1, load_desc(T.desc2 + (size_t)idx2 * 32));
+        if (dist > TH_LOW) continue;
+        const float k2x = T.kp2[2 * idx2], k2y = T.kp2[2 * idx2 + 1];
+        const int o2 = T.oct2[idx2];
+        if (!bStereo1 && !bStereo2 && !T.rig) {
+            const float ex = __fsub_rn(T.epx, k2x), ey = __fsub_rn(T.epy, k2y);
+            if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.f, T.sf2[o2])) continue;
+        }
+        bool ok = T.coarse != 0;
+        if (!ok) {
+            const bool bRight2 = !(T.Nleft2 == -1 || idx2 < T.Nleft2);
+            const int sel = T.rig ? (bRight1 ? 2 : 0) + (bRight2 ? 1 : 0) : 0; // ll, lr, rl, rr (:1342-1370)
+            const float* P1 = T.P[(T.rig && bRight1) ? 1 : 0];
+            const float* P2 = T.P[(T.rig && bRight2) ? 3 : 2];
+            ok = orbfe_kb8_triangulate_dev(P1, P2, k1x, k1y, k2x, k2y, T.R12[sel], T.t12[sel], sigma1, T.sig2[o2]) > 0.0001f;
+        }
+        if (!ok) continue;
+        best = min(best, ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c)); // smallest dist, then last position
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) T.match12[idx1] = best == 0xFFFFFFFFu ? -1 : T.ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+}
+// test hook: the gate value (z1 or -1) of explicit pairs
+__global__ __launch_bounds__(256) void k_kb8_triangulate(const float* __restrict__ P1, const float* __restrict__ P2,
+                                                         const float* __restrict__ kp1, const float* __restrict__ kp2,
+                                                         const float* __restrict__ R12, const float* __restrict__ t12,
+                                                         const float* __restrict__ sigma1, const float* __restrict__ sigma2,
+                                                         int n, float* __restrict__ z1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    z1[i] = orbfe_kb8_triangulate_dev(P1, P2, kp1[2 * i], kp1[2 * i + 1], kp2[2 * i], kp2[2 * i + 1], R12, t12, sigma1[i],
+                                      sigma2[i]);
 }
 
 // ------------------------------------------------------------------ K-PROJ
@@ -1150,6 +1224,127 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
         np++;
     }
     return np;
+}
+
+int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs)
+{
+    if (!a || !pairs || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
+    if (a->n1 == 0 || a->n2 == 0) return 0;
+    if (!a->desc1 || !a->desc2 || !a->hasMP1 || !a->hasMP2 || !a->kp1_xy || !a->kp2_xy || !a->octave1 || !a->octave2 ||
+        !a->scaleFactors2 || !a->levelSigma2_1 || !a->levelSigma2_2 || a->nlevels1 < 1 || a->nlevels2 < 1 || !a->kb8_1L ||
+        !a->kb8_2L || !a->R12 || !a->t12)
+        return ORBFE_ERR_ARGS;
+    const bool rig = a->Nleft1 != -1 && a->Nleft2 != -1;
+    if ((a->Nleft1 == -1) != (a->Nleft2 == -1)) return ORBFE_ERR_ARGS; // the reference dereferences both second cameras
+    if (rig && (!a->kb8_1R || !a->kb8_2R || a->Nleft1 < 0 || a->Nleft1 > a->n1 || a->Nleft2 < 0 || a->Nleft2 > a->n2))
+        return ORBFE_ERR_ARGS;
+    if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < a->n1; i++)
+        if (a->octave1[i] < 0 || a->octave1[i] >= a->nlevels1) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < a->n2; i++)
+        if (a->octave2[i] < 0 || a->octave2[i] >= a->nlevels2) return ORBFE_ERR_ARGS;
+    std::vector<TriRow> rows;
+    for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
+        const int off2 = a->fv2.offsets[j], n2 = a->fv2.offsets[j + 1] - off2;
+        for (int k = a->fv1.offsets[i]; k < a->fv1.offsets[i + 1]; k++) {
+            const int idx1 = a->fv1.indices[k];
+            if (a->hasMP1[idx1]) continue;
+            const bool bStereo1 = !rig && a->uRight1 && a->uRight1[idx1] >= 0;
+            if (a->only_stereo && !bStereo1) continue;
+            if (n2 > 0) rows.push_back(TriRow{idx1, off2, n2});
+        }
+    });
+    if (rows.empty()) return 0;
+    for (const TriRow& t : rows)
+        if (t.n2 >= (1 << 20)) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    TriKb8Dev T{};
+    TriRow* dR;
+    uint8_t *d1, *d2, *h2;
+    float *k1, *k2, *u1 = nullptr, *u2 = nullptr, *sf, *sg1, *sg2;
+    int32_t *o1, *o2, *i2, *dM;
+    if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
+    if ((r = s.up(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
+    if ((r = s.up(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
+    if ((r = s.up(&h2, a->hasMP2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&k1, a->kp1_xy, (size_t)a->n1 * 2)) < 0) return r;
+    if ((r = s.up(&k2, a->kp2_xy, (size_t)a->n2 * 2)) < 0) return r;
+    if (a->uRight1 && (r = s.up(&u1, a->uRight1, (size_t)a->n1)) < 0) return r;
+    if (a->uRight2 && (r = s.up(&u2, a->uRight2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&sf, a->scaleFactors2, (size_t)a->nlevels2)) < 0) return r;
+    if ((r = s.up(&sg1, a->levelSigma2_1, (size_t)a->nlevels1)) < 0) return r;
+    if ((r = s.up(&sg2, a->levelSigma2_2, (size_t)a->nlevels2)) < 0) return r;
+    if ((r = s.up(&o1, a->octave1, (size_t)a->n1)) < 0) return r;
+    if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
+    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), 0));
+    T.rows = dR; T.nRows = (int)rows.size(); T.desc1 = d1; T.desc2 = d2; T.hasMP2 = h2; T.kp1 = k1; T.kp2 = k2;
+    T.uR1 = u1; T.uR2 = u2; T.oct1 = o1; T.oct2 = o2; T.ind2 = i2; T.Nleft1 = a->Nleft1; T.Nleft2 = a->Nleft2;
+    T.rig = rig ? 1 : 0;
+    const float* Ps[4] = {a->kb8_1L, rig ? a->kb8_1R : a->kb8_1L, a->kb8_2L, rig ? a->kb8_2R : a->kb8_2L};
+    for (int c = 0; c < 4; c++) std::memcpy(T.P[c], Ps[c], 8 * sizeof(float));
+    const int nposes = rig ? 4 : 1;
+    for (int c = 0; c < 4; c++) {
+        std::memcpy(T.R12[c], a->R12 + 9 * (c < nposes ? c : 0), 9 * sizeof(float));
+        std::memcpy(T.t12[c], a->t12 + 3 * (c < nposes ? c : 0), 3 * sizeof(float));
+    }
+    T.epx = a->ep[0]; T.epy = a->ep[1]; T.sf2 = sf; T.sig1 = sg1; T.sig2 = sg2;
+    T.onlyStereo = a->only_stereo; T.coarse = a->coarse; T.match12 = dM;
+    {
+        KernelTimer timer;
+        hipLaunchKernelGGL(k_search_tri_kb8, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, T);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> m12(a->n1);
+    HIP_TRY(hipMemcpy(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int8_t> bins(a->n1, -1);
+    if (a->check_orientation) {
+        for (int i = 0; i < a->n1; i++)
+            if (m12[i] >= 0) {
+                float rot = a->angle1[i] - a->angle2[m12[i]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[i] = (int8_t)bin;
+            }
+    }
+    cull_by_rotation(m12.data(), bins.data(), a->n1, a->check_orientation != 0);
+    int np = 0;
+    for (int i = 0; i < a->n1; i++) {
+        if (m12[i] < 0) continue;
+        pairs[2 * np] = i;
+        pairs[2 * np + 1] = m12[i];
+        np++;
+    }
+    return np;
+}
+
+int orbfe_kb8_triangulate(int device, const float* params1, const float* params2, const float* kp1_xy, const float* kp2_xy,
+                          const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1)
+{
+    if (!params1 || !params2 || !kp1_xy || !kp2_xy || !R12 || !t12 || !sigma1 || !sigma2 || !z1 || n < 0) return ORBFE_ERR_ARGS;
+    if (n == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    float *dP1, *dP2, *dK1, *dK2, *dR, *dT, *dS1, *dS2, *dZ;
+    if ((r = s.up(&dP1, params1, 8)) < 0) return r;
+    if ((r = s.up(&dP2, params2, 8)) < 0) return r;
+    if ((r = s.up(&dK1, kp1_xy, (size_t)2 * n)) < 0) return r;
+    if ((r = s.up(&dK2, kp2_xy, (size_t)2 * n)) < 0) return r;
+    if ((r = s.up(&dR, R12, 9)) < 0) return r;
+    if ((r = s.up(&dT, t12, 3)) < 0) return r;
+    if ((r = s.up(&dS1, sigma1, (size_t)n)) < 0) return r;
+    if ((r = s.up(&dS2, sigma2, (size_t)n)) < 0) return r;
+    if ((r = s.up<float>(&dZ, nullptr, (size_t)n)) < 0) return r;
+    hipLaunchKernelGGL(k_kb8_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP1, dP2, dK1, dK2, dR, dT, dS1,
+                       dS2, n, dZ);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(z1, dZ, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)

@@ -60,6 +60,105 @@ def tri_inputs(n1, n2, seed):
                 has1=has1, has2=has2, F12=F12, sf=sf, sig=sig, ep=ep)
 
 
+KB8_TUMVI = np.array([190.978477, 190.973307, 254.931706, 256.897442, 0.003482389, 0.000715034, -0.002053236,
+                      0.000202937], np.float32)  # Examples/Stereo-Inertial/TUM_512.yaml:9-30
+
+
+def kb8_project64(P, X):
+    """KannalaBrandt8::project in float64 (data generation only)."""
+    P = np.asarray(P, np.float64)
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    th = np.arctan2(np.sqrt(x * x + y * y), z)
+    psi = np.arctan2(y, x)
+    r = th + P[4] * th ** 3 + P[5] * th ** 5 + P[6] * th ** 7 + P[7] * th ** 9
+    return np.stack([P[0] * r * np.cos(psi) + P[2], P[1] * r * np.sin(psi) + P[3]], 1)
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def kb8_pairs(seed, n=4000):
+    """Keypoint pairs for TriangulateMatches_: true correspondences of 3-D points seen by two fisheye cameras
+    (a few pixels of noise, so the reprojection tests bite), random pairs, and low-parallax pairs."""
+    rng = np.random.default_rng(seed)
+    P1 = KB8_TUMVI.copy()
+    P2 = (KB8_TUMVI * np.float32(1.0) + np.array([0.7, -0.4, 1.3, -2.1, 0, 0, 0, 0], np.float32)).astype(np.float32)
+    R12 = _rot(0.03, -0.05, 0.02)
+    t12 = np.array([0.25, -0.03, 0.06])
+    X1 = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(0.6, 12, n)], 1)
+    far = rng.random(n) < 0.15
+    X1[far] *= 60.0                                   # distant points: parallax below the 0.9998 gate
+    X2 = (R12.T @ (X1 - t12).T).T                     # x1 = R12 x2 + t12
+    kp1 = kb8_project64(P1, X1) + rng.normal(0, 0.4, (n, 2))
+    noise = np.where(rng.random(n)[:, None] < 0.3, rng.normal(0, 3.0, (n, 2)), rng.normal(0, 0.5, (n, 2)))
+    kp2 = kb8_project64(P2, X2) + noise
+    rnd = rng.random(n) < 0.2
+    kp2[rnd] = np.stack([rng.uniform(40, 470, rnd.sum()), rng.uniform(40, 470, rnd.sum())], 1)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    sig = (sf * sf).astype(np.float32)
+    o1, o2 = rng.integers(0, 8, n), rng.integers(0, 8, n)
+    return dict(P1=P1, P2=P2, R12=R12.astype(np.float32), t12=t12.astype(np.float32), kp1=kp1.astype(np.float32),
+                kp2=kp2.astype(np.float32), sigma1=sig[o1], sigma2=sig[o2], X1=X1)
+
+
+def tri_kb8_inputs(n1, n2, seed, rig=False):
+    """SearchForTriangulation_ inputs for fisheye keyframes: descriptors / FeatureVectors as tri_inputs, keypoints
+    from a common 3-D scene so that true correspondences pass the triangulation gate."""
+    rng = np.random.default_rng(seed)
+    d1, d2, a1, a2 = descriptor_sets(n1, n2, seed, flip=12)
+    # recover which rows of set 2 are noisy copies of rows of set 1: nearest by Hamming distance
+    lut = np.array([bin(v).count("1") for v in range(256)], np.uint8)
+    D = lut[d1[:, None, :] ^ d2[None, :, :]].sum(2, dtype=np.int32)
+    fv1, fv2 = feature_vectors(d1, d2, seed + 1, 5, 2)
+    P1L = KB8_TUMVI.copy()
+    P1R = (KB8_TUMVI + np.array([0.5, 0.3, -1.1, 0.8, 0, 0, 0, 0], np.float32)).astype(np.float32)
+    P2L, P2R = P1L.copy(), P1R.copy()
+    Nleft1 = n1 * 3 // 5 if rig else -1
+    Nleft2 = n2 * 3 // 5 if rig else -1
+    # poses: x_{1,cam} = R x_{2,cam} + t for the four camera combinations
+    Rll, tll = _rot(0.02, -0.04, 0.01), np.array([0.22, -0.02, 0.05])
+    Rlr_rig, tlr_rig = _rot(0.0, 0.06, 0.0), np.array([0.10, 0.0, 0.0])   # right camera of a rig w.r.t. its left one
+    def compose(Ra, ta, Rb, tb):  # x_a = Ra x_b + ta, x_b = Rb x_c + tb -> x_a = Ra Rb x_c + Ra tb + ta
+        return Ra @ Rb, Ra @ tb + ta
+    # left1 <- left2: (Rll, tll); left1 <- right2: left2 <- right2 composed; right1 <- *: invert rig transform first
+    Rrl_inv, trl_inv = Rlr_rig.T, -Rlr_rig.T @ tlr_rig                        # x_right = R^T x_left - R^T t
+    R_lr, t_lr = compose(Rll, tll, Rlr_rig, tlr_rig)
+    R_rl, t_rl = compose(Rrl_inv, trl_inv, Rll, tll)
+    R_rr, t_rr = compose(R_rl, t_rl, Rlr_rig, tlr_rig)
+    Rs = np.stack([Rll, R_lr, R_rl, R_rr]).astype(np.float32)
+    ts = np.stack([tll, t_lr, t_rl, t_rr]).astype(np.float32)
+    # scene points in the frame of camera 1-left; feature i of set 1 sees point i, feature j of set 2 sees the point
+    # of its nearest descriptor in set 1 (so descriptor matches are geometric matches) or a random point
+    X = np.stack([rng.uniform(-4, 4, n1), rng.uniform(-3, 3, n1), rng.uniform(0.8, 10, n1)], 1)
+    src = D.argmin(0)
+    good = D.min(0) < 60
+    Xs2 = np.where(good[:, None], X[src], np.stack([rng.uniform(-4, 4, n2), rng.uniform(-3, 3, n2), rng.uniform(0.8, 10, n2)], 1))
+    def to_cam1(Xl, right):   # camera-1-left frame -> camera-1-left / right frame
+        return np.where(right[:, None], (Rrl_inv @ Xl.T).T + trl_inv, Xl)
+    def to_cam2(Xl, right):   # camera-1-left frame -> camera-2-left / right frame
+        X2l = (Rll.T @ (Xl - tll).T).T
+        return np.where(right[:, None], (Rrl_inv @ X2l.T).T + trl_inv, X2l)
+    right1 = (np.arange(n1) >= Nleft1) if rig else np.zeros(n1, bool)
+    right2 = (np.arange(n2) >= Nleft2) if rig else np.zeros(n2, bool)
+    Xc1, Xc2 = to_cam1(X, right1), to_cam2(Xs2, right2)
+    kp1 = np.where(right1[:, None], kb8_project64(P1R, Xc1), kb8_project64(P1L, Xc1)) + rng.normal(0, 0.3, (n1, 2))
+    kp2 = np.where(right2[:, None], kb8_project64(P2R, Xc2), kb8_project64(P2L, Xc2)) + rng.normal(0, 0.5, (n2, 2))
+    oct1 = rng.integers(0, 8, n1).astype(np.int32)
+    oct2 = rng.integers(0, 8, n2).astype(np.int32)
+    has1 = (rng.uniform(size=n1) < 0.3).astype(np.uint8)
+    has2 = (rng.uniform(size=n2) < 0.3).astype(np.uint8)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    sig = (sf * sf).astype(np.float32)
+    return dict(d1=d1, d2=d2, a1=a1, a2=a2, fv1=fv1, fv2=fv2, kp1=kp1.astype(np.float32), kp2=kp2.astype(np.float32),
+                oct1=oct1, oct2=oct2, has1=has1, has2=has2, Nleft1=Nleft1, Nleft2=Nleft2, P1L=P1L, P1R=P1R, P2L=P2L,
+                P2R=P2R, R12=Rs if rig else Rs[:1], t12=ts if rig else ts[:1], ep=(300.0, 250.0), sf=sf, sig1=sig, sig2=sig)
+
+
 def projection_problem(seed, n=1200, nq=900, mode=0, stereo=False, Nleft=-1, th=1.0, nnratio=0.8, taken_frac=0.1,
                        crowd=True, check_orientation=False, partners=False, blocks=None, w=752, h=480, loop=None):
     """Flattened SearchByProjection problem (fields of orbfe_proj_args).  Queries are map points that project

@@ -254,3 +254,40 @@ def test_search_projection_errors(pkg):
     pr = projection_problem(1, n=50, nq=0)
     n, q, f = pkg.search_projection(pr)
     assert n == 0 and len(q) == 0 and (f == -1).all()
+
+
+def test_kb8_triangulate_gate(pkg, oracle):
+    """KannalaBrandt8::TriangulateMatches_ (the fisheye gate of SearchForTriangulation_): parity by tolerance.  The
+    device evaluates atan2f / tanf / cosf / sinf / hypot through double, the oracle calls host libm: depths agree to
+    2e-5 relative and the accept / reject decision is identical wherever no test of the gate is close to its threshold
+    (cos parallax within 2e-6, depth sign within 1e-4 of the scene scale, reprojection error within 0.1 %; margins from
+    the float64 evaluation of tests/test_oracle_matcher.py)."""
+    from matcher_inputs import kb8_pairs
+    from test_oracle_matcher import kb8_triangulate_f64
+    G = kb8_pairs(42, 3000)
+    z_ref, _ = oracle.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
+    z = pkg.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
+    _, margin = kb8_triangulate_f64(G)
+    clear = (margin[:, 0] > 2e-6) & (margin[:, 1] > 1e-4) & (margin[:, 2] > 1e-3)
+    acc, acc_ref = z > 1e-4, z_ref > 1e-4
+    assert clear.sum() > 2900 and acc_ref.sum() > 1000 and (~acc_ref).sum() > 500
+    assert np.array_equal(acc[clear], acc_ref[clear])
+    both = acc & acc_ref
+    assert np.allclose(z[both], z_ref[both], rtol=2e-5)
+    assert (acc != acc_ref).sum() <= 2  # borderline candidates are rare
+
+
+@pytest.mark.parametrize("rig,seed", [(False, 61), (False, 62), (True, 63), (True, 64)])
+@pytest.mark.parametrize("coarse", [False, True])
+def test_search_for_triangulation_kb8(pkg, oracle, rig, seed, coarse):
+    """SearchForTriangulation_ with the KannalaBrandt8 gate: monocular fisheye pair and two-camera rig (the four
+    relative poses ll / lr / rl / rr).  Identical pairs to the oracle on these seeds (no candidate of theirs sits
+    within rounding distance of a gate threshold; parity of the gate itself is by tolerance, see above)."""
+    from matcher_inputs import tri_kb8_inputs
+    I = tri_kb8_inputs(1100, 1000, seed, rig=rig)
+    got = pkg.search_triangulation_kb8(I, coarse=coarse)
+    ref = oracle.search_triangulation_kb8(I, coarse=coarse)
+    assert len(ref) > 50
+    assert np.array_equal(got, ref)
+    if not coarse:
+        assert len(ref) < len(oracle.search_triangulation_kb8(I, coarse=True))  # the gate rejected something

@@ -239,3 +239,103 @@ def test_search_projection_against_bruteforce_spec(oracle, case):
     assert np.array_equal(q_got, q_ref)
     assert np.array_equal(f_got, f_ref)
     assert n_got == n_ref
+
+
+# ---------------------------------------------------------------- KannalaBrandt8 triangulation gate
+def kb8_triangulate_f64(G):
+    """TriangulateMatches_ (KannalaBrandt8.cpp:409-480) in float64 with LAPACK's SVD: (z1 or -1, margins[n,3]) with
+    how far the evaluated tests are from their thresholds: |cos - 0.9998|, min |z| / |X|, min |e - th| / th
+    (inf where a test was not reached)."""
+    from matcher_inputs import kb8_project64
+    P1, P2 = G["P1"].astype(np.float64), G["P2"].astype(np.float64)
+    R12, t12 = G["R12"].astype(np.float64), G["t12"].astype(np.float64)
+    n = len(G["kp1"])
+    z = np.full(n, -1.0)
+    margin = np.full((n, 3), np.inf)
+
+    def unproject(P, uv):
+        pw = (uv - P[2:4]) / P[0:2]
+        td = min(max(np.hypot(pw[0], pw[1]), -np.pi / 2), np.pi / 2)
+        scale = 1.0
+        if td > 1e-8:
+            th = td
+            for _ in range(10):
+                t2, t4 = th * th, th ** 4
+                t6, t8 = t4 * t2, t4 * t4
+                fix = (th * (1 + P[4] * t2 + P[5] * t4 + P[6] * t6 + P[7] * t8) - td) / \
+                      (1 + 3 * P[4] * t2 + 5 * P[5] * t4 + 7 * P[6] * t6 + 9 * P[7] * t8)
+                th -= fix
+                if abs(fix) < 1e-6:
+                    break
+            scale = np.tan(th) / td
+        return np.array([pw[0] * scale, pw[1] * scale, 1.0])
+
+    R21 = R12.T
+    t21 = -R21 @ t12
+    T1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    T2 = np.hstack([R21, t21[:, None]])
+    for i in range(n):
+        k1, k2 = G["kp1"][i].astype(np.float64), G["kp2"][i].astype(np.float64)
+        r1, r2 = unproject(P1, k1), unproject(P2, k2)
+        r21 = R12 @ r2
+        cosp = r1 @ r21 / (np.linalg.norm(r1) * np.linalg.norm(r21))
+        margin[i, 0] = abs(cosp - 0.9998)
+        if cosp > 0.9998:
+            continue
+        A = np.stack([r1[0] * T1[2] - T1[0], r1[1] * T1[2] - T1[1], r2[0] * T2[2] - T2[0], r2[1] * T2[2] - T2[1]])
+        h = np.linalg.svd(A)[2][3]
+        X = h[:3] / h[3]
+        z1, z2 = X[2], R21[2] @ X + t21[2]
+        margin[i, 1] = min(abs(z1), abs(z2)) / max(abs(X).max(), 1e-9)
+        ok = z1 > 0 and z2 > 0
+        if ok:
+            e1 = ((kb8_project64(P1, X[None])[0] - k1) ** 2).sum()
+            th1 = 5.991 * float(G["sigma1"][i])
+            margin[i, 2] = abs(e1 - th1) / th1
+            ok = e1 <= th1
+            if ok:
+                X2 = R21 @ X + t21
+                e2 = ((kb8_project64(P2, X2[None])[0] - k2) ** 2).sum()
+                th2 = 5.991 * float(G["sigma2"][i])
+                margin[i, 2] = min(margin[i, 2], abs(e2 - th2) / th2)
+                ok = e2 <= th2
+        if ok:
+            z[i] = z1
+    return z, margin
+
+
+def test_kb8_triangulate_against_float64_lapack(oracle):
+    # the oracle's float restatement (Jacobi SVD as cv::SVD::compute, float Matx arithmetic) against an independent
+    # float64 evaluation: same decisions wherever no test is close to its threshold, depths within 2e-3
+    from matcher_inputs import kb8_pairs
+    G = kb8_pairs(41, 1500)
+    z, X = oracle.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
+    z64, margin = kb8_triangulate_f64(G)
+    clear = (margin[:, 0] > 1e-5) & (margin[:, 1] > 1e-3) & (margin[:, 2] > 2e-2)
+    acc, acc64 = z > 1e-4, z64 > 1e-4
+    assert clear.sum() > 1300 and acc64.sum() > 500 and (~acc64).sum() > 300
+    assert np.array_equal(acc[clear], acc64[clear])
+    both = acc & acc64
+    assert np.allclose(z[both], z64[both], rtol=2e-3)
+    # every rejection reason occurs: low parallax, reprojection error (checked through the accepted share above)
+    assert np.isinf(margin[:, 1]).sum() > 50 and (np.isfinite(margin[:, 2]) & ~acc64).sum() > 50
+
+
+def test_search_triangulation_kb8_oracle_is_consistent(oracle):
+    # coarse accepts every candidate the gate would test, so the gated result is a subset in idx1 and every gated pair
+    # passes the gate when evaluated on its own
+    from matcher_inputs import tri_kb8_inputs
+    for rig in (False, True):
+        I = tri_kb8_inputs(500, 460, 51 + rig, rig=rig)
+        gated = oracle.search_triangulation_kb8(I, check_ori=False)
+        coarse = oracle.search_triangulation_kb8(I, coarse=True, check_ori=False)
+        assert 20 < len(gated) < len(coarse)
+        assert set(gated[:, 0]) <= set(coarse[:, 0])
+        for i1, i2 in gated[:40]:
+            r1 = rig and i1 >= I["Nleft1"]
+            r2 = rig and i2 >= I["Nleft2"]
+            sel = (2 if r1 else 0) + (1 if r2 else 0) if rig else 0
+            z, _ = oracle.kb8_triangulate(I["P1R"] if r1 else I["P1L"], I["P2R"] if r2 else I["P2L"], I["kp1"][i1:i1 + 1],
+                                          I["kp2"][i2:i2 + 1], I["R12"][sel], I["t12"][sel],
+                                          I["sig1"][I["oct1"][i1:i1 + 1]], I["sig2"][I["oct2"][i2:i2 + 1]])
+            assert z[0] > 1e-4
