@@ -213,10 +213,13 @@ typedef struct {
     int only_stereo, coarse, check_orientation;
 } orbfe_tri_kb8_args;
 int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args*, int32_t* pairs /* 2*n1 */);
-/* KannalaBrandt8::TriangulateMatches_ for n explicit keypoint pairs (the gate above; also what
- * ComputeStereoFishEyeMatches' matchAndtriangulate evaluates per knn match): z1[i] = depth in camera 1 or -1. */
+/* KannalaBrandt8::TriangulateMatches(_) for n explicit keypoint pairs -- the gate above, and what
+ * Frame::ComputeStereoFishEyeMatches evaluates for every knn match that passes the ratio test (src/Frame.cc:1146-1155,
+ * KannalaBrandt8.cpp:337-407): z1[i] = depth in camera 1 or -1 (accepted when > 0.0001f), p3D[3*i..] = the
+ * triangulated point (mvStereo3Dpoints; zeros for rejected pairs; p3D may be NULL). */
 int orbfe_kb8_triangulate(int device, const float* params1, const float* params2, const float* kp1_xy, const float* kp2_xy,
-                          const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1);
+                          const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1,
+                          float* p3D);
 
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);

@@ -528,15 +528,16 @@ def search_triangulation_kb8(I, only_stereo=False, coarse=False, check_ori=True,
 
 
 def kb8_triangulate(P1, P2, kp1, kp2, R12, t12, sigma1, sigma2, device=0):
-    """KannalaBrandt8::TriangulateMatches_ for explicit pairs: z1 (depth in camera 1) or -1."""
+    """KannalaBrandt8::TriangulateMatches_ for explicit pairs: (z1 = depth in camera 1 or -1, p3D[n,3])."""
     kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
     kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
     n = len(kp1)
     A = [np.ascontiguousarray(v, np.float32) for v in (P1, P2, R12, t12, sigma1, sigma2)]
     z = np.zeros(max(n, 1), np.float32)
+    X = np.zeros((max(n, 1), 3), np.float32)
     _chk(lib().orbfe_kb8_triangulate(device, _p(A[0]), _p(A[1]), _p(kp1), _p(kp2), _p(A[2]), _p(A[3]), _p(A[4]), _p(A[5]), n,
-                                     _p(z)), "orbfe_kb8_triangulate")
-    return z[:n]
+                                     _p(z), _p(X)), "orbfe_kb8_triangulate")
+    return z[:n], X[:n]
 
 
 def search_projection(problem, device=0):

@@ -142,7 +142,8 @@ __device__ inline void orbfe_svd4_last_vt(const float* A, float* h)
 /* KannalaBrandt8::TriangulateMatches_ (KannalaBrandt8.cpp:409-480): z1 of the triangulated point or -1. */
 __device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, const float* __restrict__ P2, float k1x,
                                                   float k1y, float k2x, float k2y, const float* __restrict__ R12,
-                                                  const float* __restrict__ t12, float sigmaLevel, float unc)
+                                                  const float* __restrict__ t12, float sigmaLevel, float unc,
+                                                  float* p3D = nullptr)
 {
     float r1[3], r2[3], r21[3];
     orbfe_kb8_unproject_dev(P1, k1x, k1y, r1);
@@ -203,6 +204,11 @@ __device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, 
     orbfe_kb8_project_dev(P2, X2[0], X2[1], X2[2], &u2, &v2);
     const float ex2 = __fsub_rn(u2, k2x), ey2 = __fsub_rn(v2, k2y);
     if ((double)__fadd_rn(__fmul_rn(ex2, ex2), __fmul_rn(ey2, ey2)) > __dmul_rn(5.991, (double)unc)) return -1.f;
+    if (p3D) {
+        p3D[0] = X[0];
+        p3D[1] = X[1];
+        p3D[2] = X[2];
+    }
     return z1;
 }
 #endif /* ORBFE_SINCOS_H */

@@ -404,12 +404,18 @@ __global__ __launch_bounds__(256) void k_kb8_triangulate(const float* __restrict
                                                          const float* __restrict__ kp1, const float* __restrict__ kp2,
                                                          const float* __restrict__ R12, const float* __restrict__ t12,
                                                          const float* __restrict__ sigma1, const float* __restrict__ sigma2,
-                                                         int n, float* __restrict__ z1)
+                                                         int n, float* __restrict__ z1, float* __restrict__ p3D)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    float X[3] = {0.f, 0.f, 0.f};
     z1[i] = orbfe_kb8_triangulate_dev(P1, P2, kp1[2 * i], kp1[2 * i + 1], kp2[2 * i], kp2[2 * i + 1], R12, t12, sigma1[i],
-                                      sigma2[i]);
+                                      sigma2[i], X);
+    if (p3D) {
+        p3D[3 * i] = X[0];
+        p3D[3 * i + 1] = X[1];
+        p3D[3 * i + 2] = X[2];
+    }
 }
 
 // ------------------------------------------------------------------ K-PROJ
@@ -1323,7 +1329,8 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
 }
 
 int orbfe_kb8_triangulate(int device, const float* params1, const float* params2, const float* kp1_xy, const float* kp2_xy,
-                          const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1)
+                          const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1,
+                          float* p3D)
 {
     if (!params1 || !params2 || !kp1_xy || !kp2_xy || !R12 || !t12 || !sigma1 || !sigma2 || !z1 || n < 0) return ORBFE_ERR_ARGS;
     if (n == 0) return 0;
@@ -1340,10 +1347,13 @@ int orbfe_kb8_triangulate(int device, const float* params1, const float* params2
     if ((r = s.up(&dS1, sigma1, (size_t)n)) < 0) return r;
     if ((r = s.up(&dS2, sigma2, (size_t)n)) < 0) return r;
     if ((r = s.up<float>(&dZ, nullptr, (size_t)n)) < 0) return r;
+    float* dX = nullptr;
+    if (p3D && (r = s.up<float>(&dX, nullptr, (size_t)3 * n)) < 0) return r;
     hipLaunchKernelGGL(k_kb8_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP1, dP2, dK1, dK2, dR, dT, dS1,
-                       dS2, n, dZ);
+                       dS2, n, dZ, dX);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(z1, dZ, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (p3D) HIP_TRY(hipMemcpy(p3D, dX, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -265,8 +265,8 @@ def test_kb8_triangulate_gate(pkg, oracle):
     from matcher_inputs import kb8_pairs
     from test_oracle_matcher import kb8_triangulate_f64
     G = kb8_pairs(42, 3000)
-    z_ref, _ = oracle.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
-    z = pkg.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
+    z_ref, X_ref = oracle.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
+    z, X = pkg.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
     _, margin = kb8_triangulate_f64(G)
     clear = (margin[:, 0] > 2e-6) & (margin[:, 1] > 1e-4) & (margin[:, 2] > 1e-3)
     acc, acc_ref = z > 1e-4, z_ref > 1e-4
@@ -274,6 +274,7 @@ def test_kb8_triangulate_gate(pkg, oracle):
     assert np.array_equal(acc[clear], acc_ref[clear])
     both = acc & acc_ref
     assert np.allclose(z[both], z_ref[both], rtol=2e-5)
+    assert np.allclose(X[both], X_ref[both], rtol=2e-5, atol=2e-5)  # mvStereo3Dpoints of ComputeStereoFishEyeMatches
     assert (acc != acc_ref).sum() <= 2  # borderline candidates are rare
 
 
