@@ -193,6 +193,21 @@ typedef struct {
 /* SearchForTriangulation_ (monocular / rectified pinhole rig).  pairs[2*k], pairs[2*k+1]; returns npairs. */
 int orbfe_search_tri(int device, const orbfe_tri_args*, int32_t* pairs /* 2*n1 */);
 
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821, monocular bootstrap): every level-0 keypoint of
+ * F1 searches a window of half-size window_size around vbPrevMatched[i1] in F2's grid (levels [0, 0]) for its best
+ * and second-best Hamming distance; a feature of F2 already held with a distance <= the candidate's is skipped
+ * (vMatchedDistance, :744) and a better match steals it (:765-772); TH_LOW, the ratio test and the orientation
+ * histogram as in the reference.  matches12[n1] = index into F2 or -1 (vnMatches12); returns nmatches.  The caller
+ * updates vbPrevMatched from the result (:813-816).  Frame side as orbfe_proj_args (grid parameters of F2). */
+typedef struct {
+    const uint8_t* desc1; int n1; const int32_t* octave1; const float* angle1;
+    const float* prev_xy;                  /* vbPrevMatched, 2 floats per F1 keypoint */
+    const uint8_t* desc2; int n2; const float* kx2; const float* ky2; const int32_t* octave2; const float* angle2;
+    float minX, minY, gridWInv, gridHInv;  /* of F2 */
+    int window_size; float nnratio; int check_orientation;
+} orbfe_init_args;
+int orbfe_search_initialization(int device, const orbfe_init_args*, int32_t* matches12);
+
 /* SearchForTriangulation_ for KannalaBrandt8 cameras (src/ORBmatcher.cc:1208-1449 with the gate
  * KannalaBrandt8::epipolarConstrain_ = TriangulateMatches_ > 0.0001f, src/CameraModels/KannalaBrandt8.cpp:239-242,
  * :409-480): a monocular fisheye keyframe pair (Nleft1 == Nleft2 == -1) or a two-camera rig (features [0, Nleft)

@@ -26,6 +26,7 @@
 #include <chrono>
 #include <thread>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -1208,6 +1209,110 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
 // :2421-2541, with the rotation histogram.  The grid is Frame::AssignFeaturesToGrid (src/Frame.cc:380-410),
 // the window Frame::GetFeaturesInArea (:643-708).  Occupancy follows F.mvpMapPoints: `taken` = non-null and
 // Observations()>0 on entry; a query's map point blocks a feature when qblocks[q] (NULL = all block).
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821), literal: F1 keypoints of level 0 search a
+// window around vbPrevMatched in F2's grid (Frame::GetFeaturesInArea, src/Frame.cc:643-708, levels [0, 0]);
+// a better match steals an F2 feature from an earlier one (vMatchedDistance / vnMatches21).
+int orb_oracle_search_initialization(const orb_oracle_init_args* a, int32_t* vnMatches12)
+{
+    const int GC = 64, GR = 48;
+    std::vector<std::vector<size_t>> mGrid((size_t)GC * GR);
+    for (int i = 0; i < a->n2; i++) {
+        const int posX = (int)std::round((a->kx2[i] - a->minX) * a->gridWInv);
+        const int posY = (int)std::round((a->ky2[i] - a->minY) * a->gridHInv);
+        if (posX < 0 || posX >= GC || posY < 0 || posY >= GR) continue;
+        mGrid[(size_t)posX * GR + posY].push_back((size_t)i);
+    }
+    auto GetFeaturesInArea = [&](float x, float y, float r, int minLevel, int maxLevel) {
+        std::vector<size_t> vIndices;
+        const float fx0 = std::floor((x - a->minX - r) * a->gridWInv);
+        if (!(fx0 < (float)GC)) return vIndices;
+        const int nMinCellX = fx0 > 0.f ? (int)fx0 : 0;
+        const float fx1 = std::ceil((x - a->minX + r) * a->gridWInv);
+        if (!(fx1 >= 0.f)) return vIndices;
+        const int nMaxCellX = fx1 < (float)(GC - 1) ? (int)fx1 : GC - 1;
+        const float fy0 = std::floor((y - a->minY - r) * a->gridHInv);
+        if (!(fy0 < (float)GR)) return vIndices;
+        const int nMinCellY = fy0 > 0.f ? (int)fy0 : 0;
+        const float fy1 = std::ceil((y - a->minY + r) * a->gridHInv);
+        if (!(fy1 >= 0.f)) return vIndices;
+        const int nMaxCellY = fy1 < (float)(GR - 1) ? (int)fy1 : GR - 1;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[(size_t)ix * GR + iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const size_t g = vCell[j];
+                    if (bCheckLevels) {
+                        if (a->octave2[g] < minLevel) continue;
+                        if (maxLevel >= 0)
+                            if (a->octave2[g] > maxLevel) continue;
+                    }
+                    const float distx = a->kx2[g] - x, disty = a->ky2[g] - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(g);
+                }
+            }
+        return vIndices;
+    };
+    int nmatches = 0;
+    for (int i = 0; i < a->n1; i++) vnMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<int> vMatchedDistance(a->n2, INT_MAX);
+    std::vector<int> vnMatches21(a->n2, -1);
+    for (int i1 = 0; i1 < a->n1; i1++) {
+        const int level1 = a->octave1[i1];
+        if (level1 > 0) continue;
+        const std::vector<size_t> vIndices2 =
+            GetFeaturesInArea(a->prev_xy[2 * i1], a->prev_xy[2 * i1 + 1], (float)a->window_size, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = a->desc1 + 32 * (size_t)i1;
+        int bestDist = INT_MAX;
+        int bestDist2 = INT_MAX;
+        int bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const size_t i2 = vIndices2[k];
+            const int dist = DescriptorDistance(d1, a->desc2 + 32 * i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * a->nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    vnMatches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (a->check_orientation) rotHist[rot_bin(a->angle1[i1], a->angle2[bestIdx2])].push_back(i1);
+            }
+        }
+    }
+    if (a->check_orientation) {
+        int counts[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                const int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) {
+                    vnMatches12[idx1] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
 int orb_oracle_search_projection(const orb_oracle_proj_args* a, int32_t* q_match, int32_t* feat_match)
 {
     const int GC = 64, GR = 48; // FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h

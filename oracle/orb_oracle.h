@@ -110,6 +110,15 @@ int orb_oracle_search_triangulation(const uint8_t* desc1, int n1, const uint8_t*
                                     const orb_oracle_fv* fv2, const float* F12 /*9, row-major*/, float epx, float epy,
                                     const float* scaleFactors2, const float* levelSigma2_2, int bOnlyStereo,
                                     int bCoarse, int checkOri, int32_t* pairs);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821) over flattened frames; vnMatches12[n1] = index
+ * into F2 or -1; returns nmatches.  (vbPrevMatched is updated by the caller from the result, :813-816.) */
+typedef struct {
+    const uint8_t* desc1; int n1; const int32_t* octave1; const float* angle1; const float* prev_xy;
+    const uint8_t* desc2; int n2; const float* kx2; const float* ky2; const int32_t* octave2; const float* angle2;
+    float minX, minY, gridWInv, gridHInv;
+    int window_size; float nnratio; int check_orientation;
+} orb_oracle_init_args;
+int orb_oracle_search_initialization(const orb_oracle_init_args* a, int32_t* vnMatches12);
 /* KannalaBrandt8::TriangulateMatches_ (src/CameraModels/KannalaBrandt8.cpp:409-480): depth of the triangulated
  * point in camera 1, or -1 (low parallax, behind a camera, reprojection error).  P = fx,fy,cx,cy,k0..k3;
  * R12 row-major 3x3, t12; p3D may be NULL.  epipolarConstrain_ (:239-242) is `> 0.0001f`. */

@@ -417,6 +417,32 @@ def _proj_args(pr):
     return a, keep, a.n, a.nq
 
 
+class _InitArgs(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("octave1", C.c_void_p), ("angle1", C.c_void_p),
+                ("prev_xy", C.c_void_p),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("kx2", C.c_void_p), ("ky2", C.c_void_p), ("octave2", C.c_void_p),
+                ("angle2", C.c_void_p),
+                ("minX", C.c_float), ("minY", C.c_float), ("gridWInv", C.c_float), ("gridHInv", C.c_float),
+                ("window_size", C.c_int), ("nnratio", C.c_float), ("check_orientation", C.c_int)]
+
+
+def search_initialization(pr):
+    keep = [np.ascontiguousarray(pr[k], dt) for k, dt in (("desc1", np.uint8), ("octave1", np.int32), ("angle1", np.float32),
+                                                           ("prev_xy", np.float32), ("desc2", np.uint8), ("kx2", np.float32),
+                                                           ("ky2", np.float32), ("octave2", np.int32), ("angle2", np.float32))]
+    d1, o1, a1, pv, d2, kx, ky, o2, a2 = keep
+    a = _InitArgs(d1.ctypes.data, len(o1), o1.ctypes.data, a1.ctypes.data, pv.ctypes.data, d2.ctypes.data, len(kx),
+                  kx.ctypes.data, ky.ctypes.data, o2.ctypes.data, a2.ctypes.data, float(pr["minX"]), float(pr["minY"]),
+                  float(pr["gridWInv"]), float(pr["gridHInv"]), int(pr["window_size"]), float(pr["nnratio"]),
+                  int(pr.get("check_orientation", 1)))
+    m = np.full(max(len(o1), 1), -1, np.int32)
+    L = lib()
+    L.orb_oracle_search_initialization.restype = C.c_int
+    L.orb_oracle_search_initialization.argtypes = [C.c_void_p, C.c_void_p]
+    r = L.orb_oracle_search_initialization(C.byref(a), _p(m))
+    return r, m[:len(o1)]
+
+
 def search_triangulation_kb8(I, only_stereo=False, coarse=False, check_ori=True):
     keep = []
 

@@ -65,6 +65,27 @@ class _TriKb8Args(C.Structure):
                 ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+class _InitArgs(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("octave1", C.c_void_p), ("angle1", C.c_void_p),
+                ("prev_xy", C.c_void_p),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("kx2", C.c_void_p), ("ky2", C.c_void_p), ("octave2", C.c_void_p),
+                ("angle2", C.c_void_p),
+                ("minX", C.c_float), ("minY", C.c_float), ("gridWInv", C.c_float), ("gridHInv", C.c_float),
+                ("window_size", C.c_int), ("nnratio", C.c_float), ("check_orientation", C.c_int)]
+
+
+def _init_args(pr):
+    keep = [np.ascontiguousarray(pr[k], dt) for k, dt in (("desc1", np.uint8), ("octave1", np.int32), ("angle1", np.float32),
+                                                           ("prev_xy", np.float32), ("desc2", np.uint8), ("kx2", np.float32),
+                                                           ("ky2", np.float32), ("octave2", np.int32), ("angle2", np.float32))]
+    d1, o1, a1, pv, d2, kx, ky, o2, a2 = keep
+    a = _InitArgs(d1.ctypes.data, len(o1), o1.ctypes.data, a1.ctypes.data, pv.ctypes.data, d2.ctypes.data, len(kx),
+                  kx.ctypes.data, ky.ctypes.data, o2.ctypes.data, a2.ctypes.data, float(pr["minX"]), float(pr["minY"]),
+                  float(pr["gridWInv"]), float(pr["gridHInv"]), int(pr["window_size"]), float(pr["nnratio"]),
+                  int(pr.get("check_orientation", 1)))
+    return a, keep, len(o1)
+
+
 class _ProjArgs(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p),
                 ("angle", C.c_void_p), ("uright", C.c_void_p), ("taken", C.c_void_p), ("Nleft", C.c_int),
@@ -190,7 +211,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -494,6 +515,14 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
     pairs = np.zeros((max(len(d1), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
     return pairs[:n].copy()
+
+
+def search_initialization(problem, device=0):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821): (nmatches, vnMatches12)."""
+    a, keep, n1 = _init_args(problem)
+    m = np.full(max(n1, 1), -1, np.int32)
+    r = _chk(lib().orbfe_search_initialization(device, C.byref(a), _p(m)), "orbfe_search_initialization")
+    return r, m[:n1]
 
 
 def search_triangulation_kb8(I, only_stereo=False, coarse=False, check_ori=True, device=0):

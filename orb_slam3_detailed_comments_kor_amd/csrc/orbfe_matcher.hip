@@ -735,6 +735,82 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps(ProjDev P)
     if (cnt) atomicAdd(&P.status[0], cnt);
 }
 
+// ------------------------------------------------------------------ K-INIT
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821) on K-PROJ's grid and sorted candidate keys.
+// The sequential rule here is distance dependent: F2 feature i2 is skipped by query q when an EARLIER query
+// holds it with a distance <= dist(q, i2) (vMatchedDistance, :744), and a better match steals it (:765-772).
+// Same fixpoint scheme as k_proj_sweeps: every sweep, each accepted query claims its feature in a per-feature
+// list; a query evaluates its sorted keys against the previous sweep's claims of queries with a smaller index.
+// The result of q depends only on queries < q, so the fixpoint is unique and equals the sequential run.
+struct InitDev {
+    ProjDev P;
+    float nnratio;
+    int32_t* head;   // 2 * n: newest claimant of a feature, per sweep parity
+    int32_t* next;   // 2 * nq: linked list through the claimants
+    int32_t* choice; // 2 * nq: claimed feature or -1
+    int32_t* cdist;  // 2 * nq: its distance
+};
+__global__ __launch_bounds__(PROJ_THREADS) void k_init_sweeps(InitDev I)
+{
+    __shared__ int sChanged;
+    const ProjDev& P = I.P;
+    const int tid = threadIdx.x, n = P.n, nq = P.nq;
+    for (int i = tid; i < 2 * n; i += PROJ_THREADS) I.head[i] = -1;
+    for (int i = tid; i < 2 * nq; i += PROJ_THREADS) {
+        I.choice[i] = -1;
+        I.cdist[i] = 0;
+        I.next[i] = -1;
+    }
+    __syncthreads();
+    int sweep = 0, last = 0;
+    for (; sweep < nq + 2; sweep++) {
+        const int pv = sweep & 1, cu = pv ^ 1;
+        last = cu;
+        const int32_t *headP = I.head + (size_t)pv * n, *nextP = I.next + (size_t)pv * nq;
+        const int32_t *choiceP = I.choice + (size_t)pv * nq, *distP = I.cdist + (size_t)pv * nq;
+        int32_t *headC = I.head + (size_t)cu * n, *nextC = I.next + (size_t)cu * nq;
+        int32_t *choiceC = I.choice + (size_t)cu * nq, *distC = I.cdist + (size_t)cu * nq;
+        for (int i = tid; i < n; i += PROJ_THREADS) headC[i] = -1;
+        if (tid == 0) sChanged = 0;
+        __syncthreads();
+        for (int q = tid; q < nq; q += PROJ_THREADS) {
+            const int m = P.qCount[q];
+            const unsigned long long* K = P.sortedKeys + P.qStart[q];
+            int g1 = -1, d1 = 0x7fffffff, d2 = 0x7fffffff;
+            for (int k = 0; k < m; k++) {
+                const unsigned long long key = K[k];
+                const int d = (int)(key >> 55), g = (int)(key & 0xFFFFFF);
+                bool blocked = false; // vMatchedDistance[i2] <= dist, as left by the queries before q (:744)
+                for (int p = headP[g]; p >= 0; p = nextP[p])
+                    if (p < q && distP[p] <= d) {
+                        blocked = true;
+                        break;
+                    }
+                if (blocked) continue;
+                if (g1 < 0) {
+                    g1 = g;
+                    d1 = d;
+                } else {
+                    d2 = d;
+                    break;
+                }
+            }
+            int c = -1;
+            if (g1 >= 0 && d1 <= TH_LOW && (float)d1 < __fmul_rn((float)d2, I.nnratio)) c = g1; // :760-763
+            choiceC[q] = c;
+            distC[q] = d1;
+            if (c != choiceP[q] || (c >= 0 && d1 != distP[q])) sChanged = 1;
+            if (c >= 0) nextC[q] = atomicExch(&headC[c], q);
+        }
+        __syncthreads();
+        if (!sChanged) break;
+        __syncthreads();
+    }
+    const int32_t* S = I.choice + (size_t)last * nq;
+    for (int q = tid; q < nq; q += PROJ_THREADS) P.qMatch[q] = S[q];
+    if (tid == 0) P.status[1] = sweep + 1;
+}
+
 // ------------------------------------------------------------------ K-DIST
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:387-419): among the N observation descriptors of
 // a map point pick the one with the least median Hamming distance to all of them (self distance 0
@@ -1230,6 +1306,125 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
         np++;
     }
     return np;
+}
+
+int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* matches12)
+{
+    if (!a || !matches12 || a->n1 < 0 || a->n2 < 0 || a->window_size < 0) return ORBFE_ERR_ARGS;
+    if (a->n1 && (!a->desc1 || !a->octave1 || !a->prev_xy)) return ORBFE_ERR_ARGS;
+    if (a->n2 && (!a->desc2 || !a->kx2 || !a->ky2 || !a->octave2)) return ORBFE_ERR_ARGS;
+    if (a->check_orientation && a->n1 && a->n2 && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+    if (a->n2 >= PROJ_MAXN) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < a->n1; i++) matches12[i] = -1;
+    if (a->n1 == 0 || a->n2 == 0) return 0;
+    // one query per level-0 keypoint of F1, in index order (:721-724)
+    std::vector<int32_t> qidx;
+    for (int i = 0; i < a->n1; i++)
+        if (!(a->octave1[i] > 0)) qidx.push_back(i);
+    const size_t n = (size_t)a->n2, nq = qidx.size();
+    if (nq == 0) return 0;
+    std::vector<uint8_t> qdesc(nq * 32);
+    std::vector<float> qx(nq), qy(nq), qr(nq, (float)a->window_size);
+    std::vector<int32_t> qlev(nq);
+    for (size_t q = 0; q < nq; q++) {
+        std::memcpy(&qdesc[q * 32], a->desc1 + (size_t)qidx[q] * 32, 32);
+        qx[q] = a->prev_xy[2 * qidx[q]];
+        qy[q] = a->prev_xy[2 * qidx[q] + 1];
+        qlev[q] = a->octave1[qidx[q]]; // GetFeaturesInArea(..., level1, level1)
+    }
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    InitDev I{};
+    ProjDev& P = I.P;
+    uint8_t *dDesc, *dQdesc;
+    float *dKx, *dKy, *dQx, *dQy, *dQr;
+    int32_t *dOct, *dQlev;
+    if ((r = s.up(&dDesc, a->desc2, n * 32)) < 0) return r;
+    if ((r = s.up(&dKx, a->kx2, n)) < 0) return r;
+    if ((r = s.up(&dKy, a->ky2, n)) < 0) return r;
+    if ((r = s.up(&dOct, a->octave2, n)) < 0) return r;
+    if ((r = s.up(&dQdesc, qdesc.data(), nq * 32)) < 0) return r;
+    if ((r = s.up(&dQx, qx.data(), nq)) < 0) return r;
+    if ((r = s.up(&dQy, qy.data(), nq)) < 0) return r;
+    if ((r = s.up(&dQr, qr.data(), nq)) < 0) return r;
+    if ((r = s.up(&dQlev, qlev.data(), nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.cellStart, nullptr, 2 * PROJ_CELLS + 1)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.cellItems, nullptr, n)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.cellOf, nullptr, n)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.qStart, nullptr, nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.qCount, nullptr, nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&I.head, nullptr, 2 * n)) < 0) return r;
+    if ((r = s.up<int32_t>(&I.next, nullptr, 2 * nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&I.choice, nullptr, 2 * nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&I.cdist, nullptr, 2 * nq)) < 0) return r;
+    int32_t* dOut;
+    if ((r = s.up<int32_t>(&dOut, nullptr, 4 + nq)) < 0) return r;
+    P.status = dOut;
+    P.qMatch = dOut + 4;
+    size_t keyCap = std::max<size_t>(64 * nq, 1 << 16);
+    if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
+    if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
+    P.keyCap = (int)keyCap;
+    P.desc = dDesc; P.kx = dKx; P.ky = dKy; P.octave = dOct; P.n = a->n2; P.Nleft = -1;
+    P.minX = a->minX; P.minY = a->minY; P.wInv = a->gridWInv; P.hInv = a->gridHInv;
+    P.nq = (int)nq; P.qdesc = dQdesc; P.qx = dQx; P.qy = dQy; P.qr = dQr; P.qmin = dQlev; P.qmax = dQlev;
+    P.mode = 1;
+    I.nnratio = a->nnratio;
+    std::vector<int32_t> out(4 + nq);
+    for (int attempt = 0;; attempt++) {
+        {
+            KernelTimer timer;
+            hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
+            hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, 0, P);
+            hipLaunchKernelGGL(k_init_sweeps, dim3(1), dim3(PROJ_THREADS), 0, 0, I);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
+        if (out[2] >= 0 && (size_t)out[2] <= keyCap) break;
+        if (attempt > 0 || out[2] < 0) return ORBFE_ERR_STATE;
+        keyCap = (size_t)out[2];
+        if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
+        if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
+        P.keyCap = (int)keyCap;
+    }
+    g_lastProjSweeps = out[1];
+    // the bookkeeping of :765-789 over the per-query choices, in query order
+    std::vector<int32_t> vnMatches21(n, -1);
+    std::vector<int8_t> bins(a->n1, -1);
+    int nmatches = 0;
+    for (size_t q = 0; q < nq; q++) {
+        const int f = out[4 + q];
+        if (f < 0) continue;
+        const int i1 = qidx[q];
+        if (vnMatches21[f] >= 0) {
+            matches12[vnMatches21[f]] = -1;
+            nmatches--;
+        }
+        matches12[i1] = f;
+        vnMatches21[f] = i1;
+        nmatches++;
+        if (a->check_orientation) {
+            float rot = a->angle1[i1] - a->angle2[f];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+            if (bin == HISTO_LENGTH) bin = 0;
+            bins[i1] = (int8_t)bin;
+        }
+    }
+    if (a->check_orientation) { // :791-811: the histogram counts every accepted query, also those robbed later
+        int histo[HISTO_LENGTH] = {0};
+        for (int i = 0; i < a->n1; i++)
+            if (bins[i] >= 0 && bins[i] < HISTO_LENGTH) histo[bins[i]]++;
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < a->n1; i++)
+            if (bins[i] >= 0 && bins[i] != ind1 && bins[i] != ind2 && bins[i] != ind3 && matches12[i] >= 0) {
+                matches12[i] = -1;
+                nmatches--;
+            }
+    }
+    return nmatches;
 }
 
 int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs)

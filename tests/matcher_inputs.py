@@ -60,6 +60,43 @@ def tri_inputs(n1, n2, seed):
                 has1=has1, has2=has2, F12=F12, sf=sf, sig=sig, ep=ep)
 
 
+def initialization_problem(seed, n1=1500, n2=1400, window=100, nnratio=0.9, check_orientation=True, crowd=True, w=752, h=480):
+    """SearchForInitialization inputs (fields of orbfe_init_args): F2 features are noisy copies of F1 features that
+    moved a little; with `crowd`, several F1 keypoints resemble the same F2 feature to different degrees, so the
+    stealing rule (vMatchedDistance / vnMatches21, src/ORBmatcher.cc:744, :765-772) decides who keeps it."""
+    rng = np.random.default_rng(seed)
+    kx1, ky1 = rng.uniform(5, w - 5, n1).astype(np.float32), rng.uniform(5, h - 5, n1).astype(np.float32)
+    octave1 = np.where(rng.random(n1) < 0.6, 0, rng.integers(1, 8, n1)).astype(np.int32)
+    desc1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    angle1 = rng.uniform(0, 360, n1).astype(np.float32)
+    src = rng.integers(0, n1, n2)
+    if crowd:  # groups of F1 keypoints share one descriptor family and sit close together
+        g = n1 // 6
+        base = rng.integers(0, n1, g)
+        members = rng.integers(0, n1, g)
+        bits = np.unpackbits(desc1[base], axis=1)
+        flips = rng.random(bits.shape) < rng.uniform(0.0, 0.08, (g, 1))
+        desc1[members] = np.packbits(bits ^ flips, axis=1)
+        kx1[members] = (kx1[base] + rng.normal(0, 8, g)).astype(np.float32)
+        ky1[members] = (ky1[base] + rng.normal(0, 8, g)).astype(np.float32)
+        octave1[members] = 0
+        octave1[base] = 0
+    bits = np.unpackbits(desc1[src], axis=1)
+    flips = rng.random(bits.shape) < rng.uniform(0.0, 0.12, (n2, 1))
+    desc2 = np.packbits(bits ^ flips, axis=1)
+    kx2 = (kx1[src] + rng.normal(0, 12, n2)).astype(np.float32)
+    ky2 = (ky1[src] + rng.normal(0, 12, n2)).astype(np.float32)
+    octave2 = np.where(rng.random(n2) < 0.7, 0, rng.integers(1, 8, n2)).astype(np.int32)
+    angle2 = np.mod(angle1[src] + rng.normal(0, 6, n2) + 15.0, 360).astype(np.float32)
+    flip = rng.random(n2) < 0.15
+    angle2[flip] = rng.uniform(0, 360, flip.sum()).astype(np.float32)
+    prev = np.stack([kx1, ky1], 1).astype(np.float32)  # first call: vbPrevMatched = F1 keypoint positions
+    return dict(desc1=desc1, octave1=octave1, angle1=angle1, prev_xy=prev, desc2=desc2, kx2=kx2, ky2=ky2, octave2=octave2,
+                angle2=angle2, minX=np.float32(0.0), minY=np.float32(0.0), gridWInv=np.float32(64) / np.float32(w),
+                gridHInv=np.float32(48) / np.float32(h), window_size=window, nnratio=nnratio,
+                check_orientation=int(check_orientation))
+
+
 KB8_TUMVI = np.array([190.978477, 190.973307, 254.931706, 256.897442, 0.003482389, 0.000715034, -0.002053236,
                       0.000202937], np.float32)  # Examples/Stereo-Inertial/TUM_512.yaml:9-30
 

@@ -292,3 +292,30 @@ def test_search_for_triangulation_kb8(pkg, oracle, rig, seed, coarse):
     assert np.array_equal(got, ref)
     if not coarse:
         assert len(ref) < len(oracle.search_triangulation_kb8(I, coarse=True))  # the gate rejected something
+
+
+@pytest.mark.parametrize("case", [dict(seed=81), dict(seed=82, window=40, nnratio=1.0), dict(seed=83, check_orientation=False),
+                                  dict(seed=84, n1=3000, n2=2800, window=200), dict(seed=85, n1=40, n2=3, crowd=False)],
+                         ids=lambda c: "s%d" % c["seed"])
+def test_search_for_initialization(pkg, oracle, case):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821) incl. the stealing rule (:744, :765-772)."""
+    from matcher_inputs import initialization_problem
+    pr = initialization_problem(**case)
+    n_ref, m_ref = oracle.search_initialization(pr)
+    n_got, m_got = pkg.search_initialization(pr)
+    assert np.array_equal(m_got, m_ref)
+    assert n_got == n_ref
+    if case["seed"] in (81, 84):
+        assert n_ref > 200
+        # the stealing rule was exercised: with only the first half of F1 some keypoints keep a match that a later,
+        # better keypoint takes away in the full problem
+        half = dict(pr)
+        h = len(pr["octave1"]) // 2
+        for k in ("desc1", "octave1", "angle1", "prev_xy"):
+            half[k] = pr[k][:h]
+        half["check_orientation"] = 0
+        full = dict(pr, check_orientation=0)
+        _, m_half = oracle.search_initialization(half)
+        _, m_full = oracle.search_initialization(full)
+        assert ((m_half >= 0) & (m_full[:h] < 0)).sum() > 0
+        assert pkg.search_projection_last_sweeps() >= 2

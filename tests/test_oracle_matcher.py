@@ -339,3 +339,89 @@ def test_search_triangulation_kb8_oracle_is_consistent(oracle):
                                           I["kp2"][i2:i2 + 1], I["R12"][sel], I["t12"][sel],
                                           I["sig1"][I["oct1"][i1:i1 + 1]], I["sig2"][I["oct2"][i2:i2 + 1]])
             assert z[0] > 1e-4
+
+
+# ---------------------------------------------------------------- SearchForInitialization
+def _init_spec(pr):
+    """Independent restatement of ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821): brute force over
+    F2 in grid-visit order instead of the cell lists."""
+    f32 = np.float32
+    n1, n2 = len(pr["octave1"]), len(pr["kx2"])
+    cx = np.round((pr["kx2"] - f32(pr["minX"])) * f32(pr["gridWInv"]))
+    cy = np.round((pr["ky2"] - f32(pr["minY"])) * f32(pr["gridHInv"]))
+    for arr, src, mn, inv in ((cx, pr["kx2"], pr["minX"], pr["gridWInv"]), (cy, pr["ky2"], pr["minY"], pr["gridHInv"])):
+        v = (src - f32(mn)) * f32(inv)
+        half = (np.abs(v - np.trunc(v)) == 0.5)
+        arr[half] = np.trunc(v[half]) + np.sign(v[half])
+    ingrid = (cx >= 0) & (cx < 64) & (cy >= 0) & (cy < 48)
+    order = np.lexsort((np.arange(n2), cy, cx))
+    lut = np.array([bin(v).count("1") for v in range(256)], np.int32)
+    r = f32(pr["window_size"])
+    m12 = np.full(n1, -1, np.int32)
+    m21 = np.full(n2, -1, np.int32)
+    held = np.full(n2, np.iinfo(np.int32).max, np.int64)
+    nm = 0
+    hist = []
+    for i1 in range(n1):
+        if pr["octave1"][i1] > 0:
+            continue
+        x, y = pr["prev_xy"][i1]
+        # cell range of GetFeaturesInArea: a feature outside the visited cells is not a candidate even if inside the window
+        c0x = max(0, int(np.floor((x - f32(pr["minX"]) - r) * f32(pr["gridWInv"]))))
+        c1x = min(63, int(np.ceil((x - f32(pr["minX"]) + r) * f32(pr["gridWInv"]))))
+        c0y = max(0, int(np.floor((y - f32(pr["minY"]) - r) * f32(pr["gridHInv"]))))
+        c1y = min(47, int(np.ceil((y - f32(pr["minY"]) + r) * f32(pr["gridHInv"]))))
+        best, best2, bi = 2 ** 31 - 1, 2 ** 31 - 1, -1
+        for g in order:
+            if not ingrid[g] or not (c0x <= cx[g] <= c1x and c0y <= cy[g] <= c1y):
+                continue
+            if pr["octave2"][g] != 0:
+                continue
+            if not (abs(pr["kx2"][g] - x) < r and abs(pr["ky2"][g] - y) < r):
+                continue
+            d = int(lut[pr["desc1"][i1] ^ pr["desc2"][g]].sum())
+            if held[g] <= d:
+                continue
+            if d < best:
+                best2, best, bi = best, d, int(g)
+            elif d < best2:
+                best2 = d
+        if best <= 50 and f32(best) < f32(f32(best2) * f32(pr["nnratio"])):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                nm -= 1
+            m12[i1], m21[bi], held[bi] = bi, i1, best
+            nm += 1
+            if pr["check_orientation"]:
+                rot = f32(pr["angle1"][i1]) - f32(pr["angle2"][bi])
+                if rot < 0:
+                    rot = f32(rot + f32(360.0))
+                b = int(np.floor(f32(rot * f32(1.0 / 30)) + f32(0.5)))
+                hist.append((0 if b == 30 else b, i1))
+    if pr["check_orientation"]:
+        cnt = np.bincount([b for b, _ in hist], minlength=30)
+        top = sorted(range(30), key=lambda i: (-cnt[i], i))[:3]
+        m1 = cnt[top[0]]
+        keep = {top[0]} if m1 > 0 else set()
+        if m1 > 0 and not cnt[top[1]] < f32(0.1) * f32(m1):
+            keep.add(top[1])
+            if not cnt[top[2]] < f32(0.1) * f32(m1):
+                keep.add(top[2])
+        for b, i1 in hist:
+            if b not in keep and m12[i1] >= 0:
+                m12[i1] = -1
+                nm -= 1
+    return nm, m12
+
+
+@pytest.mark.parametrize("case", [dict(seed=71, n1=260, n2=240, window=100), dict(seed=72, n1=260, n2=240, window=40, nnratio=1.0),
+                                  dict(seed=73, n1=200, n2=260, window=150, check_orientation=False)],
+                         ids=lambda c: "s%d" % c["seed"])
+def test_search_initialization_against_bruteforce_spec(oracle, case):
+    from matcher_inputs import initialization_problem
+    pr = initialization_problem(**case)
+    n_ref, m_ref = _init_spec(pr)
+    n_got, m_got = oracle.search_initialization(pr)
+    assert n_ref > 20
+    assert np.array_equal(m_got, m_ref)
+    assert n_got == n_ref
