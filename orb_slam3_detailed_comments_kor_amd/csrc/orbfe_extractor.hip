@@ -149,6 +149,7 @@ struct orbfe_ctx {
     bool pyrFused = true;
     DevBuf<int> d_taps;
     bool tapsDirty = true;
+    int lapDev0 = 0, lapDev1 = 0, lapDevCount = 0; // what d_lap currently holds (orbfe_extract_batch_device)
     DevBuf<float4> d_patternF;
     PinBuf<int32_t> h_n, h_mono;
     PinBuf<float> h_kps;
@@ -524,6 +525,7 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_lvlKp.ensure(B * c->kpStride)) < 0) return r;
     if ((r = c->d_lvlCount.ensure(B * c->nlevels)) < 0) return r;
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
+    c->lapDevCount = 0; // possibly a new buffer
     if ((r = c->d_work.ensure(B * K)) < 0) return r;
     if ((r = c->d_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
@@ -979,14 +981,21 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     int r;
     if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
     if ((r = ensure_capacity(c, nimg, std::max(cap_per_img, c->maxKp))) < 0) return r;
-    std::vector<int32_t> lap((size_t)nimg * 2);
-    for (int i = 0; i < nimg; i++) {
-        lap[2 * i] = lap0;
-        lap[2 * i + 1] = lap1;
+    // The per-image lapping table only changes when the caller changes (lap0, lap1) or grows the batch: upload
+    // it then (with a synchronisation, the source is a stack buffer) and never again -- the steady state of this
+    // entry point issues kernels only and does not block the host.
+    if (c->lapDev0 != lap0 || c->lapDev1 != lap1 || c->lapDevCount < nimg) {
+        std::vector<int32_t> lap((size_t)nimg * 2);
+        for (int i = 0; i < nimg; i++) {
+            lap[2 * i] = lap0;
+            lap[2 * i + 1] = lap1;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_lap.p, lap.data(), lap.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->lapDev0 = lap0;
+        c->lapDev1 = lap1;
+        c->lapDevCount = nimg;
     }
-    // small, pageable: staged by the runtime, ordered on the stream
-    HIP_TRY(hipMemcpyAsync(c->d_lap.p, lap.data(), lap.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream)); // `lap` is a stack-lifetime buffer
     return run_device(c, nimg, d_imgs, rows, cols, pitch, img_stride_bytes, c->d_lap.p, (float*)d_kps, d_desc,
                       cap_per_img, d_n_out, d_mono_out);
 }
@@ -1023,6 +1032,7 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     if (lap)
         for (int i = 0; i < 2 * nimg; i++) lapv[i] = lap[i];
     HIP_TRY(hipMemcpyAsync(c->d_lap.p, lapv.data(), lapv.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    c->lapDevCount = 0; // per-image values: the cached uniform table of orbfe_extract_batch_device is gone
     for (int i = 0; i < nimg; i++)
         HIP_TRY(hipMemcpy2DAsync(c->d_img.p + (size_t)i * c->imgStride, c->imgPitch, imgs[i], stride, (size_t)cols,
                                  (size_t)rows, hipMemcpyHostToDevice, s));
