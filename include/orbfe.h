@@ -60,10 +60,11 @@ int orbfe_set_gaussian_taps(orbfe_ctx*, const int* taps7);
 /* Rotation trig of the descriptor (src/ORBextractor.cc:110-111):
  *   ORBFE_TRIG_LIBM (default): bit-identical to this host's libm cosf/sinf.  The first extraction of a
  *       process evaluates libm for every float angle in [2^-7, 360] degrees (all cores, a fraction of a
- *       second) and keeps, per angle, how it differs from the device's correctly rounded value (65 MB
- *       table in HBM); every later batch runs without any host involvement.  If the table cannot be built
- *       (libm further than one bit pattern from correctly rounded, allocation failure, ORBFE_TRIG_TABLE=0
- *       in the environment) the mode behaves like ORBFE_TRIG_LIBM_HOSTCHECK.
+ *       second) and keeps the values in HBM (1.03 GB, the descriptor kernel just looks its angle up); every
+ *       later batch runs without any host involvement.  ORBFE_TRIG_TABLE=1 in the environment (or a failed
+ *       allocation) selects the compact form instead: 65 MB of 4-bit codes saying how libm differs from the
+ *       device's correctly rounded value, which the kernel then still evaluates; ORBFE_TRIG_TABLE=0, or a libm
+ *       that cannot be tabulated, makes the mode behave like ORBFE_TRIG_LIBM_HOSTCHECK.
  *   ORBFE_TRIG_LIBM_HOSTCHECK: same results, no table: the device flags keypoints whose sampling grid could
  *       change under a 1-ulp difference of sin/cos, the host evaluates libm for those after the batch (one
  *       stream synchronisation per call) and they are re-evaluated on the device with the libm values.
@@ -136,7 +137,8 @@ int orbfe_debug_candidates(orbfe_ctx*, int img_index, int level, uint32_t* out, 
 int orbfe_debug_level_keypoints(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
 int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm trig in the last call */
 /* (cos, sin) the descriptor kernel uses for the given keypoint angles (degrees) in the context's trig mode;
- * returns 1 when the libm table was used, 0 when not (ORBFE_TRIG_CR, or no table), < 0 on error. */
+ * returns 2 when the table of libm values was used, 1 for the compact code table, 0 for none (ORBFE_TRIG_CR, or
+ * no table), < 0 on error. */
 int orbfe_debug_trig(orbfe_ctx*, const float* angles_deg, int n, float* a_out, float* b_out);
 
 /* Frame::ComputeStereoMatches (src/Frame.cc:797-967), rectified stereo.  `left` / `right` are the contexts

@@ -386,13 +386,13 @@ class ORBextractor:
         return self.L.orbfe_debug_fixups(self.h)
 
     def debug_trig(self, angles_deg):
-        """(used_table, cos, sin) the descriptor kernel uses for these keypoint angles in this trig mode."""
+        """(table kind: 2 libm values / 1 libm codes / 0 none, cos, sin) the descriptor kernel uses for these angles."""
         ang = np.ascontiguousarray(angles_deg, np.float32)
         a = np.empty_like(ang)
         b = np.empty_like(ang)
         r = _chk(self.L.orbfe_debug_trig(self.h, ang.ctypes.data, len(ang), a.ctypes.data, b.ctypes.data),
                  "orbfe_debug_trig")
-        return bool(r), a, b
+        return int(r), a, b
 
 
 def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):

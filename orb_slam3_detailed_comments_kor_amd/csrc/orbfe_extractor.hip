@@ -355,7 +355,7 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         c->fastRecipP = (uint32_t)(((1ull << 32) + c->fastPitch - 1) / (uint64_t)c->fastPitch);
         int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
         if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
-            nt = std::max(nt, c->fastThreadsOverride);
+            nt = c->fastThreadsOverride; // ORBFE_FAST_THREADS: tuning experiments
         c->fastThreads = nt;
     }
     c->qtKeyOff = 64 + std::max(24 * maxLC, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
@@ -557,8 +557,13 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
 // small-angle check fails, the table is not used and ORBFE_TRIG_LIBM falls back to the per-batch host
 // check of the fragile keypoints.
 struct TrigTable {
-    uint8_t* d = nullptr; // device, (U1 - U0 + 2) / 2 bytes
+    uint8_t* d = nullptr;   // compact form: 4-bit codes, (U1 - U0 + 2) / 2 bytes
+    float2* full = nullptr; // full form: libm's (cosf, sinf) per angle, 8 B x (U1 - U0 + 1) = 1.03 GB
     bool tried = false, ok = false;
+};
+struct TrigTabs { // what a launch gets: at most one of the two is set
+    const uint8_t* codes;
+    const float2* full;
 };
 std::mutex g_trigMutex;
 TrigTable g_trig[16];
@@ -611,47 +616,73 @@ bool small_angles_ok()
     return true;
 }
 
-// returns the device table or nullptr (not available); never fails the caller
-const uint8_t* trig_table(int device, hipStream_t s)
+// The libm table of this process for `device` (both pointers null: not available); never fails the caller.
+// ORBFE_TRIG_TABLE = 0: none (per-batch host check), 1: compact 4-bit codes (65 MB; the device still evaluates the
+// correctly rounded sin/cos and applies the code), 2 or unset: libm's values themselves (1.03 GB of the 288 GB; the
+// descriptor kernel then needs no double-precision sin/cos at all, and libm may be arbitrarily inaccurate), falling
+// back to the compact form when that allocation fails.
+TrigTabs trig_table(int device, hipStream_t s)
 {
-    if (device < 0 || device >= 16) return nullptr;
+    TrigTabs none{nullptr, nullptr};
+    if (device < 0 || device >= 16) return none;
     std::lock_guard<std::mutex> lock(g_trigMutex);
     TrigTable& t = g_trig[device];
-    if (t.tried) return t.ok ? t.d : nullptr;
+    if (t.tried) return t.ok ? TrigTabs{t.d, t.full} : none;
     t.tried = true;
-    if (const char* e = getenv("ORBFE_TRIG_TABLE"))
-        if (atoi(e) == 0) return nullptr;
-    if (!small_angles_ok()) return nullptr;
+    int mode = 2;
+    if (const char* e = getenv("ORBFE_TRIG_TABLE")) mode = atoi(e);
+    if (mode <= 0) return none;
+    if (!small_angles_ok()) return none;
     const uint32_t N = ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u;
     const uint32_t chunk = 1u << 22; // 4M angles = 32 MB of (cosf, sinf) per transfer
     float2* h = nullptr;
-    float2* dAB = nullptr;
-    int32_t* dBad = nullptr;
-    int32_t bad = 0;
-    bool fine = hipHostMalloc((void**)&h, (size_t)chunk * sizeof(float2)) == hipSuccess &&
-                hipMalloc((void**)&dAB, (size_t)chunk * sizeof(float2)) == hipSuccess &&
-                hipMalloc((void**)&dBad, sizeof(int32_t)) == hipSuccess &&
-                hipMalloc((void**)&t.d, (size_t)(N + 1) / 2) == hipSuccess &&
-                hipMemsetAsync(dBad, 0, sizeof(int32_t), s) == hipSuccess;
-    for (uint32_t i0 = 0; fine && i0 < N; i0 += chunk) { // chunk is even: whole table bytes per chunk
-        const uint32_t n = std::min(chunk, N - i0);
-        fill_libm(h, ORBFE_TRIG_U0 + i0, n);
-        fine = hipMemcpyAsync(dAB, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess;
-        if (!fine) break;
-        hipLaunchKernelGGL(k_trig_codes, dim3((n / 2 + 256) / 256), dim3(256), 0, s, dAB, ORBFE_TRIG_U0 + i0, n,
-                           t.d + i0 / 2, dBad);
-        fine = hipStreamSynchronize(s) == hipSuccess; // h is refilled next
+    if (hipHostMalloc((void**)&h, (size_t)chunk * sizeof(float2)) != hipSuccess) return none;
+    bool fine = false;
+    if (mode >= 2 && hipMalloc((void**)&t.full, (size_t)N * sizeof(float2)) == hipSuccess) {
+        fine = true;
+        for (uint32_t i0 = 0; fine && i0 < N; i0 += chunk) {
+            const uint32_t n = std::min(chunk, N - i0);
+            fill_libm(h, ORBFE_TRIG_U0 + i0, n);
+            fine = hipMemcpyAsync(t.full + i0, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess &&
+                   hipStreamSynchronize(s) == hipSuccess; // h is refilled next
+        }
+        if (!fine) {
+            (void)hipFree(t.full);
+            t.full = nullptr;
+        }
+    } else {
+        (void)hipGetLastError(); // a failed 1-GB allocation is not an error of the caller
+        t.full = nullptr;
     }
-    if (fine) fine = hipMemcpy(&bad, dBad, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
-    if (h) (void)hipHostFree(h);
-    if (dAB) (void)hipFree(dAB);
-    if (dBad) (void)hipFree(dBad);
-    if (!fine && t.d) {
-        (void)hipFree(t.d);
-        t.d = nullptr;
+    if (!fine) { // compact form
+        float2* dAB = nullptr;
+        int32_t* dBad = nullptr;
+        int32_t bad = 0;
+        fine = hipMalloc((void**)&dAB, (size_t)chunk * sizeof(float2)) == hipSuccess &&
+               hipMalloc((void**)&dBad, sizeof(int32_t)) == hipSuccess &&
+               hipMalloc((void**)&t.d, (size_t)(N + 1) / 2) == hipSuccess &&
+               hipMemsetAsync(dBad, 0, sizeof(int32_t), s) == hipSuccess;
+        for (uint32_t i0 = 0; fine && i0 < N; i0 += chunk) { // chunk is even: whole table bytes per chunk
+            const uint32_t n = std::min(chunk, N - i0);
+            fill_libm(h, ORBFE_TRIG_U0 + i0, n);
+            fine = hipMemcpyAsync(dAB, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess;
+            if (!fine) break;
+            hipLaunchKernelGGL(k_trig_codes, dim3((n / 2 + 256) / 256), dim3(256), 0, s, dAB, ORBFE_TRIG_U0 + i0, n,
+                               t.d + i0 / 2, dBad);
+            fine = hipStreamSynchronize(s) == hipSuccess;
+        }
+        // a libm value further than one bit pattern from the correctly rounded one cannot be coded
+        if (fine) fine = hipMemcpy(&bad, dBad, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+        if (dAB) (void)hipFree(dAB);
+        if (dBad) (void)hipFree(dBad);
+        if (!fine && t.d) {
+            (void)hipFree(t.d);
+            t.d = nullptr;
+        }
     }
+    (void)hipHostFree(h);
     t.ok = fine;
-    return t.ok ? t.d : nullptr;
+    return t.ok ? TrigTabs{t.d, t.full} : none;
 }
 
 inline void rec(orbfe_ctx* c, int i)
@@ -673,8 +704,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     const int nl = c->nlevels;
     // ORBFE_TRIG_LIBM: with the libm table the device reproduces host cosf/sinf by itself; without it the
     // fragile keypoints are listed and checked on the host after the batch
-    const uint8_t* trigTab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, s) : nullptr;
-    const bool hostTrigCheck = c->trigMode != ORBFE_TRIG_CR && trigTab == nullptr;
+    const TrigTabs trigTab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, s) : TrigTabs{nullptr, nullptr};
+    const bool hostTrigCheck = c->trigMode != ORBFE_TRIG_CR && !trigTab.codes && !trigTab.full;
     if (c->tapsDirty) { // 28 bytes, but a separate command on the stream: only when they changed
         HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
         c->tapsDirty = false;
@@ -754,12 +785,12 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         hipLaunchKernelGGL((k_orient_blur_desc<0, true>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab);
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full);
             else
         hipLaunchKernelGGL((k_orient_blur_desc<0, false>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab);
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full);
         }
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
@@ -809,7 +840,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr);
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr);
         c->lastFixups = nFix;
     }
     rec(c, 6);
@@ -1281,13 +1312,13 @@ int orbfe_debug_trig(orbfe_ctx* c, const float* angles_deg, int n, float* a_out,
     if (!c || !angles_deg || !a_out || !b_out || n < 0) return ORBFE_ERR_ARGS;
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    const uint8_t* tab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, c->stream) : nullptr;
+    const TrigTabs tab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, c->stream) : TrigTabs{nullptr, nullptr};
     DevBuf<float> d;
     int r = d.ensure((size_t)3 * n);
     if (r < 0) return r;
     hipError_t e = hipMemcpyAsync(d.p, angles_deg, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_trig, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d.p, n, tab, d.p + n,
+        hipLaunchKernelGGL(k_debug_trig, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d.p, n, tab.codes, tab.full, d.p + n,
                            d.p + 2 * (size_t)n);
         e = hipMemcpyAsync(a_out, d.p + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     }
@@ -1295,7 +1326,7 @@ int orbfe_debug_trig(orbfe_ctx* c, const float* angles_deg, int n, float* a_out,
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     d.release();
     if (e != hipSuccess) return -(1000 + (int)e);
-    return tab ? 1 : 0; /* 1: the libm table was used */
+    return tab.full ? 2 : tab.codes ? 1 : 0; /* 2: libm values, 1: libm codes, 0: no table */
 }
 
 } // extern "C"

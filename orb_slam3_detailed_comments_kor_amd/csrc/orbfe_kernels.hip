@@ -1197,29 +1197,55 @@ __device__ __forceinline__ float trig_apply(float v, unsigned code)
 {
     return __uint_as_float(__float_as_uint(v) + (code == 1u ? 1u : code == 2u ? 0xFFFFFFFFu : 0u));
 }
-// the libm codes of one keypoint angle (0 = "same as correctly rounded" outside the table or without one)
-__device__ __forceinline__ unsigned trig_lookup(const uint8_t* __restrict__ trigTab, float angleDeg)
+// What K-DESC fetches for its angle as soon as the angle is known (the load then overlaps the blur): with the
+// full table libm's (cosf, sinf) themselves, with the compact table the 4-bit code, else nothing.
+struct TrigFetch {
+    float2 ab;    // full table: libm values (valid when `have`)
+    unsigned nib; // compact table: code
+    bool have;
+};
+__device__ __forceinline__ TrigFetch trig_fetch(const uint8_t* __restrict__ codes, const float2* __restrict__ full,
+                                                float angleDeg)
 {
-    if (!trigTab) return 0u;
+    TrigFetch f;
+    f.ab = make_float2(0.f, 0.f);
+    f.nib = 0u;
+    f.have = false;
     const uint32_t idx = __float_as_uint(angleDeg) - ORBFE_TRIG_U0;
-    return idx <= ORBFE_TRIG_U1 - ORBFE_TRIG_U0 ? ((unsigned)trigTab[idx >> 1] >> (4u * (idx & 1u))) & 15u : 0u;
+    const bool inTable = idx <= ORBFE_TRIG_U1 - ORBFE_TRIG_U0;
+    if (full) {
+        f.have = true;
+        if (inTable) {
+            f.ab = full[idx];
+        } else { // below 2^-7 degrees: x < 2^-12 rad, cosf(x) == 1 and sinf(x) == x (checked when the table is built)
+            f.ab = make_float2(1.0f, __fmul_rn(angleDeg, (float)(3.14159265358979323846 / 180.f)));
+        }
+    } else if (codes && inTable) {
+        f.nib = ((unsigned)codes[idx >> 1] >> (4u * (idx & 1u))) & 15u;
+    }
+    return f;
 }
 // a = cos, b = sin of the keypoint angle as the descriptor uses them (src/ORBextractor.cc:110-111)
-__device__ __forceinline__ void trig_rotation(float angleDeg, unsigned nib, float* a, float* b)
+__device__ __forceinline__ void trig_rotation(float angleDeg, const TrigFetch& f, float* a, float* b)
 {
+    if (f.have) { // wave-uniform in K-DESC
+        *a = f.ab.x;
+        *b = f.ab.y;
+        return;
+    }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     orbfe_sincos_cr(__fmul_rn(angleDeg, factorPI), b, a);
-    *a = trig_apply(*a, nib & 3u); // host libm's cosf / sinf, bit for bit (no-ops without the table)
-    *b = trig_apply(*b, nib >> 2);
+    *a = trig_apply(*a, f.nib & 3u); // host libm's cosf / sinf, bit for bit (no-ops without a table)
+    *b = trig_apply(*b, f.nib >> 2);
 }
 // test hook (orbfe_debug_trig): the rotation K-DESC would use for the given angles
 __global__ __launch_bounds__(256) void k_debug_trig(const float* __restrict__ angles, int n,
-                                                    const uint8_t* __restrict__ trigTab, float* __restrict__ a,
-                                                    float* __restrict__ b)
+                                                    const uint8_t* __restrict__ codes, const float2* __restrict__ full,
+                                                    float* __restrict__ a, float* __restrict__ b)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    trig_rotation(angles[i], trig_lookup(trigTab, angles[i]), &a[i], &b[i]);
+    trig_rotation(angles[i], trig_fetch(codes, full, angles[i]), &a[i], &b[i]);
 }
 
 // Sum over the 64 lanes with DPP (quad permutes, half-row and row mirrors) and four v_readlane: no LDS
@@ -1274,7 +1300,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                                            bits) after a 16-B header whose first word
                                                                            is the count; MODE 1: in {img<<16|g, -, a, b} */,
                                                           int nFix, int listFragile, int imgBase, int xcdAffine,
-                                                          const uint8_t* __restrict__ trigTab /* libm codes or nullptr */)
+                                                          const uint8_t* __restrict__ trigTab /* libm codes or nullptr */,
+                                                          const float2* __restrict__ trigFull /* libm values or nullptr */)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1390,7 +1417,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     m01 = wave_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // libm codes of this angle (issued now, used after the blur)
-    const unsigned trigNib = MODE == 0 ? trig_lookup(trigTab, angle) : 0u;
+    TrigFetch trigF;
+    if (MODE == 0) trigF = trig_fetch(trigTab, trigFull, angle);
 
     // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
     const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
@@ -1505,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     // ---- steered BRIEF (:106-145)
     float a, b;
     if (MODE == 0) {
-        trig_rotation(angle, trigNib, &a, &b);
+        trig_rotation(angle, trigF, &a, &b);
     } else {
         const int f = blockIdx.x * 4 + wave;
         a = __int_as_float(fixList[f].z);

@@ -4,6 +4,10 @@ Reads like a test of ORB_SLAM3::ORBextractor: construct with the YAML parameters
 operator(), compare keypoints (x, y, size, angle, response, octave, class_id) and the 32-byte
 descriptors, plus the intermediate stages (pyramid with border, FAST candidates, quadtree output).
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -121,7 +125,7 @@ def test_libm_table_reproduces_host_libm_bit_for_bit(pkg, oracle):
     ang = np.concatenate(parts)
     ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
     used, a, b = ex.debug_trig(ang)
-    assert used, "the libm table was not built on this box"
+    assert used == int(os.environ.get("ORBFE_TRIG_TABLE", "2")), "the libm table was not built on this box"
     ra, rb = _host_libm_sincos(ang)
     assert np.array_equal(a.view(np.uint32), ra.view(np.uint32))
     assert np.array_equal(b.view(np.uint32), rb.view(np.uint32))
@@ -138,6 +142,17 @@ def test_libm_table_reproduces_host_libm_bit_for_bit(pkg, oracle):
         assert np.float32(c_) == ca[i] and np.float32(s_) == cb[i]
     ex.close()
     exc.close()
+
+
+def test_compact_libm_table_in_a_fresh_process():
+    # the 65-MB code table (ORBFE_TRIG_TABLE=1; the default is the 1-GB table of libm values) is chosen once per
+    # process, so the same two checks run again in a child process: libm bit for bit, and a full extraction
+    env = dict(os.environ, ORBFE_TRIG_TABLE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_libm_table_reproduces_host_libm_bit_for_bit or test_libm_trig_fixups_are_exercised"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout
 
 
 def test_mono_init_extractor_5x_features(pkg, oracle):
