@@ -653,19 +653,30 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 // exclusive scan of a[0..n) in LDS, in place; returns the total to every thread.
 // One barrier per 512-element chunk plus one at the end (every wave sums the <= 8 wave totals
 // itself; the totals are double buffered so that a chunk never overwrites values still being read).
-__device__ int qt_scan(int* a, int n, int* wsum /* 2 * QT_WAVES */)
+// inclusive prefix sum over the 64 lanes with DPP (row shifts inside the 16-lane rows, row broadcasts across
+// them): six dependent VALU instructions instead of six ds_bpermute round trips through the LDS
+__device__ __forceinline__ int wave_incl_scan_i32(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// F maps the stored element to the value that is scanned (identity for a plain scan): lets a caller fold the
+// pass that would have prepared the scan input -- and its barrier -- into the scan itself.
+template <class F>
+__device__ int qt_scan_map(const int* src, int* a, int n, int* wsum /* 2 * QT_WAVES */, F f)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 0, chunk = 0;
     for (int base = 0; base < n; base += QT_THREADS, chunk ^= 1) {
         const int i = base + tid;
-        const int v = i < n ? a[i] : 0;
-        int x = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(x, off);
-            if (lane >= off) x += y;
-        }
+        const int v = i < n ? f(src[i]) : 0;
+        const int x = wave_incl_scan_i32(v);
         int* ws = wsum + chunk * QT_WAVES;
         if (lane == 63) ws[wave] = x;
         __syncthreads();
@@ -681,6 +692,27 @@ __device__ int qt_scan(int* a, int n, int* wsum /* 2 * QT_WAVES */)
     }
     __syncthreads();
     return carry;
+}
+__device__ int qt_scan(int* a, int n, int* wsum /* 2 * QT_WAVES */)
+{
+    return qt_scan_map(a, a, n, wsum, [](int v) { return v; });
+}
+
+// cc[idx] += 1 for every lane with idx >= 0, but with one LDS atomic per RUN of equal neighbouring indices: the
+// keys of a level arrive in cell order, so in the first passes (a handful of nodes) whole stretches of a
+// wavefront hit the same counter and plain per-lane atomics serialise 64 deep.
+__device__ __forceinline__ void qt_hist_add(int* cc, int idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int prev = __builtin_amdgcn_update_dpp(-2, idx, 0x138, 0xF, 0xF, false); // wave_shr:1; lane 0 keeps -2
+    const bool leader = idx >= 0 && idx != prev;
+    const unsigned long long L = __ballot(leader), A = __ballot(idx >= 0);
+    if (leader) {
+        const unsigned long long rest = lane == 63 ? 0ull : (L >> (lane + 1));
+        const int next = rest ? lane + 1 + (int)__builtin_ctzll(rest) : 64; // first lane of the next run
+        const unsigned long long range = (next == 64 ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << lane) - 1ull);
+        atomicAdd(&cc[idx], (int)__popcll(A & range)); // inactive lanes can only sit at the tail of a run
+    }
 }
 
 __device__ __forceinline__ int qt_quadrant(int ul, int br, int x, int y)
@@ -802,12 +834,16 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     }
     if (tid < nIni) cc[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += QT_THREADS) {
-        const uint32_t k = keys[i];
-        int r = (int)__fdiv_rn((float)(k & 0xFFF), L.hX);
-        r = min(r, nIni - 1);
-        atomicAdd(&cc[r], 1);
-        keyNode[i] = (uint16_t)r;
+    for (int base = 0; base < n; base += QT_THREADS) { // whole wavefronts enter qt_hist_add
+        const int i = base + tid;
+        int r = -1;
+        if (i < n) {
+            const uint32_t k = keys[i];
+            r = (int)__fdiv_rn((float)(k & 0xFFF), L.hX);
+            r = min(r, nIni - 1);
+            keyNode[i] = (uint16_t)r;
+        }
+        qt_hist_add(cc, r);
     }
     __syncthreads();
     if (tid < nIni) gpre[tid] = cc[tid] > 0 ? 1 : 0;
@@ -830,25 +866,26 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     auto expand = [&](int nE, bool histDone, int& nMultiOut) -> int {
         const int* ul = nodeUL[cur];
         const int* br = nodeBR[cur];
-        if (!histDone) {
-            for (int i = tid; i < 4 * nE; i += QT_THREADS) cc[i] = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += QT_THREADS) {
-                const int p = keyNode[i];
-                const int k = kOf[p];
-                if (k >= 0) {
-                    const uint32_t key = keys[i];
-                    atomicAdd(&cc[4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF)], 1);
+        if (!histDone) { // cc[0 .. 4 nE) was cleared by the caller, before its last barrier
+            for (int base = 0; base < n; base += QT_THREADS) {
+                const int i = base + tid;
+                int c = -1;
+                if (i < n) {
+                    const int p = keyNode[i];
+                    const int k = kOf[p];
+                    if (k >= 0) {
+                        const uint32_t key = keys[i];
+                        c = 4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
+                    }
                 }
+                qt_hist_add(cc, c);
             }
             __syncthreads();
         }
         // One packed scan over i = 4k+q: low half counts multi-key children (creation order), high
         // half counts non-empty children.  Children are push_front'ed, so their list order is the
         // REVERSE of i (n4,n3,n2,n1 of the last parent first): position = nChildren - 1 - (#non-empty before i).
-        for (int i = tid; i < 4 * nE; i += QT_THREADS) mpos[i] = (cc[i] > 1 ? 1 : 0) | (cc[i] > 0 ? 0x10000 : 0);
-        __syncthreads();
-        const int tot = qt_scan(mpos, 4 * nE, wsum);
+        const int tot = qt_scan_map(cc, mpos, 4 * nE, wsum, [](int c) { return (c > 1 ? 1 : 0) | (c > 0 ? 0x10000 : 0); });
         const int nChildren = tot >> 16, nMulti = tot & 0xFFFF;
         const int nb = cur ^ 1;
         const int newSize = nChildren + (size - nE);
@@ -905,9 +942,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     while (!finish) {
         // ---- full pass (:598-663): every node with more than one key is divided
         const int prevSize = size;
-        for (int p = tid; p < size; p += QT_THREADS) sidx[p] = nodeCnt[cur][p] > 1 ? 1 : 0;
-        __syncthreads();
-        for (int p = tid; p < size; p += QT_THREADS) kOf[p] = sidx[p] ? 0 : -1; // flag, index filled below
+        for (int p = tid; p < size; p += QT_THREADS) {
+            const int e = nodeCnt[cur][p] > 1 ? 1 : 0;
+            sidx[p] = e;
+            kOf[p] = e ? 0 : -1; // flag, index filled below
+        }
         __syncthreads();
         const int nE = qt_scan(sidx, size, wsum);
         if (nE == 0) break;
@@ -916,6 +955,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 kOf[p] = sidx[p];
                 par[sidx[p]] = p;
             }
+        for (int i = tid; i < 4 * nE; i += QT_THREADS) cc[i] = 0; // histogram of expand(), cleared in this phase
         __syncthreads();
         int nMulti = 0;
         const int ns = expand(nE, false, nMulti);
@@ -948,13 +988,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 {
                     const int* ul = nodeUL[cur];
                     const int* br = nodeBR[cur];
-                    for (int i = tid; i < n; i += QT_THREADS) {
-                        const int p = keyNode[i];
-                        const int k = kOf[p];
-                        if (k >= 0) {
-                            const uint32_t key = keys[i];
-                            atomicAdd(&cc[4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF)], 1);
+                    for (int base = 0; base < n; base += QT_THREADS) {
+                        const int i = base + tid;
+                        int c = -1;
+                        if (i < n) {
+                            const int p = keyNode[i];
+                            const int k = kOf[p];
+                            if (k >= 0) {
+                                const uint32_t key = keys[i];
+                                c = 4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
+                            }
                         }
+                        qt_hist_add(cc, c);
                     }
                 }
                 __syncthreads();
