@@ -238,6 +238,18 @@ int orbfe_kb8_triangulate(int device, const float* params1, const float* params2
                           const float* R12, const float* t12, const float* sigma1, const float* sigma2, int n, float* z1,
                           float* p3D);
 
+/* Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1119-1159) in one call: knn-2 brute force between the
+ * lapping-area descriptors (stereoDescLeft / stereoDescRight, i.e. the rows from monoLeft / monoRight on), Lowe
+ * ratio 0.7, KannalaBrandt8::TriangulateMatches(mRlr, mtlr) of every survivor.  All arrays are the lapping-area
+ * slices; the caller adds monoLeft / monoRight to the returned indices.  leftToRight[nL], rightToLeft[nR] = -1 or
+ * the partner, depth[nL] = mvDepth (or -1), p3D[3*nL] = mvStereo3Dpoints; returns nMatches.  The triangulation is
+ * parity-by-tolerance like orbfe_search_tri_kb8. */
+int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* kpL_xy, const int32_t* octL, int nL,
+                                 const uint8_t* descR, const float* kpR_xy, const int32_t* octR, int nR,
+                                 const float* params1, const float* params2, const float* Rlr, const float* tlr,
+                                 const float* levelSigma2, int nlevels, int32_t* leftToRight, int32_t* rightToLeft,
+                                 float* depth, float* p3D);
+
 /* KannalaBrandt8::unproject for n pixels (params = fx,fy,cx,cy,k0..k3). rays = 3 floats per pixel. */
 int orbfe_kb8_unproject(int device, const float* params8, const float* uv, int n, float* rays);
 

@@ -1839,6 +1839,45 @@ float orb_oracle_kb8_triangulate_matches(const float* P1, const float* P2, const
     return z1;
 }
 
+// Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1119-1159): knn-2 brute force between the lapping-area
+// descriptors of the two fisheye images, Lowe ratio 0.7, then KannalaBrandt8::TriangulateMatches per survivor.
+// Inputs are the lapping-area slices (the caller adds monoLeft / monoRight to the indices).
+int orb_oracle_stereo_fisheye_matches(const uint8_t* descL, const float* kpL_xy, const int32_t* octL, int nL,
+                                      const uint8_t* descR, const float* kpR_xy, const int32_t* octR, int nR,
+                                      const float* P1, const float* P2, const float* Rlr, const float* tlr,
+                                      const float* levelSigma2, int32_t* leftToRight, int32_t* rightToLeft,
+                                      float* depth, float* p3D)
+{
+    for (int i = 0; i < nL; i++) {
+        leftToRight[i] = -1;
+        depth[i] = -1.0f;
+        p3D[3 * i] = p3D[3 * i + 1] = p3D[3 * i + 2] = 0.f;
+    }
+    for (int i = 0; i < nR; i++) rightToLeft[i] = -1;
+    if (nL == 0 || nR == 0) return 0;
+    std::vector<int32_t> idx(2 * (size_t)nL), dist(2 * (size_t)nL);
+    orb_oracle_bfknn2(descL, nL, descR, nR, idx.data(), dist.data());
+    int nMatches = 0;
+    for (int q = 0; q < nL; q++) {
+        if (nR < 2) continue;                                                        // (*it).size() >= 2
+        if (!((float)dist[2 * q] < (float)dist[2 * q + 1] * 0.7)) continue;          // float distance * double 0.7
+        const int t = idx[2 * q];
+        const float sigma1 = levelSigma2[octL[q]], sigma2 = levelSigma2[octR[t]];
+        float X[3] = {0.f, 0.f, 0.f};
+        const float d = orb_oracle_kb8_triangulate_matches(P1, P2, kpL_xy + 2 * q, kpR_xy + 2 * t, Rlr, tlr, sigma1, sigma2, X);
+        if (d > 0.0001f) {
+            leftToRight[q] = t;
+            rightToLeft[t] = q;
+            p3D[3 * q] = X[0];
+            p3D[3 * q + 1] = X[1];
+            p3D[3 * q + 2] = X[2];
+            depth[q] = d;
+            nMatches++;
+        }
+    }
+    return nMatches;
+}
+
 // SearchForTriangulation_ (src/ORBmatcher.cc:1208-1449) with KannalaBrandt8 cameras: a monocular fisheye
 // keyframe pair (Nleft == -1, one camera each) or a two-camera rig (features [0, Nleft) from the left camera,
 // the rest from the right one, :1293-1297, and the four relative poses ll / lr / rl / rr of :1238-1248).

@@ -124,6 +124,12 @@ int orb_oracle_search_initialization(const orb_oracle_init_args* a, int32_t* vnM
  * R12 row-major 3x3, t12; p3D may be NULL.  epipolarConstrain_ (:239-242) is `> 0.0001f`. */
 float orb_oracle_kb8_triangulate_matches(const float* P1, const float* P2, const float* kp1xy, const float* kp2xy,
                                          const float* R12, const float* t12, float sigmaLevel, float unc, float* p3D);
+/* Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1119-1159) on the lapping-area slices; returns nMatches. */
+int orb_oracle_stereo_fisheye_matches(const uint8_t* descL, const float* kpL_xy, const int32_t* octL, int nL,
+                                      const uint8_t* descR, const float* kpR_xy, const int32_t* octR, int nR,
+                                      const float* P1, const float* P2, const float* Rlr, const float* tlr,
+                                      const float* levelSigma2, int32_t* leftToRight, int32_t* rightToLeft,
+                                      float* depth, float* p3D);
 /* SearchForTriangulation_ with the KannalaBrandt8 gate (fisheye monocular pair or two-camera rig). */
 typedef struct {
     const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1xy; const float* ang1; const int32_t* oct1;

@@ -489,6 +489,27 @@ def kb8_triangulate(P1, P2, kp1, kp2, R12, t12, sigma1, sigma2):
     return z, X
 
 
+def stereo_fisheye_matches(descL, kpL, octL, descR, kpR, octR, P1, P2, Rlr, tlr, level_sigma2):
+    dL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    dR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    kL = np.ascontiguousarray(kpL, np.float32).reshape(-1, 2)
+    kR = np.ascontiguousarray(kpR, np.float32).reshape(-1, 2)
+    oL = np.ascontiguousarray(octL, np.int32)
+    oR = np.ascontiguousarray(octR, np.int32)
+    A = [np.ascontiguousarray(v, np.float32) for v in (P1, P2, Rlr, tlr, level_sigma2)]
+    nL, nR = len(dL), len(dR)
+    l2r = np.zeros(max(nL, 1), np.int32)
+    r2l = np.zeros(max(nR, 1), np.int32)
+    dep = np.zeros(max(nL, 1), np.float32)
+    X = np.zeros((max(nL, 1), 3), np.float32)
+    L = lib()
+    L.orb_oracle_stereo_fisheye_matches.restype = C.c_int
+    L.orb_oracle_stereo_fisheye_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] * 2 + [C.c_void_p] * 9
+    n = L.orb_oracle_stereo_fisheye_matches(_p(dL), _p(kL), _p(oL), nL, _p(dR), _p(kR), _p(oR), nR, _p(A[0]), _p(A[1]), _p(A[2]),
+                                            _p(A[3]), _p(A[4]), _p(l2r), _p(r2l), _p(dep), _p(X))
+    return n, l2r[:nL], r2l[:nR], dep[:nL], X[:nL]
+
+
 def search_projection(problem):
     a, keep, n, nq = _proj_args(problem)
     qm = np.full(max(nq, 1), -1, np.int32)

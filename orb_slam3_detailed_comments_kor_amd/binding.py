@@ -211,7 +211,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -567,6 +567,26 @@ def kb8_triangulate(P1, P2, kp1, kp2, R12, t12, sigma1, sigma2, device=0):
     _chk(lib().orbfe_kb8_triangulate(device, _p(A[0]), _p(A[1]), _p(kp1), _p(kp2), _p(A[2]), _p(A[3]), _p(A[4]), _p(A[5]), n,
                                      _p(z), _p(X)), "orbfe_kb8_triangulate")
     return z[:n], X[:n]
+
+
+def stereo_fisheye_matches(descL, kpL, octL, descR, kpR, octR, P1, P2, Rlr, tlr, level_sigma2, device=0):
+    """Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1119-1159): (nMatches, leftToRight, rightToLeft, depth, p3D)."""
+    dL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    dR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    kL = np.ascontiguousarray(kpL, np.float32).reshape(-1, 2)
+    kR = np.ascontiguousarray(kpR, np.float32).reshape(-1, 2)
+    oL = np.ascontiguousarray(octL, np.int32)
+    oR = np.ascontiguousarray(octR, np.int32)
+    A = [np.ascontiguousarray(v, np.float32) for v in (P1, P2, Rlr, tlr, level_sigma2)]
+    nL, nR = len(dL), len(dR)
+    l2r = np.zeros(max(nL, 1), np.int32)
+    r2l = np.zeros(max(nR, 1), np.int32)
+    dep = np.zeros(max(nL, 1), np.float32)
+    X = np.zeros((max(nL, 1), 3), np.float32)
+    n = _chk(lib().orbfe_stereo_fisheye_matches(device, _p(dL), _p(kL), _p(oL), nL, _p(dR), _p(kR), _p(oR), nR, _p(A[0]),
+                                                _p(A[1]), _p(A[2]), _p(A[3]), _p(A[4]), len(A[4]), _p(l2r), _p(r2l), _p(dep),
+                                                _p(X)), "orbfe_stereo_fisheye_matches")
+    return n, l2r[:nL], r2l[:nR], dep[:nL], X[:nL]
 
 
 def search_projection(problem, device=0):

@@ -418,6 +418,39 @@ __global__ __launch_bounds__(256) void k_kb8_triangulate(const float* __restrict
     }
 }
 
+// Frame::ComputeStereoFishEyeMatches after the knn search (src/Frame.cc:1142-1157): Lowe ratio on the two
+// nearest right descriptors, then KannalaBrandt8::TriangulateMatches of the survivor with its best neighbour.
+__global__ __launch_bounds__(256) void k_fisheye_stereo(const int32_t* __restrict__ knnIdx, const int32_t* __restrict__ knnDist,
+                                                        int nL, int nR, const float* __restrict__ kpL,
+                                                        const float* __restrict__ kpR, const int32_t* __restrict__ octL,
+                                                        const int32_t* __restrict__ octR, const float* __restrict__ P1,
+                                                        const float* __restrict__ P2, const float* __restrict__ Rlr,
+                                                        const float* __restrict__ tlr, const float* __restrict__ sigma2,
+                                                        int32_t* __restrict__ l2r, float* __restrict__ depth,
+                                                        float* __restrict__ p3D)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nL) return;
+    int match = -1;
+    float d = -1.f, X[3] = {0.f, 0.f, 0.f};
+    if (nR >= 2 && (double)(float)knnDist[2 * q] < __dmul_rn((double)(float)knnDist[2 * q + 1], 0.7)) {
+        const int t = knnIdx[2 * q];
+        const float z = orbfe_kb8_triangulate_dev(P1, P2, kpL[2 * q], kpL[2 * q + 1], kpR[2 * t], kpR[2 * t + 1], Rlr, tlr,
+                                                  sigma2[octL[q]], sigma2[octR[t]], X);
+        if (z > 0.0001f) {
+            match = t;
+            d = z;
+        } else {
+            X[0] = X[1] = X[2] = 0.f;
+        }
+    }
+    l2r[q] = match;
+    depth[q] = d;
+    p3D[3 * q] = X[0];
+    p3D[3 * q + 1] = X[1];
+    p3D[3 * q + 2] = X[2];
+}
+
 // ------------------------------------------------------------------ K-PROJ
 // Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197, :2193-2419, :2421-2541): window
 // query in the frame grid (Frame::GetFeaturesInArea, src/Frame.cc:643-708) + best / second-best Hamming
@@ -1306,6 +1339,68 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
         np++;
     }
     return np;
+}
+
+int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* kpL_xy, const int32_t* octL, int nL,
+                                 const uint8_t* descR, const float* kpR_xy, const int32_t* octR, int nR,
+                                 const float* params1, const float* params2, const float* Rlr, const float* tlr,
+                                 const float* levelSigma2, int nlevels, int32_t* leftToRight, int32_t* rightToLeft,
+                                 float* depth, float* p3D)
+{
+    if (nL < 0 || nR < 0 || nR >= (1 << 20) || nlevels < 1 || !params1 || !params2 || !Rlr || !tlr || !levelSigma2)
+        return ORBFE_ERR_ARGS;
+    if (nL && (!descL || !kpL_xy || !octL || !leftToRight || !depth || !p3D)) return ORBFE_ERR_ARGS;
+    if (nR && (!descR || !kpR_xy || !octR || !rightToLeft)) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nL; i++)
+        if (octL[i] < 0 || octL[i] >= nlevels) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nR; i++)
+        if (octR[i] < 0 || octR[i] >= nlevels) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nR; i++) rightToLeft[i] = -1;
+    for (int i = 0; i < nL; i++) {
+        leftToRight[i] = -1;
+        depth[i] = -1.0f;
+        p3D[3 * i] = p3D[3 * i + 1] = p3D[3 * i + 2] = 0.f;
+    }
+    if (nL == 0 || nR == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    uint8_t *dQ, *dT;
+    int32_t *dI, *dD, *dOL, *dOR, *dL2R;
+    float *dKL, *dKR, *dP1, *dP2, *dR, *dt, *dSig, *dDepth, *dX;
+    if ((r = s.up(&dQ, descL, (size_t)nL * 32)) < 0) return r;
+    if ((r = s.up(&dT, descR, (size_t)nR * 32)) < 0) return r;
+    if ((r = s.up(&dKL, kpL_xy, (size_t)nL * 2)) < 0) return r;
+    if ((r = s.up(&dKR, kpR_xy, (size_t)nR * 2)) < 0) return r;
+    if ((r = s.up(&dOL, octL, (size_t)nL)) < 0) return r;
+    if ((r = s.up(&dOR, octR, (size_t)nR)) < 0) return r;
+    if ((r = s.up(&dP1, params1, 8)) < 0) return r;
+    if ((r = s.up(&dP2, params2, 8)) < 0) return r;
+    if ((r = s.up(&dR, Rlr, 9)) < 0) return r;
+    if ((r = s.up(&dt, tlr, 3)) < 0) return r;
+    if ((r = s.up(&dSig, levelSigma2, (size_t)nlevels)) < 0) return r;
+    if ((r = s.up<int32_t>(&dI, nullptr, (size_t)nL * 2)) < 0) return r;
+    if ((r = s.up<int32_t>(&dD, nullptr, (size_t)nL * 2)) < 0) return r;
+    if ((r = s.up<int32_t>(&dL2R, nullptr, (size_t)nL)) < 0) return r;
+    if ((r = s.up<float>(&dDepth, nullptr, (size_t)nL)) < 0) return r;
+    if ((r = s.up<float>(&dX, nullptr, (size_t)nL * 3)) < 0) return r;
+    {
+        KernelTimer timer;
+        hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, 0, dQ, nL, dT, nR, dI, dD);
+        hipLaunchKernelGGL(k_fisheye_stereo, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, 0, dI, dD, nL, nR, dKL, dKR, dOL,
+                           dOR, dP1, dP2, dR, dt, dSig, dL2R, dDepth, dX);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(leftToRight, dL2R, (size_t)nL * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(depth, dDepth, (size_t)nL * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(p3D, dX, (size_t)nL * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    int nMatches = 0;
+    for (int q = 0; q < nL; q++) // mvRightToLeftMatch: the last left keypoint that chose a right one keeps it (:1150)
+        if (leftToRight[q] >= 0) {
+            rightToLeft[leftToRight[q]] = q;
+            nMatches++;
+        }
+    return nMatches;
 }
 
 int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* matches12)

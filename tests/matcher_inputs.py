@@ -143,6 +143,33 @@ def kb8_pairs(seed, n=4000):
                 kp2=kp2.astype(np.float32), sigma1=sig[o1], sigma2=sig[o2], X1=X1)
 
 
+def stereo_fisheye_inputs(seed, nL=900, nR=850):
+    """Lapping-area slices of a fisheye stereo frame: right descriptors are noisy copies of left ones, keypoints are
+    projections of common 3-D points through two KB8 cameras related by (Rlr, tlr); some pairs are mismatched."""
+    rng = np.random.default_rng(seed)
+    P1 = KB8_TUMVI.copy()
+    P2 = (KB8_TUMVI + np.array([0.6, -0.2, -1.4, 0.9, 0, 0, 0, 0], np.float32)).astype(np.float32)
+    Rlr, tlr = _rot(0.01, -0.02, 0.005), np.array([0.101, 0.0006, -0.0012])   # x_left = Rlr x_right + tlr
+    descL = rng.integers(0, 256, (nL, 32), dtype=np.uint8)
+    X = np.stack([rng.uniform(-1.5, 1.5, nL), rng.uniform(-1.2, 1.2, nL), rng.uniform(0.4, 6, nL)], 1)
+    far = rng.random(nL) < 0.1
+    X[far] *= 200.0
+    kpL = kb8_project64(P1, X) + rng.normal(0, 0.3, (nL, 2))
+    src = rng.permutation(nL)[:nR] if nR <= nL else rng.integers(0, nL, nR)
+    bits = np.unpackbits(descL[src], axis=1)
+    flips = rng.random(bits.shape) < rng.uniform(0.0, 0.1, (nR, 1))
+    descR = np.packbits(bits ^ flips, axis=1)
+    rnd = rng.random(nR) < 0.25
+    descR[rnd] = rng.integers(0, 256, (rnd.sum(), 32), dtype=np.uint8)
+    XR = (Rlr.T @ (X[src] - tlr).T).T
+    kpR = kb8_project64(P2, XR) + np.where(rng.random(nR)[:, None] < 0.2, rng.normal(0, 4.0, (nR, 2)), rng.normal(0, 0.4, (nR, 2)))
+    octL = rng.integers(0, 8, nL).astype(np.int32)
+    octR = rng.integers(0, 8, nR).astype(np.int32)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    return dict(descL=descL, kpL=kpL.astype(np.float32), octL=octL, descR=descR, kpR=kpR.astype(np.float32), octR=octR,
+                P1=P1, P2=P2, Rlr=Rlr.astype(np.float32), tlr=tlr.astype(np.float32), sig=(sf * sf).astype(np.float32))
+
+
 def tri_kb8_inputs(n1, n2, seed, rig=False):
     """SearchForTriangulation_ inputs for fisheye keyframes: descriptors / FeatureVectors as tri_inputs, keypoints
     from a common 3-D scene so that true correspondences pass the triangulation gate."""

@@ -319,3 +319,20 @@ def test_search_for_initialization(pkg, oracle, case):
         _, m_full = oracle.search_initialization(full)
         assert ((m_half >= 0) & (m_full[:h] < 0)).sum() > 0
         assert pkg.search_projection_last_sweeps() >= 2
+
+
+@pytest.mark.parametrize("seed,nL,nR", [(91, 900, 850), (92, 1500, 1500), (93, 40, 1), (94, 5, 300)])
+def test_stereo_fisheye_matches(pkg, oracle, seed, nL, nR):
+    """Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1119-1159): knn-2 + ratio exact, triangulation by tolerance;
+    on these scenes the accepted set is identical to the oracle's."""
+    from matcher_inputs import stereo_fisheye_inputs
+    I = stereo_fisheye_inputs(seed, nL, nR)
+    args = (I["descL"], I["kpL"], I["octL"], I["descR"], I["kpR"], I["octR"], I["P1"], I["P2"], I["Rlr"], I["tlr"], I["sig"])
+    n_ref, l2r_ref, r2l_ref, dep_ref, X_ref = oracle.stereo_fisheye_matches(*args)
+    n, l2r, r2l, dep, X = pkg.stereo_fisheye_matches(*args)
+    assert n == n_ref and np.array_equal(l2r, l2r_ref) and np.array_equal(r2l, r2l_ref)
+    ok = l2r_ref >= 0
+    assert np.allclose(dep[ok], dep_ref[ok], rtol=2e-5) and np.array_equal(dep[~ok], dep_ref[~ok])
+    assert np.allclose(X[ok], X_ref[ok], rtol=2e-5, atol=2e-5) and not X[~ok].any()
+    if nL >= 900:
+        assert 100 < n_ref < nL  # the ratio test and the triangulation both reject something
