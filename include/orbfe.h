@@ -335,6 +335,8 @@ int orbfe_vocab_transform(orbfe_vocab_dev*, const uint8_t* feats, int n, int lev
 
 /* Device time (ms, hipEvents) of the matcher kernel launched by the last matcher call of this thread. */
 float orbfe_matcher_last_kernel_ms(void);
+/* Kernel timing of the matcher calls of this thread (events + a synchronisation per call): off by default. */
+void orbfe_matcher_time_kernels(int on);
 
 const char* orbfe_version(void);
 

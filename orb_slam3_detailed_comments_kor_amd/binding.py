@@ -216,7 +216,7 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
-           "orbfe_matcher_last_kernel_ms", "orbfe_search_projection", "orbfe_search_projection_last_sweeps",
+           "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps",
            "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
 
 
@@ -420,6 +420,10 @@ def _fv(fv):
 
 def matcher_last_kernel_ms():
     return float(lib().orbfe_matcher_last_kernel_ms())
+
+
+def matcher_time_kernels(on=True):
+    lib().orbfe_matcher_time_kernels(int(on))
 
 
 def hamming_pairs(A, B, device=0):

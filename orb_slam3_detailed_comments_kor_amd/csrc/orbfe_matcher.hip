@@ -945,6 +945,7 @@ __global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__
 struct Arena {
     int device = -1;
     uint8_t* base = nullptr;
+    uint8_t* pin = nullptr; // pinned host mirror of the arena: inputs are staged here and go up in ONE transfer
     size_t cap = 0, off = 0, want = 0;
 };
 thread_local Arena g_arena[16];
@@ -952,18 +953,23 @@ thread_local Arena g_arena[16];
 struct Scratch { // device allocations of one call
     Arena* ar = nullptr;
     std::vector<void*> overflow;
+    std::vector<std::pair<size_t, size_t>> staged; // (offset, bytes) runs waiting in the pinned mirror
     explicit Scratch(int device)
     {
         ar = &g_arena[device & 15];
         if (ar->want > ar->cap) { // grow between calls
             if (ar->base) (void)hipFree(ar->base);
-            ar->base = nullptr;
+            if (ar->pin) (void)hipHostFree(ar->pin);
+            ar->base = ar->pin = nullptr;
             ar->cap = 0;
             void* p = nullptr;
             const size_t want = std::max<size_t>(ar->want * 2, 1 << 20);
             if (hipMalloc(&p, want) == hipSuccess) {
                 ar->base = (uint8_t*)p;
                 ar->cap = want;
+                void* h = nullptr;
+                if (hipHostMalloc(&h, want) == hipSuccess) ar->pin = (uint8_t*)h;
+                else (void)hipGetLastError();
             }
         }
         ar->off = 0;
@@ -980,36 +986,62 @@ struct Scratch { // device allocations of one call
         const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
         void* p = nullptr;
         ar->want += bytes;
+        bool inArena = false;
+        size_t at = 0;
         if (ar->base && ar->off + bytes <= ar->cap) {
+            at = ar->off;
             p = ar->base + ar->off;
             ar->off += bytes;
+            inArena = true;
         } else {
             hipError_t e = hipMalloc(&p, bytes);
             if (e != hipSuccess) return -(1000 + (int)e);
             overflow.push_back(p);
         }
         if (host && n) {
-            hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, 0);
-            if (e != hipSuccess) return -(1000 + (int)e);
+            if (inArena && ar->pin) { // stage; adjacent uploads merge into one run
+                std::memcpy(ar->pin + at, host, n * sizeof(T));
+                if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
+                else staged.emplace_back(at, bytes);
+            } else {
+                hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, 0);
+                if (e != hipSuccess) return -(1000 + (int)e);
+            }
         }
         *out = (T*)p;
         return 0;
     }
+    // send the staged inputs (called before the first kernel of the call, by KernelScope)
+    int flush()
+    {
+        for (const auto& r : staged) {
+            hipError_t e = hipMemcpyAsync(ar->base + r.first, ar->pin + r.first, r.second, hipMemcpyHostToDevice, 0);
+            if (e != hipSuccess) return -(1000 + (int)e);
+        }
+        staged.clear();
+        return 0;
+    }
 };
 
-// device time of the last matcher kernel launched by this thread (hipEvents around the launch)
 thread_local float g_lastKernelMs = -1.f;
 thread_local int g_lastProjSweeps = 0;
+thread_local bool g_timeKernels = false; // orbfe_matcher_time_kernels(): bench / tests only
+// Brackets the kernel launches of one call: uploads the staged inputs first; with timing enabled also measures the
+// launches with events (two event creations and a synchronisation per call, so off by default).
 struct KernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
-    KernelTimer()
+    explicit KernelTimer(Scratch& s)
     {
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, 0);
+        (void)s.flush();
+        if (g_timeKernels) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, 0);
+        }
     }
     ~KernelTimer()
     {
+        if (!a) return;
         (void)hipEventRecord(b, 0);
         (void)hipEventSynchronize(b);
         float ms = -1.f;
@@ -1123,7 +1155,7 @@ int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, 
     if ((r = s.up(&dB, B, (size_t)nB * 32)) < 0) return r;
     if ((r = s.up<uint16_t>(&dD, nullptr, (size_t)nA * nB)) < 0) return r;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
     hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, 0, dA,
                        nA, dB, nB, dD);
     }
@@ -1146,7 +1178,7 @@ int orbfe_bfknn2(int device, const uint8_t* Q, int nQ, const uint8_t* T, int nT,
     if ((r = s.up<int32_t>(&dI, nullptr, (size_t)nQ * 2)) < 0) return r;
     if ((r = s.up<int32_t>(&dD, nullptr, (size_t)nQ * 2)) < 0) return r;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
     hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, 0, dQ, nQ, dT, nT, dI, dD);
     }
     HIP_TRY(hipGetLastError());
@@ -1241,7 +1273,7 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, 0));
     HIP_TRY(hipMemsetAsync(taken, 0, (size_t)rows, 0));
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, 0, dN, (int)nodes.size(),
                            dP, dDesc, dMask, dAng, dInd, dM, dB, taken);
     }
@@ -1312,7 +1344,7 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
     HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), 0));
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
     hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, dR, (int)rows.size(), d1,
                        k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM);
     }
@@ -1385,7 +1417,7 @@ int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* 
     if ((r = s.up<float>(&dDepth, nullptr, (size_t)nL)) < 0) return r;
     if ((r = s.up<float>(&dX, nullptr, (size_t)nL * 3)) < 0) return r;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
         hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, 0, dQ, nL, dT, nR, dI, dD);
         hipLaunchKernelGGL(k_fisheye_stereo, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, 0, dI, dD, nL, nR, dKL, dKR, dOL,
                            dOR, dP1, dP2, dR, dt, dSig, dL2R, dDepth, dX);
@@ -1469,7 +1501,7 @@ int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* m
     std::vector<int32_t> out(4 + nq);
     for (int attempt = 0;; attempt++) {
         {
-            KernelTimer timer;
+            KernelTimer timer(s);
             hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
             hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, 0, P);
             hipLaunchKernelGGL(k_init_sweeps, dim3(1), dim3(PROJ_THREADS), 0, 0, I);
@@ -1590,7 +1622,7 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
     T.epx = a->ep[0]; T.epy = a->ep[1]; T.sf2 = sf; T.sig1 = sg1; T.sig2 = sg2;
     T.onlyStereo = a->only_stereo; T.coarse = a->coarse; T.match12 = dM;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri_kb8, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, T);
     }
     HIP_TRY(hipGetLastError());
@@ -1639,8 +1671,11 @@ int orbfe_kb8_triangulate(int device, const float* params1, const float* params2
     if ((r = s.up<float>(&dZ, nullptr, (size_t)n)) < 0) return r;
     float* dX = nullptr;
     if (p3D && (r = s.up<float>(&dX, nullptr, (size_t)3 * n)) < 0) return r;
-    hipLaunchKernelGGL(k_kb8_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP1, dP2, dK1, dK2, dR, dT, dS1,
-                       dS2, n, dZ, dX);
+    {
+        KernelTimer timer(s);
+        hipLaunchKernelGGL(k_kb8_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP1, dP2, dK1, dK2, dR, dT,
+                           dS1, dS2, n, dZ, dX);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(z1, dZ, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     if (p3D) HIP_TRY(hipMemcpy(p3D, dX, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1737,7 +1772,7 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     std::vector<int32_t> out(4 + nq + n);
     for (int attempt = 0;; attempt++) {
         {
-            KernelTimer timer;
+            KernelTimer timer(s);
             hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
             hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, 0, P);
             hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
@@ -1798,7 +1833,7 @@ int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t
     if ((r = s.up(&dO, offsets, (size_t)npts + 1)) < 0) return r;
     if ((r = s.up<int32_t>(&dB, nullptr, (size_t)npts)) < 0) return r;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
         hipLaunchKernelGGL(k_distinctive, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, 0, dP, dO, npts, dB);
     }
     HIP_TRY(hipGetLastError());
@@ -1807,6 +1842,7 @@ int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t
 }
 
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
+void orbfe_matcher_time_kernels(int on) { g_timeKernels = on != 0; }
 
 struct orbfe_vocab_dev {
     int device, nnodes, L;
@@ -1878,7 +1914,7 @@ int orbfe_vocab_transform(orbfe_vocab_dev* d, const uint8_t* feats, int n, int l
     if ((r = s.up<int32_t>(&dN, nullptr, (size_t)n)) < 0) return r;
     if ((r = s.up<double>(&dWt, nullptr, (size_t)n)) < 0) return r;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
         hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, 0, d->desc, d->childOff,
                            d->childIds, d->word, d->weight, d->L, dF, n, levelsup, dW, dN, dWt);
     }
@@ -1901,7 +1937,7 @@ int orbfe_kb8_unproject(int device, const float* P, const float* uv, int n, floa
     if ((r = s.up(&dU, uv, (size_t)n * 2)) < 0) return r;
     if ((r = s.up<float>(&dR, nullptr, (size_t)n * 3)) < 0) return r;
     {
-        KernelTimer timer;
+        KernelTimer timer(s);
     hipLaunchKernelGGL(k_kb8_unproject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP, dU, n, dR);
     }
     HIP_TRY(hipGetLastError());
