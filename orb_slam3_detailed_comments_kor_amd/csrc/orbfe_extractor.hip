@@ -1067,45 +1067,35 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     for (int i = 0; i < nimg; i++)
         HIP_TRY(hipMemcpy2DAsync(c->d_img.p + (size_t)i * c->imgStride, c->imgPitch, imgs[i], stride, (size_t)cols,
                                  (size_t)rows, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // no synchronisation here: the kernels are ordered after the copies on the stream, and both `lapv` and the
+    // caller's images outlive this call
     r = run_device(c, nimg, c->d_img.p, rows, cols, c->imgPitch, c->imgStride, c->d_lap.p, c->d_kps.p, c->d_desc.p,
                    cap_per_img, c->d_n.p, c->d_mono.p);
     if (r < 0) return r;
+    // ONE round trip for everything the host needs: counts, the error word, and the keypoint / descriptor slabs of
+    // all images into pinned staging (per-image copies sized by the counts would need a second synchronisation, and
+    // 2 x nimg small copies cost more than the slack of the slabs); then the rows each image produced are copied out
+    const size_t Kc = (size_t)cap_per_img;
+    if ((r = c->h_kps.ensure((size_t)nimg * Kc * 7)) < 0) return r;
+    if ((r = c->h_desc.ensure((size_t)nimg * Kc * 32)) < 0) return r;
+    if ((r = c->h_fix.ensure(1)) < 0) return r;
     HIP_TRY(hipMemcpyAsync(c->h_n.p, c->d_n.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(c->h_mono.p, c->d_mono.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!c->lastHostTrigCheck) // otherwise run_device has already looked at the error word
+        HIP_TRY(hipMemcpyAsync(c->h_fix.p, c->d_fix.p, sizeof(int4), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_kps.p, c->d_kps.p, (size_t)nimg * Kc * 28, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_desc.p, c->d_desc.p, (size_t)nimg * Kc * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (!c->lastHostTrigCheck) { // otherwise run_device has already looked at the error word
-        int32_t err = 0;
-        HIP_TRY(hipMemcpy(&err, reinterpret_cast<int32_t*>(c->d_fix.p) + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (err) return ORBFE_ERR_STATE;
-    }
-    // two slab downloads into pinned staging (128 small copies cost ~1 ms for 64 images), then the
-    // rows each image actually produced are copied out
-    int nmax = 0;
-    for (int i = 0; i < nimg; i++) nmax = std::max(nmax, c->h_n.p[i]);
-    if (nimg > 1 && nmax > 0) {
-        const size_t K = (size_t)cap_per_img;
-        if ((r = c->h_kps.ensure((size_t)nimg * K * 7)) < 0) return r;
-        if ((r = c->h_desc.ensure((size_t)nimg * K * 32)) < 0) return r;
-        HIP_TRY(hipMemcpyAsync(c->h_kps.p, c->d_kps.p, (size_t)nimg * K * 28, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(c->h_desc.p, c->d_desc.p, (size_t)nimg * K * 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
+    if (!c->lastHostTrigCheck && c->h_fix.p[0].y != 0) return ORBFE_ERR_STATE;
     for (int i = 0; i < nimg; i++) {
         const int n = c->h_n.p[i];
         n_out[i] = n;
         if (mono_out) mono_out[i] = c->h_mono.p[i];
         if (n <= 0) continue;
-        if (nimg > 1) {
-            std::memcpy((uint8_t*)kps + (size_t)i * cap_per_img * sizeof(orbfe_kp),
-                        c->h_kps.p + (size_t)i * cap_per_img * 7, (size_t)n * sizeof(orbfe_kp));
-            std::memcpy(desc + (size_t)i * cap_per_img * 32, c->h_desc.p + (size_t)i * cap_per_img * 32, (size_t)n * 32);
-        } else {
-            HIP_TRY(hipMemcpyAsync((uint8_t*)kps, c->d_kps.p, (size_t)n * sizeof(orbfe_kp), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(desc, c->d_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-        }
+        std::memcpy((uint8_t*)kps + (size_t)i * Kc * sizeof(orbfe_kp), c->h_kps.p + (size_t)i * Kc * 7,
+                    (size_t)n * sizeof(orbfe_kp));
+        std::memcpy(desc + (size_t)i * Kc * 32, c->h_desc.p + (size_t)i * Kc * 32, (size_t)n * 32);
     }
-    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
