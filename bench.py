@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--trig", choices=["libm", "cr", "hostcheck"], default="libm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=6,
                     help="record the per-stage hipEvents on every N-th timed step (7 event records cost ~25 us)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-context measurement")
     ap.add_argument("--contexts", type=int, default=1,

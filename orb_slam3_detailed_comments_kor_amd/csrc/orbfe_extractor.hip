@@ -115,7 +115,7 @@ struct orbfe_ctx {
     int nCells = 0, maxKp = 0, maxListCap = 0;
     size_t qtLdsBytes = 0;
     int qtKeyOff = 0, qtKeyCap = 0;
-    int fastPitch = 0, fastRows = 0, fastThreads = 256, fastKqOff = 0, fastCqOff = 0;
+    int fastPitch = 0, fastRows = 0, fastThreads = 256;
     uint32_t fastRecipP = 0;
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
@@ -346,8 +346,6 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         }
         c->fastPitch = (int)align_up((size_t)maxCw + 3, 4) + 4; // + one dword: phase A reads d+1
         c->fastRows = maxCh;
-        c->fastKqOff = (int)align_up((size_t)2 * c->fastRows * c->fastPitch + 2 * (size_t)std::max(maxZone, 1), 16);
-        c->fastCqOff = 0;
         // the survivor list of the NMS (4 B per slot) lives in the tile area after phase B
         // (4 * slotCap <= zone area < tile area, so it always fits)
         if (4 * (size_t)maxSlots > (size_t)c->fastRows * c->fastPitch) return ORBFE_ERR_ARGS;
@@ -758,7 +756,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
 #define ORBFE_FAST_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
                        c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0, c->fastKqOff, c->fastRecipP, c->fastCqOff)
+                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0, c->fastRecipP)
             if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
             else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
             else ORBFE_FAST_LAUNCH(256);

@@ -375,28 +375,6 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
     return max(bright, -darkNeg) - 1;
 }
 
-typedef short fast_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ fast_s2 fast_unpack_lo(uint32_t x) // bytes 0,1 -> two i16
-{
-    const uint32_t r = __builtin_amdgcn_perm(0u, x, 0x0C010C00u);
-    return *reinterpret_cast<const fast_s2*>(&r);
-}
-__device__ __forceinline__ fast_s2 fast_unpack_hi(uint32_t x) // bytes 2,3 -> two i16
-{
-    const uint32_t r = __builtin_amdgcn_perm(0u, x, 0x0C030C02u);
-    return *reinterpret_cast<const fast_s2*>(&r);
-}
-// sign bits (15, 31) set where the pixel survives the (0,8)&(4,12) opposite-pair test at threshold t
-__device__ __forceinline__ uint32_t fast_pass_pair(fast_s2 v, fast_s2 r0, fast_s2 r8, fast_s2 r4, fast_s2 r12, int t)
-{
-    const fast_s2 tt = {(short)t, (short)t};
-    const fast_s2 hi = v + tt, lo = v - tt;
-    const fast_s2 bmin = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
-    const fast_s2 dmax = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
-    const fast_s2 o = (hi - bmin) | (dmax - lo);
-    return *reinterpret_cast<const uint32_t*>(&o) & 0x80008000u;
-}
-
 // One LDS atomic per LANE (ds_add_rtn_u32 on a wave-uniform address, values differ per lane).  Written as
 // inline asm because the compiler's atomic optimizer would otherwise turn it into a scalar loop over the
 // active lanes (readlane / writelane per lane), which costs far more than the LDS serialising the adds.
@@ -419,19 +397,19 @@ __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (in
 //
 // The ROI is staged as aligned dwords (tile column 0 = level column iniX & ~3, ROI rows of the
 // pyramid are 64-B aligned), phase A tests 4 pixels per lane from 5 dword LDS reads, phase B
-// scores the queued survivors with all lanes busy, phase C does NMS + threshold choice + ordered
-// compaction with one block-wide scan.
+// scores the queued survivors with all lanes busy, phase C does the NMS on the corners only; the
+// survivors are ranked by position for the ordered output.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                    const OrbLevelGeom* __restrict__ lg,
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
-                                                   int tileRows, int xcdGroup, int dbgStop, int imgBase, int kqOff,
-                                                   unsigned mP /* ceil(2^32 / P) */, int cqOff)
+                                                   int tileRows, int xcdGroup, int dbgStop, int imgBase,
+                                                   unsigned mP /* ceil(2^32 / P) */)
 {
-    // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[max zone] u16 | kq[max slotCap] u32 -- sized by the
-    // host from the largest cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
+    // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[max zone] u16 -- sized by the host from the largest
+    // cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
     const int PD = P >> 2;
     uint8_t* tile = fast_lds;
@@ -442,8 +420,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     // from the front, the NMS survivors (pos | score<<16) overwrite the tile once phase B is done.
     uint32_t* kq = reinterpret_cast<uint32_t*>(tile);
     uint16_t* cq = queue;
-    (void)kqOff;
-    (void)cqOff;
     __shared__ int qn, cn, kn;
 
     const int tid = threadIdx.x, lane = tid & 63;
