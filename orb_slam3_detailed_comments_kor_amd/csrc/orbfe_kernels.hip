@@ -1379,36 +1379,29 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R + 1 < L.w && w.y + DESC_R < L.h;
     if (inside) {
         const uint8_t* p0 = roi + (size_t)(w.y - DESC_R) * L.pitch + (w.x - DESC_R);
-        // 473 dwords = 8 per lane, all loads in flight before the first LDS store; global dword
-        // loads may be unaligned (the patch origin is arbitrary)
+        // 473 dwords = 8 per lane (item idx = 11 * row + dword = lane + 64 k), all loads in flight before the first
+        // LDS store; global dword loads may be unaligned (the patch origin is arbitrary).  The LDS patch has 11
+        // dwords per row, so its byte offset is simply 4 * idx; the global offset advances by 5 rows + 9 dwords, or
+        // 6 rows - 2 dwords when the dword index wraps.
         uint32_t v[8];
-        const int r0 = lane / 11, c0 = lane - 11 * (lane / 11); // item = (row, dword); +64 items = +5 rows +9 dwords
         {
-            int r = r0, c4 = c0;
+            int c4 = lane - 11 * (lane / 11);
+            int off = (lane / 11) * L.pitch + 4 * c4;
+            const int stepA = 5 * L.pitch + 36, stepB = 6 * L.pitch - 8;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int rr = min(r, DESC_RAW - 1);
-                __builtin_memcpy(&v[k], p0 + (size_t)rr * L.pitch + 4 * c4, 4);
-                r += 5;
-                c4 += 9;
-                if (c4 >= 11) {
-                    c4 -= 11;
-                    r += 1;
-                }
+                const bool valid = lane + 64 * k < DESC_RAW * 11; // only the last round has lanes past the patch
+                __builtin_memcpy(&v[k], p0 + (valid ? off : 0), 4);
+                const bool wrap = c4 >= 2;
+                off += wrap ? stepB : stepA;
+                c4 += wrap ? -2 : 9;
             }
         }
         {
-            int r = r0, c4 = c0;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(raw) + lane;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (r < DESC_RAW) *reinterpret_cast<uint32_t*>(raw + r * DESC_RAWP + 4 * c4) = v[k];
-                r += 5;
-                c4 += 9;
-                if (c4 >= 11) {
-                    c4 -= 11;
-                    r += 1;
-                }
-            }
+            for (int k = 0; k < 8; k++)
+                if (lane + 64 * k < DESC_RAW * 11) dst[64 * k] = v[k];
         }
     } else { // BORDER_REFLECT_101 at the level edges (keypoints within 21 px of an edge)
         for (int idx = lane; idx < DESC_RAW * DESC_RAW; idx += 64) {
