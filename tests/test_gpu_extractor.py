@@ -268,10 +268,10 @@ def test_alternative_gaussian_taps(pkg, oracle):
 
 
 def test_device_resident_batch_and_full_size_properties(pkg, oracle):
-    """BASELINE config sizes through the device-pointer entry point: 16 x 1280x720 frames.
-    Size-independent properties + spot parity on two frames."""
+    """BASELINE configs[3] through the device-pointer entry point: a batch of 64 x 1280x720 frames.
+    Size-independent properties + spot parity on three frames."""
     import torch
-    B, H, W = 16, 720, 1280
+    B, H, W = 64, 720, 1280
     base = [_frame(pkg, H, W, 900 + i) for i in range(4)]
     imgs = np.stack([np.roll(base[i % 4], 17 * (i // 4), axis=1) for i in range(B)])
     ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
@@ -309,7 +309,7 @@ def test_device_resident_batch_and_full_size_properties(pkg, oracle):
         assert torch.equal(d_kps[i, : n[i]].view(torch.int32), d_kps2[i, : n[i]].view(torch.int32))
         assert torch.equal(d_desc[i, : n[i]], d_desc2[i, : n[i]])
     ref = oracle.Extractor(1000, 1.2, 8, 20, 7)
-    for i in (0, 9):
+    for i in (0, 9, 63):
         rmono, rkps, rdesc = ref.extract(imgs[i], (0, 0))
         got = np.zeros(n[i], pkg.KP_DTYPE)
         raw = kps[i, : n[i]]
