@@ -30,6 +30,13 @@ CASES = [  # (name, rows, cols, seed, nfeatures, lap)
 ]
 
 
+WINDOW_CASES = [("proj_local_map", dict(seed=7101, mode=0, n=600, nq=500)),
+                ("proj_last_frame", dict(seed=7102, mode=1, n=600, nq=500, th=7.0, check_orientation=True)),
+                ("proj_rig", dict(seed=7103, mode=0, n=640, nq=520, Nleft=350, partners=True, th=3.0)),
+                ("fuse_stereo", dict(seed=7104, mode=1, n=600, nq=500, th=3.0, loop="fuse", stereo=True)),
+                ("sim3_projection", dict(seed=7105, mode=1, n=600, nq=500, th=4.0, loop="sim3_projection", taken_frac=0.3))]
+
+
 def main():
     for name, rows, cols, seed, nf, lap in CASES:
         img = synth.make_frame(rows, cols, seed)
@@ -54,6 +61,21 @@ def main():
     np.savez_compressed(os.path.join(HERE, "matcher_400x380.npz"), bow_n=np.int32(n), bow_match=m, knn_idx=idx,
                         knn_dist=dist, d1_sha256=np.frombuffer(hashlib.sha256(d1.tobytes()).digest(), np.uint8))
     print("matcher", n)
+    # window searches (SearchByProjection modes, Fuse, SearchForInitialization, SearchForTriangulation_)
+    out = {}
+    for tag, kw in WINDOW_CASES:
+        pr = MI.projection_problem(**kw)
+        n, qm, fm = O.search_projection(pr)
+        out[tag + "_n"], out[tag + "_q"], out[tag + "_f"] = np.int32(n), qm, fm
+    pr = MI.initialization_problem(7001, n1=700, n2=650)
+    n, m = O.search_initialization(pr)
+    out["init_n"], out["init_m"] = np.int32(n), m
+    I = MI.tri_inputs(1100, 1000, 30)
+    out["tri_pairs"] = O.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"], I["d2"],
+                                              I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"], I["F12"], I["ep"],
+                                              I["sf"], I["sig"], False, True, True)
+    np.savez_compressed(os.path.join(HERE, "matcher_window_searches.npz"), **out)
+    print("window searches", {k: int(v) for k, v in out.items() if k.endswith("_n")}, len(out["tri_pairs"]))
 
 
 if __name__ == "__main__":
