@@ -52,6 +52,10 @@ typedef struct {
 int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
                  int device /* HIP device ordinal */);
 void orbfe_destroy(orbfe_ctx*);
+/* Frees what the library keeps per process and device beyond the contexts: the libm trig table (1.03 GB or 65 MB,
+ * see orbfe_set_trig_mode).  It is rebuilt by the next ORBFE_TRIG_LIBM extraction.  No extraction may be in flight
+ * on that device. */
+int orbfe_release_caches(int device);
 
 /* Run on an existing hipStream_t (e.g. the caller's torch stream); NULL = context-owned stream. */
 int orbfe_set_stream(orbfe_ctx*, void* hip_stream);

@@ -211,7 +211,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -416,6 +416,11 @@ def _fv(fv):
     indices = np.ascontiguousarray(indices, np.int32)
     s = _FV(len(node_ids), node_ids.ctypes.data, offsets.ctypes.data, indices.ctypes.data)
     return s, (node_ids, offsets, indices)
+
+
+def release_caches(device=0):
+    """Frees the per-process libm trig table of `device` (rebuilt on the next ORBFE_TRIG_LIBM extraction)."""
+    _chk(lib().orbfe_release_caches(device), "orbfe_release_caches")
 
 
 def matcher_last_kernel_ms():

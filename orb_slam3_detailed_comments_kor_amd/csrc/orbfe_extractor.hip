@@ -918,6 +918,21 @@ void orbfe_destroy(orbfe_ctx* c)
     delete c;
 }
 
+int orbfe_release_caches(int device)
+{
+    if (device < 0 || device >= 16) return ORBFE_ERR_ARGS;
+    std::lock_guard<std::mutex> lock(g_trigMutex);
+    TrigTable& t = g_trig[device];
+    if (t.d || t.full) {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipDeviceSynchronize()); // a kernel of some context may still be reading the table
+        if (t.d) (void)hipFree(t.d);
+        if (t.full) (void)hipFree(t.full);
+    }
+    t = TrigTable(); // built again by the next ORBFE_TRIG_LIBM extraction
+    return 0;
+}
+
 int orbfe_set_stream(orbfe_ctx* c, void* hip_stream)
 {
     if (!c) return ORBFE_ERR_ARGS;

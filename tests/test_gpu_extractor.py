@@ -144,6 +144,20 @@ def test_libm_table_reproduces_host_libm_bit_for_bit(pkg, oracle):
     exc.close()
 
 
+def test_release_caches_and_rebuild(pkg, oracle):
+    # the libm table can be dropped and is rebuilt transparently; results are unchanged
+    img = _frame(pkg, 240, 376, 555)
+    ex = pkg.ORBextractor(400, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(400, 1.2, 8, 20, 7)
+    rmono, rkps, rdesc = ref.extract(img, (0, 0))
+    for _ in range(2):
+        mono, kps, desc = ex(img, (0, 0))
+        assert mono == rmono
+        _same(kps, rkps, desc, rdesc)
+        pkg.binding.release_caches(0)
+    ex.close()
+
+
 def test_compact_libm_table_in_a_fresh_process():
     # the 65-MB code table (ORBFE_TRIG_TABLE=1; the default is the 1-GB table of libm values) is chosen once per
     # process, so the same two checks run again in a child process: libm bit for bit, and a full extraction
