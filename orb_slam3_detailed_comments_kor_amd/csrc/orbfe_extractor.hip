@@ -119,7 +119,8 @@ struct orbfe_ctx {
     uint32_t fastRecipP = 0;
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
-    int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning)
+    int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning; 0 = whole images per XCD always)
+    bool fastByImage = true;     // ORBFE_FAST_BY_IMAGE=0 keeps the grouped order for every batch size
     int nStreams = 1;            // ORBFE_STREAMS env / orbfe_set_streams: sub-batches on separate streams
     hipStream_t sub[8] = {};
     hipEvent_t evFork = nullptr, evJoin[8] = {};
@@ -735,7 +736,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                c->pyrLdsBytes, q, d_imgs,
                                pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p,
                                c->pyrNtx, c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
-                               cols, i0, kernelClearsHdr ? d_hdr : nullptr);
+                               cols, i0, kernelClearsHdr ? d_hdr : nullptr, (c->xcdAffine && ni % 8 == 0) ? 1 : 0);
         } else {
             const OrbLevelGeom& L0 = c->lg[0];
             dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);
@@ -751,12 +752,17 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nsub == 1) rec(c, 1);
         // K-FAST
         {
-            const int G = c->fastXcdGroup;
-            const dim3 grid((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)ni); // whole groups per XCD
+            // whole images per XCD when the batch fills the 8 XCDs evenly enough (<= 1/8 idle), else groups of
+            // G neighbouring cells per XCD
+            const int perXcd = (ni + 7) / 8;
+            const bool byImage = c->fastXcdGroup <= 0 ? true : (c->xcdAffine && c->fastByImage && ni >= 8 && perXcd * 8 - ni <= ni / 8);
+            const int G = byImage ? 0 : std::max(1, c->fastXcdGroup);
+            const dim3 grid = byImage ? dim3((unsigned)(8 * c->nCells * perXcd), 1u)
+                                      : dim3((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)ni);
 #define ORBFE_FAST_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
                        c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0, c->fastRecipP)
+                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0, c->fastRecipP, ni)
             if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
             else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
             else ORBFE_FAST_LAUNCH(256);
@@ -875,7 +881,8 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     c->device = device;
     init_tables(c);
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
-    if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(1, atoi(e));
+    if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(0, atoi(e));
+    if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_FAST_STOP")) c->fastDbgStop = atoi(e);
     if (const char* e = getenv("ORBFE_XCD_AFFINE")) c->xcdAffine = atoi(e);
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                                                    const OrbResizeX* __restrict__ xtab,
                                                    const OrbResizeY* __restrict__ ytab, int bufBytes0,
                                                    int bufBytes1, int stageX, int imgCols, int imgBase,
-                                                   int32_t* __restrict__ clearHdr /* 4 words or nullptr */)
+                                                   int32_t* __restrict__ clearHdr /* 4 words or nullptr */,
+                                                   int xcdAffine)
 {
     // first kernel of a batch: clear the {fragile count, error flag, -, -} header the later kernels append to
     if (clearHdr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < 4) clearHdr[threadIdx.x] = 0;
@@ -121,7 +122,17 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     uint2* xt = reinterpret_cast<uint2*>(pyr_lds + bufBytes0 + bufBytes1);
     uint2* yt = xt + stageX;
     const int tid = threadIdx.x;
-    const int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z + imgBase;
+    int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z;
+    if (xcdAffine) {
+        // whole images per XCD (the batch is a multiple of 8): the halo columns and rows neighbouring tiles
+        // re-read, and the partial lines they write side by side, then meet in ONE L2
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, k = lin >> 3;
+        const unsigned perImg = gridDim.x * gridDim.y, j = k / perImg, t = k - j * perImg;
+        img = (int)(8u * j + (lin & 7u));
+        tj = (int)(t / gridDim.x);
+        ti = (int)(t - (unsigned)tj * gridDim.x);
+    }
+    img += imgBase;
     uint8_t* base = pyr + (size_t)img * pyrImgStride;
 
     // per-level parameters once into LDS (one round of global loads instead of a dependent scalar
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
                                                    int tileRows, int xcdGroup, int dbgStop, int imgBase,
-                                                   unsigned mP /* ceil(2^32 / P) */)
+                                                   unsigned mP /* ceil(2^32 / P) */, int nImg)
 {
     // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[max zone] u16 -- sized by the host from the largest
     // cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
@@ -430,10 +441,23 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     // stay round-robin so that every XCD sees cells from all over the image (a contiguous chunk per
     // XCD cut the fetched bytes 3.6x but lost 25% to load imbalance: busy and flat regions are
     // spatially correlated).
+    // xcdGroup == 0 (batches that fill all XCDs evenly): WHOLE IMAGES per XCD -- image xcd + 8 j is the
+    // j-th image of its XCD, cells in level order -- so that every 128-B line of a pyramid is fetched into
+    // one L2 only, once (a group of four 35-px cells spans 146 B of a row = 2.1 lines: the grouped order
+    // fetches twice the bytes it uses); all XCDs then see statistically equal work.
     const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
-    const int cell = ((slot / xcdGroup) * 8 + xcd) * xcdGroup + slot % xcdGroup;
-    const int img = (int)blockIdx.y + imgBase;
-    if (cell >= nCellsTotal) return;
+    int cell, img;
+    if (xcdGroup == 0) {
+        const int j = slot / nCellsTotal;
+        cell = slot - j * nCellsTotal;
+        img = xcd + 8 * j;
+        if (img >= nImg) return;
+        img += imgBase;
+    } else {
+        cell = ((slot / xcdGroup) * 8 + xcd) * xcdGroup + slot % xcdGroup;
+        img = (int)blockIdx.y + imgBase;
+        if (cell >= nCellsTotal) return;
+    }
     const OrbCellGeom c = cg[cell];
     (void)lg;
     const int cw = c.cw, ch = c.ch;
