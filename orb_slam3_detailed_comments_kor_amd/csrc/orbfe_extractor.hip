@@ -350,7 +350,10 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         // the survivor list of the NMS (4 B per slot) lives in the tile area after phase B
         // (4 * slotCap <= zone area < tile area, so it always fits)
         if (4 * (size_t)maxSlots > (size_t)c->fastRows * c->fastPitch) return ORBFE_ERR_ARGS;
-        c->fastLdsBytes = align_up((size_t)2 * c->fastRows * c->fastPitch + 2 * (size_t)std::max(maxZone, 1), 16);
+        // survivor queue (2 B per zone pixel); the output ranking reuses it for a position bitmap + its prefix sums
+        // (2 x 4 B per 32 tile pixels)
+        const size_t rankBytes = 8 * (((size_t)c->fastRows * c->fastPitch + 31) / 32);
+        c->fastLdsBytes = align_up((size_t)2 * c->fastRows * c->fastPitch + std::max(2 * (size_t)std::max(maxZone, 1), rankBytes), 16);
         c->fastRecipP = (uint32_t)(((1ull << 32) + c->fastPitch - 1) / (uint64_t)c->fastPitch);
         int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
         if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)

@@ -349,41 +349,77 @@ __global__ __launch_bounds__(256) void k_border(uint8_t* __restrict__ pyr, size_
 // ----------------------------------------------------------------- K-FAST
 // FAST-9/16 corner score = largest threshold for which the pixel is still a corner
 // (cv::cornerScore<16>): max over the 16 arcs of 9 of min(r-v) and of min(v-r), minus 1.
+// Every arc of 9 is {r[k]} + W or W + {r[k+9]} for one of the eight 8-windows W = r[k+1..k+8] with even k, and
+// max(min(W, r[k]), min(W, r[k+9])) = min(W, max(r[k], r[k+9])): eight window minima by doubling (24 two-input
+// minima), then three operations per window -- 47 per polarity instead of 16 + 16 three-input minima plus the
+// reduction.  All of it on the raw 8-bit values (v is subtracted from the two results only) with the NON-packed
+// 16-bit min/max, which issue at the fast rate on gfx950 (2.7 cycles per wave, tools/valu_rate.hip; v_min3_i32,
+// v_min_i32 and the packed forms take 4.5).
+__device__ __forceinline__ uint32_t min16(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t max16(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
 {
     const int v = c[0];
-    int d[16];
-    d[0] = c[3 * P + 0] - v;
-    d[1] = c[3 * P + 1] - v;
-    d[2] = c[2 * P + 2] - v;
-    d[3] = c[1 * P + 3] - v;
-    d[4] = c[0 * P + 3] - v;
-    d[5] = c[-1 * P + 3] - v;
-    d[6] = c[-2 * P + 2] - v;
-    d[7] = c[-3 * P + 1] - v;
-    d[8] = c[-3 * P + 0] - v;
-    d[9] = c[-3 * P - 1] - v;
-    d[10] = c[-2 * P - 2] - v;
-    d[11] = c[-1 * P - 3] - v;
-    d[12] = c[0 * P - 3] - v;
-    d[13] = c[1 * P - 3] - v;
-    d[14] = c[2 * P - 2] - v;
-    d[15] = c[3 * P - 1] - v;
-    int mn3[16], mx3[16];
+    uint32_t r[16];
+    r[0] = c[3 * P + 0];
+    r[1] = c[3 * P + 1];
+    r[2] = c[2 * P + 2];
+    r[3] = c[1 * P + 3];
+    r[4] = c[0 * P + 3];
+    r[5] = c[-1 * P + 3];
+    r[6] = c[-2 * P + 2];
+    r[7] = c[-3 * P + 1];
+    r[8] = c[-3 * P + 0];
+    r[9] = c[-3 * P - 1];
+    r[10] = c[-2 * P - 2];
+    r[11] = c[-1 * P - 3];
+    r[12] = c[0 * P - 3];
+    r[13] = c[1 * P - 3];
+    r[14] = c[2 * P - 2];
+    r[15] = c[3 * P - 1];
+    uint32_t lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    for (int j = 0; j < 8; j++) { // r[2j+1], r[2j+2]
+        lo2[j] = min16(r[2 * j + 1], r[(2 * j + 2) & 15]);
+        hi2[j] = max16(r[2 * j + 1], r[(2 * j + 2) & 15]);
     }
-    int bright = -255, darkNeg = 255;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
-        const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
-        bright = max(bright, mn9);
-        darkNeg = min(darkNeg, mx9);
+    for (int j = 0; j < 8; j++) { // r[2j+1 .. 2j+4]
+        lo4[j] = min16(lo2[j], lo2[(j + 1) & 7]);
+        hi4[j] = max16(hi2[j], hi2[(j + 1) & 7]);
     }
-    return max(bright, -darkNeg) - 1;
+    uint32_t bright = 0, dark = 255; // max over arcs of the arc minimum / min over arcs of the arc maximum
+#pragma unroll
+    for (int j = 0; j < 8; j++) { // window r[2j+1 .. 2j+8], arcs starting at 2j and 2j+1
+        const uint32_t lo8 = min16(lo4[j], lo4[(j + 2) & 7]), hi8 = max16(hi4[j], hi4[(j + 2) & 7]);
+        const uint32_t a = r[2 * j], b = r[(2 * j + 9) & 15];
+        bright = max16(bright, min16(lo8, max16(a, b)));
+        dark = min16(dark, max16(hi8, min16(a, b)));
+    }
+    return max((int)bright - v, v - (int)dark) - 1;
+}
+
+// inclusive prefix sum over the 64 lanes with DPP (row shifts inside the 16-lane rows, row broadcasts across
+// them): six dependent VALU instructions instead of six ds_bpermute round trips through the LDS
+__device__ __forceinline__ int wave_incl_scan_i32(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); // row_bcast:31 into rows 2 and 3
+    return x;
 }
 
 // One LDS atomic per LANE (ds_add_rtn_u32 on a wave-uniform address, values differ per lane).  Written as
@@ -629,17 +665,41 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         __syncthreads();
     }
     if (dbgStop == 4) return;
-    // output: row-major = ascending pos, obtained by ranking the (few) survivors against each other
+    // output: row-major = ascending pos.  The rank of a survivor is the number of survivors before it: a bitmap
+    // of their positions (in the survivor queue's storage, dead by now) and a prefix sum over its words' popcounts
+    // give it in constant work per survivor instead of one comparison per pair.
     const int nk = kn;
     uint32_t* out = cand + (size_t)img * candImgStride + c.slotBase;
-    for (int i = tid; i < nk; i += NT) {
-        const uint32_t e = kq[i];
-        const uint32_t pos = e & 0xFFFFu;
-        int rank = 0;
-        for (int j = 0; j < nk; j++) rank += (kq[j] & 0xFFFFu) < pos;
-        const int y = fast_div(pos, mP), x = (int)pos - y * P; // tile coordinates
-        if (rank < c.slotCap)
-            out[rank] = (uint32_t)(x - ox + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((e >> 16) << 24);
+    if (nk > 0) {
+        uint32_t* bm = reinterpret_cast<uint32_t*>(queue);
+        const int nW = (ch * P + 31) >> 5; // positions are < ch * P
+        int* pre = reinterpret_cast<int*>(bm + nW);
+        for (int i = tid; i < nW; i += NT) bm[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < nk; i += NT) {
+            const uint32_t pos = kq[i] & 0xFFFFu;
+            atomicOr(&bm[pos >> 5], 1u << (pos & 31u));
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int carry = 0;
+            for (int base = 0; base < nW; base += 64) {
+                const int i = base + lane;
+                const int w = i < nW ? __popc(bm[i]) : 0;
+                const int x = wave_incl_scan_i32(w);
+                if (i < nW) pre[i] = x - w + carry;
+                carry += __builtin_amdgcn_readlane(x, 63);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nk; i += NT) {
+            const uint32_t e = kq[i];
+            const uint32_t pos = e & 0xFFFFu;
+            const int rank = pre[pos >> 5] + __popc(bm[pos >> 5] & ((1u << (pos & 31u)) - 1u));
+            const int y = fast_div(pos, mP), x = (int)pos - y * P; // tile coordinates
+            if (rank < c.slotCap)
+                out[rank] = (uint32_t)(x - ox + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((e >> 16) << 24);
+        }
     }
     if (tid == 0) cellCount[(size_t)img * nCellsTotal + cell] = min(nk, c.slotCap);
 }
@@ -653,19 +713,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 // exclusive scan of a[0..n) in LDS, in place; returns the total to every thread.
 // One barrier per 512-element chunk plus one at the end (every wave sums the <= 8 wave totals
 // itself; the totals are double buffered so that a chunk never overwrites values still being read).
-// inclusive prefix sum over the 64 lanes with DPP (row shifts inside the 16-lane rows, row broadcasts across
-// them): six dependent VALU instructions instead of six ds_bpermute round trips through the LDS
-__device__ __forceinline__ int wave_incl_scan_i32(int x)
-{
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); // row_bcast:31 into rows 2 and 3
-    return x;
-}
-
 // F maps the stored element to the value that is scanned (identity for a plain scan): lets a caller fold the
 // pass that would have prepared the scan input -- and its barrier -- into the scan itself.
 template <class F>

@@ -24,7 +24,8 @@ for case in range(ncases):
     lap = (int(rng.integers(0, W // 2)), int(rng.integers(W // 2, W + 200))) if rng.random() < 0.6 else (0, 0)
     trig = [pkg.binding.TRIG_LIBM, pkg.binding.TRIG_CR, pkg.binding.TRIG_LIBM_HOSTCHECK][case % 3]
     otrig = O.TRIG_CR if trig == pkg.binding.TRIG_CR else O.TRIG_LIBM
-    nb = int(rng.integers(1, 4))
+    # batches of >= 8 frames take the whole-images-per-XCD orders of K-PYR / K-FAST / K-DESC
+    nb = int(rng.choice([1, 2, 3, 8, 9, 16])) if H * W < 450000 else int(rng.integers(1, 4))
     kind = case % 4
     imgs = []
     for b in range(nb):
