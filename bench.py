@@ -107,8 +107,8 @@ def cpu_baseline(rows, cols, nfeatures, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=752)
@@ -262,6 +262,7 @@ def main():
         # separate --pmc runs and corrected with the FETCH_SIZE calibration), if they match this workload
         traffic = None
         valu_issue = None
+        per_kernel = {}
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
                      "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -269,6 +270,10 @@ def main():
             try:
                 j = json.load(open(pmc))
                 if j.get("workload") == {"batch": B, "rows": H, "cols": W, "nfeatures": args.nfeatures}:
+                    for st, kn in kernel_of.items():
+                        for k, e in j.get("kernels", {}).items():
+                            if k.startswith(kn) and "hbm_bytes_per_launch" in e:
+                                per_kernel[st] = e["hbm_bytes_per_launch"]
                     for k, e in j.get("kernels", {}).items():
                         if k.startswith(kernel_of[dom]) and "hbm_bytes_per_launch" in e:
                             traffic = e["hbm_bytes_per_launch"]
@@ -316,6 +321,17 @@ def main():
                 "event_sampling": "stage hipEvents on every %d-th of the timed steps" % max(args.event_every, 1),
                 "avg_launch_ms": stage_ms[dom],
                 "stage_ms": stage_ms,
+                # the same figures for every kernel of the step (the two largest are within a few per cent of
+                # each other, so which one is "dominant" can change from run to run) and for the whole step
+                "kernels": {st: {"kernel": kernel_of[st], "avg_launch_ms": ms,
+                                 "algorithmic_bytes_per_launch": abytes[st] * B,
+                                 "achieved": abytes[st] * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                                 "frac": (abytes[st] * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms > 0 else 0.0,
+                                 "traffic": per_kernel.get(st)}
+                            for st, ms in stage_ms.items() if st != "trigfix"},
+                "whole_step": {"algorithmic_bytes": sum(abytes.values()) * B,
+                               "achieved": sum(abytes.values()) * B / dt * args.steps / 1e9,
+                               "frac": sum(abytes.values()) * B / dt * args.steps / 1e9 / HBM_PEAK_GBPS},
             },
         }
         if pipelined is not None:
