@@ -347,6 +347,23 @@ def test_context_reuse_across_sizes_and_batches(pkg, oracle):
             _same(kps, rkps, desc, rdesc)
 
 
+@pytest.mark.parametrize("nb", [8, 15, 17, 24])
+def test_batch_sizes_around_the_xcd_orders(pkg, oracle, nb):
+    """Batches of >= 8 frames take the whole-images-per-XCD workgroup orders: K-PYR and K-DESC when the batch is a
+    multiple of 8, K-FAST also when at most an eighth of the XCD slots stay empty (15: one XCD has an image
+    less; 17: falls back to the grouped order).  Every image must still match the oracle."""
+    imgs = [_frame(pkg, 240, 376, 4100 + 31 * nb + i) for i in range(nb)]
+    laps = [(0, 0) if i % 3 else (40, 300) for i in range(nb)]
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(500, 1.2, 8, 20, 7)
+    res = ex.extract_batch(imgs, laps)
+    assert len(res) == nb
+    for i, (mono, kps, desc) in enumerate(res):
+        rmono, rkps, rdesc = ref.extract(imgs[i], laps[i])
+        assert mono == rmono
+        _same(kps, rkps, desc, rdesc)
+
+
 def test_device_batch_with_row_pitch(pkg, oracle):
     """Device-resident input with a row pitch larger than the width and an image stride with padding."""
     import torch
