@@ -311,6 +311,14 @@ typedef struct {
  * Returns nmatches, or an error. */
 int orbfe_search_projection(int device, const orbfe_proj_args*, int32_t* q_match, int32_t* feat_match);
 int orbfe_search_projection_last_sweeps(void); /* sweeps the last call on this thread needed (diagnostic) */
+/* `count` independent searches in one upload / three launches / one download (one workgroup column per search):
+ * the searches of a multi-camera rig's frames against the local map (src/Tracking.cc:2927, one call per camera in
+ * the reference), the keyframe-by-keyframe Fuse calls of LocalMapping::SearchInNeighbors (src/LocalMapping.cc
+ * :803-870), or the frames of several trackers served by one GPU.  items[k] / q_match[k] / feat_match[k] are
+ * the arguments of the k-th orbfe_search_projection call, nmatches[k] its return value.  Returns 0 or an error
+ * (then no output is defined). */
+int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match,
+                                  int32_t* const* feat_match, int32_t* nmatches);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:355-420) for npts map points in one launch: the
  * observation descriptors are pooled, point p owns rows offsets[p] .. offsets[p+1); best[p] = index (relative

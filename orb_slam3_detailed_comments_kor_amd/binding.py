@@ -202,6 +202,8 @@ def lib():
         L.orbfe_matcher_last_kernel_ms.restype = C.c_float
         L.orbfe_search_projection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbfe_search_projection_last_sweeps.argtypes = []
+        L.orbfe_search_projection_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                    C.c_void_p]
         L.orbfe_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_vocab_upload.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(_Vocab)]
         L.orbfe_vocab_free.argtypes = [C.c_void_p]
@@ -216,7 +218,7 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
-           "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps",
+           "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps", "orbfe_search_projection_batch",
            "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
 
 
@@ -606,6 +608,25 @@ def search_projection(problem, device=0):
     fm = np.full(max(n, 1), -1, np.int32)
     r = _chk(lib().orbfe_search_projection(device, C.byref(a), _p(qm), _p(fm)), "orbfe_search_projection")
     return r, qm[:nq], fm[:n]
+
+
+def search_projection_batch(problems, device=0):
+    """`len(problems)` independent projection searches in one call (orbfe_search_projection_batch); returns a list
+    of (nmatches, q_match, feat_match), one per problem."""
+    cnt = len(problems)
+    arr = (_ProjArgs * max(cnt, 1))()
+    keeps, qms, fms = [], [], []
+    for k, pr in enumerate(problems):
+        a, keep, n, nq = _proj_args(pr)
+        arr[k] = a
+        keeps.append(keep)
+        qms.append(np.full(max(nq, 1), -1, np.int32))
+        fms.append(np.full(max(n, 1), -1, np.int32))
+    qp = (C.c_void_p * max(cnt, 1))(*[q.ctypes.data for q in qms])
+    fp = (C.c_void_p * max(cnt, 1))(*[f.ctypes.data for f in fms])
+    nm = np.zeros(max(cnt, 1), np.int32)
+    _chk(lib().orbfe_search_projection_batch(device, C.addressof(arr), cnt, qp, fp, _p(nm)), "orbfe_search_projection_batch")
+    return [(int(nm[k]), qms[k][:arr[k].nq], fms[k][:arr[k].n]) for k in range(cnt)]
 
 
 def search_projection_last_sweeps():

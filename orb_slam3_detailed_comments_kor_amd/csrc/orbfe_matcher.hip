@@ -496,6 +496,7 @@ struct ProjDev {
     int32_t* qMatch;    // nq
     int32_t* featMatch; // n
     int32_t* status;    // nmatches, sweeps, keys needed
+    int sweepLds;       // k_proj_sweeps keeps minW and state in its dynamic LDS
 };
 #define PROJ_GC 64
 #define PROJ_GR 48
@@ -504,7 +505,7 @@ struct ProjDev {
 // key = dist(9) << 55 | cell sequence(12) << 43 | position in cell(19) << 24 | feature(24, only 19 used)
 #define PROJ_MAXN (1 << 19)
 
-__global__ __launch_bounds__(PROJ_THREADS) void k_proj_grid(ProjDev P)
+__device__ __forceinline__ void proj_grid_body(const ProjDev& P)
 {
     __shared__ int sCnt[2 * PROJ_CELLS];
     __shared__ int sWave[PROJ_THREADS / 64];
@@ -600,10 +601,20 @@ __device__ __forceinline__ bool proj_static_ok(const ProjDev& P, int g, int loca
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
+// The window of a query is a run of grid columns, and inside a column the cells cy0..cy1 are neighbours in the
+// CSR: the candidates of one column are ONE contiguous stretch of cellItems, and the reference's visit order
+// (columns, rows, push_back order: Frame::GetFeaturesInArea :682-703) is the order of the concatenated stretches.
+// Lanes first fetch the <= 64 stretch bounds, a prefix sum turns them into one flat candidate range, and every
+// lane then handles candidates flat = lane, lane + 64, ...: all loads of a round are independent, and the
+// dependent chain is bounds -> item -> keypoint -> descriptor whatever the window holds.  Keys are collected and
+// rank-sorted in LDS (PROJ_KCAP per query); a window with more candidates takes the global two-pass path.
+#define PROJ_KCAP 192
+__device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
 {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int sLo[4][64], sBase[4][65];
+    __shared__ unsigned long long sKeys[4][PROJ_KCAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
     if (q >= P.nq) return;
     const int flags = P.qflags ? P.qflags[q] : 0;
     const bool bRight = flags & 1;
@@ -616,17 +627,16 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
     if (fx0 < (float)PROJ_GC && fx1 >= 0.f && fy0 < (float)PROJ_GR && fy1 >= 0.f) {
         const int cx0 = fx0 > 0.f ? (int)fx0 : 0, cx1 = fx1 < (float)(PROJ_GC - 1) ? (int)fx1 : PROJ_GC - 1;
         const int cy0 = fy0 > 0.f ? (int)fy0 : 0, cy1 = fy1 < (float)(PROJ_GR - 1) ? (int)fy1 : PROJ_GR - 1;
-        const int ncy = cy1 - cy0 + 1, total = (cx1 - cx0 + 1) * ncy;
+        const int ncy = cy1 - cy0 + 1, ncols = cx1 - cx0 + 1; // ncols <= PROJ_GC = 64
         const int fbase = bRight ? P.Nleft : 0, side = bRight ? PROJ_CELLS : 0;
         const int minLevel = P.qmin[q], maxLevel = P.qmax[q];
         const bool gate = !bRight && P.Nleft == -1 && P.uright != nullptr;
         const float xr = (gate || (P.chi2 && P.qxr)) ? P.qxr[q] : 0.f;
-        int cnt = 0;
-        for (int s = lane; s < total; s += 64) {
-            const int c = side + (cx0 + s / ncy) * PROJ_GR + cy0 + s % ncy;
-            const int st = P.cellStart[c], en = P.cellStart[c + 1];
-            for (int j = st; j < en; j++)
-                cnt += proj_static_ok(P, P.cellItems[j] + fbase, P.cellItems[j], x, y, r, minLevel, maxLevel, gate, xr);
+        int lo = 0, cnt = 0;
+        if (lane < ncols) {
+            const int c0 = side + (cx0 + lane) * PROJ_GR + cy0;
+            lo = P.cellStart[c0];
+            cnt = P.cellStart[c0 + ncy] - lo;
         }
         int inc = cnt;
 #pragma unroll
@@ -634,28 +644,62 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
             const int v = __shfl_up(inc, off);
             if (lane >= off) inc += v;
         }
-        m = __shfl(inc, 63);
+        const int T = __shfl(inc, 63);
+        sLo[wave][lane] = lo;
+        sBase[wave][lane] = inc - cnt;
+        if (lane == 0) sBase[wave][64] = T; // (entries >= ncols hold T as well: cnt = 0 there)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const Desc dq = load_desc(P.qdesc + (size_t)q * 32);
+        // pass over the flat range; keep = 0: count and collect in LDS; keep = 1 (only when the window overflowed
+        // the LDS buffer): write to the reserved stretch of rawKeys
+        auto enumerate = [&](bool toGlobal) -> int {
+            int mm = 0;
+            for (int i0 = 0; i0 < T; i0 += 64) {
+                const int i = i0 + lane;
+                bool ok = false;
+                unsigned long long key = 0ull;
+                if (i < T) {
+                    int col = 0; // last column whose base <= i and which is not empty
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1)
+                        if (col + step < ncols && sBase[wave][col + step] <= i) col += step;
+                    const int local = P.cellItems[sLo[wave][col] + (i - sBase[wave][col])];
+                    const int g = local + fbase;
+                    ok = proj_static_ok(P, g, local, x, y, r, minLevel, maxLevel, gate, xr);
+                    if (ok) {
+                        const int dist = hamming(dq, load_desc(P.desc + (size_t)g * 32));
+                        key = ((unsigned long long)dist << 55) | ((unsigned long long)i << 24) | (unsigned long long)g;
+                    }
+                }
+                const unsigned long long mask = __ballot(ok);
+                if (ok) {
+                    const int pos = mm + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (toGlobal) P.rawKeys[base + pos] = key;
+                    else if (pos < PROJ_KCAP) sKeys[wave][pos] = key;
+                }
+                mm += __popcll(mask);
+            }
+            return mm;
+        };
+        m = enumerate(false);
         if (m > 0) {
             if (lane == 0) base = atomicAdd(&P.status[2], m);
             base = __shfl(base, 0);
             if (base + m > P.keyCap) {
                 m = -1; // the host enlarges the key buffers and runs again
-            } else {
-                const Desc dq = load_desc(P.qdesc + (size_t)q * 32);
-                int o = base + inc - cnt;
-                for (int s = lane; s < total; s += 64) {
-                    const int c = side + (cx0 + s / ncy) * PROJ_GR + cy0 + s % ncy;
-                    const int st = P.cellStart[c], en = P.cellStart[c + 1];
-                    for (int j = st; j < en; j++) {
-                        const int g = P.cellItems[j] + fbase;
-                        if (!proj_static_ok(P, g, g - fbase, x, y, r, minLevel, maxLevel, gate, xr)) continue;
-                        const int dist = hamming(dq, load_desc(P.desc + (size_t)g * 32));
-                        P.rawKeys[o++] = ((unsigned long long)dist << 55) | ((unsigned long long)s << 43) |
-                                         ((unsigned long long)(j - st) << 24) | (unsigned long long)g;
-                    }
+            } else if (m <= PROJ_KCAP) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < m; e += 64) { // rank sort in LDS (keys are distinct)
+                    const unsigned long long key = sKeys[wave][e];
+                    int rank = 0;
+                    for (int k = 0; k < m; k++) rank += sKeys[wave][k] < key;
+                    P.sortedKeys[base + rank] = key;
                 }
+            } else {
+                enumerate(true);
                 __threadfence();
-                // rank sort (keys are distinct); a window rarely holds more than a few dozen candidates
                 for (int e = lane; e < m; e += 64) {
                     const unsigned long long key = P.rawKeys[base + e];
                     int rank = 0;
@@ -671,20 +715,25 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P)
     }
 }
 
-__global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps(ProjDev P)
+__device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
 {
     __shared__ int sChanged;
+    extern __shared__ int32_t projLds[]; // (2 n + 6 nq) ints when the host found that they fit, else nothing
     const int tid = threadIdx.x;
     const int n = P.n, nq = P.nq;
-    for (int i = tid; i < 2 * n; i += PROJ_THREADS) P.minW[i] = 0x7fffffff;
-    for (int i = tid; i < 2 * 3 * nq; i += PROJ_THREADS) P.state[i] = -2;
+    // the per-feature "least blocking writer" tables and the per-query states of both sweep parities: every sweep
+    // reads and rewrites all of them, so they live in LDS whenever the frame is small enough (the usual case)
+    int32_t* const minW = P.sweepLds ? projLds : P.minW;
+    int32_t* const state = P.sweepLds ? projLds + 2 * (size_t)n : P.state;
+    for (int i = tid; i < 2 * n; i += PROJ_THREADS) minW[i] = 0x7fffffff;
+    for (int i = tid; i < 2 * 3 * nq; i += PROJ_THREADS) state[i] = -2;
     __syncthreads();
     int sweep = 0, last = 0;
     for (; sweep < nq + 2; sweep++) {
-        const int32_t* prevW = P.minW + (size_t)(sweep & 1) * n;
-        int32_t* newW = P.minW + (size_t)((sweep + 1) & 1) * n;
-        const int32_t* prevS = P.state + (size_t)(sweep & 1) * 3 * nq;
-        int32_t* newS = P.state + (size_t)((sweep + 1) & 1) * 3 * nq;
+        const int32_t* prevW = minW + (size_t)(sweep & 1) * n;
+        int32_t* newW = minW + (size_t)((sweep + 1) & 1) * n;
+        const int32_t* prevS = state + (size_t)(sweep & 1) * 3 * nq;
+        int32_t* newS = state + (size_t)((sweep + 1) & 1) * 3 * nq;
         last = (sweep + 1) & 1;
         for (int i = tid; i < n; i += PROJ_THREADS) newW[i] = 0x7fffffff;
         if (tid == 0) sChanged = 0;
@@ -745,7 +794,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps(ProjDev P)
     }
 
     // ---- final state of F.mvpMapPoints: the last writer of every feature
-    const int32_t* S = P.state + (size_t)last * 3 * nq;
+    const int32_t* S = state + (size_t)last * 3 * nq;
     for (int i = tid; i < n; i += PROJ_THREADS) P.featMatch[i] = -1;
     if (tid == 0) {
         P.status[0] = 0;
@@ -766,6 +815,26 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps(ProjDev P)
         }
     }
     if (cnt) atomicAdd(&P.status[0], cnt);
+}
+
+// one problem per launch (argument by value) / one problem per blockIdx.y (orbfe_search_projection_batch)
+__global__ __launch_bounds__(PROJ_THREADS) void k_proj_grid(ProjDev P) { proj_grid_body(P); }
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjDev P) { proj_candidates_body(P); }
+__global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps(ProjDev P) { proj_sweeps_body(P); }
+__global__ __launch_bounds__(PROJ_THREADS) void k_proj_grid_batch(const ProjDev* __restrict__ Ps)
+{
+    const ProjDev P = Ps[blockIdx.y];
+    proj_grid_body(P);
+}
+__global__ __launch_bounds__(256) void k_proj_candidates_batch(const ProjDev* __restrict__ Ps)
+{
+    const ProjDev P = Ps[blockIdx.y];
+    proj_candidates_body(P);
+}
+__global__ __launch_bounds__(PROJ_THREADS) void k_proj_sweeps_batch(const ProjDev* __restrict__ Ps)
+{
+    const ProjDev P = Ps[blockIdx.y];
+    proj_sweeps_body(P);
 }
 
 // ------------------------------------------------------------------ K-INIT
@@ -1682,7 +1751,9 @@ int orbfe_kb8_triangulate(int device, const float* params1, const float* params2
     return 0;
 }
 
-int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)
+namespace {
+// argument checks of one projection search (everything the kernels rely on)
+int proj_validate(const orbfe_proj_args* a, const int32_t* q_match, const int32_t* feat_match)
 {
     if (!a || a->n < 0 || a->nq < 0 || (a->mode != 0 && a->mode != 1)) return ORBFE_ERR_ARGS;
     if (a->n && (!a->desc || !a->kx || !a->ky || !a->octave || !feat_match)) return ORBFE_ERR_ARGS;
@@ -1706,16 +1777,26 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
         if (a->qblocks && !a->qblocks[q] && a->mode == 0 && a->Nleft != -1 && (a->left_to_right || a->right_to_left))
             return ORBFE_ERR_ARGS;
     }
-    for (int i = 0; i < a->n; i++) feat_match[i] = -1;
-    if (a->nq == 0) return 0;
-    if (a->n == 0) {
-        for (int q = 0; q < a->nq; q++) q_match[q] = -1;
-        return 0;
+    if (a->Nleft != -1 && a->mode == 0 && a->n && a->nq) {
+        for (int i = 0; a->left_to_right && i < a->Nleft; i++)
+            if (a->left_to_right[i] < -1 || a->left_to_right[i] >= a->n - a->Nleft) return ORBFE_ERR_ARGS;
+        for (int i = 0; a->right_to_left && i < a->n - a->Nleft; i++)
+            if (a->right_to_left[i] < -1 || a->right_to_left[i] >= a->Nleft) return ORBFE_ERR_ARGS;
     }
-    int r;
-    if ((r = select_device(device)) < 0) return r;
-    Scratch s(device);
+    return 0;
+}
+
+struct ProjJob {
     ProjDev P{};
+    size_t keyCap = 0, outOff = 0; // outputs of the job: status[4] | qMatch[nq] | featMatch[n] at dOut + outOff
+    size_t sweepBytes = 0;
+};
+
+// inputs and work arrays of one search on the device (outputs are assigned by the caller: one block per call)
+int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J)
+{
+    int r;
+    ProjDev& P = J.P;
     const size_t n = (size_t)a->n, nq = (size_t)a->nq;
     uint8_t *dDesc, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
     float *dKx, *dKy, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
@@ -1731,10 +1812,6 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     if (a->Nleft != -1 && a->mode == 0) {
         if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
         if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
-        for (int i = 0; a->left_to_right && i < a->Nleft; i++)
-            if (a->left_to_right[i] < -1 || a->left_to_right[i] >= a->n - a->Nleft) return ORBFE_ERR_ARGS;
-        for (int i = 0; a->right_to_left && i < a->n - a->Nleft; i++)
-            if (a->right_to_left[i] < -1 || a->right_to_left[i] >= a->Nleft) return ORBFE_ERR_ARGS;
     }
     if ((r = s.up(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
     if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
@@ -1752,16 +1829,10 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     if ((r = s.up<int32_t>(&P.state, nullptr, 6 * nq)) < 0) return r;
     if ((r = s.up<int32_t>(&P.qStart, nullptr, nq)) < 0) return r;
     if ((r = s.up<int32_t>(&P.qCount, nullptr, nq)) < 0) return r;
-    // outputs in one block: status[4] | qMatch[nq] | featMatch[n]
-    int32_t* dOut;
-    if ((r = s.up<int32_t>(&dOut, nullptr, 4 + nq + n)) < 0) return r;
-    P.status = dOut;
-    P.qMatch = dOut + 4;
-    P.featMatch = dOut + 4 + nq;
-    size_t keyCap = std::max<size_t>(64 * nq, 1 << 16);
-    if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
-    if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
-    P.keyCap = (int)keyCap;
+    J.keyCap = std::max<size_t>(64 * nq, 1 << 16);
+    if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, J.keyCap)) < 0) return r;
+    if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
+    P.keyCap = (int)J.keyCap;
     P.desc = dDesc; P.kx = dKx; P.ky = dKy; P.octave = dOct; P.uright = dUr; P.taken = dTaken;
     P.l2r = dL2r; P.r2l = dR2l; P.n = a->n; P.Nleft = a->Nleft;
     P.minX = a->minX; P.minY = a->minY; P.wInv = a->gridWInv; P.hInv = a->gridHInv;
@@ -1769,29 +1840,21 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
     P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
     P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
     P.invSigma2 = dInvSigma2; P.chi2 = a->chi2_gate ? 1 : 0;
-    std::vector<int32_t> out(4 + nq + n);
-    for (int attempt = 0;; attempt++) {
-        {
-            KernelTimer timer(s);
-            hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
-            hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, 0, P);
-            hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
-        if (out[2] >= 0 && (size_t)out[2] <= keyCap) break;
-        // more candidate keys than the buffers hold: the kernel reported how many it needs
-        if (attempt > 0 || out[2] < 0) return ORBFE_ERR_STATE;
-        keyCap = (size_t)out[2];
-        if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
-        if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
-        P.keyCap = (int)keyCap;
-    }
+    J.sweepBytes = (2 * n + 6 * nq) * sizeof(int32_t);
+    P.sweepLds = J.sweepBytes <= 60 * 1024 ? 1 : 0;
+    if (!P.sweepLds) J.sweepBytes = 0;
+    return 0;
+}
+
+// host tail of one search: outputs from the downloaded block, then the rotation histogram of :2307-2323 /
+// :2397-2416 over the matches in query order
+int proj_finish(const orbfe_proj_args* a, const int32_t* out, int32_t* q_match, int32_t* feat_match)
+{
+    const size_t n = (size_t)a->n, nq = (size_t)a->nq;
     int nmatches = out[0];
-    g_lastProjSweeps = out[1];
-    std::copy(out.begin() + 4, out.begin() + 4 + nq, q_match);
-    std::copy(out.begin() + 4 + nq, out.end(), feat_match);
-    if (orient) { // rotation histogram of :2307-2323 / :2397-2416 over the matches in query order
+    std::copy(out + 4, out + 4 + nq, q_match);
+    std::copy(out + 4 + nq, out + 4 + nq + n, feat_match);
+    if (a->mode == 1 && a->check_orientation) {
         std::vector<int8_t> bins(nq, -1);
         int histo[HISTO_LENGTH] = {0};
         for (size_t q = 0; q < nq; q++)
@@ -1812,6 +1875,103 @@ int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_mat
             }
     }
     return nmatches;
+}
+} // namespace
+
+int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match,
+                                  int32_t* const* feat_match, int32_t* nmatches)
+{
+    if (count < 0 || (count && (!items || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
+    int r;
+    for (int k = 0; k < count; k++)
+        if ((r = proj_validate(&items[k], q_match[k], feat_match[k])) < 0) return r;
+    // searches with nothing to do are answered here; the others become device jobs
+    std::vector<int> live;
+    for (int k = 0; k < count; k++) {
+        const orbfe_proj_args* a = &items[k];
+        for (int i = 0; i < a->n; i++) feat_match[k][i] = -1;
+        for (int q = 0; q < a->nq; q++) q_match[k][q] = -1;
+        nmatches[k] = 0;
+        if (a->n > 0 && a->nq > 0) live.push_back(k);
+    }
+    if (live.empty()) return 0;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    std::vector<ProjJob> jobs(live.size());
+    size_t outInts = 0, sweepBytes = 0;
+    unsigned maxBlocks = 1;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const orbfe_proj_args* a = &items[live[j]];
+        if ((r = proj_stage(s, a, jobs[j])) < 0) return r;
+        jobs[j].outOff = outInts;
+        outInts += 4 + (size_t)a->nq + (size_t)a->n;
+        sweepBytes = std::max(sweepBytes, jobs[j].sweepBytes);
+        maxBlocks = std::max(maxBlocks, (unsigned)((a->nq + 3) / 4));
+    }
+    int32_t* dOut;
+    if ((r = s.up<int32_t>(&dOut, nullptr, outInts)) < 0) return r;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const orbfe_proj_args* a = &items[live[j]];
+        jobs[j].P.status = dOut + jobs[j].outOff;
+        jobs[j].P.qMatch = jobs[j].P.status + 4;
+        jobs[j].P.featMatch = jobs[j].P.qMatch + a->nq;
+    }
+    std::vector<int32_t> out(outInts);
+    std::vector<ProjDev> hostP(jobs.size());
+    for (int attempt = 0;; attempt++) {
+        ProjDev* dP = nullptr;
+        if (jobs.size() > 1) {
+            for (size_t j = 0; j < jobs.size(); j++) hostP[j] = jobs[j].P;
+            if ((r = s.up(&dP, hostP.data(), hostP.size())) < 0) return r;
+        }
+        {
+            KernelTimer timer(s);
+            if (jobs.size() == 1) {
+                const ProjDev& P = jobs[0].P;
+                hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
+                hipLaunchKernelGGL(k_proj_candidates, dim3(maxBlocks), dim3(256), 0, 0, P);
+                hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), sweepBytes, 0, P);
+            } else {
+                const unsigned nj = (unsigned)jobs.size();
+                hipLaunchKernelGGL(k_proj_grid_batch, dim3(1, nj), dim3(PROJ_THREADS), 0, 0, dP);
+                hipLaunchKernelGGL(k_proj_candidates_batch, dim3(maxBlocks, nj), dim3(256), 0, 0, dP);
+                hipLaunchKernelGGL(k_proj_sweeps_batch, dim3(1, nj), dim3(PROJ_THREADS), sweepBytes, 0, dP);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
+        // more candidate keys than a job's buffers hold: the kernel reported how many it needs; run again
+        bool again = false;
+        for (ProjJob& J : jobs) {
+            const int need = out[J.outOff + 2];
+            if (need < 0) return ORBFE_ERR_STATE;
+            if ((size_t)need > J.keyCap) {
+                if (attempt > 0) return ORBFE_ERR_STATE;
+                J.keyCap = (size_t)need;
+                if ((r = s.up<unsigned long long>(&J.P.rawKeys, nullptr, J.keyCap)) < 0) return r;
+                if ((r = s.up<unsigned long long>(&J.P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
+                J.P.keyCap = (int)J.keyCap;
+                again = true;
+            }
+        }
+        if (!again) break;
+    }
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const int k = live[j];
+        g_lastProjSweeps = out[jobs[j].outOff + 1];
+        nmatches[k] = proj_finish(&items[k], out.data() + jobs[j].outOff, q_match[k], feat_match[k]);
+    }
+    return 0;
+}
+
+int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)
+{
+    int32_t nm = 0;
+    int32_t* qm[1] = {q_match};
+    int32_t* fm[1] = {feat_match};
+    const int r = orbfe_search_projection_batch(device, a, a ? 1 : 0, qm, fm, &nm);
+    if (!a) return ORBFE_ERR_ARGS;
+    return r < 0 ? r : (int)nm;
 }
 
 int orbfe_search_projection_last_sweeps(void) { return g_lastProjSweeps; }

@@ -221,6 +221,9 @@ PROJ_CASES = [
     dict(seed=17, mode=1, th=3.0, loop="fuse", Nleft=700),                    # two-camera rig, bRight queries
     dict(seed=18, mode=1, th=4.0, loop="fuse_sim3"),                          # :1843-1965
     dict(seed=19, mode=1, th=7.5, loop="search_by_sim3", n=2000, nq=1500),    # :1967-2191, one direction
+    # dense frame: windows of 50..600 candidates, on both sides of the per-query LDS key buffer (192)
+    dict(seed=20, mode=1, n=5000, nq=400, th=12.0, w=320, h=240),
+    dict(seed=21, mode=0, n=5000, nq=400, th=6.0, w=320, h=240, stereo=True),
 ]
 
 
@@ -244,6 +247,22 @@ def test_search_projection(pkg, oracle, case):
         plain["chi2_gate"] = 0
         plain.pop("uright", None)
         assert not np.array_equal(oracle.search_projection(plain)[1], q_ref)
+
+
+def test_search_projection_batch(pkg, oracle):
+    """orbfe_search_projection_batch: every kind of search side by side in one call (one workgroup column per
+    search), including an empty one and one whose key buffers have to grow; each must equal its own oracle run."""
+    from matcher_inputs import projection_problem
+    cases = [PROJ_CASES[i] for i in (0, 1, 2, 4, 6, 8, 12, 13, 15, 16, 20)] + [dict(seed=1, n=50, nq=0), dict(seed=3, mode=1, n=4000, nq=3000, th=9.0)]
+    prs = [projection_problem(**c) for c in cases]
+    got = pkg.search_projection_batch(prs)
+    assert len(got) == len(prs)
+    for pr, (n_got, q_got, f_got) in zip(prs, got):
+        n_ref, q_ref, f_ref = oracle.search_projection(pr)
+        assert n_got == n_ref
+        assert np.array_equal(q_got, q_ref)
+        assert np.array_equal(f_got, f_ref)
+    assert pkg.search_projection_batch([]) == []
 
 
 def test_search_projection_errors(pkg):

@@ -97,6 +97,9 @@ def main():
     pr2 = MI.projection_problem(32, n=2000, nq=1500, mode=1, stereo=True, th=15.0, crowd=False, check_orientation=True)
     report("SearchByProjection(Current, Last) N=2000, 1500 points, th=15", 1500, "map points",
            lambda: pkg.search_projection(pr2), lambda: O.search_projection(pr2))
+    prs = [MI.projection_problem(100 + k, n=2000, nq=1500, mode=0, stereo=True, th=1.0, crowd=False) for k in range(64)]
+    report("SearchByProjection batch of 64 (F, local map) N=2000, 1500 points", 64 * 1500, "map points",
+           lambda: pkg.search_projection_batch(prs), lambda: [O.search_projection(p) for p in prs], reps=10)
     sizes = rng.integers(2, 25, size=4000)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     pool = rng.integers(0, 256, size=(int(offs[-1]), 32), dtype=np.uint8)
