@@ -21,12 +21,17 @@ def main():
     ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
     for f in frames[:4]:
         ex(f)
-    t0 = time.perf_counter()
     nkp = 0
-    for f in frames:
-        _, k, _ = ex(f)
-        nkp += len(k)
-    single = (time.perf_counter() - t0) / B
+    lat = []
+    for rep in range(8): # 512 single-frame calls: mean and latency percentiles (ms/frame p50/p99)
+        for f in frames:
+            t0 = time.perf_counter()
+            _, k, _ = ex(f)
+            lat.append(time.perf_counter() - t0)
+            if rep == 0:
+                nkp += len(k)
+    lat = np.array(lat)
+    single = float(lat.mean())
 
     ex.extract_batch(frames)
     reps = 10
@@ -35,7 +40,9 @@ def main():
         out = ex.extract_batch(frames)
     tb = (time.perf_counter() - t0) / reps
     print(json.dumps({"frame": "%dx%d" % (cols, rows), "single_call_ms": 1e3 * single,
-                      "single_frames_per_s": 1.0 / single, "batch": B, "batch_call_ms": 1e3 * tb,
+                      "single_frames_per_s": 1.0 / single,
+                      "single_call_ms_p50": 1e3 * float(np.percentile(lat, 50)),
+                      "single_call_ms_p99": 1e3 * float(np.percentile(lat, 99)), "batch": B, "batch_call_ms": 1e3 * tb,
                       "batch_keypoints_per_s": nkp / tb, "keypoints_per_frame": nkp / B}))
 
 
