@@ -105,6 +105,18 @@ def main():
     pool = rng.integers(0, 256, size=(int(offs[-1]), 32), dtype=np.uint8)
     report("ComputeDistinctiveDescriptors, 4000 map points", 4000, "map points",
            lambda: pkg.distinctive_descriptors(pool, offs), lambda: O.distinctive_descriptors(pool, offs))
+    # Frame::ComputeStereoMatches on the pyramids the two extractors left on the device (EuRoC stereo, config 3)
+    mbf, mb = 47.90639384423901, 47.90639384423901 / 435.2046959714599
+    left, right = pkg.synth.make_stereo_pair(480, 752, 31, shift=24)
+    exL, exR = pkg.ORBextractor(1200, 1.2, 8, 20, 7), pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    (_, kL, dL), (_, kR, dR) = exL(left, (0, 0)), exR(right, (0, 0))
+    oL, oR = O.Extractor(1200, 1.2, 8, 20, 7), O.Extractor(1200, 1.2, 8, 20, 7)
+    (_, rkL, rdL), (_, rkR, rdR) = oL.extract(left, (0, 0)), oR.extract(right, (0, 0))
+    g = timeit(lambda: pkg.compute_stereo_matches(exL, exR, kL, dL, kR, dR, mb, mbf), 20)
+    c = timeit(lambda: O.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf), 4)
+    print(json.dumps({"op": "ComputeStereoMatches 752x480 pair, %d x %d keypoints" % (len(kL), len(kR)), "units": len(kL),
+                      "unit": "left keypoints", "call_ms": 1e3 * g, "cpu_oracle_ms_1core": 1e3 * c,
+                      "call_units_per_s": len(kL) / g, "cpu_units_per_s": len(kL) / c}))
     print(json.dumps({"op": "projection sweeps", "mode0": None, "last": pkg.search_projection_last_sweeps()}))
 
 
