@@ -364,6 +364,31 @@ def test_batch_sizes_around_the_xcd_orders(pkg, oracle, nb):
         _same(kps, rkps, desc, rdesc)
 
 
+def test_create_destroy_cycles_do_not_leak_device_memory(pkg):
+    """A tracker that is restarted (System::Reset, new sessions on a shared GPU) creates and destroys extractors
+    many times: the free device memory after 40 create / extract / destroy cycles must be what it was after the
+    first few (the per-process libm table and the allocator's pools are allocated once)."""
+    import torch
+    img = _frame(pkg, 240, 376, 5)
+
+    def cycle(k):
+        ex = pkg.ORBextractor(400 + (k % 3) * 100, 1.2, 8, 20, 7)
+        ex(img, (0, 0))
+        if k % 2:
+            ex.extract_batch([img] * 3, [(0, 0)] * 3)
+        ex.close()
+
+    for k in range(4):
+        cycle(k)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(40):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 40 cycles" % (free0 - free1)
+
+
 def test_device_batch_with_row_pitch(pkg, oracle):
     """Device-resident input with a row pitch larger than the width and an image stride with padding."""
     import torch
