@@ -13,6 +13,8 @@ torch.cuda.synchronize(), MAX over ranks; rank 0 prints one JSON line.
 Extra objects in the line:
   roofline     -- dominant kernel (by hipEvent time on the extractor's stream, measured live over
                   the timed steps): algorithmic bytes per launch / average launch time vs 8 TB/s HBM.
+  pipelined    -- not `value`: the same batches alternating between two extractor contexts on two streams.
+  single_frame -- not `value`: configs[1] read literally, ONE resident frame per call (latency-bound).
   cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
                   built without OpenCV) timed on this host's cores on a bounded sample.
 """
@@ -244,6 +246,29 @@ def main():
                      "value": float(d_n.sum().item()) * args.steps / tp, "unit": "keypoints/s"}
         e2.close()
 
+    # Also not part of `value`: BASELINE configs[1] read literally -- ONE resident frame per call (what a monocular
+    # tracker issues), the latency-bound end of the same pipeline.
+    single = None
+    if world == 1 and not extra and not args.no_pipelined and B > 1:
+        k1 = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
+        de1 = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+        n1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        m1 = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def step1():
+            ex.extract_batch_device(d_img.data_ptr(), 1, H, W, W, H * W, lap, k1.data_ptr(), de1.data_ptr(), cap,
+                                    n1.data_ptr(), m1.data_ptr())
+        for _ in range(20):
+            step1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t1
+        single = {"frames_per_call": 1, "ms_per_frame": 1e3 * t1 / args.steps,
+                  "value": float(n1.item()) * args.steps / t1, "unit": "keypoints/s"}
+
     n_local = int(d_n.sum().item())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     cnt = torch.tensor([n_local], dtype=torch.float64, device=dev)
@@ -336,6 +361,8 @@ def main():
         }
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if single is not None:
+            out["single_frame"] = single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
         print(json.dumps(out))
