@@ -826,7 +826,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
 
     // Every pass walks the key arrays twice; keep them in LDS when the level's candidates fit (the
     // usual case), else in the global scratch arrays.  (Generic pointers: flat loads serve both.)
-    {
+    // A level of up to QT_THREADS cells (every level of a 752x480 frame) learns its total from the gather's own
+    // scan below; only larger levels pay a separate pass over the cell counts (one more dependent global round trip).
+    const bool oneChunk = L.nCells <= QT_THREADS;
+    if (!oneChunk) {
         int part = 0;
         for (int ci = tid; ci < L.nCells; ci += QT_THREADS) part += cnts[ci];
 #pragma unroll
@@ -856,6 +859,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         }
         __syncthreads();
         const int tot = qt_scan(gscan, nc, wsum); // exclusive prefix of the counts
+        if (oneChunk && tot <= keyLdsCap) {       // (uniform) the key arrays do not overlap gscan / gbase
+            keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
+            keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
+        }
         for (int i = tid; i < tot; i += QT_THREADS) {
             int lo = 0, hi = nc - 1; // last cell whose prefix <= i (cells with zero keys share a prefix; take the last)
             while (lo < hi) {
