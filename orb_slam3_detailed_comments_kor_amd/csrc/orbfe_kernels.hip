@@ -713,9 +713,11 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 // One barrier per 512-element chunk plus one at the end (every wave sums the <= 8 wave totals
 // itself; the totals are double buffered so that a chunk never overwrites values still being read).
 // F maps the stored element to the value that is scanned (identity for a plain scan): lets a caller fold the
-// pass that would have prepared the scan input -- and its barrier -- into the scan itself.
-template <class F>
-__device__ int qt_scan_map(const int* src, int* a, int n, int* wsum /* 2 * QT_WAVES */, F f)
+// pass that would have prepared the scan input -- and its barrier -- into the scan itself.  G(i, exclusive
+// prefix, value) runs where element i is written: a caller that only needs to look at (prefix, value) pairs once
+// saves the pass and the barrier after the scan as well.
+template <class T, class F, class G>
+__device__ int qt_scan_map(const T* src, int* a, int n, int* wsum /* 2 * QT_WAVES */, F f, G post)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 0, chunk = 0;
@@ -733,11 +735,20 @@ __device__ int qt_scan_map(const int* src, int* a, int n, int* wsum /* 2 * QT_WA
             total += t;
             if (w < wave) prefix += t;
         }
-        if (i < n) a[i] = x - v + prefix + carry;
+        if (i < n) {
+            const int e = x - v + prefix + carry;
+            a[i] = e;
+            post(i, e, v);
+        }
         carry += total;
     }
     __syncthreads();
     return carry;
+}
+template <class T, class F>
+__device__ int qt_scan_map(const T* src, int* a, int n, int* wsum, F f)
+{
+    return qt_scan_map(src, a, n, wsum, f, [](int, int, int) {});
 }
 __device__ int qt_scan(int* a, int n, int* wsum /* 2 * QT_WAVES */)
 {
@@ -995,19 +1006,16 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     while (!finish) {
         // ---- full pass (:598-663): every node with more than one key is divided
         const int prevSize = size;
-        for (int p = tid; p < size; p += QT_THREADS) {
-            const int e = nodeCnt[cur][p] > 1 ? 1 : 0;
-            sidx[p] = e;
-            kOf[p] = e ? 0 : -1; // flag, index filled below
-        }
-        __syncthreads();
-        const int nE = qt_scan(sidx, size, wsum);
+        // sidx[p] = number of divided nodes before p; kOf[p] = its own expansion index or -1 (written where the
+        // scan writes, no separate pass).  The nodes were written before the barrier that ended the last pass.
+        int* const kOfW = kOf;
+        int* const parW = par;
+        const int nE = qt_scan_map(nodeCnt[cur], sidx, size, wsum, [](int c) { return c > 1 ? 1 : 0; },
+                                   [kOfW, parW](int p, int e, int v) {
+                                       kOfW[p] = v ? e : -1;
+                                       if (v) parW[e] = p;
+                                   });
         if (nE == 0) break;
-        for (int p = tid; p < size; p += QT_THREADS)
-            if (kOf[p] == 0) {
-                kOf[p] = sidx[p];
-                par[sidx[p]] = p;
-            }
         for (int i = tid; i < 4 * nE; i += QT_THREADS) cc[i] = 0; // histogram of expand(), cleared in this phase
         __syncthreads();
         int nMulti = 0;
@@ -1026,6 +1034,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 for (int p = tid; p < size; p += QT_THREADS) kOf[p] = -1;
                 for (int t = tid; t < m; t += QT_THREADS) gpre[t] = nodeCnt[cur][mcur[t]];
                 for (int i = tid; i < 4 * m; i += QT_THREADS) cc[i] = 0;
+                if (tid == 0) misc[0] = m;
                 __syncthreads();
                 for (int t = tid; t < m; t += QT_THREADS) {
                     const int ct = gpre[t];
@@ -1056,21 +1065,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                     }
                 }
                 __syncthreads();
-                for (int r = tid; r < m; r += QT_THREADS)
-                    gpre[r] = (cc[4 * r] > 0) + (cc[4 * r + 1] > 0) + (cc[4 * r + 2] > 0) + (cc[4 * r + 3] > 0) - 1;
-                if (tid == 0) misc[0] = m;
-                __syncthreads();
-                qt_scan(gpre, m, wsum); // exclusive: gpre[r] = growth of candidates before r
-                for (int r = tid; r < m; r += QT_THREADS) {
-                    const int g = (cc[4 * r] > 0) + (cc[4 * r + 1] > 0) + (cc[4 * r + 2] > 0) + (cc[4 * r + 3] > 0) - 1;
-                    const int before = size + gpre[r];
-                    if (before < N && before + g >= N) misc[0] = r + 1; // the break of :728-729
+                // growth of candidate r = its non-empty children - 1; the exclusive prefix says where the list
+                // size stands before r, and the one candidate at which it reaches N is the break of :728-729
+                // (misc[0] was preset to m before the histogram's barrier)
+                {
+                    int* const cut = misc;
+                    const int sz = size;
+                    qt_scan_map(reinterpret_cast<const int4*>(cc), gpre, m, wsum,
+                                [](int4 c) { return (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0) - 1; },
+                                [cut, sz, N](int r, int e, int g) {
+                                    const int before = sz + e;
+                                    if (before < N && before + g >= N) cut[0] = r + 1;
+                                });
                 }
-                __syncthreads();
                 const int nE2 = misc[0];
-                for (int p = tid; p < size; p += QT_THREADS) sidx[p] = (kOf[p] >= 0 && kOf[p] < nE2) ? 1 : 0;
-                __syncthreads();
-                qt_scan(sidx, size, wsum);
+                qt_scan_map(kOf, sidx, size, wsum, [nE2](int k) { return (k >= 0 && k < nE2) ? 1 : 0; });
                 int nM2 = 0;
                 const int ns2 = expand(nE2, true, nM2);
                 if (ns2 < 0) {
