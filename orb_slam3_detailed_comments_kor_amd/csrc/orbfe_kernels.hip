@@ -816,15 +816,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     int* misc = lds;
     int* wsum = misc + 8;
     int* A = lds + 64;
-    int* nodeUL[2] = {A, A + LC};
-    int* nodeBR[2] = {A + 2 * LC, A + 3 * LC};
-    int* nodeCnt[2] = {A + 4 * LC, A + 5 * LC};
+    // (functions of the buffer index, not pointer arrays: indexing an array of pointers with the run-time `cur`
+    // hides from the compiler that these are LDS addresses, and every access became a flat load / store)
+    auto nodeUL = [A, LC](int b) { return A + b * LC; };
+    auto nodeBR = [A, LC](int b) { return A + (2 + b) * LC; };
+    auto nodeCnt = [A, LC](int b) { return A + (4 + b) * LC; };
     int* kOf = A + 6 * LC;       // list position -> expansion index k (or -1)
     int* sidx = A + 7 * LC;      // list position -> #expanded nodes before it
     int* cc = A + 8 * LC;        // [4*LC] child key counts, index 4k+q
     int* cpos = A + 12 * LC;     // [4*LC] child list positions, index 4k+q
     int* mpos = A + 16 * LC;     // [4*LC] packed scan: multi-key children (low 16) | non-empty children (high 16)
-    int* multi[2] = {A + 20 * LC, A + 21 * LC}; // candidate list (list positions), creation order
+    auto multi = [A, LC](int b) { return A + (20 + b) * LC; }; // candidate list (list positions), creation order
     int* par = A + 22 * LC;      // expansion index k -> parent list position
     int* gpre = A + 23 * LC;     // growth prefix (final phase) / scratch
     int* gscan = A;              // gather only
@@ -916,9 +918,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     if (tid < nIni && cc[tid] > 0) {
         const int p = gpre[tid];
         const int x0 = (int)__fmul_rn(L.hX, (float)tid), x1 = (int)__fmul_rn(L.hX, (float)(tid + 1));
-        nodeUL[0][p] = x0;                                 // UL = (x0, 0)
-        nodeBR[0][p] = x1 | ((L.maxBY - ORBFE_MINB) << 16); // BR = (x1, maxY-minY)
-        nodeCnt[0][p] = cc[tid];
+        nodeUL(0)[p] = x0;                                 // UL = (x0, 0)
+        nodeBR(0)[p] = x1 | ((L.maxBY - ORBFE_MINB) << 16); // BR = (x1, maxY-minY)
+        nodeCnt(0)[p] = cc[tid];
     }
     __syncthreads();
     for (int i = tid; i < n; i += QT_THREADS) keyNode[i] = (uint16_t)gpre[keyNode[i]];
@@ -928,8 +930,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     // Preconditions: kOf/sidx valid for the current list; par[k] for k < nE; if !histDone, cc is
     // computed here for the nE expanded nodes, else cc[4k+q] already holds the counts.
     auto expand = [&](int nE, bool histDone, int& nMultiOut) -> int {
-        const int* ul = nodeUL[cur];
-        const int* br = nodeBR[cur];
+        const int* ul = nodeUL(cur);
+        const int* br = nodeBR(cur);
         if (!histDone) { // cc[0 .. 4 nE) was cleared by the caller, before its last barrier
             for (int base = 0; base < n; base += QT_THREADS) {
                 const int i = base + tid;
@@ -967,10 +969,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 const int p = par[k];
                 int cul, cbr;
                 qt_child(ul[p], br[p], q, cul, cbr);
-                nodeUL[nb][pos] = cul;
-                nodeBR[nb][pos] = cbr;
-                nodeCnt[nb][pos] = cnt;
-                if (cnt > 1) multi[nb][mpos[i] & 0xFFFF] = pos;
+                nodeUL(nb)[pos] = cul;
+                nodeBR(nb)[pos] = cbr;
+                nodeCnt(nb)[pos] = cnt;
+                if (cnt > 1) multi(nb)[mpos[i] & 0xFFFF] = pos;
             }
         }
         __syncthreads();
@@ -978,9 +980,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             const int k = kOf[p];
             if (!(k >= 0 && k < nE)) {
                 const int pos = nChildren + p - sidx[p];
-                nodeUL[nb][pos] = ul[p];
-                nodeBR[nb][pos] = br[p];
-                nodeCnt[nb][pos] = nodeCnt[cur][p];
+                nodeUL(nb)[pos] = ul[p];
+                nodeBR(nb)[pos] = br[p];
+                nodeCnt(nb)[pos] = nodeCnt(cur)[p];
             }
         }
         for (int i = tid; i < n; i += QT_THREADS) {
@@ -1010,7 +1012,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         // scan writes, no separate pass).  The nodes were written before the barrier that ended the last pass.
         int* const kOfW = kOf;
         int* const parW = par;
-        const int nE = qt_scan_map(nodeCnt[cur], sidx, size, wsum, [](int c) { return c > 1 ? 1 : 0; },
+        const int nE = qt_scan_map(nodeCnt(cur), sidx, size, wsum, [](int c) { return c > 1 ? 1 : 0; },
                                    [kOfW, parW](int p, int e, int v) {
                                        kOfW[p] = v ? e : -1;
                                        if (v) parW[e] = p;
@@ -1029,27 +1031,49 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             int m = nMulti;
             while (!finish) {
                 const int prev2 = size;
-                const int* mcur = multi[cur];
+                const int* mcur = multi(cur);
                 // rank of candidate t in descending (count, creation index) order
                 for (int p = tid; p < size; p += QT_THREADS) kOf[p] = -1;
-                for (int t = tid; t < m; t += QT_THREADS) gpre[t] = nodeCnt[cur][mcur[t]];
+                for (int t = tid; t < m; t += QT_THREADS) gpre[t] = nodeCnt(cur)[mcur[t]];
                 for (int i = tid; i < 4 * m; i += QT_THREADS) cc[i] = 0;
+                for (int t = tid; t < m; t += QT_THREADS) sidx[t] = 0; // rank accumulators (sidx is rebuilt below)
                 if (tid == 0) misc[0] = m;
                 __syncthreads();
-                for (int t = tid; t < m; t += QT_THREADS) {
-                    const int ct = gpre[t];
-                    int rank = 0;
-                    for (int j = 0; j < m; j++) {
-                        const int cj = gpre[j];
-                        rank += (cj > ct) || (cj == ct && j > t);
+                // rank = number of candidates ahead in (count descending, creation index descending) order.  All
+                // eight wavefronts work on it: wavefront w compares every candidate t with its own slice of the
+                // j range and adds the partial count (the plain loop -- one thread per t over all j, each LDS read
+                // waited for -- took 4.4 of this kernel's 31 us at ~120 candidates).
+                {
+                    const int per = (m + QT_WAVES - 1) / QT_WAVES;
+                    const int j0 = wave * per, j1 = min(m, j0 + per);
+                    for (int t = lane; t < m; t += 64) {
+                        const int ct = gpre[t];
+                        int part = 0;
+                        int j = j0;
+                        for (; j + 4 <= j1; j += 4) {
+                            const int c0 = gpre[j], c1 = gpre[j + 1], c2 = gpre[j + 2], c3 = gpre[j + 3];
+                            part += (c0 > ct) || (c0 == ct && j > t);
+                            part += (c1 > ct) || (c1 == ct && j + 1 > t);
+                            part += (c2 > ct) || (c2 == ct && j + 2 > t);
+                            part += (c3 > ct) || (c3 == ct && j + 3 > t);
+                        }
+                        for (; j < j1; j++) {
+                            const int cj = gpre[j];
+                            part += (cj > ct) || (cj == ct && j > t);
+                        }
+                        if (part) atomicAdd(&sidx[t], part);
                     }
+                }
+                __syncthreads();
+                for (int t = tid; t < m; t += QT_THREADS) {
+                    const int rank = sidx[t];
                     kOf[mcur[t]] = rank;
                     par[rank] = mcur[t];
                 }
                 __syncthreads();
                 {
-                    const int* ul = nodeUL[cur];
-                    const int* br = nodeBR[cur];
+                    const int* ul = nodeUL(cur);
+                    const int* br = nodeBR(cur);
                     for (int base = 0; base < n; base += QT_THREADS) {
                         const int i = base + tid;
                         int c = -1;
