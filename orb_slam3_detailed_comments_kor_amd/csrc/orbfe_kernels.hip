@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     __shared__ int lvYlo[ORBFE_MAX_LEVELS], lvYown[ORBFE_MAX_LEVELS], lvYneed[ORBFE_MAX_LEVELS];
     __shared__ int lvRoi[ORBFE_MAX_LEVELS], lvPitch[ORBFE_MAX_LEVELS], lvXt[ORBFE_MAX_LEVELS], lvYt[ORBFE_MAX_LEVELS];
     __shared__ unsigned lvRecip[ORBFE_MAX_LEVELS]; // ceil(2^32 / column groups per row), 0 when there is one
+    __shared__ int lvXo[ORBFE_MAX_LEVELS + 1], lvYo[ORBFE_MAX_LEVELS + 1]; // first staged x / y entry of a level; [nlevels] = total
     if (tid < nlevels) {
         const OrbPyrRange X = rx[tid * ntx + ti], Y = ry[tid * nty + tj];
         lvXlo[tid] = X.lo;
@@ -155,29 +156,46 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         lvYt[tid] = lg[tid].ytabOff;
         const int ng = (X.needHi - X.lo + 3) >> 2; // groups of 4 columns per region row
         lvRecip[tid] = ng > 1 ? (unsigned)(((1ull << 32) + (unsigned)ng - 1) / (unsigned)ng) : 0u;
+        // where this level's staged x / y entries start (levels 1 .. tid-1 precede it); the last level also
+        // leaves the totals.  A handful of independent loads per lane, no second barrier.
+        int xs = 0, ys = 0;
+        for (int j = 1; j < tid; j++) {
+            const OrbPyrRange Xj = rx[j * ntx + ti], Yj = ry[j * nty + tj];
+            xs += Xj.needHi - Xj.lo;
+            ys += Yj.needHi - Yj.lo;
+        }
+        lvXo[tid] = xs;
+        lvYo[tid] = ys;
+        if (tid == nlevels - 1) {
+            lvXo[nlevels] = tid > 0 ? xs + (X.needHi - X.lo) : 0;
+            lvYo[nlevels] = tid > 0 ? ys + (Y.needHi - Y.lo) : 0;
+        }
     }
     __syncthreads();
     // stage the interpolation tables of every level, already reduced to what the inner loop needs
     // (region-relative LDS offsets, packed weights); all global loads are in flight at once and the
     // per-pixel loop below then touches LDS only
+    // One flat pass over the entries of all levels (an entry finds its level in the start table): a thread's two or
+    // three table loads are independent and in flight together.  (A loop per level and table waited for fourteen
+    // global round trips in turn: 8 of the 22 us a workgroup lives.)
     {
-        int xo = 0, yo = 0;
-        for (int l = 1; l < nlevels; l++) {
-            const int nW = lvXneed[l] - lvXlo[l], nH = lvYneed[l] - lvYlo[l];
-            const int xb = lvXt[l] + lvXlo[l], yb = lvYt[l] + lvYlo[l];
-            const int sLoX = lvXlo[l - 1], sLoY = lvYlo[l - 1];
-            const int sPitch = (lvXneed[l - 1] - sLoX + 3) & ~3; // LDS pitch of the source region
-            for (int k = tid; k < nW; k += 256) {
-                const OrbResizeX e = xtab[xb + k];
-                xt[xo + k] = make_uint2((unsigned)((int)e.sx - sLoX), (unsigned)(uint16_t)e.a0 | ((unsigned)(uint16_t)e.a1 << 16));
-            }
-            for (int k = tid; k < nH; k += 256) {
-                const OrbResizeY e = ytab[yb + k];
-                yt[yo + k] = make_uint2((unsigned)(((int)e.sy0 - sLoY) * sPitch) | ((unsigned)(((int)e.sy1 - sLoY) * sPitch) << 16),
-                                        (unsigned)(uint16_t)e.b0 | ((unsigned)(uint16_t)e.b1 << 16));
-            }
-            xo += nW;
-            yo += nH;
+        const int totalX = lvXo[nlevels], totalY = lvYo[nlevels];
+        for (int idx = tid; idx < totalX; idx += 256) {
+            int l = 1;
+            for (int j = 2; j < nlevels; j++) l = lvXo[j] <= idx ? j : l;
+            const int k = idx - lvXo[l];
+            const OrbResizeX e = xtab[lvXt[l] + lvXlo[l] + k];
+            xt[idx] = make_uint2((unsigned)((int)e.sx - lvXlo[l - 1]), (unsigned)(uint16_t)e.a0 | ((unsigned)(uint16_t)e.a1 << 16));
+        }
+        for (int idx = tid; idx < totalY; idx += 256) {
+            int l = 1;
+            for (int j = 2; j < nlevels; j++) l = lvYo[j] <= idx ? j : l;
+            const int k = idx - lvYo[l];
+            const OrbResizeY e = ytab[lvYt[l] + lvYlo[l] + k];
+            const int sLoY = lvYlo[l - 1];
+            const int sPitch = (lvXneed[l - 1] - lvXlo[l - 1] + 3) & ~3; // LDS pitch of the source region
+            yt[idx] = make_uint2((unsigned)(((int)e.sy0 - sLoY) * sPitch) | ((unsigned)(((int)e.sy1 - sLoY) * sPitch) << 16),
+                                 (unsigned)(uint16_t)e.b0 | ((unsigned)(uint16_t)e.b1 << 16));
         }
     }
     // level 0: stage the needed region of the input image, write the owned part
