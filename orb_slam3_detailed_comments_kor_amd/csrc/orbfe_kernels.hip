@@ -1265,19 +1265,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     const float p7 = -0.04432655554792128f * scale;
     const float eps = (float)2.2204460492503131e-16;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(
-            __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(
-            90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1),
-                            c));
-    }
+    // the two branches of the reference (ax >= ay: c = ay / (ax + eps); else c = ax / (ay + eps), a = 90 - a) differ
+    // only in which of the two is the numerator: one division and one polynomial, then the branch's subtraction
+    const bool steep = !(ax >= ay);
+    const float num = steep ? ax : ay, den = steep ? ay : ax;
+    const float c = __fdiv_rn(num, __fadd_rn(den, eps));
+    const float c2 = __fmul_rn(c, c);
+    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (steep) a = __fsub_rn(90.f, a);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
