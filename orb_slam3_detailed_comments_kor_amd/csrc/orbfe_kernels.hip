@@ -231,8 +231,14 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                         const uint8_t* pk = p + k * pStep;
                         if (fullLoad) {
                             __builtin_memcpy(&v[k], pk, 4);
-                        } else {
-                            for (int b = 0; c + b < safeW && b < 4; b++) v[k] |= (uint32_t)pk[b] << (8 * b);
+                        } else if (safeW > c) { // the image's last 1..3 columns: one 16-bit and / or one 8-bit load
+                            const int rem = safeW - c;
+                            if (rem & 2) {
+                                uint16_t h;
+                                __builtin_memcpy(&h, pk, 2);
+                                v[k] = h;
+                            }
+                            if (rem & 1) v[k] |= (uint32_t)pk[rem & 2] << (8 * (rem & 2));
                         }
                     }
                 }
@@ -246,7 +252,12 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                             if (fullStore) {
                                 __builtin_memcpy(qk, &v[k], 4);
                             } else {
-                                for (int b = 0; c + b < ownW; b++) qk[b] = (uint8_t)(v[k] >> (8 * b));
+                                const int rem = ownW - c; // 1..3
+                                if (rem & 2) {
+                                    const uint16_t h = (uint16_t)v[k];
+                                    __builtin_memcpy(qk, &h, 2);
+                                }
+                                if (rem & 1) qk[rem & 2] = (uint8_t)(v[k] >> (8 * (rem & 2)));
                             }
                         }
                     }
@@ -328,8 +339,13 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                 if (r < ownH && colOwned) {
                     if (fullDword) {
                         __builtin_memcpy(q, &packed, 4);
-                    } else {
-                        for (int k = 0; c0 + k < ownW; k++) q[k] = (uint8_t)(packed >> (8 * k));
+                    } else { // the tile's last owned group: 1..3 bytes as at most one 16-bit and one 8-bit store
+                        const int rem = ownW - c0;
+                        if (rem & 2) {
+                            const uint16_t h = (uint16_t)packed;
+                            __builtin_memcpy(q, &h, 2);
+                        }
+                        if (rem & 1) q[rem & 2] = (uint8_t)(packed >> (8 * (rem & 2)));
                     }
                 }
             }
