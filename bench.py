@@ -10,18 +10,35 @@ shard of frames (weak scaling) and ONE RCCL all-gather per step exchanges the de
 cross-camera matching.  Timing: W warm-up steps, then exactly K steps between barrier +
 torch.cuda.synchronize(), MAX over ranks; rank 0 prints one JSON line.
 
-Extra objects in the line:
-  roofline     -- dominant kernel (by hipEvent time on the extractor's stream, measured live over
-                  the timed steps): algorithmic bytes per launch / average launch time vs 8 TB/s HBM.
-  pipelined    -- not `value`: the same batches alternating between two extractor contexts on two streams.
-  single_frame -- not `value`: configs[1] read literally, ONE resident frame per call (latency-bound).
-  cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
-                  built without OpenCV) timed on this host's cores on a bounded sample.
+Clock settling: after the W warm-up steps the same step keeps running, untimed, until at least
+--settle seconds (default 0.5) have passed, whatever W is -- with few warm-up steps the GPU clocks have
+not ramped up and the timed steps read several per cent slow.  Then exactly K steps are timed.
+
+Extra objects in the line (none of them is `value`):
+  roofline       -- dominant kernel (by hipEvent time on the extractor's stream, measured live over
+                    the timed steps): algorithmic bytes per launch / average launch time vs 8 TB/s HBM.
+                    `traffic` / `valu_issue_frac` are NOT measured in this run: they are read from the
+                    committed rocprofv3 counter summary named in `traffic_source`.
+  pcie_inclusive -- the metric as SURVEY.md 8(d) defines it for the drop-in boundary: wall time of
+                    orbfe_extract* with HOST pointers, H2D of the images and D2H of keypoints +
+                    descriptors included; measured by the C++ caller tools/hostbench (child process):
+                    single frame (pageable / pinned, p50 / p99), batch of 64 (pageable / pinned /
+                    two batches in flight), the bare-copy PCIe floor of the same bytes, and the
+                    reference's stereo protocol (2 extractors, 2 threads, + ComputeStereoMatches).
+  pipelined      -- the same resident batches alternating between two extractor contexts on two streams.
+  single_frame   -- configs[1] read literally, ONE resident frame per call (latency-bound).
+  first_call_ms  -- the first extraction of the process (libm trig table build + upload, allocations).
+  cpu_baseline   -- the CPU oracle (a port of the reference path; the reference itself cannot be
+                    built without OpenCV), rebuilt on this host with BASELINE.md's flags and timed on a
+                    bounded sample: 1 thread (mono protocol), 2 threads / 2 extractors (the reference's
+                    stereo protocol, src/Frame.cc:119-122), and all usable cores.
 """
 import argparse
 import json
 import os
 import sys
+import subprocess
+import tempfile
 import time
 
 import numpy as np
@@ -79,31 +96,68 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(rows, cols, nfeatures, seconds=12.0):
-    """Oracle extractor (C++ threads, one extractor per thread) over independent frames, bounded sample."""
+def cpu_baseline(rows, cols, nfeatures, seconds=14.0):
+    """Oracle extractor (C++ threads, one extractor per thread) over independent frames, bounded sample.
+    Protocols of SURVEY.md 8(d): (i) 1 thread, (ii) 2 threads / 2 extractors, (iii) all usable cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orb_oracle_py as O
     from orb_slam3_detailed_comments_kor_amd import synth
     O.build()
+    native = O.lib_native() is not None  # -O3 -march=native build made on THIS host; portable -O2 build otherwise
+    flags = O.NATIVE_FLAGS if native else O.PORTABLE_FLAGS
     cores = usable_cores()
     frames = np.stack([synth.make_frame(rows, cols, 1234 + i) for i in range(4)])
-    # single-thread rate first (mono protocol, reference src/Frame.cc:306)
-    n1, t1 = O.extract_many(frames, 1, 4, nfeatures, lap=(0, 1000))
-    reps1 = max(4, int(0.2 * seconds / (t1 / 4)))
-    n1, t1 = O.extract_many(frames, 1, reps1, nfeatures, lap=(0, 1000))
-    per_frame = t1 / reps1
-    # all cores: calibrate with 2 frames per thread, then size the run for the remaining budget
-    nc, tc = O.extract_many(frames, cores, 2, nfeatures, lap=(0, 1000))
-    reps = int(min(max(2, 0.6 * seconds / (tc / 2)), 200))
-    n, dt = O.extract_many(frames, cores, reps, nfeatures, lap=(0, 1000))
+
+    def run(threads, budget, lap):
+        n, t = O.extract_many(frames, threads, 2, nfeatures, lap=lap, native=native)  # calibrate
+        reps = int(min(max(2, budget / (t / 2)), 400))
+        n, t = O.extract_many(frames, threads, reps, nfeatures, lap=lap, native=native)
+        return n, t, reps
+
+    n1, t1, r1 = run(1, 0.2 * seconds, (0, 1000))       # (i) mono protocol, reference src/Frame.cc:306
+    n2, t2, r2 = run(2, 0.2 * seconds, (0, 0))          # (ii) stereo protocol: left + right extractor threads
+    n, dt, reps = run(cores, 0.5 * seconds, (0, 1000))  # (iii) best-case CPU throughput over independent frames
     return {
         "value": n / dt,
         "unit": "keypoints/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d threads x %d frames of %dx%d (nF=%d) in %.1f s; 1 thread: %.0f keypoints/s (%.1f ms/frame)"
-                  % (cores, reps, cols, rows, nfeatures, dt, n1 / t1, 1e3 * per_frame),
+        "flags": "g++ " + flags,
+        "one_thread": {"value": n1 / t1, "ms_per_frame": 1e3 * t1 / r1},
+        "two_threads_stereo": {"value": n2 / t2, "ms_per_pair": 1e3 * t2 / r2,
+                               "note": "2 threads x 1 extractor each, one frame per thread per pair (src/Frame.cc:119-122)"},
+        "sample": "oracle built with `g++ %s`; %d threads x %d frames of %dx%d (nF=%d) in %.1f s; "
+                  "1 thread: %.0f keypoints/s (%.1f ms/frame, %d frames); 2 threads: %.1f ms per stereo pair (%d pairs)"
+                  % (flags, cores, reps, cols, rows, nfeatures, dt, n1 / t1, 1e3 * t1 / r1, r1, 1e3 * t2 / r2, r2),
     }
+
+
+def bench_frames(rows, cols, batch, rank=0):
+    """The synthetic batch: a few generated frames, horizontally rolled to fill the batch (distinct per rank)."""
+    from orb_slam3_detailed_comments_kor_amd import synth
+    nuniq = min(batch, 8)
+    base = [synth.make_frame(rows, cols, 1234 + rank * 1000 + i) for i in range(nuniq)]
+    return np.stack([np.roll(base[i % nuniq], 23 * (i // nuniq), axis=1) for i in range(batch)])
+
+
+def pcie_inclusive(rows, cols, batch, nfeatures, device=0, as_text=False):
+    """Runs tools/hostbench (C++ caller of the C ABI, built by __graft_entry__.build()) on the bench frames and
+    returns its JSON object: the PCIe-inclusive rates of the drop-in boundary."""
+    exe = os.path.join(ROOT, "tools", "hostbench")
+    if not os.path.exists(exe):
+        raise SystemExit("tools/hostbench is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as f:
+        f.write(bench_frames(rows, cols, batch).tobytes())
+        path = f.name
+    try:
+        out = subprocess.run([exe, path, str(rows), str(cols), str(batch), str(nfeatures), str(device)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    if out.returncode != 0:
+        raise SystemExit("tools/hostbench failed (%d): %s" % (out.returncode, out.stderr[-500:]))
+    line = out.stdout.strip().splitlines()[-1]
+    return line if as_text else json.loads(line)
 
 
 def main():
@@ -117,6 +171,9 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--trig", choices=["libm", "cr", "hostcheck"], default="libm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive child process (tools/hostbench)")
+    ap.add_argument("--settle", type=float, default=0.5,
+                    help="keep running untimed steps after the warm-up until this many seconds have passed")
     ap.add_argument("--event-every", type=int, default=6,
                     help="record the per-stage hipEvents on every N-th timed step (7 event records cost ~25 us)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-context measurement")
@@ -131,6 +188,9 @@ def main():
     from orb_slam3_detailed_comments_kor_amd.multicam import PipelinedExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -143,10 +203,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, H, W = args.batch, args.rows, args.cols
-    # distinct frames per rank: a few generated frames, horizontally rolled to fill the batch
-    nuniq = min(B, 8)
-    base = [pkg.synth.make_frame(H, W, 1234 + rank * 1000 + i) for i in range(nuniq)]
-    imgs = np.stack([np.roll(base[i % nuniq], 23 * (i // nuniq), axis=1) for i in range(B)])
+    imgs = bench_frames(H, W, B, rank)  # distinct frames per rank
     d_img = torch.from_numpy(imgs).to(dev)
 
     ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank,
@@ -201,8 +258,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the first extraction of the process builds and uploads the libm trig table and allocates every buffer
+    tf = time.perf_counter()
+    step()
+    barrier()
+    first_call_ms = 1e3 * (time.perf_counter() - tf)
+    for _ in range(max(args.warmup - 1, 0)):
         step()
+    barrier()
+    # clock settling by TIME, not by step count: keep stepping (untimed) until --settle seconds have passed
+    settle_steps = 0
+    ts = time.perf_counter()
+    while time.perf_counter() - ts < args.settle:
+        for _ in range(8):
+            step()
+        settle_steps += 8
+        torch.cuda.synchronize()
     barrier()
     ex.profile(args.event_every)
     t0 = time.perf_counter()
@@ -290,8 +361,11 @@ def main():
         per_kernel = {}
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
                      "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc):
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
+                                os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) if os.path.exists(q)), "")
+        traffic_source = None
+        if pmc:
+            traffic_source = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this workload; not measured in this run)"
             try:
                 j = json.load(open(pmc))
                 if j.get("workload") == {"batch": B, "rows": H, "cols": W, "nfeatures": args.nfeatures}:
@@ -316,6 +390,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -342,8 +417,11 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "valu_issue_frac": valu_issue,
+                "traffic_source": traffic_source if traffic is not None else None,
                 "algorithmic_bytes_per_launch": launch_bytes,
-                "event_sampling": "stage hipEvents on every %d-th of the timed steps" % max(args.event_every, 1),
+                "event_sampling": "stage hipEvents on every %d-th of the timed steps; the sampled steps carry the seven "
+                                  "event records, so the stage times add up to a few per cent more than ms_per_step"
+                                  % max(args.event_every, 1),
                 "avg_launch_ms": stage_ms[dom],
                 "stage_ms": stage_ms,
                 # the same figures for every kernel of the step (the two largest are within a few per cent of
@@ -363,6 +441,10 @@ def main():
             out["pipelined"] = pipelined
         if single is not None:
             out["single_frame"] = single
+        out["first_call_ms"] = first_call_ms
+        if world == 1 and not args.no_pcie:
+            torch.cuda.synchronize()
+            out["pcie_inclusive"] = pcie_inclusive(H, W, B, args.nfeatures, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
         print(json.dumps(out))

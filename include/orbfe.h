@@ -103,12 +103,36 @@ int orbfe_extract_batch(orbfe_ctx*, int nimg, const uint8_t* const* imgs, int ro
                         const int* lap /* 2*nimg or NULL (= {0,0}) */, orbfe_kp* kps, uint8_t* desc, int cap_per_img,
                         int* n_out, int* mono_out);
 
+/* The same call split in two, for callers that keep the PCIe link and the GPU busy at once: submit queues the
+ * transfer of the images, the kernels and the transfer of the results and returns; wait completes the OLDEST
+ * submitted batch (its n_out / mono_out / kps / desc are valid afterwards, not before).  Up to two batches may be in
+ * flight per context: the images of batch i+1 and the results of batch i-1 then cross the link while the kernels
+ * of batch i run.  ORBFE_ERR_STATE when a third batch is submitted, or nothing is in flight.  The blocking calls
+ * above may not be mixed with batches in flight.  All arrays (and the images) must stay valid until the wait. */
+int orbfe_extract_batch_submit(orbfe_ctx*, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride,
+                               const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out);
+int orbfe_extract_batch_wait(orbfe_ctx*);
+
+/* Page-locked host memory.  A DMA engine moves pinned memory at the full PCIe rate with one command; pageable
+ * memory is staged (by this library, with a few host threads) at a fraction of it.  Every host-pointer entry point
+ * of the extractor recognises images and output arrays that are pinned -- allocated here, registered here, or
+ * pinned by someone else (hipHostMalloc, torch pin_memory) -- and takes the direct path for them; rows of the
+ * output arrays beyond n_out[i] are then unspecified.  Registering pins an existing buffer (e.g. a camera driver's
+ * ring); it is expensive (page-locking), so do it once per buffer, not per frame. */
+void* orbfe_host_alloc(size_t bytes);
+void orbfe_host_free(void*);
+int orbfe_host_register(void* p, size_t bytes);
+int orbfe_host_unregister(void* p);
+
 /* Same, with every buffer already resident in device memory (no PCIe traffic).  Asynchronous on the
  * context's stream unless the trig mode needs the host (ORBFE_TRIG_LIBM_HOSTCHECK synchronises once per call).
  * d_imgs: nimg images, image i at d_imgs + i*img_stride_bytes, row pitch `pitch`. */
 int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch,
                                size_t img_stride_bytes, int lap0, int lap1, orbfe_kp* d_kps, uint8_t* d_desc,
                                int cap_per_img, int32_t* d_n_out, int32_t* d_mono_out);
+/* Waits for the context's stream and returns ORBFE_ERR_STATE when a kernel of the finished work raised the device
+ * error word (a quadtree list overflow, which the bounds of SURVEY.md A.9 rule out): the asynchronous call above
+ * cannot report it itself. */
 int orbfe_sync(orbfe_ctx*);
 
 /* Scale getters (include/ORBextractor.h:61-81) and mvImagePyramid (:83). */
@@ -152,6 +176,13 @@ int orbfe_debug_trig(orbfe_ctx*, const float* angles_deg, int n, float* a_out, f
 int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_kp* kpsL, const uint8_t* descL, int nL,
                                  const orbfe_kp* kpsR, const uint8_t* descR, int nR, float mb, float mbf, float* uRight,
                                  float* depth);
+
+/* The same on what the two contexts' LAST extraction left on the device (image imgL of the left context's batch
+ * against image imgR of the right one): keypoints, descriptors, counts and both pyramids are read in place, so a
+ * stereo frame costs two image uploads and one download of uRight / depth.  nL = entries of uRight / depth
+ * (the left image's n_out). */
+int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf,
+                                          float* uRight, float* depth, int nL);
 
 /* ---- matcher ---- */
 /* DescriptorDistance over all pairs: D[i*nB+j] = popcount(A_i xor B_j).  Host pointers. */

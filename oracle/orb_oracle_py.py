@@ -198,13 +198,37 @@ class Extractor:
         return self._kps(self.L.orb_oracle_get_level_keypoints, level)
 
 
-def extract_many(imgs, nthreads, reps, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, lap=(0, 0)):
+_NATIVE = None
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off -fno-fast-math"
+PORTABLE_FLAGS = "-O2 -ffp-contract=off -fno-fast-math"
+
+
+def lib_native():
+    """The same source built with BASELINE.md section 3's flags (-O3 -march=native -ffp-contract=off) ON THIS HOST,
+    for the timed CPU baseline only (a -march=native binary must not travel between machines, so it is rebuilt
+    whenever it is asked for in a new process).  Returns None when the build fails."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+            L = C.CDLL(os.path.join(_HERE, "liborb_oracle_native.so"))
+            L.orb_oracle_extract_many.restype = C.c_long
+            L.orb_oracle_extract_many.argtypes = lib().orb_oracle_extract_many.argtypes
+            _NATIVE = L
+        except Exception:
+            _NATIVE = False
+    return _NATIVE or None
+
+
+def extract_many(imgs, nthreads, reps, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, lap=(0, 0),
+                 native=False):
     """Threaded CPU baseline: returns (total keypoints, seconds)."""
     imgs = np.ascontiguousarray(imgs, np.uint8)
     assert imgs.ndim == 3
     sec = C.c_double(0)
-    n = lib().orb_oracle_extract_many(nthreads, reps, nfeatures, scale, nlevels, ini_th, min_th, _p(imgs),
-                                      imgs.shape[0], imgs.shape[1], imgs.shape[2], lap[0], lap[1], C.byref(sec))
+    L = (lib_native() if native else None) or lib()
+    n = L.orb_oracle_extract_many(nthreads, reps, nfeatures, scale, nlevels, ini_th, min_th, _p(imgs),
+                                  imgs.shape[0], imgs.shape[1], imgs.shape[2], lap[0], lap[1], C.byref(sec))
     return int(n), sec.value
 
 

@@ -172,6 +172,16 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.orbfe_extract_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_size_t,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_extract_batch_submit.argtypes = L.orbfe_extract_batch.argtypes
+        L.orbfe_extract_batch_wait.argtypes = [C.c_void_p]
+        L.orbfe_host_alloc.restype = C.c_void_p
+        L.orbfe_host_alloc.argtypes = [C.c_size_t]
+        L.orbfe_host_free.restype = None
+        L.orbfe_host_free.argtypes = [C.c_void_p]
+        L.orbfe_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.orbfe_host_unregister.argtypes = [C.c_void_p]
+        L.orbfe_compute_stereo_matches_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                                            C.c_void_p, C.c_void_p, C.c_int]
         L.orbfe_extract_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
                                                  C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p]
@@ -219,11 +229,50 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
            "orbfe_hamming_pairs", "orbfe_bfknn2", "orbfe_search_bow", "orbfe_search_tri", "orbfe_search_bow_batch", "orbfe_kb8_unproject",
            "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps", "orbfe_search_projection_batch",
-           "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform"]
+           "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform",
+           "orbfe_extract_batch_submit", "orbfe_extract_batch_wait", "orbfe_host_alloc", "orbfe_host_free",
+           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident"]
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class PinnedBuffer:
+    """Page-locked host memory from orbfe_host_alloc, viewed as numpy arrays (`array(shape, dtype, offset)`)."""
+
+    def __init__(self, nbytes):
+        self.L = lib()
+        self.nbytes = int(nbytes)
+        self.ptr = self.L.orbfe_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("orbfe_host_alloc(%d) failed" % nbytes)
+        self._raw = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+
+    def array(self, shape, dtype=np.uint8, offset=0):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        assert offset + n <= self.nbytes
+        return np.frombuffer(self._raw, dtype=dtype, count=int(np.prod(shape)), offset=offset).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self._raw = None
+            self.L.orbfe_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+def host_register(arr):
+    """Pin an existing numpy array (orbfe_host_register); returns the array.  Unpin with host_unregister."""
+    _chk(lib().orbfe_host_register(arr.ctypes.data, arr.nbytes), "orbfe_host_register")
+    return arr
+
+
+def host_unregister(arr):
+    _chk(lib().orbfe_host_unregister(arr.ctypes.data), "orbfe_host_unregister")
 
 
 def _chk(r, what):
@@ -308,6 +357,48 @@ class ORBextractor:
         _chk(self.L.orbfe_extract_batch(self.h, nimg, ptrs, rows, cols, cols, None if lap is None else _p(lap),
                                         _p(kps), _p(desc), cap, _p(n), _p(mono)), "orbfe_extract_batch")
         return [(int(mono[i]), kps[i, : n[i]].copy(), desc[i, : n[i]].copy()) for i in range(nimg)]
+
+    class Batch:
+        """Caller-side arrays of one host-pointer batch; reusable across calls (pinned=True: in page-locked
+        memory, the zero-staging path)."""
+
+        def __init__(self, ex, nimg, rows, cols, pinned=False):
+            self.nimg, self.rows, self.cols = nimg, rows, cols
+            self.cap = ex.max_keypoints(rows, cols)
+            nb_img, nb_k, nb_d = nimg * rows * cols, nimg * self.cap * 28, nimg * self.cap * 32
+            if pinned:
+                self.pin = PinnedBuffer(nb_img + nb_k + nb_d + 256)
+                o1 = (nb_img + 63) // 64 * 64
+                o2 = (o1 + nb_k + 63) // 64 * 64
+                self.images = self.pin.array((nimg, rows, cols), np.uint8, 0)
+                self.kps = self.pin.array((nimg, self.cap), KP_DTYPE, o1)
+                self.desc = self.pin.array((nimg, self.cap, 32), np.uint8, o2)
+            else:
+                self.pin = None
+                self.images = np.zeros((nimg, rows, cols), np.uint8)
+                self.kps = np.zeros((nimg, self.cap), KP_DTYPE)
+                self.desc = np.zeros((nimg, self.cap, 32), np.uint8)
+            self.n = np.zeros(nimg, np.int32)
+            self.mono = np.zeros(nimg, np.int32)
+            self.lap = np.zeros((nimg, 2), np.int32)
+            self.ptrs = (C.c_void_p * nimg)(*[self.images[i].ctypes.data for i in range(nimg)])
+
+        def results(self):
+            return [(int(self.mono[i]), self.kps[i, : self.n[i]].copy(), self.desc[i, : self.n[i]].copy())
+                    for i in range(self.nimg)]
+
+    def run_batch(self, b):
+        """Blocking orbfe_extract_batch on a Batch's arrays (no allocation, no copies on the Python side)."""
+        _chk(self.L.orbfe_extract_batch(self.h, b.nimg, b.ptrs, b.rows, b.cols, b.cols, _p(b.lap), _p(b.kps), _p(b.desc),
+                                        b.cap, _p(b.n), _p(b.mono)), "orbfe_extract_batch")
+
+    def submit_batch(self, b):
+        """orbfe_extract_batch_submit: queue the batch (at most two in flight), results valid after wait_batch()."""
+        _chk(self.L.orbfe_extract_batch_submit(self.h, b.nimg, b.ptrs, b.rows, b.cols, b.cols, _p(b.lap), _p(b.kps),
+                                               _p(b.desc), b.cap, _p(b.n), _p(b.mono)), "orbfe_extract_batch_submit")
+
+    def wait_batch(self):
+        _chk(self.L.orbfe_extract_batch_wait(self.h), "orbfe_extract_batch_wait")
 
     def extract_batch_device(self, d_imgs_ptr, nimg, rows, cols, pitch, img_stride, lap, d_kps_ptr, d_desc_ptr, cap,
                              d_n_ptr, d_mono_ptr):
@@ -408,6 +499,15 @@ def compute_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
     n = _chk(lib().orbfe_compute_stereo_matches(exL.h, exR.h, _p(kpsL), _p(dL), len(kpsL), _p(kpsR), _p(dR), len(kpsR),
                                                 mb, mbf, _p(uR), _p(dep)), "orbfe_compute_stereo_matches")
     return n, uR, dep
+
+
+def compute_stereo_matches_resident(exL, exR, nL, mb, mbf, imgL=0, imgR=0):
+    """The same on what the two extractors' last calls left on the device (no keypoint / descriptor upload)."""
+    uR = np.zeros(max(nL, 1), np.float32)
+    dep = np.zeros(max(nL, 1), np.float32)
+    n = _chk(lib().orbfe_compute_stereo_matches_resident(exL.h, imgL, exR.h, imgR, mb, mbf, _p(uR), _p(dep), nL),
+             "orbfe_compute_stereo_matches_resident")
+    return n, uR[:nL], dep[:nL]
 
 
 # ------------------------------------------------------------------------ matcher

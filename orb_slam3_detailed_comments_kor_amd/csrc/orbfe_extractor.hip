@@ -14,8 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <sched.h>
@@ -82,6 +86,13 @@ struct PinBuf {
         n = count;
         return 0;
     }
+    // the address a kernel uses to read this buffer in place (zero-copy over PCIe)
+    T* dev() const
+    {
+        void* d = nullptr;
+        if (!p || hipHostGetDevicePointer(&d, (void*)p, 0) != hipSuccess) return p;
+        return (T*)d;
+    }
     void release()
     {
         if (p) (void)hipHostFree(p);
@@ -129,12 +140,12 @@ struct orbfe_ctx {
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
-    DevBuf<uint8_t> d_pyr, d_desc, d_img;
+    DevBuf<uint8_t> d_pyr;
     DevBuf<uint32_t> d_cand, d_keys, d_lvlKp;
     DevBuf<uint16_t> d_keyNode;
-    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap, d_n, d_mono;
+    DevBuf<int32_t> d_cellCount, d_lvlCount, d_lap;
     DevBuf<int4> d_fix; // [0] = {count,0,0,0}, then one entry per flagged keypoint
-    DevBuf<float> d_kps, d_kb8, d_rays;
+    DevBuf<float> d_kb8, d_rays;
     bool kb8On = false;
     float kb8[8] = {0};
     float* userRays = nullptr; // device pointer supplied by orbfe_set_ray_output
@@ -152,11 +163,38 @@ struct orbfe_ctx {
     bool tapsDirty = true;
     int lapDev0 = 0, lapDev1 = 0, lapDevCount = 0; // what d_lap currently holds (orbfe_extract_batch_device)
     DevBuf<float4> d_patternF;
-    PinBuf<int32_t> h_n, h_mono;
-    PinBuf<float> h_kps;
-    PinBuf<uint8_t> h_desc;
     PinBuf<int4> h_fix, h_fixAB; // pinned: h_fixAB is read by the fix-up kernel directly (zero-copy)
-    size_t imgPitch = 0, imgStride = 0;
+
+    // Host-pointer path (orbfe_extract, orbfe_extract_batch, orbfe_extract_batch_submit / _wait): two slots, each
+    // with its own device input and output buffers and pinned staging, so that the H2D of batch i+1 and the D2H of
+    // batch i-1 run beside the kernels of batch i.
+    struct HostSlot {
+        DevBuf<uint8_t> d_img;  // the batch's images
+        DevBuf<uint8_t> d_out;  // [meta: n[B] | mono[B] | err, 64-B padded][kps B*cap*28][desc B*cap*32]
+        PinBuf<uint8_t> h_in;   // staging of images that are not in pinned memory
+        PinBuf<uint8_t> h_out;  // meta always; the keypoint / descriptor slabs when the caller's arrays are pageable
+        PinBuf<int32_t> h_lap;  // per-image lapping ranges, read in place by K-PACK (no H2D command)
+        int32_t* d_lapAlias = nullptr;
+        hipEvent_t evIn = nullptr, evK = nullptr, evDone = nullptr;
+        bool busy = false, pipelined = false, outPinned = false;
+        int nimg = 0, cap = 0;
+        size_t metaBytes = 0;
+        orbfe_kp* kps = nullptr;
+        uint8_t* desc = nullptr;
+        int* n_out = nullptr;
+        int* mono_out = nullptr;
+    } slot[2];
+    long slotSubmitted = 0, slotRetired = 0; // FIFO over the two slots
+    hipStream_t sIn = nullptr, sOut = nullptr; // copy streams of the pipelined form
+    std::unordered_map<const void*, bool> pinnedCache; // what hipPointerGetAttributes said about a caller pointer
+    // where the last call left its outputs on the device (orbfe_compute_stereo_matches_resident, orbfe_frame_*)
+    const float* lastKps = nullptr;
+    const uint8_t* lastDesc = nullptr;
+    const int32_t* lastN = nullptr;
+    int lastCap = 0;
+    DevBuf<float> d_stereo; // uRight | depth | sad of orbfe_compute_stereo_matches_resident
+    PinBuf<float> h_stereo;
+    hipEvent_t evStereo = nullptr;
 
     int lastImgs = 0;
     int lastFixups = 0;
@@ -696,7 +734,8 @@ inline void rec(orbfe_ctx* c, int i)
 
 // The whole pipeline on the context's stream.  All pointers are device pointers.
 int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch, size_t imgStride,
-               const int32_t* d_lap, float* d_kps, uint8_t* d_desc, int capPerImg, int32_t* d_n, int32_t* d_mono)
+               const int32_t* d_lap, float* d_kps, uint8_t* d_desc, int capPerImg, int32_t* d_n, int32_t* d_mono,
+               int32_t* d_errOut = nullptr /* K-PACK copies the batch's error word here (host-pointer path) */)
 {
     int r;
     if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
@@ -782,7 +821,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(PACK_THREADS), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
                            c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
                            c->kb8On ? c->d_kb8.p : nullptr,
-                           c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0);
+                           c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
+                           k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr);
         if (nsub == 1) rec(c, 4);
         // K-DESC
         {
@@ -804,10 +844,17 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
         }
     }
-    if (nsub > 1)
+    if (nsub > 1) {
         for (int i = 1; i <= 4; i++) rec(c, i);
+        // every sub-batch has joined: only now is the error word final
+        if (d_errOut) HIP_TRY(hipMemcpyAsync(d_errOut, d_hdr + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
     rec(c, 5);
     c->lastImgs = nimg;
+    c->lastKps = d_kps;
+    c->lastDesc = d_desc;
+    c->lastN = d_n;
+    c->lastCap = capPerImg;
     c->lastFixups = 0;
     c->lastHostTrigCheck = hostTrigCheck;
     if (hostTrigCheck) {
@@ -855,6 +902,341 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     if (c->profile) c->profSeen++;
     c->recNow = false;
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Host-pointer path: pinned memory registry, staging-copy pool, the two-slot pipeline.
+//
+// What a DMA engine can read or write directly is page-locked ("pinned") host memory; a transfer from or to
+// pageable memory is staged by the runtime through an internal bounce buffer on the calling thread, at a fraction
+// of the PCIe rate, and blocks.  The boundary therefore (i) recognises caller buffers that are pinned -- allocated
+// with orbfe_host_alloc, registered with orbfe_host_register, or pinned by anyone else (hipHostMalloc, torch's
+// pin_memory: asked from the runtime once per pointer and remembered) -- and moves them with one DMA command, and
+// (ii) stages pageable buffers itself, through pinned memory the slot owns, with several host threads and in
+// chunks, so that the DMA of one chunk runs while the next is staged.
+struct PinRange {
+    const uint8_t* p;
+    size_t n;
+    bool owned;
+};
+std::mutex g_pinMutex;
+std::vector<PinRange> g_pins;
+
+void pin_add(const void* p, size_t n, bool owned)
+{
+    std::lock_guard<std::mutex> lock(g_pinMutex);
+    g_pins.push_back(PinRange{(const uint8_t*)p, n, owned});
+}
+bool pin_remove(const void* p)
+{
+    std::lock_guard<std::mutex> lock(g_pinMutex);
+    for (size_t i = 0; i < g_pins.size(); i++)
+        if (g_pins[i].p == (const uint8_t*)p) {
+            g_pins.erase(g_pins.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+bool pin_known(const void* p, size_t n)
+{
+    std::lock_guard<std::mutex> lock(g_pinMutex);
+    for (const PinRange& r : g_pins)
+        if ((const uint8_t*)p >= r.p && (const uint8_t*)p + n <= r.p + r.n) return true;
+    return false;
+}
+// Is [p, p+n) page-locked?  Registry first; otherwise the runtime is asked once per pointer value and the answer is
+// cached in the context (a camera driver reuses its buffers).  A stale answer is harmless: a copy from memory
+// wrongly believed pinned is staged by the runtime, one wrongly believed pageable is staged here.
+bool is_pinned(orbfe_ctx* c, const void* p, size_t n)
+{
+    if (pin_known(p, n)) return true;
+    auto it = c->pinnedCache.find(p);
+    if (it != c->pinnedCache.end()) return it->second;
+    hipPointerAttribute_t a;
+    bool pinned = false;
+    if (hipPointerGetAttributes(&a, p) == hipSuccess) pinned = a.type == hipMemoryTypeHost;
+    else (void)hipGetLastError(); // plain malloc'ed memory is "invalid value" for older runtimes: not an error here
+    if (c->pinnedCache.size() > 8192) c->pinnedCache.clear();
+    c->pinnedCache[p] = pinned;
+    return pinned;
+}
+
+// A few persistent host threads for the staging copies of pageable caller memory (memcpy from one thread moves
+// ~10 GB/s, a batch of 64 frames is 23 MB in and 4 MB out).  run(n, f) executes f(0..n-1) on the workers and the
+// caller and returns when all are done.  One run at a time; a second concurrent caller does its work inline.
+class CopyPool {
+public:
+    static CopyPool& get()
+    {
+        static CopyPool* p = new CopyPool(); // never destroyed: the workers are detached and die with the process
+        return *p;
+    }
+    void run(int n, const std::function<void(int)>& f)
+    {
+        if (n <= 0) return;
+        std::unique_lock<std::mutex> only(runM_, std::try_to_lock);
+        if (!only.owns_lock() || nWorkers_ == 0 || n == 1) {
+            for (int i = 0; i < n; i++) f(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &f;
+            ntasks_ = n;
+            next_.store(0);
+            checkedIn_ = 0;
+            gen_++;
+        }
+        cvWork_.notify_all();
+        for (int i; (i = next_.fetch_add(1)) < n;) f(i);
+        std::unique_lock<std::mutex> lk(m_);
+        cvDone_.wait(lk, [this] { return checkedIn_ == nWorkers_; }); // no worker touches fn_ after this
+        fn_ = nullptr;
+    }
+
+private:
+    CopyPool()
+    {
+        int T = std::min(8, host_threads()) - 1;
+        if (const char* e = getenv("ORBFE_COPY_THREADS")) T = std::min(15, std::max(0, atoi(e) - 1));
+        for (int t = 0; t < T; t++) {
+            std::thread([this] { worker(); }).detach();
+            nWorkers_++;
+        }
+    }
+    void worker()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cvWork_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                f = fn_;
+                n = ntasks_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < n;) (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                checkedIn_++;
+            }
+            cvDone_.notify_one();
+        }
+    }
+    std::mutex runM_, m_;
+    std::condition_variable cvWork_, cvDone_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int ntasks_ = 0, nWorkers_ = 0, checkedIn_ = 0;
+    unsigned long gen_ = 0;
+    std::atomic<int> next_{0};
+};
+
+inline void copy_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, int rows)
+{
+    if (dpitch == width && spitch == width) {
+        std::memcpy(dst, src, width * (size_t)rows);
+        return;
+    }
+    for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * dpitch, src + (size_t)y * spitch, width);
+}
+
+int slot_prepare(orbfe_ctx* c, orbfe_ctx::HostSlot& sl, bool pipelined)
+{
+    if (!sl.evDone) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.evK, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
+    }
+    if (pipelined && !c->sIn) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->sIn, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->sOut, hipStreamNonBlocking));
+    }
+    return 0;
+}
+
+// Queue one host-pointer batch: H2D of the images, the five kernels, D2H of the results.  `pipelined` puts the
+// copies on their own streams (ordered by events) so that they overlap the kernels of the neighbouring batches;
+// the blocking calls keep everything on the context's stream (no event traffic on the latency path).
+int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
+                orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined)
+{
+    if (!c || nimg < 1 || !imgs || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < nimg; i++) {
+        n_out[i] = 0;
+        if (mono_out) mono_out[i] = 0;
+    }
+    if (rows <= 0 || cols <= 0) return -1;
+    for (int i = 0; i < nimg; i++)
+        if (!imgs[i]) return -1;
+    if (stride < (size_t)cols) return ORBFE_ERR_ARGS;
+    if (c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: wait for one first
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if (cap_per_img < c->maxKp) return ORBFE_ERR_ARGS;
+    if ((r = ensure_capacity(c, nimg, cap_per_img)) < 0) return r;
+    orbfe_ctx::HostSlot& sl = c->slot[c->slotSubmitted & 1];
+    if ((r = slot_prepare(c, sl, pipelined)) < 0) return r;
+    hipStream_t s = c->stream;
+    hipStream_t sIn = pipelined ? c->sIn : s, sOut = pipelined ? c->sOut : s;
+    const size_t Kc = (size_t)cap_per_img;
+    const size_t imgBytes = (size_t)(rows - 1) * stride + (size_t)cols; // what may be read behind an image pointer
+
+    // ---- lapping ranges: written into pinned memory K-PACK reads in place
+    if (sl.h_lap.n < (size_t)2 * nimg) {
+        if ((r = sl.h_lap.ensure((size_t)2 * std::max(nimg, 64))) < 0) return r;
+        sl.d_lapAlias = sl.h_lap.dev();
+    }
+    for (int i = 0; i < 2 * nimg; i++) sl.h_lap.p[i] = lap ? lap[i] : 0;
+
+    // ---- images
+    bool allPinned = true;
+    for (int i = 0; i < nimg && allPinned; i++) allPinned = is_pinned(c, imgs[i], imgBytes);
+    size_t devPitch, devStride;
+    if (allPinned) {
+        // DMA straight from the caller's memory.  Rows are copied with their padding ((rows-1)*stride + cols bytes,
+        // one linear command per image, or ONE command for the whole batch when the images are evenly spaced in one
+        // buffer); the kernels then read the image with the caller's pitch.
+        bool even = stride <= 2 * (size_t)cols;
+        ptrdiff_t D = nimg > 1 ? imgs[1] - imgs[0] : (ptrdiff_t)align_up(imgBytes, 256);
+        for (int i = 1; i < nimg && even; i++) even = imgs[i] - imgs[i - 1] == D;
+        // (the bytes between two images are read too: they must belong to the same pinned buffer -- known from the
+        // registry, or because the images follow each other without a gap)
+        even = even && D >= (ptrdiff_t)imgBytes && (size_t)D <= 2 * align_up(imgBytes, 256) &&
+               ((size_t)D == (size_t)rows * stride || pin_known(imgs[0], (size_t)(nimg - 1) * (size_t)D + imgBytes));
+        if (stride <= 2 * (size_t)cols) {
+            devPitch = stride;
+            devStride = even ? (size_t)D : align_up(imgBytes, 256);
+            if ((r = sl.d_img.ensure((size_t)nimg * devStride + 256)) < 0) return r;
+            if (even) {
+                HIP_TRY(hipMemcpyAsync(sl.d_img.p, imgs[0], (size_t)(nimg - 1) * devStride + imgBytes,
+                                       hipMemcpyHostToDevice, sIn));
+            } else {
+                for (int i = 0; i < nimg; i++)
+                    HIP_TRY(hipMemcpyAsync(sl.d_img.p + (size_t)i * devStride, imgs[i], imgBytes, hipMemcpyHostToDevice,
+                                           sIn));
+            }
+        } else { // views with a large pitch: 2-D copies
+            devPitch = align_up((size_t)cols, 64);
+            devStride = devPitch * rows;
+            if ((r = sl.d_img.ensure((size_t)nimg * devStride + 256)) < 0) return r;
+            for (int i = 0; i < nimg; i++)
+                HIP_TRY(hipMemcpy2DAsync(sl.d_img.p + (size_t)i * devStride, devPitch, imgs[i], stride, (size_t)cols,
+                                         (size_t)rows, hipMemcpyHostToDevice, sIn));
+        }
+    } else {
+        // pageable (or mixed) images: dense staging copy by the pool, one DMA command per chunk of images while the
+        // next chunk is being staged
+        devPitch = (size_t)cols;
+        devStride = (size_t)cols * rows;
+        if ((r = sl.d_img.ensure((size_t)nimg * devStride + 256)) < 0) return r;
+        if ((r = sl.h_in.ensure((size_t)nimg * devStride)) < 0) return r;
+        const int chunk = nimg * devStride <= (2u << 20) ? nimg : std::max(1, (int)((4u << 20) / devStride));
+        for (int i0 = 0; i0 < nimg; i0 += chunk) {
+            const int ni = std::min(chunk, nimg - i0);
+            if ((size_t)ni * devStride < (1u << 20)) { // a frame or two: the pool's wake-up costs more than it saves
+                for (int i = i0; i < i0 + ni; i++)
+                    copy_rows(sl.h_in.p + (size_t)i * devStride, devPitch, imgs[i], stride, (size_t)cols, rows);
+            } else {
+                // split every image into row bands so that the work divides evenly whatever the chunk holds
+                const int bands = std::max(1, std::min(rows, 16 / ni + 1));
+                CopyPool::get().run(ni * bands, [&](int t) {
+                    const int i = i0 + t / bands, b = t % bands;
+                    const int y0 = (int)((long)rows * b / bands), y1 = (int)((long)rows * (b + 1) / bands);
+                    copy_rows(sl.h_in.p + (size_t)i * devStride + (size_t)y0 * devPitch, devPitch,
+                              imgs[i] + (size_t)y0 * stride, stride, (size_t)cols, y1 - y0);
+                });
+            }
+            HIP_TRY(hipMemcpyAsync(sl.d_img.p + (size_t)i0 * devStride, sl.h_in.p + (size_t)i0 * devStride,
+                                   (size_t)ni * devStride, hipMemcpyHostToDevice, sIn));
+        }
+    }
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(sl.evIn, sIn));
+        HIP_TRY(hipStreamWaitEvent(s, sl.evIn, 0));
+    }
+
+    // ---- kernels
+    sl.metaBytes = align_up(((size_t)2 * nimg + 1) * sizeof(int32_t), 64);
+    const size_t kpsBytes = (size_t)nimg * Kc * 28, descBytes = (size_t)nimg * Kc * 32;
+    if ((r = sl.d_out.ensure(sl.metaBytes + kpsBytes + descBytes)) < 0) return r;
+    int32_t* d_meta = reinterpret_cast<int32_t*>(sl.d_out.p);
+    float* d_kps = reinterpret_cast<float*>(sl.d_out.p + sl.metaBytes);
+    uint8_t* d_desc = sl.d_out.p + sl.metaBytes + kpsBytes;
+    r = run_device(c, nimg, sl.d_img.p, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc, cap_per_img,
+                   d_meta, d_meta + nimg, d_meta + 2 * nimg);
+    if (r < 0) return r;
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(sl.evK, s));
+        HIP_TRY(hipStreamWaitEvent(sOut, sl.evK, 0));
+    }
+
+    // ---- results: into the caller's arrays directly when those are pinned (the layouts are the same: nimg slabs of
+    // cap entries), else ONE transfer of [meta | keypoints | descriptors] into the slot's pinned staging
+    sl.outPinned = is_pinned(c, kps, kpsBytes) && is_pinned(c, desc, descBytes);
+    if (sl.outPinned) {
+        if ((r = sl.h_out.ensure(sl.metaBytes)) < 0) return r;
+        HIP_TRY(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.metaBytes, hipMemcpyDeviceToHost, sOut));
+        HIP_TRY(hipMemcpyAsync(kps, d_kps, kpsBytes, hipMemcpyDeviceToHost, sOut));
+        HIP_TRY(hipMemcpyAsync(desc, d_desc, descBytes, hipMemcpyDeviceToHost, sOut));
+    } else {
+        if ((r = sl.h_out.ensure(sl.metaBytes + kpsBytes + descBytes)) < 0) return r;
+        HIP_TRY(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.metaBytes + kpsBytes + descBytes, hipMemcpyDeviceToHost, sOut));
+    }
+    if (pipelined) HIP_TRY(hipEventRecord(sl.evDone, sOut));
+    sl.busy = true;
+    sl.pipelined = pipelined;
+    sl.nimg = nimg;
+    sl.cap = cap_per_img;
+    sl.kps = kps;
+    sl.desc = desc;
+    sl.n_out = n_out;
+    sl.mono_out = mono_out;
+    c->slotSubmitted++;
+    return 0;
+}
+
+// Complete the oldest submitted batch: wait for its transfers, hand out the counts, and -- for pageable output
+// arrays -- copy the rows each image produced out of the staging buffer.
+int host_wait(orbfe_ctx* c)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    if (c->slotSubmitted == c->slotRetired) return ORBFE_ERR_STATE;
+    orbfe_ctx::HostSlot& sl = c->slot[c->slotRetired & 1];
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = sl.pipelined ? hipEventSynchronize(sl.evDone) : hipStreamSynchronize(c->stream);
+    sl.busy = false;
+    c->slotRetired++;
+    if (e != hipSuccess) return -(1000 + (int)e);
+    const int nimg = sl.nimg;
+    const int32_t* meta = reinterpret_cast<const int32_t*>(sl.h_out.p);
+    if (meta[2 * nimg] != 0) return ORBFE_ERR_STATE; // a device-side list overflowed (cannot happen)
+    const size_t Kc = (size_t)sl.cap;
+    size_t total = 0;
+    for (int i = 0; i < nimg; i++) {
+        sl.n_out[i] = meta[i];
+        if (sl.mono_out) sl.mono_out[i] = meta[nimg + i];
+        total += (size_t)std::max(meta[i], 0);
+    }
+    if (!sl.outPinned && total > 0) {
+        const uint8_t* hk = sl.h_out.p + sl.metaBytes;
+        const uint8_t* hd = hk + (size_t)nimg * Kc * 28;
+        auto one = [&](int i) {
+            const int n = meta[i];
+            if (n <= 0) return;
+            std::memcpy((uint8_t*)sl.kps + (size_t)i * Kc * 28, hk + (size_t)i * Kc * 28, (size_t)n * 28);
+            std::memcpy(sl.desc + (size_t)i * Kc * 32, hd + (size_t)i * Kc * 32, (size_t)n * 32);
+        };
+        if (total * 60 < (1u << 20)) {
+            for (int i = 0; i < nimg; i++) one(i);
+        } else {
+            CopyPool::get().run(nimg, one);
+        }
+    }
     return 0;
 }
 
@@ -910,13 +1292,22 @@ void orbfe_destroy(orbfe_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_pyr.release(); c->d_desc.release(); c->d_img.release();
+    c->d_pyr.release();
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
-    c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release(); c->d_n.release(); c->d_mono.release();
-    c->d_fix.release(); c->d_kps.release(); c->d_kb8.release(); c->d_rays.release();
+    c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release();
+    c->d_fix.release(); c->d_kb8.release(); c->d_rays.release();
     c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
     c->d_taps.release(); c->d_patternF.release();
-    c->h_fix.release(); c->h_n.release(); c->h_mono.release(); c->h_fixAB.release(); c->h_kps.release(); c->h_desc.release();
+    c->h_fix.release(); c->h_fixAB.release(); c->d_stereo.release(); c->h_stereo.release();
+    for (auto& sl : c->slot) {
+        sl.d_img.release(); sl.d_out.release(); sl.h_in.release(); sl.h_out.release(); sl.h_lap.release();
+        if (sl.evIn) (void)hipEventDestroy(sl.evIn);
+        if (sl.evK) (void)hipEventDestroy(sl.evK);
+        if (sl.evDone) (void)hipEventDestroy(sl.evDone);
+    }
+    if (c->evStereo) (void)hipEventDestroy(c->evStereo);
+    if (c->sIn) (void)hipStreamDestroy(c->sIn);
+    if (c->sOut) (void)hipStreamDestroy(c->sOut);
     if (c->evReady)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1021,6 +1412,12 @@ int orbfe_sync(orbfe_ctx* c)
     if (!c) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_fix.p && c->lastImgs > 0) { // the error word of the last batch (k_octree raises it, nothing else does)
+        int r = c->h_fix.ensure(1);
+        if (r < 0) return r;
+        HIP_TRY(hipMemcpy(c->h_fix.p, c->d_fix.p, sizeof(int4), hipMemcpyDeviceToHost));
+        if (c->h_fix.p[0].y != 0) return ORBFE_ERR_STATE;
+    }
     return 0;
 }
 
@@ -1054,72 +1451,52 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
                       cap_per_img, d_n_out, d_mono_out);
 }
 
+// ---- pinned host memory ---------------------------------------------------------------------------
+int orbfe_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    pin_add(p, bytes, false);
+    return 0;
+}
+int orbfe_host_unregister(void* p)
+{
+    if (!p || !pin_remove(p)) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipHostUnregister(p));
+    return 0;
+}
+void* orbfe_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    pin_add(p, bytes, true);
+    return p;
+}
+void orbfe_host_free(void* p)
+{
+    if (!p) return;
+    if (pin_remove(p)) (void)hipHostFree(p);
+}
+
+// ---- host-pointer path ------------------------------------------------------------------------------
+int orbfe_extract_batch_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride,
+                               const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out)
+{
+    return host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, true);
+}
+
+int orbfe_extract_batch_wait(orbfe_ctx* c) { return host_wait(c); }
+
 int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride,
                         const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out)
 {
-    if (!c || nimg < 1 || !imgs || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
-    for (int i = 0; i < nimg; i++) {
-        n_out[i] = 0;
-        if (mono_out) mono_out[i] = 0;
-    }
-    if (rows <= 0 || cols <= 0) return -1;
-    for (int i = 0; i < nimg; i++)
-        if (!imgs[i]) return -1;
-    if (stride < (size_t)cols) return ORBFE_ERR_ARGS;
-    HIP_TRY(hipSetDevice(c->device));
-    int r;
-    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
-    if (cap_per_img < c->maxKp) return ORBFE_ERR_ARGS;
-    if ((r = ensure_capacity(c, nimg, cap_per_img)) < 0) return r;
-    const size_t B = (size_t)c->capImgs, K = (size_t)c->capKp;
-    c->imgPitch = align_up((size_t)cols, 64);
-    c->imgStride = c->imgPitch * rows;
-    if ((r = c->d_img.ensure(B * c->imgStride)) < 0) return r;
-    if ((r = c->d_kps.ensure(B * K * 7)) < 0) return r;
-    if ((r = c->d_desc.ensure(B * K * 32)) < 0) return r;
-    if ((r = c->d_n.ensure(B)) < 0) return r;
-    if ((r = c->d_mono.ensure(B)) < 0) return r;
-    if ((r = c->h_n.ensure(B)) < 0) return r;
-    if ((r = c->h_mono.ensure(B)) < 0) return r;
-    hipStream_t s = c->stream;
-    std::vector<int32_t> lapv((size_t)nimg * 2, 0);
-    if (lap)
-        for (int i = 0; i < 2 * nimg; i++) lapv[i] = lap[i];
-    HIP_TRY(hipMemcpyAsync(c->d_lap.p, lapv.data(), lapv.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    c->lapDevCount = 0; // per-image values: the cached uniform table of orbfe_extract_batch_device is gone
-    for (int i = 0; i < nimg; i++)
-        HIP_TRY(hipMemcpy2DAsync(c->d_img.p + (size_t)i * c->imgStride, c->imgPitch, imgs[i], stride, (size_t)cols,
-                                 (size_t)rows, hipMemcpyHostToDevice, s));
-    // no synchronisation here: the kernels are ordered after the copies on the stream, and both `lapv` and the
-    // caller's images outlive this call
-    r = run_device(c, nimg, c->d_img.p, rows, cols, c->imgPitch, c->imgStride, c->d_lap.p, c->d_kps.p, c->d_desc.p,
-                   cap_per_img, c->d_n.p, c->d_mono.p);
+    if (c && c->slotSubmitted != c->slotRetired) return ORBFE_ERR_STATE; // submitted batches must be waited for first
+    const int r = host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false);
     if (r < 0) return r;
-    // ONE round trip for everything the host needs: counts, the error word, and the keypoint / descriptor slabs of
-    // all images into pinned staging (per-image copies sized by the counts would need a second synchronisation, and
-    // 2 x nimg small copies cost more than the slack of the slabs); then the rows each image produced are copied out
-    const size_t Kc = (size_t)cap_per_img;
-    if ((r = c->h_kps.ensure((size_t)nimg * Kc * 7)) < 0) return r;
-    if ((r = c->h_desc.ensure((size_t)nimg * Kc * 32)) < 0) return r;
-    if ((r = c->h_fix.ensure(1)) < 0) return r;
-    HIP_TRY(hipMemcpyAsync(c->h_n.p, c->d_n.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c->h_mono.p, c->d_mono.p, (size_t)nimg * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (!c->lastHostTrigCheck) // otherwise run_device has already looked at the error word
-        HIP_TRY(hipMemcpyAsync(c->h_fix.p, c->d_fix.p, sizeof(int4), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c->h_kps.p, c->d_kps.p, (size_t)nimg * Kc * 28, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c->h_desc.p, c->d_desc.p, (size_t)nimg * Kc * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (!c->lastHostTrigCheck && c->h_fix.p[0].y != 0) return ORBFE_ERR_STATE;
-    for (int i = 0; i < nimg; i++) {
-        const int n = c->h_n.p[i];
-        n_out[i] = n;
-        if (mono_out) mono_out[i] = c->h_mono.p[i];
-        if (n <= 0) continue;
-        std::memcpy((uint8_t*)kps + (size_t)i * Kc * sizeof(orbfe_kp), c->h_kps.p + (size_t)i * Kc * 7,
-                    (size_t)n * sizeof(orbfe_kp));
-        std::memcpy(desc + (size_t)i * Kc * 32, c->h_desc.p + (size_t)i * Kc * 32, (size_t)n * 32);
-    }
-    return 0;
+    return host_wait(c);
 }
 
 int orbfe_extract(orbfe_ctx* c, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
@@ -1223,7 +1600,7 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
     ST_TRY(hipMemcpyAsync(dDL, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s));
     ST_TRY(hipMemcpyAsync(dDR, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_stereo_match, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, s, left->d_pyr.p, right->d_pyr.p,
-                       left->d_lg.p, left->nlevels, dKL, dDL, nL, dKR, dDR, nR, mb, mbf, dU, dD, dS);
+                       left->d_lg.p, left->nlevels, dKL, dDL, nL, dKR, dDR, nR, mb, mbf, dU, dD, dS, nullptr, nullptr);
     std::vector<int32_t> sad(nL);
     ST_TRY(hipMemcpyAsync(uRight, dU, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
     ST_TRY(hipMemcpyAsync(depth, dD, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
@@ -1245,6 +1622,68 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
         uRight[vDistIdx[i].second] = -1;
         depth[vDistIdx[i].second] = -1;
         kept--;
+    }
+    return kept;
+}
+
+// The same on what the two extractors' last calls left on the device: keypoints, descriptors, counts and both
+// pyramids are read in place; only uRight / depth / SAD come back (one transfer).
+int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf,
+                                          float* uRight, float* depth, int nL)
+{
+    if (!left || !right || nL < 0 || (nL && (!uRight || !depth)) || !(mb > 0)) return ORBFE_ERR_ARGS;
+    if (left->lg.empty() || right->lg.empty() || !left->lastKps || !right->lastKps || imgL < 0 || imgR < 0 ||
+        imgL >= left->lastImgs || imgR >= right->lastImgs || left->device != right->device ||
+        left->rows != right->rows || left->cols != right->cols || left->nlevels != right->nlevels ||
+        left->scaleFactor != right->scaleFactor || nL > left->lastCap || right->lastCap >= (1 << 20))
+        return ORBFE_ERR_STATE;
+    HIP_TRY(hipSetDevice(left->device));
+    int r;
+    const size_t cap = (size_t)left->lastCap;
+    if ((r = left->d_stereo.ensure(3 * cap)) < 0) return r;
+    if ((r = left->h_stereo.ensure(3 * cap)) < 0) return r;
+    hipStream_t s = left->stream;
+    if (right->stream != s) { // the right extractor's kernels must have finished: order the streams, not the host
+        if (!left->evStereo) HIP_TRY(hipEventCreateWithFlags(&left->evStereo, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(left->evStereo, right->stream));
+        HIP_TRY(hipStreamWaitEvent(s, left->evStereo, 0));
+    }
+    float* dU = left->d_stereo.p;
+    float* dD = dU + cap;
+    int32_t* dS = reinterpret_cast<int32_t*>(dD + cap);
+    const int capL = left->lastCap, capR = right->lastCap;
+    hipLaunchKernelGGL(k_stereo_match, dim3((unsigned)((capL + 3) / 4)), dim3(256), 0, s,
+                       left->d_pyr.p + (size_t)imgL * left->pyrStride, right->d_pyr.p + (size_t)imgR * right->pyrStride,
+                       left->d_lg.p, left->nlevels, left->lastKps + (size_t)imgL * capL * 7,
+                       left->lastDesc + (size_t)imgL * capL * 32, capL, right->lastKps + (size_t)imgR * capR * 7,
+                       right->lastDesc + (size_t)imgR * capR * 32, capR, mb, mbf, dU, dD, dS, left->lastN + imgL,
+                       right->lastN + imgR);
+    HIP_TRY(hipMemcpyAsync(left->h_stereo.p, dU, 3 * cap * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const float* hU = left->h_stereo.p;
+    const float* hD = hU + cap;
+    const int32_t* hS = reinterpret_cast<const int32_t*>(hD + cap);
+    // outlier cut (:952-966): sorted by SAD, the matches from the back down to the first one below 1.5*1.4*median go
+    // -- i.e. every match with SAD >= that bound; the median is the element size/2 of the sorted list
+    std::vector<int> sads;
+    sads.reserve((size_t)nL);
+    for (int i = 0; i < nL; i++) {
+        uRight[i] = hU[i];
+        depth[i] = hD[i];
+        if (hS[i] >= 0) sads.push_back(hS[i]);
+    }
+    if (sads.empty()) return 0;
+    std::nth_element(sads.begin(), sads.begin() + (long)(sads.size() / 2), sads.end());
+    const float thDist = 1.5f * 1.4f * (float)sads[sads.size() / 2];
+    int kept = 0;
+    for (int i = 0; i < nL; i++) {
+        if (hS[i] < 0) continue;
+        if ((float)hS[i] >= thDist) {
+            uRight[i] = -1;
+            depth[i] = -1;
+        } else {
+            kept++;
+        }
     }
     return kept;
 }

@@ -1178,7 +1178,9 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
                                               float* __restrict__ kpsOut /* 7 floats per kp */, int capPerImg,
                                               OrbDescWork* __restrict__ work, int32_t* __restrict__ nOut,
                                               int32_t* __restrict__ monoOut, const float* __restrict__ kb8 /* or NULL */,
-                                              float* __restrict__ raysOut /* 3 floats per kp, or NULL */, int imgBase)
+                                              float* __restrict__ raysOut /* 3 floats per kp, or NULL */, int imgBase,
+                                              const int32_t* __restrict__ errIn /* the batch's error word or NULL */,
+                                              int32_t* __restrict__ errOut /* where the host path reads it, or NULL */)
 {
     __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
     __shared__ int waveCnt[PACK_THREADS / 64];
@@ -1260,6 +1262,10 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
     if (tid == 0) {
         nOut[img] = n;
         monoOut[img] = n - runStereo;
+        // K-QT (the only kernel that raises the error word) has finished: hand the word to the host path's one
+        // metadata transfer.  With sub-batches on several streams only the first sub-batch's K-QT is ordered before
+        // this, which is why the host path runs on one stream.
+        if (errOut && errIn && blockIdx.x == 0) errOut[0] = errIn[0];
     }
 }
 
@@ -1774,10 +1780,14 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
                                                       int nL, const float* __restrict__ kpsR,
                                                       const uint8_t* __restrict__ descR, int nR, float mb, float mbf,
                                                       float* __restrict__ uRight, float* __restrict__ depth,
-                                                      int32_t* __restrict__ sadOut)
+                                                      int32_t* __restrict__ sadOut,
+                                                      const int32_t* __restrict__ nLdev /* counts still on the device */,
+                                                      const int32_t* __restrict__ nRdev /* (resident form), or NULL   */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iL = blockIdx.x * 4 + wave;
+    if (nLdev) nL = min(nL, nLdev[0]);
+    if (nRdev) nR = min(nR, nRdev[0]);
     if (iL >= nL) return;
     const float uL = kpsL[iL * 7 + 0], vL = kpsL[iL * 7 + 1];
     const int levelL = reinterpret_cast<const int32_t*>(kpsL)[iL * 7 + 5];

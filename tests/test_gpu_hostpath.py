@@ -1,0 +1,189 @@
+"""The drop-in boundary with HOST pointers (what an unmodified Frame::ExtractORB hands over, reference
+src/Frame.cc:413-420): pageable, pinned and registered caller memory, strided views, the two-deep
+submit / wait pipeline, and the resident form of Frame::ComputeStereoMatches -- all bit-exact vs the oracle."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def _same(kps, rkps, desc, rdesc):
+    assert len(kps) == len(rkps)
+    for f in FIELDS:
+        assert np.array_equal(kps[f], rkps[f]), f
+    assert np.array_equal(desc, rdesc)
+
+
+def _refs(oracle, frames, nf, laps):
+    ref = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    return [ref.extract(f, tuple(l)) for f, l in zip(frames, laps)]
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("nimg,hw", [(1, (240, 376)), (5, (240, 376)), (24, (480, 752))])
+def test_batch_pageable_and_pinned(pkg, oracle, pinned, nimg, hw):
+    """24 x 752x480 is 8.7 MB: the pageable form goes through the staging pool in chunks, the pinned one is a single
+    DMA command from the caller's buffer; per-image lapping ranges travel in the zero-copy table."""
+    ex = pkg.ORBextractor(700, 1.2, 8, 20, 7)
+    b = ex.Batch(ex, nimg, hw[0], hw[1], pinned=pinned)
+    uniq = [pkg.synth.make_frame(hw[0], hw[1], 900 + i) for i in range(min(nimg, 6))]
+    for i in range(nimg):
+        b.images[i] = np.roll(uniq[i % len(uniq)], 17 * (i // len(uniq)), axis=1)
+        b.lap[i] = (0, 0) if i % 3 == 0 else (50 * i, 50 * i + 200)
+    refs = _refs(oracle, b.images, 700, b.lap)
+    for rep in range(2):  # second call: slot buffers and the pinned-pointer cache are warm
+        b.kps[:] = 0
+        b.desc[:] = 0
+        ex.run_batch(b)
+        for (mono, kps, desc), r in zip(b.results(), refs):
+            assert mono == r[0]
+            _same(kps, r[1], desc, r[2])
+    ex.close()
+
+
+def test_registered_caller_memory_and_strided_views(pkg, oracle):
+    H, W = 240, 376
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    big = np.zeros((3, H, W + 40), np.uint8)       # views with a row pitch > cols
+    frames = [pkg.synth.make_frame(H, W, 40 + i) for i in range(3)]
+    for i in range(3):
+        big[i, :, 20:20 + W] = frames[i]
+    refs = _refs(oracle, frames, 500, [(0, 0)] * 3)
+    cap = ex.max_keypoints(H, W)
+    for registered in (False, True):
+        if registered:
+            pkg.binding.host_register(big)
+        kps = np.zeros((3, cap), pkg.KP_DTYPE)
+        desc = np.zeros((3, cap, 32), np.uint8)
+        n = np.zeros(3, np.int32)
+        mono = np.zeros(3, np.int32)
+        ptrs = (C.c_void_p * 3)(*[big[i, :, 20:].ctypes.data for i in range(3)])
+        r = ex.L.orbfe_extract_batch(ex.h, 3, ptrs, H, W, W + 40, None, kps.ctypes.data, desc.ctypes.data, cap,
+                                     n.ctypes.data, mono.ctypes.data)
+        assert r == 0
+        for i in range(3):
+            assert mono[i] == refs[i][0]
+            _same(kps[i, :n[i]], refs[i][1], desc[i, :n[i]], refs[i][2])
+        if registered:
+            pkg.binding.host_unregister(big)
+    # a view whose pitch is more than twice its width takes the 2-D copy path when pinned
+    wide = pkg.binding.PinnedBuffer(H * 3 * W)
+    arr = wide.array((H, 3 * W), np.uint8)
+    arr[:, W:2 * W] = frames[0]
+    kp1 = np.zeros(cap, pkg.KP_DTYPE)
+    de1 = np.zeros((cap, 32), np.uint8)
+    n1 = C.c_int(0)
+    r = ex.L.orbfe_extract(ex.h, arr[:, W:].ctypes.data, H, W, 3 * W, 0, 0, kp1.ctypes.data, de1.ctypes.data, cap, C.byref(n1))
+    assert r == refs[0][0]
+    _same(kp1[:n1.value], refs[0][1], de1[:n1.value], refs[0][2])
+    ex.close()
+    wide.close()
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_submit_wait_pipeline_two_in_flight(pkg, oracle, pinned):
+    """Two batches in flight: the copies of one overlap the kernels of the other; results are those of the blocking
+    call, in submission order; the queue refuses a third batch and a blocking call while batches are in flight."""
+    H, W, B = 240, 376, 6
+    ex = pkg.ORBextractor(600, 1.2, 8, 20, 7)
+    sets = [ex.Batch(ex, B, H, W, pinned=pinned) for _ in range(3)]
+    refs = []
+    for k, b in enumerate(sets):
+        for i in range(B):
+            b.images[i] = pkg.synth.make_frame(H, W, 7000 + 10 * k + i)
+            b.lap[i] = (0, 1000) if k == 1 else (0, 0)
+        refs.append(_refs(oracle, b.images, 600, b.lap))
+    ERR_STATE = pkg.binding.ERR_STATE
+    with pytest.raises(pkg.OrbfeError) as e:
+        ex.wait_batch()
+    assert e.value.code == ERR_STATE
+    ex.submit_batch(sets[0])
+    ex.submit_batch(sets[1])
+    with pytest.raises(pkg.OrbfeError) as e:
+        ex.submit_batch(sets[2])
+    assert e.value.code == ERR_STATE
+    with pytest.raises(pkg.OrbfeError) as e:
+        ex.run_batch(sets[2])
+    assert e.value.code == ERR_STATE
+    order = [0, 1]
+    for step in range(6):  # steady state: wait for the oldest, submit the next
+        ex.wait_batch()
+        k = order.pop(0)
+        for (mono, kps, desc), r in zip(sets[k].results(), refs[k]):
+            assert mono == r[0]
+            _same(kps, r[1], desc, r[2])
+        nxt = (k + 2) % 3
+        sets[nxt].kps[:] = 0
+        sets[nxt].desc[:] = 0
+        ex.submit_batch(sets[nxt])
+        order.append(nxt)
+    ex.wait_batch()
+    ex.wait_batch()
+    ex.run_batch(sets[0])  # the blocking call works again once the queue is empty
+    for (mono, kps, desc), r in zip(sets[0].results(), refs[0]):
+        _same(kps, r[1], desc, r[2])
+    ex.close()
+
+
+def test_stereo_pair_two_threads_resident_matches(pkg, oracle):
+    """The reference's stereo protocol (two extractors, two threads, src/Frame.cc:119-122) followed by
+    Frame::ComputeStereoMatches on what the extractors left on the device: no keypoint / descriptor upload."""
+    mb, mbf = 47.90639384423901 / 435.2046959714599, 47.90639384423901
+    for seed, shift in ((11, 20), (12, 6)):
+        left, right = pkg.synth.make_stereo_pair(480, 752, seed, shift=shift)
+        exL = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+        exR = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+        res = {}
+
+        def run(tag, ex, im):
+            res[tag] = ex(im, (0, 0))
+
+        tl = threading.Thread(target=run, args=("L", exL, left))
+        tr = threading.Thread(target=run, args=("R", exR, right))
+        tl.start(); tr.start(); tl.join(); tr.join()
+        _, kL, dL = res["L"]
+        _, kR, dR = res["R"]
+        n, uR, dep = pkg.binding.compute_stereo_matches_resident(exL, exR, len(kL), mb, mbf)
+        n2, uR2, dep2 = pkg.compute_stereo_matches(exL, exR, kL, dL, kR, dR, mb, mbf)
+        oL = oracle.Extractor(1200, 1.2, 8, 20, 7)
+        oR = oracle.Extractor(1200, 1.2, 8, 20, 7)
+        _, rkL, rdL = oL.extract(left, (0, 0))
+        _, rkR, rdR = oR.extract(right, (0, 0))
+        rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf)
+        assert n == n2 == rn and n > 100
+        assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)
+        assert np.array_equal(uR2, ruR) and np.array_equal(dep2, rdep)
+        exL.close()
+        exR.close()
+
+
+def test_sync_reports_no_error_and_device_path_still_matches(pkg, oracle):
+    import torch
+    H, W = 240, 376
+    ex = pkg.ORBextractor(400, 1.2, 8, 20, 7)
+    img = pkg.synth.make_frame(H, W, 77)
+    cap = ex.max_keypoints(H, W)
+    d_img = torch.from_numpy(img).cuda()
+    d_k = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda")
+    d_d = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_m = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_img.data_ptr(), 1, H, W, W, H * W, (0, 0), d_k.data_ptr(), d_d.data_ptr(), cap,
+                            d_n.data_ptr(), d_m.data_ptr())
+    ex.sync()  # also reads the device error word
+    r = oracle.Extractor(400, 1.2, 8, 20, 7).extract(img, (0, 0))
+    n = int(d_n.item())
+    assert n == len(r[1])
+    assert np.array_equal(d_d[0, :n].cpu().numpy(), r[2])
+    ex.close()

@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $root/gpurun_out
 rm -rf $root/gpurun_out/pmc_* $root/gpurun_out/prof_trace $root/gpurun_out/calib
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_trace -- python3 $root/bench.py --no-cpu-baseline --no-pipelined > $root/gpurun_out/prof_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_trace -- python3 $root/bench.py --no-cpu-baseline --no-pipelined --no-pcie > $root/gpurun_out/prof_trace.log 2>&1
 cd $root
 tools/pmc_pass.sh fetch "FETCH_SIZE"
 tools/pmc_pass.sh write "WRITE_SIZE"
