@@ -25,6 +25,8 @@ Extra objects in the line (none of them is `value`):
                     single frame (pageable / pinned, p50 / p99), batch of 64 (pageable / pinned /
                     two batches in flight), the bare-copy PCIe floor of the same bytes, and the
                     reference's stereo protocol (2 extractors, 2 threads, + ComputeStereoMatches).
+  cross_camera   -- the step plus the consumer of the exchanged descriptors: knn-2 of every local frame
+                    against the next camera of the ring, read from the gathered buffer in place (one launch).
   pipelined      -- the same resident batches alternating between two extractor contexts on two streams.
   single_frame   -- configs[1] read literally, ONE resident frame per call (latency-bound).
   first_call_ms  -- the first extraction of the process (libm trig table build + upload, allocations).
@@ -171,6 +173,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--trig", choices=["libm", "cr", "hostcheck"], default="libm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cross", action="store_true", help="skip the cross-camera matching leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive child process (tools/hostbench)")
     ap.add_argument("--settle", type=float, default=0.5,
                     help="keep running untimed steps after the warm-up until this many seconds have passed")
@@ -185,7 +188,7 @@ def main():
     import torch
     import torch.distributed as dist
     import orb_slam3_detailed_comments_kor_amd as pkg
-    from orb_slam3_detailed_comments_kor_amd.multicam import PipelinedExchange
+    from orb_slam3_detailed_comments_kor_amd.multicam import CrossCameraMatcher, PipelinedExchange, ring_pairs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
@@ -283,6 +286,59 @@ def main():
     dt = time.perf_counter() - t0
     stage_ms = ex.stage_ms()  # hipEvent times averaged over the timed steps
     ex.profile(False)
+
+    # Not part of `value`: the step followed by the consumer of the exchanged descriptors -- cross-camera matching,
+    # sharded by query frame: knn-2 of each of this rank's frames against the next camera of the ring
+    # (global frame g+1; the last local frame's partner lives on the next rank), read from the gathered buffer in
+    # place, one launch per batch.  The match of batch i-1 is queued behind the extraction of batch i, so it overlaps
+    # batch i's all-gather.  Runs at every N (at N=1 the "gather" is the local slab copy).
+    cross = None
+    if not extra and not args.no_cross:
+        cm = CrossCameraMatcher(pipe.x, ring_pairs(world, B, rank), dev)
+        prev = [None]
+
+        def step_cross():
+            x = pipe.begin()
+            ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(),
+                                    cap, x.count_view().data_ptr(), d_mono.data_ptr())
+            k = pipe.i % len(pipe.x)
+            pipe.submit()  # world 1 without a process group: the local copy into the gathered buffer
+            if prev[0] is not None:
+                kp, xp = prev[0]
+                if pipe.pending[kp] is not None:
+                    pipe.pending[kp].wait()  # the stream waits for batch i-1's collective; begin() clears the handle
+                cm.match(xp)
+            prev[0] = (k, x)
+
+        for _ in range(10):
+            step_cross()
+        barrier()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step_cross()
+        barrier()
+        tc = time.perf_counter() - tc
+        # the matching launch alone, by events on the stream it runs on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        xl = pipe.completed()
+        cm.match(xl)
+        e0.record()
+        for _ in range(20):
+            cm.match(xl)
+        e1.record()
+        torch.cuda.synchronize()
+        knn_ms = e0.elapsed_time(e1) / 20
+        cnt = xl.count_view().to(torch.float64)
+        tcount = torch.stack([xl.unpack(g // B)[0][g % B] for _, g in cm.pairs]).to(torch.float64)
+        ndist = float((cnt * tcount).sum().item())
+        good = cm.dist[:, :, 0].to(torch.float64) < 0.7 * cm.dist[:, :, 1].to(torch.float64)
+        valid = torch.arange(cap, device=dev)[None, :] < xl.count_view()[:, None]
+        cross = {"jobs_per_step": cm.njobs * world, "pairing": "every frame against the next camera of the ring (global "
+                 "frame g+1), train frames read from the gathered buffer in place",
+                 "ms_per_step": 1e3 * tc / args.steps, "knn2_launch_ms": knn_ms,
+                 "distances_per_launch": ndist, "distances_per_s": ndist / (knn_ms * 1e-3),
+                 "ratio_test_survivors_per_frame": float((good & valid).sum().item()) / max(cm.njobs, 1)}
+        prev[0] = None
 
     # Not part of `value`: the same batches alternating between TWO extractor contexts on two streams (how
     # a multi-camera rig drives one extractor per camera, reference src/Frame.cc:119-122).  Consecutive
@@ -441,6 +497,8 @@ def main():
             out["pipelined"] = pipelined
         if single is not None:
             out["single_frame"] = single
+        if cross is not None:
+            out["cross_camera"] = cross
         out["first_call_ms"] = first_call_ms
         if world == 1 and not args.no_pcie:
             torch.cuda.synchronize()

@@ -191,6 +191,35 @@ int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, 
  * ascending distance, ties -> lower train index; -1 when fewer than 1/2 train rows exist. */
 int orbfe_bfknn2(int device, const uint8_t* Q, int nQ, const uint8_t* T, int nT, int32_t* idx, int32_t* dist);
 
+/* Device-resident forms of the two calls above: every pointer is DEVICE memory (for instance the descriptor slab
+ * an extractor context left in HBM, orbfe_get_device_outputs, or the slab an all-gather delivered), nothing is
+ * copied and the call does not wait: the kernel is queued on `hip_stream` (NULL = the calling thread's matcher
+ * stream; synchronise it with orbfe_matcher_sync). */
+int orbfe_hamming_pairs_device(int device, void* hip_stream, const uint8_t* dA, int nA, const uint8_t* dB, int nB,
+                               uint16_t* dD);
+int orbfe_bfknn2_device(int device, void* hip_stream, const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int32_t* d_idx,
+                        int32_t* d_dist);
+/* Cross-camera matching (the consumer of the multi-GPU all-gather of descriptors): njobs independent
+ * knn-2 problems in ONE launch.  A job names a query frame and a train frame by device pointers -- their descriptor
+ * rows (32 B each) and the address of their keypoint count -- wherever they live: an extractor's resident output, this
+ * rank's slab, the slab the all-gather delivered.  Results as orbfe_bfknn2 per job: d_idx / d_dist hold
+ * njobs x cap x 2 entries (rows beyond a query frame's count are not written); cap >= every count. */
+typedef struct {
+    const uint8_t* q_desc; const int32_t* q_count;
+    const uint8_t* t_desc; const int32_t* t_count;
+} orbfe_knn2_job;
+int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
+                               int32_t* d_idx, int32_t* d_dist);
+/* Waits for the calling thread's matcher stream on `device`. */
+int orbfe_matcher_sync(int device);
+/* Where the LAST extraction of a context left its results in HBM (valid until the next call on that context):
+ * nimg slabs of cap keypoints (28 B, orbfe_kp) / descriptors (32 B) and the per-image counts.  For the host-pointer
+ * calls these are the context's own buffers; for orbfe_extract_batch_device the caller's. */
+int orbfe_get_device_outputs(orbfe_ctx*, const orbfe_kp** d_kps, const uint8_t** d_desc, const int32_t** d_n, int* cap,
+                             int* nimg);
+/* In every matcher call below the DESCRIPTOR arrays (desc1 / desc2 / desc / qdesc / pool ...) may also be device
+ * pointers: the call recognises them (hipPointerGetAttributes) and reads them in place instead of uploading. */
+
 /* DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:24-25) in CSR form. */
 typedef struct {
     int nn;                   /* distinct nodes                      */

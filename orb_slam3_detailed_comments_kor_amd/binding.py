@@ -182,6 +182,13 @@ def lib():
         L.orbfe_host_unregister.argtypes = [C.c_void_p]
         L.orbfe_compute_stereo_matches_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                             C.c_void_p, C.c_void_p, C.c_int]
+        L.orbfe_hamming_pairs_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbfe_bfknn2_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p]
+        L.orbfe_bfknn2_frames_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_matcher_sync.argtypes = [C.c_int]
+        L.orbfe_get_device_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orbfe_extract_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
                                                  C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p]
@@ -231,7 +238,9 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps", "orbfe_search_projection_batch",
            "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform",
            "orbfe_extract_batch_submit", "orbfe_extract_batch_wait", "orbfe_host_alloc", "orbfe_host_free",
-           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident"]
+           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident",
+           "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
+           "orbfe_get_device_outputs"]
 
 
 def _p(a):
@@ -407,6 +416,14 @@ class ORBextractor:
                                                       int(lap[0]), int(lap[1]), d_kps_ptr, d_desc_ptr, cap, d_n_ptr,
                                                       d_mono_ptr), "orbfe_extract_batch_device")
 
+    def device_outputs(self):
+        """(d_kps, d_desc, d_n, cap, nimg): where the last extraction left its results in HBM (device addresses)."""
+        k, d, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap, nimg = C.c_int(), C.c_int()
+        _chk(self.L.orbfe_get_device_outputs(self.h, C.byref(k), C.byref(d), C.byref(n), C.byref(cap), C.byref(nimg)),
+             "orbfe_get_device_outputs")
+        return k.value, d.value, n.value, cap.value, nimg.value
+
     def set_stream(self, stream_ptr):
         _chk(self.L.orbfe_set_stream(self.h, stream_ptr), "orbfe_set_stream")
 
@@ -552,36 +569,65 @@ def bfknn2(Q, T, device=0):
     return idx, dist
 
 
+KNN2_JOB_DTYPE = np.dtype([("q_desc", "<u8"), ("q_count", "<u8"), ("t_desc", "<u8"), ("t_count", "<u8")])  # orbfe_knn2_job
+
+
+def hamming_pairs_device(dA, nA, dB, nB, dD, stream=None, device=0):
+    """orbfe_hamming_pairs_device: device addresses (ints), asynchronous on `stream` (a hipStream_t value or None)."""
+    _chk(lib().orbfe_hamming_pairs_device(device, stream, dA, nA, dB, nB, dD), "orbfe_hamming_pairs_device")
+
+
+def bfknn2_device(dQ, nQ, dT, nT, d_idx, d_dist, stream=None, device=0):
+    _chk(lib().orbfe_bfknn2_device(device, stream, dQ, nQ, dT, nT, d_idx, d_dist), "orbfe_bfknn2_device")
+
+
+def bfknn2_frames_device(d_jobs, njobs, cap, d_idx, d_dist, stream=None, device=0):
+    """Cross-camera knn-2: `njobs` orbfe_knn2_job records at device address d_jobs (KNN2_JOB_DTYPE)."""
+    _chk(lib().orbfe_bfknn2_frames_device(device, stream, d_jobs, njobs, cap, d_idx, d_dist), "orbfe_bfknn2_frames_device")
+
+
+def matcher_sync(device=0):
+    _chk(lib().orbfe_matcher_sync(device), "orbfe_matcher_sync")
+
+
+def _desc_arg(d):
+    """Descriptor argument of a matcher call: a host array, or an (address, rows) pair naming device memory."""
+    if isinstance(d, tuple):
+        return int(d[0]), int(d[1]), None
+    a = np.ascontiguousarray(d, np.uint8).reshape(-1, 32)
+    return a.ctypes.data, len(a), a
+
+
 def search_bow(desc1, mask1, ang1, fv1, desc2, mask2, ang2, fv2, variant, nnratio, check_ori=True, Nleft=-1,
                limit1=-1, limit2=-1, device=0):
     """ORBmatcher::SearchByBoW: variant 0 = (KeyFrame*, Frame&) :269-471, 1 = (KeyFrame*, KeyFrame*) :823-963."""
-    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
-    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    p1, n1, k1d = _desc_arg(desc1)
+    p2, n2, k2d = _desc_arg(desc2)
     m1 = np.ascontiguousarray(mask1, np.uint8)
-    m2 = np.ascontiguousarray(mask2 if mask2 is not None else np.ones(len(d2)), np.uint8)
+    m2 = np.ascontiguousarray(mask2 if mask2 is not None else np.ones(n2), np.uint8)
     a1 = np.ascontiguousarray(ang1, np.float32)
     a2 = np.ascontiguousarray(ang2, np.float32)
     f1, k1 = _fv(fv1)
     f2, k2 = _fv(fv2)
-    args = _BowArgs(d1.ctypes.data, len(d1), m1.ctypes.data, a1.ctypes.data, f1, limit1, d2.ctypes.data, len(d2),
+    args = _BowArgs(p1, n1, m1.ctypes.data, a1.ctypes.data, f1, limit1, p2, n2,
                     m2.ctypes.data, a2.ctypes.data, f2, limit2, Nleft, nnratio, int(check_ori), variant)
-    match = np.zeros(len(d2) if variant == 0 else len(d1), np.int32)
+    match = np.zeros(n2 if variant == 0 else n1, np.int32)
     n = _chk(lib().orbfe_search_bow(device, C.byref(args), _p(match)), "orbfe_search_bow")
     return n, match
 
 
 def _bow_args(desc1, mask1, ang1, fv1, desc2, mask2, ang2, fv2, variant, nnratio, check_ori, Nleft, limit1, limit2):
-    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
-    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    p1, n1, d1 = _desc_arg(desc1)
+    p2, n2, d2 = _desc_arg(desc2)
     m1 = np.ascontiguousarray(mask1, np.uint8)
-    m2 = np.ascontiguousarray(mask2 if mask2 is not None else np.ones(len(d2)), np.uint8)
+    m2 = np.ascontiguousarray(mask2 if mask2 is not None else np.ones(n2), np.uint8)
     a1 = np.ascontiguousarray(ang1, np.float32)
     a2 = np.ascontiguousarray(ang2, np.float32)
     f1, k1 = _fv(fv1)
     f2, k2 = _fv(fv2)
-    args = _BowArgs(d1.ctypes.data, len(d1), m1.ctypes.data, a1.ctypes.data, f1, limit1, d2.ctypes.data, len(d2),
+    args = _BowArgs(p1, n1, m1.ctypes.data, a1.ctypes.data, f1, limit1, p2, n2,
                     m2.ctypes.data, a2.ctypes.data, f2, limit2, Nleft, nnratio, int(check_ori), variant)
-    return args, (d1, d2, m1, m2, a1, a2, k1, k2), (len(d2) if variant == 0 else len(d1))
+    return args, (d1, d2, m1, m2, a1, a2, k1, k2), (n2 if variant == 0 else n1)
 
 
 def search_bow_batch(problems, device=0):

@@ -1177,7 +1177,8 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
 
     // ---- results: into the caller's arrays directly when those are pinned (the layouts are the same: nimg slabs of
     // cap entries), else ONE transfer of [meta | keypoints | descriptors] into the slot's pinned staging
-    sl.outPinned = is_pinned(c, kps, kpsBytes) && is_pinned(c, desc, descBytes);
+    // (a frame or two: one command into the staging buffer and a 60-KB memcpy beat three DMA commands)
+    sl.outPinned = kpsBytes + descBytes >= (1u << 20) && is_pinned(c, kps, kpsBytes) && is_pinned(c, desc, descBytes);
     if (sl.outPinned) {
         if ((r = sl.h_out.ensure(sl.metaBytes)) < 0) return r;
         HIP_TRY(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.metaBytes, hipMemcpyDeviceToHost, sOut));
@@ -1512,6 +1513,19 @@ int orbfe_extract(orbfe_ctx* c, const uint8_t* img, int rows, int cols, size_t s
     if (r < 0) return r;
     if (n_out) *n_out = n;
     return mono;
+}
+
+int orbfe_get_device_outputs(orbfe_ctx* c, const orbfe_kp** d_kps, const uint8_t** d_desc, const int32_t** d_n, int* cap,
+                             int* nimg)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    if (!c->lastKps || c->lastImgs < 1) return ORBFE_ERR_STATE;
+    if (d_kps) *d_kps = reinterpret_cast<const orbfe_kp*>(c->lastKps);
+    if (d_desc) *d_desc = c->lastDesc;
+    if (d_n) *d_n = c->lastN;
+    if (cap) *cap = c->lastCap;
+    if (nimg) *nimg = c->lastImgs;
+    return 0;
 }
 
 int orbfe_get_levels(orbfe_ctx* c) { return c ? c->nlevels : ORBFE_ERR_ARGS; }

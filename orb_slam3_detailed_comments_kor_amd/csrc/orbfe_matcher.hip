@@ -32,6 +32,12 @@
         if (_e != hipSuccess) return -(1000 + (int)_e); \
     } while (0)
 
+#define INT_TRY(expr)            \
+    do {                         \
+        const int _r = (expr);   \
+        if (_r < 0) return _r;   \
+    } while (0)
+
 namespace {
 
 const int TH_LOW = 50;       // src/ORBmatcher.cc:37
@@ -139,6 +145,74 @@ __global__ __launch_bounds__(256) void k_bfknn2(const uint8_t* __restrict__ Q, i
         dist[2 * q] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> 20);
         idx[2 * q + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 & 0xFFFFF);
         dist[2 * q + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 >> 20);
+    }
+}
+
+// knn-2 of many (query frame, train frame) pairs in one launch -- the cross-camera matching that consumes the
+// all-gathered descriptors.  A job names its two frames by device pointers (descriptor rows + count).
+// One LANE per query (its descriptor stays in eight registers), the train descriptors are wave-uniform and arrive
+// through the scalar cache; a workgroup's SPLIT wavefronts share the same 64 queries and take every SPLIT-th train
+// row each, then merge their (best, second) pairs through LDS.  Per distance and lane: 8 xor + 8 popcount-accumulate
+// + 4 for the running two smallest keys -- the VALU issue rate bounds it, not memory (a train row is fetched once
+// per wavefront, for 64 distances).  Keys are distance<<20 | train index, so the two smallest keys are the
+// sequential scan's best and second best with ties going to the lower train index.
+template <int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void k_bfknn2_frames(const orbfe_knn2_job* __restrict__ jobs, int cap,
+                                                             int32_t* __restrict__ idx, int32_t* __restrict__ dist)
+{
+    __shared__ unsigned sk0[SPLIT][64], sk1[SPLIT][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int p = blockIdx.y;
+    const orbfe_knn2_job J = jobs[p];
+    const int nQ = min(J.q_count[0], cap), nT = min(J.t_count[0], cap);
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= nQ) return; // uniform
+    const int q = q0 + lane;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (q < nQ) {
+        const uint4* qp = reinterpret_cast<const uint4*>(J.q_desc + (size_t)q * 32);
+        a = qp[0];
+        b = qp[1];
+    }
+    // (a pointer read from memory is a generic one to the compiler; as a constant-address-space pointer with a
+    // wave-uniform index the train rows become s_load_dwordx8 and feed the VALU straight from scalar registers)
+    typedef const uint4 __attribute__((address_space(4))) * scalar_rows;
+    const scalar_rows T = (scalar_rows)(uintptr_t)J.t_desc;
+    unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+#pragma unroll 2
+    for (int t = wave; t < nT; t += SPLIT) {
+        const uint4 u = T[2 * t], v = T[2 * t + 1]; // wave-uniform address: scalar loads
+        unsigned d = __popc(a.x ^ u.x);
+        d += __popc(a.y ^ u.y);
+        d += __popc(a.z ^ u.z);
+        d += __popc(a.w ^ u.w);
+        d += __popc(b.x ^ v.x);
+        d += __popc(b.y ^ v.y);
+        d += __popc(b.z ^ v.z);
+        d += __popc(b.w ^ v.w);
+        const unsigned key = (d << 20) | (unsigned)t;
+        k1 = min(k1, max(k0, key));
+        k0 = min(k0, key);
+    }
+    if (SPLIT > 1) {
+        sk0[wave][lane] = k0;
+        sk1[wave][lane] = k1;
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < SPLIT; w++) {
+            const unsigned o0 = sk0[w][lane], o1 = sk1[w][lane];
+            k1 = min(min(k1, o1), max(k0, o0));
+            k0 = min(k0, o0);
+        }
+    }
+    if (q < nQ) {
+        const size_t o = ((size_t)p * cap + q) * 2;
+        idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 & 0xFFFFF);
+        dist[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> 20);
+        idx[o + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 & 0xFFFFF);
+        dist[o + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 >> 20);
     }
 }
 
@@ -1011,21 +1085,59 @@ __global__ __launch_bounds__(256) void k_kb8_unproject(const float* __restrict__
 // would cost more than the kernels.  The arena is a bump allocator over one persistent device
 // buffer; a call that outgrows it falls back to hipMalloc for the overflow and the arena is
 // enlarged before the next call.
+bool is_device_ptr(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // ordinary host memory is "invalid value" to some runtimes
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
 struct Arena {
     int device = -1;
     uint8_t* base = nullptr;
-    uint8_t* pin = nullptr; // pinned host mirror of the arena: inputs are staged here and go up in ONE transfer
+    uint8_t* pin = nullptr; // pinned host mirror of the arena: inputs are staged here and go up in ONE transfer,
+                            // outputs come down into it in ONE transfer
     size_t cap = 0, off = 0, want = 0;
+    // The calling thread's own non-blocking stream on this device: matcher calls of the Tracking, LocalMapping and
+    // LoopClosing threads neither serialise with each other nor synchronise with the legacy null stream (and through
+    // it with every blocking stream of the process, e.g. torch's default stream).
+    hipStream_t stream = nullptr;
+    ~Arena()
+    { // thread exit: give the scratch back (a thread that called the matcher once used to leak it)
+        if (device < 0) return;
+        if (hipSetDevice(device) != hipSuccess) return;
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (base) (void)hipFree(base);
+        if (pin) (void)hipHostFree(pin);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
-thread_local Arena g_arena[16];
+const int kMaxDevices = 16;
+thread_local Arena g_arena[kMaxDevices];
+thread_local hipStream_t g_ms = nullptr; // stream of the matcher call in progress on this thread
 
 struct Scratch { // device allocations of one call
     Arena* ar = nullptr;
     std::vector<void*> overflow;
     std::vector<std::pair<size_t, size_t>> staged; // (offset, bytes) runs waiting in the pinned mirror
+    struct Down {
+        void* host;
+        const void* dev;
+        size_t bytes;
+    };
+    std::vector<Down> downs; // results the caller wants back (see down / fetch)
     explicit Scratch(int device)
     {
-        ar = &g_arena[device & 15];
+        ar = &g_arena[device]; // select_device() has checked 0 <= device < kMaxDevices
+        ar->device = device;
+        if (!ar->stream && hipStreamCreateWithFlags(&ar->stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            ar->stream = nullptr; // the null stream still works
+        }
+        g_ms = ar->stream;
         if (ar->want > ar->cap) { // grow between calls
             if (ar->base) (void)hipFree(ar->base);
             if (ar->pin) (void)hipHostFree(ar->pin);
@@ -1046,6 +1158,7 @@ struct Scratch { // device allocations of one call
     }
     ~Scratch()
     {
+        if (!overflow.empty()) (void)hipStreamSynchronize(g_ms);
         for (void* p : overflow) (void)hipFree(p);
     }
     template <class T>
@@ -1073,22 +1186,68 @@ struct Scratch { // device allocations of one call
                 if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
                 else staged.emplace_back(at, bytes);
             } else {
-                hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, 0);
+                hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, g_ms);
+                if (e != hipSuccess) return -(1000 + (int)e);
+                e = hipStreamSynchronize(g_ms); // `host` is the caller's (pageable) memory
                 if (e != hipSuccess) return -(1000 + (int)e);
             }
         }
         *out = (T*)p;
         return 0;
     }
+    // Descriptor arrays may already live on the device (an extractor's resident output slab, a gathered slab):
+    // then they are read in place.
+    int up_desc(uint8_t** out, const uint8_t* hostOrDev, size_t n)
+    {
+        if (hostOrDev && n && is_device_ptr(hostOrDev)) {
+            *out = const_cast<uint8_t*>(hostOrDev);
+            return 0;
+        }
+        return up(out, hostOrDev, n);
+    }
     // send the staged inputs (called before the first kernel of the call, by KernelScope)
     int flush()
     {
         for (const auto& r : staged) {
-            hipError_t e = hipMemcpyAsync(ar->base + r.first, ar->pin + r.first, r.second, hipMemcpyHostToDevice, 0);
+            hipError_t e = hipMemcpyAsync(ar->base + r.first, ar->pin + r.first, r.second, hipMemcpyHostToDevice, g_ms);
             if (e != hipSuccess) return -(1000 + (int)e);
         }
         staged.clear();
         return 0;
+    }
+    // Results: down() names a device range the caller wants in `host`; fetch() brings all of them back with ONE
+    // transfer of the arena stretch that covers them into the pinned mirror (the outputs of a call are neighbours in
+    // the arena), one stream synchronisation, and a memcpy each -- instead of one blocking pageable copy per array.
+    int down(void* host, const void* dev, size_t bytes)
+    {
+        if (bytes) downs.push_back(Down{host, dev, bytes});
+        return 0;
+    }
+    int fetch()
+    {
+        bool inArena = ar->base && ar->pin && !downs.empty();
+        size_t lo = ~(size_t)0, hi = 0;
+        for (const Down& d : downs) {
+            const uint8_t* p = (const uint8_t*)d.dev;
+            if (!(ar->base && p >= ar->base && p + d.bytes <= ar->base + ar->cap)) inArena = false;
+            else {
+                lo = std::min(lo, (size_t)(p - ar->base));
+                hi = std::max(hi, (size_t)(p - ar->base) + d.bytes);
+            }
+        }
+        hipError_t e = hipSuccess;
+        if (inArena) {
+            e = hipMemcpyAsync(ar->pin + lo, ar->base + lo, hi - lo, hipMemcpyDeviceToHost, g_ms);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+            if (e == hipSuccess)
+                for (const Down& d : downs) std::memcpy(d.host, ar->pin + ((const uint8_t*)d.dev - ar->base), d.bytes);
+        } else {
+            for (const Down& d : downs)
+                if (e == hipSuccess) e = hipMemcpyAsync(d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, g_ms);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+        }
+        downs.clear();
+        return e == hipSuccess ? 0 : -(1000 + (int)e);
     }
 };
 
@@ -1105,13 +1264,13 @@ struct KernelTimer {
         if (g_timeKernels) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, 0);
+            (void)hipEventRecord(a, g_ms);
         }
     }
     ~KernelTimer()
     {
         if (!a) return;
-        (void)hipEventRecord(b, 0);
+        (void)hipEventRecord(b, g_ms);
         (void)hipEventSynchronize(b);
         float ms = -1.f;
         if (hipEventElapsedTime(&ms, a, b) == hipSuccess) g_lastKernelMs = ms;
@@ -1124,6 +1283,7 @@ int select_device(int device)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return ORBFE_ERR_NODEV;
+    if (device >= kMaxDevices) return ORBFE_ERR_ARGS; // one scratch arena per (thread, device ordinal < 16)
     HIP_TRY(hipSetDevice(device));
     return 0;
 }
@@ -1220,16 +1380,17 @@ int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, 
     Scratch s(device);
     uint8_t *dA, *dB;
     uint16_t* dD;
-    if ((r = s.up(&dA, A, (size_t)nA * 32)) < 0) return r;
-    if ((r = s.up(&dB, B, (size_t)nB * 32)) < 0) return r;
+    if ((r = s.up_desc(&dA, A, (size_t)nA * 32)) < 0) return r;
+    if ((r = s.up_desc(&dB, B, (size_t)nB * 32)) < 0) return r;
     if ((r = s.up<uint16_t>(&dD, nullptr, (size_t)nA * nB)) < 0) return r;
     {
         KernelTimer timer(s);
-    hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, 0, dA,
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, g_ms, dA,
                        nA, dB, nB, dD);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(D, dD, (size_t)nA * nB * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(D, dD, (size_t)nA * nB * sizeof(uint16_t)));
+    INT_TRY(s.fetch());
     return 0;
 }
 
@@ -1242,17 +1403,78 @@ int orbfe_bfknn2(int device, const uint8_t* Q, int nQ, const uint8_t* T, int nT,
     Scratch s(device);
     uint8_t *dQ, *dT;
     int32_t *dI, *dD;
-    if ((r = s.up(&dQ, Q, (size_t)nQ * 32)) < 0) return r;
-    if ((r = s.up(&dT, T, (size_t)nT * 32)) < 0) return r;
+    if ((r = s.up_desc(&dQ, Q, (size_t)nQ * 32)) < 0) return r;
+    if ((r = s.up_desc(&dT, T, (size_t)nT * 32)) < 0) return r;
     if ((r = s.up<int32_t>(&dI, nullptr, (size_t)nQ * 2)) < 0) return r;
     if ((r = s.up<int32_t>(&dD, nullptr, (size_t)nQ * 2)) < 0) return r;
     {
         KernelTimer timer(s);
-    hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, 0, dQ, nQ, dT, nT, dI, dD);
+    hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, g_ms, dQ, nQ, dT, nT, dI, dD);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(idx, dI, (size_t)nQ * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dist, dD, (size_t)nQ * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(idx, dI, (size_t)nQ * 2 * sizeof(int32_t)));
+    INT_TRY(s.down(dist, dD, (size_t)nQ * 2 * sizeof(int32_t)));
+    INT_TRY(s.fetch());
+    return 0;
+}
+
+// ---- device-resident forms: every pointer is device memory, nothing is copied, nothing is waited for ----
+static hipStream_t matcher_stream(int device, void* hip_stream)
+{
+    if (hip_stream) return (hipStream_t)hip_stream;
+    Scratch s(device); // makes sure the calling thread's matcher stream exists
+    return g_ms;
+}
+
+int orbfe_hamming_pairs_device(int device, void* hip_stream, const uint8_t* dA, int nA, const uint8_t* dB, int nB,
+                               uint16_t* dD)
+{
+    if (nA < 0 || nB < 0 || (nA && !dA) || (nB && !dB) || (nA && nB && !dD)) return ORBFE_ERR_ARGS;
+    if (nA == 0 || nB == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0,
+                       matcher_stream(device, hip_stream), dA, nA, dB, nB, dD);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int orbfe_bfknn2_device(int device, void* hip_stream, const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int32_t* d_idx,
+                        int32_t* d_dist)
+{
+    if (nQ < 0 || nT < 0 || (nQ && (!dQ || !d_idx || !d_dist)) || (nT && !dT) || nT >= (1 << 20)) return ORBFE_ERR_ARGS;
+    if (nQ == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, matcher_stream(device, hip_stream), dQ, nQ,
+                       dT, nT, d_idx, d_dist);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
+                               int32_t* d_idx, int32_t* d_dist)
+{
+    if (njobs < 0 || cap < 1 || cap >= (1 << 20) || (njobs && (!d_jobs || !d_idx || !d_dist))) return ORBFE_ERR_ARGS;
+    if (njobs == 0) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    hipStream_t st = matcher_stream(device, hip_stream);
+    const dim3 grid((unsigned)((cap + 63) / 64), (unsigned)njobs);
+    // few workgroups: more wavefronts per workgroup share the 64 queries (and fill the chip)
+    if ((long)grid.x * njobs >= 2048)
+        hipLaunchKernelGGL(k_bfknn2_frames<4>, grid, dim3(256), 0, st, d_jobs, cap, d_idx, d_dist);
+    else
+        hipLaunchKernelGGL(k_bfknn2_frames<8>, grid, dim3(512), 0, st, d_jobs, cap, d_idx, d_dist);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int orbfe_matcher_sync(int device)
+{
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    if (g_arena[device].stream) HIP_TRY(hipStreamSynchronize(g_arena[device].stream));
     return 0;
 }
 
@@ -1266,6 +1488,12 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     std::vector<BowNode> nodes;
     std::vector<BowProb> probs(count);
     std::vector<uint8_t> descPool, maskPool;
+    struct D2D {
+        size_t off;
+        const uint8_t* src;
+        size_t bytes;
+    };
+    std::vector<D2D> d2d;
     std::vector<float> angPool;
     std::vector<int32_t> indPool;
     std::vector<int> outN(count);
@@ -1308,8 +1536,20 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
             if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
         });
         if (bad) return ORBFE_ERR_ARGS;
-        descPool.insert(descPool.end(), a->desc1, a->desc1 + (size_t)a->n1 * 32);
-        descPool.insert(descPool.end(), a->desc2, a->desc2 + (size_t)a->n2 * 32);
+        // descriptor sets that already live on the device are copied device-to-device into the pool below
+        const bool dev1 = is_device_ptr(a->desc1), dev2 = is_device_ptr(a->desc2);
+        if (dev1) {
+            d2d.push_back(D2D{descPool.size(), a->desc1, (size_t)a->n1 * 32});
+            descPool.resize(descPool.size() + (size_t)a->n1 * 32);
+        } else {
+            descPool.insert(descPool.end(), a->desc1, a->desc1 + (size_t)a->n1 * 32);
+        }
+        if (dev2) {
+            d2d.push_back(D2D{descPool.size(), a->desc2, (size_t)a->n2 * 32});
+            descPool.resize(descPool.size() + (size_t)a->n2 * 32);
+        } else {
+            descPool.insert(descPool.end(), a->desc2, a->desc2 + (size_t)a->n2 * 32);
+        }
         maskPool.insert(maskPool.end(), a->mask1, a->mask1 + a->n1);
         if (a->variant == 1) maskPool.insert(maskPool.end(), a->mask2, a->mask2 + a->n2);
         else maskPool.insert(maskPool.end(), (size_t)a->n2, (uint8_t)1);
@@ -1338,19 +1578,22 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
     if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
     if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)rows)) < 0) return r;
-    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), 0));
-    HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, 0));
-    HIP_TRY(hipMemsetAsync(taken, 0, (size_t)rows, 0));
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), g_ms));
+    HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
+    HIP_TRY(hipMemsetAsync(taken, 0, (size_t)rows, g_ms));
     {
-        KernelTimer timer(s);
-        hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, 0, dN, (int)nodes.size(),
+        KernelTimer timer(s); // (sends the staged pool; the device-resident sets then overwrite their places in it)
+        for (const D2D& c : d2d)
+            HIP_TRY(hipMemcpyAsync(dDesc + c.off, c.src, c.bytes, hipMemcpyDeviceToDevice, g_ms));
+        hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, g_ms, dN, (int)nodes.size(),
                            dP, dDesc, dMask, dAng, dInd, dM, dB, taken);
     }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m(outTotal);
     std::vector<int8_t> bins(outTotal);
-    HIP_TRY(hipMemcpy(m.data(), dM, (size_t)outTotal * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(bins.data(), dB, (size_t)outTotal, hipMemcpyDeviceToHost));
+    INT_TRY(s.down(m.data(), dM, (size_t)outTotal * sizeof(int32_t)));
+    INT_TRY(s.down(bins.data(), dB, (size_t)outTotal));
+    INT_TRY(s.fetch());
     for (int p = 0; p < count; p++) {
         std::memcpy(match[p], m.data() + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
         nmatches[p] = cull_by_rotation(match[p], bins.data() + probs[p].outBase, outN[p], args[p].check_orientation != 0);
@@ -1398,8 +1641,8 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     float *k1, *k2, *u1, *u2, *dF, *sf, *sg;
     int32_t *o2, *i2, *dM;
     if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
-    if ((r = s.up(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
-    if ((r = s.up(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
+    if ((r = s.up_desc(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
+    if ((r = s.up_desc(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
     if ((r = s.up(&h2, a->hasMP2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&k1, a->kp1_xy, (size_t)a->n1 * 2)) < 0) return r;
     if ((r = s.up(&k2, a->kp2_xy, (size_t)a->n2 * 2)) < 0) return r;
@@ -1411,15 +1654,16 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
-    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), 0));
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), g_ms));
     {
         KernelTimer timer(s);
-    hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, dR, (int)rows.size(), d1,
+    hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), d1,
                        k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM);
     }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m12(a->n1);
-    HIP_TRY(hipMemcpy(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t)));
+    INT_TRY(s.fetch());
     std::vector<int8_t> bins(a->n1, -1);
     if (a->check_orientation) {
         for (int i = 0; i < a->n1; i++)
@@ -1469,8 +1713,8 @@ int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* 
     uint8_t *dQ, *dT;
     int32_t *dI, *dD, *dOL, *dOR, *dL2R;
     float *dKL, *dKR, *dP1, *dP2, *dR, *dt, *dSig, *dDepth, *dX;
-    if ((r = s.up(&dQ, descL, (size_t)nL * 32)) < 0) return r;
-    if ((r = s.up(&dT, descR, (size_t)nR * 32)) < 0) return r;
+    if ((r = s.up_desc(&dQ, descL, (size_t)nL * 32)) < 0) return r;
+    if ((r = s.up_desc(&dT, descR, (size_t)nR * 32)) < 0) return r;
     if ((r = s.up(&dKL, kpL_xy, (size_t)nL * 2)) < 0) return r;
     if ((r = s.up(&dKR, kpR_xy, (size_t)nR * 2)) < 0) return r;
     if ((r = s.up(&dOL, octL, (size_t)nL)) < 0) return r;
@@ -1487,14 +1731,15 @@ int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* 
     if ((r = s.up<float>(&dX, nullptr, (size_t)nL * 3)) < 0) return r;
     {
         KernelTimer timer(s);
-        hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, 0, dQ, nL, dT, nR, dI, dD);
-        hipLaunchKernelGGL(k_fisheye_stereo, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, 0, dI, dD, nL, nR, dKL, dKR, dOL,
+        hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, g_ms, dQ, nL, dT, nR, dI, dD);
+        hipLaunchKernelGGL(k_fisheye_stereo, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, g_ms, dI, dD, nL, nR, dKL, dKR, dOL,
                            dOR, dP1, dP2, dR, dt, dSig, dL2R, dDepth, dX);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(leftToRight, dL2R, (size_t)nL * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(depth, dDepth, (size_t)nL * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(p3D, dX, (size_t)nL * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(leftToRight, dL2R, (size_t)nL * sizeof(int32_t)));
+    INT_TRY(s.down(depth, dDepth, (size_t)nL * sizeof(float)));
+    INT_TRY(s.down(p3D, dX, (size_t)nL * 3 * sizeof(float)));
+    INT_TRY(s.fetch());
     int nMatches = 0;
     for (int q = 0; q < nL; q++) // mvRightToLeftMatch: the last left keypoint that chose a right one keeps it (:1150)
         if (leftToRight[q] >= 0) {
@@ -1536,7 +1781,7 @@ int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* m
     uint8_t *dDesc, *dQdesc;
     float *dKx, *dKy, *dQx, *dQy, *dQr;
     int32_t *dOct, *dQlev;
-    if ((r = s.up(&dDesc, a->desc2, n * 32)) < 0) return r;
+    if ((r = s.up_desc(&dDesc, a->desc2, n * 32)) < 0) return r;
     if ((r = s.up(&dKx, a->kx2, n)) < 0) return r;
     if ((r = s.up(&dKy, a->ky2, n)) < 0) return r;
     if ((r = s.up(&dOct, a->octave2, n)) < 0) return r;
@@ -1571,12 +1816,13 @@ int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* m
     for (int attempt = 0;; attempt++) {
         {
             KernelTimer timer(s);
-            hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
-            hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, 0, P);
-            hipLaunchKernelGGL(k_init_sweeps, dim3(1), dim3(PROJ_THREADS), 0, 0, I);
+            hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
+            hipLaunchKernelGGL(k_proj_candidates, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, g_ms, P);
+            hipLaunchKernelGGL(k_init_sweeps, dim3(1), dim3(PROJ_THREADS), 0, g_ms, I);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
+        INT_TRY(s.down(out.data(), dOut, out.size() * 4));
+        INT_TRY(s.fetch());
         if (out[2] >= 0 && (size_t)out[2] <= keyCap) break;
         if (attempt > 0 || out[2] < 0) return ORBFE_ERR_STATE;
         keyCap = (size_t)out[2];
@@ -1663,8 +1909,8 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
     float *k1, *k2, *u1 = nullptr, *u2 = nullptr, *sf, *sg1, *sg2;
     int32_t *o1, *o2, *i2, *dM;
     if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
-    if ((r = s.up(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
-    if ((r = s.up(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
+    if ((r = s.up_desc(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
+    if ((r = s.up_desc(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
     if ((r = s.up(&h2, a->hasMP2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&k1, a->kp1_xy, (size_t)a->n1 * 2)) < 0) return r;
     if ((r = s.up(&k2, a->kp2_xy, (size_t)a->n2 * 2)) < 0) return r;
@@ -1677,7 +1923,7 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
     if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
-    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), 0));
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), g_ms));
     T.rows = dR; T.nRows = (int)rows.size(); T.desc1 = d1; T.desc2 = d2; T.hasMP2 = h2; T.kp1 = k1; T.kp2 = k2;
     T.uR1 = u1; T.uR2 = u2; T.oct1 = o1; T.oct2 = o2; T.ind2 = i2; T.Nleft1 = a->Nleft1; T.Nleft2 = a->Nleft2;
     T.rig = rig ? 1 : 0;
@@ -1692,11 +1938,12 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
     T.onlyStereo = a->only_stereo; T.coarse = a->coarse; T.match12 = dM;
     {
         KernelTimer timer(s);
-        hipLaunchKernelGGL(k_search_tri_kb8, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, 0, T);
+        hipLaunchKernelGGL(k_search_tri_kb8, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, T);
     }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m12(a->n1);
-    HIP_TRY(hipMemcpy(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t)));
+    INT_TRY(s.fetch());
     std::vector<int8_t> bins(a->n1, -1);
     if (a->check_orientation) {
         for (int i = 0; i < a->n1; i++)
@@ -1742,12 +1989,13 @@ int orbfe_kb8_triangulate(int device, const float* params1, const float* params2
     if (p3D && (r = s.up<float>(&dX, nullptr, (size_t)3 * n)) < 0) return r;
     {
         KernelTimer timer(s);
-        hipLaunchKernelGGL(k_kb8_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP1, dP2, dK1, dK2, dR, dT,
+        hipLaunchKernelGGL(k_kb8_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ms, dP1, dP2, dK1, dK2, dR, dT,
                            dS1, dS2, n, dZ, dX);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(z1, dZ, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    if (p3D) HIP_TRY(hipMemcpy(p3D, dX, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(z1, dZ, (size_t)n * sizeof(float)));
+    if (p3D) INT_TRY(s.down(p3D, dX, (size_t)3 * n * sizeof(float)));
+    INT_TRY(s.fetch());
     return 0;
 }
 
@@ -1801,7 +2049,7 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J)
     uint8_t *dDesc, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
     float *dKx, *dKy, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
     int32_t *dOct, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
-    if ((r = s.up(&dDesc, a->desc, n * 32)) < 0) return r;
+    if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
     if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
     if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
     if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
@@ -1813,7 +2061,7 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J)
         if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
         if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
     }
-    if ((r = s.up(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
+    if ((r = s.up_desc(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
     if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
     if ((r = s.up(&dQy, a->qy, nq)) < 0) return r;
     if ((r = s.up(&dQr, a->qr, nq)) < 0) return r;
@@ -1928,18 +2176,19 @@ int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int 
             KernelTimer timer(s);
             if (jobs.size() == 1) {
                 const ProjDev& P = jobs[0].P;
-                hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, 0, P);
-                hipLaunchKernelGGL(k_proj_candidates, dim3(maxBlocks), dim3(256), 0, 0, P);
-                hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), sweepBytes, 0, P);
+                hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
+                hipLaunchKernelGGL(k_proj_candidates, dim3(maxBlocks), dim3(256), 0, g_ms, P);
+                hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), sweepBytes, g_ms, P);
             } else {
                 const unsigned nj = (unsigned)jobs.size();
-                hipLaunchKernelGGL(k_proj_grid_batch, dim3(1, nj), dim3(PROJ_THREADS), 0, 0, dP);
-                hipLaunchKernelGGL(k_proj_candidates_batch, dim3(maxBlocks, nj), dim3(256), 0, 0, dP);
-                hipLaunchKernelGGL(k_proj_sweeps_batch, dim3(1, nj), dim3(PROJ_THREADS), sweepBytes, 0, dP);
+                hipLaunchKernelGGL(k_proj_grid_batch, dim3(1, nj), dim3(PROJ_THREADS), 0, g_ms, dP);
+                hipLaunchKernelGGL(k_proj_candidates_batch, dim3(maxBlocks, nj), dim3(256), 0, g_ms, dP);
+                hipLaunchKernelGGL(k_proj_sweeps_batch, dim3(1, nj), dim3(PROJ_THREADS), sweepBytes, g_ms, dP);
             }
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
+        INT_TRY(s.down(out.data(), dOut, out.size() * 4));
+        INT_TRY(s.fetch());
         // more candidate keys than a job's buffers hold: the kernel reported how many it needs; run again
         bool again = false;
         for (ProjJob& J : jobs) {
@@ -1989,15 +2238,16 @@ int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t
     Scratch s(device);
     uint8_t* dP;
     int32_t *dO, *dB;
-    if ((r = s.up(&dP, pool, (size_t)total * 32)) < 0) return r;
+    if ((r = s.up_desc(&dP, pool, (size_t)total * 32)) < 0) return r;
     if ((r = s.up(&dO, offsets, (size_t)npts + 1)) < 0) return r;
     if ((r = s.up<int32_t>(&dB, nullptr, (size_t)npts)) < 0) return r;
     {
         KernelTimer timer(s);
-        hipLaunchKernelGGL(k_distinctive, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, 0, dP, dO, npts, dB);
+        hipLaunchKernelGGL(k_distinctive, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, g_ms, dP, dO, npts, dB);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(best, dB, (size_t)npts * 4, hipMemcpyDeviceToHost));
+    INT_TRY(s.down(best, dB, (size_t)npts * 4));
+    INT_TRY(s.fetch());
     return 0;
 }
 
@@ -2069,19 +2319,20 @@ int orbfe_vocab_transform(orbfe_vocab_dev* d, const uint8_t* feats, int n, int l
     uint8_t* dF;
     int32_t *dW, *dN;
     double* dWt;
-    if ((r = s.up(&dF, feats, (size_t)n * 32)) < 0) return r;
+    if ((r = s.up_desc(&dF, feats, (size_t)n * 32)) < 0) return r;
     if ((r = s.up<int32_t>(&dW, nullptr, (size_t)n)) < 0) return r;
     if ((r = s.up<int32_t>(&dN, nullptr, (size_t)n)) < 0) return r;
     if ((r = s.up<double>(&dWt, nullptr, (size_t)n)) < 0) return r;
     {
         KernelTimer timer(s);
-        hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, 0, d->desc, d->childOff,
+        hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, g_ms, d->desc, d->childOff,
                            d->childIds, d->word, d->weight, d->L, dF, n, levelsup, dW, dN, dWt);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(word_id, dW, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(node_id, dN, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(weight, dWt, (size_t)n * 8, hipMemcpyDeviceToHost));
+    INT_TRY(s.down(word_id, dW, (size_t)n * 4));
+    INT_TRY(s.down(node_id, dN, (size_t)n * 4));
+    INT_TRY(s.down(weight, dWt, (size_t)n * 8));
+    INT_TRY(s.fetch());
     return 0;
 }
 
@@ -2098,10 +2349,11 @@ int orbfe_kb8_unproject(int device, const float* P, const float* uv, int n, floa
     if ((r = s.up<float>(&dR, nullptr, (size_t)n * 3)) < 0) return r;
     {
         KernelTimer timer(s);
-    hipLaunchKernelGGL(k_kb8_unproject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dP, dU, n, dR);
+    hipLaunchKernelGGL(k_kb8_unproject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_ms, dP, dU, n, dR);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(rays, dR, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    INT_TRY(s.down(rays, dR, (size_t)n * 3 * sizeof(float)));
+    INT_TRY(s.fetch());
     return 0;
 }
 

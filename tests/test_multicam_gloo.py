@@ -58,6 +58,29 @@ def _worker(rank, world, port, frames, cap, q):
             ed = rb.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
             gn, gd = pipe.completed().unpack(r)
             ok &= np.array_equal(gn.numpy(), en) and np.array_equal(gd.numpy(), ed)
+        # cross-camera matching bookkeeping (query shard -> job records -> frames inside the gathered buffer), with a
+        # CPU stand-in for the knn-2 kernel: every local frame against the next camera of the ring and the one after
+        from orb_slam3_detailed_comments_kor_amd.multicam import job_offsets, ring_pairs
+        pairs = ring_pairs(world, frames, rank, hops=(1, 2))
+        off = job_offsets(frames, cap, xch.slab_bytes, pairs)
+        slab, gathered = xch.slab.numpy(), xch.gathered.numpy()
+        seen_remote = False
+        for (qi, g), (qd, qc, td, tc) in zip(pairs, off):
+            nq = int(slab[qc:qc + 4].view(np.int32)[0])
+            nt = int(gathered[tc:tc + 4].view(np.int32)[0])
+            Q = slab[qd:qd + nq * 32].reshape(nq, 32)
+            T = gathered[td:td + nt * 32].reshape(nt, 32)
+            r, j = divmod(g, frames)
+            seen_remote |= r != rank
+            rr = np.random.default_rng(100 + r)
+            en = rr.integers(cap // 2, cap, size=frames).astype(np.int32)
+            ed = rr.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
+            ok &= nq == n[qi] and nt == en[j] and np.array_equal(Q, d[qi, :nq]) and np.array_equal(T, ed[j, :nt])
+            # the stand-in matcher on the slices == the same on the frames' original data
+            D = np.unpackbits(Q[:, None, :] ^ T[None, :, :], axis=2).sum(axis=2)
+            D0 = np.unpackbits(d[qi, :nq, None, :] ^ ed[j, None, :nt, :], axis=2).sum(axis=2)
+            ok &= np.array_equal(np.argsort(D, axis=1, kind="stable")[:, :2], np.argsort(D0, axis=1, kind="stable")[:, :2])
+        ok &= seen_remote  # at least one partner frame came from the other rank
         qs = list(xch.query_shard())
         first, count = shard_frames(world * frames, world, rank)
         ok &= qs == list(range(first, first + count))
@@ -94,3 +117,57 @@ def test_shard_frames_partition():
                 for f in range(first, first + count):
                     assert owner_of_frame(f, nframes, world) == r
             assert seen == list(range(nframes))
+
+
+class _FakeWork:
+    def __init__(self, completed, exc=None):
+        self.completed, self.exc, self.waited = completed, exc, 0
+
+    def is_completed(self):
+        return self.completed
+
+    def exception(self):
+        return self.exc
+
+    def wait(self):
+        self.waited += 1
+        if self.exc is not None:
+            raise self.exc
+        return True
+
+
+def test_pipelined_exchange_never_skips_a_failed_collective():
+    """begin() may skip the ordering wait only for a collective that completed CLEANLY: is_completed() is also true
+    for one that ended with an exception, and wait() is the only call that raises it."""
+    from orb_slam3_detailed_comments_kor_amd.multicam import PipelinedExchange
+    pipe = PipelinedExchange(2, 8, torch.device("cpu"), world=1, rank=0)
+    clean = _FakeWork(True)
+    pipe.pending[0] = clean
+    pipe.begin()
+    assert clean.waited == 0 and pipe.waits_skipped == 1 and pipe.pending[0] is None   # completed branch taken
+    running = _FakeWork(False)
+    pipe.pending[0] = running
+    pipe.begin()
+    assert running.waited == 1 and pipe.waits_skipped == 1
+    failed = _FakeWork(True, RuntimeError("NCCL communicator was aborted"))
+    pipe.pending[0] = failed
+    with pytest.raises(RuntimeError):
+        pipe.begin()
+    assert failed.waited == 1
+
+
+def test_ring_pairs_and_job_offsets():
+    from orb_slam3_detailed_comments_kor_amd.multicam import job_offsets, ring_pairs
+    world, frames, cap = 4, 3, 10
+    slab_bytes = (frames * cap * 32 + 4 * frames + 255) // 256 * 256
+    seen = set()
+    for r in range(world):
+        pr = ring_pairs(world, frames, r)
+        assert [q for q, _ in pr] == list(range(frames))
+        for q, g in pr:
+            assert g == (r * frames + q + 1) % (world * frames)
+            seen.add(g)
+        off = job_offsets(frames, cap, slab_bytes, pr)
+        assert off.shape == (frames, 4) and (off[:, 2] % 32 == 0).all() and (off[:, 0] == np.arange(frames) * cap * 32).all()
+        assert (off[:, 3] - off[:, 2] >= 0).all() and (off[:, 3] < world * slab_bytes).all()
+    assert seen == set(range(world * frames))  # every frame is somebody's train frame exactly once
