@@ -144,7 +144,8 @@ def _share_hip_runtime_with_torch():
 
 
 def lib_path():
-    return os.path.join(_HERE, "liborbfe.so")
+    # ORBFE_LIB: another build of the library (kernel variants side by side on one GPU box: tools/ab_build.sh)
+    return os.environ.get("ORBFE_LIB") or os.path.join(_HERE, "liborbfe.so")
 
 
 def lib():

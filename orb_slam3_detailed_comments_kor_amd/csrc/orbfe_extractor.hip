@@ -127,7 +127,6 @@ struct orbfe_ctx {
     size_t qtLdsBytes = 0;
     int qtKeyOff = 0, qtKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
-    uint32_t fastRecipP = 0;
     size_t fastLdsBytes = 0;
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
     int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning; 0 = whole images per XCD always)
@@ -304,7 +303,8 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
                     g.mNd = recip(nd);
                     g.mNdz = recip(ndz);
                     g.mZw = recip(zw1);
-                    g.pad2[0] = g.pad2[1] = g.pad2[2] = 0;
+                    g.mZh = recip(std::max(g.ch - 6, 1));
+                    g.pad2[0] = g.pad2[1] = 0;
                     g.roiOff = L.roiOff;
                     g.pitch = L.pitch;
                 }
@@ -383,7 +383,13 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             maxZone = std::max(maxZone, std::max(g.cw - 6, 0) * std::max(g.ch - 6, 0));
             maxSlots = std::max(maxSlots, (int)g.slotCap);
         }
-        c->fastPitch = (int)align_up((size_t)maxCw + 3, 4) + 4; // + one dword: phase A reads d+1
+        // Tile pitch in dwords: the widest staged row (its dwords + one: phase A reads d+1), rounded up to one of
+        // the ODD pitches the kernel is instantiated for (an odd pitch spreads a dword column over all LDS banks).
+        int maxNd = 1;
+        for (const OrbCellGeom& g : c->cg) maxNd = std::max<int>(maxNd, g.nd);
+        const int pd = maxNd + 1 <= 13 ? 13 : maxNd + 1 <= 17 ? 17 : 21;
+        if (maxNd + 1 > 21) return ORBFE_ERR_ARGS; // cannot happen: cw <= 75 -> nd <= 20
+        c->fastPitch = 4 * pd;
         c->fastRows = maxCh;
         // the survivor list of the NMS (4 B per slot) lives in the tile area after phase B
         // (4 * slotCap <= zone area < tile area, so it always fits)
@@ -392,7 +398,6 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         // (2 x 4 B per 32 tile pixels)
         const size_t rankBytes = 8 * (((size_t)c->fastRows * c->fastPitch + 31) / 32);
         c->fastLdsBytes = align_up((size_t)2 * c->fastRows * c->fastPitch + std::max(2 * (size_t)std::max(maxZone, 1), rankBytes), 16);
-        c->fastRecipP = (uint32_t)(((1ull << 32) + c->fastPitch - 1) / (uint64_t)c->fastPitch);
         int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
         if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
             nt = c->fastThreadsOverride; // ORBFE_FAST_THREADS: tuning experiments
@@ -801,13 +806,20 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             const int G = byImage ? 0 : std::max(1, c->fastXcdGroup);
             const dim3 grid = byImage ? dim3((unsigned)(8 * c->nCells * perXcd), 1u)
                                       : dim3((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)ni);
-#define ORBFE_FAST_LAUNCH(NT)                                                                                        \
-    hipLaunchKernelGGL(k_fast_cells<NT>, grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_lg.p,   \
-                       c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST,           \
-                       c->minThFAST, c->fastPitch, c->fastRows, G, c->fastDbgStop, i0, c->fastRecipP, ni)
-            if (c->fastThreads == 64) ORBFE_FAST_LAUNCH(64);
-            else if (c->fastThreads == 128) ORBFE_FAST_LAUNCH(128);
-            else ORBFE_FAST_LAUNCH(256);
+#define ORBFE_FAST_LAUNCH(NT, PD)                                                                                    \
+    hipLaunchKernelGGL((k_fast_cells<NT, PD>), grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_cg.p, \
+                       c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST, c->minThFAST,          \
+                       c->fastRows, G, c->fastDbgStop, i0, ni)
+#define ORBFE_FAST_PD(NT)                                \
+    do {                                                 \
+        if (c->fastPitch == 52) ORBFE_FAST_LAUNCH(NT, 13); \
+        else if (c->fastPitch == 68) ORBFE_FAST_LAUNCH(NT, 17); \
+        else ORBFE_FAST_LAUNCH(NT, 21);                  \
+    } while (0)
+            if (c->fastThreads == 64) ORBFE_FAST_PD(64);
+            else if (c->fastThreads == 128) ORBFE_FAST_PD(128);
+            else ORBFE_FAST_PD(256);
+#undef ORBFE_FAST_PD
 #undef ORBFE_FAST_LAUNCH
         }
         if (nsub == 1) rec(c, 2);

@@ -17,7 +17,6 @@
 #define ORBFE_ROI_X0 64        /* byte column of ROI x=0 in a pyramid row (64-B aligned rows) */
 #define ORBFE_MAX_DIM 4096     /* packed candidate = x | y<<12 | score<<24 */
 #define ORBFE_FAST_TILE 76     /* max ROI side: wCell+6 <= 75              */
-#define ORBFE_FAST_PITCH 80
 
 struct OrbLevelGeom {
     int w, h;             /* level size (cvRound((float)cols*inv), :1157)                     */
@@ -50,7 +49,8 @@ struct OrbCellGeom {
     uint32_t mNd, mNdz, mZw;
     uint32_t roiOff;    /* copy of the level's roiOff and pitch: saves the kernel a dependent load */
     int32_t pitch;
-    int32_t pad2[3];
+    uint32_t mZh;       /* reciprocal of the zone height ch - 6 */
+    int32_t pad2[2];
 };
 
 /* resize tables: per destination column / row */

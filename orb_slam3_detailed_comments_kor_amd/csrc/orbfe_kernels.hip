@@ -22,6 +22,9 @@
 #include "orb_pattern.inc"
 
 #define WAVE 64
+#ifndef ORBFE_FAST_COLMAJOR
+#define ORBFE_FAST_COLMAJOR 0 /* K-FAST phase A lane order: 1 = column by column (bank-conflict free), 0 = row by row */
+#endif
 
 __device__ const int8_t ORB_PATTERN_31_DEV[256][4] = ORBFE_PATTERN_31_INIT;
 
@@ -401,26 +404,32 @@ __device__ __forceinline__ uint32_t max16(uint32_t a, uint32_t b)
     asm("v_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-__device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
+// P = tile pitch, a compile-time constant: the sixteen ring reads are ds_read_u8 with immediate offsets from one base
+// (c - 3P - 3, so that every offset is non-negative and fits the instruction's offset field).
+template <int P>
+__device__ __forceinline__ int fast_score(const uint8_t* c)
 {
     const int v = c[0];
+    const uint8_t* b = c - 3 * P - 3;
+#define ORBFE_RING(dy, dx) b[((dy) + 3) * P + (dx) + 3]
     uint32_t r[16];
-    r[0] = c[3 * P + 0];
-    r[1] = c[3 * P + 1];
-    r[2] = c[2 * P + 2];
-    r[3] = c[1 * P + 3];
-    r[4] = c[0 * P + 3];
-    r[5] = c[-1 * P + 3];
-    r[6] = c[-2 * P + 2];
-    r[7] = c[-3 * P + 1];
-    r[8] = c[-3 * P + 0];
-    r[9] = c[-3 * P - 1];
-    r[10] = c[-2 * P - 2];
-    r[11] = c[-1 * P - 3];
-    r[12] = c[0 * P - 3];
-    r[13] = c[1 * P - 3];
-    r[14] = c[2 * P - 2];
-    r[15] = c[3 * P - 1];
+    r[0] = ORBFE_RING(3, 0);
+    r[1] = ORBFE_RING(3, 1);
+    r[2] = ORBFE_RING(2, 2);
+    r[3] = ORBFE_RING(1, 3);
+    r[4] = ORBFE_RING(0, 3);
+    r[5] = ORBFE_RING(-1, 3);
+    r[6] = ORBFE_RING(-2, 2);
+    r[7] = ORBFE_RING(-3, 1);
+    r[8] = ORBFE_RING(-3, 0);
+    r[9] = ORBFE_RING(-3, -1);
+    r[10] = ORBFE_RING(-2, -2);
+    r[11] = ORBFE_RING(-1, -3);
+    r[12] = ORBFE_RING(0, -3);
+    r[13] = ORBFE_RING(1, -3);
+    r[14] = ORBFE_RING(2, -2);
+    r[15] = ORBFE_RING(3, -1);
+#undef ORBFE_RING
     uint32_t lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { // r[2j+1], r[2j+2]
@@ -436,9 +445,9 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, const int P)
 #pragma unroll
     for (int j = 0; j < 8; j++) { // window r[2j+1 .. 2j+8], arcs starting at 2j and 2j+1
         const uint32_t lo8 = min16(lo4[j], lo4[(j + 2) & 7]), hi8 = max16(hi4[j], hi4[(j + 2) & 7]);
-        const uint32_t a = r[2 * j], b = r[(2 * j + 9) & 15];
-        bright = max16(bright, min16(lo8, max16(a, b)));
-        dark = min16(dark, max16(hi8, min16(a, b)));
+        const uint32_t a = r[2 * j], b2 = r[(2 * j + 9) & 15];
+        bright = max16(bright, min16(lo8, max16(a, b2)));
+        dark = min16(dark, max16(hi8, min16(a, b2)));
     }
     return max((int)bright - v, v - (int)dark) - 1;
 }
@@ -480,19 +489,21 @@ __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (in
 // pyramid are 64-B aligned), phase A tests 4 pixels per lane from 5 dword LDS reads, phase B
 // scores the queued survivors with all lanes busy, phase C does the NMS on the corners only; the
 // survivors are ranked by position for the ordered output.
-template <int NT>
+//
+// The tile pitch is a compile-time constant of PD dwords, PD odd: every neighbour / ring / NMS read is an immediate
+// offset from one address, and phase A deals the zone's dwords to the lanes COLUMN by column (consecutive lanes =
+// consecutive rows), so that the 32 lanes of an LDS access group hit 32 different banks.
+template <int NT, int PD>
 __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
-                                                   const OrbLevelGeom* __restrict__ lg,
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
-                                                   int nCellsTotal, int iniTh, int minTh, int P /* tile pitch, bytes */,
-                                                   int tileRows, int xcdGroup, int dbgStop, int imgBase,
-                                                   unsigned mP /* ceil(2^32 / P) */, int nImg)
+                                                   int nCellsTotal, int iniTh, int minTh, int tileRows, int xcdGroup,
+                                                   int dbgStop, int imgBase, int nImg)
 {
+    constexpr int P = 4 * PD; // tile pitch, bytes
     // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[max zone] u16 -- sized by the host from the largest
     // cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
-    const int PD = P >> 2;
     uint8_t* tile = fast_lds;
     uint8_t* smap = fast_lds + tileRows * P;
     uint16_t* queue = reinterpret_cast<uint16_t*>(fast_lds + 2 * tileRows * P);
@@ -529,7 +540,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         if (cell >= nCellsTotal) return;
     }
     const OrbCellGeom c = cg[cell];
-    (void)lg;
     const int cw = c.cw, ch = c.ch;
     const int ox = c.iniX & 3; // tile x = roi x + ox
     const int gpitch = c.pitch;
@@ -597,6 +607,49 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         // for 30 plain 32-bit operations per four pixels instead of 52.
         if (nz > 0) {
             const int d0 = txLo >> 2, ndz = (txHi >> 2) - d0 + 1;
+            const uint32_t Q = 0x3F3F3F3Fu;
+            const int tb = (th + 1) >> 2;
+            const uint32_t KH = (uint32_t)(tb - 1 + 0x80) * 0x01010101u, KL = (uint32_t)(0x80 - tb) * 0x01010101u;
+            const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+            // the SWAR test of the four pixels of dword `a`; returns bits 7 / 15 / 23 / 31
+            auto test4 = [&](uint32_t C, uint32_t Lf, uint32_t R, uint32_t U, uint32_t Dn) -> uint32_t {
+                // x-3: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
+                const uint32_t Cq = (C >> 2) & Q, Uq = (U >> 2) & Q, Dq = (Dn >> 2) & Q;
+                const uint32_t Lq = (__builtin_amdgcn_alignbyte(C, Lf, 1) >> 2) & Q;
+                const uint32_t Rq = (__builtin_amdgcn_alignbyte(R, C, 3) >> 2) & Q;
+                const uint32_t H = Cq + KH, L = Cq + KL;
+                const uint32_t notBright = ((H - Dq) & (H - Uq)) | ((H - Rq) & (H - Lq));
+                const uint32_t dark = ((L - Dq) | (L - Uq)) & ((L - Rq) | (L - Lq));
+                return (~notBright | dark) & 0x80808080u;
+            };
+            // the order of the queue is irrelevant (scores go to the map by position, the output is ranked by
+            // position): every lane reserves its own slots
+            auto push = [&](uint32_t p, int a) {
+                if (p) {
+                    int slot = lds_add_per_lane(&qn, __popc(p));
+                    const int pos0 = a << 2;
+                    if (p & 0x80u) queue[slot++] = (uint16_t)pos0;
+                    if (p & 0x8000u) queue[slot++] = (uint16_t)(pos0 + 1);
+                    if (p & 0x800000u) queue[slot++] = (uint16_t)(pos0 + 2);
+                    if (p >> 31) queue[slot] = (uint16_t)(pos0 + 3);
+                }
+            };
+#if ORBFE_FAST_COLMAJOR
+            // zone dwords dealt to the lanes column by column (consecutive lanes = consecutive rows)
+            const int nItems = ndz * zh;
+            // only the zone columns [txLo, txHi] count: the first and the last dword column are partial
+            const uint32_t mLo = 0x80808080u << (8 * (txLo & 3)), mHi = 0x80808080u >> (8 * (3 - (txHi & 3)));
+            for (int i = tid; i < nItems; i += NT) {
+                const int dz = fast_div((unsigned)i, c.mZh), r = i - dz * zh;
+                const int a = (r + 3) * PD + d0 + dz; // dword index of the four centre pixels
+                uint32_t p = test4(T[a], T[a - 1], T[a + 1], T[a - 3 * PD], T[a + 3 * PD]);
+                if (dz == 0) p &= mLo;
+                if (dz == ndz - 1) p &= mHi;
+                push(p, a);
+            }
+#else
+            // A thread keeps one dword column of the zone (4 pixels per row) and walks down the rows, so addresses
+            // advance by a constant and the column mask is a per-thread constant.
             const int r0 = fast_div((unsigned)tid, c.mNdz), dz = tid - r0 * ndz;
             const int rpp = fast_div((unsigned)NT, c.mNdz); // zone rows per pass
             if (r0 < rpp) {
@@ -605,34 +658,12 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                 if (tx0 < txLo) valid &= 0xFu << (txLo - tx0);
                 if (tx0 + 3 > txHi) valid &= 0xFu >> (tx0 + 3 - txHi);
                 const uint32_t vM = ((valid & 1u) << 7) | ((valid & 2u) << 14) | ((valid & 4u) << 21) | ((valid & 8u) << 28);
-                const uint32_t Q = 0x3F3F3F3Fu;
-                const int tb = (th + 1) >> 2;
-                const uint32_t KH = (uint32_t)(tb - 1 + 0x80) * 0x01010101u, KL = (uint32_t)(0x80 - tb) * 0x01010101u;
-                const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
-                const int P3 = 3 * PD, aStep = rpp * PD;
+                const int aStep = rpp * PD;
                 int a = (r0 + 3) * PD + d; // dword index of the four centre pixels
-                for (int r = r0; r < zh; r += rpp, a += aStep) {
-                    const uint32_t C = T[a], Lf = T[a - 1], R = T[a + 1], U = T[a - P3], Dn = T[a + P3];
-                    // x-3: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
-                    const uint32_t Cq = (C >> 2) & Q, Uq = (U >> 2) & Q, Dq = (Dn >> 2) & Q;
-                    const uint32_t Lq = (__builtin_amdgcn_alignbyte(C, Lf, 1) >> 2) & Q;
-                    const uint32_t Rq = (__builtin_amdgcn_alignbyte(R, C, 3) >> 2) & Q;
-                    const uint32_t H = Cq + KH, L = Cq + KL;
-                    const uint32_t notBright = ((H - Dq) & (H - Uq)) | ((H - Rq) & (H - Lq));
-                    const uint32_t dark = ((L - Dq) | (L - Uq)) & ((L - Rq) | (L - Lq));
-                    const uint32_t p = (~notBright | dark) & vM; // bits 7 / 15 / 23 / 31
-                    // the order of the queue is irrelevant (scores go to the map by position, the output is
-                    // ranked by position): every lane reserves its own slots
-                    if (p) {
-                        int slot = lds_add_per_lane(&qn, __popc(p));
-                        const int pos0 = a << 2;
-                        if (p & 0x80u) queue[slot++] = (uint16_t)pos0;
-                        if (p & 0x8000u) queue[slot++] = (uint16_t)(pos0 + 1);
-                        if (p & 0x800000u) queue[slot++] = (uint16_t)(pos0 + 2);
-                        if (p >> 31) queue[slot] = (uint16_t)(pos0 + 3);
-                    }
-                }
+                for (int r = r0; r < zh; r += rpp, a += aStep)
+                    push(test4(T[a], T[a - 1], T[a + 1], T[a - 3 * PD], T[a + 3 * PD]) & vM, a);
             }
+#endif
         }
         __syncthreads();
         if (dbgStop == 2) return;
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
             int pos = 0, sc = 0;
             if (qi < nq) {
                 pos = queue[qi];
-                sc = fast_score(&tile[pos], P);
+                sc = fast_score<P>(&tile[pos]);
                 if (sc >= th) smap[pos] = (uint8_t)sc;
             }
             __syncthreads(); // every entry of this round has been read: cq may overwrite the queue up to here
@@ -670,9 +701,10 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
             uint32_t ent = 0;
             if (qi < nc) {
                 const int pos = cq[qi];
-                const int s0 = smap[pos];
-                const int n0 = smap[pos - 1], n1 = smap[pos + 1], n2 = smap[pos - P - 1], n3 = smap[pos - P],
-                          n4 = smap[pos - P + 1], n5 = smap[pos + P - 1], n6 = smap[pos + P], n7 = smap[pos + P + 1];
+                const uint8_t* sp = smap + pos - P - 1; // immediate offsets below
+                const int s0 = sp[P + 1];
+                const int n0 = sp[P], n1 = sp[P + 2], n2 = sp[0], n3 = sp[1], n4 = sp[2], n5 = sp[2 * P],
+                          n6 = sp[2 * P + 1], n7 = sp[2 * P + 2];
                 const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
                 keep = s0 > mx; // s0 >= th already (phase B)
                 ent = (uint32_t)pos | ((uint32_t)s0 << 16);
@@ -729,7 +761,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
             const uint32_t e = kq[i];
             const uint32_t pos = e & 0xFFFFu;
             const int rank = pre[pos >> 5] + __popc(bm[pos >> 5] & ((1u << (pos & 31u)) - 1u));
-            const int y = fast_div(pos, mP), x = (int)pos - y * P; // tile coordinates
+            const int y = (int)(pos / (unsigned)P), x = (int)pos - y * P; // tile coordinates
             if (rank < c.slotCap)
                 out[rank] = (uint32_t)(x - ox + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((e >> 16) << 24);
         }

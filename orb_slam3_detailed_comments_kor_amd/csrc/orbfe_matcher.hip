@@ -177,12 +177,13 @@ __global__ __launch_bounds__(64 * SPLIT) void k_bfknn2_frames(const orbfe_knn2_j
     }
     // (a pointer read from memory is a generic one to the compiler; as a constant-address-space pointer with a
     // wave-uniform index the train rows become s_load_dwordx8 and feed the VALU straight from scalar registers)
-    typedef const uint4 __attribute__((address_space(4))) * scalar_rows;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef const v4u __attribute__((address_space(4))) * scalar_rows;
     const scalar_rows T = (scalar_rows)(uintptr_t)J.t_desc;
     unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
 #pragma unroll 2
     for (int t = wave; t < nT; t += SPLIT) {
-        const uint4 u = T[2 * t], v = T[2 * t + 1]; // wave-uniform address: scalar loads
+        const v4u u = T[2 * t], v = T[2 * t + 1]; // wave-uniform address: scalar loads
         unsigned d = __popc(a.x ^ u.x);
         d += __popc(a.y ^ u.y);
         d += __popc(a.z ^ u.z);

@@ -283,7 +283,7 @@ def test_alternative_gaussian_taps(pkg, oracle):
 
 def test_device_resident_batch_and_full_size_properties(pkg, oracle):
     """BASELINE configs[3] through the device-pointer entry point: a batch of 64 x 1280x720 frames.
-    Size-independent properties + spot parity on three frames."""
+    Size-independent properties + bit-exact parity of every one of the 64 frames."""
     import torch
     B, H, W = 64, 720, 1280
     base = [_frame(pkg, H, W, 900 + i) for i in range(4)]
@@ -322,14 +322,21 @@ def test_device_resident_batch_and_full_size_properties(pkg, oracle):
     for i in range(B):
         assert torch.equal(d_kps[i, : n[i]].view(torch.int32), d_kps2[i, : n[i]].view(torch.int32))
         assert torch.equal(d_desc[i, : n[i]], d_desc2[i, : n[i]])
-    ref = oracle.Extractor(1000, 1.2, 8, 20, 7)
-    for i in (0, 9, 63):
+    # parity on ALL 64 frames: one oracle extractor per host thread (the ctypes call releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def check(i):
+        ref = oracle.Extractor(1000, 1.2, 8, 20, 7)
         rmono, rkps, rdesc = ref.extract(imgs[i], (0, 0))
         got = np.zeros(n[i], pkg.KP_DTYPE)
         raw = kps[i, : n[i]]
         for j, f in enumerate(FIELDS):
             got[f] = raw[:, j].view(np.int32) if f in ("octave", "class_id") else raw[:, j]
         _same(got, rkps, desc[i, : n[i]], rdesc)
+        return rmono == n[i]
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        assert all(pool.map(check, range(B)))
 
 
 def test_context_reuse_across_sizes_and_batches(pkg, oracle):
