@@ -24,57 +24,7 @@
 
 #include "../include/orbfe.h"
 
-#if !defined(ORBFE_NO_OPENCV) && defined(__has_include)
-#if __has_include(<opencv2/core/core.hpp>)
-#include <opencv2/core/core.hpp>
-#define ORBFE_HAVE_OPENCV 1
-#endif
-#endif
-
-#ifndef ORBFE_HAVE_OPENCV
-namespace cv {
-struct Point2f {
-    float x, y;
-};
-struct KeyPoint { // same layout as cv::KeyPoint
-    Point2f pt;
-    float size, angle, response;
-    int octave, class_id;
-};
-class Mat { // 8-bit single-channel rows x cols with a row step; just enough for the adapter
-public:
-    int rows = 0, cols = 0;
-    size_t step = 0;
-    uint8_t* data = nullptr;
-    Mat() {}
-    Mat(int r, int c) { create(r, c); }
-    Mat(int r, int c, uint8_t* ext, size_t s) : rows(r), cols(c), step(s), data(ext) {}
-    void create(int r, int c)
-    {
-        rows = r;
-        cols = c;
-        step = (size_t)c;
-        store.assign((size_t)r * c, 0);
-        data = store.data();
-    }
-    void release()
-    {
-        rows = cols = 0;
-        step = 0;
-        store.clear();
-        data = nullptr;
-    }
-    bool empty() const { return rows == 0 || cols == 0 || !data; }
-    uint8_t* ptr(int r) { return data + (size_t)r * step; }
-    const uint8_t* ptr(int r) const { return data + (size_t)r * step; }
-
-private:
-    std::vector<uint8_t> store;
-};
-typedef const Mat& InputArray;
-typedef Mat& OutputArray;
-} // namespace cv
-#endif
+#include "cv_standins.h"
 
 namespace ORB_SLAM3 {
 
@@ -94,6 +44,7 @@ public:
         orbfe_get_scale_tables(ctx, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
                                mvInvLevelSigma2.data());
         mvImagePyramid.resize(nlevels);
+        pyramidStore.resize(nlevels);
     }
     ~ORBextractor() { orbfe_destroy(ctx); }
     ORBextractor(const ORBextractor&) = delete;
@@ -176,7 +127,7 @@ protected:
     int nlevels;
     double scaleFactor;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
-    std::vector<cv::Mat> pyramidStore = std::vector<cv::Mat>(16);
+    std::vector<cv::Mat> pyramidStore; // one padded buffer per level (sized by the constructor)
 };
 
 } // namespace ORB_SLAM3

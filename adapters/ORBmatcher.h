@@ -1,0 +1,599 @@
+/*
+ * adapters/ORBmatcher.h -- ORB_SLAM3::ORBmatcher with its reference signatures (include/ORBmatcher.h:39-97),
+ * its Hamming loops served by liborbfe.so through the C ABI (include/orbfe.h).
+ *
+ * The methods keep what only the host can do -- the walk over the KeyFrame / Frame / MapPoint object graph, the
+ * projections, the write-back into vpMapPointMatches / mvpMapPoints / vMatchedPairs -- and hand the inner loops
+ * (every DescriptorDistance, best / second-best, ratio and orientation tests) to the device in ONE call each:
+ *
+ *   SearchByBoW(KeyFrame*, Frame&, ...)                 src/ORBmatcher.cc:269-471    orbfe_search_bow, variant 0
+ *   SearchByBoW(KeyFrame*, KeyFrame*, ...)              src/ORBmatcher.cc:823-963    orbfe_search_bow, variant 1
+ *   SearchForTriangulation_(KF1, KF2, F12, ...)         src/ORBmatcher.cc:1208-1449  orbfe_search_tri (pinhole gate)
+ *   SearchByProjection(Frame&, vpMapPoints, th, ...)    src/ORBmatcher.cc:44-197     orbfe_search_projection, mode 0
+ *   SearchByProjection(CurrentFrame, LastFrame, ...)    src/ORBmatcher.cc:2193-2419  orbfe_search_projection, mode 1
+ *   Fuse(KeyFrame*, vpMapPoints, th, bRight)            src/ORBmatcher.cc:1643-1841  orbfe_search_projection, mode 1 + chi2
+ *   DescriptorDistance                                  src/ORBmatcher.cc:2591-2607  (host, one pair: a call per pair
+ *                                                                                     would cost more than it computes)
+ *
+ * Inside ORB-SLAM3 include the real Frame.h / KeyFrame.h / MapPoint.h before this header (and drop src/ORBmatcher.cc
+ * from the build); here, where OpenCV / Eigen / DBoW2 are absent, adapters/orbslam_standins.h provides classes with
+ * the same member names, and adapters/test_matcher_adapter.cpp drives every method through the C ABI against the
+ * oracle (tests/test_gpu_matcher_adapter.py).  Two-camera (fisheye) rigs: Nleft / NLeft != -1 is handled where the
+ * shim takes it (both SearchByBoW, SearchByProjection mode 0 queries); the KannalaBrandt8 triangulation gate is
+ * orbfe_search_tri_kb8, not wrapped here.
+ */
+#ifndef ORBFE_ADAPTER_ORBMATCHER_H
+#define ORBFE_ADAPTER_ORBMATCHER_H
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "../include/orbfe.h"
+#include "cv_standins.h"
+#ifndef ORBFE_HAVE_ORBSLAM
+#include "orbslam_standins.h"
+#endif
+
+namespace ORB_SLAM3 {
+
+namespace orbfe_adapter {
+
+// DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>) -> CSR.  Build once per Frame / KeyFrame and keep it
+// next to mFeatVec in a real integration; the methods below rebuild it per call to stay drop-in.
+struct CSR {
+    std::vector<uint32_t> ids;
+    std::vector<int32_t> off, ind;
+    orbfe_fv view() const
+    {
+        orbfe_fv f;
+        f.nn = (int)ids.size();
+        f.node_ids = ids.data();
+        f.offsets = off.data();
+        f.indices = ind.data();
+        return f;
+    }
+};
+inline CSR toCSR(const DBoW2::FeatureVector& fv)
+{
+    CSR c;
+    c.off.push_back(0);
+    for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+        c.ids.push_back((uint32_t)it->first);
+        for (size_t k = 0; k < it->second.size(); k++) c.ind.push_back((int32_t)it->second[k]);
+        c.off.push_back((int32_t)c.ind.size());
+    }
+    return c;
+}
+
+// rows of a CV_8U descriptor matrix as one dense n x 32 block (cv::Mat rows of 32 bytes are contiguous unless the
+// matrix is a view: then they are gathered)
+inline const uint8_t* dense_descriptors(const cv::Mat& D, int n, std::vector<uint8_t>& tmp)
+{
+    if (n == 0) return nullptr;
+    if ((size_t)D.step == 32) return D.data;
+    tmp.resize((size_t)n * 32);
+    for (int i = 0; i < n; i++) std::memcpy(tmp.data() + (size_t)i * 32, D.data + (size_t)i * D.step, 32);
+    return tmp.data();
+}
+
+// the keypoint a method reads for feature idx of a keyframe / frame with an optional second camera
+// (e.g. :377-381, :1278-1283): mvKeysUn without a rig, else mvKeys / mvKeysRight
+template <class T>
+inline const cv::KeyPoint& rig_keypoint(const T& f, int nLeft, size_t idx)
+{
+    return nLeft == -1 ? f.mvKeysUn[idx] : ((int)idx < nLeft ? f.mvKeys[idx] : f.mvKeysRight[idx - nLeft]);
+}
+
+#ifdef ORBFE_HAVE_OPENCV_MATS // inside ORB-SLAM3: poses and positions are cv::Mat (CV_32F)
+inline void frame_pose(const Frame& F, float R[9], float t[3])
+{
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) R[3 * i + j] = F.mTcw.at<float>(i, j);
+        t[i] = F.mTcw.at<float>(i, 3);
+    }
+}
+inline void world_pos(MapPoint* p, float x[3])
+{
+    const cv::Mat w = p->GetWorldPos();
+    for (int i = 0; i < 3; i++) x[i] = w.at<float>(i);
+}
+inline void normal_of(MapPoint* p, float x[3])
+{
+    const cv::Mat w = p->GetNormal();
+    for (int i = 0; i < 3; i++) x[i] = w.at<float>(i);
+}
+inline void kf_pose(KeyFrame* pKF, bool bRight, float R[9], float t[3], float O[3])
+{
+    const cv::Mat Rm = bRight ? pKF->GetRightRotation() : pKF->GetRotation();
+    const cv::Mat tm = bRight ? pKF->GetRightTranslation() : pKF->GetTranslation();
+    const cv::Mat Om = bRight ? pKF->GetRightCameraCenter() : pKF->GetCameraCenter();
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) R[3 * i + j] = Rm.at<float>(i, j);
+        t[i] = tm.at<float>(i);
+        O[i] = Om.at<float>(i);
+    }
+}
+#else
+inline void frame_pose(const Frame& F, float R[9], float t[3])
+{
+    for (int i = 0; i < 9; i++) R[i] = F.mRcw_.val[i];
+    for (int i = 0; i < 3; i++) t[i] = F.mtcw_.val[i];
+}
+inline void world_pos(MapPoint* p, float x[3])
+{
+    const cv::Matx31f w = p->GetWorldPos_();
+    for (int i = 0; i < 3; i++) x[i] = w(i);
+}
+inline void normal_of(MapPoint* p, float x[3])
+{
+    const cv::Matx31f w = p->GetNormal_();
+    for (int i = 0; i < 3; i++) x[i] = w(i);
+}
+inline void kf_pose(KeyFrame* pKF, bool /*bRight*/, float R[9], float t[3], float O[3])
+{
+    const cv::Matx33f Rm = pKF->GetRotation_();
+    const cv::Matx31f tm = pKF->GetTranslation_(), Om = pKF->GetCameraCenter_();
+    for (int i = 0; i < 9; i++) R[i] = Rm.val[i];
+    for (int i = 0; i < 3; i++) {
+        t[i] = tm(i);
+        O[i] = Om(i);
+    }
+}
+#endif
+
+// x_c = R x_w + t as cv::Mat evaluates `Rcw*x3Dw+tcw` for CV_32F (one gemm with double accumulators, rounded once)
+inline void transform(const float R[9], const float t[3], const float xw[3], float xc[3])
+{
+    for (int i = 0; i < 3; i++)
+        xc[i] = (float)((double)R[3 * i] * xw[0] + (double)R[3 * i + 1] * xw[1] + (double)R[3 * i + 2] * xw[2] + (double)t[i]);
+}
+
+// queries of one orbfe_search_projection call, appended in the reference's loop order
+struct Queries {
+    std::vector<uint8_t> desc, flags, blocks;
+    std::vector<float> x, y, r, xr, angle;
+    std::vector<int32_t> minLevel, maxLevel;
+    std::vector<MapPoint*> mp;
+    void push(MapPoint* p, const uint8_t* d, float qx, float qy, float qr, int lo, int hi, float qxr, int fl, float ang, int blk)
+    {
+        mp.push_back(p);
+        desc.insert(desc.end(), d, d + 32);
+        x.push_back(qx);
+        y.push_back(qy);
+        r.push_back(qr);
+        minLevel.push_back(lo);
+        maxLevel.push_back(hi);
+        xr.push_back(qxr);
+        flags.push_back((uint8_t)fl);
+        angle.push_back(ang);
+        blocks.push_back((uint8_t)blk);
+    }
+    int size() const { return (int)mp.size(); }
+};
+
+// the frame side of orbfe_proj_args: the keypoints GetFeaturesInArea reads (mvKeysUn without a rig, else
+// mvKeys ++ mvKeysRight), split into the arrays the shim takes
+struct FeatureArrays {
+    std::vector<float> kx, ky, angle;
+    std::vector<int32_t> octave;
+    template <class T>
+    void fill(const T& f, int n, int nLeft)
+    {
+        kx.resize(n);
+        ky.resize(n);
+        angle.resize(n);
+        octave.resize(n);
+        for (int i = 0; i < n; i++) {
+            const cv::KeyPoint& kp = rig_keypoint(f, nLeft, (size_t)i);
+            kx[i] = kp.pt.x;
+            ky[i] = kp.pt.y;
+            angle[i] = kp.angle;
+            octave[i] = kp.octave;
+        }
+    }
+};
+
+} // namespace orbfe_adapter
+
+class ORBmatcher {
+public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), mDevice(device)
+    {
+    }
+
+    // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2591-2607)
+    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b)
+    {
+        const uint32_t* pa = reinterpret_cast<const uint32_t*>(a.data);
+        const uint32_t* pb = reinterpret_cast<const uint32_t*>(b.data);
+        int dist = 0;
+        for (int i = 0; i < 8; i++) dist += __builtin_popcount(pa[i] ^ pb[i]);
+        return dist;
+    }
+
+    // ---- src/ORBmatcher.cc:269-471
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)
+    {
+        using namespace orbfe_adapter;
+        const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+        const int n1 = (int)vpMapPointsKF.size();
+        std::vector<uint8_t> good(n1), tmp1, tmp2;
+        std::vector<float> ang1(n1), ang2(F.N);
+        for (int i = 0; i < n1; i++) { // :301-307: only features with a good MapPoint search
+            MapPoint* pMP = vpMapPointsKF[i];
+            good[i] = (pMP && !pMP->isBad()) ? 1 : 0;
+            // :377-381: the keyframe keypoint is mvKeysUn without a second camera
+            ang1[i] = (!pKF->mpCamera2) ? pKF->mvKeysUn[i].angle
+                                        : (i >= pKF->NLeft ? pKF->mvKeysRight[i - pKF->NLeft].angle : pKF->mvKeys[i].angle);
+        }
+        for (int i = 0; i < F.N; i++) // :385-388 / :414-417: mvKeys, or mvKeysRight for the right half of a rig
+            ang2[i] = (F.Nleft == -1 || !F.mpCamera2 || i < F.Nleft) ? F.mvKeys[i].angle : F.mvKeysRight[i - F.Nleft].angle;
+        const CSR c1 = toCSR(pKF->mFeatVec), c2 = toCSR(F.mFeatVec);
+        orbfe_bow_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc1 = dense_descriptors(pKF->mDescriptors, n1, tmp1);
+        a.n1 = n1;
+        a.mask1 = good.data();
+        a.angle1 = ang1.data();
+        a.fv1 = c1.view();
+        a.limit1 = -1;
+        a.desc2 = dense_descriptors(F.mDescriptors, F.N, tmp2);
+        a.n2 = F.N;
+        a.mask2 = nullptr;
+        a.angle2 = ang2.data();
+        a.fv2 = c2.view();
+        a.limit2 = -1;
+        a.Nleft = F.Nleft;
+        a.nnratio = mfNNratio;
+        a.check_orientation = mbCheckOrientation ? 1 : 0;
+        a.variant = 0;
+        std::vector<int32_t> match((size_t)std::max(F.N, 1), -1);
+        const int nmatches = orbfe_search_bow(mDevice, &a, match.data());
+        if (nmatches < 0) throw std::runtime_error("orbfe_search_bow failed");
+        for (int i = 0; i < F.N; i++)
+            if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]]; // :376, :406
+        return nmatches;
+    }
+
+    // ---- src/ORBmatcher.cc:823-963
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12)
+    {
+        using namespace orbfe_adapter;
+        const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+        const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+        vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+        std::vector<uint8_t> good1(n1), good2(n2), tmp1, tmp2;
+        std::vector<float> ang1(n1, 0.f), ang2(n2, 0.f);
+        for (int i = 0; i < n1; i++) {
+            good1[i] = (vpMapPoints1[i] && !vpMapPoints1[i]->isBad()) ? 1 : 0; // :862-866
+            if (i < (int)pKF1->mvKeysUn.size()) ang1[i] = pKF1->mvKeysUn[i].angle;
+        }
+        for (int i = 0; i < n2; i++) {
+            good2[i] = (vpMapPoints2[i] && !vpMapPoints2[i]->isBad()) ? 1 : 0; // :884-888
+            if (i < (int)pKF2->mvKeysUn.size()) ang2[i] = pKF2->mvKeysUn[i].angle;
+        }
+        const CSR c1 = toCSR(pKF1->mFeatVec), c2 = toCSR(pKF2->mFeatVec);
+        orbfe_bow_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc1 = dense_descriptors(pKF1->mDescriptors, n1, tmp1);
+        a.n1 = n1;
+        a.mask1 = good1.data();
+        a.angle1 = ang1.data();
+        a.fv1 = c1.view();
+        a.limit1 = pKF1->NLeft != -1 ? (int)pKF1->mvKeysUn.size() : -1; // :855-857: right-camera features are skipped
+        a.desc2 = dense_descriptors(pKF2->mDescriptors, n2, tmp2);
+        a.n2 = n2;
+        a.mask2 = good2.data();
+        a.angle2 = ang2.data();
+        a.fv2 = c2.view();
+        a.limit2 = pKF2->NLeft != -1 ? (int)pKF2->mvKeysUn.size() : -1; // :874-876
+        a.Nleft = -1;
+        a.nnratio = mfNNratio;
+        a.check_orientation = mbCheckOrientation ? 1 : 0;
+        a.variant = 1;
+        std::vector<int32_t> match((size_t)std::max(n1, 1), -1);
+        const int nmatches = orbfe_search_bow(mDevice, &a, match.data());
+        if (nmatches < 0) throw std::runtime_error("orbfe_search_bow failed");
+        for (int i = 0; i < n1; i++)
+            if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]]; // :910
+        return nmatches;
+    }
+
+    // ---- src/ORBmatcher.cc:1208-1449 (pinhole cameras without a second camera; the F12 argument is not read by
+    // the reference either: its gate, Pinhole::epipolarConstrain_, rebuilds the matrix from R12, t12)
+    int SearchForTriangulation_(KeyFrame* pKF1, KeyFrame* pKF2, cv::Matx33f /*F12*/,
+                                std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo,
+                                const bool bCoarse = false)
+    {
+        using namespace orbfe_adapter;
+        if (pKF1->mpCamera2 || pKF2->mpCamera2)
+            throw std::runtime_error("two-camera rigs: use orbfe_search_tri_kb8 (INTEGRATION.md)");
+        // epipole in the second image (:1215-1220)
+        const cv::Matx31f Cw = pKF1->GetCameraCenter_();
+        const cv::Matx33f R2w = pKF2->GetRotation_();
+        const cv::Matx31f t2w = pKF2->GetTranslation_();
+        const cv::Matx31f C2 = R2w * Cw + t2w;
+        const cv::Point2f ep = pKF2->mpCamera->project(C2);
+        const cv::Matx33f R1w = pKF1->GetRotation_();
+        const cv::Matx31f t1w = pKF1->GetTranslation_();
+        const cv::Matx33f R12 = R1w * R2w.t();                  // :1234
+        const cv::Matx31f t12 = -R1w * R2w.t() * t2w + t1w;     // :1235
+        // what Pinhole::epipolarConstrain_ evaluates per candidate (Pinhole.cpp:161-164), once per keyframe pair
+        cv::Matx33f t12x;
+        t12x(0, 1) = -t12(2); t12x(0, 2) = t12(1);
+        t12x(1, 0) = t12(2);  t12x(1, 2) = -t12(0);
+        t12x(2, 0) = -t12(1); t12x(2, 1) = t12(0);
+        const cv::Matx33f K1 = pKF1->mpCamera->toK_(), K2 = pKF2->mpCamera->toK_();
+        const cv::Matx33f F12 = K1.t().inv() * t12x * R12 * K2.inv();
+        lastF12 = F12;
+        lastEp = ep;
+
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        std::vector<uint8_t> has1(n1), has2(n2), tmp1, tmp2;
+        std::vector<float> xy1(2 * (size_t)n1), xy2(2 * (size_t)n2), ang1(n1), ang2(n2);
+        std::vector<int32_t> oct1(n1), oct2(n2);
+        for (int i = 0; i < n1; i++) {
+            has1[i] = pKF1->GetMapPoint(i) ? 1 : 0; // :1268-1274
+            const cv::KeyPoint& kp = rig_keypoint(*pKF1, pKF1->NLeft, (size_t)i);
+            xy1[2 * i] = kp.pt.x; xy1[2 * i + 1] = kp.pt.y; ang1[i] = kp.angle; oct1[i] = kp.octave;
+        }
+        for (int i = 0; i < n2; i++) {
+            has2[i] = pKF2->GetMapPoint(i) ? 1 : 0; // :1307-1311
+            const cv::KeyPoint& kp = rig_keypoint(*pKF2, pKF2->NLeft, (size_t)i);
+            xy2[2 * i] = kp.pt.x; xy2[2 * i + 1] = kp.pt.y; ang2[i] = kp.angle; oct2[i] = kp.octave;
+        }
+        const CSR c1 = toCSR(pKF1->mFeatVec), c2 = toCSR(pKF2->mFeatVec);
+        orbfe_tri_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc1 = dense_descriptors(pKF1->mDescriptors, n1, tmp1); a.n1 = n1; a.hasMP1 = has1.data();
+        a.kp1_xy = xy1.data(); a.angle1 = ang1.data(); a.octave1 = oct1.data(); a.uRight1 = pKF1->mvuRight.data();
+        a.fv1 = c1.view();
+        a.desc2 = dense_descriptors(pKF2->mDescriptors, n2, tmp2); a.n2 = n2; a.hasMP2 = has2.data();
+        a.kp2_xy = xy2.data(); a.angle2 = ang2.data(); a.octave2 = oct2.data(); a.uRight2 = pKF2->mvuRight.data();
+        a.fv2 = c2.view();
+        for (int i = 0; i < 9; i++) a.F12[i] = F12.val[i];
+        a.ep[0] = ep.x; a.ep[1] = ep.y;
+        a.scaleFactors2 = pKF2->mvScaleFactors.data();
+        a.levelSigma2_2 = pKF2->mvLevelSigma2.data();
+        a.nlevels2 = (int)pKF2->mvScaleFactors.size();
+        a.only_stereo = bOnlyStereo ? 1 : 0;
+        a.coarse = bCoarse ? 1 : 0;
+        a.check_orientation = mbCheckOrientation ? 1 : 0;
+        std::vector<int32_t> pairs(2 * (size_t)std::max(n1, 1));
+        const int np = orbfe_search_tri(mDevice, &a, pairs.data());
+        if (np < 0) throw std::runtime_error("orbfe_search_tri failed");
+        vMatchedPairs.clear(); // :1435-1446
+        vMatchedPairs.reserve(np);
+        for (int k = 0; k < np; k++) vMatchedPairs.push_back(std::make_pair((size_t)pairs[2 * k], (size_t)pairs[2 * k + 1]));
+        return np;
+    }
+
+    // ---- src/ORBmatcher.cc:44-197 (Tracking::SearchLocalPoints)
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3,
+                           const bool bFarPoints = false, const float thFarPoints = 50.0f)
+    {
+        using namespace orbfe_adapter;
+        const bool bFactor = th != 1.0;
+        Queries q;
+        for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) { // the object walk of :50-63, :137-143
+            MapPoint* pMP = vpMapPoints[iMP];
+            if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
+            if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
+            if (pMP->isBad()) continue;
+            bool left = false;
+            const cv::Mat d = pMP->GetDescriptor();
+            if (pMP->mbTrackInView) {
+                const int nPredictedLevel = pMP->mnTrackScaleLevel;
+                float r = RadiusByViewingCos(pMP->mTrackViewCos);
+                if (bFactor) r *= th;
+                q.push(pMP, d.data, pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel],
+                       nPredictedLevel - 1, nPredictedLevel, pMP->mTrackProjXR, 0, 0.f, pMP->Observations() > 0);
+                left = true;
+            }
+            if (F.Nleft != -1 && pMP->mbTrackInViewR) {
+                const int nPredictedLevel = pMP->mnTrackScaleLevelR;
+                if (nPredictedLevel != -1) {
+                    const float r = RadiusByViewingCos(pMP->mTrackViewCosR);
+                    q.push(pMP, d.data, pMP->mTrackProjXR, pMP->mTrackProjYR, r * F.mvScaleFactors[nPredictedLevel],
+                           nPredictedLevel - 1, nPredictedLevel, 0.f, 1 | (left ? 2 : 0), 0.f, pMP->Observations() > 0);
+                }
+            }
+        }
+        std::vector<int32_t> qMatch, featMatch;
+        const int nmatches = run_projection(F, F.N, F.Nleft, F.mDescriptors, F.mvuRight.empty() ? nullptr : F.mvuRight.data(),
+                                            taken_of(F.mvpMapPoints, F.N), F.mnMinX, F.mnMinY, F.mfGridElementWidthInv,
+                                            F.mfGridElementHeightInv, q, 0, TH_HIGH, false, nullptr, 0, false,
+                                            F.Nleft != -1 && !F.mvLeftToRightMatch.empty() ? F.mvLeftToRightMatch.data() : nullptr,
+                                            F.Nleft != -1 && !F.mvRightToLeftMatch.empty() ? F.mvRightToLeftMatch.data() : nullptr,
+                                            qMatch, featMatch);
+        for (int i = 0; i < F.N; i++)
+            if (featMatch[i] >= 0) F.mvpMapPoints[i] = q.mp[featMatch[i]]; // :112, :117-121, :171
+        return nmatches;
+    }
+
+    // ---- src/ORBmatcher.cc:2193-2419 (Tracking::TrackWithMotionModel); frames without a second camera
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
+    {
+        using namespace orbfe_adapter;
+        if (CurrentFrame.Nleft != -1) throw std::runtime_error("two-camera rigs are not wrapped by this overload");
+        float Rcw[9], tcw[3], Rlw[9], tlw[3];
+        frame_pose(CurrentFrame, Rcw, tcw);
+        frame_pose(LastFrame, Rlw, tlw);
+        // twc = -Rcw^T tcw; tlc = Rlw twc + tlw (:2207-2212)
+        float twc[3], tlc[3];
+        for (int i = 0; i < 3; i++)
+            twc[i] = (float)(-((double)Rcw[i] * tcw[0] + (double)Rcw[3 + i] * tcw[1] + (double)Rcw[6 + i] * tcw[2]));
+        transform(Rlw, tlw, twc, tlc);
+        const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
+        const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
+        Queries q;
+        for (int i = 0; i < LastFrame.N; i++) {
+            MapPoint* pMP = LastFrame.mvpMapPoints[i];
+            if (!pMP || LastFrame.mvbOutlier[i]) continue;
+            float x3Dw[3], x3Dc[3];
+            world_pos(pMP, x3Dw);
+            transform(Rcw, tcw, x3Dw, x3Dc);
+            const float invzc = 1.0 / x3Dc[2];
+            if (invzc < 0) continue;
+            const cv::Point2f uv = CurrentFrame.mpCamera->project(cv::Point3f(x3Dc[0], x3Dc[1], x3Dc[2]));
+            if (uv.x < CurrentFrame.mnMinX || uv.x > CurrentFrame.mnMaxX) continue;
+            if (uv.y < CurrentFrame.mnMinY || uv.y > CurrentFrame.mnMaxY) continue;
+            const int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave
+                                                                                   : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+            const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+            int lo, hi; // the arguments of GetFeaturesInArea (:2248-2253)
+            if (bForward) { lo = nLastOctave; hi = -1; }
+            else if (bBackward) { lo = 0; hi = nLastOctave; }
+            else { lo = nLastOctave - 1; hi = nLastOctave + 1; }
+            const cv::KeyPoint& kpLF = rig_keypoint(LastFrame, LastFrame.Nleft, (size_t)i);
+            const float ur = uv.x - CurrentFrame.mbf * invzc; // :2272
+            // (a temporal point of UpdateLastFrame has no observations: it does not hide its feature from later points)
+            q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, radius, lo, hi, ur, 0, kpLF.angle, pMP->Observations() > 0);
+        }
+        std::vector<int32_t> qMatch, featMatch;
+        const int nmatches = run_projection(CurrentFrame, CurrentFrame.N, -1, CurrentFrame.mDescriptors,
+                                            CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
+                                            taken_of(CurrentFrame.mvpMapPoints, CurrentFrame.N), CurrentFrame.mnMinX,
+                                            CurrentFrame.mnMinY, CurrentFrame.mfGridElementWidthInv,
+                                            CurrentFrame.mfGridElementHeightInv, q, 1, TH_HIGH, mbCheckOrientation, nullptr, 0,
+                                            false, nullptr, nullptr, qMatch, featMatch);
+        // :2301 and the cull of :2399-2415: the features the cull cleared are reset to NULL, the survivors hold pMP
+        for (int i = 0; i < CurrentFrame.N; i++)
+            if (featMatch[i] >= 0) CurrentFrame.mvpMapPoints[i] = q.mp[featMatch[i]];
+        for (size_t k = 0; k < q.mp.size(); k++) // a feature some point wrote that holds none now: cleared by the cull
+            if (qMatch[k] >= 0 && featMatch[qMatch[k]] < 0) CurrentFrame.mvpMapPoints[qMatch[k]] = static_cast<MapPoint*>(NULL);
+        return nmatches;
+    }
+
+    // ---- src/ORBmatcher.cc:1643-1841 (LocalMapping::SearchInNeighbors); keyframes without a second camera
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false)
+    {
+        using namespace orbfe_adapter;
+        if (bRight || pKF->NLeft != -1) throw std::runtime_error("two-camera rigs are not wrapped by this overload");
+        float Rcw[9], tcw[3], Ow[3];
+        kf_pose(pKF, bRight, Rcw, tcw, Ow);
+        const float bf = pKF->mbf;
+        Queries q;
+        for (size_t i = 0; i < vpMapPoints.size(); i++) { // :1690-1742, unchanged conditions
+            MapPoint* pMP = vpMapPoints[i];
+            if (!pMP) continue;
+            if (pMP->isBad()) continue;
+            if (pMP->IsInKeyFrame(pKF)) continue;
+            float p3Dw[3], p3Dc[3], Pn[3];
+            world_pos(pMP, p3Dw);
+            transform(Rcw, tcw, p3Dw, p3Dc);
+            if (p3Dc[2] < 0.0f) continue;
+            const float invz = 1 / p3Dc[2];
+            const cv::Point2f uv = pKF->mpCamera->project(cv::Point3f(p3Dc[0], p3Dc[1], p3Dc[2]));
+            if (!pKF->IsInImage(uv.x, uv.y)) continue;
+            const float ur = uv.x - bf * invz;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+            const float dist3D = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]); // cv::norm
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            normal_of(pMP, Pn);
+            if ((double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2] < 0.5 * dist3D) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+            const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+            // the level test of :1771-1772 is the window's level range; the chi2 test of :1774-1799 runs on the device
+            q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, radius, nPredictedLevel - 1, nPredictedLevel, ur, 0, 0.f, 0);
+        }
+        std::vector<int32_t> qMatch, featMatch;
+        std::vector<uint8_t> none((size_t)std::max(pKF->N, 1), 0);
+        run_projection(*pKF, pKF->N, -1, pKF->mDescriptors, pKF->mvuRight.data(), none, pKF->mnMinX, pKF->mnMinY,
+                       pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, q, 1, TH_LOW, false,
+                       pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), true, nullptr, nullptr, qMatch,
+                       featMatch);
+        int nFused = 0;
+        for (size_t k = 0; k < q.mp.size(); k++) { // :1813-1838: the sequential object logic, unchanged
+            const int bestIdx = qMatch[k];
+            if (bestIdx < 0) continue;
+            MapPoint* pMP = q.mp[k];
+            MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx);
+                pKF->AddMapPoint(pMP, bestIdx);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+public:
+    static const int TH_LOW = 50;
+    static const int TH_HIGH = 100;
+    static const int HISTO_LENGTH = 30;
+    cv::Matx33f lastF12; // what SearchForTriangulation_ formed from the poses (read by the adapter's test)
+    cv::Point2f lastEp;
+
+protected:
+    float RadiusByViewingCos(const float& viewCos) // :199-205
+    {
+        if (viewCos > 0.998) return 2.5;
+        else return 4.0;
+    }
+
+    static std::vector<uint8_t> taken_of(const std::vector<MapPoint*>& v, int n)
+    { // F.mvpMapPoints[idx] && Observations() > 0 (:83-85, :2262-2264)
+        std::vector<uint8_t> t((size_t)std::max(n, 1), 0);
+        for (int i = 0; i < n && i < (int)v.size(); i++) t[i] = (v[i] && v[i]->Observations() > 0) ? 1 : 0;
+        return t;
+    }
+
+    template <class T>
+    int run_projection(const T& f, int n, int nLeft, const cv::Mat& D, const float* uright, const std::vector<uint8_t>& taken,
+                       float minX, float minY, float gwInv, float ghInv, const orbfe_adapter::Queries& q, int mode,
+                       int thHigh, bool checkOri, const float* invSigma2, int nLevels, bool chi2, const int* l2r,
+                       const int* r2l, std::vector<int32_t>& qMatch, std::vector<int32_t>& featMatch)
+    {
+        using namespace orbfe_adapter;
+        FeatureArrays fa;
+        fa.fill(f, n, nLeft);
+        std::vector<uint8_t> tmp;
+        orbfe_proj_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc = dense_descriptors(D, n, tmp);
+        a.n = n;
+        a.kx = fa.kx.data(); a.ky = fa.ky.data(); a.octave = fa.octave.data(); a.angle = fa.angle.data();
+        a.uright = nLeft == -1 ? uright : nullptr;
+        a.taken = taken.data();
+        a.Nleft = nLeft;
+        a.left_to_right = l2r; a.right_to_left = r2l;
+        a.minX = minX; a.minY = minY; a.gridWInv = gwInv; a.gridHInv = ghInv;
+        a.nq = q.size();
+        a.qdesc = q.desc.data(); a.qx = q.x.data(); a.qy = q.y.data(); a.qr = q.r.data();
+        a.qmin_level = q.minLevel.data(); a.qmax_level = q.maxLevel.data();
+        a.qxr = a.uright ? q.xr.data() : nullptr;
+        a.qflags = nLeft != -1 ? q.flags.data() : nullptr;
+        a.qangle = q.angle.data();
+        a.qblocks = q.blocks.data();
+        a.mode = mode; a.nnratio = mfNNratio; a.th_high = thHigh; a.check_orientation = checkOri ? 1 : 0;
+        a.inv_level_sigma2 = invSigma2; a.n_levels = nLevels; a.chi2_gate = chi2 ? 1 : 0;
+        qMatch.assign((size_t)std::max(q.size(), 1), -1);
+        featMatch.assign((size_t)std::max(n, 1), -1);
+        const int r = orbfe_search_projection(mDevice, &a, qMatch.data(), featMatch.data());
+        if (r < 0) throw std::runtime_error("orbfe_search_projection failed");
+        return r;
+    }
+
+    float mfNNratio;
+    bool mbCheckOrientation;
+    int mDevice;
+};
+
+} // namespace ORB_SLAM3
+
+#endif

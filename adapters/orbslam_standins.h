@@ -1,0 +1,144 @@
+/*
+ * adapters/orbslam_standins.h -- minimal stand-ins for the ORB-SLAM3 classes ORBmatcher walks (Frame, KeyFrame,
+ * MapPoint, GeometricCamera / Pinhole, DBoW2::FeatureVector), with exactly the member names the reference uses
+ * (include/Frame.h, include/KeyFrame.h, include/MapPoint.h, include/CameraModels/Pinhole.h,
+ * Thirdparty/DBoW2/DBoW2/FeatureVector.h), so that adapters/ORBmatcher.h compiles against them here -- where OpenCV,
+ * Eigen and DBoW2 are absent -- and against the real classes inside ORB-SLAM3 without a change.
+ * Only what the adapted methods read or write exists; nothing here computes anything of the hot path.
+ */
+#ifndef ORBFE_ADAPTER_ORBSLAM_STANDINS_H
+#define ORBFE_ADAPTER_ORBSLAM_STANDINS_H
+
+#include <cmath>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "cv_standins.h"
+
+namespace DBoW2 {
+typedef unsigned int NodeId;
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
+} // namespace DBoW2
+
+namespace ORB_SLAM3 {
+
+class KeyFrame;
+
+class GeometricCamera { // the Pinhole model (src/CameraModels/Pinhole.cpp)
+public:
+    std::vector<float> mvParameters; // fx, fy, cx, cy
+    cv::Point2f project(const cv::Matx31f& m) const
+    { // Pinhole::project(const cv::Matx31f&), Pinhole.cpp:45-51
+        cv::Point2f p;
+        p.x = mvParameters[0] * m(0) / m(2) + mvParameters[2];
+        p.y = mvParameters[1] * m(1) / m(2) + mvParameters[3];
+        return p;
+    }
+    cv::Point2f project(const cv::Point3f& p3) const
+    {
+        cv::Point2f p;
+        p.x = mvParameters[0] * p3.x / p3.z + mvParameters[2];
+        p.y = mvParameters[1] * p3.y / p3.z + mvParameters[3];
+        return p;
+    }
+    cv::Matx33f toK_() const
+    {
+        cv::Matx33f K;
+        K(0, 0) = mvParameters[0];
+        K(1, 1) = mvParameters[1];
+        K(0, 2) = mvParameters[2];
+        K(1, 2) = mvParameters[3];
+        K(2, 2) = 1.f;
+        return K;
+    }
+};
+
+class MapPoint {
+public:
+    long unsigned int mnId = 0;
+    // Tracking::SearchLocalPoints / Frame::isInFrustum results (include/MapPoint.h:111-121)
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0, mTrackProjYR = 0, mTrackViewCos = 0,
+          mTrackViewCosR = 0;
+    bool mbTrackInView = false, mbTrackInViewR = false;
+    int mnTrackScaleLevel = 0, mnTrackScaleLevelR = -1;
+
+    bool isBad() { return mbBad; }
+    int Observations() { return nObs; }
+    cv::Mat GetDescriptor() { return cv::Mat(1, 32, mDescriptor, 32); }
+    cv::Matx31f GetWorldPos_() { return mWorldPos; }
+    cv::Matx31f GetNormal_() { return mNormalVector; }
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+    int PredictScale(const float& currentDist, KeyFrame* pKF); // MapPoint.cc:548-563, below
+    // what Fuse does to the map (MapPoint.cc Replace / AddObservation): recorded for the test
+    void Replace(MapPoint* pMP) { mpReplaced = pMP; }
+    void AddObservation(KeyFrame* pKF, int idx) { mObservations[pKF] = idx; }
+
+    bool mbBad = false;
+    int nObs = 1;
+    uint8_t mDescriptor[32] = {0};
+    cv::Matx31f mWorldPos, mNormalVector;
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    std::map<KeyFrame*, int> mObservations;
+    MapPoint* mpReplaced = nullptr;
+};
+
+class Frame {
+public:
+    int N = 0, Nleft = -1;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+    std::vector<float> mvuRight;
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    std::vector<float> mvScaleFactors;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    float mbf = 0, mb = 0;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
+    cv::Matx33f mRcw_; // rotation / translation of mTcw (the reference slices the 4x4 cv::Mat mTcw, ORBmatcher.cc:2204-2205)
+    cv::Matx31f mtcw_;
+};
+
+class KeyFrame {
+public:
+    int N = 0, NLeft = -1;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+    std::vector<float> mvuRight;
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    float mfLogScaleFactor = 0;
+    int mnScaleLevels = 8;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    cv::Matx33f GetRotation_() { return Rcw; }
+    cv::Matx31f GetTranslation_() { return tcw; }
+    cv::Matx31f GetCameraCenter_() { return Ow; }
+    bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
+
+    std::vector<MapPoint*> mvpMapPoints;
+    cv::Matx33f Rcw;
+    cv::Matx31f tcw, Ow;
+};
+
+inline int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF)
+{
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / pKF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+    return nScale;
+}
+
+} // namespace ORB_SLAM3
+
+#endif

@@ -1,0 +1,415 @@
+"""adapters/ORBmatcher.h keeps the reference's ORBmatcher signatures (include/ORBmatcher.h:39-97): a C++ caller
+written like Tracking / LocalMapping / LoopClosing (adapters/test_matcher_adapter.cpp, object graphs of stand-in
+KeyFrame / Frame / MapPoint) gets, from every wrapped method, the object state the oracle predicts.
+
+The scenarios are generated here as OBJECT-level data (per-feature map-point states, vocabulary node per feature,
+poses, world points); the expectation is derived by this file's own flattening of the same data + the oracle, so the
+adapter's toCSR, mask / angle flattening, query construction (projections, radii, level ranges) and write-back are
+all checked against an independent implementation.  Geometry uses dyadic numbers so that projections are exact in
+every evaluation order."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SF = (1.2 ** np.arange(8)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ scenario / result files
+def _put(f, name, arr):
+    arr = np.ascontiguousarray(arr)
+    code = {np.dtype(np.uint8): 0, np.dtype(np.int32): 1, np.dtype(np.float32): 2}[arr.dtype]
+    nb = name.encode()
+    f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<II", code, arr.size) + arr.tobytes())
+
+
+def _read(path):
+    out = {}
+    raw = open(path, "rb").read()
+    o = 0
+    while o < len(raw):
+        (nl,) = struct.unpack_from("<I", raw, o)
+        name = raw[o + 4:o + 4 + nl].decode()
+        code, cnt = struct.unpack_from("<II", raw, o + 4 + nl)
+        o += 12 + nl
+        dt = [np.uint8, np.int32, np.float32][code]
+        out[name] = np.frombuffer(raw, dt, cnt, o).copy()
+        o += cnt * np.dtype(dt).itemsize
+    return out
+
+
+def _csr_from_nodes(node):
+    """DBoW2::FeatureVector as the C++ side builds it from the same per-feature node ids: std::map order (ascending
+    node id), features of a node in ascending index order."""
+    ids = np.unique(node[node >= 0])
+    off = [0]
+    ind = []
+    for v in ids:
+        ind += list(np.nonzero(node == v)[0])
+        off.append(len(ind))
+    return ids.astype(np.uint32), np.array(off, np.int32), np.array(ind, np.int32)
+
+
+def _nodes(desc, seed, branching=6):
+    """vocabulary node per feature (nearest of `branching`^2 random centroids), -1 for a tenth of them (stop words)."""
+    rng = np.random.default_rng(seed)
+    cent = rng.integers(0, 256, (branching * branching, 32), dtype=np.uint8)
+    D = np.unpackbits(desc[:, None, :] ^ cent[None, :, :], axis=2).sum(axis=2)
+    node = (100 + 3 * D.argmin(axis=1)).astype(np.int32)
+    node[rng.random(len(desc)) < 0.1] = -1
+    return node
+
+
+def _desc_pair(n1, n2, seed):
+    import matcher_inputs as MI
+    return MI.descriptor_sets(n1, n2, seed)
+
+
+# ------------------------------------------------------------------ scenario builders (+ expectation closures)
+def _bow_kf_f(f, tag, oracle, seed, n1, n2, nleft, ratio, ori):
+    rng = np.random.default_rng(seed)
+    d1, d2, a1, a2 = _desc_pair(n1, n2, seed)
+    node1 = _nodes(np.concatenate([d1, d2]), seed + 1)
+    node1, node2 = node1[:n1].copy(), node1[n1:].copy()
+    mp1 = rng.choice([0, 1, 1, 2], n1).astype(np.int32)
+    for k, v in (("d1", d1), ("a1", a1), ("node1", node1), ("mp1", mp1), ("d2", d2), ("a2", a2), ("node2", node2),
+                 ("Nleft", np.array([nleft], np.int32)), ("ratio", np.array([ratio], np.float32)),
+                 ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, v)
+
+    def check(res):
+        n, m = oracle.search_bow_kf_f(d1, (mp1 == 1).astype(np.uint8), a1, _csr_from_nodes(node1), d2, a2,
+                                      _csr_from_nodes(node2), nleft, ratio, ori)
+        assert res[tag + "n"][0] == n and n > 20, tag
+        assert np.array_equal(res[tag + "match"], m), tag
+    return check
+
+
+def _bow_kf_kf(f, tag, oracle, seed, n1, n2, ratio, ori):
+    rng = np.random.default_rng(seed)
+    d1, d2, a1, a2 = _desc_pair(n1, n2, seed)
+    nodes = _nodes(np.concatenate([d1, d2]), seed + 1)
+    node1, node2 = nodes[:n1].copy(), nodes[n1:].copy()
+    mp1 = rng.choice([0, 1, 1, 2], n1).astype(np.int32)
+    mp2 = rng.choice([0, 1, 1, 1, 2], n2).astype(np.int32)
+    for k, v in (("d1", d1), ("a1", a1), ("node1", node1), ("mp1", mp1), ("d2", d2), ("a2", a2), ("node2", node2),
+                 ("mp2", mp2), ("ratio", np.array([ratio], np.float32)), ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, v)
+
+    def check(res):
+        n, m = oracle.search_bow_kf_kf(d1, (mp1 == 1).astype(np.uint8), a1, _csr_from_nodes(node1), d2,
+                                       (mp2 == 1).astype(np.uint8), a2, _csr_from_nodes(node2), -1, -1, ratio, ori)
+        assert res[tag + "n"][0] == n and n > 20, tag
+        assert np.array_equal(res[tag + "match"], m), tag
+    return check
+
+
+def _tri(f, tag, oracle, seed, n1, n2, stereo, coarse, ori):
+    rng = np.random.default_rng(seed)
+    d1, d2, a1, a2 = _desc_pair(n1, n2, seed)
+    nodes = _nodes(np.concatenate([d1, d2]), seed + 1, 5)
+    node1, node2 = nodes[:n1].copy(), nodes[n1:].copy()
+    cam = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    R2 = np.eye(3)
+    t2 = np.array([-0.11, 0.004, 0.02])
+    kp1 = np.stack([rng.uniform(20, 730, n1), rng.uniform(20, 460, n1)], 1)
+    # keypoints of keyframe 2 = projections of points seen by keyframe 1 (world = camera-1 frame) + noise
+    src = rng.integers(0, n1, n2)
+    z = rng.uniform(2.0, 12.0, n2)
+    X = np.stack([(kp1[src, 0] - cam[2]) / cam[0] * z, (kp1[src, 1] - cam[3]) / cam[1] * z, z], 1)
+    Xc2 = X @ R2.T + t2
+    kp2 = np.stack([cam[0] * Xc2[:, 0] / Xc2[:, 2] + cam[2], cam[1] * Xc2[:, 1] / Xc2[:, 2] + cam[3]], 1)
+    kp2 += rng.normal(0, 0.6, kp2.shape)
+    far = rng.random(n2) < 0.3
+    kp2[far] = np.stack([rng.uniform(20, 730, far.sum()), rng.uniform(20, 460, far.sum())], 1)
+    kp1, kp2 = kp1.astype(np.float32), kp2.astype(np.float32)
+    d2 = _noisy(d1[src], rng, 0.0, 0.12)   # the descriptor of a point seen again, a few bits away
+    nodes = _nodes(np.concatenate([d1, d2]), seed + 1, 5)
+    node1, node2 = nodes[:n1].copy(), nodes[n1:].copy()
+    oct1, oct2 = rng.integers(0, 8, n1).astype(np.int32), rng.integers(0, 8, n2).astype(np.int32)
+    u1 = np.where(rng.random(n1) < 0.3, rng.uniform(0, 700, n1), -1).astype(np.float32)
+    u2 = np.where(rng.random(n2) < 0.3, rng.uniform(0, 700, n2), -1).astype(np.float32)
+    mp1 = (rng.random(n1) < 0.4).astype(np.int32)
+    mp2 = (rng.random(n2) < 0.4).astype(np.int32)
+    for s, (kp, a, oc, d, u, node, mp) in (("1", (kp1, a1, oct1, d1, u1, node1, mp1)), ("2", (kp2, a2, oct2, d2, u2, node2, mp2))):
+        for k, v in (("x", kp[:, 0]), ("y", kp[:, 1]), ("a", a), ("oct", oc), ("d", d), ("ur", u), ("node", node), ("mp", mp)):
+            _put(f, tag + k + s, v)
+    for k, v in (("sf", SF), ("cam1", cam), ("cam2", cam), ("R1", np.eye(3, dtype=np.float32)), ("t1", np.zeros(3, np.float32)),
+                 ("O1", np.zeros(3, np.float32)), ("R2", R2.astype(np.float32)), ("t2", t2.astype(np.float32)),
+                 ("stereo", np.array([int(stereo)], np.int32)), ("coarse", np.array([int(coarse)], np.int32)),
+                 ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, v)
+
+    def check(res):
+        K = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1]], np.float64)
+        t12 = -(R2.T @ t2.astype(np.float32).astype(np.float64))  # R1 = I, t1 = 0: R12 = R2^T, t12 = -R2^T t2
+        tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+        F = np.linalg.inv(K).T @ tx @ R2.T @ np.linalg.inv(K)
+        F12 = res[tag + "F12"].reshape(3, 3)
+        assert np.allclose(F12, F, rtol=2e-3, atol=1e-9), tag  # the adapter's float pose algebra
+        t2f = t2.astype(np.float32).astype(np.float64)
+        ep = (cam[0] * t2f[0] / t2f[2] + cam[2], cam[1] * t2f[1] / t2f[2] + cam[3])
+        assert np.allclose(res[tag + "ep"], ep, rtol=1e-5), tag
+        pairs = oracle.search_triangulation(d1, mp1, kp1, a1, oct1, u1, _csr_from_nodes(node1), d2, mp2, kp2, a2, oct2, u2,
+                                            _csr_from_nodes(node2), F12, res[tag + "ep"], SF, SF * SF, stereo, coarse, ori)
+        assert res[tag + "n"][0] == len(pairs) and (len(pairs) > 15 or stereo), (tag, len(pairs))
+        assert np.array_equal(res[tag + "pairs"].reshape(-1, 2), pairs), tag
+    return check
+
+
+GRID = dict(minX=np.float32(0), minY=np.float32(0), maxX=np.float32(768), maxY=np.float32(512))
+
+
+def _frame_arrays(rng, n, stereo):
+    kx = rng.uniform(2, 766, n).astype(np.float32)
+    ky = rng.uniform(2, 510, n).astype(np.float32)
+    k = n // 4  # clusters: several features inside one search window
+    c = rng.integers(0, 12, k)
+    cx, cy = rng.uniform(60, 700, 12), rng.uniform(60, 450, 12)
+    kx[:k] = (cx[c] + rng.normal(0, 6, k)).astype(np.float32)
+    ky[:k] = (cy[c] + rng.normal(0, 6, k)).astype(np.float32)
+    d = dict(kx=kx, ky=ky, oct=rng.integers(0, 8, n).astype(np.int32), desc=rng.integers(0, 256, (n, 32), dtype=np.uint8),
+             ang=rng.uniform(0, 360, n).astype(np.float32))
+    if stereo:
+        d["uright"] = np.where(rng.random(n) < 0.6, kx - rng.uniform(1, 40, n), -1).astype(np.float32)
+    return d
+
+
+def _put_frame(f, tag, fr, fstate):
+    for k in ("kx", "ky", "oct", "desc", "ang"):
+        _put(f, tag + k, fr[k])
+    if "uright" in fr:
+        _put(f, tag + "uright", fr["uright"])
+    _put(f, tag + "fstate", fstate)
+    _put(f, tag + "grid", np.array([0, 0, 768, 512, np.float32(64) / np.float32(768), np.float32(48) / np.float32(512)], np.float32))
+    _put(f, tag + "sf", SF)
+
+
+def _frame_problem(fr, fstate):
+    pr = dict(desc=fr["desc"], kx=fr["kx"], ky=fr["ky"], octave=fr["oct"], angle=fr["ang"], Nleft=-1,
+              minX=np.float32(0), minY=np.float32(0), gridWInv=np.float32(64) / np.float32(768),
+              gridHInv=np.float32(48) / np.float32(512), taken=((fstate == 1) | (fstate == 2)).astype(np.uint8))
+    pr["uright"] = fr["uright"] if "uright" in fr else np.full(len(fr["kx"]), -1, np.float32)
+    return pr
+
+
+def _noisy(desc, rng, lo=0.0, hi=0.25):
+    bits = np.unpackbits(desc, axis=1)
+    return np.packbits(bits ^ (rng.random(bits.shape) < rng.uniform(lo, hi, (len(desc), 1))), axis=1)
+
+
+def _expect_points(fstate, feat_match, q_match, ids):
+    exp = np.where(fstate > 0, 100000 + np.arange(len(fstate)), -1).astype(np.int32)
+    for k, fidx in enumerate(q_match):            # written by a point and holding none now: cleared by the cull
+        if fidx >= 0 and feat_match[fidx] < 0:
+            exp[fidx] = -1
+    w = feat_match >= 0
+    exp[w] = np.asarray(ids, np.int32)[feat_match[w]]
+    return exp
+
+
+def _proj_local(f, tag, oracle, seed, n, m, th, stereo, far):
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, stereo)
+    fstate = rng.choice([0, 0, 0, 0, 0, 0, 1, 3], n).astype(np.int32)   # 1 point with observations, 3 without
+    _put_frame(f, tag, fr, fstate)
+    tgt = rng.integers(0, n, m)
+    tgt[: m // 3] = rng.integers(0, max(n // 4, 1), m // 3)              # compete inside the clusters
+    tgt[m // 3: m // 2] = tgt[: m // 2 - m // 3]
+    pdesc = _noisy(fr["desc"][tgt], rng)
+    px = (fr["kx"][tgt] + rng.normal(0, 2.0, m)).astype(np.float32)
+    py = (fr["ky"][tgt] + rng.normal(0, 2.0, m)).astype(np.float32)
+    level = np.clip(fr["oct"][tgt] + rng.integers(0, 2, m), 0, 7).astype(np.int32)
+    pcos = np.where(rng.random(m) < 0.5, 0.9995, 0.97).astype(np.float32)
+    pxr = np.where(fr.get("uright", np.full(n, -1, np.float32))[tgt] > 0,
+                   fr.get("uright", np.zeros(n, np.float32))[tgt] + rng.normal(0, 3.0, m), px - 10).astype(np.float32)
+    depth = rng.uniform(1, 60, m).astype(np.float32)
+    pstate = np.where(rng.random(m) < 0.85, 1, 0).astype(np.int32)        # bit0: in view
+    pstate |= (rng.random(m) < 0.06).astype(np.int32) << 1               # bit1: bad
+    pstate |= (rng.random(m) < 0.15).astype(np.int32) << 2               # bit2: no observations
+    thfar = np.float32(45.0)
+    for k, v in (("px", px), ("py", py), ("pxr", pxr), ("pcos", pcos), ("pdepth", depth), ("plevel", level), ("pdesc", pdesc),
+                 ("pstate", pstate), ("ratio", np.array([0.8], np.float32)), ("th", np.array([th], np.float32)),
+                 ("far", np.array([int(far)], np.int32)), ("thfar", np.array([thfar], np.float32))):
+        _put(f, tag + k, v)
+
+    def check(res):
+        keep = [k for k in range(m) if (pstate[k] & 1) and not (far and depth[k] > thfar) and not (pstate[k] & 2)]
+        keep = np.array(keep)
+        r = np.where(pcos[keep] > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)
+        if th != 1.0:
+            r = (r * np.float32(th)).astype(np.float32)
+        pr = _frame_problem(fr, fstate)
+        pr.update(mode=0, nnratio=0.8, th_high=100, check_orientation=0, qdesc=pdesc[keep], qx=px[keep], qy=py[keep],
+                  qr=(r * SF[level[keep]]).astype(np.float32), qmin_level=(level[keep] - 1).astype(np.int32),
+                  qmax_level=level[keep], qxr=pxr[keep], qangle=np.zeros(len(keep), np.float32),
+                  qblocks=((pstate[keep] & 4) == 0).astype(np.uint8))
+        nm, qm, fm = oracle.search_projection(pr)
+        assert res[tag + "n"][0] == nm and nm > 30, (tag, nm)
+        assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, [-1] * 0, keep)), tag
+    return check
+
+
+def _proj_last(f, tag, oracle, seed, n, nl, th, stereo, tlz, mono, ori):
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, stereo)
+    fstate = rng.choice([0, 0, 0, 0, 0, 0, 1, 3], n).astype(np.int32)
+    _put_frame(f, tag, fr, fstate)
+    cam = np.array([512, 512, 384, 256], np.float32)
+    bf, mb = np.float32(40.0), np.float32(0.125)
+    tc = np.array([0.25, -0.5, 0.0], np.float32)
+    tl = np.array([0.25, -0.5, tlz], np.float32)  # tlc = Rlw (-Rcw^T tcw) + tlw = (0, 0, tlz)
+    tgt = rng.integers(0, n, nl)
+    tgt[: nl // 3] = rng.integers(0, max(n // 4, 1), nl // 3)
+    u = np.round((fr["kx"][tgt] + rng.normal(0, 2.0, nl)) * 8) / 8          # dyadic pixels: exact projections
+    v = np.round((fr["ky"][tgt] + rng.normal(0, 2.0, nl)) * 8) / 8
+    out = rng.random(nl) < 0.04
+    u[out] = rng.choice([-40.0, 800.0], out.sum())                         # outside the image bounds: skipped
+    z = rng.choice([2.0, 4.0, 8.0], nl)
+    z[rng.random(nl) < 0.04] = -2.0                                        # behind the camera: skipped
+    xc = np.stack([(u - 384) * z / 512, (v - 256) * z / 512, z], 1)
+    lpos = (xc - tc.astype(np.float64)).astype(np.float32)                  # Rcw = I: x_c = x_w + tcw
+    assert np.array_equal(lpos.astype(np.float64) + tc, xc)
+    lstate = rng.choice([0, 1, 1, 1, 1, 2, 3], nl).astype(np.int32)
+    loct = np.clip(fr["oct"][tgt] + rng.integers(-1, 2, nl), 0, 7).astype(np.int32)
+    lang = rng.uniform(0, 360, nl).astype(np.float32)
+    ldesc = _noisy(fr["desc"][tgt], rng)
+    for k, val in (("cam", cam), ("bf", np.array([bf, mb], np.float32)), ("Rc", np.eye(3, dtype=np.float32)), ("tc", tc),
+                   ("Rl", np.eye(3, dtype=np.float32)), ("tl", tl), ("loct", loct), ("lang", lang), ("lstate", lstate),
+                   ("lpos", lpos), ("ldesc", ldesc), ("th", np.array([th], np.float32)),
+                   ("mono", np.array([int(mono)], np.int32)), ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        fwd, bwd = (tlz > mb and not mono), (-tlz > mb and not mono)
+        keep = [i for i in range(nl) if lstate[i] in (1, 3) and z[i] > 0 and 0 <= u[i] <= 768 and 0 <= v[i] <= 512]
+        keep = np.array(keep)
+        o = loct[keep]
+        lo = o if fwd else (np.zeros_like(o) if bwd else o - 1)
+        hi = np.full_like(o, -1) if fwd else (o if bwd else o + 1)
+        pr = _frame_problem(fr, fstate)
+        pr.update(mode=1, nnratio=0.9, th_high=100, check_orientation=int(ori), qdesc=ldesc[keep],
+                  qx=u[keep].astype(np.float32), qy=v[keep].astype(np.float32), qr=(np.float32(th) * SF[o]).astype(np.float32),
+                  qmin_level=lo.astype(np.int32), qmax_level=hi.astype(np.int32),
+                  qxr=(u[keep] - 40.0 / z[keep]).astype(np.float32), qangle=lang[keep],
+                  qblocks=(lstate[keep] == 1).astype(np.uint8))
+        nm, qm, fm = oracle.search_projection(pr)
+        assert res[tag + "n"][0] == nm and nm > 30, (tag, nm)
+        assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, qm, keep)), tag
+    return check
+
+
+def _fuse(f, tag, oracle, seed, n, m, th):
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, True)
+    fr["uright"] = np.where(rng.random(n) < 0.5, fr["kx"] - rng.uniform(0, 30, n), -1).astype(np.float32)
+    fstate = rng.choice([0, 0, 1, 1, 2], n).astype(np.int32)               # none / good / bad point at the feature
+    fobs = rng.integers(1, 6, n).astype(np.int32)
+    _put_frame(f, tag, fr, fstate)
+    _put(f, tag + "fobs", fobs)
+    cam = np.array([512, 512, 384, 256], np.float32)
+    bf = np.float32(40.0)
+    tgt = rng.integers(0, n, m)
+    tgt[: m // 3] = rng.integers(0, max(n // 4, 1), m // 3)
+    tgt[m // 3: m // 2] = tgt[: m // 2 - m // 3]                            # several candidates fuse into one feature
+    u = np.round((fr["kx"][tgt] + rng.normal(0, 1.0, m)) * 8) / 8
+    v = np.round((fr["ky"][tgt] + rng.normal(0, 1.0, m)) * 8) / 8
+    out = rng.random(m) < 0.04
+    u[out] = 900.0                                                         # not IsInImage
+    z = rng.choice([2.0, 4.0, 8.0], m)
+    z[rng.random(m) < 0.04] = -4.0                                         # negative depth
+    pos = np.stack([(u - 384) * z / 512, (v - 256) * z / 512, z], 1).astype(np.float32)   # R = I, t = 0, Ow = 0
+    dist = np.linalg.norm(pos.astype(np.float64), axis=1)
+    level = np.clip(fr["oct"][tgt] + rng.integers(0, 2, m), 0, 7)
+    maxd = (dist * 1.2 ** (level - 0.5)).astype(np.float32)               # PredictScale = ceil(level - 0.5) = level
+    mind = (maxd / np.float32(1.2 ** 7)).astype(np.float32)
+    wrong = rng.random(m) < 0.05
+    maxd[wrong] = (dist[wrong] * 0.5).astype(np.float32)                   # outside the scale-invariance range
+    normal = (pos.astype(np.float64) / np.maximum(dist, 1e-9)[:, None])
+    flip = rng.random(m) < 0.05
+    normal[flip] *= -1                                                     # viewing angle > 60 degrees
+    pstate = rng.choice([0, 1, 1, 1, 1, 1, 1, 2, 3], m).astype(np.int32)
+    pobs = rng.integers(1, 6, m).astype(np.int32)
+    pdesc = _noisy(fr["desc"][tgt], rng, 0.0, 0.2)
+    for k, val in (("cam", cam), ("bf", np.array([bf], np.float32)), ("R", np.eye(3, dtype=np.float32)),
+                   ("t", np.zeros(3, np.float32)), ("O", np.zeros(3, np.float32)), ("logsf", np.array([np.log(1.2)], np.float32)),
+                   ("pstate", pstate), ("pobs", pobs), ("ppos", pos), ("pnormal", normal.astype(np.float32)),
+                   ("pdist", np.stack([mind, maxd], 1)), ("pdesc", pdesc), ("th", np.array([th], np.float32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        ok = (pstate == 1) & (z > 0) & (u >= 0) & (u < 768) & (v >= 0) & (v < 512) & ~wrong & ~flip
+        keep = np.nonzero(ok)[0]
+        lv = level[keep].astype(np.int32)
+        pr = _frame_problem(fr, np.zeros(n, np.int32))
+        pr.update(mode=1, nnratio=0.6, th_high=50, check_orientation=0, chi2_gate=1,
+                  inv_level_sigma2=(np.float32(1.0) / (SF * SF)).astype(np.float32), qdesc=pdesc[keep],
+                  qx=u[keep].astype(np.float32), qy=v[keep].astype(np.float32), qr=(np.float32(th) * SF[lv]).astype(np.float32),
+                  qmin_level=lv - 1, qmax_level=lv, qxr=(u[keep] - 40.0 / z[keep]).astype(np.float32),
+                  qangle=np.zeros(len(keep), np.float32), qblocks=np.zeros(len(keep), np.uint8), taken=np.zeros(n, np.uint8))
+        _, qm, _ = oracle.search_projection(pr)
+        # the sequential object logic of :1813-1838 on this side
+        point = np.where(fstate > 0, 100000 + np.arange(n), -1)              # id of the point each feature holds
+        obs_of = {100000 + i: int(fobs[i]) for i in range(n)}
+        obs_of.update({int(q): int(pobs[q]) for q in range(m)})
+        bad_of = {100000 + i: bool(fstate[i] == 2) for i in range(n)}
+        obs_idx, repl, kf_repl = np.full(m, -1), np.full(m, -1), np.full(n, -1)
+        nfused = 0
+        for k, q in enumerate(keep):
+            idx = qm[k]
+            if idx < 0:
+                continue
+            pid = point[idx]
+            if pid >= 0:
+                if not bad_of.get(pid, False):
+                    if obs_of[pid] > obs_of[int(q)]:
+                        repl[q] = pid
+                    elif pid >= 100000:
+                        kf_repl[pid - 100000] = q
+                    else:
+                        repl[pid] = q
+            else:
+                obs_idx[q] = idx
+                point[idx] = q
+            nfused += 1
+        assert res[tag + "n"][0] == nfused and nfused > 50, (tag, nfused)
+        assert np.array_equal(res[tag + "obsIdx"], obs_idx), tag
+        assert np.array_equal(res[tag + "replacedBy"], repl), tag
+        assert np.array_equal(res[tag + "kfPoint"], point), tag
+        assert np.array_equal(res[tag + "kfReplacedBy"], kf_repl), tag
+    return check
+
+
+def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle):
+    exe = str(tmp_path / "test_matcher_adapter")
+    libdir = os.path.join(ROOT, "orb_slam3_detailed_comments_kor_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "adapters"),
+                           os.path.join(ROOT, "adapters", "test_matcher_adapter.cpp"), "-o", exe, "-L" + libdir, "-lorbfe",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    scen, resf = str(tmp_path / "scenario.bin"), str(tmp_path / "result.bin")
+    checks = []
+    with open(scen, "wb") as f:
+        checks.append(_bow_kf_f(f, "bow0.", oracle, 11, 1100, 1200, -1, 0.7, True))
+        checks.append(_bow_kf_f(f, "bow1.", oracle, 12, 900, 1000, 600, 0.8, True))   # two-camera frame: left / right tracks
+        checks.append(_bow_kf_f(f, "bow2.", oracle, 13, 300, 500, -1, 0.9, False))
+        checks.append(_bow_kf_kf(f, "kk0.", oracle, 21, 1000, 1100, 0.8, True))
+        checks.append(_bow_kf_kf(f, "kk1.", oracle, 22, 400, 350, 0.75, False))
+        checks.append(_tri(f, "tri0.", oracle, 31, 1000, 1100, False, False, True))
+        checks.append(_tri(f, "tri1.", oracle, 32, 800, 700, True, False, True))
+        checks.append(_tri(f, "tri2.", oracle, 33, 600, 600, False, True, False))
+        checks.append(_proj_local(f, "p0_0.", oracle, 41, 1500, 1200, 1.0, True, False))
+        checks.append(_proj_local(f, "p0_1.", oracle, 42, 1200, 900, 3.0, False, True))
+        checks.append(_proj_last(f, "p1_0.", oracle, 51, 1500, 1000, 7.0, True, 0.0, False, True))     # neither direction
+        checks.append(_proj_last(f, "p1_1.", oracle, 52, 1200, 900, 15.0, False, 1.0, False, True))    # forward
+        checks.append(_proj_last(f, "p1_2.", oracle, 53, 1200, 900, 7.0, True, -1.0, False, False))    # backward
+        checks.append(_proj_last(f, "p1_3.", oracle, 54, 1000, 800, 15.0, False, 1.0, True, True))     # monocular
+        checks.append(_fuse(f, "fu0.", oracle, 61, 1500, 1200, 3.0))
+        checks.append(_fuse(f, "fu1.", oracle, 62, 900, 700, 4.0))
+    subprocess.check_call([exe, scen, resf])
+    res = _read(resf)
+    for c in checks:
+        c(res)
