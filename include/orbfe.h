@@ -78,6 +78,12 @@ int orbfe_set_gaussian_taps(orbfe_ctx*, const int* taps7);
 #define ORBFE_TRIG_LIBM_HOSTCHECK 2
 int orbfe_set_trig_mode(orbfe_ctx*, int mode);
 
+/* cv::fastAtan2's polynomial (src/ORBextractor.cc:101): seven separately rounded operations (default, the generic
+ * C++ path) or, with on = 1, its three inner Horner steps as fused multiply-adds -- what an OpenCV whose AVX2
+ * translation unit was built with -mfma evaluates.  ORBFE_ATAN_FMA=1 in the environment sets the
+ * default of new contexts. */
+int orbfe_set_atan_fma(orbfe_ctx*, int on);
+
 /* Fisheye rigs (KannalaBrandt8, src/CameraModels/KannalaBrandt8.cpp:96-123): when params8 = {fx,fy,cx,cy,k0..k3}
  * is set, the extractor also unprojects every keypoint to its bearing ray in the output-packing kernel
  * (no extra pass).  Rays are indexed like the keypoints: 3 floats each.  NULL disables.
@@ -102,6 +108,14 @@ int orbfe_extract(orbfe_ctx*, const uint8_t* img, int rows, int cols, size_t str
 int orbfe_extract_batch(orbfe_ctx*, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride,
                         const int* lap /* 2*nimg or NULL (= {0,0}) */, orbfe_kp* kps, uint8_t* desc, int cap_per_img,
                         int* n_out, int* mono_out);
+
+/* Images of DIFFERENT sizes in one call (a rig with unequal cameras): rows[i] / cols[i] / strides[i] per image.  The
+ * images are grouped by size and each group runs as one batch; the context keeps the tables of the sizes it has seen
+ * (up to eight), so alternating sizes rebuild nothing.  cap_per_img >= orbfe_max_keypoints of every size.  Returns 0,
+ * or the error of the first group that failed (its images get n_out = 0; an empty image makes its group return -1). */
+int orbfe_extract_batch_sizes(orbfe_ctx*, int nimg, const uint8_t* const* imgs, const int* rows, const int* cols,
+                              const size_t* strides, const int* lap /* 2*nimg or NULL */, orbfe_kp* kps, uint8_t* desc,
+                              int cap_per_img, int* n_out, int* mono_out);
 
 /* The same call split in two, for callers that keep the PCIe link and the GPU busy at once: submit queues the
  * transfer of the images, the kernels and the transfer of the results and returns; wait completes the OLDEST
@@ -163,6 +177,9 @@ int orbfe_profile_read(orbfe_ctx*, float* ms_per_stage /* ORBFE_STAGE_COUNT */);
  * with x,y relative to (minBorderX, minBorderY) = (16,16) of the level. */
 int orbfe_debug_candidates(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
 int orbfe_debug_level_keypoints(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
+/* The 37 x 37 bytes of GaussianBlur's output (src/ORBextractor.cc:1114-1115) around keypoint `kp_index` (output
+ * order) of image `img` of the last call: the fused kernel's blurred patch, for a direct comparison. */
+int orbfe_debug_blurred_patch(orbfe_ctx*, int img, int kp_index, uint8_t* out37x37);
 int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm trig in the last call */
 /* (cos, sin) the descriptor kernel uses for the given keypoint angles (degrees) in the context's trig mode;
  * returns 2 when the table of libm values was used, 1 for the compact code table, 0 for none (ORBFE_TRIG_CR, or
@@ -398,6 +415,10 @@ typedef struct {
 } orbfe_vocab;
 typedef struct orbfe_vocab_dev orbfe_vocab_dev; /* the tree resident on one device */
 int orbfe_vocab_upload(orbfe_vocab_dev** out, int device, const orbfe_vocab* v);
+/* TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1423): ORBvoc.txt-style text file ("k L scoring
+ * weighting", then "parent isLeaf d0..d31 weight" per node) straight onto the device; children in file order, word
+ * ids to the leaves in file order, as the reference builds them.  k / L / number of words are returned when asked. */
+int orbfe_vocab_load_text(orbfe_vocab_dev** out, int device, const char* path, int* k_out, int* L_out, int* nwords_out);
 void orbfe_vocab_free(orbfe_vocab_dev*);
 /* TemplatedVocabulary::transform(feature, word_id, weight, &nid, levelsup) (:1217-1259) for n features in one
  * launch (Frame::ComputeBoW, src/Frame.cc:724-731, uses levelsup = 4).  The caller folds the per-feature

@@ -326,7 +326,8 @@ void gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint
 
 // ---------------------------------------------------------------- fastAtan2
 // cv::fastAtan2 (degrees); single precision, no FMA.
-float fast_atan2(float y, float x)
+// fma_horner: the three inner Horner steps fused (an OpenCV AVX2 build with -mfma)
+float fast_atan2(float y, float x, bool fma_horner = false)
 {
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale;
@@ -339,11 +340,13 @@ float fast_atan2(float y, float x)
     if (ax >= ay) {
         c = ay / (ax + eps);
         c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = fma_horner ? std::fmaf(std::fmaf(std::fmaf(p7, c2, p5), c2, p3), c2, p1) * c
+                       : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     } else {
         c = ax / (ay + eps);
         c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - (fma_horner ? std::fmaf(std::fmaf(std::fmaf(p7, c2, p5), c2, p3), c2, p1) * c
+                                : (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c);
     }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
@@ -531,6 +534,7 @@ struct orb_oracle {
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     int taps[7] = {18, 34, 48, 56, 48, 34, 18};
     int trig_mode = ORB_ORACLE_TRIG_LIBM;
+    bool atan_fma = false;
     std::vector<Level> pyr;
     std::vector<std::vector<KP>> cands, allKeypoints;
 
@@ -616,7 +620,7 @@ struct orb_oracle {
             }
             m_01 += v * v_sum;
         }
-        return fast_atan2((float)m_01, (float)m_10);
+        return fast_atan2((float)m_01, (float)m_10, atan_fma);
     }
 
     // reference :763-878.  Returns false when a level is too small for the 35-px cell grid.
@@ -853,6 +857,7 @@ void orb_oracle_set_gauss_taps(orb_oracle* o, const int* t)
     for (int i = 0; i < 7; i++) o->taps[i] = t[i];
 }
 void orb_oracle_set_trig_mode(orb_oracle* o, int mode) { o->trig_mode = mode; }
+void orb_oracle_set_atan_fma(orb_oracle* o, int on) { o->atan_fma = on != 0; }
 
 int orb_oracle_extract(orb_oracle* o, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
                        orb_oracle_kp* kps, uint8_t* desc, int cap, int* n_out)
@@ -938,6 +943,7 @@ void orb_oracle_gaussian_blur7(const uint8_t* src, int rows, int cols, size_t ss
     gaussian_blur7(src, rows, cols, sstride, dst, dstride, taps7 ? taps7 : def);
 }
 float orb_oracle_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+float orb_oracle_fast_atan2_fma(float y, float x) { return fast_atan2(y, x, true); }
 void orb_oracle_sincos_cr(float a, float* s, float* c) { orb_sincos_cr_impl(a, s, c); }
 
 int orb_oracle_distribute_octree(const orb_oracle_kp* cands, int n, int minX, int maxX, int minY, int maxY, int N,

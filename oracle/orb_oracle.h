@@ -38,6 +38,7 @@ orb_oracle* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int
 void orb_oracle_destroy(orb_oracle*);
 void orb_oracle_set_gauss_taps(orb_oracle*, const int* taps7);
 void orb_oracle_set_trig_mode(orb_oracle*, int mode);
+void orb_oracle_set_atan_fma(orb_oracle*, int on); /* fused Horner steps in fastAtan2 */
 
 /* ORBextractor::operator() -- returns monoIndex (>=0), -1 for an empty image, -2 bad args/too small. */
 int orb_oracle_extract(orb_oracle*, const uint8_t* img, int rows, int cols, size_t stride,
@@ -70,6 +71,7 @@ int orb_oracle_fast_score_2loop(const uint8_t* center, size_t stride, int thresh
 void orb_oracle_gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride,
                                const int* taps7);
 float orb_oracle_fast_atan2(float y, float x);
+float orb_oracle_fast_atan2_fma(float y, float x);
 void orb_oracle_sincos_cr(float angle_rad, float* s, float* c);
 int orb_oracle_distribute_octree(const orb_oracle_kp* cands, int n, int minX, int maxX, int minY, int maxY, int N,
                                  orb_oracle_kp* out, int cap);

@@ -38,6 +38,9 @@ def lib():
         L.orb_oracle_destroy.argtypes = [C.c_void_p]
         L.orb_oracle_set_gauss_taps.argtypes = [C.c_void_p, C.c_void_p]
         L.orb_oracle_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orb_oracle_set_atan_fma.argtypes = [C.c_void_p, C.c_int]
+        L.orb_oracle_fast_atan2_fma.restype = C.c_float
+        L.orb_oracle_fast_atan2_fma.argtypes = [C.c_float, C.c_float]
         L.orb_oracle_extract.restype = C.c_int
         L.orb_oracle_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -131,6 +134,9 @@ class Extractor:
         if taps is not None:
             t = np.ascontiguousarray(taps, np.int32)
             self.L.orb_oracle_set_gauss_taps(self.h, _p(t))
+
+    def set_atan_fma(self, on=True):
+        self.L.orb_oracle_set_atan_fma(self.h, int(on))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -274,6 +280,10 @@ def gaussian_blur7(img, taps=None):
     lib().orb_oracle_gaussian_blur7(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(dst), dst.strides[0],
                                     None if t is None else _p(t))
     return dst
+
+
+def fast_atan2_fma(y, x):
+    return float(lib().orb_oracle_fast_atan2_fma(float(y), float(x)))
 
 
 def fast_atan2(y, x):

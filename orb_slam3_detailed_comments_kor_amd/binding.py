@@ -173,6 +173,12 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.orbfe_extract_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_size_t,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_extract_batch_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_set_atan_fma.argtypes = [C.c_void_p, C.c_int]
+        L.orbfe_debug_blurred_patch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orbfe_vocab_load_text.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int)]
         L.orbfe_extract_batch_submit.argtypes = L.orbfe_extract_batch.argtypes
         L.orbfe_extract_batch_wait.argtypes = [C.c_void_p]
         L.orbfe_host_alloc.restype = C.c_void_p
@@ -241,7 +247,8 @@ EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream",
            "orbfe_extract_batch_submit", "orbfe_extract_batch_wait", "orbfe_host_alloc", "orbfe_host_free",
            "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident",
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
-           "orbfe_get_device_outputs"]
+           "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
+           "orbfe_vocab_load_text"]
 
 
 def _p(a):
@@ -409,6 +416,33 @@ class ORBextractor:
 
     def wait_batch(self):
         _chk(self.L.orbfe_extract_batch_wait(self.h), "orbfe_extract_batch_wait")
+
+    def extract_batch_sizes(self, images, lapping_areas=None):
+        """orbfe_extract_batch_sizes: images of different sizes in one call.  Returns list of (mono, kps, desc)."""
+        images = [np.ascontiguousarray(im, np.uint8) for im in images]
+        nimg = len(images)
+        cap = max(self.max_keypoints(*im.shape) for im in images)
+        rows = np.array([im.shape[0] for im in images], np.int32)
+        cols = np.array([im.shape[1] for im in images], np.int32)
+        strides = np.array([im.strides[0] for im in images], np.uint64)
+        kps = np.zeros((nimg, cap), KP_DTYPE)
+        desc = np.zeros((nimg, cap, 32), np.uint8)
+        n = np.zeros(nimg, np.int32)
+        mono = np.zeros(nimg, np.int32)
+        ptrs = (C.c_void_p * nimg)(*[im.ctypes.data for im in images])
+        lap = None if lapping_areas is None else np.ascontiguousarray(lapping_areas, np.int32).reshape(nimg, 2)
+        _chk(self.L.orbfe_extract_batch_sizes(self.h, nimg, ptrs, _p(rows), _p(cols), _p(strides),
+                                              None if lap is None else _p(lap), _p(kps), _p(desc), cap, _p(n), _p(mono)),
+             "orbfe_extract_batch_sizes")
+        return [(int(mono[i]), kps[i, : n[i]].copy(), desc[i, : n[i]].copy()) for i in range(nimg)]
+
+    def set_atan_fma(self, on=True):
+        _chk(self.L.orbfe_set_atan_fma(self.h, int(on)), "orbfe_set_atan_fma")
+
+    def debug_blurred_patch(self, kp_index, img_index=0):
+        out = np.zeros((37, 37), np.uint8)
+        _chk(self.L.orbfe_debug_blurred_patch(self.h, img_index, kp_index, _p(out)), "orbfe_debug_blurred_patch")
+        return out
 
     def extract_batch_device(self, d_imgs_ptr, nimg, rows, cols, pitch, img_stride, lap, d_kps_ptr, d_desc_ptr, cap,
                              d_n_ptr, d_mono_ptr):
@@ -803,6 +837,19 @@ class Vocabulary:
         h = C.c_void_p()
         _chk(self.L.orbfe_vocab_upload(C.byref(h), device, C.byref(v)), "orbfe_vocab_upload")
         self.h = h
+
+    @classmethod
+    def from_text_file(cls, path, device=0):
+        """TemplatedVocabulary::loadFromTextFile (ORBvoc.txt format) straight onto the device."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self._keep = {}
+        h = C.c_void_p()
+        k, L_, nw = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.L.orbfe_vocab_load_text(C.byref(h), device, os.fsencode(path), C.byref(k), C.byref(L_), C.byref(nw)),
+             "orbfe_vocab_load_text")
+        self.h, self.k, self.levels, self.nwords = h, k.value, L_.value, nw.value
+        return self
 
     def transform(self, feats, levelsup=4):
         """Per feature: (word id, node id `levelsup` levels above the leaves, weight)."""

@@ -103,22 +103,10 @@ struct PinBuf {
 
 } // namespace
 
-struct orbfe_ctx {
-    // parameters (reference include/ORBextractor.h:89-105)
-    int nfeatures;
-    double scaleFactor; // a double initialised from a float, :96
-    int nlevels, iniThFAST, minThFAST;
-    int device;
-    std::vector<int> mnFeaturesPerLevel;
-    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
-    int taps[7] = {18, 34, 48, 56, 48, 34, 18};
-    int trigMode = ORBFE_TRIG_LIBM;
-    bool lastHostTrigCheck = false;
-
-    hipStream_t stream = nullptr;
-    bool ownStream = false;
-
-    // geometry of the current image size
+// Everything that depends on the image SIZE (derived tables on the host and their device copies).  A context keeps
+// the state of the sizes it has seen (up to eight) so that a rig with unequal cameras -- or one extractor fed
+// different sizes in turn -- does not rebuild and re-upload the tables at every switch.
+struct orbfe_geom_state {
     int rows = 0, cols = 0;
     std::vector<OrbLevelGeom> lg;
     std::vector<OrbCellGeom> cg;
@@ -128,6 +116,38 @@ struct orbfe_ctx {
     int qtKeyOff = 0, qtKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
     size_t fastLdsBytes = 0;
+    DevBuf<OrbLevelGeom> d_lg;
+    DevBuf<OrbCellGeom> d_cg;
+    DevBuf<OrbResizeX> d_xtab;
+    DevBuf<OrbResizeY> d_ytab;
+    DevBuf<OrbPyrRange> d_prx, d_pry;
+    int pyrNtx = 0, pyrNty = 0, pyrBuf0 = 0, pyrBuf1 = 0, pyrStageX = 0, pyrStageY = 0;
+    size_t pyrLdsBytes = 0;
+    bool pyrWeightsOk = true; // all resize weights in [0, 2050] with a0+a1, b0+b1 <= 2050 (k_pyr_fused drops the clamp)
+    bool pyrFused = true;
+    void release_tables()
+    {
+        d_lg.release(); d_cg.release(); d_xtab.release(); d_ytab.release(); d_prx.release(); d_pry.release();
+    }
+};
+
+struct orbfe_ctx : orbfe_geom_state {
+    std::vector<orbfe_geom_state> geomCache; // the other sizes this context has been used with
+    // parameters (reference include/ORBextractor.h:89-105)
+    int nfeatures;
+    double scaleFactor; // a double initialised from a float, :96
+    int nlevels, iniThFAST, minThFAST;
+    int device;
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    int trigMode = ORBFE_TRIG_LIBM;
+    int atanFma = 0; // orbfe_set_atan_fma / ORBFE_ATAN_FMA: fused Horner steps in fastAtan2
+    bool lastHostTrigCheck = false;
+
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
     int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning; 0 = whole images per XCD always)
     bool fastByImage = true;     // ORBFE_FAST_BY_IMAGE=0 keeps the grouped order for every batch size
@@ -149,15 +169,6 @@ struct orbfe_ctx {
     float kb8[8] = {0};
     float* userRays = nullptr; // device pointer supplied by orbfe_set_ray_output
     DevBuf<OrbDescWork> d_work;
-    DevBuf<OrbLevelGeom> d_lg;
-    DevBuf<OrbCellGeom> d_cg;
-    DevBuf<OrbResizeX> d_xtab;
-    DevBuf<OrbResizeY> d_ytab;
-    DevBuf<OrbPyrRange> d_prx, d_pry;
-    int pyrNtx = 0, pyrNty = 0, pyrBuf0 = 0, pyrBuf1 = 0, pyrStageX = 0, pyrStageY = 0;
-    size_t pyrLdsBytes = 0;
-    bool pyrWeightsOk = true; // all resize weights in [0, 2050] with a0+a1, b0+b1 <= 2050 (k_pyr_fused drops the clamp)
-    bool pyrFused = true;
     DevBuf<int> d_taps;
     bool tapsDirty = true;
     int lapDev0 = 0, lapDev1 = 0, lapDevCount = 0; // what d_lap currently holds (orbfe_extract_batch_device)
@@ -466,6 +477,27 @@ void build_pyr_ranges(int nlevels, const std::vector<int>& extent, const std::ve
 int ensure_geometry(orbfe_ctx* c, int rows, int cols)
 {
     if (rows == c->rows && cols == c->cols && !c->lg.empty()) return 0;
+    orbfe_geom_state& cur = *c;
+    // a size this context has seen before: swap its tables back in (no rebuild, no upload)
+    for (size_t i = 0; i < c->geomCache.size(); i++)
+        if (c->geomCache[i].rows == rows && c->geomCache[i].cols == cols) {
+            std::swap(cur, c->geomCache[i]);
+            if (c->geomCache[i].lg.empty()) c->geomCache.erase(c->geomCache.begin() + (long)i);
+            if (c->qtLdsBytes > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)c->qtLdsBytes));
+            c->capImgs = 0; // the per-image strides changed: re-check every buffer's size
+            return 0;
+        }
+    if (!c->lg.empty()) { // keep the current size's tables for later
+        if (c->geomCache.size() >= 8) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->geomCache.front().release_tables();
+            c->geomCache.erase(c->geomCache.begin());
+        }
+        c->geomCache.push_back(cur);
+        cur = orbfe_geom_state(); // (the copy above owns the device tables now)
+    }
     std::vector<OrbResizeX> xtab;
     std::vector<OrbResizeY> ytab;
     c->rows = c->cols = 0;
@@ -561,7 +593,7 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     const size_t B = (size_t)std::max(nimg, c->capImgs);
     const size_t K = (size_t)std::max(capKp, c->capKp);
     int r;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // (a buffer that has to grow is freed first, and hipFree waits for the device by itself)
     if ((r = c->d_pyr.ensure(B * c->pyrStride + 256)) < 0) return r;
     if ((r = c->d_cand.ensure(B * c->candStride)) < 0) return r;
     if ((r = c->d_cellCount.ensure(B * c->nCells)) < 0) return r;
@@ -844,12 +876,12 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         hipLaunchKernelGGL((k_orient_blur_desc<0, true>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full);
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0);
             else
         hipLaunchKernelGGL((k_orient_blur_desc<0, false>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full);
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0);
         }
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
@@ -906,7 +938,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr);
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr, c->atanFma, nullptr, 0);
         c->lastFixups = nFix;
     }
     rec(c, 6);
@@ -1278,6 +1310,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     c->minThFAST = minThFAST;
     c->device = device;
     init_tables(c);
+    if (const char* e = getenv("ORBFE_ATAN_FMA")) c->atanFma = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;
@@ -1309,7 +1342,9 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release();
     c->d_fix.release(); c->d_kb8.release(); c->d_rays.release();
-    c->d_work.release(); c->d_lg.release(); c->d_cg.release(); c->d_xtab.release(); c->d_ytab.release(); c->d_prx.release(); c->d_pry.release();
+    c->d_work.release();
+    c->release_tables();
+    for (auto& g : c->geomCache) g.release_tables();
     c->d_taps.release(); c->d_patternF.release();
     c->h_fix.release(); c->h_fixAB.release(); c->d_stereo.release(); c->h_stereo.release();
     for (auto& sl : c->slot) {
@@ -1380,6 +1415,13 @@ int orbfe_set_trig_mode(orbfe_ctx* c, int mode)
 {
     if (!c || (mode != ORBFE_TRIG_LIBM && mode != ORBFE_TRIG_CR && mode != ORBFE_TRIG_LIBM_HOSTCHECK)) return ORBFE_ERR_ARGS;
     c->trigMode = mode;
+    return 0;
+}
+
+int orbfe_set_atan_fma(orbfe_ctx* c, int on)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    c->atanFma = on != 0;
     return 0;
 }
 
@@ -1510,6 +1552,57 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     const int r = host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false);
     if (r < 0) return r;
     return host_wait(c);
+}
+
+// Images of different sizes in one call (a rig with unequal cameras): the images are grouped by size and every group
+// runs as one batch on this context, whose per-size tables are kept (orbfe_geom_state), so nothing is rebuilt when
+// the sizes alternate.  Outputs land in the caller's per-image slabs in the caller's order.
+int orbfe_extract_batch_sizes(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, const int* rows, const int* cols,
+                              const size_t* strides, const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img,
+                              int* n_out, int* mono_out)
+{
+    if (!c || nimg < 1 || !imgs || !rows || !cols || !strides || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
+    if (c->slotSubmitted != c->slotRetired) return ORBFE_ERR_STATE;
+    std::vector<int> order(nimg);
+    for (int i = 0; i < nimg; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (rows[a] != rows[b]) return rows[a] < rows[b];
+        if (cols[a] != cols[b]) return cols[a] < cols[b];
+        return strides[a] < strides[b];
+    });
+    int worst = 0;
+    for (int g0 = 0; g0 < nimg;) {
+        int g1 = g0 + 1;
+        while (g1 < nimg && rows[order[g1]] == rows[order[g0]] && cols[order[g1]] == cols[order[g0]] &&
+               strides[order[g1]] == strides[order[g0]])
+            g1++;
+        const int ng = g1 - g0;
+        std::vector<const uint8_t*> gi(ng);
+        std::vector<int> glap(2 * (size_t)ng, 0), gn(ng, 0), gm(ng, 0);
+        for (int k = 0; k < ng; k++) {
+            gi[k] = imgs[order[g0 + k]];
+            if (lap) {
+                glap[2 * k] = lap[2 * order[g0 + k]];
+                glap[2 * k + 1] = lap[2 * order[g0 + k] + 1];
+            }
+        }
+        std::vector<orbfe_kp> gk((size_t)ng * cap_per_img);
+        std::vector<uint8_t> gd((size_t)ng * cap_per_img * 32);
+        const int r = orbfe_extract_batch(c, ng, gi.data(), rows[order[g0]], cols[order[g0]], strides[order[g0]], glap.data(),
+                                          gk.data(), gd.data(), cap_per_img, gn.data(), gm.data());
+        for (int k = 0; k < ng; k++) {
+            const int i = order[g0 + k];
+            n_out[i] = r < 0 ? 0 : gn[k];
+            if (mono_out) mono_out[i] = r < 0 ? 0 : gm[k];
+            if (r >= 0 && gn[k] > 0) {
+                std::memcpy(kps + (size_t)i * cap_per_img, gk.data() + (size_t)k * cap_per_img, (size_t)gn[k] * sizeof(orbfe_kp));
+                std::memcpy(desc + (size_t)i * cap_per_img * 32, gd.data() + (size_t)k * cap_per_img * 32, (size_t)gn[k] * 32);
+            }
+        }
+        if (r < 0 && worst == 0) worst = r; // the first failing group's code; the other groups still ran
+        g0 = g1;
+    }
+    return worst;
 }
 
 int orbfe_extract(orbfe_ctx* c, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
@@ -1784,6 +1877,38 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
 }
 
 int orbfe_debug_fixups(orbfe_ctx* c) { return c ? c->lastFixups : ORBFE_ERR_ARGS; }
+
+// GaussianBlur's output under one keypoint of the last call: re-runs the descriptor kernel for that image (same
+// results) with the tap armed, so that the fused blur is compared with the oracle's blurred level directly.
+int orbfe_debug_blurred_patch(orbfe_ctx* c, int img, int kp_index, uint8_t* out37x37)
+{
+    if (!c || c->lg.empty() || !out37x37 || img < 0 || img >= c->lastImgs || kp_index < 0 || kp_index >= c->lastCap ||
+        !c->lastKps)
+        return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<uint8_t> d;
+    int r = d.ensure(37 * 37);
+    if (r < 0) return r;
+    HIP_TRY(hipMemsetAsync(d.p, 0, 37 * 37, c->stream));
+    const TrigTabs trigTab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, c->stream) : TrigTabs{nullptr, nullptr};
+    int tapSum = 0;
+    for (int i = 0; i < 7; i++) tapSum += c->taps[i];
+    float* kps = const_cast<float*>(c->lastKps);
+    uint8_t* desc = const_cast<uint8_t*>(c->lastDesc);
+    const dim3 grid((unsigned)((c->maxKp + 3) / 4), 1u);
+    if (tapSum > 256)
+        hipLaunchKernelGGL((k_orient_blur_desc<0, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
+                           c->d_work.p, c->lastN, c->lastCap, kps, desc, c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0,
+                           trigTab.codes, trigTab.full, c->atanFma, d.p, kp_index);
+    else
+        hipLaunchKernelGGL((k_orient_blur_desc<0, false>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
+                           c->d_work.p, c->lastN, c->lastCap, kps, desc, c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0,
+                           trigTab.codes, trigTab.full, c->atanFma, d.p, kp_index);
+    hipError_t e = hipMemcpyAsync(out37x37, d.p, 37 * 37, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}
 
 int orbfe_debug_trig(orbfe_ctx* c, const float* angles_deg, int n, float* a_out, float* b_out)
 {

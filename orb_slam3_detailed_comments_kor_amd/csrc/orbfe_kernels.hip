@@ -1310,7 +1310,9 @@ __device__ __forceinline__ int reflect101(int i, int n)
 }
 
 // cv::fastAtan2: seven separately rounded single-precision operations.
-__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+// fmaHorner: the three inner Horner steps as fused multiply-adds -- what an OpenCV build evaluates whose AVX2
+// translation unit of fastAtan2 was compiled with -mfma and contraction; default off.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x, bool fmaHorner = false)
 {
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale;
@@ -1325,7 +1327,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     const float num = steep ? ax : ay, den = steep ? ay : ax;
     const float c = __fdiv_rn(num, __fadd_rn(den, eps));
     const float c2 = __fmul_rn(c, c);
-    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    float a;
+    if (fmaHorner) a = __fmul_rn(__fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1), c);
+    else a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
     if (steep) a = __fsub_rn(90.f, a);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
@@ -1499,7 +1503,10 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                                            is the count; MODE 1: in {img<<16|g, -, a, b} */,
                                                           int nFix, int listFragile, int imgBase, int xcdAffine,
                                                           const uint8_t* __restrict__ trigTab /* libm codes or nullptr */,
-                                                          const float2* __restrict__ trigFull /* libm values or nullptr */)
+                                                          const float2* __restrict__ trigFull /* libm values or nullptr */,
+                                                          int atanFma /* fused Horner steps in fastAtan2 (D2) */,
+                                                          uint8_t* __restrict__ dbgPatch /* test tap: 37x37 blurred patch */,
+                                                          int dbgDest /* ... of the keypoint with this output slot */)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1629,7 +1636,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     m10 = wave_sum_i32(m10);
     m01 = wave_sum_i32(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    const float angle = fast_atan2_deg((float)m01, (float)m10, atanFma != 0);
     // libm codes of this angle (issued now, used after the blur)
     TrigFetch trigF;
     if (MODE == 0) trigF = trig_fetch(trigTab, trigFull, angle);
@@ -1744,6 +1751,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     WAVE_SYNC();
 
+    if (dbgPatch && w.dest == dbgDest) // test tap (orbfe_debug_blurred_patch): GaussianBlur's output under this keypoint
+        for (int i = lane; i < DESC_BW * DESC_BW; i += 64) dbgPatch[i] = bl[(i / DESC_BW) * DESC_BP + i % DESC_BW];
     // ---- steered BRIEF (:106-145)
     float a, b;
     if (MODE == 0) {

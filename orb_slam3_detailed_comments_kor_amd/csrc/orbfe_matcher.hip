@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -2295,6 +2296,70 @@ int orbfe_vocab_upload(orbfe_vocab_dev** out, int device, const orbfe_vocab* v)
     }
     *out = d;
     return 0;
+}
+
+// TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423): first line
+// "k L scoring weighting", then one line per node in id order (ids from 1; node 0 is the root): "parent isLeaf
+// d0 ... d31 weight".  Children keep their file order, word ids are handed out to the leaves in file order -- as the
+// reference builds m_nodes / m_words.  The tree goes straight to the device.
+int orbfe_vocab_load_text(orbfe_vocab_dev** out, int device, const char* path, int* k_out, int* L_out, int* nwords_out)
+{
+    if (!out || !path) return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    FILE* f = fopen(path, "r");
+    if (!f) return ORBFE_ERR_ARGS;
+    int k = 0, L = 0, n1 = 0, n2 = 0;
+    if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 ||
+        n2 > 3) { // the reference's own sanity test (:1357-1361)
+        fclose(f);
+        return ORBFE_ERR_ARGS;
+    }
+    std::vector<uint8_t> desc(32, 0);
+    std::vector<int32_t> parent(1, -1), word(1, -1);
+    std::vector<double> weight(1, 0.0);
+    int nwords = 0;
+    for (;;) {
+        int pid = 0, leaf = 0;
+        if (fscanf(f, "%d %d", &pid, &leaf) != 2) break; // end of file (or a trailing blank line)
+        const int nid = (int)parent.size();
+        uint8_t d[32];
+        bool ok = pid >= 0 && pid < nid;
+        for (int i = 0; i < 32 && ok; i++) {
+            int v = 0;
+            ok = fscanf(f, "%d", &v) == 1 && v >= 0 && v <= 255;
+            d[i] = (uint8_t)v;
+        }
+        double w = 0;
+        ok = ok && fscanf(f, "%lf", &w) == 1;
+        if (!ok) {
+            fclose(f);
+            return ORBFE_ERR_ARGS;
+        }
+        parent.push_back(pid);
+        desc.insert(desc.end(), d, d + 32);
+        weight.push_back(w);
+        word.push_back(leaf > 0 ? nwords++ : -1);
+    }
+    fclose(f);
+    const int nn = (int)parent.size();
+    if (nn < 2) return ORBFE_ERR_ARGS;
+    // children lists in file order -> CSR
+    std::vector<int32_t> childOff(nn + 1, 0), childIds(nn - 1), fill(nn, 0);
+    for (int i = 1; i < nn; i++) childOff[parent[i] + 1]++;
+    for (int i = 0; i < nn; i++) childOff[i + 1] += childOff[i];
+    for (int i = 1; i < nn; i++) childIds[childOff[parent[i]] + fill[parent[i]]++] = i;
+    orbfe_vocab v;
+    v.nnodes = nn;
+    v.node_desc = desc.data();
+    v.child_off = childOff.data();
+    v.child_ids = childIds.data();
+    v.node_word = word.data();
+    v.node_weight = weight.data();
+    v.L = L;
+    if (k_out) *k_out = k;
+    if (L_out) *L_out = L;
+    if (nwords_out) *nwords_out = nwords;
+    return orbfe_vocab_upload(out, device, &v);
 }
 
 void orbfe_vocab_free(orbfe_vocab_dev* d)

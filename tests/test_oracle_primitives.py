@@ -304,3 +304,16 @@ def test_ic_angle_of_ramps(oracle):
         a = oracle.fast_atan2(float(m01), float(m10))
         d = abs(a - expect)
         assert min(d, 360 - d) < 0.5
+
+
+def test_fast_atan2_fma_variant(oracle):
+    """the fused-Horner evaluation (an AVX2 OpenCV build) stays within an ulp or two of the generic one
+    and differs from it somewhere -- it is a distinct, selectable arithmetic."""
+    rng = np.random.default_rng(4)
+    ys, xs = rng.integers(-70000, 70000, 4000), rng.integers(-70000, 70000, 4000)
+    a = np.array([oracle.fast_atan2(float(y), float(x)) for y, x in zip(ys, xs)], np.float32)
+    b = np.array([oracle.fast_atan2_fma(float(y), float(x)) for y, x in zip(ys, xs)], np.float32)
+    assert np.max(np.abs(a - b)) < 1e-4 and (a != b).any()
+    ref = (np.degrees(np.arctan2(ys.astype(np.float64), xs.astype(np.float64))) + 360.0) % 360.0
+    d = np.abs(b.astype(np.float64) - ref)
+    assert np.max(np.minimum(d, 360 - d)) < 0.3
