@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "orbfe_geom.h"
 #include "orbfe_sincos.h"
 #include "orbfe_kb8.h"
@@ -854,6 +856,29 @@ __device__ __forceinline__ void qt_child(int ul, int br, int q, int& cul, int& c
     cbr = x1 | (y1 << 16);
 }
 
+// Keys per thread that stay in REGISTERS for a whole level (key, list index of its node, child slot of the current
+// pass): the usual level (one chunk of cells, <= QT_KPT * QT_THREADS candidates) then walks registers, and a pass
+// reads only the node tables from LDS -- kOf / UL / BR for the histogram, cpos / sidx for the relabelling -- instead
+// of chasing keyNode -> kOf -> key -> UL / BR twice per key and pass through LDS.
+#define QT_KPT 4
+template <int J, class F>
+__device__ __forceinline__ void qt_reg_step(int n, F& f)
+{
+    if (J * QT_THREADS < n) f(std::integral_constant<int, J>(), (int)threadIdx.x + J * QT_THREADS); // uniform guard
+}
+template <class F>
+__device__ __forceinline__ void qt_each_key(bool regp, int n, F f)
+{
+    if (regp) {
+        qt_reg_step<0>(n, f);
+        qt_reg_step<1>(n, f);
+        qt_reg_step<2>(n, f);
+        qt_reg_step<3>(n, f);
+    } else {
+        for (int base = 0; base < n; base += QT_THREADS) f(std::integral_constant<int, 0>(), base + (int)threadIdx.x);
+    }
+}
+
 // One workgroup per (image, level).  Level-synchronous restatement of DistributeOctTree
 // (tests/qt_model.py is the executable specification, checked against the literal list
 // transcription in the oracle): keys never move, every key carries the list index of its node,
@@ -929,6 +954,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     // chunk's prefix array, so all global loads of the copy are independent (a per-cell copy loop
     // serialised three dependent global loads per cell and dominated this kernel).
     int n = 0;
+    bool regp = false;
+    uint32_t kReg[QT_KPT] = {0, 0, 0, 0};
+    int nReg[QT_KPT] = {0, 0, 0, 0}, cReg[QT_KPT] = {-1, -1, -1, -1};
     int* gbase = gscan + QT_THREADS; // slot base of the chunk's cells
     for (int cbase = 0; cbase < L.nCells; cbase += QT_THREADS) {
         const int nc = min(QT_THREADS, L.nCells - cbase);
@@ -942,14 +970,26 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
             keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
         }
-        for (int i = tid; i < tot; i += QT_THREADS) {
+        regp = oneChunk && tot <= QT_KPT * QT_THREADS; // (uniform)
+        auto fetch = [&](int i) -> uint32_t {
             int lo = 0, hi = nc - 1; // last cell whose prefix <= i (cells with zero keys share a prefix; take the last)
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (gscan[mid] <= i) lo = mid;
                 else hi = mid - 1;
             }
-            keys[n + i] = candImg[gbase[lo] + (i - gscan[lo])];
+            return candImg[gbase[lo] + (i - gscan[lo])];
+        };
+        if (regp) {
+            qt_each_key(true, tot, [&](auto J, int i) {
+                constexpr int j = decltype(J)::value;
+                if (i < tot) {
+                    kReg[j] = fetch(i);
+                    keys[i] = kReg[j]; // the retained key of a node is looked up by index at the end
+                }
+            });
+        } else {
+            for (int i = tid; i < tot; i += QT_THREADS) keys[n + i] = fetch(i);
         }
         n += tot;
         __syncthreads();
@@ -966,17 +1006,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     }
     if (tid < nIni) cc[tid] = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += QT_THREADS) { // whole wavefronts enter qt_hist_add
-        const int i = base + tid;
+    qt_each_key(regp, n, [&](auto J, int i) { // whole wavefronts enter qt_hist_add
+        constexpr int j = decltype(J)::value;
         int r = -1;
         if (i < n) {
-            const uint32_t k = keys[i];
+            const uint32_t k = regp ? kReg[j] : keys[i];
             r = (int)__fdiv_rn((float)(k & 0xFFF), L.hX);
             r = min(r, nIni - 1);
-            keyNode[i] = (uint16_t)r;
+            if (regp) nReg[j] = r;
+            else keyNode[i] = (uint16_t)r;
         }
         qt_hist_add(cc, r);
-    }
+    });
     __syncthreads();
     if (tid < nIni) gpre[tid] = cc[tid] > 0 ? 1 : 0;
     __syncthreads();
@@ -989,7 +1030,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         nodeCnt(0)[p] = cc[tid];
     }
     __syncthreads();
-    for (int i = tid; i < n; i += QT_THREADS) keyNode[i] = (uint16_t)gpre[keyNode[i]];
+    qt_each_key(regp, n, [&](auto J, int i) {
+        constexpr int j = decltype(J)::value;
+        if (i < n) {
+            if (regp) nReg[j] = gpre[nReg[j]];
+            else keyNode[i] = (uint16_t)gpre[keyNode[i]];
+        }
+    });
     __syncthreads();
 
     // expansion step shared by the full passes and the final-phase rounds.
@@ -999,19 +1046,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         const int* ul = nodeUL(cur);
         const int* br = nodeBR(cur);
         if (!histDone) { // cc[0 .. 4 nE) was cleared by the caller, before its last barrier
-            for (int base = 0; base < n; base += QT_THREADS) {
-                const int i = base + tid;
+            qt_each_key(regp, n, [&](auto J, int i) {
+                constexpr int j = decltype(J)::value;
                 int c = -1;
                 if (i < n) {
-                    const int p = keyNode[i];
+                    const int p = regp ? nReg[j] : (int)keyNode[i];
                     const int k = kOf[p];
                     if (k >= 0) {
-                        const uint32_t key = keys[i];
+                        const uint32_t key = regp ? kReg[j] : keys[i];
                         c = 4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
                     }
                 }
+                if (regp) cReg[j] = c; // the child slot is reused by the relabelling below
                 qt_hist_add(cc, c);
-            }
+            });
             __syncthreads();
         }
         // One packed scan over i = 4k+q: low half counts multi-key children (creation order), high
@@ -1051,19 +1099,26 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 nodeCnt(nb)[pos] = nodeCnt(cur)[p];
             }
         }
-        for (int i = tid; i < n; i += QT_THREADS) {
-            const int p = keyNode[i];
-            const int k = kOf[p];
-            int np;
-            if (k >= 0 && k < nE) {
-                const uint32_t key = keys[i];
-                const int q = qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
-                np = cpos[4 * k + q];
+        qt_each_key(regp, n, [&](auto J, int i) {
+            constexpr int j = decltype(J)::value;
+            if (i >= n) return;
+            if (regp) { // the child slot 4k+q is still in the register the histogram left it in
+                const int c = cReg[j], p = nReg[j];
+                nReg[j] = (c >= 0 && (c >> 2) < nE) ? cpos[c] : nChildren + p - sidx[p];
             } else {
-                np = nChildren + p - sidx[p];
+                const int p = keyNode[i];
+                const int k = kOf[p];
+                int np;
+                if (k >= 0 && k < nE) {
+                    const uint32_t key = keys[i];
+                    const int q = qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
+                    np = cpos[4 * k + q];
+                } else {
+                    np = nChildren + p - sidx[p];
+                }
+                keyNode[i] = (uint16_t)np;
             }
-            keyNode[i] = (uint16_t)np;
-        }
+        });
         __syncthreads();
         cur = nb;
         nMultiOut = nMulti;
@@ -1140,19 +1195,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 {
                     const int* ul = nodeUL(cur);
                     const int* br = nodeBR(cur);
-                    for (int base = 0; base < n; base += QT_THREADS) {
-                        const int i = base + tid;
+                    qt_each_key(regp, n, [&](auto J, int i) {
+                        constexpr int j = decltype(J)::value;
                         int c = -1;
                         if (i < n) {
-                            const int p = keyNode[i];
+                            const int p = regp ? nReg[j] : (int)keyNode[i];
                             const int k = kOf[p];
                             if (k >= 0) {
-                                const uint32_t key = keys[i];
+                                const uint32_t key = regp ? kReg[j] : keys[i];
                                 c = 4 * k + qt_quadrant(ul[p], br[p], key & 0xFFF, (key >> 12) & 0xFFF);
                             }
                         }
+                        if (regp) cReg[j] = c;
                         qt_hist_add(cc, c);
-                    }
+                    });
                 }
                 __syncthreads();
                 // growth of candidate r = its non-empty children - 1; the exclusive prefix says where the list
@@ -1187,10 +1243,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     unsigned* best = reinterpret_cast<unsigned*>(cc);
     for (int p = tid; p < size; p += QT_THREADS) best[p] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += QT_THREADS) {
-        const uint32_t key = keys[i];
-        atomicMax(&best[keyNode[i]], ((key >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
-    }
+    qt_each_key(regp, n, [&](auto J, int i) {
+        constexpr int j = decltype(J)::value;
+        if (i >= n) return;
+        const uint32_t key = regp ? kReg[j] : keys[i];
+        atomicMax(&best[regp ? nReg[j] : (int)keyNode[i]], ((key >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
+    });
     __syncthreads();
     uint32_t* out = lvlKp + (size_t)img * kpImgStride + L.kpBase;
     const int nout = min(size, L.kpCap);
