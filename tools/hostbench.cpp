@@ -160,6 +160,22 @@ int main(int argc, char** argv)
     if (batch(false, &msPg, &bkPg)) return 2;
     if (batch(true, &msPin, &bkPin)) return 2;
 
+    // ---- one batch at a time through the submit / wait entry points (copies on their own streams)
+    double msSW = 0;
+    {
+        const int reps = 20;
+        for (int w = 0; w < 3; w++) {
+            CHECK(orbfe_extract_batch_submit(ex, B, pPin0.data(), rows, cols, cols, lap.data(), (orbfe_kp*)pinK[0], pinD[0], cap, n.data(), mono.data()));
+            CHECK(orbfe_extract_batch_wait(ex));
+        }
+        const double t0 = now_s();
+        for (int r = 0; r < reps; r++) {
+            CHECK(orbfe_extract_batch_submit(ex, B, pPin0.data(), rows, cols, cols, lap.data(), (orbfe_kp*)pinK[0], pinD[0], cap, n.data(), mono.data()));
+            CHECK(orbfe_extract_batch_wait(ex));
+        }
+        msSW = 1e3 * (now_s() - t0) / reps;
+    }
+
     // ---- two batches in flight (pinned buffers, two sets)
     double msPipe = 0, bkPipe = 0;
     {
@@ -264,6 +280,7 @@ int main(int argc, char** argv)
            "\"single_pinned\": {\"ms_mean\": %.4f, \"ms_p50\": %.4f, \"ms_p99\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"batch_pageable\": {\"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"batch_pinned\": {\"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
+           "\"batch_submit_wait\": {\"in_flight\": 1, \"ms_per_batch\": %.4f}, "
            "\"batch_pipelined\": {\"in_flight\": 2, \"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"pcie_floor\": {\"h2d_ms\": %.4f, \"d2h_ms\": %.4f, \"h2d_GBps\": %.1f, \"d2h_GBps\": %.1f, "
            "\"in_MB\": %.2f, \"out_MB\": %.2f, \"note\": \"bare hipMemcpyAsync of the batch's images / full output slabs, pinned\"}, "
@@ -271,7 +288,7 @@ int main(int argc, char** argv)
            "then orbfe_compute_stereo_matches_resident\", \"pairs\": %d, \"ms_per_pair_mean\": %.4f, \"ms_per_pair_p50\": %.4f, "
            "\"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f, \"keypoints_per_s\": %.0f, \"matches_per_pair\": %.1f}}\n",
            cols, rows, nF, B, kpBatch, createMs, firstCallMs, 1e3 * sPg.mean, 1e3 * sPg.p50, 1e3 * sPg.p99, kpsPg,
-           1e3 * sPin.mean, 1e3 * sPin.p50, 1e3 * sPin.p99, kpsPin, msPg, bkPg, msPin, bkPin, msPipe, bkPipe, floorInMs,
+           1e3 * sPin.mean, 1e3 * sPin.p50, 1e3 * sPin.p99, kpsPin, msPg, bkPg, msPin, bkPin, msSW, msPipe, bkPipe, floorInMs,
            floorOutMs, inMB / floorInMs, (kB + dB) * B / 1e6 / floorOutMs, inMB, outMB, nPairs, 1e3 * sStereo.mean,
            1e3 * sStereo.p50, 1e3 * sStereo.p99, 1e3 * sStereoExtract.p50, stereoKp / (sStereo.mean * nPairs),
            stereoMatches / nPairs);
