@@ -110,14 +110,14 @@ def cpu_baseline(rows, cols, nfeatures, seconds=14.0):
     cores = usable_cores()
     frames = np.stack([synth.make_frame(rows, cols, 1234 + i) for i in range(4)])
 
-    def run(threads, budget, lap):
-        n, t = O.extract_many(frames, threads, 2, nfeatures, lap=lap, native=native)  # calibrate
+    def run(threads, budget, lap, nf=nfeatures):
+        n, t = O.extract_many(frames, threads, 2, nf, lap=lap, native=native)  # calibrate
         reps = int(min(max(2, budget / (t / 2)), 400))
-        n, t = O.extract_many(frames, threads, reps, nfeatures, lap=lap, native=native)
+        n, t = O.extract_many(frames, threads, reps, nf, lap=lap, native=native)
         return n, t, reps
 
     n1, t1, r1 = run(1, 0.2 * seconds, (0, 1000))       # (i) mono protocol, reference src/Frame.cc:306
-    n2, t2, r2 = run(2, 0.2 * seconds, (0, 0))          # (ii) stereo protocol: left + right extractor threads
+    n2, t2, r2 = run(2, 0.2 * seconds, (0, 0), 1200)    # (ii) stereo protocol: left + right extractor threads, nF 1200
     n, dt, reps = run(cores, 0.5 * seconds, (0, 1000))  # (iii) best-case CPU throughput over independent frames
     return {
         "value": n / dt,
@@ -127,7 +127,9 @@ def cpu_baseline(rows, cols, nfeatures, seconds=14.0):
         "flags": "g++ " + flags,
         "one_thread": {"value": n1 / t1, "ms_per_frame": 1e3 * t1 / r1},
         "two_threads_stereo": {"value": n2 / t2, "ms_per_pair": 1e3 * t2 / r2,
-                               "note": "2 threads x 1 extractor each, one frame per thread per pair (src/Frame.cc:119-122)"},
+                               "nfeatures": 1200,
+                               "note": "2 threads x 1 extractor each, one frame per thread per pair (src/Frame.cc:119-122, "
+                                       "Examples/Stereo/EuRoC.yaml nFeatures 1200)"},
         "sample": "oracle built with `g++ %s`; %d threads x %d frames of %dx%d (nF=%d) in %.1f s; "
                   "1 thread: %.0f keypoints/s (%.1f ms/frame, %d frames); 2 threads: %.1f ms per stereo pair (%d pairs)"
                   % (flags, cores, reps, cols, rows, nfeatures, dt, n1 / t1, 1e3 * t1 / r1, r1, 1e3 * t2 / r2, r2),

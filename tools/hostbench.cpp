@@ -229,11 +229,13 @@ int main(int argc, char** argv)
     Stat sStereo{0, 0, 0}, sStereoExtract{0, 0, 0};
     double stereoMatches = 0;
     long stereoKp = 0;
-    const int nPairs = 200;
+    const int nPairs = 200, nFstereo = 1200;
     {
         orbfe_ctx *exL = nullptr, *exR = nullptr;
-        CHECK(orbfe_create(&exL, nF, 1.2f, 8, 20, 7, dev));
-        CHECK(orbfe_create(&exR, nF, 1.2f, 8, 20, 7, dev));
+        CHECK(orbfe_create(&exL, nFstereo, 1.2f, 8, 20, 7, dev)); // Examples/Stereo/EuRoC.yaml: ORBextractor.nFeatures: 1200
+        CHECK(orbfe_create(&exR, nFstereo, 1.2f, 8, 20, 7, dev));
+        const int capS = orbfe_max_keypoints(exL, rows, cols);
+        CHECK(capS);
         std::vector<uint8_t> right(imgBytes * B);
         for (int i = 0; i < B; i++)
             for (int y = 0; y < rows; y++) {
@@ -242,16 +244,16 @@ int main(int argc, char** argv)
                 memcpy(d, s + 12, cols - 12);
                 memcpy(d + cols - 12, s, 12);
             }
-        std::vector<uint8_t> kL(kB), dL(dB), kR(kB), dR(dB);
-        std::vector<float> uR(cap), depth(cap);
+        std::vector<uint8_t> kL((size_t)capS * 28), dL((size_t)capS * 32), kR((size_t)capS * 28), dR((size_t)capS * 32);
+        std::vector<float> uR(capS), depth(capS);
         const float bf = 47.90639384423901f, fx = 435.2046959714599f; // Examples/Stereo/EuRoC.yaml
         std::vector<double> lat, latE;
         for (int r = -10; r < nPairs; r++) {
             const int i = (r + 10) % B;
             int nL = 0, nR = 0, rcL = 0, rcR = 0;
             const double a = now_s();
-            std::thread tl([&] { rcL = orbfe_extract(exL, frames.data() + imgBytes * i, rows, cols, cols, 0, 0, (orbfe_kp*)kL.data(), dL.data(), cap, &nL); });
-            std::thread tr([&] { rcR = orbfe_extract(exR, right.data() + imgBytes * i, rows, cols, cols, 0, 0, (orbfe_kp*)kR.data(), dR.data(), cap, &nR); });
+            std::thread tl([&] { rcL = orbfe_extract(exL, frames.data() + imgBytes * i, rows, cols, cols, 0, 0, (orbfe_kp*)kL.data(), dL.data(), capS, &nL); });
+            std::thread tr([&] { rcR = orbfe_extract(exR, right.data() + imgBytes * i, rows, cols, cols, 0, 0, (orbfe_kp*)kR.data(), dR.data(), capS, &nR); });
             tl.join();
             tr.join();
             const double b = now_s();
@@ -284,7 +286,7 @@ int main(int argc, char** argv)
            "\"batch_pipelined\": {\"in_flight\": 2, \"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"pcie_floor\": {\"h2d_ms\": %.4f, \"d2h_ms\": %.4f, \"h2d_GBps\": %.1f, \"d2h_GBps\": %.1f, "
            "\"in_MB\": %.2f, \"out_MB\": %.2f, \"note\": \"bare hipMemcpyAsync of the batch's images / full output slabs, pinned\"}, "
-           "\"stereo_pair\": {\"protocol\": \"2 contexts, 2 threads started per frame (src/Frame.cc:119-122), pageable images, "
+           "\"stereo_pair\": {\"nfeatures\": 1200, \"protocol\": \"2 contexts, 2 threads started per frame (src/Frame.cc:119-122), pageable images, "
            "then orbfe_compute_stereo_matches_resident\", \"pairs\": %d, \"ms_per_pair_mean\": %.4f, \"ms_per_pair_p50\": %.4f, "
            "\"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f, \"keypoints_per_s\": %.0f, \"matches_per_pair\": %.1f}}\n",
            cols, rows, nF, B, kpBatch, createMs, firstCallMs, 1e3 * sPg.mean, 1e3 * sPg.p50, 1e3 * sPg.p99, kpsPg,
