@@ -275,20 +275,52 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
     // "already matched" state of this node's set-2 features: only this wave touches them, so the
     // first 4096 candidates live in one register bit per (lane, step); the rest go through taken2[].
     unsigned long long takenMask = 0ull;
+    // Everything the row loop needs is fetched ONCE, up front, with all loads in flight together: lane r holds row r
+    // of the node (index, eligibility, descriptor), lane c holds candidate c (index, static eligibility, descriptor).
+    // The sequential row loop then runs on registers (a row's descriptor is broadcast with v_readlane) -- it used to
+    // chase index -> mask -> descriptor through global memory for every row and again for every candidate of every
+    // row, five dependent round trips per row.  Rows / candidates beyond the first 64 of a node take the old path.
+    int rIdx = 0, cIdx = 0;
+    bool rOk = false, cOk = false;
+    Desc rD = {}, cD = {};
+    if (lane < N.n1) {
+        rIdx = ind1[N.off1 + lane];
+        rOk = !(variant == 1 && limit1 != -1 && rIdx >= limit1) && mask1[rIdx] != 0;
+        rD = load_desc(desc1 + (size_t)rIdx * 32);
+    }
+    if (lane < N.n2) {
+        cIdx = ind2[N.off2 + lane];
+        cOk = variant != 1 || (!(limit2 != -1 && cIdx >= limit2) && mask2[cIdx] != 0);
+        cD = load_desc(desc2 + (size_t)cIdx * 32);
+    }
     for (int r = 0; r < N.n1; r++) {
-        const int idx1 = ind1[N.off1 + r];
-        if (variant == 1 && limit1 != -1 && idx1 >= limit1) continue;
-        if (!mask1[idx1]) continue;
-        const Desc d1 = load_desc(desc1 + (size_t)idx1 * 32);
+        int idx1;
+        Desc d1;
+        if (r < 64) { // (uniform)
+            if (!__builtin_amdgcn_readlane((int)rOk, r)) continue;
+            idx1 = __builtin_amdgcn_readlane(rIdx, r);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] & 0xFFFFFFFFull), r);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] >> 32), r);
+                d1.w[w] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            }
+        } else {
+            idx1 = ind1[N.off1 + r];
+            if (variant == 1 && limit1 != -1 && idx1 >= limit1) continue;
+            if (!mask1[idx1]) continue;
+            d1 = load_desc(desc1 + (size_t)idx1 * 32);
+        }
         // key = dist<<20 | position in the node's list (iteration order breaks ties)
         unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
         for (int c = lane; c < N.n2; c += 64) {
-            const int idx2 = ind2[N.off2 + c];
             const int step = c >> 6;
+            const int idx2 = step == 0 ? cIdx : ind2[N.off2 + c];
             bool ok = step < 64 ? !((takenMask >> step) & 1ull) : !taken2[idx2];
-            if (variant == 1) ok = ok && !(limit2 != -1 && idx2 >= limit2) && mask2[idx2];
+            if (step == 0) ok = ok && cOk;
+            else if (variant == 1) ok = ok && !(limit2 != -1 && idx2 >= limit2) && mask2[idx2];
             if (!ok) continue;
-            const unsigned key = ((unsigned)hamming(d1, load_desc(desc2 + (size_t)idx2 * 32)) << 20) | (unsigned)c;
+            const unsigned key = ((unsigned)hamming(d1, step == 0 ? cD : load_desc(desc2 + (size_t)idx2 * 32)) << 20) | (unsigned)c;
             const bool right = (variant == 0 && Nleft != -1 && idx2 >= Nleft);
             if (!right) {
                 if (key < k0) {
@@ -1197,6 +1229,41 @@ struct Scratch { // device allocations of one call
         *out = (T*)p;
         return 0;
     }
+    // Arena space the caller fills itself: *stage points into the pinned mirror (the bytes go up with the other
+    // staged inputs in flush()), so a pooled upload needs no intermediate copy.  Falls back to a temporary host
+    // buffer when the arena is too small for this call (it is enlarged before the next one).
+    std::vector<std::vector<uint8_t>> temps;
+    struct LateUp {
+        void* dev;
+        size_t temp, bytes;
+    };
+    std::vector<LateUp> lateUps;
+    template <class T>
+    int reserve(T** dev, T** stage, size_t n)
+    {
+        *dev = nullptr;
+        *stage = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        ar->want += bytes;
+        if (ar->base && ar->pin && ar->off + bytes <= ar->cap) {
+            const size_t at = ar->off;
+            ar->off += bytes;
+            *dev = (T*)(ar->base + at);
+            *stage = (T*)(ar->pin + at);
+            if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
+            else staged.emplace_back(at, bytes);
+            return 0;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        overflow.push_back(p);
+        temps.emplace_back(bytes);
+        lateUps.push_back(LateUp{p, temps.size() - 1, bytes});
+        *dev = (T*)p;
+        *stage = (T*)temps.back().data();
+        return 0;
+    }
     // Descriptor arrays may already live on the device (an extractor's resident output slab, a gathered slab):
     // then they are read in place.
     int up_desc(uint8_t** out, const uint8_t* hostOrDev, size_t n)
@@ -1215,6 +1282,15 @@ struct Scratch { // device allocations of one call
             if (e != hipSuccess) return -(1000 + (int)e);
         }
         staged.clear();
+        for (const LateUp& u : lateUps) {
+            hipError_t e = hipMemcpyAsync(u.dev, temps[u.temp].data(), u.bytes, hipMemcpyHostToDevice, g_ms);
+            if (e != hipSuccess) return -(1000 + (int)e);
+        }
+        if (!lateUps.empty()) {
+            hipError_t e = hipStreamSynchronize(g_ms); // pageable sources
+            if (e != hipSuccess) return -(1000 + (int)e);
+            lateUps.clear();
+        }
         return 0;
     }
     // Results: down() names a device range the caller wants in `host`; fetch() brings all of them back with ONE
@@ -1228,7 +1304,9 @@ struct Scratch { // device allocations of one call
     int fetch()
     {
         bool inArena = ar->base && ar->pin && !downs.empty();
-        size_t lo = ~(size_t)0, hi = 0;
+        size_t lo = ~(size_t)0, hi = 0, total = 0;
+        for (const Down& d : downs) total += d.bytes;
+        if (total > (1u << 20)) inArena = false; // a distance matrix: straight into the caller's memory, no second copy
         for (const Down& d : downs) {
             const uint8_t* p = (const uint8_t*)d.dev;
             if (!(ar->base && p >= ar->base && p + d.bytes <= ar->base + ar->cap)) inArena = false;
@@ -1487,19 +1565,13 @@ int orbfe_matcher_sync(int device)
 int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, int32_t* const* match, int* nmatches)
 {
     if (count < 0 || (count && (!args || !match || !nmatches))) return ORBFE_ERR_ARGS;
+    // pass 1: validate, lay the pools out, list the shared vocabulary nodes (merge-join of the two FeatureVectors)
     std::vector<BowNode> nodes;
     std::vector<BowProb> probs(count);
-    std::vector<uint8_t> descPool, maskPool;
-    struct D2D {
-        size_t off;
-        const uint8_t* src;
-        size_t bytes;
-    };
-    std::vector<D2D> d2d;
-    std::vector<float> angPool;
-    std::vector<int32_t> indPool;
-    std::vector<int> outN(count);
+    std::vector<int> outN(count), i1Base(count, 0), i2Base(count, 0);
+    std::vector<uint8_t> active(count, 0);
     int rows = 0, outTotal = 0;
+    size_t indTotal = 0;
     for (int p = 0; p < count; p++) {
         const orbfe_bow_args* a = &args[p];
         if (!match[p] || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2) ||
@@ -1522,43 +1594,24 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
         if (a->n1 == 0 || a->n2 == 0) continue;
         if (!a->desc1 || !a->desc2 || !a->mask1 || (a->variant == 1 && !a->mask2)) return ORBFE_ERR_ARGS;
         if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
-        const int i1Base = (int)indPool.size();
-        indPool.insert(indPool.end(), a->fv1.indices, a->fv1.indices + a->fv1.offsets[a->fv1.nn]);
-        const int i2Base = (int)indPool.size();
-        indPool.insert(indPool.end(), a->fv2.indices, a->fv2.indices + a->fv2.offsets[a->fv2.nn]);
+        active[p] = 1;
+        i1Base[p] = (int)indTotal;
+        indTotal += (size_t)(a->fv1.nn ? a->fv1.offsets[a->fv1.nn] : 0);
+        i2Base[p] = (int)indTotal;
+        indTotal += (size_t)(a->fv2.nn ? a->fv2.offsets[a->fv2.nn] : 0);
         bool bad = false;
+        const int b1 = i1Base[p], b2 = i2Base[p];
         for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
             BowNode n;
-            n.off1 = i1Base + a->fv1.offsets[i];
+            n.off1 = b1 + a->fv1.offsets[i];
             n.n1 = a->fv1.offsets[i + 1] - a->fv1.offsets[i];
-            n.off2 = i2Base + a->fv2.offsets[j];
+            n.off2 = b2 + a->fv2.offsets[j];
             n.n2 = a->fv2.offsets[j + 1] - a->fv2.offsets[j];
             n.prob = p;
             if (n.n2 >= (1 << 20)) bad = true;
             if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
         });
         if (bad) return ORBFE_ERR_ARGS;
-        // descriptor sets that already live on the device are copied device-to-device into the pool below
-        const bool dev1 = is_device_ptr(a->desc1), dev2 = is_device_ptr(a->desc2);
-        if (dev1) {
-            d2d.push_back(D2D{descPool.size(), a->desc1, (size_t)a->n1 * 32});
-            descPool.resize(descPool.size() + (size_t)a->n1 * 32);
-        } else {
-            descPool.insert(descPool.end(), a->desc1, a->desc1 + (size_t)a->n1 * 32);
-        }
-        if (dev2) {
-            d2d.push_back(D2D{descPool.size(), a->desc2, (size_t)a->n2 * 32});
-            descPool.resize(descPool.size() + (size_t)a->n2 * 32);
-        } else {
-            descPool.insert(descPool.end(), a->desc2, a->desc2 + (size_t)a->n2 * 32);
-        }
-        maskPool.insert(maskPool.end(), a->mask1, a->mask1 + a->n1);
-        if (a->variant == 1) maskPool.insert(maskPool.end(), a->mask2, a->mask2 + a->n2);
-        else maskPool.insert(maskPool.end(), (size_t)a->n2, (uint8_t)1);
-        if (a->angle1) angPool.insert(angPool.end(), a->angle1, a->angle1 + a->n1);
-        else angPool.insert(angPool.end(), (size_t)a->n1, 0.f);
-        if (a->angle2) angPool.insert(angPool.end(), a->angle2, a->angle2 + a->n2);
-        else angPool.insert(angPool.end(), (size_t)a->n2, 0.f);
         rows += a->n1 + a->n2;
     }
     if (nodes.empty()) return 0;
@@ -1567,24 +1620,50 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     Scratch s(device);
     BowNode* dN;
     BowProb* dP;
-    uint8_t *dDesc, *dMask, *taken;
-    float* dAng;
-    int32_t *dInd, *dM;
+    uint8_t *dDesc, *dMask, *taken, *hDesc, *hMask;
+    float *dAng, *hAng;
+    int32_t *dInd, *dM, *hInd;
     int8_t* dB;
     if ((r = s.up(&dN, nodes.data(), nodes.size())) < 0) return r;
     if ((r = s.up(&dP, probs.data(), probs.size())) < 0) return r;
-    if ((r = s.up(&dDesc, descPool.data(), descPool.size())) < 0) return r;
-    if ((r = s.up(&dMask, maskPool.data(), maskPool.size())) < 0) return r;
-    if ((r = s.up(&dAng, angPool.data(), angPool.size())) < 0) return r;
-    if ((r = s.up(&dInd, indPool.data(), indPool.size())) < 0) return r;
+    if ((r = s.reserve(&dDesc, &hDesc, (size_t)rows * 32)) < 0) return r;
+    if ((r = s.reserve(&dMask, &hMask, (size_t)rows)) < 0) return r;
+    if ((r = s.reserve(&dAng, &hAng, (size_t)rows)) < 0) return r;
+    if ((r = s.reserve(&dInd, &hInd, indTotal)) < 0) return r;
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
     if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
     if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)rows)) < 0) return r;
+    // pass 2: every problem's arrays go straight into the pinned mirror of the pools (one copy, no intermediate
+    // vectors); descriptor sets that already live on the device are copied device-to-device after the upload
+    struct D2D {
+        size_t off;
+        const uint8_t* src;
+        size_t bytes;
+    };
+    std::vector<D2D> d2d;
+    for (int p = 0; p < count; p++) {
+        if (!active[p]) continue;
+        const orbfe_bow_args* a = &args[p];
+        const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
+        if (is_device_ptr(a->desc1)) d2d.push_back(D2D{r1 * 32, a->desc1, (size_t)a->n1 * 32});
+        else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
+        if (is_device_ptr(a->desc2)) d2d.push_back(D2D{r2 * 32, a->desc2, (size_t)a->n2 * 32});
+        else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
+        std::memcpy(hMask + r1, a->mask1, (size_t)a->n1);
+        if (a->variant == 1) std::memcpy(hMask + r2, a->mask2, (size_t)a->n2);
+        else std::memset(hMask + r2, 1, (size_t)a->n2);
+        if (a->angle1) std::memcpy(hAng + r1, a->angle1, (size_t)a->n1 * sizeof(float));
+        else std::memset(hAng + r1, 0, (size_t)a->n1 * sizeof(float));
+        if (a->angle2) std::memcpy(hAng + r2, a->angle2, (size_t)a->n2 * sizeof(float));
+        else std::memset(hAng + r2, 0, (size_t)a->n2 * sizeof(float));
+        if (a->fv1.nn) std::memcpy(hInd + i1Base[p], a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn] * sizeof(int32_t));
+        if (a->fv2.nn) std::memcpy(hInd + i2Base[p], a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn] * sizeof(int32_t));
+    }
     HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), g_ms));
     HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
     HIP_TRY(hipMemsetAsync(taken, 0, (size_t)rows, g_ms));
     {
-        KernelTimer timer(s); // (sends the staged pool; the device-resident sets then overwrite their places in it)
+        KernelTimer timer(s); // (sends the staged pools; the device-resident sets then overwrite their places)
         for (const D2D& c : d2d)
             HIP_TRY(hipMemcpyAsync(dDesc + c.off, c.src, c.bytes, hipMemcpyDeviceToDevice, g_ms));
         hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, g_ms, dN, (int)nodes.size(),

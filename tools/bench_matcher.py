@@ -117,6 +117,23 @@ def main():
     print(json.dumps({"op": "ComputeStereoMatches 752x480 pair, %d x %d keypoints" % (len(kL), len(kR)), "units": len(kL),
                       "unit": "left keypoints", "call_ms": 1e3 * g, "cpu_oracle_ms_1core": 1e3 * c,
                       "call_units_per_s": len(kL) / g, "cpu_units_per_s": len(kL) / c}))
+    gr = timeit(lambda: pkg.binding.compute_stereo_matches_resident(exL, exR, len(kL), mb, mbf), 50)
+    print(json.dumps({"op": "ComputeStereoMatches, resident form (no keypoint / descriptor upload)", "units": len(kL),
+                      "unit": "left keypoints", "call_ms": 1e3 * gr, "cpu_oracle_ms_1core": 1e3 * c}))
+    # knn-2 on descriptors that are already on the device (the extractors' resident outputs)
+    import torch
+    _, pL, _, _, _ = exL.device_outputs()
+    _, pR, _, _, _ = exR.device_outputs()
+    d_idx = torch.zeros((len(kL), 2), dtype=torch.int32, device="cuda")
+    d_dist = torch.zeros((len(kL), 2), dtype=torch.int32, device="cuda")
+
+    def knn_dev():
+        pkg.binding.bfknn2_device(pL, len(kL), pR, len(kR), d_idx.data_ptr(), d_dist.data_ptr())
+        pkg.binding.matcher_sync()
+    kd = timeit(knn_dev, 50)
+    kh = timeit(lambda: pkg.bfknn2(dL, dR), 50)
+    print(json.dumps({"op": "bfknn2 %d x %d: device-resident call + sync vs host-pointer call" % (len(kL), len(kR)),
+                      "device_call_ms": 1e3 * kd, "host_call_ms": 1e3 * kh}))
     print(json.dumps({"op": "projection sweeps", "mode0": None, "last": pkg.search_projection_last_sweeps()}))
 
 
