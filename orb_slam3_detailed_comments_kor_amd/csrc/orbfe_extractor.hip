@@ -108,6 +108,7 @@ struct PinBuf {
 // different sizes in turn -- does not rebuild and re-upload the tables at every switch.
 struct orbfe_geom_state {
     int rows = 0, cols = 0;
+    int pyrTile = 0; // tile side of the fused pyramid kernel at the coarsest level: part of the state's key
     std::vector<OrbLevelGeom> lg;
     std::vector<OrbCellGeom> cg;
     size_t pyrStride = 0, candStride = 0, keyStride = 0, kpStride = 0;
@@ -474,13 +475,24 @@ void build_pyr_ranges(int nlevels, const std::vector<int>& extent, const std::ve
     }
 }
 
-int ensure_geometry(orbfe_ctx* c, int rows, int cols)
+// Tile side of the fused pyramid kernel at the coarsest level.  A big batch wants few, large tiles (less halo work:
+// 24 is the fastest for 64 frames); a frame or two wants MANY workgroups, because then the kernel lasts as long as one
+// workgroup's walk down the eight levels and the chip is nearly empty: 12 instead of 24 takes a single 752x480 frame's
+// pyramid from 18.1 to 13.6 us (tile 16: 14.5, 20: 16.5, 32: 22.1).
+int pyr_tile_for(int nimg)
 {
-    if (rows == c->rows && cols == c->cols && !c->lg.empty()) return 0;
+    if (const char* e = getenv("ORBFE_PYR_TILE")) return std::min(64, std::max(8, atoi(e)));
+    return nimg <= 4 ? 12 : ORBFE_PYR_TILE;
+}
+
+int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
+{
+    const int tile = pyr_tile_for(nimg);
+    if (rows == c->rows && cols == c->cols && tile == c->pyrTile && !c->lg.empty()) return 0;
     orbfe_geom_state& cur = *c;
     // a size this context has seen before: swap its tables back in (no rebuild, no upload)
     for (size_t i = 0; i < c->geomCache.size(); i++)
-        if (c->geomCache[i].rows == rows && c->geomCache[i].cols == cols) {
+        if (c->geomCache[i].rows == rows && c->geomCache[i].cols == cols && c->geomCache[i].pyrTile == tile) {
             std::swap(cur, c->geomCache[i]);
             if (c->geomCache[i].lg.empty()) c->geomCache.erase(c->geomCache.begin() + (long)i);
             if (c->qtLdsBytes > 64 * 1024)
@@ -539,8 +551,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
                 yhi[l][t] = ytab[c->lg[l].ytabOff + t].sy1;
             }
         }
-        int T = ORBFE_PYR_TILE;
-        if (const char* e = getenv("ORBFE_PYR_TILE")) T = std::min(64, std::max(8, atoi(e)));
+        const int T = tile;
         c->pyrNtx = (ex[nl - 1] + T - 1) / T;
         c->pyrNty = (ey[nl - 1] + T - 1) / T;
         std::vector<OrbPyrRange> prx, pry;
@@ -577,12 +588,13 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols)
                                     (int)c->qtLdsBytes));
     c->rows = rows;
     c->cols = cols;
+    c->pyrTile = tile;
     c->capImgs = 0; // per-image strides changed: force re-allocation
     if (getenv("ORBFE_VERBOSE"))
         fprintf(stderr,
                 "orbfe: %dx%d: pyramid %zu B/img, %d FAST cells; LDS per workgroup: k_pyr_fused %zu B (%dx%d tiles of "
                 "%d px, fused=%d), k_fast_cells %zu B (%d threads), k_octree %zu B\n",
-                cols, rows, c->pyrStride, c->nCells, c->pyrLdsBytes, c->pyrNtx, c->pyrNty, ORBFE_PYR_TILE,
+                cols, rows, c->pyrStride, c->nCells, c->pyrLdsBytes, c->pyrNtx, c->pyrNty, tile,
                 (int)c->pyrFused, c->fastLdsBytes, c->fastThreads, c->qtLdsBytes);
     return 0;
 }
@@ -775,7 +787,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                int32_t* d_errOut = nullptr /* K-PACK copies the batch's error word here (host-pointer path) */)
 {
     int r;
-    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if (capPerImg < c->maxKp || capPerImg > 65535 || nimg > 32767) return ORBFE_ERR_ARGS; // fix-list packing
     if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
     hipStream_t s = c->stream;
@@ -1120,7 +1132,7 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
     if (c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: wait for one first
     HIP_TRY(hipSetDevice(c->device));
     int r;
-    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if (cap_per_img < c->maxKp) return ORBFE_ERR_ARGS;
     if ((r = ensure_capacity(c, nimg, cap_per_img)) < 0) return r;
     orbfe_ctx::HostSlot& sl = c->slot[c->slotSubmitted & 1];
@@ -1485,7 +1497,7 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     if (pitch < (size_t)cols) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
     int r;
-    if ((r = ensure_geometry(c, rows, cols)) < 0) return r;
+    if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if ((r = ensure_capacity(c, nimg, std::max(cap_per_img, c->maxKp))) < 0) return r;
     // The per-image lapping table only changes when the caller changes (lap0, lap1) or grows the batch: upload
     // it then (with a synchronisation, the source is a stack buffer) and never again -- the steady state of this
@@ -1881,6 +1893,15 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
 }
 
 int orbfe_debug_fixups(orbfe_ctx* c) { return c ? c->lastFixups : ORBFE_ERR_ARGS; }
+
+#ifdef ORBFE_QT_TIMING
+extern "C" int orbfe_debug_qt_times(unsigned long long* out64)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_qtTimes), 64 * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
 
 // GaussianBlur's output under one keypoint of the last call: re-runs the descriptor kernel for that image (same
 // results) with the tap armed, so that the fused blur is compared with the oracle's blurred level directly.

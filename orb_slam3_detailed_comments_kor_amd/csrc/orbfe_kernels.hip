@@ -879,6 +879,16 @@ __device__ __forceinline__ void qt_each_key(bool regp, int n, F f)
     }
 }
 
+#ifdef ORBFE_QT_TIMING // tuning only (tools/ab_build.sh qtt "-DORBFE_QT_TIMING"): phase timestamps of one workgroup
+__device__ unsigned long long g_qtTimes[64];
+#define QT_STAMP(k)                                                                            \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qtTimes[k] = wall_clock64(); \
+    } while (0)
+#else
+#define QT_STAMP(k) do { } while (0)
+#endif
+
 // One workgroup per (image, level).  Level-synchronous restatement of DistributeOctTree
 // (tests/qt_model.py is the executable specification, checked against the literal list
 // transcription in the oracle): keys never move, every key carries the list index of its node,
@@ -897,6 +907,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int level = blockIdx.x, img = (int)blockIdx.y + imgBase;
+    QT_STAMP(0);
     const OrbLevelGeom L = lg[level];
     const int LC = L.listCap;
     const int N = L.nFeat;
@@ -995,6 +1006,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         __syncthreads();
     }
     if (n > L.keyCap) n = L.keyCap; // cannot happen (keyCap = sum of slot caps)
+    QT_STAMP(1);
 
     int cur = 0;
     int size = 0;
@@ -1125,8 +1137,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         return newSize;
     };
 
+    QT_STAMP(2);
+    int stampK = 3;
     bool finish = false;
     while (!finish) {
+        QT_STAMP(stampK); stampK = min(stampK + 1, 40);
         // ---- full pass (:598-663): every node with more than one key is divided
         const int prevSize = size;
         // sidx[p] = number of divided nodes before p; kOf[p] = its own expansion index or -1 (written where the
@@ -1150,7 +1165,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         } else if (size + 3 * nMulti > N) {
             // ---- final phase (:671-736): expand the largest nodes first until N is reached
             int m = nMulti;
+            QT_STAMP(41);
+            int stampF = 42;
             while (!finish) {
+                QT_STAMP(stampF); stampF = min(stampF + 1, 58);
                 const int prev2 = size;
                 const int* mcur = multi(cur);
                 // rank of candidate t in descending (count, creation index) order
@@ -1239,6 +1257,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         }
     }
 
+    QT_STAMP(59);
     // ---- retain the best key of every node (:739-758): max response, first key wins ties
     unsigned* best = reinterpret_cast<unsigned*>(cc);
     for (int p = tid; p < size; p += QT_THREADS) best[p] = 0;
@@ -1254,6 +1273,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     const int nout = min(size, L.kpCap);
     for (int p = tid; p < nout; p += QT_THREADS) out[p] = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
     if (tid == 0) lvlCount[(size_t)img * nlevels + level] = nout;
+    QT_STAMP(60);
 }
 
 // ----------------------------------------------------------------- K-PACK

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Phase timestamps of K-QT's level-0 workgroup (tuning; needs a library built with -DORBFE_QT_TIMING:
+tools/ab_build.sh qtt "-DORBFE_QT_TIMING"; ORBFE_LIB=.../liborbfe_qtt.so python tools/qt_times.py [batch])."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+imgs = [pkg.synth.make_frame(480, 752, 1234 + i) for i in range(B)]
+ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+for _ in range(5):
+    ex.extract_batch(imgs)
+t = np.zeros(64, np.uint64)
+pkg.lib().orbfe_debug_qt_times(t.ctypes.data_as(C.c_void_p))
+t = t.astype(np.int64)
+names = {0: "start", 1: "gather done", 2: "roots done", 41: "final phase begins", 59: "tree done", 60: "output written"}
+prev = t[0]
+for k in range(61):
+    if t[k] == 0:
+        continue
+    print("%2d %-20s +%.2f us (at %.2f)" % (k, names.get(k, "pass / round"), (t[k] - prev) / 100.0, (t[k] - t[0]) / 100.0))
+    prev = t[k]
