@@ -12,6 +12,13 @@
  *   SearchByProjection(Frame&, vpMapPoints, th, ...)    src/ORBmatcher.cc:44-197     orbfe_search_projection, mode 0
  *   SearchByProjection(CurrentFrame, LastFrame, ...)    src/ORBmatcher.cc:2193-2419  orbfe_search_projection, mode 1
  *   Fuse(KeyFrame*, vpMapPoints, th, bRight)            src/ORBmatcher.cc:1643-1841  orbfe_search_projection, mode 1 + chi2
+ *   SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist)  :2421-2541  mode 1 (relocalisation)
+ *   SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratio) and its vpMatchedKF twin  :473-704  mode 1
+ *   Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)        src/ORBmatcher.cc:1843-1965  mode 1, independent queries
+ *   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  :1967-2191           mode 1, one call per direction
+ *   SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  :706-821  orbfe_search_initialization
+ *   SearchForTriangulation(KF1, KF2, cv::Mat F12, ...)  src/ORBmatcher.cc:965-1206  = SearchForTriangulation_
+ *   (the matchAndtriangulate overload :1452-1641 has no caller in the reference: declared, throws)
  *   DescriptorDistance                                  src/ORBmatcher.cc:2591-2607  (host, one pair: a call per pair
  *                                                                                     would cost more than it computes)
  *
@@ -28,7 +35,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <set>
 #include <stdexcept>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -152,12 +161,33 @@ inline void transform(const float R[9], const float t[3], const float xw[3], flo
         xc[i] = (float)((double)R[3 * i] * xw[0] + (double)R[3 * i + 1] * xw[1] + (double)R[3 * i + 2] * xw[2] + (double)t[i]);
 }
 
+// Scw (4x4, CV_32F) -> Rcw, tcw, Ow as :479-486 / :1850-1856 form them with cv::Mat expressions: sRcw / scw and
+// tcw / scw are scalings by the double 1/scw rounded to float, Ow = -Rcw^T tcw one gemm
+inline void decompose_sim3(const cv::Mat& Scw, float Rcw[9], float tcw[3], float Ow[3])
+{
+    double d = 0;
+    for (int j = 0; j < 3; j++) d += (double)Scw.at<float>(0, j) * (double)Scw.at<float>(0, j);
+    const float scw = (float)std::sqrt(d);
+    const double inv = 1.0 / (double)scw;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rcw[3 * i + j] = (float)((double)Scw.at<float>(i, j) * inv);
+        tcw[i] = (float)((double)Scw.at<float>(i, 3) * inv);
+    }
+    for (int i = 0; i < 3; i++)
+        Ow[i] = (float)(-((double)Rcw[i] * tcw[0] + (double)Rcw[3 + i] * tcw[1] + (double)Rcw[6 + i] * tcw[2]));
+}
+inline float norm3(const float v[3])
+{
+    return (float)std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); // cv::norm (L2, double)
+}
+
 // queries of one orbfe_search_projection call, appended in the reference's loop order
 struct Queries {
     std::vector<uint8_t> desc, flags, blocks;
     std::vector<float> x, y, r, xr, angle;
     std::vector<int32_t> minLevel, maxLevel;
     std::vector<MapPoint*> mp;
+    std::vector<int> src; // index of the point in the caller's vector (set by the caller when it needs it)
     void push(MapPoint* p, const uint8_t* d, float qx, float qy, float qr, int lo, int hi, float qxr, int fl, float ang, int blk)
     {
         mp.push_back(p);
@@ -532,6 +562,221 @@ public:
         return nFused;
     }
 
+    // ---- src/ORBmatcher.cc:2421-2541 (Tracking::Relocalization): project the keyframe's points into the frame
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                           const int ORBdist)
+    {
+        using namespace orbfe_adapter;
+        float Rcw[9], tcw[3], Ow[3];
+        frame_pose(CurrentFrame, Rcw, tcw);
+        for (int i = 0; i < 3; i++)
+            Ow[i] = (float)(-((double)Rcw[i] * tcw[0] + (double)Rcw[3 + i] * tcw[1] + (double)Rcw[6 + i] * tcw[2]));
+        const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+        Queries q;
+        for (size_t i = 0; i < vpMPs.size(); i++) {
+            MapPoint* pMP = vpMPs[i];
+            if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+            float x3Dw[3], x3Dc[3];
+            world_pos(pMP, x3Dw);
+            transform(Rcw, tcw, x3Dw, x3Dc);
+            const cv::Point2f uv = CurrentFrame.mpCamera->project(cv::Point3f(x3Dc[0], x3Dc[1], x3Dc[2]));
+            if (uv.x < CurrentFrame.mnMinX || uv.x > CurrentFrame.mnMaxX) continue;
+            if (uv.y < CurrentFrame.mnMinY || uv.y > CurrentFrame.mnMaxY) continue;
+            const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+            const float dist3D = norm3(PO);
+            if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+            const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+            q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, radius, nPredictedLevel - 1, nPredictedLevel + 1, 0.f, 0,
+                   pKF->mvKeysUn[i].angle, 1);
+        }
+        std::vector<uint8_t> taken((size_t)std::max(CurrentFrame.N, 1), 0); // :2484: any point at the feature hides it
+        for (int i = 0; i < CurrentFrame.N; i++) taken[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;
+        std::vector<int32_t> qMatch, featMatch;
+        const int nmatches = run_projection(CurrentFrame, CurrentFrame.N, -1, CurrentFrame.mDescriptors, nullptr, taken,
+                                            CurrentFrame.mnMinX, CurrentFrame.mnMinY, CurrentFrame.mfGridElementWidthInv,
+                                            CurrentFrame.mfGridElementHeightInv, q, 1, ORBdist, mbCheckOrientation, nullptr, 0,
+                                            false, nullptr, nullptr, qMatch, featMatch);
+        for (int i = 0; i < CurrentFrame.N; i++)
+            if (featMatch[i] >= 0) CurrentFrame.mvpMapPoints[i] = q.mp[featMatch[i]];
+        for (size_t k = 0; k < q.mp.size(); k++)
+            if (qMatch[k] >= 0 && featMatch[qMatch[k]] < 0) CurrentFrame.mvpMapPoints[qMatch[k]] = static_cast<MapPoint*>(NULL);
+        return nmatches;
+    }
+
+    // ---- src/ORBmatcher.cc:473-586 (LoopClosing: points seen from a Sim3-corrected pose) and its twin :588-704
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints,
+                           std::vector<MapPoint*>& vpMatched, int th, float ratioHamming = 1.0)
+    {
+        std::vector<KeyFrame*> none;
+        return sim3_projection(pKF, Scw, vpPoints, nullptr, vpMatched, none, th, ratioHamming);
+    }
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints,
+                           const std::vector<KeyFrame*>& vpPointsKFs, std::vector<MapPoint*>& vpMatched,
+                           std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming = 1.0)
+    {
+        return sim3_projection(pKF, Scw, vpPoints, &vpPointsKFs, vpMatched, vpMatchedKF, th, ratioHamming);
+    }
+
+    // ---- src/ORBmatcher.cc:706-821 (monocular initialisation)
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10)
+    {
+        using namespace orbfe_adapter;
+        const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+        vnMatches12 = std::vector<int>(n1, -1);
+        std::vector<int32_t> oct1(n1), oct2(n2);
+        std::vector<float> ang1(n1), ang2(n2), prev(2 * (size_t)std::max(n1, 1)), kx2(n2), ky2(n2);
+        std::vector<uint8_t> tmp1, tmp2;
+        for (int i = 0; i < n1; i++) {
+            oct1[i] = F1.mvKeysUn[i].octave;
+            ang1[i] = F1.mvKeysUn[i].angle;
+            prev[2 * i] = vbPrevMatched[i].x;
+            prev[2 * i + 1] = vbPrevMatched[i].y;
+        }
+        for (int i = 0; i < n2; i++) {
+            oct2[i] = F2.mvKeysUn[i].octave;
+            ang2[i] = F2.mvKeysUn[i].angle;
+            kx2[i] = F2.mvKeysUn[i].pt.x;
+            ky2[i] = F2.mvKeysUn[i].pt.y;
+        }
+        orbfe_init_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc1 = dense_descriptors(F1.mDescriptors, n1, tmp1); a.n1 = n1; a.octave1 = oct1.data(); a.angle1 = ang1.data();
+        a.prev_xy = prev.data();
+        a.desc2 = dense_descriptors(F2.mDescriptors, n2, tmp2); a.n2 = n2; a.kx2 = kx2.data(); a.ky2 = ky2.data();
+        a.octave2 = oct2.data(); a.angle2 = ang2.data();
+        a.minX = F2.mnMinX; a.minY = F2.mnMinY; a.gridWInv = F2.mfGridElementWidthInv; a.gridHInv = F2.mfGridElementHeightInv;
+        a.window_size = windowSize; a.nnratio = mfNNratio; a.check_orientation = mbCheckOrientation ? 1 : 0;
+        std::vector<int32_t> m((size_t)std::max(n1, 1), -1);
+        const int nmatches = orbfe_search_initialization(mDevice, &a, m.data());
+        if (nmatches < 0) throw std::runtime_error("orbfe_search_initialization failed");
+        for (int i = 0; i < n1; i++) {
+            vnMatches12[i] = m[i];
+            if (m[i] >= 0) vbPrevMatched[i] = F2.mvKeysUn[m[i]].pt; // :813-816
+        }
+        return nmatches;
+    }
+
+    // ---- src/ORBmatcher.cc:965-1206: the cv::Mat twin of SearchForTriangulation_ (Tracking.cc:4313); F12 is not read
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat /*F12*/,
+                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo,
+                               const bool bCoarse = false)
+    {
+        return SearchForTriangulation_(pKF1, pKF2, cv::Matx33f(), vMatchedPairs, bOnlyStereo, bCoarse);
+    }
+    // ---- src/ORBmatcher.cc:1452-1641: the matchAndtriangulate overload has no caller in the reference; not built
+    int SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t, size_t>>&, const bool,
+                               std::vector<cv::Mat>&)
+    {
+        throw std::runtime_error("SearchForTriangulation(..., vMatchedPoints): uncalled in the reference, not built");
+    }
+
+    // ---- src/ORBmatcher.cc:1967-2191 (LoopClosing / merging): mutual projection search under a Sim3
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12,
+                     const cv::Mat& R12, const cv::Mat& t12, const float th)
+    {
+        using namespace orbfe_adapter;
+        float R1w[9], t1w[3], O1[3], R2w[9], t2w[3], O2[3];
+        kf_pose(pKF1, false, R1w, t1w, O1);
+        kf_pose(pKF2, false, R2w, t2w, O2);
+        // sR12 = s12*R12; sR21 = (1/s12)*R12^T; t21 = -sR21*t12 (:1983-1985; scalings by a double, one gemm)
+        float sR12[9], sR21[9], t12f[3], t21[3];
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) {
+                sR12[3 * i + j] = (float)((double)s12 * (double)R12.at<float>(i, j));
+                sR21[3 * i + j] = (float)((1.0 / s12) * (double)R12.at<float>(j, i));
+            }
+            t12f[i] = t12.at<float>(i);
+        }
+        for (int i = 0; i < 3; i++)
+            t21[i] = (float)(-((double)sR21[3 * i] * t12f[0] + (double)sR21[3 * i + 1] * t12f[1] + (double)sR21[3 * i + 2] * t12f[2]));
+        const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+        std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+        for (int i = 0; i < N1; i++) {
+            MapPoint* pMP = vpMatches12[i];
+            if (pMP) {
+                vbAlreadyMatched1[i] = true;
+                const int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+                if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+            }
+        }
+        // one direction: the points of `from` (camera pose Rw, tw) seen in `into` through (sR, t)
+        auto direction = [&](KeyFrame* into, const std::vector<MapPoint*>& pts, const std::vector<bool>& done,
+                             const float Rw[9], const float tw[3], const float sR[9], const float t[3],
+                             std::vector<int>& vnMatch) {
+            Queries q;
+            for (int i = 0; i < (int)pts.size(); i++) {
+                MapPoint* pMP = pts[i];
+                if (!pMP || done[i] || pMP->isBad()) continue;
+                float p3Dw[3], pA[3], pB[3];
+                world_pos(pMP, p3Dw);
+                transform(Rw, tw, p3Dw, pA);
+                transform(sR, t, pA, pB);
+                if (pB[2] < 0.0) continue;
+                const float invz = 1.0 / pB[2];
+                const float x = pB[0] * invz, y = pB[1] * invz;
+                const float u = into->fx * x + into->cx, v = into->fy * y + into->cy;
+                if (!into->IsInImage(u, v)) continue;
+                const float dist3D = norm3(pB);
+                if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+                const int nPredictedLevel = pMP->PredictScale(dist3D, into);
+                q.push(pMP, pMP->GetDescriptor().data, u, v, th * into->mvScaleFactors[nPredictedLevel], nPredictedLevel - 1,
+                       nPredictedLevel, 0.f, 0, 0.f, 0);
+                q.src.push_back(i);
+            }
+            std::vector<uint8_t> none((size_t)std::max(into->N, 1), 0);
+            std::vector<int32_t> qMatch, featMatch;
+            run_projection(*into, into->N, -1, into->mDescriptors, nullptr, none, into->mnMinX, into->mnMinY,
+                           into->mfGridElementWidthInv, into->mfGridElementHeightInv, q, 1, TH_HIGH, false, nullptr, 0, false,
+                           nullptr, nullptr, qMatch, featMatch);
+            for (size_t k = 0; k < q.mp.size(); k++) vnMatch[q.src[k]] = qMatch[k];
+        };
+        std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+        direction(pKF2, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, vnMatch1);
+        direction(pKF1, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12f, vnMatch2);
+        int nFound = 0;
+        for (int i1 = 0; i1 < N1; i1++) { // :2167-2188: keep what both directions agree on
+            const int idx2 = vnMatch1[i1];
+            if (idx2 >= 0 && vnMatch2[idx2] == i1) {
+                vpMatches12[i1] = vpMapPoints2[idx2];
+                nFound++;
+            }
+        }
+        return nFound;
+    }
+
+    // ---- src/ORBmatcher.cc:1843-1965 (LoopClosing::SearchAndFuse)
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint)
+    {
+        using namespace orbfe_adapter;
+        float Rcw[9], tcw[3], Ow[3];
+        decompose_sim3(Scw, Rcw, tcw, Ow);
+        const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+        Queries q;
+        project_points(pKF, Rcw, tcw, Ow, vpPoints, spAlreadyFound, (float)th, q);
+        std::vector<uint8_t> none((size_t)std::max(pKF->N, 1), 0);
+        for (auto& b : q.blocks) b = 0; // candidates do not hide features from each other
+        std::vector<int32_t> qMatch, featMatch;
+        run_projection(*pKF, pKF->N, -1, pKF->mDescriptors, nullptr, none, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
+                       pKF->mfGridElementHeightInv, q, 1, TH_LOW, false, nullptr, 0, false, nullptr, nullptr, qMatch, featMatch);
+        int nFused = 0;
+        for (size_t k = 0; k < q.mp.size(); k++) { // :1941-1958
+            const int bestIdx = qMatch[k];
+            if (bestIdx < 0) continue;
+            MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[q.src[k]] = pMPinKF;
+            } else {
+                q.mp[k]->AddObservation(pKF, bestIdx);
+                pKF->AddMapPoint(q.mp[k], bestIdx);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
 public:
     static const int TH_LOW = 50;
     static const int TH_HIGH = 100;
@@ -544,6 +789,61 @@ protected:
     {
         if (viewCos > 0.998) return 2.5;
         else return 4.0;
+    }
+
+    // the object walk shared by the Sim3 projection overloads and Fuse(Scw) (:491-531, :1862-1905): project every
+    // eligible point into the keyframe and queue one window search per point
+    void project_points(KeyFrame* pKF, const float Rcw[9], const float tcw[3], const float Ow[3],
+                        const std::vector<MapPoint*>& vpPoints, const std::set<MapPoint*>& spAlreadyFound, float th,
+                        orbfe_adapter::Queries& q)
+    {
+        using namespace orbfe_adapter;
+        for (int iMP = 0; iMP < (int)vpPoints.size(); iMP++) {
+            MapPoint* pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            float p3Dw[3], p3Dc[3], Pn[3];
+            world_pos(pMP, p3Dw);
+            transform(Rcw, tcw, p3Dw, p3Dc);
+            if (p3Dc[2] < 0.0) continue;
+            const cv::Point2f uv = pKF->mpCamera->project(cv::Point3f(p3Dc[0], p3Dc[1], p3Dc[2]));
+            if (!pKF->IsInImage(uv.x, uv.y)) continue;
+            const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+            const float dist = norm3(PO);
+            if (dist < pMP->GetMinDistanceInvariance() || dist > pMP->GetMaxDistanceInvariance()) continue;
+            normal_of(pMP, Pn);
+            if ((double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2] < 0.5 * dist) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist, pKF);
+            q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, th * pKF->mvScaleFactors[nPredictedLevel], nPredictedLevel - 1,
+                   nPredictedLevel, 0.f, 0, 0.f, 1);
+            q.src.push_back(iMP);
+        }
+    }
+
+    int sim3_projection(KeyFrame* pKF, const cv::Mat& Scw, const std::vector<MapPoint*>& vpPoints,
+                        const std::vector<KeyFrame*>* vpPointsKFs, std::vector<MapPoint*>& vpMatched,
+                        std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming)
+    {
+        using namespace orbfe_adapter;
+        float Rcw[9], tcw[3], Ow[3];
+        decompose_sim3(Scw, Rcw, tcw, Ow);
+        std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+        Queries q;
+        project_points(pKF, Rcw, tcw, Ow, vpPoints, spAlreadyFound, (float)th, q);
+        std::vector<uint8_t> taken((size_t)std::max(pKF->N, 1), 0); // :547-548: a feature that already has a match
+        for (int i = 0; i < pKF->N && i < (int)vpMatched.size(); i++) taken[i] = vpMatched[i] ? 1 : 0;
+        std::vector<int32_t> qMatch, featMatch;
+        // bestDist <= TH_LOW * ratioHamming on integers: th_high = floor of the product
+        const int nmatches = run_projection(*pKF, pKF->N, -1, pKF->mDescriptors, nullptr, taken, pKF->mnMinX, pKF->mnMinY,
+                                            pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, q, 1,
+                                            (int)std::floor(TH_LOW * ratioHamming), false, nullptr, 0, false, nullptr, nullptr,
+                                            qMatch, featMatch);
+        for (int i = 0; i < pKF->N; i++)
+            if (featMatch[i] >= 0) {
+                vpMatched[i] = q.mp[featMatch[i]];
+                if (vpPointsKFs) vpMatchedKF[i] = (*vpPointsKFs)[q.src[featMatch[i]]];
+            }
+        return nmatches;
     }
 
     static std::vector<uint8_t> taken_of(const std::vector<MapPoint*>& v, int n)

@@ -29,20 +29,33 @@ struct KeyPoint { // same layout as cv::KeyPoint
     float size, angle, response;
     int octave, class_id;
 };
-class Mat { // 8-bit single-channel rows x cols with a row step; just enough for the adapter
+#ifndef CV_8U
+#define CV_8U 0
+#define CV_32F 5
+#endif
+class Mat { // rows x cols of CV_8U (images, descriptors) or CV_32F (poses) with a row step; just enough for the adapters
 public:
     int rows = 0, cols = 0;
-    size_t step = 0;
+    size_t step = 0; // bytes
     uint8_t* data = nullptr;
     Mat() {}
-    Mat(int r, int c) { create(r, c); }
+    Mat(int r, int c, int type = CV_8U) { create(r, c, type); }
     Mat(int r, int c, uint8_t* ext, size_t s) : rows(r), cols(c), step(s), data(ext) {}
-    void create(int r, int c)
+    Mat(const Mat& o) { *this = o; }
+    Mat& operator=(const Mat& o)
+    {
+        rows = o.rows; cols = o.cols; step = o.step; type_ = o.type_;
+        store = o.store;
+        data = o.store.empty() ? o.data : store.data(); // owning matrices copy deep, views stay views
+        return *this;
+    }
+    void create(int r, int c, int type = CV_8U)
     {
         rows = r;
         cols = c;
-        step = (size_t)c;
-        store.assign((size_t)r * c, 0);
+        type_ = type;
+        step = (size_t)c * (type == CV_32F ? 4 : 1);
+        store.assign((size_t)r * step, 0);
         data = store.data();
     }
     void release()
@@ -53,10 +66,14 @@ public:
         data = nullptr;
     }
     bool empty() const { return rows == 0 || cols == 0 || !data; }
+    int type() const { return type_; }
     uint8_t* ptr(int r) { return data + (size_t)r * step; }
     const uint8_t* ptr(int r) const { return data + (size_t)r * step; }
+    template <class T> T& at(int r, int c = 0) { return reinterpret_cast<T*>(data + (size_t)r * step)[c]; }
+    template <class T> const T& at(int r, int c = 0) const { return reinterpret_cast<const T*>(data + (size_t)r * step)[c]; }
 
 private:
+    int type_ = CV_8U;
     std::vector<uint8_t> store;
 };
 typedef const Mat& InputArray;

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <map>
 #include <set>
+#include <tuple>
 #include <vector>
 
 #include "cv_standins.h"
@@ -71,6 +72,12 @@ public:
     float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
     bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF)
+    {
+        auto it = mObservations.find(pKF);
+        return it == mObservations.end() ? std::tuple<int, int>(-1, -1) : std::tuple<int, int>(it->second, -1);
+    }
+    int PredictScale(const float& currentDist, class Frame* pF); // MapPoint.cc:565-580, below
     int PredictScale(const float& currentDist, KeyFrame* pKF); // MapPoint.cc:548-563, below
     // what Fuse does to the map (MapPoint.cc Replace / AddObservation): recorded for the test
     void Replace(MapPoint* pMP) { mpReplaced = pMP; }
@@ -99,6 +106,8 @@ public:
     float mbf = 0, mb = 0;
     GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
     std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
+    float mfLogScaleFactor = 0;
+    int mnScaleLevels = 8;
     cv::Matx33f mRcw_; // rotation / translation of mTcw (the reference slices the 4x4 cv::Mat mTcw, ORBmatcher.cc:2204-2205)
     cv::Matx31f mtcw_;
 };
@@ -120,6 +129,13 @@ public:
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
     void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    std::set<MapPoint*> GetMapPoints()
+    { // KeyFrame.cc:467-481: the non-null, non-bad points
+        std::set<MapPoint*> s;
+        for (MapPoint* p : mvpMapPoints)
+            if (p && !p->isBad()) s.insert(p);
+        return s;
+    }
     cv::Matx33f GetRotation_() { return Rcw; }
     cv::Matx31f GetTranslation_() { return tcw; }
     cv::Matx31f GetCameraCenter_() { return Ow; }
@@ -136,6 +152,15 @@ inline int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF)
     int nScale = (int)std::ceil(std::log(ratio) / pKF->mfLogScaleFactor);
     if (nScale < 0) nScale = 0;
     else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+    return nScale;
+}
+
+inline int MapPoint::PredictScale(const float& currentDist, Frame* pF)
+{
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
     return nScale;
 }
 

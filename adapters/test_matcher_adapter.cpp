@@ -381,6 +381,220 @@ static void test_fuse(const std::string& P)
     put_i(P + "n", std::vector<int32_t>(1, nf));
 }
 
+// keyframe with features, grid, scale tables, camera (pinhole members fx.. as KeyFrame has them) and identity-free pose
+static void fill_keyframe(KeyFrame& k, GeometricCamera& cam, const std::string& P, const char* sfx = "")
+{
+    const std::string S(sfx);
+    const int n = (int)in(P + "kx" + S).count;
+    k.N = n;
+    set_keys(k.mvKeysUn, n, in(P + "kx" + S).f32(), in(P + "ky" + S).f32(), has(P + "ang" + S) ? in(P + "ang" + S).f32() : nullptr,
+             in(P + "oct" + S).i32());
+    set_desc(k.mDescriptors, n, in(P + "desc" + S).u8());
+    k.mvuRight.assign(n, -1.f);
+    const float* g = in(P + "grid").f32();
+    k.mnMinX = g[0]; k.mnMinY = g[1]; k.mnMaxX = g[2]; k.mnMaxY = g[3];
+    k.mfGridElementWidthInv = g[4]; k.mfGridElementHeightInv = g[5];
+    const Arr& sf = in(P + "sf");
+    k.mvScaleFactors.assign(sf.f32(), sf.f32() + sf.count);
+    k.mvInvLevelSigma2.resize(sf.count);
+    for (size_t i = 0; i < sf.count; i++) k.mvInvLevelSigma2[i] = 1.0f / (k.mvScaleFactors[i] * k.mvScaleFactors[i]);
+    k.mnScaleLevels = (int)sf.count;
+    k.mfLogScaleFactor = in(P + "logsf").f32()[0];
+    cam.mvParameters.assign(in(P + "cam").f32(), in(P + "cam").f32() + 4);
+    k.mpCamera = &cam;
+    k.fx = cam.mvParameters[0]; k.fy = cam.mvParameters[1]; k.cx = cam.mvParameters[2]; k.cy = cam.mvParameters[3];
+}
+static void set_point_geometry(MapPoint* p, const std::string& P, const char* sfx, size_t q)
+{
+    const std::string S(sfx);
+    p->mWorldPos = m31(in(P + "ppos" + S).f32() + 3 * q);
+    if (has(P + "pnormal" + S)) p->mNormalVector = m31(in(P + "pnormal" + S).f32() + 3 * q);
+    p->mfMinDistance = in(P + "pdist" + S).f32()[2 * q];
+    p->mfMaxDistance = in(P + "pdist" + S).f32()[2 * q + 1];
+    memcpy(p->mDescriptor, in(P + "pdesc" + S).u8() + 32 * q, 32);
+}
+static cv::Mat mat32(const float* v, int r, int c)
+{
+    cv::Mat m(r, c, CV_32F);
+    for (int i = 0; i < r; i++)
+        for (int j = 0; j < c; j++) m.at<float>(i, j) = v[i * c + j];
+    return m;
+}
+
+static void test_reloc(const std::string& P)
+{
+    Frame C;
+    GeometricCamera cam, camK;
+    fill_frame(C, P);
+    cam.mvParameters.assign(in(P + "cam").f32(), in(P + "cam").f32() + 4);
+    C.mpCamera = &cam;
+    C.mRcw_ = m33(in(P + "Rc").f32());
+    C.mtcw_ = m31(in(P + "tc").f32());
+    C.mfLogScaleFactor = in(P + "logsf").f32()[0];
+    C.mnScaleLevels = (int)in(P + "sf").count;
+    KeyFrame k;
+    const int nk = (int)in(P + "kstate").count;
+    k.N = nk;
+    set_keys(k.mvKeysUn, nk, nullptr, nullptr, in(P + "kang").f32(), nullptr);
+    k.mvpMapPoints.assign(nk, nullptr);
+    std::set<MapPoint*> found;
+    const int32_t* ks = in(P + "kstate").i32(); // 0 none, 1 ok, 2 bad, 3 already found
+    for (int i = 0; i < nk; i++) {
+        if (!ks[i]) continue;
+        MapPoint* p = k.mvpMapPoints[i] = new_point(i);
+        p->mbBad = ks[i] == 2;
+        if (ks[i] == 3) found.insert(p);
+        set_point_geometry(p, P, "", (size_t)i);
+    }
+    ORBmatcher matcher(0.9f, in(P + "ori").i32()[0] != 0);
+    const int nm = matcher.SearchByProjection(C, &k, found, in(P + "th").f32()[0], in(P + "orbdist").i32()[0]);
+    dump_frame_points(C, P + "points");
+    put_i(P + "n", std::vector<int32_t>(1, nm));
+}
+
+static void test_sim3_projection(const std::string& P)
+{
+    KeyFrame k;
+    GeometricCamera cam;
+    fill_keyframe(k, cam, P);
+    const int n = k.N, m = (int)in(P + "pstate").count;
+    std::vector<MapPoint*> pts(m);
+    std::vector<KeyFrame> kfs(5);
+    std::vector<KeyFrame*> ptKFs(m);
+    const int32_t* ps = in(P + "pstate").i32(); // 1 ok, 2 bad
+    for (int q = 0; q < m; q++) {
+        pts[q] = new_point(q);
+        pts[q]->mbBad = ps[q] == 2;
+        set_point_geometry(pts[q], P, "", (size_t)q);
+        ptKFs[q] = &kfs[q % 5];
+    }
+    std::vector<MapPoint*> vpMatched(n, nullptr);
+    std::vector<KeyFrame*> vpMatchedKF(n, nullptr);
+    const int32_t* pre = in(P + "mpre").i32(); // -1 none, >= 0 that candidate point, -2 a foreign point
+    for (int i = 0; i < n; i++)
+        if (pre[i] >= 0) vpMatched[i] = pts[pre[i]];
+        else if (pre[i] == -2) vpMatched[i] = new_point(500000 + i);
+    ORBmatcher matcher;
+    const cv::Mat Scw = mat32(in(P + "Scw").f32(), 4, 4);
+    int nm;
+    if (in(P + "twin").i32()[0])
+        nm = matcher.SearchByProjection(&k, Scw, pts, ptKFs, vpMatched, vpMatchedKF, in(P + "th").i32()[0], in(P + "ratio").f32()[0]);
+    else
+        nm = matcher.SearchByProjection(&k, Scw, pts, vpMatched, in(P + "th").i32()[0], in(P + "ratio").f32()[0]);
+    std::vector<int32_t> out(n, -1), outKF(n, -1);
+    for (int i = 0; i < n; i++) {
+        if (vpMatched[i]) out[i] = (int32_t)vpMatched[i]->mnId;
+        if (vpMatchedKF[i]) outKF[i] = (int32_t)(vpMatchedKF[i] - kfs.data());
+    }
+    put_i(P + "matched", out);
+    put_i(P + "matchedKF", outKF);
+    put_i(P + "n", std::vector<int32_t>(1, nm));
+}
+
+static void test_fuse_sim3(const std::string& P)
+{
+    KeyFrame k;
+    GeometricCamera cam;
+    fill_keyframe(k, cam, P);
+    const int n = k.N, m = (int)in(P + "pstate").count;
+    set_points(k.mvpMapPoints, n, in(P + "fstate").i32(), 100000);
+    std::vector<MapPoint*> pts(m);
+    const int32_t* ps = in(P + "pstate").i32(); // 1 ok, 2 bad, 3 one of the keyframe's own points
+    for (int q = 0; q < m; q++) {
+        if (ps[q] == 3) {
+            pts[q] = k.mvpMapPoints[in(P + "own").i32()[q]];
+            continue;
+        }
+        pts[q] = new_point(q);
+        pts[q]->mbBad = ps[q] == 2;
+        set_point_geometry(pts[q], P, "", (size_t)q);
+    }
+    std::vector<MapPoint*> vpReplacePoint(m, nullptr);
+    ORBmatcher matcher;
+    const int nf = matcher.Fuse(&k, mat32(in(P + "Scw").f32(), 4, 4), pts, in(P + "th").f32()[0], vpReplacePoint);
+    std::vector<int32_t> repl(m, -1), obsIdx(m, -1), kfPoint(n, -1);
+    for (int q = 0; q < m; q++) {
+        if (vpReplacePoint[q]) repl[q] = (int32_t)vpReplacePoint[q]->mnId;
+        if (ps[q] != 3) {
+            auto it = pts[q]->mObservations.find(&k);
+            if (it != pts[q]->mObservations.end()) obsIdx[q] = it->second;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        if (k.mvpMapPoints[i]) kfPoint[i] = (int32_t)k.mvpMapPoints[i]->mnId;
+    put_i(P + "replace", repl);
+    put_i(P + "obsIdx", obsIdx);
+    put_i(P + "kfPoint", kfPoint);
+    put_i(P + "n", std::vector<int32_t>(1, nf));
+}
+
+static void test_search_by_sim3(const std::string& P)
+{
+    KeyFrame k1, k2;
+    GeometricCamera c1, c2;
+    fill_keyframe(k1, c1, P, "1");
+    fill_keyframe(k2, c2, P, "2");
+    k1.Rcw = m33(in(P + "R1").f32()); k1.tcw = m31(in(P + "t1").f32());
+    k2.Rcw = m33(in(P + "R2").f32()); k2.tcw = m31(in(P + "t2").f32());
+    auto points = [&](KeyFrame& k, const char* sfx, long idBase) {
+        const std::string S(sfx);
+        const int32_t* st = in(P + "kstate" + S).i32(); // 0 none, 1 ok, 2 bad
+        k.mvpMapPoints.assign(k.N, nullptr);
+        for (int i = 0; i < k.N; i++) {
+            if (!st[i]) continue;
+            MapPoint* p = k.mvpMapPoints[i] = new_point(idBase + i);
+            p->mbBad = st[i] == 2;
+            p->mObservations[&k] = i;
+            set_point_geometry(p, P, sfx, (size_t)i);
+        }
+    };
+    points(k1, "1", 300000);
+    points(k2, "2", 400000);
+    std::vector<MapPoint*> vpMatches12(k1.N, nullptr);
+    const int32_t* pre = in(P + "pre12").i32(); // -1, or the index in keyframe 2 it is already matched to
+    for (int i = 0; i < k1.N; i++)
+        if (pre[i] >= 0) vpMatches12[i] = k2.mvpMapPoints[pre[i]];
+    ORBmatcher matcher;
+    const float s12 = in(P + "s12").f32()[0];
+    const int nf = matcher.SearchBySim3(&k1, &k2, vpMatches12, s12, mat32(in(P + "R12").f32(), 3, 3), mat32(in(P + "t12").f32(), 3, 1),
+                                        in(P + "th").f32()[0]);
+    std::vector<int32_t> out(k1.N, -1);
+    for (int i = 0; i < k1.N; i++)
+        if (vpMatches12[i]) out[i] = (int32_t)vpMatches12[i]->mnId - 400000;
+    put_i(P + "matches12", out);
+    put_i(P + "n", std::vector<int32_t>(1, nf));
+}
+
+static void test_initialization(const std::string& P)
+{
+    Frame F1, F2;
+    const int n1 = (int)in(P + "oct1").count, n2 = (int)in(P + "oct2").count;
+    F1.N = n1;
+    F2.N = n2;
+    set_keys(F1.mvKeysUn, n1, nullptr, nullptr, in(P + "ang1").f32(), in(P + "oct1").i32());
+    set_keys(F2.mvKeysUn, n2, in(P + "kx2").f32(), in(P + "ky2").f32(), in(P + "ang2").f32(), in(P + "oct2").i32());
+    set_desc(F1.mDescriptors, n1, in(P + "desc1").u8());
+    set_desc(F2.mDescriptors, n2, in(P + "desc2").u8());
+    const float* g = in(P + "grid").f32();
+    F2.mnMinX = g[0]; F2.mnMinY = g[1]; F2.mfGridElementWidthInv = g[2]; F2.mfGridElementHeightInv = g[3];
+    std::vector<cv::Point2f> prev(n1);
+    for (int i = 0; i < n1; i++) {
+        prev[i].x = in(P + "prev").f32()[2 * i];
+        prev[i].y = in(P + "prev").f32()[2 * i + 1];
+    }
+    std::vector<int> vnMatches12;
+    ORBmatcher matcher(in(P + "ratio").f32()[0], in(P + "ori").i32()[0] != 0);
+    const int nm = matcher.SearchForInitialization(F1, F2, prev, vnMatches12, in(P + "window").i32()[0]);
+    std::vector<float> prevOut(2 * (size_t)n1);
+    for (int i = 0; i < n1; i++) {
+        prevOut[2 * i] = prev[i].x;
+        prevOut[2 * i + 1] = prev[i].y;
+    }
+    put_i(P + "matches12", std::vector<int32_t>(vnMatches12.begin(), vnMatches12.end()));
+    put(P + "prev", 2, prevOut.data(), prevOut.size());
+    put_i(P + "n", std::vector<int32_t>(1, nm));
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 3 || !load(argv[1])) return 2;
@@ -393,6 +607,11 @@ int main(int argc, char** argv)
         for (int k = 0; has("p0_" + std::to_string(k) + ".kx"); k++) test_proj_local("p0_" + std::to_string(k) + ".");
         for (int k = 0; has("p1_" + std::to_string(k) + ".kx"); k++) test_proj_last("p1_" + std::to_string(k) + ".");
         for (int k = 0; has("fu" + std::to_string(k) + ".kx"); k++) test_fuse("fu" + std::to_string(k) + ".");
+        for (int k = 0; has("p2_" + std::to_string(k) + ".kx"); k++) test_reloc("p2_" + std::to_string(k) + ".");
+        for (int k = 0; has("s3_" + std::to_string(k) + ".kx"); k++) test_sim3_projection("s3_" + std::to_string(k) + ".");
+        for (int k = 0; has("fs" + std::to_string(k) + ".kx"); k++) test_fuse_sim3("fs" + std::to_string(k) + ".");
+        for (int k = 0; has("ss" + std::to_string(k) + ".kx1"); k++) test_search_by_sim3("ss" + std::to_string(k) + ".");
+        for (int k = 0; has("in" + std::to_string(k) + ".oct1"); k++) test_initialization("in" + std::to_string(k) + ".");
     } catch (const std::exception& e) {
         fprintf(stderr, "adapter threw: %s\n", e.what());
         return 4;

@@ -384,6 +384,284 @@ def _fuse(f, tag, oracle, seed, n, m, th):
     return check
 
 
+CAM = np.array([512, 512, 384, 256], np.float32)
+
+
+def _projected_points(rng, fr, m, tcw, level_of, far_frac=0.04, zchoices=(2.0, 4.0, 8.0), noise=1.0):
+    """m world points that project (camera pose R = I, t = tcw, CAM) onto dyadic pixels near random features of `fr`.
+    Returns (tgt, u, v, z, world pos float32, camera-frame distance, predicted level)."""
+    n = len(fr["kx"])
+    tgt = rng.integers(0, n, m)
+    tgt[: m // 3] = rng.integers(0, max(n // 4, 1), m // 3)
+    tgt[m // 3: m // 2] = tgt[: m // 2 - m // 3]
+    u = np.round((fr["kx"][tgt] + rng.normal(0, noise, m)) * 8) / 8
+    v = np.round((fr["ky"][tgt] + rng.normal(0, noise, m)) * 8) / 8
+    u[rng.random(m) < far_frac] = 900.0                                   # outside the image
+    z = rng.choice(list(zchoices), m)
+    z[rng.random(m) < far_frac] = -4.0                                    # behind the camera
+    xc = np.stack([(u - 384) * z / 512, (v - 256) * z / 512, z], 1)
+    pos = (xc - np.asarray(tcw, np.float64)).astype(np.float32)
+    assert np.array_equal(pos.astype(np.float64) + np.asarray(tcw, np.float64), xc)
+    dist = np.linalg.norm(xc, axis=1)
+    level = np.clip(fr["oct"][tgt] + level_of(rng, m), 0, 7)
+    return tgt, u, v, z, pos, xc, dist, level
+
+
+def _dist_range(dist, level, wrong):
+    maxd = (dist * 1.2 ** (level - 0.5)).astype(np.float32)               # PredictScale = ceil(level - 0.5) = level
+    maxd[wrong] = (dist[wrong] * 0.5).astype(np.float32)                   # outside the scale-invariance range
+    return np.stack([(maxd / np.float32(1.2 ** 7)).astype(np.float32), maxd], 1)
+
+
+def _kf_common(f, tag, fr, sfx=""):
+    for k in ("kx", "ky", "oct", "desc", "ang"):
+        _put(f, tag + k + sfx, fr[k])
+    if not sfx or sfx == "1":
+        _put(f, tag + "grid", np.array([0, 0, 768, 512, np.float32(64) / np.float32(768), np.float32(48) / np.float32(512)], np.float32))
+        _put(f, tag + "sf", SF)
+        _put(f, tag + "logsf", np.array([np.log(1.2)], np.float32))
+        _put(f, tag + "cam", CAM)
+
+
+def _reloc(f, tag, oracle, seed, n, nk, th, orbdist, ori):
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, False)
+    fstate = rng.choice([0, 0, 0, 0, 0, 1, 3], n).astype(np.int32)         # any point at a feature hides it (:2484)
+    _put_frame(f, tag, fr, fstate)
+    tc = np.array([0.25, -0.5, 0.125], np.float32)
+    tgt, u, v, z, pos, xc, dist, level = _projected_points(rng, fr, nk, tc, lambda r, m: r.integers(-1, 2, m), noise=2.0)
+    wrong = rng.random(nk) < 0.05
+    kstate = rng.choice([0, 1, 1, 1, 1, 2, 3], nk).astype(np.int32)
+    kang = rng.uniform(0, 360, nk).astype(np.float32)
+    pdesc = _noisy(fr["desc"][tgt], rng)
+    for k, val in (("cam", CAM), ("Rc", np.eye(3, dtype=np.float32)), ("tc", tc), ("logsf", np.array([np.log(1.2)], np.float32)),
+                   ("kstate", kstate), ("kang", kang), ("ppos", pos), ("pdist", _dist_range(dist, level, wrong)), ("pdesc", pdesc),
+                   ("th", np.array([th], np.float32)), ("orbdist", np.array([orbdist], np.int32)), ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        # (this overload has no depth test: a point behind the camera projects to the same pixel, :2444-2449)
+        ok = (kstate == 1) & (u >= 0) & (u <= 768) & (v >= 0) & (v <= 512) & ~wrong
+        keep = np.nonzero(ok)[0]
+        lv = level[keep].astype(np.int32)
+        pr = _frame_problem(fr, fstate)
+        pr["taken"] = (fstate > 0).astype(np.uint8)
+        pr.update(mode=1, nnratio=0.9, th_high=orbdist, check_orientation=int(ori), qdesc=pdesc[keep], qx=u[keep].astype(np.float32),
+                  qy=v[keep].astype(np.float32), qr=(np.float32(th) * SF[lv]).astype(np.float32), qmin_level=lv - 1,
+                  qmax_level=lv + 1, qxr=np.zeros(len(keep), np.float32), qangle=kang[keep], qblocks=np.ones(len(keep), np.uint8))
+        nm, qm, fm = oracle.search_projection(pr)
+        assert res[tag + "n"][0] == nm and nm > 30, (tag, nm)
+        assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, qm, keep)), tag
+    return check
+
+
+def _sim3_objects(rng, fr, m, tcw):
+    tgt, u, v, z, pos, xc, dist, level = _projected_points(rng, fr, m, tcw, lambda r, mm: r.integers(0, 2, mm))
+    wrong = rng.random(m) < 0.05
+    flip = rng.random(m) < 0.05
+    normal = xc / np.maximum(dist, 1e-9)[:, None]
+    normal[flip] *= -1
+    visible = (z > 0) & (u >= 0) & (u < 768) & (v >= 0) & (v < 512) & ~wrong & ~flip
+    return tgt, u, v, z, pos, dist, level, wrong, normal.astype(np.float32), visible
+
+
+def _scw(s, tcw):
+    S = np.zeros((4, 4), np.float32)
+    S[:3, :3] = np.float32(s) * np.eye(3, dtype=np.float32)
+    S[:3, 3] = np.float32(s) * np.asarray(tcw, np.float32)
+    S[3, 3] = 1
+    return S
+
+
+def _sim3_projection(f, tag, oracle, seed, n, m, th, ratio, twin):
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, False)
+    _kf_common(f, tag, fr)
+    tcw = np.array([0.5, 0.25, -0.125])
+    tgt, u, v, z, pos, dist, level, wrong, normal, visible = _sim3_objects(rng, fr, m, tcw)
+    pstate = rng.choice([1, 1, 1, 1, 1, 2], m).astype(np.int32)
+    pdesc = _noisy(fr["desc"][tgt], rng, 0.0, 0.2)
+    # vpMatched on entry: a tenth of the features hold one of the candidate points already (those points are then
+    # skipped, :488-495), another tenth a foreign point
+    mpre = np.full(n, -1, np.int32)
+    pick = rng.permutation(n)[: n // 5]
+    cand = rng.permutation(m)[: n // 10]
+    mpre[pick[: n // 10]] = cand
+    mpre[pick[n // 10:]] = -2
+    for k, val in (("Scw", _scw(2.0, tcw)), ("pstate", pstate), ("ppos", pos), ("pnormal", normal), ("pdist", _dist_range(dist, level, wrong)),
+                   ("pdesc", pdesc), ("mpre", mpre), ("th", np.array([th], np.int32)), ("ratio", np.array([ratio], np.float32)),
+                   ("twin", np.array([int(twin)], np.int32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        found = set(int(c) for c in cand)
+        keep = np.array([q for q in range(m) if pstate[q] == 1 and q not in found and visible[q]])
+        lv = level[keep].astype(np.int32)
+        pr = _frame_problem(fr, np.zeros(n, np.int32))
+        pr.pop("uright")
+        pr.update(taken=(mpre != -1).astype(np.uint8), mode=1, nnratio=0.6, th_high=int(np.floor(50 * ratio)), check_orientation=0,
+                  qdesc=pdesc[keep], qx=u[keep].astype(np.float32), qy=v[keep].astype(np.float32),
+                  qr=(np.float32(th) * SF[lv]).astype(np.float32), qmin_level=lv - 1, qmax_level=lv,
+                  qangle=np.zeros(len(keep), np.float32), qblocks=np.ones(len(keep), np.uint8))
+        nm, qm, fm = oracle.search_projection(pr)
+        assert res[tag + "n"][0] == nm and nm > 30, (tag, nm)
+        exp = np.where(mpre >= 0, mpre, np.where(mpre == -2, 500000 + np.arange(n), -1)).astype(np.int32)
+        w = fm >= 0
+        exp[w] = keep[fm[w]]
+        assert np.array_equal(res[tag + "matched"], exp), tag
+        expkf = np.full(n, -1, np.int32)
+        if twin:
+            expkf[w] = keep[fm[w]] % 5
+        assert np.array_equal(res[tag + "matchedKF"], expkf), tag
+    return check
+
+
+def _fuse_sim3(f, tag, oracle, seed, n, m, th):
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, False)
+    _kf_common(f, tag, fr)
+    fstate = rng.choice([0, 0, 1, 1, 2], n).astype(np.int32)
+    _put(f, tag + "fstate", fstate)
+    tcw = np.array([-0.25, 0.5, 0.0625])
+    tgt, u, v, z, pos, dist, level, wrong, normal, visible = _sim3_objects(rng, fr, m, tcw)
+    pstate = rng.choice([1, 1, 1, 1, 1, 1, 2, 3], m).astype(np.int32)
+    good = np.nonzero(fstate == 1)[0]
+    own = good[rng.integers(0, len(good), m)].astype(np.int32)             # for pstate 3: one of the keyframe's points
+    pdesc = _noisy(fr["desc"][tgt], rng, 0.0, 0.2)
+    for k, val in (("Scw", _scw(2.0, tcw)), ("pstate", pstate), ("own", own), ("ppos", pos), ("pnormal", normal),
+                   ("pdist", _dist_range(dist, level, wrong)), ("pdesc", pdesc), ("th", np.array([th], np.float32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        keep = np.nonzero((pstate == 1) & visible)[0]
+        lv = level[keep].astype(np.int32)
+        pr = _frame_problem(fr, np.zeros(n, np.int32))
+        pr.pop("uright")
+        pr.update(mode=1, nnratio=0.6, th_high=50, check_orientation=0, qdesc=pdesc[keep], qx=u[keep].astype(np.float32),
+                  qy=v[keep].astype(np.float32), qr=(np.float32(th) * SF[lv]).astype(np.float32), qmin_level=lv - 1, qmax_level=lv,
+                  qangle=np.zeros(len(keep), np.float32), qblocks=np.zeros(len(keep), np.uint8), taken=np.zeros(n, np.uint8))
+        _, qm, _ = oracle.search_projection(pr)
+        point = np.where(fstate > 0, 100000 + np.arange(n), -1)
+        bad = {100000 + i: bool(fstate[i] == 2) for i in range(n)}
+        repl, obs_idx = np.full(m, -1), np.full(m, -1)
+        nfused = 0
+        for k, q in enumerate(keep):                                        # :1941-1958
+            idx = qm[k]
+            if idx < 0:
+                continue
+            if point[idx] >= 0:
+                if not bad.get(int(point[idx]), False):
+                    repl[q] = point[idx]
+            else:
+                obs_idx[q] = idx
+                point[idx] = q
+            nfused += 1
+        assert res[tag + "n"][0] == nfused and nfused > 50, (tag, nfused)
+        assert np.array_equal(res[tag + "replace"], repl) and np.array_equal(res[tag + "obsIdx"], obs_idx), tag
+        assert np.array_equal(res[tag + "kfPoint"], point), tag
+    return check
+
+
+def _search_by_sim3(f, tag, oracle, seed, n, th):
+    """Two keyframes that see the same n world points; keyframe 2 is keyframe 1 shifted by 1/16 along x (so that the
+    projections into both are exact), the Sim3 handed over is the true relative pose (s12 = 1, R12 = I)."""
+    rng = np.random.default_rng(seed)
+    fr1 = _frame_arrays(rng, n, False)
+    t1 = np.array([0.25, -0.5, 0.0])
+    t2 = t1 + np.array([0.0625, 0.0, 0.0])
+    u1 = np.round(fr1["kx"] * 8) / 8
+    v1 = np.round(fr1["ky"] * 8) / 8
+    z = rng.choice([2.0, 4.0, 8.0], n)
+    xc1 = np.stack([(u1 - 384) * z / 512, (v1 - 256) * z / 512, z], 1)
+    world = xc1 - t1
+    xc2 = world + t2
+    u2, v2 = 512 * xc2[:, 0] / z + 384, 512 * xc2[:, 1] / z + 256
+    assert np.array_equal(np.round(u2 * 8) / 8, u2)
+    fr1["kx"], fr1["ky"] = (u1 + rng.normal(0, 1.0, n)).astype(np.float32), (v1 + rng.normal(0, 1.0, n)).astype(np.float32)
+    perm = rng.permutation(n)                                               # keyframe 2 lists the points in another order
+    fr2 = dict(kx=(u2 + rng.normal(0, 1.0, n)).astype(np.float32)[perm], ky=(v2 + rng.normal(0, 1.0, n)).astype(np.float32)[perm],
+               oct=np.clip(fr1["oct"] + rng.integers(-1, 1, n), 0, 7).astype(np.int32)[perm],
+               desc=_noisy(fr1["desc"], rng, 0.0, 0.15)[perm], ang=fr1["ang"][perm])
+    _kf_common(f, tag, fr1, "1")
+    _kf_common(f, tag, fr2, "2")
+    pos = world.astype(np.float32)
+    assert np.array_equal(pos.astype(np.float64), world)
+    level = np.clip(fr1["oct"] + rng.integers(0, 2, n), 0, 7)
+    dmean = 0.5 * (np.linalg.norm(xc1, axis=1) + np.linalg.norm(xc2, axis=1))
+    pdist = _dist_range(dmean, level, rng.random(n) < 0.04)
+    k1 = rng.choice([0, 1, 1, 1, 1, 2], n).astype(np.int32)
+    k2 = rng.choice([0, 1, 1, 1, 1, 2], n).astype(np.int32)
+    d1p, d2p = _noisy(fr1["desc"], rng, 0.0, 0.1), _noisy(fr1["desc"], rng, 0.0, 0.1)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)                                               # world point j is feature inv[j] of keyframe 2
+    pre12 = np.full(n, -1, np.int32)
+    cand = np.nonzero((k1 == 1) & (k2 == 1))[0][:: 9]
+    pre12[cand] = inv[cand]                                                # some pairs are matched already
+    for k, val in (("kstate1", k1), ("ppos1", pos), ("pdist1", pdist), ("pdesc1", d1p),
+                   ("kstate2", k2[perm]), ("ppos2", pos[perm]), ("pdist2", pdist[perm]), ("pdesc2", d2p[perm]),
+                   ("R1", np.eye(3, dtype=np.float32)), ("t1", t1.astype(np.float32)), ("R2", np.eye(3, dtype=np.float32)),
+                   ("t2", t2.astype(np.float32)), ("s12", np.array([1.0], np.float32)), ("R12", np.eye(3, dtype=np.float32)),
+                   ("t12", (t1 - t2).astype(np.float32)), ("pre12", pre12), ("th", np.array([th], np.float32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        def direction(fr_into, pts_state, done, uu, vv, xc, lv_src, desc, order):
+            dist = np.linalg.norm(xc, axis=1)
+            lvl = np.array([int(np.clip(np.ceil(np.log(pdist[j, 1] / dist[j]) / np.log(1.2)), 0, 7)) for j in range(n)])
+            ok = [j for j in order if pts_state[j] == 1 and not done[j] and 0 <= uu[j] < 768 and 0 <= vv[j] < 512
+                  and pdist[j, 0] * np.float32(0.8) <= np.float32(dist[j]) <= pdist[j, 1] * np.float32(1.2)]
+            ok = np.array(ok)
+            lv = lvl[ok].astype(np.int32)
+            pr = _frame_problem(fr_into, np.zeros(n, np.int32))
+            pr.pop("uright")
+            pr.update(mode=1, nnratio=0.6, th_high=100, check_orientation=0, qdesc=desc[ok], qx=uu[ok].astype(np.float32),
+                      qy=vv[ok].astype(np.float32), qr=(np.float32(th) * SF[lv]).astype(np.float32), qmin_level=lv - 1,
+                      qmax_level=lv, qangle=np.zeros(len(ok), np.float32), qblocks=np.zeros(len(ok), np.uint8),
+                      taken=np.zeros(n, np.uint8))
+            _, qm, _ = oracle.search_projection(pr)
+            return ok, qm
+        done1 = pre12 >= 0                                                   # by keyframe-1 feature (= world point) index
+        done2w = np.zeros(n, bool)
+        done2w[np.nonzero(done1)[0]] = True                                 # the same world points, seen from keyframe 2
+        ok1, qm1 = direction(fr2, k1, done1, u2, v2, xc2, level, d1p, range(n))          # points of 1 into keyframe 2
+        ok2, qm2 = direction(fr1, k2, done2w, u1, v1, xc1, level, d2p, list(perm))       # points of 2 (its order) into 1
+        m1 = np.full(n, -1)
+        m1[ok1] = qm1                                                       # keyframe-1 feature -> keyframe-2 feature
+        m2 = np.full(n, -1)
+        m2[inv[ok2]] = qm2                                                  # keyframe-2 feature -> keyframe-1 feature
+        exp = pre12.copy()
+        nfound = 0
+        for i1 in range(n):
+            if m1[i1] >= 0 and m2[m1[i1]] == i1:
+                exp[i1] = m1[i1]
+                nfound += 1
+        assert res[tag + "n"][0] == nfound and nfound > 100, (tag, nfound)
+        assert np.array_equal(res[tag + "matches12"], exp), tag
+    return check
+
+
+def _initialization(f, tag, oracle, seed, n1, n2, window, ratio, ori):
+    import matcher_inputs as MI
+    pr = MI.initialization_problem(seed, n1=n1, n2=n2, window=window, nnratio=ratio, check_orientation=ori)
+    for k, val in (("oct1", pr["octave1"]), ("ang1", pr["angle1"]), ("desc1", pr["desc1"]), ("prev", pr["prev_xy"]),
+                   ("oct2", pr["octave2"]), ("ang2", pr["angle2"]), ("desc2", pr["desc2"]), ("kx2", pr["kx2"]), ("ky2", pr["ky2"]),
+                   ("grid", np.array([pr["minX"], pr["minY"], pr["gridWInv"], pr["gridHInv"]], np.float32)),
+                   ("window", np.array([pr["window_size"]], np.int32)), ("ratio", np.array([ratio], np.float32)),
+                   ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, np.ascontiguousarray(val))
+
+    def check(res):
+        nm, m12 = oracle.search_initialization(pr)
+        assert res[tag + "n"][0] == nm and nm > 50, (tag, nm)
+        assert np.array_equal(res[tag + "matches12"], m12), tag
+        prev = np.ascontiguousarray(pr["prev_xy"], np.float32).reshape(-1, 2).copy()
+        w = m12 >= 0
+        prev[w, 0] = pr["kx2"][m12[w]]
+        prev[w, 1] = pr["ky2"][m12[w]]
+        assert np.array_equal(res[tag + "prev"].reshape(-1, 2), prev), tag
+    return check
+
+
 def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle):
     exe = str(tmp_path / "test_matcher_adapter")
     libdir = os.path.join(ROOT, "orb_slam3_detailed_comments_kor_amd")
@@ -409,6 +687,14 @@ def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle):
         checks.append(_proj_last(f, "p1_3.", oracle, 54, 1000, 800, 15.0, False, 1.0, True, True))     # monocular
         checks.append(_fuse(f, "fu0.", oracle, 61, 1500, 1200, 3.0))
         checks.append(_fuse(f, "fu1.", oracle, 62, 900, 700, 4.0))
+        checks.append(_reloc(f, "p2_0.", oracle, 71, 1500, 1100, 10.0, 100, True))
+        checks.append(_reloc(f, "p2_1.", oracle, 72, 1000, 900, 3.0, 64, False))
+        checks.append(_sim3_projection(f, "s3_0.", oracle, 81, 1500, 1200, 8, 0.9, True))
+        checks.append(_sim3_projection(f, "s3_1.", oracle, 82, 1000, 800, 10, 1.0, False))
+        checks.append(_fuse_sim3(f, "fs0.", oracle, 91, 1500, 1200, 4.0))
+        checks.append(_search_by_sim3(f, "ss0.", oracle, 101, 1200, 7.5))
+        checks.append(_initialization(f, "in0.", oracle, 111, 1500, 1400, 100, 0.9, True))
+        checks.append(_initialization(f, "in1.", oracle, 112, 900, 1000, 30, 0.7, False))
     subprocess.check_call([exe, scen, resf])
     res = _read(resf)
     for c in checks:
