@@ -495,8 +495,11 @@ __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (in
 // The tile pitch is a compile-time constant of PD dwords, PD odd: every neighbour / ring / NMS read is an immediate
 // offset from one address, and phase A deals the zone's dwords to the lanes COLUMN by column (consecutive lanes =
 // consecutive rows), so that the 32 lanes of an LDS access group hit 32 different banks.
+#ifndef ORBFE_FAST_WAVES_ATTR
+#define ORBFE_FAST_WAVES_ATTR
+#endif
 template <int NT, int PD>
-__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
+__global__ __launch_bounds__(NT) ORBFE_FAST_WAVES_ATTR void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                    const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
                                                    size_t candImgStride, int32_t* __restrict__ cellCount,
                                                    int nCellsTotal, int iniTh, int minTh, int tileRows, int xcdGroup,
