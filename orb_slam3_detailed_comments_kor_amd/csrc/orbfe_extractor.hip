@@ -1922,11 +1922,11 @@ int orbfe_debug_blurred_patch(orbfe_ctx* c, int img, int kp_index, uint8_t* out3
     uint8_t* desc = const_cast<uint8_t*>(c->lastDesc);
     const dim3 grid((unsigned)((c->maxKp + 3) / 4), 1u);
     if (tapSum > 256)
-        hipLaunchKernelGGL((k_orient_blur_desc<0, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
+        hipLaunchKernelGGL((k_orient_blur_desc<0, true, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
                            c->d_work.p, c->lastN, c->lastCap, kps, desc, c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0,
                            trigTab.codes, trigTab.full, c->atanFma, d.p, kp_index);
     else
-        hipLaunchKernelGGL((k_orient_blur_desc<0, false>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
+        hipLaunchKernelGGL((k_orient_blur_desc<0, false, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
                            c->d_work.p, c->lastN, c->lastCap, kps, desc, c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0,
                            trigTab.codes, trigTab.full, c->atanFma, d.p, kp_index);
     hipError_t e = hipMemcpyAsync(out37x37, d.p, 37 * 37, hipMemcpyDeviceToHost, c->stream);

@@ -1571,7 +1571,8 @@ __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
 }
 // SAT: the taps sum to more than 256 (non-default taps only), so the horizontal pass can exceed 16 bits and
 //      saturates like ufixedpoint16; with the default taps the sum is at most 255 * 256 and the min is dropped.
-template <int MODE, bool SAT>
+// DBG: the instantiation orbfe_debug_blurred_patch launches (the tap's loop would otherwise sit in the hot kernel).
+template <int MODE, bool SAT, bool DBG = false>
 __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                           const OrbLevelGeom* __restrict__ lg,
                                                           const OrbDescWork* __restrict__ work,
@@ -1832,8 +1833,10 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     WAVE_SYNC();
 
-    if (dbgPatch && w.dest == dbgDest) // test tap (orbfe_debug_blurred_patch): GaussianBlur's output under this keypoint
+    if (DBG && dbgPatch && w.dest == dbgDest) { // test tap (orbfe_debug_blurred_patch): GaussianBlur's output under this keypoint
+#pragma nounroll
         for (int i = lane; i < DESC_BW * DESC_BW; i += 64) dbgPatch[i] = bl[(i / DESC_BW) * DESC_BP + i % DESC_BW];
+    }
     // ---- steered BRIEF (:106-145)
     float a, b;
     if (MODE == 0) {
