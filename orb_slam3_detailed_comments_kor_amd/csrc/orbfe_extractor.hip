@@ -1350,6 +1350,8 @@ void orbfe_destroy(orbfe_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->sIn) (void)hipStreamSynchronize(c->sIn);   // submitted batches nobody waited for: their copies still
+    if (c->sOut) (void)hipStreamSynchronize(c->sOut); // touch the slots' buffers (and the caller's arrays)
     c->d_pyr.release();
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release();
