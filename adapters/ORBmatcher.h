@@ -142,10 +142,11 @@ inline void normal_of(MapPoint* p, float x[3])
     const cv::Matx31f w = p->GetNormal_();
     for (int i = 0; i < 3; i++) x[i] = w(i);
 }
-inline void kf_pose(KeyFrame* pKF, bool /*bRight*/, float R[9], float t[3], float O[3])
+inline void kf_pose(KeyFrame* pKF, bool bRight, float R[9], float t[3], float O[3])
 {
-    const cv::Matx33f Rm = pKF->GetRotation_();
-    const cv::Matx31f tm = pKF->GetTranslation_(), Om = pKF->GetCameraCenter_();
+    const cv::Matx33f Rm = bRight ? pKF->GetRightRotation_() : pKF->GetRotation_();
+    const cv::Matx31f tm = bRight ? pKF->GetRightTranslation_() : pKF->GetTranslation_();
+    const cv::Matx31f Om = bRight ? pKF->GetRightCameraCenter_() : pKF->GetCameraCenter_();
     for (int i = 0; i < 9; i++) R[i] = Rm.val[i];
     for (int i = 0; i < 3; i++) {
         t[i] = tm(i);
@@ -153,6 +154,15 @@ inline void kf_pose(KeyFrame* pKF, bool /*bRight*/, float R[9], float t[3], floa
     }
 }
 #endif
+
+// rotation / translation of the 3x4 CV_32F Frame::mTrl (left camera -> right camera, include/Frame.h)
+inline void frame_trl(const Frame& F, float R[9], float t[3])
+{
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) R[3 * i + j] = F.mTrl.at<float>(i, j);
+        t[i] = F.mTrl.at<float>(i, 3);
+    }
+}
 
 // x_c = R x_w + t as cv::Mat evaluates `Rcw*x3Dw+tcw` for CV_32F (one gemm with double accumulators, rounded once)
 inline void transform(const float R[9], const float t[3], const float xw[3], float xc[3])
@@ -448,14 +458,16 @@ public:
         return nmatches;
     }
 
-    // ---- src/ORBmatcher.cc:2193-2419 (Tracking::TrackWithMotionModel); frames without a second camera
+    // ---- src/ORBmatcher.cc:2193-2419 (Tracking::TrackWithMotionModel), with the right-camera searches of a
+    // two-camera rig (:2326-2395): one more query per point, into the right grid
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
     {
         using namespace orbfe_adapter;
-        if (CurrentFrame.Nleft != -1) throw std::runtime_error("two-camera rigs are not wrapped by this overload");
-        float Rcw[9], tcw[3], Rlw[9], tlw[3];
+        const bool rig = CurrentFrame.Nleft != -1;
+        float Rcw[9], tcw[3], Rlw[9], tlw[3], Rrl[9], trl[3];
         frame_pose(CurrentFrame, Rcw, tcw);
         frame_pose(LastFrame, Rlw, tlw);
+        if (rig) frame_trl(CurrentFrame, Rrl, trl);
         // twc = -Rcw^T tcw; tlc = Rlw twc + tlw (:2207-2212)
         float twc[3], tlc[3];
         for (int i = 0; i < 3; i++)
@@ -486,9 +498,18 @@ public:
             const float ur = uv.x - CurrentFrame.mbf * invzc; // :2272
             // (a temporal point of UpdateLastFrame has no observations: it does not hide its feature from later points)
             q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, radius, lo, hi, ur, 0, kpLF.angle, pMP->Observations() > 0);
+            if (rig) {
+                // :2326-2341: the point in the right camera, projected with mpCamera (sic); same radius and levels, no
+                // image-bounds test; the block stands behind `if(vIndices2.empty()) continue;` of the left search (bit 2)
+                float x3Dr[3];
+                transform(Rrl, trl, x3Dc, x3Dr);
+                const cv::Point2f uvR = CurrentFrame.mpCamera->project(cv::Point3f(x3Dr[0], x3Dr[1], x3Dr[2]));
+                q.push(pMP, pMP->GetDescriptor().data, uvR.x, uvR.y, radius, lo, hi, 0.f, 1 | 4, kpLF.angle,
+                       pMP->Observations() > 0);
+            }
         }
         std::vector<int32_t> qMatch, featMatch;
-        const int nmatches = run_projection(CurrentFrame, CurrentFrame.N, -1, CurrentFrame.mDescriptors,
+        const int nmatches = run_projection(CurrentFrame, CurrentFrame.N, CurrentFrame.Nleft, CurrentFrame.mDescriptors,
                                             CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data(),
                                             taken_of(CurrentFrame.mvpMapPoints, CurrentFrame.N), CurrentFrame.mnMinX,
                                             CurrentFrame.mnMinY, CurrentFrame.mfGridElementWidthInv,
@@ -502,13 +523,14 @@ public:
         return nmatches;
     }
 
-    // ---- src/ORBmatcher.cc:1643-1841 (LocalMapping::SearchInNeighbors); keyframes without a second camera
+    // ---- src/ORBmatcher.cc:1643-1841 (LocalMapping::SearchInNeighbors); bRight = the right camera of a rig (:1647-1658)
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false)
     {
         using namespace orbfe_adapter;
-        if (bRight || pKF->NLeft != -1) throw std::runtime_error("two-camera rigs are not wrapped by this overload");
+        if (bRight && pKF->NLeft == -1) throw std::runtime_error("Fuse(bRight): the keyframe has no second camera");
         float Rcw[9], tcw[3], Ow[3];
         kf_pose(pKF, bRight, Rcw, tcw, Ow);
+        GeometricCamera* pCamera = bRight ? pKF->mpCamera2 : pKF->mpCamera;
         const float bf = pKF->mbf;
         Queries q;
         for (size_t i = 0; i < vpMapPoints.size(); i++) { // :1690-1742, unchanged conditions
@@ -521,7 +543,7 @@ public:
             transform(Rcw, tcw, p3Dw, p3Dc);
             if (p3Dc[2] < 0.0f) continue;
             const float invz = 1 / p3Dc[2];
-            const cv::Point2f uv = pKF->mpCamera->project(cv::Point3f(p3Dc[0], p3Dc[1], p3Dc[2]));
+            const cv::Point2f uv = pCamera->project(cv::Point3f(p3Dc[0], p3Dc[1], p3Dc[2]));
             if (!pKF->IsInImage(uv.x, uv.y)) continue;
             const float ur = uv.x - bf * invz;
             const float maxDistance = pMP->GetMaxDistanceInvariance();
@@ -534,11 +556,14 @@ public:
             const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
             const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
             // the level test of :1771-1772 is the window's level range; the chi2 test of :1774-1799 runs on the device
-            q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, radius, nPredictedLevel - 1, nPredictedLevel, ur, 0, 0.f, 0);
+            // (a right-camera query reads its candidates from the right grid and mvuRight with the camera-local index,
+            // :1762-1775, :1801 -- both on the device)
+            q.push(pMP, pMP->GetDescriptor().data, uv.x, uv.y, radius, nPredictedLevel - 1, nPredictedLevel, ur, bRight ? 1 : 0,
+                   0.f, 0);
         }
         std::vector<int32_t> qMatch, featMatch;
         std::vector<uint8_t> none((size_t)std::max(pKF->N, 1), 0);
-        run_projection(*pKF, pKF->N, -1, pKF->mDescriptors, pKF->mvuRight.data(), none, pKF->mnMinX, pKF->mnMinY,
+        run_projection(*pKF, pKF->N, pKF->NLeft, pKF->mDescriptors, pKF->mvuRight.data(), none, pKF->mnMinX, pKF->mnMinY,
                        pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, q, 1, TH_LOW, false,
                        pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), true, nullptr, nullptr, qMatch,
                        featMatch);
@@ -868,7 +893,7 @@ protected:
         a.desc = dense_descriptors(D, n, tmp);
         a.n = n;
         a.kx = fa.kx.data(); a.ky = fa.ky.data(); a.octave = fa.octave.data(); a.angle = fa.angle.data();
-        a.uright = nLeft == -1 ? uright : nullptr;
+        a.uright = (nLeft == -1 || chi2) ? uright : nullptr; // (Fuse reads mvuRight of a rig's keyframe too, :1775)
         a.taken = taken.data();
         a.Nleft = nLeft;
         a.left_to_right = l2r; a.right_to_left = r2l;

@@ -110,6 +110,7 @@ public:
     int mnScaleLevels = 8;
     cv::Matx33f mRcw_; // rotation / translation of mTcw (the reference slices the 4x4 cv::Mat mTcw, ORBmatcher.cc:2204-2205)
     cv::Matx31f mtcw_;
+    cv::Mat mTrl;      // 3x4 CV_32F, left camera -> right camera (two-camera rigs, ORBmatcher.cc:2327)
 };
 
 class KeyFrame {
@@ -139,11 +140,14 @@ public:
     cv::Matx33f GetRotation_() { return Rcw; }
     cv::Matx31f GetTranslation_() { return tcw; }
     cv::Matx31f GetCameraCenter_() { return Ow; }
+    cv::Matx33f GetRightRotation_() { return RcwR; }
+    cv::Matx31f GetRightTranslation_() { return tcwR; }
+    cv::Matx31f GetRightCameraCenter_() { return OwR; }
     bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
 
     std::vector<MapPoint*> mvpMapPoints;
-    cv::Matx33f Rcw;
-    cv::Matx31f tcw, Ow;
+    cv::Matx33f Rcw, RcwR; // ..R: the right camera of a rig (KeyFrame::GetRightPose, KeyFrame.cc)
+    cv::Matx31f tcw, Ow, tcwR, OwR;
 };
 
 inline int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF)

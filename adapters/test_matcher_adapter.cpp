@@ -121,6 +121,14 @@ static cv::Matx31f m31(const float* p)
     return m;
 }
 
+static cv::Mat mat32(const float* v, int r, int c)
+{
+    cv::Mat m(r, c, CV_32F);
+    for (int i = 0; i < r; i++)
+        for (int j = 0; j < c; j++) m.at<float>(i, j) = v[i * c + j];
+    return m;
+}
+
 static void test_bow_kf_f(const std::string& P)
 {
     const int n1 = (int)in(P + "a1").count, n2 = (int)in(P + "a2").count, Nleft = in(P + "Nleft").i32()[0];
@@ -237,6 +245,12 @@ static void fill_frame(Frame& F, const std::string& P)
     F.N = n;
     set_keys(F.mvKeysUn, n, in(P + "kx").f32(), in(P + "ky").f32(), in(P + "ang").f32(), in(P + "oct").i32());
     F.mvKeys = F.mvKeysUn;
+    if (has(P + "Nleft") && in(P + "Nleft").i32()[0] != -1) { // two-camera rig: mvKeys ++ mvKeysRight, mvKeysUn is not read
+        F.Nleft = in(P + "Nleft").i32()[0];
+        F.mvKeysRight.assign(F.mvKeys.begin() + F.Nleft, F.mvKeys.end());
+        F.mvKeys.resize(F.Nleft);
+        set_keys(F.mvKeysUn, n, nullptr, nullptr, nullptr, nullptr);
+    }
     set_desc(F.mDescriptors, n, in(P + "desc").u8());
     if (has(P + "uright")) F.mvuRight.assign(in(P + "uright").f32(), in(P + "uright").f32() + n);
     else F.mvuRight.assign(n, -1.f);
@@ -273,7 +287,17 @@ static void test_proj_local(const std::string& P)
         p->mTrackViewCos = in(P + "pcos").f32()[k];
         p->mTrackDepth = in(P + "pdepth").f32()[k];
         p->mnTrackScaleLevel = in(P + "plevel").i32()[k];
+        if (F.Nleft != -1) { // Frame::isInFrustumChecks for the right camera
+            p->mbTrackInViewR = (pstate[k] & 8) != 0;
+            p->mTrackProjYR = in(P + "pyR").f32()[k];
+            p->mTrackViewCosR = in(P + "pcosR").f32()[k];
+            p->mnTrackScaleLevelR = in(P + "plevelR").i32()[k];
+        }
         memcpy(p->mDescriptor, in(P + "pdesc").u8() + 32 * (size_t)k, 32);
+    }
+    if (F.Nleft != -1) {
+        F.mvLeftToRightMatch.assign(in(P + "l2r").i32(), in(P + "l2r").i32() + in(P + "l2r").count);
+        F.mvRightToLeftMatch.assign(in(P + "r2l").i32(), in(P + "r2l").i32() + in(P + "r2l").count);
     }
     ORBmatcher matcher(in(P + "ratio").f32()[0], true);
     const int nm = matcher.SearchByProjection(F, pts, in(P + "th").f32()[0], in(P + "far").i32()[0] != 0, in(P + "thfar").f32()[0]);
@@ -294,6 +318,7 @@ static void test_proj_last(const std::string& P)
     C.mtcw_ = m31(in(P + "tc").f32());
     L.mRcw_ = m33(in(P + "Rl").f32());
     L.mtcw_ = m31(in(P + "tl").f32());
+    if (has(P + "Trl")) C.mTrl = mat32(in(P + "Trl").f32(), 3, 4);
     const int nl = (int)in(P + "loct").count;
     L.N = nl;
     set_keys(L.mvKeysUn, nl, nullptr, nullptr, in(P + "lang").f32(), in(P + "loct").i32());
@@ -342,6 +367,20 @@ static void test_fuse(const std::string& P)
     k.Rcw = m33(in(P + "R").f32());
     k.tcw = m31(in(P + "t").f32());
     k.Ow = m31(in(P + "O").f32());
+    GeometricCamera cam2;
+    bool bRight = false;
+    if (has(P + "NLeft")) { // two-camera rig: mvKeys ++ mvKeysRight, the right camera's pose and model
+        k.NLeft = in(P + "NLeft").i32()[0];
+        k.mvKeys.assign(k.mvKeysUn.begin(), k.mvKeysUn.begin() + k.NLeft);
+        k.mvKeysRight.assign(k.mvKeysUn.begin() + k.NLeft, k.mvKeysUn.end());
+        set_keys(k.mvKeysUn, n, nullptr, nullptr, nullptr, nullptr);
+        cam2.mvParameters.assign(in(P + "cam2").f32(), in(P + "cam2").f32() + 4);
+        k.mpCamera2 = &cam2;
+        k.RcwR = m33(in(P + "RR").f32());
+        k.tcwR = m31(in(P + "tR").f32());
+        k.OwR = m31(in(P + "OR").f32());
+        bRight = in(P + "bRight").i32()[0] != 0;
+    }
     const int m = (int)in(P + "pstate").count;
     std::vector<MapPoint*> pts(m, nullptr);
     const int32_t* ps = in(P + "pstate").i32(); // 0 null, 1 ok, 2 bad, 3 already observed in the keyframe
@@ -359,7 +398,7 @@ static void test_fuse(const std::string& P)
     }
     const std::vector<MapPoint*> original = k.mvpMapPoints; // the points the keyframe held before
     ORBmatcher matcher;
-    const int nf = matcher.Fuse(&k, pts, in(P + "th").f32()[0]);
+    const int nf = matcher.Fuse(&k, pts, in(P + "th").f32()[0], bRight);
     // what Fuse left in the objects: per candidate the feature it was added to as an observation (-1 none) and the id
     // of the point that replaced it (-1 none); per keyframe feature the id of the point it holds now and, for the
     // keyframe's original point there, the id of the point that replaced it.  (ids: candidates q, originals 100000 + i)
@@ -413,14 +452,6 @@ static void set_point_geometry(MapPoint* p, const std::string& P, const char* sf
     p->mfMaxDistance = in(P + "pdist" + S).f32()[2 * q + 1];
     memcpy(p->mDescriptor, in(P + "pdesc" + S).u8() + 32 * q, 32);
 }
-static cv::Mat mat32(const float* v, int r, int c)
-{
-    cv::Mat m(r, c, CV_32F);
-    for (int i = 0; i < r; i++)
-        for (int j = 0; j < c; j++) m.at<float>(i, j) = v[i * c + j];
-    return m;
-}
-
 static void test_reloc(const std::string& P)
 {
     Frame C;

@@ -372,7 +372,10 @@ typedef struct {
     const float* qxr;                      /* mTrackProjXR (:89) or uv.x - mbf*invzc (:2272); with uright */
     const uint8_t* qflags;                 /* or NULL. bit0: right-camera grid (bRight); bit1: right-camera
                                               search of the previous query's map point, skipped when that
-                                              query was rejected by the ratio test (`continue`, :128)     */
+                                              query was rejected by the ratio test (`continue`, :128);
+                                              bit2: skipped when the previous query's GetFeaturesInArea came
+                                              back empty (`if(vIndices2.empty()) continue;` :2255 stands
+                                              before the right-camera block :2326 of the same point)      */
     const float* qangle;                   /* keypoint angle in the last frame / keyframe (mode 1)        */
     const uint8_t* qblocks;                /* or NULL = all. pMP->Observations()>0 of the query's point   */
     int mode; float nnratio; int th_high; int check_orientation;

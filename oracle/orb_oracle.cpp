@@ -1381,18 +1381,25 @@ int orb_oracle_search_projection(const orb_oracle_proj_args* a, int32_t* q_match
     };
     std::vector<int> rotHist[HISTO_LENGTH];
     int nmatches = 0;
-    bool prevRatioRejected = false;
+    bool prevRatioRejected = false, prevAreaEmpty = false;
     for (int q = 0; q < a->nq; q++) {
         q_match[q] = -1;
         const bool bRight = a->qflags && (a->qflags[q] & 1);
         const bool linked = a->qflags && (a->qflags[q] & 2);
-        const bool skip = linked && prevRatioRejected;
+        // bit 2: the right-camera search of a point of SearchByProjection(CurrentFrame, LastFrame) sits behind the
+        // `if(vIndices2.empty()) continue;` of its left-camera search (src/ORBmatcher.cc:2255-2256, :2326)
+        const bool behindArea = a->qflags && (a->qflags[q] & 4);
+        const bool skip = (linked && prevRatioRejected) || (behindArea && prevAreaEmpty);
         prevRatioRejected = false;
+        prevAreaEmpty = false;
         if (skip) continue;
         const size_t base = bRight ? (size_t)Nleft : 0;
         const float r = a->qr[q];
         const std::vector<size_t> vIndices = GetFeaturesInArea(a->qx[q], a->qy[q], r, a->qmin_level[q], a->qmax_level[q], bRight);
-        if (vIndices.empty()) continue;
+        if (vIndices.empty()) {
+            prevAreaEmpty = true;
+            continue;
+        }
         const uint8_t* MPdescriptor = a->qdesc + 32 * (size_t)q;
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         for (size_t k = 0; k < vIndices.size(); k++) {

@@ -599,6 +599,7 @@ struct ProjDev {
     unsigned long long *rawKeys, *sortedKeys;
     int keyCap;
     int32_t *qStart, *qCount; // nq
+    int32_t* qArea;     // nq or NULL: 1 = GetFeaturesInArea returned something (read by queries with flag bit 2)
     int32_t* minW;      // 2 * n
     int32_t* state;     // 2 * 3 * nq: choice, partner, rejected
     int32_t* qMatch;    // nq
@@ -682,14 +683,16 @@ __device__ __forceinline__ void proj_grid_body(const ProjDev& P)
 
 // static tests of one candidate (everything except "taken by an earlier query"); g = feature index into the
 // frame arrays, local = its index inside its camera's list (what the grid cells hold)
-__device__ __forceinline__ bool proj_static_ok(const ProjDev& P, int g, int local, float x, float y, float r,
-                                               int minLevel, int maxLevel, bool gate, float xr)
+// Returns 0 = not in the area (GetFeaturesInArea would not return it), 1 = in the area but rejected by the loop over
+// vIndices, 2 = a candidate.
+__device__ __forceinline__ int proj_static_ok(const ProjDev& P, int g, int local, float x, float y, float r,
+                                              int minLevel, int maxLevel, bool gate, float xr)
 {
     const int oct = P.octave[g];
-    if (oct < minLevel || (maxLevel >= 0 && oct > maxLevel)) return false;
+    if (oct < minLevel || (maxLevel >= 0 && oct > maxLevel)) return 0;
     const float kpx = P.kx[g], kpy = P.ky[g];
-    if (!(fabsf(__fsub_rn(kpx, x)) < r && fabsf(__fsub_rn(kpy, y)) < r)) return false;
-    if (P.taken && P.taken[g]) return false;
+    if (!(fabsf(__fsub_rn(kpx, x)) < r && fabsf(__fsub_rn(kpy, y)) < r)) return 0;
+    if (P.taken && P.taken[g]) return 1;
     if (P.chi2) {
         // Fuse (src/ORBmatcher.cc:1773-1799): mvuRight is read with the camera-local index (before :1801)
         const float ex = __fsub_rn(x, kpx), ey = __fsub_rn(y, kpy);
@@ -701,12 +704,12 @@ __device__ __forceinline__ bool proj_static_ok(const ProjDev& P, int g, int loca
             e2 = __fadd_rn(e2, __fmul_rn(er, er));
             lim = 7.8;
         }
-        if ((double)__fmul_rn(e2, P.invSigma2[oct]) > lim) return false;
+        if ((double)__fmul_rn(e2, P.invSigma2[oct]) > lim) return 1;
     } else if (gate) {
         const float ur = P.uright[g];
-        if (ur > 0.f && fabsf(__fsub_rn(xr, ur)) > r) return false;
+        if (ur > 0.f && fabsf(__fsub_rn(xr, ur)) > r) return 1;
     }
-    return true;
+    return 2;
 }
 
 // The window of a query is a run of grid columns, and inside a column the cells cy0..cy1 are neighbours in the
@@ -732,6 +735,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
     const float fy0 = floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.minY), r), P.hInv));
     const float fy1 = ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, P.minY), r), P.hInv));
     int m = 0, base = 0;
+    bool inArea = false; // (per lane) some feature of the window passed GetFeaturesInArea's own tests
     if (fx0 < (float)PROJ_GC && fx1 >= 0.f && fy0 < (float)PROJ_GR && fy1 >= 0.f) {
         const int cx0 = fx0 > 0.f ? (int)fx0 : 0, cx1 = fx1 < (float)(PROJ_GC - 1) ? (int)fx1 : PROJ_GC - 1;
         const int cy0 = fy0 > 0.f ? (int)fy0 : 0, cy1 = fy1 < (float)(PROJ_GR - 1) ? (int)fy1 : PROJ_GR - 1;
@@ -774,7 +778,9 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
                         if (col + step < ncols && sBase[wave][col + step] <= i) col += step;
                     const int local = P.cellItems[sLo[wave][col] + (i - sBase[wave][col])];
                     const int g = local + fbase;
-                    ok = proj_static_ok(P, g, local, x, y, r, minLevel, maxLevel, gate, xr);
+                    const int verdict = proj_static_ok(P, g, local, x, y, r, minLevel, maxLevel, gate, xr);
+                    inArea = inArea || verdict != 0;
+                    ok = verdict == 2;
                     if (ok) {
                         const int dist = hamming(dq, load_desc(P.desc + (size_t)g * 32));
                         key = ((unsigned long long)dist << 55) | ((unsigned long long)i << 24) | (unsigned long long)g;
@@ -817,9 +823,11 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
             }
         }
     }
+    const bool anyInArea = __ballot(inArea) != 0ull;
     if (lane == 0) {
         P.qStart[q] = base;
         P.qCount[q] = m;
+        if (P.qArea) P.qArea[q] = anyInArea ? 1 : 0;
     }
 }
 
@@ -850,7 +858,7 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
             const int flags = P.qflags ? P.qflags[q] : 0;
             const bool bRight = flags & 1;
             int choice = -1, partner = -1, rejected = 0;
-            const bool skip = (flags & 2) && q > 0 && prevS[3 * (q - 1) + 2] == 1;
+            const bool skip = q > 0 && (((flags & 2) && prevS[3 * (q - 1) + 2] == 1) || ((flags & 4) && P.qArea[q - 1] == 0));
             const int m = skip ? 0 : P.qCount[q];
             const unsigned long long* K = P.sortedKeys + P.qStart[q];
             int g1 = -1, d1 = 256, g2 = -1, d2 = 256;
@@ -2101,6 +2109,8 @@ int proj_validate(const orbfe_proj_args* a, const int32_t* q_match, const int32_
     for (int q = 0; q < a->nq; q++) {
         const int f = a->qflags ? a->qflags[q] : 0;
         if ((f & 1) && a->Nleft == -1) return ORBFE_ERR_ARGS; // there is no right grid
+        // bit 2 refers to the query before, which must be an unconditional one
+        if ((f & 4) && (q == 0 || (a->qflags[q - 1] & 6))) return ORBFE_ERR_ARGS;
         // a non-blocking map point (Observations()==0) that overwrites a stereo partner could free a taken
         // feature again (:117-121); the sweep formulation does not represent that
         if (a->qblocks && !a->qblocks[q] && a->mode == 0 && a->Nleft != -1 && (a->left_to_right || a->right_to_left))
@@ -2158,6 +2168,9 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J)
     if ((r = s.up<int32_t>(&P.state, nullptr, 6 * nq)) < 0) return r;
     if ((r = s.up<int32_t>(&P.qStart, nullptr, nq)) < 0) return r;
     if ((r = s.up<int32_t>(&P.qCount, nullptr, nq)) < 0) return r;
+    P.qArea = nullptr;
+    for (size_t q = 0; a->qflags && q < nq && !P.qArea; q++)
+        if ((a->qflags[q] & 4) && (r = s.up<int32_t>(&P.qArea, nullptr, nq)) < 0) return r;
     J.keyCap = std::max<size_t>(64 * nq, 1 << 16);
     if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, J.keyCap)) < 0) return r;
     if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, J.keyCap)) < 0) return r;

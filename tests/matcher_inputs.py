@@ -281,9 +281,18 @@ def projection_problem(seed, n=1200, nq=900, mode=0, stereo=False, Nleft=-1, th=
     if Nleft != -1:
         right = (tgt >= Nleft)
         flags = right.astype(np.uint8)
+        prev_left = np.concatenate([[False], ~right[:-1]])
         if mode == 0:  # right-camera searches directly after a left one are linked to it
-            prev_left = np.concatenate([[False], ~right[:-1]])
             flags |= ((right & prev_left & (rng.random(nq) < 0.7)).astype(np.uint8) << 1)
+        elif loop is None:  # frame-to-frame: the right search of a point is skipped when its left window was empty (:2255)
+            behind = right & prev_left & (rng.random(nq) < 0.7)
+            flags |= behind.astype(np.uint8) << 2
+            # empty a good share of those left windows: far outside the grid, or no level passes
+            prev = np.nonzero(behind)[0] - 1
+            far = prev[rng.random(len(prev)) < 0.25]
+            qx[far] = np.float32(w + 400)
+            lvlless = prev[rng.random(len(prev)) < 0.25]
+            pr["qmin_level"][lvlless] = 9
         pr["qflags"] = flags
         if partners:
             nr = n - Nleft

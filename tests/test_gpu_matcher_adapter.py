@@ -303,18 +303,166 @@ def _proj_last(f, tag, oracle, seed, n, nl, th, stereo, tlz, mono, ori):
     return check
 
 
-def _fuse(f, tag, oracle, seed, n, m, th):
+def _proj_local_rig(f, tag, oracle, seed, n, m, th):
+    """Tracking::SearchLocalPoints on a two-camera frame: per point a left-camera search and / or a right-camera one
+    (src/ORBmatcher.cc:58-139, :141-195), stereo partners through mvLeftToRightMatch / mvRightToLeftMatch."""
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, False)
+    nleft = n * 3 // 5
+    fstate = rng.choice([0, 0, 0, 0, 0, 0, 1], n).astype(np.int32)
+    tl = rng.integers(0, nleft, m)
+    tl[: m // 3] = rng.integers(0, max(nleft // 4, 1), m // 3)
+    tr = rng.integers(nleft, n, m)
+    tr[m // 3: m // 2] = tr[: m // 2 - m // 3]
+    pdesc = _noisy(fr["desc"][tl], rng)
+    for k in range(m):                                                  # the right targets look like their points too
+        fr["desc"][tr[k]] = _noisy(pdesc[k:k + 1], rng, 0.0, 0.15)[0]
+    _put_frame(f, tag, fr, fstate)
+    nr = n - nleft
+    l2r, r2l = np.full(nleft, -1, np.int32), np.full(nr, -1, np.int32)
+    li, ri = rng.permutation(nleft)[: nr // 3], rng.permutation(nr)[: nr // 3]
+    l2r[li], r2l[ri] = ri, li
+    px = (fr["kx"][tl] + rng.normal(0, 2.0, m)).astype(np.float32)
+    py = (fr["ky"][tl] + rng.normal(0, 2.0, m)).astype(np.float32)
+    pxr = (fr["kx"][tr] + rng.normal(0, 2.0, m)).astype(np.float32)
+    pyr = (fr["ky"][tr] + rng.normal(0, 2.0, m)).astype(np.float32)
+    level = np.clip(fr["oct"][tl] + rng.integers(0, 2, m), 0, 7).astype(np.int32)
+    levelr = np.clip(fr["oct"][tr] + rng.integers(0, 2, m), 0, 7).astype(np.int32)
+    levelr[rng.random(m) < 0.1] = -1                                     # no prediction for the right camera: no search
+    pcos = np.where(rng.random(m) < 0.5, 0.9995, 0.97).astype(np.float32)
+    pcosr = np.where(rng.random(m) < 0.5, 0.9995, 0.97).astype(np.float32)
+    pstate = np.where(rng.random(m) < 0.8, 1, 0).astype(np.int32)        # bit0: in view (left)
+    pstate |= (rng.random(m) < 0.05).astype(np.int32) << 1              # bit1: bad
+    pstate |= (rng.random(m) < 0.7).astype(np.int32) << 3               # bit3: in view of the right camera
+    for k, v in (("Nleft", np.array([nleft], np.int32)), ("l2r", l2r), ("r2l", r2l), ("px", px), ("py", py), ("pxr", pxr),
+                 ("pyR", pyr), ("pcos", pcos), ("pcosR", pcosr), ("pdepth", np.ones(m, np.float32)), ("plevel", level),
+                 ("plevelR", levelr), ("pdesc", pdesc), ("pstate", pstate), ("ratio", np.array([0.8], np.float32)),
+                 ("th", np.array([th], np.float32)), ("far", np.array([0], np.int32)), ("thfar", np.array([50.0], np.float32))):
+        _put(f, tag + k, v)
+
+    def check(res):
+        rad = lambda c: np.float32(2.5) if c > 0.998 else np.float32(4.0)
+        Q = dict(ids=[], x=[], y=[], r=[], lo=[], hi=[], fl=[])
+        for k in range(m):
+            if not (pstate[k] & 9) or (pstate[k] & 2):
+                continue
+            left = False
+            if pstate[k] & 1:
+                r = rad(pcos[k])
+                if th != 1.0:
+                    r = np.float32(r * np.float32(th))
+                for key, v in (("ids", k), ("x", px[k]), ("y", py[k]), ("r", np.float32(r * SF[level[k]])), ("lo", level[k] - 1),
+                               ("hi", level[k]), ("fl", 0)):
+                    Q[key].append(v)
+                left = True
+            if (pstate[k] & 8) and levelr[k] != -1:
+                for key, v in (("ids", k), ("x", pxr[k]), ("y", pyr[k]), ("r", np.float32(rad(pcosr[k]) * SF[levelr[k]])),
+                               ("lo", levelr[k] - 1), ("hi", levelr[k]), ("fl", 1 | (2 if left else 0))):
+                    Q[key].append(v)
+        ids = np.array(Q["ids"])
+        pr = _frame_problem(fr, fstate)
+        pr.update(Nleft=nleft, left_to_right=l2r, right_to_left=r2l, mode=0, nnratio=0.8, th_high=100, check_orientation=0,
+                  qdesc=pdesc[ids], qx=np.array(Q["x"], np.float32), qy=np.array(Q["y"], np.float32),
+                  qr=np.array(Q["r"], np.float32), qmin_level=np.array(Q["lo"], np.int32), qmax_level=np.array(Q["hi"], np.int32),
+                  qxr=np.zeros(len(ids), np.float32), qflags=np.array(Q["fl"], np.uint8),
+                  qangle=np.zeros(len(ids), np.float32), qblocks=np.ones(len(ids), np.uint8))
+        pr.pop("uright")
+        nm, qm, fm = oracle.search_projection(pr)
+        assert res[tag + "n"][0] == nm and nm > 60, (tag, nm)
+        assert (fm[nleft:] >= 0).sum() > 20 and (np.array(Q["fl"]) == 3).sum() > 20, tag
+        assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, [], ids)), tag
+    return check
+
+
+def _proj_last_rig(f, tag, oracle, seed, n, nl, th, tlz, ori):
+    """Tracking::TrackWithMotionModel on a two-camera frame: every point of the last frame is also searched in the right
+    camera (src/ORBmatcher.cc:2326-2395), unless its left window held no feature (:2255)."""
+    rng = np.random.default_rng(seed)
+    fr = _frame_arrays(rng, n, False)
+    nleft = n * 3 // 5
+    fstate = rng.choice([0, 0, 0, 0, 0, 0, 1, 3], n).astype(np.int32)
+    cam = np.array([512, 512, 384, 256], np.float32)
+    tc = np.array([0.25, -0.5, 0.0], np.float32)
+    tl = np.array([0.25, -0.5, tlz], np.float32)
+    trl = np.array([[1, 0, 0, -0.125], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)   # right camera 0.125 to the right
+    tgt = rng.integers(0, nleft, nl)
+    tgt[: nl // 3] = rng.integers(0, max(nleft // 4, 1), nl // 3)
+    u = np.round((fr["kx"][tgt] + rng.normal(0, 2.0, nl)) * 8) / 8
+    v = np.round((fr["ky"][tgt] + rng.normal(0, 2.0, nl)) * 8) / 8
+    lonely = rng.random(nl) < 0.15                                        # anywhere: mostly an empty left window
+    u[lonely] = np.round(rng.uniform(20, 740, lonely.sum()) * 8) / 8
+    v[lonely] = np.round(rng.uniform(20, 490, lonely.sum()) * 8) / 8
+    z = rng.choice([2.0, 4.0, 8.0], nl)
+    z[rng.random(nl) < 0.03] = -2.0
+    ur = u - 64.0 / z                                                     # fx * (-0.125) / z: exact
+    xc = np.stack([(u - 384) * z / 512, (v - 256) * z / 512, z], 1)
+    lpos = (xc - tc.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(lpos.astype(np.float64) + tc, xc)
+    lstate = rng.choice([0, 1, 1, 1, 1, 2, 3], nl).astype(np.int32)
+    loct = np.clip(fr["oct"][tgt] + rng.integers(-1, 2, nl), 0, 7).astype(np.int32)
+    lang = rng.uniform(0, 360, nl).astype(np.float32)
+    ldesc = _noisy(fr["desc"][tgt], rng)
+    # the right camera's features: most of them are the last frame's points seen from there
+    nr = n - nleft
+    src = np.where(rng.random(nr) < 0.8, rng.integers(0, nl, nr), -1)
+    for j in range(nr):
+        if src[j] >= 0 and z[src[j]] > 0:
+            p = src[j]
+            fr["kx"][nleft + j] = np.float32(ur[p] + rng.normal(0, 1.5))
+            fr["ky"][nleft + j] = np.float32(v[p] + rng.normal(0, 1.5))
+            fr["oct"][nleft + j] = np.clip(loct[p] + rng.integers(-1, 2), 0, 7)
+            fr["desc"][nleft + j] = _noisy(ldesc[p:p + 1], rng, 0.0, 0.2)[0]
+    _put_frame(f, tag, fr, fstate)
+    for k, val in (("Nleft", np.array([nleft], np.int32)), ("Trl", trl), ("cam", cam), ("bf", np.array([40.0, 0.125], np.float32)),
+                   ("Rc", np.eye(3, dtype=np.float32)), ("tc", tc), ("Rl", np.eye(3, dtype=np.float32)), ("tl", tl),
+                   ("loct", loct), ("lang", lang), ("lstate", lstate), ("lpos", lpos), ("ldesc", ldesc),
+                   ("th", np.array([th], np.float32)), ("mono", np.array([0], np.int32)), ("ori", np.array([int(ori)], np.int32))):
+        _put(f, tag + k, val)
+
+    def check(res):
+        fwd, bwd = tlz > 0.125, -tlz > 0.125
+        keep = [i for i in range(nl) if lstate[i] in (1, 3) and z[i] > 0 and 0 <= u[i] <= 768 and 0 <= v[i] <= 512]
+        ids = np.repeat(keep, 2)
+        o = loct[ids]
+        lo = o if fwd else (np.zeros_like(o) if bwd else o - 1)
+        hi = np.full_like(o, -1) if fwd else (o if bwd else o + 1)
+        qx = np.stack([u[keep], ur[keep]], 1).reshape(-1).astype(np.float32)
+        pr = _frame_problem(fr, fstate)
+        pr.update(Nleft=nleft, mode=1, nnratio=0.9, th_high=100, check_orientation=int(ori), qdesc=ldesc[ids], qx=qx,
+                  qy=v[ids].astype(np.float32), qr=(np.float32(th) * SF[o]).astype(np.float32), qmin_level=lo.astype(np.int32),
+                  qmax_level=hi.astype(np.int32), qxr=np.zeros(len(ids), np.float32), qangle=lang[ids],
+                  qflags=np.tile(np.array([0, 5], np.uint8), len(keep)), qblocks=(lstate[ids] == 1).astype(np.uint8))
+        pr.pop("uright")
+        nm, qm, fm = oracle.search_projection(pr)
+        pr["qflags"] = pr["qflags"] & 1
+        nm_all, _, _ = oracle.search_projection(pr)                         # (the rule of :2255 matters in this scenario)
+        assert nm_all > nm, (tag, nm, nm_all)
+        assert res[tag + "n"][0] == nm and nm > 60 and (fm[nleft:] >= 0).sum() > 20, (tag, nm)
+        assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, qm, ids)), tag
+    return check
+
+
+def _fuse(f, tag, oracle, seed, n, m, th, rig=None):
+    """rig = None, "left" or "right": a keyframe of a two-camera rig, fused into through its left / right camera
+    (bRight, src/ORBmatcher.cc:1647-1658: right pose, mpCamera2, right grid, features NLeft..)."""
     rng = np.random.default_rng(seed)
     fr = _frame_arrays(rng, n, True)
     fr["uright"] = np.where(rng.random(n) < 0.5, fr["kx"] - rng.uniform(0, 30, n), -1).astype(np.float32)
+    nleft = n * 3 // 5 if rig else -1
+    lo_f, hi_f = (nleft, n) if rig == "right" else (0, nleft if rig else n)   # the features this camera owns
+    cx = 400.0 if rig == "right" else 384.0
+    tx = -0.125 if rig == "right" else 0.0                                 # the right camera sits 0.125 to the right
+    if rig == "right":                                                      # the clusters of _frame_arrays, seen by this camera too
+        fr["kx"][nleft:nleft + n // 8] = fr["kx"][:n // 8]
+        fr["ky"][nleft:nleft + n // 8] = fr["ky"][:n // 8]
     fstate = rng.choice([0, 0, 1, 1, 2], n).astype(np.int32)               # none / good / bad point at the feature
     fobs = rng.integers(1, 6, n).astype(np.int32)
     _put_frame(f, tag, fr, fstate)
     _put(f, tag + "fobs", fobs)
     cam = np.array([512, 512, 384, 256], np.float32)
     bf = np.float32(40.0)
-    tgt = rng.integers(0, n, m)
-    tgt[: m // 3] = rng.integers(0, max(n // 4, 1), m // 3)
+    tgt = rng.integers(lo_f, hi_f, m)
+    tgt[: m // 3] = rng.integers(lo_f, lo_f + max((hi_f - lo_f) // 4, 1), m // 3)
     tgt[m // 3: m // 2] = tgt[: m // 2 - m // 3]                            # several candidates fuse into one feature
     u = np.round((fr["kx"][tgt] + rng.normal(0, 1.0, m)) * 8) / 8
     v = np.round((fr["ky"][tgt] + rng.normal(0, 1.0, m)) * 8) / 8
@@ -322,14 +470,16 @@ def _fuse(f, tag, oracle, seed, n, m, th):
     u[out] = 900.0                                                         # not IsInImage
     z = rng.choice([2.0, 4.0, 8.0], m)
     z[rng.random(m) < 0.04] = -4.0                                         # negative depth
-    pos = np.stack([(u - 384) * z / 512, (v - 256) * z / 512, z], 1).astype(np.float32)   # R = I, t = 0, Ow = 0
-    dist = np.linalg.norm(pos.astype(np.float64), axis=1)
+    xc = np.stack([(u - cx) * z / 512, (v - 256) * z / 512, z], 1)        # in the camera that is fused into
+    pos = (xc - np.array([tx, 0, 0])).astype(np.float32)                   # R = I, t = (tx, 0, 0), O = (-tx, 0, 0)
+    assert np.array_equal(pos.astype(np.float64) + np.array([tx, 0, 0]), xc)
+    dist = np.linalg.norm(xc, axis=1)
     level = np.clip(fr["oct"][tgt] + rng.integers(0, 2, m), 0, 7)
     maxd = (dist * 1.2 ** (level - 0.5)).astype(np.float32)               # PredictScale = ceil(level - 0.5) = level
     mind = (maxd / np.float32(1.2 ** 7)).astype(np.float32)
     wrong = rng.random(m) < 0.05
     maxd[wrong] = (dist[wrong] * 0.5).astype(np.float32)                   # outside the scale-invariance range
-    normal = (pos.astype(np.float64) / np.maximum(dist, 1e-9)[:, None])
+    normal = (xc / np.maximum(dist, 1e-9)[:, None])
     flip = rng.random(m) < 0.05
     normal[flip] *= -1                                                     # viewing angle > 60 degrees
     pstate = rng.choice([0, 1, 1, 1, 1, 1, 1, 2, 3], m).astype(np.int32)
@@ -340,12 +490,19 @@ def _fuse(f, tag, oracle, seed, n, m, th):
                    ("pstate", pstate), ("pobs", pobs), ("ppos", pos), ("pnormal", normal.astype(np.float32)),
                    ("pdist", np.stack([mind, maxd], 1)), ("pdesc", pdesc), ("th", np.array([th], np.float32))):
         _put(f, tag + k, val)
+    if rig:
+        for k, val in (("NLeft", np.array([nleft], np.int32)), ("bRight", np.array([int(rig == "right")], np.int32)),
+                       ("cam2", np.array([512, 512, 400, 256], np.float32)), ("RR", np.eye(3, dtype=np.float32)),
+                       ("tR", np.array([-0.125, 0, 0], np.float32)), ("OR", np.array([0.125, 0, 0], np.float32))):
+            _put(f, tag + k, val)
 
     def check(res):
         ok = (pstate == 1) & (z > 0) & (u >= 0) & (u < 768) & (v >= 0) & (v < 512) & ~wrong & ~flip
         keep = np.nonzero(ok)[0]
         lv = level[keep].astype(np.int32)
         pr = _frame_problem(fr, np.zeros(n, np.int32))
+        if rig:
+            pr.update(Nleft=nleft, qflags=np.full(len(keep), int(rig == "right"), np.uint8))
         pr.update(mode=1, nnratio=0.6, th_high=50, check_orientation=0, chi2_gate=1,
                   inv_level_sigma2=(np.float32(1.0) / (SF * SF)).astype(np.float32), qdesc=pdesc[keep],
                   qx=u[keep].astype(np.float32), qy=v[keep].astype(np.float32), qr=(np.float32(th) * SF[lv]).astype(np.float32),
@@ -687,6 +844,12 @@ def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle):
         checks.append(_proj_last(f, "p1_3.", oracle, 54, 1000, 800, 15.0, False, 1.0, True, True))     # monocular
         checks.append(_fuse(f, "fu0.", oracle, 61, 1500, 1200, 3.0))
         checks.append(_fuse(f, "fu1.", oracle, 62, 900, 700, 4.0))
+        checks.append(_fuse(f, "fu2.", oracle, 63, 1500, 1000, 3.0, rig="left"))                       # two-camera rigs
+        checks.append(_fuse(f, "fu3.", oracle, 64, 1500, 1000, 3.0, rig="right"))
+        checks.append(_proj_local_rig(f, "p0_2.", oracle, 43, 1500, 1200, 1.0))
+        checks.append(_proj_local_rig(f, "p0_3.", oracle, 44, 1200, 1000, 3.0))
+        checks.append(_proj_last_rig(f, "p1_4.", oracle, 55, 1500, 1000, 7.0, 0.0, True))
+        checks.append(_proj_last_rig(f, "p1_5.", oracle, 56, 1400, 900, 15.0, 1.0, False))
         checks.append(_reloc(f, "p2_0.", oracle, 71, 1500, 1100, 10.0, 100, True))
         checks.append(_reloc(f, "p2_1.", oracle, 72, 1000, 900, 3.0, 64, False))
         checks.append(_sim3_projection(f, "s3_0.", oracle, 81, 1500, 1200, 8, 0.9, True))

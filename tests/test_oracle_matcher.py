@@ -133,14 +133,17 @@ def _proj_spec(pr):
     feat = np.full(n, -1, np.int32)
     qm = np.full(nq, -1, np.int32)
     flags = pr.get("qflags")
-    nmatches, prev_rej = 0, False
+    nmatches, prev_rej, prev_empty = 0, False, False
     writes_hist = []
     for q in range(nq):
         right = bool(flags is not None and flags[q] & 1)
         linked = bool(flags is not None and flags[q] & 2)
-        skip, prev_rej = linked and prev_rej, False
+        behind = bool(flags is not None and flags[q] & 4)
+        skip = (linked and prev_rej) or (behind and prev_empty)
+        prev_rej, prev_empty = False, False
         if skip:
             continue
+        in_area = 0
         x, y, r = pr["qx"][q], pr["qy"][q], pr["qr"][q]
         mn, mx = pr["qmin_level"][q], pr["qmax_level"][q]
         best = (256, -1, -1)
@@ -154,6 +157,7 @@ def _proj_spec(pr):
                 continue
             if not (abs(pr["kx"][g] - x) < r and abs(pr["ky"][g] - y) < r):
                 continue
+            in_area += 1
             o = occ[g]
             if o == -1 or (o >= 0 and (blocks is None or blocks[o])):
                 continue
@@ -177,6 +181,7 @@ def _proj_spec(pr):
                 best = (d, int(pr["octave"][g]), int(g))
             elif mode == 0 and d < second[0]:
                 second = (d, int(pr["octave"][g]))
+        prev_empty = in_area == 0
         if best[2] < 0 or best[0] > pr["th_high"]:
             continue
         if mode == 0 and best[1] == second[1] and f32(best[0]) > f32(pr["nnratio"]) * f32(second[0]):
