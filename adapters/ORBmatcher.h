@@ -8,7 +8,8 @@
  *
  *   SearchByBoW(KeyFrame*, Frame&, ...)                 src/ORBmatcher.cc:269-471    orbfe_search_bow, variant 0
  *   SearchByBoW(KeyFrame*, KeyFrame*, ...)              src/ORBmatcher.cc:823-963    orbfe_search_bow, variant 1
- *   SearchForTriangulation_(KF1, KF2, F12, ...)         src/ORBmatcher.cc:1208-1449  orbfe_search_tri (pinhole gate)
+ *   SearchForTriangulation_(KF1, KF2, F12, ...)         src/ORBmatcher.cc:1208-1449  orbfe_search_tri (pinhole gate) /
+ *                                                                                    orbfe_search_tri_kb8 (fisheye, rigs)
  *   SearchByProjection(Frame&, vpMapPoints, th, ...)    src/ORBmatcher.cc:44-197     orbfe_search_projection, mode 0
  *   SearchByProjection(CurrentFrame, LastFrame, ...)    src/ORBmatcher.cc:2193-2419  orbfe_search_projection, mode 1
  *   Fuse(KeyFrame*, vpMapPoints, th, bRight)            src/ORBmatcher.cc:1643-1841  orbfe_search_projection, mode 1 + chi2
@@ -25,9 +26,10 @@
  * Inside ORB-SLAM3 include the real Frame.h / KeyFrame.h / MapPoint.h before this header (and drop src/ORBmatcher.cc
  * from the build); here, where OpenCV / Eigen / DBoW2 are absent, adapters/orbslam_standins.h provides classes with
  * the same member names, and adapters/test_matcher_adapter.cpp drives every method through the C ABI against the
- * oracle (tests/test_gpu_matcher_adapter.py).  Two-camera (fisheye) rigs: Nleft / NLeft != -1 is handled where the
- * shim takes it (both SearchByBoW, SearchByProjection mode 0 queries); the KannalaBrandt8 triangulation gate is
- * orbfe_search_tri_kb8, not wrapped here.
+ * oracle (tests/test_gpu_matcher_adapter.py).  Two-camera (fisheye) rigs -- Nleft / NLeft != -1, mpCamera2 -- are
+ * handled wherever the reference handles them: both SearchByBoW, both frame-side SearchByProjection overloads (right-
+ * camera queries into the right grid), Fuse(..., bRight), and SearchForTriangulation_ with the KannalaBrandt8 gate
+ * (orbfe_search_tri_kb8: monocular fisheye pair or the four relative poses of a rig).
  */
 #ifndef ORBFE_ADAPTER_ORBMATCHER_H
 #define ORBFE_ADAPTER_ORBMATCHER_H
@@ -353,8 +355,10 @@ public:
                                 const bool bCoarse = false)
     {
         using namespace orbfe_adapter;
-        if (pKF1->mpCamera2 || pKF2->mpCamera2)
-            throw std::runtime_error("two-camera rigs: use orbfe_search_tri_kb8 (INTEGRATION.md)");
+        if ((pKF1->mpCamera2 != nullptr) != (pKF2->mpCamera2 != nullptr))
+            throw std::runtime_error("SearchForTriangulation_: one keyframe of a rig, one without (the reference reads both second cameras)");
+        if (pKF1->mpCamera2 || pKF1->mpCamera->GetType() == 1u /* GeometricCamera::CAM_FISHEYE */)
+            return SearchForTriangulationKB8(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse);
         // epipole in the second image (:1215-1220)
         const cv::Matx31f Cw = pKF1->GetCameraCenter_();
         const cv::Matx33f R2w = pKF2->GetRotation_();
@@ -410,6 +414,92 @@ public:
         const int np = orbfe_search_tri(mDevice, &a, pairs.data());
         if (np < 0) throw std::runtime_error("orbfe_search_tri failed");
         vMatchedPairs.clear(); // :1435-1446
+        vMatchedPairs.reserve(np);
+        for (int k = 0; k < np; k++) vMatchedPairs.push_back(std::make_pair((size_t)pairs[2 * k], (size_t)pairs[2 * k + 1]));
+        return np;
+    }
+
+    // ---- src/ORBmatcher.cc:1208-1449 for KannalaBrandt8 cameras: a monocular fisheye pair, or a two-camera rig with its
+    // four relative poses (:1238-1248) and per-candidate camera pair (:1342-1370); the gate is
+    // KannalaBrandt8::epipolarConstrain_ (a triangulation per candidate, on the device: orbfe_search_tri_kb8)
+    int SearchForTriangulationKB8(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
+                                  const bool bOnlyStereo, const bool bCoarse)
+    {
+        using namespace orbfe_adapter;
+        const bool rig = pKF1->mpCamera2 != nullptr;
+        const cv::Matx31f Cw = pKF1->GetCameraCenter_();
+        const cv::Matx33f R2w = pKF2->GetRotation_();
+        const cv::Matx31f t2w = pKF2->GetTranslation_();
+        const cv::Point2f ep = pKF2->mpCamera->project(R2w * Cw + t2w); // :1215-1220 (read without a rig only)
+        const cv::Matx33f R1w = pKF1->GetRotation_();
+        const cv::Matx31f t1w = pKF1->GetTranslation_();
+        cv::Matx33f R[4];
+        cv::Matx31f t[4];
+        if (!rig) {
+            R[0] = R1w * R2w.t();                  // :1234-1235
+            t[0] = -R1w * R2w.t() * t2w + t1w;
+        } else {                                    // :1238-1248: ll, lr, rl, rr
+            const cv::Matx33f R1r = pKF1->GetRightRotation_(), R2r = pKF2->GetRightRotation_();
+            const cv::Matx31f t1r = pKF1->GetRightTranslation_(), t2r = pKF2->GetRightTranslation_();
+            R[0] = R1w * R2w.t();
+            R[1] = R1w * R2r.t();
+            R[2] = R1r * R2w.t();
+            R[3] = R1r * R2r.t();
+            t[0] = R1w * (-R2w.t() * t2w) + t1w;
+            t[1] = R1w * (-R2r.t() * t2r) + t1w;
+            t[2] = R1r * (-R2w.t() * t2w) + t1r;
+            t[3] = R1r * (-R2r.t() * t2r) + t1r;
+        }
+        const int nposes = rig ? 4 : 1;
+        lastR12.assign(9 * (size_t)nposes, 0.f);
+        lastT12.assign(3 * (size_t)nposes, 0.f);
+        for (int c = 0; c < nposes; c++) {
+            for (int i = 0; i < 9; i++) lastR12[9 * c + i] = R[c].val[i];
+            for (int i = 0; i < 3; i++) lastT12[3 * c + i] = t[c].val[i];
+        }
+        lastEp = ep;
+        float P[4][8];
+        GeometricCamera* cams[4] = {pKF1->mpCamera, rig ? pKF1->mpCamera2 : pKF1->mpCamera, pKF2->mpCamera,
+                                    rig ? pKF2->mpCamera2 : pKF2->mpCamera};
+        for (int c = 0; c < 4; c++)
+            for (int i = 0; i < 8; i++) P[c][i] = cams[c]->getParameter(i);
+
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        std::vector<uint8_t> has1(n1), has2(n2), tmp1, tmp2;
+        std::vector<float> xy1(2 * (size_t)n1), xy2(2 * (size_t)n2), ang1(n1), ang2(n2);
+        std::vector<int32_t> oct1(n1), oct2(n2);
+        for (int i = 0; i < n1; i++) {
+            has1[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+            const cv::KeyPoint& kp = rig_keypoint(*pKF1, pKF1->NLeft, (size_t)i);
+            xy1[2 * i] = kp.pt.x; xy1[2 * i + 1] = kp.pt.y; ang1[i] = kp.angle; oct1[i] = kp.octave;
+        }
+        for (int i = 0; i < n2; i++) {
+            has2[i] = pKF2->GetMapPoint(i) ? 1 : 0;
+            const cv::KeyPoint& kp = rig_keypoint(*pKF2, pKF2->NLeft, (size_t)i);
+            xy2[2 * i] = kp.pt.x; xy2[2 * i + 1] = kp.pt.y; ang2[i] = kp.angle; oct2[i] = kp.octave;
+        }
+        const CSR c1 = toCSR(pKF1->mFeatVec), c2 = toCSR(pKF2->mFeatVec);
+        orbfe_tri_kb8_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc1 = dense_descriptors(pKF1->mDescriptors, n1, tmp1); a.n1 = n1; a.hasMP1 = has1.data();
+        a.kp1_xy = xy1.data(); a.angle1 = ang1.data(); a.octave1 = oct1.data();
+        a.uRight1 = pKF1->mvuRight.empty() ? nullptr : pKF1->mvuRight.data(); a.fv1 = c1.view(); a.Nleft1 = pKF1->NLeft;
+        a.desc2 = dense_descriptors(pKF2->mDescriptors, n2, tmp2); a.n2 = n2; a.hasMP2 = has2.data();
+        a.kp2_xy = xy2.data(); a.angle2 = ang2.data(); a.octave2 = oct2.data();
+        a.uRight2 = pKF2->mvuRight.empty() ? nullptr : pKF2->mvuRight.data(); a.fv2 = c2.view(); a.Nleft2 = pKF2->NLeft;
+        a.kb8_1L = P[0]; a.kb8_1R = rig ? P[1] : nullptr; a.kb8_2L = P[2]; a.kb8_2R = rig ? P[3] : nullptr;
+        a.R12 = lastR12.data(); a.t12 = lastT12.data();
+        a.ep[0] = ep.x; a.ep[1] = ep.y;
+        a.scaleFactors2 = pKF2->mvScaleFactors.data();
+        a.levelSigma2_1 = pKF1->mvLevelSigma2.data(); a.levelSigma2_2 = pKF2->mvLevelSigma2.data();
+        a.nlevels1 = (int)pKF1->mvLevelSigma2.size(); a.nlevels2 = (int)pKF2->mvLevelSigma2.size();
+        a.only_stereo = bOnlyStereo ? 1 : 0;
+        a.coarse = bCoarse ? 1 : 0;
+        a.check_orientation = mbCheckOrientation ? 1 : 0;
+        std::vector<int32_t> pairs(2 * (size_t)std::max(n1, 1));
+        const int np = orbfe_search_tri_kb8(mDevice, &a, pairs.data());
+        if (np < 0) throw std::runtime_error("orbfe_search_tri_kb8 failed");
+        vMatchedPairs.clear();
         vMatchedPairs.reserve(np);
         for (int k = 0; k < np; k++) vMatchedPairs.push_back(std::make_pair((size_t)pairs[2 * k], (size_t)pairs[2 * k + 1]));
         return np;
@@ -808,6 +898,7 @@ public:
     static const int HISTO_LENGTH = 30;
     cv::Matx33f lastF12; // what SearchForTriangulation_ formed from the poses (read by the adapter's test)
     cv::Point2f lastEp;
+    std::vector<float> lastR12, lastT12; // the relative poses SearchForTriangulationKB8 formed (1 or 4: ll, lr, rl, rr)
 
 protected:
     float RadiusByViewingCos(const float& viewCos) // :199-205

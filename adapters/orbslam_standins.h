@@ -26,20 +26,26 @@ namespace ORB_SLAM3 {
 
 class KeyFrame;
 
-class GeometricCamera { // the Pinhole model (src/CameraModels/Pinhole.cpp)
+class GeometricCamera { // Pinhole (src/CameraModels/Pinhole.cpp) or, with mnType = 1, KannalaBrandt8
 public:
-    std::vector<float> mvParameters; // fx, fy, cx, cy
-    cv::Point2f project(const cv::Matx31f& m) const
-    { // Pinhole::project(const cv::Matx31f&), Pinhole.cpp:45-51
-        cv::Point2f p;
-        p.x = mvParameters[0] * m(0) / m(2) + mvParameters[2];
-        p.y = mvParameters[1] * m(1) / m(2) + mvParameters[3];
-        return p;
-    }
+    std::vector<float> mvParameters; // fx, fy, cx, cy (+ k0..k3 for the fisheye model)
+    unsigned int mnType = 0;         // GeometricCamera::CAM_PINHOLE = 0, CAM_FISHEYE = 1 (GeometricCamera.h:84-85)
+    unsigned int GetType() { return mnType; }
+    float getParameter(const int i) { return mvParameters[i]; }
+    cv::Point2f project(const cv::Matx31f& m) const { return project(cv::Point3f(m(0), m(1), m(2))); }
     cv::Point2f project(const cv::Point3f& p3) const
     {
         cv::Point2f p;
-        p.x = mvParameters[0] * p3.x / p3.z + mvParameters[2];
+        if (mnType == 1) { // equidistant model: image radius = polynomial of the angle to the optical axis
+            const float rho2 = p3.x * p3.x + p3.y * p3.y;
+            const float th = atan2f(sqrtf(rho2), p3.z), az = atan2f(p3.y, p3.x);
+            const float t2 = th * th, t3 = th * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+            const float rd = th + mvParameters[4] * t3 + mvParameters[5] * t5 + mvParameters[6] * t7 + mvParameters[7] * t9;
+            p.x = mvParameters[0] * rd * cosf(az) + mvParameters[2];
+            p.y = mvParameters[1] * rd * sinf(az) + mvParameters[3];
+            return p;
+        }
+        p.x = mvParameters[0] * p3.x / p3.z + mvParameters[2]; // Pinhole.cpp:45-51
         p.y = mvParameters[1] * p3.y / p3.z + mvParameters[3];
         return p;
     }

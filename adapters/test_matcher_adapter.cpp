@@ -239,6 +239,59 @@ static void test_tri(const std::string& P)
     put(P + "ep", 2, ep, 2);
 }
 
+// fisheye keyframes: a monocular pair, or a two-camera rig (features [0, NLeft) from the left camera)
+static void test_tri_kb8(const std::string& P)
+{
+    KeyFrame k1, k2;
+    GeometricCamera c[4]; // 1L, 1R, 2L, 2R
+    fill_kf_geom(k1, P, "1");
+    fill_kf_geom(k2, P, "2");
+    set_featvec(k1.mFeatVec, k1.N, in(P + "node1").i32());
+    set_featvec(k2.mFeatVec, k2.N, in(P + "node2").i32());
+    set_points(k1.mvpMapPoints, k1.N, in(P + "mp1").i32(), 0);
+    set_points(k2.mvpMapPoints, k2.N, in(P + "mp2").i32(), 0);
+    const char* names[4] = {"cam1L", "cam1R", "cam2L", "cam2R"};
+    const bool rig = in(P + "rig").i32()[0] != 0;
+    for (int i = 0; i < 4; i++) {
+        if (!rig && (i & 1)) continue;
+        c[i].mvParameters.assign(in(P + names[i]).f32(), in(P + names[i]).f32() + 8);
+        c[i].mnType = 1;
+    }
+    k1.mpCamera = &c[0];
+    k2.mpCamera = &c[2];
+    k1.Rcw = m33(in(P + "R1").f32()); k1.tcw = m31(in(P + "t1").f32()); k1.Ow = m31(in(P + "O1").f32());
+    k2.Rcw = m33(in(P + "R2").f32()); k2.tcw = m31(in(P + "t2").f32());
+    if (rig) {
+        KeyFrame* ks[2] = {&k1, &k2};
+        for (int j = 0; j < 2; j++) {
+            KeyFrame& k = *ks[j];
+            const std::string S = j ? "2" : "1";
+            k.NLeft = in(P + "NLeft" + S).i32()[0];
+            k.mvKeys.assign(k.mvKeysUn.begin(), k.mvKeysUn.begin() + k.NLeft);
+            k.mvKeysRight.assign(k.mvKeysUn.begin() + k.NLeft, k.mvKeysUn.end());
+            set_keys(k.mvKeysUn, k.NLeft, nullptr, nullptr, nullptr, nullptr); // (a rig's mvKeysUn holds NLeft entries, :857)
+            k.mpCamera2 = &c[2 * j + 1];
+            k.RcwR = m33(in(P + "R" + S + "R").f32());
+            k.tcwR = m31(in(P + "t" + S + "R").f32());
+        }
+    }
+    ORBmatcher matcher(0.6f, in(P + "ori").i32()[0] != 0);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    const int nm = matcher.SearchForTriangulation_(&k1, &k2, cv::Matx33f(), pairs, in(P + "stereo").i32()[0] != 0,
+                                                   in(P + "coarse").i32()[0] != 0);
+    std::vector<int32_t> out;
+    for (auto& pr : pairs) {
+        out.push_back((int32_t)pr.first);
+        out.push_back((int32_t)pr.second);
+    }
+    put_i(P + "pairs", out);
+    put_i(P + "n", std::vector<int32_t>(1, nm));
+    put(P + "R12", 2, matcher.lastR12.data(), matcher.lastR12.size());
+    put(P + "t12", 2, matcher.lastT12.data(), matcher.lastT12.size());
+    const float ep[2] = {matcher.lastEp.x, matcher.lastEp.y};
+    put(P + "ep", 2, ep, 2);
+}
+
 static void fill_frame(Frame& F, const std::string& P)
 {
     const int n = (int)in(P + "kx").count;
@@ -635,6 +688,7 @@ int main(int argc, char** argv)
         for (int k = 0; has("bow" + std::to_string(k) + ".a1"); k++) test_bow_kf_f("bow" + std::to_string(k) + ".");
         for (int k = 0; has("kk" + std::to_string(k) + ".a1"); k++) test_bow_kf_kf("kk" + std::to_string(k) + ".");
         for (int k = 0; has("tri" + std::to_string(k) + ".a1"); k++) test_tri("tri" + std::to_string(k) + ".");
+        for (int k = 0; has("tk" + std::to_string(k) + ".a1"); k++) test_tri_kb8("tk" + std::to_string(k) + ".");
         for (int k = 0; has("p0_" + std::to_string(k) + ".kx"); k++) test_proj_local("p0_" + std::to_string(k) + ".");
         for (int k = 0; has("p1_" + std::to_string(k) + ".kx"); k++) test_proj_last("p1_" + std::to_string(k) + ".");
         for (int k = 0; has("fu" + std::to_string(k) + ".kx"); k++) test_fuse("fu" + std::to_string(k) + ".");

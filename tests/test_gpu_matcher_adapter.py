@@ -161,6 +161,51 @@ def _tri(f, tag, oracle, seed, n1, n2, stereo, coarse, ori):
     return check
 
 
+def _tri_kb8(f, tag, oracle, seed, n1, n2, rig, coarse):
+    """SearchForTriangulation_ between fisheye keyframes (KannalaBrandt8 gate): a monocular pair, or two-camera rigs with
+    the four relative poses of src/ORBmatcher.cc:1238-1248 formed by the adapter from the keyframes' poses."""
+    import matcher_inputs as MI
+    I = MI.tri_kb8_inputs(n1, n2, seed, rig=rig)
+    nodes = _nodes(np.concatenate([I["d1"], I["d2"]]), seed + 1, 5)
+    node1, node2 = nodes[:n1].copy(), nodes[n1:].copy()
+    I["fv1"], I["fv2"] = _csr_from_nodes(node1), _csr_from_nodes(node2)
+    I["u1"], I["u2"] = np.full(n1, -1, np.float32), np.full(n2, -1, np.float32)
+    # keyframe poses that give the generator's relative poses: keyframe 1 (left) is the world frame
+    R64, t64 = I["R12"].astype(np.float64), I["t12"].astype(np.float64)
+    Rll, tll = R64[0], t64[0]
+    R2, t2 = Rll.T, -Rll.T @ tll
+    arrays = [("R1", np.eye(3)), ("t1", np.zeros(3)), ("O1", np.zeros(3)), ("R2", R2), ("t2", t2)]
+    if rig:
+        Rrl = R64[2] @ Rll.T                      # x_right = Rrl x_left + trl inside a rig
+        trl = t64[2] - Rrl @ tll
+        arrays += [("R1R", Rrl), ("t1R", trl), ("R2R", Rrl @ R2), ("t2R", Rrl @ t2 + trl),
+                   ("NLeft1", np.array([I["Nleft1"]], np.int32)), ("NLeft2", np.array([I["Nleft2"]], np.int32)),
+                   ("cam1R", I["P1R"]), ("cam2R", I["P2R"])]
+    for s_, (kp, a, oc, d, u, node, mp) in (("1", (I["kp1"], I["a1"], I["oct1"], I["d1"], I["u1"], node1, I["has1"])),
+                                           ("2", (I["kp2"], I["a2"], I["oct2"], I["d2"], I["u2"], node2, I["has2"]))):
+        for k, v in (("x", kp[:, 0]), ("y", kp[:, 1]), ("a", a), ("oct", oc), ("d", d), ("ur", u), ("node", node),
+                     ("mp", mp.astype(np.int32))):
+            _put(f, tag + k + s_, np.ascontiguousarray(v))
+    for k, v in arrays + [("sf", SF), ("cam1L", I["P1L"]), ("cam2L", I["P2L"]), ("rig", np.array([int(rig)], np.int32)),
+                          ("stereo", np.array([0], np.int32)), ("coarse", np.array([int(coarse)], np.int32)),
+                          ("ori", np.array([1], np.int32))]:
+        _put(f, tag + k, v if np.asarray(v).dtype in (np.int32, np.uint8) else np.asarray(v, np.float32))
+
+    def check(res):
+        nposes = 4 if rig else 1
+        R12, t12 = res[tag + "R12"].reshape(nposes, 3, 3), res[tag + "t12"].reshape(nposes, 3)
+        assert np.allclose(R12, I["R12"], atol=2e-6) and np.allclose(t12, I["t12"], atol=2e-6), tag   # the float pose algebra
+        ep = MI.kb8_project64(I["P2L"], (R2 @ np.zeros(3) + t2)[None, :])[0]
+        assert np.allclose(res[tag + "ep"], ep, rtol=1e-4), (tag, res[tag + "ep"], ep)
+        J = dict(I, R12=R12, t12=t12, ep=res[tag + "ep"])
+        pairs = oracle.search_triangulation_kb8(J, coarse=coarse)
+        assert res[tag + "n"][0] == len(pairs) and len(pairs) > 40, (tag, len(pairs))
+        assert np.array_equal(res[tag + "pairs"].reshape(-1, 2), pairs), tag
+        if not coarse:
+            assert len(pairs) < len(oracle.search_triangulation_kb8(J, coarse=True)), tag   # the gate rejected something
+    return check
+
+
 GRID = dict(minX=np.float32(0), minY=np.float32(0), maxX=np.float32(768), maxY=np.float32(512))
 
 
@@ -836,6 +881,9 @@ def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle):
         checks.append(_tri(f, "tri0.", oracle, 31, 1000, 1100, False, False, True))
         checks.append(_tri(f, "tri1.", oracle, 32, 800, 700, True, False, True))
         checks.append(_tri(f, "tri2.", oracle, 33, 600, 600, False, True, False))
+        checks.append(_tri_kb8(f, "tk0.", oracle, 35, 1000, 900, False, False))               # monocular fisheye pair
+        checks.append(_tri_kb8(f, "tk1.", oracle, 36, 1100, 1000, True, False))               # two-camera rigs
+        checks.append(_tri_kb8(f, "tk2.", oracle, 37, 800, 900, True, True))
         checks.append(_proj_local(f, "p0_0.", oracle, 41, 1500, 1200, 1.0, True, False))
         checks.append(_proj_local(f, "p0_1.", oracle, 42, 1200, 900, 3.0, False, True))
         checks.append(_proj_last(f, "p1_0.", oracle, 51, 1500, 1000, 7.0, True, 0.0, False, True))     # neither direction
