@@ -19,7 +19,8 @@
  *   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  :1967-2191           mode 1, one call per direction
  *   SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  :706-821  orbfe_search_initialization
  *   SearchForTriangulation(KF1, KF2, cv::Mat F12, ...)  src/ORBmatcher.cc:965-1206  = SearchForTriangulation_
- *   (the matchAndtriangulate overload :1452-1641 has no caller in the reference: declared, throws)
+ *   SearchForTriangulation(KF1, KF2, F12, ..., vMatchedPoints)  :1452-1641  orbfe_search_tri_3d (no caller in the
+ *                                                                 reference; KannalaBrandt8::matchAndtriangulate gate)
  *   DescriptorDistance                                  src/ORBmatcher.cc:2591-2607  (host, one pair: a call per pair
  *                                                                                     would cost more than it computes)
  *
@@ -780,11 +781,68 @@ public:
     {
         return SearchForTriangulation_(pKF1, pKF2, cv::Matx33f(), vMatchedPairs, bOnlyStereo, bCoarse);
     }
-    // ---- src/ORBmatcher.cc:1452-1641: the matchAndtriangulate overload has no caller in the reference; not built
-    int SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t, size_t>>&, const bool,
-                               std::vector<cv::Mat>&)
+    // ---- src/ORBmatcher.cc:1452-1641: the overload that also returns the triangulated points (declared :73-75 of the
+    // header, no caller in the reference).  Neither F12 nor bOnlyStereo is read by it; its gate is
+    // pCamera1->matchAndtriangulate, which only KannalaBrandt8 implements (Pinhole's returns false: no pairs).
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat /*F12*/,
+                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool /*bOnlyStereo*/,
+                               std::vector<cv::Mat>& vMatchedPoints)
     {
-        throw std::runtime_error("SearchForTriangulation(..., vMatchedPoints): uncalled in the reference, not built");
+        using namespace orbfe_adapter;
+        const bool rig1 = pKF1->NLeft != -1, rig2 = pKF2->NLeft != -1;
+        GeometricCamera* cams[4] = {pKF1->mpCamera, rig1 ? pKF1->mpCamera2 : pKF1->mpCamera, pKF2->mpCamera,
+                                    rig2 ? pKF2->mpCamera2 : pKF2->mpCamera};
+        const bool fisheye = pKF1->mpCamera->GetType() == 1u /* GeometricCamera::CAM_FISHEYE */;
+        float P[4][8], T[4][12];
+        KeyFrame* kfs[2] = {pKF1, pKF2};
+        for (int c = 0; c < 4; c++) {
+            float R[9], t[3], O[3];
+            kf_pose(kfs[c / 2], (c & 1) && (c / 2 ? rig2 : rig1), R, t, O); // GetPose / GetRightPose (:1519-1533)
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) T[c][4 * i + j] = R[3 * i + j];
+                T[c][4 * i + 3] = t[i];
+            }
+            for (int i = 0; i < 8; i++) P[c][i] = (fisheye && cams[c]->GetType() == 1u) ? cams[c]->getParameter(i) : 0.f;
+        }
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        std::vector<uint8_t> has1(n1), has2(n2), tmp1, tmp2;
+        std::vector<float> xy1(2 * (size_t)n1), xy2(2 * (size_t)n2), ang1(n1), ang2(n2);
+        std::vector<int32_t> oct1(n1), oct2(n2);
+        for (int i = 0; i < n1; i++) {
+            has1[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+            const cv::KeyPoint& kp = rig_keypoint(*pKF1, pKF1->NLeft, (size_t)i);
+            xy1[2 * i] = kp.pt.x; xy1[2 * i + 1] = kp.pt.y; ang1[i] = kp.angle; oct1[i] = kp.octave;
+        }
+        for (int i = 0; i < n2; i++) {
+            has2[i] = pKF2->GetMapPoint(i) ? 1 : 0;
+            const cv::KeyPoint& kp = rig_keypoint(*pKF2, pKF2->NLeft, (size_t)i);
+            xy2[2 * i] = kp.pt.x; xy2[2 * i + 1] = kp.pt.y; ang2[i] = kp.angle; oct2[i] = kp.octave;
+        }
+        const CSR c1 = toCSR(pKF1->mFeatVec), c2 = toCSR(pKF2->mFeatVec);
+        orbfe_tri3d_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.desc1 = dense_descriptors(pKF1->mDescriptors, n1, tmp1); a.n1 = n1; a.hasMP1 = has1.data();
+        a.kp1_xy = xy1.data(); a.angle1 = ang1.data(); a.octave1 = oct1.data(); a.fv1 = c1.view(); a.Nleft1 = pKF1->NLeft;
+        a.desc2 = dense_descriptors(pKF2->mDescriptors, n2, tmp2); a.n2 = n2; a.hasMP2 = has2.data();
+        a.kp2_xy = xy2.data(); a.angle2 = ang2.data(); a.octave2 = oct2.data(); a.fv2 = c2.view(); a.Nleft2 = pKF2->NLeft;
+        a.kb8_1L = fisheye ? P[0] : nullptr; a.kb8_1R = P[1]; a.kb8_2L = P[2]; a.kb8_2R = P[3];
+        a.Tcw1L = T[0]; a.Tcw1R = T[1]; a.Tcw2L = T[2]; a.Tcw2R = T[3];
+        a.levelSigma2_1 = pKF1->mvLevelSigma2.data(); a.levelSigma2_2 = pKF2->mvLevelSigma2.data();
+        a.nlevels1 = (int)pKF1->mvLevelSigma2.size(); a.nlevels2 = (int)pKF2->mvLevelSigma2.size();
+        a.check_orientation = mbCheckOrientation ? 1 : 0;
+        std::vector<int32_t> pairs(2 * (size_t)std::max(n1, 1));
+        std::vector<float> points(3 * (size_t)std::max(n1, 1));
+        const int np = orbfe_search_tri_3d(mDevice, &a, pairs.data(), points.data());
+        if (np < 0) throw std::runtime_error("orbfe_search_tri_3d failed");
+        vMatchedPairs.clear(); // :1625-1637
+        vMatchedPairs.reserve(np);
+        for (int k = 0; k < np; k++) {
+            vMatchedPairs.push_back(std::make_pair((size_t)pairs[2 * k], (size_t)pairs[2 * k + 1]));
+            cv::Mat x3D(3, 1, CV_32F);
+            for (int i = 0; i < 3; i++) x3D.at<float>(i) = points[3 * (size_t)k + i];
+            vMatchedPoints.push_back(x3D);
+        }
+        return np;
     }
 
     // ---- src/ORBmatcher.cc:1967-2191 (LoopClosing / merging): mutual projection search under a Sim3

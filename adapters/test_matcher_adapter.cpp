@@ -237,6 +237,9 @@ static void test_tri(const std::string& P)
     put(P + "F12", 2, matcher.lastF12.val, 9);
     const float ep[2] = {matcher.lastEp.x, matcher.lastEp.y};
     put(P + "ep", 2, ep, 2);
+    std::vector<std::pair<size_t, size_t>> pairs3; // pinhole cameras: Pinhole::matchAndtriangulate accepts nothing
+    std::vector<cv::Mat> pts3;
+    put_i(P + "n3d", std::vector<int32_t>(1, matcher.SearchForTriangulation(&k1, &k2, cv::Mat(), pairs3, false, pts3)));
 }
 
 // fisheye keyframes: a monocular pair, or a two-camera rig (features [0, NLeft) from the left camera)
@@ -290,6 +293,20 @@ static void test_tri_kb8(const std::string& P)
     put(P + "t12", 2, matcher.lastT12.data(), matcher.lastT12.size());
     const float ep[2] = {matcher.lastEp.x, matcher.lastEp.y};
     put(P + "ep", 2, ep, 2);
+    // the overload that also triangulates (src/ORBmatcher.cc:1452-1641) on the same keyframes
+    std::vector<std::pair<size_t, size_t>> pairs3;
+    std::vector<cv::Mat> pts3;
+    const int n3 = matcher.SearchForTriangulation(&k1, &k2, cv::Mat(), pairs3, false, pts3);
+    std::vector<int32_t> out3;
+    std::vector<float> x3;
+    for (size_t k = 0; k < pairs3.size(); k++) {
+        out3.push_back((int32_t)pairs3[k].first);
+        out3.push_back((int32_t)pairs3[k].second);
+        for (int i = 0; i < 3; i++) x3.push_back(pts3[k].at<float>(i));
+    }
+    put_i(P + "pairs3d", out3);
+    put(P + "points3d", 2, x3.data(), x3.size());
+    put_i(P + "n3d", std::vector<int32_t>(1, n3));
 }
 
 static void fill_frame(Frame& F, const std::string& P)

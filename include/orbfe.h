@@ -311,6 +311,26 @@ typedef struct {
     int only_stereo, coarse, check_orientation;
 } orbfe_tri_kb8_args;
 int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args*, int32_t* pairs /* 2*n1 */);
+/* The SearchForTriangulation overload that also returns the triangulated points (src/ORBmatcher.cc:1452-1641;
+ * declared in include/ORBmatcher.h:73-75, no caller in the reference).  Same walk over the shared vocabulary nodes
+ * as SearchForTriangulation_, without the stereo and epipole gates (bOnlyStereo and F12 are not read by it); the
+ * gate is pCamera1->matchAndtriangulate(kp1, kp2, pCamera2, Tcw1, Tcw2, sigma1, sigma2, x3D):
+ * KannalaBrandt8's (src/CameraModels/KannalaBrandt8.cpp:244-335: parallax of the world rays, cv::Mat Triangulate
+ * :498-512, both depths, both reprojection errors) -- parity by tolerance like orbfe_search_tri_kb8 -- while
+ * Pinhole's returns false (include/CameraModels/Pinhole.h:88-91): kb8_1L == NULL (a pinhole first camera) yields 0
+ * pairs.  Tcw* = rows 0..2 of KeyFrame::GetPose / GetRightPose (3x4 row-major); the ..R entries are read for
+ * keyframes of a two-camera rig (Nleft != -1).  points[3*k..] is the world point of pairs[2*k..]. */
+typedef struct {
+    const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1_xy; const float* angle1;
+    const int32_t* octave1; orbfe_fv fv1; int Nleft1;
+    const uint8_t* desc2; int n2; const uint8_t* hasMP2; const float* kp2_xy; const float* angle2;
+    const int32_t* octave2; orbfe_fv fv2; int Nleft2;
+    const float* kb8_1L; const float* kb8_1R; const float* kb8_2L; const float* kb8_2R; /* fx,fy,cx,cy,k0..k3 */
+    const float* Tcw1L; const float* Tcw1R; const float* Tcw2L; const float* Tcw2R;     /* 12 floats each */
+    const float* levelSigma2_1; const float* levelSigma2_2; int nlevels1, nlevels2;
+    int check_orientation;
+} orbfe_tri3d_args;
+int orbfe_search_tri_3d(int device, const orbfe_tri3d_args*, int32_t* pairs /* 2*n1 */, float* points /* 3*n1 */);
 /* KannalaBrandt8::TriangulateMatches(_) for n explicit keypoint pairs -- the gate above, and what
  * Frame::ComputeStereoFishEyeMatches evaluates for every knn match that passes the ratio test (src/Frame.cc:1146-1155,
  * KannalaBrandt8.cpp:337-407): z1[i] = depth in camera 1 or -1 (accepted when > 0.0001f), p3D[3*i..] = the

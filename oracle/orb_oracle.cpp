@@ -1852,6 +1852,129 @@ float orb_oracle_kb8_triangulate_matches(const float* P1, const float* P2, const
     return z1;
 }
 
+// KannalaBrandt8::matchAndtriangulate (src/CameraModels/KannalaBrandt8.cpp:244-335) and the cv::Mat Triangulate it
+// calls (:498-512).  cv::Mat arithmetic on CV_32F: a matrix product (gemm) and Mat::dot accumulate in double and
+// round once; `s*row - row` is float (addWeighted); `m / s` scales by (float)(1.0 / s); cv::norm is double.
+int orb_oracle_kb8_match_and_triangulate(const float* P1, const float* P2, const float* kp1, const float* kp2,
+                                         const float* Tcw1, const float* Tcw2, float sigmaLevel1, float sigmaLevel2,
+                                         float* x3Dout)
+{
+    auto Rc = [](const float* T, int i, int j) { return T[i * 4 + j]; };
+    float r1[3], r2[3];
+    orb_oracle_kb8_unproject(P1, kp1, 1, r1); // ray1c, ray2c
+    orb_oracle_kb8_unproject(P2, kp2, 1, r2);
+    // Check parallax between rays: ray = Rwc * r (Rwc = Rcw^T)
+    float ray1[3], ray2[3];
+    for (int i = 0; i < 3; i++) {
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < 3; k++) {
+            s1 += (double)Rc(Tcw1, k, i) * (double)r1[k];
+            s2 += (double)Rc(Tcw2, k, i) * (double)r2[k];
+        }
+        ray1[i] = (float)s1;
+        ray2[i] = (float)s2;
+    }
+    double dot = 0;
+    for (int i = 0; i < 3; i++) dot += (double)ray1[i] * (double)ray2[i];
+    const float cosParallaxRays = (float)(dot / (matx_norm3(ray1) * matx_norm3(ray2)));
+    if (cosParallaxRays > 0.9998) return 0;
+    // Triangulate(p11, p22, Tcw1, Tcw2, x3D)
+    float A[16];
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = r1[0] * Tcw1[2 * 4 + k] - Tcw1[0 * 4 + k];
+        A[1 * 4 + k] = r1[1] * Tcw1[2 * 4 + k] - Tcw1[1 * 4 + k];
+        A[2 * 4 + k] = r2[0] * Tcw2[2 * 4 + k] - Tcw2[0 * 4 + k];
+        A[3 * 4 + k] = r2[1] * Tcw2[2 * 4 + k] - Tcw2[1 * 4 + k];
+    }
+    float vt[16];
+    jacobi_svd_vt_4x4(A, vt);
+    const float inv = (float)(1.0 / (double)vt[3 * 4 + 3]);
+    const float x3D[3] = {vt[3 * 4 + 0] * inv, vt[3 * 4 + 1] * inv, vt[3 * 4 + 2] * inv};
+    // Check triangulation in front of cameras
+    auto depth = [&](const float* T) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Rc(T, 2, k) * (double)x3D[k];
+        return (float)(s + (double)T[2 * 4 + 3]);
+    };
+    if (depth(Tcw1) <= 0) return 0;
+    if (depth(Tcw2) <= 0) return 0;
+    // Check reprojection errors: x3Dc = Rcw * x3D + tcw (one gemm)
+    auto reproj_ok = [&](const float* P, const float* T, const float* kp, float sigma) {
+        float xc[3];
+        for (int i = 0; i < 3; i++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)Rc(T, i, k) * (double)x3D[k];
+            xc[i] = (float)(s + (double)T[i * 4 + 3]);
+        }
+        float u, v;
+        kb8_project_pt(P, xc[0], xc[1], xc[2], &u, &v);
+        const float errX = u - kp[0];
+        const float errY = v - kp[1];
+        return !((errX * errX + errY * errY) > 5.991 * sigma);
+    };
+    if (!reproj_ok(P1, Tcw1, kp1, sigmaLevel1)) return 0;
+    if (!reproj_ok(P2, Tcw2, kp2, sigmaLevel2)) return 0;
+    for (int i = 0; i < 3; i++) x3Dout[i] = x3D[i];
+    return 1;
+}
+
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, vMatchedPoints), src/ORBmatcher.cc
+// :1452-1641 (bOnlyStereo and F12 are not read by it; no epipole gate; the gate is matchAndtriangulate).
+int orb_oracle_search_triangulation_3d(const orb_oracle_tri3d_args* a, int32_t* pairs, float* points)
+{
+    std::vector<int32_t> vMatches12(a->n1, -1);
+    std::vector<float> vMatchesPoints12(3 * (size_t)a->n1, 0.f);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for_each_shared_node(a->fv1, a->fv2, [&](int na, int nb) {
+        for (int i1 = a->fv1->offsets[na]; i1 < a->fv1->offsets[na + 1]; i1++) {
+            const int idx1 = a->fv1->indices[i1];
+            if (a->hasMP1[idx1]) continue;
+            const float* kp1 = a->kp1xy + 2 * idx1;
+            const bool bRight1 = !(a->Nleft1 == -1 || idx1 < a->Nleft1);
+            const uint8_t* d1 = a->desc1 + 32 * (size_t)idx1;
+            int bestDist = TH_LOW;
+            int bestIdx2 = -1;
+            float bestPoint[3] = {0.f, 0.f, 0.f};
+            for (int i2 = a->fv2->offsets[nb]; i2 < a->fv2->offsets[nb + 1]; i2++) {
+                const int idx2 = a->fv2->indices[i2];
+                if (a->hasMP2[idx2]) continue; // (vbMatched2 is never set, :1506)
+                const int dist = DescriptorDistance(d1, a->desc2 + 32 * (size_t)idx2);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const float* kp2 = a->kp2xy + 2 * idx2;
+                const bool bRight2 = !(a->Nleft2 == -1 || idx2 < a->Nleft2);
+                const float* P1 = bRight1 ? a->kb8_1R : a->kb8_1L;
+                const float* P2 = bRight2 ? a->kb8_2R : a->kb8_2L;
+                if (!P1) continue; // Pinhole::matchAndtriangulate returns false
+                float x3D[3];
+                if (orb_oracle_kb8_match_and_triangulate(P1, P2, kp1, kp2, bRight1 ? a->Tcw1R : a->Tcw1L,
+                                                         bRight2 ? a->Tcw2R : a->Tcw2L, a->levelSigma2_1[a->oct1[idx1]],
+                                                         a->levelSigma2_2[a->oct2[idx2]], x3D)) {
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                    for (int k = 0; k < 3; k++) bestPoint[k] = x3D[k];
+                }
+            }
+            if (bestIdx2 >= 0) {
+                vMatches12[idx1] = bestIdx2;
+                for (int k = 0; k < 3; k++) vMatchesPoints12[3 * (size_t)idx1 + k] = bestPoint[k];
+                nmatches++;
+                if (a->check_orientation) rotHist[rot_bin(a->ang1[idx1], a->ang2[bestIdx2])].push_back(idx1);
+            }
+        }
+    });
+    if (a->check_orientation) nmatches = cull_rotation(rotHist, vMatches12.data(), nmatches);
+    int np = 0;
+    for (int i = 0; i < a->n1; i++) {
+        if (vMatches12[i] < 0) continue;
+        pairs[2 * np] = i;
+        pairs[2 * np + 1] = vMatches12[i];
+        for (int k = 0; k < 3; k++) points[3 * np + k] = vMatchesPoints12[3 * (size_t)i + k];
+        np++;
+    }
+    return np;
+}
+
 // Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1119-1159): knn-2 brute force between the lapping-area
 // descriptors of the two fisheye images, Lowe ratio 0.7, then KannalaBrandt8::TriangulateMatches per survivor.
 // Inputs are the lapping-area slices (the caller adds monoLeft / monoRight to the indices).

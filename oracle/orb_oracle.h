@@ -145,6 +145,26 @@ typedef struct {
     int only_stereo, coarse, check_orientation;
 } orb_oracle_tri_kb8_args;
 int orb_oracle_search_triangulation_kb8(const orb_oracle_tri_kb8_args* a, int32_t* pairs);
+/* KannalaBrandt8::matchAndtriangulate (src/CameraModels/KannalaBrandt8.cpp:244-335, with Triangulate :498-512):
+ * 1 and the triangulated world point, or 0.  Tcw = rows 0..2 of the camera pose (3x4 row-major). */
+int orb_oracle_kb8_match_and_triangulate(const float* P1, const float* P2, const float* kp1xy, const float* kp2xy,
+                                         const float* Tcw1, const float* Tcw2, float sigmaLevel1, float sigmaLevel2,
+                                         float* x3D);
+/* The SearchForTriangulation overload that also returns the triangulated points (src/ORBmatcher.cc:1452-1641; no
+ * caller in the reference).  Its gate is pCamera1->matchAndtriangulate: Pinhole's returns false (include/
+ * CameraModels/Pinhole.h:88-91), so kb8_1L == NULL (pinhole camera 1) yields no pairs.  Poses are 3x4 row-major
+ * (GetPose / GetRightPose); points[3*k..] belongs to pairs[2*k..]. */
+typedef struct {
+    const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1xy; const float* ang1; const int32_t* oct1;
+    const orb_oracle_fv* fv1; int Nleft1;
+    const uint8_t* desc2; int n2; const uint8_t* hasMP2; const float* kp2xy; const float* ang2; const int32_t* oct2;
+    const orb_oracle_fv* fv2; int Nleft2;
+    const float* kb8_1L; const float* kb8_1R; const float* kb8_2L; const float* kb8_2R;
+    const float* Tcw1L; const float* Tcw1R; const float* Tcw2L; const float* Tcw2R;
+    const float* levelSigma2_1; const float* levelSigma2_2;
+    int check_orientation;
+} orb_oracle_tri3d_args;
+int orb_oracle_search_triangulation_3d(const orb_oracle_tri3d_args* a, int32_t* pairs, float* points);
 /* Inner loops of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:44-197 mode 0, :2193-2419 / :2421-2541
  * mode 1) over flattened inputs; same layout as orbfe_proj_args (include/orbfe.h).  Mode 1 also covers the
  * Sim3 overloads (:473-586, :588-704), and with qblocks all zero (independent queries) Fuse (:1643-1841 with

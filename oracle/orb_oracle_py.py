@@ -408,6 +408,16 @@ class _TriKb8Args(C.Structure):
                 ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+class _Tri3dArgs(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("hasMP1", C.c_void_p), ("kp1xy", C.c_void_p), ("ang1", C.c_void_p),
+                ("oct1", C.c_void_p), ("fv1", C.POINTER(_FV)), ("Nleft1", C.c_int),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("hasMP2", C.c_void_p), ("kp2xy", C.c_void_p), ("ang2", C.c_void_p),
+                ("oct2", C.c_void_p), ("fv2", C.POINTER(_FV)), ("Nleft2", C.c_int),
+                ("kb8_1L", C.c_void_p), ("kb8_1R", C.c_void_p), ("kb8_2L", C.c_void_p), ("kb8_2R", C.c_void_p),
+                ("Tcw1L", C.c_void_p), ("Tcw1R", C.c_void_p), ("Tcw2L", C.c_void_p), ("Tcw2R", C.c_void_p),
+                ("levelSigma2_1", C.c_void_p), ("levelSigma2_2", C.c_void_p), ("check_orientation", C.c_int)]
+
+
 class _ProjArgs(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p),
                 ("angle", C.c_void_p), ("uright", C.c_void_p), ("taken", C.c_void_p), ("Nleft", C.c_int),
@@ -505,6 +515,53 @@ def search_triangulation_kb8(I, only_stereo=False, coarse=False, check_ori=True)
     L.orb_oracle_search_triangulation_kb8.argtypes = [C.c_void_p, C.c_void_p]
     n = L.orb_oracle_search_triangulation_kb8(C.byref(a), _p(pairs))
     return pairs[:n].copy()
+
+
+def search_triangulation_3d(I, check_ori=True):
+    """ORBmatcher::SearchForTriangulation(..., vMatchedPoints) src/ORBmatcher.cc:1452-1641: (pairs[n,2], points[n,3])."""
+    keep = []
+
+    def arr(v, dt):
+        if v is None:
+            return None
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    f1 = _fv(I["fv1"])
+    f2 = _fv(I["fv2"])
+    T = I["Tcw"]
+    a = _Tri3dArgs(arr(I["d1"], np.uint8), len(I["d1"]), arr(I["has1"], np.uint8), arr(I["kp1"], np.float32),
+                   arr(I["a1"], np.float32), arr(I["oct1"], np.int32), C.pointer(f1), int(I["Nleft1"]),
+                   arr(I["d2"], np.uint8), len(I["d2"]), arr(I["has2"], np.uint8), arr(I["kp2"], np.float32),
+                   arr(I["a2"], np.float32), arr(I["oct2"], np.int32), C.pointer(f2), int(I["Nleft2"]),
+                   arr(I.get("P1L"), np.float32), arr(I.get("P1R"), np.float32), arr(I.get("P2L"), np.float32),
+                   arr(I.get("P2R"), np.float32), arr(T[0], np.float32), arr(T[1], np.float32), arr(T[2], np.float32),
+                   arr(T[3], np.float32), arr(I["sig1"], np.float32), arr(I["sig2"], np.float32), int(check_ori))
+    n1 = max(len(I["d1"]), 1)
+    pairs = np.zeros((n1, 2), np.int32)
+    points = np.zeros((n1, 3), np.float32)
+    L = lib()
+    L.orb_oracle_search_triangulation_3d.restype = C.c_int
+    L.orb_oracle_search_triangulation_3d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.orb_oracle_search_triangulation_3d(C.byref(a), _p(pairs), _p(points))
+    return pairs[:n].copy(), points[:n].copy()
+
+
+def kb8_match_and_triangulate(P1, P2, kp1, kp2, Tcw1, Tcw2, sigma1, sigma2):
+    """KannalaBrandt8::matchAndtriangulate per pair: (ok[n] bool, x3D[n,3])."""
+    L = lib()
+    L.orb_oracle_kb8_match_and_triangulate.restype = C.c_int
+    L.orb_oracle_kb8_match_and_triangulate.argtypes = [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_void_p]
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    A = [np.ascontiguousarray(v, np.float32) for v in (P1, P2, Tcw1, Tcw2)]
+    ok = np.zeros(len(kp1), bool)
+    X = np.zeros((len(kp1), 3), np.float32)
+    for i in range(len(kp1)):
+        ok[i] = L.orb_oracle_kb8_match_and_triangulate(_p(A[0]), _p(A[1]), kp1[i].ctypes.data, kp2[i].ctypes.data, _p(A[2]),
+                                                       _p(A[3]), float(sigma1[i]), float(sigma2[i]), X[i].ctypes.data) != 0
+    return ok, X
 
 
 def kb8_triangulate(P1, P2, kp1, kp2, R12, t12, sigma1, sigma2):

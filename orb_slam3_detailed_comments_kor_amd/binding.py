@@ -65,6 +65,17 @@ class _TriKb8Args(C.Structure):
                 ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
 
 
+class _Tri3dArgs(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("hasMP1", C.c_void_p), ("kp1_xy", C.c_void_p),
+                ("angle1", C.c_void_p), ("octave1", C.c_void_p), ("fv1", _FV), ("Nleft1", C.c_int),
+                ("desc2", C.c_void_p), ("n2", C.c_int), ("hasMP2", C.c_void_p), ("kp2_xy", C.c_void_p),
+                ("angle2", C.c_void_p), ("octave2", C.c_void_p), ("fv2", _FV), ("Nleft2", C.c_int),
+                ("kb8_1L", C.c_void_p), ("kb8_1R", C.c_void_p), ("kb8_2L", C.c_void_p), ("kb8_2R", C.c_void_p),
+                ("Tcw1L", C.c_void_p), ("Tcw1R", C.c_void_p), ("Tcw2L", C.c_void_p), ("Tcw2R", C.c_void_p),
+                ("levelSigma2_1", C.c_void_p), ("levelSigma2_2", C.c_void_p), ("nlevels1", C.c_int), ("nlevels2", C.c_int),
+                ("check_orientation", C.c_int)]
+
+
 class _InitArgs(C.Structure):
     _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int), ("octave1", C.c_void_p), ("angle1", C.c_void_p),
                 ("prev_xy", C.c_void_p),
@@ -237,7 +248,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_search_tri_3d", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -746,6 +757,37 @@ def search_triangulation_kb8(I, only_stereo=False, coarse=False, check_ori=True,
     pairs = np.zeros((max(len(I["d1"]), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri_kb8(device, C.byref(a), _p(pairs)), "orbfe_search_tri_kb8")
     return pairs[:n].copy()
+
+
+def search_triangulation_3d(I, check_ori=True, device=0):
+    """The SearchForTriangulation overload that returns the triangulated points (src/ORBmatcher.cc:1452-1641);
+    I = dict of tests/matcher_inputs.tri3d_inputs.  Returns (pairs[n,2], points[n,3])."""
+    keep = []
+
+    def arr(v, dt):
+        if v is None:
+            return None
+        a = np.ascontiguousarray(v, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    f1, k1 = _fv(I["fv1"])
+    f2, k2 = _fv(I["fv2"])
+    s1 = np.ascontiguousarray(I["sig1"], np.float32)
+    s2 = np.ascontiguousarray(I["sig2"], np.float32)
+    T = I["Tcw"]  # 1L, 1R, 2L, 2R
+    a = _Tri3dArgs(arr(I["d1"], np.uint8), len(I["d1"]), arr(I["has1"], np.uint8), arr(I["kp1"], np.float32),
+                   arr(I["a1"], np.float32), arr(I["oct1"], np.int32), f1, int(I["Nleft1"]),
+                   arr(I["d2"], np.uint8), len(I["d2"]), arr(I["has2"], np.uint8), arr(I["kp2"], np.float32),
+                   arr(I["a2"], np.float32), arr(I["oct2"], np.int32), f2, int(I["Nleft2"]),
+                   arr(I.get("P1L"), np.float32), arr(I.get("P1R"), np.float32), arr(I.get("P2L"), np.float32),
+                   arr(I.get("P2R"), np.float32), arr(T[0], np.float32), arr(T[1], np.float32), arr(T[2], np.float32),
+                   arr(T[3], np.float32), s1.ctypes.data, s2.ctypes.data, len(s1), len(s2), int(check_ori))
+    n1 = max(len(I["d1"]), 1)
+    pairs = np.zeros((n1, 2), np.int32)
+    points = np.zeros((n1, 3), np.float32)
+    n = _chk(lib().orbfe_search_tri_3d(device, C.byref(a), _p(pairs), _p(points)), "orbfe_search_tri_3d")
+    return pairs[:n].copy(), points[:n].copy()
 
 
 def kb8_triangulate(P1, P2, kp1, kp2, R12, t12, sigma1, sigma2, device=0):

@@ -211,5 +211,66 @@ __device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, 
     }
     return z1;
 }
+
+/* KannalaBrandt8::matchAndtriangulate (KannalaBrandt8.cpp:244-335) with the cv::Mat Triangulate (:498-512): true and
+ * the world point, or false.  T = rows 0..2 of the camera pose (3x4 row-major).  cv::Mat products and dots
+ * accumulate in double and round once; the rows of A are float; `/ w` scales by (float)(1.0 / w). */
+__device__ inline bool orbfe_kb8_match_triangulate_dev(const float* __restrict__ P1, const float* __restrict__ P2, float k1x,
+                                                       float k1y, float k2x, float k2y, const float* __restrict__ T1,
+                                                       const float* __restrict__ T2, float sigma1, float sigma2, float* X)
+{
+    float r1[3], r2[3], ray1[3], ray2[3];
+    orbfe_kb8_unproject_dev(P1, k1x, k1y, r1);
+    orbfe_kb8_unproject_dev(P2, k2x, k2y, r2);
+    for (int i = 0; i < 3; i++) {
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < 3; k++) {
+            s1 = __dadd_rn(s1, __dmul_rn((double)T1[k * 4 + i], (double)r1[k]));
+            s2 = __dadd_rn(s2, __dmul_rn((double)T2[k * 4 + i], (double)r2[k]));
+        }
+        ray1[i] = (float)s1;
+        ray2[i] = (float)s2;
+    }
+    double dot = 0, n1 = 0, n2 = 0;
+    for (int i = 0; i < 3; i++) {
+        dot = __dadd_rn(dot, __dmul_rn((double)ray1[i], (double)ray2[i]));
+        n1 = __dadd_rn(n1, __dmul_rn((double)ray1[i], (double)ray1[i]));
+        n2 = __dadd_rn(n2, __dmul_rn((double)ray2[i], (double)ray2[i]));
+    }
+    const float cosParallax = (float)__ddiv_rn(dot, __dmul_rn(__dsqrt_rn(n1), __dsqrt_rn(n2)));
+    if ((double)cosParallax > 0.9998) return false;
+    float A[16];
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = __fsub_rn(__fmul_rn(r1[0], T1[8 + k]), T1[k]);
+        A[1 * 4 + k] = __fsub_rn(__fmul_rn(r1[1], T1[8 + k]), T1[4 + k]);
+        A[2 * 4 + k] = __fsub_rn(__fmul_rn(r2[0], T2[8 + k]), T2[k]);
+        A[3 * 4 + k] = __fsub_rn(__fmul_rn(r2[1], T2[8 + k]), T2[4 + k]);
+    }
+    float h[4];
+    orbfe_svd4_last_vt(A, h);
+    const float inv = (float)__ddiv_rn(1.0, (double)h[3]);
+    const float Xw[3] = {__fmul_rn(h[0], inv), __fmul_rn(h[1], inv), __fmul_rn(h[2], inv)};
+    const float* Ts[2] = {T1, T2};
+    const float* Ps[2] = {P1, P2};
+    const float kx[2] = {k1x, k2x}, ky[2] = {k1y, k2y}, sg[2] = {sigma1, sigma2};
+    float xc[2][3];
+    for (int c = 0; c < 2; c++) // both depths are tested before either reprojection (:295-306)
+        for (int i = 0; i < 3; i++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s = __dadd_rn(s, __dmul_rn((double)Ts[c][i * 4 + k], (double)Xw[k]));
+            xc[c][i] = (float)__dadd_rn(s, (double)Ts[c][i * 4 + 3]);
+        }
+    if (xc[0][2] <= 0.f || xc[1][2] <= 0.f) return false;
+    for (int c = 0; c < 2; c++) {
+        float u, v;
+        orbfe_kb8_project_dev(Ps[c], xc[c][0], xc[c][1], xc[c][2], &u, &v);
+        const float ex = __fsub_rn(u, kx[c]), ey = __fsub_rn(v, ky[c]);
+        if ((double)__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) > __dmul_rn(5.991, (double)sg[c])) return false;
+    }
+    X[0] = Xw[0];
+    X[1] = Xw[1];
+    X[2] = Xw[2];
+    return true;
+}
 #endif /* ORBFE_SINCOS_H */
 #endif

@@ -526,6 +526,65 @@ __global__ __launch_bounds__(256) void k_kb8_triangulate(const float* __restrict
     }
 }
 
+// The SearchForTriangulation overload that returns the triangulated points (src/ORBmatcher.cc:1452-1641): rows as in
+// k_search_tri_kb8, no stereo / epipole gates, the gate is KannalaBrandt8::matchAndtriangulate with the world poses
+// of the two cameras a candidate pair belongs to; the winner's point goes to points[3 * idx1].
+struct Tri3dDev {
+    const TriRow* rows;
+    int nRows;
+    const uint8_t *desc1, *desc2, *hasMP2;
+    const float *kp1, *kp2;
+    const int32_t *oct1, *oct2, *ind2;
+    int Nleft1, Nleft2;
+    float P[4][8];  // 1L, 1R, 2L, 2R
+    float T[4][12]; // their poses
+    const float *sig1, *sig2;
+    int32_t* match12;
+    float* points;
+};
+__global__ __launch_bounds__(256) void k_search_tri_3d(Tri3dDev T)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rix = blockIdx.x * 4 + wave;
+    if (rix >= T.nRows) return;
+    const TriRow R = T.rows[rix];
+    const int idx1 = R.idx1;
+    const Desc d1 = load_desc(T.desc1 + (size_t)idx1 * 32);
+    const float k1x = T.kp1[2 * idx1], k1y = T.kp1[2 * idx1 + 1];
+    const int c1 = (T.Nleft1 == -1 || idx1 < T.Nleft1) ? 0 : 1;
+    const float sigma1 = T.sig1[T.oct1[idx1]];
+    unsigned best = 0xFFFFFFFFu;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    for (int c = lane; c < R.n2; c += 64) {
+        const int idx2 = T.ind2[R.off2 + c];
+        if (T.hasMP2[idx2]) continue;
+        const int dist = hamming(d1, load_desc(T.desc2 + (size_t)idx2 * 32));
+        if (dist > TH_LOW) continue;
+        const unsigned key = ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c); // smallest dist, then last position
+        if (key >= best) continue;                                              // (cannot win: skip its triangulation)
+        const int c2 = (T.Nleft2 == -1 || idx2 < T.Nleft2) ? 2 : 3;
+        float X[3];
+        if (!orbfe_kb8_match_triangulate_dev(T.P[c1], T.P[c2], k1x, k1y, T.kp2[2 * idx2], T.kp2[2 * idx2 + 1], T.T[c1], T.T[c2],
+                                             sigma1, T.sig2[T.oct2[idx2]], X))
+            continue;
+        best = key;
+        bx = X[0];
+        by = X[1];
+        bz = X[2];
+    }
+    const unsigned win = wave_min_u32(best);
+    if (win == 0xFFFFFFFFu) {
+        if (lane == 0) T.match12[idx1] = -1;
+        return;
+    }
+    if (best == win) { // keys are distinct: exactly one lane
+        T.match12[idx1] = T.ind2[R.off2 + (int)(0xFFFFFu - (win & 0xFFFFFu))];
+        T.points[3 * (size_t)idx1] = bx;
+        T.points[3 * (size_t)idx1 + 1] = by;
+        T.points[3 * (size_t)idx1 + 2] = bz;
+    }
+}
+
 // Frame::ComputeStereoFishEyeMatches after the knn search (src/Frame.cc:1142-1157): Lowe ratio on the two
 // nearest right descriptors, then KannalaBrandt8::TriangulateMatches of the survivor with its best neighbour.
 __global__ __launch_bounds__(256) void k_fisheye_stereo(const int32_t* __restrict__ knnIdx, const int32_t* __restrict__ knnDist,
@@ -2050,6 +2109,98 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
         if (m12[i] < 0) continue;
         pairs[2 * np] = i;
         pairs[2 * np + 1] = m12[i];
+        np++;
+    }
+    return np;
+}
+
+int orbfe_search_tri_3d(int device, const orbfe_tri3d_args* a, int32_t* pairs, float* points)
+{
+    if (!a || !pairs || !points || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
+    if (a->n1 == 0 || a->n2 == 0) return 0;
+    if (!a->desc1 || !a->desc2 || !a->hasMP1 || !a->hasMP2 || !a->kp1_xy || !a->kp2_xy || !a->octave1 || !a->octave2 ||
+        !a->levelSigma2_1 || !a->levelSigma2_2 || a->nlevels1 < 1 || a->nlevels2 < 1)
+        return ORBFE_ERR_ARGS;
+    if (!a->kb8_1L) return 0; // Pinhole::matchAndtriangulate returns false (include/CameraModels/Pinhole.h:88-91)
+    if (!a->kb8_2L || !a->Tcw1L || !a->Tcw2L) return ORBFE_ERR_ARGS;
+    if (a->Nleft1 != -1 && (a->Nleft1 < 0 || a->Nleft1 > a->n1 || !a->kb8_1R || !a->Tcw1R)) return ORBFE_ERR_ARGS;
+    if (a->Nleft2 != -1 && (a->Nleft2 < 0 || a->Nleft2 > a->n2 || !a->kb8_2R || !a->Tcw2R)) return ORBFE_ERR_ARGS;
+    if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < a->n1; i++)
+        if (a->octave1[i] < 0 || a->octave1[i] >= a->nlevels1) return ORBFE_ERR_ARGS;
+    for (int i = 0; i < a->n2; i++)
+        if (a->octave2[i] < 0 || a->octave2[i] >= a->nlevels2) return ORBFE_ERR_ARGS;
+    std::vector<TriRow> rows;
+    for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
+        const int off2 = a->fv2.offsets[j], n2 = a->fv2.offsets[j + 1] - off2;
+        for (int k = a->fv1.offsets[i]; k < a->fv1.offsets[i + 1]; k++) {
+            const int idx1 = a->fv1.indices[k];
+            if (a->hasMP1[idx1]) continue;
+            if (n2 > 0) rows.push_back(TriRow{idx1, off2, n2});
+        }
+    });
+    if (rows.empty()) return 0;
+    for (const TriRow& t : rows)
+        if (t.n2 >= (1 << 20)) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    Tri3dDev T{};
+    TriRow* dR;
+    uint8_t *d1, *d2, *h2;
+    float *k1, *k2, *sg1, *sg2, *dX;
+    int32_t *o1, *o2, *i2, *dM;
+    if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
+    if ((r = s.up_desc(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
+    if ((r = s.up_desc(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
+    if ((r = s.up(&h2, a->hasMP2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&k1, a->kp1_xy, (size_t)a->n1 * 2)) < 0) return r;
+    if ((r = s.up(&k2, a->kp2_xy, (size_t)a->n2 * 2)) < 0) return r;
+    if ((r = s.up(&sg1, a->levelSigma2_1, (size_t)a->nlevels1)) < 0) return r;
+    if ((r = s.up(&sg2, a->levelSigma2_2, (size_t)a->nlevels2)) < 0) return r;
+    if ((r = s.up(&o1, a->octave1, (size_t)a->n1)) < 0) return r;
+    if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
+    if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
+    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
+    if ((r = s.up<float>(&dX, nullptr, (size_t)a->n1 * 3)) < 0) return r;
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), g_ms));
+    T.rows = dR; T.nRows = (int)rows.size(); T.desc1 = d1; T.desc2 = d2; T.hasMP2 = h2; T.kp1 = k1; T.kp2 = k2;
+    T.oct1 = o1; T.oct2 = o2; T.ind2 = i2; T.Nleft1 = a->Nleft1; T.Nleft2 = a->Nleft2;
+    const float* Ps[4] = {a->kb8_1L, a->Nleft1 != -1 ? a->kb8_1R : a->kb8_1L, a->kb8_2L, a->Nleft2 != -1 ? a->kb8_2R : a->kb8_2L};
+    const float* Ts[4] = {a->Tcw1L, a->Nleft1 != -1 ? a->Tcw1R : a->Tcw1L, a->Tcw2L, a->Nleft2 != -1 ? a->Tcw2R : a->Tcw2L};
+    for (int c = 0; c < 4; c++) {
+        std::memcpy(T.P[c], Ps[c], 8 * sizeof(float));
+        std::memcpy(T.T[c], Ts[c], 12 * sizeof(float));
+    }
+    T.sig1 = sg1; T.sig2 = sg2; T.match12 = dM; T.points = dX;
+    {
+        KernelTimer timer(s);
+        hipLaunchKernelGGL(k_search_tri_3d, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, T);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> m12(a->n1);
+    std::vector<float> X((size_t)a->n1 * 3);
+    INT_TRY(s.down(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t)));
+    INT_TRY(s.down(X.data(), dX, X.size() * sizeof(float)));
+    INT_TRY(s.fetch());
+    std::vector<int8_t> bins(a->n1, -1);
+    if (a->check_orientation) {
+        for (int i = 0; i < a->n1; i++)
+            if (m12[i] >= 0) {
+                float rot = a->angle1[i] - a->angle2[m12[i]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[i] = (int8_t)bin;
+            }
+    }
+    cull_by_rotation(m12.data(), bins.data(), a->n1, a->check_orientation != 0);
+    int np = 0;
+    for (int i = 0; i < a->n1; i++) {
+        if (m12[i] < 0) continue;
+        pairs[2 * np] = i;
+        pairs[2 * np + 1] = m12[i];
+        for (int k = 0; k < 3; k++) points[3 * np + k] = X[3 * (size_t)i + k];
         np++;
     }
     return np;

@@ -223,6 +223,24 @@ def tri_kb8_inputs(n1, n2, seed, rig=False):
                 P2R=P2R, R12=Rs if rig else Rs[:1], t12=ts if rig else ts[:1], ep=(300.0, 250.0), sf=sf, sig1=sig, sig2=sig)
 
 
+def tri3d_inputs(n1, n2, seed, rig=False):
+    """tri_kb8_inputs plus the world poses (rows 0..2, 3x4) of the cameras 1L, 1R, 2L, 2R that give its relative poses:
+    keyframe 1's left camera is the world frame."""
+    I = tri_kb8_inputs(n1, n2, seed, rig=rig)
+    R64, t64 = I["R12"].astype(np.float64), I["t12"].astype(np.float64)
+    Rll, tll = R64[0], t64[0]                                   # x_1 = Rll x_2 + tll
+    R2, t2 = Rll.T, -Rll.T @ tll
+    T = [np.hstack([np.eye(3), np.zeros((3, 1))])]
+    if rig:
+        Rrl = R64[2] @ Rll.T                                     # x_right = Rrl x_left + trl inside a rig
+        trl = t64[2] - Rrl @ tll
+        T += [np.hstack([Rrl, trl[:, None]]), np.hstack([R2, t2[:, None]]), np.hstack([Rrl @ R2, (Rrl @ t2 + trl)[:, None]])]
+    else:
+        T += [T[0], np.hstack([R2, t2[:, None]]), np.hstack([R2, t2[:, None]])]
+    I["Tcw"] = np.stack(T).astype(np.float32)
+    return I
+
+
 def projection_problem(seed, n=1200, nq=900, mode=0, stereo=False, Nleft=-1, th=1.0, nnratio=0.8, taken_frac=0.1,
                        crowd=True, check_orientation=False, partners=False, blocks=None, w=752, h=480, loop=None):
     """Flattened SearchByProjection problem (fields of orbfe_proj_args).  Queries are map points that project

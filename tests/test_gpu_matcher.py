@@ -313,6 +313,22 @@ def test_search_for_triangulation_kb8(pkg, oracle, rig, seed, coarse):
         assert len(ref) < len(oracle.search_triangulation_kb8(I, coarse=True))  # the gate rejected something
 
 
+@pytest.mark.parametrize("rig,seed", [(False, 65), (False, 66), (True, 67), (True, 68)])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_for_triangulation_3d(pkg, oracle, rig, seed, check_ori):
+    """The SearchForTriangulation overload that returns the triangulated points (src/ORBmatcher.cc:1452-1641) with the
+    KannalaBrandt8::matchAndtriangulate gate: identical pairs on these seeds (the gate is parity by tolerance, like
+    the other KB8 gate), points within float rounding; a pinhole first camera yields nothing."""
+    from matcher_inputs import tri3d_inputs
+    I = tri3d_inputs(1100, 1000, seed, rig=rig)
+    pairs, pts = pkg.search_triangulation_3d(I, check_ori=check_ori)
+    rp, rx = oracle.search_triangulation_3d(I, check_ori=check_ori)
+    assert len(rp) > 50
+    assert np.array_equal(pairs, rp)
+    assert np.allclose(pts, rx, rtol=2e-5, atol=2e-5)
+    assert len(pkg.search_triangulation_3d(dict(I, P1L=None, P1R=None))[0]) == 0
+
+
 @pytest.mark.parametrize("case", [dict(seed=81), dict(seed=82, window=40, nnratio=1.0), dict(seed=83, check_orientation=False),
                                   dict(seed=84, n1=3000, n2=2800, window=200), dict(seed=85, n1=40, n2=3, crowd=False)],
                          ids=lambda c: "s%d" % c["seed"])

@@ -158,6 +158,7 @@ def _tri(f, tag, oracle, seed, n1, n2, stereo, coarse, ori):
                                             _csr_from_nodes(node2), F12, res[tag + "ep"], SF, SF * SF, stereo, coarse, ori)
         assert res[tag + "n"][0] == len(pairs) and (len(pairs) > 15 or stereo), (tag, len(pairs))
         assert np.array_equal(res[tag + "pairs"].reshape(-1, 2), pairs), tag
+        assert res[tag + "n3d"][0] == 0, tag     # the triangulating overload with pinhole cameras: never a pair
     return check
 
 
@@ -175,6 +176,7 @@ def _tri_kb8(f, tag, oracle, seed, n1, n2, rig, coarse):
     Rll, tll = R64[0], t64[0]
     R2, t2 = Rll.T, -Rll.T @ tll
     arrays = [("R1", np.eye(3)), ("t1", np.zeros(3)), ("O1", np.zeros(3)), ("R2", R2), ("t2", t2)]
+    Rrl = trl = None
     if rig:
         Rrl = R64[2] @ Rll.T                      # x_right = Rrl x_left + trl inside a rig
         trl = t64[2] - Rrl @ tll
@@ -203,6 +205,18 @@ def _tri_kb8(f, tag, oracle, seed, n1, n2, rig, coarse):
         assert np.array_equal(res[tag + "pairs"].reshape(-1, 2), pairs), tag
         if not coarse:
             assert len(pairs) < len(oracle.search_triangulation_kb8(J, coarse=True)), tag   # the gate rejected something
+        # the overload that also triangulates (:1452-1641), on the poses the keyframes were given
+        T = [np.hstack([np.eye(3), np.zeros((3, 1))]), None, np.hstack([R2, t2[:, None]]), None]
+        if rig:
+            T[1] = np.hstack([Rrl, trl[:, None]])
+            T[3] = np.hstack([Rrl @ R2, (Rrl @ t2 + trl)[:, None]])
+        else:
+            T[1], T[3] = T[0], T[2]
+        J3 = dict(I, Tcw=np.stack(T).astype(np.float32))
+        p3, x3 = oracle.search_triangulation_3d(J3)
+        assert res[tag + "n3d"][0] == len(p3) and len(p3) > 40, (tag, len(p3))
+        assert np.array_equal(res[tag + "pairs3d"].reshape(-1, 2), p3), tag
+        assert np.allclose(res[tag + "points3d"].reshape(-1, 3), x3, rtol=2e-5, atol=2e-5), tag
     return check
 
 

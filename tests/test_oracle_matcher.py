@@ -346,6 +346,47 @@ def test_search_triangulation_kb8_oracle_is_consistent(oracle):
             assert z[0] > 1e-4
 
 
+def test_kb8_match_and_triangulate_agrees_with_triangulate_matches(oracle):
+    """KannalaBrandt8::matchAndtriangulate (world poses, cv::Mat arithmetic, :244-335) and TriangulateMatches_ (relative
+    pose, Matx arithmetic, :409-480) are two routines of the reference for the same geometry: with camera 1 as the world
+    frame they must take the same decisions wherever no test is near its threshold and find the same point."""
+    from matcher_inputs import kb8_pairs
+    G = kb8_pairs(43, 1200)
+    R12, t12 = G["R12"].astype(np.float64), G["t12"].astype(np.float64)
+    T1 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+    T2 = np.hstack([R12.T, (-R12.T @ t12)[:, None]]).astype(np.float32)
+    z, X = oracle.kb8_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], G["R12"], G["t12"], G["sigma1"], G["sigma2"])
+    ok, Xw = oracle.kb8_match_and_triangulate(G["P1"], G["P2"], G["kp1"], G["kp2"], T1, T2, G["sigma1"], G["sigma2"])
+    _, margin = kb8_triangulate_f64(G)
+    clear = (margin[:, 0] > 1e-5) & (margin[:, 1] > 1e-3) & (margin[:, 2] > 2e-2)
+    assert clear.sum() > 1000 and ok.sum() > 400 and (~ok).sum() > 200
+    assert np.array_equal(ok[clear], (z > 0)[clear])       # (TriangulateMatches_ returns z1 > 0 exactly when it accepts)
+    both = ok & (z > 0)
+    assert np.allclose(Xw[both], X[both], rtol=1e-4, atol=1e-5)
+
+
+def test_search_triangulation_3d_oracle_is_consistent(oracle):
+    # every returned pair passes matchAndtriangulate on its own with the returned point; a pinhole first camera gives
+    # nothing (Pinhole::matchAndtriangulate returns false)
+    from matcher_inputs import tri3d_inputs
+    for rig in (False, True):
+        I = tri3d_inputs(500, 460, 57 + rig, rig=rig)
+        pairs, pts = oracle.search_triangulation_3d(I, check_ori=False)
+        assert len(pairs) > 20
+        for (i1, i2), x in list(zip(pairs, pts))[:40]:
+            r1 = rig and i1 >= I["Nleft1"]
+            r2 = rig and i2 >= I["Nleft2"]
+            ok, X = oracle.kb8_match_and_triangulate(I["P1R"] if r1 else I["P1L"], I["P2R"] if r2 else I["P2L"],
+                                                     I["kp1"][i1:i1 + 1], I["kp2"][i2:i2 + 1], I["Tcw"][1 if r1 else 0],
+                                                     I["Tcw"][3 if r2 else 2], I["sig1"][I["oct1"][i1:i1 + 1]],
+                                                     I["sig2"][I["oct2"][i2:i2 + 1]])
+            assert ok[0] and np.array_equal(X[0], x)
+        with_ori, _ = oracle.search_triangulation_3d(I, check_ori=True)
+        assert len(with_ori) <= len(pairs)
+        J = dict(I, P1L=None, P1R=None)
+        assert len(oracle.search_triangulation_3d(J)[0]) == 0
+
+
 # ---------------------------------------------------------------- SearchForInitialization
 def _init_spec(pr):
     """Independent restatement of ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821): brute force over
