@@ -1901,6 +1901,8 @@ extern "C" int orbfe_debug_qt_times(unsigned long long* out64)
 {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_qtTimes), 64 * sizeof(unsigned long long)));
+    static const unsigned long long zeros[64] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_qtTimes), zeros, sizeof(zeros))); // the next read sees one run only
     return 0;
 }
 #endif

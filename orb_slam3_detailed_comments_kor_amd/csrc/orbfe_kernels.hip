@@ -779,6 +779,9 @@ __global__ __launch_bounds__(NT) ORBFE_FAST_WAVES_ATTR void k_fast_cells(const u
 #define QT_THREADS 512 /* measured: 1024 -> 85 us, 512 -> 61 us, 256 -> 79 us (64 x 752x480) */
 #endif
 #define QT_WAVES (QT_THREADS / WAVE)
+#ifndef ORBFE_QT_FASTFWD
+#define ORBFE_QT_FASTFWD 1 /* 0: always run the quadtree pass by pass (A/B, tools/ab_build.sh) */
+#endif
 
 // exclusive scan of a[0..n) in LDS, in place; returns the total to every thread.
 // One barrier per 512-element chunk plus one at the end (every wave sums the <= 8 wave totals
@@ -888,8 +891,17 @@ __device__ unsigned long long g_qtTimes[64];
     do {                                                                                       \
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qtTimes[k] = wall_clock64(); \
     } while (0)
+// slowest workgroup per level since the last read: (duration in 10-ns ticks) << 16 | image, slots 30..37
+#define QT_WG_BEGIN() const unsigned long long qtT0 = wall_clock64()
+#define QT_WG_END()                                                                                                     \
+    do {                                                                                                                \
+        if (threadIdx.x == 0)                                                                                           \
+            atomicMax(&g_qtTimes[30 + (blockIdx.x & 7)], ((wall_clock64() - qtT0) << 16) | (blockIdx.y & 0xFFFF));      \
+    } while (0)
 #else
 #define QT_STAMP(k) do { } while (0)
+#define QT_WG_BEGIN() do { } while (0)
+#define QT_WG_END() do { } while (0)
 #endif
 
 // One workgroup per (image, level).  Level-synchronous restatement of DistributeOctTree
@@ -911,6 +923,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int level = blockIdx.x, img = (int)blockIdx.y + imgBase;
     QT_STAMP(0);
+    QT_WG_BEGIN();
     const OrbLevelGeom L = lg[level];
     const int LC = L.listCap;
     const int N = L.nFeat;
@@ -1019,6 +1032,107 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         if (tid == 0) lvlCount[(size_t)img * nlevels + level] = 0;
         return;
     }
+    // ---- the first passes in closed form.  While 4 * (number of cells of a depth) <= N neither `size >= N` nor the
+    // final-phase test `size + 3 * nToExpand > N` can fire there, so if in addition every node above depth FF holds
+    // more than one key (a full pass divides every one of them) and every pass enlarges the list, the list after FF
+    // full passes is known without running them: the non-empty depth-FF cells, in the order the push_fronts leave
+    // them -- children of later parents first, n4 before n1, i.e. (parent position descending, quadrant descending),
+    // which unrolls to the path digits compared in alternating direction.  One key walk bins the keys in that order
+    // and the checks run on the bin counts; anything unusual falls through to the pass-by-pass code below.
+    // (Replaying the loop's tests on the counts of depths 0..3 and entering the final phase directly skips one pass
+    // more but costs as much as it saves: tried)
+    int FF = 0;
+#if ORBFE_QT_FASTFWD
+    while (FF < 3 && 16 * nIni * (1 << (2 * FF)) <= N) FF++; // 4 * nIni * 4^d <= N for every depth d <= FF
+#endif
+    bool forwarded = false;
+    if (FF > 0) {
+        const int B = nIni << (2 * FF); // <= N / 4 < LC
+        for (int i = tid; i < B; i += QT_THREADS) cc[i] = 0;
+        if (tid == 0) misc[1] = 0;
+        __syncthreads();
+        const int top = FF & 1; // the root digit runs backwards when FF is odd
+        qt_each_key(regp, n, [&](auto J, int i) {
+            constexpr int j = decltype(J)::value;
+            int b = -1;
+            if (i < n) {
+                const uint32_t k = regp ? kReg[j] : keys[i];
+                const int x = (int)(k & 0xFFF), y = (int)((k >> 12) & 0xFFF);
+                int r = (int)__fdiv_rn((float)x, L.hX);
+                r = min(r, nIni - 1);
+                int ul = (int)__fmul_rn(L.hX, (float)r), br = (int)__fmul_rn(L.hX, (float)(r + 1)) | ((L.maxBY - ORBFE_MINB) << 16);
+                b = top ? nIni - 1 - r : r;
+                for (int d = 1; d <= FF; d++) {
+                    const int q = qt_quadrant(ul, br, x, y);
+                    int cul, cbr;
+                    qt_child(ul, br, q, cul, cbr);
+                    ul = cul;
+                    br = cbr;
+                    b = 4 * b + (((FF - d) & 1) ? q : 3 - q);
+                }
+                if (regp) cReg[j] = b;
+                else keyNode[i] = (uint16_t)b;
+            }
+            qt_hist_add(cc, b); // (whole wavefronts)
+        });
+        __syncthreads();
+        // checks: no node above depth FF with exactly one key; at every depth some node with two non-empty children
+        {
+            int flags = 0;
+            for (int d = 0; d < FF; d++) { // nodes of depth d = runs of 4^(FF-d) bins
+                const int span = 1 << (2 * (FF - d)), quarter = span >> 2;
+                for (int g = tid; g < (nIni << (2 * d)); g += QT_THREADS) {
+                    int total = 0, kids = 0;
+                    for (int c4 = 0; c4 < 4; c4++) {
+                        int sub = 0;
+                        for (int e = 0; e < quarter; e++) sub += cc[g * span + c4 * quarter + e];
+                        total += sub;
+                        kids += sub > 0;
+                    }
+                    if (total == 1) flags |= 1;
+                    if (kids >= 2) flags |= 2 << d;
+                }
+            }
+            if (flags) atomicOr(&misc[1], flags);
+        }
+        __syncthreads();
+        forwarded = misc[1] == ((2 << FF) - 2); // every pass grew the list, no single-key node
+        if (forwarded) {
+            int* const ulW = nodeUL(0);
+            int* const brW = nodeBR(0);
+            int* const cntW = nodeCnt(0);
+            const int* const ccR = cc;
+            const float hX = L.hX;
+            const int maxY = L.maxBY - ORBFE_MINB;
+            size = qt_scan_map(cc, gpre, B, wsum, [](int c) { return c > 0 ? 1 : 0; },
+                               [=](int b, int pos, int v) {
+                                   if (!v) return;
+                                   // the path of bin b: root digit, then FF quadrant digits (most significant first)
+                                   const int rd = b >> (2 * FF);
+                                   const int r = top ? nIni - 1 - rd : rd;
+                                   int ul = (int)__fmul_rn(hX, (float)r), br = (int)__fmul_rn(hX, (float)(r + 1)) | (maxY << 16);
+                                   for (int d = 1; d <= FF; d++) {
+                                       const int dg = (b >> (2 * (FF - d))) & 3;
+                                       int cul, cbr;
+                                       qt_child(ul, br, ((FF - d) & 1) ? dg : 3 - dg, cul, cbr);
+                                       ul = cul;
+                                       br = cbr;
+                                   }
+                                   ulW[pos] = ul;
+                                   brW[pos] = br;
+                                   cntW[pos] = ccR[b];
+                               });
+            qt_each_key(regp, n, [&](auto J, int i) {
+                constexpr int j = decltype(J)::value;
+                if (i < n) {
+                    if (regp) nReg[j] = gpre[cReg[j]];
+                    else keyNode[i] = (uint16_t)gpre[keyNode[i]];
+                }
+            });
+            __syncthreads();
+        }
+    }
+    if (!forwarded) {
     if (tid < nIni) cc[tid] = 0;
     __syncthreads();
     qt_each_key(regp, n, [&](auto J, int i) { // whole wavefronts enter qt_hist_add
@@ -1053,6 +1167,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         }
     });
     __syncthreads();
+    } // !forwarded
 
     // expansion step shared by the full passes and the final-phase rounds.
     // Preconditions: kOf/sidx valid for the current list; par[k] for k < nE; if !histDone, cc is
@@ -1277,6 +1392,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     for (int p = tid; p < nout; p += QT_THREADS) out[p] = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
     if (tid == 0) lvlCount[(size_t)img * nlevels + level] = nout;
     QT_STAMP(60);
+    QT_WG_END();
 }
 
 // ----------------------------------------------------------------- K-PACK

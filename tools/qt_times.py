@@ -14,10 +14,17 @@ import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 imgs = [pkg.synth.make_frame(480, 752, 1234 + i) for i in range(B)]
 ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+t = np.zeros(64, np.uint64)
 for _ in range(5):
     ex.extract_batch(imgs)
-t = np.zeros(64, np.uint64)
+pkg.lib().orbfe_debug_qt_times(t.ctypes.data_as(C.c_void_p))  # (reading clears: the next batch is measured alone)
+ex.extract_batch(imgs)
 pkg.lib().orbfe_debug_qt_times(t.ctypes.data_as(C.c_void_p))
+for lvl in range(8):
+    v = int(t[30 + lvl])
+    if v:
+        print("level %d: slowest workgroup %.2f us (image %d)" % (lvl, (v >> 16) / 100.0, v & 0xFFFF))
+    t[30 + lvl] = 0
 t = t.astype(np.int64)
 names = {0: "start", 1: "gather done", 2: "roots done", 41: "final phase begins", 59: "tree done", 60: "output written"}
 prev = t[0]
