@@ -165,6 +165,11 @@ def pcie_inclusive(rows, cols, batch, nfeatures, device=0, as_text=False):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator
+    # creation, for one): until the line is ready, file descriptor 1 points at stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -296,51 +301,54 @@ def main():
     # batch i's all-gather.  Runs at every N (at N=1 the "gather" is the local slab copy).
     cross = None
     if not extra and not args.no_cross:
-        cm = CrossCameraMatcher(pipe.x, ring_pairs(world, B, rank), dev)
-        prev = [None]
+        try:  # (a secondary leg: if it fails, the line still carries `value` and says why this object is missing)
+            cm = CrossCameraMatcher(pipe.x, ring_pairs(world, B, rank), dev)
+            prev = [None]
 
-        def step_cross():
-            x = pipe.begin()
-            ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(),
-                                    cap, x.count_view().data_ptr(), d_mono.data_ptr())
-            k = pipe.i % len(pipe.x)
-            pipe.submit()  # world 1 without a process group: the local copy into the gathered buffer
-            if prev[0] is not None:
-                kp, xp = prev[0]
-                if pipe.pending[kp] is not None:
-                    pipe.pending[kp].wait()  # the stream waits for batch i-1's collective; begin() clears the handle
-                cm.match(xp)
-            prev[0] = (k, x)
+            def step_cross():
+                x = pipe.begin()
+                ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(),
+                                        cap, x.count_view().data_ptr(), d_mono.data_ptr())
+                k = pipe.i % len(pipe.x)
+                pipe.submit()  # world 1 without a process group: the local copy into the gathered buffer
+                if prev[0] is not None:
+                    kp, xp = prev[0]
+                    if pipe.pending[kp] is not None:
+                        pipe.pending[kp].wait()  # the stream waits for batch i-1's collective; begin() clears the handle
+                    cm.match(xp)
+                prev[0] = (k, x)
 
-        for _ in range(10):
-            step_cross()
-        barrier()
-        tc = time.perf_counter()
-        for _ in range(args.steps):
-            step_cross()
-        barrier()
-        tc = time.perf_counter() - tc
-        # the matching launch alone, by events on the stream it runs on
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        xl = pipe.completed()
-        cm.match(xl)
-        e0.record()
-        for _ in range(20):
+            for _ in range(10):
+                step_cross()
+            barrier()
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                step_cross()
+            barrier()
+            tc = time.perf_counter() - tc
+            # the matching launch alone, by events on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            xl = pipe.completed()
             cm.match(xl)
-        e1.record()
-        torch.cuda.synchronize()
-        knn_ms = e0.elapsed_time(e1) / 20
-        cnt = xl.count_view().to(torch.float64)
-        tcount = torch.stack([xl.unpack(g // B)[0][g % B] for _, g in cm.pairs]).to(torch.float64)
-        ndist = float((cnt * tcount).sum().item())
-        good = cm.dist[:, :, 0].to(torch.float64) < 0.7 * cm.dist[:, :, 1].to(torch.float64)
-        valid = torch.arange(cap, device=dev)[None, :] < xl.count_view()[:, None]
-        cross = {"jobs_per_step": cm.njobs * world, "pairing": "every frame against the next camera of the ring (global "
-                 "frame g+1), train frames read from the gathered buffer in place",
-                 "ms_per_step": 1e3 * tc / args.steps, "knn2_launch_ms": knn_ms,
-                 "distances_per_launch": ndist, "distances_per_s": ndist / (knn_ms * 1e-3),
-                 "ratio_test_survivors_per_frame": float((good & valid).sum().item()) / max(cm.njobs, 1)}
-        prev[0] = None
+            e0.record()
+            for _ in range(20):
+                cm.match(xl)
+            e1.record()
+            torch.cuda.synchronize()
+            knn_ms = e0.elapsed_time(e1) / 20
+            cnt = xl.count_view().to(torch.float64)
+            tcount = torch.stack([xl.unpack(g // B)[0][g % B] for _, g in cm.pairs]).to(torch.float64)
+            ndist = float((cnt * tcount).sum().item())
+            good = cm.dist[:, :, 0].to(torch.float64) < 0.7 * cm.dist[:, :, 1].to(torch.float64)
+            valid = torch.arange(cap, device=dev)[None, :] < xl.count_view()[:, None]
+            cross = {"jobs_per_step": cm.njobs * world, "pairing": "every frame against the next camera of the ring (global "
+                     "frame g+1), train frames read from the gathered buffer in place",
+                     "ms_per_step": 1e3 * tc / args.steps, "knn2_launch_ms": knn_ms,
+                     "distances_per_launch": ndist, "distances_per_s": ndist / (knn_ms * 1e-3),
+                     "ratio_test_survivors_per_frame": float((good & valid).sum().item()) / max(cm.njobs, 1)}
+            prev[0] = None
+        except Exception as e:  # noqa: BLE001
+            cross = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # Not part of `value`: the same batches alternating between TWO extractor contexts on two streams (how
     # a multi-camera rig drives one extractor per camera, reference src/Frame.cc:119-122).  Consecutive
@@ -507,7 +515,10 @@ def main():
             out["pcie_inclusive"] = pcie_inclusive(H, W, B, args.nfeatures, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)  # (whatever the teardown prints is not part of the line either)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
