@@ -164,6 +164,25 @@ def pcie_inclusive(rows, cols, batch, nfeatures, device=0, as_text=False):
     return line if as_text else json.loads(line)
 
 
+def settle_together(seconds, body, world, dev):
+    """Call body() until `seconds` have passed -- on EVERY rank the same number of times: body() holds a collective
+    (the all-gather of the step), so the ranks must not decide by their own clocks.  Returns the number of calls."""
+    import torch
+    import torch.distributed as dist
+    calls = 0
+    ts = time.perf_counter()
+    while True:
+        more = time.perf_counter() - ts < seconds
+        if world > 1:
+            flag = torch.tensor([1 if more else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item())
+        if not more:
+            return calls
+        body()
+        calls += 1
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator
     # creation, for one): until the line is ready, file descriptor 1 points at stderr.
@@ -277,13 +296,12 @@ def main():
         step()
     barrier()
     # clock settling by TIME, not by step count: keep stepping (untimed) until --settle seconds have passed
-    settle_steps = 0
-    ts = time.perf_counter()
-    while time.perf_counter() - ts < args.settle:
+    def eight_steps():
         for _ in range(8):
             step()
-        settle_steps += 8
         torch.cuda.synchronize()
+
+    settle_steps = 8 * settle_together(args.settle, eight_steps, world, dev)
     barrier()
     ex.profile(args.event_every)
     t0 = time.perf_counter()

@@ -171,3 +171,48 @@ def test_ring_pairs_and_job_offsets():
         assert off.shape == (frames, 4) and (off[:, 2] % 32 == 0).all() and (off[:, 0] == np.arange(frames) * cap * 32).all()
         assert (off[:, 3] - off[:, 2] >= 0).all() and (off[:, 3] < world * slab_bytes).all()
     assert seen == set(range(world * frames))  # every frame is somebody's train frame exactly once
+
+
+def _settle_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        acc = torch.zeros(1)
+
+        def body():  # a step with a collective in it; the ranks run at different speeds
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            acc.add_(t)
+            time.sleep(0.002 if rank == 0 else 0.011)
+
+        calls = bench.settle_together(0.25 if rank == 0 else 0.05, body, world, dev)  # (even the limits differ)
+        dist.barrier()
+        q.put((rank, calls, float(acc.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_settle_loop_runs_the_same_number_of_collectives_on_every_rank():
+    # bench.py settles the clocks by time; every step holds the all-gather, so the ranks must agree on the step count
+    # (a per-rank `while elapsed < settle` deadlocks the job at N > 1)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_settle_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][1] >= 5
+    assert res[0][2] == res[1][2] == world * res[0][1]
