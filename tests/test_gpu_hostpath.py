@@ -167,6 +167,26 @@ def test_stereo_pair_two_threads_resident_matches(pkg, oracle):
         exR.close()
 
 
+def test_stereo_pair_in_one_batched_call_resident_matches(pkg, oracle):
+    """Both images of a pair in ONE batched call on one context (in place of the two threads), then
+    Frame::ComputeStereoMatches between image 0 and image 1 of that context's resident results."""
+    mb, mbf = 47.90639384423901 / 435.2046959714599, 47.90639384423901
+    left, right = pkg.synth.make_stereo_pair(480, 752, 13, shift=14)
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    (_, kL, dL), (_, kR, dR) = ex.extract_batch([left, right], [(0, 0), (0, 0)])
+    n, uR, dep = pkg.binding.compute_stereo_matches_resident(ex, ex, len(kL), mb, mbf, imgL=0, imgR=1)
+    oL = oracle.Extractor(1200, 1.2, 8, 20, 7)
+    oR = oracle.Extractor(1200, 1.2, 8, 20, 7)
+    _, rkL, rdL = oL.extract(left, (0, 0))
+    _, rkR, rdR = oR.extract(right, (0, 0))
+    _same(kL, rkL, dL, rdL)
+    _same(kR, rkR, dR, rdR)
+    rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf)
+    assert n == rn and n > 100
+    assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)
+    ex.close()
+
+
 def test_sync_reports_no_error_and_device_path_still_matches(pkg, oracle):
     import torch
     H, W = 240, 376
