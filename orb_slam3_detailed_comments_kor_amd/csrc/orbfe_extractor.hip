@@ -868,7 +868,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         }
         if (nsub == 1) rec(c, 2);
         // K-QT
-        hipLaunchKernelGGL(k_octree, dim3((unsigned)nl, (unsigned)ni), dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
+        hipLaunchKernelGGL(k_octree, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, (unsigned)nl) : dim3((unsigned)nl, (unsigned)ni),
+                           dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                            c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
                            c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
                            c->qtKeyOff, c->qtKeyCap);

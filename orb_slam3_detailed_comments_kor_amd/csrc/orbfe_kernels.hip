@@ -779,6 +779,9 @@ __global__ __launch_bounds__(NT) ORBFE_FAST_WAVES_ATTR void k_fast_cells(const u
 #define QT_THREADS 512 /* measured: 1024 -> 85 us, 512 -> 61 us, 256 -> 79 us (64 x 752x480) */
 #endif
 #define QT_WAVES (QT_THREADS / WAVE)
+#ifndef ORBFE_QT_IMG_MAJOR
+#define ORBFE_QT_IMG_MAJOR 1
+#endif
 #ifndef ORBFE_QT_FASTFWD
 #define ORBFE_QT_FASTFWD 1 /* 0: always run the quadtree pass by pass (A/B, tools/ab_build.sh) */
 #endif
@@ -885,6 +888,13 @@ __device__ __forceinline__ void qt_each_key(bool regp, int n, F f)
     }
 }
 
+#if ORBFE_QT_IMG_MAJOR
+#define QT_LEVEL_IDX blockIdx.y
+#define QT_IMG_IDX blockIdx.x
+#else
+#define QT_LEVEL_IDX blockIdx.x
+#define QT_IMG_IDX blockIdx.y
+#endif
 #ifdef ORBFE_QT_TIMING // tuning only (tools/ab_build.sh qtt "-DORBFE_QT_TIMING"): phase timestamps of one workgroup
 __device__ unsigned long long g_qtTimes[64];
 #define QT_STAMP(k)                                                                            \
@@ -896,7 +906,7 @@ __device__ unsigned long long g_qtTimes[64];
 #define QT_WG_END()                                                                                                     \
     do {                                                                                                                \
         if (threadIdx.x == 0)                                                                                           \
-            atomicMax(&g_qtTimes[30 + (blockIdx.x & 7)], ((wall_clock64() - qtT0) << 16) | (blockIdx.y & 0xFFFF));      \
+            atomicMax(&g_qtTimes[30 + (QT_LEVEL_IDX & 7)], ((wall_clock64() - qtT0) << 16) | (QT_IMG_IDX & 0xFFFF));      \
     } while (0)
 #else
 #define QT_STAMP(k) do { } while (0)
@@ -921,7 +931,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if ORBFE_QT_IMG_MAJOR
+    // workgroup id = image + nimg * level: with batches that are a multiple of 8 an image's levels run on the XCD
+    // (id mod 8) whose L2 K-FAST left the image's candidates in, and where K-PACK / K-DESC will read the result
+    const int level = blockIdx.y, img = (int)blockIdx.x + imgBase;
+#else
     const int level = blockIdx.x, img = (int)blockIdx.y + imgBase;
+#endif
     QT_STAMP(0);
     QT_WG_BEGIN();
     const OrbLevelGeom L = lg[level];
