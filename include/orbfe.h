@@ -420,6 +420,20 @@ int orbfe_search_projection_last_sweeps(void); /* sweeps the last call on this t
 int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match,
                                   int32_t* const* feat_match, int32_t* nmatches);
 
+/* The frame side of the projection searches kept on the device between calls.  Tracking runs several of them against
+ * the same Frame -- SearchByProjection(CurrentFrame, LastFrame, th, ...) and again with 2*th when too few matches came
+ * back (src/Tracking.cc:2817-2827), then SearchLocalPoints (:2927) -- and every call re-uploads the frame's descriptors
+ * and keypoints and rebuilds Frame::AssignFeaturesToGrid.  orbfe_frame_create uploads desc / kx / ky / octave
+ * (+ angle, uright when given), Nleft and the grid parameters of an orbfe_proj_args once and builds the grid once; `desc`
+ * may be a device pointer (orbfe_get_device_outputs of the extractor that produced the frame: nothing crosses PCIe
+ * for it).  orbfe_search_projection_frame is orbfe_search_projection with the frame side taken from the handle: of the
+ * argument only the queries, mode / thresholds, `taken` and the stereo-partner tables are read.  A handle is read-only
+ * after creation and may serve several threads at once. */
+typedef struct orbfe_frame orbfe_frame;
+int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* frame_side);
+int orbfe_search_projection_frame(orbfe_frame*, const orbfe_proj_args* queries, int32_t* q_match, int32_t* feat_match);
+void orbfe_frame_destroy(orbfe_frame*);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:355-420) for npts map points in one launch: the
  * observation descriptors are pooled, point p owns rows offsets[p] .. offsets[p+1); best[p] = index (relative
  * to the point) of the descriptor with the least median distance to the others, -1 if the point has none. */

@@ -248,7 +248,7 @@ def lib():
 
 
 EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_search_tri_3d", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_search_tri_3d", "orbfe_frame_create", "orbfe_search_projection_frame", "orbfe_frame_destroy", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -831,6 +831,56 @@ def search_projection(problem, device=0):
     fm = np.full(max(n, 1), -1, np.int32)
     r = _chk(lib().orbfe_search_projection(device, C.byref(a), _p(qm), _p(fm)), "orbfe_search_projection")
     return r, qm[:nq], fm[:n]
+
+
+class ProjectionFrame:
+    """orbfe_frame: the frame side of the projection searches (descriptors, keypoints, mvuRight, the grid) resident on
+    the device.  `problem` supplies the frame fields of orbfe_proj_args; `desc_ptr` = (device pointer, n) uses
+    descriptors that are already in HBM (ORBextractor.device_outputs())."""
+
+    def __init__(self, problem, device=0, desc_ptr=None):
+        pr = dict(problem)
+        n = len(pr["kx"])
+        for q in ("qdesc", "qx", "qy", "qr", "qmin_level", "qmax_level"):  # (no queries yet)
+            pr.setdefault(q, np.zeros((0, 32), np.uint8) if q == "qdesc" else np.zeros(0, np.float32))
+        pr.setdefault("mode", 0)
+        pr.setdefault("nnratio", 0.8)
+        a, keep, _, _ = _proj_args(pr)
+        if desc_ptr is not None:
+            a.desc = int(desc_ptr[0])
+            assert int(desc_ptr[1]) == n
+        self.n = n
+        self.h = C.c_void_p()
+        L = lib()
+        L.orbfe_frame_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+        L.orbfe_search_projection_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbfe_frame_destroy.argtypes = [C.c_void_p]
+        L.orbfe_frame_destroy.restype = None
+        _chk(L.orbfe_frame_create(C.byref(self.h), device, C.byref(a)), "orbfe_frame_create")
+
+    def search(self, problem):
+        """orbfe_search_projection_frame: only the queries, thresholds, `taken` and the partner tables of `problem` are read."""
+        pr = dict(problem)
+        for k in ("desc", "kx", "ky", "octave", "angle", "uright"):
+            pr.pop(k, None)
+        pr["kx"] = np.zeros(0, np.float32)  # (_proj_args takes n from it; the library takes it from the handle)
+        a, keep, _, nq = _proj_args(pr)
+        a.kx = None
+        qm = np.full(max(nq, 1), -1, np.int32)
+        fm = np.full(max(self.n, 1), -1, np.int32)
+        r = _chk(lib().orbfe_search_projection_frame(self.h, C.byref(a), _p(qm), _p(fm)), "orbfe_search_projection_frame")
+        return r, qm[:nq], fm[:self.n]
+
+    def close(self):
+        if self.h:
+            lib().orbfe_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def search_projection_batch(problems, device=0):

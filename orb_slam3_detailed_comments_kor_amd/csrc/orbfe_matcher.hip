@@ -2282,20 +2282,41 @@ struct ProjJob {
     size_t sweepBytes = 0;
 };
 
+} // namespace
+
+// Frame side of the projection searches kept on the device between calls (orbfe_frame_create): the feature arrays and
+// the grid of Frame::AssignFeaturesToGrid, built once; host copies of what the host tail of a search reads.
+struct orbfe_frame {
+    int device = 0, n = 0, Nleft = -1;
+    float minX = 0, minY = 0, wInv = 0, hInv = 0;
+    uint8_t* block = nullptr; // one allocation: everything below points into it
+    uint8_t* desc = nullptr;
+    float *kx = nullptr, *ky = nullptr, *uright = nullptr;
+    int32_t *octave = nullptr, *cellStart = nullptr, *cellItems = nullptr, *cellOf = nullptr, *status = nullptr;
+    std::vector<int32_t> hOctave;
+    std::vector<float> hAngle;
+};
+
+namespace {
 // inputs and work arrays of one search on the device (outputs are assigned by the caller: one block per call)
-int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J)
+int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_frame* F = nullptr)
 {
     int r;
     ProjDev& P = J.P;
     const size_t n = (size_t)a->n, nq = (size_t)a->nq;
-    uint8_t *dDesc, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
-    float *dKx, *dKy, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
-    int32_t *dOct, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
+    uint8_t *dDesc = nullptr, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
+    float *dKx = nullptr, *dKy = nullptr, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
+    int32_t *dOct = nullptr, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
+    if (F) { // the frame's arrays and grid are resident
+        dDesc = F->desc; dKx = F->kx; dKy = F->ky; dOct = F->octave;
+        if (F->uright && (a->Nleft == -1 || a->chi2_gate)) dUr = F->uright;
+    } else {
     if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
     if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
     if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
     if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
     if (a->uright && (a->Nleft == -1 || a->chi2_gate) && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+    }
     float* dInvSigma2 = nullptr;
     if (a->chi2_gate && (r = s.up(&dInvSigma2, a->inv_level_sigma2, (size_t)a->n_levels)) < 0) return r;
     if (a->taken && (r = s.up(&dTaken, a->taken, n)) < 0) return r;
@@ -2312,9 +2333,13 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J)
     if ((r = s.up(&dQmax, a->qmax_level, nq)) < 0) return r;
     if (a->qflags && (r = s.up(&dQflags, a->qflags, nq)) < 0) return r;
     if (a->qblocks && (r = s.up(&dQblocks, a->qblocks, nq)) < 0) return r;
+    if (F) {
+        P.cellStart = F->cellStart; P.cellItems = F->cellItems; P.cellOf = F->cellOf;
+    } else {
     if ((r = s.up<int32_t>(&P.cellStart, nullptr, 2 * PROJ_CELLS + 1)) < 0) return r;
     if ((r = s.up<int32_t>(&P.cellItems, nullptr, n)) < 0) return r;
     if ((r = s.up<int32_t>(&P.cellOf, nullptr, n)) < 0) return r;
+    }
     if ((r = s.up<int32_t>(&P.minW, nullptr, 2 * n)) < 0) return r;
     if ((r = s.up<int32_t>(&P.state, nullptr, 6 * nq)) < 0) return r;
     if ((r = s.up<int32_t>(&P.qStart, nullptr, nq)) < 0) return r;
@@ -2371,10 +2396,13 @@ int proj_finish(const orbfe_proj_args* a, const int32_t* out, int32_t* q_match, 
 }
 } // namespace
 
-int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match,
-                                  int32_t* const* feat_match, int32_t* nmatches)
+namespace {
+// `frame`: the one search (count == 1) runs against a resident frame: its arrays and grid are not staged or rebuilt
+int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match, int32_t* const* feat_match,
+             int32_t* nmatches, const orbfe_frame* frame)
 {
     if (count < 0 || (count && (!items || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
+    if (frame && count != 1) return ORBFE_ERR_ARGS;
     int r;
     for (int k = 0; k < count; k++)
         if ((r = proj_validate(&items[k], q_match[k], feat_match[k])) < 0) return r;
@@ -2395,7 +2423,7 @@ int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int 
     unsigned maxBlocks = 1;
     for (size_t j = 0; j < jobs.size(); j++) {
         const orbfe_proj_args* a = &items[live[j]];
-        if ((r = proj_stage(s, a, jobs[j])) < 0) return r;
+        if ((r = proj_stage(s, a, jobs[j], frame)) < 0) return r;
         jobs[j].outOff = outInts;
         outInts += 4 + (size_t)a->nq + (size_t)a->n;
         sweepBytes = std::max(sweepBytes, jobs[j].sweepBytes);
@@ -2421,7 +2449,8 @@ int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int 
             KernelTimer timer(s);
             if (jobs.size() == 1) {
                 const ProjDev& P = jobs[0].P;
-                hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
+                if (frame) HIP_TRY(hipMemsetAsync(P.status, 0, 4 * sizeof(int32_t), g_ms)); // (what k_proj_grid resets)
+                else hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
                 hipLaunchKernelGGL(k_proj_candidates, dim3(maxBlocks), dim3(256), 0, g_ms, P);
                 hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), sweepBytes, g_ms, P);
             } else {
@@ -2456,6 +2485,90 @@ int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int 
         nmatches[k] = proj_finish(&items[k], out.data() + jobs[j].outOff, q_match[k], feat_match[k]);
     }
     return 0;
+}
+
+} // namespace
+
+int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match,
+                                  int32_t* const* feat_match, int32_t* nmatches)
+{
+    return proj_run(device, items, count, q_match, feat_match, nmatches, nullptr);
+}
+
+int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
+{
+    if (!out) return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    if (!a || a->n < 1 || a->n >= PROJ_MAXN || !a->desc || !a->kx || !a->ky || !a->octave) return ORBFE_ERR_ARGS;
+    if (a->Nleft != -1 && (a->Nleft < 0 || a->Nleft > a->n)) return ORBFE_ERR_ARGS;
+    if (is_device_ptr(a->kx) || is_device_ptr(a->octave)) return ORBFE_ERR_ARGS; // (only the descriptors may be resident already)
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    const size_t n = (size_t)a->n;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oDesc = 0, oKx = oDesc + al(n * 32), oKy = oKx + al(n * 4), oOct = oKy + al(n * 4), oUr = oOct + al(n * 4),
+                 oCs = oUr + al(n * 4), oCi = oCs + al((2 * PROJ_CELLS + 1) * 4), oCo = oCi + al(n * 4), oSt = oCo + al(n * 4),
+                 total = oSt + 256;
+    void* blk = nullptr;
+    HIP_TRY(hipMalloc(&blk, total));
+    orbfe_frame* F = new orbfe_frame();
+    F->device = device; F->n = a->n; F->Nleft = a->Nleft;
+    F->minX = a->minX; F->minY = a->minY; F->wInv = a->gridWInv; F->hInv = a->gridHInv;
+    F->block = (uint8_t*)blk;
+    F->desc = F->block + oDesc;
+    F->kx = (float*)(F->block + oKx); F->ky = (float*)(F->block + oKy);
+    F->octave = (int32_t*)(F->block + oOct);
+    F->uright = a->uright ? (float*)(F->block + oUr) : nullptr;
+    F->cellStart = (int32_t*)(F->block + oCs); F->cellItems = (int32_t*)(F->block + oCi); F->cellOf = (int32_t*)(F->block + oCo);
+    F->status = (int32_t*)(F->block + oSt);
+    F->hOctave.assign(a->octave, a->octave + n);
+    if (a->angle) F->hAngle.assign(a->angle, a->angle + n);
+    Scratch s(device); // (this thread's matcher stream)
+    hipError_t e = hipMemcpyAsync(F->desc, a->desc, n * 32, is_device_ptr(a->desc) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess) e = hipMemcpyAsync(F->octave, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess && F->uright) e = hipMemcpyAsync(F->uright, a->uright, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess) {
+        ProjDev P{};
+        P.kx = F->kx; P.ky = F->ky; P.n = F->n; P.Nleft = F->Nleft;
+        P.minX = F->minX; P.minY = F->minY; P.wInv = F->wInv; P.hInv = F->hInv;
+        P.cellStart = F->cellStart; P.cellItems = F->cellItems; P.cellOf = F->cellOf; P.status = F->status;
+        hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ms); // the caller's arrays are free again; the handle is complete
+    if (e != hipSuccess) {
+        (void)hipFree(blk);
+        delete F;
+        return -(1000 + (int)e);
+    }
+    *out = F;
+    return 0;
+}
+
+void orbfe_frame_destroy(orbfe_frame* F)
+{
+    if (!F) return;
+    if (hipSetDevice(F->device) == hipSuccess) (void)hipFree(F->block);
+    delete F;
+}
+
+int orbfe_search_projection_frame(orbfe_frame* F, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)
+{
+    if (!F || !a) return ORBFE_ERR_ARGS;
+    orbfe_proj_args b = *a; // the frame side comes from the handle; taken / stereo partners / queries from the caller
+    b.n = F->n; b.Nleft = F->Nleft;
+    b.desc = F->desc; b.kx = F->kx; b.ky = F->ky;
+    b.octave = F->hOctave.data();
+    b.angle = F->hAngle.empty() ? nullptr : F->hAngle.data();
+    b.uright = F->uright;
+    b.minX = F->minX; b.minY = F->minY; b.gridWInv = F->wInv; b.gridHInv = F->hInv;
+    int32_t nm = 0;
+    int32_t* qm[1] = {q_match};
+    int32_t* fm[1] = {feat_match};
+    const int r = proj_run(F->device, &b, 1, qm, fm, &nm, F);
+    return r < 0 ? r : (int)nm;
 }
 
 int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)

@@ -313,6 +313,52 @@ def test_search_for_triangulation_kb8(pkg, oracle, rig, seed, coarse):
         assert len(ref) < len(oracle.search_triangulation_kb8(I, coarse=True))  # the gate rejected something
 
 
+def test_projection_searches_on_a_resident_frame(pkg, oracle):
+    """orbfe_frame: the frame side uploaded and gridded ONCE, then the searches Tracking runs against the same Frame --
+    last frame at th and 2 th, local map, a rig's left / right queries, Fuse's chi2 gate -- each identical to the
+    one-shot call and to the oracle; `taken` changes between the calls like F.mvpMapPoints does."""
+    from matcher_inputs import projection_problem
+    base = projection_problem(201, n=1800, nq=10, mode=1, stereo=True, check_orientation=True)
+    fr = pkg.ProjectionFrame(base)
+    for k, kw in enumerate((dict(mode=1, th=7.0, check_orientation=True), dict(mode=1, th=14.0, check_orientation=True),
+                            dict(mode=0, th=1.0), dict(mode=0, th=3.0, nnratio=0.9), dict(mode=1, th=3.0, loop="fuse"))):
+        q = projection_problem(300 + k, n=1800, nq=1200, stereo=True, **kw)
+        pr = dict(base)
+        for key, v in q.items():                      # the queries (and this call's `taken`) of q on the frame of `base`
+            if key.startswith("q") or key in ("mode", "nnratio", "th_high", "check_orientation", "taken", "chi2_gate",
+                                              "inv_level_sigma2"):
+                pr[key] = v
+        # aim the queries at this frame's features
+        tgt = np.random.default_rng(400 + k).integers(0, 1800, 1200)
+        pr["qx"] = (base["kx"][tgt] + np.random.default_rng(500 + k).normal(0, 2, 1200)).astype(np.float32)
+        pr["qy"] = (base["ky"][tgt] + np.random.default_rng(600 + k).normal(0, 2, 1200)).astype(np.float32)
+        bits = np.unpackbits(base["desc"][tgt], axis=1)
+        pr["qdesc"] = np.packbits(bits ^ (np.random.default_rng(700 + k).random(bits.shape) < 0.1), axis=1)
+        if "qxr" in pr:
+            pr["qxr"] = np.where(base["uright"][tgt] > 0, base["uright"][tgt] + 1.0, pr["qx"] - 10).astype(np.float32)
+        ref = oracle.search_projection(pr)
+        one = pkg.search_projection(pr)
+        got = fr.search(pr)
+        assert ref[0] > 100, (k, ref[0])
+        for a, b in ((ref, one), (ref, got)):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
+    fr.close()
+    # a two-camera frame, and descriptors that are already on the device
+    import torch
+    rig = projection_problem(211, n=1500, nq=1100, mode=0, Nleft=800, partners=True)
+    d_desc = torch.from_numpy(rig["desc"]).cuda()
+    fr = pkg.ProjectionFrame(rig, desc_ptr=(d_desc.data_ptr(), len(rig["desc"])))
+    ref = oracle.search_projection(rig)
+    got = fr.search(rig)
+    assert ref[0] > 100 and ref[0] == got[0] and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+    rig1 = projection_problem(212, n=1500, nq=900, mode=1, Nleft=800, th=15.0)
+    rig1.update({k: rig[k] for k in ("desc", "kx", "ky", "octave", "angle")})
+    ref = oracle.search_projection(rig1)
+    got = fr.search(rig1)
+    assert ref[0] == got[0] and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+    fr.close()
+
+
 @pytest.mark.parametrize("rig,seed", [(False, 65), (False, 66), (True, 67), (True, 68)])
 @pytest.mark.parametrize("check_ori", [True, False])
 def test_search_for_triangulation_3d(pkg, oracle, rig, seed, check_ori):

@@ -97,6 +97,15 @@ def main():
     pr2 = MI.projection_problem(32, n=2000, nq=1500, mode=1, stereo=True, th=15.0, crowd=False, check_orientation=True)
     report("SearchByProjection(Current, Last) N=2000, 1500 points, th=15", 1500, "map points",
            lambda: pkg.search_projection(pr2), lambda: O.search_projection(pr2))
+    # the same two searches against a resident frame (orbfe_frame: frame arrays and grid on the device once)
+    fr = pkg.ProjectionFrame(pr)
+    report("SearchByProjection(F, local map) on a resident frame (orbfe_frame)", 1500, "map points",
+           lambda: fr.search(pr), lambda: O.search_projection(pr))
+    fr.close()
+    fr2 = pkg.ProjectionFrame(pr2)
+    report("SearchByProjection(Current, Last) on a resident frame (orbfe_frame)", 1500, "map points",
+           lambda: fr2.search(pr2), lambda: O.search_projection(pr2))
+    fr2.close()
     prs = [MI.projection_problem(100 + k, n=2000, nq=1500, mode=0, stereo=True, th=1.0, crowd=False) for k in range(64)]
     report("SearchByProjection batch of 64 (F, local map) N=2000, 1500 points", 64 * 1500, "map points",
            lambda: pkg.search_projection_batch(prs), lambda: [O.search_projection(p) for p in prs], reps=10)
