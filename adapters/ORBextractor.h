@@ -111,6 +111,51 @@ public:
         return mono;
     }
 
+    // A rectified stereo frame in one go: BOTH images through one batched call on this extractor's context -- in place
+    // of the two threads Frame::Frame starts for mpORBextractorLeft / mpORBextractorRight (src/Frame.cc:119-122; both
+    // are built with the same parameters, src/Tracking.cc:1151-1155) -- then Frame::ComputeStereoMatches (src/Frame.cc
+    // :797-967) between the two results while keypoints, descriptors and pyramids are still on the device:
+    // mvuRight / mvDepth come back with the keypoints, no pyramid is downloaded.  Returns the number of stereo
+    // matches, or a negative code; monoLeft / monoRight as the two operator() calls would return them.
+    int ExtractStereoPair(cv::InputArray imLeft, cv::InputArray imRight, std::vector<cv::KeyPoint>& keysLeft,
+                          cv::OutputArray descLeft, std::vector<cv::KeyPoint>& keysRight, cv::OutputArray descRight,
+                          const std::vector<int>& lapLeft, const std::vector<int>& lapRight, float mb, float mbf,
+                          std::vector<float>& mvuRight, std::vector<float>& mvDepth, int* monoLeft = nullptr,
+                          int* monoRight = nullptr)
+    {
+#ifdef ORBFE_HAVE_OPENCV
+        cv::Mat L = imLeft.getMat(), R = imRight.getMat();
+#else
+        const cv::Mat &L = imLeft, &R = imRight;
+#endif
+        if (L.empty() || R.empty()) return -1;
+        if (L.rows != R.rows || L.cols != R.cols || L.step != R.step) throw std::runtime_error("ExtractStereoPair: unequal images");
+        const int cap = orbfe_max_keypoints(ctx, L.rows, L.cols);
+        if (cap < 0) throw std::runtime_error("image too small for the 8-level 35-px cell grid");
+        std::vector<cv::KeyPoint> kps((size_t)2 * cap);
+        std::vector<uint8_t> desc((size_t)2 * cap * 32);
+        const uint8_t* two[2] = {L.data, R.data};
+        const int lap[4] = {lapLeft[0], lapLeft[1], lapRight[0], lapRight[1]};
+        int n[2] = {0, 0}, mono[2] = {0, 0};
+        if (orbfe_extract_batch(ctx, 2, two, L.rows, L.cols, L.step, lap, reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(),
+                                cap, n, mono) < 0)
+            throw std::runtime_error("orbfe_extract_batch failed");
+        mvuRight.assign((size_t)n[0], -1.0f);
+        mvDepth.assign((size_t)n[0], -1.0f);
+        int matches = 0;
+        if (n[0] > 0) {
+            matches = orbfe_compute_stereo_matches_resident(ctx, 0, ctx, 1, mb, mbf, mvuRight.data(), mvDepth.data(), n[0]);
+            if (matches < 0) throw std::runtime_error("orbfe_compute_stereo_matches_resident failed");
+        }
+        keysLeft.assign(kps.begin(), kps.begin() + n[0]);
+        keysRight.assign(kps.begin() + cap, kps.begin() + cap + n[1]);
+        fill_descriptors(descLeft, desc.data(), n[0]);
+        fill_descriptors(descRight, desc.data() + (size_t)cap * 32, n[1]);
+        if (monoLeft) *monoLeft = mono[0];
+        if (monoRight) *monoRight = mono[1];
+        return matches;
+    }
+
     int inline GetLevels() { return nlevels; }
     float inline GetScaleFactor() { return (float)scaleFactor; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
@@ -123,6 +168,25 @@ public:
     orbfe_ctx* handle() { return ctx; }
 
 protected:
+    static void fill_descriptors(cv::OutputArray out, const uint8_t* rows, int n)
+    {
+#ifdef ORBFE_HAVE_OPENCV
+        if (n == 0) {
+            out.release();
+            return;
+        }
+        out.create(n, 32, CV_8U);
+        cv::Mat d = out.getMat();
+        for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), rows + (size_t)i * 32, 32);
+#else
+        if (n == 0) {
+            out.release();
+            return;
+        }
+        out.create(n, 32);
+        std::memcpy(out.data, rows, (size_t)n * 32);
+#endif
+    }
     orbfe_ctx* ctx;
     int nlevels;
     double scaleFactor;

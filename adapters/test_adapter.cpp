@@ -32,6 +32,28 @@ int main(int argc, char** argv)
            mpORBextractorLeft->mvImagePyramid[3].rows, mpORBextractorLeft->mvImagePyramid[3].cols);
     cv::Mat empty;
     printf("%d\n", (*mpORBextractorLeft)(empty, mask, mvKeys, mDescriptors, vLapping));
+    if (argc > 5) { // a right image: the stereo frame in one call (ExtractStereoPair), results as checksums
+        FILE* g = fopen(argv[5], "rb");
+        if (!g) return 3;
+        cv::Mat right(rows, cols);
+        if (fread(right.data, 1, (size_t)rows * cols, g) != (size_t)rows * cols) return 4;
+        fclose(g);
+        std::vector<cv::KeyPoint> kl, kr;
+        cv::Mat dl, dr;
+        std::vector<int> lap = {0, 0};
+        std::vector<float> uR, depth;
+        int ml = 0, mr = 0;
+        const float mbf = 47.90639384423901f, mb = mbf / 435.2046959714599f;
+        const int m = mpORBextractorLeft->ExtractStereoPair(im, right, kl, dl, kr, dr, lap, lap, mb, mbf, uR, depth, &ml, &mr);
+        unsigned long long hl = 1469598103934665603ull, hr = hl, hu = hl;
+        for (int i = 0; i < dl.rows * 32; i++) hl = (hl ^ dl.data[i]) * 1099511628211ull;
+        for (size_t i = 0; i < kl.size() * 28; i++) hl = (hl ^ reinterpret_cast<const unsigned char*>(kl.data())[i]) * 1099511628211ull;
+        for (int i = 0; i < dr.rows * 32; i++) hr = (hr ^ dr.data[i]) * 1099511628211ull;
+        for (size_t i = 0; i < kr.size() * 28; i++) hr = (hr ^ reinterpret_cast<const unsigned char*>(kr.data())[i]) * 1099511628211ull;
+        for (size_t i = 0; i < uR.size() * 4; i++) hu = (hu ^ reinterpret_cast<const unsigned char*>(uR.data())[i]) * 1099511628211ull;
+        for (size_t i = 0; i < depth.size() * 4; i++) hu = (hu ^ reinterpret_cast<const unsigned char*>(depth.data())[i]) * 1099511628211ull;
+        printf("%d %zu %zu %llu %llu %llu %d %d\n", m, kl.size(), kr.size(), hl, hr, hu, ml, mr);
+    }
     delete mpORBextractorLeft;
     return 0;
 }

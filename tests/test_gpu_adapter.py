@@ -35,3 +35,29 @@ def test_cpp_adapter_matches_oracle(tmp_path, oracle):
     assert h == _fnv(rdesc, rkps)
     assert (prow, pcol) == (278, 435)          # mvImagePyramid[3] of a 752x480 frame
     assert int(out[1]) == -1                   # empty image -> -1 (:1072-1073)
+
+
+def test_cpp_adapter_stereo_pair_in_one_call(tmp_path, oracle):
+    """ORBextractor::ExtractStereoPair of the adapter: both images in one batched call, ComputeStereoMatches on the
+    resident results -- keypoints, descriptors, mvuRight and mvDepth as the oracle's two extractions + matching give them."""
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    exe = str(tmp_path / "test_adapter")
+    libdir = os.path.join(ROOT, "orb_slam3_detailed_comments_kor_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "adapters"),
+                           os.path.join(ROOT, "adapters", "test_adapter.cpp"), "-o", exe, "-L" + libdir, "-lorbfe",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    left, right = pkg.synth.make_stereo_pair(480, 752, 77, shift=18)
+    (tmp_path / "l.raw").write_bytes(left.tobytes())
+    (tmp_path / "r.raw").write_bytes(right.tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "l.raw"), "480", "752", "1200", str(tmp_path / "r.raw")], text=True).split("\n")
+    m, nl, nr, hl, hr, hu, ml, mr = [int(v) for v in out[2].split()]
+    oL, oR = oracle.Extractor(1200, 1.2, 8, 20, 7), oracle.Extractor(1200, 1.2, 8, 20, 7)
+    rml, kL, dL = oL.extract(left, (0, 0))
+    rmr, kR, dR = oR.extract(right, (0, 0))
+    mbf = np.float32(47.90639384423901)
+    mb = np.float32(mbf / np.float32(435.2046959714599))
+    rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, kL, dL, kR, dR, float(mb), float(mbf))
+    assert (nl, nr, ml, mr) == (len(kL), len(kR), rml, rmr)
+    assert hl == _fnv(dL, kL) and hr == _fnv(dR, kR)
+    assert m == rn and m > 100
+    assert hu == _fnv(ruR.astype(np.float32), rdep.astype(np.float32))
