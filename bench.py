@@ -530,9 +530,15 @@ def main():
         out["first_call_ms"] = first_call_ms
         if world == 1 and not args.no_pcie:
             torch.cuda.synchronize()
-            out["pcie_inclusive"] = pcie_inclusive(H, W, B, args.nfeatures, local_rank)
+            try:  # (a secondary leg measured by a child process: its failure must not take `value` down)
+                out["pcie_inclusive"] = pcie_inclusive(H, W, B, args.nfeatures, local_rank)
+            except (SystemExit, Exception) as e:  # noqa: BLE001
+                out["pcie_inclusive"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
+            try:
+                out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
+            except (SystemExit, Exception) as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": str(e)}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
