@@ -5,6 +5,12 @@ A "step" = one pass of the whole extractor hot path (pyramid -> FAST -> quadtree
 orientation+blur+descriptor with host-libm-exact trig) over one batch of synthetic frames that
 is ALREADY RESIDENT in HBM; outputs stay in HBM.  Workload = BASELINE.json configs[1]: 752x480,
 8 levels, scale 1.2, nFeatures 1000, FAST 20/7 -- as a batch of --batch frames per GPU per step.
+`value` is that resident rate because the bench contract of this build says so in as many words ("value is
+whole-job throughput with inputs already resident in HBM when the timed region starts; if the boundary hands over
+host buffers, note the PCIe-inclusive rate ... it is never value").  The rate SURVEY.md 8(d) defines for the
+drop-in boundary -- host pointers in, host arrays out, H2D and D2H inside the clock -- is measured in the same run and
+printed next to it: `boundary_value` (= pcie_inclusive.batch_pipelined), with `vs_cpu` ratios for both.
+--config c4 switches to BASELINE configs[3]: 64 frames of 1280x720 IN TOTAL, sharded over the ranks (strong scaling).
 With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank extracts its own
 shard of frames (weak scaling) and ONE RCCL all-gather per step exchanges the descriptor slabs for
 cross-camera matching.  Timing: W warm-up steps, then exactly K steps between barrier +
@@ -206,6 +212,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=6,
                     help="record the per-stage hipEvents on every N-th timed step (7 event records cost ~25 us)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-context measurement")
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2: BASELINE configs[1] batched (752x480, --batch frames per GPU, weak scaling); c4: configs[3], "
+                         "64 frames of 1280x720 in total, 64 / N per GPU (strong scaling)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
@@ -217,6 +226,9 @@ def main():
     from orb_slam3_detailed_comments_kor_amd.multicam import CrossCameraMatcher, PipelinedExchange, ring_pairs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.config == "c4":
+        args.rows, args.cols = 720, 1280
+        args.batch = max(64 // max(world, 1), 1)
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`" % (args.gpus, world))
@@ -311,6 +323,21 @@ def main():
     dt = time.perf_counter() - t0
     stage_ms = ex.stage_ms()  # hipEvent times averaged over the timed steps
     ex.profile(False)
+    # Not part of `value`: the same step K more times with one event per step boundary on the stream (an event record
+    # costs ~3.5 us, which is why the timed region above carries none): the distribution a single average hides.
+    step_dist = None
+    if not extra:
+        nd = min(max(args.steps, 20), 400)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nd + 1)]
+        evs[0].record(stream)
+        for i in range(nd):
+            step()
+            evs[i + 1].record(stream)
+        barrier()
+        per = np.sort(np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nd)]))
+        step_dist = {"steps": nd, "min_ms": float(per[0]), "p50_ms": float(per[nd // 2]), "p90_ms": float(per[(9 * nd) // 10]),
+                     "max_ms": float(per[-1]), "note": "hipEvent between consecutive steps on the extractor's stream; each "
+                     "step carries one event record (~3.5 us), so these read slightly above ms_per_step"}
 
     # Not part of `value`: the step followed by the consumer of the exchanged descriptors -- cross-camera matching,
     # sharded by query frame: knn-2 of each of this rank's frames against the next camera of the ring
@@ -445,7 +472,8 @@ def main():
         per_kernel = {}
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
                      "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
+                                os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
                                 os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         traffic_source = None
         if pmc:
@@ -460,11 +488,13 @@ def main():
                     for k, e in j.get("kernels", {}).items():
                         if k.startswith(kernel_of[dom]) and "hbm_bytes_per_launch" in e:
                             traffic = e["hbm_bytes_per_launch"]
-                            # share of the chip's VALU issue slots this kernel's wave-instructions occupy
-                            # (1024 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz): the bound that
-                            # actually binds these integer kernels
+                            # share of the chip's VALU issue slots this kernel's wave-instructions occupy at the
+                            # guide's nominal 2 cycles per wave64 instruction (1024 SIMDs, 2.4 GHz): a LOWER bound on
+                            # how busy the vector ALUs are -- on this chip only add/sub/and/or/xor/shift-right/mov and
+                            # the non-packed 16-bit min/max measured ~2.7 cycles, everything else ~4.5
+                            # (profiles/r01_valu_rate.txt)
                             if "SQ_INSTS_VALU" in e and e.get("avg_duration_us"):
-                                valu_issue = e["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6)
+                                valu_issue = min(1.0, e["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6))
             except Exception:
                 traffic = None
         out = {
@@ -477,13 +507,16 @@ def main():
             "settle_steps": settle_steps,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.config == "c4" else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
                 "workload": "%dx%d grayscale, 8-level pyramid, nFeatures=%d, FAST 20/7, %d frames/GPU/step "
-                            "resident in HBM (BASELINE configs[1] batched)" % (W, H, args.nfeatures, B),
+                            "resident in HBM, outputs left in HBM (%s); the host-pointer rate of the same workload "
+                            "(H2D + D2H inside the clock) is `boundary_value`"
+                            % (W, H, args.nfeatures, B, "BASELINE configs[3]: 64 frames in total, sharded over the ranks"
+                               if args.config == "c4" else "BASELINE configs[1] batched"),
                 "frames_per_step": B * world,
                 "keypoints_per_step": kp_per_step,
                 "trig": args.trig,
@@ -501,6 +534,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "valu_issue_frac": valu_issue,
+                "valu_issue_cycles_assumed": 2,
                 "traffic_source": traffic_source if traffic is not None else None,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "event_sampling": "stage hipEvents on every %d-th of the timed steps; the sampled steps carry the seven "
@@ -527,6 +561,8 @@ def main():
             out["single_frame"] = single
         if cross is not None:
             out["cross_camera"] = cross
+        if step_dist is not None:
+            out["step_ms_dist"] = step_dist
         out["first_call_ms"] = first_call_ms
         if world == 1 and not args.no_pcie:
             torch.cuda.synchronize()
@@ -539,6 +575,22 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)
             except (SystemExit, Exception) as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": str(e)}
+        # the SURVEY 8(d) metric (host pointers, H2D + D2H inside the clock) and both rates against the CPU path, as
+        # top-level fields next to `value` (`vs_baseline` stays null: BASELINE.md holds no published number)
+        pi = out.get("pcie_inclusive") or {}
+        bp = (pi.get("batch_pipelined") or {}) if isinstance(pi, dict) else {}
+        if "keypoints_per_s" in bp:
+            out["boundary_value"] = bp["keypoints_per_s"]
+            out["boundary_definition"] = ("orbfe_extract_batch_submit/_wait with host pointers, two pinned batches in flight, "
+                                          "H2D of the images and D2H of keypoints + descriptors inside the clock (SURVEY.md 8d)")
+        cb = out.get("cpu_baseline") or {}
+        if isinstance(cb, dict) and cb.get("value"):
+            out["vs_cpu"] = {"value_over_cpu_all_cores": out["value"] / cb["value"],
+                             "value_over_cpu_one_thread": out["value"] / cb["one_thread"]["value"],
+                             "cpu_cores": cb["cores"]}
+            if "boundary_value" in out:
+                out["vs_cpu"]["boundary_over_cpu_all_cores"] = out["boundary_value"] / cb["value"]
+                out["vs_cpu"]["boundary_over_cpu_one_thread"] = out["boundary_value"] / cb["one_thread"]["value"]
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -117,6 +117,9 @@ struct orbfe_geom_state {
     int qtKeyOff = 0, qtKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
     size_t fastLdsBytes = 0;
+    std::vector<OrbFastCell> fc; // K-FAST's cell records
+    DevBuf<OrbFastCell> d_fc;
+    int fastTileBytes = 0, fastBmWords = 0;
     DevBuf<OrbLevelGeom> d_lg;
     DevBuf<OrbCellGeom> d_cg;
     DevBuf<OrbResizeX> d_xtab;
@@ -128,7 +131,7 @@ struct orbfe_geom_state {
     bool pyrFused = true;
     void release_tables()
     {
-        d_lg.release(); d_cg.release(); d_xtab.release(); d_ytab.release(); d_prx.release(); d_pry.release();
+        d_lg.release(); d_cg.release(); d_fc.release(); d_xtab.release(); d_ytab.release(); d_prx.release(); d_pry.release();
     }
 };
 
@@ -156,7 +159,6 @@ struct orbfe_ctx : orbfe_geom_state {
     hipStream_t sub[8] = {};
     hipEvent_t evFork = nullptr, evJoin[8] = {};
     int xcdAffine = 1;           // ORBFE_XCD_AFFINE env: whole images per XCD when the batch is a multiple of 8
-    int fastDbgStop = 0;         // ORBFE_FAST_STOP env: phase ablation for profiling only (results invalid)
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
@@ -388,12 +390,11 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     c->maxKp = maxKp;
     c->maxListCap = maxLC;
     {
-        int maxCw = 0, maxCh = 0, maxZone = 0, maxSlots = 1;
+        int maxCw = 0, maxCh = 0, maxZone = 0;
         for (const OrbCellGeom& g : c->cg) {
             maxCw = std::max<int>(maxCw, g.cw);
             maxCh = std::max<int>(maxCh, g.ch);
             maxZone = std::max(maxZone, std::max(g.cw - 6, 0) * std::max(g.ch - 6, 0));
-            maxSlots = std::max(maxSlots, (int)g.slotCap);
         }
         // Tile pitch in dwords: the widest staged row (its dwords + one: phase A reads d+1), rounded up to one of
         // the ODD pitches the kernel is instantiated for (an odd pitch spreads a dword column over all LDS banks).
@@ -403,13 +404,26 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         if (maxNd + 1 > 21) return ORBFE_ERR_ARGS; // cannot happen: cw <= 75 -> nd <= 20
         c->fastPitch = 4 * pd;
         c->fastRows = maxCh;
-        // the survivor list of the NMS (4 B per slot) lives in the tile area after phase B
-        // (4 * slotCap <= zone area < tile area, so it always fits)
-        if (4 * (size_t)maxSlots > (size_t)c->fastRows * c->fastPitch) return ORBFE_ERR_ARGS;
-        // survivor queue (2 B per zone pixel); the output ranking reuses it for a position bitmap + its prefix sums
-        // (2 x 4 B per 32 tile pixels)
-        const size_t rankBytes = 8 * (((size_t)c->fastRows * c->fastPitch + 31) / 32);
-        c->fastLdsBytes = align_up((size_t)2 * c->fastRows * c->fastPitch + std::max(2 * (size_t)std::max(maxZone, 1), rankBytes), 16);
+        // LDS: tile | score map | zone bitmap | its prefix sums | survivor queue (u16 per zone pixel)
+        c->fastTileBytes = (int)(align_up((size_t)c->fastRows, 4) * c->fastPitch);
+        c->fastBmWords = (int)align_up(((size_t)std::max(maxZone, 1) + 31) / 32, 4);
+        c->fastLdsBytes = align_up((size_t)2 * c->fastTileBytes + 8 * (size_t)c->fastBmWords + 2 * (size_t)std::max(maxZone, 1), 16);
+        c->fc.clear();
+        for (const OrbCellGeom& g : c->cg) {
+            OrbFastCell f;
+            const int ox = g.iniX & 3;
+            const int txLo = 3 + ox, txHi = g.cw - 4 + ox;
+            const int ndz = std::max((txHi >> 2) - (txLo >> 2) + 1, 1);
+            f.gOff = g.roiOff + (uint32_t)g.iniY * (uint32_t)g.pitch + (uint32_t)(g.iniX - ox);
+            f.pitch = (uint32_t)g.pitch;
+            f.dims = (uint32_t)g.cw | ((uint32_t)g.ch << 8) | ((uint32_t)ox << 16) | ((uint32_t)ndz << 20);
+            f.off = (uint32_t)(uint16_t)g.offX | ((uint32_t)(uint16_t)g.offY << 16);
+            f.slotBase = (uint32_t)g.slotBase;
+            f.slotCap = (uint32_t)g.slotCap;
+            f.mNdz = g.mNdz;
+            f.pad = 0;
+            c->fc.push_back(f);
+        }
         int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
         if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
             nt = c->fastThreadsOverride; // ORBFE_FAST_THREADS: tuning experiments
@@ -520,11 +534,13 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     }
     if ((r = c->d_lg.ensure(c->lg.size())) < 0) return r;
     if ((r = c->d_cg.ensure(c->cg.size())) < 0) return r;
+    if ((r = c->d_fc.ensure(c->fc.size())) < 0) return r;
     if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
     if ((r = c->d_ytab.ensure(std::max<size_t>(ytab.size(), 1))) < 0) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_fc.p, c->fc.data(), c->fc.size() * sizeof(OrbFastCell), hipMemcpyHostToDevice));
     if (!xtab.empty())
         HIP_TRY(hipMemcpy(c->d_xtab.p, xtab.data(), xtab.size() * sizeof(OrbResizeX), hipMemcpyHostToDevice));
     if (!ytab.empty())
@@ -821,6 +837,10 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         const int ni = i1 - i0;
         if (ni <= 0) continue;
         hipStream_t q = nsub > 1 ? c->sub[k] : s;
+        // K-FAST's order: whole images per XCD when the batch fills the 8 XCDs evenly enough (<= 1/8 idle), else groups of
+        // G neighbouring cells per XCD
+        const int perXcd = (ni + 7) / 8;
+        const bool byImage = c->fastXcdGroup <= 0 ? true : (c->xcdAffine && c->fastByImage && ni >= 8 && perXcd * 8 - ni <= ni / 8);
         // K-PYR
         if (c->pyrFused) {
             hipLaunchKernelGGL(k_pyr_fused, dim3((unsigned)c->pyrNtx, (unsigned)c->pyrNty, (unsigned)ni), dim3(256),
@@ -843,17 +863,17 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nsub == 1) rec(c, 1);
         // K-FAST
         {
-            // whole images per XCD when the batch fills the 8 XCDs evenly enough (<= 1/8 idle), else groups of
-            // G neighbouring cells per XCD
-            const int perXcd = (ni + 7) / 8;
-            const bool byImage = c->fastXcdGroup <= 0 ? true : (c->xcdAffine && c->fastByImage && ni >= 8 && perXcd * 8 - ni <= ni / 8);
-            const int G = byImage ? 0 : std::max(1, c->fastXcdGroup);
-            const dim3 grid = byImage ? dim3((unsigned)(8 * c->nCells * perXcd), 1u)
-                                      : dim3((unsigned)(((c->nCells + 8 * G - 1) / (8 * G)) * 8 * G), (unsigned)ni);
-#define ORBFE_FAST_LAUNCH(NT, PD)                                                                                    \
-    hipLaunchKernelGGL((k_fast_cells<NT, PD>), grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_cg.p, \
-                       c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST, c->minThFAST,          \
-                       c->fastRows, G, c->fastDbgStop, i0, ni)
+            // the image group is the grid's y coordinate (no division in the kernel); cell groups per XCD are powers of two
+            int gShift = -1;
+            if (!byImage)
+                for (gShift = 0; (2 << gShift) <= std::max(1, c->fastXcdGroup); gShift++) {}
+            const int G2 = byImage ? 0 : 1 << gShift;
+            const dim3 grid = byImage ? dim3((unsigned)(8 * c->nCells), (unsigned)perXcd)
+                                      : dim3((unsigned)(((c->nCells + 8 * G2 - 1) / (8 * G2)) * 8 * G2), (unsigned)ni);
+#define ORBFE_FAST_LAUNCH(NT, PD)                                                                                       \
+    hipLaunchKernelGGL((k_fast_cells<NT, PD>), grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_fc.p,   \
+                       c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST, c->minThFAST,            \
+                       c->fastTileBytes, c->fastBmWords, gShift, i0, ni)
 #define ORBFE_FAST_PD(NT)                                \
     do {                                                 \
         if (c->fastPitch == 52) ORBFE_FAST_LAUNCH(NT, 13); \
@@ -1327,7 +1347,6 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_FAST_STOP")) c->fastDbgStop = atoi(e);
     if (const char* e = getenv("ORBFE_XCD_AFFINE")) c->xcdAffine = atoi(e);
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (c->nStreams > 1) {
@@ -1904,6 +1923,20 @@ extern "C" int orbfe_debug_qt_times(unsigned long long* out64)
     HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_qtTimes), 64 * sizeof(unsigned long long)));
     static const unsigned long long zeros[64] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_qtTimes), zeros, sizeof(zeros))); // the next read sees one run only
+    return 0;
+}
+#endif
+
+#ifdef ORBFE_FAST_TIMING
+extern "C" int orbfe_debug_fast_times(unsigned long long* out16)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> all(4096 * 16);
+    HIP_TRY(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_fastTimes), all.size() * sizeof(unsigned long long)));
+    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (size_t i = 0; i < all.size(); i++) out16[i & 15] += all[i];
+    std::fill(all.begin(), all.end(), 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fastTimes), all.data(), all.size() * sizeof(unsigned long long)));
     return 0;
 }
 #endif

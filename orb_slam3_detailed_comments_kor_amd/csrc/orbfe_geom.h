@@ -53,6 +53,19 @@ struct OrbCellGeom {
     int32_t pad2[2];
 };
 
+/* K-FAST's own view of a cell: 32 B, fetched with one scalar load.  Everything the kernel would otherwise derive per
+ * workgroup is folded on the host (tile origin as one byte offset, zone geometry, reciprocal). */
+struct OrbFastCell {
+    uint32_t gOff;     /* byte offset of the tile origin (ROI row iniY, column iniX & ~3) inside one image's pyramid slab */
+    uint32_t pitch;    /* row pitch of the level                                                                        */
+    uint32_t dims;     /* cw | ch << 8 | (iniX & 3) << 16 | ndz << 20  (ndz = dword columns of the detection zone)      */
+    uint32_t off;      /* offX | offY << 16 (added to the candidates' coordinates)                                      */
+    uint32_t slotBase; /* first candidate slot of this cell                                                             */
+    uint32_t slotCap;
+    uint32_t mNdz;     /* ceil(2^32 / ndz), 0 encodes ndz == 1                                                          */
+    uint32_t pad;
+};
+
 /* resize tables: per destination column / row */
 struct OrbResizeX {
     uint16_t sx;

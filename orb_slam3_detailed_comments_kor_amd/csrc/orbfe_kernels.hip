@@ -24,9 +24,6 @@
 #include "orb_pattern.inc"
 
 #define WAVE 64
-#ifndef ORBFE_FAST_COLMAJOR
-#define ORBFE_FAST_COLMAJOR 0 /* K-FAST phase A lane order: 1 = column by column (bank-conflict free), 0 = row by row */
-#endif
 
 __device__ const int8_t ORB_PATTERN_31_DEV[256][4] = ORBFE_PATTERN_31_INIT;
 
@@ -481,180 +478,143 @@ __device__ __forceinline__ int lds_add_per_lane(int* p, int v)
 // x / d with a host-made reciprocal m = ceil(2^32 / d) (m == 0 encodes d == 1): exact while x*d < 2^32.
 __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (int)__umulhi(x, m) : (int)x; }
 
-// One workgroup per FAST cell (reference: one cv::FAST call per cell, plus a second call with
-// minThFAST when the first finds nothing) -- and the kernel does exactly that: a pass at iniThFAST and,
-// only for a cell where it keeps nothing, a pass at minThFAST.  corner_at(t) <=> score >= t and the
-// strict 8-neighbour NMS only ever loses to higher scores, so one score map serves both
-// passes.  Output: row-major ordered list per cell, packed x|y<<12|s<<24.
+// K-FAST: one 128-thread workgroup per FAST cell.  The reference makes one cv::FAST call per cell at iniThFAST and a second
+// one at minThFAST when the first finds nothing (src/ORBextractor.cc:787-854) -- and the kernel does exactly that: a pass
+// at iniThFAST and, only for a cell where it keeps nothing, a pass at minThFAST.  corner_at(t) <=> score >= t and the strict
+// 8-neighbour NMS only ever loses to higher scores, so one score map serves both passes.  NMS does not see
+// across the cell seam, exactly like per-cell cv::FAST.  Output: row-major ordered list per cell, packed x | y<<12 | s<<24.
 //
-// The ROI is staged as aligned dwords (tile column 0 = level column iniX & ~3, ROI rows of the
-// pyramid are 64-B aligned), phase A tests 4 pixels per lane from 5 dword LDS reads, phase B
-// scores the queued survivors with all lanes busy, phase C does the NMS on the corners only; the
-// survivors are ranked by position for the ordered output.
-//
-// The tile pitch is a compile-time constant of PD dwords, PD odd: every neighbour / ring / NMS read is an immediate
-// offset from one address, and phase A deals the zone's dwords to the lanes COLUMN by column (consecutive lanes =
-// consecutive rows), so that the 32 lanes of an LDS access group hit 32 different banks.
-#ifndef ORBFE_FAST_WAVES_ATTR
-#define ORBFE_FAST_WAVES_ATTR
+// Round 3's form (round 2's kernel spent 0.53 scalar instructions per vector instruction, ten barriers per cell and a
+// 190-instruction scalar prologue on per-workgroup overhead):
+//  * the cell record is 32 B of host-folded values (OrbFastCell) fetched by one scalar load; the workgroup -> (image,
+//    cell) mapping needs no division (the image group is the grid's y coordinate);
+//  * the ROI is staged as aligned dwords (tile column 0 = level column iniX & ~3; ROI rows of the pyramid are 64-B aligned)
+//    as a flat item list: tile dword i of the PD-pitched tile is LDS dword i, a thread's items are tid, tid + NT, ...,
+//    five loads in flight, a clamp instead of a branch for the tail.  The tile pitch PD is a compile-time odd number of
+//    dwords: every neighbour / ring / NMS read is an immediate offset from one address;
+//  * phase A tests 4 pixels per lane from 5 dword LDS reads (SWAR on 6-bit-quantised bytes), phase B computes the exact
+//    score of the queued survivors with all lanes busy;
+//  * no corner queue and no survivor list: the NMS (phase C) walks the survivor queue itself (the score map says which
+//    entries are corners at this threshold), marks the entries it keeps in place (bit 15) and sets their bit in a zone
+//    bitmap; every wavefront then scans that bitmap for itself (no barrier) and writes its kept entries at their
+//    row-major rank.  Four barriers per pass instead of ten, no LDS atomics except the queue counter;
+//  * the pass at minThFAST has its own queue counter, so nothing has to be reset (and no barrier is needed) between
+//    the passes.
+// Measured and not kept: one wavefront per cell, a persistent grid with prefetched tiles, two pixels
+// per lane with packed 16-bit min / max, a flat item list for phase A, 16 lanes per tile row for the staging.
+// LDS: tile | score map | zone bitmap | its prefix sums | survivor queue (u16 per zone pixel).
+#ifdef ORBFE_FAST_TIMING // tuning only (tools/ab_build.sh ft "-DORBFE_FAST_TIMING"): phase durations summed over all workgroups
+// (spread over 4096 slots: atomics of all workgroups on one address would serialise and show up in the phases)
+__device__ unsigned long long g_fastTimes[4096 * 16];
+#define FT_BEGIN()                                \
+    __shared__ unsigned ftL[16];                  \
+    int ftPass = 0;                               \
+    unsigned long long ftPrev = wall_clock64()
+#define FT(k)                                                              \
+    do {                                                                   \
+        if (threadIdx.x == 0) {                                            \
+            const unsigned long long ftNow = wall_clock64();               \
+            ftL[k] = ((k) >= 3 && ftPass ? ftL[k] : 0u) + (unsigned)(ftNow - ftPrev); \
+            ftPrev = ftNow;                                                \
+        }                                                                  \
+    } while (0)
+#else
+#define FT_BEGIN() do { } while (0)
+#define FT(k) do { } while (0)
 #endif
 template <int NT, int PD>
-__global__ __launch_bounds__(NT) ORBFE_FAST_WAVES_ATTR void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
-                                                   const OrbCellGeom* __restrict__ cg, uint32_t* __restrict__ cand,
-                                                   size_t candImgStride, int32_t* __restrict__ cellCount,
-                                                   int nCellsTotal, int iniTh, int minTh, int tileRows, int xcdGroup,
-                                                   int dbgStop, int imgBase, int nImg)
+__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
+                                              const OrbFastCell* __restrict__ cells, uint32_t* __restrict__ cand,
+                                              size_t candImgStride, int32_t* __restrict__ cellCount, int nCellsTotal,
+                                              int iniTh, int minTh, int tileBytes /* rows * 4 PD, multiple of 16 */,
+                                              int bmWords /* multiple of 4 */, int gShift, int imgBase, int nImg)
 {
-    constexpr int P = 4 * PD; // tile pitch, bytes
-    // dynamic LDS: tile[tileRows*P] | smap[tileRows*P] | queue[max zone] u16 -- sized by the host from the largest
-    // cell of the current image size (a 752x480 frame needs ~10 KB, not 22)
+    constexpr int P = 4 * PD;
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
-    uint8_t* tile = fast_lds;
-    uint8_t* smap = fast_lds + tileRows * P;
-    uint16_t* queue = reinterpret_cast<uint16_t*>(fast_lds + 2 * tileRows * P);
-    // LDS is what limits residency here (more resident workgroups = better latency hiding: +4 KB cost
-    // 10 %), so the later phases reuse dead storage: the corner queue overwrites the survivor queue
-    // from the front, the NMS survivors (pos | score<<16) overwrite the tile once phase B is done.
-    uint32_t* kq = reinterpret_cast<uint32_t*>(tile);
-    uint16_t* cq = queue;
-    __shared__ int qn, cn, kn;
+    uint8_t* const tile = fast_lds;
+    uint8_t* const smap = fast_lds + tileBytes;
+    uint32_t* const bm = reinterpret_cast<uint32_t*>(smap + tileBytes);
+    int* const pre = reinterpret_cast<int*>(bm + bmWords);
+    uint16_t* const queue = reinterpret_cast<uint16_t*>(pre + bmWords);
+    __shared__ int qn[2]; // survivors of the pass at iniThFAST / at minThFAST
 
     const int tid = threadIdx.x, lane = tid & 63;
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2);
-    // neighbouring cells share 128-B lines of the level rows (their ROIs overlap by 6 px), which
-    // should hit in ONE L2 instead of being fetched by several.
-    // Groups of `xcdGroup` consecutive cells (row neighbours) go to one XCD; the groups themselves
-    // stay round-robin so that every XCD sees cells from all over the image (a contiguous chunk per
-    // XCD cut the fetched bytes 3.6x but lost 25% to load imbalance: busy and flat regions are
-    // spatially correlated).
-    // xcdGroup == 0 (batches that fill all XCDs evenly): WHOLE IMAGES per XCD -- image xcd + 8 j is the
-    // j-th image of its XCD, cells in level order -- so that every 128-B line of a pyramid is fetched into
-    // one L2 only, once (a group of four 35-px cells spans 146 B of a row = 2.1 lines: the grouped order
-    // fetches twice the bytes it uses); all XCDs then see statistically equal work.
-    const int slot = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    // XCD-aware order (workgroups go round-robin over the 8 XCDs, each with its own L2).  gShift < 0: whole images per
+    // XCD -- image xcd + 8 y; else groups of 1 << gShift row-neighbouring cells per XCD (small batches).
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
     int cell, img;
-    if (xcdGroup == 0) {
-        const int j = slot / nCellsTotal;
-        cell = slot - j * nCellsTotal;
-        img = xcd + 8 * j;
+    if (gShift < 0) {
+        cell = slot;
+        img = xcd + 8 * (int)blockIdx.y;
         if (img >= nImg) return;
-        img += imgBase;
     } else {
-        cell = ((slot / xcdGroup) * 8 + xcd) * xcdGroup + slot % xcdGroup;
-        img = (int)blockIdx.y + imgBase;
+        cell = ((((slot >> gShift) << 3) + xcd) << gShift) + (slot & ((1 << gShift) - 1));
+        img = (int)blockIdx.y;
         if (cell >= nCellsTotal) return;
     }
-    const OrbCellGeom c = cg[cell];
-    const int cw = c.cw, ch = c.ch;
-    const int ox = c.iniX & 3; // tile x = roi x + ox
-    const int gpitch = c.pitch;
-    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + c.roiOff + (size_t)c.iniY * gpitch + (c.iniX - ox);
-    const int nd = c.nd; // dwords per tile row
+    img += imgBase;
+    FT_BEGIN();
+    const OrbFastCell c = cells[cell];
+#ifdef ORBFE_FAST_TIMING
+    asm volatile("" ::"s"(c.pitch)); // the record has arrived
+    FT(0);
+#endif
+    const int cw = (int)(c.dims & 0xFFu), ch = (int)((c.dims >> 8) & 0xFFu), ox = (int)((c.dims >> 16) & 3u);
+    const int ndz = (int)(c.dims >> 20);
+    const uint8_t* const gbase = pyr + (size_t)img * pyrImgStride + c.gOff;
 
     if (tid == 0) {
-        qn = 0;
-        cn = 0;
-        kn = 0;
+        qn[0] = 0;
+        qn[1] = 0;
     }
-    // stage the ROI (rows x nd dwords) and clear the score map.  A thread keeps one dword column and walks
-    // down the rows (one division per thread by a host-made reciprocal, then constant strides); up to six
-    // loads are in flight before the first LDS store.
+    // clear the score map and the bitmap (contiguous), 16 B per store
+    for (int o = tid * 16; o < tileBytes + 4 * bmWords; o += NT * 16) *reinterpret_cast<uint4*>(smap + o) = make_uint4(0u, 0u, 0u, 0u);
+    // stage the ROI flat: tile dword i of the PD-pitched tile is LDS dword i (every row as PD dwords; the dwords past the
+    // cell's own are never looked at), a thread's items are tid, tid + NT, ..., five loads in flight, a clamp instead of
+    // a branch for the tail
     {
-        const int r0 = fast_div((unsigned)tid, c.mNd), d = tid - r0 * nd;
-        const int rpp = fast_div((unsigned)NT, c.mNd); // rows per pass
-        if (r0 < rpp) {
-            const uint8_t* gp = roi + (size_t)r0 * gpitch + 4 * d;
-            const size_t gStep = (size_t)rpp * gpitch;
-            int off = r0 * PD + d;
-            const int oStep = rpp * PD;
-            for (int r = r0; r < ch; r += 6 * rpp) {
-                uint32_t v[6];
+        const uint32_t nItems = (uint32_t)ch * PD, last = nItems - 1u;
+        uint32_t* const T = reinterpret_cast<uint32_t*>(tile);
+        for (uint32_t i0 = (uint32_t)tid; i0 < nItems; i0 += 5u * NT) {
+            uint32_t v[5], idx[5];
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    v[k] = 0;
-                    if (r + k * rpp < ch) v[k] = *reinterpret_cast<const uint32_t*>(gp + k * gStep);
-                }
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    if (r + k * rpp < ch) {
-                        reinterpret_cast<uint32_t*>(smap)[off + k * oStep] = 0u;
-                        reinterpret_cast<uint32_t*>(tile)[off + k * oStep] = v[k];
-                    }
-                gp += 6 * gStep;
-                off += 6 * oStep;
+            for (int k = 0; k < 5; k++) {
+                idx[k] = min(i0 + (uint32_t)(k * NT), last);
+                const uint32_t row = idx[k] / (uint32_t)PD, d = idx[k] - row * (uint32_t)PD;
+                v[k] = *reinterpret_cast<const uint32_t*>(gbase + (row * c.pitch + 4u * d));
             }
+#pragma unroll
+            for (int k = 0; k < 5; k++) T[idx[k]] = v[k];
         }
     }
+    FT(1);
     __syncthreads();
+    FT(2);
 
-    if (dbgStop == 1) return;
     const int zw = cw - 6, zh = ch - 6; // detection zone
     const int nz = (zw > 0 && zh > 0) ? zw * zh : 0;
     const int txLo = 3 + ox, txHi = cw - 4 + ox; // zone columns in tile coordinates (inclusive)
-    // The reference's two calls, literally: pass 0 = cv::FAST(iniThFAST); only when it returns nothing,
-    // pass 1 = cv::FAST(minThFAST) (:808-828).  At iniTh far fewer pixels survive the cheap test than at
-    // minTh, so the common cell scores a third of the pixels a single pass at min(iniTh, minTh) would, and
-    // only the few flat cells pay for a second pass.  (cv::FAST's NMS compares against scores of corners at
-    // the SAME threshold only; a neighbour that is a corner only at a lower threshold has a lower score and
-    // never suppresses, so the map may keep scores of an earlier pass.)
-    int th = iniTh;
+    uint32_t* const out = cand + (size_t)img * candImgStride + c.slotBase;
+    int th = iniTh, nk = 0;
     for (int pass = 0;; pass++) {
-        // phase A: cheap necessary test.  Every arc of 9 contains one pixel of each opposite pair
-        // (k, k+8); test the pairs (0,8) and (4,12).  A thread keeps one dword column of the zone (4 pixels
-        // per row) and walks down the rows, so addresses advance by a constant and the column mask is a
-        // per-thread constant.
-        // The test is SWAR on all four pixels of a dword at once, on values quantised to 6 bits (x >> 2) so that a
-        // byte field has room for the comparison: r > v + t implies (r >> 2) >= (v >> 2) + ((t + 1) >> 2) =: q(v) + tb
-        // (floor((a + b) / 4) >= floor(a / 4) + floor(b / 4)), likewise for darker.  With H = q(v) + tb - 1 + 0x80 and
-        // L = q(v) - tb + 0x80 per byte, bit 7 of (H - q(r)) says "cannot be brighter" and bit 7 of (L - q(r)) "may be
-        // darker"; no byte ever borrows from its neighbour (H - q(r) >= 0x7f - 63, L - q(r) >= 0x80 - 64 - 63 = 1, both <= 254).
-        // It lets ~a quarter more pixels through than the exact test would (they fail the exact score in phase B),
-        // for 30 plain 32-bit operations per four pixels instead of 52.
+        // phase A: cheap necessary test.  Every arc of 9 contains one pixel of each opposite pair (k, k+8); test the pairs
+        // (0,8) and (4,12).  The test is SWAR on all four pixels of a dword at once, on values quantised to 6 bits (x >> 2)
+        // so that a byte field has room for the comparison: r > v + t implies (r >> 2) >= (v >> 2) + ((t + 1) >> 2) =:
+        // q(v) + tb (floor((a + b) / 4) >= floor(a / 4) + floor(b / 4)), likewise for darker.  With H = q(v) + tb - 1 + 0x80
+        // and L = q(v) - tb + 0x80 per byte, bit 7 of (H - q(r)) says "cannot be brighter" and bit 7 of (L - q(r)) "may be
+        // darker"; no byte ever borrows from its neighbour (H - q(r) >= 0x7f - 63, L - q(r) >= 0x80 - 64 - 63 = 1, both
+        // <= 254).  It lets ~a quarter more pixels through than the exact test would (they fail the exact score in phase
+        // B), for 30 plain 32-bit operations per four pixels instead of 52.  At iniThFAST far fewer pixels survive it than
+        // at minThFAST, so the usual cell scores a third of the pixels a single pass at min(iniTh, minTh) would.
         if (nz > 0) {
-            const int d0 = txLo >> 2, ndz = (txHi >> 2) - d0 + 1;
+            const int d0 = txLo >> 2;
             const uint32_t Q = 0x3F3F3F3Fu;
             const int tb = (th + 1) >> 2;
             const uint32_t KH = (uint32_t)(tb - 1 + 0x80) * 0x01010101u, KL = (uint32_t)(0x80 - tb) * 0x01010101u;
-            const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
-            // the SWAR test of the four pixels of dword `a`; returns bits 7 / 15 / 23 / 31
-            auto test4 = [&](uint32_t C, uint32_t Lf, uint32_t R, uint32_t U, uint32_t Dn) -> uint32_t {
-                // x-3: bytes 1,2,3 of Lf and byte 0 of C; x+3: byte 3 of C and bytes 0,1,2 of R
-                const uint32_t Cq = (C >> 2) & Q, Uq = (U >> 2) & Q, Dq = (Dn >> 2) & Q;
-                const uint32_t Lq = (__builtin_amdgcn_alignbyte(C, Lf, 1) >> 2) & Q;
-                const uint32_t Rq = (__builtin_amdgcn_alignbyte(R, C, 3) >> 2) & Q;
-                const uint32_t H = Cq + KH, L = Cq + KL;
-                const uint32_t notBright = ((H - Dq) & (H - Uq)) | ((H - Rq) & (H - Lq));
-                const uint32_t dark = ((L - Dq) | (L - Uq)) & ((L - Rq) | (L - Lq));
-                return (~notBright | dark) & 0x80808080u;
-            };
-            // the order of the queue is irrelevant (scores go to the map by position, the output is ranked by
-            // position): every lane reserves its own slots
-            auto push = [&](uint32_t p, int a) {
-                if (p) {
-                    int slot = lds_add_per_lane(&qn, __popc(p));
-                    const int pos0 = a << 2;
-                    if (p & 0x80u) queue[slot++] = (uint16_t)pos0;
-                    if (p & 0x8000u) queue[slot++] = (uint16_t)(pos0 + 1);
-                    if (p & 0x800000u) queue[slot++] = (uint16_t)(pos0 + 2);
-                    if (p >> 31) queue[slot] = (uint16_t)(pos0 + 3);
-                }
-            };
-#if ORBFE_FAST_COLMAJOR
-            // zone dwords dealt to the lanes column by column (consecutive lanes = consecutive rows)
-            const int nItems = ndz * zh;
-            // only the zone columns [txLo, txHi] count: the first and the last dword column are partial
-            const uint32_t mLo = 0x80808080u << (8 * (txLo & 3)), mHi = 0x80808080u >> (8 * (3 - (txHi & 3)));
-            for (int i = tid; i < nItems; i += NT) {
-                const int dz = fast_div((unsigned)i, c.mZh), r = i - dz * zh;
-                const int a = (r + 3) * PD + d0 + dz; // dword index of the four centre pixels
-                uint32_t p = test4(T[a], T[a - 1], T[a + 1], T[a - 3 * PD], T[a + 3 * PD]);
-                if (dz == 0) p &= mLo;
-                if (dz == ndz - 1) p &= mHi;
-                push(p, a);
-            }
-#else
-            // A thread keeps one dword column of the zone (4 pixels per row) and walks down the rows, so addresses
-            // advance by a constant and the column mask is a per-thread constant.
+            const uint32_t* const T = reinterpret_cast<const uint32_t*>(tile);
+            // A thread keeps one dword column of the zone (4 pixels per row) and walks down the rows: addresses advance by
+            // a constant and the column mask is a per-thread constant.  The order of the queue is irrelevant (scores go to
+            // the map by position, the output is ranked by position): every lane reserves its own slots.
             const int r0 = fast_div((unsigned)tid, c.mNdz), dz = tid - r0 * ndz;
             const int rpp = fast_div((unsigned)NT, c.mNdz); // zone rows per pass
             if (r0 < rpp) {
@@ -665,93 +625,62 @@ __global__ __launch_bounds__(NT) ORBFE_FAST_WAVES_ATTR void k_fast_cells(const u
                 const uint32_t vM = ((valid & 1u) << 7) | ((valid & 2u) << 14) | ((valid & 4u) << 21) | ((valid & 8u) << 28);
                 const int aStep = rpp * PD;
                 int a = (r0 + 3) * PD + d; // dword index of the four centre pixels
-                for (int r = r0; r < zh; r += rpp, a += aStep)
-                    push(test4(T[a], T[a - 1], T[a + 1], T[a - 3 * PD], T[a + 3 * PD]) & vM, a);
-            }
-#endif
-        }
-        __syncthreads();
-        if (dbgStop == 2) return;
-        // phase B: exact score for the survivors (all lanes busy); the corners of this pass (score >= th) are
-        // recorded in a second queue for the NMS
-        const int nq = qn;
-        for (int base = 0; base < nq; base += NT) {
-            const int qi = base + tid;
-            int pos = 0, sc = 0;
-            if (qi < nq) {
-                pos = queue[qi];
-                sc = fast_score<P>(&tile[pos]);
-                if (sc >= th) smap[pos] = (uint8_t)sc;
-            }
-            __syncthreads(); // every entry of this round has been read: cq may overwrite the queue up to here
-            const bool isc = qi < nq && sc >= th;
-            const unsigned long long m = __ballot(isc);
-            if (m) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&cn, __popcll(m));
-                wbase = __shfl(wbase, 0);
-                if (isc) cq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+                for (int r = r0; r < zh; r += rpp, a += aStep) {
+                    const uint32_t C = T[a], Lf = T[a - 1], R = T[a + 1], U = T[a - 3 * PD], Dn = T[a + 3 * PD];
+                    const uint32_t Cq = (C >> 2) & Q, Uq = (U >> 2) & Q, Dq = (Dn >> 2) & Q;
+                    const uint32_t Lq = (__builtin_amdgcn_alignbyte(C, Lf, 1) >> 2) & Q;
+                    const uint32_t Rq = (__builtin_amdgcn_alignbyte(R, C, 3) >> 2) & Q;
+                    const uint32_t H = Cq + KH, L = Cq + KL;
+                    const uint32_t notBright = ((H - Dq) & (H - Uq)) | ((H - Rq) & (H - Lq));
+                    const uint32_t dark = ((L - Dq) | (L - Uq)) & ((L - Rq) | (L - Lq));
+                    const uint32_t p = (~notBright | dark) & vM;
+                    if (p) {
+                        int s = lds_add_per_lane(&qn[pass], __popc(p));
+                        const int pos0 = a << 2;
+                        if (p & 0x80u) queue[s++] = (uint16_t)pos0;
+                        if (p & 0x8000u) queue[s++] = (uint16_t)(pos0 + 1);
+                        if (p & 0x800000u) queue[s++] = (uint16_t)(pos0 + 2);
+                        if (p >> 31) queue[s] = (uint16_t)(pos0 + 3);
+                    }
+                }
             }
         }
+        FT(3);
         __syncthreads();
-        if (dbgStop == 3) return;
-        // phase C: strict 8-neighbour NMS of the corners only (all 8 reads issued together; the score map
-        // is not modified, so every comparison sees the true scores).  Survivors are compacted into kq
-        // as pos | score<<16 (kq aliases the tile: nothing is written when no corner survives, so a second
-        // pass still finds the pixels).
-        const int nc = cn;
-        for (int base = 0; base < nc; base += NT) {
-            const int qi = base + tid;
-            bool keep = false;
-            uint32_t ent = 0;
-            if (qi < nc) {
-                const int pos = cq[qi];
-                const uint8_t* sp = smap + pos - P - 1; // immediate offsets below
-                const int s0 = sp[P + 1];
-                const int n0 = sp[P], n1 = sp[P + 2], n2 = sp[0], n3 = sp[1], n4 = sp[2], n5 = sp[2 * P],
-                          n6 = sp[2 * P + 1], n7 = sp[2 * P + 2];
-                const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                keep = s0 > mx; // s0 >= th already (phase B)
-                ent = (uint32_t)pos | ((uint32_t)s0 << 16);
+        FT(4);
+        // phase B: exact score of the survivors, all lanes busy; corners of this pass go to the score map
+        const int nq = qn[pass];
+        for (int qi = tid; qi < nq; qi += NT) {
+            const int pos = queue[qi];
+            const int sc = fast_score<P>(&tile[pos]);
+            if (sc >= th) smap[pos] = (uint8_t)sc;
+        }
+        FT(5);
+        __syncthreads();
+        FT(6);
+        // phase C: strict 8-neighbour NMS over the queue (an entry is a corner of this pass iff its score is >= th);
+        // a kept entry is marked in place and sets its bit in the zone bitmap (row-major zone index)
+        for (int qi = tid; qi < nq; qi += NT) {
+            const int pos = queue[qi];
+            const uint8_t* sp = smap + pos - P - 1; // immediate offsets below
+            const int s0 = sp[P + 1];
+            const int n0 = sp[P], n1 = sp[P + 2], n2 = sp[0], n3 = sp[1], n4 = sp[2], n5 = sp[2 * P], n6 = sp[2 * P + 1],
+                      n7 = sp[2 * P + 2];
+            const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+            if (s0 >= th && s0 > mx) {
+                const int y = (int)((unsigned)pos / (unsigned)P), x = pos - y * P;
+                const int z = (y - 3) * zw + (x - txLo);
+                atomicOr(&bm[z >> 5], 1u << (z & 31));
+                queue[qi] = (uint16_t)(pos | 0x8000);
             }
-            const unsigned long long m = __ballot(keep);
-            if (m) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&kn, __popcll(m));
-                wbase = __shfl(wbase, 0);
-                if (keep) kq[wbase + __popcll(m & ((1ull << lane) - 1ull))] = ent;
-            }
         }
-        __syncthreads(); // kn and kq are final for this pass
-        if (kn > 0 || pass == 1 || minTh == iniTh) break;
-        // nothing at iniThFAST: the same again with minThFAST (:825-828).  The barrier below separates the
-        // reads of kn above from the reset.
-        th = minTh;
+        FT(7);
         __syncthreads();
-        if (tid == 0) {
-            qn = 0;
-            cn = 0;
-        }
-        __syncthreads();
-    }
-    if (dbgStop == 4) return;
-    // output: row-major = ascending pos.  The rank of a survivor is the number of survivors before it: a bitmap
-    // of their positions (in the survivor queue's storage, dead by now) and a prefix sum over its words' popcounts
-    // give it in constant work per survivor instead of one comparison per pair.
-    const int nk = kn;
-    uint32_t* out = cand + (size_t)img * candImgStride + c.slotBase;
-    if (nk > 0) {
-        uint32_t* bm = reinterpret_cast<uint32_t*>(queue);
-        const int nW = (ch * P + 31) >> 5; // positions are < ch * P
-        int* pre = reinterpret_cast<int*>(bm + nW);
-        for (int i = tid; i < nW; i += NT) bm[i] = 0u;
-        __syncthreads();
-        for (int i = tid; i < nk; i += NT) {
-            const uint32_t pos = kq[i] & 0xFFFFu;
-            atomicOr(&bm[pos >> 5], 1u << (pos & 31u));
-        }
-        __syncthreads();
-        if (tid < 64) {
+        FT(8);
+        // output: every wavefront scans the bitmap for itself (identical values, so the redundant stores to `pre` are
+        // benign and no barrier is needed), then writes its kept entries at their rank
+        const int nW = (nz + 31) >> 5;
+        {
             int carry = 0;
             for (int base = 0; base < nW; base += 64) {
                 const int i = base + lane;
@@ -760,18 +689,42 @@ __global__ __launch_bounds__(NT) ORBFE_FAST_WAVES_ATTR void k_fast_cells(const u
                 if (i < nW) pre[i] = x - w + carry;
                 carry += __builtin_amdgcn_readlane(x, 63);
             }
+            nk = carry;
         }
-        __syncthreads();
-        for (int i = tid; i < nk; i += NT) {
-            const uint32_t e = kq[i];
-            const uint32_t pos = e & 0xFFFFu;
-            const int rank = pre[pos >> 5] + __popc(bm[pos >> 5] & ((1u << (pos & 31u)) - 1u));
-            const int y = (int)(pos / (unsigned)P), x = (int)pos - y * P; // tile coordinates
-            if (rank < c.slotCap)
-                out[rank] = (uint32_t)(x - ox + c.offX) | ((uint32_t)(y + c.offY) << 12) | ((e >> 16) << 24);
+        if (nk > 0) {
+            WAVE_SYNC();
+            for (int qi = tid; qi < nq; qi += NT) {
+                const int e = queue[qi];
+                if (e & 0x8000) {
+                    const int pos = e & 0x7FFF;
+                    const int y = (int)((unsigned)pos / (unsigned)P), x = pos - y * P; // tile coordinates
+                    const int z = (y - 3) * zw + (x - txLo);
+                    const int rank = pre[z >> 5] + __popc(bm[z >> 5] & ((1u << (z & 31)) - 1u));
+                    if (rank < (int)c.slotCap)
+                        out[rank] = (uint32_t)(x - ox + (int)(c.off & 0xFFFFu)) | ((uint32_t)(y + (int)(c.off >> 16)) << 12) |
+                                    ((uint32_t)smap[pos] << 24);
+                }
+            }
+            break;
         }
+        // nothing at iniThFAST: the same again with minThFAST (:825-828).  The queue may be overwritten at once (the
+        // other wavefront is past its last read of it: nk == 0 skips the output loop), the bitmap is still clear.
+        if (pass == 1 || minTh == iniTh) break;
+        th = minTh;
+#ifdef ORBFE_FAST_TIMING
+        FT(9);
+        ftPass = 1;
+#endif
     }
-    if (tid == 0) cellCount[(size_t)img * nCellsTotal + cell] = min(nk, c.slotCap);
+    if (tid == 0) cellCount[(size_t)img * nCellsTotal + cell] = min(nk, (int)c.slotCap);
+    FT(9);
+#ifdef ORBFE_FAST_TIMING
+    if (tid == 0) {
+        unsigned long long* g = g_fastTimes + 16 * ((blockIdx.x + 977u * blockIdx.y) & 4095u);
+        for (int k = 0; k < 10; k++) atomicAdd(&g[k], (unsigned long long)ftL[k]);
+        atomicAdd(&g[15], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------- K-QT
