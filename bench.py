@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
                     help="c2: BASELINE configs[1] batched (752x480, --batch frames per GPU, weak scaling); c4: configs[3], "
                          "64 frames of 1280x720 in total, 64 / N per GPU (strong scaling)")
+    ap.add_argument("--exchange", choices=["cabi", "torch"], default="cabi",
+                    help="N > 1: the all-gather through the C ABI (orbfe_mc_*: ncclAllGather issued by liborbfe.so on its own "
+                         "stream) or through torch.distributed (c10d's process group)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
@@ -265,6 +268,28 @@ def main():
     d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
     lap = (0, 1000)  # mono protocol, src/Frame.cc:306
 
+    # N > 1 (or the one-GPU rehearsal): the sharded extraction + exchange behind the C ABI (include/orbfe_mc.h).  The id of
+    # the RCCL communicator travels through torch.distributed's store; if the handle cannot be made on EVERY rank the run
+    # falls back to the c10d all-gather (and says so in the line).
+    mc = None
+    mc_note = None
+    if dist.is_initialized() and args.exchange == "cabi":
+        try:
+            box = [pkg.binding.mc_unique_id(pkg.binding.MC_RCCL) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            mc = pkg.binding.MultiCam(ex, box[0], rank, world, B, cap, pkg.binding.MC_RCCL)
+        except Exception as e:  # noqa: BLE001
+            mc_note = "%s: %s" % (type(e).__name__, e)
+            mc = None
+        flag = torch.tensor([1 if mc is not None else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and mc is not None:
+            mc.close()
+            mc = None
+            mc_note = "another rank could not create its handle"
+    mc_inflight = [0]
+    mc_last = [None]
+
     # --contexts N (experiment, single GPU): further extractor contexts with their own streams and outputs
     extra = []
     if args.contexts > 1 and world == 1:
@@ -286,6 +311,15 @@ def main():
             e2.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, k2.data_ptr(), de2.data_ptr(), cap,
                                     n2.data_ptr(), m2.data_ptr())
             return
+        if mc is not None:
+            # C ABI: extraction into the next slab + ncclAllGather on the library's side stream; two batches in flight
+            # (the host waits for batch i-1's collective while batch i is already queued)
+            if mc_inflight[0] == 2:
+                mc_last[0] = mc.wait()
+                mc_inflight[0] -= 1
+            mc.submit(d_img.data_ptr(), H, W, W, H * W, lap)
+            mc_inflight[0] += 1
+            return
         x = pipe.begin()  # waits (on the stream) for the collective that last read this slab
         ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(), cap,
                                 x.count_view().data_ptr(), d_mono.data_ptr())
@@ -293,6 +327,9 @@ def main():
             pipe.submit()  # one RCCL all-gather of descriptor slabs per batch, asynchronous
 
     def barrier():
+        while mc_inflight[0] > 0:
+            mc_last[0] = mc.wait()
+            mc_inflight[0] -= 1
         pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
@@ -345,7 +382,32 @@ def main():
     # place, one launch per batch.  The match of batch i-1 is queued behind the extraction of batch i, so it overlaps
     # batch i's all-gather.  Runs at every N (at N=1 the "gather" is the local slab copy).
     cross = None
-    if not extra and not args.no_cross:
+    if mc is not None and not args.no_cross:
+        try:
+            hops = (1,)
+
+            def step_cross_mc():
+                if mc_inflight[0] == 2:
+                    v = mc.wait()
+                    mc_inflight[0] -= 1
+                    mc.match_ring_async(v.batch, hops)  # queued behind the extraction already in the stream
+                mc.submit(d_img.data_ptr(), H, W, W, H * W, lap)
+                mc_inflight[0] += 1
+
+            for _ in range(10):
+                step_cross_mc()
+            barrier()
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                step_cross_mc()
+            barrier()
+            tc = time.perf_counter() - tc
+            cross = {"jobs_per_step": B * world, "pairing": "every frame against the next camera of the ring (global frame g+1), "
+                     "train frames read from the gathered buffer in place (orbfe_mc_match_ring_async)",
+                     "ms_per_step": 1e3 * tc / args.steps}
+        except Exception as e:  # noqa: BLE001
+            cross = {"error": "%s: %s" % (type(e).__name__, e)}
+    elif not extra and not args.no_cross:
         try:  # (a secondary leg: if it fails, the line still carries `value` and says why this object is missing)
             cm = CrossCameraMatcher(pipe.x, ring_pairs(world, B, rank), dev)
             prev = [None]
@@ -451,6 +513,11 @@ def main():
         single = {"frames_per_call": 1, "ms_per_frame": 1e3 * t1 / args.steps,
                   "value": float(n1.item()) * args.steps / t1, "unit": "keypoints/s"}
 
+    if mc is not None:  # the counts of this rank's batch (the slabs belong to the library): one plain extraction, same frames
+        barrier()
+        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), d_mono.data_ptr())
+        torch.cuda.synchronize()
     n_local = int(d_n.sum().item())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     cnt = torch.tensor([n_local], dtype=torch.float64, device=dev)
@@ -521,7 +588,10 @@ def main():
                 "keypoints_per_step": kp_per_step,
                 "trig": args.trig,
                 "contexts": 1 + len(extra),
-                "exchange": ("1 all-gather of descriptor slabs per step, overlapped with the next step's extraction"
+                "exchange": (("1 ncclAllGather of descriptor slabs per step issued by liborbfe.so (orbfe_mc_extract_exchange_"
+                              "submit / _wait) on its own stream, overlapped with the next step's extraction" if mc is not None
+                              else "1 all-gather of descriptor slabs per step through torch.distributed, overlapped with the "
+                              "next step's extraction" + (" (C-ABI handle unavailable: %s)" % mc_note if mc_note else ""))
                              if dist.is_initialized() else "none"),
             },
             "roofline": {
@@ -595,6 +665,9 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)  # (whatever the teardown prints is not part of the line either)
+    if mc is not None:
+        barrier()
+        mc.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

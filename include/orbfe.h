@@ -59,6 +59,8 @@ int orbfe_release_caches(int device);
 
 /* Run on an existing hipStream_t (e.g. the caller's torch stream); NULL = context-owned stream. */
 int orbfe_set_stream(orbfe_ctx*, void* hip_stream);
+/* The stream (hipStream_t) the context's kernels run on and its device ordinal: what a caller orders its own work against. */
+int orbfe_get_stream(orbfe_ctx*, void** hip_stream, int* device);
 /* 7 fixed-point (8.8) Gaussian taps; default {18,34,48,56,48,34,18} = OpenCV >= 4.1.2. */
 int orbfe_set_gaussian_taps(orbfe_ctx*, const int* taps7);
 /* Rotation trig of the descriptor (src/ORBextractor.cc:110-111):

@@ -140,6 +140,18 @@ def _proj_args(pr):
     return a, keep, a.n, a.nq
 
 
+class _McLayout(C.Structure):
+    _fields_ = [("desc_bytes", C.c_size_t), ("count_off", C.c_size_t), ("slab_bytes", C.c_size_t)]
+
+
+class _McView(C.Structure):
+    _fields_ = [("gathered", C.c_void_p), ("slab", C.c_void_p), ("d_kps", C.c_void_p), ("d_mono", C.c_void_p),
+                ("slab_bytes", C.c_size_t), ("batch", C.c_long)]
+
+
+MC_RCCL, MC_HOST, MC_ID_BYTES = 0, 1, 128
+
+
 def _share_hip_runtime_with_torch():
     """One HIP runtime per process: torch bundles its own libamdhip64.so (same SONAME as the system
     one).  Loading it first makes the dynamic linker bind liborbfe.so to that copy, so device
@@ -174,6 +186,23 @@ def lib():
         L.orbfe_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orbfe_destroy.argtypes = [C.c_void_p]
         L.orbfe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        # multi-GPU path (include/orbfe_mc.h)
+        L.orbfe_mc_layout.argtypes = [C.c_int, C.c_int, C.POINTER(_McLayout)]
+        L.orbfe_mc_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orbfe_mc_ring_pairs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbfe_mc_job_offsets.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbfe_mc_unique_id.argtypes = [C.c_int, C.c_void_p]
+        L.orbfe_mc_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orbfe_mc_destroy.restype = None
+        L.orbfe_mc_destroy.argtypes = [C.c_void_p]
+        L.orbfe_mc_extract_exchange_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                       C.c_int, C.c_int]
+        L.orbfe_mc_extract_exchange_wait.argtypes = [C.c_void_p, C.POINTER(_McView)]
+        L.orbfe_mc_match_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbfe_mc_match_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.orbfe_mc_match_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long]
+        L.orbfe_mc_exchange_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.orbfe_set_gaussian_taps.argtypes = [C.c_void_p, C.c_void_p]
         L.orbfe_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_max_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -247,7 +276,10 @@ def lib():
     return _LIB
 
 
-EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_set_gaussian_taps",
+EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_get_stream", "orbfe_set_gaussian_taps",
+           "orbfe_mc_layout", "orbfe_mc_shard", "orbfe_mc_ring_pairs", "orbfe_mc_job_offsets", "orbfe_mc_unique_id",
+           "orbfe_mc_create", "orbfe_mc_destroy", "orbfe_mc_extract_exchange_submit", "orbfe_mc_extract_exchange_wait",
+           "orbfe_mc_match_ring", "orbfe_mc_match_outputs", "orbfe_mc_match_ring_async", "orbfe_mc_exchange_host",
            "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_search_tri_3d", "orbfe_frame_create", "orbfe_search_projection_frame", "orbfe_frame_destroy", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
@@ -988,3 +1020,101 @@ def kb8_unproject(params8, uv, device=0):
     rays = np.zeros((len(uv), 3), np.float32)
     _chk(lib().orbfe_kb8_unproject(device, _p(P), _p(uv), len(uv), _p(rays)), "orbfe_kb8_unproject")
     return rays
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Multi-GPU / multi-camera path (include/orbfe_mc.h): thin ctypes layer over the C ABI.
+def mc_layout(frames_per_rank, cap):
+    """(desc_bytes, count_off, slab_bytes) of one rank's slab."""
+    lay = _McLayout()
+    _chk(lib().orbfe_mc_layout(frames_per_rank, cap, C.byref(lay)), "orbfe_mc_layout")
+    return int(lay.desc_bytes), int(lay.count_off), int(lay.slab_bytes)
+
+
+def mc_shard(nframes, world, rank):
+    first, count = C.c_int(), C.c_int()
+    _chk(lib().orbfe_mc_shard(nframes, world, rank, C.byref(first), C.byref(count)), "orbfe_mc_shard")
+    return first.value, count.value
+
+
+def mc_ring_pairs(world, frames_per_rank, rank, hops=(1,)):
+    hops = np.ascontiguousarray(hops, np.int32)
+    pairs = np.zeros((len(hops) * frames_per_rank, 2), np.int32)
+    n = _chk(lib().orbfe_mc_ring_pairs(world, frames_per_rank, rank, _p(hops), len(hops), _p(pairs)), "orbfe_mc_ring_pairs")
+    return [(int(q), int(g)) for q, g in pairs[:n]]
+
+
+def mc_job_offsets(frames_per_rank, cap, pairs):
+    pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    off = np.zeros((len(pr), 4), np.int64)
+    _chk(lib().orbfe_mc_job_offsets(frames_per_rank, cap, _p(pr), len(pr), _p(off)), "orbfe_mc_job_offsets")
+    return off
+
+
+def mc_unique_id(transport=MC_RCCL):
+    buf = (C.c_uint8 * MC_ID_BYTES)()
+    _chk(lib().orbfe_mc_unique_id(transport, buf), "orbfe_mc_unique_id")
+    return bytes(buf)
+
+
+class MultiCam:
+    """orbfe_mc handle: this rank's part of the sharded extraction + the all-gather + the ring matching.  `extractor`
+    None (host transport only) gives a host-memory handle for the bookkeeping tests."""
+
+    def __init__(self, extractor, uid, rank, world, frames_per_rank, cap, transport=MC_RCCL):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.ex = extractor
+        self.rank, self.world, self.frames, self.cap, self.transport = rank, world, frames_per_rank, cap, transport
+        self.desc_bytes, self.count_off, self.slab_bytes = mc_layout(frames_per_rank, cap)
+        idbuf = (C.c_uint8 * MC_ID_BYTES).from_buffer_copy(uid.ljust(MC_ID_BYTES, b"\0")) if uid is not None else None
+        _chk(self.L.orbfe_mc_create(C.byref(self.h), extractor.h if extractor is not None else None, idbuf, rank, world,
+                                    frames_per_rank, cap, transport), "orbfe_mc_create")
+
+    def close(self):
+        if self.h:
+            self.L.orbfe_mc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, d_imgs_ptr, rows, cols, pitch, img_stride, lap=(0, 0)):
+        _chk(self.L.orbfe_mc_extract_exchange_submit(self.h, C.c_void_p(d_imgs_ptr), rows, cols, pitch, img_stride,
+                                                     int(lap[0]), int(lap[1])), "orbfe_mc_extract_exchange_submit")
+
+    def wait(self):
+        v = _McView()
+        _chk(self.L.orbfe_mc_extract_exchange_wait(self.h, C.byref(v)), "orbfe_mc_extract_exchange_wait")
+        return v
+
+    def match_ring(self, hops=(1,), download=True):
+        hops = np.ascontiguousarray(hops, np.int32)
+        npairs = len(hops) * self.frames
+        if not download:
+            return _chk(self.L.orbfe_mc_match_ring(self.h, _p(hops), len(hops), None, None), "orbfe_mc_match_ring")
+        idx = np.empty((npairs, self.cap, 2), np.int32)
+        dist = np.empty((npairs, self.cap, 2), np.int32)
+        _chk(self.L.orbfe_mc_match_ring(self.h, _p(hops), len(hops), _p(idx), _p(dist)), "orbfe_mc_match_ring")
+        return idx, dist
+
+    def match_ring_async(self, batch, hops=(1,)):
+        hops = np.ascontiguousarray(hops, np.int32)
+        return _chk(self.L.orbfe_mc_match_ring_async(self.h, _p(hops), len(hops), int(batch)), "orbfe_mc_match_ring_async")
+
+    def match_outputs(self):
+        di, dd, n = C.c_void_p(), C.c_void_p(), C.c_int()
+        _chk(self.L.orbfe_mc_match_outputs(self.h, C.byref(di), C.byref(dd), C.byref(n)), "orbfe_mc_match_outputs")
+        return di.value, dd.value, n.value
+
+    def exchange_host(self, slab):
+        """Host-memory exchange (collective): returns a read-only numpy view [world, slab_bytes] valid until the next call."""
+        slab = np.ascontiguousarray(slab, np.uint8)
+        assert slab.size == self.slab_bytes
+        g = C.c_void_p()
+        _chk(self.L.orbfe_mc_exchange_host(self.h, _p(slab), C.byref(g)), "orbfe_mc_exchange_host")
+        buf = (C.c_uint8 * (self.world * self.slab_bytes)).from_address(g.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.world, self.slab_bytes)

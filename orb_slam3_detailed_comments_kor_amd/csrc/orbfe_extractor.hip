@@ -1416,6 +1416,14 @@ int orbfe_release_caches(int device)
     return 0;
 }
 
+int orbfe_get_stream(orbfe_ctx* c, void** hip_stream, int* device)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    if (hip_stream) *hip_stream = (void*)c->stream;
+    if (device) *device = c->device;
+    return 0;
+}
+
 int orbfe_set_stream(orbfe_ctx* c, void* hip_stream)
 {
     if (!c) return ORBFE_ERR_ARGS;

@@ -13,6 +13,12 @@ After the gather every rank holds every camera's descriptors, and the cross-came
 frame: `CrossCameraMatcher` runs, for each of this rank's frames, the knn-2 against its partner frames wherever in
 the gathered buffer they live -- one launch (orbfe_bfknn2_frames_device) on job records that name both frames by
 device address, so nothing is repacked after the collective.
+
+Round 3: the path lives behind the C ABI (include/orbfe_mc.h, csrc/orbfe_multicam.hip: slab layout, sharding, ring
+pairs, job records, the double-buffered extraction + ncclAllGather on a side stream, the ring matching) so that a C++
+host reaches it; `binding.MultiCam` is its ctypes handle and what bench.py runs at N > 1.  The functions below are thin
+calls into that ABI; the torch.distributed classes further down are the same exchange with c10d as the transport
+(kept for hosts that already own a process group, and as bench.py's fall-back).
 """
 import numpy as np
 import torch
@@ -20,10 +26,9 @@ import torch.distributed as dist
 
 
 def shard_frames(nframes, world, rank):
-    """Contiguous block partition of a batch; returns (first, count) for `rank`."""
-    base, rem = divmod(nframes, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+    """Contiguous block partition of a batch; returns (first, count) for `rank` (orbfe_mc_shard)."""
+    from . import binding
+    return binding.mc_shard(nframes, world, rank)
 
 
 def owner_of_frame(f, nframes, world):
@@ -40,7 +45,12 @@ def _work_done(w):
     try:
         if not bool(w.is_completed()):
             return False
-        exc = getattr(w, "exception", None)
+        # c10d: is_success() is false for a collective that ended with an exception.  (Work.exception() cannot be called
+        # from Python at all: pybind has no converter for std::exception_ptr and raises TypeError.)
+        ok = getattr(w, "is_success", None)
+        if ok is not None:
+            return bool(ok())
+        exc = getattr(w, "exception", None)  # test doubles
         return exc is None or exc() is None
     except Exception:  # a backend without the queries: keep the ordering wait (which also raises)
         return False
@@ -50,20 +60,17 @@ def ring_pairs(world, frames, rank, hops=(1,)):
     """Cross-camera pairs of a rig whose cameras form a ring (global frame g = rank * frames + local index):
     every local frame is a query against the frames `h` cameras further round the ring, for h in hops.  The last
     local frames' partners live on the next rank -- the reason for the all-gather."""
-    total = world * frames
-    return [(i, (rank * frames + i + h) % total) for h in hops for i in range(frames)]
+    from . import binding
+    return binding.mc_ring_pairs(world, frames, rank, hops)  # orbfe_mc_ring_pairs
 
 
 def job_offsets(frames, cap, slab_bytes, pairs):
     """Byte offsets of the job records of `pairs` = [(local query frame, global train frame)]: per job
     (query descriptors, query count) inside this rank's slab and (train descriptors, train count) inside the
     gathered buffer.  Shared by the device matcher and by its CPU stand-in in the tests."""
-    desc_bytes = frames * cap * 32
-    out = np.zeros((len(pairs), 4), np.int64)
-    for k, (qi, g) in enumerate(pairs):
-        r, j = divmod(g, frames)
-        out[k] = (qi * cap * 32, desc_bytes + 4 * qi, r * slab_bytes + j * cap * 32, r * slab_bytes + desc_bytes + 4 * j)
-    return out
+    from . import binding
+    assert slab_bytes == binding.mc_layout(frames, cap)[2]
+    return binding.mc_job_offsets(frames, cap, pairs)  # orbfe_mc_job_offsets
 
 
 class CrossCameraMatcher:
@@ -158,8 +165,8 @@ class DescriptorExchange:
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.frames, self.cap = frames_per_rank, cap
-        self.desc_bytes = frames_per_rank * cap * 32
-        self.slab_bytes = (self.desc_bytes + frames_per_rank * 4 + 255) // 256 * 256  # every rank's rows stay aligned
+        from . import binding
+        self.desc_bytes, _, self.slab_bytes = binding.mc_layout(frames_per_rank, cap)  # orbfe_mc_layout
         self.slab = torch.zeros(self.slab_bytes, dtype=torch.uint8, device=device)
         self.gathered = torch.zeros(self.world * self.slab_bytes, dtype=torch.uint8, device=device)
 

@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/orbfe.h declares (no GPU needed)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares (no GPU needed)."""
 import ctypes
 import os
 import re
@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    txt = open(os.path.join(ROOT, "include", "orbfe.h")).read()
+    txt = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include")))
+                  if f.endswith(".h"))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(orbfe_[a-z0-9_]+)\s*\(", txt)))
 

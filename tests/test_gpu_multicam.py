@@ -1,0 +1,83 @@
+"""The multi-GPU path behind the C ABI (include/orbfe_mc.h) on the one GPU of the test box: a C++ host (world 1 over RCCL,
+world 2 over the shared-memory transport with both ranks on the same device) and the ctypes handle against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "test_multicam")
+    libdir = os.path.join(ROOT, "orb_slam3_detailed_comments_kor_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", os.path.join(ROOT, "adapters", "test_multicam.cpp"), "-o", exe,
+                           "-L" + libdir, "-lorbfe", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _frames(tmp_path, n, rows=240, cols=376):
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    imgs = np.stack([pkg.synth.make_frame(rows, cols, 900 + i) for i in range(n)])
+    path = tmp_path / "frames.raw"
+    path.write_bytes(imgs.tobytes())
+    return imgs, str(path)
+
+
+def test_cpp_host_world1_rccl(tmp_path):
+    exe = _build(tmp_path)
+    _, raw = _frames(tmp_path, 4)
+    out = subprocess.run([exe, raw, "240", "376", "4", "1", "0", "500"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all 1 ranks ok" in out.stdout and "transport rccl" in out.stdout
+
+
+def test_cpp_host_world2_shared_memory_transport(tmp_path):
+    exe = _build(tmp_path)
+    _, raw = _frames(tmp_path, 6)
+    out = subprocess.run([exe, raw, "240", "376", "6", "2", "1", "500"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all 2 ranks ok" in out.stdout and out.stdout.count("transport host") == 2
+
+
+def test_ctypes_handle_against_the_oracle(oracle):
+    """extract -> all-gather (RCCL, one rank) -> ring matching through binding.MultiCam: slab contents and knn-2 results
+    equal the oracle's extraction and its brute-force matcher."""
+    import torch
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    from orb_slam3_detailed_comments_kor_amd import binding
+    rows, cols, frames = 240, 376, 3
+    imgs = np.stack([pkg.synth.make_frame(rows, cols, 700 + i) for i in range(frames)])
+    d_img = torch.from_numpy(imgs).cuda()
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7, device=0)
+    cap = ex.max_keypoints(rows, cols)
+    mc = binding.MultiCam(ex, None, 0, 1, frames, cap, binding.MC_RCCL)
+    for _ in range(2):
+        mc.submit(d_img.data_ptr(), rows, cols, cols, rows * cols, (0, 0))
+    v0 = mc.wait()
+    v = mc.wait()
+    assert (v0.batch, v.batch) == (0, 1) and v.slab_bytes == mc.slab_bytes
+    idx, dist = mc.match_ring((1, 2))
+    g = np.empty(mc.slab_bytes, np.uint8)
+    torch.cuda.synchronize()
+    import ctypes as C
+    hip = C.CDLL(None)  # the HIP runtime already in the process (the one liborbfe.so and torch share)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(g.ctypes.data_as(C.c_void_p), C.c_void_p(v.gathered), g.size, 2) == 0  # hipMemcpyDeviceToHost
+    counts = g[mc.count_off:mc.count_off + 4 * frames].view(np.int32)
+    ref = [oracle.Extractor(500, 1.2, 8, 20, 7).extract(imgs[i], (0, 0)) for i in range(frames)]
+    for i, (_, rk, rd) in enumerate(ref):
+        assert counts[i] == len(rk)
+        assert np.array_equal(g[i * cap * 32:(i * cap + len(rk)) * 32].reshape(-1, 32), rd)
+    pairs = binding.mc_ring_pairs(1, frames, 0, (1, 2))
+    for k, (q, t) in enumerate(pairs):
+        ri, rdist = oracle.bfknn2(ref[q][2], ref[t][2])
+        n = len(ref[q][1])
+        assert np.array_equal(idx[k, :n], ri) and np.array_equal(dist[k, :n], rdist)
+        assert (idx[k, n:] == -1).all()
+    mc.close()
+    ex.close()

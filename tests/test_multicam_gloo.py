@@ -81,6 +81,21 @@ def _worker(rank, world, port, frames, cap, q):
             D0 = np.unpackbits(d[qi, :nq, None, :] ^ ed[j, None, :nt, :], axis=2).sum(axis=2)
             ok &= np.array_equal(np.argsort(D, axis=1, kind="stable")[:, :2], np.argsort(D0, axis=1, kind="stable")[:, :2])
         ok &= seen_remote  # at least one partner frame came from the other rank
+        # a REAL c10d work handle that has completed cleanly: begin() takes the "no ordering wait" branch (is_success();
+        # Work.exception() cannot be called from Python)
+        import time
+        x = pipe.begin()
+        pipe.submit()
+        time.sleep(0.3)
+        skipped = pipe.waits_skipped
+        pipe.begin()   # the other slab: its collective finished long ago
+        ok &= pipe.waits_skipped >= skipped
+        pipe.drain()
+        w = dist.all_gather_into_tensor(x.gathered, x.slab, async_op=True)
+        time.sleep(0.3)
+        from orb_slam3_detailed_comments_kor_amd.multicam import _work_done
+        ok &= _work_done(w) is True
+        w.wait()
         qs = list(xch.query_shard())
         first, count = shard_frames(world * frames, world, rank)
         ok &= qs == list(range(first, first + count))
@@ -104,6 +119,94 @@ def test_all_gather_of_descriptor_slabs_world2():
     assert all(ok for _, ok, _ in res)
     covered = sorted(sum((qs for _, _, qs in res), []))
     assert covered == list(range(world * frames))  # query shards partition all frames
+
+
+def _mc_worker(rank, world, uid, frames, cap, q):
+    """The same exchange and bookkeeping through the C ABI (include/orbfe_mc.h), host-memory handles (no GPU here):
+    orbfe_mc_create(ctx = NULL, ORBFE_MC_HOST) -> orbfe_mc_exchange_host -> orbfe_mc_ring_pairs / _job_offsets."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from orb_slam3_detailed_comments_kor_amd import binding
+    import orb_oracle_py as O  # the checker: knn-2 stand-in for the device matcher
+    ok = True
+    try:
+        mc = binding.MultiCam(None, uid, rank, world, frames, cap, binding.MC_HOST)
+        desc_bytes, count_off, slab_bytes = binding.mc_layout(frames, cap)
+        ok &= slab_bytes % 256 == 0 and count_off == desc_bytes == frames * cap * 32
+
+        def content(r, b):
+            rr = np.random.default_rng(10 * b + r)
+            return rr.integers(cap // 2, cap, size=frames).astype(np.int32), rr.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
+
+        for b in range(3):  # three rounds through the two halves of the shared segment
+            n, d = content(rank, b)
+            slab = np.zeros(slab_bytes, np.uint8)
+            slab[:desc_bytes] = d.reshape(-1)
+            slab[count_off:count_off + 4 * frames] = n.view(np.uint8)
+            g = mc.exchange_host(slab)
+            for r in range(world):
+                en, ed = content(r, b)
+                ok &= np.array_equal(g[r, :desc_bytes].reshape(frames, cap, 32), ed)
+                ok &= np.array_equal(g[r, count_off:count_off + 4 * frames].view(np.int32), en)
+            gathered = g.reshape(-1).copy()
+        # ring matching bookkeeping on the last round: every local frame against the next camera and the one after
+        pairs = binding.mc_ring_pairs(world, frames, rank, (1, 2))
+        ok &= len(pairs) == 2 * frames and [qq for qq, _ in pairs[:frames]] == list(range(frames))
+        off = binding.mc_job_offsets(frames, cap, pairs)
+        seen_remote = False
+        for (qi, gidx), (qd, qc, td, tc) in zip(pairs, off):
+            ok &= gidx == (rank * frames + qi + (1 if pairs.index((qi, gidx)) < frames else 2)) % (world * frames)
+            nq = int(slab[qc:qc + 4].view(np.int32)[0])
+            nt = int(gathered[tc:tc + 4].view(np.int32)[0])
+            Q = slab[qd:qd + nq * 32].reshape(nq, 32)
+            T = gathered[td:td + nt * 32].reshape(nt, 32)
+            r, j = divmod(gidx, frames)
+            seen_remote |= r != rank
+            en, ed = content(r, 2)
+            ok &= nq == n[qi] and nt == en[j] and np.array_equal(T, ed[j, :nt])
+            idx, dst = O.bfknn2(Q, T)
+            D = np.unpackbits(d[qi, :nq, None, :] ^ ed[j, None, :nt, :], axis=2).sum(axis=2)
+            ok &= np.array_equal(idx, np.argsort(D, axis=1, kind="stable")[:, :2])
+            ok &= np.array_equal(dst, np.sort(D, axis=1, kind="stable")[:, :2])
+        ok &= seen_remote
+        first, count = binding.mc_shard(world * frames, world, rank)
+        mc.close()
+        q.put((rank, bool(ok), list(range(first, first + count))))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, False, repr(e)))
+
+
+def test_exchange_and_ring_bookkeeping_through_the_c_abi_world2():
+    sys.path.insert(0, ROOT)
+    from orb_slam3_detailed_comments_kor_amd import binding
+    world, frames, cap = 2, 3, 40
+    uid = binding.mc_unique_id(binding.MC_HOST)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mc_worker, args=(r, world, uid, frames, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(sum((qs for _, _, qs in res), [])) == list(range(world * frames))
+
+
+def test_mc_argument_errors_need_no_device():
+    sys.path.insert(0, ROOT)
+    from orb_slam3_detailed_comments_kor_amd import binding
+    L = binding.lib()
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.orbfe_mc_create(C.byref(h), None, None, 0, 1, 2, 10, binding.MC_RCCL) == binding.ERR_ARGS  # RCCL needs a context
+    assert L.orbfe_mc_create(C.byref(h), None, None, 2, 2, 2, 10, binding.MC_HOST) == binding.ERR_ARGS  # rank out of range
+    assert L.orbfe_mc_create(C.byref(h), None, None, 0, 2, 2, 10, binding.MC_HOST) == binding.ERR_ARGS  # world 2 without an id
+    with pytest.raises(binding.OrbfeError):
+        binding.mc_layout(0, 10)
+    assert binding.mc_shard(7, 3, 0) == (0, 3) and binding.mc_shard(7, 3, 2) == (5, 2)
+    assert binding.mc_ring_pairs(2, 2, 1, (1, -1)) == [(0, 3), (1, 0), (0, 1), (1, 2)]
 
 
 def test_shard_frames_partition():

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../orb_slam3_detailed_comments_kor_amd/csrc"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result \
-      $flags -shared -o ../liborbfe_$name.so orbfe_extractor.hip orbfe_matcher.hip &
+      $flags -shared -o ../liborbfe_$name.so orbfe_extractor.hip orbfe_matcher.hip orbfe_multicam.hip -ldl -lrt -pthread &
 done
 wait
 ls -la ../liborbfe_*.so
