@@ -663,6 +663,11 @@ public:
             const int bestIdx = qMatch[k];
             if (bestIdx < 0) continue;
             MapPoint* pMP = q.mp[k];
+            // :1690-1692 tests isBad() / IsInKeyFrame() per ITERATION, i.e. after the earlier iterations' AddObservation /
+            // Replace: a point that occurs twice in vpMapPoints (a rig's keyframe holds the same point at its left and at
+            // its right index, LocalMapping.cc:829-870) is fused once.  The search itself does not depend on object
+            // state, so re-testing here is equivalent.
+            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
             MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
             if (pMPinKF) {
                 if (!pMPinKF->isBad()) {

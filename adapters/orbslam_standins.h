@@ -86,7 +86,12 @@ public:
     int PredictScale(const float& currentDist, class Frame* pF); // MapPoint.cc:565-580, below
     int PredictScale(const float& currentDist, KeyFrame* pKF); // MapPoint.cc:548-563, below
     // what Fuse does to the map (MapPoint.cc Replace / AddObservation): recorded for the test
-    void Replace(MapPoint* pMP) { mpReplaced = pMP; }
+    void Replace(MapPoint* pMP)
+    { // MapPoint.cc:213-270: the replaced point is dead from here on
+        if (pMP == this) return;
+        mbBad = true;
+        mpReplaced = pMP;
+    }
     void AddObservation(KeyFrame* pKF, int idx) { mObservations[pKF] = idx; }
 
     bool mbBad = false;

@@ -454,8 +454,13 @@ static void test_fuse(const std::string& P)
     const int m = (int)in(P + "pstate").count;
     std::vector<MapPoint*> pts(m, nullptr);
     const int32_t* ps = in(P + "pstate").i32(); // 0 null, 1 ok, 2 bad, 3 already observed in the keyframe
+    const int32_t* dup = has(P + "pdup") ? in(P + "pdup").i32() : nullptr; // the same point twice in the list (>= 0: of which entry)
     for (int q = 0; q < m; q++) {
         if (!ps[q]) continue;
+        if (dup && dup[q] >= 0) {
+            pts[q] = pts[dup[q]];
+            continue;
+        }
         MapPoint* p = pts[q] = new_point(q);
         p->mbBad = ps[q] == 2;
         if (ps[q] == 3) p->mObservations[&k] = 0;

@@ -236,6 +236,16 @@ int orbfe_matcher_sync(int device);
  * calls these are the context's own buffers; for orbfe_extract_batch_device the caller's. */
 int orbfe_get_device_outputs(orbfe_ctx*, const orbfe_kp** d_kps, const uint8_t** d_desc, const int32_t** d_n, int* cap,
                              int* nimg);
+/* ORDERING of resident pointers.  orbfe_extract_batch_device is asynchronous on the context's stream; the arrays above
+ * may still be being written when this call returns them.  The call therefore marks that point on the context's stream,
+ * and every matcher entry point of this library (the host-pointer forms that recognise device pointers, the *_device
+ * forms, orbfe_frame_create, orbfe_search_bow_batch ...) that is later handed one of these pointers makes ITS stream wait
+ * for the mark before it reads: extraction -> orbfe_get_device_outputs -> matcher call needs no orbfe_sync in between.
+ * Call it again after every extraction (a new batch moves the mark).  A caller's OWN kernels or copies on the arrays
+ * must be ordered by the caller: run them on the context's stream (orbfe_set_stream / orbfe_get_stream) or after
+ * orbfe_sync.  Buffers the caller owns and never passed through this call (e.g. the d_desc given to
+ * orbfe_extract_batch_device and then straight to a *_device matcher form on ANOTHER stream) are likewise the caller's
+ * to order. */
 /* In every matcher call below the DESCRIPTOR arrays (desc1 / desc2 / desc / qdesc / pool ...) may also be device
  * pointers: the call recognises them (hipPointerGetAttributes) and reads them in place instead of uploading. */
 

@@ -26,6 +26,7 @@
 
 #include "../../include/orbfe.h"
 #include "orbfe_geom.h"
+#include "orbfe_order.h"
 #include "orbfe_sincos.h"
 
 // single translation unit: the kernels are compiled together with their launch code
@@ -208,6 +209,7 @@ struct orbfe_ctx : orbfe_geom_state {
     DevBuf<float> d_stereo; // uRight | depth | sad of orbfe_compute_stereo_matches_resident
     PinBuf<float> h_stereo;
     hipEvent_t evStereo = nullptr;
+    hipEvent_t evOutputs = nullptr; // recorded by orbfe_get_device_outputs: the point after which the resident outputs are final
 
     int lastImgs = 0;
     int lastFixups = 0;
@@ -1388,6 +1390,10 @@ void orbfe_destroy(orbfe_ctx* c)
         if (sl.evDone) (void)hipEventDestroy(sl.evDone);
     }
     if (c->evStereo) (void)hipEventDestroy(c->evStereo);
+    if (c->evOutputs) {
+        orbfe_producer_retire(c->evOutputs);
+        (void)hipEventDestroy(c->evOutputs);
+    }
     if (c->sIn) (void)hipStreamDestroy(c->sIn);
     if (c->sOut) (void)hipStreamDestroy(c->sOut);
     if (c->evReady)
@@ -1671,6 +1677,15 @@ int orbfe_get_device_outputs(orbfe_ctx* c, const orbfe_kp** d_kps, const uint8_t
 {
     if (!c) return ORBFE_ERR_ARGS;
     if (!c->lastKps || c->lastImgs < 1) return ORBFE_ERR_STATE;
+    // The arrays may still be being written (orbfe_extract_batch_device returns at once): mark the point on the producing
+    // stream and publish the ranges, so that a matcher call that is handed one of these pointers orders itself after it
+    // (orbfe_order.h).  The caller's own kernels must still be ordered by the caller (same stream, or orbfe_sync).
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->evOutputs) HIP_TRY(hipEventCreateWithFlags(&c->evOutputs, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->evOutputs, c->stream));
+    orbfe_producer_publish(c->lastDesc, (size_t)c->lastImgs * c->lastCap * 32, c->evOutputs);
+    orbfe_producer_publish(c->lastKps, (size_t)c->lastImgs * c->lastCap * sizeof(orbfe_kp), c->evOutputs);
+    orbfe_producer_publish(c->lastN, (size_t)c->lastImgs * sizeof(int32_t), c->evOutputs);
     if (d_kps) *d_kps = reinterpret_cast<const orbfe_kp*>(c->lastKps);
     if (d_desc) *d_desc = c->lastDesc;
     if (d_n) *d_n = c->lastN;

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/orbfe.h"
+#include "orbfe_order.h"
 #include "orbfe_sincos.h"
 #include "orbfe_kb8.h"
 
@@ -1336,6 +1337,8 @@ struct Scratch { // device allocations of one call
     int up_desc(uint8_t** out, const uint8_t* hostOrDev, size_t n)
     {
         if (hostOrDev && n && is_device_ptr(hostOrDev)) {
+            // (an extractor may still be writing it on its own stream: orbfe_order.h)
+            (void)orbfe_producer_wait(hostOrDev, g_ms);
             *out = const_cast<uint8_t*>(hostOrDev);
             return 0;
         }
@@ -1580,8 +1583,11 @@ int orbfe_hamming_pairs_device(int device, void* hip_stream, const uint8_t* dA, 
     if (nA == 0 || nB == 0) return 0;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0,
-                       matcher_stream(device, hip_stream), dA, nA, dB, nB, dD);
+    hipStream_t st = matcher_stream(device, hip_stream);
+    (void)orbfe_producer_wait(dA, st);
+    (void)orbfe_producer_wait(dB, st);
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, st, dA, nA, dB, nB,
+                       dD);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1593,8 +1599,10 @@ int orbfe_bfknn2_device(int device, void* hip_stream, const uint8_t* dQ, int nQ,
     if (nQ == 0) return 0;
     int r;
     if ((r = select_device(device)) < 0) return r;
-    hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, matcher_stream(device, hip_stream), dQ, nQ,
-                       dT, nT, d_idx, d_dist);
+    hipStream_t st = matcher_stream(device, hip_stream);
+    (void)orbfe_producer_wait(dQ, st);
+    (void)orbfe_producer_wait(dT, st);
+    hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, st, dQ, nQ, dT, nT, d_idx, d_dist);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1712,9 +1720,15 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
         if (!active[p]) continue;
         const orbfe_bow_args* a = &args[p];
         const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
-        if (is_device_ptr(a->desc1)) d2d.push_back(D2D{r1 * 32, a->desc1, (size_t)a->n1 * 32});
+        if (is_device_ptr(a->desc1)) {
+            (void)orbfe_producer_wait(a->desc1, g_ms);
+            d2d.push_back(D2D{r1 * 32, a->desc1, (size_t)a->n1 * 32});
+        }
         else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
-        if (is_device_ptr(a->desc2)) d2d.push_back(D2D{r2 * 32, a->desc2, (size_t)a->n2 * 32});
+        if (is_device_ptr(a->desc2)) {
+            (void)orbfe_producer_wait(a->desc2, g_ms);
+            d2d.push_back(D2D{r2 * 32, a->desc2, (size_t)a->n2 * 32});
+        }
         else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
         std::memcpy(hMask + r1, a->mask1, (size_t)a->n1);
         if (a->variant == 1) std::memcpy(hMask + r2, a->mask2, (size_t)a->n2);
@@ -2524,7 +2538,9 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
     F->hOctave.assign(a->octave, a->octave + n);
     if (a->angle) F->hAngle.assign(a->angle, a->angle + n);
     Scratch s(device); // (this thread's matcher stream)
-    hipError_t e = hipMemcpyAsync(F->desc, a->desc, n * 32, is_device_ptr(a->desc) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
+    const bool descResident = is_device_ptr(a->desc);
+    if (descResident) (void)orbfe_producer_wait(a->desc, g_ms);
+    hipError_t e = hipMemcpyAsync(F->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess) e = hipMemcpyAsync(F->octave, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);

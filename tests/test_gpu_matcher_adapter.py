@@ -501,9 +501,12 @@ def _proj_last_rig(f, tag, oracle, seed, n, nl, th, tlz, ori):
     return check
 
 
-def _fuse(f, tag, oracle, seed, n, m, th, rig=None):
+def _fuse(f, tag, oracle, seed, n, m, th, rig=None, dup=False):
     """rig = None, "left" or "right": a keyframe of a two-camera rig, fused into through its left / right camera
-    (bRight, src/ORBmatcher.cc:1647-1658: right pose, mpCamera2, right grid, features NLeft..)."""
+    (bRight, src/ORBmatcher.cc:1647-1658: right pose, mpCamera2, right grid, features NLeft..).
+    dup: a tenth of the candidates are the SAME MapPoint object as an earlier entry of the list (what
+    GetMapPointMatches() of a rig keyframe holds at the left and the right index): the reference tests isBad() /
+    IsInKeyFrame() per iteration (:1690-1692), so the second occurrence is skipped once the first one fused."""
     rng = np.random.default_rng(seed)
     fr = _frame_arrays(rng, n, True)
     fr["uright"] = np.where(rng.random(n) < 0.5, fr["kx"] - rng.uniform(0, 30, n), -1).astype(np.float32)
@@ -544,6 +547,17 @@ def _fuse(f, tag, oracle, seed, n, m, th, rig=None):
     pstate = rng.choice([0, 1, 1, 1, 1, 1, 1, 2, 3], m).astype(np.int32)
     pobs = rng.integers(1, 6, m).astype(np.int32)
     pdesc = _noisy(fr["desc"][tgt], rng, 0.0, 0.2)
+    pdup = np.full(m, -1, np.int32)
+    if dup:
+        for q in np.sort(rng.choice(np.arange(1, m), m // 10, replace=False)):  # ascending: a root's state is final
+            r = int(rng.integers(0, q))
+            r = int(pdup[r]) if pdup[r] >= 0 else r
+            if pstate[r] == 0 or pstate[q] == 0:
+                continue
+            pdup[q] = r                                                     # the same object: every property is the root's
+            for arr in (u, v, z, pos, xc, dist, level, maxd, mind, wrong, normal, flip, pstate, pobs, pdesc, out):
+                arr[q] = arr[r]
+        _put(f, tag + "pdup", pdup)
     for k, val in (("cam", cam), ("bf", np.array([bf], np.float32)), ("R", np.eye(3, dtype=np.float32)),
                    ("t", np.zeros(3, np.float32)), ("O", np.zeros(3, np.float32)), ("logsf", np.array([np.log(1.2)], np.float32)),
                    ("pstate", pstate), ("pobs", pobs), ("ppos", pos), ("pnormal", normal.astype(np.float32)),
@@ -574,24 +588,34 @@ def _fuse(f, tag, oracle, seed, n, m, th, rig=None):
         obs_of.update({int(q): int(pobs[q]) for q in range(m)})
         bad_of = {100000 + i: bool(fstate[i] == 2) for i in range(n)}
         obs_idx, repl, kf_repl = np.full(m, -1), np.full(m, -1), np.full(n, -1)
+        root = np.where(pdup >= 0, pdup, np.arange(m))                      # the object behind a list entry
+        in_kf = set()
         nfused = 0
         for k, q in enumerate(keep):
             idx = qm[k]
             if idx < 0:
                 continue
+            o = int(root[q])
+            if bad_of.get(o, False) or o in in_kf:                           # :1690-1692, evaluated per iteration
+                continue
             pid = point[idx]
             if pid >= 0:
                 if not bad_of.get(pid, False):
-                    if obs_of[pid] > obs_of[int(q)]:
-                        repl[q] = pid
+                    if obs_of[pid] > obs_of[o]:
+                        repl[o] = pid
+                        bad_of[o] = True                                     # MapPoint::Replace kills the replaced point
                     elif pid >= 100000:
-                        kf_repl[pid - 100000] = q
+                        kf_repl[pid - 100000] = o
+                        bad_of[pid] = True
                     else:
-                        repl[pid] = q
+                        repl[pid] = o
+                        bad_of[pid] = True
             else:
-                obs_idx[q] = idx
-                point[idx] = q
+                obs_idx[o] = idx
+                point[idx] = o
+                in_kf.add(o)
             nfused += 1
+        obs_idx, repl = obs_idx[root], repl[root]                            # list entries of one object report the same
         assert res[tag + "n"][0] == nfused and nfused > 50, (tag, nfused)
         assert np.array_equal(res[tag + "obsIdx"], obs_idx), tag
         assert np.array_equal(res[tag + "replacedBy"], repl), tag
@@ -908,6 +932,8 @@ def test_cpp_matcher_adapter_matches_oracle(tmp_path, oracle):
         checks.append(_fuse(f, "fu1.", oracle, 62, 900, 700, 4.0))
         checks.append(_fuse(f, "fu2.", oracle, 63, 1500, 1000, 3.0, rig="left"))                       # two-camera rigs
         checks.append(_fuse(f, "fu3.", oracle, 64, 1500, 1000, 3.0, rig="right"))
+        checks.append(_fuse(f, "fu4.", oracle, 65, 1500, 1000, 3.0, rig="left", dup=True))             # one point, two list entries
+        checks.append(_fuse(f, "fu5.", oracle, 66, 1200, 900, 3.0, dup=True))
         checks.append(_proj_local_rig(f, "p0_2.", oracle, 43, 1500, 1200, 1.0))
         checks.append(_proj_local_rig(f, "p0_3.", oracle, 44, 1200, 1000, 3.0))
         checks.append(_proj_last_rig(f, "p1_4.", oracle, 55, 1500, 1000, 7.0, 0.0, True))

@@ -122,3 +122,35 @@ def test_frames_knn2_ragged_counts_and_both_kernel_shapes(pkg, oracle):
             ri, rd = oracle.bfknn2(desc[q, :counts[q]], desc[t, :counts[t]])
             assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), (frames, k)
             assert (idx[k, counts[q]:] == -7).all()  # rows beyond the query count are untouched
+
+
+def test_matcher_orders_itself_after_an_asynchronous_extraction(pkg, oracle):
+    """orbfe_extract_batch_device returns at once; orbfe_get_device_outputs marks the context's stream and a matcher call
+    that is handed the resident descriptors waits for that mark on its own stream -- no orbfe_sync in between (the calls
+    used to race).  A large batch in front makes the window wide."""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, H, W, nf = 24, 480, 752, 1000
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    cap = ex.max_keypoints(H, W)
+    imgs = np.stack([pkg.synth.make_frame(H, W, 40 + i) for i in range(B)])
+    d_img = torch.from_numpy(imgs).to(dev)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    refs = [oracle.Extractor(nf, 1.2, 8, 20, 7).extract(imgs[i], (0, 0)) for i in (0, B - 1)]
+    n0, n1 = len(refs[0][1]), len(refs[1][1])
+    ri, rd = oracle.bfknn2(refs[0][2], refs[1][2])
+    for rep in range(3):
+        d_desc.zero_()
+        torch.cuda.synchronize()
+        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, (0, 0), d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), d_mono.data_ptr())
+        _, p_desc, _, pcap, pn = ex.device_outputs()   # no sync: the batch is still running
+        assert (pcap, pn) == (cap, B) and p_desc == d_desc.data_ptr()
+        idx, dist = np.zeros((n0, 2), np.int32), np.zeros((n0, 2), np.int32)
+        r = pkg.lib().orbfe_bfknn2(0, p_desc, n0, p_desc + (B - 1) * cap * 32, n1, idx.ctypes.data, dist.ctypes.data)
+        assert r == 0 and np.array_equal(idx, ri) and np.array_equal(dist, rd), rep
+    ex.close()
