@@ -208,6 +208,8 @@ struct orbfe_ctx : orbfe_geom_state {
     int lastCap = 0;
     DevBuf<float> d_stereo; // uRight | depth | sad of orbfe_compute_stereo_matches_resident
     PinBuf<float> h_stereo;
+    DevBuf<uint8_t> d_stereoIo; // orbfe_compute_stereo_matches: keypoints and descriptors of both images | uRight | depth | sad
+    PinBuf<uint8_t> h_stereoIo;
     hipEvent_t evStereo = nullptr;
     hipEvent_t evOutputs = nullptr; // recorded by orbfe_get_device_outputs: the point after which the resident outputs are final
 
@@ -1140,8 +1142,8 @@ int slot_prepare(orbfe_ctx* c, orbfe_ctx::HostSlot& sl, bool pipelined)
 // Queue one host-pointer batch: H2D of the images, the five kernels, D2H of the results.  `pipelined` puts the
 // copies on their own streams (ordered by events) so that they overlap the kernels of the neighbouring batches;
 // the blocking calls keep everything on the context's stream (no event traffic on the latency path).
-int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
-                orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined)
+int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
+                     orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined)
 {
     if (!c || nimg < 1 || !imgs || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
     for (int i = 0; i < nimg; i++) {
@@ -1280,6 +1282,25 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
     return 0;
 }
 
+// A submit that fails after its first copy or kernel has been queued returns an error without marking the slot busy: the
+// caller cannot wait for it and may free or reuse its buffers at once.  So nothing may still be in flight then: the three
+// streams are drained before the error is handed back (DMA engines read the images, and write pinned result arrays, in
+// place).
+int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
+                orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined)
+{
+    if (c && c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: nothing was queued
+    const int r = host_submit_impl(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, pipelined);
+    if (r < 0 && c && r != ORBFE_ERR_ARGS && r != -1) {
+        if (hipSetDevice(c->device) == hipSuccess) {
+            if (c->sIn) (void)hipStreamSynchronize(c->sIn);
+            (void)hipStreamSynchronize(c->stream);
+            if (c->sOut) (void)hipStreamSynchronize(c->sOut);
+        }
+    }
+    return r;
+}
+
 // Complete the oldest submitted batch: wait for its transfers, hand out the counts, and -- for pageable output
 // arrays -- copy the rows each image produced out of the staging buffer.
 int host_wait(orbfe_ctx* c)
@@ -1383,6 +1404,7 @@ void orbfe_destroy(orbfe_ctx* c)
     for (auto& g : c->geomCache) g.release_tables();
     c->d_taps.release(); c->d_patternF.release();
     c->h_fix.release(); c->h_fixAB.release(); c->d_stereo.release(); c->h_stereo.release();
+    c->d_stereoIo.release(); c->h_stereoIo.release();
     for (auto& sl : c->slot) {
         sl.d_img.release(); sl.d_out.release(); sl.h_in.release(); sl.h_out.release(); sl.h_lap.release();
         if (sl.evIn) (void)hipEventDestroy(sl.evIn);
@@ -1750,44 +1772,38 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
         left->nlevels != right->nlevels || left->scaleFactor != right->scaleFactor)
         return ORBFE_ERR_STATE;
     HIP_TRY(hipSetDevice(left->device));
-    HIP_TRY(hipStreamSynchronize(left->stream));
-    HIP_TRY(hipStreamSynchronize(right->stream));
-    float *dKL = nullptr, *dKR = nullptr, *dU = nullptr, *dD = nullptr;
-    uint8_t *dDL = nullptr, *dDR = nullptr;
-    int32_t* dS = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(dKL); (void)hipFree(dKR); (void)hipFree(dU); (void)hipFree(dD); (void)hipFree(dDL);
-        (void)hipFree(dDR); (void)hipFree(dS);
-    };
-#define ST_TRY(expr)                                 \
-    do {                                             \
-        hipError_t _e = (expr);                      \
-        if (_e != hipSuccess) {                      \
-            cleanup();                               \
-            return -(1000 + (int)_e);                \
-        }                                            \
-    } while (0)
-    ST_TRY(hipMalloc((void**)&dKL, (size_t)nL * 28));
-    ST_TRY(hipMalloc((void**)&dKR, (size_t)nR * 28));
-    ST_TRY(hipMalloc((void**)&dDL, (size_t)nL * 32));
-    ST_TRY(hipMalloc((void**)&dDR, (size_t)nR * 32));
-    ST_TRY(hipMalloc((void**)&dU, (size_t)nL * 4));
-    ST_TRY(hipMalloc((void**)&dD, (size_t)nL * 4));
-    ST_TRY(hipMalloc((void**)&dS, (size_t)nL * 4));
+    // Inputs and outputs live in the left context's arenas (no allocation per call): everything is staged in pinned memory,
+    // goes up in ONE transfer and comes back in ONE; the right extractor's kernels are ordered by an event, not by the host.
+    const size_t oKL = 0, oKR = align_up(oKL + (size_t)nL * 28, 16), oDL = align_up(oKR + (size_t)nR * 28, 16),
+                 oDR = align_up(oDL + (size_t)nL * 32, 16), oOut = align_up(oDR + (size_t)nR * 32, 16),
+                 total = oOut + 3 * (size_t)nL * 4;
+    int r;
+    if ((r = left->d_stereoIo.ensure(total)) < 0) return r;
+    if ((r = left->h_stereoIo.ensure(total)) < 0) return r;
+    uint8_t* const hb = left->h_stereoIo.p;
+    uint8_t* const db = left->d_stereoIo.p;
+    std::memcpy(hb + oKL, kpsL, (size_t)nL * 28);
+    std::memcpy(hb + oKR, kpsR, (size_t)nR * 28);
+    std::memcpy(hb + oDL, descL, (size_t)nL * 32);
+    std::memcpy(hb + oDR, descR, (size_t)nR * 32);
     hipStream_t s = left->stream;
-    ST_TRY(hipMemcpyAsync(dKL, kpsL, (size_t)nL * 28, hipMemcpyHostToDevice, s));
-    ST_TRY(hipMemcpyAsync(dKR, kpsR, (size_t)nR * 28, hipMemcpyHostToDevice, s));
-    ST_TRY(hipMemcpyAsync(dDL, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s));
-    ST_TRY(hipMemcpyAsync(dDR, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s));
+    if (right->stream != s) {
+        if (!left->evStereo) HIP_TRY(hipEventCreateWithFlags(&left->evStereo, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(left->evStereo, right->stream));
+        HIP_TRY(hipStreamWaitEvent(s, left->evStereo, 0));
+    }
+    HIP_TRY(hipMemcpyAsync(db, hb, oOut, hipMemcpyHostToDevice, s));
+    float* dU = reinterpret_cast<float*>(db + oOut);
+    float* dD = dU + nL;
+    int32_t* dS = reinterpret_cast<int32_t*>(dD + nL);
     hipLaunchKernelGGL(k_stereo_match, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, s, left->d_pyr.p, right->d_pyr.p,
-                       left->d_lg.p, left->nlevels, dKL, dDL, nL, dKR, dDR, nR, mb, mbf, dU, dD, dS, nullptr, nullptr);
-    std::vector<int32_t> sad(nL);
-    ST_TRY(hipMemcpyAsync(uRight, dU, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
-    ST_TRY(hipMemcpyAsync(depth, dD, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
-    ST_TRY(hipMemcpyAsync(sad.data(), dS, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
-    ST_TRY(hipStreamSynchronize(s));
-#undef ST_TRY
-    cleanup();
+                       left->d_lg.p, left->nlevels, reinterpret_cast<const float*>(db + oKL), db + oDL, nL,
+                       reinterpret_cast<const float*>(db + oKR), db + oDR, nR, mb, mbf, dU, dD, dS, nullptr, nullptr);
+    HIP_TRY(hipMemcpyAsync(hb + oOut, db + oOut, 3 * (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(uRight, hb + oOut, (size_t)nL * 4);
+    std::memcpy(depth, hb + oOut + (size_t)nL * 4, (size_t)nL * 4);
+    const int32_t* sad = reinterpret_cast<const int32_t*>(hb + oOut + 2 * (size_t)nL * 4);
     // outlier cut (:952-966): matches whose SAD is >= 1.5*1.4*median are dropped
     std::vector<std::pair<int, int>> vDistIdx;
     for (int i = 0; i < nL; i++)

@@ -1996,9 +1996,17 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iL = blockIdx.x * 4 + wave;
+    const int rowsL = nL; // rows of the output arrays
     if (nLdev) nL = min(nL, nLdev[0]);
     if (nRdev) nR = min(nR, nRdev[0]);
-    if (iL >= nL) return;
+    if (iL >= nL) { // rows past the keypoint count: "no match", so that a caller that asks for more rows never reads stale data
+        if (iL < rowsL && lane == 0) {
+            uRight[iL] = -1.0f;
+            depth[iL] = -1.0f;
+            sadOut[iL] = -1;
+        }
+        return;
+    }
     const float uL = kpsL[iL * 7 + 0], vL = kpsL[iL * 7 + 1];
     const int levelL = reinterpret_cast<const int32_t*>(kpsL)[iL * 7 + 5];
     const int vLi = (int)vL;
