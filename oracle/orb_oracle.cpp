@@ -2081,6 +2081,10 @@ int orb_oracle_search_triangulation_kb8(const orb_oracle_tri_kb8_args* a, int32_
     return np;
 }
 
+// cv::SVD::compute of a 4 x 4 float matrix as restated above (rows of vt = right singular vectors by descending singular
+// value): exported for the OpenCV differential harness (adapters/diff_opencv.cpp)
+void orb_oracle_svd_vt_4x4(const float* A16, float* vt16) { jacobi_svd_vt_4x4(A16, vt16); }
+
 void orb_oracle_kb8_unproject(const float* P, const float* uv, int n, float* rays)
 {
     const float precision = 1e-6f; // reference include/CameraModels/KannalaBrandt8.h (precision member)

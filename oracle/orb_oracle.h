@@ -198,6 +198,8 @@ int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_or
                                       float mbf, float* uRight, float* depth);
 /* KannalaBrandt8::unproject src/CameraModels/KannalaBrandt8.cpp:96-123; params = fx,fy,cx,cy,k0..k3 */
 void orb_oracle_kb8_unproject(const float* params8, const float* uv, int n, float* rays3);
+/* cv::SVD::compute(A, w, u, vt) of a 4x4 CV_32F matrix: vt only (KannalaBrandt8::Triangulate_, KannalaBrandt8.cpp:514-535) */
+void orb_oracle_svd_vt_4x4(const float* A16, float* vt16);
 
 #ifdef __cplusplus
 }

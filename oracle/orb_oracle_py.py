@@ -29,7 +29,8 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liborb_oracle.so")
+        # ORB_ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle asan`)
+        path = os.environ.get("ORB_ORACLE_LIB") or os.path.join(_HERE, "liborb_oracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
