@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../include/orbfe.h"
@@ -36,7 +37,7 @@ public:
         : ctx(nullptr), nlevels(nlevels), scaleFactor(scaleFactor)
     {
         const int r = orbfe_create(&ctx, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device);
-        if (r < 0) throw std::runtime_error("orbfe_create failed (no HIP device or bad parameters)");
+        if (r < 0) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(r));
         mvScaleFactor.resize(nlevels);
         mvInvScaleFactor.resize(nlevels);
         mvLevelSigma2.resize(nlevels);
@@ -67,14 +68,14 @@ public:
         const size_t step = image.step;
 #endif
         const int cap = orbfe_max_keypoints(ctx, image.rows, image.cols);
-        if (cap < 0) throw std::runtime_error("image too small for the 8-level 35-px cell grid");
+        if (cap < 0) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(cap));
         static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_kp), "cv::KeyPoint layout");
         std::vector<cv::KeyPoint> kps((size_t)cap);
         std::vector<uint8_t> desc((size_t)cap * 32);
         int n = 0;
         const int mono = orbfe_extract(ctx, data, image.rows, image.cols, step, vLappingArea[0], vLappingArea[1],
                                        reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(), cap, &n);
-        if (mono < -1) throw std::runtime_error("orbfe_extract failed");
+        if (mono < -1) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(mono));
         kps.resize((size_t)n);
         _keypoints.swap(kps);
 #ifdef ORBFE_HAVE_OPENCV
@@ -131,7 +132,7 @@ public:
         if (L.empty() || R.empty()) return -1;
         if (L.rows != R.rows || L.cols != R.cols || L.step != R.step) throw std::runtime_error("ExtractStereoPair: unequal images");
         const int cap = orbfe_max_keypoints(ctx, L.rows, L.cols);
-        if (cap < 0) throw std::runtime_error("image too small for the 8-level 35-px cell grid");
+        if (cap < 0) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(cap));
         std::vector<cv::KeyPoint> kps((size_t)2 * cap);
         std::vector<uint8_t> desc((size_t)2 * cap * 32);
         const uint8_t* two[2] = {L.data, R.data};

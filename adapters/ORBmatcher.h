@@ -41,6 +41,7 @@
 #include <set>
 #include <stdexcept>
 #include <tuple>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -90,6 +91,63 @@ inline const uint8_t* dense_descriptors(const cv::Mat& D, int n, std::vector<uin
     tmp.resize((size_t)n * 32);
     for (int i = 0; i < n; i++) std::memcpy(tmp.data() + (size_t)i * 32, D.data + (size_t)i * D.step, 32);
     return tmp.data();
+}
+
+// Frame handles (orbfe_frame, include/orbfe.h): Tracking searches the SAME Frame two or three times per image -- the last
+// frame at th, again at 2 th when that finds too little (src/Tracking.cc:2817-2827), then the local map (:2927) -- and every
+// search used to flatten and upload the frame side (descriptors, keypoints, grid) again.  The adapter keeps the handles of
+// the last few Frames it has seen, per calling thread (Tracking is the one thread that searches Frames; a thread-local
+// table needs no lock and no handle is ever freed under another thread's search).  A Frame is recognised by its address,
+// its mnId (Frame.cc: mnId = nNextId++, a new value per image although mCurrentFrame keeps its address), its feature
+// count and descriptor buffer; its features never change after construction, its map points do and travel per search.
+struct FrameHandles {
+    struct Entry {
+        const void* obj = nullptr;
+        unsigned long id = 0;
+        int n = 0, device = 0;
+        const void* desc = nullptr;
+        orbfe_frame* h = nullptr;
+        unsigned long used = 0;
+    };
+    Entry e[4];
+    unsigned long clock = 0;
+    long creates = 0, hits = 0; // (what the tests look at)
+    ~FrameHandles()
+    {
+        for (Entry& x : e)
+            if (x.h) orbfe_frame_destroy(x.h);
+    }
+    Entry* find(const void* obj, unsigned long id, int n, const void* desc, int device)
+    {
+        for (Entry& x : e)
+            if (x.h && x.obj == obj && x.id == id && x.n == n && x.desc == desc && x.device == device) {
+                x.used = ++clock;
+                hits++;
+                return &x;
+            }
+        return nullptr;
+    }
+    Entry* slot()
+    { // an empty entry, else the least recently used one
+        Entry* best = &e[0];
+        for (Entry& x : e) {
+            if (!x.h) return &x;
+            if (x.used < best->used) best = &x;
+        }
+        orbfe_frame_destroy(best->h);
+        best->h = nullptr;
+        return best;
+    }
+};
+inline FrameHandles& frame_handles()
+{
+    static thread_local FrameHandles f;
+    return f;
+}
+inline bool& use_frame_handles()
+{
+    static bool on = true; // (tests switch it off to compare the two paths)
+    return on;
 }
 
 // the keypoint a method reads for feature idx of a keyframe / frame with an optional second camera
@@ -1039,15 +1097,43 @@ protected:
                        const int* r2l, std::vector<int32_t>& qMatch, std::vector<int32_t>& featMatch)
     {
         using namespace orbfe_adapter;
-        FeatureArrays fa;
-        fa.fill(f, n, nLeft);
         std::vector<uint8_t> tmp;
         orbfe_proj_args a;
         std::memset(&a, 0, sizeof(a));
-        a.desc = dense_descriptors(D, n, tmp);
         a.n = n;
-        a.kx = fa.kx.data(); a.ky = fa.ky.data(); a.octave = fa.octave.data(); a.angle = fa.angle.data();
         a.uright = (nLeft == -1 || chi2) ? uright : nullptr; // (Fuse reads mvuRight of a rig's keyframe too, :1775)
+        // a Frame: its side of the search lives in a handle on the device, made on first sight (see FrameHandles above)
+        orbfe_frame* handle = nullptr;
+        FeatureArrays fa;
+        if constexpr (std::is_same<T, Frame>::value) {
+            if (use_frame_handles() && n > 0) {
+                FrameHandles& H = frame_handles();
+                FrameHandles::Entry* e = H.find(&f, f.mnId, n, D.data, mDevice);
+                if (!e) {
+                    fa.fill(f, n, nLeft);
+                    orbfe_proj_args fs = a;
+                    fs.desc = dense_descriptors(D, n, tmp);
+                    fs.kx = fa.kx.data(); fs.ky = fa.ky.data(); fs.octave = fa.octave.data(); fs.angle = fa.angle.data();
+                    fs.Nleft = nLeft;
+                    fs.minX = minX; fs.minY = minY; fs.gridWInv = gwInv; fs.gridHInv = ghInv;
+                    fs.inv_level_sigma2 = invSigma2; fs.n_levels = nLevels;
+                    e = H.slot();
+                    if (orbfe_frame_create(&e->h, mDevice, &fs) < 0) {
+                        e->h = nullptr;
+                        throw std::runtime_error("orbfe_frame_create failed");
+                    }
+                    e->obj = &f; e->id = f.mnId; e->n = n; e->desc = D.data; e->device = mDevice;
+                    e->used = ++H.clock;
+                    H.creates++;
+                }
+                handle = e->h;
+            }
+        }
+        if (!handle) {
+            fa.fill(f, n, nLeft);
+            a.desc = dense_descriptors(D, n, tmp);
+            a.kx = fa.kx.data(); a.ky = fa.ky.data(); a.octave = fa.octave.data(); a.angle = fa.angle.data();
+        }
         a.taken = taken.data();
         a.Nleft = nLeft;
         a.left_to_right = l2r; a.right_to_left = r2l;
@@ -1063,7 +1149,8 @@ protected:
         a.inv_level_sigma2 = invSigma2; a.n_levels = nLevels; a.chi2_gate = chi2 ? 1 : 0;
         qMatch.assign((size_t)std::max(q.size(), 1), -1);
         featMatch.assign((size_t)std::max(n, 1), -1);
-        const int r = orbfe_search_projection(mDevice, &a, qMatch.data(), featMatch.data());
+        const int r = handle ? orbfe_search_projection_frame(handle, &a, qMatch.data(), featMatch.data())
+                             : orbfe_search_projection(mDevice, &a, qMatch.data(), featMatch.data());
         if (r < 0) throw std::runtime_error("orbfe_search_projection failed");
         return r;
     }

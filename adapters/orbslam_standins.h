@@ -105,6 +105,13 @@ public:
 
 class Frame {
 public:
+    // include/Frame.h: `static long unsigned int nNextId; long unsigned int mnId;`, Frame.cc: mnId = nNextId++
+    long unsigned int mnId = next_id()++;
+    static long unsigned int& next_id()
+    {
+        static long unsigned int n = 0;
+        return n;
+    }
     int N = 0, Nleft = -1;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
     std::vector<float> mvuRight;

@@ -405,9 +405,31 @@ static void test_proj_last(const std::string& P)
         memcpy(p->mDescriptor, in(P + "ldesc").u8() + 32 * (size_t)i, 32);
     }
     ORBmatcher matcher(0.9f, in(P + "ori").i32()[0] != 0);
+    const std::vector<MapPoint*> before = C.mvpMapPoints;
     const int nm = matcher.SearchByProjection(C, L, in(P + "th").f32()[0], in(P + "mono").i32()[0] != 0);
     dump_frame_points(C, P + "points");
     put_i(P + "n", std::vector<int32_t>(1, nm));
+    // Tracking's pattern on ONE frame (src/Tracking.cc:2817-2827): the last frame at th, again at 2 th, and a third search --
+    // with frame handles the frame side was uploaded once (by the search above) and the three searches below only hit the
+    // handle; without handles every search uploads it again.  Same results either way.
+    orbfe_adapter::FrameHandles& H = orbfe_adapter::frame_handles();
+    const float th = in(P + "th").f32()[0];
+    const bool mono = in(P + "mono").i32()[0] != 0;
+    auto three = [&](std::vector<int32_t>& out) {
+        for (float t : {th, 2 * th, th}) {
+            C.mvpMapPoints = before;
+            out.push_back(matcher.SearchByProjection(C, L, t, mono));
+            for (int i = 0; i < C.N; i++) out.push_back(C.mvpMapPoints[i] ? (int32_t)C.mvpMapPoints[i]->mnId : -1);
+        }
+    };
+    const long c0 = H.creates, h0 = H.hits;
+    std::vector<int32_t> withHandles, without;
+    three(withHandles);
+    const long dc = H.creates - c0, dh = H.hits - h0;
+    orbfe_adapter::use_frame_handles() = false;
+    three(without);
+    orbfe_adapter::use_frame_handles() = true;
+    put_i(P + "handles", std::vector<int32_t>{(int32_t)dc, (int32_t)dh, withHandles == without ? 1 : 0});
 }
 
 static void test_fuse(const std::string& P)

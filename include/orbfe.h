@@ -20,8 +20,9 @@
  *
  * Conventions: return >= 0 on success, negative on error; nothing throws or aborts.
  *   -1                 empty image (same value ORBextractor::operator() returns, :1072-1073)
- *   ORBFE_ERR_ARGS     bad argument / unsupported size / capacity too small
+ *   ORBFE_ERR_ARGS     bad argument / capacity too small
  *   ORBFE_ERR_NODEV    no usable HIP device (the library never falls back to the CPU)
+ *   ORBFE_ERR_IMAGE_SMALL / _LARGE / ORBFE_ERR_NFEATURES   the documented limits of the extractor (below)
  *   <= -1000           -(1000 + hipError_t)
  * Thread-safety: distinct contexts may be used concurrently; one context = one caller at a time
  * (same rule as an ORBextractor instance, which owns mvImagePyramid).
@@ -39,6 +40,18 @@ extern "C" {
 #define ORBFE_ERR_ARGS (-2)
 #define ORBFE_ERR_NODEV (-3)
 #define ORBFE_ERR_STATE (-4)
+/* The extractor's documented limits, each with its own code (orbfe_max_keypoints and every extraction call report them;
+ * orbfe_error_string has the sentence):
+ *   ORBFE_ERR_IMAGE_SMALL  some pyramid level is narrower or lower than 32 + 35 px: the reference's cell grid has no cell
+ *                          there and divides by zero (src/ORBextractor.cc:779-782)
+ *   ORBFE_ERR_IMAGE_LARGE  an image side above 4096 px (the packed candidate format holds 12-bit coordinates)
+ *   ORBFE_ERR_NFEATURES    nfeatures so large that one level's quadtree does not fit a workgroup's LDS (~1500 nodes per
+ *                          level, nfeatures <~ 6500 at 8 levels / 1.2) */
+#define ORBFE_ERR_IMAGE_SMALL (-5)
+#define ORBFE_ERR_IMAGE_LARGE (-6)
+#define ORBFE_ERR_NFEATURES (-7)
+/* One sentence for any code this library returns (static storage; never NULL). */
+const char* orbfe_error_string(int code);
 
 typedef struct orbfe_ctx orbfe_ctx; /* one per ORBextractor instance */
 
@@ -138,6 +151,14 @@ int orbfe_extract_batch_wait(orbfe_ctx*);
 void* orbfe_host_alloc(size_t bytes);
 void orbfe_host_free(void*);
 int orbfe_host_register(void* p, size_t bytes);
+/* For callers that cannot be changed (Frame::ExtractORB hands over whatever cv::Mat it was given) but whose image buffers
+ * are long-lived -- a camera driver's ring, a preallocated cv::Mat that every frame is copied or decoded into: with
+ * on != 0 the host-pointer calls page-lock a PAGEABLE image buffer themselves the second time they see the same address and
+ * size, and from then on it takes the DMA path like memory from orbfe_host_alloc (at most 16 registrations per context,
+ * least recently used out, all released by orbfe_set_auto_register(ctx, 0) / orbfe_destroy).  Off by default: a buffer
+ * that is freed while registered must be unregistered first, which only the owner can know -- switch it on when the
+ * buffers outlive the context, as they do in the drivers above. */
+int orbfe_set_auto_register(orbfe_ctx*, int on);
 int orbfe_host_unregister(void* p);
 
 /* Same, with every buffer already resident in device memory (no PCIe traffic).  Asynchronous on the

@@ -15,7 +15,7 @@ _LIB = None
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
 
-ERR_ARGS, ERR_NODEV, ERR_STATE = -2, -3, -4
+ERR_ARGS, ERR_NODEV, ERR_STATE, ERR_IMAGE_SMALL, ERR_IMAGE_LARGE, ERR_NFEATURES = -2, -3, -4, -5, -6, -7
 TRIG_LIBM, TRIG_CR, TRIG_LIBM_HOSTCHECK = 0, 1, 2
 STAGES = ("pyramid", "fast", "octree", "pack", "desc", "trigfix")
 
@@ -182,6 +182,8 @@ def lib():
         _share_hip_runtime_with_torch()
         L = C.CDLL(path)
         L.orbfe_version.restype = C.c_char_p
+        L.orbfe_error_string.restype = C.c_char_p
+        L.orbfe_error_string.argtypes = [C.c_int]
         L.orbfe_create.restype = C.c_int
         L.orbfe_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orbfe_destroy.argtypes = [C.c_void_p]
@@ -226,6 +228,7 @@ def lib():
         L.orbfe_host_free.restype = None
         L.orbfe_host_free.argtypes = [C.c_void_p]
         L.orbfe_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.orbfe_set_auto_register.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_host_unregister.argtypes = [C.c_void_p]
         L.orbfe_compute_stereo_matches_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                             C.c_void_p, C.c_void_p, C.c_int]
@@ -276,7 +279,7 @@ def lib():
     return _LIB
 
 
-EXPORTS = ["orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_get_stream", "orbfe_set_gaussian_taps",
+EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "orbfe_create", "orbfe_destroy", "orbfe_set_stream", "orbfe_get_stream", "orbfe_set_gaussian_taps",
            "orbfe_mc_layout", "orbfe_mc_shard", "orbfe_mc_ring_pairs", "orbfe_mc_job_offsets", "orbfe_mc_unique_id",
            "orbfe_mc_create", "orbfe_mc_destroy", "orbfe_mc_extract_exchange_submit", "orbfe_mc_extract_exchange_wait",
            "orbfe_mc_match_ring", "orbfe_mc_match_outputs", "orbfe_mc_match_ring_async", "orbfe_mc_exchange_host",

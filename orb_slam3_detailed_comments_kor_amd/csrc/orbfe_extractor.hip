@@ -201,6 +201,17 @@ struct orbfe_ctx : orbfe_geom_state {
     long slotSubmitted = 0, slotRetired = 0; // FIFO over the two slots
     hipStream_t sIn = nullptr, sOut = nullptr; // copy streams of the pipelined form
     std::unordered_map<const void*, bool> pinnedCache; // what hipPointerGetAttributes said about a caller pointer
+    // orbfe_set_auto_register: pageable caller buffers that came back (same address, same size) are page-locked by the
+    // library on their second sighting and from then on take the DMA path; at most 16 at a time, least recently used out
+    bool autoRegister = false;
+    struct AutoPin {
+        const void* p;
+        size_t n;
+        bool registered;
+        unsigned long used;
+    };
+    std::vector<AutoPin> autoPins;
+    unsigned long autoClock = 0;
     // where the last call left its outputs on the device (orbfe_compute_stereo_matches_resident, orbfe_frame_*)
     const float* lastKps = nullptr;
     const uint8_t* lastDesc = nullptr;
@@ -274,20 +285,20 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         const float inv = c->mvInvScaleFactor[l];
         L.w = cv_round_f((float)cols * inv);
         L.h = cv_round_f((float)rows * inv);
-        if (L.w > ORBFE_MAX_DIM || L.h > ORBFE_MAX_DIM) return ORBFE_ERR_ARGS;
+        if (L.w > ORBFE_MAX_DIM || L.h > ORBFE_MAX_DIM) return ORBFE_ERR_IMAGE_LARGE;
         L.pitch = (int)align_up((size_t)ORBFE_ROI_X0 + L.w + ORBFE_EDGE, 64);
         L.bufOff = (uint32_t)off;
         L.roiOff = (uint32_t)(off + (size_t)ORBFE_EDGE * L.pitch + ORBFE_ROI_X0);
         off = align_up(off + (size_t)(L.h + 2 * ORBFE_EDGE) * L.pitch, 256);
-        if (off > 0xFFFFFFFFull) return ORBFE_ERR_ARGS;
+        if (off > 0xFFFFFFFFull) return ORBFE_ERR_IMAGE_LARGE;
         L.maxBX = L.w - ORBFE_EDGE + 3;
         L.maxBY = L.h - ORBFE_EDGE + 3;
         const float width = (float)(L.maxBX - ORBFE_MINB), height = (float)(L.maxBY - ORBFE_MINB);
         const float W = 35;
-        if (!(width > 0) || !(height > 0)) return ORBFE_ERR_ARGS;
+        if (!(width > 0) || !(height > 0)) return ORBFE_ERR_IMAGE_SMALL;
         L.nCols = (int)(width / W);
         L.nRows = (int)(height / W);
-        if (L.nCols < 1 || L.nRows < 1) return ORBFE_ERR_ARGS; // the reference divides by zero here
+        if (L.nCols < 1 || L.nRows < 1) return ORBFE_ERR_IMAGE_SMALL; // the reference divides by zero here
         L.wCell = (int)std::ceil(width / L.nCols);
         L.hCell = (int)std::ceil(height / L.nRows);
         L.cellBase = (int)c->cg.size();
@@ -435,7 +446,7 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     }
     c->qtKeyOff = 64 + std::max(24 * maxLC, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
     c->qtLdsBytes = sizeof(int) * (size_t)c->qtKeyOff;
-    if (c->qtLdsBytes > 160 * 1024) return ORBFE_ERR_ARGS; // nfeatures too large for one workgroup's LDS
+    if (c->qtLdsBytes > 160 * 1024) return ORBFE_ERR_NFEATURES; // nfeatures too large for one workgroup's LDS
     // room for the key arrays (4 B key + 2 B node index each) while staying under 64 KB
     c->qtKeyCap = 0;
     if (c->qtLdsBytes + 6 * 1024 <= 64 * 1024) {
@@ -452,7 +463,8 @@ int max_kp_for(orbfe_ctx* c, int rows, int cols)
         const int w = cv_round_f((float)cols * c->mvInvScaleFactor[l]);
         const int h = cv_round_f((float)rows * c->mvInvScaleFactor[l]);
         const int bx = w - 32, by = h - 32;
-        if (bx < 35 || by < 35) return ORBFE_ERR_ARGS;
+        if (w > ORBFE_MAX_DIM || h > ORBFE_MAX_DIM) return ORBFE_ERR_IMAGE_LARGE;
+        if (bx < 35 || by < 35) return ORBFE_ERR_IMAGE_SMALL;
         const int nIni = (int)std::round(static_cast<float>(bx) / by);
         total += std::max(c->mnFeaturesPerLevel[l] + 3, 4 * std::max(nIni, 0)) + 1;
     }
@@ -1044,6 +1056,62 @@ bool is_pinned(orbfe_ctx* c, const void* p, size_t n)
     return pinned;
 }
 
+// orbfe_set_auto_register: a caller that hands over the same pageable buffer again (a camera driver's ring, a preallocated
+// cv::Mat) gets it page-locked on the second sighting.  Buffers seen once stay pageable (registering costs more than one
+// staged copy), at most 16 registrations live per context.
+bool auto_pin(orbfe_ctx* c, const void* p, size_t n)
+{
+    if (!c->autoRegister || !p || !n) return false;
+    c->autoClock++;
+    auto unpin = [&](orbfe_ctx::AutoPin& o) { // (nothing of this context may still be reading it)
+        (void)hipStreamSynchronize(c->stream);
+        if (c->sIn) (void)hipStreamSynchronize(c->sIn);
+        if (pin_remove(o.p)) (void)hipHostUnregister(const_cast<void*>(o.p));
+        c->pinnedCache.erase(o.p);
+        o.registered = false;
+    };
+    long idx = -1;
+    for (size_t i = 0; i < c->autoPins.size(); i++)
+        if (c->autoPins[i].p == p && c->autoPins[i].n == n) idx = (long)i;
+    if (idx < 0) { // first sighting: remember it, evicting the least recently used entry of a full table
+        if (c->autoPins.size() >= 16) {
+            size_t lru = 0;
+            for (size_t i = 1; i < c->autoPins.size(); i++)
+                if (c->autoPins[i].used < c->autoPins[lru].used) lru = i;
+            if (c->autoPins[lru].registered) unpin(c->autoPins[lru]);
+            c->autoPins.erase(c->autoPins.begin() + (long)lru);
+        }
+        c->autoPins.push_back(orbfe_ctx::AutoPin{p, n, false, c->autoClock});
+        return false;
+    }
+    c->autoPins[(size_t)idx].used = c->autoClock;
+    if (c->autoPins[(size_t)idx].registered) return true;
+    // second sighting.  Ranges of ours that overlap this one (single images of a buffer that now arrives whole, or the
+    // reverse) are given up first: a range must not be registered twice.
+    const uint8_t* lo = (const uint8_t*)p;
+    for (long i = (long)c->autoPins.size() - 1; i >= 0; i--) {
+        orbfe_ctx::AutoPin& o = c->autoPins[(size_t)i];
+        if (i == idx || !((const uint8_t*)o.p < lo + n && lo < (const uint8_t*)o.p + o.n)) continue;
+        if (o.registered) unpin(o);
+        c->autoPins.erase(c->autoPins.begin() + i);
+        if (i < idx) idx--;
+    }
+    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError(); // (registered by its owner already, or not registrable: the staging path takes it)
+        return false;
+    }
+    pin_add(p, n, false);
+    c->pinnedCache.erase(p);
+    c->autoPins[(size_t)idx].registered = true;
+    return true;
+}
+void auto_pin_release(orbfe_ctx* c)
+{
+    for (orbfe_ctx::AutoPin& a : c->autoPins)
+        if (a.registered && pin_remove(a.p)) (void)hipHostUnregister(const_cast<void*>(a.p));
+    c->autoPins.clear();
+}
+
 // A few persistent host threads for the staging copies of pageable caller memory (memcpy from one thread moves
 // ~10 GB/s, a batch of 64 frames is 23 MB in and 4 MB out).  run(n, f) executes f(0..n-1) on the workers and the
 // caller and returns when all are done.  One run at a time; a second concurrent caller does its work inline.
@@ -1175,6 +1243,17 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     for (int i = 0; i < 2 * nimg; i++) sl.h_lap.p[i] = lap ? lap[i] : 0;
 
     // ---- images
+    if (c->autoRegister) { // a batch whose images sit evenly spaced in one buffer is one range, else one range per image
+        bool oneBuffer = nimg > 1;
+        for (int i = 1; i < nimg && oneBuffer; i++) oneBuffer = imgs[i] - imgs[i - 1] == imgs[1] - imgs[0] && imgs[1] > imgs[0];
+        if (oneBuffer && (size_t)(imgs[1] - imgs[0]) <= 2 * align_up(imgBytes, 256)) {
+            if (!pin_known(imgs[0], (size_t)(nimg - 1) * (size_t)(imgs[1] - imgs[0]) + imgBytes))
+                (void)auto_pin(c, imgs[0], (size_t)(nimg - 1) * (size_t)(imgs[1] - imgs[0]) + imgBytes);
+        } else {
+            for (int i = 0; i < nimg; i++)
+                if (!pin_known(imgs[i], imgBytes)) (void)auto_pin(c, imgs[i], imgBytes);
+        }
+    }
     bool allPinned = true;
     for (int i = 0; i < nimg && allPinned; i++) allPinned = is_pinned(c, imgs[i], imgBytes);
     size_t devPitch, devStride;
@@ -1291,7 +1370,7 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
 {
     if (c && c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: nothing was queued
     const int r = host_submit_impl(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, pipelined);
-    if (r < 0 && c && r != ORBFE_ERR_ARGS && r != -1) {
+    if (r <= -1000 && c) { // (a HIP error: something may have been queued; validation errors come before the first command)
         if (hipSetDevice(c->device) == hipSuccess) {
             if (c->sIn) (void)hipStreamSynchronize(c->sIn);
             (void)hipStreamSynchronize(c->stream);
@@ -1346,6 +1425,25 @@ int host_wait(orbfe_ctx* c)
 extern "C" {
 
 const char* orbfe_version(void) { return "orbfe 0.1 (gfx950)"; }
+
+const char* orbfe_error_string(int code)
+{
+    switch (code) {
+    case -1: return "empty image";
+    case ORBFE_ERR_ARGS: return "bad argument (null pointer, negative size, or an output capacity below orbfe_max_keypoints)";
+    case ORBFE_ERR_NODEV: return "no usable HIP device (the library has no CPU path)";
+    case ORBFE_ERR_STATE: return "call out of order (nothing in flight / too much in flight / no results yet), or a device-side list overflowed";
+    case ORBFE_ERR_IMAGE_SMALL:
+        return "image too small: some pyramid level is narrower or lower than 32 + 35 px, where the reference's cell grid has no cell";
+    case ORBFE_ERR_IMAGE_LARGE: return "image too large: a side above 4096 px (candidates are packed with 12-bit coordinates)";
+    case ORBFE_ERR_NFEATURES:
+        return "nfeatures too large: one level's quadtree does not fit a workgroup's LDS (about 6500 features at 8 levels, scale 1.2)";
+    default: break;
+    }
+    if (code >= 0) return "success";
+    if (code <= -1000) return hipGetErrorString((hipError_t)(-code - 1000));
+    return "unknown error code";
+}
 
 int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
                  int device)
@@ -1411,6 +1509,7 @@ void orbfe_destroy(orbfe_ctx* c)
         if (sl.evK) (void)hipEventDestroy(sl.evK);
         if (sl.evDone) (void)hipEventDestroy(sl.evDone);
     }
+    auto_pin_release(c);
     if (c->evStereo) (void)hipEventDestroy(c->evStereo);
     if (c->evOutputs) {
         orbfe_producer_retire(c->evOutputs);
@@ -1577,6 +1676,19 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
 }
 
 // ---- pinned host memory ---------------------------------------------------------------------------
+int orbfe_set_auto_register(orbfe_ctx* c, int on)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!on && c->autoRegister) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->sIn) HIP_TRY(hipStreamSynchronize(c->sIn));
+        auto_pin_release(c);
+    }
+    c->autoRegister = on != 0;
+    return 0;
+}
+
 int orbfe_host_register(void* p, size_t bytes)
 {
     if (!p || !bytes) return ORBFE_ERR_ARGS;

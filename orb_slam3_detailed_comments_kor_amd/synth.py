@@ -152,3 +152,38 @@ def make_vocabulary(seed, k=10, L=4, ragged=True):
             weight[i] = float(rng.uniform(0.5, 9.0)) if rng.uniform() > 0.02 else 0.0  # a few stop words
     return dict(desc=np.ascontiguousarray(np.stack(desc)), child_off=child_off, child_ids=child_ids, word=word,
                 weight=weight, L=L)
+
+
+def make_vocabulary_full(seed, k=10, L=6, flip_p=0.18):
+    """A COMPLETE k-ary tree of depth L in the layout of make_vocabulary -- the size of the vocabulary ORB-SLAM3 ships
+    (Vocabulary/ORBvoc.txt: k = 10, L = 6, 1 111 111 nodes incl. the root, 10^6 words, ~35 MB of descriptors; the file
+    itself is a blob this repo does not have).  Vectorised: level by level, the children of a node are copies of it with
+    each bit flipped with probability flip_p (the first level is random).  Breadth-first ids, node 0 = root."""
+    rng = np.random.default_rng(int(seed))
+    levels = [np.zeros((1, 32), np.uint8)]
+    for lvl in range(1, L + 1):
+        parent = levels[-1]
+        n = parent.shape[0] * k
+        out = np.empty((n, 32), np.uint8)
+        for i0 in range(0, n, 1 << 17):
+            i1 = min(n, i0 + (1 << 17))
+            if lvl == 1:
+                out[i0:i1] = rng.integers(0, 256, size=(i1 - i0, 32), dtype=np.uint8)
+            else:
+                flips = np.packbits(rng.random((i1 - i0, 256)) < flip_p, axis=1)
+                out[i0:i1] = parent[np.arange(i0, i1) // k] ^ flips
+        levels.append(out)
+    desc = np.ascontiguousarray(np.concatenate(levels))
+    nn = desc.shape[0]
+    first = np.cumsum([0] + [lv.shape[0] for lv in levels])       # first node id of every level
+    inner = int(first[L])                                          # nodes with children
+    child_off = np.zeros(nn + 1, np.int32)
+    child_off[1:inner + 1] = k * np.arange(1, inner + 1)
+    child_off[inner + 1:] = k * inner
+    child_ids = np.arange(1, nn, dtype=np.int32)                   # breadth-first: node i's children are 1 + k i .. k + k i
+    word = -np.ones(nn, np.int32)
+    word[inner:] = np.arange(nn - inner, dtype=np.int32)
+    weight = np.zeros(nn, np.float64)
+    weight[inner:] = rng.uniform(0.5, 9.0, nn - inner)
+    weight[inner:][rng.random(nn - inner) < 0.02] = 0.0            # a few stop words
+    return dict(desc=desc, child_off=child_off, child_ids=child_ids, word=word, weight=weight, L=L)

@@ -453,3 +453,26 @@ def test_many_candidates_use_global_key_arrays(pkg, oracle):
     assert len(ref.candidates(0)) > 4096
     assert mono == rmono
     _same(kps, rkps, desc, rdesc)
+
+
+def test_documented_limits_have_their_own_error_codes(pkg):
+    """Image side <= 4096, every level >= 32 + 35 px, nfeatures bounded by K-QT's LDS: each limit reports its own code
+    (include/orbfe.h) and orbfe_error_string says which; the adapter used to call all of them "image too small"."""
+    from orb_slam3_detailed_comments_kor_amd import binding as b
+    L = pkg.lib()
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert L.orbfe_max_keypoints(ex.h, 480, 752) > 1000
+    assert L.orbfe_max_keypoints(ex.h, 200, 752) == b.ERR_IMAGE_SMALL     # level 7 is 56 px high
+    assert L.orbfe_max_keypoints(ex.h, 480, 5000) == b.ERR_IMAGE_LARGE
+    for code, word in ((b.ERR_IMAGE_SMALL, b"too small"), (b.ERR_IMAGE_LARGE, b"4096"), (b.ERR_NFEATURES, b"nfeatures"),
+                       (b.ERR_ARGS, b"argument"), (b.ERR_NODEV, b"HIP device"), (-1, b"empty")):
+        assert word in L.orbfe_error_string(code)
+    with pytest.raises(pkg.OrbfeError) as e:
+        ex(np.zeros((100, 100), np.uint8))
+    assert e.value.code == b.ERR_IMAGE_SMALL
+    ex.close()
+    big = pkg.ORBextractor(30000, 1.2, 8, 20, 7)
+    with pytest.raises(pkg.OrbfeError) as e:
+        big(pkg.synth.make_frame(480, 752, 1))
+    assert e.value.code == b.ERR_NFEATURES
+    big.close()

@@ -207,3 +207,25 @@ def test_sync_reports_no_error_and_device_path_still_matches(pkg, oracle):
     assert n == len(r[1])
     assert np.array_equal(d_d[0, :n].cpu().numpy(), r[2])
     ex.close()
+
+
+def test_auto_register_pins_a_returning_pageable_buffer(pkg, oracle):
+    """orbfe_set_auto_register: a pageable caller buffer that comes back is page-locked on its second sighting and takes
+    the DMA path; the results do not change, and switching it off (or destroying the context) releases the registration."""
+    ex = pkg.ORBextractor(600, 1.2, 8, 20, 7)
+    L = pkg.lib()
+    assert L.orbfe_set_auto_register(ex.h, 1) == 0
+    imgs = [np.ascontiguousarray(pkg.synth.make_frame(240, 376, 500 + i)) for i in range(3)]   # three long-lived buffers
+    ref = [oracle.Extractor(600, 1.2, 8, 20, 7).extract(im, (0, 0)) for im in imgs]
+    for rep in range(4):               # sighting 1: staged, sighting 2: registered, 3 and 4: DMA in place
+        for im, (rm, rk, rd) in zip(imgs, ref):
+            mono, kps, desc = ex(im, (0, 0))
+            assert mono == rm and np.array_equal(desc, rd) and np.array_equal(kps["x"], rk["x"]), rep
+    # while registered by the library the range is in its registry: the owner-side call finds (and would release) it
+    assert L.orbfe_set_auto_register(ex.h, 0) == 0
+    assert L.orbfe_host_unregister(imgs[0].ctypes.data) == pkg.binding.ERR_ARGS   # switched off: released, unknown again
+    assert L.orbfe_host_register(imgs[0].ctypes.data, imgs[0].nbytes) == 0         # the owner can pin it himself now
+    assert L.orbfe_host_unregister(imgs[0].ctypes.data) == 0
+    mono, kps, desc = ex(imgs[1], (0, 0))
+    assert np.array_equal(desc, ref[1][2])
+    ex.close()

@@ -178,6 +178,30 @@ def test_vocabulary_transform(pkg, oracle, k, L, ragged, levelsup):
     V.close()
 
 
+def test_vocabulary_transform_production_size(pkg, oracle):
+    """The size ORB-SLAM3 runs on (Vocabulary/ORBvoc.txt: k = 10, L = 6, 1 111 111 nodes, 10^6 words; the blob itself is
+    absent, the tree is synthetic): 1500 features, levelsup = 4 as KeyFrame::ComputeBoW calls it (src/KeyFrame.cc:110-112).
+    Reference: Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259."""
+    vocab = pkg.synth.make_vocabulary_full(2024, 10, 6)
+    assert vocab["desc"].shape == (1111111, 32) and int(vocab["word"].max()) == 999999
+    rng = np.random.default_rng(9)
+    leaves = rng.integers(111111, 1111111, size=1500)
+    bits = np.unpackbits(vocab["desc"][leaves], axis=1)
+    bits ^= (rng.random(bits.shape) < 0.05).astype(np.uint8)       # features near (not at) words: real descents
+    d = np.packbits(bits, axis=1)
+    d[1400:] = rng.integers(0, 256, size=(100, 32), dtype=np.uint8)  # and some that belong nowhere
+    V = pkg.Vocabulary(vocab)
+    for levelsup in (4, 0, 6):
+        w, nid, wt = V.transform(d, levelsup)
+        rw, rnid, rwt = oracle.vocab_transform(vocab, d, levelsup)
+        assert np.array_equal(w, rw) and np.array_equal(nid, rnid) and np.array_equal(wt, rwt), levelsup
+    w, nid, wt = V.transform(d, 4)
+    assert len(np.unique(nid)) <= 100 and (nid >= 11).all() and (nid < 111).all()   # node level L - 4 = 2: <= 100 nodes
+    bow, fv = pkg.bow_from_transform(w, nid, wt)
+    assert abs(sum(bow.values()) - 1.0) < 1e-9 and sum(len(v) for v in fv[2:3]) >= 0
+    V.close()
+
+
 def test_distinctive_descriptors(pkg, oracle):
     """MapPoint::ComputeDistinctiveDescriptors for a batch of map points (1..130 observations each, ties)."""
     rng = np.random.default_rng(8)

@@ -359,6 +359,7 @@ def _proj_last(f, tag, oracle, seed, n, nl, th, stereo, tlz, mono, ori):
         nm, qm, fm = oracle.search_projection(pr)
         assert res[tag + "n"][0] == nm and nm > 30, (tag, nm)
         assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, qm, keep)), tag
+        assert list(res[tag + "handles"]) == [0, 3, 1], tag   # Tracking's three searches of one frame: one upload
     return check
 
 
@@ -498,6 +499,7 @@ def _proj_last_rig(f, tag, oracle, seed, n, nl, th, tlz, ori):
         assert nm_all > nm, (tag, nm, nm_all)
         assert res[tag + "n"][0] == nm and nm > 60 and (fm[nleft:] >= 0).sum() > 20, (tag, nm)
         assert np.array_equal(res[tag + "points"], _expect_points(fstate, fm, qm, ids)), tag
+        assert list(res[tag + "handles"]) == [0, 3, 1], tag   # three more searches of the frame: no upload, three handle hits, same results
     return check
 
 

@@ -44,8 +44,11 @@ def report(name, units, unit_name, gpu_call, cpu_call, reps=20, algo_bytes=None)
            "cpu_oracle_ms_1core": 1e3 * cpu, "kernel_units_per_s": units / (kernel_ms * 1e-3),
            "call_units_per_s": units / e2e, "cpu_units_per_s": units / cpu}
     if algo_bytes:
+        # SURVEY.md 8(d)'s matcher byte model evaluated: algorithmic bytes / kernel time against the 8 TB/s HBM peak
+        out["algorithmic_bytes"] = algo_bytes
         out["kernel_GBps_algorithmic"] = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    print(json.dumps(out))
+        out["frac_of_hbm_peak"] = out["kernel_GBps_algorithmic"] / 8000.0
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -79,9 +82,11 @@ def main():
             if int(b) in common:
                 i = common[int(b)]
                 npb += int(f1[1][i + 1] - f1[1][i]) * int(f2[1][j + 1] - f2[1][j])
+    # byte model (8d): per shared node the descriptors of both sides + angles, + the match array out
+    bow_bytes = sum((len(p["desc1"]) + len(p["desc2"])) * (32 + 4) + len(p["desc2"]) * 4 for p in probs)
     report("SearchByBoW batch of 64 (KF,F) pairs, N=1200", npb, "candidate pairs", lambda: pkg.search_bow_batch(probs),
            lambda: [O.search_bow_kf_f(p["desc1"], p["mask1"], p["ang1"], p["fv1"], p["desc2"], p["ang2"], p["fv2"], -1,
-                                      0.75, True) for p in probs], reps=10)
+                                      0.75, True) for p in probs], reps=10, algo_bytes=bow_bytes)
     I = MI.tri_inputs(1200, 1200, 9)
     report("SearchForTriangulation_ N=1200", npairs, "candidate pairs",
            lambda: pkg.search_triangulation(I["d1"], I["has1"], I["kp1"], I["a1"], I["oct1"], I["u1"], I["fv1"],
@@ -107,8 +112,23 @@ def main():
            lambda: fr2.search(pr2), lambda: O.search_projection(pr2))
     fr2.close()
     prs = [MI.projection_problem(100 + k, n=2000, nq=1500, mode=0, stereo=True, th=1.0, crowd=False) for k in range(64)]
+    # byte model: frame side (descriptor 32 + x, y, octave, uRight 16 per feature) + query side (descriptor 32 + x, y, r,
+    # levels, xr 24 per map point) in, one match per query and per feature out
+    proj_bytes = 64 * (2000 * (32 + 16) + 1500 * (32 + 24) + 1500 * 4 + 2000 * 4)
     report("SearchByProjection batch of 64 (F, local map) N=2000, 1500 points", 64 * 1500, "map points",
-           lambda: pkg.search_projection_batch(prs), lambda: [O.search_projection(p) for p in prs], reps=10)
+           lambda: pkg.search_projection_batch(prs), lambda: [O.search_projection(p) for p in prs], reps=10,
+           algo_bytes=proj_bytes)
+    # DBoW2 transform on a vocabulary of the size ORB-SLAM3 ships (k = 10, L = 6: 1 111 111 nodes, 35.5 MB), 1500 features,
+    # levelsup = 4 (KeyFrame::ComputeBoW); byte model: L x k node descriptors per feature + the feature's own
+    vocab = pkg.synth.make_vocabulary_full(2024, 10, 6)
+    leaves = rng.integers(111111, 1111111, size=1500)
+    bits = np.unpackbits(vocab["desc"][leaves], axis=1)
+    bits ^= (rng.random(bits.shape) < 0.05).astype(np.uint8)
+    dv = np.packbits(bits, axis=1)
+    V = pkg.Vocabulary(vocab)
+    report("DBoW2 transform, k=10 L=6 (1.1 M nodes), 1500 features, levelsup 4", 1500, "features", lambda: V.transform(dv, 4),
+           lambda: O.vocab_transform(vocab, dv, 4), algo_bytes=1500 * (6 * 10 * 32 + 32 + 16))
+    V.close()
     sizes = rng.integers(2, 25, size=4000)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     pool = rng.integers(0, 256, size=(int(offs[-1]), 32), dtype=np.uint8)
@@ -143,6 +163,35 @@ def main():
     kh = timeit(lambda: pkg.bfknn2(dL, dR), 50)
     print(json.dumps({"op": "bfknn2 %d x %d: device-resident call + sync vs host-pointer call" % (len(kL), len(kR)),
                       "device_call_ms": 1e3 * kd, "host_call_ms": 1e3 * kh}))
+    # cross-camera knn-2, 64 jobs of ~1000 x 1000 in one launch (K-KNN2F), device resident
+    cap, frames = 1008, 64
+    counts = rng.integers(900, cap, size=frames).astype(np.int32)
+    desc = rng.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
+    dd, dc = torch.from_numpy(desc).cuda(), torch.from_numpy(counts).cuda()
+    rec = np.zeros(frames, pkg.binding.KNN2_JOB_DTYPE)
+    for k in range(frames):
+        t = (k + 1) % frames
+        rec[k] = (dd.data_ptr() + k * cap * 32, dc.data_ptr() + 4 * k, dd.data_ptr() + t * cap * 32, dc.data_ptr() + 4 * t)
+    dj = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    di = torch.zeros((frames, cap, 2), dtype=torch.int32, device="cuda")
+    ds = torch.zeros((frames, cap, 2), dtype=torch.int32, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = torch.cuda.Stream()  # (a NULL stream argument would mean "the calling thread's matcher stream")
+    torch.cuda.synchronize()
+    st = ts.cuda_stream
+    pkg.binding.bfknn2_frames_device(dj.data_ptr(), frames, cap, di.data_ptr(), ds.data_ptr(), stream=st)
+    e0.record(ts)
+    for _ in range(20):
+        pkg.binding.bfknn2_frames_device(dj.data_ptr(), frames, cap, di.data_ptr(), ds.data_ptr(), stream=st)
+    e1.record(ts)
+    torch.cuda.synchronize()
+    kms = e0.elapsed_time(e1) / 20
+    nd = float((counts.astype(np.float64) * counts[(np.arange(frames) + 1) % frames]).sum())
+    kb = float(2 * counts.sum() * 32 + counts.sum() * 16)
+    print(json.dumps({"op": "bfknn2_frames x64 (K-KNN2F, cross-camera ring)", "units": nd, "unit": "distances", "kernel_ms": kms,
+                      "kernel_units_per_s": nd / (kms * 1e-3), "algorithmic_bytes": kb,
+                      "kernel_GBps_algorithmic": kb / (kms * 1e-3) / 1e9, "frac_of_hbm_peak": kb / (kms * 1e-3) / 1e9 / 8000.0,
+                      "note": "72 KB of operands per job: the bound of this kernel is the popcount rate, not HBM"}), flush=True)
     print(json.dumps({"op": "projection sweeps", "mode0": None, "last": pkg.search_projection_last_sweeps()}))
 
 

@@ -108,19 +108,21 @@ int main(int argc, char** argv)
     const double firstCallMs = 1e3 * (now_s() - tFirst0), createMs = 1e3 * (tFirst0 - tCreate0);
 
     // ---- single frame per call
-    auto single = [&](bool pinned, Stat* st, double* kpPerS) -> int {
+    auto single = [&](bool pinned, Stat* st, double* kpPerS, int ring = 0) -> int {
         std::vector<double> lat;
         long kp = 0;
+        const int R = ring > 0 ? std::min(ring, B) : B; // the caller's buffers: all B frames, or a ring of a few (a camera driver)
         for (int w = 0; w < 20; w++) {
             int nn = 0;
-            const int i = w % B;
+            const int i = w % R;
             CHECK(orbfe_extract(ex, pinned ? pPin0[i] : pPg[i], rows, cols, cols, 0, 1000,
                                 (orbfe_kp*)(pinned ? pinK[0] : pgK.data()), pinned ? pinD[0] : pgD.data(), cap, &nn) + 1);
         }
         const double t0 = now_s();
         for (int rep = 0; rep < 8; rep++)
-            for (int i = 0; i < B; i++) {
+            for (int j = 0; j < B; j++) {
                 int nn = 0;
+                const int i = j % R;
                 const double a = now_s();
                 CHECK(orbfe_extract(ex, pinned ? pPin0[i] : pPg[i], rows, cols, cols, 0, 1000,
                                     (orbfe_kp*)(pinned ? pinK[0] : pgK.data()), pinned ? pinD[0] : pgD.data(), cap, &nn) + 1);
@@ -159,6 +161,15 @@ int main(int argc, char** argv)
     double msPg, msPin, bkPg, bkPin;
     if (batch(false, &msPg, &bkPg)) return 2;
     if (batch(true, &msPin, &bkPin)) return 2;
+
+    // ---- the unmodified caller with long-lived pageable buffers (orbfe_set_auto_register): the library page-locks a buffer
+    // the second time it sees it; single frames from a ring of 8 buffers, and the whole batch from its one buffer
+    Stat sAuto{0, 0, 0};
+    double kpsAuto = 0, msAuto = 0, bkAuto = 0;
+    CHECK(orbfe_set_auto_register(ex, 1));
+    if (single(false, &sAuto, &kpsAuto, 8)) return 2;
+    if (batch(false, &msAuto, &bkAuto)) return 2;
+    CHECK(orbfe_set_auto_register(ex, 0));
 
     // ---- one batch at a time through the submit / wait entry points (copies on their own streams)
     double msSW = 0;
@@ -306,6 +317,9 @@ int main(int argc, char** argv)
            "\"single_pinned\": {\"ms_mean\": %.4f, \"ms_p50\": %.4f, \"ms_p99\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"batch_pageable\": {\"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"batch_pinned\": {\"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
+           "\"single_pageable_autoreg\": {\"ms_mean\": %.4f, \"ms_p50\": %.4f, \"ms_p99\": %.4f, \"keypoints_per_s\": %.0f, "
+           "\"note\": \"pageable ring of 8 caller buffers, orbfe_set_auto_register(ctx, 1)\"}, "
+           "\"batch_pageable_autoreg\": {\"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"batch_submit_wait\": {\"in_flight\": 1, \"ms_per_batch\": %.4f}, "
            "\"batch_pipelined\": {\"in_flight\": 2, \"ms_per_batch\": %.4f, \"keypoints_per_s\": %.0f}, "
            "\"pcie_floor\": {\"h2d_ms\": %.4f, \"d2h_ms\": %.4f, \"h2d_GBps\": %.1f, \"d2h_GBps\": %.1f, "
@@ -317,7 +331,8 @@ int main(int argc, char** argv)
            "then orbfe_compute_stereo_matches_resident between image 0 and image 1\", \"ms_per_pair_mean\": %.4f, "
            "\"ms_per_pair_p50\": %.4f, \"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f, \"matches_per_pair\": %.1f}}\n",
            cols, rows, nF, B, kpBatch, createMs, firstCallMs, 1e3 * sPg.mean, 1e3 * sPg.p50, 1e3 * sPg.p99, kpsPg,
-           1e3 * sPin.mean, 1e3 * sPin.p50, 1e3 * sPin.p99, kpsPin, msPg, bkPg, msPin, bkPin, msSW, msPipe, bkPipe, floorInMs,
+           1e3 * sPin.mean, 1e3 * sPin.p50, 1e3 * sPin.p99, kpsPin, msPg, bkPg, msPin, bkPin, 1e3 * sAuto.mean, 1e3 * sAuto.p50,
+           1e3 * sAuto.p99, kpsAuto, msAuto, bkAuto, msSW, msPipe, bkPipe, floorInMs,
            floorOutMs, inMB / floorInMs, (kB + dB) * B / 1e6 / floorOutMs, inMB, outMB, nPairs, 1e3 * sStereo.mean,
            1e3 * sStereo.p50, 1e3 * sStereo.p99, 1e3 * sStereoExtract.p50, stereoKp / (sStereo.mean * nPairs),
            stereoMatches / nPairs, 1e3 * sStereo1.mean, 1e3 * sStereo1.p50, 1e3 * sStereo1.p99, 1e3 * sStereoExtract1.p50,
