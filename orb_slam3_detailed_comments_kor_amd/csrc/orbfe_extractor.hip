@@ -17,6 +17,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -203,6 +204,8 @@ struct orbfe_ctx : orbfe_geom_state {
     std::unordered_map<const void*, bool> pinnedCache; // what hipPointerGetAttributes said about a caller pointer
     // orbfe_set_auto_register: pageable caller buffers that came back (same address, same size) are page-locked by the
     // library on their second sighting and from then on take the DMA path; at most 16 at a time, least recently used out
+    bool zeroCopy = true; // ORBFE_ZEROCOPY=0: the latency path downloads its results with a copy command (A/B)
+    int mirrorMaxImgs = 2; // ORBFE_MIRROR_MAX: blocking calls of up to this many images write their results to pinned memory from the kernels
     bool autoRegister = false;
     struct AutoPin {
         const void* p;
@@ -816,7 +819,10 @@ inline void rec(orbfe_ctx* c, int i)
 // The whole pipeline on the context's stream.  All pointers are device pointers.
 int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch, size_t imgStride,
                const int32_t* d_lap, float* d_kps, uint8_t* d_desc, int capPerImg, int32_t* d_n, int32_t* d_mono,
-               int32_t* d_errOut = nullptr /* K-PACK copies the batch's error word here (host-pointer path) */)
+               int32_t* d_errOut = nullptr /* K-PACK copies the batch's error word here (host-pointer path) */,
+               uint8_t* mirror = nullptr /* pinned host slab [meta | keypoints | descriptors] the kernels write the results
+                                            into as well (device-side address; latency path of a frame or two) */,
+               size_t mirrorMetaBytes = 0)
 {
     int r;
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
@@ -915,22 +921,25 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                            c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
                            c->kb8On ? c->d_kb8.p : nullptr,
                            c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
-                           k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr);
+                           k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr,
+                           mirror ? reinterpret_cast<int32_t*>(mirror) : nullptr, nimg);
         if (nsub == 1) rec(c, 4);
         // K-DESC
         {
             int tapSum = 0;
             for (int i = 0; i < 7; i++) tapSum += c->taps[i];
+            float* const mKps = mirror ? reinterpret_cast<float*>(mirror + mirrorMetaBytes) : nullptr;
+            uint8_t* const mDesc = mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr;
             if (tapSum > 256)
         hipLaunchKernelGGL((k_orient_blur_desc<0, true>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0);
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0, mKps, mDesc);
             else
         hipLaunchKernelGGL((k_orient_blur_desc<0, false>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
                            c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
                            c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0);
+                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0, mKps, mDesc);
         }
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
@@ -987,7 +996,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr, c->atanFma, nullptr, 0);
+                               c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr, c->atanFma, nullptr, 0, nullptr,
+                               mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr);
         c->lastFixups = nFix;
     }
     rec(c, 6);
@@ -1257,6 +1267,13 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     bool allPinned = true;
     for (int i = 0; i < nimg && allPinned; i++) allPinned = is_pinned(c, imgs[i], imgBytes);
     size_t devPitch, devStride;
+    // Latency path (a frame or a stereo pair per blocking call -- how ORB-SLAM3 itself calls the extractor): the RESULTS need
+    // no copy command.  K-PACK / K-DESC write them into the slot's pinned slab as well as into HBM (posted writes over
+    // PCIe, 60 KB per frame), which takes the download command and its ~10 us of latency off the end of the call: 0.089 ->
+    // 0.080 ms per pinned frame, 0.177 -> 0.157 ms per stereo pair in one call.  (The same idea for the INPUT -- K-PYR
+    // reading the image over PCIe where it lies in page-locked memory -- was measured and dropped: 0.089 -> 0.106 ms, reads
+    // across the link stall the kernel far longer than the upload command costs.)
+    const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs;
     if (allPinned) {
         // DMA straight from the caller's memory.  Rows are copied with their padding ((rows-1)*stride + cols bytes,
         // one linear command per image, or ONE command for the whole batch when the images are evenly spaced in one
@@ -1266,16 +1283,21 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
         for (int i = 1; i < nimg && even; i++) even = imgs[i] - imgs[i - 1] == D;
         // (the bytes between two images are read too: they must belong to the same pinned buffer -- known from the
         // registry, or because the images follow each other without a gap)
+        // ONE registered range must cover them all (images page-locked one by one cannot be read by one command), or they
+        // are pinned by somebody else's allocation and follow each other without a gap
         even = even && D >= (ptrdiff_t)imgBytes && (size_t)D <= 2 * align_up(imgBytes, 256) &&
-               ((size_t)D == (size_t)rows * stride || pin_known(imgs[0], (size_t)(nimg - 1) * (size_t)D + imgBytes));
+               (pin_known(imgs[0], (size_t)(nimg - 1) * (size_t)D + imgBytes) ||
+                ((size_t)D == (size_t)rows * stride && !pin_known(imgs[0], imgBytes)));
         if (stride <= 2 * (size_t)cols) {
             devPitch = stride;
             devStride = even ? (size_t)D : align_up(imgBytes, 256);
             if ((r = sl.d_img.ensure((size_t)nimg * devStride + 256)) < 0) return r;
-            if (even) {
-                HIP_TRY(hipMemcpyAsync(sl.d_img.p, imgs[0], (size_t)(nimg - 1) * devStride + imgBytes,
-                                       hipMemcpyHostToDevice, sIn));
-            } else {
+            if (even && hipMemcpyAsync(sl.d_img.p, imgs[0], (size_t)(nimg - 1) * devStride + imgBytes, hipMemcpyHostToDevice,
+                                       sIn) != hipSuccess) {
+                (void)hipGetLastError(); // (not one allocation after all: image by image)
+                even = false;
+            }
+            if (!even) {
                 for (int i = 0; i < nimg; i++)
                     HIP_TRY(hipMemcpyAsync(sl.d_img.p + (size_t)i * devStride, imgs[i], imgBytes, hipMemcpyHostToDevice,
                                            sIn));
@@ -1327,8 +1349,13 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     int32_t* d_meta = reinterpret_cast<int32_t*>(sl.d_out.p);
     float* d_kps = reinterpret_cast<float*>(sl.d_out.p + sl.metaBytes);
     uint8_t* d_desc = sl.d_out.p + sl.metaBytes + kpsBytes;
-    r = run_device(c, nimg, sl.d_img.p, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc, cap_per_img,
-                   d_meta, d_meta + nimg, d_meta + 2 * nimg);
+    uint8_t* mirror = nullptr;
+    if (mirrorOut) {
+        if ((r = sl.h_out.ensure(sl.metaBytes + kpsBytes + descBytes)) < 0) return r;
+        mirror = sl.h_out.dev();
+    }
+    r = run_device(c, nimg, sl.d_img.p, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc,
+                   cap_per_img, d_meta, d_meta + nimg, d_meta + 2 * nimg, mirror, sl.metaBytes);
     if (r < 0) return r;
     if (pipelined) {
         HIP_TRY(hipEventRecord(sl.evK, s));
@@ -1338,8 +1365,10 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     // ---- results: into the caller's arrays directly when those are pinned (the layouts are the same: nimg slabs of
     // cap entries), else ONE transfer of [meta | keypoints | descriptors] into the slot's pinned staging
     // (a frame or two: one command into the staging buffer and a 60-KB memcpy beat three DMA commands)
-    sl.outPinned = kpsBytes + descBytes >= (1u << 20) && is_pinned(c, kps, kpsBytes) && is_pinned(c, desc, descBytes);
-    if (sl.outPinned) {
+    sl.outPinned = !mirror && kpsBytes + descBytes >= (1u << 20) && is_pinned(c, kps, kpsBytes) && is_pinned(c, desc, descBytes);
+    if (mirror) {
+        // (the kernels have written the slot's pinned slab themselves: nothing to queue)
+    } else if (sl.outPinned) {
         if ((r = sl.h_out.ensure(sl.metaBytes)) < 0) return r;
         HIP_TRY(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, sl.metaBytes, hipMemcpyDeviceToHost, sOut));
         HIP_TRY(hipMemcpyAsync(kps, d_kps, kpsBytes, hipMemcpyDeviceToHost, sOut));
@@ -1469,6 +1498,8 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_XCD_AFFINE")) c->xcdAffine = atoi(e);
+    if (const char* e = getenv("ORBFE_ZEROCOPY")) c->zeroCopy = atoi(e) != 0;
+    if (const char* e = getenv("ORBFE_MIRROR_MAX")) c->mirrorMaxImgs = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (c->nStreams > 1) {
         bool ok = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;

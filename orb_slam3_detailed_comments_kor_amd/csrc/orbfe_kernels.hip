@@ -1378,7 +1378,10 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
                                               int32_t* __restrict__ monoOut, const float* __restrict__ kb8 /* or NULL */,
                                               float* __restrict__ raysOut /* 3 floats per kp, or NULL */, int imgBase,
                                               const int32_t* __restrict__ errIn /* the batch's error word or NULL */,
-                                              int32_t* __restrict__ errOut /* where the host path reads it, or NULL */)
+                                              int32_t* __restrict__ errOut /* where the host path reads it, or NULL */,
+                                              int32_t* __restrict__ mirrorMeta /* [n | mono | err] in pinned HOST memory
+                                                                                  (latency path of a frame or two), or NULL */,
+                                              int mirrorImgs)
 {
     __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
     __shared__ int waveCnt[PACK_THREADS / 64];
@@ -1464,6 +1467,11 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
         // metadata transfer.  With sub-batches on several streams only the first sub-batch's K-QT is ordered before
         // this, which is why the host path runs on one stream.
         if (errOut && errIn && blockIdx.x == 0) errOut[0] = errIn[0];
+        if (mirrorMeta) { // the caller reads these straight from pinned memory: no download command
+            mirrorMeta[blockIdx.x] = n;
+            mirrorMeta[mirrorImgs + blockIdx.x] = n - runStereo;
+            if (blockIdx.x == 0) mirrorMeta[2 * mirrorImgs] = errIn ? errIn[0] : 0;
+        }
     }
 }
 
@@ -1673,7 +1681,9 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           const float2* __restrict__ trigFull /* libm values or nullptr */,
                                                           int atanFma /* fused Horner steps in fastAtan2 (D2) */,
                                                           uint8_t* __restrict__ dbgPatch /* test tap: 37x37 blurred patch */,
-                                                          int dbgDest /* ... of the keypoint with this output slot */)
+                                                          int dbgDest /* ... of the keypoint with this output slot */,
+                                                          float* __restrict__ mirrorKps = nullptr /* the same outputs once more, */,
+                                                          uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1962,8 +1972,15 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     if (lane < 4) {
         const unsigned long long v = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
         reinterpret_cast<unsigned long long*>(descOut + slot * 32)[lane] = v;
+        // latency path of a frame or two: the caller's copy is written from here (posted writes over PCIe to pinned memory,
+        // same layout as the device arrays) instead of by a download command after the kernel
+        if (mirrorDesc) reinterpret_cast<unsigned long long*>(mirrorDesc + slot * 32)[lane] = v;
     }
     if (MODE == 0) {
+        if (mirrorKps && lane < 7) { // the 28-byte keypoint record: six fields from K-PACK, the angle from here
+            const float f = lane == 3 ? angle : kpsOut[slot * 7 + lane];
+            mirrorKps[slot * 7 + lane] = f;
+        }
         const bool anyFrag = __ballot(frag) != 0ull;
         if (lane == 0) {
             kpsOut[slot * 7 + 3] = angle;
