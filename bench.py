@@ -150,6 +150,30 @@ def bench_frames(rows, cols, batch, rank=0):
     return np.stack([np.roll(base[i % nuniq], 23 * (i // nuniq), axis=1) for i in range(batch)])
 
 
+def startup_cost(rows, cols, nfeatures, device=0):
+    """create + first call of a fresh process (tools/hostbench ... first) in three states of the libm trig table: built from
+    libm with no cache file, full table from the cache file (expanded on the device), compact table from the cache file."""
+    exe = os.path.join(ROOT, "tools", "hostbench")
+    with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as f:
+        f.write(bench_frames(rows, cols, 1).tobytes())
+        path = f.name
+    out = {}
+    try:
+        for tag, env in (("full_table_no_cache", {"ORBFE_TRIG_CACHE": "0", "ORBFE_TRIG_TABLE": "2"}),
+                         ("full_table_cached", {"ORBFE_TRIG_TABLE": "2"}),
+                         ("compact_table_cached", {"ORBFE_TRIG_TABLE": "1"})):
+            e = dict(os.environ)
+            e.update(env)
+            r = subprocess.run([exe, path, str(rows), str(cols), "1", str(nfeatures), str(device), "first"], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=120, env=e)
+            out[tag] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-200:]}
+    finally:
+        os.unlink(path)
+    out["note"] = ("libm trig table of the process: 65 MB of codes cached in /dev/shm after the first build; the 1.03 GB table is "
+                   "expanded from them on the device; ranks of a multi-process job default to the compact form")
+    return out
+
+
 def pcie_inclusive(rows, cols, batch, nfeatures, device=0, as_text=False):
     """Runs tools/hostbench (C++ caller of the C ABI, built by __graft_entry__.build()) on the bench frames and
     returns its JSON object: the PCIe-inclusive rates of the drop-in boundary."""
@@ -640,6 +664,10 @@ def main():
                 out["pcie_inclusive"] = pcie_inclusive(H, W, B, args.nfeatures, local_rank)
             except (SystemExit, Exception) as e:  # noqa: BLE001
                 out["pcie_inclusive"] = {"error": str(e)}
+            try:
+                out["startup"] = startup_cost(H, W, args.nfeatures, local_rank)
+            except (SystemExit, Exception) as e:  # noqa: BLE001
+                out["startup"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(H, W, args.nfeatures)

@@ -19,11 +19,16 @@
 #include <functional>
 #include <chrono>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
+#include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/orbfe.h"
 #include "orbfe_geom.h"
@@ -740,11 +745,111 @@ bool small_angles_ok()
     return true;
 }
 
+// ---- the compact table's cache file.  Building the table means evaluating libm's cosf / sinf for 1.29e8 angles (all
+// host cores, and every rank of a node would do it at once).  The 65 MB of codes are therefore kept in a file (default
+// directory /dev/shm, ORBFE_TRIG_CACHE=<dir> or =0 for none) named after a fingerprint of THIS host's libm, and the
+// next process -- a rank of the same job, the next run -- reads them back instead: first call 60-90 ms -> ~15 ms.
+struct TrigCacheHeader {
+    char magic[8];       // "ORBFETC2"
+    uint32_t u0, n;      // first angle (bit pattern) and count
+    uint64_t libmPrint;  // FNV-1a over libm's results on a sample
+    uint64_t payloadSum; // FNV-1a over the code bytes
+};
+uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+// checksum of the 65-MB payload: four independent 64-bit lanes over whole words (a byte-wise FNV over 65 MB costs 60 ms --
+// as much as building the table)
+uint64_t words_sum(const void* p, size_t n)
+{
+    const uint64_t* w = (const uint64_t*)p;
+    const size_t nw = n / 8;
+    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full, c = 0x165667B19E3779F9ull, d = 0x27D4EB2F165667C5ull;
+    size_t i = 0;
+    for (; i + 4 <= nw; i += 4 * 16) { // (every 16th group of four words: a truncated or foreign file shows, in half a ms)
+        a = (a ^ w[i]) * 0x100000001B3ull;
+        b = (b ^ w[i + 1]) * 0x100000001B3ull;
+        c = (c ^ w[i + 2]) * 0x100000001B3ull;
+        d = (d ^ w[i + 3]) * 0x100000001B3ull;
+    }
+    for (; i < nw; i++) a = (a ^ w[i]) * 0x100000001B3ull;
+    return fnv1a((const uint8_t*)p + nw * 8, n - nw * 8, a ^ (b << 1) ^ (c << 2) ^ (d << 3));
+}
+uint64_t libm_fingerprint()
+{
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    uint64_t h = 1469598103934665603ull;
+    for (uint32_t u = ORBFE_TRIG_U0; u <= ORBFE_TRIG_U1; u += 30011u) { // ~4300 angles over the whole table
+        float deg;
+        std::memcpy(&deg, &u, 4);
+        volatile float ang = deg * factorPI;
+        const float v[2] = {cosf(ang), sinf(ang)};
+        h = fnv1a(v, sizeof v, h);
+    }
+    return h;
+}
+std::string trig_cache_path(uint64_t print)
+{
+    const char* dir = getenv("ORBFE_TRIG_CACHE");
+    if (dir && (!*dir || !std::strcmp(dir, "0"))) return std::string();
+    char name[96];
+    std::snprintf(name, sizeof name, "/orbfe_trigcodes_%016llx.bin", (unsigned long long)print);
+    return std::string(dir ? dir : "/dev/shm") + name;
+}
+// maps the cache file and returns its payload (nullptr: absent / stale / damaged); *map / *mapBytes for munmap
+const uint8_t* trig_cache_map(const std::string& path, uint64_t print, size_t bytes, void** map, size_t* mapBytes)
+{
+    *map = nullptr;
+    if (path.empty()) return nullptr;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    const size_t want = sizeof(TrigCacheHeader) + bytes;
+    void* m = MAP_FAILED;
+    if (fstat(fd, &st) == 0 && (size_t)st.st_size == want) m = mmap(nullptr, want, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return nullptr;
+    const TrigCacheHeader* hd = (const TrigCacheHeader*)m;
+    const uint8_t* payload = (const uint8_t*)m + sizeof(TrigCacheHeader);
+    if (std::memcmp(hd->magic, "ORBFETC2", 8) || hd->u0 != ORBFE_TRIG_U0 || hd->n != ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u ||
+        hd->libmPrint != print || words_sum(payload, bytes) != hd->payloadSum) {
+        munmap(m, want);
+        return nullptr;
+    }
+    *map = m;
+    *mapBytes = want;
+    return payload;
+}
+void trig_cache_store(const std::string& path, uint64_t print, const uint8_t* src, size_t bytes)
+{
+    if (path.empty()) return;
+    char tmp[64];
+    std::snprintf(tmp, sizeof tmp, ".tmp%ld", (long)getpid());
+    const std::string t = path + tmp;
+    FILE* f = std::fopen(t.c_str(), "wb");
+    if (!f) return;
+    TrigCacheHeader hd;
+    std::memcpy(hd.magic, "ORBFETC2", 8);
+    hd.u0 = ORBFE_TRIG_U0;
+    hd.n = ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u;
+    hd.libmPrint = print;
+    hd.payloadSum = words_sum(src, bytes);
+    const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(src, 1, bytes, f) == bytes;
+    std::fclose(f);
+    if (!ok || std::rename(t.c_str(), path.c_str()) != 0) std::remove(t.c_str()); // (atomic: a reader sees all or nothing)
+}
+
 // The libm table of this process for `device` (both pointers null: not available); never fails the caller.
 // ORBFE_TRIG_TABLE = 0: none (per-batch host check), 1: compact 4-bit codes (65 MB; the device still evaluates the
-// correctly rounded sin/cos and applies the code), 2 or unset: libm's values themselves (1.03 GB of the 288 GB; the
-// descriptor kernel then needs no double-precision sin/cos at all, and libm may be arbitrarily inaccurate), falling
-// back to the compact form when that allocation fails.
+// correctly rounded sin/cos and applies the code), 2: libm's values themselves (1.03 GB of the 288 GB; the descriptor
+// kernel then needs no double-precision sin/cos at all), expanded ON THE DEVICE from the codes; falls back to the compact
+// form when that allocation fails.  Unset: 2 for a process on its own, 1 when the process is one rank of several
+// (WORLD_SIZE / LOCAL_WORLD_SIZE > 1: eight ranks then hold 8 x 65 MB instead of 8 x 1.03 GB, at 0.259 instead of 0.253 ms
+// per 64-frame batch).  A libm that is ever further than one bit pattern from the correctly rounded value cannot be coded:
+// then mode 2 uploads libm's values directly (the first design) and mode 1 is unavailable.
 TrigTabs trig_table(int device, hipStream_t s)
 {
     TrigTabs none{nullptr, nullptr};
@@ -754,58 +859,100 @@ TrigTabs trig_table(int device, hipStream_t s)
     if (t.tried) return t.ok ? TrigTabs{t.d, t.full} : none;
     t.tried = true;
     int mode = 2;
+    for (const char* v : {"WORLD_SIZE", "LOCAL_WORLD_SIZE"})
+        if (const char* e = getenv(v))
+            if (atoi(e) > 1) mode = 1;
     if (const char* e = getenv("ORBFE_TRIG_TABLE")) mode = atoi(e);
     if (mode <= 0) return none;
+    const auto tBuild0 = std::chrono::steady_clock::now();
     if (!small_angles_ok()) return none;
     const uint32_t N = ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u;
+    const size_t codeBytes = (size_t)(N + 1) / 2;
     const uint32_t chunk = 1u << 22; // 4M angles = 32 MB of (cosf, sinf) per transfer
-    float2* h = nullptr;
-    if (hipHostMalloc((void**)&h, (size_t)chunk * sizeof(float2)) != hipSuccess) return none;
-    bool fine = false;
-    if (mode >= 2 && hipMalloc((void**)&t.full, (size_t)N * sizeof(float2)) == hipSuccess) {
-        fine = true;
-        for (uint32_t i0 = 0; fine && i0 < N; i0 += chunk) {
-            const uint32_t n = std::min(chunk, N - i0);
-            fill_libm(h, ORBFE_TRIG_U0 + i0, n);
-            fine = hipMemcpyAsync(t.full + i0, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess &&
-                   hipStreamSynchronize(s) == hipSuccess; // h is refilled next
+    float2* h = nullptr; // pinned staging, only when libm has to be evaluated
+    // ---- the codes: from the cache file (mapped, sent as it lies), else from libm
+    const uint64_t print = libm_fingerprint();
+    const std::string cache = trig_cache_path(print);
+    bool fine = hipMalloc((void**)&t.d, codeBytes) == hipSuccess;
+    bool coded = false;
+    if (fine) {
+        void* map = nullptr;
+        size_t mapBytes = 0;
+        if (const uint8_t* payload = trig_cache_map(cache, print, codeBytes, &map, &mapBytes)) {
+            coded = hipMemcpy(t.d, payload, codeBytes, hipMemcpyHostToDevice) == hipSuccess;
+            munmap(map, mapBytes);
         }
-        if (!fine) {
-            (void)hipFree(t.full);
-            t.full = nullptr;
-        }
-    } else {
-        (void)hipGetLastError(); // a failed 1-GB allocation is not an error of the caller
-        t.full = nullptr;
     }
-    if (!fine) { // compact form
+    if (!coded && hipHostMalloc((void**)&h, std::max((size_t)chunk * sizeof(float2), codeBytes)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (t.d) (void)hipFree(t.d);
+        t.d = nullptr;
+        return none;
+    }
+    if (fine && !coded) {
         float2* dAB = nullptr;
         int32_t* dBad = nullptr;
         int32_t bad = 0;
-        fine = hipMalloc((void**)&dAB, (size_t)chunk * sizeof(float2)) == hipSuccess &&
-               hipMalloc((void**)&dBad, sizeof(int32_t)) == hipSuccess &&
-               hipMalloc((void**)&t.d, (size_t)(N + 1) / 2) == hipSuccess &&
-               hipMemsetAsync(dBad, 0, sizeof(int32_t), s) == hipSuccess;
-        for (uint32_t i0 = 0; fine && i0 < N; i0 += chunk) { // chunk is even: whole table bytes per chunk
+        coded = hipMalloc((void**)&dAB, (size_t)chunk * sizeof(float2)) == hipSuccess &&
+                hipMalloc((void**)&dBad, sizeof(int32_t)) == hipSuccess && hipMemsetAsync(dBad, 0, sizeof(int32_t), s) == hipSuccess;
+        for (uint32_t i0 = 0; coded && i0 < N; i0 += chunk) { // chunk is even: whole table bytes per chunk
             const uint32_t n = std::min(chunk, N - i0);
             fill_libm(h, ORBFE_TRIG_U0 + i0, n);
-            fine = hipMemcpyAsync(dAB, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess;
-            if (!fine) break;
+            coded = hipMemcpyAsync(dAB, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess;
+            if (!coded) break;
             hipLaunchKernelGGL(k_trig_codes, dim3((n / 2 + 256) / 256), dim3(256), 0, s, dAB, ORBFE_TRIG_U0 + i0, n,
                                t.d + i0 / 2, dBad);
-            fine = hipStreamSynchronize(s) == hipSuccess;
+            coded = hipStreamSynchronize(s) == hipSuccess;
         }
         // a libm value further than one bit pattern from the correctly rounded one cannot be coded
-        if (fine) fine = hipMemcpy(&bad, dBad, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+        if (coded) coded = hipMemcpy(&bad, dBad, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
         if (dAB) (void)hipFree(dAB);
         if (dBad) (void)hipFree(dBad);
-        if (!fine && t.d) {
-            (void)hipFree(t.d);
-            t.d = nullptr;
+        if (coded && !cache.empty() && hipMemcpy(h, t.d, codeBytes, hipMemcpyDeviceToHost) == hipSuccess)
+            trig_cache_store(cache, print, reinterpret_cast<const uint8_t*>(h), codeBytes);
+    }
+    if (!coded && t.d) {
+        (void)hipFree(t.d);
+        t.d = nullptr;
+    }
+    (void)hipGetLastError();
+    // ---- the full table
+    fine = coded;
+    if (mode >= 2) {
+        if (hipMalloc((void**)&t.full, (size_t)N * sizeof(float2)) == hipSuccess) {
+            bool filled;
+            if (coded) { // expanded on the device from the codes
+                hipLaunchKernelGGL(k_trig_expand, dim3((N + 255) / 256), dim3(256), 0, s, t.d, ORBFE_TRIG_U0, N, t.full);
+                filled = hipStreamSynchronize(s) == hipSuccess;
+            } else { // an uncodable libm: its values themselves, evaluated here and sent over
+                filled = h != nullptr;
+                for (uint32_t i0 = 0; filled && i0 < N; i0 += chunk) {
+                    const uint32_t n = std::min(chunk, N - i0);
+                    fill_libm(h, ORBFE_TRIG_U0 + i0, n);
+                    filled = hipMemcpyAsync(t.full + i0, h, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s) == hipSuccess &&
+                             hipStreamSynchronize(s) == hipSuccess; // h is refilled next
+                }
+            }
+            if (filled) {
+                fine = true;
+                if (t.d) (void)hipFree(t.d); // K-DESC reads the full table; the codes have done their work
+                t.d = nullptr;
+            } else {
+                (void)hipFree(t.full);
+                t.full = nullptr;
+            }
+        } else {
+            (void)hipGetLastError(); // a failed 1-GB allocation is not an error of the caller: the compact form serves
+            t.full = nullptr;
         }
     }
-    (void)hipHostFree(h);
-    t.ok = fine;
+    if (h) (void)hipHostFree(h);
+    t.ok = fine && (t.d || t.full);
+    if (getenv("ORBFE_VERBOSE"))
+        fprintf(stderr, "orbfe: libm trig table on device %d: %s, codes %s, %.1f ms\n", device,
+                t.full ? "1.03 GB of values" : t.d ? "65 MB of codes" : "none",
+                coded ? (cache.empty() ? "from libm (no cache)" : "from the cache file or libm") : "not codable",
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count());
     return t.ok ? TrigTabs{t.d, t.full} : none;
 }
 

@@ -1573,6 +1573,19 @@ __device__ __forceinline__ float trig_apply(float v, unsigned code)
 {
     return __uint_as_float(__float_as_uint(v) + (code == 1u ? 1u : code == 2u ? 0xFFFFFFFFu : 0u));
 }
+// The full table from the compact one, on the device: libm's (cosf, sinf) of angle u0 + i = the correctly rounded pair
+// moved by its code.  1.03 GB written at HBM speed instead of being evaluated by the host and sent over PCIe.
+__global__ __launch_bounds__(256) void k_trig_expand(const uint8_t* __restrict__ codes, uint32_t u0, uint32_t n,
+                                                     float2* __restrict__ full)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float sc, cc;
+    orbfe_sincos_cr(__fmul_rn(__uint_as_float(u0 + i), factorPI), &sc, &cc);
+    const unsigned nib = (codes[i >> 1] >> (4u * (i & 1u))) & 0xFu;
+    full[i] = make_float2(trig_apply(cc, nib & 3u), trig_apply(sc, nib >> 2));
+}
 // What K-DESC fetches for its angle as soon as the angle is known (the load then overlaps the blur): with the
 // full table libm's (cosf, sinf) themselves, with the compact table the 4-bit code, else nothing.
 struct TrigFetch {

@@ -106,6 +106,11 @@ int main(int argc, char** argv)
     const double tFirst0 = now_s();
     CHECK(orbfe_extract(ex, pPg[0], rows, cols, cols, 0, 1000, (orbfe_kp*)pgK.data(), pgD.data(), cap, &n0) + 1);
     const double firstCallMs = 1e3 * (now_s() - tFirst0), createMs = 1e3 * (tFirst0 - tCreate0);
+    if (argc > 7 && !strcmp(argv[7], "first")) { // start-up cost only (bench.py runs this with and without the table cache)
+        printf("{\"create_ms\": %.2f, \"first_call_ms\": %.2f}\n", createMs, firstCallMs);
+        orbfe_destroy(ex);
+        return 0;
+    }
 
     // ---- single frame per call
     auto single = [&](bool pinned, Stat* st, double* kpPerS, int ring = 0) -> int {
