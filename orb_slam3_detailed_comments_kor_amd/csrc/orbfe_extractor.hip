@@ -54,6 +54,8 @@ inline int cv_floor_d(double v)
 }
 inline int16_t sat_s16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// ceil(2^32 / d) for the kernels' fast_div (0 encodes d == 1): x / d == umulhi(x, m) while x * d < 2^32
+inline uint32_t recip32(unsigned d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }
 
 template <class T>
 struct DevBuf {
@@ -1016,7 +1018,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                c->pyrLdsBytes, q, d_imgs,
                                pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p,
                                c->pyrNtx, c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
-                               cols, i0, kernelClearsHdr ? d_hdr : nullptr, (c->xcdAffine && ni % 8 == 0) ? 1 : 0);
+                               cols, i0, kernelClearsHdr ? d_hdr : nullptr, (c->xcdAffine && ni % 8 == 0) ? 1 : 0,
+                               recip32((unsigned)(c->pyrNtx * c->pyrNty)), recip32((unsigned)c->pyrNtx));
         } else {
             const OrbLevelGeom& L0 = c->lg[0];
             dim3 grid((unsigned)((L0.w + 1023) / 1024), (unsigned)L0.h, (unsigned)nimg);

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, s
     }
 }
 
+// x / d with a host-made reciprocal m = ceil(2^32 / d) (m == 0 encodes d == 1): exact while x*d < 2^32.
+__device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (int)__umulhi(x, m) : (int)x; }
+
 // Whole pyramid in ONE launch.  A workgroup owns one ORBFE_PYR_TILE^2 tile of the coarsest level
 // and walks the chain level 0 -> nlevels-1 through two LDS buffers: it loads the level-0 region its
 // chain needs from the caller's image, and at every level interpolates the next region from LDS
@@ -110,7 +113,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                                                    const OrbResizeY* __restrict__ ytab, int bufBytes0,
                                                    int bufBytes1, int stageX, int imgCols, int imgBase,
                                                    int32_t* __restrict__ clearHdr /* 4 words or nullptr */,
-                                                   int xcdAffine)
+                                                   int xcdAffine, uint32_t mPerImg /* reciprocals of ntx * nty */,
+                                                   uint32_t mNtx /* and of ntx (fast_div) */)
 {
     // first kernel of a batch: clear the {fragile count, error flag, -, -} header the later kernels append to
     if (clearHdr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < 4) clearHdr[threadIdx.x] = 0;
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         // whole images per XCD (the batch is a multiple of 8): the halo columns and rows neighbouring tiles
         // re-read, and the partial lines they write side by side, then meet in ONE L2
         const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, k = lin >> 3;
-        const unsigned perImg = gridDim.x * gridDim.y, j = k / perImg, t = k - j * perImg;
+        const unsigned perImg = gridDim.x * gridDim.y, j = (unsigned)fast_div(k, mPerImg), t = k - j * perImg;
         img = (int)(8u * j + (lin & 7u));
-        tj = (int)(t / gridDim.x);
+        tj = fast_div(t, mNtx);
         ti = (int)(t - (unsigned)tj * gridDim.x);
     }
     img += imgBase;
@@ -206,8 +210,11 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         const int sp = (nW + 3) & ~3; // LDS pitch of the level-0 region
         const int pitch0 = lvPitch[0];
         const int xlo = lvXlo[0], ylo = lvYlo[0];
-        const uint8_t* s0 = src + (size_t)img * srcImgStride + (size_t)ylo * srcPitch + xlo;
-        uint8_t* d0 = base + (uint32_t)lvRoi[0] + (size_t)ylo * pitch0 + xlo;
+        // (32-bit offsets from two wave-uniform bases: an image and a pyramid slab are below 4 GB)
+        const uint8_t* const s0 = src + (size_t)img * srcImgStride;
+        uint8_t* const d0 = base;
+        const uint32_t sOrg = (uint32_t)ylo * (uint32_t)srcPitch + (uint32_t)xlo;
+        const uint32_t dOrg = (uint32_t)lvRoi[0] + (uint32_t)ylo * (uint32_t)pitch0 + (uint32_t)xlo;
         const int ownW = lvXown[0] - xlo, ownH = lvYown[0] - ylo;
         // dword granularity (global dword accesses may be unaligned).  A thread keeps one dword column
         // and walks down the rows, four loads in flight per step; no per-item division.
@@ -219,10 +226,10 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         const int rpp = rcp0 ? (int)__umulhi(256u, rcp0) : 256;        // rows per pass
         if (rr < rpp) {
             const bool fullLoad = c + 4 <= safeW, colOwned = c < ownW, fullStore = c + 4 <= ownW;
-            const uint8_t* p = s0 + (size_t)rr * srcPitch + c;
-            uint8_t* q = d0 + (size_t)rr * pitch0 + c;
+            uint32_t po = sOrg + (uint32_t)rr * (uint32_t)srcPitch + (uint32_t)c;
+            uint32_t qo = dOrg + (uint32_t)(rr * pitch0 + c);
             uint8_t* dq = bufA + rr * sp + c;
-            const size_t pStep = (size_t)rpp * srcPitch;
+            const uint32_t pStep = (uint32_t)rpp * (uint32_t)srcPitch;
             const int qStep = rpp * pitch0, dStep = rpp * sp;
             for (int r = rr; r < nH; r += 4 * rpp) {
                 uint32_t v[4];
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                 for (int k = 0; k < 4; k++) {
                     v[k] = 0;
                     if (r + k * rpp < nH) {
-                        const uint8_t* pk = p + k * pStep;
+                        const uint8_t* pk = s0 + (po + (uint32_t)k * pStep);
                         if (fullLoad) {
                             __builtin_memcpy(&v[k], pk, 4);
                         } else if (safeW > c) { // the image's last 1..3 columns: one 16-bit and / or one 8-bit load
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                     if (rk < nH) {
                         *reinterpret_cast<uint32_t*>(dq + k * dStep) = v[k];
                         if (rk < ownH && colOwned) {
-                            uint8_t* qk = q + (size_t)k * qStep;
+                            uint8_t* qk = d0 + (qo + (uint32_t)(k * qStep));
                             if (fullStore) {
                                 __builtin_memcpy(qk, &v[k], 4);
                             } else {
@@ -264,8 +271,8 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                         }
                     }
                 }
-                p += 4 * pStep;
-                q += 4 * (size_t)qStep;
+                po += 4u * pStep;
+                qo += (uint32_t)(4 * qStep);
                 dq += 4 * dStep;
             }
         }
@@ -307,12 +314,14 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                 const uint32_t o = X[k].x - X[0].x; // 0..6
                 sel[k] = 0x0C000C00u | o | ((o + 1u) << 16);
             }
-            // destination addresses advance by whole passes (no per-row multiplies)
-            uint8_t* q = base + (uint32_t)lvRoi[l] + (size_t)(ylo + rr) * gpitch + xlo + c0;
+            // destination addresses advance by whole passes (no per-row multiplies); the global one is a 32-bit offset from
+            // the image's slab (a slab is below 4 GB: one scalar base + one vector offset per store, no 64-bit vector adds)
+            uint32_t qo = (uint32_t)lvRoi[l] + (uint32_t)((ylo + rr) * gpitch + xlo + c0);
             uint8_t* dq = D + rr * dp + c0;
             const int qStep = rowsPerPass * gpitch, dStep = rowsPerPass * dp;
             const bool colOwned = c0 < ownW, fullDword = c0 + 4 <= ownW;
-            for (int r = rr; r < nH; r += rowsPerPass, q += qStep, dq += dStep) {
+            for (int r = rr; r < nH; r += rowsPerPass, qo += (uint32_t)qStep, dq += dStep) {
+                uint8_t* const q = base + qo;
                 const uint2 Yp = yt[yo + r];
                 const uint4 Y = make_uint4(Yp.x & 0xFFFFu, Yp.x >> 16, Yp.y << 16, Yp.y & 0xFFFF0000u);
                 const uint32_t* S0 = reinterpret_cast<const uint32_t*>(S + Y.x + xbase);
@@ -475,8 +484,6 @@ __device__ __forceinline__ int lds_add_per_lane(int* p, int v)
     return r;
 }
 
-// x / d with a host-made reciprocal m = ceil(2^32 / d) (m == 0 encodes d == 1): exact while x*d < 2^32.
-__device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (int)__umulhi(x, m) : (int)x; }
 
 // K-FAST: one 128-thread workgroup per FAST cell.  The reference makes one cv::FAST call per cell at iniThFAST and a second
 // one at minThFAST when the first finds nothing (src/ORBextractor.cc:787-854) -- and the kernel does exactly that: a pass
@@ -1907,8 +1914,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             if (lane + 64 * k < 19 * 10) {
                 const uint4* sp4 = src + 64 * k;
                 const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
-                uint32_t outE = 0, outO = 0;
-#define ORBFE_VCOL(F, SHIFT)                                                                           \
+                uint32_t aE[4], aO[4]; // 16.16 sums of the even / odd output row, columns x y z w
+#define ORBFE_VCOL(F, I)                                                                               \
     {                                                                                                   \
         U2 q0, q1, q2, q3;                                                                              \
         q0.u = p0.F;                                                                                    \
@@ -1918,19 +1925,27 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         uint32_t acc = __builtin_amdgcn_udot2(q0.v, e0.v, 32768u, false);                               \
         acc = __builtin_amdgcn_udot2(q1.v, e1.v, acc, false);                                           \
         acc = __builtin_amdgcn_udot2(q2.v, e2.v, acc, false);                                           \
-        acc = __builtin_amdgcn_udot2(q3.v, e3.v, acc, false);                                           \
-        outE |= min(acc >> 16, 255u) << SHIFT;                                                          \
+        aE[I] = __builtin_amdgcn_udot2(q3.v, e3.v, acc, false);                                         \
         acc = __builtin_amdgcn_udot2(q0.v, o0.v, 32768u, false);                                        \
         acc = __builtin_amdgcn_udot2(q1.v, o1.v, acc, false);                                           \
         acc = __builtin_amdgcn_udot2(q2.v, o2.v, acc, false);                                           \
-        acc = __builtin_amdgcn_udot2(q3.v, o3.v, acc, false);                                           \
-        outO |= min(acc >> 16, 255u) << SHIFT;                                                          \
+        aO[I] = __builtin_amdgcn_udot2(q3.v, o3.v, acc, false);                                         \
     }
                 ORBFE_VCOL(x, 0)
-                ORBFE_VCOL(y, 8)
-                ORBFE_VCOL(z, 16)
-                ORBFE_VCOL(w, 24)
+                ORBFE_VCOL(y, 1)
+                ORBFE_VCOL(z, 2)
+                ORBFE_VCOL(w, 3)
 #undef ORBFE_VCOL
+                uint32_t outE, outO;
+                if (SAT) { // taps that sum to more than 256: the result can exceed 255 and saturates (ufixedpoint16 -> uchar)
+                    outE = min(aE[0] >> 16, 255u) | (min(aE[1] >> 16, 255u) << 8) | (min(aE[2] >> 16, 255u) << 16) | (min(aE[3] >> 16, 255u) << 24);
+                    outO = min(aO[0] >> 16, 255u) | (min(aO[1] >> 16, 255u) << 8) | (min(aO[2] >> 16, 255u) << 16) | (min(aO[3] >> 16, 255u) << 24);
+                } else { // <= 255 * 256 * 256 + 32768: byte 2 of each sum IS the pixel; three v_perm_b32 gather four of them
+                    outE = __builtin_amdgcn_perm(__builtin_amdgcn_perm(aE[3], aE[2], 0x0C0C0602u),
+                                                 __builtin_amdgcn_perm(aE[1], aE[0], 0x0C0C0602u), 0x05040100u);
+                    outO = __builtin_amdgcn_perm(__builtin_amdgcn_perm(aO[3], aO[2], 0x0C0C0602u),
+                                                 __builtin_amdgcn_perm(aO[1], aO[0], 0x0C0C0602u), 0x05040100u);
+                }
                 *reinterpret_cast<uint32_t*>(bl + boff) = outE;
                 *reinterpret_cast<uint32_t*>(bl + boff + DESC_BP) = outO;
             }
