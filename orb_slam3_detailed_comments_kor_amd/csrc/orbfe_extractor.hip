@@ -128,6 +128,7 @@ struct orbfe_geom_state {
     size_t fastLdsBytes = 0;
     std::vector<OrbFastCell> fc; // K-FAST's cell records
     DevBuf<OrbFastCell> d_fc;
+    DevBuf<OrbDescSlot> d_ds; // K-DESC's per-slot records (level geometry of every keypoint slot)
     int fastTileBytes = 0, fastBmWords = 0;
     DevBuf<OrbLevelGeom> d_lg;
     DevBuf<OrbCellGeom> d_cg;
@@ -140,7 +141,7 @@ struct orbfe_geom_state {
     bool pyrFused = true;
     void release_tables()
     {
-        d_lg.release(); d_cg.release(); d_fc.release(); d_xtab.release(); d_ytab.release(); d_prx.release(); d_pry.release();
+        d_lg.release(); d_cg.release(); d_fc.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_prx.release(); d_pry.release();
     }
 };
 
@@ -180,7 +181,8 @@ struct orbfe_ctx : orbfe_geom_state {
     bool kb8On = false;
     float kb8[8] = {0};
     float* userRays = nullptr; // device pointer supplied by orbfe_set_ray_output
-    DevBuf<OrbDescWork> d_work;
+    DevBuf<int32_t> d_destMap; // K-PACK's output slot per keypoint slot (fisheye rays only)
+    DevBuf<uint32_t> d_lvlPre; // K-QT's partition word per keypoint slot
     DevBuf<int> d_taps;
     bool tapsDirty = true;
     int lapDev0 = 0, lapDev1 = 0, lapDevCount = 0; // what d_lap currently holds (orbfe_extract_batch_device)
@@ -227,6 +229,7 @@ struct orbfe_ctx : orbfe_geom_state {
     const uint8_t* lastDesc = nullptr;
     const int32_t* lastN = nullptr;
     int lastCap = 0;
+    bool lastPacked = false; // the last batch ran K-PACK (d_destMap holds its output slots)
     DevBuf<float> d_stereo; // uRight | depth | sad of orbfe_compute_stereo_matches_resident
     PinBuf<float> h_stereo;
     DevBuf<uint8_t> d_stereoIo; // orbfe_compute_stereo_matches: keypoints and descriptors of both images | uRight | depth | sad
@@ -561,12 +564,31 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     if ((r = c->d_lg.ensure(c->lg.size())) < 0) return r;
     if ((r = c->d_cg.ensure(c->cg.size())) < 0) return r;
     if ((r = c->d_fc.ensure(c->fc.size())) < 0) return r;
+    if ((r = c->d_ds.ensure(std::max<size_t>(c->kpStride, 1))) < 0) return r;
     if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
     if ((r = c->d_ytab.ensure(std::max<size_t>(ytab.size(), 1))) < 0) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_fc.p, c->fc.data(), c->fc.size() * sizeof(OrbFastCell), hipMemcpyHostToDevice));
+    {
+        // K-DESC's slot records: slot kpBase + k of every level carries that level's geometry
+        std::vector<OrbDescSlot> ds(c->kpStride);
+        for (int l = 0; l < c->nlevels; l++) {
+            const OrbLevelGeom& L = c->lg[l];
+            for (int k = 0; k < L.kpCap; k++) {
+                OrbDescSlot& d = ds[(size_t)L.kpBase + k];
+                d.roiOff = L.roiOff;
+                d.pitch = L.pitch;
+                d.wh = (uint32_t)L.w | ((uint32_t)L.h << 16);
+                d.lk = (uint32_t)l | ((uint32_t)k << 8);
+                d.scale = L.scale;
+                d.size = L.size;
+                d.pad[0] = d.pad[1] = 0;
+            }
+        }
+        if (!ds.empty()) HIP_TRY(hipMemcpy(c->d_ds.p, ds.data(), ds.size() * sizeof(OrbDescSlot), hipMemcpyHostToDevice));
+    }
     if (!xtab.empty())
         HIP_TRY(hipMemcpy(c->d_xtab.p, xtab.data(), xtab.size() * sizeof(OrbResizeX), hipMemcpyHostToDevice));
     if (!ytab.empty())
@@ -654,10 +676,11 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_keys.ensure(B * c->keyStride)) < 0) return r;
     if ((r = c->d_keyNode.ensure(B * c->keyStride)) < 0) return r;
     if ((r = c->d_lvlKp.ensure(B * c->kpStride)) < 0) return r;
-    if ((r = c->d_lvlCount.ensure(B * c->nlevels)) < 0) return r;
+    if ((r = c->d_lvlPre.ensure(B * c->kpStride)) < 0) return r;
+    if ((r = c->d_lvlCount.ensure(B * c->nlevels + 16)) < 0) return r; // (+ 16: K-DESC reads the counts as whole int4s)
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
     c->lapDevCount = 0; // possibly a new buffer
-    if ((r = c->d_work.ensure(B * K)) < 0) return r;
+    if ((r = c->d_destMap.ensure(B * std::max(K, c->kpStride))) < 0) return r;
     if ((r = c->d_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fixAB.ensure(B * K + 1)) < 0) return r;
@@ -1064,15 +1087,19 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                            dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                            c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
                            c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
-                           c->qtKeyOff, c->qtKeyCap);
+                           c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p);
         if (nsub == 1) rec(c, 3);
-        // K-PACK
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(PACK_THREADS), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
-                           c->d_lvlCount.p, d_lap, d_kps, capPerImg, c->d_work.p, d_n, d_mono,
-                           c->kb8On ? c->d_kb8.p : nullptr,
-                           c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
-                           k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr,
-                           mirror ? reinterpret_cast<int32_t*>(mirror) : nullptr, nimg);
+        // K-PACK: only when bearing rays are wanted (orbfe_set_kb8).  Otherwise K-QT has left the mono / stereo partition
+        // of every level behind and K-DESC derives its output slots, the keypoint records, the counts and the error word
+        // itself: four launches per batch
+        const bool needPack = c->kb8On;
+        int32_t* const mMeta = mirror ? reinterpret_cast<int32_t*>(mirror) : nullptr;
+        if (needPack)
+            hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(PACK_THREADS), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
+                               c->d_lvlCount.p, d_lap, capPerImg, c->d_destMap.p, d_n, d_mono,
+                               c->kb8On ? c->d_kb8.p : nullptr,
+                               c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
+                               k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr, mMeta, nimg);
         if (nsub == 1) rec(c, 4);
         // K-DESC
         {
@@ -1080,16 +1107,16 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             for (int i = 0; i < 7; i++) tapSum += c->taps[i];
             float* const mKps = mirror ? reinterpret_cast<float*>(mirror + mirrorMetaBytes) : nullptr;
             uint8_t* const mDesc = mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr;
-            if (tapSum > 256)
-        hipLaunchKernelGGL((k_orient_blur_desc<0, true>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
-                           c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                           c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0, mKps, mDesc);
-            else
-        hipLaunchKernelGGL((k_orient_blur_desc<0, false>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,
-                           c->d_pyr.p, c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
-                           c->d_patternF.p, c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0,
-                           (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes, trigTab.full, c->atanFma, nullptr, 0, mKps, mDesc);
+#define ORBFE_DESC_LAUNCH(SAT)                                                                                            \
+    hipLaunchKernelGGL((k_orient_blur_desc<0, SAT>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,  \
+                       c->d_pyr.p, c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,     \
+                       c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
+                       c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes,     \
+                       trigTab.full, c->atanFma, nullptr, 0, d_n, d_mono, k == 0 ? d_hdr + 1 : nullptr,                    \
+                       k == 0 ? d_errOut : nullptr, needPack ? nullptr : mMeta, nimg, mKps, mDesc)
+            if (tapSum > 256) ORBFE_DESC_LAUNCH(true);
+            else ORBFE_DESC_LAUNCH(false);
+#undef ORBFE_DESC_LAUNCH
         }
         if (nsub > 1) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
@@ -1107,6 +1134,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     c->lastDesc = d_desc;
     c->lastN = d_n;
     c->lastCap = capPerImg;
+    c->lastPacked = c->kb8On;
     c->lastFixups = 0;
     c->lastHostTrigCheck = hostTrigCheck;
     if (hostTrigCheck) {
@@ -1145,8 +1173,10 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         }
         if (nFix > 0) // the kernel reads the pinned list in place
             hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
-                               c->pyrStride, c->d_lg.p, c->d_work.p, d_n, capPerImg, d_kps, d_desc, c->d_taps.p,
+                               c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,
+                               c->d_lvlPre.p, c->kb8On ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p,
                                c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr, c->atanFma, nullptr, 0, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                                mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr);
         c->lastFixups = nFix;
     }
@@ -1678,7 +1708,8 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_cand.release(); c->d_keys.release(); c->d_lvlKp.release(); c->d_keyNode.release();
     c->d_cellCount.release(); c->d_lvlCount.release(); c->d_lap.release();
     c->d_fix.release(); c->d_kb8.release(); c->d_rays.release();
-    c->d_work.release();
+    c->d_destMap.release();
+    c->d_lvlPre.release();
     c->release_tables();
     for (auto& g : c->geomCache) g.release_tables();
     c->d_taps.release(); c->d_patternF.release();
@@ -2239,6 +2270,7 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
     HIP_TRY(hipStreamSynchronize(c->stream));
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, c->d_lvlCount.p + (size_t)img * c->nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
+    n &= 0xFFFF; // (high half: the level's count of lapping-range keypoints)
     const int k = std::min(n, cap);
     if (k > 0)
         HIP_TRY(hipMemcpy(out, c->d_lvlKp.p + (size_t)img * c->kpStride + c->lg[level].kpBase, (size_t)k * 4,
@@ -2291,14 +2323,15 @@ int orbfe_debug_blurred_patch(orbfe_ctx* c, int img, int kp_index, uint8_t* out3
     float* kps = const_cast<float*>(c->lastKps);
     uint8_t* desc = const_cast<uint8_t*>(c->lastDesc);
     const dim3 grid((unsigned)((c->maxKp + 3) / 4), 1u);
-    if (tapSum > 256)
-        hipLaunchKernelGGL((k_orient_blur_desc<0, true, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
-                           c->d_work.p, c->lastN, c->lastCap, kps, desc, c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0,
-                           trigTab.codes, trigTab.full, c->atanFma, d.p, kp_index);
-    else
-        hipLaunchKernelGGL((k_orient_blur_desc<0, false, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_lg.p,
-                           c->d_work.p, c->lastN, c->lastCap, kps, desc, c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0,
-                           trigTab.codes, trigTab.full, c->atanFma, d.p, kp_index);
+    const int32_t* const dm = c->lastPacked ? c->d_destMap.p : nullptr;
+#define ORBFE_DBG_LAUNCH(SAT)                                                                                              \
+    hipLaunchKernelGGL((k_orient_blur_desc<0, SAT, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_ds.p, \
+                       c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, c->nlevels, c->d_lvlPre.p, dm, c->lastCap, kps, desc,         \
+                       c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0, trigTab.codes, trigTab.full, c->atanFma, d.p, \
+                       kp_index)
+    if (tapSum > 256) ORBFE_DBG_LAUNCH(true);
+    else ORBFE_DBG_LAUNCH(false);
+#undef ORBFE_DBG_LAUNCH
     hipError_t e = hipMemcpyAsync(out37x37, d.p, 37 * 37, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     d.release();

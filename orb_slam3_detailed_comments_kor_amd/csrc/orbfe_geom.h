@@ -85,15 +85,18 @@ struct OrbPyrRange {
 };
 #define ORBFE_PYR_TILE 24 /* tile side at the coarsest level (16: 157 us, 24: 130 us, 32: 129 us per 64 frames) */
 
-/* work item produced by K-PACK for K-DESC */
-struct OrbDescWork {
-    int16_t level, x, y; /* level coordinates of the keypoint */
-    int16_t pad;
-    int32_t dest;        /* output slot                       */
-    uint32_t roiOff;     /* level geometry copied by K-PACK: saves K-DESC a dependent load */
+/* K-DESC's view of one slot of an image's level-major keypoint slot array (slot g = lg[level].kpBase + k, the k-th
+ * keypoint K-QT kept at that level): 32 B per slot, the same for every image of a size, fetched with one scalar load.
+ * With it a wavefront needs nothing from K-PACK: its level's geometry is here, its key is lvlKp[g], its output slot the
+ * number of keypoints of the lower levels plus k. */
+struct OrbDescSlot {
+    uint32_t roiOff; /* level geometry: byte offset of ROI(0,0) inside one image's pyramid slab */
     int32_t pitch;
-    int16_t w, h;
-    int32_t pad2[2];
+    uint32_t wh;     /* w | h << 16                                                              */
+    uint32_t lk;     /* level | k << 8                                                           */
+    float scale;     /* mvScaleFactor[level]                                                     */
+    float size;      /* keypoint size of the level                                               */
+    int32_t pad[2];
 };
 
 #endif

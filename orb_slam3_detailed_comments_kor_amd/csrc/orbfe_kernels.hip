@@ -887,7 +887,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                                        size_t keyImgStride, uint32_t* __restrict__ lvlKp,
                                                        size_t kpImgStride, int32_t* __restrict__ lvlCount, int nlevels,
                                                        int32_t* __restrict__ errFlag, int imgBase, int keyLdsOff /* ints */,
-                                                       int keyLdsCap /* keys */)
+                                                       int keyLdsCap /* keys */,
+                                                       const int32_t* __restrict__ lap /* lapping range per image */,
+                                                       uint32_t* __restrict__ lvlPre /* per keypoint slot: stereo flag << 15 |
+                                                                                       stereo keypoints before it in its level */)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1365,24 +1368,56 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     __syncthreads();
     uint32_t* out = lvlKp + (size_t)img * kpImgStride + L.kpBase;
     const int nout = min(size, L.kpCap);
-    for (int p = tid; p < nout; p += QT_THREADS) out[p] = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
-    if (tid == 0) lvlCount[(size_t)img * nlevels + level] = nout;
+    // The mono / stereo partition of operator() (:1100-1147) is decided here, where the level's keypoints are final: a
+    // keypoint whose level-0 x lies in the image's lapping range goes to the back of the output.  Its flag and the number of
+    // such keypoints before it in the level go to lvlPre, the level's total into the high half of its count: K-DESC derives
+    // every output slot from these (no K-PACK launch).
+    {
+        const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1], scale = L.scale;
+        uint32_t* const pre = lvlPre + (size_t)img * kpImgStride + L.kpBase;
+        int run = 0, buf = 0;
+        for (int base = 0; base < nout; base += QT_THREADS, buf ^= 1) { // (uniform trip count; one barrier per round)
+            const int p = base + tid;
+            bool st = false;
+            if (p < nout) {
+                const uint32_t key = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+                out[p] = key;
+                const float sx = __fmul_rn((float)((int)(key & 0xFFF) + ORBFE_MINB), scale); // keypoint->pt *= scale (:1131-1133)
+                st = sx >= lap0 && sx <= lap1;
+            }
+            const unsigned long long m = __ballot(st);
+            int* const wc = wsum + buf * QT_WAVES;
+            if (lane == 0) wc[wave] = __popcll(m);
+            __syncthreads();
+            int before = run;
+#pragma unroll
+            for (int w = 0; w < QT_WAVES; w++) {
+                const int c = wc[w];
+                before += w < wave ? c : 0;
+                run += c;
+            }
+            if (p < nout) pre[p] = (st ? 0x8000u : 0u) | (uint32_t)(before + __popcll(m & ((1ull << lane) - 1ull)));
+        }
+        if (tid == 0) lvlCount[(size_t)img * nlevels + level] = nout | (run << 16);
+    }
     QT_STAMP(60);
     QT_WG_END();
 }
 
 // ----------------------------------------------------------------- K-PACK
-// Output order and mono/stereo partition of ORBextractor::operator() (:1100-1147): level-major,
-// list order inside a level; keypoints whose level-0 x lies in [lap0, lap1] fill the output from
-// the back, the others from the front.  Writes every KeyPoint field except the angle and a work
-// item per keypoint for K-DESC.
-#define PACK_THREADS 1024 /* one round for the usual <= 1024 keypoints per image (256: four rounds, 8.8 -> see DESIGN.md) */
+// Output order and mono/stereo partition of ORBextractor::operator() (:1100-1147): level-major, list order inside a
+// level; keypoints whose level-0 x lies in [lap0, lap1] fill the output from the back, the others from the front.
+// Round 3: only launched when that partition is not the identity -- a lapping range that can hold a keypoint (fisheye
+// rigs) -- or when bearing rays are wanted (orbfe_set_kb8).  It then writes the output slot of every keypoint slot
+// (destMap, read by K-DESC), the counts and the rays; without it K-DESC derives everything itself (output slot = number of
+// keypoints of the lower levels + index inside the level) and the pipeline is four launches.
+#define PACK_THREADS 1024 /* one round for the usual <= 1024 keypoints per image */
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __restrict__ lg, int nlevels,
                                               const uint32_t* __restrict__ lvlKp, size_t kpImgStride,
                                               const int32_t* __restrict__ lvlCount, const int32_t* __restrict__ lap,
-                                              float* __restrict__ kpsOut /* 7 floats per kp */, int capPerImg,
-                                              OrbDescWork* __restrict__ work, int32_t* __restrict__ nOut,
-                                              int32_t* __restrict__ monoOut, const float* __restrict__ kb8 /* or NULL */,
+                                              int capPerImg, int32_t* __restrict__ destMap /* per keypoint slot */,
+                                              int32_t* __restrict__ nOut, int32_t* __restrict__ monoOut,
+                                              const float* __restrict__ kb8 /* or NULL */,
                                               float* __restrict__ raysOut /* 3 floats per kp, or NULL */, int imgBase,
                                               const int32_t* __restrict__ errIn /* the batch's error word or NULL */,
                                               int32_t* __restrict__ errOut /* where the host path reads it, or NULL */,
@@ -1399,7 +1434,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
         int acc = 0;
         for (int l = 0; l < nlevels; l++) {
             lvlOff[l] = acc;
-            acc += lvlCount[(size_t)img * nlevels + l];
+            acc += lvlCount[(size_t)img * nlevels + l] & 0xFFFF; // (high half: K-QT's count of lapping-range keypoints)
         }
         lvlOff[nlevels] = acc;
         runStereo = 0;
@@ -1407,25 +1442,17 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
     __syncthreads();
     const int n = min(lvlOff[nlevels], capPerImg);
     const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1];
-    float* kimg = kpsOut + (size_t)img * capPerImg * 7;
-    OrbDescWork* wimg = work + (size_t)img * capPerImg;
     for (int base = 0; base < n; base += PACK_THREADS) {
         const int g = base + tid;
         bool stereo = false;
-        int level = 0, px = 0, py = 0;
-        float sx = 0, sy = 0, resp = 0;
+        int level = 0;
+        float sx = 0, sy = 0;
         if (g < n) {
             while (g >= lvlOff[level + 1]) level++;
             const uint32_t key = lvlKp[(size_t)img * kpImgStride + lg[level].kpBase + (g - lvlOff[level])];
-            px = (int)(key & 0xFFF) + ORBFE_MINB;
-            py = (int)((key >> 12) & 0xFFF) + ORBFE_MINB;
-            resp = (float)(key >> 24);
-            sx = (float)px;
-            sy = (float)py;
-            if (level != 0) { // keypoint->pt *= scale (:1131-1133)
-                sx = __fmul_rn(sx, lg[level].scale);
-                sy = __fmul_rn(sy, lg[level].scale);
-            }
+            // keypoint->pt *= scale (:1131-1133); the scale of level 0 is 1
+            sx = __fmul_rn((float)((int)(key & 0xFFF) + ORBFE_MINB), lg[level].scale);
+            sy = __fmul_rn((float)((int)((key >> 12) & 0xFFF) + ORBFE_MINB), lg[level].scale);
             stereo = sx >= lap0 && sx <= lap1;
         }
         const unsigned long long m = __ballot(stereo);
@@ -1436,28 +1463,9 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
         sBefore += __popcll(m & ((1ull << lane) - 1ull));
         if (g < n) {
             const int dest = stereo ? (n - 1 - sBefore) : (g - sBefore);
-            float* k = kimg + (size_t)dest * 7;
-            k[0] = sx;
-            k[1] = sy;
-            k[2] = lg[level].size;
-            k[3] = 0.f;
-            k[4] = resp;
-            reinterpret_cast<int32_t*>(k)[5] = level;
-            reinterpret_cast<int32_t*>(k)[6] = -1;
+            destMap[(size_t)img * kpImgStride + lg[level].kpBase + (g - lvlOff[level])] = dest;
             // fisheye rigs: bearing ray of the keypoint, KannalaBrandt8::unproject fused into the pack
             if (kb8 && raysOut) orbfe_kb8_unproject_dev(kb8, sx, sy, raysOut + ((size_t)img * capPerImg + dest) * 3);
-            OrbDescWork w;
-            w.level = (int16_t)level;
-            w.x = (int16_t)px;
-            w.y = (int16_t)py;
-            w.pad = 0;
-            w.dest = dest;
-            w.roiOff = lg[level].roiOff;
-            w.pitch = lg[level].pitch;
-            w.w = (int16_t)lg[level].w;
-            w.h = (int16_t)lg[level].h;
-            w.pad2[0] = w.pad2[1] = 0;
-            wimg[g] = w;
         }
         __syncthreads();
         if (tid == 0) {
@@ -1687,27 +1695,40 @@ __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
 // DBG: the instantiation orbfe_debug_blurred_patch launches (the tap's loop would otherwise sit in the hot kernel).
 template <int MODE, bool SAT, bool DBG = false>
 __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
-                                                          const OrbLevelGeom* __restrict__ lg,
-                                                          const OrbDescWork* __restrict__ work,
-                                                          const int32_t* __restrict__ nOut, int capPerImg,
+                                                          const OrbDescSlot* __restrict__ slots /* per keypoint slot */,
+                                                          int nSlots,
+                                                          const uint32_t* __restrict__ lvlKp /* K-QT's keypoints */,
+                                                          size_t kpImgStride,
+                                                          const int32_t* __restrict__ lvlCount /* count | lapping-range
+                                                                                  keypoints << 16; + 16 ints of slack */,
+                                                          int nlevels,
+                                                          const uint32_t* __restrict__ lvlPre /* K-QT's partition word per slot */,
+                                                          const int32_t* __restrict__ destMap /* K-PACK's output slots, or
+                                                                                               nullptr: identity partition */,
+                                                          int capPerImg,
                                                           float* __restrict__ kpsOut, uint8_t* __restrict__ descOut,
                                                           const int* __restrict__ taps,
                                                           const float4* __restrict__ patternF,
-                                                          int4* fixList /* MODE 0: out {img<<16|g, angle, a, b} (float
+                                                          int4* fixList /* MODE 0: out {img<<16|slot, angle, a, b} (float
                                                                            bits) after a 16-B header whose first word
-                                                                           is the count; MODE 1: in {img<<16|g, -, a, b} */,
+                                                                           is the count; MODE 1: in {img<<16|slot, -, a, b} */,
                                                           int nFix, int listFragile, int imgBase, int xcdAffine,
                                                           const uint8_t* __restrict__ trigTab /* libm codes or nullptr */,
                                                           const float2* __restrict__ trigFull /* libm values or nullptr */,
                                                           int atanFma /* fused Horner steps in fastAtan2 (D2) */,
                                                           uint8_t* __restrict__ dbgPatch /* test tap: 37x37 blurred patch */,
                                                           int dbgDest /* ... of the keypoint with this output slot */,
+                                                          int32_t* __restrict__ nOut = nullptr /* without K-PACK: counts, */,
+                                                          int32_t* __restrict__ monoOut = nullptr /* error word and the    */,
+                                                          const int32_t* __restrict__ errIn = nullptr /* mirrored metadata */,
+                                                          int32_t* __restrict__ errOut = nullptr /* are written from here */,
+                                                          int32_t* __restrict__ mirrorMeta = nullptr, int mirrorImgs = 0,
                                                           float* __restrict__ mirrorKps = nullptr /* the same outputs once more, */,
                                                           uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int img, g;
+    int img, g, imgLocal = 0;
     if (MODE == 0) {
         // XCD affinity: workgroups are dealt round-robin over the 8 XCDs in linear-id order; with a
         // multiple of 8 images every XCD keeps whole images to itself, so a pyramid is fetched into one
@@ -1718,21 +1739,79 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             by = 8 * (int)(k / gridDim.x) + (int)(lin & 7);
             bx = (int)(k % gridDim.x);
         }
+        imgLocal = by;
         img = by + imgBase;
         g = bx * 4 + wave;
-        if (g >= nOut[img]) return; // wave-uniform
     } else {
         const int f = blockIdx.x * 4 + wave;
         if (f >= nFix) return;
         img = fixList[f].x >> 16;
         g = fixList[f].x & 0xFFFF;
     }
-    const OrbDescWork w = work[(size_t)img * capPerImg + g];
-    (void)lg;
+    // The work item is wave-uniform: everything below is scalar loads, all independent of each other (one round trip in
+    // front of the patch loads): the slot's level geometry, K-QT's key in that slot, the image's level counts.
+    g = __builtin_amdgcn_readfirstlane(g);
+    img = __builtin_amdgcn_readfirstlane(img);
+    if (g >= nSlots) return;
+    typedef int i8v __attribute__((ext_vector_type(8)));
+    i8v sv, cv, cv2 = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t key, pre;
+    {
+        // one asm block so that the four loads are in flight together (left to itself the compiler waits for each in turn)
+        const OrbDescSlot* const sp = slots + g;
+        const uint32_t* const kp = lvlKp + (size_t)img * kpImgStride + g;
+        const uint32_t* const pp = lvlPre + (size_t)img * kpImgStride + g;
+        const int32_t* const cp = lvlCount + (size_t)img * nlevels;
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\t"
+                     "s_load_dwordx8 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(sv), "=&s"(key), "=&s"(pre), "=&s"(cv)
+                     : "s"(sp), "s"(kp), "s"(pp), "s"(cp)
+                     : "memory");
+        if (nlevels > 8)
+            asm volatile("s_load_dwordx8 %0, %1, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(cv2) : "s"(cp) : "memory");
+    }
+    const int level = sv[3] & 0xFF, kIn = (int)((unsigned)sv[3] >> 8);
+    // level counts: keypoints (low half) and lapping-range keypoints (high half) of the lower levels, of this level, in all
+    int below = 0, mine = 0, total = 0;
+    {
+        const int cnt[16] = {cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7], cv2[0], cv2[1], cv2[2], cv2[3], cv2[4], cv2[5], cv2[6], cv2[7]};
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            const int c = l < nlevels ? cnt[l] : 0;
+            total += c; // (both halves at once: neither sum reaches 2^15)
+            below += l < level ? c : 0;
+            mine = l == level ? c : mine;
+        }
+    }
+    const int n = total & 0xFFFF, nStereo = (int)((unsigned)total >> 16);
+    if (MODE == 0 && !destMap && nOut && g == 0 && lane == 0) {
+        // slot 0 of an image speaks for the image (what K-PACK did when it was a launch of its own)
+        nOut[img] = n;
+        monoOut[img] = n - nStereo;
+        if (errOut && errIn && imgLocal == 0) errOut[0] = errIn[0];
+        if (mirrorMeta) { // the caller reads these straight from pinned memory: no download command
+            mirrorMeta[imgLocal] = n;
+            mirrorMeta[mirrorImgs + imgLocal] = n - nStereo;
+            if (imgLocal == 0) mirrorMeta[2 * mirrorImgs] = errIn ? errIn[0] : 0;
+        }
+    }
+    if (kIn >= (mine & 0xFFFF)) return; // wave-uniform: K-QT kept fewer keypoints at this level
+    int dest;
+    if (destMap) {
+        dest = destMap[(size_t)img * kpImgStride + g];
+    } else {
+        // output order of operator() (:1100-1147): level-major; lapping-range keypoints fill the output from the back
+        const int gC = (below & 0xFFFF) + kIn, sBefore = (int)((unsigned)below >> 16) + (int)(pre & 0x7FFFu);
+        dest = (pre & 0x8000u) ? n - 1 - sBefore : gC - sBefore;
+    }
+    if ((unsigned)dest >= (unsigned)capPerImg) return;
+    struct {
+        int x, y, dest;
+    } w = {(int)(key & 0xFFF) + ORBFE_MINB, (int)((key >> 12) & 0xFFF) + ORBFE_MINB, dest};
     struct {
         int w, h, pitch;
-    } L = {w.w, w.h, w.pitch};
-    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + w.roiOff;
+    } L = {(int)(sv[2] & 0xFFFF), (int)((unsigned)sv[2] >> 16), sv[1]};
+    const uint8_t* roi = pyr + (size_t)img * pyrImgStride + (uint32_t)sv[0];
     uint8_t* raw = s_all[wave];
     uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave] + DESC_RAW_BYTES);
     uint8_t* bl = raw; // the blurred patch overwrites the raw patch once the horizontal pass is done
@@ -2005,13 +2084,23 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         if (mirrorDesc) reinterpret_cast<unsigned long long*>(mirrorDesc + slot * 32)[lane] = v;
     }
     if (MODE == 0) {
-        if (mirrorKps && lane < 7) { // the 28-byte keypoint record: six fields from K-PACK, the angle from here
-            const float f = lane == 3 ? angle : kpsOut[slot * 7 + lane];
-            mirrorKps[slot * 7 + lane] = f;
-        }
         const bool anyFrag = __ballot(frag) != 0ull;
         if (lane == 0) {
-            kpsOut[slot * 7 + 3] = angle;
+            // the 28-byte cv::KeyPoint record (:1100-1147): pt scaled to level 0 (the scale of level 0 is 1), size of the
+            // level, the angle, the FAST response, the octave, class_id -1
+            struct __attribute__((packed, aligned(4))) Rec {
+                float x, y, size, angle, response;
+                int32_t octave, classId;
+            } r;
+            r.x = __fmul_rn((float)w.x, __int_as_float(sv[4]));
+            r.y = __fmul_rn((float)w.y, __int_as_float(sv[4]));
+            r.size = __int_as_float(sv[5]);
+            r.angle = angle;
+            r.response = (float)(key >> 24);
+            r.octave = level;
+            r.classId = -1;
+            *reinterpret_cast<Rec*>(kpsOut + slot * 7) = r;
+            if (mirrorKps) *reinterpret_cast<Rec*>(mirrorKps + slot * 7) = r;
             if (anyFrag && listFragile) {
                 const int idx = atomicAdd(reinterpret_cast<int*>(fixList), 1);
                 fixList[1 + idx] = make_int4((img << 16) | g, __float_as_int(angle), __float_as_int(a), __float_as_int(b));
