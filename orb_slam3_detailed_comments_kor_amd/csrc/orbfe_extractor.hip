@@ -214,6 +214,7 @@ struct orbfe_ctx : orbfe_geom_state {
     // orbfe_set_auto_register: pageable caller buffers that came back (same address, same size) are page-locked by the
     // library on their second sighting and from then on take the DMA path; at most 16 at a time, least recently used out
     bool zeroCopy = true; // ORBFE_ZEROCOPY=0: the latency path downloads its results with a copy command (A/B)
+    bool uploadKernel = true; // ORBFE_UPLOAD_KERNEL=0: the latency path uploads its images with copy commands (A/B)
     int mirrorMaxImgs = 2; // ORBFE_MIRROR_MAX: blocking calls of up to this many images write their results to pinned memory from the kernels
     bool autoRegister = false;
     struct AutoPin {
@@ -1397,6 +1398,25 @@ int slot_prepare(orbfe_ctx* c, orbfe_ctx::HostSlot& sl, bool pipelined)
     return 0;
 }
 
+// Upload of one image out of page-locked host memory by a kernel (latency path).  Returns the device address the image
+// starts at (the destination carries the source's offset inside a 16-byte block), or nullptr when the runtime has no
+// device-side address for the host pointer (the caller then uses a copy command).
+const uint8_t* upload_by_kernel(hipStream_t s, uint8_t* d_dst /* 256-B aligned, 32 bytes of slack */, const uint8_t* h_src,
+                                size_t bytes)
+{
+    void* dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, const_cast<uint8_t*>(h_src), 0) != hipSuccess || !dv) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const size_t mis = (size_t)((uintptr_t)dv & 15u);
+    const unsigned n16 = (unsigned)((mis + bytes + 15) / 16);
+    const unsigned grid = std::min(512u, (n16 + 255u) / 256u);
+    hipLaunchKernelGGL(k_upload, dim3(grid), dim3(256), 0, s, reinterpret_cast<const orbfe_u4v*>((const uint8_t*)dv - mis),
+                       reinterpret_cast<orbfe_u4v*>(d_dst), n16);
+    return d_dst + mis;
+}
+
 // Queue one host-pointer batch: H2D of the images, the five kernels, D2H of the results.  `pipelined` puts the
 // copies on their own streams (ordered by events) so that they overlap the kernels of the neighbouring batches;
 // the blocking calls keep everything on the context's stream (no event traffic on the latency path).
@@ -1454,7 +1474,27 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     // reading the image over PCIe where it lies in page-locked memory -- was measured and dropped: 0.089 -> 0.106 ms, reads
     // across the link stall the kernel far longer than the upload command costs.)
     const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs;
-    if (allPinned) {
+    // ... and the IMAGES of such a call come in through a kernel that reads the page-locked source in 16-byte pieces
+    // (k_upload): no copy engine, hence no queue hand-over, between the host call and the first kernel.
+    const bool kernelIn = c->uploadKernel && !pipelined && nimg <= c->mirrorMaxImgs;
+    const uint8_t* d_imgBase = nullptr; // where image 0 starts on the device (set by whichever upload ran)
+    if (allPinned && kernelIn && stride <= 2 * (size_t)cols) {
+        devPitch = stride;
+        devStride = align_up(imgBytes + 32, 256);
+        if ((r = sl.d_img.ensure((size_t)nimg * devStride + 256)) < 0) return r;
+        for (int i = 0; i < nimg; i++) {
+            const uint8_t* at = upload_by_kernel(s, sl.d_img.p + (size_t)i * devStride, imgs[i], imgBytes);
+            const uint8_t* want = at ? at - (size_t)i * devStride : nullptr;
+            if (!at || (i > 0 && want != d_imgBase)) { // no device alias, or sources at different offsets in their 16-B block
+                d_imgBase = nullptr;
+                break;
+            }
+            d_imgBase = want;
+        }
+    }
+    if (d_imgBase) {
+        // (uploaded above)
+    } else if (allPinned) {
         // DMA straight from the caller's memory.  Rows are copied with their padding ((rows-1)*stride + cols bytes,
         // one linear command per image, or ONE command for the whole batch when the images are evenly spaced in one
         // buffer); the kernels then read the image with the caller's pitch.
@@ -1513,10 +1553,14 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
                               imgs[i] + (size_t)y0 * stride, stride, (size_t)cols, y1 - y0);
                 });
             }
+            if (kernelIn && upload_by_kernel(s, sl.d_img.p + (size_t)i0 * devStride, sl.h_in.p + (size_t)i0 * devStride,
+                                             (size_t)ni * devStride))
+                continue; // (the staging buffer is 16-byte aligned: the copy lands at the buffer's start)
             HIP_TRY(hipMemcpyAsync(sl.d_img.p + (size_t)i0 * devStride, sl.h_in.p + (size_t)i0 * devStride,
                                    (size_t)ni * devStride, hipMemcpyHostToDevice, sIn));
         }
     }
+    if (!d_imgBase) d_imgBase = sl.d_img.p;
     if (pipelined) {
         HIP_TRY(hipEventRecord(sl.evIn, sIn));
         HIP_TRY(hipStreamWaitEvent(s, sl.evIn, 0));
@@ -1534,7 +1578,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
         if ((r = sl.h_out.ensure(sl.metaBytes + kpsBytes + descBytes)) < 0) return r;
         mirror = sl.h_out.dev();
     }
-    r = run_device(c, nimg, sl.d_img.p, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc,
+    r = run_device(c, nimg, d_imgBase, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc,
                    cap_per_img, d_meta, d_meta + nimg, d_meta + 2 * nimg, mirror, sl.metaBytes);
     if (r < 0) return r;
     if (pipelined) {
@@ -1679,6 +1723,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_XCD_AFFINE")) c->xcdAffine = atoi(e);
     if (const char* e = getenv("ORBFE_ZEROCOPY")) c->zeroCopy = atoi(e) != 0;
+    if (const char* e = getenv("ORBFE_UPLOAD_KERNEL")) c->uploadKernel = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_MIRROR_MAX")) c->mirrorMaxImgs = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (c->nStreams > 1) {

@@ -1404,6 +1404,28 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     QT_WG_END();
 }
 
+// ----------------------------------------------------------------- K-UPLOAD
+// Latency path of a frame or two: the image comes out of page-locked HOST memory through this kernel (coalesced 16-byte
+// reads over PCIe, every thread's requests in flight at once) instead of through a copy command: a copy engine between the
+// host call and the first kernel costs a queue hand-over on each side of it.  src / dst are 16-byte aligned (the caller
+// aligns the source down and gives the destination the same offset).
+typedef unsigned int orbfe_u4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_upload(const orbfe_u4v* __restrict__ src, orbfe_u4v* __restrict__ dst, unsigned n16)
+{
+    const unsigned stride = gridDim.x * 256u;
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3u * stride < n16; i += 4u * stride) {
+        const orbfe_u4v a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                        c = __builtin_nontemporal_load(src + i + 2u * stride),
+                        d = __builtin_nontemporal_load(src + i + 3u * stride);
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2u * stride] = c;
+        dst[i + 3u * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 // ----------------------------------------------------------------- K-PACK
 // Output order and mono/stereo partition of ORBextractor::operator() (:1100-1147): level-major, list order inside a
 // level; keypoints whose level-0 x lies in [lap0, lap1] fill the output from the back, the others from the front.
