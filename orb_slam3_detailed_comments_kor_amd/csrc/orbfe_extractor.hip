@@ -1476,6 +1476,9 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs;
     // ... and the IMAGES of such a call come in through a kernel that reads the page-locked source in 16-byte pieces
     // (k_upload): no copy engine, hence no queue hand-over, between the host call and the first kernel.
+    // (Measured and not kept: staging and uploading a pageable image band by band so that the upload of one band overlaps
+    // the host copy of the next -- 2 / 3 / 4 bands: -1 / +2 / +10 us per frame, +7..13 us per stereo pair: the extra launches
+    // cost the host more than the overlap returns.)
     const bool kernelIn = c->uploadKernel && !pipelined && nimg <= c->mirrorMaxImgs;
     const uint8_t* d_imgBase = nullptr; // where image 0 starts on the device (set by whichever upload ran)
     if (allPinned && kernelIn && stride <= 2 * (size_t)cols) {
@@ -1553,9 +1556,10 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
                               imgs[i] + (size_t)y0 * stride, stride, (size_t)cols, y1 - y0);
                 });
             }
-            if (kernelIn && upload_by_kernel(s, sl.d_img.p + (size_t)i0 * devStride, sl.h_in.p + (size_t)i0 * devStride,
-                                             (size_t)ni * devStride))
-                continue; // (the staging buffer is 16-byte aligned: the copy lands at the buffer's start)
+            if (kernelIn && upload_by_kernel(s, sl.d_img.p + (((size_t)i0 * devStride) & ~(size_t)15),
+                                             sl.h_in.p + (size_t)i0 * devStride, (size_t)ni * devStride) ==
+                                sl.d_img.p + (size_t)i0 * devStride)
+                continue; // (the staging buffer is 16-byte aligned: same offset inside a 16-byte block on both sides)
             HIP_TRY(hipMemcpyAsync(sl.d_img.p + (size_t)i0 * devStride, sl.h_in.p + (size_t)i0 * devStride,
                                    (size_t)ni * devStride, hipMemcpyHostToDevice, sIn));
         }
@@ -2213,7 +2217,9 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
         HIP_TRY(hipEventRecord(left->evStereo, right->stream));
         HIP_TRY(hipStreamWaitEvent(s, left->evStereo, 0));
     }
-    float* dU = left->d_stereo.p;
+    // the kernel writes its three result arrays (one value per left keypoint each) straight into the pinned host arena:
+    // no download command between the kernel and the host's wait (ORBFE_ZEROCOPY=0: device arena + copy, for A/B)
+    float* dU = left->zeroCopy ? left->h_stereo.dev() : left->d_stereo.p;
     float* dD = dU + cap;
     int32_t* dS = reinterpret_cast<int32_t*>(dD + cap);
     const int capL = left->lastCap, capR = right->lastCap;
@@ -2223,7 +2229,7 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
                        left->lastDesc + (size_t)imgL * capL * 32, capL, right->lastKps + (size_t)imgR * capR * 7,
                        right->lastDesc + (size_t)imgR * capR * 32, capR, mb, mbf, dU, dD, dS, left->lastN + imgL,
                        right->lastN + imgR);
-    HIP_TRY(hipMemcpyAsync(left->h_stereo.p, dU, 3 * cap * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (!left->zeroCopy) HIP_TRY(hipMemcpyAsync(left->h_stereo.p, dU, 3 * cap * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const float* hU = left->h_stereo.p;
     const float* hD = hU + cap;
