@@ -1571,6 +1571,42 @@ __host__ __device__ constexpr AngleMaskTab make_angle_masks()
 }
 __constant__ AngleMaskTab c_angleMask = make_angle_masks();
 
+// IC_Angle as K-DESC evaluates it: item idx = lane + 64 k (k < 5) is dword (row r = idx / 9, dword d = idx % 9) of the
+// 31 x 9 dwords that cover the circular patch.  Everything about an item that does not depend on the pixels is in this
+// table, one 16-byte entry per (k, lane): three tap words for v_dot4_u32_u8 -- byte j holds u + 21, v + 15 and 1 where the
+// pixel (u = 4 (d + 1) + j - 21, v = r - 15) lies inside the circle, 0 elsewhere -- and the dword's byte offset in the
+// wave's raw patch.  The moments are then three accumulating dot products per item (no masks, no multiplications, no
+// index arithmetic): m10 = sum (u + 21) I - 21 sum I, m01 = sum (v + 15) I - 15 sum I.
+struct IcTab {
+    uint32_t t[5][64][4];
+};
+__host__ __device__ constexpr IcTab make_ic_tab()
+{
+    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    IcTab t = {};
+    for (int k = 0; k < 5; k++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int idx = lane + 64 * k;
+            if (idx >= 31 * 9) continue; // (all-zero taps, offset 0)
+            const int r = idx / 9, d = idx % 9, v = r - 15, av = v < 0 ? -v : v;
+            uint32_t tu = 0, tv = 0, t1 = 0;
+            for (int j = 0; j < 4; j++) {
+                const int u = 4 * (d + 1) + j - 21;
+                if (u >= -umax[av] && u <= umax[av]) {
+                    tu |= (uint32_t)(u + 21) << (8 * j);
+                    tv |= (uint32_t)(v + 15) << (8 * j);
+                    t1 |= 1u << (8 * j);
+                }
+            }
+            t.t[k][lane][0] = tu;
+            t.t[k][lane][1] = tv;
+            t.t[k][lane][2] = t1;
+            t.t[k][lane][3] = (uint32_t)((r + 6) * 44 + 4 * (d + 1));
+        }
+    return t;
+}
+__constant__ IcTab c_icTab = make_ic_tab();
+
 #define DESC_R 21    /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
 // --------------------------------------------------------------- libm trig table
 // ORBFE_TRIG_LIBM without a host round trip: for every float angle the IC_Angle can produce in
@@ -1838,52 +1874,35 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave] + DESC_RAW_BYTES);
     uint8_t* bl = raw; // the blurred patch overwrites the raw patch once the horizontal pass is done
 
-    // ---- IC_Angle masks first: they do not depend on the patch, so their loads overlap the staging
-    // item = (r, d) = (idx / 9, idx % 9), idx = lane + 64 k; +64 items = +7 rows +1 dword.  Fully unrolled
-    // so that the five mask loads (constant table, L2 latency) are all in flight before the first use.
-    int icR = lane / 9, icD = lane - 9 * (lane / 9);
-    uint32_t msk[5];
-    int rr[5], dd[5];
+    // ---- IC_Angle table entries first: they do not depend on the patch, so their loads overlap the staging
+    uint4 ict[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        rr[k] = icR;
-        dd[k] = icD;
-        const int v = min(icR, 30) - 15; // r > 30 only for lanes past the last item (k == 4), masked below
-        msk[k] = (lane + 64 * k < 31 * 9) ? c_angleMask.m[v < 0 ? -v : v][icD] : 0u;
-        icR += 7;
-        icD += 1;
-        if (icD >= 9) {
-            icD -= 9;
-            icR += 1;
-        }
-    }
+    for (int k = 0; k < 5; k++) ict[k] = *reinterpret_cast<const uint4*>(c_icTab.t[k][lane]);
     // ---- raw 43x43 patch (11 dwords per row; the 44th column is never used)
     const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R + 1 < L.w && w.y + DESC_R < L.h;
     if (inside) {
-        const uint8_t* p0 = roi + (size_t)(w.y - DESC_R) * L.pitch + (w.x - DESC_R);
-        // 473 dwords = 8 per lane (item idx = 11 * row + dword = lane + 64 k), all loads in flight before the first
-        // LDS store; global dword loads may be unaligned (the patch origin is arbitrary).  The LDS patch has 11
-        // dwords per row, so its byte offset is simply 4 * idx; the global offset advances by 5 rows + 9 dwords, or
-        // 6 rows - 2 dwords when the dword index wraps.
-        uint32_t v[8];
-        {
-            int c4 = lane - 11 * (lane / 11);
-            int off = (lane / 11) * L.pitch + 4 * c4;
-            const int stepA = 5 * L.pitch + 36, stepB = 6 * L.pitch - 8;
+        const uint8_t* p0 = roi + (size_t)(w.y - DESC_R) * L.pitch + (w.x - DESC_R); // wave-uniform
+        // Sixteen lanes per patch row, four rows per round, eleven rounds: the global offset advances by 4 rows per round
+        // (one addition) and the LDS offset by a constant (an immediate); all loads in flight before the first LDS store;
+        // global dword loads may be unaligned (the patch origin is arbitrary).  Lanes 11..15 of a row repeat column 10 and
+        // the last round's fourth row repeats row 42 (identical stores): no branches.  (The flat item list this replaces --
+        // item = lane + 64 k, 8 per lane -- needed a compare, two selects, two additions and a 64-bit address per item.)
+        const uint32_t r4 = (uint32_t)lane >> 4, c4 = min((uint32_t)lane & 15u, 10u);
+        const uint32_t pitch4 = 4u * (uint32_t)L.pitch;
+        uint32_t off = r4 * (uint32_t)L.pitch + 4u * c4;
+        const uint32_t rLast = min(40u + r4, 42u);
+        uint32_t v[11];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool valid = lane + 64 * k < DESC_RAW * 11; // only the last round has lanes past the patch
-                __builtin_memcpy(&v[k], p0 + (valid ? off : 0), 4);
-                const bool wrap = c4 >= 2;
-                off += wrap ? stepB : stepA;
-                c4 += wrap ? -2 : 9;
-            }
+        for (int k = 0; k < 10; k++) {
+            __builtin_memcpy(&v[k], p0 + off, 4);
+            off += pitch4;
         }
+        __builtin_memcpy(&v[10], p0 + (rLast * (uint32_t)L.pitch + 4u * c4), 4);
         {
-            uint32_t* dst = reinterpret_cast<uint32_t*>(raw) + lane;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(raw + r4 * DESC_RAWP + 4u * c4);
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (lane + 64 * k < DESC_RAW * 11) dst[64 * k] = v[k];
+            for (int k = 0; k < 10; k++) dst[k * DESC_RAWP] = v[k]; // (+ 4 rows = + 4 * 44 bytes = 44 dwords)
+            *reinterpret_cast<uint32_t*>(raw + rLast * DESC_RAWP + 4u * c4) = v[10];
         }
     } else {
         // BORDER_REFLECT_101 at the level edges (keypoints within 21 px of an edge, ~7 % of them): the same 8 dword
@@ -1919,18 +1938,18 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
 
     // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch of radius 15.
     // items = (row, dword): rows 6..36, dwords 1..9 (columns 4..39 cover u = -15..15 = columns 6..36)
-    int m10 = 0, m01 = 0;
+    int m10, m01;
     {
+        uint32_t a10 = 0, a01 = 0, aS = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            const int rk = min(rr[k], 30), v = rk - 15;
-            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + (rk + 6) * DESC_RAWP + 4 * (dd[k] + 1)) & msk[k];
-            // sum_k (u0 + k) * I_k = u0 * sum I_k + sum k * I_k  (two byte dot products)
-            const int S = (int)__builtin_amdgcn_udot4(px, 0x01010101u, 0u, false);
-            const int K = (int)__builtin_amdgcn_udot4(px, 0x03020100u, 0u, false);
-            m10 += __mul24(4 * (dd[k] + 1) - DESC_R, S) + K;
-            m01 += __mul24(v, S);
+            const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + ict[k].w);
+            a10 = __builtin_amdgcn_udot4(px, ict[k].x, a10, false);
+            a01 = __builtin_amdgcn_udot4(px, ict[k].y, a01, false);
+            aS = __builtin_amdgcn_udot4(px, ict[k].z, aS, false);
         }
+        m10 = (int)a10 - 21 * (int)aS;
+        m01 = (int)a01 - 15 * (int)aS;
     }
     m10 = wave_sum_i32(m10);
     m01 = wave_sum_i32(m01);
@@ -1972,10 +1991,11 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
 #define ORBFE_H3(A, B, C) \
     desc_hsat<SAT>(__builtin_amdgcn_udot4(C, C3, __builtin_amdgcn_udot4(B, B3, __builtin_amdgcn_udot4(A, A3, 0u, false), false), false))
                 uint4 o;
-                o.x = ORBFE_H0(a0, a1, a2) | (ORBFE_H0(b0, b1, b2) << 16);
-                o.y = ORBFE_H1(a0, a1, a2) | (ORBFE_H1(b0, b1, b2) << 16);
-                o.z = ORBFE_H2(a0, a1, a2) | (ORBFE_H2(b0, b1, b2) << 16);
-                o.w = ORBFE_H3(a0, a1, a2) | (ORBFE_H3(b0, b1, b2) << 16);
+                // (low halves of two sums into one dword: one v_perm_b32 instead of a shift and an or)
+                o.x = __builtin_amdgcn_perm(ORBFE_H0(b0, b1, b2), ORBFE_H0(a0, a1, a2), 0x05040100u);
+                o.y = __builtin_amdgcn_perm(ORBFE_H1(b0, b1, b2), ORBFE_H1(a0, a1, a2), 0x05040100u);
+                o.z = __builtin_amdgcn_perm(ORBFE_H2(b0, b1, b2), ORBFE_H2(a0, a1, a2), 0x05040100u);
+                o.w = __builtin_amdgcn_perm(ORBFE_H3(b0, b1, b2), ORBFE_H3(a0, a1, a2), 0x05040100u);
 #undef ORBFE_H0
 #undef ORBFE_H1
 #undef ORBFE_H2
@@ -2087,9 +2107,9 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         const float fx1 = __fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b));
         // cvRound (:113-118) = round-half-even: v_rndne_f32, reused by the fragility test below
         const float ry0 = rintf(fy0), rx0 = rintf(fx0), ry1 = rintf(fy1), rx1 = rintf(fx1);
-        const int iy0 = (int)ry0, ix0 = (int)rx0, iy1 = (int)ry1, ix1 = (int)rx1;
-        const int v0 = center[iy0 * DESC_BP + ix0];
-        const int v1 = center[iy1 * DESC_BP + ix1];
+        // byte offset iy * 40 + ix in float (small integers: exact), one conversion per tap
+        const int v0 = center[(int)__fmaf_rn(ry0, (float)DESC_BP, rx0)];
+        const int v1 = center[(int)__fmaf_rn(ry1, (float)DESC_BP, rx1)];
         word[q] = __ballot(v0 < v1);
         if (MODE == 0 && listFragile) { // wave-uniform
             // |f - round(f)| > 0.5 - FR  <=>  f is within FR of a half-integer
