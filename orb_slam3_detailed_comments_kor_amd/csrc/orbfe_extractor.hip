@@ -678,7 +678,14 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_keyNode.ensure(B * c->keyStride)) < 0) return r;
     if ((r = c->d_lvlKp.ensure(B * c->kpStride)) < 0) return r;
     if ((r = c->d_lvlPre.ensure(B * c->kpStride)) < 0) return r;
-    if ((r = c->d_lvlCount.ensure(B * c->nlevels + 16)) < 0) return r; // (+ 16: K-DESC reads the counts as whole int4s)
+    {
+        // rows of ORBFE_MAX_LEVELS counts per image, zeroed once: the levels an extractor does not have stay 0 and
+        // K-DESC sums whole rows
+        const size_t before = c->d_lvlCount.n;
+        if ((r = c->d_lvlCount.ensure(B * ORBFE_MAX_LEVELS)) < 0) return r;
+        if (c->d_lvlCount.n != before)
+            HIP_TRY(hipMemsetAsync(c->d_lvlCount.p, 0, c->d_lvlCount.n * sizeof(int32_t), c->stream)); // (ordered before K-QT)
+    }
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
     c->lapDevCount = 0; // possibly a new buffer
     if ((r = c->d_destMap.ensure(B * std::max(K, c->kpStride))) < 0) return r;
@@ -1108,15 +1115,24 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             for (int i = 0; i < 7; i++) tapSum += c->taps[i];
             float* const mKps = mirror ? reinterpret_cast<float*>(mirror + mirrorMetaBytes) : nullptr;
             uint8_t* const mDesc = mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr;
-#define ORBFE_DESC_LAUNCH(SAT)                                                                                            \
-    hipLaunchKernelGGL((k_orient_blur_desc<0, SAT>), dim3((unsigned)((c->maxKp + 3) / 4), (unsigned)ni), dim3(256), 0, q,  \
+            // whole images per XCD: (8 x workgroups per image, images / 8), image = workgroup id mod 8 + 8 y
+            const bool descAffine = c->xcdAffine && ni % 8 == 0;
+            const unsigned descWg = (unsigned)((c->maxKp + 3) / 4);
+            const dim3 descGrid = descAffine ? dim3(8u * descWg, (unsigned)(ni / 8)) : dim3(descWg, (unsigned)ni);
+#define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
+    hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid, dim3(256), 0, q,                                           \
                        c->d_pyr.p, c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,     \
                        c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
-                       c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, (c->xcdAffine && ni % 8 == 0) ? 1 : 0, trigTab.codes,     \
+                       c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, descAffine ? 1 : 0, trigTab.codes,                          \
                        trigTab.full, c->atanFma, nullptr, 0, d_n, d_mono, k == 0 ? d_hdr + 1 : nullptr,                    \
                        k == 0 ? d_errOut : nullptr, needPack ? nullptr : mMeta, nimg, mKps, mDesc)
-            if (tapSum > 256) ORBFE_DESC_LAUNCH(true);
-            else ORBFE_DESC_LAUNCH(false);
+            if (hostTrigCheck) { // (the listing of fragile keypoints is an instantiation of its own)
+                if (tapSum > 256) ORBFE_DESC_LAUNCH(2, true);
+                else ORBFE_DESC_LAUNCH(2, false);
+            } else {
+                if (tapSum > 256) ORBFE_DESC_LAUNCH(0, true);
+                else ORBFE_DESC_LAUNCH(0, false);
+            }
 #undef ORBFE_DESC_LAUNCH
         }
         if (nsub > 1) {
@@ -2320,7 +2336,7 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int32_t n = 0;
-    HIP_TRY(hipMemcpy(&n, c->d_lvlCount.p + (size_t)img * c->nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, c->d_lvlCount.p + (size_t)img * ORBFE_MAX_LEVELS + level, sizeof(int32_t), hipMemcpyDeviceToHost));
     n &= 0xFFFF; // (high half: the level's count of lapping-range keypoints)
     const int k = std::min(n, cap);
     if (k > 0)

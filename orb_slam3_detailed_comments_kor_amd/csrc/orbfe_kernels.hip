@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     // ---- roots (:540-583)
     const int nIni = L.nIni;
     if (n == 0 || nIni < 1) {
-        if (tid == 0) lvlCount[(size_t)img * nlevels + level] = 0;
+        if (tid == 0) lvlCount[(size_t)img * ORBFE_MAX_LEVELS + level] = 0;
+        for (int p = tid; p < L.kpCap; p += QT_THREADS) lvlPre[(size_t)img * kpImgStride + L.kpBase + p] = 0u; // no slot is valid
         return;
     }
     // ---- the first passes in closed form.  While 4 * (number of cells of a depth) <= N neither `size >= N` nor the
@@ -1371,7 +1372,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     // The mono / stereo partition of operator() (:1100-1147) is decided here, where the level's keypoints are final: a
     // keypoint whose level-0 x lies in the image's lapping range goes to the back of the output.  Its flag and the number of
     // such keypoints before it in the level go to lvlPre, the level's total into the high half of its count: K-DESC derives
-    // every output slot from these (no K-PACK launch).
+    // every output slot from these (no K-PACK launch).  Bit 16 marks a slot that holds a keypoint of THIS batch (the slots
+    // past the level's count are cleared), so that K-DESC's wavefronts know without the counts whether they have work.
     {
         const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1], scale = L.scale;
         uint32_t* const pre = lvlPre + (size_t)img * kpImgStride + L.kpBase;
@@ -1396,9 +1398,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 before += w < wave ? c : 0;
                 run += c;
             }
-            if (p < nout) pre[p] = (st ? 0x8000u : 0u) | (uint32_t)(before + __popcll(m & ((1ull << lane) - 1ull)));
+            if (p < nout) pre[p] = 0x10000u | (st ? 0x8000u : 0u) | (uint32_t)(before + __popcll(m & ((1ull << lane) - 1ull)));
         }
-        if (tid == 0) lvlCount[(size_t)img * nlevels + level] = nout | (run << 16);
+        for (int p = nout + tid; p < L.kpCap; p += QT_THREADS) pre[p] = 0u;
+        if (tid == 0) lvlCount[(size_t)img * ORBFE_MAX_LEVELS + level] = nout | (run << 16);
     }
     QT_STAMP(60);
     QT_WG_END();
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
         int acc = 0;
         for (int l = 0; l < nlevels; l++) {
             lvlOff[l] = acc;
-            acc += lvlCount[(size_t)img * nlevels + l] & 0xFFFF; // (high half: K-QT's count of lapping-range keypoints)
+            acc += lvlCount[(size_t)img * ORBFE_MAX_LEVELS + l] & 0xFFFF; // (high half: K-QT's count of lapping-range keypoints)
         }
         lvlOff[nlevels] = acc;
         runStereo = 0;
@@ -1722,6 +1725,21 @@ __device__ __forceinline__ int wave_sum_i32(int v)
            __builtin_amdgcn_readlane(v, 48);
 }
 
+// one IEEE single multiplication, as an instruction the compiler cannot fuse or pair
+__device__ __forceinline__ float fmul_single(float x, float y)
+{
+    float d;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+
+__device__ __forceinline__ float fma_single(float x, float k /* wave-uniform */, float z)
+{
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(k), "v"(z));
+    return d;
+}
+
 #define DESC_RAW 43  /* raw patch side */
 #define DESC_RAWP 44 /* raw pitch in bytes = 11 dwords */
 #define DESC_BW 37   /* blurred patch side */
@@ -1730,7 +1748,24 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 #define DESC_BP 40   /* pitch of the blurred patch in bytes */
 #define DESC_RAW_BYTES (DESC_RAW * DESC_RAWP + 28) /* + slack (last column group reads 12 B); multiple of 16 */
 #define DESC_H_BYTES (DESC_HPAIRS * DESC_HP * 4)
+#ifndef ORBFE_DESC_ALIAS
+#define ORBFE_DESC_ALIAS 0 /* measured: 67.8 us with (8 wavefronts per SIMD), 67.9 without (7): occupancy is not what limits it */
+#endif
+#if ORBFE_DESC_ALIAS
+// One region per wavefront holds all three buffers in turn (5440 -> 3520 bytes: eight wavefronts per SIMD instead of seven).
+// The H buffer starts at the region's base and the raw patch DESC_RAW_OFF bytes into it.  Both passes work through their
+// items in ascending row order, 64 items per round, and a round's LDS reads are issued before its writes (LDS executes a
+// wavefront's instructions in order), so a buffer may overwrite rows of its source that no LATER round reads:
+//  * horizontal pass, round k writes H pair-rows <= floor(6.4 k + 6.3) (160 B each) and later rounds read raw rows
+//    >= 2 floor(6.4 (k + 1)) (44 B each): base + 160 (p + 1) <= base + OFF + 88 floor(6.4 (k + 1)) for k = 0, 1, 2 needs
+//    OFF >= 592, 1024, 1528;
+//  * vertical pass, round k writes blurred row pairs <= floor(6.4 k + 6.3) (80 B each) at the base and later rounds read H
+//    pair-rows >= floor(6.4 (k + 1)) (160 B each): always below.
+#define DESC_RAW_OFF 1536
+#define DESC_LDS_PER_WAVE (DESC_H_BYTES > DESC_RAW_OFF + DESC_RAW_BYTES ? DESC_H_BYTES : DESC_RAW_OFF + DESC_RAW_BYTES)
+#else
 #define DESC_LDS_PER_WAVE (DESC_RAW_BYTES + DESC_H_BYTES) /* blurred patch aliases the raw patch */
+#endif
 
 // One wavefront per keypoint.  Stages the 43x43 raw neighbourhood in LDS, computes the
 // intensity-centroid angle on the raw pixels (IC_Angle :75-102), blurs only the 37x37 patch the
@@ -1740,8 +1775,9 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 //   LDS traffic is kept wide: the patch is staged as dwords, the horizontal pass is
 //   v_dot4_u32_u8 on (aligned / v_alignbyte-shifted) dwords producing 4 outputs per lane and one
 //   ds_write_b64, the vertical pass reads 4 x u16 per ds_read_b64.
-// MODE 0: trig = orbfe_sincos_cr; keypoints whose sampling grid could differ under a 1-ulp change
-//         of sin/cos are appended to fixList (angle in fixF) when listFragile is set.
+// MODE 0: trig from the libm table / orbfe_sincos_cr.
+// MODE 2: the same, and keypoints whose sampling grid could differ under a 1-ulp change of sin/cos are appended to
+//         fixList (ORBFE_TRIG_LIBM_HOSTCHECK; a mode of its own so that the hot instantiation does not carry the test).
 // MODE 1: fix-up launch: one wave per fixList entry, trig (a, b) given in fixF.
 template <bool SAT>
 __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
@@ -1757,8 +1793,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           int nSlots,
                                                           const uint32_t* __restrict__ lvlKp /* K-QT's keypoints */,
                                                           size_t kpImgStride,
-                                                          const int32_t* __restrict__ lvlCount /* count | lapping-range
-                                                                                  keypoints << 16; + 16 ints of slack */,
+                                                          const int32_t* __restrict__ lvlCount /* 16 per image: count |
+                                                                                  lapping-range keypoints << 16 */,
                                                           int nlevels,
                                                           const uint32_t* __restrict__ lvlPre /* K-QT's partition word per slot */,
                                                           const int32_t* __restrict__ destMap /* K-PACK's output slots, or
@@ -1787,92 +1823,96 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int img, g, imgLocal = 0;
-    if (MODE == 0) {
-        // XCD affinity: workgroups are dealt round-robin over the 8 XCDs in linear-id order; with a
-        // multiple of 8 images every XCD keeps whole images to itself, so a pyramid is fetched into one
-        // L2 instead of eight (measured: 258 MB -> see DESIGN.md per 64 frames)
-        int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (MODE != 1) {
+        // XCD affinity (workgroups are dealt round-robin over the 8 XCDs in linear-id order): with a multiple of 8 images
+        // the grid is (8 x workgroups per image, images / 8) and image = id mod 8 + 8 y, so every XCD keeps whole images to
+        // itself and a pyramid is fetched into one L2 instead of eight (measured: 258 MB -> see DESIGN.md per 64 frames)
         if (xcdAffine) {
-            const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, k = lin >> 3;
-            by = 8 * (int)(k / gridDim.x) + (int)(lin & 7);
-            bx = (int)(k % gridDim.x);
+            imgLocal = (int)(blockIdx.x & 7u) + 8 * (int)blockIdx.y;
+            g = (int)(blockIdx.x >> 3) * 4 + wave;
+        } else {
+            imgLocal = (int)blockIdx.y;
+            g = (int)blockIdx.x * 4 + wave;
         }
-        imgLocal = by;
-        img = by + imgBase;
-        g = bx * 4 + wave;
+        img = imgLocal + imgBase;
     } else {
         const int f = blockIdx.x * 4 + wave;
         if (f >= nFix) return;
         img = fixList[f].x >> 16;
         g = fixList[f].x & 0xFFFF;
     }
-    // The work item is wave-uniform: everything below is scalar loads, all independent of each other (one round trip in
-    // front of the patch loads): the slot's level geometry, K-QT's key in that slot, the image's level counts.
+    // The work item is wave-uniform: three scalar loads, independent of each other (one round trip in front of the patch
+    // loads): the slot's level geometry, K-QT's key in that slot and its partition word.
     g = __builtin_amdgcn_readfirstlane(g);
     img = __builtin_amdgcn_readfirstlane(img);
     if (g >= nSlots) return;
     typedef int i8v __attribute__((ext_vector_type(8)));
-    i8v sv, cv, cv2 = {0, 0, 0, 0, 0, 0, 0, 0};
+    i8v sv;
     uint32_t key, pre;
+    const uint32_t slotIdx = (uint32_t)img * (uint32_t)kpImgStride + (uint32_t)g; // (a batch's slot arrays stay below 2^32 entries)
     {
-        // one asm block so that the four loads are in flight together (left to itself the compiler waits for each in turn)
+        // one asm block so that the loads are in flight together (left to itself the compiler waits for each in turn)
         const OrbDescSlot* const sp = slots + g;
-        const uint32_t* const kp = lvlKp + (size_t)img * kpImgStride + g;
-        const uint32_t* const pp = lvlPre + (size_t)img * kpImgStride + g;
-        const int32_t* const cp = lvlCount + (size_t)img * nlevels;
-        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\t"
-                     "s_load_dwordx8 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(sv), "=&s"(key), "=&s"(pre), "=&s"(cv)
-                     : "s"(sp), "s"(kp), "s"(pp), "s"(cp)
+        const uint32_t* const kp = lvlKp + slotIdx;
+        const uint32_t* const pp = lvlPre + slotIdx;
+        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(sv), "=&s"(key), "=&s"(pre)
+                     : "s"(sp), "s"(kp), "s"(pp)
                      : "memory");
-        if (nlevels > 8)
-            asm volatile("s_load_dwordx8 %0, %1, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(cv2) : "s"(cp) : "memory");
     }
+    // the image's level counts, one per lane (keypoints in the low half, lapping-range keypoints in the high half: neither
+    // sum reaches 2^15): only the output slot needs them, at the end of the kernel
+    const int cntL = lane < ORBFE_MAX_LEVELS ? lvlCount[(size_t)img * ORBFE_MAX_LEVELS + lane] : 0;
     const int level = sv[3] & 0xFF, kIn = (int)((unsigned)sv[3] >> 8);
-    // level counts: keypoints (low half) and lapping-range keypoints (high half) of the lower levels, of this level, in all
-    int below = 0, mine = 0, total = 0;
-    {
-        const int cnt[16] = {cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7], cv2[0], cv2[1], cv2[2], cv2[3], cv2[4], cv2[5], cv2[6], cv2[7]};
-#pragma unroll
-        for (int l = 0; l < 16; l++) {
-            const int c = l < nlevels ? cnt[l] : 0;
-            total += c; // (both halves at once: neither sum reaches 2^15)
-            below += l < level ? c : 0;
-            mine = l == level ? c : mine;
+    // sums over the levels below this one / over all levels: an inclusive scan across lanes 0..15
+    auto level_sums = [&](int& below, int& total) {
+        int inc = cntL;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true); // row_shr:1
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true); // row_shr:2
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true); // row_shr:4
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true); // row_shr:8
+        total = __builtin_amdgcn_readlane(inc, ORBFE_MAX_LEVELS - 1);
+        below = __builtin_amdgcn_readlane(inc, level) - __builtin_amdgcn_readlane(cntL, level);
+    };
+    const bool speaks = MODE != 1 && !destMap && nOut && g == 0; // slot 0 of an image speaks for the image (K-PACK's
+                                                                 // duties when it is not launched)
+    auto image_outputs = [&](int total) {
+        const int n = total & 0xFFFF, nStereo = (int)((unsigned)total >> 16);
+        if (lane == 0) {
+            nOut[img] = n;
+            monoOut[img] = n - nStereo;
+            if (errOut && errIn && imgLocal == 0) errOut[0] = errIn[0];
+            if (mirrorMeta) { // the caller reads these straight from pinned memory: no download command
+                mirrorMeta[imgLocal] = n;
+                mirrorMeta[mirrorImgs + imgLocal] = n - nStereo;
+                if (imgLocal == 0) mirrorMeta[2 * mirrorImgs] = errIn ? errIn[0] : 0;
+            }
         }
-    }
-    const int n = total & 0xFFFF, nStereo = (int)((unsigned)total >> 16);
-    if (MODE == 0 && !destMap && nOut && g == 0 && lane == 0) {
-        // slot 0 of an image speaks for the image (what K-PACK did when it was a launch of its own)
-        nOut[img] = n;
-        monoOut[img] = n - nStereo;
-        if (errOut && errIn && imgLocal == 0) errOut[0] = errIn[0];
-        if (mirrorMeta) { // the caller reads these straight from pinned memory: no download command
-            mirrorMeta[imgLocal] = n;
-            mirrorMeta[mirrorImgs + imgLocal] = n - nStereo;
-            if (imgLocal == 0) mirrorMeta[2 * mirrorImgs] = errIn ? errIn[0] : 0;
+    };
+    if (!(pre & 0x10000u)) { // wave-uniform: K-QT kept fewer keypoints at this level
+        if (speaks) {
+            int below, total;
+            level_sums(below, total);
+            image_outputs(total);
         }
+        return;
     }
-    if (kIn >= (mine & 0xFFFF)) return; // wave-uniform: K-QT kept fewer keypoints at this level
-    int dest;
-    if (destMap) {
-        dest = destMap[(size_t)img * kpImgStride + g];
-    } else {
-        // output order of operator() (:1100-1147): level-major; lapping-range keypoints fill the output from the back
-        const int gC = (below & 0xFFFF) + kIn, sBefore = (int)((unsigned)below >> 16) + (int)(pre & 0x7FFFu);
-        dest = (pre & 0x8000u) ? n - 1 - sBefore : gC - sBefore;
-    }
-    if ((unsigned)dest >= (unsigned)capPerImg) return;
     struct {
         int x, y, dest;
-    } w = {(int)(key & 0xFFF) + ORBFE_MINB, (int)((key >> 12) & 0xFFF) + ORBFE_MINB, dest};
+    } w = {(int)(key & 0xFFF) + ORBFE_MINB, (int)((key >> 12) & 0xFFF) + ORBFE_MINB, 0};
     struct {
         int w, h, pitch;
     } L = {(int)(sv[2] & 0xFFFF), (int)((unsigned)sv[2] >> 16), sv[1]};
     const uint8_t* roi = pyr + (size_t)img * pyrImgStride + (uint32_t)sv[0];
+#if ORBFE_DESC_ALIAS
+    uint8_t* raw = s_all[wave] + DESC_RAW_OFF;
+    uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave]);
+    uint8_t* bl = s_all[wave]; // the blurred patch overwrites the H rows the vertical pass has consumed
+#else
     uint8_t* raw = s_all[wave];
     uint16_t* hp = reinterpret_cast<uint16_t*>(s_all[wave] + DESC_RAW_BYTES);
     uint8_t* bl = raw; // the blurred patch overwrites the raw patch once the horizontal pass is done
+#endif
 
     // ---- IC_Angle table entries first: they do not depend on the patch, so their loads overlap the staging
     uint4 ict[5];
@@ -1936,6 +1976,22 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     WAVE_SYNC();
 
+    // ---- output slot (the counts were requested at the top; by now they have arrived)
+    {
+        int below, total;
+        level_sums(below, total);
+        if (speaks) image_outputs(total);
+        if (destMap) {
+            w.dest = destMap[slotIdx];
+        } else {
+            // output order of operator() (:1100-1147): level-major; lapping-range keypoints fill the output from the back
+            const int n = total & 0xFFFF;
+            const int gC = (below & 0xFFFF) + kIn, sBefore = (int)((unsigned)below >> 16) + (int)(pre & 0x7FFFu);
+            w.dest = (pre & 0x8000u) ? n - 1 - sBefore : gC - sBefore;
+        }
+        if ((unsigned)w.dest >= (unsigned)capPerImg) return; // (cannot happen: cap >= the sum of the levels' capacities)
+    }
+
     // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the circular patch of radius 15.
     // items = (row, dword): rows 6..36, dwords 1..9 (columns 4..39 cover u = -15..15 = columns 6..36)
     int m10, m01;
@@ -1956,7 +2012,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     const float angle = fast_atan2_deg((float)m01, (float)m10, atanFma != 0);
     // libm codes of this angle (issued now, used after the blur)
     TrigFetch trigF;
-    if (MODE == 0) trigF = trig_fetch(trigTab, trigFull, angle);
+    if (MODE != 1) trigF = trig_fetch(trigTab, trigFull, angle);
 
     // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
     const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
@@ -2083,7 +2139,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     }
     // ---- steered BRIEF (:106-145)
     float a, b;
-    if (MODE == 0) {
+    if (MODE != 1) {
         trig_rotation(angle, trigF, &a, &b);
     } else {
         const int f = blockIdx.x * 4 + wave;
@@ -2101,17 +2157,18 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float4 pt = patternF[q * 64 + lane]; // (x0, y0, x1, y1) of test bit q*64+lane
-        const float fy0 = __fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a));
-        const float fx0 = __fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b));
-        const float fy1 = __fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a));
-        const float fx1 = __fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b));
+        // (single v_mul_f32: the compiler would pair these into v_pk_mul_f32, which issues at a third of the rate)
+        const float fy0 = __fadd_rn(fmul_single(pt.x, b), fmul_single(pt.y, a));
+        const float fx0 = __fsub_rn(fmul_single(pt.x, a), fmul_single(pt.y, b));
+        const float fy1 = __fadd_rn(fmul_single(pt.z, b), fmul_single(pt.w, a));
+        const float fx1 = __fsub_rn(fmul_single(pt.z, a), fmul_single(pt.w, b));
         // cvRound (:113-118) = round-half-even: v_rndne_f32, reused by the fragility test below
         const float ry0 = rintf(fy0), rx0 = rintf(fx0), ry1 = rintf(fy1), rx1 = rintf(fx1);
         // byte offset iy * 40 + ix in float (small integers: exact), one conversion per tap
-        const int v0 = center[(int)__fmaf_rn(ry0, (float)DESC_BP, rx0)];
-        const int v1 = center[(int)__fmaf_rn(ry1, (float)DESC_BP, rx1)];
+        const int v0 = center[(int)fma_single(ry0, (float)DESC_BP, rx0)];
+        const int v1 = center[(int)fma_single(ry1, (float)DESC_BP, rx1)];
         word[q] = __ballot(v0 < v1);
-        if (MODE == 0 && listFragile) { // wave-uniform
+        if (MODE == 2) { // (compile-time: only the host-check instantiation carries the test)
             // |f - round(f)| > 0.5 - FR  <=>  f is within FR of a half-integer
             const float TH = 0.5f - FR;
             frag |= fmaxf(fmaxf(fabsf(fy0 - ry0), fabsf(fx0 - rx0)), fmaxf(fabsf(fy1 - ry1), fabsf(fx1 - rx1))) > TH;
@@ -2125,8 +2182,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         // same layout as the device arrays) instead of by a download command after the kernel
         if (mirrorDesc) reinterpret_cast<unsigned long long*>(mirrorDesc + slot * 32)[lane] = v;
     }
-    if (MODE == 0) {
-        const bool anyFrag = __ballot(frag) != 0ull;
+    if (MODE != 1) {
+        const bool anyFrag = MODE == 2 && __ballot(frag) != 0ull;
         if (lane == 0) {
             // the 28-byte cv::KeyPoint record (:1100-1147): pt scaled to level 0 (the scale of level 0 is 1), size of the
             // level, the angle, the FAST response, the octave, class_id -1
@@ -2143,7 +2200,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             r.classId = -1;
             *reinterpret_cast<Rec*>(kpsOut + slot * 7) = r;
             if (mirrorKps) *reinterpret_cast<Rec*>(mirrorKps + slot * 7) = r;
-            if (anyFrag && listFragile) {
+            if (MODE == 2 && anyFrag) {
                 const int idx = atomicAdd(reinterpret_cast<int*>(fixList), 1);
                 fixList[1 + idx] = make_int4((img << 16) | g, __float_as_int(angle), __float_as_int(a), __float_as_int(b));
             }
