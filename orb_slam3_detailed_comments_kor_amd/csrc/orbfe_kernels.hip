@@ -2118,6 +2118,8 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                     outE = min(aE[0] >> 16, 255u) | (min(aE[1] >> 16, 255u) << 8) | (min(aE[2] >> 16, 255u) << 16) | (min(aE[3] >> 16, 255u) << 24);
                     outO = min(aO[0] >> 16, 255u) | (min(aO[1] >> 16, 255u) << 8) | (min(aO[2] >> 16, 255u) << 16) | (min(aO[3] >> 16, 255u) << 24);
                 } else { // <= 255 * 256 * 256 + 32768: byte 2 of each sum IS the pixel; three v_perm_b32 gather four of them
+                    // (eight ds_write_b8_d16_hi -- which store exactly that byte -- instead of six v_perm_b32 and two dword
+                    // stores: measured, 64.7 -> 65.5 us)
                     outE = __builtin_amdgcn_perm(__builtin_amdgcn_perm(aE[3], aE[2], 0x0C0C0602u),
                                                  __builtin_amdgcn_perm(aE[1], aE[0], 0x0C0C0602u), 0x05040100u);
                     outO = __builtin_amdgcn_perm(__builtin_amdgcn_perm(aO[3], aO[2], 0x0C0C0602u),
