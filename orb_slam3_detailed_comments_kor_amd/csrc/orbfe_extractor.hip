@@ -633,7 +633,8 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
         c->pyrStageX = c->pyrStageY = 0;
         for (int i = 0; i < c->pyrNtx; i++) {
             int sum = 0;
-            for (int l = 1; l < nl; l++) sum += prx[(size_t)l * c->pyrNtx + i].needHi - prx[(size_t)l * c->pyrNtx + i].lo;
+            for (int l = 1; l < nl; l++) // (x entries are staged per group of four destination columns)
+                sum += (prx[(size_t)l * c->pyrNtx + i].needHi - prx[(size_t)l * c->pyrNtx + i].lo + 3) >> 2;
             c->pyrStageX = std::max(c->pyrStageX, sum);
         }
         for (int j = 0; j < c->pyrNty; j++) {
@@ -644,7 +645,9 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
         // staged x and y entries 8 B each (y: 16-bit LDS row offsets, so a region must stay below 64 KB -- it
         // does, the whole allocation is); the kernel deals whole column groups (4 px) of a region row to its
         // 256 threads
-        c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + 8 * ((size_t)c->pyrStageX + c->pyrStageY);
+        // (x: 16 B of selectors + 16 B of weights + 4 B of source position per group; y: 8 B per row)
+        c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + 32 * (size_t)c->pyrStageX + 4 * align_up((size_t)c->pyrStageX, 4) +
+                         8 * (size_t)c->pyrStageY;
         c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk &&
                       getenv("ORBFE_PYR_UNFUSED") == nullptr;
     }

@@ -122,11 +122,15 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
     uint8_t* bufA = pyr_lds;
     uint8_t* bufB = pyr_lds + bufBytes0;
-    // staged x entry: .x = source column relative to the source region, .y = a0 | a1 << 16
+    // staged x entries, one per GROUP of four destination columns (what a thread of the level loop keeps in registers):
+    //   xsel: the four v_perm_b32 selectors that pick (I[sx], I[sx+1]) out of the group's eight source bytes,
+    //   xa:   a0 | a1 << 16 of the four columns,  xb: dword-aligned source column of the group | byte shift << 16
     // staged y entry (8 B, to keep seven workgroups per CU): .x = LDS byte offsets of the source rows sy0 | sy1 << 16
     //                 inside the source region, .y = b0 | b1 << 16  ((b * t) >> 16 == mulhi(b << 16, t))
-    uint2* xt = reinterpret_cast<uint2*>(pyr_lds + bufBytes0 + bufBytes1);
-    uint2* yt = xt + stageX;
+    uint4* xsel = reinterpret_cast<uint4*>(pyr_lds + bufBytes0 + bufBytes1);
+    uint4* xa = xsel + stageX;
+    uint32_t* xb = reinterpret_cast<uint32_t*>(xa + stageX);
+    uint2* yt = reinterpret_cast<uint2*>(xb + ((stageX + 3) & ~3));
     const int tid = threadIdx.x;
     int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z;
     if (xcdAffine) {
@@ -164,16 +168,16 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         lvRecip[tid] = ng > 1 ? (unsigned)(((1ull << 32) + (unsigned)ng - 1) / (unsigned)ng) : 0u;
         // where this level's staged x / y entries start (levels 1 .. tid-1 precede it); the last level also
         // leaves the totals.  A handful of independent loads per lane, no second barrier.
-        int xs = 0, ys = 0;
+        int xs = 0, ys = 0; // (x: in groups of four columns)
         for (int j = 1; j < tid; j++) {
             const OrbPyrRange Xj = rx[j * ntx + ti], Yj = ry[j * nty + tj];
-            xs += Xj.needHi - Xj.lo;
+            xs += (Xj.needHi - Xj.lo + 3) >> 2;
             ys += Yj.needHi - Yj.lo;
         }
         lvXo[tid] = xs;
         lvYo[tid] = ys;
         if (tid == nlevels - 1) {
-            lvXo[nlevels] = tid > 0 ? xs + (X.needHi - X.lo) : 0;
+            lvXo[nlevels] = tid > 0 ? xs + ng : 0;
             lvYo[nlevels] = tid > 0 ? ys + (Y.needHi - Y.lo) : 0;
         }
     }
@@ -186,12 +190,25 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     // global round trips in turn: 8 of the 22 us a workgroup lives.)
     {
         const int totalX = lvXo[nlevels], totalY = lvYo[nlevels];
-        for (int idx = tid; idx < totalX; idx += 256) {
+        for (int idx = tid; idx < totalX; idx += 256) { // one column group per item
             int l = 1;
             for (int j = 2; j < nlevels; j++) l = lvXo[j] <= idx ? j : l;
-            const int k = idx - lvXo[l];
-            const OrbResizeX e = xtab[lvXt[l] + lvXlo[l] + k];
-            xt[idx] = make_uint2((unsigned)((int)e.sx - lvXlo[l - 1]), (unsigned)(uint16_t)e.a0 | ((unsigned)(uint16_t)e.a1 << 16));
+            const int c0 = 4 * (idx - lvXo[l]), last = lvXneed[l] - lvXlo[l] - 1;
+            const OrbResizeX* const tab = xtab + lvXt[l] + lvXlo[l];
+            OrbResizeX e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = tab[min(c0 + k, last)];
+            uint32_t sel[4], a[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t o = (uint32_t)e[k].sx - (uint32_t)e[0].sx; // 0..6 (the host checks)
+                sel[k] = 0x0C000C00u | o | ((o + 1u) << 16);
+                a[k] = (unsigned)(uint16_t)e[k].a0 | ((unsigned)(uint16_t)e[k].a1 << 16);
+            }
+            const uint32_t x0 = (uint32_t)((int)e[0].sx - lvXlo[l - 1]); // relative to the source region
+            xsel[idx] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+            xa[idx] = make_uint4(a[0], a[1], a[2], a[3]);
+            xb[idx] = (x0 & ~3u) | ((x0 & 3u) << 16);
         }
         for (int idx = tid; idx < totalY; idx += 256) {
             int l = 1;
@@ -304,16 +321,10 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         const int rowsPerPass = rcp ? (int)__umulhi(256u, rcp) : 256;  // 256 / nG (host guarantees nG <= 256)
         const int c0 = 4 * g;
         if (rr < rowsPerPass) {
-            uint2 X[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) X[k] = xt[xo + min(c0 + k, nW - 1)];
-            const uint32_t xbase = X[0].x & ~3u, sh = X[0].x & 3u;
-            uint32_t sel[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t o = X[k].x - X[0].x; // 0..6
-                sel[k] = 0x0C000C00u | o | ((o + 1u) << 16);
-            }
+            const uint4 selv = xsel[xo + g], av = xa[xo + g];
+            const uint32_t xbw = xb[xo + g];
+            const uint32_t xbase = xbw & 0xFFFFu, sh = xbw >> 16;
+            const uint32_t sel[4] = {selv.x, selv.y, selv.z, selv.w}, aw[4] = {av.x, av.y, av.z, av.w};
             // destination addresses advance by whole passes (no per-row multiplies); the global one is a 32-bit offset from
             // the image's slab (a slab is below 4 GB: one scalar base + one vector offset per store, no 64-bit vector adds)
             uint32_t qo = (uint32_t)lvRoi[l] + (uint32_t)((ylo + rr) * gpitch + xlo + c0);
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
                 for (int k = 0; k < 4; k++) {
                     const uint32_t p0 = __builtin_amdgcn_perm(W1, W0, sel[k]); // (I[sx], I[sx+1]) as two u16
                     const uint32_t p1 = __builtin_amdgcn_perm(V1, V0, sel[k]);
-                    const pyr_us2 a = *reinterpret_cast<const pyr_us2*>(&X[k].y);
+                    const pyr_us2 a = *reinterpret_cast<const pyr_us2*>(&aw[k]);
                     const uint32_t h0 = __builtin_amdgcn_udot2(*reinterpret_cast<const pyr_us2*>(&p0), a, 0u, false);
                     const uint32_t h1 = __builtin_amdgcn_udot2(*reinterpret_cast<const pyr_us2*>(&p1), a, 0u, false);
                     // cv::resize: (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
             }
         }
         __syncthreads();
-        xo += nW;
+        xo += nG;
         yo += nH;
         uint8_t* t = const_cast<uint8_t*>(S);
         S = D;
