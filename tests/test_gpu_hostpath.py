@@ -229,3 +229,53 @@ def test_auto_register_pins_a_returning_pageable_buffer(pkg, oracle):
     mono, kps, desc = ex(imgs[1], (0, 0))
     assert np.array_equal(desc, ref[1][2])
     ex.close()
+
+
+def test_latency_path_upload_kernel_with_sources_at_odd_offsets(pkg, oracle):
+    """Blocking calls of one or two frames upload their images with a kernel that reads the page-locked source in 16-byte
+    pieces (k_upload): sources that start at any byte offset, with a row pitch that is not a multiple of four, two
+    images at different offsets inside their 16-byte blocks (the copy-command fallback), pageable sources (staged first)."""
+    H, W = 240, 376
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    cap = ex.max_keypoints(H, W)
+    frames = [pkg.synth.make_frame(H, W, 700 + i) for i in range(2)]
+    refs = _refs(oracle, frames, 500, [(0, 0)] * 2)
+    pitch = W + 11
+    buf = pkg.binding.PinnedBuffer(2 * H * pitch + 64)
+    raw = buf.array((2 * H * pitch + 64,), np.uint8)
+    for off0, off1 in ((5, 5 + H * pitch), (3, 7 + H * pitch), (16, 16 + H * pitch)):
+        raw[:] = 0
+        for i, off in enumerate((off0, off1)):
+            view = np.lib.stride_tricks.as_strided(raw[off:], shape=(H, W), strides=(pitch, 1))
+            view[:] = frames[i]
+        base = raw.ctypes.data
+        # one frame
+        kp1 = np.zeros(cap, pkg.KP_DTYPE)
+        de1 = np.zeros((cap, 32), np.uint8)
+        n1 = C.c_int(0)
+        r = ex.L.orbfe_extract(ex.h, base + off0, H, W, pitch, 0, 0, kp1.ctypes.data, de1.ctypes.data, cap, C.byref(n1))
+        assert r == refs[0][0]
+        _same(kp1[:n1.value], refs[0][1], de1[:n1.value], refs[0][2])
+        # the pair in one call
+        kps = np.zeros((2, cap), pkg.KP_DTYPE)
+        desc = np.zeros((2, cap, 32), np.uint8)
+        n = np.zeros(2, np.int32)
+        mono = np.zeros(2, np.int32)
+        ptrs = (C.c_void_p * 2)(base + off0, base + off1)
+        assert ex.L.orbfe_extract_batch(ex.h, 2, ptrs, H, W, pitch, None, kps.ctypes.data, desc.ctypes.data, cap,
+                                        n.ctypes.data, mono.ctypes.data) == 0
+        for i in range(2):
+            assert mono[i] == refs[i][0]
+            _same(kps[i, :n[i]], refs[i][1], desc[i, :n[i]], refs[i][2])
+    # pageable sources at an odd offset and pitch
+    page = np.zeros(2 * H * pitch + 64, np.uint8)
+    v = np.lib.stride_tricks.as_strided(page[9:], shape=(H, W), strides=(pitch, 1))
+    v[:] = frames[1]
+    kp1 = np.zeros(cap, pkg.KP_DTYPE)
+    de1 = np.zeros((cap, 32), np.uint8)
+    n1 = C.c_int(0)
+    r = ex.L.orbfe_extract(ex.h, page.ctypes.data + 9, H, W, pitch, 0, 0, kp1.ctypes.data, de1.ctypes.data, cap, C.byref(n1))
+    assert r == refs[1][0]
+    _same(kp1[:n1.value], refs[1][1], de1[:n1.value], refs[1][2])
+    ex.close()
+    buf.close()
