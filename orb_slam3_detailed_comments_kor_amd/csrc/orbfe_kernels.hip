@@ -593,13 +593,17 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     {
         const uint32_t nItems = (uint32_t)ch * PD, last = nItems - 1u;
         uint32_t* const T = reinterpret_cast<uint32_t*>(tile);
+        // tile dword i sits in row i / PD: global byte offset = row * pitch + 4 (i - row PD) = 4 i + row (pitch - 4 PD); the
+        // row by one multiply-high against ceil(2^32 / PD) (exact for the few thousand items of a tile)
+        constexpr uint32_t MPD = 0xFFFFFFFFu / (uint32_t)PD + 1u;
+        const uint32_t delta = c.pitch - 4u * (uint32_t)PD;
         for (uint32_t i0 = (uint32_t)tid; i0 < nItems; i0 += 5u * NT) {
             uint32_t v[5], idx[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 idx[k] = min(i0 + (uint32_t)(k * NT), last);
-                const uint32_t row = idx[k] / (uint32_t)PD, d = idx[k] - row * (uint32_t)PD;
-                v[k] = *reinterpret_cast<const uint32_t*>(gbase + (row * c.pitch + 4u * d));
+                const uint32_t row = __umulhi(idx[k], MPD);
+                v[k] = *reinterpret_cast<const uint32_t*>(gbase + (__umul24(row, delta) + 4u * idx[k]));
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) T[idx[k]] = v[k];
