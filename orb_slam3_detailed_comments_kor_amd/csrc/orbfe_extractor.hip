@@ -786,7 +786,7 @@ bool small_angles_ok()
 // directory /dev/shm, ORBFE_TRIG_CACHE=<dir> or =0 for none) named after a fingerprint of THIS host's libm, and the
 // next process -- a rank of the same job, the next run -- reads them back instead: first call 60-90 ms -> ~15 ms.
 struct TrigCacheHeader {
-    char magic[8];       // "ORBFETC2"
+    char magic[8];       // "ORBFETC3"
     uint32_t u0, n;      // first angle (bit pattern) and count
     uint64_t libmPrint;  // FNV-1a over libm's results on a sample
     uint64_t payloadSum; // FNV-1a over the code bytes
@@ -850,7 +850,7 @@ const uint8_t* trig_cache_map(const std::string& path, uint64_t print, size_t by
     if (m == MAP_FAILED) return nullptr;
     const TrigCacheHeader* hd = (const TrigCacheHeader*)m;
     const uint8_t* payload = (const uint8_t*)m + sizeof(TrigCacheHeader);
-    if (std::memcmp(hd->magic, "ORBFETC2", 8) || hd->u0 != ORBFE_TRIG_U0 || hd->n != ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u ||
+    if (std::memcmp(hd->magic, "ORBFETC3", 8) || hd->u0 != ORBFE_TRIG_U0 || hd->n != ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u ||
         hd->libmPrint != print || words_sum(payload, bytes) != hd->payloadSum) {
         munmap(m, want);
         return nullptr;
@@ -868,7 +868,7 @@ void trig_cache_store(const std::string& path, uint64_t print, const uint8_t* sr
     FILE* f = std::fopen(t.c_str(), "wb");
     if (!f) return;
     TrigCacheHeader hd;
-    std::memcpy(hd.magic, "ORBFETC2", 8);
+    std::memcpy(hd.magic, "ORBFETC3", 8);
     hd.u0 = ORBFE_TRIG_U0;
     hd.n = ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u;
     hd.libmPrint = print;

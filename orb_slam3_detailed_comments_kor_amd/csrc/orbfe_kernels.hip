@@ -1636,6 +1636,40 @@ __constant__ IcTab c_icTab = make_ic_tab();
 #define ORBFE_TRIG_U0 0x3C000000u /* bits of 2^-7 deg: below, x = angle * pi/180 < 2^-12 and cos = 1, sin = x */
 #define ORBFE_TRIG_U1 0x43B40000u /* bits of 360.0f (fastAtan2 can round up to it) */
 
+// The device-side function the codes are relative to.  It does not have to be the correctly rounded value (that is
+// orbfe_sincos_cr, ~64 double operations): any deterministic value within one bit pattern of libm's will do, and a value
+// whose relative error stays below 0.4 float ulp always is (libm's is below 0.56 ulp, so both are one of the two floats
+// that bracket the true value).  Double arithmetic with fused steps and Taylor series up to r^9 / r^10 on |r| <= pi/4
+// (truncation < 2e-9 relative): ~25 instructions, which is what K-DESC pays per keypoint with the compact table.  The
+// table build checks every angle (a code other than same / up / down raises `bad` and the mode falls back).
+__device__ __forceinline__ void trig_tab_sincos(float angle, float* s_out, float* c_out)
+{
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double x = (double)angle;
+    const double kd = floor(fma(x, TWO_OVER_PI, 0.5));
+    const int ki = (int)kd;
+    const double r = fma(-kd, PIO2_LO, fma(-kd, PIO2_HI, x));
+    const double r2 = r * r;
+    double ps = 1.0 / 362880.0;
+    ps = fma(ps, r2, -1.0 / 5040.0);
+    ps = fma(ps, r2, 1.0 / 120.0);
+    ps = fma(ps, r2, -1.0 / 6.0);
+    const float sr = (float)fma(r * r2, ps, r);
+    double pc = -1.0 / 3628800.0;
+    pc = fma(pc, r2, 1.0 / 40320.0);
+    pc = fma(pc, r2, -1.0 / 720.0);
+    pc = fma(pc, r2, 1.0 / 24.0);
+    pc = fma(pc, r2, -0.5);
+    const float cr = (float)fma(r2, pc, 1.0);
+    // quadrant: (s, c) = (sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr)
+    const bool swap = ki & 1;
+    const float s = swap ? cr : sr, c = swap ? sr : cr;
+    *s_out = __uint_as_float(__float_as_uint(s) ^ ((ki & 2) ? 0x80000000u : 0u));
+    *c_out = __uint_as_float(__float_as_uint(c) ^ (((ki + 1) & 2) ? 0x80000000u : 0u));
+}
+
 __device__ __forceinline__ unsigned trig_code(float libm, float cr)
 {
     const int d = (int)__float_as_uint(libm) - (int)__float_as_uint(cr);
@@ -1652,7 +1686,7 @@ __global__ __launch_bounds__(256) void k_trig_codes(const float2* __restrict__ l
     unsigned byte = 0;
     for (uint32_t k = 0; k < 2 && i + k < n; k++) {
         float sc, cc;
-        orbfe_sincos_cr(__fmul_rn(__uint_as_float(u0 + i + k), factorPI), &sc, &cc);
+        trig_tab_sincos(__fmul_rn(__uint_as_float(u0 + i + k), factorPI), &sc, &cc);
         const float2 L = libmAB[i + k];
         const unsigned ca = trig_code(L.x, cc), cb = trig_code(L.y, sc);
         if (ca == 3u || cb == 3u) atomicAdd(bad, 1);
@@ -1673,7 +1707,7 @@ __global__ __launch_bounds__(256) void k_trig_expand(const uint8_t* __restrict__
     if (i >= n) return;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float sc, cc;
-    orbfe_sincos_cr(__fmul_rn(__uint_as_float(u0 + i), factorPI), &sc, &cc);
+    trig_tab_sincos(__fmul_rn(__uint_as_float(u0 + i), factorPI), &sc, &cc);
     const unsigned nib = (codes[i >> 1] >> (4u * (i & 1u))) & 0xFu;
     full[i] = make_float2(trig_apply(cc, nib & 3u), trig_apply(sc, nib >> 2));
 }
@@ -1683,6 +1717,7 @@ struct TrigFetch {
     float2 ab;    // full table: libm values (valid when `have`)
     unsigned nib; // compact table: code
     bool have;
+    bool tab;     // compact table in use: the codes are relative to trig_tab_sincos
 };
 __device__ __forceinline__ TrigFetch trig_fetch(const uint8_t* __restrict__ codes, const float2* __restrict__ full,
                                                 float angleDeg)
@@ -1691,6 +1726,7 @@ __device__ __forceinline__ TrigFetch trig_fetch(const uint8_t* __restrict__ code
     f.ab = make_float2(0.f, 0.f);
     f.nib = 0u;
     f.have = false;
+    f.tab = false;
     const uint32_t idx = __float_as_uint(angleDeg) - ORBFE_TRIG_U0;
     const bool inTable = idx <= ORBFE_TRIG_U1 - ORBFE_TRIG_U0;
     if (full) {
@@ -1700,8 +1736,14 @@ __device__ __forceinline__ TrigFetch trig_fetch(const uint8_t* __restrict__ code
         } else { // below 2^-7 degrees: x < 2^-12 rad, cosf(x) == 1 and sinf(x) == x (checked when the table is built)
             f.ab = make_float2(1.0f, __fmul_rn(angleDeg, (float)(3.14159265358979323846 / 180.f)));
         }
-    } else if (codes && inTable) {
-        f.nib = ((unsigned)codes[idx >> 1] >> (4u * (idx & 1u))) & 15u;
+    } else if (codes) {
+        if (inTable) {
+            f.tab = true;
+            f.nib = ((unsigned)codes[idx >> 1] >> (4u * (idx & 1u))) & 15u;
+        } else { // (as above)
+            f.have = true;
+            f.ab = make_float2(1.0f, __fmul_rn(angleDeg, (float)(3.14159265358979323846 / 180.f)));
+        }
     }
     return f;
 }
@@ -1714,9 +1756,13 @@ __device__ __forceinline__ void trig_rotation(float angleDeg, const TrigFetch& f
         return;
     }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    orbfe_sincos_cr(__fmul_rn(angleDeg, factorPI), b, a);
-    *a = trig_apply(*a, f.nib & 3u); // host libm's cosf / sinf, bit for bit (no-ops without a table)
-    *b = trig_apply(*b, f.nib >> 2);
+    if (f.tab) { // wave-uniform: compact table -- the cheap device value moved by its code = host libm's cosf / sinf, bit for bit
+        trig_tab_sincos(__fmul_rn(angleDeg, factorPI), b, a);
+        *a = trig_apply(*a, f.nib & 3u);
+        *b = trig_apply(*b, f.nib >> 2);
+    } else { // no table: the correctly rounded value (ORBFE_TRIG_CR, and the first guess of ORBFE_TRIG_LIBM_HOSTCHECK)
+        orbfe_sincos_cr(__fmul_rn(angleDeg, factorPI), b, a);
+    }
 }
 // test hook (orbfe_debug_trig): the rotation K-DESC would use for the given angles
 __global__ __launch_bounds__(256) void k_debug_trig(const float* __restrict__ angles, int n,
