@@ -197,7 +197,7 @@ struct orbfe_ctx : orbfe_geom_state {
         DevBuf<uint8_t> d_out;  // [meta: n[B] | mono[B] | err, 64-B padded][kps B*cap*28][desc B*cap*32]
         PinBuf<uint8_t> h_in;   // staging of images that are not in pinned memory
         PinBuf<uint8_t> h_out;  // meta always; the keypoint / descriptor slabs when the caller's arrays are pageable
-        PinBuf<int32_t> h_lap;  // per-image lapping ranges, read in place by K-PACK (no H2D command)
+        PinBuf<int32_t> h_lap;  // per-image lapping ranges, read in place by K-QT (no H2D command)
         int32_t* d_lapAlias = nullptr;
         hipEvent_t evIn = nullptr, evK = nullptr, evDone = nullptr;
         bool busy = false, pipelined = false, outPinned = false;
@@ -1002,7 +1002,7 @@ inline void rec(orbfe_ctx* c, int i)
 // The whole pipeline on the context's stream.  All pointers are device pointers.
 int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch, size_t imgStride,
                const int32_t* d_lap, float* d_kps, uint8_t* d_desc, int capPerImg, int32_t* d_n, int32_t* d_mono,
-               int32_t* d_errOut = nullptr /* K-PACK copies the batch's error word here (host-pointer path) */,
+               int32_t* d_errOut = nullptr /* K-DESC (or K-PACK) copies the batch's error word here (host-pointer path) */,
                uint8_t* mirror = nullptr /* pinned host slab [meta | keypoints | descriptors] the kernels write the results
                                             into as well (device-side address; latency path of a frame or two) */,
                size_t mirrorMetaBytes = 0)
@@ -1436,7 +1436,7 @@ const uint8_t* upload_by_kernel(hipStream_t s, uint8_t* d_dst /* 256-B aligned, 
     return d_dst + mis;
 }
 
-// Queue one host-pointer batch: H2D of the images, the five kernels, D2H of the results.  `pipelined` puts the
+// Queue one host-pointer batch: H2D of the images, the four kernels, D2H of the results.  `pipelined` puts the
 // copies on their own streams (ordered by events) so that they overlap the kernels of the neighbouring batches;
 // the blocking calls keep everything on the context's stream (no event traffic on the latency path).
 int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
@@ -1464,7 +1464,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     const size_t Kc = (size_t)cap_per_img;
     const size_t imgBytes = (size_t)(rows - 1) * stride + (size_t)cols; // what may be read behind an image pointer
 
-    // ---- lapping ranges: written into pinned memory K-PACK reads in place
+    // ---- lapping ranges: written into pinned memory K-QT reads in place
     if (sl.h_lap.n < (size_t)2 * nimg) {
         if ((r = sl.h_lap.ensure((size_t)2 * std::max(nimg, 64))) < 0) return r;
         sl.d_lapAlias = sl.h_lap.dev();
@@ -1487,7 +1487,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     for (int i = 0; i < nimg && allPinned; i++) allPinned = is_pinned(c, imgs[i], imgBytes);
     size_t devPitch, devStride;
     // Latency path (a frame or a stereo pair per blocking call -- how ORB-SLAM3 itself calls the extractor): the RESULTS need
-    // no copy command.  K-PACK / K-DESC write them into the slot's pinned slab as well as into HBM (posted writes over
+    // no copy command.  K-DESC writes them into the slot's pinned slab as well as into HBM (posted writes over
     // PCIe, 60 KB per frame), which takes the download command and its ~10 us of latency off the end of the call: 0.089 ->
     // 0.080 ms per pinned frame, 0.177 -> 0.157 ms per stereo pair in one call.  (The same idea for the INPUT -- K-PYR
     // reading the image over PCIe where it lies in page-locked memory -- was measured and dropped: 0.089 -> 0.106 ms, reads

@@ -1,12 +1,15 @@
 /*
  * orbfe_kernels.hip -- gfx950 (CDNA4) kernels of the ORB extractor.
  *
- *   K-PYR   k_pyr_level0 / k_pyr_resize   ComputePyramid            src/ORBextractor.cc:1152-1177
+ *   K-PYR   k_pyr_fused (k_pyr_level0 / k_pyr_resize: unfused fallback)
+ *                                         ComputePyramid            src/ORBextractor.cc:1152-1177
  *   K-FAST  k_fast_cells                  cell loop + cv::FAST      src/ORBextractor.cc:769-854
  *   K-QT    k_octree                      DistributeOctTree         src/ORBextractor.cc:537-761
- *   K-PACK  k_pack                        output partition          src/ORBextractor.cc:1100-1147
- *   K-DESC  k_orient_blur_desc            IC_Angle + GaussianBlur + computeOrbDescriptor
- *                                                                   src/ORBextractor.cc:75-145,1114-1120
+ *                                         + the mono / stereo partition of each level (:1136-1143)
+ *   K-DESC  k_orient_blur_desc            IC_Angle + GaussianBlur + computeOrbDescriptor + the output records
+ *                                                                   src/ORBextractor.cc:75-145,1100-1147
+ *   K-PACK  k_pack                        output slots + KannalaBrandt8 rays, only with orbfe_set_kb8
+ *   K-UPLOAD k_upload                     image upload of the latency path (a frame or two per blocking call)
  *   K-BORDER k_border                     copyMakeBorder (only when mvImagePyramid is read)
  *
  * Integer / bitwise work, no MFMA.  64-lane wavefronts throughout (ballot masks are 64-bit).
