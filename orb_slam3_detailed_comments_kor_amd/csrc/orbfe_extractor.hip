@@ -249,6 +249,7 @@ struct orbfe_ctx : orbfe_geom_state {
     std::vector<hipEvent_t> ev; // kProfSets * (ORBFE_STAGE_COUNT + 1)
     bool evReady = false;
     long profCalls = 0;
+    bool packSkipped[kProfSets] = {}; // event set k was recorded without a K-PACK launch (no event between K-QT and K-DESC)
 };
 
 namespace {
@@ -1111,7 +1112,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                c->kb8On ? c->d_kb8.p : nullptr,
                                c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
                                k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr, mMeta, nimg);
-        if (nsub == 1) rec(c, 4);
+        if (nsub == 1 && needPack) rec(c, 4); // (without K-PACK no event separates K-QT from K-DESC: a record costs ~3.5 us)
+        if (c->recNow) c->packSkipped[c->profCalls % orbfe_ctx::kProfSets] = !(nsub == 1 && needPack);
         // K-DESC
         {
             int tapSum = 0;
@@ -2304,7 +2306,8 @@ int orbfe_profile_read(orbfe_ctx* c, float* ms)
         const hipEvent_t* e = &c->ev[(size_t)k * (ORBFE_STAGE_COUNT + 1)];
         for (int i = 0; i < ORBFE_STAGE_COUNT; i++) {
             float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, e[i], e[i + 1]));
+            if (c->packSkipped[k] && i == 3) continue; // no K-PACK in this set: the stage is empty ...
+            HIP_TRY(hipEventElapsedTime(&t, e[(c->packSkipped[k] && i == 4) ? 3 : i], e[i + 1])); // ... and K-DESC starts at K-QT's end
             acc[i] += t;
         }
     }
