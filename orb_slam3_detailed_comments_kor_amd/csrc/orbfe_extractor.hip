@@ -185,6 +185,7 @@ struct orbfe_ctx : orbfe_geom_state {
     DevBuf<uint32_t> d_lvlPre; // K-QT's partition word per keypoint slot
     DevBuf<int> d_taps;
     bool tapsDirty = true;
+    uint32_t tapWords[32] = {}; // host copy of what d_taps holds (stays alive while the upload is in flight)
     int lapDev0 = 0, lapDev1 = 0, lapDevCount = 0; // what d_lap currently holds (orbfe_extract_batch_device)
     DevBuf<float4> d_patternF;
     PinBuf<int4> h_fix, h_fixAB; // pinned: h_fixAB is read by the fix-up kernel directly (zero-copy)
@@ -696,7 +697,7 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
     if ((r = c->d_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fixAB.ensure(B * K + 1)) < 0) return r;
-    if ((r = c->d_taps.ensure(8)) < 0) return r;
+    if ((r = c->d_taps.ensure(32)) < 0) return r; // the seven taps, then (from word 8) K-DESC's eighteen packed tap words
     if ((r = c->d_kb8.ensure(8)) < 0) return r;
     if (c->kb8On && (r = c->d_rays.ensure(B * K * 3)) < 0) return r;
     if (!c->d_patternF.p) {
@@ -1019,7 +1020,32 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     const TrigTabs trigTab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, s) : TrigTabs{nullptr, nullptr};
     const bool hostTrigCheck = c->trigMode != ORBFE_TRIG_CR && !trigTab.codes && !trigTab.full;
     if (c->tapsDirty) { // 28 bytes, but a separate command on the stream: only when they changed
-        HIP_TRY(hipMemcpyAsync(c->d_taps.p, c->taps, 7 * sizeof(int), hipMemcpyHostToDevice, s));
+        const uint32_t t0 = (uint32_t)c->taps[0], t1 = (uint32_t)c->taps[1], t2 = (uint32_t)c->taps[2], t3 = (uint32_t)c->taps[3],
+                       t4 = (uint32_t)c->taps[4], t5 = (uint32_t)c->taps[5], t6 = (uint32_t)c->taps[6];
+        uint32_t* const w = c->tapWords;
+        for (int i = 0; i < 7; i++) w[i] = (uint32_t)c->taps[i];
+        w[7] = 0;
+        // horizontal pass: byte taps of output j of a group against the three aligned dwords of its row (shifted TAPS)
+        w[8] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);
+        w[9] = t4 | (t5 << 8) | (t6 << 16);
+        w[10] = (t0 << 8) | (t1 << 16) | (t2 << 24);
+        w[11] = t3 | (t4 << 8) | (t5 << 16) | (t6 << 24);
+        w[12] = (t0 << 16) | (t1 << 24);
+        w[13] = t2 | (t3 << 8) | (t4 << 16) | (t5 << 24);
+        w[14] = t6;
+        w[15] = t0 << 24;
+        w[16] = t1 | (t2 << 8) | (t3 << 16) | (t4 << 24);
+        w[17] = t5 | (t6 << 8);
+        // vertical pass: u16 tap pairs of the even / odd output row of a pair
+        w[18] = t0 | (t1 << 16);
+        w[19] = t2 | (t3 << 16);
+        w[20] = t4 | (t5 << 16);
+        w[21] = t6;
+        w[22] = t0 << 16;
+        w[23] = t1 | (t2 << 16);
+        w[24] = t3 | (t4 << 16);
+        w[25] = t5 | (t6 << 16);
+        HIP_TRY(hipMemcpyAsync(c->d_taps.p, w, 26 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         c->tapsDirty = false;
     }
     if (c->kb8On) HIP_TRY(hipMemcpyAsync(c->d_kb8.p, c->kb8, 8 * sizeof(float), hipMemcpyHostToDevice, s));

@@ -2079,7 +2079,9 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     if (MODE != 1) trigF = trig_fetch(trigTab, trigFull, angle);
 
     // ---- separable 7-tap blur (8.8 taps; horizontal exact in u16, vertical 16.16 rounded)
-    const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3], t4 = taps[4], t5 = taps[5], t6 = taps[6];
+    // (taps[0..6] are the seven taps; taps[8..25] the eighteen tap words below, packed by the host when the taps change:
+    // forty-odd scalar shifts and ors per wavefront otherwise)
+    const uint32_t* const tw = reinterpret_cast<const uint32_t*>(taps) + 8;
     // horizontal: item = (pair of rows 2p, 2p+1; group of 4 output columns) -> 22 x 10 items; the two
     // rows are packed as the low / high u16 of one dword so that the vertical pass can use
     // v_dot2_u32_u16 on vertically adjacent values.  Output j of a group needs source bytes j..j+6 of the
@@ -2087,10 +2089,11 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     // shifted -- ten v_dot4_u32_u8 per row against wave-uniform tap words, no byte shuffles.
     uint32_t* hp2 = reinterpret_cast<uint32_t*>(hp);
     {
-        const uint32_t A0 = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), B0 = t4 | (t5 << 8) | (t6 << 16);
-        const uint32_t A1 = (t0 << 8) | (t1 << 16) | (t2 << 24), B1 = t3 | (t4 << 8) | (t5 << 16) | (t6 << 24);
-        const uint32_t A2 = (t0 << 16) | (t1 << 24), B2 = t2 | (t3 << 8) | (t4 << 16) | (t5 << 24), C2 = t6;
-        const uint32_t A3 = t0 << 24, B3 = t1 | (t2 << 8) | (t3 << 16) | (t4 << 24), C3 = t5 | (t6 << 8);
+        // A0 = t0 | t1 << 8 | t2 << 16 | t3 << 24, B0 = t4 | t5 << 8 | t6 << 16;  A1 = t0 << 8 | t1 << 16 | t2 << 24,
+        // B1 = t3 | t4 << 8 | t5 << 16 | t6 << 24;  A2 = t0 << 16 | t1 << 24, B2 = t2 | t3 << 8 | t4 << 16 | t5 << 24, C2 = t6;
+        // A3 = t0 << 24, B3 = t1 | t2 << 8 | t3 << 16 | t4 << 24, C3 = t5 | t6 << 8
+        const uint32_t A0 = tw[0], B0 = tw[1], A1 = tw[2], B1 = tw[3], A2 = tw[4], B2 = tw[5], C2 = tw[6], A3 = tw[7], B3 = tw[8],
+                       C3 = tw[9];
         // item idx = 10 * pr + hg = lane + 64 k: the H buffer is linear in idx (16 B per item); the raw offset
         // 88 * pr + 4 * hg advances by 544 (pr += 6, hg += 4) or, when hg wraps, by 592 (pr += 7, hg -= 6).
         // Pair-row 21 reads "row 43" past the patch: its values only ever meet a zero tap (row 43 is the
@@ -2139,14 +2142,15 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
             us2 v;
         };
         U2 e0, e1, e2, e3, o0, o1, o2, o3;
-        e0.u = t0 | (t1 << 16);
-        e1.u = t2 | (t3 << 16);
-        e2.u = t4 | (t5 << 16);
-        e3.u = t6;
-        o0.u = t0 << 16;
-        o1.u = t1 | (t2 << 16);
-        o2.u = t3 | (t4 << 16);
-        o3.u = t5 | (t6 << 16);
+        // e: t0 | t1 << 16, t2 | t3 << 16, t4 | t5 << 16, t6;   o: t0 << 16, t1 | t2 << 16, t3 | t4 << 16, t5 | t6 << 16
+        e0.u = tw[10];
+        e1.u = tw[11];
+        e2.u = tw[12];
+        e3.u = tw[13];
+        o0.u = tw[14];
+        o1.u = tw[15];
+        o2.u = tw[16];
+        o3.u = tw[17];
         int hg = lane - 10 * (lane / 10);
         int boff = 2 * DESC_BP * (lane / 10) + 4 * hg; // byte offset of output row 2k in the blurred patch
         const uint4* src = reinterpret_cast<const uint4*>(hp2) + lane;
