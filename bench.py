@@ -560,7 +560,6 @@ def main():
         # separate --pmc runs and corrected with the FETCH_SIZE calibration), if they match this workload
         traffic = None
         valu_issue = None
-        valu_busy = None
         per_kernel = {}
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
                      "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
@@ -587,11 +586,6 @@ def main():
                             # (profiles/r01_valu_rate.txt)
                             if "SQ_INSTS_VALU" in e and e.get("avg_duration_us"):
                                 valu_issue = min(1.0, e["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6))
-                            # the hardware's own figure: SQ_ACTIVE_INST_VALU counts, per SIMD, the 4-cycle slots in which a
-                            # vector instruction was executing; over the slots the kernel's duration offers (1024 SIMDs,
-                            # 2.4 GHz) -- it reads a few per cent above 1 when the clock runs above nominal
-                            if "SQ_ACTIVE_INST_VALU" in e and e.get("avg_duration_us"):
-                                valu_busy = e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6)
             except Exception:
                 traffic = None
         out = {
@@ -635,8 +629,6 @@ def main():
                 "traffic": traffic,
                 "valu_issue_frac": valu_issue,
                 "valu_issue_cycles_assumed": 2,
-                "valu_busy_frac": valu_busy,
-                "valu_busy_definition": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel duration), from the same counter summary",
                 "traffic_source": traffic_source if traffic is not None else None,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "event_sampling": "stage hipEvents on every %d-th of the timed steps; the sampled steps carry the seven "
