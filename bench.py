@@ -75,7 +75,7 @@ def algorithmic_bytes_per_frame(rows, cols, n_kp, nlevels=8):
         "pyramid": 2 * sp - P[-1],          # SumP_{l<7} read + SumP written
         "fast": sp,                          # every level read once
         "octree": 0,                         # candidate lists: second order, excluded by 8d
-        "pack": 0,                           # (K-PACK only runs for lapping ranges / fisheye rays since round 3)
+        "pack": 0,                           # (K-PACK only runs for fisheye rays since round 3; the records are K-DESC's)
         "desc": 2 * sp + (31 * 31 + 37 * 37) * n_kp + (32 + 28) * n_kp,  # blur r/w + patches + descriptors + KeyPoint records
         "trigfix": 0,                        # host libm check + fix-up of a handful of keypoints
     }

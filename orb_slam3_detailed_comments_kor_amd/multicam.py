@@ -197,7 +197,7 @@ class DescriptorExchange:
         (makes the current stream wait) before the slab or the gathered buffer is touched again.
         The slab must have been written on the current stream, or on `producer_stream` (a torch.cuda.Stream /
         ExternalStream), which the current stream is then made to wait for first: a collective that is not ordered
-        after the extractor's K-DESC / K-PACK would race with their writes."""
+        after the extractor's K-DESC would race with its writes."""
         if producer_stream is not None and self.slab.is_cuda:
             cur = torch.cuda.current_stream(self.slab.device)
             if producer_stream.cuda_stream != cur.cuda_stream:
