@@ -1396,6 +1396,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1], scale = L.scale;
         uint32_t* const pre = lvlPre + (size_t)img * kpImgStride + L.kpBase;
         int run = 0, buf = 0;
+        // the two usual ranges need no counting: (0, 0) of the rectified-stereo / RGB-D constructors holds no keypoint (a
+        // keypoint's level-0 x is at least ORBFE_MINB), (0, 1000) of the monocular constructor (src/Frame.cc:306) holds
+        // every keypoint of an image up to 1000 px wide
+        const float sxMax = __fmul_rn((float)L.w, scale); // >= every keypoint's level-0 x (rounding is monotonic)
+        const bool none = !(lap1 >= (float)ORBFE_MINB) || lap0 > lap1, all = !none && lap0 <= (float)ORBFE_MINB && lap1 >= sxMax;
+        if (none || all) {
+            const uint32_t flag = all ? 0x18000u : 0x10000u;
+            for (int p = tid; p < nout; p += QT_THREADS) {
+                out[p] = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+                pre[p] = flag | (all ? (uint32_t)p : 0u);
+            }
+            run = all ? nout : 0;
+        } else
         for (int base = 0; base < nout; base += QT_THREADS, buf ^= 1) { // (uniform trip count; one barrier per round)
             const int p = base + tid;
             bool st = false;
