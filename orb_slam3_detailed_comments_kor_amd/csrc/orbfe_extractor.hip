@@ -438,7 +438,9 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         // LDS: tile | score map | zone bitmap | its prefix sums | survivor queue (u16 per zone pixel)
         c->fastTileBytes = (int)(align_up((size_t)c->fastRows, 4) * c->fastPitch);
         c->fastBmWords = (int)align_up(((size_t)std::max(maxZone, 1) + 31) / 32, 4);
-        c->fastLdsBytes = align_up((size_t)2 * c->fastTileBytes + 8 * (size_t)c->fastBmWords + 2 * (size_t)std::max(maxZone, 1), 16);
+        // (the score map has four rows less than the tile: rows 2 .. rows-3)
+        c->fastLdsBytes = align_up((size_t)2 * c->fastTileBytes - (size_t)4 * c->fastPitch + 8 * (size_t)c->fastBmWords +
+                                       2 * (size_t)std::max(maxZone, 1), 16);
         c->fc.clear();
         for (const OrbCellGeom& g : c->cg) {
             OrbFastCell f;
@@ -1148,10 +1150,10 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             uint8_t* const mDesc = mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr;
             // whole images per XCD: (8 x workgroups per image, images / 8), image = workgroup id mod 8 + 8 y
             const bool descAffine = c->xcdAffine && ni % 8 == 0;
-            const unsigned descWg = (unsigned)((c->maxKp + 3) / 4);
+            const unsigned descWg = (unsigned)((c->maxKp + ORBFE_DESC_WPW - 1) / ORBFE_DESC_WPW);
             const dim3 descGrid = descAffine ? dim3(8u * descWg, (unsigned)(ni / 8)) : dim3(descWg, (unsigned)ni);
 #define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
-    hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid, dim3(256), 0, q,                                           \
+    hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid, dim3(64 * ORBFE_DESC_WPW), 0, q,                                           \
                        c->d_pyr.p, c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,     \
                        c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
                        c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, descAffine ? 1 : 0, trigTab.codes,                          \
@@ -1220,7 +1222,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             }
         }
         if (nFix > 0) // the kernel reads the pinned list in place
-            hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + 3) / 4)), dim3(256), 0, s, c->d_pyr.p,
+            hipLaunchKernelGGL((k_orient_blur_desc<1, true>), dim3((unsigned)((nFix + ORBFE_DESC_WPW - 1) / ORBFE_DESC_WPW)),
+                               dim3(64 * ORBFE_DESC_WPW), 0, s, c->d_pyr.p,
                                c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,
                                c->d_lvlPre.p, c->kb8On ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p,
                                c->d_patternF.p, c->h_fixAB.p, nFix, 0, 0, 0, nullptr, nullptr, c->atanFma, nullptr, 0, nullptr,
@@ -2421,10 +2424,10 @@ int orbfe_debug_blurred_patch(orbfe_ctx* c, int img, int kp_index, uint8_t* out3
     for (int i = 0; i < 7; i++) tapSum += c->taps[i];
     float* kps = const_cast<float*>(c->lastKps);
     uint8_t* desc = const_cast<uint8_t*>(c->lastDesc);
-    const dim3 grid((unsigned)((c->maxKp + 3) / 4), 1u);
+    const dim3 grid((unsigned)((c->maxKp + ORBFE_DESC_WPW - 1) / ORBFE_DESC_WPW), 1u);
     const int32_t* const dm = c->lastPacked ? c->d_destMap.p : nullptr;
 #define ORBFE_DBG_LAUNCH(SAT)                                                                                              \
-    hipLaunchKernelGGL((k_orient_blur_desc<0, SAT, true>), grid, dim3(256), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_ds.p, \
+    hipLaunchKernelGGL((k_orient_blur_desc<0, SAT, true>), grid, dim3(64 * ORBFE_DESC_WPW), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_ds.p, \
                        c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, c->nlevels, c->d_lvlPre.p, dm, c->lastCap, kps, desc,         \
                        c->d_taps.p, c->d_patternF.p, c->d_fix.p, 0, 0, img, 0, trigTab.codes, trigTab.full, c->atanFma, d.p, \
                        kp_index)

@@ -553,8 +553,12 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     constexpr int P = 4 * PD;
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
     uint8_t* const tile = fast_lds;
-    uint8_t* const smap = fast_lds + tileBytes;
-    uint32_t* const bm = reinterpret_cast<uint32_t*>(smap + tileBytes);
+    // the score map only has rows 2 .. rows-3 (scores live in rows 3 .. ch-4, the NMS looks one row further): its storage
+    // starts where row 2 would be, `smap` is the virtual origin of row 0
+    const int smapBytes = tileBytes - 4 * P;
+    uint8_t* const smapStore = fast_lds + tileBytes;
+    uint8_t* const smap = smapStore - 2 * P;
+    uint32_t* const bm = reinterpret_cast<uint32_t*>(smapStore + smapBytes);
     int* const pre = reinterpret_cast<int*>(bm + bmWords);
     uint16_t* const queue = reinterpret_cast<uint16_t*>(pre + bmWords);
     __shared__ int qn[2]; // survivors of the pass at iniThFAST / at minThFAST
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         qn[1] = 0;
     }
     // clear the score map and the bitmap (contiguous), 16 B per store
-    for (int o = tid * 16; o < tileBytes + 4 * bmWords; o += NT * 16) *reinterpret_cast<uint4*>(smap + o) = make_uint4(0u, 0u, 0u, 0u);
+    for (int o = tid * 16; o < smapBytes + 4 * bmWords; o += NT * 16) *reinterpret_cast<uint4*>(smapStore + o) = make_uint4(0u, 0u, 0u, 0u);
     // stage the ROI flat: tile dword i of the PD-pitched tile is LDS dword i (every row as PD dwords; the dwords past the
     // cell's own are never looked at), a thread's items are tid, tid + NT, ..., five loads in flight, a clamp instead of
     // a branch for the tail
@@ -1826,7 +1830,8 @@ __device__ __forceinline__ float fma_single(float x, float k /* wave-uniform */,
 #define DESC_RAW_BYTES (DESC_RAW * DESC_RAWP + 28) /* + slack (last column group reads 12 B); multiple of 16 */
 #define DESC_H_BYTES (DESC_HPAIRS * DESC_HP * 4)
 #ifndef ORBFE_DESC_ALIAS
-#define ORBFE_DESC_ALIAS 0 /* measured: 67.8 us with (8 wavefronts per SIMD), 67.9 without (7): occupancy is not what limits it */
+#define ORBFE_DESC_ALIAS 1 /* with four wavefronts per workgroup it made no difference (67.8 vs 67.9 us); with one it is what
+                              lifts the kernel to eight wavefronts per SIMD: 62.4 -> 59.0 us */
 #endif
 #if ORBFE_DESC_ALIAS
 // One region per wavefront holds all three buffers in turn (5440 -> 3520 bytes: eight wavefronts per SIMD instead of seven).
@@ -1864,8 +1869,14 @@ __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
 // SAT: the taps sum to more than 256 (non-default taps only), so the horizontal pass can exceed 16 bits and
 //      saturates like ufixedpoint16; with the default taps the sum is at most 255 * 256 and the min is dropped.
 // DBG: the instantiation orbfe_debug_blurred_patch launches (the tap's loop would otherwise sit in the hot kernel).
+#ifndef ORBFE_DESC_WPW
+#define ORBFE_DESC_WPW 1 /* wavefronts (= keypoint slots) per workgroup.  One: a workgroup's LDS is only released when its last
+                            wavefront ends, so with four keypoints per workgroup a slow one (a border patch) keeps the LDS
+                            of three finished ones; measured 64.7 (4) / 64.5 (2) / 62.4 (1) us, and 59.0 with one wavefront
+                            per workgroup AND the aliased buffers below (eight wavefronts per SIMD) */
+#endif
 template <int MODE, bool SAT, bool DBG = false>
-__global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
+__global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                           const OrbDescSlot* __restrict__ slots /* per keypoint slot */,
                                                           int nSlots,
                                                           const uint32_t* __restrict__ lvlKp /* K-QT's keypoints */,
@@ -1897,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
                                                           float* __restrict__ mirrorKps = nullptr /* the same outputs once more, */,
                                                           uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_all[4][(DESC_LDS_PER_WAVE + 15) & ~15];
+    __shared__ __attribute__((aligned(16))) uint8_t s_all[ORBFE_DESC_WPW][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int img, g, imgLocal = 0;
     if (MODE != 1) {
@@ -1906,14 +1917,14 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
         // itself and a pyramid is fetched into one L2 instead of eight (measured: 258 MB -> see DESIGN.md per 64 frames)
         if (xcdAffine) {
             imgLocal = (int)(blockIdx.x & 7u) + 8 * (int)blockIdx.y;
-            g = (int)(blockIdx.x >> 3) * 4 + wave;
+            g = (int)(blockIdx.x >> 3) * ORBFE_DESC_WPW + wave;
         } else {
             imgLocal = (int)blockIdx.y;
-            g = (int)blockIdx.x * 4 + wave;
+            g = (int)blockIdx.x * ORBFE_DESC_WPW + wave;
         }
         img = imgLocal + imgBase;
     } else {
-        const int f = blockIdx.x * 4 + wave;
+        const int f = blockIdx.x * ORBFE_DESC_WPW + wave;
         if (f >= nFix) return;
         img = fixList[f].x >> 16;
         g = fixList[f].x & 0xFFFF;
@@ -2225,7 +2236,7 @@ __global__ __launch_bounds__(256) void k_orient_blur_desc(const uint8_t* __restr
     if (MODE != 1) {
         trig_rotation(angle, trigF, &a, &b);
     } else {
-        const int f = blockIdx.x * 4 + wave;
+        const int f = blockIdx.x * ORBFE_DESC_WPW + wave;
         a = __int_as_float(fixList[f].z);
         b = __int_as_float(fixList[f].w);
     }
