@@ -246,6 +246,10 @@ def main():
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
     args = ap.parse_args()
+    # The same table form at every N (the scaling curve compares like with like): libm's values themselves, 1.03 GB per
+    # GPU, expanded on the device from the 65 MB of codes every rank maps from /dev/shm.  The LIBRARY's default for a rank
+    # of a multi-process job is the compact form (65 MB, K-DESC 5 us slower per 64 frames); ORBFE_TRIG_TABLE=1 measures it.
+    os.environ.setdefault("ORBFE_TRIG_TABLE", "2")
 
     import torch
     import torch.distributed as dist
@@ -611,6 +615,9 @@ def main():
                 "frames_per_step": B * world,
                 "keypoints_per_step": kp_per_step,
                 "trig": args.trig,
+                "trig_table": {"2": "full (1.03 GB per GPU, expanded on the device from the shared 65 MB of codes)",
+                               "1": "compact (65 MB of codes)", "0": "none (host check)"}.get(
+                                   os.environ.get("ORBFE_TRIG_TABLE", ""), os.environ.get("ORBFE_TRIG_TABLE", "")),
                 "contexts": 1 + len(extra),
                 "exchange": (("1 ncclAllGather of descriptor slabs per step issued by liborbfe.so (orbfe_mc_extract_exchange_"
                               "submit / _wait) on its own stream, overlapped with the next step's extraction" if mc is not None
