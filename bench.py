@@ -233,8 +233,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive child process (tools/hostbench)")
     ap.add_argument("--settle", type=float, default=0.5,
                     help="keep running untimed steps after the warm-up until this many seconds have passed")
-    ap.add_argument("--event-every", type=int, default=6,
-                    help="record the per-stage hipEvents on every N-th timed step (7 event records cost ~25 us)")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="record the per-stage hipEvents on every N-th timed step (a set of records costs ~20 us of stream "
+                         "time); 0 = max(6, steps / 20): twenty samples over the default 300 steps")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-context measurement")
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
                     help="c2: BASELINE configs[1] batched (752x480, --batch frames per GPU, weak scaling); c4: configs[3], "
@@ -246,6 +247,8 @@ def main():
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
     args = ap.parse_args()
+    if args.event_every <= 0:
+        args.event_every = max(6, args.steps // 20)
     # The same table form at every N (the scaling curve compares like with like): libm's values themselves, 1.03 GB per
     # GPU, expanded on the device from the 65 MB of codes every rank maps from /dev/shm.  The LIBRARY's default for a rank
     # of a multi-process job is the compact form (65 MB, K-DESC 5 us slower per 64 frames); ORBFE_TRIG_TABLE=1 measures it.
@@ -638,8 +641,8 @@ def main():
                 "valu_issue_cycles_assumed": 2,
                 "traffic_source": traffic_source if traffic is not None else None,
                 "algorithmic_bytes_per_launch": launch_bytes,
-                "event_sampling": "stage hipEvents on every %d-th of the timed steps; the sampled steps carry the seven "
-                                  "event records, so the stage times add up to a few per cent more than ms_per_step"
+                "event_sampling": "stage hipEvents on every %d-th of the timed steps; the sampled steps carry six event "
+                                  "records, so the stage times add up to a few per cent more than ms_per_step"
                                   % max(args.event_every, 1),
                 "avg_launch_ms": stage_ms[dom],
                 "stage_ms": stage_ms,
