@@ -1609,24 +1609,25 @@ __host__ __device__ constexpr AngleMaskTab make_angle_masks()
 }
 __constant__ AngleMaskTab c_angleMask = make_angle_masks();
 
-// IC_Angle as K-DESC evaluates it: item idx = lane + 64 k (k < 5) is dword (row r = idx / 9, dword d = idx % 9) of the
-// 31 x 9 dwords that cover the circular patch.  Everything about an item that does not depend on the pixels is in this
+// IC_Angle as K-DESC evaluates it: item idx = lane + 64 k (k < 4) is one of the 213 dwords (row r, dword d of the 31 x 9
+// that cover the circular patch's bounding box) that hold a pixel of the circle.  Everything about an item that does not depend on the pixels is in this
 // table, one 16-byte entry per (k, lane): three tap words for v_dot4_u32_u8 -- byte j holds u + 21, v + 15 and 1 where the
 // pixel (u = 4 (d + 1) + j - 21, v = r - 15) lies inside the circle, 0 elsewhere -- and the dword's byte offset in the
 // wave's raw patch.  The moments are then three accumulating dot products per item (no masks, no multiplications, no
 // index arithmetic): m10 = sum (u + 21) I - 21 sum I, m01 = sum (v + 15) I - 15 sum I.
 struct IcTab {
-    uint32_t t[5][64][4];
+    uint32_t t[4][64][4];
+    int n;
 };
 __host__ __device__ constexpr IcTab make_ic_tab()
 {
     const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     IcTab t = {};
-    for (int k = 0; k < 5; k++)
-        for (int lane = 0; lane < 64; lane++) {
-            const int idx = lane + 64 * k;
-            if (idx >= 31 * 9) continue; // (all-zero taps, offset 0)
-            const int r = idx / 9, d = idx % 9, v = r - 15, av = v < 0 ? -v : v;
+    // the 31 x 9 dwords that cover the circle's bounding box, row by row; the 66 that lie outside the circle altogether
+    // are dropped: 213 items = four rounds of 64 lanes (unused entries: all-zero taps, offset 0)
+    for (int r = 0; r < 31; r++)
+        for (int d = 0; d < 9; d++) {
+            const int v = r - 15, av = v < 0 ? -v : v;
             uint32_t tu = 0, tv = 0, t1 = 0;
             for (int j = 0; j < 4; j++) {
                 const int u = 4 * (d + 1) + j - 21;
@@ -1636,14 +1637,61 @@ __host__ __device__ constexpr IcTab make_ic_tab()
                     t1 |= 1u << (8 * j);
                 }
             }
-            t.t[k][lane][0] = tu;
-            t.t[k][lane][1] = tv;
-            t.t[k][lane][2] = t1;
-            t.t[k][lane][3] = (uint32_t)((r + 6) * 44 + 4 * (d + 1));
+            if (t1 == 0u || t.n >= 256) continue;
+            uint32_t* const e = t.t[t.n / 64][t.n % 64];
+            e[0] = tu;
+            e[1] = tv;
+            e[2] = t1;
+            e[3] = (uint32_t)((r + 6) * 44 + 4 * (d + 1));
+            t.n++;
         }
     return t;
 }
 __constant__ IcTab c_icTab = make_ic_tab();
+static_assert(make_ic_tab().n == 213, "every dword of the circle has a table entry");
+
+// The items of K-DESC's horizontal pass that can matter.  A rotated tap lands within 18.385 (the largest norm of a pattern
+// point) + 0.5 sqrt(2) (cvRound of both coordinates) of the patch centre, so the corners of the 37x37 blurred patch are
+// never sampled: of the 19 x 10 (row pair, column group) items of the vertical pass 160 hold such a pixel, and of the
+// 22 x 10 items of the horizontal pass the 190 that feed them (a vertical item reads the four row pairs below its first
+// row) -- which fit three rounds of 64 lanes instead of four.  Entry = raw byte offset 88 pr + 4 hg | item index
+// 10 pr + hg << 16, in ascending item order (the buffer-aliasing argument of the kernel's LDS layout needs ascending rows).
+struct DescHItems {
+    uint32_t t[192];
+    int n;
+    int maxPr[3]; // last row pair of rounds 0..2
+    int minPr[3]; // first row pair of rounds 0..2
+};
+__host__ __device__ constexpr DescHItems make_desc_h_items()
+{
+    DescHItems r = {};
+    bool hneed[22][10] = {};
+    for (int q = 0; q < 19; q++)
+        for (int g = 0; g < 10; g++) {
+            bool need = false;
+            for (int y = 2 * q; y <= 2 * q + 1 && y < 37; y++)
+                for (int x = 4 * g; x < 4 * g + 4 && x < 37; x++)
+                    if ((x - 18) * (x - 18) + (y - 18) * (y - 18) <= 366) need = true; // (18.385 + 0.75)^2 = 366.15
+            if (need)
+                for (int p = q; p <= q + 3; p++) hneed[p][g] = true;
+        }
+    for (int k = 0; k < 3; k++) {
+        r.maxPr[k] = -1;
+        r.minPr[k] = 99;
+    }
+    for (int p = 0; p < 22; p++)
+        for (int g = 0; g < 10; g++)
+            if (hneed[p][g] && r.n < 192) {
+                const int k = r.n / 64;
+                r.t[r.n++] = (uint32_t)(88 * p + 4 * g) | ((uint32_t)(10 * p + g) << 16);
+                if (p > r.maxPr[k]) r.maxPr[k] = p;
+                if (p < r.minPr[k]) r.minPr[k] = p;
+            }
+    return r;
+}
+__constant__ DescHItems c_descHItems = make_desc_h_items();
+constexpr DescHItems kDescHItems = make_desc_h_items();
+static_assert(kDescHItems.n > 128 && kDescHItems.n <= 192, "three rounds of 64 lanes");
 
 #define DESC_R 21    /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
 // --------------------------------------------------------------- libm trig table
@@ -1844,6 +1892,11 @@ __device__ __forceinline__ float fma_single(float x, float k /* wave-uniform */,
 //  * vertical pass, round k writes blurred row pairs <= floor(6.4 k + 6.3) (80 B each) at the base and later rounds read H
 //    pair-rows >= floor(6.4 (k + 1)) (160 B each): always below.
 #define DESC_RAW_OFF 1536
+// (the same condition for the compacted item list of the horizontal pass, whose rounds move through the row pairs faster
+// where the corners are skipped: round k's last H row pair must end below the first raw rows round k + 1 reads)
+static_assert(160 * (kDescHItems.maxPr[0] + 1) <= DESC_RAW_OFF + 88 * kDescHItems.minPr[1] &&
+                  160 * (kDescHItems.maxPr[1] + 1) <= DESC_RAW_OFF + 88 * kDescHItems.minPr[2],
+              "horizontal pass would overwrite raw rows it still has to read");
 #define DESC_LDS_PER_WAVE (DESC_H_BYTES > DESC_RAW_OFF + DESC_RAW_BYTES ? DESC_H_BYTES : DESC_RAW_OFF + DESC_RAW_BYTES)
 #else
 #define DESC_LDS_PER_WAVE (DESC_RAW_BYTES + DESC_H_BYTES) /* blurred patch aliases the raw patch */
@@ -2003,9 +2056,15 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
 #endif
 
     // ---- IC_Angle table entries first: they do not depend on the patch, so their loads overlap the staging
-    uint4 ict[5];
+    uint4 ict[4];
 #pragma unroll
-    for (int k = 0; k < 5; k++) ict[k] = *reinterpret_cast<const uint4*>(c_icTab.t[k][lane]);
+    for (int k = 0; k < 4; k++) ict[k] = *reinterpret_cast<const uint4*>(c_icTab.t[k][lane]);
+    // ... and the horizontal pass's item list (three rounds; the test tap's instantiation computes all four)
+    uint32_t hItem[3] = {0u, 0u, 0u};
+    if (!DBG) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) hItem[k] = c_descHItems.t[lane + 64 * k];
+    }
     // ---- raw 43x43 patch (11 dwords per row; the 44th column is never used)
     const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R + 1 < L.w && w.y + DESC_R < L.h;
     if (inside) {
@@ -2086,7 +2145,7 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
     {
         uint32_t a10 = 0, a01 = 0, aS = 0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 4; k++) {
             const uint32_t px = *reinterpret_cast<const uint32_t*>(raw + ict[k].w);
             a10 = __builtin_amdgcn_udot4(px, ict[k].x, a10, false);
             a01 = __builtin_amdgcn_udot4(px, ict[k].y, a01, false);
@@ -2122,36 +2181,43 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
         // 88 * pr + 4 * hg advances by 544 (pr += 6, hg += 4) or, when hg wraps, by 592 (pr += 7, hg -= 6).
         // Pair-row 21 reads "row 43" past the patch: its values only ever meet a zero tap (row 43 is the
         // high half of the last pair), and the bytes lie inside this wave's LDS region.
-        int hg = lane - 10 * (lane / 10);
-        int off = 88 * (lane / 10) + 4 * hg;
-        uint4* dst = reinterpret_cast<uint4*>(hp2) + lane;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (lane + 64 * k < DESC_HPAIRS * 10) {
-                const uint32_t* sa = reinterpret_cast<const uint32_t*>(raw + off);
-                const uint32_t a0 = sa[0], a1 = sa[1], a2 = sa[2];
-                const uint32_t b0 = sa[11], b1 = sa[12], b2 = sa[13]; // next row: + DESC_RAWP bytes
+        auto h_item = [&](int off, int idx) {
+            const uint32_t* sa = reinterpret_cast<const uint32_t*>(raw + off);
+            const uint32_t a0 = sa[0], a1 = sa[1], a2 = sa[2];
+            const uint32_t b0 = sa[11], b1 = sa[12], b2 = sa[13]; // next row: + DESC_RAWP bytes
 #define ORBFE_H0(A, B, C) desc_hsat<SAT>(__builtin_amdgcn_udot4(B, B0, __builtin_amdgcn_udot4(A, A0, 0u, false), false))
 #define ORBFE_H1(A, B, C) desc_hsat<SAT>(__builtin_amdgcn_udot4(B, B1, __builtin_amdgcn_udot4(A, A1, 0u, false), false))
 #define ORBFE_H2(A, B, C) \
     desc_hsat<SAT>(__builtin_amdgcn_udot4(C, C2, __builtin_amdgcn_udot4(B, B2, __builtin_amdgcn_udot4(A, A2, 0u, false), false), false))
 #define ORBFE_H3(A, B, C) \
     desc_hsat<SAT>(__builtin_amdgcn_udot4(C, C3, __builtin_amdgcn_udot4(B, B3, __builtin_amdgcn_udot4(A, A3, 0u, false), false), false))
-                uint4 o;
-                // (low halves of two sums into one dword: one v_perm_b32 instead of a shift and an or)
-                o.x = __builtin_amdgcn_perm(ORBFE_H0(b0, b1, b2), ORBFE_H0(a0, a1, a2), 0x05040100u);
-                o.y = __builtin_amdgcn_perm(ORBFE_H1(b0, b1, b2), ORBFE_H1(a0, a1, a2), 0x05040100u);
-                o.z = __builtin_amdgcn_perm(ORBFE_H2(b0, b1, b2), ORBFE_H2(a0, a1, a2), 0x05040100u);
-                o.w = __builtin_amdgcn_perm(ORBFE_H3(b0, b1, b2), ORBFE_H3(a0, a1, a2), 0x05040100u);
+            uint4 o;
+            // (low halves of two sums into one dword: one v_perm_b32 instead of a shift and an or)
+            o.x = __builtin_amdgcn_perm(ORBFE_H0(b0, b1, b2), ORBFE_H0(a0, a1, a2), 0x05040100u);
+            o.y = __builtin_amdgcn_perm(ORBFE_H1(b0, b1, b2), ORBFE_H1(a0, a1, a2), 0x05040100u);
+            o.z = __builtin_amdgcn_perm(ORBFE_H2(b0, b1, b2), ORBFE_H2(a0, a1, a2), 0x05040100u);
+            o.w = __builtin_amdgcn_perm(ORBFE_H3(b0, b1, b2), ORBFE_H3(a0, a1, a2), 0x05040100u);
 #undef ORBFE_H0
 #undef ORBFE_H1
 #undef ORBFE_H2
 #undef ORBFE_H3
-                dst[64 * k] = o;
+            reinterpret_cast<uint4*>(hp2)[idx] = o;
+        };
+        if (!DBG) {
+            // the 190 items whose output a rotated tap can reach (c_descHItems), three rounds
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (lane + 64 * k < kDescHItems.n) h_item((int)(hItem[k] & 0xFFFFu), (int)(hItem[k] >> 16));
+        } else {
+            int hg = lane - 10 * (lane / 10);
+            int off = 88 * (lane / 10) + 4 * hg;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (lane + 64 * k < DESC_HPAIRS * 10) h_item(off, lane + 64 * k);
+                const bool wrap = hg >= 6;
+                off += wrap ? 592 : 544;
+                hg += wrap ? -6 : 4;
             }
-            const bool wrap = hg >= 6;
-            off += wrap ? 592 : 544;
-            hg += wrap ? -6 : 4;
         }
     }
     WAVE_SYNC();
