@@ -1452,7 +1452,9 @@ int slot_prepare(orbfe_ctx* c, orbfe_ctx::HostSlot& sl, bool pipelined)
 // starts at (the destination carries the source's offset inside a 16-byte block), or nullptr when the runtime has no
 // device-side address for the host pointer (the caller then uses a copy command).
 const uint8_t* upload_by_kernel(hipStream_t s, uint8_t* d_dst /* 256-B aligned, 32 bytes of slack */, const uint8_t* h_src,
-                                size_t bytes)
+                                size_t bytes, uint8_t* d_dst2 = nullptr, const uint8_t* h_src2 = nullptr /* a second image of the
+                                same size in the same launch (both stream at once); must sit at the same offset inside its
+                                16-byte block as the first, else nothing is launched and nullptr returned */)
 {
     void* dv = nullptr;
     if (hipHostGetDevicePointer(&dv, const_cast<uint8_t*>(h_src), 0) != hipSuccess || !dv) {
@@ -1461,9 +1463,25 @@ const uint8_t* upload_by_kernel(hipStream_t s, uint8_t* d_dst /* 256-B aligned, 
     }
     const size_t mis = (size_t)((uintptr_t)dv & 15u);
     const unsigned n16 = (unsigned)((mis + bytes + 15) / 16);
-    const unsigned grid = std::min(512u, (n16 + 255u) / 256u);
-    hipLaunchKernelGGL(k_upload, dim3(grid), dim3(256), 0, s, reinterpret_cast<const orbfe_u4v*>((const uint8_t*)dv - mis),
-                       reinterpret_cast<orbfe_u4v*>(d_dst), n16);
+    OrbUploadSegs segs = {};
+    segs.src[0] = reinterpret_cast<const orbfe_u4v*>((const uint8_t*)dv - mis);
+    segs.dst[0] = reinterpret_cast<orbfe_u4v*>(d_dst);
+    segs.n16[0] = n16;
+    unsigned nseg = 1;
+    if (h_src2) {
+        void* dv2 = nullptr;
+        if (hipHostGetDevicePointer(&dv2, const_cast<uint8_t*>(h_src2), 0) != hipSuccess || !dv2 ||
+            (size_t)((uintptr_t)dv2 & 15u) != mis) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        segs.src[1] = reinterpret_cast<const orbfe_u4v*>((const uint8_t*)dv2 - mis);
+        segs.dst[1] = reinterpret_cast<orbfe_u4v*>(d_dst2);
+        segs.n16[1] = n16;
+        nseg = 2;
+    }
+    const unsigned grid = std::min(512u / nseg, (n16 + 255u) / 256u);
+    hipLaunchKernelGGL(k_upload, dim3(grid, nseg), dim3(256), 0, s, segs);
     return d_dst + mis;
 }
 
@@ -1535,14 +1553,18 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
         devPitch = stride;
         devStride = align_up(imgBytes + 32, 256);
         if ((r = sl.d_img.ensure((size_t)nimg * devStride + 256)) < 0) return r;
-        for (int i = 0; i < nimg; i++) {
-            const uint8_t* at = upload_by_kernel(s, sl.d_img.p + (size_t)i * devStride, imgs[i], imgBytes);
-            const uint8_t* want = at ? at - (size_t)i * devStride : nullptr;
-            if (!at || (i > 0 && want != d_imgBase)) { // no device alias, or sources at different offsets in their 16-B block
-                d_imgBase = nullptr;
-                break;
+        if (nimg == 2) { // a stereo pair: one launch, both images stream at once
+            d_imgBase = upload_by_kernel(s, sl.d_img.p, imgs[0], imgBytes, sl.d_img.p + devStride, imgs[1]);
+        } else {
+            for (int i = 0; i < nimg; i++) {
+                const uint8_t* at = upload_by_kernel(s, sl.d_img.p + (size_t)i * devStride, imgs[i], imgBytes);
+                const uint8_t* want = at ? at - (size_t)i * devStride : nullptr;
+                if (!at || (i > 0 && want != d_imgBase)) { // no device alias, or sources at different offsets in their 16-B block
+                    d_imgBase = nullptr;
+                    break;
+                }
+                d_imgBase = want;
             }
-            d_imgBase = want;
         }
     }
     if (d_imgBase) {

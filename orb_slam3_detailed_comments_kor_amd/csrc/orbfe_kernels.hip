@@ -1448,8 +1448,16 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
 // host call and the first kernel costs a queue hand-over on each side of it.  src / dst are 16-byte aligned (the caller
 // aligns the source down and gives the destination the same offset).
 typedef unsigned int orbfe_u4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_upload(const orbfe_u4v* __restrict__ src, orbfe_u4v* __restrict__ dst, unsigned n16)
+struct OrbUploadSegs { // up to two images per launch (a stereo pair): blockIdx.y selects the segment, so both stream at once
+    const orbfe_u4v* src[2];
+    orbfe_u4v* dst[2];
+    unsigned n16[2];
+};
+__global__ __launch_bounds__(256) void k_upload(OrbUploadSegs segs)
 {
+    const orbfe_u4v* __restrict__ src = segs.src[blockIdx.y];
+    orbfe_u4v* __restrict__ dst = segs.dst[blockIdx.y];
+    const unsigned n16 = segs.n16[blockIdx.y];
     const unsigned stride = gridDim.x * 256u;
     unsigned i = blockIdx.x * 256u + threadIdx.x;
     for (; i + 3u * stride < n16; i += 4u * stride) {
