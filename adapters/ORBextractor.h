@@ -138,16 +138,14 @@ public:
         const uint8_t* two[2] = {L.data, R.data};
         const int lap[4] = {lapLeft[0], lapLeft[1], lapRight[0], lapRight[1]};
         int n[2] = {0, 0}, mono[2] = {0, 0};
-        if (orbfe_extract_batch(ctx, 2, two, L.rows, L.cols, L.step, lap, reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(),
-                                cap, n, mono) < 0)
-            throw std::runtime_error("orbfe_extract_batch failed");
-        mvuRight.assign((size_t)n[0], -1.0f);
-        mvDepth.assign((size_t)n[0], -1.0f);
-        int matches = 0;
-        if (n[0] > 0) {
-            matches = orbfe_compute_stereo_matches_resident(ctx, 0, ctx, 1, mb, mbf, mvuRight.data(), mvDepth.data(), n[0]);
-            if (matches < 0) throw std::runtime_error("orbfe_compute_stereo_matches_resident failed");
-        }
+        // one call, one host wait: both images as a batch of two, ComputeStereoMatches queued behind them on the same stream
+        std::vector<float> uR((size_t)cap, -1.0f), dep((size_t)cap, -1.0f);
+        const int matches = orbfe_extract_stereo_pair(ctx, two[0], two[1], L.rows, L.cols, L.step, lap,
+                                                      reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(), cap, n, mono, mb, mbf,
+                                                      uR.data(), dep.data());
+        if (matches < 0) throw std::runtime_error(std::string("orbfe_extract_stereo_pair: ") + orbfe_error_string(matches));
+        mvuRight.assign(uR.begin(), uR.begin() + n[0]);
+        mvDepth.assign(dep.begin(), dep.begin() + n[0]);
         keysLeft.assign(kps.begin(), kps.begin() + n[0]);
         keysRight.assign(kps.begin() + cap, kps.begin() + cap + n[1]);
         fill_descriptors(descLeft, desc.data(), n[0]);

@@ -224,6 +224,15 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
 int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf,
                                           float* uRight, float* depth, int nL);
 
+/* A rectified stereo frame in ONE call with ONE host wait: what Frame::Frame (stereo) does with two extractor threads
+ * (src/Frame.cc:119-122) followed by ComputeStereoMatches (:797-967).  Both images go through the extractor as a batch of
+ * two (kps / desc / n_out / mono_out as orbfe_extract_batch with nimg = 2: image 0 = left, 1 = right; lap = 4 ints or
+ * NULL), the matching is queued behind the extraction on the same stream, and uRight / depth (cap_per_img floats each)
+ * receive one value per LEFT keypoint (-1 = no match).  Returns the number of stereo matches, or a negative error. */
+int orbfe_extract_stereo_pair(orbfe_ctx*, const uint8_t* imgL, const uint8_t* imgR, int rows, int cols, size_t stride,
+                              const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out,
+                              float mb, float mbf, float* uRight, float* depth);
+
 /* ---- matcher ---- */
 /* DescriptorDistance over all pairs: D[i*nB+j] = popcount(A_i xor B_j).  Host pointers. */
 int orbfe_hamming_pairs(int device, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);

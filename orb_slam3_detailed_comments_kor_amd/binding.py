@@ -230,6 +230,10 @@ def lib():
         L.orbfe_host_register.argtypes = [C.c_void_p, C.c_size_t]
         L.orbfe_set_auto_register.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_host_unregister.argtypes = [C.c_void_p]
+        L.orbfe_extract_stereo_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                                C.c_void_p, C.c_void_p]
+        L.orbfe_extract_stereo_pair.restype = C.c_int
         L.orbfe_compute_stereo_matches_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                             C.c_void_p, C.c_void_p, C.c_int]
         L.orbfe_hamming_pairs_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -291,7 +295,7 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps", "orbfe_search_projection_batch",
            "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform",
            "orbfe_extract_batch_submit", "orbfe_extract_batch_wait", "orbfe_host_alloc", "orbfe_host_free",
-           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident",
+           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident", "orbfe_extract_stereo_pair",
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
            "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
            "orbfe_vocab_load_text"]
@@ -606,6 +610,29 @@ def compute_stereo_matches_resident(exL, exR, nL, mb, mbf, imgL=0, imgR=0):
     n = _chk(lib().orbfe_compute_stereo_matches_resident(exL.h, imgL, exR.h, imgR, mb, mbf, _p(uR), _p(dep), nL),
              "orbfe_compute_stereo_matches_resident")
     return n, uR[:nL], dep[:nL]
+
+
+def extract_stereo_pair(ex, imgL, imgR, mb, mbf, lap=None):
+    """orbfe_extract_stereo_pair: both images and Frame::ComputeStereoMatches in one call with one host wait.
+    Returns (matches, (monoL, kpsL, descL), (monoR, kpsR, descR), uRight, depth)."""
+    imgL = np.ascontiguousarray(imgL, np.uint8)
+    imgR = np.ascontiguousarray(imgR, np.uint8)
+    assert imgL.shape == imgR.shape and imgL.ndim == 2
+    rows, cols = imgL.shape
+    cap = ex.max_keypoints(rows, cols)
+    kps = np.zeros((2, cap), KP_DTYPE)
+    desc = np.zeros((2, cap, 32), np.uint8)
+    n = np.zeros(2, np.int32)
+    mono = np.zeros(2, np.int32)
+    uR = np.zeros(cap, np.float32)
+    dep = np.zeros(cap, np.float32)
+    lap4 = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(4)
+    m = _chk(lib().orbfe_extract_stereo_pair(ex.h, imgL.ctypes.data, imgR.ctypes.data, rows, cols, cols,
+                                             None if lap4 is None else lap4.ctypes.data, kps.ctypes.data, desc.ctypes.data, cap,
+                                             n.ctypes.data, mono.ctypes.data, mb, mbf, uR.ctypes.data, dep.ctypes.data),
+             "orbfe_extract_stereo_pair")
+    return (m, (int(mono[0]), kps[0, :n[0]].copy(), desc[0, :n[0]].copy()), (int(mono[1]), kps[1, :n[1]].copy(), desc[1, :n[1]].copy()),
+            uR[:n[0]].copy(), dep[:n[0]].copy())
 
 
 # ------------------------------------------------------------------------ matcher

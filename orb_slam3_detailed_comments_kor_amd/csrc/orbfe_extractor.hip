@@ -237,6 +237,7 @@ struct orbfe_ctx : orbfe_geom_state {
     DevBuf<uint8_t> d_stereoIo; // orbfe_compute_stereo_matches: keypoints and descriptors of both images | uRight | depth | sad
     PinBuf<uint8_t> h_stereoIo;
     hipEvent_t evStereo = nullptr;
+    std::vector<int> stereoSads; // scratch of the outlier cut (kept: no allocation per frame)
     hipEvent_t evOutputs = nullptr; // recorded by orbfe_get_device_outputs: the point after which the resident outputs are final
 
     int lastImgs = 0;
@@ -2269,16 +2270,15 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
 
 // The same on what the two extractors' last calls left on the device: keypoints, descriptors, counts and both
 // pyramids are read in place; only uRight / depth / SAD come back (one transfer).
-int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf,
-                                          float* uRight, float* depth, int nL)
+// K-STEREO on what the two contexts' last extraction left on the device, queued on the left context's stream; the three
+// result arrays go straight into the left context's pinned arena (or, ORBFE_ZEROCOPY=0, into a device arena + copy).
+static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf)
 {
-    if (!left || !right || nL < 0 || (nL && (!uRight || !depth)) || !(mb > 0)) return ORBFE_ERR_ARGS;
     if (left->lg.empty() || right->lg.empty() || !left->lastKps || !right->lastKps || imgL < 0 || imgR < 0 ||
         imgL >= left->lastImgs || imgR >= right->lastImgs || left->device != right->device ||
         left->rows != right->rows || left->cols != right->cols || left->nlevels != right->nlevels ||
-        left->scaleFactor != right->scaleFactor || nL > left->lastCap || right->lastCap >= (1 << 20))
+        left->scaleFactor != right->scaleFactor || right->lastCap >= (1 << 20))
         return ORBFE_ERR_STATE;
-    HIP_TRY(hipSetDevice(left->device));
     int r;
     const size_t cap = (size_t)left->lastCap;
     if ((r = left->d_stereo.ensure(3 * cap)) < 0) return r;
@@ -2302,14 +2302,19 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
                        right->lastDesc + (size_t)imgR * capR * 32, capR, mb, mbf, dU, dD, dS, left->lastN + imgL,
                        right->lastN + imgR);
     if (!left->zeroCopy) HIP_TRY(hipMemcpyAsync(left->h_stereo.p, dU, 3 * cap * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+// ... and, once the stream has been waited for, the host part: the outlier cut of :952-966 over the nL results
+static int stereo_resident_finish(orbfe_ctx* left, float* uRight, float* depth, int nL)
+{
+    const size_t cap = (size_t)left->lastCap;
     const float* hU = left->h_stereo.p;
     const float* hD = hU + cap;
     const int32_t* hS = reinterpret_cast<const int32_t*>(hD + cap);
-    // outlier cut (:952-966): sorted by SAD, the matches from the back down to the first one below 1.5*1.4*median go
-    // -- i.e. every match with SAD >= that bound; the median is the element size/2 of the sorted list
-    std::vector<int> sads;
-    sads.reserve((size_t)nL);
+    // sorted by SAD, the matches from the back down to the first one below 1.5*1.4*median go -- i.e. every match with
+    // SAD >= that bound; the median is the element size/2 of the sorted list
+    std::vector<int>& sads = left->stereoSads;
+    sads.clear();
     for (int i = 0; i < nL; i++) {
         uRight[i] = hU[i];
         depth[i] = hD[i];
@@ -2329,6 +2334,39 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
         }
     }
     return kept;
+}
+
+int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf,
+                                          float* uRight, float* depth, int nL)
+{
+    if (!left || !right || nL < 0 || (nL && (!uRight || !depth)) || !(mb > 0)) return ORBFE_ERR_ARGS;
+    if (nL > left->lastCap) return ORBFE_ERR_STATE;
+    HIP_TRY(hipSetDevice(left->device));
+    int r;
+    if ((r = stereo_resident_launch(left, imgL, right, imgR, mb, mbf)) < 0) return r;
+    HIP_TRY(hipStreamSynchronize(left->stream));
+    return stereo_resident_finish(left, uRight, depth, nL);
+}
+
+// A rectified stereo frame in ONE call and ONE host wait: both images through orbfe_extract_batch's latency path and
+// Frame::ComputeStereoMatches (K-STEREO) queued behind the extraction on the same stream -- what Frame::Frame (stereo,
+// src/Frame.cc:119-122, :797-967) does with two threads, two extractors and a host loop.
+int orbfe_extract_stereo_pair(orbfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int rows, int cols, size_t stride,
+                              const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out,
+                              float mb, float mbf, float* uRight, float* depth)
+{
+    if (!c || !imgL || !imgR || !kps || !desc || !n_out || !uRight || !depth || !(mb > 0)) return ORBFE_ERR_ARGS;
+    if (c->slotSubmitted != c->slotRetired) return ORBFE_ERR_STATE; // submitted batches must be waited for first
+    const uint8_t* two[2] = {imgL, imgR};
+    int r = host_submit(c, 2, two, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false);
+    if (r < 0) return r;
+    // (the extraction is queued, c->last* describe its outputs: the matching goes behind it on the same stream)
+    r = stereo_resident_launch(c, 0, c, 1, mb, mbf);
+    const int w = host_wait(c); // always: the slot must be retired
+    if (r < 0) return r;
+    if (w < 0) return w;
+    if (n_out[0] > cap_per_img) return ORBFE_ERR_STATE;
+    return stereo_resident_finish(c, uRight, depth, n_out[0]);
 }
 
 int orbfe_profile_enable(orbfe_ctx* c, int on)

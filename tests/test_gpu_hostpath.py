@@ -279,3 +279,31 @@ def test_latency_path_upload_kernel_with_sources_at_odd_offsets(pkg, oracle):
     _same(kp1[:n1.value], refs[1][1], de1[:n1.value], refs[1][2])
     ex.close()
     buf.close()
+
+
+def test_stereo_pair_extraction_and_matching_in_one_call(pkg, oracle):
+    """orbfe_extract_stereo_pair: both images and Frame::ComputeStereoMatches behind one host wait -- keypoints, descriptors,
+    mvuRight and mvDepth identical to the oracle's (and so to the two-call form), for page-locked and pageable images, and a
+    pair whose right image holds nothing."""
+    mb, mbf = 47.90639384423901 / 435.2046959714599, 47.90639384423901
+    left, right = pkg.synth.make_stereo_pair(480, 752, 21, shift=11)
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    oL = oracle.Extractor(1200, 1.2, 8, 20, 7)
+    oR = oracle.Extractor(1200, 1.2, 8, 20, 7)
+    _, rkL, rdL = oL.extract(left, (0, 0))
+    _, rkR, rdR = oR.extract(right, (0, 0))
+    rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf)
+    buf = pkg.binding.PinnedBuffer(2 * 480 * 752)
+    pin = buf.array((2, 480, 752), np.uint8)
+    pin[0], pin[1] = left, right
+    for L, R in ((left, right), (pin[0], pin[1]), (left, right)):
+        m, (monoL, kL, dL), (monoR, kR, dR), uR, dep = pkg.binding.extract_stereo_pair(ex, L, R, mb, mbf)
+        _same(kL, rkL, dL, rdL)
+        _same(kR, rkR, dR, rdR)
+        assert m == rn and m > 100 and monoL == len(rkL)
+        assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)
+    flat = np.full((480, 752), 90, np.uint8)
+    m, (_, kL, _), (_, kR, _), uR, dep = pkg.binding.extract_stereo_pair(ex, left, flat, mb, mbf)
+    assert m == 0 and len(kR) == 0 and len(kL) == len(rkL) and np.all(uR == -1) and np.all(dep == -1)
+    ex.close()
+    buf.close()

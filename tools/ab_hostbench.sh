@@ -15,6 +15,7 @@ for v in a b; do
 import json,sys
 v=sys.argv[1]
 p=json.loads(open("gpurun_out/hb_%s.json"%v).read().strip().splitlines()[-1])
+print(v, 'fused pair', p.get('stereo_pair_fused'))
 print(v, sys.argv[2], {k:p[k].get('ms_p50', p[k].get('ms_per_pair_p50', p[k].get('ms_per_batch'))) for k in ("single_pageable","single_pinned","single_pageable_autoreg","stereo_pair","stereo_pair_one_call","stereo_pair_one_call_pinned","batch_pageable","batch_pinned","batch_pipelined")})
 PY
 done

@@ -243,7 +243,7 @@ int main(int argc, char** argv)
     // ---- stereo pair: two extractors (nFeatures as given), two threads started per frame (src/Frame.cc:119-122),
     // then ComputeStereoMatches on the resident results.  The right image is the left one shifted by 12 px.
     Stat sStereo{0, 0, 0}, sStereoExtract{0, 0, 0}, sStereo1{0, 0, 0}, sStereoExtract1{0, 0, 0}, sStereo1P{0, 0, 0},
-        sStereoExtract1P{0, 0, 0};
+        sStereoExtract1P{0, 0, 0}, sStereoF{0, 0, 0}, sStereoFP{0, 0, 0};
     double stereoMatches = 0, stereoMatches1 = 0;
     long stereoKp = 0;
     const int nPairs = 200, nFstereo = 1200;
@@ -309,6 +309,21 @@ int main(int argc, char** argv)
             }
             sStereo1 = stat_of(lat1);
             sStereoExtract1 = stat_of(latE1);
+            // ... and extraction + matching behind ONE host wait (orbfe_extract_stereo_pair), pageable images
+            {
+                std::vector<double> lat3;
+                std::vector<float> uR2(capS), dep2(capS);
+                for (int r = -10; r < nPairs; r++) {
+                    const int i = (r + 10) % B;
+                    const double a = now_s();
+                    const int m = orbfe_extract_stereo_pair(exL, frames.data() + imgBytes * i, right.data() + imgBytes * i, rows, cols, cols,
+                                                            lap2, (orbfe_kp*)kLR.data(), dLR.data(), capS, n2, mono2, bf / fx, bf,
+                                                            uR2.data(), dep2.data());
+                    CHECK(m);
+                    if (r >= 0) lat3.push_back(now_s() - a);
+                }
+                sStereoF = stat_of(lat3);
+            }
             // ... and with the caller's image buffers page-locked (orbfe_host_register once: a camera driver's ring)
             if (orbfe_host_register(frames.data(), imgBytes * B) == 0 && orbfe_host_register(right.data(), imgBytes * B) == 0) {
                 std::vector<double> lat2, latE2;
@@ -327,6 +342,18 @@ int main(int argc, char** argv)
                 }
                 sStereo1P = stat_of(lat2);
                 sStereoExtract1P = stat_of(latE2);
+                std::vector<double> lat4;
+                std::vector<float> uR2(capS), dep2(capS);
+                for (int r = -10; r < nPairs; r++) {
+                    const int i = (r + 10) % B;
+                    const double a = now_s();
+                    const int m = orbfe_extract_stereo_pair(exL, frames.data() + imgBytes * i, right.data() + imgBytes * i, rows, cols, cols,
+                                                            lap2, (orbfe_kp*)kLR.data(), dLR.data(), capS, n2, mono2, bf / fx, bf,
+                                                            uR2.data(), dep2.data());
+                    CHECK(m);
+                    if (r >= 0) lat4.push_back(now_s() - a);
+                }
+                sStereoFP = stat_of(lat4);
                 (void)orbfe_host_unregister(frames.data());
                 (void)orbfe_host_unregister(right.data());
             }
@@ -358,14 +385,18 @@ int main(int argc, char** argv)
            "then orbfe_compute_stereo_matches_resident between image 0 and image 1\", \"ms_per_pair_mean\": %.4f, "
            "\"ms_per_pair_p50\": %.4f, \"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f, \"matches_per_pair\": %.1f}, "
            "\"stereo_pair_one_call_pinned\": {\"protocol\": \"the same with the caller's image buffers page-locked (orbfe_host_register)\", "
-           "\"ms_per_pair_mean\": %.4f, \"ms_per_pair_p50\": %.4f, \"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f}}\n",
+           "\"ms_per_pair_mean\": %.4f, \"ms_per_pair_p50\": %.4f, \"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f}, "
+           "\"stereo_pair_fused\": {\"protocol\": \"orbfe_extract_stereo_pair: both images and ComputeStereoMatches behind one host wait\", "
+           "\"pageable\": {\"ms_per_pair_p50\": %.4f, \"ms_per_pair_p99\": %.4f}, \"pinned\": {\"ms_per_pair_p50\": %.4f, "
+           "\"ms_per_pair_p99\": %.4f}}}\n",
            cols, rows, nF, B, kpBatch, createMs, firstCallMs, 1e3 * sPg.mean, 1e3 * sPg.p50, 1e3 * sPg.p99, kpsPg,
            1e3 * sPin.mean, 1e3 * sPin.p50, 1e3 * sPin.p99, kpsPin, msPg, bkPg, msPin, bkPin, 1e3 * sAuto.mean, 1e3 * sAuto.p50,
            1e3 * sAuto.p99, kpsAuto, msAuto, bkAuto, msSW, msPipe, bkPipe, floorInMs,
            floorOutMs, inMB / floorInMs, (kB + dB) * B / 1e6 / floorOutMs, inMB, outMB, nPairs, 1e3 * sStereo.mean,
            1e3 * sStereo.p50, 1e3 * sStereo.p99, 1e3 * sStereoExtract.p50, stereoKp / (sStereo.mean * nPairs),
            stereoMatches / nPairs, 1e3 * sStereo1.mean, 1e3 * sStereo1.p50, 1e3 * sStereo1.p99, 1e3 * sStereoExtract1.p50,
-           stereoMatches1 / nPairs, 1e3 * sStereo1P.mean, 1e3 * sStereo1P.p50, 1e3 * sStereo1P.p99, 1e3 * sStereoExtract1P.p50);
+           stereoMatches1 / nPairs, 1e3 * sStereo1P.mean, 1e3 * sStereo1P.p50, 1e3 * sStereo1P.p99, 1e3 * sStereoExtract1P.p50,
+           1e3 * sStereoF.p50, 1e3 * sStereoF.p99, 1e3 * sStereoFP.p50, 1e3 * sStereoFP.p99);
     for (int k = 0; k < 2; k++) {
         orbfe_host_free(pinImg[k]);
         orbfe_host_free(pinK[k]);
