@@ -1666,6 +1666,8 @@ static_assert(make_ic_tab().n == 213, "every dword of the circle has a table ent
 // 10 pr + hg << 16, in ascending item order (the buffer-aliasing argument of the kernel's LDS layout needs ascending rows).
 struct DescHItems {
     uint32_t t[192];
+    uint32_t v[160]; // the vertical pass's items that hold a reachable pixel: H item index 10 q + g | blurred byte offset 80 q + 4 g << 16
+    int nv;
     int n;
     int maxPr[3]; // last row pair of rounds 0..2
     int minPr[3]; // first row pair of rounds 0..2
@@ -1680,8 +1682,11 @@ __host__ __device__ constexpr DescHItems make_desc_h_items()
             for (int y = 2 * q; y <= 2 * q + 1 && y < 37; y++)
                 for (int x = 4 * g; x < 4 * g + 4 && x < 37; x++)
                     if ((x - 18) * (x - 18) + (y - 18) * (y - 18) <= 366) need = true; // (18.385 + 0.75)^2 = 366.15
-            if (need)
+            if (need) {
                 for (int p = q; p <= q + 3; p++) hneed[p][g] = true;
+                if (r.nv < 160) r.v[r.nv] = (uint32_t)(10 * q + g) | ((uint32_t)(80 * q + 4 * g) << 16);
+                r.nv++;
+            }
         }
     for (int k = 0; k < 3; k++) {
         r.maxPr[k] = -1;
@@ -1700,6 +1705,7 @@ __host__ __device__ constexpr DescHItems make_desc_h_items()
 __constant__ DescHItems c_descHItems = make_desc_h_items();
 constexpr DescHItems kDescHItems = make_desc_h_items();
 static_assert(kDescHItems.n > 128 && kDescHItems.n <= 192, "three rounds of 64 lanes");
+static_assert(kDescHItems.nv == 160, "vertical pass: two rounds of whole items and one of 32 items split into their two rows");
 
 #define DESC_R 21    /* raw patch radius: 18 (rotated tap reach) + 3 (blur) */
 // --------------------------------------------------------------- libm trig table
@@ -2068,10 +2074,13 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
 #pragma unroll
     for (int k = 0; k < 4; k++) ict[k] = *reinterpret_cast<const uint4*>(c_icTab.t[k][lane]);
     // ... and the horizontal pass's item list (three rounds; the test tap's instantiation computes all four)
-    uint32_t hItem[3] = {0u, 0u, 0u};
+    uint32_t hItem[3] = {0u, 0u, 0u}, vItem[3] = {0u, 0u, 0u};
     if (!DBG) {
 #pragma unroll
         for (int k = 0; k < 3; k++) hItem[k] = c_descHItems.t[lane + 64 * k];
+        vItem[0] = c_descHItems.v[lane];
+        vItem[1] = c_descHItems.v[lane + 64];
+        vItem[2] = c_descHItems.v[128 + (lane & 31)];
     }
     // ---- raw 43x43 patch (11 dwords per row; the 44th column is never used)
     const bool inside = w.x >= DESC_R && w.y >= DESC_R && w.x + DESC_R + 1 < L.w && w.y + DESC_R < L.h;
@@ -2249,54 +2258,77 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
         o1.u = tw[15];
         o2.u = tw[16];
         o3.u = tw[17];
-        int hg = lane - 10 * (lane / 10);
-        int boff = 2 * DESC_BP * (lane / 10) + 4 * hg; // byte offset of output row 2k in the blurred patch
-        const uint4* src = reinterpret_cast<const uint4*>(hp2) + lane;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (lane + 64 * k < 19 * 10) {
-                const uint4* sp4 = src + 64 * k;
-                const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
-                uint32_t aE[4], aO[4]; // 16.16 sums of the even / odd output row, columns x y z w
-#define ORBFE_VCOL(F, I)                                                                               \
-    {                                                                                                   \
-        U2 q0, q1, q2, q3;                                                                              \
-        q0.u = p0.F;                                                                                    \
-        q1.u = p1.F;                                                                                    \
-        q2.u = p2.F;                                                                                    \
-        q3.u = p3.F;                                                                                    \
-        uint32_t acc = __builtin_amdgcn_udot2(q0.v, e0.v, 32768u, false);                               \
-        acc = __builtin_amdgcn_udot2(q1.v, e1.v, acc, false);                                           \
-        acc = __builtin_amdgcn_udot2(q2.v, e2.v, acc, false);                                           \
-        aE[I] = __builtin_amdgcn_udot2(q3.v, e3.v, acc, false);                                         \
-        acc = __builtin_amdgcn_udot2(q0.v, o0.v, 32768u, false);                                        \
-        acc = __builtin_amdgcn_udot2(q1.v, o1.v, acc, false);                                           \
-        acc = __builtin_amdgcn_udot2(q2.v, o2.v, acc, false);                                           \
-        aO[I] = __builtin_amdgcn_udot2(q3.v, o3.v, acc, false);                                         \
+        // one output row of an item: four columns x four u16-pair dot products against the row's tap pairs, packed to four bytes
+        auto v_row = [&](const uint4& p0, const uint4& p1, const uint4& p2, const uint4& p3, uint32_t w0, uint32_t w1, uint32_t w2,
+                         uint32_t w3) -> uint32_t {
+            U2 t0, t1, t2, t3;
+            t0.u = w0;
+            t1.u = w1;
+            t2.u = w2;
+            t3.u = w3;
+            uint32_t a[4]; // 16.16 sums of the columns x y z w
+#define ORBFE_VCOL(F, I)                                                              \
+    {                                                                                  \
+        U2 q0, q1, q2, q3;                                                             \
+        q0.u = p0.F;                                                                   \
+        q1.u = p1.F;                                                                   \
+        q2.u = p2.F;                                                                   \
+        q3.u = p3.F;                                                                   \
+        uint32_t acc = __builtin_amdgcn_udot2(q0.v, t0.v, 32768u, false);              \
+        acc = __builtin_amdgcn_udot2(q1.v, t1.v, acc, false);                          \
+        acc = __builtin_amdgcn_udot2(q2.v, t2.v, acc, false);                          \
+        a[I] = __builtin_amdgcn_udot2(q3.v, t3.v, acc, false);                         \
     }
-                ORBFE_VCOL(x, 0)
-                ORBFE_VCOL(y, 1)
-                ORBFE_VCOL(z, 2)
-                ORBFE_VCOL(w, 3)
+            ORBFE_VCOL(x, 0)
+            ORBFE_VCOL(y, 1)
+            ORBFE_VCOL(z, 2)
+            ORBFE_VCOL(w, 3)
 #undef ORBFE_VCOL
-                uint32_t outE, outO;
-                if (SAT) { // taps that sum to more than 256: the result can exceed 255 and saturates (ufixedpoint16 -> uchar)
-                    outE = min(aE[0] >> 16, 255u) | (min(aE[1] >> 16, 255u) << 8) | (min(aE[2] >> 16, 255u) << 16) | (min(aE[3] >> 16, 255u) << 24);
-                    outO = min(aO[0] >> 16, 255u) | (min(aO[1] >> 16, 255u) << 8) | (min(aO[2] >> 16, 255u) << 16) | (min(aO[3] >> 16, 255u) << 24);
-                } else { // <= 255 * 256 * 256 + 32768: byte 2 of each sum IS the pixel; three v_perm_b32 gather four of them
-                    // (eight ds_write_b8_d16_hi -- which store exactly that byte -- instead of six v_perm_b32 and two dword
-                    // stores: measured, 64.7 -> 65.5 us)
-                    outE = __builtin_amdgcn_perm(__builtin_amdgcn_perm(aE[3], aE[2], 0x0C0C0602u),
-                                                 __builtin_amdgcn_perm(aE[1], aE[0], 0x0C0C0602u), 0x05040100u);
-                    outO = __builtin_amdgcn_perm(__builtin_amdgcn_perm(aO[3], aO[2], 0x0C0C0602u),
-                                                 __builtin_amdgcn_perm(aO[1], aO[0], 0x0C0C0602u), 0x05040100u);
-                }
+            if (SAT) // taps that sum to more than 256: the result can exceed 255 and saturates (ufixedpoint16 -> uchar)
+                return min(a[0] >> 16, 255u) | (min(a[1] >> 16, 255u) << 8) | (min(a[2] >> 16, 255u) << 16) | (min(a[3] >> 16, 255u) << 24);
+            // <= 255 * 256 * 256 + 32768: byte 2 of each sum IS the pixel; three v_perm_b32 gather four of them
+            // (ds_write_b8_d16_hi -- which stores exactly that byte -- instead of the v_perm_b32 and a dword store: measured,
+            // 64.7 -> 65.5 us)
+            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(a[3], a[2], 0x0C0C0602u), __builtin_amdgcn_perm(a[1], a[0], 0x0C0C0602u),
+                                         0x05040100u);
+        };
+        const uint4* const H4 = reinterpret_cast<const uint4*>(hp2);
+        if (!DBG) {
+            // The 160 items that hold a pixel a rotated tap can reach (c_descHItems.v, ascending): two rounds of whole items,
+            // and the last 32 split into their two rows over the 64 lanes (lane >= 32: the odd row), so that the third round
+            // costs half of a whole one.
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint4* sp4 = H4 + (vItem[k] & 0xFFFFu);
+                const uint32_t boff = vItem[k] >> 16;
+                const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
+                const uint32_t outE = v_row(p0, p1, p2, p3, e0.u, e1.u, e2.u, e3.u), outO = v_row(p0, p1, p2, p3, o0.u, o1.u, o2.u, o3.u);
                 *reinterpret_cast<uint32_t*>(bl + boff) = outE;
                 *reinterpret_cast<uint32_t*>(bl + boff + DESC_BP) = outO;
             }
-            const bool wrap = hg >= 6;
-            boff += wrap ? (7 * 2 * DESC_BP - 24) : (6 * 2 * DESC_BP + 16);
-            hg += wrap ? -6 : 4;
+            {
+                const bool odd = lane >= 32;
+                const uint4* sp4 = H4 + (vItem[2] & 0xFFFFu);
+                const uint32_t boff = (vItem[2] >> 16) + (odd ? DESC_BP : 0);
+                const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
+                *reinterpret_cast<uint32_t*>(bl + boff) =
+                    v_row(p0, p1, p2, p3, odd ? o0.u : e0.u, odd ? o1.u : e1.u, odd ? o2.u : e2.u, odd ? o3.u : e3.u);
+            }
+        } else {
+            int hg = lane - 10 * (lane / 10);
+            int boff = 2 * DESC_BP * (lane / 10) + 4 * hg; // byte offset of output row 2k in the blurred patch
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (lane + 64 * k < 19 * 10) {
+                    const uint4* sp4 = H4 + lane + 64 * k;
+                    const uint4 p0 = sp4[0], p1 = sp4[DESC_HP / 4], p2 = sp4[2 * (DESC_HP / 4)], p3 = sp4[3 * (DESC_HP / 4)];
+                    *reinterpret_cast<uint32_t*>(bl + boff) = v_row(p0, p1, p2, p3, e0.u, e1.u, e2.u, e3.u);
+                    *reinterpret_cast<uint32_t*>(bl + boff + DESC_BP) = v_row(p0, p1, p2, p3, o0.u, o1.u, o2.u, o3.u);
+                }
+                const bool wrap = hg >= 6;
+                boff += wrap ? (7 * 2 * DESC_BP - 24) : (6 * 2 * DESC_BP + 16);
+                hg += wrap ? -6 : 4;
+            }
         }
     }
     WAVE_SYNC();
