@@ -1151,7 +1151,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             uint8_t* const mDesc = mirror ? mirror + mirrorMetaBytes + (size_t)nimg * capPerImg * 28 : nullptr;
             // whole images per XCD: (8 x workgroups per image, images / 8), image = workgroup id mod 8 + 8 y
             const bool descAffine = c->xcdAffine && ni % 8 == 0;
-            const unsigned descWg = (unsigned)((c->maxKp + ORBFE_DESC_WPW - 1) / ORBFE_DESC_WPW);
+            const unsigned descWg = (unsigned)((c->maxKp + ORBFE_DESC_WPW * ORBFE_DESC_KPW - 1) / (ORBFE_DESC_WPW * ORBFE_DESC_KPW));
             const dim3 descGrid = descAffine ? dim3(8u * descWg, (unsigned)(ni / 8)) : dim3(descWg, (unsigned)ni);
 #define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
     hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid, dim3(64 * ORBFE_DESC_WPW), 0, q,                                           \
@@ -2484,7 +2484,7 @@ int orbfe_debug_blurred_patch(orbfe_ctx* c, int img, int kp_index, uint8_t* out3
     for (int i = 0; i < 7; i++) tapSum += c->taps[i];
     float* kps = const_cast<float*>(c->lastKps);
     uint8_t* desc = const_cast<uint8_t*>(c->lastDesc);
-    const dim3 grid((unsigned)((c->maxKp + ORBFE_DESC_WPW - 1) / ORBFE_DESC_WPW), 1u);
+    const dim3 grid((unsigned)((c->maxKp + ORBFE_DESC_WPW * ORBFE_DESC_KPW - 1) / (ORBFE_DESC_WPW * ORBFE_DESC_KPW)), 1u);
     const int32_t* const dm = c->lastPacked ? c->d_destMap.p : nullptr;
 #define ORBFE_DBG_LAUNCH(SAT)                                                                                              \
     hipLaunchKernelGGL((k_orient_blur_desc<0, SAT, true>), grid, dim3(64 * ORBFE_DESC_WPW), 0, c->stream, c->d_pyr.p, c->pyrStride, c->d_ds.p, \

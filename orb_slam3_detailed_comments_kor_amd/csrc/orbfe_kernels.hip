@@ -1936,6 +1936,11 @@ __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
 // SAT: the taps sum to more than 256 (non-default taps only), so the horizontal pass can exceed 16 bits and
 //      saturates like ufixedpoint16; with the default taps the sum is at most 255 * 256 and the min is dropped.
 // DBG: the instantiation orbfe_debug_blurred_patch launches (the tap's loop would otherwise sit in the hot kernel).
+#ifndef ORBFE_DESC_KPW
+#define ORBFE_DESC_KPW 1 /* keypoint slots a wavefront works through in turn.  Two (half the wavefront launches, the item
+                            tables loaded once for both): 58.1 against 54.6 us -- a fresh wavefront per keypoint lets the
+                            hardware overlap one keypoint's patch loads with the others' arithmetic */
+#endif
 #ifndef ORBFE_DESC_WPW
 #define ORBFE_DESC_WPW 1 /* wavefronts (= keypoint slots) per workgroup.  One: a workgroup's LDS is only released when its last
                             wavefront ends, so with four keypoints per workgroup a slow one (a border patch) keeps the LDS
@@ -1984,10 +1989,10 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
         // itself and a pyramid is fetched into one L2 instead of eight (measured: 258 MB -> see DESIGN.md per 64 frames)
         if (xcdAffine) {
             imgLocal = (int)(blockIdx.x & 7u) + 8 * (int)blockIdx.y;
-            g = (int)(blockIdx.x >> 3) * ORBFE_DESC_WPW + wave;
+            g = ((int)(blockIdx.x >> 3) * ORBFE_DESC_WPW + wave) * ORBFE_DESC_KPW;
         } else {
             imgLocal = (int)blockIdx.y;
-            g = (int)blockIdx.x * ORBFE_DESC_WPW + wave;
+            g = ((int)blockIdx.x * ORBFE_DESC_WPW + wave) * ORBFE_DESC_KPW;
         }
         img = imgLocal + imgBase;
     } else {
@@ -1998,8 +2003,9 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
     }
     // The work item is wave-uniform: three scalar loads, independent of each other (one round trip in front of the patch
     // loads): the slot's level geometry, K-QT's key in that slot and its partition word.
-    g = __builtin_amdgcn_readfirstlane(g);
     img = __builtin_amdgcn_readfirstlane(img);
+    auto desc_one = [&](int g) {
+    g = __builtin_amdgcn_readfirstlane(g);
     if (g >= nSlots) return;
     typedef int i8v __attribute__((ext_vector_type(8)));
     i8v sv;
@@ -2404,6 +2410,15 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
                 const int idx = atomicAdd(reinterpret_cast<int*>(fixList), 1);
                 fixList[1 + idx] = make_int4((img << 16) | g, __float_as_int(angle), __float_as_int(a), __float_as_int(b));
             }
+        }
+    }
+    }; // desc_one
+    desc_one(g);
+    if (MODE != 1 && ORBFE_DESC_KPW > 1) {
+#pragma unroll
+        for (int rep = 1; rep < ORBFE_DESC_KPW; rep++) {
+            WAVE_SYNC();
+            desc_one(g + rep);
         }
     }
 }
