@@ -134,14 +134,15 @@ struct orbfe_geom_state {
     DevBuf<OrbCellGeom> d_cg;
     DevBuf<OrbResizeX> d_xtab;
     DevBuf<OrbResizeY> d_ytab;
-    DevBuf<OrbPyrRange> d_prx, d_pry;
+    DevBuf<uint4> d_pyrRecs; // the fused pyramid kernel's per-tile records (OrbPyrTileHdr + staged x groups + y entries)
+    int pyrRecBytes = 0;
     int pyrNtx = 0, pyrNty = 0, pyrBuf0 = 0, pyrBuf1 = 0, pyrStageX = 0, pyrStageY = 0;
     size_t pyrLdsBytes = 0;
     bool pyrWeightsOk = true; // all resize weights in [0, 2050] with a0+a1, b0+b1 <= 2050 (k_pyr_fused drops the clamp)
     bool pyrFused = true;
     void release_tables()
     {
-        d_lg.release(); d_cg.release(); d_fc.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_prx.release(); d_pry.release();
+        d_lg.release(); d_cg.release(); d_fc.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
     }
 };
 
@@ -631,10 +632,6 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
         // + 16 B slack: the interpolation reads 3 aligned dwords per source row from its first pixel
         c->pyrBuf0 = (int)align_up((size_t)((mx0 + 3) & ~3) * my0 + 16, 16);
         c->pyrBuf1 = (int)align_up((size_t)((mx1 + 3) & ~3) * std::max(my1, 1) + 16, 16);
-        if ((r = c->d_prx.ensure(prx.size())) < 0) return r;
-        if ((r = c->d_pry.ensure(pry.size())) < 0) return r;
-        HIP_TRY(hipMemcpy(c->d_prx.p, prx.data(), prx.size() * sizeof(OrbPyrRange), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_pry.p, pry.data(), pry.size() * sizeof(OrbPyrRange), hipMemcpyHostToDevice));
         c->pyrStageX = c->pyrStageY = 0;
         for (int i = 0; i < c->pyrNtx; i++) {
             int sum = 0;
@@ -647,12 +644,77 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
             for (int l = 1; l < nl; l++) sum += pry[(size_t)l * c->pyrNty + j].needHi - pry[(size_t)l * c->pyrNty + j].lo;
             c->pyrStageY = std::max(c->pyrStageY, sum);
         }
-        // staged x and y entries 8 B each (y: 16-bit LDS row offsets, so a region must stay below 64 KB -- it
-        // does, the whole allocation is); the kernel deals whole column groups (4 px) of a region row to its
-        // 256 threads
-        // (x: 16 B of selectors + 16 B of weights + 4 B of source position per group; y: 8 B per row)
-        c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + 32 * (size_t)c->pyrStageX + 4 * align_up((size_t)c->pyrStageX, 4) +
-                         8 * (size_t)c->pyrStageY;
+        // The per-tile records (orbfe_geom.h): header | x groups (16 B of selectors + 16 B of weights + 4 B of source
+        // position each) | y entries (8 B: 16-bit LDS row offsets -- a region stays below 64 KB, the whole allocation does --
+        // and the two weights).  Everything the kernel used to derive per workgroup is folded here, once per image size.
+        {
+            const size_t SX = (size_t)c->pyrStageX, SY = (size_t)c->pyrStageY;
+            const size_t recBytes = sizeof(OrbPyrTileHdr) + 32 * SX + 4 * align_up(SX, 4) + 8 * align_up(SY, 2);
+            c->pyrRecBytes = (int)recBytes;
+            const size_t ntiles = (size_t)c->pyrNtx * c->pyrNty;
+            std::vector<uint8_t> recs(ntiles * recBytes, 0);
+            for (int tj = 0; tj < c->pyrNty; tj++)
+                for (int ti = 0; ti < c->pyrNtx; ti++) {
+                    uint8_t* const rec = recs.data() + ((size_t)tj * c->pyrNtx + ti) * recBytes;
+                    OrbPyrTileHdr H;
+                    std::memset(&H, 0, sizeof H);
+                    int xs = 0, ys = 0;
+                    for (int l = 0; l < nl; l++) {
+                        const OrbPyrRange X = prx[(size_t)l * c->pyrNtx + ti], Y = pry[(size_t)l * c->pyrNty + tj];
+                        H.xlo[l] = X.lo;
+                        H.xown[l] = X.ownHi;
+                        H.xneed[l] = X.needHi;
+                        H.ylo[l] = Y.lo;
+                        H.yown[l] = Y.ownHi;
+                        H.yneed[l] = Y.needHi;
+                        H.roi[l] = (int32_t)c->lg[l].roiOff;
+                        H.pitch[l] = c->lg[l].pitch;
+                        const int ng = (X.needHi - X.lo + 3) >> 2; // groups of 4 columns per region row
+                        H.recip[l] = ng > 1 ? (uint32_t)(((1ull << 32) + (unsigned)ng - 1) / (unsigned)ng) : 0u;
+                        H.xo[l] = xs; // (levels 1 .. l-1 precede level l; level 0 stages nothing)
+                        H.yo[l] = ys;
+                        if (l >= 1) {
+                            xs += ng;
+                            ys += Y.needHi - Y.lo;
+                        }
+                    }
+                    H.xo[nl] = xs;
+                    H.yo[nl] = ys;
+                    std::memcpy(rec, &H, sizeof H);
+                    uint32_t* const xsel = reinterpret_cast<uint32_t*>(rec + sizeof H);
+                    uint32_t* const xaw = xsel + 4 * SX;
+                    uint32_t* const xbw = xaw + 4 * SX;
+                    uint32_t* const ytw = xbw + align_up(SX, 4);
+                    for (int l = 1; l < nl; l++) {
+                        const int nW = H.xneed[l] - H.xlo[l], nH = H.yneed[l] - H.ylo[l];
+                        const OrbResizeX* const tabx = xtab.data() + c->lg[l].xtabOff + H.xlo[l];
+                        for (int g = 0; g < ((nW + 3) >> 2); g++) {
+                            const size_t idx = (size_t)H.xo[l] + g;
+                            OrbResizeX e[4];
+                            for (int k = 0; k < 4; k++) e[k] = tabx[std::min(4 * g + k, nW - 1)];
+                            for (int k = 0; k < 4; k++) {
+                                const uint32_t o = (uint32_t)e[k].sx - (uint32_t)e[0].sx; // 0..6 (pyrWeightsOk / the scale check)
+                                xsel[4 * idx + k] = 0x0C000C00u | o | ((o + 1u) << 16);
+                                xaw[4 * idx + k] = (uint32_t)(uint16_t)e[k].a0 | ((uint32_t)(uint16_t)e[k].a1 << 16);
+                            }
+                            const uint32_t x0 = (uint32_t)((int)e[0].sx - H.xlo[l - 1]); // relative to the source region
+                            xbw[idx] = (x0 & ~3u) | ((x0 & 3u) << 16);
+                        }
+                        const int sLoY = H.ylo[l - 1];
+                        const int sPitch = (H.xneed[l - 1] - H.xlo[l - 1] + 3) & ~3; // LDS pitch of the source region
+                        const OrbResizeY* const taby = ytab.data() + c->lg[l].ytabOff + H.ylo[l];
+                        for (int rr = 0; rr < nH; rr++) {
+                            const OrbResizeY e = taby[rr];
+                            const size_t idx = (size_t)H.yo[l] + rr;
+                            ytw[2 * idx] = (uint32_t)(((int)e.sy0 - sLoY) * sPitch) | ((uint32_t)(((int)e.sy1 - sLoY) * sPitch) << 16);
+                            ytw[2 * idx + 1] = (uint32_t)(uint16_t)e.b0 | ((uint32_t)(uint16_t)e.b1 << 16);
+                        }
+                    }
+                }
+            if ((r = c->d_pyrRecs.ensure(recs.size() / 16 + 1)) < 0) return r;
+            HIP_TRY(hipMemcpy(c->d_pyrRecs.p, recs.data(), recs.size(), hipMemcpyHostToDevice));
+            c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + recBytes;
+        }
         c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk &&
                       getenv("ORBFE_PYR_UNFUSED") == nullptr;
     }
@@ -1080,8 +1142,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         if (c->pyrFused) {
             hipLaunchKernelGGL(k_pyr_fused, dim3((unsigned)c->pyrNtx, (unsigned)c->pyrNty, (unsigned)ni), dim3(256),
                                c->pyrLdsBytes, q, d_imgs,
-                               pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_lg.p, nl, c->d_prx.p, c->d_pry.p,
-                               c->pyrNtx, c->pyrNty, c->d_xtab.p, c->d_ytab.p, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
+                               pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_pyrRecs.p, c->pyrRecBytes, nl,
+                               c->pyrNtx, c->pyrNty, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
                                cols, i0, kernelClearsHdr ? d_hdr : nullptr, (c->xcdAffine && ni % 8 == 0) ? 1 : 0,
                                recip32((unsigned)(c->pyrNtx * c->pyrNty)), recip32((unsigned)c->pyrNtx));
         } else {

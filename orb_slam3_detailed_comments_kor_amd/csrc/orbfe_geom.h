@@ -85,6 +85,23 @@ struct OrbPyrRange {
 };
 #define ORBFE_PYR_TILE 24 /* tile side at the coarsest level (16: 157 us, 24: 130 us, 32: 129 us per 64 frames) */
 
+/* Everything a workgroup of the fused pyramid kernel needs about ITS tile, built on the host once per image size and
+ * copied into LDS as one block (round 3; the kernel used to derive it per workgroup: range lookups, table staging with a
+ * level search per entry, selector arithmetic).  Record of tile (ti, tj), at (tj * ntx + ti) * recBytes:
+ *   OrbPyrTileHdr | xsel[stageX] (uint4: the four v_perm_b32 selectors of a group of four destination columns)
+ *                 | xa[stageX] (uint4: a0 | a1 << 16 of the four columns) | xb[align4(stageX)] (u32: dword-aligned source
+ *                   column of the group | byte shift << 16) | yt[align2(stageY)] (uint2: LDS byte offsets of the two source
+ *                   rows sy0 | sy1 << 16 inside the source region, b0 | b1 << 16)
+ * stageX / stageY = the largest group / row totals of any tile (the kernel's pointer offsets). */
+struct OrbPyrTileHdr {
+    int32_t xlo[ORBFE_MAX_LEVELS], xown[ORBFE_MAX_LEVELS], xneed[ORBFE_MAX_LEVELS]; /* owned [lo, own), computed [lo, need) */
+    int32_t ylo[ORBFE_MAX_LEVELS], yown[ORBFE_MAX_LEVELS], yneed[ORBFE_MAX_LEVELS];
+    int32_t roi[ORBFE_MAX_LEVELS], pitch[ORBFE_MAX_LEVELS];                         /* level geometry                   */
+    uint32_t recip[ORBFE_MAX_LEVELS]; /* ceil(2^32 / column groups per region row), 0 when there is one */
+    int32_t xo[ORBFE_MAX_LEVELS + 1], yo[ORBFE_MAX_LEVELS + 1]; /* first staged x group / y entry of a level; [nlevels] = total */
+    int32_t pad[2];
+};
+
 /* K-DESC's view of one slot of an image's level-major keypoint slot array (slot g = lg[level].kpBase + k, the k-th
  * keypoint K-QT kept at that level): 32 B per slot, the same for every image of a size, fetched with one scalar load.
  * With it a wavefront needs nothing from K-PACK: its level's geometry is here, its key is lvlKp[g], its output slot the

@@ -109,31 +109,26 @@ __device__ __forceinline__ int fast_div(unsigned x, unsigned m) { return m ? (in
 // and no level is ever read back.
 __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ src, size_t srcPitch,
                                                    size_t srcImgStride, uint8_t* __restrict__ pyr,
-                                                   size_t pyrImgStride, const OrbLevelGeom* __restrict__ lg,
-                                                   int nlevels, const OrbPyrRange* __restrict__ rx,
-                                                   const OrbPyrRange* __restrict__ ry, int ntx, int nty,
-                                                   const OrbResizeX* __restrict__ xtab,
-                                                   const OrbResizeY* __restrict__ ytab, int bufBytes0,
+                                                   size_t pyrImgStride, const uint4* __restrict__ tileRecs,
+                                                   int recBytes, int nlevels, int ntx, int nty, int bufBytes0,
                                                    int bufBytes1, int stageX, int imgCols, int imgBase,
                                                    int32_t* __restrict__ clearHdr /* 4 words or nullptr */,
                                                    int xcdAffine, uint32_t mPerImg /* reciprocals of ntx * nty */,
                                                    uint32_t mNtx /* and of ntx (fast_div) */)
 {
+    static_assert(sizeof(OrbPyrTileHdr) % 16 == 0, "the tables behind the header are read as uint4");
     // first kernel of a batch: clear the {fragile count, error flag, -, -} header the later kernels append to
     if (clearHdr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < 4) clearHdr[threadIdx.x] = 0;
-    // dynamic LDS: region buffer A | region buffer B | staged x entries (8 B) | staged y entries (8 B)
+    // dynamic LDS: region buffer A | region buffer B | this tile's record (orbfe_geom.h: header, x groups, y entries)
     extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
     uint8_t* bufA = pyr_lds;
     uint8_t* bufB = pyr_lds + bufBytes0;
-    // staged x entries, one per GROUP of four destination columns (what a thread of the level loop keeps in registers):
-    //   xsel: the four v_perm_b32 selectors that pick (I[sx], I[sx+1]) out of the group's eight source bytes,
-    //   xa:   a0 | a1 << 16 of the four columns,  xb: dword-aligned source column of the group | byte shift << 16
-    // staged y entry (8 B, to keep seven workgroups per CU): .x = LDS byte offsets of the source rows sy0 | sy1 << 16
-    //                 inside the source region, .y = b0 | b1 << 16  ((b * t) >> 16 == mulhi(b << 16, t))
-    uint4* xsel = reinterpret_cast<uint4*>(pyr_lds + bufBytes0 + bufBytes1);
-    uint4* xa = xsel + stageX;
-    uint32_t* xb = reinterpret_cast<uint32_t*>(xa + stageX);
-    uint2* yt = reinterpret_cast<uint2*>(xb + ((stageX + 3) & ~3));
+    uint4* const tab = reinterpret_cast<uint4*>(pyr_lds + bufBytes0 + bufBytes1);
+    const OrbPyrTileHdr* const H = reinterpret_cast<const OrbPyrTileHdr*>(tab);
+    const uint4* const xsel = tab + sizeof(OrbPyrTileHdr) / 16;
+    const uint4* const xa = xsel + stageX;
+    const uint32_t* const xb = reinterpret_cast<const uint32_t*>(xa + stageX);
+    const uint2* const yt = reinterpret_cast<const uint2*>(xb + ((stageX + 3) & ~3));
     const int tid = threadIdx.x;
     int ti = blockIdx.x, tj = blockIdx.y, img = (int)blockIdx.z;
     if (xcdAffine) {
@@ -147,100 +142,28 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     }
     img += imgBase;
     uint8_t* base = pyr + (size_t)img * pyrImgStride;
-
-    // per-level parameters once into LDS (one round of global loads instead of a dependent scalar
-    // load chain per level)
-    __shared__ int lvXlo[ORBFE_MAX_LEVELS], lvXown[ORBFE_MAX_LEVELS], lvXneed[ORBFE_MAX_LEVELS];
-    __shared__ int lvYlo[ORBFE_MAX_LEVELS], lvYown[ORBFE_MAX_LEVELS], lvYneed[ORBFE_MAX_LEVELS];
-    __shared__ int lvRoi[ORBFE_MAX_LEVELS], lvPitch[ORBFE_MAX_LEVELS], lvXt[ORBFE_MAX_LEVELS], lvYt[ORBFE_MAX_LEVELS];
-    __shared__ unsigned lvRecip[ORBFE_MAX_LEVELS]; // ceil(2^32 / column groups per row), 0 when there is one
-    __shared__ int lvXo[ORBFE_MAX_LEVELS + 1], lvYo[ORBFE_MAX_LEVELS + 1]; // first staged x / y entry of a level; [nlevels] = total
-    if (tid < nlevels) {
-        const OrbPyrRange X = rx[tid * ntx + ti], Y = ry[tid * nty + tj];
-        lvXlo[tid] = X.lo;
-        lvXown[tid] = X.ownHi;
-        lvXneed[tid] = X.needHi;
-        lvYlo[tid] = Y.lo;
-        lvYown[tid] = Y.ownHi;
-        lvYneed[tid] = Y.needHi;
-        lvRoi[tid] = (int)lg[tid].roiOff;
-        lvPitch[tid] = lg[tid].pitch;
-        lvXt[tid] = lg[tid].xtabOff;
-        lvYt[tid] = lg[tid].ytabOff;
-        const int ng = (X.needHi - X.lo + 3) >> 2; // groups of 4 columns per region row
-        lvRecip[tid] = ng > 1 ? (unsigned)(((1ull << 32) + (unsigned)ng - 1) / (unsigned)ng) : 0u;
-        // where this level's staged x / y entries start (levels 1 .. tid-1 precede it); the last level also
-        // leaves the totals.  A handful of independent loads per lane, no second barrier.
-        int xs = 0, ys = 0; // (x: in groups of four columns)
-        for (int j = 1; j < tid; j++) {
-            const OrbPyrRange Xj = rx[j * ntx + ti], Yj = ry[j * nty + tj];
-            xs += (Xj.needHi - Xj.lo + 3) >> 2;
-            ys += Yj.needHi - Yj.lo;
-        }
-        lvXo[tid] = xs;
-        lvYo[tid] = ys;
-        if (tid == nlevels - 1) {
-            lvXo[nlevels] = tid > 0 ? xs + ng : 0;
-            lvYo[nlevels] = tid > 0 ? ys + (Y.needHi - Y.lo) : 0;
-        }
-    }
-    __syncthreads();
-    // stage the interpolation tables of every level, already reduced to what the inner loop needs
-    // (region-relative LDS offsets, packed weights); all global loads are in flight at once and the
-    // per-pixel loop below then touches LDS only
-    // One flat pass over the entries of all levels (an entry finds its level in the start table): a thread's two or
-    // three table loads are independent and in flight together.  (A loop per level and table waited for fourteen
-    // global round trips in turn: 8 of the 22 us a workgroup lives.)
-    {
-        const int totalX = lvXo[nlevels], totalY = lvYo[nlevels];
-        for (int idx = tid; idx < totalX; idx += 256) { // one column group per item
-            int l = 1;
-            for (int j = 2; j < nlevels; j++) l = lvXo[j] <= idx ? j : l;
-            const int c0 = 4 * (idx - lvXo[l]), last = lvXneed[l] - lvXlo[l] - 1;
-            const OrbResizeX* const tab = xtab + lvXt[l] + lvXlo[l];
-            OrbResizeX e[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) e[k] = tab[min(c0 + k, last)];
-            uint32_t sel[4], a[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t o = (uint32_t)e[k].sx - (uint32_t)e[0].sx; // 0..6 (the host checks)
-                sel[k] = 0x0C000C00u | o | ((o + 1u) << 16);
-                a[k] = (unsigned)(uint16_t)e[k].a0 | ((unsigned)(uint16_t)e[k].a1 << 16);
-            }
-            const uint32_t x0 = (uint32_t)((int)e[0].sx - lvXlo[l - 1]); // relative to the source region
-            xsel[idx] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
-            xa[idx] = make_uint4(a[0], a[1], a[2], a[3]);
-            xb[idx] = (x0 & ~3u) | ((x0 & 3u) << 16);
-        }
-        for (int idx = tid; idx < totalY; idx += 256) {
-            int l = 1;
-            for (int j = 2; j < nlevels; j++) l = lvYo[j] <= idx ? j : l;
-            const int k = idx - lvYo[l];
-            const OrbResizeY e = ytab[lvYt[l] + lvYlo[l] + k];
-            const int sLoY = lvYlo[l - 1];
-            const int sPitch = (lvXneed[l - 1] - lvXlo[l - 1] + 3) & ~3; // LDS pitch of the source region
-            yt[idx] = make_uint2((unsigned)(((int)e.sy0 - sLoY) * sPitch) | ((unsigned)(((int)e.sy1 - sLoY) * sPitch) << 16),
-                                 (unsigned)(uint16_t)e.b0 | ((unsigned)(uint16_t)e.b1 << 16));
-        }
-    }
+    // the tile's record: one flat copy into LDS (it is complete at the barrier that ends the level-0 staging below, which
+    // itself takes what it needs -- the level-0 ranges -- from the global copy through scalar loads)
+    const uint4* const rec = tileRecs + (size_t)(tj * ntx + ti) * (size_t)(recBytes >> 4);
+    for (int i = tid; i < (recBytes >> 4); i += 256) tab[i] = rec[i];
+    const OrbPyrTileHdr* const G = reinterpret_cast<const OrbPyrTileHdr*>(rec); // (wave-uniform address)
     // level 0: stage the needed region of the input image, write the owned part
-    int nW = lvXneed[0] - lvXlo[0], nH = lvYneed[0] - lvYlo[0];
+    int nW = G->xneed[0] - G->xlo[0], nH = G->yneed[0] - G->ylo[0];
     {
         const int sp = (nW + 3) & ~3; // LDS pitch of the level-0 region
-        const int pitch0 = lvPitch[0];
-        const int xlo = lvXlo[0], ylo = lvYlo[0];
+        const int pitch0 = G->pitch[0];
+        const int xlo = G->xlo[0], ylo = G->ylo[0];
         // (32-bit offsets from two wave-uniform bases: an image and a pyramid slab are below 4 GB)
         const uint8_t* const s0 = src + (size_t)img * srcImgStride;
         uint8_t* const d0 = base;
         const uint32_t sOrg = (uint32_t)ylo * (uint32_t)srcPitch + (uint32_t)xlo;
-        const uint32_t dOrg = (uint32_t)lvRoi[0] + (uint32_t)ylo * (uint32_t)pitch0 + (uint32_t)xlo;
-        const int ownW = lvXown[0] - xlo, ownH = lvYown[0] - ylo;
+        const uint32_t dOrg = (uint32_t)G->roi[0] + (uint32_t)ylo * (uint32_t)pitch0 + (uint32_t)xlo;
+        const int ownW = G->xown[0] - xlo, ownH = G->yown[0] - ylo;
         // dword granularity (global dword accesses may be unaligned).  A thread keeps one dword column
         // and walks down the rows, four loads in flight per step; no per-item division.
         const int ndw = (nW + 3) >> 2;           // dwords per region row (LDS pitch sp == 4*ndw)
         const int safeW = imgCols - xlo;         // bytes readable in a row without leaving the image row
-        const unsigned rcp0 = lvRecip[0];
+        const unsigned rcp0 = G->recip[0];
         const int rr = rcp0 ? (int)__umulhi((unsigned)tid, rcp0) : tid; // tid / ndw
         const int c = 4 * (tid - rr * ndw);
         const int rpp = rcp0 ? (int)__umulhi(256u, rcp0) : 256;        // rows per pass
@@ -303,11 +226,11 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
     uint8_t* D = bufB;
     typedef unsigned short pyr_us2 __attribute__((ext_vector_type(2)));
     for (int l = 1; l < nlevels; l++) {
-        const int xlo = lvXlo[l], ylo = lvYlo[l], gpitch = lvPitch[l];
-        nW = lvXneed[l] - xlo;
-        nH = lvYneed[l] - ylo;
+        const int xlo = H->xlo[l], ylo = H->ylo[l], gpitch = H->pitch[l];
+        nW = H->xneed[l] - xlo;
+        nH = H->yneed[l] - ylo;
         const int dp = (nW + 3) & ~3;
-        const int ownW = lvXown[l] - xlo, ownH = lvYown[l] - ylo;
+        const int ownW = H->xown[l] - xlo, ownH = H->yown[l] - ylo;
         // A thread keeps one group of 4 destination columns (its four x entries stay in registers) and
         // walks down the rows.  Per row: one 16-B y entry and, from each of the two source rows, three
         // ALIGNED dwords starting at the dword of the group's first source pixel (a misaligned LDS access
@@ -318,7 +241,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
         // packed (a0, a1) and two v_mul_hi_u32 against b << 16.  sx+1 instead of min(sx+1, w-1) is
         // harmless: a1 == 0 there.
         const int nG = dp >> 2;
-        const unsigned rcp = lvRecip[l];
+        const unsigned rcp = H->recip[l];
         const int rr = rcp ? (int)__umulhi((unsigned)tid, rcp) : tid; // tid / nG
         const int g = tid - rr * nG;
         const int rowsPerPass = rcp ? (int)__umulhi(256u, rcp) : 256;  // 256 / nG (host guarantees nG <= 256)
@@ -330,7 +253,7 @@ __global__ __launch_bounds__(256) void k_pyr_fused(const uint8_t* __restrict__ s
             const uint32_t sel[4] = {selv.x, selv.y, selv.z, selv.w}, aw[4] = {av.x, av.y, av.z, av.w};
             // destination addresses advance by whole passes (no per-row multiplies); the global one is a 32-bit offset from
             // the image's slab (a slab is below 4 GB: one scalar base + one vector offset per store, no 64-bit vector adds)
-            uint32_t qo = (uint32_t)lvRoi[l] + (uint32_t)((ylo + rr) * gpitch + xlo + c0);
+            uint32_t qo = (uint32_t)H->roi[l] + (uint32_t)((ylo + rr) * gpitch + xlo + c0);
             uint8_t* dq = D + rr * dp + c0;
             const int qStep = rowsPerPass * gpitch, dStep = rowsPerPass * dp;
             const bool colOwned = c0 < ownW, fullDword = c0 + 4 <= ownW;
