@@ -128,6 +128,8 @@ struct orbfe_geom_state {
     size_t fastLdsBytes = 0;
     std::vector<OrbFastCell> fc; // K-FAST's cell records
     DevBuf<OrbFastCell> d_fc;
+    std::vector<uint2> fastPat; // phase A's per-thread constants, fastThreads entries per pattern (OrbFastCell::pad names the pattern)
+    DevBuf<uint2> d_fastPat;
     DevBuf<OrbDescSlot> d_ds; // K-DESC's per-slot records (level geometry of every keypoint slot)
     int fastTileBytes = 0, fastBmWords = 0;
     DevBuf<OrbLevelGeom> d_lg;
@@ -142,7 +144,7 @@ struct orbfe_geom_state {
     bool pyrFused = true;
     void release_tables()
     {
-        d_lg.release(); d_cg.release(); d_fc.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
+        d_lg.release(); d_cg.release(); d_fc.release(); d_fastPat.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
     }
 };
 
@@ -443,7 +445,12 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         // (the score map has four rows less than the tile: rows 2 .. rows-3)
         c->fastLdsBytes = align_up((size_t)2 * c->fastTileBytes - (size_t)4 * c->fastPitch + 8 * (size_t)c->fastBmWords +
                                        2 * (size_t)std::max(maxZone, 1), 16);
+        int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
+        if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
+            nt = c->fastThreadsOverride; // ORBFE_FAST_THREADS: tuning experiments
         c->fc.clear();
+        c->fastPat.clear();
+        std::vector<std::pair<int, int>> patKeys; // (cw, ox) of the patterns built so far
         for (const OrbCellGeom& g : c->cg) {
             OrbFastCell f;
             const int ox = g.iniX & 3;
@@ -456,12 +463,33 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             f.slotBase = (uint32_t)g.slotBase;
             f.slotCap = (uint32_t)g.slotCap;
             f.mNdz = g.mNdz;
-            f.pad = 0;
+            // phase A's per-thread constants depend on the cell's width and alignment only: thread t works on zone rows
+            // t / ndz, t / ndz + rpp, ... (rpp = threads / ndz) of dword column (txLo >> 2) + t % ndz; of its four pixels those
+            // inside the zone columns [txLo, txHi] count (bit 7 of each byte of the mask)
+            const std::pair<int, int> key(g.cw, ox);
+            size_t pi = 0;
+            while (pi < patKeys.size() && patKeys[pi] != key) pi++;
+            if (pi == patKeys.size()) {
+                patKeys.push_back(key);
+                const int rpp = nt / ndz, d0 = txLo >> 2, pd = c->fastPitch / 4;
+                for (int t = 0; t < nt; t++) {
+                    const int r0 = t / ndz, dz = t - r0 * ndz;
+                    uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+                    if (r0 < rpp) {
+                        const int d = d0 + dz, tx0 = 4 * d;
+                        unsigned valid = 0xFu;
+                        if (tx0 < txLo) valid &= 0xFu << (txLo - tx0);
+                        if (tx0 + 3 > txHi) valid &= 0xFu >> (tx0 + 3 - txHi);
+                        valid &= 0xFu;
+                        e.x = (uint32_t)((r0 + 3) * pd + d) | ((uint32_t)r0 << 16);
+                        e.y = ((valid & 1u) << 7) | ((valid & 2u) << 14) | ((valid & 4u) << 21) | ((valid & 8u) << 28);
+                    }
+                    c->fastPat.push_back(e);
+                }
+            }
+            f.pad = (uint32_t)pi;
             c->fc.push_back(f);
         }
-        int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
-        if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
-            nt = c->fastThreadsOverride; // ORBFE_FAST_THREADS: tuning experiments
         c->fastThreads = nt;
     }
     c->qtKeyOff = 64 + std::max(24 * maxLC, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
@@ -571,6 +599,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     if ((r = c->d_lg.ensure(c->lg.size())) < 0) return r;
     if ((r = c->d_cg.ensure(c->cg.size())) < 0) return r;
     if ((r = c->d_fc.ensure(c->fc.size())) < 0) return r;
+    if ((r = c->d_fastPat.ensure(std::max<size_t>(c->fastPat.size(), 1))) < 0) return r;
     if ((r = c->d_ds.ensure(std::max<size_t>(c->kpStride, 1))) < 0) return r;
     if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
     if ((r = c->d_ytab.ensure(std::max<size_t>(ytab.size(), 1))) < 0) return r;
@@ -578,6 +607,8 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_fc.p, c->fc.data(), c->fc.size() * sizeof(OrbFastCell), hipMemcpyHostToDevice));
+    if (!c->fastPat.empty())
+        HIP_TRY(hipMemcpy(c->d_fastPat.p, c->fastPat.data(), c->fastPat.size() * sizeof(uint2), hipMemcpyHostToDevice));
     {
         // K-DESC's slot records: slot kpBase + k of every level carries that level's geometry
         std::vector<OrbDescSlot> ds(c->kpStride);
@@ -1171,7 +1202,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
 #define ORBFE_FAST_LAUNCH(NT, PD)                                                                                       \
     hipLaunchKernelGGL((k_fast_cells<NT, PD>), grid, dim3(NT), c->fastLdsBytes, q, c->d_pyr.p, c->pyrStride, c->d_fc.p,   \
                        c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->iniThFAST, c->minThFAST,            \
-                       c->fastTileBytes, c->fastBmWords, gShift, i0, ni)
+                       c->fastTileBytes, c->fastBmWords, gShift, i0, ni, c->d_fastPat.p)
 #define ORBFE_FAST_PD(NT)                                \
     do {                                                 \
         if (c->fastPitch == 52) ORBFE_FAST_LAUNCH(NT, 13); \

@@ -471,7 +471,11 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                                               const OrbFastCell* __restrict__ cells, uint32_t* __restrict__ cand,
                                               size_t candImgStride, int32_t* __restrict__ cellCount, int nCellsTotal,
                                               int iniTh, int minTh, int tileBytes /* rows * 4 PD, multiple of 16 */,
-                                              int bmWords /* multiple of 4 */, int gShift, int imgBase, int nImg)
+                                              int bmWords /* multiple of 4 */, int gShift, int imgBase, int nImg,
+                                              const uint2* __restrict__ pat /* phase A's per-thread constants, NT entries per
+                                                                              pattern (cell width, alignment): .x = first centre
+                                                                              dword | first zone row << 16 (all ones: no work),
+                                                                              .y = column mask */)
 {
     constexpr int P = 4 * PD;
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
@@ -507,8 +511,8 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     asm volatile("" ::"s"(c.pitch)); // the record has arrived
     FT(0);
 #endif
+    const uint2 patE = pat[(size_t)c.pad * NT + tid]; // (arrives during the staging)
     const int cw = (int)(c.dims & 0xFFu), ch = (int)((c.dims >> 8) & 0xFFu), ox = (int)((c.dims >> 16) & 3u);
-    const int ndz = (int)(c.dims >> 20);
     const uint8_t* const gbase = pyr + (size_t)img * pyrImgStride + c.gOff;
 
     if (tid == 0) {
@@ -559,7 +563,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         // B), for 30 plain 32-bit operations per four pixels instead of 52.  At iniThFAST far fewer pixels survive it than
         // at minThFAST, so the usual cell scores a third of the pixels a single pass at min(iniTh, minTh) would.
         if (nz > 0) {
-            const int d0 = txLo >> 2;
             const uint32_t Q = 0x3F3F3F3Fu;
             const int tb = (th + 1) >> 2;
             const uint32_t KH = (uint32_t)(tb - 1 + 0x80) * 0x01010101u, KL = (uint32_t)(0x80 - tb) * 0x01010101u;
@@ -567,16 +570,15 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
             // A thread keeps one dword column of the zone (4 pixels per row) and walks down the rows: addresses advance by
             // a constant and the column mask is a per-thread constant.  The order of the queue is irrelevant (scores go to
             // the map by position, the output is ranked by position): every lane reserves its own slots.
-            const int r0 = fast_div((unsigned)tid, c.mNdz), dz = tid - r0 * ndz;
+            // (r0 = tid / ndz: the thread's first zone row; its dword column d0 + tid % ndz; the mask of the zone columns
+            // [txLo, txHi] among its four pixels: per-thread constants of the cell's pattern, folded on the host)
             const int rpp = fast_div((unsigned)NT, c.mNdz); // zone rows per pass
-            if (r0 < rpp) {
-                const int d = d0 + dz, tx0 = 4 * d;
-                unsigned valid = 0xFu; // only the zone columns [txLo, txHi] count
-                if (tx0 < txLo) valid &= 0xFu << (txLo - tx0);
-                if (tx0 + 3 > txHi) valid &= 0xFu >> (tx0 + 3 - txHi);
-                const uint32_t vM = ((valid & 1u) << 7) | ((valid & 2u) << 14) | ((valid & 4u) << 21) | ((valid & 8u) << 28);
+            const uint2 pe = patE;
+            if (pe.x != 0xFFFFFFFFu) {
+                const int r0 = (int)(pe.x >> 16);
+                const uint32_t vM = pe.y;
                 const int aStep = rpp * PD;
-                int a = (r0 + 3) * PD + d; // dword index of the four centre pixels
+                int a = (int)(pe.x & 0xFFFFu); // dword index of the four centre pixels
                 for (int r = r0; r < zh; r += rpp, a += aStep) {
                     const uint32_t C = T[a], Lf = T[a - 1], R = T[a + 1], U = T[a - 3 * PD], Dn = T[a + 3 * PD];
                     const uint32_t Cq = (C >> 2) & Q, Uq = (U >> 2) & Q, Dq = (Dn >> 2) & Q;
