@@ -126,6 +126,8 @@ def test_libm_table_reproduces_host_libm_bit_for_bit(pkg, oracle):
     ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
     used, a, b = ex.debug_trig(ang)
     assert used == int(os.environ.get("ORBFE_TRIG_TABLE", "2")), "the libm table was not built on this box"
+    if used == 0:
+        pytest.skip("ORBFE_TRIG_TABLE=0: no table, the device values are the correctly rounded ones (host check fixes the descriptors)")
     ra, rb = _host_libm_sincos(ang)
     assert np.array_equal(a.view(np.uint32), ra.view(np.uint32))
     assert np.array_equal(b.view(np.uint32), rb.view(np.uint32))
