@@ -67,6 +67,99 @@ def make_frame(h, w, seed, nrect=None, noise_sigma=2.0, flat_frac=0.08):
     return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
 
 
+def _blur(img, sigma):
+    """Separable Gaussian blur (float64, reflect-101 borders), self-contained so that the frames do not depend on scipy."""
+    r = max(1, int(np.ceil(3.0 * sigma)))
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= k.sum()
+    a = np.pad(np.asarray(img, np.float64), r, mode="reflect")
+    a = sum(k[i] * a[:, i:i + a.shape[1] - 2 * r] for i in range(2 * r + 1))
+    a = sum(k[i] * a[i:i + a.shape[0] - 2 * r, :] for i in range(2 * r + 1))
+    return a
+
+
+FRAME_KINDS = ("rects", "blurred", "plateaus", "checker2", "sinus", "ramp", "mixed")
+
+
+def make_frame_kind(h, w, seed, kind):
+    """Frames that stress what `make_frame` does not; deterministic in (h, w, seed, kind).
+
+    rects     make_frame itself.
+    blurred   make_frame blurred with sigma 3..6: nearly every FAST cell falls through to the minThFAST call
+              (reference src/ORBextractor.cc:825-828) and most of those stay empty.
+    plateaus  saturated 0 / 255 regions and large exactly-flat regions between textured ones: runs of equal pixels at the
+              clamp values, score ties, empty cells next to busy ones.
+    checker2  a 2-px checkerboard (contrast from the seed) with a few flat holes: thousands of equal scores -> the strict
+              `>` of the 8-neighbour NMS and the quadtree's (size, sequence) ties at scale.
+    sinus     fine sinusoidal texture (periods 3..7 px, two orientations) on a slow gradient.
+    ramp      a pure linear ramp (no corner anywhere at iniThFAST; a few at low thresholds from quantisation steps).
+    mixed     quadrants of the above, seams included."""
+    rng = np.random.default_rng(int(seed) * 7 + 13)
+    if kind == "rects":
+        return make_frame(h, w, seed)
+    if kind == "blurred":
+        sigma = float(rng.uniform(3.0, 6.0))
+        return np.ascontiguousarray(np.clip(np.rint(_blur(make_frame(h, w, seed), sigma)), 0, 255).astype(np.uint8))
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "plateaus":
+        img = make_frame(h, w, seed, noise_sigma=1.0).astype(np.float64)
+        img = (img - 128.0) * 2.6 + 128.0  # stretch: a good part of the frame clips to 0 / 255
+        for _ in range(int(rng.integers(6, 14))):  # exactly flat boxes, some at the clamp values
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            x1, y1 = min(w, x0 + int(rng.integers(20, max(21, w // 3)))), min(h, y0 + int(rng.integers(20, max(21, h // 3))))
+            img[y0:y1, x0:x1] = float(rng.choice([0.0, 255.0, 255.0, 0.0, rng.uniform(0, 255)]))
+        return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    if kind == "checker2":
+        lo = float(rng.uniform(0, 110))
+        hi = lo + float(rng.uniform(30, 145))
+        p = int(rng.choice([2, 2, 3]))
+        img = np.where(((xx // p) + (yy // p)) % 2 == 0, lo, hi)
+        for _ in range(int(rng.integers(3, 9))):  # flat holes: corners along their rims, empty cells inside
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            img[y0:y0 + int(rng.integers(10, 90)), x0:x0 + int(rng.integers(10, 90))] = float(rng.uniform(0, 255))
+        return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    if kind == "sinus":
+        p1, p2 = float(rng.uniform(3, 7)), float(rng.uniform(3, 7))
+        a1, a2 = float(rng.uniform(0, np.pi)), float(rng.uniform(0, np.pi))
+        amp = float(rng.uniform(25, 60))
+        img = 128.0 + 50.0 * (xx / max(w - 1, 1) - 0.5) + amp * np.sin(2 * np.pi * (xx * np.cos(a1) + yy * np.sin(a1)) / p1) \
+            * np.sin(2 * np.pi * (xx * np.cos(a2) + yy * np.sin(a2)) / p2)
+        return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    if kind == "ramp":
+        gx, gy = float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4))
+        img = 128.0 + gx * (xx - w / 2.0) + gy * (yy - h / 2.0)
+        return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    if kind == "mixed":
+        out = make_frame(h, w, seed).copy()
+        hy, hx = h // 2, w // 2
+        out[:hy, hx:] = make_frame_kind(h, w, seed + 1, "checker2")[:hy, hx:]
+        out[hy:, :hx] = make_frame_kind(h, w, seed + 2, "blurred")[hy:, :hx]
+        out[hy:, hx:] = make_frame_kind(h, w, seed + 3, "plateaus")[hy:, hx:]
+        return np.ascontiguousarray(out)
+    raise ValueError("unknown frame kind %r" % (kind,))
+
+
+def narrow_last_column_widths(scale=1.2, nlevels=8, lo=300, hi=2000):
+    """Image widths at which the LAST FAST cell column of some pyramid level is at most 12 px wide, i.e. its detection zone
+    is 1..6 px wide, or the column is skipped altogether by the `iniX >= maxBorderX - 6` test of
+    src/ORBextractor.cc:792-802 (zone <= 0).  Returns (width, level, zone_width) triples, the arithmetic restated from
+    :771-802 (minBorderX = 16, maxBorderX = cols - 16, W = 35).  Needs >= 25 cell columns, i.e. levels >= ~900 px wide."""
+    out = []
+    for wd in range(lo, hi):
+        for lvl in range(nlevels):
+            wl = int(np.rint(np.float32(wd) * (np.float32(1.0) / np.float32(scale) ** np.float32(lvl))))
+            width = wl - 32
+            if width < 35:
+                break
+            ncols = int(np.float32(width) / np.float32(35))
+            wcell = int(np.ceil(np.float32(width) / np.float32(ncols)))
+            zone = width - (ncols - 1) * wcell - 6
+            if zone <= 6:
+                out.append((wd, lvl, zone))
+                break
+    return out
+
+
 def make_stereo_pair(h, w, seed, shift=24):
     """Left frame and a horizontally shifted, re-noised right frame (config C3)."""
     left = make_frame(h, w, seed)

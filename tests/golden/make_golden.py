@@ -29,6 +29,12 @@ CASES = [  # (name, rows, cols, seed, nfeatures, lap)
     ("fisheye_320x320", 320, 320, 2026, 500, (60, 250)),
 ]
 
+# round 4: content the rectangle frames do not have (synth.make_frame_kind)
+KIND_CASES = [  # (name, rows, cols, seed, nfeatures, lap, kind)
+    ("blurred_376x240", 240, 376, 2031, 400, (0, 0), "blurred"),
+    ("checker_320x320", 320, 320, 2032, 600, (0, 1000), "checker2"),
+    ("plateaus_376x240", 240, 376, 2033, 400, (50, 300), "plateaus"),
+]
 
 WINDOW_CASES = [("proj_local_map", dict(seed=7101, mode=0, n=600, nq=500)),
                 ("proj_last_frame", dict(seed=7102, mode=1, n=600, nq=500, th=7.0, check_orientation=True)),
@@ -37,9 +43,9 @@ WINDOW_CASES = [("proj_local_map", dict(seed=7101, mode=0, n=600, nq=500)),
                 ("sim3_projection", dict(seed=7105, mode=1, n=600, nq=500, th=4.0, loop="sim3_projection", taken_frac=0.3))]
 
 
-def main():
-    for name, rows, cols, seed, nf, lap in CASES:
-        img = synth.make_frame(rows, cols, seed)
+def extractor_cases(cases):
+    for name, rows, cols, seed, nf, lap, kind in cases:
+        img = synth.make_frame_kind(rows, cols, seed, kind)
         out = {"image_sha256": np.frombuffer(hashlib.sha256(img.tobytes()).digest(), np.uint8)}
         for mode, tag in ((O.TRIG_LIBM, "libm"), (O.TRIG_CR, "cr")):
             ex = O.Extractor(nf, 1.2, 8, 20, 7, trig=mode)
@@ -52,6 +58,13 @@ def main():
                 out["level3"] = ex.level(3)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, int(out["mono_libm"]), len(out["kps_libm"]))
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "kinds":  # only the fixtures added in round 4
+        extractor_cases(KIND_CASES)
+        return
+    extractor_cases([c + ("rects",) for c in CASES] + KIND_CASES)
     # matcher fixture
     d1, d2, a1, a2 = MI.descriptor_sets(400, 380, 77)
     fv1, fv2 = MI.feature_vectors(d1, d2, 77)

@@ -1,0 +1,101 @@
+"""GPU parity on image CONTENT the rectangle frames do not have: heavily blurred frames (most FAST cells
+on the minThFAST call, src/ORBextractor.cc:825-828), saturated 0 / 255 plateaus and exactly flat regions, a 2-px
+checkerboard and fine sinusoids (thousands of equal scores: NMS strictness, quadtree (size, sequence) ties at scale), a
+pure ramp (no keypoint at all), quadrants of these with seams, and image widths whose last cell column is 1..6 px wide or
+skipped (:792-802).  HIP extractor through the C ABI vs the CPU oracle, every stage, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def _compare(pkg, oracle, img, nf, lap, ini=20, mn=7, stages=True, nlevels=8):
+    ex = pkg.ORBextractor(nf, 1.2, nlevels, ini, mn)
+    ref = oracle.Extractor(nf, 1.2, nlevels, ini, mn)
+    try:
+        mono, kps, desc = ex(img, lap)
+        rmono, rkps, rdesc = ref.extract(img, lap, cap=8 * nf + 400)
+        if stages:
+            for lvl in range(nlevels):
+                cx, cy, cs = ex.debug_candidates(lvl)
+                rc = ref.candidates(lvl)
+                assert len(cx) == len(rc), "candidate count level %d: %d vs %d" % (lvl, len(cx), len(rc))
+                assert np.array_equal(cx, rc["x"].astype(np.int32)) and np.array_equal(cy, rc["y"].astype(np.int32))
+                assert np.array_equal(cs, rc["response"].astype(np.int32))
+                kx, ky, ks = ex.debug_level_keypoints(lvl)
+                rk = ref.level_keypoints(lvl)
+                assert len(kx) == len(rk), "quadtree count level %d" % lvl
+                assert np.array_equal(kx + 16, rk["x"].astype(np.int32)) and np.array_equal(ky + 16, rk["y"].astype(np.int32))
+        assert mono == rmono and len(kps) == len(rkps)
+        for f in FIELDS:
+            assert np.array_equal(kps[f], rkps[f]), f
+        assert np.array_equal(desc, rdesc)
+        return len(kps), [len(ref.candidates(l)) for l in range(nlevels)]
+    finally:
+        ex.close()
+
+
+@pytest.mark.parametrize("kind", ["blurred", "plateaus", "checker2", "sinus", "ramp", "mixed"])
+@pytest.mark.parametrize("hw,nf,lap,seed", [((480, 752), 1000, (0, 1000), 31), ((240, 376), 600, (0, 0), 32),
+                                            ((376, 1241), 2000, (300, 900), 33)])
+def test_content_kinds(pkg, oracle, kind, hw, nf, lap, seed):
+    img = pkg.synth.make_frame_kind(hw[0], hw[1], seed, kind)
+    n, cands = _compare(pkg, oracle, img, nf, lap)
+    if kind == "ramp":
+        assert n == 0
+    elif kind in ("checker2", "sinus"):
+        assert max(cands) > 1500  # the levels with thousands of (equal-score) candidates exist
+
+
+def test_blurred_frames_live_on_the_min_threshold(pkg, oracle):
+    # >= 80 % of the FAST cells of a sigma 3..6 frame find nothing at iniThFAST (the second cv::FAST call of :825-828 runs):
+    # counted with the oracle, level 0, by comparing the candidates of (20, 7) with those of (20, 20)
+    img = pkg.synth.make_frame_kind(480, 752, 41, "blurred")
+    a = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    b = oracle.Extractor(1000, 1.2, 8, 20, 20)
+    a.extract(img, (0, 0))
+    b.extract(img, (0, 0))
+    ca, cb = a.candidates(0), b.candidates(0)
+
+    def cells(c):
+        return set(zip((c["x"].astype(int) // 36).tolist(), (c["y"].astype(int) // 36).tolist()))  # (relative to the border)
+    total = ((752 - 32) // 35) * ((480 - 32) // 35)
+    assert len(cells(cb)) <= 0.2 * total, (len(cells(cb)), total)
+    assert len(cells(ca)) > len(cells(cb))
+    for th in ((20, 7), (30, 5), (12, 3)):
+        _compare(pkg, oracle, img, 1000, (0, 0), th[0], th[1])
+
+
+@pytest.mark.parametrize("width", [908, 1083, 1084, 1118, 1153, 1223])
+def test_last_cell_column_1_to_6_px_or_skipped(pkg, oracle, width):
+    # widths from synth.narrow_last_column_widths(): zone of the last column 6, 1, 2, 0 (skipped), -1, -3 px
+    hit = [t for t in pkg.synth.narrow_last_column_widths(lo=width, hi=width + 1)]
+    assert hit and hit[0][0] == width and hit[0][2] <= 6
+    for kind, seed in (("rects", 5), ("checker2", 6)):
+        img = pkg.synth.make_frame_kind(260, width, seed, kind)
+        _compare(pkg, oracle, img, 1500, (0, 0), nlevels=6)
+
+
+def test_batches_of_mixed_content(pkg, oracle):
+    # 16 frames (whole images per XCD in K-PYR / K-FAST / K-DESC) of every kind, one call
+    kinds = list(pkg.synth.FRAME_KINDS)
+    imgs = [pkg.synth.make_frame_kind(300, 500, 70 + i, kinds[i % len(kinds)]) for i in range(16)]
+    laps = [(0, 0) if i % 2 else (100, 350) for i in range(16)]
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7)
+    ref = oracle.Extractor(800, 1.2, 8, 20, 7)
+    res = ex.extract_batch(imgs, laps)
+    for i, (mono, kps, desc) in enumerate(res):
+        rmono, rkps, rdesc = ref.extract(imgs[i], laps[i], cap=8 * 800 + 400)
+        assert mono == rmono and len(kps) == len(rkps), (i, kinds[i % len(kinds)])
+        for f in FIELDS:
+            assert np.array_equal(kps[f], rkps[f]), (i, f)
+        assert np.array_equal(desc, rdesc), i
+    ex.close()

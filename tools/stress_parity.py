@@ -37,13 +37,15 @@ def _one(case, rng, max_side, log, bad):
         otrig = O.TRIG_CR if trig == pkg.binding.TRIG_CR else O.TRIG_LIBM
         # batches of >= 8 frames take the whole-images-per-XCD orders of K-PYR / K-FAST / K-DESC
         nb = int(rng.choice([1, 2, 3, 8, 9, 16])) if H * W < 450000 else int(rng.integers(1, 4))
-        kind = case % 4
+        # content: rectangle frames, uniform noise, and (round 4) the kinds of synth.make_frame_kind -- blurred, saturated /
+        # flat plateaus, 2-px checkerboard, fine sinusoids, pure ramp, quadrants of these
+        kind = ("rects", "rects", "blurred", "noise", "plateaus", "checker2", "rects", "sinus", "mixed", "ramp", "rects", "noise")[case % 12]
         imgs = []
         for b in range(nb):
-            if kind == 3:
+            if kind == "noise":
                 imgs.append(rng.integers(0, 256, size=(H, W), dtype=np.uint8))
             else:
-                imgs.append(pkg.synth.make_frame(H, W, int(rng.integers(0, 1 << 30))))
+                imgs.append(pkg.synth.make_frame_kind(H, W, int(rng.integers(0, 1 << 30)), kind))
         try:
             ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, trig=trig)
         except Exception as e:
@@ -63,7 +65,7 @@ def _one(case, rng, max_side, log, bad):
                 same = mono == rmono and len(kps) == len(rkps) and np.array_equal(desc, rdesc) and \
                     all(np.array_equal(kps[f], rkps[f]) for f in FIELDS)
                 ok &= bool(same)
-            desc = "%s lev %d sf %s nF %d th %s lap %s trig %d batch %d n %s" % ((H, W), nlev, scale, nf, (ini, mn), lap, trig, nb,
+            desc = "%s %s lev %d sf %s nF %d th %s lap %s trig %d batch %d n %s" % (kind, (H, W), nlev, scale, nf, (ini, mn), lap, trig, nb,
                                                                                  [len(o[1]) for o in outs])
             log(case, desc, "OK" if ok else "MISMATCH")
             if not ok:
