@@ -11,12 +11,17 @@
  *
  * With OpenCV present the cv:: types are used; without it (this repo's own test build) a minimal
  * stand-in for cv::KeyPoint / cv::Mat is provided so the adapter itself can be compiled and
- * exercised.  mvImagePyramid is filled lazily: set ORBextractor::fetchPyramid = true (rectified
- * stereo needs it for the SAD refinement in Frame::ComputeStereoMatches, src/Frame.cc:894-909).
+ * exercised.  mvImagePyramid needs no flag (round 4): the pyramid stays on the device and a level is
+ * downloaded the first time it is INDEXED after an extraction, which is how its only reader -- the SAD
+ * refinement of Frame::ComputeStereoMatches, src/Frame.cc:804, :894-909 -- uses it; monocular and
+ * fisheye callers, which never look, pay nothing.  ORBextractor::fetchPyramid = true downloads all
+ * levels right after every operator() instead (a caller that hands the extractor to another thread
+ * while the next frame is being extracted).
  */
 #ifndef ORBFE_ADAPTER_ORBEXTRACTOR_H
 #define ORBFE_ADAPTER_ORBEXTRACTOR_H
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -44,8 +49,9 @@ public:
         mvInvLevelSigma2.resize(nlevels);
         orbfe_get_scale_tables(ctx, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
                                mvInvLevelSigma2.data());
-        mvImagePyramid.resize(nlevels);
+        mvImagePyramid.bind(this, nlevels);
         pyramidStore.resize(nlevels);
+        levelValid.assign((size_t)nlevels, 0);
     }
     ~ORBextractor() { orbfe_destroy(ctx); }
     ORBextractor(const ORBextractor&) = delete;
@@ -70,45 +76,20 @@ public:
         const int cap = orbfe_max_keypoints(ctx, image.rows, image.cols);
         if (cap < 0) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(cap));
         static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_kp), "cv::KeyPoint layout");
-        std::vector<cv::KeyPoint> kps((size_t)cap);
-        std::vector<uint8_t> desc((size_t)cap * 32);
+        // (the cap-sized result buffers are members: no allocation and no zero-fill per frame)
+        if (scratchKps.size() < (size_t)cap) scratchKps.resize((size_t)cap);
+        if (scratchDesc.size() < (size_t)cap * 32) scratchDesc.resize((size_t)cap * 32);
         int n = 0;
+        std::fill(levelValid.begin(), levelValid.end(), 0); // whatever mvImagePyramid held belongs to the previous frame
+        haveFrame = false;
         const int mono = orbfe_extract(ctx, data, image.rows, image.cols, step, vLappingArea[0], vLappingArea[1],
-                                       reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(), cap, &n);
+                                       reinterpret_cast<orbfe_kp*>(scratchKps.data()), scratchDesc.data(), cap, &n);
         if (mono < -1) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(mono));
-        kps.resize((size_t)n);
-        _keypoints.swap(kps);
-#ifdef ORBFE_HAVE_OPENCV
-        if (n == 0) {
-            _descriptors.release();
-        } else {
-            _descriptors.create(n, 32, CV_8U);
-            cv::Mat d = _descriptors.getMat();
-            for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), desc.data() + (size_t)i * 32, 32);
-        }
-#else
-        if (n == 0) {
-            _descriptors.release();
-        } else {
-            _descriptors.create(n, 32);
-            std::memcpy(_descriptors.data, desc.data(), (size_t)n * 32);
-        }
-#endif
-        if (fetchPyramid) {
-            for (int l = 0; l < nlevels; l++) {
-                int r = 0, c = 0;
-                orbfe_get_level(ctx, 0, l, nullptr, 0, &r, &c);
-#ifdef ORBFE_HAVE_OPENCV
-                pyramidStore[l].create(r, c, CV_8U);
-                orbfe_get_level(ctx, 0, l, pyramidStore[l].data, pyramidStore[l].step, &r, &c);
-                mvImagePyramid[l] = pyramidStore[l](cv::Rect(19, 19, c - 38, r - 38)); // ROI inside the padded buffer
-#else
-                pyramidStore[l].create(r, c);
-                orbfe_get_level(ctx, 0, l, pyramidStore[l].data, pyramidStore[l].step, &r, &c);
-                mvImagePyramid[l] = cv::Mat(r - 38, c - 38, pyramidStore[l].ptr(19) + 19, pyramidStore[l].step);
-#endif
-            }
-        }
+        haveFrame = mono >= 0;
+        _keypoints.assign(scratchKps.begin(), scratchKps.begin() + n);
+        fill_descriptors(_descriptors, scratchDesc.data(), n);
+        if (fetchPyramid)
+            for (int l = 0; l < nlevels; l++) ensure_level(l);
         return mono;
     }
 
@@ -133,17 +114,24 @@ public:
         if (L.rows != R.rows || L.cols != R.cols || L.step != R.step) throw std::runtime_error("ExtractStereoPair: unequal images");
         const int cap = orbfe_max_keypoints(ctx, L.rows, L.cols);
         if (cap < 0) throw std::runtime_error(std::string("ORBextractor: ") + orbfe_error_string(cap));
-        std::vector<cv::KeyPoint> kps((size_t)2 * cap);
-        std::vector<uint8_t> desc((size_t)2 * cap * 32);
+        if (scratchKps.size() < (size_t)2 * cap) scratchKps.resize((size_t)2 * cap);
+        if (scratchDesc.size() < (size_t)2 * cap * 32) scratchDesc.resize((size_t)2 * cap * 32);
+        std::vector<cv::KeyPoint>& kps = scratchKps;
+        std::vector<uint8_t>& desc = scratchDesc;
+        std::fill(levelValid.begin(), levelValid.end(), 0);
+        haveFrame = false;
         const uint8_t* two[2] = {L.data, R.data};
         const int lap[4] = {lapLeft[0], lapLeft[1], lapRight[0], lapRight[1]};
         int n[2] = {0, 0}, mono[2] = {0, 0};
         // one call, one host wait: both images as a batch of two, ComputeStereoMatches queued behind them on the same stream
-        std::vector<float> uR((size_t)cap, -1.0f), dep((size_t)cap, -1.0f);
+        scratchU.assign((size_t)cap, -1.0f);
+        scratchD.assign((size_t)cap, -1.0f);
+        std::vector<float>&uR = scratchU, &dep = scratchD;
         const int matches = orbfe_extract_stereo_pair(ctx, two[0], two[1], L.rows, L.cols, L.step, lap,
                                                       reinterpret_cast<orbfe_kp*>(kps.data()), desc.data(), cap, n, mono, mb, mbf,
                                                       uR.data(), dep.data());
         if (matches < 0) throw std::runtime_error(std::string("orbfe_extract_stereo_pair: ") + orbfe_error_string(matches));
+        haveFrame = true; // (mvImagePyramid then shows the LEFT image's levels, image 0 of the pair)
         mvuRight.assign(uR.begin(), uR.begin() + n[0]);
         mvDepth.assign(dep.begin(), dep.begin() + n[0]);
         keysLeft.assign(kps.begin(), kps.begin() + n[0]);
@@ -162,11 +150,67 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    std::vector<cv::Mat> mvImagePyramid;
-    bool fetchPyramid = false;
+    // Stands where `std::vector<cv::Mat> mvImagePyramid` stood (reference include/ORBextractor.h:83).  Indexing a level
+    // downloads it on first use after an extraction (the reference's readers only index: src/Frame.cc:804, :894-909);
+    // size() / iteration behave like the vector's.  The Mats are views of padded buffers, like the reference's
+    // (:1165-1172: mvImagePyramid[level] = temp(Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, sz.width, sz.height))), so the
+    // 19-px reflected frame around a level is addressable from its Mat.
+    class PyramidView {
+    public:
+        size_t size() const { return mats.size(); }
+        bool empty() const { return mats.empty(); }
+        cv::Mat& operator[](size_t l)
+        {
+            owner->ensure_level((int)l);
+            return mats[l];
+        }
+        const cv::Mat& operator[](size_t l) const
+        {
+            owner->ensure_level((int)l);
+            return mats[l];
+        }
+        cv::Mat& at(size_t l) { return (*this)[l]; }
+        std::vector<cv::Mat>::iterator begin() { return all().begin(); }
+        std::vector<cv::Mat>::iterator end() { return all().end(); }
+        operator const std::vector<cv::Mat>&() { return all(); }
+
+    private:
+        friend class ORBextractor;
+        void bind(ORBextractor* o, int n)
+        {
+            owner = o;
+            mats.resize((size_t)n);
+        }
+        std::vector<cv::Mat>& all()
+        {
+            for (size_t l = 0; l < mats.size(); l++) owner->ensure_level((int)l);
+            return mats;
+        }
+        ORBextractor* owner = nullptr;
+        mutable std::vector<cv::Mat> mats;
+    };
+    PyramidView mvImagePyramid;
+    bool fetchPyramid = false; // true: every operator() downloads all levels at once (see the header comment)
     orbfe_ctx* handle() { return ctx; }
 
 protected:
+    // one level of the last extracted image, device -> the level's padded host buffer (once per frame and level)
+    void ensure_level(int l)
+    {
+        if (l < 0 || l >= nlevels || levelValid[(size_t)l] || !haveFrame) return;
+        int r = 0, c = 0;
+        if (orbfe_get_level(ctx, 0, l, nullptr, 0, &r, &c) < 0) return;
+#ifdef ORBFE_HAVE_OPENCV
+        pyramidStore[l].create(r, c, CV_8U);
+        if (orbfe_get_level(ctx, 0, l, pyramidStore[l].data, pyramidStore[l].step, &r, &c) < 0) return;
+        mvImagePyramid.mats[l] = pyramidStore[l](cv::Rect(19, 19, c - 38, r - 38)); // ROI inside the padded buffer
+#else
+        if (pyramidStore[l].rows != r || pyramidStore[l].cols != c) pyramidStore[l].create(r, c);
+        if (orbfe_get_level(ctx, 0, l, pyramidStore[l].data, pyramidStore[l].step, &r, &c) < 0) return;
+        mvImagePyramid.mats[l] = cv::Mat(r - 38, c - 38, pyramidStore[l].ptr(19) + 19, pyramidStore[l].step);
+#endif
+        levelValid[(size_t)l] = 1;
+    }
     static void fill_descriptors(cv::OutputArray out, const uint8_t* rows, int n)
     {
 #ifdef ORBFE_HAVE_OPENCV
@@ -176,7 +220,9 @@ protected:
         }
         out.create(n, 32, CV_8U);
         cv::Mat d = out.getMat();
-        for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), rows + (size_t)i * 32, 32);
+        if (d.isContinuous()) std::memcpy(d.data, rows, (size_t)n * 32);
+        else
+            for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), rows + (size_t)i * 32, 32);
 #else
         if (n == 0) {
             out.release();
@@ -191,6 +237,11 @@ protected:
     double scaleFactor;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::vector<cv::Mat> pyramidStore; // one padded buffer per level (sized by the constructor)
+    std::vector<char> levelValid;      // mvImagePyramid[l] shows the last extracted image
+    bool haveFrame = false;
+    std::vector<cv::KeyPoint> scratchKps; // cap-sized result buffers, reused from call to call
+    std::vector<uint8_t> scratchDesc;
+    std::vector<float> scratchU, scratchD;
 };
 
 } // namespace ORB_SLAM3

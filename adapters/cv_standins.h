@@ -66,6 +66,10 @@ public:
         data = nullptr;
     }
     bool empty() const { return rows == 0 || cols == 0 || !data; }
+    bool isContinuous() const { return step == (size_t)cols * (type_ == CV_32F ? 4 : 1); }
+    // views, as cv::Mat::rowRange / colRange give them (what Frame::ComputeStereoMatches takes of a pyramid level)
+    Mat rowRange(int r0, int r1) const { return Mat(r1 - r0, cols, data + (size_t)r0 * step, step); }
+    Mat colRange(int c0, int c1) const { return Mat(rows, c1 - c0, data + (size_t)c0 * (type_ == CV_32F ? 4 : 1), step); }
     int type() const { return type_; }
     uint8_t* ptr(int r) { return data + (size_t)r * step; }
     const uint8_t* ptr(int r) const { return data + (size_t)r * step; }

@@ -20,7 +20,7 @@ int main(int argc, char** argv)
     std::vector<cv::KeyPoint> mvKeys;
     cv::Mat mDescriptors, mask;
     std::vector<int> vLapping = {0, 1000};
-    mpORBextractorLeft->fetchPyramid = true;
+    // (no flag set: mvImagePyramid is filled when it is indexed)
     int monoLeft = (*mpORBextractorLeft)(im, mask, mvKeys, mDescriptors, vLapping);
     unsigned long long h = 1469598103934665603ull;
     for (int i = 0; i < mDescriptors.rows * 32; i++) h = (h ^ mDescriptors.data[i]) * 1099511628211ull;
@@ -30,6 +30,25 @@ int main(int argc, char** argv)
     }
     printf("%d %zu %llu %d %d %d\n", monoLeft, mvKeys.size(), h, mpORBextractorLeft->GetLevels(),
            mpORBextractorLeft->mvImagePyramid[3].rows, mpORBextractorLeft->mvImagePyramid[3].cols);
+    {
+        // the access pattern of Frame::ComputeStereoMatches (src/Frame.cc:804, :894-909) on mvImagePyramid, with no flag set:
+        // the 11x11 window around every keypoint at its own octave, summed and hashed
+        const int w = 5;
+        const std::vector<float> inv = mpORBextractorLeft->GetInverseScaleFactors();
+        unsigned long long hp = 1469598103934665603ull;
+        const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
+        for (size_t i = 0; i < mvKeys.size(); i++) {
+            const cv::KeyPoint& kpL = mvKeys[i];
+            const float scaleFactor = inv[kpL.octave];
+            const int scaleduL = (int)(kpL.pt.x * scaleFactor + 0.5f), scaledvL = (int)(kpL.pt.y * scaleFactor + 0.5f);
+            cv::Mat IL = mpORBextractorLeft->mvImagePyramid[kpL.octave].rowRange(scaledvL - w, scaledvL + w + 1).colRange(scaleduL - w, scaleduL + w + 1);
+            unsigned sum = 0;
+            for (int r = 0; r < IL.rows; r++)
+                for (int c = 0; c < IL.cols; c++) sum += IL.ptr(r)[c];
+            hp = (hp ^ sum) * 1099511628211ull;
+        }
+        printf("%d %llu\n", nRows, hp);
+    }
     cv::Mat empty;
     printf("%d\n", (*mpORBextractorLeft)(empty, mask, mvKeys, mDescriptors, vLapping));
     if (argc > 5) { // a right image: the stereo frame in one call (ExtractStereoPair), results as checksums

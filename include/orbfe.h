@@ -45,8 +45,9 @@ extern "C" {
  *   ORBFE_ERR_IMAGE_SMALL  some pyramid level is narrower or lower than 32 + 35 px: the reference's cell grid has no cell
  *                          there and divides by zero (src/ORBextractor.cc:779-782)
  *   ORBFE_ERR_IMAGE_LARGE  an image side above 4096 px (the packed candidate format holds 12-bit coordinates)
- *   ORBFE_ERR_NFEATURES    nfeatures so large that one level's quadtree does not fit a workgroup's LDS (~1500 nodes per
- *                          level, nfeatures <~ 6500 at 8 levels / 1.2) */
+ *   ORBFE_ERR_NFEATURES    nfeatures so large that an image would need more than 65535 keypoint slots (round 4: levels whose
+ *                          quadtree tables exceed a workgroup's LDS -- nfeatures above ~7800 at 8 levels / 1.2, such as the
+ *                          5 x nFeatures initialisation extractor of src/Tracking.cc:1157 -- run on a global-memory table) */
 #define ORBFE_ERR_IMAGE_SMALL (-5)
 #define ORBFE_ERR_IMAGE_LARGE (-6)
 #define ORBFE_ERR_NFEATURES (-7)
@@ -208,6 +209,18 @@ int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm tri
  * returns 2 when the table of libm values was used, 1 for the compact code table, 0 for none (ORBFE_TRIG_CR, or
  * no table), < 0 on error. */
 int orbfe_debug_trig(orbfe_ctx*, const float* angles_deg, int n, float* a_out, float* b_out);
+/* The cache file of the libm table (65 MB of 4-bit codes; default directory /dev/shm, ORBFE_TRIG_CACHE=<dir> moves it, =0
+ * disables it), host side only -- these need no device.  The file is trusted only when it is a regular file (symbolic links
+ * are not followed) owned by the calling user, not writable by group or others, of the expected size, with the expected
+ * magic / angle range / libm fingerprint and a matching checksum over its WHOLE payload (the library verifies that checksum
+ * on the device after the upload; `_check` runs the same tests on the host and names the first one that fails).
+ * `_path`: the file this process would use (returns its length, 0 when disabled).  `_write`: a file in the library's
+ * format around `payload` (`_payload_bytes()` bytes), created exclusively with mode 0600 under a temporary name and
+ * renamed. */
+int orbfe_debug_trig_cache_path(char* out, int cap);
+size_t orbfe_debug_trig_cache_payload_bytes(void);
+int orbfe_debug_trig_cache_write(const char* path, const uint8_t* payload, size_t bytes);
+int orbfe_debug_trig_cache_check(const char* path, const char** why);
 
 /* Frame::ComputeStereoMatches (src/Frame.cc:797-967), rectified stereo.  `left` / `right` are the contexts
  * that just extracted the two images (same size and parameters, same device): their pyramids are read in

@@ -298,7 +298,8 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident", "orbfe_extract_stereo_pair",
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
            "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
-           "orbfe_vocab_load_text"]
+           "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
+           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check"]
 
 
 def _p(a):

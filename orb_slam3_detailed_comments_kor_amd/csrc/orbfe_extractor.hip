@@ -124,6 +124,9 @@ struct orbfe_geom_state {
     int nCells = 0, maxKp = 0, maxListCap = 0;
     size_t qtLdsBytes = 0;
     int qtKeyOff = 0, qtKeyCap = 0;
+    std::vector<int> qtSmall, qtBig; // levels whose quadtree tables live in LDS / in the global scratch area (k_octree<true>)
+    size_t qtBigLdsBytes = 0, qtScratchStride = 0;
+    int qtBigKeyOff = 0, qtBigKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
     size_t fastLdsBytes = 0;
     std::vector<OrbFastCell> fc; // K-FAST's cell records
@@ -186,6 +189,7 @@ struct orbfe_ctx : orbfe_geom_state {
     float* userRays = nullptr; // device pointer supplied by orbfe_set_ray_output
     DevBuf<int32_t> d_destMap; // K-PACK's output slot per keypoint slot (fisheye rays only)
     DevBuf<uint32_t> d_lvlPre; // K-QT's partition word per keypoint slot
+    DevBuf<int> d_qtScratch;   // node tables of the levels that do not fit the LDS (k_octree<true>)
     DevBuf<int> d_taps;
     bool tapsDirty = true;
     uint32_t tapWords[32] = {}; // host copy of what d_taps holds (stays alive while the upload is in flight)
@@ -492,15 +496,39 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         }
         c->fastThreads = nt;
     }
-    c->qtKeyOff = 64 + std::max(24 * maxLC, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
+    // K-QT: a level's node tables take 24 ints per list entry.  Levels whose tables fit a workgroup's LDS (160 KB) run the
+    // LDS instantiation; larger ones (round 4: nfeatures above ~7800, e.g. the 5 x nFeatures initialisation extractor of
+    // src/Tracking.cc:1157 with KITTI's 2000) run k_octree<true> on a global scratch area instead of being refused.
+    if (maxKp > 65535) return ORBFE_ERR_NFEATURES; // keypoint slots / list positions are packed in 16 bits
+    c->qtSmall.clear();
+    c->qtBig.clear();
+    int maxLCsmall = 0, maxLCbig = 0;
+    const int ldsNodeBudget = (160 * 1024 - 64 * (int)sizeof(int)) / (24 * (int)sizeof(int)); // list entries per workgroup
+    int forceBig = -1;
+    if (const char* e = getenv("ORBFE_QT_GLOBAL_FROM")) forceBig = atoi(e); // tests: list capacities >= this take the global path
+    for (int l = 0; l < nl; l++) {
+        const int LC = c->lg[l].listCap;
+        if (LC > ldsNodeBudget || (forceBig >= 0 && LC >= forceBig)) {
+            c->qtBig.push_back(l);
+            maxLCbig = std::max(maxLCbig, LC);
+        } else {
+            c->qtSmall.push_back(l);
+            maxLCsmall = std::max(maxLCsmall, LC);
+        }
+    }
+    c->qtKeyOff = 64 + std::max(24 * maxLCsmall, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
     c->qtLdsBytes = sizeof(int) * (size_t)c->qtKeyOff;
-    if (c->qtLdsBytes > 160 * 1024) return ORBFE_ERR_NFEATURES; // nfeatures too large for one workgroup's LDS
     // room for the key arrays (4 B key + 2 B node index each) while staying under 64 KB
     c->qtKeyCap = 0;
     if (c->qtLdsBytes + 6 * 1024 <= 64 * 1024) {
         c->qtKeyCap = (int)std::min<size_t>(4096, (64 * 1024 - c->qtLdsBytes) / 6) & ~63;
         c->qtLdsBytes += 6 * (size_t)c->qtKeyCap;
     }
+    // the global instantiation: LDS holds the scalars, the gather's scan buffers and the key arrays only
+    c->qtBigKeyOff = 64 + 2048;
+    c->qtBigKeyCap = 4096;
+    c->qtBigLdsBytes = sizeof(int) * (size_t)c->qtBigKeyOff + 6 * (size_t)c->qtBigKeyCap;
+    c->qtScratchStride = align_up((size_t)24 * (size_t)std::max(maxLCbig, 1), 4);
     return 0;
 }
 
@@ -574,7 +602,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
             std::swap(cur, c->geomCache[i]);
             if (c->geomCache[i].lg.empty()) c->geomCache.erase(c->geomCache.begin() + (long)i);
             if (c->qtLdsBytes > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
+                HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)c->qtLdsBytes));
             c->capImgs = 0; // the per-image strides changed: re-check every buffer's size
             return 0;
@@ -750,7 +778,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
                       getenv("ORBFE_PYR_UNFUSED") == nullptr;
     }
     if (c->qtLdsBytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)c->qtLdsBytes));
     c->rows = rows;
     c->cols = cols;
@@ -787,6 +815,7 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
         if (c->d_lvlCount.n != before)
             HIP_TRY(hipMemsetAsync(c->d_lvlCount.p, 0, c->d_lvlCount.n * sizeof(int32_t), c->stream)); // (ordered before K-QT)
     }
+    if (!c->qtBig.empty() && (r = c->d_qtScratch.ensure(B * c->qtBig.size() * c->qtScratchStride)) < 0) return r;
     if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
     c->lapDevCount = 0; // possibly a new buffer
     if ((r = c->d_destMap.ensure(B * std::max(K, c->kpStride))) < 0) return r;
@@ -881,13 +910,18 @@ bool small_angles_ok()
 
 // ---- the compact table's cache file.  Building the table means evaluating libm's cosf / sinf for 1.29e8 angles (all
 // host cores, and every rank of a node would do it at once).  The 65 MB of codes are therefore kept in a file (default
-// directory /dev/shm, ORBFE_TRIG_CACHE=<dir> or =0 for none) named after a fingerprint of THIS host's libm, and the
-// next process -- a rank of the same job, the next run -- reads them back instead: first call 60-90 ms -> ~15 ms.
+// directory /dev/shm, ORBFE_TRIG_CACHE=<dir> or =0 for none) named after the user and a fingerprint of THIS host's libm, and
+// the next process -- a rank of the same job, the next run -- reads them back instead: first call 60-90 ms -> ~15 ms.
+// Round 4: the directory is world-writable, so the file is only trusted when it is a regular
+// file (no symlink followed) that belongs to this user and that nobody else may write; it is created exclusively with mode
+// 0600 under a per-user name; its WHOLE payload is checksummed -- on the device, where it has just been uploaded -- and a
+// file that fails any of this is ignored and rebuilt; the bytes are read() into pinned staging, never mapped (a file
+// truncated under a mapping would raise SIGBUS inside the copy).
 struct TrigCacheHeader {
-    char magic[8];       // "ORBFETC3"
+    char magic[8];       // "ORBFETC4"
     uint32_t u0, n;      // first angle (bit pattern) and count
-    uint64_t libmPrint;  // FNV-1a over libm's results on a sample
-    uint64_t payloadSum; // FNV-1a over the code bytes
+    uint64_t libmPrint;  // FNV-1a over libm's results on a sample and the C library's version string
+    uint64_t payloadSum; // trig_payload_sum of the code bytes (zero-padded to whole 8-byte words)
 };
 uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
 {
@@ -895,23 +929,25 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
     for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
     return h;
 }
-// checksum of the 65-MB payload: four independent 64-bit lanes over whole words (a byte-wise FNV over 65 MB costs 60 ms --
-// as much as building the table)
-uint64_t words_sum(const void* p, size_t n)
+// the checksum k_trig_checksum computes, on the host (used when a file is written from host memory and by the checker the
+// CPU tests call); the tail of a payload that is not a multiple of 8 bytes counts as zero-padded
+uint64_t trig_payload_sum(const uint8_t* p, size_t n, uint64_t firstWord = 0)
 {
-    const uint64_t* w = (const uint64_t*)p;
+    uint64_t acc = 0;
     const size_t nw = n / 8;
-    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full, c = 0x165667B19E3779F9ull, d = 0x27D4EB2F165667C5ull;
-    size_t i = 0;
-    for (; i + 4 <= nw; i += 4 * 16) { // (every 16th group of four words: a truncated or foreign file shows, in half a ms)
-        a = (a ^ w[i]) * 0x100000001B3ull;
-        b = (b ^ w[i + 1]) * 0x100000001B3ull;
-        c = (c ^ w[i + 2]) * 0x100000001B3ull;
-        d = (d ^ w[i + 3]) * 0x100000001B3ull;
+    for (size_t i = 0; i < nw; i++) {
+        uint64_t w;
+        std::memcpy(&w, p + 8 * i, 8);
+        acc += trig_mix64(w, firstWord + i);
     }
-    for (; i < nw; i++) a = (a ^ w[i]) * 0x100000001B3ull;
-    return fnv1a((const uint8_t*)p + nw * 8, n - nw * 8, a ^ (b << 1) ^ (c << 2) ^ (d << 3));
+    if (n > nw * 8) {
+        uint64_t w = 0;
+        std::memcpy(&w, p + 8 * nw, n - nw * 8);
+        acc += trig_mix64(w, firstWord + nw);
+    }
+    return acc;
 }
+extern "C" const char* gnu_get_libc_version(void);
 uint64_t libm_fingerprint()
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -923,57 +959,130 @@ uint64_t libm_fingerprint()
         const float v[2] = {cosf(ang), sinf(ang)};
         h = fnv1a(v, sizeof v, h);
     }
+    const char* ver = gnu_get_libc_version(); // another C library build gets another file even if the sample agrees
+    if (ver) h = fnv1a(ver, std::strlen(ver), h);
     return h;
 }
 std::string trig_cache_path(uint64_t print)
 {
     const char* dir = getenv("ORBFE_TRIG_CACHE");
     if (dir && (!*dir || !std::strcmp(dir, "0"))) return std::string();
-    char name[96];
-    std::snprintf(name, sizeof name, "/orbfe_trigcodes_%016llx.bin", (unsigned long long)print);
+    char name[112];
+    std::snprintf(name, sizeof name, "/orbfe_trigcodes_u%lu_%016llx.bin", (unsigned long)geteuid(), (unsigned long long)print);
     return std::string(dir ? dir : "/dev/shm") + name;
 }
-// maps the cache file and returns its payload (nullptr: absent / stale / damaged); *map / *mapBytes for munmap
-const uint8_t* trig_cache_map(const std::string& path, uint64_t print, size_t bytes, void** map, size_t* mapBytes)
+// Opens the cache file if it may be trusted and its header fits: a regular file (O_NOFOLLOW: no symlink), owned by this
+// user, not writable by group or others, of exactly the expected size, with the right magic / range / libm fingerprint.
+// Returns the descriptor positioned at the payload (the caller closes it), or -1; *hdOut receives the header.
+int trig_cache_open(const std::string& path, uint64_t print, size_t bytes, TrigCacheHeader* hdOut, const char** why = nullptr)
 {
-    *map = nullptr;
-    if (path.empty()) return nullptr;
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return nullptr;
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = "no cache directory";
+    if (path.empty()) return -1;
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC | O_NONBLOCK);
+    *why = "cannot be opened (absent, or a symbolic link)";
+    if (fd < 0) return -1;
     struct stat st;
-    const size_t want = sizeof(TrigCacheHeader) + bytes;
-    void* m = MAP_FAILED;
-    if (fstat(fd, &st) == 0 && (size_t)st.st_size == want) m = mmap(nullptr, want, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return nullptr;
-    const TrigCacheHeader* hd = (const TrigCacheHeader*)m;
-    const uint8_t* payload = (const uint8_t*)m + sizeof(TrigCacheHeader);
-    if (std::memcmp(hd->magic, "ORBFETC3", 8) || hd->u0 != ORBFE_TRIG_U0 || hd->n != ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u ||
-        hd->libmPrint != print || words_sum(payload, bytes) != hd->payloadSum) {
-        munmap(m, want);
-        return nullptr;
+    TrigCacheHeader hd;
+    *why = nullptr;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) *why = "not a regular file";
+    else if (st.st_uid != geteuid()) *why = "owned by another user";
+    else if (st.st_mode & (S_IWGRP | S_IWOTH)) *why = "writable by group or others";
+    else if ((size_t)st.st_size != sizeof(TrigCacheHeader) + bytes) *why = "wrong size";
+    else if (read(fd, &hd, sizeof hd) != (ssize_t)sizeof hd) *why = "short read";
+    else if (std::memcmp(hd.magic, "ORBFETC4", 8) || hd.u0 != ORBFE_TRIG_U0 || hd.n != ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u)
+        *why = "another format or angle range";
+    else if (hd.libmPrint != print) *why = "another libm";
+    if (*why) {
+        close(fd);
+        return -1;
     }
-    *map = m;
-    *mapBytes = want;
-    return payload;
+    *hdOut = hd;
+    return fd;
 }
-void trig_cache_store(const std::string& path, uint64_t print, const uint8_t* src, size_t bytes)
+bool read_fully(int fd, uint8_t* dst, size_t n)
 {
-    if (path.empty()) return;
+    while (n) {
+        const ssize_t k = read(fd, dst, n);
+        if (k <= 0) return false;
+        dst += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+// Cache file -> device table `d` (codeBytes, allocated with room for the zero padding to whole words), through two pinned
+// staging buffers (read() of chunk i+1 beside the DMA of chunk i), then the full-payload checksum on the device.
+bool trig_cache_load(const std::string& path, uint64_t print, size_t bytes, uint8_t* d, hipStream_t s)
+{
+    TrigCacheHeader hd;
+    const int fd = trig_cache_open(path, print, bytes, &hd);
+    if (fd < 0) return false;
+    const size_t chunk = 8u << 20;
+    uint8_t* h[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    unsigned long long* dSum = nullptr;
+    bool ok = hipHostMalloc((void**)&h[0], chunk) == hipSuccess && hipHostMalloc((void**)&h[1], chunk) == hipSuccess &&
+              hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess && hipMalloc((void**)&dSum, 8) == hipSuccess &&
+              hipMemsetAsync(dSum, 0, 8, s) == hipSuccess;
+    const size_t padded = (bytes + 7) & ~(size_t)7;
+    if (ok && padded > bytes) ok = hipMemsetAsync(d + bytes, 0, padded - bytes, s) == hipSuccess;
+    int k = 0;
+    for (size_t off = 0; ok && off < bytes; off += chunk, k ^= 1) {
+        const size_t n = std::min(chunk, bytes - off);
+        if (off >= 2 * chunk) ok = hipEventSynchronize(ev[k]) == hipSuccess; // this buffer's previous DMA has finished
+        ok = ok && read_fully(fd, h[k], n) && hipMemcpyAsync(d + off, h[k], n, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipEventRecord(ev[k], s) == hipSuccess;
+    }
+    close(fd);
+    unsigned long long sum = 0;
+    if (ok) {
+        hipLaunchKernelGGL(k_trig_checksum, dim3(2048), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d),
+                           (unsigned long long)(padded / 8), dSum);
+        ok = hipMemcpyAsync(&sum, dSum, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess &&
+             sum == hd.payloadSum;
+    } else {
+        (void)hipStreamSynchronize(s);
+    }
+    (void)hipGetLastError();
+    for (int i = 0; i < 2; i++) {
+        if (h[i]) (void)hipHostFree(h[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    if (dSum) (void)hipFree(dSum);
+    if (!ok && getenv("ORBFE_VERBOSE")) fprintf(stderr, "orbfe: trig cache %s rejected (checksum or read error): rebuilding\n", path.c_str());
+    return ok;
+}
+// Written under a temporary name that is created exclusively (O_EXCL | O_NOFOLLOW, mode 0600) and renamed: a reader sees all
+// or nothing, a planted link or file under the temporary name makes the store fail instead of being followed.
+bool trig_cache_store(const std::string& path, uint64_t print, const uint8_t* src, size_t bytes, uint64_t payloadSum)
+{
+    if (path.empty()) return false;
     char tmp[64];
     std::snprintf(tmp, sizeof tmp, ".tmp%ld", (long)getpid());
     const std::string t = path + tmp;
-    FILE* f = std::fopen(t.c_str(), "wb");
-    if (!f) return;
+    (void)unlink(t.c_str()); // (a leftover of a crashed process with this pid)
+    const int fd = open(t.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return false;
     TrigCacheHeader hd;
-    std::memcpy(hd.magic, "ORBFETC3", 8);
+    std::memcpy(hd.magic, "ORBFETC4", 8);
     hd.u0 = ORBFE_TRIG_U0;
     hd.n = ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u;
     hd.libmPrint = print;
-    hd.payloadSum = words_sum(src, bytes);
-    const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(src, 1, bytes, f) == bytes;
-    std::fclose(f);
-    if (!ok || std::rename(t.c_str(), path.c_str()) != 0) std::remove(t.c_str()); // (atomic: a reader sees all or nothing)
+    hd.payloadSum = payloadSum;
+    bool ok = fchmod(fd, 0600) == 0 && write(fd, &hd, sizeof hd) == (ssize_t)sizeof hd;
+    for (size_t off = 0; ok && off < bytes;) {
+        const ssize_t k = write(fd, src + off, std::min<size_t>(bytes - off, 16u << 20));
+        ok = k > 0;
+        off += ok ? (size_t)k : 0;
+    }
+    ok = close(fd) == 0 && ok;
+    if (!ok || std::rename(t.c_str(), path.c_str()) != 0) {
+        (void)unlink(t.c_str());
+        return false;
+    }
+    return true;
 }
 
 // The libm table of this process for `device` (both pointers null: not available); never fails the caller.
@@ -1007,16 +1116,9 @@ TrigTabs trig_table(int device, hipStream_t s)
     // ---- the codes: from the cache file (mapped, sent as it lies), else from libm
     const uint64_t print = libm_fingerprint();
     const std::string cache = trig_cache_path(print);
-    bool fine = hipMalloc((void**)&t.d, codeBytes) == hipSuccess;
+    bool fine = hipMalloc((void**)&t.d, ((codeBytes + 7) & ~(size_t)7)) == hipSuccess; // (whole 8-byte words: the checksum kernel)
     bool coded = false;
-    if (fine) {
-        void* map = nullptr;
-        size_t mapBytes = 0;
-        if (const uint8_t* payload = trig_cache_map(cache, print, codeBytes, &map, &mapBytes)) {
-            coded = hipMemcpy(t.d, payload, codeBytes, hipMemcpyHostToDevice) == hipSuccess;
-            munmap(map, mapBytes);
-        }
-    }
+    if (fine) coded = trig_cache_load(cache, print, codeBytes, t.d, s);
     if (!coded && hipHostMalloc((void**)&h, std::max((size_t)chunk * sizeof(float2), codeBytes)) != hipSuccess) {
         (void)hipGetLastError();
         if (t.d) (void)hipFree(t.d);
@@ -1043,7 +1145,8 @@ TrigTabs trig_table(int device, hipStream_t s)
         if (dAB) (void)hipFree(dAB);
         if (dBad) (void)hipFree(dBad);
         if (coded && !cache.empty() && hipMemcpy(h, t.d, codeBytes, hipMemcpyDeviceToHost) == hipSuccess)
-            trig_cache_store(cache, print, reinterpret_cast<const uint8_t*>(h), codeBytes);
+            (void)trig_cache_store(cache, print, reinterpret_cast<const uint8_t*>(h), codeBytes,
+                                   trig_payload_sum(reinterpret_cast<const uint8_t*>(h), codeBytes));
     }
     if (!coded && t.d) {
         (void)hipFree(t.d);
@@ -1217,11 +1320,27 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         }
         if (nsub == 1) rec(c, 2);
         // K-QT
-        hipLaunchKernelGGL(k_octree, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, (unsigned)nl) : dim3((unsigned)nl, (unsigned)ni),
-                           dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
-                           c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
-                           c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
-                           c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p);
+        {
+            OrbQtLevels lv = {};
+            for (size_t i = 0; i < c->qtSmall.size(); i++) lv.v[i] = c->qtSmall[i];
+            const unsigned nS = (unsigned)c->qtSmall.size(), nB = (unsigned)c->qtBig.size();
+            if (nS)
+                hipLaunchKernelGGL(k_octree<false>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nS) : dim3(nS, (unsigned)ni),
+                                   dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
+                                   c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
+                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
+                                   c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p, lv, (int*)nullptr, (size_t)0);
+            if (nB) { // levels whose node tables exceed the LDS: same kernel on a global scratch area (i0-relative slices)
+                OrbQtLevels lb = {};
+                for (size_t i = 0; i < c->qtBig.size(); i++) lb.v[i] = c->qtBig[i];
+                hipLaunchKernelGGL(k_octree<true>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nB) : dim3(nB, (unsigned)ni),
+                                   dim3(QT_THREADS), c->qtBigLdsBytes, q, c->d_lg.p,
+                                   c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
+                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
+                                   c->qtBigKeyOff, c->qtBigKeyCap, d_lap, c->d_lvlPre.p, lb,
+                                   c->d_qtScratch.p + (size_t)i0 * c->qtBig.size() * c->qtScratchStride, c->qtScratchStride);
+            }
+        }
         if (nsub == 1) rec(c, 3);
         // K-PACK: only when bearing rays are wanted (orbfe_set_kb8).  Otherwise K-QT has left the mono / stereo partition
         // of every level behind and K-DESC derives its output slots, the keypoint records, the counts and the error word
@@ -1635,7 +1754,10 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     // 0.080 ms per pinned frame, 0.177 -> 0.157 ms per stereo pair in one call.  (The same idea for the INPUT -- K-PYR
     // reading the image over PCIe where it lies in page-locked memory -- was measured and dropped: 0.089 -> 0.106 ms, reads
     // across the link stall the kernel far longer than the upload command costs.)
-    const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs;
+    // (not with sub-batches on several streams, ORBFE_STREAMS > 1: the mirrored error word is written by the first sub-batch's
+    // K-DESC, before the other sub-batches' K-QT have run -- such a call takes the download command, which is queued behind
+    // the join of all sub-batches)
+    const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs && !(c->nStreams > 1 && nimg > 1);
     // ... and the IMAGES of such a call come in through a kernel that reads the page-locked source in 16-byte pieces
     // (k_upload): no copy engine, hence no queue hand-over, between the host call and the first kernel.
     // (Measured and not kept: staging and uploading a pageable image band by band so that the upload of one band overlaps
@@ -1860,7 +1982,7 @@ const char* orbfe_error_string(int code)
         return "image too small: some pyramid level is narrower or lower than 32 + 35 px, where the reference's cell grid has no cell";
     case ORBFE_ERR_IMAGE_LARGE: return "image too large: a side above 4096 px (candidates are packed with 12-bit coordinates)";
     case ORBFE_ERR_NFEATURES:
-        return "nfeatures too large: one level's quadtree does not fit a workgroup's LDS (about 6500 features at 8 levels, scale 1.2)";
+        return "nfeatures too large: more than 65535 keypoint slots per image";
     default: break;
     }
     if (code >= 0) return "success";
@@ -1925,6 +2047,7 @@ void orbfe_destroy(orbfe_ctx* c)
     c->d_fix.release(); c->d_kb8.release(); c->d_rays.release();
     c->d_destMap.release();
     c->d_lvlPre.release();
+    c->d_qtScratch.release();
     c->release_tables();
     for (auto& g : c->geomCache) g.release_tables();
     c->d_taps.release(); c->d_patternF.release();
@@ -2613,6 +2736,51 @@ int orbfe_debug_trig(orbfe_ctx* c, const float* angles_deg, int n, float* a_out,
     d.release();
     if (e != hipSuccess) return -(1000 + (int)e);
     return tab.full ? 2 : tab.codes ? 1 : 0; /* 2: libm values, 1: libm codes, 0: no table */
+}
+
+// ---- the libm table's cache file, host side only (no device needed): what the CPU tests exercise
+int orbfe_debug_trig_cache_path(char* out, int cap)
+{
+    if (!out || cap < 1) return ORBFE_ERR_ARGS;
+    const std::string p = trig_cache_path(libm_fingerprint());
+    if ((int)p.size() + 1 > cap) return ORBFE_ERR_ARGS;
+    std::memcpy(out, p.c_str(), p.size() + 1);
+    return (int)p.size();
+}
+size_t orbfe_debug_trig_cache_payload_bytes(void) { return ((size_t)(ORBFE_TRIG_U1 - ORBFE_TRIG_U0 + 1u) + 1) / 2; }
+int orbfe_debug_trig_cache_write(const char* path, const uint8_t* payload, size_t bytes)
+{
+    if (!path || !payload || bytes != orbfe_debug_trig_cache_payload_bytes()) return ORBFE_ERR_ARGS;
+    return trig_cache_store(path, libm_fingerprint(), payload, bytes, trig_payload_sum(payload, bytes)) ? 0 : ORBFE_ERR_STATE;
+}
+int orbfe_debug_trig_cache_check(const char* path, const char** why)
+{
+    static const char* const kSum = "payload checksum mismatch";
+    static const char* const kRead = "short read";
+    if (why) *why = nullptr;
+    if (!path) return ORBFE_ERR_ARGS;
+    const size_t bytes = orbfe_debug_trig_cache_payload_bytes();
+    TrigCacheHeader hd;
+    const char* w = nullptr;
+    const int fd = trig_cache_open(path, libm_fingerprint(), bytes, &hd, &w);
+    if (fd < 0) {
+        if (why) *why = w;
+        return ORBFE_ERR_STATE;
+    }
+    std::vector<uint8_t> buf(8u << 20); // (a multiple of 8: the word index carries over from chunk to chunk)
+    uint64_t sum = 0;
+    bool ok = true;
+    for (size_t off = 0; ok && off < bytes; off += buf.size()) {
+        const size_t n = std::min(buf.size(), bytes - off);
+        ok = read_fully(fd, buf.data(), n);
+        if (ok) sum += trig_payload_sum(buf.data(), n, off / 8);
+    }
+    close(fd);
+    if (!ok || sum != hd.payloadSum) {
+        if (why) *why = ok ? kSum : kRead;
+        return ORBFE_ERR_STATE;
+    }
+    return 0;
 }
 
 } // extern "C"

@@ -819,10 +819,10 @@ __device__ __forceinline__ void qt_each_key(bool regp, int n, F f)
 }
 
 #if ORBFE_QT_IMG_MAJOR
-#define QT_LEVEL_IDX blockIdx.y
+#define QT_LEVEL_IDX levels.v[blockIdx.y]
 #define QT_IMG_IDX blockIdx.x
 #else
-#define QT_LEVEL_IDX blockIdx.x
+#define QT_LEVEL_IDX levels.v[blockIdx.x]
 #define QT_IMG_IDX blockIdx.y
 #endif
 #ifdef ORBFE_QT_TIMING // tuning only (tools/ab_build.sh qtt "-DORBFE_QT_TIMING"): phase timestamps of one workgroup
@@ -849,6 +849,15 @@ __device__ unsigned long long g_qtTimes[64];
 // transcription in the oracle): keys never move, every key carries the list index of its node,
 // and each pass is a histogram + prefix sums.  Sort tie-break of :682 = creation order
 // (SURVEY.md D1).
+// GLOBAL (round 4): a level whose node tables do not fit a workgroup's LDS (24 ints per list entry: above ~1700 entries,
+// i.e. nfeatures >~ 7800 at 8 levels -- the 5 x nFeatures initialisation extractor of src/Tracking.cc:1157 with KITTI's 2000)
+// keeps them in a global scratch area of its own instead.  Same code: the arrays are reached through one base pointer, the
+// atomics are generic, and __syncthreads orders a workgroup's global accesses as it orders its LDS accesses.  Slower (every
+// table access is an L2 round trip), which only the few frames before the map is initialised pay.
+struct OrbQtLevels {
+    int32_t v[ORBFE_MAX_LEVELS]; // the levels this launch works on (grid coordinate -> level)
+};
+template <bool GLOBAL>
 __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __restrict__ lg,
                                                        const OrbCellGeom* __restrict__ cg,
                                                        const uint32_t* __restrict__ cand, size_t candImgStride,
@@ -860,16 +869,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                                        int keyLdsCap /* keys */,
                                                        const int32_t* __restrict__ lap /* lapping range per image */,
                                                        uint32_t* __restrict__ lvlPre /* per keypoint slot: stereo flag << 15 |
-                                                                                       stereo keypoints before it in its level */)
+                                                                                       stereo keypoints before it in its level */,
+                                                       const OrbQtLevels levels, int* __restrict__ gScratch /* GLOBAL: node
+                                                       tables, scratchStride ints per workgroup */, size_t scratchStride)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if ORBFE_QT_IMG_MAJOR
     // workgroup id = image + nimg * level: with batches that are a multiple of 8 an image's levels run on the XCD
     // (id mod 8) whose L2 K-FAST left the image's candidates in, and where K-PACK / K-DESC will read the result
-    const int level = blockIdx.y, img = (int)blockIdx.x + imgBase;
+    const int level = levels.v[blockIdx.y], img = (int)blockIdx.x + imgBase;
+    const size_t wgLinear = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
 #else
-    const int level = blockIdx.x, img = (int)blockIdx.y + imgBase;
+    const int level = levels.v[blockIdx.x], img = (int)blockIdx.y + imgBase;
+    const size_t wgLinear = (size_t)blockIdx.y + (size_t)gridDim.y * blockIdx.x;
 #endif
     QT_STAMP(0);
     QT_WG_BEGIN();
@@ -882,7 +895,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     // as 64 + max(24*LC, 1024) ints).
     int* misc = lds;
     int* wsum = misc + 8;
-    int* A = lds + 64;
+    int* const A = GLOBAL ? gScratch + wgLinear * scratchStride : lds + 64;
     // (functions of the buffer index, not pointer arrays: indexing an array of pointers with the run-time `cur`
     // hides from the compiler that these are LDS addresses, and every access became a flat load / store)
     auto nodeUL = [A, LC](int b) { return A + b * LC; };
@@ -896,7 +909,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     auto multi = [A, LC](int b) { return A + (20 + b) * LC; }; // candidate list (list positions), creation order
     int* par = A + 22 * LC;      // expansion index k -> parent list position
     int* gpre = A + 23 * LC;     // growth prefix (final phase) / scratch
-    int* gscan = A;              // gather only
+    int* gscan = GLOBAL ? lds + 64 : A; // gather only (always LDS)
 
     uint32_t* keys = keysAll + (size_t)img * keyImgStride + L.keyBase;
     uint16_t* keyNode = keyNodeAll + (size_t)img * keyImgStride + L.keyBase;
@@ -1499,8 +1512,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
         // this, which is why the host path runs on one stream.
         if (errOut && errIn && blockIdx.x == 0) errOut[0] = errIn[0];
         if (mirrorMeta) { // the caller reads these straight from pinned memory: no download command
-            mirrorMeta[blockIdx.x] = n;
-            mirrorMeta[mirrorImgs + blockIdx.x] = n - runStereo;
+            mirrorMeta[img] = n; // (the image's index in the CALL, not in the sub-batch: ADVICE r03)
+            mirrorMeta[mirrorImgs + img] = n - runStereo;
             if (blockIdx.x == 0) mirrorMeta[2 * mirrorImgs] = errIn ? errIn[0] : 0;
         }
     }
@@ -1740,6 +1753,29 @@ __global__ __launch_bounds__(256) void k_trig_expand(const uint8_t* __restrict__
     trig_tab_sincos(__fmul_rn(__uint_as_float(u0 + i), factorPI), &sc, &cc);
     const unsigned nib = (codes[i >> 1] >> (4u * (i & 1u))) & 0xFu;
     full[i] = make_float2(trig_apply(cc, nib & 3u), trig_apply(sc, nib >> 2));
+}
+// Checksum of the code table on the device (the cache file's payload is verified in full where it has just been uploaded:
+// 65 MB at HBM speed instead of a host pass; the host has the same formula in trig_payload_sum).  Order-independent: the
+// sum over the 8-byte words of mix(word + (index + 1) * C), so any number of threads may add their parts.
+__host__ __device__ __forceinline__ unsigned long long trig_mix64(unsigned long long w, unsigned long long i)
+{
+    unsigned long long x = w + (i + 1ull) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 29;
+    x *= 0xC2B2AE3D27D4EB4Full;
+    x ^= x >> 32;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_trig_checksum(const unsigned long long* __restrict__ words, unsigned long long nWords,
+                                                       unsigned long long* __restrict__ sum)
+{
+    unsigned long long acc = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < nWords; i += (unsigned long long)gridDim.x * 256u)
+        acc += trig_mix64(words[i], i);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
 }
 // What K-DESC fetches for its angle as soon as the angle is known (the load then overlaps the blur): with the
 // full table libm's (cosf, sinf) themselves, with the compact table the 4-bit code, else nothing.
@@ -1992,8 +2028,8 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
             monoOut[img] = n - nStereo;
             if (errOut && errIn && imgLocal == 0) errOut[0] = errIn[0];
             if (mirrorMeta) { // the caller reads these straight from pinned memory: no download command
-                mirrorMeta[imgLocal] = n;
-                mirrorMeta[mirrorImgs + imgLocal] = n - nStereo;
+                mirrorMeta[img] = n; // (the image's index in the CALL, not in the sub-batch: ADVICE r03)
+                mirrorMeta[mirrorImgs + img] = n - nStereo;
                 if (imgLocal == 0) mirrorMeta[2 * mirrorImgs] = errIn ? errIn[0] : 0;
             }
         }

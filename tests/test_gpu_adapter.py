@@ -34,7 +34,20 @@ def test_cpp_adapter_matches_oracle(tmp_path, oracle):
     assert (mono, n, levels) == (rmono, len(rkps), 8)
     assert h == _fnv(rdesc, rkps)
     assert (prow, pcol) == (278, 435)          # mvImagePyramid[3] of a 752x480 frame
-    assert int(out[1]) == -1                   # empty image -> -1 (:1072-1073)
+    # Frame::ComputeStereoMatches' reads of mvImagePyramid (11x11 windows at the keypoints' octaves), no flag set
+    nrows, hp = [int(v) for v in out[1].split()]
+    inv = ref.scale_tables()[1]
+    h2 = 1469598103934665603
+    levels_ = [ref.level(l)[19:-19, 19:-19].astype(np.int64) for l in range(8)]
+    for k in rkps:
+        sf = np.float32(inv[int(k["octave"])])
+        u = int(np.float32(np.float32(k["x"]) * sf) + np.float32(0.5))
+        v = int(np.float32(np.float32(k["y"]) * sf) + np.float32(0.5))
+        win = levels_[int(k["octave"])][v - 5:v + 6, u - 5:u + 6]
+        assert win.shape == (11, 11)
+        h2 = ((h2 ^ int(win.sum())) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert nrows == 480 and hp == h2
+    assert int(out[2]) == -1                   # empty image -> -1 (:1072-1073)
 
 
 def test_cpp_adapter_stereo_pair_in_one_call(tmp_path, oracle):
@@ -50,7 +63,7 @@ def test_cpp_adapter_stereo_pair_in_one_call(tmp_path, oracle):
     (tmp_path / "l.raw").write_bytes(left.tobytes())
     (tmp_path / "r.raw").write_bytes(right.tobytes())
     out = subprocess.check_output([exe, str(tmp_path / "l.raw"), "480", "752", "1200", str(tmp_path / "r.raw")], text=True).split("\n")
-    m, nl, nr, hl, hr, hu, ml, mr = [int(v) for v in out[2].split()]
+    m, nl, nr, hl, hr, hu, ml, mr = [int(v) for v in out[3].split()]
     oL, oR = oracle.Extractor(1200, 1.2, 8, 20, 7), oracle.Extractor(1200, 1.2, 8, 20, 7)
     rml, kL, dL = oL.extract(left, (0, 0))
     rmr, kR, dR = oR.extract(right, (0, 0))

@@ -2,6 +2,9 @@
 src/Frame.cc:413-420): pageable, pinned and registered caller memory, strided views, the two-deep
 submit / wait pipeline, and the resident form of Frame::ComputeStereoMatches -- all bit-exact vs the oracle."""
 import ctypes as C
+import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -307,3 +310,15 @@ def test_stereo_pair_extraction_and_matching_in_one_call(pkg, oracle):
     assert m == 0 and len(kR) == 0 and len(kL) == len(rkL) and np.all(uR == -1) and np.all(dep == -1)
     ex.close()
     buf.close()
+
+
+def test_latency_path_with_sub_batches_on_several_streams():
+    # with ORBFE_STREAMS=2 a blocking two-image call runs as two sub-batches; the pinned result mirror used to be
+    # indexed by the image's position in its SUB-batch (both wrote entry 0, entry 1 stayed stale).  The variable is read at
+    # orbfe_create, so the stereo-pair and two-image checks run again in a child process.
+    env = dict(os.environ, ORBFE_STREAMS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_stereo_pair_extraction_and_matching_in_one_call or test_stereo_pair_in_one_batched_call_resident_matches"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout
