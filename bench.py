@@ -243,6 +243,11 @@ def main():
     ap.add_argument("--exchange", choices=["cabi", "torch"], default="cabi",
                     help="N > 1: the all-gather through the C ABI (orbfe_mc_*: ncclAllGather issued by liborbfe.so on its own "
                          "stream) or through torch.distributed (c10d's process group)")
+    ap.add_argument("--lanes", type=int, choices=[1, 2], default=2,
+                    help="orbfe_set_lanes for the TIMED region: 2 = every batch runs as two half-batches on two streams of the ONE "
+                         "extractor context (the latency-bound quadtree kernel and the kernel tails of one half beside the "
+                         "throughput-bound kernels of the other).  The per-kernel times of `roofline` are always measured with "
+                         "one lane, in a second region of the same run: overlapped kernels have no per-launch duration")
     ap.add_argument("--contexts", type=int, default=1,
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
@@ -290,6 +295,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ex.set_stream(stream.cuda_stream)
+    ex.set_lanes(args.lanes)
     cap = ex.max_keypoints(H, W)
     # two slab pairs: the all-gather of batch i (process group's stream) overlaps the extraction of batch i+1
     pipe = PipelinedExchange(B, cap, dev, world, rank)
@@ -355,6 +361,7 @@ def main():
         ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(), cap,
                                 x.count_view().data_ptr(), d_mono.data_ptr())
         if dist.is_initialized():
+            ex.lanes_join()  # (the collective orders itself after THIS stream: the second lane's half must be behind it)
             pipe.submit()  # one RCCL all-gather of descriptor slabs per batch, asynchronous
 
     def barrier():
@@ -383,14 +390,29 @@ def main():
 
     settle_steps = 8 * settle_together(args.settle, eight_steps, world, dev)
     barrier()
-    ex.profile(args.event_every)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()  # every event_every-th call records one set of stage events on the stream (no extra sync)
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    stage_ms = ex.stage_ms()  # hipEvent times averaged over the timed steps
+    # Per-kernel launch durations for `roofline`: hipEvents between the kernels on the stream they run on, in a SECOND
+    # region of the same run with ONE lane (orbfe_set_lanes(1)), at least 60 steps, every event_every-th of them recording
+    # one set of stage events.  With two lanes the kernels of the two half-batches overlap on the GPU, so a launch has a
+    # wall-clock duration but no throughput of its own; the one-lane durations are what `rocprofv3 --kernel-trace --stats`
+    # of `bench.py --lanes 1` reports (profiles/).
+    ex.set_lanes(1)
+    barrier()
+    roof_steps = max(args.steps, 60)
+    ex.profile(args.event_every)
+    t1l = time.perf_counter()
+    for _ in range(roof_steps):
+        step()  # every event_every-th call records one set of stage events on the stream (no extra sync)
+    barrier()
+    one_lane_ms = 1e3 * (time.perf_counter() - t1l) / roof_steps
+    stage_ms = ex.stage_ms()  # hipEvent times averaged over the sampled steps
     ex.profile(False)
+    ex.set_lanes(args.lanes)
+    barrier()
     # Not part of `value`: the same step K more times with one event per step boundary on the stream (an event record
     # costs ~3.5 us, which is why the timed region above carries none): the distribution a single average hides.
     step_dist = None
@@ -496,6 +518,7 @@ def main():
         e2 = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank, trig=ex.trig)
         s2 = torch.cuda.Stream(device=dev)
         e2.set_stream(s2.cuda_stream)
+        ex.set_lanes(1)  # (this leg: two contexts with one lane each)
         k2 = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
         de2 = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
         n2 = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -517,9 +540,10 @@ def main():
         torch.cuda.synchronize()
         tp = time.perf_counter() - tp
         assert torch.equal(n2, d_n)
-        pipelined = {"contexts": 2, "ms_per_step": 1e3 * tp / args.steps,
+        pipelined = {"contexts": 2, "lanes_per_context": 1, "ms_per_step": 1e3 * tp / args.steps,
                      "value": float(d_n.sum().item()) * args.steps / tp, "unit": "keypoints/s"}
         e2.close()
+        ex.set_lanes(args.lanes)
 
     # Also not part of `value`: BASELINE configs[1] read literally -- ONE resident frame per call (what a monocular
     # tracker issues), the latency-bound end of the same pipeline.
@@ -622,6 +646,10 @@ def main():
                                "1": "compact (65 MB of codes)", "0": "none (host check)"}.get(
                                    os.environ.get("ORBFE_TRIG_TABLE", ""), os.environ.get("ORBFE_TRIG_TABLE", "")),
                 "contexts": 1 + len(extra),
+                "lanes": args.lanes,
+                "lanes_note": ("two half-batches per step on two streams of the one extractor context (orbfe_set_lanes): "
+                               "identical outputs, complete when the timed region's closing synchronisation returns"
+                               if args.lanes == 2 else "one stream"),
                 "exchange": (("1 ncclAllGather of descriptor slabs per step issued by liborbfe.so (orbfe_mc_extract_exchange_"
                               "submit / _wait) on its own stream, overlapped with the next step's extraction" if mc is not None
                               else "1 all-gather of descriptor slabs per step through torch.distributed, overlapped with the "
@@ -645,6 +673,9 @@ def main():
                                   "records, so the stage times add up to a few per cent more than ms_per_step"
                                   % max(args.event_every, 1),
                 "avg_launch_ms": stage_ms[dom],
+                "measured_with": "one lane (orbfe_set_lanes(1)), %d steps right after the timed region of the same run; "
+                                 "ms_per_step of that region: %.5f" % (roof_steps, one_lane_ms),
+                "one_lane_ms_per_step": one_lane_ms,
                 "stage_ms": stage_ms,
                 # the same figures for every kernel of the step (the two largest are within a few per cent of
                 # each other, so which one is "dominant" can change from run to run) and for the whole step

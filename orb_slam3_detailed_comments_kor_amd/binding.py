@@ -299,7 +299,7 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
            "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
            "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
-           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check"]
+           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_lanes_join", "orbfe_lanes_record"]
 
 
 def _p(a):
@@ -515,6 +515,14 @@ class ORBextractor:
 
     def sync(self):
         _chk(self.L.orbfe_sync(self.h), "orbfe_sync")
+
+    def set_lanes(self, lanes):
+        """orbfe_set_lanes: 2 = device-pointer batches of >= 16 images run as two half-batches on two streams (see orbfe.h)."""
+        _chk(self.L.orbfe_set_lanes(self.h, int(lanes)), "orbfe_set_lanes")
+
+    def lanes_join(self):
+        """orbfe_lanes_join: the context's stream waits for the second lane (no host wait)."""
+        _chk(self.L.orbfe_lanes_join(self.h), "orbfe_lanes_join")
 
     # -- getters (include/ORBextractor.h:61-83) -------------------------------------
     def GetLevels(self):

@@ -175,6 +175,20 @@ struct orbfe_ctx : orbfe_geom_state {
     hipStream_t sub[8] = {};
     hipEvent_t evFork = nullptr, evJoin[8] = {};
     int xcdAffine = 1;           // ORBFE_XCD_AFFINE env: whole images per XCD when the batch is a multiple of 8
+    // Two lanes (round 4, orbfe_set_lanes / ORBFE_LANES=2): a device-pointer batch of >= 16 images runs as two half-batches,
+    // the first on the context's stream and the second on a stream of the context's own, with NO event between them inside
+    // a call -- so the latency-bound K-QT and the kernel tails of one half run beside the throughput-bound kernels of the
+    // other, and consecutive calls keep both lanes busy.  Cross-stream waits only go one way and only where they cost nothing:
+    // the second lane waits for the point of the call on the context's stream (inputs ready), and the context's stream
+    // waits for the second lane when somebody needs the results there (lane_join: orbfe_get_device_outputs, orbfe_sync,
+    // any other entry point).  Measured (tools/overlap_probe.hip): a fork + join pair per call costs ~13 us of latency
+    // each way when the two streams ping-pong, a one-way wait ~3 us.
+    int lanes = 1;
+    hipStream_t laneStream = nullptr;
+    hipEvent_t evLaneFork = nullptr, evLaneJoin = nullptr;
+    bool lastLanes = false;      // the last batch ran on two lanes
+    bool lanePending = false;    // the second lane holds work the context's stream has not been ordered after
+    int laneSplit = 0, laneImgs = 0; // the split of the last two-lane call (a call with another split joins first)
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
@@ -262,6 +276,30 @@ struct orbfe_ctx : orbfe_geom_state {
 };
 
 namespace {
+
+// Orders the context's stream after whatever the second lane still has in flight (one-way wait: a few us on the stream).
+int lane_join(orbfe_ctx* c)
+{
+    if (!c || !c->lanePending) return 0;
+    HIP_TRY(hipEventRecord(c->evLaneJoin, c->laneStream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->evLaneJoin, 0));
+    c->lanePending = false;
+    return 0;
+}
+// ... and the host: before buffers are freed / tables replaced / a stream is given up
+void lane_quiesce(orbfe_ctx* c)
+{
+    if (c && c->laneStream) (void)hipStreamSynchronize(c->laneStream);
+    if (c) c->lanePending = false;
+}
+int lane_setup(orbfe_ctx* c)
+{
+    if (c->laneStream) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&c->laneStream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->evLaneFork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evLaneJoin, hipEventDisableTiming));
+    return 0;
+}
 
 // ORBextractor ctor, reference src/ORBextractor.cc:408-444
 void init_tables(orbfe_ctx* c)
@@ -599,6 +637,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     // a size this context has seen before: swap its tables back in (no rebuild, no upload)
     for (size_t i = 0; i < c->geomCache.size(); i++)
         if (c->geomCache[i].rows == rows && c->geomCache[i].cols == cols && c->geomCache[i].pyrTile == tile) {
+            lane_quiesce(c); // (the second lane may still be working with the other size's tables and strides)
             std::swap(cur, c->geomCache[i]);
             if (c->geomCache[i].lg.empty()) c->geomCache.erase(c->geomCache.begin() + (long)i);
             if (c->qtLdsBytes > 64 * 1024)
@@ -609,6 +648,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
         }
     if (!c->lg.empty()) { // keep the current size's tables for later
         if (c->geomCache.size() >= 8) {
+            lane_quiesce(c);
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->geomCache.front().release_tables();
             c->geomCache.erase(c->geomCache.begin());
@@ -631,6 +671,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     if ((r = c->d_ds.ensure(std::max<size_t>(c->kpStride, 1))) < 0) return r;
     if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
     if ((r = c->d_ytab.ensure(std::max<size_t>(ytab.size(), 1))) < 0) return r;
+    lane_quiesce(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
@@ -796,6 +837,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
 int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
 {
     if (nimg <= c->capImgs && capKp <= c->capKp) return 0;
+    lane_quiesce(c); // (buffers are about to be replaced)
     const size_t B = (size_t)std::max(nimg, c->capImgs);
     const size_t K = (size_t)std::max(capKp, c->capKp);
     int r;
@@ -1206,7 +1248,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                int32_t* d_errOut = nullptr /* K-DESC (or K-PACK) copies the batch's error word here (host-pointer path) */,
                uint8_t* mirror = nullptr /* pinned host slab [meta | keypoints | descriptors] the kernels write the results
                                             into as well (device-side address; latency path of a frame or two) */,
-               size_t mirrorMetaBytes = 0)
+               size_t mirrorMetaBytes = 0, bool allowLanes = false /* the caller tolerates results that are only ordered on the
+                                            context's stream after lane_join (orbfe_extract_batch_device) */)
 {
     int r;
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
@@ -1251,23 +1294,38 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     // 16-B header of the fix list = {fragile count, error flag, 0, 0}.  The fused pyramid kernel clears it
     // (first command of the batch on this stream); the other configurations need a memset command.
     int32_t* const d_hdr = reinterpret_cast<int32_t*>(c->d_fix.p);
+    // Two lanes (see orbfe_ctx::lanes): halves that are multiples of 8 images where possible (whole images per XCD)
+    int laneSplit = ((nimg / 2 + 7) / 8) * 8;
+    if (laneSplit >= nimg) laneSplit = nimg / 2;
+    const bool useLanes = allowLanes && c->lanes == 2 && nimg >= 16 && c->pyrFused && !hostTrigCheck && !mirror && !d_errOut &&
+                          c->nStreams == 1;
+    if (c->lanePending && !(useLanes && c->laneSplit == laneSplit && c->laneImgs == nimg)) {
+        if ((r = lane_join(c)) < 0) return r; // another shape of work: first order this stream after the second lane
+    }
+    if (useLanes && (r = lane_setup(c)) < 0) return r;
     const bool kernelClearsHdr = c->pyrFused && !(c->nStreams > 1 && nimg > 1);
     if (!kernelClearsHdr) HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
-    c->recNow = c->profile && c->evReady && c->profSeen % c->profEvery == 0;
+    c->recNow = !useLanes && c->profile && c->evReady && c->profSeen % c->profEvery == 0; // (stage events: one stream only)
     rec(c, 0);
     // Sub-batches on separate streams (ORBFE_STREAMS > 1): the image pipelines are independent, so the
     // latency-bound stages of one sub-batch overlap with the issue-bound stages of another.  Stage
     // events are only meaningful with one stream.
-    const int nsub = (c->pyrFused && c->nStreams > 1) ? std::min(c->nStreams, nimg) : 1;
-    if (nsub > 1) {
+    const int nsub = useLanes ? 2 : (c->pyrFused && c->nStreams > 1) ? std::min(c->nStreams, nimg) : 1;
+    if (useLanes) { // the second lane starts no earlier than this point of the context's stream (inputs, taps, tables)
+        HIP_TRY(hipEventRecord(c->evLaneFork, s));
+        HIP_TRY(hipStreamWaitEvent(c->laneStream, c->evLaneFork, 0));
+    } else if (nsub > 1) {
         HIP_TRY(hipEventRecord(c->evFork, s));
         for (int k = 0; k < nsub; k++) HIP_TRY(hipStreamWaitEvent(c->sub[k], c->evFork, 0));
     }
     for (int k = 0; k < nsub; k++) {
-        const int i0 = (int)((long)nimg * k / nsub), i1 = (int)((long)nimg * (k + 1) / nsub);
+        const int i0 = useLanes ? (k ? laneSplit : 0) : (int)((long)nimg * k / nsub);
+        const int i1 = useLanes ? (k ? nimg : laneSplit) : (int)((long)nimg * (k + 1) / nsub);
         const int ni = i1 - i0;
         if (ni <= 0) continue;
-        hipStream_t q = nsub > 1 ? c->sub[k] : s;
+        hipStream_t q = useLanes ? (k ? c->laneStream : s) : nsub > 1 ? c->sub[k] : s;
+        // (each lane has a status header of its own: its K-PYR clears it, its K-QT raises the error word in it)
+        int32_t* const d_hdrK = useLanes ? reinterpret_cast<int32_t*>(c->d_fix.p + k) : d_hdr;
         // K-FAST's order: whole images per XCD when the batch fills the 8 XCDs evenly enough (<= 1/8 idle), else groups of
         // G neighbouring cells per XCD
         const int perXcd = (ni + 7) / 8;
@@ -1278,7 +1336,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                c->pyrLdsBytes, q, d_imgs,
                                pitch, imgStride, c->d_pyr.p, c->pyrStride, c->d_pyrRecs.p, c->pyrRecBytes, nl,
                                c->pyrNtx, c->pyrNty, c->pyrBuf0, c->pyrBuf1, c->pyrStageX,
-                               cols, i0, kernelClearsHdr ? d_hdr : nullptr, (c->xcdAffine && ni % 8 == 0) ? 1 : 0,
+                               cols, i0, kernelClearsHdr ? d_hdrK : nullptr, (c->xcdAffine && ni % 8 == 0) ? 1 : 0,
                                recip32((unsigned)(c->pyrNtx * c->pyrNty)), recip32((unsigned)c->pyrNtx));
         } else {
             const OrbLevelGeom& L0 = c->lg[0];
@@ -1328,7 +1386,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 hipLaunchKernelGGL(k_octree<false>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nS) : dim3(nS, (unsigned)ni),
                                    dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                                    c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
-                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
+                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
                                    c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p, lv, (int*)nullptr, (size_t)0);
             if (nB) { // levels whose node tables exceed the LDS: same kernel on a global scratch area (i0-relative slices)
                 OrbQtLevels lb = {};
@@ -1336,7 +1394,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 hipLaunchKernelGGL(k_octree<true>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nB) : dim3(nB, (unsigned)ni),
                                    dim3(QT_THREADS), c->qtBigLdsBytes, q, c->d_lg.p,
                                    c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
-                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdr + 1, i0,
+                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
                                    c->qtBigKeyOff, c->qtBigKeyCap, d_lap, c->d_lvlPre.p, lb,
                                    c->d_qtScratch.p + (size_t)i0 * c->qtBig.size() * c->qtScratchStride, c->qtScratchStride);
             }
@@ -1381,18 +1439,23 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             }
 #undef ORBFE_DESC_LAUNCH
         }
-        if (nsub > 1) {
+        if (nsub > 1 && !useLanes) {
             HIP_TRY(hipEventRecord(c->evJoin[k], q));
             HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
         }
     }
-    if (nsub > 1) {
+    if (useLanes) {
+        c->lanePending = true;
+        c->laneSplit = laneSplit;
+        c->laneImgs = nimg;
+    } else if (nsub > 1) {
         for (int i = 1; i <= 4; i++) rec(c, i);
         // every sub-batch has joined: only now is the error word final
         if (d_errOut) HIP_TRY(hipMemcpyAsync(d_errOut, d_hdr + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     }
     rec(c, 5);
     c->lastImgs = nimg;
+    c->lastLanes = useLanes;
     c->lastKps = d_kps;
     c->lastDesc = d_desc;
     c->lastN = d_n;
@@ -1716,6 +1779,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     if (c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: wait for one first
     HIP_TRY(hipSetDevice(c->device));
     int r;
+    if ((r = lane_join(c)) < 0) return r;
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if (cap_per_img < c->maxKp) return ORBFE_ERR_ARGS;
     if ((r = ensure_capacity(c, nimg, cap_per_img)) < 0) return r;
@@ -2018,6 +2082,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_UPLOAD_KERNEL")) c->uploadKernel = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_MIRROR_MAX")) c->mirrorMaxImgs = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
+    if (const char* e = getenv("ORBFE_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
     if (c->nStreams > 1) {
         bool ok = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < c->nStreams && ok; k++)
@@ -2038,6 +2103,7 @@ void orbfe_destroy(orbfe_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    lane_quiesce(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->sIn) (void)hipStreamSynchronize(c->sIn);   // submitted batches nobody waited for: their copies still
     if (c->sOut) (void)hipStreamSynchronize(c->sOut); // touch the slots' buffers (and the caller's arrays)
@@ -2071,6 +2137,9 @@ void orbfe_destroy(orbfe_ctx* c)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evLaneFork) (void)hipEventDestroy(c->evLaneFork);
+    if (c->evLaneJoin) (void)hipEventDestroy(c->evLaneJoin);
+    if (c->laneStream) (void)hipStreamDestroy(c->laneStream);
     for (int k = 0; k < 8; k++) {
         if (c->sub[k]) (void)hipStreamDestroy(c->sub[k]);
         if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
@@ -2105,6 +2174,7 @@ int orbfe_set_stream(orbfe_ctx* c, void* hip_stream)
 {
     if (!c) return ORBFE_ERR_ARGS;
     (void)hipSetDevice(c->device);
+    lane_quiesce(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
     c->ownStream = false;
@@ -2168,6 +2238,7 @@ int orbfe_get_rays(orbfe_ctx* c, int img_index, int cap_per_img, float* rays, in
         n > cap_per_img || (n && !rays))
         return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
+    lane_quiesce(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (n)
         HIP_TRY(hipMemcpy(rays, c->d_rays.p + (size_t)img_index * cap_per_img * 3, (size_t)n * 3 * sizeof(float),
@@ -2185,12 +2256,15 @@ int orbfe_sync(orbfe_ctx* c)
 {
     if (!c) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->laneStream) HIP_TRY(hipStreamSynchronize(c->laneStream));
+    c->lanePending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_fix.p && c->lastImgs > 0) { // the error word of the last batch (k_octree raises it, nothing else does)
-        int r = c->h_fix.ensure(1);
+        int r = c->h_fix.ensure(2);
         if (r < 0) return r;
-        HIP_TRY(hipMemcpy(c->h_fix.p, c->d_fix.p, sizeof(int4), hipMemcpyDeviceToHost));
-        if (c->h_fix.p[0].y != 0) return ORBFE_ERR_STATE;
+        const bool two = c->lastLanes && c->d_fix.n >= 2; // (a two-lane batch has a status header per lane)
+        HIP_TRY(hipMemcpy(c->h_fix.p, c->d_fix.p, (two ? 2 : 1) * sizeof(int4), hipMemcpyDeviceToHost));
+        if (c->h_fix.p[0].y != 0 || (two && c->h_fix.p[1].y != 0)) return ORBFE_ERR_STATE;
     }
     return 0;
 }
@@ -2210,6 +2284,7 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     // it then (with a synchronisation, the source is a stack buffer) and never again -- the steady state of this
     // entry point issues kernels only and does not block the host.
     if (c->lapDev0 != lap0 || c->lapDev1 != lap1 || c->lapDevCount < nimg) {
+        lane_quiesce(c); // (the second lane's K-QT may still be reading the table)
         std::vector<int32_t> lap((size_t)nimg * 2);
         for (int i = 0; i < nimg; i++) {
             lap[2 * i] = lap0;
@@ -2222,7 +2297,33 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
         c->lapDevCount = nimg;
     }
     return run_device(c, nimg, d_imgs, rows, cols, pitch, img_stride_bytes, c->d_lap.p, (float*)d_kps, d_desc,
-                      cap_per_img, d_n_out, d_mono_out);
+                      cap_per_img, d_n_out, d_mono_out, nullptr, nullptr, 0, /*allowLanes=*/true);
+}
+
+int orbfe_set_lanes(orbfe_ctx* c, int lanes)
+{
+    if (!c || (lanes != 1 && lanes != 2)) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = lane_join(c);
+    if (r < 0) return r;
+    c->lanes = lanes;
+    return 0;
+}
+
+int orbfe_lanes_join(orbfe_ctx* c)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    return lane_join(c);
+}
+
+int orbfe_lanes_record(orbfe_ctx* c, void* hip_event)
+{
+    if (!c || !hip_event) return ORBFE_ERR_ARGS;
+    if (!c->lanePending) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord((hipEvent_t)hip_event, c->laneStream));
+    return 1;
 }
 
 // ---- pinned host memory ---------------------------------------------------------------------------
@@ -2365,6 +2466,10 @@ int orbfe_get_device_outputs(orbfe_ctx* c, const orbfe_kp** d_kps, const uint8_t
     // stream and publish the ranges, so that a matcher call that is handed one of these pointers orders itself after it
     // (orbfe_order.h).  The caller's own kernels must still be ordered by the caller (same stream, or orbfe_sync).
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int rj = lane_join(c); // (two lanes: the mark below must lie behind BOTH halves of the batch)
+        if (rj < 0) return rj;
+    }
     if (!c->evOutputs) HIP_TRY(hipEventCreateWithFlags(&c->evOutputs, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->evOutputs, c->stream));
     orbfe_producer_publish(c->lastDesc, (size_t)c->lastImgs * c->lastCap * 32, c->evOutputs);
@@ -2407,6 +2512,10 @@ int orbfe_get_level(orbfe_ctx* c, int img_index, int level, uint8_t* dst, size_t
     if (!dst) return 0;
     if (dst_stride < (size_t)W) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int rj = lane_join(c);
+        if (rj < 0) return rj;
+    }
     hipLaunchKernelGGL(k_border, dim3((unsigned)((W * H + 255) / 256)), dim3(256), 0, c->stream, c->d_pyr.p,
                        c->pyrStride, L, img_index);
     const uint8_t* src = c->d_pyr.p + (size_t)img_index * c->pyrStride + L.bufOff + (ORBFE_ROI_X0 - ORBFE_EDGE);
@@ -2434,6 +2543,11 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
         left->nlevels != right->nlevels || left->scaleFactor != right->scaleFactor)
         return ORBFE_ERR_STATE;
     HIP_TRY(hipSetDevice(left->device));
+    {
+        int rj = lane_join(left);
+        if (rj >= 0) rj = lane_join(right);
+        if (rj < 0) return rj;
+    }
     // Inputs and outputs live in the left context's arenas (no allocation per call): everything is staged in pinned memory,
     // goes up in ONE transfer and comes back in ONE; the right extractor's kernels are ordered by an event, not by the host.
     const size_t oKL = 0, oKR = align_up(oKL + (size_t)nL * 28, 16), oDL = align_up(oKR + (size_t)nR * 28, 16),
@@ -2496,6 +2610,7 @@ static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, i
         left->scaleFactor != right->scaleFactor || right->lastCap >= (1 << 20))
         return ORBFE_ERR_STATE;
     int r;
+    if ((r = lane_join(left)) < 0 || (r = lane_join(right)) < 0) return r;
     const size_t cap = (size_t)left->lastCap;
     if ((r = left->d_stereo.ensure(3 * cap)) < 0) return r;
     if ((r = left->h_stereo.ensure(3 * cap)) < 0) return r;
@@ -2624,6 +2739,7 @@ int orbfe_debug_candidates(orbfe_ctx* c, int img, int level, uint32_t* out, int 
 {
     if (!c || c->lg.empty() || level < 0 || level >= c->nlevels || img < 0 || img >= c->lastImgs) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
+    lane_quiesce(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     const OrbLevelGeom& L = c->lg[level];
     std::vector<int32_t> cnt(L.nCells);
@@ -2645,6 +2761,7 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
 {
     if (!c || c->lg.empty() || level < 0 || level >= c->nlevels || img < 0 || img >= c->lastImgs) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
+    lane_quiesce(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, c->d_lvlCount.p + (size_t)img * ORBFE_MAX_LEVELS + level, sizeof(int32_t), hipMemcpyDeviceToHost));

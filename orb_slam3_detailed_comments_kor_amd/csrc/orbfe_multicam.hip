@@ -40,6 +40,7 @@
     } while (0)
 
 extern "C" int orbfe_get_stream(orbfe_ctx*, void** hip_stream, int* device);
+extern "C" int orbfe_lanes_record(orbfe_ctx*, void* hip_event);
 
 namespace {
 
@@ -167,7 +168,7 @@ struct orbfe_mc {
     struct Buf {
         uint8_t* slab = nullptr;     // device (host for a ctx == NULL handle)
         uint8_t* gathered = nullptr;
-        hipEvent_t evProduced = nullptr, evGathered = nullptr;
+        hipEvent_t evProduced = nullptr, evProduced2 = nullptr, evGathered = nullptr;
         int status = 0;
         long batch = -1;
         orbfe_knn2_job* d_jobs = nullptr; // job table of the last hops used on this buffer
@@ -273,6 +274,7 @@ void orbfe_mc_destroy(orbfe_mc* m)
             if (b.gathered) (void)hipFree(b.gathered);
             if (b.d_jobs) (void)hipFree(b.d_jobs);
             if (b.evProduced) (void)hipEventDestroy(b.evProduced);
+            if (b.evProduced2) (void)hipEventDestroy(b.evProduced2);
             if (b.evGathered) (void)hipEventDestroy(b.evGathered);
         } else {
             std::free(b.slab);
@@ -376,6 +378,17 @@ int orbfe_mc_extract_exchange_submit(orbfe_mc* m, const uint8_t* d_imgs, int row
     if (!m || !m->ctx || !d_imgs) return ORBFE_ERR_ARGS;
     if (m->submitted - m->retired >= 2) return ORBFE_ERR_STATE;
     MC_HIP_TRY(hipSetDevice(m->device));
+    {
+        // (the extractor's stream is asked for at every submit -- orbfe_set_stream after orbfe_mc_create replaces it,
+        // and a cached handle would then name a destroyed stream)
+        void* st = nullptr;
+        const int rs = orbfe_get_stream(m->ctx, &st, nullptr);
+        if (rs < 0) return rs;
+        if ((hipStream_t)st != m->sCtx) {
+            if (m->submitted != m->retired) return ORBFE_ERR_STATE; // batches in flight were queued on the old stream
+            m->sCtx = (hipStream_t)st;
+        }
+    }
     const int k = (int)(m->submitted & 1);
     orbfe_mc::Buf& b = m->buf[k];
     // the slab pair was last read by the collective (and the matcher) of two batches ago: the extractor's stream waits
@@ -386,6 +399,14 @@ int orbfe_mc_extract_exchange_submit(orbfe_mc* m, const uint8_t* d_imgs, int row
     if (r < 0) return r;
     MC_HIP_TRY(hipEventRecord(b.evProduced, m->sCtx));
     MC_HIP_TRY(hipStreamWaitEvent(m->sComm, b.evProduced, 0));
+    {
+        // a context with two lanes (orbfe_set_lanes): the second half of the batch is produced on the context's second stream;
+        // the collective waits for that lane too, the extractor's stream is not held back
+        if (!b.evProduced2) MC_HIP_TRY(hipEventCreateWithFlags(&b.evProduced2, hipEventDisableTiming));
+        const int two = orbfe_lanes_record(m->ctx, (void*)b.evProduced2);
+        if (two < 0) return two;
+        if (two == 1) MC_HIP_TRY(hipStreamWaitEvent(m->sComm, b.evProduced2, 0));
+    }
     b.status = 0;
     if (m->transport == ORBFE_MC_RCCL) {
         const int e = rccl().AllGather(b.slab, b.gathered, m->lay.slab_bytes, kNcclUint8, m->comm, m->sComm);

@@ -81,3 +81,44 @@ def test_ctypes_handle_against_the_oracle(oracle):
         assert (idx[k, n:] == -1).all()
     mc.close()
     ex.close()
+
+
+def test_two_lane_context_behind_the_exchange(oracle):
+    """A context with orbfe_set_lanes(2) under orbfe_mc_*: 16 frames per batch run as two half-batches on two streams; the
+    collective waits for BOTH lanes (orbfe_lanes_record), the extractor's stream is not held back.  Slabs of consecutive
+    batches (two in flight) equal the oracle's extraction, including the second lane's frames."""
+    import torch
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    from orb_slam3_detailed_comments_kor_amd import binding
+    rows, cols, frames = 240, 376, 16
+    sets = [np.stack([pkg.synth.make_frame(rows, cols, 1200 + 40 * s + i) for i in range(frames)]) for s in range(2)]
+    d_sets = [torch.from_numpy(a).cuda() for a in sets]
+    ex = pkg.ORBextractor(400, 1.2, 8, 20, 7, device=0)
+    ex.set_lanes(2)
+    cap = ex.max_keypoints(rows, cols)
+    mc = binding.MultiCam(ex, None, 0, 1, frames, cap, binding.MC_RCCL)
+    import ctypes as C
+    hip = C.CDLL(None)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    ref = [[oracle.Extractor(400, 1.2, 8, 20, 7).extract(a[i], (0, 0)) for i in (0, 7, 8, 15)] for a in sets]
+    inflight = 0
+    views = []
+    for b in range(6):
+        if inflight == 2:
+            views.append(mc.wait())
+            inflight -= 1
+            g = np.empty(mc.slab_bytes, np.uint8)
+            assert hip.hipMemcpy(g.ctypes.data_as(C.c_void_p), C.c_void_p(views[-1].gathered), g.size, 2) == 0
+            counts = g[mc.count_off:mc.count_off + 4 * frames].view(np.int32)
+            s = views[-1].batch % 2
+            for j, i in enumerate((0, 7, 8, 15)):
+                _, rk, rd = ref[s][j]
+                assert counts[i] == len(rk), (views[-1].batch, i)
+                assert np.array_equal(g[i * cap * 32:(i * cap + len(rk)) * 32].reshape(-1, 32), rd), (views[-1].batch, i)
+        mc.submit(d_sets[b % 2].data_ptr(), rows, cols, cols, rows * cols, (0, 0))
+        inflight += 1
+    while inflight:
+        mc.wait()
+        inflight -= 1
+    mc.close()
+    ex.close()
