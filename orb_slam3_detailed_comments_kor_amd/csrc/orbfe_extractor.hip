@@ -131,6 +131,10 @@ struct orbfe_geom_state {
     size_t fastLdsBytes = 0;
     std::vector<OrbFastCell> fc; // K-FAST's cell records
     DevBuf<OrbFastCell> d_fc;
+    std::vector<OrbFastRun> fr;  // ... and its run records (round 4: a workgroup per run of up to four cells of a cell row)
+    DevBuf<OrbFastRun> d_fr;
+    int fastRunTileBytes = 0, fastRunBmW = 0;
+    size_t fastRunLdsBytes = 0;
     std::vector<uint2> fastPat; // phase A's per-thread constants, fastThreads entries per pattern (OrbFastCell::pad names the pattern)
     DevBuf<uint2> d_fastPat;
     DevBuf<OrbDescSlot> d_ds; // K-DESC's per-slot records (level geometry of every keypoint slot)
@@ -147,7 +151,7 @@ struct orbfe_geom_state {
     bool pyrFused = true;
     void release_tables()
     {
-        d_lg.release(); d_cg.release(); d_fc.release(); d_fastPat.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
+        d_lg.release(); d_cg.release(); d_fc.release(); d_fr.release(); d_fastPat.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
     }
 };
 
@@ -168,6 +172,7 @@ struct orbfe_ctx : orbfe_geom_state {
     hipStream_t stream = nullptr;
     bool ownStream = false;
 
+    bool fastRuns = false;       // ORBFE_FAST_RUNS=1: a workgroup per run of up to four cells (k_fast_runs; measured slower)
     int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
     int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning; 0 = whole images per XCD always)
     bool fastByImage = true;     // ORBFE_FAST_BY_IMAGE=0 keeps the grouped order for every batch size
@@ -533,6 +538,58 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             c->fc.push_back(f);
         }
         c->fastThreads = nt;
+        // ---- runs of cells (k_fast_runs): every cell row of every level is cut into runs of as many cells as fit the
+        // kernel's compile-time tile pitch (ORBFE_FASTR_PD dwords), balanced
+        c->fr.clear();
+        int maxRows = 1;
+        for (int l = 0; l < nl; l++) {
+            const OrbLevelGeom& L = c->lg[l];
+            int i0 = L.cellBase;
+            const int iEnd = L.cellBase + L.nCells;
+            while (i0 < iEnd) {
+                int i1 = i0;
+                while (i1 < iEnd && c->cg[i1].iniY == c->cg[i0].iniY) i1++;
+                const int ncRow = i1 - i0;
+                // tile width of a run of n cells: ox + (n - 1) wCell + cw(last) < 4 PD (phase A reads one dword past the zone)
+                int nmax = std::min(ORBFE_FAST_RUN_MAXC, std::max(1, (4 * ORBFE_FASTR_PD - 10) / std::max(L.wCell, 1)));
+                const int nRunsRow = (ncRow + nmax - 1) / nmax;
+                for (int rr = 0; rr < nRunsRow; rr++) {
+                    const int a = i0 + (int)((long)ncRow * rr / nRunsRow), b = i0 + (int)((long)ncRow * (rr + 1) / nRunsRow);
+                    const OrbCellGeom &g0 = c->cg[a], &g1 = c->cg[b - 1];
+                    const int n = b - a, ox = g0.iniX & 3;
+                    const int tw = ox + (g1.iniX + g1.cw - g0.iniX);
+                    if (tw >= 4 * ORBFE_FASTR_PD || tw > 1023 || g0.ch > 255) return ORBFE_ERR_ARGS; // (cannot happen: cw <= 75)
+                    const int zwL = g1.cw - 6, zwF = n > 1 ? g0.cw - 6 : zwL;
+                    OrbFastRun f;
+                    f.gOff = g0.roiOff + (uint32_t)g0.iniY * (uint32_t)g0.pitch + (uint32_t)(g0.iniX - ox);
+                    f.pitch = (uint32_t)g0.pitch;
+                    f.dims = (uint32_t)tw | ((uint32_t)g0.ch << 10) | ((uint32_t)ox << 18) | ((uint32_t)n << 20);
+                    f.off = (uint32_t)(uint16_t)g0.offX | ((uint32_t)(uint16_t)g0.offY << 16);
+                    f.cell0 = (uint32_t)a;
+                    f.slotBase = (uint32_t)g0.slotBase;
+                    f.zw = (uint32_t)std::max(zwF, 0) | ((uint32_t)std::max(zwL, 0) << 16);
+                    f.cap = (uint32_t)(n > 1 ? g0.slotCap : g1.slotCap) | ((uint32_t)g1.slotCap << 16);
+                    f.mZw = recip32((unsigned)std::max(zwF, 1));
+                    const int txLo = 3 + ox, txHi = tw - 4;
+                    const int ndz = std::max((txHi >> 2) - (txLo >> 2) + 1, 1);
+                    f.ndz = (uint32_t)ndz;
+                    f.mNdz = recip32((unsigned)ndz);
+                    f.pad = 0;
+                    for (int k = a; k < b; k++) // (what the kernel's slot / zone arithmetic relies on)
+                        if (c->cg[k].slotBase != g0.slotBase + (k - a) * g0.slotCap || (k < b - 1 && c->cg[k].cw - 6 != zwF) ||
+                            c->cg[k].ch != g0.ch || c->cg[k].iniX != g0.iniX + (k - a) * L.wCell)
+                            return ORBFE_ERR_ARGS;
+                    c->fr.push_back(f);
+                    maxRows = std::max<int>(maxRows, g0.ch);
+                }
+                i0 = i1;
+            }
+        }
+        c->fastRunTileBytes = (int)(align_up((size_t)maxRows, 4) * 4 * ORBFE_FASTR_PD);
+        c->fastRunBmW = (int)align_up(((size_t)std::max(maxZone, 1) + 31) / 32, 4);
+        c->fastRunLdsBytes = align_up((size_t)2 * c->fastRunTileBytes - (size_t)16 * ORBFE_FASTR_PD +
+                                          8 * (size_t)ORBFE_FAST_RUN_MAXC * c->fastRunBmW +
+                                          2 * ((size_t)ORBFE_FASTR_QCAP + ORBFE_FASTR_CQ), 16);
     }
     // K-QT: a level's node tables take 24 ints per list entry.  Levels whose tables fit a workgroup's LDS (160 KB) run the
     // LDS instantiation; larger ones (round 4: nfeatures above ~7800, e.g. the 5 x nFeatures initialisation extractor of
@@ -667,6 +724,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     if ((r = c->d_lg.ensure(c->lg.size())) < 0) return r;
     if ((r = c->d_cg.ensure(c->cg.size())) < 0) return r;
     if ((r = c->d_fc.ensure(c->fc.size())) < 0) return r;
+    if ((r = c->d_fr.ensure(std::max<size_t>(c->fr.size(), 1))) < 0) return r;
     if ((r = c->d_fastPat.ensure(std::max<size_t>(c->fastPat.size(), 1))) < 0) return r;
     if ((r = c->d_ds.ensure(std::max<size_t>(c->kpStride, 1))) < 0) return r;
     if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
@@ -676,6 +734,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_fc.p, c->fc.data(), c->fc.size() * sizeof(OrbFastCell), hipMemcpyHostToDevice));
+    if (!c->fr.empty()) HIP_TRY(hipMemcpy(c->d_fr.p, c->fr.data(), c->fr.size() * sizeof(OrbFastRun), hipMemcpyHostToDevice));
     if (!c->fastPat.empty())
         HIP_TRY(hipMemcpy(c->d_fastPat.p, c->fastPat.data(), c->fastPat.size() * sizeof(uint2), hipMemcpyHostToDevice));
     {
@@ -1370,7 +1429,13 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         else if (c->fastPitch == 68) ORBFE_FAST_LAUNCH(NT, 17); \
         else ORBFE_FAST_LAUNCH(NT, 21);                  \
     } while (0)
-            if (c->fastThreads == 64) ORBFE_FAST_PD(64);
+            if (c->fastRuns && c->fastRunLdsBytes <= 64 * 1024) {
+                const int nRuns = (int)c->fr.size();
+                const dim3 rgrid = byImage ? dim3((unsigned)(8 * nRuns), (unsigned)perXcd) : dim3((unsigned)nRuns, (unsigned)ni);
+                hipLaunchKernelGGL((k_fast_runs<ORBFE_FASTR_NT, ORBFE_FASTR_PD>), rgrid, dim3(ORBFE_FASTR_NT), c->fastRunLdsBytes, q,
+                                   c->d_pyr.p, c->pyrStride, c->d_fr.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells,
+                                   nRuns, c->iniThFAST, c->minThFAST, c->fastRunTileBytes, c->fastRunBmW, byImage ? 1 : 0, i0, ni);
+            } else if (c->fastThreads == 64) ORBFE_FAST_PD(64);
             else if (c->fastThreads == 128) ORBFE_FAST_PD(128);
             else ORBFE_FAST_PD(256);
 #undef ORBFE_FAST_PD
@@ -2074,6 +2139,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     c->device = device;
     init_tables(c);
     if (const char* e = getenv("ORBFE_ATAN_FMA")) c->atanFma = atoi(e) != 0;
+    if (const char* e = getenv("ORBFE_FAST_RUNS")) c->fastRuns = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
     if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;

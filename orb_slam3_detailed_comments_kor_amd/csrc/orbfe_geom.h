@@ -66,6 +66,26 @@ struct OrbFastCell {
     uint32_t pad;
 };
 
+/* K-FAST, round 4: a workgroup's unit of work is a RUN of up to ORBFE_FAST_RUN_MAXC cells of one cell row (one coalesced tile,
+ * the aprons between the cells shared, one survivor stream for the score phase, cell seams as masks in the NMS, one rank
+ * space per cell).  48 B, host-built per image size.  The cells of a run are consecutive in the cell table and in the
+ * candidate slots; all but the last have the level's wCell as their zone width. */
+#define ORBFE_FAST_RUN_MAXC 4
+struct OrbFastRun {
+    uint32_t gOff;     /* byte offset of the tile origin (ROI row iniY, column iniX & ~3 of the first cell) in an image's slab */
+    uint32_t pitch;    /* row pitch of the level                                                                            */
+    uint32_t dims;     /* tile width in px (ox + zone + 6) | rows << 10 | ox << 18 | cells << 20                             */
+    uint32_t off;      /* offX | offY << 16 of the first cell (added to the candidates' coordinates)                         */
+    uint32_t cell0;    /* index of the first cell in the cell table (cellCount entry)                                       */
+    uint32_t slotBase; /* first candidate slot of the first cell                                                            */
+    uint32_t zw;       /* zone width of every cell but the last | of the last << 16                                         */
+    uint32_t cap;      /* slot capacity of every cell but the last | of the last << 16                                      */
+    uint32_t mZw;      /* ceil(2^32 / zone width of the non-last cells)                                                     */
+    uint32_t mNdz;     /* ceil(2^32 / dword columns of the run's zone)                                                      */
+    uint32_t ndz;      /* dword columns of the run's zone                                                                   */
+    uint32_t pad;
+};
+
 /* resize tables: per destination column / row */
 struct OrbResizeX {
     uint16_t sx;

@@ -3,6 +3,10 @@ on the minThFAST call, src/ORBextractor.cc:825-828), saturated 0 / 255 plateaus 
 checkerboard and fine sinusoids (thousands of equal scores: NMS strictness, quadtree (size, sequence) ties at scale), a
 pure ramp (no keypoint at all), quadrants of these with seams, and image widths whose last cell column is 1..6 px wide or
 skipped (:792-802).  HIP extractor through the C ABI vs the CPU oracle, every stage, bit-exact."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -99,3 +103,17 @@ def test_batches_of_mixed_content(pkg, oracle):
             assert np.array_equal(kps[f], rkps[f]), (i, f)
         assert np.array_equal(desc, rdesc), i
     ex.close()
+
+
+@pytest.mark.parametrize("env", [{"ORBFE_FAST_RUNS": "1"}])
+def test_alternative_fast_kernel_in_a_fresh_process(env):
+    # k_fast_runs (a workgroup per run of up to four cells: one survivor queue and one corner queue per run, seam-masked NMS,
+    # one rank space per cell, band-wise redo on queue overflow, map-scanning NMS on corner-queue overflow) ships as an option
+    # (ORBFE_FAST_RUNS=1; measured slower than the per-cell kernel): the content kinds -- sinus / checker2 drive
+    # both overflow paths, blurred the second pass per cell -- and the narrow-column widths again with it
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_content_kinds or test_last_cell_column or test_blurred_frames or test_batches_of_mixed"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -23,6 +23,9 @@ pkg.lib().orbfe_debug_fast_times(t.ctypes.data_as(C.c_void_p))
 n = int(t[15])
 names = ["cell record", "staging issue+wait", "barrier", "phase A", "barrier", "phase B (score)", "barrier", "phase C (NMS)",
          "barrier", "scan + output"]
+if os.environ.get("ORBFE_FAST_RUNS", "0") not in ("0", ""):  # round 4's kernel: a workgroup per run of cells, two more phases
+    names = ["run record", "staging issue+wait", "barrier", "phase A", "barrier", "phase B (score + corner queue)", "barrier",
+             "NMS over the corners", "barrier", "per-cell ranks", "barrier", "ranked output"]
 tot = 0.0
 for k, nm in enumerate(names):
     us = float(t[k]) / 100.0 / max(n, 1)
