@@ -340,6 +340,45 @@ int orbfe_search_bow(int device, const orbfe_bow_args*, int32_t* match);
  * match[p] sized like the single call's output; nmatches[p] per problem.  Returns 0 or an error. */
 int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, int32_t* const* match, int* nmatches);
 
+/* ---- resident keyframes (round 4) ----
+ * The BoW / triangulation searches run one CURRENT frame or keyframe against MANY keyframes that do not change between
+ * calls: Tracking::Relocalization and LoopClosing search one frame against every candidate (src/Tracking.cc:3784,
+ * src/LoopClosing.cc:725), LocalMapping::CreateNewMapPoints one keyframe against its 10-20 best covisible neighbours
+ * (src/LocalMapping.cc:556-621).  The calls above re-pack and re-upload both sides every time.  A keyframe handle keeps one
+ * side on the device: descriptors (`desc` may be a device pointer -- orbfe_get_device_outputs of the extractor that produced
+ * the frame --, then nothing of it crosses PCIe), the per-feature flag (mask = "has a good MapPoint": SearchByBoW's
+ * mask1 / mask2 and SearchForTriangulation_'s hasMP), angles, and the FeatureVector; with kp_xy / octave / uRight given it
+ * can also be a side of the triangulation search.  Descriptors, keypoints and the FeatureVector of a KeyFrame never change
+ * (ComputeBoW runs once); its MapPoints do: orbfe_keyframe_set_mask re-sends the n flag bytes when they differ from the last
+ * ones.  A handle is read by the searches of any thread; create / set_mask / destroy are the owner's. */
+typedef struct orbfe_keyframe orbfe_keyframe;
+typedef struct {
+    const uint8_t* desc; int n;            /* 32-B rows; host or device pointer                                      */
+    const uint8_t* mask;                   /* 1 = the feature has a (good) MapPoint                                  */
+    const float* angle;                    /* mvKeysUn[i].angle, or NULL when no search checks the orientation       */
+    const float* kp_xy;                    /* 2 floats per feature, or NULL: BoW searches only                        */
+    const int32_t* octave; const float* uRight; /* required with kp_xy                                               */
+    orbfe_fv fv;                           /* KeyFrame::mFeatVec                                                      */
+} orbfe_keyframe_args;
+int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe_args*);
+int orbfe_keyframe_set_mask(orbfe_keyframe*, const uint8_t* mask);
+void orbfe_keyframe_destroy(orbfe_keyframe*);
+/* orbfe_search_bow_batch with sets taken from handles: kf1[p] / kf2[p] non-null replaces set 1 / set 2 of args[p] (its
+ * desc / n / mask / angle / fv fields are then ignored; limit, Nleft, nnratio, check_orientation and variant still come from
+ * args[p]).  kf1 / kf2 may be NULL (no handle on that side).  One upload of whatever is not resident, one launch, one download. */
+int orbfe_search_bow_keyframes(int device, int count, orbfe_keyframe* const* kf1, orbfe_keyframe* const* kf2,
+                               const orbfe_bow_args* args, int32_t* const* match, int* nmatches);
+/* SearchForTriangulation_ (src/ORBmatcher.cc:1208-1449, pinhole gate) of ONE keyframe against `count` neighbours in ONE
+ * launch; both sides are handles created with kp_xy.  pair[p] holds what depends on the pair; pairs[p] (2 * n1 ints) and
+ * npairs[p] are the outputs of the p-th orbfe_search_tri call.  Returns 0 or an error. */
+typedef struct {
+    float F12[9]; float ep[2];
+    const float* scaleFactors2; const float* levelSigma2_2; int nlevels2;
+    int only_stereo, coarse, check_orientation;
+} orbfe_tri_pair;
+int orbfe_search_tri_batch(orbfe_keyframe* kf1, int count, orbfe_keyframe* const* kf2, const orbfe_tri_pair* pair,
+                           int32_t* const* pairs, int* npairs);
+
 typedef struct {
     const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1_xy; const float* angle1;
     const int32_t* octave1; const float* uRight1; orbfe_fv fv1;

@@ -299,7 +299,9 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
            "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
            "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
-           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_lanes_join", "orbfe_lanes_record"]
+           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_lanes_join", "orbfe_lanes_record",
+           "orbfe_keyframe_create", "orbfe_keyframe_set_mask", "orbfe_keyframe_destroy", "orbfe_search_bow_keyframes",
+           "orbfe_search_tri_batch"]
 
 
 def _p(a):
@@ -789,6 +791,105 @@ def search_triangulation(desc1, hasMP1, kp1xy, ang1, oct1, uR1, fv1, desc2, hasM
     pairs = np.zeros((max(len(d1), 1), 2), np.int32)
     n = _chk(lib().orbfe_search_tri(device, C.byref(args), _p(pairs)), "orbfe_search_tri")
     return pairs[:n].copy()
+
+
+class _KeyFrameArgs(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("n", C.c_int), ("mask", C.c_void_p), ("angle", C.c_void_p), ("kp_xy", C.c_void_p),
+                ("octave", C.c_void_p), ("uRight", C.c_void_p), ("fv", _FV)]
+
+
+class _TriPair(C.Structure):
+    _fields_ = [("F12", C.c_float * 9), ("ep", C.c_float * 2), ("scaleFactors2", C.c_void_p), ("levelSigma2_2", C.c_void_p),
+                ("nlevels2", C.c_int), ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
+
+
+class KeyFrameHandle:
+    """orbfe_keyframe_*: a keyframe's descriptors, flags, angles, FeatureVector (and keypoints / octaves / mvuRight when
+    given) resident on the device.  `desc` may be a device address (int)."""
+
+    def __init__(self, desc, mask, angle, fv, kp_xy=None, octave=None, uRight=None, device=0):
+        self.L = lib()
+        self.device = device
+        p, n, keep = _desc_arg(desc)
+        m = np.ascontiguousarray(mask, np.uint8)
+        a = None if angle is None else np.ascontiguousarray(angle, np.float32)
+        f, kf = _fv(fv)
+        xy = None if kp_xy is None else np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+        oc = None if octave is None else np.ascontiguousarray(octave, np.int32)
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        args = _KeyFrameArgs(p, n, m.ctypes.data, None if a is None else a.ctypes.data, None if xy is None else xy.ctypes.data,
+                             None if oc is None else oc.ctypes.data, None if ur is None else ur.ctypes.data, f)
+        self.h = C.c_void_p()
+        self.n = n
+        _chk(self.L.orbfe_keyframe_create(C.byref(self.h), device, C.byref(args)), "orbfe_keyframe_create")
+
+    def set_mask(self, mask):
+        m = np.ascontiguousarray(mask, np.uint8)
+        assert len(m) == self.n
+        _chk(self.L.orbfe_keyframe_set_mask(self.h, _p(m)), "orbfe_keyframe_set_mask")
+
+    def close(self):
+        if self.h:
+            self.L.orbfe_keyframe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def search_bow_keyframes(problems, device=0):
+    """orbfe_search_bow_keyframes: problems as for search_bow_batch; `kf1` / `kf2` (KeyFrameHandle) replace set 1 / set 2,
+    whose array arguments may then be omitted.  Returns [(nmatches, match), ...]."""
+    n = len(problems)
+    arr = (_BowArgs * n)()
+    k1 = (C.c_void_p * n)()
+    k2 = (C.c_void_p * n)()
+    keep, outs = [], []
+    for i, pr in enumerate(problems):
+        h1, h2 = pr.get("kf1"), pr.get("kf2")
+        dummy = np.zeros((1, 32), np.uint8)
+        one = np.ones(1, np.uint8)
+        efv = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+        a, k, nout = _bow_args(dummy if h1 else pr["desc1"], one if h1 else pr["mask1"], np.zeros(1) if h1 else pr["ang1"],
+                               efv if h1 else pr["fv1"], dummy if h2 else pr["desc2"], one if h2 else pr.get("mask2"),
+                               np.zeros(1) if h2 else pr["ang2"], efv if h2 else pr["fv2"], pr["variant"], pr["nnratio"],
+                               pr.get("check_ori", True), pr.get("Nleft", -1), pr.get("limit1", -1), pr.get("limit2", -1))
+        arr[i] = a
+        k1[i] = h1.h if h1 else None
+        k2[i] = h2.h if h2 else None
+        n1 = h1.n if h1 else a.n1
+        n2 = h2.n if h2 else a.n2
+        keep.append(k)
+        outs.append(np.zeros(n2 if pr["variant"] == 0 else n1, np.int32))
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    nm = np.zeros(n, np.int32)
+    _chk(lib().orbfe_search_bow_keyframes(device, n, k1, k2, arr, ptrs, _p(nm)), "orbfe_search_bow_keyframes")
+    return [(int(nm[i]), outs[i]) for i in range(n)]
+
+
+def search_tri_batch(kf1, neighbours):
+    """orbfe_search_tri_batch: kf1 (KeyFrameHandle with keypoints) against neighbours = [dict(kf=handle, F12, ep, sf, sig,
+    only_stereo, coarse, check_ori)], one launch.  Returns a list of pairs[n, 2] arrays."""
+    n = len(neighbours)
+    arr = (_TriPair * n)()
+    kfs = (C.c_void_p * n)()
+    keep, outs = [], []
+    for i, q in enumerate(neighbours):
+        sf = np.ascontiguousarray(q["sf"], np.float32)
+        sg = np.ascontiguousarray(q["sig"], np.float32)
+        keep += [sf, sg]
+        arr[i] = _TriPair((C.c_float * 9)(*[float(v) for v in np.asarray(q["F12"], np.float32).reshape(9)]),
+                          (C.c_float * 2)(float(q["ep"][0]), float(q["ep"][1])), sf.ctypes.data, sg.ctypes.data, len(sf),
+                          int(q.get("only_stereo", False)), int(q.get("coarse", False)), int(q.get("check_ori", True)))
+        kfs[i] = q["kf"].h
+        outs.append(np.zeros((max(kf1.n, 1), 2), np.int32))
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    npairs = np.zeros(max(n, 1), np.int32)
+    _chk(lib().orbfe_search_tri_batch(kf1.h, n, kfs, arr, ptrs, _p(npairs)), "orbfe_search_tri_batch")
+    return [outs[i][:npairs[i]].copy() for i in range(n)]
 
 
 def search_initialization(problem, device=0):

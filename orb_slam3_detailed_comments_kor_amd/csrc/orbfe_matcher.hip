@@ -229,6 +229,11 @@ struct BowProb {
     int d1Base, d2Base, outBase;
     int limit1, limit2, Nleft, variant;
     float nnratio;
+    int tBase; // set 2's row in the pooled "taken" flags
+    // Round 4: a set may live in a keyframe handle (orbfe_keyframe_create) instead of the pooled arrays of the call: then
+    // these name its resident arrays (and the node offsets of that set are relative to its own index array); null = pooled.
+    const uint8_t* rDesc1; const uint8_t* rMask1; const float* rAng1; const int32_t* rInd1;
+    const uint8_t* rDesc2; const uint8_t* rMask2; const float* rAng2; const int32_t* rInd2;
 };
 
 __device__ __forceinline__ int rot_bin(float a1, float a2)
@@ -260,17 +265,17 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
     if (nd >= nNodes) return;
     const BowNode N = nodes[nd];
     const BowProb Pb = probs[N.prob];
-    const uint8_t* desc1 = descPool + (size_t)Pb.d1Base * 32;
-    const uint8_t* desc2 = descPool + (size_t)Pb.d2Base * 32;
-    const uint8_t* mask1 = maskPool + Pb.d1Base;
-    const uint8_t* mask2 = maskPool + Pb.d2Base;
-    const float* ang1 = angPool + Pb.d1Base;
-    const float* ang2 = angPool + Pb.d2Base;
-    const int32_t* ind1 = indPool; // node offsets are already pooled
-    const int32_t* ind2 = indPool;
+    const uint8_t* desc1 = Pb.rDesc1 ? Pb.rDesc1 : descPool + (size_t)Pb.d1Base * 32;
+    const uint8_t* desc2 = Pb.rDesc2 ? Pb.rDesc2 : descPool + (size_t)Pb.d2Base * 32;
+    const uint8_t* mask1 = Pb.rDesc1 ? Pb.rMask1 : maskPool + Pb.d1Base;
+    const uint8_t* mask2 = Pb.rDesc2 ? Pb.rMask2 : maskPool + Pb.d2Base;
+    const float* ang1 = Pb.rDesc1 ? Pb.rAng1 : angPool + Pb.d1Base;
+    const float* ang2 = Pb.rDesc2 ? Pb.rAng2 : angPool + Pb.d2Base;
+    const int32_t* ind1 = Pb.rDesc1 ? Pb.rInd1 : indPool; // node offsets of a pooled set are already pooled
+    const int32_t* ind2 = Pb.rDesc2 ? Pb.rInd2 : indPool;
     int32_t* match = matchPool + Pb.outBase;
     int8_t* bins = binsPool + Pb.outBase;
-    uint8_t* taken2 = takenPool + Pb.d2Base;
+    uint8_t* taken2 = takenPool + Pb.tBase;
     const int limit1 = Pb.limit1, limit2 = Pb.limit2, Nleft = Pb.Nleft, variant = Pb.variant;
     const float nnratio = Pb.nnratio;
     // "already matched" state of this node's set-2 features: only this wave touches them, so the
@@ -446,6 +451,69 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     }
     best = wave_min_u32(best);
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+}
+
+// K-TRI for ONE current keyframe against several neighbours in one launch (round 4; LocalMapping::CreateNewMapPoints
+// runs SearchForTriangulation_ of the current keyframe against 10-20 covisible keyframes, src/LocalMapping.cc:556-621):
+// the same row as above with the neighbour's arrays and pair geometry taken from a per-problem record.
+struct TriProb {
+    const uint8_t* desc2; const uint8_t* hasMP2; const float* kp2; const int32_t* oct2; const float* uR2; const int32_t* ind2;
+    const float* sf2; const float* sig2;
+    float F12[9];
+    float epx, epy;
+    int onlyStereo, coarse;
+    int outBase; // this problem's match12 row in the pooled output
+    int pad;
+};
+struct TriRowB {
+    int idx1, off2, n2, prob;
+};
+__global__ __launch_bounds__(256) void k_search_tri_batch(const TriRowB* __restrict__ rows, int nRows,
+                                                          const TriProb* __restrict__ probs,
+                                                          const uint8_t* __restrict__ desc1, const float* __restrict__ kp1,
+                                                          const float* __restrict__ uR1, int32_t* __restrict__ matchPool)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rix = blockIdx.x * 4 + wave;
+    if (rix >= nRows) return;
+    const TriRowB R = rows[rix];
+    const TriProb& Q = probs[R.prob];
+    const int idx1 = R.idx1;
+    const Desc d1 = load_desc(desc1 + (size_t)idx1 * 32);
+    const float k1x = kp1[2 * idx1], k1y = kp1[2 * idx1 + 1];
+    const bool bStereo1 = uR1[idx1] >= 0;
+    const float la = __fadd_rn(__fadd_rn(__fmul_rn(k1x, Q.F12[0]), __fmul_rn(k1y, Q.F12[3])), Q.F12[6]);
+    const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1x, Q.F12[1]), __fmul_rn(k1y, Q.F12[4])), Q.F12[7]);
+    const float lc = __fadd_rn(__fadd_rn(__fmul_rn(k1x, Q.F12[2]), __fmul_rn(k1y, Q.F12[5])), Q.F12[8]);
+    const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+    const uint8_t* const desc2 = Q.desc2;
+    const int32_t* const ind2 = Q.ind2;
+    unsigned best = 0xFFFFFFFFu;
+    for (int c = lane; c < R.n2; c += 64) {
+        const int idx2 = ind2[R.off2 + c];
+        if (Q.hasMP2[idx2]) continue;
+        const bool bStereo2 = Q.uR2[idx2] >= 0;
+        if (Q.onlyStereo && !bStereo2) continue;
+        const int dist = hamming(d1, load_desc(desc2 + (size_t)idx2 * 32));
+        if (dist > TH_LOW) continue;
+        const float k2x = Q.kp2[2 * idx2], k2y = Q.kp2[2 * idx2 + 1];
+        const int o2 = Q.oct2[idx2];
+        if (!bStereo1 && !bStereo2) {
+            const float ex = __fsub_rn(Q.epx, k2x), ey = __fsub_rn(Q.epy, k2y);
+            if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.f, Q.sf2[o2])) continue;
+        }
+        bool ok = Q.coarse != 0;
+        if (!ok && den != 0.f) {
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2x), __fmul_rn(lb, k2y)), lc);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            ok = (double)dsqr < __dmul_rn(3.84, (double)Q.sig2[o2]);
+        }
+        if (!ok) continue;
+        best = min(best, ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c)); // smallest dist, then last position
+    }
+    best = wave_min_u32(best);
+    if (lane == 0)
+        matchPool[Q.outBase + idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
 }
 
 // K-TRI with the KannalaBrandt8 gate (fisheye monocular pairs and two-camera rigs): same row / candidate
@@ -1633,11 +1701,35 @@ int orbfe_matcher_sync(int device)
     return 0;
 }
 
-// Batched SearchByBoW: `count` independent (set 1, set 2) problems -- e.g. the relocalisation
-// candidates of Tracking::Relocalization (src/Tracking.cc:3784, one call per candidate KF) or the
-// covisible keyframes of LoopClosing (src/LoopClosing.cc:725) -- pooled into ONE upload, ONE launch
-// (one wavefront per shared vocabulary node of any problem) and ONE download.
-int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, int32_t* const* match, int* nmatches)
+// A keyframe's matching data kept on the device between calls (round 4): descriptors, the good-MapPoint /
+// has-MapPoint flags, angles, keypoints, octaves, mvuRight and the FeatureVector's index array; host copies of what the host
+// side of a search reads (the FeatureVector's node ids / offsets / indices for the merge-join, flags, angles, mvuRight).
+struct orbfe_keyframe {
+    int device = 0, n = 0;
+    uint8_t* block = nullptr; // one allocation: everything below points into it
+    uint8_t *desc = nullptr, *mask = nullptr;
+    float *ang = nullptr, *kp = nullptr, *uR = nullptr;
+    int32_t *oct = nullptr, *ind = nullptr;
+    bool hasTri = false; // keypoints / octaves / mvuRight were given: usable as a side of SearchForTriangulation_
+    std::vector<uint32_t> nodeIds;
+    std::vector<int32_t> offsets, indices, hOct;
+    std::vector<uint8_t> hMask;
+    std::vector<float> hAng, hUR;
+    orbfe_fv fv() const
+    {
+        orbfe_fv f;
+        f.nn = (int)nodeIds.size();
+        f.node_ids = nodeIds.data();
+        f.offsets = offsets.data();
+        f.indices = indices.data();
+        return f;
+    }
+};
+
+namespace {
+// SearchByBoW over `count` problems; kf1 / kf2 (arrays or null, entries may be null) name sets that live in handles
+int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* const* kf1, orbfe_keyframe* const* kf2,
+            int32_t* const* match, int* nmatches)
 {
     if (count < 0 || (count && (!args || !match || !nmatches))) return ORBFE_ERR_ARGS;
     // pass 1: validate, lay the pools out, list the shared vocabulary nodes (merge-join of the two FeatureVectors)
@@ -1645,10 +1737,24 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     std::vector<BowProb> probs(count);
     std::vector<int> outN(count), i1Base(count, 0), i2Base(count, 0);
     std::vector<uint8_t> active(count, 0);
-    int rows = 0, outTotal = 0;
+    std::vector<orbfe_bow_args> eff(count); // the arguments with the handles' host views filled in
+    int rows = 0, outTotal = 0, takenRows = 0;
     size_t indTotal = 0;
     for (int p = 0; p < count; p++) {
-        const orbfe_bow_args* a = &args[p];
+        orbfe_bow_args& e = eff[p];
+        e = args[p];
+        const orbfe_keyframe* K1 = kf1 ? kf1[p] : nullptr;
+        const orbfe_keyframe* K2 = kf2 ? kf2[p] : nullptr;
+        if ((K1 && K1->device != device) || (K2 && K2->device != device)) return ORBFE_ERR_ARGS;
+        if (K1) {
+            e.desc1 = K1->desc; e.n1 = K1->n; e.mask1 = K1->hMask.data(); e.angle1 = K1->hAng.empty() ? nullptr : K1->hAng.data();
+            e.fv1 = K1->fv();
+        }
+        if (K2) {
+            e.desc2 = K2->desc; e.n2 = K2->n; e.mask2 = K2->hMask.data(); e.angle2 = K2->hAng.empty() ? nullptr : K2->hAng.data();
+            e.fv2 = K2->fv();
+        }
+        const orbfe_bow_args* a = &e;
         if (!match[p] || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2) ||
             (a->variant != 0 && a->variant != 1))
             return ORBFE_ERR_ARGS;
@@ -1657,25 +1763,36 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
         for (int i = 0; i < nOut; i++) match[p][i] = -1;
         nmatches[p] = 0;
         BowProb& P = probs[p];
+        std::memset(&P, 0, sizeof P);
         P.d1Base = rows;
-        P.d2Base = rows + a->n1;
+        P.d2Base = rows + (K1 ? 0 : a->n1);
         P.outBase = outTotal;
+        P.tBase = takenRows;
         P.limit1 = a->limit1;
         P.limit2 = a->limit2;
         P.Nleft = a->Nleft;
         P.variant = a->variant;
         P.nnratio = a->nnratio;
         outTotal += nOut;
+        takenRows += a->n2;
         if (a->n1 == 0 || a->n2 == 0) continue;
         if (!a->desc1 || !a->desc2 || !a->mask1 || (a->variant == 1 && !a->mask2)) return ORBFE_ERR_ARGS;
         if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
         active[p] = 1;
-        i1Base[p] = (int)indTotal;
-        indTotal += (size_t)(a->fv1.nn ? a->fv1.offsets[a->fv1.nn] : 0);
-        i2Base[p] = (int)indTotal;
-        indTotal += (size_t)(a->fv2.nn ? a->fv2.offsets[a->fv2.nn] : 0);
+        if (K1) {
+            P.rDesc1 = K1->desc; P.rMask1 = K1->mask; P.rAng1 = K1->ang; P.rInd1 = K1->ind;
+        } else {
+            i1Base[p] = (int)indTotal;
+            indTotal += (size_t)(a->fv1.nn ? a->fv1.offsets[a->fv1.nn] : 0);
+        }
+        if (K2) {
+            P.rDesc2 = K2->desc; P.rMask2 = K2->mask; P.rAng2 = K2->ang; P.rInd2 = K2->ind;
+        } else {
+            i2Base[p] = (int)indTotal;
+            indTotal += (size_t)(a->fv2.nn ? a->fv2.offsets[a->fv2.nn] : 0);
+        }
         bool bad = false;
-        const int b1 = i1Base[p], b2 = i2Base[p];
+        const int b1 = i1Base[p], b2 = i2Base[p]; // (0 for a set in a handle: its offsets are relative to its own index array)
         for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
             BowNode n;
             n.off1 = b1 + a->fv1.offsets[i];
@@ -1687,7 +1804,7 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
             if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
         });
         if (bad) return ORBFE_ERR_ARGS;
-        rows += a->n1 + a->n2;
+        rows += (K1 ? 0 : a->n1) + (K2 ? 0 : a->n2);
     }
     if (nodes.empty()) return 0;
     int r;
@@ -1707,9 +1824,10 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     if ((r = s.reserve(&dInd, &hInd, indTotal)) < 0) return r;
     if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
     if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
-    if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)rows)) < 0) return r;
+    if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)takenRows)) < 0) return r;
     // pass 2: every problem's arrays go straight into the pinned mirror of the pools (one copy, no intermediate
-    // vectors); descriptor sets that already live on the device are copied device-to-device after the upload
+    // vectors); descriptor sets that already live on the device are copied device-to-device after the upload; sets in
+    // handles are read where they are
     struct D2D {
         size_t off;
         const uint8_t* src;
@@ -1718,31 +1836,34 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     std::vector<D2D> d2d;
     for (int p = 0; p < count; p++) {
         if (!active[p]) continue;
-        const orbfe_bow_args* a = &args[p];
+        const orbfe_bow_args* a = &eff[p];
+        const bool R1 = probs[p].rDesc1 != nullptr, R2 = probs[p].rDesc2 != nullptr;
         const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
-        if (is_device_ptr(a->desc1)) {
-            (void)orbfe_producer_wait(a->desc1, g_ms);
-            d2d.push_back(D2D{r1 * 32, a->desc1, (size_t)a->n1 * 32});
+        if (!R1) {
+            if (is_device_ptr(a->desc1)) {
+                (void)orbfe_producer_wait(a->desc1, g_ms);
+                d2d.push_back(D2D{r1 * 32, a->desc1, (size_t)a->n1 * 32});
+            } else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
+            std::memcpy(hMask + r1, a->mask1, (size_t)a->n1);
+            if (a->angle1) std::memcpy(hAng + r1, a->angle1, (size_t)a->n1 * sizeof(float));
+            else std::memset(hAng + r1, 0, (size_t)a->n1 * sizeof(float));
+            if (a->fv1.nn) std::memcpy(hInd + i1Base[p], a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn] * sizeof(int32_t));
         }
-        else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
-        if (is_device_ptr(a->desc2)) {
-            (void)orbfe_producer_wait(a->desc2, g_ms);
-            d2d.push_back(D2D{r2 * 32, a->desc2, (size_t)a->n2 * 32});
+        if (!R2) {
+            if (is_device_ptr(a->desc2)) {
+                (void)orbfe_producer_wait(a->desc2, g_ms);
+                d2d.push_back(D2D{r2 * 32, a->desc2, (size_t)a->n2 * 32});
+            } else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
+            if (a->variant == 1) std::memcpy(hMask + r2, a->mask2, (size_t)a->n2);
+            else std::memset(hMask + r2, 1, (size_t)a->n2);
+            if (a->angle2) std::memcpy(hAng + r2, a->angle2, (size_t)a->n2 * sizeof(float));
+            else std::memset(hAng + r2, 0, (size_t)a->n2 * sizeof(float));
+            if (a->fv2.nn) std::memcpy(hInd + i2Base[p], a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn] * sizeof(int32_t));
         }
-        else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
-        std::memcpy(hMask + r1, a->mask1, (size_t)a->n1);
-        if (a->variant == 1) std::memcpy(hMask + r2, a->mask2, (size_t)a->n2);
-        else std::memset(hMask + r2, 1, (size_t)a->n2);
-        if (a->angle1) std::memcpy(hAng + r1, a->angle1, (size_t)a->n1 * sizeof(float));
-        else std::memset(hAng + r1, 0, (size_t)a->n1 * sizeof(float));
-        if (a->angle2) std::memcpy(hAng + r2, a->angle2, (size_t)a->n2 * sizeof(float));
-        else std::memset(hAng + r2, 0, (size_t)a->n2 * sizeof(float));
-        if (a->fv1.nn) std::memcpy(hInd + i1Base[p], a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn] * sizeof(int32_t));
-        if (a->fv2.nn) std::memcpy(hInd + i2Base[p], a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn] * sizeof(int32_t));
     }
     HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), g_ms));
     HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
-    HIP_TRY(hipMemsetAsync(taken, 0, (size_t)rows, g_ms));
+    HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
     {
         KernelTimer timer(s); // (sends the staged pools; the device-resident sets then overwrite their places)
         for (const D2D& c : d2d)
@@ -1762,6 +1883,16 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
     }
     return 0;
 }
+} // namespace
+
+// Batched SearchByBoW: `count` independent (set 1, set 2) problems -- e.g. the relocalisation
+// candidates of Tracking::Relocalization (src/Tracking.cc:3784, one call per candidate KF) or the
+// covisible keyframes of LoopClosing (src/LoopClosing.cc:725) -- pooled into ONE upload, ONE launch
+// (one wavefront per shared vocabulary node of any problem) and ONE download.
+int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, int32_t* const* match, int* nmatches)
+{
+    return bow_run(device, count, args, nullptr, nullptr, match, nmatches);
+}
 
 int orbfe_search_bow(int device, const orbfe_bow_args* a, int32_t* match)
 {
@@ -1770,6 +1901,201 @@ int orbfe_search_bow(int device, const orbfe_bow_args* a, int32_t* match)
     int32_t* mp[1] = {match};
     const int r = orbfe_search_bow_batch(device, 1, a, mp, &n);
     return r < 0 ? r : n;
+}
+
+int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe_args* a)
+{
+    if (!out) return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    if (!a || a->n < 1 || a->n >= (1 << 20) || !a->desc || !a->mask || !fv_ok(a->fv)) return ORBFE_ERR_ARGS;
+    const bool tri = a->kp_xy != nullptr;
+    if (tri && (!a->octave || !a->uRight)) return ORBFE_ERR_ARGS;
+    const size_t n = (size_t)a->n, ni = a->fv.nn ? (size_t)a->fv.offsets[a->fv.nn] : 0;
+    for (size_t i = 0; i < ni; i++)
+        if (a->fv.indices[i] < 0 || a->fv.indices[i] >= a->n) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oDesc = 0, oMask = oDesc + al(n * 32), oAng = oMask + al(n), oKp = oAng + al(n * 4), oUr = oKp + al(n * 8),
+                 oOct = oUr + al(n * 4), oInd = oOct + al(n * 4), total = oInd + al(std::max<size_t>(ni, 1) * 4);
+    void* blk = nullptr;
+    HIP_TRY(hipMalloc(&blk, total));
+    orbfe_keyframe* K = new orbfe_keyframe();
+    K->device = device;
+    K->n = a->n;
+    K->block = (uint8_t*)blk;
+    K->desc = K->block + oDesc;
+    K->mask = K->block + oMask;
+    K->ang = (float*)(K->block + oAng);
+    K->kp = (float*)(K->block + oKp);
+    K->uR = (float*)(K->block + oUr);
+    K->oct = (int32_t*)(K->block + oOct);
+    K->ind = (int32_t*)(K->block + oInd);
+    K->hasTri = tri;
+    K->nodeIds.assign(a->fv.node_ids, a->fv.node_ids + a->fv.nn);
+    K->offsets.assign(a->fv.offsets, a->fv.offsets + a->fv.nn + (a->fv.nn ? 1 : 0));
+    if (K->offsets.empty()) K->offsets.push_back(0);
+    K->indices.assign(a->fv.indices, a->fv.indices + ni);
+    K->hMask.assign(a->mask, a->mask + n);
+    if (a->angle) K->hAng.assign(a->angle, a->angle + n);
+    if (tri) {
+        K->hUR.assign(a->uRight, a->uRight + n);
+        K->hOct.assign(a->octave, a->octave + n);
+    }
+    Scratch s(device); // (this thread's matcher stream)
+    const bool descResident = is_device_ptr(a->desc);
+    if (descResident) (void)orbfe_producer_wait(a->desc, g_ms);
+    hipError_t e = hipMemcpyAsync(K->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess) e = hipMemcpyAsync(K->mask, a->mask, n, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess && a->angle) e = hipMemcpyAsync(K->ang, a->angle, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess && !a->angle) e = hipMemsetAsync(K->ang, 0, n * 4, g_ms);
+    if (e == hipSuccess && tri) e = hipMemcpyAsync(K->kp, a->kp_xy, n * 8, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess && tri) e = hipMemcpyAsync(K->uR, a->uRight, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess && tri) e = hipMemcpyAsync(K->oct, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess && ni) e = hipMemcpyAsync(K->ind, a->fv.indices, ni * 4, hipMemcpyHostToDevice, g_ms);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ms); // the caller's arrays are free again; the handle is complete
+    if (e != hipSuccess) {
+        (void)hipFree(blk);
+        delete K;
+        return -(1000 + (int)e);
+    }
+    *out = K;
+    return 0;
+}
+
+int orbfe_keyframe_set_mask(orbfe_keyframe* K, const uint8_t* mask)
+{
+    if (!K || !mask) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(K->device)) < 0) return r;
+    if (std::memcmp(K->hMask.data(), mask, (size_t)K->n) == 0) return 0; // unchanged since the last call: nothing to send
+    K->hMask.assign(mask, mask + K->n);
+    Scratch s(K->device);
+    // (ordered on this thread's matcher stream, which is the stream this thread's searches run on; the source is the
+    // handle's own host copy, which lives until the next set_mask: wait here so that a second update cannot overtake it)
+    HIP_TRY(hipMemcpyAsync(K->mask, K->hMask.data(), (size_t)K->n, hipMemcpyHostToDevice, g_ms));
+    HIP_TRY(hipStreamSynchronize(g_ms));
+    return 0;
+}
+
+void orbfe_keyframe_destroy(orbfe_keyframe* K)
+{
+    if (!K) return;
+    if (hipSetDevice(K->device) == hipSuccess) {
+        (void)hipDeviceSynchronize(); // (a search of another thread may still be reading it)
+        (void)hipFree(K->block);
+    }
+    delete K;
+}
+
+int orbfe_search_bow_keyframes(int device, int count, orbfe_keyframe* const* kf1, orbfe_keyframe* const* kf2,
+                               const orbfe_bow_args* args, int32_t* const* match, int* nmatches)
+{
+    return bow_run(device, count, args, kf1, kf2, match, nmatches);
+}
+
+// SearchForTriangulation_ of ONE keyframe against `count` neighbours (src/LocalMapping.cc:556-621), all sides resident:
+// one upload of the row lists and pair records, ONE launch, one download.
+int orbfe_search_tri_batch(orbfe_keyframe* K1, int count, orbfe_keyframe* const* kf2, const orbfe_tri_pair* pair,
+                           int32_t* const* pairs, int* npairs)
+{
+    if (!K1 || count < 0 || (count && (!kf2 || !pair || !pairs || !npairs)) || !K1->hasTri) return ORBFE_ERR_ARGS;
+    const int device = K1->device, n1 = K1->n;
+    std::vector<TriRowB> rows;
+    std::vector<TriProb> probs(count);
+    const orbfe_fv f1 = K1->fv();
+    size_t tabFloats = 0;
+    for (int p = 0; p < count; p++) {
+        const orbfe_keyframe* K2 = kf2[p];
+        const orbfe_tri_pair& q = pair[p];
+        if (!K2 || !K2->hasTri || K2->device != device || !pairs[p] || !q.scaleFactors2 || !q.levelSigma2_2 || q.nlevels2 < 1)
+            return ORBFE_ERR_ARGS;
+        if (q.check_orientation && (K1->hAng.empty() || K2->hAng.empty())) return ORBFE_ERR_ARGS;
+        for (int i = 0; i < K2->n; i++)
+            if (K2->hOct[i] < 0 || K2->hOct[i] >= q.nlevels2) return ORBFE_ERR_ARGS;
+        npairs[p] = 0;
+        tabFloats += 2 * (size_t)q.nlevels2;
+        const orbfe_fv f2 = K2->fv();
+        bool bad = false;
+        for_each_shared_node(f1, f2, [&](int i, int j) {
+            const int off2 = f2.offsets[j], n2 = f2.offsets[j + 1] - off2;
+            if (n2 >= (1 << 20)) bad = true;
+            for (int k = f1.offsets[i]; k < f1.offsets[i + 1]; k++) {
+                const int idx1 = f1.indices[k];
+                if (K1->hMask[idx1]) continue;                             // :1279-1282
+                if (q.only_stereo && !(K1->hUR[idx1] >= 0)) continue;       // :1286-1288
+                if (n2 > 0) rows.push_back(TriRowB{idx1, off2, n2, p});
+            }
+        });
+        if (bad) return ORBFE_ERR_ARGS;
+    }
+    if (rows.empty()) return 0;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    TriRowB* dR;
+    TriProb *dP, *hP;
+    float *dTab, *hTab;
+    int32_t* dM;
+    if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
+    if ((r = s.reserve(&dTab, &hTab, tabFloats)) < 0) return r;
+    if ((r = s.reserve(&dP, &hP, (size_t)count)) < 0) return r;
+    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
+    size_t tOff = 0;
+    for (int p = 0; p < count; p++) {
+        const orbfe_keyframe* K2 = kf2[p];
+        const orbfe_tri_pair& q = pair[p];
+        TriProb& Q = hP[p];
+        Q.desc2 = K2->desc; Q.hasMP2 = K2->mask; Q.kp2 = K2->kp; Q.oct2 = K2->oct; Q.uR2 = K2->uR; Q.ind2 = K2->ind;
+        std::memcpy(hTab + tOff, q.scaleFactors2, (size_t)q.nlevels2 * sizeof(float));
+        std::memcpy(hTab + tOff + q.nlevels2, q.levelSigma2_2, (size_t)q.nlevels2 * sizeof(float));
+        Q.sf2 = dTab + tOff;
+        Q.sig2 = dTab + tOff + q.nlevels2;
+        tOff += 2 * (size_t)q.nlevels2;
+        std::memcpy(Q.F12, q.F12, sizeof Q.F12);
+        Q.epx = q.ep[0];
+        Q.epy = q.ep[1];
+        Q.onlyStereo = q.only_stereo;
+        Q.coarse = q.coarse;
+        Q.outBase = p * n1;
+        Q.pad = 0;
+    }
+    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
+    {
+        KernelTimer timer(s);
+        hipLaunchKernelGGL(k_search_tri_batch, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), dP,
+                           K1->desc, K1->kp, K1->uR, dM);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> m((size_t)count * n1);
+    INT_TRY(s.down(m.data(), dM, m.size() * sizeof(int32_t)));
+    INT_TRY(s.fetch());
+    std::vector<int8_t> bins(n1);
+    for (int p = 0; p < count; p++) {
+        int32_t* m12 = m.data() + (size_t)p * n1;
+        const orbfe_keyframe* K2 = kf2[p];
+        std::fill(bins.begin(), bins.end(), (int8_t)-1);
+        if (pair[p].check_orientation) {
+            for (int i = 0; i < n1; i++)
+                if (m12[i] >= 0) {
+                    float rot = K1->hAng[i] - K2->hAng[m12[i]];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    bins[i] = (int8_t)bin;
+                }
+        }
+        cull_by_rotation(m12, bins.data(), n1, pair[p].check_orientation != 0);
+        int np = 0;
+        for (int i = 0; i < n1; i++) { // :1441-1446
+            if (m12[i] < 0) continue;
+            pairs[p][2 * np] = i;
+            pairs[p][2 * np + 1] = m12[i];
+            np++;
+        }
+        npairs[p] = np;
+    }
+    return 0;
 }
 
 int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)

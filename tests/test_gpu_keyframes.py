@@ -1,0 +1,118 @@
+"""Resident keyframes (orbfe_keyframe_*, round 4): SearchByBoW with one or both sides in handles and SearchForTriangulation_ of one
+keyframe against many neighbours in one launch give exactly what the per-call forms give -- which the other matcher tests compare
+with the oracle -- and what the oracle gives directly."""
+import numpy as np
+import pytest
+
+import matcher_inputs as MI
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def _noisy_copy(d1, n2, seed, flip=12, frac=0.6):
+    """n2 descriptors of which `frac` are noisy copies of rows of d1 (returns d2 and, per row, its source row or -1)."""
+    rng = np.random.default_rng(seed)
+    d2 = rng.integers(0, 256, size=(n2, 32), dtype=np.uint8)
+    k = int(min(len(d1), n2) * frac)
+    src = rng.permutation(len(d1))[:k]
+    dst = rng.permutation(n2)[:k]
+    bits = np.unpackbits(d1[src], axis=1)
+    for r in range(k):
+        bits[r, rng.permutation(256)[: rng.integers(0, 2 * flip)]] ^= 1
+    d2[dst] = np.packbits(bits, axis=1)
+    origin = -np.ones(n2, np.int64)
+    origin[dst] = src
+    return d2, origin
+
+
+def test_bow_with_keyframe_handles(pkg, oracle):
+    from orb_slam3_detailed_comments_kor_amd import synth
+    rng = np.random.default_rng(5)
+    kfs, sets = [], []
+    dF = rng.integers(0, 256, size=(900, 32), dtype=np.uint8)
+    aF = rng.uniform(0, 360, 900).astype(np.float32)
+    fvF = synth.make_feature_vectors(dF, 300, 6, 2)  # one vocabulary (seed) for the frame and every keyframe
+    for k in range(6):  # six candidate keyframes, one current frame (relocalisation, src/Tracking.cc:3784)
+        d, origin = _noisy_copy(dF, 700 + 40 * k, 200 + k)
+        a = np.where(origin >= 0, aF[np.maximum(origin, 0)] + rng.normal(0, 4, len(d)), rng.uniform(0, 360, len(d))).astype(np.float32) % 360
+        fvK = synth.make_feature_vectors(d, 300, 6, 2)
+        mask = (rng.uniform(size=len(d)) < 0.7).astype(np.uint8)
+        sets.append((d, mask, a, fvK, fvF))
+        kfs.append(pkg.KeyFrameHandle(d, mask, a, fvK))
+    # variant 0 (KeyFrame*, Frame&): set 1 in a handle, the frame side passed per call
+    probs = [dict(kf1=kfs[k], desc2=dF, ang2=aF, fv2=sets[k][4], variant=0, nnratio=0.75, check_ori=True) for k in range(6)]
+    got = pkg.search_bow_keyframes(probs)
+    for k in range(6):
+        d, mask, a, fvK, fvF = sets[k]
+        rn, rm = oracle.search_bow_kf_f(d, mask, a, fvK, dF, aF, fvF, -1, 0.75, True)
+        assert got[k][0] == rn and np.array_equal(got[k][1], rm), k
+        n1, m1 = pkg.search_bow(d, mask, a, fvK, dF, None, aF, fvF, 0, 0.75, True)
+        assert n1 == rn and np.array_equal(m1, rm)
+    assert sum(g[0] for g in got) > 300
+    # the flags of a keyframe change as the map grows: set_mask, then the same search
+    mask2 = (rng.uniform(size=len(sets[2][0])) < 0.3).astype(np.uint8)
+    kfs[2].set_mask(mask2)
+    d, _, a, fvK, fvF = sets[2]
+    rn, rm = oracle.search_bow_kf_f(d, mask2, a, fvK, dF, aF, fvF, -1, 0.75, True)
+    n, m = pkg.search_bow_keyframes([probs[2]])[0]
+    assert n == rn and np.array_equal(m, rm)
+    # variant 1 (KeyFrame*, KeyFrame*): both sides in handles (loop closing); per-pair FeatureVectors are the handles' own
+    dA, mA, aA, fvA, _ = sets[0]
+    dB, mB, aB, _, _ = sets[1]
+    fvA2, fvB2 = MI.feature_vectors(dA, dB, 999)
+    hA = pkg.KeyFrameHandle(dA, mA, aA, fvA2)
+    hB = pkg.KeyFrameHandle(dB, mB, aB, fvB2)
+    rn, rm = oracle.search_bow_kf_kf(dA, mA, aA, fvA2, dB, mB, aB, fvB2, -1, -1, 0.8, True)
+    (n, m), (nh, mh) = pkg.search_bow_keyframes([dict(kf1=hA, kf2=hB, variant=1, nnratio=0.8, check_ori=True),
+                                                  dict(kf1=hA, desc2=dB, mask2=mB, ang2=aB, fv2=fvB2, variant=1, nnratio=0.8)])
+    assert n == rn and np.array_equal(m, rm) and nh == rn and np.array_equal(mh, rm)
+    for h in kfs + [hA, hB]:
+        h.close()
+
+
+def test_triangulation_search_against_many_neighbours(pkg, oracle):
+    from orb_slam3_detailed_comments_kor_amd import synth
+    I0 = MI.tri_inputs(1100, 900, 40)
+    rng = np.random.default_rng(77)
+    fv1 = synth.make_feature_vectors(I0["d1"], 41, 5, 2)  # (= I0["fv1"]: tri_inputs uses seed + 1, branching 5, depth 2)
+    assert all(np.array_equal(x, y) for x, y in zip(fv1, I0["fv1"]))
+    cur = pkg.KeyFrameHandle(I0["d1"], I0["has1"], I0["a1"], fv1, kp_xy=I0["kp1"], octave=I0["oct1"], uRight=I0["u1"])
+    neigh, want = [], []
+    for k in range(12):  # the current keyframe against 12 covisible keyframes (src/LocalMapping.cc:556-621)
+        n2 = 800 + 30 * k
+        d2, origin = _noisy_copy(I0["d1"], n2, 500 + k)
+        src = np.maximum(origin, 0)
+        kp2 = np.stack([rng.uniform(20, 730, n2), np.where(origin >= 0, I0["kp1"][src, 1] + rng.normal(0, 0.7, n2),
+                                                           rng.uniform(20, 460, n2))], 1).astype(np.float32)
+        a2 = np.where(origin >= 0, I0["a1"][src] + rng.normal(0, 3, n2), rng.uniform(0, 360, n2)).astype(np.float32) % 360
+        oct2 = rng.integers(0, 8, n2).astype(np.int32)
+        u2 = np.where(rng.uniform(size=n2) < 0.3, rng.uniform(0, 700, n2), -1).astype(np.float32)
+        has2 = (rng.uniform(size=n2) < 0.4).astype(np.uint8)
+        fv2 = synth.make_feature_vectors(d2, 41, 5, 2)  # the same vocabulary as the current keyframe's
+        flags = dict(only_stereo=(k % 5 == 4), coarse=(k % 4 == 3), check_ori=(k % 3 != 2))
+        h = pkg.KeyFrameHandle(d2, has2, a2, fv2, kp_xy=kp2, octave=oct2, uRight=u2)
+        F12 = I0["F12"] * np.float32(1.0 + 0.01 * k)
+        ep = (900.0 - 10 * k, 250.0)
+        neigh.append(dict(kf=h, F12=F12, ep=ep, sf=I0["sf"], sig=I0["sig"], **flags))
+        args = (I0["d1"], I0["has1"], I0["kp1"], I0["a1"], I0["oct1"], I0["u1"], fv1, d2, has2, kp2, a2, oct2, u2, fv2, F12, ep,
+                I0["sf"], I0["sig"], flags["only_stereo"], flags["coarse"], flags["check_ori"])
+        want.append(pkg.search_triangulation(*args))
+        assert np.array_equal(want[-1], oracle.search_triangulation(*args)), k
+    got = pkg.search_tri_batch(cur, neigh)
+    assert sum(len(g) for g in got) > 200
+    for k in range(12):
+        assert np.array_equal(got[k], want[k]), k
+    # a handle without keypoints cannot be a side of the triangulation search
+    bow_only = pkg.KeyFrameHandle(I0["d1"], I0["has1"], I0["a1"], I0["fv1"])
+    with pytest.raises(pkg.OrbfeError):
+        pkg.search_tri_batch(bow_only, neigh[:1])
+    bow_only.close()
+    cur.close()
+    for q in neigh:
+        q["kf"].close()
