@@ -72,11 +72,47 @@ __device__ __forceinline__ int hamming(const Desc& a, const Desc& b)
     return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) +
            __popcll(a.w[3] ^ b.w[3]);
 }
+// Wave-wide reductions without the LDS (round 4): four DPP exchange steps inside the 16-lane rows -- partners xor 1, xor 2
+// (quad permutes), 7 - i inside a group of 8 (row_half_mirror), 15 - i inside the row (row_mirror): at every step a lane
+// meets a lane of a DISJOINT group that already agrees on its partial result -- then the four row results are read with
+// v_readlane and merged on the scalar side.  A ds_bpermute round trip per step (what __shfl_xor compiles to) made the
+// sequential row loop of K-BOW latency-bound: ~24 dependent LDS round trips per row.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_xchg(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, false);
+}
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, off));
-    return v;
+    // (inline asm: left to itself the compiler emits a v_mov_b32_dpp and a v_min_u32 per step instead of the one
+    // v_min_u32_dpp; the s_nop keeps the hazard distance between a VALU write and a DPP read of the same register)
+    asm volatile("s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+// the two smallest keys of the wavefront (keys of different lanes are distinct, or the sentinel 0xFFFFFFFF): on return k0 <= k1
+// hold them in every lane.  Groups that meet are disjoint, so no key is counted twice.
+__device__ __forceinline__ void two_min_merge(unsigned& k0, unsigned& k1, unsigned o0, unsigned o1)
+{
+    const unsigned lo = min(k0, o0), hi = max(k0, o0);
+    k1 = min(hi, min(k1, o1));
+    k0 = lo;
+}
+__device__ __forceinline__ void wave_two_min(unsigned& k0, unsigned& k1)
+{
+    // as two plain minima (v_min_u32 with a DPP operand: four instructions each): the smallest key, then the smallest of
+    // what is left when the lane that holds it puts its second key forward -- a third of the merge form's dependent chain,
+    // which is what a row of K-BOW costs when its wavefront has the SIMD to itself
+    const unsigned g0 = wave_min_u32(k0);
+    const unsigned g1 = wave_min_u32(k0 == g0 ? k1 : k0);
+    k0 = g0;
+    k1 = g1;
 }
 
 // ------------------------------------------------------------------ K-HAM
@@ -265,14 +301,15 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
     if (nd >= nNodes) return;
     const BowNode N = nodes[nd];
     const BowProb Pb = probs[N.prob];
+    // (array by array: a set whose descriptors alone are resident -- an extractor's output slab -- pools the rest)
     const uint8_t* desc1 = Pb.rDesc1 ? Pb.rDesc1 : descPool + (size_t)Pb.d1Base * 32;
     const uint8_t* desc2 = Pb.rDesc2 ? Pb.rDesc2 : descPool + (size_t)Pb.d2Base * 32;
-    const uint8_t* mask1 = Pb.rDesc1 ? Pb.rMask1 : maskPool + Pb.d1Base;
-    const uint8_t* mask2 = Pb.rDesc2 ? Pb.rMask2 : maskPool + Pb.d2Base;
-    const float* ang1 = Pb.rDesc1 ? Pb.rAng1 : angPool + Pb.d1Base;
-    const float* ang2 = Pb.rDesc2 ? Pb.rAng2 : angPool + Pb.d2Base;
-    const int32_t* ind1 = Pb.rDesc1 ? Pb.rInd1 : indPool; // node offsets of a pooled set are already pooled
-    const int32_t* ind2 = Pb.rDesc2 ? Pb.rInd2 : indPool;
+    const uint8_t* mask1 = Pb.rMask1 ? Pb.rMask1 : maskPool + Pb.d1Base;
+    const uint8_t* mask2 = Pb.rMask2 ? Pb.rMask2 : maskPool + Pb.d2Base;
+    const float* ang1 = Pb.rAng1 ? Pb.rAng1 : angPool + Pb.d1Base;
+    const float* ang2 = Pb.rAng2 ? Pb.rAng2 : angPool + Pb.d2Base;
+    const int32_t* ind1 = Pb.rInd1 ? Pb.rInd1 : indPool; // node offsets of a pooled set are already pooled
+    const int32_t* ind2 = Pb.rInd2 ? Pb.rInd2 : indPool;
     int32_t* match = matchPool + Pb.outBase;
     int8_t* bins = binsPool + Pb.outBase;
     uint8_t* taken2 = takenPool + Pb.tBase;
@@ -289,22 +326,27 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
     int rIdx = 0, cIdx = 0;
     bool rOk = false, cOk = false;
     Desc rD = {}, cD = {};
+    float rAng = 0.f, cAng = 0.f; // (round 4: the angles too, so that accepting a match needs no load behind the reduction)
     if (lane < N.n1) {
         rIdx = ind1[N.off1 + lane];
         rOk = !(variant == 1 && limit1 != -1 && rIdx >= limit1) && mask1[rIdx] != 0;
         rD = load_desc(desc1 + (size_t)rIdx * 32);
+        rAng = ang1[rIdx];
     }
     if (lane < N.n2) {
         cIdx = ind2[N.off2 + lane];
         cOk = variant != 1 || (!(limit2 != -1 && cIdx >= limit2) && mask2[cIdx] != 0);
         cD = load_desc(desc2 + (size_t)cIdx * 32);
+        cAng = ang2[cIdx];
     }
     for (int r = 0; r < N.n1; r++) {
         int idx1;
+        float a1;
         Desc d1;
         if (r < 64) { // (uniform)
             if (!__builtin_amdgcn_readlane((int)rOk, r)) continue;
             idx1 = __builtin_amdgcn_readlane(rIdx, r);
+            a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rAng), r));
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] & 0xFFFFFFFFull), r);
@@ -316,6 +358,7 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
             if (variant == 1 && limit1 != -1 && idx1 >= limit1) continue;
             if (!mask1[idx1]) continue;
             d1 = load_desc(desc1 + (size_t)idx1 * 32);
+            a1 = ang1[idx1];
         }
         // key = dist<<20 | position in the node's list (iteration order breaks ties)
         unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
@@ -342,48 +385,40 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
                     r1 = key;
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            unsigned o0 = (unsigned)__shfl_xor((int)k0, off), o1 = (unsigned)__shfl_xor((int)k1, off);
-            unsigned lo = min(k0, o0), hi = max(k0, o0);
-            k1 = min(hi, min(k1, o1));
-            k0 = lo;
-            o0 = (unsigned)__shfl_xor((int)r0, off);
-            o1 = (unsigned)__shfl_xor((int)r1, off);
-            lo = min(r0, o0);
-            hi = max(r0, o0);
-            r1 = min(hi, min(r1, o1));
-            r0 = lo;
-        }
+        wave_two_min(k0, k1);
+        if (variant == 0 && Nleft != -1) wave_two_min(r0, r1); // (right-camera candidates only exist for a two-camera frame)
         // acceptance (wave-uniform values; lane 0 writes)
         const int bestDist1 = k0 == 0xFFFFFFFFu ? 256 : (int)(k0 >> 20);
         const int bestDist2 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 20);
         const int bestDist1R = r0 == 0xFFFFFFFFu ? 256 : (int)(r0 >> 20);
         const bool passTh = variant == 0 ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW); // :373 vs :906
         if (passTh) {
+            // (a winner among the node's first 64 candidates is described by registers of lane cpos)
             if ((float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
                 const int cpos = (int)(k0 & 0xFFFFF);
-                const int idx2 = ind2[N.off2 + cpos];
+                const int idx2 = cpos < 64 ? __builtin_amdgcn_readlane(cIdx, cpos) : ind2[N.off2 + cpos];
+                const float a2 = cpos < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cAng), cpos)) : ang2[idx2];
                 if ((cpos & 63) == lane && (cpos >> 6) < 64) takenMask |= 1ull << (cpos >> 6);
                 if (lane == 0) {
                     if ((cpos >> 6) >= 64) taken2[idx2] = 1;
                     if (variant == 0) {
                         match[idx2] = idx1;
-                        bins[idx2] = (int8_t)rot_bin(ang1[idx1], ang2[idx2]);
+                        bins[idx2] = (int8_t)rot_bin(a1, a2);
                     } else {
                         match[idx1] = idx2;
-                        bins[idx1] = (int8_t)rot_bin(ang1[idx1], ang2[idx2]);
+                        bins[idx1] = (int8_t)rot_bin(a1, a2);
                     }
                 }
             }
             if (variant == 0 && bestDist1R <= TH_LOW) { // ratio test is "|| true" in the reference (:405)
                 const int cpos = (int)(r0 & 0xFFFFF);
-                const int idx2 = ind2[N.off2 + cpos];
+                const int idx2 = cpos < 64 ? __builtin_amdgcn_readlane(cIdx, cpos) : ind2[N.off2 + cpos];
+                const float a2 = cpos < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cAng), cpos)) : ang2[idx2];
                 if ((cpos & 63) == lane && (cpos >> 6) < 64) takenMask |= 1ull << (cpos >> 6);
                 if (lane == 0) {
                     if ((cpos >> 6) >= 64) taken2[idx2] = 1;
                     match[idx2] = idx1;
-                    bins[idx2] = (int8_t)rot_bin(ang1[idx1], ang2[idx2]);
+                    bins[idx2] = (int8_t)rot_bin(a1, a2);
                 }
             }
         }
@@ -1270,6 +1305,7 @@ struct Arena {
     uint8_t* base = nullptr;
     uint8_t* pin = nullptr; // pinned host mirror of the arena: inputs are staged here and go up in ONE transfer,
                             // outputs come down into it in ONE transfer
+    uint8_t* pinDev = nullptr; // the address a KERNEL uses for `pin` (results written into the mirror by the kernel itself)
     size_t cap = 0, off = 0, want = 0;
     // The calling thread's own non-blocking stream on this device: matcher calls of the Tracking, LocalMapping and
     // LoopClosing threads neither serialise with each other nor synchronise with the legacy null stream (and through
@@ -1319,8 +1355,13 @@ struct Scratch { // device allocations of one call
                 ar->base = (uint8_t*)p;
                 ar->cap = want;
                 void* h = nullptr;
-                if (hipHostMalloc(&h, want) == hipSuccess) ar->pin = (uint8_t*)h;
-                else (void)hipGetLastError();
+                ar->pinDev = nullptr;
+                if (hipHostMalloc(&h, want) == hipSuccess) {
+                    ar->pin = (uint8_t*)h;
+                    void* dv = nullptr;
+                    if (hipHostGetDevicePointer(&dv, h, 0) == hipSuccess) ar->pinDev = (uint8_t*)dv;
+                    else (void)hipGetLastError();
+                } else (void)hipGetLastError();
             }
         }
         ar->off = 0;
@@ -1398,6 +1439,24 @@ struct Scratch { // device allocations of one call
         lateUps.push_back(LateUp{p, temps.size() - 1, bytes});
         *dev = (T*)p;
         *stage = (T*)temps.back().data();
+        return 0;
+    }
+    // Small results the KERNEL writes straight into the pinned mirror (posted writes over PCIe): no download command at
+    // the end of the call, the caller reads *host after the stream synchronisation.  *dev is the kernel's address of that
+    // host memory; the caller pre-fills *host (e.g. with -1) before the launch.  Fails (returns 1) when the arena has no
+    // mirror or no room: the caller then takes the download path.
+    template <class T>
+    int mirror_out(T** dev, T** host, size_t n)
+    {
+        *dev = nullptr;
+        *host = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        ar->want += bytes;
+        if (!(ar->base && ar->pin && ar->pinDev && ar->off + bytes <= ar->cap)) return 1;
+        const size_t at = ar->off;
+        ar->off += bytes;
+        *dev = (T*)(ar->pinDev + at);
+        *host = (T*)(ar->pin + at);
         return 0;
     }
     // Descriptor arrays may already live on the device (an extractor's resident output slab, a gathered slab):
@@ -1782,12 +1841,14 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         if (K1) {
             P.rDesc1 = K1->desc; P.rMask1 = K1->mask; P.rAng1 = K1->ang; P.rInd1 = K1->ind;
         } else {
+            if (is_device_ptr(a->desc1)) P.rDesc1 = a->desc1; // read where the extractor left them
             i1Base[p] = (int)indTotal;
             indTotal += (size_t)(a->fv1.nn ? a->fv1.offsets[a->fv1.nn] : 0);
         }
         if (K2) {
             P.rDesc2 = K2->desc; P.rMask2 = K2->mask; P.rAng2 = K2->ang; P.rInd2 = K2->ind;
         } else {
+            if (is_device_ptr(a->desc2)) P.rDesc2 = a->desc2;
             i2Base[p] = (int)indTotal;
             indTotal += (size_t)(a->fv2.nn ? a->fv2.offsets[a->fv2.nn] : 0);
         }
@@ -1807,6 +1868,8 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         rows += (K1 ? 0 : a->n1) + (K2 ? 0 : a->n2);
     }
     if (nodes.empty()) return 0;
+    bool needTaken = false; // the "taken" flags in memory are only touched by nodes with more than 4096 candidates
+    for (const BowNode& nd : nodes) needTaken = needTaken || nd.n2 > 4096;
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
@@ -1822,8 +1885,18 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     if ((r = s.reserve(&dMask, &hMask, (size_t)rows)) < 0) return r;
     if ((r = s.reserve(&dAng, &hAng, (size_t)rows)) < 0) return r;
     if ((r = s.reserve(&dInd, &hInd, indTotal)) < 0) return r;
-    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
-    if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
+    // results: written by the kernel into the pinned mirror when they are small (no download command), else downloaded
+    int32_t* hM = nullptr;
+    int8_t* hB = nullptr;
+    const bool mirrored = (size_t)outTotal * 5 <= (256u << 10) && s.mirror_out(&dM, &hM, (size_t)outTotal) == 0 &&
+                          s.mirror_out(&dB, &hB, (size_t)outTotal) == 0;
+    if (mirrored) {
+        std::memset(hM, 0xFF, (size_t)outTotal * sizeof(int32_t));
+        std::memset(hB, 0xFF, (size_t)outTotal);
+    } else {
+        if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
+        if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
+    }
     if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)takenRows)) < 0) return r;
     // pass 2: every problem's arrays go straight into the pinned mirror of the pools (one copy, no intermediate
     // vectors); descriptor sets that already live on the device are copied device-to-device after the upload; sets in
@@ -1837,23 +1910,19 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     for (int p = 0; p < count; p++) {
         if (!active[p]) continue;
         const orbfe_bow_args* a = &eff[p];
-        const bool R1 = probs[p].rDesc1 != nullptr, R2 = probs[p].rDesc2 != nullptr;
+        const bool R1 = probs[p].rInd1 != nullptr, R2 = probs[p].rInd2 != nullptr; // the whole set lives in a handle
         const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
         if (!R1) {
-            if (is_device_ptr(a->desc1)) {
-                (void)orbfe_producer_wait(a->desc1, g_ms);
-                d2d.push_back(D2D{r1 * 32, a->desc1, (size_t)a->n1 * 32});
-            } else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
+            if (is_device_ptr(a->desc1)) (void)orbfe_producer_wait(a->desc1, g_ms); // (read in place: BowProb::rDesc1)
+            else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
             std::memcpy(hMask + r1, a->mask1, (size_t)a->n1);
             if (a->angle1) std::memcpy(hAng + r1, a->angle1, (size_t)a->n1 * sizeof(float));
             else std::memset(hAng + r1, 0, (size_t)a->n1 * sizeof(float));
             if (a->fv1.nn) std::memcpy(hInd + i1Base[p], a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn] * sizeof(int32_t));
         }
         if (!R2) {
-            if (is_device_ptr(a->desc2)) {
-                (void)orbfe_producer_wait(a->desc2, g_ms);
-                d2d.push_back(D2D{r2 * 32, a->desc2, (size_t)a->n2 * 32});
-            } else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
+            if (is_device_ptr(a->desc2)) (void)orbfe_producer_wait(a->desc2, g_ms);
+            else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
             if (a->variant == 1) std::memcpy(hMask + r2, a->mask2, (size_t)a->n2);
             else std::memset(hMask + r2, 1, (size_t)a->n2);
             if (a->angle2) std::memcpy(hAng + r2, a->angle2, (size_t)a->n2 * sizeof(float));
@@ -1861,25 +1930,39 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             if (a->fv2.nn) std::memcpy(hInd + i2Base[p], a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn] * sizeof(int32_t));
         }
     }
-    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), g_ms));
-    HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
-    HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
+    if (!mirrored) {
+        HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), g_ms));
+        HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
+    }
+    if (needTaken) HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
     {
-        KernelTimer timer(s); // (sends the staged pools; the device-resident sets then overwrite their places)
+        KernelTimer timer(s); // (sends the staged pools)
         for (const D2D& c : d2d)
             HIP_TRY(hipMemcpyAsync(dDesc + c.off, c.src, c.bytes, hipMemcpyDeviceToDevice, g_ms));
         hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, g_ms, dN, (int)nodes.size(),
                            dP, dDesc, dMask, dAng, dInd, dM, dB, taken);
     }
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> m(outTotal);
-    std::vector<int8_t> bins(outTotal);
-    INT_TRY(s.down(m.data(), dM, (size_t)outTotal * sizeof(int32_t)));
-    INT_TRY(s.down(bins.data(), dB, (size_t)outTotal));
-    INT_TRY(s.fetch());
+    std::vector<int32_t> m;
+    std::vector<int8_t> bins;
+    const int32_t* pm;
+    const int8_t* pb;
+    if (mirrored) { // the kernel has written the pinned mirror: wait, read
+        HIP_TRY(hipStreamSynchronize(g_ms));
+        pm = hM;
+        pb = hB;
+    } else {
+        m.resize(outTotal);
+        bins.resize(outTotal);
+        INT_TRY(s.down(m.data(), dM, (size_t)outTotal * sizeof(int32_t)));
+        INT_TRY(s.down(bins.data(), dB, (size_t)outTotal));
+        INT_TRY(s.fetch());
+        pm = m.data();
+        pb = bins.data();
+    }
     for (int p = 0; p < count; p++) {
-        std::memcpy(match[p], m.data() + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
-        nmatches[p] = cull_by_rotation(match[p], bins.data() + probs[p].outBase, outN[p], args[p].check_orientation != 0);
+        std::memcpy(match[p], pm + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
+        nmatches[p] = cull_by_rotation(match[p], pb + probs[p].outBase, outN[p], args[p].check_orientation != 0);
     }
     return 0;
 }
@@ -2040,7 +2123,10 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, int count, orbfe_keyframe* const*
     if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
     if ((r = s.reserve(&dTab, &hTab, tabFloats)) < 0) return r;
     if ((r = s.reserve(&dP, &hP, (size_t)count)) < 0) return r;
-    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
+    int32_t* hMir = nullptr;
+    const bool mirrored = (size_t)count * n1 * 4 <= (256u << 10) && s.mirror_out(&dM, &hMir, (size_t)count * n1) == 0;
+    if (mirrored) std::memset(hMir, 0xFF, (size_t)count * n1 * sizeof(int32_t));
+    else if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
     size_t tOff = 0;
     for (int p = 0; p < count; p++) {
         const orbfe_keyframe* K2 = kf2[p];
@@ -2060,19 +2146,27 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, int count, orbfe_keyframe* const*
         Q.outBase = p * n1;
         Q.pad = 0;
     }
-    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
+    if (!mirrored) HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri_batch, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), dP,
                            K1->desc, K1->kp, K1->uR, dM);
     }
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> m((size_t)count * n1);
-    INT_TRY(s.down(m.data(), dM, m.size() * sizeof(int32_t)));
-    INT_TRY(s.fetch());
+    std::vector<int32_t> m;
+    int32_t* mAll;
+    if (mirrored) {
+        HIP_TRY(hipStreamSynchronize(g_ms));
+        mAll = hMir;
+    } else {
+        m.resize((size_t)count * n1);
+        INT_TRY(s.down(m.data(), dM, m.size() * sizeof(int32_t)));
+        INT_TRY(s.fetch());
+        mAll = m.data();
+    }
     std::vector<int8_t> bins(n1);
     for (int p = 0; p < count; p++) {
-        int32_t* m12 = m.data() + (size_t)p * n1;
+        int32_t* m12 = mAll + (size_t)p * n1;
         const orbfe_keyframe* K2 = kf2[p];
         std::fill(bins.begin(), bins.end(), (int8_t)-1);
         if (pair[p].check_orientation) {

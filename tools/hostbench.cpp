@@ -3,7 +3,7 @@
 // orbfe_extract* including H2D of the images and D2H of keypoints + descriptors).  bench.py runs this program as
 // a child process and embeds its one JSON line as the `pcie_inclusive` object; it is never bench.py's `value`.
 //
-//   hostbench <frames.raw> rows cols nframes nfeatures [device]
+//   hostbench <frames.raw> rows cols nframes nfeatures [device] [first | c5 | matcher]
 //
 // frames.raw = nframes images of rows x cols bytes (bench.py writes its synthetic frames there).
 //   single_pageable / single_pinned : orbfe_extract, one frame per call (mono protocol, reference src/Frame.cc:306)
@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <functional>
 #include <vector>
 
 #include "../include/orbfe.h"
@@ -51,6 +52,408 @@ static Stat stat_of(std::vector<double>& v)
         }                                                                    \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Mode "c5" (BASELINE configs[4]): a fisheye stereo frame -- two 1024 x 1024 images, nFeatures 1500, KannalaBrandt8
+// bearing rays fused into the extractor (orbfe_set_kb8), both images in the lapping area, then
+// Frame::ComputeStereoFishEyeMatches (knn-2 brute force + ratio test + triangulation, orbfe_stereo_fisheye_matches).
+// Two protocols per pair, like the rectified leg: the reference's (two extractors, two threads started per frame,
+// src/Frame.cc:119-122 of the stereo-fisheye constructor) and one batched call on one context.
+static int run_c5(const std::vector<uint8_t>& frames, int rows, int cols, int B, int nF, int dev)
+{
+    const size_t imgBytes = (size_t)rows * cols;
+    // TUM-VI 512 parameters (Examples/Stereo-Inertial/TUM_512.yaml) scaled to the image size
+    const float sc = (float)cols / 512.f;
+    const float P[8] = {190.978477f * sc, 190.973307f * sc, 254.931706f * sc, 256.897442f * sc, 0.003482389f, 0.000715034f,
+                        -0.002053236f, 0.000202937f};
+    const float Rlr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tlr[3] = {0.101f, 0.0f, 0.0f}; // (a 10-cm rectified-like baseline)
+    orbfe_ctx *exL = nullptr, *exR = nullptr;
+    CHECK(orbfe_create(&exL, nF, 1.2f, 8, 20, 7, dev));
+    CHECK(orbfe_create(&exR, nF, 1.2f, 8, 20, 7, dev));
+    CHECK(orbfe_set_kb8(exL, P));
+    CHECK(orbfe_set_kb8(exR, P));
+    const int cap = orbfe_max_keypoints(exL, rows, cols);
+    CHECK(cap);
+    std::vector<float> sigma2(8);
+    orbfe_get_scale_tables(exL, nullptr, nullptr, sigma2.data(), nullptr);
+    std::vector<uint8_t> right(imgBytes * B);
+    const int shift = 40;
+    for (int i = 0; i < B; i++)
+        for (int y = 0; y < rows; y++) {
+            const uint8_t* s = frames.data() + imgBytes * i + (size_t)y * cols;
+            uint8_t* d = right.data() + imgBytes * i + (size_t)y * cols;
+            memcpy(d, s + shift, cols - shift);
+            memcpy(d + cols - shift, s, shift);
+        }
+    std::vector<orbfe_kp> kps((size_t)2 * cap);
+    std::vector<uint8_t> desc((size_t)2 * cap * 32);
+    std::vector<float> xyL((size_t)2 * cap), xyR((size_t)2 * cap), depth(cap), p3d((size_t)3 * cap);
+    std::vector<int32_t> octL(cap), octR(cap), l2r(cap), r2l(cap);
+    const int lapX0 = 0, lapX1 = cols - 1; // everything lies in the lapping area (the usual TUM-VI setting is a sub-range)
+    auto match = [&](const orbfe_kp* kL, const uint8_t* dL, int nL, int monoL, const orbfe_kp* kR, const uint8_t* dR, int nR,
+                     int monoR) -> int {
+        const int sL = nL - monoL, sR = nR - monoR;
+        for (int i = 0; i < sL; i++) {
+            xyL[2 * i] = kL[monoL + i].x;
+            xyL[2 * i + 1] = kL[monoL + i].y;
+            octL[i] = kL[monoL + i].octave;
+        }
+        for (int i = 0; i < sR; i++) {
+            xyR[2 * i] = kR[monoR + i].x;
+            xyR[2 * i + 1] = kR[monoR + i].y;
+            octR[i] = kR[monoR + i].octave;
+        }
+        return orbfe_stereo_fisheye_matches(dev, dL + (size_t)monoL * 32, xyL.data(), octL.data(), sL, dR + (size_t)monoR * 32,
+                                            xyR.data(), octR.data(), sR, P, P, Rlr, tlr, sigma2.data(), 8, l2r.data(), r2l.data(),
+                                            depth.data(), p3d.data());
+    };
+    const int nPairs = 120;
+    std::vector<double> lat2, latE2, lat1, latE1;
+    double matches = 0;
+    long kpTotal = 0;
+    for (int r = -8; r < nPairs; r++) { // (a) two contexts, two threads per frame
+        const int i = (r + 8) % B;
+        int nL = 0, nR = 0, rcL = 0, rcR = 0;
+        const double a = now_s();
+        std::thread tl([&] { rcL = orbfe_extract(exL, frames.data() + imgBytes * i, rows, cols, cols, lapX0, lapX1, kps.data(), desc.data(), cap, &nL); });
+        std::thread tr([&] { rcR = orbfe_extract(exR, right.data() + imgBytes * i, rows, cols, cols, lapX0, lapX1, kps.data() + cap, desc.data() + (size_t)cap * 32, cap, &nR); });
+        tl.join();
+        tr.join();
+        const double b = now_s();
+        if (rcL < 0 || rcR < 0) return 2;
+        const int m = match(kps.data(), desc.data(), nL, rcL, kps.data() + cap, desc.data() + (size_t)cap * 32, nR, rcR);
+        CHECK(m);
+        if (r >= 0) {
+            lat2.push_back(now_s() - a);
+            latE2.push_back(b - a);
+            matches += m;
+            kpTotal += nL + nR;
+        }
+    }
+    for (int r = -8; r < nPairs; r++) { // (b) one context, both images in one batched call
+        const int i = (r + 8) % B;
+        const uint8_t* two[2] = {frames.data() + imgBytes * i, right.data() + imgBytes * i};
+        const int lap4[4] = {lapX0, lapX1, lapX0, lapX1};
+        int n2[2] = {0, 0}, mono2[2] = {0, 0};
+        const double a = now_s();
+        CHECK(orbfe_extract_batch(exL, 2, two, rows, cols, cols, lap4, kps.data(), desc.data(), cap, n2, mono2));
+        const double b = now_s();
+        const int m = match(kps.data(), desc.data(), n2[0], mono2[0], kps.data() + cap, desc.data() + (size_t)cap * 32, n2[1], mono2[1]);
+        CHECK(m);
+        if (r >= 0) {
+            lat1.push_back(now_s() - a);
+            latE1.push_back(b - a);
+        }
+    }
+    const Stat s2 = stat_of(lat2), e2 = stat_of(latE2), s1 = stat_of(lat1), e1 = stat_of(latE1);
+    printf("{\"config\": \"c5\", \"frame\": \"%dx%d\", \"nfeatures\": %d, \"pairs\": %d, \"keypoints_per_pair\": %.1f, "
+           "\"matches_per_pair\": %.1f, "
+           "\"two_threads\": {\"protocol\": \"2 contexts with orbfe_set_kb8, 2 threads started per frame, pageable images, then "
+           "orbfe_stereo_fisheye_matches on host arrays\", \"ms_per_pair_mean\": %.4f, \"ms_per_pair_p50\": %.4f, "
+           "\"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f, \"keypoints_per_s\": %.0f}, "
+           "\"one_call\": {\"protocol\": \"1 context, both images in one orbfe_extract_batch, then orbfe_stereo_fisheye_matches\", "
+           "\"ms_per_pair_mean\": %.4f, \"ms_per_pair_p50\": %.4f, \"ms_per_pair_p99\": %.4f, \"extract_ms_p50\": %.4f, "
+           "\"keypoints_per_s\": %.0f}}\n",
+           cols, rows, nF, nPairs, (double)kpTotal / nPairs, matches / nPairs, 1e3 * s2.mean, 1e3 * s2.p50, 1e3 * s2.p99,
+           1e3 * e2.p50, kpTotal / (s2.mean * nPairs), 1e3 * s1.mean, 1e3 * s1.p50, 1e3 * s1.p99, 1e3 * e1.p50,
+           kpTotal / (s1.mean * nPairs));
+    orbfe_destroy(exL);
+    orbfe_destroy(exR);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mode "matcher" (VERDICT r03 #5a): the matcher entry points from C++, so that the cost of a call is not mixed with
+// ctypes marshalling.  Inputs are real: two frames are extracted (frame B = frame A shifted by 7 px), FeatureVectors are the
+// nearest of 100 random 256-bit centroids.  For every call: p50 / p99 of the wall time with host arrays, with the
+// descriptors left on the device by the extractor (device pointers), and with the keyframe side in a handle.
+struct HostFv {
+    std::vector<uint32_t> ids;
+    std::vector<int32_t> off, ind;
+    orbfe_fv view() const { return orbfe_fv{(int)ids.size(), ids.data(), off.data(), ind.data()}; }
+};
+static HostFv make_fv(const uint8_t* desc, int n, const std::vector<uint8_t>& cent, int ncent)
+{
+    std::vector<int> node(n);
+    for (int i = 0; i < n; i++) {
+        int best = 0, bd = 1 << 30;
+        for (int c = 0; c < ncent; c++) {
+            int d = 0;
+            for (int w = 0; w < 4; w++) {
+                unsigned long long a, b;
+                memcpy(&a, desc + (size_t)i * 32 + 8 * w, 8);
+                memcpy(&b, cent.data() + (size_t)c * 32 + 8 * w, 8);
+                d += __builtin_popcountll(a ^ b);
+            }
+            if (d < bd) {
+                bd = d;
+                best = c;
+            }
+        }
+        node[i] = best;
+    }
+    HostFv f;
+    f.off.push_back(0);
+    for (int c = 0; c < ncent; c++) {
+        size_t before = f.ind.size();
+        for (int i = 0; i < n; i++)
+            if (node[i] == c) f.ind.push_back(i);
+        if (f.ind.size() > before) {
+            f.ids.push_back((uint32_t)c);
+            f.off.push_back((int32_t)f.ind.size());
+        }
+    }
+    return f;
+}
+template <class F>
+static int timeit(const char* name, int reps, F body, std::string& out)
+{
+    std::vector<double> lat;
+    for (int r = -10; r < reps; r++) {
+        const double a = now_s();
+        const long rc = (long)body();
+        if (rc < 0) {
+            fprintf(stderr, "hostbench: %s failed: %ld\n", name, rc);
+            return 2;
+        }
+        if (r >= 0) lat.push_back(now_s() - a);
+    }
+    const Stat s = stat_of(lat);
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_p50\": %.4f, \"ms_p99\": %.4f, \"ms_mean\": %.4f}", out.empty() ? "" : ", ", name,
+             1e3 * s.p50, 1e3 * s.p99, 1e3 * s.mean);
+    out += buf;
+    return 0;
+}
+static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, int B, int nF, int dev)
+{
+    const size_t imgBytes = (size_t)rows * cols;
+    orbfe_ctx *exA = nullptr, *exB = nullptr;
+    CHECK(orbfe_create(&exA, nF, 1.2f, 8, 20, 7, dev));
+    CHECK(orbfe_create(&exB, nF, 1.2f, 8, 20, 7, dev));
+    const int cap = orbfe_max_keypoints(exA, rows, cols);
+    CHECK(cap);
+    std::vector<uint8_t> imgB(imgBytes);
+    for (int y = 0; y < rows; y++) {
+        memcpy(imgB.data() + (size_t)y * cols, frames.data() + (size_t)y * cols + 7, cols - 7);
+        memcpy(imgB.data() + (size_t)y * cols + cols - 7, frames.data() + (size_t)y * cols, 7);
+    }
+    std::vector<orbfe_kp> kA(cap), kB(cap);
+    std::vector<uint8_t> dA((size_t)cap * 32), dB((size_t)cap * 32);
+    int nA = 0, nB = 0;
+    CHECK(orbfe_extract(exA, frames.data(), rows, cols, cols, 0, 0, kA.data(), dA.data(), cap, &nA) + 1);
+    CHECK(orbfe_extract(exB, imgB.data(), rows, cols, cols, 0, 0, kB.data(), dB.data(), cap, &nB) + 1);
+    const orbfe_kp *dkA, *dkB;
+    const uint8_t *ddA, *ddB;
+    CHECK(orbfe_get_device_outputs(exA, &dkA, &ddA, nullptr, nullptr, nullptr));
+    CHECK(orbfe_get_device_outputs(exB, &dkB, &ddB, nullptr, nullptr, nullptr));
+    CHECK(orbfe_sync(exA));
+    CHECK(orbfe_sync(exB));
+    // FeatureVectors over one "vocabulary" of 100 centroids.  The centroids are descriptors of frame A picked at a fixed
+    // stride (a vocabulary is trained on ORB descriptors; uniformly random 256-bit strings are not descriptor-like and send
+    // most features to a handful of nodes, which turns the node-sequential kernel into one long row loop)
+    std::vector<uint8_t> cent(100 * 32);
+    unsigned long long lcg = 88172645463325252ull;
+    for (int c = 0; c < 100; c++) memcpy(cent.data() + (size_t)c * 32, dA.data() + (size_t)((c * 977) % nA) * 32, 32);
+    const HostFv fA = make_fv(dA.data(), nA, cent, 100), fB = make_fv(dB.data(), nB, cent, 100);
+    std::vector<uint8_t> maskA(nA), maskB(nB), hasA(nA), hasB(nB);
+    std::vector<float> angA(nA), angB(nB), xyA((size_t)2 * nA), xyB((size_t)2 * nB), uA(nA, -1.f), uB(nB, -1.f);
+    std::vector<int32_t> octA(nA), octB(nB);
+    for (int i = 0; i < nA; i++) {
+        maskA[i] = (i % 10) < 7;
+        hasA[i] = (i % 10) < 4;
+        angA[i] = kA[i].angle;
+        xyA[2 * i] = kA[i].x;
+        xyA[2 * i + 1] = kA[i].y;
+        octA[i] = kA[i].octave;
+        if (i % 3 == 0) uA[i] = kA[i].x - 20.f;
+    }
+    for (int i = 0; i < nB; i++) {
+        maskB[i] = (i % 10) < 7;
+        hasB[i] = (i % 10) < 4;
+        angB[i] = kB[i].angle;
+        xyB[2 * i] = kB[i].x;
+        xyB[2 * i + 1] = kB[i].y;
+        octB[i] = kB[i].octave;
+        if (i % 3 == 0) uB[i] = kB[i].x - 20.f;
+    }
+    float sf[8], sig[8];
+    orbfe_get_scale_tables(exA, sf, nullptr, sig, nullptr);
+    int maxNodeA = 0, maxNodeB = 0;
+    for (size_t i = 0; i + 1 < fA.off.size(); i++) maxNodeA = std::max(maxNodeA, fA.off[i + 1] - fA.off[i]);
+    for (size_t i = 0; i + 1 < fB.off.size(); i++) maxNodeB = std::max(maxNodeB, fB.off[i + 1] - fB.off[i]);
+    std::string out;
+    std::vector<int32_t> match((size_t)std::max(nA, nB));
+    // ---- SearchByBoW(KeyFrame*, Frame&): keyframe = A, frame = B
+    orbfe_bow_args bow{};
+    bow.desc1 = dA.data(); bow.n1 = nA; bow.mask1 = maskA.data(); bow.angle1 = angA.data(); bow.fv1 = fA.view(); bow.limit1 = -1;
+    bow.desc2 = dB.data(); bow.n2 = nB; bow.mask2 = nullptr; bow.angle2 = angB.data(); bow.fv2 = fB.view(); bow.limit2 = -1;
+    bow.Nleft = -1; bow.nnratio = 0.7f; bow.check_orientation = 1; bow.variant = 0;
+    int nmHost = 0, nmDev = 0, nmKf = 0;
+    if (timeit("search_bow_host_arrays", 300, [&] { return nmHost = orbfe_search_bow(dev, &bow, match.data()); }, out)) return 2;
+    orbfe_bow_args bowDev = bow;
+    bowDev.desc1 = ddA;
+    bowDev.desc2 = ddB;
+    if (timeit("search_bow_device_descriptors", 300, [&] { return nmDev = orbfe_search_bow(dev, &bowDev, match.data()); }, out)) return 2;
+    orbfe_keyframe_args ka{};
+    ka.desc = ddA; ka.n = nA; ka.mask = maskA.data(); ka.angle = angA.data(); ka.kp_xy = xyA.data(); ka.octave = octA.data();
+    ka.uRight = uA.data(); ka.fv = fA.view();
+    orbfe_keyframe* kfA = nullptr;
+    CHECK(orbfe_keyframe_create(&kfA, dev, &ka));
+    orbfe_keyframe* kf1[1] = {kfA};
+    int32_t* mp[1] = {match.data()};
+    if (timeit("search_bow_keyframe_handle", 300, [&] { int nm = 0; const int r = orbfe_search_bow_keyframes(dev, 1, kf1, nullptr, &bowDev, mp, &nm); nmKf = nm; return r; }, out)) return 2;
+    if (nmHost != nmDev || nmHost != nmKf) {
+        fprintf(stderr, "hostbench: SearchByBoW forms disagree: %d %d %d\n", nmHost, nmDev, nmKf);
+        return 2;
+    }
+    float bowKernelMs = -1.f;
+    {
+        orbfe_matcher_time_kernels(1); // (events + a synchronisation per call: only for this one measurement)
+        int nm = 0;
+        for (int i = 0; i < 5; i++) CHECK(orbfe_search_bow_keyframes(dev, 1, kf1, nullptr, &bowDev, mp, &nm));
+        bowKernelMs = orbfe_matcher_last_kernel_ms();
+        orbfe_matcher_time_kernels(0);
+    }
+    // ---- 64 candidates per call (relocalisation, src/Tracking.cc:3784)
+    const int NB = 64;
+    std::vector<orbfe_bow_args> many(NB, bow), manyDev(NB, bowDev);
+    std::vector<std::vector<int32_t>> outs(NB, std::vector<int32_t>((size_t)nB));
+    std::vector<int32_t*> outp(NB);
+    std::vector<int> nms(NB);
+    std::vector<orbfe_keyframe*> kfs(NB, kfA);
+    for (int i = 0; i < NB; i++) outp[i] = outs[i].data();
+    if (timeit("search_bow_batch64_host_arrays", 60, [&] { return orbfe_search_bow_batch(dev, NB, many.data(), outp.data(), nms.data()); }, out)) return 2;
+    if (timeit("search_bow_batch64_keyframe_handles", 60, [&] { return orbfe_search_bow_keyframes(dev, NB, kfs.data(), nullptr, manyDev.data(), outp.data(), nms.data()); }, out)) return 2;
+    // ---- SearchForTriangulation_: A against B (pure x-translation geometry)
+    orbfe_tri_args tri{};
+    tri.desc1 = dA.data(); tri.n1 = nA; tri.hasMP1 = hasA.data(); tri.kp1_xy = xyA.data(); tri.angle1 = angA.data(); tri.octave1 = octA.data();
+    tri.uRight1 = uA.data(); tri.fv1 = fA.view();
+    tri.desc2 = dB.data(); tri.n2 = nB; tri.hasMP2 = hasB.data(); tri.kp2_xy = xyB.data(); tri.angle2 = angB.data(); tri.octave2 = octB.data();
+    tri.uRight2 = uB.data(); tri.fv2 = fB.view();
+    const float fx = 458.654f, fy = 457.296f, tx = 0.11f;
+    const float F12[9] = {0, 0, 0, 0, 0, -tx / fy, 0, tx / fy, 0}; // K^-T [t]x K^-1 for t = (tx, 0, 0), cy cancels in l . x2
+    (void)fx;
+    memcpy(tri.F12, F12, sizeof F12);
+    tri.ep[0] = 5000.f; tri.ep[1] = 240.f;
+    tri.scaleFactors2 = sf; tri.levelSigma2_2 = sig; tri.nlevels2 = 8;
+    tri.only_stereo = 0; tri.coarse = 0; tri.check_orientation = 1;
+    std::vector<int32_t> pairs((size_t)2 * nA);
+    int npHost = 0;
+    if (timeit("search_tri_host_arrays", 300, [&] { return npHost = orbfe_search_tri(dev, &tri, pairs.data()); }, out)) return 2;
+    orbfe_keyframe_args kb{};
+    kb.desc = ddB; kb.n = nB; kb.mask = hasB.data(); kb.angle = angB.data(); kb.kp_xy = xyB.data(); kb.octave = octB.data();
+    kb.uRight = uB.data(); kb.fv = fB.view();
+    orbfe_keyframe *kfB = nullptr, *kfAt = nullptr;
+    CHECK(orbfe_keyframe_create(&kfB, dev, &kb));
+    ka.mask = hasA.data(); // (the triangulation search reads "has a MapPoint", the BoW search "has a good MapPoint")
+    CHECK(orbfe_keyframe_create(&kfAt, dev, &ka));
+    orbfe_tri_pair tp{};
+    memcpy(tp.F12, F12, sizeof F12);
+    tp.ep[0] = tri.ep[0]; tp.ep[1] = tri.ep[1];
+    tp.scaleFactors2 = sf; tp.levelSigma2_2 = sig; tp.nlevels2 = 8; tp.only_stereo = 0; tp.coarse = 0; tp.check_orientation = 1;
+    const int NN = 20;
+    std::vector<orbfe_keyframe*> neigh(NN, kfB);
+    std::vector<orbfe_tri_pair> tps(NN, tp);
+    std::vector<std::vector<int32_t>> pout(NN, std::vector<int32_t>((size_t)2 * nA));
+    std::vector<int32_t*> pp(NN);
+    std::vector<int> nps(NN);
+    for (int i = 0; i < NN; i++) pp[i] = pout[i].data();
+    if (timeit("search_tri_keyframe_handles_1", 300, [&] { return orbfe_search_tri_batch(kfAt, 1, neigh.data(), tps.data(), pp.data(), nps.data()); }, out)) return 2;
+    if (nps[0] != npHost) {
+        fprintf(stderr, "hostbench: SearchForTriangulation forms disagree: %d %d\n", npHost, nps[0]);
+        return 2;
+    }
+    float triKernelMs = -1.f;
+    {
+        orbfe_matcher_time_kernels(1);
+        for (int i = 0; i < 5; i++) CHECK(orbfe_search_tri_batch(kfAt, NN, neigh.data(), tps.data(), pp.data(), nps.data()));
+        triKernelMs = orbfe_matcher_last_kernel_ms();
+        orbfe_matcher_time_kernels(0);
+    }
+    if (timeit("search_tri_batch20_keyframe_handles", 100, [&] { return orbfe_search_tri_batch(kfAt, NN, neigh.data(), tps.data(), pp.data(), nps.data()); }, out)) return 2;
+    if (timeit("search_tri_20_calls_host_arrays", 30, [&] { int r = 0; for (int i = 0; i < NN && r >= 0; i++) r = orbfe_search_tri(dev, &tri, pairs.data()); return r; }, out)) return 2;
+    // ---- SearchByProjection (Frame, local map points): 64 searches of nA map points into frame B
+    orbfe_proj_args pr{};
+    std::vector<float> kxB(nB), kyB(nB), qx(nA), qy(nA), qr(nA, 15.f);
+    std::vector<int32_t> qlo(nA), qhi(nA);
+    for (int i = 0; i < nB; i++) {
+        kxB[i] = kB[i].x;
+        kyB[i] = kB[i].y;
+    }
+    for (int i = 0; i < nA; i++) {
+        qx[i] = kA[i].x - 7.f;
+        qy[i] = kA[i].y;
+        qlo[i] = std::max(0, kA[i].octave - 1);
+        qhi[i] = std::min(7, kA[i].octave + 1);
+    }
+    pr.desc = dB.data(); pr.n = nB; pr.kx = kxB.data(); pr.ky = kyB.data(); pr.octave = octB.data(); pr.angle = angB.data();
+    pr.Nleft = -1; pr.minX = 0; pr.minY = 0; pr.gridWInv = 64.f / cols; pr.gridHInv = 48.f / rows;
+    pr.nq = nA; pr.qdesc = dA.data(); pr.qx = qx.data(); pr.qy = qy.data(); pr.qr = qr.data(); pr.qmin_level = qlo.data();
+    pr.qmax_level = qhi.data(); pr.mode = 0; pr.nnratio = 0.8f; pr.th_high = 100; pr.check_orientation = 0;
+    std::vector<int32_t> qm(nA), fm(nB);
+    int nProj = 0;
+    if (timeit("search_projection_host_arrays", 200, [&] { return nProj = orbfe_search_projection(dev, &pr, qm.data(), fm.data()); }, out)) return 2;
+    std::vector<orbfe_proj_args> prs(NB, pr);
+    std::vector<std::vector<int32_t>> qms(NB, std::vector<int32_t>(nA)), fms(NB, std::vector<int32_t>(nB));
+    std::vector<int32_t*> qmp(NB), fmp(NB);
+    std::vector<int32_t> nmp(NB);
+    for (int i = 0; i < NB; i++) {
+        qmp[i] = qms[i].data();
+        fmp[i] = fms[i].data();
+    }
+    if (timeit("search_projection_batch64_host_arrays", 40, [&] { return orbfe_search_projection_batch(dev, prs.data(), NB, qmp.data(), fmp.data(), nmp.data()); }, out)) return 2;
+    orbfe_proj_args prDev = pr;
+    prDev.desc = ddB;
+    std::vector<orbfe_proj_args> prsDev(NB, prDev);
+    if (timeit("search_projection_batch64_device_descriptors", 40, [&] { return orbfe_search_projection_batch(dev, prsDev.data(), NB, qmp.data(), fmp.data(), nmp.data()); }, out)) return 2;
+    // ---- DBoW2 transform of one frame's descriptors: k = 10, L = 4 synthetic tree (11111 nodes)
+    {
+        const int k = 10, L = 4;
+        int nn = 0;
+        for (int l = 0, c = 1; l <= L; l++, c *= k) nn += c;
+        std::vector<uint8_t> nd((size_t)nn * 32);
+        for (auto& c : nd) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            c = (uint8_t)(lcg >> 56);
+        }
+        std::vector<int32_t> coff(nn + 1), cids, word(nn, -1);
+        std::vector<double> weight(nn, 0.0);
+        int inner = 0;
+        for (int l = 0, c = 1; l < L; l++, c *= k) inner += c;
+        int wid = 0;
+        for (int i = 0; i < nn; i++) {
+            coff[i] = (int32_t)cids.size();
+            if (i < inner)
+                for (int c = 0; c < k; c++) cids.push_back(1 + k * i + c);
+            else {
+                word[i] = wid++;
+                weight[i] = 1.0 + (i % 7);
+            }
+        }
+        coff[nn] = (int32_t)cids.size();
+        orbfe_vocab v{};
+        v.nnodes = nn; v.node_desc = nd.data(); v.child_off = coff.data(); v.child_ids = cids.data(); v.node_word = word.data();
+        v.node_weight = weight.data(); v.L = L;
+        orbfe_vocab_dev* vd = nullptr;
+        CHECK(orbfe_vocab_upload(&vd, dev, &v));
+        std::vector<int32_t> wi(nB), ni(nB);
+        std::vector<double> ww(nB);
+        if (timeit("vocab_transform_host_descriptors", 300, [&] { return orbfe_vocab_transform(vd, dB.data(), nB, 4, wi.data(), ni.data(), ww.data()); }, out)) return 2;
+        if (timeit("vocab_transform_device_descriptors", 300, [&] { return orbfe_vocab_transform(vd, ddB, nB, 4, wi.data(), ni.data(), ww.data()); }, out)) return 2;
+        orbfe_vocab_free(vd);
+    }
+    printf("{\"config\": \"matcher\", \"frame\": \"%dx%d\", \"nA\": %d, \"nB\": %d, \"bow_matches\": %d, \"tri_pairs\": %d, "
+           "\"projection_matches\": %d, \"feature_vector\": {\"nodes\": %d, \"largest_node\": [%d, %d]}, \"kernel_ms\": {\"search_bow\": %.4f, \"search_tri_batch20\": %.4f}, \"calls\": {%s}}\n",
+           cols, rows, nA, nB, nmHost, npHost, nProj, (int)fA.ids.size(), maxNodeA, maxNodeB, bowKernelMs, triKernelMs, out.c_str());
+    orbfe_keyframe_destroy(kfA);
+    orbfe_keyframe_destroy(kfAt);
+    orbfe_keyframe_destroy(kfB);
+    orbfe_destroy(exA);
+    orbfe_destroy(exB);
+    (void)B;
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 6) {
@@ -70,6 +473,8 @@ int main(int argc, char** argv)
         }
         fclose(f);
     }
+    if (argc > 7 && !strcmp(argv[7], "c5")) return run_c5(frames, rows, cols, B, nF, dev);
+    if (argc > 7 && !strcmp(argv[7], "matcher")) return run_matcher(frames, rows, cols, B, nF, dev);
     orbfe_ctx* ex = nullptr;
     const double tCreate0 = now_s();
     CHECK(orbfe_create(&ex, nF, 1.2f, 8, 20, 7, dev));
