@@ -38,6 +38,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <stdexcept>
 #include <tuple>
@@ -145,6 +147,112 @@ inline FrameHandles& frame_handles()
     return f;
 }
 inline bool& use_frame_handles()
+{
+    static bool on = true; // (tests switch it off to compare the two paths)
+    return on;
+}
+
+// Keyframe handles (orbfe_keyframe, include/orbfe.h; round 4): SearchByBoW and SearchForTriangulation_ run one current
+// frame or keyframe against keyframes whose descriptors, keypoints and FeatureVector never change after construction, and
+// used to flatten and upload both sides on every call.  The adapter keeps a handle per KeyFrame it has searched -- process
+// wide, because Tracking (relocalisation), LocalMapping and LoopClosing search the same keyframes from three threads: a
+// mutex guards the table, an entry is reference-counted so that an eviction cannot free a handle under another thread's
+// search.  What DOES change -- which features hold a MapPoint -- travels with every call (mask1 / mask2 / hasMP arguments of
+// the handle searches), never through the shared handle.  A KeyFrame is recognised by its address, mnId, feature count and
+// descriptor buffer; at most 512 handles (~60 KB of device memory each), least recently used out.
+struct KeyFrameHandles {
+    struct Handle {
+        orbfe_keyframe* h = nullptr;
+        bool tri = false; // created with keypoints / octaves / mvuRight
+        ~Handle()
+        {
+            if (h) orbfe_keyframe_destroy(h);
+        }
+    };
+    struct Entry {
+        const void* obj = nullptr;
+        unsigned long id = 0;
+        int n = 0, device = 0;
+        const void* desc = nullptr;
+        std::shared_ptr<Handle> h;
+        unsigned long used = 0;
+    };
+    std::mutex m;
+    std::vector<Entry> e;
+    unsigned long clock = 0;
+    long creates = 0, hits = 0; // (what the tests look at)
+    template <class KF>
+    std::shared_ptr<Handle> get(KF* pKF, int device)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        const int n = pKF->N;
+        for (Entry& x : e)
+            if (x.obj == pKF && x.id == pKF->mnId && x.n == n && x.desc == pKF->mDescriptors.data && x.device == device) {
+                x.used = ++clock;
+                hits++;
+                return x.h;
+            }
+        if (n < 1 || pKF->mDescriptors.rows < n) return nullptr;
+        // flatten once: what rig_keypoint reads (mvKeysUn without a second camera, else mvKeys / mvKeysRight)
+        std::vector<uint8_t> tmp, mask((size_t)n, 0);
+        std::vector<float> xy(2 * (size_t)n), ang((size_t)n);
+        std::vector<int32_t> oct((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const cv::KeyPoint& kp = pKF->NLeft == -1 ? pKF->mvKeysUn[i]
+                                                      : (i < pKF->NLeft ? pKF->mvKeys[i] : pKF->mvKeysRight[i - pKF->NLeft]);
+            xy[2 * (size_t)i] = kp.pt.x;
+            xy[2 * (size_t)i + 1] = kp.pt.y;
+            ang[i] = kp.angle;
+            oct[i] = kp.octave;
+        }
+        const CSR c = toCSR(pKF->mFeatVec);
+        orbfe_keyframe_args a;
+        std::memset(&a, 0, sizeof a);
+        a.desc = dense_descriptors(pKF->mDescriptors, n, tmp);
+        a.n = n;
+        a.mask = mask.data(); // (every search sends its own flags)
+        a.angle = ang.data();
+        const bool tri = (int)pKF->mvuRight.size() >= n;
+        if (tri) {
+            a.kp_xy = xy.data();
+            a.octave = oct.data();
+            a.uRight = pKF->mvuRight.data();
+        }
+        a.fv = c.view();
+        std::shared_ptr<Handle> H = std::make_shared<Handle>();
+        if (orbfe_keyframe_create(&H->h, device, &a) < 0) return nullptr;
+        H->tri = tri;
+        creates++;
+        Entry* slot = nullptr;
+        if (e.size() < 512) {
+            e.emplace_back();
+            slot = &e.back();
+        } else {
+            slot = &e[0];
+            for (Entry& x : e)
+                if (x.used < slot->used) slot = &x;
+        }
+        slot->obj = pKF;
+        slot->id = pKF->mnId;
+        slot->n = n;
+        slot->device = device;
+        slot->desc = pKF->mDescriptors.data;
+        slot->h = H; // (the evicted handle dies with its last user)
+        slot->used = ++clock;
+        return H;
+    }
+    void clear()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        e.clear();
+    }
+};
+inline KeyFrameHandles& keyframe_handles()
+{
+    static KeyFrameHandles k;
+    return k;
+}
+inline bool& use_keyframe_handles()
 {
     static bool on = true; // (tests switch it off to compare the two paths)
     return on;
@@ -355,7 +463,18 @@ public:
         a.check_orientation = mbCheckOrientation ? 1 : 0;
         a.variant = 0;
         std::vector<int32_t> match((size_t)std::max(F.N, 1), -1);
-        const int nmatches = orbfe_search_bow(mDevice, &a, match.data());
+        int nmatches;
+        std::shared_ptr<KeyFrameHandles::Handle> H =
+            use_keyframe_handles() && n1 == pKF->N ? keyframe_handles().get(pKF, mDevice) : nullptr;
+        if (H) { // the keyframe side is resident: only this call's flags and the frame side travel
+            orbfe_keyframe* k1[1] = {H->h};
+            int32_t* mp[1] = {match.data()};
+            int nm = 0;
+            const int r = orbfe_search_bow_keyframes(mDevice, 1, k1, nullptr, &a, mp, &nm);
+            nmatches = r < 0 ? r : nm;
+        } else {
+            nmatches = orbfe_search_bow(mDevice, &a, match.data());
+        }
         if (nmatches < 0) throw std::runtime_error("orbfe_search_bow failed");
         for (int i = 0; i < F.N; i++)
             if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]]; // :376, :406
@@ -400,7 +519,23 @@ public:
         a.check_orientation = mbCheckOrientation ? 1 : 0;
         a.variant = 1;
         std::vector<int32_t> match((size_t)std::max(n1, 1), -1);
-        const int nmatches = orbfe_search_bow(mDevice, &a, match.data());
+        int nmatches;
+        // (handles for keyframes without a second camera: the angle this overload reads, mvKeysUn[i].angle, is then what a
+        // handle holds for every feature)
+        const bool plain = pKF1->NLeft == -1 && pKF2->NLeft == -1 && n1 == pKF1->N && n2 == pKF2->N &&
+                           (int)pKF1->mvKeysUn.size() >= n1 && (int)pKF2->mvKeysUn.size() >= n2;
+        std::shared_ptr<KeyFrameHandles::Handle> H1 = use_keyframe_handles() && plain ? keyframe_handles().get(pKF1, mDevice) : nullptr;
+        std::shared_ptr<KeyFrameHandles::Handle> H2 = H1 ? keyframe_handles().get(pKF2, mDevice) : nullptr;
+        if (H1 && H2) {
+            orbfe_keyframe* k1[1] = {H1->h};
+            orbfe_keyframe* k2[1] = {H2->h};
+            int32_t* mp[1] = {match.data()};
+            int nm = 0;
+            const int r = orbfe_search_bow_keyframes(mDevice, 1, k1, k2, &a, mp, &nm);
+            nmatches = r < 0 ? r : nm;
+        } else {
+            nmatches = orbfe_search_bow(mDevice, &a, match.data());
+        }
         if (nmatches < 0) throw std::runtime_error("orbfe_search_bow failed");
         for (int i = 0; i < n1; i++)
             if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]]; // :910
@@ -470,7 +605,25 @@ public:
         a.coarse = bCoarse ? 1 : 0;
         a.check_orientation = mbCheckOrientation ? 1 : 0;
         std::vector<int32_t> pairs(2 * (size_t)std::max(n1, 1));
-        const int np = orbfe_search_tri(mDevice, &a, pairs.data());
+        int np;
+        std::shared_ptr<KeyFrameHandles::Handle> H1 = use_keyframe_handles() ? keyframe_handles().get(pKF1, mDevice) : nullptr;
+        std::shared_ptr<KeyFrameHandles::Handle> H2 = H1 && H1->tri ? keyframe_handles().get(pKF2, mDevice) : nullptr;
+        if (H1 && H2 && H1->tri && H2->tri) { // both keyframes resident: the pair geometry and the has-MapPoint flags travel
+            orbfe_tri_pair q;
+            std::memset(&q, 0, sizeof q);
+            for (int i = 0; i < 9; i++) q.F12[i] = F12.val[i];
+            q.ep[0] = ep.x; q.ep[1] = ep.y;
+            q.scaleFactors2 = a.scaleFactors2; q.levelSigma2_2 = a.levelSigma2_2; q.nlevels2 = a.nlevels2;
+            q.only_stereo = a.only_stereo; q.coarse = a.coarse; q.check_orientation = a.check_orientation;
+            q.hasMP2 = has2.data();
+            orbfe_keyframe* k2[1] = {H2->h};
+            int32_t* pp[1] = {pairs.data()};
+            int cnt = 0;
+            const int r = orbfe_search_tri_batch(H1->h, has1.data(), 1, k2, &q, pp, &cnt);
+            np = r < 0 ? r : cnt;
+        } else {
+            np = orbfe_search_tri(mDevice, &a, pairs.data());
+        }
         if (np < 0) throw std::runtime_error("orbfe_search_tri failed");
         vMatchedPairs.clear(); // :1435-1446
         vMatchedPairs.reserve(np);

@@ -133,6 +133,13 @@ public:
 
 class KeyFrame {
 public:
+    // include/KeyFrame.h: `static long unsigned int nNextId; long unsigned int mnId;`, KeyFrame.cc: mnId = nNextId++
+    static long unsigned int& next_id()
+    {
+        static long unsigned int n = 0;
+        return n;
+    }
+    long unsigned int mnId = next_id()++;
     int N = 0, NLeft = -1;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
     std::vector<float> mvuRight;

@@ -160,6 +160,27 @@ static void test_bow_kf_f(const std::string& P)
         if (vpMapPointMatches[i]) out[i] = (int32_t)vpMapPointMatches[i]->mnId; // id == keyframe feature index
     put_i(P + "match", out);
     put_i(P + "n", std::vector<int32_t>(1, nm));
+    // keyframe handles (round 4): the search above created the keyframe's handle; the same search again only hits it, and a
+    // search with changed MapPoint flags still hits it (the flags travel with the call); handles off gives the same results
+    orbfe_adapter::KeyFrameHandles& H = orbfe_adapter::keyframe_handles();
+    const long c0 = H.creates, h0 = H.hits;
+    auto run = [&](std::vector<int32_t>& o) {
+        std::vector<MapPoint*> v;
+        o.push_back(matcher.SearchByBoW(&kf, F, v));
+        for (int i = 0; i < n2; i++) o.push_back(v[i] ? (int32_t)v[i]->mnId : -1);
+    };
+    std::vector<int32_t> ra1, ra2, rb1, rb2;
+    run(ra1);
+    std::vector<MapPoint*> saved = kf.mvpMapPoints;
+    for (int i = 0; i < n1; i += 3) kf.mvpMapPoints[i] = nullptr; // (the map changed)
+    run(ra2);
+    const long dc = H.creates - c0, dh = H.hits - h0;
+    orbfe_adapter::use_keyframe_handles() = false;
+    run(rb2);
+    kf.mvpMapPoints = saved;
+    run(rb1);
+    orbfe_adapter::use_keyframe_handles() = true;
+    put_i(P + "kfhandles", std::vector<int32_t>{(int32_t)dc, (int32_t)dh, (ra1 == rb1 && ra2 == rb2 && ra1[0] == nm) ? 1 : 0});
 }
 
 static void test_bow_kf_kf(const std::string& P)
@@ -184,6 +205,20 @@ static void test_bow_kf_kf(const std::string& P)
         if (vpMatches12[i]) out[i] = (int32_t)vpMatches12[i]->mnId; // id == index in keyframe 2
     put_i(P + "match", out);
     put_i(P + "n", std::vector<int32_t>(1, nm));
+    orbfe_adapter::KeyFrameHandles& H = orbfe_adapter::keyframe_handles();
+    const long c0 = H.creates, h0 = H.hits;
+    auto run = [&](std::vector<int32_t>& o) {
+        std::vector<MapPoint*> v;
+        o.push_back(matcher.SearchByBoW(&k1, &k2, v));
+        for (int i = 0; i < n1; i++) o.push_back(v[i] ? (int32_t)v[i]->mnId : -1);
+    };
+    std::vector<int32_t> a1, b1;
+    run(a1);
+    const long dc = H.creates - c0, dh = H.hits - h0;
+    orbfe_adapter::use_keyframe_handles() = false;
+    run(b1);
+    orbfe_adapter::use_keyframe_handles() = true;
+    put_i(P + "kfhandles", std::vector<int32_t>{(int32_t)dc, (int32_t)dh, (a1 == b1 && a1[0] == nm) ? 1 : 0});
 }
 
 static void fill_kf_geom(KeyFrame& k, const std::string& P, const char* sfx)
@@ -237,6 +272,33 @@ static void test_tri(const std::string& P)
     put(P + "F12", 2, matcher.lastF12.val, 9);
     const float ep[2] = {matcher.lastEp.x, matcher.lastEp.y};
     put(P + "ep", 2, ep, 2);
+    {
+        orbfe_adapter::KeyFrameHandles& H = orbfe_adapter::keyframe_handles();
+        const long c0 = H.creates, h0 = H.hits;
+        auto run = [&](std::vector<int32_t>& o) {
+            std::vector<std::pair<size_t, size_t>> pr;
+            o.push_back(matcher.SearchForTriangulation_(&k1, &k2, cv::Matx33f(), pr, in(P + "stereo").i32()[0] != 0,
+                                                        in(P + "coarse").i32()[0] != 0));
+            for (auto& q : pr) {
+                o.push_back((int32_t)q.first);
+                o.push_back((int32_t)q.second);
+            }
+        };
+        std::vector<int32_t> a1, a2, b1, b2;
+        run(a1);
+        std::vector<MapPoint*> s1 = k1.mvpMapPoints, s2 = k2.mvpMapPoints;
+        for (int i = 0; i < k1.N; i += 2) k1.mvpMapPoints[i] = nullptr; // more features without a MapPoint: more rows search
+        for (int i = 1; i < k2.N; i += 2) k2.mvpMapPoints[i] = nullptr;
+        run(a2);
+        const long dc = H.creates - c0, dh = H.hits - h0;
+        orbfe_adapter::use_keyframe_handles() = false;
+        run(b2);
+        k1.mvpMapPoints = s1;
+        k2.mvpMapPoints = s2;
+        run(b1);
+        orbfe_adapter::use_keyframe_handles() = true;
+        put_i(P + "kfhandles", std::vector<int32_t>{(int32_t)dc, (int32_t)dh, (a1 == b1 && a2 == b2 && a1[0] == nm) ? 1 : 0});
+    }
     std::vector<std::pair<size_t, size_t>> pairs3; // pinhole cameras: Pinhole::matchAndtriangulate accepts nothing
     std::vector<cv::Mat> pts3;
     put_i(P + "n3d", std::vector<int32_t>(1, matcher.SearchForTriangulation(&k1, &k2, cv::Mat(), pairs3, false, pts3)));

@@ -364,8 +364,12 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
 int orbfe_keyframe_set_mask(orbfe_keyframe*, const uint8_t* mask);
 void orbfe_keyframe_destroy(orbfe_keyframe*);
 /* orbfe_search_bow_batch with sets taken from handles: kf1[p] / kf2[p] non-null replaces set 1 / set 2 of args[p] (its
- * desc / n / mask / angle / fv fields are then ignored; limit, Nleft, nnratio, check_orientation and variant still come from
- * args[p]).  kf1 / kf2 may be NULL (no handle on that side).  One upload of whatever is not resident, one launch, one download. */
+ * desc / n / angle / fv fields are then ignored; limit, Nleft, nnratio, check_orientation and variant still come from
+ * args[p]).  The FLAGS of a set in a handle may still be given per call: args[p].mask1 (mask2, variant 1) non-null is used
+ * instead of the handle's -- a KeyFrame's MapPoints change while Tracking, LocalMapping and LoopClosing search it from
+ * three threads, so a caller like adapters/ORBmatcher.h sends the current flags with every call (n bytes) rather than
+ * writing them into the shared handle.  kf1 / kf2 may be NULL (no handle on that side).  One upload of whatever is not
+ * resident, one launch; small results are written by the kernel straight into pinned host memory (no download command). */
 int orbfe_search_bow_keyframes(int device, int count, orbfe_keyframe* const* kf1, orbfe_keyframe* const* kf2,
                                const orbfe_bow_args* args, int32_t* const* match, int* nmatches);
 /* SearchForTriangulation_ (src/ORBmatcher.cc:1208-1449, pinhole gate) of ONE keyframe against `count` neighbours in ONE
@@ -375,9 +379,10 @@ typedef struct {
     float F12[9]; float ep[2];
     const float* scaleFactors2; const float* levelSigma2_2; int nlevels2;
     int only_stereo, coarse, check_orientation;
+    const uint8_t* hasMP2; /* this call's has-MapPoint flags of the neighbour, or NULL = the handle's */
 } orbfe_tri_pair;
-int orbfe_search_tri_batch(orbfe_keyframe* kf1, int count, orbfe_keyframe* const* kf2, const orbfe_tri_pair* pair,
-                           int32_t* const* pairs, int* npairs);
+int orbfe_search_tri_batch(orbfe_keyframe* kf1, const uint8_t* hasMP1 /* this call's flags of kf1, or NULL = the handle's */,
+                           int count, orbfe_keyframe* const* kf2, const orbfe_tri_pair* pair, int32_t* const* pairs, int* npairs);
 
 typedef struct {
     const uint8_t* desc1; int n1; const uint8_t* hasMP1; const float* kp1_xy; const float* angle1;

@@ -206,6 +206,15 @@ def lib():
         L.orbfe_mc_match_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long]
         L.orbfe_mc_exchange_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.orbfe_set_gaussian_taps.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_keyframe_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+        L.orbfe_keyframe_set_mask.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbfe_keyframe_destroy.argtypes = [C.c_void_p]
+        L.orbfe_keyframe_destroy.restype = None
+        L.orbfe_search_bow_keyframes.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbfe_search_tri_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbfe_set_lanes.argtypes = [C.c_void_p, C.c_int]
+        L.orbfe_lanes_join.argtypes = [C.c_void_p]
+        L.orbfe_lanes_record.argtypes = [C.c_void_p, C.c_void_p]
         L.orbfe_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_max_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orbfe_set_kb8.argtypes = [C.c_void_p, C.c_void_p]
@@ -800,7 +809,8 @@ class _KeyFrameArgs(C.Structure):
 
 class _TriPair(C.Structure):
     _fields_ = [("F12", C.c_float * 9), ("ep", C.c_float * 2), ("scaleFactors2", C.c_void_p), ("levelSigma2_2", C.c_void_p),
-                ("nlevels2", C.c_int), ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int)]
+                ("nlevels2", C.c_int), ("only_stereo", C.c_int), ("coarse", C.c_int), ("check_orientation", C.c_int),
+                ("hasMP2", C.c_void_p)]
 
 
 class KeyFrameHandle:
@@ -853,10 +863,16 @@ def search_bow_keyframes(problems, device=0):
         dummy = np.zeros((1, 32), np.uint8)
         one = np.ones(1, np.uint8)
         efv = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
-        a, k, nout = _bow_args(dummy if h1 else pr["desc1"], one if h1 else pr["mask1"], np.zeros(1) if h1 else pr["ang1"],
-                               efv if h1 else pr["fv1"], dummy if h2 else pr["desc2"], one if h2 else pr.get("mask2"),
+        a, k, nout = _bow_args(dummy if h1 else pr["desc1"], pr["mask1"] if (not h1 or pr.get("mask1") is not None) else one,
+                               np.zeros(1) if h1 else pr["ang1"],
+                               efv if h1 else pr["fv1"], dummy if h2 else pr["desc2"],
+                               pr.get("mask2") if (not h2 or pr.get("mask2") is not None) else one,
                                np.zeros(1) if h2 else pr["ang2"], efv if h2 else pr["fv2"], pr["variant"], pr["nnratio"],
                                pr.get("check_ori", True), pr.get("Nleft", -1), pr.get("limit1", -1), pr.get("limit2", -1))
+        if h1 and pr.get("mask1") is None:
+            a.mask1 = None  # (NULL = the handle's own flags; a non-null pointer is read as this call's n1 flags)
+        if h2 and pr.get("mask2") is None:
+            a.mask2 = None
         arr[i] = a
         k1[i] = h1.h if h1 else None
         k2[i] = h2.h if h2 else None
@@ -870,9 +886,16 @@ def search_bow_keyframes(problems, device=0):
     return [(int(nm[i]), outs[i]) for i in range(n)]
 
 
-def search_tri_batch(kf1, neighbours):
+def _keep(keep, v, dt):
+    a = np.ascontiguousarray(v, dt)
+    keep.append(a)
+    return a.ctypes.data
+
+
+def search_tri_batch(kf1, neighbours, hasMP1=None):
     """orbfe_search_tri_batch: kf1 (KeyFrameHandle with keypoints) against neighbours = [dict(kf=handle, F12, ep, sf, sig,
-    only_stereo, coarse, check_ori)], one launch.  Returns a list of pairs[n, 2] arrays."""
+    only_stereo, coarse, check_ori[, hasMP2])], one launch; hasMP1 / hasMP2 = this call's flags instead of the handles'.
+    Returns a list of pairs[n, 2] arrays."""
     n = len(neighbours)
     arr = (_TriPair * n)()
     kfs = (C.c_void_p * n)()
@@ -883,12 +906,14 @@ def search_tri_batch(kf1, neighbours):
         keep += [sf, sg]
         arr[i] = _TriPair((C.c_float * 9)(*[float(v) for v in np.asarray(q["F12"], np.float32).reshape(9)]),
                           (C.c_float * 2)(float(q["ep"][0]), float(q["ep"][1])), sf.ctypes.data, sg.ctypes.data, len(sf),
-                          int(q.get("only_stereo", False)), int(q.get("coarse", False)), int(q.get("check_ori", True)))
+                          int(q.get("only_stereo", False)), int(q.get("coarse", False)), int(q.get("check_ori", True)),
+                          None if q.get("hasMP2") is None else _keep(keep, q["hasMP2"], np.uint8))
         kfs[i] = q["kf"].h
         outs.append(np.zeros((max(kf1.n, 1), 2), np.int32))
     ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
     npairs = np.zeros(max(n, 1), np.int32)
-    _chk(lib().orbfe_search_tri_batch(kf1.h, n, kfs, arr, ptrs, _p(npairs)), "orbfe_search_tri_batch")
+    h1 = None if hasMP1 is None else _keep(keep, hasMP1, np.uint8)
+    _chk(lib().orbfe_search_tri_batch(kf1.h, h1, n, kfs, arr, ptrs, _p(npairs)), "orbfe_search_tri_batch")
     return [outs[i][:npairs[i]].copy() for i in range(n)]
 
 

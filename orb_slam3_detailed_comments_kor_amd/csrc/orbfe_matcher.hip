@@ -1798,21 +1798,33 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     std::vector<uint8_t> active(count, 0);
     std::vector<orbfe_bow_args> eff(count); // the arguments with the handles' host views filled in
     int rows = 0, outTotal = 0, takenRows = 0;
-    size_t indTotal = 0;
+    size_t indTotal = 0, ovTotal = 0;
+    std::vector<long> ovOff1(count, -1), ovOff2(count, -1); // per-call flags of sets in handles: offsets into their own pool
     for (int p = 0; p < count; p++) {
         orbfe_bow_args& e = eff[p];
         e = args[p];
         const orbfe_keyframe* K1 = kf1 ? kf1[p] : nullptr;
         const orbfe_keyframe* K2 = kf2 ? kf2[p] : nullptr;
         if ((K1 && K1->device != device) || (K2 && K2->device != device)) return ORBFE_ERR_ARGS;
+        // (a set in a handle: its arrays come from the handle; the flags alone may be given per call -- args[p].mask1 / mask2
+        // non-null --, because a keyframe's MapPoints change while several threads search it: they then travel with the call
+        // instead of being written into the shared handle)
+        const uint8_t* ov1 = K1 ? args[p].mask1 : nullptr;
+        const uint8_t* ov2 = K2 && args[p].variant == 1 ? args[p].mask2 : nullptr;
         if (K1) {
-            e.desc1 = K1->desc; e.n1 = K1->n; e.mask1 = K1->hMask.data(); e.angle1 = K1->hAng.empty() ? nullptr : K1->hAng.data();
+            e.desc1 = K1->desc; e.n1 = K1->n; e.mask1 = ov1 ? ov1 : K1->hMask.data();
+            e.angle1 = K1->hAng.empty() ? nullptr : K1->hAng.data();
             e.fv1 = K1->fv();
         }
         if (K2) {
-            e.desc2 = K2->desc; e.n2 = K2->n; e.mask2 = K2->hMask.data(); e.angle2 = K2->hAng.empty() ? nullptr : K2->hAng.data();
+            e.desc2 = K2->desc; e.n2 = K2->n; e.mask2 = ov2 ? ov2 : K2->hMask.data();
+            e.angle2 = K2->hAng.empty() ? nullptr : K2->hAng.data();
             e.fv2 = K2->fv();
         }
+        ovOff1[p] = ov1 ? (long)ovTotal : -1;
+        if (ov1) ovTotal += ((size_t)K1->n + 63) & ~(size_t)63;
+        ovOff2[p] = ov2 ? (long)ovTotal : -1;
+        if (ov2) ovTotal += ((size_t)K2->n + 63) & ~(size_t)63;
         const orbfe_bow_args* a = &e;
         if (!match[p] || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2) ||
             (a->variant != 0 && a->variant != 1))
@@ -1880,6 +1892,22 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     int32_t *dInd, *dM, *hInd;
     int8_t* dB;
     if ((r = s.up(&dN, nodes.data(), nodes.size())) < 0) return r;
+    {
+        uint8_t *dOv = nullptr, *hOv = nullptr;
+        if (ovTotal) {
+            if ((r = s.reserve(&dOv, &hOv, ovTotal)) < 0) return r;
+            for (int p = 0; p < count; p++) {
+                if (ovOff1[p] >= 0) {
+                    std::memcpy(hOv + ovOff1[p], eff[p].mask1, (size_t)eff[p].n1);
+                    probs[p].rMask1 = dOv + ovOff1[p];
+                }
+                if (ovOff2[p] >= 0) {
+                    std::memcpy(hOv + ovOff2[p], eff[p].mask2, (size_t)eff[p].n2);
+                    probs[p].rMask2 = dOv + ovOff2[p];
+                }
+            }
+        }
+    }
     if ((r = s.up(&dP, probs.data(), probs.size())) < 0) return r;
     if ((r = s.reserve(&dDesc, &hDesc, (size_t)rows * 32)) < 0) return r;
     if ((r = s.reserve(&dMask, &hMask, (size_t)rows)) < 0) return r;
@@ -2079,10 +2107,11 @@ int orbfe_search_bow_keyframes(int device, int count, orbfe_keyframe* const* kf1
 
 // SearchForTriangulation_ of ONE keyframe against `count` neighbours (src/LocalMapping.cc:556-621), all sides resident:
 // one upload of the row lists and pair records, ONE launch, one download.
-int orbfe_search_tri_batch(orbfe_keyframe* K1, int count, orbfe_keyframe* const* kf2, const orbfe_tri_pair* pair,
-                           int32_t* const* pairs, int* npairs)
+int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count, orbfe_keyframe* const* kf2,
+                           const orbfe_tri_pair* pair, int32_t* const* pairs, int* npairs)
 {
     if (!K1 || count < 0 || (count && (!kf2 || !pair || !pairs || !npairs)) || !K1->hasTri) return ORBFE_ERR_ARGS;
+    const uint8_t* const has1 = hasMP1 ? hasMP1 : K1->hMask.data(); // (per call when given: see orbfe_search_bow_keyframes)
     const int device = K1->device, n1 = K1->n;
     std::vector<TriRowB> rows;
     std::vector<TriProb> probs(count);
@@ -2105,7 +2134,7 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, int count, orbfe_keyframe* const*
             if (n2 >= (1 << 20)) bad = true;
             for (int k = f1.offsets[i]; k < f1.offsets[i + 1]; k++) {
                 const int idx1 = f1.indices[k];
-                if (K1->hMask[idx1]) continue;                             // :1279-1282
+                if (has1[idx1]) continue;                                   // :1279-1282
                 if (q.only_stereo && !(K1->hUR[idx1] >= 0)) continue;       // :1286-1288
                 if (n2 > 0) rows.push_back(TriRowB{idx1, off2, n2, p});
             }
@@ -2121,18 +2150,28 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, int count, orbfe_keyframe* const*
     float *dTab, *hTab;
     int32_t* dM;
     if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
+    size_t ovTotal = 0;
+    for (int p = 0; p < count; p++)
+        if (pair[p].hasMP2) ovTotal += ((size_t)kf2[p]->n + 63) & ~(size_t)63;
+    uint8_t *dOv = nullptr, *hOv = nullptr;
+    if (ovTotal && (r = s.reserve(&dOv, &hOv, ovTotal)) < 0) return r;
     if ((r = s.reserve(&dTab, &hTab, tabFloats)) < 0) return r;
     if ((r = s.reserve(&dP, &hP, (size_t)count)) < 0) return r;
     int32_t* hMir = nullptr;
     const bool mirrored = (size_t)count * n1 * 4 <= (256u << 10) && s.mirror_out(&dM, &hMir, (size_t)count * n1) == 0;
     if (mirrored) std::memset(hMir, 0xFF, (size_t)count * n1 * sizeof(int32_t));
     else if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
-    size_t tOff = 0;
+    size_t tOff = 0, ovAt = 0;
     for (int p = 0; p < count; p++) {
         const orbfe_keyframe* K2 = kf2[p];
         const orbfe_tri_pair& q = pair[p];
         TriProb& Q = hP[p];
         Q.desc2 = K2->desc; Q.hasMP2 = K2->mask; Q.kp2 = K2->kp; Q.oct2 = K2->oct; Q.uR2 = K2->uR; Q.ind2 = K2->ind;
+        if (q.hasMP2) { // this call's flags of the neighbour
+            std::memcpy(hOv + ovAt, q.hasMP2, (size_t)K2->n);
+            Q.hasMP2 = dOv + ovAt;
+            ovAt += ((size_t)K2->n + 63) & ~(size_t)63;
+        }
         std::memcpy(hTab + tOff, q.scaleFactors2, (size_t)q.nlevels2 * sizeof(float));
         std::memcpy(hTab + tOff + q.nlevels2, q.levelSigma2_2, (size_t)q.nlevels2 * sizeof(float));
         Q.sf2 = dTab + tOff;

@@ -62,6 +62,14 @@ def test_bow_with_keyframe_handles(pkg, oracle):
     rn, rm = oracle.search_bow_kf_f(d, mask2, a, fvK, dF, aF, fvF, -1, 0.75, True)
     n, m = pkg.search_bow_keyframes([probs[2]])[0]
     assert n == rn and np.array_equal(m, rm)
+    # ... or travel with the call (what adapters/ORBmatcher.h does: several threads search one keyframe)
+    mask3 = (rng.uniform(size=len(sets[2][0])) < 0.5).astype(np.uint8)
+    rn, rm = oracle.search_bow_kf_f(d, mask3, a, fvK, dF, aF, fvF, -1, 0.75, True)
+    n, m = pkg.search_bow_keyframes([dict(probs[2], mask1=mask3)])[0]
+    assert n == rn and np.array_equal(m, rm)
+    n, m = pkg.search_bow_keyframes([probs[2]])[0]  # (the handle's own flags are untouched)
+    rn, rm = oracle.search_bow_kf_f(d, mask2, a, fvK, dF, aF, fvF, -1, 0.75, True)
+    assert n == rn and np.array_equal(m, rm)
     # variant 1 (KeyFrame*, KeyFrame*): both sides in handles (loop closing); per-pair FeatureVectors are the handles' own
     dA, mA, aA, fvA, _ = sets[0]
     dB, mB, aB, _, _ = sets[1]
@@ -83,7 +91,7 @@ def test_triangulation_search_against_many_neighbours(pkg, oracle):
     fv1 = synth.make_feature_vectors(I0["d1"], 41, 5, 2)  # (= I0["fv1"]: tri_inputs uses seed + 1, branching 5, depth 2)
     assert all(np.array_equal(x, y) for x, y in zip(fv1, I0["fv1"]))
     cur = pkg.KeyFrameHandle(I0["d1"], I0["has1"], I0["a1"], fv1, kp_xy=I0["kp1"], octave=I0["oct1"], uRight=I0["u1"])
-    neigh, want = [], []
+    neigh, want, argsets = [], [], []
     for k in range(12):  # the current keyframe against 12 covisible keyframes (src/LocalMapping.cc:556-621)
         n2 = 800 + 30 * k
         d2, origin = _noisy_copy(I0["d1"], n2, 500 + k)
@@ -102,12 +110,23 @@ def test_triangulation_search_against_many_neighbours(pkg, oracle):
         neigh.append(dict(kf=h, F12=F12, ep=ep, sf=I0["sf"], sig=I0["sig"], **flags))
         args = (I0["d1"], I0["has1"], I0["kp1"], I0["a1"], I0["oct1"], I0["u1"], fv1, d2, has2, kp2, a2, oct2, u2, fv2, F12, ep,
                 I0["sf"], I0["sig"], flags["only_stereo"], flags["coarse"], flags["check_ori"])
+        argsets.append(args)
         want.append(pkg.search_triangulation(*args))
         assert np.array_equal(want[-1], oracle.search_triangulation(*args)), k
     got = pkg.search_tri_batch(cur, neigh)
     assert sum(len(g) for g in got) > 200
     for k in range(12):
         assert np.array_equal(got[k], want[k]), k
+    # this call's has-MapPoint flags instead of the handles' (current keyframe and two of the neighbours)
+    h1 = (rng.uniform(size=len(I0["d1"])) < 0.2).astype(np.uint8)
+    ov = {3: (rng.uniform(size=neigh[3]["kf"].n) < 0.6).astype(np.uint8), 7: np.zeros(neigh[7]["kf"].n, np.uint8)}
+    got2 = pkg.search_tri_batch(cur, [dict(q, hasMP2=ov.get(k)) for k, q in enumerate(neigh)], hasMP1=h1)
+    for k in (0, 3, 7):
+        a_ = list(argsets[k])
+        a_[1] = h1
+        if k in ov:
+            a_[8] = ov[k]
+        assert np.array_equal(got2[k], oracle.search_triangulation(*a_)), k
     # a handle without keypoints cannot be a side of the triangulation search
     bow_only = pkg.KeyFrameHandle(I0["d1"], I0["has1"], I0["a1"], I0["fv1"])
     with pytest.raises(pkg.OrbfeError):

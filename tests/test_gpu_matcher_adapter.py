@@ -86,6 +86,9 @@ def _bow_kf_f(f, tag, oracle, seed, n1, n2, nleft, ratio, ori):
                                       _csr_from_nodes(node2), nleft, ratio, ori)
         assert res[tag + "n"][0] == n and n > 20, tag
         assert np.array_equal(res[tag + "match"], m), tag
+        # keyframe handle: created by the first search, hit by the two that follow (one with changed MapPoint flags, which travel
+        # with the call); the same results with handles switched off
+        assert list(res[tag + "kfhandles"]) == [0, 2, 1], (tag, res[tag + "kfhandles"])
     return check
 
 
@@ -105,6 +108,7 @@ def _bow_kf_kf(f, tag, oracle, seed, n1, n2, ratio, ori):
                                        (mp2 == 1).astype(np.uint8), a2, _csr_from_nodes(node2), -1, -1, ratio, ori)
         assert res[tag + "n"][0] == n and n > 20, tag
         assert np.array_equal(res[tag + "match"], m), tag
+        assert list(res[tag + "kfhandles"]) == [0, 2, 1], (tag, res[tag + "kfhandles"])  # both keyframes' handles hit again
     return check
 
 
@@ -159,6 +163,7 @@ def _tri(f, tag, oracle, seed, n1, n2, stereo, coarse, ori):
         assert res[tag + "n"][0] == len(pairs) and (len(pairs) > 15 or stereo), (tag, len(pairs))
         assert np.array_equal(res[tag + "pairs"].reshape(-1, 2), pairs), tag
         assert res[tag + "n3d"][0] == 0, tag     # the triangulating overload with pinhole cameras: never a pair
+        assert list(res[tag + "kfhandles"]) == [0, 4, 1], (tag, res[tag + "kfhandles"])  # two searches x two resident keyframes
     return check
 
 

@@ -358,7 +358,7 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     std::vector<int32_t*> pp(NN);
     std::vector<int> nps(NN);
     for (int i = 0; i < NN; i++) pp[i] = pout[i].data();
-    if (timeit("search_tri_keyframe_handles_1", 300, [&] { return orbfe_search_tri_batch(kfAt, 1, neigh.data(), tps.data(), pp.data(), nps.data()); }, out)) return 2;
+    if (timeit("search_tri_keyframe_handles_1", 300, [&] { return orbfe_search_tri_batch(kfAt, nullptr, 1, neigh.data(), tps.data(), pp.data(), nps.data()); }, out)) return 2;
     if (nps[0] != npHost) {
         fprintf(stderr, "hostbench: SearchForTriangulation forms disagree: %d %d\n", npHost, nps[0]);
         return 2;
@@ -366,11 +366,11 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     float triKernelMs = -1.f;
     {
         orbfe_matcher_time_kernels(1);
-        for (int i = 0; i < 5; i++) CHECK(orbfe_search_tri_batch(kfAt, NN, neigh.data(), tps.data(), pp.data(), nps.data()));
+        for (int i = 0; i < 5; i++) CHECK(orbfe_search_tri_batch(kfAt, nullptr, NN, neigh.data(), tps.data(), pp.data(), nps.data()));
         triKernelMs = orbfe_matcher_last_kernel_ms();
         orbfe_matcher_time_kernels(0);
     }
-    if (timeit("search_tri_batch20_keyframe_handles", 100, [&] { return orbfe_search_tri_batch(kfAt, NN, neigh.data(), tps.data(), pp.data(), nps.data()); }, out)) return 2;
+    if (timeit("search_tri_batch20_keyframe_handles", 100, [&] { return orbfe_search_tri_batch(kfAt, nullptr, NN, neigh.data(), tps.data(), pp.data(), nps.data()); }, out)) return 2;
     if (timeit("search_tri_20_calls_host_arrays", 30, [&] { int r = 0; for (int i = 0; i < NN && r >= 0; i++) r = orbfe_search_tri(dev, &tri, pairs.data()); return r; }, out)) return 2;
     // ---- SearchByProjection (Frame, local map points): 64 searches of nA map points into frame B
     orbfe_proj_args pr{};
