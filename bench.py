@@ -174,6 +174,118 @@ def startup_cost(rows, cols, nfeatures, device=0):
     return out
 
 
+def hostbench_mode(mode, rows, cols, batch, nfeatures, device=0):
+    """tools/hostbench in one of its extra modes ("c5": fisheye stereo frame, "matcher": the matcher entry points from C++)."""
+    exe = os.path.join(ROOT, "tools", "hostbench")
+    if not os.path.exists(exe):
+        raise SystemExit("tools/hostbench is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as f:
+        f.write(bench_frames(rows, cols, batch).tobytes())
+        path = f.name
+    try:
+        out = subprocess.run([exe, path, str(rows), str(cols), str(batch), str(nfeatures), str(device), mode],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    if out.returncode != 0:
+        raise SystemExit("tools/hostbench %s failed (%d): %s" % (mode, out.returncode, out.stderr[-500:]))
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def cpu_stereo_baseline(rows, cols, nfeatures, fisheye, seconds=10.0):
+    """The CPU path of a stereo frame, timed on this host: the oracle's two extractors on two threads (src/Frame.cc:119-122),
+    then the consumer of the pair -- Frame::ComputeStereoMatches (rectified, config 3) or the knn-2 brute force of
+    Frame::ComputeStereoFishEyeMatches (config 5) -- on one thread, as the reference runs it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orb_oracle_py as O
+    from orb_slam3_detailed_comments_kor_amd import synth
+    O.build()
+    native = O.lib_native() is not None
+    left, right = synth.make_stereo_pair(rows, cols, 51, shift=40 if fisheye else 12)
+    frames = np.stack([left, right])
+    lap = (0, cols - 1) if fisheye else (0, 0)
+    n, t = O.extract_many(frames, 2, 2, nfeatures, lap=lap, native=native)
+    reps = int(min(max(2, 0.6 * seconds / (t / 2)), 200))
+    n, t = O.extract_many(frames, 2, reps, nfeatures, lap=lap, native=native)
+    ms_extract = 1e3 * t / reps
+    exL, exR = O.Extractor(nfeatures, 1.2, 8, 20, 7), O.Extractor(nfeatures, 1.2, 8, 20, 7)
+    mL, kL, dL = exL.extract(left, lap)
+    mR, kR, dR = exR.extract(right, lap)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < 0.3 * seconds or k < 2:
+        if fisheye:
+            O.bfknn2(dL[mL:], dR[mR:])
+        else:
+            O.compute_stereo_matches(exL, exR, kL, dL, kR, dR, 47.90639384423901 / 435.2046959714599, 47.90639384423901)
+        k += 1
+    ms_match = 1e3 * (time.perf_counter() - t0) / k
+    return {"value": (len(kL) + len(kR)) / ((ms_extract + ms_match) * 1e-3), "unit": "keypoints/s", "cores": 2, "kind": "port",
+            "flags": "g++ " + (O.NATIVE_FLAGS if native else O.PORTABLE_FLAGS),
+            "ms_per_pair": ms_extract + ms_match, "extract_ms_per_pair": ms_extract, "match_ms_per_pair": ms_match,
+            "sample": "%d stereo pairs of %dx%d (nF=%d) on 2 threads + %d runs of %s on 1 thread" %
+                      (reps, cols, rows, nfeatures, k, "the knn-2 brute force of ComputeStereoFishEyeMatches (python wrapper "
+                       "around the C++ oracle)" if fisheye else "ComputeStereoMatches")}
+
+
+def per_call_config(args, real_stdout):
+    """BASELINE configs[2] (`--config c3`: EuRoC stereo pair per call, nFeatures 1200, rectified matching on the GPU) and
+    configs[4] (`--config c5`: 1024 x 1024 fisheye stereo frame, nFeatures 1500, KB8 rays in the extractor, knn-2 matching +
+    triangulation): per-CALL configurations at the drop-in boundary, measured by the C++ caller tools/hostbench with host
+    images in and host arrays out.  `value` = keypoints (with descriptors) per second through the whole stereo frame."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.config == "c3":
+        rows, cols, nf = 480, 752, 1200
+        hb = pcie_inclusive(rows, cols, 8, nf, 0)
+        fused = hb["stereo_pair_fused"]
+        kp_pair = hb["stereo_pair"]["keypoints_per_s"] * hb["stereo_pair"]["ms_per_pair_mean"] * 1e-3
+        ms = fused["pinned"]["ms_per_pair_p50"]
+        protocols = {"one_call_pinned (orbfe_extract_stereo_pair)": fused["pinned"],
+                     "one_call_pageable (orbfe_extract_stereo_pair)": fused["pageable"],
+                     "two_threads_two_contexts (reference protocol, src/Frame.cc:119-122)":
+                         {k: hb["stereo_pair"][k] for k in ("ms_per_pair_mean", "ms_per_pair_p50", "ms_per_pair_p99", "extract_ms_p50")},
+                     "one_batched_call_then_resident_matching": {k: hb["stereo_pair_one_call"][k] for k in
+                                                                 ("ms_per_pair_mean", "ms_per_pair_p50", "ms_per_pair_p99")}}
+        workload = ("EuRoC stereo pair per call: 2 x 752x480, nFeatures 1200, both extractions + Frame::ComputeStereoMatches on the "
+                    "GPU, host images in, host keypoints / descriptors / mvuRight / mvDepth out (BASELINE configs[2])")
+        matches = hb["stereo_pair"]["matches_per_pair"]
+        fisheye = False
+    else:
+        rows, cols, nf = 1024, 1024, 1500
+        hb = hostbench_mode("c5", rows, cols, 8, nf, 0)
+        kp_pair = hb["keypoints_per_pair"]
+        ms = hb["one_call"]["ms_per_pair_p50"]
+        protocols = {"one_batched_call + orbfe_stereo_fisheye_matches": hb["one_call"],
+                     "two_threads_two_contexts (reference protocol) + orbfe_stereo_fisheye_matches": hb["two_threads"]}
+        workload = ("TUM-VI-like fisheye stereo frame per call: 2 x 1024x1024, nFeatures 1500, KannalaBrandt8 bearing rays fused "
+                    "into the extractor (orbfe_set_kb8), every keypoint in the lapping area, then "
+                    "Frame::ComputeStereoFishEyeMatches (knn-2 + ratio + triangulation) on the GPU (BASELINE configs[4])")
+        matches = hb["matches_per_pair"]
+        fisheye = True
+    out = {"metric": "keypoints+descriptors/sec through one stereo frame per call (%s)" % args.config, "value": kp_pair / (ms * 1e-3),
+           "unit": "keypoints/s", "n_gpus": 1, "steps": hb.get("pairs", 200), "warmup": 10, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": workload, "keypoints_per_pair": kp_pair, "stereo_matches_per_pair": matches,
+                      "timing": "p50 of the wall time per stereo frame at the C ABI, PCIe inside the clock (tools/hostbench)"},
+           "protocols_ms": protocols,
+           "roofline": None,
+           "roofline_note": "a per-call latency configuration: the frame is launch- and PCIe-latency-bound, no kernel runs long "
+                            "enough to be priced against a roofline; the batched headline (`python bench.py`) carries it"}
+    if not args.no_cpu_baseline:
+        try:
+            cb = cpu_stereo_baseline(rows, cols, nf, fisheye)
+            out["cpu_baseline"] = cb
+            out["vs_cpu"] = {"stereo_frame_speedup": cb["ms_per_pair"] / ms, "cpu_protocol": "2 threads (reference)"}
+        except (SystemExit, Exception) as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": str(e)}
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+
+
 def pcie_inclusive(rows, cols, batch, nfeatures, device=0, as_text=False):
     """Runs tools/hostbench (C++ caller of the C ABI, built by __graft_entry__.build()) on the bench frames and
     returns its JSON object: the PCIe-inclusive rates of the drop-in boundary."""
@@ -223,7 +335,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 64; with --config c4: 64 / N, "
+                    "e.g. --config c4 --batch 8 = the shard ONE of eight ranks runs, timed on one GPU)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=752)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -237,9 +350,10 @@ def main():
                     help="record the per-stage hipEvents on every N-th timed step (a set of records costs ~20 us of stream "
                          "time); 0 = max(6, steps / 20): twenty samples over the default 300 steps")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-context measurement")
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="c2: BASELINE configs[1] batched (752x480, --batch frames per GPU, weak scaling); c4: configs[3], "
-                         "64 frames of 1280x720 in total, 64 / N per GPU (strong scaling)")
+                         "64 frames of 1280x720 in total, 64 / N per GPU (strong scaling); c3 / c5: the per-call stereo "
+                         "configurations (EuRoC rectified pair nF 1200 / 1024^2 fisheye pair nF 1500) through tools/hostbench")
     ap.add_argument("--exchange", choices=["cabi", "torch"], default="cabi",
                     help="N > 1: the all-gather through the C ABI (orbfe_mc_*: ncclAllGather issued by liborbfe.so on its own "
                          "stream) or through torch.distributed (c10d's process group)")
@@ -252,6 +366,9 @@ def main():
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
     args = ap.parse_args()
+    if args.config in ("c3", "c5"):
+        os.environ.setdefault("ORBFE_TRIG_TABLE", "2")
+        return per_call_config(args, real_stdout)
     if args.event_every <= 0:
         args.event_every = max(6, args.steps // 20)
     # The same table form at every N (the scaling curve compares like with like): libm's values themselves, 1.03 GB per
@@ -265,9 +382,15 @@ def main():
     from orb_slam3_detailed_comments_kor_amd.multicam import CrossCameraMatcher, PipelinedExchange, ring_pairs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 64
     if args.config == "c4":
         args.rows, args.cols = 720, 1280
-        args.batch = max(64 // max(world, 1), 1)
+        if not batch_given:
+            if 64 % max(world, 1):
+                raise SystemExit("--config c4 shares 64 frames among the ranks: the world size must divide 64 (ADVICE r03)")
+            args.batch = max(64 // max(world, 1), 1)
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`" % (args.gpus, world))
@@ -594,7 +717,12 @@ def main():
         per_kernel = {}
         kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
                      "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
+        # class-weighted issue cycles per vector wave-instruction of each kernel: tools/isa/cost.py over the kernel's listing
+        # (2.7 cycles for the simple 32-bit / 16-bit operations, 4.5 for the rest, measured in profiles/r01_valu_rate.txt)
+        valu_cycles = {"fast": 3.2, "pyramid": 3.66, "octree": 3.73, "desc": 4.57}
+        valu_roof = None
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r04_pmc_summary.json"),
+                                os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
                                 os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
                                 os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         traffic_source = None
@@ -617,6 +745,15 @@ def main():
                             # (profiles/r01_valu_rate.txt)
                             if "SQ_INSTS_VALU" in e and e.get("avg_duration_us"):
                                 valu_issue = min(1.0, e["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6))
+                                # the VALU roof: issue time of the kernel's vector instructions if every one of
+                                # the chip's 1024 SIMDs issued back to back, against the duration measured in THIS run
+                                w = valu_cycles.get(dom)
+                                if w and stage_ms[dom] > 0:
+                                    issue_us = e["SQ_INSTS_VALU"] * w / (1024 * 2.4e3)
+                                    valu_roof = {"issue_us": issue_us, "frac": issue_us / (stage_ms[dom] * 1e3),
+                                                 "wave_instructions": e["SQ_INSTS_VALU"], "cycles_per_instruction": w,
+                                                 "note": "SQ_INSTS_VALU of the counter summary x class-weighted issue cycles "
+                                                         "(tools/isa/cost.py) / (1024 SIMDs x 2.4 GHz) / this run's launch duration"}
             except Exception:
                 traffic = None
         out = {
@@ -629,7 +766,7 @@ def main():
             "settle_steps": settle_steps,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if args.config == "c4" else "weak",
+            "scaling": "strong" if args.config == "c4" and not batch_given else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
@@ -637,7 +774,9 @@ def main():
                 "workload": "%dx%d grayscale, 8-level pyramid, nFeatures=%d, FAST 20/7, %d frames/GPU/step "
                             "resident in HBM, outputs left in HBM (%s); the host-pointer rate of the same workload "
                             "(H2D + D2H inside the clock) is `boundary_value`"
-                            % (W, H, args.nfeatures, B, "BASELINE configs[3]: 64 frames in total, sharded over the ranks"
+                            % (W, H, args.nfeatures, B, ("BASELINE configs[3]: 64 frames in total, sharded over the ranks" if not batch_given
+                                                         else "BASELINE configs[3]'s frame size, %d frames per GPU: the shard one of %d "
+                                                         "ranks runs" % (B, max(64 // B, 1)))
                                if args.config == "c4" else "BASELINE configs[1] batched"),
                 "frames_per_step": B * world,
                 "keypoints_per_step": kp_per_step,
@@ -657,7 +796,10 @@ def main():
                              if dist.is_initialized() else "none"),
             },
             "roofline": {
-                "bound": "hbm",
+                # the kernel's binding roof: HBM by the contract's accounting (achieved / peak / frac below), but its vector
+                # ALUs are busier than its memory system by far -- `valu` prices it against instruction issue instead
+                "bound": "valu" if (valu_roof and valu_roof["frac"] > achieved / HBM_PEAK_GBPS) else "hbm",
+                "valu": valu_roof,
                 "kernel": kernel_of[dom],
                 "stage": dom,
                 "achieved": achieved,

@@ -170,7 +170,7 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
                                int cap_per_img, int32_t* d_n_out, int32_t* d_mono_out);
 /* Two lanes (round 4; the reference's own concurrency on this path is two extractors on two threads, src/Frame.cc:119-122).
  * With lanes = 2 (orbfe_set_lanes, or ORBFE_LANES=2 in the environment when the context is created; default 1) a call of
- * orbfe_extract_batch_device with >= 16 images runs as two half-batches: images [0, h) on the context's stream, [h, nimg) on
+ * orbfe_extract_batch_device with >= 8 images runs as two half-batches: images [0, h) on the context's stream, [h, nimg) on
  * a second stream the context owns, with no event between the two inside a call.  The latency-bound quadtree kernel and
  * the tails of every kernel of one half then run beside the throughput-bound kernels of the other half, and consecutive calls
  * keep both lanes busy (64 x 752x480: 0.19 -> ~0.17 ms per batch).  Results are bit-identical.  What changes is ORDERING:
@@ -182,7 +182,7 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
  * the stereo-matching calls, the host-pointer extract calls, orbfe_mc_*).  A caller that launches its OWN kernels on
  * orbfe_get_stream()'s stream right behind orbfe_extract_batch_device must call orbfe_lanes_join first -- which is why two lanes
  * are opt-in.  The second lane waits for the point of the call on the context's stream, so inputs written on that stream
- * before the call are complete when either half reads them.  Host-pointer calls and batches below 16 images use one lane. */
+ * before the call are complete when either half reads them.  Host-pointer calls and batches below 8 images (ORBFE_LANES_MIN) use one lane. */
 int orbfe_set_lanes(orbfe_ctx*, int lanes /* 1 or 2 */);
 int orbfe_lanes_join(orbfe_ctx*);
 /* For a consumer on a stream of its own that must not hold the context's stream back: records `hip_event` (a hipEvent_t)

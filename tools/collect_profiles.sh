@@ -6,9 +6,13 @@
 set -x
 root=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $root/gpurun_out
-rm -rf $root/gpurun_out/pmc_* $root/gpurun_out/prof_trace $root/gpurun_out/calib
+rm -rf $root/gpurun_out/pmc_* $root/gpurun_out/prof_trace $root/gpurun_out/prof_trace_default $root/gpurun_out/calib
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_trace -- python3 $root/bench.py --no-cpu-baseline --no-pipelined --no-pcie > $root/gpurun_out/prof_trace.log 2>&1
+# (one lane: with two lanes the kernels of the two half-batches overlap and a launch's wall duration is not its throughput;
+# the roofline object of the bench line is measured with one lane too)
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_trace -- python3 $root/bench.py --lanes 1 --no-cpu-baseline --no-pipelined --no-pcie > $root/gpurun_out/prof_trace.log 2>&1
+# ... and the default command (two lanes in the timed region, one lane in the roofline region), for the record
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_trace_default -- python3 $root/bench.py --no-cpu-baseline --no-pipelined --no-pcie --no-cross > $root/gpurun_out/prof_trace_default.log 2>&1
 cd $root
 tools/pmc_pass.sh fetch "FETCH_SIZE"
 tools/pmc_pass.sh write "WRITE_SIZE"
