@@ -1646,9 +1646,10 @@ bool auto_pin(orbfe_ctx* c, const void* p, size_t n)
 {
     if (!c->autoRegister || !p || !n) return false;
     c->autoClock++;
-    auto unpin = [&](orbfe_ctx::AutoPin& o) { // (nothing of this context may still be reading it)
-        (void)hipStreamSynchronize(c->stream);
-        if (c->sIn) (void)hipStreamSynchronize(c->sIn);
+    auto unpin = [&](orbfe_ctx::AutoPin& o) { // (nothing may still be reading it: the range is published process-wide, so another
+        // context -- the right extractor fed from the same driver ring -- may have a copy or an upload kernel in flight on it;
+        // evictions are rare, so the whole device is waited for: ADVICE r03)
+        (void)hipDeviceSynchronize();
         if (pin_remove(o.p)) (void)hipHostUnregister(const_cast<void*>(o.p));
         c->pinnedCache.erase(o.p);
         o.registered = false;
@@ -1690,6 +1691,9 @@ bool auto_pin(orbfe_ctx* c, const void* p, size_t n)
 }
 void auto_pin_release(orbfe_ctx* c)
 {
+    bool any = false;
+    for (const orbfe_ctx::AutoPin& a : c->autoPins) any = any || a.registered;
+    if (any) (void)hipDeviceSynchronize(); // (other contexts may be reading the ranges: see auto_pin)
     for (orbfe_ctx::AutoPin& a : c->autoPins)
         if (a.registered && pin_remove(a.p)) (void)hipHostUnregister(const_cast<void*>(a.p));
     c->autoPins.clear();

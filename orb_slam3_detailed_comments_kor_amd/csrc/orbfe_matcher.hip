@@ -1465,7 +1465,8 @@ struct Scratch { // device allocations of one call
     {
         if (hostOrDev && n && is_device_ptr(hostOrDev)) {
             // (an extractor may still be writing it on its own stream: orbfe_order.h)
-            (void)orbfe_producer_wait(hostOrDev, g_ms);
+            const int w = orbfe_producer_wait(hostOrDev, g_ms);
+            if (w < 0) return w;
             *out = const_cast<uint8_t*>(hostOrDev);
             return 0;
         }
@@ -1711,8 +1712,8 @@ int orbfe_hamming_pairs_device(int device, void* hip_stream, const uint8_t* dA, 
     int r;
     if ((r = select_device(device)) < 0) return r;
     hipStream_t st = matcher_stream(device, hip_stream);
-    (void)orbfe_producer_wait(dA, st);
-    (void)orbfe_producer_wait(dB, st);
+    if (int w = orbfe_producer_wait(dA, st); w < 0) return w;
+    if (int w = orbfe_producer_wait(dB, st); w < 0) return w;
     hipLaunchKernelGGL(k_hamming_pairs, dim3((unsigned)((nB + 63) / 64), (unsigned)((nA + 63) / 64)), dim3(256), 0, st, dA, nA, dB, nB,
                        dD);
     HIP_TRY(hipGetLastError());
@@ -1727,8 +1728,8 @@ int orbfe_bfknn2_device(int device, void* hip_stream, const uint8_t* dQ, int nQ,
     int r;
     if ((r = select_device(device)) < 0) return r;
     hipStream_t st = matcher_stream(device, hip_stream);
-    (void)orbfe_producer_wait(dQ, st);
-    (void)orbfe_producer_wait(dT, st);
+    if (int w = orbfe_producer_wait(dQ, st); w < 0) return w;
+    if (int w = orbfe_producer_wait(dT, st); w < 0) return w;
     hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nQ + 3) / 4)), dim3(256), 0, st, dQ, nQ, dT, nT, d_idx, d_dist);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1742,6 +1743,9 @@ int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_jo
     int r;
     if ((r = select_device(device)) < 0) return r;
     hipStream_t st = matcher_stream(device, hip_stream);
+    // the job records live on the device, so the frames they name cannot be looked up one by one: this stream waits for
+    // every extraction whose outputs were handed out (orbfe_get_device_outputs) -- a few events, fired long ago as a rule
+    if ((r = orbfe_producer_wait_all(st)) < 0) return r;
     const dim3 grid((unsigned)((cap + 63) / 64), (unsigned)njobs);
     // few workgroups: more wavefronts per workgroup share the 64 queries (and fill the chip)
     if ((long)grid.x * njobs >= 2048)
@@ -1941,7 +1945,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         const bool R1 = probs[p].rInd1 != nullptr, R2 = probs[p].rInd2 != nullptr; // the whole set lives in a handle
         const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
         if (!R1) {
-            if (is_device_ptr(a->desc1)) (void)orbfe_producer_wait(a->desc1, g_ms); // (read in place: BowProb::rDesc1)
+            if (is_device_ptr(a->desc1)) { // (read in place: BowProb::rDesc1)
+                if (int w = orbfe_producer_wait(a->desc1, g_ms); w < 0) return w;
+            }
             else std::memcpy(hDesc + r1 * 32, a->desc1, (size_t)a->n1 * 32);
             std::memcpy(hMask + r1, a->mask1, (size_t)a->n1);
             if (a->angle1) std::memcpy(hAng + r1, a->angle1, (size_t)a->n1 * sizeof(float));
@@ -1949,7 +1955,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             if (a->fv1.nn) std::memcpy(hInd + i1Base[p], a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn] * sizeof(int32_t));
         }
         if (!R2) {
-            if (is_device_ptr(a->desc2)) (void)orbfe_producer_wait(a->desc2, g_ms);
+            if (is_device_ptr(a->desc2)) {
+                if (int w = orbfe_producer_wait(a->desc2, g_ms); w < 0) return w;
+            }
             else std::memcpy(hDesc + r2 * 32, a->desc2, (size_t)a->n2 * 32);
             if (a->variant == 1) std::memcpy(hMask + r2, a->mask2, (size_t)a->n2);
             else std::memset(hMask + r2, 1, (size_t)a->n2);
@@ -2055,7 +2063,9 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     }
     Scratch s(device); // (this thread's matcher stream)
     const bool descResident = is_device_ptr(a->desc);
-    if (descResident) (void)orbfe_producer_wait(a->desc, g_ms);
+    if (descResident) {
+        if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) return w;
+    }
     hipError_t e = hipMemcpyAsync(K->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess) e = hipMemcpyAsync(K->mask, a->mask, n, hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess && a->angle) e = hipMemcpyAsync(K->ang, a->angle, n * 4, hipMemcpyHostToDevice, g_ms);
@@ -2998,7 +3008,9 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
     if (a->angle) F->hAngle.assign(a->angle, a->angle + n);
     Scratch s(device); // (this thread's matcher stream)
     const bool descResident = is_device_ptr(a->desc);
-    if (descResident) (void)orbfe_producer_wait(a->desc, g_ms);
+    if (descResident) {
+        if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) return w;
+    }
     hipError_t e = hipMemcpyAsync(F->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
     if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);

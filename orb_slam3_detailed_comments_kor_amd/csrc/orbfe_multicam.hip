@@ -84,7 +84,8 @@ struct ShmHeader {
     std::atomic<int> arrived;
     std::atomic<int> generation;
     std::atomic<int> attached;
-    int pad[13];
+    std::atomic<int> poisoned; // a rank gave up in a barrier: the arrive count is off for good, every later call fails
+    int pad[12];
 };
 struct HostXfer {
     std::string name;
@@ -118,6 +119,7 @@ struct HostXfer {
     int barrier(double seconds = 60.0)
     {
         ShmHeader* h = hdr();
+        if (h->poisoned.load()) return ORBFE_ERR_STATE;
         const int gen = h->generation.load();
         if (h->arrived.fetch_add(1) + 1 == world) {
             h->arrived.store(0);
@@ -126,7 +128,12 @@ struct HostXfer {
         }
         const auto t0 = std::chrono::steady_clock::now();
         while (h->generation.load() == gen) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return ORBFE_ERR_STATE;
+            if (h->poisoned.load()) return ORBFE_ERR_STATE;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+                // this rank's arrival stays counted, so the segment cannot be used again: mark it, for every rank
+                h->poisoned.store(1);
+                return ORBFE_ERR_STATE;
+            }
             std::this_thread::yield();
         }
         return 0;

@@ -46,19 +46,35 @@ inline void orbfe_producer_retire(hipEvent_t ev)
         if (g_orbfeProduced[i].ev == ev) g_orbfeProduced.erase(g_orbfeProduced.begin() + (long)i);
         else i++;
 }
-/* If p lies inside a published range: hipStreamWaitEvent(consumer, its event).  Returns true when a wait was queued. */
-inline bool orbfe_producer_wait(const void* p, hipStream_t consumer)
+/* If p lies inside a published range: hipStreamWaitEvent(consumer, its event).  Returns 1 when a wait was queued, 0 when the
+ * pointer is nobody's published range (the caller's own buffer), < 0 when the wait could not be queued -- the read would then
+ * be unordered, so callers hand the error on.  The wait is issued while the registry is locked:
+ * orbfe_producer_retire (orbfe_destroy on another thread) takes the same lock before the event is destroyed, so the event is
+ * alive for the duration of the call. */
+inline int orbfe_producer_wait(const void* p, hipStream_t consumer)
 {
-    hipEvent_t ev = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_orbfeProdMutex);
-        for (const OrbfeProducedRange& r : g_orbfeProduced)
-            if ((const unsigned char*)p >= r.lo && (const unsigned char*)p < r.hi) {
-                ev = r.ev;
-                break;
-            }
+    std::lock_guard<std::mutex> lock(g_orbfeProdMutex);
+    for (const OrbfeProducedRange& r : g_orbfeProduced)
+        if ((const unsigned char*)p >= r.lo && (const unsigned char*)p < r.hi) {
+            const hipError_t e = hipStreamWaitEvent(consumer, r.ev, 0);
+            return e == hipSuccess ? 1 : -(1000 + (int)e);
+        }
+    return 0;
+}
+/* The same for a call that is handed device pointers it cannot see one by one (orbfe_bfknn2_frames_device: the job table lives
+ * on the device): wait for EVERY published event.  A handful of entries; each wait is a no-op on the device once its event
+ * has fired. */
+inline int orbfe_producer_wait_all(hipStream_t consumer)
+{
+    std::lock_guard<std::mutex> lock(g_orbfeProdMutex);
+    hipEvent_t last = nullptr;
+    for (const OrbfeProducedRange& r : g_orbfeProduced) {
+        if (r.ev == last) continue; // (the three ranges of one context share an event)
+        const hipError_t e = hipStreamWaitEvent(consumer, r.ev, 0);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        last = r.ev;
     }
-    return ev && hipStreamWaitEvent(consumer, ev, 0) == hipSuccess;
+    return 0;
 }
 
 #endif
