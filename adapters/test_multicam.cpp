@@ -1,7 +1,7 @@
 // C++ host of the multi-GPU path (include/orbfe_mc.h): what a multi-camera ORB-SLAM3 process per GPU would run.
 // Spawns `world` ranks (fork before any HIP call), each of which extracts its shard of the frames straight into its
 // slab, exchanges the slabs (ORBFE_MC_RCCL: ncclAllGather over xGMI, one GPU per rank; ORBFE_MC_HOST: shared memory, the
-// ranks may share a device) with two batches in flight, matches its frames against the next camera of the ring, and
+// ranks may share a device) with up to three batches in flight, matches its frames against the next camera of the ring, and
 // checks everything against plain single-GPU calls of the same C ABI (orbfe_extract_batch, orbfe_bfknn2):
 //   * rank r's slab inside the gathered buffer == the descriptors / counts a local extraction of r's frames gives,
 //   * the ring matching == orbfe_bfknn2 on those descriptor sets.
@@ -64,15 +64,19 @@ static int run_rank(int rank, int world, int transport, const std::vector<unsign
     CHECK(hipSetDevice(dev) == hipSuccess, "hipSetDevice");
     CHECK(hipMalloc((void**)&d_img, per * fsz) == hipSuccess, "hipMalloc");
     CHECK(hipMemcpy(d_img, frames.data() + (size_t)rank * per * fsz, per * fsz, hipMemcpyHostToDevice) == hipSuccess, "upload");
-    // three batches through the two slab pairs, two in flight
+    // five batches through the four slab pairs, up to ORBFE_MC_MAX_IN_FLIGHT (3) in flight; a fourth one is refused
     orbfe_mc_view_t v;
     CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == 0, "submit 0");
     CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == 0, "submit 1");
-    CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == ORBFE_ERR_STATE, "a third batch in flight is refused");
-    CHECK(orbfe_mc_extract_exchange_wait(mc, &v) == 0 && v.batch == 0, "wait 0");
     CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == 0, "submit 2");
+    CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == ORBFE_ERR_STATE, "a fourth batch in flight is refused");
+    CHECK(orbfe_mc_extract_exchange_wait(mc, &v) == 0 && v.batch == 0, "wait 0");
+    CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == 0, "submit 3");
     CHECK(orbfe_mc_extract_exchange_wait(mc, &v) == 0 && v.batch == 1, "wait 1");
+    CHECK(orbfe_mc_extract_exchange_submit(mc, d_img, rows, cols, cols, fsz, 0, 0) == 0, "submit 4 (reuses the slab pair of batch 0)");
     CHECK(orbfe_mc_extract_exchange_wait(mc, &v) == 0 && v.batch == 2, "wait 2");
+    CHECK(orbfe_mc_extract_exchange_wait(mc, &v) == 0 && v.batch == 3, "wait 3");
+    CHECK(orbfe_mc_extract_exchange_wait(mc, &v) == 0 && v.batch == 4, "wait 4");
     CHECK(v.slab_bytes == lay.slab_bytes, "slab size");
     std::vector<unsigned char> g((size_t)world * lay.slab_bytes);
     CHECK(hipMemcpy(g.data(), v.gathered, g.size(), hipMemcpyDeviceToHost) == hipSuccess, "download gathered");

@@ -474,7 +474,7 @@ def main():
         if mc is not None:
             # C ABI: extraction into the next slab + ncclAllGather on the library's side stream; two batches in flight
             # (the host waits for batch i-1's collective while batch i is already queued)
-            if mc_inflight[0] == 2:
+            if mc_inflight[0] == pkg.binding.MC_MAX_IN_FLIGHT:  # (three batches in flight: include/orbfe_mc.h)
                 mc_last[0] = mc.wait()
                 mc_inflight[0] -= 1
             mc.submit(d_img.data_ptr(), H, W, W, H * W, lap)
@@ -563,7 +563,7 @@ def main():
             hops = (1,)
 
             def step_cross_mc():
-                if mc_inflight[0] == 2:
+                if mc_inflight[0] == pkg.binding.MC_MAX_IN_FLIGHT:
                     v = mc.wait()
                     mc_inflight[0] -= 1
                     mc.match_ring_async(v.batch, hops)  # queued behind the extraction already in the stream

@@ -72,11 +72,13 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
 void orbfe_mc_destroy(orbfe_mc*);
 
 /* Extraction of this rank's `frames_per_rank` images (DEVICE pointer, as orbfe_extract_batch_device) into the next slab
- * and, ordered after it on a side stream, the all-gather.  Returns at once; at most two batches in flight
- * (ORBFE_ERR_STATE otherwise).  Keypoints of the batch stay in a device buffer of the handle (orbfe_mc_view_t::d_kps). */
+ * and, ordered after it on a side stream, the all-gather.  Returns at once; at most ORBFE_MC_MAX_IN_FLIGHT (3; round 3: 2)
+ * batches in flight (ORBFE_ERR_STATE otherwise): the handle owns ORBFE_MC_SLOTS (4) slab / gathered buffer pairs.  Keypoints of the batch stay in a device buffer of the handle (orbfe_mc_view_t::d_kps). */
 int orbfe_mc_extract_exchange_submit(orbfe_mc*, const uint8_t* d_imgs, int rows, int cols, size_t pitch,
                                      size_t img_stride_bytes, int lap0, int lap1);
 
+#define ORBFE_MC_SLOTS 4
+#define ORBFE_MC_MAX_IN_FLIGHT 3
 typedef struct {
     const uint8_t* gathered;   /* world * slab_bytes, device memory (host memory for a ctx == NULL handle) */
     const uint8_t* slab;       /* this rank's slab of the same batch                                       */

@@ -150,6 +150,7 @@ class _McView(C.Structure):
 
 
 MC_RCCL, MC_HOST, MC_ID_BYTES = 0, 1, 128
+MC_MAX_IN_FLIGHT = 3  # ORBFE_MC_MAX_IN_FLIGHT (include/orbfe_mc.h): batches a handle accepts before a wait is due
 
 
 def _share_hip_runtime_with_torch():

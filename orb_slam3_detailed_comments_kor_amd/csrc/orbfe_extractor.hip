@@ -301,7 +301,22 @@ void lane_quiesce(orbfe_ctx* c)
 int lane_setup(orbfe_ctx* c)
 {
     if (c->laneStream) return 0;
-    HIP_TRY(hipStreamCreateWithFlags(&c->laneStream, hipStreamNonBlocking));
+    {
+        // The second lane runs on a stream of the LOWEST priority (ORBFE_LANE_PRIO: 1 = lowest, the default; 0 = normal;
+        // -1 = highest).  Priorities have hardware queues of their own, while the streams of one priority are dealt round-robin
+        // to four queues (GPU_MAX_HW_QUEUES): on a normal-priority stream the lane can land in a queue behind another stream's
+        // event wait -- with the all-gather's stream of orbfe_mc_* in the process it did: 0.262 ms per step instead of 0.175.
+        // Measured, 64 x 752x480 (profiles/r04_lane_priority.txt): lowest 0.1685, normal 0.1701, highest 0.1809 ms per step;
+        // behind a one-rank RCCL exchange: lowest 0.1724, normal 0.1803, highest 0.1748.
+        int prio = 1, least = 0, greatest = 0;
+        if (const char* e = getenv("ORBFE_LANE_PRIO")) prio = atoi(e);
+        if (prio != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->laneStream, hipStreamNonBlocking, prio < 0 ? greatest : least) == hipSuccess) {
+        } else {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&c->laneStream, hipStreamNonBlocking));
+        }
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->evLaneFork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evLaneJoin, hipEventDisableTiming));
     return 0;

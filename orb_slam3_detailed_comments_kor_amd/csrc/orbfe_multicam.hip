@@ -181,10 +181,14 @@ struct orbfe_mc {
         orbfe_knn2_job* d_jobs = nullptr; // job table of the last hops used on this buffer
         int njobs = 0;
         std::vector<int> jobHops;
-    } buf[2];
-    uint8_t* h_stage[2] = {nullptr, nullptr}; // pinned staging of the host transport per buffer: slab out | gathered in
-    orbfe_kp* d_kps[2] = {nullptr, nullptr};
-    int32_t* d_mono[2] = {nullptr, nullptr};
+    } buf[ORBFE_MC_SLOTS];
+    // (round 4: four slab pairs and three batches in flight instead of two and two.  With two, the host could submit batch
+    // k + 1 only after the collective of batch k - 1; once a context runs its batches on two lanes the second lane finishes --
+    // and the collective starts -- late in the step, the host was released late, and the GPU ran dry between batches:
+    // 0.268 instead of 0.206 ms per step on the one-GPU rehearsal.)
+    uint8_t* h_stage[ORBFE_MC_SLOTS] = {}; // pinned staging of the host transport per buffer: slab out | gathered in
+    orbfe_kp* d_kps[ORBFE_MC_SLOTS] = {};
+    int32_t* d_mono[ORBFE_MC_SLOTS] = {};
     long submitted = 0, retired = 0;
     int lastView = -1; // buffer index of the batch last returned by _wait
     int32_t *d_idx = nullptr, *d_dist = nullptr;
@@ -287,11 +291,11 @@ void orbfe_mc_destroy(orbfe_mc* m)
             std::free(b.slab);
         }
     }
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < ORBFE_MC_SLOTS; k++) {
         if (m->d_kps[k]) (void)hipFree(m->d_kps[k]);
         if (m->d_mono[k]) (void)hipFree(m->d_mono[k]);
     }
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < ORBFE_MC_SLOTS; k++)
         if (m->h_stage[k]) (void)hipHostFree(m->h_stage[k]);
     if (m->d_idx) (void)hipFree(m->d_idx);
     if (m->d_dist) (void)hipFree(m->d_dist);
@@ -327,8 +331,23 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
         if ((r = orbfe_get_stream(ctx, &st, &m->device)) < 0) return fail(r);
         m->sCtx = (hipStream_t)st;
         if (hipSetDevice(m->device) != hipSuccess) return fail(ORBFE_ERR_NODEV);
-        if (hipStreamCreateWithFlags(&m->sComm, hipStreamNonBlocking) != hipSuccess) return fail(ORBFE_ERR_STATE);
-        for (int k = 0; k < 2; k++) {
+        {
+            // The collective's stream gets the HIGHEST priority: priorities have hardware queues of their own, and the runtime
+            // deals the streams of one priority round-robin to only four queues (GPU_MAX_HW_QUEUES) -- with the context's two
+            // lanes, torch's streams and this one, the collective's event wait ended up in FRONT of the second lane's kernels in
+            // a shared queue and stalled them (round 4, one-GPU rehearsal: 0.262 ms per step, 0.175 with eight queues).  The
+            // all-gather is tiny and on the critical path of the other ranks, so priority is right for it anyway.
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+                (void)hipGetLastError();
+                least = greatest = 0;
+            }
+            if (hipStreamCreateWithPriority(&m->sComm, hipStreamNonBlocking, greatest) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipStreamCreateWithFlags(&m->sComm, hipStreamNonBlocking) != hipSuccess) return fail(ORBFE_ERR_STATE);
+            }
+        }
+        for (int k = 0; k < ORBFE_MC_SLOTS; k++) {
             orbfe_mc::Buf& b = m->buf[k];
             if (hipMalloc((void**)&b.slab, m->lay.slab_bytes) != hipSuccess ||
                 hipMalloc((void**)&b.gathered, (size_t)world * m->lay.slab_bytes) != hipSuccess ||
@@ -364,7 +383,7 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
         if (id128) std::memcpy(idz, id128, ORBFE_MC_ID_BYTES);
         else std::snprintf(idz, sizeof idz, "solo%ld", (long)getpid());
         if ((r = m->host.open_(idz, rank, world, m->lay.slab_bytes)) < 0) return fail(r);
-        for (int k = 0; ctx && k < 2; k++)
+        for (int k = 0; ctx && k < ORBFE_MC_SLOTS; k++)
             if (hipHostMalloc((void**)&m->h_stage[k], (size_t)(world + 1) * m->lay.slab_bytes, hipHostMallocDefault) != hipSuccess)
                 return fail(ORBFE_ERR_STATE);
         if ((r = m->host.barrier()) < 0) return fail(r); // everybody is attached before the first exchange
@@ -383,7 +402,7 @@ int orbfe_mc_extract_exchange_submit(orbfe_mc* m, const uint8_t* d_imgs, int row
                                      size_t img_stride_bytes, int lap0, int lap1)
 {
     if (!m || !m->ctx || !d_imgs) return ORBFE_ERR_ARGS;
-    if (m->submitted - m->retired >= 2) return ORBFE_ERR_STATE;
+    if (m->submitted - m->retired >= ORBFE_MC_MAX_IN_FLIGHT) return ORBFE_ERR_STATE;
     MC_HIP_TRY(hipSetDevice(m->device));
     {
         // (the extractor's stream is asked for at every submit -- orbfe_set_stream after orbfe_mc_create replaces it,
@@ -396,9 +415,9 @@ int orbfe_mc_extract_exchange_submit(orbfe_mc* m, const uint8_t* d_imgs, int row
             m->sCtx = (hipStream_t)st;
         }
     }
-    const int k = (int)(m->submitted & 1);
+    const int k = (int)(m->submitted % ORBFE_MC_SLOTS);
     orbfe_mc::Buf& b = m->buf[k];
-    // the slab pair was last read by the collective (and the matcher) of two batches ago: the extractor's stream waits
+    // the slab pair was last read by the collective (and the matcher) of ORBFE_MC_SLOTS batches ago: the extractor's stream waits
     // for that collective; the matcher runs on the extractor's stream itself
     if (b.batch >= 0) MC_HIP_TRY(hipStreamWaitEvent(m->sCtx, b.evGathered, 0));
     int r = orbfe_extract_batch_device(m->ctx, m->frames, d_imgs, rows, cols, pitch, img_stride_bytes, lap0, lap1, m->d_kps[k],
@@ -439,7 +458,7 @@ int orbfe_mc_extract_exchange_wait(orbfe_mc* m, orbfe_mc_view_t* view)
     if (!m || !m->ctx || !view) return ORBFE_ERR_ARGS;
     if (m->submitted == m->retired) return ORBFE_ERR_STATE;
     MC_HIP_TRY(hipSetDevice(m->device));
-    const int k = (int)(m->retired & 1);
+    const int k = (int)(m->retired % ORBFE_MC_SLOTS);
     orbfe_mc::Buf& b = m->buf[k];
     MC_HIP_TRY(hipEventSynchronize(b.evGathered));
     if (m->transport == ORBFE_MC_HOST && m->world > 1) {
@@ -509,7 +528,7 @@ int orbfe_mc_match_ring_async(orbfe_mc* m, const int* hops, int nhops, long batc
     if (!m || !m->ctx || nhops <= 0 || !hops) return ORBFE_ERR_ARGS;
     MC_HIP_TRY(hipSetDevice(m->device));
     int k = -1;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < ORBFE_MC_SLOTS; i++)
         if (m->buf[i].batch == batch) k = i;
     if (k < 0) return ORBFE_ERR_STATE;
     orbfe_mc::Buf& b = m->buf[k];

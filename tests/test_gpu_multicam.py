@@ -86,7 +86,7 @@ def test_ctypes_handle_against_the_oracle(oracle):
 def test_two_lane_context_behind_the_exchange(oracle):
     """A context with orbfe_set_lanes(2) under orbfe_mc_*: 16 frames per batch run as two half-batches on two streams; the
     collective waits for BOTH lanes (orbfe_lanes_record), the extractor's stream is not held back.  Slabs of consecutive
-    batches (two in flight) equal the oracle's extraction, including the second lane's frames."""
+    batches (three in flight) equal the oracle's extraction, including the second lane's frames."""
     import torch
     import orb_slam3_detailed_comments_kor_amd as pkg
     from orb_slam3_detailed_comments_kor_amd import binding
@@ -104,7 +104,7 @@ def test_two_lane_context_behind_the_exchange(oracle):
     inflight = 0
     views = []
     for b in range(6):
-        if inflight == 2:
+        if inflight == binding.MC_MAX_IN_FLIGHT:
             views.append(mc.wait())
             inflight -= 1
             g = np.empty(mc.slab_bytes, np.uint8)
