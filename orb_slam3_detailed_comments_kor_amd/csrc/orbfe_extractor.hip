@@ -189,6 +189,7 @@ struct orbfe_ctx : orbfe_geom_state {
     // any other entry point).  Measured (tools/overlap_probe.hip): a fork + join pair per call costs ~13 us of latency
     // each way when the two streams ping-pong, a one-way wait ~3 us.
     int lanes = 1;
+    int laneSplitPct = 0;        // ORBFE_LANE_SPLIT (tuning)
     int lanesMin = 8;            // smallest batch that is split (ORBFE_LANES_MIN; 8 x 1280x720: 0.085 -> 0.080 ms, 4: 0.069 -> 0.066)
     hipStream_t laneStream = nullptr;
     hipEvent_t evLaneFork = nullptr, evLaneJoin = nullptr;
@@ -1372,6 +1373,9 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     // Two lanes (see orbfe_ctx::lanes): halves that are multiples of 8 images where possible (whole images per XCD)
     int laneSplit = ((nimg / 2 + 7) / 8) * 8;
     if (laneSplit >= nimg) laneSplit = nimg / 2;
+    if (c->laneSplitPct > 0) { // ORBFE_LANE_SPLIT (tuning): per cent of the batch on the context's own stream
+        laneSplit = std::min(nimg - 1, std::max(1, (nimg * c->laneSplitPct / 100 + 4) / 8 * 8));
+    }
     const bool useLanes = allowLanes && c->lanes == 2 && nimg >= c->lanesMin && c->pyrFused && !hostTrigCheck && !mirror && !d_errOut &&
                           c->nStreams == 1;
     if (c->lanePending && !(useLanes && c->laneSplit == laneSplit && c->laneImgs == nimg)) {
@@ -2170,6 +2174,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("ORBFE_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("ORBFE_LANES_MIN")) c->lanesMin = std::max(2, atoi(e));
+    if (const char* e = getenv("ORBFE_LANE_SPLIT")) c->laneSplitPct = std::min(95, std::max(0, atoi(e)));
     if (c->nStreams > 1) {
         bool ok = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < c->nStreams && ok; k++)

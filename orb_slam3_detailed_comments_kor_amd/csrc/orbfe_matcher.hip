@@ -339,6 +339,98 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
         cD = load_desc(desc2 + (size_t)cIdx * 32);
         cAng = ang2[cIdx];
     }
+    // ---- Round 4: nodes of at most 64 x 64 (every node of a real FeatureVector) in two phases instead of one dependent chain
+    // per row.  Phase 1: LANE r scans ALL candidates for ROW r by itself (the candidates' descriptors come as wave-uniform
+    // broadcasts, v_readlane; no cross-lane reduction, iterations independent of each other) and keeps the two smallest keys
+    // among the left-camera candidates and the smallest among the right-camera ones -- ignoring which candidates earlier rows
+    // will have taken.  Phase 2: the rows in order, as the reference walks them: a row whose remembered keys name no taken
+    // candidate is decided from them (the common case: its scan would have seen exactly these); a row that lost one of its
+    // keys to an earlier row is scanned again across the lanes without the taken candidates.  The sequential part shrinks from
+    // ~150 dependent instructions per row to the acceptance alone.
+    if (N.n1 <= 64 && N.n2 <= 64) {
+        unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, r0 = 0xFFFFFFFFu;
+        for (int c = 0; c < N.n2; c++) { // (uniform)
+            if (!__builtin_amdgcn_readlane((int)cOk, c)) continue;
+            Desc d2;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cD.w[w] & 0xFFFFFFFFull), c);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cD.w[w] >> 32), c);
+                d2.w[w] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            }
+            const unsigned key = ((unsigned)hamming(rD, d2) << 20) | (unsigned)c;
+            const bool right = variant == 0 && Nleft != -1 && __builtin_amdgcn_readlane(cIdx, c) >= Nleft; // (uniform)
+            if (!right) {
+                if (key < k0) {
+                    k1 = k0;
+                    k0 = key;
+                } else if (key < k1)
+                    k1 = key;
+            } else if (key < r0)
+                r0 = key;
+        }
+        unsigned long long takenBits = 0ull; // candidates (positions in the node's list) matched so far
+        for (int r = 0; r < N.n1; r++) {
+            if (!__builtin_amdgcn_readlane((int)rOk, r)) continue;
+            const int idx1 = __builtin_amdgcn_readlane(rIdx, r);
+            const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rAng), r));
+            unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)k0, r), b1 = (unsigned)__builtin_amdgcn_readlane((int)k1, r),
+                     q0 = (unsigned)__builtin_amdgcn_readlane((int)r0, r);
+            auto gone = [&](unsigned k) { return k != 0xFFFFFFFFu && ((takenBits >> (k & 63u)) & 1ull) != 0ull; };
+            if (gone(b0) || gone(b1) || gone(q0)) { // (uniform) an earlier row took one of them: this row's scan again, without
+                Desc d1;                            // the taken candidates, across the lanes (lane c = candidate c)
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] & 0xFFFFFFFFull), r);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] >> 32), r);
+                    d1.w[w] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+                }
+                unsigned e0 = 0xFFFFFFFFu, e1 = 0xFFFFFFFFu, f0 = 0xFFFFFFFFu, f1 = 0xFFFFFFFFu;
+                if (lane < N.n2 && cOk && !((takenBits >> lane) & 1ull)) {
+                    const unsigned key = ((unsigned)hamming(d1, cD) << 20) | (unsigned)lane;
+                    if (variant == 0 && Nleft != -1 && cIdx >= Nleft) f0 = key;
+                    else e0 = key;
+                }
+                wave_two_min(e0, e1);
+                wave_two_min(f0, f1);
+                b0 = e0;
+                b1 = e1;
+                q0 = f0;
+            }
+            const int bestDist1 = b0 == 0xFFFFFFFFu ? 256 : (int)(b0 >> 20);
+            const int bestDist2 = b1 == 0xFFFFFFFFu ? 256 : (int)(b1 >> 20);
+            const int bestDist1R = q0 == 0xFFFFFFFFu ? 256 : (int)(q0 >> 20);
+            const bool passTh = variant == 0 ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW); // :373 vs :906
+            if (passTh) {
+                if ((float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+                    const int cpos = (int)(b0 & 0xFFFFF);
+                    const int idx2 = __builtin_amdgcn_readlane(cIdx, cpos);
+                    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cAng), cpos));
+                    takenBits |= 1ull << cpos;
+                    if (lane == 0) {
+                        if (variant == 0) {
+                            match[idx2] = idx1;
+                            bins[idx2] = (int8_t)rot_bin(a1, a2);
+                        } else {
+                            match[idx1] = idx2;
+                            bins[idx1] = (int8_t)rot_bin(a1, a2);
+                        }
+                    }
+                }
+                if (variant == 0 && bestDist1R <= TH_LOW) { // ratio test is "|| true" in the reference (:405)
+                    const int cpos = (int)(q0 & 0xFFFFF);
+                    const int idx2 = __builtin_amdgcn_readlane(cIdx, cpos);
+                    const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cAng), cpos));
+                    takenBits |= 1ull << cpos;
+                    if (lane == 0) {
+                        match[idx2] = idx1;
+                        bins[idx2] = (int8_t)rot_bin(a1, a2);
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int r = 0; r < N.n1; r++) {
         int idx1;
         float a1;
@@ -1327,6 +1419,10 @@ thread_local hipStream_t g_ms = nullptr; // stream of the matcher call in progre
 
 struct Scratch { // device allocations of one call
     Arena* ar = nullptr;
+    // Latency path (round 4): a call whose staged inputs are a few KB hands the KERNEL the pinned mirror itself (device-side
+    // address of the host memory) instead of copying it to the device first: one stream command less in front of the launch.
+    // Set before the first up() / reserve(); needs the arena's mirror (else the call takes the copy path as before).
+    bool inPlace = false;
     std::vector<void*> overflow;
     std::vector<std::pair<size_t, size_t>> staged; // (offset, bytes) runs waiting in the pinned mirror
     struct Down {
@@ -1394,6 +1490,10 @@ struct Scratch { // device allocations of one call
         if (host && n) {
             if (inArena && ar->pin) { // stage; adjacent uploads merge into one run
                 std::memcpy(ar->pin + at, host, n * sizeof(T));
+                if (inPlace && ar->pinDev) {
+                    *out = (T*)(ar->pinDev + at); // (read where it lies)
+                    return 0;
+                }
                 if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
                 else staged.emplace_back(at, bytes);
             } else {
@@ -1425,8 +1525,12 @@ struct Scratch { // device allocations of one call
         if (ar->base && ar->pin && ar->off + bytes <= ar->cap) {
             const size_t at = ar->off;
             ar->off += bytes;
-            *dev = (T*)(ar->base + at);
             *stage = (T*)(ar->pin + at);
+            if (inPlace && ar->pinDev) {
+                *dev = (T*)(ar->pinDev + at);
+                return 0;
+            }
+            *dev = (T*)(ar->base + at);
             if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
             else staged.emplace_back(at, bytes);
             return 0;
@@ -1889,6 +1993,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
+    // (what travels: node list, problem records, the pooled sets.  A search against resident keyframes sends ~15 KB: the kernel
+    // reads that from the pinned staging in place)
+    s.inPlace = nodes.size() * sizeof(BowNode) + (size_t)rows * 37 + indTotal * 4 + ovTotal <= (48u << 10);
     BowNode* dN;
     BowProb* dP;
     uint8_t *dDesc, *dMask, *taken, *hDesc, *hMask;
@@ -2155,6 +2262,7 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
+    s.inPlace = rows.size() * sizeof(TriRowB) + (size_t)count * (sizeof(TriProb) + 64) <= (48u << 10); // (rows + pair records only)
     TriRowB* dR;
     TriProb *dP, *hP;
     float *dTab, *hTab;
