@@ -17,10 +17,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "../../include/orbfe.h"
@@ -282,23 +284,57 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
     return bin;
 }
 
+// Completion word of a latency-path call (round 4).  The kernels below write their (small) results into page-locked HOST memory
+// themselves; the last workgroup to finish then writes the call's sequence number into a flag word next to them, and the host
+// spins on that word instead of going through hipStreamSynchronize: the end-of-kernel cache release, the completion signal and
+// the runtime's wait cost ~5 us of a 12-us launch + wait round trip on this box (tools/latency_probe.hip: 12.4 -> 7.5 us).
+// A wavefront that is done waits for its own result stores to be acknowledged (the mirror is fine-grained host memory:
+// uncached on the device, so there is nothing to write back) and counts itself in LDS; the last wavefront of a workgroup adds
+// one to a device counter; the workgroup that brings the counter to `total` resets it for the next call (calls on one stream
+// are ordered) and publishes the flag behind a system-scope fence.  Only for grids of a few hundred workgroups: the counter
+// is one address (a 12 000-wavefront triangulation batch with a system fence and an atomic per wavefront took 0.36 ms
+// instead of 0.13).
+struct DoneSig {
+    unsigned* ctr;  // device memory, zero between calls
+    unsigned* flag; // the kernel's address of the page-locked flag word; nullptr: no completion word (the host synchronises)
+    unsigned seq, total /* workgroups */, waves /* wavefronts of the whole grid that report */;
+};
+// at the top of the kernel, before any wavefront can leave (every wavefront of the workgroup executes it)
+__device__ __forceinline__ void done_begin(const DoneSig& d, unsigned* wgCnt)
+{
+    if (!d.flag) return; // (uniform)
+    if (threadIdx.x == 0) *wgCnt = 0u;
+    __syncthreads();
+}
+// wavesPerWG = 4; the last workgroup may hold fewer reporting wavefronts
+__device__ __forceinline__ void wave_done(const DoneSig& d, unsigned* wgCnt)
+{
+    if (!d.flag) return; // (wave-uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's result stores have been acknowledged
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned mine = min(4u, d.waves - 4u * blockIdx.x);
+        if (atomicAdd(wgCnt, 1u) + 1u == mine) {
+            if (atomicAdd(d.ctr, 1u) + 1u == d.total) {
+                *d.ctr = 0u;
+                __threadfence_system();
+                *(volatile unsigned*)d.flag = d.seq;
+            }
+        }
+    }
+}
+
 // One wavefront per vocabulary node shared by both feature vectors.  Every feature belongs to
 // exactly one node, so nodes are independent; inside a node the rows of set 1 stay sequential
 // (a match removes its set-2 feature from later rows, :324,:884,:911) while the candidates of a
 // row are spread over the lanes.  variant 0: (KeyFrame*,Frame&), match2[idx2] = idx1;
 // variant 1: (KeyFrame*,KeyFrame*), match1[idx1] = idx2.  bins[] gets the rotation bin per match.
-__global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ nodes, int nNodes,
-                                                    const BowProb* __restrict__ probs,
-                                                    const uint8_t* __restrict__ descPool,
-                                                    const uint8_t* __restrict__ maskPool,
-                                                    const float* __restrict__ angPool,
-                                                    const int32_t* __restrict__ indPool,
-                                                    int32_t* __restrict__ matchPool, int8_t* __restrict__ binsPool,
-                                                    uint8_t* __restrict__ takenPool)
+__device__ __forceinline__ void bow_node(int nd, const BowNode* __restrict__ nodes, const BowProb* __restrict__ probs,
+                                         const uint8_t* __restrict__ descPool, const uint8_t* __restrict__ maskPool,
+                                         const float* __restrict__ angPool, const int32_t* __restrict__ indPool,
+                                         int32_t* __restrict__ matchPool, int8_t* __restrict__ binsPool,
+                                         uint8_t* __restrict__ takenPool)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nd = blockIdx.x * 4 + wave;
-    if (nd >= nNodes) return;
+    const int lane = threadIdx.x & 63;
     const BowNode N = nodes[nd];
     const BowProb Pb = probs[N.prob];
     // (array by array: a set whose descriptors alone are resident -- an extractor's output slab -- pools the rest)
@@ -521,6 +557,23 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ nodes, int nNodes,
+                                                    const BowProb* __restrict__ probs,
+                                                    const uint8_t* __restrict__ descPool,
+                                                    const uint8_t* __restrict__ maskPool,
+                                                    const float* __restrict__ angPool,
+                                                    const int32_t* __restrict__ indPool,
+                                                    int32_t* __restrict__ matchPool, int8_t* __restrict__ binsPool,
+                                                    uint8_t* __restrict__ takenPool, const DoneSig done)
+{
+    __shared__ unsigned wgCnt;
+    done_begin(done, &wgCnt);
+    const int nd = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (nd >= nNodes) return;
+    bow_node(nd, nodes, probs, descPool, maskPool, angPool, indPool, matchPool, binsPool, takenPool);
+    wave_done(done, &wgCnt);
+}
+
 // ------------------------------------------------------------------- K-TRI
 struct TriRow {
     int idx1, off2, n2;
@@ -538,8 +591,10 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
                                                     const int32_t* __restrict__ ind2, const float* __restrict__ F12,
                                                     float epx, float epy, const float* __restrict__ sf2,
                                                     const float* __restrict__ sig2, int onlyStereo, int coarse,
-                                                    int32_t* __restrict__ match12)
+                                                    int32_t* __restrict__ match12, const DoneSig done)
 {
+    __shared__ unsigned wgCnt;
+    done_begin(done, &wgCnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rix = blockIdx.x * 4 + wave;
     if (rix >= nRows) return;
@@ -578,6 +633,7 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     }
     best = wave_min_u32(best);
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+    wave_done(done, &wgCnt);
 }
 
 // K-TRI for ONE current keyframe against several neighbours in one launch (round 4; LocalMapping::CreateNewMapPoints
@@ -598,8 +654,11 @@ struct TriRowB {
 __global__ __launch_bounds__(256) void k_search_tri_batch(const TriRowB* __restrict__ rows, int nRows,
                                                           const TriProb* __restrict__ probs,
                                                           const uint8_t* __restrict__ desc1, const float* __restrict__ kp1,
-                                                          const float* __restrict__ uR1, int32_t* __restrict__ matchPool)
+                                                          const float* __restrict__ uR1, int32_t* __restrict__ matchPool,
+                                                          const DoneSig done)
 {
+    __shared__ unsigned wgCnt;
+    done_begin(done, &wgCnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rix = blockIdx.x * 4 + wave;
     if (rix >= nRows) return;
@@ -641,6 +700,7 @@ __global__ __launch_bounds__(256) void k_search_tri_batch(const TriRowB* __restr
     best = wave_min_u32(best);
     if (lane == 0)
         matchPool[Q.outBase + idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+    wave_done(done, &wgCnt);
 }
 
 // K-TRI with the KannalaBrandt8 gate (fisheye monocular pairs and two-camera rigs): same row / candidate
@@ -1398,11 +1458,17 @@ struct Arena {
     uint8_t* pin = nullptr; // pinned host mirror of the arena: inputs are staged here and go up in ONE transfer,
                             // outputs come down into it in ONE transfer
     uint8_t* pinDev = nullptr; // the address a KERNEL uses for `pin` (results written into the mirror by the kernel itself)
+    bool pinCoherent = false;  // `pin` was allocated hipHostMallocCoherent
     size_t cap = 0, off = 0, want = 0;
     // The calling thread's own non-blocking stream on this device: matcher calls of the Tracking, LocalMapping and
     // LoopClosing threads neither serialise with each other nor synchronise with the legacy null stream (and through
     // it with every blocking stream of the process, e.g. torch's default stream).
     hipStream_t stream = nullptr;
+    // completion word of the latency-path calls (DoneSig): device counter, page-locked flag, sequence number
+    unsigned* doneCtr = nullptr;
+    unsigned* doneFlag = nullptr;    // host address
+    unsigned* doneFlagDev = nullptr; // the kernel's address of the same word
+    unsigned doneSeq = 0;
     ~Arena()
     { // thread exit: give the scratch back (a thread that called the matcher once used to leak it)
         if (device < 0) return;
@@ -1410,6 +1476,8 @@ struct Arena {
         if (stream) (void)hipStreamSynchronize(stream);
         if (base) (void)hipFree(base);
         if (pin) (void)hipHostFree(pin);
+        if (doneCtr) (void)hipFree(doneCtr);
+        if (doneFlag) (void)hipHostFree(doneFlag);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1452,7 +1520,11 @@ struct Scratch { // device allocations of one call
                 ar->cap = want;
                 void* h = nullptr;
                 ar->pinDev = nullptr;
-                if (hipHostMalloc(&h, want) == hipSuccess) {
+                // (explicitly fine-grained: kernels write results into it that the host reads while the kernel is, for the
+                // runtime, still running -- DoneSig; without the flag the default allocation serves the same way)
+                ar->pinCoherent = hipHostMalloc(&h, want, hipHostMallocCoherent) == hipSuccess;
+                if (!ar->pinCoherent) (void)hipGetLastError();
+                if (ar->pinCoherent || hipHostMalloc(&h, want) == hipSuccess) {
                     ar->pin = (uint8_t*)h;
                     void* dv = nullptr;
                     if (hipHostGetDevicePointer(&dv, h, 0) == hipSuccess) ar->pinDev = (uint8_t*)dv;
@@ -1629,6 +1701,58 @@ struct Scratch { // device allocations of one call
             if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
         }
         downs.clear();
+        return e == hipSuccess ? 0 : -(1000 + (int)e);
+    }
+    // Completion word of a call whose results the kernel writes into the pinned mirror (DoneSig above).  done_sig() hands the
+    // kernel the call's sequence number (total = the wavefronts that will report); wait_done() spins on the flag for a bounded
+    // time -- a call that takes longer than that gains nothing from spinning -- and falls back to the stream synchronisation,
+    // which also surfaces a failed launch.  ORBFE_MATCHER_SPIN=0 switches the flag off (A/B).  The flag word is allocated
+    // coherent like the mirror.
+    DoneSig done_sig(unsigned waves /* the kernel runs four per workgroup */)
+    {
+        DoneSig d{nullptr, nullptr, 0u, (waves + 3u) / 4u, waves};
+        static const bool enabled = [] {
+            const char* e = getenv("ORBFE_MATCHER_SPIN");
+            return !(e && e[0] == '0');
+        }();
+        // (only where nothing is uploaded in front of the kernel: a copy command queued behind a kernel the runtime still
+        // holds as running came out slower -- and only for small grids, see DoneSig)
+        if (!enabled || waves == 0 || d.total > 256u || !inPlace || !ar->pinCoherent) return d;
+        if (!ar->doneCtr) {
+            void *c = nullptr, *h = nullptr, *dv = nullptr;
+            if (hipMalloc(&c, 64) != hipSuccess || hipMemset(c, 0, 64) != hipSuccess || hipHostMalloc(&h, 64, hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (c) (void)hipFree(c);
+                if (h) (void)hipHostFree(h);
+                return d;
+            }
+            ar->doneCtr = (unsigned*)c;
+            ar->doneFlag = (unsigned*)h;
+            ar->doneFlagDev = (unsigned*)dv;
+            *ar->doneFlag = 0u;
+        }
+        if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+        d.ctr = ar->doneCtr;
+        d.flag = ar->doneFlagDev;
+        d.seq = ar->doneSeq;
+        return d;
+    }
+    int wait_done(const DoneSig& d)
+    {
+        if (d.flag) {
+            const volatile unsigned* f = ar->doneFlag;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0;; it++) {
+                if (*f == d.seq) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    return 0;
+                }
+                __builtin_ia32_pause();
+                if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
+            }
+        }
+        const hipError_t e = hipStreamSynchronize(g_ms);
         return e == hipSuccess ? 0 : -(1000 + (int)e);
     }
 };
@@ -1895,10 +2019,33 @@ struct orbfe_keyframe {
 
 namespace {
 // SearchByBoW over `count` problems; kf1 / kf2 (arrays or null, entries may be null) name sets that live in handles
+// staged inputs up to this size are read by the kernel from the pinned staging in place (ORBFE_MATCHER_INPLACE_KB, default 128: 85 KB of a host-array SearchByBoW read in place took 0.037 instead of 0.045 ms)
+static size_t inplace_limit()
+{
+    static const size_t v = [] {
+        const char* e = getenv("ORBFE_MATCHER_INPLACE_KB");
+        const long kb = e ? atol(e) : 128;
+        return (size_t)(kb < 0 ? 0 : kb) << 10;
+    }();
+    return v;
+}
+// tuning only (tools/ab_build.sh trace "-DORBFE_CALL_TRACE", ORBFE_CALL_TRACE=1 in the environment): where the host time of a
+// matcher call goes, printed per call
+#ifdef ORBFE_CALL_TRACE
+#define PTR_BEGIN()                                   \
+    auto tr0 = std::chrono::steady_clock::now();      \
+    double trT[8] = {0};                              \
+    int trK = 0
+#define PTR() do { auto n_ = std::chrono::steady_clock::now(); trT[trK++] = std::chrono::duration<double, std::micro>(n_ - tr0).count(); tr0 = n_; } while (0)
+#else
+#define PTR_BEGIN() do { } while (0)
+#define PTR() do { } while (0)
+#endif
 int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* const* kf1, orbfe_keyframe* const* kf2,
             int32_t* const* match, int* nmatches)
 {
     if (count < 0 || (count && (!args || !match || !nmatches))) return ORBFE_ERR_ARGS;
+    PTR_BEGIN();
     // pass 1: validate, lay the pools out, list the shared vocabulary nodes (merge-join of the two FeatureVectors)
     std::vector<BowNode> nodes;
     std::vector<BowProb> probs(count);
@@ -1988,6 +2135,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         rows += (K1 ? 0 : a->n1) + (K2 ? 0 : a->n2);
     }
     if (nodes.empty()) return 0;
+    PTR(); // pass 1
     bool needTaken = false; // the "taken" flags in memory are only touched by nodes with more than 4096 candidates
     for (const BowNode& nd : nodes) needTaken = needTaken || nd.n2 > 4096;
     int r;
@@ -1995,7 +2143,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     Scratch s(device);
     // (what travels: node list, problem records, the pooled sets.  A search against resident keyframes sends ~15 KB: the kernel
     // reads that from the pinned staging in place)
-    s.inPlace = nodes.size() * sizeof(BowNode) + (size_t)rows * 37 + indTotal * 4 + ovTotal <= (48u << 10);
+    s.inPlace = nodes.size() * sizeof(BowNode) + (size_t)rows * 37 + indTotal * 4 + ovTotal <= inplace_limit();
     BowNode* dN;
     BowProb* dP;
     uint8_t *dDesc, *dMask, *taken, *hDesc, *hMask;
@@ -2078,20 +2226,25 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
     }
     if (needTaken) HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
+    // (completion word: only where the kernel writes the results into the pinned mirror itself and nobody times the kernel)
+    const DoneSig done = mirrored && !g_timeKernels ? s.done_sig((unsigned)nodes.size()) : DoneSig{nullptr, nullptr, 0u, 0u, 0u};
+    PTR(); // staging
     {
         KernelTimer timer(s); // (sends the staged pools)
         for (const D2D& c : d2d)
             HIP_TRY(hipMemcpyAsync(dDesc + c.off, c.src, c.bytes, hipMemcpyDeviceToDevice, g_ms));
         hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, g_ms, dN, (int)nodes.size(),
-                           dP, dDesc, dMask, dAng, dInd, dM, dB, taken);
+                           dP, dDesc, dMask, dAng, dInd, dM, dB, taken, done);
     }
     HIP_TRY(hipGetLastError());
+    PTR(); // launch
     std::vector<int32_t> m;
     std::vector<int8_t> bins;
     const int32_t* pm;
     const int8_t* pb;
     if (mirrored) { // the kernel has written the pinned mirror: wait, read
-        HIP_TRY(hipStreamSynchronize(g_ms));
+        INT_TRY(s.wait_done(done));
+        PTR(); // sync
         pm = hM;
         pb = hB;
     } else {
@@ -2107,6 +2260,10 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         std::memcpy(match[p], pm + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
         nmatches[p] = cull_by_rotation(match[p], pb + probs[p].outBase, outN[p], args[p].check_orientation != 0);
     }
+    PTR();
+#ifdef ORBFE_CALL_TRACE
+    if (getenv("ORBFE_CALL_TRACE") && mirrored) fprintf(stderr, "bow_run count=%d: pass1 %.1f stage %.1f launch %.1f sync %.1f tail %.1f us\n", count, trT[0], trT[1], trT[2], trT[3], trT[4]);
+#endif
     return 0;
 }
 } // namespace
@@ -2262,7 +2419,7 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
-    s.inPlace = rows.size() * sizeof(TriRowB) + (size_t)count * (sizeof(TriProb) + 64) <= (48u << 10); // (rows + pair records only)
+    s.inPlace = rows.size() * sizeof(TriRowB) + (size_t)count * (sizeof(TriProb) + 64) <= inplace_limit(); // (rows + pair records only)
     TriRowB* dR;
     TriProb *dP, *hP;
     float *dTab, *hTab;
@@ -2304,16 +2461,17 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
         Q.pad = 0;
     }
     if (!mirrored) HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
+    const DoneSig done = mirrored && !g_timeKernels ? s.done_sig((unsigned)rows.size()) : DoneSig{nullptr, nullptr, 0u, 0u, 0u};
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri_batch, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), dP,
-                           K1->desc, K1->kp, K1->uR, dM);
+                           K1->desc, K1->kp, K1->uR, dM, done);
     }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m;
     int32_t* mAll;
     if (mirrored) {
-        HIP_TRY(hipStreamSynchronize(g_ms));
+        INT_TRY(s.wait_done(done));
         mAll = hMir;
     } else {
         m.resize((size_t)count * n1);
@@ -2379,6 +2537,10 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     uint8_t *d1, *d2, *h2;
     float *k1, *k2, *u1, *u2, *dF, *sf, *sg;
     int32_t *o2, *i2, *dM;
+    // (latency path as in bow_run: two keyframes of ~1200 features stage ~110 KB, which the kernel reads in place; the
+    // matches come back through the pinned mirror and its completion word)
+    s.inPlace = rows.size() * sizeof(TriRow) + (size_t)a->n1 * 44 + (size_t)a->n2 * 53 + (size_t)a->fv2.offsets[a->fv2.nn] * 4 +
+                    (size_t)a->nlevels2 * 8 + 4096 <= inplace_limit();
     if ((r = s.up(&dR, rows.data(), rows.size())) < 0) return r;
     if ((r = s.up_desc(&d1, a->desc1, (size_t)a->n1 * 32)) < 0) return r;
     if ((r = s.up_desc(&d2, a->desc2, (size_t)a->n2 * 32)) < 0) return r;
@@ -2392,17 +2554,28 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     if ((r = s.up(&sg, a->levelSigma2_2, (size_t)a->nlevels2)) < 0) return r;
     if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
-    if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
-    HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), g_ms));
+    int32_t* hM = nullptr;
+    const bool mirrored = (size_t)a->n1 * 4 <= (256u << 10) && s.mirror_out(&dM, &hM, (size_t)a->n1) == 0;
+    if (mirrored) std::memset(hM, 0xFF, (size_t)a->n1 * sizeof(int32_t));
+    else {
+        if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
+        HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), g_ms));
+    }
+    const DoneSig done = mirrored && !g_timeKernels ? s.done_sig((unsigned)rows.size()) : DoneSig{nullptr, nullptr, 0u, 0u, 0u};
     {
         KernelTimer timer(s);
-    hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), d1,
-                       k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM);
+        hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), d1,
+                           k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM, done);
     }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m12(a->n1);
-    INT_TRY(s.down(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t)));
-    INT_TRY(s.fetch());
+    if (mirrored) {
+        INT_TRY(s.wait_done(done));
+        std::memcpy(m12.data(), hM, (size_t)a->n1 * sizeof(int32_t));
+    } else {
+        INT_TRY(s.down(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t)));
+        INT_TRY(s.fetch());
+    }
     std::vector<int8_t> bins(a->n1, -1);
     if (a->check_orientation) {
         for (int i = 0; i < a->n1; i++)
@@ -2889,47 +3062,59 @@ struct orbfe_frame {
 };
 
 namespace {
-// inputs and work arrays of one search on the device (outputs are assigned by the caller: one block per call)
-int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_frame* F = nullptr)
+// inputs and work arrays of one search on the device (outputs are assigned by the caller: one block per call).  Two phases,
+// so that a batch stages the inputs of ALL its searches next to each other (one run of the pinned mirror = one upload
+// command for the batch instead of one per search) and the work arrays after them: phase 0 = inputs, phase 1 = the rest.
+int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_frame* F, int phase)
 {
     int r;
     ProjDev& P = J.P;
     const size_t n = (size_t)a->n, nq = (size_t)a->nq;
-    uint8_t *dDesc = nullptr, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
-    float *dKx = nullptr, *dKy = nullptr, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
-    int32_t *dOct = nullptr, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
-    if (F) { // the frame's arrays and grid are resident
-        dDesc = F->desc; dKx = F->kx; dKy = F->ky; dOct = F->octave;
-        if (F->uright && (a->Nleft == -1 || a->chi2_gate)) dUr = F->uright;
-    } else {
-    if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
-    if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
-    if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
-    if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
-    if (a->uright && (a->Nleft == -1 || a->chi2_gate) && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+    if (phase == 0) {
+        uint8_t *dDesc = nullptr, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
+        float *dKx = nullptr, *dKy = nullptr, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
+        int32_t *dOct = nullptr, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
+        if (F) { // the frame's arrays and grid are resident
+            dDesc = F->desc; dKx = F->kx; dKy = F->ky; dOct = F->octave;
+            if (F->uright && (a->Nleft == -1 || a->chi2_gate)) dUr = F->uright;
+        } else {
+            if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
+            if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
+            if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
+            if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
+            if (a->uright && (a->Nleft == -1 || a->chi2_gate) && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+        }
+        float* dInvSigma2 = nullptr;
+        if (a->chi2_gate && (r = s.up(&dInvSigma2, a->inv_level_sigma2, (size_t)a->n_levels)) < 0) return r;
+        if (a->taken && (r = s.up(&dTaken, a->taken, n)) < 0) return r;
+        if (a->Nleft != -1 && a->mode == 0) {
+            if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
+            if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
+        }
+        if ((r = s.up_desc(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
+        if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
+        if ((r = s.up(&dQy, a->qy, nq)) < 0) return r;
+        if ((r = s.up(&dQr, a->qr, nq)) < 0) return r;
+        if (dUr && (r = s.up(&dQxr, a->qxr, nq)) < 0) return r;
+        if ((r = s.up(&dQmin, a->qmin_level, nq)) < 0) return r;
+        if ((r = s.up(&dQmax, a->qmax_level, nq)) < 0) return r;
+        if (a->qflags && (r = s.up(&dQflags, a->qflags, nq)) < 0) return r;
+        if (a->qblocks && (r = s.up(&dQblocks, a->qblocks, nq)) < 0) return r;
+        P.desc = dDesc; P.kx = dKx; P.ky = dKy; P.octave = dOct; P.uright = dUr; P.taken = dTaken;
+        P.l2r = dL2r; P.r2l = dR2l; P.n = a->n; P.Nleft = a->Nleft;
+        P.minX = a->minX; P.minY = a->minY; P.wInv = a->gridWInv; P.hInv = a->gridHInv;
+        P.nq = a->nq; P.qdesc = dQdesc; P.qx = dQx; P.qy = dQy; P.qr = dQr; P.qxr = dQxr;
+        P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
+        P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
+        P.invSigma2 = dInvSigma2; P.chi2 = a->chi2_gate ? 1 : 0;
+        return 0;
     }
-    float* dInvSigma2 = nullptr;
-    if (a->chi2_gate && (r = s.up(&dInvSigma2, a->inv_level_sigma2, (size_t)a->n_levels)) < 0) return r;
-    if (a->taken && (r = s.up(&dTaken, a->taken, n)) < 0) return r;
-    if (a->Nleft != -1 && a->mode == 0) {
-        if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
-        if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
-    }
-    if ((r = s.up_desc(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
-    if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
-    if ((r = s.up(&dQy, a->qy, nq)) < 0) return r;
-    if ((r = s.up(&dQr, a->qr, nq)) < 0) return r;
-    if (dUr && (r = s.up(&dQxr, a->qxr, nq)) < 0) return r;
-    if ((r = s.up(&dQmin, a->qmin_level, nq)) < 0) return r;
-    if ((r = s.up(&dQmax, a->qmax_level, nq)) < 0) return r;
-    if (a->qflags && (r = s.up(&dQflags, a->qflags, nq)) < 0) return r;
-    if (a->qblocks && (r = s.up(&dQblocks, a->qblocks, nq)) < 0) return r;
     if (F) {
         P.cellStart = F->cellStart; P.cellItems = F->cellItems; P.cellOf = F->cellOf;
     } else {
-    if ((r = s.up<int32_t>(&P.cellStart, nullptr, 2 * PROJ_CELLS + 1)) < 0) return r;
-    if ((r = s.up<int32_t>(&P.cellItems, nullptr, n)) < 0) return r;
-    if ((r = s.up<int32_t>(&P.cellOf, nullptr, n)) < 0) return r;
+        if ((r = s.up<int32_t>(&P.cellStart, nullptr, 2 * PROJ_CELLS + 1)) < 0) return r;
+        if ((r = s.up<int32_t>(&P.cellItems, nullptr, n)) < 0) return r;
+        if ((r = s.up<int32_t>(&P.cellOf, nullptr, n)) < 0) return r;
     }
     if ((r = s.up<int32_t>(&P.minW, nullptr, 2 * n)) < 0) return r;
     if ((r = s.up<int32_t>(&P.state, nullptr, 6 * nq)) < 0) return r;
@@ -2942,13 +3127,6 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_fra
     if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, J.keyCap)) < 0) return r;
     if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
     P.keyCap = (int)J.keyCap;
-    P.desc = dDesc; P.kx = dKx; P.ky = dKy; P.octave = dOct; P.uright = dUr; P.taken = dTaken;
-    P.l2r = dL2r; P.r2l = dR2l; P.n = a->n; P.Nleft = a->Nleft;
-    P.minX = a->minX; P.minY = a->minY; P.wInv = a->gridWInv; P.hInv = a->gridHInv;
-    P.nq = a->nq; P.qdesc = dQdesc; P.qx = dQx; P.qy = dQy; P.qr = dQr; P.qxr = dQxr;
-    P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
-    P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
-    P.invSigma2 = dInvSigma2; P.chi2 = a->chi2_gate ? 1 : 0;
     J.sweepBytes = (2 * n + 6 * nq) * sizeof(int32_t);
     P.sweepLds = J.sweepBytes <= 60 * 1024 ? 1 : 0;
     if (!P.sweepLds) J.sweepBytes = 0;
@@ -2994,6 +3172,7 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
 {
     if (count < 0 || (count && (!items || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
     if (frame && count != 1) return ORBFE_ERR_ARGS;
+    PTR_BEGIN();
     int r;
     for (int k = 0; k < count; k++)
         if ((r = proj_validate(&items[k], q_match[k], feat_match[k])) < 0) return r;
@@ -3007,14 +3186,17 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         if (a->n > 0 && a->nq > 0) live.push_back(k);
     }
     if (live.empty()) return 0;
+    PTR(); // validate + prefill
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
     std::vector<ProjJob> jobs(live.size());
     size_t outInts = 0, sweepBytes = 0;
     unsigned maxBlocks = 1;
+    for (size_t j = 0; j < jobs.size(); j++) // (the inputs of all searches first: one upload for the batch)
+        if ((r = proj_stage(s, &items[live[j]], jobs[j], frame, 0)) < 0) return r;
     for (size_t j = 0; j < jobs.size(); j++) {
         const orbfe_proj_args* a = &items[live[j]];
-        if ((r = proj_stage(s, a, jobs[j], frame)) < 0) return r;
+        if ((r = proj_stage(s, a, jobs[j], frame, 1)) < 0) return r;
         jobs[j].outOff = outInts;
         outInts += 4 + (size_t)a->nq + (size_t)a->n;
         sweepBytes = std::max(sweepBytes, jobs[j].sweepBytes);
@@ -3030,6 +3212,7 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     }
     std::vector<int32_t> out(outInts);
     std::vector<ProjDev> hostP(jobs.size());
+    PTR(); // staging
     for (int attempt = 0;; attempt++) {
         ProjDev* dP = nullptr;
         if (jobs.size() > 1) {
@@ -3052,8 +3235,10 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
             }
         }
         HIP_TRY(hipGetLastError());
+        PTR(); // flush + launches
         INT_TRY(s.down(out.data(), dOut, out.size() * 4));
         INT_TRY(s.fetch());
+        PTR(); // fetch
         // more candidate keys than a job's buffers hold: the kernel reported how many it needs; run again
         bool again = false;
         for (ProjJob& J : jobs) {
@@ -3075,6 +3260,10 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         g_lastProjSweeps = out[jobs[j].outOff + 1];
         nmatches[k] = proj_finish(&items[k], out.data() + jobs[j].outOff, q_match[k], feat_match[k]);
     }
+    PTR();
+#ifdef ORBFE_CALL_TRACE
+    if (getenv("ORBFE_CALL_TRACE")) fprintf(stderr, "proj_run count=%d: validate %.1f stage %.1f launch %.1f fetch %.1f finish %.1f us\n", count, trT[0], trT[1], trT[2], trT[3], trT[4]);
+#endif
     return 0;
 }
 

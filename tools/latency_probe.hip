@@ -1,0 +1,65 @@
+// latency_probe.hip -- what one "launch a kernel, wait for its result" round trip costs on this box, and how much of it is
+// the end-of-kernel signal path: (a) empty kernel + hipStreamSynchronize, (b) the kernel writes a flag into page-locked host
+// memory and the host spins on it, (c) the same two with a kernel that runs ~10 us.  Tuning only.
+//   hipcc -O2 --offload-arch=gfx950 -o tools/latency_probe tools/latency_probe.hip && tools/latency_probe
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <vector>
+#include <atomic>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void k_work(int spin, volatile unsigned* flag, unsigned seq, int* sink)
+{
+    int acc = 0;
+    for (int i = 0; i < spin; i++) acc += __builtin_amdgcn_s_memtime() & 1; // ~ 40 ns per iteration
+    if (acc == -1) *sink = acc;
+    if (flag && threadIdx.x == 0) {
+        __threadfence_system();
+        *flag = seq;
+    }
+}
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main()
+{
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    unsigned* hflag;
+    CK(hipHostMalloc((void**)&hflag, 64));
+    unsigned* dflag;
+    CK(hipHostGetDevicePointer((void**)&dflag, hflag, 0));
+    int* sink;
+    CK(hipMalloc((void**)&sink, 4));
+    *hflag = 0;
+    unsigned seq = 0;
+    for (int spin : {0, 64, 256}) {
+        for (int mode = 0; mode < 3; mode++) { // 0: sync, 1: flag spin (then sync outside the timed part), 2: hipEventSynchronize
+            std::vector<double> t;
+            hipEvent_t ev;
+            CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            for (int it = 0; it < 400; it++) {
+                seq++;
+                const double t0 = now_us();
+                hipLaunchKernelGGL(k_work, dim3(25), dim3(256), 0, st, spin, mode == 1 ? dflag : nullptr, seq, sink);
+                if (mode == 0) CK(hipStreamSynchronize(st));
+                else if (mode == 1) {
+                    while (*(volatile unsigned*)hflag != seq) { }
+                } else {
+                    CK(hipEventRecord(ev, st));
+                    CK(hipEventSynchronize(ev));
+                }
+                const double t1 = now_us();
+                if (mode == 1) CK(hipStreamSynchronize(st));
+                if (it >= 50) t.push_back(t1 - t0);
+            }
+            std::sort(t.begin(), t.end());
+            printf("spin %4d  %-22s p50 %6.2f us  p99 %6.2f us\n", spin, mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "flag in pinned memory" : "event synchronize",
+                   t[t.size() / 2], t[t.size() * 99 / 100]);
+        }
+    }
+    return 0;
+}
