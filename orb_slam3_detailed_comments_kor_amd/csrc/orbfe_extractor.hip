@@ -90,11 +90,19 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         n = 0;
-        hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+        // (fine-grained explicitly: kernels write results here that the host reads behind the completion word while the
+        // kernel is, for the runtime, still running; the default is the same on this runtime unless HIP_HOST_COHERENT=0)
+        hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocCoherent);
+        coherent = e == hipSuccess;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+        }
         if (e != hipSuccess) return -(1000 + (int)e);
         n = count;
         return 0;
     }
+    bool coherent = false;
     // the address a kernel uses to read this buffer in place (zero-copy over PCIe)
     T* dev() const
     {
@@ -230,6 +238,7 @@ struct orbfe_ctx : orbfe_geom_state {
         int32_t* d_lapAlias = nullptr;
         hipEvent_t evIn = nullptr, evK = nullptr, evDone = nullptr;
         bool busy = false, pipelined = false, outPinned = false;
+        unsigned doneSeq = 0; // != 0: K-DESC publishes this number in the context's completion word when the slab is complete
         int nimg = 0, cap = 0;
         size_t metaBytes = 0;
         orbfe_kp* kps = nullptr;
@@ -245,6 +254,13 @@ struct orbfe_ctx : orbfe_geom_state {
     bool zeroCopy = true; // ORBFE_ZEROCOPY=0: the latency path downloads its results with a copy command (A/B)
     bool uploadKernel = true; // ORBFE_UPLOAD_KERNEL=0: the latency path uploads its images with copy commands (A/B)
     int mirrorMaxImgs = 2; // ORBFE_MIRROR_MAX: blocking calls of up to this many images write their results to pinned memory from the kernels
+    // completion word of those calls (OrbDone in orbfe_kernels.hip; ORBFE_SPIN=0: wait in hipStreamSynchronize as before)
+    bool spinWait = true;
+    DevBuf<unsigned> d_done;  // 65 counters
+    PinBuf<unsigned> h_done;  // the flag word
+    unsigned doneSeq = 0;     // last sequence number handed out
+    bool doneWant = false;    // host_submit -> run_device: the caller wants the word for this call
+    unsigned doneGot = 0;     // run_device -> host_submit: the number K-DESC will publish, or 0
     bool autoRegister = false;
     struct AutoPin {
         const void* p;
@@ -1508,13 +1524,25 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             const bool descAffine = c->xcdAffine && ni % 8 == 0;
             const unsigned descWg = (unsigned)((c->maxKp + ORBFE_DESC_WPW * ORBFE_DESC_KPW - 1) / (ORBFE_DESC_WPW * ORBFE_DESC_KPW));
             const dim3 descGrid = descAffine ? dim3(8u * descWg, (unsigned)(ni / 8)) : dim3(descWg, (unsigned)ni);
+            // completion word: K-DESC is the call's last kernel and writes the mirror (not with K-PACK's rays, the host-side
+            // trig check's fix-up launch or sub-batches behind it)
+            OrbDone done{nullptr, nullptr, 0u, 0u};
+            if (c->doneWant) {
+                c->doneWant = false;
+                if (mirror && !needPack && !hostTrigCheck && nsub == 1 && !descAffine && c->spinWait && c->d_done.p && c->h_done.p &&
+                    c->h_done.coherent && ORBFE_DESC_WPW == 1 && ORBFE_DESC_KPW == 1) {
+                    if (++c->doneSeq == 0u) c->doneSeq = 1u;
+                    done = OrbDone{c->d_done.p, c->h_done.dev(), c->doneSeq, (unsigned)ni * (unsigned)c->maxKp};
+                    c->doneGot = c->doneSeq; // (what the caller waits for)
+                }
+            }
 #define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
     hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid, dim3(64 * ORBFE_DESC_WPW), 0, q,                                           \
                        c->d_pyr.p, c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,     \
                        c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
                        c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, descAffine ? 1 : 0, trigTab.codes,                          \
                        trigTab.full, c->atanFma, nullptr, 0, d_n, d_mono, k == 0 ? d_hdr + 1 : nullptr,                    \
-                       k == 0 ? d_errOut : nullptr, needPack ? nullptr : mMeta, nimg, mKps, mDesc)
+                       k == 0 ? d_errOut : nullptr, needPack ? nullptr : mMeta, nimg, mKps, mDesc, done)
             if (hostTrigCheck) { // (the listing of fragile keypoints is an instantiation of its own)
                 if (tapSum > 256) ORBFE_DESC_LAUNCH(2, true);
                 else ORBFE_DESC_LAUNCH(2, false);
@@ -1854,7 +1882,7 @@ const uint8_t* upload_by_kernel(hipStream_t s, uint8_t* d_dst /* 256-B aligned, 
 // copies on their own streams (ordered by events) so that they overlap the kernels of the neighbouring batches;
 // the blocking calls keep everything on the context's stream (no event traffic on the latency path).
 int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
-                     orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined)
+                     orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined, bool spinOk)
 {
     if (!c || nimg < 1 || !imgs || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
     for (int i = 0; i < nimg; i++) {
@@ -2019,12 +2047,27 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     float* d_kps = reinterpret_cast<float*>(sl.d_out.p + sl.metaBytes);
     uint8_t* d_desc = sl.d_out.p + sl.metaBytes + kpsBytes;
     uint8_t* mirror = nullptr;
+    sl.doneSeq = 0;
     if (mirrorOut) {
         if ((r = sl.h_out.ensure(sl.metaBytes + kpsBytes + descBytes)) < 0) return r;
         mirror = sl.h_out.dev();
+        // completion word (the caller's wait is the next thing that happens to this slot, and K-DESC the call's last kernel)
+        if (spinOk && c->spinWait && sl.h_out.coherent) {
+            if (!c->d_done.p) {
+                if ((r = c->d_done.ensure(80)) < 0) return r;
+                HIP_TRY(hipMemset(c->d_done.p, 0, 80 * sizeof(unsigned)));
+                if ((r = c->h_done.ensure(16)) < 0) return r;
+                c->h_done.p[0] = 0u;
+            }
+            c->doneWant = true;
+            c->doneGot = 0u;
+        }
     }
     r = run_device(c, nimg, d_imgBase, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc,
                    cap_per_img, d_meta, d_meta + nimg, d_meta + 2 * nimg, mirror, sl.metaBytes);
+    sl.doneSeq = c->doneGot;
+    c->doneGot = 0u;
+    c->doneWant = false;
     if (r < 0) return r;
     if (pipelined) {
         HIP_TRY(hipEventRecord(sl.evK, s));
@@ -2064,10 +2107,12 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
 // streams are drained before the error is handed back (DMA engines read the images, and write pinned result arrays, in
 // place).
 int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
-                orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined)
+                orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined,
+                bool spinOk = false /* the caller waits at once and queues nothing behind the extraction */)
 {
     if (c && c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: nothing was queued
-    const int r = host_submit_impl(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, pipelined);
+    const int r = host_submit_impl(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, pipelined,
+                                   spinOk);
     if (r <= -1000 && c) { // (a HIP error: something may have been queued; validation errors come before the first command)
         if (hipSetDevice(c->device) == hipSuccess) {
             if (c->sIn) (void)hipStreamSynchronize(c->sIn);
@@ -2078,6 +2123,22 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
     return r;
 }
 
+// Spin on the context's completion word for `seq` (bounded), true when it was seen.
+static bool spin_done(orbfe_ctx* c, unsigned seq)
+{
+    if (!seq || !c->h_done.p) return false;
+    const volatile unsigned* f = c->h_done.p;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; it++) {
+        if (*f == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return true;
+        }
+        __builtin_ia32_pause();
+        if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) return false;
+    }
+}
+
 // Complete the oldest submitted batch: wait for its transfers, hand out the counts, and -- for pageable output
 // arrays -- copy the rows each image produced out of the staging buffer.
 int host_wait(orbfe_ctx* c)
@@ -2086,7 +2147,10 @@ int host_wait(orbfe_ctx* c)
     if (c->slotSubmitted == c->slotRetired) return ORBFE_ERR_STATE;
     orbfe_ctx::HostSlot& sl = c->slot[c->slotRetired & 1];
     HIP_TRY(hipSetDevice(c->device));
-    hipError_t e = sl.pipelined ? hipEventSynchronize(sl.evDone) : hipStreamSynchronize(c->stream);
+    hipError_t e = hipSuccess;
+    // (the completion word the call's last kernel publishes behind the results it has written: OrbDone)
+    const bool seen = !sl.pipelined && spin_done(c, sl.doneSeq);
+    if (!seen) e = sl.pipelined ? hipEventSynchronize(sl.evDone) : hipStreamSynchronize(c->stream);
     sl.busy = false;
     c->slotRetired++;
     if (e != hipSuccess) return -(1000 + (int)e);
@@ -2171,6 +2235,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_ZEROCOPY")) c->zeroCopy = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_UPLOAD_KERNEL")) c->uploadKernel = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_MIRROR_MAX")) c->mirrorMaxImgs = std::max(0, atoi(e));
+    if (const char* e = getenv("ORBFE_SPIN")) c->spinWait = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("ORBFE_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("ORBFE_LANES_MIN")) c->lanesMin = std::max(2, atoi(e));
@@ -2478,7 +2543,8 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     // copies go to the copy streams like the pipelined form -- measured: a 23-MB upload queued on the stream the
     // kernels run on takes 0.8 ms instead of the 0.41 ms the DMA engine needs on a stream of its own.
     const bool ownCopyStreams = rows > 0 && cols > 0 && (size_t)nimg * (size_t)rows * (size_t)cols >= (2u << 20);
-    const int r = host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, ownCopyStreams);
+    const int r = host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, ownCopyStreams,
+                              true);
     if (r < 0) return r;
     return host_wait(c);
 }
@@ -2694,8 +2760,12 @@ int orbfe_compute_stereo_matches(orbfe_ctx* left, orbfe_ctx* right, const orbfe_
 // pyramids are read in place; only uRight / depth / SAD come back (one transfer).
 // K-STEREO on what the two contexts' last extraction left on the device, queued on the left context's stream; the three
 // result arrays go straight into the left context's pinned arena (or, ORBFE_ZEROCOPY=0, into a device arena + copy).
-static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf)
+// *doneSeq (when asked for): the number K-STEREO will publish in left's completion word once its three arrays are in the pinned
+// arena, or 0 (the caller then synchronises the stream)
+static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, int imgR, float mb, float mbf,
+                                  unsigned* doneSeq = nullptr)
 {
+    if (doneSeq) *doneSeq = 0u;
     if (left->lg.empty() || right->lg.empty() || !left->lastKps || !right->lastKps || imgL < 0 || imgR < 0 ||
         imgL >= left->lastImgs || imgR >= right->lastImgs || left->device != right->device ||
         left->rows != right->rows || left->cols != right->cols || left->nlevels != right->nlevels ||
@@ -2718,12 +2788,26 @@ static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, i
     float* dD = dU + cap;
     int32_t* dS = reinterpret_cast<int32_t*>(dD + cap);
     const int capL = left->lastCap, capR = right->lastCap;
+    OrbDone done{nullptr, nullptr, 0u, 0u};
+    if (doneSeq && left->zeroCopy && left->spinWait && left->h_stereo.coherent) {
+        if (!left->d_done.p) {
+            if ((r = left->d_done.ensure(80)) < 0) return r;
+            HIP_TRY(hipMemset(left->d_done.p, 0, 80 * sizeof(unsigned)));
+            if ((r = left->h_done.ensure(16)) < 0) return r;
+            left->h_done.p[0] = 0u;
+        }
+        if (left->h_done.coherent) {
+            if (++left->doneSeq == 0u) left->doneSeq = 1u;
+            done = OrbDone{left->d_done.p + 72, left->h_done.dev(), left->doneSeq, (unsigned)((capL + 3) / 4)};
+            *doneSeq = left->doneSeq;
+        }
+    }
     hipLaunchKernelGGL(k_stereo_match, dim3((unsigned)((capL + 3) / 4)), dim3(256), 0, s,
                        left->d_pyr.p + (size_t)imgL * left->pyrStride, right->d_pyr.p + (size_t)imgR * right->pyrStride,
                        left->d_lg.p, left->nlevels, left->lastKps + (size_t)imgL * capL * 7,
                        left->lastDesc + (size_t)imgL * capL * 32, capL, right->lastKps + (size_t)imgR * capR * 7,
                        right->lastDesc + (size_t)imgR * capR * 32, capR, mb, mbf, dU, dD, dS, left->lastN + imgL,
-                       right->lastN + imgR);
+                       right->lastN + imgR, done);
     if (!left->zeroCopy) HIP_TRY(hipMemcpyAsync(left->h_stereo.p, dU, 3 * cap * sizeof(float), hipMemcpyDeviceToHost, s));
     return 0;
 }
@@ -2766,8 +2850,9 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
     if (nL > left->lastCap) return ORBFE_ERR_STATE;
     HIP_TRY(hipSetDevice(left->device));
     int r;
-    if ((r = stereo_resident_launch(left, imgL, right, imgR, mb, mbf)) < 0) return r;
-    HIP_TRY(hipStreamSynchronize(left->stream));
+    unsigned seq = 0;
+    if ((r = stereo_resident_launch(left, imgL, right, imgR, mb, mbf, &seq)) < 0) return r;
+    if (!spin_done(left, seq)) HIP_TRY(hipStreamSynchronize(left->stream));
     return stereo_resident_finish(left, uRight, depth, nL);
 }
 
@@ -2784,7 +2869,9 @@ int orbfe_extract_stereo_pair(orbfe_ctx* c, const uint8_t* imgL, const uint8_t* 
     int r = host_submit(c, 2, two, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false);
     if (r < 0) return r;
     // (the extraction is queued, c->last* describe its outputs: the matching goes behind it on the same stream)
-    r = stereo_resident_launch(c, 0, c, 1, mb, mbf);
+    unsigned seq = 0;
+    r = stereo_resident_launch(c, 0, c, 1, mb, mbf, &seq);
+    c->slot[(c->slotSubmitted - 1) & 1].doneSeq = r < 0 ? 0u : seq; // (K-STEREO is the call's last kernel: its word ends the wait)
     const int w = host_wait(c); // always: the slot must be retired
     if (r < 0) return r;
     if (w < 0) return w;

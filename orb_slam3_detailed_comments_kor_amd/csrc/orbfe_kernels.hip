@@ -2276,6 +2276,58 @@ static_assert(160 * (kDescHItems.maxPr[0] + 1) <= DESC_RAW_OFF + 88 * kDescHItem
 #define DESC_LDS_PER_WAVE (DESC_RAW_BYTES + DESC_H_BYTES) /* blurred patch aliases the raw patch */
 #endif
 
+// Completion word of the latency path (a blocking call of a frame or two, results mirrored into page-locked host memory by
+// this kernel): the host spins on a flag word the last wavefront publishes instead of waiting in hipStreamSynchronize for the
+// end-of-kernel release and the runtime's signal (~5 us of a 12-us round trip, tools/latency_probe.hip).  A wavefront that is
+// done -- with or without a keypoint -- waits for its own stores to be acknowledged (the mirror is fine-grained host memory:
+// uncached on the device) and counts itself in one of 64 counters (slot index mod 64: a thousand wavefronts on ONE address
+// serialise), the wavefront that completes a counter resets it and counts it in the 65th, the one that completes that one
+// resets it and writes the call's sequence number behind a system-scope fence.
+struct OrbDone {
+    unsigned* ctr;  // 65 words of device memory, zero between calls (calls on one stream are ordered)
+    unsigned* flag; // the kernel's address of the page-locked flag word; nullptr: none
+    unsigned seq, nWaves;
+};
+__device__ __forceinline__ void desc_done(const OrbDone& d, unsigned wl /* this wavefront's index among the nWaves */)
+{
+    if (!d.flag) return; // (uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned k = wl & 63u, want = (d.nWaves + 63u - k) >> 6;
+        if (atomicAdd(&d.ctr[k], 1u) + 1u == want) {
+            d.ctr[k] = 0u;
+            if (atomicAdd(&d.ctr[64], 1u) + 1u == min(d.nWaves, 64u)) {
+                d.ctr[64] = 0u;
+                __threadfence_system();
+                *(volatile unsigned*)d.flag = d.seq;
+            }
+        }
+    }
+}
+
+// The same word for a kernel of four-wavefront workgroups in which EVERY wavefront reports (K-STEREO): wavefronts count in
+// LDS, workgroups in d.ctr[0], nWaves = number of workgroups.  wg_done_begin before the first exit of any wavefront.
+__device__ __forceinline__ void wg_done_begin(const OrbDone& d, unsigned* wgCnt)
+{
+    if (!d.flag) return; // (uniform)
+    if (threadIdx.x == 0) *wgCnt = 0u;
+    __syncthreads();
+}
+__device__ __forceinline__ void wg_done(const OrbDone& d, unsigned* wgCnt)
+{
+    if (!d.flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) {
+        if (atomicAdd(wgCnt, 1u) + 1u == 4u) {
+            if (atomicAdd(&d.ctr[0], 1u) + 1u == d.nWaves) {
+                d.ctr[0] = 0u;
+                __threadfence_system();
+                *(volatile unsigned*)d.flag = d.seq;
+            }
+        }
+    }
+}
+
 // One wavefront per keypoint.  Stages the 43x43 raw neighbourhood in LDS, computes the
 // intensity-centroid angle on the raw pixels (IC_Angle :75-102), blurs only the 37x37 patch the
 // rotated taps can reach (GaussianBlur 7x7 sigma 2 fixed point, identical to blurring the whole
@@ -2338,7 +2390,8 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
                                                           int32_t* __restrict__ errOut = nullptr /* are written from here */,
                                                           int32_t* __restrict__ mirrorMeta = nullptr, int mirrorImgs = 0,
                                                           float* __restrict__ mirrorKps = nullptr /* the same outputs once more, */,
-                                                          uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */)
+                                                          uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */,
+                                                          const OrbDone done = OrbDone{nullptr, nullptr, 0u, 0u})
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[ORBFE_DESC_WPW][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2774,6 +2827,7 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
     }
     }; // desc_one
     desc_one(g);
+    if (MODE == 0 && ORBFE_DESC_KPW == 1 && ORBFE_DESC_WPW == 1 && g < nSlots) desc_done(done, (unsigned)(imgLocal * nSlots + g));
     if (MODE != 1 && ORBFE_DESC_KPW > 1) {
 #pragma unroll
         for (int rep = 1; rep < ORBFE_DESC_KPW; rep++) {
@@ -2800,8 +2854,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
                                                       float* __restrict__ uRight, float* __restrict__ depth,
                                                       int32_t* __restrict__ sadOut,
                                                       const int32_t* __restrict__ nLdev /* counts still on the device */,
-                                                      const int32_t* __restrict__ nRdev /* (resident form), or NULL   */)
+                                                      const int32_t* __restrict__ nRdev /* (resident form), or NULL   */,
+                                                      const OrbDone done = OrbDone{nullptr, nullptr, 0u, 0u})
 {
+    __shared__ unsigned wgCnt;
+    wg_done_begin(done, &wgCnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iL = blockIdx.x * 4 + wave;
     const int rowsL = nL; // rows of the output arrays
@@ -2813,6 +2870,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
             depth[iL] = -1.0f;
             sadOut[iL] = -1;
         }
+        wg_done(done, &wgCnt);
         return;
     }
     const float uL = kpsL[iL * 7 + 0], vL = kpsL[iL * 7 + 1];
@@ -2908,4 +2966,5 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
         depth[iL] = outD;
         sadOut[iL] = outS;
     }
+    wg_done(done, &wgCnt);
 }

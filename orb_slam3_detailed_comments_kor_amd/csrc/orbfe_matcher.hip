@@ -1713,6 +1713,7 @@ struct Scratch { // device allocations of one call
         DoneSig d{nullptr, nullptr, 0u, (waves + 3u) / 4u, waves};
         static const bool enabled = [] {
             const char* e = getenv("ORBFE_MATCHER_SPIN");
+            if (!e) e = getenv("ORBFE_SPIN"); // (the extractor's switch for the same mechanism)
             return !(e && e[0] == '0');
         }();
         // (only where nothing is uploaded in front of the kernel: a copy command queued behind a kernel the runtime still
