@@ -322,3 +322,35 @@ def test_latency_path_with_sub_batches_on_several_streams():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "2 passed" in r.stdout
+
+
+def test_latency_path_without_the_completion_word():
+    # The blocking calls of a frame or two end on a completion word the last kernel publishes in page-locked memory (the host
+    # spins on it instead of waiting in hipStreamSynchronize).  ORBFE_SPIN=0 restores the stream synchronisation:
+    # the same checks in a child process (the variable is read when a context is created / at the first matcher call), so that
+    # both waits stay covered whatever the default is.
+    env = dict(os.environ, ORBFE_SPIN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_stereo_pair_extraction_and_matching_in_one_call or test_batch_pageable_and_pinned or "
+                        "test_stereo_pair_two_threads_resident_matches"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_completion_word_survives_many_calls_and_changing_shapes(pkg, oracle):
+    # the word's sequence number, its 64 + 1 counters (reset by the wavefronts that complete them) and the slot bookkeeping over
+    # a few hundred blocking calls of alternating shapes and image counts: every call's result equals the first one's
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7, device=0)
+    a = pkg.synth.make_frame(240, 376, 5)
+    b = pkg.synth.make_frame(300, 400, 6)
+    ra = oracle.Extractor(500, 1.2, 8, 20, 7).extract(a, (0, 0))
+    rb = oracle.Extractor(500, 1.2, 8, 20, 7).extract(b, (0, 0))  # (an oracle instance keeps to the size it has seen)
+    for it in range(150):
+        img, r = (a, ra) if it % 3 else (b, rb)
+        mono, kps, desc = ex(img, (0, 0))
+        assert mono == r[0] and np.array_equal(desc, r[2]) and np.array_equal(kps["angle"], r[1]["angle"]), it
+        if it % 7 == 0:  # a two-image blocking call in between (K-DESC counts 2 x slots wavefronts)
+            res = ex.extract_batch([a, a[:, ::-1].copy()], [(0, 0), (0, 0)])
+            assert res[0][0] == ra[0] and np.array_equal(res[0][2], ra[2]), it
+    ex.close()
