@@ -2055,7 +2055,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
         if (spinOk && c->spinWait && sl.h_out.coherent) {
             if (!c->d_done.p) {
                 if ((r = c->d_done.ensure(80)) < 0) return r;
-                HIP_TRY(hipMemset(c->d_done.p, 0, 80 * sizeof(unsigned)));
+                HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), c->stream)); // (ordered with the kernels that count)
                 if ((r = c->h_done.ensure(16)) < 0) return r;
                 c->h_done.p[0] = 0u;
             }
@@ -2135,8 +2135,12 @@ static bool spin_done(orbfe_ctx* c, unsigned seq)
             return true;
         }
         __builtin_ia32_pause();
-        if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) return false;
+        if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
     }
+    // The word did not come within the bound (the caller now synchronises the stream).  Should a counter ever be left non-zero
+    // -- a kernel that died half-way -- every later call would time out as well: clear them behind whatever is still queued.
+    (void)hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), c->stream);
+    return false;
 }
 
 // Complete the oldest submitted batch: wait for its transfers, hand out the counts, and -- for pageable output
@@ -2792,7 +2796,7 @@ static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, i
     if (doneSeq && left->zeroCopy && left->spinWait && left->h_stereo.coherent) {
         if (!left->d_done.p) {
             if ((r = left->d_done.ensure(80)) < 0) return r;
-            HIP_TRY(hipMemset(left->d_done.p, 0, 80 * sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(left->d_done.p, 0, 80 * sizeof(unsigned), s));
             if ((r = left->h_done.ensure(16)) < 0) return r;
             left->h_done.p[0] = 0u;
         }

@@ -1721,7 +1721,9 @@ struct Scratch { // device allocations of one call
         if (!enabled || waves == 0 || d.total > 256u || !inPlace || !ar->pinCoherent) return d;
         if (!ar->doneCtr) {
             void *c = nullptr, *h = nullptr, *dv = nullptr;
-            if (hipMalloc(&c, 64) != hipSuccess || hipMemset(c, 0, 64) != hipSuccess || hipHostMalloc(&h, 64, hipHostMallocCoherent) != hipSuccess ||
+            // (cleared on the call's own stream: the null stream is not ordered with a non-blocking one)
+            if (hipMalloc(&c, 64) != hipSuccess || hipMemsetAsync(c, 0, 64, g_ms) != hipSuccess ||
+                hipHostMalloc(&h, 64, hipHostMallocCoherent) != hipSuccess ||
                 hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 if (c) (void)hipFree(c);
@@ -1753,7 +1755,10 @@ struct Scratch { // device allocations of one call
                 if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
             }
         }
-        const hipError_t e = hipStreamSynchronize(g_ms);
+        hipError_t e = hipStreamSynchronize(g_ms);
+        // the word did not come within the bound: normally a long call (its counter is back at zero by now); should the counter
+        // ever be left non-zero -- a kernel that died half-way -- every later call would time out, so it is cleared here
+        if (e == hipSuccess && d.flag) e = hipMemsetAsync(d.ctr, 0, sizeof(unsigned), g_ms);
         return e == hipSuccess ? 0 : -(1000 + (int)e);
     }
 };
