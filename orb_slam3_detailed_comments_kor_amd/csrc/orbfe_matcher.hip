@@ -298,7 +298,38 @@ struct DoneSig {
     unsigned* ctr;  // device memory, zero between calls
     unsigned* flag; // the kernel's address of the page-locked flag word; nullptr: no completion word (the host synchronises)
     unsigned seq, total /* workgroups */, waves /* wavefronts of the whole grid that report */;
+    // Where the results go.  A kernel whose wavefronts store a 4-byte match here and a byte there STRAIGHT into the pinned mirror
+    // turns every one of them into a write transaction of its own across PCIe, and the flag word queues behind all of them: a
+    // SearchByBoW with 500 matches kept the host waiting 13 us after its last wavefront had ended (tools/hostbench with a
+    // -DORBFE_BOW_TIMING library: wavefronts done 13 us after the first one started, call 35 us).  So the results are
+    // scattered into a block of DEVICE memory that is all ones (-1) between calls, and the wavefront that completes the count
+    // copies the block to the mirror as whole 16-byte rows of 64 lanes (full-line writes), puts the all-ones back, and only
+    // then publishes the flag.  (Large grids: k_copy_out does the same as a kernel of its own behind the main one.)
+    uint4* outDev;    // the clean block (device memory), or nullptr: the kernel's output pointers are the final destination
+    uint4* outMirror; // the kernel's address of the block's pinned mirror
+    unsigned out16;   // 16-byte units
 };
+__device__ __forceinline__ DoneSig no_done() { return DoneSig{nullptr, nullptr, 0u, 0u, 0u, nullptr, nullptr, 0u}; }
+// the wavefront that completed the count (all 64 lanes): results to the mirror, block clean again, flag
+__device__ __forceinline__ void done_publish(const DoneSig& d)
+{
+    const int lane = threadIdx.x & 63;
+    if (d.outDev) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' stores (released before they counted)
+        const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (unsigned i = (unsigned)lane; i < d.out16; i += 64u) {
+            const uint4 v = d.outDev[i];
+            d.outMirror[i] = v;
+            d.outDev[i] = ones;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) {
+        *d.ctr = 0u; // for the next call (calls on one stream are ordered)
+        __threadfence_system();
+        *(volatile unsigned*)d.flag = d.seq;
+    }
+}
 // at the top of the kernel, before any wavefront can leave (every wavefront of the workgroup executes it)
 __device__ __forceinline__ void done_begin(const DoneSig& d, unsigned* wgCnt)
 {
@@ -306,20 +337,47 @@ __device__ __forceinline__ void done_begin(const DoneSig& d, unsigned* wgCnt)
     if (threadIdx.x == 0) *wgCnt = 0u;
     __syncthreads();
 }
-// wavesPerWG = 4; the last workgroup may hold fewer reporting wavefronts
+// every wavefront of a four-wavefront workgroup reports (the last workgroup may hold fewer reporting wavefronts)
 __device__ __forceinline__ void wave_done(const DoneSig& d, unsigned* wgCnt)
 {
     if (!d.flag) return; // (wave-uniform)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's result stores have been acknowledged
+    // this wavefront's result stores: visible to the device (the clean block) / acknowledged (stores into the mirror itself)
+    if (d.outDev) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned last = 0u;
     if ((threadIdx.x & 63) == 0) {
         const unsigned mine = min(4u, d.waves - 4u * blockIdx.x);
-        if (atomicAdd(wgCnt, 1u) + 1u == mine) {
-            if (atomicAdd(d.ctr, 1u) + 1u == d.total) {
-                *d.ctr = 0u;
-                __threadfence_system();
-                *(volatile unsigned*)d.flag = d.seq;
-            }
-        }
+        if (atomicAdd(wgCnt, 1u) + 1u == mine) last = atomicAdd(d.ctr, 1u) + 1u == d.total ? 1u : 0u;
+    }
+    if (__builtin_amdgcn_readfirstlane(last)) done_publish(d);
+}
+// ... and for a kernel in which ONE wavefront per workgroup reports (d.total = workgroups)
+__device__ __forceinline__ void wg1_done(const DoneSig& d)
+{
+    if (!d.flag) return;
+    if (d.outDev) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned last = 0u;
+    if ((threadIdx.x & 63) == 0) last = atomicAdd(d.ctr, 1u) + 1u == d.total ? 1u : 0u;
+    if (__builtin_amdgcn_readfirstlane(last)) done_publish(d);
+}
+// The same copy as a kernel of its own, for grids too large to count on one address: queued behind the main kernel, a few
+// workgroups copy the block to the mirror, clean it and count themselves; the last one publishes the flag (d.total = gridDim.x).
+__global__ __launch_bounds__(256) void k_copy_out(const DoneSig d)
+{
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < d.out16; i += gridDim.x * 256u) {
+        const uint4 v = d.outDev[i];
+        d.outMirror[i] = v;
+        d.outDev[i] = ones;
+    }
+    if (!d.flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(d.ctr, 1u) + 1u == d.total) {
+        *d.ctr = 0u;
+        __threadfence_system();
+        *(volatile unsigned*)d.flag = d.seq;
     }
 }
 
@@ -328,6 +386,31 @@ __device__ __forceinline__ void wave_done(const DoneSig& d, unsigned* wgCnt)
 // (a match removes its set-2 feature from later rows, :324,:884,:911) while the candidates of a
 // row are spread over the lanes.  variant 0: (KeyFrame*,Frame&), match2[idx2] = idx1;
 // variant 1: (KeyFrame*,KeyFrame*), match1[idx1] = idx2.  bins[] gets the rotation bin per match.
+#ifdef ORBFE_BOW_TIMING // tuning only (tools/ab_build.sh bowt "-DORBFE_BOW_TIMING"): where a node's first wavefront spends its time.
+// Stamps stay in registers until the wavefront is done (an atomic or a store per stamp would sit in front of the kernel's own
+// s_waitcnt and be measured as part of the next stage); then one record per node: 8 x 100-MHz ticks since the wavefront began.
+__device__ unsigned long long g_bowTimes[16];     // max over the nodes of every stage's duration; [4..6]: counters
+#define BT_BEGIN()                                                    \
+    unsigned long long btS[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0}; \
+    int btRounds = 0
+#define BT(k) btS[(k) + 1] = (unsigned long long)wall_clock64()
+#define BT_END()                                                                                              \
+    do {                                                                                                      \
+        if ((threadIdx.x & 63) == 0) {                                                                         \
+            for (int k_ = 0; k_ < 5; k_++)                                                                     \
+                if (btS[k_ + 1] && btS[k_]) atomicMax(&g_bowTimes[k_ == 4 ? 7 : k_], btS[k_ + 1] - btS[k_]);  \
+            atomicAdd(&g_bowTimes[5], 1ull);                                                                   \
+            atomicMin(&g_bowTimes[11], btS[0]);                                                                \
+            atomicMax(&g_bowTimes[12], (unsigned long long)wall_clock64());                                    \
+            atomicMax(&g_bowTimes[13], btS[0]);                                                                \
+            atomicAdd(&g_bowTimes[6], (unsigned long long)btRounds);                                           \
+        }                                                                                                      \
+    } while (0)
+#else
+#define BT_BEGIN() do { } while (0)
+#define BT(k) do { } while (0)
+#define BT_END() do { } while (0)
+#endif
 __device__ __forceinline__ void bow_node(int nd, const BowNode* __restrict__ nodes, const BowProb* __restrict__ probs,
                                          const uint8_t* __restrict__ descPool, const uint8_t* __restrict__ maskPool,
                                          const float* __restrict__ angPool, const int32_t* __restrict__ indPool,
@@ -557,6 +640,54 @@ __device__ __forceinline__ void bow_node(int nd, const BowNode* __restrict__ nod
     }
 }
 
+// exclusive prefix OR over the 64 lanes (lane 0 gets 0): wave_shr:1, then the DPP scan steps of wave_incl_scan (row shifts
+// inside the 16-lane rows, row broadcasts across them)
+__device__ __forceinline__ unsigned wave_excl_or_u32(unsigned x)
+{
+    unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true); // wave_shr:1
+    y |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)y, 0x111, 0xF, 0xF, true);          // row_shr:1
+    y |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)y, 0x112, 0xF, 0xF, true);          // row_shr:2
+    y |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)y, 0x114, 0xF, 0xF, true);          // row_shr:4
+    y |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)y, 0x118, 0xF, 0xF, true);          // row_shr:8
+    y |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)y, 0x142, 0xA, 0xF, true);          // row_bcast:15 into rows 1 and 3
+    y |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)y, 0x143, 0xC, 0xF, true);          // row_bcast:31 into rows 2 and 3
+    return y;
+}
+// sorted insertion of `key` into k[0] <= k[1] <= ... (keys are distinct or the sentinel): 2 N - 1 min / max
+template <int N>
+__device__ __forceinline__ void sorted_insert(unsigned (&k)[N], unsigned key)
+{
+    unsigned t = key;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const unsigned lo = min(k[i], t);
+        t = max(k[i], t);
+        k[i] = lo;
+    }
+}
+
+// K-BOW, one WORKGROUP per shared vocabulary node (round 4, second form).  `bow_node` above -- one wavefront per node, rows
+// decided one after the other -- spends 25 us on a 39 x 38 node (tools/hostbench with a -DORBFE_BOW_TIMING library: records 3,
+// prefetch 5, scan 7, row decisions 13 us): a single wavefront pays the full latency of every dependent instruction, 430 cycles
+// per candidate of the scan and 790 per row.  Nodes of at most 64 x 64 (every node of a real FeatureVector) now take this path:
+//  * scan: the four wavefronts of the workgroup split the CANDIDATES; in each, lane r scans the wavefront's quarter for row r
+//    and keeps the FOUR smallest keys among the left-camera candidates and the two smallest among the right-camera ones
+//    (sorted insertion, 7 / 3 min-max per candidate); the quarters meet in LDS and wavefront 0 merges them;
+//  * decisions without the row-by-row chain.  The reference walks the rows in order and removes a matched candidate from the
+//    later rows (:324, :884, :911); row r's outcome is a function d(r, T_r) of the candidates taken before it, T_r = the union
+//    of the earlier rows' outcomes.  Iterate ALL rows at once (lane = row): T = exclusive prefix OR of the outcomes across the
+//    lanes (DPP), new outcome = d(r, T) from the stored keys -- until nothing changes.  Row r is final after r + 1 rounds at
+//    the latest (induction over the rows), so the fixed point is unique and is the sequential result; real nodes settle in two
+//    to four rounds of ~60 instructions instead of n1 rows of ~100;
+//  * d(r, T) needs the best and second-best NON-taken left candidate and the best non-taken right one.  Four / two stored keys
+//    decide that exactly unless so many of them are taken that an unseen candidate could matter (fewer than two free left keys
+//    with more candidates than keys, and neither "nothing can pass the threshold" nor "the ratio test passes against any
+//    unseen candidate" settles it): such a row is scanned again across the lanes (lane c = candidate c, descriptors from LDS)
+//    without the candidates in its T, and keeps the exact keys for as long as its T stays that set.  (The first version sent
+//    the whole node back to `bow_node` instead: with the hostbench frames some node of nearly every call did, and the call
+//    stayed at 34 us -- found with ORBFE_BOW_STOP, the run-time cut after a stage or a number of rounds.)
+//  * all accepted rows store their match at once (lane = row) instead of lane 0 row by row.
+// Larger nodes: wavefront 0 runs `bow_node`.
 __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ nodes, int nNodes,
                                                     const BowProb* __restrict__ probs,
                                                     const uint8_t* __restrict__ descPool,
@@ -564,14 +695,260 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
                                                     const float* __restrict__ angPool,
                                                     const int32_t* __restrict__ indPool,
                                                     int32_t* __restrict__ matchPool, int8_t* __restrict__ binsPool,
-                                                    uint8_t* __restrict__ takenPool, const DoneSig done)
+                                                    uint8_t* __restrict__ takenPool, const DoneSig done, const int stopAt)
 {
-    __shared__ unsigned wgCnt;
-    done_begin(done, &wgCnt);
-    const int nd = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    __shared__ unsigned partK[3][6][64]; // wavefronts 1..3: keys of their quarter, per row
+    __shared__ int sIdx[64];             // candidate position -> feature index / angle (for the stores)
+    __shared__ float sAng[64];
+    __shared__ __attribute__((aligned(16))) unsigned long long sDesc[64][4]; // ... -> descriptor, eligibility (rescans)
+    __shared__ uint8_t sOk[64];
+    const int nd = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (nd >= nNodes) return;
-    bow_node(nd, nodes, probs, descPool, maskPool, angPool, indPool, matchPool, binsPool, takenPool);
-    wave_done(done, &wgCnt);
+    BT_BEGIN();
+    const BowNode N = nodes[nd];
+    if (!(N.n1 <= 64 && N.n2 <= 64)) { // (uniform over the workgroup)
+        if (wave == 0) {
+            bow_node(nd, nodes, probs, descPool, maskPool, angPool, indPool, matchPool, binsPool, takenPool);
+            wg1_done(done);
+        }
+        return;
+    }
+    const BowProb Pb = probs[N.prob];
+#ifdef ORBFE_BOW_TIMING
+    asm volatile("" ::"s"(Pb.outBase), "s"(N.n1));
+    if (wave == 0) BT(0);
+#endif
+    if (stopAt == 1) { // tuning (ORBFE_BOW_STOP in the environment): the kernel cut short after its n-th stage; results are wrong
+        asm volatile("" ::"s"(Pb.outBase), "s"(N.n1));
+        if (wave == 0) wg1_done(done);
+        return;
+    }
+    const uint8_t* desc1 = Pb.rDesc1 ? Pb.rDesc1 : descPool + (size_t)Pb.d1Base * 32;
+    const uint8_t* desc2 = Pb.rDesc2 ? Pb.rDesc2 : descPool + (size_t)Pb.d2Base * 32;
+    const uint8_t* mask1 = Pb.rMask1 ? Pb.rMask1 : maskPool + Pb.d1Base;
+    const uint8_t* mask2 = Pb.rMask2 ? Pb.rMask2 : maskPool + Pb.d2Base;
+    const float* ang1 = Pb.rAng1 ? Pb.rAng1 : angPool + Pb.d1Base;
+    const float* ang2 = Pb.rAng2 ? Pb.rAng2 : angPool + Pb.d2Base;
+    const int32_t* ind1 = Pb.rInd1 ? Pb.rInd1 : indPool;
+    const int32_t* ind2 = Pb.rInd2 ? Pb.rInd2 : indPool;
+    const int limit1 = Pb.limit1, limit2 = Pb.limit2, Nleft = Pb.Nleft, variant = Pb.variant;
+    const float nnratio = Pb.nnratio;
+    // lane r: row r (every wavefront); lane j: candidate c0 + j of this wavefront's quarter
+    const int per = (N.n2 + 3) >> 2, c0 = wave * per, cn = max(0, min(per, N.n2 - c0));
+    int rIdx = 0, cIdx = 0;
+    bool rOk = false, cOk = false;
+    Desc rD = {}, cD = {};
+    float rAng = 0.f, cAng = 0.f;
+    if (lane < N.n1) {
+        rIdx = ind1[N.off1 + lane];
+        rOk = !(variant == 1 && limit1 != -1 && rIdx >= limit1) && mask1[rIdx] != 0;
+        rD = load_desc(desc1 + (size_t)rIdx * 32);
+        rAng = ang1[rIdx];
+    }
+    if (lane < cn) {
+        cIdx = ind2[N.off2 + c0 + lane];
+        cOk = variant != 1 || (!(limit2 != -1 && cIdx >= limit2) && mask2[cIdx] != 0);
+        cD = load_desc(desc2 + (size_t)cIdx * 32);
+        cAng = ang2[cIdx];
+        sIdx[c0 + lane] = cIdx;
+        sAng[c0 + lane] = cAng;
+        sOk[c0 + lane] = cOk ? 1 : 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) sDesc[c0 + lane][w] = cD.w[w];
+    }
+#ifdef ORBFE_BOW_TIMING
+    asm volatile("" ::"v"(rD.w[0]), "v"(cD.w[0]), "v"(rAng), "v"(cAng), "v"(rOk), "v"(cOk));
+    if (wave == 0) BT(1);
+#endif
+    if (stopAt == 2) {
+        asm volatile("" ::"v"(rD.w[0]), "v"(cD.w[0]), "v"(rAng), "v"(cAng), "v"(rOk), "v"(cOk), "v"(rD.w[3]), "v"(cD.w[3]));
+        if (wave == 0) wg1_done(done);
+        return;
+    }
+    const unsigned INF = 0xFFFFFFFFu;
+    unsigned kL[4] = {INF, INF, INF, INF}, kR[2] = {INF, INF};
+    for (int j = 0; j < cn; j++) { // (uniform)
+        if (!__builtin_amdgcn_readlane((int)cOk, j)) continue;
+        Desc d2;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cD.w[w] & 0xFFFFFFFFull), j);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cD.w[w] >> 32), j);
+            d2.w[w] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
+        const unsigned key = ((unsigned)hamming(rD, d2) << 20) | (unsigned)(c0 + j);
+        const bool right = variant == 0 && Nleft != -1 && __builtin_amdgcn_readlane(cIdx, j) >= Nleft; // (uniform)
+        if (!right) sorted_insert(kL, key);
+        else sorted_insert(kR, key);
+    }
+    if (wave != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) partK[wave - 1][i][lane] = kL[i];
+        partK[wave - 1][4][lane] = kR[0];
+        partK[wave - 1][5][lane] = kR[1];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) sorted_insert(kL, partK[w][i][lane]);
+        sorted_insert(kR, partK[w][4][lane]);
+        sorted_insert(kR, partK[w][5][lane]);
+    }
+#ifdef ORBFE_BOW_TIMING
+    asm volatile("" ::"v"(kL[0]), "v"(kL[3]), "v"(kR[0]));
+    BT(2);
+#endif
+    if (stopAt == 3) {
+        asm volatile("" ::"v"(kL[0]), "v"(kL[1]), "v"(kL[2]), "v"(kL[3]), "v"(kR[0]), "v"(kR[1]));
+        wg1_done(done);
+        return;
+    }
+    // ---- decisions: fixed point of "outcome of row r given what the earlier rows take"
+    // (for the rows the stored keys cannot decide: lane c = candidate c, all candidates, from LDS)
+    Desc aD = {};
+    bool aOk = false, aRight = false;
+    if (lane < N.n2) {
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(&sDesc[lane][0]);
+        const ulonglong2 u = q[0], v = q[1];
+        aD.w[0] = u.x;
+        aD.w[1] = u.y;
+        aD.w[2] = v.x;
+        aD.w[3] = v.y;
+        aOk = sOk[lane] != 0;
+        aRight = variant == 0 && Nleft != -1 && sIdx[lane] >= Nleft;
+    }
+    const bool active = lane < N.n1 && rOk;
+    unsigned long long acc = 0ull; // this row's outcome as candidate bits (at most one left and one right candidate)
+    int accL = -1, accR = -1;
+    // a row's exact keys for one particular set of taken candidates (valid while its T is exactly that set)
+    unsigned long long cT = 0ull;
+    unsigned cE0 = INF, cE1 = INF, cF0 = INF;
+    bool cValid = false;
+    auto passes = [&](int d) { return variant == 0 ? d <= TH_LOW : d < TH_LOW; }; // :373 vs :906
+    const int roundCap = stopAt > 10 ? stopAt - 10 : N.n1 + 2; // (tuning: ORBFE_BOW_STOP=10+k ends after k rounds)
+    for (int round = 0; round < roundCap; round++) { // (settles within n1 + 1 rounds; normally 2-4)
+        const unsigned long long T =
+            ((unsigned long long)wave_excl_or_u32((unsigned)(acc >> 32)) << 32) | (unsigned long long)wave_excl_or_u32((unsigned)acc);
+        auto isFree = [&](unsigned k) { return k != INF && ((T >> (k & 63u)) & 1ull) == 0ull; };
+        int nL = -1, nR = -1;
+        bool un = false;
+        // the exact rule on keys that are known to be the best / second-best free left and the best free right candidate
+        auto decide = [&](unsigned b0, unsigned b1, unsigned q0) {
+            const int d1 = b0 == INF ? 256 : (int)(b0 >> 20), d2 = b1 == INF ? 256 : (int)(b1 >> 20),
+                      dR = q0 == INF ? 256 : (int)(q0 >> 20);
+            nL = -1;
+            nR = -1;
+            if (passes(d1)) {
+                if ((float)d1 < __fmul_rn(nnratio, (float)d2)) nL = (int)(b0 & 63u);
+                if (variant == 0 && dR <= TH_LOW) nR = (int)(q0 & 63u); // ratio test is "|| true" in the reference (:405)
+            }
+        };
+        if (active) {
+            if (cValid && cT == T) {
+                decide(cE0, cE1, cF0);
+            } else {
+                unsigned b0 = INF, b1 = INF;
+                int nb = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool f = isFree(kL[i]);
+                    b1 = (f && nb == 1) ? kL[i] : b1;
+                    b0 = (f && nb == 0) ? kL[i] : b0;
+                    nb += f ? 1 : 0;
+                }
+                const bool moreL = kL[3] != INF; // the row may have left candidates beyond the four stored (all with keys > kL[3])
+                const int dLast = (int)(kL[3] >> 20);
+                const unsigned q0 = isFree(kR[0]) ? kR[0] : (isFree(kR[1]) ? kR[1] : INF);
+                const bool moreR = kR[1] != INF && q0 == INF;
+                const int d1 = b0 == INF ? 256 : (int)(b0 >> 20);
+                if (nb == 0 && moreL) {
+                    un = passes(dLast); // an unseen candidate (distance >= dLast) might pass
+                } else if (passes(d1)) {
+                    if (nb == 1 && moreL) { // the second-best is an unseen candidate: its distance is >= dLast
+                        if ((float)d1 < __fmul_rn(nnratio, (float)dLast)) nL = (int)(b0 & 63u); // passes against any of them
+                        else un = true;
+                    } else {
+                        decide(b0, b1, q0);
+                    }
+                    if (variant == 0 && !un) {
+                        const int dR = q0 == INF ? 256 : (int)(q0 >> 20);
+                        nR = dR <= TH_LOW ? (int)(q0 & 63u) : -1;
+                        if (nR < 0 && moreR && (int)(kR[1] >> 20) <= TH_LOW) un = true;
+                    }
+                }
+            }
+        }
+        // rows the stored keys do not decide: their scan again, across the lanes, without the candidates taken before them
+        for (unsigned long long m = __ballot(un); m; m &= m - 1ull) { // (uniform)
+            const int r = (int)__builtin_ctzll(m);
+            const unsigned long long Tr = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(T >> 32), r) << 32) |
+                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)T, r);
+            Desc d1;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] & 0xFFFFFFFFull), r);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rD.w[w] >> 32), r);
+                d1.w[w] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            }
+            unsigned e0 = INF, e1 = INF, f0 = INF;
+            if (lane < N.n2 && aOk && !((Tr >> lane) & 1ull)) {
+                const unsigned key = ((unsigned)hamming(d1, aD) << 20) | (unsigned)lane;
+                if (aRight) f0 = key;
+                else e0 = key;
+            }
+            wave_two_min(e0, e1);
+            f0 = wave_min_u32(f0);
+            if (lane == r) {
+                cE0 = e0;
+                cE1 = e1;
+                cF0 = f0;
+                cT = T;
+                cValid = true;
+                decide(e0, e1, f0);
+            }
+        }
+        const unsigned long long nacc = (nL >= 0 ? 1ull << nL : 0ull) | (nR >= 0 ? 1ull << nR : 0ull);
+        const bool changed = nacc != acc || nL != accL || nR != accR;
+        acc = nacc;
+        accL = nL;
+        accR = nR;
+#ifdef ORBFE_BOW_TIMING
+        btRounds++;
+#endif
+        if (__ballot(changed) == 0ull) break;
+    }
+#ifdef ORBFE_BOW_TIMING
+    asm volatile("" ::"v"(acc), "v"(accL), "v"(accR));
+    BT(3); // the rounds
+#endif
+    if (stopAt == 4) {
+        asm volatile("" ::"v"(acc), "v"(accL), "v"(accR));
+        wg1_done(done);
+        return;
+    }
+    int32_t* match = matchPool + Pb.outBase;
+    int8_t* bins = binsPool + Pb.outBase;
+    if (accL >= 0) {
+        const int idx2 = sIdx[accL];
+        const int8_t bin = (int8_t)rot_bin(rAng, sAng[accL]);
+        if (variant == 0) {
+            match[idx2] = rIdx;
+            bins[idx2] = bin;
+        } else {
+            match[rIdx] = idx2;
+            bins[rIdx] = bin;
+        }
+    }
+    if (accR >= 0) { // (variant 0 only)
+        const int idx2 = sIdx[accR];
+        match[idx2] = rIdx;
+        bins[idx2] = (int8_t)rot_bin(rAng, sAng[accR]);
+    }
+    BT(4); // stores issued
+    wg1_done(done);
+    BT_END();
 }
 
 // ------------------------------------------------------------------- K-TRI
@@ -921,6 +1298,12 @@ struct ProjDev {
     int32_t* featMatch; // n
     int32_t* status;    // nmatches, sweeps, keys needed
     int sweepLds;       // k_proj_sweeps keeps minW and state in its dynamic LDS
+    // latency path (one search against a resident frame): k_proj_sweeps -- one workgroup -- copies status | qMatch | featMatch
+    // (contiguous) into the pinned mirror and publishes the call's completion word (DoneSig; no counter: one workgroup)
+    int32_t* mirror;
+    int mirrorInts;
+    unsigned* doneFlag;
+    unsigned doneSeq;
 };
 #define PROJ_GC 64
 #define PROJ_GR 48
@@ -1246,6 +1629,19 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
         }
     }
     if (cnt) atomicAdd(&P.status[0], cnt);
+    if (P.mirror) { // (uniform)
+        // the results were built with atomics in device memory (no atomics across PCIe); now that every thread's are done,
+        // the block goes to the host as plain stores, and the completion word behind them
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < P.mirrorInts; i += PROJ_THREADS) P.mirror[i] = P.status[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && P.doneFlag) {
+            __threadfence_system();
+            *(volatile unsigned*)P.doneFlag = P.doneSeq;
+        }
+    }
 }
 
 // one problem per launch (argument by value) / one problem per blockIdx.y (orbfe_search_projection_batch)
@@ -1469,6 +1865,10 @@ struct Arena {
     unsigned* doneFlag = nullptr;    // host address
     unsigned* doneFlagDev = nullptr; // the kernel's address of the same word
     unsigned doneSeq = 0;
+    // the clean block: device memory that is all ones between calls (the kernels' scattered results; DoneSig)
+    uint8_t* cleanDev = nullptr;
+    size_t cleanCap = 0;
+    bool cleanDirty = false;
     ~Arena()
     { // thread exit: give the scratch back (a thread that called the matcher once used to leak it)
         if (device < 0) return;
@@ -1477,6 +1877,7 @@ struct Arena {
         if (base) (void)hipFree(base);
         if (pin) (void)hipHostFree(pin);
         if (doneCtr) (void)hipFree(doneCtr);
+        if (cleanDev) (void)hipFree(cleanDev);
         if (doneFlag) (void)hipHostFree(doneFlag);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1708,46 +2109,153 @@ struct Scratch { // device allocations of one call
     // time -- a call that takes longer than that gains nothing from spinning -- and falls back to the stream synchronisation,
     // which also surfaces a failed launch.  ORBFE_MATCHER_SPIN=0 switches the flag off (A/B).  The flag word is allocated
     // coherent like the mirror.
-    DoneSig done_sig(unsigned waves /* the kernel runs four per workgroup */)
+    // ---- results of the latency-path calls (DoneSig above)
+    struct OutBlock {
+        uint8_t* dev = nullptr;   // the arena's clean block: device memory, all ones between calls; the kernel scatters into it
+        uint8_t* host = nullptr;  // its pinned mirror (host address): complete when complete() returns
+        uint4* mirrorDev = nullptr;
+        size_t bytes = 0;
+        bool direct = false;      // dev IS the mirror (the kernel's address of it): the kernel's stores cross PCIe themselves
+    };
+    // 0: *ob describes where the kernel puts `bytes` of results (all ones to begin with) and where the host finds them;
+    // 1: not available (the caller downloads as before).  `wgs` = workgroups of the kernel: which of the two forms is used
+    // (ORBFE_MATCHER_BLOCK: 0 = always straight into the mirror -- the default: on one box the three policies were within
+    // 1 us of each other for the 12 000-row triangulation batch, and the block cost the small calls 2-9 us (the copy is
+    // one wavefront's work behind the last workgroup) --, 2 = always through the clean block, 1 = the block for grids too
+    // large for the in-kernel completion word)
+    int out_block(OutBlock* ob, size_t bytes, unsigned wgs)
     {
-        DoneSig d{nullptr, nullptr, 0u, (waves + 3u) / 4u, waves};
+        bytes = (bytes + 15) & ~(size_t)15;
+        if (!ar->pinCoherent) return 1;
+        static const int policy = [] {
+            const char* e = getenv("ORBFE_MATCHER_BLOCK");
+            return e ? atoi(e) : 0;
+        }();
+        if (policy == 0 || (policy == 1 && wgs <= 256u)) {
+            uint8_t *md = nullptr, *mh = nullptr;
+            if (mirror_out(&md, &mh, bytes) != 0) return 1;
+            std::memset(mh, 0xFF, bytes);
+            ob->dev = md;
+            ob->host = mh;
+            ob->mirrorDev = nullptr;
+            ob->bytes = bytes;
+            ob->direct = true;
+            return 0;
+        }
+        if (ar->cleanCap < bytes || ar->cleanDirty) {
+            if (ar->cleanCap < bytes) {
+                if (ar->cleanDev) {
+                    (void)hipStreamSynchronize(g_ms);
+                    (void)hipFree(ar->cleanDev);
+                    ar->cleanDev = nullptr;
+                    ar->cleanCap = 0;
+                }
+                void* p = nullptr;
+                const size_t want = std::max<size_t>(2 * bytes, 64u << 10);
+                if (hipMalloc(&p, want) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return 1;
+                }
+                ar->cleanDev = (uint8_t*)p;
+                ar->cleanCap = want;
+            }
+            if (hipMemsetAsync(ar->cleanDev, 0xFF, ar->cleanCap, g_ms) != hipSuccess) { // (on the call's own stream)
+                (void)hipGetLastError();
+                return 1;
+            }
+            ar->cleanDirty = false;
+        }
+        uint8_t *md = nullptr, *mh = nullptr;
+        if (mirror_out(&md, &mh, bytes) != 0) return 1;
+        ob->dev = ar->cleanDev;
+        ob->host = mh;
+        ob->mirrorDev = reinterpret_cast<uint4*>(md);
+        ob->bytes = bytes;
+        return 0;
+    }
+    static bool spin_enabled()
+    {
         static const bool enabled = [] {
             const char* e = getenv("ORBFE_MATCHER_SPIN");
             if (!e) e = getenv("ORBFE_SPIN"); // (the extractor's switch for the same mechanism)
             return !(e && e[0] == '0');
         }();
-        // (only where nothing is uploaded in front of the kernel: a copy command queued behind a kernel the runtime still
-        // holds as running came out slower -- and only for small grids, see DoneSig)
-        if (!enabled || waves == 0 || d.total > 256u || !inPlace || !ar->pinCoherent) return d;
-        if (!ar->doneCtr) {
-            void *c = nullptr, *h = nullptr, *dv = nullptr;
-            // (cleared on the call's own stream: the null stream is not ordered with a non-blocking one)
-            if (hipMalloc(&c, 64) != hipSuccess || hipMemsetAsync(c, 0, 64, g_ms) != hipSuccess ||
-                hipHostMalloc(&h, 64, hipHostMallocCoherent) != hipSuccess ||
-                hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                if (c) (void)hipFree(c);
-                if (h) (void)hipHostFree(h);
-                return d;
-            }
-            ar->doneCtr = (unsigned*)c;
-            ar->doneFlag = (unsigned*)h;
-            ar->doneFlagDev = (unsigned*)dv;
-            *ar->doneFlag = 0u;
+        return enabled;
+    }
+    bool done_words()
+    {
+        if (ar->doneCtr) return true;
+        void *c = nullptr, *h = nullptr, *dv = nullptr;
+        // (cleared on the call's own stream: the null stream is not ordered with a non-blocking one)
+        if (hipMalloc(&c, 64) != hipSuccess || hipMemsetAsync(c, 0, 64, g_ms) != hipSuccess ||
+            hipHostMalloc(&h, 64, hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c) (void)hipFree(c);
+            if (h) (void)hipHostFree(h);
+            return false;
         }
+        ar->doneCtr = (unsigned*)c;
+        ar->doneFlag = (unsigned*)h;
+        ar->doneFlagDev = (unsigned*)dv;
+        *ar->doneFlag = 0u;
+        return true;
+    }
+    // The main kernel's completion record.  With a flag (ctr / flag / seq set): the kernel counts its workgroups and the last
+    // one copies the block and publishes -- small grids whose inputs are read in place (a copy command queued behind a kernel
+    // the runtime still holds as running came out slower) and nobody timing the kernel.  Otherwise only the block's addresses
+    // are filled in (the kernel scatters into it) and complete() queues k_copy_out behind the kernel.
+    DoneSig done_sig(unsigned waves /* the kernel runs four per workgroup */, const OutBlock* ob, bool timed)
+    {
+        DoneSig d{nullptr, nullptr, 0u, (waves + 3u) / 4u, waves, nullptr, nullptr, 0u};
+        if (!ob || !ob->dev) return d;
+        if (!ob->direct) {
+            d.outDev = reinterpret_cast<uint4*>(ob->dev);
+            d.outMirror = ob->mirrorDev;
+            d.out16 = (unsigned)(ob->bytes >> 4);
+        }
+        if (!spin_enabled() || timed || waves == 0 || d.total > 256u || !inPlace || !done_words()) return d;
         if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
         d.ctr = ar->doneCtr;
         d.flag = ar->doneFlagDev;
         d.seq = ar->doneSeq;
         return d;
     }
-    int wait_done(const DoneSig& d)
+    // a word without a block or a counter: for a kernel whose one workgroup writes the mirror itself (K-PROJ's sweeps)
+    DoneSig flag_only()
     {
-        if (d.flag) {
+        DoneSig d{nullptr, nullptr, 0u, 1u, 1u, nullptr, nullptr, 0u};
+        if (!spin_enabled() || !inPlace || !ar->pinCoherent || !done_words()) return d;
+        if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+        d.ctr = ar->doneCtr;
+        d.flag = ar->doneFlagDev;
+        d.seq = ar->doneSeq;
+        return d;
+    }
+    // after the main kernel has been launched: the block's mirror is complete when this returns
+    int complete(const DoneSig& d)
+    {
+        DoneSig w = d;
+        if (!d.flag && d.outDev) { // the copy as a kernel of its own (it publishes the flag when the word may be used)
+            const unsigned wgs = std::min(32u, std::max(1u, d.out16 / 1024u));
+            w.total = wgs;
+            if (spin_enabled() && done_words()) {
+                if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+                w.ctr = ar->doneCtr;
+                w.flag = ar->doneFlagDev;
+                w.seq = ar->doneSeq;
+            }
+            hipLaunchKernelGGL(k_copy_out, dim3(wgs), dim3(256), 0, g_ms, w);
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                ar->cleanDirty = true;
+                return -(1000 + (int)le);
+            }
+        }
+        if (w.flag) {
             const volatile unsigned* f = ar->doneFlag;
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0;; it++) {
-                if (*f == d.seq) {
+                if (*f == w.seq) {
                     std::atomic_thread_fence(std::memory_order_acquire);
                     return 0;
                 }
@@ -1758,7 +2266,8 @@ struct Scratch { // device allocations of one call
         hipError_t e = hipStreamSynchronize(g_ms);
         // the word did not come within the bound: normally a long call (its counter is back at zero by now); should the counter
         // ever be left non-zero -- a kernel that died half-way -- every later call would time out, so it is cleared here
-        if (e == hipSuccess && d.flag) e = hipMemsetAsync(d.ctr, 0, sizeof(unsigned), g_ms);
+        if (e == hipSuccess && w.flag) e = hipMemsetAsync(w.ctr, 0, sizeof(unsigned), g_ms);
+        if (e != hipSuccess) ar->cleanDirty = true; // (the block may hold half a call's results)
         return e == hipSuccess ? 0 : -(1000 + (int)e);
     }
 };
@@ -2035,6 +2544,15 @@ static size_t inplace_limit()
     }();
     return v;
 }
+// tuning: ORBFE_BOW_STOP=n cuts K-BOW short after its n-th stage (wrong results; where the time of a call goes)
+static int bow_stop_at()
+{
+    static const int v = [] {
+        const char* e = getenv("ORBFE_BOW_STOP");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
 // tuning only (tools/ab_build.sh trace "-DORBFE_CALL_TRACE", ORBFE_CALL_TRACE=1 in the environment): where the host time of a
 // matcher call goes, printed per call
 #ifdef ORBFE_CALL_TRACE
@@ -2181,11 +2699,14 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     // results: written by the kernel into the pinned mirror when they are small (no download command), else downloaded
     int32_t* hM = nullptr;
     int8_t* hB = nullptr;
-    const bool mirrored = (size_t)outTotal * 5 <= (256u << 10) && s.mirror_out(&dM, &hM, (size_t)outTotal) == 0 &&
-                          s.mirror_out(&dB, &hB, (size_t)outTotal) == 0;
-    if (mirrored) {
-        std::memset(hM, 0xFF, (size_t)outTotal * sizeof(int32_t));
-        std::memset(hB, 0xFF, (size_t)outTotal);
+    Scratch::OutBlock ob;
+    const size_t mBytes = ((size_t)outTotal * sizeof(int32_t) + 15) & ~(size_t)15;
+    const bool mirrored = (size_t)outTotal * 5 <= (256u << 10) && s.out_block(&ob, mBytes + (size_t)outTotal, (unsigned)nodes.size()) == 0;
+    if (mirrored) { // (the kernel scatters into the clean device block; its mirror arrives whole: DoneSig)
+        dM = reinterpret_cast<int32_t*>(ob.dev);
+        dB = reinterpret_cast<int8_t*>(ob.dev + mBytes);
+        hM = reinterpret_cast<int32_t*>(ob.host);
+        hB = reinterpret_cast<int8_t*>(ob.host + mBytes);
     } else {
         if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
         if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
@@ -2232,15 +2753,14 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
     }
     if (needTaken) HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
-    // (completion word: only where the kernel writes the results into the pinned mirror itself and nobody times the kernel)
-    const DoneSig done = mirrored && !g_timeKernels ? s.done_sig((unsigned)nodes.size()) : DoneSig{nullptr, nullptr, 0u, 0u, 0u};
+    const DoneSig done = s.done_sig(4u * (unsigned)nodes.size() /* (a workgroup per node) */, mirrored ? &ob : nullptr, g_timeKernels);
     PTR(); // staging
     {
         KernelTimer timer(s); // (sends the staged pools)
         for (const D2D& c : d2d)
             HIP_TRY(hipMemcpyAsync(dDesc + c.off, c.src, c.bytes, hipMemcpyDeviceToDevice, g_ms));
-        hipLaunchKernelGGL(k_search_bow, dim3((unsigned)((nodes.size() + 3) / 4)), dim3(256), 0, g_ms, dN, (int)nodes.size(),
-                           dP, dDesc, dMask, dAng, dInd, dM, dB, taken, done);
+        hipLaunchKernelGGL(k_search_bow, dim3((unsigned)nodes.size()), dim3(256), 0, g_ms, dN, (int)nodes.size(),
+                           dP, dDesc, dMask, dAng, dInd, dM, dB, taken, done, bow_stop_at());
     }
     HIP_TRY(hipGetLastError());
     PTR(); // launch
@@ -2248,8 +2768,8 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     std::vector<int8_t> bins;
     const int32_t* pm;
     const int8_t* pb;
-    if (mirrored) { // the kernel has written the pinned mirror: wait, read
-        INT_TRY(s.wait_done(done));
+    if (mirrored) { // the results arrive in the pinned mirror: wait, read
+        INT_TRY(s.complete(done));
         PTR(); // sync
         pm = hM;
         pb = hB;
@@ -2439,9 +2959,12 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     if ((r = s.reserve(&dTab, &hTab, tabFloats)) < 0) return r;
     if ((r = s.reserve(&dP, &hP, (size_t)count)) < 0) return r;
     int32_t* hMir = nullptr;
-    const bool mirrored = (size_t)count * n1 * 4 <= (256u << 10) && s.mirror_out(&dM, &hMir, (size_t)count * n1) == 0;
-    if (mirrored) std::memset(hMir, 0xFF, (size_t)count * n1 * sizeof(int32_t));
-    else if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
+    Scratch::OutBlock ob;
+    const bool mirrored = (size_t)count * n1 * 4 <= (256u << 10) && s.out_block(&ob, (size_t)count * n1 * sizeof(int32_t), (unsigned)((rows.size() + 3) / 4)) == 0;
+    if (mirrored) {
+        dM = reinterpret_cast<int32_t*>(ob.dev);
+        hMir = reinterpret_cast<int32_t*>(ob.host);
+    } else if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
     size_t tOff = 0, ovAt = 0;
     for (int p = 0; p < count; p++) {
         const orbfe_keyframe* K2 = kf2[p];
@@ -2467,7 +2990,7 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
         Q.pad = 0;
     }
     if (!mirrored) HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
-    const DoneSig done = mirrored && !g_timeKernels ? s.done_sig((unsigned)rows.size()) : DoneSig{nullptr, nullptr, 0u, 0u, 0u};
+    const DoneSig done = s.done_sig((unsigned)rows.size(), mirrored ? &ob : nullptr, g_timeKernels);
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri_batch, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), dP,
@@ -2477,7 +3000,7 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     std::vector<int32_t> m;
     int32_t* mAll;
     if (mirrored) {
-        INT_TRY(s.wait_done(done));
+        INT_TRY(s.complete(done));
         mAll = hMir;
     } else {
         m.resize((size_t)count * n1);
@@ -2561,13 +3084,16 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     if ((r = s.up(&o2, a->octave2, (size_t)a->n2)) < 0) return r;
     if ((r = s.up(&i2, a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn])) < 0) return r;
     int32_t* hM = nullptr;
-    const bool mirrored = (size_t)a->n1 * 4 <= (256u << 10) && s.mirror_out(&dM, &hM, (size_t)a->n1) == 0;
-    if (mirrored) std::memset(hM, 0xFF, (size_t)a->n1 * sizeof(int32_t));
-    else {
+    Scratch::OutBlock ob;
+    const bool mirrored = (size_t)a->n1 * 4 <= (256u << 10) && s.out_block(&ob, (size_t)a->n1 * sizeof(int32_t), (unsigned)((rows.size() + 3) / 4)) == 0;
+    if (mirrored) {
+        dM = reinterpret_cast<int32_t*>(ob.dev);
+        hM = reinterpret_cast<int32_t*>(ob.host);
+    } else {
         if ((r = s.up<int32_t>(&dM, nullptr, (size_t)a->n1)) < 0) return r;
         HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)a->n1 * sizeof(int32_t), g_ms));
     }
-    const DoneSig done = mirrored && !g_timeKernels ? s.done_sig((unsigned)rows.size()) : DoneSig{nullptr, nullptr, 0u, 0u, 0u};
+    const DoneSig done = s.done_sig((unsigned)rows.size(), mirrored ? &ob : nullptr, g_timeKernels);
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), d1,
@@ -2576,7 +3102,7 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m12(a->n1);
     if (mirrored) {
-        INT_TRY(s.wait_done(done));
+        INT_TRY(s.complete(done));
         std::memcpy(m12.data(), hM, (size_t)a->n1 * sizeof(int32_t));
     } else {
         INT_TRY(s.down(m12.data(), dM, (size_t)a->n1 * sizeof(int32_t)));
@@ -3196,6 +3722,11 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
     std::vector<ProjJob> jobs(live.size());
+    // latency path: ONE search against a resident frame (what Tracking issues per frame).  Only the queries travel: the kernels
+    // read them from the pinned staging in place, the last kernel copies the results into the pinned mirror and publishes the
+    // completion word -- no upload command, no download command, no stream synchronisation
+    const bool latency = frame && live.size() == 1;
+    if (latency) s.inPlace = (size_t)items[live[0]].nq * 72 + (size_t)items[live[0]].n * 9 + 4096 <= inplace_limit();
     size_t outInts = 0, sweepBytes = 0;
     unsigned maxBlocks = 1;
     for (size_t j = 0; j < jobs.size(); j++) // (the inputs of all searches first: one upload for the batch)
@@ -3216,7 +3747,11 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         jobs[j].P.qMatch = jobs[j].P.status + 4;
         jobs[j].P.featMatch = jobs[j].P.qMatch + a->nq;
     }
-    std::vector<int32_t> out(outInts);
+    int32_t *dMir = nullptr, *hMir = nullptr;
+    const bool mirrored = latency && s.inPlace && !g_timeKernels && outInts * 4 <= (256u << 10) &&
+                          s.mirror_out(&dMir, &hMir, outInts) == 0;
+    std::vector<int32_t> outv(mirrored ? 0 : outInts);
+    const int32_t* out = mirrored ? hMir : outv.data();
     std::vector<ProjDev> hostP(jobs.size());
     PTR(); // staging
     for (int attempt = 0;; attempt++) {
@@ -3224,6 +3759,14 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         if (jobs.size() > 1) {
             for (size_t j = 0; j < jobs.size(); j++) hostP[j] = jobs[j].P;
             if ((r = s.up(&dP, hostP.data(), hostP.size())) < 0) return r;
+        }
+        DoneSig done{nullptr, nullptr, 0u, 0u, 0u, nullptr, nullptr, 0u};
+        if (mirrored) {
+            done = s.flag_only(); // (one workgroup writes the mirror and publishes: neither block nor counter)
+            jobs[0].P.mirror = dMir;
+            jobs[0].P.mirrorInts = (int)outInts;
+            jobs[0].P.doneFlag = done.flag;
+            jobs[0].P.doneSeq = done.seq;
         }
         {
             KernelTimer timer(s);
@@ -3242,8 +3785,11 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         }
         HIP_TRY(hipGetLastError());
         PTR(); // flush + launches
-        INT_TRY(s.down(out.data(), dOut, out.size() * 4));
-        INT_TRY(s.fetch());
+        if (mirrored) INT_TRY(s.complete(done));
+        else {
+            INT_TRY(s.down(outv.data(), dOut, outv.size() * 4));
+            INT_TRY(s.fetch());
+        }
         PTR(); // fetch
         // more candidate keys than a job's buffers hold: the kernel reported how many it needs; run again
         bool again = false;
@@ -3264,7 +3810,7 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     for (size_t j = 0; j < jobs.size(); j++) {
         const int k = live[j];
         g_lastProjSweeps = out[jobs[j].outOff + 1];
-        nmatches[k] = proj_finish(&items[k], out.data() + jobs[j].outOff, q_match[k], feat_match[k]);
+        nmatches[k] = proj_finish(&items[k], out + jobs[j].outOff, q_match[k], feat_match[k]);
     }
     PTR();
 #ifdef ORBFE_CALL_TRACE
@@ -3401,6 +3947,18 @@ int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t
 
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
 void orbfe_matcher_time_kernels(int on) { g_timeKernels = on != 0; }
+#ifdef ORBFE_BOW_TIMING
+extern "C" int orbfe_debug_bow_times(unsigned long long* out8 /* 16 */, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bowTimes), sizeof(g_bowTimes)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        z[11] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bowTimes), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 struct orbfe_vocab_dev {
     int device, nnodes, L;

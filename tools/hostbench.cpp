@@ -14,6 +14,7 @@
 //                                     from two threads started per frame, then Frame::ComputeStereoMatches on the
 //                                     device-resident results (orbfe_compute_stereo_matches_resident)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -306,6 +307,30 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
         fprintf(stderr, "hostbench: SearchByBoW forms disagree: %d %d %d\n", nmHost, nmDev, nmKf);
         return 2;
     }
+    // (a library built with -DORBFE_BOW_TIMING exports the phase times of K-BOW's slowest wavefront: tuning only)
+    if (auto bt = (int (*)(unsigned long long*, int))dlsym(RTLD_DEFAULT, "orbfe_debug_bow_times")) {
+        unsigned long long t[16];
+        bt(t, 1);
+        for (int i = 0; i < 20; i++) {
+            int nm = 0;
+            CHECK(orbfe_search_bow_keyframes(dev, 1, kf1, nullptr, &bowDev, mp, &nm));
+        }
+        for (int i = 0; i < 3; i++) { // one launch at a time: when its wavefronts started and ended (100-MHz counter common to the chip)
+            unsigned long long u[16];
+            bt(u, 1);
+            int nm = 0;
+            const auto h0 = std::chrono::steady_clock::now();
+            CHECK(orbfe_search_bow_keyframes(dev, 1, kf1, nullptr, &bowDev, mp, &nm));
+            const double callUs = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+            hipDeviceSynchronize();
+            bt(u, 0);
+            fprintf(stderr, "K-BOW launch %d: call %.1f us; first wavefront start -> last start %.2f us, -> last end %.2f us\n", i, callUs,
+                    (u[13] - u[11]) * 0.01, (u[12] - u[11]) * 0.01);
+        }
+        if (bt(t, 0) == 0)
+            fprintf(stderr, "K-BOW, first wavefront of a node, max over the nodes (us): records %.2f  prefetch %.2f  scan + merge %.2f  rounds %.2f  stores issued %.2f  stores acknowledged %.2f  counter %.2f  fence + flag %.2f; nodes %llu, rounds %llu\n",
+                    t[0] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[7] * 0.01, t[9] * 0.01, t[10] * 0.01, t[4] * 0.01, t[5], t[6]);
+    }
     float bowKernelMs = -1.f;
     {
         orbfe_matcher_time_kernels(1); // (events + a synchronisation per call: only for this one measurement)
@@ -393,6 +418,19 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     std::vector<int32_t> qm(nA), fm(nB);
     int nProj = 0;
     if (timeit("search_projection_host_arrays", 200, [&] { return nProj = orbfe_search_projection(dev, &pr, qm.data(), fm.data()); }, out)) return 2;
+    {   // the frame side resident (orbfe_frame_create: what the adapter keeps per Frame; Tracking searches one Frame several
+        // times -- src/Tracking.cc:2817-2827, :2927): only the queries travel
+        orbfe_frame* fr = nullptr;
+        CHECK(orbfe_frame_create(&fr, dev, &pr));
+        std::vector<int32_t> qm2(nA), fm2(nB);
+        int n2 = 0;
+        if (timeit("search_projection_frame_handle", 300, [&] { return n2 = orbfe_search_projection_frame(fr, &pr, qm2.data(), fm2.data()); }, out)) return 2;
+        orbfe_frame_destroy(fr);
+        if (n2 != nProj || qm2 != qm || fm2 != fm) {
+            fprintf(stderr, "hostbench: SearchByProjection forms disagree: %d %d\n", nProj, n2);
+            return 2;
+        }
+    }
     std::vector<orbfe_proj_args> prs(NB, pr);
     std::vector<std::vector<int32_t>> qms(NB, std::vector<int32_t>(nA)), fms(NB, std::vector<int32_t>(nB));
     std::vector<int32_t*> qmp(NB), fmp(NB);

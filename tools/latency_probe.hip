@@ -22,6 +22,26 @@ __global__ void k_work(int spin, volatile unsigned* flag, unsigned seq, int* sin
     }
 }
 
+// the same round trip for a kernel that scatters `nw` 4-byte results first: into page-locked host memory (what the matcher's
+// latency path does) or into device memory
+__global__ void k_scatter(int spin, volatile unsigned* flag, unsigned seq, int* sink, unsigned* out, int nw, unsigned* ctr)
+{
+    int acc = 0;
+    for (int i = 0; i < spin; i++) acc += __builtin_amdgcn_s_memtime() & 1;
+    if (acc == -1) *sink = acc;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nw) out[(t * 37) % nw * 3] = (unsigned)t; // scattered, 12 bytes apart
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ctr, 1u) + 1u == gridDim.x) {
+        *ctr = 0u;
+        if (flag) {
+            __threadfence_system();
+            *flag = seq;
+        }
+    }
+}
+
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main()
@@ -59,6 +79,45 @@ int main()
             std::sort(t.begin(), t.end());
             printf("spin %4d  %-22s p50 %6.2f us  p99 %6.2f us\n", spin, mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "flag in pinned memory" : "event synchronize",
                    t[t.size() / 2], t[t.size() * 99 / 100]);
+        }
+    }
+    {
+        unsigned *hout, *dhout, *dout, *ctr;
+        CK(hipHostMalloc((void**)&hout, 1 << 20));
+        CK(hipHostGetDevicePointer((void**)&dhout, hout, 0));
+        CK(hipMalloc((void**)&dout, 1 << 20));
+        CK(hipMalloc((void**)&ctr, 64));
+        CK(hipMemset(ctr, 0, 64));
+        hipEvent_t ea, eb;
+        CK(hipEventCreate(&ea));
+        CK(hipEventCreate(&eb));
+        for (int nw : {0, 1000, 4000}) {
+            for (int where = 0; where < 2; where++) {
+                for (int mode = 0; mode < 2; mode++) { // 0: flag, 1: events around the kernel
+                    std::vector<double> t;
+                    for (int it = 0; it < 300; it++) {
+                        seq++;
+                        const double t0 = now_us();
+                        float ms = 0.f;
+                        if (mode == 1) CK(hipEventRecord(ea, st));
+                        hipLaunchKernelGGL(k_scatter, dim3(100), dim3(256), 0, st, 64, mode == 0 ? dflag : nullptr, seq, sink,
+                                           where ? dout : dhout, nw, ctr);
+                        if (mode == 0) {
+                            while (*(volatile unsigned*)hflag != seq) { }
+                        } else {
+                            CK(hipEventRecord(eb, st));
+                            CK(hipEventSynchronize(eb));
+                            CK(hipEventElapsedTime(&ms, ea, eb));
+                        }
+                        const double t1 = now_us();
+                        CK(hipStreamSynchronize(st));
+                        if (it >= 50) t.push_back(mode == 0 ? t1 - t0 : ms * 1000.0);
+                    }
+                    std::sort(t.begin(), t.end());
+                    printf("100 x 256 threads, %4d scattered 4-byte stores to %-6s  %-28s p50 %6.2f us\n", nw, where ? "device" : "host",
+                           mode == 0 ? "launch -> flag seen" : "kernel by events", t[t.size() / 2]);
+                }
+            }
         }
     }
     return 0;
