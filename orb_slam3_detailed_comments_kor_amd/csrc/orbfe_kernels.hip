@@ -585,7 +585,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 
     const int zw = cw - 6, zh = ch - 6; // detection zone
     const int nz = (zw > 0 && zh > 0) ? zw * zh : 0;
-    const int txLo = 3 + ox, txHi = cw - 4 + ox; // zone columns in tile coordinates (inclusive)
+    const int txLo = 3 + ox; // first zone column in tile coordinates (the last one is cw - 4 + ox)
     uint32_t* const out = cand + (size_t)img * candImgStride + c.slotBase;
     int th = iniTh, nk = 0;
     for (int pass = 0;; pass++) {

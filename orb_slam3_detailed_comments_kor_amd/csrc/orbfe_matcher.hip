@@ -99,13 +99,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return min(min(a, b), min(c, d));
 }
 // the two smallest keys of the wavefront (keys of different lanes are distinct, or the sentinel 0xFFFFFFFF): on return k0 <= k1
-// hold them in every lane.  Groups that meet are disjoint, so no key is counted twice.
-__device__ __forceinline__ void two_min_merge(unsigned& k0, unsigned& k1, unsigned o0, unsigned o1)
-{
-    const unsigned lo = min(k0, o0), hi = max(k0, o0);
-    k1 = min(hi, min(k1, o1));
-    k0 = lo;
-}
+// hold them in every lane
 __device__ __forceinline__ void wave_two_min(unsigned& k0, unsigned& k1)
 {
     // as two plain minima (v_min_u32 with a DPP operand: four instructions each): the smallest key, then the smallest of
@@ -956,6 +950,53 @@ struct TriRow {
     int idx1, off2, n2;
 };
 
+// The candidates of one row (lane = candidate, 64 per round): smallest distance, then the LAST position (:1323 rejects only
+// dist > bestDist).  Round 4: everything a candidate needs is loaded at once -- index first, then flag, mvuRight, descriptor,
+// keypoint and octave in flight together -- instead of one load behind each `continue` of the reference's loop (six dependent
+// round trips per wavefront, each ~1 us in HBM and ~2 us when the arrays are read in place from pinned memory); the two level
+// tables come from lanes 0..nlevels-1 with a lane shuffle instead of a seventh dependent load.
+__device__ __forceinline__ unsigned tri_scan(const Desc& d1, bool bStereo1, float la, float lb, float lc, float den, int n2,
+                                             const int32_t* __restrict__ ind2row, const uint8_t* __restrict__ desc2,
+                                             const uint8_t* __restrict__ hasMP2, const float* __restrict__ kp2,
+                                             const int32_t* __restrict__ oct2, const float* __restrict__ uR2,
+                                             const float* __restrict__ sf2, const float* __restrict__ sig2, int nlevels2, float epx,
+                                             float epy, int onlyStereo, int coarse)
+{
+    const int lane = threadIdx.x & 63;
+    const float sfL = lane < nlevels2 ? sf2[lane] : 0.f, sgL = lane < nlevels2 ? sig2[lane] : 0.f;
+    unsigned best = 0xFFFFFFFFu;
+    for (int c0 = 0; c0 < n2; c0 += 64) { // (uniform)
+        const int c = c0 + lane;
+        const bool in = c < n2;
+        const int idx2 = in ? ind2row[c] : 0;
+        const uint8_t mp = in ? hasMP2[idx2] : (uint8_t)1;
+        const float ur = in ? uR2[idx2] : -1.f;
+        const Desc d2 = in ? load_desc(desc2 + (size_t)idx2 * 32) : d1;
+        const float2 k2 = in ? *reinterpret_cast<const float2*>(kp2 + 2 * (size_t)idx2) : make_float2(0.f, 0.f);
+        const int o2 = in ? oct2[idx2] : 0;
+        const float sfo = __shfl(sfL, o2), sgo = __shfl(sgL, o2); // (whole wavefront: before any lane drops out)
+        if (mp) continue;
+        const bool bStereo2 = ur >= 0;
+        if (onlyStereo && !bStereo2) continue;
+        const int dist = hamming(d1, d2);
+        if (dist > TH_LOW) continue;
+        const float k2x = k2.x, k2y = k2.y;
+        if (!bStereo1 && !bStereo2) {
+            const float ex = __fsub_rn(epx, k2x), ey = __fsub_rn(epy, k2y);
+            if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.f, sfo)) continue;
+        }
+        bool ok = coarse != 0;
+        if (!ok && den != 0.f) {
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2x), __fmul_rn(lb, k2y)), lc);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            ok = (double)dsqr < __dmul_rn(3.84, (double)sgo);
+        }
+        if (!ok) continue;
+        best = min(best, ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c));
+    }
+    return wave_min_u32(best);
+}
+
 // One wavefront per unmatched keypoint of KF1 (vbMatched2 is never set in the reference, so rows
 // are independent).  A candidate passes when dist <= TH_LOW, the epipole gate (:1332-1340) and
 // Pinhole::epipolarConstrain_ (Pinhole.cpp:159-181) hold (or bCoarse); the sequential scan keeps
@@ -967,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
                                                     const int32_t* __restrict__ oct2, const float* __restrict__ uR2,
                                                     const int32_t* __restrict__ ind2, const float* __restrict__ F12,
                                                     float epx, float epy, const float* __restrict__ sf2,
-                                                    const float* __restrict__ sig2, int onlyStereo, int coarse,
+                                                    const float* __restrict__ sig2, int nlevels2, int onlyStereo, int coarse,
                                                     int32_t* __restrict__ match12, const DoneSig done)
 {
     __shared__ unsigned wgCnt;
@@ -985,30 +1026,8 @@ __global__ __launch_bounds__(256) void k_search_tri(const TriRow* __restrict__ r
     const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1x, F12[1]), __fmul_rn(k1y, F12[4])), F12[7]);
     const float lc = __fadd_rn(__fadd_rn(__fmul_rn(k1x, F12[2]), __fmul_rn(k1y, F12[5])), F12[8]);
     const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
-    unsigned best = 0xFFFFFFFFu;
-    for (int c = lane; c < R.n2; c += 64) {
-        const int idx2 = ind2[R.off2 + c];
-        if (hasMP2[idx2]) continue;
-        const bool bStereo2 = uR2[idx2] >= 0;
-        if (onlyStereo && !bStereo2) continue;
-        const int dist = hamming(d1, load_desc(desc2 + (size_t)idx2 * 32));
-        if (dist > TH_LOW) continue;
-        const float k2x = kp2[2 * idx2], k2y = kp2[2 * idx2 + 1];
-        const int o2 = oct2[idx2];
-        if (!bStereo1 && !bStereo2) {
-            const float ex = __fsub_rn(epx, k2x), ey = __fsub_rn(epy, k2y);
-            if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.f, sf2[o2])) continue;
-        }
-        bool ok = coarse != 0;
-        if (!ok && den != 0.f) {
-            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2x), __fmul_rn(lb, k2y)), lc);
-            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-            ok = (double)dsqr < __dmul_rn(3.84, (double)sig2[o2]);
-        }
-        if (!ok) continue;
-        best = min(best, ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c)); // smallest dist, then last position
-    }
-    best = wave_min_u32(best);
+    const unsigned best = tri_scan(d1, bStereo1, la, lb, lc, den, R.n2, ind2 + R.off2, desc2, hasMP2, kp2, oct2, uR2, sf2, sig2, nlevels2,
+                                   epx, epy, onlyStereo, coarse);
     if (lane == 0) match12[idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
     wave_done(done, &wgCnt);
 }
@@ -1023,7 +1042,7 @@ struct TriProb {
     float epx, epy;
     int onlyStereo, coarse;
     int outBase; // this problem's match12 row in the pooled output
-    int pad;
+    int nlevels2; // entries of sf2 / sig2
 };
 struct TriRowB {
     int idx1, off2, n2, prob;
@@ -1051,30 +1070,8 @@ __global__ __launch_bounds__(256) void k_search_tri_batch(const TriRowB* __restr
     const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
     const uint8_t* const desc2 = Q.desc2;
     const int32_t* const ind2 = Q.ind2;
-    unsigned best = 0xFFFFFFFFu;
-    for (int c = lane; c < R.n2; c += 64) {
-        const int idx2 = ind2[R.off2 + c];
-        if (Q.hasMP2[idx2]) continue;
-        const bool bStereo2 = Q.uR2[idx2] >= 0;
-        if (Q.onlyStereo && !bStereo2) continue;
-        const int dist = hamming(d1, load_desc(desc2 + (size_t)idx2 * 32));
-        if (dist > TH_LOW) continue;
-        const float k2x = Q.kp2[2 * idx2], k2y = Q.kp2[2 * idx2 + 1];
-        const int o2 = Q.oct2[idx2];
-        if (!bStereo1 && !bStereo2) {
-            const float ex = __fsub_rn(Q.epx, k2x), ey = __fsub_rn(Q.epy, k2y);
-            if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.f, Q.sf2[o2])) continue;
-        }
-        bool ok = Q.coarse != 0;
-        if (!ok && den != 0.f) {
-            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2x), __fmul_rn(lb, k2y)), lc);
-            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-            ok = (double)dsqr < __dmul_rn(3.84, (double)Q.sig2[o2]);
-        }
-        if (!ok) continue;
-        best = min(best, ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)c)); // smallest dist, then last position
-    }
-    best = wave_min_u32(best);
+    const unsigned best = tri_scan(d1, bStereo1, la, lb, lc, den, R.n2, ind2 + R.off2, desc2, Q.hasMP2, Q.kp2, Q.oct2, Q.uR2, Q.sf2, Q.sig2,
+                                   Q.nlevels2, Q.epx, Q.epy, Q.onlyStereo, Q.coarse);
     if (lane == 0)
         matchPool[Q.outBase + idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
     wave_done(done, &wgCnt);
@@ -2521,6 +2518,7 @@ struct orbfe_keyframe {
     std::vector<int32_t> offsets, indices, hOct;
     std::vector<uint8_t> hMask;
     std::vector<float> hAng, hUR;
+    int octMin = 0, octMax = -1; // range of hOct (the triangulation search checks it against the caller's level tables per call)
     orbfe_fv fv() const
     {
         orbfe_fv f;
@@ -2850,6 +2848,11 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     if (tri) {
         K->hUR.assign(a->uRight, a->uRight + n);
         K->hOct.assign(a->octave, a->octave + n);
+        if (n > 0) {
+            const auto mm = std::minmax_element(K->hOct.begin(), K->hOct.end());
+            K->octMin = *mm.first;
+            K->octMax = *mm.second;
+        }
     }
     Scratch s(device); // (this thread's matcher stream)
     const bool descResident = is_device_ptr(a->desc);
@@ -2911,11 +2914,13 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
                            const orbfe_tri_pair* pair, int32_t* const* pairs, int* npairs)
 {
     if (!K1 || count < 0 || (count && (!kf2 || !pair || !pairs || !npairs)) || !K1->hasTri) return ORBFE_ERR_ARGS;
+    PTR_BEGIN();
     const uint8_t* const has1 = hasMP1 ? hasMP1 : K1->hMask.data(); // (per call when given: see orbfe_search_bow_keyframes)
     const int device = K1->device, n1 = K1->n;
     std::vector<TriRowB> rows;
     std::vector<TriProb> probs(count);
     const orbfe_fv f1 = K1->fv();
+    std::vector<int> rowOff[2], rowIdx[2]; // per bOnlyStereo: CSR of K1's rows (features without a MapPoint) by node
     size_t tabFloats = 0;
     for (int p = 0; p < count; p++) {
         const orbfe_keyframe* K2 = kf2[p];
@@ -2923,25 +2928,37 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
         if (!K2 || !K2->hasTri || K2->device != device || !pairs[p] || !q.scaleFactors2 || !q.levelSigma2_2 || q.nlevels2 < 1)
             return ORBFE_ERR_ARGS;
         if (q.check_orientation && (K1->hAng.empty() || K2->hAng.empty())) return ORBFE_ERR_ARGS;
-        for (int i = 0; i < K2->n; i++)
-            if (K2->hOct[i] < 0 || K2->hOct[i] >= q.nlevels2) return ORBFE_ERR_ARGS;
+        if (K2->n > 0 && (K2->octMin < 0 || K2->octMax >= q.nlevels2)) return ORBFE_ERR_ARGS; // (range kept by the handle)
         npairs[p] = 0;
         tabFloats += 2 * (size_t)q.nlevels2;
         const orbfe_fv f2 = K2->fv();
         bool bad = false;
+        // (the rows of a node of K1 are the same for every neighbour with the same bOnlyStereo: listed once per call)
+        const int so = q.only_stereo ? 1 : 0;
+        if (rowOff[so].empty()) {
+            rowOff[so].assign((size_t)f1.nn + 1, 0);
+            rowIdx[so].reserve((size_t)n1);
+            for (int i = 0; i < f1.nn; i++) {
+                for (int k = f1.offsets[i]; k < f1.offsets[i + 1]; k++) {
+                    const int idx1 = f1.indices[k];
+                    if (has1[idx1]) continue;                              // :1279-1282
+                    if (so && !(K1->hUR[idx1] >= 0)) continue;             // :1286-1288
+                    rowIdx[so].push_back(idx1);
+                }
+                rowOff[so][(size_t)i + 1] = (int)rowIdx[so].size();
+            }
+            rows.reserve(rows.size() + rowIdx[so].size() * (size_t)(count - p));
+        }
         for_each_shared_node(f1, f2, [&](int i, int j) {
             const int off2 = f2.offsets[j], n2 = f2.offsets[j + 1] - off2;
             if (n2 >= (1 << 20)) bad = true;
-            for (int k = f1.offsets[i]; k < f1.offsets[i + 1]; k++) {
-                const int idx1 = f1.indices[k];
-                if (has1[idx1]) continue;                                   // :1279-1282
-                if (q.only_stereo && !(K1->hUR[idx1] >= 0)) continue;       // :1286-1288
-                if (n2 > 0) rows.push_back(TriRowB{idx1, off2, n2, p});
-            }
+            if (n2 > 0)
+                for (int k = rowOff[so][(size_t)i]; k < rowOff[so][(size_t)i + 1]; k++) rows.push_back(TriRowB{rowIdx[so][(size_t)k], off2, n2, p});
         });
         if (bad) return ORBFE_ERR_ARGS;
     }
     if (rows.empty()) return 0;
+    PTR(); // rows
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
@@ -2987,10 +3004,11 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
         Q.onlyStereo = q.only_stereo;
         Q.coarse = q.coarse;
         Q.outBase = p * n1;
-        Q.pad = 0;
+        Q.nlevels2 = q.nlevels2;
     }
     if (!mirrored) HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
     const DoneSig done = s.done_sig((unsigned)rows.size(), mirrored ? &ob : nullptr, g_timeKernels);
+    PTR(); // staging
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri_batch, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), dP,
@@ -2999,8 +3017,10 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m;
     int32_t* mAll;
+    PTR(); // launch
     if (mirrored) {
         INT_TRY(s.complete(done));
+        PTR(); // wait
         mAll = hMir;
     } else {
         m.resize((size_t)count * n1);
@@ -3008,31 +3028,52 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
         INT_TRY(s.fetch());
         mAll = m.data();
     }
-    std::vector<int8_t> bins(n1);
+    // one pass over a neighbour's row collects its matches in index order (:1441-1446); the rotation histogram and its cull
+    // (:1402-1438) then run over those alone
+    std::vector<int8_t> bins;
     for (int p = 0; p < count; p++) {
-        int32_t* m12 = mAll + (size_t)p * n1;
+        const int32_t* m12 = mAll + (size_t)p * n1;
         const orbfe_keyframe* K2 = kf2[p];
-        std::fill(bins.begin(), bins.end(), (int8_t)-1);
-        if (pair[p].check_orientation) {
-            for (int i = 0; i < n1; i++)
-                if (m12[i] >= 0) {
-                    float rot = K1->hAng[i] - K2->hAng[m12[i]];
-                    if (rot < 0.0) rot += 360.0f;
-                    int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
-                    if (bin == HISTO_LENGTH) bin = 0;
-                    bins[i] = (int8_t)bin;
-                }
-        }
-        cull_by_rotation(m12, bins.data(), n1, pair[p].check_orientation != 0);
+        int32_t* out = pairs[p];
         int np = 0;
-        for (int i = 0; i < n1; i++) { // :1441-1446
-            if (m12[i] < 0) continue;
-            pairs[p][2 * np] = i;
-            pairs[p][2 * np + 1] = m12[i];
+        for (int i = 0; i < n1; i++) {
+            const int32_t m = m12[i];
+            if (m < 0) continue;
+            out[2 * np] = i;
+            out[2 * np + 1] = m;
             np++;
+        }
+        if (pair[p].check_orientation && np > 0) {
+            bins.resize((size_t)np);
+            int histo[HISTO_LENGTH] = {0};
+            for (int k = 0; k < np; k++) {
+                float rot = K1->hAng[out[2 * k]] - K2->hAng[out[2 * k + 1]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[(size_t)k] = (int8_t)bin;
+                if (bin >= 0 && bin < HISTO_LENGTH) histo[bin]++;
+            }
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+            int kept = 0;
+            for (int k = 0; k < np; k++) {
+                const int b = bins[(size_t)k];
+                if (!(b == ind1 || b == ind2 || b == ind3)) continue;
+                out[2 * kept] = out[2 * k];
+                out[2 * kept + 1] = out[2 * k + 1];
+                kept++;
+            }
+            np = kept;
         }
         npairs[p] = np;
     }
+    PTR();
+#ifdef ORBFE_CALL_TRACE
+    if (getenv("ORBFE_CALL_TRACE") && mirrored)
+        fprintf(stderr, "tri_batch count=%d rows=%zu: rows %.1f stage %.1f launch %.1f wait %.1f tail %.1f us\n", count, rows.size(), trT[0], trT[1],
+                trT[2], trT[3], trT[4]);
+#endif
     return 0;
 }
 
@@ -3097,7 +3138,7 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_search_tri, dim3((unsigned)((rows.size() + 3) / 4)), dim3(256), 0, g_ms, dR, (int)rows.size(), d1,
-                           k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->only_stereo, a->coarse, dM, done);
+                           k1, u1, d2, h2, k2, o2, u2, i2, dF, a->ep[0], a->ep[1], sf, sg, a->nlevels2, a->only_stereo, a->coarse, dM, done);
     }
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> m12(a->n1);
