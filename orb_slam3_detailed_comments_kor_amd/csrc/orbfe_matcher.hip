@@ -1526,9 +1526,26 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
     }
 }
 
+#ifdef ORBFE_PROJ_TIMING // tuning only (tools/ab_build.sh projt "-DORBFE_PROJ_TIMING"): stage times of K-PROJ's sweeps workgroup
+__device__ unsigned long long g_projTimes[16]; // 100-MHz ticks since the workgroup began: init, cache, sweeps, final, mirror; [8] = sweeps
+#define PT_BEGIN() unsigned long long ptS[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0}
+#define PT(k) ptS[k] = (unsigned long long)wall_clock64()
+#define PT_END(nsweeps)                                                           \
+    do {                                                                          \
+        if (threadIdx.x == 0) {                                                   \
+            for (int k_ = 1; k_ < 8; k_++) g_projTimes[k_] = ptS[k_] ? ptS[k_] - ptS[0] : 0ull; \
+            g_projTimes[8] = (unsigned long long)(nsweeps);                       \
+        }                                                                         \
+    } while (0)
+#else
+#define PT_BEGIN() do { } while (0)
+#define PT(k) do { } while (0)
+#define PT_END(n) do { } while (0)
+#endif
 __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
 {
     __shared__ int sChanged;
+    PT_BEGIN();
     extern __shared__ int32_t projLds[]; // (2 n + 6 nq) ints when the host found that they fit, else nothing
     const int tid = threadIdx.x;
     const int n = P.n, nq = P.nq;
@@ -1539,6 +1556,31 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
     for (int i = tid; i < 2 * n; i += PROJ_THREADS) minW[i] = 0x7fffffff;
     for (int i = tid; i < 2 * 3 * nq; i += PROJ_THREADS) state[i] = -2;
     __syncthreads();
+    // Round 4: what a query reads in EVERY sweep is fetched once.  A sweep used to walk the query's sorted keys in global memory
+    // until it met a feature no earlier query blocks -- one dependent load per key, then the octaves of the two survivors, the
+    // query's flags (in pinned host memory on the latency path: a PCIe round trip per sweep) -- ~5 us per sweep for work that is
+    // a handful of compares.  The first PROJ_CK keys of the thread's first query, the octaves of their features and the query's
+    // flags now sit in registers; a sweep touches LDS only, and goes back to the key array only when all cached keys are blocked.
+    PT(1); // init
+    constexpr int PROJ_CK = 4;
+    unsigned long long ck[PROJ_CK];
+    int co[PROJ_CK];
+    int cFlags = 0, cBlocks = 1, cM = 0;
+    const unsigned long long* cK = nullptr;
+    if (tid < nq) {
+        cFlags = P.qflags ? P.qflags[tid] : 0;
+        cBlocks = (!P.qblocks || P.qblocks[tid]) ? 1 : 0;
+        cM = P.qCount[tid];
+        cK = P.sortedKeys + P.qStart[tid];
+#pragma unroll
+        for (int k = 0; k < PROJ_CK; k++) ck[k] = k < cM ? cK[k] : ~0ull;
+#pragma unroll
+        for (int k = 0; k < PROJ_CK; k++) co[k] = (P.mode == 0 && k < cM && (int)(ck[k] >> 55) < 256) ? P.octave[(int)(ck[k] & 0xFFFFFF)] : -1;
+    }
+#ifdef ORBFE_PROJ_TIMING
+    asm volatile("" ::"v"(ck[0]), "v"(ck[3]), "v"(co[0]), "v"(co[3]), "v"(cFlags));
+#endif
+    PT(2); // cache
     int sweep = 0, last = 0;
     for (; sweep < nq + 2; sweep++) {
         const int32_t* prevW = minW + (size_t)(sweep & 1) * n;
@@ -1550,34 +1592,51 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
         if (tid == 0) sChanged = 0;
         __syncthreads();
         for (int q = tid; q < nq; q += PROJ_THREADS) {
-            const int flags = P.qflags ? P.qflags[q] : 0;
+            const bool mine = q == tid; // (the thread's first query: cached)
+            const int flags = mine ? cFlags : (P.qflags ? P.qflags[q] : 0);
             const bool bRight = flags & 1;
             int choice = -1, partner = -1, rejected = 0;
             const bool skip = q > 0 && (((flags & 2) && prevS[3 * (q - 1) + 2] == 1) || ((flags & 4) && P.qArea[q - 1] == 0));
-            const int m = skip ? 0 : P.qCount[q];
-            const unsigned long long* K = P.sortedKeys + P.qStart[q];
-            int g1 = -1, d1 = 256, g2 = -1, d2 = 256;
-            for (int k = 0; k < m; k++) {
-                const unsigned long long key = K[k];
+            const int m = skip ? 0 : (mine ? cM : P.qCount[q]);
+            const unsigned long long* K = mine ? cK : P.sortedKeys + P.qStart[q];
+            int g1 = -1, d1 = 256, g2 = -1, d2 = 256, o1 = -1, o2 = -1;
+            bool done_ = false; // the walk over the keys is over (two survivors, or one in mode 1, or the distances ran out)
+            auto visit = [&](unsigned long long key, int oct) { // one key of the walk (:90-131 / :2285-2296); oct: its feature's octave or -2 = not loaded
                 const int d = (int)(key >> 55);
-                if (d >= 256) break; // `dist<bestDist` with bestDist = 256 never accepts these
+                if (d >= 256) { // `dist<bestDist` with bestDist = 256 never accepts these
+                    done_ = true;
+                    return;
+                }
                 const int g = (int)(key & 0xFFFFFF);
-                if (prevW[g] < q) continue;
+                if (prevW[g] < q) return;
                 if (g1 < 0) {
                     g1 = g;
                     d1 = d;
-                    if (P.mode != 0) break;
+                    o1 = oct;
+                    if (P.mode != 0) done_ = true;
                 } else {
                     g2 = g;
                     d2 = d;
-                    break;
+                    o2 = oct;
+                    done_ = true;
                 }
+            };
+            int k = 0;
+            if (mine) {
+#pragma unroll
+                for (int c = 0; c < PROJ_CK; c++)
+                    if (!done_ && c < m) {
+                        visit(ck[c], co[c]);
+                        k = c + 1;
+                    }
             }
+            for (; !done_ && k < m; k++) visit(K[k], -2);
             if (g1 >= 0 && d1 <= P.thHigh) {
                 bool ok = true;
                 if (P.mode == 0) {
-                    const int bestLevel2 = g2 >= 0 ? P.octave[g2] : -1;
-                    if (P.octave[g1] == bestLevel2 && (float)d1 > __fmul_rn(P.nnratio, (float)d2)) {
+                    const int lvl1 = o1 != -2 ? o1 : P.octave[g1];
+                    const int bestLevel2 = g2 >= 0 ? (o2 != -2 ? o2 : P.octave[g2]) : -1;
+                    if (lvl1 == bestLevel2 && (float)d1 > __fmul_rn(P.nnratio, (float)d2)) {
                         ok = false;
                         rejected = 1;
                     }
@@ -1594,7 +1653,7 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
             newS[3 * q + 1] = partner;
             newS[3 * q + 2] = rejected;
             if (choice != prevS[3 * q] || partner != prevS[3 * q + 1] || rejected != prevS[3 * q + 2]) sChanged = 1;
-            if (!P.qblocks || P.qblocks[q]) {
+            if (mine ? cBlocks != 0 : (!P.qblocks || P.qblocks[q])) {
                 if (choice >= 0) atomicMin(&newW[choice], q);
                 if (partner >= 0) atomicMin(&newW[partner], q);
             }
@@ -1604,8 +1663,51 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
         __syncthreads();
     }
 
+    PT(3); // sweeps
     // ---- final state of F.mvpMapPoints: the last writer of every feature
     const int32_t* S = state + (size_t)last * 3 * nq;
+    if (P.mirror && P.sweepLds) {
+        // latency path: the feature table is built in LDS (the sweeps' minW buffer is free now) and goes straight to the pinned
+        // mirror as plain stores -- no atomics in global memory, no copy out of it -- with the completion word behind it
+        __shared__ int sCnt;
+        int32_t* const fm = minW; // n entries
+        for (int i = tid; i < n; i += PROJ_THREADS) fm[i] = -1;
+        if (tid == 0) sCnt = 0;
+        // (k_proj_candidates' count: the host checks it against the buffers.  Counting in a word of the arena that this kernel
+        // puts back to zero, so that no memset has to run in front of the call, was measured 9 us SLOWER per call -- 0.0637
+        // against 0.0546 ms, twice each on one box -- and is gone.)
+        const int keysNeeded = tid == 0 ? P.status[2] : 0;
+        __syncthreads();
+        int cnt = 0;
+        for (int q = tid; q < nq; q += PROJ_THREADS) {
+            const int c = S[3 * q], p = S[3 * q + 1];
+            P.mirror[4 + q] = c;
+            if (c >= 0) {
+                atomicMax(&fm[c], q);
+                cnt++;
+            }
+            if (p >= 0) {
+                atomicMax(&fm[p], q);
+                cnt++;
+            }
+        }
+        if (cnt) atomicAdd(&sCnt, cnt);
+        __syncthreads();
+        PT(4); // final
+        for (int i = tid; i < n; i += PROJ_THREADS) P.mirror[4 + nq + i] = fm[i];
+        if (tid == 0) {
+            P.mirror[0] = sCnt;
+            P.mirror[1] = sweep + 1;
+            P.mirror[2] = keysNeeded;
+            P.mirror[3] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && P.doneFlag) {
+            __threadfence_system();
+            *(volatile unsigned*)P.doneFlag = P.doneSeq;
+        }
+    } else {
     for (int i = tid; i < n; i += PROJ_THREADS) P.featMatch[i] = -1;
     if (tid == 0) {
         P.status[0] = 0;
@@ -1626,9 +1728,8 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
         }
     }
     if (cnt) atomicAdd(&P.status[0], cnt);
-    if (P.mirror) { // (uniform)
-        // the results were built with atomics in device memory (no atomics across PCIe); now that every thread's are done,
-        // the block goes to the host as plain stores, and the completion word behind them
+    PT(4); // final
+    if (P.mirror) { // (uniform) the sweeps' tables did not fit LDS: results built in device memory, then copied
         __threadfence();
         __syncthreads();
         for (int i = tid; i < P.mirrorInts; i += PROJ_THREADS) P.mirror[i] = P.status[i];
@@ -1639,6 +1740,9 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
             *(volatile unsigned*)P.doneFlag = P.doneSeq;
         }
     }
+    }
+    PT(5); // mirror
+    PT_END(sweep + 1);
 }
 
 // one problem per launch (argument by value) / one problem per blockIdx.y (orbfe_search_projection_batch)
@@ -2263,7 +2367,7 @@ struct Scratch { // device allocations of one call
         hipError_t e = hipStreamSynchronize(g_ms);
         // the word did not come within the bound: normally a long call (its counter is back at zero by now); should the counter
         // ever be left non-zero -- a kernel that died half-way -- every later call would time out, so it is cleared here
-        if (e == hipSuccess && w.flag) e = hipMemsetAsync(w.ctr, 0, sizeof(unsigned), g_ms);
+        if (e == hipSuccess && w.flag) e = hipMemsetAsync(ar->doneCtr, 0, 64, g_ms); // (all its words: K-PROJ keeps a counter there too)
         if (e != hipSuccess) ar->cleanDirty = true; // (the block may hold half a call's results)
         return e == hipSuccess ? 0 : -(1000 + (int)e);
     }
@@ -3988,6 +4092,12 @@ int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t
 
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
 void orbfe_matcher_time_kernels(int on) { g_timeKernels = on != 0; }
+#ifdef ORBFE_PROJ_TIMING
+extern "C" int orbfe_debug_proj_times(unsigned long long* out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_projTimes), sizeof(g_projTimes)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef ORBFE_BOW_TIMING
 extern "C" int orbfe_debug_bow_times(unsigned long long* out8 /* 16 */, int reset)
 {

@@ -425,6 +425,13 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
         std::vector<int32_t> qm2(nA), fm2(nB);
         int n2 = 0;
         if (timeit("search_projection_frame_handle", 300, [&] { return n2 = orbfe_search_projection_frame(fr, &pr, qm2.data(), fm2.data()); }, out)) return 2;
+        if (auto pt = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "orbfe_debug_proj_times")) { // (-DORBFE_PROJ_TIMING library)
+            unsigned long long t[16];
+            hipDeviceSynchronize();
+            if (pt(t) == 0)
+                fprintf(stderr, "K-PROJ sweeps workgroup (us since its start): init %.2f  cache %.2f  sweeps %.2f (%llu)  final %.2f  mirror %.2f\n",
+                        t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[8], t[4] * 0.01, t[5] * 0.01);
+        }
         orbfe_frame_destroy(fr);
         if (n2 != nProj || qm2 != qm || fm2 != fm) {
             fprintf(stderr, "hostbench: SearchByProjection forms disagree: %d %d\n", nProj, n2);
