@@ -2845,6 +2845,7 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
 // brute-force pass across the lanes.  The 11x11 SAD refinement reads both image pyramids where the
 // extractors left them in HBM (no mvImagePyramid download).  The median-based outlier cut
 // (:952-966) needs all matches and stays O(N) host code.
+#define STEREO_CHUNK 2048 /* right keypoints staged per round: 8 + 8 + 16 KB of LDS */
 __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict__ pyrL,
                                                       const uint8_t* __restrict__ pyrR,
                                                       const OrbLevelGeom* __restrict__ lg, int nlevels,
@@ -2858,14 +2859,18 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
                                                       const OrbDone done = OrbDone{nullptr, nullptr, 0u, 0u})
 {
     __shared__ unsigned wgCnt;
+    __shared__ float sScale[ORBFE_MAX_LEVELS];
+    __shared__ float sU[STEREO_CHUNK];
+    __shared__ uint32_t sBand[STEREO_CHUNK];
+    __shared__ uint16_t sCand[4][STEREO_CHUNK];
     wg_done_begin(done, &wgCnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iL = blockIdx.x * 4 + wave;
     const int rowsL = nL; // rows of the output arrays
     if (nLdev) nL = min(nL, nLdev[0]);
     if (nRdev) nR = min(nR, nRdev[0]);
-    if (iL >= nL) { // rows past the keypoint count: "no match", so that a caller that asks for more rows never reads stale data
-        if (iL < rowsL && lane == 0) {
+    if (blockIdx.x * 4 >= nL) { // (uniform over the workgroup) rows past the keypoint count: "no match", so that a caller that
+        if (iL < rowsL && lane == 0) { // asks for more rows never reads stale data
             uRight[iL] = -1.0f;
             depth[iL] = -1.0f;
             sadOut[iL] = -1;
@@ -2873,26 +2878,76 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
         wg_done(done, &wgCnt);
         return;
     }
-    const float uL = kpsL[iL * 7 + 0], vL = kpsL[iL * 7 + 1];
-    const int levelL = reinterpret_cast<const int32_t*>(kpsL)[iL * 7 + 5];
+    if (threadIdx.x < ORBFE_MAX_LEVELS) sScale[threadIdx.x] = (int)threadIdx.x < nlevels ? lg[threadIdx.x].scale : 0.f;
+    // (a workgroup that straddles the count: its wavefronts past it take part in the staging and the barriers with a left
+    // keypoint that matches nothing, and write "no match")
+    const bool live = iL < nL;
+    if (!live) {
+        if (iL < rowsL && lane == 0) {
+            uRight[iL] = -1.0f;
+            depth[iL] = -1.0f;
+            sadOut[iL] = -1;
+        }
+    }
+    const int iLs = live ? iL : 0; // (what a wavefront past the count reads; it writes nothing more)
+    const float uL = kpsL[iLs * 7 + 0], vL = kpsL[iLs * 7 + 1];
+    const int levelL = reinterpret_cast<const int32_t*>(kpsL)[iLs * 7 + 5];
     const int vLi = (int)vL;
     const float maxD = __fdiv_rn(mbf, mb); // mbf / minZ, minZ = mb (:825-827)
     const float minU = __fsub_rn(uL, maxD), maxU = uL;
-    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(descL + (size_t)iL * 32);
+    const OrbLevelGeom G = lg[(levelL >= 0 && levelL < nlevels) ? levelL : 0]; // (for the SAD search: requested now, needed after the scan)
+    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(descL + (size_t)iLs * 32);
     const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
     unsigned best = 0xFFFFFFFFu;
-    for (int iR = lane; iR < nR; iR += 64) {
-        const float uR = kpsR[iR * 7 + 0], kpY = kpsR[iR * 7 + 1];
-        const int octR = reinterpret_cast<const int32_t*>(kpsR)[iR * 7 + 5];
-        if (octR < 0 || octR >= nlevels) continue;
-        const float r = __fmul_rn(2.0f, lg[octR].scale);
-        const int maxr = (int)ceilf(__fadd_rn(kpY, r)), minr = (int)floorf(__fsub_rn(kpY, r));
-        if (vLi < minr || vLi > maxr) continue;
-        if (octR < levelL - 1 || octR > levelL + 1) continue;
-        if (!(uR >= minU && uR <= maxU)) continue;
-        const unsigned long long* dr = reinterpret_cast<const unsigned long long*>(descR + (size_t)iR * 32);
-        const int dist = __popcll(l0 ^ dr[0]) + __popcll(l1 ^ dr[1]) + __popcll(l2 ^ dr[2]) + __popcll(l3 ^ dr[3]);
-        if (dist < 100) best = min(best, ((unsigned)dist << 20) | (unsigned)iR); // TH_HIGH
+    // Round 4: the scan over the right keypoints in two phases.  It used to load a right keypoint's x, y and octave (three
+    // strided loads from the 28-byte records) and its level's scale inside the loop, with the descriptor load behind the row /
+    // level / disparity tests: ~19 rounds of dependent global round trips per wavefront.  Now (a) the workgroup stages the right
+    // keypoints ONCE per chunk as (uR, row band | octave) in LDS -- coalesced loads, the band computed as the reference does
+    // (:812-822) --, (b) every wavefront scans the table from LDS and collects the indices that pass the three tests, and (c)
+    // loads the descriptors of those (a dozen) with all loads in flight.
+    for (int base = 0; base < nR; base += STEREO_CHUNK) { // (uniform over the workgroup)
+        const int cn = min(STEREO_CHUNK, nR - base);
+        __syncthreads(); // (the previous chunk's table and lists are no longer read)
+        for (int j = threadIdx.x; j < cn; j += 256) {
+            const int iR = base + j;
+            const float uR = kpsR[iR * 7 + 0], kpY = kpsR[iR * 7 + 1];
+            const int octR = reinterpret_cast<const int32_t*>(kpsR)[iR * 7 + 5];
+            uint32_t band = 0xFFFFFFFFu; // (an octave outside the table: never a candidate)
+            if (octR >= 0 && octR < nlevels) {
+                const float r = __fmul_rn(2.0f, sScale[octR]);
+                const int maxr = (int)ceilf(__fadd_rn(kpY, r)), minr = (int)floorf(__fsub_rn(kpY, r));
+                // rows fit 13 bits each (image side <= 4096; minr may be -1..: clamp keeps the comparison with vLi >= 0 intact)
+                band = (uint32_t)max(minr, 0) | ((uint32_t)min(max(maxr, -1) + 1, 8191) << 13) | ((uint32_t)octR << 26);
+            }
+            sU[j] = uR;
+            sBand[j] = band;
+        }
+        __syncthreads();
+        int nc = 0;
+        for (int j0 = 0; j0 < cn; j0 += 64) { // (uniform)
+            const int j = j0 + lane;
+            bool ok = false;
+            if (j < cn) {
+                const uint32_t b = sBand[j];
+                const int minr = (int)(b & 8191u), maxr1 = (int)((b >> 13) & 8191u), octR = (int)(b >> 26);
+                const float uR = sU[j];
+                ok = live && b != 0xFFFFFFFFu && vLi >= minr && vLi < maxr1 && !(octR < levelL - 1 || octR > levelL + 1) && (uR >= minU && uR <= maxU);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) sCand[wave][nc + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
+            nc += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k0 = 0; k0 < nc; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < nc) {
+                const int iR = base + (int)sCand[wave][k];
+                const unsigned long long* dr = reinterpret_cast<const unsigned long long*>(descR + (size_t)iR * 32);
+                const int dist = __popcll(l0 ^ dr[0]) + __popcll(l1 ^ dr[1]) + __popcll(l2 ^ dr[2]) + __popcll(l3 ^ dr[3]);
+                if (dist < 100) best = min(best, ((unsigned)dist << 20) | (unsigned)iR); // TH_HIGH
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
@@ -2902,7 +2957,6 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
     if (bestDist < 75 && levelL >= 0 && levelL < nlevels) { // thOrbDist = (TH_HIGH+TH_LOW)/2
         const int bestIdxR = (int)(best & 0xFFFFF);
         const float uR0 = kpsR[bestIdxR * 7 + 0];
-        const OrbLevelGeom G = lg[levelL];
         const float sf = __fdiv_rn(1.0f, G.scale); // mvInvScaleFactors[octave]
         const float scaleduL = roundf(__fmul_rn(uL, sf)), scaledvL = roundf(__fmul_rn(vL, sf));
         const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
@@ -2924,9 +2978,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
                 for (int k = 0; k < 11; k++) sad[k] += abs(vl - (int)rr[k - Lw]);
             }
 #pragma unroll
-            for (int k = 0; k < 11; k++)
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) sad[k] += __shfl_xor(sad[k], off);
+            for (int k = 0; k < 11; k++) sad[k] = wave_sum_i32(sad[k]); // (DPP + v_readlane: no LDS round trips)
             int bestS = 0x7fffffff, bestinc = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++)
@@ -2961,7 +3013,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
             }
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && live) {
         uRight[iL] = outU;
         depth[iL] = outD;
         sadOut[iL] = outS;
