@@ -303,7 +303,6 @@ struct DoneSig {
     uint4* outMirror; // the kernel's address of the block's pinned mirror
     unsigned out16;   // 16-byte units
 };
-__device__ __forceinline__ DoneSig no_done() { return DoneSig{nullptr, nullptr, 0u, 0u, 0u, nullptr, nullptr, 0u}; }
 // the wavefront that completed the count (all 64 lanes): results to the mirror, block clean again, flag
 __device__ __forceinline__ void done_publish(const DoneSig& d)
 {
@@ -2205,12 +2204,11 @@ struct Scratch { // device allocations of one call
         downs.clear();
         return e == hipSuccess ? 0 : -(1000 + (int)e);
     }
-    // Completion word of a call whose results the kernel writes into the pinned mirror (DoneSig above).  done_sig() hands the
-    // kernel the call's sequence number (total = the wavefronts that will report); wait_done() spins on the flag for a bounded
-    // time -- a call that takes longer than that gains nothing from spinning -- and falls back to the stream synchronisation,
-    // which also surfaces a failed launch.  ORBFE_MATCHER_SPIN=0 switches the flag off (A/B).  The flag word is allocated
-    // coherent like the mirror.
-    // ---- results of the latency-path calls (DoneSig above)
+    // ---- results and completion of the latency-path calls (DoneSig above): out_block() says where the kernel puts its results
+    // and where the host finds them, done_sig() hands the kernel the call's sequence number when the completion word may be
+    // used, complete() spins on the word for a bounded time -- a call that takes longer gains nothing from spinning -- and
+    // falls back to the stream synchronisation, which also surfaces a failed launch.  ORBFE_MATCHER_SPIN=0 (or ORBFE_SPIN=0)
+    // switches the word off.  The flag word is allocated coherent like the mirror.
     struct OutBlock {
         uint8_t* dev = nullptr;   // the arena's clean block: device memory, all ones between calls; the kernel scatters into it
         uint8_t* host = nullptr;  // its pinned mirror (host address): complete when complete() returns
@@ -2872,7 +2870,6 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     const int8_t* pb;
     if (mirrored) { // the results arrive in the pinned mirror: wait, read
         INT_TRY(s.complete(done));
-        PTR(); // sync
         pm = hM;
         pb = hB;
     } else {
@@ -2884,13 +2881,14 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         pm = m.data();
         pb = bins.data();
     }
+    PTR(); // wait
     for (int p = 0; p < count; p++) {
         std::memcpy(match[p], pm + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
         nmatches[p] = cull_by_rotation(match[p], pb + probs[p].outBase, outN[p], args[p].check_orientation != 0);
     }
     PTR();
 #ifdef ORBFE_CALL_TRACE
-    if (getenv("ORBFE_CALL_TRACE") && mirrored) fprintf(stderr, "bow_run count=%d: pass1 %.1f stage %.1f launch %.1f sync %.1f tail %.1f us\n", count, trT[0], trT[1], trT[2], trT[3], trT[4]);
+    if (getenv("ORBFE_CALL_TRACE")) fprintf(stderr, "bow_run count=%d: pass1 %.1f stage %.1f launch %.1f sync %.1f tail %.1f us\n", count, trT[0], trT[1], trT[2], trT[3], trT[4]);
 #endif
     return 0;
 }

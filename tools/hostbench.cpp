@@ -322,7 +322,7 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
             const auto h0 = std::chrono::steady_clock::now();
             CHECK(orbfe_search_bow_keyframes(dev, 1, kf1, nullptr, &bowDev, mp, &nm));
             const double callUs = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             bt(u, 0);
             fprintf(stderr, "K-BOW launch %d: call %.1f us; first wavefront start -> last start %.2f us, -> last end %.2f us\n", i, callUs,
                     (u[13] - u[11]) * 0.01, (u[12] - u[11]) * 0.01);
@@ -427,7 +427,7 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
         if (timeit("search_projection_frame_handle", 300, [&] { return n2 = orbfe_search_projection_frame(fr, &pr, qm2.data(), fm2.data()); }, out)) return 2;
         if (auto pt = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "orbfe_debug_proj_times")) { // (-DORBFE_PROJ_TIMING library)
             unsigned long long t[16];
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             if (pt(t) == 0)
                 fprintf(stderr, "K-PROJ sweeps workgroup (us since its start): init %.2f  cache %.2f  sweeps %.2f (%llu)  final %.2f  mirror %.2f\n",
                         t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[8], t[4] * 0.01, t[5] * 0.01);
