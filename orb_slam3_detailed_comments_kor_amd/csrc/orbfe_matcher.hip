@@ -268,6 +268,38 @@ struct BowProb {
     const uint8_t* rDesc2; const uint8_t* rMask2; const float* rAng2; const int32_t* rInd2;
 };
 
+// ComputeThreeMaxima (:2545-2586), the device twin of three_maxima() below
+__device__ __forceinline__ void three_maxima_dev(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            ind3 = ind2;
+            ind2 = ind1;
+            ind1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            ind3 = ind2;
+            ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+        ind3 = -1;
+    }
+}
+
 __device__ __forceinline__ int rot_bin(float a1, float a2)
 {
     // :391-396 -- factor is 1/HISTO_LENGTH (sic)
@@ -1042,6 +1074,8 @@ struct TriProb {
     int onlyStereo, coarse;
     int outBase; // this problem's match12 row in the pooled output
     int nlevels2; // entries of sf2 / sig2
+    const float* ang2; // keypoint angles of the neighbour (k_tri_compact's rotation histogram)
+    int checkOri, pad;
 };
 struct TriRowB {
     int idx1, off2, n2, prob;
@@ -1074,6 +1108,86 @@ __global__ __launch_bounds__(256) void k_search_tri_batch(const TriRowB* __restr
     if (lane == 0)
         matchPool[Q.outBase + idx1] = best == 0xFFFFFFFFu ? -1 : ind2[R.off2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
     wave_done(done, &wgCnt);
+}
+
+// What the host used to do with the batch's match rows (:1402-1446), per neighbour on the device: the matches of row p in index
+// order, the rotation histogram over them, ComputeThreeMaxima, the cull, the surviving pairs compacted in order -- so that the
+// host reads ~150 pairs per neighbour instead of walking 1200 row entries of freshly written pinned memory (20 of 80 us of a
+// 20-neighbour call).  One workgroup per neighbour; a thread owns a contiguous stretch of the row, so a block prefix sum over
+// the threads' counts gives the ordered positions.  The row block is the arena's clean block: entries go back to -1 as they
+// are read.  The last workgroup publishes the call's completion word (few workgroups: the counter is cheap here).
+__global__ __launch_bounds__(256) void k_tri_compact(int32_t* __restrict__ rowsBlk, int n1, const TriProb* __restrict__ probs,
+                                                     const float* __restrict__ ang1, int32_t* __restrict__ outPairs /* count x 2 n1 */,
+                                                     int32_t* __restrict__ outN /* count */, const DoneSig done)
+{
+    __shared__ int sHist[32], sInd[3], sWave[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TriProb& Q = probs[p];
+    int32_t* const m12 = rowsBlk + (size_t)p * n1;
+    int32_t* const out = outPairs + (size_t)p * 2 * n1;
+    const int per = (n1 + 255) >> 8, i0 = min(n1, tid * per), i1 = min(n1, i0 + per);
+    const bool check = Q.checkOri != 0;
+    if (tid < 32) sHist[tid] = 0;
+    __syncthreads();
+    if (check)
+        for (int i = i0; i < i1; i++) {
+            const int m = m12[i];
+            if (m >= 0) atomicAdd(&sHist[rot_bin(ang1[i], Q.ang2[m])], 1);
+        }
+    __syncthreads();
+    if (tid == 0) {
+        int a, b, c;
+        three_maxima_dev(sHist, 30, a, b, c);
+        sInd[0] = a;
+        sInd[1] = b;
+        sInd[2] = c;
+    }
+    __syncthreads();
+    const int ind1 = sInd[0], ind2 = sInd[1], ind3 = sInd[2];
+    auto keeps = [&](int i, int m) {
+        if (m < 0) return false;
+        if (!check) return true;
+        const int b = rot_bin(ang1[i], Q.ang2[m]);
+        return b == ind1 || b == ind2 || b == ind3;
+    };
+    int kept = 0;
+    for (int i = i0; i < i1; i++) kept += keeps(i, m12[i]) ? 1 : 0;
+    // exclusive prefix of `kept` over the 256 threads
+    int inc = kept;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) sWave[wave] = inc;
+    __syncthreads();
+    int before = inc - kept, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int t = sWave[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    int pos = before;
+    for (int i = i0; i < i1; i++) {
+        const int m = m12[i];
+        if (m < 0) continue;
+        if (keeps(i, m)) {
+            out[2 * pos] = i;
+            out[2 * pos + 1] = m;
+            pos++;
+        }
+        m12[i] = -1; // (the clean block stays clean)
+    }
+    if (tid == 0) outN[p] = total;
+    if (!done.flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && atomicAdd(done.ctr, 1u) + 1u == done.total) {
+        *done.ctr = 0u;
+        __threadfence_system();
+        *(volatile unsigned*)done.flag = done.seq;
+    }
 }
 
 // K-TRI with the KannalaBrandt8 gate (fisheye monocular pairs and two-camera rigs): same row / candidate
@@ -2216,6 +2330,36 @@ struct Scratch { // device allocations of one call
         size_t bytes = 0;
         bool direct = false;      // dev IS the mirror (the kernel's address of it): the kernel's stores cross PCIe themselves
     };
+    // `bytes` of the arena's clean block: device memory that is all ones between calls (whoever scatters into it puts the ones
+    // back when it reads the results).  0 / 1 = not available.
+    int clean_dev(uint8_t** dev, size_t bytes)
+    {
+        if (ar->cleanCap < bytes || ar->cleanDirty) {
+            if (ar->cleanCap < bytes) {
+                if (ar->cleanDev) {
+                    (void)hipStreamSynchronize(g_ms);
+                    (void)hipFree(ar->cleanDev);
+                    ar->cleanDev = nullptr;
+                    ar->cleanCap = 0;
+                }
+                void* p = nullptr;
+                const size_t want = std::max<size_t>(2 * bytes, 64u << 10);
+                if (hipMalloc(&p, want) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return 1;
+                }
+                ar->cleanDev = (uint8_t*)p;
+                ar->cleanCap = want;
+            }
+            if (hipMemsetAsync(ar->cleanDev, 0xFF, ar->cleanCap, g_ms) != hipSuccess) { // (on the call's own stream)
+                (void)hipGetLastError();
+                return 1;
+            }
+            ar->cleanDirty = false;
+        }
+        *dev = ar->cleanDev;
+        return 0;
+    }
     // 0: *ob describes where the kernel puts `bytes` of results (all ones to begin with) and where the host finds them;
     // 1: not available (the caller downloads as before).  `wgs` = workgroups of the kernel: which of the two forms is used
     // (ORBFE_MATCHER_BLOCK: 0 = always straight into the mirror -- the default: on one box the three policies were within
@@ -2241,32 +2385,11 @@ struct Scratch { // device allocations of one call
             ob->direct = true;
             return 0;
         }
-        if (ar->cleanCap < bytes || ar->cleanDirty) {
-            if (ar->cleanCap < bytes) {
-                if (ar->cleanDev) {
-                    (void)hipStreamSynchronize(g_ms);
-                    (void)hipFree(ar->cleanDev);
-                    ar->cleanDev = nullptr;
-                    ar->cleanCap = 0;
-                }
-                void* p = nullptr;
-                const size_t want = std::max<size_t>(2 * bytes, 64u << 10);
-                if (hipMalloc(&p, want) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return 1;
-                }
-                ar->cleanDev = (uint8_t*)p;
-                ar->cleanCap = want;
-            }
-            if (hipMemsetAsync(ar->cleanDev, 0xFF, ar->cleanCap, g_ms) != hipSuccess) { // (on the call's own stream)
-                (void)hipGetLastError();
-                return 1;
-            }
-            ar->cleanDirty = false;
-        }
+        uint8_t* cd = nullptr;
+        if (clean_dev(&cd, bytes) != 0) return 1;
         uint8_t *md = nullptr, *mh = nullptr;
         if (mirror_out(&md, &mh, bytes) != 0) return 1;
-        ob->dev = ar->cleanDev;
+        ob->dev = cd;
         ob->host = mh;
         ob->mirrorDev = reinterpret_cast<uint4*>(md);
         ob->bytes = bytes;
@@ -2324,6 +2447,17 @@ struct Scratch { // device allocations of one call
     {
         DoneSig d{nullptr, nullptr, 0u, 1u, 1u, nullptr, nullptr, 0u};
         if (!spin_enabled() || !inPlace || !ar->pinCoherent || !done_words()) return d;
+        if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+        d.ctr = ar->doneCtr;
+        d.flag = ar->doneFlagDev;
+        d.seq = ar->doneSeq;
+        return d;
+    }
+    // a word for a small final kernel of `wgs` workgroups that count themselves (no block: the kernel writes the mirror)
+    DoneSig word_for(unsigned wgs)
+    {
+        DoneSig d{nullptr, nullptr, 0u, wgs, wgs, nullptr, nullptr, 0u};
+        if (!spin_enabled() || !ar->pinCoherent || wgs > 256u || !done_words()) return d;
         if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
         d.ctr = ar->doneCtr;
         d.flag = ar->doneFlagDev;
@@ -3079,8 +3213,25 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     if ((r = s.reserve(&dP, &hP, (size_t)count)) < 0) return r;
     int32_t* hMir = nullptr;
     Scratch::OutBlock ob;
-    const bool mirrored = (size_t)count * n1 * 4 <= (256u << 10) && s.out_block(&ob, (size_t)count * n1 * sizeof(int32_t), (unsigned)((rows.size() + 3) / 4)) == 0;
-    if (mirrored) {
+    // Form A (the usual one): the match rows stay on the device (the arena's clean block), k_tri_compact turns every
+    // neighbour's row into its final pair list -- index order, rotation cull -- in the pinned mirror, and the host copies
+    // those.  ORBFE_TRI_COMPACT=0: form B, the rows themselves come back and the host does it (A/B, and for batches whose
+    // pair lists would not fit the mirror).
+    static const bool compactOn = [] {
+        const char* e = getenv("ORBFE_TRI_COMPACT");
+        return !(e && e[0] == '0');
+    }();
+    uint8_t* cleanRows = nullptr;
+    int32_t *dPairs = nullptr, *hPairs = nullptr, *dNp = nullptr, *hNp = nullptr;
+    // (a single neighbour: its row is a microsecond of host work, the second kernel costs seven -- 0.018 against 0.025 ms)
+    const bool compact = compactOn && count >= 4 && !g_timeKernels && (size_t)count * n1 * 8 <= (256u << 10) &&
+                         s.clean_dev(&cleanRows, (size_t)count * n1 * sizeof(int32_t)) == 0 &&
+                         s.mirror_out(&dPairs, &hPairs, (size_t)count * n1 * 2) == 0 && s.mirror_out(&dNp, &hNp, (size_t)count) == 0;
+    const bool mirrored = !compact && (size_t)count * n1 * 4 <= (256u << 10) &&
+                          s.out_block(&ob, (size_t)count * n1 * sizeof(int32_t), (unsigned)((rows.size() + 3) / 4)) == 0;
+    if (compact) {
+        dM = reinterpret_cast<int32_t*>(cleanRows);
+    } else if (mirrored) {
         dM = reinterpret_cast<int32_t*>(ob.dev);
         hMir = reinterpret_cast<int32_t*>(ob.host);
     } else if ((r = s.up<int32_t>(&dM, nullptr, (size_t)count * n1)) < 0) return r;
@@ -3107,8 +3258,11 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
         Q.coarse = q.coarse;
         Q.outBase = p * n1;
         Q.nlevels2 = q.nlevels2;
+        Q.ang2 = K2->ang;
+        Q.checkOri = q.check_orientation ? 1 : 0;
+        Q.pad = 0;
     }
-    if (!mirrored) HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
+    if (!mirrored && !compact) HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)count * n1 * sizeof(int32_t), g_ms));
     const DoneSig done = s.done_sig((unsigned)rows.size(), mirrored ? &ob : nullptr, g_timeKernels);
     PTR(); // staging
     {
@@ -3117,6 +3271,31 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
                            K1->desc, K1->kp, K1->uR, dM, done);
     }
     HIP_TRY(hipGetLastError());
+    if (compact) {
+        DoneSig w = s.word_for((unsigned)count); // (the compaction's workgroups count themselves: one per neighbour)
+        hipLaunchKernelGGL(k_tri_compact, dim3((unsigned)count), dim3(256), 0, g_ms, dM, n1, dP, K1->ang, dPairs, dNp, w);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            s.ar->cleanDirty = true;
+            return -(1000 + (int)le);
+        }
+        PTR(); // launch
+        INT_TRY(s.complete(w));
+        PTR(); // wait
+        for (int p = 0; p < count; p++) {
+            const int np = hNp[p];
+            if (np < 0 || np > n1) return ORBFE_ERR_STATE;
+            std::memcpy(pairs[p], hPairs + (size_t)p * 2 * n1, (size_t)np * 2 * sizeof(int32_t));
+            npairs[p] = np;
+        }
+        PTR();
+#ifdef ORBFE_CALL_TRACE
+        if (getenv("ORBFE_CALL_TRACE"))
+            fprintf(stderr, "tri_batch (compact) count=%d rows=%zu: rows %.1f stage %.1f launch %.1f wait %.1f tail %.1f us\n", count, rows.size(),
+                    trT[0], trT[1], trT[2], trT[3], trT[4]);
+#endif
+        return 0;
+    }
     std::vector<int32_t> m;
     int32_t* mAll;
     PTR(); // launch

@@ -141,14 +141,15 @@ def test_matcher_latency_paths_in_their_other_forms():
     # The latency-path calls (SearchByBoW, SearchForTriangulation_, SearchByProjection against resident sets) end on a
     # completion word and write their results straight into the pinned mirror.  The other forms stay in the library as
     # switches: ORBFE_SPIN=0 (stream synchronisation instead of the word), ORBFE_MATCHER_BLOCK=2 (results through the clean device
-    # block and k_copy_out / the publishing wavefront), ORBFE_MATCHER_INPLACE_KB=0 (inputs uploaded, not read in place): the
+    # block and k_copy_out / the publishing wavefront), ORBFE_MATCHER_INPLACE_KB=0 (inputs uploaded, not read in place), ORBFE_TRI_COMPACT=0 (the triangulation batch's rows come
+    # back and the host compacts and culls them instead of k_tri_compact): the
     # handle, adapter and matcher tests again under each, in child processes (the switches are read once per process).
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for env in ({"ORBFE_SPIN": "0"}, {"ORBFE_MATCHER_BLOCK": "2"}, {"ORBFE_MATCHER_BLOCK": "2", "ORBFE_SPIN": "0"},
-                {"ORBFE_MATCHER_INPLACE_KB": "0"}):
+                {"ORBFE_MATCHER_INPLACE_KB": "0"}, {"ORBFE_TRI_COMPACT": "0"}):
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_keyframes.py"),
                             os.path.join(here, "test_gpu_matcher.py"), "-k", "not other_forms and (bow or tri or projection or handles or neighbours)"],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
