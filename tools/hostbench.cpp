@@ -432,6 +432,36 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
                 fprintf(stderr, "K-PROJ sweeps workgroup (us since its start): init %.2f  cache %.2f  sweeps %.2f (%llu)  final %.2f  mirror %.2f\n",
                         t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[8], t[4] * 0.01, t[5] * 0.01);
         }
+        {   // ... and a tracking-like search against the same resident frame: the queries ARE the frame's features seen again --
+            // positions moved by a pixel or two, a dozen descriptor bits flipped, the last-frame form (mode 1, window 15 px
+            // x the level's scale, src/Tracking.cc:2817) -- instead of another image's keypoints thrown at it (the problem
+            // above: every query competes with a dozen others for the same features, eight resolution sweeps)
+            std::vector<float> tx(nB), ty(nB), tr(nB);
+            std::vector<int32_t> tlo(nB), thi(nB);
+            std::vector<uint8_t> td(dB);
+            uint32_t rs = 99u;
+            auto rnd = [&] { return rs = rs * 1664525u + 1013904223u; };
+            for (int i = 0; i < nB; i++) {
+                tx[i] = kB[i].x + (float)((int)(rnd() >> 28) - 8) * 0.25f;
+                ty[i] = kB[i].y + (float)((int)(rnd() >> 28) - 8) * 0.25f;
+                float sc = 1.f;
+                for (int l = 0; l < kB[i].octave; l++) sc *= 1.2f;
+                tr[i] = 15.f * sc;
+                tlo[i] = std::max(0, kB[i].octave - 1);
+                thi[i] = std::min(7, kB[i].octave + 1);
+                for (int b = 0; b < 12; b++) {
+                    const uint32_t bit = rnd() >> 24;
+                    td[(size_t)i * 32 + (bit >> 3)] ^= (uint8_t)(1u << (bit & 7u));
+                }
+            }
+            orbfe_proj_args pt = pr;
+            pt.nq = nB; pt.qdesc = td.data(); pt.qx = tx.data(); pt.qy = ty.data(); pt.qr = tr.data(); pt.qmin_level = tlo.data();
+            pt.qmax_level = thi.data(); pt.mode = 1; pt.th_high = 100; pt.check_orientation = 0;
+            std::vector<int32_t> qm3(nB), fm3(nB);
+            int n3 = 0;
+            if (timeit("search_projection_frame_handle_tracking_like", 300, [&] { return n3 = orbfe_search_projection_frame(fr, &pt, qm3.data(), fm3.data()); }, out)) return 2;
+            fprintf(stderr, "hostbench: tracking-like projection search: %d of %d queries matched, %d sweeps\n", n3, nB, orbfe_search_projection_last_sweeps());
+        }
         orbfe_frame_destroy(fr);
         if (n2 != nProj || qm2 != qm || fm2 != fm) {
             fprintf(stderr, "hostbench: SearchByProjection forms disagree: %d %d\n", nProj, n2);
