@@ -2002,8 +2002,10 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restri
                                                          const double* __restrict__ nodeWeight, int L,
                                                          const uint8_t* __restrict__ feats, int n, int levelsup,
                                                          int32_t* __restrict__ wordOut, int32_t* __restrict__ nodeOut,
-                                                         double* __restrict__ weightOut)
+                                                         double* __restrict__ weightOut, const DoneSig doneSig)
 {
+    __shared__ unsigned wgCnt;
+    done_begin(doneSig, &wgCnt);
     const int sub = threadIdx.x & 15;
     const int f = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const bool live = f < n;
@@ -2036,6 +2038,7 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restri
         weightOut[f] = nodeWeight[finalId];
         nodeOut[f] = nid;
     }
+    wave_done(doneSig, &wgCnt);
 }
 
 // ------------------------------------------------------------------ K-KB8
@@ -4417,16 +4420,37 @@ int orbfe_vocab_transform(orbfe_vocab_dev* d, const uint8_t* feats, int n, int l
     uint8_t* dF;
     int32_t *dW, *dN;
     double* dWt;
+    // latency path (Frame::ComputeBoW of one frame): descriptors read in place, the three result arrays written into the
+    // pinned mirror by the kernel, the completion word instead of a download and a stream synchronisation
+    s.inPlace = (size_t)n * 32 <= inplace_limit();
+    const unsigned wgs = (unsigned)((n * 16 + 255) / 256);
     if ((r = s.up_desc(&dF, feats, (size_t)n * 32)) < 0) return r;
-    if ((r = s.up<int32_t>(&dW, nullptr, (size_t)n)) < 0) return r;
-    if ((r = s.up<int32_t>(&dN, nullptr, (size_t)n)) < 0) return r;
-    if ((r = s.up<double>(&dWt, nullptr, (size_t)n)) < 0) return r;
+    Scratch::OutBlock ob;
+    const size_t iBytes = ((size_t)n * 8 + 15) & ~(size_t)15; // word ids | node ids, then the weights (8-byte aligned)
+    const bool mirrored = (size_t)n * 16 <= (256u << 10) && s.out_block(&ob, iBytes + (size_t)n * 8, wgs) == 0;
+    if (mirrored) {
+        dW = reinterpret_cast<int32_t*>(ob.dev);
+        dN = dW + n;
+        dWt = reinterpret_cast<double*>(ob.dev + iBytes);
+    } else {
+        if ((r = s.up<int32_t>(&dW, nullptr, (size_t)n)) < 0) return r;
+        if ((r = s.up<int32_t>(&dN, nullptr, (size_t)n)) < 0) return r;
+        if ((r = s.up<double>(&dWt, nullptr, (size_t)n)) < 0) return r;
+    }
+    const DoneSig done = s.done_sig(4u * wgs, mirrored ? &ob : nullptr, g_timeKernels);
     {
         KernelTimer timer(s);
-        hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, g_ms, d->desc, d->childOff,
-                           d->childIds, d->word, d->weight, d->L, dF, n, levelsup, dW, dN, dWt);
+        hipLaunchKernelGGL(k_vocab_transform, dim3(wgs), dim3(256), 0, g_ms, d->desc, d->childOff, d->childIds, d->word, d->weight, d->L,
+                           dF, n, levelsup, dW, dN, dWt, done);
     }
     HIP_TRY(hipGetLastError());
+    if (mirrored) {
+        INT_TRY(s.complete(done));
+        std::memcpy(word_id, ob.host, (size_t)n * 4);
+        std::memcpy(node_id, ob.host + (size_t)n * 4, (size_t)n * 4);
+        std::memcpy(weight, ob.host + iBytes, (size_t)n * 8);
+        return 0;
+    }
     INT_TRY(s.down(word_id, dW, (size_t)n * 4));
     INT_TRY(s.down(node_id, dN, (size_t)n * 4));
     INT_TRY(s.down(weight, dWt, (size_t)n * 8));
