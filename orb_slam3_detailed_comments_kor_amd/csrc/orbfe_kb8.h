@@ -121,22 +121,45 @@ __device__ inline void orbfe_svd4_last_vt(const float* A, float* h)
         for (int k = 0; k < 4; k++) sd = __dadd_rn(sd, __dmul_rn((double)At[i * 4 + k], (double)At[i * 4 + k]));
         W[i] = __dsqrt_rn(sd);
     }
-    // the descending selection sort of the reference moves the row with the least W to position 3: simulate it
-    int perm[4] = {0, 1, 2, 3};
-    for (int i = 0; i < 3; i++) {
-        int j = i;
-        for (int k = i + 1; k < 4; k++)
-            if (W[j] < W[k]) j = k;
-        if (i != j) {
-            const double tw = W[i];
-            W[i] = W[j];
-            W[j] = tw;
-            const int tp = perm[i];
-            perm[i] = perm[j];
-            perm[j] = tp;
+    // the descending selection sort of the reference moves the row with the least W to position 3: simulate it.  (On scalars
+    // with selects: indexing W / perm / Vt with a run-time index put them into scratch memory -- 80 bytes per thread and a
+    // memory round trip per access at the end of every triangulation.)
+    double w0 = W[0], w1 = W[1], w2 = W[2], w3 = W[3];
+    int q0 = 0, q1 = 1, q2 = 2, q3 = 3;
+    { // i = 0: j = first maximum among 0..3 by the scan `if (W[j] < W[k]) j = k`
+        double mv = w0;
+        int mi = 0, mq = q0;
+        if (mv < w1) { mv = w1; mi = 1; mq = q1; }
+        if (mv < w2) { mv = w2; mi = 2; mq = q2; }
+        if (mv < w3) { mv = w3; mi = 3; mq = q3; }
+        const double ow = w0;
+        const int oq = q0;
+        w0 = mv; q0 = mq;
+        if (mi == 1) { w1 = ow; q1 = oq; }
+        if (mi == 2) { w2 = ow; q2 = oq; }
+        if (mi == 3) { w3 = ow; q3 = oq; }
+    }
+    { // i = 1
+        double mv = w1;
+        int mi = 1, mq = q1;
+        if (mv < w2) { mv = w2; mi = 2; mq = q2; }
+        if (mv < w3) { mv = w3; mi = 3; mq = q3; }
+        const double ow = w1;
+        const int oq = q1;
+        w1 = mv; q1 = mq;
+        if (mi == 2) { w2 = ow; q2 = oq; }
+        if (mi == 3) { w3 = ow; q3 = oq; }
+    }
+    { // i = 2
+        if (w2 < w3) {
+            const int oq = q2;
+            q2 = q3;
+            q3 = oq;
         }
     }
-    for (int k = 0; k < 4; k++) h[k] = Vt[perm[3] * 4 + k];
+    (void)q0; (void)q1; (void)q2;
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = q3 == 0 ? Vt[k] : q3 == 1 ? Vt[4 + k] : q3 == 2 ? Vt[8 + k] : Vt[12 + k];
 }
 
 /* KannalaBrandt8::TriangulateMatches_ (KannalaBrandt8.cpp:409-480): z1 of the triangulated point or -1. */

@@ -269,10 +269,10 @@ struct BowProb {
 };
 
 // ComputeThreeMaxima (:2545-2586), the device twin of three_maxima() below
-__device__ __forceinline__ void three_maxima_dev(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+__device__ __forceinline__ void three_maxima_dev(const int* histo, int L, int* out3)
 {
     int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
+    int ind1 = -1, ind2 = -1, ind3 = -1;
     for (int i = 0; i < L; i++) {
         const int s = histo[i];
         if (s > max1) {
@@ -298,6 +298,9 @@ __device__ __forceinline__ void three_maxima_dev(const int* histo, int L, int& i
     } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
         ind3 = -1;
     }
+    out3[0] = ind1;
+    out3[1] = ind2;
+    out3[2] = ind3;
 }
 
 __device__ __forceinline__ int rot_bin(float a1, float a2)
@@ -1135,13 +1138,7 @@ __global__ __launch_bounds__(256) void k_tri_compact(int32_t* __restrict__ rowsB
             if (m >= 0) atomicAdd(&sHist[rot_bin(ang1[i], Q.ang2[m])], 1);
         }
     __syncthreads();
-    if (tid == 0) {
-        int a, b, c;
-        three_maxima_dev(sHist, 30, a, b, c);
-        sInd[0] = a;
-        sInd[1] = b;
-        sInd[2] = c;
-    }
+    if (tid == 0) three_maxima_dev(sHist, 30, sInd);
     __syncthreads();
     const int ind1 = sInd[0], ind2 = sInd[1], ind3 = sInd[2];
     auto keeps = [&](int i, int m) {
