@@ -115,7 +115,11 @@ int orbfe_max_keypoints(orbfe_ctx*, int rows, int cols);
 
 /* Replaces ORBextractor::operator() (src/ORBextractor.cc:1068-1150).  Host pointers.
  * Returns monoIndex (>= 0), -1 for an empty image; *n_out = number of keypoints (rows of desc).
- * lap0/lap1 = vLappingArea[0..1].  kps/desc must hold `cap` entries (cap*28 and cap*32 bytes). */
+ * lap0/lap1 = vLappingArea[0..1].  kps/desc must hold `cap` entries (cap*28 and cap*32 bytes).
+ * (Waiting: the blocking calls of a frame or two -- this one, orbfe_extract_batch with <= 2 images,
+ * orbfe_extract_stereo_pair, orbfe_compute_stereo_matches_resident -- and the matcher calls whose results come back through
+ * page-locked memory spin, for a bounded time, on a completion word the last kernel publishes there instead of blocking in
+ * hipStreamSynchronize; ORBFE_SPIN=0 in the environment restores the latter.  INTEGRATION.md.) */
 int orbfe_extract(orbfe_ctx*, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
                   orbfe_kp* kps, uint8_t* desc, int cap, int* n_out);
 
