@@ -1130,25 +1130,48 @@ __global__ __launch_bounds__(256) void k_tri_compact(int32_t* __restrict__ rowsB
     int32_t* const out = outPairs + (size_t)p * 2 * n1;
     const int per = (n1 + 255) >> 8, i0 = min(n1, tid * per), i1 = min(n1, i0 + per);
     const bool check = Q.checkOri != 0;
+    // a thread's stretch of the row is read ONCE (entries and, for matches, the rotation bin) when it fits eight registers --
+    // rows of up to 2048 features --; longer rows walk global memory three times (the first form: 9.9 us per launch, each pass
+    // a chain of dependent loads)
+    constexpr int CAP = 8;
+    const bool inRegs = per <= CAP; // (uniform)
+    int mReg[CAP], bReg[CAP];
     if (tid < 32) sHist[tid] = 0;
-    __syncthreads();
-    if (check)
-        for (int i = i0; i < i1; i++) {
-            const int m = m12[i];
-            if (m >= 0) atomicAdd(&sHist[rot_bin(ang1[i], Q.ang2[m])], 1);
+    if (inRegs) {
+#pragma unroll
+        for (int k = 0; k < CAP; k++) {
+            const int i = i0 + k;
+            mReg[k] = i < i1 ? m12[i] : -1;
         }
+#pragma unroll
+        for (int k = 0; k < CAP; k++) bReg[k] = (check && mReg[k] >= 0) ? rot_bin(ang1[i0 + k], Q.ang2[mReg[k]]) : 0;
+    }
+    __syncthreads();
+    if (check) {
+        if (inRegs) {
+#pragma unroll
+            for (int k = 0; k < CAP; k++)
+                if (mReg[k] >= 0) atomicAdd(&sHist[bReg[k]], 1);
+        } else {
+            for (int i = i0; i < i1; i++) {
+                const int m = m12[i];
+                if (m >= 0) atomicAdd(&sHist[rot_bin(ang1[i], Q.ang2[m])], 1);
+            }
+        }
+    }
     __syncthreads();
     if (tid == 0) three_maxima_dev(sHist, 30, sInd);
     __syncthreads();
     const int ind1 = sInd[0], ind2 = sInd[1], ind3 = sInd[2];
-    auto keeps = [&](int i, int m) {
-        if (m < 0) return false;
-        if (!check) return true;
-        const int b = rot_bin(ang1[i], Q.ang2[m]);
-        return b == ind1 || b == ind2 || b == ind3;
-    };
+    auto binKept = [&](int b) { return !check || b == ind1 || b == ind2 || b == ind3; };
+    auto keeps = [&](int i, int m) { return m >= 0 && (!check || binKept(rot_bin(ang1[i], Q.ang2[m]))); };
     int kept = 0;
-    for (int i = i0; i < i1; i++) kept += keeps(i, m12[i]) ? 1 : 0;
+    if (inRegs) {
+#pragma unroll
+        for (int k = 0; k < CAP; k++) kept += (mReg[k] >= 0 && binKept(bReg[k])) ? 1 : 0;
+    } else {
+        for (int i = i0; i < i1; i++) kept += keeps(i, m12[i]) ? 1 : 0;
+    }
     // exclusive prefix of `kept` over the 256 threads
     int inc = kept;
 #pragma unroll
@@ -1166,15 +1189,28 @@ __global__ __launch_bounds__(256) void k_tri_compact(int32_t* __restrict__ rowsB
         total += t;
     }
     int pos = before;
-    for (int i = i0; i < i1; i++) {
-        const int m = m12[i];
-        if (m < 0) continue;
-        if (keeps(i, m)) {
-            out[2 * pos] = i;
-            out[2 * pos + 1] = m;
-            pos++;
+    if (inRegs) {
+#pragma unroll
+        for (int k = 0; k < CAP; k++) {
+            if (mReg[k] < 0) continue;
+            if (binKept(bReg[k])) {
+                out[2 * pos] = i0 + k;
+                out[2 * pos + 1] = mReg[k];
+                pos++;
+            }
+            m12[i0 + k] = -1; // (the clean block stays clean)
         }
-        m12[i] = -1; // (the clean block stays clean)
+    } else {
+        for (int i = i0; i < i1; i++) {
+            const int m = m12[i];
+            if (m < 0) continue;
+            if (keeps(i, m)) {
+                out[2 * pos] = i;
+                out[2 * pos + 1] = m;
+                pos++;
+            }
+            m12[i] = -1;
+        }
     }
     if (tid == 0) outN[p] = total;
     if (!done.flag) return;
@@ -2290,6 +2326,19 @@ struct Scratch { // device allocations of one call
         if (bytes) downs.push_back(Down{host, dev, bytes});
         return 0;
     }
+    // One stretch of the arena brought into its pinned mirror and handed out where it lies (no second copy into the caller's
+    // buffers): *view = host address of dev[0].  Falls back (returns 1) when the stretch is not in the arena.
+    int fetch_view(const void* dev, size_t bytes, const uint8_t** view)
+    {
+        const uint8_t* p = (const uint8_t*)dev;
+        if (!(ar->base && ar->pin && p >= ar->base && p + bytes <= ar->base + ar->cap)) return 1;
+        const size_t lo = (size_t)(p - ar->base);
+        hipError_t e = hipMemcpyAsync(ar->pin + lo, ar->base + lo, bytes, hipMemcpyDeviceToHost, g_ms);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        *view = ar->pin + lo;
+        return 0;
+    }
     int fetch()
     {
         bool inArena = ar->base && ar->pin && !downs.empty();
@@ -3007,13 +3056,24 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         pm = hM;
         pb = hB;
     } else {
-        m.resize(outTotal);
-        bins.resize(outTotal);
-        INT_TRY(s.down(m.data(), dM, (size_t)outTotal * sizeof(int32_t)));
-        INT_TRY(s.down(bins.data(), dB, (size_t)outTotal));
-        INT_TRY(s.fetch());
-        pm = m.data();
-        pb = bins.data();
+        // (a batch: both arrays are neighbours in the arena -- one download, read where it lands)
+        const uint8_t* view = nullptr;
+        const uint8_t* lo = (const uint8_t*)dM;
+        const size_t span = (size_t)((const uint8_t*)dB - lo) + (size_t)outTotal;
+        int fv = (const uint8_t*)dB > lo ? s.fetch_view(lo, span, &view) : 1;
+        if (fv < 0) return fv;
+        if (fv == 0) {
+            pm = reinterpret_cast<const int32_t*>(view);
+            pb = reinterpret_cast<const int8_t*>(view + ((const uint8_t*)dB - lo));
+        } else {
+            m.resize(outTotal);
+            bins.resize(outTotal);
+            INT_TRY(s.down(m.data(), dM, (size_t)outTotal * sizeof(int32_t)));
+            INT_TRY(s.down(bins.data(), dB, (size_t)outTotal));
+            INT_TRY(s.fetch());
+            pm = m.data();
+            pb = bins.data();
+        }
     }
     PTR(); // wait
     for (int p = 0; p < count; p++) {
