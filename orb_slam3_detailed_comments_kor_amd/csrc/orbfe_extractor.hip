@@ -1537,7 +1537,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 }
             }
 #define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
-    hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid, dim3(64 * ORBFE_DESC_WPW), 0, q,                                           \
+    hipLaunchKernelGGL((done.flag ? k_orient_blur_desc<M, SAT, false, true> : k_orient_blur_desc<M, SAT>), descGrid,      \
+                       dim3(64 * ORBFE_DESC_WPW), 0, q,                                                                   \
                        c->d_pyr.p, c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,     \
                        c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
                        c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, descAffine ? 1 : 0, trigTab.codes,                          \

@@ -2359,7 +2359,9 @@ __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
                             of three finished ones; measured 64.7 (4) / 64.5 (2) / 62.4 (1) us, and 59.0 with one wavefront
                             per workgroup AND the aliased buffers below (eight wavefronts per SIMD) */
 #endif
-template <int MODE, bool SAT, bool DBG = false>
+// WORD: the instantiation of the latency path, whose wavefronts report to the call's completion word (OrbDone): kept out of the
+//       batch instantiation (the extra argument and test cost it 0.8 of 52 us)
+template <int MODE, bool SAT, bool DBG = false, bool WORD = false>
 __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                           const OrbDescSlot* __restrict__ slots /* per keypoint slot */,
                                                           int nSlots,
@@ -2827,7 +2829,7 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
     }
     }; // desc_one
     desc_one(g);
-    if (MODE == 0 && ORBFE_DESC_KPW == 1 && ORBFE_DESC_WPW == 1 && g < nSlots) desc_done(done, (unsigned)(imgLocal * nSlots + g));
+    if (WORD && MODE == 0 && ORBFE_DESC_KPW == 1 && ORBFE_DESC_WPW == 1 && g < nSlots) desc_done(done, (unsigned)(imgLocal * nSlots + g));
     if (MODE != 1 && ORBFE_DESC_KPW > 1) {
 #pragma unroll
         for (int rep = 1; rep < ORBFE_DESC_KPW; rep++) {
