@@ -1571,6 +1571,10 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
     const int flags = P.qflags ? P.qflags[q] : 0;
     const bool bRight = flags & 1;
     const float x = P.qx[q], y = P.qy[q], r = P.qr[q];
+    // (the query's descriptor and level range with its other fields -- on the latency path they all sit in pinned host memory,
+    // a PCIe round trip each when they are asked for one after the other)
+    const Desc dq = load_desc(P.qdesc + (size_t)q * 32);
+    const int minLevel = P.qmin[q], maxLevel = P.qmax[q];
     const float fx0 = floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, P.minX), r), P.wInv));
     const float fx1 = ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, P.minX), r), P.wInv));
     const float fy0 = floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, P.minY), r), P.hInv));
@@ -1582,7 +1586,6 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
         const int cy0 = fy0 > 0.f ? (int)fy0 : 0, cy1 = fy1 < (float)(PROJ_GR - 1) ? (int)fy1 : PROJ_GR - 1;
         const int ncy = cy1 - cy0 + 1, ncols = cx1 - cx0 + 1; // ncols <= PROJ_GC = 64
         const int fbase = bRight ? P.Nleft : 0, side = bRight ? PROJ_CELLS : 0;
-        const int minLevel = P.qmin[q], maxLevel = P.qmax[q];
         const bool gate = !bRight && P.Nleft == -1 && P.uright != nullptr;
         const float xr = (gate || (P.chi2 && P.qxr)) ? P.qxr[q] : 0.f;
         int lo = 0, cnt = 0;
@@ -1603,7 +1606,6 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
         if (lane == 0) sBase[wave][64] = T; // (entries >= ncols hold T as well: cnt = 0 there)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const Desc dq = load_desc(P.qdesc + (size_t)q * 32);
         // pass over the flat range; keep = 0: count and collect in LDS; keep = 1 (only when the window overflowed
         // the LDS buffer): write to the reserved stretch of rawKeys
         auto enumerate = [&](bool toGlobal) -> int {
