@@ -259,6 +259,7 @@ struct orbfe_ctx : orbfe_geom_state {
     DevBuf<unsigned> d_done;  // 65 counters
     PinBuf<unsigned> h_done;  // the flag word
     unsigned doneSeq = 0;     // last sequence number handed out
+    int lapInlineN = 0, lapInline[4] = {0, 0, 0, 0}; // host_submit -> run_device: the lapping ranges of a call of <= 2 images
     bool doneWant = false;    // host_submit -> run_device: the caller wants the word for this call
     unsigned doneGot = 0;     // run_device -> host_submit: the number K-DESC will publish, or 0
     bool autoRegister = false;
@@ -1344,6 +1345,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                             context's stream after lane_join (orbfe_extract_batch_device) */)
 {
     int r;
+    const int lapInlineN = c->lapInlineN; // (a host-path call of <= 2 images: its lapping ranges go to K-QT by value)
+    c->lapInlineN = 0;
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if (capPerImg < c->maxKp || capPerImg > 65535 || nimg > 32767) return ORBFE_ERR_ARGS; // fix-list packing
     if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
@@ -1482,13 +1485,18 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         {
             OrbQtLevels lv = {};
             for (size_t i = 0; i < c->qtSmall.size(); i++) lv.v[i] = c->qtSmall[i];
+            OrbLapInline lapIn = {}; // (the host path of a frame or two hands the ranges over by value)
+            if (lapInlineN > 0 && i0 == 0) {
+                lapIn.n = lapInlineN;
+                for (int i = 0; i < 4; i++) lapIn.v[i] = c->lapInline[i];
+            }
             const unsigned nS = (unsigned)c->qtSmall.size(), nB = (unsigned)c->qtBig.size();
             if (nS)
                 hipLaunchKernelGGL(k_octree<false>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nS) : dim3(nS, (unsigned)ni),
                                    dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                                    c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
                                    c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
-                                   c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p, lv, (int*)nullptr, (size_t)0);
+                                   c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p, lv, (int*)nullptr, (size_t)0, lapIn);
             if (nB) { // levels whose node tables exceed the LDS: same kernel on a global scratch area (i0-relative slices)
                 OrbQtLevels lb = {};
                 for (size_t i = 0; i < c->qtBig.size(); i++) lb.v[i] = c->qtBig[i];
@@ -1497,7 +1505,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                    c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
                                    c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
                                    c->qtBigKeyOff, c->qtBigKeyCap, d_lap, c->d_lvlPre.p, lb,
-                                   c->d_qtScratch.p + (size_t)i0 * c->qtBig.size() * c->qtScratchStride, c->qtScratchStride);
+                                   c->d_qtScratch.p + (size_t)i0 * c->qtBig.size() * c->qtScratchStride, c->qtScratchStride, lapIn);
             }
         }
         if (nsub == 1) rec(c, 3);
@@ -2064,6 +2072,8 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
             c->doneGot = 0u;
         }
     }
+    c->lapInlineN = nimg <= 2 ? nimg : 0; // (consumed and cleared by run_device)
+    for (int i = 0; i < 2 * c->lapInlineN; i++) c->lapInline[i] = lap ? lap[i] : 0;
     r = run_device(c, nimg, d_imgBase, rows, cols, devPitch, devStride, sl.d_lapAlias, d_kps, d_desc,
                    cap_per_img, d_meta, d_meta + nimg, d_meta + 2 * nimg, mirror, sl.metaBytes);
     sl.doneSeq = c->doneGot;

@@ -1233,6 +1233,14 @@ __device__ unsigned long long g_qtTimes[64];
 struct OrbQtLevels {
     int32_t v[ORBFE_MAX_LEVELS]; // the levels this launch works on (grid coordinate -> level)
 };
+// The lapping ranges of a call of one or two images travel as kernel arguments: the host path keeps them in pinned HOST memory
+// (no upload command for eight bytes), and reading them there was a PCIe round trip of ~2 us in every level's workgroup --
+// behind its last barrier where it was first used (tools/qt_times.py: "output written" 1.96 us), in front of its first barrier
+// when requested early (loads return in order).
+struct OrbLapInline {
+    int32_t n;    // images whose range is in v (0: read `lap`)
+    int32_t v[4]; // lap0, lap1 of image 0, of image 1
+};
 template <bool GLOBAL>
 __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __restrict__ lg,
                                                        const OrbCellGeom* __restrict__ cg,
@@ -1247,7 +1255,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                                        uint32_t* __restrict__ lvlPre /* per keypoint slot: stereo flag << 15 |
                                                                                        stereo keypoints before it in its level */,
                                                        const OrbQtLevels levels, int* __restrict__ gScratch /* GLOBAL: node
-                                                       tables, scratchStride ints per workgroup */, size_t scratchStride)
+                                                       tables, scratchStride ints per workgroup */, size_t scratchStride,
+                                                       const OrbLapInline lapIn)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1330,7 +1339,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             gbase[tid] = cells[cbase + tid].slotBase;
         }
         __syncthreads();
+        QT_STAMP(5);
         const int tot = qt_scan(gscan, nc, wsum); // exclusive prefix of the counts
+        QT_STAMP(6);
         if (oneChunk && tot <= keyLdsCap) {       // (uniform) the key arrays do not overlap gscan / gbase
             keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
             keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
@@ -1415,19 +1426,25 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             qt_hist_add(cc, b); // (whole wavefronts)
         });
         __syncthreads();
-        // checks: no node above depth FF with exactly one key; at every depth some node with two non-empty children
+        QT_STAMP(10);
+        // checks: no node above depth FF with exactly one key; at every depth some node with two non-empty children.
+        // One lane per (depth, node, child): the child's key count is a short run of bins, the node's total and its number of
+        // non-empty children are sums over the quad of lanes (DPP).  (One thread per node summing its whole span -- 64 dependent
+        // LDS reads for a root at FF = 3 -- was 0.8 of this kernel's 18 us for a single frame.)
         {
             int flags = 0;
             for (int d = 0; d < FF; d++) { // nodes of depth d = runs of 4^(FF-d) bins
                 const int span = 1 << (2 * (FF - d)), quarter = span >> 2;
-                for (int g = tid; g < (nIni << (2 * d)); g += QT_THREADS) {
-                    int total = 0, kids = 0;
-                    for (int c4 = 0; c4 < 4; c4++) {
-                        int sub = 0;
-                        for (int e = 0; e < quarter; e++) sub += cc[g * span + c4 * quarter + e];
-                        total += sub;
-                        kids += sub > 0;
-                    }
+                const int nItems = (nIni << (2 * d)) * 4; // (a multiple of 4: the lanes of a quad are in range together)
+                for (int it = tid; it < nItems; it += QT_THREADS) {
+                    const int g = it >> 2, c4 = it & 3;
+                    int sub = 0;
+                    for (int e = 0; e < quarter; e++) sub += cc[g * span + c4 * quarter + e];
+                    int total = sub + __builtin_amdgcn_mov_dpp(sub, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+                    total += __builtin_amdgcn_mov_dpp(total, 0x4E, 0xF, 0xF, true);        // quad_perm [2,3,0,1]
+                    int kids = sub > 0 ? 1 : 0;
+                    kids += __builtin_amdgcn_mov_dpp(kids, 0xB1, 0xF, 0xF, true);
+                    kids += __builtin_amdgcn_mov_dpp(kids, 0x4E, 0xF, 0xF, true);
                     if (total == 1) flags |= 1;
                     if (kids >= 2) flags |= 2 << d;
                 }
@@ -1435,6 +1452,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             if (flags) atomicOr(&misc[1], flags);
         }
         __syncthreads();
+        QT_STAMP(11);
         forwarded = misc[1] == ((2 << FF) - 2); // every pass grew the list, no single-key node
         if (forwarded) {
             int* const ulW = nodeUL(0);
@@ -1635,6 +1653,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 for (int t = tid; t < m; t += QT_THREADS) sidx[t] = 0; // rank accumulators (sidx is rebuilt below)
                 if (tid == 0) misc[0] = m;
                 __syncthreads();
+                if (stampF == 43) QT_STAMP(20);
                 // rank = number of candidates ahead in (count descending, creation index descending) order.  All
                 // eight wavefronts work on it: wavefront w compares every candidate t with its own slice of the
                 // j range and adds the partial count (the plain loop -- one thread per t over all j, each LDS read
@@ -1661,12 +1680,14 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                     }
                 }
                 __syncthreads();
+                if (stampF == 43) QT_STAMP(21);
                 for (int t = tid; t < m; t += QT_THREADS) {
                     const int rank = sidx[t];
                     kOf[mcur[t]] = rank;
                     par[rank] = mcur[t];
                 }
                 __syncthreads();
+                if (stampF == 43) QT_STAMP(22);
                 {
                     const int* ul = nodeUL(cur);
                     const int* br = nodeBR(cur);
@@ -1686,6 +1707,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                     });
                 }
                 __syncthreads();
+                if (stampF == 43) QT_STAMP(23);
                 // growth of candidate r = its non-empty children - 1; the exclusive prefix says where the list
                 // size stands before r, and the one candidate at which it reaches N is the break of :728-729
                 // (misc[0] was preset to m before the histogram's barrier)
@@ -1700,9 +1722,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                 });
                 }
                 const int nE2 = misc[0];
+                if (stampF == 43) QT_STAMP(24);
                 qt_scan_map(kOf, sidx, size, wsum, [nE2](int k) { return (k >= 0 && k < nE2) ? 1 : 0; });
+                if (stampF == 43) QT_STAMP(25);
                 int nM2 = 0;
                 const int ns2 = expand(nE2, true, nM2);
+                if (stampF == 43) QT_STAMP(26);
                 if (ns2 < 0) {
                     finish = true;
                     break;
@@ -1726,6 +1751,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         atomicMax(&best[regp ? nReg[j] : (int)keyNode[i]], ((key >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
     });
     __syncthreads();
+    QT_STAMP(27);
     uint32_t* out = lvlKp + (size_t)img * kpImgStride + L.kpBase;
     const int nout = min(size, L.kpCap);
     // The mono / stereo partition of operator() (:1100-1147) is decided here, where the level's keypoints are final: a
@@ -1734,7 +1760,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     // every output slot from these (no K-PACK launch).  Bit 16 marks a slot that holds a keypoint of THIS batch (the slots
     // past the level's count are cleared), so that K-DESC's wavefronts know without the counts whether they have work.
     {
-        const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1], scale = L.scale;
+        const bool inl = img < lapIn.n; // (uniform)
+        const float lap0 = (float)(inl ? lapIn.v[2 * img] : lap[2 * img]), lap1 = (float)(inl ? lapIn.v[2 * img + 1] : lap[2 * img + 1]),
+                    scale = L.scale;
         uint32_t* const pre = lvlPre + (size_t)img * kpImgStride + L.kpBase;
         int run = 0, buf = 0;
         // the two usual ranges need no counting: (0, 0) of the rectified-stereo / RGB-D constructors holds no keypoint (a
