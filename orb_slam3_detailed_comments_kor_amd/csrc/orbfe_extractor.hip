@@ -1514,12 +1514,17 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         // itself: four launches per batch
         const bool needPack = c->kb8On;
         int32_t* const mMeta = mirror ? reinterpret_cast<int32_t*>(mirror) : nullptr;
+        OrbLapInline lapInPack = {};
+        if (lapInlineN > 0 && i0 == 0) {
+            lapInPack.n = lapInlineN;
+            for (int i = 0; i < 4; i++) lapInPack.v[i] = c->lapInline[i];
+        }
         if (needPack)
             hipLaunchKernelGGL(k_pack, dim3((unsigned)ni), dim3(PACK_THREADS), 0, q, c->d_lg.p, nl, c->d_lvlKp.p, c->kpStride,
                                c->d_lvlCount.p, d_lap, capPerImg, c->d_destMap.p, d_n, d_mono,
                                c->kb8On ? c->d_kb8.p : nullptr,
                                c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
-                               k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr, mMeta, nimg);
+                               k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr, mMeta, nimg, lapInPack);
         if (nsub == 1 && needPack) rec(c, 4); // (without K-PACK no event separates K-QT from K-DESC: a record costs ~3.5 us)
         if (c->recNow) c->packSkipped[c->profCalls % orbfe_ctx::kProfSets] = !(nsub == 1 && needPack);
         // K-DESC

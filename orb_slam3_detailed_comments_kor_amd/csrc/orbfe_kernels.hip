@@ -1856,7 +1856,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
                                               int32_t* __restrict__ errOut /* where the host path reads it, or NULL */,
                                               int32_t* __restrict__ mirrorMeta /* [n | mono | err] in pinned HOST memory
                                                                                   (latency path of a frame or two), or NULL */,
-                                              int mirrorImgs)
+                                              int mirrorImgs, const OrbLapInline lapIn)
 {
     __shared__ int lvlOff[ORBFE_MAX_LEVELS + 1];
     __shared__ int waveCnt[PACK_THREADS / 64];
@@ -1874,7 +1874,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(const OrbLevelGeom* __res
     }
     __syncthreads();
     const int n = min(lvlOff[nlevels], capPerImg);
-    const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1];
+    const bool lapInl = img < lapIn.n; // (uniform; see OrbLapInline)
+    const float lap0 = (float)(lapInl ? lapIn.v[2 * img] : lap[2 * img]), lap1 = (float)(lapInl ? lapIn.v[2 * img + 1] : lap[2 * img + 1]);
     for (int base = 0; base < n; base += PACK_THREADS) {
         const int g = base + tid;
         bool stereo = false;
