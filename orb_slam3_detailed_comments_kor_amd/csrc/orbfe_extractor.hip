@@ -259,6 +259,7 @@ struct orbfe_ctx : orbfe_geom_state {
     DevBuf<unsigned> d_done;  // 65 counters
     PinBuf<unsigned> h_done;  // the flag word
     unsigned doneSeq = 0;     // last sequence number handed out
+    int spinMisses = 0;       // consecutive waits without the word inside the bound: at 8 spinWait is switched off for this context
     int lapInlineN = 0, lapInline[4] = {0, 0, 0, 0}; // host_submit -> run_device: the lapping ranges of a call of <= 2 images
     bool doneWant = false;    // host_submit -> run_device: the caller wants the word for this call
     unsigned doneGot = 0;     // run_device -> host_submit: the number K-DESC will publish, or 0
@@ -2148,6 +2149,7 @@ static bool spin_done(orbfe_ctx* c, unsigned seq)
     for (unsigned it = 0;; it++) {
         if (*f == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
+            c->spinMisses = 0;
             return true;
         }
         __builtin_ia32_pause();
@@ -2156,6 +2158,7 @@ static bool spin_done(orbfe_ctx* c, unsigned seq)
     // The word did not come within the bound (the caller now synchronises the stream).  Should a counter ever be left non-zero
     // -- a kernel that died half-way -- every later call would time out as well: clear them behind whatever is still queued.
     (void)hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), c->stream);
+    if (++c->spinMisses >= 8) c->spinWait = false; // (the word does not arrive on this platform: stop paying the bound)
     return false;
 }
 

@@ -2117,6 +2117,9 @@ struct Arena {
     unsigned* doneFlag = nullptr;    // host address
     unsigned* doneFlagDev = nullptr; // the kernel's address of the same word
     unsigned doneSeq = 0;
+    int spinMisses = 0; // consecutive waits in which the word did not arrive within the bound; at 8 the word is given up for
+                        // this thread (a platform where the kernel's flag store does not reach the host while the kernel runs
+                        // would otherwise cost every call the full bound)
     // the clean block: device memory that is all ones between calls (the kernels' scattered results; DoneSig)
     uint8_t* cleanDev = nullptr;
     size_t cleanCap = 0;
@@ -2444,6 +2447,7 @@ struct Scratch { // device allocations of one call
     }
     bool done_words()
     {
+        if (ar->spinMisses >= 8) return false;
         if (ar->doneCtr) return true;
         void *c = nullptr, *h = nullptr, *dv = nullptr;
         // (cleared on the call's own stream: the null stream is not ordered with a non-blocking one)
@@ -2528,12 +2532,14 @@ struct Scratch { // device allocations of one call
             for (unsigned it = 0;; it++) {
                 if (*f == w.seq) {
                     std::atomic_thread_fence(std::memory_order_acquire);
+                    ar->spinMisses = 0;
                     return 0;
                 }
                 __builtin_ia32_pause();
                 if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
             }
         }
+        if (w.flag) ar->spinMisses++;
         hipError_t e = hipStreamSynchronize(g_ms);
         // the word did not come within the bound: normally a long call (its counter is back at zero by now); should the counter
         // ever be left non-zero -- a kernel that died half-way -- every later call would time out, so it is cleared here
