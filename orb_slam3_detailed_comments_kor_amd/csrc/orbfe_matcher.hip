@@ -2141,6 +2141,55 @@ const int kMaxDevices = 16;
 thread_local Arena g_arena[kMaxDevices];
 thread_local hipStream_t g_ms = nullptr; // stream of the matcher call in progress on this thread
 
+// Device blocks of the resident handles (orbfe_keyframe_*, orbfe_frame_*): a Frame handle lives for a frame, a KeyFrame handle
+// for as long as the adapter's table keeps it, and hipMalloc / hipFree cost 10-20 us each -- as much as the search the handle
+// is made for.  Freed blocks wait here (per device, up to 64 of them) for the next handle of about their size.
+struct BlockPool {
+    std::mutex m;
+    struct Blk {
+        void* p;
+        size_t cap;
+    };
+    std::vector<Blk> freeBlocks[kMaxDevices];
+    void* get(int device, size_t bytes, size_t* cap)
+    {
+        const size_t want = (bytes + 0xFFFF) & ~(size_t)0xFFFF; // 64-KB classes
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto& v = freeBlocks[device];
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i].cap >= want && v[i].cap <= 2 * want) {
+                    const Blk b = v[i];
+                    v[i] = v.back();
+                    v.pop_back();
+                    *cap = b.cap;
+                    return b.p;
+                }
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        *cap = want;
+        return p;
+    }
+    void put(int device, void* p, size_t cap)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto& v = freeBlocks[device];
+            if (v.size() < 64) {
+                v.push_back(Blk{p, cap});
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+};
+BlockPool g_blockPool;
+
 struct Scratch { // device allocations of one call
     Arena* ar = nullptr;
     // Latency path (round 4): a call whose staged inputs are a few KB hands the KERNEL the pinned mirror itself (device-side
@@ -2290,6 +2339,16 @@ struct Scratch { // device allocations of one call
         *dev = (T*)(ar->pinDev + at);
         *host = (T*)(ar->pin + at);
         return 0;
+    }
+    // `bytes` of the arena's pinned mirror as plain staging (the caller copies from it itself): nullptr when it does not fit
+    uint8_t* pin_scratch(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        ar->want += bytes;
+        if (!(ar->base && ar->pin && ar->off + bytes <= ar->cap)) return nullptr;
+        uint8_t* p = ar->pin + ar->off;
+        ar->off += bytes;
+        return p;
     }
     // Descriptor arrays may already live on the device (an extractor's resident output slab, a gathered slab):
     // then they are read in place.
@@ -2790,6 +2849,7 @@ int orbfe_matcher_sync(int device)
 struct orbfe_keyframe {
     int device = 0, n = 0;
     uint8_t* block = nullptr; // one allocation: everything below points into it
+    size_t blockCap = 0;
     uint8_t *desc = nullptr, *mask = nullptr;
     float *ang = nullptr, *kp = nullptr, *uR = nullptr;
     int32_t *oct = nullptr, *ind = nullptr;
@@ -3107,12 +3167,14 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t oDesc = 0, oMask = oDesc + al(n * 32), oAng = oMask + al(n), oKp = oAng + al(n * 4), oUr = oKp + al(n * 8),
                  oOct = oUr + al(n * 4), oInd = oOct + al(n * 4), total = oInd + al(std::max<size_t>(ni, 1) * 4);
-    void* blk = nullptr;
-    HIP_TRY(hipMalloc(&blk, total));
+    size_t blkCap = 0;
+    void* blk = g_blockPool.get(device, total, &blkCap);
+    if (!blk) return -(1000 + (int)hipErrorOutOfMemory);
     orbfe_keyframe* K = new orbfe_keyframe();
     K->device = device;
     K->n = a->n;
     K->block = (uint8_t*)blk;
+    K->blockCap = blkCap;
     K->desc = K->block + oDesc;
     K->mask = K->block + oMask;
     K->ang = (float*)(K->block + oAng);
@@ -3141,17 +3203,38 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     if (descResident) {
         if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) return w;
     }
-    hipError_t e = hipMemcpyAsync(K->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess) e = hipMemcpyAsync(K->mask, a->mask, n, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess && a->angle) e = hipMemcpyAsync(K->ang, a->angle, n * 4, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess && !a->angle) e = hipMemsetAsync(K->ang, 0, n * 4, g_ms);
-    if (e == hipSuccess && tri) e = hipMemcpyAsync(K->kp, a->kp_xy, n * 8, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess && tri) e = hipMemcpyAsync(K->uR, a->uRight, n * 4, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess && tri) e = hipMemcpyAsync(K->oct, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess && ni) e = hipMemcpyAsync(K->ind, a->fv.indices, ni * 4, hipMemcpyHostToDevice, g_ms);
+    // the whole block staged in this thread's pinned arena in the block's own layout, then ONE upload (seven pageable copies,
+    // each staged and waited for by the runtime, were most of the 38 us this call took)
+    hipError_t e = hipSuccess;
+    const size_t first = descResident ? oMask : 0; // (resident descriptors: copied on the device)
+    uint8_t* st = s.pin_scratch(total - first);
+    if (st) {
+        uint8_t* const b = st - first; // so that b + o* addresses the staged copy of block + o*
+        if (!descResident) std::memcpy(b + oDesc, a->desc, n * 32);
+        std::memcpy(b + oMask, a->mask, n);
+        if (a->angle) std::memcpy(b + oAng, a->angle, n * 4);
+        else std::memset(b + oAng, 0, n * 4);
+        if (tri) {
+            std::memcpy(b + oKp, a->kp_xy, n * 8);
+            std::memcpy(b + oUr, a->uRight, n * 4);
+            std::memcpy(b + oOct, a->octave, n * 4);
+        }
+        if (ni) std::memcpy(b + oInd, a->fv.indices, ni * 4);
+        if (descResident) e = hipMemcpyAsync(K->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(K->block + first, st, total - first, hipMemcpyHostToDevice, g_ms);
+    } else { // (the arena is too small this once: array by array)
+        e = hipMemcpyAsync(K->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(K->mask, a->mask, n, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && a->angle) e = hipMemcpyAsync(K->ang, a->angle, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && !a->angle) e = hipMemsetAsync(K->ang, 0, n * 4, g_ms);
+        if (e == hipSuccess && tri) e = hipMemcpyAsync(K->kp, a->kp_xy, n * 8, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && tri) e = hipMemcpyAsync(K->uR, a->uRight, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && tri) e = hipMemcpyAsync(K->oct, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && ni) e = hipMemcpyAsync(K->ind, a->fv.indices, ni * 4, hipMemcpyHostToDevice, g_ms);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(g_ms); // the caller's arrays are free again; the handle is complete
     if (e != hipSuccess) {
-        (void)hipFree(blk);
+        g_blockPool.put(device, blk, blkCap);
         delete K;
         return -(1000 + (int)e);
     }
@@ -3179,7 +3262,7 @@ void orbfe_keyframe_destroy(orbfe_keyframe* K)
     if (!K) return;
     if (hipSetDevice(K->device) == hipSuccess) {
         (void)hipDeviceSynchronize(); // (a search of another thread may still be reading it)
-        (void)hipFree(K->block);
+        g_blockPool.put(K->device, K->block, K->blockCap);
     }
     delete K;
 }
@@ -3954,6 +4037,7 @@ struct orbfe_frame {
     int device = 0, n = 0, Nleft = -1;
     float minX = 0, minY = 0, wInv = 0, hInv = 0;
     uint8_t* block = nullptr; // one allocation: everything below points into it
+    size_t blockCap = 0;
     uint8_t* desc = nullptr;
     float *kx = nullptr, *ky = nullptr, *uright = nullptr;
     int32_t *octave = nullptr, *cellStart = nullptr, *cellItems = nullptr, *cellOf = nullptr, *status = nullptr;
@@ -4209,12 +4293,14 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
     const size_t oDesc = 0, oKx = oDesc + al(n * 32), oKy = oKx + al(n * 4), oOct = oKy + al(n * 4), oUr = oOct + al(n * 4),
                  oCs = oUr + al(n * 4), oCi = oCs + al((2 * PROJ_CELLS + 1) * 4), oCo = oCi + al(n * 4), oSt = oCo + al(n * 4),
                  total = oSt + 256;
-    void* blk = nullptr;
-    HIP_TRY(hipMalloc(&blk, total));
+    size_t blkCap = 0;
+    void* blk = g_blockPool.get(device, total, &blkCap);
+    if (!blk) return -(1000 + (int)hipErrorOutOfMemory);
     orbfe_frame* F = new orbfe_frame();
     F->device = device; F->n = a->n; F->Nleft = a->Nleft;
     F->minX = a->minX; F->minY = a->minY; F->wInv = a->gridWInv; F->hInv = a->gridHInv;
     F->block = (uint8_t*)blk;
+    F->blockCap = blkCap;
     F->desc = F->block + oDesc;
     F->kx = (float*)(F->block + oKx); F->ky = (float*)(F->block + oKy);
     F->octave = (int32_t*)(F->block + oOct);
@@ -4228,11 +4314,26 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
     if (descResident) {
         if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) return w;
     }
-    hipError_t e = hipMemcpyAsync(F->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess) e = hipMemcpyAsync(F->octave, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
-    if (e == hipSuccess && F->uright) e = hipMemcpyAsync(F->uright, a->uright, n * 4, hipMemcpyHostToDevice, g_ms);
+    // (staged in the block's own layout and sent as ONE upload, like orbfe_keyframe_create)
+    hipError_t e = hipSuccess;
+    const size_t first = descResident ? oKx : 0, upTo = oCs; // desc | kx | ky | octave | uright lie in front of the grid arrays
+    uint8_t* st = s.pin_scratch(upTo - first);
+    if (st) {
+        uint8_t* const b = st - first;
+        if (!descResident) std::memcpy(b + oDesc, a->desc, n * 32);
+        std::memcpy(b + oKx, a->kx, n * 4);
+        std::memcpy(b + oKy, a->ky, n * 4);
+        std::memcpy(b + oOct, a->octave, n * 4);
+        if (F->uright) std::memcpy(b + oUr, a->uright, n * 4);
+        if (descResident) e = hipMemcpyAsync(F->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->block + first, st, upTo - first, hipMemcpyHostToDevice, g_ms);
+    } else {
+        e = hipMemcpyAsync(F->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->octave, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && F->uright) e = hipMemcpyAsync(F->uright, a->uright, n * 4, hipMemcpyHostToDevice, g_ms);
+    }
     if (e == hipSuccess) {
         ProjDev P{};
         P.kx = F->kx; P.ky = F->ky; P.n = F->n; P.Nleft = F->Nleft;
@@ -4241,9 +4342,12 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
         hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(g_ms); // the caller's arrays are free again; the handle is complete
+    // the handle is complete (and may serve other threads) when the grid is built.  (Waiting on a completion word published by
+    // the grid kernel instead was tried: 0.036 against 0.029 ms -- the next creation's upload command then queues behind a
+    // kernel the runtime still holds as running, the case the search calls avoid by reading their inputs in place.)
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
     if (e != hipSuccess) {
-        (void)hipFree(blk);
+        g_blockPool.put(device, blk, blkCap);
         delete F;
         return -(1000 + (int)e);
     }
@@ -4254,7 +4358,9 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
 void orbfe_frame_destroy(orbfe_frame* F)
 {
     if (!F) return;
-    if (hipSetDevice(F->device) == hipSuccess) (void)hipFree(F->block);
+    // (the block goes back to the pool: the handle is no longer in use by any thread -- its searches have returned --, and a
+    // search's kernel has done all its reads before the search returns, with the completion word as without it)
+    g_blockPool.put(F->device, F->block, F->blockCap);
     delete F;
 }
 

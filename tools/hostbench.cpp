@@ -299,6 +299,7 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     ka.desc = ddA; ka.n = nA; ka.mask = maskA.data(); ka.angle = angA.data(); ka.kp_xy = xyA.data(); ka.octave = octA.data();
     ka.uRight = uA.data(); ka.fv = fA.view();
     orbfe_keyframe* kfA = nullptr;
+    if (timeit("keyframe_create_destroy", 100, [&] { orbfe_keyframe* k = nullptr; const int r = orbfe_keyframe_create(&k, dev, &ka); orbfe_keyframe_destroy(k); return r; }, out)) return 2;
     CHECK(orbfe_keyframe_create(&kfA, dev, &ka));
     orbfe_keyframe* kf1[1] = {kfA};
     int32_t* mp[1] = {match.data()};
@@ -421,6 +422,13 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     {   // the frame side resident (orbfe_frame_create: what the adapter keeps per Frame; Tracking searches one Frame several
         // times -- src/Tracking.cc:2817-2827, :2927): only the queries travel
         orbfe_frame* fr = nullptr;
+        // (what making the frame resident costs: once per Frame, before its first search)
+        if (timeit("frame_create_destroy_host_arrays", 100, [&] { orbfe_frame* f = nullptr; const int r = orbfe_frame_create(&f, dev, &pr); orbfe_frame_destroy(f); return r; }, out)) return 2;
+        {
+            orbfe_proj_args prd = pr;
+            prd.desc = ddB; // the descriptors where the extractor left them
+            if (timeit("frame_create_destroy_device_descriptors", 100, [&] { orbfe_frame* f = nullptr; const int r = orbfe_frame_create(&f, dev, &prd); orbfe_frame_destroy(f); return r; }, out)) return 2;
+        }
         CHECK(orbfe_frame_create(&fr, dev, &pr));
         std::vector<int32_t> qm2(nA), fm2(nB);
         int n2 = 0;
