@@ -1448,6 +1448,11 @@ struct ProjDev {
     unsigned* doneFlag;
     unsigned doneSeq;
 };
+// Every query owns PROJ_QUOTA key slots (its stretch starts at PROJ_QUOTA * q); a query with more candidates takes a stretch of
+// the overflow region behind them, handed out by an atomic on status[2].  (Handing out EVERY stretch that way -- 300 wavefronts
+// adding to one word and waiting for the old value -- cost each of them 4.5 of its 9.6 us, tools/hostbench with a
+// -DORBFE_PROJ_TIMING library.)  keyCap counts both regions; the host adds PROJ_QUOTA * nq to status[2] when it sizes a retry.
+#define PROJ_QUOTA 32
 #define PROJ_GC 64
 #define PROJ_GR 48
 #define PROJ_CELLS (PROJ_GC * PROJ_GR)
@@ -1608,6 +1613,9 @@ __device__ __forceinline__ int proj_static_ok(const ProjDev& P, int g, int local
 // dependent chain is bounds -> item -> keypoint -> descriptor whatever the window holds.  Keys are collected and
 // rank-sorted in LDS (PROJ_KCAP per query); a window with more candidates takes the global two-pass path.
 #define PROJ_KCAP 192
+#ifdef ORBFE_PROJ_TIMING
+__device__ unsigned long long g_projTimes[16]; // [1..8] the sweeps workgroup, [10..13] sums over [14] candidate wavefronts (100-MHz ticks)
+#endif
 __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
 {
     __shared__ int sLo[4][64], sBase[4][65];
@@ -1615,6 +1623,12 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
     if (q >= P.nq) return;
+#ifdef ORBFE_PROJ_TIMING
+    unsigned long long ctS[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
+#define CT(k) ctS[k] = (unsigned long long)wall_clock64()
+#else
+#define CT(k) do { } while (0)
+#endif
     const int flags = P.qflags ? P.qflags[q] : 0;
     const bool bRight = flags & 1;
     const float x = P.qx[q], y = P.qy[q], r = P.qr[q];
@@ -1648,6 +1662,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
             if (lane >= off) inc += v;
         }
         const int T = __shfl(inc, 63);
+        CT(1); // query fields + cell ranges
         sLo[wave][lane] = lo;
         sBase[wave][lane] = inc - cnt;
         if (lane == 0) sBase[wave][64] = T; // (entries >= ncols hold T as well: cnt = 0 there)
@@ -1687,9 +1702,15 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
             return mm;
         };
         m = enumerate(false);
+        CT(2); // candidates enumerated and scored
         if (m > 0) {
-            if (lane == 0) base = atomicAdd(&P.status[2], m);
-            base = __shfl(base, 0);
+            if (m <= PROJ_QUOTA) {
+                base = PROJ_QUOTA * q;
+            } else {
+                if (lane == 0) base = PROJ_QUOTA * P.nq + atomicAdd(&P.status[2], m);
+                base = __shfl(base, 0);
+            }
+            CT(3); // key range reserved
             if (base + m > P.keyCap) {
                 m = -1; // the host enlarges the key buffers and runs again
             } else if (m <= PROJ_KCAP) {
@@ -1719,10 +1740,17 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
         P.qCount[q] = m;
         if (P.qArea) P.qArea[q] = anyInArea ? 1 : 0;
     }
+    CT(4); // keys sorted and written
+#ifdef ORBFE_PROJ_TIMING
+    if (lane == 0 && ctS[1] && ctS[2] && ctS[4]) { // (sums over the wavefronts that went through every stage)
+        for (int k = 1; k <= 4; k++) atomicAdd(&g_projTimes[9 + k], (ctS[k] ? ctS[k] : ctS[k - 1]) - ctS[0]);
+        atomicAdd(&g_projTimes[14], 1ull);
+    }
+#endif
+#undef CT
 }
 
-#ifdef ORBFE_PROJ_TIMING // tuning only (tools/ab_build.sh projt "-DORBFE_PROJ_TIMING"): stage times of K-PROJ's sweeps workgroup
-__device__ unsigned long long g_projTimes[16]; // 100-MHz ticks since the workgroup began: init, cache, sweeps, final, mirror; [8] = sweeps
+#ifdef ORBFE_PROJ_TIMING // tuning only (tools/ab_build.sh projt "-DORBFE_PROJ_TIMING"): stage times of K-PROJ's sweeps workgroup // 100-MHz ticks since the workgroup began: init, cache, sweeps, final, mirror; [8] = sweeps
 #define PT_BEGIN() unsigned long long ptS[8] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0, 0, 0}
 #define PT(k) ptS[k] = (unsigned long long)wall_clock64()
 #define PT_END(nsweeps)                                                           \
@@ -3745,7 +3773,7 @@ int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* m
     if ((r = s.up<int32_t>(&dOut, nullptr, 4 + nq)) < 0) return r;
     P.status = dOut;
     P.qMatch = dOut + 4;
-    size_t keyCap = std::max<size_t>(64 * nq, 1 << 16);
+    size_t keyCap = PROJ_QUOTA * nq + std::max<size_t>(PROJ_QUOTA * nq, 1 << 15); // (the queries' own stretches + overflow)
     if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
     if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
     P.keyCap = (int)keyCap;
@@ -3765,9 +3793,9 @@ int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* m
         HIP_TRY(hipGetLastError());
         INT_TRY(s.down(out.data(), dOut, out.size() * 4));
         INT_TRY(s.fetch());
-        if (out[2] >= 0 && (size_t)out[2] <= keyCap) break;
+        if (out[2] >= 0 && PROJ_QUOTA * nq + (size_t)out[2] <= keyCap) break;
         if (attempt > 0 || out[2] < 0) return ORBFE_ERR_STATE;
-        keyCap = (size_t)out[2];
+        keyCap = PROJ_QUOTA * nq + (size_t)out[2];
         if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, keyCap)) < 0) return r;
         if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, keyCap)) < 0) return r;
         P.keyCap = (int)keyCap;
@@ -4154,7 +4182,7 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_fra
     P.qArea = nullptr;
     for (size_t q = 0; a->qflags && q < nq && !P.qArea; q++)
         if ((a->qflags[q] & 4) && (r = s.up<int32_t>(&P.qArea, nullptr, nq)) < 0) return r;
-    J.keyCap = std::max<size_t>(64 * nq, 1 << 16);
+    J.keyCap = PROJ_QUOTA * nq + std::max<size_t>(PROJ_QUOTA * nq, 1 << 15); // (the queries' own stretches + overflow)
     if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, J.keyCap)) < 0) return r;
     if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
     P.keyCap = (int)J.keyCap;
@@ -4293,11 +4321,11 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         // more candidate keys than a job's buffers hold: the kernel reported how many it needs; run again
         bool again = false;
         for (ProjJob& J : jobs) {
-            const int need = out[J.outOff + 2];
-            if (need < 0) return ORBFE_ERR_STATE;
-            if ((size_t)need > J.keyCap) {
+            if (out[J.outOff + 2] < 0) return ORBFE_ERR_STATE;
+            const size_t need = (size_t)PROJ_QUOTA * (size_t)J.P.nq + (size_t)out[J.outOff + 2]; // (own stretches + overflow asked for)
+            if (need > J.keyCap) {
                 if (attempt > 0) return ORBFE_ERR_STATE;
-                J.keyCap = (size_t)need;
+                J.keyCap = need;
                 if ((r = s.up<unsigned long long>(&J.P.rawKeys, nullptr, J.keyCap)) < 0) return r;
                 if ((r = s.up<unsigned long long>(&J.P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
                 J.P.keyCap = (int)J.keyCap;

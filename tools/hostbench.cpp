@@ -437,8 +437,11 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
             unsigned long long t[16];
             (void)hipDeviceSynchronize();
             if (pt(t) == 0)
-                fprintf(stderr, "K-PROJ sweeps workgroup (us since its start): init %.2f  cache %.2f  sweeps %.2f (%llu)  final %.2f  mirror %.2f\n",
-                        t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[8], t[4] * 0.01, t[5] * 0.01);
+                fprintf(stderr, "K-PROJ sweeps workgroup (us since its start): init %.2f  cache %.2f  sweeps %.2f (%llu)  final %.2f  mirror %.2f\n"
+                                "K-PROJ candidate wavefronts (mean over %llu, us since a wavefront's start): query + cell ranges %.2f  enumerated + scored %.2f  range reserved %.2f  sorted + written %.2f\n",
+                        t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[8], t[4] * 0.01, t[5] * 0.01, t[14], t[10] * 0.01 / (double)std::max<unsigned long long>(t[14], 1),
+                        t[11] * 0.01 / (double)std::max<unsigned long long>(t[14], 1), t[12] * 0.01 / (double)std::max<unsigned long long>(t[14], 1),
+                        t[13] * 0.01 / (double)std::max<unsigned long long>(t[14], 1));
         }
         {   // ... and a tracking-like search against the same resident frame: the queries ARE the frame's features seen again --
             // positions moved by a pixel or two, a dozen descriptor bits flipped, the last-frame form (mode 1, window 15 px
