@@ -2977,6 +2977,17 @@ int orbfe_debug_level_keypoints(orbfe_ctx* c, int img, int level, uint32_t* out,
 
 int orbfe_debug_fixups(orbfe_ctx* c) { return c ? c->lastFixups : ORBFE_ERR_ARGS; }
 
+#ifdef ORBFE_STEREO_TIMING
+extern "C" int orbfe_debug_stereo_times(unsigned long long* out8)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stereoTimes), 8 * sizeof(unsigned long long)));
+    static const unsigned long long zeros[8] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stereoTimes), zeros, sizeof(zeros)));
+    return 0;
+}
+#endif
+
 #ifdef ORBFE_QT_TIMING
 extern "C" int orbfe_debug_qt_times(unsigned long long* out64)
 {

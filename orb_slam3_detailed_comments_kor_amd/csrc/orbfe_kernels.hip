@@ -2877,6 +2877,26 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
 // extractors left them in HBM (no mvImagePyramid download).  The median-based outlier cut
 // (:952-966) needs all matches and stays O(N) host code.
 #define STEREO_CHUNK 2048 /* right keypoints staged per round: 8 + 8 + 16 KB of LDS */
+#ifdef ORBFE_STEREO_TIMING // tuning only (tools/ab_build.sh stt "-DORBFE_STEREO_TIMING"): stage times, summed over the live wavefronts
+__device__ unsigned long long g_stereoTimes[8]; // [1..5] sums of (stage end - wavefront start) in 100-MHz ticks, [7] wavefronts
+#define ST_BEGIN() unsigned long long stS[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0}
+#define ST(k) stS[k] = (unsigned long long)wall_clock64()
+#define ST_END()                                                                                  \
+    do {                                                                                          \
+        if (lane == 0 && live) {                                                                  \
+            unsigned long long prev_ = stS[0];                                                    \
+            for (int k_ = 1; k_ <= 5; k_++) {                                                     \
+                if (stS[k_]) prev_ = stS[k_];                                                     \
+                atomicAdd(&g_stereoTimes[k_], prev_ - stS[0]);                                    \
+            }                                                                                     \
+            atomicAdd(&g_stereoTimes[7], 1ull);                                                   \
+        }                                                                                         \
+    } while (0)
+#else
+#define ST_BEGIN() do { } while (0)
+#define ST(k) do { } while (0)
+#define ST_END() do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict__ pyrL,
                                                       const uint8_t* __restrict__ pyrR,
                                                       const OrbLevelGeom* __restrict__ lg, int nlevels,
@@ -2894,7 +2914,9 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
     __shared__ float sU[STEREO_CHUNK];
     __shared__ uint32_t sBand[STEREO_CHUNK];
     __shared__ uint16_t sCand[4][STEREO_CHUNK];
+    __shared__ uint32_t sWinR[4][66], sWinL[4][36]; // the SAD windows of a wavefront's keypoint: 11 rows x 6 / x 3 dwords
     wg_done_begin(done, &wgCnt);
+    ST_BEGIN();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iL = blockIdx.x * 4 + wave;
     const int rowsL = nL; // rows of the output arrays
@@ -2954,22 +2976,31 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
             sBand[j] = band;
         }
         __syncthreads();
+        ST(1); // table staged
         int nc = 0;
-        for (int j0 = 0; j0 < cn; j0 += 64) { // (uniform)
-            const int j = j0 + lane;
-            bool ok = false;
-            if (j < cn) {
-                const uint32_t b = sBand[j];
-                const int minr = (int)(b & 8191u), maxr1 = (int)((b >> 13) & 8191u), octR = (int)(b >> 26);
-                const float uR = sU[j];
-                ok = live && b != 0xFFFFFFFFu && vLi >= minr && vLi < maxr1 && !(octR < levelL - 1 || octR > levelL + 1) && (uR >= minU && uR <= maxU);
+        for (int j0 = 0; j0 < cn; j0 += 256) { // (uniform) four rows of 64 entries per step: their LDS reads are in flight together
+            uint32_t bb[4];
+            float uu[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = j0 + 64 * t + lane;
+                bb[t] = j < cn ? sBand[j] : 0xFFFFFFFFu;
+                uu[t] = j < cn ? sU[j] : 0.f;
             }
-            const unsigned long long m = __ballot(ok);
-            if (ok) sCand[wave][nc + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
-            nc += __popcll(m);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t b = bb[t];
+                const int minr = (int)(b & 8191u), maxr1 = (int)((b >> 13) & 8191u), octR = (int)(b >> 26);
+                const bool ok = live && b != 0xFFFFFFFFu && vLi >= minr && vLi < maxr1 && !(octR < levelL - 1 || octR > levelL + 1) &&
+                                (uu[t] >= minU && uu[t] <= maxU);
+                const unsigned long long m = __ballot(ok);
+                if (ok) sCand[wave][nc + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(j0 + 64 * t + lane);
+                nc += __popcll(m);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        ST(2); // table scanned
         for (int k0 = 0; k0 < nc; k0 += 64) {
             const int k = k0 + lane;
             if (k < nc) {
@@ -2982,6 +3013,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
+    ST(3); // candidates scored, best found
     float outU = -1.0f, outD = -1.0f;
     int outS = -1;
     const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 20);
@@ -2998,18 +3030,45 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
         if (!(iniu < 0 || endu >= (float)G.w) && inside) {
             const uint8_t* PL = pyrL + G.roiOff;
             const uint8_t* PR = pyrR + G.roiOff;
+            // Round 4: the two windows (left 11 x 11, right 11 x 21) come into LDS as dwords first -- 99 loads, all in flight
+            // together -- and the 121 x 11 absolute differences read bytes from there.  (One byte load per pixel and shift,
+            // twelve per lane and round, from the pyramids in global memory: 8.5 of this wavefront's 15.5 us.)
+            {
+                const uint8_t* const rowL = PL + (size_t)(sv - w) * G.pitch + (su - w);
+                const uint8_t* const rowR = PR + (size_t)(sv - w) * G.pitch + (sr - Lw - w);
+                uint32_t v0 = 0, v1 = 0;
+                { // item i < 66: right window, row i / 6, dword i % 6; item 66 + j: left window, row j / 3, dword j % 3
+                    const int r = lane / 6, c = lane - 6 * r; // (lanes 0..63: right items 0..63)
+                    __builtin_memcpy(&v0, rowR + (size_t)r * G.pitch + 4 * c, 4);
+                    const int i = 64 + lane;
+                    if (i < 66) {
+                        __builtin_memcpy(&v1, rowR + (size_t)10 * G.pitch + 4 * (i - 60), 4);
+                    } else if (i < 99) {
+                        const int j = i - 66, rl = j / 3, cl = j - 3 * rl;
+                        __builtin_memcpy(&v1, rowL + (size_t)rl * G.pitch + 4 * cl, 4);
+                    }
+                    sWinR[wave][lane] = v0;
+                    if (i < 66) sWinR[wave][i] = v1;
+                    else if (i < 99) sWinL[wave][i - 66] = v1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint8_t* const wL = reinterpret_cast<const uint8_t*>(sWinL[wave]); // pitch 12
+            const uint8_t* const wR = reinterpret_cast<const uint8_t*>(sWinR[wave]); // pitch 24
             int sad[11];
 #pragma unroll
             for (int k = 0; k < 11; k++) sad[k] = 0;
             for (int p = lane; p < 121; p += 64) {
-                const int dy = p / 11 - w, dx = p - (p / 11) * 11 - w;
-                const int vl = PL[(size_t)(sv + dy) * G.pitch + su + dx];
-                const uint8_t* rr = PR + (size_t)(sv + dy) * G.pitch + sr + dx;
+                const int dyi = p / 11, dxi = p - dyi * 11;
+                const int vl = wL[dyi * 12 + dxi];
+                const uint8_t* rr = wR + dyi * 24 + dxi; // column sr + dx + (k - Lw) of the level = window column dxi + k
 #pragma unroll
-                for (int k = 0; k < 11; k++) sad[k] += abs(vl - (int)rr[k - Lw]);
+                for (int k = 0; k < 11; k++) sad[k] += abs(vl - (int)rr[k]);
             }
 #pragma unroll
             for (int k = 0; k < 11; k++) sad[k] = wave_sum_i32(sad[k]); // (DPP + v_readlane: no LDS round trips)
+            ST(4); // SAD windows loaded and summed
             int bestS = 0x7fffffff, bestinc = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++)
@@ -3049,5 +3108,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
         depth[iL] = outD;
         sadOut[iL] = outS;
     }
+    ST(5); // results stored
     wg_done(done, &wgCnt);
+    ST_END();
 }

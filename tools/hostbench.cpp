@@ -845,6 +845,15 @@ int main(int argc, char** argv)
                     if (r >= 0) lat4.push_back(now_s() - a);
                 }
                 sStereoFP = stat_of(lat4);
+                if (auto stt = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "orbfe_debug_stereo_times")) { // (-DORBFE_STEREO_TIMING library)
+                    unsigned long long t[8];
+                    const int sr = stt(t);
+                    if (sr != 0 || !t[7]) fprintf(stderr, "K-STEREO timing: rc %d, wavefronts %llu\n", sr, t[7]);
+                    if (sr == 0 && t[7])
+                        fprintf(stderr, "K-STEREO, mean over %llu wavefronts (us since a wavefront's start): table staged %.2f  scanned %.2f  scored %.2f  "
+                                        "SAD summed %.2f  stored %.2f\n",
+                                t[7], t[1] * 0.01 / t[7], t[2] * 0.01 / t[7], t[3] * 0.01 / t[7], t[4] * 0.01 / t[7], t[5] * 0.01 / t[7]);
+                }
                 (void)orbfe_host_unregister(frames.data());
                 (void)orbfe_host_unregister(right.data());
             }
