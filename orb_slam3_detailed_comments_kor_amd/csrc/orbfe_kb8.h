@@ -6,6 +6,19 @@
  */
 #ifndef ORBFE_KB8_H
 #define ORBFE_KB8_H
+#ifdef ORBFE_KB8_TIMING // tuning only: where a thread of the triangulation spends its time (sums over threads, 100-MHz ticks)
+static __device__ unsigned long long g_kb8Times[8];
+#define KT_BEGIN() unsigned long long ktPrev = (unsigned long long)wall_clock64()
+#define KT(k)                                                              \
+    do {                                                                   \
+        const unsigned long long n_ = (unsigned long long)wall_clock64();  \
+        atomicAdd(&g_kb8Times[k], n_ - ktPrev);                            \
+        ktPrev = n_;                                                       \
+    } while (0)
+#else
+#define KT_BEGIN() do { } while (0)
+#define KT(k) do { } while (0)
+#endif
 __device__ __forceinline__ void orbfe_kb8_unproject_dev(const float* __restrict__ P, float u, float v, float* ray)
 {
     const float pwx = __fdiv_rn(__fsub_rn(u, P[2]), P[0]);
@@ -169,8 +182,10 @@ __device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, 
                                                   float* p3D = nullptr)
 {
     float r1[3], r2[3], r21[3];
+    KT_BEGIN();
     orbfe_kb8_unproject_dev(P1, k1x, k1y, r1);
     orbfe_kb8_unproject_dev(P2, k2x, k2y, r2);
+    KT(0); // two unprojections
     for (int i = 0; i < 3; i++) {
         float s = 0.f;
         for (int k = 0; k < 3; k++) s = __fadd_rn(s, __fmul_rn(R12[i * 3 + k], r2[k]));
@@ -204,7 +219,9 @@ __device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, 
         A[3 * 4 + k] = __fsub_rn(__fmul_rn(r2[1], T2[8 + k]), T2[4 + k]);
     }
     float h[4];
+    KT(1); // parallax, A
     orbfe_svd4_last_vt(A, h);
+    KT(2); // SVD
     const float inv = __fdiv_rn(1.f, h[3]);
     const float X[3] = {__fmul_rn(h[0], inv), __fmul_rn(h[1], inv), __fmul_rn(h[2], inv)};
     const float z1 = X[2];
@@ -227,6 +244,7 @@ __device__ inline float orbfe_kb8_triangulate_dev(const float* __restrict__ P1, 
     orbfe_kb8_project_dev(P2, X2[0], X2[1], X2[2], &u2, &v2);
     const float ex2 = __fsub_rn(u2, k2x), ey2 = __fsub_rn(v2, k2y);
     if ((double)__fadd_rn(__fmul_rn(ex2, ex2), __fmul_rn(ey2, ey2)) > __dmul_rn(5.991, (double)unc)) return -1.f;
+    KT(3); // two projections
     if (p3D) {
         p3D[0] = X[0];
         p3D[1] = X[1];

@@ -4496,6 +4496,12 @@ int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t
 
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
 void orbfe_matcher_time_kernels(int on) { g_timeKernels = on != 0; }
+#ifdef ORBFE_KB8_TIMING
+extern "C" int orbfe_debug_kb8_times(unsigned long long* out8)
+{
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_kb8Times), sizeof(g_kb8Times)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef ORBFE_PROJ_TIMING
 extern "C" int orbfe_debug_proj_times(unsigned long long* out16)
 {
