@@ -155,3 +155,132 @@ def test_matcher_latency_paths_in_their_other_forms():
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, str(env) + r.stdout[-1500:] + r.stderr[-1500:]
         assert " passed" in r.stdout and "failed" not in r.stdout, str(env) + r.stdout[-500:]
+
+
+def test_three_threads_search_shared_handles_while_handles_come_and_go(pkg, oracle):
+    """ORB-SLAM3 calls ORBmatcher from Tracking, LocalMapping and LoopClosing at once (src/Tracking.cc:2817-2927,
+    src/LocalMapping.cc:556-621, src/LoopClosing.cc:470-520).  Three host threads here: projection + BoW searches against a
+    resident frame and shared keyframes, the triangulation batch against the same keyframes, and a third that creates and
+    destroys keyframe / frame handles (so that pooled device blocks change hands) between KF-KF searches.  Every thread has
+    its own staging, completion word and stream; every answer must equal what the same call gave alone (checked against the
+    oracle first)."""
+    import threading
+    from matcher_inputs import projection_problem
+    from orb_slam3_detailed_comments_kor_amd import synth
+    I0 = MI.tri_inputs(1000, 800, 60)
+    rng = np.random.default_rng(91)
+    fv1 = I0["fv1"]
+    cur = pkg.KeyFrameHandle(I0["d1"], I0["has1"], I0["a1"], fv1, kp_xy=I0["kp1"], octave=I0["oct1"], uRight=I0["u1"])
+    neigh, sets = [], []
+    for k in range(6):
+        n2 = 700 + 50 * k
+        d2, origin = _noisy_copy(I0["d1"], n2, 900 + k)
+        src = np.maximum(origin, 0)
+        kp2 = np.stack([rng.uniform(20, 730, n2), np.where(origin >= 0, I0["kp1"][src, 1] + rng.normal(0, 0.7, n2),
+                                                           rng.uniform(20, 460, n2))], 1).astype(np.float32)
+        a2 = np.where(origin >= 0, I0["a1"][src] + rng.normal(0, 3, n2), rng.uniform(0, 360, n2)).astype(np.float32) % 360
+        oct2 = rng.integers(0, 8, n2).astype(np.int32)
+        u2 = np.where(rng.uniform(size=n2) < 0.3, rng.uniform(0, 700, n2), -1).astype(np.float32)
+        has2 = (rng.uniform(size=n2) < 0.5).astype(np.uint8)
+        fv2 = synth.make_feature_vectors(d2, 61, 5, 2)
+        h = pkg.KeyFrameHandle(d2, has2, a2, fv2, kp_xy=kp2, octave=oct2, uRight=u2)
+        neigh.append(dict(kf=h, F12=I0["F12"] * np.float32(1.0 + 0.01 * k), ep=(880.0 - 10 * k, 250.0), sf=I0["sf"], sig=I0["sig"],
+                          only_stereo=(k == 4), coarse=(k == 3), check_ori=(k != 2)))
+        sets.append((d2, has2, a2, fv2))
+    base = projection_problem(801, n=1500, nq=10, mode=1, stereo=True, check_orientation=True)
+    fr = pkg.ProjectionFrame(base)
+    pq = []
+    for k, kw in enumerate((dict(mode=1, th=7.0, check_orientation=True), dict(mode=0, th=3.0, nnratio=0.9))):
+        q = projection_problem(810 + k, n=1500, nq=700, stereo=True, **kw)
+        pr = dict(base)
+        for key, v in q.items():
+            if key.startswith("q") or key in ("mode", "nnratio", "th_high", "check_orientation", "taken", "chi2_gate", "inv_level_sigma2"):
+                pr[key] = v
+        tgt = np.random.default_rng(820 + k).integers(0, 1500, 700)
+        pr["qx"] = (base["kx"][tgt] + np.random.default_rng(830 + k).normal(0, 2, 700)).astype(np.float32)
+        pr["qy"] = (base["ky"][tgt] + np.random.default_rng(840 + k).normal(0, 2, 700)).astype(np.float32)
+        bits = np.unpackbits(base["desc"][tgt], axis=1)
+        pr["qdesc"] = np.packbits(bits ^ (np.random.default_rng(850 + k).random(bits.shape) < 0.1), axis=1)
+        if "qxr" in pr:
+            pr["qxr"] = np.where(base["uright"][tgt] > 0, base["uright"][tgt] + 1.0, pr["qx"] - 10).astype(np.float32)
+        pq.append(pr)
+    # what each call gives alone (and the oracle's word on it)
+    wantP = [fr.search(pr) for pr in pq]
+    for pr, w in zip(pq, wantP):
+        ref = oracle.search_projection(pr)
+        assert ref[0] == w[0] and np.array_equal(ref[1], w[1]) and np.array_equal(ref[2], w[2])
+    bowProbs = [dict(kf1=neigh[k]["kf"], kf2=cur, variant=1, nnratio=0.8, check_ori=True) for k in range(6)]
+    wantB = pkg.search_bow_keyframes(bowProbs)
+    for k in range(6):
+        d2, has2, a2, fv2 = sets[k]
+        rn, rm = oracle.search_bow_kf_kf(d2, has2, a2, fv2, I0["d1"], I0["has1"], I0["a1"], fv1, -1, -1, 0.8, True)
+        assert wantB[k][0] == rn and np.array_equal(wantB[k][1], rm), k
+    wantT = pkg.search_tri_batch(cur, neigh)
+    wantT1 = [pkg.search_tri_batch(cur, [q])[0] for q in neigh]
+    for a, b in zip(wantT, wantT1):
+        assert np.array_equal(a, b)
+
+    bad, stop = [], threading.Event()
+
+    def guard(fn):
+        def run():
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001 (reported below)
+                bad.append(repr(e))
+                stop.set()
+        return run
+
+    ROUNDS = 500
+
+    def tracking():
+        for it in range(ROUNDS):
+            if stop.is_set():
+                return
+            for pr, w in zip(pq, wantP):
+                g = fr.search(pr)
+                if g[0] != w[0] or not np.array_equal(g[1], w[1]) or not np.array_equal(g[2], w[2]):
+                    bad.append("projection differs in round %d" % it)
+            k = it % 6
+            g = pkg.search_bow_keyframes([bowProbs[k]])[0]
+            if g[0] != wantB[k][0] or not np.array_equal(g[1], wantB[k][1]):
+                bad.append("BoW differs in round %d" % it)
+
+    def mapping():
+        for it in range(ROUNDS):
+            if stop.is_set():
+                return
+            g = pkg.search_tri_batch(cur, neigh) if it % 2 == 0 else [pkg.search_tri_batch(cur, [neigh[it % 6]])[0]]
+            w = wantT if it % 2 == 0 else [wantT1[it % 6]]
+            if len(g) != len(w) or any(not np.array_equal(a, b) for a, b in zip(g, w)):
+                bad.append("triangulation differs in round %d" % it)
+
+    def closing():
+        for it in range(ROUNDS):
+            if stop.is_set():
+                return
+            k = it % 6
+            d2, has2, a2, fv2 = sets[k]
+            h = pkg.KeyFrameHandle(d2, has2, a2, fv2)                 # a block from the pool ...
+            f2 = pkg.ProjectionFrame(base)
+            g = pkg.search_bow_keyframes([dict(kf1=h, kf2=cur, variant=1, nnratio=0.8, check_ori=True)])[0]
+            gp = f2.search(pq[it % 2])
+            h.close()                                                 # ... and back
+            f2.close()
+            if g[0] != wantB[k][0] or not np.array_equal(g[1], wantB[k][1]):
+                bad.append("BoW on a fresh handle differs in round %d" % it)
+            w = wantP[it % 2]
+            if gp[0] != w[0] or not np.array_equal(gp[1], w[1]) or not np.array_equal(gp[2], w[2]):
+                bad.append("projection on a fresh frame differs in round %d" % it)
+
+    ts = [threading.Thread(target=guard(f)) for f in (tracking, mapping, closing)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in ts), "a thread hangs"
+    assert not bad, bad[:5]
+    fr.close()
+    cur.close()
+    for q in neigh:
+        q["kf"].close()
