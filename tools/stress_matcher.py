@@ -12,8 +12,10 @@ import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
 import orb_oracle_py as O  # noqa: E402
 import matcher_inputs as MI  # noqa: E402
 
-def run(ncases=60, seed=3, scale=1.0, log=print):
-    """Returns the list of mismatch descriptions.  scale < 1 shrinks the random problem sizes (test-suite slice)."""
+def run(ncases=60, seed=3, scale=1.0, log=print, kinds=10):
+    """Returns the list of mismatch descriptions.  scale < 1 shrinks the random problem sizes (test-suite slice).
+    kinds = 6: the one-shot entry points only; 10: also the resident forms (keyframe / frame handles, the triangulation
+    batch) and the stereo pair in one call."""
     O.build()
     rng = np.random.default_rng(seed)
     bad = []
@@ -22,7 +24,7 @@ def run(ncases=60, seed=3, scale=1.0, log=print):
         return int(rng.integers(lo, max(lo + 1, int(lo + (hi - lo) * scale))))
 
     for case in range(ncases):
-        kind = case % 6
+        kind = case % kinds
         seed = int(rng.integers(0, 1 << 30))
         ok = True
         desc = ""
@@ -80,6 +82,104 @@ def run(ncases=60, seed=3, scale=1.0, log=print):
             a, b = O.search_triangulation(*args), pkg.search_triangulation(*args)
             ok = np.array_equal(a, b)
             desc = "tri n1=%d n2=%d stereo=%s coarse=%s -> %d" % (n1, n2, os_, co, len(a))
+        elif kind == 6:  # SearchByBoW with one or both sides in keyframe handles
+            n1, n2 = size(30, 2000), size(30, 2000)
+            d1, d2, a1, a2 = MI.descriptor_sets(n1, n2, seed % 100000)
+            fv1, fv2 = MI.feature_vectors(d1, d2, seed % 1000, int(rng.integers(3, 11)), 2)
+            m1 = (rng.uniform(size=n1) < 0.6).astype(np.uint8)
+            m2 = (rng.uniform(size=n2) < 0.6).astype(np.uint8)
+            ori = bool(rng.integers(0, 2))
+            ratio = float(rng.choice([0.6, 0.7, 0.9]))
+            h1, h2 = pkg.KeyFrameHandle(d1, m1, a1, fv1), pkg.KeyFrameHandle(d2, m2, a2, fv2)
+            a = O.search_bow_kf_f(d1, m1, a1, fv1, d2, a2, fv2, -1, ratio, ori)
+            c = O.search_bow_kf_kf(d1, m1, a1, fv1, d2, m2, a2, fv2, -1, -1, ratio, ori)
+            b, d = pkg.search_bow_keyframes([dict(kf1=h1, desc2=d2, ang2=a2, fv2=fv2, variant=0, nnratio=ratio, check_ori=ori),
+                                             dict(kf1=h1, kf2=h2, variant=1, nnratio=ratio, check_ori=ori)])
+            h1.close()
+            h2.close()
+            ok = a[0] == b[0] and np.array_equal(a[1], b[1]) and c[0] == d[0] and np.array_equal(c[1], d[1])
+            desc = "bow handles n1=%d n2=%d -> %d / %d" % (n1, n2, a[0], c[0])
+        elif kind == 7:  # SearchForTriangulation_ of one keyframe against several neighbours in one launch
+            n1 = size(50, 1500)
+            cnt = int(rng.integers(1, 9))
+            I0 = MI.tri_inputs(n1, 60, seed % 100000)
+            cur = pkg.KeyFrameHandle(I0["d1"], I0["has1"], I0["a1"], I0["fv1"], kp_xy=I0["kp1"], octave=I0["oct1"], uRight=I0["u1"])
+            neigh, want = [], []
+            for k in range(cnt):
+                I = MI.tri_inputs(n1, size(50, 1500), seed % 100000)  # (the same set 1 and vocabulary: same seed)
+                flags = dict(only_stereo=bool(rng.integers(0, 2)), coarse=bool(rng.integers(0, 2)), check_ori=bool(rng.integers(0, 2)))
+                F12 = (I["F12"] * np.float32(1.0 + 0.01 * k)).astype(np.float32)
+                h = pkg.KeyFrameHandle(I["d2"], I["has2"], I["a2"], I["fv2"], kp_xy=I["kp2"], octave=I["oct2"], uRight=I["u2"])
+                neigh.append(dict(kf=h, F12=F12, ep=I["ep"], sf=I["sf"], sig=I["sig"], **flags))
+                want.append(O.search_triangulation(I0["d1"], I0["has1"], I0["kp1"], I0["a1"], I0["oct1"], I0["u1"], I0["fv1"], I["d2"],
+                                                   I["has2"], I["kp2"], I["a2"], I["oct2"], I["u2"], I["fv2"], F12, I["ep"], I["sf"],
+                                                   I["sig"], flags["only_stereo"], flags["coarse"], flags["check_ori"]))
+            got = pkg.search_tri_batch(cur, neigh)
+            cur.close()
+            for q in neigh:
+                q["kf"].close()
+            ok = len(got) == cnt and all(np.array_equal(g, w) for g, w in zip(got, want))
+            desc = "tri batch n1=%d x %d -> %s" % (n1, cnt, [len(w) for w in want])
+        elif kind == 8:  # projection searches against a resident frame, several calls on one handle
+            n = size(50, 2500)
+            base = MI.projection_problem(seed, n=n, nq=5, mode=1, stereo=bool(rng.integers(0, 2)), check_orientation=True)
+            fr = pkg.ProjectionFrame(base)
+            ok, outs = True, []
+            for rep in range(3):
+                mode = int(rng.integers(0, 2))
+                nq = size(1, 2000)
+                q = MI.projection_problem(seed + 1 + rep, n=n, nq=nq, mode=mode, stereo="uright" in base and base["uright"] is not None,
+                                          th=float(rng.choice([1.0, 3.0, 7.0, 15.0])), check_orientation=bool(mode and rng.integers(0, 2)),
+                                          nnratio=float(rng.choice([0.6, 0.8, 0.9])), taken_frac=float(rng.uniform(0, 0.4)))
+                pr = dict(base)
+                for key, v in q.items():
+                    if key.startswith("q") or key in ("mode", "nnratio", "th_high", "check_orientation", "taken", "chi2_gate", "inv_level_sigma2"):
+                        pr[key] = v
+                tgt = rng.integers(0, n, nq)
+                pr["qx"] = (base["kx"][tgt] + rng.normal(0, 2, nq)).astype(np.float32)
+                pr["qy"] = (base["ky"][tgt] + rng.normal(0, 2, nq)).astype(np.float32)
+                bits = np.unpackbits(base["desc"][tgt], axis=1)
+                pr["qdesc"] = np.packbits(bits ^ (rng.random(bits.shape) < 0.1), axis=1)
+                if pr.get("qxr") is not None and base.get("uright") is not None:
+                    pr["qxr"] = np.where(base["uright"][tgt] > 0, base["uright"][tgt] + 1.0, pr["qx"] - 10).astype(np.float32)
+                a, b = O.search_projection(pr), fr.search(pr)
+                ok = ok and a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+                outs.append(a[0])
+            fr.close()
+            desc = "proj frame n=%d -> %s" % (n, outs)
+        elif kind == 9:  # a stereo pair in one call: both extractions + Frame::ComputeStereoMatches
+            from orb_slam3_detailed_comments_kor_amd import synth
+            h, w = int(rng.integers(200, 520)), int(rng.integers(320, 800))
+            nf = int(rng.choice([300, 800, 1200, 2000]))
+            shift = int(rng.integers(0, 70))
+            left, right = synth.make_stereo_pair(h, w, seed % 100000, shift=min(shift, w // 4))
+            if rng.random() < 0.3:  # other content on both sides
+                kind_ = str(rng.choice(["blurred", "plateaus", "checker2", "sinus", "ramp", "mixed"]))
+                left = synth.make_frame_kind(h, w, seed % 100000, kind_)
+                right = np.ascontiguousarray(np.roll(left, -min(shift, w // 4), axis=1))
+            mbf = float(rng.choice([47.90639384423901, 20.0, 120.0]))
+            mb = mbf / float(rng.choice([435.2046959714599, 300.0, 700.0]))
+            ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+            oL, oR = O.Extractor(nf, 1.2, 8, 20, 7), O.Extractor(nf, 1.2, 8, 20, 7)
+            try:
+                rL, rR = oL.extract(left, (0, 0)), oR.extract(right, (0, 0))
+            except Exception as e:  # noqa: BLE001 (geometry the oracle refuses: the library must refuse it too)
+                rL = None
+                why = repr(e)
+            if rL is None:
+                try:
+                    pkg.binding.extract_stereo_pair(ex, left, right, mb, mbf)
+                    ok = False
+                except pkg.OrbfeError:
+                    ok = True
+                desc = "stereo pair %dx%d refused (%s)" % (h, w, why[:40])
+            else:
+                rn, ruR, rdep = O.compute_stereo_matches(oL, oR, rL[1], rL[2], rR[1], rR[2], mb, mbf)
+                m, gL, gR, uR, dep = pkg.binding.extract_stereo_pair(ex, left, right, mb, mbf)
+                ok = (m == rn and gL[0] == rL[0] and gR[0] == rR[0] and np.array_equal(gL[1], rL[1]) and np.array_equal(gL[2], rL[2])
+                      and np.array_equal(gR[1], rR[1]) and np.array_equal(gR[2], rR[2]) and np.array_equal(uR, ruR) and np.array_equal(dep, rdep))
+                desc = "stereo pair %dx%d nF=%d shift=%d -> %d kp, %d matches" % (h, w, nf, shift, len(rL[1]), rn)
+            ex.close()
         else:            # knn-2 and all-pairs distances, ragged sizes
             nq, nt = size(1, 1800), size(1, 1800)
             Q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
@@ -95,6 +195,7 @@ def run(ncases=60, seed=3, scale=1.0, log=print):
 
 
 if __name__ == "__main__":
-    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 3,
+              log=(lambda *a: None) if os.environ.get("STRESS_QUIET") else print)
     print("mismatches:", len(bad))
     sys.exit(1 if bad else 0)
