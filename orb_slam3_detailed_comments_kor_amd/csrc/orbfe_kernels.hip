@@ -1357,13 +1357,30 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             return candImg[gbase[lo] + (i - gscan[lo])];
         };
         if (regp) {
-            qt_each_key(true, tot, [&](auto J, int i) {
-                constexpr int j = decltype(J)::value;
+            // the thread's four searches side by side: fixed steps 256 .. 1 (nc <= QT_THREADS = 512), the four LDS reads of a
+            // step independent of each other -- 9 LDS latencies in a row instead of 36 (four while-loops one after the other)
+            static_assert(QT_KPT == 4 && QT_THREADS <= 512, "the interleaved search covers 512 cells and four keys per thread");
+            int lo4[QT_KPT] = {0, 0, 0, 0};
+#pragma unroll
+            for (int step = 256; step >= 1; step >>= 1) {
+                int m[QT_KPT], pv[QT_KPT];
+#pragma unroll
+                for (int j = 0; j < QT_KPT; j++) {
+                    m[j] = lo4[j] + step;
+                    pv[j] = gscan[min(m[j], nc - 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < QT_KPT; j++)
+                    if (m[j] < nc && pv[j] <= tid + j * QT_THREADS) lo4[j] = m[j];
+            }
+#pragma unroll
+            for (int j = 0; j < QT_KPT; j++) {
+                const int i = tid + j * QT_THREADS;
                 if (i < tot) {
-                    kReg[j] = fetch(i);
+                    kReg[j] = candImg[gbase[lo4[j]] + (i - gscan[lo4[j]])];
                     keys[i] = kReg[j]; // the retained key of a node is looked up by index at the end
                 }
-            });
+            }
         } else {
             for (int i = tid; i < tot; i += QT_THREADS) keys[n + i] = fetch(i);
         }
@@ -1449,7 +1466,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                     if (kids >= 2) flags |= 2 << d;
                 }
             }
-            if (flags) atomicOr(&misc[1], flags);
+            // (one LDS atomic per wavefront: with a value per lane on one address the compiler's atomic optimizer emits a
+            // scalar loop over the active lanes -- 1.0 of this kernel's 17 us for a single frame, tools/qt_times.py)
+            flags |= __builtin_amdgcn_mov_dpp(flags, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+            flags |= __builtin_amdgcn_mov_dpp(flags, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+            flags |= __builtin_amdgcn_mov_dpp(flags, 0x141, 0xF, 0xF, true); // row_half_mirror
+            flags |= __builtin_amdgcn_mov_dpp(flags, 0x140, 0xF, 0xF, true); // row_mirror
+            flags = __builtin_amdgcn_readlane(flags, 0) | __builtin_amdgcn_readlane(flags, 16) | __builtin_amdgcn_readlane(flags, 32) |
+                    __builtin_amdgcn_readlane(flags, 48);
+            QT_STAMP(12);
+            if (lane == 0 && flags) atomicOr(&misc[1], flags);
+            QT_STAMP(13);
         }
         __syncthreads();
         QT_STAMP(11);
@@ -1648,17 +1675,67 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 const int* mcur = multi(cur);
                 // rank of candidate t in descending (count, creation index) order
                 for (int p = tid; p < size; p += QT_THREADS) kOf[p] = -1;
-                for (int t = tid; t < m; t += QT_THREADS) gpre[t] = nodeCnt(cur)[mcur[t]];
+                // (count and creation index in one word where they fit: the rank below is then one comparison per pair)
+                const bool packedRank = m <= 8 * 64 && n < 65536; // (uniform)
+                for (int t = tid; t < m; t += QT_THREADS) gpre[t] = packedRank ? (nodeCnt(cur)[mcur[t]] << 16) | t : nodeCnt(cur)[mcur[t]];
                 for (int i = tid; i < 4 * m; i += QT_THREADS) cc[i] = 0;
                 for (int t = tid; t < m; t += QT_THREADS) sidx[t] = 0; // rank accumulators (sidx is rebuilt below)
                 if (tid == 0) misc[0] = m;
                 __syncthreads();
                 if (stampF == 43) QT_STAMP(20);
+#ifdef ORBFE_QT_TIMING
+                if (stampF == 43 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qtTimes[61] = ((unsigned long long)m << 32) | (unsigned)size;
+#endif
                 // rank = number of candidates ahead in (count descending, creation index descending) order.  All
                 // eight wavefronts work on it: wavefront w compares every candidate t with its own slice of the
                 // j range and adds the partial count (the plain loop -- one thread per t over all j, each LDS read
                 // waited for -- took 4.4 of this kernel's 31 us at ~120 candidates).
-                {
+                if (packedRank) {
+                    // the wavefront's slice of j sits in one register (lane l: key of j0 + l), the candidates t it is compared
+                    // with in up to eight more; per j one v_readlane and, per 64 candidates, a compare and an add-with-carry --
+                    // no LDS read inside the loop (the form below: 1.4 us of this kernel's 16 for a single frame, this one 0.5)
+                    const int per = (m + QT_WAVES - 1) / QT_WAVES; // <= 64
+                    const int j0 = wave * per, nj = min(m, j0 + per) - j0;
+                    const unsigned mine = lane < nj ? (unsigned)gpre[j0 + lane] : 0u; // (0 is ahead of nobody: keys are >= 2 << 16)
+                    // (one instantiation per number of 64-candidate groups: no test inside the loop)
+                    auto rank_groups = [&](auto UC) {
+                        constexpr int U = decltype(UC)::value;
+                        unsigned tk[U];
+                        int part[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            tk[u] = lane + 64 * u < m ? (unsigned)gpre[lane + 64 * u] : 0xFFFFFFFFu;
+                            part[u] = 0;
+                        }
+                        if (stampF == 43) QT_STAMP(14);
+                        // (four j per step, independent of each other; the lanes past the slice hold 0, which is ahead of nobody)
+                        const int njU = __builtin_amdgcn_readfirstlane(nj);
+                        for (int l = 0; l < njU; l += 4) {
+                            const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)mine, l),
+                                           k1 = (unsigned)__builtin_amdgcn_readlane((int)mine, l + 1),
+                                           k2 = (unsigned)__builtin_amdgcn_readlane((int)mine, l + 2),
+                                           k3 = (unsigned)__builtin_amdgcn_readlane((int)mine, l + 3);
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+                                part[u] += (k0 > tk[u] ? 1 : 0) + (k1 > tk[u] ? 1 : 0) + (k2 > tk[u] ? 1 : 0) + (k3 > tk[u] ? 1 : 0);
+                        }
+                        if (stampF == 43) QT_STAMP(15);
+#pragma unroll
+                        for (int u = 0; u < U; u++)
+                            if (lane + 64 * u < m && part[u]) atomicAdd(&sidx[lane + 64 * u], part[u]);
+                        if (stampF == 43) QT_STAMP(16);
+                    };
+                    switch ((m + 63) >> 6) { // (uniform)
+                    case 1: rank_groups(std::integral_constant<int, 1>()); break;
+                    case 2: rank_groups(std::integral_constant<int, 2>()); break;
+                    case 3: rank_groups(std::integral_constant<int, 3>()); break;
+                    case 4: rank_groups(std::integral_constant<int, 4>()); break;
+                    case 5: rank_groups(std::integral_constant<int, 5>()); break;
+                    case 6: rank_groups(std::integral_constant<int, 6>()); break;
+                    case 7: rank_groups(std::integral_constant<int, 7>()); break;
+                    default: rank_groups(std::integral_constant<int, 8>()); break;
+                    }
+                } else {
                     const int per = (m + QT_WAVES - 1) / QT_WAVES;
                     const int j0 = wave * per, j1 = min(m, j0 + per);
                     for (int t = lane; t < m; t += 64) {
@@ -1777,6 +1854,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 pre[p] = flag | (all ? (uint32_t)p : 0u);
             }
             run = all ? nout : 0;
+            QT_STAMP(28);
         } else
         for (int base = 0; base < nout; base += QT_THREADS, buf ^= 1) { // (uniform trip count; one barrier per round)
             const int p = base + tid;
@@ -1801,6 +1879,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             if (p < nout) pre[p] = 0x10000u | (st ? 0x8000u : 0u) | (uint32_t)(before + __popcll(m & ((1ull << lane) - 1ull)));
         }
         for (int p = nout + tid; p < L.kpCap; p += QT_THREADS) pre[p] = 0u;
+        QT_STAMP(29);
         if (tid == 0) lvlCount[(size_t)img * ORBFE_MAX_LEVELS + level] = nout | (run << 16);
     }
     QT_STAMP(60);

@@ -98,6 +98,18 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
                    c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
     return min(min(a, b), min(c, d));
 }
+// Sum over the 64 lanes (all active) with DPP and four v_readlane; the result is wave-uniform.  For counters: `atomicAdd(&word,
+// perLaneValue)` on one address makes the compiler's atomic optimizer emit a scalar loop over the active lanes (~1 us per
+// wavefront); one lane adding the wavefront's sum does not.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); // row_mirror: every lane holds its row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
 // the two smallest keys of the wavefront (keys of different lanes are distinct, or the sentinel 0xFFFFFFFF): on return k0 <= k1
 // hold them in every lane
 __device__ __forceinline__ void wave_two_min(unsigned& k0, unsigned& k1)
@@ -1914,7 +1926,8 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
                 cnt++;
             }
         }
-        if (cnt) atomicAdd(&sCnt, cnt);
+        cnt = wave_sum_i32(cnt);
+        if ((tid & 63) == 0 && cnt) atomicAdd(&sCnt, cnt);
         __syncthreads();
         PT(4); // final
         for (int i = tid; i < n; i += PROJ_THREADS) P.mirror[4 + nq + i] = fm[i];
@@ -1950,7 +1963,8 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
             cnt++;
         }
     }
-    if (cnt) atomicAdd(&P.status[0], cnt);
+    cnt = wave_sum_i32(cnt);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&P.status[0], cnt);
     PT(4); // final
     if (P.mirror) { // (uniform) the sweeps' tables did not fit LDS: results built in device memory, then copied
         __threadfence();
