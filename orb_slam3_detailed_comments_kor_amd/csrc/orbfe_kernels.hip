@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 if (packedRank) {
                     // the wavefront's slice of j sits in one register (lane l: key of j0 + l), the candidates t it is compared
                     // with in up to eight more; per j one v_readlane and, per 64 candidates, a compare and an add-with-carry --
-                    // no LDS read inside the loop (the form below: 1.4 us of this kernel's 16 for a single frame, this one 0.5)
+                    // no LDS read inside the loop (the form below: 1.4 us of this kernel's 16 for a single frame, this one 1.05)
                     const int per = (m + QT_WAVES - 1) / QT_WAVES; // <= 64
                     const int j0 = wave * per, nj = min(m, j0 + per) - j0;
                     const unsigned mine = lane < nj ? (unsigned)gpre[j0 + lane] : 0u; // (0 is ahead of nobody: keys are >= 2 << 16)
