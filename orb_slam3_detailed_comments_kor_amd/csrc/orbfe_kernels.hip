@@ -1302,6 +1302,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     const int32_t* cnts = cellCount + (size_t)img * nCellsTotal + L.cellBase;
     const OrbCellGeom* cells = cg + L.cellBase;
 
+    // (`keys` may point into LDS or into the global scratch, so the compiler reaches it with flat instructions; the two
+    // accesses every level makes -- the gather's store and the retained key's look-up at the end -- go through keysL, the same
+    // LDS words addressed as LDS, when keysInLds says so)
+    uint32_t* const keysL = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
+    bool keysInLds = false; // (uniform)
     // Every pass walks the key arrays twice; keep them in LDS when the level's candidates fit (the
     // usual case), else in the global scratch arrays.  (Generic pointers: flat loads serve both.)
     // A level of up to QT_THREADS cells (every level of a 752x480 frame) learns its total from the gather's own
@@ -1320,6 +1325,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         if (total <= keyLdsCap) {
             keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
             keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
+            keysInLds = true;
         }
     }
 
@@ -1345,6 +1351,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         if (oneChunk && tot <= keyLdsCap) {       // (uniform) the key arrays do not overlap gscan / gbase
             keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
             keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
+            keysInLds = true;
         }
         regp = oneChunk && tot <= QT_KPT * QT_THREADS; // (uniform)
         auto fetch = [&](int i) -> uint32_t {
@@ -1378,7 +1385,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 const int i = tid + j * QT_THREADS;
                 if (i < tot) {
                     kReg[j] = candImg[gbase[lo4[j]] + (i - gscan[lo4[j]])];
-                    keys[i] = kReg[j]; // the retained key of a node is looked up by index at the end
+                    if (keysInLds) keysL[i] = kReg[j]; // the retained key of a node is looked up by index at the end
+                    else keys[i] = kReg[j];
                 }
             }
         } else {
@@ -1847,10 +1855,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         // every keypoint of an image up to 1000 px wide
         const float sxMax = __fmul_rn((float)L.w, scale); // >= every keypoint's level-0 x (rounding is monotonic)
         const bool none = !(lap1 >= (float)ORBFE_MINB) || lap0 > lap1, all = !none && lap0 <= (float)ORBFE_MINB && lap1 >= sxMax;
+        QT_STAMP(17);
         if (none || all) {
             const uint32_t flag = all ? 0x18000u : 0x10000u;
             for (int p = tid; p < nout; p += QT_THREADS) {
-                out[p] = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+                const uint32_t at = 0xFFFFFFu - (best[p] & 0xFFFFFFu);
+                out[p] = keysInLds ? keysL[at] : keys[at];
                 pre[p] = flag | (all ? (uint32_t)p : 0u);
             }
             run = all ? nout : 0;
@@ -1860,7 +1870,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             const int p = base + tid;
             bool st = false;
             if (p < nout) {
-                const uint32_t key = keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+                const uint32_t at = 0xFFFFFFu - (best[p] & 0xFFFFFFu);
+                const uint32_t key = keysInLds ? keysL[at] : keys[at];
                 out[p] = key;
                 const float sx = __fmul_rn((float)((int)(key & 0xFFF) + ORBFE_MINB), scale); // keypoint->pt *= scale (:1131-1133)
                 st = sx >= lap0 && sx <= lap1;

@@ -29,7 +29,7 @@ t = t.astype(np.int64)
 names = {0: "start", 1: "gather done", 2: "roots done", 41: "final phase begins", 59: "tree done", 60: "output written",
          5: "(gather) counts loaded", 6: "(gather) counts scanned", 10: "(roots) keys binned", 11: "(roots) checks done", 12: "(roots) check loops", 13: "(roots) check flags merged",
          20: "(round 1) cleared", 21: "(round 1) ranks", 22: "(round 1) kOf / par", 23: "(round 1) child histogram",
-         24: "(round 1) growth scan + cut", 25: "(round 1) sidx scan", 26: "(round 1) expand", 27: "(output) best key per node", 28: "(output) keys + flags stored", 14: "(round 1) rank keys loaded", 15: "(round 1) rank loop", 16: "(round 1) rank atomics", 29: "(output) tail slots cleared"}
+         24: "(round 1) growth scan + cut", 25: "(round 1) sidx scan", 26: "(round 1) expand", 27: "(output) best key per node", 28: "(output) keys + flags stored", 17: "(output) lapping range read", 14: "(round 1) rank keys loaded", 15: "(round 1) rank loop", 16: "(round 1) rank atomics", 29: "(output) tail slots cleared"}
 print("first largest-first round: %d candidates, list size %d" % (int(t[61]) >> 32, int(t[61]) & 0xFFFFFFFF))
 t[61] = 0
 prev = t[0]
