@@ -2790,6 +2790,50 @@ void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
     }
 }
 
+// The rotation-consistency cull (:450-468) on the device for a batch whose results come back by a download command (dozens of problems: the host's two
+// passes over every problem's match array were 45 of a 64-candidate call's 180 us): a workgroup per problem builds the
+// histogram of the rotation bins of its matches, takes the three maxima, clears the matches outside them in place and leaves
+// the number kept in nm[problem].  cull_by_rotation() below is the statement it follows line by line.
+struct BowCull {
+    int outBase, n, check, pad;
+};
+__global__ __launch_bounds__(256) void k_bow_cull(const BowCull* __restrict__ C, int32_t* __restrict__ M, const int8_t* __restrict__ B,
+                                                  int32_t* __restrict__ nm)
+{
+    __shared__ int sHist[32], sInd[3], sCnt;
+    const BowCull c = C[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < 32) sHist[tid] = 0;
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    int32_t* const m = M + c.outBase;
+    const int8_t* const b = B + c.outBase;
+    int cnt = 0;
+    for (int i = tid; i < c.n; i += 256)
+        if (m[i] >= 0) {
+            cnt++;
+            const int bin = b[i];
+            if (c.check && bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&sHist[bin], 1);
+        }
+    if (c.check) {
+        __syncthreads();
+        if (tid == 0) three_maxima_dev(sHist, HISTO_LENGTH, sInd);
+        __syncthreads();
+        const int ind1 = sInd[0], ind2 = sInd[1], ind3 = sInd[2];
+        cnt = 0;
+        for (int i = tid; i < c.n; i += 256)
+            if (m[i] >= 0) {
+                const int bin = b[i];
+                if (bin == ind1 || bin == ind2 || bin == ind3) cnt++;
+                else m[i] = -1;
+            }
+    }
+    cnt = wave_sum_i32(cnt);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&sCnt, cnt);
+    __syncthreads();
+    if (tid == 0) nm[blockIdx.x] = sCnt;
+}
+
 // rotation-consistency cull (:450-468): returns the number of surviving matches
 int cull_by_rotation(int32_t* match, const int8_t* bins, int n, bool check)
 {
@@ -3006,6 +3050,29 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     int rows = 0, outTotal = 0, takenRows = 0;
     size_t indTotal = 0, ovTotal = 0;
     std::vector<long> ovOff1(count, -1), ovOff2(count, -1); // per-call flags of sets in handles: offsets into their own pool
+    // A set that is not in a handle travels with the call -- once: the problems of a call usually share one side (the current
+    // frame against every relocalisation candidate, src/Tracking.cc:3784; the current keyframe against its covisibles), and the
+    // same arrays (same pointers, same sizes) are staged and uploaded a single time (64 candidates: 1.3 MB -> 41 KB).
+    struct SeenSet {
+        const void *desc, *mask, *ang, *ind, *offs;
+        int n, nn, rowBase, indBase;
+    };
+    std::vector<SeenSet> seen;
+    std::vector<uint8_t> own1(count, 0), own2(count, 0); // this problem stages the set (first occurrence)
+    auto place_set = [&](const uint8_t* desc, int n, const uint8_t* mask, const float* ang, const orbfe_fv& fv, int& rowBase, int& indBase) -> bool {
+        for (const SeenSet& q : seen)
+            if (q.desc == desc && q.n == n && q.mask == mask && q.ang == ang && q.ind == fv.indices && q.offs == fv.offsets && q.nn == fv.nn) {
+                rowBase = q.rowBase;
+                indBase = q.indBase;
+                return false;
+            }
+        rowBase = rows;
+        indBase = (int)indTotal;
+        seen.push_back(SeenSet{desc, mask, ang, fv.indices, fv.offsets, n, fv.nn, rowBase, indBase});
+        rows += n;
+        indTotal += (size_t)(fv.nn ? fv.offsets[fv.nn] : 0);
+        return true;
+    };
     for (int p = 0; p < count; p++) {
         orbfe_bow_args& e = eff[p];
         e = args[p];
@@ -3037,12 +3104,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             return ORBFE_ERR_ARGS;
         const int nOut = a->variant == 0 ? a->n2 : a->n1;
         outN[p] = nOut;
-        for (int i = 0; i < nOut; i++) match[p][i] = -1;
         nmatches[p] = 0;
         BowProb& P = probs[p];
         std::memset(&P, 0, sizeof P);
-        P.d1Base = rows;
-        P.d2Base = rows + (K1 ? 0 : a->n1);
         P.outBase = outTotal;
         P.tBase = takenRows;
         P.limit1 = a->limit1;
@@ -3056,19 +3120,19 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         if (!a->desc1 || !a->desc2 || !a->mask1 || (a->variant == 1 && !a->mask2)) return ORBFE_ERR_ARGS;
         if (a->check_orientation && (!a->angle1 || !a->angle2)) return ORBFE_ERR_ARGS;
         active[p] = 1;
+        P.d1Base = P.d2Base = rows; // (not read for a set in a handle)
         if (K1) {
             P.rDesc1 = K1->desc; P.rMask1 = K1->mask; P.rAng1 = K1->ang; P.rInd1 = K1->ind;
         } else {
             if (is_device_ptr(a->desc1)) P.rDesc1 = a->desc1; // read where the extractor left them
-            i1Base[p] = (int)indTotal;
-            indTotal += (size_t)(a->fv1.nn ? a->fv1.offsets[a->fv1.nn] : 0);
+            own1[p] = place_set(a->desc1, a->n1, a->mask1, a->angle1, a->fv1, P.d1Base, i1Base[p]) ? 1 : 0;
         }
         if (K2) {
             P.rDesc2 = K2->desc; P.rMask2 = K2->mask; P.rAng2 = K2->ang; P.rInd2 = K2->ind;
         } else {
             if (is_device_ptr(a->desc2)) P.rDesc2 = a->desc2;
-            i2Base[p] = (int)indTotal;
-            indTotal += (size_t)(a->fv2.nn ? a->fv2.offsets[a->fv2.nn] : 0);
+            // (the flags of set 2 are all ones in variant 0: such a set and one with real flags are different sets)
+            own2[p] = place_set(a->desc2, a->n2, a->variant == 1 ? a->mask2 : nullptr, a->angle2, a->fv2, P.d2Base, i2Base[p]) ? 1 : 0;
         }
         bool bad = false;
         const int b1 = i1Base[p], b2 = i2Base[p]; // (0 for a set in a handle: its offsets are relative to its own index array)
@@ -3083,9 +3147,16 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             if (n.n1 > 0 && n.n2 > 0) nodes.push_back(n);
         });
         if (bad) return ORBFE_ERR_ARGS;
-        rows += (K1 ? 0 : a->n1) + (K2 ? 0 : a->n2);
     }
-    if (nodes.empty()) return 0;
+    // (every array is written whole at the end; the calls that end here have no match anywhere)
+    auto none = [&]() {
+        for (int p = 0; p < count; p++)
+            for (int i = 0; i < outN[p]; i++) match[p][i] = -1;
+    };
+    if (nodes.empty()) {
+        none();
+        return 0;
+    }
     PTR(); // pass 1
     bool needTaken = false; // the "taken" flags in memory are only touched by nodes with more than 4096 candidates
     for (const BowNode& nd : nodes) needTaken = needTaken || nd.n2 > 4096;
@@ -3135,8 +3206,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         hM = reinterpret_cast<int32_t*>(ob.host);
         hB = reinterpret_cast<int8_t*>(ob.host + mBytes);
     } else {
-        if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal)) < 0) return r;
-        if ((r = s.up<int8_t>(&dB, nullptr, (size_t)outTotal)) < 0) return r;
+        // [matches | kept per problem | bins]: one clearing command, one download (matches + counts; k_bow_cull consumes the bins)
+        if ((r = s.up<int32_t>(&dM, nullptr, (size_t)outTotal + (size_t)count + ((size_t)outTotal + 3) / 4)) < 0) return r;
+        dB = reinterpret_cast<int8_t*>(dM + outTotal + count);
     }
     if ((r = s.up<uint8_t>(&taken, nullptr, (size_t)takenRows)) < 0) return r;
     // pass 2: every problem's arrays go straight into the pinned mirror of the pools (one copy, no intermediate
@@ -3153,7 +3225,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         const orbfe_bow_args* a = &eff[p];
         const bool R1 = probs[p].rInd1 != nullptr, R2 = probs[p].rInd2 != nullptr; // the whole set lives in a handle
         const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
-        if (!R1) {
+        if (!R1 && own1[p]) {
             if (is_device_ptr(a->desc1)) { // (read in place: BowProb::rDesc1)
                 if (int w = orbfe_producer_wait(a->desc1, g_ms); w < 0) return w;
             }
@@ -3163,7 +3235,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             else std::memset(hAng + r1, 0, (size_t)a->n1 * sizeof(float));
             if (a->fv1.nn) std::memcpy(hInd + i1Base[p], a->fv1.indices, (size_t)a->fv1.offsets[a->fv1.nn] * sizeof(int32_t));
         }
-        if (!R2) {
+        if (!R2 && own2[p]) {
             if (is_device_ptr(a->desc2)) {
                 if (int w = orbfe_producer_wait(a->desc2, g_ms); w < 0) return w;
             }
@@ -3175,9 +3247,12 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             if (a->fv2.nn) std::memcpy(hInd + i2Base[p], a->fv2.indices, (size_t)a->fv2.offsets[a->fv2.nn] * sizeof(int32_t));
         }
     }
+    BowCull* dC = nullptr;
     if (!mirrored) {
-        HIP_TRY(hipMemsetAsync(dM, 0xFF, (size_t)outTotal * sizeof(int32_t), g_ms));
-        HIP_TRY(hipMemsetAsync(dB, 0xFF, (size_t)outTotal, g_ms));
+        std::vector<BowCull> cu((size_t)count);
+        for (int p = 0; p < count; p++) cu[(size_t)p] = BowCull{probs[p].outBase, outN[p], args[p].check_orientation != 0 ? 1 : 0, 0};
+        if ((r = s.up(&dC, cu.data(), cu.size())) < 0) return r;
+        HIP_TRY(hipMemsetAsync(dM, 0xFF, ((size_t)outTotal + (size_t)count) * sizeof(int32_t) + (size_t)outTotal, g_ms));
     }
     if (needTaken) HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
     const DoneSig done = s.done_sig(4u * (unsigned)nodes.size() /* (a workgroup per node) */, mirrored ? &ob : nullptr, g_timeKernels);
@@ -3190,11 +3265,14 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
                            dP, dDesc, dMask, dAng, dInd, dM, dB, taken, done, bow_stop_at());
     }
     HIP_TRY(hipGetLastError());
+    if (!mirrored) {
+        hipLaunchKernelGGL(k_bow_cull, dim3((unsigned)count), dim3(256), 0, g_ms, dC, dM, dB, dM + outTotal);
+        HIP_TRY(hipGetLastError());
+    }
     PTR(); // launch
     std::vector<int32_t> m;
-    std::vector<int8_t> bins;
     const int32_t* pm;
-    const int8_t* pb;
+    const int8_t* pb = nullptr;
     if (mirrored) { // the results arrive in the pinned mirror: wait, read
         INT_TRY(s.complete(done));
         pm = hM;
@@ -3202,18 +3280,21 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     } else {
         // (reading the download where it lands in the pinned mirror instead of copying it out first was tried: the copy is a
         // streaming pass, the cull loop on freshly DMA-written lines is not -- 206 against 188 us for wait + tail of a 64-problem call)
-        m.resize(outTotal);
-        bins.resize(outTotal);
-        INT_TRY(s.down(m.data(), dM, (size_t)outTotal * sizeof(int32_t)));
-        INT_TRY(s.down(bins.data(), dB, (size_t)outTotal));
+        m.resize((size_t)outTotal + (size_t)count);
+        INT_TRY(s.down(m.data(), dM, m.size() * sizeof(int32_t)));
         INT_TRY(s.fetch());
         pm = m.data();
-        pb = bins.data();
     }
     PTR(); // wait
     for (int p = 0; p < count; p++) {
         std::memcpy(match[p], pm + probs[p].outBase, (size_t)outN[p] * sizeof(int32_t));
-        nmatches[p] = cull_by_rotation(match[p], pb + probs[p].outBase, outN[p], args[p].check_orientation != 0);
+        if (pb) {
+            nmatches[p] = cull_by_rotation(match[p], pb + probs[p].outBase, outN[p], args[p].check_orientation != 0);
+        } else { // (culled and counted by k_bow_cull)
+            const int kept = pm[(size_t)outTotal + (size_t)p];
+            if (kept < 0 || kept > outN[p]) return ORBFE_ERR_STATE;
+            nmatches[p] = kept;
+        }
     }
     PTR();
 #ifdef ORBFE_CALL_TRACE

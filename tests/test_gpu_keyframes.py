@@ -284,3 +284,54 @@ def test_three_threads_search_shared_handles_while_handles_come_and_go(pkg, orac
     cur.close()
     for q in neigh:
         q["kf"].close()
+
+
+def test_bow_batch_stages_shared_sets_once(pkg, oracle):
+    """A call's problems usually share a side (one frame against every relocalisation candidate, src/Tracking.cc:3784): arrays
+    that come with the same pointers and sizes are staged and uploaded once.  Mixed here: two keyframes against the same frame,
+    a third against another frame, the same arrays again as a KF-KF problem with real flags (a different set: variant 0 reads
+    all-ones flags), a set that appears as set 1 of one problem and set 2 of another, and a repeat of the first problem."""
+    rng = np.random.default_rng(17)
+    dA, dF, aA, aF = MI.descriptor_sets(900, 1000, 31)
+    dB, dG, aB, aG = MI.descriptor_sets(700, 800, 32)
+    fvA, fvF = MI.feature_vectors(dA, dF, 5)
+    fvB, fvG = MI.feature_vectors(dB, dG, 5)
+    mA = (rng.uniform(size=900) < 0.6).astype(np.uint8)
+    mB = (rng.uniform(size=700) < 0.6).astype(np.uint8)
+    mF = (rng.uniform(size=1000) < 0.5).astype(np.uint8)
+    P = [dict(desc1=dA, mask1=mA, ang1=aA, fv1=fvA, desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75),
+         dict(desc1=dB, mask1=mB, ang1=aB, fv1=fvB, desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75),
+         dict(desc1=dA, mask1=mA, ang1=aA, fv1=fvA, desc2=dG, ang2=aG, fv2=fvG, variant=0, nnratio=0.9, check_ori=False),
+         dict(desc1=dB, mask1=mB, ang1=aB, fv1=fvB, desc2=dF, mask2=mF, ang2=aF, fv2=fvF, variant=1, nnratio=0.8),
+         dict(desc1=dF, mask1=mF, ang1=aF, fv1=fvF, desc2=dA, mask2=mA, ang2=aA, fv2=fvA, variant=1, nnratio=0.8),
+         dict(desc1=dA, mask1=mA, ang1=aA, fv1=fvA, desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75)]
+    got = pkg.search_bow_batch(P)
+    total = 0
+    for k, pr in enumerate(P):
+        if pr["variant"] == 0:
+            rn, rm = oracle.search_bow_kf_f(pr["desc1"], pr["mask1"], pr["ang1"], pr["fv1"], pr["desc2"], pr["ang2"], pr["fv2"], -1,
+                                            pr["nnratio"], pr.get("check_ori", True))
+        else:
+            rn, rm = oracle.search_bow_kf_kf(pr["desc1"], pr["mask1"], pr["ang1"], pr["fv1"], pr["desc2"], pr["mask2"], pr["ang2"],
+                                             pr["fv2"], -1, -1, pr["nnratio"], pr.get("check_ori", True))
+        assert got[k][0] == rn and np.array_equal(got[k][1], rm), k
+        one = pkg.search_bow_batch([pr])[0]
+        assert one[0] == rn and np.array_equal(one[1], rm), k
+        total += rn
+    assert total > 300
+    assert got[0][0] == got[5][0] and np.array_equal(got[0][1], got[5][1])
+    # sixty problems: the results no longer fit the mirror -- download form, rotation cull and counts by k_bow_cull on the device
+    big = pkg.search_bow_batch(P * 10)
+    assert sum(len(g[1]) for g in big) * 5 > 256 * 1024
+    for k, g in enumerate(big):
+        assert g[0] == got[k % 6][0] and np.array_equal(g[1], got[k % 6][1]), k
+    # ... also with an empty problem among them (no features on one side: nothing matches, nothing is read)
+    empty = dict(P[0], desc2=np.zeros((0, 32), np.uint8), ang2=np.zeros(0, np.float32), fv2=synth_empty_fv())
+    mixed = pkg.search_bow_batch(P * 5 + [empty] + P * 5)
+    assert mixed[30][0] == 0 and len(mixed[30][1]) == 0
+    for k, g in enumerate(mixed[:30] + mixed[31:]):
+        assert g[0] == got[k % 6][0] and np.array_equal(g[1], got[k % 6][1]), k
+
+
+def synth_empty_fv():
+    return (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
