@@ -2821,7 +2821,7 @@ static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, i
         }
         if (left->h_done.coherent) {
             if (++left->doneSeq == 0u) left->doneSeq = 1u;
-            done = OrbDone{left->d_done.p + 72, left->h_done.dev(), left->doneSeq, (unsigned)((capL + 3) / 4)};
+            done = OrbDone{left->d_done.p + 16, left->h_done.dev(), left->doneSeq, (unsigned)((capL + 3) / 4)};
             *doneSeq = left->doneSeq;
         }
     }

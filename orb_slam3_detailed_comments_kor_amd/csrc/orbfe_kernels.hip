@@ -2396,36 +2396,70 @@ static_assert(160 * (kDescHItems.maxPr[0] + 1) <= DESC_RAW_OFF + 88 * kDescHItem
 #endif
 
 // Completion word of the latency path (a blocking call of a frame or two, results mirrored into page-locked host memory by
-// this kernel): the host spins on a flag word the last wavefront publishes instead of waiting in hipStreamSynchronize for the
-// end-of-kernel release and the runtime's signal (~5 us of a 12-us round trip, tools/latency_probe.hip).  A wavefront that is
-// done -- with or without a keypoint -- waits for its own stores to be acknowledged (the mirror is fine-grained host memory:
-// uncached on the device) and counts itself in one of 64 counters (slot index mod 64: a thousand wavefronts on ONE address
-// serialise), the wavefront that completes a counter resets it and counts it in the 65th, the one that completes that one
-// resets it and writes the call's sequence number behind a system-scope fence.
+// this kernel): the host spins on a flag word the kernel publishes instead of waiting in hipStreamSynchronize for the
+// end-of-kernel release and the runtime's signal (~5 us of a 12-us round trip, tools/latency_probe.hip).
+// The flag may only land in host memory after every result store has.  A wavefront's own acknowledgements (s_waitcnt vmcnt(0))
+// do not say that: they say that its stores have reached its XCD's L2, and the flag -- written by another wavefront, possibly on
+// another XCD -- travels by a path of its own.  (Found by tests/test_gpu_keyframes.py's three host threads, which load the link:
+// a search now and then read a row of its mirror before the row's stores had arrived.)  What does say it is a system-scope
+// release (buffer_wbl2 sc0 sc1 + s_waitcnt: write-back of the XCD's L2 and a wait for it) issued on the SAME XCD after the
+// acknowledgements -- and a thousand of those, one per K-DESC wavefront, queue behind each other: 0.066 -> 0.081 ms per frame.
+// So the workgroups count per XCD: workgroups are dealt to the eight XCDs round-robin in linear-id order (tools/xcc_probe.hip
+// reads the XCC_ID register: no exception on any grid), a workgroup counts itself -- after its own acknowledgements -- in the
+// counter of the XCD its id says, the one that completes an XCD's count does ONE release there and counts the XCD, and the one
+// that completes the eight writes the flag.  Every workgroup checks the register against its id: one that runs elsewhere
+// releases its own stores before it counts; an XCD whose count is completed from elsewhere cannot be vouched for, and then the
+// flag is not written at all -- the host's wait runs into its bound, synchronises the stream (always correct) and, after eight of
+// those, stops using the word.
 struct OrbDone {
-    unsigned* ctr;  // 65 words of device memory, zero between calls (calls on one stream are ordered)
+    unsigned* ctr;  // 10 words of device memory, zero between calls (calls on one stream are ordered): [0..7] workgroups of the
+                    // XCD done, [8] XCDs done, [9] "an XCD's count was completed from another XCD"
     unsigned* flag; // the kernel's address of the page-locked flag word; nullptr: none
-    unsigned seq, nWaves;
+    unsigned seq, nWaves /* reporting workgroups = the kernel's whole grid, in linear-id order */;
 };
-__device__ __forceinline__ void desc_done(const OrbDone& d, unsigned wl /* this wavefront's index among the nWaves */)
+__device__ __forceinline__ unsigned orb_xcc_id()
 {
-    if (!d.flag) return; // (uniform)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+// By ONE wavefront of a reporting workgroup (all lanes), once every wavefront of the workgroup has waited for its own store
+// acknowledgements.  L = the workgroup's linear id in the grid.
+__device__ __forceinline__ void xcd_done(const OrbDone& d, unsigned L)
+{
+    const unsigned a = L & 7u;
+    const bool off = orb_xcc_id() != a; // (uniform)
+    if (off) __threadfence_system();    // not where the count assumes: its stores land by its own release
+    unsigned closes = 0u;
+    if ((threadIdx.x & 63) == 0) closes = atomicAdd(&d.ctr[a], 1u) + 1u == ((d.nWaves + 7u - a) >> 3) ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane(closes)) return;
+#ifndef ORBFE_DONE_ACK_ONLY // (defined: the acknowledgements alone, as first built -- to show the difference, never to ship)
+    __threadfence_system(); // the XCD's last workgroup: everything its workgroups stored has reached this L2 -- now it lands
+#endif
     if ((threadIdx.x & 63) == 0) {
-        const unsigned k = wl & 63u, want = (d.nWaves + 63u - k) >> 6;
-        if (atomicAdd(&d.ctr[k], 1u) + 1u == want) {
-            d.ctr[k] = 0u;
-            if (atomicAdd(&d.ctr[64], 1u) + 1u == min(d.nWaves, 64u)) {
-                d.ctr[64] = 0u;
+        d.ctr[a] = 0u;
+        if (off) { // (this L2 is not XCD a's)
+            atomicExch(&d.ctr[9], 1u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        if (atomicAdd(&d.ctr[8], 1u) + 1u == min(d.nWaves, 8u)) {
+            d.ctr[8] = 0u;
+            if (atomicExch(&d.ctr[9], 0u) == 0u) {
                 __threadfence_system();
                 *(volatile unsigned*)d.flag = d.seq;
             }
         }
     }
 }
+// K-DESC: a workgroup is one wavefront
+__device__ __forceinline__ void desc_done(const OrbDone& d, unsigned wl /* the workgroup's linear id */)
+{
+    if (!d.flag) return; // (uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xcd_done(d, wl);
+}
 
 // The same word for a kernel of four-wavefront workgroups in which EVERY wavefront reports (K-STEREO): wavefronts count in
-// LDS, workgroups in d.ctr[0], nWaves = number of workgroups.  wg_done_begin before the first exit of any wavefront.
+// LDS, the one that completes the workgroup's count reports for it; nWaves = number of workgroups (a one-dimensional grid).
+// wg_done_begin before the first exit of any wavefront.
 __device__ __forceinline__ void wg_done_begin(const OrbDone& d, unsigned* wgCnt)
 {
     if (!d.flag) return; // (uniform)
@@ -2436,15 +2470,9 @@ __device__ __forceinline__ void wg_done(const OrbDone& d, unsigned* wgCnt)
 {
     if (!d.flag) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) {
-        if (atomicAdd(wgCnt, 1u) + 1u == 4u) {
-            if (atomicAdd(&d.ctr[0], 1u) + 1u == d.nWaves) {
-                d.ctr[0] = 0u;
-                __threadfence_system();
-                *(volatile unsigned*)d.flag = d.seq;
-            }
-        }
-    }
+    unsigned closes = 0u;
+    if ((threadIdx.x & 63) == 0) closes = atomicAdd(wgCnt, 1u) + 1u == 4u ? 1u : 0u;
+    if (__builtin_amdgcn_readfirstlane(closes)) xcd_done(d, blockIdx.x);
 }
 
 // One wavefront per keypoint.  Stages the 43x43 raw neighbourhood in LDS, computes the

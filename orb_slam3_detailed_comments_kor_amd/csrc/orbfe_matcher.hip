@@ -350,6 +350,23 @@ struct DoneSig {
     uint4* outMirror; // the kernel's address of the block's pinned mirror
     unsigned out16;   // 16-byte units
 };
+// Result stores into the pinned mirror must have LANDED in host memory before the flag does: the flag is written by another
+// wavefront, possibly on another XCD, and travels to the host by a path of its own.  A wavefront's own acknowledgements
+// (s_waitcnt vmcnt(0)) only say that its stores have reached its XCD's L2 -- measured fast, and found NOT sufficient: with
+// three host threads loading the link a search now and then read a row of its mirror before the row's stores had arrived
+// (tests/test_gpu_keyframes.py, three threads: 4 failures in 16 runs; none in 24 with the release below).  So: every wavefront
+// waits for its own acknowledgements, and ONE wavefront per workgroup -- the one that completes the workgroup's count; all of a
+// workgroup's wavefronts sit on one CU, hence behind one L2 -- does a system-scope release (write-back of that L2 and a wait for
+// it: buffer_wbl2 sc0 sc1, s_waitcnt) before the workgroup counts itself.  (A release per WAVEFRONT costs SearchByBoW 2 us and
+// a triangulation search 12: the write-backs of one XCD queue behind each other.)
+__device__ __forceinline__ void own_stores_acknowledged()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void workgroup_stores_landed() // (by one wavefront, after every wavefront's own_stores_acknowledged)
+{
+    __threadfence_system();
+}
 // the wavefront that completed the count (all 64 lanes): results to the mirror, block clean again, flag
 __device__ __forceinline__ void done_publish(const DoneSig& d)
 {
@@ -362,7 +379,7 @@ __device__ __forceinline__ void done_publish(const DoneSig& d)
             d.outMirror[i] = v;
             d.outDev[i] = ones;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (this wavefront's own stores: the fence below covers them)
     }
     if (lane == 0) {
         *d.ctr = 0u; // for the next call (calls on one stream are ordered)
@@ -383,12 +400,15 @@ __device__ __forceinline__ void wave_done(const DoneSig& d, unsigned* wgCnt)
     if (!d.flag) return; // (wave-uniform)
     // this wavefront's result stores: visible to the device (the clean block) / acknowledged (stores into the mirror itself)
     if (d.outDev) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned last = 0u;
+    else own_stores_acknowledged();
+    unsigned closes = 0u, last = 0u;
     if ((threadIdx.x & 63) == 0) {
         const unsigned mine = min(4u, d.waves - 4u * blockIdx.x);
-        if (atomicAdd(wgCnt, 1u) + 1u == mine) last = atomicAdd(d.ctr, 1u) + 1u == d.total ? 1u : 0u;
+        closes = atomicAdd(wgCnt, 1u) + 1u == mine ? 1u : 0u;
     }
+    if (!__builtin_amdgcn_readfirstlane(closes)) return;
+    if (!d.outDev) workgroup_stores_landed();
+    if ((threadIdx.x & 63) == 0) last = atomicAdd(d.ctr, 1u) + 1u == d.total ? 1u : 0u;
     if (__builtin_amdgcn_readfirstlane(last)) done_publish(d);
 }
 // ... and for a kernel in which ONE wavefront per workgroup reports (d.total = workgroups)
@@ -396,7 +416,7 @@ __device__ __forceinline__ void wg1_done(const DoneSig& d)
 {
     if (!d.flag) return;
     if (d.outDev) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else workgroup_stores_landed(); // (the reporting wavefront is the workgroup's only writer, or stands behind its barrier)
     unsigned last = 0u;
     if ((threadIdx.x & 63) == 0) last = atomicAdd(d.ctr, 1u) + 1u == d.total ? 1u : 0u;
     if (__builtin_amdgcn_readfirstlane(last)) done_publish(d);
@@ -412,12 +432,15 @@ __global__ __launch_bounds__(256) void k_copy_out(const DoneSig d)
         d.outDev[i] = ones;
     }
     if (!d.flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    own_stores_acknowledged();
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(d.ctr, 1u) + 1u == d.total) {
-        *d.ctr = 0u;
-        __threadfence_system();
-        *(volatile unsigned*)d.flag = d.seq;
+    if (threadIdx.x == 0) {
+        workgroup_stores_landed();
+        if (atomicAdd(d.ctr, 1u) + 1u == d.total) {
+            *d.ctr = 0u;
+            __threadfence_system();
+            *(volatile unsigned*)d.flag = d.seq;
+        }
     }
 }
 
@@ -1226,12 +1249,15 @@ __global__ __launch_bounds__(256) void k_tri_compact(int32_t* __restrict__ rowsB
     }
     if (tid == 0) outN[p] = total;
     if (!done.flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    own_stores_acknowledged();
     __syncthreads();
-    if (tid == 0 && atomicAdd(done.ctr, 1u) + 1u == done.total) {
-        *done.ctr = 0u;
-        __threadfence_system();
-        *(volatile unsigned*)done.flag = done.seq;
+    if (tid == 0) {
+        workgroup_stores_landed();
+        if (atomicAdd(done.ctr, 1u) + 1u == done.total) {
+            *done.ctr = 0u;
+            __threadfence_system();
+            *(volatile unsigned*)done.flag = done.seq;
+        }
     }
 }
 
@@ -1937,7 +1963,7 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
             P.mirror[2] = keysNeeded;
             P.mirror[3] = 0;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        own_stores_acknowledged(); // (one workgroup: the release in front of the flag below is the workgroup's)
         __syncthreads();
         if (tid == 0 && P.doneFlag) {
             __threadfence_system();
@@ -1970,7 +1996,7 @@ __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
         __threadfence();
         __syncthreads();
         for (int i = tid; i < P.mirrorInts; i += PROJ_THREADS) P.mirror[i] = P.status[i];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        own_stores_acknowledged(); // (one workgroup: the release in front of the flag below is the workgroup's)
         __syncthreads();
         if (tid == 0 && P.doneFlag) {
             __threadfence_system();
@@ -4219,12 +4245,18 @@ namespace {
 // inputs and work arrays of one search on the device (outputs are assigned by the caller: one block per call).  Two phases,
 // so that a batch stages the inputs of ALL its searches next to each other (one run of the pinned mirror = one upload
 // command for the batch instead of one per search) and the work arrays after them: phase 0 = inputs, phase 1 = the rest.
-int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_frame* F, int phase)
+// `prev` / `prevJ`: the search staged just before this one in the same call.  The searches of a batch usually share a side --
+// one keyframe's map points fused into every neighbour (the same query descriptors), or every neighbour's points into the one
+// keyframe (the same frame side), src/LocalMapping.cc:803-870 -- and a read-only array that comes with the same pointer and
+// size as its predecessor's is staged and uploaded once.
+int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_frame* F, int phase, const orbfe_proj_args* prev = nullptr,
+               const ProjJob* prevJ = nullptr)
 {
     int r;
     ProjDev& P = J.P;
     const size_t n = (size_t)a->n, nq = (size_t)a->nq;
     if (phase == 0) {
+        const bool sameN = prev && prev->n == a->n, sameQ = prev && prev->nq == a->nq;
         uint8_t *dDesc = nullptr, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
         float *dKx = nullptr, *dKy = nullptr, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
         int32_t *dOct = nullptr, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
@@ -4232,11 +4264,18 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_fra
             dDesc = F->desc; dKx = F->kx; dKy = F->ky; dOct = F->octave;
             if (F->uright && (a->Nleft == -1 || a->chi2_gate)) dUr = F->uright;
         } else {
-            if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
-            if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
-            if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
-            if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
-            if (a->uright && (a->Nleft == -1 || a->chi2_gate) && (r = s.up(&dUr, a->uright, n)) < 0) return r;
+            if (sameN && prev->desc == a->desc) dDesc = const_cast<uint8_t*>(prevJ->P.desc);
+            else if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
+            if (sameN && prev->kx == a->kx) dKx = const_cast<float*>(prevJ->P.kx);
+            else if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
+            if (sameN && prev->ky == a->ky) dKy = const_cast<float*>(prevJ->P.ky);
+            else if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
+            if (sameN && prev->octave == a->octave) dOct = const_cast<int32_t*>(prevJ->P.octave);
+            else if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
+            if (a->uright && (a->Nleft == -1 || a->chi2_gate)) {
+                if (sameN && prev->uright == a->uright && prevJ->P.uright) dUr = const_cast<float*>(prevJ->P.uright);
+                else if ((r = s.up(&dUr, a->uright, n)) < 0) return r;
+            }
         }
         float* dInvSigma2 = nullptr;
         if (a->chi2_gate && (r = s.up(&dInvSigma2, a->inv_level_sigma2, (size_t)a->n_levels)) < 0) return r;
@@ -4245,7 +4284,8 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_fra
             if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
             if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
         }
-        if ((r = s.up_desc(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
+        if (sameQ && prev->qdesc == a->qdesc) dQdesc = const_cast<uint8_t*>(prevJ->P.qdesc);
+        else if ((r = s.up_desc(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
         if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
         if ((r = s.up(&dQy, a->qy, nq)) < 0) return r;
         if ((r = s.up(&dQr, a->qr, nq)) < 0) return r;
@@ -4352,7 +4392,7 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     size_t outInts = 0, sweepBytes = 0;
     unsigned maxBlocks = 1;
     for (size_t j = 0; j < jobs.size(); j++) // (the inputs of all searches first: one upload for the batch)
-        if ((r = proj_stage(s, &items[live[j]], jobs[j], frame, 0)) < 0) return r;
+        if ((r = proj_stage(s, &items[live[j]], jobs[j], frame, 0, j ? &items[live[j - 1]] : nullptr, j ? &jobs[j - 1] : nullptr)) < 0) return r;
     for (size_t j = 0; j < jobs.size(); j++) {
         const orbfe_proj_args* a = &items[live[j]];
         if ((r = proj_stage(s, a, jobs[j], frame, 1)) < 0) return r;

@@ -354,3 +354,86 @@ def test_completion_word_survives_many_calls_and_changing_shapes(pkg, oracle):
             res = ex.extract_batch([a, a[:, ::-1].copy()], [(0, 0), (0, 0)])
             assert res[0][0] == ra[0] and np.array_equal(res[0][2], ra[2]), it
     ex.close()
+
+
+def test_latency_paths_under_link_load_from_other_threads(pkg, oracle):
+    """The completion word may only reach the host after every result the kernels mirrored has.  Alone on the link that is hard
+    to get wrong; the matcher's first protocol (store acknowledgements only) was caught by three host threads.  So: a frame per
+    call and a stereo pair per call from two threads with an extractor each, while a third keeps the link busy with batched
+    searches on host arrays (uploads and downloads) -- every result against the oracle's, several hundred times."""
+    import threading
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import matcher_inputs as MI
+    mb, mbf = 47.90639384423901 / 435.2046959714599, 47.90639384423901
+    left, right = pkg.synth.make_stereo_pair(480, 752, 77, shift=17)
+    frames = [pkg.synth.make_frame(480, 752, 500 + k) for k in range(3)]
+    oL, oR = oracle.Extractor(1200, 1.2, 8, 20, 7), oracle.Extractor(1200, 1.2, 8, 20, 7)
+    _, rkL, rdL = oL.extract(left, (0, 0))
+    _, rkR, rdR = oR.extract(right, (0, 0))
+    rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf)
+    o1 = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    want = [o1.extract(f, (0, 1000)) for f in frames]
+    exS, exM = pkg.ORBextractor(1200, 1.2, 8, 20, 7), pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    d1, d2, a1, a2 = MI.descriptor_sets(1000, 1000, 9)
+    fv1, fv2 = MI.feature_vectors(d1, d2, 9)
+    m1 = np.ones(1000, np.uint8)
+    loadP = [dict(desc1=d1.copy(), mask1=m1, ang1=a1, fv1=fv1, desc2=d2.copy(), ang2=a2, fv2=fv2, variant=0, nnratio=0.8) for _ in range(24)]
+    bad, stop = [], threading.Event()
+
+    def same(k, rk, d, rd):
+        return len(k) == len(rk) and np.array_equal(d, rd) and all(np.array_equal(k[f], rk[f]) for f in FIELDS)
+
+    def stereo():
+        for it in range(250):
+            if stop.is_set():
+                return
+            m, (monoL, kL, dL), (monoR, kR, dR), uR, dep = pkg.binding.extract_stereo_pair(exS, left, right, mb, mbf)
+            if not (m == rn and same(kL, rkL, dL, rdL) and same(kR, rkR, dR, rdR) and np.array_equal(uR, ruR) and np.array_equal(dep, rdep)):
+                bad.append("stereo pair differs in round %d" % it)
+
+    def mono():
+        for it in range(400):
+            if stop.is_set():
+                return
+            mono_, k, d = exM(frames[it % 3], (0, 1000))
+            w = want[it % 3]
+            if not (mono_ == w[0] and same(k, w[1], d, w[2])):
+                bad.append("frame differs in round %d" % it)
+
+    def load():
+        while not stop.is_set():
+            pkg.search_bow_batch(loadP)
+
+    def copies():  # ... and with large transfers in both directions
+        import torch
+        h = torch.empty(48 << 20, dtype=torch.uint8).pin_memory()
+        d = torch.empty(48 << 20, dtype=torch.uint8, device="cuda")
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            while not stop.is_set():
+                d.copy_(h, non_blocking=True)
+                h.copy_(d, non_blocking=True)
+                s2.synchronize()
+
+    def guard(fn):
+        def run():
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                bad.append(repr(e))
+        return run
+
+    tls = [threading.Thread(target=guard(load)), threading.Thread(target=guard(copies))]
+    ts = [threading.Thread(target=guard(stereo)), threading.Thread(target=guard(mono))]
+    for t in tls + ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    stop.set()
+    for t in tls:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ts + tls), "a thread hangs"
+    assert not bad, bad[:5]
+    exS.close()
+    exM.close()

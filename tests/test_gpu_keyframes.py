@@ -335,3 +335,33 @@ def test_bow_batch_stages_shared_sets_once(pkg, oracle):
 
 def synth_empty_fv():
     return (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+
+
+def test_projection_batch_shares_arrays_between_neighbouring_searches(pkg, oracle):
+    """The searches of a batch usually share a side (src/LocalMapping.cc:803-870: one keyframe's map points into every
+    neighbour = the same query descriptors; every neighbour's points into the one keyframe = the same frame side): a read-only
+    array that comes with its predecessor's pointer and size is uploaded once.  Every search must still be what it is alone."""
+    from matcher_inputs import projection_problem
+    A = projection_problem(901, n=1400, nq=900, mode=1, stereo=True, th=3.0, loop="fuse")
+    B = projection_problem(902, n=1100, nq=900, mode=1, stereo=True, th=3.0, loop="fuse")
+    C = projection_problem(903, n=1400, nq=700, mode=0, stereo=True, th=3.0)
+    same_frame_other_queries = dict(A)
+    for k, v in projection_problem(904, n=1400, nq=900, mode=1, stereo=True, th=7.0, loop="fuse").items():
+        if k.startswith("q") or k in ("th_high", "taken"):
+            same_frame_other_queries[k] = v
+    same_queries_other_frame = dict(B)
+    same_queries_other_frame["qdesc"] = A["qdesc"]            # (the map points of one keyframe projected into another)
+    same_frame_fewer_queries = dict(C)
+    for k in ("desc", "kx", "ky", "octave", "angle", "uright"):
+        same_frame_fewer_queries[k] = A[k]                    # A's frame side with C's (fewer) queries
+    same_frame_fewer_queries["taken"] = A["taken"] if "taken" in A else None
+    batch = [A, same_frame_other_queries, same_queries_other_frame, A, same_frame_fewer_queries, B, C]
+    got = pkg.search_projection_batch(batch)
+    hits = 0
+    for k, pr in enumerate(batch):
+        ref = oracle.search_projection(pr)
+        one = pkg.search_projection(pr)
+        for a, b in ((ref, one), (ref, got[k])):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
+        hits += ref[0]
+    assert hits > 500
