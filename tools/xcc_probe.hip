@@ -1,4 +1,6 @@
-// WG -> XCD mapping probe: every workgroup records the XCC_ID hardware register; the host checks id % 8 == XCC_ID
+// WG -> XCD mapping probe (hipcc -O2 --offload-arch=gfx950 -o tools/xcc_probe tools/xcc_probe.hip): every workgroup records the
+// XCC_ID hardware register; the host checks linear id % 8 == XCC_ID.  The extractor's completion word counts per XCD on that rule
+// (and checks it in every workgroup): csrc/orbfe_kernels.hip, xcd_done.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
