@@ -380,12 +380,13 @@ def test_latency_paths_under_link_load_from_other_threads(pkg, oracle):
     m1 = np.ones(1000, np.uint8)
     loadP = [dict(desc1=d1.copy(), mask1=m1, ang1=a1, fv1=fv1, desc2=d2.copy(), ang2=a2, fv2=fv2, variant=0, nnratio=0.8) for _ in range(24)]
     bad, stop = [], threading.Event()
+    SOAK = int(os.environ.get("ORBFE_TEST_ROUNDS", "400"))  # (a soak run sets more)
 
     def same(k, rk, d, rd):
         return len(k) == len(rk) and np.array_equal(d, rd) and all(np.array_equal(k[f], rk[f]) for f in FIELDS)
 
     def stereo():
-        for it in range(250):
+        for it in range(SOAK // 2):
             if stop.is_set():
                 return
             m, (monoL, kL, dL), (monoR, kR, dR), uR, dep = pkg.binding.extract_stereo_pair(exS, left, right, mb, mbf)
@@ -393,7 +394,7 @@ def test_latency_paths_under_link_load_from_other_threads(pkg, oracle):
                 bad.append("stereo pair differs in round %d" % it)
 
     def mono():
-        for it in range(400):
+        for it in range(SOAK):
             if stop.is_set():
                 return
             mono_, k, d = exM(frames[it % 3], (0, 1000))

@@ -231,7 +231,8 @@ def test_three_threads_search_shared_handles_while_handles_come_and_go(pkg, orac
                 stop.set()
         return run
 
-    ROUNDS = 500
+    import os
+    ROUNDS = int(os.environ.get("ORBFE_TEST_ROUNDS", "500"))  # (a soak run sets more)
 
     def tracking():
         for it in range(ROUNDS):
