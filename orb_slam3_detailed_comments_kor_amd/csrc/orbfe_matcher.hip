@@ -3068,7 +3068,12 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     if (count < 0 || (count && (!args || !match || !nmatches))) return ORBFE_ERR_ARGS;
     PTR_BEGIN();
     // pass 1: validate, lay the pools out, list the shared vocabulary nodes (merge-join of the two FeatureVectors)
-    std::vector<BowNode> nodes;
+    // (the node list of a 64-candidate call is 128 KB, its download 256 KB: as fresh vectors they are mmap'ed, faulted in and
+    // unmapped by every call; the thread keeps them)
+    static thread_local std::vector<BowNode> nodesKeep;
+    static thread_local std::vector<int32_t> downKeep;
+    std::vector<BowNode>& nodes = nodesKeep;
+    nodes.clear();
     std::vector<BowProb> probs(count);
     std::vector<int> outN(count), i1Base(count, 0), i2Base(count, 0);
     std::vector<uint8_t> active(count, 0);
@@ -3296,7 +3301,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         HIP_TRY(hipGetLastError());
     }
     PTR(); // launch
-    std::vector<int32_t> m;
+    std::vector<int32_t>& m = downKeep;
     const int32_t* pm;
     const int8_t* pb = nullptr;
     if (mirrored) { // the results arrive in the pinned mirror: wait, read
@@ -3306,8 +3311,8 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     } else {
         // (reading the download where it lands in the pinned mirror instead of copying it out first was tried: the copy is a
         // streaming pass, the cull loop on freshly DMA-written lines is not -- 206 against 188 us for wait + tail of a 64-problem call)
-        m.resize((size_t)outTotal + (size_t)count);
-        INT_TRY(s.down(m.data(), dM, m.size() * sizeof(int32_t)));
+        if (m.size() < (size_t)outTotal + (size_t)count) m.resize((size_t)outTotal + (size_t)count);
+        INT_TRY(s.down(m.data(), dM, ((size_t)outTotal + (size_t)count) * sizeof(int32_t)));
         INT_TRY(s.fetch());
         pm = m.data();
     }
@@ -4374,10 +4379,13 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     std::vector<int> live;
     for (int k = 0; k < count; k++) {
         const orbfe_proj_args* a = &items[k];
+        nmatches[k] = 0;
+        if (a->n > 0 && a->nq > 0) {
+            live.push_back(k); // (proj_finish writes both arrays whole)
+            continue;
+        }
         for (int i = 0; i < a->n; i++) feat_match[k][i] = -1;
         for (int q = 0; q < a->nq; q++) q_match[k][q] = -1;
-        nmatches[k] = 0;
-        if (a->n > 0 && a->nq > 0) live.push_back(k);
     }
     if (live.empty()) return 0;
     PTR(); // validate + prefill
@@ -4412,7 +4420,11 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     int32_t *dMir = nullptr, *hMir = nullptr;
     const bool mirrored = latency && s.inPlace && !g_timeKernels && outInts * 4 <= (256u << 10) &&
                           s.mirror_out(&dMir, &hMir, outInts) == 0;
-    std::vector<int32_t> outv(mirrored ? 0 : outInts);
+    // (kept by the thread: as a fresh vector the download buffer of a 64-search call -- 600 KB -- is mapped, zeroed, faulted in
+    // and unmapped by every call)
+    static thread_local std::vector<int32_t> outKeep;
+    std::vector<int32_t>& outv = outKeep;
+    if (!mirrored && outv.size() < outInts) outv.resize(outInts);
     const int32_t* out = mirrored ? hMir : outv.data();
     std::vector<ProjDev> hostP(jobs.size());
     PTR(); // staging
@@ -4449,7 +4461,7 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         PTR(); // flush + launches
         if (mirrored) INT_TRY(s.complete(done));
         else {
-            INT_TRY(s.down(outv.data(), dOut, outv.size() * 4));
+            INT_TRY(s.down(outv.data(), dOut, outInts * 4));
             INT_TRY(s.fetch());
         }
         PTR(); // fetch
