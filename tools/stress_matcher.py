@@ -12,10 +12,10 @@ import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
 import orb_oracle_py as O  # noqa: E402
 import matcher_inputs as MI  # noqa: E402
 
-def run(ncases=60, seed=3, scale=1.0, log=print, kinds=10):
+def run(ncases=60, seed=3, scale=1.0, log=print, kinds=11):
     """Returns the list of mismatch descriptions.  scale < 1 shrinks the random problem sizes (test-suite slice).
     kinds = 6: the one-shot entry points only; 10: also the resident forms (keyframe / frame handles, the triangulation
-    batch) and the stereo pair in one call."""
+    batch) and the stereo pair in one call; 11: also batched calls whose problems share sides (staged once per call)."""
     O.build()
     rng = np.random.default_rng(seed)
     bad = []
@@ -180,6 +180,53 @@ def run(ncases=60, seed=3, scale=1.0, log=print, kinds=10):
                       and np.array_equal(gR[1], rR[1]) and np.array_equal(gR[2], rR[2]) and np.array_equal(uR, ruR) and np.array_equal(dep, rdep))
                 desc = "stereo pair %dx%d nF=%d shift=%d -> %d kp, %d matches" % (h, w, nf, shift, len(rL[1]), rn)
             ex.close()
+        elif kind == 10:  # batched calls: problems that share a side, repeat each other, or share nothing; small and large batches
+            nb = int(rng.choice([2, 3, 7, 20, 70]))
+            sets = []
+            for k in range(3):  # three (set 1, set 2) worlds to draw from
+                n1, n2 = size(30, 1200), size(30, 1200)
+                d1, d2, a1, a2 = MI.descriptor_sets(n1, n2, (seed + k) % 100000)
+                fv1, fv2 = MI.feature_vectors(d1, d2, seed % 1000, int(rng.integers(3, 9)), 2)
+                sets.append(dict(d1=d1, d2=d2, a1=a1, a2=a2, fv1=fv1, fv2=fv2, m1=(rng.uniform(size=n1) < 0.6).astype(np.uint8),
+                                 m2=(rng.uniform(size=n2) < 0.6).astype(np.uint8)))
+            P, want = [], {}
+            for j in range(nb):
+                S1, S2 = sets[int(rng.integers(0, 3))], sets[int(rng.integers(0, 3))]
+                if rng.random() < 0.6:
+                    S2 = S1  # (matching sides most of the time: something to find)
+                variant = int(rng.integers(0, 2))
+                ratio = float(rng.choice([0.6, 0.75, 0.9]))
+                ori = bool(rng.integers(0, 2))
+                P.append(dict(desc1=S1["d1"], mask1=S1["m1"], ang1=S1["a1"], fv1=S1["fv1"], desc2=S2["d2"], mask2=S2["m2"] if variant else None,
+                              ang2=S2["a2"], fv2=S2["fv2"], variant=variant, nnratio=ratio, check_ori=ori))
+                key = (id(S1), id(S2), variant, ratio, ori)
+                if key not in want:
+                    want[key] = (O.search_bow_kf_kf(S1["d1"], S1["m1"], S1["a1"], S1["fv1"], S2["d2"], S2["m2"], S2["a2"], S2["fv2"], -1, -1, ratio, ori)
+                                 if variant else O.search_bow_kf_f(S1["d1"], S1["m1"], S1["a1"], S1["fv1"], S2["d2"], S2["a2"], S2["fv2"], -1, ratio, ori))
+                P[-1]["_key"] = key
+            got = pkg.search_bow_batch([{k: v for k, v in pr.items() if k != "_key"} for pr in P])
+            ok = all(g[0] == want[pr["_key"]][0] and np.array_equal(g[1], want[pr["_key"]][1]) for g, pr in zip(got, P))
+            # ... and a projection batch: the same frame with other queries, other frames with the same query descriptors
+            n = size(50, 1500)
+            nq = size(1, 1200)
+            base = MI.projection_problem(seed, n=n, nq=nq, mode=1, stereo=True, th=3.0, loop="fuse")
+            other = MI.projection_problem(seed + 1, n=n, nq=nq, mode=1, stereo=True, th=7.0, loop="fuse")
+            B = [base]
+            q2 = dict(base)
+            for key, v in other.items():
+                if key.startswith("q") or key in ("th_high", "taken"):
+                    q2[key] = v
+            B.append(q2)
+            f2 = dict(other)
+            f2["qdesc"] = base["qdesc"]
+            B.append(f2)
+            B.append(base)
+            B = [B[int(rng.integers(0, len(B)))] for _ in range(int(rng.choice([2, 5, 12])))]
+            gotp = pkg.search_projection_batch(B)
+            for pr, g in zip(B, gotp):
+                a = O.search_projection(pr)
+                ok = ok and a[0] == g[0] and np.array_equal(a[1], g[1]) and np.array_equal(a[2], g[2])
+            desc = "batches: bow x %d, projection x %d" % (nb, len(B))
         else:            # knn-2 and all-pairs distances, ragged sizes
             nq, nt = size(1, 1800), size(1, 1800)
             Q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
