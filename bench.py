@@ -54,6 +54,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_LANES = 2
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -357,11 +358,21 @@ def main():
     ap.add_argument("--exchange", choices=["cabi", "torch"], default="cabi",
                     help="N > 1: the all-gather through the C ABI (orbfe_mc_*: ncclAllGather issued by liborbfe.so on its own "
                          "stream) or through torch.distributed (c10d's process group)")
-    ap.add_argument("--lanes", type=int, choices=[1, 2], default=2,
-                    help="orbfe_set_lanes for the TIMED region: 2 = every batch runs as two half-batches on two streams of the ONE "
-                         "extractor context (the latency-bound quadtree kernel and the kernel tails of one half beside the "
-                         "throughput-bound kernels of the other).  The per-kernel times of `roofline` are always measured with "
-                         "one lane, in a second region of the same run: overlapped kernels have no per-launch duration")
+    ap.add_argument("--lanes", type=int, choices=[1, 2, 3, 4], default=DEFAULT_LANES,
+                    help="orbfe_set_lanes for the TIMED region: up to this many batches in flight on streams of the ONE extractor "
+                         "context (the latency-bound quadtree kernel and the kernel tails of one batch beside the throughput-bound "
+                         "kernels of its neighbours).  The per-kernel times of `roofline` are always measured with one lane, in a "
+                         "second region of the same run: overlapped kernels have no per-launch duration")
+    ap.add_argument("--lane-mode", choices=["batch", "split"], default="batch",
+                    help="batch (round 5): whole batches dealt round-robin to the lanes, each with its own intermediate buffers; "
+                         "split (round 4, two lanes only): every batch as two half-batches")
+    ap.add_argument("--rotate", type=int, default=12,
+                    help="the timed region rotates through this many DISTINCT resident input batches (and as many output sets as "
+                         "there are lanes), so that nothing a step reads or writes is still in the 256-MiB Infinity Cache from the "
+                         "previous use (VERDICT r04 weak #5); 1 = the same batch every step, which is also measured and reported "
+                         "as `same_batch`")
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4 per priority)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
@@ -375,6 +386,8 @@ def main():
     # GPU, expanded on the device from the 65 MB of codes every rank maps from /dev/shm.  The LIBRARY's default for a rank
     # of a multi-process job is the compact form (65 MB, K-DESC 5 us slower per 64 frames); ORBFE_TRIG_TABLE=1 measures it.
     os.environ.setdefault("ORBFE_TRIG_TABLE", "2")
+    if args.hw_queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)  # (read by the HIP runtime when it starts: before torch is imported)
 
     import torch
     import torch.distributed as dist
@@ -418,8 +431,15 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ex.set_stream(stream.cuda_stream)
-    ex.set_lanes(args.lanes)
+    lane_mode = pkg.binding.LANES_SPLIT if (args.lane_mode == "split" and args.lanes == 2) else pkg.binding.LANES_BATCH
+    ex.set_lanes(args.lanes, lane_mode)
     cap = ex.max_keypoints(H, W)
+    # Rotating inputs: R distinct resident batches -- batch j is batch 0 with every frame shifted cyclically
+    # by (7 j, 13 j) pixels, made on the device: other bytes at other addresses, the same corner statistics -- so that a step's
+    # images, pyramids and outputs have been pushed out of the 256-MiB Infinity Cache by the steps in between.
+    R = max(1, args.rotate)
+    d_rot = [d_img] + [torch.roll(d_img, shifts=(7 * j, 13 * j), dims=(1, 2)).contiguous() for j in range(1, R)]
+    rot_on = [True]
     # two slab pairs: the all-gather of batch i (process group's stream) overlaps the extraction of batch i+1
     pipe = PipelinedExchange(B, cap, dev, world, rank)
     d_desc = pipe.x[0].desc_view()
@@ -427,6 +447,10 @@ def main():
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
     lap = (0, 1000)  # mono protocol, src/Frame.cc:306
+    # batch lanes: calls in flight together need output sets of their own (include/orbfe.h) -- a ring of `lanes` sets
+    nring = max(args.lanes, 1)
+    ring = [(torch.zeros((B, cap, 7), dtype=torch.float32, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+             torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(nring)]
 
     # N > 1 (or the one-GPU rehearsal): the sharded extraction + exchange behind the C ABI (include/orbfe_mc.h).  The id of
     # the RCCL communicator travels through torch.distributed's store; if the handle cannot be made on EVERY rank the run
@@ -463,13 +487,23 @@ def main():
     torch.cuda.synchronize()
     counter = [0]
 
+    used = []  # the input batch of every step since the last reset (the keypoints of a region = sum of its batches' counts)
+
     def step():
         k = counter[0] % (1 + len(extra))
+        j = (counter[0] % R) if rot_on[0] else 0
+        d_img = d_rot[j]
+        used.append(j)
         counter[0] += 1
         if k > 0:
             e2, _, k2, de2, n2, m2 = extra[k - 1]
             e2.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, k2.data_ptr(), de2.data_ptr(), cap,
                                     n2.data_ptr(), m2.data_ptr())
+            return
+        if not dist.is_initialized():  # one GPU, no exchange: the ring of output sets (one per lane)
+            o = ring[counter[0] % nring]
+            ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, o[0].data_ptr(), o[1].data_ptr(), cap,
+                                    o[2].data_ptr(), o[3].data_ptr())
             return
         if mc is not None:
             # C ABI: extraction into the next slab + ncclAllGather on the library's side stream; two batches in flight
@@ -513,11 +547,40 @@ def main():
 
     settle_steps = 8 * settle_together(args.settle, eight_steps, world, dev)
     barrier()
+    # keypoints of every input batch (one plain extraction each, outside every clock)
+    kp_of = []
+    for j in range(R):
+        ex.extract_batch_device(d_rot[j].data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), d_mono.data_ptr())
+        ex.sync()
+        kp_of.append(int(d_n.sum().item()))
+    barrier()
+    # `same_batch` (round 4's measurement, reported beside `value`): the same step on ONE batch, cache-resident between steps
+    same_batch = None
+    if R > 1:
+        rot_on[0] = False
+        for _ in range(8):
+            step()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        ts = time.perf_counter() - ts
+        same_batch = {"ms_per_step": 1e3 * ts / args.steps, "value_this_rank": kp_of[0] * args.steps / ts, "unit": "keypoints/s",
+                      "note": "every step re-reads ONE resident batch (images + pyramids + outputs < 256 MiB: mostly Infinity "
+                              "Cache hits); `value` rotates through %d batches" % R}
+        rot_on[0] = True
+        for _ in range(8):
+            step()
+        barrier()
+    del used[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    kp_timed = sum(kp_of[j] for j in used)
     # Per-kernel launch durations for `roofline`: hipEvents between the kernels on the stream they run on, in a SECOND
     # region of the same run with ONE lane (orbfe_set_lanes(1)), at least 60 steps, every event_every-th of them recording
     # one set of stage events.  With two lanes the kernels of the two half-batches overlap on the GPU, so a launch has a
@@ -534,7 +597,7 @@ def main():
     one_lane_ms = 1e3 * (time.perf_counter() - t1l) / roof_steps
     stage_ms = ex.stage_ms()  # hipEvent times averaged over the sampled steps
     ex.profile(False)
-    ex.set_lanes(args.lanes)
+    ex.set_lanes(args.lanes, lane_mode)
     barrier()
     # Not part of `value`: the same step K more times with one event per step boundary on the stream (an event record
     # costs ~3.5 us, which is why the timed region above carries none): the distribution a single average hides.
@@ -550,7 +613,8 @@ def main():
         per = np.sort(np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nd)]))
         step_dist = {"steps": nd, "min_ms": float(per[0]), "p50_ms": float(per[nd // 2]), "p90_ms": float(per[(9 * nd) // 10]),
                      "max_ms": float(per[-1]), "note": "hipEvent between consecutive steps on the extractor's stream; each "
-                     "step carries one event record (~3.5 us), so these read slightly above ms_per_step"}
+                     "step carries one event record (~3.5 us), so these read slightly above ms_per_step (with batch lanes the "
+                     "context's stream only carries the ordering: an event then marks the end of a step's pyramid kernel)"}
 
     # Not part of `value`: the step followed by the consumer of the exchanged descriptors -- cross-camera matching,
     # sharded by query frame: knn-2 of each of this rank's frames against the next camera of the ring
@@ -593,6 +657,7 @@ def main():
                 ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), x.desc_view().data_ptr(),
                                         cap, x.count_view().data_ptr(), d_mono.data_ptr())
                 k = pipe.i % len(pipe.x)
+                ex.lanes_join()  # (the copy below runs on the context's stream: behind the lane that holds this batch)
                 pipe.submit()  # world 1 without a process group: the local copy into the gathered buffer
                 if prev[0] is not None:
                     kp, xp = prev[0]
@@ -666,7 +731,7 @@ def main():
         pipelined = {"contexts": 2, "lanes_per_context": 1, "ms_per_step": 1e3 * tp / args.steps,
                      "value": float(d_n.sum().item()) * args.steps / tp, "unit": "keypoints/s"}
         e2.close()
-        ex.set_lanes(args.lanes)
+        ex.set_lanes(args.lanes, lane_mode)
 
     # Also not part of `value`: BASELINE configs[1] read literally -- ONE resident frame per call (what a monocular
     # tracker issues), the latency-bound end of the same pipeline.
@@ -680,23 +745,27 @@ def main():
         def step1():
             ex.extract_batch_device(d_img.data_ptr(), 1, H, W, W, H * W, lap, k1.data_ptr(), de1.data_ptr(), cap,
                                     n1.data_ptr(), m1.data_ptr())
-        for _ in range(20):
-            step1()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step1()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter() - t1
+
+        def timed1():
+            for _ in range(20):
+                step1()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        ex.set_lanes(1)  # ms_per_frame is the one-stream figure (calls back to back on one stream: the chain of four kernels)
+        t1 = timed1()
         single = {"frames_per_call": 1, "ms_per_frame": 1e3 * t1 / args.steps,
                   "value": float(n1.item()) * args.steps / t1, "unit": "keypoints/s"}
+        if args.lanes > 1:  # ... and the same calls dealt to the lanes (frames of several cameras / trackers in flight together)
+            ex.set_lanes(args.lanes, lane_mode)
+            tl = timed1()
+            single["ms_per_frame_lanes"] = 1e3 * tl / args.steps
+            single["lanes"] = args.lanes
 
-    if mc is not None:  # the counts of this rank's batch (the slabs belong to the library): one plain extraction, same frames
-        barrier()
-        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                d_n.data_ptr(), d_mono.data_ptr())
-        torch.cuda.synchronize()
-    n_local = int(d_n.sum().item())
+    n_local = kp_timed / max(args.steps, 1)  # keypoints of this rank's average step
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     cnt = torch.tensor([n_local], dtype=torch.float64, device=dev)
     if world > 1:
@@ -757,7 +826,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "keypoints+descriptors/sec on 752x480x8-level pyramid",
+            "metric": "keypoints+descriptors/sec on %dx%dx8-level pyramid" % (W, H),
             "value": kp_per_step * args.steps / dt,
             "unit": "keypoints/s",
             "n_gpus": world,
@@ -772,9 +841,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%dx%d grayscale, 8-level pyramid, nFeatures=%d, FAST 20/7, %d frames/GPU/step "
-                            "resident in HBM, outputs left in HBM (%s); the host-pointer rate of the same workload "
-                            "(H2D + D2H inside the clock) is `boundary_value`"
-                            % (W, H, args.nfeatures, B, ("BASELINE configs[3]: 64 frames in total, sharded over the ranks" if not batch_given
+                            "resident in HBM, rotating %d distinct input batches (%.0f MiB of images, %.0f MiB of pyramids and "
+                            "outputs per lane touched between two uses of a batch), outputs left in HBM (%s); the "
+                            "host-pointer rate of the same workload (H2D + D2H inside the clock) is `boundary_value`"
+                            % (W, H, args.nfeatures, B, R, R * B * H * W / 2.0 ** 20,
+                               B * (3.096 * 1.4 * H * W + cap * 60) / 2.0 ** 20, ("BASELINE configs[3]: 64 frames in total, sharded over the ranks" if not batch_given
                                                          else "BASELINE configs[3]'s frame size, %d frames per GPU: the shard one of %d "
                                                          "ranks runs" % (B, max(64 // B, 1)))
                                if args.config == "c4" else "BASELINE configs[1] batched"),
@@ -786,9 +857,14 @@ def main():
                                    os.environ.get("ORBFE_TRIG_TABLE", ""), os.environ.get("ORBFE_TRIG_TABLE", "")),
                 "contexts": 1 + len(extra),
                 "lanes": args.lanes,
-                "lanes_note": ("two half-batches per step on two streams of the one extractor context (orbfe_set_lanes): "
-                               "identical outputs, complete when the timed region's closing synchronisation returns"
-                               if args.lanes == 2 else "one stream"),
+                "lane_mode": args.lane_mode if args.lanes > 1 else None,
+                "rotate": R,
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "lanes_note": (("whole batches dealt round-robin to %d streams of the one extractor context (orbfe_set_lanes), a "
+                                "ring of %d output sets" % (args.lanes, nring) if lane_mode == pkg.binding.LANES_BATCH else
+                                "two half-batches per step on two streams of the one extractor context (orbfe_set_lane_mode "
+                                "SPLIT)") + ": identical outputs, complete when the timed region's closing synchronisation returns"
+                               if args.lanes >= 2 else "one stream"),
                 "exchange": (("1 ncclAllGather of descriptor slabs per step issued by liborbfe.so (orbfe_mc_extract_exchange_"
                               "submit / _wait) on its own stream, overlapped with the next step's extraction" if mc is not None
                               else "1 all-gather of descriptor slabs per step through torch.distributed, overlapped with the "
@@ -832,6 +908,8 @@ def main():
                                "frac": sum(abytes.values()) * B / dt * args.steps / 1e9 / HBM_PEAK_GBPS},
             },
         }
+        if same_batch is not None:
+            out["same_batch"] = same_batch
         if pipelined is not None:
             out["pipelined"] = pipelined
         if single is not None:

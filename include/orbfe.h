@@ -172,27 +172,46 @@ int orbfe_host_unregister(void* p);
 int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int rows, int cols, size_t pitch,
                                size_t img_stride_bytes, int lap0, int lap1, orbfe_kp* d_kps, uint8_t* d_desc,
                                int cap_per_img, int32_t* d_n_out, int32_t* d_mono_out);
-/* Two lanes (round 4; the reference's own concurrency on this path is two extractors on two threads, src/Frame.cc:119-122).
- * With lanes = 2 (orbfe_set_lanes, or ORBFE_LANES=2 in the environment when the context is created; default 1) a call of
- * orbfe_extract_batch_device with >= 8 images runs as two half-batches: images [0, h) on the context's stream, [h, nimg) on
- * a second stream the context owns, with no event between the two inside a call.  The latency-bound quadtree kernel and
- * the tails of every kernel of one half then run beside the throughput-bound kernels of the other half, and consecutive calls
- * keep both lanes busy (64 x 752x480: 0.19 -> ~0.17 ms per batch).  Results are bit-identical.  What changes is ORDERING:
- * after such a call the second half's outputs are NOT yet ordered on the context's stream.  They are after any of
- *   orbfe_lanes_join(ctx)            -- the context's stream waits for the second lane (no host wait; a few us on the stream),
- *   orbfe_get_device_outputs(ctx, …) -- joins, then marks the stream (matcher calls of this library order themselves after it),
- *   orbfe_sync(ctx)                  -- waits for both lanes on the host,
+/* Lanes (the reference's own concurrency on this path is two extractors on two threads, src/Frame.cc:119-122; a rig or a
+ * multi-GPU shard has more).  orbfe_set_lanes(ctx, n) with n = 2..ORBFE_MAX_LANES (or ORBFE_LANES=n in the environment when the
+ * context is created; default 1) lets the context keep up to n device-pointer batches in flight on streams it owns.
+ *
+ * ORBFE_LANES_BATCH (default mode, round 5): every orbfe_extract_batch_device call goes, WHOLE, to the next lane round-robin.
+ * Each lane has its own intermediate buffers (pyramids, candidates, quadtree keys, status header), so the kernels of
+ * DIFFERENT batches overlap: the latency-bound chain of a small batch (8 x 1280x720 is four kernels of 15-30 us each on a
+ * nearly empty chip) runs beside the chains of its neighbours -- 0.084 ms per batch with one lane, 0.05 with two, 0.043-0.045
+ * with three or four.  The context's stream carries no kernels in this mode, only ordering:
+ *   - a lane waits for the point of the call on the context's stream: images written on that stream before the call are
+ *     complete when the lane reads them;
+ *   - the context's stream waits for the lane's pyramid kernel, the only reader of the caller's images: a caller may refill
+ *     the SAME image buffer on the context's stream right after the call returns (stream order, exactly as with one lane);
+ *   - OUTPUTS are not ordered on the context's stream until a join (below), and calls that are in flight together must be
+ *     given different output arrays (n lanes: a ring of n output sets; the call n calls ago on the same lane has finished
+ *     before the lane writes again -- a lane is a stream).
+ * ORBFE_LANES_SPLIT (round 4; n = 2 only): a call with >= 8 images (ORBFE_LANES_MIN) runs as two half-batches, images [0, h)
+ * on the context's stream and [h, nimg) on a second stream, no event between the two inside a call (64 x 752x480: 0.19 ->
+ * ~0.17 ms per batch).  Kept for A/B; for small batches it splits what is already too small.
+ *
+ * Results are bit-identical in every mode.  What changes is ORDERING: after a call the outputs are NOT yet ordered on the
+ * context's stream.  They are after any of
+ *   orbfe_lanes_join(ctx)            -- the context's stream waits for every lane (no host wait; a few us on the stream),
+ *   orbfe_get_device_outputs(ctx, ...) -- joins, then marks the stream (matcher calls of this library order themselves after it),
+ *   orbfe_sync(ctx)                  -- waits for all lanes on the host,
  * and every other entry point of this header that reads the context's results or buffers joins by itself (orbfe_get_level,
- * the stereo-matching calls, the host-pointer extract calls, orbfe_mc_*).  A caller that launches its OWN kernels on
- * orbfe_get_stream()'s stream right behind orbfe_extract_batch_device must call orbfe_lanes_join first -- which is why two lanes
- * are opt-in.  The second lane waits for the point of the call on the context's stream, so inputs written on that stream
- * before the call are complete when either half reads them.  Host-pointer calls and batches below 8 images (ORBFE_LANES_MIN) use one lane. */
-int orbfe_set_lanes(orbfe_ctx*, int lanes /* 1 or 2 */);
+ * the stereo-matching calls, the host-pointer extract calls, orbfe_mc_*; "the last call" they refer to is the last call
+ * whatever lane it ran on).  A caller that launches its OWN kernels on orbfe_get_stream()'s stream right behind
+ * orbfe_extract_batch_device must call orbfe_lanes_join first -- which is why lanes are opt-in.  Host-pointer calls use one
+ * lane (orbfe_extract_stereo_pair_submit keeps several stereo frames in flight by itself). */
+#define ORBFE_MAX_LANES 4
+#define ORBFE_LANES_BATCH 0
+#define ORBFE_LANES_SPLIT 1
+int orbfe_set_lanes(orbfe_ctx*, int lanes /* 1 .. ORBFE_MAX_LANES */);
+int orbfe_set_lane_mode(orbfe_ctx*, int mode /* ORBFE_LANES_BATCH | ORBFE_LANES_SPLIT (two lanes only) */);
 int orbfe_lanes_join(orbfe_ctx*);
 /* For a consumer on a stream of its own that must not hold the context's stream back: records `hip_event` (a hipEvent_t)
- * on the second lane when that lane holds work the context's stream has not been ordered after, and returns 1 (0: nothing
- * pending, the event was not touched).  The consumer waits for this event AND for one it records on orbfe_get_stream()'s
- * stream (what orbfe_mc_extract_exchange_submit does for its collective). */
+ * behind the LAST call's work on the lane that holds it, when the context's stream has not been ordered after that lane, and
+ * returns 1 (0: nothing pending, the event was not touched).  The consumer waits for this event AND for one it records on
+ * orbfe_get_stream()'s stream (what orbfe_mc_extract_exchange_submit does for its collective). */
 int orbfe_lanes_record(orbfe_ctx*, void* hip_event);
 /* Waits for the context's stream and returns ORBFE_ERR_STATE when a kernel of the finished work raised the device
  * error word (a quadtree list overflow, which the bounds of SURVEY.md A.9 rule out): the asynchronous call above

@@ -17,6 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 ERR_ARGS, ERR_NODEV, ERR_STATE, ERR_IMAGE_SMALL, ERR_IMAGE_LARGE, ERR_NFEATURES = -2, -3, -4, -5, -6, -7
 TRIG_LIBM, TRIG_CR, TRIG_LIBM_HOSTCHECK = 0, 1, 2
+LANES_BATCH, LANES_SPLIT, MAX_LANES = 0, 1, 4  # ORBFE_LANES_BATCH / _SPLIT / ORBFE_MAX_LANES (include/orbfe.h)
 STAGES = ("pyramid", "fast", "octree", "pack", "desc", "trigfix")
 
 
@@ -215,6 +216,7 @@ def lib():
         L.orbfe_search_tri_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbfe_set_lanes.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_lanes_join.argtypes = [C.c_void_p]
+        L.orbfe_set_lane_mode.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_lanes_record.argtypes = [C.c_void_p, C.c_void_p]
         L.orbfe_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_max_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -309,7 +311,7 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
            "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
            "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
-           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_lanes_join", "orbfe_lanes_record",
+           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_set_lane_mode", "orbfe_lanes_join", "orbfe_lanes_record",
            "orbfe_keyframe_create", "orbfe_keyframe_set_mask", "orbfe_keyframe_destroy", "orbfe_search_bow_keyframes",
            "orbfe_search_tri_batch"]
 
@@ -528,12 +530,16 @@ class ORBextractor:
     def sync(self):
         _chk(self.L.orbfe_sync(self.h), "orbfe_sync")
 
-    def set_lanes(self, lanes):
-        """orbfe_set_lanes: 2 = device-pointer batches of >= 16 images run as two half-batches on two streams (see orbfe.h)."""
+    def set_lanes(self, lanes, mode=None):
+        """orbfe_set_lanes: up to `lanes` (1..4) device-pointer batches in flight on streams the context owns; mode
+        LANES_BATCH (default: whole batches round-robin) or LANES_SPLIT (two half-batches of every call of >= 8 images; two
+        lanes only).  See include/orbfe.h for the ordering rules."""
         _chk(self.L.orbfe_set_lanes(self.h, int(lanes)), "orbfe_set_lanes")
+        if mode is not None:
+            _chk(self.L.orbfe_set_lane_mode(self.h, int(mode)), "orbfe_set_lane_mode")
 
     def lanes_join(self):
-        """orbfe_lanes_join: the context's stream waits for the second lane (no host wait)."""
+        """orbfe_lanes_join: the context's stream waits for every lane (no host wait)."""
         _chk(self.L.orbfe_lanes_join(self.h), "orbfe_lanes_join")
 
     # -- getters (include/ORBextractor.h:61-83) -------------------------------------

@@ -204,6 +204,41 @@ struct orbfe_ctx : orbfe_geom_state {
     bool lastLanes = false;      // the last batch ran on two lanes
     bool lanePending = false;    // the second lane holds work the context's stream has not been ordered after
     int laneSplit = 0, laneImgs = 0; // the split of the last two-lane call (a call with another split joins first)
+    // Batch lanes (round 5; the default lane mode, orbfe_set_lanes(ctx, 2..4)): WHOLE device-pointer batches are dealt
+    // round-robin to streams the context owns, so that kernels of DIFFERENT batches overlap -- the regime below 16 frames per
+    // call (the per-rank shard of BASELINE configs[3], a stereo pair, a single frame) is a chain of four latency-bound kernels,
+    // and two half-batches of one small call (the round-4 form, laneMode 1) only make every link of that chain smaller.
+    // Measured with separate contexts first (profiles/r05_lanes_probe.txt: 8 x 1280x720, 0.084 ms per batch on one stream,
+    // 0.052 / 0.045 / 0.043 with 2 / 3 / 4 contexts).  Each lane owns the per-batch device state (LaneBufs: the members of the same
+    // names below, swapped into the context for the lane's turn, so every other entry point keeps reading "the last batch" from
+    // the context's own members); the size-dependent tables, taps, pattern and lapping table are shared and read-only while
+    // lanes are busy.  The context's stream carries no kernels in this mode, only the ordering: a lane waits for the point of
+    // the call on it (inputs ready), it waits for the lane's K-PYR (inputs consumed: a caller may refill the images in stream
+    // order, as with one lane), and for whole lanes only at the joins.
+    int laneMode = 0;            // 0 = whole batches per lane, 1 = two half-batches of one call (lanes == 2 only; ORBFE_LANE_MODE=split)
+    struct LaneBufs {
+        DevBuf<uint8_t> d_pyr;
+        DevBuf<uint32_t> d_cand, d_keys, d_lvlKp, d_lvlPre;
+        DevBuf<uint16_t> d_keyNode;
+        DevBuf<int32_t> d_cellCount, d_lvlCount, d_destMap;
+        DevBuf<int4> d_fix;
+        DevBuf<int> d_qtScratch;
+        PinBuf<int4> h_fix, h_fixAB;
+        int capImgs = 0, capKp = 0;
+    };
+    struct Lane {
+        LaneBufs parked;          // this lane's buffers while another lane's are in the context (empty while its own are)
+        hipStream_t stream = nullptr;
+        hipEvent_t evJoin = nullptr, evRead = nullptr;
+        bool pending = false;     // holds work the context's stream has not been ordered after
+        int imgs = 0;             // images of its last batch (orbfe_sync reads that many ... one status header)
+    } lane[ORBFE_MAX_LANES];
+    int curSet = 0;               // the lane whose buffers the context's members hold
+    int laneNext = 0, laneLast = -1; // lane of the next whole-batch call / of the last one (-1: the last call ran on the context's stream)
+    hipEvent_t evBatchFork = nullptr;
+    bool inputGuard = true;       // ORBFE_LANES_INPUT_GUARD=0 (A/B): the context's stream does not wait for a lane's K-PYR
+    hipStream_t runStream = nullptr; // run_device / ensure_capacity: the stream of the call being queued (nullptr: `stream`)
+    hipEvent_t guardEv = nullptr;    // run_device records it behind K-PYR (the call's last reader of the caller's images)
 
     // device state
     int capImgs = 0, capKp = 0; // allocated batch size / per-image keypoint capacity
@@ -302,10 +337,20 @@ struct orbfe_ctx : orbfe_geom_state {
 
 namespace {
 
-// Orders the context's stream after whatever the second lane still has in flight (one-way wait: a few us on the stream).
+inline hipStream_t run_stream(const orbfe_ctx* c) { return c->runStream ? c->runStream : c->stream; }
+
+// Orders the context's stream after whatever the lanes still have in flight (one-way waits: a few us on the stream).
 int lane_join(orbfe_ctx* c)
 {
-    if (!c || !c->lanePending) return 0;
+    if (!c) return 0;
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) {
+        orbfe_ctx::Lane& L = c->lane[k];
+        if (!L.pending) continue;
+        HIP_TRY(hipEventRecord(L.evJoin, L.stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, L.evJoin, 0));
+        L.pending = false;
+    }
+    if (!c->lanePending) return 0;
     HIP_TRY(hipEventRecord(c->evLaneJoin, c->laneStream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->evLaneJoin, 0));
     c->lanePending = false;
@@ -314,8 +359,83 @@ int lane_join(orbfe_ctx* c)
 // ... and the host: before buffers are freed / tables replaced / a stream is given up
 void lane_quiesce(orbfe_ctx* c)
 {
-    if (c && c->laneStream) (void)hipStreamSynchronize(c->laneStream);
-    if (c) c->lanePending = false;
+    if (!c) return;
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) {
+        if (c->lane[k].stream) (void)hipStreamSynchronize(c->lane[k].stream);
+        c->lane[k].pending = false;
+    }
+    if (c->laneStream) (void)hipStreamSynchronize(c->laneStream);
+    c->lanePending = false;
+}
+bool lanes_busy(const orbfe_ctx* c)
+{
+    bool any = c->lanePending;
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) any = any || c->lane[k].pending;
+    return any;
+}
+// The per-batch buffers of the context <-> a parking place
+void lane_swap_bufs(orbfe_ctx* c, orbfe_ctx::LaneBufs& b)
+{
+    std::swap(c->d_pyr, b.d_pyr);
+    std::swap(c->d_cand, b.d_cand);
+    std::swap(c->d_keys, b.d_keys);
+    std::swap(c->d_lvlKp, b.d_lvlKp);
+    std::swap(c->d_lvlPre, b.d_lvlPre);
+    std::swap(c->d_keyNode, b.d_keyNode);
+    std::swap(c->d_cellCount, b.d_cellCount);
+    std::swap(c->d_lvlCount, b.d_lvlCount);
+    std::swap(c->d_destMap, b.d_destMap);
+    std::swap(c->d_fix, b.d_fix);
+    std::swap(c->d_qtScratch, b.d_qtScratch);
+    std::swap(c->h_fix, b.h_fix);
+    std::swap(c->h_fixAB, b.h_fixAB);
+    std::swap(c->capImgs, b.capImgs);
+    std::swap(c->capKp, b.capKp);
+}
+// Lane k's buffers into the context (the current ones are parked with their lane)
+void lane_select(orbfe_ctx* c, int k)
+{
+    if (k == c->curSet) return;
+    lane_swap_bufs(c, c->lane[c->curSet].parked);
+    lane_swap_bufs(c, c->lane[k].parked);
+    c->curSet = k;
+}
+// (the per-image strides changed: every lane re-checks its buffers' sizes)
+void lanes_invalidate_caps(orbfe_ctx* c)
+{
+    c->capImgs = 0;
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) c->lane[k].parked.capImgs = 0;
+}
+// Streams and events of the batch lanes.  Streams of ONE priority share four hardware queues (GPU_MAX_HW_QUEUES) with every other
+// stream of the process, and two lanes in one queue serialise (three contexts on normal-priority streams: 0.063 ms per
+// 8 x 1280x720 batch against 0.045 with GPU_MAX_HW_QUEUES=8, profiles/r05_lanes_probe.txt); priorities have queues of their own,
+// so the lanes are spread over the priorities first: normal, lowest, highest, normal (ORBFE_LANE_PRIOS="0,1,-1,0" overrides).
+int batch_lane_setup(orbfe_ctx* c)
+{
+    int prios[ORBFE_MAX_LANES] = {0, 1, -1, 0};
+    if (const char* e = getenv("ORBFE_LANE_PRIOS")) {
+        int k = 0;
+        for (const char* p = e; *p && k < ORBFE_MAX_LANES; k++) {
+            prios[k] = atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+    }
+    int least = 0, greatest = 0;
+    const bool ranged = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    for (int k = 0; k < c->lanes && k < ORBFE_MAX_LANES; k++) {
+        orbfe_ctx::Lane& L = c->lane[k];
+        if (L.stream) continue;
+        if (!(ranged && prios[k] != 0 &&
+              hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prios[k] < 0 ? greatest : least) == hipSuccess)) {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&L.evJoin, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.evRead, hipEventDisableTiming));
+    }
+    if (!c->evBatchFork) HIP_TRY(hipEventCreateWithFlags(&c->evBatchFork, hipEventDisableTiming));
+    return 0;
 }
 int lane_setup(orbfe_ctx* c)
 {
@@ -735,7 +855,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
             if (c->qtLdsBytes > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)c->qtLdsBytes));
-            c->capImgs = 0; // the per-image strides changed: re-check every buffer's size
+            lanes_invalidate_caps(c); // the per-image strides changed: re-check every buffer's size
             return 0;
         }
     if (!c->lg.empty()) { // keep the current size's tables for later
@@ -918,7 +1038,7 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     c->rows = rows;
     c->cols = cols;
     c->pyrTile = tile;
-    c->capImgs = 0; // per-image strides changed: force re-allocation
+    lanes_invalidate_caps(c); // per-image strides changed: force re-allocation
     if (getenv("ORBFE_VERBOSE"))
         fprintf(stderr,
                 "orbfe: %dx%d: pyramid %zu B/img, %d FAST cells; LDS per workgroup: k_pyr_fused %zu B (%dx%d tiles of "
@@ -949,11 +1069,14 @@ int ensure_capacity(orbfe_ctx* c, int nimg, int capKp)
         const size_t before = c->d_lvlCount.n;
         if ((r = c->d_lvlCount.ensure(B * ORBFE_MAX_LEVELS)) < 0) return r;
         if (c->d_lvlCount.n != before)
-            HIP_TRY(hipMemsetAsync(c->d_lvlCount.p, 0, c->d_lvlCount.n * sizeof(int32_t), c->stream)); // (ordered before K-QT)
+            HIP_TRY(hipMemsetAsync(c->d_lvlCount.p, 0, c->d_lvlCount.n * sizeof(int32_t), run_stream(c))); // (ordered before K-QT)
     }
     if (!c->qtBig.empty() && (r = c->d_qtScratch.ensure(B * c->qtBig.size() * c->qtScratchStride)) < 0) return r;
-    if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
-    c->lapDevCount = 0; // possibly a new buffer
+    {
+        const int32_t* const before = c->d_lap.p; // (shared by the lanes: read-only while any of them is busy)
+        if ((r = c->d_lap.ensure(B * 2)) < 0) return r;
+        if (c->d_lap.p != before) c->lapDevCount = 0; // a new buffer
+    }
     if ((r = c->d_destMap.ensure(B * std::max(K, c->kpStride))) < 0) return r;
     if ((r = c->d_fix.ensure(B * K + 1)) < 0) return r;
     if ((r = c->h_fix.ensure(B * K + 1)) < 0) return r;
@@ -1351,12 +1474,13 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if (capPerImg < c->maxKp || capPerImg > 65535 || nimg > 32767) return ORBFE_ERR_ARGS; // fix-list packing
     if ((r = ensure_capacity(c, nimg, capPerImg)) < 0) return r;
-    hipStream_t s = c->stream;
+    hipStream_t s = run_stream(c); // (a batch lane's stream when orbfe_extract_batch_device deals the call to one)
     const int nl = c->nlevels;
     // ORBFE_TRIG_LIBM: with the libm table the device reproduces host cosf/sinf by itself; without it the
     // fragile keypoints are listed and checked on the host after the batch
     const TrigTabs trigTab = c->trigMode == ORBFE_TRIG_LIBM ? trig_table(c->device, s) : TrigTabs{nullptr, nullptr};
     const bool hostTrigCheck = c->trigMode != ORBFE_TRIG_CR && !trigTab.codes && !trigTab.full;
+    if (c->tapsDirty && lanes_busy(c)) lane_quiesce(c); // (the shared tap words are about to change under the other lanes' K-DESC)
     if (c->tapsDirty) { // 28 bytes, but a separate command on the stream: only when they changed
         const uint32_t t0 = (uint32_t)c->taps[0], t1 = (uint32_t)c->taps[1], t2 = (uint32_t)c->taps[2], t3 = (uint32_t)c->taps[3],
                        t4 = (uint32_t)c->taps[4], t5 = (uint32_t)c->taps[5], t6 = (uint32_t)c->taps[6];
@@ -1396,15 +1520,15 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     if (c->laneSplitPct > 0) { // ORBFE_LANE_SPLIT (tuning): per cent of the batch on the context's own stream
         laneSplit = std::min(nimg - 1, std::max(1, (nimg * c->laneSplitPct / 100 + 4) / 8 * 8));
     }
-    const bool useLanes = allowLanes && c->lanes == 2 && nimg >= c->lanesMin && c->pyrFused && !hostTrigCheck && !mirror && !d_errOut &&
-                          c->nStreams == 1;
+    const bool useLanes = allowLanes && c->lanes == 2 && c->laneMode == 1 && nimg >= c->lanesMin && c->pyrFused && !hostTrigCheck &&
+                          !mirror && !d_errOut && c->nStreams == 1;
     if (c->lanePending && !(useLanes && c->laneSplit == laneSplit && c->laneImgs == nimg)) {
         if ((r = lane_join(c)) < 0) return r; // another shape of work: first order this stream after the second lane
     }
     if (useLanes && (r = lane_setup(c)) < 0) return r;
     const bool kernelClearsHdr = c->pyrFused && !(c->nStreams > 1 && nimg > 1);
     if (!kernelClearsHdr) HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
-    c->recNow = !useLanes && c->profile && c->evReady && c->profSeen % c->profEvery == 0; // (stage events: one stream only)
+    c->recNow = !useLanes && !c->runStream && c->profile && c->evReady && c->profSeen % c->profEvery == 0; // (stage events: one stream only)
     rec(c, 0);
     // Sub-batches on separate streams (ORBFE_STREAMS > 1): the image pipelines are independent, so the
     // latency-bound stages of one sub-batch overlap with the issue-bound stages of another.  Stage
@@ -1450,6 +1574,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             }
         }
         if (nsub == 1) rec(c, 1);
+        if (c->guardEv && k == nsub - 1) HIP_TRY(hipEventRecord(c->guardEv, q)); // (the caller's images have been read)
         // K-FAST
         {
             // the image group is the grid's y coordinate (no division in the kernel); cell groups per XCD are powers of two
@@ -2260,7 +2385,9 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_MIRROR_MAX")) c->mirrorMaxImgs = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_SPIN")) c->spinWait = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
-    if (const char* e = getenv("ORBFE_LANES")) c->lanes = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("ORBFE_LANES")) c->lanes = std::min(ORBFE_MAX_LANES, std::max(1, atoi(e)));
+    if (const char* e = getenv("ORBFE_LANE_MODE")) c->laneMode = (!strcmp(e, "split") || atoi(e) == 1) && c->lanes <= 2 ? 1 : 0;
+    if (const char* e = getenv("ORBFE_LANES_INPUT_GUARD")) c->inputGuard = atoi(e) != 0;
     if (const char* e = getenv("ORBFE_LANES_MIN")) c->lanesMin = std::max(2, atoi(e));
     if (const char* e = getenv("ORBFE_LANE_SPLIT")) c->laneSplitPct = std::min(95, std::max(0, atoi(e)));
     if (c->nStreams > 1) {
@@ -2320,6 +2447,17 @@ void orbfe_destroy(orbfe_ctx* c)
     if (c->evLaneFork) (void)hipEventDestroy(c->evLaneFork);
     if (c->evLaneJoin) (void)hipEventDestroy(c->evLaneJoin);
     if (c->laneStream) (void)hipStreamDestroy(c->laneStream);
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) {
+        orbfe_ctx::Lane& L = c->lane[k];
+        orbfe_ctx::LaneBufs& b = L.parked; // (the current lane's buffers are the context's own members, released above)
+        b.d_pyr.release(); b.d_cand.release(); b.d_keys.release(); b.d_lvlKp.release(); b.d_lvlPre.release(); b.d_keyNode.release();
+        b.d_cellCount.release(); b.d_lvlCount.release(); b.d_destMap.release(); b.d_fix.release(); b.d_qtScratch.release();
+        b.h_fix.release(); b.h_fixAB.release();
+        if (L.evJoin) (void)hipEventDestroy(L.evJoin);
+        if (L.evRead) (void)hipEventDestroy(L.evRead);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->evBatchFork) (void)hipEventDestroy(c->evBatchFork);
     for (int k = 0; k < 8; k++) {
         if (c->sub[k]) (void)hipStreamDestroy(c->sub[k]);
         if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
@@ -2436,9 +2574,23 @@ int orbfe_sync(orbfe_ctx* c)
 {
     if (!c) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
+    bool laneErr = false;
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) { // batch lanes: the status header of every lane that held work
+        orbfe_ctx::Lane& L = c->lane[k];
+        if (!L.stream) continue;
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        const DevBuf<int4>& fx = k == c->curSet ? c->d_fix : L.parked.d_fix;
+        if (L.pending && fx.p && k != c->curSet) {
+            int4 h = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(&h, fx.p, sizeof(int4), hipMemcpyDeviceToHost));
+            laneErr = laneErr || h.y != 0;
+        }
+        L.pending = false;
+    }
     if (c->laneStream) HIP_TRY(hipStreamSynchronize(c->laneStream));
     c->lanePending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (laneErr) return ORBFE_ERR_STATE;
     if (c->d_fix.p && c->lastImgs > 0) { // the error word of the last batch (k_octree raises it, nothing else does)
         int r = c->h_fix.ensure(2);
         if (r < 0) return r;
@@ -2458,6 +2610,15 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     if (pitch < (size_t)cols) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
     int r;
+    // Batch lanes (orbfe_ctx::laneMode 0): this call goes, whole, to the next lane's stream with that lane's buffers
+    const bool batchLanes = c->lanes >= 2 && c->laneMode == 0 && !c->kb8On && c->nStreams == 1;
+    if (batchLanes) {
+        if ((r = batch_lane_setup(c)) < 0) return r;
+        if (c->laneNext >= c->lanes) c->laneNext = 0;
+        lane_select(c, c->laneNext);
+    } else if (lanes_busy(c) && !(c->lanes == 2 && c->laneMode == 1)) {
+        if ((r = lane_join(c)) < 0) return r; // a one-stream call behind lane calls
+    }
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if ((r = ensure_capacity(c, nimg, std::max(cap_per_img, c->maxKp))) < 0) return r;
     // The per-image lapping table only changes when the caller changes (lap0, lap1) or grows the batch: upload
@@ -2476,17 +2637,52 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
         c->lapDev1 = lap1;
         c->lapDevCount = nimg;
     }
+    if (batchLanes) {
+        orbfe_ctx::Lane& L = c->lane[c->laneNext];
+        // the lane starts no earlier than this point of the context's stream (inputs, tables); one-way
+        HIP_TRY(hipEventRecord(c->evBatchFork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(L.stream, c->evBatchFork, 0));
+        c->runStream = L.stream;
+        c->guardEv = c->inputGuard ? L.evRead : nullptr;
+        r = run_device(c, nimg, d_imgs, rows, cols, pitch, img_stride_bytes, c->d_lap.p, (float*)d_kps, d_desc, cap_per_img,
+                       d_n_out, d_mono_out);
+        c->runStream = nullptr;
+        c->guardEv = nullptr;
+        L.pending = true; // (also after an error: something may have been queued)
+        L.imgs = nimg;
+        c->laneLast = c->laneNext;
+        c->laneNext = (c->laneNext + 1) % c->lanes;
+        if (r < 0) return r;
+        // ... and whatever the caller queues on the context's stream after this call -- the next frame's upload into the same
+        // image buffer -- comes after the lane's K-PYR, the only reader of the images (stream order, as with one lane)
+        if (c->inputGuard) HIP_TRY(hipStreamWaitEvent(c->stream, L.evRead, 0));
+        return 0;
+    }
+    c->laneLast = -1;
     return run_device(c, nimg, d_imgs, rows, cols, pitch, img_stride_bytes, c->d_lap.p, (float*)d_kps, d_desc,
                       cap_per_img, d_n_out, d_mono_out, nullptr, nullptr, 0, /*allowLanes=*/true);
 }
 
 int orbfe_set_lanes(orbfe_ctx* c, int lanes)
 {
-    if (!c || (lanes != 1 && lanes != 2)) return ORBFE_ERR_ARGS;
+    if (!c || lanes < 1 || lanes > ORBFE_MAX_LANES) return ORBFE_ERR_ARGS;
     HIP_TRY(hipSetDevice(c->device));
     int r = lane_join(c);
     if (r < 0) return r;
     c->lanes = lanes;
+    if (lanes > 2) c->laneMode = 0; // (half-batches exist for two lanes only)
+    c->laneNext = 0;
+    return 0;
+}
+
+int orbfe_set_lane_mode(orbfe_ctx* c, int mode)
+{
+    if (!c || (mode != ORBFE_LANES_BATCH && mode != ORBFE_LANES_SPLIT)) return ORBFE_ERR_ARGS;
+    if (mode == ORBFE_LANES_SPLIT && c->lanes > 2) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = lane_join(c);
+    if (r < 0) return r;
+    c->laneMode = mode;
     return 0;
 }
 
@@ -2500,6 +2696,12 @@ int orbfe_lanes_join(orbfe_ctx* c)
 int orbfe_lanes_record(orbfe_ctx* c, void* hip_event)
 {
     if (!c || !hip_event) return ORBFE_ERR_ARGS;
+    if (c->laneLast >= 0) { // batch lanes: the last call's work is on its lane's stream
+        if (!c->lane[c->laneLast].pending) return 0;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipEventRecord((hipEvent_t)hip_event, c->lane[c->laneLast].stream));
+        return 1;
+    }
     if (!c->lanePending) return 0;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord((hipEvent_t)hip_event, c->laneStream));

@@ -36,6 +36,14 @@ KIND_CASES = [  # (name, rows, cols, seed, nfeatures, lap, kind)
     ("plateaus_376x240", 240, 376, 2033, 400, (50, 300), "plateaus"),
 ]
 
+# round 5: camera imagery (tests/natural.py): two photographs that ship inside scikit-learn, decoded once here, luma committed
+NATURAL_CASES = [  # (name, photograph, rows, cols, (oy, ox, flip), nfeatures, lap)
+    ("natural_china_640x427", "china", 427, 640, (0, 0, False), 1000, (0, 1000)),      # the photograph itself, mono protocol
+    ("natural_flower_640x427", "flower", 427, 640, (0, 0, False), 1200, (0, 0)),       # stereo protocol, dark low-texture frame
+    ("natural_china_752x480", "china", 480, 752, (200, 310, False), 1200, (120, 600)),  # EuRoC size, mirror-tiled, lapping range
+    ("natural_flower_1280x720", "flower", 720, 1280, (100, 500, True), 2000, (0, 1000)),  # C4 size, x > 1000 in the front block
+]
+
 WINDOW_CASES = [("proj_local_map", dict(seed=7101, mode=0, n=600, nq=500)),
                 ("proj_last_frame", dict(seed=7102, mode=1, n=600, nq=500, th=7.0, check_orientation=True)),
                 ("proj_rig", dict(seed=7103, mode=0, n=640, nq=520, Nleft=350, partners=True, th=3.0)),
@@ -60,11 +68,46 @@ def extractor_cases(cases):
         print(name, int(out["mono_libm"]), len(out["kps_libm"]))
 
 
+def natural_luma():
+    """Decode the two photographs (scikit-learn + Pillow, build container only) and commit their luma planes."""
+    from sklearn.datasets import load_sample_image
+    import natural
+    planes = {n: natural.rgb_to_luma(load_sample_image(n + ".jpg")) for n in natural.NAMES}
+    np.savez_compressed(natural.LUMA_FILE, **planes)
+    print("natural_luma", {n: (p.shape, hashlib.sha256(p.tobytes()).hexdigest()[:16]) for n, p in planes.items()})
+
+
+def natural_cases():
+    import natural
+    if not os.path.exists(natural.LUMA_FILE):
+        natural_luma()
+    for name, photo, rows, cols, (oy, ox, flip), nf, lap in NATURAL_CASES:
+        img = natural.frame(photo, rows, cols, oy, ox, flip)
+        out = {"image_sha256": np.frombuffer(hashlib.sha256(img.tobytes()).digest(), np.uint8)}
+        for mode, tag in ((O.TRIG_LIBM, "libm"), (O.TRIG_CR, "cr")):
+            ex = O.Extractor(nf, 1.2, 8, 20, 7, trig=mode)
+            mono, kps, desc = ex.extract(img, lap)
+            out["mono_" + tag] = np.int32(mono)
+            out["kps_" + tag] = kps
+            out["desc_" + tag] = desc
+            if tag == "libm":
+                out["ncand"] = np.array([len(ex.candidates(l)) for l in range(8)], np.int32)
+                out["nlevel"] = np.array([len(ex.level_keypoints(l)) for l in range(8)], np.int32)
+                out["level3"] = ex.level(3)
+                out["level7"] = ex.level(7)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, int(out["mono_libm"]), len(out["kps_libm"]), out["ncand"].tolist())
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "natural":  # only the fixtures added in round 5
+        natural_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "kinds":  # only the fixtures added in round 4
         extractor_cases(KIND_CASES)
         return
     extractor_cases([c + ("rects",) for c in CASES] + KIND_CASES)
+    natural_cases()
     # matcher fixture
     d1, d2, a1, a2 = MI.descriptor_sets(400, 380, 77)
     fv1, fv2 = MI.feature_vectors(d1, d2, 77)

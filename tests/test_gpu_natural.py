@@ -1,0 +1,111 @@
+"""GPU parity on camera imagery (VERDICT r04 missing #3 / next #2a): the two photographs of tests/natural.py -- native
+427 x 640, cut / mirror-tiled to 752 x 480 (EuRoC) and 1280 x 720 (C4) -- through the HIP extractor and the CPU oracle,
+every stage (padded pyramid bytes, FAST candidates per level, quadtree output per level, all KeyPoint fields, descriptors),
+both lapping modes, nFeatures 1000 / 1200 / 2000, batches, the stereo pair in one call, and knn-2 on photograph descriptors.
+Photographs differ from the synth.py frames where it matters here: 7 000 - 15 000 FAST candidates on level 0 (texture
+everywhere instead of rectangle corners), soft anti-aliased edges at every level, large dark low-contrast areas (flower)."""
+import numpy as np
+import pytest
+
+import natural
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def _same(kps, rkps, desc, rdesc):
+    assert len(kps) == len(rkps)
+    for f in FIELDS:
+        assert np.array_equal(kps[f], rkps[f]), f
+    assert np.array_equal(desc, rdesc)
+
+
+def _stagewise(pkg, oracle, img, nf, lap, ini=20, mn=7, trig=None):
+    trig_gpu, trig_ref = trig or (pkg.binding.TRIG_LIBM, oracle.TRIG_LIBM)
+    ex = pkg.ORBextractor(nf, 1.2, 8, ini, mn, trig=trig_gpu)
+    ref = oracle.Extractor(nf, 1.2, 8, ini, mn, trig=trig_ref)
+    try:
+        mono, kps, desc = ex(img, lap)
+        rmono, rkps, rdesc = ref.extract(img, lap, cap=8 * nf + 400)
+        for lvl in range(8):
+            assert np.array_equal(ex.image_pyramid_level(lvl), ref.level(lvl)), "pyramid level %d" % lvl
+            cx, cy, cs = ex.debug_candidates(lvl)
+            rc = ref.candidates(lvl)
+            assert len(cx) == len(rc), "candidate count level %d: %d vs %d" % (lvl, len(cx), len(rc))
+            assert np.array_equal(cx, rc["x"].astype(np.int32)) and np.array_equal(cy, rc["y"].astype(np.int32))
+            assert np.array_equal(cs, rc["response"].astype(np.int32))
+            kx, ky, ks = ex.debug_level_keypoints(lvl)
+            rk = ref.level_keypoints(lvl)
+            assert len(kx) == len(rk), "quadtree count level %d" % lvl
+            assert np.array_equal(kx + 16, rk["x"].astype(np.int32)) and np.array_equal(ky + 16, rk["y"].astype(np.int32))
+        assert mono == rmono
+        _same(kps, rkps, desc, rdesc)
+        return len(kps), [len(ref.candidates(l)) for l in range(8)]
+    finally:
+        ex.close()
+
+
+@pytest.mark.parametrize("photo", natural.NAMES)
+@pytest.mark.parametrize("hw,cut", [((427, 640), (0, 0, False)), ((480, 752), (37, 411, False)), ((720, 1280), (250, 90, True))])
+@pytest.mark.parametrize("nf,lap", [(1000, (0, 1000)), (1200, (0, 0)), (2000, (150, 520))])
+def test_photographs_every_stage(pkg, oracle, photo, hw, cut, nf, lap):
+    img = natural.frame(photo, hw[0], hw[1], *cut)
+    n, cands = _stagewise(pkg, oracle, img, nf, lap)
+    assert n >= 0.9 * nf  # a photograph fills the budget
+    if photo == "china":
+        assert cands[0] > 5000  # texture everywhere: an order of magnitude more candidates than the rectangle frames
+
+
+@pytest.mark.parametrize("photo", natural.NAMES)
+def test_photographs_other_trig_modes_and_thresholds(pkg, oracle, photo):
+    img = natural.frame(photo, 480, 752, 120, 700, photo == "flower")
+    for trig in ((pkg.binding.TRIG_CR, oracle.TRIG_CR), (pkg.binding.TRIG_LIBM_HOSTCHECK, oracle.TRIG_LIBM)):
+        _stagewise(pkg, oracle, img, 1200, (0, 0), trig=trig)
+    for ini, mn in ((40, 7), (12, 3), (60, 25)):
+        _stagewise(pkg, oracle, img, 1000, (0, 1000), ini, mn)
+
+
+def test_photograph_batches_two_lanes(pkg, oracle):
+    # 16 distinct cuts in one call (whole images per XCD; two lanes split it 8 + 8), device-pointer path included via the binding
+    imgs = [natural.random_frame(480, 752, 900 + i) for i in range(16)]
+    laps = [(0, 1000) if i % 3 else (100, 500) for i in range(16)]
+    ref = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    for lanes in (1, 2):
+        ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+        ex.set_lanes(lanes)
+        res = ex.extract_batch(imgs, laps)
+        for i, (mono, kps, desc) in enumerate(res):
+            rmono, rkps, rdesc = ref.extract(imgs[i], laps[i], cap=8400)
+            assert mono == rmono, i
+            _same(kps, rkps, desc, rdesc)
+        ex.close()
+
+
+def test_photograph_stereo_pair_and_knn2(pkg, oracle):
+    # two views 24 px apart: ComputeStereoMatches on photograph descriptors (bit-exact mvuRight / mvDepth), then knn-2
+    left, right = natural.stereo_pair("china", 480, 752, shift=24, oy=60, ox=100)
+    exl, exr = pkg.ORBextractor(1200, 1.2, 8, 20, 7), pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    rl, rr = oracle.Extractor(1200, 1.2, 8, 20, 7), oracle.Extractor(1200, 1.2, 8, 20, 7)
+    _, kl, dl = exl(left, (0, 0))
+    _, kr, dr = exr(right, (0, 0))
+    _, rkl, rdl = rl.extract(left, (0, 0))
+    _, rkr, rdr = rr.extract(right, (0, 0))
+    _same(kl, rkl, dl, rdl)
+    _same(kr, rkr, dr, rdr)
+    bf, b = 435.2 * 0.11, 0.11
+    u, d = pkg.compute_stereo_matches(exl, exr, kl, dl, kr, dr, bf, b)
+    ru, rd = oracle.compute_stereo_matches(rl, rr, rkl, rdl, rkr, rdr, bf, b)
+    assert np.array_equal(u, ru) and np.array_equal(d, rd)
+    assert int((u >= 0).sum()) > 200  # the scene is a plane at disparity 24: most keypoints find their partner
+    idx, dist = pkg.bfknn2(dl, dr)
+    ridx, rdist = oracle.bfknn2(rdl, rdr)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    exl.close()
+    exr.close()
