@@ -54,7 +54,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_LANES = 2
+DEFAULT_LANES = None  # by batch size: 3 lanes below 16 frames per step (a chain of latency-bound kernels per batch), else 2
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -249,6 +249,12 @@ def per_call_config(args, real_stdout):
                          {k: hb["stereo_pair"][k] for k in ("ms_per_pair_mean", "ms_per_pair_p50", "ms_per_pair_p99", "extract_ms_p50")},
                      "one_batched_call_then_resident_matching": {k: hb["stereo_pair_one_call"][k] for k in
                                                                  ("ms_per_pair_mean", "ms_per_pair_p50", "ms_per_pair_p99")}}
+        try:  # round 5: the same frames as a STREAM with 1..4 frames in flight on one context (orbfe_extract_stereo_pair_submit)
+            st = hostbench_mode("stream", rows, cols, 8, nf, 0)
+            protocols["frames_in_flight (orbfe_extract_stereo_pair_submit / _wait, sustained ms per frame)"] = {
+                "pinned": st["pinned"], "pageable": st["pageable"]}
+        except (SystemExit, Exception) as e:  # noqa: BLE001
+            protocols["frames_in_flight"] = {"error": str(e)}
         workload = ("EuRoC stereo pair per call: 2 x 752x480, nFeatures 1200, both extractions + Frame::ComputeStereoMatches on the "
                     "GPU, host images in, host keypoints / descriptors / mvuRight / mvDepth out (BASELINE configs[2])")
         matches = hb["stereo_pair"]["matches_per_pair"]
@@ -371,6 +377,11 @@ def main():
                          "there are lanes), so that nothing a step reads or writes is still in the 256-MiB Infinity Cache from the "
                          "previous use (VERDICT r04 weak #5); 1 = the same batch every step, which is also measured and reported "
                          "as `same_batch`")
+    ap.add_argument("--input-guard", type=int, choices=[0, 1], default=0,
+                    help="orbfe_set_lane_input_guard: 1 = after every call the context's stream waits for the lane's pyramid "
+                         "kernel so that the caller may refill the SAME image buffer in stream order (the library's default); "
+                         "0 = the images of calls in flight are never rewritten -- true of this bench, whose inputs are resident "
+                         "and rotate through --rotate buffers")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4 per priority)")
     ap.add_argument("--contexts", type=int, default=1,
@@ -418,6 +429,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
+    if args.lanes is None:
+        args.lanes = 3 if args.batch < 16 else 2
     B, H, W = args.batch, args.rows, args.cols
     imgs = bench_frames(H, W, B, rank)  # distinct frames per rank
     d_img = torch.from_numpy(imgs).to(dev)
@@ -433,6 +446,7 @@ def main():
     ex.set_stream(stream.cuda_stream)
     lane_mode = pkg.binding.LANES_SPLIT if (args.lane_mode == "split" and args.lanes == 2) else pkg.binding.LANES_BATCH
     ex.set_lanes(args.lanes, lane_mode)
+    ex.set_lane_input_guard(args.input_guard)
     cap = ex.max_keypoints(H, W)
     # Rotating inputs: R distinct resident batches -- batch j is batch 0 with every frame shifted cyclically
     # by (7 j, 13 j) pixels, made on the device: other bytes at other addresses, the same corner statistics -- so that a step's
@@ -545,9 +559,8 @@ def main():
             step()
         torch.cuda.synchronize()
 
-    settle_steps = 8 * settle_together(args.settle, eight_steps, world, dev)
-    barrier()
-    # keypoints of every input batch (one plain extraction each, outside every clock)
+    # keypoints of every input batch (one plain extraction each, outside every clock and BEFORE the settling: the host
+    # round trips of this loop let the clocks drop)
     kp_of = []
     for j in range(R):
         ex.extract_batch_device(d_rot[j].data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
@@ -557,10 +570,10 @@ def main():
     barrier()
     # `same_batch` (round 4's measurement, reported beside `value`): the same step on ONE batch, cache-resident between steps
     same_batch = None
+    settle_steps = 0
     if R > 1:
         rot_on[0] = False
-        for _ in range(8):
-            step()
+        settle_steps += 8 * settle_together(args.settle, eight_steps, world, dev)
         barrier()
         ts = time.perf_counter()
         for _ in range(args.steps):
@@ -571,9 +584,8 @@ def main():
                       "note": "every step re-reads ONE resident batch (images + pyramids + outputs < 256 MiB: mostly Infinity "
                               "Cache hits); `value` rotates through %d batches" % R}
         rot_on[0] = True
-        for _ in range(8):
-            step()
-        barrier()
+    settle_steps += 8 * settle_together(args.settle, eight_steps, world, dev)
+    barrier()
     del used[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -859,6 +871,7 @@ def main():
                 "lanes": args.lanes,
                 "lane_mode": args.lane_mode if args.lanes > 1 else None,
                 "rotate": R,
+                "input_guard": bool(args.input_guard),
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "lanes_note": (("whole batches dealt round-robin to %d streams of the one extractor context (orbfe_set_lanes), a "
                                 "ring of %d output sets" % (args.lanes, nring) if lane_mode == pkg.binding.LANES_BATCH else

@@ -208,6 +208,13 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
 int orbfe_set_lanes(orbfe_ctx*, int lanes /* 1 .. ORBFE_MAX_LANES */);
 int orbfe_set_lane_mode(orbfe_ctx*, int mode /* ORBFE_LANES_BATCH | ORBFE_LANES_SPLIT (two lanes only) */);
 int orbfe_lanes_join(orbfe_ctx*);
+/* Batch lanes, the input guard (on by default): after every call the context's stream waits for the lane's pyramid kernel, so
+ * that the caller may overwrite the call's images in stream order.  That wait chains the pyramid kernels of consecutive calls
+ * behind each other through two event hops (8 x 1280x720, three lanes: 0.055 ms per batch with the guard, 0.045 without).  A
+ * caller that never rewrites the images of a call that may still be in flight -- a ring of at least `lanes` + 1 input buffers,
+ * or images that stay resident -- switches it off: the images then belong to the library, like the outputs, until a join, an
+ * orbfe_sync, or until `lanes` later calls have been made and joined. */
+int orbfe_set_lane_input_guard(orbfe_ctx*, int on);
 /* For a consumer on a stream of its own that must not hold the context's stream back: records `hip_event` (a hipEvent_t)
  * behind the LAST call's work on the lane that holds it, when the context's stream has not been ordered after that lane, and
  * returns 1 (0: nothing pending, the event was not touched).  The consumer waits for this event AND for one it records on
@@ -290,6 +297,17 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
 int orbfe_extract_stereo_pair(orbfe_ctx*, const uint8_t* imgL, const uint8_t* imgR, int rows, int cols, size_t stride,
                               const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out,
                               float mb, float mbf, float* uRight, float* depth);
+/* Stereo frames IN FLIGHT (round 5): _submit queues the same work on the context's next lane (orbfe_set_lanes: its stream, its
+ * pyramids, its pinned result slab and completion word) and returns; _wait completes the OLDEST submitted frame, fills the
+ * arrays THAT _submit was given and returns its number of stereo matches.  Up to `lanes` frames are accepted before a _wait is
+ * due (ORBFE_ERR_STATE beyond that); the images and every output array of a frame belong to the library until its _wait
+ * returns.  A tracker that may run one frame behind -- or several trackers / cameras sharing a context -- gets 2-3 frames
+ * per latency of one (0.10 ms per EuRoC frame with the blocking call, see DESIGN.md 7.5 for the in-flight rates).  Not to
+ * be mixed with orbfe_extract_batch_submit while frames are in flight. */
+int orbfe_extract_stereo_pair_submit(orbfe_ctx*, const uint8_t* imgL, const uint8_t* imgR, int rows, int cols, size_t stride,
+                                     const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out,
+                                     float mb, float mbf, float* uRight, float* depth);
+int orbfe_extract_stereo_pair_wait(orbfe_ctx*);
 
 /* ---- matcher ---- */
 /* DescriptorDistance over all pairs: D[i*nB+j] = popcount(A_i xor B_j).  Host pointers. */

@@ -217,6 +217,7 @@ def lib():
         L.orbfe_set_lanes.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_lanes_join.argtypes = [C.c_void_p]
         L.orbfe_set_lane_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orbfe_set_lane_input_guard.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_lanes_record.argtypes = [C.c_void_p, C.c_void_p]
         L.orbfe_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
         L.orbfe_max_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -246,6 +247,8 @@ def lib():
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                                 C.c_void_p, C.c_void_p]
         L.orbfe_extract_stereo_pair.restype = C.c_int
+        L.orbfe_extract_stereo_pair_submit.argtypes = L.orbfe_extract_stereo_pair.argtypes
+        L.orbfe_extract_stereo_pair_wait.argtypes = [C.c_void_p]
         L.orbfe_compute_stereo_matches_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                                             C.c_void_p, C.c_void_p, C.c_int]
         L.orbfe_hamming_pairs_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -307,11 +310,11 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_matcher_last_kernel_ms", "orbfe_matcher_time_kernels", "orbfe_search_projection", "orbfe_search_projection_last_sweeps", "orbfe_search_projection_batch",
            "orbfe_distinctive_descriptors", "orbfe_vocab_upload", "orbfe_vocab_free", "orbfe_vocab_transform",
            "orbfe_extract_batch_submit", "orbfe_extract_batch_wait", "orbfe_host_alloc", "orbfe_host_free",
-           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident", "orbfe_extract_stereo_pair",
+           "orbfe_host_register", "orbfe_host_unregister", "orbfe_compute_stereo_matches_resident", "orbfe_extract_stereo_pair", "orbfe_extract_stereo_pair_submit", "orbfe_extract_stereo_pair_wait",
            "orbfe_hamming_pairs_device", "orbfe_bfknn2_device", "orbfe_bfknn2_frames_device", "orbfe_matcher_sync",
            "orbfe_get_device_outputs", "orbfe_extract_batch_sizes", "orbfe_set_atan_fma", "orbfe_debug_blurred_patch",
            "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
-           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_set_lane_mode", "orbfe_lanes_join", "orbfe_lanes_record",
+           "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_set_lane_mode", "orbfe_set_lane_input_guard", "orbfe_lanes_join", "orbfe_lanes_record",
            "orbfe_keyframe_create", "orbfe_keyframe_set_mask", "orbfe_keyframe_destroy", "orbfe_search_bow_keyframes",
            "orbfe_search_tri_batch"]
 
@@ -538,6 +541,10 @@ class ORBextractor:
         if mode is not None:
             _chk(self.L.orbfe_set_lane_mode(self.h, int(mode)), "orbfe_set_lane_mode")
 
+    def set_lane_input_guard(self, on):
+        """orbfe_set_lane_input_guard: off = the caller never rewrites the images of a call that may still be in flight."""
+        _chk(self.L.orbfe_set_lane_input_guard(self.h, 1 if on else 0), "orbfe_set_lane_input_guard")
+
     def lanes_join(self):
         """orbfe_lanes_join: the context's stream waits for every lane (no host wait)."""
         _chk(self.L.orbfe_lanes_join(self.h), "orbfe_lanes_join")
@@ -660,6 +667,37 @@ def extract_stereo_pair(ex, imgL, imgR, mb, mbf, lap=None):
              "orbfe_extract_stereo_pair")
     return (m, (int(mono[0]), kps[0, :n[0]].copy(), desc[0, :n[0]].copy()), (int(mono[1]), kps[1, :n[1]].copy(), desc[1, :n[1]].copy()),
             uR[:n[0]].copy(), dep[:n[0]].copy())
+
+
+class StereoPairStream:
+    """orbfe_extract_stereo_pair_submit / _wait: up to `lanes` stereo frames in flight on one context.  submit() queues a frame,
+    wait() returns the OLDEST frame's result in the format of extract_stereo_pair()."""
+
+    def __init__(self, ex, rows, cols):
+        self.ex, self.rows, self.cols = ex, rows, cols
+        self.cap = ex.max_keypoints(rows, cols)
+        self.q = []
+
+    def submit(self, imgL, imgR, mb, mbf, lap=None):
+        imgL = np.ascontiguousarray(imgL, np.uint8)
+        imgR = np.ascontiguousarray(imgR, np.uint8)
+        assert imgL.shape == imgR.shape == (self.rows, self.cols)
+        cap = self.cap
+        b = dict(imgL=imgL, imgR=imgR, kps=np.zeros((2, cap), KP_DTYPE), desc=np.zeros((2, cap, 32), np.uint8),
+                 n=np.zeros(2, np.int32), mono=np.zeros(2, np.int32), uR=np.zeros(cap, np.float32), dep=np.zeros(cap, np.float32),
+                 lap=None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(4))
+        _chk(lib().orbfe_extract_stereo_pair_submit(self.ex.h, imgL.ctypes.data, imgR.ctypes.data, self.rows, self.cols, self.cols,
+                                                    None if b["lap"] is None else b["lap"].ctypes.data, b["kps"].ctypes.data,
+                                                    b["desc"].ctypes.data, cap, b["n"].ctypes.data, b["mono"].ctypes.data, mb, mbf,
+                                                    b["uR"].ctypes.data, b["dep"].ctypes.data), "orbfe_extract_stereo_pair_submit")
+        self.q.append(b)  # (the arrays belong to the library until the frame's wait returns)
+
+    def wait(self):
+        m = _chk(lib().orbfe_extract_stereo_pair_wait(self.ex.h), "orbfe_extract_stereo_pair_wait")
+        b = self.q.pop(0)
+        n, mono, kps, desc = b["n"], b["mono"], b["kps"], b["desc"]
+        return (m, (int(mono[0]), kps[0, :n[0]].copy(), desc[0, :n[0]].copy()), (int(mono[1]), kps[1, :n[1]].copy(), desc[1, :n[1]].copy()),
+                b["uR"][:n[0]].copy(), b["dep"][:n[0]].copy())
 
 
 # ------------------------------------------------------------------------ matcher

@@ -224,19 +224,30 @@ struct orbfe_ctx : orbfe_geom_state {
         DevBuf<int4> d_fix;
         DevBuf<int> d_qtScratch;
         PinBuf<int4> h_fix, h_fixAB;
+        DevBuf<unsigned> d_done; // the completion word's counters and flag, K-STEREO's result arrays: one set per lane, so that the
+        PinBuf<unsigned> h_done; // stereo frames orbfe_extract_stereo_pair_submit keeps in flight do not count into each other's words
+        DevBuf<float> d_stereo;
+        PinBuf<float> h_stereo;
         int capImgs = 0, capKp = 0;
     };
     struct Lane {
         LaneBufs parked;          // this lane's buffers while another lane's are in the context (empty while its own are)
         hipStream_t stream = nullptr;
+        hipStream_t pairStream = nullptr; // stereo frames in flight (orbfe_extract_stereo_pair_submit): a stream of NORMAL priority per
+                                          // lane -- frames are collected in submission order, and a frame on a low-priority queue
+                                          // waits behind its younger neighbours (three in flight: 0.091 ms per frame with the batch
+                                          // lanes' mixed priorities, 0.045 with equal ones)
+        bool pendingPair = false; // pairStream holds work the context's stream has not been ordered after
         hipEvent_t evJoin = nullptr, evRead = nullptr;
         bool pending = false;     // holds work the context's stream has not been ordered after
         int imgs = 0;             // images of its last batch (orbfe_sync reads that many ... one status header)
     } lane[ORBFE_MAX_LANES];
     int curSet = 0;               // the lane whose buffers the context's members hold
     int laneNext = 0, laneLast = -1; // lane of the next whole-batch call / of the last one (-1: the last call ran on the context's stream)
+    int pairLast = -1;               // lane of the newest stereo frame submitted with orbfe_extract_stereo_pair_submit
     hipEvent_t evBatchFork = nullptr;
-    bool inputGuard = true;       // ORBFE_LANES_INPUT_GUARD=0 (A/B): the context's stream does not wait for a lane's K-PYR
+    bool inputGuard = true;       // orbfe_set_lane_input_guard / ORBFE_LANES_INPUT_GUARD=0: the context's stream does not wait for a lane's K-PYR
+    bool forkSkipIdle = true;     // ORBFE_LANES_FORK_ALWAYS=1 (A/B): record + wait even when the context's stream is idle
     hipStream_t runStream = nullptr; // run_device / ensure_capacity: the stream of the call being queued (nullptr: `stream`)
     hipEvent_t guardEv = nullptr;    // run_device records it behind K-PYR (the call's last reader of the caller's images)
 
@@ -280,8 +291,11 @@ struct orbfe_ctx : orbfe_geom_state {
         uint8_t* desc = nullptr;
         int* n_out = nullptr;
         int* mono_out = nullptr;
-    } slot[2];
+        float* uRight = nullptr; // orbfe_extract_stereo_pair_submit: where _wait leaves Frame::ComputeStereoMatches' results
+        float* depth = nullptr;
+    } slot[ORBFE_MAX_LANES]; // [0], [1]: the two-slot pipeline of the host-pointer calls; [k]: lane k's stereo frame in flight
     long slotSubmitted = 0, slotRetired = 0; // FIFO over the two slots
+    long pairSubmitted = 0, pairRetired = 0; // FIFO of orbfe_extract_stereo_pair_submit / _wait (slot = lane = sequence % lanes)
     hipStream_t sIn = nullptr, sOut = nullptr; // copy streams of the pipelined form
     std::unordered_map<const void*, bool> pinnedCache; // what hipPointerGetAttributes said about a caller pointer
     // orbfe_set_auto_register: pageable caller buffers that came back (same address, same size) are page-locked by the
@@ -345,6 +359,11 @@ int lane_join(orbfe_ctx* c)
     if (!c) return 0;
     for (int k = 0; k < ORBFE_MAX_LANES; k++) {
         orbfe_ctx::Lane& L = c->lane[k];
+        if (L.pendingPair) {
+            HIP_TRY(hipEventRecord(L.evJoin, L.pairStream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, L.evJoin, 0));
+            L.pendingPair = false;
+        }
         if (!L.pending) continue;
         HIP_TRY(hipEventRecord(L.evJoin, L.stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, L.evJoin, 0));
@@ -362,7 +381,8 @@ void lane_quiesce(orbfe_ctx* c)
     if (!c) return;
     for (int k = 0; k < ORBFE_MAX_LANES; k++) {
         if (c->lane[k].stream) (void)hipStreamSynchronize(c->lane[k].stream);
-        c->lane[k].pending = false;
+        if (c->lane[k].pairStream) (void)hipStreamSynchronize(c->lane[k].pairStream);
+        c->lane[k].pending = c->lane[k].pendingPair = false;
     }
     if (c->laneStream) (void)hipStreamSynchronize(c->laneStream);
     c->lanePending = false;
@@ -370,7 +390,7 @@ void lane_quiesce(orbfe_ctx* c)
 bool lanes_busy(const orbfe_ctx* c)
 {
     bool any = c->lanePending;
-    for (int k = 0; k < ORBFE_MAX_LANES; k++) any = any || c->lane[k].pending;
+    for (int k = 0; k < ORBFE_MAX_LANES; k++) any = any || c->lane[k].pending || c->lane[k].pendingPair;
     return any;
 }
 // The per-batch buffers of the context <-> a parking place
@@ -389,6 +409,10 @@ void lane_swap_bufs(orbfe_ctx* c, orbfe_ctx::LaneBufs& b)
     std::swap(c->d_qtScratch, b.d_qtScratch);
     std::swap(c->h_fix, b.h_fix);
     std::swap(c->h_fixAB, b.h_fixAB);
+    std::swap(c->d_done, b.d_done);
+    std::swap(c->h_done, b.h_done);
+    std::swap(c->d_stereo, b.d_stereo);
+    std::swap(c->h_stereo, b.h_stereo);
     std::swap(c->capImgs, b.capImgs);
     std::swap(c->capKp, b.capKp);
 }
@@ -409,10 +433,12 @@ void lanes_invalidate_caps(orbfe_ctx* c)
 // Streams and events of the batch lanes.  Streams of ONE priority share four hardware queues (GPU_MAX_HW_QUEUES) with every other
 // stream of the process, and two lanes in one queue serialise (three contexts on normal-priority streams: 0.063 ms per
 // 8 x 1280x720 batch against 0.045 with GPU_MAX_HW_QUEUES=8, profiles/r05_lanes_probe.txt); priorities have queues of their own,
-// so the lanes are spread over the priorities first: normal, lowest, highest, normal (ORBFE_LANE_PRIOS="0,1,-1,0" overrides).
+// so the lanes are spread over the priorities first: normal, lowest, highest, lowest (ORBFE_LANE_PRIOS="0,1,-1,1" overrides;
+// 8 x 1280x720, profiles/r05_lanes_probe.txt: three lanes 0.0432 ms per batch with these, 0.0620 all normal, 0.0452 all lowest;
+// a FOURTH lane at normal priority beside the first: 0.0555, all four lowest: 0.0436).
 int batch_lane_setup(orbfe_ctx* c)
 {
-    int prios[ORBFE_MAX_LANES] = {0, 1, -1, 0};
+    int prios[ORBFE_MAX_LANES] = {0, 1, -1, 1};
     if (const char* e = getenv("ORBFE_LANE_PRIOS")) {
         int k = 0;
         for (const char* p = e; *p && k < ORBFE_MAX_LANES; k++) {
@@ -1670,7 +1696,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 c->doneWant = false;
                 if (mirror && !needPack && !hostTrigCheck && nsub == 1 && !descAffine && c->spinWait && c->d_done.p && c->h_done.p &&
                     c->h_done.coherent && ORBFE_DESC_WPW == 1 && ORBFE_DESC_KPW == 1) {
-                    if (++c->doneSeq == 0u) c->doneSeq = 1u;
+                    if (++c->doneSeq >= 0x80000000u) c->doneSeq = 1u; // (bit 31 of the word: "finished, not vouched for")
                     done = OrbDone{c->d_done.p, c->h_done.dev(), c->doneSeq, (unsigned)ni * (unsigned)c->maxKp};
                     c->doneGot = c->doneSeq; // (what the caller waits for)
                 }
@@ -2022,7 +2048,9 @@ const uint8_t* upload_by_kernel(hipStream_t s, uint8_t* d_dst /* 256-B aligned, 
 // copies on their own streams (ordered by events) so that they overlap the kernels of the neighbouring batches;
 // the blocking calls keep everything on the context's stream (no event traffic on the latency path).
 int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, int cols, size_t stride, const int* lap,
-                     orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined, bool spinOk)
+                     orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out, bool pipelined, bool spinOk,
+                     int laneSlot = -1 /* >= 0: orbfe_extract_stereo_pair_submit -- slot and lane of that index, the lane's buffers
+                                          are in the context and c->runStream is the lane's stream; no FIFO bookkeeping here */)
 {
     if (!c || nimg < 1 || !imgs || !kps || !desc || !n_out) return ORBFE_ERR_ARGS;
     for (int i = 0; i < nimg; i++) {
@@ -2033,16 +2061,16 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     for (int i = 0; i < nimg; i++)
         if (!imgs[i]) return -1;
     if (stride < (size_t)cols) return ORBFE_ERR_ARGS;
-    if (c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: wait for one first
+    if (laneSlot < 0 && c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: wait for one first
     HIP_TRY(hipSetDevice(c->device));
     int r;
-    if ((r = lane_join(c)) < 0) return r;
+    if (laneSlot < 0 && (r = lane_join(c)) < 0) return r;
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
     if (cap_per_img < c->maxKp) return ORBFE_ERR_ARGS;
     if ((r = ensure_capacity(c, nimg, cap_per_img)) < 0) return r;
-    orbfe_ctx::HostSlot& sl = c->slot[c->slotSubmitted & 1];
+    orbfe_ctx::HostSlot& sl = c->slot[laneSlot >= 0 ? laneSlot : (int)(c->slotSubmitted & 1)];
     if ((r = slot_prepare(c, sl, pipelined)) < 0) return r;
-    hipStream_t s = c->stream;
+    hipStream_t s = run_stream(c);
     hipStream_t sIn = pipelined ? c->sIn : s, sOut = pipelined ? c->sOut : s;
     const size_t Kc = (size_t)cap_per_img;
     const size_t imgBytes = (size_t)(rows - 1) * stride + (size_t)cols; // what may be read behind an image pointer
@@ -2195,7 +2223,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
         if (spinOk && c->spinWait && sl.h_out.coherent) {
             if (!c->d_done.p) {
                 if ((r = c->d_done.ensure(80)) < 0) return r;
-                HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), c->stream)); // (ordered with the kernels that count)
+                HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), s)); // (ordered with the kernels that count)
                 if ((r = c->h_done.ensure(16)) < 0) return r;
                 c->h_done.p[0] = 0u;
             }
@@ -2240,7 +2268,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     sl.desc = desc;
     sl.n_out = n_out;
     sl.mono_out = mono_out;
-    c->slotSubmitted++;
+    if (laneSlot < 0) c->slotSubmitted++;
     return 0;
 }
 
@@ -2253,6 +2281,7 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
                 bool spinOk = false /* the caller waits at once and queues nothing behind the extraction */)
 {
     if (c && c->slotSubmitted - c->slotRetired >= 2) return ORBFE_ERR_STATE; // both slots in flight: nothing was queued
+    if (c && c->pairSubmitted != c->pairRetired) return ORBFE_ERR_STATE;     // stereo frames in flight own the slots
     const int r = host_submit_impl(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, pipelined,
                                    spinOk);
     if (r <= -1000 && c) { // (a HIP error: something may have been queued; validation errors come before the first command)
@@ -2272,35 +2301,37 @@ static bool spin_done(orbfe_ctx* c, unsigned seq)
     const volatile unsigned* f = c->h_done.p;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0;; it++) {
-        if (*f == seq) {
+        const unsigned v = *f;
+        if (v == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             c->spinMisses = 0;
             return true;
         }
+        if (v == (seq | 0x80000000u)) return false; // the kernel finished but does not vouch for its stores' order: synchronise
         __builtin_ia32_pause();
         if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
     }
     // The word did not come within the bound (the caller now synchronises the stream).  Should a counter ever be left non-zero
     // -- a kernel that died half-way -- every later call would time out as well: clear them behind whatever is still queued.
-    (void)hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), c->stream);
+    (void)hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), run_stream(c));
     if (++c->spinMisses >= 8) c->spinWait = false; // (the word does not arrive on this platform: stop paying the bound)
     return false;
 }
 
 // Complete the oldest submitted batch: wait for its transfers, hand out the counts, and -- for pageable output
 // arrays -- copy the rows each image produced out of the staging buffer.
-int host_wait(orbfe_ctx* c)
+int host_wait(orbfe_ctx* c, int laneSlot = -1 /* as in host_submit_impl */)
 {
     if (!c) return ORBFE_ERR_ARGS;
-    if (c->slotSubmitted == c->slotRetired) return ORBFE_ERR_STATE;
-    orbfe_ctx::HostSlot& sl = c->slot[c->slotRetired & 1];
+    if (laneSlot < 0 && c->slotSubmitted == c->slotRetired) return ORBFE_ERR_STATE;
+    orbfe_ctx::HostSlot& sl = c->slot[laneSlot >= 0 ? laneSlot : (int)(c->slotRetired & 1)];
     HIP_TRY(hipSetDevice(c->device));
     hipError_t e = hipSuccess;
     // (the completion word the call's last kernel publishes behind the results it has written: OrbDone)
     const bool seen = !sl.pipelined && spin_done(c, sl.doneSeq);
-    if (!seen) e = sl.pipelined ? hipEventSynchronize(sl.evDone) : hipStreamSynchronize(c->stream);
+    if (!seen) e = sl.pipelined ? hipEventSynchronize(sl.evDone) : hipStreamSynchronize(run_stream(c));
     sl.busy = false;
-    c->slotRetired++;
+    if (laneSlot < 0) c->slotRetired++;
     if (e != hipSuccess) return -(1000 + (int)e);
     const int nimg = sl.nimg;
     const int32_t* meta = reinterpret_cast<const int32_t*>(sl.h_out.p);
@@ -2388,6 +2419,7 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     if (const char* e = getenv("ORBFE_LANES")) c->lanes = std::min(ORBFE_MAX_LANES, std::max(1, atoi(e)));
     if (const char* e = getenv("ORBFE_LANE_MODE")) c->laneMode = (!strcmp(e, "split") || atoi(e) == 1) && c->lanes <= 2 ? 1 : 0;
     if (const char* e = getenv("ORBFE_LANES_INPUT_GUARD")) c->inputGuard = atoi(e) != 0;
+    if (const char* e = getenv("ORBFE_LANES_FORK_ALWAYS")) c->forkSkipIdle = atoi(e) == 0;
     if (const char* e = getenv("ORBFE_LANES_MIN")) c->lanesMin = std::max(2, atoi(e));
     if (const char* e = getenv("ORBFE_LANE_SPLIT")) c->laneSplitPct = std::min(95, std::max(0, atoi(e)));
     if (c->nStreams > 1) {
@@ -2424,7 +2456,7 @@ void orbfe_destroy(orbfe_ctx* c)
     c->release_tables();
     for (auto& g : c->geomCache) g.release_tables();
     c->d_taps.release(); c->d_patternF.release();
-    c->h_fix.release(); c->h_fixAB.release(); c->d_stereo.release(); c->h_stereo.release();
+    c->h_fix.release(); c->h_fixAB.release(); c->d_stereo.release(); c->h_stereo.release(); c->d_done.release(); c->h_done.release();
     c->d_stereoIo.release(); c->h_stereoIo.release();
     for (auto& sl : c->slot) {
         sl.d_img.release(); sl.d_out.release(); sl.h_in.release(); sl.h_out.release(); sl.h_lap.release();
@@ -2452,10 +2484,11 @@ void orbfe_destroy(orbfe_ctx* c)
         orbfe_ctx::LaneBufs& b = L.parked; // (the current lane's buffers are the context's own members, released above)
         b.d_pyr.release(); b.d_cand.release(); b.d_keys.release(); b.d_lvlKp.release(); b.d_lvlPre.release(); b.d_keyNode.release();
         b.d_cellCount.release(); b.d_lvlCount.release(); b.d_destMap.release(); b.d_fix.release(); b.d_qtScratch.release();
-        b.h_fix.release(); b.h_fixAB.release();
+        b.h_fix.release(); b.h_fixAB.release(); b.d_done.release(); b.h_done.release(); b.d_stereo.release(); b.h_stereo.release();
         if (L.evJoin) (void)hipEventDestroy(L.evJoin);
         if (L.evRead) (void)hipEventDestroy(L.evRead);
         if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.pairStream) (void)hipStreamDestroy(L.pairStream);
     }
     if (c->evBatchFork) (void)hipEventDestroy(c->evBatchFork);
     for (int k = 0; k < 8; k++) {
@@ -2577,6 +2610,8 @@ int orbfe_sync(orbfe_ctx* c)
     bool laneErr = false;
     for (int k = 0; k < ORBFE_MAX_LANES; k++) { // batch lanes: the status header of every lane that held work
         orbfe_ctx::Lane& L = c->lane[k];
+        if (L.pairStream) HIP_TRY(hipStreamSynchronize(L.pairStream));
+        L.pendingPair = false;
         if (!L.stream) continue;
         HIP_TRY(hipStreamSynchronize(L.stream));
         const DevBuf<int4>& fx = k == c->curSet ? c->d_fix : L.parked.d_fix;
@@ -2608,6 +2643,7 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     if (!c || nimg < 1 || !d_imgs || !d_kps || !d_desc || !d_n_out || !d_mono_out) return ORBFE_ERR_ARGS;
     if (rows <= 0 || cols <= 0) return -1;
     if (pitch < (size_t)cols) return ORBFE_ERR_ARGS;
+    if (c->pairSubmitted != c->pairRetired) return ORBFE_ERR_STATE; // stereo frames in flight hold the lanes' buffers
     HIP_TRY(hipSetDevice(c->device));
     int r;
     // Batch lanes (orbfe_ctx::laneMode 0): this call goes, whole, to the next lane's stream with that lane's buffers
@@ -2639,9 +2675,14 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     }
     if (batchLanes) {
         orbfe_ctx::Lane& L = c->lane[c->laneNext];
-        // the lane starts no earlier than this point of the context's stream (inputs, tables); one-way
-        HIP_TRY(hipEventRecord(c->evBatchFork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(L.stream, c->evBatchFork, 0));
+        // the lane starts no earlier than this point of the context's stream (inputs, tables); one-way.  An idle stream --
+        // resident inputs, nothing queued by the caller -- orders nothing: the event record and the wait (two barrier packets,
+        // two queues) are skipped then
+        if (!c->forkSkipIdle || hipStreamQuery(c->stream) != hipSuccess) {
+            (void)hipGetLastError(); // (hipErrorNotReady is not an error here)
+            HIP_TRY(hipEventRecord(c->evBatchFork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(L.stream, c->evBatchFork, 0));
+        }
         c->runStream = L.stream;
         c->guardEv = c->inputGuard ? L.evRead : nullptr;
         r = run_device(c, nimg, d_imgs, rows, cols, pitch, img_stride_bytes, c->d_lap.p, (float*)d_kps, d_desc, cap_per_img,
@@ -2672,6 +2713,16 @@ int orbfe_set_lanes(orbfe_ctx* c, int lanes)
     c->lanes = lanes;
     if (lanes > 2) c->laneMode = 0; // (half-batches exist for two lanes only)
     c->laneNext = 0;
+    return 0;
+}
+
+int orbfe_set_lane_input_guard(orbfe_ctx* c, int on)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = lane_join(c);
+    if (r < 0) return r;
+    c->inputGuard = on != 0;
     return 0;
 }
 
@@ -2997,12 +3048,12 @@ static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, i
         left->scaleFactor != right->scaleFactor || right->lastCap >= (1 << 20))
         return ORBFE_ERR_STATE;
     int r;
-    if ((r = lane_join(left)) < 0 || (r = lane_join(right)) < 0) return r;
+    if (!left->runStream && ((r = lane_join(left)) < 0 || (r = lane_join(right)) < 0)) return r; // (not for a frame on its lane)
     const size_t cap = (size_t)left->lastCap;
     if ((r = left->d_stereo.ensure(3 * cap)) < 0) return r;
     if ((r = left->h_stereo.ensure(3 * cap)) < 0) return r;
-    hipStream_t s = left->stream;
-    if (right->stream != s) { // the right extractor's kernels must have finished: order the streams, not the host
+    hipStream_t s = run_stream(left);
+    if (run_stream(right) != s) { // the right extractor's kernels must have finished: order the streams, not the host
         if (!left->evStereo) HIP_TRY(hipEventCreateWithFlags(&left->evStereo, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(left->evStereo, right->stream));
         HIP_TRY(hipStreamWaitEvent(s, left->evStereo, 0));
@@ -3022,7 +3073,7 @@ static int stereo_resident_launch(orbfe_ctx* left, int imgL, orbfe_ctx* right, i
             left->h_done.p[0] = 0u;
         }
         if (left->h_done.coherent) {
-            if (++left->doneSeq == 0u) left->doneSeq = 1u;
+            if (++left->doneSeq >= 0x80000000u) left->doneSeq = 1u;
             done = OrbDone{left->d_done.p + 16, left->h_done.dev(), left->doneSeq, (unsigned)((capL + 3) / 4)};
             *doneSeq = left->doneSeq;
         }
@@ -3089,7 +3140,7 @@ int orbfe_extract_stereo_pair(orbfe_ctx* c, const uint8_t* imgL, const uint8_t* 
                               float mb, float mbf, float* uRight, float* depth)
 {
     if (!c || !imgL || !imgR || !kps || !desc || !n_out || !uRight || !depth || !(mb > 0)) return ORBFE_ERR_ARGS;
-    if (c->slotSubmitted != c->slotRetired) return ORBFE_ERR_STATE; // submitted batches must be waited for first
+    if (c->slotSubmitted != c->slotRetired || c->pairSubmitted != c->pairRetired) return ORBFE_ERR_STATE; // submitted work must be waited for first
     const uint8_t* two[2] = {imgL, imgR};
     int r = host_submit(c, 2, two, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false);
     if (r < 0) return r;
@@ -3102,6 +3153,90 @@ int orbfe_extract_stereo_pair(orbfe_ctx* c, const uint8_t* imgL, const uint8_t* 
     if (w < 0) return w;
     if (n_out[0] > cap_per_img) return ORBFE_ERR_STATE;
     return stereo_resident_finish(c, uRight, depth, n_out[0]);
+}
+
+// Stereo frames IN FLIGHT (round 5): the same work as orbfe_extract_stereo_pair, queued on the next batch lane -- its stream, its
+// pyramids and quadtree buffers, its pinned result slab, its completion word -- and collected by _wait in submission order, so
+// that the latency chain of one stereo frame (upload, four kernels on two images, K-STEREO: ~80 us on a nearly empty chip)
+// runs beside its neighbours'.  Up to `lanes` frames (orbfe_set_lanes) are accepted before a _wait is due.
+int orbfe_extract_stereo_pair_submit(orbfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int rows, int cols, size_t stride,
+                                     const int* lap, orbfe_kp* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out,
+                                     float mb, float mbf, float* uRight, float* depth)
+{
+    if (!c || !imgL || !imgR || !kps || !desc || !n_out || !uRight || !depth || !(mb > 0)) return ORBFE_ERR_ARGS;
+    if (c->slotSubmitted != c->slotRetired) return ORBFE_ERR_STATE; // (the two-slot pipeline shares the slots)
+    if (c->kb8On || c->nStreams > 1) return ORBFE_ERR_STATE;
+    const int depthMax = std::max(1, std::min(c->lanes, ORBFE_MAX_LANES));
+    if (c->pairSubmitted - c->pairRetired >= depthMax) return ORBFE_ERR_STATE; // every lane holds a frame: wait for one first
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if (c->pairSubmitted == c->pairRetired && lanes_busy(c) && (r = lane_join(c)) < 0) return r; // (behind device-pointer calls)
+    const int k = (int)(c->pairSubmitted % depthMax);
+    orbfe_ctx::Lane& L = c->lane[k];
+    if (!L.pairStream) HIP_TRY(hipStreamCreateWithFlags(&L.pairStream, hipStreamNonBlocking));
+    if (!L.evJoin) HIP_TRY(hipEventCreateWithFlags(&L.evJoin, hipEventDisableTiming));
+    lane_select(c, k);
+    c->runStream = L.pairStream;
+    const uint8_t* two[2] = {imgL, imgR};
+    // The completion word only for a pipeline of ONE: with kernels of several queues on the chip the workgroups do not run on
+    // the XCDs their ids name, every one of them releases for itself and the word is withheld (OrbDone) -- and a pipeline that
+    // is kept full gains nothing from a wait that ends 5 us earlier.
+    const bool word = depthMax == 1;
+    // (a pipeline of one alternates between two slots like the blocking call: the kernels write their results into the slot's
+    // page-locked slab, and lines the host has just read are slow to write again -- 0.165 against 0.104 ms per frame)
+    const int ks = depthMax == 1 ? (int)(c->pairSubmitted & 1) : k;
+    r = host_submit_impl(c, 2, two, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false, /*spinOk=*/word, ks);
+    unsigned seq = 0;
+    int rs = 0;
+    if (r >= 0) {
+        rs = stereo_resident_launch(c, 0, c, 1, mb, mbf, word ? &seq : nullptr);
+        c->slot[ks].doneSeq = rs < 0 ? 0u : seq; // (K-STEREO is the frame's last kernel: its word ends the wait)
+        c->slot[ks].uRight = uRight;
+        c->slot[ks].depth = depth;
+    }
+    c->runStream = nullptr;
+    L.pendingPair = true;
+    c->pairLast = k;
+    if (r <= -1000 || rs < 0) (void)hipStreamSynchronize(L.pairStream); // (something may be queued that reads the caller's images)
+    if (r < 0) return r;
+    if (rs < 0) {
+        c->slot[ks].busy = false;
+        return rs;
+    }
+    c->pairSubmitted++;
+    return 0;
+}
+
+// Completes the OLDEST submitted stereo frame: returns its number of stereo matches (as orbfe_extract_stereo_pair does) with the
+// arrays handed to that _submit filled.
+int orbfe_extract_stereo_pair_wait(orbfe_ctx* c)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    if (c->pairSubmitted == c->pairRetired) return ORBFE_ERR_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const int depthMax = std::max(1, std::min(c->lanes, ORBFE_MAX_LANES));
+    const int k = (int)(c->pairRetired % depthMax);
+    lane_select(c, k);
+    const int ks = depthMax == 1 ? (int)(c->pairRetired & 1) : k;
+    orbfe_ctx::HostSlot& sl = c->slot[ks];
+    c->runStream = c->lane[k].pairStream;
+    const int w = host_wait(c, ks);
+    c->runStream = nullptr;
+    c->pairRetired++;
+    int m = w;
+    if (w >= 0) {
+        if (sl.n_out[0] > sl.cap) {
+            m = ORBFE_ERR_STATE;
+        } else { // (h_stereo is lane k's -- lane_select above --, laid out by the capacity of the frame's own submit)
+            const int keepCap = c->lastCap;
+            c->lastCap = sl.cap;
+            m = stereo_resident_finish(c, sl.uRight, sl.depth, sl.n_out[0]);
+            c->lastCap = keepCap;
+        }
+    }
+    c->lane[k].pendingPair = false; // (the host has seen the frame's last kernel finish)
+    if (c->pairLast >= 0) lane_select(c, c->pairLast); // "the last call" of the getters = the newest submitted frame
+    return m;
 }
 
 int orbfe_profile_enable(orbfe_ctx* c, int on)

@@ -312,6 +312,81 @@ def test_stereo_pair_extraction_and_matching_in_one_call(pkg, oracle):
     buf.close()
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
+def test_stereo_frames_in_flight(pkg, oracle, lanes):
+    """orbfe_extract_stereo_pair_submit / _wait: up to `lanes` stereo frames in flight on one context, each on a lane of its own
+    (stream, pyramids, pinned result slab, completion word).  Six different frames (synthetic and photograph pairs, one with an
+    empty right image), forty submits with the pipeline kept full, under PCIe load from two other host threads: every _wait
+    returns ITS frame's keypoints, descriptors, mvuRight and mvDepth, bit-exact against the oracle; one submit too many is
+    refused; the blocking calls still work before, between and after."""
+    import threading
+    import torch
+    import natural
+    from test_gpu_lanes import _load_threads
+    mb, mbf = 47.90639384423901 / 435.2046959714599, 47.90639384423901
+    H, W, nf = 480, 752, 1200
+    pairs = [pkg.synth.make_stereo_pair(H, W, 40 + k, shift=9 + 3 * k) for k in range(3)]
+    pairs.append(natural.stereo_pair("china", H, W, shift=24, oy=60, ox=100))
+    pairs.append(natural.stereo_pair("flower", H, W, shift=17, oy=300, ox=500))
+    pairs.append((pairs[0][0], np.full((H, W), 90, np.uint8)))
+    refs = []
+    for left, right in pairs:
+        oL, oR = oracle.Extractor(nf, 1.2, 8, 20, 7), oracle.Extractor(nf, 1.2, 8, 20, 7)
+        _, rkL, rdL = oL.extract(left, (0, 0))
+        _, rkR, rdR = oR.extract(right, (0, 0))
+        rn, ruR, rdep = oracle.compute_stereo_matches(oL, oR, rkL, rdL, rkR, rdR, mb, mbf)
+        refs.append((rkL, rdL, rkR, rdR, rn, ruR, rdep))
+
+    def check(res, k):
+        m, (monoL, kL, dL), (monoR, kR, dR), uR, dep = res
+        rkL, rdL, rkR, rdR, rn, ruR, rdep = refs[k]
+        _same(kL, rkL, dL, rdL)
+        _same(kR, rkR, dR, rdR)
+        assert m == rn and np.array_equal(uR, ruR) and np.array_equal(dep, rdep), k
+
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ex.set_lanes(lanes)
+    check(pkg.binding.extract_stereo_pair(ex, *pairs[1], mb, mbf), 1)  # the blocking call first
+    st = pkg.binding.StereoPairStream(ex, H, W)
+    buf = pkg.binding.PinnedBuffer(2 * H * W * len(pairs))
+    pin = buf.array((len(pairs), 2, H, W), np.uint8)
+    for k, (left, right) in enumerate(pairs):
+        pin[k, 0], pin[k, 1] = left, right
+    stop = threading.Event()
+    ts = _load_threads(torch, torch.device("cuda:0"), stop)
+    try:
+        order = []
+        for i in range(40):
+            k = (i * 5 + i // 7) % len(pairs)
+            if len(order) == lanes:
+                check(st.wait(), order.pop(0))
+            if i % 3 == 0:  # pageable caller memory / page-locked caller memory in turn
+                st.submit(pairs[k][0], pairs[k][1], mb, mbf)
+            else:
+                st.submit(pin[k, 0], pin[k, 1], mb, mbf)
+            order.append(k)
+        # the pipeline is full: one more is refused, nothing is disturbed
+        while len(order) < lanes:
+            st.submit(pin[0, 0], pin[0, 1], mb, mbf)
+            order.append(0)
+        with pytest.raises(pkg.OrbfeError):
+            st.submit(pin[0, 0], pin[0, 1], mb, mbf)
+        while order:
+            check(st.wait(), order.pop(0))
+        with pytest.raises(pkg.OrbfeError):
+            st.wait()
+    finally:
+        stop.set()
+        for t in ts:
+            t.join()
+    # "the last call" of the getters is the newest frame; the blocking forms still work afterwards
+    check(pkg.binding.extract_stereo_pair(ex, *pairs[4], mb, mbf), 4)
+    mono, kps, desc = ex(pairs[2][0], (0, 0))
+    _same(kps, refs[2][0], desc, refs[2][1])
+    ex.close()
+    buf.close()
+
+
 def test_latency_path_with_sub_batches_on_several_streams():
     # ADVICE r03: with ORBFE_STREAMS=2 a blocking two-image call runs as two sub-batches; the pinned result mirror used to be
     # indexed by the image's position in its SUB-batch (both wrote entry 0, entry 1 stayed stale).  The variable is read at

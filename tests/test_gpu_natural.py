@@ -99,10 +99,10 @@ def test_photograph_stereo_pair_and_knn2(pkg, oracle):
     _, rkr, rdr = rr.extract(right, (0, 0))
     _same(kl, rkl, dl, rdl)
     _same(kr, rkr, dr, rdr)
-    bf, b = 435.2 * 0.11, 0.11
-    u, d = pkg.compute_stereo_matches(exl, exr, kl, dl, kr, dr, bf, b)
-    ru, rd = oracle.compute_stereo_matches(rl, rr, rkl, rdl, rkr, rdr, bf, b)
-    assert np.array_equal(u, ru) and np.array_equal(d, rd)
+    mb, mbf = 0.11, 435.2 * 0.11  # EuRoC: baseline 0.11 m, fx 435.2 (Examples/Stereo/EuRoC.yaml)
+    n, u, d = pkg.compute_stereo_matches(exl, exr, kl, dl, kr, dr, mb, mbf)
+    rn, ru, rd = oracle.compute_stereo_matches(rl, rr, rkl, rdl, rkr, rdr, mb, mbf)
+    assert n == rn and np.array_equal(u, ru) and np.array_equal(d, rd)
     assert int((u >= 0).sum()) > 200  # the scene is a plane at disparity 24: most keypoints find their partner
     idx, dist = pkg.bfknn2(dl, dr)
     ridx, rdist = oracle.bfknn2(rdl, rdr)

@@ -3,7 +3,7 @@
 // orbfe_extract* including H2D of the images and D2H of keypoints + descriptors).  bench.py runs this program as
 // a child process and embeds its one JSON line as the `pcie_inclusive` object; it is never bench.py's `value`.
 //
-//   hostbench <frames.raw> rows cols nframes nfeatures [device] [first | c5 | matcher]
+//   hostbench <frames.raw> rows cols nframes nfeatures [device] [first | c5 | matcher | stream]
 //
 // frames.raw = nframes images of rows x cols bytes (bench.py writes its synthetic frames there).
 //   single_pageable / single_pinned : orbfe_extract, one frame per call (mono protocol, reference src/Frame.cc:306)
@@ -52,6 +52,118 @@ static Stat stat_of(std::vector<double>& v)
             return 2;                                                        \
         }                                                                    \
     } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mode "stream" (round 5): a STREAM of EuRoC stereo frames with 1..4 frames in flight on ONE context
+// (orbfe_extract_stereo_pair_submit / _wait on the context's batch lanes): sustained wall time per frame, host images in,
+// host keypoints / descriptors / mvuRight / mvDepth out, for pageable and page-locked caller images.  in_flight = 1 is the
+// blocking protocol (submit, wait); the blocking call orbfe_extract_stereo_pair is timed beside it.
+static int run_stream(const std::vector<uint8_t>& frames, int rows, int cols, int B, int nF, int dev)
+{
+    const size_t imgBytes = (size_t)rows * cols;
+    std::vector<uint8_t> right(imgBytes * B);
+    for (int i = 0; i < B; i++)
+        for (int y = 0; y < rows; y++) {
+            const uint8_t* s = frames.data() + imgBytes * i + (size_t)y * cols;
+            uint8_t* d = right.data() + imgBytes * i + (size_t)y * cols;
+            memcpy(d, s + 12, cols - 12);
+            memcpy(d + cols - 12, s, 12);
+        }
+    const float bf = 47.90639384423901f, fx = 435.2046959714599f; // Examples/Stereo/EuRoC.yaml
+    const int lap2[4] = {0, 0, 0, 0};
+    const int nFrames = 600;
+    std::string out = "{\"frame\": \"" + std::to_string(cols) + "x" + std::to_string(rows) + "\", \"nfeatures\": " + std::to_string(nF) +
+                      ", \"frames\": " + std::to_string(nFrames);
+    double kpPerFrame = 0, matchesPerFrame = 0;
+    for (int pinned = 0; pinned < 2; pinned++) {
+        if (pinned) {
+            CHECK(orbfe_host_register((void*)frames.data(), imgBytes * B));
+            CHECK(orbfe_host_register(right.data(), imgBytes * B));
+        }
+        out += std::string(", \"") + (pinned ? "pinned" : "pageable") + "\": {";
+        for (int depth = 0; depth <= ORBFE_MAX_LANES; depth++) { // depth 0: the blocking call
+            orbfe_ctx* ex = nullptr;
+            CHECK(orbfe_create(&ex, nF, 1.2f, 8, 20, 7, dev));
+            CHECK(orbfe_set_lanes(ex, std::max(depth, 1)));
+            const int cap = orbfe_max_keypoints(ex, rows, cols);
+            CHECK(cap);
+            struct Out {
+                std::vector<uint8_t> k, d;
+                std::vector<float> u, z;
+                int n[2], mono[2];
+            };
+            std::vector<Out> ring((size_t)std::max(depth, 1));
+            for (auto& o : ring) {
+                o.k.resize((size_t)2 * cap * 28);
+                o.d.resize((size_t)2 * cap * 32);
+                o.u.resize(cap);
+                o.z.resize(cap);
+            }
+            long kp = 0, matches = 0;
+            double t0 = 0;
+            int inFlight = 0;
+            for (int r = -30; r < nFrames; r++) {
+                if (r == 0) {
+                    while (inFlight > 0) { // (the clock starts on an empty pipeline and stops on one)
+                        CHECK(orbfe_extract_stereo_pair_wait(ex));
+                        inFlight--;
+                    }
+                    t0 = now_s();
+                }
+                const int i = (r + 30) % B;
+                Out& o = ring[(size_t)((r + 30) % (int)ring.size())];
+                if (depth == 0) {
+                    const int m = orbfe_extract_stereo_pair(ex, frames.data() + imgBytes * i, right.data() + imgBytes * i, rows, cols, cols,
+                                                            lap2, (orbfe_kp*)o.k.data(), o.d.data(), cap, o.n, o.mono, bf / fx, bf,
+                                                            o.u.data(), o.z.data());
+                    CHECK(m);
+                    if (r >= 0) {
+                        kp += o.n[0] + o.n[1];
+                        matches += m;
+                    }
+                    continue;
+                }
+                if (inFlight == depth) {
+                    const int m = orbfe_extract_stereo_pair_wait(ex); // (the oldest frame: the ring entry about to be reused)
+                    CHECK(m);
+                    inFlight--;
+                    if (r >= depth) {
+                        kp += o.n[0] + o.n[1];
+                        matches += m;
+                    }
+                }
+                CHECK(orbfe_extract_stereo_pair_submit(ex, frames.data() + imgBytes * i, right.data() + imgBytes * i, rows, cols, cols,
+                                                       lap2, (orbfe_kp*)o.k.data(), o.d.data(), cap, o.n, o.mono, bf / fx, bf,
+                                                       o.u.data(), o.z.data()));
+                inFlight++;
+            }
+            while (inFlight > 0) {
+                CHECK(orbfe_extract_stereo_pair_wait(ex));
+                inFlight--;
+            }
+            const double dt = now_s() - t0;
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_per_frame\": %.4f}", depth ? ", " : "",
+                     depth ? ("in_flight_" + std::to_string(depth)).c_str() : "blocking_call", 1e3 * dt / nFrames);
+            out += buf;
+            if (depth == 0) {
+                kpPerFrame = (double)kp / nFrames;
+                matchesPerFrame = (double)matches / nFrames;
+            }
+            orbfe_destroy(ex);
+        }
+        out += "}";
+        if (pinned) {
+            (void)orbfe_host_unregister((void*)frames.data());
+            (void)orbfe_host_unregister(right.data());
+        }
+    }
+    char tail[256];
+    snprintf(tail, sizeof tail, ", \"keypoints_per_frame\": %.1f, \"matches_per_frame\": %.1f}", kpPerFrame, matchesPerFrame);
+    out += tail;
+    printf("%s\n", out.c_str());
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Mode "c5" (BASELINE configs[4]): a fisheye stereo frame -- two 1024 x 1024 images, nFeatures 1500, KannalaBrandt8
@@ -561,6 +673,7 @@ int main(int argc, char** argv)
     }
     if (argc > 7 && !strcmp(argv[7], "c5")) return run_c5(frames, rows, cols, B, nF, dev);
     if (argc > 7 && !strcmp(argv[7], "matcher")) return run_matcher(frames, rows, cols, B, nF, dev);
+    if (argc > 7 && !strcmp(argv[7], "stream")) return run_stream(frames, rows, cols, B, nF, dev);
     orbfe_ctx* ex = nullptr;
     const double tCreate0 = now_s();
     CHECK(orbfe_create(&ex, nF, 1.2f, 8, 20, 7, dev));
