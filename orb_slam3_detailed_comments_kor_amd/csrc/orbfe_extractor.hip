@@ -247,6 +247,7 @@ struct orbfe_ctx : orbfe_geom_state {
     int pairLast = -1;               // lane of the newest stereo frame submitted with orbfe_extract_stereo_pair_submit
     hipEvent_t evBatchFork = nullptr;
     bool inputGuard = true;       // orbfe_set_lane_input_guard / ORBFE_LANES_INPUT_GUARD=0: the context's stream does not wait for a lane's K-PYR
+    bool exchangeHint = false;    // orbfe_mc_create: a collective stream of the highest priority waits for this context's lanes
     bool forkSkipIdle = true;     // ORBFE_LANES_FORK_ALWAYS=1 (A/B): record + wait even when the context's stream is idle
     hipStream_t runStream = nullptr; // run_device / ensure_capacity: the stream of the call being queued (nullptr: `stream`)
     hipEvent_t guardEv = nullptr;    // run_device records it behind K-PYR (the call's last reader of the caller's images)
@@ -431,14 +432,23 @@ void lanes_invalidate_caps(orbfe_ctx* c)
     for (int k = 0; k < ORBFE_MAX_LANES; k++) c->lane[k].parked.capImgs = 0;
 }
 // Streams and events of the batch lanes.  Streams of ONE priority share four hardware queues (GPU_MAX_HW_QUEUES) with every other
-// stream of the process, and two lanes in one queue serialise (three contexts on normal-priority streams: 0.063 ms per
-// 8 x 1280x720 batch against 0.045 with GPU_MAX_HW_QUEUES=8, profiles/r05_lanes_probe.txt); priorities have queues of their own,
-// so the lanes are spread over the priorities first: normal, lowest, highest, lowest (ORBFE_LANE_PRIOS="0,1,-1,1" overrides;
-// 8 x 1280x720, profiles/r05_lanes_probe.txt: three lanes 0.0432 ms per batch with these, 0.0620 all normal, 0.0452 all lowest;
-// a FOURTH lane at normal priority beside the first: 0.0555, all four lowest: 0.0436).
+// stream of that priority in the process, and two lanes in one queue serialise (three contexts on normal-priority streams
+// beside torch's: 0.063 ms per 8 x 1280x720 batch against 0.045 with GPU_MAX_HW_QUEUES=8, profiles/r05_lanes_probe.txt).
+// Priorities have queues of their own, so the lanes live in the LOWEST class, where nothing else of the process does
+// (ORBFE_LANE_PRIOS="1,1,1,1": 1 = lowest, 0 = normal, -1 = highest; measured on that workload: three lanes 0.0452 ms per batch
+// all lowest, 0.0432 as normal / lowest / highest, 0.0620 all normal; four lanes 0.0436 all lowest, 0.0555 with a second
+// normal one).  The mixed form is 4 % faster on an otherwise idle process but puts a lane into the class of orbfe_mc's
+// collective stream (highest): behind a one-rank RCCL exchange three mixed lanes took 0.070 ms per batch, two took 0.055.
+// Behind an exchange (orbfe_mc_create marks the context) the all-lowest form loses instead -- the collective's stream sits in a
+// higher class with a wait for the lane that is not yet satisfied, and the low queues are served less while it does: 8 x
+// 1280x720 with two lanes 0.092-0.098 ms per batch all lowest, 0.055 as normal / lowest; 64 x 752x480 0.186 against 0.178-0.180
+// (profiles/r05_lanes_probe.txt) -- so a context that feeds orbfe_mc_* uses normal / lowest / normal / lowest.
 int batch_lane_setup(orbfe_ctx* c)
 {
-    int prios[ORBFE_MAX_LANES] = {0, 1, -1, 1};
+    int prios[ORBFE_MAX_LANES] = {1, 1, 1, 1};
+    if (c->exchangeHint) { // orbfe_mc_*: see the end of the comment above
+        prios[0] = prios[2] = 0;
+    }
     if (const char* e = getenv("ORBFE_LANE_PRIOS")) {
         int k = 0;
         for (const char* p = e; *p && k < ORBFE_MAX_LANES; k++) {
@@ -2713,6 +2723,14 @@ int orbfe_set_lanes(orbfe_ctx* c, int lanes)
     c->lanes = lanes;
     if (lanes > 2) c->laneMode = 0; // (half-batches exist for two lanes only)
     c->laneNext = 0;
+    return 0;
+}
+
+// (not in the public header: orbfe_mc_create tells the context that an exchange consumes its batches -- lane priorities above)
+int orbfe_internal_exchange_hint(orbfe_ctx* c, int on)
+{
+    if (!c) return ORBFE_ERR_ARGS;
+    c->exchangeHint = on != 0;
     return 0;
 }
 

@@ -41,6 +41,7 @@
 
 extern "C" int orbfe_get_stream(orbfe_ctx*, void** hip_stream, int* device);
 extern "C" int orbfe_lanes_record(orbfe_ctx*, void* hip_event);
+extern "C" int orbfe_internal_exchange_hint(orbfe_ctx*, int on);
 
 namespace {
 
@@ -330,6 +331,7 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
         void* st = nullptr;
         if ((r = orbfe_get_stream(ctx, &st, &m->device)) < 0) return fail(r);
         m->sCtx = (hipStream_t)st;
+        (void)orbfe_internal_exchange_hint(ctx, 1); // (lane streams created from here on take the priorities that suit an exchange)
         if (hipSetDevice(m->device) != hipSuccess) return fail(ORBFE_ERR_NODEV);
         {
             // The collective's stream gets the HIGHEST priority: priorities have hardware queues of their own, and the runtime
@@ -342,7 +344,9 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
                 (void)hipGetLastError();
                 least = greatest = 0;
             }
-            if (hipStreamCreateWithPriority(&m->sComm, hipStreamNonBlocking, greatest) != hipSuccess) {
+            int prio = greatest;
+            if (const char* e = getenv("ORBFE_MC_COMM_PRIO")) prio = atoi(e) < 0 ? greatest : atoi(e) > 0 ? least : 0; // (tuning)
+            if (hipStreamCreateWithPriority(&m->sComm, hipStreamNonBlocking, prio) != hipSuccess) {
                 (void)hipGetLastError();
                 if (hipStreamCreateWithFlags(&m->sComm, hipStreamNonBlocking) != hipSuccess) return fail(ORBFE_ERR_STATE);
             }
