@@ -174,6 +174,7 @@ struct KeyFrameHandles {
         unsigned long id = 0;
         int n = 0, device = 0;
         const void* desc = nullptr;
+        size_t fvNodes = 0, fvFeat = 0; // the FeatureVector the handle was built from (nodes, indexed features)
         std::shared_ptr<Handle> h;
         unsigned long used = 0;
     };
@@ -181,18 +182,34 @@ struct KeyFrameHandles {
     std::vector<Entry> e;
     unsigned long clock = 0;
     long creates = 0, hits = 0; // (what the tests look at)
+    // (i) a KeyFrame's mFeatVec is EMPTY between its construction from a frame the motion model tracked
+    // (KeyFrame(F, ...) copies F.mFeatVec, src/KeyFrame.cc) and LocalMapping's ComputeBoW (src/LocalMapping.cc:380), while
+    // Tracking already searches it as mpReferenceKF (src/Tracking.cc:3290): no handle is made or cached in that window -- the
+    // caller takes the per-call path, which reads the vector as it is, like the reference -- and the vector's size is part of
+    // an entry's key, so a handle never outlives the vector it was built from; (ii) handles are created and destroyed OUTSIDE
+    // the table's lock (a creation uploads and waits for its stream, a destruction waits for the handle's users): Tracking,
+    // LocalMapping and LoopClosing only ever contend for the table walk.
     template <class KF>
     std::shared_ptr<Handle> get(KF* pKF, int device)
     {
-        std::lock_guard<std::mutex> lock(m);
         const int n = pKF->N;
-        for (Entry& x : e)
-            if (x.obj == pKF && x.id == pKF->mnId && x.n == n && x.desc == pKF->mDescriptors.data && x.device == device) {
-                x.used = ++clock;
-                hits++;
-                return x.h;
-            }
-        if (n < 1 || pKF->mDescriptors.rows < n) return nullptr;
+        const size_t fvNodes = pKF->mFeatVec.size();
+        if (fvNodes == 0 || n < 1 || pKF->mDescriptors.rows < n) return nullptr;
+        size_t fvFeat = 0;
+        for (DBoW2::FeatureVector::const_iterator it = pKF->mFeatVec.begin(); it != pKF->mFeatVec.end(); ++it) fvFeat += it->second.size();
+        auto same = [&](const Entry& x) {
+            return x.h && x.obj == pKF && x.id == pKF->mnId && x.n == n && x.desc == pKF->mDescriptors.data && x.device == device &&
+                   x.fvNodes == fvNodes && x.fvFeat == fvFeat;
+        };
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (Entry& x : e)
+                if (same(x)) {
+                    x.used = ++clock;
+                    hits++;
+                    return x.h;
+                }
+        }
         // flatten once: what rig_keypoint reads (mvKeysUn without a second camera, else mvKeys / mvKeysRight)
         std::vector<uint8_t> tmp, mask((size_t)n, 0);
         std::vector<float> xy(2 * (size_t)n), ang((size_t)n);
@@ -222,29 +239,51 @@ struct KeyFrameHandles {
         std::shared_ptr<Handle> H = std::make_shared<Handle>();
         if (orbfe_keyframe_create(&H->h, device, &a) < 0) return nullptr;
         H->tri = tri;
-        creates++;
-        Entry* slot = nullptr;
-        if (e.size() < 512) {
-            e.emplace_back();
-            slot = &e.back();
-        } else {
-            slot = &e[0];
+        std::shared_ptr<Handle> evicted; // (released after the lock: its destructor may wait for the device)
+        {
+            std::lock_guard<std::mutex> lock(m);
             for (Entry& x : e)
-                if (x.used < slot->used) slot = &x;
+                if (same(x)) { // another thread made it meanwhile: use theirs, ours dies behind the lock
+                    x.used = ++clock;
+                    hits++;
+                    evicted = std::move(H);
+                    H = x.h;
+                    break;
+                }
+            if (!evicted) {
+                creates++;
+                Entry* slot = nullptr;
+                for (Entry& x : e) // a stale entry of the same KeyFrame (its FeatureVector has been computed since) goes first
+                    if (x.obj == pKF && x.id == pKF->mnId && x.device == device) slot = &x;
+                if (!slot && e.size() < 512) {
+                    e.emplace_back();
+                    slot = &e.back();
+                } else if (!slot) {
+                    slot = &e[0];
+                    for (Entry& x : e)
+                        if (x.used < slot->used) slot = &x;
+                }
+                evicted = std::move(slot->h); // (dies with its last user, and not under the lock)
+                slot->obj = pKF;
+                slot->id = pKF->mnId;
+                slot->n = n;
+                slot->device = device;
+                slot->desc = pKF->mDescriptors.data;
+                slot->fvNodes = fvNodes;
+                slot->fvFeat = fvFeat;
+                slot->h = H;
+                slot->used = ++clock;
+            }
         }
-        slot->obj = pKF;
-        slot->id = pKF->mnId;
-        slot->n = n;
-        slot->device = device;
-        slot->desc = pKF->mDescriptors.data;
-        slot->h = H; // (the evicted handle dies with its last user)
-        slot->used = ++clock;
         return H;
     }
     void clear()
     {
-        std::lock_guard<std::mutex> lock(m);
-        e.clear();
+        std::vector<Entry> dead;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            dead.swap(e);
+        }
     }
 };
 inline KeyFrameHandles& keyframe_handles()

@@ -181,6 +181,28 @@ static void test_bow_kf_f(const std::string& P)
     run(rb1);
     orbfe_adapter::use_keyframe_handles() = true;
     put_i(P + "kfhandles", std::vector<int32_t>{(int32_t)dc, (int32_t)dh, (ra1 == rb1 && ra2 == rb2 && ra1[0] == nm) ? 1 : 0});
+    // a KeyFrame built from a frame the motion model tracked has an EMPTY mFeatVec until LocalMapping's ComputeBoW
+    // (src/LocalMapping.cc:380) while Tracking already searches it as mpReferenceKF (src/Tracking.cc:3290).  Searched in that
+    // window it must behave like the reference -- no common node, no match -- WITHOUT leaving a handle behind; searched again
+    // after ComputeBoW it must find what the keyframe above finds, through a handle made then.
+    {
+        KeyFrame late;
+        late.N = n1;
+        late.mnId = kf.mnId + 1000;
+        late.mvKeysUn = kf.mvKeysUn;
+        late.mDescriptors = kf.mDescriptors;
+        late.mvpMapPoints = kf.mvpMapPoints;
+        const long c1 = H.creates;
+        std::vector<MapPoint*> v;
+        const int before = matcher.SearchByBoW(&late, F, v);
+        const long createdBefore = H.creates - c1;
+        late.mFeatVec = kf.mFeatVec; // ComputeBoW
+        std::vector<MapPoint*> v2;
+        const int after = matcher.SearchByBoW(&late, F, v2);
+        bool same = after == nm;
+        for (int i = 0; i < n2 && same; i++) same = (v2[i] ? (int32_t)v2[i]->mnId : -1) == out[i];
+        put_i(P + "fvlate", std::vector<int32_t>{before, (int32_t)createdBefore, same ? 1 : 0, (int32_t)(H.creates - c1)});
+    }
 }
 
 static void test_bow_kf_kf(const std::string& P)

@@ -190,7 +190,8 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
  *     before the lane writes again -- a lane is a stream).
  * ORBFE_LANES_SPLIT (round 4; n = 2 only): a call with >= 8 images (ORBFE_LANES_MIN) runs as two half-batches, images [0, h)
  * on the context's stream and [h, nimg) on a second stream, no event between the two inside a call (64 x 752x480: 0.19 ->
- * ~0.17 ms per batch).  Kept for A/B; for small batches it splits what is already too small.
+ * ~0.17 ms per batch).  Kept for A/B; for small batches it splits what is already too small.  This mode has NO input guard:
+ * the images [h, nimg) of a call must not be rewritten before orbfe_lanes_join or orbfe_sync.
  *
  * Results are bit-identical in every mode.  What changes is ORDERING: after a call the outputs are NOT yet ordered on the
  * context's stream.  They are after any of
@@ -391,7 +392,11 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
  * mask1 / mask2 and SearchForTriangulation_'s hasMP), angles, and the FeatureVector; with kp_xy / octave / uRight given it
  * can also be a side of the triangulation search.  Descriptors, keypoints and the FeatureVector of a KeyFrame never change
  * (ComputeBoW runs once); its MapPoints do: orbfe_keyframe_set_mask re-sends the n flag bytes when they differ from the last
- * ones.  A handle is read by the searches of any thread; create / set_mask / destroy are the owner's. */
+ * ones.  A handle is read by the searches of any thread; create / set_mask / destroy are the owner's: set_mask rewrites the
+ * handle's flags in place and must not run while a search of another thread that relies on them (one that passes no flags of
+ * its own: mask1 / mask2 / hasMP == NULL) is in progress -- callers that search one keyframe from several threads send the flags
+ * with every call instead, as adapters/ORBmatcher.h does --, and destroy must not run while ANY call that was given the handle
+ * is in progress (it does not wait for the device: a search has done all its device reads before it returns). */
 typedef struct orbfe_keyframe orbfe_keyframe;
 typedef struct {
     const uint8_t* desc; int n;            /* 32-B rows; host or device pointer                                      */

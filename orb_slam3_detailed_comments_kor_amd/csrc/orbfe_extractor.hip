@@ -309,7 +309,8 @@ struct orbfe_ctx : orbfe_geom_state {
     DevBuf<unsigned> d_done;  // 65 counters
     PinBuf<unsigned> h_done;  // the flag word
     unsigned doneSeq = 0;     // last sequence number handed out
-    int spinMisses = 0;       // consecutive waits without the word inside the bound: at 8 spinWait is switched off for this context
+    int spinMisses = 0;       // consecutive waits in which the word never came (spin_settle): at 8 spinWait is switched off for this context
+    unsigned spinLate = 0;    // the number a wait ran into its bound for (spin_done -> spin_settle)
     int lapInlineN = 0, lapInline[4] = {0, 0, 0, 0}; // host_submit -> run_device: the lapping ranges of a call of <= 2 images
     bool doneWant = false;    // host_submit -> run_device: the caller wants the word for this call
     unsigned doneGot = 0;     // run_device -> host_submit: the number K-DESC will publish, or 0
@@ -2307,6 +2308,7 @@ int host_submit(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int rows, in
 // Spin on the context's completion word for `seq` (bounded), true when it was seen.
 static bool spin_done(orbfe_ctx* c, unsigned seq)
 {
+    c->spinLate = 0u;
     if (!seq || !c->h_done.p) return false;
     const volatile unsigned* f = c->h_done.p;
     const auto t0 = std::chrono::steady_clock::now();
@@ -2324,8 +2326,19 @@ static bool spin_done(orbfe_ctx* c, unsigned seq)
     // The word did not come within the bound (the caller now synchronises the stream).  Should a counter ever be left non-zero
     // -- a kernel that died half-way -- every later call would time out as well: clear them behind whatever is still queued.
     (void)hipMemsetAsync(c->d_done.p, 0, 80 * sizeof(unsigned), run_stream(c));
-    if (++c->spinMisses >= 8) c->spinWait = false; // (the word does not arrive on this platform: stop paying the bound)
+    c->spinLate = seq; // (spin_settle, once the caller has synchronised the stream, says whether this was a miss)
     return false;
+}
+// After the stream synchronisation that follows a spin_done() == false: a word that is there now was merely late (a long
+// call, a kernel queued behind somebody else's work); one that is still missing counts, and eight of those in a row switch
+// the word off for this context (lateness alone used to count).
+static void spin_settle(orbfe_ctx* c)
+{
+    if (!c->spinLate || !c->h_done.p) return;
+    const unsigned v = *(const volatile unsigned*)c->h_done.p;
+    if (v == c->spinLate || v == (c->spinLate | 0x80000000u)) c->spinMisses = 0;
+    else if (++c->spinMisses >= 8) c->spinWait = false; // (the word does not arrive on this platform: stop paying the bound)
+    c->spinLate = 0u;
 }
 
 // Complete the oldest submitted batch: wait for its transfers, hand out the counts, and -- for pageable output
@@ -2340,6 +2353,7 @@ int host_wait(orbfe_ctx* c, int laneSlot = -1 /* as in host_submit_impl */)
     // (the completion word the call's last kernel publishes behind the results it has written: OrbDone)
     const bool seen = !sl.pipelined && spin_done(c, sl.doneSeq);
     if (!seen) e = sl.pipelined ? hipEventSynchronize(sl.evDone) : hipStreamSynchronize(run_stream(c));
+    if (!seen && !sl.pipelined) spin_settle(c);
     sl.busy = false;
     if (laneSlot < 0) c->slotRetired++;
     if (e != hipSuccess) return -(1000 + (int)e);
@@ -3146,7 +3160,10 @@ int orbfe_compute_stereo_matches_resident(orbfe_ctx* left, int imgL, orbfe_ctx* 
     int r;
     unsigned seq = 0;
     if ((r = stereo_resident_launch(left, imgL, right, imgR, mb, mbf, &seq)) < 0) return r;
-    if (!spin_done(left, seq)) HIP_TRY(hipStreamSynchronize(left->stream));
+    if (!spin_done(left, seq)) {
+        HIP_TRY(hipStreamSynchronize(left->stream));
+        spin_settle(left);
+    }
     return stereo_resident_finish(left, uRight, depth, nL);
 }
 

@@ -2232,6 +2232,7 @@ struct Arena {
     unsigned* doneFlag = nullptr;    // host address
     unsigned* doneFlagDev = nullptr; // the kernel's address of the same word
     unsigned doneSeq = 0;
+    unsigned spinProbe = 0; // calls since the word was given up (done_words re-probes now and then)
     int spinMisses = 0; // consecutive waits in which the word did not arrive within the bound; at 8 the word is given up for
                         // this thread (a platform where the kernel's flag store does not reach the host while the kernel runs
                         // would otherwise cost every call the full bound)
@@ -2621,7 +2622,9 @@ struct Scratch { // device allocations of one call
     }
     bool done_words()
     {
-        if (ar->spinMisses >= 8) return false;
+        // (eight waits in a row in which the word NEVER arrived -- not merely late, see complete() -- switch it off for
+        // this thread; one call in 256 still carries it, so a thread that lost it on a loaded GPU gets it back)
+        if (ar->spinMisses >= 8 && (++ar->spinProbe & 255u) != 0u) return false;
         if (ar->doneCtr) return true;
         void *c = nullptr, *h = nullptr, *dv = nullptr;
         // (cleared on the call's own stream: the null stream is not ordered with a non-blocking one)
@@ -2713,8 +2716,10 @@ struct Scratch { // device allocations of one call
                 if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
             }
         }
-        if (w.flag) ar->spinMisses++;
         hipError_t e = hipStreamSynchronize(g_ms);
+        // a miss is a word that has still not arrived when the stream is idle; a word that came after the bound belongs to a long
+        // call, a first call (code object load) or a kernel queued behind somebody else's work, and says nothing about the platform
+        if (w.flag) ar->spinMisses = (*(const volatile unsigned*)ar->doneFlag == w.seq) ? 0 : ar->spinMisses + 1;
         // the word did not come within the bound: normally a long call (its counter is back at zero by now); should the counter
         // ever be left non-zero -- a kernel that died half-way -- every later call would time out, so it is cleared here
         if (e == hipSuccess && w.flag) e = hipMemsetAsync(ar->doneCtr, 0, 64, g_ms); // (all its words: K-PROJ keeps a counter there too)
@@ -3402,7 +3407,11 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     Scratch s(device); // (this thread's matcher stream)
     const bool descResident = is_device_ptr(a->desc);
     if (descResident) {
-        if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) return w;
+        if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) {
+            g_blockPool.put(device, blk, blkCap); // (this path used to leak the handle and its block)
+            delete K;
+            return w;
+        }
     }
     // the whole block staged in this thread's pinned arena in the block's own layout, then ONE upload (seven pageable copies,
     // each staged and waited for by the runtime, were most of the 38 us this call took)
@@ -3461,10 +3470,11 @@ int orbfe_keyframe_set_mask(orbfe_keyframe* K, const uint8_t* mask)
 void orbfe_keyframe_destroy(orbfe_keyframe* K)
 {
     if (!K) return;
-    if (hipSetDevice(K->device) == hipSuccess) {
-        (void)hipDeviceSynchronize(); // (a search of another thread may still be reading it)
-        g_blockPool.put(K->device, K->block, K->blockCap);
-    }
+    // (no hipDeviceSynchronize here -- it drained the extractor's batches in flight and every other thread's
+    // searches whenever the adapter's table evicted a keyframe.  The contract is the one of orbfe_frame_destroy: no call that
+    // was given this handle is still running -- the adapter's reference count sees to it --, and every search has done all its
+    // device reads before it returns, with the completion word as without it.)
+    g_blockPool.put(K->device, K->block, K->blockCap);
     delete K;
 }
 

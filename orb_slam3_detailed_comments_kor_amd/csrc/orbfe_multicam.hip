@@ -43,6 +43,25 @@ extern "C" int orbfe_get_stream(orbfe_ctx*, void** hip_stream, int* device);
 extern "C" int orbfe_lanes_record(orbfe_ctx*, void* hip_event);
 extern "C" int orbfe_internal_exchange_hint(orbfe_ctx*, int on);
 
+// RCCL is resolved at run time (dlopen: the single-GPU library has no link dependency on it), so the few facts about its ABI
+// this file relies on are mirrored by hand below.  Where the header exists at build time they are CHECKED:
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert(sizeof(ncclUniqueId) == ORBFE_MC_ID_BYTES, "ORBFE_MC_ID_BYTES must be sizeof(ncclUniqueId)");
+static_assert((int)ncclUint8 == 1 && (int)ncclInt8 == 0, "kNcclUint8 mirrors ncclUint8");
+static_assert((int)ncclSuccess == 0, "0 is ncclSuccess");
+static_assert(std::is_same<decltype(&ncclAllGather),
+                           ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value,
+              "ncclAllGather's signature changed");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>::value,
+              "ncclCommInitRank's signature changed");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId*)>::value, "ncclGetUniqueId's signature changed");
+#define ORBFE_RCCL_HEADER_CHECKED 1
+#endif
+#endif
+
 namespace {
 
 inline size_t align_up_mc(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -89,6 +89,9 @@ def _bow_kf_f(f, tag, oracle, seed, n1, n2, nleft, ratio, ori):
         # keyframe handle: created by the first search, hit by the two that follow (one with changed MapPoint flags, which travel
         # with the call); the same results with handles switched off
         assert list(res[tag + "kfhandles"]) == [0, 2, 1], (tag, res[tag + "kfhandles"])
+        # searched before ComputeBoW (empty FeatureVector) -> no match and NO handle cached; after it -> the same
+        # matches as the keyframe above, through a handle created then
+        assert list(res[tag + "fvlate"]) == [0, 0, 1, 1], (tag, res[tag + "fvlate"])
     return check
 
 
