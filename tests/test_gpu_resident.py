@@ -1,5 +1,7 @@
 """Extract -> match without leaving the device: the matcher reads the descriptors where the extractor (or the
 all-gather) left them in HBM.  Every result is compared with the oracle run on the downloaded descriptors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -122,6 +124,90 @@ def test_frames_knn2_ragged_counts_and_both_kernel_shapes(pkg, oracle):
             ri, rd = oracle.bfknn2(desc[q, :counts[q]], desc[t, :counts[t]])
             assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), (frames, k)
             assert (idx[k, counts[q]:] == -7).all()  # rows beyond the query count are untouched
+
+
+def _frames_knn2(pkg, torch, dev, desc, counts, pairs, cap):
+    d_desc = torch.from_numpy(desc).to(dev)
+    d_cnt = torch.from_numpy(counts).to(dev)
+    rec = np.zeros(len(pairs), pkg.binding.KNN2_JOB_DTYPE)
+    for k, (q, t) in enumerate(pairs):
+        rec[k] = (d_desc.data_ptr() + q * cap * 32, d_cnt.data_ptr() + 4 * q, d_desc.data_ptr() + t * cap * 32, d_cnt.data_ptr() + 4 * t)
+    d_jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    d_idx = torch.full((len(pairs), cap, 2), -7, dtype=torch.int32, device=dev)
+    d_dist = torch.full((len(pairs), cap, 2), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    pkg.binding.bfknn2_frames_device(d_jobs.data_ptr(), len(pairs), cap, d_idx.data_ptr(), d_dist.data_ptr())
+    pkg.binding.matcher_sync()
+    return d_idx.cpu().numpy(), d_dist.cpu().numpy()
+
+
+def test_frames_knn2_on_the_matrix_pipe_is_exact(pkg, oracle):
+    """k_bfknn2_frames_mfma (round 5): the knn-2 of many frame pairs as i8 MFMAs whose accumulator IS the scan's key.  Exact
+    means exact: distances, indices and TIE ORDER (lower train index first, also for the second best) against the oracle's
+    sequential scan, on (a) train counts around every tile boundary (0, 1, 2, 31, 32, 33, 63, 64, 65, cap), (b) descriptor sets
+    drawn from a handful of prototypes so that most distances tie, (c) all-zero / all-one descriptors (distance 0 and 256, the
+    ends of the key's range), (d) the largest frame the 11 index bits allow (2048), (e) query counts that leave the last
+    workgroup / wavefront / tile partly empty, (f) job counts that are and are not multiples of 8 (the XCD-affine order)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2025)
+    # (a) + (e) + (f): boundaries
+    cap = 300
+    tcounts = [0, 1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, cap, 100, 7, 290]
+    frames = len(tcounts)
+    counts = np.array(tcounts, np.int32)
+    desc = rng.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
+    pairs = [(q, t) for q in (12, 11, 9, 5, 1, 0) for t in range(frames)]  # 96 jobs: a multiple of 8
+    idx, dist = _frames_knn2(pkg, torch, dev, desc, counts, pairs, cap)
+    for k, (q, t) in enumerate(pairs):
+        ri, rd = oracle.bfknn2(desc[q, :counts[q]], desc[t, :counts[t]])
+        assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), ("boundaries", q, t)
+        assert (idx[k, counts[q]:] == -7).all()
+    pairs = pairs[:13]  # not a multiple of 8
+    idx, dist = _frames_knn2(pkg, torch, dev, desc, counts, pairs, cap)
+    for k, (q, t) in enumerate(pairs):
+        ri, rd = oracle.bfknn2(desc[q, :counts[q]], desc[t, :counts[t]])
+        assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), ("13 jobs", q, t)
+    # (b) + (c): ties everywhere
+    cap = 520
+    proto = rng.integers(0, 256, size=(6, 32), dtype=np.uint8)
+    proto[0] = 0
+    proto[1] = 255
+    frames = 8
+    desc = proto[rng.integers(0, 6, size=(frames, cap))]
+    flip = rng.random((frames, cap)) < 0.3  # a third of the rows one bit away from their prototype
+    desc[flip, 7] ^= 0x10
+    counts = rng.integers(400, cap + 1, size=frames).astype(np.int32)
+    pairs = [(i, (i + 3) % frames) for i in range(frames)]
+    idx, dist = _frames_knn2(pkg, torch, dev, desc, counts, pairs, cap)
+    for k, (q, t) in enumerate(pairs):
+        ri, rd = oracle.bfknn2(desc[q, :counts[q]], desc[t, :counts[t]])
+        assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), ("ties", q, t)
+        assert (rd[:, 0] == rd[:, 1]).mean() > 0.5  # (the case really is about ties)
+    # (d): 2048 rows -- the index field full -- and just above it (the vector-pipe kernel takes over: keys of 20 index bits)
+    for cap in (2048, 2100):
+        frames = 3
+        counts = np.array([cap, cap - 37, 1999], np.int32)
+        desc = rng.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
+        desc[1, cap - 40] = desc[0, 2047]  # a best match at the very last index of the field
+        pairs = [(0, 1), (1, 0), (2, 0), (1, 2)]
+        idx, dist = _frames_knn2(pkg, torch, dev, desc, counts, pairs, cap)
+        for k, (q, t) in enumerate(pairs):
+            ri, rd = oracle.bfknn2(desc[q, :counts[q]], desc[t, :counts[t]])
+            assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), (cap, q, t)
+
+
+def test_frames_knn2_vector_pipe_kernel_in_a_fresh_process():
+    # ORBFE_KNN2_MFMA=0 keeps k_bfknn2_frames (the form for frames of more than 2048 keypoints, and the A/B of the MFMA
+    # kernel): the same checks through it
+    import subprocess
+    import sys
+    env = dict(os.environ, ORBFE_KNN2_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_frames_knn2_on_the_matrix_pipe_is_exact or test_frames_knn2_ragged_counts"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout
 
 
 def test_matcher_orders_itself_after_an_asynchronous_extraction(pkg, oracle):
