@@ -706,6 +706,49 @@ def main():
                      "ms_per_step": 1e3 * tc / args.steps, "knn2_launch_ms": knn_ms,
                      "distances_per_launch": ndist, "distances_per_s": ndist / (knn_ms * 1e-3),
                      "ratio_test_survivors_per_frame": float((good & valid).sum().item()) / max(cm.njobs, 1)}
+            # The brute force's roofs (VERDICT r04 #4a).  Matrix-pipe form (k_bfknn2_frames_mfma, frames of <= 2048 keypoints): per
+            # distance 256 + 32 i8 MACs (the descriptor's bits + the index block) against the dense i8 MFMA peak, 1024 SIMDs x
+            # 32x32x32 MACs per 32 cycles at 2.4 GHz; vector-pipe form (k_bfknn2_frames, ORBFE_KNN2_MFMA=0 / larger frames): 8
+            # v_xor + 8 v_bcnt per 64 distances per SIMD at the issue costs of profiles/r01_valu_rate.txt (2.7 / 4.45 cycles).
+            mfma_on = os.environ.get("ORBFE_KNN2_MFMA", "1") != "0" and cap <= 2048
+            i8_peak = 1024 * (32 * 32 * 32 * 2 / 32.0) * 2.4e9 / 1e12  # TOP/s
+            vec_peak = 1024 * 64 / (8 * 2.7 + 8 * 4.45) * 2.4e9        # distances/s
+            if mfma_on:
+                tops = ndist * 2 * 288 / (knn_ms * 1e-3) / 1e12
+                cross["roofline"] = {"bound": "mfma", "kernel": "k_bfknn2_frames_mfma", "achieved": tops, "peak": i8_peak,
+                                     "unit": "TOP/s", "frac": tops / i8_peak, "traffic": None,
+                                     "algorithmic_ops_per_launch": ndist * 2 * 288,
+                                     "note": "exact: the i32 accumulator of v_mfma_i32_32x32x32_i8 is the sequential scan's key "
+                                             "(DESIGN.md 7.5); 2 x (256 + 32) i8 operations per distance",
+                                     "vector_pipe_peak_distances_per_s": vec_peak,
+                                     "distances_per_s_over_vector_pipe_peak": ndist / (knn_ms * 1e-3) / vec_peak}
+            else:
+                cross["roofline"] = {"bound": "valu", "kernel": "k_bfknn2_frames<8>", "achieved": ndist / (knn_ms * 1e-3),
+                                     "peak": vec_peak, "unit": "distances/s", "frac": ndist / (knn_ms * 1e-3) / vec_peak,
+                                     "traffic": None}
+            # ... and the single-problem kernel at BASELINE configs[4]'s size (orbfe_bfknn2 inside
+            # Frame::ComputeStereoFishEyeMatches: 1500 x 1500, one wavefront per query)
+            try:
+                nb = 1500
+                dq = torch.randint(0, 256, (nb, 32), dtype=torch.uint8, device=dev)
+                dt2 = torch.randint(0, 256, (nb, 32), dtype=torch.uint8, device=dev)
+                di = torch.zeros((nb, 2), dtype=torch.int32, device=dev)
+                dd = torch.zeros((nb, 2), dtype=torch.int32, device=dev)
+                for _ in range(3):
+                    pkg.binding.bfknn2_device(dq.data_ptr(), nb, dt2.data_ptr(), nb, di.data_ptr(), dd.data_ptr(), stream=stream.cuda_stream)
+                e0.record()
+                for _ in range(20):
+                    pkg.binding.bfknn2_device(dq.data_ptr(), nb, dt2.data_ptr(), nb, di.data_ptr(), dd.data_ptr(), stream=stream.cuda_stream)
+                e1.record()
+                torch.cuda.synchronize()
+                ms1 = e0.elapsed_time(e1) / 20
+                cross["bfknn2_1500x1500"] = {"kernel": "k_bfknn2", "launch_ms": ms1, "distances_per_s": nb * nb / (ms1 * 1e-3),
+                                             "roofline": {"bound": "valu", "achieved": nb * nb / (ms1 * 1e-3), "peak": vec_peak,
+                                                          "unit": "distances/s", "frac": nb * nb / (ms1 * 1e-3) / vec_peak,
+                                                          "note": "2.25 M distances are 0.8 us of popcount issue: the launch is its "
+                                                                  "own latency (1500 wavefronts of 24 dependent iterations)"}}
+            except Exception as e:  # noqa: BLE001
+                cross["bfknn2_1500x1500"] = {"error": "%s: %s" % (type(e).__name__, e)}
             prev[0] = None
         except Exception as e:  # noqa: BLE001
             cross = {"error": "%s: %s" % (type(e).__name__, e)}

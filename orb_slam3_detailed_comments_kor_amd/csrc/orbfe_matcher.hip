@@ -1749,6 +1749,13 @@ struct ProjDev {
     int mirrorInts;
     unsigned* doneFlag;
     unsigned doneSeq;
+    // Round 5: the one state the fixpoint of k_proj_sweeps does not represent -- map points with Observations() == 0 among
+    // the queries TOGETHER with stereo-partner writes (src/ORBmatcher.cc:83-85, :117-121: the partner entry is overwritten
+    // without looking at its occupant, so a non-blocking point can FREE a feature an earlier point had taken) -- walks the
+    // queries in order instead (proj_inorder_body).  `taken` is then null for the candidates kernel (a feature that is
+    // occupied on entry may become free) and the entry state travels in taken0.
+    int inorder;
+    const uint8_t* taken0;
 };
 // Every query owns PROJ_QUOTA key slots (its stretch starts at PROJ_QUOTA * q); a query with more candidates takes a stretch of
 // the overflow region behind them, handed out by an atomic on status[2].  (Handing out EVERY stretch that way -- 300 wavefronts
@@ -2067,8 +2074,103 @@ __device__ __forceinline__ void proj_candidates_body(const ProjDev& P)
 #define PT(k) do { } while (0)
 #define PT_END(n) do { } while (0)
 #endif
+// The sequential walk itself (ProjDev::inorder): ONE wavefront takes the queries in the reference's order over the keys
+// k_proj_candidates left sorted by (distance, visit order); the lanes look at 64 keys of a query at a time, the first two
+// whose feature is not blocked RIGHT NOW are the loop's best and second best.  Per feature: blocked (the occupant has
+// Observations() > 0) and the last writer -- F.mvpMapPoints as the reference mutates it.  ~1 us per query (dependent reads);
+// only the state above pays it, every other search keeps the fixpoint kernel.
+__device__ __forceinline__ void proj_inorder_body(const ProjDev& P)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = P.n, nq = P.nq;
+    int32_t* const blocked = P.minW; // n entries (the sweeps' table, unused here)
+    for (int i = tid; i < n; i += PROJ_THREADS) {
+        blocked[i] = (P.taken0 && P.taken0[i]) ? 1 : 0;
+        P.featMatch[i] = -1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid >= 64) return; // (no barrier below)
+    int cnt = 0, prevRejected = 0;
+    for (int q = 0; q < nq; q++) {
+        const int flags = P.qflags ? P.qflags[q] : 0;
+        const bool bRight = flags & 1;
+        const bool skip = q > 0 && (((flags & 2) && prevRejected) || ((flags & 4) && P.qArea[q - 1] == 0));
+        prevRejected = 0;
+        const int m = skip ? 0 : P.qCount[q];
+        const unsigned long long* const K = P.sortedKeys + P.qStart[q];
+        int g1 = -1, d1 = 256, g2 = -1, d2 = 256;
+        bool done_ = false;
+        for (int base = 0; base < m && !done_; base += 64) {
+            const unsigned long long key = base + lane < m ? K[base + lane] : ~0ull;
+            const int d = (int)(key >> 55);
+            const int g = (int)(key & 0xFFFFFF);
+            const bool live = d < 256; // (`dist<bestDist` with bestDist = 256 never accepts the others; keys are sorted)
+            const bool cand = live && blocked[g] == 0;
+            unsigned long long mask = __ballot(cand);
+            const bool ended = __ballot(!live) != 0ull; // (the keys are sorted: nothing behind this round can be accepted)
+            while (mask && !done_) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int gl = __shfl(g, l), dl = __shfl(d, l);
+                if (g1 < 0) {
+                    g1 = gl;
+                    d1 = dl;
+                    if (P.mode != 0) done_ = true;
+                } else {
+                    g2 = gl;
+                    d2 = dl;
+                    done_ = true;
+                }
+            }
+            if (ended) done_ = true;
+        }
+        int choice = -1, partner = -1;
+        if (g1 >= 0 && d1 <= P.thHigh) {
+            bool ok = true;
+            if (P.mode == 0) {
+                const int lvl1 = P.octave[g1];
+                const int bestLevel2 = g2 >= 0 ? P.octave[g2] : -1;
+                if (lvl1 == bestLevel2 && (float)d1 > __fmul_rn(P.nnratio, (float)d2)) {
+                    ok = false;
+                    prevRejected = 1;
+                }
+            }
+            if (ok) {
+                choice = g1;
+                if (P.mode == 0 && P.Nleft != -1) {
+                    if (!bRight && P.l2r && P.l2r[g1] != -1) partner = P.l2r[g1] + P.Nleft;
+                    if (bRight && P.r2l && P.r2l[g1 - P.Nleft] != -1) partner = P.r2l[g1 - P.Nleft];
+                }
+            }
+        }
+        if (lane == 0) {
+            const int blocks = (!P.qblocks || P.qblocks[q]) ? 1 : 0;
+            P.qMatch[q] = choice;
+            if (choice >= 0) { // F.mvpMapPoints[bestIdx] = pMP
+                blocked[choice] = blocks;
+                P.featMatch[choice] = q;
+            }
+            if (partner >= 0) { // ... and the stereo partner's entry, whoever held it (:117-121)
+                blocked[partner] = blocks;
+                P.featMatch[partner] = q;
+            }
+        }
+        cnt += (choice >= 0) + (partner >= 0);
+        __threadfence_block(); // the next query's lanes read what lane 0 has just written
+    }
+    if (lane == 0) {
+        P.status[0] = cnt;
+        P.status[1] = 1;
+    }
+}
+
 __device__ __forceinline__ void proj_sweeps_body(const ProjDev& P)
 {
+    if (P.inorder) { // (uniform)
+        proj_inorder_body(P);
+        return;
+    }
     __shared__ int sChanged;
     PT_BEGIN();
     extern __shared__ int32_t projLds[]; // (2 n + 6 nq) ints when the host found that they fit, else nothing
@@ -4508,10 +4610,8 @@ int proj_validate(const orbfe_proj_args* a, const int32_t* q_match, const int32_
         if ((f & 1) && a->Nleft == -1) return ORBFE_ERR_ARGS; // there is no right grid
         // bit 2 refers to the query before, which must be an unconditional one
         if ((f & 4) && (q == 0 || (a->qflags[q - 1] & 6))) return ORBFE_ERR_ARGS;
-        // a non-blocking map point (Observations()==0) that overwrites a stereo partner could free a taken
-        // feature again (:117-121); the sweep formulation does not represent that
-        if (a->qblocks && !a->qblocks[q] && a->mode == 0 && a->Nleft != -1 && (a->left_to_right || a->right_to_left))
-            return ORBFE_ERR_ARGS;
+        // (a non-blocking map point -- Observations() == 0 -- that overwrites a stereo partner can free a taken feature again,
+        // :117-121: that search walks its queries in order, proj_needs_inorder / proj_inorder_body; refused until round 5)
     }
     if (a->Nleft != -1 && a->mode == 0 && a->n && a->nq) {
         for (int i = 0; a->left_to_right && i < a->Nleft; i++)
@@ -4520,6 +4620,14 @@ int proj_validate(const orbfe_proj_args* a, const int32_t* q_match, const int32_
             if (a->right_to_left[i] < -1 || a->right_to_left[i] >= a->Nleft) return ORBFE_ERR_ARGS;
     }
     return 0;
+}
+
+bool proj_needs_inorder(const orbfe_proj_args* a)
+{
+    if (!(a->qblocks && a->mode == 0 && a->Nleft != -1 && (a->left_to_right || a->right_to_left))) return false;
+    for (int q = 0; q < a->nq; q++)
+        if (!a->qblocks[q]) return true;
+    return false;
 }
 
 struct ProjJob {
@@ -4604,6 +4712,12 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_fra
         P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
         P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
         P.invSigma2 = dInvSigma2; P.chi2 = a->chi2_gate ? 1 : 0;
+        P.inorder = proj_needs_inorder(a) ? 1 : 0;
+        P.taken0 = nullptr;
+        if (P.inorder) { // (the entry state is applied by the walk, not by the candidates' static test)
+            P.taken0 = P.taken;
+            P.taken = nullptr;
+        }
         return 0;
     }
     if (F) {
@@ -4716,7 +4830,9 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
         jobs[j].P.featMatch = jobs[j].P.qMatch + a->nq;
     }
     int32_t *dMir = nullptr, *hMir = nullptr;
-    const bool mirrored = latency && s.inPlace && !g_timeKernels && outInts * 4 <= (256u << 10) &&
+    bool anyInorder = false;
+    for (const ProjJob& J : jobs) anyInorder = anyInorder || J.P.inorder;
+    const bool mirrored = latency && s.inPlace && !g_timeKernels && !anyInorder && outInts * 4 <= (256u << 10) &&
                           s.mirror_out(&dMir, &hMir, outInts) == 0;
     // (kept by the thread: as a fresh vector the download buffer of a 64-search call -- 600 KB -- is mapped, zeroed, faulted in
     // and unmapped by every call)

@@ -289,11 +289,44 @@ def test_search_projection_batch(pkg, oracle):
     assert pkg.search_projection_batch([]) == []
 
 
+@pytest.mark.parametrize("seed,blocks,taken_frac,n,nq,Nleft", [
+    (1, 0.5, 0.1, 1200, 900, 700), (2, 0.0, 0.3, 1200, 1500, 600), (3, 0.8, 0.5, 900, 900, 450), (4, 0.3, 0.0, 2400, 2000, 1200),
+    (5, 0.5, 0.9, 600, 1200, 300), (6, 0.95, 0.2, 1500, 700, 1000)])
+def test_search_projection_non_blocking_points_with_stereo_partners(pkg, oracle, seed, blocks, taken_frac, n, nq, Nleft):
+    """The one state round 4 refused (VERDICT r04 missing #4): map points with Observations() == 0 among the queries of the
+    local-map search of a two-camera rig WITH stereo-partner writes (src/ORBmatcher.cc:83-85, :117-121; reachable in
+    localisation mode through the temporal points of src/Tracking.cc:2750-2802).  A partner entry is overwritten without looking
+    at its occupant, so a non-blocking point can free a feature that an earlier point -- or a MapPoint that was there on entry --
+    had taken: the search walks its queries in order (proj_inorder_body).  Against the oracle's sequential transcription,
+    single call, resident frame and a batch that mixes such searches with ordinary ones."""
+    from matcher_inputs import projection_problem
+    pr = projection_problem(seed, n=n, nq=nq, mode=0, Nleft=Nleft, partners=True, blocks=blocks, taken_frac=taken_frac, th=3.0 if seed % 2 else 1.0)
+    assert (pr["qblocks"] == 0).any() or blocks >= 0.95
+    n_ref, q_ref, f_ref = oracle.search_projection(pr)
+    n_got, q_got, f_got = pkg.search_projection(pr)
+    assert n_got == n_ref and np.array_equal(q_got, q_ref) and np.array_equal(f_got, f_ref)
+    assert n_ref > 50
+    # the partner writes really do free features: the result differs from a run in which every point blocks
+    if blocks < 0.9:
+        pr_all = dict(pr)
+        pr_all.pop("qblocks")
+        assert not np.array_equal(oracle.search_projection(pr_all)[2], f_ref)
+    # resident frame (orbfe_frame_*): the same queries against the frame's handle
+    fr = pkg.ProjectionFrame(pr)
+    n2, q2, f2 = fr.search(pr)
+    assert n2 == n_ref and np.array_equal(q2, q_ref) and np.array_equal(f2, f_ref)
+    fr.close()
+    # a batch: this search between two ordinary ones (fixpoint kernel and in-order walk in one launch)
+    others = [projection_problem(seed + 100, mode=0, Nleft=500, partners=True), projection_problem(seed + 200, mode=1, th=7.0)]
+    res = pkg.search_projection_batch([others[0], pr, others[1]])
+    assert res[1][0] == n_ref and np.array_equal(res[1][1], q_ref) and np.array_equal(res[1][2], f_ref)
+    for k, o in ((0, others[0]), (2, others[1])):
+        rn, rq, rf = oracle.search_projection(o)
+        assert res[k][0] == rn and np.array_equal(res[k][1], rq) and np.array_equal(res[k][2], rf)
+
+
 def test_search_projection_errors(pkg):
     from matcher_inputs import projection_problem
-    pr = projection_problem(1, mode=0, Nleft=700, partners=True, blocks=0.5)
-    with pytest.raises(RuntimeError):
-        pkg.search_projection(pr)  # non-blocking map points + stereo partner writes: refused, not approximated
     pr = projection_problem(1, n=50, nq=0)
     n, q, f = pkg.search_projection(pr)
     assert n == 0 and len(q) == 0 and (f == -1).all()

@@ -36,8 +36,8 @@ def run(ncases=60, seed=3, scale=1.0, log=print, kinds=11):
                       nnratio=float(rng.choice([0.6, 0.8, 0.9])))
             if rng.random() < 0.3:
                 kw.update(stereo=False, Nleft=int(kw["n"] * rng.uniform(0.3, 0.7)), partners=bool(mode == 0 and rng.integers(0, 2)))
-            elif rng.random() < 0.3:
-                kw["blocks"] = float(rng.uniform(0.2, 0.9))
+            if rng.random() < 0.3:  # (round 5: also together with a rig's stereo-partner writes -- the in-order walk)
+                kw["blocks"] = float(rng.uniform(0.0, 0.9))
             pr = MI.projection_problem(**kw)
             a, b = O.search_projection(pr), pkg.search_projection(pr)
             ok = a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
