@@ -245,6 +245,7 @@ struct orbfe_ctx : orbfe_geom_state {
     int curSet = 0;               // the lane whose buffers the context's members hold
     int laneNext = 0, laneLast = -1; // lane of the next whole-batch call / of the last one (-1: the last call ran on the context's stream)
     int pairLast = -1;               // lane of the newest stereo frame submitted with orbfe_extract_stereo_pair_submit
+    int pairBlockingResult = 0;      // ... and, with one lane, what the blocking call inside _submit returned
     hipEvent_t evBatchFork = nullptr;
     bool inputGuard = true;       // orbfe_set_lane_input_guard / ORBFE_LANES_INPUT_GUARD=0: the context's stream does not wait for a lane's K-PYR
     bool exchangeHint = false;    // orbfe_mc_create: a collective stream of the highest priority waits for this context's lanes
@@ -3203,6 +3204,14 @@ int orbfe_extract_stereo_pair_submit(orbfe_ctx* c, const uint8_t* imgL, const ui
     if (c->kb8On || c->nStreams > 1) return ORBFE_ERR_STATE;
     const int depthMax = std::max(1, std::min(c->lanes, ORBFE_MAX_LANES));
     if (c->pairSubmitted - c->pairRetired >= depthMax) return ORBFE_ERR_STATE; // every lane holds a frame: wait for one first
+    if (depthMax == 1) { // a pipeline of one IS the blocking call (measured: a lone frame on a lane's stream is no faster)
+        const int m = orbfe_extract_stereo_pair(c, imgL, imgR, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, mb, mbf,
+                                                uRight, depth);
+        if (m < 0) return m;
+        c->pairBlockingResult = m;
+        c->pairSubmitted++;
+        return 0;
+    }
     HIP_TRY(hipSetDevice(c->device));
     int r;
     if (c->pairSubmitted == c->pairRetired && lanes_busy(c) && (r = lane_join(c)) < 0) return r; // (behind device-pointer calls)
@@ -3213,13 +3222,11 @@ int orbfe_extract_stereo_pair_submit(orbfe_ctx* c, const uint8_t* imgL, const ui
     lane_select(c, k);
     c->runStream = L.pairStream;
     const uint8_t* two[2] = {imgL, imgR};
-    // The completion word only for a pipeline of ONE: with kernels of several queues on the chip the workgroups do not run on
-    // the XCDs their ids name, every one of them releases for itself and the word is withheld (OrbDone) -- and a pipeline that
-    // is kept full gains nothing from a wait that ends 5 us earlier.
-    const bool word = depthMax == 1;
-    // (a pipeline of one alternates between two slots like the blocking call: the kernels write their results into the slot's
-    // page-locked slab, and lines the host has just read are slow to write again -- 0.165 against 0.104 ms per frame)
-    const int ks = depthMax == 1 ? (int)(c->pairSubmitted & 1) : k;
+    // No completion word here: with kernels of several queues on the chip the workgroups do not run on the XCDs their ids name,
+    // every one of them releases for itself and the word is withheld (OrbDone) -- and a pipeline that is kept full gains nothing
+    // from a wait that ends 5 us earlier.  _wait synchronises the frame's stream.
+    const bool word = false;
+    const int ks = k;
     r = host_submit_impl(c, 2, two, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, false, /*spinOk=*/word, ks);
     unsigned seq = 0;
     int rs = 0;
@@ -3250,9 +3257,13 @@ int orbfe_extract_stereo_pair_wait(orbfe_ctx* c)
     if (c->pairSubmitted == c->pairRetired) return ORBFE_ERR_STATE;
     HIP_TRY(hipSetDevice(c->device));
     const int depthMax = std::max(1, std::min(c->lanes, ORBFE_MAX_LANES));
+    if (depthMax == 1) {
+        c->pairRetired++;
+        return c->pairBlockingResult;
+    }
     const int k = (int)(c->pairRetired % depthMax);
     lane_select(c, k);
-    const int ks = depthMax == 1 ? (int)(c->pairRetired & 1) : k;
+    const int ks = k;
     orbfe_ctx::HostSlot& sl = c->slot[ks];
     c->runStream = c->lane[k].pairStream;
     const int w = host_wait(c, ks);

@@ -323,11 +323,22 @@ __global__ __launch_bounds__(KNN2M_THREADS) void k_bfknn2_frames_mfma(const orbf
     // The workgroups of a job (one per 256 queries) all stream the same train rows: workgroups are dealt to the XCDs round-robin
     // in linear-id order, so job = id % 8 + 8 (id / (8 nqb)) and query block = (id / 8) % nqb put them behind ONE L2
     // (speed only: nothing depends on where a workgroup runs).  Grids whose job count is no multiple of 8 keep the plain order.
-    int p = blockIdx.y, qb = blockIdx.x;
-    if ((gridDim.y & 7) == 0) {
-        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
-        p = (int)(L & 7u) + 8 * (int)(L / (8u * gridDim.x));
-        qb = (int)((L >> 3) % gridDim.x);
+    // The LAST query block of a job is mostly air when cap is no multiple of 256 (cap 1032 for nFeatures 1000: queries 1024 ..
+    // 1031, normally beyond the frame's count): those workgroups come last in dispatch order, behind the full ones, so that a
+    // grid of 4 + 1 blocks x 64 jobs still starts as 256 workgroups on 256 CUs (see the LDS request at the launch).
+    const int nqb = (int)gridDim.x, njob = (int)gridDim.y;
+    const int mainCols = (cap % KNN2M_QUERIES != 0 && nqb > 1) ? nqb - 1 : nqb;
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+    int p, qb;
+    if (L >= (unsigned)(mainCols * njob)) {
+        p = (int)L - mainCols * njob;
+        qb = mainCols;
+    } else if ((njob & 7) == 0) {
+        p = (int)(L & 7u) + 8 * (int)(L / (8u * (unsigned)mainCols));
+        qb = (int)((L >> 3) % (unsigned)mainCols);
+    } else {
+        p = (int)(L / (unsigned)mainCols);
+        qb = (int)(L % (unsigned)mainCols);
     }
 #ifdef ORBFE_KNN2_TIMING
     __shared__ unsigned long long sStamp_[16];
@@ -3368,7 +3379,9 @@ int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_jo
         // with the rest of the chip idle -- the dispatcher does exactly that when two fit: 26.0 us per launch against 18.0
         // when each asks for more than half a CU's LDS (82 KB and more: 17.9-18.3 us; 81 KB still let two in).  Larger grids
         // keep their real size (two per CU then overlap).
-        if ((size_t)mgrid.x * mgrid.y <= 256) lds = std::max(lds, (size_t)96 * 1024);
+        // (the last query block of every job does not count when it is the mostly empty one: it is dispatched last)
+        const unsigned mainCols = (cap % KNN2M_QUERIES != 0 && mgrid.x > 1) ? mgrid.x - 1 : mgrid.x;
+        if ((size_t)mainCols * mgrid.y <= 256) lds = std::max(lds, (size_t)96 * 1024);
         if (const char* e = getenv("ORBFE_KNN2_LDS_KB")) lds = std::max(lds, (size_t)atoi(e) * 1024); // (tuning)
         static std::atomic<size_t> ldsSet{0};
         if (lds > 64 * 1024 && ldsSet.load() < lds) {
