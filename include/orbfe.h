@@ -599,6 +599,12 @@ int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int 
 typedef struct orbfe_frame orbfe_frame;
 int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* frame_side);
 int orbfe_search_projection_frame(orbfe_frame*, const orbfe_proj_args* queries, int32_t* q_match, int32_t* feat_match);
+/* `count` searches against resident frame sides in ONE upload, three launches, one download (round 5): frames[k] is the handle
+ * search k runs against -- entries may repeat (Tracking::Relocalization projects every candidate keyframe's points into the one
+ * current frame, src/Tracking.cc:3846-3870) or differ (one keyframe's points fused into each neighbour that has a handle) --,
+ * queries[k] its queries / taken / partner tables as for orbfe_search_projection_frame; outputs as orbfe_search_projection_batch. */
+int orbfe_search_projection_frames(orbfe_frame* const* frames, const orbfe_proj_args* queries, int count, int32_t* const* q_match,
+                                   int32_t* const* feat_match, int32_t* nmatches);
 void orbfe_frame_destroy(orbfe_frame*);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:355-420) for npts map points in one launch: the

@@ -302,7 +302,7 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_mc_layout", "orbfe_mc_shard", "orbfe_mc_ring_pairs", "orbfe_mc_job_offsets", "orbfe_mc_unique_id",
            "orbfe_mc_create", "orbfe_mc_destroy", "orbfe_mc_extract_exchange_submit", "orbfe_mc_extract_exchange_wait",
            "orbfe_mc_match_ring", "orbfe_mc_match_outputs", "orbfe_mc_match_ring_async", "orbfe_mc_exchange_host",
-           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_search_tri_3d", "orbfe_frame_create", "orbfe_search_projection_frame", "orbfe_frame_destroy", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
+           "orbfe_set_trig_mode", "orbfe_debug_trig", "orbfe_release_caches", "orbfe_search_tri_kb8", "orbfe_search_tri_3d", "orbfe_frame_create", "orbfe_search_projection_frame", "orbfe_search_projection_frames", "orbfe_frame_destroy", "orbfe_kb8_triangulate", "orbfe_search_initialization", "orbfe_stereo_fisheye_matches", "orbfe_set_kb8", "orbfe_set_ray_output", "orbfe_get_rays", "orbfe_max_keypoints", "orbfe_extract", "orbfe_extract_batch",
            "orbfe_extract_batch_device", "orbfe_sync", "orbfe_compute_stereo_matches", "orbfe_get_levels", "orbfe_get_scale_factor",
            "orbfe_get_scale_tables", "orbfe_get_features_per_level", "orbfe_get_level", "orbfe_profile_enable",
            "orbfe_profile_read", "orbfe_debug_candidates", "orbfe_debug_level_keypoints", "orbfe_debug_fixups",
@@ -1112,6 +1112,37 @@ class ProjectionFrame:
         fm = np.full(max(self.n, 1), -1, np.int32)
         r = _chk(lib().orbfe_search_projection_frame(self.h, C.byref(a), _p(qm), _p(fm)), "orbfe_search_projection_frame")
         return r, qm[:nq], fm[:self.n]
+
+    @staticmethod
+    def search_many(frames, problems):
+        """orbfe_search_projection_frames: problems[k] against frames[k] (handles may repeat) in one call.  Returns a list of
+        (nmatches, q_match, feat_match)."""
+        count = len(problems)
+        assert len(frames) == count
+        if count == 0:
+            return []
+        args = (_ProjArgs * count)()
+        keep, qms, fms, nqs = [], [], [], []
+        for k, (fr, problem) in enumerate(zip(frames, problems)):
+            pr = dict(problem)
+            for key in ("desc", "kx", "ky", "octave", "angle", "uright"):
+                pr.pop(key, None)
+            pr["kx"] = np.zeros(0, np.float32)
+            a, kp, _, nq = _proj_args(pr)
+            a.kx = None
+            args[k] = a
+            keep.append(kp)
+            nqs.append(nq)
+            qms.append(np.full(max(nq, 1), -1, np.int32))
+            fms.append(np.full(max(fr.n, 1), -1, np.int32))
+        hs = (C.c_void_p * count)(*[fr.h for fr in frames])
+        qp = (C.c_void_p * count)(*[q.ctypes.data for q in qms])
+        fp = (C.c_void_p * count)(*[f.ctypes.data for f in fms])
+        nm = np.zeros(count, np.int32)
+        L = lib()
+        L.orbfe_search_projection_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.orbfe_search_projection_frames(hs, args, count, qp, fp, _p(nm)), "orbfe_search_projection_frames")
+        return [(int(nm[k]), qms[k][:nqs[k]], fms[k][:frames[k].n]) for k in range(count)]
 
     def close(self):
         if self.h:

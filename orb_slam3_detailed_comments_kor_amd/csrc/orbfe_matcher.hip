@@ -1767,6 +1767,7 @@ struct ProjDev {
     // occupied on entry may become free) and the entry state travels in taken0.
     int inorder;
     const uint8_t* taken0;
+    int resident; // the frame side and its grid come from an orbfe_frame handle: k_proj_grid_batch has nothing to build
 };
 // Every query owns PROJ_QUOTA key slots (its stretch starts at PROJ_QUOTA * q); a query with more candidates takes a stretch of
 // the overflow region behind them, handed out by an atomic on status[2].  (Handing out EVERY stretch that way -- 300 wavefronts
@@ -1782,6 +1783,10 @@ struct ProjDev {
 
 __device__ __forceinline__ void proj_grid_body(const ProjDev& P)
 {
+    if (P.resident) { // (uniform; a batch that mixes resident and staged frame sides)
+        if (threadIdx.x == 0) P.status[2] = 0;
+        return;
+    }
     // Round 4: the cell of a thread's first features stays in a register between the counting and the filling pass, and a
     // frame of up to PROJ_ITEMS_LDS features builds and orders its cell lists in LDS (one coalesced write at the end) -- the
     // first form filled and insertion-sorted them in global memory, behind its own stores: 11.6 us for one workgroup, most of
@@ -4733,6 +4738,7 @@ int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_fra
         }
         return 0;
     }
+    P.resident = F ? 1 : 0;
     if (F) {
         P.cellStart = F->cellStart; P.cellItems = F->cellItems; P.cellOf = F->cellOf;
     } else {
@@ -4792,10 +4798,10 @@ int proj_finish(const orbfe_proj_args* a, const int32_t* out, int32_t* q_match, 
 namespace {
 // `frame`: the one search (count == 1) runs against a resident frame: its arrays and grid are not staged or rebuilt
 int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match, int32_t* const* feat_match,
-             int32_t* nmatches, const orbfe_frame* frame)
+             int32_t* nmatches, const orbfe_frame* const* frames /* per search, or NULL; entries may be NULL and may repeat */)
 {
     if (count < 0 || (count && (!items || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
-    if (frame && count != 1) return ORBFE_ERR_ARGS;
+    const orbfe_frame* const frame = (frames && count == 1) ? frames[0] : nullptr; // the latency path of ONE resident search
     PTR_BEGIN();
     int r;
     for (int k = 0; k < count; k++)
@@ -4825,10 +4831,12 @@ int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const
     size_t outInts = 0, sweepBytes = 0;
     unsigned maxBlocks = 1;
     for (size_t j = 0; j < jobs.size(); j++) // (the inputs of all searches first: one upload for the batch)
-        if ((r = proj_stage(s, &items[live[j]], jobs[j], frame, 0, j ? &items[live[j - 1]] : nullptr, j ? &jobs[j - 1] : nullptr)) < 0) return r;
+        if ((r = proj_stage(s, &items[live[j]], jobs[j], frames ? frames[live[j]] : nullptr, 0, j ? &items[live[j - 1]] : nullptr,
+                            j ? &jobs[j - 1] : nullptr)) < 0)
+            return r;
     for (size_t j = 0; j < jobs.size(); j++) {
         const orbfe_proj_args* a = &items[live[j]];
-        if ((r = proj_stage(s, a, jobs[j], frame, 1)) < 0) return r;
+        if ((r = proj_stage(s, a, jobs[j], frames ? frames[live[j]] : nullptr, 1)) < 0) return r;
         jobs[j].outOff = outInts;
         outInts += 4 + (size_t)a->nq + (size_t)a->n;
         sweepBytes = std::max(sweepBytes, jobs[j].sweepBytes);
@@ -5026,8 +5034,32 @@ int orbfe_search_projection_frame(orbfe_frame* F, const orbfe_proj_args* a, int3
     int32_t nm = 0;
     int32_t* qm[1] = {q_match};
     int32_t* fm[1] = {feat_match};
-    const int r = proj_run(F->device, &b, 1, qm, fm, &nm, F);
+    const orbfe_frame* fr[1] = {F};
+    const int r = proj_run(F->device, &b, 1, qm, fm, &nm, fr);
     return r < 0 ? r : (int)nm;
+}
+
+// Many searches against RESIDENT frame sides in one upload, three launches, one download (round 5): the
+// candidate keyframes' map points against the one current frame of a relocalisation (src/Tracking.cc:3846-3870: every entry
+// names the same handle), or one keyframe's points fused into every neighbour that has a handle.  Only the queries, `taken` and
+// the partner tables travel; no grid is rebuilt.
+int orbfe_search_projection_frames(orbfe_frame* const* frames, const orbfe_proj_args* queries, int count, int32_t* const* q_match,
+                                   int32_t* const* feat_match, int32_t* nmatches)
+{
+    if (count < 0 || (count && (!frames || !queries || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
+    if (count == 0) return 0;
+    std::vector<orbfe_proj_args> b(queries, queries + count);
+    for (int k = 0; k < count; k++) {
+        const orbfe_frame* F = frames[k];
+        if (!F || F->device != frames[0]->device) return ORBFE_ERR_ARGS;
+        b[k].n = F->n; b[k].Nleft = F->Nleft;
+        b[k].desc = F->desc; b[k].kx = F->kx; b[k].ky = F->ky;
+        b[k].octave = F->hOctave.data();
+        b[k].angle = F->hAngle.empty() ? nullptr : F->hAngle.data();
+        b[k].uright = F->uright;
+        b[k].minX = F->minX; b[k].minY = F->minY; b[k].gridWInv = F->wInv; b[k].gridHInv = F->hInv;
+    }
+    return proj_run(frames[0]->device, b.data(), count, q_match, feat_match, nmatches, frames);
 }
 
 int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)

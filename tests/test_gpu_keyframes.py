@@ -366,3 +366,48 @@ def test_projection_batch_shares_arrays_between_neighbouring_searches(pkg, oracl
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
         hits += ref[0]
     assert hits > 500
+
+
+def test_projection_searches_against_resident_frames_in_one_call(pkg, oracle):
+    """orbfe_search_projection_frames (round 5): many searches in one call, every frame side a resident handle.
+    (a) relocalisation shape: 24 different query sets (mode 1, one with the orientation cull) against ONE frame handle named 24
+    times; (b) fusion shape: one query set against six different handles, two of them rigs with stereo partners, one search in the
+    in-order state (non-blocking points + partner writes); (c) a call that mixes both.  Against the oracle, and against the
+    one-at-a-time form of the same handles."""
+    from matcher_inputs import projection_problem
+    base = projection_problem(900, n=1400, nq=2400, mode=1, th=7.0, stereo=True)
+    fr = pkg.ProjectionFrame(base)
+    rng = np.random.default_rng(17)
+    probs = []
+    for k in range(24):  # random subsets of the frame's 2400 queries, in random order: the occupancy rule sees another sequence
+        idx = rng.permutation(2400)[: 300 + 80 * k]
+        pr = dict(base)
+        for key in ("qdesc", "qx", "qy", "qr", "qmin_level", "qmax_level", "qxr", "qangle", "qflags", "qblocks"):
+            if key in base:
+                pr[key] = np.ascontiguousarray(base[key][idx])
+        pr["check_orientation"] = int(k == 5)
+        pr["taken"] = (rng.random(1400) < 0.1 * (k % 4)).astype(np.uint8)
+        probs.append(pr)
+    got = pkg.ProjectionFrame.search_many([fr] * len(probs), probs)
+    for k, pr in enumerate(probs):
+        rn, rq, rf = oracle.search_projection(pr)
+        assert got[k][0] == rn and np.array_equal(got[k][1], rq) and np.array_equal(got[k][2], rf), k
+        one = fr.search(pr)
+        assert one[0] == rn and np.array_equal(one[1], rq)
+    # (b) six frames, two of them rigs
+    sides = [projection_problem(950 + k, n=900 + 150 * k, nq=700, mode=0, Nleft=(500 if k in (2, 4) else -1), partners=(k in (2, 4)),
+                                blocks=(0.5 if k == 4 else None), th=3.0) for k in range(6)]
+    frames = [pkg.ProjectionFrame(p_) for p_ in sides]
+    got = pkg.ProjectionFrame.search_many(frames, sides)
+    for k, pr in enumerate(sides):
+        rn, rq, rf = oracle.search_projection(pr)
+        assert got[k][0] == rn and np.array_equal(got[k][1], rq) and np.array_equal(got[k][2], rf), ("frames", k)
+    # (c) mixed
+    got = pkg.ProjectionFrame.search_many([fr, frames[4], fr, frames[0]], [probs[3], sides[4], probs[7], sides[0]])
+    for g, pr in zip(got, (probs[3], sides[4], probs[7], sides[0])):
+        rn, rq, rf = oracle.search_projection(pr)
+        assert g[0] == rn and np.array_equal(g[1], rq) and np.array_equal(g[2], rf)
+    assert pkg.ProjectionFrame.search_many([], []) == []
+    for f in frames:
+        f.close()
+    fr.close()

@@ -604,6 +604,18 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     prDev.desc = ddB;
     std::vector<orbfe_proj_args> prsDev(NB, prDev);
     if (timeit("search_projection_batch64_device_descriptors", 40, [&] { return orbfe_search_projection_batch(dev, prsDev.data(), NB, qmp.data(), fmp.data(), nmp.data()); }, out)) return 2;
+    {   // ... and with the frame side in a handle that all 64 searches name (round 5: orbfe_search_projection_frames)
+        orbfe_frame* frB = nullptr;
+        orbfe_proj_args prf = pr;
+        CHECK(orbfe_frame_create(&frB, dev, &prf));
+        std::vector<orbfe_frame*> frs(NB, frB);
+        if (timeit("search_projection_batch64_frame_handle", 40, [&] { return orbfe_search_projection_frames(frs.data(), prs.data(), NB, qmp.data(), fmp.data(), nmp.data()); }, out)) return 2;
+        orbfe_frame_destroy(frB);
+        if (nmp[0] != nProj || nmp[NB - 1] != nProj || qms[NB - 1] != qm) {
+            fprintf(stderr, "hostbench: projection batch over a frame handle disagrees: %d %d\n", nmp[0], nProj);
+            return 2;
+        }
+    }
     // ---- DBoW2 transform of one frame's descriptors: k = 10, L = 4 synthetic tree (11111 nodes)
     {
         const int k = 10, L = 4;

@@ -8,6 +8,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import natural  # noqa: E402  (round 5: cuts of the two committed photographs, tests/natural.py)
 import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
 import orb_oracle_py as O  # noqa: E402
 
@@ -39,11 +41,13 @@ def _one(case, rng, max_side, log, bad):
         nb = int(rng.choice([1, 2, 3, 8, 9, 16])) if H * W < 450000 else int(rng.integers(1, 4))
         # content: rectangle frames, uniform noise, and (round 4) the kinds of synth.make_frame_kind -- blurred, saturated /
         # flat plateaus, 2-px checkerboard, fine sinusoids, pure ramp, quadrants of these
-        kind = ("rects", "rects", "blurred", "noise", "plateaus", "checker2", "rects", "sinus", "mixed", "ramp", "rects", "noise")[case % 12]
+        kind = ("rects", "natural", "blurred", "noise", "plateaus", "checker2", "natural", "sinus", "mixed", "ramp", "rects", "noise")[case % 12]
         imgs = []
         for b in range(nb):
             if kind == "noise":
                 imgs.append(rng.integers(0, 256, size=(H, W), dtype=np.uint8))
+            elif kind == "natural":  # a photograph, cut / mirror-tiled to the case's size at a random offset and direction
+                imgs.append(natural.random_frame(H, W, int(rng.integers(0, 1 << 30))))
             else:
                 imgs.append(pkg.synth.make_frame_kind(H, W, int(rng.integers(0, 1 << 30)), kind))
         try:
