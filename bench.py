@@ -332,6 +332,26 @@ def settle_together(seconds, body, world, dev):
         calls += 1
 
 
+def knn2_roofline(ndist, knn_ms, cap):
+    """The brute force's roofs (VERDICT r04 #4a).  Matrix-pipe form (k_bfknn2_frames_mfma, frames of <= 2048 keypoints): per
+    distance 256 + 32 i8 MACs (the descriptor's bits + the index block) against the dense i8 MFMA peak, 1024 SIMDs x 32x32x32
+    MACs per 32 cycles at 2.4 GHz; vector-pipe form (k_bfknn2_frames, ORBFE_KNN2_MFMA=0 / larger frames): 8 v_xor + 8 v_bcnt per
+    64 distances per SIMD at the issue costs of profiles/r01_valu_rate.txt (2.7 / 4.45 cycles)."""
+    mfma_on = os.environ.get("ORBFE_KNN2_MFMA", "1") != "0" and cap <= 2048
+    i8_peak = 1024 * (32 * 32 * 32 * 2 / 32.0) * 2.4e9 / 1e12  # TOP/s
+    vec_peak = 1024 * 64 / (8 * 2.7 + 8 * 4.45) * 2.4e9        # distances/s
+    rate = ndist / (knn_ms * 1e-3)
+    if mfma_on:
+        tops = ndist * 2 * 288 / (knn_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "k_bfknn2_frames_mfma", "achieved": tops, "peak": i8_peak, "unit": "TOP/s",
+                "frac": tops / i8_peak, "traffic": None, "algorithmic_ops_per_launch": ndist * 2 * 288,
+                "note": "exact: the i32 accumulator of v_mfma_i32_32x32x32_i8 is the sequential scan's key (DESIGN.md 7.5); "
+                        "2 x (256 + 32) i8 operations per distance",
+                "vector_pipe_peak_distances_per_s": vec_peak, "distances_per_s_over_vector_pipe_peak": rate / vec_peak}, vec_peak
+    return {"bound": "valu", "kernel": "k_bfknn2_frames<8>", "achieved": rate, "peak": vec_peak, "unit": "distances/s",
+            "frac": rate / vec_peak, "traffic": None}, vec_peak
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator
     # creation, for one): until the line is ready, file descriptor 1 points at stderr.
@@ -561,12 +581,13 @@ def main():
 
     # keypoints of every input batch (one plain extraction each, outside every clock and BEFORE the settling: the host
     # round trips of this loop let the clocks drop)
-    kp_of = []
+    kp_of, n_of = [], []
     for j in range(R):
         ex.extract_batch_device(d_rot[j].data_ptr(), B, H, W, W, H * W, lap, d_kps.data_ptr(), d_desc.data_ptr(), cap,
                                 d_n.data_ptr(), d_mono.data_ptr())
         ex.sync()
         kp_of.append(int(d_n.sum().item()))
+        n_of.append(d_n.to(torch.float64).clone())
     barrier()
     # `same_batch` (round 4's measurement, reported beside `value`): the same step on ONE batch, cache-resident between steps
     same_batch = None
@@ -634,31 +655,94 @@ def main():
     # place, one launch per batch.  The match of batch i-1 is queued behind the extraction of batch i, so it overlaps
     # batch i's all-gather.  Runs at every N (at N=1 the "gather" is the local slab copy).
     cross = None
-    if mc is not None and not args.no_cross:
+    # World 1 without a process group: the same leg through the C ABI (orbfe_mc_* with a world of one: the "gather" is a device
+    # copy on the handle's side stream), so that the matching rides on the batch lanes like the N > 1 path does (round 4 ran
+    # it through the torch classes, whose local copy needs the lanes joined every step)
+    mcx, mcl = mc, None
+    if mcx is None and world == 1 and not dist.is_initialized() and not extra and not args.no_cross:
+        try:
+            mcl = pkg.binding.MultiCam(ex, pkg.binding.mc_unique_id(pkg.binding.MC_HOST), 0, 1, B, cap, pkg.binding.MC_HOST)
+            mcx = mcl
+        except Exception:  # noqa: BLE001
+            mcx = mcl = None
+    if mcx is not None and not args.no_cross:
         try:
             hops = (1,)
+            fifo = []      # input batch of every submit in flight
+            last = [None]  # (view, input batch) of the newest completed exchange
 
             def step_cross_mc():
+                j = (counter[0] % R) if rot_on[0] else 0
+                counter[0] += 1
                 if mc_inflight[0] == pkg.binding.MC_MAX_IN_FLIGHT:
-                    v = mc.wait()
+                    v = mcx.wait()
                     mc_inflight[0] -= 1
-                    mc.match_ring_async(v.batch, hops)  # queued behind the extraction already in the stream
-                mc.submit(d_img.data_ptr(), H, W, W, H * W, lap)
+                    last[0] = (v, fifo.pop(0))
+                    mcx.match_ring_async(v.batch, hops)  # queued behind the extraction already in the stream
+                mcx.submit(d_rot[j].data_ptr(), H, W, W, H * W, lap)
+                fifo.append(j)
                 mc_inflight[0] += 1
+
+            def drain():
+                while mc_inflight[0] > 0:
+                    last[0] = (mcx.wait(), fifo.pop(0))
+                    mc_inflight[0] -= 1
+                barrier()
 
             for _ in range(10):
                 step_cross_mc()
-            barrier()
+            drain()
             tc = time.perf_counter()
             for _ in range(args.steps):
                 step_cross_mc()
-            barrier()
+            drain()
             tc = time.perf_counter() - tc
             cross = {"jobs_per_step": B * world, "pairing": "every frame against the next camera of the ring (global frame g+1), "
                      "train frames read from the gathered buffer in place (orbfe_mc_match_ring_async)",
                      "ms_per_step": 1e3 * tc / args.steps}
+            if world == 1 and last[0] is not None:
+                # the matching launch alone, by events on the stream it runs on (the handle's buffers of the last batch)
+                v, jb = last[0]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                mcx.match_ring_async(v.batch, hops)
+                e0.record()
+                for _ in range(20):
+                    mcx.match_ring_async(v.batch, hops)
+                e1.record()
+                torch.cuda.synchronize()
+                knn_ms = e0.elapsed_time(e1) / 20
+                cnt = n_of[jb]
+                ndist = float((cnt * torch.roll(cnt, -1)).sum().item())
+                cross.update({"knn2_launch_ms": knn_ms, "distances_per_launch": ndist, "distances_per_s": ndist / (knn_ms * 1e-3)})
+                cross["roofline"], vec_peak = knn2_roofline(ndist, knn_ms, cap)
+                # ... and the single-problem kernel at BASELINE configs[4]'s size (orbfe_bfknn2 inside
+                # Frame::ComputeStereoFishEyeMatches: 1500 x 1500, one wavefront per query)
+                nb = 1500
+                dq = torch.randint(0, 256, (nb, 32), dtype=torch.uint8, device=dev)
+                dt2 = torch.randint(0, 256, (nb, 32), dtype=torch.uint8, device=dev)
+                di = torch.zeros((nb, 2), dtype=torch.int32, device=dev)
+                dd = torch.zeros((nb, 2), dtype=torch.int32, device=dev)
+                for _ in range(3):
+                    pkg.binding.bfknn2_device(dq.data_ptr(), nb, dt2.data_ptr(), nb, di.data_ptr(), dd.data_ptr(), stream=stream.cuda_stream)
+                e0.record()
+                for _ in range(20):
+                    pkg.binding.bfknn2_device(dq.data_ptr(), nb, dt2.data_ptr(), nb, di.data_ptr(), dd.data_ptr(), stream=stream.cuda_stream)
+                e1.record()
+                torch.cuda.synchronize()
+                ms1 = e0.elapsed_time(e1) / 20
+                cross["bfknn2_1500x1500"] = {"kernel": "k_bfknn2", "launch_ms": ms1, "distances_per_s": nb * nb / (ms1 * 1e-3),
+                                             "roofline": {"bound": "valu", "achieved": nb * nb / (ms1 * 1e-3), "peak": vec_peak,
+                                                          "unit": "distances/s", "frac": nb * nb / (ms1 * 1e-3) / vec_peak,
+                                                          "note": "2.25 M distances are 0.8 us of popcount issue: the launch is its "
+                                                                  "own latency (1500 wavefronts of 24 dependent iterations)"}}
         except Exception as e:  # noqa: BLE001
             cross = {"error": "%s: %s" % (type(e).__name__, e)}
+        if mcl is not None:
+            try:
+                barrier()
+                mcl.close()
+            except Exception:  # noqa: BLE001
+                pass
     elif not extra and not args.no_cross:
         try:  # (a secondary leg: if it fails, the line still carries `value` and says why this object is missing)
             cm = CrossCameraMatcher(pipe.x, ring_pairs(world, B, rank), dev)
@@ -706,26 +790,7 @@ def main():
                      "ms_per_step": 1e3 * tc / args.steps, "knn2_launch_ms": knn_ms,
                      "distances_per_launch": ndist, "distances_per_s": ndist / (knn_ms * 1e-3),
                      "ratio_test_survivors_per_frame": float((good & valid).sum().item()) / max(cm.njobs, 1)}
-            # The brute force's roofs (VERDICT r04 #4a).  Matrix-pipe form (k_bfknn2_frames_mfma, frames of <= 2048 keypoints): per
-            # distance 256 + 32 i8 MACs (the descriptor's bits + the index block) against the dense i8 MFMA peak, 1024 SIMDs x
-            # 32x32x32 MACs per 32 cycles at 2.4 GHz; vector-pipe form (k_bfknn2_frames, ORBFE_KNN2_MFMA=0 / larger frames): 8
-            # v_xor + 8 v_bcnt per 64 distances per SIMD at the issue costs of profiles/r01_valu_rate.txt (2.7 / 4.45 cycles).
-            mfma_on = os.environ.get("ORBFE_KNN2_MFMA", "1") != "0" and cap <= 2048
-            i8_peak = 1024 * (32 * 32 * 32 * 2 / 32.0) * 2.4e9 / 1e12  # TOP/s
-            vec_peak = 1024 * 64 / (8 * 2.7 + 8 * 4.45) * 2.4e9        # distances/s
-            if mfma_on:
-                tops = ndist * 2 * 288 / (knn_ms * 1e-3) / 1e12
-                cross["roofline"] = {"bound": "mfma", "kernel": "k_bfknn2_frames_mfma", "achieved": tops, "peak": i8_peak,
-                                     "unit": "TOP/s", "frac": tops / i8_peak, "traffic": None,
-                                     "algorithmic_ops_per_launch": ndist * 2 * 288,
-                                     "note": "exact: the i32 accumulator of v_mfma_i32_32x32x32_i8 is the sequential scan's key "
-                                             "(DESIGN.md 7.5); 2 x (256 + 32) i8 operations per distance",
-                                     "vector_pipe_peak_distances_per_s": vec_peak,
-                                     "distances_per_s_over_vector_pipe_peak": ndist / (knn_ms * 1e-3) / vec_peak}
-            else:
-                cross["roofline"] = {"bound": "valu", "kernel": "k_bfknn2_frames<8>", "achieved": ndist / (knn_ms * 1e-3),
-                                     "peak": vec_peak, "unit": "distances/s", "frac": ndist / (knn_ms * 1e-3) / vec_peak,
-                                     "traffic": None}
+            cross["roofline"], vec_peak = knn2_roofline(ndist, knn_ms, cap)
             # ... and the single-problem kernel at BASELINE configs[4]'s size (orbfe_bfknn2 inside
             # Frame::ComputeStereoFishEyeMatches: 1500 x 1500, one wavefront per query)
             try:

@@ -2732,6 +2732,7 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
 int orbfe_set_lanes(orbfe_ctx* c, int lanes)
 {
     if (!c || lanes < 1 || lanes > ORBFE_MAX_LANES) return ORBFE_ERR_ARGS;
+    if (c->pairSubmitted != c->pairRetired) return ORBFE_ERR_STATE; // stereo frames in flight are indexed by the lane count
     HIP_TRY(hipSetDevice(c->device));
     int r = lane_join(c);
     if (r < 0) return r;

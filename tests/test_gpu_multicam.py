@@ -26,20 +26,24 @@ def _frames(tmp_path, n, rows=240, cols=376):
     return imgs, str(path)
 
 
-def test_cpp_host_world1_rccl(tmp_path):
+@pytest.mark.parametrize("lanes", ["1", "3"])
+def test_cpp_host_world1_rccl(tmp_path, lanes):
+    # (ORBFE_LANES is read by orbfe_create: with 3 the handle's batches ride on the context's batch lanes -- round 5 --, the
+    # collective's stream waiting for the lane that holds the batch; the program's checks are the same)
     exe = _build(tmp_path)
     _, raw = _frames(tmp_path, 4)
     out = subprocess.run([exe, raw, "240", "376", "4", "1", "0", "500"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                         timeout=300)
+                         timeout=300, env=dict(os.environ, ORBFE_LANES=lanes))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all 1 ranks ok" in out.stdout and "transport rccl" in out.stdout
 
 
-def test_cpp_host_world2_shared_memory_transport(tmp_path):
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_cpp_host_world2_shared_memory_transport(tmp_path, lanes):
     exe = _build(tmp_path)
     _, raw = _frames(tmp_path, 6)
     out = subprocess.run([exe, raw, "240", "376", "6", "2", "1", "500"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                         timeout=300)
+                         timeout=300, env=dict(os.environ, ORBFE_LANES=lanes))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all 2 ranks ok" in out.stdout and out.stdout.count("transport host") == 2
 
@@ -54,6 +58,8 @@ def test_ctypes_handle_against_the_oracle(oracle):
     imgs = np.stack([pkg.synth.make_frame(rows, cols, 700 + i) for i in range(frames)])
     d_img = torch.from_numpy(imgs).cuda()
     ex = pkg.ORBextractor(500, 1.2, 8, 20, 7, device=0)
+    ex.set_lanes(3)  # (round 5: the exchange rides on the batch lanes)
+    ex.set_lane_input_guard(False)
     cap = ex.max_keypoints(rows, cols)
     mc = binding.MultiCam(ex, None, 0, 1, frames, cap, binding.MC_RCCL)
     for _ in range(2):
