@@ -133,6 +133,7 @@ struct orbfe_geom_state {
     size_t qtLdsBytes = 0;
     int qtKeyOff = 0, qtKeyCap = 0;
     std::vector<int> qtSmall, qtBig; // levels whose quadtree tables live in LDS / in the global scratch area (k_octree<true>)
+    std::vector<int> qtWide;         // LDS levels of more than 512 FAST cells (level 0 from ~1100 x 620 px): 1024-thread workgroups (round 5)
     size_t qtBigLdsBytes = 0, qtScratchStride = 0;
     int qtBigKeyOff = 0, qtBigKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
@@ -790,6 +791,15 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     if (maxKp > 65535) return ORBFE_ERR_NFEATURES; // keypoint slots / list positions are packed in 16 bits
     c->qtSmall.clear();
     c->qtBig.clear();
+    c->qtWide.clear();
+    // A level of more than 512 cells (level 0 of a 1280x720 or 1024x1024 frame) does not fit the one-chunk gather of a 512-thread
+    // workgroup: separate count pass, serial binary searches, keys in LDS instead of registers in every pass.  ORBFE_QT_WIDE=1
+    // gives the images that have such a level 1024-thread workgroups (one chunk of up to 1024 cells, four keys per thread in
+    // registers up to 4096 candidates; k_octree<false, 1024>, bit-identical).  MEASURED AND NOT THE DEFAULT (round 5,
+    // profiles/r05_qt_wide.txt): K-QT 25.9 -> 24.1 us on 8 x 1280x720 (the step with three lanes: 0.0450 -> 0.0459 ms),
+    // 27.8 -> 40.5 us on 64 x 1280x720 (512 workgroups of sixteen wavefronts no longer fit the chip at once), a 1024^2 stereo
+    // frame 0.359 -> 0.336 ms on one box: the level-0 chain is long because it holds 4000 keys, not because of the gather's form.
+    const bool wideOk = getenv("ORBFE_QT_WIDE") && atoi(getenv("ORBFE_QT_WIDE")) != 0;
     int maxLCsmall = 0, maxLCbig = 0;
     const int ldsNodeBudget = (160 * 1024 - 64 * (int)sizeof(int)) / (24 * (int)sizeof(int)); // list entries per workgroup
     int forceBig = -1;
@@ -800,9 +810,16 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             c->qtBig.push_back(l);
             maxLCbig = std::max(maxLCbig, LC);
         } else {
-            c->qtSmall.push_back(l);
+            if (wideOk && c->lg[l].nCells > QT_THREADS && c->lg[l].nCells <= 1024) c->qtWide.push_back(l);
+            else c->qtSmall.push_back(l);
             maxLCsmall = std::max(maxLCsmall, LC);
         }
+    }
+    // (one launch for all of them: the levels' chains run side by side, and a second launch behind the wide one made K-QT
+    // 42 us instead of 26 -- the other levels are roughly indifferent to the workgroup size: 0.0446 / 0.045 ms per 752x480 frame)
+    if (!c->qtWide.empty()) {
+        c->qtWide.insert(c->qtWide.end(), c->qtSmall.begin(), c->qtSmall.end());
+        c->qtSmall.clear();
     }
     c->qtKeyOff = 64 + std::max(24 * maxLCsmall, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
     c->qtLdsBytes = sizeof(int) * (size_t)c->qtKeyOff;
@@ -890,9 +907,12 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
             lane_quiesce(c); // (the second lane may still be working with the other size's tables and strides)
             std::swap(cur, c->geomCache[i]);
             if (c->geomCache[i].lg.empty()) c->geomCache.erase(c->geomCache.begin() + (long)i);
-            if (c->qtLdsBytes > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (c->qtLdsBytes > 64 * 1024) {
+                HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, QT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)c->qtLdsBytes));
+                HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)c->qtLdsBytes));
+            }
             lanes_invalidate_caps(c); // the per-image strides changed: re-check every buffer's size
             return 0;
         }
@@ -1070,9 +1090,12 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
         c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk &&
                       getenv("ORBFE_PYR_UNFUSED") == nullptr;
     }
-    if (c->qtLdsBytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (c->qtLdsBytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, QT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)c->qtLdsBytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)c->qtLdsBytes));
+    }
     c->rows = rows;
     c->cols = cols;
     c->pyrTile = tile;
@@ -1654,9 +1677,18 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 lapIn.n = lapInlineN;
                 for (int i = 0; i < 4; i++) lapIn.v[i] = c->lapInline[i];
             }
-            const unsigned nS = (unsigned)c->qtSmall.size(), nB = (unsigned)c->qtBig.size();
+            const unsigned nS = (unsigned)c->qtSmall.size(), nB = (unsigned)c->qtBig.size(), nW = (unsigned)c->qtWide.size();
+            if (nW) { // (first: the longest chains of the batch)
+                OrbQtLevels lw = {};
+                for (size_t i = 0; i < c->qtWide.size(); i++) lw.v[i] = c->qtWide[i];
+                hipLaunchKernelGGL((k_octree<false, 1024>), ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nW) : dim3(nW, (unsigned)ni),
+                                   dim3(1024), c->qtLdsBytes, q, c->d_lg.p,
+                                   c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
+                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
+                                   c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p, lw, (int*)nullptr, (size_t)0, lapIn);
+            }
             if (nS)
-                hipLaunchKernelGGL(k_octree<false>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nS) : dim3(nS, (unsigned)ni),
+                hipLaunchKernelGGL((k_octree<false, QT_THREADS>), ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nS) : dim3(nS, (unsigned)ni),
                                    dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
                                    c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
                                    c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
@@ -1664,7 +1696,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             if (nB) { // levels whose node tables exceed the LDS: same kernel on a global scratch area (i0-relative slices)
                 OrbQtLevels lb = {};
                 for (size_t i = 0; i < c->qtBig.size(); i++) lb.v[i] = c->qtBig[i];
-                hipLaunchKernelGGL(k_octree<true>, ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nB) : dim3(nB, (unsigned)ni),
+                hipLaunchKernelGGL((k_octree<true, QT_THREADS>), ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nB) : dim3(nB, (unsigned)ni),
                                    dim3(QT_THREADS), c->qtBigLdsBytes, q, c->d_lg.p,
                                    c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
                                    c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,

@@ -1099,21 +1099,21 @@ __global__ __launch_bounds__(NT) void k_fast_runs(const uint8_t* __restrict__ py
 // pass that would have prepared the scan input -- and its barrier -- into the scan itself.  G(i, exclusive
 // prefix, value) runs where element i is written: a caller that only needs to look at (prefix, value) pairs once
 // saves the pass and the barrier after the scan as well.
-template <class T, class F, class G>
-__device__ int qt_scan_map(const T* src, int* a, int n, int* wsum /* 2 * QT_WAVES */, F f, G post)
+template <int NT, class T, class F, class G>
+__device__ int qt_scan_map(const T* src, int* a, int n, int* wsum /* 2 * NT / 64 */, F f, G post)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 0, chunk = 0;
-    for (int base = 0; base < n; base += QT_THREADS, chunk ^= 1) {
+    for (int base = 0; base < n; base += NT, chunk ^= 1) {
         const int i = base + tid;
         const int v = i < n ? f(src[i]) : 0;
         const int x = wave_incl_scan_i32(v);
-        int* ws = wsum + chunk * QT_WAVES;
+        int* ws = wsum + chunk * (NT / 64);
         if (lane == 63) ws[wave] = x;
         __syncthreads();
         int prefix = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < QT_WAVES; w++) {
+        for (int w = 0; w < (NT / 64); w++) {
             const int t = ws[w];
             total += t;
             if (w < wave) prefix += t;
@@ -1128,14 +1128,15 @@ __device__ int qt_scan_map(const T* src, int* a, int n, int* wsum /* 2 * QT_WAVE
     __syncthreads();
     return carry;
 }
-template <class T, class F>
+template <int NT, class T, class F>
 __device__ int qt_scan_map(const T* src, int* a, int n, int* wsum, F f)
 {
-    return qt_scan_map(src, a, n, wsum, f, [](int, int, int) {});
+    return qt_scan_map<NT>(src, a, n, wsum, f, [](int, int, int) {});
 }
-__device__ int qt_scan(int* a, int n, int* wsum /* 2 * QT_WAVES */)
+template <int NT>
+__device__ int qt_scan(int* a, int n, int* wsum /* 2 * NT / 64 */)
 {
-    return qt_scan_map(a, a, n, wsum, [](int v) { return v; });
+    return qt_scan_map<NT>(a, a, n, wsum, [](int v) { return v; });
 }
 
 // cc[idx] += 1 for every lane with idx >= 0, but with one LDS atomic per RUN of equal neighbouring indices: the
@@ -1172,25 +1173,25 @@ __device__ __forceinline__ void qt_child(int ul, int br, int q, int& cul, int& c
 }
 
 // Keys per thread that stay in REGISTERS for a whole level (key, list index of its node, child slot of the current
-// pass): the usual level (one chunk of cells, <= QT_KPT * QT_THREADS candidates) then walks registers, and a pass
+// pass): the usual level (one chunk of cells, <= QT_KPT * NT candidates) then walks registers, and a pass
 // reads only the node tables from LDS -- kOf / UL / BR for the histogram, cpos / sidx for the relabelling -- instead
 // of chasing keyNode -> kOf -> key -> UL / BR twice per key and pass through LDS.
 #define QT_KPT 4
-template <int J, class F>
+template <int NT, int J, class F>
 __device__ __forceinline__ void qt_reg_step(int n, F& f)
 {
-    if (J * QT_THREADS < n) f(std::integral_constant<int, J>(), (int)threadIdx.x + J * QT_THREADS); // uniform guard
+    if (J * NT < n) f(std::integral_constant<int, J>(), (int)threadIdx.x + J * NT); // uniform guard
 }
-template <class F>
+template <int NT, class F>
 __device__ __forceinline__ void qt_each_key(bool regp, int n, F f)
 {
     if (regp) {
-        qt_reg_step<0>(n, f);
-        qt_reg_step<1>(n, f);
-        qt_reg_step<2>(n, f);
-        qt_reg_step<3>(n, f);
+        qt_reg_step<NT, 0>(n, f);
+        qt_reg_step<NT, 1>(n, f);
+        qt_reg_step<NT, 2>(n, f);
+        qt_reg_step<NT, 3>(n, f);
     } else {
-        for (int base = 0; base < n; base += QT_THREADS) f(std::integral_constant<int, 0>(), base + (int)threadIdx.x);
+        for (int base = 0; base < n; base += NT) f(std::integral_constant<int, 0>(), base + (int)threadIdx.x);
     }
 }
 
@@ -1241,8 +1242,8 @@ struct OrbLapInline {
     int32_t n;    // images whose range is in v (0: read `lap`)
     int32_t v[4]; // lap0, lap1 of image 0, of image 1
 };
-template <bool GLOBAL>
-__global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __restrict__ lg,
+template <bool GLOBAL, int NT>
+__global__ __launch_bounds__(NT) void k_octree(const OrbLevelGeom* __restrict__ lg,
                                                        const OrbCellGeom* __restrict__ cg,
                                                        const uint32_t* __restrict__ cand, size_t candImgStride,
                                                        const int32_t* __restrict__ cellCount, int nCellsTotal,
@@ -1309,18 +1310,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     bool keysInLds = false; // (uniform)
     // Every pass walks the key arrays twice; keep them in LDS when the level's candidates fit (the
     // usual case), else in the global scratch arrays.  (Generic pointers: flat loads serve both.)
-    // A level of up to QT_THREADS cells (every level of a 752x480 frame) learns its total from the gather's own
+    // A level of up to NT cells (every level of a 752x480 frame) learns its total from the gather's own
     // scan below; only larger levels pay a separate pass over the cell counts (one more dependent global round trip).
-    const bool oneChunk = L.nCells <= QT_THREADS;
+    const bool oneChunk = L.nCells <= NT;
     if (!oneChunk) {
         int part = 0;
-        for (int ci = tid; ci < L.nCells; ci += QT_THREADS) part += cnts[ci];
+        for (int ci = tid; ci < L.nCells; ci += NT) part += cnts[ci];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
         if (lane == 0) wsum[wave] = part;
         __syncthreads();
         int total = 0;
-        for (int w = 0; w < QT_WAVES; w++) total += wsum[w];
+        for (int w = 0; w < (NT / 64); w++) total += wsum[w];
         __syncthreads();
         if (total <= keyLdsCap) {
             keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
@@ -1337,23 +1338,23 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     bool regp = false;
     uint32_t kReg[QT_KPT] = {0, 0, 0, 0};
     int nReg[QT_KPT] = {0, 0, 0, 0}, cReg[QT_KPT] = {-1, -1, -1, -1};
-    int* gbase = gscan + QT_THREADS; // slot base of the chunk's cells
-    for (int cbase = 0; cbase < L.nCells; cbase += QT_THREADS) {
-        const int nc = min(QT_THREADS, L.nCells - cbase);
+    int* gbase = gscan + NT; // slot base of the chunk's cells
+    for (int cbase = 0; cbase < L.nCells; cbase += NT) {
+        const int nc = min(NT, L.nCells - cbase);
         if (tid < nc) {
             gscan[tid] = cnts[cbase + tid];
             gbase[tid] = cells[cbase + tid].slotBase;
         }
         __syncthreads();
         QT_STAMP(5);
-        const int tot = qt_scan(gscan, nc, wsum); // exclusive prefix of the counts
+        const int tot = qt_scan<NT>(gscan, nc, wsum); // exclusive prefix of the counts
         QT_STAMP(6);
         if (oneChunk && tot <= keyLdsCap) {       // (uniform) the key arrays do not overlap gscan / gbase
             keys = reinterpret_cast<uint32_t*>(lds + keyLdsOff);
             keyNode = reinterpret_cast<uint16_t*>(lds + keyLdsOff + keyLdsCap);
             keysInLds = true;
         }
-        regp = oneChunk && tot <= QT_KPT * QT_THREADS; // (uniform)
+        regp = oneChunk && tot <= QT_KPT * NT; // (uniform)
         auto fetch = [&](int i) -> uint32_t {
             int lo = 0, hi = nc - 1; // last cell whose prefix <= i (cells with zero keys share a prefix; take the last)
             while (lo < hi) {
@@ -1364,12 +1365,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             return candImg[gbase[lo] + (i - gscan[lo])];
         };
         if (regp) {
-            // the thread's four searches side by side: fixed steps 256 .. 1 (nc <= QT_THREADS = 512), the four LDS reads of a
+            // the thread's four searches side by side: fixed steps 256 .. 1 (nc <= NT = 512), the four LDS reads of a
             // step independent of each other -- 9 LDS latencies in a row instead of 36 (four while-loops one after the other)
-            static_assert(QT_KPT == 4 && QT_THREADS <= 512, "the interleaved search covers 512 cells and four keys per thread");
+            static_assert(QT_KPT == 4 && (NT == 512 || NT == 1024), "the interleaved search starts at NT / 2 and keeps four keys per thread");
             int lo4[QT_KPT] = {0, 0, 0, 0};
 #pragma unroll
-            for (int step = 256; step >= 1; step >>= 1) {
+            for (int step = NT / 2; step >= 1; step >>= 1) {
                 int m[QT_KPT], pv[QT_KPT];
 #pragma unroll
                 for (int j = 0; j < QT_KPT; j++) {
@@ -1378,11 +1379,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 }
 #pragma unroll
                 for (int j = 0; j < QT_KPT; j++)
-                    if (m[j] < nc && pv[j] <= tid + j * QT_THREADS) lo4[j] = m[j];
+                    if (m[j] < nc && pv[j] <= tid + j * NT) lo4[j] = m[j];
             }
 #pragma unroll
             for (int j = 0; j < QT_KPT; j++) {
-                const int i = tid + j * QT_THREADS;
+                const int i = tid + j * NT;
                 if (i < tot) {
                     kReg[j] = candImg[gbase[lo4[j]] + (i - gscan[lo4[j]])];
                     if (keysInLds) keysL[i] = kReg[j]; // the retained key of a node is looked up by index at the end
@@ -1390,7 +1391,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 }
             }
         } else {
-            for (int i = tid; i < tot; i += QT_THREADS) keys[n + i] = fetch(i);
+            for (int i = tid; i < tot; i += NT) keys[n + i] = fetch(i);
         }
         n += tot;
         __syncthreads();
@@ -1404,7 +1405,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     const int nIni = L.nIni;
     if (n == 0 || nIni < 1) {
         if (tid == 0) lvlCount[(size_t)img * ORBFE_MAX_LEVELS + level] = 0;
-        for (int p = tid; p < L.kpCap; p += QT_THREADS) lvlPre[(size_t)img * kpImgStride + L.kpBase + p] = 0u; // no slot is valid
+        for (int p = tid; p < L.kpCap; p += NT) lvlPre[(size_t)img * kpImgStride + L.kpBase + p] = 0u; // no slot is valid
         return;
     }
     // ---- the first passes in closed form.  While 4 * (number of cells of a depth) <= N neither `size >= N` nor the
@@ -1423,11 +1424,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     bool forwarded = false;
     if (FF > 0) {
         const int B = nIni << (2 * FF); // <= N / 4 < LC
-        for (int i = tid; i < B; i += QT_THREADS) cc[i] = 0;
+        for (int i = tid; i < B; i += NT) cc[i] = 0;
         if (tid == 0) misc[1] = 0;
         __syncthreads();
         const int top = FF & 1; // the root digit runs backwards when FF is odd
-        qt_each_key(regp, n, [&](auto J, int i) {
+        qt_each_key<NT>(regp, n, [&](auto J, int i) {
             constexpr int j = decltype(J)::value;
             int b = -1;
             if (i < n) {
@@ -1461,7 +1462,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             for (int d = 0; d < FF; d++) { // nodes of depth d = runs of 4^(FF-d) bins
                 const int span = 1 << (2 * (FF - d)), quarter = span >> 2;
                 const int nItems = (nIni << (2 * d)) * 4; // (a multiple of 4: the lanes of a quad are in range together)
-                for (int it = tid; it < nItems; it += QT_THREADS) {
+                for (int it = tid; it < nItems; it += NT) {
                     const int g = it >> 2, c4 = it & 3;
                     int sub = 0;
                     for (int e = 0; e < quarter; e++) sub += cc[g * span + c4 * quarter + e];
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             const int* const ccR = cc;
             const float hX = L.hX;
             const int maxY = L.maxBY - ORBFE_MINB;
-            size = qt_scan_map(cc, gpre, B, wsum, [](int c) { return c > 0 ? 1 : 0; },
+            size = qt_scan_map<NT>(cc, gpre, B, wsum, [](int c) { return c > 0 ? 1 : 0; },
                                [=](int b, int pos, int v) {
                                    if (!v) return;
                                    // the path of bin b: root digit, then FF quadrant digits (most significant first)
@@ -1514,7 +1515,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                                    brW[pos] = br;
                                    cntW[pos] = ccR[b];
                                });
-            qt_each_key(regp, n, [&](auto J, int i) {
+            qt_each_key<NT>(regp, n, [&](auto J, int i) {
                 constexpr int j = decltype(J)::value;
                 if (i < n) {
                     if (regp) nReg[j] = gpre[cReg[j]];
@@ -1527,7 +1528,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     if (!forwarded) {
     if (tid < nIni) cc[tid] = 0;
     __syncthreads();
-    qt_each_key(regp, n, [&](auto J, int i) { // whole wavefronts enter qt_hist_add
+    qt_each_key<NT>(regp, n, [&](auto J, int i) { // whole wavefronts enter qt_hist_add
         constexpr int j = decltype(J)::value;
         int r = -1;
         if (i < n) {
@@ -1542,7 +1543,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     __syncthreads();
     if (tid < nIni) gpre[tid] = cc[tid] > 0 ? 1 : 0;
     __syncthreads();
-    size = qt_scan(gpre, nIni, wsum);
+    size = qt_scan<NT>(gpre, nIni, wsum);
     if (tid < nIni && cc[tid] > 0) {
         const int p = gpre[tid];
         const int x0 = (int)__fmul_rn(L.hX, (float)tid), x1 = (int)__fmul_rn(L.hX, (float)(tid + 1));
@@ -1551,7 +1552,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         nodeCnt(0)[p] = cc[tid];
     }
     __syncthreads();
-    qt_each_key(regp, n, [&](auto J, int i) {
+    qt_each_key<NT>(regp, n, [&](auto J, int i) {
         constexpr int j = decltype(J)::value;
         if (i < n) {
             if (regp) nReg[j] = gpre[nReg[j]];
@@ -1568,7 +1569,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         const int* ul = nodeUL(cur);
         const int* br = nodeBR(cur);
         if (!histDone) { // cc[0 .. 4 nE) was cleared by the caller, before its last barrier
-            qt_each_key(regp, n, [&](auto J, int i) {
+            qt_each_key<NT>(regp, n, [&](auto J, int i) {
                 constexpr int j = decltype(J)::value;
                 int c = -1;
                 if (i < n) {
@@ -1587,7 +1588,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         // One packed scan over i = 4k+q: low half counts multi-key children (creation order), high
         // half counts non-empty children.  Children are push_front'ed, so their list order is the
         // REVERSE of i (n4,n3,n2,n1 of the last parent first): position = nChildren - 1 - (#non-empty before i).
-        const int tot = qt_scan_map(cc, mpos, 4 * nE, wsum, [](int c) { return (c > 1 ? 1 : 0) | (c > 0 ? 0x10000 : 0); });
+        const int tot = qt_scan_map<NT>(cc, mpos, 4 * nE, wsum, [](int c) { return (c > 1 ? 1 : 0) | (c > 0 ? 0x10000 : 0); });
         const int nChildren = tot >> 16, nMulti = tot & 0xFFFF;
         const int nb = cur ^ 1;
         const int newSize = nChildren + (size - nE);
@@ -1596,7 +1597,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             nMultiOut = 0;
             return -1;
         }
-        for (int i = tid; i < 4 * nE; i += QT_THREADS) {
+        for (int i = tid; i < 4 * nE; i += NT) {
             const int k = i >> 2, q = i & 3;
             const int cnt = cc[i];
             if (cnt > 0) {
@@ -1612,7 +1613,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             }
         }
         __syncthreads();
-        for (int p = tid; p < size; p += QT_THREADS) {
+        for (int p = tid; p < size; p += NT) {
             const int k = kOf[p];
             if (!(k >= 0 && k < nE)) {
                 const int pos = nChildren + p - sidx[p];
@@ -1621,7 +1622,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 nodeCnt(nb)[pos] = nodeCnt(cur)[p];
             }
         }
-        qt_each_key(regp, n, [&](auto J, int i) {
+        qt_each_key<NT>(regp, n, [&](auto J, int i) {
             constexpr int j = decltype(J)::value;
             if (i >= n) return;
             if (regp) { // the child slot 4k+q is still in the register the histogram left it in
@@ -1658,13 +1659,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         // scan writes, no separate pass).  The nodes were written before the barrier that ended the last pass.
         int* const kOfW = kOf;
         int* const parW = par;
-        const int nE = qt_scan_map(nodeCnt(cur), sidx, size, wsum, [](int c) { return c > 1 ? 1 : 0; },
+        const int nE = qt_scan_map<NT>(nodeCnt(cur), sidx, size, wsum, [](int c) { return c > 1 ? 1 : 0; },
                                    [kOfW, parW](int p, int e, int v) {
                                        kOfW[p] = v ? e : -1;
                                        if (v) parW[e] = p;
                                    });
         if (nE == 0) break;
-        for (int i = tid; i < 4 * nE; i += QT_THREADS) cc[i] = 0; // histogram of expand(), cleared in this phase
+        for (int i = tid; i < 4 * nE; i += NT) cc[i] = 0; // histogram of expand(), cleared in this phase
         __syncthreads();
         int nMulti = 0;
         const int ns = expand(nE, false, nMulti);
@@ -1682,12 +1683,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 const int prev2 = size;
                 const int* mcur = multi(cur);
                 // rank of candidate t in descending (count, creation index) order
-                for (int p = tid; p < size; p += QT_THREADS) kOf[p] = -1;
+                for (int p = tid; p < size; p += NT) kOf[p] = -1;
                 // (count and creation index in one word where they fit: the rank below is then one comparison per pair)
                 const bool packedRank = m <= 8 * 64 && n < 65536; // (uniform)
-                for (int t = tid; t < m; t += QT_THREADS) gpre[t] = packedRank ? (nodeCnt(cur)[mcur[t]] << 16) | t : nodeCnt(cur)[mcur[t]];
-                for (int i = tid; i < 4 * m; i += QT_THREADS) cc[i] = 0;
-                for (int t = tid; t < m; t += QT_THREADS) sidx[t] = 0; // rank accumulators (sidx is rebuilt below)
+                for (int t = tid; t < m; t += NT) gpre[t] = packedRank ? (nodeCnt(cur)[mcur[t]] << 16) | t : nodeCnt(cur)[mcur[t]];
+                for (int i = tid; i < 4 * m; i += NT) cc[i] = 0;
+                for (int t = tid; t < m; t += NT) sidx[t] = 0; // rank accumulators (sidx is rebuilt below)
                 if (tid == 0) misc[0] = m;
                 __syncthreads();
                 if (stampF == 43) QT_STAMP(20);
@@ -1702,7 +1703,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                     // the wavefront's slice of j sits in one register (lane l: key of j0 + l), the candidates t it is compared
                     // with in up to eight more; per j one v_readlane and, per 64 candidates, a compare and an add-with-carry --
                     // no LDS read inside the loop (the form below: 1.4 us of this kernel's 16 for a single frame, this one 1.05)
-                    const int per = (m + QT_WAVES - 1) / QT_WAVES; // <= 64
+                    const int per = (m + (NT / 64) - 1) / (NT / 64); // <= 64
                     const int j0 = wave * per, nj = min(m, j0 + per) - j0;
                     const unsigned mine = lane < nj ? (unsigned)gpre[j0 + lane] : 0u; // (0 is ahead of nobody: keys are >= 2 << 16)
                     // (one instantiation per number of 64-candidate groups: no test inside the loop)
@@ -1744,7 +1745,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                     default: rank_groups(std::integral_constant<int, 8>()); break;
                     }
                 } else {
-                    const int per = (m + QT_WAVES - 1) / QT_WAVES;
+                    const int per = (m + (NT / 64) - 1) / (NT / 64);
                     const int j0 = wave * per, j1 = min(m, j0 + per);
                     for (int t = lane; t < m; t += 64) {
                         const int ct = gpre[t];
@@ -1766,7 +1767,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 }
                 __syncthreads();
                 if (stampF == 43) QT_STAMP(21);
-                for (int t = tid; t < m; t += QT_THREADS) {
+                for (int t = tid; t < m; t += NT) {
                     const int rank = sidx[t];
                     kOf[mcur[t]] = rank;
                     par[rank] = mcur[t];
@@ -1776,7 +1777,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 {
                     const int* ul = nodeUL(cur);
                     const int* br = nodeBR(cur);
-                    qt_each_key(regp, n, [&](auto J, int i) {
+                    qt_each_key<NT>(regp, n, [&](auto J, int i) {
                         constexpr int j = decltype(J)::value;
                         int c = -1;
                         if (i < n) {
@@ -1799,7 +1800,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 {
                     int* const cut = misc;
                     const int sz = size;
-                    qt_scan_map(reinterpret_cast<const int4*>(cc), gpre, m, wsum,
+                    qt_scan_map<NT>(reinterpret_cast<const int4*>(cc), gpre, m, wsum,
                                 [](int4 c) { return (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0) - 1; },
                                 [cut, sz, N](int r, int e, int g) {
                                     const int before = sz + e;
@@ -1808,7 +1809,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 }
                 const int nE2 = misc[0];
                 if (stampF == 43) QT_STAMP(24);
-                qt_scan_map(kOf, sidx, size, wsum, [nE2](int k) { return (k >= 0 && k < nE2) ? 1 : 0; });
+                qt_scan_map<NT>(kOf, sidx, size, wsum, [nE2](int k) { return (k >= 0 && k < nE2) ? 1 : 0; });
                 if (stampF == 43) QT_STAMP(25);
                 int nM2 = 0;
                 const int ns2 = expand(nE2, true, nM2);
@@ -1827,9 +1828,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
     QT_STAMP(59);
     // ---- retain the best key of every node (:739-758): max response, first key wins ties
     unsigned* best = reinterpret_cast<unsigned*>(cc);
-    for (int p = tid; p < size; p += QT_THREADS) best[p] = 0;
+    for (int p = tid; p < size; p += NT) best[p] = 0;
     __syncthreads();
-    qt_each_key(regp, n, [&](auto J, int i) {
+    qt_each_key<NT>(regp, n, [&](auto J, int i) {
         constexpr int j = decltype(J)::value;
         if (i >= n) return;
         const uint32_t key = regp ? kReg[j] : keys[i];
@@ -1858,7 +1859,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
         QT_STAMP(17);
         if (none || all) {
             const uint32_t flag = all ? 0x18000u : 0x10000u;
-            for (int p = tid; p < nout; p += QT_THREADS) {
+            for (int p = tid; p < nout; p += NT) {
                 const uint32_t at = 0xFFFFFFu - (best[p] & 0xFFFFFFu);
                 out[p] = keysInLds ? keysL[at] : keys[at];
                 pre[p] = flag | (all ? (uint32_t)p : 0u);
@@ -1866,7 +1867,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
             run = all ? nout : 0;
             QT_STAMP(28);
         } else
-        for (int base = 0; base < nout; base += QT_THREADS, buf ^= 1) { // (uniform trip count; one barrier per round)
+        for (int base = 0; base < nout; base += NT, buf ^= 1) { // (uniform trip count; one barrier per round)
             const int p = base + tid;
             bool st = false;
             if (p < nout) {
@@ -1877,19 +1878,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_octree(const OrbLevelGeom* __res
                 st = sx >= lap0 && sx <= lap1;
             }
             const unsigned long long m = __ballot(st);
-            int* const wc = wsum + buf * QT_WAVES;
+            int* const wc = wsum + buf * (NT / 64);
             if (lane == 0) wc[wave] = __popcll(m);
             __syncthreads();
             int before = run;
 #pragma unroll
-            for (int w = 0; w < QT_WAVES; w++) {
+            for (int w = 0; w < (NT / 64); w++) {
                 const int c = wc[w];
                 before += w < wave ? c : 0;
                 run += c;
             }
             if (p < nout) pre[p] = 0x10000u | (st ? 0x8000u : 0u) | (uint32_t)(before + __popcll(m & ((1ull << lane) - 1ull)));
         }
-        for (int p = nout + tid; p < L.kpCap; p += QT_THREADS) pre[p] = 0u;
+        for (int p = nout + tid; p < L.kpCap; p += NT) pre[p] = 0u;
         QT_STAMP(29);
         if (tid == 0) lvlCount[(size_t)img * ORBFE_MAX_LEVELS + level] = nout | (run << 16);
     }
