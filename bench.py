@@ -42,6 +42,7 @@ Extra objects in the line (none of them is `value`):
                     stereo protocol, src/Frame.cc:119-122), and all usable cores.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -358,6 +359,10 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # No collector pauses inside timed loops: with torch loaded one full collection of the interpreter's heap takes 35-65 ms,
+    # and it fell once into the cross-camera leg of every 300-step run (0.196 ms per step read as 0.34-0.42; found with
+    # ORBFE_BENCH_CROSS_TRACE=1).  The loops below allocate a few small objects per step; nothing here builds cycles.
+    gc.disable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -674,14 +679,26 @@ def main():
             def step_cross_mc():
                 j = (counter[0] % R) if rot_on[0] else 0
                 counter[0] += 1
+                v = None
+                t0 = time.perf_counter()
                 if mc_inflight[0] == pkg.binding.MC_MAX_IN_FLIGHT:
                     v = mcx.wait()
                     mc_inflight[0] -= 1
                     last[0] = (v, fifo.pop(0))
-                    mcx.match_ring_async(v.batch, hops)  # queued behind the extraction already in the stream
+                t1 = time.perf_counter()
                 mcx.submit(d_rot[j].data_ptr(), H, W, W, H * W, lap)
+                t2 = time.perf_counter()
                 fifo.append(j)
                 mc_inflight[0] += 1
+                # the matching of the batch that has just arrived goes behind the next submit: the lane of that submit starts at
+                # the point of the call on this stream, so it does not queue behind a matching kernel that shares the CUs with
+                # two extractions (70-210 us per launch there against 18-22 alone)
+                if v is not None:
+                    mcx.match_ring_async(v.batch, hops)
+                t3 = time.perf_counter()
+                worst[0], worst[1], worst[2] = max(worst[0], t1 - t0), max(worst[1], t2 - t1), max(worst[2], t3 - t2)
+
+            worst = [0.0, 0.0, 0.0]  # (diagnostic: the longest wait / submit / match call of the leg)
 
             def drain():
                 while mc_inflight[0] > 0:
@@ -692,11 +709,20 @@ def main():
             for _ in range(10):
                 step_cross_mc()
             drain()
+            stamps = [] if os.environ.get("ORBFE_BENCH_CROSS_TRACE") else None
+            worst[:] = [0.0, 0.0, 0.0]
             tc = time.perf_counter()
             for _ in range(args.steps):
                 step_cross_mc()
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
             drain()
             tc = time.perf_counter() - tc
+            if stamps is not None:
+                print("cross worst calls ms: wait %.3f submit %.3f match %.3f" % tuple(1e3 * w for w in worst), file=sys.stderr)
+            if stamps is not None:  # (diagnostic: host time of every 10 steps of the leg, to stderr)
+                print("cross trace (ms per step over 10 steps):", " ".join("%.3f" % (1e2 * (stamps[i + 10] - stamps[i]))
+                                                                            for i in range(0, len(stamps) - 10, 10)), file=sys.stderr)
             cross = {"jobs_per_step": B * world, "pairing": "every frame against the next camera of the ring (global frame g+1), "
                      "train frames read from the gathered buffer in place (orbfe_mc_match_ring_async)",
                      "ms_per_step": 1e3 * tc / args.steps}
@@ -910,7 +936,8 @@ def main():
         # (2.7 cycles for the simple 32-bit / 16-bit operations, 4.5 for the rest, measured in profiles/r01_valu_rate.txt)
         valu_cycles = {"fast": 3.2, "pyramid": 3.66, "octree": 3.73, "desc": 4.57}
         valu_roof = None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r04_pmc_summary.json"),
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc_summary.json"),
+                                os.path.join(ROOT, "profiles", "r04_pmc_summary.json"),
                                 os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
                                 os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
                                 os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) if os.path.exists(q)), "")

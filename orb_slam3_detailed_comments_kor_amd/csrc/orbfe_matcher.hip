@@ -3360,8 +3360,18 @@ int orbfe_bfknn2_device(int device, void* hip_stream, const uint8_t* dQ, int nQ,
     return 0;
 }
 
+// `shared` != 0: the caller knows of other kernels in flight on the device (orbfe_mc_match_ring_async with extractions queued)
+extern "C" int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
+                                            int32_t* d_idx, int32_t* d_dist, int shared);
+
 int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
                                int32_t* d_idx, int32_t* d_dist)
+{
+    return orbfe_internal_bfknn2_frames(device, hip_stream, d_jobs, njobs, cap, d_idx, d_dist, 0);
+}
+
+int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
+                                 int32_t* d_idx, int32_t* d_dist, int shared)
 {
     if (njobs < 0 || cap < 1 || cap >= (1 << 20) || (njobs && (!d_jobs || !d_idx || !d_dist))) return ORBFE_ERR_ARGS;
     if (njobs == 0) return 0;
@@ -3383,10 +3393,13 @@ int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_jo
         // A grid that fits the chip once (64 jobs x 4 query blocks = 256 workgroups on 256 CUs) must not be packed two to a CU
         // with the rest of the chip idle -- the dispatcher does exactly that when two fit: 26.0 us per launch against 18.0
         // when each asks for more than half a CU's LDS (82 KB and more: 17.9-18.3 us; 81 KB still let two in).  Larger grids
-        // keep their real size (two per CU then overlap).
+        // keep their real size (two per CU then overlap), and so does a launch that shares the chip with extraction kernels
+        // (`shared`): a workgroup that needs 96 KB waits longer for a CU there -- the cross-camera step of bench.py with two
+        // extractions in flight: 0.196-0.199 ms padded, 0.190-0.193 not (three runs each).
         // (the last query block of every job does not count when it is the mostly empty one: it is dispatched last)
         const unsigned mainCols = (cap % KNN2M_QUERIES != 0 && mgrid.x > 1) ? mgrid.x - 1 : mgrid.x;
-        if ((size_t)mainCols * mgrid.y <= 256) lds = std::max(lds, (size_t)96 * 1024);
+        static const bool pad = !(getenv("ORBFE_KNN2_PAD") && atoi(getenv("ORBFE_KNN2_PAD")) == 0);
+        if (pad && !shared && (size_t)mainCols * mgrid.y <= 256) lds = std::max(lds, (size_t)96 * 1024);
         if (const char* e = getenv("ORBFE_KNN2_LDS_KB")) lds = std::max(lds, (size_t)atoi(e) * 1024); // (tuning)
         static std::atomic<size_t> ldsSet{0};
         if (lds > 64 * 1024 && ldsSet.load() < lds) {

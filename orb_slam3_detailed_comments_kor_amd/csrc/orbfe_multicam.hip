@@ -42,6 +42,8 @@
 extern "C" int orbfe_get_stream(orbfe_ctx*, void** hip_stream, int* device);
 extern "C" int orbfe_lanes_record(orbfe_ctx*, void* hip_event);
 extern "C" int orbfe_internal_exchange_hint(orbfe_ctx*, int on);
+extern "C" int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
+                                            int32_t* d_idx, int32_t* d_dist, int shared);
 
 // RCCL is resolved at run time (dlopen: the single-GPU library has no link dependency on it), so the few facts about its ABI
 // this file relies on are mirrored by hand below.  Where the header exists at build time they are CHECKED:
@@ -561,7 +563,8 @@ int orbfe_mc_match_ring_async(orbfe_mc* m, const int* hops, int nhops, long batc
     MC_HIP_TRY(hipStreamWaitEvent(m->sCtx, b.evGathered, 0));
     MC_HIP_TRY(hipMemsetAsync(m->d_idx, 0xFF, (size_t)np * m->cap * 2 * sizeof(int32_t), m->sCtx));
     MC_HIP_TRY(hipMemsetAsync(m->d_dist, 0xFF, (size_t)np * m->cap * 2 * sizeof(int32_t), m->sCtx));
-    int r = orbfe_bfknn2_frames_device(m->device, m->sCtx, b.d_jobs, np, m->cap, m->d_idx, m->d_dist);
+    // (with batches in flight the kernel shares the CUs with their extraction: it then asks for no more LDS than it uses)
+    int r = orbfe_internal_bfknn2_frames(m->device, m->sCtx, b.d_jobs, np, m->cap, m->d_idx, m->d_dist, m->submitted != m->retired);
     if (r < 0) return r;
     m->lastPairs = np;
     return np;
