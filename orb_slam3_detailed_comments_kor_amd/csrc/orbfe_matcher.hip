@@ -553,6 +553,11 @@ struct BowProb {
     // these name its resident arrays (and the node offsets of that set are relative to its own index array); null = pooled.
     const uint8_t* rDesc1; const uint8_t* rMask1; const float* rAng1; const int32_t* rInd1;
     const uint8_t* rDesc2; const uint8_t* rMask2; const float* rAng2; const int32_t* rInd2;
+    // Round 5: the FeatureVectors' node ids (ascending) and offsets on the device -- a handle's own arrays or the call's pool --
+    // for launches that find the shared nodes themselves (k_search_bow with nodes == nullptr: workgroup (i, p) is node i of set 1
+    // of problem p); i?Base = where the set's index array starts in the pool (0 for a handle)
+    const uint32_t* node1; const int32_t* offs1; int nn1, i1Base;
+    const uint32_t* node2; const int32_t* offs2; int nn2, i2Base;
 };
 
 // ComputeThreeMaxima (:2545-2586), the device twin of three_maxima() below
@@ -749,14 +754,13 @@ __device__ unsigned long long g_bowTimes[16];     // max over the nodes of every
 #define BT(k) do { } while (0)
 #define BT_END() do { } while (0)
 #endif
-__device__ __forceinline__ void bow_node(int nd, const BowNode* __restrict__ nodes, const BowProb* __restrict__ probs,
+__device__ __forceinline__ void bow_node(const BowNode N, const BowProb* __restrict__ probs,
                                          const uint8_t* __restrict__ descPool, const uint8_t* __restrict__ maskPool,
                                          const float* __restrict__ angPool, const int32_t* __restrict__ indPool,
                                          int32_t* __restrict__ matchPool, int8_t* __restrict__ binsPool,
                                          uint8_t* __restrict__ takenPool)
 {
     const int lane = threadIdx.x & 63;
-    const BowNode N = nodes[nd];
     const BowProb Pb = probs[N.prob];
     // (array by array: a set whose descriptors alone are resident -- an extractor's output slab -- pools the rest)
     const uint8_t* desc1 = Pb.rDesc1 ? Pb.rDesc1 : descPool + (size_t)Pb.d1Base * 32;
@@ -1041,12 +1045,43 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
     __shared__ __attribute__((aligned(16))) unsigned long long sDesc[64][4]; // ... -> descriptor, eligibility (rescans)
     __shared__ uint8_t sOk[64];
     const int nd = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (nd >= nNodes) return;
     BT_BEGIN();
-    const BowNode N = nodes[nd];
+    BowNode N;
+    if (nodes) {
+        if (nd >= nNodes) return;
+        N = nodes[nd];
+    } else {
+        // The merge-join of the two FeatureVectors (the loop heads of :300-318 / :851-866) done here: this workgroup is node
+        // blockIdx.x of set 1 of problem blockIdx.y; its partner in set 2 is the entry with the same id, found by all lanes at
+        // once (ids are unique within a vector).  Every wavefront of the workgroup does the same look-up -- two dependent round
+        // trips -- and leaves together when there is no partner; such a launch carries no completion count (bow_run).
+        const int pi = (int)blockIdx.y;
+        const BowProb* __restrict__ Q = probs + pi;
+        const int nn1 = Q->nn1, nn2 = Q->nn2;
+        if (nd >= nn1) return;
+        const uint32_t* __restrict__ node2 = Q->node2;
+        const int32_t* __restrict__ offs1 = Q->offs1;
+        const uint32_t id = Q->node1[nd];
+        const int o1 = offs1[nd], e1 = offs1[nd + 1];
+        int j = -1;
+        for (int base = 0; base < nn2 && j < 0; base += 64) { // (uniform)
+            const int k = base + lane;
+            const unsigned long long hit = __ballot(k < nn2 && node2[k] == id);
+            if (hit) j = base + __ffsll((long long)hit) - 1;
+        }
+        if (j < 0) return;
+        const int32_t* __restrict__ offs2 = Q->offs2;
+        const int o2 = offs2[j], e2 = offs2[j + 1];
+        N.off1 = Q->i1Base + o1;
+        N.n1 = e1 - o1;
+        N.off2 = Q->i2Base + o2;
+        N.n2 = e2 - o2;
+        N.prob = pi;
+        if (N.n1 <= 0 || N.n2 <= 0) return;
+    }
     if (!(N.n1 <= 64 && N.n2 <= 64)) { // (uniform over the workgroup)
         if (wave == 0) {
-            bow_node(nd, nodes, probs, descPool, maskPool, angPool, indPool, matchPool, binsPool, takenPool);
+            bow_node(N, probs, descPool, maskPool, angPool, indPool, matchPool, binsPool, takenPool);
             wg1_done(done);
         }
         return;
@@ -2688,6 +2723,27 @@ struct BlockPool {
 };
 BlockPool g_blockPool;
 
+// The staged inputs of a call brought to the device by a KERNEL (16 bytes per thread out of the pinned mirror) which also puts
+// the all-ones into the result region -- instead of a clearing command, a copy command and the ~10 us the queue spends between
+// two commands of different engines (SearchByBoW x 64 with the nodes paired on the device: fill 6 + gap 10 + copy 9 + gap 10 in
+// front of the kernel -> one launch of ~5 us).  Used when what is staged is small (Scratch::flush_by_kernel).
+struct StageRuns {
+    const uint4* src[4];
+    uint4* dst[4];
+    unsigned n16[4]; // 16-byte units per run (unused runs: 0)
+    uint4* fill;
+    unsigned fill16;
+};
+__global__ __launch_bounds__(256) void k_stage_in(const StageRuns R)
+{
+    const unsigned t = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        for (unsigned i = t; i < R.n16[k]; i += step) R.dst[k][i] = R.src[k][i];
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (unsigned i = t; i < R.fill16; i += step) R.fill[i] = ones;
+}
+
 struct Scratch { // device allocations of one call
     Arena* ar = nullptr;
     // Latency path (round 4): a call whose staged inputs are a few KB hands the KERNEL the pinned mirror itself (device-side
@@ -2879,6 +2935,31 @@ struct Scratch { // device allocations of one call
             lateUps.clear();
         }
         return 0;
+    }
+    // flush() as ONE kernel that also fills [fill, fill + fillBytes) with ones (k_stage_in); false: not applicable (no device
+    // alias of the mirror, more than four runs, a lot of bytes, late uploads) -- nothing was queued, the caller takes flush()
+    // and a clearing command
+    bool flush_by_kernel(void* fill, size_t fillBytes)
+    {
+        if (!ar->pinDev || !ar->base || staged.size() > 4 || !lateUps.empty()) return false;
+        size_t total = 0;
+        for (const auto& r : staged) total += r.second;
+        if (total > (256u << 10) || (fillBytes >> 4) > 0xFFFFFFFFull) return false;
+        StageRuns R;
+        std::memset(&R, 0, sizeof R);
+        for (size_t k = 0; k < staged.size(); k++) {
+            R.src[k] = reinterpret_cast<const uint4*>(ar->pinDev + staged[k].first);
+            R.dst[k] = reinterpret_cast<uint4*>(ar->base + staged[k].first);
+            R.n16[k] = (unsigned)(staged[k].second >> 4);
+        }
+        R.fill = reinterpret_cast<uint4*>(fill);
+        R.fill16 = (unsigned)((fillBytes + 15) >> 4);
+        const size_t units = std::max<size_t>(total >> 4, R.fill16);
+        const unsigned wgs = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (units + 255) / 256));
+        hipLaunchKernelGGL(k_stage_in, dim3(wgs), dim3(256), 0, g_ms, R);
+        if (hipGetLastError() != hipSuccess) return false;
+        staged.clear();
+        return true;
     }
     // Results: down() names a device range the caller wants in `host`; fetch() brings all of them back with ONE
     // transfer of the arena stretch that covers them into the pinned mirror (the outputs of a call are neighbours in
@@ -3210,8 +3291,11 @@ void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
 struct BowCull {
     int outBase, n, check, pad;
 };
+// Mout / nmOut (round 5): the culled rows and the counts written to a second place as well -- the call's pinned mirror, whole
+// rows of consecutive 4-byte stores per wavefront -- so that no download command (and no ~9 us of queue hand-over in front of it)
+// follows the kernel; null: in place only, the caller downloads M and nm.
 __global__ __launch_bounds__(256) void k_bow_cull(const BowCull* __restrict__ C, int32_t* __restrict__ M, const int8_t* __restrict__ B,
-                                                  int32_t* __restrict__ nm)
+                                                  int32_t* __restrict__ nm, int32_t* __restrict__ Mout, int32_t* __restrict__ nmOut)
 {
     __shared__ int sHist[32], sInd[3], sCnt;
     const BowCull c = C[blockIdx.x];
@@ -3234,17 +3318,25 @@ __global__ __launch_bounds__(256) void k_bow_cull(const BowCull* __restrict__ C,
         __syncthreads();
         const int ind1 = sInd[0], ind2 = sInd[1], ind3 = sInd[2];
         cnt = 0;
-        for (int i = tid; i < c.n; i += 256)
-            if (m[i] >= 0) {
+        for (int i = tid; i < c.n; i += 256) {
+            int v = m[i];
+            if (v >= 0) {
                 const int bin = b[i];
                 if (bin == ind1 || bin == ind2 || bin == ind3) cnt++;
-                else m[i] = -1;
+                else m[i] = v = -1;
             }
+            if (Mout) Mout[c.outBase + i] = v;
+        }
+    } else if (Mout) {
+        for (int i = tid; i < c.n; i += 256) Mout[c.outBase + i] = m[i];
     }
     cnt = wave_sum_i32(cnt);
     if ((tid & 63) == 0 && cnt) atomicAdd(&sCnt, cnt);
     __syncthreads();
-    if (tid == 0) nm[blockIdx.x] = sCnt;
+    if (tid == 0) {
+        nm[blockIdx.x] = sCnt;
+        if (nmOut) nmOut[blockIdx.x] = sCnt;
+    }
 }
 
 // rotation-consistency cull (:450-468): returns the number of surviving matches
@@ -3438,6 +3530,9 @@ struct orbfe_keyframe {
     uint8_t *desc = nullptr, *mask = nullptr;
     float *ang = nullptr, *kp = nullptr, *uR = nullptr;
     int32_t *oct = nullptr, *ind = nullptr;
+    uint32_t* dNode = nullptr; // the FeatureVector's node ids and offsets (nn, nn + 1 entries) for launches that pair the nodes
+    int32_t* dOffs = nullptr;  // of two vectors themselves (bow_run, round 5)
+    int maxNode = 0;           // features of the largest node
     bool hasTri = false; // keypoints / octaves / mvuRight were given: usable as a side of SearchForTriangulation_
     std::vector<uint32_t> nodeIds;
     std::vector<int32_t> offsets, indices, hOct;
@@ -3506,29 +3601,60 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     std::vector<orbfe_bow_args> eff(count); // the arguments with the handles' host views filled in
     int rows = 0, outTotal = 0, takenRows = 0;
     size_t indTotal = 0, ovTotal = 0;
+    bool needTakenDev = false;
     std::vector<long> ovOff1(count, -1), ovOff2(count, -1); // per-call flags of sets in handles: offsets into their own pool
     // A set that is not in a handle travels with the call -- once: the problems of a call usually share one side (the current
     // frame against every relocalisation candidate, src/Tracking.cc:3784; the current keyframe against its covisibles), and the
     // same arrays (same pointers, same sizes) are staged and uploaded a single time (64 candidates: 1.3 MB -> 41 KB).
     struct SeenSet {
-        const void *desc, *mask, *ang, *ind, *offs;
-        int n, nn, rowBase, indBase;
+        const void *desc, *mask, *ang, *ind, *offs, *ids;
+        int n, nn, rowBase, indBase, nodeBase /* in the pooled node ids; offsets: nodeBase + index of the set */, maxNode;
     };
     std::vector<SeenSet> seen;
     std::vector<uint8_t> own1(count, 0), own2(count, 0); // this problem stages the set (first occurrence)
-    auto place_set = [&](const uint8_t* desc, int n, const uint8_t* mask, const float* ang, const orbfe_fv& fv, int& rowBase, int& indBase) -> bool {
-        for (const SeenSet& q : seen)
-            if (q.desc == desc && q.n == n && q.mask == mask && q.ang == ang && q.ind == fv.indices && q.offs == fv.offsets && q.nn == fv.nn) {
+    std::vector<int> set1(count, -1), set2(count, -1);  // index into `seen` of a pooled side
+    size_t nodeTotal = 0;
+    // Round 5: a call whose results are downloaded anyway (more than 256 KB of them: the 64 candidates of a
+    // relocalisation) leaves the merge-join of the FeatureVectors to the kernel -- 33 us of host time and a 128-KB node list per
+    // call of 64; the node ids / offsets of sets that are not in handles travel in the pool (~1 KB per set).
+    // (Calls whose results come back through the pinned mirror keep the host list: their launch counts its workgroups for the
+    // completion word.)  ORBFE_BOW_DEVNODES=0: host lists always (A/B).
+    static const int devNodesPolicy = [] {
+        const char* e = getenv("ORBFE_BOW_DEVNODES");
+        return e ? atoi(e) : 1;
+    }();
+    bool devNodes = false;
+    if (devNodesPolicy != 0) {
+        size_t outPre = 0;
+        for (int p = 0; p < count; p++) {
+            const orbfe_keyframe* K1 = kf1 ? kf1[p] : nullptr;
+            const orbfe_keyframe* K2 = kf2 ? kf2[p] : nullptr;
+            const int v = args[p].variant;
+            const int n = v == 0 ? (K2 ? K2->n : args[p].n2) : (K1 ? K1->n : args[p].n1);
+            outPre += (size_t)std::max(n, 0);
+        }
+        devNodes = outPre * 5 > (256u << 10) && count <= 65535; // (the same test as `mirrored` below; problems = grid rows)
+    }
+    int maxNN1 = 0;
+    auto place_set = [&](const uint8_t* desc, int n, const uint8_t* mask, const float* ang, const orbfe_fv& fv, int& rowBase, int& indBase) -> int {
+        for (size_t k = 0; k < seen.size(); k++) {
+            const SeenSet& q = seen[k];
+            if (q.desc == desc && q.n == n && q.mask == mask && q.ang == ang && q.ind == fv.indices && q.offs == fv.offsets && q.nn == fv.nn &&
+                q.ids == fv.node_ids) {
                 rowBase = q.rowBase;
                 indBase = q.indBase;
-                return false;
+                return -(int)k - 1; // (seen before)
             }
+        }
         rowBase = rows;
         indBase = (int)indTotal;
-        seen.push_back(SeenSet{desc, mask, ang, fv.indices, fv.offsets, n, fv.nn, rowBase, indBase});
+        int mx = 0;
+        for (int i = 0; i < fv.nn; i++) mx = std::max(mx, fv.offsets[i + 1] - fv.offsets[i]);
+        seen.push_back(SeenSet{desc, mask, ang, fv.indices, fv.offsets, fv.node_ids, n, fv.nn, rowBase, indBase, (int)nodeTotal, mx});
         rows += n;
         indTotal += (size_t)(fv.nn ? fv.offsets[fv.nn] : 0);
-        return true;
+        nodeTotal += (size_t)fv.nn;
+        return (int)seen.size();
     };
     for (int p = 0; p < count; p++) {
         orbfe_bow_args& e = eff[p];
@@ -3582,17 +3708,34 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             P.rDesc1 = K1->desc; P.rMask1 = K1->mask; P.rAng1 = K1->ang; P.rInd1 = K1->ind;
         } else {
             if (is_device_ptr(a->desc1)) P.rDesc1 = a->desc1; // read where the extractor left them
-            own1[p] = place_set(a->desc1, a->n1, a->mask1, a->angle1, a->fv1, P.d1Base, i1Base[p]) ? 1 : 0;
+            const int k = place_set(a->desc1, a->n1, a->mask1, a->angle1, a->fv1, P.d1Base, i1Base[p]);
+            own1[p] = k > 0 ? 1 : 0;
+            set1[p] = k > 0 ? k - 1 : -k - 1;
         }
         if (K2) {
             P.rDesc2 = K2->desc; P.rMask2 = K2->mask; P.rAng2 = K2->ang; P.rInd2 = K2->ind;
         } else {
             if (is_device_ptr(a->desc2)) P.rDesc2 = a->desc2;
             // (the flags of set 2 are all ones in variant 0: such a set and one with real flags are different sets)
-            own2[p] = place_set(a->desc2, a->n2, a->variant == 1 ? a->mask2 : nullptr, a->angle2, a->fv2, P.d2Base, i2Base[p]) ? 1 : 0;
+            const int k = place_set(a->desc2, a->n2, a->variant == 1 ? a->mask2 : nullptr, a->angle2, a->fv2, P.d2Base, i2Base[p]);
+            own2[p] = k > 0 ? 1 : 0;
+            set2[p] = k > 0 ? k - 1 : -k - 1;
         }
         bool bad = false;
         const int b1 = i1Base[p], b2 = i2Base[p]; // (0 for a set in a handle: its offsets are relative to its own index array)
+        if (devNodes) { // (the kernel pairs the nodes: what the host still checks is the size of set 2's largest node)
+            const int mx2 = K2 ? K2->maxNode : seen[(size_t)set2[p]].maxNode;
+            if (mx2 >= (1 << 20)) return ORBFE_ERR_ARGS;
+            needTakenDev = needTakenDev || mx2 > 4096;
+            P.nn1 = a->fv1.nn;
+            P.nn2 = a->fv2.nn;
+            P.i1Base = b1;
+            P.i2Base = b2;
+            if (K1) { P.node1 = K1->dNode; P.offs1 = K1->dOffs; }
+            if (K2) { P.node2 = K2->dNode; P.offs2 = K2->dOffs; }
+            maxNN1 = std::max(maxNN1, P.nn1);
+            continue;
+        }
         for_each_shared_node(a->fv1, a->fv2, [&](int i, int j) {
             BowNode n;
             n.off1 = b1 + a->fv1.offsets[i];
@@ -3610,26 +3753,53 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         for (int p = 0; p < count; p++)
             for (int i = 0; i < outN[p]; i++) match[p][i] = -1;
     };
-    if (nodes.empty()) {
+    if (devNodes ? maxNN1 == 0 : nodes.empty()) {
         none();
         return 0;
     }
     PTR(); // pass 1
-    bool needTaken = false; // the "taken" flags in memory are only touched by nodes with more than 4096 candidates
+    bool needTaken = needTakenDev; // the "taken" flags in memory are only touched by nodes with more than 4096 candidates
     for (const BowNode& nd : nodes) needTaken = needTaken || nd.n2 > 4096;
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
     // (what travels: node list, problem records, the pooled sets.  A search against resident keyframes sends ~15 KB: the kernel
     // reads that from the pinned staging in place)
-    s.inPlace = nodes.size() * sizeof(BowNode) + (size_t)rows * 37 + indTotal * 4 + ovTotal <= inplace_limit();
+    // (not when the kernel pairs the nodes: every workgroup then starts with two or three DEPENDENT reads of the problem record
+    // and the node ids -- across PCIe that made the 64-candidate kernel 48 us instead of 25; such a call's staged inputs go up
+    // through k_stage_in, below)
+    s.inPlace = !devNodes && nodes.size() * sizeof(BowNode) + (size_t)rows * 37 + indTotal * 4 + ovTotal <= inplace_limit();
     BowNode* dN;
     BowProb* dP;
     uint8_t *dDesc, *dMask, *taken, *hDesc, *hMask;
     float *dAng, *hAng;
     int32_t *dInd, *dM, *hInd;
     int8_t* dB;
-    if ((r = s.up(&dN, nodes.data(), nodes.size())) < 0) return r;
+    if (devNodes) dN = nullptr;
+    else if ((r = s.up(&dN, nodes.data(), nodes.size())) < 0) return r;
+    if (devNodes && !seen.empty()) { // node ids and offsets of the pooled sets (set k: ids at nodeBase, offsets at nodeBase + k)
+        uint32_t *dIds = nullptr, *hIds = nullptr;
+        int32_t *dOf = nullptr, *hOf = nullptr;
+        if ((r = s.reserve(&dIds, &hIds, nodeTotal)) < 0) return r;
+        if ((r = s.reserve(&dOf, &hOf, nodeTotal + seen.size())) < 0) return r;
+        for (size_t k = 0; k < seen.size(); k++) {
+            const SeenSet& q = seen[k];
+            if (q.nn) std::memcpy(hIds + q.nodeBase, q.ids, (size_t)q.nn * sizeof(uint32_t));
+            if (q.nn) std::memcpy(hOf + q.nodeBase + k, q.offs, ((size_t)q.nn + 1) * sizeof(int32_t));
+            else hOf[q.nodeBase + k] = 0;
+        }
+        for (int p = 0; p < count; p++) {
+            if (!active[p]) continue;
+            if (set1[p] >= 0) {
+                probs[p].node1 = dIds + seen[(size_t)set1[p]].nodeBase;
+                probs[p].offs1 = dOf + seen[(size_t)set1[p]].nodeBase + set1[p];
+            }
+            if (set2[p] >= 0) {
+                probs[p].node2 = dIds + seen[(size_t)set2[p]].nodeBase;
+                probs[p].offs2 = dOf + seen[(size_t)set2[p]].nodeBase + set2[p];
+            }
+        }
+    }
     {
         uint8_t *dOv = nullptr, *hOv = nullptr;
         if (ovTotal) {
@@ -3656,7 +3826,8 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     int8_t* hB = nullptr;
     Scratch::OutBlock ob;
     const size_t mBytes = ((size_t)outTotal * sizeof(int32_t) + 15) & ~(size_t)15;
-    const bool mirrored = (size_t)outTotal * 5 <= (256u << 10) && s.out_block(&ob, mBytes + (size_t)outTotal, (unsigned)nodes.size()) == 0;
+    const bool mirrored = !devNodes && (size_t)outTotal * 5 <= (256u << 10) &&
+                          s.out_block(&ob, mBytes + (size_t)outTotal, (unsigned)nodes.size()) == 0;
     if (mirrored) { // (the kernel scatters into the clean device block; its mirror arrives whole: DoneSig)
         dM = reinterpret_cast<int32_t*>(ob.dev);
         dB = reinterpret_cast<int8_t*>(ob.dev + mBytes);
@@ -3709,7 +3880,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         std::vector<BowCull> cu((size_t)count);
         for (int p = 0; p < count; p++) cu[(size_t)p] = BowCull{probs[p].outBase, outN[p], args[p].check_orientation != 0 ? 1 : 0, 0};
         if ((r = s.up(&dC, cu.data(), cu.size())) < 0) return r;
-        HIP_TRY(hipMemsetAsync(dM, 0xFF, ((size_t)outTotal + (size_t)count) * sizeof(int32_t) + (size_t)outTotal, g_ms));
+        const size_t clearBytes = ((size_t)outTotal + (size_t)count) * sizeof(int32_t) + (size_t)outTotal;
+        // (the region is 256-byte aligned and rounded: the kernel's whole 16-byte units stay inside it)
+        if (!(devNodes && s.flush_by_kernel(dM, clearBytes))) HIP_TRY(hipMemsetAsync(dM, 0xFF, clearBytes, g_ms));
     }
     if (needTaken) HIP_TRY(hipMemsetAsync(taken, 0, (size_t)takenRows, g_ms));
     const DoneSig done = s.done_sig(4u * (unsigned)nodes.size() /* (a workgroup per node) */, mirrored ? &ob : nullptr, g_timeKernels);
@@ -3718,12 +3891,19 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         KernelTimer timer(s); // (sends the staged pools)
         for (const D2D& c : d2d)
             HIP_TRY(hipMemcpyAsync(dDesc + c.off, c.src, c.bytes, hipMemcpyDeviceToDevice, g_ms));
+        if (devNodes) // (workgroup (i, p): node i of set 1 of problem p; no completion count: `done` carries no flag here)
+            hipLaunchKernelGGL(k_search_bow, dim3((unsigned)maxNN1, (unsigned)count), dim3(256), 0, g_ms, (const BowNode*)nullptr, 0,
+                               dP, dDesc, dMask, dAng, dInd, dM, dB, taken, done, bow_stop_at());
+        else
         hipLaunchKernelGGL(k_search_bow, dim3((unsigned)nodes.size()), dim3(256), 0, g_ms, dN, (int)nodes.size(),
                            dP, dDesc, dMask, dAng, dInd, dM, dB, taken, done, bow_stop_at());
     }
     HIP_TRY(hipGetLastError());
+    int32_t *dMir = nullptr, *hMir = nullptr; // the culled rows + counts in the pinned mirror (written by k_bow_cull)
     if (!mirrored) {
-        hipLaunchKernelGGL(k_bow_cull, dim3((unsigned)count), dim3(256), 0, g_ms, dC, dM, dB, dM + outTotal);
+        if (devNodes && s.mirror_out(&dMir, &hMir, (size_t)outTotal + (size_t)count) != 0) dMir = hMir = nullptr;
+        hipLaunchKernelGGL(k_bow_cull, dim3((unsigned)count), dim3(256), 0, g_ms, dC, dM, dB, dM + outTotal, dMir,
+                           dMir ? dMir + outTotal : nullptr);
         HIP_TRY(hipGetLastError());
     }
     PTR(); // launch
@@ -3734,6 +3914,9 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         INT_TRY(s.complete(done));
         pm = hM;
         pb = hB;
+    } else if (hMir) { // written by k_bow_cull: complete when the stream is
+        HIP_TRY(hipStreamSynchronize(g_ms));
+        pm = hMir;
     } else {
         // (reading the download where it lands in the pinned mirror instead of copying it out first was tried: the copy is a
         // streaming pass, the cull loop on freshly DMA-written lines is not -- 206 against 188 us for wait + tail of a 64-problem call)
@@ -3793,7 +3976,8 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     if ((r = select_device(device)) < 0) return r;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t oDesc = 0, oMask = oDesc + al(n * 32), oAng = oMask + al(n), oKp = oAng + al(n * 4), oUr = oKp + al(n * 8),
-                 oOct = oUr + al(n * 4), oInd = oOct + al(n * 4), total = oInd + al(std::max<size_t>(ni, 1) * 4);
+                 oOct = oUr + al(n * 4), oInd = oOct + al(n * 4), oNode = oInd + al(std::max<size_t>(ni, 1) * 4),
+                 oOffs = oNode + al(std::max<size_t>((size_t)a->fv.nn, 1) * 4), total = oOffs + al(((size_t)a->fv.nn + 1) * 4);
     size_t blkCap = 0;
     void* blk = g_blockPool.get(device, total, &blkCap);
     if (!blk) return -(1000 + (int)hipErrorOutOfMemory);
@@ -3809,10 +3993,13 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     K->uR = (float*)(K->block + oUr);
     K->oct = (int32_t*)(K->block + oOct);
     K->ind = (int32_t*)(K->block + oInd);
+    K->dNode = (uint32_t*)(K->block + oNode);
+    K->dOffs = (int32_t*)(K->block + oOffs);
     K->hasTri = tri;
     K->nodeIds.assign(a->fv.node_ids, a->fv.node_ids + a->fv.nn);
     K->offsets.assign(a->fv.offsets, a->fv.offsets + a->fv.nn + (a->fv.nn ? 1 : 0));
     if (K->offsets.empty()) K->offsets.push_back(0);
+    for (int i = 0; i < a->fv.nn; i++) K->maxNode = std::max(K->maxNode, K->offsets[(size_t)i + 1] - K->offsets[(size_t)i]);
     K->indices.assign(a->fv.indices, a->fv.indices + ni);
     K->hMask.assign(a->mask, a->mask + n);
     if (a->angle) K->hAng.assign(a->angle, a->angle + n);
@@ -3851,6 +4038,8 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
             std::memcpy(b + oOct, a->octave, n * 4);
         }
         if (ni) std::memcpy(b + oInd, a->fv.indices, ni * 4);
+        if (a->fv.nn) std::memcpy(b + oNode, K->nodeIds.data(), (size_t)a->fv.nn * 4);
+        std::memcpy(b + oOffs, K->offsets.data(), ((size_t)a->fv.nn + 1) * 4);
         if (descResident) e = hipMemcpyAsync(K->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms);
         if (e == hipSuccess) e = hipMemcpyAsync(K->block + first, st, total - first, hipMemcpyHostToDevice, g_ms);
     } else { // (the arena is too small this once: array by array)
@@ -3862,6 +4051,8 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
         if (e == hipSuccess && tri) e = hipMemcpyAsync(K->uR, a->uRight, n * 4, hipMemcpyHostToDevice, g_ms);
         if (e == hipSuccess && tri) e = hipMemcpyAsync(K->oct, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
         if (e == hipSuccess && ni) e = hipMemcpyAsync(K->ind, a->fv.indices, ni * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && a->fv.nn) e = hipMemcpyAsync(K->dNode, K->nodeIds.data(), (size_t)a->fv.nn * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(K->dOffs, K->offsets.data(), ((size_t)a->fv.nn + 1) * 4, hipMemcpyHostToDevice, g_ms);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(g_ms); // the caller's arrays are free again; the handle is complete
     if (e != hipSuccess) {

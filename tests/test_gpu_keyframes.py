@@ -334,6 +334,67 @@ def test_bow_batch_stages_shared_sets_once(pkg, oracle):
         assert g[0] == got[k % 6][0] and np.array_equal(g[1], got[k % 6][1]), k
 
 
+@pytest.mark.parametrize("branching,depth", [(2, 2), (10, 2), (12, 2)])
+def test_bow_of_many_candidates_pairs_the_nodes_on_the_device(pkg, oracle, branching, depth):
+    """A relocalisation's worth of candidates (src/Tracking.cc:3784) in one call: the results are downloaded, and such a call
+    leaves the merge-join of the two FeatureVectors to k_search_bow (round 5) -- keyframes in handles against a frame that comes
+    with the call, handles on both sides, and host arrays on both sides; vocabularies of 4 nodes (hundreds of features per node:
+    the wide-node path), 100 and 144 nodes (more than one 64-lane chunk of ids per look-up, ids missing on either side).  Every
+    problem against the oracle and against the same problem alone (whose small result takes the host's node list)."""
+    from orb_slam3_detailed_comments_kor_amd import synth
+    rng = np.random.default_rng(1000 + branching)
+    NK = 64
+    dF = rng.integers(0, 256, size=(1100, 32), dtype=np.uint8)
+    aF = rng.uniform(0, 360, 1100).astype(np.float32)
+    mF = (rng.uniform(size=1100) < 0.6).astype(np.uint8)
+    fvF = synth.make_feature_vectors(dF, 77, branching, depth)
+    sets, kfs = [], []
+    for k in range(NK):
+        n = 1000 + 3 * k  # (64 x ~1100 x 5 bytes of results: above the mirror's 256 KB)
+        d, origin = _noisy_copy(dF, n, 300 + k)
+        a = np.where(origin >= 0, aF[np.maximum(origin, 0)] + rng.normal(0, 4, n), rng.uniform(0, 360, n)).astype(np.float32) % 360
+        if k % 7 == 3:  # a keyframe that misses part of the vocabulary: ids of the frame without a partner, and the reverse
+            d[: n // 2] = d[n // 2: 2 * (n // 2)]
+        fvK = synth.make_feature_vectors(d, 77, branching, depth)
+        mask = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+        sets.append((d, mask, a, fvK))
+        kfs.append(pkg.KeyFrameHandle(d, mask, a, fvK))
+    hF = pkg.KeyFrameHandle(dF, mF, aF, fvF)
+    assert sum(len(s[0]) for s in sets) * 5 > 256 * 1024
+    want0 = [oracle.search_bow_kf_f(d, m, a, fv, dF, aF, fvF, -1, 0.75, True) for d, m, a, fv in sets]
+    want1 = [oracle.search_bow_kf_kf(d, m, a, fv, dF, mF, aF, fvF, -1, -1, 0.8, True) for d, m, a, fv in sets[:NK]]
+    assert sum(w[0] for w in want0) > 2000
+    # variant 0, set 1 in handles, the frame passed with the call (staged once)
+    got = pkg.search_bow_keyframes([dict(kf1=kfs[k], desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75, check_ori=True) for k in range(NK)])
+    for k in range(NK):
+        assert got[k][0] == want0[k][0] and np.array_equal(got[k][1], want0[k][1]), k
+    one = pkg.search_bow_keyframes([dict(kf1=kfs[5], desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75, check_ori=True)])[0]
+    assert one[0] == want0[5][0] and np.array_equal(one[1], want0[5][1])
+    # variant 1, both sides in handles (the results of variant 1 have set 1's length: 64 x ~1100 again)
+    got = pkg.search_bow_keyframes([dict(kf1=kfs[k], kf2=hF, variant=1, nnratio=0.8, check_ori=True) for k in range(NK)])
+    for k in range(NK):
+        assert got[k][0] == want1[k][0] and np.array_equal(got[k][1], want1[k][1]), k
+    # host arrays on both sides, and the three forms mixed in one call
+    got = pkg.search_bow_batch([dict(desc1=sets[k][0], mask1=sets[k][1], ang1=sets[k][2], fv1=sets[k][3], desc2=dF, ang2=aF, fv2=fvF,
+                                     variant=0, nnratio=0.75) for k in range(NK)])
+    for k in range(NK):
+        assert got[k][0] == want0[k][0] and np.array_equal(got[k][1], want0[k][1]), k
+    mixed = []
+    for k in range(NK):
+        if k % 3 == 0:
+            mixed.append(dict(kf1=kfs[k], kf2=hF, variant=1, nnratio=0.8, check_ori=True))
+        elif k % 3 == 1:
+            mixed.append(dict(kf1=kfs[k], desc2=dF, mask2=mF, ang2=aF, fv2=fvF, variant=1, nnratio=0.8, check_ori=True))
+        else:
+            mixed.append(dict(desc1=sets[k][0], mask1=sets[k][1], ang1=sets[k][2], fv1=sets[k][3], kf2=hF, variant=1, nnratio=0.8,
+                              check_ori=True))
+    got = pkg.search_bow_keyframes(mixed)
+    for k in range(NK):
+        assert got[k][0] == want1[k][0] and np.array_equal(got[k][1], want1[k][1]), k
+    for h in kfs + [hF]:
+        h.close()
+
+
 def synth_empty_fv():
     return (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
 
