@@ -2884,7 +2884,15 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     // A frame or two: everything on the context's stream (no event traffic on the latency path).  A real batch: the
     // copies go to the copy streams like the pipelined form -- measured: a 23-MB upload queued on the stream the
     // kernels run on takes 0.8 ms instead of the 0.41 ms the DMA engine needs on a stream of its own.
-    const bool ownCopyStreams = rows > 0 && cols > 0 && (size_t)nimg * (size_t)rows * (size_t)cols >= (2u << 20);
+    // (Round 5: not for a frame or a PAIR however large -- two 1024 x 1024 fisheye images are exactly 2 MB and took the batch
+    // form: copy engine 44 us + 16 us of hand-over instead of the upload kernel's 32, a download command instead of the mirror.
+    // ORBFE_COPY_STREAMS_FROM=2 restores that for A/B.)
+    static const int copyStreamsFrom = [] {
+        const char* e = getenv("ORBFE_COPY_STREAMS_FROM");
+        return e ? std::max(1, atoi(e)) : 3;
+    }();
+    const bool ownCopyStreams = rows > 0 && cols > 0 && nimg >= copyStreamsFrom &&
+                                (size_t)nimg * (size_t)rows * (size_t)cols >= (2u << 20);
     const int r = host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, ownCopyStreams,
                               true);
     if (r < 0) return r;

@@ -4431,6 +4431,11 @@ int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* 
     uint8_t *dQ, *dT;
     int32_t *dI, *dD, *dOL, *dOR, *dL2R;
     float *dKL, *dKR, *dP1, *dP2, *dR, *dt, *dSig, *dDepth, *dX;
+    // Round 5 (C5 taken apart, profiles/r05_c5_stages.txt): with both descriptor sets resident what travels is 12 bytes per
+    // keypoint -- read by the triangulation kernel where it lies in the pinned staging (every thread reads its own few words once,
+    // under an 85-us kernel) instead of a copy command and the queue's hand-over in front of the first kernel.  (Not with host
+    // descriptors: the knn kernel reads every train row once per query block.)
+    s.inPlace = is_device_ptr(descL) && is_device_ptr(descR) && ((size_t)nL + (size_t)nR) * 12 + 4096 <= inplace_limit();
     if ((r = s.up_desc(&dQ, descL, (size_t)nL * 32)) < 0) return r;
     if ((r = s.up_desc(&dT, descR, (size_t)nR * 32)) < 0) return r;
     if ((r = s.up(&dKL, kpL_xy, (size_t)nL * 2)) < 0) return r;
@@ -4444,9 +4449,21 @@ int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* 
     if ((r = s.up(&dSig, levelSigma2, (size_t)nlevels)) < 0) return r;
     if ((r = s.up<int32_t>(&dI, nullptr, (size_t)nL * 2)) < 0) return r;
     if ((r = s.up<int32_t>(&dD, nullptr, (size_t)nL * 2)) < 0) return r;
-    if ((r = s.up<int32_t>(&dL2R, nullptr, (size_t)nL)) < 0) return r;
-    if ((r = s.up<float>(&dDepth, nullptr, (size_t)nL)) < 0) return r;
-    if ((r = s.up<float>(&dX, nullptr, (size_t)nL * 3)) < 0) return r;
+    // ... and the results (20 bytes per left keypoint) are stored by the kernel's threads into the pinned mirror themselves: the
+    // threads end at very different times (Jacobi sweeps), so all but the last one's stores cross the link under the kernel, and
+    // no download command follows it
+    uint8_t *dMir = nullptr, *hMir = nullptr;
+    const size_t oDepth = ((size_t)nL * 4 + 255) & ~(size_t)255, oX = 2 * oDepth;
+    if (s.mirror_out(&dMir, &hMir, oX + (size_t)nL * 12) == 0) {
+        dL2R = reinterpret_cast<int32_t*>(dMir);
+        dDepth = reinterpret_cast<float*>(dMir + oDepth);
+        dX = reinterpret_cast<float*>(dMir + oX);
+    } else {
+        dMir = hMir = nullptr;
+        if ((r = s.up<int32_t>(&dL2R, nullptr, (size_t)nL)) < 0) return r;
+        if ((r = s.up<float>(&dDepth, nullptr, (size_t)nL)) < 0) return r;
+        if ((r = s.up<float>(&dX, nullptr, (size_t)nL * 3)) < 0) return r;
+    }
     {
         KernelTimer timer(s);
         hipLaunchKernelGGL(k_bfknn2, dim3((unsigned)((nL + 3) / 4)), dim3(256), 0, g_ms, dQ, nL, dT, nR, dI, dD);
@@ -4454,10 +4471,17 @@ int orbfe_stereo_fisheye_matches(int device, const uint8_t* descL, const float* 
                            dOR, dP1, dP2, dR, dt, dSig, dL2R, dDepth, dX);
     }
     HIP_TRY(hipGetLastError());
-    INT_TRY(s.down(leftToRight, dL2R, (size_t)nL * sizeof(int32_t)));
-    INT_TRY(s.down(depth, dDepth, (size_t)nL * sizeof(float)));
-    INT_TRY(s.down(p3D, dX, (size_t)nL * 3 * sizeof(float)));
-    INT_TRY(s.fetch());
+    if (hMir) {
+        HIP_TRY(hipStreamSynchronize(g_ms));
+        std::memcpy(leftToRight, hMir, (size_t)nL * sizeof(int32_t));
+        std::memcpy(depth, hMir + oDepth, (size_t)nL * sizeof(float));
+        std::memcpy(p3D, hMir + oX, (size_t)nL * 3 * sizeof(float));
+    } else {
+        INT_TRY(s.down(leftToRight, dL2R, (size_t)nL * sizeof(int32_t)));
+        INT_TRY(s.down(depth, dDepth, (size_t)nL * sizeof(float)));
+        INT_TRY(s.down(p3D, dX, (size_t)nL * 3 * sizeof(float)));
+        INT_TRY(s.fetch());
+    }
     int nMatches = 0;
     for (int q = 0; q < nL; q++) // mvRightToLeftMatch: the last left keypoint that chose a right one keeps it (:1150)
         if (leftToRight[q] >= 0) {
