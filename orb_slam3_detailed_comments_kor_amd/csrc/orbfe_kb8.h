@@ -88,7 +88,15 @@ __device__ inline void orbfe_svd4_last_vt(const float* A, float* h)
         W[i] = sd;
         for (int k = 0; k < 4; k++) Vt[i * 4 + k] = (i == k) ? 1.f : 0.f;
     }
-    for (int iter = 0; iter < 30; iter++) {
+#ifndef ORBFE_SVD_MAXIT
+#define ORBFE_SVD_MAXIT 30 /* OpenCV: max(m, 30) sweeps; other values are for timing experiments only (tools/r05_svd.sh) */
+#endif
+    // (Round 5, measured on tools/hostbench c5, whose matrices run all 30 sweeps -- sweeps 4..30 are 70 of the call's 300 us --
+    // and not kept, each bit-identical on 180 000 triangulations, tools/kb8_ab.py: v_fma_f64 for the exact float x float products
+    // and a v_sqrt_f64 filter in front of the convergence test's square root, -15 % instructions: no change; rotations on
+    // disjoint rows -- (0,3) with (1,2), (2,3) with the next sweep's (0,1) -- as two branch-free chains: +50 us, because the
+    // branch-free form pays hypot, two divisions and two square roots for every pair the `continue` below skips.)
+    for (int iter = 0; iter < ORBFE_SVD_MAXIT; iter++) {
         bool changed = false;
         for (int i = 0; i < 3; i++)
             for (int j = i + 1; j < 4; j++) {
