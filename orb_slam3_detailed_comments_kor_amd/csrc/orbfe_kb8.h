@@ -95,7 +95,9 @@ __device__ inline void orbfe_svd4_last_vt(const float* A, float* h)
     // and not kept, each bit-identical on 180 000 triangulations, tools/kb8_ab.py: v_fma_f64 for the exact float x float products
     // and a v_sqrt_f64 filter in front of the convergence test's square root, -15 % instructions: no change; rotations on
     // disjoint rows -- (0,3) with (1,2), (2,3) with the next sweep's (0,1) -- as two branch-free chains: +50 us, because the
-    // branch-free form pays hypot, two divisions and two square roots for every pair the `continue` below skips.)
+    // branch-free form pays hypot, two divisions and two square roots for every pair the `continue` below skips; leaving the loop
+    // after a sweep that rotated and yet left At, Vt and W bit for bit as they were -- an exact shortcut: the next sweep would
+    // repeat it -- no change either: the matrices that take all 30 sweeps keep moving in their last bits.)
     for (int iter = 0; iter < ORBFE_SVD_MAXIT; iter++) {
         bool changed = false;
         for (int i = 0; i < 3; i++)

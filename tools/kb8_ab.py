@@ -29,8 +29,29 @@ t = time.perf_counter()
 for _ in range(300): r = pkg.stereo_fisheye_matches(*args)
 print("ms per stereo_fisheye_matches (1500 x 1500): %%.4f" %% (1e3 * (time.perf_counter() - t) / 300))
 out["l2r"], out["dep"], out["p3d"] = r[1], r[3], r[4]
+# ... and what tools/hostbench c5 matches: a 1024 x 1024 frame against itself shifted by 40 px (matrices that never meet the
+# convergence test), TUM-VI parameters scaled to the image, a 10-cm baseline
+sys.path.insert(0, %r)
+import bench
+fr = bench.bench_frames(1024, 1024, 2)
+ex = pkg.ORBextractor(1500, 1.2, 8, 20, 7)
+sc = 1024 / 512.0
+P = np.array([190.978477 * sc, 190.973307 * sc, 254.931706 * sc, 256.897442 * sc, 0.003482389, 0.000715034, -0.002053236, 0.000202937], np.float32)
+sig = (1.2 ** np.arange(8)).astype(np.float32) ** 2
+for k in range(2):
+    L = fr[k]; R = np.roll(L, -40, axis=1)
+    (mL, kL, dL), (mR, kR, dR) = ex.extract_batch([L, R], [(0, 1023)] * 2)
+    xyL = np.stack([kL["x"][mL:], kL["y"][mL:]], 1); xyR = np.stack([kR["x"][mR:], kR["y"][mR:]], 1)
+    a2 = (dL[mL:], xyL, kL["octave"][mL:], dR[mR:], xyR, kR["octave"][mR:], P, P, np.eye(3, dtype=np.float32), np.array([0.101, 0, 0], np.float32), sig)
+    r = pkg.stereo_fisheye_matches(*a2)
+    for _ in range(20): pkg.stereo_fisheye_matches(*a2)
+    t = time.perf_counter()
+    for _ in range(100): pkg.stereo_fisheye_matches(*a2)
+    print("shifted pair %%d: %%d x %%d keypoints, %%d matches, %%.4f ms per call" %% (k, len(xyL), len(xyR), r[0], 1e3 * (time.perf_counter() - t) / 100))
+    out["s_l2r%%d" %% k], out["s_dep%%d" %% k], out["s_p3d%%d" %% k] = r[1], r[3], r[4]
+ex.close()
 np.savez(sys.argv[1], **out)
-""" % (ROOT, ROOT)
+""" % (ROOT, ROOT, ROOT)
 
 
 def run(lib, n, seeds):
@@ -41,7 +62,7 @@ def run(lib, n, seeds):
     else:
         env.pop("ORBFE_LIB", None)
     r = subprocess.run([sys.executable, "-c", CHILD, f, str(seeds), str(n)], env=env, capture_output=True, text=True)
-    print(lib or "liborbfe.so (default)", "|", r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "")
+    print(lib or "liborbfe.so (default)", "|", r.stdout.strip().replace("\n", " | "), r.stderr.strip()[-600:] if r.returncode else "")
     if r.returncode:
         sys.exit(1)
     return dict(np.load(f))
