@@ -202,9 +202,11 @@ __global__ __launch_bounds__(256) void k_bfknn2(const uint8_t* __restrict__ Q, i
 // + 4 for the running two smallest keys -- the VALU issue rate bounds it, not memory (a train row is fetched once
 // per wavefront, for 64 distances).  Keys are distance<<20 | train index, so the two smallest keys are the
 // sequential scan's best and second best with ties going to the lower train index.
+// fillTail: the rows between a query frame's count and `cap` get -1 | -1 from the kernel (the caller would otherwise clear both
+// output arrays in front of every launch: orbfe_mc_match_ring_async, two fill commands of 0.5 MB)
 template <int SPLIT>
 __global__ __launch_bounds__(64 * SPLIT) void k_bfknn2_frames(const orbfe_knn2_job* __restrict__ jobs, int cap,
-                                                             int32_t* __restrict__ idx, int32_t* __restrict__ dist)
+                                                             int32_t* __restrict__ idx, int32_t* __restrict__ dist, int fillTail)
 {
     __shared__ unsigned sk0[SPLIT][64], sk1[SPLIT][64];
     const int lane = threadIdx.x & 63;
@@ -213,6 +215,10 @@ __global__ __launch_bounds__(64 * SPLIT) void k_bfknn2_frames(const orbfe_knn2_j
     const orbfe_knn2_job J = jobs[p];
     const int nQ = min(J.q_count[0], cap), nT = min(J.t_count[0], cap);
     const int q0 = blockIdx.x * 64;
+    if (fillTail && wave == 0 && q0 + lane >= nQ && q0 + lane < cap) {
+        const size_t o = ((size_t)p * cap + q0 + lane) * 2;
+        idx[o] = idx[o + 1] = dist[o] = dist[o + 1] = -1;
+    }
     if (q0 >= nQ) return; // uniform
     const int q = q0 + lane;
     uint4 a = make_uint4(0, 0, 0, 0), b = a;
@@ -313,7 +319,8 @@ struct Knn2mFrag {
     v4i_t k[8];
 };
 __global__ __launch_bounds__(KNN2M_THREADS) void k_bfknn2_frames_mfma(const orbfe_knn2_job* __restrict__ jobs, int cap,
-                                                                      int32_t* __restrict__ idx, int32_t* __restrict__ dist)
+                                                                      int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                                                      int fillTail /* as k_bfknn2_frames */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t knn2m_lds[];
     uint8_t* const sT = knn2m_lds;                                                 // three expanded tiles
@@ -353,6 +360,13 @@ __global__ __launch_bounds__(KNN2M_THREADS) void k_bfknn2_frames_mfma(const orbf
     // pointer, and a read past the end of somebody's allocation can fault.  Requesting the rows together with the counts --
     // one memory round trip less in front of the first MFMA -- saved 1 us of 20 when it was tried.)
     const int nQ = min(J.q_count[0], cap), nT = min(J.t_count[0], cap);
+    if (fillTail) {
+        const int q = qwg + tid; // (KNN2M_THREADS == KNN2M_QUERIES: one row per thread)
+        if (q >= nQ && q < cap) {
+            const size_t o = ((size_t)p * cap + q) * 2;
+            idx[o] = idx[o + 1] = dist[o] = dist[o + 1] = -1;
+        }
+    }
     if (qwg >= nQ) return; // uniform over the workgroup
     uint4 qlo[2], qhi[2];
 #pragma unroll
@@ -3452,9 +3466,10 @@ int orbfe_bfknn2_device(int device, void* hip_stream, const uint8_t* dQ, int nQ,
     return 0;
 }
 
-// `shared` != 0: the caller knows of other kernels in flight on the device (orbfe_mc_match_ring_async with extractions queued)
+// flags: bit 0 = the caller knows of other kernels in flight on the device (orbfe_mc_match_ring_async with extractions queued);
+// bit 1 = rows between a query frame's count and `cap` are written too, as -1 | -1
 extern "C" int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
-                                            int32_t* d_idx, int32_t* d_dist, int shared);
+                                            int32_t* d_idx, int32_t* d_dist, int flags);
 
 int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
                                int32_t* d_idx, int32_t* d_dist)
@@ -3463,8 +3478,9 @@ int orbfe_bfknn2_frames_device(int device, void* hip_stream, const orbfe_knn2_jo
 }
 
 int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
-                                 int32_t* d_idx, int32_t* d_dist, int shared)
+                                 int32_t* d_idx, int32_t* d_dist, int flags)
 {
+    const int shared = flags & 1, fillTail = (flags >> 1) & 1;
     if (njobs < 0 || cap < 1 || cap >= (1 << 20) || (njobs && (!d_jobs || !d_idx || !d_dist))) return ORBFE_ERR_ARGS;
     if (njobs == 0) return 0;
     int r;
@@ -3498,16 +3514,16 @@ int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_
             HIP_TRY(hipFuncSetAttribute((const void*)k_bfknn2_frames_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ldsSet.store(lds);
         }
-        hipLaunchKernelGGL(k_bfknn2_frames_mfma, mgrid, dim3(KNN2M_THREADS), lds, st, d_jobs, cap, d_idx, d_dist);
+        hipLaunchKernelGGL(k_bfknn2_frames_mfma, mgrid, dim3(KNN2M_THREADS), lds, st, d_jobs, cap, d_idx, d_dist, fillTail);
         HIP_TRY(hipGetLastError());
         return 0;
     }
     const dim3 grid((unsigned)((cap + 63) / 64), (unsigned)njobs);
     // few workgroups: more wavefronts per workgroup share the 64 queries (and fill the chip)
     if ((long)grid.x * njobs >= 2048)
-        hipLaunchKernelGGL(k_bfknn2_frames<4>, grid, dim3(256), 0, st, d_jobs, cap, d_idx, d_dist);
+        hipLaunchKernelGGL(k_bfknn2_frames<4>, grid, dim3(256), 0, st, d_jobs, cap, d_idx, d_dist, fillTail);
     else
-        hipLaunchKernelGGL(k_bfknn2_frames<8>, grid, dim3(512), 0, st, d_jobs, cap, d_idx, d_dist);
+        hipLaunchKernelGGL(k_bfknn2_frames<8>, grid, dim3(512), 0, st, d_jobs, cap, d_idx, d_dist, fillTail);
     HIP_TRY(hipGetLastError());
     return 0;
 }

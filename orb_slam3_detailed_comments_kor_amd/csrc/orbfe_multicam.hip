@@ -43,7 +43,7 @@ extern "C" int orbfe_get_stream(orbfe_ctx*, void** hip_stream, int* device);
 extern "C" int orbfe_lanes_record(orbfe_ctx*, void* hip_event);
 extern "C" int orbfe_internal_exchange_hint(orbfe_ctx*, int on);
 extern "C" int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_job* d_jobs, int njobs, int cap,
-                                            int32_t* d_idx, int32_t* d_dist, int shared);
+                                            int32_t* d_idx, int32_t* d_dist, int flags /* 1: shares the chip, 2: fills the tails */);
 
 // RCCL is resolved at run time (dlopen: the single-GPU library has no link dependency on it), so the few facts about its ABI
 // this file relies on are mirrored by hand below.  Where the header exists at build time they are CHECKED:
@@ -561,10 +561,10 @@ int orbfe_mc_match_ring_async(orbfe_mc* m, const int* hops, int nhops, long batc
     if (np < 0) return np;
     // the launch is queued on the extractor's stream, after the collective that fills the gathered buffer
     MC_HIP_TRY(hipStreamWaitEvent(m->sCtx, b.evGathered, 0));
-    MC_HIP_TRY(hipMemsetAsync(m->d_idx, 0xFF, (size_t)np * m->cap * 2 * sizeof(int32_t), m->sCtx));
-    MC_HIP_TRY(hipMemsetAsync(m->d_dist, 0xFF, (size_t)np * m->cap * 2 * sizeof(int32_t), m->sCtx));
-    // (with batches in flight the kernel shares the CUs with their extraction: it then asks for no more LDS than it uses)
-    int r = orbfe_internal_bfknn2_frames(m->device, m->sCtx, b.d_jobs, np, m->cap, m->d_idx, m->d_dist, m->submitted != m->retired);
+    // (with batches in flight the kernel shares the CUs with their extraction: it then asks for no more LDS than it uses; the rows
+    // between a frame's count and cap are set to -1 by the kernel itself -- two 0.5-MB clearing commands per launch until round 5)
+    int r = orbfe_internal_bfknn2_frames(m->device, m->sCtx, b.d_jobs, np, m->cap, m->d_idx, m->d_dist,
+                                         (m->submitted != m->retired ? 1 : 0) | 2);
     if (r < 0) return r;
     m->lastPairs = np;
     return np;

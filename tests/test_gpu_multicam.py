@@ -84,7 +84,7 @@ def test_ctypes_handle_against_the_oracle(oracle):
         ri, rdist = oracle.bfknn2(ref[q][2], ref[t][2])
         n = len(ref[q][1])
         assert np.array_equal(idx[k, :n], ri) and np.array_equal(dist[k, :n], rdist)
-        assert (idx[k, n:] == -1).all()
+        assert (idx[k, n:] == -1).all() and (dist[k, n:] == -1).all()  # (written by the kernel: no clearing command in front)
     mc.close()
     ex.close()
 
