@@ -358,7 +358,8 @@ __global__ __launch_bounds__(KNN2M_THREADS) void k_bfknn2_frames_mfma(const orbf
     const int n = lane & 31, h = lane >> 5;
     // (Rows are only read below the frames' counts: the call's contract is cap >= every count, not cap rows behind every
     // pointer, and a read past the end of somebody's allocation can fault.  Requesting the rows together with the counts --
-    // one memory round trip less in front of the first MFMA -- saved 1 us of 20 when it was tried.)
+    // one memory round trip less in front of the first MFMA -- saved 1 us of 20 when it was first tried, and nothing (17.7-18.0
+    // against 17.9-18.0 us) when orbfe_mc, whose slabs do hold cap rows per frame, asked for it through a flag late in round 5.)
     const int nQ = min(J.q_count[0], cap), nT = min(J.t_count[0], cap);
     if (fillTail) {
         const int q = qwg + tid; // (KNN2M_THREADS == KNN2M_QUERIES: one row per thread)
