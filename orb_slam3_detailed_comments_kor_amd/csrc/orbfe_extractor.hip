@@ -2155,7 +2155,8 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     // (k_upload): no copy engine, hence no queue hand-over, between the host call and the first kernel.
     // (Measured and not kept: staging and uploading a pageable image band by band so that the upload of one band overlaps
     // the host copy of the next -- 2 / 3 / 4 bands: -1 / +2 / +10 us per frame, +7..13 us per stereo pair: the extra launches
-    // cost the host more than the overlap returns.)
+    // cost the host more than the overlap returns.  Round 5, a pair of 1024 x 1024 images staged and uploaded image by image: the
+    // same, 0.327-0.370 against 0.309-0.322 ms per fisheye stereo frame, tools/r05_c5d.sh.)
     const bool kernelIn = c->uploadKernel && !pipelined && nimg <= c->mirrorMaxImgs;
     const uint8_t* d_imgBase = nullptr; // where image 0 starts on the device (set by whichever upload ran)
     if (allPinned && kernelIn && stride <= 2 * (size_t)cols) {
