@@ -267,6 +267,8 @@ def per_call_config(args, real_stdout):
         ms = hb["one_call"]["ms_per_pair_p50"]
         protocols = {"one_batched_call + orbfe_stereo_fisheye_matches": hb["one_call"],
                      "two_threads_two_contexts (reference protocol) + orbfe_stereo_fisheye_matches": hb["two_threads"]}
+        if hb.get("one_call_pinned", {}).get("ms_per_pair_p50"):
+            protocols["one_batched_call, page-locked images (orbfe_host_register) + orbfe_stereo_fisheye_matches"] = hb["one_call_pinned"]
         if "one_call_resident_matching" in hb:
             protocols["one_batched_call + orbfe_stereo_fisheye_matches on the resident descriptors"] = hb["one_call_resident_matching"]
         workload = ("TUM-VI-like fisheye stereo frame per call: 2 x 1024x1024, nFeatures 1500, KannalaBrandt8 bearing rays fused "
