@@ -33,10 +33,12 @@ def _refs(oracle, frames, nf, laps):
 
 
 @pytest.mark.parametrize("pinned", [False, True])
-@pytest.mark.parametrize("nimg,hw", [(1, (240, 376)), (5, (240, 376)), (24, (480, 752))])
+@pytest.mark.parametrize("nimg,hw", [(1, (240, 376)), (5, (240, 376)), (24, (480, 752)), (2, (1024, 1280)), (3, (1024, 1024))])
 def test_batch_pageable_and_pinned(pkg, oracle, pinned, nimg, hw):
     """24 x 752x480 is 8.7 MB: the pageable form goes through the staging pool in chunks, the pinned one is a single
-    DMA command from the caller's buffer; per-image lapping ranges travel in the zero-copy table."""
+    DMA command from the caller's buffer; per-image lapping ranges travel in the zero-copy table.  A PAIR of large images
+    (2 x 1024 x 1280 = 2.6 MB; round 5) stays on the latency path -- upload kernel, results in the pinned mirror -- where three
+    images of that size take the batch form (copy streams)."""
     ex = pkg.ORBextractor(700, 1.2, 8, 20, 7)
     b = ex.Batch(ex, nimg, hw[0], hw[1], pinned=pinned)
     uniq = [pkg.synth.make_frame(hw[0], hw[1], 900 + i) for i in range(min(nimg, 6))]
