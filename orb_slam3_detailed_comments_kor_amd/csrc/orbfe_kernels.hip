@@ -1204,9 +1204,12 @@ __device__ __forceinline__ void qt_each_key(bool regp, int n, F f)
 #endif
 #ifdef ORBFE_QT_TIMING // tuning only (tools/ab_build.sh qtt "-DORBFE_QT_TIMING"): phase timestamps of one workgroup
 __device__ unsigned long long g_qtTimes[64];
+#ifndef ORBFE_QT_TIMING_LEVEL
+#define ORBFE_QT_TIMING_LEVEL 0 /* the level whose workgroup (of image 0) leaves the stamps */
+#endif
 #define QT_STAMP(k)                                                                            \
     do {                                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qtTimes[k] = wall_clock64(); \
+        if (threadIdx.x == 0 && QT_IMG_IDX == 0 && QT_LEVEL_IDX == ORBFE_QT_TIMING_LEVEL) g_qtTimes[k] = wall_clock64(); \
     } while (0)
 // slowest workgroup per level since the last read: (duration in 10-ns ticks) << 16 | image, slots 30..37
 #define QT_WG_BEGIN() const unsigned long long qtT0 = wall_clock64()
@@ -1693,7 +1696,7 @@ __global__ __launch_bounds__(NT) void k_octree(const OrbLevelGeom* __restrict__ 
                 __syncthreads();
                 if (stampF == 43) QT_STAMP(20);
 #ifdef ORBFE_QT_TIMING
-                if (stampF == 43 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qtTimes[61] = ((unsigned long long)m << 32) | (unsigned)size;
+                if (stampF == 43 && threadIdx.x == 0 && QT_IMG_IDX == 0 && QT_LEVEL_IDX == ORBFE_QT_TIMING_LEVEL) g_qtTimes[61] = ((unsigned long long)m << 32) | (unsigned)size;
 #endif
                 // rank = number of candidates ahead in (count descending, creation index descending) order.  All
                 // eight wavefronts work on it: wavefront w compares every candidate t with its own slice of the
