@@ -7,7 +7,7 @@ mkdir -p $out
 cd $root
 gcc -shared -fPIC -O1 -o /tmp/libabrt_bt.so tools/diag/abrt_bt.c || exit 1
 export LIBC_FATAL_STDERR_=1
-for k in 1 2 3 4 5 6 7 8; do
+for k in 1 2 3 4 5 6 7 8 9 10 11 12; do
   LD_PRELOAD=/tmp/libabrt_bt.so timeout -k 10 400 python3 -m pytest -p no:faulthandler tests/test_gpu_lanes.py tests/test_gpu_hostpath.py tests/test_gpu_multicam.py tests/test_gpu_keyframes.py -m gpu -x -q > $out/bt$k.log 2> $out/bt$k.err
   rc=$?
   tail -1 $out/bt$k.log
