@@ -2396,6 +2396,16 @@ int host_wait(orbfe_ctx* c, int laneSlot = -1 /* as in host_submit_impl */)
     if (meta[2 * nimg] != 0) return ORBFE_ERR_STATE; // a device-side list overflowed (cannot happen)
     const size_t Kc = (size_t)sl.cap;
     size_t total = 0;
+    // (the counts come out of the page-locked slab the kernels wrote: a count outside [0, cap] cannot be a result -- never copy
+    // by it into the caller's arrays, whatever made it so)
+    for (int i = 0; i < nimg; i++)
+        if (meta[i] < 0 || (size_t)meta[i] > Kc || meta[nimg + i] < 0 || meta[nimg + i] > meta[i]) {
+            for (int k = 0; k < nimg; k++) {
+                sl.n_out[k] = 0;
+                if (sl.mono_out) sl.mono_out[k] = 0;
+            }
+            return ORBFE_ERR_STATE;
+        }
     for (int i = 0; i < nimg; i++) {
         sl.n_out[i] = meta[i];
         if (sl.mono_out) sl.mono_out[i] = meta[nimg + i];
