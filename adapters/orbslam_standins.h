@@ -19,7 +19,10 @@
 
 namespace DBoW2 {
 typedef unsigned int NodeId;
+typedef unsigned int WordId;
+typedef double WordValue;
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
+class BowVector : public std::map<WordId, WordValue> {}; // Thirdparty/DBoW2/DBoW2/BowVector.h:59-60
 } // namespace DBoW2
 
 namespace ORB_SLAM3 {

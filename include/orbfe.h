@@ -363,6 +363,9 @@ typedef struct {
     const int32_t* offsets;   /* nn+1                                */
     const int32_t* indices;   /* offsets[nn] feature indices         */
 } orbfe_fv;
+/* nn == ORBFE_FV_RESIDENT: the vector lives in an orbfe_bow handle (orbfe_bow_fv below fills such an orbfe_fv); accepted by
+ * every call that takes an orbfe_fv. */
+#define ORBFE_FV_RESIDENT (-0x0B0F)
 
 typedef struct {
     const uint8_t* desc1; int n1; const uint8_t* mask1 /* 1 = good MapPoint */; const float* angle1;
@@ -635,6 +638,48 @@ void orbfe_vocab_free(orbfe_vocab_dev*);
  * results into BowVector::addWeight / FeatureVector::addFeature in feature order (:1147-1160). */
 int orbfe_vocab_transform(orbfe_vocab_dev*, const uint8_t* feats, int n, int levelsup, int32_t* word_id,
                           int32_t* node_id, double* weight);
+
+/* WeightingType / ScoringType of the vocabulary (Thirdparty/DBoW2/DBoW2/BowVector.h:39-56: weighting 0 TF_IDF, 1 TF, 2 IDF,
+ * 3 BINARY; scoring 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT).  orbfe_vocab_load_text takes
+ * them from the file's first line ("k L scoring weighting", :1366-1368); an uploaded tree starts as TF_IDF / L1_NORM, what
+ * Vocabulary/ORBvoc.txt ("10 6 0 0") is. */
+int orbfe_vocab_set_types(orbfe_vocab_dev*, int weighting, int scoring);
+int orbfe_vocab_get_types(orbfe_vocab_dev*, int* weighting, int* scoring);
+
+/* Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:724-731, src/KeyFrame.cc:105-114) as a device-resident step:
+ * TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (TemplatedVocabulary.h:1127-1192) -- the
+ * per-feature descent AND the fold into the two maps (BowVector::addWeight / addIfNotExist / normalize, BowVector.cpp:34-86;
+ * FeatureVector::addFeature, FeatureVector.cpp:31-45), bit-identical to the reference's maps for every weighting / scoring type.
+ *   orbfe_bow_create(&bow, vocab, cap)       a handle for frames of up to `cap` features (<= 65535); reused frame after frame
+ *   orbfe_compute_bow(bow, desc, n, levelsup) `desc`: host or DEVICE pointer (orbfe_get_device_outputs: nothing crosses PCIe).
+ *                                            Asynchronous on the calling thread's matcher stream -- three kernels and one copy
+ *                                            command; returns when they are queued.  One caller per handle at a time.
+ *   orbfe_bow_fv(bow, &fv)                   the FeatureVector as an orbfe_fv that names the handle: a SearchByBoW batch against
+ *                                            keyframe handles reads it where it lies (no host round trip between ComputeBoW and
+ *                                            the search); every other consumer waits for the host copy itself.  Valid until the
+ *                                            next orbfe_compute_bow on the handle.
+ *   orbfe_bow_host(bow, &view)               the host copy, on request: waits for the call's copy command; pointers into
+ *                                            page-locked memory of the handle, valid until the next orbfe_compute_bow.
+ *                                            BowVector = (word_ids[i], word_values[i]), i < nw, ascending id (std::map order);
+ *                                            FeatureVector = CSR (node_ids ascending, offsets[nn + 1], indices).
+ *   orbfe_bow_device(bow, &view)             the same arrays on the device (stream-ordered behind the call; counts in
+ *                                            d_header[0..3] = kept features, nodes, words, features of the largest node).
+ *   orbfe_bow_destroy(bow)                   deferred until no search that was given the handle's vector is in progress.
+ * A feature whose word has weight 0 ("stopped", :1157) enters neither vector.  When the tree's leaves are shallower than
+ * L - levelsup the reference leaves the node id uninitialised; here it is 0 (the root), as in orbfe_vocab_transform. */
+typedef struct orbfe_bow orbfe_bow;
+typedef struct {
+    int n_kept, nn, nw, max_node;
+    const uint32_t* node_ids; const int32_t* offsets; const int32_t* indices; /* FeatureVector */
+    const uint32_t* word_ids; const double* word_values;                      /* BowVector     */
+    const int32_t* d_header;                                                  /* device: the four counts */
+} orbfe_bow_view;
+int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev*, int cap);
+void orbfe_bow_destroy(orbfe_bow*);
+int orbfe_compute_bow(orbfe_bow*, const uint8_t* desc, int n, int levelsup);
+int orbfe_bow_fv(orbfe_bow*, orbfe_fv* fv);
+int orbfe_bow_host(orbfe_bow*, orbfe_bow_view* view);
+int orbfe_bow_device(orbfe_bow*, orbfe_bow_view* view);
 
 /* Device time (ms, hipEvents) of the matcher kernel launched by the last matcher call of this thread. */
 float orbfe_matcher_last_kernel_ms(void);

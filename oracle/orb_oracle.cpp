@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstring>
 #include <list>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -1538,6 +1539,78 @@ void orb_oracle_vocab_transform(int nnodes, const uint8_t* node_desc, const int3
         weight[f] = node_weight[final_id];
         node_id[f] = nid;
     }
+}
+
+// TemplatedVocabulary::transform(features, v, fv, levelsup), reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1192,
+// on the containers the reference uses: BowVector = std::map<WordId, WordValue> (BowVector.h:59-60), FeatureVector =
+// std::map<NodeId, std::vector<unsigned int>> (FeatureVector.h:23-24).
+int orb_oracle_compute_bow(int nnodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_ids,
+                           const int32_t* node_word, const double* node_weight, int L, const uint8_t* feats, int n, int levelsup,
+                           int weighting, int scoring, uint32_t* bow_ids, double* bow_vals, uint32_t* node_ids, int32_t* offsets,
+                           int32_t* indices, int* nn_out)
+{
+    std::map<unsigned, double> v;                 // v.clear()  :1131
+    std::map<unsigned, std::vector<unsigned>> fv; // fv.clear() :1132
+    // m_scoring_object->mustNormalize(norm) (ScoringObject.h:73-89): every scoring but DOT_PRODUCT normalises, L2_NORM with L2
+    const bool must = scoring != 5;
+    const bool normL2 = scoring == 1;
+    std::vector<int32_t> word((size_t)std::max(n, 1)), nid((size_t)std::max(n, 1));
+    std::vector<double> wt((size_t)std::max(n, 1));
+    orb_oracle_vocab_transform(nnodes, node_desc, child_off, child_ids, node_word, node_weight, L, feats, n, levelsup, word.data(),
+                               nid.data(), wt.data());
+    const bool tf = weighting == 0 || weighting == 1; // TF_IDF || TF :1145
+    for (int i = 0; i < n; i++) {                     // i_feature :1147 / :1174
+        const unsigned id = (unsigned)word[(size_t)i];
+        const double w = wt[(size_t)i];
+        if (w > 0) { // not stopped :1157 / :1184
+            auto vit = v.lower_bound(id);
+            if (tf) { // BowVector::addWeight (BowVector.cpp:34-46)
+                if (vit != v.end() && !(v.key_comp()(id, vit->first))) vit->second += w;
+                else v.insert(vit, std::make_pair(id, w));
+            } else { // BowVector::addIfNotExist (BowVector.cpp:50-58)
+                if (vit == v.end() || v.key_comp()(id, vit->first)) v.insert(vit, std::make_pair(id, w));
+            }
+            // FeatureVector::addFeature (FeatureVector.cpp:31-45)
+            const unsigned node = (unsigned)nid[(size_t)i];
+            auto fit = fv.lower_bound(node);
+            if (fit != fv.end() && fit->first == node) fit->second.push_back((unsigned)i);
+            else {
+                fit = fv.insert(fit, std::make_pair(node, std::vector<unsigned>()));
+                fit->second.push_back((unsigned)i);
+            }
+        }
+    }
+    if (tf && !v.empty() && !must) { // unnecessary when normalizing :1164-1170
+        const double nd = (double)v.size();
+        for (auto& e : v) e.second /= nd;
+    }
+    if (must) { // BowVector::normalize (BowVector.cpp:62-86)
+        double norm = 0.0;
+        if (!normL2) {
+            for (auto& e : v) norm += std::fabs(e.second);
+        } else {
+            for (auto& e : v) norm += e.second * e.second;
+            norm = std::sqrt(norm);
+        }
+        if (norm > 0.0)
+            for (auto& e : v) e.second /= norm;
+    }
+    int k = 0;
+    for (auto& e : v) {
+        bow_ids[k] = e.first;
+        bow_vals[k] = e.second;
+        k++;
+    }
+    int s = 0, at = 0;
+    for (auto& e : fv) {
+        node_ids[s] = e.first;
+        offsets[s] = at;
+        for (unsigned f : e.second) indices[at++] = (int32_t)f;
+        s++;
+    }
+    offsets[s] = at;
+    if (nn_out) *nn_out = s;
+    return k;
 }
 
 // Frame::ComputeStereoMatches, reference src/Frame.cc:797-967.  L / R are the oracle extractors that

@@ -191,6 +191,17 @@ void orb_oracle_distinctive_descriptors(const uint8_t* pool, const int32_t* offs
 void orb_oracle_vocab_transform(int nnodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_ids,
                                 const int32_t* node_word, const double* node_weight, int L, const uint8_t* feats, int n,
                                 int levelsup, int32_t* word_id, int32_t* node_id, double* weight);
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (TemplatedVocabulary.h:1127-1192) -- what
+ * Frame::ComputeBoW (src/Frame.cc:724-731) and KeyFrame::ComputeBoW (src/KeyFrame.cc:105-114) call with levelsup = 4 -- with
+ * BowVector::addWeight / addIfNotExist / normalize (BowVector.cpp:34-86) and FeatureVector::addFeature (FeatureVector.cpp:31-45)
+ * done on real std::maps.  weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1_NORM .. 5 DOT_PRODUCT (BowVector.h:39-56;
+ * ORBvoc.txt is "10 6 0 0").  Outputs: the BowVector as (word id, value) in map order (ascending id), the FeatureVector as CSR
+ * (node ids ascending, offsets[nn + 1], feature indices in push_back order); every array sized n (offsets n + 1).
+ * Returns the number of words; *nn_out = number of nodes. */
+int orb_oracle_compute_bow(int nnodes, const uint8_t* node_desc, const int32_t* child_off, const int32_t* child_ids,
+                           const int32_t* node_word, const double* node_weight, int L, const uint8_t* feats, int n, int levelsup,
+                           int weighting, int scoring, uint32_t* bow_ids, double* bow_vals, uint32_t* node_ids, int32_t* offsets,
+                           int32_t* indices, int* nn_out);
 /* Frame::ComputeStereoMatches src/Frame.cc:797-967 (rectified stereo).  L, R = the oracle extractors that
  * processed the left / right image.  uRight/depth sized N (left keypoints), -1 = no match.  Returns #matches. */
 int orb_oracle_compute_stereo_matches(orb_oracle* L, orb_oracle* R, const orb_oracle_kp* kpsL, const uint8_t* descL,

@@ -631,6 +631,27 @@ def vocab_transform(vocab, feats, levelsup=4):
     return w, nid, wt
 
 
+def compute_bow(vocab, feats, levelsup=4, weighting=0, scoring=0):
+    """TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup): returns
+    ((word_ids u32, values f64), (node_ids u32, offsets i32, indices i32))."""
+    feats = np.ascontiguousarray(feats, np.uint8).reshape(-1, 32)
+    n = len(feats)
+    L = lib()
+    L.orb_oracle_compute_bow.restype = C.c_int
+    L.orb_oracle_compute_bow.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+    ids = np.zeros(max(n, 1), np.uint32)
+    vals = np.zeros(max(n, 1), np.float64)
+    node_ids = np.zeros(max(n, 1), np.uint32)
+    offsets = np.zeros(n + 1, np.int32)
+    indices = np.zeros(max(n, 1), np.int32)
+    nn = C.c_int(0)
+    nw = L.orb_oracle_compute_bow(len(vocab["word"]), _p(vocab["desc"]), _p(vocab["child_off"]), _p(vocab["child_ids"]),
+                                  _p(vocab["word"]), _p(vocab["weight"]), int(vocab["L"]), _p(feats), n, levelsup, weighting, scoring,
+                                  _p(ids), _p(vals), _p(node_ids), _p(offsets), _p(indices), C.cast(C.byref(nn), C.c_void_p))
+    k = nn.value
+    return (ids[:nw].copy(), vals[:nw].copy()), (node_ids[:k].copy(), offsets[:k + 1].copy(), indices[:offsets[k]].copy())
+
+
 def kb8_unproject(params8, uv):
     P = np.ascontiguousarray(params8, np.float32)
     uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)

@@ -293,6 +293,8 @@ def lib():
         L.orbfe_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbfe_vocab_upload.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(_Vocab)]
         L.orbfe_vocab_free.argtypes = [C.c_void_p]
+        L.orbfe_vocab_set_types.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orbfe_vocab_get_types.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbfe_vocab_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
@@ -316,6 +318,7 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
            "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_set_lane_mode", "orbfe_set_lane_input_guard", "orbfe_lanes_join", "orbfe_lanes_record",
            "orbfe_keyframe_create", "orbfe_keyframe_set_mask", "orbfe_keyframe_destroy", "orbfe_search_bow_keyframes",
+           "orbfe_vocab_set_types", "orbfe_vocab_get_types", "orbfe_bow_create", "orbfe_bow_destroy", "orbfe_compute_bow", "orbfe_bow_fv", "orbfe_bow_host", "orbfe_bow_device",
            "orbfe_search_tri_batch"]
 
 
@@ -693,15 +696,42 @@ class StereoPairStream:
         self.q.append(b)  # (the arrays belong to the library until the frame's wait returns)
 
     def wait(self):
-        m = _chk(lib().orbfe_extract_stereo_pair_wait(self.ex.h), "orbfe_extract_stereo_pair_wait")
+        # (the record leaves the queue whatever the call returns -- the library has retired the frame either way, and a
+        # record left behind would hand every later wait() the previous frame's arrays)
+        if not self.q:
+            raise OrbfeError(ERR_STATE, "StereoPairStream.wait without a frame in flight")
         b = self.q.pop(0)
+        m = _chk(lib().orbfe_extract_stereo_pair_wait(self.ex.h), "orbfe_extract_stereo_pair_wait")
         n, mono, kps, desc = b["n"], b["mono"], b["kps"], b["desc"]
         return (m, (int(mono[0]), kps[0, :n[0]].copy(), desc[0, :n[0]].copy()), (int(mono[1]), kps[1, :n[1]].copy(), desc[1, :n[1]].copy()),
                 b["uR"][:n[0]].copy(), b["dep"][:n[0]].copy())
 
+    def close(self):
+        """Collects every frame still in flight: their output arrays belong to the library until their wait returns, and this
+        object is what keeps them alive -- dropping it with frames in flight would let the next wait on the context copy into
+        freed memory."""
+        while self.q:
+            b = self.q.pop(0)
+            if getattr(self.ex, "h", None):
+                lib().orbfe_extract_stereo_pair_wait(self.ex.h)  # (an error code is all the same here: the frame is retired)
+            del b
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 # ------------------------------------------------------------------------ matcher
+FV_RESIDENT = -0x0B0F  # ORBFE_FV_RESIDENT (include/orbfe.h)
+
+
 def _fv(fv):
+    if isinstance(fv, Bow):  # the FeatureVector of an orbfe_bow handle, read where orbfe_compute_bow left it (orbfe_bow_fv)
+        s = _FV()
+        _chk(lib().orbfe_bow_fv(fv.h, C.byref(s)), "orbfe_bow_fv")
+        return s, fv
     node_ids, offsets, indices = fv
     node_ids = np.ascontiguousarray(node_ids, np.uint32)
     offsets = np.ascontiguousarray(offsets, np.int32)
@@ -1216,6 +1246,15 @@ class Vocabulary:
         self.h, self.k, self.levels, self.nwords = h, k.value, L_.value, nw.value
         return self
 
+    def set_types(self, weighting, scoring):
+        """WeightingType (0 TF_IDF, 1 TF, 2 IDF, 3 BINARY) / ScoringType (0 L1_NORM .. 5 DOT_PRODUCT), BowVector.h:39-56."""
+        _chk(self.L.orbfe_vocab_set_types(self.h, int(weighting), int(scoring)), "orbfe_vocab_set_types")
+
+    def get_types(self):
+        w, sc = C.c_int(), C.c_int()
+        _chk(self.L.orbfe_vocab_get_types(self.h, C.byref(w), C.byref(sc)), "orbfe_vocab_get_types")
+        return w.value, sc.value
+
     def transform(self, feats, levelsup=4):
         """Per feature: (word id, node id `levelsup` levels above the leaves, weight)."""
         feats = np.ascontiguousarray(feats, np.uint8).reshape(-1, 32)
@@ -1233,6 +1272,69 @@ class Vocabulary:
 
     def __del__(self):
         self.close()
+
+
+class _BowView(C.Structure):
+    _fields_ = [("n_kept", C.c_int), ("nn", C.c_int), ("nw", C.c_int), ("max_node", C.c_int), ("node_ids", C.c_void_p),
+                ("offsets", C.c_void_p), ("indices", C.c_void_p), ("word_ids", C.c_void_p), ("word_values", C.c_void_p),
+                ("d_header", C.c_void_p)]
+
+
+class Bow:
+    """orbfe_bow_*: Frame::ComputeBoW / KeyFrame::ComputeBoW on the device (TemplatedVocabulary::transform with both maps;
+    src/Frame.cc:724-731).  compute() is asynchronous; host() is the host copy on request; the object itself may be passed as
+    the `fv` of a search (the vector is then read on the device)."""
+
+    def __init__(self, vocabulary, cap):
+        self.L = lib()
+        self.vocabulary = vocabulary  # (keeps the tree alive)
+        self.h = C.c_void_p()
+        self.cap = int(cap)
+        self.L.orbfe_bow_fv.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orbfe_bow_host.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orbfe_bow_device.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orbfe_bow_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L.orbfe_bow_destroy.argtypes = [C.c_void_p]
+        self.L.orbfe_bow_destroy.restype = None
+        self.L.orbfe_compute_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _chk(self.L.orbfe_bow_create(C.byref(self.h), vocabulary.h, self.cap), "orbfe_bow_create")
+
+    def compute(self, desc, levelsup=4):
+        """desc: host array [n, 32] or an (address, rows) pair naming device memory."""
+        p, n, keep = _desc_arg(desc)
+        _chk(self.L.orbfe_compute_bow(self.h, C.c_void_p(p), n, levelsup), "orbfe_compute_bow")
+        return self
+
+    def host(self):
+        """((word_ids, values), (node_ids, offsets, indices)) -- copies of the handle's page-locked host view."""
+        v = _BowView()
+        _chk(self.L.orbfe_bow_host(self.h, C.byref(v)), "orbfe_bow_host")
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+        bow = (arr(v.word_ids, v.nw, np.uint32), arr(v.word_values, v.nw, np.float64))
+        offsets = arr(v.offsets, v.nn + 1, np.int32)
+        fv = (arr(v.node_ids, v.nn, np.uint32), offsets, arr(v.indices, v.n_kept, np.int32))
+        self.last_counts = (v.n_kept, v.nn, v.nw, v.max_node)
+        return bow, fv
+
+    def device(self):
+        v = _BowView()
+        _chk(self.L.orbfe_bow_device(self.h, C.byref(v)), "orbfe_bow_device")
+        return v
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_bow_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def bow_from_transform(word, node, weight):

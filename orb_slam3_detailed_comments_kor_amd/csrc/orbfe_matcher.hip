@@ -573,6 +573,9 @@ struct BowProb {
     // of problem p); i?Base = where the set's index array starts in the pool (0 for a handle)
     const uint32_t* node1; const int32_t* offs1; int nn1, i1Base;
     const uint32_t* node2; const int32_t* offs2; int nn2, i2Base;
+    // Round 6: a FeatureVector that orbfe_compute_bow left on the device (orbfe_bow_fv): the host has never seen its node count,
+    // the kernel reads it from the handle's header (null: nn1 / nn2 above)
+    const int32_t* dnn1; const int32_t* dnn2;
 };
 
 // ComputeThreeMaxima (:2545-2586), the device twin of three_maxima() below
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_search_bow(const BowNode* __restrict__ 
         // trips -- and leaves together when there is no partner; such a launch carries no completion count (bow_run).
         const int pi = (int)blockIdx.y;
         const BowProb* __restrict__ Q = probs + pi;
-        const int nn1 = Q->nn1, nn2 = Q->nn2;
+        const int nn1 = Q->dnn1 ? *Q->dnn1 : Q->nn1, nn2 = Q->dnn2 ? *Q->dnn2 : Q->nn2;
         if (nd >= nn1) return;
         const uint32_t* __restrict__ node2 = Q->node2;
         const int32_t* __restrict__ offs1 = Q->offs1;
@@ -3245,8 +3248,16 @@ int select_device(int device)
 
 bool fv_ok(const orbfe_fv& f)
 {
+    if (f.nn == ORBFE_FV_RESIDENT) return f.node_ids != nullptr; // names an orbfe_bow handle (fv_resolve / bow_run)
     if (f.nn < 0) return false;
     if (f.nn > 0 && (!f.node_ids || !f.offsets)) return false;
+    // A FeatureVector is a std::map<NodeId, ...> (Thirdparty/DBoW2/DBoW2/FeatureVector.h:27): its ids come strictly ascending
+    // and therefore unique.  The merge-join, the binary searches and the in-kernel pairing (one ballot over 64 ids of set 2 per
+    // step finds THE partner of a node) all rely on it, so it is checked, not assumed; ~100 ids per vector.
+    for (int i = 1; i < f.nn; i++)
+        if (f.node_ids[i] <= f.node_ids[i - 1]) return false;
+    for (int i = 0; i < f.nn; i++)
+        if (f.offsets[i] < 0 || f.offsets[i + 1] < f.offsets[i]) return false;
     return true;
 }
 
@@ -3509,11 +3520,11 @@ int orbfe_internal_bfknn2_frames(int device, void* hip_stream, const orbfe_knn2_
         const unsigned mainCols = (cap % KNN2M_QUERIES != 0 && mgrid.x > 1) ? mgrid.x - 1 : mgrid.x;
         static const bool pad = !(getenv("ORBFE_KNN2_PAD") && atoi(getenv("ORBFE_KNN2_PAD")) == 0);
         if (pad && !shared && (size_t)mainCols * mgrid.y <= 256) lds = std::max(lds, (size_t)96 * 1024);
-        if (const char* e = getenv("ORBFE_KNN2_LDS_KB")) lds = std::max(lds, (size_t)atoi(e) * 1024); // (tuning)
-        static std::atomic<size_t> ldsSet{0};
-        if (lds > 64 * 1024 && ldsSet.load() < lds) {
+        // (the attribute belongs to the CURRENT device's copy of the kernel: one high-water mark per device -- ADVICE r05)
+        static std::atomic<size_t> ldsSet[kMaxDevices];
+        if (lds > 64 * 1024 && ldsSet[device].load() < lds) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_bfknn2_frames_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ldsSet.store(lds);
+            ldsSet[device].store(lds);
         }
         hipLaunchKernelGGL(k_bfknn2_frames_mfma, mgrid, dim3(KNN2M_THREADS), lds, st, d_jobs, cap, d_idx, d_dist, fillTail);
         HIP_TRY(hipGetLastError());
@@ -3540,6 +3551,33 @@ int orbfe_matcher_sync(int device)
 // A keyframe's matching data kept on the device between calls (round 4): descriptors, the good-MapPoint /
 // has-MapPoint flags, angles, keypoints, octaves, mvuRight and the FeatureVector's index array; host copies of what the host
 // side of a search reads (the FeatureVector's node ids / offsets / indices for the merge-join, flags, angles, mvuRight).
+// orbfe_bow (orbfe_matcher_bowvec.hip): a FeatureVector that lives on the device
+struct orbfe_bow;
+namespace {
+struct BowResident {
+    const uint32_t* nodeIds;
+    const int32_t *offsets, *indices, *hdr; // hdr[1] = number of nodes
+    hipEvent_t ready;                       // behind the kernels that wrote them
+    int n, device;
+};
+int bow_resident(orbfe_bow*, BowResident*);   // takes a use of the handle (bow_release gives it back)
+int bow_host_fv(orbfe_bow*, orbfe_fv* host);  // waits for the host copy; takes no use: valid until the next orbfe_compute_bow
+void bow_release(orbfe_bow*);
+// An orbfe_fv that names a handle, replaced by the handle's host copy (every consumer but the in-kernel pairing of bow_run)
+int fv_resolve(orbfe_fv* f)
+{
+    if (f->nn != ORBFE_FV_RESIDENT) return 0;
+    return bow_host_fv(reinterpret_cast<orbfe_bow*>(const_cast<uint32_t*>(f->node_ids)), f);
+}
+struct BowHold { // the uses bow_run took, given back on every way out
+    std::vector<orbfe_bow*> v;
+    ~BowHold()
+    {
+        for (orbfe_bow* b : v) bow_release(b);
+    }
+};
+} // namespace
+
 struct orbfe_keyframe {
     int device = 0, n = 0;
     uint8_t* block = nullptr; // one allocation: everything below points into it
@@ -3628,6 +3666,11 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         int n, nn, rowBase, indBase, nodeBase /* in the pooled node ids; offsets: nodeBase + index of the set */, maxNode;
     };
     std::vector<SeenSet> seen;
+    // Round 6: a set whose FeatureVector is resident (orbfe_bow_fv).  With the nodes paired in the kernel the vector is read where
+    // orbfe_compute_bow left it; otherwise the handle's host copy takes its place (a wait for a copy that was queued with it).
+    std::vector<BowResident> res1(count), res2(count);
+    std::vector<uint8_t> isRes1(count, 0), isRes2(count, 0), inKf1(count, 0), inKf2(count, 0);
+    BowHold hold;
     std::vector<uint8_t> own1(count, 0), own2(count, 0); // this problem stages the set (first occurrence)
     std::vector<int> set1(count, -1), set2(count, -1);  // index into `seen` of a pooled side
     size_t nodeTotal = 0;
@@ -3694,6 +3737,28 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             e.angle2 = K2->hAng.empty() ? nullptr : K2->hAng.data();
             e.fv2 = K2->fv();
         }
+        for (int side = 0; side < 2; side++) {
+            orbfe_fv& f = side ? e.fv2 : e.fv1;
+            if ((side ? K2 : K1) || f.nn != ORBFE_FV_RESIDENT) continue;
+            if (!f.node_ids) return ORBFE_ERR_ARGS;
+            orbfe_bow* B = reinterpret_cast<orbfe_bow*>(const_cast<uint32_t*>(f.node_ids));
+            if (!devNodes) { // host lists: the handle's host copy
+                const int rr = bow_host_fv(B, &f);
+                if (rr < 0) return rr;
+                continue;
+            }
+            BowResident& R = side ? res2[p] : res1[p];
+            const int rr = bow_resident(B, &R);
+            if (rr < 0) return rr;
+            hold.v.push_back(B);
+            if (R.device != device || R.n != (side ? e.n2 : e.n1)) return ORBFE_ERR_ARGS; // (the vector indexes THIS set's features)
+            (side ? isRes2 : isRes1)[p] = 1;
+            f.nn = 0; // (for the pooled layout below: the set brings no node list and no index array of its own)
+            f.node_ids = nullptr;
+            f.offsets = f.indices = nullptr;
+        }
+        inKf1[p] = K1 ? 1 : 0;
+        inKf2[p] = K2 ? 1 : 0;
         ovOff1[p] = ov1 ? (long)ovTotal : -1;
         if (ov1) ovTotal += ((size_t)K1->n + 63) & ~(size_t)63;
         ovOff2[p] = ov2 ? (long)ovTotal : -1;
@@ -3741,10 +3806,11 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
         bool bad = false;
         const int b1 = i1Base[p], b2 = i2Base[p]; // (0 for a set in a handle: its offsets are relative to its own index array)
         if (devNodes) { // (the kernel pairs the nodes: what the host still checks is the size of set 2's largest node)
-            const int mx2 = K2 ? K2->maxNode : seen[(size_t)set2[p]].maxNode;
+            // (a resident vector's largest node is not known here: every feature of the set at most)
+            const int mx2 = K2 ? K2->maxNode : isRes2[p] ? a->n2 : seen[(size_t)set2[p]].maxNode;
             if (mx2 >= (1 << 20)) return ORBFE_ERR_ARGS;
             needTakenDev = needTakenDev || mx2 > 4096;
-            P.nn1 = a->fv1.nn;
+            P.nn1 = isRes1[p] ? a->n1 : a->fv1.nn; // (resident: an upper bound for the grid; the kernel reads the count, dnn1)
             P.nn2 = a->fv2.nn;
             P.i1Base = b1;
             P.i2Base = b2;
@@ -3780,6 +3846,11 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     int r;
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
+    for (int p = 0; p < count; p++) { // resident vectors: this stream behind the kernels that wrote them (another thread's, maybe)
+        if (isRes1[p]) HIP_TRY(hipStreamWaitEvent(g_ms, res1[p].ready, 0));
+        if (isRes2[p] && !(isRes1[p] && res2[p].ready == res1[p].ready) && !(p > 0 && isRes2[p - 1] && res2[p - 1].ready == res2[p].ready))
+            HIP_TRY(hipStreamWaitEvent(g_ms, res2[p].ready, 0));
+    }
     // (what travels: node list, problem records, the pooled sets.  A search against resident keyframes sends ~15 KB: the kernel
     // reads that from the pinned staging in place)
     // (not when the kernel pairs the nodes: every workgroup then starts with two or three DEPENDENT reads of the problem record
@@ -3815,6 +3886,17 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
                 probs[p].node2 = dIds + seen[(size_t)set2[p]].nodeBase;
                 probs[p].offs2 = dOf + seen[(size_t)set2[p]].nodeBase + set2[p];
             }
+        }
+    }
+    for (int p = 0; devNodes && p < count; p++) { // resident vectors: node ids, offsets, indices and the node count where they lie
+        if (!active[p]) continue;
+        if (isRes1[p]) {
+            probs[p].node1 = res1[p].nodeIds; probs[p].offs1 = res1[p].offsets; probs[p].dnn1 = res1[p].hdr + 1;
+            probs[p].rInd1 = res1[p].indices; probs[p].i1Base = 0;
+        }
+        if (isRes2[p]) {
+            probs[p].node2 = res2[p].nodeIds; probs[p].offs2 = res2[p].offsets; probs[p].dnn2 = res2[p].hdr + 1;
+            probs[p].rInd2 = res2[p].indices; probs[p].i2Base = 0;
         }
     }
     {
@@ -3868,7 +3950,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     for (int p = 0; p < count; p++) {
         if (!active[p]) continue;
         const orbfe_bow_args* a = &eff[p];
-        const bool R1 = probs[p].rInd1 != nullptr, R2 = probs[p].rInd2 != nullptr; // the whole set lives in a handle
+        const bool R1 = inKf1[p] != 0, R2 = inKf2[p] != 0; // the whole set lives in a keyframe handle
         const size_t r1 = (size_t)probs[p].d1Base, r2 = (size_t)probs[p].d2Base;
         if (!R1 && own1[p]) {
             if (is_device_ptr(a->desc1)) { // (read in place: BowProb::rDesc1)
@@ -3979,10 +4061,17 @@ int orbfe_search_bow(int device, const orbfe_bow_args* a, int32_t* match)
     return r < 0 ? r : n;
 }
 
-int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe_args* a)
+int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe_args* a0)
 {
     if (!out) return ORBFE_ERR_ARGS;
     *out = nullptr;
+    orbfe_keyframe_args aLocal;
+    const orbfe_keyframe_args* a = a0;
+    if (a0 && a0->fv.nn == ORBFE_FV_RESIDENT) { // the vector of an orbfe_bow handle: its host copy (the handle keeps host views)
+        aLocal = *a0;
+        if (int rr = fv_resolve(&aLocal.fv); rr < 0) return rr;
+        a = &aLocal;
+    }
     if (!a || a->n < 1 || a->n >= (1 << 20) || !a->desc || !a->mask || !fv_ok(a->fv)) return ORBFE_ERR_ARGS;
     const bool tri = a->kp_xy != nullptr;
     if (tri && (!a->octave || !a->uRight)) return ORBFE_ERR_ARGS;
@@ -4327,8 +4416,16 @@ int orbfe_search_tri_batch(orbfe_keyframe* K1, const uint8_t* hasMP1, int count,
     return 0;
 }
 
-int orbfe_search_tri(int device, const orbfe_tri_args* a, int32_t* pairs)
+int orbfe_search_tri(int device, const orbfe_tri_args* a0, int32_t* pairs)
 {
+    orbfe_tri_args aLocal;
+    const orbfe_tri_args* a = a0;
+    if (a0 && (a0->fv1.nn == ORBFE_FV_RESIDENT || a0->fv2.nn == ORBFE_FV_RESIDENT)) { // vectors of orbfe_bow handles: their host copies
+        aLocal = *a0;
+        if (int rr = fv_resolve(&aLocal.fv1); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv2); rr < 0) return rr;
+        a = &aLocal;
+    }
     if (!a || !pairs || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
     if (a->n1 == 0 || a->n2 == 0) return 0;
     if (!a->desc1 || !a->desc2 || !a->hasMP1 || !a->hasMP2 || !a->kp1_xy || !a->kp2_xy || !a->octave2 ||
@@ -4628,8 +4725,16 @@ int orbfe_search_initialization(int device, const orbfe_init_args* a, int32_t* m
     return nmatches;
 }
 
-int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs)
+int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a0, int32_t* pairs)
 {
+    orbfe_tri_kb8_args aLocal;
+    const orbfe_tri_kb8_args* a = a0;
+    if (a0 && (a0->fv1.nn == ORBFE_FV_RESIDENT || a0->fv2.nn == ORBFE_FV_RESIDENT)) { // vectors of orbfe_bow handles: their host copies
+        aLocal = *a0;
+        if (int rr = fv_resolve(&aLocal.fv1); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv2); rr < 0) return rr;
+        a = &aLocal;
+    }
     if (!a || !pairs || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
     if (a->n1 == 0 || a->n2 == 0) return 0;
     if (!a->desc1 || !a->desc2 || !a->hasMP1 || !a->hasMP2 || !a->kp1_xy || !a->kp2_xy || !a->octave1 || !a->octave2 ||
@@ -4725,8 +4830,16 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a, int32_t* pairs
     return np;
 }
 
-int orbfe_search_tri_3d(int device, const orbfe_tri3d_args* a, int32_t* pairs, float* points)
+int orbfe_search_tri_3d(int device, const orbfe_tri3d_args* a0, int32_t* pairs, float* points)
 {
+    orbfe_tri3d_args aLocal;
+    const orbfe_tri3d_args* a = a0;
+    if (a0 && (a0->fv1.nn == ORBFE_FV_RESIDENT || a0->fv2.nn == ORBFE_FV_RESIDENT)) { // vectors of orbfe_bow handles: their host copies
+        aLocal = *a0;
+        if (int rr = fv_resolve(&aLocal.fv1); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv2); rr < 0) return rr;
+        a = &aLocal;
+    }
     if (!a || !pairs || !points || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
     if (a->n1 == 0 || a->n2 == 0) return 0;
     if (!a->desc1 || !a->desc2 || !a->hasMP1 || !a->hasMP2 || !a->kp1_xy || !a->kp2_xy || !a->octave1 || !a->octave2 ||
@@ -5374,6 +5487,7 @@ extern "C" int orbfe_debug_bow_times(unsigned long long* out8 /* 16 */, int rese
 
 struct orbfe_vocab_dev {
     int device, nnodes, L;
+    int weighting = 0, scoring = 0; // WeightingType / ScoringType (BowVector.h:39-56); ORBvoc.txt: TF_IDF, L1_NORM
     uint8_t* desc;
     int32_t *childOff, *childIds, *word;
     double* weight;
@@ -5475,7 +5589,12 @@ int orbfe_vocab_load_text(orbfe_vocab_dev** out, int device, const char* path, i
     if (k_out) *k_out = k;
     if (L_out) *L_out = L;
     if (nwords_out) *nwords_out = nwords;
-    return orbfe_vocab_upload(out, device, &v);
+    const int r = orbfe_vocab_upload(out, device, &v);
+    if (r == 0) { // the header's "scoring weighting" (:1366-1368: m_scoring = n1, m_weighting = n2)
+        (*out)->scoring = n1;
+        (*out)->weighting = n2;
+    }
+    return r;
 }
 
 void orbfe_vocab_free(orbfe_vocab_dev* d)
@@ -5538,6 +5657,10 @@ int orbfe_vocab_transform(orbfe_vocab_dev* d, const uint8_t* feats, int n, int l
     INT_TRY(s.fetch());
     return 0;
 }
+
+} // extern "C"
+#include "orbfe_matcher_bowvec.hip"
+extern "C" {
 
 int orbfe_kb8_unproject(int device, const float* P, const float* uv, int n, float* rays)
 {

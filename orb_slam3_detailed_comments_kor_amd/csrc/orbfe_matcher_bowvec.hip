@@ -1,0 +1,468 @@
+/*
+ * orbfe_matcher_bowvec.hip -- Frame::ComputeBoW / KeyFrame::ComputeBoW as a device-resident step (round 6; SURVEY.md 8f rank 3,
+ * VERDICT r05 missing #2).  Part of the matcher's translation unit (included by orbfe_matcher.hip behind K-VOC and the
+ * vocabulary handle): it uses the calling thread's matcher stream, k_vocab_transform and struct orbfe_vocab_dev.
+ *
+ * Reference: TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1192), BowVector::addWeight / addIfNotExist / normalize
+ * (BowVector.cpp:34-86), FeatureVector::addFeature (FeatureVector.cpp:31-45); callers src/Frame.cc:724-731,
+ * src/KeyFrame.cc:105-114 (levelsup = 4).
+ *
+ * What the reference builds, one feature after the other, are two ordered maps:
+ *   BowVector      word id -> sum of the word's weight over the features that fell into it, in feature order, then L1 (L2)
+ *                  normalised over the words in ascending id order;
+ *   FeatureVector  node id -> the indices of its features in ascending order.
+ * Both are a SORT of the per-feature results of K-VOC by (id, feature index) followed by a segmentation, and that is how they
+ * are built here -- three launches on the caller's matcher stream, no host involvement:
+ *   K-VOC      (k_vocab_transform)  word, node `levelsup` levels above the leaves, weight per feature;
+ *   K-BOWRANK  (k_bow_rank)         one wavefront per kept feature (weight > 0: "not stopped", :1157): its rank among the kept
+ *                                   features by (node, index) and by (word, index), counted across the lanes -- n / 64 steps per
+ *                                   wavefront, n wavefronts: the whole sort is a few microseconds for the 1000-2000 features of a
+ *                                   frame and needs neither LDS nor a size limit; rank = final position, so the FeatureVector's
+ *                                   index array is complete after this launch;
+ *   K-BOWFOLD  (k_bow_fold)         one workgroup: segment heads of both sorted id lists (a prefix sum), node ids / offsets, word
+ *                                   ids, and the word values in the reference's OWN arithmetic: the c-fold sequential double sum
+ *                                   w + w + ... of addWeight (not c * w: the roundings differ), the sequential sum of |value| in
+ *                                   ascending word order of normalize (one lane, a dependent chain of ~1000 v_add_f64: 4 us),
+ *                                   IEEE division.  Bit-identical to the maps of the reference for every weighting / scoring
+ *                                   type (tests/test_gpu_bow.py).
+ * The results stay on the device in exactly the arrays the searches read (orbfe_fv layout: node ids, offsets, indices) and are
+ * mirrored into page-locked host memory by one copy command behind the kernels; orbfe_bow_host waits for that copy -- the
+ * "host copy on request".  A SearchByBoW against keyframe handles takes the FeatureVector from the handle itself
+ * (orbfe_bow_fv), without the host ever seeing it: extract -> ComputeBoW -> SearchByBoW x 64 runs without a host round trip
+ * between its stages (bow_run, "resident FeatureVector").
+ */
+
+// ---------------------------------------------------------------- K-BOWRANK
+__global__ __launch_bounds__(256) void k_bow_rank(const int32_t* __restrict__ word, const int32_t* __restrict__ node,
+                                                  const double* __restrict__ weight, int n, uint32_t* __restrict__ sortedNode,
+                                                  int32_t* __restrict__ indices, uint32_t* __restrict__ sortedWord,
+                                                  double* __restrict__ sortedWt)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (i >= n) return; // (wave-uniform)
+    const double wi = weight[i];
+    if (!(wi > 0.0)) return; // stopped word: neither vector sees the feature (:1157)
+    const uint32_t ni = (uint32_t)node[i], wdi = (uint32_t)word[i];
+    int rn = 0, rw = 0;
+    for (int base = 0; base < n; base += 64) { // (uniform)
+        const int j = base + lane;
+        if (j < n && weight[j] > 0.0) {
+            const uint32_t nj = (uint32_t)node[j], wj = (uint32_t)word[j];
+            rn += (nj < ni || (nj == ni && j < i)) ? 1 : 0;
+            rw += (wj < wdi || (wj == wdi && j < i)) ? 1 : 0;
+        }
+    }
+    rn = wave_sum_i32(rn);
+    rw = wave_sum_i32(rw);
+    if (lane == 0) {
+        sortedNode[rn] = ni;
+        indices[rn] = i;
+        sortedWord[rw] = wdi;
+        sortedWt[rw] = wi;
+    }
+}
+
+// ---------------------------------------------------------------- K-BOWFOLD
+// exclusive prefix sum of one int per thread over a 1024-thread workgroup; *total = the sum (same in every thread)
+__device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 16 ints */, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < 16; w++) {
+        const int s = sWave[w];
+        if (w < wave) before += s;
+        all += s;
+    }
+    __syncthreads(); // (sWave is reused by the next scan)
+    *total = all;
+    return before + incl - v;
+}
+
+struct BowFoldArgs {
+    const double* weight; // K-VOC's weight per feature
+    int n;
+    const uint32_t* sortedNode; // [m] node id by rank
+    const uint32_t* sortedWord; // [m] word id by rank
+    const double* sortedWt;     // [m] the word's weight by rank
+    int32_t* hdr;               // [8]: kept features m, nodes nn, words nw, features of the largest node
+    uint32_t* nodeIds;          // [cap]
+    int32_t* offsets;           // [cap + 1]
+    uint32_t* wordIds;          // [cap]
+    double* values;             // [cap]
+    int32_t* headPos;           // [cap + 1] scratch: first rank of every word
+    int addWeight;              // TF_IDF / TF: BowVector::addWeight; IDF / BINARY: addIfNotExist
+    int must;                   // the scoring object normalises (all but DOT_PRODUCT)
+    int normL2;                 // ... with the L2 norm (L2_NORM)
+};
+
+__global__ __launch_bounds__(1024) void k_bow_fold(const BowFoldArgs A)
+{
+    __shared__ int sWave[16];
+    __shared__ int sMax;
+    __shared__ double sNorm;
+    const int t = (int)threadIdx.x;
+    if (t == 0) sMax = 0;
+    // kept features
+    int cnt = 0;
+    for (int j = t; j < A.n; j += 1024) cnt += A.weight[j] > 0.0 ? 1 : 0;
+    int m = 0;
+    (void)bow_block_scan(cnt, sWave, &m);
+    // segment heads of both lists: thread t owns ranks [r0, r1)
+    const int C = (m + 1023) / 1024, r0 = min(m, t * C), r1 = min(m, r0 + C);
+    int hn = 0, hw = 0;
+    for (int r = r0; r < r1; r++) {
+        hn += (r == 0 || A.sortedNode[r] != A.sortedNode[r - 1]) ? 1 : 0;
+        hw += (r == 0 || A.sortedWord[r] != A.sortedWord[r - 1]) ? 1 : 0;
+    }
+    int nn = 0, nw = 0;
+    int sn = bow_block_scan(hn, sWave, &nn);
+    int sw = bow_block_scan(hw, sWave, &nw);
+    for (int r = r0; r < r1; r++) {
+        const uint32_t nd = A.sortedNode[r], wd = A.sortedWord[r];
+        if (r == 0 || nd != A.sortedNode[r - 1]) {
+            A.nodeIds[sn] = nd;
+            A.offsets[sn] = r;
+            sn++;
+        }
+        if (r == 0 || wd != A.sortedWord[r - 1]) {
+            A.wordIds[sw] = wd;
+            A.headPos[sw] = r;
+            sw++;
+        }
+    }
+    if (t == 0) {
+        A.offsets[nn] = m;
+        A.headPos[nw] = m;
+    }
+    __syncthreads(); // (the workgroup's global stores above are visible to its threads below)
+    // word values: BowVector::addWeight adds the word's weight once per feature, in feature order -- c sequential additions
+    for (int s = t; s < nw; s += 1024) {
+        const int p = A.headPos[s], c = A.headPos[s + 1] - p;
+        const double w = A.sortedWt[p];
+        double v = w;
+        if (A.addWeight)
+            for (int k = 1; k < c; k++) v = __dadd_rn(v, w);
+        A.values[s] = v;
+    }
+    int mx = 0;
+    for (int s = t; s < nn; s += 1024) mx = max(mx, A.offsets[s + 1] - A.offsets[s]);
+    if (mx) atomicMax(&sMax, mx);
+    __syncthreads();
+    if (A.addWeight && !A.must && nw > 0) { // "unnecessary when normalizing" (:1164-1170): value / number of words
+        const double nd = (double)nw;
+        for (int s = t; s < nw; s += 1024) A.values[s] = __ddiv_rn(A.values[s], nd);
+    }
+    if (A.must) { // BowVector::normalize (BowVector.cpp:62-86): the sum runs over the map in ascending id order, one term at a time
+        if (t == 0) {
+            double norm = 0.0;
+            int s = 0;
+            for (; s + 8 <= nw; s += 8) { // (eight loads in flight, then the dependent additions)
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = A.values[s + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v[k], v[k]) : fabs(v[k]));
+            }
+            for (; s < nw; s++) {
+                const double v = A.values[s];
+                norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v, v) : fabs(v));
+            }
+            if (A.normL2) norm = __dsqrt_rn(norm);
+            sNorm = norm;
+        }
+        __syncthreads();
+        const double norm = sNorm;
+        if (norm > 0.0)
+            for (int s = t; s < nw; s += 1024) A.values[s] = __ddiv_rn(A.values[s], norm);
+    }
+    if (t == 0) {
+        A.hdr[0] = m;
+        A.hdr[1] = nn;
+        A.hdr[2] = nw;
+        A.hdr[3] = sMax;
+    }
+}
+
+// ---------------------------------------------------------------- the handle
+struct orbfe_bow {
+    orbfe_vocab_dev* vocab = nullptr;
+    int device = 0, cap = 0;
+    int n = 0, levelsup = 0; // of the last orbfe_compute_bow
+    bool computed = false, pending = false;
+    // ONE device block.  Results first, in one run (mirrored to the host by one copy): header | node ids | offsets | indices |
+    // word ids | word values; then the scratch of the three kernels and a descriptor buffer for host-side callers.
+    uint8_t* block = nullptr;
+    size_t outBytes = 0;
+    int32_t* hdr = nullptr;
+    uint32_t* nodeIds = nullptr;
+    int32_t* offsets = nullptr;
+    int32_t* indices = nullptr;
+    uint32_t* wordIds = nullptr;
+    double* values = nullptr;
+    int32_t *word = nullptr, *node = nullptr, *headPos = nullptr;
+    double *weight = nullptr, *sortedWt = nullptr;
+    uint32_t *sortedNode = nullptr, *sortedWord = nullptr;
+    uint8_t* dDesc = nullptr;
+    const uint8_t* lastDesc = nullptr; // device address of the descriptors of the last call (the caller's, or dDesc)
+    uint8_t* hOut = nullptr;           // pinned mirror of the results
+    uint8_t* hDesc = nullptr;          // pinned staging of host descriptors
+    hipEvent_t ev = nullptr;           // behind the mirror copy of the last call
+    std::atomic<int> uses{1};          // the owner + every search in progress that was given the handle's vector (bow_run)
+    std::atomic<bool> dead{false};
+    size_t off(const void* p) const { return (size_t)((const uint8_t*)p - block); }
+};
+
+namespace {
+void bow_free(orbfe_bow* b)
+{
+    (void)hipSetDevice(b->device);
+    if (b->ev) {
+        (void)hipEventSynchronize(b->ev); // kernels of the last call may still be writing the block
+        (void)hipEventDestroy(b->ev);
+    }
+    if (b->block) (void)hipFree(b->block);
+    if (b->hOut) (void)hipHostFree(b->hOut);
+    if (b->hDesc) (void)hipHostFree(b->hDesc);
+    delete b;
+}
+void bow_release(orbfe_bow* b)
+{
+    if (b->uses.fetch_sub(1) == 1) bow_free(b);
+}
+int bow_resident(orbfe_bow* b, BowResident* R)
+{
+    if (!b->computed || b->dead.load()) return ORBFE_ERR_STATE;
+    b->uses.fetch_add(1);
+    R->nodeIds = b->nodeIds;
+    R->offsets = b->offsets;
+    R->indices = b->indices;
+    R->hdr = b->hdr;
+    R->ready = b->ev;
+    R->n = b->n;
+    R->device = b->device;
+    return 0;
+}
+int bow_host_view(orbfe_bow* b, orbfe_bow_view* v);
+int bow_host_fv(orbfe_bow* b, orbfe_fv* host)
+{
+    if (!b || b->dead.load()) return ORBFE_ERR_ARGS;
+    orbfe_bow_view v;
+    const int r = bow_host_view(b, &v);
+    if (r < 0) return r;
+    host->nn = v.nn;
+    host->node_ids = v.node_ids;
+    host->offsets = v.offsets;
+    host->indices = v.indices;
+    return 0;
+}
+// host view of the last call's results (waits for the mirror copy)
+int bow_host_view(orbfe_bow* b, orbfe_bow_view* v)
+{
+    if (!b->computed) return ORBFE_ERR_STATE;
+    if (b->pending) {
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipEventSynchronize(b->ev));
+        b->pending = false;
+    }
+    const int32_t* h = reinterpret_cast<const int32_t*>(b->hOut);
+    if (h[0] < 0 || h[0] > b->n || h[1] < 0 || h[1] > h[0] || h[2] < 0 || h[2] > h[0]) return ORBFE_ERR_STATE;
+    v->n_kept = h[0];
+    v->nn = h[1];
+    v->nw = h[2];
+    v->max_node = h[3];
+    v->node_ids = reinterpret_cast<const uint32_t*>(b->hOut + b->off(b->nodeIds));
+    v->offsets = reinterpret_cast<const int32_t*>(b->hOut + b->off(b->offsets));
+    v->indices = reinterpret_cast<const int32_t*>(b->hOut + b->off(b->indices));
+    v->word_ids = reinterpret_cast<const uint32_t*>(b->hOut + b->off(b->wordIds));
+    v->word_values = reinterpret_cast<const double*>(b->hOut + b->off(b->values));
+    v->d_header = b->hdr;
+    return 0;
+}
+} // namespace
+
+extern "C" {
+
+int orbfe_vocab_set_types(orbfe_vocab_dev* d, int weighting, int scoring)
+{
+    if (!d || weighting < 0 || weighting > 3 || scoring < 0 || scoring > 5) return ORBFE_ERR_ARGS;
+    d->weighting = weighting;
+    d->scoring = scoring;
+    return 0;
+}
+
+int orbfe_vocab_get_types(orbfe_vocab_dev* d, int* weighting, int* scoring)
+{
+    if (!d) return ORBFE_ERR_ARGS;
+    if (weighting) *weighting = d->weighting;
+    if (scoring) *scoring = d->scoring;
+    return 0;
+}
+
+int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
+{
+    if (!out) return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    if (!vocab || cap < 1 || cap > 65535) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(vocab->device)) < 0) return r;
+    orbfe_bow* b = new (std::nothrow) orbfe_bow();
+    if (!b) return ORBFE_ERR_STATE;
+    b->vocab = vocab;
+    b->device = vocab->device;
+    b->cap = cap;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t c = (size_t)cap;
+    size_t o = 0;
+    const size_t oHdr = o; o += al(32);
+    const size_t oNode = o; o += al(c * 4);
+    const size_t oOffs = o; o += al((c + 1) * 4);
+    const size_t oInd = o; o += al(c * 4);
+    const size_t oWid = o; o += al(c * 4);
+    const size_t oVal = o; o += al(c * 8);
+    b->outBytes = o;
+    const size_t oWord = o; o += al(c * 4);
+    const size_t oNd = o; o += al(c * 4);
+    const size_t oWt = o; o += al(c * 8);
+    const size_t oSn = o; o += al(c * 4);
+    const size_t oSw = o; o += al(c * 4);
+    const size_t oSwt = o; o += al(c * 8);
+    const size_t oHead = o; o += al((c + 1) * 4);
+    const size_t oDesc = o; o += al(c * 32);
+    bool ok = hipMalloc((void**)&b->block, o) == hipSuccess && hipHostMalloc((void**)&b->hOut, b->outBytes) == hipSuccess &&
+              hipHostMalloc((void**)&b->hDesc, c * 32) == hipSuccess &&
+              hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (b->ev) (void)hipEventDestroy(b->ev);
+        b->ev = nullptr;
+        bow_free(b);
+        return -(1000 + (int)hipErrorOutOfMemory);
+    }
+    uint8_t* B = b->block;
+    b->hdr = (int32_t*)(B + oHdr);
+    b->nodeIds = (uint32_t*)(B + oNode);
+    b->offsets = (int32_t*)(B + oOffs);
+    b->indices = (int32_t*)(B + oInd);
+    b->wordIds = (uint32_t*)(B + oWid);
+    b->values = (double*)(B + oVal);
+    b->word = (int32_t*)(B + oWord);
+    b->node = (int32_t*)(B + oNd);
+    b->weight = (double*)(B + oWt);
+    b->sortedNode = (uint32_t*)(B + oSn);
+    b->sortedWord = (uint32_t*)(B + oSw);
+    b->sortedWt = (double*)(B + oSwt);
+    b->headPos = (int32_t*)(B + oHead);
+    b->dDesc = B + oDesc;
+    std::memset(b->hOut, 0, 32);
+    *out = b;
+    return 0;
+}
+
+void orbfe_bow_destroy(orbfe_bow* b)
+{
+    if (!b) return;
+    b->dead.store(true);
+    bow_release(b); // (freed now, or by the last search that still reads its arrays)
+}
+
+/* Frame::ComputeBoW: mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) on n descriptors (host or device
+ * pointer).  Asynchronous on the calling thread's matcher stream: returns when the kernels and the mirror copy are queued. */
+int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
+{
+    if (!b || n < 0 || n > b->cap || (n && !desc) || b->dead.load()) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(b->device)) < 0) return r;
+    Scratch s(b->device); // (this thread's matcher stream: g_ms)
+    if (b->pending) { // the previous call's copy still owns the mirror (and hDesc)
+        HIP_TRY(hipEventSynchronize(b->ev));
+        b->pending = false;
+    }
+    b->n = n;
+    b->levelsup = levelsup;
+    const uint8_t* dF = b->dDesc;
+    if (n && is_device_ptr(desc)) {
+        if (int w = orbfe_producer_wait(desc, g_ms); w < 0) return w; // an extractor may still be writing them (orbfe_order.h)
+        dF = desc;
+    } else if (n) {
+        std::memcpy(b->hDesc, desc, (size_t)n * 32); // (the caller's array is free when the call returns)
+        HIP_TRY(hipMemcpyAsync(b->dDesc, b->hDesc, (size_t)n * 32, hipMemcpyHostToDevice, g_ms));
+    }
+    b->lastDesc = dF;
+    const orbfe_vocab_dev* d = b->vocab;
+    if (n) {
+        const DoneSig none = {};
+        hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, g_ms, d->desc, d->childOff, d->childIds,
+                           d->word, d->weight, d->L, dF, n, levelsup, b->word, b->node, b->weight, none);
+        hipLaunchKernelGGL(k_bow_rank, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, g_ms, b->word, b->node, b->weight, n, b->sortedNode,
+                           b->indices, b->sortedWord, b->sortedWt);
+    }
+    BowFoldArgs A;
+    A.weight = b->weight;
+    A.n = n;
+    A.sortedNode = b->sortedNode;
+    A.sortedWord = b->sortedWord;
+    A.sortedWt = b->sortedWt;
+    A.hdr = b->hdr;
+    A.nodeIds = b->nodeIds;
+    A.offsets = b->offsets;
+    A.wordIds = b->wordIds;
+    A.values = b->values;
+    A.headPos = b->headPos;
+    A.addWeight = d->weighting == 0 || d->weighting == 1; // TF_IDF || TF (:1145)
+    A.must = d->scoring != 5;                             // every scoring object but DotProductScoring (ScoringObject.h:73-89)
+    A.normL2 = d->scoring == 1;
+    hipLaunchKernelGGL(k_bow_fold, dim3(1), dim3(1024), 0, g_ms, A);
+    HIP_TRY(hipGetLastError());
+    // the results' mirror: header + the arrays up to what n features can fill (one run of the block; cap-sized tails are not sent)
+    HIP_TRY(hipMemcpyAsync(b->hOut, b->block, b->outBytes, hipMemcpyDeviceToHost, g_ms));
+    HIP_TRY(hipEventRecord(b->ev, g_ms));
+    b->pending = true;
+    b->computed = true;
+    return 0;
+}
+
+int orbfe_bow_host(orbfe_bow* b, orbfe_bow_view* view)
+{
+    if (!b || !view) return ORBFE_ERR_ARGS;
+    return bow_host_view(b, view);
+}
+
+int orbfe_bow_device(orbfe_bow* b, orbfe_bow_view* view)
+{
+    if (!b || !view) return ORBFE_ERR_ARGS;
+    if (!b->computed) return ORBFE_ERR_STATE;
+    view->n_kept = view->nn = view->nw = view->max_node = -1; // (on the device: d_header[0..3])
+    view->node_ids = b->nodeIds;
+    view->offsets = b->offsets;
+    view->indices = b->indices;
+    view->word_ids = b->wordIds;
+    view->word_values = b->values;
+    view->d_header = b->hdr;
+    return 0;
+}
+
+/* The FeatureVector of the last orbfe_compute_bow as an orbfe_fv that names the HANDLE (nn = ORBFE_FV_RESIDENT): accepted
+ * wherever a search or orbfe_keyframe_create takes an orbfe_fv.  A SearchByBoW that pairs the nodes on the device reads the
+ * handle's arrays where they lie (no host copy is ever made); every other consumer asks for the host view first. */
+int orbfe_bow_fv(orbfe_bow* b, orbfe_fv* fv)
+{
+    if (!b || !fv) return ORBFE_ERR_ARGS;
+    if (!b->computed) return ORBFE_ERR_STATE;
+    fv->nn = ORBFE_FV_RESIDENT;
+    fv->node_ids = reinterpret_cast<const uint32_t*>(b);
+    fv->offsets = nullptr;
+    fv->indices = nullptr;
+    return 0;
+}
+
+} // extern "C"

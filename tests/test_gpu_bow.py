@@ -1,0 +1,193 @@
+"""Frame::ComputeBoW / KeyFrame::ComputeBoW on the device (orbfe_bow_*, round 6): the BowVector and the FeatureVector that
+TemplatedVocabulary::transform(features, v, fv, levelsup) builds (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1192), bit
+for bit against the oracle's std::map restatement -- every weighting / scoring type, stop words, features that share words
+(the c-fold sum of BowVector::addWeight), levelsup 0 / 4 / L, host and device descriptors -- and the chain the step exists for:
+extraction -> ComputeBoW -> SearchByBoW against 64 keyframe handles with the FeatureVector never leaving the device."""
+import numpy as np
+import pytest
+
+from test_oracle_bow import near_leaf_features
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import orb_slam3_detailed_comments_kor_amd as p
+    return p
+
+
+def _same(got, want):
+    (ids, vals), (nodes, offs, ind) = got
+    (rids, rvals), (rnodes, roffs, rind) = want
+    assert np.array_equal(ids, rids), "word ids"
+    assert np.array_equal(vals.view(np.uint64), rvals.view(np.uint64)), "word values (bit for bit)"
+    assert np.array_equal(nodes, rnodes) and np.array_equal(offs, roffs) and np.array_equal(ind, rind), "FeatureVector"
+
+
+@pytest.mark.parametrize("weighting,scoring", [(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (0, 5), (1, 5), (3, 5), (0, 2)])
+def test_compute_bow_every_weighting_and_scoring(pkg, oracle, weighting, scoring):
+    vocab = pkg.synth.make_vocabulary(77, 8, 4, True)
+    vocab["weight"] = vocab["weight"].copy()
+    leaves = np.nonzero(vocab["word"] >= 0)[0]
+    vocab["weight"][leaves[::7]] = 0.0          # stop words
+    feats = near_leaf_features(vocab, 1300, 5)
+    feats[1200:] = feats[:100]                   # exact duplicates
+    V = pkg.Vocabulary(vocab)
+    V.set_types(weighting, scoring)
+    assert V.get_types() == (weighting, scoring)
+    B = pkg.Bow(V, 2048)
+    for levelsup in (0, 2, 4, 1):
+        got = B.compute(feats, levelsup).host()
+        _same(got, oracle.compute_bow(vocab, feats, levelsup, weighting, scoring))
+        assert B.last_counts[0] < len(feats) and B.last_counts[2] < B.last_counts[0]   # stopped features; shared words
+    B.close()
+    V.close()
+
+
+def test_compute_bow_sizes_reuse_and_errors(pkg, oracle):
+    vocab = pkg.synth.make_vocabulary(11, 10, 3, False)
+    V = pkg.Vocabulary(vocab)
+    B = pkg.Bow(V, 3000)
+    with pytest.raises(pkg.OrbfeError) as e:
+        B.host()                                  # nothing computed yet
+    assert e.value.code == pkg.binding.ERR_STATE
+    for n in (0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 3000, 5, 0, 777):   # one handle, frame after frame
+        feats = near_leaf_features(vocab, max(n, 1), 100 + n)[:n]
+        _same(B.compute(feats, 1).host(), oracle.compute_bow(vocab, feats, 1))
+    with pytest.raises(pkg.OrbfeError) as e:
+        B.compute(np.zeros((3001, 32), np.uint8), 1)
+    assert e.value.code == pkg.binding.ERR_ARGS
+    # every feature in ONE word (a frame of identical descriptors): the longest addWeight chain, a single node
+    one = np.repeat(near_leaf_features(vocab, 1, 3), 2500, axis=0)
+    got = B.compute(one, 2).host()
+    _same(got, oracle.compute_bow(vocab, one, 2))
+    assert len(got[0][0]) == 1 and got[0][1][0] == 1.0 and B.last_counts == (2500, 1, 1, 2500)
+    B.close()
+    V.close()
+
+
+def test_compute_bow_production_size_vocabulary(pkg, oracle):
+    """k = 10, L = 6 (what Vocabulary/ORBvoc.txt is; the blob is absent, the tree synthetic), levelsup as KeyFrame::ComputeBoW
+    calls it (4) and the two extremes."""
+    vocab = pkg.synth.make_vocabulary_full(2024, 10, 6)
+    rng = np.random.default_rng(9)
+    leaves = rng.integers(111111, 1111111, size=1300)
+    bits = np.unpackbits(vocab["desc"][leaves], axis=1)
+    bits ^= (rng.random(bits.shape) < 0.05).astype(np.uint8)
+    d = np.packbits(bits, axis=1)
+    d = np.concatenate([d, d[:150], rng.integers(0, 256, size=(50, 32), dtype=np.uint8)])   # 1500: shared words + strays
+    V = pkg.Vocabulary(vocab)
+    B = pkg.Bow(V, 1500)
+    for levelsup in (4, 0, 6):
+        got = B.compute(d, levelsup).host()
+        _same(got, oracle.compute_bow(vocab, d, levelsup))
+        if levelsup == 4:
+            assert 10 < len(got[1][0]) <= 100 and abs(got[0][1].sum() - 1.0) < 1e-12
+    B.close()
+    V.close()
+
+
+def test_compute_bow_on_the_extractors_device_outputs(pkg, oracle):
+    """The descriptors never leave the device: extraction (device outputs) -> ComputeBoW on the resident rows."""
+    import torch
+    vocab = pkg.synth.make_vocabulary(5, 9, 3, True)
+    img = pkg.synth.make_frame(480, 752, 31)
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, device=0)
+    mono, kps, desc = ex(img, (0, 0))
+    cap = ex.max_keypoints(480, 752)
+    d_img = torch.from_numpy(img).cuda()
+    d_kps = torch.zeros(cap * 28, dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros((cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_mono = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img.data_ptr(), 1, 480, 752, 752, 480 * 752, (0, 0), d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                            d_n.data_ptr(), d_mono.data_ptr())
+    k, dd, nn, cap2, nimg = ex.device_outputs()      # (marks the producer: the matcher's stream waits for the extraction)
+    V = pkg.Vocabulary(vocab)
+    B = pkg.Bow(V, cap)
+    got = B.compute((dd, len(kps)), 2).host()
+    _same(got, oracle.compute_bow(vocab, desc, 2))
+    assert len(kps) > 800
+    B.close()
+    V.close()
+    ex.close()
+
+
+def _noisy_copy(d1, n2, seed, flip=10, frac=0.6):
+    rng = np.random.default_rng(seed)
+    d2 = rng.integers(0, 256, size=(n2, 32), dtype=np.uint8)
+    k = int(min(len(d1), n2) * frac)
+    src = rng.permutation(len(d1))[:k]
+    dst = rng.permutation(n2)[:k]
+    bits = np.unpackbits(d1[src], axis=1)
+    for r in range(k):
+        bits[r, rng.permutation(256)[: rng.integers(0, 2 * flip)]] ^= 1
+    d2[dst] = np.packbits(bits, axis=1)
+    origin = -np.ones(n2, np.int64)
+    origin[dst] = src
+    return d2, origin
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 1), (12, 2, 0), (4, 3, 2)])
+def test_relocalisation_chain_without_a_host_copy_of_the_vector(pkg, oracle, k, L, levelsup):
+    """Tracking::Relocalization (src/Tracking.cc:3760-3790): ComputeBoW of the current frame, then SearchByBoW against every
+    candidate keyframe.  The keyframes sit in handles (their vectors computed by the same device step, through its host copy);
+    the frame's vector is passed as the Bow handle itself and is read where ComputeBoW left it (64 candidates: the nodes are
+    paired in the kernel); one candidate alone takes the host's node list, i.e. the handle's host copy.  Both against the
+    oracle's SearchByBoW on the oracle's vectors."""
+    import torch
+    vocab = pkg.synth.make_vocabulary(900 + k, k, L, True)
+    V = pkg.Vocabulary(vocab)
+    rng = np.random.default_rng(40 + k)
+    nF = 1100
+    dF = near_leaf_features(vocab, nF, 7, flips=20)
+    aF = rng.uniform(0, 360, nF).astype(np.float32)
+    BF = pkg.Bow(V, nF)
+    BK = pkg.Bow(V, 1300)
+    NK = 64
+    sets, kfs = [], []
+    for c in range(NK):
+        n = 1000 + 3 * c
+        d, origin = _noisy_copy(dF, n, 300 + c)
+        a = np.where(origin >= 0, aF[np.maximum(origin, 0)] + rng.normal(0, 4, n), rng.uniform(0, 360, n)).astype(np.float32) % 360
+        mask = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+        _, fvK = BK.compute(d, levelsup).host()
+        rb, rfv = oracle.compute_bow(vocab, d, levelsup)
+        assert all(np.array_equal(x, y) for x, y in zip(fvK, rfv))
+        sets.append((d, mask, a, rfv))
+        # KeyFrame::ComputeBoW -> handle: the vector goes from the Bow handle into the keyframe handle (its host views included)
+        kfs.append(pkg.KeyFrameHandle(d, mask, a, BK))
+    _, fvF = oracle.compute_bow(vocab, dF, levelsup)
+    want = [oracle.search_bow_kf_f(d, m, a, fv, dF, aF, fvF, -1, 0.75, True) for d, m, a, fv in sets]
+    assert sum(w[0] for w in want) > 2000
+    # the frame's descriptors on the device, its vector in the Bow handle: nothing of the frame but angles travels with the call
+    d_dF = torch.from_numpy(dF).cuda()
+    torch.cuda.synchronize()
+    BF.compute((d_dF.data_ptr(), nF), levelsup)          # asynchronous; no host() in between
+    got = pkg.search_bow_keyframes([dict(kf1=kfs[c], desc2=(d_dF.data_ptr(), nF), ang2=aF, fv2=BF, variant=0, nnratio=0.75,
+                                         check_ori=True) for c in range(NK)])
+    for c in range(NK):
+        assert got[c][0] == want[c][0] and np.array_equal(got[c][1], want[c][1]), c
+    # host descriptors with the resident vector, and one candidate alone (host node list <- the handle's host copy)
+    got = pkg.search_bow_keyframes([dict(kf1=kfs[c], desc2=dF, ang2=aF, fv2=BF, variant=0, nnratio=0.75, check_ori=True)
+                                    for c in range(NK)])
+    for c in range(NK):
+        assert got[c][0] == want[c][0] and np.array_equal(got[c][1], want[c][1]), c
+    one = pkg.search_bow_keyframes([dict(kf1=kfs[9], desc2=dF, ang2=aF, fv2=BF, variant=0, nnratio=0.75, check_ori=True)])[0]
+    assert one[0] == want[9][0] and np.array_equal(one[1], want[9][1])
+    # the frame as set 1 of the KeyFrame-KeyFrame variant (resident vector on side 1: the grid is sized by an upper bound)
+    mF = (rng.uniform(size=nF) < 0.6).astype(np.uint8)
+    want1 = [oracle.search_bow_kf_kf(dF, mF, aF, fvF, d, m, a, fv, -1, -1, 0.8, True) for d, m, a, fv in sets]
+    got = pkg.search_bow_keyframes([dict(desc1=dF, mask1=mF, ang1=aF, fv1=BF, kf2=kfs[c], variant=1, nnratio=0.8, check_ori=True)
+                                    for c in range(NK)])
+    for c in range(NK):
+        assert got[c][0] == want1[c][0] and np.array_equal(got[c][1], want1[c][1]), c
+    # a wrong-sized set for the vector is refused
+    with pytest.raises(pkg.OrbfeError):
+        pkg.search_bow_keyframes([dict(kf1=kfs[c], desc2=dF[:-1], ang2=aF[:-1], fv2=BF, variant=0, nnratio=0.75) for c in range(NK)])
+    for h in kfs:
+        h.close()
+    BF.close()
+    BK.close()
+    V.close()
