@@ -23,8 +23,11 @@ not ramped up and the timed steps read several per cent slow.  Then exactly K st
 Extra objects in the line (none of them is `value`):
   roofline       -- dominant kernel (by hipEvent time on the extractor's stream, measured live over
                     the timed steps): algorithmic bytes per launch / average launch time vs 8 TB/s HBM.
-                    `traffic` / `valu_issue_frac` are NOT measured in this run: they are read from the
-                    committed rocprofv3 counter summary named in `traffic_source`.
+                    `traffic` (HBM bytes per launch) and the wave-instruction count behind `issue_frac` are MEASURED for
+                    the tree that runs: two `rocprofv3 --pmc` child passes of this script (--pmc-child: the same
+                    batches, one lane) before the timed region, corrected by a known-size copy in the same pass
+                    (--no-pmc skips them; the fields are then null).  `issue_frac` has ONE definition, in
+                    tools/isa/issue_table.py.  `step` prices the whole step by SURVEY 8(d)'s bytes.
   pcie_inclusive -- the metric as SURVEY.md 8(d) defines it for the drop-in boundary: wall time of
                     orbfe_extract* with HOST pointers, H2D of the images and D2H of keypoints +
                     descriptors included; measured by the C++ caller tools/hostbench (child process):
@@ -106,9 +109,13 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(rows, cols, nfeatures, seconds=14.0):
-    """Oracle extractor (C++ threads, one extractor per thread) over independent frames, bounded sample.
-    Protocols of SURVEY.md 8(d): (i) 1 thread, (ii) 2 threads / 2 extractors, (iii) all usable cores."""
+def cpu_baseline(rows, cols, nfeatures, seconds=16.0):
+    """The CPU path timed on this host's cores, bounded sample.  Two builds of the SAME source (oracle/orb_oracle.cpp, g++ -O3
+    -march=native): the scalar port that is the parity oracle, and its timing-only fast path -- SIMD rejection test in FAST, a blur
+    and a resize vertical pass the compiler vectorises, source rows of the resize reused as OpenCV reuses them -- whose results are
+    asserted equal to the scalar path's on the timed frames before anything is timed (OpenCV's own FAST / blur /
+    resize are SIMD code; a baseline timed on a scalar port flatters the GPU).  `value` is the FASTER of the two, all cores.
+    Protocols of SURVEY.md 8(d): (i) 1 thread, (ii) 2 threads / 2 extractors, (iii) all usable cores; per-stage CPU ms from (i)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orb_oracle_py as O
     from orb_slam3_detailed_comments_kor_amd import synth
@@ -117,31 +124,49 @@ def cpu_baseline(rows, cols, nfeatures, seconds=14.0):
     flags = O.NATIVE_FLAGS if native else O.PORTABLE_FLAGS
     cores = usable_cores()
     frames = np.stack([synth.make_frame(rows, cols, 1234 + i) for i in range(4)])
+    # the fast path computes what the scalar path computes: checked on the frames that are timed
+    simd = False
+    for f in frames:
+        a = O.Extractor(nfeatures, 1.2, 8, 20, 7, native=native)
+        b = O.Extractor(nfeatures, 1.2, 8, 20, 7, native=native)
+        simd = b.set_fastpath(True)
+        ra, rb = a.extract(f, (0, 1000)), b.extract(f, (0, 1000))
+        if not (ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])):
+            raise SystemExit("cpu_baseline: the timing-only fast path differs from the scalar oracle")
 
-    def run(threads, budget, lap, nf=nfeatures):
-        n, t = O.extract_many(frames, threads, 2, nf, lap=lap, native=native)  # calibrate
+    def run(threads, budget, lap, fast, nf=nfeatures):
+        n, t, _ = O.extract_many_stages(frames, threads, 2, nf, lap=lap, native=native, fastpath=fast)  # calibrate
         reps = int(min(max(2, budget / (t / 2)), 400))
-        n, t = O.extract_many(frames, threads, reps, nf, lap=lap, native=native)
-        return n, t, reps
+        n, t, st = O.extract_many_stages(frames, threads, reps, nf, lap=lap, native=native, fastpath=fast)
+        return n, t, reps, st
 
-    n1, t1, r1 = run(1, 0.2 * seconds, (0, 1000))       # (i) mono protocol, reference src/Frame.cc:306
-    n2, t2, r2 = run(2, 0.2 * seconds, (0, 0), 1200)    # (ii) stereo protocol: left + right extractor threads, nF 1200
-    n, dt, reps = run(cores, 0.5 * seconds, (0, 1000))  # (iii) best-case CPU throughput over independent frames
-    return {
-        "value": n / dt,
-        "unit": "keypoints/s",
-        "cores": cores,
+    def leg(fast, share):
+        n1, t1, r1, st1 = run(1, 0.2 * share, (0, 1000), fast)       # (i) mono protocol, reference src/Frame.cc:306
+        n2, t2, r2, _ = run(2, 0.2 * share, (0, 0), fast, 1200)      # (ii) stereo protocol: left + right extractor threads, nF 1200
+        n, dt, reps, _ = run(cores, 0.5 * share, (0, 1000), fast)    # (iii) best-case CPU throughput over independent frames
+        return {"value": n / dt, "unit": "keypoints/s", "cores": cores,
+                "one_thread": {"value": n1 / t1, "ms_per_frame": 1e3 * t1 / r1,
+                               "stage_ms": {k: 1e3 * v / r1 for k, v in st1.items()}},
+                "two_threads_stereo": {"value": n2 / t2, "ms_per_pair": 1e3 * t2 / r2, "nfeatures": 1200,
+                                       "note": "2 threads x 1 extractor each, one frame per thread per pair (src/Frame.cc:119-122, "
+                                               "Examples/Stereo/EuRoC.yaml nFeatures 1200)"},
+                "sample": "%d threads x %d frames of %dx%d (nF=%d) in %.1f s; 1 thread: %.0f keypoints/s (%.1f ms/frame, %d frames); "
+                          "2 threads: %.1f ms per stereo pair (%d pairs)"
+                          % (cores, reps, cols, rows, nfeatures, dt, n1 / t1, 1e3 * t1 / r1, r1, 1e3 * t2 / r2, r2)}
+
+    vec = leg(True, 0.6 * seconds)
+    sca = leg(False, 0.4 * seconds)
+    out = dict(vec)
+    out.update({
         "kind": "port",
+        "variant": ("vectorised timing build of the port: " + ("AVX2 rejection test in FAST, " if simd else "scalar FAST (no AVX2 on this host), ")
+                    + "blur and resize written for the compiler's vectoriser, resize rows reused; results asserted equal to the scalar "
+                    "oracle on the timed frames"),
         "flags": "g++ " + flags,
-        "one_thread": {"value": n1 / t1, "ms_per_frame": 1e3 * t1 / r1},
-        "two_threads_stereo": {"value": n2 / t2, "ms_per_pair": 1e3 * t2 / r2,
-                               "nfeatures": 1200,
-                               "note": "2 threads x 1 extractor each, one frame per thread per pair (src/Frame.cc:119-122, "
-                                       "Examples/Stereo/EuRoC.yaml nFeatures 1200)"},
-        "sample": "oracle built with `g++ %s`; %d threads x %d frames of %dx%d (nF=%d) in %.1f s; "
-                  "1 thread: %.0f keypoints/s (%.1f ms/frame, %d frames); 2 threads: %.1f ms per stereo pair (%d pairs)"
-                  % (flags, cores, reps, cols, rows, nfeatures, dt, n1 / t1, 1e3 * t1 / r1, r1, 1e3 * t2 / r2, r2),
-    }
+        "scalar_port": sca,
+        "sample": "oracle built with `g++ %s`, timing-only fast path; %s" % (flags, vec["sample"]),
+    })
+    return out
 
 
 def bench_frames(rows, cols, batch, rank=0):
@@ -206,10 +231,19 @@ def cpu_stereo_baseline(rows, cols, nfeatures, fisheye, seconds=10.0):
     left, right = synth.make_stereo_pair(rows, cols, 51, shift=40 if fisheye else 12)
     frames = np.stack([left, right])
     lap = (0, cols - 1) if fisheye else (0, 0)
-    n, t = O.extract_many(frames, 2, 2, nfeatures, lap=lap, native=native)
+    # (the extraction through the timing-only fast path of the oracle, as in cpu_baseline; equality with the scalar path checked first)
+    for f in frames:
+        a, b = O.Extractor(nfeatures, 1.2, 8, 20, 7, native=native), O.Extractor(nfeatures, 1.2, 8, 20, 7, native=native)
+        b.set_fastpath(True)
+        ra, rb = a.extract(f, lap, cap=nfeatures * 2 + 256), b.extract(f, lap, cap=nfeatures * 2 + 256)
+        if not (ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])):
+            raise SystemExit("cpu_stereo_baseline: the timing-only fast path differs from the scalar oracle")
+    n, t, _ = O.extract_many_stages(frames, 2, 2, nfeatures, lap=lap, native=native, fastpath=True)
     reps = int(min(max(2, 0.6 * seconds / (t / 2)), 200))
-    n, t = O.extract_many(frames, 2, reps, nfeatures, lap=lap, native=native)
+    n, t, st = O.extract_many_stages(frames, 2, reps, nfeatures, lap=lap, native=native, fastpath=True)
     ms_extract = 1e3 * t / reps
+    n0, t0s, _ = O.extract_many_stages(frames, 2, max(2, reps // 3), nfeatures, lap=lap, native=native, fastpath=False)
+    ms_extract_scalar = 1e3 * t0s / max(2, reps // 3)
     exL, exR = O.Extractor(nfeatures, 1.2, 8, 20, 7), O.Extractor(nfeatures, 1.2, 8, 20, 7)
     mL, kL, dL = exL.extract(left, lap)
     mR, kR, dR = exR.extract(right, lap)
@@ -225,6 +259,9 @@ def cpu_stereo_baseline(rows, cols, nfeatures, fisheye, seconds=10.0):
     return {"value": (len(kL) + len(kR)) / ((ms_extract + ms_match) * 1e-3), "unit": "keypoints/s", "cores": 2, "kind": "port",
             "flags": "g++ " + (O.NATIVE_FLAGS if native else O.PORTABLE_FLAGS),
             "ms_per_pair": ms_extract + ms_match, "extract_ms_per_pair": ms_extract, "match_ms_per_pair": ms_match,
+            "variant": "vectorised timing build of the port (cpu_baseline of the default run says what that is)",
+            "extract_stage_ms_per_frame": {k: 1e3 * v / (2 * reps) for k, v in st.items()},
+            "scalar_port": {"extract_ms_per_pair": ms_extract_scalar, "ms_per_pair": ms_extract_scalar + ms_match},
             "sample": "%d stereo pairs of %dx%d (nF=%d) on 2 threads + %d runs of %s on 1 thread" %
                       (reps, cols, rows, nfeatures, k, "the knn-2 brute force of ComputeStereoFishEyeMatches (python wrapper "
                        "around the C++ oracle)" if fisheye else "ComputeStereoMatches")}
@@ -357,6 +394,99 @@ def knn2_roofline(ndist, knn_ms, cap):
             "frac": rate / vec_peak, "traffic": None}, vec_peak
 
 
+def pmc_child(args):
+    """--pmc-child: what the counter passes profile -- the default step (one lane, rotating resident batches) a few times, then a
+    256-MiB device copy whose bytes are known (the calibration of FETCH_SIZE / WRITE_SIZE the guide asks for, in the same pass
+    and the same process).  Prints nothing."""
+    os.environ.setdefault("ORBFE_TRIG_TABLE", "2")
+    import torch
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    B, H, W = args.batch or 64, args.rows, args.cols
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(bench_frames(H, W, B, 0)).to(dev)
+    ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ex.set_stream(stream.cuda_stream)
+    ex.set_lanes(1)
+    cap = ex.max_keypoints(H, W)
+    R = max(1, min(args.rotate, 12))
+    d_rot = [d_img] + [torch.roll(d_img, shifts=(7 * j, 13 * j), dims=(1, 2)).contiguous() for j in range(1, R)]
+    o = (torch.zeros((B, cap, 7), dtype=torch.float32, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+         torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
+    for k in range(2 + 2 * R):  # (the first call builds tables; every batch twice after that)
+        ex.extract_batch_device(d_rot[k % R].data_ptr(), B, H, W, W, H * W, (0, 1000), o[0].data_ptr(), o[1].data_ptr(), cap,
+                                o[2].data_ptr(), o[3].data_ptr())
+    ex.sync()
+    x = torch.empty(PMC_CALIB_BYTES // 16, 4, dtype=torch.int32, device=dev)
+    x.fill_(3)
+    for _ in range(3):
+        y = x.clone()  # a vectorised copy kernel: PMC_CALIB_BYTES read, PMC_CALIB_BYTES written
+    torch.cuda.synchronize()
+    del y
+    ex.close()
+
+
+PMC_CALIB_BYTES = 256 << 20
+KERNEL_OF = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
+             "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
+
+
+def pmc_measure(args, batch):
+    """Two rocprofv3 --pmc passes over `bench.py --pmc-child` (the program itself behind `--`; counters only, beside
+    --kernel-trace): FETCH_SIZE + SQ_INSTS_VALU, then WRITE_SIZE.  Returns {kernel name prefix: {hbm_bytes_per_launch,
+    SQ_INSTS_VALU, ...}} + the correction factors, or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    roc = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(roc):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="orbfe_pmc_", dir="/tmp")
+    acc, calib = {}, {}
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for tag, ctrs in (("a", ["FETCH_SIZE", "SQ_INSTS_VALU", "SQ_WAVES"]), ("b", ["WRITE_SIZE", "SQ_INSTS_SALU", "SQ_INSTS_LDS"])):
+            cmd = [roc, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--batch", str(batch), "--rows", str(args.rows), "--cols", str(args.cols),
+                   "--nfeatures", str(args.nfeatures), "--rotate", str(args.rotate)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            if r.returncode != 0:
+                return {"error": "rocprofv3 pass %s failed (rc %d): %s" % (tag, r.returncode, (r.stderr or r.stdout)[-300:])}
+            rows = {}
+            for f in glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    rows.setdefault((name, row["Counter_Name"]), []).append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
+            for (name, ctr), v in rows.items():
+                v.sort()
+                vals = [x for _, x in v]
+                if name.startswith("k_"):
+                    use = vals[2:] if len(vals) > 4 else vals  # (not the first calls of the process)
+                    acc.setdefault(name, {})[ctr] = sum(use) / len(use)
+                    acc[name]["dispatches"] = len(use)
+                elif ctr in ("FETCH_SIZE", "WRITE_SIZE") and vals and max(vals) * 1024 > 0.3 * PMC_CALIB_BYTES:
+                    # the known-size copy: the largest mover of the pass that is not ours (last repetition: warm)
+                    big = [x for x in vals if x * 1024 > 0.3 * PMC_CALIB_BYTES]
+                    calib[ctr] = PMC_CALIB_BYTES / (1024.0 * big[-1])
+        out = {"calibration": {"bytes": PMC_CALIB_BYTES, "fetch_bytes_per_FETCH_SIZE_KB": calib.get("FETCH_SIZE"),
+                               "write_bytes_per_WRITE_SIZE_KB": calib.get("WRITE_SIZE")}, "kernels": {}}
+        fc, wc = calib.get("FETCH_SIZE"), calib.get("WRITE_SIZE")
+        if not fc or not wc or not (0.8 < fc < 2.6) or not (0.8 < wc < 2.6):
+            out["error"] = "calibration copy not found or implausible: %r" % (calib,)
+            return out
+        for name, e in acc.items():
+            if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                e["hbm_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * fc + e["WRITE_SIZE"] * 1024 * wc
+            out["kernels"][name] = e
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        import shutil as _sh
+        _sh.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator
     # creation, for one): until the line is ready, file descriptor 1 points at stderr.
@@ -413,10 +543,14 @@ def main():
                          "and rotate through --rotate buffers")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4 per priority)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes (roofline.traffic / issue_frac: null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--contexts", type=int, default=1,
                     help="experiment: consecutive steps alternate between this many extractor contexts, each with "
                          "its own stream and output buffers (like the reference's left/right extractor threads)")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     if args.config in ("c3", "c5"):
         os.environ.setdefault("ORBFE_TRIG_TABLE", "2")
         return per_call_config(args, real_stdout)
@@ -449,6 +583,13 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HBM traffic and wave-instruction counts of THIS tree, by two counter passes over a child of this script -- before this
+    # process touches the GPU (the child has the chip to itself; nothing here forks after HIP is initialised)
+    pmc_live = None
+    if world == 1 and not args.no_pmc:
+        tp = time.perf_counter()
+        pmc_live = pmc_measure(args, args.batch)
+        pmc_live["seconds"] = time.perf_counter() - tp
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -644,7 +785,7 @@ def main():
     # Not part of `value`: the same step K more times with one event per step boundary on the stream (an event record
     # costs ~3.5 us, which is why the timed region above carries none): the distribution a single average hides.
     step_dist = None
-    if not extra:
+    if not extra and args.lanes == 1:  # (with lanes the context's stream carries only the ordering: an event there marks nothing)
         nd = min(max(args.steps, 20), 400)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nd + 1)]
         evs[0].record(stream)
@@ -654,9 +795,8 @@ def main():
         barrier()
         per = np.sort(np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nd)]))
         step_dist = {"steps": nd, "min_ms": float(per[0]), "p50_ms": float(per[nd // 2]), "p90_ms": float(per[(9 * nd) // 10]),
-                     "max_ms": float(per[-1]), "note": "hipEvent between consecutive steps on the extractor's stream; each "
-                     "step carries one event record (~3.5 us), so these read slightly above ms_per_step (with batch lanes the "
-                     "context's stream only carries the ordering: an event then marks the end of a step's pyramid kernel)"}
+                     "max_ms": float(per[-1]), "note": "hipEvent between consecutive steps on the extractor's stream (one lane); each "
+                     "step carries one event record (~3.5 us), so these read slightly above ms_per_step"}
 
     # Not part of `value`: the step followed by the consumer of the exchanged descriptors -- cross-camera matching,
     # sharded by query frame: knn-2 of each of this rank's frames against the next camera of the ring
@@ -929,53 +1069,53 @@ def main():
         abytes = algorithmic_bytes_per_frame(H, W, n_local / B)
         launch_bytes = abytes[dom] * B
         achieved = launch_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-        # HBM bytes per launch from the rocprofv3 counter passes (tools/collect_profiles.sh, collected in
-        # separate --pmc runs and corrected with the FETCH_SIZE calibration), if they match this workload
+        # HBM bytes per launch and vector wave-instructions per launch: measured for this tree by pmc_measure() above
         traffic = None
-        valu_issue = None
         per_kernel = {}
-        kernel_of = {"pyramid": "k_pyr_fused", "fast": "k_fast_cells", "octree": "k_octree", "pack": "k_pack",
-                     "desc": "k_orient_blur_desc<0", "trigfix": "k_orient_blur_desc<1"}
-        # class-weighted issue cycles per vector wave-instruction of each kernel: tools/isa/cost.py over the kernel's listing
-        # (2.7 cycles for the simple 32-bit / 16-bit operations, 4.5 for the rest, measured in profiles/r01_valu_rate.txt)
-        valu_cycles = {"fast": 3.2, "pyramid": 3.66, "octree": 3.73, "desc": 4.57}
-        valu_roof = None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05_pmc_summary.json"),
-                                os.path.join(ROOT, "profiles", "r04_pmc_summary.json"),
-                                os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
-                                os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
-                                os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) if os.path.exists(q)), "")
+        kernel_of = KERNEL_OF
+        issue = None
         traffic_source = None
-        if pmc:
-            traffic_source = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of an earlier run of this workload; not measured in this run)"
+        pk = (pmc_live or {}).get("kernels") or {}
+        if pmc_live is not None and "error" not in pmc_live:
+            traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_WAVES / --pmc WRITE_SIZE ... over "
+                              "`bench.py --pmc-child` (same batches, one lane), bytes per FETCH_SIZE / WRITE_SIZE unit from a %d-MiB "
+                              "device copy in the same passes (%.3f / %.3f KB); %.0f s"
+                              % (PMC_CALIB_BYTES >> 20, pmc_live["calibration"]["fetch_bytes_per_FETCH_SIZE_KB"],
+                                 pmc_live["calibration"]["write_bytes_per_WRITE_SIZE_KB"], pmc_live.get("seconds", 0.0)))
+            for st, kn in kernel_of.items():
+                for k, e in pk.items():
+                    if k.startswith(kn) and "hbm_bytes_per_launch" in e:
+                        per_kernel[st] = e["hbm_bytes_per_launch"]
+            traffic = per_kernel.get(dom)
+        elif pmc_live is not None:
+            traffic_source = "not measured: " + str(pmc_live.get("error"))
+        # the vector-issue roof, ONE definition (tools/isa/issue_table.py): wave-instructions counted in this run x the static-mix
+        # mean of the per-opcode issue costs measured on this chip / (1024 SIMDs x 2.4 GHz x this run's launch duration)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools", "isa"))
+            import issue_table as IT
             try:
-                j = json.load(open(pmc))
-                if j.get("workload") == {"batch": B, "rows": H, "cols": W, "nfeatures": args.nfeatures}:
-                    for st, kn in kernel_of.items():
-                        for k, e in j.get("kernels", {}).items():
-                            if k.startswith(kn) and "hbm_bytes_per_launch" in e:
-                                per_kernel[st] = e["hbm_bytes_per_launch"]
-                    for k, e in j.get("kernels", {}).items():
-                        if k.startswith(kernel_of[dom]) and "hbm_bytes_per_launch" in e:
-                            traffic = e["hbm_bytes_per_launch"]
-                            # share of the chip's VALU issue slots this kernel's wave-instructions occupy at the
-                            # guide's nominal 2 cycles per wave64 instruction (1024 SIMDs, 2.4 GHz): a LOWER bound on
-                            # how busy the vector ALUs are -- on this chip only add/sub/and/or/xor/shift-right/mov and
-                            # the non-packed 16-bit min/max measured ~2.7 cycles, everything else ~4.5
-                            # (profiles/r01_valu_rate.txt)
-                            if "SQ_INSTS_VALU" in e and e.get("avg_duration_us"):
-                                valu_issue = min(1.0, e["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * e["avg_duration_us"] * 1e-6))
-                                # the VALU roof: issue time of the kernel's vector instructions if every one of
-                                # the chip's 1024 SIMDs issued back to back, against the duration measured in THIS run
-                                w = valu_cycles.get(dom)
-                                if w and stage_ms[dom] > 0:
-                                    issue_us = e["SQ_INSTS_VALU"] * w / (1024 * 2.4e3)
-                                    valu_roof = {"issue_us": issue_us, "frac": issue_us / (stage_ms[dom] * 1e3),
-                                                 "wave_instructions": e["SQ_INSTS_VALU"], "cycles_per_instruction": w,
-                                                 "note": "SQ_INSTS_VALU of the counter summary x class-weighted issue cycles "
-                                                         "(tools/isa/cost.py) / (1024 SIMDs x 2.4 GHz) / this run's launch duration"}
-            except Exception:
-                traffic = None
+                table = IT.issue_table()
+                table_src = "llvm-objdump of the library this run loaded"
+            except Exception:  # noqa: BLE001 (no llvm-objdump on this host: the committed table of the same sources)
+                table = json.load(open(os.path.join(ROOT, "profiles", "r06_issue_table.json")))
+                table_src = "profiles/r06_issue_table.json"
+            issue_all = {}
+            for st, kn in kernel_of.items():
+                ms = stage_ms.get(st, 0.0)
+                ek = next((e for k, e in pk.items() if k.startswith(kn) and "SQ_INSTS_VALU" in e), None)
+                tk = next((t for k, t in table["kernels"].items() if k.startswith(kn) and (ek is None or k in pk)), None) or \
+                    next((t for k, t in table["kernels"].items() if k.startswith(kn)), None)
+                if ek is None or tk is None or ms <= 0:
+                    continue
+                cyc = ek["SQ_INSTS_VALU"] * tk["cycles_per_instruction"]
+                issue_all[st] = {"wave_instructions": ek["SQ_INSTS_VALU"], "cycles_per_instruction": tk["cycles_per_instruction"],
+                                 "issue_us": cyc / (1024 * 2.4e3), "issue_frac": cyc / (1024 * 2.4e3) / (ms * 1e3)}
+            if dom in issue_all:
+                issue = dict(issue_all[dom], table=table_src, definition=table["definition"], kernels=issue_all)
+        except Exception as e:  # noqa: BLE001
+            issue = {"error": "%s: %s" % (type(e).__name__, e)}
+        step_bytes = sum(abytes.values()) * B
         out = {
             "metric": "keypoints+descriptors/sec on %dx%dx8-level pyramid" % (W, H),
             "value": kp_per_step * args.steps / dt,
@@ -1024,10 +1164,12 @@ def main():
                              if dist.is_initialized() else "none"),
             },
             "roofline": {
-                # the kernel's binding roof: HBM by the contract's accounting (achieved / peak / frac below), but its vector
-                # ALUs are busier than its memory system by far -- `valu` prices it against instruction issue instead
-                "bound": "valu" if (valu_roof and valu_roof["frac"] > achieved / HBM_PEAK_GBPS) else "hbm",
-                "valu": valu_roof,
+                # the contract's accounting: algorithmic bytes against the HBM roof (achieved / peak / frac).  What actually limits
+                # the kernel is named in `limiter`: its vector ALUs are busier than its memory system by far (`issue_frac`)
+                "bound": "hbm",
+                "limiter": ("valu-issue" if (issue and issue.get("issue_frac", 0) > achieved / HBM_PEAK_GBPS) else "hbm"),
+                "issue_frac": issue.get("issue_frac") if issue else None,
+                "issue": issue,
                 "kernel": kernel_of[dom],
                 "stage": dom,
                 "achieved": achieved,
@@ -1035,9 +1177,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "valu_issue_frac": valu_issue,
-                "valu_issue_cycles_assumed": 2,
-                "traffic_source": traffic_source if traffic is not None else None,
+                "traffic_source": traffic_source,
+                "traffic_over_algorithmic": (traffic / launch_bytes) if (traffic and launch_bytes) else None,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "event_sampling": "stage hipEvents on every %d-th of the timed steps; the sampled steps carry six event "
                                   "records, so the stage times add up to a few per cent more than ms_per_step"
@@ -1055,9 +1196,13 @@ def main():
                                  "frac": (abytes[st] * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms > 0 else 0.0,
                                  "traffic": per_kernel.get(st)}
                             for st, ms in stage_ms.items() if st != "trigfix"},
-                "whole_step": {"algorithmic_bytes": sum(abytes.values()) * B,
-                               "achieved": sum(abytes.values()) * B / dt * args.steps / 1e9,
-                               "frac": sum(abytes.values()) * B / dt * args.steps / 1e9 / HBM_PEAK_GBPS},
+                # the whole step against the same roof: SURVEY 8(d)'s bytes per step / ms_per_step (all lanes) / 8 TB/s, and the
+                # measured traffic of its kernels the same way
+                "step": {"algorithmic_bytes": step_bytes,
+                         "achieved": step_bytes / dt * args.steps / 1e9,
+                         "frac": step_bytes / dt * args.steps / 1e9 / HBM_PEAK_GBPS,
+                         "traffic": sum(per_kernel.values()) if per_kernel else None,
+                         "traffic_frac": (sum(per_kernel.values()) / dt * args.steps / 1e9 / HBM_PEAK_GBPS) if per_kernel else None},
             },
         }
         if same_batch is not None:
@@ -1098,7 +1243,10 @@ def main():
         if isinstance(cb, dict) and cb.get("value"):
             out["vs_cpu"] = {"value_over_cpu_all_cores": out["value"] / cb["value"],
                              "value_over_cpu_one_thread": out["value"] / cb["one_thread"]["value"],
-                             "cpu_cores": cb["cores"]}
+                             "cpu_cores": cb["cores"], "cpu": "vectorised timing build (cpu_baseline.variant)"}
+            if isinstance(cb.get("scalar_port"), dict):  # (the ratio rounds 1-5 quoted: against the scalar parity oracle)
+                out["vs_cpu"]["value_over_scalar_port_all_cores"] = out["value"] / cb["scalar_port"]["value"]
+                out["vs_cpu"]["value_over_scalar_port_one_thread"] = out["value"] / cb["scalar_port"]["one_thread"]["value"]
             if "boundary_value" in out:
                 out["vs_cpu"]["boundary_over_cpu_all_cores"] = out["boundary_value"] / cb["value"]
                 out["vs_cpu"]["boundary_over_cpu_one_thread"] = out["boundary_value"] / cb["one_thread"]["value"]

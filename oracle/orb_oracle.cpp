@@ -325,6 +325,202 @@ void gaussian_blur7(const uint8_t* src, int rows, int cols, size_t sstride, uint
     }
 }
 
+// ---- timing-only fast path ("an honest CPU leg") ----------------------------------------------------------
+// The functions above are the PARITY oracle: scalar, one pixel at a time.  OpenCV's own cv::FAST and GaussianBlur are SIMD
+// code, so a CPU baseline timed on the scalar port flatters the GPU.  orb_oracle_set_fastpath(o, 1) swaps in the two below for
+// the TIMED CPU leg of bench.py only: the same results (bench.py asserts equality with the scalar path on the timed frames
+// before it times anything; tests/test_oracle_fastpath.py does the same on the CPU), computed the way a SIMD library computes
+// them.  Never used by a parity test as the checker.
+#if defined(__AVX2__)
+#include <immintrin.h>
+// 32 centre pixels at once through the "one pixel of each opposite pair" rejection test (what cv::FAST does with its vector
+// path before it counts arcs); returns the bit mask of the pixels that survive it
+static inline unsigned fast_prefilter32(const uint8_t* c, ptrdiff_t s, int t)
+{
+    const __m256i v = _mm256_loadu_si256((const __m256i*)c);
+    const __m256i tt = _mm256_set1_epi8((char)t);
+    const __m256i hi = _mm256_adds_epu8(v, tt), lo = _mm256_subs_epu8(v, tt), z = _mm256_setzero_si256();
+    auto pair = [&](const uint8_t* a, const uint8_t* b, __m256i& B, __m256i& D) {
+        const __m256i ra = _mm256_loadu_si256((const __m256i*)a), rb = _mm256_loadu_si256((const __m256i*)b);
+        // r > hi  <=>  r -sat hi != 0;   r < lo  <=>  lo -sat r != 0
+        const __m256i nb = _mm256_cmpeq_epi8(_mm256_or_si256(_mm256_subs_epu8(ra, hi), _mm256_subs_epu8(rb, hi)), z);
+        const __m256i nd = _mm256_cmpeq_epi8(_mm256_or_si256(_mm256_subs_epu8(lo, ra), _mm256_subs_epu8(lo, rb)), z);
+        B = _mm256_andnot_si256(nb, B);
+        D = _mm256_andnot_si256(nd, D);
+    };
+    __m256i B = _mm256_set1_epi8((char)0xFF), D = B;
+    pair(c + 3 * s, c - 3 * s, B, D);
+    if (_mm256_testz_si256(_mm256_or_si256(B, D), _mm256_or_si256(B, D))) return 0u;
+    pair(c + 3, c - 3, B, D);
+    if (_mm256_testz_si256(_mm256_or_si256(B, D), _mm256_or_si256(B, D))) return 0u;
+    pair(c + 2 * s + 2, c - 2 * s - 2, B, D);
+    pair(c - 2 * s + 2, c + 2 * s - 2, B, D);
+    return (unsigned)_mm256_movemask_epi8(_mm256_or_si256(B, D));
+}
+#define ORB_ORACLE_HAVE_SIMD 1
+#else
+#define ORB_ORACLE_HAVE_SIMD 0
+#endif
+
+// resize_linear with OpenCV's row reuse: the horizontal interpolation of a source row is computed once and serves every
+// destination row that reads it (at scale 1.2 most source rows serve two); the vertical pass is a plain row loop the compiler
+// vectorises.  The same fixed-point arithmetic per pixel, hence the same bytes.
+void resize_linear_fastpath(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh, int dw, size_t dstride)
+{
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    static thread_local std::vector<int> xofs, xofs1, Hb[2];
+    static thread_local std::vector<int16_t> a0v, a1v;
+    xofs.resize(dw);
+    xofs1.resize(dw);
+    a0v.resize(dw);
+    a1v.resize(dw);
+    Hb[0].resize(dw);
+    Hb[1].resize(dw);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        xofs1[dx] = std::min(sx + 1, sw - 1);
+        a0v[dx] = sat_s16(cv_round((1.f - fx) * 2048));
+        a1v[dx] = sat_s16(cv_round(fx * 2048));
+    }
+    int tag[2] = {-1, -1};
+    auto hrow = [&](int sy, int other) -> const int* {
+        for (int k = 0; k < 2; k++)
+            if (tag[k] == sy) return Hb[k].data();
+        const int k = (tag[0] == other) ? 1 : 0; // not the buffer the other row of this step lives in
+        const uint8_t* S = src + (size_t)sy * sstride;
+        int* __restrict H = Hb[k].data();
+        const int *__restrict x0 = xofs.data(), *__restrict x1 = xofs1.data();
+        const int16_t *__restrict a0 = a0v.data(), *__restrict a1 = a1v.data();
+        for (int dx = 0; dx < dw; dx++) H[dx] = S[x0[dx]] * a0[dx] + S[x1[dx]] * a1[dx];
+        tag[k] = sy;
+        return H;
+    };
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        const int b0 = sat_s16(cv_round((1.f - fy) * 2048)), b1 = sat_s16(cv_round(fy * 2048));
+        const int sy0 = std::min(std::max(sy, 0), sh - 1), sy1 = std::min(std::max(sy + 1, 0), sh - 1);
+        const int* __restrict H0 = hrow(sy0, sy1);
+        const int* __restrict H1 = hrow(sy1, sy0);
+        uint8_t* __restrict D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int v = (((b0 * (H0[dx] >> 4)) >> 16) + ((b1 * (H1[dx] >> 4)) >> 16) + 2) >> 2;
+            D[dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+// fast_detect with the vector prefilter (scalar finish: exact arc test + score on the few survivors) and an NMS pass over the
+// list of corners instead of over every pixel.  Same output as fast_detect, element for element.
+void fast_detect_fastpath(const uint8_t* img, int rows, int cols, size_t stride, int threshold, bool nms, std::vector<KP>& out)
+{
+#if ORB_ORACLE_HAVE_SIMD
+    out.clear();
+    threshold = std::min(std::max(threshold, 0), 255);
+    if (rows < 7 || cols < 7) return;
+    if (cols - 6 < 32) return fast_detect(img, rows, cols, stride, threshold, nms, out); // narrower than one vector
+    static thread_local std::vector<int> score;
+    static thread_local std::vector<int> pos;
+    score.assign((size_t)rows * cols, 0);
+    pos.clear();
+    const ptrdiff_t s = (ptrdiff_t)stride;
+    for (int y = 3; y < rows - 3; y++) {
+        const uint8_t* row = img + (size_t)y * stride;
+        int x = 3;
+        auto finish = [&](int x0, unsigned m, int from) { // survivors of one vector, ascending x; `from`: first x not yet done
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const int xx = x0 + b;
+                if (xx < from) continue;
+                const uint8_t* c = row + xx;
+                if (fast_is_corner(c, stride, threshold)) {
+                    pos.push_back(y * cols + xx);
+                    if (nms) score[(size_t)y * cols + xx] = fast_score_closed(c, stride);
+                }
+            }
+        };
+        for (; x + 32 <= cols - 3; x += 32) finish(x, fast_prefilter32(row + x, s, threshold), x);
+        if (x < cols - 3) { // the tail: one more vector that ends at the last interior pixel (overlaps the previous one)
+            const int x0 = cols - 3 - 32;
+            finish(x0, fast_prefilter32(row + x0, s, threshold), x);
+        }
+    }
+    for (int p : pos) {
+        const int y = p / cols, x = p - y * cols;
+        const int sc = score[(size_t)p];
+        if (nms) {
+            const int* r0 = &score[(size_t)(y - 1) * cols + x];
+            const int* r1 = &score[(size_t)y * cols + x];
+            const int* r2 = &score[(size_t)(y + 1) * cols + x];
+            if (!(sc > r0[-1] && sc > r0[0] && sc > r0[1] && sc > r1[-1] && sc > r1[1] && sc > r2[-1] && sc > r2[0] && sc > r2[1])) continue;
+        }
+        KP k;
+        k.x = (float)x;
+        k.y = (float)y;
+        k.size = 7.f;
+        k.angle = -1.f;
+        k.response = nms ? (float)sc : 0.f;
+        k.octave = 0;
+        k.class_id = -1;
+        out.push_back(k);
+    }
+#else
+    fast_detect(img, rows, cols, stride, threshold, nms, out);
+#endif
+}
+
+// gaussian_blur7 written as whole-row passes per tap, which the compiler vectorises (-O3 -march=native: vpmullw / vpaddw rows).
+// The u16 accumulator of the horizontal pass is exact while the taps sum to <= 257 (255 * 257 = 65535: ufixedpoint16's
+// saturation cannot trigger); other taps take the scalar function.
+void gaussian_blur7_fastpath(const uint8_t* src, int rows, int cols, size_t sstride, uint8_t* dst, size_t dstride, const int* taps)
+{
+    int sum = 0;
+    for (int i = 0; i < 7; i++) sum += taps[i];
+    if (sum > 257) return gaussian_blur7(src, rows, cols, sstride, dst, dstride, taps);
+    static thread_local std::vector<uint16_t> H;
+    static thread_local std::vector<uint8_t> prow;
+    static thread_local std::vector<uint32_t> acc;
+    H.resize((size_t)rows * cols);
+    prow.resize((size_t)cols + 6);
+    acc.resize((size_t)cols);
+    uint16_t t16[7];
+    for (int i = 0; i < 7; i++) t16[i] = (uint16_t)taps[i];
+    for (int y = 0; y < rows; y++) {
+        const uint8_t* sr = src + (size_t)y * sstride;
+        for (int x = -3; x < 0; x++) prow[x + 3] = sr[reflect101(x, cols)];
+        memcpy(&prow[3], sr, (size_t)cols);
+        for (int x = cols; x < cols + 3; x++) prow[x + 3] = sr[reflect101(x, cols)];
+        uint16_t* __restrict h = &H[(size_t)y * cols];
+        const uint8_t* __restrict p = prow.data();
+        for (int x = 0; x < cols; x++)
+            h[x] = (uint16_t)(t16[0] * p[x] + t16[1] * p[x + 1] + t16[2] * p[x + 2] + t16[3] * p[x + 3] + t16[4] * p[x + 4] +
+                              t16[5] * p[x + 5] + t16[6] * p[x + 6]);
+    }
+    for (int y = 0; y < rows; y++) {
+        const uint16_t* r[7];
+        for (int j = 0; j < 7; j++) r[j] = &H[(size_t)reflect101(y + j - 3, rows) * cols];
+        uint8_t* __restrict d = dst + (size_t)y * dstride;
+        uint32_t* __restrict a = acc.data();
+        const uint32_t t0 = (uint32_t)taps[0], t1 = (uint32_t)taps[1], t2 = (uint32_t)taps[2], t3 = (uint32_t)taps[3],
+                       t4 = (uint32_t)taps[4], t5 = (uint32_t)taps[5], t6 = (uint32_t)taps[6];
+        const uint16_t *r0 = r[0], *r1 = r[1], *r2 = r[2], *r3 = r[3], *r4 = r[4], *r5 = r[5], *r6 = r[6];
+        for (int x = 0; x < cols; x++)
+            a[x] = t0 * r0[x] + t1 * r1[x] + t2 * r2[x] + t3 * r3[x] + t4 * r4[x] + t5 * r5[x] + t6 * r6[x];
+        for (int x = 0; x < cols; x++) {
+            const uint32_t v = (a[x] + 32768u) >> 16;
+            d[x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- fastAtan2
 // cv::fastAtan2 (degrees); single precision, no FMA.
 // fma_horner: the three inner Horner steps fused (an OpenCV AVX2 build with -mfma)
@@ -538,6 +734,10 @@ struct orb_oracle {
     bool atan_fma = false;
     std::vector<Level> pyr;
     std::vector<std::vector<KP>> cands, allKeypoints;
+    bool fastpath = false; // timing-only SIMD FAST + vector-friendly blur (orb_oracle_set_fastpath)
+    double stage_s[6] = {0, 0, 0, 0, 0, 0}; // accumulated: pyramid, FAST (cell loop), quadtree, orientation, blur, descriptors
+    long stage_calls = 0;
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     // reference src/ORBextractor.cc:408-468
     orb_oracle(int _nfeatures, float _scaleFactor, int _nlevels, int _ini, int _min)
@@ -595,7 +795,8 @@ struct orb_oracle {
             L.blur.clear();
             if (level != 0) {
                 Level& P = pyr[level - 1];
-                resize_linear(P.roi(), P.rows, P.cols, P.stride, L.roi(), L.rows, L.cols, L.stride);
+                if (fastpath) resize_linear_fastpath(P.roi(), P.rows, P.cols, P.stride, L.roi(), L.rows, L.cols, L.stride);
+                else resize_linear(P.roi(), P.rows, P.cols, P.stride, L.roi(), L.rows, L.cols, L.stride);
             } else {
                 for (int y = 0; y < rows; y++) memcpy(L.roi() + (size_t)y * L.stride, img + (size_t)y * stride, cols);
             }
@@ -631,6 +832,7 @@ struct orb_oracle {
         cands.assign(nlevels, std::vector<KP>());
         const float W = 35;
         for (int level = 0; level < nlevels; ++level) {
+            const double tLevel = now_s();
             Level& L = pyr[level];
             const int minBorderX = EDGE_THRESHOLD - 3;
             const int minBorderY = minBorderX;
@@ -657,8 +859,13 @@ struct orb_oracle {
                     std::vector<KP> vKeysCell;
                     const uint8_t* roi = L.roi() + (size_t)(int)iniY * L.stride + (int)iniX;
                     const int rr = (int)maxY - (int)iniY, cc = (int)maxX - (int)iniX;
-                    fast_detect(roi, rr, cc, L.stride, iniThFAST, true, vKeysCell);
-                    if (vKeysCell.empty()) fast_detect(roi, rr, cc, L.stride, minThFAST, true, vKeysCell);
+                    if (fastpath) {
+                        fast_detect_fastpath(roi, rr, cc, L.stride, iniThFAST, true, vKeysCell);
+                        if (vKeysCell.empty()) fast_detect_fastpath(roi, rr, cc, L.stride, minThFAST, true, vKeysCell);
+                    } else {
+                        fast_detect(roi, rr, cc, L.stride, iniThFAST, true, vKeysCell);
+                        if (vKeysCell.empty()) fast_detect(roi, rr, cc, L.stride, minThFAST, true, vKeysCell);
+                    }
                     for (KP& k : vKeysCell) {
                         k.x += j * wCell;
                         k.y += i * hCell;
@@ -666,9 +873,12 @@ struct orb_oracle {
                     }
                 }
             }
+            const double tq = now_s();
+            stage_s[1] += tq - tLevel;
             std::vector<KP>& keypoints = allKeypoints[level];
             keypoints = DistributeOctTree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY,
                                           mnFeaturesPerLevel[level]);
+            stage_s[2] += now_s() - tq;
             const int scaledPatchSize = (int)(PATCH_SIZE * mvScaleFactor[level]);
             for (KP& k : keypoints) {
                 k.x += minBorderX;
@@ -677,8 +887,10 @@ struct orb_oracle {
                 k.size = (float)scaledPatchSize;
             }
         }
+        const double ta = now_s();
         for (int level = 0; level < nlevels; ++level)
             for (KP& k : allKeypoints[level]) k.angle = IC_Angle(pyr[level], k.x, k.y);
+        stage_s[3] += now_s() - ta;
         return true;
     }
 
@@ -713,7 +925,10 @@ struct orb_oracle {
     {
         if (n_out) *n_out = 0;
         if (!img || rows <= 0 || cols <= 0) return -1;
+        const double tp = now_s();
         ComputePyramid(img, rows, cols, stride);
+        stage_s[0] += now_s() - tp;
+        stage_calls++;
         if (!ComputeKeyPointsOctTree()) return -2;
         int nkeypoints = 0;
         for (int level = 0; level < nlevels; ++level) nkeypoints += (int)allKeypoints[level].size();
@@ -725,7 +940,11 @@ struct orb_oracle {
             if (keypoints.empty()) continue;
             Level& L = pyr[level];
             L.blur.resize((size_t)L.rows * L.cols);
-            gaussian_blur7(L.roi(), L.rows, L.cols, L.stride, L.blur.data(), (size_t)L.cols, taps);
+            const double tb = now_s();
+            if (fastpath) gaussian_blur7_fastpath(L.roi(), L.rows, L.cols, L.stride, L.blur.data(), (size_t)L.cols, taps);
+            else gaussian_blur7(L.roi(), L.rows, L.cols, L.stride, L.blur.data(), (size_t)L.cols, taps);
+            const double td = now_s();
+            stage_s[4] += td - tb;
             float scale = mvScaleFactor[level];
             for (KP& kp0 : keypoints) {
                 uint8_t d[32];
@@ -741,6 +960,7 @@ struct orb_oracle {
                 kps[dst] = kp;
                 memcpy(desc + (size_t)dst * 32, d, 32);
             }
+            stage_s[5] += now_s() - td;
         }
         return monoIndex;
     }
@@ -858,6 +1078,20 @@ void orb_oracle_set_gauss_taps(orb_oracle* o, const int* t)
     for (int i = 0; i < 7; i++) o->taps[i] = t[i];
 }
 void orb_oracle_set_trig_mode(orb_oracle* o, int mode) { o->trig_mode = mode; }
+int orb_oracle_set_fastpath(orb_oracle* o, int on)
+{
+    o->fastpath = on != 0;
+    return ORB_ORACLE_HAVE_SIMD; // 1: the FAST prefilter is AVX2 code in this build; 0: only the blur differs
+}
+void orb_oracle_get_stage_seconds(orb_oracle* o, double* s6, long* calls, int reset)
+{
+    for (int i = 0; i < 6; i++) s6[i] = o->stage_s[i];
+    if (calls) *calls = o->stage_calls;
+    if (reset) {
+        for (int i = 0; i < 6; i++) o->stage_s[i] = 0;
+        o->stage_calls = 0;
+    }
+}
 void orb_oracle_set_atan_fma(orb_oracle* o, int on) { o->atan_fma = on != 0; }
 
 int orb_oracle_extract(orb_oracle* o, const uint8_t* img, int rows, int cols, size_t stride, int lap0, int lap1,
@@ -959,11 +1193,24 @@ int orb_oracle_distribute_octree(const orb_oracle_kp* cands, int n, int minX, in
 // CPU-baseline helper: `nthreads` threads, each with its own extractor (the reference's
 // one-extractor-per-thread protocol, src/Frame.cc:119-122), each running `reps` extractions over the
 // given frames.  Returns the total number of keypoints; *seconds = wall time.
+long orb_oracle_extract_many2(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
+                              const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, int fastpath, double* seconds,
+                              double* stage_s6 /* summed over the threads; may be NULL */);
 long orb_oracle_extract_many(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
                              const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, double* seconds)
 {
+    return orb_oracle_extract_many2(nthreads, reps, nfeatures, scaleFactor, nlevels, iniTh, minTh, imgs, nimg, rows, cols, lap0, lap1, 0,
+                                    seconds, nullptr);
+}
+long orb_oracle_extract_many2(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
+                              const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, int fastpath, double* seconds,
+                              double* stage_s6)
+{
     std::vector<orb_oracle*> ex(nthreads);
-    for (auto& e : ex) e = new orb_oracle(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    for (auto& e : ex) {
+        e = new orb_oracle(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+        e->fastpath = fastpath != 0;
+    }
     std::vector<long> counts(nthreads, 0);
     const int cap = nfeatures + 64 + 16 * nlevels;
     auto t0 = std::chrono::steady_clock::now();
@@ -985,6 +1232,11 @@ long orb_oracle_extract_many(int nthreads, int reps, int nfeatures, float scaleF
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     long total = 0;
     for (long c : counts) total += c;
+    if (stage_s6)
+        for (int i = 0; i < 6; i++) {
+            stage_s6[i] = 0;
+            for (auto& e : ex) stage_s6[i] += e->stage_s[i];
+        }
     for (auto& e : ex) delete e;
     return total;
 }

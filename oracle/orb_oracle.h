@@ -38,6 +38,12 @@ orb_oracle* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int
 void orb_oracle_destroy(orb_oracle*);
 void orb_oracle_set_gauss_taps(orb_oracle*, const int* taps7);
 void orb_oracle_set_trig_mode(orb_oracle*, int mode);
+/* Timing-only fast path (never the checker of a parity test): SIMD prefilter in FAST (AVX2 builds) + a blur the compiler
+ * vectorises; results identical to the scalar path.  Returns 1 when the build has the AVX2 prefilter. */
+int orb_oracle_set_fastpath(orb_oracle*, int on);
+/* Wall time accumulated per stage over the extract calls so far: pyramid, FAST cell loop, quadtree, orientation, blur,
+ * descriptors (seconds); reset != 0 clears the accumulators. */
+void orb_oracle_get_stage_seconds(orb_oracle*, double* s6, long* calls, int reset);
 void orb_oracle_set_atan_fma(orb_oracle*, int on); /* fused Horner steps in fastAtan2 */
 
 /* ORBextractor::operator() -- returns monoIndex (>=0), -1 for an empty image, -2 bad args/too small. */
@@ -47,6 +53,11 @@ int orb_oracle_extract(orb_oracle*, const uint8_t* img, int rows, int cols, size
 /* CPU-baseline helper: nthreads threads x reps extractions, one extractor per thread. */
 long orb_oracle_extract_many(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
                              const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, double* seconds);
+/* ... with the timing-only fast path on (fastpath != 0) and the per-stage wall seconds summed over the threads (stage_s6:
+ * pyramid, FAST, quadtree, orientation, blur, descriptors; NULL = not wanted). */
+long orb_oracle_extract_many2(int nthreads, int reps, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
+                              const uint8_t* imgs, int nimg, int rows, int cols, int lap0, int lap1, int fastpath, double* seconds,
+                              double* stage_s6);
 
 /* tables (ctor) */
 void orb_oracle_get_scale_tables(orb_oracle*, float* sf, float* inv, float* sigma2, float* inv_sigma2);

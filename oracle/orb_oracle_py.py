@@ -125,8 +125,8 @@ def _fv(fv):
 class Extractor:
     """Oracle ORBextractor (reference src/ORBextractor.cc)."""
 
-    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, trig=TRIG_LIBM, taps=None):
-        self.L = lib()
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, trig=TRIG_LIBM, taps=None, native=False):
+        self.L = (_native_for_extractor() if native else None) or lib()
         self.h = self.L.orb_oracle_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
             raise ValueError("bad ORBextractor parameters")
@@ -138,6 +138,13 @@ class Extractor:
 
     def set_atan_fma(self, on=True):
         self.L.orb_oracle_set_atan_fma(self.h, int(on))
+
+    def set_fastpath(self, on=True):
+        """Timing-only SIMD FAST prefilter + vector-friendly blur (identical results; never the checker of a parity test).
+        Returns True when the build has the AVX2 prefilter."""
+        self.L.orb_oracle_set_fastpath.restype = C.c_int
+        self.L.orb_oracle_set_fastpath.argtypes = [C.c_void_p, C.c_int]
+        return bool(self.L.orb_oracle_set_fastpath(self.h, int(on)))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -227,6 +234,24 @@ def lib_native():
     return _NATIVE or None
 
 
+def _native_for_extractor():
+    """The -march=native build with the Extractor's entry points typed (timing-only uses: tests/test_oracle_fastpath.py, bench.py)."""
+    L = lib_native()
+    if L is None:
+        return None
+    if not getattr(L, "_typed", False):
+        b = lib()
+        for name in ("orb_oracle_create", "orb_oracle_destroy", "orb_oracle_extract", "orb_oracle_set_trig_mode", "orb_oracle_set_gauss_taps",
+                     "orb_oracle_set_atan_fma", "orb_oracle_get_scale_tables", "orb_oracle_get_features_per_level", "orb_oracle_get_umax",
+                     "orb_oracle_get_level", "orb_oracle_get_blurred", "orb_oracle_get_candidates", "orb_oracle_get_level_keypoints"):
+            f, g = getattr(L, name), getattr(b, name)
+            f.restype = g.restype
+            if g.argtypes is not None:
+                f.argtypes = g.argtypes
+        L._typed = True
+    return L
+
+
 def extract_many(imgs, nthreads, reps, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, lap=(0, 0),
                  native=False):
     """Threaded CPU baseline: returns (total keypoints, seconds)."""
@@ -237,6 +262,27 @@ def extract_many(imgs, nthreads, reps, nfeatures=1000, scale=1.2, nlevels=8, ini
     n = L.orb_oracle_extract_many(nthreads, reps, nfeatures, scale, nlevels, ini_th, min_th, _p(imgs),
                                   imgs.shape[0], imgs.shape[1], imgs.shape[2], lap[0], lap[1], C.byref(sec))
     return int(n), sec.value
+
+
+STAGES = ("pyramid", "fast", "quadtree", "orientation", "blur", "descriptors")
+
+
+def extract_many_stages(imgs, nthreads, reps, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, lap=(0, 0), native=False,
+                        fastpath=False):
+    """extract_many with the timing-only fast path selectable and the wall seconds per stage (summed over the threads).
+    Returns (total keypoints, seconds, {stage: seconds})."""
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    assert imgs.ndim == 3
+    sec = C.c_double(0)
+    st = (C.c_double * 6)()
+    L = (lib_native() if native else None) or lib()
+    L.orb_oracle_extract_many2.restype = C.c_long
+    L.orb_oracle_extract_many2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = L.orb_oracle_extract_many2(nthreads, reps, nfeatures, scale, nlevels, ini_th, min_th, _p(imgs), imgs.shape[0], imgs.shape[1],
+                                   imgs.shape[2], lap[0], lap[1], int(bool(fastpath)), C.cast(C.byref(sec), C.c_void_p),
+                                   C.cast(st, C.c_void_p))
+    return int(n), sec.value, dict(zip(STAGES, list(st)))
 
 
 def resize_linear(src, dh, dw):
