@@ -528,9 +528,6 @@ def main():
                          "context (the latency-bound quadtree kernel and the kernel tails of one batch beside the throughput-bound "
                          "kernels of its neighbours).  The per-kernel times of `roofline` are always measured with one lane, in a "
                          "second region of the same run: overlapped kernels have no per-launch duration")
-    ap.add_argument("--lane-mode", choices=["batch", "split"], default="batch",
-                    help="batch (round 5): whole batches dealt round-robin to the lanes, each with its own intermediate buffers; "
-                         "split (round 4, two lanes only): every batch as two half-batches")
     ap.add_argument("--rotate", type=int, default=12,
                     help="the timed region rotates through this many DISTINCT resident input batches (and as many output sets as "
                          "there are lanes), so that nothing a step reads or writes is still in the 256-MiB Infinity Cache from the "
@@ -614,7 +611,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ex.set_stream(stream.cuda_stream)
-    lane_mode = pkg.binding.LANES_SPLIT if (args.lane_mode == "split" and args.lanes == 2) else pkg.binding.LANES_BATCH
+    lane_mode = pkg.binding.LANES_BATCH
     ex.set_lanes(args.lanes, lane_mode)
     ex.set_lane_input_guard(args.input_guard)
     cap = ex.max_keypoints(H, W)
@@ -1148,15 +1145,12 @@ def main():
                                    os.environ.get("ORBFE_TRIG_TABLE", ""), os.environ.get("ORBFE_TRIG_TABLE", "")),
                 "contexts": 1 + len(extra),
                 "lanes": args.lanes,
-                "lane_mode": args.lane_mode if args.lanes > 1 else None,
                 "rotate": R,
                 "input_guard": bool(args.input_guard),
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                "lanes_note": (("whole batches dealt round-robin to %d streams of the one extractor context (orbfe_set_lanes), a "
-                                "ring of %d output sets" % (args.lanes, nring) if lane_mode == pkg.binding.LANES_BATCH else
-                                "two half-batches per step on two streams of the one extractor context (orbfe_set_lane_mode "
-                                "SPLIT)") + ": identical outputs, complete when the timed region's closing synchronisation returns"
-                               if args.lanes >= 2 else "one stream"),
+                "lanes_note": ("whole batches dealt round-robin to %d streams of the one extractor context (orbfe_set_lanes), a ring of %d "
+                               "output sets: identical outputs, complete when the timed region's closing synchronisation returns"
+                               % (args.lanes, nring) if args.lanes >= 2 else "one stream"),
                 "exchange": (("1 ncclAllGather of descriptor slabs per step issued by liborbfe.so (orbfe_mc_extract_exchange_"
                               "submit / _wait) on its own stream, overlapped with the next step's extraction" if mc is not None
                               else "1 all-gather of descriptor slabs per step through torch.distributed, overlapped with the "

@@ -176,7 +176,7 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
  * multi-GPU shard has more).  orbfe_set_lanes(ctx, n) with n = 2..ORBFE_MAX_LANES (or ORBFE_LANES=n in the environment when the
  * context is created; default 1) lets the context keep up to n device-pointer batches in flight on streams it owns.
  *
- * ORBFE_LANES_BATCH (default mode, round 5): every orbfe_extract_batch_device call goes, WHOLE, to the next lane round-robin.
+ * Every orbfe_extract_batch_device call goes, WHOLE, to the next lane round-robin.
  * Each lane has its own intermediate buffers (pyramids, candidates, quadtree keys, status header), so the kernels of
  * DIFFERENT batches overlap: the latency-bound chain of a small batch (8 x 1280x720 is four kernels of 15-30 us each on a
  * nearly empty chip) runs beside the chains of its neighbours -- 0.084 ms per batch with one lane, 0.05 with two, 0.043-0.045
@@ -188,12 +188,9 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
  *   - OUTPUTS are not ordered on the context's stream until a join (below), and calls that are in flight together must be
  *     given different output arrays (n lanes: a ring of n output sets; the call n calls ago on the same lane has finished
  *     before the lane writes again -- a lane is a stream).
- * ORBFE_LANES_SPLIT (round 4; n = 2 only): a call with >= 8 images (ORBFE_LANES_MIN) runs as two half-batches, images [0, h)
- * on the context's stream and [h, nimg) on a second stream, no event between the two inside a call (64 x 752x480: 0.19 ->
- * ~0.17 ms per batch).  Kept for A/B; for small batches it splits what is already too small.  This mode has NO input guard:
- * the images [h, nimg) of a call must not be rewritten before orbfe_lanes_join or orbfe_sync.
+ * (Round 4's other form -- one call as two half-batches, ORBFE_LANES_SPLIT -- was measured slower and left with round 6.)
  *
- * Results are bit-identical in every mode.  What changes is ORDERING: after a call the outputs are NOT yet ordered on the
+ * Results are bit-identical with any number of lanes.  What changes is ORDERING: after a call the outputs are NOT yet ordered on the
  * context's stream.  They are after any of
  *   orbfe_lanes_join(ctx)            -- the context's stream waits for every lane (no host wait; a few us on the stream),
  *   orbfe_get_device_outputs(ctx, ...) -- joins, then marks the stream (matcher calls of this library order themselves after it),
@@ -205,9 +202,8 @@ int orbfe_extract_batch_device(orbfe_ctx*, int nimg, const uint8_t* d_imgs, int 
  * lane (orbfe_extract_stereo_pair_submit keeps several stereo frames in flight by itself). */
 #define ORBFE_MAX_LANES 4
 #define ORBFE_LANES_BATCH 0
-#define ORBFE_LANES_SPLIT 1
 int orbfe_set_lanes(orbfe_ctx*, int lanes /* 1 .. ORBFE_MAX_LANES */);
-int orbfe_set_lane_mode(orbfe_ctx*, int mode /* ORBFE_LANES_BATCH | ORBFE_LANES_SPLIT (two lanes only) */);
+int orbfe_set_lane_mode(orbfe_ctx*, int mode /* ORBFE_LANES_BATCH: the one mode left (any other value: ORBFE_ERR_ARGS) */);
 int orbfe_lanes_join(orbfe_ctx*);
 /* Batch lanes, the input guard (on by default): after every call the context's stream waits for the lane's pyramid kernel, so
  * that the caller may overwrite the call's images in stream order.  That wait chains the pyramid kernels of consecutive calls
@@ -250,30 +246,7 @@ int orbfe_get_level(orbfe_ctx*, int img_index, int level, uint8_t* dst, size_t d
 int orbfe_profile_enable(orbfe_ctx*, int on);
 int orbfe_profile_read(orbfe_ctx*, float* ms_per_stage /* ORBFE_STAGE_COUNT */);
 
-/* Stage taps for parity tests: state of the last call. Packed entry = x | y<<12 | response<<24
- * with x,y relative to (minBorderX, minBorderY) = (16,16) of the level. */
-int orbfe_debug_candidates(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
-int orbfe_debug_level_keypoints(orbfe_ctx*, int img_index, int level, uint32_t* out, int cap);
-/* The 37 x 37 bytes of GaussianBlur's output (src/ORBextractor.cc:1114-1115) around keypoint `kp_index` (output
- * order) of image `img` of the last call: the fused kernel's blurred patch, for a direct comparison. */
-int orbfe_debug_blurred_patch(orbfe_ctx*, int img, int kp_index, uint8_t* out37x37);
-int orbfe_debug_fixups(orbfe_ctx*); /* keypoints re-evaluated with host libm trig in the last call */
-/* (cos, sin) the descriptor kernel uses for the given keypoint angles (degrees) in the context's trig mode;
- * returns 2 when the table of libm values was used, 1 for the compact code table, 0 for none (ORBFE_TRIG_CR, or
- * no table), < 0 on error. */
-int orbfe_debug_trig(orbfe_ctx*, const float* angles_deg, int n, float* a_out, float* b_out);
-/* The cache file of the libm table (65 MB of 4-bit codes; default directory /dev/shm, ORBFE_TRIG_CACHE=<dir> moves it, =0
- * disables it), host side only -- these need no device.  The file is trusted only when it is a regular file (symbolic links
- * are not followed) owned by the calling user, not writable by group or others, of the expected size, with the expected
- * magic / angle range / libm fingerprint and a matching checksum over its WHOLE payload (the library verifies that checksum
- * on the device after the upload; `_check` runs the same tests on the host and names the first one that fails).
- * `_path`: the file this process would use (returns its length, 0 when disabled).  `_write`: a file in the library's
- * format around `payload` (`_payload_bytes()` bytes), created exclusively with mode 0600 under a temporary name and
- * renamed. */
-int orbfe_debug_trig_cache_path(char* out, int cap);
-size_t orbfe_debug_trig_cache_payload_bytes(void);
-int orbfe_debug_trig_cache_write(const char* path, const uint8_t* payload, size_t bytes);
-int orbfe_debug_trig_cache_check(const char* path, const char** why);
+/* (The stage taps of the parity tests and the trig-cache file checks -- orbfe_debug_* -- are declared in include/orbfe_debug.h.) */
 
 /* Frame::ComputeStereoMatches (src/Frame.cc:797-967), rectified stereo.  `left` / `right` are the contexts
  * that just extracted the two images (same size and parameters, same device): their pyramids are read in
@@ -398,8 +371,11 @@ int orbfe_search_bow_batch(int device, int count, const orbfe_bow_args* args, in
  * ones.  A handle is read by the searches of any thread; create / set_mask / destroy are the owner's: set_mask rewrites the
  * handle's flags in place and must not run while a search of another thread that relies on them (one that passes no flags of
  * its own: mask1 / mask2 / hasMP == NULL) is in progress -- callers that search one keyframe from several threads send the flags
- * with every call instead, as adapters/ORBmatcher.h does --, and destroy must not run while ANY call that was given the handle
- * is in progress (it does not wait for the device: a search has done all its device reads before it returns). */
+ * with every call instead, as adapters/ORBmatcher.h does.  orbfe_keyframe_destroy may be called at any time (round 6): a call of
+ * another thread that was given the handle keeps it alive until it returns -- the last such call frees it --, and a call that is
+ * handed a handle that has already been destroyed returns ORBFE_ERR_ARGS instead of touching it (every entry point takes a use
+ * of its handles under a lock that knows which handles are alive).  Destroy does not wait for the device: a search has done all
+ * its device reads before it returns.  The same holds for orbfe_frame / orbfe_frame_destroy and orbfe_bow / orbfe_bow_destroy. */
 typedef struct orbfe_keyframe orbfe_keyframe;
 typedef struct {
     const uint8_t* desc; int n;            /* 32-B rows; host or device pointer                                      */

@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 ERR_ARGS, ERR_NODEV, ERR_STATE, ERR_IMAGE_SMALL, ERR_IMAGE_LARGE, ERR_NFEATURES = -2, -3, -4, -5, -6, -7
 TRIG_LIBM, TRIG_CR, TRIG_LIBM_HOSTCHECK = 0, 1, 2
-LANES_BATCH, LANES_SPLIT, MAX_LANES = 0, 1, 4  # ORBFE_LANES_BATCH / _SPLIT / ORBFE_MAX_LANES (include/orbfe.h)
+LANES_BATCH, MAX_LANES = 0, 4  # ORBFE_LANES_BATCH / ORBFE_MAX_LANES (include/orbfe.h)
 STAGES = ("pyramid", "fast", "octree", "pack", "desc", "trigfix")
 
 
@@ -537,9 +537,8 @@ class ORBextractor:
         _chk(self.L.orbfe_sync(self.h), "orbfe_sync")
 
     def set_lanes(self, lanes, mode=None):
-        """orbfe_set_lanes: up to `lanes` (1..4) device-pointer batches in flight on streams the context owns; mode
-        LANES_BATCH (default: whole batches round-robin) or LANES_SPLIT (two half-batches of every call of >= 8 images; two
-        lanes only).  See include/orbfe.h for the ordering rules."""
+        """orbfe_set_lanes: up to `lanes` (1..4) device-pointer batches in flight on streams the context owns, whole batches
+        round-robin.  See include/orbfe.h for the ordering rules."""
         _chk(self.L.orbfe_set_lanes(self.h, int(lanes)), "orbfe_set_lanes")
         if mode is not None:
             _chk(self.L.orbfe_set_lane_mode(self.h, int(mode)), "orbfe_set_lane_mode")

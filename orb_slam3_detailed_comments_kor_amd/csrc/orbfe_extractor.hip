@@ -31,6 +31,7 @@
 #include <unistd.h>
 
 #include "../../include/orbfe.h"
+#include "../../include/orbfe_debug.h"
 #include "orbfe_geom.h"
 #include "orbfe_order.h"
 #include "orbfe_sincos.h"
@@ -133,17 +134,12 @@ struct orbfe_geom_state {
     size_t qtLdsBytes = 0;
     int qtKeyOff = 0, qtKeyCap = 0;
     std::vector<int> qtSmall, qtBig; // levels whose quadtree tables live in LDS / in the global scratch area (k_octree<true>)
-    std::vector<int> qtWide;         // LDS levels of more than 512 FAST cells (level 0 from ~1100 x 620 px): 1024-thread workgroups (round 5)
     size_t qtBigLdsBytes = 0, qtScratchStride = 0;
     int qtBigKeyOff = 0, qtBigKeyCap = 0;
     int fastPitch = 0, fastRows = 0, fastThreads = 256;
     size_t fastLdsBytes = 0;
     std::vector<OrbFastCell> fc; // K-FAST's cell records
     DevBuf<OrbFastCell> d_fc;
-    std::vector<OrbFastRun> fr;  // ... and its run records (round 4: a workgroup per run of up to four cells of a cell row)
-    DevBuf<OrbFastRun> d_fr;
-    int fastRunTileBytes = 0, fastRunBmW = 0;
-    size_t fastRunLdsBytes = 0;
     std::vector<uint2> fastPat; // phase A's per-thread constants, fastThreads entries per pattern (OrbFastCell::pad names the pattern)
     DevBuf<uint2> d_fastPat;
     DevBuf<OrbDescSlot> d_ds; // K-DESC's per-slot records (level geometry of every keypoint slot)
@@ -160,7 +156,7 @@ struct orbfe_geom_state {
     bool pyrFused = true;
     void release_tables()
     {
-        d_lg.release(); d_cg.release(); d_fc.release(); d_fr.release(); d_fastPat.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
+        d_lg.release(); d_cg.release(); d_fc.release(); d_fastPat.release(); d_ds.release(); d_xtab.release(); d_ytab.release(); d_pyrRecs.release();
     }
 };
 
@@ -181,34 +177,14 @@ struct orbfe_ctx : orbfe_geom_state {
     hipStream_t stream = nullptr;
     bool ownStream = false;
 
-    bool fastRuns = false;       // ORBFE_FAST_RUNS=1: a workgroup per run of up to four cells (k_fast_runs; measured slower)
-    int fastThreadsOverride = 0; // ORBFE_FAST_THREADS env (tuning)
-    int fastXcdGroup = 4;        // ORBFE_FAST_GROUP env (tuning; 0 = whole images per XCD always)
-    bool fastByImage = true;     // ORBFE_FAST_BY_IMAGE=0 keeps the grouped order for every batch size
-    int nStreams = 1;            // ORBFE_STREAMS env / orbfe_set_streams: sub-batches on separate streams
-    hipStream_t sub[8] = {};
-    hipEvent_t evFork = nullptr, evJoin[8] = {};
-    int xcdAffine = 1;           // ORBFE_XCD_AFFINE env: whole images per XCD when the batch is a multiple of 8
-    // Two lanes (round 4, orbfe_set_lanes / ORBFE_LANES=2): a device-pointer batch of >= 16 images runs as two half-batches,
-    // the first on the context's stream and the second on a stream of the context's own, with NO event between them inside
-    // a call -- so the latency-bound K-QT and the kernel tails of one half run beside the throughput-bound kernels of the
-    // other, and consecutive calls keep both lanes busy.  Cross-stream waits only go one way and only where they cost nothing:
-    // the second lane waits for the point of the call on the context's stream (inputs ready), and the context's stream
-    // waits for the second lane when somebody needs the results there (lane_join: orbfe_get_device_outputs, orbfe_sync,
-    // any other entry point).  Measured (tools/overlap_probe.hip): a fork + join pair per call costs ~13 us of latency
-    // each way when the two streams ping-pong, a one-way wait ~3 us.
+    int fastXcdGroup = 4;        // cells per XCD group when a batch does not give whole images to the XCDs
+    bool fastByImage = true;     // whole images per XCD for batches that fill the eight XCDs evenly
+    int xcdAffine = 1;           // whole images per XCD when the batch is a multiple of 8
     int lanes = 1;
-    int laneSplitPct = 0;        // ORBFE_LANE_SPLIT (tuning)
-    int lanesMin = 8;            // smallest batch that is split (ORBFE_LANES_MIN; 8 x 1280x720: 0.085 -> 0.080 ms, 4: 0.069 -> 0.066)
-    hipStream_t laneStream = nullptr;
-    hipEvent_t evLaneFork = nullptr, evLaneJoin = nullptr;
-    bool lastLanes = false;      // the last batch ran on two lanes
-    bool lanePending = false;    // the second lane holds work the context's stream has not been ordered after
-    int laneSplit = 0, laneImgs = 0; // the split of the last two-lane call (a call with another split joins first)
-    // Batch lanes (round 5; the default lane mode, orbfe_set_lanes(ctx, 2..4)): WHOLE device-pointer batches are dealt
+    // Batch lanes (round 5; orbfe_set_lanes(ctx, 2..4)): WHOLE device-pointer batches are dealt
     // round-robin to streams the context owns, so that kernels of DIFFERENT batches overlap -- the regime below 16 frames per
     // call (the per-rank shard of BASELINE configs[3], a stereo pair, a single frame) is a chain of four latency-bound kernels,
-    // and two half-batches of one small call (the round-4 form, laneMode 1) only make every link of that chain smaller.
+    // and two half-batches of one small call (round 4's form, removed in round 6) only made every link of that chain smaller.
     // Measured with separate contexts first (profiles/r05_lanes_probe.txt: 8 x 1280x720, 0.084 ms per batch on one stream,
     // 0.052 / 0.045 / 0.043 with 2 / 3 / 4 contexts).  Each lane owns the per-batch device state (LaneBufs: the members of the same
     // names below, swapped into the context for the lane's turn, so every other entry point keeps reading "the last batch" from
@@ -216,7 +192,6 @@ struct orbfe_ctx : orbfe_geom_state {
     // lanes are busy.  The context's stream carries no kernels in this mode, only the ordering: a lane waits for the point of
     // the call on it (inputs ready), it waits for the lane's K-PYR (inputs consumed: a caller may refill the images in stream
     // order, as with one lane), and for whole lanes only at the joins.
-    int laneMode = 0;            // 0 = whole batches per lane, 1 = two half-batches of one call (lanes == 2 only; ORBFE_LANE_MODE=split)
     struct LaneBufs {
         DevBuf<uint8_t> d_pyr;
         DevBuf<uint32_t> d_cand, d_keys, d_lvlKp, d_lvlPre;
@@ -373,10 +348,6 @@ int lane_join(orbfe_ctx* c)
         HIP_TRY(hipStreamWaitEvent(c->stream, L.evJoin, 0));
         L.pending = false;
     }
-    if (!c->lanePending) return 0;
-    HIP_TRY(hipEventRecord(c->evLaneJoin, c->laneStream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->evLaneJoin, 0));
-    c->lanePending = false;
     return 0;
 }
 // ... and the host: before buffers are freed / tables replaced / a stream is given up
@@ -388,12 +359,10 @@ void lane_quiesce(orbfe_ctx* c)
         if (c->lane[k].pairStream) (void)hipStreamSynchronize(c->lane[k].pairStream);
         c->lane[k].pending = c->lane[k].pendingPair = false;
     }
-    if (c->laneStream) (void)hipStreamSynchronize(c->laneStream);
-    c->lanePending = false;
 }
 bool lanes_busy(const orbfe_ctx* c)
 {
-    bool any = c->lanePending;
+    bool any = false;
     for (int k = 0; k < ORBFE_MAX_LANES; k++) any = any || c->lane[k].pending || c->lane[k].pendingPair;
     return any;
 }
@@ -438,7 +407,7 @@ void lanes_invalidate_caps(orbfe_ctx* c)
 // stream of that priority in the process, and two lanes in one queue serialise (three contexts on normal-priority streams
 // beside torch's: 0.063 ms per 8 x 1280x720 batch against 0.045 with GPU_MAX_HW_QUEUES=8, profiles/r05_lanes_probe.txt).
 // Priorities have queues of their own, so the lanes live in the LOWEST class, where nothing else of the process does
-// (ORBFE_LANE_PRIOS="1,1,1,1": 1 = lowest, 0 = normal, -1 = highest; measured on that workload: three lanes 0.0452 ms per batch
+// (1 = lowest, 0 = normal, -1 = highest; measured on that workload: three lanes 0.0452 ms per batch
 // all lowest, 0.0432 as normal / lowest / highest, 0.0620 all normal; four lanes 0.0436 all lowest, 0.0555 with a second
 // normal one).  The mixed form is 4 % faster on an otherwise idle process but puts a lane into the class of orbfe_mc's
 // collective stream (highest): behind a one-rank RCCL exchange three mixed lanes took 0.070 ms per batch, two took 0.055.
@@ -451,14 +420,6 @@ int batch_lane_setup(orbfe_ctx* c)
     int prios[ORBFE_MAX_LANES] = {1, 1, 1, 1};
     if (c->exchangeHint) { // orbfe_mc_*: see the end of the comment above
         prios[0] = prios[2] = 0;
-    }
-    if (const char* e = getenv("ORBFE_LANE_PRIOS")) {
-        int k = 0;
-        for (const char* p = e; *p && k < ORBFE_MAX_LANES; k++) {
-            prios[k] = atoi(p);
-            while (*p && *p != ',') p++;
-            if (*p == ',') p++;
-        }
     }
     int least = 0, greatest = 0;
     const bool ranged = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
@@ -474,29 +435,6 @@ int batch_lane_setup(orbfe_ctx* c)
         HIP_TRY(hipEventCreateWithFlags(&L.evRead, hipEventDisableTiming));
     }
     if (!c->evBatchFork) HIP_TRY(hipEventCreateWithFlags(&c->evBatchFork, hipEventDisableTiming));
-    return 0;
-}
-int lane_setup(orbfe_ctx* c)
-{
-    if (c->laneStream) return 0;
-    {
-        // The second lane runs on a stream of the LOWEST priority (ORBFE_LANE_PRIO: 1 = lowest, the default; 0 = normal;
-        // -1 = highest).  Priorities have hardware queues of their own, while the streams of one priority are dealt round-robin
-        // to four queues (GPU_MAX_HW_QUEUES): on a normal-priority stream the lane can land in a queue behind another stream's
-        // event wait -- with the all-gather's stream of orbfe_mc_* in the process it did: 0.262 ms per step instead of 0.175.
-        // Measured, 64 x 752x480 (profiles/r04_lane_priority.txt): lowest 0.1685, normal 0.1701, highest 0.1809 ms per step;
-        // behind a one-rank RCCL exchange: lowest 0.1724, normal 0.1803, highest 0.1748.
-        int prio = 1, least = 0, greatest = 0;
-        if (const char* e = getenv("ORBFE_LANE_PRIO")) prio = atoi(e);
-        if (prio != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
-            hipStreamCreateWithPriority(&c->laneStream, hipStreamNonBlocking, prio < 0 ? greatest : least) == hipSuccess) {
-        } else {
-            (void)hipGetLastError();
-            HIP_TRY(hipStreamCreateWithFlags(&c->laneStream, hipStreamNonBlocking));
-        }
-    }
-    HIP_TRY(hipEventCreateWithFlags(&c->evLaneFork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evLaneJoin, hipEventDisableTiming));
     return 0;
 }
 
@@ -687,8 +625,6 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
         c->fastLdsBytes = align_up((size_t)2 * c->fastTileBytes - (size_t)4 * c->fastPitch + 8 * (size_t)c->fastBmWords +
                                        2 * (size_t)std::max(maxZone, 1), 16);
         int nt = maxZone <= 128 * 64 ? 128 : 256; // 128 measured fastest (198 us vs 257 @64, 234 @256; 64x 752x480)
-        if (c->fastThreadsOverride == 64 || c->fastThreadsOverride == 128 || c->fastThreadsOverride == 256)
-            nt = c->fastThreadsOverride; // ORBFE_FAST_THREADS: tuning experiments
         c->fc.clear();
         c->fastPat.clear();
         std::vector<std::pair<int, int>> patKeys; // (cw, ox) of the patterns built so far
@@ -732,58 +668,6 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             c->fc.push_back(f);
         }
         c->fastThreads = nt;
-        // ---- runs of cells (k_fast_runs): every cell row of every level is cut into runs of as many cells as fit the
-        // kernel's compile-time tile pitch (ORBFE_FASTR_PD dwords), balanced
-        c->fr.clear();
-        int maxRows = 1;
-        for (int l = 0; l < nl; l++) {
-            const OrbLevelGeom& L = c->lg[l];
-            int i0 = L.cellBase;
-            const int iEnd = L.cellBase + L.nCells;
-            while (i0 < iEnd) {
-                int i1 = i0;
-                while (i1 < iEnd && c->cg[i1].iniY == c->cg[i0].iniY) i1++;
-                const int ncRow = i1 - i0;
-                // tile width of a run of n cells: ox + (n - 1) wCell + cw(last) < 4 PD (phase A reads one dword past the zone)
-                int nmax = std::min(ORBFE_FAST_RUN_MAXC, std::max(1, (4 * ORBFE_FASTR_PD - 10) / std::max(L.wCell, 1)));
-                const int nRunsRow = (ncRow + nmax - 1) / nmax;
-                for (int rr = 0; rr < nRunsRow; rr++) {
-                    const int a = i0 + (int)((long)ncRow * rr / nRunsRow), b = i0 + (int)((long)ncRow * (rr + 1) / nRunsRow);
-                    const OrbCellGeom &g0 = c->cg[a], &g1 = c->cg[b - 1];
-                    const int n = b - a, ox = g0.iniX & 3;
-                    const int tw = ox + (g1.iniX + g1.cw - g0.iniX);
-                    if (tw >= 4 * ORBFE_FASTR_PD || tw > 1023 || g0.ch > 255) return ORBFE_ERR_ARGS; // (cannot happen: cw <= 75)
-                    const int zwL = g1.cw - 6, zwF = n > 1 ? g0.cw - 6 : zwL;
-                    OrbFastRun f;
-                    f.gOff = g0.roiOff + (uint32_t)g0.iniY * (uint32_t)g0.pitch + (uint32_t)(g0.iniX - ox);
-                    f.pitch = (uint32_t)g0.pitch;
-                    f.dims = (uint32_t)tw | ((uint32_t)g0.ch << 10) | ((uint32_t)ox << 18) | ((uint32_t)n << 20);
-                    f.off = (uint32_t)(uint16_t)g0.offX | ((uint32_t)(uint16_t)g0.offY << 16);
-                    f.cell0 = (uint32_t)a;
-                    f.slotBase = (uint32_t)g0.slotBase;
-                    f.zw = (uint32_t)std::max(zwF, 0) | ((uint32_t)std::max(zwL, 0) << 16);
-                    f.cap = (uint32_t)(n > 1 ? g0.slotCap : g1.slotCap) | ((uint32_t)g1.slotCap << 16);
-                    f.mZw = recip32((unsigned)std::max(zwF, 1));
-                    const int txLo = 3 + ox, txHi = tw - 4;
-                    const int ndz = std::max((txHi >> 2) - (txLo >> 2) + 1, 1);
-                    f.ndz = (uint32_t)ndz;
-                    f.mNdz = recip32((unsigned)ndz);
-                    f.pad = 0;
-                    for (int k = a; k < b; k++) // (what the kernel's slot / zone arithmetic relies on)
-                        if (c->cg[k].slotBase != g0.slotBase + (k - a) * g0.slotCap || (k < b - 1 && c->cg[k].cw - 6 != zwF) ||
-                            c->cg[k].ch != g0.ch || c->cg[k].iniX != g0.iniX + (k - a) * L.wCell)
-                            return ORBFE_ERR_ARGS;
-                    c->fr.push_back(f);
-                    maxRows = std::max<int>(maxRows, g0.ch);
-                }
-                i0 = i1;
-            }
-        }
-        c->fastRunTileBytes = (int)(align_up((size_t)maxRows, 4) * 4 * ORBFE_FASTR_PD);
-        c->fastRunBmW = (int)align_up(((size_t)std::max(maxZone, 1) + 31) / 32, 4);
-        c->fastRunLdsBytes = align_up((size_t)2 * c->fastRunTileBytes - (size_t)16 * ORBFE_FASTR_PD +
-                                          8 * (size_t)ORBFE_FAST_RUN_MAXC * c->fastRunBmW +
-                                          2 * ((size_t)ORBFE_FASTR_QCAP + ORBFE_FASTR_CQ), 16);
     }
     // K-QT: a level's node tables take 24 ints per list entry.  Levels whose tables fit a workgroup's LDS (160 KB) run the
     // LDS instantiation; larger ones (round 4: nfeatures above ~7800, e.g. the 5 x nFeatures initialisation extractor of
@@ -791,15 +675,6 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
     if (maxKp > 65535) return ORBFE_ERR_NFEATURES; // keypoint slots / list positions are packed in 16 bits
     c->qtSmall.clear();
     c->qtBig.clear();
-    c->qtWide.clear();
-    // A level of more than 512 cells (level 0 of a 1280x720 or 1024x1024 frame) does not fit the one-chunk gather of a 512-thread
-    // workgroup: separate count pass, serial binary searches, keys in LDS instead of registers in every pass.  ORBFE_QT_WIDE=1
-    // gives the images that have such a level 1024-thread workgroups (one chunk of up to 1024 cells, four keys per thread in
-    // registers up to 4096 candidates; k_octree<false, 1024>, bit-identical).  MEASURED AND NOT THE DEFAULT (round 5,
-    // profiles/r05_qt_wide.txt): K-QT 25.9 -> 24.1 us on 8 x 1280x720 (the step with three lanes: 0.0450 -> 0.0459 ms),
-    // 27.8 -> 40.5 us on 64 x 1280x720 (512 workgroups of sixteen wavefronts no longer fit the chip at once), a 1024^2 stereo
-    // frame 0.359 -> 0.336 ms on one box: the level-0 chain is long because it holds 4000 keys, not because of the gather's form.
-    const bool wideOk = getenv("ORBFE_QT_WIDE") && atoi(getenv("ORBFE_QT_WIDE")) != 0;
     int maxLCsmall = 0, maxLCbig = 0;
     const int ldsNodeBudget = (160 * 1024 - 64 * (int)sizeof(int)) / (24 * (int)sizeof(int)); // list entries per workgroup
     int forceBig = -1;
@@ -810,16 +685,9 @@ int build_geometry(orbfe_ctx* c, int rows, int cols, std::vector<OrbResizeX>& xt
             c->qtBig.push_back(l);
             maxLCbig = std::max(maxLCbig, LC);
         } else {
-            if (wideOk && c->lg[l].nCells > QT_THREADS && c->lg[l].nCells <= 1024) c->qtWide.push_back(l);
-            else c->qtSmall.push_back(l);
+            c->qtSmall.push_back(l);
             maxLCsmall = std::max(maxLCsmall, LC);
         }
-    }
-    // (one launch for all of them: the levels' chains run side by side, and a second launch behind the wide one made K-QT
-    // 42 us instead of 26 -- the other levels are roughly indifferent to the workgroup size: 0.0446 / 0.045 ms per 752x480 frame)
-    if (!c->qtWide.empty()) {
-        c->qtWide.insert(c->qtWide.end(), c->qtSmall.begin(), c->qtSmall.end());
-        c->qtSmall.clear();
     }
     c->qtKeyOff = 64 + std::max(24 * maxLCsmall, 2048); // ints (the gather uses 2 x 1024 ints of the array area)
     c->qtLdsBytes = sizeof(int) * (size_t)c->qtKeyOff;
@@ -892,7 +760,6 @@ void build_pyr_ranges(int nlevels, const std::vector<int>& extent, const std::ve
 // pyramid from 18.1 to 13.6 us (tile 16: 14.5, 20: 16.5, 32: 22.1).
 int pyr_tile_for(int nimg)
 {
-    if (const char* e = getenv("ORBFE_PYR_TILE")) return std::min(64, std::max(8, atoi(e)));
     return nimg <= 4 ? 12 : ORBFE_PYR_TILE;
 }
 
@@ -937,7 +804,6 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     if ((r = c->d_lg.ensure(c->lg.size())) < 0) return r;
     if ((r = c->d_cg.ensure(c->cg.size())) < 0) return r;
     if ((r = c->d_fc.ensure(c->fc.size())) < 0) return r;
-    if ((r = c->d_fr.ensure(std::max<size_t>(c->fr.size(), 1))) < 0) return r;
     if ((r = c->d_fastPat.ensure(std::max<size_t>(c->fastPat.size(), 1))) < 0) return r;
     if ((r = c->d_ds.ensure(std::max<size_t>(c->kpStride, 1))) < 0) return r;
     if ((r = c->d_xtab.ensure(std::max<size_t>(xtab.size(), 1))) < 0) return r;
@@ -947,7 +813,6 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
     HIP_TRY(hipMemcpy(c->d_lg.p, c->lg.data(), c->lg.size() * sizeof(OrbLevelGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cg.p, c->cg.data(), c->cg.size() * sizeof(OrbCellGeom), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_fc.p, c->fc.data(), c->fc.size() * sizeof(OrbFastCell), hipMemcpyHostToDevice));
-    if (!c->fr.empty()) HIP_TRY(hipMemcpy(c->d_fr.p, c->fr.data(), c->fr.size() * sizeof(OrbFastRun), hipMemcpyHostToDevice));
     if (!c->fastPat.empty())
         HIP_TRY(hipMemcpy(c->d_fastPat.p, c->fastPat.data(), c->fastPat.size() * sizeof(uint2), hipMemcpyHostToDevice));
     {
@@ -1087,13 +952,10 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
             HIP_TRY(hipMemcpy(c->d_pyrRecs.p, recs.data(), recs.size(), hipMemcpyHostToDevice));
             c->pyrLdsBytes = (size_t)c->pyrBuf0 + c->pyrBuf1 + recBytes;
         }
-        c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk &&
-                      getenv("ORBFE_PYR_UNFUSED") == nullptr;
+        c->pyrFused = c->pyrLdsBytes <= 64 * 1024 && mx0 <= 1024 && mx1 <= 1024 && c->pyrWeightsOk;
     }
     if (c->qtLdsBytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, QT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)c->qtLdsBytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)c->qtLdsBytes));
     }
     c->rows = rows;
@@ -1575,41 +1437,16 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
     // 16-B header of the fix list = {fragile count, error flag, 0, 0}.  The fused pyramid kernel clears it
     // (first command of the batch on this stream); the other configurations need a memset command.
     int32_t* const d_hdr = reinterpret_cast<int32_t*>(c->d_fix.p);
-    // Two lanes (see orbfe_ctx::lanes): halves that are multiples of 8 images where possible (whole images per XCD)
-    int laneSplit = ((nimg / 2 + 7) / 8) * 8;
-    if (laneSplit >= nimg) laneSplit = nimg / 2;
-    if (c->laneSplitPct > 0) { // ORBFE_LANE_SPLIT (tuning): per cent of the batch on the context's own stream
-        laneSplit = std::min(nimg - 1, std::max(1, (nimg * c->laneSplitPct / 100 + 4) / 8 * 8));
-    }
-    const bool useLanes = allowLanes && c->lanes == 2 && c->laneMode == 1 && nimg >= c->lanesMin && c->pyrFused && !hostTrigCheck &&
-                          !mirror && !d_errOut && c->nStreams == 1;
-    if (c->lanePending && !(useLanes && c->laneSplit == laneSplit && c->laneImgs == nimg)) {
-        if ((r = lane_join(c)) < 0) return r; // another shape of work: first order this stream after the second lane
-    }
-    if (useLanes && (r = lane_setup(c)) < 0) return r;
-    const bool kernelClearsHdr = c->pyrFused && !(c->nStreams > 1 && nimg > 1);
+    (void)allowLanes; // (round 4's split of one call into two half-batches left with round 6; lanes are whole batches per stream)
+    const bool kernelClearsHdr = c->pyrFused;
     if (!kernelClearsHdr) HIP_TRY(hipMemsetAsync(c->d_fix.p, 0, sizeof(int4), s));
-    c->recNow = !useLanes && !c->runStream && c->profile && c->evReady && c->profSeen % c->profEvery == 0; // (stage events: one stream only)
+    c->recNow = !c->runStream && c->profile && c->evReady && c->profSeen % c->profEvery == 0; // (stage events: one stream only)
     rec(c, 0);
-    // Sub-batches on separate streams (ORBFE_STREAMS > 1): the image pipelines are independent, so the
-    // latency-bound stages of one sub-batch overlap with the issue-bound stages of another.  Stage
-    // events are only meaningful with one stream.
-    const int nsub = useLanes ? 2 : (c->pyrFused && c->nStreams > 1) ? std::min(c->nStreams, nimg) : 1;
-    if (useLanes) { // the second lane starts no earlier than this point of the context's stream (inputs, taps, tables)
-        HIP_TRY(hipEventRecord(c->evLaneFork, s));
-        HIP_TRY(hipStreamWaitEvent(c->laneStream, c->evLaneFork, 0));
-    } else if (nsub > 1) {
-        HIP_TRY(hipEventRecord(c->evFork, s));
-        for (int k = 0; k < nsub; k++) HIP_TRY(hipStreamWaitEvent(c->sub[k], c->evFork, 0));
-    }
-    for (int k = 0; k < nsub; k++) {
-        const int i0 = useLanes ? (k ? laneSplit : 0) : (int)((long)nimg * k / nsub);
-        const int i1 = useLanes ? (k ? nimg : laneSplit) : (int)((long)nimg * (k + 1) / nsub);
-        const int ni = i1 - i0;
-        if (ni <= 0) continue;
-        hipStream_t q = useLanes ? (k ? c->laneStream : s) : nsub > 1 ? c->sub[k] : s;
-        // (each lane has a status header of its own: its K-PYR clears it, its K-QT raises the error word in it)
-        int32_t* const d_hdrK = useLanes ? reinterpret_cast<int32_t*>(c->d_fix.p + k) : d_hdr;
+    const int nsub = 1;
+    {
+        const int k = 0, i0 = 0, ni = nimg;
+        hipStream_t q = s;
+        int32_t* const d_hdrK = d_hdr;
         // K-FAST's order: whole images per XCD when the batch fills the 8 XCDs evenly enough (<= 1/8 idle), else groups of
         // G neighbouring cells per XCD
         const int perXcd = (ni + 7) / 8;
@@ -1655,13 +1492,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
         else if (c->fastPitch == 68) ORBFE_FAST_LAUNCH(NT, 17); \
         else ORBFE_FAST_LAUNCH(NT, 21);                  \
     } while (0)
-            if (c->fastRuns && c->fastRunLdsBytes <= 64 * 1024) {
-                const int nRuns = (int)c->fr.size();
-                const dim3 rgrid = byImage ? dim3((unsigned)(8 * nRuns), (unsigned)perXcd) : dim3((unsigned)nRuns, (unsigned)ni);
-                hipLaunchKernelGGL((k_fast_runs<ORBFE_FASTR_NT, ORBFE_FASTR_PD>), rgrid, dim3(ORBFE_FASTR_NT), c->fastRunLdsBytes, q,
-                                   c->d_pyr.p, c->pyrStride, c->d_fr.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells,
-                                   nRuns, c->iniThFAST, c->minThFAST, c->fastRunTileBytes, c->fastRunBmW, byImage ? 1 : 0, i0, ni);
-            } else if (c->fastThreads == 64) ORBFE_FAST_PD(64);
+            if (c->fastThreads == 64) ORBFE_FAST_PD(64);
             else if (c->fastThreads == 128) ORBFE_FAST_PD(128);
             else ORBFE_FAST_PD(256);
 #undef ORBFE_FAST_PD
@@ -1677,16 +1508,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 lapIn.n = lapInlineN;
                 for (int i = 0; i < 4; i++) lapIn.v[i] = c->lapInline[i];
             }
-            const unsigned nS = (unsigned)c->qtSmall.size(), nB = (unsigned)c->qtBig.size(), nW = (unsigned)c->qtWide.size();
-            if (nW) { // (first: the longest chains of the batch)
-                OrbQtLevels lw = {};
-                for (size_t i = 0; i < c->qtWide.size(); i++) lw.v[i] = c->qtWide[i];
-                hipLaunchKernelGGL((k_octree<false, 1024>), ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nW) : dim3(nW, (unsigned)ni),
-                                   dim3(1024), c->qtLdsBytes, q, c->d_lg.p,
-                                   c->d_cg.p, c->d_cand.p, c->candStride, c->d_cellCount.p, c->nCells, c->d_keys.p,
-                                   c->d_keyNode.p, c->keyStride, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl, d_hdrK + 1, i0,
-                                   c->qtKeyOff, c->qtKeyCap, d_lap, c->d_lvlPre.p, lw, (int*)nullptr, (size_t)0, lapIn);
-            }
+            const unsigned nS = (unsigned)c->qtSmall.size(), nB = (unsigned)c->qtBig.size();
             if (nS)
                 hipLaunchKernelGGL((k_octree<false, QT_THREADS>), ORBFE_QT_IMG_MAJOR ? dim3((unsigned)ni, nS) : dim3(nS, (unsigned)ni),
                                    dim3(QT_THREADS), c->qtLdsBytes, q, c->d_lg.p,
@@ -1762,23 +1584,9 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             }
 #undef ORBFE_DESC_LAUNCH
         }
-        if (nsub > 1 && !useLanes) {
-            HIP_TRY(hipEventRecord(c->evJoin[k], q));
-            HIP_TRY(hipStreamWaitEvent(s, c->evJoin[k], 0));
-        }
-    }
-    if (useLanes) {
-        c->lanePending = true;
-        c->laneSplit = laneSplit;
-        c->laneImgs = nimg;
-    } else if (nsub > 1) {
-        for (int i = 1; i <= 4; i++) rec(c, i);
-        // every sub-batch has joined: only now is the error word final
-        if (d_errOut) HIP_TRY(hipMemcpyAsync(d_errOut, d_hdr + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     }
     rec(c, 5);
     c->lastImgs = nimg;
-    c->lastLanes = useLanes;
     c->lastKps = d_kps;
     c->lastDesc = d_desc;
     c->lastN = d_n;
@@ -2150,7 +1958,7 @@ int host_submit_impl(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int row
     // (not with sub-batches on several streams, ORBFE_STREAMS > 1: the mirrored error word is written by the first sub-batch's
     // K-DESC, before the other sub-batches' K-QT have run -- such a call takes the download command, which is queued behind
     // the join of all sub-batches)
-    const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs && !(c->nStreams > 1 && nimg > 1);
+    const bool mirrorOut = c->zeroCopy && !pipelined && nimg <= c->mirrorMaxImgs;
     // ... and the IMAGES of such a call come in through a kernel that reads the page-locked source in 16-byte pieces
     // (k_upload): no copy engine, hence no queue hand-over, between the host call and the first kernel.
     // (Measured and not kept: staging and uploading a pageable image band by band so that the upload of one band overlaps
@@ -2474,29 +2282,9 @@ int orbfe_create(orbfe_ctx** out, int nfeatures, float scaleFactor, int nlevels,
     c->device = device;
     init_tables(c);
     if (const char* e = getenv("ORBFE_ATAN_FMA")) c->atanFma = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_FAST_RUNS")) c->fastRuns = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_FAST_THREADS")) c->fastThreadsOverride = atoi(e);
-    if (const char* e = getenv("ORBFE_FAST_GROUP")) c->fastXcdGroup = std::max(0, atoi(e));
-    if (const char* e = getenv("ORBFE_FAST_BY_IMAGE")) c->fastByImage = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_XCD_AFFINE")) c->xcdAffine = atoi(e);
-    if (const char* e = getenv("ORBFE_ZEROCOPY")) c->zeroCopy = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_UPLOAD_KERNEL")) c->uploadKernel = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_MIRROR_MAX")) c->mirrorMaxImgs = std::max(0, atoi(e));
     if (const char* e = getenv("ORBFE_SPIN")) c->spinWait = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_STREAMS")) c->nStreams = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("ORBFE_LANES")) c->lanes = std::min(ORBFE_MAX_LANES, std::max(1, atoi(e)));
-    if (const char* e = getenv("ORBFE_LANE_MODE")) c->laneMode = (!strcmp(e, "split") || atoi(e) == 1) && c->lanes <= 2 ? 1 : 0;
     if (const char* e = getenv("ORBFE_LANES_INPUT_GUARD")) c->inputGuard = atoi(e) != 0;
-    if (const char* e = getenv("ORBFE_LANES_FORK_ALWAYS")) c->forkSkipIdle = atoi(e) == 0;
-    if (const char* e = getenv("ORBFE_LANES_MIN")) c->lanesMin = std::max(2, atoi(e));
-    if (const char* e = getenv("ORBFE_LANE_SPLIT")) c->laneSplitPct = std::min(95, std::max(0, atoi(e)));
-    if (c->nStreams > 1) {
-        bool ok = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < c->nStreams && ok; k++)
-            ok = hipStreamCreateWithFlags(&c->sub[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) c->nStreams = 1;
-    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ORBFE_ERR_NODEV;
@@ -2543,10 +2331,6 @@ void orbfe_destroy(orbfe_ctx* c)
     if (c->evReady)
         for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->evFork) (void)hipEventDestroy(c->evFork);
-    if (c->evLaneFork) (void)hipEventDestroy(c->evLaneFork);
-    if (c->evLaneJoin) (void)hipEventDestroy(c->evLaneJoin);
-    if (c->laneStream) (void)hipStreamDestroy(c->laneStream);
     for (int k = 0; k < ORBFE_MAX_LANES; k++) {
         orbfe_ctx::Lane& L = c->lane[k];
         orbfe_ctx::LaneBufs& b = L.parked; // (the current lane's buffers are the context's own members, released above)
@@ -2559,10 +2343,6 @@ void orbfe_destroy(orbfe_ctx* c)
         if (L.pairStream) (void)hipStreamDestroy(L.pairStream);
     }
     if (c->evBatchFork) (void)hipEventDestroy(c->evBatchFork);
-    for (int k = 0; k < 8; k++) {
-        if (c->sub[k]) (void)hipStreamDestroy(c->sub[k]);
-        if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
-    }
     delete c;
 }
 
@@ -2690,16 +2470,13 @@ int orbfe_sync(orbfe_ctx* c)
         }
         L.pending = false;
     }
-    if (c->laneStream) HIP_TRY(hipStreamSynchronize(c->laneStream));
-    c->lanePending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (laneErr) return ORBFE_ERR_STATE;
     if (c->d_fix.p && c->lastImgs > 0) { // the error word of the last batch (k_octree raises it, nothing else does)
         int r = c->h_fix.ensure(2);
         if (r < 0) return r;
-        const bool two = c->lastLanes && c->d_fix.n >= 2; // (a two-lane batch has a status header per lane)
-        HIP_TRY(hipMemcpy(c->h_fix.p, c->d_fix.p, (two ? 2 : 1) * sizeof(int4), hipMemcpyDeviceToHost));
-        if (c->h_fix.p[0].y != 0 || (two && c->h_fix.p[1].y != 0)) return ORBFE_ERR_STATE;
+        HIP_TRY(hipMemcpy(c->h_fix.p, c->d_fix.p, sizeof(int4), hipMemcpyDeviceToHost));
+        if (c->h_fix.p[0].y != 0) return ORBFE_ERR_STATE;
     }
     return 0;
 }
@@ -2714,13 +2491,13 @@ int orbfe_extract_batch_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, in
     if (c->pairSubmitted != c->pairRetired) return ORBFE_ERR_STATE; // stereo frames in flight hold the lanes' buffers
     HIP_TRY(hipSetDevice(c->device));
     int r;
-    // Batch lanes (orbfe_ctx::laneMode 0): this call goes, whole, to the next lane's stream with that lane's buffers
-    const bool batchLanes = c->lanes >= 2 && c->laneMode == 0 && !c->kb8On && c->nStreams == 1;
+    // Batch lanes: this call goes, whole, to the next lane's stream with that lane's buffers
+    const bool batchLanes = c->lanes >= 2 && !c->kb8On;
     if (batchLanes) {
         if ((r = batch_lane_setup(c)) < 0) return r;
         if (c->laneNext >= c->lanes) c->laneNext = 0;
         lane_select(c, c->laneNext);
-    } else if (lanes_busy(c) && !(c->lanes == 2 && c->laneMode == 1)) {
+    } else if (lanes_busy(c)) {
         if ((r = lane_join(c)) < 0) return r; // a one-stream call behind lane calls
     }
     if ((r = ensure_geometry(c, rows, cols, nimg)) < 0) return r;
@@ -2780,7 +2557,6 @@ int orbfe_set_lanes(orbfe_ctx* c, int lanes)
     int r = lane_join(c);
     if (r < 0) return r;
     c->lanes = lanes;
-    if (lanes > 2) c->laneMode = 0; // (half-batches exist for two lanes only)
     c->laneNext = 0;
     return 0;
 }
@@ -2805,12 +2581,9 @@ int orbfe_set_lane_input_guard(orbfe_ctx* c, int on)
 
 int orbfe_set_lane_mode(orbfe_ctx* c, int mode)
 {
-    if (!c || (mode != ORBFE_LANES_BATCH && mode != ORBFE_LANES_SPLIT)) return ORBFE_ERR_ARGS;
-    if (mode == ORBFE_LANES_SPLIT && c->lanes > 2) return ORBFE_ERR_ARGS;
-    HIP_TRY(hipSetDevice(c->device));
-    int r = lane_join(c);
-    if (r < 0) return r;
-    c->laneMode = mode;
+    // (ORBFE_LANES_SPLIT -- round 4's two half-batches of one call -- was measured slower than whole batches per lane in round 5
+    // and left with round 6; the entry point stays so that callers which select ORBFE_LANES_BATCH explicitly keep linking)
+    if (!c || mode != ORBFE_LANES_BATCH) return ORBFE_ERR_ARGS;
     return 0;
 }
 
@@ -2830,10 +2603,7 @@ int orbfe_lanes_record(orbfe_ctx* c, void* hip_event)
         HIP_TRY(hipEventRecord((hipEvent_t)hip_event, c->lane[c->laneLast].stream));
         return 1;
     }
-    if (!c->lanePending) return 0;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventRecord((hipEvent_t)hip_event, c->laneStream));
-    return 1;
+    return 0;
 }
 
 // ---- pinned host memory ---------------------------------------------------------------------------
@@ -2897,11 +2667,8 @@ int orbfe_extract_batch(orbfe_ctx* c, int nimg, const uint8_t* const* imgs, int 
     // kernels run on takes 0.8 ms instead of the 0.41 ms the DMA engine needs on a stream of its own.
     // (Round 5: not for a frame or a PAIR however large -- two 1024 x 1024 fisheye images are exactly 2 MB and took the batch
     // form: copy engine 44 us + 16 us of hand-over instead of the upload kernel's 32, a download command instead of the mirror.
-    // ORBFE_COPY_STREAMS_FROM=2 restores that for A/B.)
-    static const int copyStreamsFrom = [] {
-        const char* e = getenv("ORBFE_COPY_STREAMS_FROM");
-        return e ? std::max(1, atoi(e)) : 3;
-    }();
+    // Measured both ways, profiles/r05_c5_stages.txt.)
+    const int copyStreamsFrom = 3;
     const bool ownCopyStreams = rows > 0 && cols > 0 && nimg >= copyStreamsFrom &&
                                 (size_t)nimg * (size_t)rows * (size_t)cols >= (2u << 20);
     const int r = host_submit(c, nimg, imgs, rows, cols, stride, lap, kps, desc, cap_per_img, n_out, mono_out, ownCopyStreams,
@@ -3253,7 +3020,7 @@ int orbfe_extract_stereo_pair_submit(orbfe_ctx* c, const uint8_t* imgL, const ui
 {
     if (!c || !imgL || !imgR || !kps || !desc || !n_out || !uRight || !depth || !(mb > 0)) return ORBFE_ERR_ARGS;
     if (c->slotSubmitted != c->slotRetired) return ORBFE_ERR_STATE; // (the two-slot pipeline shares the slots)
-    if (c->kb8On || c->nStreams > 1) return ORBFE_ERR_STATE;
+    if (c->kb8On) return ORBFE_ERR_STATE;
     const int depthMax = std::max(1, std::min(c->lanes, ORBFE_MAX_LANES));
     if (c->pairSubmitted - c->pairRetired >= depthMax) return ORBFE_ERR_STATE; // every lane holds a frame: wait for one first
     if (depthMax == 1) { // a pipeline of one IS the blocking call (measured: a lone frame on a lane's stream is no faster)

@@ -466,16 +466,6 @@ __device__ unsigned long long g_fastTimes[4096 * 16];
 #define FT_BEGIN() do { } while (0)
 #define FT(k) do { } while (0)
 #endif
-#ifndef ORBFE_FAST_CORNERQ
-#define ORBFE_FAST_CORNERQ 0 /* 0: round 3's form, the NMS and the output walk the survivor queue (A/B) */
-#endif
-#ifndef ORBFE_FAST_PRIO
-#define ORBFE_FAST_PRIO 0 /* bit 0: phase A, bit 1: phase B run at raised wave priority (s_setprio; A/B) */
-#endif
-#ifndef ORBFE_FAST_LDSDMA
-#define ORBFE_FAST_LDSDMA 0 /* 1: the tile goes from L2 into LDS with global_load_lds_dword (no staging registers, no ds_write);
-                                measured: 74.8-75.0 against 74.5-74.6 us, bit-identical results */
-#endif
 template <int NT, int PD>
 __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                               const OrbFastCell* __restrict__ cells, uint32_t* __restrict__ cand,
@@ -499,9 +489,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     int* const pre = reinterpret_cast<int*>(bm + bmWords);
     uint16_t* const queue = reinterpret_cast<uint16_t*>(pre + bmWords);
     __shared__ int qn[2]; // survivors of the pass at iniThFAST / at minThFAST
-#if ORBFE_FAST_CORNERQ
-    __shared__ int cqn[2]; // ... and its corners (round 4: the NMS and the output walk the corners only)
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware order (workgroups go round-robin over the 8 XCDs, each with its own L2).  gShift < 0: whole images per
@@ -531,10 +518,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     if (tid == 0) {
         qn[0] = 0;
         qn[1] = 0;
-#if ORBFE_FAST_CORNERQ
-        cqn[0] = 0;
-        cqn[1] = 0;
-#endif
     }
     // clear the score map and the bitmap (contiguous), 16 B per store
     for (int o = tid * 16; o < smapBytes + 4 * bmWords; o += NT * 16) *reinterpret_cast<uint4*>(smapStore + o) = make_uint4(0u, 0u, 0u, 0u);
@@ -548,24 +531,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         // row by one multiply-high against ceil(2^32 / PD) (exact for the few thousand items of a tile)
         constexpr uint32_t MPD = 0xFFFFFFFFu / (uint32_t)PD + 1u;
         const uint32_t delta = c.pitch - 4u * (uint32_t)PD;
-#if ORBFE_FAST_LDSDMA
-        // straight from L2 into LDS (global_load_lds_dword: lane l of a wavefront writes LDS dword base + l, which is exactly
-        // the flat layout): no staging registers, no ds_write.  A lane past the last item repeats the last item's address
-        // and lands in the tile's padding rows; past the tile's storage it is switched off.
-        const uint32_t tileDw = (uint32_t)tileBytes >> 2;
-        for (uint32_t b0 = 0; b0 < nItems; b0 += 5u * NT) { // (wave-uniform trip count)
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const uint32_t i = b0 + (uint32_t)(k * NT) + (uint32_t)tid;
-                if (i < tileDw) {
-                    const uint32_t idx = min(i, last), row = __umulhi(idx, MPD);
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(gbase + (__umul24(row, delta) + 4u * idx)),
-                                                     T + (b0 + (uint32_t)(k * NT) + ((uint32_t)tid & ~63u)), 4, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         for (uint32_t i0 = (uint32_t)tid; i0 < nItems; i0 += 5u * NT) {
             uint32_t v[5], idx[5];
 #pragma unroll
@@ -577,7 +542,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
 #pragma unroll
             for (int k = 0; k < 5; k++) T[idx[k]] = v[k];
         }
-#endif
     }
     FT(1);
     __syncthreads();
@@ -598,9 +562,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
         // <= 254).  It lets ~a quarter more pixels through than the exact test would (they fail the exact score in phase
         // B), for 30 plain 32-bit operations per four pixels instead of 52.  At iniThFAST far fewer pixels survive it than
         // at minThFAST, so the usual cell scores a third of the pixels a single pass at min(iniTh, minTh) would.
-#if ORBFE_FAST_PRIO & 1
-        __builtin_amdgcn_s_setprio(2);
-#endif
         if (nz > 0) {
             const uint32_t Q = 0x3F3F3F3Fu;
             const int tb = (th + 1) >> 2;
@@ -638,50 +599,20 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
                 }
             }
         }
-#if ORBFE_FAST_PRIO & 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
         FT(3);
         __syncthreads();
         FT(4);
-#if ORBFE_FAST_PRIO & 2
-        __builtin_amdgcn_s_setprio(2);
-#endif
         // phase B: exact score of the survivors, all lanes busy; corners of this pass go to the score map
         const int nq = qn[pass];
-#if ORBFE_FAST_CORNERQ
-        // Round 4: 29 % of the survivors are corners (bench frames), yet the NMS and the output used to walk all of them.  The
-        // corners are collected at the TOP of the queue's own storage, growing downwards (one LDS atomic per corner lane):
-        // survivors occupy [0, nq), corners [nz - ncorners, nz), which cannot meet while nq <= nz / 2 (corners <= survivors).
-        // A denser cell keeps round 3's form (the NMS walks the survivors).
-        const bool compact = 2 * nq <= nz; // (uniform)
-        for (int qi = tid; qi < nq; qi += NT) {
-            const int pos = queue[qi];
-            const int sc = fast_score<P>(&tile[pos]);
-            if (sc >= th) {
-                smap[pos] = (uint8_t)sc;
-                if (compact) queue[nz - 1 - lds_add_per_lane(&cqn[pass], 1)] = (uint16_t)pos;
-            }
-        }
-        FT(5);
-        __syncthreads();
-        FT(6);
-        const int nw = compact ? cqn[pass] : nq;     // entries the NMS and the output walk ...
-        const int wBase = compact ? nz - 1 : 0, wDir = compact ? -1 : 1; // ... at queue[wBase + wDir * i]
-#else
         for (int qi = tid; qi < nq; qi += NT) {
             const int pos = queue[qi];
             const int sc = fast_score<P>(&tile[pos]);
             if (sc >= th) smap[pos] = (uint8_t)sc;
         }
-#if ORBFE_FAST_PRIO & 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
         FT(5);
         __syncthreads();
         FT(6);
         const int nw = nq, wBase = 0, wDir = 1;
-#endif
         // phase C: strict 8-neighbour NMS over the queue (an entry is a corner of this pass iff its score is >= th);
         // a kept entry is marked in place and sets its bit in the zone bitmap (row-major zone index)
         for (int qi = tid; qi < nw; qi += NT) {
@@ -746,335 +677,6 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t* __restrict__ p
     if (tid == 0) {
         unsigned long long* g = g_fastTimes + 16 * ((blockIdx.x + 977u * blockIdx.y) & 4095u);
         for (int k = 0; k < 10; k++) atomicAdd(&g[k], (unsigned long long)ftL[k]);
-        atomicAdd(&g[15], 1ull);
-    }
-#endif
-}
-
-// ------------------------------------------------------------ K-FAST, runs of cells (round 4)
-// "remove work, do not re-tune".  The per-cell kernel above spends its instructions where the counters say
-// (45.8 M vector + 18.1 M scalar wave-instructions per 64 frames = 38 lane-operations per pixel); this kernel keeps its phases
-// and changes the unit of work and what flows between the phases:
-//  * unit of work = a RUN of up to four cells of a cell row: one coalesced tile whose inner aprons are staged once instead
-//    of twice, one record / prologue / set of five barriers per ~5000 px instead of per ~1700; phase A's items are dealt flat
-//    over the run's zone (dword column x row), so the threads that the per-cell mapping leaves idle (8 of 128) and its
-//    half-used edge dwords (35 of 40 columns) mostly disappear;
-//  * ONE survivor queue per run: phase B scores the survivors of all its cells together, so its last round is short once
-//    per run, not once per cell (per-cell queues: 85 % of the lanes busy at 173 survivors per cell; pooled: 95 %);
-//  * only CORNERS go on: phase B appends the entries whose score reaches the threshold (29 % of the survivors) to a corner
-//    queue (one LDS atomic per corner lane), and the NMS and the ranked output walk ~50 entries per cell instead of ~173;
-//  * NMS is blind across the cell seams exactly like per-cell cv::FAST (src/ORBextractor.cc:808-828): a corner in a cell's
-//    first / last zone column ignores the three neighbours on the other side;
-//  * one rank space per cell: a bitmap per cell (cell-local row-major zone index), wavefront w prefix-sums cell w's bitmap.
-// The reference's second call (minThFAST where the first call returned nothing, :825-828) is a second pass over the columns
-// of exactly those cells, one cell after the other.  Capacities: the survivor queue holds QCAP entries -- a run whose phase A
-// finds more (dense texture) is redone in bands of rows that cannot overflow it; the corner queue holds CQ entries -- a run with
-// more corners takes the map-scanning forms of the NMS and the output (every pixel of the zone looked at), same results.
-// A first version of this kernel fused phases A and B per wavefront (survivors into a ring of the wavefront's own, scored 64 at
-// a time, no survivor queue and no barrier between the phases): bit-exact and 40 % SLOWER than the per-cell kernel (104 vs
-// 75 us) -- the per-iteration prefix sum over the lanes (six DPP steps) and the serial append -> score -> append chain cost
-// more than the barrier they replace.  DESIGN.md 7.4.
-// LDS: tile | score map (rows 2 .. rows-3) | per-cell bitmaps | their prefix sums | survivor queue | corner queue.
-#ifndef ORBFE_FASTR_CQ
-#define ORBFE_FASTR_CQ 1024
-#endif
-#ifndef ORBFE_FASTR_QCAP
-#define ORBFE_FASTR_QCAP 1536
-#endif
-#ifndef ORBFE_FASTR_NT
-#define ORBFE_FASTR_NT 256
-#endif
-#ifndef ORBFE_FASTR_PD
-#define ORBFE_FASTR_PD 39 /* tile pitch in dwords (odd): four 36-px cells + aprons */
-#endif
-template <int NT, int PD>
-__global__ __launch_bounds__(NT) void k_fast_runs(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
-                                                  const OrbFastRun* __restrict__ runs, uint32_t* __restrict__ cand,
-                                                  size_t candImgStride, int32_t* __restrict__ cellCount, int nCellsTotal,
-                                                  int nRuns, int iniTh, int minTh, int tileBytes /* rows * 4 PD, multiple of 16 */,
-                                                  int bmW /* bitmap words per cell, multiple of 4 */, int byImage, int imgBase,
-                                                  int nImg)
-{
-    constexpr int P = 4 * PD, NW = NT / 64, MAXC = ORBFE_FAST_RUN_MAXC, QCAP = ORBFE_FASTR_QCAP, CQ = ORBFE_FASTR_CQ;
-    extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
-    uint8_t* const tile = fast_lds;
-    const int smapBytes = tileBytes - 4 * P;
-    uint8_t* const smapStore = fast_lds + tileBytes;
-    uint8_t* const smap = smapStore - 2 * P; // virtual origin of row 0 (rows 2 .. rows-3 are stored)
-    uint32_t* const bm = reinterpret_cast<uint32_t*>(smapStore + smapBytes); // MAXC x bmW words
-    int* const pre = reinterpret_cast<int*>(bm + MAXC * bmW);                // MAXC x bmW
-    uint16_t* const queue = reinterpret_cast<uint16_t*>(pre + MAXC * bmW);   // QCAP
-    uint16_t* const cq = queue + QCAP;                                       // CQ
-    __shared__ int qnS[2]; // survivors of the current band (alternating, so that no clearing pass separates two bands)
-    __shared__ int cqn;
-    __shared__ int nkS[MAXC];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
-    int run, img;
-    if (byImage) { // whole images per XCD: image xcd + 8 y
-        run = slot;
-        img = xcd + 8 * (int)blockIdx.y;
-        if (img >= nImg) return;
-    } else {
-        run = (int)blockIdx.x;
-        img = (int)blockIdx.y;
-        if (run >= nRuns) return;
-    }
-    img += imgBase;
-    FT_BEGIN();
-    const OrbFastRun c = runs[run];
-#ifdef ORBFE_FAST_TIMING
-    asm volatile("" ::"s"(c.pitch)); // the record has arrived
-    FT(0);
-#endif
-    const int tw = (int)(c.dims & 0x3FFu), ch = (int)((c.dims >> 10) & 0xFFu), ox = (int)((c.dims >> 18) & 3u),
-              nc = (int)(c.dims >> 20);
-    const int zwF = (int)(c.zw & 0xFFFFu), zwL = (int)(c.zw >> 16), capF = (int)(c.cap & 0xFFFFu), capL = (int)(c.cap >> 16);
-    const uint8_t* const gbase = pyr + (size_t)img * pyrImgStride + c.gOff;
-    const int zh = ch - 6;
-    const int txLo = 3 + ox, txHi = tw - 4; // zone columns of the run in tile coordinates (inclusive)
-    int32_t* const cnt = cellCount + (size_t)img * nCellsTotal + c.cell0;
-    if (zh <= 0 || txHi < txLo) { // (a last cell row too low to hold a detection zone: the reference's FAST finds nothing there)
-        if (tid < nc) cnt[tid] = 0;
-        return;
-    }
-    if (tid == 0) {
-        qnS[0] = 0;
-        qnS[1] = 0;
-        cqn = 0;
-    }
-    for (int o = tid * 16; o < smapBytes + 4 * MAXC * bmW; o += NT * 16) *reinterpret_cast<uint4*>(smapStore + o) = make_uint4(0u, 0u, 0u, 0u);
-    {
-        // the tile, flat: tile dword i of the PD-pitched tile is LDS dword i; five loads in flight per thread
-        const uint32_t nItems = (uint32_t)ch * PD, last = nItems - 1u;
-        uint32_t* const T = reinterpret_cast<uint32_t*>(tile);
-        constexpr uint32_t MPD = 0xFFFFFFFFu / (uint32_t)PD + 1u;
-        const uint32_t delta = c.pitch - 4u * (uint32_t)PD;
-        for (uint32_t i0 = (uint32_t)tid; i0 < nItems; i0 += 5u * NT) {
-            uint32_t v[5], idx[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                idx[k] = min(i0 + (uint32_t)(k * NT), last);
-                const uint32_t row = __umulhi(idx[k], MPD);
-                v[k] = *reinterpret_cast<const uint32_t*>(gbase + (__umul24(row, delta) + 4u * idx[k]));
-            }
-#pragma unroll
-            for (int k = 0; k < 5; k++) T[idx[k]] = v[k];
-        }
-    }
-    FT(1);
-    __syncthreads();
-    FT(2);
-
-    uint32_t* const out0 = cand + (size_t)img * candImgStride + c.slotBase;
-    const uint32_t* const T = reinterpret_cast<const uint32_t*>(tile);
-    unsigned redo = 0; // cells of the second pass (bit j)
-    int th = iniTh;
-    int qsel = 0; // which of the two survivor counters the next band uses
-    for (int pass = 0;; pass++) {
-        const uint32_t Q = 0x3F3F3F3Fu;
-        const int tb = (th + 1) >> 2;
-        const uint32_t KH = (uint32_t)(tb - 1 + 0x80) * 0x01010101u, KL = (uint32_t)(0x80 - tb) * 0x01010101u;
-        // ---- phases A and B over a range of zone columns: the whole run in the first pass, one cell after the other of
-        // those that found nothing in the second
-        unsigned todo = pass == 0 ? 1u : redo;
-        while (todo) { // (uniform)
-            const int jr = __builtin_ctz(todo);
-            todo &= todo - 1u;
-            const int lo = pass == 0 ? txLo : txLo + jr * zwF;
-            const int hi = pass == 0 ? txHi : lo + (jr == nc - 1 ? zwL : zwF) - 1;
-            const int d0 = lo >> 2, nd = (hi >> 2) - d0 + 1; // dword columns of the range (<= 39)
-            // the masks of the range's first and last dword column (bit 7 of the bytes that are zone columns)
-            uint32_t mF = 0, mL = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if (4 * d0 + b >= lo && 4 * d0 + b <= hi) mF |= 0x80u << (8 * b);
-                if (4 * (d0 + nd - 1) + b >= lo && 4 * (d0 + nd - 1) + b <= hi) mL |= 0x80u << (8 * b);
-            }
-            // items = (row, dword column) pairs, flat: item i = row * nd + column; a thread's items are tid, tid + NT, ...
-            // (row, column) advance by (NT / nd, NT % nd) with a carry: no division in the loop
-            const uint32_t rcp = (uint32_t)((1u << 24) / (unsigned)nd) + 1u; // tid / nd exactly for tid < 2^9, nd < 64
-            const int stepR = (int)(((unsigned long long)NT * rcp) >> 24), stepD = NT - stepR * nd;
-            int bandRows = zh;
-            for (int rb = 0; rb < zh;) { // (uniform; one band unless the survivor queue overflowed)
-                const int rEnd = min(zh, rb + bandRows);
-                int* const qn = &qnS[qsel];
-                {
-                    int r = (int)(((uint32_t)tid * rcp) >> 24);
-                    int dz = tid - r * nd;
-                    r += rb;
-                    for (; r < rEnd;) {
-                        const int a = (r + 3) * PD + d0 + dz;
-                        const uint32_t vM = dz == 0 ? (nd == 1 ? (mF & mL) : mF) : dz == nd - 1 ? mL : 0x80808080u;
-                        const uint32_t C = T[a], Lf = T[a - 1], R = T[a + 1], U = T[a - 3 * PD], Dn = T[a + 3 * PD];
-                        const uint32_t Cq = (C >> 2) & Q, Uq = (U >> 2) & Q, Dq = (Dn >> 2) & Q;
-                        const uint32_t Lq = (__builtin_amdgcn_alignbyte(C, Lf, 1) >> 2) & Q;
-                        const uint32_t Rq = (__builtin_amdgcn_alignbyte(R, C, 3) >> 2) & Q;
-                        const uint32_t H = Cq + KH, L = Cq + KL;
-                        const uint32_t notBright = ((H - Dq) & (H - Uq)) | ((H - Rq) & (H - Lq));
-                        const uint32_t dark = ((L - Dq) | (L - Uq)) & ((L - Rq) | (L - Lq));
-                        const uint32_t p = (~notBright | dark) & vM;
-                        if (p) {
-                            // (past the capacity the slots are clamped into the queue's last four entries: the overflow is
-                            // seen in the count and the queue's content is then not used)
-                            int s = min(lds_add_per_lane(qn, __popc(p)), QCAP - 4);
-                            const int pos0 = a << 2;
-                            if (p & 0x80u) queue[s++] = (uint16_t)pos0;
-                            if (p & 0x8000u) queue[s++] = (uint16_t)(pos0 + 1);
-                            if (p & 0x800000u) queue[s++] = (uint16_t)(pos0 + 2);
-                            if (p >> 31) queue[s] = (uint16_t)(pos0 + 3);
-                        }
-                        r += stepR;
-                        dz += stepD;
-                        if (dz >= nd) {
-                            dz -= nd;
-                            r++;
-                        }
-                    }
-                }
-                FT(3);
-                __syncthreads();
-                FT(4);
-                const int nq = *qn;
-                if (tid == 0) qnS[qsel ^ 1] = 0; // (the other counter: nobody touches it before the next barrier)
-                qsel ^= 1;
-                if (nq > QCAP) { // (uniform) dense texture: again, in bands of rows whose worst case fits the queue
-                    bandRows = max(1, QCAP / (4 * nd));
-                    __syncthreads();
-                    continue; // rb unchanged: nothing of this band has been scored
-                }
-                // phase B: exact score of the band's survivors, all lanes busy; corners go to the score map and the corner queue
-                for (int qi = tid; qi < nq; qi += NT) {
-                    const int pos = queue[qi];
-                    const int sc = fast_score<P>(&tile[pos]);
-                    if (sc >= th) {
-                        smap[pos] = (uint8_t)sc;
-                        const int s = lds_add_per_lane(&cqn, 1);
-                        if (s < CQ) cq[s] = (uint16_t)pos;
-                    }
-                }
-                rb = rEnd;
-                FT(5);
-                __syncthreads(); // (also orders the queue's reuse by the next band / range)
-                FT(6);
-            }
-        }
-        // ---- NMS (strict, 8 neighbours, blind across the cell seams) over the corners
-        const int nq = cqn;
-        const bool scan = nq > CQ; // more corners than the queue holds: look at every pixel of the zone instead
-        const int zwAll = txHi - txLo + 1;
-        auto cellOf = [&](int zx, int& j, int& xl, int& zwj) {
-            j = fast_div((unsigned)zx, c.mZw);
-            if (j >= nc) j = nc - 1; // (a 1-px zone width has the reciprocal 0: fast_div returns zx itself)
-            xl = zx - j * zwF;
-            zwj = j == nc - 1 ? zwL : zwF;
-        };
-        auto keeps = [&](int pos, int xl, int zwj) -> bool {
-            const uint8_t* sp = smap + pos - P - 1;
-            const int s0 = sp[P + 1];
-            const int up = sp[1], dn = sp[2 * P + 1];
-            int lt = max(max((int)sp[0], (int)sp[P]), (int)sp[2 * P]), rt = max(max((int)sp[2], (int)sp[P + 2]), (int)sp[2 * P + 2]);
-            if (xl == 0) lt = 0;          // the left neighbours belong to the previous cell
-            if (xl == zwj - 1) rt = 0;    // the right neighbours to the next one
-            return s0 >= th && s0 > max(max(up, dn), max(lt, rt));
-        };
-        if (!scan) {
-            for (int qi = tid; qi < nq; qi += NT) {
-                const int pos = cq[qi];
-                const int y = (int)((unsigned)pos / (unsigned)P), x = pos - y * P;
-                int j, xl, zwj;
-                cellOf(x - txLo, j, xl, zwj);
-                if (keeps(pos, xl, zwj)) {
-                    const int z = (y - 3) * zwj + xl;
-                    atomicOr(&bm[j * bmW + (z >> 5)], 1u << (z & 31));
-                    cq[qi] = (uint16_t)(pos | 0x8000);
-                }
-            }
-        } else {
-            for (int f = tid; f < zwAll * zh; f += NT) {
-                const int y = f / zwAll, zx = f - y * zwAll;
-                int j, xl, zwj;
-                cellOf(zx, j, xl, zwj);
-                if (pass && !((redo >> j) & 1u)) continue;
-                const int pos = (y + 3) * P + txLo + zx;
-                if (keeps(pos, xl, zwj)) {
-                    const int z = y * zwj + xl;
-                    atomicOr(&bm[j * bmW + (z >> 5)], 1u << (z & 31));
-                }
-            }
-        }
-        FT(7);
-        __syncthreads();
-        FT(8);
-        // ---- one rank space per cell: wavefront w prefix-sums the bitmap of cells w, w + NW, ...
-        for (int j = wave; j < nc; j += NW) {
-            if (pass && !((redo >> j) & 1u)) continue; // (wave-uniform)
-            int carry = 0;
-            for (int base = 0; base < bmW; base += 64) { // (one round unless a cell's zone exceeds 2048 px)
-                const int i = base + lane;
-                const int w = i < bmW ? __popc(bm[j * bmW + i]) : 0; // (words past the cell's zone are zero)
-                const int x = wave_incl_scan_i32(w);
-                if (i < bmW) pre[j * bmW + i] = x - w + carry;
-                carry += __builtin_amdgcn_readlane(x, 63);
-            }
-            if (lane == 0) {
-                nkS[j] = carry;
-                cnt[j] = min(carry, j == nc - 1 ? capL : capF);
-            }
-        }
-        FT(9);
-        __syncthreads();
-        FT(10);
-        // ---- ranked output (row-major inside the cell, like cv::FAST's own order)
-        auto emit = [&](int pos, int x, int y, int j, int z) {
-            const int rank = pre[j * bmW + (z >> 5)] + __popc(bm[j * bmW + (z >> 5)] & ((1u << (z & 31)) - 1u));
-            if (rank < (j == nc - 1 ? capL : capF))
-                out0[j * capF + rank] = (uint32_t)(x - ox + (int)(c.off & 0xFFFFu)) | ((uint32_t)(y + (int)(c.off >> 16)) << 12) |
-                                        ((uint32_t)smap[pos] << 24);
-        };
-        if (!scan) {
-            for (int qi = tid; qi < nq; qi += NT) {
-                const int e = cq[qi];
-                if (e & 0x8000) {
-                    const int pos = e & 0x7FFF;
-                    const int y = (int)((unsigned)pos / (unsigned)P), x = pos - y * P;
-                    int j, xl, zwj;
-                    cellOf(x - txLo, j, xl, zwj);
-                    emit(pos, x, y, j, (y - 3) * zwj + xl);
-                }
-            }
-        } else {
-            for (int f = tid; f < zwAll * zh; f += NT) {
-                const int y = f / zwAll, zx = f - y * zwAll;
-                int j, xl, zwj;
-                cellOf(zx, j, xl, zwj);
-                if (pass && !((redo >> j) & 1u)) continue;
-                const int z = y * zwj + xl;
-                if ((bm[j * bmW + (z >> 5)] >> (z & 31)) & 1u) emit((y + 3) * P + txLo + zx, txLo + zx, y + 3, j, z);
-            }
-        }
-        FT(11);
-#ifdef ORBFE_FAST_TIMING
-        ftPass = 1;
-#endif
-        // nothing at iniThFAST in some cell: the same again with minThFAST for those cells (:825-828)
-        if (pass == 1 || minTh == iniTh) break;
-        unsigned again = 0;
-#pragma unroll
-        for (int j = 0; j < MAXC; j++)
-            if (j < nc && nkS[j] == 0) again |= 1u << j;
-        if (!again) break;
-        redo = again;
-        th = minTh;
-        __syncthreads(); // every thread is done with the corner queue and has read the counts
-        if (tid == 0) cqn = 0;
-        __syncthreads();
-    }
-#ifdef ORBFE_FAST_TIMING
-    if (tid == 0) {
-        unsigned long long* g = g_fastTimes + 16 * ((blockIdx.x + 977u * blockIdx.y) & 4095u);
-        for (int k = 0; k < 12; k++) atomicAdd(&g[k], (unsigned long long)ftL[k]);
         atomicAdd(&g[15], 1ull);
     }
 #endif

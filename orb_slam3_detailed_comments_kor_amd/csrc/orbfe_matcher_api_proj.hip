@@ -1,0 +1,512 @@
+// orbfe_matcher_api_proj.hip -- entry points: SearchByProjection (single, batch, frame handles), distinctive descriptors.
+// Part of the matcher's translation unit: included by orbfe_matcher.hip, in this order, behind the common device helpers
+// (the text is the one translation unit it always was, cut at its family borders -- VERDICT r05 #6).
+namespace {
+// argument checks of one projection search (everything the kernels rely on)
+int proj_validate(const orbfe_proj_args* a, const int32_t* q_match, const int32_t* feat_match)
+{
+    if (!a || a->n < 0 || a->nq < 0 || (a->mode != 0 && a->mode != 1)) return ORBFE_ERR_ARGS;
+    if (a->n && (!a->desc || !a->kx || !a->ky || !a->octave || !feat_match)) return ORBFE_ERR_ARGS;
+    if (a->nq && (!a->qdesc || !a->qx || !a->qy || !a->qr || !a->qmin_level || !a->qmax_level || !q_match))
+        return ORBFE_ERR_ARGS;
+    if (a->Nleft != -1 && (a->Nleft < 0 || a->Nleft > a->n)) return ORBFE_ERR_ARGS;
+    if (a->n >= PROJ_MAXN || a->nq >= (1 << 28)) return ORBFE_ERR_ARGS;
+    const bool orient = a->mode == 1 && a->check_orientation;
+    if (orient && a->nq && (!a->angle || !a->qangle)) return ORBFE_ERR_ARGS;
+    if (a->Nleft == -1 && a->uright && a->nq && !a->qxr) return ORBFE_ERR_ARGS;
+    if (a->chi2_gate) { // Fuse's reprojection test: sigma table indexed by the candidates' octaves
+        if (a->mode != 1 || !a->inv_level_sigma2 || a->n_levels < 1 || (a->uright && a->nq && !a->qxr)) return ORBFE_ERR_ARGS;
+        for (int i = 0; i < a->n; i++)
+            if (a->octave[i] < 0 || a->octave[i] >= a->n_levels) return ORBFE_ERR_ARGS;
+    }
+    for (int q = 0; q < a->nq; q++) {
+        const int f = a->qflags ? a->qflags[q] : 0;
+        if ((f & 1) && a->Nleft == -1) return ORBFE_ERR_ARGS; // there is no right grid
+        // bit 2 refers to the query before, which must be an unconditional one
+        if ((f & 4) && (q == 0 || (a->qflags[q - 1] & 6))) return ORBFE_ERR_ARGS;
+        // (a non-blocking map point -- Observations() == 0 -- that overwrites a stereo partner can free a taken feature again,
+        // :117-121: that search walks its queries in order, proj_needs_inorder / proj_inorder_body; refused until round 5)
+    }
+    if (a->Nleft != -1 && a->mode == 0 && a->n && a->nq) {
+        for (int i = 0; a->left_to_right && i < a->Nleft; i++)
+            if (a->left_to_right[i] < -1 || a->left_to_right[i] >= a->n - a->Nleft) return ORBFE_ERR_ARGS;
+        for (int i = 0; a->right_to_left && i < a->n - a->Nleft; i++)
+            if (a->right_to_left[i] < -1 || a->right_to_left[i] >= a->Nleft) return ORBFE_ERR_ARGS;
+    }
+    return 0;
+}
+
+bool proj_needs_inorder(const orbfe_proj_args* a)
+{
+    if (!(a->qblocks && a->mode == 0 && a->Nleft != -1 && (a->left_to_right || a->right_to_left))) return false;
+    for (int q = 0; q < a->nq; q++)
+        if (!a->qblocks[q]) return true;
+    return false;
+}
+
+struct ProjJob {
+    ProjDev P{};
+    size_t keyCap = 0, outOff = 0; // outputs of the job: status[4] | qMatch[nq] | featMatch[n] at dOut + outOff
+    size_t sweepBytes = 0;
+};
+
+} // namespace
+
+// Frame side of the projection searches kept on the device between calls (orbfe_frame_create): the feature arrays and
+// the grid of Frame::AssignFeaturesToGrid, built once; host copies of what the host tail of a search reads.
+struct orbfe_frame {
+    int device = 0, n = 0, Nleft = -1;
+    float minX = 0, minY = 0, wInv = 0, hInv = 0;
+    uint8_t* block = nullptr; // one allocation: everything below points into it
+    size_t blockCap = 0;
+    uint8_t* desc = nullptr;
+    float *kx = nullptr, *ky = nullptr, *uright = nullptr;
+    int32_t *octave = nullptr, *cellStart = nullptr, *cellItems = nullptr, *cellOf = nullptr, *status = nullptr;
+    std::vector<int32_t> hOctave;
+    std::vector<float> hAngle;
+};
+
+namespace {
+// inputs and work arrays of one search on the device (outputs are assigned by the caller: one block per call).  Two phases,
+// so that a batch stages the inputs of ALL its searches next to each other (one run of the pinned mirror = one upload
+// command for the batch instead of one per search) and the work arrays after them: phase 0 = inputs, phase 1 = the rest.
+// `prev` / `prevJ`: the search staged just before this one in the same call.  The searches of a batch usually share a side --
+// one keyframe's map points fused into every neighbour (the same query descriptors), or every neighbour's points into the one
+// keyframe (the same frame side), src/LocalMapping.cc:803-870 -- and a read-only array that comes with the same pointer and
+// size as its predecessor's is staged and uploaded once.
+int proj_stage(Scratch& s, const orbfe_proj_args* a, ProjJob& J, const orbfe_frame* F, int phase, const orbfe_proj_args* prev = nullptr,
+               const ProjJob* prevJ = nullptr)
+{
+    int r;
+    ProjDev& P = J.P;
+    const size_t n = (size_t)a->n, nq = (size_t)a->nq;
+    if (phase == 0) {
+        const bool sameN = prev && prev->n == a->n, sameQ = prev && prev->nq == a->nq;
+        uint8_t *dDesc = nullptr, *dTaken = nullptr, *dQdesc, *dQflags = nullptr, *dQblocks = nullptr;
+        float *dKx = nullptr, *dKy = nullptr, *dUr = nullptr, *dQx, *dQy, *dQr, *dQxr = nullptr;
+        int32_t *dOct = nullptr, *dL2r = nullptr, *dR2l = nullptr, *dQmin, *dQmax;
+        if (F) { // the frame's arrays and grid are resident
+            dDesc = F->desc; dKx = F->kx; dKy = F->ky; dOct = F->octave;
+            if (F->uright && (a->Nleft == -1 || a->chi2_gate)) dUr = F->uright;
+        } else {
+            if (sameN && prev->desc == a->desc) dDesc = const_cast<uint8_t*>(prevJ->P.desc);
+            else if ((r = s.up_desc(&dDesc, a->desc, n * 32)) < 0) return r;
+            if (sameN && prev->kx == a->kx) dKx = const_cast<float*>(prevJ->P.kx);
+            else if ((r = s.up(&dKx, a->kx, n)) < 0) return r;
+            if (sameN && prev->ky == a->ky) dKy = const_cast<float*>(prevJ->P.ky);
+            else if ((r = s.up(&dKy, a->ky, n)) < 0) return r;
+            if (sameN && prev->octave == a->octave) dOct = const_cast<int32_t*>(prevJ->P.octave);
+            else if ((r = s.up(&dOct, a->octave, n)) < 0) return r;
+            if (a->uright && (a->Nleft == -1 || a->chi2_gate)) {
+                if (sameN && prev->uright == a->uright && prevJ->P.uright) dUr = const_cast<float*>(prevJ->P.uright);
+                else if ((r = s.up(&dUr, a->uright, n)) < 0) return r;
+            }
+        }
+        float* dInvSigma2 = nullptr;
+        if (a->chi2_gate && (r = s.up(&dInvSigma2, a->inv_level_sigma2, (size_t)a->n_levels)) < 0) return r;
+        if (a->taken && (r = s.up(&dTaken, a->taken, n)) < 0) return r;
+        if (a->Nleft != -1 && a->mode == 0) {
+            if (a->left_to_right && (r = s.up(&dL2r, a->left_to_right, (size_t)a->Nleft)) < 0) return r;
+            if (a->right_to_left && (r = s.up(&dR2l, a->right_to_left, n - (size_t)a->Nleft)) < 0) return r;
+        }
+        if (sameQ && prev->qdesc == a->qdesc) dQdesc = const_cast<uint8_t*>(prevJ->P.qdesc);
+        else if ((r = s.up_desc(&dQdesc, a->qdesc, nq * 32)) < 0) return r;
+        if ((r = s.up(&dQx, a->qx, nq)) < 0) return r;
+        if ((r = s.up(&dQy, a->qy, nq)) < 0) return r;
+        if ((r = s.up(&dQr, a->qr, nq)) < 0) return r;
+        if (dUr && (r = s.up(&dQxr, a->qxr, nq)) < 0) return r;
+        if ((r = s.up(&dQmin, a->qmin_level, nq)) < 0) return r;
+        if ((r = s.up(&dQmax, a->qmax_level, nq)) < 0) return r;
+        if (a->qflags && (r = s.up(&dQflags, a->qflags, nq)) < 0) return r;
+        if (a->qblocks && (r = s.up(&dQblocks, a->qblocks, nq)) < 0) return r;
+        P.desc = dDesc; P.kx = dKx; P.ky = dKy; P.octave = dOct; P.uright = dUr; P.taken = dTaken;
+        P.l2r = dL2r; P.r2l = dR2l; P.n = a->n; P.Nleft = a->Nleft;
+        P.minX = a->minX; P.minY = a->minY; P.wInv = a->gridWInv; P.hInv = a->gridHInv;
+        P.nq = a->nq; P.qdesc = dQdesc; P.qx = dQx; P.qy = dQy; P.qr = dQr; P.qxr = dQxr;
+        P.qmin = dQmin; P.qmax = dQmax; P.qflags = dQflags; P.qblocks = dQblocks;
+        P.mode = a->mode; P.nnratio = a->nnratio; P.thHigh = a->th_high;
+        P.invSigma2 = dInvSigma2; P.chi2 = a->chi2_gate ? 1 : 0;
+        P.inorder = proj_needs_inorder(a) ? 1 : 0;
+        P.taken0 = nullptr;
+        if (P.inorder) { // (the entry state is applied by the walk, not by the candidates' static test)
+            P.taken0 = P.taken;
+            P.taken = nullptr;
+        }
+        return 0;
+    }
+    P.resident = F ? 1 : 0;
+    if (F) {
+        P.cellStart = F->cellStart; P.cellItems = F->cellItems; P.cellOf = F->cellOf;
+    } else {
+        if ((r = s.up<int32_t>(&P.cellStart, nullptr, 2 * PROJ_CELLS + 1)) < 0) return r;
+        if ((r = s.up<int32_t>(&P.cellItems, nullptr, n)) < 0) return r;
+        if ((r = s.up<int32_t>(&P.cellOf, nullptr, n)) < 0) return r;
+    }
+    if ((r = s.up<int32_t>(&P.minW, nullptr, 2 * n)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.state, nullptr, 6 * nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.qStart, nullptr, nq)) < 0) return r;
+    if ((r = s.up<int32_t>(&P.qCount, nullptr, nq)) < 0) return r;
+    P.qArea = nullptr;
+    for (size_t q = 0; a->qflags && q < nq && !P.qArea; q++)
+        if ((a->qflags[q] & 4) && (r = s.up<int32_t>(&P.qArea, nullptr, nq)) < 0) return r;
+    J.keyCap = PROJ_QUOTA * nq + std::max<size_t>(PROJ_QUOTA * nq, 1 << 15); // (the queries' own stretches + overflow)
+    if ((r = s.up<unsigned long long>(&P.rawKeys, nullptr, J.keyCap)) < 0) return r;
+    if ((r = s.up<unsigned long long>(&P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
+    P.keyCap = (int)J.keyCap;
+    J.sweepBytes = (2 * n + 6 * nq) * sizeof(int32_t);
+    P.sweepLds = J.sweepBytes <= 60 * 1024 ? 1 : 0;
+    if (!P.sweepLds) J.sweepBytes = 0;
+    return 0;
+}
+
+// host tail of one search: outputs from the downloaded block, then the rotation histogram of :2307-2323 /
+// :2397-2416 over the matches in query order
+int proj_finish(const orbfe_proj_args* a, const int32_t* out, int32_t* q_match, int32_t* feat_match)
+{
+    const size_t n = (size_t)a->n, nq = (size_t)a->nq;
+    int nmatches = out[0];
+    std::copy(out + 4, out + 4 + nq, q_match);
+    std::copy(out + 4 + nq, out + 4 + nq + n, feat_match);
+    if (a->mode == 1 && a->check_orientation) {
+        std::vector<int8_t> bins(nq, -1);
+        int histo[HISTO_LENGTH] = {0};
+        for (size_t q = 0; q < nq; q++)
+            if (q_match[q] >= 0) {
+                float rot = a->qangle[q] - a->angle[q_match[q]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[q] = (int8_t)bin;
+                if (bin >= 0 && bin < HISTO_LENGTH) histo[bin]++;
+            }
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        for (size_t q = 0; q < nq; q++)
+            if (q_match[q] >= 0 && bins[q] != ind1 && bins[q] != ind2 && bins[q] != ind3) {
+                feat_match[q_match[q]] = -1;
+                nmatches--;
+            }
+    }
+    return nmatches;
+}
+} // namespace
+
+namespace {
+// `frame`: the one search (count == 1) runs against a resident frame: its arrays and grid are not staged or rebuilt
+int proj_run(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match, int32_t* const* feat_match,
+             int32_t* nmatches, const orbfe_frame* const* frames /* per search, or NULL; entries may be NULL and may repeat */)
+{
+    if (count < 0 || (count && (!items || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
+    const orbfe_frame* const frame = (frames && count == 1) ? frames[0] : nullptr; // the latency path of ONE resident search
+    PTR_BEGIN();
+    int r;
+    for (int k = 0; k < count; k++)
+        if ((r = proj_validate(&items[k], q_match[k], feat_match[k])) < 0) return r;
+    // searches with nothing to do are answered here; the others become device jobs
+    std::vector<int> live;
+    for (int k = 0; k < count; k++) {
+        const orbfe_proj_args* a = &items[k];
+        nmatches[k] = 0;
+        if (a->n > 0 && a->nq > 0) {
+            live.push_back(k); // (proj_finish writes both arrays whole)
+            continue;
+        }
+        for (int i = 0; i < a->n; i++) feat_match[k][i] = -1;
+        for (int q = 0; q < a->nq; q++) q_match[k][q] = -1;
+    }
+    if (live.empty()) return 0;
+    PTR(); // validate + prefill
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    std::vector<ProjJob> jobs(live.size());
+    // latency path: ONE search against a resident frame (what Tracking issues per frame).  Only the queries travel: the kernels
+    // read them from the pinned staging in place, the last kernel copies the results into the pinned mirror and publishes the
+    // completion word -- no upload command, no download command, no stream synchronisation
+    const bool latency = frame && live.size() == 1;
+    if (latency) s.inPlace = (size_t)items[live[0]].nq * 72 + (size_t)items[live[0]].n * 9 + 4096 <= inplace_limit();
+    size_t outInts = 0, sweepBytes = 0;
+    unsigned maxBlocks = 1;
+    for (size_t j = 0; j < jobs.size(); j++) // (the inputs of all searches first: one upload for the batch)
+        if ((r = proj_stage(s, &items[live[j]], jobs[j], frames ? frames[live[j]] : nullptr, 0, j ? &items[live[j - 1]] : nullptr,
+                            j ? &jobs[j - 1] : nullptr)) < 0)
+            return r;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const orbfe_proj_args* a = &items[live[j]];
+        if ((r = proj_stage(s, a, jobs[j], frames ? frames[live[j]] : nullptr, 1)) < 0) return r;
+        jobs[j].outOff = outInts;
+        outInts += 4 + (size_t)a->nq + (size_t)a->n;
+        sweepBytes = std::max(sweepBytes, jobs[j].sweepBytes);
+        maxBlocks = std::max(maxBlocks, (unsigned)((a->nq + 3) / 4));
+    }
+    int32_t* dOut;
+    if ((r = s.up<int32_t>(&dOut, nullptr, outInts)) < 0) return r;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const orbfe_proj_args* a = &items[live[j]];
+        jobs[j].P.status = dOut + jobs[j].outOff;
+        jobs[j].P.qMatch = jobs[j].P.status + 4;
+        jobs[j].P.featMatch = jobs[j].P.qMatch + a->nq;
+    }
+    int32_t *dMir = nullptr, *hMir = nullptr;
+    bool anyInorder = false;
+    for (const ProjJob& J : jobs) anyInorder = anyInorder || J.P.inorder;
+    const bool mirrored = latency && s.inPlace && !g_timeKernels && !anyInorder && outInts * 4 <= (256u << 10) &&
+                          s.mirror_out(&dMir, &hMir, outInts) == 0;
+    // (kept by the thread: as a fresh vector the download buffer of a 64-search call -- 600 KB -- is mapped, zeroed, faulted in
+    // and unmapped by every call)
+    static thread_local std::vector<int32_t> outKeep;
+    std::vector<int32_t>& outv = outKeep;
+    if (!mirrored && outv.size() < outInts) outv.resize(outInts);
+    const int32_t* out = mirrored ? hMir : outv.data();
+    std::vector<ProjDev> hostP(jobs.size());
+    PTR(); // staging
+    for (int attempt = 0;; attempt++) {
+        ProjDev* dP = nullptr;
+        if (jobs.size() > 1) {
+            for (size_t j = 0; j < jobs.size(); j++) hostP[j] = jobs[j].P;
+            if ((r = s.up(&dP, hostP.data(), hostP.size())) < 0) return r;
+        }
+        DoneSig done{nullptr, nullptr, 0u, 0u, 0u};
+        if (mirrored) {
+            done = s.flag_only(); // (one workgroup writes the mirror and publishes: neither block nor counter)
+            jobs[0].P.mirror = dMir;
+            jobs[0].P.mirrorInts = (int)outInts;
+            jobs[0].P.doneFlag = done.flag;
+            jobs[0].P.doneSeq = done.seq;
+        }
+        {
+            KernelTimer timer(s);
+            if (jobs.size() == 1) {
+                const ProjDev& P = jobs[0].P;
+                if (frame) HIP_TRY(hipMemsetAsync(P.status, 0, 4 * sizeof(int32_t), g_ms)); // (what k_proj_grid resets)
+                else hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
+                hipLaunchKernelGGL(k_proj_candidates, dim3(maxBlocks), dim3(256), 0, g_ms, P);
+                hipLaunchKernelGGL(k_proj_sweeps, dim3(1), dim3(PROJ_THREADS), sweepBytes, g_ms, P);
+            } else {
+                const unsigned nj = (unsigned)jobs.size();
+                hipLaunchKernelGGL(k_proj_grid_batch, dim3(1, nj), dim3(PROJ_THREADS), 0, g_ms, dP);
+                hipLaunchKernelGGL(k_proj_candidates_batch, dim3(maxBlocks, nj), dim3(256), 0, g_ms, dP);
+                hipLaunchKernelGGL(k_proj_sweeps_batch, dim3(1, nj), dim3(PROJ_THREADS), sweepBytes, g_ms, dP);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        PTR(); // flush + launches
+        if (mirrored) INT_TRY(s.complete(done));
+        else {
+            INT_TRY(s.down(outv.data(), dOut, outInts * 4));
+            INT_TRY(s.fetch());
+        }
+        PTR(); // fetch
+        // more candidate keys than a job's buffers hold: the kernel reported how many it needs; run again
+        bool again = false;
+        for (ProjJob& J : jobs) {
+            if (out[J.outOff + 2] < 0) return ORBFE_ERR_STATE;
+            const size_t need = (size_t)PROJ_QUOTA * (size_t)J.P.nq + (size_t)out[J.outOff + 2]; // (own stretches + overflow asked for)
+            if (need > J.keyCap) {
+                if (attempt > 0) return ORBFE_ERR_STATE;
+                J.keyCap = need;
+                if ((r = s.up<unsigned long long>(&J.P.rawKeys, nullptr, J.keyCap)) < 0) return r;
+                if ((r = s.up<unsigned long long>(&J.P.sortedKeys, nullptr, J.keyCap)) < 0) return r;
+                J.P.keyCap = (int)J.keyCap;
+                again = true;
+            }
+        }
+        if (!again) break;
+    }
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const int k = live[j];
+        g_lastProjSweeps = out[jobs[j].outOff + 1];
+        nmatches[k] = proj_finish(&items[k], out + jobs[j].outOff, q_match[k], feat_match[k]);
+    }
+    PTR();
+#ifdef ORBFE_CALL_TRACE
+    fprintf(stderr, "proj_run count=%d: validate %.1f stage %.1f launch %.1f fetch %.1f finish %.1f us\n", count, trT[0], trT[1], trT[2], trT[3], trT[4]);
+#endif
+    return 0;
+}
+
+} // namespace
+
+int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int count, int32_t* const* q_match,
+                                  int32_t* const* feat_match, int32_t* nmatches)
+{
+    return proj_run(device, items, count, q_match, feat_match, nmatches, nullptr);
+}
+
+int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
+{
+    if (!out) return ORBFE_ERR_ARGS;
+    *out = nullptr;
+    if (!a || a->n < 1 || a->n >= PROJ_MAXN || !a->desc || !a->kx || !a->ky || !a->octave) return ORBFE_ERR_ARGS;
+    if (a->Nleft != -1 && (a->Nleft < 0 || a->Nleft > a->n)) return ORBFE_ERR_ARGS;
+    if (is_device_ptr(a->kx) || is_device_ptr(a->octave)) return ORBFE_ERR_ARGS; // (only the descriptors may be resident already)
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    const size_t n = (size_t)a->n;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oDesc = 0, oKx = oDesc + al(n * 32), oKy = oKx + al(n * 4), oOct = oKy + al(n * 4), oUr = oOct + al(n * 4),
+                 oCs = oUr + al(n * 4), oCi = oCs + al((2 * PROJ_CELLS + 1) * 4), oCo = oCi + al(n * 4), oSt = oCo + al(n * 4),
+                 total = oSt + 256;
+    size_t blkCap = 0;
+    void* blk = g_blockPool.get(device, total, &blkCap);
+    if (!blk) return -(1000 + (int)hipErrorOutOfMemory);
+    orbfe_frame* F = new orbfe_frame();
+    F->device = device; F->n = a->n; F->Nleft = a->Nleft;
+    F->minX = a->minX; F->minY = a->minY; F->wInv = a->gridWInv; F->hInv = a->gridHInv;
+    F->block = (uint8_t*)blk;
+    F->blockCap = blkCap;
+    F->desc = F->block + oDesc;
+    F->kx = (float*)(F->block + oKx); F->ky = (float*)(F->block + oKy);
+    F->octave = (int32_t*)(F->block + oOct);
+    F->uright = a->uright ? (float*)(F->block + oUr) : nullptr;
+    F->cellStart = (int32_t*)(F->block + oCs); F->cellItems = (int32_t*)(F->block + oCi); F->cellOf = (int32_t*)(F->block + oCo);
+    F->status = (int32_t*)(F->block + oSt);
+    F->hOctave.assign(a->octave, a->octave + n);
+    if (a->angle) F->hAngle.assign(a->angle, a->angle + n);
+    Scratch s(device); // (this thread's matcher stream)
+    const bool descResident = is_device_ptr(a->desc);
+    if (descResident) {
+        if (int w = orbfe_producer_wait(a->desc, g_ms); w < 0) return w;
+    }
+    // (staged in the block's own layout and sent as ONE upload, like orbfe_keyframe_create)
+    hipError_t e = hipSuccess;
+    const size_t first = descResident ? oKx : 0, upTo = oCs; // desc | kx | ky | octave | uright lie in front of the grid arrays
+    uint8_t* st = s.pin_scratch(upTo - first);
+    if (st) {
+        uint8_t* const b = st - first;
+        if (!descResident) std::memcpy(b + oDesc, a->desc, n * 32);
+        std::memcpy(b + oKx, a->kx, n * 4);
+        std::memcpy(b + oKy, a->ky, n * 4);
+        std::memcpy(b + oOct, a->octave, n * 4);
+        if (F->uright) std::memcpy(b + oUr, a->uright, n * 4);
+        if (descResident) e = hipMemcpyAsync(F->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->block + first, st, upTo - first, hipMemcpyHostToDevice, g_ms);
+    } else {
+        e = hipMemcpyAsync(F->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess) e = hipMemcpyAsync(F->octave, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && F->uright) e = hipMemcpyAsync(F->uright, a->uright, n * 4, hipMemcpyHostToDevice, g_ms);
+    }
+    if (e == hipSuccess) {
+        ProjDev P{};
+        P.kx = F->kx; P.ky = F->ky; P.n = F->n; P.Nleft = F->Nleft;
+        P.minX = F->minX; P.minY = F->minY; P.wInv = F->wInv; P.hInv = F->hInv;
+        P.cellStart = F->cellStart; P.cellItems = F->cellItems; P.cellOf = F->cellOf; P.status = F->status;
+        hipLaunchKernelGGL(k_proj_grid, dim3(1), dim3(PROJ_THREADS), 0, g_ms, P);
+        e = hipGetLastError();
+    }
+    // the handle is complete (and may serve other threads) when the grid is built.  (Waiting on a completion word published by
+    // the grid kernel instead was tried: 0.036 against 0.029 ms -- the next creation's upload command then queues behind a
+    // kernel the runtime still holds as running, the case the search calls avoid by reading their inputs in place.)
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+    if (e != hipSuccess) {
+        g_blockPool.put(device, blk, blkCap);
+        delete F;
+        return -(1000 + (int)e);
+    }
+    g_handles.add(F);
+    *out = F;
+    return 0;
+}
+
+namespace {
+void frame_free(void* h)
+{
+    orbfe_frame* F = static_cast<orbfe_frame*>(h);
+    g_blockPool.put(F->device, F->block, F->blockCap);
+    delete F;
+}
+} // namespace
+
+void orbfe_frame_destroy(orbfe_frame* F)
+{
+    if (!F) return;
+    // (the block goes back to the pool when no search holds the handle any more -- g_handles; a search's kernel has done all its
+    // reads before the search returns, with the completion word as without it)
+    if (g_handles.destroy(F)) frame_free(F);
+}
+
+int orbfe_search_projection_frame(orbfe_frame* F, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)
+{
+    if (!F || !a) return ORBFE_ERR_ARGS;
+    HandleUses uses;
+    if (!uses.take(F, frame_free)) return ORBFE_ERR_ARGS; // (destroyed)
+    orbfe_proj_args b = *a; // the frame side comes from the handle; taken / stereo partners / queries from the caller
+    b.n = F->n; b.Nleft = F->Nleft;
+    b.desc = F->desc; b.kx = F->kx; b.ky = F->ky;
+    b.octave = F->hOctave.data();
+    b.angle = F->hAngle.empty() ? nullptr : F->hAngle.data();
+    b.uright = F->uright;
+    b.minX = F->minX; b.minY = F->minY; b.gridWInv = F->wInv; b.gridHInv = F->hInv;
+    int32_t nm = 0;
+    int32_t* qm[1] = {q_match};
+    int32_t* fm[1] = {feat_match};
+    const orbfe_frame* fr[1] = {F};
+    const int r = proj_run(F->device, &b, 1, qm, fm, &nm, fr);
+    return r < 0 ? r : (int)nm;
+}
+
+// Many searches against RESIDENT frame sides in one upload, three launches, one download (round 5): the
+// candidate keyframes' map points against the one current frame of a relocalisation (src/Tracking.cc:3846-3870: every entry
+// names the same handle), or one keyframe's points fused into every neighbour that has a handle.  Only the queries, `taken` and
+// the partner tables travel; no grid is rebuilt.
+int orbfe_search_projection_frames(orbfe_frame* const* frames, const orbfe_proj_args* queries, int count, int32_t* const* q_match,
+                                   int32_t* const* feat_match, int32_t* nmatches)
+{
+    if (count < 0 || (count && (!frames || !queries || !q_match || !feat_match || !nmatches))) return ORBFE_ERR_ARGS;
+    if (count == 0) return 0;
+    HandleUses uses;
+    for (int k = 0; k < count; k++)
+        if (!frames[k] || !uses.take(frames[k], frame_free)) return ORBFE_ERR_ARGS;
+    std::vector<orbfe_proj_args> b(queries, queries + count);
+    for (int k = 0; k < count; k++) {
+        const orbfe_frame* F = frames[k];
+        if (!F || F->device != frames[0]->device) return ORBFE_ERR_ARGS;
+        b[k].n = F->n; b[k].Nleft = F->Nleft;
+        b[k].desc = F->desc; b[k].kx = F->kx; b[k].ky = F->ky;
+        b[k].octave = F->hOctave.data();
+        b[k].angle = F->hAngle.empty() ? nullptr : F->hAngle.data();
+        b[k].uright = F->uright;
+        b[k].minX = F->minX; b[k].minY = F->minY; b[k].gridWInv = F->wInv; b[k].gridHInv = F->hInv;
+    }
+    return proj_run(frames[0]->device, b.data(), count, q_match, feat_match, nmatches, frames);
+}
+
+int orbfe_search_projection(int device, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)
+{
+    int32_t nm = 0;
+    int32_t* qm[1] = {q_match};
+    int32_t* fm[1] = {feat_match};
+    const int r = orbfe_search_projection_batch(device, a, a ? 1 : 0, qm, fm, &nm);
+    if (!a) return ORBFE_ERR_ARGS;
+    return r < 0 ? r : (int)nm;
+}
+
+int orbfe_search_projection_last_sweeps(void) { return g_lastProjSweeps; }
+
+int orbfe_distinctive_descriptors(int device, const uint8_t* pool, const int32_t* offsets, int npts, int32_t* best)
+{
+    if (npts < 0 || (npts && (!offsets || !best))) return ORBFE_ERR_ARGS;
+    if (npts == 0) return 0;
+    const int total = offsets[npts];
+    if (offsets[0] != 0 || total < 0 || (total && !pool)) return ORBFE_ERR_ARGS;
+    for (int p = 0; p < npts; p++)
+        if (offsets[p + 1] < offsets[p] || offsets[p + 1] - offsets[p] >= (1 << 20)) return ORBFE_ERR_ARGS;
+    int r;
+    if ((r = select_device(device)) < 0) return r;
+    Scratch s(device);
+    uint8_t* dP;
+    int32_t *dO, *dB;
+    if ((r = s.up_desc(&dP, pool, (size_t)total * 32)) < 0) return r;
+    if ((r = s.up(&dO, offsets, (size_t)npts + 1)) < 0) return r;
+    if ((r = s.up<int32_t>(&dB, nullptr, (size_t)npts)) < 0) return r;
+    {
+        KernelTimer timer(s);
+        hipLaunchKernelGGL(k_distinctive, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, g_ms, dP, dO, npts, dB);
+    }
+    HIP_TRY(hipGetLastError());
+    INT_TRY(s.down(best, dB, (size_t)npts * 4));
+    INT_TRY(s.fetch());
+    return 0;
+}
+

@@ -1,0 +1,783 @@
+// orbfe_matcher_host.hip -- host helpers: per-thread arena, Scratch, completion word, kernel timer.
+// Part of the matcher's translation unit: included by orbfe_matcher.hip, in this order, behind the common device helpers
+// (the text is the one translation unit it always was, cut at its family borders -- VERDICT r05 #6).
+// ------------------------------------------------------------- host helpers
+// Per-thread, per-device arena: matcher calls are tiny (tens of KB), so hipMalloc/hipFree per call
+// would cost more than the kernels.  The arena is a bump allocator over one persistent device
+// buffer; a call that outgrows it falls back to hipMalloc for the overflow and the arena is
+// enlarged before the next call.
+bool is_device_ptr(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // ordinary host memory is "invalid value" to some runtimes
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+struct Arena {
+    int device = -1;
+    uint8_t* base = nullptr;
+    uint8_t* pin = nullptr; // pinned host mirror of the arena: inputs are staged here and go up in ONE transfer,
+                            // outputs come down into it in ONE transfer
+    uint8_t* pinDev = nullptr; // the address a KERNEL uses for `pin` (results written into the mirror by the kernel itself)
+    bool pinCoherent = false;  // `pin` was allocated hipHostMallocCoherent
+    size_t cap = 0, off = 0, want = 0;
+    // The calling thread's own non-blocking stream on this device: matcher calls of the Tracking, LocalMapping and
+    // LoopClosing threads neither serialise with each other nor synchronise with the legacy null stream (and through
+    // it with every blocking stream of the process, e.g. torch's default stream).
+    hipStream_t stream = nullptr;
+    // completion word of the latency-path calls (DoneSig): device counter, page-locked flag, sequence number
+    unsigned* doneCtr = nullptr;
+    unsigned* doneFlag = nullptr;    // host address
+    unsigned* doneFlagDev = nullptr; // the kernel's address of the same word
+    unsigned doneSeq = 0;
+    unsigned spinProbe = 0; // calls since the word was given up (done_words re-probes now and then)
+    int spinMisses = 0; // consecutive waits in which the word did not arrive within the bound; at 8 the word is given up for
+                        // this thread (a platform where the kernel's flag store does not reach the host while the kernel runs
+                        // would otherwise cost every call the full bound)
+    // the clean block: device memory that is all ones between calls (the kernels' scattered results; DoneSig)
+    uint8_t* cleanDev = nullptr;
+    size_t cleanCap = 0;
+    bool cleanDirty = false;
+    ~Arena()
+    { // thread exit: give the scratch back (a thread that called the matcher once used to leak it)
+        if (device < 0) return;
+        if (hipSetDevice(device) != hipSuccess) return;
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (base) (void)hipFree(base);
+        if (pin) (void)hipHostFree(pin);
+        if (doneCtr) (void)hipFree(doneCtr);
+        if (cleanDev) (void)hipFree(cleanDev);
+        if (doneFlag) (void)hipHostFree(doneFlag);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+const int kMaxDevices = 16;
+thread_local Arena g_arena[kMaxDevices];
+thread_local hipStream_t g_ms = nullptr; // stream of the matcher call in progress on this thread
+
+// Device blocks of the resident handles (orbfe_keyframe_*, orbfe_frame_*): a Frame handle lives for a frame, a KeyFrame handle
+// for as long as the adapter's table keeps it, and hipMalloc / hipFree cost 10-20 us each -- as much as the search the handle
+// is made for.  Freed blocks wait here (per device, up to 64 of them) for the next handle of about their size.
+struct BlockPool {
+    std::mutex m;
+    struct Blk {
+        void* p;
+        size_t cap;
+    };
+    std::vector<Blk> freeBlocks[kMaxDevices];
+    void* get(int device, size_t bytes, size_t* cap)
+    {
+        const size_t want = (bytes + 0xFFFF) & ~(size_t)0xFFFF; // 64-KB classes
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto& v = freeBlocks[device];
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i].cap >= want && v[i].cap <= 2 * want) {
+                    const Blk b = v[i];
+                    v[i] = v.back();
+                    v.pop_back();
+                    *cap = b.cap;
+                    return b.p;
+                }
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        *cap = want;
+        return p;
+    }
+    void put(int device, void* p, size_t cap)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto& v = freeBlocks[device];
+            if (v.size() < 64) {
+                v.push_back(Blk{p, cap});
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+};
+BlockPool g_blockPool;
+
+// Resident handles (orbfe_keyframe, orbfe_frame) are searched from several threads while their owner may destroy them
+// (Tracking, LocalMapping and LoopClosing of ORB-SLAM3 share keyframes; the adapter's table evicts).  Until round 5 the contract
+// was "destroy must not run while a call that was given the handle is in progress" -- a use-after-free by contract.  Now every
+// entry point that is handed a handle takes a USE of it for the duration of the call, under a lock that also knows which
+// handles are alive: a handle that has been destroyed is refused (ORBFE_ERR_ARGS) instead of dereferenced, and a destroy that
+// finds uses outstanding marks the handle dead and leaves the freeing to the last use that is given back.
+struct HandleTable {
+    std::mutex m;
+    struct Ent {
+        int uses;
+        bool dead;
+    };
+    std::unordered_map<const void*, Ent> live;
+    void add(const void* h)
+    {
+        std::lock_guard<std::mutex> g(m);
+        live[h] = Ent{0, false};
+    }
+    bool acquire(const void* h)
+    {
+        std::lock_guard<std::mutex> g(m);
+        auto it = live.find(h);
+        if (it == live.end() || it->second.dead) return false;
+        it->second.uses++;
+        return true;
+    }
+    // true: the caller must free the handle now (it was destroyed while this use was out, and this was the last one)
+    bool release(const void* h)
+    {
+        std::lock_guard<std::mutex> g(m);
+        auto it = live.find(h);
+        if (it == live.end()) return false;
+        if (--it->second.uses == 0 && it->second.dead) {
+            live.erase(it);
+            return true;
+        }
+        return false;
+    }
+    // true: free now; false: in use (freed by the last release) or unknown (already destroyed: nothing to do)
+    bool destroy(const void* h)
+    {
+        std::lock_guard<std::mutex> g(m);
+        auto it = live.find(h);
+        if (it == live.end() || it->second.dead) return false;
+        if (it->second.uses == 0) {
+            live.erase(it);
+            return true;
+        }
+        it->second.dead = true;
+        return false;
+    }
+};
+HandleTable g_handles;
+// the uses one call took (given back on every way out; `freeFn` frees a handle whose destroy was deferred to this call)
+struct HandleUses {
+    std::vector<std::pair<const void*, void (*)(void*)>> held;
+    bool take(const void* h, void (*freeFn)(void*))
+    {
+        for (const auto& e : held)
+            if (e.first == h) return true; // (the same handle on several problems of one call: one use)
+        if (!g_handles.acquire(h)) return false;
+        held.emplace_back(h, freeFn);
+        return true;
+    }
+    ~HandleUses()
+    {
+        for (const auto& e : held)
+            if (g_handles.release(e.first)) e.second(const_cast<void*>(e.first));
+    }
+};
+
+// The staged inputs of a call brought to the device by a KERNEL (16 bytes per thread out of the pinned mirror) which also puts
+// the all-ones into the result region -- instead of a clearing command, a copy command and the ~10 us the queue spends between
+// two commands of different engines (SearchByBoW x 64 with the nodes paired on the device: fill 6 + gap 10 + copy 9 + gap 10 in
+// front of the kernel -> one launch of ~5 us).  Used when what is staged is small (Scratch::flush_by_kernel).
+struct StageRuns {
+    const uint4* src[4];
+    uint4* dst[4];
+    unsigned n16[4]; // 16-byte units per run (unused runs: 0)
+    uint4* fill;
+    unsigned fill16;
+};
+__global__ __launch_bounds__(256) void k_stage_in(const StageRuns R)
+{
+    const unsigned t = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        for (unsigned i = t; i < R.n16[k]; i += step) R.dst[k][i] = R.src[k][i];
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (unsigned i = t; i < R.fill16; i += step) R.fill[i] = ones;
+}
+
+struct Scratch { // device allocations of one call
+    Arena* ar = nullptr;
+    // Latency path (round 4): a call whose staged inputs are a few KB hands the KERNEL the pinned mirror itself (device-side
+    // address of the host memory) instead of copying it to the device first: one stream command less in front of the launch.
+    // Set before the first up() / reserve(); needs the arena's mirror (else the call takes the copy path as before).
+    bool inPlace = false;
+    std::vector<void*> overflow;
+    std::vector<std::pair<size_t, size_t>> staged; // (offset, bytes) runs waiting in the pinned mirror
+    struct Down {
+        void* host;
+        const void* dev;
+        size_t bytes;
+    };
+    std::vector<Down> downs; // results the caller wants back (see down / fetch)
+    explicit Scratch(int device)
+    {
+        ar = &g_arena[device]; // select_device() has checked 0 <= device < kMaxDevices
+        ar->device = device;
+        if (!ar->stream && hipStreamCreateWithFlags(&ar->stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            ar->stream = nullptr; // the null stream still works
+        }
+        g_ms = ar->stream;
+        if (ar->want > ar->cap) { // grow between calls
+            if (ar->base) (void)hipFree(ar->base);
+            if (ar->pin) (void)hipHostFree(ar->pin);
+            ar->base = ar->pin = nullptr;
+            ar->cap = 0;
+            void* p = nullptr;
+            const size_t want = std::max<size_t>(ar->want * 2, 1 << 20);
+            if (hipMalloc(&p, want) == hipSuccess) {
+                ar->base = (uint8_t*)p;
+                ar->cap = want;
+                void* h = nullptr;
+                ar->pinDev = nullptr;
+                // (explicitly fine-grained: kernels write results into it that the host reads while the kernel is, for the
+                // runtime, still running -- DoneSig; without the flag the default allocation serves the same way)
+                ar->pinCoherent = hipHostMalloc(&h, want, hipHostMallocCoherent) == hipSuccess;
+                if (!ar->pinCoherent) (void)hipGetLastError();
+                if (ar->pinCoherent || hipHostMalloc(&h, want) == hipSuccess) {
+                    ar->pin = (uint8_t*)h;
+                    void* dv = nullptr;
+                    if (hipHostGetDevicePointer(&dv, h, 0) == hipSuccess) ar->pinDev = (uint8_t*)dv;
+                    else (void)hipGetLastError();
+                } else (void)hipGetLastError();
+            }
+        }
+        ar->off = 0;
+        ar->want = 0;
+    }
+    ~Scratch()
+    {
+        if (!overflow.empty()) (void)hipStreamSynchronize(g_ms);
+        for (void* p : overflow) (void)hipFree(p);
+    }
+    template <class T>
+    int up(T** out, const T* host, size_t n)
+    {
+        *out = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        void* p = nullptr;
+        ar->want += bytes;
+        bool inArena = false;
+        size_t at = 0;
+        if (ar->base && ar->off + bytes <= ar->cap) {
+            at = ar->off;
+            p = ar->base + ar->off;
+            ar->off += bytes;
+            inArena = true;
+        } else {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return -(1000 + (int)e);
+            overflow.push_back(p);
+        }
+        if (host && n) {
+            if (inArena && ar->pin) { // stage; adjacent uploads merge into one run
+                std::memcpy(ar->pin + at, host, n * sizeof(T));
+                if (inPlace && ar->pinDev) {
+                    *out = (T*)(ar->pinDev + at); // (read where it lies)
+                    return 0;
+                }
+                if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
+                else staged.emplace_back(at, bytes);
+            } else {
+                hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, g_ms);
+                if (e != hipSuccess) return -(1000 + (int)e);
+                e = hipStreamSynchronize(g_ms); // `host` is the caller's (pageable) memory
+                if (e != hipSuccess) return -(1000 + (int)e);
+            }
+        }
+        *out = (T*)p;
+        return 0;
+    }
+    // Arena space the caller fills itself: *stage points into the pinned mirror (the bytes go up with the other
+    // staged inputs in flush()), so a pooled upload needs no intermediate copy.  Falls back to a temporary host
+    // buffer when the arena is too small for this call (it is enlarged before the next one).
+    std::vector<std::vector<uint8_t>> temps;
+    struct LateUp {
+        void* dev;
+        size_t temp, bytes;
+    };
+    std::vector<LateUp> lateUps;
+    template <class T>
+    int reserve(T** dev, T** stage, size_t n)
+    {
+        *dev = nullptr;
+        *stage = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        ar->want += bytes;
+        if (ar->base && ar->pin && ar->off + bytes <= ar->cap) {
+            const size_t at = ar->off;
+            ar->off += bytes;
+            *stage = (T*)(ar->pin + at);
+            if (inPlace && ar->pinDev) {
+                *dev = (T*)(ar->pinDev + at);
+                return 0;
+            }
+            *dev = (T*)(ar->base + at);
+            if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
+            else staged.emplace_back(at, bytes);
+            return 0;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        overflow.push_back(p);
+        temps.emplace_back(bytes);
+        lateUps.push_back(LateUp{p, temps.size() - 1, bytes});
+        *dev = (T*)p;
+        *stage = (T*)temps.back().data();
+        return 0;
+    }
+    // Small results the KERNEL writes straight into the pinned mirror (posted writes over PCIe): no download command at
+    // the end of the call, the caller reads *host after the stream synchronisation.  *dev is the kernel's address of that
+    // host memory; the caller pre-fills *host (e.g. with -1) before the launch.  Fails (returns 1) when the arena has no
+    // mirror or no room: the caller then takes the download path.
+    template <class T>
+    int mirror_out(T** dev, T** host, size_t n)
+    {
+        *dev = nullptr;
+        *host = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        ar->want += bytes;
+        if (!(ar->base && ar->pin && ar->pinDev && ar->off + bytes <= ar->cap)) return 1;
+        const size_t at = ar->off;
+        ar->off += bytes;
+        *dev = (T*)(ar->pinDev + at);
+        *host = (T*)(ar->pin + at);
+        return 0;
+    }
+    // `bytes` of the arena's pinned mirror as plain staging (the caller copies from it itself): nullptr when it does not fit
+    uint8_t* pin_scratch(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        ar->want += bytes;
+        if (!(ar->base && ar->pin && ar->off + bytes <= ar->cap)) return nullptr;
+        uint8_t* p = ar->pin + ar->off;
+        ar->off += bytes;
+        return p;
+    }
+    // Descriptor arrays may already live on the device (an extractor's resident output slab, a gathered slab):
+    // then they are read in place.
+    int up_desc(uint8_t** out, const uint8_t* hostOrDev, size_t n)
+    {
+        if (hostOrDev && n && is_device_ptr(hostOrDev)) {
+            // (an extractor may still be writing it on its own stream: orbfe_order.h)
+            const int w = orbfe_producer_wait(hostOrDev, g_ms);
+            if (w < 0) return w;
+            *out = const_cast<uint8_t*>(hostOrDev);
+            return 0;
+        }
+        return up(out, hostOrDev, n);
+    }
+    // send the staged inputs (called before the first kernel of the call, by KernelScope)
+    int flush()
+    {
+        for (const auto& r : staged) {
+            hipError_t e = hipMemcpyAsync(ar->base + r.first, ar->pin + r.first, r.second, hipMemcpyHostToDevice, g_ms);
+            if (e != hipSuccess) return -(1000 + (int)e);
+        }
+        staged.clear();
+        for (const LateUp& u : lateUps) {
+            hipError_t e = hipMemcpyAsync(u.dev, temps[u.temp].data(), u.bytes, hipMemcpyHostToDevice, g_ms);
+            if (e != hipSuccess) return -(1000 + (int)e);
+        }
+        if (!lateUps.empty()) {
+            hipError_t e = hipStreamSynchronize(g_ms); // pageable sources
+            if (e != hipSuccess) return -(1000 + (int)e);
+            lateUps.clear();
+        }
+        return 0;
+    }
+    // flush() as ONE kernel that also fills [fill, fill + fillBytes) with ones (k_stage_in); false: not applicable (no device
+    // alias of the mirror, more than four runs, a lot of bytes, late uploads) -- nothing was queued, the caller takes flush()
+    // and a clearing command
+    bool flush_by_kernel(void* fill, size_t fillBytes)
+    {
+        if (!ar->pinDev || !ar->base || staged.size() > 4 || !lateUps.empty()) return false;
+        size_t total = 0;
+        for (const auto& r : staged) total += r.second;
+        if (total > (256u << 10) || (fillBytes >> 4) > 0xFFFFFFFFull) return false;
+        StageRuns R;
+        std::memset(&R, 0, sizeof R);
+        for (size_t k = 0; k < staged.size(); k++) {
+            R.src[k] = reinterpret_cast<const uint4*>(ar->pinDev + staged[k].first);
+            R.dst[k] = reinterpret_cast<uint4*>(ar->base + staged[k].first);
+            R.n16[k] = (unsigned)(staged[k].second >> 4);
+        }
+        R.fill = reinterpret_cast<uint4*>(fill);
+        R.fill16 = (unsigned)((fillBytes + 15) >> 4);
+        const size_t units = std::max<size_t>(total >> 4, R.fill16);
+        const unsigned wgs = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (units + 255) / 256));
+        hipLaunchKernelGGL(k_stage_in, dim3(wgs), dim3(256), 0, g_ms, R);
+        if (hipGetLastError() != hipSuccess) return false;
+        staged.clear();
+        return true;
+    }
+    // Results: down() names a device range the caller wants in `host`; fetch() brings all of them back with ONE
+    // transfer of the arena stretch that covers them into the pinned mirror (the outputs of a call are neighbours in
+    // the arena), one stream synchronisation, and a memcpy each -- instead of one blocking pageable copy per array.
+    int down(void* host, const void* dev, size_t bytes)
+    {
+        if (bytes) downs.push_back(Down{host, dev, bytes});
+        return 0;
+    }
+    int fetch()
+    {
+        bool inArena = ar->base && ar->pin && !downs.empty();
+        size_t lo = ~(size_t)0, hi = 0, total = 0;
+        for (const Down& d : downs) total += d.bytes;
+        if (total > (1u << 20)) inArena = false; // a distance matrix: straight into the caller's memory, no second copy
+        for (const Down& d : downs) {
+            const uint8_t* p = (const uint8_t*)d.dev;
+            if (!(ar->base && p >= ar->base && p + d.bytes <= ar->base + ar->cap)) inArena = false;
+            else {
+                lo = std::min(lo, (size_t)(p - ar->base));
+                hi = std::max(hi, (size_t)(p - ar->base) + d.bytes);
+            }
+        }
+        hipError_t e = hipSuccess;
+        if (inArena) {
+            e = hipMemcpyAsync(ar->pin + lo, ar->base + lo, hi - lo, hipMemcpyDeviceToHost, g_ms);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+            if (e == hipSuccess)
+                for (const Down& d : downs) std::memcpy(d.host, ar->pin + ((const uint8_t*)d.dev - ar->base), d.bytes);
+        } else {
+            for (const Down& d : downs)
+                if (e == hipSuccess) e = hipMemcpyAsync(d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, g_ms);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+        }
+        downs.clear();
+        return e == hipSuccess ? 0 : -(1000 + (int)e);
+    }
+    // ---- results and completion of the latency-path calls (DoneSig above): out_block() says where the kernel puts its results
+    // and where the host finds them, done_sig() hands the kernel the call's sequence number when the completion word may be
+    // used, complete() spins on the word for a bounded time -- a call that takes longer gains nothing from spinning -- and
+    // falls back to the stream synchronisation, which also surfaces a failed launch.  ORBFE_SPIN=0
+    // switches the word off.  The flag word is allocated coherent like the mirror.
+    struct OutBlock {
+        uint8_t* dev = nullptr;   // where the kernel writes: its address of the pinned mirror (its stores cross PCIe themselves)
+        uint8_t* host = nullptr;  // the mirror's host address: complete when complete() returns
+        size_t bytes = 0;
+    };
+    // `bytes` of the arena's clean block: device memory that is all ones between calls (whoever scatters into it puts the ones
+    // back when it reads the results).  0 / 1 = not available.
+    int clean_dev(uint8_t** dev, size_t bytes)
+    {
+        if (ar->cleanCap < bytes || ar->cleanDirty) {
+            if (ar->cleanCap < bytes) {
+                if (ar->cleanDev) {
+                    (void)hipStreamSynchronize(g_ms);
+                    (void)hipFree(ar->cleanDev);
+                    ar->cleanDev = nullptr;
+                    ar->cleanCap = 0;
+                }
+                void* p = nullptr;
+                const size_t want = std::max<size_t>(2 * bytes, 64u << 10);
+                if (hipMalloc(&p, want) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return 1;
+                }
+                ar->cleanDev = (uint8_t*)p;
+                ar->cleanCap = want;
+            }
+            if (hipMemsetAsync(ar->cleanDev, 0xFF, ar->cleanCap, g_ms) != hipSuccess) { // (on the call's own stream)
+                (void)hipGetLastError();
+                return 1;
+            }
+            ar->cleanDirty = false;
+        }
+        *dev = ar->cleanDev;
+        return 0;
+    }
+    // 0: *ob describes where the kernel puts `bytes` of results (all ones to begin with) and where the host finds them;
+    // 1: not available (the caller downloads as before)
+    int out_block(OutBlock* ob, size_t bytes, unsigned /* workgroups of the kernel */)
+    {
+        bytes = (bytes + 15) & ~(size_t)15;
+        if (!ar->pinCoherent) return 1;
+        uint8_t *md = nullptr, *mh = nullptr;
+        if (mirror_out(&md, &mh, bytes) != 0) return 1;
+        std::memset(mh, 0xFF, bytes);
+        ob->dev = md;
+        ob->host = mh;
+        ob->bytes = bytes;
+        return 0;
+    }
+    static bool spin_enabled()
+    {
+        static const bool enabled = [] {
+            const char* e = getenv("ORBFE_SPIN"); // (the extractor's switch for the same mechanism)
+            return !(e && e[0] == '0');
+        }();
+        return enabled;
+    }
+    bool done_words()
+    {
+        // (eight waits in a row in which the word NEVER arrived -- not merely late, see complete() -- switch it off for
+        // this thread; one call in 256 still carries it, so a thread that lost it on a loaded GPU gets it back)
+        if (ar->spinMisses >= 8 && (++ar->spinProbe & 255u) != 0u) return false;
+        if (ar->doneCtr) return true;
+        void *c = nullptr, *h = nullptr, *dv = nullptr;
+        // (cleared on the call's own stream: the null stream is not ordered with a non-blocking one)
+        if (hipMalloc(&c, 64) != hipSuccess || hipMemsetAsync(c, 0, 64, g_ms) != hipSuccess ||
+            hipHostMalloc(&h, 64, hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c) (void)hipFree(c);
+            if (h) (void)hipHostFree(h);
+            return false;
+        }
+        ar->doneCtr = (unsigned*)c;
+        ar->doneFlag = (unsigned*)h;
+        ar->doneFlagDev = (unsigned*)dv;
+        *ar->doneFlag = 0u;
+        return true;
+    }
+    // The main kernel's completion record.  With a flag (ctr / flag / seq set): the kernel counts its workgroups and the last one
+    // publishes -- small grids whose inputs are read in place and nobody timing the kernel.  Otherwise the host synchronises.
+    DoneSig done_sig(unsigned waves /* the kernel runs four per workgroup */, const OutBlock* ob, bool timed)
+    {
+        DoneSig d{nullptr, nullptr, 0u, (waves + 3u) / 4u, waves};
+        if (!ob || !ob->dev) return d;
+        if (!spin_enabled() || timed || waves == 0 || d.total > 256u || !inPlace || !done_words()) return d;
+        if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+        d.ctr = ar->doneCtr;
+        d.flag = ar->doneFlagDev;
+        d.seq = ar->doneSeq;
+        return d;
+    }
+    // a word without a block or a counter: for a kernel whose one workgroup writes the mirror itself (K-PROJ's sweeps)
+    DoneSig flag_only()
+    {
+        DoneSig d{nullptr, nullptr, 0u, 1u, 1u};
+        if (!spin_enabled() || !inPlace || !ar->pinCoherent || !done_words()) return d;
+        if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+        d.ctr = ar->doneCtr;
+        d.flag = ar->doneFlagDev;
+        d.seq = ar->doneSeq;
+        return d;
+    }
+    // a word for a small final kernel of `wgs` workgroups that count themselves (no block: the kernel writes the mirror)
+    DoneSig word_for(unsigned wgs)
+    {
+        DoneSig d{nullptr, nullptr, 0u, wgs, wgs};
+        if (!spin_enabled() || !ar->pinCoherent || wgs > 256u || !done_words()) return d;
+        if (++ar->doneSeq == 0u) ar->doneSeq = 1u;
+        d.ctr = ar->doneCtr;
+        d.flag = ar->doneFlagDev;
+        d.seq = ar->doneSeq;
+        return d;
+    }
+    // after the main kernel has been launched: the block's mirror is complete when this returns
+    int complete(const DoneSig& d)
+    {
+        DoneSig w = d;
+        if (w.flag) {
+            const volatile unsigned* f = ar->doneFlag;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0;; it++) {
+                if (*f == w.seq) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    ar->spinMisses = 0;
+                    return 0;
+                }
+                __builtin_ia32_pause();
+                if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
+            }
+        }
+        hipError_t e = hipStreamSynchronize(g_ms);
+        // a miss is a word that has still not arrived when the stream is idle; a word that came after the bound belongs to a long
+        // call, a first call (code object load) or a kernel queued behind somebody else's work, and says nothing about the platform
+        if (w.flag) ar->spinMisses = (*(const volatile unsigned*)ar->doneFlag == w.seq) ? 0 : ar->spinMisses + 1;
+        // the word did not come within the bound: normally a long call (its counter is back at zero by now); should the counter
+        // ever be left non-zero -- a kernel that died half-way -- every later call would time out, so it is cleared here
+        if (e == hipSuccess && w.flag) e = hipMemsetAsync(ar->doneCtr, 0, 64, g_ms); // (all its words: K-PROJ keeps a counter there too)
+        if (e != hipSuccess) ar->cleanDirty = true; // (the block may hold half a call's results)
+        return e == hipSuccess ? 0 : -(1000 + (int)e);
+    }
+};
+
+thread_local float g_lastKernelMs = -1.f;
+thread_local int g_lastProjSweeps = 0;
+thread_local bool g_timeKernels = false; // orbfe_matcher_time_kernels(): bench / tests only
+// Brackets the kernel launches of one call: uploads the staged inputs first; with timing enabled also measures the
+// launches with events (two event creations and a synchronisation per call, so off by default).
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit KernelTimer(Scratch& s)
+    {
+        (void)s.flush();
+        if (g_timeKernels) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, g_ms);
+        }
+    }
+    ~KernelTimer()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, g_ms);
+        (void)hipEventSynchronize(b);
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess) g_lastKernelMs = ms;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+};
+
+int select_device(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return ORBFE_ERR_NODEV;
+    if (device >= kMaxDevices) return ORBFE_ERR_ARGS; // one scratch arena per (thread, device ordinal < 16)
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+bool fv_ok(const orbfe_fv& f)
+{
+    if (f.nn == ORBFE_FV_RESIDENT) return f.node_ids != nullptr; // names an orbfe_bow handle (fv_resolve / bow_run)
+    if (f.nn < 0) return false;
+    if (f.nn > 0 && (!f.node_ids || !f.offsets)) return false;
+    // A FeatureVector is a std::map<NodeId, ...> (Thirdparty/DBoW2/DBoW2/FeatureVector.h:27): its ids come strictly ascending
+    // and therefore unique.  The merge-join, the binary searches and the in-kernel pairing (one ballot over 64 ids of set 2 per
+    // step finds THE partner of a node) all rely on it, so it is checked, not assumed; ~100 ids per vector.
+    for (int i = 1; i < f.nn; i++)
+        if (f.node_ids[i] <= f.node_ids[i - 1]) return false;
+    for (int i = 0; i < f.nn; i++)
+        if (f.offsets[i] < 0 || f.offsets[i + 1] < f.offsets[i]) return false;
+    return true;
+}
+
+// merge-join of two ascending node-id lists (std::map iteration + lower_bound, :285-448)
+template <class F>
+void for_each_shared_node(const orbfe_fv& a, const orbfe_fv& b, F f)
+{
+    int i = 0, j = 0;
+    while (i < a.nn && j < b.nn) {
+        if (a.node_ids[i] == b.node_ids[j]) {
+            f(i, j);
+            i++;
+            j++;
+        } else if (a.node_ids[i] < b.node_ids[j]) {
+            i = (int)(std::lower_bound(a.node_ids + i, a.node_ids + a.nn, b.node_ids[j]) - a.node_ids);
+        } else {
+            j = (int)(std::lower_bound(b.node_ids + j, b.node_ids + b.nn, a.node_ids[i]) - b.node_ids);
+        }
+    }
+}
+
+// ComputeThreeMaxima, src/ORBmatcher.cc:2545-2586
+void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            ind3 = ind2;
+            ind2 = ind1;
+            ind1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            ind3 = ind2;
+            ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+// The rotation-consistency cull (:450-468) on the device for a batch whose results come back by a download command (dozens of problems: the host's two
+// passes over every problem's match array were 45 of a 64-candidate call's 180 us): a workgroup per problem builds the
+// histogram of the rotation bins of its matches, takes the three maxima, clears the matches outside them in place and leaves
+// the number kept in nm[problem].  cull_by_rotation() below is the statement it follows line by line.
+struct BowCull {
+    int outBase, n, check, pad;
+};
+// Mout / nmOut (round 5): the culled rows and the counts written to a second place as well -- the call's pinned mirror, whole
+// rows of consecutive 4-byte stores per wavefront -- so that no download command (and no ~9 us of queue hand-over in front of it)
+// follows the kernel; null: in place only, the caller downloads M and nm.
+__global__ __launch_bounds__(256) void k_bow_cull(const BowCull* __restrict__ C, int32_t* __restrict__ M, const int8_t* __restrict__ B,
+                                                  int32_t* __restrict__ nm, int32_t* __restrict__ Mout, int32_t* __restrict__ nmOut)
+{
+    __shared__ int sHist[32], sInd[3], sCnt;
+    const BowCull c = C[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < 32) sHist[tid] = 0;
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    int32_t* const m = M + c.outBase;
+    const int8_t* const b = B + c.outBase;
+    int cnt = 0;
+    for (int i = tid; i < c.n; i += 256)
+        if (m[i] >= 0) {
+            cnt++;
+            const int bin = b[i];
+            if (c.check && bin >= 0 && bin < HISTO_LENGTH) atomicAdd(&sHist[bin], 1);
+        }
+    if (c.check) {
+        __syncthreads();
+        if (tid == 0) three_maxima_dev(sHist, HISTO_LENGTH, sInd);
+        __syncthreads();
+        const int ind1 = sInd[0], ind2 = sInd[1], ind3 = sInd[2];
+        cnt = 0;
+        for (int i = tid; i < c.n; i += 256) {
+            int v = m[i];
+            if (v >= 0) {
+                const int bin = b[i];
+                if (bin == ind1 || bin == ind2 || bin == ind3) cnt++;
+                else m[i] = v = -1;
+            }
+            if (Mout) Mout[c.outBase + i] = v;
+        }
+    } else if (Mout) {
+        for (int i = tid; i < c.n; i += 256) Mout[c.outBase + i] = m[i];
+    }
+    cnt = wave_sum_i32(cnt);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&sCnt, cnt);
+    __syncthreads();
+    if (tid == 0) {
+        nm[blockIdx.x] = sCnt;
+        if (nmOut) nmOut[blockIdx.x] = sCnt;
+    }
+}
+
+// rotation-consistency cull (:450-468): returns the number of surviving matches
+int cull_by_rotation(int32_t* match, const int8_t* bins, int n, bool check)
+{
+    int nmatches = 0;
+    int histo[HISTO_LENGTH] = {0};
+    for (int i = 0; i < n; i++)
+        if (match[i] >= 0) {
+            nmatches++;
+            if (check && bins[i] >= 0 && bins[i] < HISTO_LENGTH) histo[bins[i]]++;
+        }
+    if (!check) return nmatches;
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < n; i++)
+        if (match[i] >= 0) {
+            const int b = bins[i];
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            match[i] = -1;
+            nmatches--;
+        }
+    return nmatches;
+}
+
+} // namespace
+
+extern "C" {

@@ -366,7 +366,6 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
                 least = greatest = 0;
             }
             int prio = greatest;
-            if (const char* e = getenv("ORBFE_MC_COMM_PRIO")) prio = atoi(e) < 0 ? greatest : atoi(e) > 0 ? least : 0; // (tuning)
             if (hipStreamCreateWithPriority(&m->sComm, hipStreamNonBlocking, prio) != hipSuccess) {
                 (void)hipGetLastError();
                 if (hipStreamCreateWithFlags(&m->sComm, hipStreamNonBlocking) != hipSuccess) return fail(ORBFE_ERR_STATE);

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/orbfe.h"
+#include "../../include/orbfe_debug.h"
 #include "../../include/orbfe_mc.h"
 
 static std::atomic<int> g_fail{0};

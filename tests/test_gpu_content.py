@@ -105,26 +105,3 @@ def test_batches_of_mixed_content(pkg, oracle):
     ex.close()
 
 
-def test_quadtree_with_1024_thread_workgroups_in_a_fresh_process():
-    # ORBFE_QT_WIDE=1 (k_octree<false, 1024> for images with a level of more than 512 cells; measured, not the default --
-    # profiles/r05_qt_wide.txt): the C4 / C5 sized checks once more through it
-    e = dict(os.environ, ORBFE_QT_WIDE="1")
-    tests = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_extractor.py")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", tests, "-k", "test_stagewise_and_final_parity"],
-                       env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
-@pytest.mark.parametrize("env", [{"ORBFE_FAST_RUNS": "1"}])
-def test_alternative_fast_kernel_in_a_fresh_process(env):
-    # k_fast_runs (a workgroup per run of up to four cells: one survivor queue and one corner queue per run, seam-masked NMS,
-    # one rank space per cell, band-wise redo on queue overflow, map-scanning NMS on corner-queue overflow) ships as an option
-    # (ORBFE_FAST_RUNS=1; measured slower than the per-cell kernel): the content kinds -- sinus / checker2 drive
-    # both overflow paths, blurred the second pass per cell -- and the narrow-column widths again with it
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_content_kinds or test_last_cell_column or test_blurred_frames or test_batches_of_mixed"],
-                       env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout

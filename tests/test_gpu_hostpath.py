@@ -389,18 +389,6 @@ def test_stereo_frames_in_flight(pkg, oracle, lanes):
     buf.close()
 
 
-def test_latency_path_with_sub_batches_on_several_streams():
-    # with ORBFE_STREAMS=2 a blocking two-image call runs as two sub-batches; the pinned result mirror used to be
-    # indexed by the image's position in its SUB-batch (both wrote entry 0, entry 1 stayed stale).  The variable is read at
-    # orbfe_create, so the stereo-pair and two-image checks run again in a child process.
-    env = dict(os.environ, ORBFE_STREAMS="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_stereo_pair_extraction_and_matching_in_one_call or test_stereo_pair_in_one_batched_call_resident_matches"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
-
-
 def test_latency_path_without_the_completion_word():
     # The blocking calls of a frame or two end on a completion word the last kernel publishes in page-locked memory (the host
     # spins on it instead of waiting in hipStreamSynchronize).  ORBFE_SPIN=0 restores the stream synchronisation:

@@ -139,17 +139,14 @@ def test_triangulation_search_against_many_neighbours(pkg, oracle):
 
 def test_matcher_latency_paths_in_their_other_forms():
     # The latency-path calls (SearchByBoW, SearchForTriangulation_, SearchByProjection against resident sets) end on a
-    # completion word and write their results straight into the pinned mirror.  The other forms stay in the library as
-    # switches: ORBFE_SPIN=0 (stream synchronisation instead of the word), ORBFE_MATCHER_BLOCK=2 (results through the clean device
-    # block and k_copy_out / the publishing wavefront), ORBFE_MATCHER_INPLACE_KB=0 (inputs uploaded, not read in place), ORBFE_TRI_COMPACT=0 (the triangulation batch's rows come
-    # back and the host compacts and culls them instead of k_tri_compact): the
-    # handle, adapter and matcher tests again under each, in child processes (the switches are read once per process).
+    # completion word and write their results straight into the pinned mirror.  ORBFE_SPIN=0 (a deployment switch: stream
+    # synchronisation instead of the word) is the one other form left after round 6's pruning: the handle, adapter and matcher
+    # tests again under it, in a child process (the switch is read once per process).
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for env in ({"ORBFE_SPIN": "0"}, {"ORBFE_MATCHER_BLOCK": "2"}, {"ORBFE_MATCHER_BLOCK": "2", "ORBFE_SPIN": "0"},
-                {"ORBFE_MATCHER_INPLACE_KB": "0"}, {"ORBFE_TRI_COMPACT": "0"}):
+    for env in ({"ORBFE_SPIN": "0"},):
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_keyframes.py"),
                             os.path.join(here, "test_gpu_matcher.py"), "-k", "not other_forms and (bow or tri or projection or handles or neighbours)"],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
@@ -472,3 +469,67 @@ def test_projection_searches_against_resident_frames_in_one_call(pkg, oracle):
     for f in frames:
         f.close()
     fr.close()
+
+
+def test_destroyed_handles_are_refused_and_destroy_under_a_search_is_deferred(pkg, oracle):
+    """Round 6: orbfe_keyframe_destroy / orbfe_frame_destroy no longer rely on the caller's discipline.
+    A handle that has been destroyed is refused by every entry point (ORBFE_ERR_ARGS, not a dereference), and a destroy that
+    arrives while another thread's search holds the handle is deferred to that search's return: one thread searches a handle
+    over and over while the main thread destroys and re-creates it -- every search either returns the oracle's result or the
+    refusal, nothing else."""
+    import ctypes as C
+    import threading
+    from orb_slam3_detailed_comments_kor_amd import synth
+    rng = np.random.default_rng(77)
+    dF = rng.integers(0, 256, size=(700, 32), dtype=np.uint8)
+    aF = rng.uniform(0, 360, 700).astype(np.float32)
+    fvF = synth.make_feature_vectors(dF, 11, 6, 2)
+    d, origin = _noisy_copy(dF, 800, 5)
+    a = rng.uniform(0, 360, 800).astype(np.float32)
+    fvK = synth.make_feature_vectors(d, 11, 6, 2)
+    mask = np.ones(800, np.uint8)
+    want = oracle.search_bow_kf_f(d, mask, a, fvK, dF, aF, fvF, -1, 0.75, True)
+
+    class Stale:  # a handle's address kept after its destruction
+        def __init__(self, kf):
+            self.h, self.n = C.c_void_p(kf.h.value), kf.n
+
+    kf = pkg.KeyFrameHandle(d, mask, a, fvK)
+    stale = Stale(kf)
+    kf.close()
+    with pytest.raises(pkg.OrbfeError) as e:
+        pkg.search_bow_keyframes([dict(kf1=stale, desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75, check_ori=True)])
+    assert e.value.code == pkg.binding.ERR_ARGS
+    assert pkg.lib().orbfe_keyframe_set_mask(stale.h, mask.ctypes.data) == pkg.binding.ERR_ARGS
+    pkg.lib().orbfe_keyframe_destroy(stale.h)  # a second destroy of the same address: ignored
+
+    box = {"kf": pkg.KeyFrameHandle(d, mask, a, fvK)}
+    stop, bad, seen = threading.Event(), [], {"ok": 0, "refused": 0}
+
+    def searcher():
+        while not stop.is_set():
+            h = Stale(box["kf"])
+            try:
+                n, m = pkg.search_bow_keyframes([dict(kf1=h, desc2=dF, ang2=aF, fv2=fvF, variant=0, nnratio=0.75, check_ori=True)])[0]
+                if n != want[0] or not np.array_equal(m, want[1]):
+                    bad.append("wrong result")
+                seen["ok"] += 1
+            except pkg.OrbfeError as ex:
+                if ex.code != pkg.binding.ERR_ARGS:
+                    bad.append(ex.code)
+                seen["refused"] += 1
+            except AttributeError:  # (box["kf"].h is None for a moment between close and re-create)
+                seen["refused"] += 1
+    t = threading.Thread(target=searcher)
+    t.start()
+    try:
+        for _ in range(150):
+            old = box["kf"]
+            box["kf"] = pkg.KeyFrameHandle(d, mask, a, fvK)
+            old.close()
+    finally:
+        stop.set()
+        t.join()
+    box["kf"].close()
+    assert not bad, bad[:5]
+    assert seen["ok"] > 20

@@ -1,5 +1,5 @@
 """Lanes (orbfe_set_lanes / orbfe_set_lane_mode, include/orbfe.h): 2..4 device-pointer batches in flight on streams the context
-owns -- whole batches round-robin (ORBFE_LANES_BATCH, round 5) or two half-batches of every call (ORBFE_LANES_SPLIT, round 4).
+owns -- whole batches round-robin.
 Outputs must be bit-identical to the one-lane results (and to the oracle's), and every documented join point must really order
 the lanes: orbfe_sync, orbfe_lanes_join + work on the context's stream, orbfe_get_device_outputs + a matcher call,
 orbfe_get_level, a host-pointer call, a batch of another size.  Batch lanes in addition: a ring of output sets with DIFFERENT
@@ -58,7 +58,7 @@ def _check_against_oracle(pkg, oracle, imgs, lap, out, nf, idxs):
         assert np.array_equal(desc[i, : n[i]], rdesc), i
 
 
-MODES = [(2, 1), (2, 0), (3, 0), (4, 0)]  # (lanes, mode): mode 1 = ORBFE_LANES_SPLIT, 0 = ORBFE_LANES_BATCH
+MODES = [(2, 0), (3, 0), (4, 0)]  # (lanes, mode): ORBFE_LANES_BATCH is the one mode (round 4's half-batches left in round 6)
 
 
 @pytest.mark.parametrize("lanes,mode", MODES)

@@ -197,19 +197,6 @@ def test_frames_knn2_on_the_matrix_pipe_is_exact(pkg, oracle):
             assert np.array_equal(idx[k, :counts[q]], ri) and np.array_equal(dist[k, :counts[q]], rd), (cap, q, t)
 
 
-def test_frames_knn2_vector_pipe_kernel_in_a_fresh_process():
-    # ORBFE_KNN2_MFMA=0 keeps k_bfknn2_frames (the form for frames of more than 2048 keypoints, and the A/B of the MFMA
-    # kernel): the same checks through it
-    import subprocess
-    import sys
-    env = dict(os.environ, ORBFE_KNN2_MFMA="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_frames_knn2_on_the_matrix_pipe_is_exact or test_frames_knn2_ragged_counts"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
-
-
 def test_matcher_orders_itself_after_an_asynchronous_extraction(pkg, oracle):
     """orbfe_extract_batch_device returns at once; orbfe_get_device_outputs marks the context's stream and a matcher call
     that is handed the resident descriptors waits for that mark on its own stream -- no orbfe_sync in between (the calls
