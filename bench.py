@@ -487,6 +487,68 @@ def pmc_measure(args, batch):
         _sh.rmtree(tmp, ignore_errors=True)
 
 
+def plan_only(args, world, rank, local_rank, batch_given, real_stdout):
+    """--plan: the N-rank launch path without a GPU.  What is rehearsed is exactly what a first run on eight GPUs has never
+    executed: RANK / LOCAL_RANK / WORLD_SIZE -> device and shard, the ranks' agreement on the exchange transport (a MIN
+    all-reduce: every rank must be able to make its orbfe_mc handle, else all fall back together), one line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_detailed_comments_kor_amd as pkg
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames_total = args.batch * world
+    first, count = pkg.binding.mc_shard(frames_total, world, rank)  # the library's own shard arithmetic (orbfe_mc_shard)
+    # can THIS rank use the C-ABI exchange?  (the library loads, knows the entry points, and finds librccl)
+    can = 0
+    try:
+        L = pkg.lib()
+        import ctypes
+        can = 1 if (hasattr(L, "orbfe_mc_create") and args.exchange == "cabi") else 0
+        if can:
+            try:
+                ctypes.CDLL("librccl.so.1")
+            except OSError:
+                try:
+                    ctypes.CDLL("/opt/rocm/lib/librccl.so.1")
+                except OSError:
+                    can = 0
+    except Exception:  # noqa: BLE001
+        can = 0
+    mine = {"rank": rank, "local_rank": local_rank, "device": "cuda:%d" % local_rank, "first_frame": first, "frames": count, "cabi": can}
+    if world > 1:
+        flag = torch.tensor([can], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        agreed = int(flag.item())
+        plans = [None] * world
+        dist.all_gather_object(plans, mine)
+    else:
+        agreed, plans = can, [mine]
+    if rank == 0:
+        H, W = args.rows, args.cols
+        lanes = args.lanes if args.lanes is not None else (3 if args.batch < 16 else 2)
+        cap_guess = None
+        out = {"metric": "keypoints+descriptors/sec on %dx%dx8-level pyramid" % (W, H), "plan": True, "value": None, "n_gpus": world,
+               "scaling": "strong" if args.config == "c4" and not batch_given else "weak",
+               "config": {"workload": "%dx%d, nFeatures=%d: %d frames in total, %d per rank%s" % (
+                              W, H, args.nfeatures, frames_total, args.batch,
+                              " (BASELINE configs[3] sharded over the ranks)" if args.config == "c4" else " (BASELINE configs[1] batched)"),
+                          "frames_per_step": frames_total, "frames_per_rank": args.batch, "lanes": lanes,
+                          "exchange": ("cabi: one ncclAllGather of %d-frame descriptor slabs per step issued by liborbfe.so" % args.batch)
+                                      if agreed and world > 1 else ("torch.distributed all-gather (some rank cannot make the C-ABI handle)"
+                                                                  if world > 1 else "none"),
+                          "ranks": plans}}
+        del cap_guess
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at communicator
     # creation, for one): until the line is ready, file descriptor 1 points at stderr.
@@ -540,6 +602,10 @@ def main():
                          "and rotate through --rotate buffers")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4 per priority)")
+    ap.add_argument("--plan", action="store_true",
+                    help="no GPU work: every rank resolves what it WOULD run (device of its LOCAL_RANK, its shard of the frames, the "
+                         "exchange transport all ranks agree on through a MIN all-reduce -- over gloo, so the launcher path of an N-GPU "
+                         "run can be rehearsed on a CPU) and rank 0 prints ONE JSON line with the plan (tests/test_bench_plan.py)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes (roofline.traffic / issue_frac: null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--contexts", type=int, default=1,
@@ -580,6 +646,8 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.plan:
+        return plan_only(args, world, rank, local_rank, batch_given, real_stdout)
     # HBM traffic and wave-instruction counts of THIS tree, by two counter passes over a child of this script -- before this
     # process touches the GPU (the child has the chip to itself; nothing here forks after HIP is initialised)
     pmc_live = None

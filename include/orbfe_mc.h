@@ -40,6 +40,9 @@ extern "C" {
 #define ORBFE_MC_RCCL 0
 #define ORBFE_MC_HOST 1
 #define ORBFE_MC_ID_BYTES 128 /* == sizeof(ncclUniqueId) */
+/* An RCCL call failed (ncclGetUniqueId / ncclCommInitRank at create: no handle is returned; ncclAllGather at submit: the batch is
+ * NOT in flight, the slot stays free).  orbfe_error_string knows the code; ORBFE_VERBOSE=1 prints RCCL's own reason to stderr. */
+#define ORBFE_MC_ERR_RCCL (-8)
 
 typedef struct orbfe_mc orbfe_mc;
 

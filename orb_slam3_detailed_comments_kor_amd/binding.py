@@ -15,7 +15,7 @@ _LIB = None
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
 
-ERR_ARGS, ERR_NODEV, ERR_STATE, ERR_IMAGE_SMALL, ERR_IMAGE_LARGE, ERR_NFEATURES = -2, -3, -4, -5, -6, -7
+ERR_ARGS, ERR_NODEV, ERR_STATE, ERR_IMAGE_SMALL, ERR_IMAGE_LARGE, ERR_NFEATURES, MC_ERR_RCCL = -2, -3, -4, -5, -6, -7, -8
 TRIG_LIBM, TRIG_CR, TRIG_LIBM_HOSTCHECK = 0, 1, 2
 LANES_BATCH, MAX_LANES = 0, 4  # ORBFE_LANES_BATCH / ORBFE_MAX_LANES (include/orbfe.h)
 STAGES = ("pyramid", "fast", "octree", "pack", "desc", "trigfix")

@@ -2255,6 +2255,7 @@ const char* orbfe_error_string(int code)
     case ORBFE_ERR_IMAGE_LARGE: return "image too large: a side above 4096 px (candidates are packed with 12-bit coordinates)";
     case ORBFE_ERR_NFEATURES:
         return "nfeatures too large: more than 65535 keypoint slots per image";
+    case -8: return "an RCCL call failed (orbfe_mc_*: ncclGetUniqueId / ncclCommInitRank / ncclAllGather); ORBFE_VERBOSE=1 prints RCCL's reason";
     default: break;
     }
     if (code >= 0) return "success";

@@ -279,7 +279,7 @@ int orbfe_mc_unique_id(int transport, void* id128)
         Rccl& R = rccl();
         if (!R.ok) return ORBFE_ERR_NODEV;
         Rccl::unique_id id;
-        if (R.GetUniqueId(&id) != 0) return ORBFE_ERR_STATE;
+        if (R.GetUniqueId(&id) != 0) return ORBFE_MC_ERR_RCCL;
         std::memcpy(id128, &id, ORBFE_MC_ID_BYTES);
         return 0;
     }
@@ -394,12 +394,13 @@ int orbfe_mc_create(orbfe_mc** out, orbfe_ctx* ctx, const void* id128, int rank,
         if (!R.ok) return fail(ORBFE_ERR_NODEV);
         Rccl::unique_id id;
         if (id128) std::memcpy(&id, id128, ORBFE_MC_ID_BYTES);
-        else if (R.GetUniqueId(&id) != 0) return fail(ORBFE_ERR_STATE); // world == 1 without an id
+        else if (R.GetUniqueId(&id) != 0) return fail(ORBFE_MC_ERR_RCCL); // world == 1 without an id
         const int e = R.CommInitRank(&m->comm, world, id, rank);
-        if (e != 0) {
-            std::fprintf(stderr, "orbfe_mc: ncclCommInitRank failed: %s\n", R.GetErrorString ? R.GetErrorString(e) : "?");
+        if (e != 0) { // (the reason goes to stderr only when asked for: a library does not print on its caller's behalf)
+            if (getenv("ORBFE_VERBOSE"))
+                std::fprintf(stderr, "orbfe_mc: ncclCommInitRank failed: %s\n", R.GetErrorString ? R.GetErrorString(e) : "?");
             m->comm = nullptr;
-            return fail(ORBFE_ERR_STATE);
+            return fail(ORBFE_MC_ERR_RCCL);
         }
     } else if (world > 1 || !ctx) {
         char idz[ORBFE_MC_ID_BYTES + 1];
@@ -461,8 +462,11 @@ int orbfe_mc_extract_exchange_submit(orbfe_mc* m, const uint8_t* d_imgs, int row
     if (m->transport == ORBFE_MC_RCCL) {
         const int e = rccl().AllGather(b.slab, b.gathered, m->lay.slab_bytes, kNcclUint8, m->comm, m->sComm);
         if (e != 0) {
-            std::fprintf(stderr, "orbfe_mc: ncclAllGather failed: %s\n", rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
-            b.status = ORBFE_ERR_STATE;
+            // The collective was not queued: the batch is NOT in flight (nothing to wait for), the slot stays free, and the
+            // caller gets the code at once -- the other ranks' matching calls will not complete, which is theirs to time out on.
+            if (getenv("ORBFE_VERBOSE"))
+                std::fprintf(stderr, "orbfe_mc: ncclAllGather failed: %s\n", rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
+            return ORBFE_MC_ERR_RCCL;
         }
     } else if (m->world == 1) {
         MC_HIP_TRY(hipMemcpyAsync(b.gathered, b.slab, m->lay.slab_bytes, hipMemcpyDeviceToDevice, m->sComm));

@@ -48,6 +48,20 @@ def test_cpp_host_world2_shared_memory_transport(tmp_path, lanes):
     assert "all 2 ranks ok" in out.stdout and out.stdout.count("transport host") == 2
 
 
+def test_cpp_host_world5_c4_shards_three_batches_in_flight(tmp_path):
+    """Multi-GPU readiness without eight GPUs: the shard ONE of eight ranks runs on BASELINE configs[3] -- 8
+    frames of 1280x720, three batch lanes, up to three batches in flight -- on five ranks at once over the shared-memory
+    transport (five, not eight: the GPU box allows six processes on the card and this test process is one of them).  Every
+    rank checks the gathered slabs of ALL ranks against its own extraction of their frames and its ring matches (the last local
+    frame's partner lives on the next rank) against orbfe_bfknn2."""
+    exe = _build(tmp_path)
+    _, raw = _frames(tmp_path, 40, 720, 1280)
+    out = subprocess.run([exe, raw, "720", "1280", "40", "5", "1", "1000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=600, env=dict(os.environ, ORBFE_LANES="3"))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all 5 ranks ok" in out.stdout and out.stdout.count("transport host") == 5 and out.stdout.count("8 frames per rank") == 5
+
+
 def test_ctypes_handle_against_the_oracle(oracle):
     """extract -> all-gather (RCCL, one rank) -> ring matching through binding.MultiCam: slab contents and knn-2 results
     equal the oracle's extraction and its brute-force matcher."""
