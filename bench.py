@@ -403,7 +403,7 @@ def pmc_child(args):
     import orb_slam3_detailed_comments_kor_amd as pkg
     B, H, W = args.batch or 64, args.rows, args.cols
     dev = torch.device("cuda", 0)
-    d_img = torch.from_numpy(bench_frames(H, W, B, 0)).to(dev)
+    d_img = torch.from_numpy(bench_frames(H, W, B, 0)).pin_memory().to(dev)
     ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=0)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -668,7 +668,7 @@ def main():
         args.lanes = 3 if args.batch < 16 else 2
     B, H, W = args.batch, args.rows, args.cols
     imgs = bench_frames(H, W, B, rank)  # distinct frames per rank
-    d_img = torch.from_numpy(imgs).to(dev)
+    d_img = torch.from_numpy(imgs).pin_memory().to(dev)
 
     ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank,
                           trig={"libm": pkg.binding.TRIG_LIBM, "cr": pkg.binding.TRIG_CR,

@@ -310,6 +310,7 @@ struct orbfe_ctx : orbfe_geom_state {
     PinBuf<float> h_stereo;
     DevBuf<uint8_t> d_stereoIo; // orbfe_compute_stereo_matches: keypoints and descriptors of both images | uRight | depth | sad
     PinBuf<uint8_t> h_stereoIo;
+    PinBuf<uint8_t> h_level; // orbfe_get_level's staging (mvImagePyramid on request)
     hipEvent_t evStereo = nullptr;
     std::vector<int> stereoSads; // scratch of the outlier cut (kept: no allocation per frame)
     hipEvent_t evOutputs = nullptr; // recorded by orbfe_get_device_outputs: the point after which the resident outputs are final
@@ -2314,7 +2315,7 @@ void orbfe_destroy(orbfe_ctx* c)
     for (auto& g : c->geomCache) g.release_tables();
     c->d_taps.release(); c->d_patternF.release();
     c->h_fix.release(); c->h_fixAB.release(); c->d_stereo.release(); c->h_stereo.release(); c->d_done.release(); c->h_done.release();
-    c->d_stereoIo.release(); c->h_stereoIo.release();
+    c->d_stereoIo.release(); c->h_stereoIo.release(); c->h_level.release();
     for (auto& sl : c->slot) {
         sl.d_img.release(); sl.d_out.release(); sl.h_in.release(); sl.h_out.release(); sl.h_lap.release();
         if (sl.evIn) (void)hipEventDestroy(sl.evIn);
@@ -2806,9 +2807,18 @@ int orbfe_get_level(orbfe_ctx* c, int img_index, int level, uint8_t* dst, size_t
     hipLaunchKernelGGL(k_border, dim3((unsigned)((W * H + 255) / 256)), dim3(256), 0, c->stream, c->d_pyr.p,
                        c->pyrStride, L, img_index);
     const uint8_t* src = c->d_pyr.p + (size_t)img_index * c->pyrStride + L.bufOff + (ORBFE_ROI_X0 - ORBFE_EDGE);
-    HIP_TRY(hipMemcpy2DAsync(dst, dst_stride, src, (size_t)L.pitch, (size_t)W, (size_t)H, hipMemcpyDeviceToHost,
-                             c->stream));
+    // Through page-locked memory of the context, never a rect copy into the caller's (pageable) array.  A 2-D copy to pageable
+    // memory makes the runtime pin the destination on the fly (a userptr mapping) and keep it in a per-stream cache keyed by host
+    // address; once the heap that held an earlier destination has been trimmed and grown again, a later call whose array lands
+    // on the same address is served from that cache with a mapping that is no longer valid, and the copy kernel dies with
+    // "Memory access fault by GPU ... on address <a host heap address>" -- seen once in this very call in round 6 (and the
+    // likeliest reading of round 5's unexplained SIGABRT: the runtime's message went to a captured stderr).  DESIGN.md 7.6.
+    const size_t bytes = (size_t)(H - 1) * L.pitch + (size_t)W;
+    int r = c->h_level.ensure(bytes);
+    if (r < 0) return r;
+    HIP_TRY(hipMemcpyAsync(c->h_level.p, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < H; y++) std::memcpy(dst + (size_t)y * dst_stride, c->h_level.p + (size_t)y * L.pitch, (size_t)W);
     return 0;
 }
 

@@ -96,7 +96,7 @@ def test_compute_bow_on_the_extractors_device_outputs(pkg, oracle):
     ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, device=0)
     mono, kps, desc = ex(img, (0, 0))
     cap = ex.max_keypoints(480, 752)
-    d_img = torch.from_numpy(img).cuda()
+    d_img = torch.from_numpy(img).pin_memory().cuda()
     d_kps = torch.zeros(cap * 28, dtype=torch.uint8, device="cuda")
     d_desc = torch.zeros((cap, 32), dtype=torch.uint8, device="cuda")
     d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -162,7 +162,7 @@ def test_relocalisation_chain_without_a_host_copy_of_the_vector(pkg, oracle, k, 
     want = [oracle.search_bow_kf_f(d, m, a, fv, dF, aF, fvF, -1, 0.75, True) for d, m, a, fv in sets]
     assert sum(w[0] for w in want) > 2000
     # the frame's descriptors on the device, its vector in the Bow handle: nothing of the frame but angles travels with the call
-    d_dF = torch.from_numpy(dF).cuda()
+    d_dF = torch.from_numpy(dF).pin_memory().cuda()
     torch.cuda.synchronize()
     BF.compute((d_dF.data_ptr(), nF), levelsup)          # asynchronous; no host() in between
     got = pkg.search_bow_keyframes([dict(kf1=kfs[c], desc2=(d_dF.data_ptr(), nF), ang2=aF, fv2=BF, variant=0, nnratio=0.75,

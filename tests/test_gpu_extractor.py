@@ -357,7 +357,7 @@ def test_device_resident_batch_and_full_size_properties(pkg, oracle):
     ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
     cap = ex.max_keypoints(H, W)
     dev = torch.device("cuda:0")
-    d_img = torch.from_numpy(imgs).to(dev)
+    d_img = torch.from_numpy(imgs).pin_memory().to(dev)
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -474,7 +474,7 @@ def test_device_batch_with_row_pitch(pkg, oracle):
     ex = pkg.ORBextractor(400, 1.2, 8, 20, 7)
     cap = ex.max_keypoints(H, W)
     dev = torch.device("cuda:0")
-    d_img = torch.from_numpy(buf).to(dev)
+    d_img = torch.from_numpy(buf).pin_memory().to(dev)
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)

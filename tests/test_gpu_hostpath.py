@@ -198,7 +198,7 @@ def test_sync_reports_no_error_and_device_path_still_matches(pkg, oracle):
     ex = pkg.ORBextractor(400, 1.2, 8, 20, 7)
     img = pkg.synth.make_frame(H, W, 77)
     cap = ex.max_keypoints(H, W)
-    d_img = torch.from_numpy(img).cuda()
+    d_img = torch.from_numpy(img).pin_memory().cuda()
     d_k = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda")
     d_d = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
     d_n = torch.zeros(1, dtype=torch.int32, device="cuda")

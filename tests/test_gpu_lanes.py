@@ -70,7 +70,7 @@ def test_lanes_equal_one_lane_and_the_oracle(pkg, oracle, B, hw, lanes, mode):
     dev = torch.device("cuda:0")
     kinds = list(pkg.synth.FRAME_KINDS)
     imgs = np.stack([pkg.synth.make_frame_kind(H, W, 500 + i, kinds[i % len(kinds)]) for i in range(B)])
-    d_img = torch.from_numpy(imgs).to(dev)
+    d_img = torch.from_numpy(imgs).pin_memory().to(dev)
     ex1 = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex2 = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex2.set_lanes(lanes, mode)
@@ -97,7 +97,7 @@ def test_join_points_order_the_lanes(pkg, oracle, lanes, mode):
     dev = torch.device("cuda:0")
     imgs = np.stack([pkg.synth.make_frame(H, W, 800 + i) for i in range(B)])
     imgs2 = np.stack([pkg.synth.make_frame(H, W, 900 + i) for i in range(B)])
-    d_a, d_b = torch.from_numpy(imgs).to(dev), torch.from_numpy(imgs2).to(dev)
+    d_a, d_b = torch.from_numpy(imgs).pin_memory().to(dev), torch.from_numpy(imgs2).pin_memory().to(dev)
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex.set_lanes(lanes, mode)
     stream = torch.cuda.Stream(device=dev)
@@ -187,7 +187,7 @@ def test_batch_lanes_ring_of_outputs_distinct_inputs_no_join(pkg, oracle, lanes)
     ncall = 12
     imgs = [np.stack([pkg.synth.make_frame_kind(H, W, 3000 + 16 * k + i, pkg.synth.FRAME_KINDS[(k + i) % 7]) for i in range(B)])
             for k in range(ncall)]
-    d_imgs = [torch.from_numpy(a).to(dev) for a in imgs]
+    d_imgs = [torch.from_numpy(a).pin_memory().to(dev) for a in imgs]
     lap = (120, 380)
     want = [_oracle_outputs(oracle, a, lap, nf) for a in imgs]
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
@@ -252,7 +252,7 @@ def test_batch_lanes_same_image_buffer_refilled_between_calls(pkg, oracle, lanes
     lap = (0, 1000)
     want = [_oracle_outputs(oracle, a, lap, nf) for a in imgs]
     pinned = [torch.from_numpy(a).pin_memory() for a in imgs]
-    resident = [torch.from_numpy(a).to(dev) for a in imgs]
+    resident = [torch.from_numpy(a).pin_memory().to(dev) for a in imgs]
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex.set_lanes(lanes)
     stream = torch.cuda.Stream(device=dev)
@@ -301,7 +301,7 @@ def test_batch_lanes_shapes_change_while_lanes_are_busy(pkg, oracle):
             imgs = np.stack([pkg.synth.make_frame(H, W, 8100 + 16 * k + i) for i in range(B)])
         cap = ex.max_keypoints(H, W)
         out = _bufs(torch, B, cap, dev)
-        d = torch.from_numpy(imgs).to(dev)
+        d = torch.from_numpy(imgs).pin_memory().to(dev)
         torch.cuda.synchronize()
         _run(ex, d, B, H, W, (0, 0), out, cap)
         outs.append((out, d))

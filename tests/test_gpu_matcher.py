@@ -403,7 +403,7 @@ def test_projection_searches_on_a_resident_frame(pkg, oracle):
     # a two-camera frame, and descriptors that are already on the device
     import torch
     rig = projection_problem(211, n=1500, nq=1100, mode=0, Nleft=800, partners=True)
-    d_desc = torch.from_numpy(rig["desc"]).cuda()
+    d_desc = torch.from_numpy(rig["desc"]).pin_memory().cuda()
     fr = pkg.ProjectionFrame(rig, desc_ptr=(d_desc.data_ptr(), len(rig["desc"])))
     ref = oracle.search_projection(rig)
     got = fr.search(rig)

@@ -70,7 +70,7 @@ def test_ctypes_handle_against_the_oracle(oracle):
     from orb_slam3_detailed_comments_kor_amd import binding
     rows, cols, frames = 240, 376, 3
     imgs = np.stack([pkg.synth.make_frame(rows, cols, 700 + i) for i in range(frames)])
-    d_img = torch.from_numpy(imgs).cuda()
+    d_img = torch.from_numpy(imgs).pin_memory().cuda()
     ex = pkg.ORBextractor(500, 1.2, 8, 20, 7, device=0)
     ex.set_lanes(3)  # (round 5: the exchange rides on the batch lanes)
     ex.set_lane_input_guard(False)
@@ -112,7 +112,7 @@ def test_two_lane_context_behind_the_exchange(oracle):
     from orb_slam3_detailed_comments_kor_amd import binding
     rows, cols, frames = 240, 376, 16
     sets = [np.stack([pkg.synth.make_frame(rows, cols, 1200 + 40 * s + i) for i in range(frames)]) for s in range(2)]
-    d_sets = [torch.from_numpy(a).cuda() for a in sets]
+    d_sets = [torch.from_numpy(a).pin_memory().cuda() for a in sets]
     ex = pkg.ORBextractor(400, 1.2, 8, 20, 7, device=0)
     ex.set_lanes(2)
     cap = ex.max_keypoints(rows, cols)

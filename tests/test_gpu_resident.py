@@ -27,7 +27,7 @@ def test_cross_camera_knn2_on_the_gathered_slab(pkg, oracle):
         ex.set_stream(stream.cuda_stream)
         cap = ex.max_keypoints(H, W)
         imgs = np.stack([pkg.synth.make_frame(H, W, 300 + i) if i != 3 else np.zeros((H, W), np.uint8) for i in range(B)])
-        d_img = torch.from_numpy(imgs).to(dev)
+        d_img = torch.from_numpy(imgs).pin_memory().to(dev)
         pipe = PipelinedExchange(B, cap, dev, 1, 0)
         d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
         d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -106,14 +106,14 @@ def test_frames_knn2_ragged_counts_and_both_kernel_shapes(pkg, oracle):
         counts[0], counts[1], counts[2] = cap, 1, 0
         desc = rng.integers(0, 256, size=(frames, cap, 32), dtype=np.uint8)
         desc[1, 0] = desc[0, 5]  # exact duplicate -> distance 0, ties elsewhere from the small sets
-        d_desc = torch.from_numpy(desc).to(dev)
-        d_cnt = torch.from_numpy(counts).to(dev)
+        d_desc = torch.from_numpy(desc).pin_memory().to(dev)
+        d_cnt = torch.from_numpy(counts).pin_memory().to(dev)
         pairs = [(i, (i + h) % frames) for h in hops for i in range(frames)]
         rec = np.zeros(len(pairs), pkg.binding.KNN2_JOB_DTYPE)
         for k, (q, t) in enumerate(pairs):
             rec[k] = (d_desc.data_ptr() + q * cap * 32, d_cnt.data_ptr() + 4 * q, d_desc.data_ptr() + t * cap * 32,
                       d_cnt.data_ptr() + 4 * t)
-        d_jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        d_jobs = torch.from_numpy(rec.view(np.uint8).copy()).pin_memory().to(dev)
         d_idx = torch.full((len(pairs), cap, 2), -7, dtype=torch.int32, device=dev)
         d_dist = torch.full((len(pairs), cap, 2), -7, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
@@ -127,12 +127,12 @@ def test_frames_knn2_ragged_counts_and_both_kernel_shapes(pkg, oracle):
 
 
 def _frames_knn2(pkg, torch, dev, desc, counts, pairs, cap):
-    d_desc = torch.from_numpy(desc).to(dev)
-    d_cnt = torch.from_numpy(counts).to(dev)
+    d_desc = torch.from_numpy(desc).pin_memory().to(dev)
+    d_cnt = torch.from_numpy(counts).pin_memory().to(dev)
     rec = np.zeros(len(pairs), pkg.binding.KNN2_JOB_DTYPE)
     for k, (q, t) in enumerate(pairs):
         rec[k] = (d_desc.data_ptr() + q * cap * 32, d_cnt.data_ptr() + 4 * q, d_desc.data_ptr() + t * cap * 32, d_cnt.data_ptr() + 4 * t)
-    d_jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    d_jobs = torch.from_numpy(rec.view(np.uint8).copy()).pin_memory().to(dev)
     d_idx = torch.full((len(pairs), cap, 2), -7, dtype=torch.int32, device=dev)
     d_dist = torch.full((len(pairs), cap, 2), -7, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -207,7 +207,7 @@ def test_matcher_orders_itself_after_an_asynchronous_extraction(pkg, oracle):
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     cap = ex.max_keypoints(H, W)
     imgs = np.stack([pkg.synth.make_frame(H, W, 40 + i) for i in range(B)])
-    d_img = torch.from_numpy(imgs).to(dev)
+    d_img = torch.from_numpy(imgs).pin_memory().to(dev)
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)

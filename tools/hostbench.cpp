@@ -24,6 +24,7 @@
 #include <string>
 #include <thread>
 #include <functional>
+#include <map>
 #include <vector>
 
 #include "../include/orbfe.h"
@@ -518,6 +519,133 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
     for (int i = 0; i < NB; i++) outp[i] = outs[i].data();
     if (timeit("search_bow_batch64_host_arrays", 60, [&] { return orbfe_search_bow_batch(dev, NB, many.data(), outp.data(), nms.data()); }, out)) return 2;
     if (timeit("search_bow_batch64_keyframe_handles", 60, [&] { return orbfe_search_bow_keyframes(dev, NB, kfs.data(), nullptr, manyDev.data(), outp.data(), nms.data()); }, out)) return 2;
+    // ---- The relocalisation chain (src/Tracking.cc:3760-3790): the current frame B is extracted, ComputeBoW, then
+    // SearchByBoW against 64 candidate keyframes in handles.  "resident": the frame's descriptors stay where the extractor left
+    // them, orbfe_compute_bow leaves the FeatureVector on the device and the search reads it there (orbfe_bow_fv) -- no host round
+    // trip between the three stages.  "host fold": round 5's form -- per-feature word / node / weight downloaded
+    // (orbfe_vocab_transform), the maps folded on the host, the vector uploaded with the search.
+    {
+        // a k = 10, L = 3 vocabulary around frame A's descriptors (a trained tree is descriptor-like): 1000 words, 100 nodes one
+        // level above the leaves (levelsup = 1, what levelsup = 4 is to ORBvoc's six levels)
+        const int K = 10, L3 = 3;
+        std::vector<uint8_t> vd(32, 0);
+        std::vector<int32_t> voff, vids, vword;
+        std::vector<double> vw;
+        std::vector<int> parentOf(1, -1), depth(1, 0);
+        unsigned long long g = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&] { g = g * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(g >> 33); };
+        std::vector<std::vector<int>> kids(1);
+        for (int lvl = 1; lvl <= L3; lvl++) {
+            const int nPrev = (int)parentOf.size();
+            for (int pnode = 0; pnode < nPrev; pnode++) {
+                if (depth[pnode] != lvl - 1) continue;
+                for (int c = 0; c < K; c++) {
+                    uint8_t d[32];
+                    if (lvl == 1) memcpy(d, dA.data() + (size_t)((c * 977 + 13) % nA) * 32, 32);
+                    else {
+                        memcpy(d, vd.data() + (size_t)pnode * 32, 32);
+                        for (int f = 0; f < 22; f++) {
+                            const unsigned b = rnd() % 256;
+                            d[b >> 3] ^= (uint8_t)(1u << (b & 7));
+                        }
+                    }
+                    const int id = (int)parentOf.size();
+                    parentOf.push_back(pnode);
+                    depth.push_back(lvl);
+                    kids.push_back({});
+                    kids[pnode].push_back(id);
+                    vd.insert(vd.end(), d, d + 32);
+                }
+            }
+        }
+        const int nn = (int)parentOf.size();
+        int nwords = 0;
+        voff.assign(nn + 1, 0);
+        for (int i = 0; i < nn; i++) {
+            voff[i + 1] = voff[i] + (int)kids[i].size();
+            for (int c : kids[i]) vids.push_back(c);
+            vword.push_back(kids[i].empty() ? nwords++ : -1);
+            vw.push_back(kids[i].empty() ? 0.5 + (rnd() % 1000) * 1e-3 : 0.0);
+        }
+        orbfe_vocab tree{nn, vd.data(), voff.data(), vids.data(), vword.data(), vw.data(), L3};
+        orbfe_vocab_dev* voc = nullptr;
+        CHECK(orbfe_vocab_upload(&voc, dev, &tree));
+        orbfe_bow *bowA = nullptr, *bowB = nullptr;
+        CHECK(orbfe_bow_create(&bowA, voc, cap));
+        CHECK(orbfe_bow_create(&bowB, voc, cap));
+        // the candidate keyframe (A): KeyFrame::ComputeBoW once, the handle keeps the vector
+        CHECK(orbfe_compute_bow(bowA, ddA, nA, 1));
+        orbfe_keyframe_args kv = ka;
+        kv.mask = maskA.data();
+        CHECK(orbfe_bow_fv(bowA, &kv.fv));
+        orbfe_keyframe* kfV = nullptr;
+        CHECK(orbfe_keyframe_create(&kfV, dev, &kv));
+        std::vector<orbfe_keyframe*> kfsV(NB, kfV);
+        orbfe_bow_args rb = bowDev; // set 2 = the frame B: device descriptors, angles from the host keypoints, the vector below
+        std::vector<orbfe_bow_args> relRes(NB, rb), relHost(NB, rb);
+        // host fold of round 5 (what binding.bow_from_transform does, in C++): FeatureVector only -- the BowVector is not needed by the search
+        std::vector<int32_t> tw(cap), tn(cap);
+        std::vector<double> twt(cap);
+        HostFv hf;
+        auto host_fold = [&]() -> int {
+            const int r = orbfe_vocab_transform(voc, ddB, nB, 1, tw.data(), tn.data(), twt.data());
+            if (r < 0) return r;
+            std::map<uint32_t, std::vector<int32_t>> m;
+            for (int i = 0; i < nB; i++)
+                if (twt[i] > 0) m[(uint32_t)tn[i]].push_back(i);
+            hf.ids.clear(); hf.off.assign(1, 0); hf.ind.clear();
+            for (auto& e : m) {
+                hf.ids.push_back(e.first);
+                hf.ind.insert(hf.ind.end(), e.second.begin(), e.second.end());
+                hf.off.push_back((int32_t)hf.ind.size());
+            }
+            return 0;
+        };
+        int nmRes = -1, nmFold = -1;
+        auto chain_resident = [&](bool extract) -> int {
+            if (extract) {
+                int r = orbfe_extract(exB, imgB.data(), rows, cols, cols, 0, 0, kB.data(), dB.data(), cap, &nB);
+                if (r < -1) return r;
+                const uint8_t* dd = nullptr;
+                if ((r = orbfe_get_device_outputs(exB, nullptr, &dd, nullptr, nullptr, nullptr)) < 0) return r;
+                for (auto& q : relRes) q.desc2 = dd;
+            }
+            int r = orbfe_compute_bow(bowB, relRes[0].desc2, nB, 1); // asynchronous: three kernels queued
+            if (r < 0) return r;
+            orbfe_fv fv;
+            if ((r = orbfe_bow_fv(bowB, &fv)) < 0) return r;
+            for (auto& q : relRes) q.fv2 = fv;
+            r = orbfe_search_bow_keyframes(dev, NB, kfsV.data(), nullptr, relRes.data(), outp.data(), nms.data());
+            nmRes = nms[NB - 1];
+            return r;
+        };
+        auto chain_host = [&](bool extract) -> int {
+            if (extract) {
+                int r = orbfe_extract(exB, imgB.data(), rows, cols, cols, 0, 0, kB.data(), dB.data(), cap, &nB);
+                if (r < -1) return r;
+            }
+            int r = host_fold();
+            if (r < 0) return r;
+            for (auto& q : relHost) q.fv2 = hf.view();
+            r = orbfe_search_bow_keyframes(dev, NB, kfsV.data(), nullptr, relHost.data(), outp.data(), nms.data());
+            nmFold = nms[NB - 1];
+            return r;
+        };
+        if (timeit("reloc_bow_search64_resident", 100, [&] { return chain_resident(false); }, out)) return 2;
+        if (timeit("reloc_bow_search64_host_fold", 100, [&] { return chain_host(false); }, out)) return 2;
+        if (timeit("reloc_extract_bow_search64_resident", 100, [&] { return chain_resident(true); }, out)) return 2;
+        if (timeit("reloc_extract_bow_search64_host_fold", 100, [&] { return chain_host(true); }, out)) return 2;
+        if (timeit("compute_bow_then_host_copy", 200, [&] { int r = orbfe_compute_bow(bowB, ddB, nB, 1); orbfe_bow_view v; return r < 0 ? r : orbfe_bow_host(bowB, &v); }, out)) return 2;
+        if (timeit("search_bow_batch64_handles_resident_vector_alone", 100, [&] { return orbfe_search_bow_keyframes(dev, NB, kfsV.data(), nullptr, relRes.data(), outp.data(), nms.data()); }, out)) return 2;
+        if (nmRes != nmFold || nmRes < 0) {
+            fprintf(stderr, "hostbench: relocalisation chains disagree: %d %d\n", nmRes, nmFold);
+            return 2;
+        }
+        orbfe_keyframe_destroy(kfV);
+        orbfe_bow_destroy(bowA);
+        orbfe_bow_destroy(bowB);
+        orbfe_vocab_free(voc);
+    }
     // ---- SearchForTriangulation_: A against B (pure x-translation geometry)
     orbfe_tri_args tri{};
     tri.desc1 = dA.data(); tri.n1 = nA; tri.hasMP1 = hasA.data(); tri.kp1_xy = xyA.data(); tri.angle1 = angA.data(); tri.octave1 = octA.data();
