@@ -143,6 +143,19 @@ public:
         return matches;
     }
 
+    // Beyond the reference's interface: where the last operator() left the frame's descriptors in HBM (rows of 32 bytes, image 0
+    // of the last call; null before the first frame).  Matcher calls of liborbfe.so that are handed this pointer order themselves
+    // after the extraction; ORBVocabulary::computeBoW(DeviceDescriptors(), N, 4) runs Frame::ComputeBoW without the descriptors
+    // crossing PCIe again.  Valid until the next call on this extractor.
+    const uint8_t* DeviceDescriptors(int* cap = nullptr)
+    {
+        const uint8_t* d = nullptr;
+        int c = 0;
+        if (!haveFrame || orbfe_get_device_outputs(ctx, nullptr, &d, nullptr, &c, nullptr) != 0) return nullptr;
+        if (cap) *cap = c;
+        return d;
+    }
+
     int inline GetLevels() { return nlevels; }
     float inline GetScaleFactor() { return (float)scaleFactor; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }

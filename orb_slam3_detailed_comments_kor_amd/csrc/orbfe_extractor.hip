@@ -778,8 +778,6 @@ int ensure_geometry(orbfe_ctx* c, int rows, int cols, int nimg)
             if (c->qtLdsBytes > 64 * 1024) {
                 HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, QT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)c->qtLdsBytes));
-                HIP_TRY(hipFuncSetAttribute((const void*)k_octree<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)c->qtLdsBytes));
             }
             lanes_invalidate_caps(c); // the per-image strides changed: re-check every buffer's size
             return 0;

@@ -39,3 +39,11 @@ def test_cmake_snippet_skips_quietly_without_opencv(tmp_path):
                          stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "OpenCV not found" in out.stdout or "diff_opencv" in out.stdout
+
+
+def test_vocabulary_adapter_parses_with_and_without_opencv():
+    # adapters/ORBVocabulary.h: the stand-in branch (what tests/test_gpu_vocabulary_adapter.py compiles) and against the mock
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DORBFE_NO_OPENCV=1", "-x", "c++",
+                          os.path.join(ROOT, "adapters", "ORBVocabulary.h")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    _syntax(os.path.join(MOCK, "use_vocabulary.cpp"))

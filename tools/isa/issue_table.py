@@ -106,7 +106,7 @@ def issue_table(lib=None):
     names = demangle(list(per))
     table = {}
     for mangled, cnt in per.items():
-        name = names[mangled].split("(")[0].replace("void ", "")
+        name = names[mangled].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if not name.startswith("k_"):
             continue
         valu = {op: n for op, n in cnt.items() if op.startswith("v_") and not op.startswith("v_mfma")}
