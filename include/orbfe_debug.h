@@ -38,6 +38,10 @@ size_t orbfe_debug_trig_cache_payload_bytes(void);
 int orbfe_debug_trig_cache_write(const char* path, const uint8_t* payload, size_t bytes);
 int orbfe_debug_trig_cache_check(const char* path, const char** why);
 
+/* Host-only exerciser of the table behind orbfe_keyframe / orbfe_frame use counts (deferred destroy, stale handles refused) for
+ * the sanitizer builds, which have no device to create real handles on: returns the number of protocol violations (0). */
+int orbfe_debug_handle_table_selftest(int threads, int slots, int rounds);
+
 #ifdef __cplusplus
 }
 #endif

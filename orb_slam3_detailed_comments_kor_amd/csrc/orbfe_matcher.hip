@@ -24,6 +24,7 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>

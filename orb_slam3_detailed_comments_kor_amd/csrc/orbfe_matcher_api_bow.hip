@@ -11,6 +11,7 @@ struct BowResident {
     const uint32_t* nodeIds;
     const int32_t *offsets, *indices, *hdr; // hdr[1] = number of nodes
     hipEvent_t ready;                       // behind the kernels that wrote them
+    hipStream_t stream;                     // ... which ran on this stream
     int n, device;
 };
 int bow_resident(orbfe_bow*, BowResident*);   // takes a use of the handle (bow_release gives it back)
@@ -287,8 +288,10 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     if ((r = select_device(device)) < 0) return r;
     Scratch s(device);
     for (int p = 0; p < count; p++) { // resident vectors: this stream behind the kernels that wrote them (another thread's, maybe)
-        if (isRes1[p]) HIP_TRY(hipStreamWaitEvent(g_ms, res1[p].ready, 0));
-        if (isRes2[p] && !(isRes1[p] && res2[p].ready == res1[p].ready) && !(p > 0 && isRes2[p - 1] && res2[p - 1].ready == res2[p].ready))
+        // (a vector computed on THIS thread's stream is ordered by the stream itself)
+        if (isRes1[p] && res1[p].stream != g_ms) HIP_TRY(hipStreamWaitEvent(g_ms, res1[p].ready, 0));
+        if (isRes2[p] && res2[p].stream != g_ms && !(isRes1[p] && res2[p].ready == res1[p].ready) &&
+            !(p > 0 && isRes2[p - 1] && res2[p - 1].ready == res2[p].ready))
             HIP_TRY(hipStreamWaitEvent(g_ms, res2[p].ready, 0));
     }
     // (what travels: node list, problem records, the pooled sets.  A search against resident keyframes sends ~15 KB: the kernel

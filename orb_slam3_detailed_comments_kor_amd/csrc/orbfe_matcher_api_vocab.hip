@@ -1,6 +1,77 @@
 // orbfe_matcher_api_vocab.hip -- entry points: kernel timing, timing taps, DBoW2 vocabulary (upload, text loader, transform).
 // Part of the matcher's translation unit: included by orbfe_matcher.hip, in this order, behind the common device helpers
 // (the text is the one translation unit it always was, cut at its family borders -- VERDICT r05 #6).
+// Host-only exerciser of the handle table (g_handles / HandleUses: who is alive, who holds a use, who frees) for the sanitizer
+// builds, which run without a device and therefore cannot create a real handle (tests/san/threads_cabi.cpp, under TSan and ASan):
+// `threads` searcher threads take and give back uses of `slots` fake handles while the calling thread destroys and re-creates
+// them `rounds` times.  Checked: a handle is freed exactly once per creation, never while a use is out, and a use is never
+// granted on a handle after its destroy.  Returns 0, or the number of violations.
+int orbfe_debug_handle_table_selftest(int threads, int slots, int rounds)
+{
+    if (threads < 1 || slots < 1 || rounds < 1 || slots > 64 || threads > 64) return ORBFE_ERR_ARGS;
+    struct Fake {
+        std::atomic<int> usesOut{0}, freed{0}, alive{0};
+    };
+    static Fake pool[64 * 2]; // (two generations per slot so that a freed object is not re-added while a searcher may still name it)
+    static std::atomic<int> violations;
+    violations.store(0);
+    std::atomic<bool> stop{false};
+    std::atomic<Fake*> cur[64];
+    auto freeFn = [](void* h) {
+        Fake* f = static_cast<Fake*>(h);
+        if (f->usesOut.load() != 0) violations.fetch_add(1); // freed while a use is out
+        if (f->freed.fetch_add(1) != 0) violations.fetch_add(1); // freed twice
+    };
+    for (int s = 0; s < slots; s++) {
+        Fake* f = &pool[2 * s];
+        f->usesOut.store(0);
+        f->freed.store(0);
+        f->alive.store(1);
+        g_handles.add(f);
+        cur[s].store(f);
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            unsigned x = 12345u + 977u * (unsigned)t;
+            while (!stop.load()) {
+                HandleUses uses;
+                for (int k = 0; k < 3; k++) {
+                    x = x * 1664525u + 1013904223u;
+                    Fake* f = cur[(x >> 8) % (unsigned)slots].load();
+                    if (uses.take(f, +freeFn)) {
+                        if (f->alive.load() == 0 && f->freed.load() != 0) violations.fetch_add(1); // a use granted on a freed handle
+                    }
+                }
+                for (const auto& e : uses.held) static_cast<Fake*>(const_cast<void*>(e.first))->usesOut.fetch_add(1);
+                for (const auto& e : uses.held) static_cast<Fake*>(const_cast<void*>(e.first))->usesOut.fetch_sub(1);
+            }
+        });
+    for (int r = 0; r < rounds; r++)
+        for (int s = 0; s < slots; s++) {
+            Fake* old = cur[s].load();
+            Fake* nw = old == &pool[2 * s] ? &pool[2 * s + 1] : &pool[2 * s];
+            // (the other generation was destroyed a whole round ago; wait until its deferred free, if any, has happened)
+            while (nw->alive.load() == 0 && nw->freed.load() == 0 && r > 0) std::this_thread::yield();
+            nw->usesOut.store(0);
+            nw->freed.store(0);
+            nw->alive.store(1);
+            g_handles.add(nw);
+            cur[s].store(nw);
+            old->alive.store(0);
+            if (g_handles.destroy(old)) freeFn(old);
+        }
+    stop.store(true);
+    for (auto& t : th) t.join();
+    for (int s = 0; s < slots; s++) {
+        Fake* f = cur[s].load();
+        f->alive.store(0);
+        if (g_handles.destroy(f)) freeFn(f);
+        if (f->freed.load() != 1) violations.fetch_add(1);
+    }
+    return violations.load();
+}
+
 float orbfe_matcher_last_kernel_ms(void) { return g_lastKernelMs; }
 void orbfe_matcher_time_kernels(int on) { g_timeKernels = on != 0; }
 #ifdef ORBFE_KB8_TIMING

@@ -13,60 +13,29 @@
  *                  normalised over the words in ascending id order;
  *   FeatureVector  node id -> the indices of its features in ascending order.
  * Both are a SORT of the per-feature results of K-VOC by (id, feature index) followed by a segmentation, and that is how they
- * are built here -- three launches on the caller's matcher stream, no host involvement:
+ * are built here -- two launches on the caller's matcher stream, no host involvement, no copy command:
  *   K-VOC      (k_vocab_transform)  word, node `levelsup` levels above the leaves, weight per feature;
- *   K-BOWRANK  (k_bow_rank)         one wavefront per kept feature (weight > 0: "not stopped", :1157): its rank among the kept
+ *   K-BOWRANK  (k_bow_rank_fold, every wavefront)  one wavefront per kept feature (weight > 0: "not stopped", :1157): its rank among the kept
  *                                   features by (node, index) and by (word, index), counted across the lanes -- n / 64 steps per
  *                                   wavefront, n wavefronts: the whole sort is a few microseconds for the 1000-2000 features of a
  *                                   frame and needs neither LDS nor a size limit; rank = final position, so the FeatureVector's
  *                                   index array is complete after this launch;
- *   K-BOWFOLD  (k_bow_fold)         one workgroup: segment heads of both sorted id lists (a prefix sum), node ids / offsets, word
+ *   K-BOWFOLD  (k_bow_rank_fold, the LAST workgroup to finish)  segment heads of both sorted id lists (a prefix sum), node ids / offsets, word
  *                                   ids, and the word values in the reference's OWN arithmetic: the c-fold sequential double sum
  *                                   w + w + ... of addWeight (not c * w: the roundings differ), the sequential sum of |value| in
  *                                   ascending word order of normalize (one lane, a dependent chain of ~1000 v_add_f64: 4 us),
  *                                   IEEE division.  Bit-identical to the maps of the reference for every weighting / scoring
  *                                   type (tests/test_gpu_bow.py).
  * The results stay on the device in exactly the arrays the searches read (orbfe_fv layout: node ids, offsets, indices) and are
- * mirrored into page-locked host memory by one copy command behind the kernels; orbfe_bow_host waits for that copy -- the
+ * mirrored into page-locked host memory by the kernel's own stores; orbfe_bow_host waits for the kernel -- the
  * "host copy on request".  A SearchByBoW against keyframe handles takes the FeatureVector from the handle itself
  * (orbfe_bow_fv), without the host ever seeing it: extract -> ComputeBoW -> SearchByBoW x 64 runs without a host round trip
  * between its stages (bow_run, "resident FeatureVector").
  */
 
-// ---------------------------------------------------------------- K-BOWRANK
-__global__ __launch_bounds__(256) void k_bow_rank(const int32_t* __restrict__ word, const int32_t* __restrict__ node,
-                                                  const double* __restrict__ weight, int n, uint32_t* __restrict__ sortedNode,
-                                                  int32_t* __restrict__ indices, uint32_t* __restrict__ sortedWord,
-                                                  double* __restrict__ sortedWt)
-{
-    const int lane = threadIdx.x & 63;
-    const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (i >= n) return; // (wave-uniform)
-    const double wi = weight[i];
-    if (!(wi > 0.0)) return; // stopped word: neither vector sees the feature (:1157)
-    const uint32_t ni = (uint32_t)node[i], wdi = (uint32_t)word[i];
-    int rn = 0, rw = 0;
-    for (int base = 0; base < n; base += 64) { // (uniform)
-        const int j = base + lane;
-        if (j < n && weight[j] > 0.0) {
-            const uint32_t nj = (uint32_t)node[j], wj = (uint32_t)word[j];
-            rn += (nj < ni || (nj == ni && j < i)) ? 1 : 0;
-            rw += (wj < wdi || (wj == wdi && j < i)) ? 1 : 0;
-        }
-    }
-    rn = wave_sum_i32(rn);
-    rw = wave_sum_i32(rw);
-    if (lane == 0) {
-        sortedNode[rn] = ni;
-        indices[rn] = i;
-        sortedWord[rw] = wdi;
-        sortedWt[rw] = wi;
-    }
-}
-
-// ---------------------------------------------------------------- K-BOWFOLD
-// exclusive prefix sum of one int per thread over a 1024-thread workgroup; *total = the sum (same in every thread)
-__device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 16 ints */, int* total)
+// ---------------------------------------------------------------- K-BOWRANK + K-BOWFOLD (one launch)
+// exclusive prefix sum of one int per thread over a 256-thread workgroup; *total = the sum (same in every thread)
+__device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 4 ints */, int* total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = v;
@@ -78,7 +47,8 @@ __device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 16 ints */, i
     if (lane == 63) sWave[wave] = incl;
     __syncthreads();
     int before = 0, all = 0;
-    for (int w = 0; w < 16; w++) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
         const int s = sWave[w];
         if (w < wave) before += s;
         all += s;
@@ -89,36 +59,82 @@ __device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 16 ints */, i
 }
 
 struct BowFoldArgs {
-    const double* weight; // K-VOC's weight per feature
+    const int32_t* word;   // K-VOC's results per feature
+    const int32_t* node;
+    const double* weight;
     int n;
-    const uint32_t* sortedNode; // [m] node id by rank
-    const uint32_t* sortedWord; // [m] word id by rank
-    const double* sortedWt;     // [m] the word's weight by rank
-    int32_t* hdr;               // [8]: kept features m, nodes nn, words nw, features of the largest node
-    uint32_t* nodeIds;          // [cap]
-    int32_t* offsets;           // [cap + 1]
-    uint32_t* wordIds;          // [cap]
-    double* values;             // [cap]
-    int32_t* headPos;           // [cap + 1] scratch: first rank of every word
-    int addWeight;              // TF_IDF / TF: BowVector::addWeight; IDF / BINARY: addIfNotExist
-    int must;                   // the scoring object normalises (all but DOT_PRODUCT)
-    int normL2;                 // ... with the L2 norm (L2_NORM)
+    uint32_t* sortedNode; // [m] node id by rank
+    uint32_t* sortedWord; // [m] word id by rank
+    double* sortedWt;     // [m] the word's weight by rank
+    int32_t* hdr;         // [8]: kept features m, nodes nn, words nw, features of the largest node; [7]: the launch's block counter
+    uint32_t* nodeIds;    // [cap]
+    int32_t* offsets;     // [cap + 1]
+    int32_t* indices;     // [cap]
+    uint32_t* wordIds;    // [cap]
+    double* values;       // [cap]
+    int32_t* headPos;     // [cap + 1] scratch: first rank of every word
+    uint8_t* mirror;      // the kernel's address of the results' page-locked mirror (same layout as the block's result run)
+    uint32_t oHdr, oNode, oOffs, oInd, oWid, oVal; // byte offsets of the result arrays inside the run / the mirror
+    int addWeight;        // TF_IDF / TF: BowVector::addWeight; IDF / BINARY: addIfNotExist
+    int must;             // the scoring object normalises (all but DOT_PRODUCT)
+    int normL2;           // ... with the L2 norm (L2_NORM)
 };
 
-__global__ __launch_bounds__(1024) void k_bow_fold(const BowFoldArgs A)
+// Grid: one wavefront per feature (four per workgroup).  Part 1, every wavefront: the feature's rank among the kept features
+// by (node, index) and by (word, index), counted across the lanes; rank = final position.  Part 2, the LAST workgroup to finish
+// (a counter in the handle's header): segment heads of both sorted lists, node ids / offsets, word ids, and the word values in
+// the reference's own arithmetic; every result is stored twice -- device array and page-locked mirror -- so that no copy
+// command follows the kernel (a copy engine command behind a kernel costs 10-15 us of queue hand-over on this chip, more than
+// the kernel).
+__global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
 {
-    __shared__ int sWave[16];
-    __shared__ int sMax;
+    __shared__ int sWave[4];
+    __shared__ int sMax, sLast;
     __shared__ double sNorm;
-    const int t = (int)threadIdx.x;
-    if (t == 0) sMax = 0;
-    // kept features
+    const int t = (int)threadIdx.x, lane = t & 63;
+    const int n = A.n;
+    {
+        const int i = (int)blockIdx.x * 4 + (t >> 6);
+        const double wi = i < n ? A.weight[i] : 0.0;
+        if (wi > 0.0) { // (wave-uniform) a stopped word (weight 0) enters neither vector (:1157)
+            const uint32_t ni = (uint32_t)A.node[i], wdi = (uint32_t)A.word[i];
+            int rn = 0, rw = 0;
+            for (int base = 0; base < n; base += 64) { // (uniform)
+                const int j = base + lane;
+                if (j < n && A.weight[j] > 0.0) {
+                    const uint32_t nj = (uint32_t)A.node[j], wj = (uint32_t)A.word[j];
+                    rn += (nj < ni || (nj == ni && j < i)) ? 1 : 0;
+                    rw += (wj < wdi || (wj == wdi && j < i)) ? 1 : 0;
+                }
+            }
+            rn = wave_sum_i32(rn);
+            rw = wave_sum_i32(rw);
+            if (lane == 0) {
+                A.sortedNode[rn] = ni;
+                A.indices[rn] = i;
+                A.sortedWord[rw] = wdi;
+                A.sortedWt[rw] = wi;
+            }
+        }
+    }
+    // ---- the last workgroup folds (release: this workgroup's stores; acquire: everybody's)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (t == 0) sLast = atomicAdd(reinterpret_cast<unsigned*>(A.hdr + 7), 1u) + 1u == gridDim.x ? 1 : 0;
+    __syncthreads();
+    if (!sLast) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (t == 0) {
+        A.hdr[7] = 0; // (for the next call: calls on one handle are ordered)
+        sMax = 0;
+    }
+    constexpr int NT = 256;
     int cnt = 0;
-    for (int j = t; j < A.n; j += 1024) cnt += A.weight[j] > 0.0 ? 1 : 0;
+    for (int j = t; j < n; j += NT) cnt += A.weight[j] > 0.0 ? 1 : 0;
     int m = 0;
     (void)bow_block_scan(cnt, sWave, &m);
     // segment heads of both lists: thread t owns ranks [r0, r1)
-    const int C = (m + 1023) / 1024, r0 = min(m, t * C), r1 = min(m, r0 + C);
+    const int C = (m + NT - 1) / NT, r0 = min(m, t * C), r1 = min(m, r0 + C);
     int hn = 0, hw = 0;
     for (int r = r0; r < r1; r++) {
         hn += (r == 0 || A.sortedNode[r] != A.sortedNode[r - 1]) ? 1 : 0;
@@ -127,26 +143,34 @@ __global__ __launch_bounds__(1024) void k_bow_fold(const BowFoldArgs A)
     int nn = 0, nw = 0;
     int sn = bow_block_scan(hn, sWave, &nn);
     int sw = bow_block_scan(hw, sWave, &nw);
+    uint32_t* const mNode = reinterpret_cast<uint32_t*>(A.mirror + A.oNode);
+    int32_t* const mOffs = reinterpret_cast<int32_t*>(A.mirror + A.oOffs);
+    uint32_t* const mWid = reinterpret_cast<uint32_t*>(A.mirror + A.oWid);
+    double* const mVal = reinterpret_cast<double*>(A.mirror + A.oVal);
     for (int r = r0; r < r1; r++) {
         const uint32_t nd = A.sortedNode[r], wd = A.sortedWord[r];
         if (r == 0 || nd != A.sortedNode[r - 1]) {
             A.nodeIds[sn] = nd;
             A.offsets[sn] = r;
+            mNode[sn] = nd;
+            mOffs[sn] = r;
             sn++;
         }
         if (r == 0 || wd != A.sortedWord[r - 1]) {
             A.wordIds[sw] = wd;
+            mWid[sw] = wd;
             A.headPos[sw] = r;
             sw++;
         }
     }
     if (t == 0) {
         A.offsets[nn] = m;
+        mOffs[nn] = m;
         A.headPos[nw] = m;
     }
     __syncthreads(); // (the workgroup's global stores above are visible to its threads below)
     // word values: BowVector::addWeight adds the word's weight once per feature, in feature order -- c sequential additions
-    for (int s = t; s < nw; s += 1024) {
+    for (int s = t; s < nw; s += NT) {
         const int p = A.headPos[s], c = A.headPos[s + 1] - p;
         const double w = A.sortedWt[p];
         double v = w;
@@ -155,12 +179,12 @@ __global__ __launch_bounds__(1024) void k_bow_fold(const BowFoldArgs A)
         A.values[s] = v;
     }
     int mx = 0;
-    for (int s = t; s < nn; s += 1024) mx = max(mx, A.offsets[s + 1] - A.offsets[s]);
+    for (int s = t; s < nn; s += NT) mx = max(mx, A.offsets[s + 1] - A.offsets[s]);
     if (mx) atomicMax(&sMax, mx);
     __syncthreads();
     if (A.addWeight && !A.must && nw > 0) { // "unnecessary when normalizing" (:1164-1170): value / number of words
         const double nd = (double)nw;
-        for (int s = t; s < nw; s += 1024) A.values[s] = __ddiv_rn(A.values[s], nd);
+        for (int s = t; s < nw; s += NT) A.values[s] = __ddiv_rn(A.values[s], nd);
     }
     if (A.must) { // BowVector::normalize (BowVector.cpp:62-86): the sum runs over the map in ascending id order, one term at a time
         if (t == 0) {
@@ -183,13 +207,25 @@ __global__ __launch_bounds__(1024) void k_bow_fold(const BowFoldArgs A)
         __syncthreads();
         const double norm = sNorm;
         if (norm > 0.0)
-            for (int s = t; s < nw; s += 1024) A.values[s] = __ddiv_rn(A.values[s], norm);
+            for (int s = t; s < nw; s += NT) A.values[s] = __ddiv_rn(A.values[s], norm);
+    }
+    for (int s = t; s < nw; s += NT) mVal[s] = A.values[s]; // (each thread mirrors the values it wrote itself)
+    {
+        // the index array, mirrored in whole rows of 64 lanes (a 4-byte store per rank from the ranking wavefronts would cross
+        // PCIe as a transaction each)
+        int32_t* const mInd = reinterpret_cast<int32_t*>(A.mirror + A.oInd);
+        for (int r = t; r < m; r += NT) mInd[r] = A.indices[r];
     }
     if (t == 0) {
+        int32_t* const mh = reinterpret_cast<int32_t*>(A.mirror + A.oHdr);
         A.hdr[0] = m;
         A.hdr[1] = nn;
         A.hdr[2] = nw;
         A.hdr[3] = sMax;
+        mh[0] = m;
+        mh[1] = nn;
+        mh[2] = nw;
+        mh[3] = sMax;
     }
 }
 
@@ -214,7 +250,9 @@ struct orbfe_bow {
     uint32_t *sortedNode = nullptr, *sortedWord = nullptr;
     uint8_t* dDesc = nullptr;
     const uint8_t* lastDesc = nullptr; // device address of the descriptors of the last call (the caller's, or dDesc)
-    uint8_t* hOut = nullptr;           // pinned mirror of the results
+    uint8_t* hOut = nullptr;           // pinned mirror of the results (written by the kernel itself)
+    uint8_t* hOutDev = nullptr;        // the kernel's address of it
+    hipStream_t stream = nullptr;      // the stream of the last call (a consumer on the same stream needs no event wait)
     uint8_t* hDesc = nullptr;          // pinned staging of host descriptors
     hipEvent_t ev = nullptr;           // behind the mirror copy of the last call
     std::atomic<int> uses{1};          // the owner + every search in progress that was given the handle's vector (bow_run)
@@ -248,6 +286,7 @@ int bow_resident(orbfe_bow* b, BowResident* R)
     R->indices = b->indices;
     R->hdr = b->hdr;
     R->ready = b->ev;
+    R->stream = b->stream;
     R->n = b->n;
     R->device = b->device;
     return 0;
@@ -323,7 +362,7 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t c = (size_t)cap;
     size_t o = 0;
-    const size_t oHdr = o; o += al(32);
+    const size_t oHdr = o; o += al(64);
     const size_t oNode = o; o += al(c * 4);
     const size_t oOffs = o; o += al((c + 1) * 4);
     const size_t oInd = o; o += al(c * 4);
@@ -347,6 +386,19 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
         b->ev = nullptr;
         bow_free(b);
         return -(1000 + (int)hipErrorOutOfMemory);
+    }
+    {
+        void* dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, b->hOut, 0) != hipSuccess || !dv) {
+            (void)hipGetLastError();
+            bow_free(b);
+            return ORBFE_ERR_STATE;
+        }
+        b->hOutDev = (uint8_t*)dv;
+    }
+    if (hipMemset(b->block, 0, 64) != hipSuccess) { // (the header with the launch's block counter)
+        bow_free(b);
+        return ORBFE_ERR_STATE;
     }
     uint8_t* B = b->block;
     b->hdr = (int32_t*)(B + oHdr);
@@ -403,10 +455,10 @@ int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
         const DoneSig none = {};
         hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, g_ms, d->desc, d->childOff, d->childIds,
                            d->word, d->weight, d->L, dF, n, levelsup, b->word, b->node, b->weight, none);
-        hipLaunchKernelGGL(k_bow_rank, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, g_ms, b->word, b->node, b->weight, n, b->sortedNode,
-                           b->indices, b->sortedWord, b->sortedWt);
     }
     BowFoldArgs A;
+    A.word = b->word;
+    A.node = b->node;
     A.weight = b->weight;
     A.n = n;
     A.sortedNode = b->sortedNode;
@@ -415,17 +467,26 @@ int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
     A.hdr = b->hdr;
     A.nodeIds = b->nodeIds;
     A.offsets = b->offsets;
+    A.indices = b->indices;
     A.wordIds = b->wordIds;
     A.values = b->values;
     A.headPos = b->headPos;
+    A.mirror = b->hOutDev;
+    A.oHdr = (uint32_t)b->off(b->hdr);
+    A.oNode = (uint32_t)b->off(b->nodeIds);
+    A.oOffs = (uint32_t)b->off(b->offsets);
+    A.oInd = (uint32_t)b->off(b->indices);
+    A.oWid = (uint32_t)b->off(b->wordIds);
+    A.oVal = (uint32_t)b->off(b->values);
     A.addWeight = d->weighting == 0 || d->weighting == 1; // TF_IDF || TF (:1145)
     A.must = d->scoring != 5;                             // every scoring object but DotProductScoring (ScoringObject.h:73-89)
     A.normL2 = d->scoring == 1;
-    hipLaunchKernelGGL(k_bow_fold, dim3(1), dim3(1024), 0, g_ms, A);
+    // (n == 0: one workgroup, which is the last one and writes the four zero counts)
+    hipLaunchKernelGGL(k_bow_rank_fold, dim3((unsigned)std::max((n + 3) / 4, 1)), dim3(256), 0, g_ms, A);
     HIP_TRY(hipGetLastError());
-    // the results' mirror: header + the arrays up to what n features can fill (one run of the block; cap-sized tails are not sent)
-    HIP_TRY(hipMemcpyAsync(b->hOut, b->block, b->outBytes, hipMemcpyDeviceToHost, g_ms));
+    // (no copy command: the kernel has written the results' mirror itself; the event marks both)
     HIP_TRY(hipEventRecord(b->ev, g_ms));
+    b->stream = g_ms;
     b->pending = true;
     b->computed = true;
     return 0;

@@ -128,6 +128,33 @@ int main(int argc, char** argv)
     std::vector<std::thread> ts;
     for (int t = 0; t < 4; t++) ts.emplace_back(worker, t, dir);
     for (auto& t : ts) t.join();
+    // Round 6: the use counts behind orbfe_keyframe_destroy / orbfe_frame_destroy (a destroy under a search is deferred, a stale
+    // handle is refused) -- the table itself, driven by three searcher threads against an owner that destroys and re-creates
+    // eight handles two thousand times; and the orbfe_bow_* argument paths (no device: every call must return a code)
+    EXPECT(orbfe_debug_handle_table_selftest(3, 8, 2000) == 0);
+    {
+        orbfe_bow* b = nullptr;
+        EXPECT(orbfe_bow_create(&b, nullptr, 100) == ORBFE_ERR_ARGS && b == nullptr);
+        EXPECT(orbfe_bow_create(nullptr, nullptr, 100) == ORBFE_ERR_ARGS);
+        EXPECT(orbfe_compute_bow(nullptr, nullptr, 0, 4) == ORBFE_ERR_ARGS);
+        orbfe_fv fv;
+        orbfe_bow_view v;
+        EXPECT(orbfe_bow_fv(nullptr, &fv) == ORBFE_ERR_ARGS && orbfe_bow_host(nullptr, &v) == ORBFE_ERR_ARGS &&
+               orbfe_bow_device(nullptr, &v) == ORBFE_ERR_ARGS);
+        orbfe_bow_destroy(nullptr);
+        EXPECT(orbfe_vocab_set_types(nullptr, 0, 0) == ORBFE_ERR_ARGS);
+        // a stale / never-created handle address is refused by every entry point that takes one, not dereferenced
+        alignas(64) static unsigned char fake[256];
+        orbfe_keyframe* stale = reinterpret_cast<orbfe_keyframe*>(fake);
+        uint8_t m[4] = {1, 1, 1, 1};
+        EXPECT(orbfe_keyframe_set_mask(stale, m) == ORBFE_ERR_ARGS);
+        orbfe_keyframe_destroy(stale);
+        orbfe_frame_destroy(reinterpret_cast<orbfe_frame*>(fake));
+        orbfe_proj_args pa;
+        std::memset(&pa, 0, sizeof pa);
+        int32_t q[1], f[1];
+        EXPECT(orbfe_search_projection_frame(reinterpret_cast<orbfe_frame*>(fake), &pa, q, f) == ORBFE_ERR_ARGS);
+    }
     std::printf("threads_cabi: %d failures\n", g_fail.load());
     return g_fail.load() ? 1 : 0;
 }

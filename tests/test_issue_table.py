@@ -28,7 +28,7 @@ def test_issue_table_of_the_built_library():
     k = t["kernels"]
     names = list(k)
     for prefix in ("k_pyr_fused", "k_fast_cells<128, 13>", "k_octree<false, 512>", "k_orient_blur_desc<0, false, false, false>",
-                   "k_bow_rank", "k_bow_fold", "k_search_bow", "k_bfknn2_frames_mfma"):
+                   "k_bow_rank_fold", "k_search_bow", "k_bfknn2_frames_mfma"):
         assert any(n.startswith(prefix) for n in names), prefix
     assert not any(n.startswith("k_fast_runs") or n.startswith("k_octree<false, 1024>") or n.startswith("k_copy_out") for n in names)
     fast = k[[n for n in names if n.startswith("k_fast_cells<128, 13>")][0]]
