@@ -1557,15 +1557,25 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             // completion word: K-DESC is the call's last kernel and writes the mirror (not with K-PACK's rays, the host-side
             // trig check's fix-up launch or sub-batches behind it)
             OrbDone done{nullptr, nullptr, 0u, 0u};
+            // Round 6: the results of a frame or two reach the page-locked slab through a copy kernel BEHIND K-DESC (k_mirror_out:
+            // one workgroup, whole 16-byte rows of 64 lanes) instead of by K-DESC's own stores -- a thousand wavefronts each writing
+            // 28 + 32 bytes across PCIe made the single frame's K-DESC 28 us against 7 resident (rocprofv3 of tools/hostbench,
+            // profiles/r06_single_frame_kernels.txt).  The copy kernel is then the call's last kernel and publishes the completion
+            // word: one workgroup behind one L2, so "all its stores, a system-scope release, the flag" is the whole protocol.
+            // (With K-PACK's rays or the host-side trig check K-DESC keeps writing the mirror itself, as before.)
+            const bool copyOut = mirror && !needPack && !hostTrigCheck;
+            OrbDone copyDone{nullptr, nullptr, 0u, 0u};
             if (c->doneWant) {
                 c->doneWant = false;
-                if (mirror && !needPack && !hostTrigCheck && nsub == 1 && !descAffine && c->spinWait && c->d_done.p && c->h_done.p &&
-                    c->h_done.coherent && ORBFE_DESC_WPW == 1 && ORBFE_DESC_KPW == 1) {
+                if (copyOut && c->spinWait && c->d_done.p && c->h_done.p && c->h_done.coherent) {
                     if (++c->doneSeq >= 0x80000000u) c->doneSeq = 1u; // (bit 31 of the word: "finished, not vouched for")
-                    done = OrbDone{c->d_done.p, c->h_done.dev(), c->doneSeq, (unsigned)ni * (unsigned)c->maxKp};
+                    copyDone = OrbDone{c->d_done.p, c->h_done.dev(), c->doneSeq, 1u};
                     c->doneGot = c->doneSeq; // (what the caller waits for)
                 }
             }
+            int32_t* const kMeta = (needPack || copyOut) ? nullptr : mMeta;
+            float* const kKps = copyOut ? nullptr : mKps;
+            uint8_t* const kDesc = copyOut ? nullptr : mDesc;
 #define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
     hipLaunchKernelGGL((done.flag ? k_orient_blur_desc<M, SAT, false, true> : k_orient_blur_desc<M, SAT>), descGrid,      \
                        dim3(64 * ORBFE_DESC_WPW), 0, q,                                                                   \
@@ -1573,7 +1583,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                        c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
                        c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, descAffine ? 1 : 0, trigTab.codes,                          \
                        trigTab.full, c->atanFma, nullptr, 0, d_n, d_mono, k == 0 ? d_hdr + 1 : nullptr,                    \
-                       k == 0 ? d_errOut : nullptr, needPack ? nullptr : mMeta, nimg, mKps, mDesc, done)
+                       k == 0 ? d_errOut : nullptr, kMeta, nimg, kKps, kDesc, done)
             if (hostTrigCheck) { // (the listing of fragile keypoints is an instantiation of its own)
                 if (tapSum > 256) ORBFE_DESC_LAUNCH(2, true);
                 else ORBFE_DESC_LAUNCH(2, false);
@@ -1582,6 +1592,9 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 else ORBFE_DESC_LAUNCH(0, false);
             }
 #undef ORBFE_DESC_LAUNCH
+            if (copyOut)
+                hipLaunchKernelGGL(k_mirror_out, dim3(1), dim3(512), 0, q, reinterpret_cast<const uint8_t*>(d_n), reinterpret_cast<const uint8_t*>(d_kps),
+                                   d_desc, mirror, (unsigned)mirrorMetaBytes, nimg, capPerImg, copyDone);
         }
     }
     rec(c, 5);

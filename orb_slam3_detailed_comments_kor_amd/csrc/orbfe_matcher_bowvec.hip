@@ -58,10 +58,10 @@ __device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 4 ints */, in
     return before + incl - v;
 }
 
+#define BOW_LDS 3072 /* kept features up to which the fold keeps its segment tables and word values in LDS (48 KB) */
 struct BowFoldArgs {
-    const int32_t* word;   // K-VOC's results per feature
-    const int32_t* node;
-    const double* weight;
+    const uint2* keys;     // K-VOC: (node, word) per feature, (~0, ~0) for a stopped one
+    const double* weight;  // K-VOC: the word's weight per feature
     int n;
     uint32_t* sortedNode; // [m] node id by rank
     uint32_t* sortedWord; // [m] word id by rank
@@ -72,7 +72,7 @@ struct BowFoldArgs {
     int32_t* indices;     // [cap]
     uint32_t* wordIds;    // [cap]
     double* values;       // [cap]
-    int32_t* headPos;     // [cap + 1] scratch: first rank of every word
+    int32_t* headPos;     // [cap + 1] scratch: first rank of every word (frames of more than BOW_LDS kept features)
     uint8_t* mirror;      // the kernel's address of the results' page-locked mirror (same layout as the block's result run)
     uint32_t oHdr, oNode, oOffs, oInd, oWid, oVal; // byte offsets of the result arrays inside the run / the mirror
     int addWeight;        // TF_IDF / TF: BowVector::addWeight; IDF / BINARY: addIfNotExist
@@ -81,39 +81,47 @@ struct BowFoldArgs {
 };
 
 // Grid: one wavefront per feature (four per workgroup).  Part 1, every wavefront: the feature's rank among the kept features
-// by (node, index) and by (word, index), counted across the lanes; rank = final position.  Part 2, the LAST workgroup to finish
-// (a counter in the handle's header): segment heads of both sorted lists, node ids / offsets, word ids, and the word values in
-// the reference's own arithmetic; every result is stored twice -- device array and page-locked mirror -- so that no copy
-// command follows the kernel (a copy engine command behind a kernel costs 10-15 us of queue hand-over on this chip, more than
-// the kernel).
+// by (node, index) and by (word, index), counted across the lanes -- the keys of 256 features per step, all loads of a step
+// independent; rank = final position.  Part 2, the LAST workgroup to finish (a counter in the handle's header): segment heads
+// of both sorted lists, node ids / offsets, word ids, and the word values in the reference's own arithmetic.  Every result is
+// stored twice -- device array and page-locked mirror -- so that no copy command follows the kernel (a copy engine command
+// behind a kernel costs 10-15 us of queue hand-over on this chip, more than the kernel).
 __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
 {
     __shared__ int sWave[4];
     __shared__ int sMax, sLast;
     __shared__ double sNorm;
+    __shared__ double sVal[BOW_LDS];
+    __shared__ int sHead[BOW_LDS + 1], sOff[BOW_LDS + 1];
     const int t = (int)threadIdx.x, lane = t & 63;
     const int n = A.n;
     {
         const int i = (int)blockIdx.x * 4 + (t >> 6);
-        const double wi = i < n ? A.weight[i] : 0.0;
-        if (wi > 0.0) { // (wave-uniform) a stopped word (weight 0) enters neither vector (:1157)
-            const uint32_t ni = (uint32_t)A.node[i], wdi = (uint32_t)A.word[i];
+        const uint2 ki = i < n ? A.keys[i] : make_uint2(~0u, ~0u);
+        if (ki.x != ~0u || ki.y != ~0u) { // (wave-uniform) a stopped word (weight 0) enters neither vector (:1157)
             int rn = 0, rw = 0;
-            for (int base = 0; base < n; base += 64) { // (uniform)
-                const int j = base + lane;
-                if (j < n && A.weight[j] > 0.0) {
-                    const uint32_t nj = (uint32_t)A.node[j], wj = (uint32_t)A.word[j];
-                    rn += (nj < ni || (nj == ni && j < i)) ? 1 : 0;
-                    rw += (wj < wdi || (wj == wdi && j < i)) ? 1 : 0;
+            for (int base = 0; base < n; base += 256) { // (uniform)
+                uint2 kj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = base + 64 * u + lane;
+                    kj[u] = j < n ? A.keys[j] : make_uint2(~0u, ~0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = base + 64 * u + lane;
+                    // (a stopped j holds ~0: never below a kept key; equal to it only for a stopped i, which is not here)
+                    rn += (kj[u].x < ki.x || (kj[u].x == ki.x && j < i)) ? 1 : 0;
+                    rw += (kj[u].y < ki.y || (kj[u].y == ki.y && j < i)) ? 1 : 0;
                 }
             }
             rn = wave_sum_i32(rn);
             rw = wave_sum_i32(rw);
             if (lane == 0) {
-                A.sortedNode[rn] = ni;
+                A.sortedNode[rn] = ki.x;
                 A.indices[rn] = i;
-                A.sortedWord[rw] = wdi;
-                A.sortedWt[rw] = wi;
+                A.sortedWord[rw] = ki.y;
+                A.sortedWt[rw] = A.weight[i];
             }
         }
     }
@@ -130,15 +138,23 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
     }
     constexpr int NT = 256;
     int cnt = 0;
-    for (int j = t; j < n; j += NT) cnt += A.weight[j] > 0.0 ? 1 : 0;
+    for (int j = t; j < n; j += NT) {
+        const uint2 k = A.keys[j];
+        cnt += (k.x != ~0u || k.y != ~0u) ? 1 : 0;
+    }
     int m = 0;
     (void)bow_block_scan(cnt, sWave, &m);
+    const bool inLds = m <= BOW_LDS; // (uniform) segment tables and values in LDS; else in the handle's device arrays
     // segment heads of both lists: thread t owns ranks [r0, r1)
     const int C = (m + NT - 1) / NT, r0 = min(m, t * C), r1 = min(m, r0 + C);
     int hn = 0, hw = 0;
+    uint32_t prevN = r0 > 0 && r0 < r1 ? A.sortedNode[r0 - 1] : 0u, prevW = r0 > 0 && r0 < r1 ? A.sortedWord[r0 - 1] : 0u;
     for (int r = r0; r < r1; r++) {
-        hn += (r == 0 || A.sortedNode[r] != A.sortedNode[r - 1]) ? 1 : 0;
-        hw += (r == 0 || A.sortedWord[r] != A.sortedWord[r - 1]) ? 1 : 0;
+        const uint32_t nd = A.sortedNode[r], wd = A.sortedWord[r];
+        hn += (r == 0 || nd != prevN) ? 1 : 0;
+        hw += (r == 0 || wd != prevW) ? 1 : 0;
+        prevN = nd;
+        prevW = wd;
     }
     int nn = 0, nw = 0;
     int sn = bow_block_scan(hn, sWave, &nn);
@@ -147,69 +163,94 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
     int32_t* const mOffs = reinterpret_cast<int32_t*>(A.mirror + A.oOffs);
     uint32_t* const mWid = reinterpret_cast<uint32_t*>(A.mirror + A.oWid);
     double* const mVal = reinterpret_cast<double*>(A.mirror + A.oVal);
+    prevN = r0 > 0 && r0 < r1 ? A.sortedNode[r0 - 1] : 0u;
+    prevW = r0 > 0 && r0 < r1 ? A.sortedWord[r0 - 1] : 0u;
     for (int r = r0; r < r1; r++) {
         const uint32_t nd = A.sortedNode[r], wd = A.sortedWord[r];
-        if (r == 0 || nd != A.sortedNode[r - 1]) {
+        if (r == 0 || nd != prevN) {
             A.nodeIds[sn] = nd;
             A.offsets[sn] = r;
             mNode[sn] = nd;
             mOffs[sn] = r;
+            if (inLds) sOff[sn] = r;
             sn++;
         }
-        if (r == 0 || wd != A.sortedWord[r - 1]) {
+        if (r == 0 || wd != prevW) {
             A.wordIds[sw] = wd;
             mWid[sw] = wd;
-            A.headPos[sw] = r;
+            if (inLds) sHead[sw] = r;
+            else A.headPos[sw] = r;
             sw++;
         }
+        prevN = nd;
+        prevW = wd;
     }
     if (t == 0) {
         A.offsets[nn] = m;
         mOffs[nn] = m;
-        A.headPos[nw] = m;
+        if (inLds) {
+            sOff[nn] = m;
+            sHead[nw] = m;
+        } else A.headPos[nw] = m;
     }
-    __syncthreads(); // (the workgroup's global stores above are visible to its threads below)
-    // word values: BowVector::addWeight adds the word's weight once per feature, in feature order -- c sequential additions
+    __syncthreads(); // (the workgroup's LDS and global stores above are visible to its threads below)
+    // word values: BowVector::addWeight adds the word's weight once per feature, in feature order -- c sequential additions.
+    // They stay in LDS until they are final: the normalisation below is ONE lane adding them up in order, and every trip to
+    // L2 in that chain costs more than the addition.
     for (int s = t; s < nw; s += NT) {
-        const int p = A.headPos[s], c = A.headPos[s + 1] - p;
+        const int p = inLds ? sHead[s] : A.headPos[s], c = (inLds ? sHead[s + 1] : A.headPos[s + 1]) - p;
         const double w = A.sortedWt[p];
         double v = w;
         if (A.addWeight)
             for (int k = 1; k < c; k++) v = __dadd_rn(v, w);
-        A.values[s] = v;
+        if (inLds) sVal[s] = v;
+        else A.values[s] = v;
     }
     int mx = 0;
-    for (int s = t; s < nn; s += NT) mx = max(mx, A.offsets[s + 1] - A.offsets[s]);
+    for (int s = t; s < nn; s += NT) mx = max(mx, inLds ? sOff[s + 1] - sOff[s] : A.offsets[s + 1] - A.offsets[s]);
     if (mx) atomicMax(&sMax, mx);
     __syncthreads();
-    if (A.addWeight && !A.must && nw > 0) { // "unnecessary when normalizing" (:1164-1170): value / number of words
-        const double nd = (double)nw;
-        for (int s = t; s < nw; s += NT) A.values[s] = __ddiv_rn(A.values[s], nd);
-    }
+    double scale = 1.0; // every value is divided by this at the end (1: left as it is)
+    if (A.addWeight && !A.must && nw > 0) scale = (double)nw; // "unnecessary when normalizing" (:1164-1170): value / number of words
     if (A.must) { // BowVector::normalize (BowVector.cpp:62-86): the sum runs over the map in ascending id order, one term at a time
         if (t == 0) {
             double norm = 0.0;
             int s = 0;
-            for (; s + 8 <= nw; s += 8) { // (eight loads in flight, then the dependent additions)
-                double v[8];
+            if (inLds) {
+                for (; s + 8 <= nw; s += 8) { // (eight reads in flight, then the dependent additions)
+                    double v[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = A.values[s + k];
+                    for (int k = 0; k < 8; k++) v[k] = sVal[s + k];
 #pragma unroll
-                for (int k = 0; k < 8; k++) norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v[k], v[k]) : fabs(v[k]));
-            }
-            for (; s < nw; s++) {
-                const double v = A.values[s];
-                norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v, v) : fabs(v));
+                    for (int k = 0; k < 8; k++) norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v[k], v[k]) : fabs(v[k]));
+                }
+                for (; s < nw; s++) norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(sVal[s], sVal[s]) : fabs(sVal[s]));
+            } else {
+                for (; s + 8 <= nw; s += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = A.values[s + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v[k], v[k]) : fabs(v[k]));
+                }
+                for (; s < nw; s++) {
+                    const double v = A.values[s];
+                    norm = __dadd_rn(norm, A.normL2 ? __dmul_rn(v, v) : fabs(v));
+                }
             }
             if (A.normL2) norm = __dsqrt_rn(norm);
             sNorm = norm;
         }
         __syncthreads();
-        const double norm = sNorm;
-        if (norm > 0.0)
-            for (int s = t; s < nw; s += NT) A.values[s] = __ddiv_rn(A.values[s], norm);
+        scale = sNorm > 0.0 ? sNorm : 1.0; // (norm > 0.0 or the values stay, BowVector.cpp:80)
     }
-    for (int s = t; s < nw; s += NT) mVal[s] = A.values[s]; // (each thread mirrors the values it wrote itself)
+    const bool divide = (A.must ? sNorm > 0.0 : (A.addWeight && nw > 0));
+    for (int s = t; s < nw; s += NT) { // final value: device array and mirror (each thread finishes the words it made)
+        double v = inLds ? sVal[s] : A.values[s];
+        if (divide) v = __ddiv_rn(v, scale);
+        A.values[s] = v;
+        mVal[s] = v;
+    }
     {
         // the index array, mirrored in whole rows of 64 lanes (a 4-byte store per rank from the ranking wavefronts would cross
         // PCIe as a transaction each)
@@ -246,6 +287,7 @@ struct orbfe_bow {
     uint32_t* wordIds = nullptr;
     double* values = nullptr;
     int32_t *word = nullptr, *node = nullptr, *headPos = nullptr;
+    uint2* keys = nullptr; // (node, word) per feature: what K-BOWRANK sorts by
     double *weight = nullptr, *sortedWt = nullptr;
     uint32_t *sortedNode = nullptr, *sortedWord = nullptr;
     uint8_t* dDesc = nullptr;
@@ -376,6 +418,7 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
     const size_t oSw = o; o += al(c * 4);
     const size_t oSwt = o; o += al(c * 8);
     const size_t oHead = o; o += al((c + 1) * 4);
+    const size_t oKeys = o; o += al(c * 8);
     const size_t oDesc = o; o += al(c * 32);
     bool ok = hipMalloc((void**)&b->block, o) == hipSuccess && hipHostMalloc((void**)&b->hOut, b->outBytes) == hipSuccess &&
               hipHostMalloc((void**)&b->hDesc, c * 32) == hipSuccess &&
@@ -414,6 +457,7 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
     b->sortedWord = (uint32_t*)(B + oSw);
     b->sortedWt = (double*)(B + oSwt);
     b->headPos = (int32_t*)(B + oHead);
+    b->keys = (uint2*)(B + oKeys);
     b->dDesc = B + oDesc;
     std::memset(b->hOut, 0, 32);
     *out = b;
@@ -454,11 +498,10 @@ int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
     if (n) {
         const DoneSig none = {};
         hipLaunchKernelGGL(k_vocab_transform, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, g_ms, d->desc, d->childOff, d->childIds,
-                           d->word, d->weight, d->L, dF, n, levelsup, b->word, b->node, b->weight, none);
+                           d->word, d->weight, d->L, dF, n, levelsup, b->word, b->node, b->weight, none, b->keys);
     }
     BowFoldArgs A;
-    A.word = b->word;
-    A.node = b->node;
+    A.keys = b->keys;
     A.weight = b->weight;
     A.n = n;
     A.sortedNode = b->sortedNode;

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restri
                                                          const double* __restrict__ nodeWeight, int L,
                                                          const uint8_t* __restrict__ feats, int n, int levelsup,
                                                          int32_t* __restrict__ wordOut, int32_t* __restrict__ nodeOut,
-                                                         double* __restrict__ weightOut, const DoneSig doneSig)
+                                                         double* __restrict__ weightOut, const DoneSig doneSig,
+                                                         uint2* __restrict__ keysOut = nullptr /* orbfe_compute_bow: (node, word)
+                                                         of a kept feature, (~0, ~0) of a stopped one */)
 {
     __shared__ unsigned wgCnt;
     done_begin(doneSig, &wgCnt);
@@ -81,9 +83,12 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restri
         }
     }
     if (live && sub == 0) {
-        wordOut[f] = nodeWord[finalId];
-        weightOut[f] = nodeWeight[finalId];
+        const int wd = nodeWord[finalId];
+        const double wt = nodeWeight[finalId];
+        wordOut[f] = wd;
+        weightOut[f] = wt;
         nodeOut[f] = nid;
+        if (keysOut) keysOut[f] = wt > 0.0 ? make_uint2((unsigned)nid, (unsigned)wd) : make_uint2(~0u, ~0u);
     }
     wave_done(doneSig, &wgCnt);
 }

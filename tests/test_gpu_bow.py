@@ -64,6 +64,13 @@ def test_compute_bow_sizes_reuse_and_errors(pkg, oracle):
     _same(got, oracle.compute_bow(vocab, one, 2))
     assert len(got[0][0]) == 1 and got[0][1][0] == 1.0 and B.last_counts == (2500, 1, 1, 2500)
     B.close()
+    # more kept features than the fold keeps in LDS (3072): its device-array path, and a handle of the largest size
+    B = pkg.Bow(V, 65535)
+    for n in (3073, 5000, 20000):
+        feats = near_leaf_features(vocab, n, 7000 + n)
+        _same(B.compute(feats, 1).host(), oracle.compute_bow(vocab, feats, 1))
+        assert B.last_counts[0] > 3072 or n == 3073
+    B.close()
     V.close()
 
 
