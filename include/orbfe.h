@@ -654,6 +654,11 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev*, int cap);
 void orbfe_bow_destroy(orbfe_bow*);
 int orbfe_compute_bow(orbfe_bow*, const uint8_t* desc, int n, int levelsup);
 int orbfe_bow_fv(orbfe_bow*, orbfe_fv* fv);
+/* on != 0: BowVector::normalize (a sum over the words in ascending id order, one dependent double addition after the other: a
+ * single lane's work, 7-15 us of the kernel for 450-1000 words) is left to orbfe_bow_host, which runs the same arithmetic on the
+ * mirrored values in a microsecond; the word values on the DEVICE then stay un-normalised -- nothing on the device reads them
+ * (the searches use the FeatureVector, KeyFrameDatabase scores on the host).  Default off: both vectors complete on the device. */
+int orbfe_bow_set_lazy_norm(orbfe_bow*, int on);
 int orbfe_bow_host(orbfe_bow*, orbfe_bow_view* view);
 int orbfe_bow_device(orbfe_bow*, orbfe_bow_view* view);
 

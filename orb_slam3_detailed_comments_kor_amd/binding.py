@@ -318,7 +318,7 @@ EXPORTS = ["orbfe_error_string", "orbfe_set_auto_register", "orbfe_version", "or
            "orbfe_vocab_load_text", "orbfe_debug_trig_cache_path", "orbfe_debug_trig_cache_payload_bytes",
            "orbfe_debug_trig_cache_write", "orbfe_debug_trig_cache_check", "orbfe_set_lanes", "orbfe_set_lane_mode", "orbfe_set_lane_input_guard", "orbfe_lanes_join", "orbfe_lanes_record",
            "orbfe_keyframe_create", "orbfe_keyframe_set_mask", "orbfe_keyframe_destroy", "orbfe_search_bow_keyframes",
-           "orbfe_debug_handle_table_selftest", "orbfe_vocab_set_types", "orbfe_vocab_get_types", "orbfe_bow_create", "orbfe_bow_destroy", "orbfe_compute_bow", "orbfe_bow_fv", "orbfe_bow_host", "orbfe_bow_device",
+           "orbfe_debug_handle_table_selftest", "orbfe_vocab_set_types", "orbfe_vocab_get_types", "orbfe_bow_create", "orbfe_bow_destroy", "orbfe_bow_set_lazy_norm", "orbfe_compute_bow", "orbfe_bow_fv", "orbfe_bow_host", "orbfe_bow_device",
            "orbfe_search_tri_batch"]
 
 
@@ -1303,6 +1303,11 @@ class Bow:
         p, n, keep = _desc_arg(desc)
         _chk(self.L.orbfe_compute_bow(self.h, C.c_void_p(p), n, levelsup), "orbfe_compute_bow")
         return self
+
+    def set_lazy_norm(self, on=True):
+        """orbfe_bow_set_lazy_norm: BowVector::normalize in the host view instead of in the kernel."""
+        self.L.orbfe_bow_set_lazy_norm.argtypes = [C.c_void_p, C.c_int]
+        _chk(self.L.orbfe_bow_set_lazy_norm(self.h, int(on)), "orbfe_bow_set_lazy_norm")
 
     def host(self):
         """((word_ids, values), (node_ids, offsets, indices)) -- copies of the handle's page-locked host view."""

@@ -1559,9 +1559,9 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             OrbDone done{nullptr, nullptr, 0u, 0u};
             // Round 6: the results of a frame or two reach the page-locked slab through a copy kernel BEHIND K-DESC (k_mirror_out:
             // one workgroup, whole 16-byte rows of 64 lanes) instead of by K-DESC's own stores -- a thousand wavefronts each writing
-            // 28 + 32 bytes across PCIe made the single frame's K-DESC 28 us against 7 resident (rocprofv3 of tools/hostbench,
+            // 28 + 32 bytes across PCIe made the single frame's K-DESC 28 us against 8 resident (rocprofv3 of tools/hostbench,
             // profiles/r06_single_frame_kernels.txt).  The copy kernel is then the call's last kernel and publishes the completion
-            // word: one workgroup behind one L2, so "all its stores, a system-scope release, the flag" is the whole protocol.
+            // word: every workgroup's stores have landed before it counts itself, the last one to count writes the flag.
             // (With K-PACK's rays or the host-side trig check K-DESC keeps writing the mirror itself, as before.)
             const bool copyOut = mirror && !needPack && !hostTrigCheck;
             OrbDone copyDone{nullptr, nullptr, 0u, 0u};
@@ -1569,7 +1569,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                 c->doneWant = false;
                 if (copyOut && c->spinWait && c->d_done.p && c->h_done.p && c->h_done.coherent) {
                     if (++c->doneSeq >= 0x80000000u) c->doneSeq = 1u; // (bit 31 of the word: "finished, not vouched for")
-                    copyDone = OrbDone{c->d_done.p, c->h_done.dev(), c->doneSeq, 1u};
+                    copyDone = OrbDone{c->d_done.p + 40, c->h_done.dev(), c->doneSeq, 1u}; // (a counter of its own among the 80)
                     c->doneGot = c->doneSeq; // (what the caller waits for)
                 }
             }
@@ -1593,7 +1593,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             }
 #undef ORBFE_DESC_LAUNCH
             if (copyOut)
-                hipLaunchKernelGGL(k_mirror_out, dim3(1), dim3(512), 0, q, reinterpret_cast<const uint8_t*>(d_n), reinterpret_cast<const uint8_t*>(d_kps),
+                hipLaunchKernelGGL(k_mirror_out, dim3(ORBFE_MIRROR_WGS), dim3(256), 0, q, reinterpret_cast<const uint8_t*>(d_n), reinterpret_cast<const uint8_t*>(d_kps),
                                    d_desc, mirror, (unsigned)mirrorMetaBytes, nimg, capPerImg, copyDone);
         }
     }

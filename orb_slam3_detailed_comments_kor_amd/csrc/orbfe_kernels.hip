@@ -2600,16 +2600,19 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
 
 // --------------------------------------------------------------- K-MIRROR
 // Results of a frame or two from the device slab [meta | keypoints | descriptors] into its page-locked twin (the same layout),
-// behind K-DESC on the same stream: the metadata block, then per image its n keypoint records and n descriptor rows, as whole
-// dwords across all lanes (256 contiguous bytes per wavefront store: full-line writes over PCIe).  ONE workgroup: every store comes from one CU, a system-scope
-// release by every thread and a barrier put them in front of the flag word the host spins on.
-__global__ __launch_bounds__(512) void k_mirror_out(const uint8_t* __restrict__ dMeta, const uint8_t* __restrict__ dKps,
+// behind K-DESC on the same stream: the metadata block, then per image its n keypoint records and n descriptor rows, as dwords
+// across all lanes (256 contiguous bytes per wavefront store: full-line writes over PCIe).  A few workgroups (one CU's stores
+// cross the link at ~7 GB/s).  Completion word: every thread's stores have LANDED (system-scope release) before its workgroup
+// counts itself; the workgroup that completes the count publishes the flag -- whatever CU or XCD it ran on, every other
+// workgroup's data is in host memory by then.
+#define ORBFE_MIRROR_WGS 8
+__global__ __launch_bounds__(256) void k_mirror_out(const uint8_t* __restrict__ dMeta, const uint8_t* __restrict__ dKps,
                                                     const uint8_t* __restrict__ dDesc, uint8_t* __restrict__ mirror,
                                                     unsigned metaBytes, int nimg, int cap, const OrbDone done)
 {
-    const unsigned t = threadIdx.x;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x, T = gridDim.x * 256u;
     const int32_t* const n = reinterpret_cast<const int32_t*>(dMeta);
-    for (unsigned i = t; i < metaBytes / 4u; i += 512u) reinterpret_cast<uint32_t*>(mirror)[i] = reinterpret_cast<const uint32_t*>(dMeta)[i];
+    for (unsigned i = t; i < metaBytes / 4u; i += T) reinterpret_cast<uint32_t*>(mirror)[i] = reinterpret_cast<const uint32_t*>(dMeta)[i];
     uint8_t* const mK = mirror + metaBytes;
     uint8_t* const mD = mK + (size_t)nimg * cap * 28;
     for (int im = 0; im < nimg; im++) {
@@ -2618,16 +2621,22 @@ __global__ __launch_bounds__(512) void k_mirror_out(const uint8_t* __restrict__ 
         // keypoint records: 28 bytes each, the image's block starts at a multiple of 4 bytes -> dwords
         const uint32_t* sk = reinterpret_cast<const uint32_t*>(dKps + (size_t)im * cap * 28);
         uint32_t* dk = reinterpret_cast<uint32_t*>(mK + (size_t)im * cap * 28);
-        for (unsigned i = t; i < (unsigned)cnt * 7u; i += 512u) dk[i] = sk[i];
+        for (unsigned i = t; i < (unsigned)cnt * 7u; i += T) dk[i] = sk[i];
         // descriptor rows: 32 bytes each (the block behind nimg * cap * 28 bytes of records is 4-byte aligned for any cap)
         const uint32_t* sd = reinterpret_cast<const uint32_t*>(dDesc + (size_t)im * cap * 32);
         uint32_t* dd = reinterpret_cast<uint32_t*>(mD + (size_t)im * cap * 32);
-        for (unsigned i = t; i < (unsigned)cnt * 8u; i += 512u) dd[i] = sd[i];
+        for (unsigned i = t; i < (unsigned)cnt * 8u; i += T) dd[i] = sd[i];
     }
     if (!done.flag) return; // (uniform)
     __threadfence_system(); // this thread's stores have landed in host memory
     __syncthreads();
-    if (t == 0) *(volatile unsigned*)done.flag = done.seq;
+    if (threadIdx.x == 0) {
+        if (atomicAdd(done.ctr, 1u) + 1u == gridDim.x) {
+            *done.ctr = 0u; // for the next call (calls on one stream are ordered)
+            __threadfence_system();
+            *(volatile unsigned*)done.flag = done.seq;
+        }
+    }
 }
 
 // --------------------------------------------------------------- K-STEREO

@@ -58,7 +58,30 @@ __device__ __forceinline__ int bow_block_scan(int v, int* sWave /* 4 ints */, in
     return before + incl - v;
 }
 
-#define BOW_LDS 3072 /* kept features up to which the fold keeps its segment tables and word values in LDS (48 KB) */
+// agent-scope relaxed stores / loads (global_store / global_load with sc1: coherent across the XCDs' L2s without a fence)
+__device__ __forceinline__ void bow_store_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bow_store_agent64(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t bow_load_agent(const uint32_t* p)
+{
+    return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long bow_load_agent64(const unsigned long long* p)
+{
+    return __hip_atomic_load(const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifdef ORBFE_BOWVEC_TIMING // tuning only (make EXTRA=-DORBFE_BOWVEC_TIMING): where k_bow_rank_fold spends its time, 100-MHz ticks
+__device__ unsigned long long g_bowvecTimes[16]; // [0] first wavefront start (min), [1] last counter increment (max), [2..] fold stamps
+#define BV_STAMP(k)                                              \
+    do {                                                         \
+        if (threadIdx.x == 0) g_bowvecTimes[k] = wall_clock64(); \
+    } while (0)
+#else
+#define BV_STAMP(k) do { } while (0)
+#endif
+#define BOW_LDS 2048 /* kept features up to which the fold works in LDS: sorted ids and weights, segment tables, values (56 KB) */
 struct BowFoldArgs {
     const uint2* keys;     // K-VOC: (node, word) per feature, (~0, ~0) for a stopped one
     const double* weight;  // K-VOC: the word's weight per feature
@@ -78,6 +101,7 @@ struct BowFoldArgs {
     int addWeight;        // TF_IDF / TF: BowVector::addWeight; IDF / BINARY: addIfNotExist
     int must;             // the scoring object normalises (all but DOT_PRODUCT)
     int normL2;           // ... with the L2 norm (L2_NORM)
+    int lazyNorm;         // leave BowVector::normalize to the host view (orbfe_bow_set_lazy_norm): the values stay un-normalised
 };
 
 // Grid: one wavefront per feature (four per workgroup).  Part 1, every wavefront: the feature's rank among the kept features
@@ -91,10 +115,14 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
     __shared__ int sWave[4];
     __shared__ int sMax, sLast;
     __shared__ double sNorm;
-    __shared__ double sVal[BOW_LDS];
-    __shared__ int sHead[BOW_LDS + 1], sOff[BOW_LDS + 1];
+    __shared__ double sVal[BOW_LDS], sWt[BOW_LDS];
+    __shared__ uint32_t sNode[BOW_LDS], sWord[BOW_LDS];
+    __shared__ uint16_t sHead[BOW_LDS + 2], sOff[BOW_LDS + 2];
     const int t = (int)threadIdx.x, lane = t & 63;
     const int n = A.n;
+#ifdef ORBFE_BOWVEC_TIMING
+    if (t == 0) atomicMin(&g_bowvecTimes[0], (unsigned long long)wall_clock64());
+#endif
     {
         const int i = (int)blockIdx.x * 4 + (t >> 6);
         const uint2 ki = i < n ? A.keys[i] : make_uint2(~0u, ~0u);
@@ -118,20 +146,27 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
             rn = wave_sum_i32(rn);
             rw = wave_sum_i32(rw);
             if (lane == 0) {
-                A.sortedNode[rn] = ki.x;
-                A.indices[rn] = i;
-                A.sortedWord[rw] = ki.y;
-                A.sortedWt[rw] = A.weight[i];
+                // (agent-scope stores: written through to where every XCD sees them.  An agent-scope RELEASE FENCE per workgroup
+                // instead -- the textbook form -- writes back the whole L2 of the workgroup's XCD, 252 times for a frame of 1000
+                // features, and the write-backs of one XCD queue behind each other: the kernel took 37 us that way, round 6.)
+                bow_store_agent(&A.sortedNode[rn], ki.x);
+                bow_store_agent(reinterpret_cast<uint32_t*>(&A.indices[rn]), (uint32_t)i);
+                bow_store_agent(&A.sortedWord[rw], ki.y);
+                bow_store_agent64(reinterpret_cast<unsigned long long*>(&A.sortedWt[rw]), (unsigned long long)__double_as_longlong(A.weight[i]));
             }
         }
     }
-    // ---- the last workgroup folds (release: this workgroup's stores; acquire: everybody's)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // ---- the last workgroup folds: every wavefront's stores above are acknowledged before its workgroup counts itself, and the
+    // folding workgroup reads them with agent-scope loads (no cache of its own between it and them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef ORBFE_BOWVEC_TIMING
+    if (t == 0) atomicMax(&g_bowvecTimes[1], (unsigned long long)wall_clock64());
+#endif
     if (t == 0) sLast = atomicAdd(reinterpret_cast<unsigned*>(A.hdr + 7), 1u) + 1u == gridDim.x ? 1 : 0;
     __syncthreads();
     if (!sLast) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    BV_STAMP(2);
     if (t == 0) {
         A.hdr[7] = 0; // (for the next call: calls on one handle are ordered)
         sMax = 0;
@@ -144,62 +179,78 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
     }
     int m = 0;
     (void)bow_block_scan(cnt, sWave, &m);
-    const bool inLds = m <= BOW_LDS; // (uniform) segment tables and values in LDS; else in the handle's device arrays
+    BV_STAMP(3);
+    // Up to BOW_LDS kept features (every frame ORB-SLAM3 makes: nFeatures 1000-2000) the sorted lists come into LDS in ONE
+    // coalesced pass and everything below walks LDS; a larger frame walks the handle's device arrays (same code, `inLds` false).
+    const bool inLds = m <= BOW_LDS; // (uniform)
+    if (inLds) {
+        for (int r = t; r < m; r += NT) {
+            sNode[r] = bow_load_agent(&A.sortedNode[r]);
+            sWord[r] = bow_load_agent(&A.sortedWord[r]);
+            sWt[r] = __longlong_as_double((long long)bow_load_agent64(reinterpret_cast<const unsigned long long*>(&A.sortedWt[r])));
+        }
+        __syncthreads();
+    }
+    BV_STAMP(4);
+    auto nodeAt = [&](int r) { return inLds ? sNode[r] : bow_load_agent(&A.sortedNode[r]); };
+    auto wordAt = [&](int r) { return inLds ? sWord[r] : bow_load_agent(&A.sortedWord[r]); };
     // segment heads of both lists: thread t owns ranks [r0, r1)
     const int C = (m + NT - 1) / NT, r0 = min(m, t * C), r1 = min(m, r0 + C);
     int hn = 0, hw = 0;
-    uint32_t prevN = r0 > 0 && r0 < r1 ? A.sortedNode[r0 - 1] : 0u, prevW = r0 > 0 && r0 < r1 ? A.sortedWord[r0 - 1] : 0u;
     for (int r = r0; r < r1; r++) {
-        const uint32_t nd = A.sortedNode[r], wd = A.sortedWord[r];
-        hn += (r == 0 || nd != prevN) ? 1 : 0;
-        hw += (r == 0 || wd != prevW) ? 1 : 0;
-        prevN = nd;
-        prevW = wd;
+        hn += (r == 0 || nodeAt(r) != nodeAt(r - 1)) ? 1 : 0;
+        hw += (r == 0 || wordAt(r) != wordAt(r - 1)) ? 1 : 0;
     }
     int nn = 0, nw = 0;
     int sn = bow_block_scan(hn, sWave, &nn);
     int sw = bow_block_scan(hw, sWave, &nw);
+    BV_STAMP(5);
     uint32_t* const mNode = reinterpret_cast<uint32_t*>(A.mirror + A.oNode);
     int32_t* const mOffs = reinterpret_cast<int32_t*>(A.mirror + A.oOffs);
     uint32_t* const mWid = reinterpret_cast<uint32_t*>(A.mirror + A.oWid);
     double* const mVal = reinterpret_cast<double*>(A.mirror + A.oVal);
-    prevN = r0 > 0 && r0 < r1 ? A.sortedNode[r0 - 1] : 0u;
-    prevW = r0 > 0 && r0 < r1 ? A.sortedWord[r0 - 1] : 0u;
     for (int r = r0; r < r1; r++) {
-        const uint32_t nd = A.sortedNode[r], wd = A.sortedWord[r];
-        if (r == 0 || nd != prevN) {
-            A.nodeIds[sn] = nd;
-            A.offsets[sn] = r;
-            mNode[sn] = nd;
-            mOffs[sn] = r;
-            if (inLds) sOff[sn] = r;
+        const uint32_t nd = nodeAt(r), wd = wordAt(r);
+        // (LDS form: the tables stay in LDS until the end of the kernel -- every store to the device arrays or, worse, across
+        // PCIe to the mirror would be waited for by the next barrier, an L2 / PCIe round trip per phase: stamps, 26 -> 18 us)
+        if (r == 0 || nd != nodeAt(r - 1)) {
+            if (inLds) sOff[sn] = (uint16_t)r;
+            else {
+                A.nodeIds[sn] = nd;
+                A.offsets[sn] = r;
+                mNode[sn] = nd;
+                mOffs[sn] = r;
+            }
             sn++;
         }
-        if (r == 0 || wd != prevW) {
-            A.wordIds[sw] = wd;
-            mWid[sw] = wd;
-            if (inLds) sHead[sw] = r;
-            else A.headPos[sw] = r;
+        if (r == 0 || wd != wordAt(r - 1)) {
+            if (inLds) sHead[sw] = (uint16_t)r;
+            else {
+                A.wordIds[sw] = wd;
+                mWid[sw] = wd;
+                A.headPos[sw] = r;
+            }
             sw++;
         }
-        prevN = nd;
-        prevW = wd;
     }
     if (t == 0) {
-        A.offsets[nn] = m;
-        mOffs[nn] = m;
         if (inLds) {
-            sOff[nn] = m;
-            sHead[nw] = m;
-        } else A.headPos[nw] = m;
+            sOff[nn] = (uint16_t)m;
+            sHead[nw] = (uint16_t)m;
+        } else {
+            A.offsets[nn] = m;
+            mOffs[nn] = m;
+            A.headPos[nw] = m;
+        }
     }
     __syncthreads(); // (the workgroup's LDS and global stores above are visible to its threads below)
+    BV_STAMP(6);
     // word values: BowVector::addWeight adds the word's weight once per feature, in feature order -- c sequential additions.
     // They stay in LDS until they are final: the normalisation below is ONE lane adding them up in order, and every trip to
     // L2 in that chain costs more than the addition.
     for (int s = t; s < nw; s += NT) {
-        const int p = inLds ? sHead[s] : A.headPos[s], c = (inLds ? sHead[s + 1] : A.headPos[s + 1]) - p;
-        const double w = A.sortedWt[p];
+        const int p = inLds ? (int)sHead[s] : A.headPos[s], c = (inLds ? (int)sHead[s + 1] : A.headPos[s + 1]) - p;
+        const double w = inLds ? sWt[p] : __longlong_as_double((long long)bow_load_agent64(reinterpret_cast<const unsigned long long*>(&A.sortedWt[p])));
         double v = w;
         if (A.addWeight)
             for (int k = 1; k < c; k++) v = __dadd_rn(v, w);
@@ -207,16 +258,20 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
         else A.values[s] = v;
     }
     int mx = 0;
-    for (int s = t; s < nn; s += NT) mx = max(mx, inLds ? sOff[s + 1] - sOff[s] : A.offsets[s + 1] - A.offsets[s]);
+    for (int s = t; s < nn; s += NT) mx = max(mx, inLds ? (int)sOff[s + 1] - (int)sOff[s] : A.offsets[s + 1] - A.offsets[s]);
     if (mx) atomicMax(&sMax, mx);
     __syncthreads();
+    BV_STAMP(7);
     double scale = 1.0; // every value is divided by this at the end (1: left as it is)
     if (A.addWeight && !A.must && nw > 0) scale = (double)nw; // "unnecessary when normalizing" (:1164-1170): value / number of words
-    if (A.must) { // BowVector::normalize (BowVector.cpp:62-86): the sum runs over the map in ascending id order, one term at a time
+    if (A.must && !A.lazyNorm) { // BowVector::normalize (BowVector.cpp:62-86): the sum runs over the map in ascending id order, one term at a time
         if (t == 0) {
             double norm = 0.0;
             int s = 0;
             if (inLds) {
+                // (v_add_f64 issues at 32 cycles per wavefront instruction on this chip whatever the number of active lanes
+                // (profiles/r01_valu_rate.txt): the chain of nw dependent additions is ~16 ns per word -- 7.4 us for 444 words --
+                // and no arrangement of the reads changes that; orbfe_bow_set_lazy_norm leaves this sum to the host)
                 for (; s + 8 <= nw; s += 8) { // (eight reads in flight, then the dependent additions)
                     double v[8];
 #pragma unroll
@@ -244,19 +299,38 @@ __global__ __launch_bounds__(256) void k_bow_rank_fold(const BowFoldArgs A)
         __syncthreads();
         scale = sNorm > 0.0 ? sNorm : 1.0; // (norm > 0.0 or the values stay, BowVector.cpp:80)
     }
-    const bool divide = (A.must ? sNorm > 0.0 : (A.addWeight && nw > 0));
+    BV_STAMP(8);
+    const bool divide = (A.must ? (!A.lazyNorm && sNorm > 0.0) : (A.addWeight && nw > 0));
     for (int s = t; s < nw; s += NT) { // final value: device array and mirror (each thread finishes the words it made)
         double v = inLds ? sVal[s] : A.values[s];
         if (divide) v = __ddiv_rn(v, scale);
         A.values[s] = v;
         mVal[s] = v;
+        if (inLds) {
+            const uint32_t wd = sWord[sHead[s]];
+            A.wordIds[s] = wd;
+            mWid[s] = wd;
+        }
+    }
+    if (inLds) { // the FeatureVector's tables, out of LDS (nn + 1 offsets)
+        for (int s2 = t; s2 <= nn; s2 += NT) {
+            const int off = (int)sOff[s2];
+            A.offsets[s2] = off;
+            mOffs[s2] = off;
+            if (s2 < nn) {
+                const uint32_t nd = sNode[off];
+                A.nodeIds[s2] = nd;
+                mNode[s2] = nd;
+            }
+        }
     }
     {
         // the index array, mirrored in whole rows of 64 lanes (a 4-byte store per rank from the ranking wavefronts would cross
         // PCIe as a transaction each)
         int32_t* const mInd = reinterpret_cast<int32_t*>(A.mirror + A.oInd);
-        for (int r = t; r < m; r += NT) mInd[r] = A.indices[r];
+        for (int r = t; r < m; r += NT) mInd[r] = (int32_t)bow_load_agent(reinterpret_cast<const uint32_t*>(&A.indices[r]));
     }
+    BV_STAMP(9);
     if (t == 0) {
         int32_t* const mh = reinterpret_cast<int32_t*>(A.mirror + A.oHdr);
         A.hdr[0] = m;
@@ -276,6 +350,8 @@ struct orbfe_bow {
     int device = 0, cap = 0;
     int n = 0, levelsup = 0; // of the last orbfe_compute_bow
     bool computed = false, pending = false;
+    bool lazyNorm = false;   // orbfe_bow_set_lazy_norm: BowVector::normalize runs in the host view, not in the kernel
+    bool hostNormDue = false; // ... and has not run yet for the last call
     // ONE device block.  Results first, in one run (mirrored to the host by one copy): header | node ids | offsets | indices |
     // word ids | word values; then the scratch of the three kernels and a descriptor buffer for host-side callers.
     uint8_t* block = nullptr;
@@ -357,6 +433,21 @@ int bow_host_view(orbfe_bow* b, orbfe_bow_view* v)
     }
     const int32_t* h = reinterpret_cast<const int32_t*>(b->hOut);
     if (h[0] < 0 || h[0] > b->n || h[1] < 0 || h[1] > h[0] || h[2] < 0 || h[2] > h[0]) return ORBFE_ERR_STATE;
+    if (b->hostNormDue) { // BowVector::normalize (BowVector.cpp:62-86) on the mirrored values: ascending word id, one term at a time
+        b->hostNormDue = false;
+        double* val = reinterpret_cast<double*>(b->hOut + b->off(b->values));
+        const int nw = h[2];
+        const bool l2 = b->vocab->scoring == 1;
+        double norm = 0.0;
+        if (!l2)
+            for (int i = 0; i < nw; i++) norm += std::fabs(val[i]);
+        else {
+            for (int i = 0; i < nw; i++) norm += val[i] * val[i];
+            norm = std::sqrt(norm);
+        }
+        if (norm > 0.0)
+            for (int i = 0; i < nw; i++) val[i] /= norm;
+    }
     v->n_kept = h[0];
     v->nn = h[1];
     v->nw = h[2];
@@ -370,6 +461,19 @@ int bow_host_view(orbfe_bow* b, orbfe_bow_view* v)
     return 0;
 }
 } // namespace
+
+#ifdef ORBFE_BOWVEC_TIMING
+extern "C" int orbfe_debug_bowvec_times(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bowvecTimes), sizeof(g_bowvecTimes)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        z[0] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bowvecTimes), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" {
 
@@ -524,6 +628,8 @@ int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
     A.addWeight = d->weighting == 0 || d->weighting == 1; // TF_IDF || TF (:1145)
     A.must = d->scoring != 5;                             // every scoring object but DotProductScoring (ScoringObject.h:73-89)
     A.normL2 = d->scoring == 1;
+    A.lazyNorm = b->lazyNorm ? 1 : 0;
+    b->hostNormDue = b->lazyNorm && A.must;
     // (n == 0: one workgroup, which is the last one and writes the four zero counts)
     hipLaunchKernelGGL(k_bow_rank_fold, dim3((unsigned)std::max((n + 3) / 4, 1)), dim3(256), 0, g_ms, A);
     HIP_TRY(hipGetLastError());
@@ -532,6 +638,17 @@ int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
     b->stream = g_ms;
     b->pending = true;
     b->computed = true;
+    return 0;
+}
+
+/* on != 0: BowVector::normalize is left to orbfe_bow_host (the sum over the words is a chain of dependent double additions, one
+ * lane's work: 7-15 us of the kernel for 450-1000 words, a microsecond on the host); the values on the DEVICE then stay
+ * un-normalised (nothing on the device reads them: the searches use the FeatureVector).  Default off: both vectors complete on
+ * the device. */
+int orbfe_bow_set_lazy_norm(orbfe_bow* b, int on)
+{
+    if (!b) return ORBFE_ERR_ARGS;
+    b->lazyNorm = on != 0;
     return 0;
 }
 

@@ -631,11 +631,32 @@ static int run_matcher(const std::vector<uint8_t>& frames, int rows, int cols, i
             nmFold = nms[NB - 1];
             return r;
         };
+        // (the relocalisation needs the FeatureVector on the device and nothing of the BowVector there: its normalisation -- one
+        // lane's chain of dependent double additions -- is left to the host view, orbfe_bow_set_lazy_norm; the entry
+        // "compute_bow_eager_then_host_copy" below times the fully device-resident form)
+        CHECK(orbfe_bow_set_lazy_norm(bowB, 1));
         if (timeit("reloc_bow_search64_resident", 100, [&] { return chain_resident(false); }, out)) return 2;
         if (timeit("reloc_bow_search64_host_fold", 100, [&] { return chain_host(false); }, out)) return 2;
         if (timeit("reloc_extract_bow_search64_resident", 100, [&] { return chain_resident(true); }, out)) return 2;
         if (timeit("reloc_extract_bow_search64_host_fold", 100, [&] { return chain_host(true); }, out)) return 2;
-        if (timeit("compute_bow_then_host_copy", 200, [&] { int r = orbfe_compute_bow(bowB, ddB, nB, 1); orbfe_bow_view v; return r < 0 ? r : orbfe_bow_host(bowB, &v); }, out)) return 2;
+        if (auto bv = (int (*)(unsigned long long*, int))dlsym(RTLD_DEFAULT, "orbfe_debug_bowvec_times")) { // (-DORBFE_BOWVEC_TIMING library)
+            unsigned long long u[16];
+            for (int rep = 0; rep < 3; rep++) {
+                bv(u, 1);
+                orbfe_bow_view v;
+                CHECK(orbfe_compute_bow(bowB, ddB, nB, 1));
+                CHECK(orbfe_bow_host(bowB, &v));
+                bv(u, 0);
+                fprintf(stderr, "k_bow_rank_fold (n %d, kept %d, nodes %d, words %d), us from the first wavefront: ranks done %.2f | fold begins %.2f  counted %.2f  "
+                        "lists in LDS %.2f  heads scanned %.2f  tables written %.2f  values %.2f  norm %.2f  end %.2f\n", nB, v.n_kept, v.nn, v.nw,
+                        (u[1] - u[0]) * 0.01, (u[2] - u[0]) * 0.01, (u[3] - u[0]) * 0.01, (u[4] - u[0]) * 0.01, (u[5] - u[0]) * 0.01,
+                        (u[6] - u[0]) * 0.01, (u[7] - u[0]) * 0.01, (u[8] - u[0]) * 0.01, (u[9] - u[0]) * 0.01);
+            }
+        }
+        if (timeit("compute_bow_lazy_norm_then_host_copy", 200, [&] { int r = orbfe_compute_bow(bowB, ddB, nB, 1); orbfe_bow_view v; return r < 0 ? r : orbfe_bow_host(bowB, &v); }, out)) return 2;
+        CHECK(orbfe_bow_set_lazy_norm(bowB, 0));
+        if (timeit("compute_bow_eager_then_host_copy", 200, [&] { int r = orbfe_compute_bow(bowB, ddB, nB, 1); orbfe_bow_view v; return r < 0 ? r : orbfe_bow_host(bowB, &v); }, out)) return 2;
+        CHECK(orbfe_compute_bow(bowB, ddB, nB, 1));
         if (timeit("search_bow_batch64_handles_resident_vector_alone", 100, [&] { return orbfe_search_bow_keyframes(dev, NB, kfsV.data(), nullptr, relRes.data(), outp.data(), nms.data()); }, out)) return 2;
         if (nmRes != nmFold || nmRes < 0) {
             fprintf(stderr, "hostbench: relocalisation chains disagree: %d %d\n", nmRes, nmFold);
