@@ -1560,7 +1560,7 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             // Round 6: the results of a frame or two reach the page-locked slab through a copy kernel BEHIND K-DESC (k_mirror_out:
             // one workgroup, whole 16-byte rows of 64 lanes) instead of by K-DESC's own stores -- a thousand wavefronts each writing
             // 28 + 32 bytes across PCIe made the single frame's K-DESC 28 us against 8 resident (rocprofv3 of tools/hostbench,
-            // profiles/r06_single_frame_kernels.txt).  The copy kernel is then the call's last kernel and publishes the completion
+            // profiles/r06_hostbench_kernel_stats.csv).  The copy kernel is then the call's last kernel and publishes the completion
             // word: every workgroup's stores have landed before it counts itself, the last one to count writes the flag.
             // (With K-PACK's rays or the host-side trig check K-DESC keeps writing the mirror itself, as before.)
             const bool copyOut = mirror && !needPack && !hostTrigCheck;

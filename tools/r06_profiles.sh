@@ -18,6 +18,16 @@ python3 bench.py --config c4 > $out/bench_c4_1280x720_b64.json 2> $out/bench_c4.
 python3 bench.py --config c4 --batch 8 > $out/bench_c4_1280x720_b8.json 2> $out/bench_c4b8.err || exit 1
 python3 bench.py --config c3 > $out/bench_c3_stereo_pair.json 2> $out/bench_c3.err || exit 1
 python3 bench.py --config c5 > $out/bench_c5_fisheye_pair.json 2> $out/bench_c5.err || exit 1
+# the boundary from C++ under the kernel trace: which kernels a single host frame / a stereo frame / a batch runs, and for how long
+python3 - <<PY > $out/frames.log 2>&1
+import sys; sys.path.insert(0, "$root")
+import numpy as np
+import orb_slam3_detailed_comments_kor_amd as pkg
+np.stack([pkg.synth.make_frame(480, 752, 77 + i) for i in range(64)]).tofile("$out/frames.raw")
+PY
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_hostbench -- $root/tools/hostbench $out/frames.raw 480 752 64 1000 0 > $out/hostbench_traced.json 2> $out/hostbench_traced.err) || exit 1
+cp $(ls -S $out/trace_hostbench/*/*_kernel_stats.csv | head -1) $out/hostbench_kernel_stats.csv
+rm -f $out/frames.raw
 # the matcher entry points from C++ (SearchByBoW x 64, the relocalisation chain, ...)
 python3 - <<PY > $out/frame.log 2>&1
 import sys; sys.path.insert(0, "$root")
