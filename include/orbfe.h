@@ -628,13 +628,14 @@ int orbfe_vocab_get_types(orbfe_vocab_dev*, int* weighting, int* scoring);
  * FeatureVector::addFeature, FeatureVector.cpp:31-45), bit-identical to the reference's maps for every weighting / scoring type.
  *   orbfe_bow_create(&bow, vocab, cap)       a handle for frames of up to `cap` features (<= 65535); reused frame after frame
  *   orbfe_compute_bow(bow, desc, n, levelsup) `desc`: host or DEVICE pointer (orbfe_get_device_outputs: nothing crosses PCIe).
- *                                            Asynchronous on the calling thread's matcher stream -- three kernels and one copy
- *                                            command; returns when they are queued.  One caller per handle at a time.
+ *                                            Asynchronous on the calling thread's matcher stream -- two kernels (the descent;
+ *                                            rank + fold, whose last workgroup also writes the host copy into page-locked
+ *                                            memory of the handle); returns when they are queued.  One caller per handle at a time.
  *   orbfe_bow_fv(bow, &fv)                   the FeatureVector as an orbfe_fv that names the handle: a SearchByBoW batch against
  *                                            keyframe handles reads it where it lies (no host round trip between ComputeBoW and
  *                                            the search); every other consumer waits for the host copy itself.  Valid until the
  *                                            next orbfe_compute_bow on the handle.
- *   orbfe_bow_host(bow, &view)               the host copy, on request: waits for the call's copy command; pointers into
+ *   orbfe_bow_host(bow, &view)               the host copy, on request: waits for the call's kernels; pointers into
  *                                            page-locked memory of the handle, valid until the next orbfe_compute_bow.
  *                                            BowVector = (word_ids[i], word_values[i]), i < nw, ascending id (std::map order);
  *                                            FeatureVector = CSR (node_ids ascending, offsets[nn + 1], indices).

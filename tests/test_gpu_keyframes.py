@@ -520,16 +520,24 @@ def test_destroyed_handles_are_refused_and_destroy_under_a_search_is_deferred(pk
                 seen["refused"] += 1
             except AttributeError:  # (box["kf"].h is None for a moment between close and re-create)
                 seen["refused"] += 1
+    import time
     t = threading.Thread(target=searcher)
     t.start()
+    cycles, t0 = 0, time.time()
     try:
-        for _ in range(150):
+        # at least 150 destroy / re-create cycles AND at least 30 completed searches under them, however the two threads' speeds
+        # compare (a fixed number of cycles alone made the number of searches a matter of timing: the searching thread's first call
+        # builds its staging, stream and completion word while the cycles run); bounded by a deadline that is itself a failure
+        while (cycles < 150 or seen["ok"] < 30) and time.time() - t0 < 60.0:
             old = box["kf"]
             box["kf"] = pkg.KeyFrameHandle(d, mask, a, fvK)
             old.close()
+            cycles += 1
     finally:
         stop.set()
         t.join()
     box["kf"].close()
+    tally = "%d cycles, %d searches answered, %d refused in %.2f s" % (cycles, seen["ok"], seen["refused"], time.time() - t0)
+    print(tally)
     assert not bad, bad[:5]
-    assert seen["ok"] > 20
+    assert cycles >= 150 and seen["ok"] >= 30, tally
