@@ -1541,7 +1541,8 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
                                c->d_lvlCount.p, d_lap, capPerImg, c->d_destMap.p, d_n, d_mono,
                                c->kb8On ? c->d_kb8.p : nullptr,
                                c->kb8On ? (c->userRays ? c->userRays : c->d_rays.p) : nullptr, i0,
-                               k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr, mMeta, nimg, lapInPack);
+                               k == 0 ? d_hdr + 1 : nullptr, k == 0 ? d_errOut : nullptr, hostTrigCheck ? mMeta : nullptr, nimg,
+                               lapInPack); // (the mirror's meta words: k_mirror_out's unless the trig check keeps the old form)
         if (nsub == 1 && needPack) rec(c, 4); // (without K-PACK no event separates K-QT from K-DESC: a record costs ~3.5 us)
         if (c->recNow) c->packSkipped[c->profCalls % orbfe_ctx::kProfSets] = !(nsub == 1 && needPack);
         // K-DESC
@@ -1562,8 +1563,9 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             // 28 + 32 bytes across PCIe made the single frame's K-DESC 28 us against 8 resident (rocprofv3 of tools/hostbench,
             // profiles/r06_hostbench_kernel_stats.csv).  The copy kernel is then the call's last kernel and publishes the completion
             // word: every workgroup's stores have landed before it counts itself, the last one to count writes the flag.
-            // (With K-PACK's rays or the host-side trig check K-DESC keeps writing the mirror itself, as before.)
-            const bool copyOut = mirror && !needPack && !hostTrigCheck;
+            // (With the host-side trig check K-DESC keeps writing the mirror itself, as before: a fix-up launch follows it.)
+            // With K-PACK (fisheye rays) in front the copy kernel takes [n | mono | err] from where K-PACK left them.
+            const bool copyOut = mirror && !hostTrigCheck;
             OrbDone copyDone{nullptr, nullptr, 0u, 0u};
             if (c->doneWant) {
                 c->doneWant = false;
