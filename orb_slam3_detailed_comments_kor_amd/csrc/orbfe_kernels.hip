@@ -972,7 +972,7 @@ __global__ __launch_bounds__(NT) void k_octree(const OrbLevelGeom* __restrict__ 
         if (regp) {
             // the thread's four searches side by side: fixed steps 256 .. 1 (nc <= NT = 512), the four LDS reads of a
             // step independent of each other -- 9 LDS latencies in a row instead of 36 (four while-loops one after the other)
-            static_assert(QT_KPT == 4 && (NT == 512 || NT == 1024), "the interleaved search starts at NT / 2 and keeps four keys per thread");
+            static_assert(QT_KPT == 4 && NT >= 64 && (NT & (NT - 1)) == 0, "the interleaved search starts at NT / 2 (a power of two) and keeps four keys per thread");
             int lo4[QT_KPT] = {0, 0, 0, 0};
 #pragma unroll
             for (int step = NT / 2; step >= 1; step >>= 1) {
