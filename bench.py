@@ -442,6 +442,12 @@ def pmc_measure(args, batch):
     roc = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(roc):
         return {"error": "rocprofv3 not found"}
+    # already inside a profiler (somebody ran `rocprofv3 ... -- python3 bench.py`): a second tool library in the children would
+    # fight the first one over the counters -- leave the fields empty and say why
+    outer = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER_")) or
+             (k == "LD_PRELOAD" and "rocprof" in os.environ[k])]
+    if outer:
+        return {"error": "running under a profiler (%s): counter passes skipped" % ", ".join(sorted(outer)[:3])}
     tmp = tempfile.mkdtemp(prefix="orbfe_pmc_", dir="/tmp")
     acc, calib = {}, {}
     try:
@@ -450,9 +456,21 @@ def pmc_measure(args, batch):
             cmd = [roc, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-child", "--batch", str(batch), "--rows", str(args.rows), "--cols", str(args.cols),
                    "--nfeatures", str(args.nfeatures), "--rotate", str(args.rotate)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
-            if r.returncode != 0:
-                return {"error": "rocprofv3 pass %s failed (rc %d): %s" % (tag, r.returncode, (r.stderr or r.stdout)[-300:])}
+            # (a pass takes ~2 s; bounded, and the whole process group goes when the bound is hit: the profiled child holds the GPU)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  start_new_session=True)
+            try:
+                so, se = pr.communicate(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)  # (the group this call started, nothing else)
+                except OSError:
+                    pass
+                pr.communicate()
+                return {"error": "rocprofv3 pass %s did not finish in 150 s" % tag}
+            if pr.returncode != 0:
+                return {"error": "rocprofv3 pass %s failed (rc %d): %s" % (tag, pr.returncode, (se or so)[-300:])}
             rows = {}
             for f in glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):

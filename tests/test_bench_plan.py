@@ -40,3 +40,20 @@ def test_two_ranks_default_config_plan_and_forced_torch_exchange():
     c = j["config"]
     assert j["scaling"] == "weak" and c["frames_per_step"] == 128 and c["frames_per_rank"] == 64
     assert all(p["cabi"] == 0 for p in c["ranks"]) and "torch.distributed" in c["exchange"]
+
+
+def test_counter_passes_are_skipped_under_an_outer_profiler(monkeypatch):
+    # `rocprofv3 ... -- python3 bench.py`: the children of bench.py's own counter passes would load a second tool library into a
+    # process that already has one.  bench.py then leaves traffic / issue_frac empty and says why (no GPU needed: it returns
+    # before anything is started).
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    args = types.SimpleNamespace(rows=480, cols=752, nfeatures=1000, rotate=12)
+    r = bench.pmc_measure(args, 64)
+    if "rocprofv3 not found" in r.get("error", ""):
+        return  # (an image without the profiler: the earlier exit)
+    assert "error" in r and "under a profiler" in r["error"], r
