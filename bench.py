@@ -1282,7 +1282,14 @@ def main():
                          "achieved": step_bytes / dt * args.steps / 1e9,
                          "frac": step_bytes / dt * args.steps / 1e9 / HBM_PEAK_GBPS,
                          "traffic": sum(per_kernel.values()) if per_kernel else None,
-                         "traffic_frac": (sum(per_kernel.values()) / dt * args.steps / 1e9 / HBM_PEAK_GBPS) if per_kernel else None},
+                         "traffic_frac": (sum(per_kernel.values()) / dt * args.steps / 1e9 / HBM_PEAK_GBPS) if per_kernel else None,
+                         # the step against the vector-issue roof: the issue time of ALL its kernels (same definition as
+                         # issue_frac, counts of this run) over the wall time of a step with the lanes overlapping them --
+                         # what is left of this is all that a better overlap could still buy
+                         "issue_us": (sum(e["issue_us"] for e in issue["kernels"].values())
+                                      if issue and issue.get("kernels") and world == 1 else None),
+                         "issue_frac": (sum(e["issue_us"] for e in issue["kernels"].values()) / (1e6 * dt / args.steps)
+                                        if issue and issue.get("kernels") and world == 1 else None)},
             },
         }
         if same_batch is not None:
