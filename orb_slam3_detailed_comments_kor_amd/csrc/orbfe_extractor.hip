@@ -1555,9 +1555,6 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             const bool descAffine = c->xcdAffine && ni % 8 == 0;
             const unsigned descWg = (unsigned)((c->maxKp + ORBFE_DESC_WPW * ORBFE_DESC_KPW - 1) / (ORBFE_DESC_WPW * ORBFE_DESC_KPW));
             const dim3 descGrid = descAffine ? dim3(8u * descWg, (unsigned)(ni / 8)) : dim3(descWg, (unsigned)ni);
-            // completion word: K-DESC is the call's last kernel and writes the mirror (not with K-PACK's rays, the host-side
-            // trig check's fix-up launch or sub-batches behind it)
-            OrbDone done{nullptr, nullptr, 0u, 0u};
             // Round 6: the results of a frame or two reach the page-locked slab through a copy kernel BEHIND K-DESC (k_mirror_out:
             // one workgroup, whole 16-byte rows of 64 lanes) instead of by K-DESC's own stores -- a thousand wavefronts each writing
             // 28 + 32 bytes across PCIe made the single frame's K-DESC 28 us against 8 resident (rocprofv3 of tools/hostbench,
@@ -1579,13 +1576,13 @@ int run_device(orbfe_ctx* c, int nimg, const uint8_t* d_imgs, int rows, int cols
             float* const kKps = copyOut ? nullptr : mKps;
             uint8_t* const kDesc = copyOut ? nullptr : mDesc;
 #define ORBFE_DESC_LAUNCH(M, SAT)                                                                                         \
-    hipLaunchKernelGGL((done.flag ? k_orient_blur_desc<M, SAT, false, true> : k_orient_blur_desc<M, SAT>), descGrid,      \
+    hipLaunchKernelGGL((k_orient_blur_desc<M, SAT>), descGrid,                                                            \
                        dim3(64 * ORBFE_DESC_WPW), 0, q,                                                                   \
                        c->d_pyr.p, c->pyrStride, c->d_ds.p, c->maxKp, c->d_lvlKp.p, c->kpStride, c->d_lvlCount.p, nl,     \
                        c->d_lvlPre.p, needPack ? c->d_destMap.p : nullptr, capPerImg, d_kps, d_desc, c->d_taps.p, c->d_patternF.p,       \
                        c->d_fix.p, 0, hostTrigCheck ? 1 : 0, i0, descAffine ? 1 : 0, trigTab.codes,                          \
                        trigTab.full, c->atanFma, nullptr, 0, d_n, d_mono, k == 0 ? d_hdr + 1 : nullptr,                    \
-                       k == 0 ? d_errOut : nullptr, kMeta, nimg, kKps, kDesc, done)
+                       k == 0 ? d_errOut : nullptr, kMeta, nimg, kKps, kDesc)
             if (hostTrigCheck) { // (the listing of fragile keypoints is an instantiation of its own)
                 if (tapSum > 256) ORBFE_DESC_LAUNCH(2, true);
                 else ORBFE_DESC_LAUNCH(2, false);

@@ -2061,14 +2061,6 @@ __device__ __forceinline__ void xcd_done(const OrbDone& d, unsigned L)
         }
     }
 }
-// K-DESC: a workgroup is one wavefront
-__device__ __forceinline__ void desc_done(const OrbDone& d, unsigned wl /* the workgroup's linear id */)
-{
-    if (!d.flag) return; // (uniform)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    xcd_done(d, wl);
-}
-
 // The same word for a kernel of four-wavefront workgroups in which EVERY wavefront reports (K-STEREO): wavefronts count in
 // LDS, the one that completes the workgroup's count reports for it; nWaves = number of workgroups (a one-dimensional grid).
 // wg_done_begin before the first exit of any wavefront.
@@ -2118,9 +2110,9 @@ __device__ __forceinline__ uint32_t desc_hsat(uint32_t v)
                             of three finished ones; measured 64.7 (4) / 64.5 (2) / 62.4 (1) us, and 59.0 with one wavefront
                             per workgroup AND the aliased buffers below (eight wavefronts per SIMD) */
 #endif
-// WORD: the instantiation of the latency path, whose wavefronts report to the call's completion word (OrbDone): kept out of the
-//       batch instantiation (the extra argument and test cost it 0.8 of 52 us)
-template <int MODE, bool SAT, bool DBG = false, bool WORD = false>
+// (Round 6: K-DESC no longer reports to a call's completion word -- on the latency path the copy kernel behind it, k_mirror_out,
+// is the call's last kernel and publishes it.)
+template <int MODE, bool SAT, bool DBG = false>
 __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const uint8_t* __restrict__ pyr, size_t pyrImgStride,
                                                           const OrbDescSlot* __restrict__ slots /* per keypoint slot */,
                                                           int nSlots,
@@ -2151,8 +2143,7 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
                                                           int32_t* __restrict__ errOut = nullptr /* are written from here */,
                                                           int32_t* __restrict__ mirrorMeta = nullptr, int mirrorImgs = 0,
                                                           float* __restrict__ mirrorKps = nullptr /* the same outputs once more, */,
-                                                          uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */,
-                                                          const OrbDone done = OrbDone{nullptr, nullptr, 0u, 0u})
+                                                          uint8_t* __restrict__ mirrorDesc = nullptr /* in pinned HOST memory   */)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_all[ORBFE_DESC_WPW][(DESC_LDS_PER_WAVE + 15) & ~15];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2588,7 +2579,6 @@ __global__ __launch_bounds__(64 * ORBFE_DESC_WPW) void k_orient_blur_desc(const 
     }
     }; // desc_one
     desc_one(g);
-    if (WORD && MODE == 0 && ORBFE_DESC_KPW == 1 && ORBFE_DESC_WPW == 1 && g < nSlots) desc_done(done, (unsigned)(imgLocal * nSlots + g));
     if (MODE != 1 && ORBFE_DESC_KPW > 1) {
 #pragma unroll
         for (int rep = 1; rep < ORBFE_DESC_KPW; rep++) {

@@ -27,7 +27,7 @@ def test_issue_table_of_the_built_library():
     t = IT.issue_table()
     k = t["kernels"]
     names = list(k)
-    for prefix in ("k_pyr_fused", "k_fast_cells<128, 13>", "k_octree<false, 512>", "k_orient_blur_desc<0, false, false, false>",
+    for prefix in ("k_pyr_fused", "k_fast_cells<128, 13>", "k_octree<false, 512>", "k_orient_blur_desc<0, false, false>",
                    "k_bow_rank_fold", "k_search_bow", "k_bfknn2_frames_mfma"):
         assert any(n.startswith(prefix) for n in names), prefix
     assert not any(n.startswith("k_fast_runs") or n.startswith("k_octree<false, 1024>") or n.startswith("k_copy_out") for n in names)
@@ -35,6 +35,6 @@ def test_issue_table_of_the_built_library():
     assert 250 < fast["static_valu_instructions"] < 400 and 2.8 < fast["cycles_per_instruction"] < 3.8
     assert fast["share_priced_by_measurement"] > 0.5
     committed = json.load(open(os.path.join(ROOT, "profiles", "r06_issue_table.json")))
-    for n in ("k_pyr_fused", "k_fast_cells<128, 13>", "k_octree<false, 512>", "k_orient_blur_desc<0, false, false, false>"):
+    for n in ("k_pyr_fused", "k_fast_cells<128, 13>", "k_octree<false, 512>", "k_orient_blur_desc<0, false, false>"):
         assert abs(committed["kernels"][n]["cycles_per_instruction"] - k[n]["cycles_per_instruction"]) < 0.02, n
         assert committed["kernels"][n]["static_valu_instructions"] == k[n]["static_valu_instructions"], n
