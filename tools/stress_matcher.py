@@ -1,5 +1,5 @@
 """Randomised parity sweep of the matcher entry points vs the oracle.  tests/test_gpu_sweeps.py runs a bounded
-fixed-seed slice of it on the GPU box; alone: python tools/stress_matcher.py [cases] [seed]"""
+fixed-seed slice of it on the GPU box; alone: python tools/stress_matcher.py [cases] [seed] [only this kind]"""
 import os
 import sys
 import numpy as np
@@ -12,10 +12,19 @@ import orb_slam3_detailed_comments_kor_amd as pkg  # noqa: E402
 import orb_oracle_py as O  # noqa: E402
 import matcher_inputs as MI  # noqa: E402
 
-def run(ncases=60, seed=3, scale=1.0, log=print, kinds=11):
+def _near_leaf_features(vocab, n, rng, flips):
+    # descriptors a few bit flips away from the vocabulary's words (with repetition: several features per word)
+    leaves = np.nonzero(vocab["word"] >= 0)[0]
+    bits = np.unpackbits(vocab["desc"][rng.choice(leaves, size=n)], axis=1)
+    flip = rng.random(bits.shape) < (rng.integers(0, flips + 1, size=(n, 1)) / 256.0)
+    return np.packbits(bits ^ flip.astype(np.uint8), axis=1)
+
+
+def run(ncases=60, seed=3, scale=1.0, log=print, kinds=12, only=None):
     """Returns the list of mismatch descriptions.  scale < 1 shrinks the random problem sizes (test-suite slice).
     kinds = 6: the one-shot entry points only; 10: also the resident forms (keyframe / frame handles, the triangulation
-    batch) and the stereo pair in one call; 11: also batched calls whose problems share sides (staged once per call)."""
+    batch) and the stereo pair in one call; 11: also batched calls whose problems share sides (staged once per call);
+    12: also Frame::ComputeBoW on the device (random trees, types, stop words) and its resident vector through SearchByBoW."""
     O.build()
     rng = np.random.default_rng(seed)
     bad = []
@@ -24,7 +33,7 @@ def run(ncases=60, seed=3, scale=1.0, log=print, kinds=11):
         return int(rng.integers(lo, max(lo + 1, int(lo + (hi - lo) * scale))))
 
     for case in range(ncases):
-        kind = case % kinds
+        kind = case % kinds if only is None else int(only)  # (only: one kind over and over, for a new kind's first runs)
         seed = int(rng.integers(0, 1 << 30))
         ok = True
         desc = ""
@@ -252,6 +261,63 @@ def run(ncases=60, seed=3, scale=1.0, log=print, kinds=11):
                 a = O.search_projection(pr)
                 ok = ok and a[0] == g[0] and np.array_equal(a[1], g[1]) and np.array_equal(a[2], g[2])
             desc = "batches: bow x %d, projection x %d" % (nb, len(B))
+        elif kind == 11:  # ComputeBoW (orbfe_bow_*): both maps against the oracle's, then the resident vector in a search
+            k, L = int(rng.integers(2, 11)), int(rng.integers(1, 5))
+            if k ** L > 20000:
+                L -= 1
+            vocab = pkg.synth.make_vocabulary(seed % 100000, k, L, bool(rng.integers(0, 2)))
+            vocab["weight"] = vocab["weight"].copy()
+            leaves = np.nonzero(vocab["word"] >= 0)[0]
+            if rng.random() < 0.6:
+                vocab["weight"][leaves[::int(rng.integers(2, 9))]] = 0.0  # stop words
+            weighting, scoring = int(rng.integers(0, 4)), int(rng.choice([0, 1, 2, 3, 4, 5]))
+            levelsup = int(rng.integers(0, L + 3))
+            V = pkg.Vocabulary(vocab)
+            V.set_types(weighting, scoring)
+            n = int(rng.choice([0, 1, 2, 64, 65])) if rng.random() < 0.15 else size(3, 4000)
+            feats = _near_leaf_features(vocab, max(n, 1), rng, int(rng.integers(0, 40)))[:n]
+            if n > 20:
+                feats[n - n // 10:] = feats[:n // 10]  # exact duplicates: the c-fold sum of addWeight
+            B = pkg.Bow(V, max(n, 1) if rng.random() < 0.5 else int(min(65535, max(n, 1) + rng.integers(0, 3000))))
+            lazy = bool(rng.integers(0, 2))
+            B.set_lazy_norm(lazy)
+            want = O.compute_bow(vocab, feats, levelsup, weighting, scoring)
+            ondev = n > 0 and bool(rng.integers(0, 2))
+            if ondev:
+                import torch
+                d_f = torch.from_numpy(feats).pin_memory().cuda()
+                torch.cuda.synchronize()
+            ok = True
+            for rep in range(2):  # (the handle reused)
+                got = B.compute((d_f.data_ptr(), n) if ondev else feats, levelsup).host()
+                (ids, vals), (nodes, offs, ind) = got
+                ok = ok and np.array_equal(ids, want[0][0]) and np.array_equal(vals.view(np.uint64), want[0][1].view(np.uint64)) and \
+                    np.array_equal(nodes, want[1][0]) and np.array_equal(offs, want[1][1]) and np.array_equal(ind, want[1][2])
+            # the vector where ComputeBoW left it, against keyframe handles (one candidate: host node list; many: paired in the kernel)
+            ncand = int(rng.choice([1, 3, 40]))
+            if n >= 30 and len(want[1][0]) > 0:
+                aF = rng.uniform(0, 360, n).astype(np.float32)
+                kfs, wants = [], []
+                for c in range(min(ncand, 3)):
+                    nk = size(30, 1500)
+                    dK = _near_leaf_features(vocab, nk, rng, 30)
+                    dK[:min(nk, n) // 2] = feats[:min(nk, n) // 2]
+                    aK = rng.uniform(0, 360, nk).astype(np.float32)
+                    mK = (rng.uniform(size=nk) < 0.7).astype(np.uint8)
+                    fvK = O.compute_bow(vocab, dK, levelsup, weighting, scoring)[1]
+                    if len(fvK[0]) == 0:  # (every feature of the candidate on a stop word: nothing to search)
+                        continue
+                    kfs.append(pkg.KeyFrameHandle(dK, mK, aK, fvK))
+                    wants.append(O.search_bow_kf_f(dK, mK, aK, fvK, feats, aF, want[1], -1, 0.75, True))
+                B.compute((d_f.data_ptr(), n) if ondev else feats, levelsup)  # asynchronous; no host() in between
+                gotS = [] if not kfs else pkg.search_bow_keyframes([dict(kf1=kfs[c % len(kfs)], desc2=(d_f.data_ptr(), n) if ondev else feats, ang2=aF, fv2=B,
+                                                      variant=0, nnratio=0.75, check_ori=True) for c in range(ncand)])
+                ok = ok and all(g[0] == wants[c % len(kfs)][0] and np.array_equal(g[1], wants[c % len(kfs)][1]) for c, g in enumerate(gotS))
+                for h in kfs:
+                    h.close()
+            B.close()
+            V.close()
+            desc = "compute_bow k=%d L=%d n=%d levelsup=%d w/s=%d/%d lazy=%d dev=%d cand=%d" % (k, L, n, levelsup, weighting, scoring, lazy, ondev, ncand)
         else:            # knn-2 and all-pairs distances, ragged sizes
             nq, nt = size(1, 1800), size(1, 1800)
             Q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
@@ -268,6 +334,6 @@ def run(ncases=60, seed=3, scale=1.0, log=print, kinds=11):
 
 if __name__ == "__main__":
     bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 3,
-              log=(lambda *a: None) if os.environ.get("STRESS_QUIET") else print)
+              log=(lambda *a: None) if os.environ.get("STRESS_QUIET") else print, only=sys.argv[3] if len(sys.argv) > 3 else None)
     print("mismatches:", len(bad))
     sys.exit(1 if bad else 0)
