@@ -641,7 +641,9 @@ int orbfe_vocab_get_types(orbfe_vocab_dev*, int* weighting, int* scoring);
  *                                            FeatureVector = CSR (node_ids ascending, offsets[nn + 1], indices).
  *   orbfe_bow_device(bow, &view)             the same arrays on the device (stream-ordered behind the call; counts in
  *                                            d_header[0..3] = kept features, nodes, words, features of the largest node).
- *   orbfe_bow_destroy(bow)                   deferred until no search that was given the handle's vector is in progress.
+ *   orbfe_bow_destroy(bow)                   at any time: deferred until no call that was given the handle (or a vector that
+ *                                            names it) is in progress; afterwards the address is refused (ORBFE_ERR_ARGS) by
+ *                                            every entry point, also inside an orbfe_fv -- looked up, never dereferenced.
  * A feature whose word has weight 0 ("stopped", :1157) enters neither vector.  When the tree's leaves are shallower than
  * L - levelsup the reference leaves the node id uninitialised; here it is 0 (the root), as in orbfe_vocab_transform. */
 typedef struct orbfe_bow orbfe_bow;

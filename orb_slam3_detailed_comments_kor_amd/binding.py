@@ -727,6 +727,8 @@ FV_RESIDENT = -0x0B0F  # ORBFE_FV_RESIDENT (include/orbfe.h)
 
 
 def _fv(fv):
+    if isinstance(fv, _FV):  # (already in the C layout: what orbfe_bow_fv returned earlier, handed on as it is)
+        return fv, fv
     if isinstance(fv, Bow):  # the FeatureVector of an orbfe_bow handle, read where orbfe_compute_bow left it (orbfe_bow_fv)
         s = _FV()
         _chk(lib().orbfe_bow_fv(fv.h, C.byref(s)), "orbfe_bow_fv")

@@ -14,22 +14,18 @@ struct BowResident {
     hipStream_t stream;                     // ... which ran on this stream
     int n, device;
 };
-int bow_resident(orbfe_bow*, BowResident*);   // takes a use of the handle (bow_release gives it back)
-int bow_host_fv(orbfe_bow*, orbfe_fv* host);  // waits for the host copy; takes no use: valid until the next orbfe_compute_bow
-void bow_release(orbfe_bow*);
-// An orbfe_fv that names a handle, replaced by the handle's host copy (every consumer but the in-kernel pairing of bow_run)
-int fv_resolve(orbfe_fv* f)
+void bow_free_v(void*);                        // what frees an orbfe_bow = its kind in the handle table (g_handles)
+int bow_resident(orbfe_bow*, BowResident*);   // (the caller holds a use of the handle: HandleUses::take(b, bow_free_v))
+int bow_host_fv(orbfe_bow*, orbfe_fv* host);  // waits for the host copy (same: under a use); valid until the next orbfe_compute_bow
+// An orbfe_fv that names a handle, replaced by the handle's host copy (every consumer but the in-kernel pairing of bow_run).
+// The use is the caller's: the host copy lives in the handle's page-locked memory and is read until the call returns.
+int fv_resolve(orbfe_fv* f, HandleUses& uses)
 {
     if (f->nn != ORBFE_FV_RESIDENT) return 0;
-    return bow_host_fv(reinterpret_cast<orbfe_bow*>(const_cast<uint32_t*>(f->node_ids)), f);
+    orbfe_bow* b = reinterpret_cast<orbfe_bow*>(const_cast<uint32_t*>(f->node_ids));
+    if (!b || !uses.take(b, bow_free_v)) return ORBFE_ERR_ARGS; // (destroyed, or not a BoW handle at all)
+    return bow_host_fv(b, f);
 }
-struct BowHold { // the uses bow_run took, given back on every way out
-    std::vector<orbfe_bow*> v;
-    ~BowHold()
-    {
-        for (orbfe_bow* b : v) bow_release(b);
-    }
-};
 } // namespace
 
 namespace {
@@ -115,7 +111,6 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
     // orbfe_compute_bow left it; otherwise the handle's host copy takes its place (a wait for a copy that was queued with it).
     std::vector<BowResident> res1(count), res2(count);
     std::vector<uint8_t> isRes1(count, 0), isRes2(count, 0), inKf1(count, 0), inKf2(count, 0);
-    BowHold hold;
     std::vector<uint8_t> own1(count, 0), own2(count, 0); // this problem stages the set (first occurrence)
     std::vector<int> set1(count, -1), set2(count, -1);  // index into `seen` of a pooled side
     size_t nodeTotal = 0;
@@ -183,6 +178,7 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             if ((side ? K2 : K1) || f.nn != ORBFE_FV_RESIDENT) continue;
             if (!f.node_ids) return ORBFE_ERR_ARGS;
             orbfe_bow* B = reinterpret_cast<orbfe_bow*>(const_cast<uint32_t*>(f.node_ids));
+            if (!uses.take(B, bow_free_v)) return ORBFE_ERR_ARGS; // (destroyed, or no BoW handle; held until this call returns)
             if (!devNodes) { // host lists: the handle's host copy
                 const int rr = bow_host_fv(B, &f);
                 if (rr < 0) return rr;
@@ -191,7 +187,6 @@ int bow_run(int device, int count, const orbfe_bow_args* args, orbfe_keyframe* c
             BowResident& R = side ? res2[p] : res1[p];
             const int rr = bow_resident(B, &R);
             if (rr < 0) return rr;
-            hold.v.push_back(B);
             if (R.device != device || R.n != (side ? e.n2 : e.n1)) return ORBFE_ERR_ARGS; // (the vector indexes THIS set's features)
             (side ? isRes2 : isRes1)[p] = 1;
             f.nn = 0; // (for the pooled layout below: the set brings no node list and no index array of its own)
@@ -510,9 +505,10 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
     *out = nullptr;
     orbfe_keyframe_args aLocal;
     const orbfe_keyframe_args* a = a0;
+    HandleUses fvUses; // (a vector that names an orbfe_bow handle: the handle is held until this call returns)
     if (a0 && a0->fv.nn == ORBFE_FV_RESIDENT) { // the vector of an orbfe_bow handle: its host copy (the handle keeps host views)
         aLocal = *a0;
-        if (int rr = fv_resolve(&aLocal.fv); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv, fvUses); rr < 0) return rr;
         a = &aLocal;
     }
     if (!a || a->n < 1 || a->n >= (1 << 20) || !a->desc || !a->mask || !fv_ok(a->fv)) return ORBFE_ERR_ARGS;
@@ -609,7 +605,7 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
         delete K;
         return -(1000 + (int)e);
     }
-    g_handles.add(K);
+    g_handles.add(K, keyframe_free);
     *out = K;
     return 0;
 }
@@ -647,7 +643,7 @@ void orbfe_keyframe_destroy(orbfe_keyframe* K)
     // (no hipDeviceSynchronize here -- it drained the extractor's batches in flight and every other thread's
     // searches whenever the adapter's table evicted a keyframe.  Round 6: a search of another thread that still holds the
     // handle keeps it alive -- the last use frees it, g_handles.)
-    if (g_handles.destroy(K)) keyframe_free(K);
+    if (g_handles.destroy(K, keyframe_free)) keyframe_free(K);
 }
 
 int orbfe_search_bow_keyframes(int device, int count, orbfe_keyframe* const* kf1, orbfe_keyframe* const* kf2,

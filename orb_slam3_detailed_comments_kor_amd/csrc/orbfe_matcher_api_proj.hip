@@ -332,6 +332,9 @@ int orbfe_search_projection_batch(int device, const orbfe_proj_args* items, int 
     return proj_run(device, items, count, q_match, feat_match, nmatches, nullptr);
 }
 
+namespace {
+void frame_free(void* h);
+}
 int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
 {
     if (!out) return ORBFE_ERR_ARGS;
@@ -404,7 +407,7 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
         delete F;
         return -(1000 + (int)e);
     }
-    g_handles.add(F);
+    g_handles.add(F, frame_free);
     *out = F;
     return 0;
 }
@@ -423,7 +426,7 @@ void orbfe_frame_destroy(orbfe_frame* F)
     if (!F) return;
     // (the block goes back to the pool when no search holds the handle any more -- g_handles; a search's kernel has done all its
     // reads before the search returns, with the completion word as without it)
-    if (g_handles.destroy(F)) frame_free(F);
+    if (g_handles.destroy(F, frame_free)) frame_free(F);
 }
 
 int orbfe_search_projection_frame(orbfe_frame* F, const orbfe_proj_args* a, int32_t* q_match, int32_t* feat_match)

@@ -221,10 +221,11 @@ int orbfe_search_tri(int device, const orbfe_tri_args* a0, int32_t* pairs)
 {
     orbfe_tri_args aLocal;
     const orbfe_tri_args* a = a0;
+    HandleUses fvUses; // (a vector that names an orbfe_bow handle: the handle is held until this call returns)
     if (a0 && (a0->fv1.nn == ORBFE_FV_RESIDENT || a0->fv2.nn == ORBFE_FV_RESIDENT)) { // vectors of orbfe_bow handles: their host copies
         aLocal = *a0;
-        if (int rr = fv_resolve(&aLocal.fv1); rr < 0) return rr;
-        if (int rr = fv_resolve(&aLocal.fv2); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv1, fvUses); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv2, fvUses); rr < 0) return rr;
         a = &aLocal;
     }
     if (!a || !pairs || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
@@ -530,10 +531,11 @@ int orbfe_search_tri_kb8(int device, const orbfe_tri_kb8_args* a0, int32_t* pair
 {
     orbfe_tri_kb8_args aLocal;
     const orbfe_tri_kb8_args* a = a0;
+    HandleUses fvUses; // (a vector that names an orbfe_bow handle: the handle is held until this call returns)
     if (a0 && (a0->fv1.nn == ORBFE_FV_RESIDENT || a0->fv2.nn == ORBFE_FV_RESIDENT)) { // vectors of orbfe_bow handles: their host copies
         aLocal = *a0;
-        if (int rr = fv_resolve(&aLocal.fv1); rr < 0) return rr;
-        if (int rr = fv_resolve(&aLocal.fv2); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv1, fvUses); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv2, fvUses); rr < 0) return rr;
         a = &aLocal;
     }
     if (!a || !pairs || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;
@@ -635,10 +637,11 @@ int orbfe_search_tri_3d(int device, const orbfe_tri3d_args* a0, int32_t* pairs, 
 {
     orbfe_tri3d_args aLocal;
     const orbfe_tri3d_args* a = a0;
+    HandleUses fvUses; // (a vector that names an orbfe_bow handle: the handle is held until this call returns)
     if (a0 && (a0->fv1.nn == ORBFE_FV_RESIDENT || a0->fv2.nn == ORBFE_FV_RESIDENT)) { // vectors of orbfe_bow handles: their host copies
         aLocal = *a0;
-        if (int rr = fv_resolve(&aLocal.fv1); rr < 0) return rr;
-        if (int rr = fv_resolve(&aLocal.fv2); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv1, fvUses); rr < 0) return rr;
+        if (int rr = fv_resolve(&aLocal.fv2, fvUses); rr < 0) return rr;
         a = &aLocal;
     }
     if (!a || !pairs || !points || a->n1 < 0 || a->n2 < 0 || !fv_ok(a->fv1) || !fv_ok(a->fv2)) return ORBFE_ERR_ARGS;

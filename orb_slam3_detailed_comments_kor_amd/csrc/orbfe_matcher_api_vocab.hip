@@ -27,7 +27,7 @@ int orbfe_debug_handle_table_selftest(int threads, int slots, int rounds)
         f->usesOut.store(0);
         f->freed.store(0);
         f->alive.store(1);
-        g_handles.add(f);
+        g_handles.add(f, +freeFn);
         cur[s].store(f);
     }
     std::vector<std::thread> th;
@@ -56,17 +56,24 @@ int orbfe_debug_handle_table_selftest(int threads, int slots, int rounds)
             nw->usesOut.store(0);
             nw->freed.store(0);
             nw->alive.store(1);
-            g_handles.add(nw);
+            g_handles.add(nw, +freeFn);
             cur[s].store(nw);
             old->alive.store(0);
-            if (g_handles.destroy(old)) freeFn(old);
+            if (g_handles.destroy(old, +freeFn)) freeFn(old);
         }
     stop.store(true);
     for (auto& t : th) t.join();
     for (int s = 0; s < slots; s++) {
         Fake* f = cur[s].load();
         f->alive.store(0);
-        if (g_handles.destroy(f)) freeFn(f);
+        // a handle of one kind is neither granted nor destroyed as another (a recycled address must not pass for the old type)
+        auto otherKind = [](void*) {};
+        {
+            HandleUses wrong;
+            if (wrong.take(f, +otherKind)) violations.fetch_add(1);
+        }
+        if (g_handles.destroy(f, +otherKind)) violations.fetch_add(1);
+        if (g_handles.destroy(f, +freeFn)) freeFn(f);
         if (f->freed.load() != 1) violations.fetch_add(1);
     }
     return violations.load();

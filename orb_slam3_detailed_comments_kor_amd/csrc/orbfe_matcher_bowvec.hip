@@ -373,8 +373,8 @@ struct orbfe_bow {
     hipStream_t stream = nullptr;      // the stream of the last call (a consumer on the same stream needs no event wait)
     uint8_t* hDesc = nullptr;          // pinned staging of host descriptors
     hipEvent_t ev = nullptr;           // behind the mirror copy of the last call
-    std::atomic<int> uses{1};          // the owner + every search in progress that was given the handle's vector (bow_run)
-    std::atomic<bool> dead{false};
+    // (lifetime: the process-wide handle table, g_handles -- every entry point takes a use by LOOK-UP before it reads the
+    // object, so a destroyed handle is refused without being dereferenced and a destroy under a search is deferred to its return)
     size_t off(const void* p) const { return (size_t)((const uint8_t*)p - block); }
 };
 
@@ -391,14 +391,10 @@ void bow_free(orbfe_bow* b)
     if (b->hDesc) (void)hipHostFree(b->hDesc);
     delete b;
 }
-void bow_release(orbfe_bow* b)
+void bow_free_v(void* p) { bow_free(static_cast<orbfe_bow*>(p)); }
+int bow_resident(orbfe_bow* b, BowResident* R) // (under a use of the handle)
 {
-    if (b->uses.fetch_sub(1) == 1) bow_free(b);
-}
-int bow_resident(orbfe_bow* b, BowResident* R)
-{
-    if (!b->computed || b->dead.load()) return ORBFE_ERR_STATE;
-    b->uses.fetch_add(1);
+    if (!b->computed) return ORBFE_ERR_STATE;
     R->nodeIds = b->nodeIds;
     R->offsets = b->offsets;
     R->indices = b->indices;
@@ -410,9 +406,9 @@ int bow_resident(orbfe_bow* b, BowResident* R)
     return 0;
 }
 int bow_host_view(orbfe_bow* b, orbfe_bow_view* v);
-int bow_host_fv(orbfe_bow* b, orbfe_fv* host)
+int bow_host_fv(orbfe_bow* b, orbfe_fv* host) // (under a use of the handle)
 {
-    if (!b || b->dead.load()) return ORBFE_ERR_ARGS;
+    if (!b) return ORBFE_ERR_ARGS;
     orbfe_bow_view v;
     const int r = bow_host_view(b, &v);
     if (r < 0) return r;
@@ -564,6 +560,7 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
     b->keys = (uint2*)(B + oKeys);
     b->dDesc = B + oDesc;
     std::memset(b->hOut, 0, 32);
+    g_handles.add(b, bow_free_v);
     *out = b;
     return 0;
 }
@@ -571,15 +568,16 @@ int orbfe_bow_create(orbfe_bow** out, orbfe_vocab_dev* vocab, int cap)
 void orbfe_bow_destroy(orbfe_bow* b)
 {
     if (!b) return;
-    b->dead.store(true);
-    bow_release(b); // (freed now, or by the last search that still reads its arrays)
+    if (g_handles.destroy(b, bow_free_v)) bow_free(b); // (else: freed by the last call that still holds it, or not a live BoW handle)
 }
 
 /* Frame::ComputeBoW: mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) on n descriptors (host or device
  * pointer).  Asynchronous on the calling thread's matcher stream: returns when the kernels and the mirror copy are queued. */
 int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
 {
-    if (!b || n < 0 || n > b->cap || (n && !desc) || b->dead.load()) return ORBFE_ERR_ARGS;
+    HandleUses uses;
+    if (!b || !uses.take(b, bow_free_v)) return ORBFE_ERR_ARGS; // (destroyed, or not a BoW handle)
+    if (n < 0 || n > b->cap || (n && !desc)) return ORBFE_ERR_ARGS;
     int r;
     if ((r = select_device(b->device)) < 0) return r;
     Scratch s(b->device); // (this thread's matcher stream: g_ms)
@@ -647,20 +645,23 @@ int orbfe_compute_bow(orbfe_bow* b, const uint8_t* desc, int n, int levelsup)
  * the device. */
 int orbfe_bow_set_lazy_norm(orbfe_bow* b, int on)
 {
-    if (!b) return ORBFE_ERR_ARGS;
+    HandleUses uses;
+    if (!b || !uses.take(b, bow_free_v)) return ORBFE_ERR_ARGS;
     b->lazyNorm = on != 0;
     return 0;
 }
 
 int orbfe_bow_host(orbfe_bow* b, orbfe_bow_view* view)
 {
-    if (!b || !view) return ORBFE_ERR_ARGS;
+    HandleUses uses;
+    if (!b || !view || !uses.take(b, bow_free_v)) return ORBFE_ERR_ARGS;
     return bow_host_view(b, view);
 }
 
 int orbfe_bow_device(orbfe_bow* b, orbfe_bow_view* view)
 {
-    if (!b || !view) return ORBFE_ERR_ARGS;
+    HandleUses uses;
+    if (!b || !view || !uses.take(b, bow_free_v)) return ORBFE_ERR_ARGS;
     if (!b->computed) return ORBFE_ERR_STATE;
     view->n_kept = view->nn = view->nw = view->max_node = -1; // (on the device: d_header[0..3])
     view->node_ids = b->nodeIds;
@@ -677,7 +678,8 @@ int orbfe_bow_device(orbfe_bow* b, orbfe_bow_view* view)
  * handle's arrays where they lie (no host copy is ever made); every other consumer asks for the host view first. */
 int orbfe_bow_fv(orbfe_bow* b, orbfe_fv* fv)
 {
-    if (!b || !fv) return ORBFE_ERR_ARGS;
+    HandleUses uses;
+    if (!b || !fv || !uses.take(b, bow_free_v)) return ORBFE_ERR_ARGS;
     if (!b->computed) return ORBFE_ERR_STATE;
     fv->nn = ORBFE_FV_RESIDENT;
     fv->node_ids = reinterpret_cast<const uint32_t*>(b);

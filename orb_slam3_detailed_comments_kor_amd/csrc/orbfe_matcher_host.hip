@@ -115,21 +115,23 @@ BlockPool g_blockPool;
 // finds uses outstanding marks the handle dead and leaves the freeing to the last use that is given back.
 struct HandleTable {
     std::mutex m;
+    typedef void (*FreeFn)(void*);
     struct Ent {
         int uses;
         bool dead;
+        FreeFn kind; // what frees it = what it is: a keyframe pointer never passes for a frame or a BoW handle at a recycled address
     };
     std::unordered_map<const void*, Ent> live;
-    void add(const void* h)
+    void add(const void* h, FreeFn kind)
     {
         std::lock_guard<std::mutex> g(m);
-        live[h] = Ent{0, false};
+        live[h] = Ent{0, false, kind};
     }
-    bool acquire(const void* h)
+    bool acquire(const void* h, FreeFn kind)
     {
         std::lock_guard<std::mutex> g(m);
         auto it = live.find(h);
-        if (it == live.end() || it->second.dead) return false;
+        if (it == live.end() || it->second.dead || it->second.kind != kind) return false;
         it->second.uses++;
         return true;
     }
@@ -145,12 +147,12 @@ struct HandleTable {
         }
         return false;
     }
-    // true: free now; false: in use (freed by the last release) or unknown (already destroyed: nothing to do)
-    bool destroy(const void* h)
+    // true: free now; false: in use (freed by the last release) or unknown (already destroyed / another kind: nothing to do)
+    bool destroy(const void* h, FreeFn kind)
     {
         std::lock_guard<std::mutex> g(m);
         auto it = live.find(h);
-        if (it == live.end() || it->second.dead) return false;
+        if (it == live.end() || it->second.dead || it->second.kind != kind) return false;
         if (it->second.uses == 0) {
             live.erase(it);
             return true;
@@ -166,8 +168,8 @@ struct HandleUses {
     bool take(const void* h, void (*freeFn)(void*))
     {
         for (const auto& e : held)
-            if (e.first == h) return true; // (the same handle on several problems of one call: one use)
-        if (!g_handles.acquire(h)) return false;
+            if (e.first == h) return e.second == freeFn; // (the same handle on several problems of one call: one use)
+        if (!g_handles.acquire(h, freeFn)) return false;
         held.emplace_back(h, freeFn);
         return true;
     }

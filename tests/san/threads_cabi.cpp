@@ -154,6 +154,35 @@ int main(int argc, char** argv)
         std::memset(&pa, 0, sizeof pa);
         int32_t q[1], f[1];
         EXPECT(orbfe_search_projection_frame(reinterpret_cast<orbfe_frame*>(fake), &pa, q, f) == ORBFE_ERR_ARGS);
+        // ... and the same with an address whose memory has been FREED: under AddressSanitizer a single read of it is a report
+        // (heap-use-after-free), so a silent run is the proof that handles are looked up, not dereferenced -- keyframe, frame
+        // and (since the BoW handles moved into the same table) orbfe_bow entry points alike
+        void* gone = std::malloc(1024);
+        std::free(gone);
+        orbfe_bow* sb = reinterpret_cast<orbfe_bow*>(gone);
+        uint8_t d32[32] = {0};
+        EXPECT(orbfe_compute_bow(sb, d32, 1, 4) == ORBFE_ERR_ARGS);
+        EXPECT(orbfe_bow_set_lazy_norm(sb, 1) == ORBFE_ERR_ARGS);
+        EXPECT(orbfe_bow_host(sb, &v) == ORBFE_ERR_ARGS && orbfe_bow_device(sb, &v) == ORBFE_ERR_ARGS && orbfe_bow_fv(sb, &fv) == ORBFE_ERR_ARGS);
+        orbfe_bow_destroy(sb);
+        EXPECT(orbfe_keyframe_set_mask(reinterpret_cast<orbfe_keyframe*>(gone), m) == ORBFE_ERR_ARGS);
+        orbfe_keyframe_destroy(reinterpret_cast<orbfe_keyframe*>(gone));
+        orbfe_frame_destroy(reinterpret_cast<orbfe_frame*>(gone));
+        EXPECT(orbfe_search_projection_frame(reinterpret_cast<orbfe_frame*>(gone), &pa, q, f) == ORBFE_ERR_ARGS);
+        // a vector that NAMES such a handle (ORBFE_FV_RESIDENT) in the calls that take an orbfe_fv
+        orbfe_fv named;
+        named.nn = ORBFE_FV_RESIDENT;
+        named.node_ids = reinterpret_cast<const uint32_t*>(gone);
+        named.offsets = nullptr;
+        named.indices = nullptr;
+        orbfe_keyframe_args ka;
+        std::memset(&ka, 0, sizeof ka);
+        ka.n = 1;
+        ka.desc = d32;
+        ka.mask = m;
+        ka.fv = named;
+        orbfe_keyframe* kout = nullptr;
+        EXPECT(orbfe_keyframe_create(&kout, 0, &ka) == ORBFE_ERR_ARGS && kout == nullptr);
     }
     std::printf("threads_cabi: %d failures\n", g_fail.load());
     return g_fail.load() ? 1 : 0;

@@ -205,3 +205,86 @@ def test_relocalisation_chain_without_a_host_copy_of_the_vector(pkg, oracle, k, 
     BF.close()
     BK.close()
     V.close()
+
+
+def test_bow_handles_are_looked_up_not_dereferenced_and_destroy_under_a_search_is_deferred(pkg, oracle):
+    """The BoW handles live in the same table as keyframe / frame handles (use counts, kind = what frees them): a destroyed handle
+    is refused by every entry point -- also when a search is handed an orbfe_fv that still names it --, a handle of another KIND
+    at the same address is refused too, and a destroy that arrives while a search reads the resident vector is deferred."""
+    import ctypes as C
+    import threading
+    import time
+    from orb_slam3_detailed_comments_kor_amd import binding
+    L = pkg.lib()
+    vocab = pkg.synth.make_vocabulary(5, 9, 3, True)
+    V = pkg.Vocabulary(vocab)
+    rng = np.random.default_rng(3)
+    n = 900
+    dF = near_leaf_features(vocab, n, 17, flips=20)
+    aF = rng.uniform(0, 360, n).astype(np.float32)
+    B = pkg.Bow(V, n)
+    B.compute(dF, 2)
+    fv_named = binding._FV()
+    assert L.orbfe_bow_fv(B.h, C.byref(fv_named)) == 0 and fv_named.nn == binding.FV_RESIDENT
+    stale = C.c_void_p(B.h.value)
+    dK, _ = _noisy_copy(dF, 1000, 9)
+    aK = rng.uniform(0, 360, 1000).astype(np.float32)
+    mK = np.ones(1000, np.uint8)
+    fvK = oracle.compute_bow(vocab, dK, 2)[1]
+    kf = pkg.KeyFrameHandle(dK, mK, aK, fvK)
+    want = oracle.search_bow_kf_f(dK, mK, aK, fvK, dF, aF, oracle.compute_bow(vocab, dF, 2)[1], -1, 0.75, True)
+    got = pkg.search_bow_keyframes([dict(kf1=kf, desc2=dF, ang2=aF, fv2=B, variant=0, nnratio=0.75, check_ori=True)])[0]
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    # a keyframe handle's address where a BoW handle is expected (and the other way round): refused by kind
+    assert L.orbfe_compute_bow(C.c_void_p(kf.h.value), dF.ctypes.data, 10, 2) == binding.ERR_ARGS
+    assert L.orbfe_keyframe_set_mask(stale, mK.ctypes.data) == binding.ERR_ARGS
+    B.close()
+    # destroyed: every entry point refuses the address; so does a search that is handed the vector that names it
+    assert L.orbfe_compute_bow(stale, dF.ctypes.data, n, 2) == binding.ERR_ARGS
+    assert L.orbfe_bow_set_lazy_norm(stale, 1) == binding.ERR_ARGS
+    out = binding._FV()
+    assert L.orbfe_bow_fv(stale, C.byref(out)) == binding.ERR_ARGS
+    L.orbfe_bow_destroy(stale)  # a second destroy: ignored
+    with pytest.raises(pkg.OrbfeError) as e:
+        pkg.search_bow_keyframes([dict(kf1=kf, desc2=dF, ang2=aF, fv2=fv_named, variant=0, nnratio=0.75, check_ori=True)])
+    assert e.value.code == binding.ERR_ARGS
+    # destroy / re-create under a thread that keeps searching with the vector of whatever handle is current
+    box = {"b": pkg.Bow(V, n)}
+    box["b"].compute(dF, 2)
+    stop, bad, seen = threading.Event(), [], {"ok": 0, "refused": 0}
+
+    def searcher():
+        while not stop.is_set():
+            b = box["b"]
+            try:
+                g = pkg.search_bow_keyframes([dict(kf1=kf, desc2=dF, ang2=aF, fv2=b, variant=0, nnratio=0.75, check_ori=True)])[0]
+                if g[0] != want[0] or not np.array_equal(g[1], want[1]):
+                    bad.append("wrong result")
+                seen["ok"] += 1
+            except pkg.OrbfeError as ex:
+                if ex.code not in (binding.ERR_ARGS, binding.ERR_STATE):
+                    bad.append(ex.code)
+                seen["refused"] += 1
+            except (AttributeError, TypeError):  # (b.h is None for a moment between close and re-create)
+                seen["refused"] += 1
+    t = threading.Thread(target=searcher)
+    t.start()
+    cycles, t0 = 0, time.time()
+    try:
+        while (cycles < 100 or seen["ok"] < 30) and time.time() - t0 < 60.0:
+            old = box["b"]
+            nb = pkg.Bow(V, n)
+            nb.compute(dF, 2)
+            box["b"] = nb
+            old.close()
+            cycles += 1
+    finally:
+        stop.set()
+        t.join()
+    tally = "%d cycles, %d searches answered, %d refused in %.2f s" % (cycles, seen["ok"], seen["refused"], time.time() - t0)
+    print(tally)
+    box["b"].close()
+    kf.close()
+    V.close()
+    assert not bad, bad[:5]
+    assert cycles >= 100 and seen["ok"] >= 30, tally
