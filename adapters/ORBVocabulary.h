@@ -111,7 +111,14 @@ public:
         if (empty() || n <= 0) return;
         orbfe_bow* b = borrow(n);
         const int r = orbfe_compute_bow(b, desc, n, levelsup);
-        if (r == 0) fill(b, v, fv);
+        if (r == 0) {
+            try {
+                fill(b, v, fv);
+            } catch (...) { // (the borrowed handle goes back whatever fill() says)
+                give_back(b);
+                throw;
+            }
+        }
         give_back(b);
         if (r != 0) throw std::runtime_error(std::string("ORBVocabulary::transform: ") + orbfe_error_string(r));
     }
@@ -172,9 +179,9 @@ private:
                 if (caps_[i] >= n) {
                     orbfe_bow* b = pool_[i];
                     pool_.erase(pool_.begin() + (long)i);
-                    lastCap_ = caps_[i];
+                    const int cap = caps_[i];
                     caps_.erase(caps_.begin() + (long)i);
-                    borrowedCap_.push_back(std::make_pair(b, lastCap_));
+                    borrowedCap_.push_back(std::make_pair(b, cap));
                     return b;
                 }
         }
@@ -208,7 +215,6 @@ private:
     mutable std::vector<orbfe_bow*> pool_;
     mutable std::vector<int> caps_;
     mutable std::vector<std::pair<orbfe_bow*, int>> borrowedCap_;
-    mutable int lastCap_ = 0;
 };
 
 } // namespace ORB_SLAM3

@@ -2818,11 +2818,10 @@ int orbfe_get_level(orbfe_ctx* c, int img_index, int level, uint8_t* dst, size_t
                        c->pyrStride, L, img_index);
     const uint8_t* src = c->d_pyr.p + (size_t)img_index * c->pyrStride + L.bufOff + (ORBFE_ROI_X0 - ORBFE_EDGE);
     // Through page-locked memory of the context, never a rect copy into the caller's (pageable) array.  A 2-D copy to pageable
-    // memory makes the runtime pin the destination on the fly (a userptr mapping) and keep it in a per-stream cache keyed by host
-    // address; once the heap that held an earlier destination has been trimmed and grown again, a later call whose array lands
-    // on the same address is served from that cache with a mapping that is no longer valid, and the copy kernel dies with
-    // "Memory access fault by GPU ... on address <a host heap address>" -- seen once in this very call in round 6 (and the
-    // likeliest reading of round 5's unexplained SIGABRT: the runtime's message went to a captured stderr).  DESIGN.md 7.6.
+    // memory makes the runtime pin the destination on the fly and write through that mapping; in round 6 this very call died
+    // once with "Memory access fault by GPU ... on address <a host heap address>" inside such a copy (what is
+    // known, and the hypothesis about the runtime's cache of pinned regions that would explain it -- not demonstrated).  A
+    // linear copy into memory this context pinned itself, and a host row copy, take the runtime's path out of the picture.
     const size_t bytes = (size_t)(H - 1) * L.pitch + (size_t)W;
     int r = c->h_level.ensure(bytes);
     if (r < 0) return r;
