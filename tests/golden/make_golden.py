@@ -99,7 +99,45 @@ def natural_cases():
         print(name, int(out["mono_libm"]), len(out["kps_libm"]), out["ncand"].tolist())
 
 
+# round 6: Frame::ComputeBoW (TemplatedVocabulary::transform with both maps): (weighting, scoring, levelsup)
+BOW_CASES = [(0, 0, 4), (0, 0, 0), (0, 0, 2), (1, 1, 2), (3, 5, 1), (2, 0, 6), (1, 3, 3)]
+BOW_VOCAB = dict(seed=4242, k=9, L=4, ragged=True, stop_every=6)
+BOW_FEATURES = dict(n=1500, seed=4243, flips=14, duplicates=120)
+
+
+def bow_inputs():
+    """The vocabulary and the descriptors of the ComputeBoW fixture, from their seeds (tests/test_golden.py makes them again)."""
+    vocab = synth.make_vocabulary(BOW_VOCAB["seed"], BOW_VOCAB["k"], BOW_VOCAB["L"], BOW_VOCAB["ragged"])
+    vocab["weight"] = vocab["weight"].copy()
+    leaves = np.nonzero(vocab["word"] >= 0)[0]
+    vocab["weight"][leaves[::BOW_VOCAB["stop_every"]]] = 0.0  # stop words (TemplatedVocabulary.h:1157)
+    rng = np.random.default_rng(BOW_FEATURES["seed"])
+    n = BOW_FEATURES["n"]
+    bits = np.unpackbits(vocab["desc"][rng.choice(leaves, size=n)], axis=1)
+    for r in range(n):
+        bits[r, rng.permutation(256)[:rng.integers(0, BOW_FEATURES["flips"])]] ^= 1
+    feats = np.packbits(bits, axis=1)
+    feats[n - BOW_FEATURES["duplicates"]:] = feats[:BOW_FEATURES["duplicates"]]  # exact duplicates: the c-fold sum of addWeight
+    return vocab, feats
+
+
+def bow_cases():
+    vocab, feats = bow_inputs()
+    out = {"vocab_desc_sha256": np.frombuffer(hashlib.sha256(vocab["desc"].tobytes()).digest(), np.uint8),
+           "features_sha256": np.frombuffer(hashlib.sha256(feats.tobytes()).digest(), np.uint8)}
+    for w, sc, lu in BOW_CASES:
+        (ids, vals), (nodes, offs, ind) = O.compute_bow(vocab, feats, lu, w, sc)
+        t = "w%d_s%d_l%d_" % (w, sc, lu)
+        out[t + "word_ids"], out[t + "word_value_bits"] = ids, vals.view(np.uint64)  # (the doubles bit for bit)
+        out[t + "node_ids"], out[t + "offsets"], out[t + "indices"] = nodes, offs, ind
+        print("bow", (w, sc, lu), len(ids), "words", len(nodes), "nodes", int(offs[-1]) if len(offs) else 0, "features kept")
+    np.savez_compressed(os.path.join(HERE, "bow_k9L4.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "bow":  # (only this fixture: the others are untouched)
+        bow_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "natural":  # only the fixtures added in round 5
         natural_cases()
         return
@@ -132,6 +170,7 @@ def main():
                                               I["sf"], I["sig"], False, True, True)
     np.savez_compressed(os.path.join(HERE, "matcher_window_searches.npz"), **out)
     print("window searches", {k: int(v) for k, v in out.items() if k.endswith("_n")}, len(out["tri_pairs"]))
+    bow_cases()
 
 
 if __name__ == "__main__":
