@@ -288,3 +288,110 @@ def test_bow_handles_are_looked_up_not_dereferenced_and_destroy_under_a_search_i
     V.close()
     assert not bad, bad[:5]
     assert cycles >= 100 and seen["ok"] >= 30, tally
+
+
+def test_compute_bow_while_other_kernels_and_copies_load_the_chip(pkg, oracle):
+    """k_bow_rank_fold hands the ranked lists from every workgroup to the LAST one through agent-scope stores / loads and a
+    counter, without a release fence.  A claim about memory ORDERING is not validated by results that agree on an
+    idle chip (round 4's lesson): here one handle is reused with inputs that CHANGE from call to call (a stale line of the
+    previous call would be a wrong vector) while a second thread runs 64-frame extractions on every XCD, a third batched
+    searches and a fourth large copies in both directions; every vector against the oracle's, and the resident vector through
+    SearchByBoW in the same loop."""
+    import os
+    import threading
+    import torch
+    vocab = pkg.synth.make_vocabulary(321, 10, 3, False)
+    V = pkg.Vocabulary(vocab)
+    rng = np.random.default_rng(8)
+    sizes = [1000, 37, 1400, 2600, 512, 1, 1999, 640]   # (2600: the fold's device-array form)
+    sets = []
+    for k, n in enumerate(sizes):
+        f = near_leaf_features(vocab, n, 900 + k, flips=16)
+        sets.append((f, oracle.compute_bow(vocab, f, 1)))
+    B = pkg.Bow(V, 4096)
+    B2 = pkg.Bow(V, 4096)
+    B2.set_lazy_norm(True)
+    # a keyframe to search against with the resident vector of set 0
+    dF, (_, fvF) = sets[0]
+    aF = rng.uniform(0, 360, len(dF)).astype(np.float32)
+    dK, _ = _noisy_copy(dF, 1100, 4)
+    aK = rng.uniform(0, 360, 1100).astype(np.float32)
+    mK = np.ones(1100, np.uint8)
+    fvK = oracle.compute_bow(vocab, dK, 1)[1]
+    kf = pkg.KeyFrameHandle(dK, mK, aK, fvK)
+    wantS = oracle.search_bow_kf_f(dK, mK, aK, fvK, dF, aF, fvF, -1, 0.75, True)
+    imgs = np.stack([pkg.synth.make_frame(240, 376, 40 + i) for i in range(64)])
+    bad, stop = [], threading.Event()
+    ROUNDS = int(os.environ.get("ORBFE_TEST_ROUNDS", "300"))
+
+    def extractions():
+        ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+        d_img = torch.from_numpy(imgs).pin_memory().cuda()
+        cap = ex.max_keypoints(240, 376)
+        o = (torch.zeros((64, cap, 7), dtype=torch.float32, device="cuda"), torch.zeros((64, cap, 32), dtype=torch.uint8, device="cuda"),
+             torch.zeros(64, dtype=torch.int32, device="cuda"), torch.zeros(64, dtype=torch.int32, device="cuda"))
+        while not stop.is_set():
+            for _ in range(4):
+                ex.extract_batch_device(d_img.data_ptr(), 64, 240, 376, 376, 240 * 376, (0, 1000), o[0].data_ptr(), o[1].data_ptr(), cap,
+                                        o[2].data_ptr(), o[3].data_ptr())
+            ex.sync()
+        ex.close()
+
+    def searches():
+        import matcher_inputs as MI
+        d1, d2, a1, a2 = MI.descriptor_sets(900, 900, 5)
+        fv1, fv2 = MI.feature_vectors(d1, d2, 5)
+        P = [dict(desc1=d1.copy(), mask1=np.ones(900, np.uint8), ang1=a1, fv1=fv1, desc2=d2.copy(), ang2=a2, fv2=fv2, variant=0, nnratio=0.8)
+             for _ in range(16)]
+        while not stop.is_set():
+            pkg.search_bow_batch(P)
+
+    def copies():
+        h = torch.empty(32 << 20, dtype=torch.uint8).pin_memory()
+        d = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            while not stop.is_set():
+                d.copy_(h, non_blocking=True)
+                h.copy_(d, non_blocking=True)
+                s2.synchronize()
+
+    def guard(fn):
+        def run():
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                bad.append(repr(e))
+        return run
+
+    load = [threading.Thread(target=guard(f)) for f in (extractions, searches, copies)]
+    for t in load:
+        t.start()
+    try:
+        for it in range(ROUNDS):
+            f, want = sets[it % len(sets)]
+            b = B if it % 3 else B2   # (eager and lazy normalisation, two handles interleaved on one stream)
+            got = b.compute(f, 1).host()
+            try:
+                _same(got, want)
+            except AssertionError as e:
+                bad.append("round %d (n = %d): %s" % (it, len(f), e))
+                break
+            if it % len(sets) == 0:   # the vector of set 0 is resident: search with it before anything reads it on the host
+                b.compute(f, 1)
+                g = pkg.search_bow_keyframes([dict(kf1=kf, desc2=dF, ang2=aF, fv2=b, variant=0, nnratio=0.75, check_ori=True)] * 40)
+                if any(x[0] != wantS[0] or not np.array_equal(x[1], wantS[1]) for x in g):
+                    bad.append("round %d: search with the resident vector differs" % it)
+                    break
+            if bad:
+                break
+    finally:
+        stop.set()
+        for t in load:
+            t.join(timeout=120)
+    assert not any(t.is_alive() for t in load), "a load thread hangs"
+    assert not bad, bad[:5]
+    kf.close()
+    B.close()
+    B2.close()
+    V.close()
