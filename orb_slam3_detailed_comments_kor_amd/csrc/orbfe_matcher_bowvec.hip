@@ -373,6 +373,8 @@ struct orbfe_bow {
     hipStream_t stream = nullptr;      // the stream of the last call (a consumer on the same stream needs no event wait)
     uint8_t* hDesc = nullptr;          // pinned staging of host descriptors
     hipEvent_t ev = nullptr;           // behind the mirror copy of the last call
+    std::mutex hostMu; // the host view's one-time work (the wait for the kernel, the lazy normalisation) when searches of several
+                       // threads name the same vector
     // (lifetime: the process-wide handle table, g_handles -- every entry point takes a use by LOOK-UP before it reads the
     // object, so a destroyed handle is refused without being dereferenced and a destroy under a search is deferred to its return)
     size_t off(const void* p) const { return (size_t)((const uint8_t*)p - block); }
@@ -421,6 +423,7 @@ int bow_host_fv(orbfe_bow* b, orbfe_fv* host) // (under a use of the handle)
 // host view of the last call's results (waits for the mirror copy)
 int bow_host_view(orbfe_bow* b, orbfe_bow_view* v)
 {
+    std::lock_guard<std::mutex> hostLock(b->hostMu);
     if (!b->computed) return ORBFE_ERR_STATE;
     if (b->pending) {
         HIP_TRY(hipSetDevice(b->device));
