@@ -626,7 +626,8 @@ int orbfe_vocab_get_types(orbfe_vocab_dev*, int* weighting, int* scoring);
  * TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (TemplatedVocabulary.h:1127-1192) -- the
  * per-feature descent AND the fold into the two maps (BowVector::addWeight / addIfNotExist / normalize, BowVector.cpp:34-86;
  * FeatureVector::addFeature, FeatureVector.cpp:31-45), bit-identical to the reference's maps for every weighting / scoring type.
- *   orbfe_bow_create(&bow, vocab, cap)       a handle for frames of up to `cap` features (<= 65535); reused frame after frame
+ *   orbfe_bow_create(&bow, vocab, cap)       a handle for frames of up to `cap` features (<= 65535); reused frame after frame.
+ *                                            The vocabulary must outlive it (orbfe_vocab_free after the last orbfe_bow_destroy).
  *   orbfe_compute_bow(bow, desc, n, levelsup) `desc`: host or DEVICE pointer (orbfe_get_device_outputs: nothing crosses PCIe).
  *                                            Asynchronous on the calling thread's matcher stream -- two kernels (the descent;
  *                                            rank + fold, whose last workgroup also writes the host copy into page-locked
