@@ -34,6 +34,7 @@
 #include "../../include/orbfe_debug.h"
 #include "orbfe_geom.h"
 #include "orbfe_order.h"
+#include "orbfe_pageable.h"
 #include "orbfe_sincos.h"
 
 // single translation unit: the kernels are compiled together with their launch code
@@ -2451,9 +2452,8 @@ int orbfe_get_rays(orbfe_ctx* c, int img_index, int cap_per_img, float* rays, in
     HIP_TRY(hipSetDevice(c->device));
     lane_quiesce(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n)
-        HIP_TRY(hipMemcpy(rays, c->d_rays.p + (size_t)img_index * cap_per_img * 3, (size_t)n * 3 * sizeof(float),
-                          hipMemcpyDeviceToHost));
+    if (n) // (the caller's array may be pageable: through page-locked memory of this thread, orbfe_pageable.h)
+        HIP_TRY(orbfe_pageable::down(rays, c->d_rays.p + (size_t)img_index * cap_per_img * 3, (size_t)n * 3 * sizeof(float), c->stream));
     return 0;
 }
 
@@ -3277,13 +3277,14 @@ int orbfe_debug_trig(orbfe_ctx* c, const float* angles_deg, int n, float* a_out,
     DevBuf<float> d;
     int r = d.ensure((size_t)3 * n);
     if (r < 0) return r;
-    hipError_t e = hipMemcpyAsync(d.p, angles_deg, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    // (a test hands over millions of angles in pageable arrays: orbfe_pageable.h)
+    hipError_t e = orbfe_pageable::up(d.p, angles_deg, (size_t)n * sizeof(float), c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_debug_trig, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d.p, n, tab.codes, tab.full, d.p + n,
                            d.p + 2 * (size_t)n);
-        e = hipMemcpyAsync(a_out, d.p + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        e = orbfe_pageable::down(a_out, d.p + n, (size_t)n * sizeof(float), c->stream);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(b_out, d.p + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = orbfe_pageable::down(b_out, d.p + 2 * (size_t)n, (size_t)n * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     d.release();
     if (e != hipSuccess) return -(1000 + (int)e);

@@ -31,6 +31,7 @@
 
 #include "../../include/orbfe.h"
 #include "orbfe_order.h"
+#include "orbfe_pageable.h"
 #include "orbfe_sincos.h"
 #include "orbfe_kb8.h"
 

@@ -588,16 +588,17 @@ int orbfe_keyframe_create(orbfe_keyframe** out, int device, const orbfe_keyframe
         if (descResident) e = hipMemcpyAsync(K->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms);
         if (e == hipSuccess) e = hipMemcpyAsync(K->block + first, st, total - first, hipMemcpyHostToDevice, g_ms);
     } else { // (the arena is too small this once: array by array)
-        e = hipMemcpyAsync(K->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess) e = hipMemcpyAsync(K->mask, a->mask, n, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess && a->angle) e = hipMemcpyAsync(K->ang, a->angle, n * 4, hipMemcpyHostToDevice, g_ms);
+        using orbfe_pageable::up; // (the caller's arrays may be pageable: through page-locked memory of this thread)
+        e = descResident ? hipMemcpyAsync(K->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms) : up(K->desc, a->desc, n * 32, g_ms);
+        if (e == hipSuccess) e = up(K->mask, a->mask, n, g_ms);
+        if (e == hipSuccess && a->angle) e = up(K->ang, a->angle, n * 4, g_ms);
         if (e == hipSuccess && !a->angle) e = hipMemsetAsync(K->ang, 0, n * 4, g_ms);
-        if (e == hipSuccess && tri) e = hipMemcpyAsync(K->kp, a->kp_xy, n * 8, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess && tri) e = hipMemcpyAsync(K->uR, a->uRight, n * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess && tri) e = hipMemcpyAsync(K->oct, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess && ni) e = hipMemcpyAsync(K->ind, a->fv.indices, ni * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess && a->fv.nn) e = hipMemcpyAsync(K->dNode, K->nodeIds.data(), (size_t)a->fv.nn * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess) e = hipMemcpyAsync(K->dOffs, K->offsets.data(), ((size_t)a->fv.nn + 1) * 4, hipMemcpyHostToDevice, g_ms);
+        if (e == hipSuccess && tri) e = up(K->kp, a->kp_xy, n * 8, g_ms);
+        if (e == hipSuccess && tri) e = up(K->uR, a->uRight, n * 4, g_ms);
+        if (e == hipSuccess && tri) e = up(K->oct, a->octave, n * 4, g_ms);
+        if (e == hipSuccess && ni) e = up(K->ind, a->fv.indices, ni * 4, g_ms);
+        if (e == hipSuccess && a->fv.nn) e = up(K->dNode, K->nodeIds.data(), (size_t)a->fv.nn * 4, g_ms);
+        if (e == hipSuccess) e = up(K->dOffs, K->offsets.data(), ((size_t)a->fv.nn + 1) * 4, g_ms);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(g_ms); // the caller's arrays are free again; the handle is complete
     if (e != hipSuccess) {

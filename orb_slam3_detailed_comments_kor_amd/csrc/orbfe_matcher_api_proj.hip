@@ -384,11 +384,12 @@ int orbfe_frame_create(orbfe_frame** out, int device, const orbfe_proj_args* a)
         if (descResident) e = hipMemcpyAsync(F->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms);
         if (e == hipSuccess) e = hipMemcpyAsync(F->block + first, st, upTo - first, hipMemcpyHostToDevice, g_ms);
     } else {
-        e = hipMemcpyAsync(F->desc, a->desc, n * 32, descResident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess) e = hipMemcpyAsync(F->kx, a->kx, n * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess) e = hipMemcpyAsync(F->ky, a->ky, n * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess) e = hipMemcpyAsync(F->octave, a->octave, n * 4, hipMemcpyHostToDevice, g_ms);
-        if (e == hipSuccess && F->uright) e = hipMemcpyAsync(F->uright, a->uright, n * 4, hipMemcpyHostToDevice, g_ms);
+        using orbfe_pageable::up; // (the caller's arrays may be pageable: through page-locked memory of this thread)
+        e = descResident ? hipMemcpyAsync(F->desc, a->desc, n * 32, hipMemcpyDeviceToDevice, g_ms) : up(F->desc, a->desc, n * 32, g_ms);
+        if (e == hipSuccess) e = up(F->kx, a->kx, n * 4, g_ms);
+        if (e == hipSuccess) e = up(F->ky, a->ky, n * 4, g_ms);
+        if (e == hipSuccess) e = up(F->octave, a->octave, n * 4, g_ms);
+        if (e == hipSuccess && F->uright) e = up(F->uright, a->uright, n * 4, g_ms);
     }
     if (e == hipSuccess) {
         ProjDev P{};

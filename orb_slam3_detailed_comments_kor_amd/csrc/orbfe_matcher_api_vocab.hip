@@ -136,11 +136,14 @@ int orbfe_vocab_upload(orbfe_vocab_dev** out, int device, const orbfe_vocab* v)
               hipMalloc((void**)&d->childIds, (size_t)std::max(nchild, 1) * 4) == hipSuccess &&
               hipMalloc((void**)&d->word, (size_t)v->nnodes * 4) == hipSuccess &&
               hipMalloc((void**)&d->weight, (size_t)v->nnodes * 8) == hipSuccess;
-    ok = ok && hipMemcpy(d->desc, v->node_desc, (size_t)v->nnodes * 32, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(d->childOff, v->child_off, (size_t)(v->nnodes + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-         (nchild == 0 || hipMemcpy(d->childIds, v->child_ids, (size_t)nchild * 4, hipMemcpyHostToDevice) == hipSuccess) &&
-         hipMemcpy(d->word, v->node_word, (size_t)v->nnodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(d->weight, v->node_weight, (size_t)v->nnodes * 8, hipMemcpyHostToDevice) == hipSuccess;
+    // (the tree of ORBvoc.txt is 35 MB of descriptors in the caller's pageable memory: in pieces through page-locked memory of
+    // this thread, orbfe_pageable.h; on the null stream, once per vocabulary)
+    using orbfe_pageable::up;
+    ok = ok && up(d->desc, v->node_desc, (size_t)v->nnodes * 32, nullptr) == hipSuccess &&
+         up(d->childOff, v->child_off, (size_t)(v->nnodes + 1) * 4, nullptr) == hipSuccess &&
+         (nchild == 0 || up(d->childIds, v->child_ids, (size_t)nchild * 4, nullptr) == hipSuccess) &&
+         up(d->word, v->node_word, (size_t)v->nnodes * 4, nullptr) == hipSuccess &&
+         up(d->weight, v->node_weight, (size_t)v->nnodes * 8, nullptr) == hipSuccess;
     if (!ok) {
         orbfe_vocab_free(d);
         return ORBFE_ERR_NODEV;

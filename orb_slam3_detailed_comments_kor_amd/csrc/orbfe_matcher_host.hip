@@ -285,9 +285,7 @@ struct Scratch { // device allocations of one call
                 if (!staged.empty() && staged.back().first + staged.back().second == at) staged.back().second += bytes;
                 else staged.emplace_back(at, bytes);
             } else {
-                hipError_t e = hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, g_ms);
-                if (e != hipSuccess) return -(1000 + (int)e);
-                e = hipStreamSynchronize(g_ms); // `host` is the caller's (pageable) memory
+                const hipError_t e = orbfe_pageable::up(p, host, n * sizeof(T), g_ms); // `host` is the caller's (pageable) memory
                 if (e != hipSuccess) return -(1000 + (int)e);
             }
         }
@@ -383,7 +381,7 @@ struct Scratch { // device allocations of one call
         }
         staged.clear();
         for (const LateUp& u : lateUps) {
-            hipError_t e = hipMemcpyAsync(u.dev, temps[u.temp].data(), u.bytes, hipMemcpyHostToDevice, g_ms);
+            const hipError_t e = orbfe_pageable::up(u.dev, temps[u.temp].data(), u.bytes, g_ms); // (a std::vector: pageable)
             if (e != hipSuccess) return -(1000 + (int)e);
         }
         if (!lateUps.empty()) {
@@ -431,7 +429,7 @@ struct Scratch { // device allocations of one call
         bool inArena = ar->base && ar->pin && !downs.empty();
         size_t lo = ~(size_t)0, hi = 0, total = 0;
         for (const Down& d : downs) total += d.bytes;
-        if (total > (1u << 20)) inArena = false; // a distance matrix: straight into the caller's memory, no second copy
+        if (total > (1u << 20)) inArena = false; // a distance matrix: not through the arena's mirror
         for (const Down& d : downs) {
             const uint8_t* p = (const uint8_t*)d.dev;
             if (!(ar->base && p >= ar->base && p + d.bytes <= ar->base + ar->cap)) inArena = false;
@@ -447,9 +445,10 @@ struct Scratch { // device allocations of one call
             if (e == hipSuccess)
                 for (const Down& d : downs) std::memcpy(d.host, ar->pin + ((const uint8_t*)d.dev - ar->base), d.bytes);
         } else {
+            // (a distance matrix, or results next to an arena that is too small this once: in pieces through page-locked memory
+            // of this thread, orbfe_pageable.h -- never a large copy into the caller's pageable array as it is)
             for (const Down& d : downs)
-                if (e == hipSuccess) e = hipMemcpyAsync(d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, g_ms);
-            if (e == hipSuccess) e = hipStreamSynchronize(g_ms);
+                if (e == hipSuccess) e = orbfe_pageable::down(d.host, d.dev, d.bytes, g_ms);
         }
         downs.clear();
         return e == hipSuccess ? 0 : -(1000 + (int)e);

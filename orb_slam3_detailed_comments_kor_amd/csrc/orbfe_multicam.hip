@@ -32,6 +32,7 @@
 #include <unistd.h>
 
 #include "../../include/orbfe_mc.h"
+#include "orbfe_pageable.h"
 
 #define MC_HIP_TRY(expr)                                   \
     do {                                                   \
@@ -579,8 +580,9 @@ int orbfe_mc_match_ring(orbfe_mc* m, const int* hops, int nhops, int32_t* idx, i
     const int np = orbfe_mc_match_ring_async(m, hops, nhops, m->buf[m->lastView].batch);
     if (np < 0) return np;
     const size_t bytes = (size_t)np * m->cap * 2 * sizeof(int32_t);
-    if (idx) MC_HIP_TRY(hipMemcpyAsync(idx, m->d_idx, bytes, hipMemcpyDeviceToHost, m->sCtx));
-    if (dist) MC_HIP_TRY(hipMemcpyAsync(dist, m->d_dist, bytes, hipMemcpyDeviceToHost, m->sCtx));
+    // (the caller's arrays may be pageable: in pieces through page-locked memory of this thread, orbfe_pageable.h)
+    if (idx) MC_HIP_TRY(orbfe_pageable::down(idx, m->d_idx, bytes, m->sCtx));
+    if (dist) MC_HIP_TRY(orbfe_pageable::down(dist, m->d_dist, bytes, m->sCtx));
     MC_HIP_TRY(hipStreamSynchronize(m->sCtx));
     return np;
 }
